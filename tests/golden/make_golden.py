@@ -1,0 +1,619 @@
+#!/opt/conda/bin/python3.9
+"""Record golden vectors by running the REFERENCE implementation.
+
+Runs only in the build container (it needs ``/root/reference`` plus h5py and
+astropy, which only ``/opt/conda/bin/python3.9`` has there)::
+
+    /opt/conda/bin/python3.9 tests/golden/make_golden.py
+
+The reference package is imported unmodified from ``/root/reference`` (never
+copied).  ``halotools`` is not installed anywhere in the image, so
+
+* a stub ``halotools`` package exposing just the names imported at
+  ``tabcorr/tabcorr.py:11-17`` is injected into ``sys.modules`` (this makes
+  ``TabCorr.tabulate`` unusable, everything else works), and
+* ``predict`` is driven by a duck-typed Zheng07 model object defined below
+  (attributes used by the reference: ``tabcorr/tabcorr.py:498-532, 556-563``,
+  ``tabcorr/interpolator.py:173``) or by raw ``numpy.ndarray`` occupations.
+
+Consequently the occupation functions themselves (Zheng et al. 2007, eqs. 1
+and 3, as also implemented by halotools' ``Zheng07Cens``/``Zheng07Sats``) are
+pinned against THIS file's duck model only ("parity unpinned" with respect to
+halotools); everything from the Gauss-Legendre bin average onwards is the
+reference's own arithmetic.
+
+Outputs: ``tests/golden/*.npz`` (inputs + expected outputs, data only).
+"""
+
+import importlib.util
+import json
+import os
+import shutil
+import sys
+import types
+import warnings
+
+import numpy as np
+
+warnings.filterwarnings('ignore')
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = '/root/reference'
+
+# -- shims -------------------------------------------------------------------
+# astropy 4.3.1 against numpy 1.26: two names that were removed from numpy.
+np.asscalar = lambda a: a.item()  # noqa: E731
+np.alen = len
+
+import astropy.cosmology  # noqa: E402
+
+if not hasattr(astropy.cosmology, 'Parameter'):
+    # Only needed by the out-of-scope tabcorr/database.py:8,76-78.
+    class _Parameter:
+        def __init__(self, *args, **kwargs):
+            pass
+    astropy.cosmology.Parameter = _Parameter
+
+
+def _stub_halotools():
+    def module(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+
+    halotools = module('halotools')
+    sim_manager = module('halotools.sim_manager')
+    sim_defaults = module('halotools.sim_manager.sim_defaults')
+    sim_defaults.Num_ptcl_requirement = 300
+    sim_manager.sim_defaults = sim_defaults
+    empirical_models = module('halotools.empirical_models')
+    model_defaults = module('halotools.empirical_models.model_defaults')
+    model_defaults.prim_haloprop_key = 'halo_mvir'
+    model_defaults.sec_haloprop_key = 'halo_nfw_conc'
+    empirical_models.model_defaults = model_defaults
+    for name in ['HodModelFactory', 'TrivialPhaseSpace', 'Zheng07Cens',
+                 'NFWPhaseSpace', 'Zheng07Sats']:
+        setattr(empirical_models, name, type(name, (), {}))
+    mock_observables = module('halotools.mock_observables')
+    mock_observables.return_xyz_formatted_array = None
+    utils = module('halotools.utils')
+    utils.crossmatch = None
+    table_utils = module('halotools.utils.table_utils')
+    table_utils.compute_conditional_percentiles = None
+    utils.table_utils = table_utils
+    halotools.sim_manager = sim_manager
+    halotools.empirical_models = empirical_models
+    halotools.mock_observables = mock_observables
+    halotools.utils = utils
+
+
+_stub_halotools()
+sys.path.insert(0, REFERENCE)
+import tabcorr  # noqa: E402  (the reference)
+from tabcorr.tabcorr import symmetric_matrix_to_array  # noqa: E402
+from tabcorr.interpolator import (  # noqa: E402
+    spline_interpolation_matrix, spline_interpolate)
+from astropy.table import Table  # noqa: E402
+from scipy.special import erf  # noqa: E402
+
+spec = importlib.util.spec_from_file_location(
+    'synthetic', os.path.join(REPO, 'tabcorr_amd', 'synthetic.py'))
+synthetic = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(synthetic)
+
+
+# -- duck-typed models --------------------------------------------------------
+
+class _Occupation:
+    def __init__(self, prim_haloprop_key, sec_haloprop_key=None):
+        self.prim_haloprop_key = prim_haloprop_key
+        if sec_haloprop_key is not None:
+            self.sec_haloprop_key = sec_haloprop_key
+
+
+class DuckZheng07:
+    """Zheng et al. (2007) HOD: <N_cen> = 1/2 [1 + erf((log M - logMmin) /
+    sigma_logM)], <N_sat> = ((M - M0) / M1)^alpha for M > M0, else 0,
+    optionally multiplied by <N_cen> (``modulate_with_cenocc``)."""
+
+    def __init__(self, theta, prim_haloprop_key='halo_mvir', redshift=0.0,
+                 modulate_with_cenocc=False, **extra):
+        self.gal_types = ['centrals', 'satellites']
+        self.redshift = redshift
+        self.modulate_with_cenocc = modulate_with_cenocc
+        self._input_model_dictionary = {
+            'centrals_occupation': _Occupation(prim_haloprop_key),
+            'satellites_occupation': _Occupation(prim_haloprop_key)}
+        self.param_dict = dict(zip(synthetic.ZHENG07_KEYS, theta))
+        self.param_dict.update(extra)
+
+    def baseline_centrals(self, prim_haloprop):
+        p = self.param_dict
+        return 0.5 * (1.0 + erf((np.log10(prim_haloprop) - p['logMmin']) /
+                                p['sigma_logM']))
+
+    def baseline_satellites(self, prim_haloprop):
+        p = self.param_dict
+        m0 = 10.0**p['logM0']
+        m1 = 10.0**p['logM1']
+        n = np.zeros(len(prim_haloprop))
+        use = prim_haloprop - m0 > 0
+        n[use] = ((prim_haloprop[use] - m0) / m1)**p['alpha']
+        if self.modulate_with_cenocc:
+            n = n * self.baseline_centrals(prim_haloprop)
+        return n
+
+    def mean_occupation_centrals(self, prim_haloprop=None,
+                                 sec_haloprop_percentile=None, **kwargs):
+        return self.baseline_centrals(prim_haloprop)
+
+    def mean_occupation_satellites(self, prim_haloprop=None,
+                                   sec_haloprop_percentile=None, **kwargs):
+        return self.baseline_satellites(prim_haloprop)
+
+
+class DuckAssembiasZheng07(DuckZheng07):
+    """Zheng07 decorated with Heaviside assembly bias (Hearin et al. 2016).
+
+    Halos above the percentile ``split`` (type 1, fraction f1 = 1 - split) get
+    <N> + d, those below get <N> - d f1 / f2, with d = A times the largest
+    perturbation that keeps both types inside [lower, upper] (centrals: [0, 1],
+    satellites: [0, inf)).  The population mean is conserved.
+    """
+
+    def __init__(self, theta, a_cen, a_sat, split=0.5, **kwargs):
+        DuckZheng07.__init__(self, theta, **kwargs)
+        key = self._input_model_dictionary[
+            'centrals_occupation'].prim_haloprop_key
+        self._input_model_dictionary = {
+            'centrals_occupation': _Occupation(key, 'halo_nfw_conc'),
+            'satellites_occupation': _Occupation(key, 'halo_nfw_conc')}
+        self.param_dict['mean_occupation_centrals_assembias_param1'] = a_cen
+        self.param_dict['mean_occupation_satellites_assembias_param1'] = a_sat
+        self.split = split
+
+    def _decorate(self, baseline, percentile, strength, lower, upper):
+        f1 = 1.0 - self.split
+        f2 = self.split
+        if strength >= 0:
+            dmax = np.minimum(upper - baseline, (baseline - lower) * f2 / f1)
+        else:
+            dmax = np.minimum(baseline - lower, (upper - baseline) * f2 / f1)
+        d1 = strength * dmax
+        return np.where(percentile > self.split, baseline + d1,
+                        baseline - d1 * f1 / f2)
+
+    def mean_occupation_centrals(self, prim_haloprop=None,
+                                 sec_haloprop_percentile=None, **kwargs):
+        return self._decorate(
+            self.baseline_centrals(prim_haloprop), sec_haloprop_percentile,
+            self.param_dict['mean_occupation_centrals_assembias_param1'],
+            0.0, 1.0)
+
+    def mean_occupation_satellites(self, prim_haloprop=None,
+                                   sec_haloprop_percentile=None, **kwargs):
+        return self._decorate(
+            self.baseline_satellites(prim_haloprop), sec_haloprop_percentile,
+            self.param_dict['mean_occupation_satellites_assembias_param1'],
+            0.0, np.inf)
+
+
+# -- helpers -------------------------------------------------------------------
+
+def make_reference_tabcorr(table):
+    halotab = tabcorr.TabCorr()
+    halotab.attrs = dict(table['attrs'])
+    halotab.tpcf_matrix = np.array(table['tpcf_matrix'], dtype=np.float64)
+    halotab.tpcf_shape = tuple(table['tpcf_shape'])
+    halotab.tpcf_args = ()
+    halotab.tpcf_kwargs = {}
+    halotab.gal_type = Table(table['gal_type'])
+    return halotab
+
+
+def table_from_reference(halotab):
+    attrs = {}
+    for key, value in halotab.attrs.items():
+        if isinstance(value, bytes):
+            value = value.decode()
+        attrs[key] = value.item() if hasattr(value, 'item') else value
+    return {'gal_type': np.array(halotab.gal_type.as_array()),
+            'tpcf_matrix': halotab.tpcf_matrix,
+            'tpcf_shape': tuple(int(s) for s in halotab.tpcf_shape),
+            'attrs': attrs}
+
+
+def pack_table(table, prefix=''):
+    # float32 keeps the fixture small and is exact: every table here either
+    # came from a float32 dataset or was rounded through float32.
+    matrix32 = table['tpcf_matrix'].astype(np.float32)
+    assert np.all(matrix32.astype(np.float64) == table['tpcf_matrix'])
+    # One plain array per gal_type column (structured dtypes do not survive
+    # the numpy 1.26 -> 2.x npz round trip).
+    arrays = {prefix + 'tpcf_matrix': matrix32,
+              prefix + 'tpcf_shape': np.array(table['tpcf_shape']),
+              prefix + 'attrs': np.array(json.dumps(table['attrs']))}
+    for column in table['gal_type'].dtype.names:
+        arrays[prefix + 'gt_' + column] = np.array(table['gal_type'][column])
+    return arrays
+
+
+def run_draws(halotab, models, n_gauss_list=(10, ), **kwargs):
+    """Run the reference on a list of models; return dict of stacked arrays."""
+    out = {}
+    auto = halotab.attrs['mode'] == 'auto'
+    for n_gauss in n_gauss_list:
+        suffix = '' if n_gauss == 10 else '_ng%d' % n_gauss
+        occ, ngal, xi = [], [], []
+        ngal_sep = {'centrals': [], 'satellites': []}
+        xi_keys = (['centrals-centrals', 'centrals-satellites',
+                    'satellites-satellites'] if auto else
+                   ['centrals', 'satellites'])
+        xi_sep = {key: [] for key in xi_keys}
+        for model in models:
+            occ.append(halotab.mean_occupation(
+                model, n_gauss_prim=n_gauss, **kwargs))
+            n, x = halotab.predict(model, n_gauss_prim=n_gauss, **kwargs)
+            ngal.append(n)
+            xi.append(x)
+            n_s, x_s = halotab.predict(model, separate_gal_type=True,
+                                       n_gauss_prim=n_gauss, **kwargs)
+            assert list(n_s.keys()) == ['centrals', 'satellites']
+            assert list(x_s.keys()) == xi_keys
+            for key in n_s:
+                ngal_sep[key].append(n_s[key])
+            for key in x_s:
+                xi_sep[key].append(x_s[key])
+        out['mean_occupation' + suffix] = np.array(occ)
+        out['ngal' + suffix] = np.array(ngal)
+        out['xi' + suffix] = np.array(xi)
+        for key in ngal_sep:
+            out['ngal_sep_%s%s' % (key, suffix)] = np.array(ngal_sep[key])
+        for key in xi_sep:
+            out['xi_sep_%s%s' % (key, suffix)] = np.array(xi_sep[key])
+    return out
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('%-34s %8.1f KB' % (name + '.npz', os.path.getsize(path) / 1024))
+
+
+# -- 1. real single tables -------------------------------------------------------
+
+PROBE_WP = (11.35, 0.25, 11.2, 12.4, 0.83)
+PROBE_DS = (12.79, 0.39, 11.92, 13.94, 1.15)
+
+
+def golden_real_tables():
+    for name, probe in [('bolplanck_wp', PROBE_WP), ('bolplanck_ds', PROBE_DS)]:
+        fname = os.path.join(REFERENCE, 'docs', 'examples', name + '.hdf5')
+        halotab = tabcorr.TabCorr.read(fname)
+        # Data files of the reference are kept as fixtures for the HDF5 reader.
+        shutil.copyfile(fname, os.path.join(HERE, name + '.hdf5'))
+        os.chmod(os.path.join(HERE, name + '.hdf5'), 0o644)
+        theta = np.vstack([probe, synthetic.zheng07_draws(32, seed=11)])
+        arrays = pack_table(table_from_reference(halotab))
+        arrays['theta'] = theta
+        for modulate in [False, True]:
+            models = [DuckZheng07(t, modulate_with_cenocc=modulate)
+                      for t in theta]
+            out = run_draws(halotab, models, (10, ) if modulate else
+                            (1, 10, 100))
+            for key in out:
+                arrays[key + ('_modulate' if modulate else '')] = out[key]
+        # The ndarray seam (tabcorr/tabcorr.py:616-621).
+        rng = np.random.default_rng(5)
+        occ = rng.uniform(0, 2, size=(8, len(halotab.gal_type)))
+        arrays['occ_in'] = occ
+        arrays['occ_ngal'] = np.array([halotab.predict(o)[0] for o in occ])
+        arrays['occ_xi'] = np.array([halotab.predict(o)[1] for o in occ])
+        save(name, **arrays)
+
+
+# -- 2. the AbacusSummit test fixture (Interpolator, K = 4, cross) ---------------
+
+def golden_abacus():
+    fname = os.path.join(
+        REFERENCE, 'tests', 'AbacusSummit', 'base_c000_ph000', '0p50',
+        'ds_efficient.hdf5')
+    shutil.copyfile(fname, os.path.join(HERE, 'ds_efficient.hdf5'))
+    os.chmod(os.path.join(HERE, 'ds_efficient.hdf5'), 0o644)
+    interp = tabcorr.Interpolator.read(fname)
+    arrays = {}
+    for i, halotab in enumerate(interp.tabcorr_list):
+        arrays.update(pack_table(table_from_reference(halotab),
+                                 'table%d_' % i))
+    keys = [k for k in interp.param_dict_table.colnames
+            if k != 'tabcorr_index']
+    arrays['keys'] = np.array(keys)
+    # Grid values in tabcorr_list order (param_dict_table is sorted, with
+    # tabcorr_index remembering the list position: interpolator.py:59-61).
+    order = np.argsort(interp.param_dict_table['tabcorr_index'])
+    arrays['points'] = np.stack(
+        [np.array(interp.param_dict_table[k])[order] for k in keys], axis=-1)
+    for d in range(len(keys)):
+        arrays['xp%d' % d] = interp.xp[d]
+        arrays['a%d' % d] = interp.a[d]
+    arrays['unique_gal_type_index'] = interp.unique_gal_type_index
+    arrays['unique_gal_type_inverse'] = interp.unique_gal_type_inverse
+
+    theta = np.vstack([(12.9, 0.25, 11.2, 14.1, 1.2),
+                       synthetic.zheng07_draws(15, seed=12)])
+    rng = np.random.default_rng(13)
+    lo, hi = interp.xp[0][0], interp.xp[0][-1]
+    x = rng.uniform(lo, hi, size=len(theta))
+    x[0] = 0.1
+    x[1] = hi  # right edge is special-cased (interpolator.py:320-321)
+    x[2] = lo
+    x[3] = interp.xp[0][1]
+    arrays['theta'] = theta
+    arrays['x'] = x[:, np.newaxis]
+    kw = dict(prim_haloprop_key='halo_m258m', redshift=0.5)
+    models = [DuckZheng07(t, log_eta=xi, **kw) for t, xi in zip(theta, x)]
+
+    out = run_draws(interp.tabcorr_list[0], models)
+    for key in out:
+        arrays['table0_' + key] = out[key]
+
+    ngal, xi = [], []
+    ngal_sep = {'centrals': [], 'satellites': []}
+    xi_sep = {'centrals': [], 'satellites': []}
+    for model in models:
+        n, x_ = interp.predict(model)
+        ngal.append(n)
+        xi.append(x_)
+        n_s, x_s = interp.predict(model, separate_gal_type=True)
+        for key in n_s:
+            ngal_sep[key].append(n_s[key])
+            xi_sep[key].append(x_s[key])
+    arrays['ngal'] = np.array(ngal)
+    arrays['xi'] = np.array(xi)
+    for key in ngal_sep:
+        arrays['ngal_sep_' + key] = np.array(ngal_sep[key])
+        arrays['xi_sep_' + key] = np.array(xi_sep[key])
+
+    # Out of range: ValueError unless extrapolate (interpolator.py:322-328).
+    x_out = np.array([lo - 0.05, hi + 0.07])
+    arrays['x_out'] = x_out[:, np.newaxis]
+    n_out, xi_out = [], []
+    for xo in x_out:
+        model = DuckZheng07(theta[0], log_eta=xo, **kw)
+        try:
+            interp.predict(model)
+            raise RuntimeError('expected ValueError')
+        except ValueError:
+            pass
+        n, x_ = interp.predict(model, extrapolate=True)
+        n_out.append(n)
+        xi_out.append(x_)
+    arrays['ngal_out'] = np.array(n_out)
+    arrays['xi_out'] = np.array(xi_out)
+    save('ds_efficient', **arrays)
+
+
+# -- 3. synthetic single tables ----------------------------------------------------
+
+def golden_synthetic():
+    # BASELINE configs[1]: 50 mass bins x {cen, sat}, 19 r_p bins.
+    table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    halotab = make_reference_tabcorr(table)
+    theta = synthetic.zheng07_draws(64, seed=1)
+    arrays = pack_table(table)
+    arrays['theta'] = theta
+    arrays.update(run_draws(halotab, [DuckZheng07(t) for t in theta]))
+    save('synthetic_cfg2', **arrays)
+
+    # BASELINE configs[2]: two secondary bins, assembly bias, separate types.
+    table = synthetic.synthetic_table(50, 2, (19, ), 'auto', seed=3)
+    halotab = make_reference_tabcorr(table)
+    theta = synthetic.zheng07_draws(32, seed=2)
+    rng = np.random.default_rng(4)
+    assembias = rng.uniform(-1, 1, size=(len(theta), 2))
+    assembias[0] = (0.0, 0.0)
+    assembias[1] = (1.0, -1.0)
+    arrays = pack_table(table)
+    arrays['theta'] = theta
+    arrays['assembias'] = assembias
+    models = [DuckAssembiasZheng07(t, a[0], a[1])
+              for t, a in zip(theta, assembias)]
+    arrays.update(run_draws(halotab, models))
+    out = run_draws(halotab, [DuckZheng07(t) for t in theta])
+    for key in out:
+        arrays['plain_' + key] = out[key]
+    save('synthetic_cfg3', **arrays)
+
+    # Small shapes: cross mode, 2-D tpcf_shape, legacy table without the
+    # prim_haloprop_dist_index column (tabcorr/tabcorr.py:568-574), G odd
+    # sizes, R = 1.
+    for name, kw in [
+            ('synthetic_small_auto', dict(n_prim=7, n_sec=1, tpcf_shape=(5, ),
+                                          mode='auto', seed=20)),
+            ('synthetic_small_cross', dict(n_prim=9, n_sec=2, tpcf_shape=(6, ),
+                                           mode='cross', seed=21)),
+            ('synthetic_rp_pi', dict(n_prim=6, n_sec=1, tpcf_shape=(5, 8),
+                                     mode='auto', seed=22)),
+            ('synthetic_r1', dict(n_prim=3, n_sec=1, tpcf_shape=(1, ),
+                                  mode='auto', seed=23))]:
+        table = synthetic.synthetic_table(**kw)
+        halotab = make_reference_tabcorr(table)
+        theta = synthetic.zheng07_draws(16, seed=kw['seed'] + 100)
+        arrays = pack_table(table)
+        arrays['theta'] = theta
+        arrays.update(run_draws(halotab, [DuckZheng07(t) for t in theta],
+                                (1, 10)))
+        if name == 'synthetic_small_auto':
+            legacy = make_reference_tabcorr(table)
+            legacy.gal_type.remove_column('prim_haloprop_dist_index')
+            out = run_draws(legacy, [DuckZheng07(t) for t in theta])
+            for key in out:
+                arrays['legacy_' + key] = out[key]
+        save(name, **arrays)
+
+
+# -- 4. synthetic interpolators -------------------------------------------------------
+
+def make_reference_interpolator(tables, keys, points):
+    tabcorr_list = [make_reference_tabcorr(t) for t in tables]
+    param_dict_table = Table()
+    for d, key in enumerate(keys):
+        param_dict_table[key] = points[:, d]
+    return tabcorr.Interpolator(tabcorr_list, param_dict_table)
+
+
+def golden_interpolators():
+    cases = [
+        ('interp_2d_auto', dict(shape=(4, 5), n_prim=8, n_sec=1,
+                                tpcf_shape=(7, ), mode='auto', seed=30), False),
+        ('interp_3d_cross', dict(shape=(4, 4, 4), n_prim=6, n_sec=1,
+                                 tpcf_shape=(5, ), mode='cross', seed=31),
+         False),
+        ('interp_2d_mixed', dict(shape=(5, 4), n_prim=5, n_sec=2,
+                                 tpcf_shape=(4, ), mode='auto', seed=32), True)]
+    for name, kw, mixed in cases:
+        tables, keys, points = synthetic.synthetic_interpolator(**kw)
+        if mixed:
+            # Two distinct gal_type tables: exercises the dedup at
+            # interpolator.py:65-70 and per-table normalisation.
+            for k, table in enumerate(tables):
+                if k % 3 == 1:
+                    table['gal_type'] = table['gal_type'].copy()
+                    table['gal_type']['n_h'] *= 1.0 + 0.25 * np.linspace(
+                        -1, 1, len(table['gal_type']))
+        # Shuffle the list order: the Interpolator must sort it back
+        # (interpolator.py:59-61).
+        perm = np.random.default_rng(kw['seed']).permutation(len(tables))
+        tables = [tables[i] for i in perm]
+        points = points[perm]
+        interp = make_reference_interpolator(tables, keys, points)
+        arrays = {'keys': np.array(keys), 'points': points, 'perm': perm}
+        arrays.update(pack_table(tables[0], 'table0_'))
+        arrays['tpcf_matrices'] = np.array(
+            [t['tpcf_matrix'] for t in tables]).astype(np.float32)
+        arrays['n_h'] = np.array([t['gal_type']['n_h'] for t in tables])
+        for d in range(len(keys)):
+            arrays['xp%d' % d] = interp.xp[d]
+            arrays['a%d' % d] = interp.a[d]
+        arrays['unique_gal_type_inverse'] = interp.unique_gal_type_inverse
+
+        n_draws = 24
+        theta = synthetic.zheng07_draws(n_draws, seed=kw['seed'] + 100)
+        rng = np.random.default_rng(kw['seed'] + 200)
+        x = np.stack([rng.uniform(xp[0], xp[-1], size=n_draws)
+                      for xp in interp.xp], axis=-1)
+        x[0] = [xp[-1] for xp in interp.xp]
+        x[1] = [xp[0] for xp in interp.xp]
+        x[2] = [xp[1] for xp in interp.xp]
+        arrays['theta'] = theta
+        arrays['x'] = x
+        auto = kw['mode'] == 'auto'
+        xi_keys = (['centrals-centrals', 'centrals-satellites',
+                    'satellites-satellites'] if auto else
+                   ['centrals', 'satellites'])
+        ngal, xi = [], []
+        ngal_sep = {'centrals': [], 'satellites': []}
+        xi_sep = {key: [] for key in xi_keys}
+        for t, xv in zip(theta, x):
+            model = DuckZheng07(t, **dict(zip(keys, xv)))
+            n, x_ = interp.predict(model)
+            ngal.append(n)
+            xi.append(x_)
+            n_s, x_s = interp.predict(model, separate_gal_type=True)
+            assert list(x_s.keys()) == xi_keys
+            for key in n_s:
+                ngal_sep[key].append(n_s[key])
+            for key in x_s:
+                xi_sep[key].append(x_s[key])
+        arrays['ngal'] = np.array(ngal)
+        arrays['xi'] = np.array(xi)
+        for key in ngal_sep:
+            arrays['ngal_sep_' + key] = np.array(ngal_sep[key])
+        for key in xi_sep:
+            arrays['xi_sep_' + key] = np.array(xi_sep[key])
+
+        # Extrapolation clamps the interval (interpolator.py:327-328).
+        x_out = x[3:7].copy()
+        x_out[0, 0] = interp.xp[0][0] - 0.1
+        x_out[1, -1] = interp.xp[-1][-1] + 0.2
+        x_out[2, 0] = interp.xp[0][-1] + 0.05
+        x_out[3] = [xp[0] - 0.01 for xp in interp.xp]
+        arrays['x_out'] = x_out
+        n_out, xi_out = [], []
+        for t, xv in zip(theta[3:7], x_out):
+            model = DuckZheng07(t, **dict(zip(keys, xv)))
+            try:
+                interp.predict(model)
+                raise RuntimeError('expected ValueError')
+            except ValueError:
+                pass
+            n, x_ = interp.predict(model, extrapolate=True)
+            n_out.append(n)
+            xi_out.append(x_)
+        arrays['ngal_out'] = np.array(n_out)
+        arrays['xi_out'] = np.array(xi_out)
+        save(name, **arrays)
+
+
+# -- 5. helpers: packed index map, spline matrices ---------------------------------------
+
+def golden_helpers():
+    arrays = {}
+    for n in range(1, 8):
+        index = np.arange(n * n).reshape(n, n)
+        arrays['sym_index_%d' % n] = symmetric_matrix_to_array(
+            index, check_symmetry=False)
+    try:
+        symmetric_matrix_to_array(np.arange(9).reshape(3, 3))
+        raise RuntimeError('expected ValueError')
+    except ValueError:
+        pass
+
+    rng = np.random.default_rng(40)
+    for n in [4, 5, 7, 12]:
+        xp = np.sort(rng.uniform(-1, 2, size=n))
+        if n == 5:
+            xp = np.linspace(0.2, 1.4, n)
+        a = spline_interpolation_matrix(xp)
+        arrays['spline_xp_%d' % n] = xp
+        arrays['spline_a_%d' % n] = a
+        yp = rng.normal(size=(n, 3))
+        x = np.concatenate([rng.uniform(xp[0], xp[-1], size=6),
+                            [xp[0], xp[-1], xp[2]]])
+        arrays['spline_yp_%d' % n] = yp
+        arrays['spline_x_%d' % n] = x
+        arrays['spline_y_%d' % n] = np.array(
+            [spline_interpolate(xi, xp, a, yp) for xi in x])
+        x_out = np.array([xp[0] - 0.3, xp[-1] + 0.4])
+        arrays['spline_x_out_%d' % n] = x_out
+        arrays['spline_y_out_%d' % n] = np.array(
+            [spline_interpolate(xi, xp, a, yp, extrapolate=True)
+             for xi in x_out])
+    try:
+        spline_interpolation_matrix(np.arange(3.0))
+        raise RuntimeError('expected ValueError')
+    except ValueError:
+        pass
+
+    # Two-dimensional interpolation.
+    xp = [np.linspace(0, 1, 4), np.array([-1.0, -0.2, 0.1, 0.9, 1.5])]
+    a = [spline_interpolation_matrix(x) for x in xp]
+    yp = rng.normal(size=(4, 5, 2, 3))
+    x = np.stack([rng.uniform(0, 1, size=8), rng.uniform(-1, 1.5, size=8)],
+                 axis=-1)
+    arrays['spline2d_yp'] = yp
+    arrays['spline2d_xp0'] = xp[0]
+    arrays['spline2d_xp1'] = xp[1]
+    arrays['spline2d_x'] = x
+    arrays['spline2d_y'] = np.array(
+        [spline_interpolate(xi, xp, a, yp) for xi in x])
+    save('helpers', **arrays)
+
+
+if __name__ == '__main__':
+    golden_helpers()
+    golden_real_tables()
+    golden_abacus()
+    golden_synthetic()
+    golden_interpolators()

@@ -1,0 +1,234 @@
+"""Pin the CPU oracle against golden vectors recorded from the reference
+(tests/golden/make_golden.py).  CPU only."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from util import (load_golden, table_from_golden, xi_keys, assert_rel,
+                  interpolator_tables_from_golden)
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+from oracle import tabcorr_oracle as oracle  # noqa: E402
+
+RTOL = 1e-12
+
+
+def check_suffix(data, table, suffix, out_suffix='', prefix='', **kwargs):
+    theta = data['theta']
+    n_gauss = kwargs.pop('n_gauss_prim', 10)
+    ngal, xi = oracle.predict_zheng07_batch(
+        table, theta, n_gauss_prim=n_gauss, **kwargs)
+    assert_rel(ngal, data[prefix + 'ngal' + suffix], RTOL)
+    assert_rel(xi, data[prefix + 'xi' + suffix], RTOL)
+    ngal_sep, xi_sep = oracle.predict_zheng07_batch(
+        table, theta, separate_gal_type=True, n_gauss_prim=n_gauss, **kwargs)
+    assert list(ngal_sep.keys()) == ['centrals', 'satellites']
+    assert list(xi_sep.keys()) == xi_keys(table)
+    for key in ngal_sep:
+        assert_rel(ngal_sep[key], data[prefix + 'ngal_sep_' + key + suffix],
+                   RTOL)
+    for key in xi_sep:
+        assert_rel(xi_sep[key], data[prefix + 'xi_sep_' + key + suffix], RTOL,
+                   key)
+
+
+@pytest.mark.parametrize('name', ['bolplanck_wp', 'bolplanck_ds'])
+def test_real_tables(name):
+    data = load_golden(name)
+    table = table_from_golden(data)
+    check_suffix(data, table, '')
+    check_suffix(data, table, '_ng1', n_gauss_prim=1)
+    check_suffix(data, table, '_ng100', n_gauss_prim=100)
+    check_suffix(data, table, '_modulate', modulate_with_cenocc=True)
+
+    for n_gauss, suffix in [(1, '_ng1'), (10, ''), (100, '_ng100')]:
+        occ = np.array([oracle.mean_occupation(
+            table, oracle.Zheng07(t), n_gauss) for t in data['theta']])
+        assert_rel(occ, data['mean_occupation' + suffix], RTOL)
+
+    # ndarray seam (tabcorr/tabcorr.py:616-621)
+    for occ, ngal, xi in zip(data['occ_in'], data['occ_ngal'],
+                             data['occ_xi']):
+        n, x = oracle.predict(table, occ)
+        assert_rel(n, ngal, RTOL)
+        assert_rel(x, xi, RTOL)
+
+
+def test_probe_values_from_survey():
+    # SURVEY.md section 8c quotes these reference outputs.
+    data = load_golden('bolplanck_wp')
+    table = table_from_golden(data)
+    ngal, xi = oracle.predict_zheng07(table, (11.35, 0.25, 11.2, 12.4, 0.83))
+    assert abs(ngal / 0.026615537375339914 - 1) < 1e-13
+    assert np.allclose(xi[:3], [330.56737881, 259.72726108, 205.4014505],
+                       rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize('name', [
+    'synthetic_cfg2', 'synthetic_small_auto', 'synthetic_small_cross',
+    'synthetic_rp_pi', 'synthetic_r1'])
+def test_synthetic(name):
+    data = load_golden(name)
+    table = table_from_golden(data)
+    check_suffix(data, table, '')
+    if 'ngal_ng1' in data.files:
+        check_suffix(data, table, '_ng1', n_gauss_prim=1)
+    assert oracle.predict_zheng07(table, data['theta'][0])[1].shape == tuple(
+        table['tpcf_shape'])
+    if name == 'synthetic_small_auto':
+        legacy = dict(table)
+        names = [n for n in table['gal_type'].dtype.names
+                 if n != 'prim_haloprop_dist_index']
+        legacy['gal_type'] = table['gal_type'][names]
+        check_suffix(data, legacy, '', prefix='legacy_')
+
+
+def test_synthetic_assembias():
+    data = load_golden('synthetic_cfg3')
+    table = table_from_golden(data)
+    check_suffix(data, table, '', assembias=data['assembias'])
+    check_suffix(data, table, '', prefix='plain_')
+
+
+def test_generator_reproduces_committed_tables():
+    """The synthetic generator is deterministic across NumPy versions up to
+    the last bits of libm-derived columns (the fixtures were written under
+    NumPy 1.26, tests run under 2.x)."""
+    from tabcorr_amd import synthetic
+    data = load_golden('synthetic_cfg2')
+    table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    golden = table_from_golden(data)
+    for column in table['gal_type'].dtype.names:
+        if column == 'gal_type':
+            assert np.array_equal(table['gal_type'][column],
+                                  golden['gal_type'][column])
+        else:
+            np.testing.assert_allclose(table['gal_type'][column],
+                                       golden['gal_type'][column], rtol=1e-14)
+    assert np.array_equal(table['gal_type']['prim_haloprop_dist_index'],
+                          golden['gal_type']['prim_haloprop_dist_index'])
+    np.testing.assert_allclose(table['tpcf_matrix'], golden['tpcf_matrix'],
+                               rtol=2e-7)
+    assert np.array_equal(synthetic.zheng07_draws(64, seed=1), data['theta'])
+
+
+def test_abacus_interpolator():
+    data = load_golden('ds_efficient')
+    tables = [table_from_golden(data, 'table%d_' % i) for i in range(4)]
+    setup = oracle.interpolator_setup(tables, data['points'])
+    assert_rel(setup['xp'][0], data['xp0'], 1e-15)
+    assert_rel(setup['a'][0], data['a0'], 1e-9)
+    assert np.array_equal(setup['unique_inverse'],
+                          data['unique_gal_type_inverse'])
+
+    check_suffix(data, tables[0], '', prefix='table0_')
+
+    ngal, xi = oracle.interpolator_predict_zheng07_batch(
+        tables, setup, data['theta'], data['x'])
+    assert_rel(ngal, data['ngal'], RTOL)
+    assert_rel(xi, data['xi'], 1e-11)
+    ngal_sep, xi_sep = oracle.interpolator_predict_zheng07_batch(
+        tables, setup, data['theta'], data['x'], separate_gal_type=True)
+    for key in ['centrals', 'satellites']:
+        assert_rel(ngal_sep[key], data['ngal_sep_' + key], RTOL)
+        assert_rel(xi_sep[key], data['xi_sep_' + key], 1e-11)
+
+    for x_out, ngal_out, xi_out in zip(data['x_out'], data['ngal_out'],
+                                       data['xi_out']):
+        model = oracle.Zheng07(data['theta'][0])
+        with pytest.raises(ValueError):
+            oracle.interpolator_predict(tables, setup, model, x_out)
+        n, x = oracle.interpolator_predict(tables, setup, model, x_out,
+                                           extrapolate=True)
+        assert_rel(n, ngal_out, RTOL)
+        assert_rel(x, xi_out, 1e-11)
+
+
+@pytest.mark.parametrize('name', ['interp_2d_auto', 'interp_3d_cross',
+                                  'interp_2d_mixed'])
+def test_synthetic_interpolators(name):
+    data = load_golden(name)
+    tables = interpolator_tables_from_golden(data)
+    setup = oracle.interpolator_setup(tables, data['points'])
+    for d in range(data['points'].shape[1]):
+        assert_rel(setup['xp'][d], data['xp%d' % d], 1e-15)
+        assert_rel(setup['a'][d], data['a%d' % d], 1e-9)
+    # Same partition into unique gal_type tables (labels may be permuted).
+    inverse = data['unique_gal_type_inverse']
+    assert len(np.unique(setup['unique_inverse'])) == len(np.unique(inverse))
+    for u in np.unique(inverse):
+        assert len(np.unique(setup['unique_inverse'][inverse == u])) == 1
+
+    ngal, xi = oracle.interpolator_predict_zheng07_batch(
+        tables, setup, data['theta'], data['x'])
+    assert_rel(ngal, data['ngal'], 1e-11)
+    assert_rel(xi, data['xi'], 1e-10)
+    ngal_sep, xi_sep = oracle.interpolator_predict_zheng07_batch(
+        tables, setup, data['theta'], data['x'], separate_gal_type=True)
+    for key in ngal_sep:
+        assert_rel(ngal_sep[key], data['ngal_sep_' + key], 1e-11)
+    assert list(xi_sep.keys()) == xi_keys(tables[0])
+    for key in xi_sep:
+        assert_rel(xi_sep[key], data['xi_sep_' + key], 1e-10)
+
+    with pytest.raises(ValueError):
+        oracle.interpolator_predict_zheng07_batch(
+            tables, setup, data['theta'][3:7], data['x_out'])
+    ngal, xi = oracle.interpolator_predict_zheng07_batch(
+        tables, setup, data['theta'][3:7], data['x_out'], extrapolate=True)
+    assert_rel(ngal, data['ngal_out'], 1e-11)
+    assert_rel(xi, data['xi_out'], 1e-10)
+
+
+def test_helpers():
+    data = load_golden('helpers')
+    for n in range(1, 8):
+        index = np.arange(n * n).reshape(n, n)
+        assert np.array_equal(
+            oracle.symmetric_matrix_to_array(index, check_symmetry=False),
+            data['sym_index_%d' % n])
+        i1, i2, pre = oracle.pair_indices(n)
+        assert np.array_equal(i1 * n + i2, data['sym_index_%d' % n])
+        assert np.array_equal(pre, np.where(i1 == i2, 1, 2))
+    with pytest.raises(ValueError):
+        oracle.symmetric_matrix_to_array(np.arange(9).reshape(3, 3))
+    with pytest.raises(ValueError):
+        oracle.spline_interpolation_matrix(np.arange(3.0))
+
+    for n in [4, 5, 7, 12]:
+        xp = data['spline_xp_%d' % n]
+        a = oracle.spline_interpolation_matrix(xp)
+        assert_rel(a, data['spline_a_%d' % n], 1e-9)
+        yp = data['spline_yp_%d' % n]
+        y = np.array([oracle.spline_interpolate(x, xp, a, yp)
+                      for x in data['spline_x_%d' % n]])
+        assert_rel(y, data['spline_y_%d' % n], 1e-10)
+        for x in data['spline_x_out_%d' % n]:
+            with pytest.raises(ValueError):
+                oracle.spline_interpolate(x, xp, a, yp)
+        y = np.array([oracle.spline_interpolate(x, xp, a, yp, extrapolate=True)
+                      for x in data['spline_x_out_%d' % n]])
+        assert_rel(y, data['spline_y_out_%d' % n], 1e-10)
+
+    xp = [data['spline2d_xp0'], data['spline2d_xp1']]
+    a = [oracle.spline_interpolation_matrix(x) for x in xp]
+    y = np.array([oracle.spline_interpolate(x, xp, a, data['spline2d_yp'])
+                  for x in data['spline2d_x']])
+    assert_rel(y, data['spline2d_y'], 1e-10)
+
+
+def test_spline_matches_scipy():
+    # The reference's own invariant (tests/test_general.py:46-69): along one
+    # axis the spline equals scipy's cubic interp1d.
+    from scipy.interpolate import interp1d
+    rng = np.random.default_rng(0)
+    xp = np.sort(rng.uniform(0, 1, size=6))
+    yp = rng.normal(size=(6, 4))
+    a = oracle.spline_interpolation_matrix(xp)
+    for x in np.linspace(xp[0], xp[-1], 10):
+        y = oracle.spline_interpolate(x, xp, a, yp)
+        y_scipy = [interp1d(xp, yp[:, i], kind='cubic')(x) for i in range(4)]
+        assert np.allclose(y, y_scipy)
