@@ -1,0 +1,212 @@
+/*
+ * tabcorr_amd.h -- C ABI of libtabcorr_hip.so, the MI355X (gfx950) implementation
+ * of TabCorr's predict() path.
+ *
+ * The reference (johannesulf/TabCorr v1.2.0) is pure Python and has no FFI layer;
+ * the seam this library sits behind is the Python class surface.  Each entry point
+ * below names the reference code it replaces (paths relative to the reference
+ * repository root).  The library is loaded with ctypes by tabcorr_amd/_lib.py;
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C symbols, opaque handles, int status return (0 = TC_OK), no exceptions
+ *     cross the boundary; tc_last_error() returns a thread-local message.
+ *   - all host arrays are caller-owned, C-contiguous, little-endian; outputs are
+ *     caller-allocated.  The library never frees caller memory.
+ *   - functions with the suffix _device take DEVICE pointers, enqueue work on the
+ *     handle's stream and return without synchronising (tc_*_synchronize waits).
+ *   - a handle is bound to the HIP device that was current when it was created and
+ *     must be used by one host thread at a time.
+ *   - there is no CPU fallback: every compute entry point fails with TC_ERR_HIP when
+ *     no gfx950 device is usable.
+ */
+#ifndef TABCORR_AMD_H
+#define TABCORR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TC_OK 0
+#define TC_ERR_INVALID 1     /* bad argument (Python side raises ValueError) */
+#define TC_ERR_HIP 2         /* HIP runtime / device failure (RuntimeError) */
+#define TC_ERR_UNSUPPORTED 3 /* valid request this build cannot serve */
+#define TC_ERR_RCCL 4        /* RCCL failure */
+
+/* tabcorr/tabcorr.py:625,648 -- attrs['mode'] */
+#define TC_MODE_AUTO 0
+#define TC_MODE_CROSS 1
+
+/* element type of a correlation matrix handed to tc_table_create */
+#define TC_DTYPE_F64 0
+#define TC_DTYPE_F32 1
+
+/* flags of the predict entry points */
+#define TC_FLAG_SEPARATE_GAL_TYPE 1u  /* predict(..., separate_gal_type=True), tabcorr.py:652-683 */
+#define TC_FLAG_MODULATE_WITH_CENOCC 2u /* <N_sat> *= <N_cen> (halotools Zheng07Sats option) */
+#define TC_FLAG_ASSEMBIAS 4u          /* theta carries 2 extra Heaviside assembly-bias strengths */
+#define TC_FLAG_LEGACY_NO_DIST_INDEX 8u /* table without prim_haloprop_dist_index, tabcorr.py:571-574 */
+
+typedef struct tc_table tc_table;
+typedef struct tc_interp tc_interp;
+typedef struct tc_comm tc_comm;
+
+/* ---- runtime ---------------------------------------------------------------------- */
+
+const char* tc_last_error(void);
+int tc_device_count(int* count);
+int tc_set_device(int device);
+int tc_get_device(int* device);
+/* HIP runtime version the library is bound to (guards against a second HIP runtime in
+ * the process) and a short device description. */
+int tc_runtime_version(int* version);
+int tc_device_name(char* buffer, size_t size);
+int tc_device_synchronize(void);
+
+/* Device memory for callers that keep draws / results resident (bench.py, multi-GPU). */
+int tc_device_malloc(void** ptr, size_t bytes);
+int tc_device_free(void* ptr);
+int tc_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes);
+int tc_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes);
+
+/* ---- helpers exported for the host-side tests (pure host code, no GPU needed) ------- */
+
+/* Gauss-Legendre nodes mapped to (0, 1) and weights, as tabcorr.py:543-546
+ * (np.polynomial.legendre.leggauss(n); x = (x + 1) / 2). */
+int tc_gauss_legendre(int n, double* x, double* w);
+
+/* Packed-pair index map of tabcorr.py:770-806 / 626-639: for every packed column p the
+ * row index i1, column index i2 (i2 <= i1) and prefactor (1 on the diagonal, else 2). */
+int tc_pair_indices(int n_bins, int32_t* index_1, int32_t* index_2, int32_t* prefactor);
+
+/* Not-a-knot cubic spline matrix a[(n-1)][4][n] of interpolator.py:219-272. */
+int tc_spline_interpolation_matrix(int n, const double* xp, double* a);
+
+/* Work decomposition used by the contraction kernel for a table with n_bins rows of which
+ * the first n_central (after the library's stable sort by gal_type) are centrals, cut into
+ * n_chunks wave-sized pieces.  Outputs one record per packed column, in processing order:
+ * entry_pair[e] = packed column p (auto) or bin (cross), entry_chunk[e], entry_class[e]
+ * (0 cen-cen / cen, 1 cen-sat, 2 sat-sat / sat).  Lets CPU tests check the kernel's
+ * traversal covers every column exactly once. */
+int tc_plan_debug(int mode, int n_bins, const uint8_t* is_central, int n_chunks,
+                  int64_t* n_entries, int32_t* entry_pair, int32_t* entry_chunk,
+                  int32_t* entry_class);
+
+/* ---- one tabulated table (replaces the state of a `TabCorr` instance) ----------------
+ *
+ * tc_table_create uploads everything predict() needs from a TabCorr object
+ * (tabcorr.py:356-368): the correlation matrix `tpcf_matrix` (R x P, row-major, P =
+ * G (G + 1) / 2 packed lower triangle in mode auto, P = G in mode cross) and the
+ * gal_type columns read at tabcorr.py:537-541, 568-570, 623.  It precomputes what the
+ * reference caches lazily on `self` (pair indices, tabcorr.py:626-639; Gauss-Legendre
+ * nodes, :543-546).  compute_dtype selects the arithmetic of the contraction: F64
+ * (default, parity <= 1e-10) or F32 (table and accumulation in float, for BASELINE
+ * configs[4]; stated tolerance 1e-5).  Occupations are always evaluated in F64.
+ */
+int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
+                    const void* tpcf_matrix, int matrix_dtype,
+                    const double* n_h,
+                    const double* log_prim_haloprop_min,
+                    const double* log_prim_haloprop_max,
+                    const double* sec_haloprop_percentile,
+                    const double* prim_haloprop_dist_index, /* NULL: legacy table */
+                    const uint8_t* is_central,              /* 1 = 'centrals' row */
+                    int compute_dtype,
+                    tc_table** table);
+int tc_table_destroy(tc_table* table);
+int tc_table_synchronize(tc_table* table);
+
+/* Shape queries: n_bins, n_r, n_pairs, number of xi components with
+ * TC_FLAG_SEPARATE_GAL_TYPE (3 auto / 2 cross), table bytes resident in HBM. */
+int tc_table_info(const tc_table* table, int* mode, int* n_bins, int* n_r,
+                  int64_t* n_pairs, int* n_components, int64_t* device_bytes);
+
+/* TabCorr.mean_occupation(model) for a batch of Zheng07 parameter vectors
+ * (tabcorr.py:465-578 with the halotools callbacks of :556-563 evaluated on device).
+ * theta: (n_draws, n_theta) with columns logMmin, sigma_logM, logM0, logM1, alpha
+ * [, A_cen, A_sat when TC_FLAG_ASSEMBIAS]; occupation out: (n_draws, n_bins). */
+int tc_mean_occupation_zheng07_batch(tc_table* table, const double* theta, int n_theta,
+                                     int64_t n_draws, int n_gauss_prim, unsigned flags,
+                                     double* occupation);
+
+/* TabCorr.predict(model) for a batch of Zheng07 draws (tabcorr.py:580-683).
+ * Outputs, without TC_FLAG_SEPARATE_GAL_TYPE: ngal (n_draws), xi (n_draws, n_r).
+ * With it: ngal (n_draws, 2) [centrals, satellites]; xi (n_draws, n_components, n_r) in
+ * the reference's dict order (centrals-centrals, centrals-satellites,
+ * satellites-satellites | centrals, satellites). */
+int tc_predict_zheng07_batch(tc_table* table, const double* theta, int n_theta,
+                             int64_t n_draws, int n_gauss_prim, unsigned flags,
+                             double* ngal, double* xi);
+int tc_predict_zheng07_batch_device(tc_table* table, const double* theta_device,
+                                    int n_theta, int64_t n_draws, int n_gauss_prim,
+                                    unsigned flags, double* ngal_device,
+                                    double* xi_device);
+
+/* TabCorr.predict(ndarray): the operator seam of tabcorr.py:616-621 for arbitrary
+ * occupation models evaluated by the caller.  occupation: (n_draws, n_bins). */
+int tc_predict_occupation_batch(tc_table* table, const double* occupation,
+                                int64_t n_draws, unsigned flags, double* ngal,
+                                double* xi);
+
+/* ---- interpolation over a grid of tables (replaces `Interpolator`) -------------------
+ *
+ * tables: K handles in tabcorr_list order.  points: (K, n_dim) extra-parameter values
+ * of each table (the rows of param_dict_table, interpolator.py:14-61).  The library
+ * validates the grid (TC_ERR_INVALID if it is not one, interpolator.py:45-57), builds
+ * the spline matrices (interpolator.py:219-272) and shares occupations between tables
+ * whose gal_type tables are identical (interpolator.py:63-70).
+ */
+int tc_interp_create(tc_table* const* tables, int n_tables, int n_dim,
+                     const double* points, tc_interp** interp);
+int tc_interp_destroy(tc_interp* interp);
+int tc_interp_synchronize(tc_interp* interp);
+/* abscissae of dimension d (sorted unique values): returns n and copies min(n, size). */
+int tc_interp_axis(const tc_interp* interp, int dim, int* n, double* xp, int size);
+
+/* Interpolator.predict(model) for a batch (interpolator.py:124-216): theta as above,
+ * x: (n_draws, n_dim) values of the extra parameters (model.param_dict[key]).
+ * Out-of-range x is clamped to the outermost spline segment (extrapolate=True,
+ * interpolator.py:327-328); the extrapolate=False ValueError is raised by the host
+ * class before the call.  Outputs as tc_predict_zheng07_batch. */
+int tc_interp_predict_zheng07_batch(tc_interp* interp, const double* theta, int n_theta,
+                                    const double* x, int64_t n_draws, int n_gauss_prim,
+                                    unsigned flags, double* ngal, double* xi);
+int tc_interp_predict_zheng07_batch_device(tc_interp* interp, const double* theta_device,
+                                           int n_theta, const double* x_device,
+                                           int64_t n_draws, int n_gauss_prim,
+                                           unsigned flags, double* ngal_device,
+                                           double* xi_device);
+
+/* ---- measurement -------------------------------------------------------------------
+ * HIP events on the handle's own stream (torch.cuda.Event would only see torch's).
+ * tc_table_timer_begin/end bracket a region; with profile = 1 every launch of the
+ * contraction kernel is additionally bracketed by its own event pair and
+ * tc_table_kernel_time reports the count and mean duration since timer_begin. */
+int tc_table_timer_begin(tc_table* table, int profile_kernels);
+int tc_table_timer_end(tc_table* table, float* elapsed_ms);
+int tc_table_kernel_time(tc_table* table, int* n_launches, float* mean_ms);
+/* Launch geometry of the last predict call (for DESIGN.md / bench.py reporting). */
+int tc_table_last_launch(const tc_table* table, int* n_workgroups, int* waves_per_workgroup,
+                         int* n_splits, int* lds_bytes);
+
+/* ---- multi-GPU: one process per GPU, results collected with one RCCL gather ---------- */
+
+#define TC_UNIQUE_ID_BYTES 128
+int tc_comm_unique_id(void* id /* TC_UNIQUE_ID_BYTES */);
+int tc_comm_create(const void* id, int n_ranks, int rank, tc_comm** comm);
+int tc_comm_destroy(tc_comm* comm);
+/* Gather `count` doubles from every rank's send_device into recv_device on `root`
+ * (rank-major), on the communicator's own stream, after `table`'s stream has drained. */
+int tc_comm_gather(tc_comm* comm, tc_table* table, const double* send_device,
+                   double* recv_device, int64_t count, int root);
+int tc_comm_barrier(tc_comm* comm);
+int tc_comm_synchronize(tc_comm* comm);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* TABCORR_AMD_H */

@@ -1,0 +1,15 @@
+"""tabcorr_amd: TabCorr's predict() path on AMD Instinct MI355X (gfx950).
+
+Same class surface as johannesulf/TabCorr (``TabCorr``, ``Interpolator``);
+the arithmetic runs in hand-written HIP kernels behind a C ABI
+(``include/tabcorr_amd.h``), loaded with ctypes.  There is no CPU fallback.
+"""
+
+from .tabcorr import TabCorr, symmetric_matrix_to_array
+from .models import Zheng07Model
+from .galtable import GalTypeTable
+from . import synthetic
+
+__version__ = '0.1.0'
+__all__ = ['TabCorr', 'Zheng07Model', 'GalTypeTable',
+           'symmetric_matrix_to_array', 'synthetic']

@@ -1,0 +1,896 @@
+// C ABI of libtabcorr_hip.so (declared in include/tabcorr_amd.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/tabcorr_amd.h"
+#include "hostmath.h"
+#include "kernels.hip.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* format, ...) {
+  char buffer[1024];
+  va_list args;
+  va_start(args, format);
+  vsnprintf(buffer, sizeof(buffer), format, args);
+  va_end(args);
+  g_last_error = buffer;
+  return code;
+}
+
+#define TC_HIP(call)                                                          \
+  do {                                                                        \
+    hipError_t tc_hip_status = (call);                                        \
+    if (tc_hip_status != hipSuccess)                                          \
+      return fail(TC_ERR_HIP, "%s failed: %s (%s:%d)", #call,                 \
+                  hipGetErrorString(tc_hip_status), __FILE__, __LINE__);      \
+  } while (0)
+
+#define TC_CHECK(condition, ...)                                              \
+  do {                                                                        \
+    if (!(condition)) return fail(TC_ERR_INVALID, __VA_ARGS__);               \
+  } while (0)
+
+// A device allocation that can only grow (never reallocated while a launch
+// that uses it may be in flight: growth synchronises the stream first).
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t need, hipStream_t stream) {
+    if (need <= bytes) return TC_OK;
+    if (ptr != nullptr) {
+      TC_HIP(hipStreamSynchronize(stream));
+      TC_HIP(hipFree(ptr));
+      ptr = nullptr;
+      bytes = 0;
+    }
+    size_t grow = need + need / 4;
+    TC_HIP(hipMalloc(&ptr, grow));
+    bytes = grow;
+    return TC_OK;
+  }
+  void release() {
+    if (ptr != nullptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+};
+
+template <typename T>
+int upload(const std::vector<T>& host, void** device) {
+  size_t bytes = std::max<size_t>(1, host.size()) * sizeof(T);
+  TC_HIP(hipMalloc(device, bytes));
+  if (!host.empty())
+    TC_HIP(hipMemcpy(*device, host.data(), host.size() * sizeof(T),
+                     hipMemcpyHostToDevice));
+  return TC_OK;
+}
+
+struct DeviceChunking {
+  tc::Chunking host;
+  void* segments = nullptr;
+  void* chunks = nullptr;
+  void* groups = nullptr;
+};
+
+struct Quadrature {
+  int n_gauss = 0;
+  void* log_m = nullptr;
+  void* m = nullptr;
+  void* weight = nullptr;
+};
+
+int env_int(const char* name, int fallback) {
+  const char* value = getenv(name);
+  if (value == nullptr || *value == 0) return fallback;
+  return atoi(value);
+}
+
+}  // namespace
+
+struct tc_table {
+  int device = 0;
+  int mode = 0;
+  int n_bins = 0;
+  int n_r = 0;
+  int64_t n_pairs = 0;
+  int compute_dtype = TC_DTYPE_F64;
+  bool legacy = false;
+  tc::Plan plan;
+  int rt = 0;          // r values per tile (compile-time kernel parameter)
+  int n_rtiles = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+
+  // host copies of the gal_type columns in library (centrals-first) order
+  std::vector<double> n_h, log_min, log_max, percentile, dist_index;
+
+  void* d_table = nullptr;       // (n_rtiles, n_entries, rt)
+  size_t table_bytes = 0;
+  void* d_n_h = nullptr;
+  void* d_percentile = nullptr;
+  void* d_perm = nullptr;
+  std::map<int, Quadrature> quadrature;
+  std::map<std::pair<int, int>, std::unique_ptr<DeviceChunking>> chunkings;
+
+  DeviceBuffer theta, nbuf, ngal2, partial, out_ngal, out_xi, occupation;
+
+  // measurement
+  bool profile_kernels = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> kernel_events;
+  size_t kernel_events_used = 0;
+  int last_workgroups = 0, last_waves = 0, last_splits = 0, last_lds = 0;
+};
+
+namespace {
+
+int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
+  auto it = t->quadrature.find(n_gauss);
+  if (it != t->quadrature.end()) {
+    *out = &it->second;
+    return TC_OK;
+  }
+  // tabcorr/tabcorr.py:543-549, 568-578: nodes, node masses and the weights
+  // w_k M^(d + 1) / sum_k w_k M^(d + 1), normalised here once per table.  The
+  // power is taken relative to the first node so that M^11 cannot overflow.
+  std::vector<double> x, w;
+  tc::gauss_legendre(n_gauss, x, w);
+  const int g = t->n_bins;
+  std::vector<double> log_m((size_t)g * n_gauss), m((size_t)g * n_gauss),
+      weight((size_t)g * n_gauss);
+  for (int i = 0; i < g; ++i) {
+    const double d_log = t->log_max[i] - t->log_min[i];
+    const double exponent = t->legacy ? 0.0 : t->dist_index[i] + 1.0;
+    long double norm = 0.0L;
+    std::vector<long double> raw(n_gauss);
+    for (int k = 0; k < n_gauss; ++k) {
+      const double mass = std::pow(10.0, t->log_min[i] + d_log * x[k]);
+      m[(size_t)i * n_gauss + k] = mass;
+      log_m[(size_t)i * n_gauss + k] = std::log10(mass);
+      const double m_ref = m[(size_t)i * n_gauss];
+      raw[k] = (long double)w[k] *
+               powl((long double)mass / (long double)m_ref, (long double)exponent);
+      norm += raw[k];
+    }
+    for (int k = 0; k < n_gauss; ++k)
+      weight[(size_t)i * n_gauss + k] = (double)(raw[k] / norm);
+  }
+  Quadrature q;
+  q.n_gauss = n_gauss;
+  int status = upload(log_m, &q.log_m);
+  if (status == TC_OK) status = upload(m, &q.m);
+  if (status == TC_OK) status = upload(weight, &q.weight);
+  if (status != TC_OK) return status;
+  t->quadrature[n_gauss] = q;
+  *out = &t->quadrature[n_gauss];
+  return TC_OK;
+}
+
+int get_chunking(tc_table* t, int n_chunks, int waves, DeviceChunking** out) {
+  auto key = std::make_pair(n_chunks, waves);
+  auto it = t->chunkings.find(key);
+  if (it != t->chunkings.end()) {
+    *out = it->second.get();
+    return TC_OK;
+  }
+  std::unique_ptr<DeviceChunking> c(new DeviceChunking);
+  tc::build_chunking(t->plan, n_chunks, waves, c->host);
+  int status = upload(c->host.segments, &c->segments);
+  if (status == TC_OK) status = upload(c->host.chunks, &c->chunks);
+  if (status == TC_OK) status = upload(c->host.groups, &c->groups);
+  if (status != TC_OK) return status;
+  *out = c.get();
+  t->chunkings[key] = std::move(c);
+  return TC_OK;
+}
+
+// Largest dynamic LDS allocation a workgroup may ask for (160 KiB per CU).
+constexpr int kMaxLdsBytes = 160 * 1024;
+
+// Pick the decomposition for a batch: enough wave-sized chunks to give every
+// SIMD of the 256 CUs several waves, grouped into workgroups whose staged rows
+// fit in LDS.
+int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
+                    DeviceChunking** out, int* lds_bytes) {
+  const int64_t n_tiles = (n_draws + 63) / 64;
+  const int64_t target_waves = env_int("TC_TARGET_WAVES", 4096);
+  int64_t n_chunks = target_waves / std::max<int64_t>(1, n_tiles * t->n_rtiles);
+  const int64_t min_entries = env_int("TC_MIN_CHUNK_ENTRIES", 48);
+  n_chunks = std::min<int64_t>(n_chunks, t->plan.n_entries / min_entries);
+  n_chunks = std::max<int64_t>(n_chunks, 1);
+  n_chunks = std::min<int64_t>(n_chunks, 4096);
+  n_chunks = env_int("TC_NCHUNKS", (int)n_chunks);
+  int waves = env_int("TC_NWAVES", 8);
+  waves = std::max(1, std::min(waves, 16));
+  waves = (int)std::min<int64_t>(waves, n_chunks);
+
+  for (int attempt = 0; attempt < 16; ++attempt) {
+    DeviceChunking* c = nullptr;
+    int status = get_chunking(t, (int)n_chunks, waves, &c);
+    if (status != TC_OK) return status;
+    int bytes = std::max(c->host.max_rows, n_comp_out * t->rt) * 64 * 8;
+    if (bytes <= kMaxLdsBytes) {
+      *out = c;
+      *lds_bytes = bytes;
+      return TC_OK;
+    }
+    // Mode cross: more, narrower groups touch fewer rows each.
+    if (t->mode == TC_MODE_CROSS) {
+      if (waves > 1) waves /= 2; else n_chunks *= 2;
+      if (n_chunks > t->plan.n_entries) break;
+      continue;
+    }
+    break;
+  }
+  return fail(TC_ERR_UNSUPPORTED,
+              "table with %d bins needs more than %d bytes of LDS per workgroup "
+              "in mode '%s'",
+              t->n_bins, kMaxLdsBytes, t->mode == TC_MODE_AUTO ? "auto" : "cross");
+}
+
+template <typename TableT>
+int launch_contract_rt(int rt, dim3 grid, dim3 block, int lds, hipStream_t stream,
+                       const tc::ContractArgs& args) {
+  switch (rt) {
+#define TC_CASE(N)                                                            \
+  case N:                                                                     \
+    hipLaunchKernelGGL((tc::contract_kernel<N, TableT>), grid, block, lds,    \
+                       stream, args);                                         \
+    break;
+    TC_CASE(2) TC_CASE(4) TC_CASE(6) TC_CASE(8) TC_CASE(10) TC_CASE(12)
+    TC_CASE(14) TC_CASE(16) TC_CASE(18) TC_CASE(20) TC_CASE(22) TC_CASE(24)
+    TC_CASE(26) TC_CASE(28) TC_CASE(30) TC_CASE(32)
+#undef TC_CASE
+    default:
+      return fail(TC_ERR_UNSUPPORTED, "no kernel for r tile %d", rt);
+  }
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+
+template <typename TableT>
+int set_lds_limit_rt(int rt, int lds) {
+  switch (rt) {
+#define TC_CASE(N)                                                            \
+  case N:                                                                     \
+    TC_HIP(hipFuncSetAttribute(                                               \
+        reinterpret_cast<const void*>(&tc::contract_kernel<N, TableT>),       \
+        hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \
+    break;
+    TC_CASE(2) TC_CASE(4) TC_CASE(6) TC_CASE(8) TC_CASE(10) TC_CASE(12)
+    TC_CASE(14) TC_CASE(16) TC_CASE(18) TC_CASE(20) TC_CASE(22) TC_CASE(24)
+    TC_CASE(26) TC_CASE(28) TC_CASE(30) TC_CASE(32)
+#undef TC_CASE
+    default:
+      break;
+  }
+  return TC_OK;
+}
+
+// Contraction + finalisation of draws whose densities are already in nbuf / ngal2.
+int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
+                    double* ngal_device, double* xi_device) {
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  const int n_comp = separate ? t->plan.n_components : 1;
+  DeviceChunking* c = nullptr;
+  int lds = 0;
+  int status = choose_chunking(t, n_draws, n_comp, &c, &lds);
+  if (status != TC_OK) return status;
+  const int n_groups = (int)c->host.groups.size();
+  const int r_stride = t->rt * t->n_rtiles;
+  status = t->partial.reserve(
+      (size_t)n_groups * n_comp * r_stride * ldb * sizeof(double), t->stream);
+  if (status != TC_OK) return status;
+
+  tc::ContractArgs ca;
+  ca.nbuf = (const double*)t->nbuf.ptr;
+  ca.ldb = ldb;
+  ca.table = t->d_table;
+  ca.n_entries = t->plan.n_entries;
+  ca.segments = (const tc::Segment*)c->segments;
+  ca.chunks = (const tc::Chunk*)c->chunks;
+  ca.groups = (const tc::Group*)c->groups;
+  ca.n_components_out = n_comp;
+  ca.r_stride = r_stride;
+  ca.partial = (double*)t->partial.ptr;
+
+  dim3 grid((unsigned)(ldb / 64), (unsigned)n_groups, (unsigned)t->n_rtiles);
+  dim3 block(64 * c->host.waves_per_group);
+  if (lds > 64 * 1024) {
+    status = t->compute_dtype == TC_DTYPE_F64 ? set_lds_limit_rt<double>(t->rt, lds)
+                                              : set_lds_limit_rt<float>(t->rt, lds);
+    if (status != TC_OK) return status;
+  }
+  hipEvent_t k0 = nullptr, k1 = nullptr;
+  if (t->profile_kernels) {
+    if (t->kernel_events_used == t->kernel_events.size()) {
+      hipEvent_t e0, e1;
+      TC_HIP(hipEventCreate(&e0));
+      TC_HIP(hipEventCreate(&e1));
+      t->kernel_events.emplace_back(e0, e1);
+    }
+    k0 = t->kernel_events[t->kernel_events_used].first;
+    k1 = t->kernel_events[t->kernel_events_used].second;
+    ++t->kernel_events_used;
+    TC_HIP(hipEventRecord(k0, t->stream));
+  }
+  status = t->compute_dtype == TC_DTYPE_F64
+               ? launch_contract_rt<double>(t->rt, grid, block, lds, t->stream, ca)
+               : launch_contract_rt<float>(t->rt, grid, block, lds, t->stream, ca);
+  if (status != TC_OK) return status;
+  if (t->profile_kernels) TC_HIP(hipEventRecord(k1, t->stream));
+  t->last_workgroups = (int)(grid.x * grid.y * grid.z);
+  t->last_waves = c->host.waves_per_group;
+  t->last_splits = n_groups;
+  t->last_lds = lds;
+
+  tc::FinalizeArgs fa;
+  fa.partial = (const double*)t->partial.ptr;
+  fa.ngal_in = (const double*)t->ngal2.ptr;
+  fa.n_groups = n_groups;
+  fa.n_comp = n_comp;
+  fa.r_stride = r_stride;
+  fa.n_r = t->n_r;
+  fa.mode = t->mode;
+  fa.ldb = ldb;
+  fa.n_draws = n_draws;
+  fa.ngal = ngal_device;
+  fa.xi = xi_device;
+  hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)((n_draws + 255) / 256)),
+                     dim3(256), 0, t->stream, fa);
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+
+int run_occupation(tc_table* t, const double* theta_device, int n_theta,
+                   int64_t n_draws, int64_t ldb, int n_gauss, unsigned flags,
+                   double* occupation_device) {
+  Quadrature* q = nullptr;
+  int status = get_quadrature(t, n_gauss, &q);
+  if (status != TC_OK) return status;
+  status = t->nbuf.reserve((size_t)t->n_bins * ldb * sizeof(double), t->stream);
+  if (status == TC_OK) status = t->ngal2.reserve(2 * ldb * sizeof(double), t->stream);
+  if (status != TC_OK) return status;
+  tc::OccArgs oa;
+  oa.theta = theta_device;
+  oa.n_theta = n_theta;
+  oa.n_draws = n_draws;
+  oa.ldb = ldb;
+  oa.n_bins = t->n_bins;
+  oa.n_central = t->plan.n_central;
+  oa.n_gauss = n_gauss;
+  oa.flags = flags;
+  oa.split = 0.5;
+  oa.log_m = (const double*)q->log_m;
+  oa.m = (const double*)q->m;
+  oa.weight = (const double*)q->weight;
+  oa.n_h = (const double*)t->d_n_h;
+  oa.percentile = (const double*)t->d_percentile;
+  oa.perm = (const int32_t*)t->d_perm;
+  oa.nbuf = (double*)t->nbuf.ptr;
+  oa.ngal = (double*)t->ngal2.ptr;
+  oa.occupation = occupation_device;
+  hipLaunchKernelGGL(tc::occ_zheng07_kernel, dim3((unsigned)(ldb / 64)),
+                     dim3(tc::kOccWaves * 64), 0, t->stream, oa);
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+
+int check_predict_args(const tc_table* t, const void* theta, int n_theta,
+                       int64_t n_draws, int n_gauss, unsigned flags) {
+  TC_CHECK(t != nullptr, "table handle is NULL");
+  TC_CHECK(n_draws >= 0, "n_draws must be non-negative");
+  TC_CHECK(n_draws == 0 || theta != nullptr, "theta is NULL");
+  TC_CHECK(n_gauss >= 1 && n_gauss <= 4096, "n_gauss_prim must be in [1, 4096]");
+  const int need = (flags & TC_FLAG_ASSEMBIAS) ? 7 : 5;
+  TC_CHECK(n_theta == need, "theta must have %d columns, got %d", need, n_theta);
+  return TC_OK;
+}
+
+// Draws are processed in slabs so that the workspaces stay bounded.
+constexpr int64_t kMaxSlab = 1 << 18;
+
+}  // namespace
+
+extern "C" {
+
+const char* tc_last_error(void) { return g_last_error.c_str(); }
+
+int tc_device_count(int* count) {
+  TC_CHECK(count != nullptr, "count is NULL");
+  *count = 0;
+  hipError_t status = hipGetDeviceCount(count);
+  if (status != hipSuccess) {
+    *count = 0;
+    return fail(TC_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(status));
+  }
+  return TC_OK;
+}
+
+int tc_set_device(int device) {
+  TC_HIP(hipSetDevice(device));
+  return TC_OK;
+}
+
+int tc_get_device(int* device) {
+  TC_CHECK(device != nullptr, "device is NULL");
+  TC_HIP(hipGetDevice(device));
+  return TC_OK;
+}
+
+int tc_runtime_version(int* version) {
+  TC_CHECK(version != nullptr, "version is NULL");
+  TC_HIP(hipRuntimeGetVersion(version));
+  return TC_OK;
+}
+
+int tc_device_name(char* buffer, size_t size) {
+  TC_CHECK(buffer != nullptr && size > 0, "buffer is NULL");
+  int device = 0;
+  TC_HIP(hipGetDevice(&device));
+  hipDeviceProp_t prop;
+  TC_HIP(hipGetDeviceProperties(&prop, device));
+  snprintf(buffer, size, "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
+           prop.multiProcessorCount);
+  return TC_OK;
+}
+
+int tc_device_synchronize(void) {
+  TC_HIP(hipDeviceSynchronize());
+  return TC_OK;
+}
+
+int tc_device_malloc(void** ptr, size_t bytes) {
+  TC_CHECK(ptr != nullptr, "ptr is NULL");
+  TC_HIP(hipMalloc(ptr, std::max<size_t>(bytes, 1)));
+  return TC_OK;
+}
+
+int tc_device_free(void* ptr) {
+  if (ptr != nullptr) TC_HIP(hipFree(ptr));
+  return TC_OK;
+}
+
+int tc_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+  TC_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return TC_OK;
+}
+
+int tc_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+  TC_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return TC_OK;
+}
+
+int tc_gauss_legendre(int n, double* x, double* w) {
+  TC_CHECK(n >= 1 && x != nullptr && w != nullptr, "invalid arguments");
+  std::vector<double> xs, ws;
+  tc::gauss_legendre(n, xs, ws);
+  std::copy(xs.begin(), xs.end(), x);
+  std::copy(ws.begin(), ws.end(), w);
+  return TC_OK;
+}
+
+int tc_pair_indices(int n_bins, int32_t* index_1, int32_t* index_2,
+                    int32_t* prefactor) {
+  TC_CHECK(n_bins >= 0 && index_1 && index_2 && prefactor, "invalid arguments");
+  int64_t p = 0;
+  for (int i = 0; i < n_bins; ++i) {
+    for (int j = 0; j <= i; ++j, ++p) {
+      index_1[p] = i;
+      index_2[p] = j;
+      prefactor[p] = i == j ? 1 : 2;
+    }
+  }
+  return TC_OK;
+}
+
+int tc_spline_interpolation_matrix(int n, const double* xp, double* a) {
+  TC_CHECK(xp != nullptr && a != nullptr, "invalid arguments");
+  // tabcorr/interpolator.py:239-241
+  TC_CHECK(n >= 4, "Cannot perform spline interpolation with less than 4 values.");
+  std::vector<double> out;
+  TC_CHECK(tc::spline_interpolation_matrix(n, xp, out),
+           "singular spline system (repeated abscissae?)");
+  std::copy(out.begin(), out.end(), a);
+  return TC_OK;
+}
+
+int tc_plan_debug(int mode, int n_bins, const uint8_t* is_central, int n_chunks,
+                  int64_t* n_entries, int32_t* entry_pair, int32_t* entry_chunk,
+                  int32_t* entry_class) {
+  TC_CHECK(mode == TC_MODE_AUTO || mode == TC_MODE_CROSS, "invalid mode");
+  TC_CHECK(n_bins >= 1 && is_central && n_entries, "invalid arguments");
+  tc::Plan plan;
+  tc::build_plan(mode, n_bins, is_central, plan);
+  tc::Chunking chunking;
+  tc::build_chunking(plan, n_chunks, 8, chunking);
+  *n_entries = plan.n_entries;
+  if (entry_pair == nullptr) return TC_OK;
+  for (int64_t e = 0; e < plan.n_entries; ++e) entry_chunk[e] = -1;
+  for (size_t c = 0; c < chunking.chunks.size(); ++c) {
+    const tc::Chunk& chunk = chunking.chunks[c];
+    for (int s = chunk.seg_begin; s < chunk.seg_end; ++s) {
+      const tc::Segment& seg = chunking.segments[s];
+      for (int k = 0; k < seg.len; ++k) {
+        const int64_t e = seg.e0 + k;
+        // recompute the reference column from (i, j) to check the entry order
+        int64_t column;
+        if (mode == TC_MODE_AUTO)
+          column = tc::packed_index(plan.perm[seg.i], plan.perm[seg.j0 + k]);
+        else
+          column = plan.perm[seg.j0 + k];
+        if (column != plan.entry_column[e])
+          return fail(TC_ERR_INVALID, "plan inconsistency at entry %lld",
+                      (long long)e);
+        if (entry_chunk[e] != -1)
+          return fail(TC_ERR_INVALID, "entry %lld covered twice", (long long)e);
+        entry_pair[e] = (int32_t)column;
+        entry_chunk[e] = (int32_t)c;
+        entry_class[e] = chunk.component;
+        if (chunk.component != plan.entry_component[e])
+          return fail(TC_ERR_INVALID, "component mismatch at entry %lld",
+                      (long long)e);
+      }
+    }
+  }
+  return TC_OK;
+}
+
+int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
+                    const void* tpcf_matrix, int matrix_dtype, const double* n_h,
+                    const double* log_min, const double* log_max,
+                    const double* percentile, const double* dist_index,
+                    const uint8_t* is_central, int compute_dtype, tc_table** out) {
+  TC_CHECK(out != nullptr, "table output pointer is NULL");
+  *out = nullptr;
+  TC_CHECK(mode == TC_MODE_AUTO || mode == TC_MODE_CROSS, "invalid mode %d", mode);
+  TC_CHECK(n_bins >= 1 && n_bins < (1 << 20), "invalid number of bins %d", n_bins);
+  TC_CHECK(n_r >= 1, "invalid number of correlation function bins %d", n_r);
+  const int64_t expect =
+      mode == TC_MODE_AUTO ? (int64_t)n_bins * (n_bins + 1) / 2 : n_bins;
+  TC_CHECK(n_pairs == expect,
+           "tpcf_matrix has %lld columns but %d bins in mode '%s' need %lld",
+           (long long)n_pairs, n_bins, mode == TC_MODE_AUTO ? "auto" : "cross",
+           (long long)expect);
+  TC_CHECK(n_pairs < (1LL << 31), "too many pair columns");
+  TC_CHECK(tpcf_matrix && n_h && log_min && log_max && percentile && is_central,
+           "NULL input array");
+  TC_CHECK(matrix_dtype == TC_DTYPE_F64 || matrix_dtype == TC_DTYPE_F32,
+           "invalid matrix dtype");
+  TC_CHECK(compute_dtype == TC_DTYPE_F64 || compute_dtype == TC_DTYPE_F32,
+           "invalid compute dtype");
+
+  std::unique_ptr<tc_table> t(new tc_table);
+  TC_HIP(hipGetDevice(&t->device));
+  t->mode = mode;
+  t->n_bins = n_bins;
+  t->n_r = n_r;
+  t->n_pairs = n_pairs;
+  t->compute_dtype = compute_dtype;
+  t->legacy = dist_index == nullptr;
+  tc::build_plan(mode, n_bins, is_central, t->plan);
+
+  for (int g = 0; g < n_bins; ++g) {
+    const int src = t->plan.perm[g];
+    t->n_h.push_back(n_h[src]);
+    t->log_min.push_back(log_min[src]);
+    t->log_max.push_back(log_max[src]);
+    t->percentile.push_back(percentile[src]);
+    t->dist_index.push_back(dist_index ? dist_index[src] : -1.0);
+  }
+
+  // r tiling: at most 32 accumulators per lane, even count.
+  const int max_rt = 32;
+  t->n_rtiles = (n_r + max_rt - 1) / max_rt;
+  int rt = (n_r + t->n_rtiles - 1) / t->n_rtiles;
+  rt += rt & 1;
+  t->rt = rt;
+
+  // Re-laid-out matrix: [r tile][entry][r in tile] with the pair prefactor
+  // (tabcorr.py:638-642) folded in (a multiplication by 2 is exact).
+  const int64_t n_entries = t->plan.n_entries;
+  const size_t elem = compute_dtype == TC_DTYPE_F64 ? 8 : 4;
+  const size_t count = (size_t)t->n_rtiles * n_entries * rt;
+  t->table_bytes = count * elem;
+  std::vector<double> tmp64;
+  std::vector<float> tmp32;
+  if (compute_dtype == TC_DTYPE_F64) tmp64.assign(count, 0.0);
+  else tmp32.assign(count, 0.0f);
+  for (int r = 0; r < n_r; ++r) {
+    const int tile = r / rt, rr = r % rt;
+    for (int64_t e = 0; e < n_entries; ++e) {
+      const int64_t column = t->plan.entry_column[e];
+      const double value =
+          (matrix_dtype == TC_DTYPE_F64
+               ? ((const double*)tpcf_matrix)[(size_t)r * n_pairs + column]
+               : (double)((const float*)tpcf_matrix)[(size_t)r * n_pairs + column]) *
+          t->plan.entry_prefactor[e];
+      const size_t dst = ((size_t)tile * n_entries + e) * rt + rr;
+      if (compute_dtype == TC_DTYPE_F64) tmp64[dst] = value;
+      else tmp32[dst] = (float)value;
+    }
+  }
+  TC_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+  TC_HIP(hipEventCreate(&t->ev_begin));
+  TC_HIP(hipEventCreate(&t->ev_end));
+  int status = compute_dtype == TC_DTYPE_F64 ? upload(tmp64, &t->d_table)
+                                             : upload(tmp32, &t->d_table);
+  if (status == TC_OK) status = upload(t->n_h, &t->d_n_h);
+  if (status == TC_OK) status = upload(t->percentile, &t->d_percentile);
+  if (status == TC_OK) status = upload(t->plan.perm, &t->d_perm);
+  if (status != TC_OK) {
+    tc_table_destroy(t.release());
+    return status;
+  }
+  *out = t.release();
+  return TC_OK;
+}
+
+int tc_table_destroy(tc_table* t) {
+  if (t == nullptr) return TC_OK;
+  (void)hipSetDevice(t->device);
+  if (t->stream) (void)hipStreamSynchronize(t->stream);
+  for (void* p : {t->d_table, t->d_n_h, t->d_percentile, t->d_perm})
+    if (p) (void)hipFree(p);
+  for (auto& kv : t->quadrature)
+    for (void* p : {kv.second.log_m, kv.second.m, kv.second.weight})
+      if (p) (void)hipFree(p);
+  for (auto& kv : t->chunkings)
+    for (void* p : {kv.second->segments, kv.second->chunks, kv.second->groups})
+      if (p) (void)hipFree(p);
+  for (DeviceBuffer* b : {&t->theta, &t->nbuf, &t->ngal2, &t->partial,
+                          &t->out_ngal, &t->out_xi, &t->occupation})
+    b->release();
+  for (auto& ev : t->kernel_events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  if (t->ev_begin) (void)hipEventDestroy(t->ev_begin);
+  if (t->ev_end) (void)hipEventDestroy(t->ev_end);
+  if (t->stream) (void)hipStreamDestroy(t->stream);
+  delete t;
+  return TC_OK;
+}
+
+int tc_table_synchronize(tc_table* t) {
+  TC_CHECK(t != nullptr, "table handle is NULL");
+  TC_HIP(hipStreamSynchronize(t->stream));
+  return TC_OK;
+}
+
+int tc_table_info(const tc_table* t, int* mode, int* n_bins, int* n_r,
+                  int64_t* n_pairs, int* n_components, int64_t* device_bytes) {
+  TC_CHECK(t != nullptr, "table handle is NULL");
+  if (mode) *mode = t->mode;
+  if (n_bins) *n_bins = t->n_bins;
+  if (n_r) *n_r = t->n_r;
+  if (n_pairs) *n_pairs = t->n_pairs;
+  if (n_components) *n_components = t->plan.n_components;
+  if (device_bytes) *device_bytes = (int64_t)t->table_bytes;
+  return TC_OK;
+}
+
+int tc_predict_zheng07_batch_device(tc_table* t, const double* theta_device,
+                                    int n_theta, int64_t n_draws, int n_gauss,
+                                    unsigned flags, double* ngal_device,
+                                    double* xi_device) {
+  int status = check_predict_args(t, theta_device, n_theta, n_draws, n_gauss, flags);
+  if (status != TC_OK) return status;
+  if (n_draws == 0) return TC_OK;
+  TC_CHECK(ngal_device && xi_device, "output pointer is NULL");
+  TC_HIP(hipSetDevice(t->device));
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  const int n_comp = separate ? t->plan.n_components : 1;
+  for (int64_t begin = 0; begin < n_draws; begin += kMaxSlab) {
+    const int64_t n = std::min(kMaxSlab, n_draws - begin);
+    const int64_t ldb = (n + 63) / 64 * 64;
+    status = run_occupation(t, theta_device + begin * n_theta, n_theta, n, ldb,
+                            n_gauss, flags, nullptr);
+    if (status != TC_OK) return status;
+    status = run_contraction(t, n, ldb, flags,
+                             ngal_device + begin * (separate ? 2 : 1),
+                             xi_device + begin * n_comp * t->n_r);
+    if (status != TC_OK) return status;
+  }
+  return TC_OK;
+}
+
+int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
+                             int64_t n_draws, int n_gauss, unsigned flags,
+                             double* ngal, double* xi) {
+  int status = check_predict_args(t, theta, n_theta, n_draws, n_gauss, flags);
+  if (status != TC_OK) return status;
+  if (n_draws == 0) return TC_OK;
+  TC_CHECK(ngal && xi, "output pointer is NULL");
+  TC_HIP(hipSetDevice(t->device));
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  const int n_comp = separate ? t->plan.n_components : 1;
+  const size_t ngal_count = (size_t)n_draws * (separate ? 2 : 1);
+  const size_t xi_count = (size_t)n_draws * n_comp * t->n_r;
+  status = t->theta.reserve((size_t)n_draws * n_theta * sizeof(double), t->stream);
+  if (status == TC_OK) status = t->out_ngal.reserve(ngal_count * 8, t->stream);
+  if (status == TC_OK) status = t->out_xi.reserve(xi_count * 8, t->stream);
+  if (status != TC_OK) return status;
+  TC_HIP(hipMemcpyAsync(t->theta.ptr, theta, (size_t)n_draws * n_theta * 8,
+                        hipMemcpyHostToDevice, t->stream));
+  status = tc_predict_zheng07_batch_device(
+      t, (const double*)t->theta.ptr, n_theta, n_draws, n_gauss, flags,
+      (double*)t->out_ngal.ptr, (double*)t->out_xi.ptr);
+  if (status != TC_OK) return status;
+  TC_HIP(hipMemcpyAsync(ngal, t->out_ngal.ptr, ngal_count * 8,
+                        hipMemcpyDeviceToHost, t->stream));
+  TC_HIP(hipMemcpyAsync(xi, t->out_xi.ptr, xi_count * 8, hipMemcpyDeviceToHost,
+                        t->stream));
+  TC_HIP(hipStreamSynchronize(t->stream));
+  return TC_OK;
+}
+
+int tc_mean_occupation_zheng07_batch(tc_table* t, const double* theta, int n_theta,
+                                     int64_t n_draws, int n_gauss, unsigned flags,
+                                     double* occupation) {
+  int status = check_predict_args(t, theta, n_theta, n_draws, n_gauss, flags);
+  if (status != TC_OK) return status;
+  if (n_draws == 0) return TC_OK;
+  TC_CHECK(occupation != nullptr, "output pointer is NULL");
+  TC_HIP(hipSetDevice(t->device));
+  for (int64_t begin = 0; begin < n_draws; begin += kMaxSlab) {
+    const int64_t n = std::min(kMaxSlab, n_draws - begin);
+    const int64_t ldb = (n + 63) / 64 * 64;
+    const size_t occ_bytes = (size_t)n * t->n_bins * 8;
+    status = t->theta.reserve((size_t)n * n_theta * 8, t->stream);
+    if (status == TC_OK) status = t->occupation.reserve(occ_bytes, t->stream);
+    if (status != TC_OK) return status;
+    TC_HIP(hipMemcpyAsync(t->theta.ptr, theta + begin * n_theta,
+                          (size_t)n * n_theta * 8, hipMemcpyHostToDevice, t->stream));
+    status = run_occupation(t, (const double*)t->theta.ptr, n_theta, n, ldb, n_gauss,
+                            flags, (double*)t->occupation.ptr);
+    if (status != TC_OK) return status;
+    TC_HIP(hipMemcpyAsync(occupation + begin * t->n_bins, t->occupation.ptr,
+                          occ_bytes, hipMemcpyDeviceToHost, t->stream));
+    TC_HIP(hipStreamSynchronize(t->stream));
+  }
+  return TC_OK;
+}
+
+int tc_predict_occupation_batch(tc_table* t, const double* occupation,
+                                int64_t n_draws, unsigned flags, double* ngal,
+                                double* xi) {
+  TC_CHECK(t != nullptr, "table handle is NULL");
+  TC_CHECK(n_draws >= 0, "n_draws must be non-negative");
+  if (n_draws == 0) return TC_OK;
+  TC_CHECK(occupation && ngal && xi, "NULL array");
+  TC_HIP(hipSetDevice(t->device));
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  const int n_comp = separate ? t->plan.n_components : 1;
+  for (int64_t begin = 0; begin < n_draws; begin += kMaxSlab) {
+    const int64_t n = std::min(kMaxSlab, n_draws - begin);
+    const int64_t ldb = (n + 63) / 64 * 64;
+    const size_t occ_bytes = (size_t)n * t->n_bins * 8;
+    const size_t ngal_count = (size_t)n * (separate ? 2 : 1);
+    const size_t xi_count = (size_t)n * n_comp * t->n_r;
+    int status = t->occupation.reserve(occ_bytes, t->stream);
+    if (status == TC_OK)
+      status = t->nbuf.reserve((size_t)t->n_bins * ldb * 8, t->stream);
+    if (status == TC_OK) status = t->ngal2.reserve(2 * ldb * 8, t->stream);
+    if (status == TC_OK) status = t->out_ngal.reserve(ngal_count * 8, t->stream);
+    if (status == TC_OK) status = t->out_xi.reserve(xi_count * 8, t->stream);
+    if (status != TC_OK) return status;
+    TC_HIP(hipMemcpyAsync(t->occupation.ptr, occupation + begin * t->n_bins,
+                          occ_bytes, hipMemcpyHostToDevice, t->stream));
+    hipLaunchKernelGGL(tc::occ_from_array_kernel,
+                       dim3((unsigned)((ldb + 255) / 256)), dim3(256), 0, t->stream,
+                       (const double*)t->occupation.ptr, n, ldb, t->n_bins,
+                       t->plan.n_central, (const double*)t->d_n_h,
+                       (const int32_t*)t->d_perm, (double*)t->nbuf.ptr,
+                       (double*)t->ngal2.ptr);
+    TC_HIP(hipGetLastError());
+    status = run_contraction(t, n, ldb, flags, (double*)t->out_ngal.ptr,
+                             (double*)t->out_xi.ptr);
+    if (status != TC_OK) return status;
+    TC_HIP(hipMemcpyAsync(ngal + begin * (separate ? 2 : 1), t->out_ngal.ptr,
+                          ngal_count * 8, hipMemcpyDeviceToHost, t->stream));
+    TC_HIP(hipMemcpyAsync(xi + begin * n_comp * t->n_r, t->out_xi.ptr, xi_count * 8,
+                          hipMemcpyDeviceToHost, t->stream));
+    TC_HIP(hipStreamSynchronize(t->stream));
+  }
+  return TC_OK;
+}
+
+int tc_table_timer_begin(tc_table* t, int profile_kernels) {
+  TC_CHECK(t != nullptr, "table handle is NULL");
+  TC_HIP(hipSetDevice(t->device));
+  t->profile_kernels = profile_kernels != 0;
+  t->kernel_events_used = 0;
+  TC_HIP(hipEventRecord(t->ev_begin, t->stream));
+  return TC_OK;
+}
+
+int tc_table_timer_end(tc_table* t, float* elapsed_ms) {
+  TC_CHECK(t != nullptr && elapsed_ms != nullptr, "NULL argument");
+  TC_HIP(hipEventRecord(t->ev_end, t->stream));
+  TC_HIP(hipEventSynchronize(t->ev_end));
+  TC_HIP(hipEventElapsedTime(elapsed_ms, t->ev_begin, t->ev_end));
+  t->profile_kernels = false;
+  return TC_OK;
+}
+
+int tc_table_kernel_time(tc_table* t, int* n_launches, float* mean_ms) {
+  TC_CHECK(t != nullptr && n_launches && mean_ms, "NULL argument");
+  double total = 0.0;
+  for (size_t i = 0; i < t->kernel_events_used; ++i) {
+    float ms = 0.0f;
+    TC_HIP(hipEventSynchronize(t->kernel_events[i].second));
+    TC_HIP(hipEventElapsedTime(&ms, t->kernel_events[i].first,
+                               t->kernel_events[i].second));
+    total += ms;
+  }
+  *n_launches = (int)t->kernel_events_used;
+  *mean_ms = t->kernel_events_used ? (float)(total / t->kernel_events_used) : 0.0f;
+  return TC_OK;
+}
+
+int tc_table_last_launch(const tc_table* t, int* n_workgroups, int* waves,
+                         int* n_splits, int* lds_bytes) {
+  TC_CHECK(t != nullptr, "table handle is NULL");
+  if (n_workgroups) *n_workgroups = t->last_workgroups;
+  if (waves) *waves = t->last_waves;
+  if (n_splits) *n_splits = t->last_splits;
+  if (lds_bytes) *lds_bytes = t->last_lds;
+  return TC_OK;
+}
+
+}  // extern "C"
+
+// ---- not yet implemented in this build ---------------------------------------------
+extern "C" {
+
+int tc_interp_create(tc_table* const*, int, int, const double*, tc_interp**) {
+  return fail(TC_ERR_UNSUPPORTED, "tc_interp_create: not implemented yet");
+}
+int tc_interp_destroy(tc_interp*) { return TC_OK; }
+int tc_interp_synchronize(tc_interp*) {
+  return fail(TC_ERR_UNSUPPORTED, "tc_interp_synchronize: not implemented yet");
+}
+int tc_interp_axis(const tc_interp*, int, int*, double*, int) {
+  return fail(TC_ERR_UNSUPPORTED, "tc_interp_axis: not implemented yet");
+}
+int tc_interp_predict_zheng07_batch(tc_interp*, const double*, int, const double*,
+                                    int64_t, int, unsigned, double*, double*) {
+  return fail(TC_ERR_UNSUPPORTED, "tc_interp_predict: not implemented yet");
+}
+int tc_interp_predict_zheng07_batch_device(tc_interp*, const double*, int,
+                                           const double*, int64_t, int, unsigned,
+                                           double*, double*) {
+  return fail(TC_ERR_UNSUPPORTED, "tc_interp_predict: not implemented yet");
+}
+int tc_comm_unique_id(void*) {
+  return fail(TC_ERR_UNSUPPORTED, "tc_comm: not implemented yet");
+}
+int tc_comm_create(const void*, int, int, tc_comm**) {
+  return fail(TC_ERR_UNSUPPORTED, "tc_comm: not implemented yet");
+}
+int tc_comm_destroy(tc_comm*) { return TC_OK; }
+int tc_comm_gather(tc_comm*, tc_table*, const double*, double*, int64_t, int) {
+  return fail(TC_ERR_UNSUPPORTED, "tc_comm: not implemented yet");
+}
+int tc_comm_barrier(tc_comm*) {
+  return fail(TC_ERR_UNSUPPORTED, "tc_comm: not implemented yet");
+}
+int tc_comm_synchronize(tc_comm*) {
+  return fail(TC_ERR_UNSUPPORTED, "tc_comm: not implemented yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,418 @@
+"""``TabCorr`` with the reference's class surface, computing on an MI355X.
+
+The public methods mirror ``tabcorr/tabcorr.py`` of johannesulf/TabCorr v1.2.0
+(``tabulate`` / ``read`` / ``write`` / ``mean_occupation`` / ``predict``, same
+arguments, return types and exception types) so that an existing likelihood
+can switch imports.  The arithmetic of ``predict`` runs in hand-written HIP
+kernels behind a C ABI (``include/tabcorr_amd.h``); there is no CPU fallback.
+
+Extensions beyond the reference (the reason to use a GPU at all):
+
+``predict_batch(theta)``
+    thousands of Zheng07 parameter vectors against the resident table in one
+    call -- the reference's usage pattern is a Python loop of ``predict``
+    calls (``README.md:72-75``).
+``predict(ndarray)`` also accepts a 2-D ``(n_draws, n_bins)`` array of mean
+    occupations (batched form of the operator seam at
+    ``tabcorr/tabcorr.py:616-621``).
+"""
+
+import ctypes
+import itertools
+import json
+import os
+
+import numpy as np
+
+from . import _lib
+from .galtable import GalTypeTable
+from .models import device_spec
+
+ATTR_KEYS = ['tpcf', 'mode', 'simname', 'redshift', 'Num_ptcl_requirement',
+             'prim_haloprop_key', 'sec_haloprop_key']
+
+XI_KEYS = {'auto': ['centrals-centrals', 'centrals-satellites',
+                    'satellites-satellites'],
+           'cross': ['centrals', 'satellites']}
+NGAL_KEYS = ['centrals', 'satellites']
+
+
+class _DeviceTable:
+    """Owner of a ``tc_table`` handle."""
+
+    def __init__(self, halotab, compute_dtype):
+        lib = _lib.load()
+        _lib.require_device()
+        gal_type = halotab.gal_type
+        mode = halotab.attrs['mode']
+        if mode not in _lib.MODE:
+            raise ValueError("Unknown mode '{}'.".format(mode))
+        matrix = np.asarray(halotab.tpcf_matrix)
+        if matrix.ndim != 2:
+            raise ValueError('tpcf_matrix must be two-dimensional.')
+        if matrix.dtype == np.float32:
+            matrix = np.ascontiguousarray(matrix)
+            matrix_dtype = _lib.DTYPE_F32
+        else:
+            matrix = _lib.contiguous(matrix)
+            matrix_dtype = _lib.DTYPE_F64
+        columns = {}
+        for name in ['n_h', 'log_prim_haloprop_min', 'log_prim_haloprop_max',
+                     'sec_haloprop_percentile']:
+            columns[name] = _lib.contiguous(gal_type[name])
+        if 'prim_haloprop_dist_index' in gal_type.colnames:
+            dist_index = _lib.contiguous(gal_type['prim_haloprop_dist_index'])
+            dist_index_p = _lib.as_double_p(dist_index)
+        else:
+            # Tables of earlier TabCorr versions (tabcorr/tabcorr.py:571-574).
+            dist_index_p = None
+        is_central = np.ascontiguousarray(gal_type.is_centrals(),
+                                          dtype=np.uint8)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.tc_table_create(
+            _lib.MODE[mode], len(gal_type), matrix.shape[0], matrix.shape[1],
+            matrix.ctypes.data_as(ctypes.c_void_p), matrix_dtype,
+            _lib.as_double_p(columns['n_h']),
+            _lib.as_double_p(columns['log_prim_haloprop_min']),
+            _lib.as_double_p(columns['log_prim_haloprop_max']),
+            _lib.as_double_p(columns['sec_haloprop_percentile']),
+            dist_index_p, is_central.ctypes.data_as(_lib.c_uint8_p),
+            _lib.DTYPE_F32 if compute_dtype == 'float32' else _lib.DTYPE_F64,
+            ctypes.byref(handle)))
+        self.handle = handle
+        self.lib = lib
+        self.n_bins = len(gal_type)
+        self.n_r = matrix.shape[0]
+        self.n_components = 3 if mode == 'auto' else 2
+        self.compute_dtype = compute_dtype
+
+    def __del__(self):
+        handle = getattr(self, 'handle', None)
+        if handle is not None and handle.value is not None:
+            try:
+                self.lib.tc_table_destroy(handle)
+            except Exception:  # interpreter shutdown
+                pass
+            self.handle = None
+
+
+class TabCorr:
+    """Tabulated halo correlation functions convolved with an HOD on a GPU."""
+
+    def __init__(self):
+        self.attrs = {}
+        self.tpcf_args = ()
+        self.tpcf_kwargs = {}
+        self.tpcf_shape = None
+        self.tpcf_matrix = None
+        self._gal_type = None
+        self._device = None
+        self.compute_dtype = 'float64'
+
+    # -- construction -------------------------------------------------------
+
+    @property
+    def gal_type(self):
+        return self._gal_type
+
+    @gal_type.setter
+    def gal_type(self, value):
+        self._gal_type = None if value is None else (
+            value if isinstance(value, GalTypeTable) else GalTypeTable(value))
+        self._device = None
+
+    @classmethod
+    def from_arrays(cls, gal_type, tpcf_matrix, tpcf_shape, attrs,
+                    tpcf_args=(), tpcf_kwargs=None, compute_dtype='float64'):
+        """Build an instance from in-memory arrays (e.g. `synthetic_table`).
+        """
+        halotab = cls()
+        halotab.gal_type = gal_type
+        halotab.tpcf_matrix = np.asarray(tpcf_matrix)
+        halotab.tpcf_shape = tuple(int(s) for s in tpcf_shape)
+        halotab.attrs = dict(attrs)
+        halotab.tpcf_args = tuple(tpcf_args)
+        halotab.tpcf_kwargs = dict(tpcf_kwargs or {})
+        halotab.compute_dtype = compute_dtype
+        return halotab
+
+    @classmethod
+    def tabulate(cls, halocat, tpcf, *tpcf_args, **kwargs):
+        """Tabulate halo correlation functions (``tabcorr/tabcorr.py:23-372``).
+
+        Tabulation is an offline, halotools-bound step outside the scope of
+        this package; it is delegated to the reference package when that (and
+        halotools) is installed and the result is adopted.
+        """
+        try:
+            import tabcorr as reference
+        except ImportError as error:
+            raise NotImplementedError(
+                'TabCorr.tabulate needs the reference `tabcorr` package and '
+                'halotools; tabcorr_amd accelerates predict() only.'
+            ) from error
+        tabulated = reference.TabCorr.tabulate(
+            halocat, tpcf, *tpcf_args, **kwargs)
+        return cls.from_arrays(
+            tabulated.gal_type, tabulated.tpcf_matrix, tabulated.tpcf_shape,
+            tabulated.attrs, tabulated.tpcf_args, tabulated.tpcf_kwargs)
+
+    @classmethod
+    def read(cls, fname):
+        """Read a table written by the reference (HDF5 layout of
+        ``tabcorr/tabcorr.py:438-463``) or by `write`.
+
+        Parameters
+        ----------
+        fname : str or h5py.Group
+        """
+        from . import io
+        return io.read_tabcorr(cls, fname)
+
+    def write(self, fname, overwrite=False, max_args_size=1000000,
+              matrix_dtype=np.float32):
+        """Write the table in the reference's HDF5 layout
+        (``tabcorr/tabcorr.py:418-463``)."""
+        from . import io
+        io.write_tabcorr(self, fname, overwrite=overwrite,
+                         max_args_size=max_args_size,
+                         matrix_dtype=matrix_dtype)
+
+    # -- device residency ----------------------------------------------------
+
+    def to_device(self, compute_dtype=None):
+        """Upload the table (done lazily by the first prediction).  The table
+        must not be mutated afterwards; call `invalidate` if it is."""
+        if compute_dtype is not None and compute_dtype != self.compute_dtype:
+            self.compute_dtype = compute_dtype
+            self._device = None
+        if self._device is None:
+            if self.compute_dtype not in ('float64', 'float32'):
+                raise ValueError('compute_dtype must be float64 or float32.')
+            self._device = _DeviceTable(self, self.compute_dtype)
+        return self._device
+
+    def invalidate(self):
+        self._device = None
+
+    # -- consistency checks ---------------------------------------------------
+
+    def _check_consistency(self, model):
+        """Same checks and messages as ``tabcorr/tabcorr.py:496-535``."""
+        if sorted(model.gal_types) != ['centrals', 'satellites']:
+            raise ValueError(
+                'The model instance must only have centrals and ' +
+                'satellites as galaxy types. Check the `gal_types` ' +
+                'attribute of the model instance.')
+        components = model._input_model_dictionary
+        for name in ['centrals_occupation', 'satellites_occupation']:
+            if (components[name].prim_haloprop_key !=
+                    self.attrs['prim_haloprop_key']):
+                raise ValueError('Mismatch in the primary halo properties ' +
+                                 'of the model and the TabCorr instance.')
+        for name in ['centrals_occupation', 'satellites_occupation']:
+            if hasattr(components[name], 'sec_haloprop_key'):
+                if (components[name].sec_haloprop_key !=
+                        self.attrs['sec_haloprop_key']):
+                    raise ValueError(
+                        'Mismatch in the secondary halo properties ' +
+                        'of the model and the TabCorr instance.')
+        if not np.abs(model.redshift - self.attrs['redshift']) < 0.05:
+            raise ValueError('Mismatch in the redshift of the model and ' +
+                             'the TabCorr instance.')
+
+    # -- mean occupation ---------------------------------------------------------
+
+    def _host_mean_occupation(self, model, n_gauss_prim, **occ_kwargs):
+        """Generic models: the callbacks are Python, so the Gauss-Legendre
+        average of ``tabcorr/tabcorr.py:537-578`` is formed on the host and
+        only the contraction runs on the device."""
+        gal_type = self.gal_type
+        nodes, weights = np.polynomial.legendre.leggauss(n_gauss_prim)
+        nodes = 0.5 * (nodes + 1.0)
+        log_lo = gal_type['log_prim_haloprop_min']
+        width = gal_type['log_prim_haloprop_max'] - log_lo
+        mass = 10.0**(log_lo[:, np.newaxis] + width[:, np.newaxis] * nodes)
+        percentile = np.repeat(
+            gal_type['sec_haloprop_percentile'][:, np.newaxis], n_gauss_prim,
+            axis=1)
+        central = gal_type.is_centrals()
+        occupation = np.zeros(mass.shape)
+        occupation[central] = np.reshape(model.mean_occupation_centrals(
+            prim_haloprop=mass[central].ravel(),
+            sec_haloprop_percentile=percentile[central].ravel(),
+            **occ_kwargs), (-1, n_gauss_prim))
+        occupation[~central] = np.reshape(model.mean_occupation_satellites(
+            prim_haloprop=mass[~central].ravel(),
+            sec_haloprop_percentile=percentile[~central].ravel(),
+            **occ_kwargs), (-1, n_gauss_prim))
+        if 'prim_haloprop_dist_index' in gal_type.colnames:
+            power = mass**(gal_type['prim_haloprop_dist_index'][
+                :, np.newaxis] + 1.0)
+        else:
+            power = np.ones_like(mass)
+        return (np.sum(weights * occupation * power, axis=-1) /
+                np.sum(weights * power, axis=-1))
+
+    def mean_occupation(self, model, n_gauss_prim=10, check_consistency=True,
+                        **occ_kwargs):
+        """Mean occupation of every halo/galaxy bin
+        (``tabcorr/tabcorr.py:465-578``).
+
+        Returns
+        -------
+        n : numpy.ndarray
+            Same length as ``self.gal_type``.
+
+        Raises
+        ------
+        ValueError
+            If the model and the table are inconsistent.
+        """
+        if check_consistency:
+            self._check_consistency(model)
+        spec = None if occ_kwargs else device_spec(model)
+        if spec is None:
+            return self._host_mean_occupation(model, n_gauss_prim,
+                                              **occ_kwargs)
+        return self.mean_occupation_batch(
+            spec.theta[np.newaxis], n_gauss_prim=n_gauss_prim,
+            modulate_with_cenocc=spec.modulate_with_cenocc,
+            assembias=spec.assembias)[0]
+
+    def mean_occupation_batch(self, theta, n_gauss_prim=10,
+                              modulate_with_cenocc=False, assembias=False):
+        """`mean_occupation` for a ``(n_draws, 5 | 7)`` array of Zheng07
+        parameters (columns: logMmin, sigma_logM, logM0, logM1, alpha
+        [, A_cen, A_sat]).  Returns ``(n_draws, n_bins)``."""
+        device = self.to_device()
+        theta = _lib.contiguous(np.atleast_2d(theta))
+        flags = _flags(False, modulate_with_cenocc, assembias)
+        occupation = np.empty((len(theta), device.n_bins))
+        _lib.check(device.lib.tc_mean_occupation_zheng07_batch(
+            device.handle, _lib.as_double_p(theta), theta.shape[1],
+            len(theta), n_gauss_prim, flags, _lib.as_double_p(occupation)))
+        return occupation
+
+    # -- predict ---------------------------------------------------------------------
+
+    def predict(self, model, separate_gal_type=False, n_gauss_prim=10,
+                check_consistency=True, **occ_kwargs):
+        """Number density and correlation function of a model
+        (``tabcorr/tabcorr.py:580-683``).
+
+        Parameters
+        ----------
+        model : HodModelFactory-like or numpy.ndarray
+            A model object (see `tabcorr_amd.models`) or the mean occupation
+            of every bin.  A 2-D array is treated as a batch.
+
+        Returns
+        -------
+        ngal : float or dict
+        xi : numpy.ndarray or dict
+        """
+        if isinstance(model, np.ndarray):
+            batched = model.ndim == 2
+            ngal, xi = self._predict_occupation(
+                np.atleast_2d(model), separate_gal_type)
+            return _unbatch(ngal, xi) if not batched else (ngal, xi)
+
+        if check_consistency:
+            self._check_consistency(model)
+        spec = None if occ_kwargs else device_spec(model)
+        if spec is None:
+            occupation = self._host_mean_occupation(
+                model, n_gauss_prim, **occ_kwargs)
+            return _unbatch(*self._predict_occupation(
+                occupation[np.newaxis], separate_gal_type))
+        return _unbatch(*self.predict_batch(
+            spec.theta[np.newaxis], separate_gal_type=separate_gal_type,
+            n_gauss_prim=n_gauss_prim,
+            modulate_with_cenocc=spec.modulate_with_cenocc,
+            assembias=spec.assembias))
+
+    def predict_batch(self, theta, separate_gal_type=False, n_gauss_prim=10,
+                      modulate_with_cenocc=False, assembias=False):
+        """`predict` for a ``(n_draws, 5 | 7)`` array of Zheng07 parameters.
+
+        Returns
+        -------
+        ngal : numpy.ndarray ``(n_draws, )`` or dict of such
+        xi : numpy.ndarray ``(n_draws, ) + tpcf_shape`` or dict of such
+        """
+        device = self.to_device()
+        theta = _lib.contiguous(np.atleast_2d(theta))
+        flags = _flags(separate_gal_type, modulate_with_cenocc, assembias)
+        n_draws = len(theta)
+        n_comp = device.n_components if separate_gal_type else 1
+        ngal = np.empty((n_draws, 2 if separate_gal_type else 1))
+        xi = np.empty((n_draws, n_comp, device.n_r))
+        _lib.check(device.lib.tc_predict_zheng07_batch(
+            device.handle, _lib.as_double_p(theta), theta.shape[1], n_draws,
+            n_gauss_prim, flags, _lib.as_double_p(ngal),
+            _lib.as_double_p(xi)))
+        return self._package(ngal, xi, separate_gal_type)
+
+    def _predict_occupation(self, occupation, separate_gal_type):
+        device = self.to_device()
+        occupation = _lib.contiguous(occupation)
+        if occupation.shape[1] != device.n_bins:
+            raise ValueError(
+                'The mean occupation array has {} entries but the table has '
+                '{} halo/galaxy bins.'.format(occupation.shape[1],
+                                              device.n_bins))
+        n_draws = len(occupation)
+        n_comp = device.n_components if separate_gal_type else 1
+        ngal = np.empty((n_draws, 2 if separate_gal_type else 1))
+        xi = np.empty((n_draws, n_comp, device.n_r))
+        _lib.check(device.lib.tc_predict_occupation_batch(
+            device.handle, _lib.as_double_p(occupation), n_draws,
+            _flags(separate_gal_type), _lib.as_double_p(ngal),
+            _lib.as_double_p(xi)))
+        return self._package(ngal, xi, separate_gal_type)
+
+    def _package(self, ngal, xi, separate_gal_type):
+        shape = (len(ngal), ) + tuple(self.tpcf_shape)
+        if not separate_gal_type:
+            return ngal[:, 0], xi[:, 0].reshape(shape)
+        # dict order: np.unique order of the gal_type column and
+        # combinations_with_replacement of it (tabcorr/tabcorr.py:660-675).
+        ngal_dict = {key: ngal[:, i] for i, key in enumerate(NGAL_KEYS)}
+        xi_dict = {key: xi[:, i].reshape(shape)
+                   for i, key in enumerate(XI_KEYS[self.attrs['mode']])}
+        return ngal_dict, xi_dict
+
+
+def _flags(separate_gal_type=False, modulate_with_cenocc=False,
+           assembias=False):
+    return ((_lib.FLAG_SEPARATE_GAL_TYPE if separate_gal_type else 0) |
+            (_lib.FLAG_MODULATE_WITH_CENOCC if modulate_with_cenocc else 0) |
+            (_lib.FLAG_ASSEMBIAS if assembias else 0))
+
+
+def _unbatch(ngal, xi):
+    """First element of a batch of one, as the scalar API returns it."""
+    if isinstance(ngal, dict):
+        return ({key: value[0] for key, value in ngal.items()},
+                {key: value[0] for key, value in xi.items()})
+    return ngal[0], xi[0]
+
+
+def symmetric_matrix_to_array(matrix, check_symmetry=True):
+    """Packed lower triangle of a symmetric matrix, ``p = i (i + 1) / 2 + j``
+    for ``j <= i`` -- the column order of ``tpcf_matrix`` in mode ``'auto'``
+    (``tabcorr/tabcorr.py:770-806``).
+
+    Raises
+    ------
+    ValueError
+        If ``check_symmetry`` and the matrix is not symmetric.
+    """
+    matrix = np.asarray(matrix)
+    if check_symmetry and (matrix.ndim != 2 or
+                           matrix.shape[0] != matrix.shape[1] or
+                           not np.array_equal(matrix, matrix.T)):
+        raise ValueError('The matrix you provided is not symmetric.')
+    rows, cols = np.tril_indices(matrix.shape[0])
+    return matrix[rows, cols]

@@ -1,0 +1,211 @@
+"""Parity of the HIP path (through the C ABI) with the golden vectors recorded
+from the reference and with the CPU oracle.  Needs an MI355X."""
+
+import numpy as np
+import pytest
+
+from util import (load_golden, table_from_golden, xi_keys, assert_rel)
+
+pytestmark = pytest.mark.gpu
+
+# north_star: within 1e-10 relative of the reference's CPU predict() in fp64.
+RTOL = 1e-10
+
+
+def make_tabcorr(table, **kwargs):
+    from tabcorr_amd import TabCorr
+    return TabCorr.from_arrays(table['gal_type'], table['tpcf_matrix'],
+                               table['tpcf_shape'], table['attrs'], **kwargs)
+
+
+def check_against_golden(halotab, data, table, suffix='', prefix='',
+                         **kwargs):
+    theta = data['theta']
+    if 'assembias' in kwargs:
+        theta = np.hstack([theta, kwargs.pop('assembias')])
+        kwargs['assembias'] = True
+    ngal, xi = halotab.predict_batch(theta, **kwargs)
+    assert_rel(ngal, data[prefix + 'ngal' + suffix], RTOL, 'ngal')
+    assert_rel(xi, data[prefix + 'xi' + suffix], RTOL, 'xi')
+    ngal_sep, xi_sep = halotab.predict_batch(
+        theta, separate_gal_type=True, **kwargs)
+    assert list(ngal_sep.keys()) == ['centrals', 'satellites']
+    assert list(xi_sep.keys()) == xi_keys(table)
+    for key in ngal_sep:
+        assert_rel(ngal_sep[key], data[prefix + 'ngal_sep_' + key + suffix],
+                   RTOL, key)
+    for key in xi_sep:
+        assert_rel(xi_sep[key], data[prefix + 'xi_sep_' + key + suffix], RTOL,
+                   key)
+    # the reference's own invariant (tests/test_general.py:8-28)
+    assert_rel(sum(ngal_sep.values()), ngal, 1e-12)
+    assert_rel(sum(xi_sep.values()), xi, 1e-12)
+
+
+@pytest.mark.parametrize('name', ['bolplanck_wp', 'bolplanck_ds'])
+def test_real_tables(name):
+    data = load_golden(name)
+    table = table_from_golden(data)
+    halotab = make_tabcorr(table)
+    check_against_golden(halotab, data, table)
+    check_against_golden(halotab, data, table, '_ng1', n_gauss_prim=1)
+    check_against_golden(halotab, data, table, '_ng100', n_gauss_prim=100)
+    check_against_golden(halotab, data, table, '_modulate',
+                         modulate_with_cenocc=True)
+    for n_gauss, suffix in [(1, '_ng1'), (10, ''), (100, '_ng100')]:
+        occ = halotab.mean_occupation_batch(data['theta'],
+                                            n_gauss_prim=n_gauss)
+        assert_rel(occ, data['mean_occupation' + suffix], RTOL)
+
+    # the ndarray seam, one by one and as a batch
+    for occ, ngal, xi in zip(data['occ_in'], data['occ_ngal'],
+                             data['occ_xi']):
+        n, x = halotab.predict(occ)
+        assert isinstance(n, float) and x.shape == tuple(table['tpcf_shape'])
+        assert_rel(n, ngal, RTOL)
+        assert_rel(x, xi, RTOL)
+    n, x = halotab.predict(data['occ_in'])
+    assert_rel(n, data['occ_ngal'], RTOL)
+    assert_rel(x, data['occ_xi'], RTOL)
+
+
+def test_scalar_api_matches_reference_signature():
+    from tabcorr_amd import Zheng07Model
+    data = load_golden('bolplanck_wp')
+    table = table_from_golden(data)
+    halotab = make_tabcorr(table)
+    model = Zheng07Model(redshift=0.0)
+    keys = ['logMmin', 'sigma_logM', 'logM0', 'logM1', 'alpha']
+    for i in range(3):
+        for key, value in zip(keys, data['theta'][i]):
+            model.param_dict[key] = value
+        ngal, xi = halotab.predict(model)
+        assert isinstance(ngal, float)
+        assert xi.shape == (19, )
+        assert_rel(ngal, data['ngal'][i], RTOL)
+        assert_rel(xi, data['xi'][i], RTOL)
+        ngal_sep, xi_sep = halotab.predict(model, separate_gal_type=True)
+        assert len(ngal_sep) == 2 and len(xi_sep) == 3
+        assert_rel(xi_sep['centrals-satellites'],
+                   data['xi_sep_centrals-satellites'][i], RTOL)
+        occ = halotab.mean_occupation(model)
+        assert_rel(occ, data['mean_occupation'][i], RTOL)
+        ngal, xi = halotab.predict(model, n_gauss_prim=1)
+        assert_rel(xi, data['xi_ng1'][i], RTOL)
+
+    # mismatches raise ValueError like tabcorr/tabcorr.py:496-535
+    with pytest.raises(ValueError):
+        halotab.predict(Zheng07Model(redshift=0.5))
+    with pytest.raises(ValueError):
+        halotab.predict(Zheng07Model(prim_haloprop_key='halo_m200m'))
+    with pytest.raises(ValueError):
+        halotab.predict(Zheng07Model(sec_haloprop_key='halo_spin'))
+    bad = Zheng07Model()
+    bad.gal_types = ['centrals']
+    with pytest.raises(ValueError):
+        halotab.predict(bad)
+    halotab.predict(Zheng07Model(redshift=0.5), check_consistency=False)
+    with pytest.raises(ValueError):
+        halotab.predict(np.ones(7))
+
+
+@pytest.mark.parametrize('name', [
+    'synthetic_cfg2', 'synthetic_small_auto', 'synthetic_small_cross',
+    'synthetic_rp_pi', 'synthetic_r1'])
+def test_synthetic(name):
+    data = load_golden(name)
+    table = table_from_golden(data)
+    halotab = make_tabcorr(table)
+    check_against_golden(halotab, data, table)
+    if 'ngal_ng1' in data.files:
+        check_against_golden(halotab, data, table, '_ng1', n_gauss_prim=1)
+    if name == 'synthetic_small_auto':
+        legacy = dict(table)
+        names = [n for n in table['gal_type'].dtype.names
+                 if n != 'prim_haloprop_dist_index']
+        legacy['gal_type'] = table['gal_type'][names]
+        check_against_golden(make_tabcorr(legacy), data, legacy,
+                             prefix='legacy_')
+
+
+def test_synthetic_assembias():
+    data = load_golden('synthetic_cfg3')
+    table = table_from_golden(data)
+    halotab = make_tabcorr(table)
+    check_against_golden(halotab, data, table, assembias=data['assembias'])
+    check_against_golden(halotab, data, table, prefix='plain_')
+
+
+def test_generic_model_host_route():
+    """A model the kernel does not know goes through host callbacks + device
+    contraction and gives the same answer."""
+    from tabcorr_amd import Zheng07Model
+
+    class Opaque(Zheng07Model):
+        _tabcorr_amd_device_model = None
+
+    data = load_golden('synthetic_cfg3')
+    table = table_from_golden(data)
+    halotab = make_tabcorr(table)
+    keys = ['logMmin', 'sigma_logM', 'logM0', 'logM1', 'alpha']
+    for i in range(2):
+        model = Opaque(sec_haloprop_key='halo_nfw_conc')
+        for key, value in zip(keys, data['theta'][i]):
+            model.param_dict[key] = value
+        model.param_dict['mean_occupation_centrals_assembias_param1'] = (
+            data['assembias'][i, 0])
+        model.param_dict['mean_occupation_satellites_assembias_param1'] = (
+            data['assembias'][i, 1])
+        ngal, xi = halotab.predict(model)
+        assert_rel(ngal, data['ngal'][i], RTOL)
+        assert_rel(xi, data['xi'][i], RTOL)
+
+
+def test_unsorted_gal_type_rows():
+    """Rows in arbitrary order (not centrals first) are handled by the
+    library's internal permutation."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+    from oracle import tabcorr_oracle as oracle
+    data = load_golden('synthetic_small_auto')
+    table = table_from_golden(data)
+    rng = np.random.default_rng(0)
+    n_bins = len(table['gal_type'])
+    perm = rng.permutation(n_bins)
+    shuffled = dict(table)
+    shuffled['gal_type'] = table['gal_type'][perm]
+    # permute the packed matrix consistently
+    full = np.zeros((table['tpcf_matrix'].shape[0], n_bins, n_bins))
+    rows, cols = np.tril_indices(n_bins)
+    full[:, rows, cols] = table['tpcf_matrix']
+    full[:, cols, rows] = table['tpcf_matrix']
+    full = full[:, perm][:, :, perm]
+    shuffled['tpcf_matrix'] = np.ascontiguousarray(full[:, rows, cols])
+    theta = data['theta']
+    expect = oracle.predict_zheng07_batch(shuffled, theta)
+    assert_rel(expect[0], data['ngal'], 1e-12)
+    halotab = make_tabcorr(shuffled)
+    ngal, xi = halotab.predict_batch(theta)
+    assert_rel(ngal, data['ngal'], RTOL)
+    assert_rel(xi, data['xi'], RTOL)
+    ngal_sep, xi_sep = halotab.predict_batch(theta, separate_gal_type=True)
+    for key in xi_sep:
+        assert_rel(xi_sep[key], data['xi_sep_' + key], RTOL)
+
+
+def test_ragged_and_empty_batches():
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+    from oracle import tabcorr_oracle as oracle
+    from tabcorr_amd import synthetic
+    data = load_golden('synthetic_cfg2')
+    table = table_from_golden(data)
+    halotab = make_tabcorr(table)
+    ngal, xi = halotab.predict_batch(np.zeros((0, 5)))
+    assert ngal.shape == (0, ) and xi.shape == (0, 19)
+    for n_draws in [1, 63, 64, 65, 200]:
+        theta = synthetic.zheng07_draws(n_draws, seed=100 + n_draws)
+        ngal, xi = halotab.predict_batch(theta)
+        expect = oracle.predict_zheng07_batch(table, theta)
+        assert_rel(ngal, expect[0], RTOL)
+        assert_rel(xi, expect[1], RTOL)
