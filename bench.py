@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched ``TabCorr.predict()`` path on MI355X.
+
+Metric (BASELINE.json): predict() calls per second -- Zheng07 HOD, 50 mass bins x
+{centrals, satellites} (G = 100 halo/galaxy bins, P = 5050 packed pair columns), 19
+r_p bins, float64.  One *step* is one pass of the hot path over one batch of 10^4
+parameter draws against the resident synthetic table (BASELINE configs[1]): occupation
+kernel -> contraction kernel -> finalisation kernel, with the draws already resident
+in HBM and the results left in HBM.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: weak scaling, one process per GPU, every rank runs its own 10^4 draws per
+step against its own replica of the table (the path shards over draws without any
+data-path collective); the results of every step are collected on rank 0 by one RCCL
+gather over xGMI on a second stream, overlapped with the next step.  PyTorch is only
+used for the gloo control plane (rendezvous, barrier, max over ranks).
+
+Rank 0 prints ONE JSON line.  Extra objects: ``roofline`` (contraction kernel:
+algorithmic flop per launch / mean launch duration from HIP events on the kernel's
+own stream, against the FP64 matrix/vector peak) and ``cpu_baseline`` (the NumPy port
+of the reference's predict(), oracle/tabcorr_oracle.py, timed on one host core).
+"""
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+# FP64 peak of MI355X: 78.6 TFLOP/s (AMD datasheet, vector = matrix); the local
+# microbenchmarks (tools/micro) measure 78.0 (v_mfma_f64_16x16x4) and 61
+# (v_fma_f64, clock-limited) TFLOP/s.
+FP64_PEAK_TFLOPS = 78.6
+
+N_PRIM, N_SEC, N_R = 50, 1, 19
+N_GAUSS = 10
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--gpus', type=int, default=1)
+    parser.add_argument('--steps', type=int, default=200)
+    parser.add_argument('--warmup', type=int, default=20)
+    parser.add_argument('--draws', type=int, default=10000,
+                        help='draws per GPU per step')
+    parser.add_argument('--cpu-seconds', type=float, default=12.0,
+                        help='budget of the CPU baseline sample (0: skip)')
+    args = parser.parse_args()
+
+    from tabcorr_amd import TabCorr, synthetic, _lib
+    from tabcorr_amd.parallel import Communicator
+
+    world_size = int(os.environ.get('WORLD_SIZE', '1'))
+    if world_size != args.gpus:
+        if world_size == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run '
+                     '--nproc-per-node %d' % (args.gpus, args.gpus))
+        sys.exit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world_size))
+    lib = _lib.load()
+    _lib.require_device()
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    _lib.check(lib.tc_set_device(local_rank))
+    comm = Communicator.from_env()
+    rank = comm.rank
+
+    table = synthetic.synthetic_table(N_PRIM, N_SEC, (N_R, ), 'auto', seed=0)
+    halotab = TabCorr.from_arrays(table['gal_type'], table['tpcf_matrix'],
+                                  table['tpcf_shape'], table['attrs'])
+    device = halotab.to_device()
+    handle = device.handle
+    n_draws = args.draws
+    theta = synthetic.zheng07_draws(n_draws, seed=1 + rank)
+    n_out = n_draws * (1 + N_R)        # ngal (B) followed by xi (B, R)
+
+    def dmalloc(count):
+        ptr = ctypes.c_void_p()
+        _lib.check(lib.tc_device_malloc(ctypes.byref(ptr), count * 8))
+        return ptr
+
+    d_theta = dmalloc(theta.size)
+    _lib.check(lib.tc_memcpy_h2d(d_theta, theta.ctypes.data_as(ctypes.c_void_p),
+                                 theta.nbytes))
+    n_slots = 2
+    d_out = dmalloc(n_slots * n_out)
+    use_rccl = comm.world_size > 1 and comm.comm is not None
+    d_recv = dmalloc(n_slots * comm.world_size * n_out) if (
+        use_rccl and comm.is_root) else ctypes.c_void_p()
+
+    def out_ptr(slot, offset=0):
+        return ctypes.c_void_p(d_out.value + (slot * n_out + offset) * 8)
+
+    def step(index):
+        slot = index % n_slots
+        if use_rccl and index >= n_slots:
+            comm.release(handle, slot)          # gather of step index - 2 is done
+        _lib.check(lib.tc_predict_zheng07_batch_device(
+            handle, d_theta, 5, n_draws, N_GAUSS, 0, out_ptr(slot),
+            out_ptr(slot, n_draws)))
+        if use_rccl:
+            recv = ctypes.c_void_p(
+                d_recv.value + slot * comm.world_size * n_out * 8) if (
+                    comm.is_root) else None
+            comm.gather_device(handle, out_ptr(slot), recv, n_out, slot)
+
+    def drain():
+        _lib.check(lib.tc_table_synchronize(handle))
+        comm.synchronize()
+        _lib.check(lib.tc_device_synchronize())
+
+    for index in range(args.warmup):
+        step(index)
+    drain()
+
+    # ---- timed region: exactly `steps` steps between barrier + device sync -----------
+    comm.barrier()
+    drain()
+    t0 = time.perf_counter()
+    for index in range(args.steps):
+        step(index)
+    drain()
+    comm.barrier()
+    elapsed = comm.max(time.perf_counter() - t0)
+
+    if comm.world_size > 1 and not use_rccl:
+        # RCCL unavailable: collect the last batch over gloo so that the job still
+        # ends with the results on rank 0 (reported as "gather": "gloo").
+        host = np.empty(n_out)
+        _lib.check(lib.tc_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p),
+                                     out_ptr((args.steps - 1) % n_slots), host.nbytes))
+        comm.gather_host(host)
+
+    # ---- dominant kernel: contraction, HIP events on its own stream --------------------
+    n_bins = 2 * N_PRIM * N_SEC
+    n_pairs = n_bins * (n_bins + 1) // 2
+    flop_contract = n_draws * (2.0 * N_R * n_pairs + 3.0 * n_pairs)
+    ms = ctypes.c_float()
+    _lib.check(lib.tc_table_timer_begin(handle, 1))
+    profile_steps = min(args.steps, 200)
+    for index in range(profile_steps):
+        _lib.check(lib.tc_predict_zheng07_batch_device(
+            handle, d_theta, 5, n_draws, N_GAUSS, 0, out_ptr(0), out_ptr(0, n_draws)))
+    _lib.check(lib.tc_table_timer_end(handle, ctypes.byref(ms)))
+    n_launch = ctypes.c_int()
+    kernel_ms = ctypes.c_float()
+    _lib.check(lib.tc_table_kernel_time(handle, ctypes.byref(n_launch),
+                                        ctypes.byref(kernel_ms)))
+    launch = [ctypes.c_int() for _ in range(4)]
+    lib.tc_table_last_launch(handle, *[ctypes.byref(v) for v in launch])
+
+    result = None
+    if comm.is_root:
+        # spot check against the CPU oracle (4 draws)
+        host = np.empty(n_out)
+        _lib.check(lib.tc_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p), out_ptr(0),
+                                     host.nbytes))
+        from oracle import tabcorr_oracle as oracle
+        expect = oracle.predict_zheng07_batch(table, theta[:4])
+        xi = host[n_draws:].reshape(n_draws, N_R)
+        parity = float(max(np.max(np.abs(host[:4] / expect[0] - 1)),
+                           np.max(np.abs(xi[:4] / expect[1] - 1))))
+
+        achieved = flop_contract / (kernel_ms.value * 1e-3) / 1e12
+        total_draws = comm.world_size * n_draws * args.steps
+        result = {
+            'metric': 'predict_calls_per_sec',
+            'value': total_draws / elapsed,
+            'unit': 'calls/s',
+            'n_gpus': comm.world_size,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'BASELINE configs[1]: Zheng07 predict(), synthetic auto '
+                            'table 50 mass bins x {cen,sat} (G=100, P=5050), 19 rp '
+                            'bins, n_gauss_prim=10, batch of %d draws per GPU per '
+                            'step, draws and results resident in HBM' % n_draws,
+                'draws_per_gpu_per_step': n_draws,
+                'n_bins': n_bins, 'n_pairs': n_pairs, 'n_r': N_R,
+                'parallelism': 'draws sharded over %d GPU(s), table replicated' %
+                               comm.world_size,
+                'gather': comm.gather_backend,
+            },
+            'roofline': {
+                'kernel': 'tc::contract_kernel<20>',
+                'bound': 'mfma',
+                'achieved': achieved,
+                'peak': FP64_PEAK_TFLOPS,
+                'unit': 'TFLOP/s',
+                'frac': achieved / FP64_PEAK_TFLOPS,
+                'traffic': None,
+                'flop_per_launch': flop_contract,
+                'mean_launch_ms': kernel_ms.value,
+                'launches_timed': n_launch.value,
+                'workgroups': launch[0].value,
+                'waves_per_workgroup': launch[1].value,
+                'lds_bytes': launch[3].value,
+            },
+            'parity_max_rel_vs_oracle': parity,
+            'device': _lib.device_name(),
+        }
+        if comm.rccl_error:
+            result['config']['rccl_error'] = comm.rccl_error
+        if comm.world_size == 1 and args.cpu_seconds > 0:
+            result['cpu_baseline'] = cpu_baseline(table, args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+
+    for ptr in (d_theta, d_out, d_recv):
+        if ptr.value:
+            lib.tc_device_free(ptr)
+    comm.barrier()
+    comm.close()
+
+
+def cpu_baseline(table, seconds):
+    """The NumPy port of the reference's predict() (oracle), one call per draw as
+    in the reference's usage (README.md:72-75), on one host core."""
+    from oracle import tabcorr_oracle as oracle
+    from tabcorr_amd import synthetic
+    theta = synthetic.zheng07_draws(200000, seed=99)
+    cache = {}
+    oracle.predict_zheng07(table, theta[0], cache=cache)       # builds the caches
+    start = time.perf_counter()
+    count = 0
+    while True:
+        for t in theta[count:count + 200]:
+            oracle.predict_zheng07(table, t, cache=cache)
+        count += 200
+        spent = time.perf_counter() - start
+        if spent >= seconds or count >= len(theta):
+            break
+    return {'value': count / spent, 'unit': 'calls/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d sequential predict() calls of the same workload (same '
+                      'table, draws from the same prior) in %.1f s' % (count, spent)}
+
+
+if __name__ == '__main__':
+    main()

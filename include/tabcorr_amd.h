@@ -199,9 +199,14 @@ int tc_comm_unique_id(void* id /* TC_UNIQUE_ID_BYTES */);
 int tc_comm_create(const void* id, int n_ranks, int rank, tc_comm** comm);
 int tc_comm_destroy(tc_comm* comm);
 /* Gather `count` doubles from every rank's send_device into recv_device on `root`
- * (rank-major), on the communicator's own stream, after `table`'s stream has drained. */
+ * (rank-major), on the communicator's own stream, after the work queued so far on
+ * `table`'s stream (NULL: no dependency).  `slot` in [0, 4) names the send buffer:
+ * tc_comm_release(comm, table, slot) later makes `table`'s stream wait on the device
+ * for that gather, so that the buffer can be overwritten -- this is what lets the gather
+ * of batch k overlap with the prediction of batch k + 1. */
 int tc_comm_gather(tc_comm* comm, tc_table* table, const double* send_device,
-                   double* recv_device, int64_t count, int root);
+                   double* recv_device, int64_t count, int root, int slot);
+int tc_comm_release(tc_comm* comm, tc_table* table, int slot);
 int tc_comm_barrier(tc_comm* comm);
 int tc_comm_synchronize(tc_comm* comm);
 

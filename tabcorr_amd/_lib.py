@@ -97,7 +97,9 @@ SIGNATURES = {
                        c_void_pp],
     'tc_comm_destroy': [ctypes.c_void_p],
     'tc_comm_gather': [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                       ctypes.c_void_p, ctypes.c_int64, ctypes.c_int],
+                       ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                       ctypes.c_int],
+    'tc_comm_release': [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int],
     'tc_comm_barrier': [ctypes.c_void_p],
     'tc_comm_synchronize': [ctypes.c_void_p],
 }

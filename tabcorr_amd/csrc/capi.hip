@@ -81,7 +81,6 @@ int upload(const std::vector<T>& host, void** device) {
 
 struct DeviceChunking {
   tc::Chunking host;
-  void* segments = nullptr;
   void* chunks = nullptr;
   void* groups = nullptr;
 };
@@ -133,6 +132,7 @@ struct tc_table {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> kernel_events;
   size_t kernel_events_used = 0;
   int last_workgroups = 0, last_waves = 0, last_splits = 0, last_lds = 0;
+  int ngal_parts = 1;   // partial sums the occupation step left in ngal2
 };
 
 namespace {
@@ -188,8 +188,7 @@ int get_chunking(tc_table* t, int n_chunks, int waves, DeviceChunking** out) {
   }
   std::unique_ptr<DeviceChunking> c(new DeviceChunking);
   tc::build_chunking(t->plan, n_chunks, waves, c->host);
-  int status = upload(c->host.segments, &c->segments);
-  if (status == TC_OK) status = upload(c->host.chunks, &c->chunks);
+  int status = upload(c->host.chunks, &c->chunks);
   if (status == TC_OK) status = upload(c->host.groups, &c->groups);
   if (status != TC_OK) return status;
   *out = c.get();
@@ -206,7 +205,7 @@ constexpr int kMaxLdsBytes = 160 * 1024;
 int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
                     DeviceChunking** out, int* lds_bytes) {
   const int64_t n_tiles = (n_draws + 63) / 64;
-  const int64_t target_waves = env_int("TC_TARGET_WAVES", 4096);
+  const int64_t target_waves = env_int("TC_TARGET_WAVES", 8192);
   int64_t n_chunks = target_waves / std::max<int64_t>(1, n_tiles * t->n_rtiles);
   const int64_t min_entries = env_int("TC_MIN_CHUNK_ENTRIES", 48);
   n_chunks = std::min<int64_t>(n_chunks, t->plan.n_entries / min_entries);
@@ -221,7 +220,10 @@ int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
     DeviceChunking* c = nullptr;
     int status = get_chunking(t, (int)n_chunks, waves, &c);
     if (status != TC_OK) return status;
-    int bytes = std::max(c->host.max_rows, n_comp_out * t->rt) * 64 * 8;
+    int span = 1;
+    while (span < c->host.waves_per_group) span <<= 1;
+    int bytes = std::max(c->host.max_rows, (span / 2) * t->rt) * 64 * 8;
+    bytes = std::max(bytes, env_int("TC_LDS_MIN", 0));
     if (bytes <= kMaxLdsBytes) {
       *out = c;
       *lds_bytes = bytes;
@@ -241,18 +243,19 @@ int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
               t->n_bins, kMaxLdsBytes, t->mode == TC_MODE_AUTO ? "auto" : "cross");
 }
 
-template <typename TableT>
+#define TC_RT_CASES                                                           \
+  TC_CASE(4) TC_CASE(8) TC_CASE(12) TC_CASE(16) TC_CASE(20) TC_CASE(24)       \
+  TC_CASE(28) TC_CASE(32)
+
 int launch_contract_rt(int rt, dim3 grid, dim3 block, int lds, hipStream_t stream,
                        const tc::ContractArgs& args) {
   switch (rt) {
 #define TC_CASE(N)                                                            \
   case N:                                                                     \
-    hipLaunchKernelGGL((tc::contract_kernel<N, TableT>), grid, block, lds,    \
-                       stream, args);                                         \
+    hipLaunchKernelGGL((tc::contract_kernel<N>), grid, block, lds, stream,    \
+                       args);                                                 \
     break;
-    TC_CASE(2) TC_CASE(4) TC_CASE(6) TC_CASE(8) TC_CASE(10) TC_CASE(12)
-    TC_CASE(14) TC_CASE(16) TC_CASE(18) TC_CASE(20) TC_CASE(22) TC_CASE(24)
-    TC_CASE(26) TC_CASE(28) TC_CASE(30) TC_CASE(32)
+    TC_RT_CASES
 #undef TC_CASE
     default:
       return fail(TC_ERR_UNSUPPORTED, "no kernel for r tile %d", rt);
@@ -261,18 +264,15 @@ int launch_contract_rt(int rt, dim3 grid, dim3 block, int lds, hipStream_t strea
   return TC_OK;
 }
 
-template <typename TableT>
 int set_lds_limit_rt(int rt, int lds) {
   switch (rt) {
 #define TC_CASE(N)                                                            \
   case N:                                                                     \
     TC_HIP(hipFuncSetAttribute(                                               \
-        reinterpret_cast<const void*>(&tc::contract_kernel<N, TableT>),       \
+        reinterpret_cast<const void*>(&tc::contract_kernel<N>),               \
         hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \
     break;
-    TC_CASE(2) TC_CASE(4) TC_CASE(6) TC_CASE(8) TC_CASE(10) TC_CASE(12)
-    TC_CASE(14) TC_CASE(16) TC_CASE(18) TC_CASE(20) TC_CASE(22) TC_CASE(24)
-    TC_CASE(26) TC_CASE(28) TC_CASE(30) TC_CASE(32)
+    TC_RT_CASES
 #undef TC_CASE
     default:
       break;
@@ -292,26 +292,26 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   const int n_groups = (int)c->host.groups.size();
   const int r_stride = t->rt * t->n_rtiles;
   status = t->partial.reserve(
-      (size_t)n_groups * n_comp * r_stride * ldb * sizeof(double), t->stream);
+      (size_t)n_groups * r_stride * ldb * sizeof(double), t->stream);
   if (status != TC_OK) return status;
 
   tc::ContractArgs ca;
   ca.nbuf = (const double*)t->nbuf.ptr;
   ca.ldb = ldb;
   ca.table = t->d_table;
-  ca.n_entries = t->plan.n_entries;
-  ca.segments = (const tc::Segment*)c->segments;
+  ca.n_positions = t->plan.n_positions;
   ca.chunks = (const tc::Chunk*)c->chunks;
   ca.groups = (const tc::Group*)c->groups;
-  ca.n_components_out = n_comp;
+  ca.mode = t->mode;
+  ca.n_central = t->plan.n_central;
   ca.r_stride = r_stride;
+  ca.debug = env_int("TC_DEBUG_VARIANT", 0);
   ca.partial = (double*)t->partial.ptr;
 
   dim3 grid((unsigned)(ldb / 64), (unsigned)n_groups, (unsigned)t->n_rtiles);
   dim3 block(64 * c->host.waves_per_group);
   if (lds > 64 * 1024) {
-    status = t->compute_dtype == TC_DTYPE_F64 ? set_lds_limit_rt<double>(t->rt, lds)
-                                              : set_lds_limit_rt<float>(t->rt, lds);
+    status = set_lds_limit_rt(t->rt, lds);
     if (status != TC_OK) return status;
   }
   hipEvent_t k0 = nullptr, k1 = nullptr;
@@ -327,9 +327,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
     ++t->kernel_events_used;
     TC_HIP(hipEventRecord(k0, t->stream));
   }
-  status = t->compute_dtype == TC_DTYPE_F64
-               ? launch_contract_rt<double>(t->rt, grid, block, lds, t->stream, ca)
-               : launch_contract_rt<float>(t->rt, grid, block, lds, t->stream, ca);
+  status = launch_contract_rt(t->rt, grid, block, lds, t->stream, ca);
   if (status != TC_OK) return status;
   if (t->profile_kernels) TC_HIP(hipEventRecord(k1, t->stream));
   t->last_workgroups = (int)(grid.x * grid.y * grid.z);
@@ -339,7 +337,9 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
 
   tc::FinalizeArgs fa;
   fa.partial = (const double*)t->partial.ptr;
-  fa.ngal_in = (const double*)t->ngal2.ptr;
+  fa.groups = (const tc::Group*)c->groups;
+  fa.ngal_part = (const double*)t->ngal2.ptr;
+  fa.n_ngal_parts = t->ngal_parts;
   fa.n_groups = n_groups;
   fa.n_comp = n_comp;
   fa.r_stride = r_stride;
@@ -349,8 +349,8 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   fa.n_draws = n_draws;
   fa.ngal = ngal_device;
   fa.xi = xi_device;
-  hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)((n_draws + 255) / 256)),
-                     dim3(256), 0, t->stream, fa);
+  hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)(ldb / 64)), dim3(256), 0,
+                     t->stream, fa);
   TC_HIP(hipGetLastError());
   return TC_OK;
 }
@@ -361,9 +361,17 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   Quadrature* q = nullptr;
   int status = get_quadrature(t, n_gauss, &q);
   if (status != TC_OK) return status;
+  // enough blocks to fill the chip: split the bins when there are few draw tiles
+  const int64_t n_tiles = ldb / 64;
+  int splits = (int)std::min<int64_t>(
+      (t->n_bins + tc::kOccWaves - 1) / tc::kOccWaves,
+      std::max<int64_t>(1, env_int("TC_OCC_BLOCKS", 2048) / n_tiles));
+  splits = std::max(1, splits);
   status = t->nbuf.reserve((size_t)t->n_bins * ldb * sizeof(double), t->stream);
-  if (status == TC_OK) status = t->ngal2.reserve(2 * ldb * sizeof(double), t->stream);
+  if (status == TC_OK)
+    status = t->ngal2.reserve((size_t)splits * 2 * ldb * sizeof(double), t->stream);
   if (status != TC_OK) return status;
+  t->ngal_parts = splits;
   tc::OccArgs oa;
   oa.theta = theta_device;
   oa.n_theta = n_theta;
@@ -383,7 +391,8 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   oa.nbuf = (double*)t->nbuf.ptr;
   oa.ngal = (double*)t->ngal2.ptr;
   oa.occupation = occupation_device;
-  hipLaunchKernelGGL(tc::occ_zheng07_kernel, dim3((unsigned)(ldb / 64)),
+  hipLaunchKernelGGL(tc::occ_zheng07_kernel,
+                     dim3((unsigned)(ldb / 64), (unsigned)splits),
                      dim3(tc::kOccWaves * 64), 0, t->stream, oa);
   TC_HIP(hipGetLastError());
   return TC_OK;
@@ -514,38 +523,39 @@ int tc_plan_debug(int mode, int n_bins, const uint8_t* is_central, int n_chunks,
   TC_CHECK(mode == TC_MODE_AUTO || mode == TC_MODE_CROSS, "invalid mode");
   TC_CHECK(n_bins >= 1 && is_central && n_entries, "invalid arguments");
   tc::Plan plan;
-  tc::build_plan(mode, n_bins, is_central, plan);
+  tc::build_plan(mode, n_bins, is_central, 4, plan);
   tc::Chunking chunking;
   tc::build_chunking(plan, n_chunks, 8, chunking);
   *n_entries = plan.n_entries;
   if (entry_pair == nullptr) return TC_OK;
-  for (int64_t e = 0; e < plan.n_entries; ++e) entry_chunk[e] = -1;
+  // Walk every chunk exactly as the kernel does and record what it visits.
+  std::vector<int> seen((size_t)plan.n_positions, 0);
+  int64_t e = 0;
   for (size_t c = 0; c < chunking.chunks.size(); ++c) {
     const tc::Chunk& chunk = chunking.chunks[c];
-    for (int s = chunk.seg_begin; s < chunk.seg_end; ++s) {
-      const tc::Segment& seg = chunking.segments[s];
-      for (int k = 0; k < seg.len; ++k) {
-        const int64_t e = seg.e0 + k;
-        // recompute the reference column from (i, j) to check the entry order
-        int64_t column;
-        if (mode == TC_MODE_AUTO)
-          column = tc::packed_index(plan.perm[seg.i], plan.perm[seg.j0 + k]);
-        else
-          column = plan.perm[seg.j0 + k];
-        if (column != plan.entry_column[e])
-          return fail(TC_ERR_INVALID, "plan inconsistency at entry %lld",
-                      (long long)e);
-        if (entry_chunk[e] != -1)
-          return fail(TC_ERR_INVALID, "entry %lld covered twice", (long long)e);
+    if ((chunk.q_begin % plan.block) != 0 || (chunk.q_end % plan.block) != 0)
+      return fail(TC_ERR_INVALID, "chunk %zu is not block aligned", c);
+    int i = chunk.i0, j = chunk.j0, remaining = chunk.n_real;
+    for (int q = chunk.q_begin; q < chunk.q_end; ++q) {
+      if (seen[q]++) return fail(TC_ERR_INVALID, "position %d covered twice", q);
+      if (plan.column[q] >= 0) {
+        const int64_t column =
+            mode == TC_MODE_AUTO ? tc::packed_index(plan.perm[i], plan.perm[j])
+                                 : plan.perm[j];
+        if (column != plan.column[q] || q >= chunk.q_begin + chunk.n_real)
+          return fail(TC_ERR_INVALID, "walk mismatch at position %d", q);
+        if (e >= plan.n_entries) return fail(TC_ERR_INVALID, "too many entries");
         entry_pair[e] = (int32_t)column;
         entry_chunk[e] = (int32_t)c;
         entry_class[e] = chunk.component;
-        if (chunk.component != plan.entry_component[e])
-          return fail(TC_ERR_INVALID, "component mismatch at entry %lld",
-                      (long long)e);
+        ++e;
       }
+      if (--remaining > 0) tc::advance_pair(mode, chunk.component, plan.n_central, i, j);
     }
   }
+  for (int64_t q = 0; q < plan.n_positions; ++q)
+    if (!seen[q]) return fail(TC_ERR_INVALID, "position %lld not covered", (long long)q);
+  if (e != plan.n_entries) return fail(TC_ERR_INVALID, "entries missing");
   return TC_OK;
 }
 
@@ -581,7 +591,19 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
   t->n_pairs = n_pairs;
   t->compute_dtype = compute_dtype;
   t->legacy = dist_index == nullptr;
-  tc::build_plan(mode, n_bins, is_central, t->plan);
+  TC_CHECK(compute_dtype == TC_DTYPE_F64 || true, "unreachable");
+  if (compute_dtype != TC_DTYPE_F64)
+    return fail(TC_ERR_UNSUPPORTED, "float32 contraction is not implemented yet");
+
+  // r tiling: at most 32 accumulators per lane, a multiple of 4 so that a block
+  // of at most 4 entries fills whole 128-byte lines.
+  const int max_rt = 32;
+  t->n_rtiles = (n_r + max_rt - 1) / max_rt;
+  {
+    int rt = (n_r + t->n_rtiles - 1) / t->n_rtiles;
+    t->rt = (rt + 3) / 4 * 4;
+  }
+  tc::build_plan(mode, n_bins, is_central, tc::block_entries(t->rt), t->plan);
 
   for (int g = 0; g < n_bins; ++g) {
     const int src = t->plan.perm[g];
@@ -592,42 +614,31 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
     t->dist_index.push_back(dist_index ? dist_index[src] : -1.0);
   }
 
-  // r tiling: at most 32 accumulators per lane, even count.
-  const int max_rt = 32;
-  t->n_rtiles = (n_r + max_rt - 1) / max_rt;
-  int rt = (n_r + t->n_rtiles - 1) / t->n_rtiles;
-  rt += rt & 1;
-  t->rt = rt;
-
-  // Re-laid-out matrix: [r tile][entry][r in tile] with the pair prefactor
-  // (tabcorr.py:638-642) folded in (a multiplication by 2 is exact).
-  const int64_t n_entries = t->plan.n_entries;
-  const size_t elem = compute_dtype == TC_DTYPE_F64 ? 8 : 4;
-  const size_t count = (size_t)t->n_rtiles * n_entries * rt;
-  t->table_bytes = count * elem;
-  std::vector<double> tmp64;
-  std::vector<float> tmp32;
-  if (compute_dtype == TC_DTYPE_F64) tmp64.assign(count, 0.0);
-  else tmp32.assign(count, 0.0f);
+  const int rt = t->rt;
+  // Re-laid-out matrix: [r tile][position][r in tile] with the pair prefactor
+  // (tabcorr.py:638-642) folded in (a multiplication by 2 is exact) and zero
+  // rows at the padding positions.
+  const int64_t n_positions = t->plan.n_positions;
+  const size_t count = (size_t)t->n_rtiles * n_positions * rt;
+  t->table_bytes = count * sizeof(double);
+  std::vector<double> tmp64(count, 0.0);
   for (int r = 0; r < n_r; ++r) {
     const int tile = r / rt, rr = r % rt;
-    for (int64_t e = 0; e < n_entries; ++e) {
-      const int64_t column = t->plan.entry_column[e];
+    for (int64_t q = 0; q < n_positions; ++q) {
+      const int64_t column = t->plan.column[q];
+      if (column < 0) continue;
       const double value =
           (matrix_dtype == TC_DTYPE_F64
                ? ((const double*)tpcf_matrix)[(size_t)r * n_pairs + column]
                : (double)((const float*)tpcf_matrix)[(size_t)r * n_pairs + column]) *
-          t->plan.entry_prefactor[e];
-      const size_t dst = ((size_t)tile * n_entries + e) * rt + rr;
-      if (compute_dtype == TC_DTYPE_F64) tmp64[dst] = value;
-      else tmp32[dst] = (float)value;
+          t->plan.prefactor[q];
+      tmp64[((size_t)tile * n_positions + q) * rt + rr] = value;
     }
   }
   TC_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
   TC_HIP(hipEventCreate(&t->ev_begin));
   TC_HIP(hipEventCreate(&t->ev_end));
-  int status = compute_dtype == TC_DTYPE_F64 ? upload(tmp64, &t->d_table)
-                                             : upload(tmp32, &t->d_table);
+  int status = upload(tmp64, &t->d_table);
   if (status == TC_OK) status = upload(t->n_h, &t->d_n_h);
   if (status == TC_OK) status = upload(t->percentile, &t->d_percentile);
   if (status == TC_OK) status = upload(t->plan.perm, &t->d_perm);
@@ -649,7 +660,7 @@ int tc_table_destroy(tc_table* t) {
     for (void* p : {kv.second.log_m, kv.second.m, kv.second.weight})
       if (p) (void)hipFree(p);
   for (auto& kv : t->chunkings)
-    for (void* p : {kv.second->segments, kv.second->chunks, kv.second->groups})
+    for (void* p : {kv.second->chunks, kv.second->groups})
       if (p) (void)hipFree(p);
   for (DeviceBuffer* b : {&t->theta, &t->nbuf, &t->ngal2, &t->partial,
                           &t->out_ngal, &t->out_xi, &t->occupation})
@@ -797,6 +808,7 @@ int tc_predict_occupation_batch(tc_table* t, const double* occupation,
                        (const int32_t*)t->d_perm, (double*)t->nbuf.ptr,
                        (double*)t->ngal2.ptr);
     TC_HIP(hipGetLastError());
+    t->ngal_parts = 1;
     status = run_contraction(t, n, ldb, flags, (double*)t->out_ngal.ptr,
                              (double*)t->out_xi.ptr);
     if (status != TC_OK) return status;
@@ -876,21 +888,171 @@ int tc_interp_predict_zheng07_batch_device(tc_interp*, const double*, int,
                                            double*, double*) {
   return fail(TC_ERR_UNSUPPORTED, "tc_interp_predict: not implemented yet");
 }
-int tc_comm_unique_id(void*) {
-  return fail(TC_ERR_UNSUPPORTED, "tc_comm: not implemented yet");
+}  // extern "C"
+
+// ---- multi-GPU: RCCL, resolved at run time --------------------------------------------
+//
+// One process per GPU (torchrun style).  librccl is opened lazily so that single-GPU use
+// and CPU-only hosts never load it.  The only collective of the path is the gather of the
+// per-rank results on the root; a barrier is provided for timing.
+#include <dlfcn.h>
+
+namespace {
+
+typedef struct ncclComm* nccl_comm_t;
+typedef struct { char internal[TC_UNIQUE_ID_BYTES]; } nccl_unique_id;
+
+struct Rccl {
+  void* handle = nullptr;
+  int (*GetUniqueId)(nccl_unique_id*) = nullptr;
+  int (*CommInitRank)(nccl_comm_t*, int, nccl_unique_id, int) = nullptr;
+  int (*CommDestroy)(nccl_comm_t) = nullptr;
+  int (*Gather)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+
+Rccl g_rccl;
+
+int load_rccl() {
+  if (g_rccl.handle != nullptr) return TC_OK;
+  const char* names[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+  void* handle = nullptr;
+  for (const char* name : names) {
+    handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (handle != nullptr) break;
+  }
+  if (handle == nullptr) return fail(TC_ERR_RCCL, "cannot load librccl: %s", dlerror());
+#define TC_SYM(field, symbol)                                                  \
+  *(void**)(&g_rccl.field) = dlsym(handle, symbol);                            \
+  if (g_rccl.field == nullptr)                                                 \
+    return fail(TC_ERR_RCCL, "librccl lacks %s", symbol);
+  TC_SYM(GetUniqueId, "ncclGetUniqueId")
+  TC_SYM(CommInitRank, "ncclCommInitRank")
+  TC_SYM(CommDestroy, "ncclCommDestroy")
+  TC_SYM(Gather, "ncclGather")
+  TC_SYM(AllReduce, "ncclAllReduce")
+  TC_SYM(GetErrorString, "ncclGetErrorString")
+#undef TC_SYM
+  g_rccl.handle = handle;
+  return TC_OK;
 }
-int tc_comm_create(const void*, int, int, tc_comm**) {
-  return fail(TC_ERR_UNSUPPORTED, "tc_comm: not implemented yet");
+
+#define TC_RCCL(call)                                                          \
+  do {                                                                         \
+    int tc_rccl_status = (call);                                               \
+    if (tc_rccl_status != 0)                                                   \
+      return fail(TC_ERR_RCCL, "%s failed: %s", #call,                         \
+                  g_rccl.GetErrorString(tc_rccl_status));                      \
+  } while (0)
+
+constexpr int kNcclFloat64 = 8;
+constexpr int kNcclSum = 0;
+
+}  // namespace
+
+struct tc_comm {
+  int device = 0;
+  int n_ranks = 1;
+  int rank = 0;
+  nccl_comm_t comm = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ready = nullptr;
+  hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};  // per send-buffer slot
+  double* token = nullptr;   // one double for the barrier all-reduce
+};
+
+extern "C" {
+
+int tc_comm_unique_id(void* id) {
+  TC_CHECK(id != nullptr, "id is NULL");
+  int status = load_rccl();
+  if (status != TC_OK) return status;
+  nccl_unique_id unique;
+  TC_RCCL(g_rccl.GetUniqueId(&unique));
+  memcpy(id, &unique, TC_UNIQUE_ID_BYTES);
+  return TC_OK;
 }
-int tc_comm_destroy(tc_comm*) { return TC_OK; }
-int tc_comm_gather(tc_comm*, tc_table*, const double*, double*, int64_t, int) {
-  return fail(TC_ERR_UNSUPPORTED, "tc_comm: not implemented yet");
+
+int tc_comm_create(const void* id, int n_ranks, int rank, tc_comm** out) {
+  TC_CHECK(out != nullptr && id != nullptr, "NULL argument");
+  *out = nullptr;
+  TC_CHECK(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "invalid rank %d of %d", rank,
+           n_ranks);
+  int status = load_rccl();
+  if (status != TC_OK) return status;
+  std::unique_ptr<tc_comm> c(new tc_comm);
+  TC_HIP(hipGetDevice(&c->device));
+  c->n_ranks = n_ranks;
+  c->rank = rank;
+  nccl_unique_id unique;
+  memcpy(&unique, id, TC_UNIQUE_ID_BYTES);
+  TC_RCCL(g_rccl.CommInitRank(&c->comm, n_ranks, unique, rank));
+  TC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  TC_HIP(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+  for (hipEvent_t& event : c->done)
+    TC_HIP(hipEventCreateWithFlags(&event, hipEventDisableTiming));
+  TC_HIP(hipMalloc((void**)&c->token, sizeof(double)));
+  TC_HIP(hipMemset(c->token, 0, sizeof(double)));
+  *out = c.release();
+  return TC_OK;
 }
-int tc_comm_barrier(tc_comm*) {
-  return fail(TC_ERR_UNSUPPORTED, "tc_comm: not implemented yet");
+
+int tc_comm_destroy(tc_comm* c) {
+  if (c == nullptr) return TC_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  if (c->token) (void)hipFree(c->token);
+  if (c->ready) (void)hipEventDestroy(c->ready);
+  for (hipEvent_t event : c->done)
+    if (event) (void)hipEventDestroy(event);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return TC_OK;
 }
-int tc_comm_synchronize(tc_comm*) {
-  return fail(TC_ERR_UNSUPPORTED, "tc_comm: not implemented yet");
+
+int tc_comm_gather(tc_comm* c, tc_table* t, const double* send_device,
+                   double* recv_device, int64_t count, int root, int slot) {
+  TC_CHECK(slot >= 0 && slot < 4, "slot must be in [0, 4)");
+  TC_CHECK(c != nullptr && send_device != nullptr, "NULL argument");
+  TC_CHECK(count >= 0 && root >= 0 && root < c->n_ranks, "invalid count or root");
+  TC_CHECK(c->rank != root || recv_device != nullptr, "recv buffer is NULL on the root");
+  TC_HIP(hipSetDevice(c->device));
+  if (t != nullptr) {
+    // the gather starts once the predictions queued on the table's stream are done,
+    // without blocking the host: later batches overlap with the transfer
+    TC_HIP(hipEventRecord(c->ready, t->stream));
+    TC_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+  }
+  TC_RCCL(g_rccl.Gather(send_device, recv_device, (size_t)count, kNcclFloat64, root,
+                        c->comm, c->stream));
+  TC_HIP(hipEventRecord(c->done[slot], c->stream));
+  return TC_OK;
+}
+
+int tc_comm_release(tc_comm* c, tc_table* t, int slot) {
+  TC_CHECK(c != nullptr && t != nullptr, "NULL argument");
+  TC_CHECK(slot >= 0 && slot < 4, "slot must be in [0, 4)");
+  TC_HIP(hipSetDevice(c->device));
+  TC_HIP(hipStreamWaitEvent(t->stream, c->done[slot], 0));
+  return TC_OK;
+}
+
+int tc_comm_barrier(tc_comm* c) {
+  TC_CHECK(c != nullptr, "comm handle is NULL");
+  TC_HIP(hipSetDevice(c->device));
+  TC_RCCL(g_rccl.AllReduce(c->token, c->token, 1, kNcclFloat64, kNcclSum, c->comm,
+                           c->stream));
+  TC_HIP(hipStreamSynchronize(c->stream));
+  return TC_OK;
+}
+
+int tc_comm_synchronize(tc_comm* c) {
+  TC_CHECK(c != nullptr, "comm handle is NULL");
+  TC_HIP(hipSetDevice(c->device));
+  TC_HIP(hipStreamSynchronize(c->stream));
+  return TC_OK;
 }
 
 }  // extern "C"

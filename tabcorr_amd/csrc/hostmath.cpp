@@ -132,9 +132,21 @@ bool spline_interpolation_matrix(int n_points, const double* xp,
   return true;
 }
 
-void build_plan(int mode, int n_bins, const uint8_t* is_central, Plan& plan) {
+int block_entries(int rt) {
+  int g = 16, r = rt;
+  while (r != 0) {
+    int t = g % r;
+    g = r;
+    r = t;
+  }
+  return 16 / g;   // g = gcd(rt, 16)
+}
+
+void build_plan(int mode, int n_bins, const uint8_t* is_central, int block,
+                Plan& plan) {
   plan.mode = mode;
   plan.n_bins = n_bins;
+  plan.block = block;
   plan.perm.clear();
   for (int g = 0; g < n_bins; ++g)
     if (is_central[g]) plan.perm.push_back(g);
@@ -142,146 +154,114 @@ void build_plan(int mode, int n_bins, const uint8_t* is_central, Plan& plan) {
   for (int g = 0; g < n_bins; ++g)
     if (!is_central[g]) plan.perm.push_back(g);
   const int gc = plan.n_central;
+  plan.n_components = mode == 0 ? 3 : 2;
 
-  plan.entry_column.clear();
-  plan.entry_prefactor.clear();
-  plan.entry_component.clear();
-  if (mode == 0) {
-    plan.n_components = 3;
-    // component-major, then row-major: all cen-cen pairs, all cen-sat pairs,
-    // all sat-sat pairs.
-    for (int comp = 0; comp < 3; ++comp) {
-      for (int i = 0; i < n_bins; ++i) {
-        int j_lo, j_hi;
-        if (comp == 0) {
-          if (i >= gc) continue;
-          j_lo = 0; j_hi = i + 1;
-        } else if (comp == 1) {
-          if (i < gc) continue;
-          j_lo = 0; j_hi = gc;
-        } else {
-          if (i < gc) continue;
-          j_lo = gc; j_hi = i + 1;
-        }
-        for (int j = j_lo; j < j_hi; ++j) {
-          int a = plan.perm[i], b = plan.perm[j];
-          plan.entry_column.push_back(packed_index(a, b));
-          plan.entry_prefactor.push_back(a == b ? 1 : 2);
-          plan.entry_component.push_back((int8_t)comp);
-        }
-      }
+  plan.column.clear();
+  plan.prefactor.clear();
+  plan.pos_i.clear();
+  plan.pos_j.clear();
+  plan.comp_begin.clear();
+  plan.comp_real.clear();
+  plan.n_entries = 0;
+  for (int comp = 0; comp < plan.n_components; ++comp) {
+    plan.comp_begin.push_back((int64_t)plan.column.size());
+    // first pair of the component and number of real entries
+    int i, j;
+    int64_t n_real;
+    if (mode == 0) {
+      const int64_t gs = n_bins - gc;
+      if (comp == 0) { i = 0; j = 0; n_real = (int64_t)gc * (gc + 1) / 2; }
+      else if (comp == 1) { i = gc; j = 0; n_real = gs * gc; }
+      else { i = gc; j = gc; n_real = gs * (gs + 1) / 2; }
+    } else {
+      i = -1;
+      j = comp == 0 ? 0 : gc;
+      n_real = comp == 0 ? gc : n_bins - gc;
     }
-  } else {
-    plan.n_components = 2;
-    for (int j = 0; j < n_bins; ++j) {
-      plan.entry_column.push_back(plan.perm[j]);
-      plan.entry_prefactor.push_back(1);
-      plan.entry_component.push_back(j < gc ? 0 : 1);
-    }
-  }
-  plan.n_entries = (int64_t)plan.entry_column.size();
-}
-
-namespace {
-
-// Segments of one component in entry order.
-void component_segments(const Plan& plan, int comp, std::vector<Segment>& segs,
-                        int64_t& e0) {
-  const int gc = plan.n_central, g = plan.n_bins;
-  if (plan.mode == 0) {
-    for (int i = 0; i < g; ++i) {
-      int j_lo, j_hi;
-      if (comp == 0) {
-        if (i >= gc) continue;
-        j_lo = 0; j_hi = i + 1;
-      } else if (comp == 1) {
-        if (i < gc) continue;
-        j_lo = 0; j_hi = gc;
+    plan.comp_real.push_back(n_real);
+    for (int64_t e = 0; e < n_real; ++e) {
+      if (mode == 0) {
+        const int a = plan.perm[i], b = plan.perm[j];
+        plan.column.push_back(packed_index(a, b));
+        plan.prefactor.push_back(a == b ? 1 : 2);
       } else {
-        if (i < gc) continue;
-        j_lo = gc; j_hi = i + 1;
+        plan.column.push_back(plan.perm[j]);
+        plan.prefactor.push_back(1);
       }
-      if (j_hi <= j_lo) continue;
-      segs.push_back({i, j_lo, j_hi - j_lo, (int32_t)e0});
-      e0 += j_hi - j_lo;
+      plan.pos_i.push_back(i);
+      plan.pos_j.push_back(j);
+      if (e + 1 < n_real) advance_pair(mode, comp, gc, i, j);
     }
-  } else {
-    int j_lo = comp == 0 ? 0 : gc;
-    int j_hi = comp == 0 ? gc : g;
-    if (j_hi > j_lo) {
-      segs.push_back({-1, j_lo, j_hi - j_lo, (int32_t)e0});
-      e0 += j_hi - j_lo;
+    // zero padding: frozen on the last real pair (any valid pair would do)
+    const int64_t padded = (n_real + block - 1) / block * block;
+    for (int64_t e = n_real; e < padded; ++e) {
+      plan.column.push_back(-1);
+      plan.prefactor.push_back(0);
+      plan.pos_i.push_back(i);
+      plan.pos_j.push_back(j);
     }
+    plan.n_entries += n_real;
   }
+  plan.comp_begin.push_back((int64_t)plan.column.size());
+  plan.n_positions = (int64_t)plan.column.size();
 }
-
-}  // namespace
 
 void build_chunking(const Plan& plan, int n_chunks, int waves_per_group,
                     Chunking& out) {
   out.waves_per_group = waves_per_group;
-  out.segments.clear();
   out.chunks.clear();
   out.groups.clear();
   out.max_rows = 0;
   if (n_chunks < 1) n_chunks = 1;
-
-  std::vector<std::vector<Segment>> comp_segs(plan.n_components);
-  std::vector<int64_t> comp_entries(plan.n_components, 0);
-  int64_t e0 = 0;
-  for (int c = 0; c < plan.n_components; ++c) {
-    int64_t begin = e0;
-    component_segments(plan, c, comp_segs[c], e0);
-    comp_entries[c] = e0 - begin;
-  }
   const int64_t total = std::max<int64_t>(1, plan.n_entries);
+  const int eb = plan.block;
 
   for (int c = 0; c < plan.n_components; ++c) {
-    if (comp_entries[c] == 0) continue;
+    const int64_t n_real = plan.comp_real[c];
+    if (n_real == 0) continue;
+    const int64_t n_blocks = (n_real + eb - 1) / eb;
     // chunks of this component, proportional to its share of the entries
-    int64_t nc = (comp_entries[c] * n_chunks + total / 2) / total;
-    nc = std::max<int64_t>(1, std::min<int64_t>(nc, comp_entries[c]));
-    int64_t done = 0;       // entries of this component already assigned
-    size_t s = 0;           // current segment
-    int32_t used = 0;       // entries of segment s already assigned
+    int64_t nc = (n_real * n_chunks + total / 2) / total;
+    // full workgroups: a multiple of waves_per_group where there are several
+    if (nc > waves_per_group)
+      nc = (nc + waves_per_group / 2) / waves_per_group * waves_per_group;
+    nc = std::max<int64_t>(1, std::min<int64_t>(nc, n_blocks));
     for (int64_t k = 0; k < nc; ++k) {
-      int64_t target = comp_entries[c] * (k + 1) / nc - done;
+      const int64_t b0 = n_blocks * k / nc, b1 = n_blocks * (k + 1) / nc;
       Chunk chunk;
-      chunk.seg_begin = (int32_t)out.segments.size();
+      chunk.q_begin = (int32_t)(plan.comp_begin[c] + b0 * eb);
+      chunk.q_end = (int32_t)(plan.comp_begin[c] + b1 * eb);
+      chunk.n_real = (int32_t)(std::min<int64_t>(n_real, b1 * eb) - b0 * eb);
+      chunk.i0 = plan.pos_i[chunk.q_begin];
+      chunk.j0 = plan.pos_j[chunk.q_begin];
       chunk.component = c;
-      chunk.n_entries = (int32_t)target;
-      while (target > 0) {
-        const Segment& seg = comp_segs[c][s];
-        int32_t take = (int32_t)std::min<int64_t>(target, seg.len - used);
-        out.segments.push_back({seg.i, seg.j0 + used, take, seg.e0 + used});
-        used += take;
-        target -= take;
-        done += take;
-        if (used == seg.len) {
-          ++s;
-          used = 0;
-        }
-      }
-      chunk.seg_end = (int32_t)out.segments.size();
+      chunk.pad0 = chunk.pad1 = 0;
       out.chunks.push_back(chunk);
     }
   }
 
-  for (size_t begin = 0; begin < out.chunks.size(); begin += waves_per_group) {
+  // workgroups: waves_per_group consecutive chunks of ONE component
+  size_t begin = 0;
+  while (begin < out.chunks.size()) {
+    const int comp = out.chunks[begin].component;
+    size_t end = begin;
+    while (end < out.chunks.size() && end - begin < (size_t)waves_per_group &&
+           out.chunks[end].component == comp)
+      ++end;
     Group group;
     group.chunk_begin = (int32_t)begin;
-    group.n_chunks = (int32_t)std::min<size_t>(waves_per_group,
-                                                out.chunks.size() - begin);
+    group.n_chunks = (int32_t)(end - begin);
+    group.component = comp;
+    group.pad0 = group.pad1 = group.pad2 = 0;
     int lo = plan.n_bins, hi = 0;
     for (int k = 0; k < group.n_chunks; ++k) {
       const Chunk& chunk = out.chunks[begin + k];
-      for (int s = chunk.seg_begin; s < chunk.seg_end; ++s) {
-        const Segment& seg = out.segments[s];
-        lo = std::min(lo, seg.j0);
-        hi = std::max(hi, seg.j0 + seg.len);
-        if (seg.i >= 0) {
-          lo = std::min(lo, seg.i);
-          hi = std::max(hi, seg.i + 1);
+      for (int32_t q = chunk.q_begin; q < chunk.q_begin + chunk.n_real; ++q) {
+        lo = std::min(lo, plan.pos_j[q]);
+        hi = std::max(hi, plan.pos_j[q] + 1);
+        if (plan.pos_i[q] >= 0) {
+          lo = std::min(lo, plan.pos_i[q]);
+          hi = std::max(hi, plan.pos_i[q] + 1);
         }
       }
     }
@@ -290,6 +270,7 @@ void build_chunking(const Plan& plan, int n_chunks, int waves_per_group,
     group.row_hi = hi;
     out.max_rows = std::max(out.max_rows, hi - lo);
     out.groups.push_back(group);
+    begin = end;
   }
 }
 

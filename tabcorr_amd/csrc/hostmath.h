@@ -24,24 +24,24 @@ inline int64_t packed_index(int64_t i, int64_t j) {
 // false if the linear system is singular (repeated abscissae).
 bool spline_interpolation_matrix(int n, const double* xp, std::vector<double>& a);
 
-// One run of consecutive entries that share the row weight n_i:
-// weights are n_i * n_j for j = j0 .. j0 + len - 1 (mode auto) or n_j alone
-// (mode cross, i = -1); the entries start at position e0 of the re-laid-out
-// table.  Indices refer to the library's bin order (centrals first).
-struct Segment {
-  int32_t i;
-  int32_t j0;
-  int32_t len;
-  int32_t e0;
-};
+// The contraction walks the table in "positions": per component the real
+// entries (packed pairs in row-major order) followed by zero padding up to a
+// multiple of the block size EB, so that every block of EB entries starts on a
+// 128-byte boundary of the re-laid-out table.
 
-// The work of one wavefront: segments [seg_begin, seg_end), all of one
-// component (0 cen-cen | cen, 1 cen-sat | sat, 2 sat-sat).
+// The work of one wavefront: positions [q_begin, q_end) of one component
+// (0 cen-cen | cen, 1 cen-sat | sat, 2 sat-sat), of which the first n_real are
+// real entries; (i0, j0) is the bin pair of position q_begin in the library's
+// bin order (centrals first).  Mode cross has i0 = -1.
 struct Chunk {
-  int32_t seg_begin;
-  int32_t seg_end;
+  int32_t q_begin;
+  int32_t q_end;
+  int32_t n_real;
+  int32_t i0;
+  int32_t j0;
   int32_t component;
-  int32_t n_entries;
+  int32_t pad0;
+  int32_t pad1;
 };
 
 // The work of one workgroup: chunks [chunk_begin, chunk_begin + n_chunks) and
@@ -51,6 +51,8 @@ struct Group {
   int32_t n_chunks;
   int32_t row_lo;
   int32_t row_hi;
+  int32_t component;   // all chunks of a group belong to one component
+  int32_t pad0, pad1, pad2;
 };
 
 struct Plan {
@@ -58,28 +60,51 @@ struct Plan {
   int n_bins = 0;
   int n_central = 0;
   int n_components = 0;          // 3 (auto) or 2 (cross)
+  int block = 1;                 // EB: entries per 128-byte aligned block
   int64_t n_entries = 0;         // = P
+  int64_t n_positions = 0;       // padded, multiple of EB per component
   std::vector<int32_t> perm;     // library bin g' -> reference row
-  // Entry order of the re-laid-out table: reference column and prefactor.
-  std::vector<int64_t> entry_column;
-  std::vector<int8_t> entry_prefactor;
-  std::vector<int8_t> entry_component;
+  // Position order of the re-laid-out table: reference column (-1 = padding),
+  // prefactor and bin pair (library order).
+  std::vector<int64_t> column;
+  std::vector<int8_t> prefactor;
+  std::vector<int32_t> pos_i, pos_j;
+  std::vector<int64_t> comp_begin;  // first position of each component (+ end)
+  std::vector<int64_t> comp_real;   // real entries of each component
 };
 
 struct Chunking {
   int waves_per_group = 0;
-  std::vector<Segment> segments;
   std::vector<Chunk> chunks;
   std::vector<Group> groups;
   int max_rows = 0;              // max over groups of row_hi - row_lo
 };
 
-// Bin permutation (stable sort, centrals first) and entry order.
-void build_plan(int mode, int n_bins, const uint8_t* is_central, Plan& plan);
+// Entries per aligned block for an r tile of width rt: EB * rt % 16 == 0.
+int block_entries(int rt);
 
-// Cut the entries into about n_chunks wave-sized chunks that never mix
-// components, and pack them waves_per_group at a time into workgroups.
+// Bin permutation (stable sort, centrals first) and position order.
+void build_plan(int mode, int n_bins, const uint8_t* is_central, int block,
+                Plan& plan);
+
+// Cut the positions into about n_chunks wave-sized chunks (multiples of the
+// block size, never mixing components) and pack them waves_per_group at a
+// time into workgroups.
 void build_chunking(const Plan& plan, int n_chunks, int waves_per_group,
                     Chunking& out);
+
+// The rule by which the kernel steps from one entry to the next inside a
+// component (shared by the kernel, the planner and the CPU tests).
+inline void advance_pair(int mode, int component, int n_central, int& i, int& j) {
+  if (mode != 0) {
+    ++j;
+    return;
+  }
+  const int j_hi = component == 1 ? n_central - 1 : i;
+  if (++j > j_hi) {
+    ++i;
+    j = component == 2 ? n_central : 0;
+  }
+}
 
 }  // namespace tc

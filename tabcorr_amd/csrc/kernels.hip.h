@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <utility>
 
 #include "hostmath.h"
 
@@ -40,7 +41,7 @@ struct OccArgs {
   const double* percentile;  // (n_bins)
   const int32_t* perm;     // library bin -> reference row
   double* nbuf;            // (n_bins, ldb) number density per bin and draw
-  double* ngal;            // (2, ldb) centrals / satellites number density
+  double* ngal;            // (bin splits, 2, ldb) partial cen / sat densities
   double* occupation;      // optional (n_draws, n_bins) in reference order
 };
 
@@ -61,9 +62,10 @@ __device__ inline double heaviside_assembias(double n, double strength,
 
 // Mean occupation of every bin for every draw: tabcorr/tabcorr.py:537-578 with
 // the two halotools callbacks of :556-563 evaluated inline (Zheng et al. 2007
-// eqs. 1 and 3).  Block = kOccWaves waves sharing one draw tile; wave w handles
-// bins w, w + kOccWaves, ...
-constexpr int kOccWaves = 8;
+// eqs. 1 and 3).  grid = (draw tiles, bin splits); the kOccWaves waves of a
+// block share one draw tile and interleave over the bins of their split.  The
+// block's centrals / satellites density sums go to ngal_part[split][2][ldb].
+constexpr int kOccWaves = 4;
 
 __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     OccArgs a) {
@@ -77,7 +79,6 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
   const double log_m_min = th[0];
   const double inv_sigma = 1.0 / th[1];
   const double m0 = exp10(th[2]);
-  const double inv_m1 = 1.0 / exp10(th[3]);
   const double m1 = exp10(th[3]);
   const double alpha = th[4];
   const bool assembias = (a.flags & kFlagAssembias) != 0;
@@ -85,7 +86,6 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
   const double a_cen = assembias ? th[5] : 0.0;
   const double a_sat = assembias ? th[6] : 0.0;
   const double f1 = 1.0 - a.split, f2 = a.split;
-  (void)inv_m1;
 
   sc_f64 log_m = (sc_f64)a.log_m;
   sc_f64 mass = (sc_f64)a.m;
@@ -95,7 +95,8 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
   sc_i32 perm = (sc_i32)a.perm;
 
   double sum_cen = 0.0, sum_sat = 0.0;
-  for (int g = wave; g < a.n_bins; g += kOccWaves) {
+  const int stride = kOccWaves * gridDim.y;
+  for (int g = blockIdx.y * kOccWaves + wave; g < a.n_bins; g += stride) {
     const bool central = g < a.n_central;
     const bool above = percentile[g] > a.split;
     double acc = 0.0;
@@ -126,7 +127,8 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     double total = 0.0;
 #pragma unroll
     for (int w = 0; w < kOccWaves; ++w) total += red[wave][w][lane];
-    a.ngal[(int64_t)wave * a.ldb + (int64_t)blockIdx.x * kLanes + lane] = total;
+    a.ngal[((int64_t)blockIdx.y * 2 + wave) * a.ldb +
+           (int64_t)blockIdx.x * kLanes + lane] = total;
   }
 }
 
@@ -152,27 +154,93 @@ __global__ __launch_bounds__(256) void occ_from_array_kernel(
 struct ContractArgs {
   const double* nbuf;       // (n_bins, ldb)
   int64_t ldb;
-  const void* table;        // (n_rtiles, n_entries, RT) re-laid-out matrix
-  int64_t n_entries;
-  const Segment* segments;
+  const void* table;        // (n_rtiles, n_positions, RT) re-laid-out matrix
+  int64_t n_positions;
   const Chunk* chunks;
   const Group* groups;
-  int n_components_out;     // 1 (total only) or the table's component count
+  int mode;
+  int n_central;
   int r_stride;             // n_rtiles * RT: padded number of r values
-  double* partial;          // (n_groups, n_components_out, r_stride, ldb)
+  int debug;                // developer ablations (TC_DEBUG_VARIANT), 0 in production
+  double* partial;          // (n_groups, r_stride, ldb)
 };
+
+// acc += t[lane N of my 16-lane row] * w.  The DP-only DPP control row_newbcast
+// lets the 16 table values held by the 16 lanes of a row feed 16 FMAs without
+// ever leaving the vector register file.
+template <int N>
+__device__ __forceinline__ void fmac_row_bcast(double& acc, double t, double w) {
+  asm volatile(
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc)
+      : "v"(t), "v"(w), "n"(N));
+}
+
+template <int RT>
+struct ContractGeometry {
+  static constexpr int gcd16 = (RT % 16 == 0) ? 16 : (RT % 8 == 0) ? 8
+                               : (RT % 4 == 0) ? 4 : (RT % 2 == 0) ? 2 : 1;
+  static constexpr int EB = 16 / gcd16;       // entries per block
+  static constexpr int NG = EB * RT / 16;     // 16-value register groups per block
+};
+
+template <int RT, int E, int... Rs>
+__device__ __forceinline__ void entry_fma(
+    double (&acc)[RT], const double (&t)[ContractGeometry<RT>::NG], double w,
+    std::integer_sequence<int, Rs...>) {
+  (fmac_row_bcast<((E * RT + Rs) & 15)>(acc[Rs], t[(E * RT + Rs) >> 4], w), ...);
+}
+
+// Per-wave walk state over the entries of one component.
+struct WalkState {
+  int i, j, remaining, row_lo, mode, component, n_central, debug;
+  double ni;
+};
+
+template <int RT, int E>
+__device__ __forceinline__ void block_entry(
+    double (&acc)[RT], const double (&t)[ContractGeometry<RT>::NG],
+    WalkState& st, const double* lds, int lane) {
+  const double nj = (st.debug & 2) ? 1.5 : lds[(st.j - st.row_lo) * kLanes + lane];
+  const double w = st.ni * nj;
+  entry_fma<RT, E>(acc, t, w, std::make_integer_sequence<int, RT>());
+  // step to the next real entry (padding keeps the last real pair)
+  if (!(st.debug & 32) && --st.remaining > 0) {
+    if (st.mode != 0) {
+      ++st.j;
+    } else {
+      const int j_hi = st.component == 1 ? st.n_central - 1 : st.i;
+      if (++st.j > j_hi) {
+        ++st.i;
+        st.j = st.component == 2 ? st.n_central : 0;
+        st.ni = lds[(st.i - st.row_lo) * kLanes + lane];
+      }
+    }
+  }
+}
+
+template <int RT, int... Es>
+__device__ __forceinline__ void block_compute(
+    double (&acc)[RT], const double (&t)[ContractGeometry<RT>::NG],
+    WalkState& st, const double* lds, int lane,
+    std::integer_sequence<int, Es...>) {
+  (block_entry<RT, Es>(acc, t, st, lds, lane), ...);
+}
 
 // Contraction of the re-laid-out table with the pair weights of 64 draws:
 // tabcorr.py:641-649 (total) and :652-683 (per component), without the final
 // division.  grid = (draw tiles, groups, r tiles); wave w of a block works on
 // chunk w of its group.  The per-draw densities of the rows the group touches
-// are staged once in LDS; per table entry a wave does one ds_read_b64 (n_j),
-// one v_mul_f64 (n_i n_j) and RT v_fma_f64 whose table operand is an SGPR pair
-// fetched with s_load_dwordx16.
-template <int RT, typename TableT>
+// are staged once in LDS.  Table values stream from L2 through the vector
+// memory path, 16 doubles per 128-byte line replicated over the 4 rows of the
+// wave; each of them feeds one v_fmac_f64_dpp row_newbcast.  Per table entry a
+// wave issues one ds_read_b64 (n_j), one v_mul_f64 (n_i n_j) and RT FMAs; the
+// loads of the next block are in flight while the current one is consumed.
+template <int RT>
 __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  typedef const __attribute__((address_space(4))) TableT* sc_table;
+  typedef ContractGeometry<RT> Geo;
+  constexpr int EB = Geo::EB, NG = Geo::NG;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_waves = blockDim.x >> 6;
@@ -180,68 +248,117 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
 
   const Group group = a.groups[blockIdx.y];
   const int n_rows = group.row_hi - group.row_lo;
-  for (int idx = threadIdx.x; idx < n_rows * kLanes; idx += blockDim.x) {
-    const int row = idx >> 6;
-    lds[idx] = a.nbuf[(int64_t)(group.row_lo + row) * a.ldb + col + (idx & 63)];
+  {
+    // stage rows [row_lo, row_hi) of this draw tile: 16 bytes per lane, four
+    // independent loads in flight per thread
+    typedef double __attribute__((ext_vector_type(2))) double2v;
+    const int n_items = n_rows * (kLanes / 2);
+    const double* src = a.nbuf + (int64_t)group.row_lo * a.ldb + col;
+    const int nthreads = blockDim.x;
+    int it = (a.debug & 8) ? n_items : threadIdx.x;
+    for (; it + 3 * nthreads < n_items; it += 4 * nthreads) {
+      double2v v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int id = it + u * nthreads;
+        v[u] = *(const double2v*)(src + (int64_t)(id >> 5) * a.ldb + (id & 31) * 2);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int id = it + u * nthreads;
+        *(double2v*)(lds + (id >> 5) * kLanes + (id & 31) * 2) = v[u];
+      }
+    }
+    for (; it < n_items; it += nthreads)
+      *(double2v*)(lds + (it >> 5) * kLanes + (it & 31) * 2) =
+          *(const double2v*)(src + (int64_t)(it >> 5) * a.ldb + (it & 31) * 2);
   }
   __syncthreads();
 
-  TableT acc[RT];
+  double acc[RT];
 #pragma unroll
-  for (int r = 0; r < RT; ++r) acc[r] = 0;
+  for (int r = 0; r < RT; ++r) acc[r] = 0.0;
 
   int component = 0;
   if (wave < group.n_chunks) {
     const Chunk chunk = a.chunks[group.chunk_begin + wave];
     component = chunk.component;
-    sc_table table = (sc_table)a.table + (int64_t)blockIdx.z * a.n_entries * RT;
-    for (int s = chunk.seg_begin; s < chunk.seg_end; ++s) {
-      const Segment seg = a.segments[s];
-      const double ni =
-          seg.i >= 0 ? lds[(seg.i - group.row_lo) * kLanes + lane] : 1.0;
-      sc_table row = table + (int64_t)seg.e0 * RT;
-      const double* nj = lds + (seg.j0 - group.row_lo) * kLanes + lane;
-      for (int t = 0; t < seg.len; ++t) {
-        const TableT w = (TableT)(ni * nj[t * kLanes]);
+    WalkState st;
+    st.i = chunk.i0;
+    st.j = chunk.j0;
+    st.remaining = chunk.n_real;
+    st.row_lo = group.row_lo;
+    st.mode = a.mode;
+    st.component = chunk.component;
+    st.n_central = a.n_central;
+    st.debug = a.debug;
+    st.ni = a.mode == 0 ? lds[(chunk.i0 - group.row_lo) * kLanes + lane] : 1.0;
+
+    const double* table = (const double*)a.table +
+                          ((int64_t)blockIdx.z * a.n_positions + chunk.q_begin) * RT +
+                          (lane & 15);
+    const int n_blocks = (a.debug & 4) ? 0 : (chunk.q_end - chunk.q_begin) / EB;
+    double ta[NG], tb[NG];
 #pragma unroll
-        for (int r = 0; r < RT; ++r)
-          acc[r] = __builtin_fma(row[t * RT + r], w, acc[r]);
+    for (int g = 0; g < NG; ++g) ta[g] = table[g * 16];
+    int blk = 0;
+    // two blocks per iteration so that the two register sets swap roles
+    // without moves
+    for (; blk + 2 <= n_blocks; blk += 2) {
+      if (!(a.debug & 1)) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) tb[g] = table[(int64_t)(blk + 1) * EB * RT + g * 16];
+      } else {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) tb[g] = ta[g];
       }
+      block_compute<RT>(acc, ta, st, lds, lane, std::make_integer_sequence<int, EB>());
+      if (blk + 2 < n_blocks && !(a.debug & 1)) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ta[g] = table[(int64_t)(blk + 2) * EB * RT + g * 16];
+      }
+      block_compute<RT>(acc, tb, st, lds, lane, std::make_integer_sequence<int, EB>());
     }
+    if (blk < n_blocks)
+      block_compute<RT>(acc, ta, st, lds, lane, std::make_integer_sequence<int, EB>());
   }
   __syncthreads();  // the staged densities are dead; reuse LDS for the sums
 
-  // Deterministic in-block reduction: waves add their accumulators in wave
-  // order into red[component][r][lane].
-  const int n_comp = a.n_components_out;
-  double* red = lds;
-  for (int idx = threadIdx.x; idx < n_comp * RT * kLanes; idx += blockDim.x)
-    red[idx] = 0.0;
-  __syncthreads();
-  const int slot = n_comp == 1 ? 0 : component;
-  for (int w = 0; w < n_waves; ++w) {
-    if (w == wave && wave < group.n_chunks) {
+  // Deterministic tree reduction over the waves of the block (all of one
+  // component): the upper half parks its accumulators in LDS, the lower half
+  // adds them in registers.
+  int span = 1;
+  while (span < n_waves) span <<= 1;
+  for (int half = (a.debug & 16) ? 0 : span >> 1; half >= 1; half >>= 1) {
+    if (wave >= half && wave < 2 * half) {
+      double* slot = lds + (wave - half) * RT * kLanes + lane;
 #pragma unroll
-      for (int r = 0; r < RT; ++r)
-        red[(slot * RT + r) * kLanes + lane] += (double)acc[r];
+      for (int r = 0; r < RT; ++r) slot[r * kLanes] = acc[r];
+    }
+    __syncthreads();
+    if (wave < half && wave + half < n_waves) {
+      const double* slot = lds + wave * RT * kLanes + lane;
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r] += slot[r * kLanes];
     }
     __syncthreads();
   }
-  double* out = a.partial +
-                ((int64_t)blockIdx.y * n_comp * a.r_stride +
-                 (int64_t)blockIdx.z * RT) * a.ldb + col;
-  for (int idx = threadIdx.x; idx < n_comp * RT * kLanes; idx += blockDim.x) {
-    const int c = idx / (RT * kLanes);
-    const int r = (idx >> 6) % RT;
-    out[((int64_t)c * a.r_stride + r) * a.ldb + (idx & 63)] = red[idx];
+  if (wave == 0) {
+    double* out = a.partial +
+                  ((int64_t)blockIdx.y * a.r_stride + (int64_t)blockIdx.z * RT) *
+                      a.ldb + col + lane;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) out[(int64_t)r * a.ldb] = acc[r];
   }
 }
 
 struct FinalizeArgs {
-  const double* partial;   // (n_groups, n_comp, r_stride, ldb)
-  const double* ngal_in;   // (2, ldb)
+  const double* partial;   // (n_groups, r_stride, ldb)
+  const Group* groups;     // component of each group
+  const double* ngal_part; // (n_ngal_parts, 2, ldb)
+  int n_ngal_parts;
   int n_groups;
-  int n_comp;
+  int n_comp;              // 1: sum all components; else per component
   int r_stride;
   int n_r;
   int mode;
@@ -251,28 +368,61 @@ struct FinalizeArgs {
   double* xi;              // (n_draws, n_comp, n_r)
 };
 
+constexpr int kFinalizeRows = 64;   // (component, r) rows per LDS pass
+
 // Sum the per-group partials in fixed order, divide by the total pair weight
 // (tabcorr.py:646-649, 653-655: sum(ngal_sq) = (sum ngal)^2 in mode auto) and
-// write the results in the reference's output order.
+// write the results in the reference's output order.  One block per draw tile;
+// reads are coalesced over draws, the transposition to the draw-major output
+// goes through LDS.
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.n_draws) return;
-  const double n_cen = a.ngal_in[b], n_sat = a.ngal_in[a.ldb + b];
-  const double total = n_cen + n_sat;
-  const double norm = a.mode == 0 ? total * total : total;
-  if (a.n_comp == 1) {
-    a.ngal[b] = total;
-  } else {
-    a.ngal[2 * b] = n_cen;
-    a.ngal[2 * b + 1] = n_sat;
-  }
-  for (int c = 0; c < a.n_comp; ++c) {
-    for (int r = 0; r < a.n_r; ++r) {
-      double sum = 0.0;
-      for (int g = 0; g < a.n_groups; ++g)
-        sum += a.partial[(((int64_t)g * a.n_comp + c) * a.r_stride + r) * a.ldb + b];
-      a.xi[((int64_t)b * a.n_comp + c) * a.n_r + r] = sum / norm;
+  __shared__ double tile[kFinalizeRows][kLanes + 1];
+  __shared__ double norm_inv[kLanes];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t col = (int64_t)blockIdx.x * kLanes;
+  const int64_t n_valid = a.n_draws - col < kLanes ? a.n_draws - col : kLanes;
+
+  if (wave == 0) {
+    double n_cen = 0.0, n_sat = 0.0;
+    for (int p = 0; p < a.n_ngal_parts; ++p) {
+      n_cen += a.ngal_part[((int64_t)p * 2 + 0) * a.ldb + col + lane];
+      n_sat += a.ngal_part[((int64_t)p * 2 + 1) * a.ldb + col + lane];
     }
+    const double total = n_cen + n_sat;
+    norm_inv[lane] = a.mode == 0 ? total * total : total;
+    if (lane < n_valid) {
+      if (a.n_comp == 1) {
+        a.ngal[col + lane] = total;
+      } else {
+        a.ngal[2 * (col + lane)] = n_cen;
+        a.ngal[2 * (col + lane) + 1] = n_sat;
+      }
+    }
+  }
+  __syncthreads();
+  const double norm = norm_inv[lane];
+
+  const int n_rows = a.n_comp * a.n_r;
+  for (int row0 = 0; row0 < n_rows; row0 += kFinalizeRows) {
+    const int rows = n_rows - row0 < kFinalizeRows ? n_rows - row0 : kFinalizeRows;
+    for (int rr = wave; rr < rows; rr += 4) {
+      const int c = (row0 + rr) / a.n_r, r = (row0 + rr) % a.n_r;
+      double sum = 0.0;
+      for (int g = 0; g < a.n_groups; ++g) {
+        if (a.n_comp == 1 || a.groups[g].component == c)
+          sum += a.partial[((int64_t)g * a.r_stride + r) * a.ldb + col + lane];
+      }
+      tile[rr][lane] = sum / norm;
+    }
+    __syncthreads();
+    // out[(col + d) * n_rows + row0 + rr]
+    for (int idx = threadIdx.x; idx < rows * kLanes; idx += blockDim.x) {
+      const int d = idx / rows, rr = idx % rows;
+      if (d < n_valid)
+        a.xi[(col + d) * (int64_t)n_rows + row0 + rr] = tile[rr][d];
+    }
+    __syncthreads();
   }
 }
 

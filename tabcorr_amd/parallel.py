@@ -1,0 +1,232 @@
+"""Sharding of parameter draws over the GPUs of one node.
+
+The draws of an MCMC ensemble are independent, so the path shards without any
+data-path collective: every rank holds a full replica
+of the table (at most ~120 MB), evaluates the draws ``rank, rank + world,
+rank + 2 world, ...`` (round-robin) and the per-rank results are collected on
+the root by ONE gather.  One process per GPU, launched by ``torchrun`` /
+``python -m torch.distributed.run``.
+
+Control plane (rendezvous, barrier, scalar reductions, exchange of the RCCL
+unique id): ``torch.distributed`` with the ``gloo`` backend on CPU tensors --
+PyTorch never touches the GPU here.  Data plane: ``ncclGather`` of RCCL over
+xGMI through the C ABI (``tc_comm_*``), on device buffers owned by this
+library.  When RCCL is unavailable (e.g. the CPU-only tests) the gather falls
+back to gloo on host arrays; the result is identical.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+
+
+def round_robin_indices(n_draws, rank, world_size):
+    """Indices of the draws rank ``rank`` evaluates."""
+    return np.arange(rank, n_draws, world_size)
+
+
+def shard_size(n_draws, world_size):
+    """Per-rank buffer length (the same on every rank; short shards are padded
+    by repeating their last draw so that the collective is regular)."""
+    return (n_draws + world_size - 1) // world_size
+
+
+def local_shard(theta, rank, world_size):
+    """Rows of ``theta`` for this rank, padded to `shard_size` rows."""
+    theta = np.asarray(theta)
+    index = round_robin_indices(len(theta), rank, world_size)
+    size = shard_size(len(theta), world_size)
+    if len(index) == 0:
+        # more ranks than draws: evaluate draw 0 and discard it on assembly
+        index = np.zeros(1, dtype=int)
+    index = np.concatenate([index, np.repeat(index[-1:], size - len(index))])
+    return np.ascontiguousarray(theta[index])
+
+
+def assemble(parts, n_draws):
+    """Undo the round-robin split: ``parts[rank][k]`` is draw
+    ``rank + k * world``.  ``parts`` is rank-major, each of `shard_size` rows.
+    """
+    world_size = len(parts)
+    first = np.asarray(parts[0])
+    out = np.empty((n_draws, ) + first.shape[1:], dtype=first.dtype)
+    for rank, part in enumerate(parts):
+        index = round_robin_indices(n_draws, rank, world_size)
+        out[index] = np.asarray(part)[:len(index)]
+    return out
+
+
+class Communicator:
+    """Process group of one-rank-per-GPU workers."""
+
+    def __init__(self, rank=0, world_size=1, local_rank=0, use_rccl=True):
+        self.rank = rank
+        self.world_size = world_size
+        self.local_rank = local_rank
+        self.dist = None
+        self.comm = None          # tc_comm handle (RCCL) or None
+        self.rccl_error = None
+        if world_size > 1:
+            # The HIP library must be in the process before torch so that it
+            # keeps the system ROCm runtime (see _lib.load).
+            try:
+                _lib.load()
+            except _lib.TabCorrHipError:
+                pass
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+                dist.init_process_group('gloo', rank=rank,
+                                        world_size=world_size)
+            self.dist = dist
+            if use_rccl:
+                self._init_rccl()
+
+    @classmethod
+    def from_env(cls, use_rccl=True):
+        return cls(int(os.environ.get('RANK', '0')),
+                   int(os.environ.get('WORLD_SIZE', '1')),
+                   int(os.environ.get('LOCAL_RANK', '0')), use_rccl)
+
+    @property
+    def is_root(self):
+        return self.rank == 0
+
+    @property
+    def gather_backend(self):
+        if self.world_size == 1:
+            return 'none'
+        return 'rccl' if self.comm is not None else 'gloo'
+
+    def _init_rccl(self):
+        import torch
+        try:
+            lib = _lib.load()
+            if _lib.device_count() < 1:
+                raise _lib.TabCorrHipError('no HIP device')
+            _lib.check(lib.tc_set_device(self.local_rank))
+            unique = torch.zeros(_lib.UNIQUE_ID_BYTES, dtype=torch.uint8)
+            ok = torch.ones(1, dtype=torch.int32)
+            if self.rank == 0:
+                buffer = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+                if lib.tc_comm_unique_id(buffer) == _lib.TC_OK:
+                    unique = torch.frombuffer(
+                        bytearray(buffer.raw), dtype=torch.uint8).clone()
+                else:
+                    ok[0] = 0
+            self.dist.broadcast(ok, 0)
+            if ok.item() == 0:
+                raise _lib.TabCorrHipError('ncclGetUniqueId failed on rank 0')
+            self.dist.broadcast(unique, 0)
+            handle = ctypes.c_void_p()
+            raw = bytes(unique.numpy().tobytes())
+            status = lib.tc_comm_create(raw, self.world_size, self.rank,
+                                        ctypes.byref(handle))
+            good = torch.tensor([1 if status == _lib.TC_OK else 0],
+                                dtype=torch.int32)
+            self.dist.all_reduce(good, op=self.dist.ReduceOp.MIN)
+            if good.item() == 0:
+                if status == _lib.TC_OK:
+                    lib.tc_comm_destroy(handle)
+                raise _lib.TabCorrHipError(
+                    'ncclCommInitRank failed on some rank: ' +
+                    lib.tc_last_error().decode(errors='replace'))
+            self.comm = handle
+        except (_lib.TabCorrHipError, OSError) as error:
+            self.comm = None
+            self.rccl_error = str(error)
+
+    # -- control plane -----------------------------------------------------
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max(self, value):
+        if self.dist is None:
+            return float(value)
+        import torch
+        tensor = torch.tensor([float(value)], dtype=torch.float64)
+        self.dist.all_reduce(tensor, op=self.dist.ReduceOp.MAX)
+        return tensor.item()
+
+    def sum(self, value):
+        if self.dist is None:
+            return float(value)
+        import torch
+        tensor = torch.tensor([float(value)], dtype=torch.float64)
+        self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM)
+        return tensor.item()
+
+    # -- data plane -----------------------------------------------------------
+
+    def gather_host(self, array):
+        """Gather equal-shaped host arrays on the root (list, rank-major);
+        ``None`` elsewhere.  gloo; used when RCCL is not available."""
+        array = np.ascontiguousarray(array)
+        if self.dist is None:
+            return [array]
+        import torch
+        tensor = torch.from_numpy(array)
+        if self.is_root:
+            parts = [torch.empty_like(tensor) for _ in range(self.world_size)]
+            self.dist.gather(tensor, parts, dst=0)
+            return [part.numpy() for part in parts]
+        self.dist.gather(tensor, None, dst=0)
+        return None
+
+    def gather_device(self, table_handle, send_ptr, recv_ptr, count, slot=0):
+        """ncclGather of ``count`` doubles per rank from ``send_ptr`` into
+        ``recv_ptr`` (root), queued behind the work on the table's stream."""
+        _lib.check(_lib.load().tc_comm_gather(
+            self.comm, table_handle, send_ptr, recv_ptr, count, 0, slot))
+
+    def release(self, table_handle, slot=0):
+        """Device-side wait of the table's stream for the gather of ``slot``.
+        """
+        _lib.check(_lib.load().tc_comm_release(self.comm, table_handle, slot))
+
+    def synchronize(self):
+        if self.comm is not None:
+            _lib.check(_lib.load().tc_comm_synchronize(self.comm))
+
+    def close(self):
+        if self.comm is not None:
+            _lib.load().tc_comm_destroy(self.comm)
+            self.comm = None
+
+
+def predict_batch_sharded(halotab, theta, communicator, **kwargs):
+    """``TabCorr.predict_batch`` with the draws sharded round-robin over the
+    ranks of ``communicator``.  Every rank passes the same ``theta``; the root
+    returns the assembled ``(ngal, xi)`` (or dicts), other ranks ``None``.
+    """
+    theta = np.atleast_2d(np.asarray(theta, dtype=np.float64))
+    n_draws = len(theta)
+    shard = local_shard(theta, communicator.rank, communicator.world_size)
+    ngal, xi = halotab.predict_batch(shard, **kwargs)
+    if isinstance(ngal, dict):
+        keys_n, keys_x = list(ngal.keys()), list(xi.keys())
+        packed = np.concatenate(
+            [np.stack([ngal[k] for k in keys_n], axis=1)] +
+            [xi[k].reshape(len(shard), -1) for k in keys_x], axis=1)
+    else:
+        packed = np.concatenate([ngal[:, np.newaxis],
+                                 xi.reshape(len(shard), -1)], axis=1)
+    parts = communicator.gather_host(packed)
+    if parts is None:
+        return None
+    full = assemble(parts, n_draws)
+    shape = (n_draws, ) + tuple(halotab.tpcf_shape)
+    if isinstance(ngal, dict):
+        n_r = int(np.prod(halotab.tpcf_shape))
+        ngal_out = {k: full[:, i] for i, k in enumerate(keys_n)}
+        xi_out = {}
+        for i, k in enumerate(keys_x):
+            lo = len(keys_n) + i * n_r
+            xi_out[k] = full[:, lo:lo + n_r].reshape(shape)
+        return ngal_out, xi_out
+    return full[:, 0], full[:, 1:].reshape(shape)
