@@ -1,0 +1,281 @@
+"""CPU-only tests: the C ABI library loads and exports every declared symbol,
+host-side mathematics of the library (quadrature nodes, packed index map,
+spline matrices, work planning), the host classes' argument handling, and the
+multi-process sharding over gloo (world size 2)."""
+
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from util import REPO, load_golden, table_from_golden
+
+sys.path.insert(0, REPO)
+
+
+def declared_symbols():
+    header = open(os.path.join(REPO, 'include', 'tabcorr_amd.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    return sorted(set(re.findall(r'\b(tc_[a-z0-9_]+)\s*\(', header)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from tabcorr_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from tabcorr_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 35
+    for name in names:
+        assert hasattr(lib, name), name
+    # and the ctypes table covers them all
+    assert set(names) == set(_lib.SIGNATURES) | {'tc_last_error'}
+
+
+def test_library_is_bound_to_system_rocm_even_next_to_torch(lib):
+    from tabcorr_amd import _lib
+    before = _lib.runtime_version()
+    import torch  # noqa: F401  (bundles its own libamdhip64)
+    assert _lib.runtime_version() == before
+    assert before >= 70200000          # ROCm 7.2 runtime, not torch's 7.0
+
+
+def test_no_gpu_fails_loudly(lib):
+    from tabcorr_amd import TabCorr, _lib
+    if _lib.device_count() > 0:
+        pytest.skip('a GPU is present')
+    data = load_golden('synthetic_small_auto')
+    table = table_from_golden(data)
+    halotab = TabCorr.from_arrays(table['gal_type'], table['tpcf_matrix'],
+                                  table['tpcf_shape'], table['attrs'])
+    with pytest.raises(_lib.TabCorrHipError):
+        halotab.predict_batch(data['theta'])
+
+
+def test_gauss_legendre(lib):
+    from tabcorr_amd import _lib
+    for n in [1, 2, 3, 7, 10, 33, 100]:
+        x = np.zeros(n)
+        w = np.zeros(n)
+        assert lib.tc_gauss_legendre(n, _lib.as_double_p(x),
+                                     _lib.as_double_p(w)) == 0
+        x_ref, w_ref = np.polynomial.legendre.leggauss(n)
+        np.testing.assert_allclose(x, (x_ref + 1) / 2, rtol=0, atol=3e-16)
+        np.testing.assert_allclose(w, w_ref, rtol=0, atol=2e-14)
+
+
+def test_pair_indices_match_reference_layout(lib):
+    from tabcorr_amd import _lib
+    golden = load_golden('helpers')
+    for n in range(1, 8):
+        p = n * (n + 1) // 2
+        i1 = np.zeros(p, np.int32)
+        i2 = np.zeros(p, np.int32)
+        pre = np.zeros(p, np.int32)
+        assert lib.tc_pair_indices(
+            n, i1.ctypes.data_as(_lib.c_int32_p),
+            i2.ctypes.data_as(_lib.c_int32_p),
+            pre.ctypes.data_as(_lib.c_int32_p)) == 0
+        assert np.array_equal(i1 * n + i2, golden['sym_index_%d' % n])
+        assert np.array_equal(pre, np.where(i1 == i2, 1, 2))
+
+
+def test_symmetric_matrix_to_array():
+    from tabcorr_amd import symmetric_matrix_to_array
+    golden = load_golden('helpers')
+    for n in range(1, 8):
+        index = np.arange(n * n).reshape(n, n)
+        assert np.array_equal(
+            symmetric_matrix_to_array(index, check_symmetry=False),
+            golden['sym_index_%d' % n])
+    with pytest.raises(ValueError):
+        symmetric_matrix_to_array(np.arange(9).reshape(3, 3))
+
+
+def test_spline_matrix(lib):
+    from tabcorr_amd import _lib
+    golden = load_golden('helpers')
+    for n in [4, 5, 7, 12]:
+        xp = np.ascontiguousarray(golden['spline_xp_%d' % n])
+        a = np.zeros((n - 1, 4, n))
+        assert lib.tc_spline_interpolation_matrix(
+            n, _lib.as_double_p(xp), _lib.as_double_p(a)) == 0
+        # monomial coefficients are ill-conditioned; compare spline VALUES
+        yp = golden['spline_yp_%d' % n]
+        for x, y in zip(golden['spline_x_%d' % n], golden['spline_y_%d' % n]):
+            seg = min(max(np.digitize(x, xp) - 1, 0), n - 2)
+            value = np.einsum('ij,j...,i', a[seg], yp, x**np.arange(4))
+            np.testing.assert_allclose(value, y, rtol=1e-9, atol=1e-11)
+    xp = np.arange(3.0)
+    a = np.zeros((2, 4, 3))
+    assert lib.tc_spline_interpolation_matrix(
+        3, _lib.as_double_p(xp), _lib.as_double_p(a)) == _lib.TC_ERR_INVALID
+    assert b'less than 4' in lib.tc_last_error()
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+def test_plan_covers_every_column_once(lib, mode):
+    from tabcorr_amd import _lib
+    rng = np.random.default_rng(mode)
+    cases = [(1, 'half'), (2, 'half'), (7, 'half'), (12, 'half'), (9, 'rand'),
+             (5, 'allcen'), (6, 'allsat'), (100, 'half'), (61, 'rand')]
+    for n_bins, pattern in cases:
+        if pattern == 'half':
+            central = np.arange(n_bins) < n_bins // 2
+        elif pattern == 'rand':
+            central = rng.integers(0, 2, n_bins).astype(bool)
+        else:
+            central = np.full(n_bins, pattern == 'allcen')
+        central = central.astype(np.uint8)
+        n_pairs = n_bins * (n_bins + 1) // 2 if mode == 0 else n_bins
+        for n_chunks in [1, 3, 8, 32, 1000]:
+            n = ctypes.c_int64()
+            pair = np.zeros(n_pairs, np.int32)
+            chunk = np.zeros(n_pairs, np.int32)
+            comp = np.zeros(n_pairs, np.int32)
+            status = lib.tc_plan_debug(
+                mode, n_bins, central.ctypes.data_as(_lib.c_uint8_p), n_chunks,
+                ctypes.byref(n), pair.ctypes.data_as(_lib.c_int32_p),
+                chunk.ctypes.data_as(_lib.c_int32_p),
+                comp.ctypes.data_as(_lib.c_int32_p))
+            assert status == 0, lib.tc_last_error()
+            assert n.value == n_pairs
+            assert sorted(pair.tolist()) == list(range(n_pairs))
+            # component of every column: number of satellite members
+            if mode == 0:
+                rows, cols = np.tril_indices(n_bins)
+                expect = (1 - central[rows]) + (1 - central[cols])
+            else:
+                expect = 1 - central
+            assert np.array_equal(comp[np.argsort(pair)], expect)
+            # chunks are contiguous runs in processing order
+            assert np.all(np.diff(chunk) >= 0)
+
+
+def test_host_class_argument_errors():
+    from tabcorr_amd import TabCorr, Zheng07Model, GalTypeTable
+    data = load_golden('synthetic_small_auto')
+    table = table_from_golden(data)
+    halotab = TabCorr.from_arrays(table['gal_type'], table['tpcf_matrix'],
+                                  table['tpcf_shape'], table['attrs'])
+    assert isinstance(halotab.gal_type, GalTypeTable)
+    assert halotab.gal_type['gal_type'][0] == 'centrals'
+    assert len(halotab.gal_type) == 14
+    # consistency checks run before anything touches the device
+    with pytest.raises(ValueError, match='redshift'):
+        halotab.predict(Zheng07Model(redshift=1.0))
+    with pytest.raises(ValueError, match='primary halo'):
+        halotab.predict(Zheng07Model(prim_haloprop_key='halo_m200b'))
+    with pytest.raises(ValueError, match='secondary halo'):
+        halotab.predict(Zheng07Model(sec_haloprop_key='halo_spin'))
+    model = Zheng07Model()
+    model.gal_types = ['centrals', 'satellites', 'orphans']
+    with pytest.raises(ValueError, match='galaxy types'):
+        halotab.predict(model)
+    with pytest.raises(NotImplementedError):
+        TabCorr.tabulate(None, None)
+
+
+def test_npz_round_trip(tmp_path):
+    from tabcorr_amd import TabCorr
+    data = load_golden('synthetic_small_cross')
+    table = table_from_golden(data)
+    halotab = TabCorr.from_arrays(table['gal_type'], table['tpcf_matrix'],
+                                  table['tpcf_shape'], table['attrs'],
+                                  tpcf_args=(np.arange(3.0), ),
+                                  tpcf_kwargs={'pi_max': 40})
+    fname = str(tmp_path / 'table.npz')
+    halotab.write(fname)
+    with pytest.raises(OSError):
+        halotab.write(fname)
+    halotab.write(fname, overwrite=True)
+    back = TabCorr.read(fname)
+    assert back.attrs == halotab.attrs
+    assert back.tpcf_shape == halotab.tpcf_shape
+    assert np.array_equal(back.tpcf_matrix, halotab.tpcf_matrix)
+    assert back.gal_type.colnames == halotab.gal_type.colnames
+    for name in back.gal_type.colnames:
+        assert np.array_equal(back.gal_type[name], halotab.gal_type[name])
+    assert np.array_equal(back.tpcf_args[0], np.arange(3.0))
+    assert back.tpcf_kwargs['pi_max'] == 40
+
+
+def test_round_robin_assembly():
+    from tabcorr_amd import parallel
+    rng = np.random.default_rng(0)
+    for n_draws in [1, 5, 16, 17]:
+        for world in [1, 2, 3, 8]:
+            theta = rng.normal(size=(n_draws, 5))
+            parts = [parallel.local_shard(theta, r, world)
+                     for r in range(world)]
+            assert all(len(p) == parallel.shard_size(n_draws, world)
+                       for p in parts)
+            assert np.array_equal(parallel.assemble(parts, n_draws), theta)
+
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(repo)r)
+sys.path.insert(0, os.path.join(%(repo)r, 'tests'))
+from util import load_golden, table_from_golden
+from oracle import tabcorr_oracle as oracle
+from tabcorr_amd import parallel
+
+class OracleTab:
+    """Stands in for the device on a CPU-only box: the test is about the
+    sharding, the gather and the reassembly, not about the kernel."""
+    def __init__(self, table):
+        self.table = table
+        self.tpcf_shape = table['tpcf_shape']
+    def predict_batch(self, theta, **kwargs):
+        return oracle.predict_zheng07_batch(self.table, theta, **kwargs)
+
+comm = parallel.Communicator.from_env(use_rccl=False)
+assert comm.world_size == 2 and comm.gather_backend == 'gloo'
+data = load_golden('synthetic_rp_pi')
+table = table_from_golden(data)
+theta = data['theta'][:15]          # odd: the last rank gets a padded shard
+for separate in [False, True]:
+    out = parallel.predict_batch_sharded(OracleTab(table), theta, comm,
+                                         separate_gal_type=separate)
+    if comm.is_root:
+        expect = oracle.predict_zheng07_batch(table, theta,
+                                              separate_gal_type=separate)
+        if separate:
+            for key in expect[1]:
+                assert out[1][key].shape == (15, 5, 8)
+                assert np.array_equal(out[1][key], expect[1][key]), key
+            for key in expect[0]:
+                assert np.array_equal(out[0][key], expect[0][key])
+        else:
+            assert np.array_equal(out[0], expect[0])
+            assert np.array_equal(out[1], expect[1])
+    else:
+        assert out is None
+assert comm.max(comm.rank + 1.0) == 2.0
+assert comm.sum(1.0) == 2.0
+comm.barrier()
+print('rank', comm.rank, 'ok')
+'''
+
+
+def test_sharded_predict_world_size_2_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % {'repo': REPO})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    result = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+         '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+         '--master-port', '29517', str(script)],
+        env=env, capture_output=True, text=True, timeout=600)
+    assert result.returncode == 0, result.stdout + result.stderr
+    assert result.stdout.count('ok') == 2
