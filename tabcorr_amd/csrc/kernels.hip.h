@@ -162,7 +162,15 @@ struct ContractArgs {
   int n_central;
   int r_stride;             // n_rtiles * RT: padded number of r values
   int debug;                // developer ablations (TC_DEBUG_VARIANT), 0 in production
-  double* partial;          // (n_groups, r_stride, ldb)
+  double* partial;          // (n_groups * k_splits, r_stride, ldb)
+  // Interpolator: the block loops over tables [k_begin, k_end) of its k split and
+  // accumulates coef[k][draw] * (table k contraction) into the same registers.
+  int n_tables;             // 0: single table (fields below unused)
+  int k_splits;             // blockIdx.y = group * k_splits + k split
+  const double* const* tables;   // (n_tables) re-laid-out matrices
+  const double* const* nbufs;    // (n_classes) density buffers
+  const int32_t* table_class;    // (n_tables) density class of each table
+  const double* coef;       // (n_tables, ldb) spline weight / pair-weight norm
 };
 
 // acc += t[lane N of my 16-lane row] * w.  The DP-only DPP control row_newbcast
@@ -194,7 +202,8 @@ __device__ __forceinline__ void entry_fma(
 // Per-wave walk state over the entries of one component.
 struct WalkState {
   int i, j, remaining, row_lo, mode, component, n_central, debug;
-  double ni;
+  double ni;      // density of row i times `scale`
+  double scale;   // per-draw weight of the current table (1 without interpolation)
 };
 
 template <int RT, int E>
@@ -213,7 +222,7 @@ __device__ __forceinline__ void block_entry(
       if (++st.j > j_hi) {
         ++st.i;
         st.j = st.component == 2 ? st.n_central : 0;
-        st.ni = lds[(st.i - st.row_lo) * kLanes + lane];
+        st.ni = lds[(st.i - st.row_lo) * kLanes + lane] * st.scale;
       }
     }
   }
@@ -246,81 +255,100 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
   const int n_waves = blockDim.x >> 6;
   const int64_t col = (int64_t)blockIdx.x * kLanes;
 
-  const Group group = a.groups[blockIdx.y];
+  const bool interp = a.n_tables > 0;
+  const int k_splits = interp ? a.k_splits : 1;
+  const Group group = a.groups[blockIdx.y / k_splits];
   const int n_rows = group.row_hi - group.row_lo;
-  {
-    // stage rows [row_lo, row_hi) of this draw tile: 16 bytes per lane, four
-    // independent loads in flight per thread
-    typedef double __attribute__((ext_vector_type(2))) double2v;
-    const int n_items = n_rows * (kLanes / 2);
-    const double* src = a.nbuf + (int64_t)group.row_lo * a.ldb + col;
-    const int nthreads = blockDim.x;
-    int it = (a.debug & 8) ? n_items : threadIdx.x;
-    for (; it + 3 * nthreads < n_items; it += 4 * nthreads) {
-      double2v v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int id = it + u * nthreads;
-        v[u] = *(const double2v*)(src + (int64_t)(id >> 5) * a.ldb + (id & 31) * 2);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int id = it + u * nthreads;
-        *(double2v*)(lds + (id >> 5) * kLanes + (id & 31) * 2) = v[u];
-      }
-    }
-    for (; it < n_items; it += nthreads)
-      *(double2v*)(lds + (it >> 5) * kLanes + (it & 31) * 2) =
-          *(const double2v*)(src + (int64_t)(it >> 5) * a.ldb + (it & 31) * 2);
+  int k_begin = 0, k_end = 1;
+  if (interp) {
+    const int split = blockIdx.y % k_splits;
+    k_begin = (int)((int64_t)a.n_tables * split / k_splits);
+    k_end = (int)((int64_t)a.n_tables * (split + 1) / k_splits);
   }
-  __syncthreads();
 
   double acc[RT];
 #pragma unroll
   for (int r = 0; r < RT; ++r) acc[r] = 0.0;
 
-  int component = 0;
-  if (wave < group.n_chunks) {
-    const Chunk chunk = a.chunks[group.chunk_begin + wave];
-    component = chunk.component;
-    WalkState st;
-    st.i = chunk.i0;
-    st.j = chunk.j0;
-    st.remaining = chunk.n_real;
-    st.row_lo = group.row_lo;
-    st.mode = a.mode;
-    st.component = chunk.component;
-    st.n_central = a.n_central;
-    st.debug = a.debug;
-    st.ni = a.mode == 0 ? lds[(chunk.i0 - group.row_lo) * kLanes + lane] : 1.0;
-
-    const double* table = (const double*)a.table +
-                          ((int64_t)blockIdx.z * a.n_positions + chunk.q_begin) * RT +
-                          (lane & 15);
-    const int n_blocks = (a.debug & 4) ? 0 : (chunk.q_end - chunk.q_begin) / EB;
-    double ta[NG], tb[NG];
+  int staged_class = -1;
+  for (int k = k_begin; k < k_end; ++k) {
+    const int density_class = interp ? a.table_class[k] : 0;
+    if (density_class != staged_class) {
+      if (staged_class >= 0) __syncthreads();   // everyone is done with the old rows
+      // stage rows [row_lo, row_hi) of this draw tile: 16 bytes per lane, four
+      // independent loads in flight per thread
+      typedef double __attribute__((ext_vector_type(2))) double2v;
+      const int n_items = n_rows * (kLanes / 2);
+      const double* src = (interp ? a.nbufs[density_class] : a.nbuf) +
+                          (int64_t)group.row_lo * a.ldb + col;
+      const int nthreads = blockDim.x;
+      int it = (a.debug & 8) ? n_items : threadIdx.x;
+      for (; it + 3 * nthreads < n_items; it += 4 * nthreads) {
+        double2v v[4];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) ta[g] = table[g * 16];
-    int blk = 0;
-    // two blocks per iteration so that the two register sets swap roles
-    // without moves
-    for (; blk + 2 <= n_blocks; blk += 2) {
-      if (!(a.debug & 1)) {
+        for (int u = 0; u < 4; ++u) {
+          const int id = it + u * nthreads;
+          v[u] = *(const double2v*)(src + (int64_t)(id >> 5) * a.ldb + (id & 31) * 2);
+        }
 #pragma unroll
-        for (int g = 0; g < NG; ++g) tb[g] = table[(int64_t)(blk + 1) * EB * RT + g * 16];
-      } else {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) tb[g] = ta[g];
+        for (int u = 0; u < 4; ++u) {
+          const int id = it + u * nthreads;
+          *(double2v*)(lds + (id >> 5) * kLanes + (id & 31) * 2) = v[u];
+        }
       }
-      block_compute<RT>(acc, ta, st, lds, lane, std::make_integer_sequence<int, EB>());
-      if (blk + 2 < n_blocks && !(a.debug & 1)) {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) ta[g] = table[(int64_t)(blk + 2) * EB * RT + g * 16];
-      }
-      block_compute<RT>(acc, tb, st, lds, lane, std::make_integer_sequence<int, EB>());
+      for (; it < n_items; it += nthreads)
+        *(double2v*)(lds + (it >> 5) * kLanes + (it & 31) * 2) =
+            *(const double2v*)(src + (int64_t)(it >> 5) * a.ldb + (it & 31) * 2);
+      __syncthreads();
+      staged_class = density_class;
     }
-    if (blk < n_blocks)
-      block_compute<RT>(acc, ta, st, lds, lane, std::make_integer_sequence<int, EB>());
+
+    if (wave < group.n_chunks) {
+      const Chunk chunk = a.chunks[group.chunk_begin + wave];
+      WalkState st;
+      st.i = chunk.i0;
+      st.j = chunk.j0;
+      st.remaining = chunk.n_real;
+      st.row_lo = group.row_lo;
+      st.mode = a.mode;
+      st.component = chunk.component;
+      st.n_central = a.n_central;
+      st.debug = a.debug;
+      st.scale = interp ? a.coef[(int64_t)k * a.ldb + col + lane] : 1.0;
+      st.ni = a.mode == 0
+                  ? lds[(chunk.i0 - group.row_lo) * kLanes + lane] * st.scale
+                  : st.scale;
+
+      const double* table = (interp ? a.tables[k] : (const double*)a.table) +
+                            ((int64_t)blockIdx.z * a.n_positions + chunk.q_begin) * RT +
+                            (lane & 15);
+      const int n_blocks = (a.debug & 4) ? 0 : (chunk.q_end - chunk.q_begin) / EB;
+      double ta[NG], tb[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) ta[g] = table[g * 16];
+      int blk = 0;
+      // two blocks per iteration so that the two register sets swap roles
+      // without moves
+      for (; blk + 2 <= n_blocks; blk += 2) {
+        if (!(a.debug & 1)) {
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+            tb[g] = table[(int64_t)(blk + 1) * EB * RT + g * 16];
+        } else {
+#pragma unroll
+          for (int g = 0; g < NG; ++g) tb[g] = ta[g];
+        }
+        block_compute<RT>(acc, ta, st, lds, lane, std::make_integer_sequence<int, EB>());
+        if (blk + 2 < n_blocks && !(a.debug & 1)) {
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+            ta[g] = table[(int64_t)(blk + 2) * EB * RT + g * 16];
+        }
+        block_compute<RT>(acc, tb, st, lds, lane, std::make_integer_sequence<int, EB>());
+      }
+      if (blk < n_blocks)
+        block_compute<RT>(acc, ta, st, lds, lane, std::make_integer_sequence<int, EB>());
+    }
   }
   __syncthreads();  // the staged densities are dead; reuse LDS for the sums
 
@@ -355,9 +383,11 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
 struct FinalizeArgs {
   const double* partial;   // (n_groups, r_stride, ldb)
   const Group* groups;     // component of each group
-  const double* ngal_part; // (n_ngal_parts, 2, ldb)
+  const double* ngal_part; // (n_ngal_parts, 2, ldb); NULL: the partials are already
+                           // normalised and ngal has been written (interpolator)
   int n_ngal_parts;
-  int n_groups;
+  int n_groups;            // partial slabs = n_groups * k_splits
+  int k_splits;
   int n_comp;              // 1: sum all components; else per component
   int r_stride;
   int n_r;
@@ -383,7 +413,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
   const int64_t col = (int64_t)blockIdx.x * kLanes;
   const int64_t n_valid = a.n_draws - col < kLanes ? a.n_draws - col : kLanes;
 
-  if (wave == 0) {
+  if (wave == 0 && a.ngal_part == nullptr) norm_inv[lane] = 1.0;
+  if (wave == 0 && a.ngal_part != nullptr) {
     double n_cen = 0.0, n_sat = 0.0;
     for (int p = 0; p < a.n_ngal_parts; ++p) {
       n_cen += a.ngal_part[((int64_t)p * 2 + 0) * a.ldb + col + lane];
@@ -409,8 +440,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     for (int rr = wave; rr < rows; rr += 4) {
       const int c = (row0 + rr) / a.n_r, r = (row0 + rr) % a.n_r;
       double sum = 0.0;
-      for (int g = 0; g < a.n_groups; ++g) {
-        if (a.n_comp == 1 || a.groups[g].component == c)
+      for (int g = 0; g < a.n_groups * a.k_splits; ++g) {
+        if (a.n_comp == 1 || a.groups[g / a.k_splits].component == c)
           sum += a.partial[((int64_t)g * a.r_stride + r) * a.ldb + col + lane];
       }
       tile[rr][lane] = sum / norm;
@@ -423,6 +454,80 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
         a.xi[(col + d) * (int64_t)n_rows + row0 + rr] = tile[rr][d];
     }
     __syncthreads();
+  }
+}
+
+constexpr int kMaxInterpDim = 8;
+constexpr int kMaxInterpAxis = 32;
+
+struct InterpArgs {
+  int n_dim;
+  int n_tables;
+  int n_classes;
+  int mode;
+  int separate;             // write ngal as (n_draws, 2)
+  int n_axis[kMaxInterpDim];
+  int axis_offset[kMaxInterpDim];   // offset of xp_d in xp
+  int a_offset[kMaxInterpDim];      // offset of a_d in a
+  const double* xp;         // concatenated abscissae
+  const double* a;          // concatenated (n_d - 1, 4, n_d) spline matrices
+  const int32_t* table_node;     // (n_tables, n_dim) grid index of each table
+  const int32_t* table_class;    // (n_tables)
+  const double* x;          // (n_draws, n_dim)
+  const double* const* ngal_parts;  // per class: (n_parts, 2, ldb)
+  int n_ngal_parts;
+  int64_t ldb;
+  int64_t n_draws;
+  double* coef;             // (n_tables, ldb)
+  double* ngal;             // (n_draws) or (n_draws, 2)
+};
+
+// Per draw: the tensor-product spline weight of every table at the draw's extra
+// parameters (interpolator.py:275-331; segment search as np.digitize with the right
+// edge special-cased, out-of-range clamped to the outermost segment), divided by the
+// table's total pair weight so that the contraction can accumulate all tables into
+// one sum (interpolation is linear in the per-table xi); and the interpolated ngal.
+__global__ __launch_bounds__(64) void interp_coef_kernel(InterpArgs a) {
+  __shared__ double weight[kMaxInterpDim][kMaxInterpAxis][kLanes];
+  const int lane = threadIdx.x;
+  const int64_t b0 = (int64_t)blockIdx.x * kLanes + lane;
+  const int64_t b = b0 < a.n_draws ? b0 : a.n_draws - 1;
+  for (int d = 0; d < a.n_dim; ++d) {
+    const int n = a.n_axis[d];
+    const double* xp = a.xp + a.axis_offset[d];
+    const double x = a.x[b * a.n_dim + d];
+    int seg = -1;
+    for (int i = 0; i < n; ++i) seg += xp[i] <= x ? 1 : 0;   // np.digitize(x, xp) - 1
+    if (x == xp[n - 1]) seg = n - 2;
+    seg = seg < 0 ? 0 : (seg > n - 2 ? n - 2 : seg);
+    const double* m = a.a + a.a_offset[d] + (int64_t)seg * 4 * n;
+    const double x2 = x * x, x3 = x2 * x;
+    for (int j = 0; j < n; ++j)
+      weight[d][j][lane] = m[j] + m[n + j] * x + m[2 * n + j] * x2 + m[3 * n + j] * x3;
+  }
+  double n_cen = 0.0, n_sat = 0.0;
+  for (int k = 0; k < a.n_tables; ++k) {
+    double c = 1.0;
+    for (int d = 0; d < a.n_dim; ++d)
+      c *= weight[d][a.table_node[k * a.n_dim + d]][lane];
+    const double* parts = a.ngal_parts[a.table_class[k]];
+    double cen = 0.0, sat = 0.0;
+    for (int p = 0; p < a.n_ngal_parts; ++p) {
+      cen += parts[((int64_t)p * 2 + 0) * a.ldb + b0];
+      sat += parts[((int64_t)p * 2 + 1) * a.ldb + b0];
+    }
+    const double total = cen + sat;
+    a.coef[(int64_t)k * a.ldb + b0] = c / (a.mode == 0 ? total * total : total);
+    n_cen += c * cen;
+    n_sat += c * sat;
+  }
+  if (b0 < a.n_draws) {
+    if (a.separate) {
+      a.ngal[2 * b0] = n_cen;
+      a.ngal[2 * b0 + 1] = n_sat;
+    } else {
+      a.ngal[b0] = n_cen + n_sat;
+    }
   }
 }
 

@@ -1,0 +1,306 @@
+"""``Interpolator`` with the reference's class surface, on an MI355X.
+
+Mirrors ``tabcorr/interpolator.py`` of johannesulf/TabCorr v1.2.0: a list of
+``TabCorr`` instances tabulated on a regular grid of extra parameters (e.g.
+``log_eta``, ``alpha_s``, ``alpha_c``) is interpolated with a tensor-product
+not-a-knot cubic spline at ``model.param_dict[key]``.
+
+For Zheng07-family models everything runs in one pass on the device: the
+occupations once per class of identical halo tables, the spline weight of
+every table for every draw, and one contraction that accumulates all tables
+(the interpolation is linear in the per-table ``xi``; each table's weight is
+divided by that table's total pair weight beforehand because ``xi`` is a
+ratio).  ``predict_batch`` exposes the batched form; ``predict`` keeps the
+reference's scalar signature.
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .models import device_spec
+from .tabcorr import TabCorr, XI_KEYS, NGAL_KEYS, _flags, _unbatch
+
+OUT_OF_RANGE = ('The x-coordinates are outside of the interpolation ' +
+                'range and extrapolation is turned off.')
+
+
+def _columns(param_dict_table):
+    """Column names and values of a parameter table given as an astropy
+    Table, a dict of columns or a NumPy structured array."""
+    if hasattr(param_dict_table, 'colnames'):
+        names = list(param_dict_table.colnames)
+        return names, [np.asarray(param_dict_table[n], dtype=np.float64)
+                       for n in names]
+    if isinstance(param_dict_table, dict):
+        names = list(param_dict_table.keys())
+        return names, [np.asarray(param_dict_table[n], dtype=np.float64)
+                       for n in names]
+    array = np.asarray(param_dict_table)
+    if array.dtype.names is None:
+        raise TypeError('param_dict_table must have named columns.')
+    names = list(array.dtype.names)
+    return names, [np.asarray(array[n], dtype=np.float64) for n in names]
+
+
+class _DeviceInterpolator:
+
+    def __init__(self, interpolator):
+        lib = _lib.load()
+        devices = [t.to_device() for t in interpolator.tabcorr_list]
+        handles = (ctypes.c_void_p * len(devices))(
+            *[d.handle for d in devices])
+        points = _lib.contiguous(interpolator.points)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.tc_interp_create(
+            ctypes.cast(handles, _lib.c_void_pp), len(devices),
+            points.shape[1], _lib.as_double_p(points), ctypes.byref(handle)))
+        self.handle = handle
+        self.lib = lib
+        self.tables = devices          # keep the table handles alive
+
+    def __del__(self):
+        handle = getattr(self, 'handle', None)
+        if handle is not None and handle.value is not None:
+            try:
+                self.lib.tc_interp_destroy(handle)
+            except Exception:
+                pass
+            self.handle = None
+
+
+class Interpolator:
+    """Interpolation of multiple `TabCorr` instances."""
+
+    def __init__(self, tabcorr_list, param_dict_table):
+        """
+        Parameters
+        ----------
+        tabcorr_list : list of TabCorr
+        param_dict_table : table
+            Keys and values of the extra parameters of each instance, same
+            length and order as ``tabcorr_list``.
+
+        Raises
+        ------
+        ValueError
+            If ``param_dict_table`` does not describe a grid
+            (``tabcorr/interpolator.py:32-57``).
+        """
+        names, columns = _columns(param_dict_table)
+        names_columns = [(n, c) for n, c in zip(names, columns)
+                         if n != 'tabcorr_index']
+        self.keys = [n for n, c in names_columns]
+        if len(tabcorr_list) != len(names_columns[0][1]):
+            raise ValueError("The number of TabCorr instances does not match" +
+                             " the number of entries in 'param_dict_table'.")
+        self.tabcorr_list = list(tabcorr_list)
+        self.points = np.stack([c for n, c in names_columns], axis=-1)
+        self.xp = [np.sort(np.unique(c)) for n, c in names_columns]
+        for xp in self.xp:
+            if len(xp) < 4:
+                raise ValueError('Cannot perform spline interpolation with ' +
+                                 'less than 4 values.')
+        if (np.prod([len(xp) for xp in self.xp]) != len(self.points) or
+                len(np.unique(self.points, axis=0)) != len(self.points)):
+            raise ValueError(
+                "The 'param_dict_table' does not describe a grid.")
+        # Grid order (lexicographic in the keys), as the sorted table with its
+        # tabcorr_index column in the reference (interpolator.py:59-61).
+        self.order = np.lexsort(self.points.T[::-1])
+        self.param_dict_table = {
+            key: self.points[self.order, d] for d, key in enumerate(self.keys)}
+        self.param_dict_table['tabcorr_index'] = self.order.copy()
+        self._device = None
+        self._a = None
+
+    # -- I/O ------------------------------------------------------------------
+
+    @classmethod
+    def read(cls, fname):
+        """Read an interpolator written by the reference or by `write`
+        (``tabcorr/interpolator.py:72-96``)."""
+        from . import io
+        return io.read_interpolator(cls, fname)
+
+    def write(self, fname, overwrite=False, max_args_size=1000000,
+              matrix_dtype=np.float32):
+        """Write in the reference's layout (``tabcorr/interpolator.py:98-122``:
+        dataset ``param_dict_table`` plus one group ``tabcorr_{i}`` per
+        instance)."""
+        from . import io
+        io.write_interpolator(self, fname, overwrite=overwrite,
+                              max_args_size=max_args_size,
+                              matrix_dtype=matrix_dtype)
+
+    # -- device ----------------------------------------------------------------
+
+    def to_device(self):
+        if self._device is None:
+            self._device = _DeviceInterpolator(self)
+        return self._device
+
+    def _x_model(self, model):
+        x = np.empty(len(self.keys))
+        for i, key in enumerate(self.keys):
+            try:
+                x[i] = model.param_dict[key]
+            except KeyError:
+                raise ValueError(
+                    'The key {} is not present in the parameter '.format(key) +
+                    'dictionary of the model.')
+        return x
+
+    def _check_range(self, x, extrapolate):
+        if extrapolate:
+            return
+        x = np.atleast_2d(x)
+        for d, xp in enumerate(self.xp):
+            if np.any(x[:, d] < xp[0]) or np.any(x[:, d] > xp[-1]):
+                raise ValueError(OUT_OF_RANGE)
+
+    # -- predict -------------------------------------------------------------------
+
+    def predict(self, model, separate_gal_type=False, n_gauss_prim=10,
+                extrapolate=False, check_consistency=True, **occ_kwargs):
+        """Interpolate the predictions of the instances
+        (``tabcorr/interpolator.py:124-216``).
+
+        Raises
+        ------
+        ValueError
+            If a key is missing from ``model.param_dict`` or a value lies
+            outside the grid and ``extrapolate`` is False.
+        """
+        x = self._x_model(model)
+        if check_consistency:
+            for halotab in self.tabcorr_list:
+                halotab._check_consistency(model)
+        spec = None if occ_kwargs else device_spec(model)
+        if spec is None:
+            return self._predict_generic(model, x, separate_gal_type,
+                                         n_gauss_prim, extrapolate,
+                                         **occ_kwargs)
+        return _unbatch(*self.predict_batch(
+            spec.theta[np.newaxis], x[np.newaxis],
+            separate_gal_type=separate_gal_type, n_gauss_prim=n_gauss_prim,
+            extrapolate=extrapolate,
+            modulate_with_cenocc=spec.modulate_with_cenocc,
+            assembias=spec.assembias))
+
+    def predict_batch(self, theta, x, separate_gal_type=False,
+                      n_gauss_prim=10, extrapolate=False,
+                      modulate_with_cenocc=False, assembias=False):
+        """`predict` for ``(n_draws, 5 | 7)`` Zheng07 parameters ``theta`` and
+        ``(n_draws, n_dim)`` values ``x`` of the extra parameters (columns in
+        the order of ``self.keys``)."""
+        theta = _lib.contiguous(np.atleast_2d(theta))
+        x = _lib.contiguous(np.atleast_2d(x))
+        if x.shape != (len(theta), len(self.keys)):
+            raise ValueError('x must have shape (n_draws, {}).'.format(
+                len(self.keys)))
+        self._check_range(x, extrapolate)
+        device = self.to_device()
+        table = device.tables[0]
+        flags = _flags(separate_gal_type, modulate_with_cenocc, assembias)
+        n_draws = len(theta)
+        n_comp = table.n_components if separate_gal_type else 1
+        ngal = np.empty((n_draws, 2 if separate_gal_type else 1))
+        xi = np.empty((n_draws, n_comp, table.n_r))
+        _lib.check(device.lib.tc_interp_predict_zheng07_batch(
+            device.handle, _lib.as_double_p(theta), theta.shape[1],
+            _lib.as_double_p(x), n_draws, n_gauss_prim, flags,
+            _lib.as_double_p(ngal), _lib.as_double_p(xi)))
+        return self.tabcorr_list[0]._package(ngal, xi, separate_gal_type)
+
+    # -- generic models: host callbacks + device contraction per table -----------------
+
+    def _spline_matrices(self):
+        if self._a is None:
+            lib = _lib.load()
+            self._a = []
+            for xp in self.xp:
+                xp = _lib.contiguous(xp)
+                a = np.zeros((len(xp) - 1, 4, len(xp)))
+                _lib.check(lib.tc_spline_interpolation_matrix(
+                    len(xp), _lib.as_double_p(xp), _lib.as_double_p(a)))
+                self._a.append(a)
+        return self._a
+
+    def _predict_generic(self, model, x, separate_gal_type, n_gauss_prim,
+                         extrapolate, **occ_kwargs):
+        self._check_range(x, extrapolate)
+        # occupations once per distinct halo table (interpolator.py:63-70,
+        # 181-184)
+        cache = []
+        results = []
+        for k in self.order:
+            halotab = self.tabcorr_list[k]
+            raw = halotab.gal_type.as_array()
+            occupation = None
+            for other, value in cache:
+                if other.dtype == raw.dtype and np.array_equal(other, raw):
+                    occupation = value
+                    break
+            if occupation is None:
+                occupation = halotab._host_mean_occupation(
+                    model, n_gauss_prim, **occ_kwargs)
+                cache.append((raw, occupation))
+            results.append(halotab.predict(
+                occupation, separate_gal_type=separate_gal_type))
+        shape = [len(xp) for xp in self.xp]
+        a = self._spline_matrices()
+        output = []
+        for i in range(2):
+            if separate_gal_type:
+                output.append({})
+                for key in results[0][i]:
+                    data = np.array([r[i][key] for r in results])
+                    data = data.reshape(shape + list(data.shape[1:]))
+                    output[-1][key] = spline_interpolate(
+                        x, self.xp, a, data, extrapolate=extrapolate)
+            else:
+                data = np.array([r[i] for r in results])
+                data = data.reshape(shape + list(data.shape[1:]))
+                output.append(spline_interpolate(
+                    x, self.xp, a, data, extrapolate=extrapolate))
+        return tuple(output)
+
+
+def spline_interpolation_matrix(xp):
+    """Matrix ``a`` of shape ``(n - 1, 4, n)`` such that
+    ``np.einsum('ij,j,i', a[i], y, x0**np.arange(4))`` is the ``i``-th segment
+    of the not-a-knot cubic spline through ``(xp, y)`` at ``x0``
+    (``tabcorr/interpolator.py:219-272``; computed by the C library).
+
+    Raises
+    ------
+    ValueError
+        If ``xp`` has fewer than 4 entries.
+    """
+    xp = _lib.contiguous(xp)
+    a = np.zeros((max(len(xp) - 1, 0), 4, len(xp)))
+    _lib.check(_lib.load().tc_spline_interpolation_matrix(
+        len(xp), _lib.as_double_p(xp), _lib.as_double_p(a)))
+    return a
+
+
+def spline_interpolate(x, xp, a, yp, extrapolate=False):
+    """Evaluate the tensor-product spline along the first ``len(x)`` axes of
+    ``yp`` (``tabcorr/interpolator.py:275-331``): segment search with
+    ``np.digitize`` (right edge included), ``ValueError`` or clamping outside
+    the grid, cubic polynomial per axis."""
+    xp = xp if isinstance(xp, list) else [xp]
+    a = a if isinstance(a, list) else [a]
+    for value, matrix, nodes in zip(np.atleast_1d(x), a, xp):
+        segment = int(np.searchsorted(nodes, value, side='right')) - 1
+        if value == nodes[-1]:
+            segment = len(nodes) - 2
+        if not 0 <= segment <= len(nodes) - 2:
+            if not extrapolate:
+                raise ValueError(OUT_OF_RANGE)
+            segment = min(max(segment, 0), len(nodes) - 2)
+        weights = matrix[segment].T @ value**np.arange(4)
+        yp = np.tensordot(weights, yp, axes=(0, 0))
+    return yp

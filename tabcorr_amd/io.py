@@ -94,24 +94,74 @@ def write_tabcorr(halotab, fname, overwrite=False, max_args_size=1000000,
 
 def _read_npz(cls, fname):
     with np.load(fname) as data:
-        attrs = json.loads(str(data['attrs']))
-        columns = {key[3:]: data[key] for key in data.files
-                   if key.startswith('gt_')}
-        args = tuple(data[key] for key in sorted(
-            k for k in data.files if k.startswith('tpcf_args/')))
-        kwargs = {key[len('tpcf_kwargs/'):]: data[key] for key in data.files
-                  if key.startswith('tpcf_kwargs/')}
-        order = [c for c in GalTypeTable.__init__.__globals__['COLUMNS']
-                 if c in columns]
-        gal_type = GalTypeTable({c: columns[c] for c in order})
-        return cls.from_arrays(
-            gal_type, data['tpcf_matrix'].astype(np.float64),
-            tuple(int(s) for s in data['tpcf_shape']), attrs, args, kwargs)
+        return _tabcorr_from_flat(cls, {key: data[key] for key in data.files})
 
 
 def _write_npz(halotab, fname, overwrite, matrix_dtype):
     if os.path.exists(fname) and not overwrite:
         raise OSError("Unable to create file (file exists): '%s'" % fname)
+    np.savez(fname, **_tabcorr_to_flat(halotab, matrix_dtype))
+
+
+# -- Interpolator ------------------------------------------------------------------
+#
+# HDF5 layout of the reference (tabcorr/interpolator.py:88-96, 118-122): a
+# compound dataset ``param_dict_table`` (one column per key plus
+# ``tabcorr_index``) and one group ``tabcorr_{i}`` per instance.
+
+def read_interpolator(cls, fname):
+    from .tabcorr import TabCorr
+    if str(fname).endswith('.npz'):
+        with np.load(fname) as data:
+            keys = [str(k) for k in data['interp_keys']]
+            points = data['interp_points']
+            tables = []
+            for i in range(len(points)):
+                prefix = 'tabcorr_%d/' % i
+                sub = {key[len(prefix):]: data[key] for key in data.files
+                       if key.startswith(prefix)}
+                tables.append(_tabcorr_from_flat(TabCorr, sub))
+        return cls(tables, {key: points[:, d] for d, key in enumerate(keys)})
+    h5py = _h5py()
+    with h5py.File(fname, 'r') as stream:
+        table = stream['param_dict_table'][()]
+        order = np.argsort(table['tabcorr_index'])
+        keys = [name for name in table.dtype.names if name != 'tabcorr_index']
+        columns = {key: np.asarray(table[key], dtype=np.float64)[order]
+                   for key in keys}
+        tables = [read_tabcorr(TabCorr, stream['tabcorr_{}'.format(i)])
+                  for i in range(len(order))]
+    return cls(tables, columns)
+
+
+def write_interpolator(interp, fname, overwrite=False, max_args_size=1000000,
+                       matrix_dtype=np.float32):
+    if str(fname).endswith('.npz'):
+        if os.path.exists(fname) and not overwrite:
+            raise OSError("Unable to create file (file exists): '%s'" % fname)
+        arrays = {'interp_keys': np.array(interp.keys),
+                  'interp_points': interp.points}
+        for i, halotab in enumerate(interp.tabcorr_list):
+            for key, value in _tabcorr_to_flat(halotab, matrix_dtype).items():
+                arrays['tabcorr_%d/%s' % (i, key)] = value
+        np.savez(fname, **arrays)
+        return
+    h5py = _h5py()
+    with h5py.File(fname, 'w' if overwrite else 'w-') as stream:
+        dtype = [(key, '<f8') for key in interp.keys] + [
+            ('tabcorr_index', '<i8')]
+        table = np.zeros(len(interp.points), dtype=dtype)
+        for key in interp.keys:
+            table[key] = interp.param_dict_table[key]
+        table['tabcorr_index'] = interp.param_dict_table['tabcorr_index']
+        stream['param_dict_table'] = table
+        for i, halotab in enumerate(interp.tabcorr_list):
+            write_tabcorr(halotab, stream.create_group('tabcorr_{}'.format(i)),
+                          max_args_size=max_args_size,
+                          matrix_dtype=matrix_dtype)
+
+
+def _tabcorr_to_flat(halotab, matrix_dtype):
     arrays = {'attrs': np.array(json.dumps(
         {key: _plain(halotab.attrs[key]) for key in ATTR_KEYS})),
         'tpcf_matrix': np.asarray(halotab.tpcf_matrix).astype(matrix_dtype),
@@ -123,4 +173,18 @@ def _write_npz(halotab, fname, overwrite, matrix_dtype):
         arrays['tpcf_args/arg_%d' % i] = np.asarray(arg)
     for key, value in halotab.tpcf_kwargs.items():
         arrays['tpcf_kwargs/' + key] = np.asarray(value)
-    np.savez(fname, **arrays)
+    return arrays
+
+
+def _tabcorr_from_flat(cls, data):
+    from .galtable import COLUMNS
+    attrs = json.loads(str(data['attrs']))
+    columns = {key[3:]: data[key] for key in data if key.startswith('gt_')}
+    gal_type = GalTypeTable({c: columns[c] for c in COLUMNS if c in columns})
+    args = tuple(data[key] for key in sorted(
+        k for k in data if k.startswith('tpcf_args/')))
+    kwargs = {key[len('tpcf_kwargs/'):]: data[key] for key in data
+              if key.startswith('tpcf_kwargs/')}
+    return cls.from_arrays(
+        gal_type, np.asarray(data['tpcf_matrix']).astype(np.float64),
+        tuple(int(s) for s in data['tpcf_shape']), attrs, args, kwargs)

@@ -209,3 +209,125 @@ def test_ragged_and_empty_batches():
         expect = oracle.predict_zheng07_batch(table, theta)
         assert_rel(ngal, expect[0], RTOL)
         assert_rel(xi, expect[1], RTOL)
+
+
+# -- Interpolator -------------------------------------------------------------------
+
+def make_interpolator(tables, keys, points):
+    from tabcorr_amd import Interpolator
+    return Interpolator([make_tabcorr(t) for t in tables],
+                        {key: points[:, d] for d, key in enumerate(keys)})
+
+
+def check_interpolator(interp, data, keys_xi):
+    ngal, xi = interp.predict_batch(data['theta'], data['x'])
+    assert_rel(ngal, data['ngal'], RTOL, 'ngal')
+    assert_rel(xi, data['xi'], RTOL, 'xi')
+    ngal_sep, xi_sep = interp.predict_batch(data['theta'], data['x'],
+                                            separate_gal_type=True)
+    assert list(ngal_sep.keys()) == ['centrals', 'satellites']
+    assert list(xi_sep.keys()) == keys_xi
+    for key in ngal_sep:
+        assert_rel(ngal_sep[key], data['ngal_sep_' + key], RTOL, key)
+    for key in xi_sep:
+        assert_rel(xi_sep[key], data['xi_sep_' + key], RTOL, key)
+    # out of range: ValueError unless extrapolate (interpolator.py:322-328)
+    n_out = len(data['x_out'])
+    theta_out = (data['theta'][3:3 + n_out] if n_out == 4 else
+                 np.repeat(data['theta'][:1], n_out, axis=0))
+    with pytest.raises(ValueError):
+        interp.predict_batch(theta_out, data['x_out'])
+    ngal, xi = interp.predict_batch(theta_out, data['x_out'], extrapolate=True)
+    assert_rel(ngal, data['ngal_out'], RTOL)
+    assert_rel(xi, data['xi_out'], RTOL)
+
+
+@pytest.mark.parametrize('name', ['interp_2d_auto', 'interp_3d_cross',
+                                  'interp_2d_mixed'])
+def test_synthetic_interpolators(name):
+    from util import interpolator_tables_from_golden
+    data = load_golden(name)
+    tables = interpolator_tables_from_golden(data)
+    interp = make_interpolator(tables, [str(k) for k in data['keys']],
+                               data['points'])
+    for d in range(data['points'].shape[1]):
+        assert_rel(interp.xp[d], data['xp%d' % d], 1e-15)
+    check_interpolator(interp, data, xi_keys(tables[0]))
+
+
+def test_abacus_interpolator_scalar_api():
+    from tabcorr_amd import Zheng07Model
+    data = load_golden('ds_efficient')
+    tables = [table_from_golden(data, 'table%d_' % i) for i in range(4)]
+    interp = make_interpolator(tables, [str(k) for k in data['keys']],
+                               data['points'])
+    check_interpolator(interp, data, ['centrals', 'satellites'])
+
+    model = Zheng07Model(prim_haloprop_key='halo_m258m', redshift=0.5)
+    keys = ['logMmin', 'sigma_logM', 'logM0', 'logM1', 'alpha']
+    for i in range(4):
+        for key, value in zip(keys, data['theta'][i]):
+            model.param_dict[key] = value
+        with pytest.raises(ValueError):       # log_eta missing
+            interp.predict(model)
+        model.param_dict['log_eta'] = data['x'][i, 0]
+        ngal, xi = interp.predict(model)
+        assert isinstance(ngal, float) and xi.shape == (13, )
+        assert_rel(ngal, data['ngal'][i], RTOL)
+        assert_rel(xi, data['xi'][i], RTOL)
+        ngal_sep, xi_sep = interp.predict(model, separate_gal_type=True)
+        assert_rel(xi_sep['satellites'], data['xi_sep_satellites'][i], RTOL)
+        del model.param_dict['log_eta']
+    model.param_dict['log_eta'] = data['x_out'][0, 0]
+    with pytest.raises(ValueError):
+        interp.predict(model)
+    ngal, xi = interp.predict(model, extrapolate=True)
+
+    # single table of the file through TabCorr
+    halotab = interp.tabcorr_list[0]
+    check_against_golden(halotab, data, tables[0], prefix='table0_')
+
+
+def test_interpolator_generic_model_route():
+    from tabcorr_amd import Zheng07Model
+    from util import interpolator_tables_from_golden
+
+    class Opaque(Zheng07Model):
+        _tabcorr_amd_device_model = None
+
+    data = load_golden('interp_2d_auto')
+    tables = interpolator_tables_from_golden(data)
+    keys = [str(k) for k in data['keys']]
+    interp = make_interpolator(tables, keys, data['points'])
+    names = ['logMmin', 'sigma_logM', 'logM0', 'logM1', 'alpha']
+    for i in [0, 3, 7]:
+        model = Opaque()
+        for key, value in zip(names, data['theta'][i]):
+            model.param_dict[key] = value
+        for key, value in zip(keys, data['x'][i]):
+            model.param_dict[key] = value
+        ngal, xi = interp.predict(model)
+        assert_rel(ngal, data['ngal'][i], RTOL)
+        assert_rel(xi, data['xi'][i], RTOL)
+        ngal_sep, xi_sep = interp.predict(model, separate_gal_type=True)
+        for key in xi_sep:
+            assert_rel(xi_sep[key], data['xi_sep_' + key][i], RTOL)
+
+
+def test_interpolator_grid_validation():
+    from tabcorr_amd import Interpolator
+    from util import interpolator_tables_from_golden
+    data = load_golden('interp_2d_auto')
+    tables = interpolator_tables_from_golden(data)
+    keys = [str(k) for k in data['keys']]
+    halotabs = [make_tabcorr(t) for t in tables]
+    points = data['points'].copy()
+    with pytest.raises(ValueError):
+        Interpolator(halotabs[:-1], {k: points[:, d] for d, k in
+                                     enumerate(keys)})
+    bad = points.copy()
+    bad[0] = bad[1]
+    with pytest.raises(ValueError, match='grid'):
+        Interpolator(halotabs, {k: bad[:, d] for d, k in enumerate(keys)})
+    with pytest.raises(ValueError, match='less than'):
+        Interpolator(halotabs[:3], {'a': np.arange(3.0)})
