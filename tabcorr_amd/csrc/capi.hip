@@ -252,8 +252,12 @@ int launch_contract_rt(int rt, dim3 grid, dim3 block, int lds, hipStream_t strea
   switch (rt) {
 #define TC_CASE(N)                                                            \
   case N:                                                                     \
-    hipLaunchKernelGGL((tc::contract_kernel<N>), grid, block, lds, stream,    \
-                       args);                                                 \
+    if (args.n_tables > 0)                                                    \
+      hipLaunchKernelGGL((tc::contract_kernel<N, true>), grid, block, lds,    \
+                         stream, args);                                       \
+    else                                                                      \
+      hipLaunchKernelGGL((tc::contract_kernel<N, false>), grid, block, lds,   \
+                         stream, args);                                       \
     break;
     TC_RT_CASES
 #undef TC_CASE
@@ -269,7 +273,10 @@ int set_lds_limit_rt(int rt, int lds) {
 #define TC_CASE(N)                                                            \
   case N:                                                                     \
     TC_HIP(hipFuncSetAttribute(                                               \
-        reinterpret_cast<const void*>(&tc::contract_kernel<N>),               \
+        reinterpret_cast<const void*>(&tc::contract_kernel<N, false>),        \
+        hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \
+    TC_HIP(hipFuncSetAttribute(                                               \
+        reinterpret_cast<const void*>(&tc::contract_kernel<N, true>),         \
         hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \
     break;
     TC_RT_CASES
@@ -356,7 +363,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   fa.n_draws = n_draws;
   fa.ngal = ngal_device;
   fa.xi = xi_device;
-  hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)(ldb / 64)), dim3(256), 0,
+  hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)(ldb / 64)), dim3(1024), 0,
                      t->stream, fa);
   TC_HIP(hipGetLastError());
   return TC_OK;
@@ -1062,7 +1069,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   fa.n_draws = n_draws;
   fa.ngal = ngal_device;
   fa.xi = xi_device;
-  hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)n_tiles), dim3(256), 0,
+  hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)n_tiles), dim3(1024), 0,
                      it->stream, fa);
   TC_HIP(hipGetLastError());
   return TC_OK;

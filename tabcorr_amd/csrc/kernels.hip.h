@@ -21,6 +21,9 @@ namespace tc {
 typedef const __attribute__((address_space(4))) double* sc_f64;
 typedef const __attribute__((address_space(4))) float* sc_f32;
 typedef const __attribute__((address_space(4))) int32_t* sc_i32;
+// Pointers that were themselves loaded from memory are generic to the compiler; this
+// tells it they point to global memory (global_load with counted vmcnt, not flat_load).
+typedef const __attribute__((address_space(1))) double* gl_f64;
 
 constexpr int kLanes = 64;
 
@@ -245,7 +248,7 @@ __device__ __forceinline__ void block_compute(
 // wave; each of them feeds one v_fmac_f64_dpp row_newbcast.  Per table entry a
 // wave issues one ds_read_b64 (n_j), one v_mul_f64 (n_i n_j) and RT FMAs; the
 // loads of the next block are in flight while the current one is consumed.
-template <int RT>
+template <int RT, bool INTERP>
 __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   typedef ContractGeometry<RT> Geo;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
   const int n_waves = blockDim.x >> 6;
   const int64_t col = (int64_t)blockIdx.x * kLanes;
 
-  const bool interp = a.n_tables > 0;
+  constexpr bool interp = INTERP;
   const int k_splits = interp ? a.k_splits : 1;
   const Group group = a.groups[blockIdx.y / k_splits];
   const int n_rows = group.row_hi - group.row_lo;
@@ -279,8 +282,8 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
       // independent loads in flight per thread
       typedef double __attribute__((ext_vector_type(2))) double2v;
       const int n_items = n_rows * (kLanes / 2);
-      const double* src = (interp ? a.nbufs[density_class] : a.nbuf) +
-                          (int64_t)group.row_lo * a.ldb + col;
+      gl_f64 src = (gl_f64)(interp ? a.nbufs[density_class] : a.nbuf) +
+                   (int64_t)group.row_lo * a.ldb + col;
       const int nthreads = blockDim.x;
       int it = (a.debug & 8) ? n_items : threadIdx.x;
       for (; it + 3 * nthreads < n_items; it += 4 * nthreads) {
@@ -288,7 +291,8 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int id = it + u * nthreads;
-          v[u] = *(const double2v*)(src + (int64_t)(id >> 5) * a.ldb + (id & 31) * 2);
+          v[u] = *(const __attribute__((address_space(1))) double2v*)(
+              src + (int64_t)(id >> 5) * a.ldb + (id & 31) * 2);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -298,7 +302,8 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
       }
       for (; it < n_items; it += nthreads)
         *(double2v*)(lds + (it >> 5) * kLanes + (it & 31) * 2) =
-            *(const double2v*)(src + (int64_t)(it >> 5) * a.ldb + (it & 31) * 2);
+            *(const __attribute__((address_space(1))) double2v*)(
+                src + (int64_t)(it >> 5) * a.ldb + (it & 31) * 2);
       __syncthreads();
       staged_class = density_class;
     }
@@ -319,31 +324,27 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
                   ? lds[(chunk.i0 - group.row_lo) * kLanes + lane] * st.scale
                   : st.scale;
 
-      const double* table = (interp ? a.tables[k] : (const double*)a.table) +
-                            ((int64_t)blockIdx.z * a.n_positions + chunk.q_begin) * RT +
-                            (lane & 15);
+      gl_f64 table = (gl_f64)(interp ? a.tables[k] : (const double*)a.table) +
+                     ((int64_t)blockIdx.z * a.n_positions + chunk.q_begin) * RT +
+                     (lane & 15);
       const int n_blocks = (a.debug & 4) ? 0 : (chunk.q_end - chunk.q_begin) / EB;
       double ta[NG], tb[NG];
 #pragma unroll
       for (int g = 0; g < NG; ++g) ta[g] = table[g * 16];
       int blk = 0;
       // two blocks per iteration so that the two register sets swap roles
-      // without moves
+      // without moves; the prefetch is unconditional (clamped to the last block) so
+      // that the compiler can count the loads in flight exactly
+      const int last = n_blocks > 0 ? n_blocks - 1 : 0;
       for (; blk + 2 <= n_blocks; blk += 2) {
-        if (!(a.debug & 1)) {
 #pragma unroll
-          for (int g = 0; g < NG; ++g)
-            tb[g] = table[(int64_t)(blk + 1) * EB * RT + g * 16];
-        } else {
-#pragma unroll
-          for (int g = 0; g < NG; ++g) tb[g] = ta[g];
-        }
+        for (int g = 0; g < NG; ++g)
+          tb[g] = table[(int64_t)(blk + 1) * EB * RT + g * 16];
         block_compute<RT>(acc, ta, st, lds, lane, std::make_integer_sequence<int, EB>());
-        if (blk + 2 < n_blocks && !(a.debug & 1)) {
+        const int next = blk + 2 < last ? blk + 2 : last;
 #pragma unroll
-          for (int g = 0; g < NG; ++g)
-            ta[g] = table[(int64_t)(blk + 2) * EB * RT + g * 16];
-        }
+        for (int g = 0; g < NG; ++g)
+          ta[g] = table[(int64_t)next * EB * RT + g * 16];
         block_compute<RT>(acc, tb, st, lds, lane, std::make_integer_sequence<int, EB>());
       }
       if (blk < n_blocks)
@@ -405,7 +406,7 @@ constexpr int kFinalizeRows = 64;   // (component, r) rows per LDS pass
 // write the results in the reference's output order.  One block per draw tile;
 // reads are coalesced over draws, the transposition to the draw-major output
 // goes through LDS.
-__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
+__global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
   __shared__ double tile[kFinalizeRows][kLanes + 1];
   __shared__ double norm_inv[kLanes];
   const int lane = threadIdx.x & 63;
@@ -435,14 +436,27 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
   const double norm = norm_inv[lane];
 
   const int n_rows = a.n_comp * a.n_r;
+  const int n_waves = blockDim.x >> 6;
+  const int n_slabs = a.n_groups * a.k_splits;
   for (int row0 = 0; row0 < n_rows; row0 += kFinalizeRows) {
     const int rows = n_rows - row0 < kFinalizeRows ? n_rows - row0 : kFinalizeRows;
-    for (int rr = wave; rr < rows; rr += 4) {
+    for (int rr = wave; rr < rows; rr += n_waves) {
       const int c = (row0 + rr) / a.n_r, r = (row0 + rr) % a.n_r;
+      const double* src = a.partial + (int64_t)r * a.ldb + col + lane;
+      const int64_t slab = (int64_t)a.r_stride * a.ldb;
       double sum = 0.0;
-      for (int g = 0; g < a.n_groups * a.k_splits; ++g) {
-        if (a.n_comp == 1 || a.groups[g / a.k_splits].component == c)
-          sum += a.partial[((int64_t)g * a.r_stride + r) * a.ldb + col + lane];
+      // eight independent loads in flight; the additions keep the slab order
+      for (int g0 = 0; g0 < n_slabs; g0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int g = g0 + u;
+          const bool use = g < n_slabs &&
+                           (a.n_comp == 1 || a.groups[g / a.k_splits].component == c);
+          v[u] = use ? src[g * slab] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += v[u];
       }
       tile[rr][lane] = sum / norm;
     }

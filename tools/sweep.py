@@ -91,3 +91,5 @@ if __name__ == '__main__':
                 for dbg in [0, 35]:
                     os.environ['TC_DEBUG_VARIANT'] = str(dbg)
                     run(50, 1, (19, ), 10000, 20, 'tw=%d nw=%d lds=%d debug=%d' % (tw, nw, lds, dbg))
+    elif which == 'stats':
+        run(50, 1, (19, ), 10000, 200, 'cfg2 default')
