@@ -82,6 +82,10 @@ int tc_gauss_legendre(int n, double* x, double* w);
  * row index i1, column index i2 (i2 <= i1) and prefactor (1 on the diagonal, else 2). */
 int tc_pair_indices(int n_bins, int32_t* index_1, int32_t* index_2, int32_t* prefactor);
 
+/* Host evaluation of the table-driven FP64 functions the occupation kernel uses in place
+ * of the device libm (tabcorr_amd/csrc/fastmath.h): kind 0 erf, 1 log (x > 0), 2 exp. */
+int tc_debug_fastmath(int kind, int64_t n, const double* x, double* y);
+
 /* Not-a-knot cubic spline matrix a[(n-1)][4][n] of interpolator.py:219-272. */
 int tc_spline_interpolation_matrix(int n, const double* xp, double* a);
 

@@ -50,6 +50,8 @@ SIGNATURES = {
     'tc_memcpy_h2d': [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t],
     'tc_memcpy_d2h': [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t],
     'tc_gauss_legendre': [ctypes.c_int, c_double_p, c_double_p],
+    'tc_debug_fastmath': [ctypes.c_int, ctypes.c_int64, c_double_p,
+                          c_double_p],
     'tc_pair_indices': [ctypes.c_int, c_int32_p, c_int32_p, c_int32_p],
     'tc_spline_interpolation_matrix': [ctypes.c_int, c_double_p, c_double_p],
     'tc_plan_debug': [ctypes.c_int, ctypes.c_int, c_uint8_p, ctypes.c_int,

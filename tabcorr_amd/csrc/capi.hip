@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/tabcorr_amd.h"
+#include "fastmath.h"
 #include "hostmath.h"
 #include "kernels.hip.h"
 
@@ -122,6 +123,7 @@ struct tc_table {
   void* d_n_h = nullptr;
   void* d_percentile = nullptr;
   void* d_perm = nullptr;
+  void* d_math_table = nullptr;  // fastmath.h tables
   std::map<int, Quadrature> quadrature;
   std::map<std::pair<int, int>, std::unique_ptr<DeviceChunking>> chunkings;
 
@@ -407,12 +409,23 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   oa.n_h = (const double*)t->d_n_h;
   oa.percentile = (const double*)t->d_percentile;
   oa.perm = (const int32_t*)t->d_perm;
+  oa.math_table = (const double*)t->d_math_table;
+  oa.debug = env_int("TC_OCC_DEBUG", 0);
   oa.nbuf = (double*)nbuf->ptr;
   oa.ngal = (double*)ngal2->ptr;
   oa.occupation = occupation_device;
-  hipLaunchKernelGGL(tc::occ_zheng07_kernel,
-                     dim3((unsigned)(ldb / 64), (unsigned)splits),
-                     dim3(tc::kOccWaves * 64), 0, stream, oa);
+  {
+    const dim3 grid((unsigned)(ldb / 64), (unsigned)splits), block(tc::kOccWaves * 64);
+    const bool assembias = (flags & TC_FLAG_ASSEMBIAS) != 0;
+    if (n_gauss == 10 && !assembias)
+      hipLaunchKernelGGL((tc::occ_zheng07_kernel<10, false>), grid, block, 0, stream, oa);
+    else if (n_gauss == 10)
+      hipLaunchKernelGGL((tc::occ_zheng07_kernel<10, true>), grid, block, 0, stream, oa);
+    else if (!assembias)
+      hipLaunchKernelGGL((tc::occ_zheng07_kernel<0, false>), grid, block, 0, stream, oa);
+    else
+      hipLaunchKernelGGL((tc::occ_zheng07_kernel<0, true>), grid, block, 0, stream, oa);
+  }
   TC_HIP(hipGetLastError());
   return TC_OK;
 }
@@ -508,6 +521,21 @@ int tc_gauss_legendre(int n, double* x, double* w) {
   tc::gauss_legendre(n, xs, ws);
   std::copy(xs.begin(), xs.end(), x);
   std::copy(ws.begin(), ws.end(), w);
+  return TC_OK;
+}
+
+int tc_debug_fastmath(int kind, int64_t n, const double* x, double* y) {
+  TC_CHECK(kind >= 0 && kind <= 2 && n >= 0 && x && y, "invalid arguments");
+  static std::vector<double> table;
+  if (table.empty()) {
+    table.resize(tc::fm::kTableDoubles);
+    tc::fm::build_tables(table.data());
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    if (kind == 0) y[i] = tc::fm::erf_fast(table.data(), x[i]);
+    if (kind == 1) y[i] = tc::fm::log_fast(table.data(), x[i]);
+    if (kind == 2) y[i] = tc::fm::exp_fast(table.data(), x[i]);
+  }
   return TC_OK;
 }
 
@@ -661,6 +689,11 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
   if (status == TC_OK) status = upload(t->n_h, &t->d_n_h);
   if (status == TC_OK) status = upload(t->percentile, &t->d_percentile);
   if (status == TC_OK) status = upload(t->plan.perm, &t->d_perm);
+  if (status == TC_OK) {
+    std::vector<double> math_table(tc::fm::kTableDoubles);
+    tc::fm::build_tables(math_table.data());
+    status = upload(math_table, &t->d_math_table);
+  }
   if (status != TC_OK) {
     tc_table_destroy(t.release());
     return status;
@@ -673,7 +706,7 @@ int tc_table_destroy(tc_table* t) {
   if (t == nullptr) return TC_OK;
   (void)hipSetDevice(t->device);
   if (t->stream) (void)hipStreamSynchronize(t->stream);
-  for (void* p : {t->d_table, t->d_n_h, t->d_percentile, t->d_perm})
+  for (void* p : {t->d_table, t->d_n_h, t->d_percentile, t->d_perm, t->d_math_table})
     if (p) (void)hipFree(p);
   for (auto& kv : t->quadrature)
     for (void* p : {kv.second.log_m, kv.second.m, kv.second.weight})

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <utility>
 
+#include "fastmath.h"
 #include "hostmath.h"
 
 namespace tc {
@@ -43,6 +44,8 @@ struct OccArgs {
   const double* n_h;       // (n_bins)
   const double* percentile;  // (n_bins)
   const int32_t* perm;     // library bin -> reference row
+  const double* math_table;  // fm::kTableDoubles doubles (fastmath.h)
+  int debug;               // developer ablations (TC_OCC_DEBUG), 0 in production
   double* nbuf;            // (n_bins, ldb) number density per bin and draw
   double* ngal;            // (bin splits, 2, ldb) partial cen / sat densities
   double* occupation;      // optional (n_draws, n_bins) in reference order
@@ -53,14 +56,15 @@ constexpr unsigned kFlagModulate = 2u;
 constexpr unsigned kFlagAssembias = 4u;
 
 __device__ inline double heaviside_assembias(double n, double strength,
-                                             bool above, double f1, double f2,
+                                             bool above, double f2_over_f1,
+                                             double f1_over_f2,
                                              bool bounded_above) {
   // Hearin et al. (2016): shift +d above the split, -d f1/f2 below, with
   // |d| limited so that both stay within [0, 1] (centrals) or [0, inf).
   double up = bounded_above ? 1.0 - n : __builtin_huge_val();
-  double dmax = strength >= 0.0 ? fmin(up, n * f2 / f1) : fmin(n, up * f2 / f1);
+  double dmax = strength >= 0.0 ? fmin(up, n * f2_over_f1) : fmin(n, up * f2_over_f1);
   double d1 = strength * dmax;
-  return above ? n + d1 : n - d1 * f1 / f2;
+  return above ? n + d1 : n - d1 * f1_over_f2;
 }
 
 // Mean occupation of every bin for every draw: tabcorr/tabcorr.py:537-578 with
@@ -70,25 +74,58 @@ __device__ inline double heaviside_assembias(double n, double strength,
 // block's centrals / satellites density sums go to ngal_part[split][2][ldb].
 constexpr int kOccWaves = 4;
 
+// NGAUSS > 0: n_gauss known at compile time, node loop fully unrolled (the scalar loads
+// of a bin's constants are batched and the independent polynomial chains interleave);
+// NGAUSS == 0: any n_gauss.
+template <int NGAUSS, bool ASSEMBIAS>
 __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     OccArgs a) {
   __shared__ double red[2][kOccWaves][kLanes];
+  __shared__ __attribute__((aligned(16))) double table[fm::kTableDoubles];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t b0 = (int64_t)blockIdx.x * kLanes + lane;
   const int64_t b = b0 < a.n_draws ? b0 : a.n_draws - 1;
+  const int n_gauss = NGAUSS > 0 ? NGAUSS : a.n_gauss;
 
+  // bins of this block: a contiguous range, so that most blocks are all-centrals or
+  // all-satellites and stage only the tables they need
+  const int per_block = (a.n_bins + gridDim.y - 1) / gridDim.y;
+  const int g_begin = blockIdx.y * per_block;
+  const int g_end = g_begin + per_block < a.n_bins ? g_begin + per_block : a.n_bins;
+  {
+    typedef double __attribute__((ext_vector_type(2))) double2v;
+    // the exp table is always needed (10^logM0, 10^logM1)
+    const bool need_erf = g_begin < a.n_central || (a.flags & kFlagModulate);
+    const int lo = need_erf ? 0 : fm::kLogOffset / 2;
+    const int hi = fm::kTableDoubles / 2;
+    const double2v* src = (const double2v*)a.math_table;
+    double2v* dst = (double2v*)table;
+    int i = (a.debug & 2) ? hi : lo + threadIdx.x;
+    for (; i + 3 * (int)blockDim.x < hi; i += 4 * blockDim.x) {
+      double2v v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = src[i + u * blockDim.x];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dst[i + u * blockDim.x] = v[u];
+    }
+    for (; i < hi; i += blockDim.x) dst[i] = src[i];
+  }
   const double* th = a.theta + b * a.n_theta;
   const double log_m_min = th[0];
   const double inv_sigma = 1.0 / th[1];
-  const double m0 = exp10(th[2]);
-  const double m1 = exp10(th[3]);
+  const double log_m0 = th[2], log_m1 = th[3];
   const double alpha = th[4];
-  const bool assembias = (a.flags & kFlagAssembias) != 0;
+  constexpr bool assembias = ASSEMBIAS;
   const bool modulate = (a.flags & kFlagModulate) != 0;
   const double a_cen = assembias ? th[5] : 0.0;
   const double a_sat = assembias ? th[6] : 0.0;
-  const double f1 = 1.0 - a.split, f2 = a.split;
+  const double f1 = (1.0 - a.split) / a.split, f2 = a.split / (1.0 - a.split);
+  // (f1 = f1/f2 and f2 = f2/f1 of Hearin et al.'s population fractions)
+  __syncthreads();
+  constexpr double kLn10 = 2.302585092994045684;
+  const double m0 = fm::exp_fast(table, log_m0 * kLn10);
+  const double inv_m1 = fm::exp_fast(table, -log_m1 * kLn10);
 
   sc_f64 log_m = (sc_f64)a.log_m;
   sc_f64 mass = (sc_f64)a.m;
@@ -98,29 +135,41 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
   sc_i32 perm = (sc_i32)a.perm;
 
   double sum_cen = 0.0, sum_sat = 0.0;
-  const int stride = kOccWaves * gridDim.y;
-  for (int g = blockIdx.y * kOccWaves + wave; g < a.n_bins; g += stride) {
+  for (int g = g_begin + wave; g < g_end; g += kOccWaves) {
     const bool central = g < a.n_central;
     const bool above = percentile[g] > a.split;
     double acc = 0.0;
-    for (int k = 0; k < a.n_gauss; ++k) {
-      const double lm = log_m[g * a.n_gauss + k];
-      double n;
-      if (central) {
-        n = 0.5 * (1.0 + erf((lm - log_m_min) * inv_sigma));
-        if (assembias) n = heaviside_assembias(n, a_cen, above, f1, f2, true);
-      } else {
-        const double x = (mass[g * a.n_gauss + k] - m0) / m1;
-        n = x > 0.0 ? exp(alpha * log(x)) : 0.0;
-        if (modulate) n *= 0.5 * (1.0 + erf((lm - log_m_min) * inv_sigma));
-        if (assembias) n = heaviside_assembias(n, a_sat, above, f1, f2, false);
+    if (a.debug & 1) {
+      acc = log_m_min;
+    } else if (central) {
+#pragma unroll
+      for (int k = 0; k < n_gauss; ++k) {
+        const double lm = log_m[g * n_gauss + k];
+        double n = fma(0.5, fm::erf_fast(table, (lm - log_m_min) * inv_sigma), 0.5);
+        if (assembias) n = heaviside_assembias(n, a_cen, above, f2, f1, true);
+        acc = fma(weight[g * n_gauss + k], n, acc);
       }
-      acc = fma(weight[g * a.n_gauss + k], n, acc);
+    } else {
+#pragma unroll
+      for (int k = 0; k < n_gauss; ++k) {
+        const double x = (mass[g * n_gauss + k] - m0) * inv_m1;
+        // ((M - M0) / M1)^alpha = exp(alpha log x); 1e-300 keeps log_fast's input a
+        // positive normal number on the lanes that are masked out anyway
+        double n = fm::exp_fast(table, alpha * fm::log_fast(table, x > 1e-300 ? x : 1e-300));
+        n = x > 0.0 ? n : 0.0;
+        if (modulate) {
+          const double lm = log_m[g * n_gauss + k];
+          n *= fma(0.5, fm::erf_fast(table, (lm - log_m_min) * inv_sigma), 0.5);
+        }
+        if (assembias) n = heaviside_assembias(n, a_sat, above, f2, f1, false);
+        acc = fma(weight[g * n_gauss + k], n, acc);
+      }
     }
     if (a.occupation != nullptr && b0 < a.n_draws)
       a.occupation[b0 * a.n_bins + perm[g]] = acc;
     const double dens = acc * n_h[g];
-    a.nbuf[(int64_t)g * a.ldb + (int64_t)blockIdx.x * kLanes + lane] = dens;
+    if (!(a.debug & 4))
+      a.nbuf[(int64_t)g * a.ldb + (int64_t)blockIdx.x * kLanes + lane] = dens;
     if (central) sum_cen += dens; else sum_sat += dens;
   }
   red[0][wave][lane] = sum_cen;
