@@ -192,6 +192,10 @@ int tc_interp_predict_zheng07_batch_device(tc_interp* interp, const double* thet
 int tc_table_timer_begin(tc_table* table, int profile_kernels);
 int tc_table_timer_end(tc_table* table, float* elapsed_ms);
 int tc_table_kernel_time(tc_table* table, int* n_launches, float* mean_ms);
+/* Developer timeline (environment TC_TRACE=1): per workgroup of the last contraction
+ * launch six words: 100 MHz timestamps at start / after staging / after the main loop /
+ * at the end, HW_ID and XCC_ID.  Copies min(capacity, n_blocks) records. */
+int tc_debug_trace(tc_table* table, uint64_t* out, int64_t capacity, int64_t* n_blocks);
 /* Launch geometry of the last predict call (for DESIGN.md / bench.py reporting). */
 int tc_table_last_launch(const tc_table* table, int* n_workgroups, int* waves_per_workgroup,
                          int* n_splits, int* lds_bytes);

@@ -127,7 +127,8 @@ struct tc_table {
   std::map<int, Quadrature> quadrature;
   std::map<std::pair<int, int>, std::unique_ptr<DeviceChunking>> chunkings;
 
-  DeviceBuffer theta, nbuf, ngal2, partial, out_ngal, out_xi, occupation;
+  DeviceBuffer theta, nbuf, ngal2, partial, out_ngal, out_xi, occupation, trace;
+  size_t trace_blocks = 0;
 
   // measurement
   bool profile_kernels = false;
@@ -201,48 +202,69 @@ int get_chunking(tc_table* t, int n_chunks, int waves, DeviceChunking** out) {
 // Largest dynamic LDS allocation a workgroup may ask for (160 KiB per CU).
 constexpr int kMaxLdsBytes = 160 * 1024;
 
-// Pick the decomposition for a batch: enough wave-sized chunks to give every
-// SIMD of the 256 CUs several waves, grouped into workgroups whose staged rows
-// fit in LDS.
+int lds_bytes_for(const tc::Chunking& chunking, int rt) {
+  int span = 1;
+  while (span < chunking.waves_per_group) span <<= 1;
+  return std::max(chunking.max_rows, (span / 2) * rt) * 64 * 8;
+}
+
+// Workgroups of this kernel that fit on one CU: LDS (160 KiB) and wave slots (the
+// kernel needs ~70 VGPRs: 7 waves per SIMD).
+int blocks_per_cu(int lds_bytes, int waves) {
+  const int by_lds = kMaxLdsBytes / std::max(lds_bytes, 1);
+  const int by_waves = 28 / waves;
+  return std::max(1, std::min(std::min(by_lds, by_waves), 8));
+}
+
+// Pick the decomposition for a batch.  Draw tiles alone rarely fill the chip (10^4
+// draws are 157 tiles), so the table is additionally cut into groups of `waves` chunks;
+// the number of groups is chosen so that all workgroups are resident at once and every
+// CU holds the same number of them (one balanced round), and small enough that a chunk
+// keeps at least TC_MIN_CHUNK_ENTRIES entries.
 int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
                     DeviceChunking** out, int* lds_bytes) {
-  const int64_t n_tiles = (n_draws + 63) / 64;
-  const int64_t target_waves = env_int("TC_TARGET_WAVES", 8192);
-  int64_t n_chunks = target_waves / std::max<int64_t>(1, n_tiles * t->n_rtiles);
-  const int64_t min_entries = env_int("TC_MIN_CHUNK_ENTRIES", 48);
-  n_chunks = std::min<int64_t>(n_chunks, t->plan.n_entries / min_entries);
-  n_chunks = std::max<int64_t>(n_chunks, 1);
-  n_chunks = std::min<int64_t>(n_chunks, 4096);
-  n_chunks = env_int("TC_NCHUNKS", (int)n_chunks);
-  int waves = env_int("TC_NWAVES", 8);
-  waves = std::max(1, std::min(waves, 16));
-  waves = (int)std::min<int64_t>(waves, n_chunks);
+  (void)n_comp_out;
+  const int64_t n_tiles = (n_draws + 63) / 64 * t->n_rtiles;
+  const int64_t min_entries = env_int("TC_MIN_CHUNK_ENTRIES", 32);
+  const int n_cus = 256;
+  int waves = std::max(1, std::min(env_int("TC_NWAVES", 4), 16));
+  const int forced_groups = env_int("TC_NGROUPS", 0);
 
-  for (int attempt = 0; attempt < 16; ++attempt) {
+  int capacity = 5;
+  DeviceChunking* best = nullptr;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    int64_t n_groups = std::max<int64_t>(1, (int64_t)capacity * n_cus / n_tiles);
+    if (forced_groups > 0) n_groups = forced_groups;
+    int64_t n_chunks = n_groups * waves;
+    n_chunks = std::min<int64_t>(n_chunks,
+                                 std::max<int64_t>(1, t->plan.n_entries / min_entries));
+    n_chunks = std::min<int64_t>(n_chunks, 4096);
+    n_chunks = env_int("TC_NCHUNKS", (int)n_chunks);
+    const int use_waves = (int)std::min<int64_t>(waves, n_chunks);
     DeviceChunking* c = nullptr;
-    int status = get_chunking(t, (int)n_chunks, waves, &c);
+    int status = get_chunking(t, (int)n_chunks, use_waves, &c);
     if (status != TC_OK) return status;
-    int span = 1;
-    while (span < c->host.waves_per_group) span <<= 1;
-    int bytes = std::max(c->host.max_rows, (span / 2) * t->rt) * 64 * 8;
-    bytes = std::max(bytes, env_int("TC_LDS_MIN", 0));
-    if (bytes <= kMaxLdsBytes) {
-      *out = c;
-      *lds_bytes = bytes;
-      return TC_OK;
+    const int bytes = lds_bytes_for(c->host, t->rt);
+    if (bytes > kMaxLdsBytes) {
+      // Mode cross: more, narrower groups touch fewer rows each.
+      if (t->mode == TC_MODE_CROSS && capacity < 64) {
+        capacity *= 2;
+        continue;
+      }
+      return fail(TC_ERR_UNSUPPORTED,
+                  "table with %d bins needs more than %d bytes of LDS per workgroup "
+                  "in mode '%s'",
+                  t->n_bins, kMaxLdsBytes,
+                  t->mode == TC_MODE_AUTO ? "auto" : "cross");
     }
-    // Mode cross: more, narrower groups touch fewer rows each.
-    if (t->mode == TC_MODE_CROSS) {
-      if (waves > 1) waves /= 2; else n_chunks *= 2;
-      if (n_chunks > t->plan.n_entries) break;
-      continue;
-    }
-    break;
+    best = c;
+    const int fit = blocks_per_cu(bytes, use_waves);
+    if (fit == capacity || forced_groups > 0) break;
+    capacity = fit;
   }
-  return fail(TC_ERR_UNSUPPORTED,
-              "table with %d bins needs more than %d bytes of LDS per workgroup "
-              "in mode '%s'",
-              t->n_bins, kMaxLdsBytes, t->mode == TC_MODE_AUTO ? "auto" : "cross");
+  *out = best;
+  *lds_bytes = std::max(lds_bytes_for(best->host, t->rt), env_int("TC_LDS_MIN", 0));
+  return TC_OK;
 }
 
 #define TC_RT_CASES                                                           \
@@ -315,6 +337,13 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   ca.n_central = t->plan.n_central;
   ca.r_stride = r_stride;
   ca.debug = env_int("TC_DEBUG_VARIANT", 0);
+  ca.trace = nullptr;
+  if (env_int("TC_TRACE", 0)) {
+    t->trace_blocks = (size_t)(ldb / 64) * n_groups * t->n_rtiles;
+    status = t->trace.reserve(t->trace_blocks * 6 * sizeof(unsigned long long), t->stream);
+    if (status != TC_OK) return status;
+    ca.trace = (unsigned long long*)t->trace.ptr;
+  }
   ca.n_tables = 0;
   ca.k_splits = 1;
   ca.tables = nullptr;
@@ -715,7 +744,7 @@ int tc_table_destroy(tc_table* t) {
     for (void* p : {kv.second->chunks, kv.second->groups})
       if (p) (void)hipFree(p);
   for (DeviceBuffer* b : {&t->theta, &t->nbuf, &t->ngal2, &t->partial,
-                          &t->out_ngal, &t->out_xi, &t->occupation})
+                          &t->out_ngal, &t->out_xi, &t->occupation, &t->trace})
     b->release();
   for (auto& ev : t->kernel_events) {
     (void)hipEventDestroy(ev.first);
@@ -906,6 +935,17 @@ int tc_table_kernel_time(tc_table* t, int* n_launches, float* mean_ms) {
   return TC_OK;
 }
 
+int tc_debug_trace(tc_table* t, uint64_t* out, int64_t capacity, int64_t* n_blocks) {
+  TC_CHECK(t != nullptr && n_blocks != nullptr, "NULL argument");
+  *n_blocks = (int64_t)t->trace_blocks;
+  if (out == nullptr || t->trace.ptr == nullptr) return TC_OK;
+  TC_HIP(hipStreamSynchronize(t->stream));
+  const int64_t n = std::min<int64_t>(capacity, (int64_t)t->trace_blocks);
+  TC_HIP(hipMemcpy(out, t->trace.ptr, (size_t)n * 6 * sizeof(uint64_t),
+                   hipMemcpyDeviceToHost));
+  return TC_OK;
+}
+
 int tc_table_last_launch(const tc_table* t, int* n_workgroups, int* waves,
                          int* n_splits, int* lds_bytes) {
   TC_CHECK(t != nullptr, "table handle is NULL");
@@ -1013,44 +1053,26 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
                      it->stream, ia);
   TC_HIP(hipGetLastError());
 
-  // decomposition: as for one table, with the tables looped inside the block; split the
-  // tables over blocks only when a single pass would leave the chip underfilled
+  // decomposition: as for one table (choose_chunking), with the tables looped inside
+  // the block; the tables are split over blocks only when one pass would leave the chip
+  // underfilled
   const int64_t n_tiles = ldb / 64;
-  const int64_t target_waves = env_int("TC_TARGET_WAVES", 8192);
-  const int64_t min_entries = env_int("TC_MIN_CHUNK_ENTRIES", 48);
-  int waves = std::max(1, std::min(env_int("TC_NWAVES", 8), 16));
-  int64_t n_chunks = target_waves / std::max<int64_t>(1, n_tiles * t0->n_rtiles);
-  n_chunks = std::max<int64_t>(
-      1, std::min<int64_t>(n_chunks, t0->plan.n_entries / min_entries));
+  DeviceChunking* c = nullptr;
+  int lds = 0;
+  {
+    // the table handle caches the chunkings; all tables share table 0's plan
+    status = choose_chunking(t0, n_draws, n_comp, &c, &lds);
+    if (status != TC_OK) return status;
+  }
   int k_splits = 1;
   {
-    const int64_t have = std::max<int64_t>(1, n_chunks) * n_tiles * t0->n_rtiles;
-    if (have < target_waves)
-      k_splits = (int)std::min<int64_t>(it->n_tables, target_waves / have);
+    const int64_t blocks = n_tiles * t0->n_rtiles * (int64_t)c->host.groups.size();
+    const int64_t want = 256 * (int64_t)blocks_per_cu(lds, c->host.waves_per_group);
+    if (blocks * 2 <= want)
+      k_splits = (int)std::min<int64_t>(it->n_tables, want / std::max<int64_t>(1, blocks));
     k_splits = std::max(1, env_int("TC_KSPLITS", k_splits));
     k_splits = std::min(k_splits, it->n_tables);
   }
-  n_chunks = env_int("TC_NCHUNKS", (int)n_chunks);
-  waves = (int)std::min<int64_t>(waves, n_chunks);
-  DeviceChunking* c = nullptr;
-  {
-    auto key = std::make_pair((int)n_chunks, waves);
-    auto found = it->chunkings.find(key);
-    if (found == it->chunkings.end()) {
-      std::unique_ptr<DeviceChunking> fresh(new DeviceChunking);
-      tc::build_chunking(t0->plan, (int)n_chunks, waves, fresh->host);
-      status = upload(fresh->host.chunks, &fresh->chunks);
-      if (status == TC_OK) status = upload(fresh->host.groups, &fresh->groups);
-      if (status != TC_OK) return status;
-      c = fresh.get();
-      it->chunkings[key] = std::move(fresh);
-    } else {
-      c = found->second.get();
-    }
-  }
-  int span = 1;
-  while (span < c->host.waves_per_group) span <<= 1;
-  const int lds = std::max(c->host.max_rows, (span / 2) * t0->rt) * 64 * 8;
   if (lds > kMaxLdsBytes)
     return fail(TC_ERR_UNSUPPORTED, "table with %d bins needs %d bytes of LDS",
                 t0->n_bins, lds);
@@ -1071,6 +1093,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   ca.n_central = t0->plan.n_central;
   ca.r_stride = r_stride;
   ca.debug = 0;
+  ca.trace = nullptr;
   ca.partial = (double*)it->partial.ptr;
   ca.n_tables = it->n_tables;
   ca.k_splits = k_splits;

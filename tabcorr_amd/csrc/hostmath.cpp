@@ -288,23 +288,42 @@ void build_chunking(const Plan& plan, int n_chunks, int waves_per_group,
     group.chunk_begin = (int32_t)begin;
     group.n_chunks = (int32_t)(end - begin);
     group.component = comp;
-    group.pad0 = group.pad1 = group.pad2 = 0;
-    int lo = plan.n_bins, hi = 0;
+    int j_lo = plan.n_bins, j_hi = 0, i_lo = plan.n_bins, i_hi = 0;
     for (int k = 0; k < group.n_chunks; ++k) {
       const Chunk& chunk = out.chunks[begin + k];
       for (int32_t q = chunk.q_begin; q < chunk.q_begin + chunk.n_real; ++q) {
-        lo = std::min(lo, plan.pos_j[q]);
-        hi = std::max(hi, plan.pos_j[q] + 1);
+        j_lo = std::min(j_lo, plan.pos_j[q]);
+        j_hi = std::max(j_hi, plan.pos_j[q] + 1);
         if (plan.pos_i[q] >= 0) {
-          lo = std::min(lo, plan.pos_i[q]);
-          hi = std::max(hi, plan.pos_i[q] + 1);
+          i_lo = std::min(i_lo, plan.pos_i[q]);
+          i_hi = std::max(i_hi, plan.pos_i[q] + 1);
         }
       }
     }
-    if (hi < lo) { lo = 0; hi = 0; }
-    group.row_lo = lo;
-    group.row_hi = hi;
-    out.max_rows = std::max(out.max_rows, hi - lo);
+    if (j_hi < j_lo) { j_lo = 0; j_hi = 0; }
+    group.j_lo = j_lo;
+    group.j_hi = j_hi;
+    int rows = j_hi - j_lo;
+    if (i_hi <= i_lo) {                       // mode cross: no row bins
+      group.i_lo = group.i_hi = 0;
+      group.i_shift = 0;
+    } else if (i_lo >= j_lo && i_hi <= j_hi) {  // row bins are among the columns
+      group.i_lo = group.i_hi = i_lo;
+      group.i_shift = -j_lo;
+    } else if (i_lo < j_hi && i_hi > j_lo) {  // overlapping: stage the union once
+      const int lo = std::min(i_lo, j_lo), hi = std::max(i_hi, j_hi);
+      group.j_lo = lo;
+      group.j_hi = hi;
+      group.i_lo = group.i_hi = i_lo;
+      group.i_shift = -lo;
+      rows = hi - lo;
+    } else {                                  // disjoint: second region
+      group.i_lo = i_lo;
+      group.i_hi = i_hi;
+      group.i_shift = (j_hi - j_lo) - i_lo;
+      rows += i_hi - i_lo;
+    }
+    out.max_rows = std::max(out.max_rows, rows);
     out.groups.push_back(group);
     begin = end;
   }

@@ -44,15 +44,19 @@ struct Chunk {
   int32_t pad1;
 };
 
-// The work of one workgroup: chunks [chunk_begin, chunk_begin + n_chunks) and
-// the rows [row_lo, row_hi) of the per-draw number densities it stages in LDS.
+// The work of one workgroup: chunks [chunk_begin, chunk_begin + n_chunks), all of one
+// component, and the rows of the per-draw number densities it stages in LDS: the
+// column bins [j_lo, j_hi) first and, unless they lie inside that range, the row bins
+// [i_lo, i_hi) behind them; bin i is found at LDS row i + i_shift.
 struct Group {
   int32_t chunk_begin;
   int32_t n_chunks;
-  int32_t row_lo;
-  int32_t row_hi;
-  int32_t component;   // all chunks of a group belong to one component
-  int32_t pad0, pad1, pad2;
+  int32_t j_lo;
+  int32_t j_hi;
+  int32_t component;
+  int32_t i_lo;
+  int32_t i_hi;        // i_hi == i_lo: nothing staged separately
+  int32_t i_shift;
 };
 
 struct Plan {
@@ -77,7 +81,7 @@ struct Chunking {
   int waves_per_group = 0;
   std::vector<Chunk> chunks;
   std::vector<Group> groups;
-  int max_rows = 0;              // max over groups of row_hi - row_lo
+  int max_rows = 0;              // max over groups of the LDS rows staged
 };
 
 // Entries per aligned block for an r tile of width rt: EB * rt % 16 == 0.

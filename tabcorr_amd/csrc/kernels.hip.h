@@ -214,6 +214,7 @@ struct ContractArgs {
   int n_central;
   int r_stride;             // n_rtiles * RT: padded number of r values
   int debug;                // developer ablations (TC_DEBUG_VARIANT), 0 in production
+  unsigned long long* trace;  // developer timeline (TC_TRACE): 6 words per block, or NULL
   double* partial;          // (n_groups * k_splits, r_stride, ldb)
   // Interpolator: the block loops over tables [k_begin, k_end) of its k split and
   // accumulates coef[k][draw] * (table k contraction) into the same registers.
@@ -253,7 +254,7 @@ __device__ __forceinline__ void entry_fma(
 
 // Per-wave walk state over the entries of one component.
 struct WalkState {
-  int i, j, remaining, row_lo, mode, component, n_central, debug;
+  int i, j, remaining, row_lo, i_shift, mode, component, n_central, debug;
   double ni;      // density of row i times `scale`
   double scale;   // per-draw weight of the current table (1 without interpolation)
 };
@@ -274,7 +275,7 @@ __device__ __forceinline__ void block_entry(
       if (++st.j > j_hi) {
         ++st.i;
         st.j = st.component == 2 ? st.n_central : 0;
-        st.ni = lds[(st.i - st.row_lo) * kLanes + lane] * st.scale;
+        st.ni = lds[(st.i + st.i_shift) * kLanes + lane] * st.scale;
       }
     }
   }
@@ -308,9 +309,12 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
   const int64_t col = (int64_t)blockIdx.x * kLanes;
 
   constexpr bool interp = INTERP;
+  unsigned long long t_start = 0, t_staged = 0, t_main = 0, c_staged = 0, c_main = 0;
+  if (a.trace) t_start = __builtin_amdgcn_s_memrealtime();
   const int k_splits = interp ? a.k_splits : 1;
   const Group group = a.groups[blockIdx.y / k_splits];
-  const int n_rows = group.row_hi - group.row_lo;
+  const int n_rows_j = group.j_hi - group.j_lo;
+  const int n_rows = n_rows_j + (group.i_hi - group.i_lo);
   int k_begin = 0, k_end = 1;
   if (interp) {
     const int split = blockIdx.y % k_splits;
@@ -327,22 +331,23 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
     const int density_class = interp ? a.table_class[k] : 0;
     if (density_class != staged_class) {
       if (staged_class >= 0) __syncthreads();   // everyone is done with the old rows
-      // stage rows [row_lo, row_hi) of this draw tile: 16 bytes per lane, four
-      // independent loads in flight per thread
+      // stage the column bins [j_lo, j_hi) and, behind them, the row bins [i_lo, i_hi)
+      // of this draw tile: 16 bytes per lane, four independent loads in flight
       typedef double __attribute__((ext_vector_type(2))) double2v;
+      typedef const __attribute__((address_space(1))) double2v* gl_f64x2;
       const int n_items = n_rows * (kLanes / 2);
-      gl_f64 src = (gl_f64)(interp ? a.nbufs[density_class] : a.nbuf) +
-                   (int64_t)group.row_lo * a.ldb + col;
+      gl_f64 src = (gl_f64)(interp ? a.nbufs[density_class] : a.nbuf) + col;
+      auto source = [&](int id) {
+        const int row = id >> 5;
+        const int bin = row < n_rows_j ? group.j_lo + row : group.i_lo + row - n_rows_j;
+        return (gl_f64x2)(src + (int64_t)bin * a.ldb + (id & 31) * 2);
+      };
       const int nthreads = blockDim.x;
       int it = (a.debug & 8) ? n_items : threadIdx.x;
       for (; it + 3 * nthreads < n_items; it += 4 * nthreads) {
         double2v v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int id = it + u * nthreads;
-          v[u] = *(const __attribute__((address_space(1))) double2v*)(
-              src + (int64_t)(id >> 5) * a.ldb + (id & 31) * 2);
-        }
+        for (int u = 0; u < 4; ++u) v[u] = *source(it + u * nthreads);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int id = it + u * nthreads;
@@ -350,11 +355,13 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
         }
       }
       for (; it < n_items; it += nthreads)
-        *(double2v*)(lds + (it >> 5) * kLanes + (it & 31) * 2) =
-            *(const __attribute__((address_space(1))) double2v*)(
-                src + (int64_t)(it >> 5) * a.ldb + (it & 31) * 2);
+        *(double2v*)(lds + (it >> 5) * kLanes + (it & 31) * 2) = *source(it);
       __syncthreads();
       staged_class = density_class;
+      if (a.trace) {
+        t_staged = __builtin_amdgcn_s_memrealtime();
+        c_staged = __builtin_amdgcn_s_memtime();
+      }
     }
 
     if (wave < group.n_chunks) {
@@ -363,14 +370,15 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
       st.i = chunk.i0;
       st.j = chunk.j0;
       st.remaining = chunk.n_real;
-      st.row_lo = group.row_lo;
+      st.row_lo = group.j_lo;
+      st.i_shift = group.i_shift;
       st.mode = a.mode;
       st.component = chunk.component;
       st.n_central = a.n_central;
       st.debug = a.debug;
       st.scale = interp ? a.coef[(int64_t)k * a.ldb + col + lane] : 1.0;
       st.ni = a.mode == 0
-                  ? lds[(chunk.i0 - group.row_lo) * kLanes + lane] * st.scale
+                  ? lds[(chunk.i0 + group.i_shift) * kLanes + lane] * st.scale
                   : st.scale;
 
       gl_f64 table = (gl_f64)(interp ? a.tables[k] : (const double*)a.table) +
@@ -400,6 +408,10 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
         block_compute<RT>(acc, ta, st, lds, lane, std::make_integer_sequence<int, EB>());
     }
   }
+  if (a.trace) {
+    t_main = __builtin_amdgcn_s_memrealtime();
+    c_main = __builtin_amdgcn_s_memtime();
+  }
   __syncthreads();  // the staged densities are dead; reuse LDS for the sums
 
   // Deterministic tree reduction over the waves of the block (all of one
@@ -427,6 +439,18 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
                       a.ldb + col + lane;
 #pragma unroll
     for (int r = 0; r < RT; ++r) out[(int64_t)r * a.ldb] = acc[r];
+  }
+  if (a.trace && threadIdx.x == 0) {
+    const unsigned long long block =
+        blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    unsigned long long* rec = a.trace + 6 * block;
+    rec[0] = t_start;
+    rec[1] = t_staged;
+    rec[2] = t_main;
+    rec[3] = __builtin_amdgcn_s_memrealtime();
+    rec[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+    rec[5] = (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf) |
+             ((c_main - c_staged) << 4);   // XCC_ID, shader cycles of the main loop
   }
 }
 

@@ -93,3 +93,9 @@ if __name__ == '__main__':
                     run(50, 1, (19, ), 10000, 20, 'tw=%d nw=%d lds=%d debug=%d' % (tw, nw, lds, dbg))
     elif which == 'stats':
         run(50, 1, (19, ), 10000, 200, 'cfg2 default')
+    elif which == 'groups':
+        for nw in [4, 8]:
+            for ng in [0, 4, 6, 8, 10, 12, 16]:
+                os.environ['TC_NWAVES'] = str(nw)
+                os.environ['TC_NGROUPS'] = str(ng)
+                run(50, 1, (19, ), 10000, 50, 'cfg2 nw=%d ngroups=%d' % (nw, ng))
