@@ -352,7 +352,10 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   ca.coef = nullptr;
   ca.partial = (double*)t->partial.ptr;
 
-  dim3 grid((unsigned)(ldb / 64), (unsigned)n_groups, (unsigned)t->n_rtiles);
+  const int n_tiles = (int)(ldb / 64);
+  ca.n_tiles = n_tiles;
+  ca.n_slabs = n_groups;
+  dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * n_groups), 1, (unsigned)t->n_rtiles);
   dim3 block(64 * c->host.waves_per_group);
   if (lds > 64 * 1024) {
     status = set_lds_limit_rt(t->rt, lds);
@@ -374,7 +377,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   status = launch_contract_rt(t->rt, grid, block, lds, t->stream, ca);
   if (status != TC_OK) return status;
   if (t->profile_kernels) TC_HIP(hipEventRecord(k1, t->stream));
-  t->last_workgroups = (int)(grid.x * grid.y * grid.z);
+  t->last_workgroups = n_tiles * n_groups * t->n_rtiles;
   t->last_waves = c->host.waves_per_group;
   t->last_splits = n_groups;
   t->last_lds = lds;
@@ -599,7 +602,7 @@ int tc_plan_debug(int mode, int n_bins, const uint8_t* is_central, int n_chunks,
   TC_CHECK(mode == TC_MODE_AUTO || mode == TC_MODE_CROSS, "invalid mode");
   TC_CHECK(n_bins >= 1 && is_central && n_entries, "invalid arguments");
   tc::Plan plan;
-  tc::build_plan(mode, n_bins, is_central, 4, plan);
+  tc::build_plan(mode, n_bins, is_central, 4, env_int("TC_ROW_BUDGET", 56), plan);
   tc::Chunking chunking;
   tc::build_chunking(plan, n_chunks, 8, chunking);
   *n_entries = plan.n_entries;
@@ -626,7 +629,7 @@ int tc_plan_debug(int mode, int n_bins, const uint8_t* is_central, int n_chunks,
         entry_class[e] = chunk.component;
         ++e;
       }
-      if (--remaining > 0) tc::advance_pair(mode, chunk.component, plan.n_central, i, j);
+      if (--remaining > 0) tc::advance_pair(chunk.j_lo, chunk.j_last, i, j);
     }
   }
   for (int64_t q = 0; q < plan.n_positions; ++q)
@@ -679,7 +682,8 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
     int rt = (n_r + t->n_rtiles - 1) / t->n_rtiles;
     t->rt = (rt + 3) / 4 * 4;
   }
-  tc::build_plan(mode, n_bins, is_central, tc::block_entries(t->rt), t->plan);
+  tc::build_plan(mode, n_bins, is_central, tc::block_entries(t->rt),
+                 env_int("TC_ROW_BUDGET", 56), t->plan);
 
   for (int g = 0; g < n_bins; ++g) {
     const int src = t->plan.perm[g];
@@ -1101,7 +1105,10 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   ca.nbufs = (const double* const*)it->d_nbufs;
   ca.table_class = (const int32_t*)it->d_table_class;
   ca.coef = (const double*)it->coef.ptr;
-  dim3 grid((unsigned)n_tiles, (unsigned)(n_groups * k_splits), (unsigned)t0->n_rtiles);
+  ca.n_tiles = (int)n_tiles;
+  ca.n_slabs = n_groups * k_splits;
+  dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * n_groups * k_splits), 1,
+            (unsigned)t0->n_rtiles);
   dim3 block(64 * c->host.waves_per_group);
   if (lds > 64 * 1024) {
     status = set_lds_limit_rt(t0->rt, lds);

@@ -178,8 +178,46 @@ int block_entries(int rt) {
   return 16 / g;   // g = gcd(rt, 16)
 }
 
+namespace {
+
+void add_triangle(std::vector<Segment>& out, int component, int lo, int hi, int budget) {
+  // rows [lo, hi), columns [lo, i]: diagonal triangles of `side` rows plus the
+  // rectangles left of them
+  const int n = hi - lo;
+  if (n <= 0) return;
+  const int pieces = (n + budget - 1) / budget;           // whole triangle if it fits
+  const int side = pieces == 1 ? n : std::max(1, std::min(n, budget / 2));
+  for (int a = lo; a < hi; a += side) {
+    const int b = std::min(hi, a + side);
+    for (int c = lo; c < a; c += side)
+      out.push_back({component, 1, a, b, c, std::min(a, c + side), 0, 0});
+    out.push_back({component, 0, a, b, a, b, 0, 0});
+  }
+}
+
+void add_rectangle(std::vector<Segment>& out, int component, int i_lo, int i_hi,
+                   int j_lo, int j_hi, int budget) {
+  const int n_i = i_hi - i_lo, n_j = j_hi - j_lo;
+  if (n_i <= 0 || n_j <= 0) return;
+  // equal column blocks of at most budget / 2 bins (the other half of the budget is
+  // left for the rows a workgroup covers); rows are cut by the chunking
+  const int width_max = std::max(1, budget / 2);
+  const int n_blocks = (n_j + width_max - 1) / width_max;
+  const int height_max = std::max(1, budget - (n_j + n_blocks - 1) / n_blocks);
+  for (int jb = 0; jb < n_blocks; ++jb) {
+    const int c0 = j_lo + (int)((int64_t)n_j * jb / n_blocks);
+    const int c1 = j_lo + (int)((int64_t)n_j * (jb + 1) / n_blocks);
+    // row blocks only when even a single row range would not fit (very many rows
+    // are handled by the chunking; a chunk never spans more than its rows)
+    (void)height_max;
+    out.push_back({component, 1, i_lo, i_hi, c0, c1, 0, 0});
+  }
+}
+
+}  // namespace
+
 void build_plan(int mode, int n_bins, const uint8_t* is_central, int block,
-                Plan& plan) {
+                int row_budget, Plan& plan) {
   plan.mode = mode;
   plan.n_bins = n_bins;
   plan.block = block;
@@ -191,30 +229,37 @@ void build_plan(int mode, int n_bins, const uint8_t* is_central, int block,
     if (!is_central[g]) plan.perm.push_back(g);
   const int gc = plan.n_central;
   plan.n_components = mode == 0 ? 3 : 2;
+  row_budget = std::max(row_budget, 4);
+
+  plan.segments.clear();
+  if (mode == 0) {
+    add_triangle(plan.segments, 0, 0, gc, row_budget);
+    add_rectangle(plan.segments, 1, gc, n_bins, 0, gc, row_budget);
+    add_triangle(plan.segments, 2, gc, n_bins, row_budget);
+  } else {
+    // one-row rectangles without a row bin; the chunking cuts them by columns
+    if (gc > 0) plan.segments.push_back({0, 1, -1, 0, 0, gc, 0, 0});
+    if (n_bins > gc) plan.segments.push_back({1, 1, -1, 0, gc, n_bins, 0, 0});
+  }
 
   plan.column.clear();
   plan.prefactor.clear();
   plan.pos_i.clear();
   plan.pos_j.clear();
-  plan.comp_begin.clear();
-  plan.comp_real.clear();
   plan.n_entries = 0;
-  for (int comp = 0; comp < plan.n_components; ++comp) {
-    plan.comp_begin.push_back((int64_t)plan.column.size());
-    // first pair of the component and number of real entries
-    int i, j;
-    int64_t n_real;
-    if (mode == 0) {
-      const int64_t gs = n_bins - gc;
-      if (comp == 0) { i = 0; j = 0; n_real = (int64_t)gc * (gc + 1) / 2; }
-      else if (comp == 1) { i = gc; j = 0; n_real = gs * gc; }
-      else { i = gc; j = gc; n_real = gs * (gs + 1) / 2; }
+  for (Segment& seg : plan.segments) {
+    seg.q_begin = (int64_t)plan.column.size();
+    const int j_last = seg.rectangular ? seg.j_hi - 1 : -1;
+    int64_t n_real = 0;
+    if (mode != 0) {
+      n_real = seg.j_hi - seg.j_lo;
+    } else if (seg.rectangular) {
+      n_real = (int64_t)(seg.i_hi - seg.i_lo) * (seg.j_hi - seg.j_lo);
     } else {
-      i = -1;
-      j = comp == 0 ? 0 : gc;
-      n_real = comp == 0 ? gc : n_bins - gc;
+      for (int i = seg.i_lo; i < seg.i_hi; ++i) n_real += i - seg.j_lo + 1;
     }
-    plan.comp_real.push_back(n_real);
+    seg.n_real = n_real;
+    int i = seg.i_lo, j = seg.j_lo;
     for (int64_t e = 0; e < n_real; ++e) {
       if (mode == 0) {
         const int a = plan.perm[i], b = plan.perm[j];
@@ -226,7 +271,9 @@ void build_plan(int mode, int n_bins, const uint8_t* is_central, int block,
       }
       plan.pos_i.push_back(i);
       plan.pos_j.push_back(j);
-      if (e + 1 < n_real) advance_pair(mode, comp, gc, i, j);
+      if (e + 1 < n_real) {
+        if (mode != 0) ++j; else advance_pair(seg.j_lo, j_last, i, j);
+      }
     }
     // zero padding: frozen on the last real pair (any valid pair would do)
     const int64_t padded = (n_real + block - 1) / block * block;
@@ -238,7 +285,6 @@ void build_plan(int mode, int n_bins, const uint8_t* is_central, int block,
     }
     plan.n_entries += n_real;
   }
-  plan.comp_begin.push_back((int64_t)plan.column.size());
   plan.n_positions = (int64_t)plan.column.size();
 }
 
@@ -252,11 +298,13 @@ void build_chunking(const Plan& plan, int n_chunks, int waves_per_group,
   const int64_t total = std::max<int64_t>(1, plan.n_entries);
   const int eb = plan.block;
 
-  for (int c = 0; c < plan.n_components; ++c) {
-    const int64_t n_real = plan.comp_real[c];
+  std::vector<int> chunk_segment;
+  for (size_t si = 0; si < plan.segments.size(); ++si) {
+    const Segment& seg = plan.segments[si];
+    const int64_t n_real = seg.n_real;
     if (n_real == 0) continue;
     const int64_t n_blocks = (n_real + eb - 1) / eb;
-    // chunks of this component, proportional to its share of the entries
+    // chunks of this segment, proportional to its share of the entries
     int64_t nc = (n_real * n_chunks + total / 2) / total;
     // full workgroups: a multiple of waves_per_group where there are several
     if (nc > waves_per_group)
@@ -265,29 +313,32 @@ void build_chunking(const Plan& plan, int n_chunks, int waves_per_group,
     for (int64_t k = 0; k < nc; ++k) {
       const int64_t b0 = n_blocks * k / nc, b1 = n_blocks * (k + 1) / nc;
       Chunk chunk;
-      chunk.q_begin = (int32_t)(plan.comp_begin[c] + b0 * eb);
-      chunk.q_end = (int32_t)(plan.comp_begin[c] + b1 * eb);
+      chunk.q_begin = (int32_t)(seg.q_begin + b0 * eb);
+      chunk.q_end = (int32_t)(seg.q_begin + b1 * eb);
       chunk.n_real = (int32_t)(std::min<int64_t>(n_real, b1 * eb) - b0 * eb);
       chunk.i0 = plan.pos_i[chunk.q_begin];
       chunk.j0 = plan.pos_j[chunk.q_begin];
-      chunk.component = c;
-      chunk.pad0 = chunk.pad1 = 0;
+      chunk.component = seg.component;
+      chunk.j_lo = seg.j_lo;
+      chunk.j_last = plan.mode != 0 ? 0x7fffffff
+                                    : (seg.rectangular ? seg.j_hi - 1 : -1);
       out.chunks.push_back(chunk);
+      chunk_segment.push_back((int)si);
     }
   }
 
-  // workgroups: waves_per_group consecutive chunks of ONE component
+  // workgroups: waves_per_group consecutive chunks of ONE segment
   size_t begin = 0;
   while (begin < out.chunks.size()) {
-    const int comp = out.chunks[begin].component;
+    const int seg = chunk_segment[begin];
     size_t end = begin;
     while (end < out.chunks.size() && end - begin < (size_t)waves_per_group &&
-           out.chunks[end].component == comp)
+           chunk_segment[end] == seg)
       ++end;
     Group group;
     group.chunk_begin = (int32_t)begin;
     group.n_chunks = (int32_t)(end - begin);
-    group.component = comp;
+    group.component = plan.segments[seg].component;
     int j_lo = plan.n_bins, j_hi = 0, i_lo = plan.n_bins, i_hi = 0;
     for (int k = 0; k < group.n_chunks; ++k) {
       const Chunk& chunk = out.chunks[begin + k];

@@ -24,15 +24,29 @@ inline int64_t packed_index(int64_t i, int64_t j) {
 // false if the linear system is singular (repeated abscissae).
 bool spline_interpolation_matrix(int n, const double* xp, std::vector<double>& a);
 
-// The contraction walks the table in "positions": per component the real
-// entries (packed pairs in row-major order) followed by zero padding up to a
-// multiple of the block size EB, so that every block of EB entries starts on a
-// 128-byte boundary of the re-laid-out table.
+// The contraction walks the table in "positions".  The packed pairs are cut into
+// SEGMENTS, each belonging to one output component (0 cen-cen | cen, 1 cen-sat | sat,
+// 2 sat-sat) and shaped either as a triangle (rows i in [i_lo, i_hi), columns j in
+// [j_lo, i]) or as a rectangle (rows [i_lo, i_hi) x columns [j_lo, j_hi)); mode cross
+// uses one-row "rectangles" without a row bin (i = -1).  Segments are sized so that the
+// density rows a workgroup has to stage (its column range plus its row range) fit in
+// LDS, which also lifts any limit on the number of bins.  Inside a segment the entries
+// are row-major and are followed by zero padding up to a multiple of the block size EB,
+// so that every block of EB entries starts on a 128-byte boundary of the re-laid-out
+// table.
+struct Segment {
+  int32_t component;
+  int32_t rectangular;   // 0: triangle (row i ends at column i), 1: rectangle
+  int32_t i_lo, i_hi;    // row bins (library order); i_lo = -1 in mode cross
+  int32_t j_lo, j_hi;    // column bins [j_lo, j_hi) (triangle: j_hi unused)
+  int64_t q_begin;       // first position
+  int64_t n_real;        // entries before the padding
+};
 
-// The work of one wavefront: positions [q_begin, q_end) of one component
-// (0 cen-cen | cen, 1 cen-sat | sat, 2 sat-sat), of which the first n_real are
-// real entries; (i0, j0) is the bin pair of position q_begin in the library's
-// bin order (centrals first).  Mode cross has i0 = -1.
+// The work of one wavefront: positions [q_begin, q_end) of one segment, of which the
+// first n_real are real entries; (i0, j0) is the bin pair of position q_begin.  The
+// walk steps j -> j + 1 and wraps to (i + 1, j_lo) after column `j_last` (rectangle)
+// or after the diagonal (j_last < 0).
 struct Chunk {
   int32_t q_begin;
   int32_t q_end;
@@ -40,12 +54,12 @@ struct Chunk {
   int32_t i0;
   int32_t j0;
   int32_t component;
-  int32_t pad0;
-  int32_t pad1;
+  int32_t j_lo;
+  int32_t j_last;
 };
 
 // The work of one workgroup: chunks [chunk_begin, chunk_begin + n_chunks), all of one
-// component, and the rows of the per-draw number densities it stages in LDS: the
+// segment, and the rows of the per-draw number densities it stages in LDS: the
 // column bins [j_lo, j_hi) first and, unless they lie inside that range, the row bins
 // [i_lo, i_hi) behind them; bin i is found at LDS row i + i_shift.
 struct Group {
@@ -66,15 +80,14 @@ struct Plan {
   int n_components = 0;          // 3 (auto) or 2 (cross)
   int block = 1;                 // EB: entries per 128-byte aligned block
   int64_t n_entries = 0;         // = P
-  int64_t n_positions = 0;       // padded, multiple of EB per component
+  int64_t n_positions = 0;       // padded, multiple of EB per segment
   std::vector<int32_t> perm;     // library bin g' -> reference row
+  std::vector<Segment> segments;
   // Position order of the re-laid-out table: reference column (-1 = padding),
   // prefactor and bin pair (library order).
   std::vector<int64_t> column;
   std::vector<int8_t> prefactor;
   std::vector<int32_t> pos_i, pos_j;
-  std::vector<int64_t> comp_begin;  // first position of each component (+ end)
-  std::vector<int64_t> comp_real;   // real entries of each component
 };
 
 struct Chunking {
@@ -87,27 +100,24 @@ struct Chunking {
 // Entries per aligned block for an r tile of width rt: EB * rt % 16 == 0.
 int block_entries(int rt);
 
-// Bin permutation (stable sort, centrals first) and position order.
+// Bin permutation (stable sort, centrals first), segmentation (no workgroup will need
+// more than about `row_budget` density rows) and position order.
 void build_plan(int mode, int n_bins, const uint8_t* is_central, int block,
-                Plan& plan);
+                int row_budget, Plan& plan);
 
 // Cut the positions into about n_chunks wave-sized chunks (multiples of the
-// block size, never mixing components) and pack them waves_per_group at a
+// block size, never crossing a segment) and pack them waves_per_group at a
 // time into workgroups.
 void build_chunking(const Plan& plan, int n_chunks, int waves_per_group,
                     Chunking& out);
 
-// The rule by which the kernel steps from one entry to the next inside a
-// component (shared by the kernel, the planner and the CPU tests).
-inline void advance_pair(int mode, int component, int n_central, int& i, int& j) {
-  if (mode != 0) {
-    ++j;
-    return;
-  }
-  const int j_hi = component == 1 ? n_central - 1 : i;
-  if (++j > j_hi) {
+// The rule by which the kernel steps from one entry to the next inside a segment
+// (shared by the kernel, the planner and the CPU tests).
+inline void advance_pair(int j_lo, int j_last, int& i, int& j) {
+  const int last = j_last >= 0 ? j_last : i;
+  if (++j > last) {
     ++i;
-    j = component == 2 ? n_central : 0;
+    j = j_lo;
   }
 }
 

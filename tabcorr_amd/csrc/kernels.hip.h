@@ -214,6 +214,8 @@ struct ContractArgs {
   int n_central;
   int r_stride;             // n_rtiles * RT: padded number of r values
   int debug;                // developer ablations (TC_DEBUG_VARIANT), 0 in production
+  int n_tiles;              // draw tiles (grid.x covers 8 * ceil(n_tiles / 8) * slabs)
+  int n_slabs;              // groups * table splits per draw tile
   unsigned long long* trace;  // developer timeline (TC_TRACE): 6 words per block, or NULL
   double* partial;          // (n_groups * k_splits, r_stride, ldb)
   // Interpolator: the block loops over tables [k_begin, k_end) of its k split and
@@ -254,7 +256,7 @@ __device__ __forceinline__ void entry_fma(
 
 // Per-wave walk state over the entries of one component.
 struct WalkState {
-  int i, j, remaining, row_lo, i_shift, mode, component, n_central, debug;
+  int i, j, remaining, row_lo, i_shift, j_lo, j_last, debug;
   double ni;      // density of row i times `scale`
   double scale;   // per-draw weight of the current table (1 without interpolation)
 };
@@ -268,15 +270,11 @@ __device__ __forceinline__ void block_entry(
   entry_fma<RT, E>(acc, t, w, std::make_integer_sequence<int, RT>());
   // step to the next real entry (padding keeps the last real pair)
   if (!(st.debug & 32) && --st.remaining > 0) {
-    if (st.mode != 0) {
-      ++st.j;
-    } else {
-      const int j_hi = st.component == 1 ? st.n_central - 1 : st.i;
-      if (++st.j > j_hi) {
-        ++st.i;
-        st.j = st.component == 2 ? st.n_central : 0;
-        st.ni = lds[(st.i + st.i_shift) * kLanes + lane] * st.scale;
-      }
+    const int last = st.j_last >= 0 ? st.j_last : st.i;
+    if (++st.j > last) {
+      ++st.i;
+      st.j = st.j_lo;
+      st.ni = lds[(st.i + st.i_shift) * kLanes + lane] * st.scale;
     }
   }
 }
@@ -306,18 +304,27 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_waves = blockDim.x >> 6;
-  const int64_t col = (int64_t)blockIdx.x * kLanes;
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with its
+  // own L2), so linear id b runs on XCD b % 8.  All slabs (groups x table splits) of a
+  // draw tile are given ids with the same b % 8, next to each other in dispatch order:
+  // the tile's density rows, re-read by every slab, then come from that XCD's L2.
+  const int xcd = blockIdx.x & 7;
+  const int rest = blockIdx.x >> 3;
+  const int tile = (rest / a.n_slabs) * 8 + xcd;
+  const int slab = rest % a.n_slabs;
+  if (tile >= a.n_tiles) return;
+  const int64_t col = (int64_t)tile * kLanes;
 
   constexpr bool interp = INTERP;
   unsigned long long t_start = 0, t_staged = 0, t_main = 0, c_staged = 0, c_main = 0;
   if (a.trace) t_start = __builtin_amdgcn_s_memrealtime();
   const int k_splits = interp ? a.k_splits : 1;
-  const Group group = a.groups[blockIdx.y / k_splits];
+  const Group group = a.groups[slab / k_splits];
   const int n_rows_j = group.j_hi - group.j_lo;
   const int n_rows = n_rows_j + (group.i_hi - group.i_lo);
   int k_begin = 0, k_end = 1;
   if (interp) {
-    const int split = blockIdx.y % k_splits;
+    const int split = slab % k_splits;
     k_begin = (int)((int64_t)a.n_tables * split / k_splits);
     k_end = (int)((int64_t)a.n_tables * (split + 1) / k_splits);
   }
@@ -372,9 +379,8 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
       st.remaining = chunk.n_real;
       st.row_lo = group.j_lo;
       st.i_shift = group.i_shift;
-      st.mode = a.mode;
-      st.component = chunk.component;
-      st.n_central = a.n_central;
+      st.j_lo = chunk.j_lo;
+      st.j_last = chunk.j_last;
       st.debug = a.debug;
       st.scale = interp ? a.coef[(int64_t)k * a.ldb + col + lane] : 1.0;
       st.ni = a.mode == 0
@@ -435,14 +441,14 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
   }
   if (wave == 0) {
     double* out = a.partial +
-                  ((int64_t)blockIdx.y * a.r_stride + (int64_t)blockIdx.z * RT) *
-                      a.ldb + col + lane;
+                  ((int64_t)slab * a.r_stride + (int64_t)blockIdx.z * RT) * a.ldb + col +
+                  lane;
 #pragma unroll
     for (int r = 0; r < RT; ++r) out[(int64_t)r * a.ldb] = acc[r];
   }
   if (a.trace && threadIdx.x == 0) {
     const unsigned long long block =
-        blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        tile + (unsigned long long)a.n_tiles * (slab + a.n_slabs * blockIdx.z);
     unsigned long long* rec = a.trace + 6 * block;
     rec[0] = t_start;
     rec[1] = t_staged;
