@@ -1,0 +1,175 @@
+"""BASELINE.json configurations at full size on the GPU: spot checks against the CPU
+oracle on a few draws plus size-independent properties (components sum to the total,
+linearity in the table, interpolation reproduces the tables at grid nodes, batch
+splitting / ordering invariance)."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+from util import assert_rel  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+
+
+def make(table, **kwargs):
+    from tabcorr_amd import TabCorr
+    return TabCorr.from_arrays(table['gal_type'], table['tpcf_matrix'],
+                               table['tpcf_shape'], table['attrs'], **kwargs)
+
+
+def oracle_check(table, theta, ngal, xi, index, **kwargs):
+    from oracle import tabcorr_oracle as oracle
+    expect = oracle.predict_zheng07_batch(table, theta[index], **kwargs)
+    assert_rel(ngal[index], expect[0], RTOL)
+    assert_rel(xi[index], expect[1], RTOL)
+
+
+def test_config2_batch_of_1e4():
+    from tabcorr_amd import synthetic
+    table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    theta = synthetic.zheng07_draws(10000, seed=1)
+    halotab = make(table)
+    ngal, xi = halotab.predict_batch(theta)
+    assert ngal.shape == (10000, ) and xi.shape == (10000, 19)
+    assert np.all(np.isfinite(xi)) and np.all(ngal > 0)
+    index = np.r_[0:6, 4093:4099, 9994:10000]
+    oracle_check(table, theta, ngal, xi, index)
+
+    ngal_sep, xi_sep = halotab.predict_batch(theta, separate_gal_type=True)
+    assert_rel(sum(ngal_sep.values()), ngal, 1e-13)
+    assert_rel(sum(xi_sep.values()), xi, 1e-12)
+
+    # deterministic: same bits on a second call; order / splitting invariance
+    ngal2, xi2 = halotab.predict_batch(theta)
+    assert np.array_equal(xi, xi2) and np.array_equal(ngal, ngal2)
+    perm = np.random.default_rng(0).permutation(len(theta))
+    ngal3, xi3 = halotab.predict_batch(theta[perm])
+    assert np.array_equal(xi3, xi[perm])
+    ngal4, xi4 = halotab.predict_batch(theta[:777])
+    assert_rel(xi4, xi[:777], 1e-13)
+
+    # linearity in the table: xi is linear in tpcf_matrix, ngal independent of it
+    doubled = dict(table)
+    doubled['tpcf_matrix'] = 2.0 * table['tpcf_matrix']
+    ngal5, xi5 = make(doubled).predict_batch(theta)
+    assert np.array_equal(ngal5, ngal)
+    assert np.array_equal(xi5, 2.0 * xi)      # same decomposition: bit-exact
+    ngal6, xi6 = make(doubled).predict_batch(theta[:2000])
+    assert_rel(ngal6, ngal[:2000], 1e-14)     # other batch size: other summation order
+    assert_rel(xi6, 2.0 * xi[:2000], 1e-13)
+
+
+def test_config3_separate_gal_type_assembias():
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(50, 2, (19, ), 'auto', seed=3)
+    theta = synthetic.zheng07_draws(10000, seed=2)
+    rng = np.random.default_rng(4)
+    theta7 = np.hstack([theta, rng.uniform(-1, 1, size=(len(theta), 2))])
+    halotab = make(table)
+    ngal, xi = halotab.predict_batch(theta7, assembias=True)
+    ngal_sep, xi_sep = halotab.predict_batch(theta7, assembias=True,
+                                             separate_gal_type=True)
+    assert list(xi_sep) == ['centrals-centrals', 'centrals-satellites',
+                            'satellites-satellites']
+    assert_rel(sum(ngal_sep.values()), ngal, 1e-13)
+    assert_rel(sum(xi_sep.values()), xi, 1e-12)
+    index = np.r_[0:4, 5000:5003, 9997:10000]
+    expect = oracle.predict_zheng07_batch(table, theta[index],
+                                          assembias=theta7[index, 5:])
+    assert_rel(ngal[index], expect[0], RTOL)
+    assert_rel(xi[index], expect[1], RTOL)
+    expect = oracle.predict_zheng07_batch(
+        table, theta[index], assembias=theta7[index, 5:],
+        separate_gal_type=True)
+    for key in xi_sep:
+        assert_rel(xi_sep[key][index], expect[1][key], RTOL, key)
+    # zero assembly bias strength = plain Zheng07
+    plain = halotab.predict_batch(theta[:500])
+    zero = halotab.predict_batch(np.hstack([theta[:500], np.zeros((500, 2))]),
+                                 assembias=True)
+    assert_rel(zero[1], plain[1], 1e-13)
+
+
+def test_config4_interpolator_5x5():
+    from tabcorr_amd import Interpolator, synthetic
+    from oracle import tabcorr_oracle as oracle
+    tables, keys, points = synthetic.synthetic_interpolator(
+        (5, 5), 50, 1, (19, ), 'auto', seed=7)
+    halotabs = [make(t) for t in tables]
+    interp = Interpolator(halotabs, {k: points[:, d] for d, k in
+                                     enumerate(keys)})
+    n_draws = 12500          # one GPU's share of the 10^5 draws of config 4
+    theta = synthetic.zheng07_draws(n_draws, seed=5)
+    rng = np.random.default_rng(6)
+    x = np.stack([rng.uniform(xp[0], xp[-1], size=n_draws)
+                  for xp in interp.xp], axis=-1)
+    # the first 25 draws sit exactly on the grid nodes
+    x[:25] = points
+    ngal, xi = interp.predict_batch(theta, x)
+    assert xi.shape == (n_draws, 19) and np.all(np.isfinite(xi))
+    for k in [0, 7, 24]:
+        single = halotabs[k].predict_batch(theta[k:k + 1])
+        assert_rel(ngal[k], single[0][0], 1e-11)
+        assert_rel(xi[k], single[1][0], 1e-11)
+    setup = oracle.interpolator_setup(tables, points)
+    index = [30, 6000, n_draws - 1]
+    expect = oracle.interpolator_predict_zheng07_batch(
+        tables, setup, theta[index], x[index])
+    assert_rel(ngal[index], expect[0], RTOL)
+    assert_rel(xi[index], expect[1], RTOL)
+    ngal_sep, xi_sep = interp.predict_batch(theta[:3000], x[:3000],
+                                            separate_gal_type=True)
+    assert_rel(sum(xi_sep.values()), xi[:3000], 1e-11)
+
+
+def test_config5_rp_pi_table_float64():
+    """AbacusSummit-scale table: 100 mass bins x {cen, sat}, tpcf_shape (19, 40);
+    R = 760 exercises the r tiling.  (The float32 variant of configs[4] is not built
+    yet; float64 is the stricter computation.)"""
+    from tabcorr_amd import synthetic
+    table = synthetic.synthetic_table(100, 1, (19, 40), 'auto', seed=9)
+    theta = synthetic.zheng07_draws(512, seed=8)
+    halotab = make(table)
+    ngal, xi = halotab.predict_batch(theta)
+    assert xi.shape == (512, 19, 40)
+    oracle_check(table, theta, ngal, xi, np.r_[0:2, 510:512])
+    ngal_sep, xi_sep = halotab.predict_batch(theta, separate_gal_type=True)
+    assert_rel(sum(xi_sep.values()), xi, 1e-12)
+
+
+def test_many_bins_auto_mode():
+    """More bins than one LDS staging can hold at once: the plan cuts the pair
+    triangle into segments."""
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(220, 1, (3, ), 'auto', seed=11)   # G = 440
+    theta = synthetic.zheng07_draws(130, seed=12)
+    halotab = make(table)
+    ngal, xi = halotab.predict_batch(theta)
+    expect = oracle.predict_zheng07_batch(table, theta[:3])
+    assert_rel(ngal[:3], expect[0], RTOL)
+    assert_rel(xi[:3], expect[1], RTOL)
+    ngal_sep, xi_sep = halotab.predict_batch(theta, separate_gal_type=True)
+    assert_rel(sum(xi_sep.values()), xi, 1e-12)
+    expect = oracle.predict_zheng07_batch(table, theta[:2],
+                                          separate_gal_type=True)
+    for key in xi_sep:
+        assert_rel(xi_sep[key][:2], expect[1][key], RTOL, key)
+
+
+def test_many_bins_cross_mode():
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(552, 1, (13, ), 'cross', seed=13)  # G = 1104
+    theta = synthetic.zheng07_draws(70, seed=14)
+    halotab = make(table)
+    ngal, xi = halotab.predict_batch(theta)
+    expect = oracle.predict_zheng07_batch(table, theta[:4])
+    assert_rel(ngal[:4], expect[0], RTOL)
+    assert_rel(xi[:4], expect[1], RTOL)
