@@ -91,7 +91,7 @@ def main():
                                  theta.nbytes))
     n_slots = 2
     d_out = dmalloc(n_slots * n_out)
-    use_rccl = comm.world_size > 1 and comm.comm is not None
+    use_rccl = comm.comm is not None
     d_recv = dmalloc(n_slots * comm.world_size * n_out) if (
         use_rccl and comm.is_root) else ctypes.c_void_p()
 
@@ -130,7 +130,7 @@ def main():
     comm.barrier()
     elapsed = comm.max(time.perf_counter() - t0)
 
-    if comm.world_size > 1 and not use_rccl:
+    if comm.dist is not None and not use_rccl:
         # RCCL unavailable: collect the last batch over gloo so that the job still
         # ends with the results on rank 0 (reported as "gather": "gloo").
         host = np.empty(n_out)

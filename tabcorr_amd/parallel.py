@@ -69,7 +69,8 @@ class Communicator:
         self.dist = None
         self.comm = None          # tc_comm handle (RCCL) or None
         self.rccl_error = None
-        if world_size > 1:
+        force = os.environ.get('TABCORR_AMD_FORCE_COMM', '0') == '1'
+        if world_size > 1 or force:
             # The HIP library must be in the process before torch so that it
             # keeps the system ROCm runtime (see _lib.load).
             try:
@@ -97,7 +98,7 @@ class Communicator:
 
     @property
     def gather_backend(self):
-        if self.world_size == 1:
+        if self.dist is None:
             return 'none'
         return 'rccl' if self.comm is not None else 'gloo'
 

@@ -1,6 +1,9 @@
 """Parity of the HIP path (through the C ABI) with the golden vectors recorded
 from the reference and with the CPU oracle.  Needs an MI355X."""
 
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -331,3 +334,77 @@ def test_interpolator_grid_validation():
         Interpolator(halotabs, {k: bad[:, d] for d, k in enumerate(keys)})
     with pytest.raises(ValueError, match='less than'):
         Interpolator(halotabs[:3], {'a': np.arange(3.0)})
+
+
+# -- multi-GPU plumbing that can be exercised on one GPU ------------------------------
+
+def test_rccl_communicator_single_rank():
+    """dlopen of librccl, ncclCommInitRank, ncclGather on the comm stream behind the
+    table's stream, slot events -- with one rank (the box has one GPU)."""
+    import ctypes
+    from tabcorr_amd import _lib, synthetic
+    lib = _lib.load()
+    buffer = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+    _lib.check(lib.tc_comm_unique_id(buffer))
+    comm = ctypes.c_void_p()
+    _lib.check(lib.tc_comm_create(buffer.raw, 1, 0, ctypes.byref(comm)))
+    data = load_golden('synthetic_cfg2')
+    table = table_from_golden(data)
+    halotab = make_tabcorr(table)
+    device = halotab.to_device()
+    theta = _lib.contiguous(data['theta'])
+    n_draws, n_r = len(theta), device.n_r
+    count = n_draws * (1 + n_r)
+
+    def dmalloc(n):
+        ptr = ctypes.c_void_p()
+        _lib.check(lib.tc_device_malloc(ctypes.byref(ptr), n * 8))
+        return ptr
+    d_theta, d_out, d_recv = dmalloc(theta.size), dmalloc(2 * count), dmalloc(2 * count)
+    _lib.check(lib.tc_memcpy_h2d(d_theta, theta.ctypes.data_as(ctypes.c_void_p),
+                                 theta.nbytes))
+    for step in range(4):
+        slot = step % 2
+        if step >= 2:
+            _lib.check(lib.tc_comm_release(comm, device.handle, slot))
+        out = ctypes.c_void_p(d_out.value + slot * count * 8)
+        _lib.check(lib.tc_predict_zheng07_batch_device(
+            device.handle, d_theta, 5, n_draws, 10, 0, out,
+            ctypes.c_void_p(out.value + n_draws * 8)))
+        _lib.check(lib.tc_comm_gather(
+            comm, device.handle, out,
+            ctypes.c_void_p(d_recv.value + slot * count * 8), count, 0, slot))
+    _lib.check(lib.tc_comm_synchronize(comm))
+    _lib.check(lib.tc_comm_barrier(comm))
+    host = np.empty(2 * count)
+    _lib.check(lib.tc_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p), d_recv,
+                                 host.nbytes))
+    for slot in range(2):
+        part = host[slot * count:(slot + 1) * count]
+        assert_rel(part[:n_draws], data['ngal'], RTOL)
+        assert_rel(part[n_draws:].reshape(n_draws, n_r), data['xi'], RTOL)
+    for ptr in (d_theta, d_out, d_recv):
+        lib.tc_device_free(ptr)
+    _lib.check(lib.tc_comm_destroy(comm))
+
+
+def test_bench_under_torchrun_single_rank():
+    """bench.py as the driver launches it (torch.distributed.run), one rank, with the
+    communicator forced on: gloo control plane next to the HIP library, RCCL gather
+    per step."""
+    import json
+    import subprocess
+    from util import REPO
+    env = dict(os.environ, TABCORR_AMD_FORCE_COMM='1', MASTER_ADDR='127.0.0.1')
+    result = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+         '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port',
+         '29533', os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '20',
+         '--warmup', '3', '--cpu-seconds', '0'],
+        env=env, capture_output=True, text=True, timeout=900)
+    assert result.returncode == 0, result.stdout[-2000:] + result.stderr[-2000:]
+    line = [l for l in result.stdout.splitlines() if l.startswith('{')][-1]
+    record = json.loads(line)
+    assert record['n_gpus'] == 1 and record['value'] > 1e6
+    assert record['config']['gather'] == 'rccl', record['config']
+    assert record['parity_max_rel_vs_oracle'] < 1e-10
