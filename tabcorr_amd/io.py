@@ -4,9 +4,10 @@ Two containers hold the same content (``tabcorr/tabcorr.py:443-463``: the
 seven root attributes, ``tpcf_matrix``, ``tpcf_shape``, ``tpcf_args/arg_%d``,
 ``tpcf_kwargs/<key>`` and the compound dataset ``gal_type``):
 
-* HDF5 in the reference's exact layout (needs ``h5py``; files written by the
-  reference are read as they are, and files written here are readable by the
-  reference), and
+* HDF5 in the reference's exact layout, through the HDF5 C library
+  (`tabcorr_amd.hdf5`, no h5py / astropy needed) or h5py when only that is
+  installed; files written by the reference are read as they are, and files
+  written here are readable by the reference, and
 * ``.npz`` with the same keys flattened, for environments without HDF5.
 """
 
@@ -21,14 +22,62 @@ ATTR_KEYS = ['tpcf', 'mode', 'simname', 'redshift', 'Num_ptcl_requirement',
              'prim_haloprop_key', 'sec_haloprop_key']
 
 
-def _h5py():
+class _H5pyNode:
+    """Adapter giving an h5py File / Group the small interface of
+    `tabcorr_amd.hdf5.Group`."""
+
+    def __init__(self, node):
+        self.node = node
+
+    def attrs(self):
+        return {key: self.node.attrs[key] for key in self.node.attrs.keys()}
+
+    def set_attr(self, name, value):
+        self.node.attrs[name] = value
+
+    def keys(self):
+        return sorted(self.node.keys())
+
+    def __contains__(self, name):
+        return name in self.node
+
+    def read(self, name):
+        return self.node[name][()]
+
+    def write(self, name, array):
+        self.node[name] = array
+
+    def group(self, name):
+        return _H5pyNode(self.node[name])
+
+    def create_group(self, name):
+        return _H5pyNode(self.node.create_group(name))
+
+    def require_group(self, name):
+        return _H5pyNode(self.node.require_group(name))
+
+    def close(self):
+        pass
+
+
+def _open(fname, mode):
+    """Return (node, must_close) for a file name, an h5py Group or a
+    `tabcorr_amd.hdf5.Group`."""
+    from . import hdf5
+    if isinstance(fname, (hdf5.Group, _H5pyNode)):
+        return fname, False
+    if _is_group(fname):
+        return _H5pyNode(fname), False
+    if hdf5.available():
+        return hdf5.File(str(fname), mode), True
     try:
         import h5py
     except ImportError as error:
         raise ImportError(
-            'Reading or writing HDF5 tables needs h5py; use the .npz '
+            'Reading or writing HDF5 tables needs the HDF5 C library '
+            '(libhdf5, see tabcorr_amd/hdf5.py) or h5py; use the .npz '
             'container otherwise.') from error
-    return h5py
+    return _H5pyNode(h5py.File(fname, mode)), True
 
 
 def _plain(value):
@@ -36,60 +85,68 @@ def _plain(value):
         return value.decode()
     if isinstance(value, np.generic):
         return value.item()
+    if isinstance(value, np.ndarray) and value.shape == ():
+        return _plain(value[()])
     return value
 
 
 def _is_group(obj):
-    return hasattr(obj, 'attrs') and hasattr(obj, 'keys')
+    return hasattr(obj, 'attrs') and hasattr(obj, 'keys') and not isinstance(
+        obj, dict)
 
 
 def read_tabcorr(cls, fname):
-    if not _is_group(fname) and str(fname).endswith('.npz'):
+    if isinstance(fname, (str, os.PathLike)) and str(fname).endswith('.npz'):
         return _read_npz(cls, fname)
-    h5py = _h5py()
-    stream = fname if _is_group(fname) else h5py.File(fname, 'r')
+    node, must_close = _open(fname, 'r')
     try:
-        attrs = {key: _plain(stream.attrs[key]) for key in stream.attrs.keys()}
-        matrix = stream['tpcf_matrix'][()].astype(np.float64)
-        args = tuple(stream['tpcf_args'][key][()]
-                     for key in stream['tpcf_args'].keys())
+        attrs = {key: _plain(value) for key, value in node.attrs().items()}
+        matrix = np.asarray(node.read('tpcf_matrix')).astype(np.float64)
+        args_group = node.group('tpcf_args')
+        args = tuple(args_group.read(key) for key in args_group.keys())
+        args_group.close()
         kwargs = {}
-        if 'tpcf_kwargs' in stream:
-            kwargs = {key: stream['tpcf_kwargs'][key][()]
-                      for key in stream['tpcf_kwargs'].keys()}
-        shape = tuple(int(s) for s in stream['tpcf_shape'][()])
-        gal_type = GalTypeTable(stream['gal_type'][()])
+        if 'tpcf_kwargs' in node:
+            kwargs_group = node.group('tpcf_kwargs')
+            kwargs = {key: kwargs_group.read(key)
+                      for key in kwargs_group.keys()}
+            kwargs_group.close()
+        shape = tuple(int(s) for s in np.atleast_1d(node.read('tpcf_shape')))
+        gal_type = GalTypeTable(node.read('gal_type'))
     finally:
-        if not _is_group(fname):
-            stream.close()
+        if must_close:
+            node.close()
     return cls.from_arrays(gal_type, matrix, shape, attrs, args, kwargs)
 
 
 def write_tabcorr(halotab, fname, overwrite=False, max_args_size=1000000,
                   matrix_dtype=np.float32):
-    if not _is_group(fname) and str(fname).endswith('.npz'):
+    if isinstance(fname, (str, os.PathLike)) and str(fname).endswith('.npz'):
         return _write_npz(halotab, fname, overwrite, matrix_dtype)
-    h5py = _h5py()
-    stream = fname if _is_group(fname) else h5py.File(
-        fname, 'w' if overwrite else 'w-')
+    node, must_close = _open(fname, 'w' if overwrite else 'w-')
     try:
         for key in ATTR_KEYS:
-            stream.attrs[key] = halotab.attrs[key]
-        stream['tpcf_matrix'] = np.asarray(halotab.tpcf_matrix).astype(
-            matrix_dtype)
+            node.set_attr(key, halotab.attrs[key])
+        node.write('tpcf_matrix', np.asarray(halotab.tpcf_matrix).astype(
+            matrix_dtype))
+        args_group = node.require_group('tpcf_args')
         for i, arg in enumerate(halotab.tpcf_args):
             if type(arg) is not np.ndarray or arg.size < max_args_size:
-                stream['tpcf_args/arg_%d' % i] = arg
-        if not halotab.tpcf_args:
-            stream.require_group('tpcf_args')
-        for key, value in halotab.tpcf_kwargs.items():
-            if type(value) is not np.ndarray or value.size < max_args_size:
-                stream['tpcf_kwargs/' + key] = value
-        stream['tpcf_shape'] = halotab.tpcf_shape
-        stream['gal_type'] = halotab.gal_type.as_array()
+                args_group.write('arg_%d' % i, np.asarray(arg))
+        args_group.close()
+        if halotab.tpcf_kwargs:
+            kwargs_group = node.require_group('tpcf_kwargs')
+            for key, value in halotab.tpcf_kwargs.items():
+                if (type(value) is not np.ndarray or
+                        value.size < max_args_size):
+                    kwargs_group.write(key, np.asarray(value))
+            kwargs_group.close()
+        node.write('tpcf_shape', np.asarray(halotab.tpcf_shape,
+                                            dtype=np.int64))
+        node.write('gal_type', halotab.gal_type.as_array())
     finally:
-        if not _is_group(fname):
-            stream.close()
+        if must_close:
+            node.close()
 
 
 def _read_npz(cls, fname):
@@ -122,15 +179,21 @@ def read_interpolator(cls, fname):
                        if key.startswith(prefix)}
                 tables.append(_tabcorr_from_flat(TabCorr, sub))
         return cls(tables, {key: points[:, d] for d, key in enumerate(keys)})
-    h5py = _h5py()
-    with h5py.File(fname, 'r') as stream:
-        table = stream['param_dict_table'][()]
+    node, must_close = _open(fname, 'r')
+    try:
+        table = node.read('param_dict_table')
         order = np.argsort(table['tabcorr_index'])
         keys = [name for name in table.dtype.names if name != 'tabcorr_index']
         columns = {key: np.asarray(table[key], dtype=np.float64)[order]
                    for key in keys}
-        tables = [read_tabcorr(TabCorr, stream['tabcorr_{}'.format(i)])
-                  for i in range(len(order))]
+        tables = []
+        for i in range(len(order)):
+            group = node.group('tabcorr_{}'.format(i))
+            tables.append(read_tabcorr(TabCorr, group))
+            group.close()
+    finally:
+        if must_close:
+            node.close()
     return cls(tables, columns)
 
 
@@ -146,19 +209,23 @@ def write_interpolator(interp, fname, overwrite=False, max_args_size=1000000,
                 arrays['tabcorr_%d/%s' % (i, key)] = value
         np.savez(fname, **arrays)
         return
-    h5py = _h5py()
-    with h5py.File(fname, 'w' if overwrite else 'w-') as stream:
+    node, must_close = _open(fname, 'w' if overwrite else 'w-')
+    try:
         dtype = [(key, '<f8') for key in interp.keys] + [
             ('tabcorr_index', '<i8')]
         table = np.zeros(len(interp.points), dtype=dtype)
         for key in interp.keys:
             table[key] = interp.param_dict_table[key]
         table['tabcorr_index'] = interp.param_dict_table['tabcorr_index']
-        stream['param_dict_table'] = table
+        node.write('param_dict_table', table)
         for i, halotab in enumerate(interp.tabcorr_list):
-            write_tabcorr(halotab, stream.create_group('tabcorr_{}'.format(i)),
-                          max_args_size=max_args_size,
+            group = node.create_group('tabcorr_{}'.format(i))
+            write_tabcorr(halotab, group, max_args_size=max_args_size,
                           matrix_dtype=matrix_dtype)
+            group.close()
+    finally:
+        if must_close:
+            node.close()
 
 
 def _tabcorr_to_flat(halotab, matrix_dtype):

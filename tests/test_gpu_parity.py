@@ -408,3 +408,24 @@ def test_bench_under_torchrun_single_rank():
     assert record['n_gpus'] == 1 and record['value'] > 1e6
     assert record['config']['gather'] == 'rccl', record['config']
     assert record['parity_max_rel_vs_oracle'] < 1e-10
+
+
+def test_read_hdf5_and_predict():
+    """End to end as a user of the reference would: read the reference's example file,
+    predict with a model object."""
+    from tabcorr_amd import TabCorr, Interpolator, Zheng07Model, hdf5
+    from util import GOLDEN
+    if not hdf5.available():
+        pytest.skip('libhdf5 not found')
+    data = load_golden('bolplanck_wp')
+    halotab = TabCorr.read(os.path.join(GOLDEN, 'bolplanck_wp.hdf5'))
+    model = Zheng07Model(redshift=0.0, **dict(zip(
+        ['logMmin', 'sigma_logM', 'logM0', 'logM1', 'alpha'], data['theta'][0])))
+    ngal, xi = halotab.predict(model)
+    assert_rel(ngal, data['ngal'][0], RTOL)
+    assert_rel(xi, data['xi'][0], RTOL)
+    golden = load_golden('ds_efficient')
+    interp = Interpolator.read(os.path.join(GOLDEN, 'ds_efficient.hdf5'))
+    ngal, xi = interp.predict_batch(golden['theta'], golden['x'])
+    assert_rel(ngal, golden['ngal'], RTOL)
+    assert_rel(xi, golden['xi'], RTOL)

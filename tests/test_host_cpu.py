@@ -279,3 +279,77 @@ def test_sharded_predict_world_size_2_gloo(tmp_path):
         env=env, capture_output=True, text=True, timeout=600)
     assert result.returncode == 0, result.stdout + result.stderr
     assert result.stdout.count('ok') == 2
+
+
+# -- HDF5 through the C library (no h5py / astropy) -------------------------------------
+
+def _need_hdf5():
+    from tabcorr_amd import hdf5
+    if not hdf5.available():
+        pytest.skip('libhdf5 not found')
+
+
+@pytest.mark.parametrize('name', ['bolplanck_wp', 'bolplanck_ds'])
+def test_read_reference_hdf5_files(name):
+    """The reference's own data files (kept as fixtures) parse to exactly the arrays
+    the reference's reader produced (npz fixtures)."""
+    _need_hdf5()
+    from tabcorr_amd import TabCorr
+    from util import GOLDEN
+    halotab = TabCorr.read(os.path.join(GOLDEN, name + '.hdf5'))
+    data = load_golden(name)
+    table = table_from_golden(data)
+    assert np.array_equal(halotab.tpcf_matrix, table['tpcf_matrix'])
+    assert halotab.tpcf_matrix.dtype == np.float64     # tabcorr.py:399
+    assert halotab.tpcf_shape == table['tpcf_shape']
+    for key, value in table['attrs'].items():
+        assert halotab.attrs[key] == value, key
+    assert halotab.gal_type.colnames == list(table['gal_type'].dtype.names)
+    for column in halotab.gal_type.colnames:
+        assert np.array_equal(halotab.gal_type.as_array()[column],
+                              table['gal_type'][column]), column
+    assert halotab.gal_type['gal_type'][-1] == 'satellites'
+    if name == 'bolplanck_wp':
+        assert halotab.tpcf_kwargs['pi_max'] == 40
+        assert halotab.tpcf_args[0].shape == (20, )
+
+
+def test_read_reference_interpolator_file_and_round_trip(tmp_path):
+    _need_hdf5()
+    from tabcorr_amd import Interpolator, TabCorr
+    from util import GOLDEN
+    interp = Interpolator.read(os.path.join(GOLDEN, 'ds_efficient.hdf5'))
+    data = load_golden('ds_efficient')
+    assert interp.keys == ['log_eta']
+    assert np.array_equal(interp.points, data['points'])
+    for i, halotab in enumerate(interp.tabcorr_list):
+        table = table_from_golden(data, 'table%d_' % i)
+        assert np.array_equal(halotab.tpcf_matrix, table['tpcf_matrix'])
+        assert halotab.attrs['simname'] == 'base_c000_ph000'
+    for d in range(1):
+        np.testing.assert_allclose(interp.xp[d], data['xp%d' % d], rtol=0)
+
+    fname = str(tmp_path / 'interp.hdf5')
+    interp.write(fname)
+    with pytest.raises(OSError):
+        interp.write(fname)                       # 'w-' semantics
+    interp.write(fname, overwrite=True)
+    back = Interpolator.read(fname)
+    assert np.array_equal(back.points, interp.points)
+    for a, b in zip(back.tabcorr_list, interp.tabcorr_list):
+        assert np.array_equal(a.tpcf_matrix, b.tpcf_matrix)
+        assert a.attrs == b.attrs
+        assert a.tpcf_shape == b.tpcf_shape
+        assert [x.shape for x in a.tpcf_args] == [x.shape for x in b.tpcf_args]
+        for column in a.gal_type.colnames:
+            assert np.array_equal(a.gal_type.as_array()[column],
+                                  b.gal_type.as_array()[column])
+
+    single = str(tmp_path / 'single.hdf5')
+    halotab = interp.tabcorr_list[2]
+    halotab.write(single, matrix_dtype=np.float64)
+    again = TabCorr.read(single)
+    assert np.array_equal(again.tpcf_matrix, halotab.tpcf_matrix)
+    npz = str(tmp_path / 'interp.npz')
+    interp.write(npz)
+    assert np.array_equal(Interpolator.read(npz).points, interp.points)
