@@ -70,6 +70,30 @@ struct DeviceBuffer {
   }
 };
 
+// Page-locked host staging for small transfers: hipMemcpyAsync from / to pageable
+// memory goes through an internal bounce buffer and costs tens of microseconds per
+// call, which dominates the latency of un-batched predict() calls.
+struct PinnedBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t need) {
+    if (need <= bytes) return TC_OK;
+    if (ptr != nullptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+    size_t grow = std::max<size_t>(need + need / 2, 4096);
+    TC_HIP(hipHostMalloc(&ptr, grow, hipHostMallocDefault));
+    bytes = grow;
+    return TC_OK;
+  }
+  void release() {
+    if (ptr != nullptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+};
+constexpr size_t kStageLimit = 1 << 20;   // larger transfers go directly
+
 template <typename T>
 int upload(const std::vector<T>& host, void** device) {
   size_t bytes = std::max<size_t>(1, host.size()) * sizeof(T);
@@ -128,6 +152,7 @@ struct tc_table {
   std::map<std::pair<int, int>, std::unique_ptr<DeviceChunking>> chunkings;
 
   DeviceBuffer theta, nbuf, ngal2, partial, out_ngal, out_xi, occupation, trace;
+  PinnedBuffer h_in, h_out;
   size_t trace_blocks = 0;
 
   // measurement
@@ -750,6 +775,8 @@ int tc_table_destroy(tc_table* t) {
   for (DeviceBuffer* b : {&t->theta, &t->nbuf, &t->ngal2, &t->partial,
                           &t->out_ngal, &t->out_xi, &t->occupation, &t->trace})
     b->release();
+  t->h_in.release();
+  t->h_out.release();
   for (auto& ev : t->kernel_events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -804,6 +831,41 @@ int tc_predict_zheng07_batch_device(tc_table* t, const double* theta_device,
   return TC_OK;
 }
 
+namespace {
+
+// Host -> device copy of a small input through the pinned staging buffer.
+int copy_in(PinnedBuffer* stage, void* device, const void* host, size_t bytes,
+            hipStream_t stream) {
+  if (bytes <= kStageLimit && stage->reserve(bytes) == TC_OK) {
+    memcpy(stage->ptr, host, bytes);
+    host = stage->ptr;
+  }
+  TC_HIP(hipMemcpyAsync(device, host, bytes, hipMemcpyHostToDevice, stream));
+  return TC_OK;
+}
+
+// Device -> host copy of [ngal | xi], synchronising the stream.
+int copy_out(PinnedBuffer* stage, double* ngal, size_t ngal_count, const void* d_ngal,
+             double* xi, size_t xi_count, const void* d_xi, hipStream_t stream) {
+  const size_t bytes = (ngal_count + xi_count) * sizeof(double);
+  if (bytes <= kStageLimit && stage->reserve(bytes) == TC_OK) {
+    double* h = (double*)stage->ptr;
+    TC_HIP(hipMemcpyAsync(h, d_ngal, ngal_count * 8, hipMemcpyDeviceToHost, stream));
+    TC_HIP(hipMemcpyAsync(h + ngal_count, d_xi, xi_count * 8, hipMemcpyDeviceToHost,
+                          stream));
+    TC_HIP(hipStreamSynchronize(stream));
+    memcpy(ngal, h, ngal_count * 8);
+    memcpy(xi, h + ngal_count, xi_count * 8);
+    return TC_OK;
+  }
+  TC_HIP(hipMemcpyAsync(ngal, d_ngal, ngal_count * 8, hipMemcpyDeviceToHost, stream));
+  TC_HIP(hipMemcpyAsync(xi, d_xi, xi_count * 8, hipMemcpyDeviceToHost, stream));
+  TC_HIP(hipStreamSynchronize(stream));
+  return TC_OK;
+}
+
+}  // namespace
+
 int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
                              int64_t n_draws, int n_gauss, unsigned flags,
                              double* ngal, double* xi) {
@@ -820,18 +882,15 @@ int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
   if (status == TC_OK) status = t->out_ngal.reserve(ngal_count * 8, t->stream);
   if (status == TC_OK) status = t->out_xi.reserve(xi_count * 8, t->stream);
   if (status != TC_OK) return status;
-  TC_HIP(hipMemcpyAsync(t->theta.ptr, theta, (size_t)n_draws * n_theta * 8,
-                        hipMemcpyHostToDevice, t->stream));
+  status = copy_in(&t->h_in, t->theta.ptr, theta, (size_t)n_draws * n_theta * 8,
+                   t->stream);
+  if (status != TC_OK) return status;
   status = tc_predict_zheng07_batch_device(
       t, (const double*)t->theta.ptr, n_theta, n_draws, n_gauss, flags,
       (double*)t->out_ngal.ptr, (double*)t->out_xi.ptr);
   if (status != TC_OK) return status;
-  TC_HIP(hipMemcpyAsync(ngal, t->out_ngal.ptr, ngal_count * 8,
-                        hipMemcpyDeviceToHost, t->stream));
-  TC_HIP(hipMemcpyAsync(xi, t->out_xi.ptr, xi_count * 8, hipMemcpyDeviceToHost,
-                        t->stream));
-  TC_HIP(hipStreamSynchronize(t->stream));
-  return TC_OK;
+  return copy_out(&t->h_out, ngal, ngal_count, t->out_ngal.ptr, xi, xi_count,
+                  t->out_xi.ptr, t->stream);
 }
 
 int tc_mean_occupation_zheng07_batch(tc_table* t, const double* theta, int n_theta,
@@ -884,8 +943,9 @@ int tc_predict_occupation_batch(tc_table* t, const double* occupation,
     if (status == TC_OK) status = t->out_ngal.reserve(ngal_count * 8, t->stream);
     if (status == TC_OK) status = t->out_xi.reserve(xi_count * 8, t->stream);
     if (status != TC_OK) return status;
-    TC_HIP(hipMemcpyAsync(t->occupation.ptr, occupation + begin * t->n_bins,
-                          occ_bytes, hipMemcpyHostToDevice, t->stream));
+    status = copy_in(&t->h_in, t->occupation.ptr, occupation + begin * t->n_bins,
+                     occ_bytes, t->stream);
+    if (status != TC_OK) return status;
     hipLaunchKernelGGL(tc::occ_from_array_kernel,
                        dim3((unsigned)((ldb + 255) / 256)), dim3(256), 0, t->stream,
                        (const double*)t->occupation.ptr, n, ldb, t->n_bins,
@@ -897,11 +957,10 @@ int tc_predict_occupation_batch(tc_table* t, const double* occupation,
     status = run_contraction(t, n, ldb, flags, (double*)t->out_ngal.ptr,
                              (double*)t->out_xi.ptr);
     if (status != TC_OK) return status;
-    TC_HIP(hipMemcpyAsync(ngal + begin * (separate ? 2 : 1), t->out_ngal.ptr,
-                          ngal_count * 8, hipMemcpyDeviceToHost, t->stream));
-    TC_HIP(hipMemcpyAsync(xi + begin * n_comp * t->n_r, t->out_xi.ptr, xi_count * 8,
-                          hipMemcpyDeviceToHost, t->stream));
-    TC_HIP(hipStreamSynchronize(t->stream));
+    status = copy_out(&t->h_out, ngal + begin * (separate ? 2 : 1), ngal_count,
+                      t->out_ngal.ptr, xi + begin * n_comp * t->n_r, xi_count,
+                      t->out_xi.ptr, t->stream);
+    if (status != TC_OK) return status;
   }
   return TC_OK;
 }
