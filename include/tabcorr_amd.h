@@ -149,6 +149,16 @@ int tc_predict_zheng07_batch_device(tc_table* table, const double* theta_device,
                                     unsigned flags, double* ngal_device,
                                     double* xi_device);
 
+/* Gaussian likelihood fused behind predict() (the step every
+ * likelihood built on the reference performs on the host, README.md:7): for each draw
+ * chi2 = (xi - data)^T precision (xi - data) over the n_r correlation function bins of
+ * the total prediction.  Outputs ngal (n_draws) and chi2 (n_draws): one pair of doubles
+ * per draw crosses PCIe instead of 1 + n_r. */
+int tc_chi2_zheng07_batch(tc_table* table, const double* theta, int n_theta,
+                          int64_t n_draws, int n_gauss_prim, unsigned flags,
+                          const double* data, const double* precision, double* ngal,
+                          double* chi2);
+
 /* TabCorr.predict(ndarray): the operator seam of tabcorr.py:616-621 for arbitrary
  * occupation models evaluated by the caller.  occupation: (n_draws, n_bins). */
 int tc_predict_occupation_batch(tc_table* table, const double* occupation,

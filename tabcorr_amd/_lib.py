@@ -73,6 +73,10 @@ SIGNATURES = {
     'tc_predict_zheng07_batch_device': [
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
         ctypes.c_int, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p],
+    'tc_chi2_zheng07_batch': [
+        ctypes.c_void_p, c_double_p, ctypes.c_int, ctypes.c_int64,
+        ctypes.c_int, ctypes.c_uint, c_double_p, c_double_p, c_double_p,
+        c_double_p],
     'tc_predict_occupation_batch': [
         ctypes.c_void_p, c_double_p, ctypes.c_int64, ctypes.c_uint,
         c_double_p, c_double_p],

@@ -893,6 +893,48 @@ int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
                   t->out_xi.ptr, t->stream);
 }
 
+int tc_chi2_zheng07_batch(tc_table* t, const double* theta, int n_theta,
+                          int64_t n_draws, int n_gauss, unsigned flags,
+                          const double* data, const double* precision, double* ngal,
+                          double* chi2) {
+  int status = check_predict_args(t, theta, n_theta, n_draws, n_gauss, flags);
+  if (status != TC_OK) return status;
+  TC_CHECK(!(flags & TC_FLAG_SEPARATE_GAL_TYPE),
+           "chi2 is defined for the total correlation function only");
+  if (n_draws == 0) return TC_OK;
+  TC_CHECK(data && precision && ngal && chi2, "NULL pointer");
+  TC_HIP(hipSetDevice(t->device));
+  const int n_r = t->n_r;
+  const size_t xi_count = (size_t)n_draws * n_r;
+  status = t->theta.reserve((size_t)n_draws * n_theta * sizeof(double), t->stream);
+  if (status == TC_OK) status = t->out_ngal.reserve((size_t)n_draws * 2 * 8, t->stream);
+  if (status == TC_OK) status = t->out_xi.reserve(xi_count * 8, t->stream);
+  if (status == TC_OK)
+    status = t->occupation.reserve((size_t)(n_r + 1) * n_r * 8, t->stream);
+  if (status != TC_OK) return status;
+  status = copy_in(&t->h_in, t->theta.ptr, theta, (size_t)n_draws * n_theta * 8,
+                   t->stream);
+  if (status != TC_OK) return status;
+  // data vector and precision matrix behind each other in a scratch buffer
+  double* d_data = (double*)t->occupation.ptr;
+  double* d_precision = d_data + n_r;
+  TC_HIP(hipMemcpyAsync(d_data, data, (size_t)n_r * 8, hipMemcpyHostToDevice, t->stream));
+  TC_HIP(hipMemcpyAsync(d_precision, precision, (size_t)n_r * n_r * 8,
+                        hipMemcpyHostToDevice, t->stream));
+  double* d_ngal = (double*)t->out_ngal.ptr;
+  double* d_chi2 = d_ngal + n_draws;
+  status = tc_predict_zheng07_batch_device(t, (const double*)t->theta.ptr, n_theta,
+                                           n_draws, n_gauss, flags, d_ngal,
+                                           (double*)t->out_xi.ptr);
+  if (status != TC_OK) return status;
+  hipLaunchKernelGGL(tc::chi2_kernel, dim3((unsigned)((n_draws + 255) / 256)), dim3(256),
+                     0, t->stream, (const double*)t->out_xi.ptr, n_draws, n_r,
+                     (const double*)d_data, (const double*)d_precision, d_chi2);
+  TC_HIP(hipGetLastError());
+  return copy_out(&t->h_out, ngal, (size_t)n_draws, d_ngal, chi2, (size_t)n_draws,
+                  d_chi2, t->stream);
+}
+
 int tc_mean_occupation_zheng07_batch(tc_table* t, const double* theta, int n_theta,
                                      int64_t n_draws, int n_gauss, unsigned flags,
                                      double* occupation) {

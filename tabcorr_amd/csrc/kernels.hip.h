@@ -624,4 +624,27 @@ __global__ __launch_bounds__(64) void interp_coef_kernel(InterpArgs a) {
   }
 }
 
+// Gaussian likelihood fused behind predict(): chi2[b] = (xi_b - d)^T P (xi_b - d) with the
+// data vector d and precision matrix P in the scalar cache; one lane per draw.  This is
+// the step every MCMC likelihood performs on the host right after predict()
+// (README.md:7 of the reference); doing it here leaves one double per draw to copy back.
+__global__ __launch_bounds__(256) void chi2_kernel(const double* xi, int64_t n_draws,
+                                                   int n_r, const double* data,
+                                                   const double* precision,
+                                                   double* chi2) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_draws) return;
+  sc_f64 d = (sc_f64)data;
+  sc_f64 p = (sc_f64)precision;
+  const double* row = xi + b * n_r;
+  double total = 0.0;
+  for (int i = 0; i < n_r; ++i) {
+    const double di = row[i] - d[i];
+    double inner = 0.0;
+    for (int j = 0; j < n_r; ++j) inner = fma(p[i * n_r + j], row[j] - d[j], inner);
+    total = fma(di, inner, total);
+  }
+  chi2[b] = total;
+}
+
 }  // namespace tc

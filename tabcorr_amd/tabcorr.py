@@ -354,6 +354,39 @@ class TabCorr:
             _lib.as_double_p(xi)))
         return self._package(ngal, xi, separate_gal_type)
 
+    def chi2_batch(self, theta, data, precision, n_gauss_prim=10,
+                   modulate_with_cenocc=False, assembias=False):
+        """Gaussian ``chi^2 = (xi - data)^T precision (xi - data)`` of every draw,
+        evaluated on the device right after the prediction (extension: the
+        reference leaves this to the user's likelihood, ``README.md:7``).
+
+        Parameters
+        ----------
+        theta : ``(n_draws, 5 | 7)`` Zheng07 parameters
+        data : array of shape ``tpcf_shape``
+        precision : inverse covariance, ``(n_r, n_r)``
+
+        Returns
+        -------
+        ngal, chi2 : numpy.ndarray ``(n_draws, )``
+        """
+        device = self.to_device()
+        theta = _lib.contiguous(np.atleast_2d(theta))
+        data = _lib.contiguous(np.ravel(data))
+        precision = _lib.contiguous(precision)
+        if data.shape != (device.n_r, ) or precision.shape != (device.n_r,
+                                                               device.n_r):
+            raise ValueError('data must have {0} entries and precision shape '
+                             '({0}, {0}).'.format(device.n_r))
+        ngal = np.empty(len(theta))
+        chi2 = np.empty(len(theta))
+        _lib.check(device.lib.tc_chi2_zheng07_batch(
+            device.handle, _lib.as_double_p(theta), theta.shape[1], len(theta),
+            n_gauss_prim, _flags(False, modulate_with_cenocc, assembias),
+            _lib.as_double_p(data), _lib.as_double_p(precision),
+            _lib.as_double_p(ngal), _lib.as_double_p(chi2)))
+        return ngal, chi2
+
     def _predict_occupation(self, occupation, separate_gal_type):
         device = self.to_device()
         occupation = _lib.contiguous(occupation)

@@ -429,3 +429,20 @@ def test_read_hdf5_and_predict():
     ngal, xi = interp.predict_batch(golden['theta'], golden['x'])
     assert_rel(ngal, golden['ngal'], RTOL)
     assert_rel(xi, golden['xi'], RTOL)
+
+
+def test_chi2_fused_likelihood():
+    data = load_golden('synthetic_cfg2')
+    table = table_from_golden(data)
+    halotab = make_tabcorr(table)
+    rng = np.random.default_rng(3)
+    observed = data['xi'][5] * (1 + 0.05 * rng.normal(size=19))
+    a = rng.normal(size=(19, 19))
+    precision = a @ a.T / np.outer(observed, observed)
+    ngal, chi2 = halotab.chi2_batch(data['theta'], observed, precision)
+    delta = data['xi'] - observed
+    expect = np.einsum('bi,ij,bj->b', delta, precision, delta)
+    assert_rel(ngal, data['ngal'], RTOL)
+    assert_rel(chi2, expect, 1e-9)
+    with pytest.raises(ValueError):
+        halotab.chi2_batch(data['theta'], observed[:5], precision)
