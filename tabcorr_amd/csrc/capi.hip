@@ -148,6 +148,7 @@ struct tc_table {
   void* d_percentile = nullptr;
   void* d_perm = nullptr;
   void* d_math_table = nullptr;  // fastmath.h tables
+  void* d_pos_ij = nullptr;      // float32 variant: packed bin pairs per position
   std::map<int, Quadrature> quadrature;
   std::map<std::pair<int, int>, std::unique_ptr<DeviceChunking>> chunkings;
 
@@ -227,10 +228,10 @@ int get_chunking(tc_table* t, int n_chunks, int waves, DeviceChunking** out) {
 // Largest dynamic LDS allocation a workgroup may ask for (160 KiB per CU).
 constexpr int kMaxLdsBytes = 160 * 1024;
 
-int lds_bytes_for(const tc::Chunking& chunking, int rt) {
+int lds_bytes_for(const tc::Chunking& chunking, int rt, int elem = 8) {
   int span = 1;
   while (span < chunking.waves_per_group) span <<= 1;
-  return std::max(chunking.max_rows, (span / 2) * rt) * 64 * 8;
+  return std::max(chunking.max_rows, (span / 2) * rt) * 64 * elem;
 }
 
 // Workgroups of this kernel that fit on one CU: LDS (160 KiB) and wave slots (the
@@ -253,6 +254,7 @@ int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
   const int64_t min_entries = env_int("TC_MIN_CHUNK_ENTRIES", 32);
   const int n_cus = 256;
   int waves = std::max(1, std::min(env_int("TC_NWAVES", 4), 16));
+  if (t->compute_dtype == TC_DTYPE_F32) waves = std::min(waves * 2, 8);
   const int forced_groups = env_int("TC_NGROUPS", 0);
 
   int capacity = 5;
@@ -269,7 +271,8 @@ int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
     DeviceChunking* c = nullptr;
     int status = get_chunking(t, (int)n_chunks, use_waves, &c);
     if (status != TC_OK) return status;
-    const int bytes = lds_bytes_for(c->host, t->rt);
+    const int elem = t->compute_dtype == TC_DTYPE_F32 ? 4 : 8;
+    const int bytes = lds_bytes_for(c->host, t->rt, elem);
     if (bytes > kMaxLdsBytes) {
       // Mode cross: more, narrower groups touch fewer rows each.
       if (t->mode == TC_MODE_CROSS && capacity < 64) {
@@ -288,7 +291,9 @@ int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
     capacity = fit;
   }
   *out = best;
-  *lds_bytes = std::max(lds_bytes_for(best->host, t->rt), env_int("TC_LDS_MIN", 0));
+  *lds_bytes = std::max(
+      lds_bytes_for(best->host, t->rt, t->compute_dtype == TC_DTYPE_F32 ? 4 : 8),
+      env_int("TC_LDS_MIN", 0));
   return TC_OK;
 }
 
@@ -363,6 +368,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   ca.r_stride = r_stride;
   ca.debug = env_int("TC_DEBUG_VARIANT", 0);
   ca.trace = nullptr;
+  ca.pos_ij = nullptr;
   if (env_int("TC_TRACE", 0)) {
     t->trace_blocks = (size_t)(ldb / 64) * n_groups * t->n_rtiles;
     status = t->trace.reserve(t->trace_blocks * 6 * sizeof(unsigned long long), t->stream);
@@ -399,8 +405,18 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
     ++t->kernel_events_used;
     TC_HIP(hipEventRecord(k0, t->stream));
   }
-  status = launch_contract_rt(t->rt, grid, block, lds, t->stream, ca);
-  if (status != TC_OK) return status;
+  if (t->compute_dtype == TC_DTYPE_F32) {
+    ca.pos_ij = (const int32_t*)t->d_pos_ij;
+    if (lds > 64 * 1024)
+      TC_HIP(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(&tc::contract_f32_kernel),
+          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(tc::contract_f32_kernel, grid, block, lds, t->stream, ca);
+    TC_HIP(hipGetLastError());
+  } else {
+    status = launch_contract_rt(t->rt, grid, block, lds, t->stream, ca);
+    if (status != TC_OK) return status;
+  }
   if (t->profile_kernels) TC_HIP(hipEventRecord(k1, t->stream));
   t->last_workgroups = n_tiles * n_groups * t->n_rtiles;
   t->last_waves = c->host.waves_per_group;
@@ -696,19 +712,21 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
   t->compute_dtype = compute_dtype;
   t->legacy = dist_index == nullptr;
   TC_CHECK(compute_dtype == TC_DTYPE_F64 || true, "unreachable");
-  if (compute_dtype != TC_DTYPE_F64)
-    return fail(TC_ERR_UNSUPPORTED, "float32 contraction is not implemented yet");
-
   // r tiling: at most 32 accumulators per lane, a multiple of 4 so that a block
-  // of at most 4 entries fills whole 128-byte lines.
+  // of at most 4 entries fills whole 128-byte lines (float64); tiles of exactly 32 r
+  // values and blocks of 8 entries for the float32 MFMA kernel.
   const int max_rt = 32;
   t->n_rtiles = (n_r + max_rt - 1) / max_rt;
-  {
+  if (compute_dtype == TC_DTYPE_F32) {
+    t->rt = tc::kF32Tile;
+    tc::build_plan(mode, n_bins, is_central, tc::kF32Block,
+                   env_int("TC_ROW_BUDGET_F32", 128), t->plan);
+  } else {
     int rt = (n_r + t->n_rtiles - 1) / t->n_rtiles;
     t->rt = (rt + 3) / 4 * 4;
+    tc::build_plan(mode, n_bins, is_central, tc::block_entries(t->rt),
+                   env_int("TC_ROW_BUDGET", 56), t->plan);
   }
-  tc::build_plan(mode, n_bins, is_central, tc::block_entries(t->rt),
-                 env_int("TC_ROW_BUDGET", 56), t->plan);
 
   for (int g = 0; g < n_bins; ++g) {
     const int src = t->plan.perm[g];
@@ -720,30 +738,62 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
   }
 
   const int rt = t->rt;
-  // Re-laid-out matrix: [r tile][position][r in tile] with the pair prefactor
-  // (tabcorr.py:638-642) folded in (a multiplication by 2 is exact) and zero
-  // rows at the padding positions.
   const int64_t n_positions = t->plan.n_positions;
   const size_t count = (size_t)t->n_rtiles * n_positions * rt;
-  t->table_bytes = count * sizeof(double);
-  std::vector<double> tmp64(count, 0.0);
-  for (int r = 0; r < n_r; ++r) {
-    const int tile = r / rt, rr = r % rt;
-    for (int64_t q = 0; q < n_positions; ++q) {
-      const int64_t column = t->plan.column[q];
-      if (column < 0) continue;
-      const double value =
-          (matrix_dtype == TC_DTYPE_F64
+  auto source = [&](int r, int64_t column) {
+    return matrix_dtype == TC_DTYPE_F64
                ? ((const double*)tpcf_matrix)[(size_t)r * n_pairs + column]
-               : (double)((const float*)tpcf_matrix)[(size_t)r * n_pairs + column]) *
-          t->plan.prefactor[q];
-      tmp64[((size_t)tile * n_positions + q) * rt + rr] = value;
+               : (double)((const float*)tpcf_matrix)[(size_t)r * n_pairs + column];
+  };
+  std::vector<double> tmp64;
+  std::vector<float> tmp32;
+  std::vector<int32_t> pos_ij;
+  if (compute_dtype == TC_DTYPE_F64) {
+    // Re-laid-out matrix: [r tile][position][r in tile] with the pair prefactor
+    // (tabcorr.py:638-642) folded in (a multiplication by 2 is exact) and zero
+    // rows at the padding positions.
+    t->table_bytes = count * sizeof(double);
+    tmp64.assign(count, 0.0);
+    for (int r = 0; r < n_r; ++r) {
+      const int tile = r / rt, rr = r % rt;
+      for (int64_t q = 0; q < n_positions; ++q) {
+        const int64_t column = t->plan.column[q];
+        if (column < 0) continue;
+        tmp64[((size_t)tile * n_positions + q) * rt + rr] =
+            source(r, column) * t->plan.prefactor[q];
+      }
+    }
+  } else {
+    // float32 MFMA layout: [r tile][block of 8 positions][k][r][k-step] (kernels.hip.h)
+    t->table_bytes = count * sizeof(float);
+    tmp32.assign(count, 0.0f);
+    for (int r = 0; r < n_r; ++r) {
+      const int tile = r / rt, rr = r % rt;
+      for (int64_t q = 0; q < n_positions; ++q) {
+        const int64_t column = t->plan.column[q];
+        if (column < 0) continue;
+        const int64_t block = q / 8;
+        const int p = (int)(q % 8) / 2, k = (int)(q % 2);
+        tmp32[((size_t)tile * n_positions + block * 8) * rt + (k * 32 + rr) * 4 + p] =
+            (float)(source(r, column) * t->plan.prefactor[q]);
+      }
+    }
+    TC_CHECK(n_bins < 65535, "too many bins for the float32 variant");
+    pos_ij.assign((size_t)n_positions, 0);
+    for (int64_t q = 0; q < n_positions; ++q) {
+      const int64_t block = q / 8;
+      const int p = (int)(q % 8) / 2, k = (int)(q % 2);
+      const int i = t->plan.pos_i[q] < 0 ? 0 : t->plan.pos_i[q];
+      pos_ij[(size_t)block * 8 + k * 4 + p] = (i << 16) | t->plan.pos_j[q];
     }
   }
   TC_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
   TC_HIP(hipEventCreate(&t->ev_begin));
   TC_HIP(hipEventCreate(&t->ev_end));
-  int status = upload(tmp64, &t->d_table);
+  int status = compute_dtype == TC_DTYPE_F64 ? upload(tmp64, &t->d_table)
+                                             : upload(tmp32, &t->d_table);
+  if (status == TC_OK && compute_dtype == TC_DTYPE_F32)
+    status = upload(pos_ij, &t->d_pos_ij);
   if (status == TC_OK) status = upload(t->n_h, &t->d_n_h);
   if (status == TC_OK) status = upload(t->percentile, &t->d_percentile);
   if (status == TC_OK) status = upload(t->plan.perm, &t->d_perm);
@@ -764,7 +814,8 @@ int tc_table_destroy(tc_table* t) {
   if (t == nullptr) return TC_OK;
   (void)hipSetDevice(t->device);
   if (t->stream) (void)hipStreamSynchronize(t->stream);
-  for (void* p : {t->d_table, t->d_n_h, t->d_percentile, t->d_perm, t->d_math_table})
+  for (void* p : {t->d_table, t->d_n_h, t->d_percentile, t->d_perm, t->d_math_table,
+                  t->d_pos_ij})
     if (p) (void)hipFree(p);
   for (auto& kv : t->quadrature)
     for (void* p : {kv.second.log_m, kv.second.m, kv.second.weight})
@@ -1199,6 +1250,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   ca.r_stride = r_stride;
   ca.debug = 0;
   ca.trace = nullptr;
+  ca.pos_ij = nullptr;
   ca.partial = (double*)it->partial.ptr;
   ca.n_tables = it->n_tables;
   ca.k_splits = k_splits;
@@ -1260,6 +1312,8 @@ int tc_interp_create(tc_table* const* tables, int n_tables, int n_dim,
     tc_table* t = tables[k];
     TC_CHECK(t != nullptr, "table %d is NULL", k);
     TC_CHECK(t->device == it->device, "table %d lives on another device", k);
+    if (t->compute_dtype != TC_DTYPE_F64)
+      return fail(TC_ERR_UNSUPPORTED, "interpolation of float32 tables is not built");
     TC_CHECK(t->mode == t0->mode && t->n_bins == t0->n_bins && t->n_r == t0->n_r &&
                  t->plan.perm == t0->plan.perm,
              "table %d differs from table 0 in mode, shape or gal_type layout", k);

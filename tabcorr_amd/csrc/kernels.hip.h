@@ -216,6 +216,7 @@ struct ContractArgs {
   int debug;                // developer ablations (TC_DEBUG_VARIANT), 0 in production
   int n_tiles;              // draw tiles (grid.x covers 8 * ceil(n_tiles / 8) * slabs)
   int n_slabs;              // groups * table splits per draw tile
+  const int32_t* pos_ij;    // float32 kernel: packed bin pairs of every position
   unsigned long long* trace;  // developer timeline (TC_TRACE): 6 words per block, or NULL
   double* partial;          // (n_groups * k_splits, r_stride, ldb)
   // Interpolator: the block loops over tables [k_begin, k_end) of its k split and
@@ -457,6 +458,134 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
     rec[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
     rec[5] = (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf) |
              ((c_main - c_staged) << 4);   // XCC_ID, shader cycles of the main loop
+  }
+}
+
+// ---- float32 variant for tables with many correlation-function bins -------------------
+//
+// BASELINE configs[4]: R = 760 (rp x pi), G ~ 200.  With hundreds of r values the
+// contraction is a GEMM with a wide N: out[r][draw] += T[r][entry] * w[entry][draw], and
+// f32 inputs may use the matrix cores: v_mfma_f32_32x32x2_f32 computes a 32 (r) x 32
+// (draws) tile over 2 entries in 64 cycles -- the f32 vector rate, but with one table
+// float and one weight float per lane per instruction instead of three VALU operands,
+// and the VALU stays free to form the weights.  A wave owns 64 draws (two 32-draw
+// accumulator tiles) x 32 r values and walks its chunk of entries 8 at a time:
+//   one global_load_dwordx4: the table values of the 8 entries (4 MFMA k-steps),
+//   one global_load_dwordx4: the bin pairs (i, j) of its 4 entries (lane half = k),
+//   per k-step and draw half: two ds_read_b32 (n_i, n_j, float in LDS), one v_mul_f32,
+//   one MFMA.
+// Table layout: [r tile][block of 8 entries][k (2)][r (32)][k-step (4)] floats, so that
+// lane l = k * 32 + r reads its 4 k-steps as one 16-byte vector.  Results are accumulated
+// in f32; the partial sums leave the kernel as f64.  Stated tolerance 1e-5 relative.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kF32Block = 8;    // entries per block
+constexpr int kF32Tile = 32;    // r values per tile
+
+__global__ __launch_bounds__(512) void contract_f32_kernel(ContractArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float ldsf[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n_waves = blockDim.x >> 6;
+  const int xcd = blockIdx.x & 7;
+  const int rest = blockIdx.x >> 3;
+  const int tile = (rest / a.n_slabs) * 8 + xcd;
+  const int slab = rest % a.n_slabs;
+  if (tile >= a.n_tiles) return;
+  const int64_t col = (int64_t)tile * kLanes;
+  const Group group = a.groups[slab];
+  const int n_rows_j = group.j_hi - group.j_lo;
+  const int n_rows = n_rows_j + (group.i_hi - group.i_lo);
+
+  // stage the density rows as float
+  {
+    gl_f64 src = (gl_f64)a.nbuf + col;
+    for (int id = threadIdx.x; id < n_rows * kLanes; id += blockDim.x) {
+      const int row = id >> 6;
+      const int bin = row < n_rows_j ? group.j_lo + row : group.i_lo + row - n_rows_j;
+      ldsf[id] = (float)src[(int64_t)bin * a.ldb + (id & 63)];
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+
+  if (wave < group.n_chunks) {
+    const Chunk chunk = a.chunks[group.chunk_begin + wave];
+    const int n_blocks = (chunk.q_end - chunk.q_begin) / kF32Block;
+    typedef const __attribute__((address_space(1))) f32x4* gl_f32x4;
+    typedef const __attribute__((address_space(1))) i32x4* gl_i32x4;
+    gl_f32x4 table = (gl_f32x4)((const float*)a.table +
+                                ((int64_t)blockIdx.z * a.n_positions + chunk.q_begin) *
+                                    kF32Tile) + lane;
+    gl_i32x4 pairs = (gl_i32x4)(a.pos_ij + chunk.q_begin) + (lane >> 5);
+    const int draw = lane & 31;
+    const bool auto_mode = a.mode == 0;
+    f32x4 ta = table[0];
+    i32x4 pa = pairs[0];
+    for (int blk = 0; blk < n_blocks; ++blk) {
+      const int next = blk + 1 < n_blocks ? blk + 1 : blk;
+      const f32x4 tn = table[(int64_t)next * 64];
+      const i32x4 pn = pairs[(int64_t)next * 2];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int jj = (pa[p] & 0xffff) - group.j_lo;
+        const int ii = (pa[p] >> 16) + group.i_shift;
+        const float* rj = ldsf + jj * kLanes + draw;
+        float w0 = rj[0], w1 = rj[32];
+        if (auto_mode) {
+          const float* ri = ldsf + ii * kLanes + draw;
+          w0 *= ri[0];
+          w1 *= ri[32];
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[p], w0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[p], w1, acc1, 0, 0, 0);
+      }
+      ta = tn;
+      pa = pn;
+    }
+  }
+  __syncthreads();
+
+  // tree reduction over the waves (all of one segment), then wave 0 writes doubles
+  int span = 1;
+  while (span < n_waves) span <<= 1;
+  for (int half = span >> 1; half >= 1; half >>= 1) {
+    if (wave >= half && wave < 2 * half) {
+      float* slot = ldsf + (wave - half) * 32 * kLanes + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        slot[r * kLanes] = acc0[r];
+        slot[(16 + r) * kLanes] = acc1[r];
+      }
+    }
+    __syncthreads();
+    if (wave < half && wave + half < n_waves) {
+      const float* slot = ldsf + wave * 32 * kLanes + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc0[r] += slot[r * kLanes];
+        acc1[r] += slot[(16 + r) * kLanes];
+      }
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    // D layout of the 32x32 MFMA: column (draw) = lane & 31,
+    // row (r) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    double* out = a.partial +
+                  ((int64_t)slab * a.r_stride + (int64_t)blockIdx.z * kF32Tile) * a.ldb +
+                  col + (lane & 31);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      out[(int64_t)r * a.ldb] = (double)acc0[reg];
+      out[(int64_t)r * a.ldb + 32] = (double)acc1[reg];
+    }
   }
 }
 

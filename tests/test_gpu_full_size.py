@@ -173,3 +173,51 @@ def test_many_bins_cross_mode():
     expect = oracle.predict_zheng07_batch(table, theta[:4])
     assert_rel(ngal[:4], expect[0], RTOL)
     assert_rel(xi[:4], expect[1], RTOL)
+
+
+# north_star / BASELINE configs[4]: float32 path, stated tolerance 1e-5 relative
+RTOL_F32 = 1e-5
+
+
+@pytest.mark.parametrize('case', [
+    dict(n_prim=12, n_sec=1, tpcf_shape=(7, 9), mode='auto', seed=41),
+    dict(n_prim=9, n_sec=2, tpcf_shape=(40, ), mode='cross', seed=42),
+    dict(n_prim=50, n_sec=1, tpcf_shape=(19, ), mode='auto', seed=0),
+    dict(n_prim=70, n_sec=2, tpcf_shape=(3, ), mode='auto', seed=43)])
+def test_float32_variant_small(case):
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(**case)
+    theta = synthetic.zheng07_draws(200, seed=case['seed'] + 1)
+    halotab = make(table, compute_dtype='float32')
+    ngal, xi = halotab.predict_batch(theta)
+    expect = oracle.predict_zheng07_batch(table, theta[:40])
+    assert_rel(ngal[:40], expect[0], 1e-12)          # occupations stay float64
+    assert_rel(xi[:40], expect[1], RTOL_F32)
+    ngal_sep, xi_sep = halotab.predict_batch(theta, separate_gal_type=True)
+    assert_rel(sum(xi_sep.values()), xi, RTOL_F32)
+    expect = oracle.predict_zheng07_batch(table, theta[:10],
+                                          separate_gal_type=True)
+    for key in xi_sep:
+        scale = np.max(np.abs(expect[1][key]))
+        np.testing.assert_allclose(xi_sep[key][:10], expect[1][key],
+                                   rtol=RTOL_F32, atol=RTOL_F32 * scale)
+
+
+def test_config5_float32_mfma():
+    """BASELINE configs[4] at full size: 100 mass bins x {cen, sat}, tpcf_shape
+    (19, 40), float32 table and accumulation on the matrix cores."""
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(100, 1, (19, 40), 'auto', seed=9)
+    theta = synthetic.zheng07_draws(2000, seed=8)
+    halotab32 = make(table, compute_dtype='float32')
+    ngal, xi = halotab32.predict_batch(theta)
+    assert xi.shape == (2000, 19, 40)
+    expect = oracle.predict_zheng07_batch(table, theta[:3])
+    assert_rel(ngal[:3], expect[0], 1e-12)
+    assert_rel(xi[:3], expect[1], RTOL_F32)
+    # against the float64 kernel on all draws
+    ngal64, xi64 = make(table).predict_batch(theta)
+    assert_rel(xi, xi64, RTOL_F32)
+    assert np.max(np.abs(xi / xi64 - 1)) < RTOL_F32
