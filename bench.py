@@ -142,17 +142,28 @@ def main():
     n_bins = 2 * N_PRIM * N_SEC
     n_pairs = n_bins * (n_bins + 1) // 2
     flop_contract = n_draws * (2.0 * N_R * n_pairs + 3.0 * n_pairs)
-    ms = ctypes.c_float()
-    _lib.check(lib.tc_table_timer_begin(handle, 1))
-    profile_steps = min(args.steps, 200)
-    for index in range(profile_steps):
-        _lib.check(lib.tc_predict_zheng07_batch_device(
-            handle, d_theta, 5, n_draws, N_GAUSS, 0, out_ptr(0), out_ptr(0, n_draws)))
-    _lib.check(lib.tc_table_timer_end(handle, ctypes.byref(ms)))
-    n_launch = ctypes.c_int()
-    kernel_ms = ctypes.c_float()
-    _lib.check(lib.tc_table_kernel_time(handle, ctypes.byref(n_launch),
-                                        ctypes.byref(kernel_ms)))
+    drain()
+    def kernel_pass():
+        ms = ctypes.c_float()
+        _lib.check(lib.tc_table_timer_begin(handle, 1))
+        for index in range(min(args.steps, 200)):
+            _lib.check(lib.tc_predict_zheng07_batch_device(
+                handle, d_theta, 5, n_draws, N_GAUSS, 0, out_ptr(index % n_slots),
+                out_ptr(index % n_slots, n_draws)))
+        _lib.check(lib.tc_table_timer_end(handle, ctypes.byref(ms)))
+        n_launch = ctypes.c_int()
+        kernel_ms = ctypes.c_float()
+        _lib.check(lib.tc_table_kernel_time(handle, ctypes.byref(n_launch),
+                                            ctypes.byref(kernel_ms)))
+        return n_launch, kernel_ms
+
+    # as in the timed region: consecutive batches overlap on the table's two lanes, so
+    # the contraction shares the chip with the next batch's occupation kernel
+    n_launch, kernel_ms = kernel_pass()
+    # the kernel alone (batches serialised), for reference
+    os.environ['TC_PIPELINE'] = '0'
+    _, isolated_ms = kernel_pass()
+    os.environ['TC_PIPELINE'] = '1'
     launch = [ctypes.c_int() for _ in range(4)]
     lib.tc_table_last_launch(handle, *[ctypes.byref(v) for v in launch])
 
@@ -205,6 +216,9 @@ def main():
                 'flop_per_launch': flop_contract,
                 'mean_launch_ms': kernel_ms.value,
                 'launches_timed': n_launch.value,
+                'isolated_launch_ms': isolated_ms.value,
+                'isolated_frac': flop_contract / (isolated_ms.value * 1e-3) / 1e12 /
+                                 FP64_PEAK_TFLOPS,
                 'workgroups': launch[0].value,
                 'waves_per_workgroup': launch[1].value,
                 'lds_bytes': launch[3].value,

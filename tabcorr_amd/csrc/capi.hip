@@ -152,7 +152,23 @@ struct tc_table {
   std::map<int, Quadrature> quadrature;
   std::map<std::pair<int, int>, std::unique_ptr<DeviceChunking>> chunkings;
 
-  DeviceBuffer theta, nbuf, ngal2, partial, out_ngal, out_xi, occupation, trace;
+  // Two independent "lanes" (stream + workspaces).  Consecutive device-pointer
+  // predict calls alternate between them, so that the occupation kernel of batch k + 1
+  // overlaps the contraction of batch k (both are FP64-issue bound and the contraction
+  // leaves issue slots free at its ramp-down); results are still produced in call order
+  // (the finalisation kernels are chained by events).  Host-buffer calls use lane 0.
+  struct Lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t finished = nullptr;   // recorded after the lane's last finalisation
+    DeviceBuffer nbuf, ngal2, partial;
+    int ngal_parts = 1;              // partial sums the occupation step left in ngal2
+  };
+  Lane lanes[2];
+  int cur = 0;                       // lane of the current / last predict call
+  int force_lane = -1;               // host-buffer entry points pin lane 0
+  uint64_t device_calls = 0;
+  bool any_finished = false;
+  DeviceBuffer theta, out_ngal, out_xi, occupation, trace;
   PinnedBuffer h_in, h_out;
   size_t trace_blocks = 0;
 
@@ -161,7 +177,6 @@ struct tc_table {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> kernel_events;
   size_t kernel_events_used = 0;
   int last_workgroups = 0, last_waves = 0, last_splits = 0, last_lds = 0;
-  int ngal_parts = 1;   // partial sums the occupation step left in ngal2
 };
 
 namespace {
@@ -350,14 +365,16 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   int lds = 0;
   int status = choose_chunking(t, n_draws, n_comp, &c, &lds);
   if (status != TC_OK) return status;
+  tc_table::Lane& lane = t->lanes[t->cur];
+  hipStream_t stream = lane.stream;
   const int n_groups = (int)c->host.groups.size();
   const int r_stride = t->rt * t->n_rtiles;
-  status = t->partial.reserve(
-      (size_t)n_groups * r_stride * ldb * sizeof(double), t->stream);
+  status = lane.partial.reserve(
+      (size_t)n_groups * r_stride * ldb * sizeof(double), stream);
   if (status != TC_OK) return status;
 
   tc::ContractArgs ca;
-  ca.nbuf = (const double*)t->nbuf.ptr;
+  ca.nbuf = (const double*)lane.nbuf.ptr;
   ca.ldb = ldb;
   ca.table = t->d_table;
   ca.n_positions = t->plan.n_positions;
@@ -371,7 +388,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   ca.pos_ij = nullptr;
   if (env_int("TC_TRACE", 0)) {
     t->trace_blocks = (size_t)(ldb / 64) * n_groups * t->n_rtiles;
-    status = t->trace.reserve(t->trace_blocks * 6 * sizeof(unsigned long long), t->stream);
+    status = t->trace.reserve(t->trace_blocks * 6 * sizeof(unsigned long long), stream);
     if (status != TC_OK) return status;
     ca.trace = (unsigned long long*)t->trace.ptr;
   }
@@ -381,7 +398,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   ca.nbufs = nullptr;
   ca.table_class = nullptr;
   ca.coef = nullptr;
-  ca.partial = (double*)t->partial.ptr;
+  ca.partial = (double*)lane.partial.ptr;
 
   const int n_tiles = (int)(ldb / 64);
   ca.n_tiles = n_tiles;
@@ -403,7 +420,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
     k0 = t->kernel_events[t->kernel_events_used].first;
     k1 = t->kernel_events[t->kernel_events_used].second;
     ++t->kernel_events_used;
-    TC_HIP(hipEventRecord(k0, t->stream));
+    TC_HIP(hipEventRecord(k0, stream));
   }
   if (t->compute_dtype == TC_DTYPE_F32) {
     ca.pos_ij = (const int32_t*)t->d_pos_ij;
@@ -411,23 +428,23 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
       TC_HIP(hipFuncSetAttribute(
           reinterpret_cast<const void*>(&tc::contract_f32_kernel),
           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(tc::contract_f32_kernel, grid, block, lds, t->stream, ca);
+    hipLaunchKernelGGL(tc::contract_f32_kernel, grid, block, lds, stream, ca);
     TC_HIP(hipGetLastError());
   } else {
-    status = launch_contract_rt(t->rt, grid, block, lds, t->stream, ca);
+    status = launch_contract_rt(t->rt, grid, block, lds, stream, ca);
     if (status != TC_OK) return status;
   }
-  if (t->profile_kernels) TC_HIP(hipEventRecord(k1, t->stream));
+  if (t->profile_kernels) TC_HIP(hipEventRecord(k1, stream));
   t->last_workgroups = n_tiles * n_groups * t->n_rtiles;
   t->last_waves = c->host.waves_per_group;
   t->last_splits = n_groups;
   t->last_lds = lds;
 
   tc::FinalizeArgs fa;
-  fa.partial = (const double*)t->partial.ptr;
+  fa.partial = (const double*)lane.partial.ptr;
   fa.groups = (const tc::Group*)c->groups;
-  fa.ngal_part = (const double*)t->ngal2.ptr;
-  fa.n_ngal_parts = t->ngal_parts;
+  fa.ngal_part = (const double*)lane.ngal2.ptr;
+  fa.n_ngal_parts = lane.ngal_parts;
   fa.n_groups = n_groups;
   fa.k_splits = 1;
   fa.n_comp = n_comp;
@@ -438,9 +455,15 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   fa.n_draws = n_draws;
   fa.ngal = ngal_device;
   fa.xi = xi_device;
+  // results appear in call order: wait for the other lane's last finalisation
+  tc_table::Lane& other = t->lanes[t->cur ^ 1];
+  if (t->any_finished && other.finished != nullptr)
+    TC_HIP(hipStreamWaitEvent(stream, other.finished, 0));
   hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)(ldb / 64)), dim3(1024), 0,
-                     t->stream, fa);
+                     stream, fa);
   TC_HIP(hipGetLastError());
+  TC_HIP(hipEventRecord(lane.finished, stream));
+  t->any_finished = true;
   return TC_OK;
 }
 
@@ -449,9 +472,10 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
                    double* occupation_device, DeviceBuffer* nbuf = nullptr,
                    DeviceBuffer* ngal2 = nullptr, hipStream_t stream = nullptr,
                    int* ngal_parts = nullptr) {
-  if (nbuf == nullptr) nbuf = &t->nbuf;
-  if (ngal2 == nullptr) ngal2 = &t->ngal2;
-  if (stream == nullptr) stream = t->stream;
+  tc_table::Lane& lane = t->lanes[t->cur];
+  if (nbuf == nullptr) nbuf = &lane.nbuf;
+  if (ngal2 == nullptr) ngal2 = &lane.ngal2;
+  if (stream == nullptr) stream = lane.stream;
   Quadrature* q = nullptr;
   int status = get_quadrature(t, n_gauss, &q);
   if (status != TC_OK) return status;
@@ -465,7 +489,7 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   if (status == TC_OK)
     status = ngal2->reserve((size_t)splits * 2 * ldb * sizeof(double), stream);
   if (status != TC_OK) return status;
-  if (ngal_parts != nullptr) *ngal_parts = splits; else t->ngal_parts = splits;
+  if (ngal_parts != nullptr) *ngal_parts = splits; else lane.ngal_parts = splits;
   tc::OccArgs oa;
   oa.theta = theta_device;
   oa.n_theta = n_theta;
@@ -787,7 +811,11 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
       pos_ij[(size_t)block * 8 + k * 4 + p] = (i << 16) | t->plan.pos_j[q];
     }
   }
-  TC_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+  for (tc_table::Lane& lane : t->lanes) {
+    TC_HIP(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
+    TC_HIP(hipEventCreateWithFlags(&lane.finished, hipEventDisableTiming));
+  }
+  t->stream = t->lanes[0].stream;
   TC_HIP(hipEventCreate(&t->ev_begin));
   TC_HIP(hipEventCreate(&t->ev_end));
   int status = compute_dtype == TC_DTYPE_F64 ? upload(tmp64, &t->d_table)
@@ -813,7 +841,8 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
 int tc_table_destroy(tc_table* t) {
   if (t == nullptr) return TC_OK;
   (void)hipSetDevice(t->device);
-  if (t->stream) (void)hipStreamSynchronize(t->stream);
+  for (tc_table::Lane& lane : t->lanes)
+    if (lane.stream) (void)hipStreamSynchronize(lane.stream);
   for (void* p : {t->d_table, t->d_n_h, t->d_percentile, t->d_perm, t->d_math_table,
                   t->d_pos_ij})
     if (p) (void)hipFree(p);
@@ -823,9 +852,15 @@ int tc_table_destroy(tc_table* t) {
   for (auto& kv : t->chunkings)
     for (void* p : {kv.second->chunks, kv.second->groups})
       if (p) (void)hipFree(p);
-  for (DeviceBuffer* b : {&t->theta, &t->nbuf, &t->ngal2, &t->partial,
-                          &t->out_ngal, &t->out_xi, &t->occupation, &t->trace})
+  for (DeviceBuffer* b : {&t->theta, &t->out_ngal, &t->out_xi, &t->occupation,
+                          &t->trace})
     b->release();
+  for (tc_table::Lane& lane : t->lanes) {
+    lane.nbuf.release();
+    lane.ngal2.release();
+    lane.partial.release();
+    if (lane.finished) (void)hipEventDestroy(lane.finished);
+  }
   t->h_in.release();
   t->h_out.release();
   for (auto& ev : t->kernel_events) {
@@ -834,14 +869,15 @@ int tc_table_destroy(tc_table* t) {
   }
   if (t->ev_begin) (void)hipEventDestroy(t->ev_begin);
   if (t->ev_end) (void)hipEventDestroy(t->ev_end);
-  if (t->stream) (void)hipStreamDestroy(t->stream);
+  for (tc_table::Lane& lane : t->lanes)
+    if (lane.stream) (void)hipStreamDestroy(lane.stream);
   delete t;
   return TC_OK;
 }
 
 int tc_table_synchronize(tc_table* t) {
   TC_CHECK(t != nullptr, "table handle is NULL");
-  TC_HIP(hipStreamSynchronize(t->stream));
+  for (tc_table::Lane& lane : t->lanes) TC_HIP(hipStreamSynchronize(lane.stream));
   return TC_OK;
 }
 
@@ -868,6 +904,10 @@ int tc_predict_zheng07_batch_device(tc_table* t, const double* theta_device,
   TC_HIP(hipSetDevice(t->device));
   const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
   const int n_comp = separate ? t->plan.n_components : 1;
+  if (t->force_lane >= 0)
+    t->cur = t->force_lane;
+  else
+    t->cur = env_int("TC_PIPELINE", 1) ? (int)(t->device_calls++ & 1) : 0;
   for (int64_t begin = 0; begin < n_draws; begin += kMaxSlab) {
     const int64_t n = std::min(kMaxSlab, n_draws - begin);
     const int64_t ldb = (n + 63) / 64 * 64;
@@ -936,9 +976,11 @@ int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
   status = copy_in(&t->h_in, t->theta.ptr, theta, (size_t)n_draws * n_theta * 8,
                    t->stream);
   if (status != TC_OK) return status;
+  t->force_lane = 0;
   status = tc_predict_zheng07_batch_device(
       t, (const double*)t->theta.ptr, n_theta, n_draws, n_gauss, flags,
       (double*)t->out_ngal.ptr, (double*)t->out_xi.ptr);
+  t->force_lane = -1;
   if (status != TC_OK) return status;
   return copy_out(&t->h_out, ngal, ngal_count, t->out_ngal.ptr, xi, xi_count,
                   t->out_xi.ptr, t->stream);
@@ -974,9 +1016,11 @@ int tc_chi2_zheng07_batch(tc_table* t, const double* theta, int n_theta,
                         hipMemcpyHostToDevice, t->stream));
   double* d_ngal = (double*)t->out_ngal.ptr;
   double* d_chi2 = d_ngal + n_draws;
+  t->force_lane = 0;
   status = tc_predict_zheng07_batch_device(t, (const double*)t->theta.ptr, n_theta,
                                            n_draws, n_gauss, flags, d_ngal,
                                            (double*)t->out_xi.ptr);
+  t->force_lane = -1;
   if (status != TC_OK) return status;
   hipLaunchKernelGGL(tc::chi2_kernel, dim3((unsigned)((n_draws + 255) / 256)), dim3(256),
                      0, t->stream, (const double*)t->out_xi.ptr, n_draws, n_r,
@@ -1003,6 +1047,7 @@ int tc_mean_occupation_zheng07_batch(tc_table* t, const double* theta, int n_the
     if (status != TC_OK) return status;
     TC_HIP(hipMemcpyAsync(t->theta.ptr, theta + begin * n_theta,
                           (size_t)n * n_theta * 8, hipMemcpyHostToDevice, t->stream));
+    t->cur = 0;
     status = run_occupation(t, (const double*)t->theta.ptr, n_theta, n, ldb, n_gauss,
                             flags, (double*)t->occupation.ptr);
     if (status != TC_OK) return status;
@@ -1031,8 +1076,9 @@ int tc_predict_occupation_batch(tc_table* t, const double* occupation,
     const size_t xi_count = (size_t)n * n_comp * t->n_r;
     int status = t->occupation.reserve(occ_bytes, t->stream);
     if (status == TC_OK)
-      status = t->nbuf.reserve((size_t)t->n_bins * ldb * 8, t->stream);
-    if (status == TC_OK) status = t->ngal2.reserve(2 * ldb * 8, t->stream);
+      status = t->lanes[0].nbuf.reserve((size_t)t->n_bins * ldb * 8, t->stream);
+    if (status == TC_OK)
+      status = t->lanes[0].ngal2.reserve(2 * ldb * 8, t->stream);
     if (status == TC_OK) status = t->out_ngal.reserve(ngal_count * 8, t->stream);
     if (status == TC_OK) status = t->out_xi.reserve(xi_count * 8, t->stream);
     if (status != TC_OK) return status;
@@ -1043,10 +1089,11 @@ int tc_predict_occupation_batch(tc_table* t, const double* occupation,
                        dim3((unsigned)((ldb + 255) / 256)), dim3(256), 0, t->stream,
                        (const double*)t->occupation.ptr, n, ldb, t->n_bins,
                        t->plan.n_central, (const double*)t->d_n_h,
-                       (const int32_t*)t->d_perm, (double*)t->nbuf.ptr,
-                       (double*)t->ngal2.ptr);
+                       (const int32_t*)t->d_perm, (double*)t->lanes[0].nbuf.ptr,
+                       (double*)t->lanes[0].ngal2.ptr);
     TC_HIP(hipGetLastError());
-    t->ngal_parts = 1;
+    t->cur = 0;
+    t->lanes[0].ngal_parts = 1;
     status = run_contraction(t, n, ldb, flags, (double*)t->out_ngal.ptr,
                              (double*)t->out_xi.ptr);
     if (status != TC_OK) return status;
@@ -1069,6 +1116,7 @@ int tc_table_timer_begin(tc_table* t, int profile_kernels) {
 
 int tc_table_timer_end(tc_table* t, float* elapsed_ms) {
   TC_CHECK(t != nullptr && elapsed_ms != nullptr, "NULL argument");
+  TC_HIP(hipStreamSynchronize(t->lanes[1].stream));
   TC_HIP(hipEventRecord(t->ev_end, t->stream));
   TC_HIP(hipEventSynchronize(t->ev_end));
   TC_HIP(hipEventElapsedTime(elapsed_ms, t->ev_begin, t->ev_end));
@@ -1095,7 +1143,7 @@ int tc_debug_trace(tc_table* t, uint64_t* out, int64_t capacity, int64_t* n_bloc
   TC_CHECK(t != nullptr && n_blocks != nullptr, "NULL argument");
   *n_blocks = (int64_t)t->trace_blocks;
   if (out == nullptr || t->trace.ptr == nullptr) return TC_OK;
-  TC_HIP(hipStreamSynchronize(t->stream));
+  for (tc_table::Lane& lane : t->lanes) TC_HIP(hipStreamSynchronize(lane.stream));
   const int64_t n = std::min<int64_t>(capacity, (int64_t)t->trace_blocks);
   TC_HIP(hipMemcpy(out, t->trace.ptr, (size_t)n * 6 * sizeof(uint64_t),
                    hipMemcpyDeviceToHost));
@@ -1624,7 +1672,7 @@ int tc_comm_gather(tc_comm* c, tc_table* t, const double* send_device,
   if (t != nullptr) {
     // the gather starts once the predictions queued on the table's stream are done,
     // without blocking the host: later batches overlap with the transfer
-    TC_HIP(hipEventRecord(c->ready, t->stream));
+    TC_HIP(hipEventRecord(c->ready, t->lanes[t->cur].stream));
     TC_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
   }
   TC_RCCL(g_rccl.Gather(send_device, recv_device, (size_t)count, kNcclFloat64, root,
@@ -1637,7 +1685,8 @@ int tc_comm_release(tc_comm* c, tc_table* t, int slot) {
   TC_CHECK(c != nullptr && t != nullptr, "NULL argument");
   TC_CHECK(slot >= 0 && slot < 4, "slot must be in [0, 4)");
   TC_HIP(hipSetDevice(c->device));
-  TC_HIP(hipStreamWaitEvent(t->stream, c->done[slot], 0));
+  for (tc_table::Lane& lane : t->lanes)
+    TC_HIP(hipStreamWaitEvent(lane.stream, c->done[slot], 0));
   return TC_OK;
 }
 

@@ -99,3 +99,9 @@ if __name__ == '__main__':
                 os.environ['TC_NWAVES'] = str(nw)
                 os.environ['TC_NGROUPS'] = str(ng)
                 run(50, 1, (19, ), 10000, 50, 'cfg2 nw=%d ngroups=%d' % (nw, ng))
+    elif which == 'cfg5':
+        for dtype in ['float64', 'float32']:
+            run(100, 1, (19, 40), 10000, 5, 'cfg5 %s' % dtype, dtype=dtype)
+        for nw in [4, 8]:
+            os.environ['TC_NWAVES'] = str(nw)
+            run(100, 1, (19, 40), 10000, 5, 'cfg5 float32 nwaves(arg)=%d' % nw, dtype='float32')
