@@ -14,9 +14,10 @@ in HBM and the results left in HBM.
 
 Multi-GPU: weak scaling, one process per GPU, every rank runs its own 10^4 draws per
 step against its own replica of the table (the path shards over draws without any
-data-path collective); the results of every step are collected on rank 0 by one RCCL
-gather over xGMI on a second stream, overlapped with the next step.  PyTorch is only
-used for the gloo control plane (rendezvous, barrier, max over ranks).
+data-path collective); the results of all steps are collected on rank 0 by one RCCL
+gather over xGMI per block of --gather-every steps, on a second stream, overlapped with
+the following steps.  PyTorch is only used for the gloo control plane (rendezvous,
+barrier, max over ranks).
 
 Rank 0 prints ONE JSON line.  Extra objects: ``roofline`` (contraction kernel:
 algorithmic flop per launch / mean launch duration from HIP events on the kernel's
@@ -52,6 +53,8 @@ def main():
     parser.add_argument('--warmup', type=int, default=20)
     parser.add_argument('--draws', type=int, default=10000,
                         help='draws per GPU per step')
+    parser.add_argument('--gather-every', type=int, default=8,
+                        help='multi-GPU: steps per RCCL gather of the results')
     parser.add_argument('--cpu-seconds', type=float, default=12.0,
                         help='budget of the CPU baseline sample (0: skip)')
     args = parser.parse_args()
@@ -89,27 +92,39 @@ def main():
     d_theta = dmalloc(theta.size)
     _lib.check(lib.tc_memcpy_h2d(d_theta, theta.ctypes.data_as(ctypes.c_void_p),
                                  theta.nbytes))
-    n_slots = 2
+    # Results ring: 2 blocks of `every` steps.  A block is gathered on rank 0 (RCCL, own
+    # stream) once its last step is queued; the other block keeps filling meanwhile.
+    every = max(1, args.gather_every)
+    n_slots = 2 * every
     d_out = dmalloc(n_slots * n_out)
     use_rccl = comm.comm is not None
-    d_recv = dmalloc(n_slots * comm.world_size * n_out) if (
+    d_recv = dmalloc(2 * comm.world_size * every * n_out) if (
         use_rccl and comm.is_root) else ctypes.c_void_p()
 
     def out_ptr(slot, offset=0):
         return ctypes.c_void_p(d_out.value + (slot * n_out + offset) * 8)
 
+    def gather_block(block, n_steps):
+        recv = ctypes.c_void_p(
+            d_recv.value + block * comm.world_size * every * n_out * 8) if (
+                comm.is_root) else None
+        comm.gather_device(handle, out_ptr(block * every), recv, n_steps * n_out, block)
+
     def step(index):
         slot = index % n_slots
-        if use_rccl and index >= n_slots:
-            comm.release(handle, slot)          # gather of step index - 2 is done
+        block = slot // every
+        if use_rccl and index >= n_slots and slot % every == 0:
+            comm.release(handle, block)         # the block's previous gather is done
         _lib.check(lib.tc_predict_zheng07_batch_device(
             handle, d_theta, 5, n_draws, N_GAUSS, 0, out_ptr(slot),
             out_ptr(slot, n_draws)))
-        if use_rccl:
-            recv = ctypes.c_void_p(
-                d_recv.value + slot * comm.world_size * n_out * 8) if (
-                    comm.is_root) else None
-            comm.gather_device(handle, out_ptr(slot), recv, n_out, slot)
+        if use_rccl and slot % every == every - 1:
+            gather_block(block, every)
+
+    def flush(n_steps):
+        """Gather the steps of a trailing, partly filled block."""
+        if use_rccl and n_steps % every:
+            gather_block(((n_steps - 1) % n_slots) // every, n_steps % every)
 
     def drain():
         _lib.check(lib.tc_table_synchronize(handle))
@@ -118,6 +133,7 @@ def main():
 
     for index in range(args.warmup):
         step(index)
+    flush(args.warmup)
     drain()
 
     # ---- timed region: exactly `steps` steps between barrier + device sync -----------
@@ -126,6 +142,7 @@ def main():
     t0 = time.perf_counter()
     for index in range(args.steps):
         step(index)
+    flush(args.steps)
     drain()
     comm.barrier()
     elapsed = comm.max(time.perf_counter() - t0)
@@ -204,9 +221,10 @@ def main():
                 'parallelism': 'draws sharded over %d GPU(s), table replicated' %
                                comm.world_size,
                 'gather': comm.gather_backend,
+                'gather_every_steps': every,
             },
             'roofline': {
-                'kernel': 'tc::contract_kernel<20>',
+                'kernel': 'tc::contract_kernel<20, false>',
                 'bound': 'mfma',
                 'achieved': achieved,
                 'peak': FP64_PEAK_TFLOPS,

@@ -163,11 +163,13 @@ struct tc_table {
     DeviceBuffer nbuf, ngal2, partial;
     int ngal_parts = 1;              // partial sums the occupation step left in ngal2
   };
-  Lane lanes[2];
+  static constexpr int kMaxLanes = 4;
+  Lane lanes[kMaxLanes];
+  int n_lanes = 2;
+  int prev = -1;                     // lane of the previous finalisation
   int cur = 0;                       // lane of the current / last predict call
   int force_lane = -1;               // host-buffer entry points pin lane 0
   uint64_t device_calls = 0;
-  bool any_finished = false;
   DeviceBuffer theta, out_ngal, out_xi, occupation, trace;
   PinnedBuffer h_in, h_out;
   size_t trace_blocks = 0;
@@ -455,15 +457,14 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   fa.n_draws = n_draws;
   fa.ngal = ngal_device;
   fa.xi = xi_device;
-  // results appear in call order: wait for the other lane's last finalisation
-  tc_table::Lane& other = t->lanes[t->cur ^ 1];
-  if (t->any_finished && other.finished != nullptr)
-    TC_HIP(hipStreamWaitEvent(stream, other.finished, 0));
+  // results appear in call order: wait for the previous call's finalisation
+  if (t->prev >= 0 && t->prev != t->cur)
+    TC_HIP(hipStreamWaitEvent(stream, t->lanes[t->prev].finished, 0));
   hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)(ldb / 64)), dim3(1024), 0,
                      stream, fa);
   TC_HIP(hipGetLastError());
   TC_HIP(hipEventRecord(lane.finished, stream));
-  t->any_finished = true;
+  t->prev = t->cur;
   return TC_OK;
 }
 
@@ -816,6 +817,7 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
     TC_HIP(hipEventCreateWithFlags(&lane.finished, hipEventDisableTiming));
   }
   t->stream = t->lanes[0].stream;
+  t->n_lanes = std::max(1, std::min(env_int("TC_LANES", 3), (int)tc_table::kMaxLanes));
   TC_HIP(hipEventCreate(&t->ev_begin));
   TC_HIP(hipEventCreate(&t->ev_end));
   int status = compute_dtype == TC_DTYPE_F64 ? upload(tmp64, &t->d_table)
@@ -907,7 +909,7 @@ int tc_predict_zheng07_batch_device(tc_table* t, const double* theta_device,
   if (t->force_lane >= 0)
     t->cur = t->force_lane;
   else
-    t->cur = env_int("TC_PIPELINE", 1) ? (int)(t->device_calls++ & 1) : 0;
+    t->cur = env_int("TC_PIPELINE", 1) ? (int)(t->device_calls++ % t->n_lanes) : 0;
   for (int64_t begin = 0; begin < n_draws; begin += kMaxSlab) {
     const int64_t n = std::min(kMaxSlab, n_draws - begin);
     const int64_t ldb = (n + 63) / 64 * 64;
@@ -1116,7 +1118,8 @@ int tc_table_timer_begin(tc_table* t, int profile_kernels) {
 
 int tc_table_timer_end(tc_table* t, float* elapsed_ms) {
   TC_CHECK(t != nullptr && elapsed_ms != nullptr, "NULL argument");
-  TC_HIP(hipStreamSynchronize(t->lanes[1].stream));
+  for (int l = 1; l < tc_table::kMaxLanes; ++l)
+    TC_HIP(hipStreamSynchronize(t->lanes[l].stream));
   TC_HIP(hipEventRecord(t->ev_end, t->stream));
   TC_HIP(hipEventSynchronize(t->ev_end));
   TC_HIP(hipEventElapsedTime(elapsed_ms, t->ev_begin, t->ev_end));
