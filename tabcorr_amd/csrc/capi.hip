@@ -385,7 +385,6 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   ca.mode = t->mode;
   ca.n_central = t->plan.n_central;
   ca.r_stride = r_stride;
-  ca.debug = env_int("TC_DEBUG_VARIANT", 0);
   ca.trace = nullptr;
   ca.pos_ij = nullptr;
   if (env_int("TC_TRACE", 0)) {
@@ -508,7 +507,6 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   oa.percentile = (const double*)t->d_percentile;
   oa.perm = (const int32_t*)t->d_perm;
   oa.math_table = (const double*)t->d_math_table;
-  oa.debug = env_int("TC_OCC_DEBUG", 0);
   oa.nbuf = (double*)nbuf->ptr;
   oa.ngal = (double*)ngal2->ptr;
   oa.occupation = occupation_device;
@@ -1299,7 +1297,6 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   ca.mode = t0->mode;
   ca.n_central = t0->plan.n_central;
   ca.r_stride = r_stride;
-  ca.debug = 0;
   ca.trace = nullptr;
   ca.pos_ij = nullptr;
   ca.partial = (double*)it->partial.ptr;

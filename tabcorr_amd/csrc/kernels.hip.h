@@ -45,7 +45,6 @@ struct OccArgs {
   const double* percentile;  // (n_bins)
   const int32_t* perm;     // library bin -> reference row
   const double* math_table;  // fm::kTableDoubles doubles (fastmath.h)
-  int debug;               // developer ablations (TC_OCC_DEBUG), 0 in production
   double* nbuf;            // (n_bins, ldb) number density per bin and draw
   double* ngal;            // (bin splits, 2, ldb) partial cen / sat densities
   double* occupation;      // optional (n_draws, n_bins) in reference order
@@ -101,7 +100,7 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     const int hi = fm::kTableDoubles / 2;
     const double2v* src = (const double2v*)a.math_table;
     double2v* dst = (double2v*)table;
-    int i = (a.debug & 2) ? hi : lo + threadIdx.x;
+    int i = lo + threadIdx.x;
     for (; i + 3 * (int)blockDim.x < hi; i += 4 * blockDim.x) {
       double2v v[4];
 #pragma unroll
@@ -139,9 +138,7 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     const bool central = g < a.n_central;
     const bool above = percentile[g] > a.split;
     double acc = 0.0;
-    if (a.debug & 1) {
-      acc = log_m_min;
-    } else if (central) {
+    if (central) {
 #pragma unroll
       for (int k = 0; k < n_gauss; ++k) {
         const double lm = log_m[g * n_gauss + k];
@@ -168,8 +165,7 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     if (a.occupation != nullptr && b0 < a.n_draws)
       a.occupation[b0 * a.n_bins + perm[g]] = acc;
     const double dens = acc * n_h[g];
-    if (!(a.debug & 4))
-      a.nbuf[(int64_t)g * a.ldb + (int64_t)blockIdx.x * kLanes + lane] = dens;
+    a.nbuf[(int64_t)g * a.ldb + (int64_t)blockIdx.x * kLanes + lane] = dens;
     if (central) sum_cen += dens; else sum_sat += dens;
   }
   red[0][wave][lane] = sum_cen;
@@ -213,7 +209,6 @@ struct ContractArgs {
   int mode;
   int n_central;
   int r_stride;             // n_rtiles * RT: padded number of r values
-  int debug;                // developer ablations (TC_DEBUG_VARIANT), 0 in production
   int n_tiles;              // draw tiles (grid.x covers 8 * ceil(n_tiles / 8) * slabs)
   int n_slabs;              // groups * table splits per draw tile
   const int32_t* pos_ij;    // float32 kernel: packed bin pairs of every position
@@ -257,7 +252,7 @@ __device__ __forceinline__ void entry_fma(
 
 // Per-wave walk state over the entries of one component.
 struct WalkState {
-  int i, j, remaining, row_lo, i_shift, j_lo, j_last, debug;
+  int i, j, remaining, row_lo, i_shift, j_lo, j_last;
   double ni;      // density of row i times `scale`
   double scale;   // per-draw weight of the current table (1 without interpolation)
 };
@@ -266,11 +261,11 @@ template <int RT, int E>
 __device__ __forceinline__ void block_entry(
     double (&acc)[RT], const double (&t)[ContractGeometry<RT>::NG],
     WalkState& st, const double* lds, int lane) {
-  const double nj = (st.debug & 2) ? 1.5 : lds[(st.j - st.row_lo) * kLanes + lane];
+  const double nj = lds[(st.j - st.row_lo) * kLanes + lane];
   const double w = st.ni * nj;
   entry_fma<RT, E>(acc, t, w, std::make_integer_sequence<int, RT>());
   // step to the next real entry (padding keeps the last real pair)
-  if (!(st.debug & 32) && --st.remaining > 0) {
+  if (--st.remaining > 0) {
     const int last = st.j_last >= 0 ? st.j_last : st.i;
     if (++st.j > last) {
       ++st.i;
@@ -351,7 +346,7 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
         return (gl_f64x2)(src + (int64_t)bin * a.ldb + (id & 31) * 2);
       };
       const int nthreads = blockDim.x;
-      int it = (a.debug & 8) ? n_items : threadIdx.x;
+      int it = threadIdx.x;
       for (; it + 3 * nthreads < n_items; it += 4 * nthreads) {
         double2v v[4];
 #pragma unroll
@@ -382,7 +377,6 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
       st.i_shift = group.i_shift;
       st.j_lo = chunk.j_lo;
       st.j_last = chunk.j_last;
-      st.debug = a.debug;
       st.scale = interp ? a.coef[(int64_t)k * a.ldb + col + lane] : 1.0;
       st.ni = a.mode == 0
                   ? lds[(chunk.i0 + group.i_shift) * kLanes + lane] * st.scale
@@ -391,7 +385,7 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
       gl_f64 table = (gl_f64)(interp ? a.tables[k] : (const double*)a.table) +
                      ((int64_t)blockIdx.z * a.n_positions + chunk.q_begin) * RT +
                      (lane & 15);
-      const int n_blocks = (a.debug & 4) ? 0 : (chunk.q_end - chunk.q_begin) / EB;
+      const int n_blocks = (chunk.q_end - chunk.q_begin) / EB;
       double ta[NG], tb[NG];
 #pragma unroll
       for (int g = 0; g < NG; ++g) ta[g] = table[g * 16];
@@ -426,7 +420,7 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
   // adds them in registers.
   int span = 1;
   while (span < n_waves) span <<= 1;
-  for (int half = (a.debug & 16) ? 0 : span >> 1; half >= 1; half >>= 1) {
+  for (int half = span >> 1; half >= 1; half >>= 1) {
     if (wave >= half && wave < 2 * half) {
       double* slot = lds + (wave - half) * RT * kLanes + lane;
 #pragma unroll

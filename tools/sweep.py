@@ -82,15 +82,6 @@ if __name__ == '__main__':
         run(50, 1, (19, ), 1000000, 3, 'cfg2 B=1e6')
     elif which == 'one':
         run(50, 1, (19, ), 10000, 50, 'cfg2 default')
-    elif which == 'ablate':
-        for tw, nw in [(4096, 8), (2048, 8)]:
-            os.environ['TC_TARGET_WAVES'] = str(tw)
-            os.environ['TC_NWAVES'] = str(nw)
-            for lds in [0, 56000, 81920]:
-                os.environ['TC_LDS_MIN'] = str(lds)
-                for dbg in [0, 35]:
-                    os.environ['TC_DEBUG_VARIANT'] = str(dbg)
-                    run(50, 1, (19, ), 10000, 20, 'tw=%d nw=%d lds=%d debug=%d' % (tw, nw, lds, dbg))
     elif which == 'stats':
         run(50, 1, (19, ), 10000, 200, 'cfg2 default')
     elif which == 'groups':
