@@ -459,8 +459,8 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   // results appear in call order: wait for the previous call's finalisation
   if (t->prev >= 0 && t->prev != t->cur)
     TC_HIP(hipStreamWaitEvent(stream, t->lanes[t->prev].finished, 0));
-  hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)(ldb / 64)), dim3(1024), 0,
-                     stream, fa);
+  hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)(ldb / 64)),
+                     dim3(env_int("TC_FINALIZE_THREADS", 256)), 0, stream, fa);
   TC_HIP(hipGetLastError());
   TC_HIP(hipEventRecord(lane.finished, stream));
   t->prev = t->cur;
@@ -1333,7 +1333,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   fa.n_draws = n_draws;
   fa.ngal = ngal_device;
   fa.xi = xi_device;
-  hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)n_tiles), dim3(1024), 0,
+  hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)n_tiles), dim3(256), 0,
                      it->stream, fa);
   TC_HIP(hipGetLastError());
   return TC_OK;

@@ -257,14 +257,11 @@ struct WalkState {
   double scale;   // per-draw weight of the current table (1 without interpolation)
 };
 
-template <int RT, int E>
-__device__ __forceinline__ void block_entry(
-    double (&acc)[RT], const double (&t)[ContractGeometry<RT>::NG],
-    WalkState& st, const double* lds, int lane) {
+// Weight of the walk's current entry, then step to the next real entry (padding keeps
+// the last real pair: its table rows are zero).
+__device__ __forceinline__ double next_weight(WalkState& st, const double* lds, int lane) {
   const double nj = lds[(st.j - st.row_lo) * kLanes + lane];
   const double w = st.ni * nj;
-  entry_fma<RT, E>(acc, t, w, std::make_integer_sequence<int, RT>());
-  // step to the next real entry (padding keeps the last real pair)
   if (--st.remaining > 0) {
     const int last = st.j_last >= 0 ? st.j_last : st.i;
     if (++st.j > last) {
@@ -273,6 +270,7 @@ __device__ __forceinline__ void block_entry(
       st.ni = lds[(st.i + st.i_shift) * kLanes + lane] * st.scale;
     }
   }
+  return w;
 }
 
 template <int RT, int... Es>
@@ -280,7 +278,11 @@ __device__ __forceinline__ void block_compute(
     double (&acc)[RT], const double (&t)[ContractGeometry<RT>::NG],
     WalkState& st, const double* lds, int lane,
     std::integer_sequence<int, Es...>) {
-  (block_entry<RT, Es>(acc, t, st, lds, lane), ...);
+  // all weights of the block first (one LDS round trip per block instead of one per
+  // entry), then the FMAs
+  double w[sizeof...(Es)];
+  ((w[Es] = next_weight(st, lds, lane)), ...);
+  (entry_fma<RT, Es>(acc, t, w[Es], std::make_integer_sequence<int, RT>()), ...);
 }
 
 // Contraction of the re-laid-out table with the pair weights of 64 draws:
@@ -601,7 +603,7 @@ struct FinalizeArgs {
   double* xi;              // (n_draws, n_comp, n_r)
 };
 
-constexpr int kFinalizeRows = 64;   // (component, r) rows per LDS pass
+constexpr int kFinalizeRows = 32;   // (component, r) rows per LDS pass
 
 // Sum the per-group partials in fixed order, divide by the total pair weight
 // (tabcorr.py:646-649, 653-655: sum(ngal_sq) = (sum ngal)^2 in mode auto) and
