@@ -151,6 +151,7 @@ struct tc_table {
   void* d_pos_ij = nullptr;      // float32 variant: packed bin pairs per position
   std::map<int, Quadrature> quadrature;
   std::map<std::pair<int, int>, std::unique_ptr<DeviceChunking>> chunkings;
+  std::map<int64_t, DeviceChunking*> choices;   // decomposition chosen per tile count
 
   // Two independent "lanes" (stream + workspaces).  Consecutive device-pointer
   // predict calls alternate between them, so that the occupation kernel of batch k + 1
@@ -260,57 +261,78 @@ int blocks_per_cu(int lds_bytes, int waves) {
 }
 
 // Pick the decomposition for a batch.  Draw tiles alone rarely fill the chip (10^4
-// draws are 157 tiles), so the table is additionally cut into groups of `waves` chunks;
-// the number of groups is chosen so that all workgroups are resident at once and every
-// CU holds the same number of them (one balanced round), and small enough that a chunk
-// keeps at least TC_MIN_CHUNK_ENTRIES entries.
+// draws are 157 tiles), so the table is additionally cut into groups of `waves` chunks.
+// Candidates (4 or 8 waves per workgroup, 1..32 groups) are ranked by a small cost model
+// of the busiest CU -- workgroups per CU x waves x (entries per wave + fixed overhead),
+// penalised when fewer than four waves per SIMD are resident or when the workgroups need
+// several scheduling rounds -- calibrated on per-workgroup timelines (tools/trace.py):
+// the main loop issues one FP64 VALU instruction per 4 cycles per SIMD as long as >= 4
+// waves per SIMD are resident, and idle time comes from uneven workgroup counts per CU.
 int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
                     DeviceChunking** out, int* lds_bytes) {
   (void)n_comp_out;
   const int64_t n_tiles = (n_draws + 63) / 64 * t->n_rtiles;
-  const int64_t min_entries = env_int("TC_MIN_CHUNK_ENTRIES", 32);
-  const int n_cus = 256;
-  int waves = std::max(1, std::min(env_int("TC_NWAVES", 4), 16));
-  if (t->compute_dtype == TC_DTYPE_F32) waves = std::min(waves * 2, 8);
+  const int elem = t->compute_dtype == TC_DTYPE_F32 ? 4 : 8;
   const int forced_groups = env_int("TC_NGROUPS", 0);
-
-  int capacity = 5;
-  DeviceChunking* best = nullptr;
-  for (int attempt = 0; attempt < 4; ++attempt) {
-    int64_t n_groups = std::max<int64_t>(1, (int64_t)capacity * n_cus / n_tiles);
-    if (forced_groups > 0) n_groups = forced_groups;
-    int64_t n_chunks = n_groups * waves;
-    n_chunks = std::min<int64_t>(n_chunks,
-                                 std::max<int64_t>(1, t->plan.n_entries / min_entries));
-    n_chunks = std::min<int64_t>(n_chunks, 4096);
-    n_chunks = env_int("TC_NCHUNKS", (int)n_chunks);
-    const int use_waves = (int)std::min<int64_t>(waves, n_chunks);
-    DeviceChunking* c = nullptr;
-    int status = get_chunking(t, (int)n_chunks, use_waves, &c);
-    if (status != TC_OK) return status;
-    const int elem = t->compute_dtype == TC_DTYPE_F32 ? 4 : 8;
-    const int bytes = lds_bytes_for(c->host, t->rt, elem);
-    if (bytes > kMaxLdsBytes) {
-      // Mode cross: more, narrower groups touch fewer rows each.
-      if (t->mode == TC_MODE_CROSS && capacity < 64) {
-        capacity *= 2;
-        continue;
-      }
-      return fail(TC_ERR_UNSUPPORTED,
-                  "table with %d bins needs more than %d bytes of LDS per workgroup "
-                  "in mode '%s'",
-                  t->n_bins, kMaxLdsBytes,
-                  t->mode == TC_MODE_AUTO ? "auto" : "cross");
+  const int forced_waves = env_int("TC_NWAVES", 0);
+  if (forced_groups == 0 && forced_waves == 0) {
+    auto cached = t->choices.find(n_tiles);
+    if (cached != t->choices.end()) {
+      *out = cached->second;
+      *lds_bytes = lds_bytes_for((*out)->host, t->rt, elem);
+      return TC_OK;
     }
-    best = c;
-    const int fit = blocks_per_cu(bytes, use_waves);
-    if (fit == capacity || forced_groups > 0) break;
-    capacity = fit;
   }
-  *out = best;
-  *lds_bytes = std::max(
-      lds_bytes_for(best->host, t->rt, t->compute_dtype == TC_DTYPE_F32 ? 4 : 8),
-      env_int("TC_LDS_MIN", 0));
+  const int64_t min_entries = env_int("TC_MIN_CHUNK_ENTRIES", 32);
+  const double overhead_entries = 24.0;
+  const int n_cus = 256;
+  double best_cost = 0.0;
+  int best_chunks = 0, best_waves = 0;
+  tc::Chunking trial;
+  for (int waves : {4, 8}) {
+    if (forced_waves > 0 && waves != (forced_waves <= 4 ? 4 : 8)) continue;
+    if (t->compute_dtype == TC_DTYPE_F32 && waves == 4) continue;
+    int last_groups = -1;
+    for (int groups = 1; groups <= 32; ++groups) {
+      if (forced_groups > 0 && groups != forced_groups) continue;
+      int64_t n_chunks = (int64_t)groups * waves;
+      n_chunks = std::min<int64_t>(
+          n_chunks, std::max<int64_t>(1, t->plan.n_entries / min_entries));
+      const int use_waves = (int)std::min<int64_t>(waves, n_chunks);
+      tc::build_chunking(t->plan, (int)n_chunks, use_waves, trial);
+      const int actual_groups = (int)trial.groups.size();
+      if (actual_groups == last_groups && forced_groups == 0) continue;
+      last_groups = actual_groups;
+      const int bytes = lds_bytes_for(trial, t->rt, elem);
+      if (bytes > kMaxLdsBytes) continue;
+      int longest = 1;
+      for (const tc::Chunk& chunk : trial.chunks)
+        longest = std::max(longest, chunk.q_end - chunk.q_begin);
+      const int fit = blocks_per_cu(bytes + 1024, use_waves);
+      const double blocks = (double)n_tiles * actual_groups;
+      const double per_cu = std::ceil(blocks / n_cus);
+      const double resident = std::min<double>(per_cu, fit) * use_waves / 4.0;
+      const double rounds = std::ceil(per_cu / fit);
+      double cost = per_cu * use_waves * (longest + overhead_entries);
+      if (resident < 4.0) cost *= 4.0 / resident;
+      cost *= 1.0 + 0.1 * (rounds - 1.0);
+      if (best_chunks == 0 || cost < best_cost) {
+        best_cost = cost;
+        best_chunks = (int)n_chunks;
+        best_waves = use_waves;
+      }
+    }
+  }
+  if (best_chunks == 0)
+    return fail(TC_ERR_UNSUPPORTED,
+                "table with %d bins needs more than %d bytes of LDS per workgroup",
+                t->n_bins, kMaxLdsBytes);
+  DeviceChunking* c = nullptr;
+  int status = get_chunking(t, best_chunks, best_waves, &c);
+  if (status != TC_OK) return status;
+  if (forced_groups == 0 && forced_waves == 0) t->choices[n_tiles] = c;
+  *out = c;
+  *lds_bytes = std::max(lds_bytes_for(c->host, t->rt, elem), env_int("TC_LDS_MIN", 0));
   return TC_OK;
 }
 
@@ -747,8 +769,11 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
   } else {
     int rt = (n_r + t->n_rtiles - 1) / t->n_rtiles;
     t->rt = (rt + 3) / 4 * 4;
+    // LDS rows a workgroup may stage: half the bins (one triangle or one column block
+    // of the cen-sat rectangle) plus a few rows, within 28..66 KB
+    const int budget = std::max(56, std::min(128, n_bins / 2 + 6));
     tc::build_plan(mode, n_bins, is_central, tc::block_entries(t->rt),
-                   env_int("TC_ROW_BUDGET", 56), t->plan);
+                   env_int("TC_ROW_BUDGET", budget), t->plan);
   }
 
   for (int g = 0; g < n_bins; ++g) {

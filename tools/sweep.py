@@ -96,3 +96,16 @@ if __name__ == '__main__':
         for nw in [4, 8]:
             os.environ['TC_NWAVES'] = str(nw)
             run(100, 1, (19, 40), 10000, 5, 'cfg5 float32 nwaves(arg)=%d' % nw, dtype='float32')
+    elif which == 'budget':
+        for budget in [56, 80, 104, 128, 200]:
+            os.environ['TC_ROW_BUDGET'] = str(budget)
+            for nw in [4, 8]:
+                os.environ['TC_NWAVES'] = str(nw)
+                run(50, 2, (19, ), 10000, 10, 'cfg3 budget=%d nw=%d' % (budget, nw), flags=1)
+    elif which == 'auto':
+        run(50, 1, (19, ), 10000, 50, 'cfg2 1e4')
+        run(50, 2, (19, ), 10000, 20, 'cfg3 1e4 separate', flags=1)
+        run(50, 1, (19, ), 1000, 50, 'cfg2 1e3')
+        run(50, 1, (19, ), 64, 50, 'cfg2 64')
+        run(50, 1, (19, ), 100000, 10, 'cfg2 1e5')
+        run(30, 1, (19, ), 10000, 50, 'bolplanck-like G=60')
