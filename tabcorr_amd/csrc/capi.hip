@@ -479,13 +479,18 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   fa.ngal = ngal_device;
   fa.xi = xi_device;
   // results appear in call order: wait for the previous call's finalisation
+  // (host-buffer calls synchronise before returning and need no chaining)
   if (t->prev >= 0 && t->prev != t->cur)
     TC_HIP(hipStreamWaitEvent(stream, t->lanes[t->prev].finished, 0));
   hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)(ldb / 64)),
                      dim3(env_int("TC_FINALIZE_THREADS", 256)), 0, stream, fa);
   TC_HIP(hipGetLastError());
-  TC_HIP(hipEventRecord(lane.finished, stream));
-  t->prev = t->cur;
+  if (t->force_lane >= 0) {
+    t->prev = -1;
+  } else {
+    TC_HIP(hipEventRecord(lane.finished, stream));
+    t->prev = t->cur;
+  }
   return TC_OK;
 }
 
