@@ -92,7 +92,14 @@ struct PinnedBuffer {
     bytes = 0;
   }
 };
-constexpr size_t kStageLimit = 1 << 20;   // larger transfers go directly
+// Larger transfers go directly (TC_STAGE_LIMIT_MB overrides).
+size_t stage_limit() {
+  static const size_t limit = [] {
+    const char* value = getenv("TC_STAGE_LIMIT_MB");
+    return (size_t)(value && *value ? atoi(value) : 1) << 20;
+  }();
+  return limit;
+}
 
 template <typename T>
 int upload(const std::vector<T>& host, void** device) {
@@ -957,7 +964,7 @@ namespace {
 // Host -> device copy of a small input through the pinned staging buffer.
 int copy_in(PinnedBuffer* stage, void* device, const void* host, size_t bytes,
             hipStream_t stream) {
-  if (bytes <= kStageLimit && stage->reserve(bytes) == TC_OK) {
+  if (bytes <= stage_limit() && stage->reserve(bytes) == TC_OK) {
     memcpy(stage->ptr, host, bytes);
     host = stage->ptr;
   }
@@ -969,7 +976,7 @@ int copy_in(PinnedBuffer* stage, void* device, const void* host, size_t bytes,
 int copy_out(PinnedBuffer* stage, double* ngal, size_t ngal_count, const void* d_ngal,
              double* xi, size_t xi_count, const void* d_xi, hipStream_t stream) {
   const size_t bytes = (ngal_count + xi_count) * sizeof(double);
-  if (bytes <= kStageLimit && stage->reserve(bytes) == TC_OK) {
+  if (bytes <= stage_limit() && stage->reserve(bytes) == TC_OK) {
     double* h = (double*)stage->ptr;
     TC_HIP(hipMemcpyAsync(h, d_ngal, ngal_count * 8, hipMemcpyDeviceToHost, stream));
     TC_HIP(hipMemcpyAsync(h + ngal_count, d_xi, xi_count * 8, hipMemcpyDeviceToHost,

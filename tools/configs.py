@@ -11,7 +11,8 @@ def make(table, **kw):
 
 
 def timeit(fn, reps):
-    fn()
+    for _ in range(5):       # buffers grow and pages fault in on the first calls
+        fn()
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()
