@@ -206,6 +206,10 @@ int tc_table_kernel_time(tc_table* table, int* n_launches, float* mean_ms);
  * launch six words: 100 MHz timestamps at start / after staging / after the main loop /
  * at the end, HW_ID and XCC_ID.  Copies min(capacity, n_blocks) records. */
 int tc_debug_trace(tc_table* table, uint64_t* out, int64_t capacity, int64_t* n_blocks);
+/* Same run, per wavefront: timestamps at the start of the main loop, after 1/4, 1/2 and
+ * 3/4 of its blocks and at the end, and HW_ID (wave slot / SIMD / CU). */
+int tc_debug_wave_trace(tc_table* table, uint64_t* out, int64_t capacity,
+                        int64_t* n_waves);
 /* Launch geometry of the last predict call (for DESIGN.md / bench.py reporting). */
 int tc_table_last_launch(const tc_table* table, int* n_workgroups, int* waves_per_workgroup,
                          int* n_splits, int* lds_bytes);

@@ -98,6 +98,8 @@ SIGNATURES = {
     'tc_table_kernel_time': [ctypes.c_void_p, c_int_p, c_float_p],
     'tc_debug_trace': [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64),
                        ctypes.c_int64, c_int64_p],
+    'tc_debug_wave_trace': [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64),
+                            ctypes.c_int64, c_int64_p],
     'tc_table_last_launch': [ctypes.c_void_p, c_int_p, c_int_p, c_int_p,
                              c_int_p],
     'tc_comm_unique_id': [ctypes.c_void_p],

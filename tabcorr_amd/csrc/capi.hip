@@ -178,7 +178,8 @@ struct tc_table {
   int cur = 0;                       // lane of the current / last predict call
   int force_lane = -1;               // host-buffer entry points pin lane 0
   uint64_t device_calls = 0;
-  DeviceBuffer theta, out_ngal, out_xi, occupation, trace;
+  DeviceBuffer theta, out_ngal, out_xi, occupation, trace, wave_trace;
+  size_t wave_trace_count = 0;
   PinnedBuffer h_in, h_out;
   size_t trace_blocks = 0;
 
@@ -415,12 +416,20 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   ca.n_central = t->plan.n_central;
   ca.r_stride = r_stride;
   ca.trace = nullptr;
+  ca.wave_trace = nullptr;
   ca.pos_ij = nullptr;
   if (env_int("TC_TRACE", 0)) {
     t->trace_blocks = (size_t)(ldb / 64) * n_groups * t->n_rtiles;
     status = t->trace.reserve(t->trace_blocks * 6 * sizeof(unsigned long long), stream);
     if (status != TC_OK) return status;
     ca.trace = (unsigned long long*)t->trace.ptr;
+    t->wave_trace_count = t->trace_blocks * c->host.waves_per_group;
+    status = t->wave_trace.reserve(t->wave_trace_count * 6 * sizeof(unsigned long long),
+                                   stream);
+    if (status != TC_OK) return status;
+    TC_HIP(hipMemsetAsync(t->wave_trace.ptr, 0,
+                          t->wave_trace_count * 6 * sizeof(unsigned long long), stream));
+    ca.wave_trace = (unsigned long long*)t->wave_trace.ptr;
   }
   ca.n_tables = 0;
   ca.k_splits = 1;
@@ -890,7 +899,7 @@ int tc_table_destroy(tc_table* t) {
     for (void* p : {kv.second->chunks, kv.second->groups})
       if (p) (void)hipFree(p);
   for (DeviceBuffer* b : {&t->theta, &t->out_ngal, &t->out_xi, &t->occupation,
-                          &t->trace})
+                          &t->trace, &t->wave_trace})
     b->release();
   for (tc_table::Lane& lane : t->lanes) {
     lane.nbuf.release();
@@ -1188,6 +1197,17 @@ int tc_debug_trace(tc_table* t, uint64_t* out, int64_t capacity, int64_t* n_bloc
   return TC_OK;
 }
 
+int tc_debug_wave_trace(tc_table* t, uint64_t* out, int64_t capacity, int64_t* n_waves) {
+  TC_CHECK(t != nullptr && n_waves != nullptr, "NULL argument");
+  *n_waves = (int64_t)t->wave_trace_count;
+  if (out == nullptr || t->wave_trace.ptr == nullptr) return TC_OK;
+  for (tc_table::Lane& lane : t->lanes) TC_HIP(hipStreamSynchronize(lane.stream));
+  const int64_t n = std::min<int64_t>(capacity, (int64_t)t->wave_trace_count);
+  TC_HIP(hipMemcpy(out, t->wave_trace.ptr, (size_t)n * 6 * sizeof(uint64_t),
+                   hipMemcpyDeviceToHost));
+  return TC_OK;
+}
+
 int tc_table_last_launch(const tc_table* t, int* n_workgroups, int* waves,
                          int* n_splits, int* lds_bytes) {
   TC_CHECK(t != nullptr, "table handle is NULL");
@@ -1335,6 +1355,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   ca.n_central = t0->plan.n_central;
   ca.r_stride = r_stride;
   ca.trace = nullptr;
+  ca.wave_trace = nullptr;
   ca.pos_ij = nullptr;
   ca.partial = (double*)it->partial.ptr;
   ca.n_tables = it->n_tables;

@@ -81,6 +81,9 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     OccArgs a) {
   __shared__ double red[2][kOccWaves][kLanes];
   __shared__ __attribute__((aligned(16))) double table[fm::kTableDoubles];
+  // short kernel on the critical path of its lane: run ahead of the contraction waves
+  // of neighbouring batches it shares the CUs with
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t b0 = (int64_t)blockIdx.x * kLanes + lane;
@@ -213,6 +216,7 @@ struct ContractArgs {
   int n_slabs;              // groups * table splits per draw tile
   const int32_t* pos_ij;    // float32 kernel: packed bin pairs of every position
   unsigned long long* trace;  // developer timeline (TC_TRACE): 6 words per block, or NULL
+  unsigned long long* wave_trace;  // TC_TRACE: 6 words per wave (progress stamps)
   double* partial;          // (n_groups * k_splits, r_stride, ldb)
   // Interpolator: the block loops over tables [k_begin, k_end) of its k split and
   // accumulates coef[k][draw] * (table k contraction) into the same registers.
@@ -391,6 +395,16 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
       double ta[NG], tb[NG];
 #pragma unroll
       for (int g = 0; g < NG; ++g) ta[g] = table[g * 16];
+      unsigned long long stamps[5] = {0, 0, 0, 0, 0};
+      if (a.wave_trace) stamps[0] = __builtin_amdgcn_s_memrealtime();
+      // The SIMD's arbiter serves the oldest waves first and a single wave can use only
+      // ~40 % of the FP64 issue slots, so without help two or three waves run while the
+      // younger ones starve and then finish one after the other at the single-wave rate
+      // (tools/trace.py).  Each wave therefore lowers its own priority as it advances
+      // (3 in its first quarter ... 0 in its last): laggards overtake, the waves progress
+      // together and the pipe stays full until the end.
+      const int quarter = (n_blocks / 8) * 2 > 0 ? (n_blocks / 8) * 2 : 2;
+      __builtin_amdgcn_s_setprio(3);
       int blk = 0;
       // two blocks per iteration so that the two register sets swap roles
       // without moves; the prefetch is unconditional (clamped to the last block) so
@@ -406,6 +420,23 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
         for (int g = 0; g < NG; ++g)
           ta[g] = table[(int64_t)next * EB * RT + g * 16];
         block_compute<RT>(acc, tb, st, lds, lane, std::make_integer_sequence<int, EB>());
+        if ((blk + 2) % quarter == 0) {
+          const int done = (blk + 2) / quarter;
+          if (done == 1) __builtin_amdgcn_s_setprio(2);
+          if (done == 2) __builtin_amdgcn_s_setprio(1);
+          if (done == 3) __builtin_amdgcn_s_setprio(0);
+          if (a.wave_trace && done <= 3) stamps[done] = __builtin_amdgcn_s_memrealtime();
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (a.wave_trace) {
+        stamps[4] = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+          unsigned long long* rec =
+              a.wave_trace + 6 * (((unsigned long long)tile * a.n_slabs + slab) * n_waves + wave);
+          for (int q = 0; q < 5; ++q) rec[q] = stamps[q];
+          rec[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        }
       }
       if (blk < n_blocks)
         block_compute<RT>(acc, ta, st, lds, lane, std::make_integer_sequence<int, EB>());
@@ -613,6 +644,7 @@ constexpr int kFinalizeRows = 32;   // (component, r) rows per LDS pass
 __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
   __shared__ double tile[kFinalizeRows][kLanes + 1];
   __shared__ double norm_inv[kLanes];
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t col = (int64_t)blockIdx.x * kLanes;

@@ -44,3 +44,21 @@ for t in ts:
 # per CU busy span
 last = np.array([end[unit == u].max() for u in units])
 print('per-CU last end: min %.1f median %.1f max %.1f' % (last.min(), np.median(last), last.max()))
+
+# ---- per-wave progress -------------------------------------------------------------
+nw = ctypes.c_int64()
+_lib.check(dev.lib.tc_debug_wave_trace(dev.handle, None, 0, ctypes.byref(nw)))
+w = np.zeros((nw.value, 6), dtype=np.uint64)
+_lib.check(dev.lib.tc_debug_wave_trace(dev.handle, w.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), nw.value, ctypes.byref(nw)))
+w = w[w[:, 0] > 0]
+ts = (w[:, :5].astype(np.int64) - int(t0)) / 100.0
+hwid = w[:, 5].astype(np.int64)
+simd = (hwid >> 4) & 0x3
+print('waves traced', len(w))
+q = np.diff(ts, axis=1)      # duration of each quarter of the main loop
+for name, col in zip(['q1', 'q2', 'q3', 'q4'], q.T):
+    print('quarter %s: median %.2f us  10%% %.2f  90%% %.2f' % (name, np.median(col), np.percentile(col, 10), np.percentile(col, 90)))
+order = np.argsort(ts[:, 4])
+for frac in [0.1, 0.3, 0.5, 0.7, 0.9, 1.0]:
+    k = order[int(frac * (len(order) - 1))]
+    print('wave finishing at %5.1f us: start %.1f quarters %s' % (ts[k, 4], ts[k, 0], np.round(q[k], 1)))
