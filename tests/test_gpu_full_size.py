@@ -221,3 +221,39 @@ def test_config5_float32_mfma():
     ngal64, xi64 = make(table).predict_batch(theta)
     assert_rel(xi, xi64, RTOL_F32)
     assert np.max(np.abs(xi / xi64 - 1)) < RTOL_F32
+
+
+def test_more_draws_than_one_slab():
+    """Batches beyond the internal slab size (2^18 draws) are processed in pieces."""
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(6, 1, (5, ), 'auto', seed=21)
+    n_draws = (1 << 18) + 1000
+    theta = synthetic.zheng07_draws(n_draws, seed=22)
+    halotab = make(table)
+    ngal, xi = halotab.predict_batch(theta)
+    assert xi.shape == (n_draws, 5) and np.all(np.isfinite(xi))
+    index = np.r_[0:3, (1 << 18) - 2:(1 << 18) + 3, n_draws - 3:n_draws]
+    oracle_check(table, theta, ngal, xi, index)
+    ngal_sep, xi_sep = halotab.predict_batch(theta, separate_gal_type=True)
+    assert_rel(sum(xi_sep.values()), xi, 1e-12)
+
+
+def test_degenerate_parameters_do_not_fault():
+    """Non-finite or absurd parameters give non-finite results, not a device fault."""
+    from tabcorr_amd import synthetic
+    table = synthetic.synthetic_table(8, 2, (4, ), 'auto', seed=23)
+    halotab = make(table)
+    theta = synthetic.zheng07_draws(64, seed=24)
+    theta[0, 1] = 0.0            # sigma_logM = 0
+    theta[1, 0] = np.nan
+    theta[2, 4] = np.inf
+    theta[3, 3] = -400.0         # M1 underflows
+    theta[4, 2] = 400.0          # M0 overflows
+    theta[5] = 0.0
+    ngal, xi = halotab.predict_batch(theta)
+    good = np.arange(6, 64)
+    assert np.all(np.isfinite(xi[good])) and np.all(ngal[good] > 0)
+    # the device is still healthy afterwards
+    ngal2, xi2 = halotab.predict_batch(theta[good])
+    assert_rel(xi2, xi[good], 1e-13)
