@@ -297,8 +297,9 @@ int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
   double best_cost = 0.0;
   int best_chunks = 0, best_waves = 0;
   tc::Chunking trial;
-  for (int waves : {4, 8}) {
-    if (forced_waves > 0 && waves != (forced_waves <= 4 ? 4 : 8)) continue;
+  for (int waves : {4, 5, 6, 7, 8}) {
+    if (forced_waves > 0 && waves != forced_waves) continue;
+    if (forced_waves == 0 && waves != 4 && waves != 8) continue;
     if (t->compute_dtype == TC_DTYPE_F32 && waves == 4) continue;
     int last_groups = -1;
     for (int groups = 1; groups <= 32; ++groups) {

@@ -284,8 +284,24 @@ __device__ __forceinline__ void block_compute(
     std::integer_sequence<int, Es...>) {
   // all weights of the block first (one LDS round trip per block instead of one per
   // entry), then the FMAs
-  double w[sizeof...(Es)];
-  ((w[Es] = next_weight(st, lds, lane)), ...);
+  constexpr int EB = (int)sizeof...(Es);
+  double w[EB];
+  const int last = st.j_last >= 0 ? st.j_last : st.i;
+  if (st.remaining > EB && st.j + EB - 1 <= last) {
+    // common case: the block lies inside one row -- one LDS address, the column
+    // densities at immediate offsets, one multiplication per entry
+    const double* p = lds + (st.j - st.row_lo) * kLanes + lane;
+    ((w[Es] = st.ni * p[Es * kLanes]), ...);
+    st.j += EB;
+    st.remaining -= EB;
+    if (st.j > last) {
+      ++st.i;
+      st.j = st.j_lo;
+      st.ni = lds[(st.i + st.i_shift) * kLanes + lane] * st.scale;
+    }
+  } else {
+    ((w[Es] = next_weight(st, lds, lane)), ...);
+  }
   (entry_fma<RT, Es>(acc, t, w[Es], std::make_integer_sequence<int, RT>()), ...);
 }
 
