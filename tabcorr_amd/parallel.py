@@ -200,15 +200,22 @@ class Communicator:
             self.comm = None
 
 
-def predict_batch_sharded(halotab, theta, communicator, **kwargs):
-    """``TabCorr.predict_batch`` with the draws sharded round-robin over the
-    ranks of ``communicator``.  Every rank passes the same ``theta``; the root
-    returns the assembled ``(ngal, xi)`` (or dicts), other ranks ``None``.
+def predict_batch_sharded(halotab, theta, communicator, x=None, **kwargs):
+    """``TabCorr.predict_batch`` (or ``Interpolator.predict_batch`` when the extra
+    parameters ``x`` are given) with the draws sharded round-robin over the
+    ranks of ``communicator``.  Every rank passes the same ``theta`` (and
+    ``x``); the root returns the assembled ``(ngal, xi)`` (or dicts), other
+    ranks ``None``.
     """
     theta = np.atleast_2d(np.asarray(theta, dtype=np.float64))
     n_draws = len(theta)
     shard = local_shard(theta, communicator.rank, communicator.world_size)
-    ngal, xi = halotab.predict_batch(shard, **kwargs)
+    if x is not None:
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        x_shard = local_shard(x, communicator.rank, communicator.world_size)
+        ngal, xi = halotab.predict_batch(shard, x_shard, **kwargs)
+    else:
+        ngal, xi = halotab.predict_batch(shard, **kwargs)
     if isinstance(ngal, dict):
         keys_n, keys_x = list(ngal.keys()), list(xi.keys())
         packed = np.concatenate(
@@ -221,9 +228,11 @@ def predict_batch_sharded(halotab, theta, communicator, **kwargs):
     if parts is None:
         return None
     full = assemble(parts, n_draws)
-    shape = (n_draws, ) + tuple(halotab.tpcf_shape)
+    tpcf_shape = (halotab.tpcf_shape if hasattr(halotab, 'tpcf_shape') else
+                  halotab.tabcorr_list[0].tpcf_shape)
+    shape = (n_draws, ) + tuple(tpcf_shape)
     if isinstance(ngal, dict):
-        n_r = int(np.prod(halotab.tpcf_shape))
+        n_r = int(np.prod(tpcf_shape))
         ngal_out = {k: full[:, i] for i, k in enumerate(keys_n)}
         xi_out = {}
         for i, k in enumerate(keys_x):

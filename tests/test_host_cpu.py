@@ -261,6 +261,21 @@ for separate in [False, True]:
             assert np.array_equal(out[1], expect[1])
     else:
         assert out is None
+# Interpolator-style objects: extra parameters are sharded alongside the draws
+from util import interpolator_tables_from_golden
+idata = load_golden('interp_2d_auto')
+itables = interpolator_tables_from_golden(idata)
+setup = oracle.interpolator_setup(itables, idata['points'])
+
+class OracleInterp:
+    tabcorr_list = [OracleTab(itables[0])]
+    def predict_batch(self, theta, x, **kwargs):
+        return oracle.interpolator_predict_zheng07_batch(itables, setup, theta, x, **kwargs)
+
+out = parallel.predict_batch_sharded(OracleInterp(), idata['theta'][:9], comm, x=idata['x'][:9])
+if comm.is_root:
+    assert np.array_equal(out[0], idata['ngal'][:9]) or np.allclose(out[0], idata['ngal'][:9], rtol=1e-11, atol=0)
+    assert np.allclose(out[1], idata['xi'][:9], rtol=1e-10, atol=0)
 assert comm.max(comm.rank + 1.0) == 2.0
 assert comm.sum(1.0) == 2.0
 comm.barrier()
