@@ -1697,6 +1697,10 @@ int tc_comm_create(const void* id, int n_ranks, int rank, tc_comm** out) {
   nccl_unique_id unique;
   memcpy(&unique, id, TC_UNIQUE_ID_BYTES);
   TC_RCCL(g_rccl.CommInitRank(&c->comm, n_ranks, unique, rank));
+  // RCCL prints a version banner through C stdio; push it out now so that it cannot
+  // trail the caller's own output (bench.py's JSON line) at process exit
+  fflush(stdout);
+  fflush(stderr);
   TC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   TC_HIP(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
   for (hipEvent_t& event : c->done)

@@ -109,18 +109,22 @@ class Communicator:
             if _lib.device_count() < 1:
                 raise _lib.TabCorrHipError('no HIP device')
             _lib.check(lib.tc_set_device(self.local_rank))
+            # Every rank probes librccl (ncclGetUniqueId) before any rank enters the
+            # blocking ncclCommInitRank: a rank that cannot load RCCL must not leave
+            # the others waiting for it.
             unique = torch.zeros(_lib.UNIQUE_ID_BYTES, dtype=torch.uint8)
-            ok = torch.ones(1, dtype=torch.int32)
-            if self.rank == 0:
-                buffer = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
-                if lib.tc_comm_unique_id(buffer) == _lib.TC_OK:
-                    unique = torch.frombuffer(
-                        bytearray(buffer.raw), dtype=torch.uint8).clone()
-                else:
-                    ok[0] = 0
-            self.dist.broadcast(ok, 0)
+            buffer = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+            ok = torch.tensor(
+                [1 if lib.tc_comm_unique_id(buffer) == _lib.TC_OK else 0],
+                dtype=torch.int32)
+            if self.rank == 0 and ok.item() == 1:
+                unique = torch.frombuffer(
+                    bytearray(buffer.raw), dtype=torch.uint8).clone()
+            self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
             if ok.item() == 0:
-                raise _lib.TabCorrHipError('ncclGetUniqueId failed on rank 0')
+                raise _lib.TabCorrHipError(
+                    'RCCL is not usable on every rank: ' +
+                    lib.tc_last_error().decode(errors='replace'))
             self.dist.broadcast(unique, 0)
             handle = ctypes.c_void_p()
             raw = bytes(unique.numpy().tobytes())
