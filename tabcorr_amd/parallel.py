@@ -204,15 +204,89 @@ class Communicator:
             self.comm = None
 
 
+class _DeviceArray:
+    """A device allocation of doubles owned through the C ABI."""
+
+    def __init__(self, count):
+        self.lib = _lib.load()
+        self.ptr = ctypes.c_void_p()
+        self.count = count
+        _lib.check(self.lib.tc_device_malloc(ctypes.byref(self.ptr),
+                                             max(count, 1) * 8))
+
+    def upload(self, array):
+        array = _lib.contiguous(array)
+        _lib.check(self.lib.tc_memcpy_h2d(
+            self.ptr, array.ctypes.data_as(ctypes.c_void_p), array.nbytes))
+
+    def download(self, count=None):
+        out = np.empty(self.count if count is None else count)
+        _lib.check(self.lib.tc_memcpy_d2h(
+            out.ctypes.data_as(ctypes.c_void_p), self.ptr, out.nbytes))
+        return out
+
+    def offset(self, count):
+        return ctypes.c_void_p(self.ptr.value + count * 8)
+
+    def __del__(self):
+        if getattr(self, 'ptr', None) is not None and self.ptr.value:
+            try:
+                self.lib.tc_device_free(self.ptr)
+            except Exception:
+                pass
+            self.ptr = ctypes.c_void_p()
+
+
+def _predict_sharded_rccl(halotab, theta, communicator, n_gauss_prim=10,
+                          modulate_with_cenocc=False, assembias=False):
+    """Total prediction of a single table with the results gathered on the
+    root over RCCL: device buffers end to end, one ``ncclGather``."""
+    from .tabcorr import _flags
+    n_draws = len(theta)
+    shard = local_shard(theta, communicator.rank, communicator.world_size)
+    device = halotab.to_device()
+    n_local, n_r = len(shard), device.n_r
+    count = n_local * (1 + n_r)
+    d_theta = _DeviceArray(shard.size)
+    d_theta.upload(shard)
+    d_out = _DeviceArray(count)
+    d_recv = _DeviceArray(count * communicator.world_size
+                          if communicator.is_root else 0)
+    _lib.check(device.lib.tc_predict_zheng07_batch_device(
+        device.handle, d_theta.ptr, shard.shape[1], n_local, n_gauss_prim,
+        _flags(False, modulate_with_cenocc, assembias), d_out.ptr,
+        d_out.offset(n_local)))
+    communicator.gather_device(
+        device.handle, d_out.ptr,
+        d_recv.ptr if communicator.is_root else None, count, 0)
+    communicator.synchronize()
+    if not communicator.is_root:
+        return None
+    flat = d_recv.download().reshape(communicator.world_size, count)
+    parts = [np.concatenate([part[:n_local, np.newaxis],
+                             part[n_local:].reshape(n_local, n_r)], axis=1)
+             for part in flat]
+    full = assemble(parts, n_draws)
+    return full[:, 0], full[:, 1:].reshape((n_draws, ) + tuple(
+        halotab.tpcf_shape))
+
+
 def predict_batch_sharded(halotab, theta, communicator, x=None, **kwargs):
     """``TabCorr.predict_batch`` (or ``Interpolator.predict_batch`` when the extra
     parameters ``x`` are given) with the draws sharded round-robin over the
     ranks of ``communicator``.  Every rank passes the same ``theta`` (and
     ``x``); the root returns the assembled ``(ngal, xi)`` (or dicts), other
-    ranks ``None``.
+    ranks ``None``.  With an RCCL communicator the total prediction of a
+    single table stays on the devices until one ``ncclGather`` has collected
+    it on the root; the other cases gather host arrays over gloo.
     """
     theta = np.atleast_2d(np.asarray(theta, dtype=np.float64))
     n_draws = len(theta)
+    if (communicator.comm is not None and x is None and
+            hasattr(halotab, 'to_device') and
+            not kwargs.get('separate_gal_type', False)):
+        kwargs.pop('separate_gal_type', None)
+        return _predict_sharded_rccl(halotab, theta, communicator, **kwargs)
     shard = local_shard(theta, communicator.rank, communicator.world_size)
     if x is not None:
         x = np.atleast_2d(np.asarray(x, dtype=np.float64))

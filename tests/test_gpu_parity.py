@@ -446,3 +446,34 @@ def test_chi2_fused_likelihood():
     assert_rel(chi2, expect, 1e-9)
     with pytest.raises(ValueError):
         halotab.chi2_batch(data['theta'], observed[:5], precision)
+
+
+def test_sharded_predict_over_rccl_single_rank():
+    """Product API for sharded prediction with the RCCL data plane (one rank here)."""
+    import subprocess
+    from util import REPO
+    script = '''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(repo)r); sys.path.insert(0, os.path.join(%(repo)r, "tests"))
+from util import load_golden, table_from_golden
+from tabcorr_amd import TabCorr, parallel
+comm = parallel.Communicator.from_env()
+assert comm.gather_backend == "rccl", (comm.gather_backend, comm.rccl_error)
+data = load_golden("synthetic_cfg2")
+table = table_from_golden(data)
+halotab = TabCorr.from_arrays(table["gal_type"], table["tpcf_matrix"], table["tpcf_shape"], table["attrs"])
+ngal, xi = parallel.predict_batch_sharded(halotab, data["theta"], comm)
+np.testing.assert_allclose(ngal, data["ngal"], rtol=1e-10)
+np.testing.assert_allclose(xi, data["xi"], rtol=1e-10)
+ngal_sep, xi_sep = parallel.predict_batch_sharded(halotab, data["theta"], comm, separate_gal_type=True)
+np.testing.assert_allclose(sum(xi_sep.values()), data["xi"], rtol=1e-10)
+comm.close()
+print("sharded ok")
+''' % {'repo': REPO}
+    env = dict(os.environ, TABCORR_AMD_FORCE_COMM='1', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT='29547', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    result = subprocess.run([sys.executable, '-c', script], env=env,
+                            capture_output=True, text=True, timeout=900)
+    assert result.returncode == 0, result.stdout[-2000:] + result.stderr[-2000:]
+    assert 'sharded ok' in result.stdout
