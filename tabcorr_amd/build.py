@@ -5,17 +5,22 @@ library lands next to this file so that it travels with the source tree; the
 loader (``tabcorr_amd/_lib.py``) never builds implicitly on a GPU box.
 """
 
+import glob
 import os
 import shutil
 import subprocess
 import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBRARY = os.path.join(HERE, 'libtabcorr_hip.so')
-SOURCES = ['capi.hip', 'hostmath.cpp']
-HEADERS = ['hostmath.h', 'kernels.hip.h',
-           os.path.join('..', '..', 'include', 'tabcorr_amd.h')]
+# launch.hip holds all device code; the other units are host-only C++
+SOURCES = ['launch.hip', 'table.cpp', 'interp.cpp', 'comm.cpp', 'runtime.cpp',
+           'hostmath.cpp']
+FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-gpu-rdc',
+         '-Wall', '-Wno-unused-function']
 
 
 def hipcc():
@@ -26,30 +31,42 @@ def hipcc():
     raise RuntimeError('hipcc not found; set HIPCC')
 
 
+def dependencies():
+    files = [os.path.join(CSRC, f) for f in SOURCES]
+    files += glob.glob(os.path.join(CSRC, '*.h'))
+    files.append(os.path.join(HERE, '..', 'include', 'tabcorr_amd.h'))
+    return files
+
+
 def is_stale():
     if not os.path.exists(LIBRARY):
         return True
     built = os.path.getmtime(LIBRARY)
-    files = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    return any(os.path.getmtime(f) > built for f in files)
+    return any(os.path.getmtime(f) > built for f in dependencies())
 
 
 def build(force=False, verbose=False):
     """Compile the library if it is missing or older than its sources."""
     if not force and not is_stale():
         return LIBRARY
-    command = [
-        hipcc(), '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC',
-        '-shared', '-fgpu-rdc' if False else '-fno-gpu-rdc',
-        '-Wall', '-Wno-unused-function',
+    compiler = hipcc()
+
+    def run(command):
+        if verbose:
+            print(' '.join(command), flush=True)
+        subprocess.run(command, check=True)
+
+    with tempfile.TemporaryDirectory(prefix='tabcorr_amd_build_') as tmp:
+        objects = [os.path.join(tmp, os.path.splitext(f)[0] + '.o')
+                   for f in SOURCES]
+        commands = [[compiler] + FLAGS + ['-c', os.path.join(CSRC, f), '-o', o]
+                    for f, o in zip(SOURCES, objects)]
+        with ThreadPoolExecutor(max_workers=min(4, len(commands))) as pool:
+            list(pool.map(run, commands))
         # bind every HIP symbol at load time to the ROCm runtime this library
         # was linked against, even if another copy is loaded later
-        '-Wl,-z,now', '-Wl,-rpath,/opt/rocm/lib',
-        '-o', LIBRARY]
-    command += [os.path.join(CSRC, f) for f in SOURCES]
-    if verbose:
-        print(' '.join(command))
-    subprocess.run(command, check=True)
+        run([compiler, '--offload-arch=gfx950', '-fno-gpu-rdc', '-shared',
+             '-Wl,-z,now', '-Wl,-rpath,/opt/rocm/lib', '-o', LIBRARY] + objects)
     return LIBRARY
 
 

@@ -1,0 +1,236 @@
+// Shared between the translation units of libtabcorr_hip.so: error reporting, device and
+// pinned buffers, the table handle, and the launch layer (launch.hip) the entry points in
+// table.cpp / interp.cpp / comm.cpp call.  Not installed; the public surface is
+// include/tabcorr_amd.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/tabcorr_amd.h"
+#include "fastmath.h"
+#include "hostmath.h"
+#include "kernel_args.h"
+
+namespace tc {
+namespace host {
+
+// Records the message tc_last_error() returns on this thread; returns `code`.
+int fail(int code, const char* format, ...);
+const char* last_error();
+
+#define TC_HIP(call)                                                          \
+  do {                                                                        \
+    hipError_t tc_hip_status = (call);                                        \
+    if (tc_hip_status != hipSuccess)                                          \
+      return ::tc::host::fail(TC_ERR_HIP, "%s failed: %s (%s:%d)", #call,     \
+                              hipGetErrorString(tc_hip_status), __FILE__,     \
+                              __LINE__);                                      \
+  } while (0)
+
+#define TC_CHECK(condition, ...)                                              \
+  do {                                                                        \
+    if (!(condition)) return ::tc::host::fail(TC_ERR_INVALID, __VA_ARGS__);   \
+  } while (0)
+
+// A device allocation that can only grow (never reallocated while a launch
+// that uses it may be in flight: growth synchronises the stream first).
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t need, hipStream_t stream) {
+    if (need <= bytes) return TC_OK;
+    if (ptr != nullptr) {
+      TC_HIP(hipStreamSynchronize(stream));
+      TC_HIP(hipFree(ptr));
+      ptr = nullptr;
+      bytes = 0;
+    }
+    size_t grow = need + need / 4;
+    TC_HIP(hipMalloc(&ptr, grow));
+    bytes = grow;
+    return TC_OK;
+  }
+  void release() {
+    if (ptr != nullptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+};
+
+// Page-locked host staging for small transfers: hipMemcpyAsync from / to pageable
+// memory goes through an internal bounce buffer and costs tens of microseconds per
+// call, which dominates the latency of un-batched predict() calls.
+struct PinnedBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t need) {
+    if (need <= bytes) return TC_OK;
+    if (ptr != nullptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+    size_t grow = std::max<size_t>(need + need / 2, 4096);
+    TC_HIP(hipHostMalloc(&ptr, grow, hipHostMallocDefault));
+    bytes = grow;
+    return TC_OK;
+  }
+  void release() {
+    if (ptr != nullptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+};
+// Larger transfers go directly (TC_STAGE_LIMIT_MB overrides).
+inline size_t stage_limit() {
+  static const size_t limit = [] {
+    const char* value = getenv("TC_STAGE_LIMIT_MB");
+    return (size_t)(value && *value ? atoi(value) : 1) << 20;
+  }();
+  return limit;
+}
+
+template <typename T>
+int upload(const std::vector<T>& host, void** device) {
+  size_t bytes = std::max<size_t>(1, host.size()) * sizeof(T);
+  TC_HIP(hipMalloc(device, bytes));
+  if (!host.empty())
+    TC_HIP(hipMemcpy(*device, host.data(), host.size() * sizeof(T),
+                     hipMemcpyHostToDevice));
+  return TC_OK;
+}
+
+struct DeviceChunking {
+  tc::Chunking host;
+  void* chunks = nullptr;
+  void* groups = nullptr;
+};
+
+struct Quadrature {
+  int n_gauss = 0;
+  void* log_m = nullptr;
+  void* m = nullptr;
+  void* weight = nullptr;
+};
+
+inline int env_int(const char* name, int fallback) {
+  const char* value = getenv(name);
+  if (value == nullptr || *value == 0) return fallback;
+  return atoi(value);
+}
+
+}  // namespace host
+}  // namespace tc
+
+struct tc_table {
+  int device = 0;
+  int mode = 0;
+  int n_bins = 0;
+  int n_r = 0;
+  int64_t n_pairs = 0;
+  int compute_dtype = TC_DTYPE_F64;
+  bool legacy = false;
+  tc::Plan plan;
+  int rt = 0;          // r values per tile (compile-time kernel parameter)
+  int n_rtiles = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+
+  // host copies of the gal_type columns in library (centrals-first) order
+  std::vector<double> n_h, log_min, log_max, percentile, dist_index;
+
+  void* d_table = nullptr;       // (n_rtiles, n_entries, rt)
+  size_t table_bytes = 0;
+  void* d_n_h = nullptr;
+  void* d_percentile = nullptr;
+  void* d_perm = nullptr;
+  void* d_math_table = nullptr;  // fastmath.h tables
+  void* d_pos_ij = nullptr;      // float32 variant: packed bin pairs per position
+  std::map<int, tc::host::Quadrature> quadrature;
+  std::map<std::pair<int, int>, std::unique_ptr<tc::host::DeviceChunking>> chunkings;
+  std::map<int64_t, tc::host::DeviceChunking*> choices;   // decomposition chosen per tile count
+
+  // Two independent "lanes" (stream + workspaces).  Consecutive device-pointer
+  // predict calls alternate between them, so that the occupation kernel of batch k + 1
+  // overlaps the contraction of batch k (both are FP64-issue bound and the contraction
+  // leaves issue slots free at its ramp-down); results are still produced in call order
+  // (the finalisation kernels are chained by events).  Host-buffer calls use lane 0.
+  struct Lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t finished = nullptr;   // recorded after the lane's last finalisation
+    tc::host::DeviceBuffer nbuf, ngal2, partial;
+    int ngal_parts = 1;              // partial sums the occupation step left in ngal2
+  };
+  static constexpr int kMaxLanes = 4;
+  Lane lanes[kMaxLanes];
+  int n_lanes = 2;
+  int prev = -1;                     // lane of the previous finalisation
+  int cur = 0;                       // lane of the current / last predict call
+  int force_lane = -1;               // host-buffer entry points pin lane 0
+  uint64_t device_calls = 0;
+  tc::host::DeviceBuffer theta, out_ngal, out_xi, occupation, trace, wave_trace;
+  size_t wave_trace_count = 0;
+  tc::host::PinnedBuffer h_in, h_out;
+  size_t trace_blocks = 0;
+
+  // measurement
+  bool profile_kernels = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> kernel_events;
+  size_t kernel_events_used = 0;
+  int last_workgroups = 0, last_waves = 0, last_splits = 0, last_lds = 0;
+};
+
+namespace tc {
+namespace host {
+
+// Largest dynamic LDS allocation a workgroup may ask for (160 KiB per CU).
+constexpr int kMaxLdsBytes = 160 * 1024;
+// Draws are processed in slabs so that the workspaces stay bounded.
+constexpr int64_t kMaxSlab = 1 << 18;
+
+// ---- launch layer (launch.hip) --------------------------------------------------------
+int get_quadrature(tc_table* t, int n_gauss, Quadrature** out);
+int get_chunking(tc_table* t, int n_chunks, int waves, DeviceChunking** out);
+int lds_bytes_for(const Chunking& chunking, int rt, int elem = 8);
+int blocks_per_cu(int lds_bytes, int waves);
+int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out, DeviceChunking** out,
+                    int* lds_bytes);
+int launch_contract_rt(int rt, dim3 grid, dim3 block, int lds, hipStream_t stream,
+                       const ContractArgs& args);
+int set_lds_limit_rt(int rt, int lds);
+// Occupation kernel for a slab of draws: densities into (nbuf, ngal2) -- the current
+// lane's by default -- and optionally the occupations in reference order.
+int run_occupation(tc_table* t, const double* theta_device, int n_theta, int64_t n_draws,
+                   int64_t ldb, int n_gauss, unsigned flags, double* occupation_device,
+                   DeviceBuffer* nbuf = nullptr, DeviceBuffer* ngal2 = nullptr,
+                   hipStream_t stream = nullptr, int* ngal_parts = nullptr);
+// Contraction + finalisation of draws whose densities are already in the current lane.
+int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
+                    double* ngal_device, double* xi_device);
+int check_predict_args(const tc_table* t, const void* theta, int n_theta, int64_t n_draws,
+                       int n_gauss, unsigned flags);
+int launch_finalize(const FinalizeArgs& args, hipStream_t stream);
+int launch_interp_coef(const InterpArgs& args, hipStream_t stream);
+int launch_occ_from_array(tc_table* t, const double* occupation_device, int64_t n_draws,
+                          int64_t ldb, double* nbuf, double* ngal2, hipStream_t stream);
+int launch_chi2(const double* xi, int64_t n_draws, int n_r, const double* data,
+                const double* precision, double* chi2, hipStream_t stream);
+
+// ---- staging (table.cpp) --------------------------------------------------------------
+int copy_in(PinnedBuffer* stage, void* device, const void* host, size_t bytes,
+            hipStream_t stream);
+int copy_out(PinnedBuffer* stage, double* ngal, size_t ngal_count, const void* d_ngal,
+             double* xi, size_t xi_count, const void* d_xi, hipStream_t stream);
+
+}  // namespace host
+}  // namespace tc

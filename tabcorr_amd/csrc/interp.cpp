@@ -1,0 +1,378 @@
+// Interpolator handle of the C ABI (include/tabcorr_amd.h): tensor-product cubic-spline
+// interpolation over a grid of tables, evaluated as one contraction over all tables
+// (tabcorr/interpolator.py:136-219).
+#include "internal.h"
+
+using namespace tc::host;
+
+struct tc_interp {
+  int device = 0;
+  int n_tables = 0;
+  int n_dim = 0;
+  std::vector<tc_table*> tables;
+  std::vector<std::vector<double>> xp;      // per dimension
+  std::vector<int32_t> table_node;          // (K, D)
+  std::vector<int32_t> table_class;         // (K)
+  std::vector<int> class_table;             // representative table of each class
+  hipStream_t stream = nullptr;
+  void* d_xp = nullptr;
+  void* d_a = nullptr;
+  void* d_table_node = nullptr;
+  void* d_table_class = nullptr;
+  void* d_tables = nullptr;                 // (K) device pointers
+  void* d_nbufs = nullptr;                  // (V) device pointers
+  void* d_ngal_parts = nullptr;             // (V) device pointers
+  std::vector<int> axis_offset, a_offset;
+  std::vector<DeviceBuffer> nbuf, ngal2;    // per class
+  std::vector<void*> nbuf_ptrs, ngal_ptrs;  // last uploaded pointer values
+  DeviceBuffer theta, x, coef, partial, out_ngal, out_xi;
+  std::map<std::pair<int, int>, std::unique_ptr<DeviceChunking>> chunkings;
+};
+
+namespace {
+
+bool same_bins(const tc_table* a, const tc_table* b) {
+  return a->n_h == b->n_h && a->log_min == b->log_min && a->log_max == b->log_max &&
+         a->percentile == b->percentile && a->dist_index == b->dist_index &&
+         a->legacy == b->legacy;
+}
+
+int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta,
+                          const double* x_device, int64_t n_draws, int n_gauss,
+                          unsigned flags, double* ngal_device, double* xi_device) {
+  tc_table* t0 = it->tables[0];
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  const int n_comp = separate ? t0->plan.n_components : 1;
+  const int n_classes = (int)it->class_table.size();
+  const int64_t ldb = (n_draws + 63) / 64 * 64;
+  int status = TC_OK;
+
+  // occupations once per class of identical halo tables (interpolator.py:181-184)
+  int ngal_parts = 1;
+  for (int v = 0; v < n_classes; ++v) {
+    status = run_occupation(it->tables[it->class_table[v]], theta_device, n_theta,
+                            n_draws, ldb, n_gauss, flags, nullptr, &it->nbuf[v],
+                            &it->ngal2[v], it->stream, &ngal_parts);
+    if (status != TC_OK) return status;
+  }
+  bool moved = false;
+  for (int v = 0; v < n_classes; ++v) {
+    moved = moved || it->nbuf_ptrs[v] != it->nbuf[v].ptr ||
+            it->ngal_ptrs[v] != it->ngal2[v].ptr;
+    it->nbuf_ptrs[v] = it->nbuf[v].ptr;
+    it->ngal_ptrs[v] = it->ngal2[v].ptr;
+  }
+  if (moved) {
+    TC_HIP(hipMemcpyAsync(it->d_nbufs, it->nbuf_ptrs.data(), n_classes * sizeof(void*),
+                          hipMemcpyHostToDevice, it->stream));
+    TC_HIP(hipMemcpyAsync(it->d_ngal_parts, it->ngal_ptrs.data(),
+                          n_classes * sizeof(void*), hipMemcpyHostToDevice, it->stream));
+    TC_HIP(hipStreamSynchronize(it->stream));   // the host vectors may change later
+  }
+
+  status = it->coef.reserve((size_t)it->n_tables * ldb * sizeof(double), it->stream);
+  if (status != TC_OK) return status;
+  tc::InterpArgs ia;
+  ia.n_dim = it->n_dim;
+  ia.n_tables = it->n_tables;
+  ia.n_classes = n_classes;
+  ia.mode = t0->mode;
+  ia.separate = separate ? 1 : 0;
+  for (int d = 0; d < it->n_dim; ++d) {
+    ia.n_axis[d] = (int)it->xp[d].size();
+    ia.axis_offset[d] = it->axis_offset[d];
+    ia.a_offset[d] = it->a_offset[d];
+  }
+  ia.xp = (const double*)it->d_xp;
+  ia.a = (const double*)it->d_a;
+  ia.table_node = (const int32_t*)it->d_table_node;
+  ia.table_class = (const int32_t*)it->d_table_class;
+  ia.x = x_device;
+  ia.ngal_parts = (const double* const*)it->d_ngal_parts;
+  ia.n_ngal_parts = ngal_parts;
+  ia.ldb = ldb;
+  ia.n_draws = n_draws;
+  ia.coef = (double*)it->coef.ptr;
+  ia.ngal = ngal_device;
+  status = launch_interp_coef(ia, it->stream);
+  if (status != TC_OK) return status;
+
+  // decomposition: as for one table (choose_chunking), with the tables looped inside
+  // the block; the tables are split over blocks only when one pass would leave the chip
+  // underfilled
+  const int64_t n_tiles = ldb / 64;
+  DeviceChunking* c = nullptr;
+  int lds = 0;
+  {
+    // the table handle caches the chunkings; all tables share table 0's plan
+    status = choose_chunking(t0, n_draws, n_comp, &c, &lds);
+    if (status != TC_OK) return status;
+  }
+  int k_splits = 1;
+  {
+    const int64_t blocks = n_tiles * t0->n_rtiles * (int64_t)c->host.groups.size();
+    const int64_t want = 256 * (int64_t)blocks_per_cu(lds, c->host.waves_per_group);
+    if (blocks * 2 <= want)
+      k_splits = (int)std::min<int64_t>(it->n_tables, want / std::max<int64_t>(1, blocks));
+    k_splits = std::max(1, env_int("TC_KSPLITS", k_splits));
+    k_splits = std::min(k_splits, it->n_tables);
+  }
+  if (lds > kMaxLdsBytes)
+    return fail(TC_ERR_UNSUPPORTED, "table with %d bins needs %d bytes of LDS",
+                t0->n_bins, lds);
+  const int n_groups = (int)c->host.groups.size();
+  const int r_stride = t0->rt * t0->n_rtiles;
+  status = it->partial.reserve(
+      (size_t)n_groups * k_splits * r_stride * ldb * sizeof(double), it->stream);
+  if (status != TC_OK) return status;
+
+  tc::ContractArgs ca;
+  ca.nbuf = nullptr;
+  ca.ldb = ldb;
+  ca.table = nullptr;
+  ca.n_positions = t0->plan.n_positions;
+  ca.chunks = (const tc::Chunk*)c->chunks;
+  ca.groups = (const tc::Group*)c->groups;
+  ca.mode = t0->mode;
+  ca.n_central = t0->plan.n_central;
+  ca.r_stride = r_stride;
+  ca.trace = nullptr;
+  ca.wave_trace = nullptr;
+  ca.pos_ij = nullptr;
+  ca.partial = (double*)it->partial.ptr;
+  ca.n_tables = it->n_tables;
+  ca.k_splits = k_splits;
+  ca.tables = (const double* const*)it->d_tables;
+  ca.nbufs = (const double* const*)it->d_nbufs;
+  ca.table_class = (const int32_t*)it->d_table_class;
+  ca.coef = (const double*)it->coef.ptr;
+  ca.n_tiles = (int)n_tiles;
+  ca.n_slabs = n_groups * k_splits;
+  dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * n_groups * k_splits), 1,
+            (unsigned)t0->n_rtiles);
+  dim3 block(64 * c->host.waves_per_group);
+  if (lds > 64 * 1024) {
+    status = set_lds_limit_rt(t0->rt, lds);
+    if (status != TC_OK) return status;
+  }
+  status = launch_contract_rt(t0->rt, grid, block, lds, it->stream, ca);
+  if (status != TC_OK) return status;
+
+  tc::FinalizeArgs fa;
+  fa.partial = (const double*)it->partial.ptr;
+  fa.groups = (const tc::Group*)c->groups;
+  fa.ngal_part = nullptr;      // already normalised; ngal written by the coef kernel
+  fa.n_ngal_parts = 0;
+  fa.n_groups = n_groups;
+  fa.k_splits = k_splits;
+  fa.n_comp = n_comp;
+  fa.r_stride = r_stride;
+  fa.n_r = t0->n_r;
+  fa.mode = t0->mode;
+  fa.ldb = ldb;
+  fa.n_draws = n_draws;
+  fa.ngal = ngal_device;
+  fa.xi = xi_device;
+  return launch_finalize(fa, it->stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tc_interp_create(tc_table* const* tables, int n_tables, int n_dim,
+                     const double* points, tc_interp** out) {
+  TC_CHECK(out != nullptr, "interp output pointer is NULL");
+  *out = nullptr;
+  TC_CHECK(tables != nullptr && points != nullptr, "NULL argument");
+  TC_CHECK(n_tables >= 1 && n_dim >= 1 && n_dim <= tc::kMaxInterpDim,
+           "invalid number of tables or dimensions");
+  std::unique_ptr<tc_interp> it(new tc_interp);
+  TC_HIP(hipGetDevice(&it->device));
+  it->n_tables = n_tables;
+  it->n_dim = n_dim;
+  it->tables.assign(tables, tables + n_tables);
+  tc_table* t0 = tables[0];
+  for (int k = 0; k < n_tables; ++k) {
+    tc_table* t = tables[k];
+    TC_CHECK(t != nullptr, "table %d is NULL", k);
+    TC_CHECK(t->device == it->device, "table %d lives on another device", k);
+    if (t->compute_dtype != TC_DTYPE_F64)
+      return fail(TC_ERR_UNSUPPORTED, "interpolation of float32 tables is not built");
+    TC_CHECK(t->mode == t0->mode && t->n_bins == t0->n_bins && t->n_r == t0->n_r &&
+                 t->plan.perm == t0->plan.perm,
+             "table %d differs from table 0 in mode, shape or gal_type layout", k);
+  }
+  // abscissae: sorted unique values per dimension (interpolator.py:41-43)
+  int64_t grid_size = 1;
+  std::vector<double> xp_all, a_all;
+  for (int d = 0; d < n_dim; ++d) {
+    std::vector<double> xp;
+    for (int k = 0; k < n_tables; ++k) xp.push_back(points[(size_t)k * n_dim + d]);
+    std::sort(xp.begin(), xp.end());
+    xp.erase(std::unique(xp.begin(), xp.end()), xp.end());
+    TC_CHECK((int)xp.size() <= tc::kMaxInterpAxis, "more than %d grid values in "
+             "dimension %d", tc::kMaxInterpAxis, d);
+    // interpolator.py:239-241
+    TC_CHECK(xp.size() >= 4,
+             "Cannot perform spline interpolation with less than 4 values.");
+    std::vector<double> a;
+    TC_CHECK(tc::spline_interpolation_matrix((int)xp.size(), xp.data(), a),
+             "singular spline system in dimension %d", d);
+    it->axis_offset.push_back((int)xp_all.size());
+    it->a_offset.push_back((int)a_all.size());
+    xp_all.insert(xp_all.end(), xp.begin(), xp.end());
+    a_all.insert(a_all.end(), a.begin(), a.end());
+    grid_size *= (int64_t)xp.size();
+    it->xp.push_back(xp);
+  }
+  // the points must form the full grid, each node once (interpolator.py:45-57)
+  TC_CHECK(grid_size == n_tables, "The 'param_dict_table' does not describe a grid.");
+  std::vector<char> taken((size_t)grid_size, 0);
+  it->table_node.resize((size_t)n_tables * n_dim);
+  for (int k = 0; k < n_tables; ++k) {
+    int64_t flat = 0;
+    for (int d = 0; d < n_dim; ++d) {
+      const std::vector<double>& xp = it->xp[d];
+      const int node = (int)(std::lower_bound(xp.begin(), xp.end(),
+                                              points[(size_t)k * n_dim + d]) -
+                             xp.begin());
+      it->table_node[(size_t)k * n_dim + d] = node;
+      flat = flat * (int64_t)xp.size() + node;
+    }
+    TC_CHECK(!taken[flat], "The 'param_dict_table' does not describe a grid.");
+    taken[flat] = 1;
+  }
+  // classes of identical halo tables share their occupations (interpolator.py:63-70)
+  it->table_class.assign(n_tables, -1);
+  for (int k = 0; k < n_tables; ++k) {
+    for (size_t v = 0; v < it->class_table.size(); ++v) {
+      if (same_bins(tables[k], tables[it->class_table[v]])) {
+        it->table_class[k] = (int32_t)v;
+        break;
+      }
+    }
+    if (it->table_class[k] < 0) {
+      it->table_class[k] = (int32_t)it->class_table.size();
+      it->class_table.push_back(k);
+    }
+  }
+  const size_t n_classes = it->class_table.size();
+  it->nbuf.resize(n_classes);
+  it->ngal2.resize(n_classes);
+  it->nbuf_ptrs.assign(n_classes, nullptr);
+  it->ngal_ptrs.assign(n_classes, nullptr);
+
+  TC_HIP(hipStreamCreateWithFlags(&it->stream, hipStreamNonBlocking));
+  std::vector<void*> table_ptrs;
+  for (int k = 0; k < n_tables; ++k) table_ptrs.push_back(tables[k]->d_table);
+  std::vector<void*> zeros(n_classes, nullptr);
+  int status = upload(xp_all, &it->d_xp);
+  if (status == TC_OK) status = upload(a_all, &it->d_a);
+  if (status == TC_OK) status = upload(it->table_node, &it->d_table_node);
+  if (status == TC_OK) status = upload(it->table_class, &it->d_table_class);
+  if (status == TC_OK) status = upload(table_ptrs, &it->d_tables);
+  if (status == TC_OK) status = upload(zeros, &it->d_nbufs);
+  if (status == TC_OK) status = upload(zeros, &it->d_ngal_parts);
+  if (status != TC_OK) {
+    tc_interp_destroy(it.release());
+    return status;
+  }
+  *out = it.release();
+  return TC_OK;
+}
+
+int tc_interp_destroy(tc_interp* it) {
+  if (it == nullptr) return TC_OK;
+  (void)hipSetDevice(it->device);
+  if (it->stream) (void)hipStreamSynchronize(it->stream);
+  for (void* p : {it->d_xp, it->d_a, it->d_table_node, it->d_table_class, it->d_tables,
+                  it->d_nbufs, it->d_ngal_parts})
+    if (p) (void)hipFree(p);
+  for (auto& kv : it->chunkings)
+    for (void* p : {kv.second->chunks, kv.second->groups})
+      if (p) (void)hipFree(p);
+  for (DeviceBuffer& b : it->nbuf) b.release();
+  for (DeviceBuffer& b : it->ngal2) b.release();
+  for (DeviceBuffer* b : {&it->theta, &it->x, &it->coef, &it->partial, &it->out_ngal,
+                          &it->out_xi})
+    b->release();
+  if (it->stream) (void)hipStreamDestroy(it->stream);
+  delete it;
+  return TC_OK;
+}
+
+int tc_interp_synchronize(tc_interp* it) {
+  TC_CHECK(it != nullptr, "interp handle is NULL");
+  TC_HIP(hipStreamSynchronize(it->stream));
+  return TC_OK;
+}
+
+int tc_interp_axis(const tc_interp* it, int dim, int* n, double* xp, int size) {
+  TC_CHECK(it != nullptr && n != nullptr, "NULL argument");
+  TC_CHECK(dim >= 0 && dim < it->n_dim, "invalid dimension %d", dim);
+  *n = (int)it->xp[dim].size();
+  if (xp != nullptr)
+    for (int i = 0; i < std::min(*n, size); ++i) xp[i] = it->xp[dim][i];
+  return TC_OK;
+}
+
+int tc_interp_predict_zheng07_batch_device(tc_interp* it, const double* theta_device,
+                                           int n_theta, const double* x_device,
+                                           int64_t n_draws, int n_gauss, unsigned flags,
+                                           double* ngal_device, double* xi_device) {
+  TC_CHECK(it != nullptr, "interp handle is NULL");
+  int status = check_predict_args(it->tables[0], theta_device, n_theta, n_draws,
+                                  n_gauss, flags);
+  if (status != TC_OK) return status;
+  if (n_draws == 0) return TC_OK;
+  TC_CHECK(x_device && ngal_device && xi_device, "NULL pointer");
+  TC_HIP(hipSetDevice(it->device));
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  const int n_comp = separate ? it->tables[0]->plan.n_components : 1;
+  for (int64_t begin = 0; begin < n_draws; begin += kMaxSlab) {
+    const int64_t n = std::min(kMaxSlab, n_draws - begin);
+    status = interp_predict_device(
+        it, theta_device + begin * n_theta, n_theta, x_device + begin * it->n_dim, n,
+        n_gauss, flags, ngal_device + begin * (separate ? 2 : 1),
+        xi_device + begin * n_comp * it->tables[0]->n_r);
+    if (status != TC_OK) return status;
+  }
+  return TC_OK;
+}
+
+int tc_interp_predict_zheng07_batch(tc_interp* it, const double* theta, int n_theta,
+                                    const double* x, int64_t n_draws, int n_gauss,
+                                    unsigned flags, double* ngal, double* xi) {
+  TC_CHECK(it != nullptr, "interp handle is NULL");
+  int status = check_predict_args(it->tables[0], theta, n_theta, n_draws, n_gauss, flags);
+  if (status != TC_OK) return status;
+  if (n_draws == 0) return TC_OK;
+  TC_CHECK(x && ngal && xi, "NULL pointer");
+  TC_HIP(hipSetDevice(it->device));
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  const int n_comp = separate ? it->tables[0]->plan.n_components : 1;
+  const size_t ngal_count = (size_t)n_draws * (separate ? 2 : 1);
+  const size_t xi_count = (size_t)n_draws * n_comp * it->tables[0]->n_r;
+  status = it->theta.reserve((size_t)n_draws * n_theta * 8, it->stream);
+  if (status == TC_OK) status = it->x.reserve((size_t)n_draws * it->n_dim * 8, it->stream);
+  if (status == TC_OK) status = it->out_ngal.reserve(ngal_count * 8, it->stream);
+  if (status == TC_OK) status = it->out_xi.reserve(xi_count * 8, it->stream);
+  if (status != TC_OK) return status;
+  TC_HIP(hipMemcpyAsync(it->theta.ptr, theta, (size_t)n_draws * n_theta * 8,
+                        hipMemcpyHostToDevice, it->stream));
+  TC_HIP(hipMemcpyAsync(it->x.ptr, x, (size_t)n_draws * it->n_dim * 8,
+                        hipMemcpyHostToDevice, it->stream));
+  status = tc_interp_predict_zheng07_batch_device(
+      it, (const double*)it->theta.ptr, n_theta, (const double*)it->x.ptr, n_draws,
+      n_gauss, flags, (double*)it->out_ngal.ptr, (double*)it->out_xi.ptr);
+  if (status != TC_OK) return status;
+  TC_HIP(hipMemcpyAsync(ngal, it->out_ngal.ptr, ngal_count * 8, hipMemcpyDeviceToHost,
+                        it->stream));
+  TC_HIP(hipMemcpyAsync(xi, it->out_xi.ptr, xi_count * 8, hipMemcpyDeviceToHost,
+                        it->stream));
+  TC_HIP(hipStreamSynchronize(it->stream));
+  return TC_OK;
+}
+
+}  // extern "C"

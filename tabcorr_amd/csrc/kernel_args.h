@@ -1,0 +1,110 @@
+// Argument blocks and compile-time constants of the kernels in kernels.hip.h, visible to
+// the host-only translation units (table.cpp, interp.cpp) that fill them in.
+#pragma once
+
+#include <cstdint>
+
+#include "hostmath.h"
+
+namespace tc {
+
+constexpr int kLanes = 64;
+constexpr unsigned kFlagSeparate = 1u;
+constexpr unsigned kFlagModulate = 2u;
+constexpr unsigned kFlagAssembias = 4u;
+constexpr int kOccWaves = 4;
+constexpr int kF32Block = 8;    // entries per block
+constexpr int kF32Tile = 32;    // r values per tile
+constexpr int kFinalizeRows = 32;   // (component, r) rows per LDS pass
+constexpr int kMaxInterpDim = 8;
+constexpr int kMaxInterpAxis = 32;
+
+struct OccArgs {
+  const double* theta;     // (n_draws, n_theta) row-major
+  int n_theta;
+  int64_t n_draws;
+  int64_t ldb;             // draws rounded up to a multiple of 64
+  int n_bins;
+  int n_central;
+  int n_gauss;
+  unsigned flags;
+  double split;
+  const double* log_m;     // (n_bins, n_gauss) log10 of the node masses
+  const double* m;         // (n_bins, n_gauss) node masses
+  const double* weight;    // (n_bins, n_gauss) normalised quadrature weights
+  const double* n_h;       // (n_bins)
+  const double* percentile;  // (n_bins)
+  const int32_t* perm;     // library bin -> reference row
+  const double* math_table;  // fm::kTableDoubles doubles (fastmath.h)
+  double* nbuf;            // (n_bins, ldb) number density per bin and draw
+  double* ngal;            // (bin splits, 2, ldb) partial cen / sat densities
+  double* occupation;      // optional (n_draws, n_bins) in reference order
+};
+
+struct ContractArgs {
+  const double* nbuf;       // (n_bins, ldb)
+  int64_t ldb;
+  const void* table;        // (n_rtiles, n_positions, RT) re-laid-out matrix
+  int64_t n_positions;
+  const Chunk* chunks;
+  const Group* groups;
+  int mode;
+  int n_central;
+  int r_stride;             // n_rtiles * RT: padded number of r values
+  int n_tiles;              // draw tiles (grid.x covers 8 * ceil(n_tiles / 8) * slabs)
+  int n_slabs;              // groups * table splits per draw tile
+  const int32_t* pos_ij;    // float32 kernel: packed bin pairs of every position
+  unsigned long long* trace;  // developer timeline (TC_TRACE): 6 words per block, or NULL
+  unsigned long long* wave_trace;  // TC_TRACE: 6 words per wave (progress stamps)
+  double* partial;          // (n_groups * k_splits, r_stride, ldb)
+  // Interpolator: the block loops over tables [k_begin, k_end) of its k split and
+  // accumulates coef[k][draw] * (table k contraction) into the same registers.
+  int n_tables;             // 0: single table (fields below unused)
+  int k_splits;             // blockIdx.y = group * k_splits + k split
+  const double* const* tables;   // (n_tables) re-laid-out matrices
+  const double* const* nbufs;    // (n_classes) density buffers
+  const int32_t* table_class;    // (n_tables) density class of each table
+  const double* coef;       // (n_tables, ldb) spline weight / pair-weight norm
+};
+
+struct FinalizeArgs {
+  const double* partial;   // (n_groups, r_stride, ldb)
+  const Group* groups;     // component of each group
+  const double* ngal_part; // (n_ngal_parts, 2, ldb); NULL: the partials are already
+                           // normalised and ngal has been written (interpolator)
+  int n_ngal_parts;
+  int n_groups;            // partial slabs = n_groups * k_splits
+  int k_splits;
+  int n_comp;              // 1: sum all components; else per component
+  int r_stride;
+  int n_r;
+  int mode;
+  int64_t ldb;
+  int64_t n_draws;
+  double* ngal;            // (n_draws) or (n_draws, 2)
+  double* xi;              // (n_draws, n_comp, n_r)
+};
+
+struct InterpArgs {
+  int n_dim;
+  int n_tables;
+  int n_classes;
+  int mode;
+  int separate;             // write ngal as (n_draws, 2)
+  int n_axis[kMaxInterpDim];
+  int axis_offset[kMaxInterpDim];   // offset of xp_d in xp
+  int a_offset[kMaxInterpDim];      // offset of a_d in a
+  const double* xp;         // concatenated abscissae
+  const double* a;          // concatenated (n_d - 1, 4, n_d) spline matrices
+  const int32_t* table_node;     // (n_tables, n_dim) grid index of each table
+  const int32_t* table_class;    // (n_tables)
+  const double* x;          // (n_draws, n_dim)
+  const double* const* ngal_parts;  // per class: (n_parts, 2, ldb)
+  int n_ngal_parts;
+  int64_t ldb;
+  int64_t n_draws;
+  double* coef;             // (n_tables, ldb)
+  double* ngal;             // (n_draws) or (n_draws, 2)
+};
+
+}  // namespace tc

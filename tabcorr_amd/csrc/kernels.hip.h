@@ -15,6 +15,7 @@
 
 #include "fastmath.h"
 #include "hostmath.h"
+#include "kernel_args.h"
 
 namespace tc {
 
@@ -25,34 +26,6 @@ typedef const __attribute__((address_space(4))) int32_t* sc_i32;
 // Pointers that were themselves loaded from memory are generic to the compiler; this
 // tells it they point to global memory (global_load with counted vmcnt, not flat_load).
 typedef const __attribute__((address_space(1))) double* gl_f64;
-
-constexpr int kLanes = 64;
-
-struct OccArgs {
-  const double* theta;     // (n_draws, n_theta) row-major
-  int n_theta;
-  int64_t n_draws;
-  int64_t ldb;             // draws rounded up to a multiple of 64
-  int n_bins;
-  int n_central;
-  int n_gauss;
-  unsigned flags;
-  double split;
-  const double* log_m;     // (n_bins, n_gauss) log10 of the node masses
-  const double* m;         // (n_bins, n_gauss) node masses
-  const double* weight;    // (n_bins, n_gauss) normalised quadrature weights
-  const double* n_h;       // (n_bins)
-  const double* percentile;  // (n_bins)
-  const int32_t* perm;     // library bin -> reference row
-  const double* math_table;  // fm::kTableDoubles doubles (fastmath.h)
-  double* nbuf;            // (n_bins, ldb) number density per bin and draw
-  double* ngal;            // (bin splits, 2, ldb) partial cen / sat densities
-  double* occupation;      // optional (n_draws, n_bins) in reference order
-};
-
-constexpr unsigned kFlagSeparate = 1u;
-constexpr unsigned kFlagModulate = 2u;
-constexpr unsigned kFlagAssembias = 4u;
 
 __device__ inline double heaviside_assembias(double n, double strength,
                                              bool above, double f2_over_f1,
@@ -71,7 +44,6 @@ __device__ inline double heaviside_assembias(double n, double strength,
 // eqs. 1 and 3).  grid = (draw tiles, bin splits); the kOccWaves waves of a
 // block share one draw tile and interleave over the bins of their split.  The
 // block's centrals / satellites density sums go to ngal_part[split][2][ldb].
-constexpr int kOccWaves = 4;
 
 // NGAUSS > 0: n_gauss known at compile time, node loop fully unrolled (the scalar loads
 // of a bin's constants are batched and the independent polynomial chains interleave);
@@ -201,32 +173,6 @@ __global__ __launch_bounds__(256) void occ_from_array_kernel(
   ngal[b0] = sum_cen;
   ngal[ldb + b0] = sum_sat;
 }
-
-struct ContractArgs {
-  const double* nbuf;       // (n_bins, ldb)
-  int64_t ldb;
-  const void* table;        // (n_rtiles, n_positions, RT) re-laid-out matrix
-  int64_t n_positions;
-  const Chunk* chunks;
-  const Group* groups;
-  int mode;
-  int n_central;
-  int r_stride;             // n_rtiles * RT: padded number of r values
-  int n_tiles;              // draw tiles (grid.x covers 8 * ceil(n_tiles / 8) * slabs)
-  int n_slabs;              // groups * table splits per draw tile
-  const int32_t* pos_ij;    // float32 kernel: packed bin pairs of every position
-  unsigned long long* trace;  // developer timeline (TC_TRACE): 6 words per block, or NULL
-  unsigned long long* wave_trace;  // TC_TRACE: 6 words per wave (progress stamps)
-  double* partial;          // (n_groups * k_splits, r_stride, ldb)
-  // Interpolator: the block loops over tables [k_begin, k_end) of its k split and
-  // accumulates coef[k][draw] * (table k contraction) into the same registers.
-  int n_tables;             // 0: single table (fields below unused)
-  int k_splits;             // blockIdx.y = group * k_splits + k split
-  const double* const* tables;   // (n_tables) re-laid-out matrices
-  const double* const* nbufs;    // (n_classes) density buffers
-  const int32_t* table_class;    // (n_tables) density class of each table
-  const double* coef;       // (n_tables, ldb) spline weight / pair-weight norm
-};
 
 // acc += t[lane N of my 16-lane row] * w.  The DP-only DPP control row_newbcast
 // lets the 16 table values held by the 16 lanes of a row feed 16 FMAs without
@@ -524,9 +470,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kF32Block = 8;    // entries per block
-constexpr int kF32Tile = 32;    // r values per tile
-
 __global__ __launch_bounds__(512) void contract_f32_kernel(ContractArgs a) {
   extern __shared__ __attribute__((aligned(16))) float ldsf[];
   const int lane = threadIdx.x & 63;
@@ -632,26 +575,6 @@ __global__ __launch_bounds__(512) void contract_f32_kernel(ContractArgs a) {
   }
 }
 
-struct FinalizeArgs {
-  const double* partial;   // (n_groups, r_stride, ldb)
-  const Group* groups;     // component of each group
-  const double* ngal_part; // (n_ngal_parts, 2, ldb); NULL: the partials are already
-                           // normalised and ngal has been written (interpolator)
-  int n_ngal_parts;
-  int n_groups;            // partial slabs = n_groups * k_splits
-  int k_splits;
-  int n_comp;              // 1: sum all components; else per component
-  int r_stride;
-  int n_r;
-  int mode;
-  int64_t ldb;
-  int64_t n_draws;
-  double* ngal;            // (n_draws) or (n_draws, 2)
-  double* xi;              // (n_draws, n_comp, n_r)
-};
-
-constexpr int kFinalizeRows = 32;   // (component, r) rows per LDS pass
-
 // Sum the per-group partials in fixed order, divide by the total pair weight
 // (tabcorr.py:646-649, 653-655: sum(ngal_sq) = (sum ngal)^2 in mode auto) and
 // write the results in the reference's output order.  One block per draw tile;
@@ -722,31 +645,6 @@ __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
     __syncthreads();
   }
 }
-
-constexpr int kMaxInterpDim = 8;
-constexpr int kMaxInterpAxis = 32;
-
-struct InterpArgs {
-  int n_dim;
-  int n_tables;
-  int n_classes;
-  int mode;
-  int separate;             // write ngal as (n_draws, 2)
-  int n_axis[kMaxInterpDim];
-  int axis_offset[kMaxInterpDim];   // offset of xp_d in xp
-  int a_offset[kMaxInterpDim];      // offset of a_d in a
-  const double* xp;         // concatenated abscissae
-  const double* a;          // concatenated (n_d - 1, 4, n_d) spline matrices
-  const int32_t* table_node;     // (n_tables, n_dim) grid index of each table
-  const int32_t* table_class;    // (n_tables)
-  const double* x;          // (n_draws, n_dim)
-  const double* const* ngal_parts;  // per class: (n_parts, 2, ldb)
-  int n_ngal_parts;
-  int64_t ldb;
-  int64_t n_draws;
-  double* coef;             // (n_tables, ldb)
-  double* ngal;             // (n_draws) or (n_draws, 2)
-};
 
 // Per draw: the tensor-product spline weight of every table at the draw's extra
 // parameters (interpolator.py:275-331; segment search as np.digitize with the right

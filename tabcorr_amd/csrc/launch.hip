@@ -1,0 +1,427 @@
+// Launch layer: the only translation unit that contains device code.  Chooses the
+// decomposition of a batch, fills the kernels' argument blocks and launches them on the
+// table's lanes (internal.h).
+#include "internal.h"
+#include "kernels.hip.h"
+
+namespace tc {
+namespace host {
+
+int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
+  auto it = t->quadrature.find(n_gauss);
+  if (it != t->quadrature.end()) {
+    *out = &it->second;
+    return TC_OK;
+  }
+  // tabcorr/tabcorr.py:543-549, 568-578: nodes, node masses and the weights
+  // w_k M^(d + 1) / sum_k w_k M^(d + 1), normalised here once per table.  The
+  // power is taken relative to the first node so that M^11 cannot overflow.
+  std::vector<double> x, w;
+  tc::gauss_legendre(n_gauss, x, w);
+  const int g = t->n_bins;
+  std::vector<double> log_m((size_t)g * n_gauss), m((size_t)g * n_gauss),
+      weight((size_t)g * n_gauss);
+  for (int i = 0; i < g; ++i) {
+    const double d_log = t->log_max[i] - t->log_min[i];
+    const double exponent = t->legacy ? 0.0 : t->dist_index[i] + 1.0;
+    long double norm = 0.0L;
+    std::vector<long double> raw(n_gauss);
+    for (int k = 0; k < n_gauss; ++k) {
+      const double mass = std::pow(10.0, t->log_min[i] + d_log * x[k]);
+      m[(size_t)i * n_gauss + k] = mass;
+      log_m[(size_t)i * n_gauss + k] = std::log10(mass);
+      const double m_ref = m[(size_t)i * n_gauss];
+      raw[k] = (long double)w[k] *
+               powl((long double)mass / (long double)m_ref, (long double)exponent);
+      norm += raw[k];
+    }
+    for (int k = 0; k < n_gauss; ++k)
+      weight[(size_t)i * n_gauss + k] = (double)(raw[k] / norm);
+  }
+  Quadrature q;
+  q.n_gauss = n_gauss;
+  int status = upload(log_m, &q.log_m);
+  if (status == TC_OK) status = upload(m, &q.m);
+  if (status == TC_OK) status = upload(weight, &q.weight);
+  if (status != TC_OK) return status;
+  t->quadrature[n_gauss] = q;
+  *out = &t->quadrature[n_gauss];
+  return TC_OK;
+}
+
+int get_chunking(tc_table* t, int n_chunks, int waves, DeviceChunking** out) {
+  auto key = std::make_pair(n_chunks, waves);
+  auto it = t->chunkings.find(key);
+  if (it != t->chunkings.end()) {
+    *out = it->second.get();
+    return TC_OK;
+  }
+  std::unique_ptr<DeviceChunking> c(new DeviceChunking);
+  tc::build_chunking(t->plan, n_chunks, waves, c->host);
+  int status = upload(c->host.chunks, &c->chunks);
+  if (status == TC_OK) status = upload(c->host.groups, &c->groups);
+  if (status != TC_OK) return status;
+  *out = c.get();
+  t->chunkings[key] = std::move(c);
+  return TC_OK;
+}
+
+int lds_bytes_for(const tc::Chunking& chunking, int rt, int elem) {
+  int span = 1;
+  while (span < chunking.waves_per_group) span <<= 1;
+  return std::max(chunking.max_rows, (span / 2) * rt) * 64 * elem;
+}
+
+// Workgroups of this kernel that fit on one CU: LDS (160 KiB) and wave slots (the
+// kernel needs ~70 VGPRs: 7 waves per SIMD).
+int blocks_per_cu(int lds_bytes, int waves) {
+  const int by_lds = kMaxLdsBytes / std::max(lds_bytes, 1);
+  const int by_waves = 28 / waves;
+  return std::max(1, std::min(std::min(by_lds, by_waves), 8));
+}
+
+// Pick the decomposition for a batch.  Draw tiles alone rarely fill the chip (10^4
+// draws are 157 tiles), so the table is additionally cut into groups of `waves` chunks.
+// Candidates (4 or 8 waves per workgroup, 1..32 groups) are ranked by a small cost model
+// of the busiest CU -- workgroups per CU x waves x (entries per wave + fixed overhead),
+// penalised when fewer than four waves per SIMD are resident or when the workgroups need
+// several scheduling rounds -- calibrated on per-workgroup timelines (tools/trace.py):
+// the main loop issues one FP64 VALU instruction per 4 cycles per SIMD as long as >= 4
+// waves per SIMD are resident, and idle time comes from uneven workgroup counts per CU.
+int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
+                    DeviceChunking** out, int* lds_bytes) {
+  (void)n_comp_out;
+  const int64_t n_tiles = (n_draws + 63) / 64 * t->n_rtiles;
+  const int elem = t->compute_dtype == TC_DTYPE_F32 ? 4 : 8;
+  const int forced_groups = env_int("TC_NGROUPS", 0);
+  const int forced_waves = env_int("TC_NWAVES", 0);
+  if (forced_groups == 0 && forced_waves == 0) {
+    auto cached = t->choices.find(n_tiles);
+    if (cached != t->choices.end()) {
+      *out = cached->second;
+      *lds_bytes = lds_bytes_for((*out)->host, t->rt, elem);
+      return TC_OK;
+    }
+  }
+  const int64_t min_entries = env_int("TC_MIN_CHUNK_ENTRIES", 32);
+  const double overhead_entries = 24.0;
+  const int n_cus = 256;
+  double best_cost = 0.0;
+  int best_chunks = 0, best_waves = 0;
+  tc::Chunking trial;
+  for (int waves : {4, 5, 6, 7, 8}) {
+    if (forced_waves > 0 && waves != forced_waves) continue;
+    if (forced_waves == 0 && waves != 4 && waves != 8) continue;
+    if (t->compute_dtype == TC_DTYPE_F32 && waves == 4) continue;
+    int last_groups = -1;
+    for (int groups = 1; groups <= 32; ++groups) {
+      if (forced_groups > 0 && groups != forced_groups) continue;
+      int64_t n_chunks = (int64_t)groups * waves;
+      n_chunks = std::min<int64_t>(
+          n_chunks, std::max<int64_t>(1, t->plan.n_entries / min_entries));
+      const int use_waves = (int)std::min<int64_t>(waves, n_chunks);
+      tc::build_chunking(t->plan, (int)n_chunks, use_waves, trial);
+      const int actual_groups = (int)trial.groups.size();
+      if (actual_groups == last_groups && forced_groups == 0) continue;
+      last_groups = actual_groups;
+      const int bytes = lds_bytes_for(trial, t->rt, elem);
+      if (bytes > kMaxLdsBytes) continue;
+      int longest = 1;
+      for (const tc::Chunk& chunk : trial.chunks)
+        longest = std::max(longest, chunk.q_end - chunk.q_begin);
+      const int fit = blocks_per_cu(bytes + 1024, use_waves);
+      const double blocks = (double)n_tiles * actual_groups;
+      const double per_cu = std::ceil(blocks / n_cus);
+      const double resident = std::min<double>(per_cu, fit) * use_waves / 4.0;
+      const double rounds = std::ceil(per_cu / fit);
+      double cost = per_cu * use_waves * (longest + overhead_entries);
+      if (resident < 4.0) cost *= 4.0 / resident;
+      cost *= 1.0 + 0.1 * (rounds - 1.0);
+      if (best_chunks == 0 || cost < best_cost) {
+        best_cost = cost;
+        best_chunks = (int)n_chunks;
+        best_waves = use_waves;
+      }
+    }
+  }
+  if (best_chunks == 0)
+    return fail(TC_ERR_UNSUPPORTED,
+                "table with %d bins needs more than %d bytes of LDS per workgroup",
+                t->n_bins, kMaxLdsBytes);
+  DeviceChunking* c = nullptr;
+  int status = get_chunking(t, best_chunks, best_waves, &c);
+  if (status != TC_OK) return status;
+  if (forced_groups == 0 && forced_waves == 0) t->choices[n_tiles] = c;
+  *out = c;
+  *lds_bytes = std::max(lds_bytes_for(c->host, t->rt, elem), env_int("TC_LDS_MIN", 0));
+  return TC_OK;
+}
+
+#define TC_RT_CASES                                                           \
+  TC_CASE(4) TC_CASE(8) TC_CASE(12) TC_CASE(16) TC_CASE(20) TC_CASE(24)       \
+  TC_CASE(28) TC_CASE(32)
+
+int launch_contract_rt(int rt, dim3 grid, dim3 block, int lds, hipStream_t stream,
+                       const tc::ContractArgs& args) {
+  switch (rt) {
+#define TC_CASE(N)                                                            \
+  case N:                                                                     \
+    if (args.n_tables > 0)                                                    \
+      hipLaunchKernelGGL((tc::contract_kernel<N, true>), grid, block, lds,    \
+                         stream, args);                                       \
+    else                                                                      \
+      hipLaunchKernelGGL((tc::contract_kernel<N, false>), grid, block, lds,   \
+                         stream, args);                                       \
+    break;
+    TC_RT_CASES
+#undef TC_CASE
+    default:
+      return fail(TC_ERR_UNSUPPORTED, "no kernel for r tile %d", rt);
+  }
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+
+int set_lds_limit_rt(int rt, int lds) {
+  switch (rt) {
+#define TC_CASE(N)                                                            \
+  case N:                                                                     \
+    TC_HIP(hipFuncSetAttribute(                                               \
+        reinterpret_cast<const void*>(&tc::contract_kernel<N, false>),        \
+        hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \
+    TC_HIP(hipFuncSetAttribute(                                               \
+        reinterpret_cast<const void*>(&tc::contract_kernel<N, true>),         \
+        hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \
+    break;
+    TC_RT_CASES
+#undef TC_CASE
+    default:
+      break;
+  }
+  return TC_OK;
+}
+
+// Contraction + finalisation of draws whose densities are already in nbuf / ngal2.
+int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
+                    double* ngal_device, double* xi_device) {
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  const int n_comp = separate ? t->plan.n_components : 1;
+  DeviceChunking* c = nullptr;
+  int lds = 0;
+  int status = choose_chunking(t, n_draws, n_comp, &c, &lds);
+  if (status != TC_OK) return status;
+  tc_table::Lane& lane = t->lanes[t->cur];
+  hipStream_t stream = lane.stream;
+  const int n_groups = (int)c->host.groups.size();
+  const int r_stride = t->rt * t->n_rtiles;
+  status = lane.partial.reserve(
+      (size_t)n_groups * r_stride * ldb * sizeof(double), stream);
+  if (status != TC_OK) return status;
+
+  tc::ContractArgs ca;
+  ca.nbuf = (const double*)lane.nbuf.ptr;
+  ca.ldb = ldb;
+  ca.table = t->d_table;
+  ca.n_positions = t->plan.n_positions;
+  ca.chunks = (const tc::Chunk*)c->chunks;
+  ca.groups = (const tc::Group*)c->groups;
+  ca.mode = t->mode;
+  ca.n_central = t->plan.n_central;
+  ca.r_stride = r_stride;
+  ca.trace = nullptr;
+  ca.wave_trace = nullptr;
+  ca.pos_ij = nullptr;
+  if (env_int("TC_TRACE", 0)) {
+    t->trace_blocks = (size_t)(ldb / 64) * n_groups * t->n_rtiles;
+    status = t->trace.reserve(t->trace_blocks * 6 * sizeof(unsigned long long), stream);
+    if (status != TC_OK) return status;
+    ca.trace = (unsigned long long*)t->trace.ptr;
+    t->wave_trace_count = t->trace_blocks * c->host.waves_per_group;
+    status = t->wave_trace.reserve(t->wave_trace_count * 6 * sizeof(unsigned long long),
+                                   stream);
+    if (status != TC_OK) return status;
+    TC_HIP(hipMemsetAsync(t->wave_trace.ptr, 0,
+                          t->wave_trace_count * 6 * sizeof(unsigned long long), stream));
+    ca.wave_trace = (unsigned long long*)t->wave_trace.ptr;
+  }
+  ca.n_tables = 0;
+  ca.k_splits = 1;
+  ca.tables = nullptr;
+  ca.nbufs = nullptr;
+  ca.table_class = nullptr;
+  ca.coef = nullptr;
+  ca.partial = (double*)lane.partial.ptr;
+
+  const int n_tiles = (int)(ldb / 64);
+  ca.n_tiles = n_tiles;
+  ca.n_slabs = n_groups;
+  dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * n_groups), 1, (unsigned)t->n_rtiles);
+  dim3 block(64 * c->host.waves_per_group);
+  if (lds > 64 * 1024) {
+    status = set_lds_limit_rt(t->rt, lds);
+    if (status != TC_OK) return status;
+  }
+  hipEvent_t k0 = nullptr, k1 = nullptr;
+  if (t->profile_kernels) {
+    if (t->kernel_events_used == t->kernel_events.size()) {
+      hipEvent_t e0, e1;
+      TC_HIP(hipEventCreate(&e0));
+      TC_HIP(hipEventCreate(&e1));
+      t->kernel_events.emplace_back(e0, e1);
+    }
+    k0 = t->kernel_events[t->kernel_events_used].first;
+    k1 = t->kernel_events[t->kernel_events_used].second;
+    ++t->kernel_events_used;
+    TC_HIP(hipEventRecord(k0, stream));
+  }
+  if (t->compute_dtype == TC_DTYPE_F32) {
+    ca.pos_ij = (const int32_t*)t->d_pos_ij;
+    if (lds > 64 * 1024)
+      TC_HIP(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(&tc::contract_f32_kernel),
+          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(tc::contract_f32_kernel, grid, block, lds, stream, ca);
+    TC_HIP(hipGetLastError());
+  } else {
+    status = launch_contract_rt(t->rt, grid, block, lds, stream, ca);
+    if (status != TC_OK) return status;
+  }
+  if (t->profile_kernels) TC_HIP(hipEventRecord(k1, stream));
+  t->last_workgroups = n_tiles * n_groups * t->n_rtiles;
+  t->last_waves = c->host.waves_per_group;
+  t->last_splits = n_groups;
+  t->last_lds = lds;
+
+  tc::FinalizeArgs fa;
+  fa.partial = (const double*)lane.partial.ptr;
+  fa.groups = (const tc::Group*)c->groups;
+  fa.ngal_part = (const double*)lane.ngal2.ptr;
+  fa.n_ngal_parts = lane.ngal_parts;
+  fa.n_groups = n_groups;
+  fa.k_splits = 1;
+  fa.n_comp = n_comp;
+  fa.r_stride = r_stride;
+  fa.n_r = t->n_r;
+  fa.mode = t->mode;
+  fa.ldb = ldb;
+  fa.n_draws = n_draws;
+  fa.ngal = ngal_device;
+  fa.xi = xi_device;
+  // results appear in call order: wait for the previous call's finalisation
+  // (host-buffer calls synchronise before returning and need no chaining)
+  if (t->prev >= 0 && t->prev != t->cur)
+    TC_HIP(hipStreamWaitEvent(stream, t->lanes[t->prev].finished, 0));
+  status = launch_finalize(fa, stream);
+  if (status != TC_OK) return status;
+  if (t->force_lane >= 0) {
+    t->prev = -1;
+  } else {
+    TC_HIP(hipEventRecord(lane.finished, stream));
+    t->prev = t->cur;
+  }
+  return TC_OK;
+}
+
+int run_occupation(tc_table* t, const double* theta_device, int n_theta,
+                   int64_t n_draws, int64_t ldb, int n_gauss, unsigned flags,
+                   double* occupation_device, DeviceBuffer* nbuf, DeviceBuffer* ngal2,
+                   hipStream_t stream, int* ngal_parts) {
+  tc_table::Lane& lane = t->lanes[t->cur];
+  if (nbuf == nullptr) nbuf = &lane.nbuf;
+  if (ngal2 == nullptr) ngal2 = &lane.ngal2;
+  if (stream == nullptr) stream = lane.stream;
+  Quadrature* q = nullptr;
+  int status = get_quadrature(t, n_gauss, &q);
+  if (status != TC_OK) return status;
+  // enough blocks to fill the chip: split the bins when there are few draw tiles
+  const int64_t n_tiles = ldb / 64;
+  int splits = (int)std::min<int64_t>(
+      (t->n_bins + tc::kOccWaves - 1) / tc::kOccWaves,
+      std::max<int64_t>(1, env_int("TC_OCC_BLOCKS", 2048) / n_tiles));
+  splits = std::max(1, splits);
+  status = nbuf->reserve((size_t)t->n_bins * ldb * sizeof(double), stream);
+  if (status == TC_OK)
+    status = ngal2->reserve((size_t)splits * 2 * ldb * sizeof(double), stream);
+  if (status != TC_OK) return status;
+  if (ngal_parts != nullptr) *ngal_parts = splits; else lane.ngal_parts = splits;
+  tc::OccArgs oa;
+  oa.theta = theta_device;
+  oa.n_theta = n_theta;
+  oa.n_draws = n_draws;
+  oa.ldb = ldb;
+  oa.n_bins = t->n_bins;
+  oa.n_central = t->plan.n_central;
+  oa.n_gauss = n_gauss;
+  oa.flags = flags;
+  oa.split = 0.5;
+  oa.log_m = (const double*)q->log_m;
+  oa.m = (const double*)q->m;
+  oa.weight = (const double*)q->weight;
+  oa.n_h = (const double*)t->d_n_h;
+  oa.percentile = (const double*)t->d_percentile;
+  oa.perm = (const int32_t*)t->d_perm;
+  oa.math_table = (const double*)t->d_math_table;
+  oa.nbuf = (double*)nbuf->ptr;
+  oa.ngal = (double*)ngal2->ptr;
+  oa.occupation = occupation_device;
+  {
+    const dim3 grid((unsigned)(ldb / 64), (unsigned)splits), block(tc::kOccWaves * 64);
+    const bool assembias = (flags & TC_FLAG_ASSEMBIAS) != 0;
+    if (n_gauss == 10 && !assembias)
+      hipLaunchKernelGGL((tc::occ_zheng07_kernel<10, false>), grid, block, 0, stream, oa);
+    else if (n_gauss == 10)
+      hipLaunchKernelGGL((tc::occ_zheng07_kernel<10, true>), grid, block, 0, stream, oa);
+    else if (!assembias)
+      hipLaunchKernelGGL((tc::occ_zheng07_kernel<0, false>), grid, block, 0, stream, oa);
+    else
+      hipLaunchKernelGGL((tc::occ_zheng07_kernel<0, true>), grid, block, 0, stream, oa);
+  }
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+
+int check_predict_args(const tc_table* t, const void* theta, int n_theta,
+                       int64_t n_draws, int n_gauss, unsigned flags) {
+  TC_CHECK(t != nullptr, "table handle is NULL");
+  TC_CHECK(n_draws >= 0, "n_draws must be non-negative");
+  TC_CHECK(n_draws == 0 || theta != nullptr, "theta is NULL");
+  TC_CHECK(n_gauss >= 1 && n_gauss <= 4096, "n_gauss_prim must be in [1, 4096]");
+  const int need = (flags & TC_FLAG_ASSEMBIAS) ? 7 : 5;
+  TC_CHECK(n_theta == need, "theta must have %d columns, got %d", need, n_theta);
+  return TC_OK;
+}
+
+int launch_finalize(const FinalizeArgs& args, hipStream_t stream) {
+  hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)(args.ldb / 64)),
+                     dim3(env_int("TC_FINALIZE_THREADS", 256)), 0, stream, args);
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+
+int launch_interp_coef(const InterpArgs& args, hipStream_t stream) {
+  hipLaunchKernelGGL(tc::interp_coef_kernel, dim3((unsigned)(args.ldb / 64)), dim3(64), 0,
+                     stream, args);
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+
+int launch_occ_from_array(tc_table* t, const double* occupation_device, int64_t n_draws,
+                          int64_t ldb, double* nbuf, double* ngal2, hipStream_t stream) {
+  hipLaunchKernelGGL(tc::occ_from_array_kernel, dim3((unsigned)((ldb + 255) / 256)),
+                     dim3(256), 0, stream, occupation_device, n_draws, ldb, t->n_bins,
+                     t->plan.n_central, (const double*)t->d_n_h, (const int32_t*)t->d_perm,
+                     nbuf, ngal2);
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+
+int launch_chi2(const double* xi, int64_t n_draws, int n_r, const double* data,
+                const double* precision, double* chi2, hipStream_t stream) {
+  hipLaunchKernelGGL(tc::chi2_kernel, dim3((unsigned)((n_draws + 255) / 256)), dim3(256),
+                     0, stream, xi, n_draws, n_r, data, precision, chi2);
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+
+}  // namespace host
+}  // namespace tc

@@ -1,0 +1,484 @@
+// Table handle of the C ABI (include/tabcorr_amd.h): upload and re-layout of one
+// tabulated correlation matrix, the batched predict / chi2 / occupation entry points,
+// and the measurement hooks bench.py uses.
+#include "internal.h"
+
+using namespace tc::host;
+
+extern "C" {
+
+int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
+                    const void* tpcf_matrix, int matrix_dtype, const double* n_h,
+                    const double* log_min, const double* log_max,
+                    const double* percentile, const double* dist_index,
+                    const uint8_t* is_central, int compute_dtype, tc_table** out) {
+  TC_CHECK(out != nullptr, "table output pointer is NULL");
+  *out = nullptr;
+  TC_CHECK(mode == TC_MODE_AUTO || mode == TC_MODE_CROSS, "invalid mode %d", mode);
+  TC_CHECK(n_bins >= 1 && n_bins < (1 << 20), "invalid number of bins %d", n_bins);
+  TC_CHECK(n_r >= 1, "invalid number of correlation function bins %d", n_r);
+  const int64_t expect =
+      mode == TC_MODE_AUTO ? (int64_t)n_bins * (n_bins + 1) / 2 : n_bins;
+  TC_CHECK(n_pairs == expect,
+           "tpcf_matrix has %lld columns but %d bins in mode '%s' need %lld",
+           (long long)n_pairs, n_bins, mode == TC_MODE_AUTO ? "auto" : "cross",
+           (long long)expect);
+  TC_CHECK(n_pairs < (1LL << 31), "too many pair columns");
+  TC_CHECK(tpcf_matrix && n_h && log_min && log_max && percentile && is_central,
+           "NULL input array");
+  TC_CHECK(matrix_dtype == TC_DTYPE_F64 || matrix_dtype == TC_DTYPE_F32,
+           "invalid matrix dtype");
+  TC_CHECK(compute_dtype == TC_DTYPE_F64 || compute_dtype == TC_DTYPE_F32,
+           "invalid compute dtype");
+
+  std::unique_ptr<tc_table> t(new tc_table);
+  TC_HIP(hipGetDevice(&t->device));
+  t->mode = mode;
+  t->n_bins = n_bins;
+  t->n_r = n_r;
+  t->n_pairs = n_pairs;
+  t->compute_dtype = compute_dtype;
+  t->legacy = dist_index == nullptr;
+  // r tiling: at most 32 accumulators per lane, a multiple of 4 so that a block
+  // of at most 4 entries fills whole 128-byte lines (float64); tiles of exactly 32 r
+  // values and blocks of 8 entries for the float32 MFMA kernel.
+  const int max_rt = 32;
+  t->n_rtiles = (n_r + max_rt - 1) / max_rt;
+  if (compute_dtype == TC_DTYPE_F32) {
+    t->rt = tc::kF32Tile;
+    tc::build_plan(mode, n_bins, is_central, tc::kF32Block,
+                   env_int("TC_ROW_BUDGET_F32", 128), t->plan);
+  } else {
+    int rt = (n_r + t->n_rtiles - 1) / t->n_rtiles;
+    t->rt = (rt + 3) / 4 * 4;
+    // LDS rows a workgroup may stage: half the bins (one triangle or one column block
+    // of the cen-sat rectangle) plus a few rows, within 28..66 KB
+    const int budget = std::max(56, std::min(128, n_bins / 2 + 6));
+    tc::build_plan(mode, n_bins, is_central, tc::block_entries(t->rt),
+                   env_int("TC_ROW_BUDGET", budget), t->plan);
+  }
+
+  for (int g = 0; g < n_bins; ++g) {
+    const int src = t->plan.perm[g];
+    t->n_h.push_back(n_h[src]);
+    t->log_min.push_back(log_min[src]);
+    t->log_max.push_back(log_max[src]);
+    t->percentile.push_back(percentile[src]);
+    t->dist_index.push_back(dist_index ? dist_index[src] : -1.0);
+  }
+
+  const int rt = t->rt;
+  const int64_t n_positions = t->plan.n_positions;
+  const size_t count = (size_t)t->n_rtiles * n_positions * rt;
+  auto source = [&](int r, int64_t column) {
+    return matrix_dtype == TC_DTYPE_F64
+               ? ((const double*)tpcf_matrix)[(size_t)r * n_pairs + column]
+               : (double)((const float*)tpcf_matrix)[(size_t)r * n_pairs + column];
+  };
+  std::vector<double> tmp64;
+  std::vector<float> tmp32;
+  std::vector<int32_t> pos_ij;
+  if (compute_dtype == TC_DTYPE_F64) {
+    // Re-laid-out matrix: [r tile][position][r in tile] with the pair prefactor
+    // (tabcorr.py:638-642) folded in (a multiplication by 2 is exact) and zero
+    // rows at the padding positions.
+    t->table_bytes = count * sizeof(double);
+    tmp64.assign(count, 0.0);
+    for (int r = 0; r < n_r; ++r) {
+      const int tile = r / rt, rr = r % rt;
+      for (int64_t q = 0; q < n_positions; ++q) {
+        const int64_t column = t->plan.column[q];
+        if (column < 0) continue;
+        tmp64[((size_t)tile * n_positions + q) * rt + rr] =
+            source(r, column) * t->plan.prefactor[q];
+      }
+    }
+  } else {
+    // float32 MFMA layout: [r tile][block of 8 positions][k][r][k-step] (kernels.hip.h)
+    t->table_bytes = count * sizeof(float);
+    tmp32.assign(count, 0.0f);
+    for (int r = 0; r < n_r; ++r) {
+      const int tile = r / rt, rr = r % rt;
+      for (int64_t q = 0; q < n_positions; ++q) {
+        const int64_t column = t->plan.column[q];
+        if (column < 0) continue;
+        const int64_t block = q / 8;
+        const int p = (int)(q % 8) / 2, k = (int)(q % 2);
+        tmp32[((size_t)tile * n_positions + block * 8) * rt + (k * 32 + rr) * 4 + p] =
+            (float)(source(r, column) * t->plan.prefactor[q]);
+      }
+    }
+    TC_CHECK(n_bins < 65535, "too many bins for the float32 variant");
+    pos_ij.assign((size_t)n_positions, 0);
+    for (int64_t q = 0; q < n_positions; ++q) {
+      const int64_t block = q / 8;
+      const int p = (int)(q % 8) / 2, k = (int)(q % 2);
+      const int i = t->plan.pos_i[q] < 0 ? 0 : t->plan.pos_i[q];
+      pos_ij[(size_t)block * 8 + k * 4 + p] = (i << 16) | t->plan.pos_j[q];
+    }
+  }
+  for (tc_table::Lane& lane : t->lanes) {
+    TC_HIP(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
+    TC_HIP(hipEventCreateWithFlags(&lane.finished, hipEventDisableTiming));
+  }
+  t->stream = t->lanes[0].stream;
+  t->n_lanes = std::max(1, std::min(env_int("TC_LANES", 3), (int)tc_table::kMaxLanes));
+  TC_HIP(hipEventCreate(&t->ev_begin));
+  TC_HIP(hipEventCreate(&t->ev_end));
+  int status = compute_dtype == TC_DTYPE_F64 ? upload(tmp64, &t->d_table)
+                                             : upload(tmp32, &t->d_table);
+  if (status == TC_OK && compute_dtype == TC_DTYPE_F32)
+    status = upload(pos_ij, &t->d_pos_ij);
+  if (status == TC_OK) status = upload(t->n_h, &t->d_n_h);
+  if (status == TC_OK) status = upload(t->percentile, &t->d_percentile);
+  if (status == TC_OK) status = upload(t->plan.perm, &t->d_perm);
+  if (status == TC_OK) {
+    std::vector<double> math_table(tc::fm::kTableDoubles);
+    tc::fm::build_tables(math_table.data());
+    status = upload(math_table, &t->d_math_table);
+  }
+  if (status != TC_OK) {
+    tc_table_destroy(t.release());
+    return status;
+  }
+  *out = t.release();
+  return TC_OK;
+}
+
+int tc_table_destroy(tc_table* t) {
+  if (t == nullptr) return TC_OK;
+  (void)hipSetDevice(t->device);
+  for (tc_table::Lane& lane : t->lanes)
+    if (lane.stream) (void)hipStreamSynchronize(lane.stream);
+  for (void* p : {t->d_table, t->d_n_h, t->d_percentile, t->d_perm, t->d_math_table,
+                  t->d_pos_ij})
+    if (p) (void)hipFree(p);
+  for (auto& kv : t->quadrature)
+    for (void* p : {kv.second.log_m, kv.second.m, kv.second.weight})
+      if (p) (void)hipFree(p);
+  for (auto& kv : t->chunkings)
+    for (void* p : {kv.second->chunks, kv.second->groups})
+      if (p) (void)hipFree(p);
+  for (DeviceBuffer* b : {&t->theta, &t->out_ngal, &t->out_xi, &t->occupation,
+                          &t->trace, &t->wave_trace})
+    b->release();
+  for (tc_table::Lane& lane : t->lanes) {
+    lane.nbuf.release();
+    lane.ngal2.release();
+    lane.partial.release();
+    if (lane.finished) (void)hipEventDestroy(lane.finished);
+  }
+  t->h_in.release();
+  t->h_out.release();
+  for (auto& ev : t->kernel_events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  if (t->ev_begin) (void)hipEventDestroy(t->ev_begin);
+  if (t->ev_end) (void)hipEventDestroy(t->ev_end);
+  for (tc_table::Lane& lane : t->lanes)
+    if (lane.stream) (void)hipStreamDestroy(lane.stream);
+  delete t;
+  return TC_OK;
+}
+
+int tc_table_synchronize(tc_table* t) {
+  TC_CHECK(t != nullptr, "table handle is NULL");
+  for (tc_table::Lane& lane : t->lanes) TC_HIP(hipStreamSynchronize(lane.stream));
+  return TC_OK;
+}
+
+int tc_table_info(const tc_table* t, int* mode, int* n_bins, int* n_r,
+                  int64_t* n_pairs, int* n_components, int64_t* device_bytes) {
+  TC_CHECK(t != nullptr, "table handle is NULL");
+  if (mode) *mode = t->mode;
+  if (n_bins) *n_bins = t->n_bins;
+  if (n_r) *n_r = t->n_r;
+  if (n_pairs) *n_pairs = t->n_pairs;
+  if (n_components) *n_components = t->plan.n_components;
+  if (device_bytes) *device_bytes = (int64_t)t->table_bytes;
+  return TC_OK;
+}
+
+int tc_predict_zheng07_batch_device(tc_table* t, const double* theta_device,
+                                    int n_theta, int64_t n_draws, int n_gauss,
+                                    unsigned flags, double* ngal_device,
+                                    double* xi_device) {
+  int status = check_predict_args(t, theta_device, n_theta, n_draws, n_gauss, flags);
+  if (status != TC_OK) return status;
+  if (n_draws == 0) return TC_OK;
+  TC_CHECK(ngal_device && xi_device, "output pointer is NULL");
+  TC_HIP(hipSetDevice(t->device));
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  const int n_comp = separate ? t->plan.n_components : 1;
+  if (t->force_lane >= 0)
+    t->cur = t->force_lane;
+  else
+    t->cur = env_int("TC_PIPELINE", 1) ? (int)(t->device_calls++ % t->n_lanes) : 0;
+  for (int64_t begin = 0; begin < n_draws; begin += kMaxSlab) {
+    const int64_t n = std::min(kMaxSlab, n_draws - begin);
+    const int64_t ldb = (n + 63) / 64 * 64;
+    status = run_occupation(t, theta_device + begin * n_theta, n_theta, n, ldb,
+                            n_gauss, flags, nullptr);
+    if (status != TC_OK) return status;
+    status = run_contraction(t, n, ldb, flags,
+                             ngal_device + begin * (separate ? 2 : 1),
+                             xi_device + begin * n_comp * t->n_r);
+    if (status != TC_OK) return status;
+  }
+  return TC_OK;
+}
+
+}  // extern "C"
+
+namespace tc {
+namespace host {
+
+// Host -> device copy of a small input through the pinned staging buffer.
+int copy_in(PinnedBuffer* stage, void* device, const void* host, size_t bytes,
+            hipStream_t stream) {
+  if (bytes <= stage_limit() && stage->reserve(bytes) == TC_OK) {
+    memcpy(stage->ptr, host, bytes);
+    host = stage->ptr;
+  }
+  TC_HIP(hipMemcpyAsync(device, host, bytes, hipMemcpyHostToDevice, stream));
+  return TC_OK;
+}
+
+// Device -> host copy of [ngal | xi], synchronising the stream.
+int copy_out(PinnedBuffer* stage, double* ngal, size_t ngal_count, const void* d_ngal,
+             double* xi, size_t xi_count, const void* d_xi, hipStream_t stream) {
+  const size_t bytes = (ngal_count + xi_count) * sizeof(double);
+  if (bytes <= stage_limit() && stage->reserve(bytes) == TC_OK) {
+    double* h = (double*)stage->ptr;
+    TC_HIP(hipMemcpyAsync(h, d_ngal, ngal_count * 8, hipMemcpyDeviceToHost, stream));
+    TC_HIP(hipMemcpyAsync(h + ngal_count, d_xi, xi_count * 8, hipMemcpyDeviceToHost,
+                          stream));
+    TC_HIP(hipStreamSynchronize(stream));
+    memcpy(ngal, h, ngal_count * 8);
+    memcpy(xi, h + ngal_count, xi_count * 8);
+    return TC_OK;
+  }
+  TC_HIP(hipMemcpyAsync(ngal, d_ngal, ngal_count * 8, hipMemcpyDeviceToHost, stream));
+  TC_HIP(hipMemcpyAsync(xi, d_xi, xi_count * 8, hipMemcpyDeviceToHost, stream));
+  TC_HIP(hipStreamSynchronize(stream));
+  return TC_OK;
+}
+
+}  // namespace host
+}  // namespace tc
+
+extern "C" {
+
+int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
+                             int64_t n_draws, int n_gauss, unsigned flags,
+                             double* ngal, double* xi) {
+  int status = check_predict_args(t, theta, n_theta, n_draws, n_gauss, flags);
+  if (status != TC_OK) return status;
+  if (n_draws == 0) return TC_OK;
+  TC_CHECK(ngal && xi, "output pointer is NULL");
+  TC_HIP(hipSetDevice(t->device));
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  const int n_comp = separate ? t->plan.n_components : 1;
+  const size_t ngal_count = (size_t)n_draws * (separate ? 2 : 1);
+  const size_t xi_count = (size_t)n_draws * n_comp * t->n_r;
+  status = t->theta.reserve((size_t)n_draws * n_theta * sizeof(double), t->stream);
+  if (status == TC_OK) status = t->out_ngal.reserve(ngal_count * 8, t->stream);
+  if (status == TC_OK) status = t->out_xi.reserve(xi_count * 8, t->stream);
+  if (status != TC_OK) return status;
+  status = copy_in(&t->h_in, t->theta.ptr, theta, (size_t)n_draws * n_theta * 8,
+                   t->stream);
+  if (status != TC_OK) return status;
+  t->force_lane = 0;
+  status = tc_predict_zheng07_batch_device(
+      t, (const double*)t->theta.ptr, n_theta, n_draws, n_gauss, flags,
+      (double*)t->out_ngal.ptr, (double*)t->out_xi.ptr);
+  t->force_lane = -1;
+  if (status != TC_OK) return status;
+  return copy_out(&t->h_out, ngal, ngal_count, t->out_ngal.ptr, xi, xi_count,
+                  t->out_xi.ptr, t->stream);
+}
+
+int tc_chi2_zheng07_batch(tc_table* t, const double* theta, int n_theta,
+                          int64_t n_draws, int n_gauss, unsigned flags,
+                          const double* data, const double* precision, double* ngal,
+                          double* chi2) {
+  int status = check_predict_args(t, theta, n_theta, n_draws, n_gauss, flags);
+  if (status != TC_OK) return status;
+  TC_CHECK(!(flags & TC_FLAG_SEPARATE_GAL_TYPE),
+           "chi2 is defined for the total correlation function only");
+  if (n_draws == 0) return TC_OK;
+  TC_CHECK(data && precision && ngal && chi2, "NULL pointer");
+  TC_HIP(hipSetDevice(t->device));
+  const int n_r = t->n_r;
+  const size_t xi_count = (size_t)n_draws * n_r;
+  status = t->theta.reserve((size_t)n_draws * n_theta * sizeof(double), t->stream);
+  if (status == TC_OK) status = t->out_ngal.reserve((size_t)n_draws * 2 * 8, t->stream);
+  if (status == TC_OK) status = t->out_xi.reserve(xi_count * 8, t->stream);
+  if (status == TC_OK)
+    status = t->occupation.reserve((size_t)(n_r + 1) * n_r * 8, t->stream);
+  if (status != TC_OK) return status;
+  status = copy_in(&t->h_in, t->theta.ptr, theta, (size_t)n_draws * n_theta * 8,
+                   t->stream);
+  if (status != TC_OK) return status;
+  // data vector and precision matrix behind each other in a scratch buffer
+  double* d_data = (double*)t->occupation.ptr;
+  double* d_precision = d_data + n_r;
+  TC_HIP(hipMemcpyAsync(d_data, data, (size_t)n_r * 8, hipMemcpyHostToDevice, t->stream));
+  TC_HIP(hipMemcpyAsync(d_precision, precision, (size_t)n_r * n_r * 8,
+                        hipMemcpyHostToDevice, t->stream));
+  double* d_ngal = (double*)t->out_ngal.ptr;
+  double* d_chi2 = d_ngal + n_draws;
+  t->force_lane = 0;
+  status = tc_predict_zheng07_batch_device(t, (const double*)t->theta.ptr, n_theta,
+                                           n_draws, n_gauss, flags, d_ngal,
+                                           (double*)t->out_xi.ptr);
+  t->force_lane = -1;
+  if (status != TC_OK) return status;
+  status = launch_chi2((const double*)t->out_xi.ptr, n_draws, n_r, d_data, d_precision,
+                       d_chi2, t->stream);
+  if (status != TC_OK) return status;
+  return copy_out(&t->h_out, ngal, (size_t)n_draws, d_ngal, chi2, (size_t)n_draws,
+                  d_chi2, t->stream);
+}
+
+int tc_mean_occupation_zheng07_batch(tc_table* t, const double* theta, int n_theta,
+                                     int64_t n_draws, int n_gauss, unsigned flags,
+                                     double* occupation) {
+  int status = check_predict_args(t, theta, n_theta, n_draws, n_gauss, flags);
+  if (status != TC_OK) return status;
+  if (n_draws == 0) return TC_OK;
+  TC_CHECK(occupation != nullptr, "output pointer is NULL");
+  TC_HIP(hipSetDevice(t->device));
+  for (int64_t begin = 0; begin < n_draws; begin += kMaxSlab) {
+    const int64_t n = std::min(kMaxSlab, n_draws - begin);
+    const int64_t ldb = (n + 63) / 64 * 64;
+    const size_t occ_bytes = (size_t)n * t->n_bins * 8;
+    status = t->theta.reserve((size_t)n * n_theta * 8, t->stream);
+    if (status == TC_OK) status = t->occupation.reserve(occ_bytes, t->stream);
+    if (status != TC_OK) return status;
+    TC_HIP(hipMemcpyAsync(t->theta.ptr, theta + begin * n_theta,
+                          (size_t)n * n_theta * 8, hipMemcpyHostToDevice, t->stream));
+    t->cur = 0;
+    status = run_occupation(t, (const double*)t->theta.ptr, n_theta, n, ldb, n_gauss,
+                            flags, (double*)t->occupation.ptr);
+    if (status != TC_OK) return status;
+    TC_HIP(hipMemcpyAsync(occupation + begin * t->n_bins, t->occupation.ptr,
+                          occ_bytes, hipMemcpyDeviceToHost, t->stream));
+    TC_HIP(hipStreamSynchronize(t->stream));
+  }
+  return TC_OK;
+}
+
+int tc_predict_occupation_batch(tc_table* t, const double* occupation,
+                                int64_t n_draws, unsigned flags, double* ngal,
+                                double* xi) {
+  TC_CHECK(t != nullptr, "table handle is NULL");
+  TC_CHECK(n_draws >= 0, "n_draws must be non-negative");
+  if (n_draws == 0) return TC_OK;
+  TC_CHECK(occupation && ngal && xi, "NULL array");
+  TC_HIP(hipSetDevice(t->device));
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  const int n_comp = separate ? t->plan.n_components : 1;
+  for (int64_t begin = 0; begin < n_draws; begin += kMaxSlab) {
+    const int64_t n = std::min(kMaxSlab, n_draws - begin);
+    const int64_t ldb = (n + 63) / 64 * 64;
+    const size_t occ_bytes = (size_t)n * t->n_bins * 8;
+    const size_t ngal_count = (size_t)n * (separate ? 2 : 1);
+    const size_t xi_count = (size_t)n * n_comp * t->n_r;
+    int status = t->occupation.reserve(occ_bytes, t->stream);
+    if (status == TC_OK)
+      status = t->lanes[0].nbuf.reserve((size_t)t->n_bins * ldb * 8, t->stream);
+    if (status == TC_OK)
+      status = t->lanes[0].ngal2.reserve(2 * ldb * 8, t->stream);
+    if (status == TC_OK) status = t->out_ngal.reserve(ngal_count * 8, t->stream);
+    if (status == TC_OK) status = t->out_xi.reserve(xi_count * 8, t->stream);
+    if (status != TC_OK) return status;
+    status = copy_in(&t->h_in, t->occupation.ptr, occupation + begin * t->n_bins,
+                     occ_bytes, t->stream);
+    if (status != TC_OK) return status;
+    status = launch_occ_from_array(t, (const double*)t->occupation.ptr, n, ldb,
+                                   (double*)t->lanes[0].nbuf.ptr,
+                                   (double*)t->lanes[0].ngal2.ptr, t->stream);
+    if (status != TC_OK) return status;
+    t->cur = 0;
+    t->lanes[0].ngal_parts = 1;
+    status = run_contraction(t, n, ldb, flags, (double*)t->out_ngal.ptr,
+                             (double*)t->out_xi.ptr);
+    if (status != TC_OK) return status;
+    status = copy_out(&t->h_out, ngal + begin * (separate ? 2 : 1), ngal_count,
+                      t->out_ngal.ptr, xi + begin * n_comp * t->n_r, xi_count,
+                      t->out_xi.ptr, t->stream);
+    if (status != TC_OK) return status;
+  }
+  return TC_OK;
+}
+
+int tc_table_timer_begin(tc_table* t, int profile_kernels) {
+  TC_CHECK(t != nullptr, "table handle is NULL");
+  TC_HIP(hipSetDevice(t->device));
+  t->profile_kernels = profile_kernels != 0;
+  t->kernel_events_used = 0;
+  TC_HIP(hipEventRecord(t->ev_begin, t->stream));
+  return TC_OK;
+}
+
+int tc_table_timer_end(tc_table* t, float* elapsed_ms) {
+  TC_CHECK(t != nullptr && elapsed_ms != nullptr, "NULL argument");
+  for (int l = 1; l < tc_table::kMaxLanes; ++l)
+    TC_HIP(hipStreamSynchronize(t->lanes[l].stream));
+  TC_HIP(hipEventRecord(t->ev_end, t->stream));
+  TC_HIP(hipEventSynchronize(t->ev_end));
+  TC_HIP(hipEventElapsedTime(elapsed_ms, t->ev_begin, t->ev_end));
+  t->profile_kernels = false;
+  return TC_OK;
+}
+
+int tc_table_kernel_time(tc_table* t, int* n_launches, float* mean_ms) {
+  TC_CHECK(t != nullptr && n_launches && mean_ms, "NULL argument");
+  double total = 0.0;
+  for (size_t i = 0; i < t->kernel_events_used; ++i) {
+    float ms = 0.0f;
+    TC_HIP(hipEventSynchronize(t->kernel_events[i].second));
+    TC_HIP(hipEventElapsedTime(&ms, t->kernel_events[i].first,
+                               t->kernel_events[i].second));
+    total += ms;
+  }
+  *n_launches = (int)t->kernel_events_used;
+  *mean_ms = t->kernel_events_used ? (float)(total / t->kernel_events_used) : 0.0f;
+  return TC_OK;
+}
+
+int tc_debug_trace(tc_table* t, uint64_t* out, int64_t capacity, int64_t* n_blocks) {
+  TC_CHECK(t != nullptr && n_blocks != nullptr, "NULL argument");
+  *n_blocks = (int64_t)t->trace_blocks;
+  if (out == nullptr || t->trace.ptr == nullptr) return TC_OK;
+  for (tc_table::Lane& lane : t->lanes) TC_HIP(hipStreamSynchronize(lane.stream));
+  const int64_t n = std::min<int64_t>(capacity, (int64_t)t->trace_blocks);
+  TC_HIP(hipMemcpy(out, t->trace.ptr, (size_t)n * 6 * sizeof(uint64_t),
+                   hipMemcpyDeviceToHost));
+  return TC_OK;
+}
+
+int tc_debug_wave_trace(tc_table* t, uint64_t* out, int64_t capacity, int64_t* n_waves) {
+  TC_CHECK(t != nullptr && n_waves != nullptr, "NULL argument");
+  *n_waves = (int64_t)t->wave_trace_count;
+  if (out == nullptr || t->wave_trace.ptr == nullptr) return TC_OK;
+  for (tc_table::Lane& lane : t->lanes) TC_HIP(hipStreamSynchronize(lane.stream));
+  const int64_t n = std::min<int64_t>(capacity, (int64_t)t->wave_trace_count);
+  TC_HIP(hipMemcpy(out, t->wave_trace.ptr, (size_t)n * 6 * sizeof(uint64_t),
+                   hipMemcpyDeviceToHost));
+  return TC_OK;
+}
+
+int tc_table_last_launch(const tc_table* t, int* n_workgroups, int* waves,
+                         int* n_splits, int* lds_bytes) {
+  TC_CHECK(t != nullptr, "table handle is NULL");
+  if (n_workgroups) *n_workgroups = t->last_workgroups;
+  if (waves) *waves = t->last_waves;
+  if (n_splits) *n_splits = t->last_splits;
+  if (lds_bytes) *lds_bytes = t->last_lds;
+  return TC_OK;
+}
+
+}  // extern "C"
