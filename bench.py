@@ -65,6 +65,8 @@ def main():
                         help='multi-GPU: steps per RCCL gather of the results')
     parser.add_argument('--cpu-seconds', type=float, default=12.0,
                         help='budget of the CPU baseline sample (0: skip)')
+    parser.add_argument('--cpu-all-cores', type=int, default=1,
+                        help='also time one independent CPU walker per host core')
     args = parser.parse_args()
 
     from tabcorr_amd import TabCorr, synthetic, _lib
@@ -76,6 +78,11 @@ def main():
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run '
                      '--nproc-per-node %d' % (args.gpus, args.gpus))
         sys.exit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world_size))
+    # The all-cores CPU baseline forks its workers, so it runs before this process
+    # touches the GPU.
+    cpu_all = None
+    if world_size == 1 and args.cpu_seconds > 0 and args.cpu_all_cores:
+        cpu_all = cpu_baseline_all_cores(args.cpu_seconds / 2)
     lib = _lib.load()
     _lib.require_device()
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -262,6 +269,8 @@ def main():
             result['config']['rccl_error'] = comm.rccl_error
         if comm.world_size == 1 and args.cpu_seconds > 0:
             result['cpu_baseline'] = cpu_baseline(table, args.cpu_seconds)
+            if cpu_all is not None:
+                result['cpu_baseline']['all_cores'] = cpu_all
         print(json.dumps(result), flush=True)
 
     for ptr in (d_theta, d_out, d_recv):
@@ -291,6 +300,37 @@ def cpu_baseline(table, seconds):
     return {'value': count / spent, 'unit': 'calls/s', 'cores': 1, 'kind': 'port',
             'sample': '%d sequential predict() calls of the same workload (same '
                       'table, draws from the same prior) in %.1f s' % (count, spent)}
+
+
+def _cpu_walker(job):
+    """One independent MCMC-style walker: sequential predict() calls for `seconds`."""
+    seed, seconds = job
+    from oracle import tabcorr_oracle as oracle
+    from tabcorr_amd import synthetic
+    table = synthetic.synthetic_table(N_PRIM, N_SEC, (N_R, ), 'auto', seed=0)
+    theta = synthetic.zheng07_draws(100000, seed=seed)
+    cache = {}
+    oracle.predict_zheng07(table, theta[0], cache=cache)
+    start = time.perf_counter()
+    count = 0
+    while time.perf_counter() - start < seconds and count < len(theta):
+        for t in theta[count:count + 100]:
+            oracle.predict_zheng07(table, t, cache=cache)
+        count += 100
+    return count, time.perf_counter() - start
+
+
+def cpu_baseline_all_cores(seconds):
+    """predict() is single-threaded in the reference, so "all host
+    cores" means one independent walker process per core."""
+    import multiprocessing
+    cores = min(len(os.sched_getaffinity(0)), 256)
+    with multiprocessing.get_context('fork').Pool(cores) as pool:
+        done = pool.map(_cpu_walker, [(1000 + i, seconds) for i in range(cores)])
+    return {'value': sum(count / spent for count, spent in done), 'unit': 'calls/s',
+            'cores': cores, 'kind': 'port',
+            'sample': '%d walker processes x %.1f s of sequential predict() calls'
+                      % (cores, seconds)}
 
 
 if __name__ == '__main__':

@@ -83,7 +83,8 @@ int tc_gauss_legendre(int n, double* x, double* w);
 int tc_pair_indices(int n_bins, int32_t* index_1, int32_t* index_2, int32_t* prefactor);
 
 /* Host evaluation of the table-driven FP64 functions the occupation kernel uses in place
- * of the device libm (tabcorr_amd/csrc/fastmath.h): kind 0 erf, 1 log (x > 0), 2 exp. */
+ * of the device libm (tabcorr_amd/csrc/fastmath.h): kind 0 erf, 1 log2 (x > 0 normal),
+ * 2 exp2, 3 exp10. */
 int tc_debug_fastmath(int kind, int64_t n, const double* x, double* y);
 
 /* Not-a-knot cubic spline matrix a[(n-1)][4][n] of interpolator.py:219-272. */

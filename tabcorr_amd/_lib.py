@@ -126,7 +126,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIBRARY):
+    # developer A/B runs: TABCORR_AMD_LIBRARY points at another build of the library
+    library = os.environ.get('TABCORR_AMD_LIBRARY') or LIBRARY
+    if not os.path.exists(library):
         raise TabCorrHipError(
             'libtabcorr_hip.so is missing: build it with '
             '`python -m tabcorr_amd.build` (needs hipcc). There is no CPU '
@@ -135,7 +137,7 @@ def load():
     # against even when another copy (e.g. the one bundled with PyTorch) is
     # already in the process.
     mode = os.RTLD_NOW | os.RTLD_LOCAL | getattr(os, 'RTLD_DEEPBIND', 0)
-    lib = ctypes.CDLL(LIBRARY, mode=mode)
+    lib = ctypes.CDLL(library, mode=mode)
     lib.tc_last_error.restype = ctypes.c_char_p
     lib.tc_last_error.argtypes = []
     for name, argtypes in SIGNATURES.items():

@@ -138,29 +138,17 @@ namespace fm {
 void build_tables(double* table) {
   const long double two_over_sqrt_pi = 1.128379167095512573896158903121545172L;
   for (int i = 0; i < kErfRows; ++i) {
-    const long double c = i / 32.0L;
-    double* row = table + kErfOffset + i * kErfStride;
-    // Taylor coefficients of erf around c: erf^(n)(c) / n!
-    const long double g = two_over_sqrt_pi * expl(-c * c);
-    long double h_prev = 0.0L, h_cur = 1.0L;     // H_{-1} (unused), H_0
-    long double factorial = 1.0L;
-    row[0] = (double)erfl(c);
-    for (int n = 1; n <= 7; ++n) {
-      factorial *= n;
-      // erf^(n) = g (-1)^(n-1) H_{n-1}(c)
-      const long double sign = ((n - 1) % 2 == 0) ? 1.0L : -1.0L;
-      row[n] = (double)(g * sign * h_cur / factorial);
-      const long double h_next = 2.0L * c * h_cur - 2.0L * (n - 1) * h_prev;
-      h_prev = h_cur;
-      h_cur = h_next;
-    }
-    row[8] = row[9] = 0.0;
+    const long double c = i / 128.0L;
+    table[kErfOffset + 2 * i] = (double)erfl(c);
+    table[kErfOffset + 2 * i + 1] = (double)(two_over_sqrt_pi * expl(-c * c));
   }
   for (int i = 0; i < kLogRows; ++i) {
-    const long double c = 0.5L + (i + 0.5L) / 512.0L;
-    const double inv = (double)(1.0L / c);
+    const long double c = 1.0L + (i + 0.5L) / 256.0L;
+    // 2 / c: the mantissa comes as m in [0.5, 1)
+    const double inv = (double)(2.0L / c);
     table[kLogOffset + 2 * i] = inv;
-    table[kLogOffset + 2 * i + 1] = (double)(-logl((long double)inv));
+    // log2 of the reciprocal actually stored, so that r = m * inv - 1 is consistent
+    table[kLogOffset + 2 * i + 1] = (double)(1.0L - log2l((long double)inv));
   }
   for (int j = 0; j < kExpRows; ++j)
     table[kExpOffset + j] = (double)exp2l(j / 256.0L);

@@ -27,6 +27,8 @@ struct OccArgs {
   int n_bins;
   int n_central;
   int n_gauss;
+  int n_tiles;             // draw tiles (ldb / 64)
+  int n_splits;            // bin ranges per draw tile
   unsigned flags;
   double split;
   const double* log_m;     // (n_bins, n_gauss) log10 of the node masses

@@ -41,36 +41,35 @@ __device__ inline double heaviside_assembias(double n, double strength,
 
 // Mean occupation of every bin for every draw: tabcorr/tabcorr.py:537-578 with
 // the two halotools callbacks of :556-563 evaluated inline (Zheng et al. 2007
-// eqs. 1 and 3).  grid = (draw tiles, bin splits); the kOccWaves waves of a
-// block share one draw tile and interleave over the bins of their split.  The
-// block's centrals / satellites density sums go to ngal_part[split][2][ldb].
+// eqs. 1 and 3).  Work items = (draw tile, bin split); the kOccWaves waves of a
+// block share an item's draw tile and interleave over the bins of its split, and
+// the blocks stride over the items (the math tables are staged once per block).
+// An item's centrals / satellites density sums go to ngal_part[split][2][ldb].
 
 // NGAUSS > 0: n_gauss known at compile time, node loop fully unrolled (the scalar loads
 // of a bin's constants are batched and the independent polynomial chains interleave);
 // NGAUSS == 0: any n_gauss.
-template <int NGAUSS, bool ASSEMBIAS>
+template <int NGAUSS, bool ASSEMBIAS, bool MODULATE>
 __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     OccArgs a) {
   __shared__ double red[2][kOccWaves][kLanes];
+  __shared__ double prm[8][kLanes];
   __shared__ __attribute__((aligned(16))) double table[fm::kTableDoubles];
+  const fm::Consts kc = fm::make_consts();
   // short kernel on the critical path of its lane: run ahead of the contraction waves
   // of neighbouring batches it shares the CUs with
   __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t b0 = (int64_t)blockIdx.x * kLanes + lane;
-  const int64_t b = b0 < a.n_draws ? b0 : a.n_draws - 1;
   const int n_gauss = NGAUSS > 0 ? NGAUSS : a.n_gauss;
-
-  // bins of this block: a contiguous range, so that most blocks are all-centrals or
-  // all-satellites and stage only the tables they need
-  const int per_block = (a.n_bins + gridDim.y - 1) / gridDim.y;
-  const int g_begin = blockIdx.y * per_block;
-  const int g_end = g_begin + per_block < a.n_bins ? g_begin + per_block : a.n_bins;
+  const int n_items = a.n_tiles * a.n_splits;
+  const int per_block = (a.n_bins + a.n_splits - 1) / a.n_splits;
   {
     typedef double __attribute__((ext_vector_type(2))) double2v;
-    // the exp table is always needed (10^logM0, 10^logM1)
-    const bool need_erf = g_begin < a.n_central || (a.flags & kFlagModulate);
+    // a block with a single all-satellites item does not need the erf rows (the exp2
+    // table is always needed: 10^logM0)
+    const bool need_erf = (int)gridDim.x < n_items || MODULATE ||
+                          ((int)blockIdx.x / a.n_tiles) * per_block < a.n_central;
     const int lo = need_erf ? 0 : fm::kLogOffset / 2;
     const int hi = fm::kTableDoubles / 2;
     const double2v* src = (const double2v*)a.math_table;
@@ -85,21 +84,7 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     }
     for (; i < hi; i += blockDim.x) dst[i] = src[i];
   }
-  const double* th = a.theta + b * a.n_theta;
-  const double log_m_min = th[0];
-  const double inv_sigma = 1.0 / th[1];
-  const double log_m0 = th[2], log_m1 = th[3];
-  const double alpha = th[4];
-  constexpr bool assembias = ASSEMBIAS;
-  const bool modulate = (a.flags & kFlagModulate) != 0;
-  const double a_cen = assembias ? th[5] : 0.0;
-  const double a_sat = assembias ? th[6] : 0.0;
-  const double f1 = (1.0 - a.split) / a.split, f2 = a.split / (1.0 - a.split);
-  // (f1 = f1/f2 and f2 = f2/f1 of Hearin et al.'s population fractions)
   __syncthreads();
-  constexpr double kLn10 = 2.302585092994045684;
-  const double m0 = fm::exp_fast(table, log_m0 * kLn10);
-  const double inv_m1 = fm::exp_fast(table, -log_m1 * kLn10);
 
   sc_f64 log_m = (sc_f64)a.log_m;
   sc_f64 mass = (sc_f64)a.m;
@@ -107,51 +92,95 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
   sc_f64 n_h = (sc_f64)a.n_h;
   sc_f64 percentile = (sc_f64)a.percentile;
   sc_i32 perm = (sc_i32)a.perm;
+  constexpr bool assembias = ASSEMBIAS;
+  constexpr bool modulate = MODULATE;
+  const double f1 = (1.0 - a.split) / a.split, f2 = a.split / (1.0 - a.split);
+  // (f1 = f1/f2 and f2 = f2/f1 of Hearin et al.'s population fractions)
 
-  double sum_cen = 0.0, sum_sat = 0.0;
-  for (int g = g_begin + wave; g < g_end; g += kOccWaves) {
-    const bool central = g < a.n_central;
-    const bool above = percentile[g] > a.split;
-    double acc = 0.0;
-    if (central) {
-#pragma unroll
-      for (int k = 0; k < n_gauss; ++k) {
-        const double lm = log_m[g * n_gauss + k];
-        double n = fma(0.5, fm::erf_fast(table, (lm - log_m_min) * inv_sigma), 0.5);
-        if (assembias) n = heaviside_assembias(n, a_cen, above, f2, f1, true);
-        acc = fma(weight[g * n_gauss + k], n, acc);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < n_gauss; ++k) {
-        const double x = (mass[g * n_gauss + k] - m0) * inv_m1;
-        // ((M - M0) / M1)^alpha = exp(alpha log x); 1e-300 keeps log_fast's input a
-        // positive normal number on the lanes that are masked out anyway
-        double n = fm::exp_fast(table, alpha * fm::log_fast(table, x > 1e-300 ? x : 1e-300));
-        n = x > 0.0 ? n : 0.0;
-        if (modulate) {
-          const double lm = log_m[g * n_gauss + k];
-          n *= fma(0.5, fm::erf_fast(table, (lm - log_m_min) * inv_sigma), 0.5);
-        }
-        if (assembias) n = heaviside_assembias(n, a_sat, above, f2, f1, false);
-        acc = fma(weight[g * n_gauss + k], n, acc);
-      }
+  // items = (draw tile, bin split): a contiguous range of bins, so that most items are
+  // all-centrals or all-satellites; the blocks stride over the items
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int tile = item % a.n_tiles, split = item / a.n_tiles;
+    const int64_t b0 = (int64_t)tile * kLanes + lane;
+    const int64_t b = b0 < a.n_draws ? b0 : a.n_draws - 1;
+    const int g_begin = split * per_block;
+    const int g_end = g_begin + per_block < a.n_bins ? g_begin + per_block : a.n_bins;
+    // per-draw quantities: computed by wave 0, shared with the other waves through LDS
+    if (wave == 0) {
+      const double* th = a.theta + b * a.n_theta;
+      const double log_m1 = th[3], alpha_0 = th[4];
+      // ((M - M0) / M1)^alpha = 2^(alpha (log2(M - M0) - log2 M1)); log2 M1 is carried
+      // in two parts, the low one applied to the finished bin sum as 2^(-alpha lo)
+      const double hi = log_m1 * fm::kLog2Of10Hi;
+      const double lo = fma(log_m1, fm::kLog2Of10Hi, -hi) + log_m1 * fm::kLog2Of10Lo;
+      prm[0][lane] = th[0];
+      prm[1][lane] = 1.0 / th[1];
+      prm[2][lane] = fm::exp10_fast(table, kc, th[2]);
+      prm[3][lane] = hi;
+      prm[4][lane] = fma(-alpha_0 * fm::kLn2, lo, 1.0);
+      prm[5][lane] = alpha_0;
+      prm[6][lane] = assembias ? th[5] : 0.0;
+      prm[7][lane] = assembias ? th[6] : 0.0;
     }
-    if (a.occupation != nullptr && b0 < a.n_draws)
-      a.occupation[b0 * a.n_bins + perm[g]] = acc;
-    const double dens = acc * n_h[g];
-    a.nbuf[(int64_t)g * a.ldb + (int64_t)blockIdx.x * kLanes + lane] = dens;
-    if (central) sum_cen += dens; else sum_sat += dens;
-  }
-  red[0][wave][lane] = sum_cen;
-  red[1][wave][lane] = sum_sat;
-  __syncthreads();
-  if (wave < 2) {
-    double total = 0.0;
+    __syncthreads();
+    const double log_m_min = prm[0][lane];
+    const double inv_sigma = prm[1][lane];
+    const double m0 = prm[2][lane];
+    const double log2_m1 = prm[3][lane];
+    const double sat_scale = prm[4][lane];
+    const double alpha = prm[5][lane];
+    const double a_cen = assembias ? prm[6][lane] : 0.0;
+    const double a_sat = assembias ? prm[7][lane] : 0.0;
+
+    double sum_cen = 0.0, sum_sat = 0.0;
+    for (int g = g_begin + wave; g < g_end; g += kOccWaves) {
+      const bool central = g < a.n_central;
+      const bool above = percentile[g] > a.split;
+      double acc = 0.0;
+      if (central) {
 #pragma unroll
-    for (int w = 0; w < kOccWaves; ++w) total += red[wave][w][lane];
-    a.ngal[((int64_t)blockIdx.y * 2 + wave) * a.ldb +
-           (int64_t)blockIdx.x * kLanes + lane] = total;
+        for (int k = 0; k < n_gauss; ++k) {
+          const double lm = log_m[g * n_gauss + k];
+          double n = fma(0.5, fm::erf_fast(table, kc, (lm - log_m_min) * inv_sigma), 0.5);
+          if (assembias) n = heaviside_assembias(n, a_cen, above, f2, f1, true);
+          acc = fma(weight[g * n_gauss + k], n, acc);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < n_gauss; ++k) {
+          const double x = mass[g * n_gauss + k] - m0;
+          // 1e-300 keeps log2's input a positive normal number on the lanes with
+          // M <= M0, whose result the scaling step of exp2 then sets to exactly 0
+          double n = fm::exp2_fast(
+              table, kc,
+              alpha * fm::log2_fast_offset(table, kc, x > 1e-300 ? x : 1e-300, log2_m1),
+              x > 0.0);
+          if (assembias) n *= sat_scale;   // (the Heaviside decoration is not linear)
+          if (modulate) {
+            const double lm = log_m[g * n_gauss + k];
+            n *= fma(0.5, fm::erf_fast(table, kc, (lm - log_m_min) * inv_sigma), 0.5);
+          }
+          if (assembias) n = heaviside_assembias(n, a_sat, above, f2, f1, false);
+          acc = fma(weight[g * n_gauss + k], n, acc);
+        }
+        if (!assembias) acc *= sat_scale;
+      }
+      if (a.occupation != nullptr && b0 < a.n_draws)
+        a.occupation[b0 * a.n_bins + perm[g]] = acc;
+      const double dens = acc * n_h[g];
+      a.nbuf[(int64_t)g * a.ldb + (int64_t)tile * kLanes + lane] = dens;
+      if (central) sum_cen += dens; else sum_sat += dens;
+    }
+    red[0][wave][lane] = sum_cen;
+    red[1][wave][lane] = sum_sat;
+    __syncthreads();
+    if (wave < 2) {
+      double total = 0.0;
+#pragma unroll
+      for (int w = 0; w < kOccWaves; ++w) total += red[wave][w][lane];
+      a.ngal[((int64_t)split * 2 + wave) * a.ldb + (int64_t)tile * kLanes + lane] = total;
+    }
+    __syncthreads();
   }
 }
 

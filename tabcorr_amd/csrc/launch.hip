@@ -311,6 +311,9 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   // (host-buffer calls synchronise before returning and need no chaining)
   if (t->prev >= 0 && t->prev != t->cur)
     TC_HIP(hipStreamWaitEvent(stream, t->lanes[t->prev].finished, 0));
+#ifdef TC_DEVELOPER_KNOBS
+  if (!env_int("TC_SKIP_FINALIZE", 0))
+#endif
   status = launch_finalize(fa, stream);
   if (status != TC_OK) return status;
   if (t->force_lane >= 0) {
@@ -333,12 +336,39 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   Quadrature* q = nullptr;
   int status = get_quadrature(t, n_gauss, &q);
   if (status != TC_OK) return status;
-  // enough blocks to fill the chip: split the bins when there are few draw tiles
+  // Work items = (draw tile, range of bins); blocks of kOccWaves waves stride over them,
+  // four per CU at most.  Pick the number of bin ranges that minimises rounds x (bins per
+  // wave per item + per-item overhead): few, long items once the chip is covered (the
+  // per-draw setup, the table staging and the block-level sums are per item; measured
+  // optimum for 157 tiles x 100 bins: 5-7 ranges), many short ones for small batches.
   const int64_t n_tiles = ldb / 64;
-  int splits = (int)std::min<int64_t>(
-      (t->n_bins + tc::kOccWaves - 1) / tc::kOccWaves,
-      std::max<int64_t>(1, env_int("TC_OCC_BLOCKS", 2048) / n_tiles));
-  splits = std::max(1, splits);
+  int splits = 1, grid_blocks = 1;
+  {
+    const int n_cus = 256;
+    const int64_t slots = (int64_t)n_cus * 4;
+    const int max_splits = (t->n_bins + tc::kOccWaves - 1) / tc::kOccWaves;
+    double best = 0.0;
+    for (int trial = 1; trial <= max_splits; ++trial) {
+      const int per_block = (t->n_bins + trial - 1) / trial;
+      if ((t->n_bins + per_block - 1) / per_block != trial) continue;
+      const int64_t items = n_tiles * trial;
+      const int64_t rounds = (items + slots - 1) / slots;
+      const int bins_per_wave = (per_block + tc::kOccWaves - 1) / tc::kOccWaves;
+      const double cost = (double)rounds * (bins_per_wave + 1.5);
+      if (best == 0.0 || cost < best) {
+        best = cost;
+        splits = trial;
+        grid_blocks = (int)std::min<int64_t>(items, slots);
+      }
+    }
+    const int forced = env_int("TC_OCC_SPLITS", 0);
+    if (forced > 0) {
+      const int per_block = (t->n_bins + forced - 1) / forced;
+      splits = (t->n_bins + per_block - 1) / per_block;
+      grid_blocks = (int)std::min<int64_t>(
+          n_tiles * splits, (int64_t)n_cus * std::max(1, env_int("TC_OCC_PER_CU", 4)));
+    }
+  }
   status = nbuf->reserve((size_t)t->n_bins * ldb * sizeof(double), stream);
   if (status == TC_OK)
     status = ngal2->reserve((size_t)splits * 2 * ldb * sizeof(double), stream);
@@ -352,6 +382,8 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   oa.n_bins = t->n_bins;
   oa.n_central = t->plan.n_central;
   oa.n_gauss = n_gauss;
+  oa.n_tiles = (int)n_tiles;
+  oa.n_splits = splits;
   oa.flags = flags;
   oa.split = 0.5;
   oa.log_m = (const double*)q->log_m;
@@ -365,16 +397,28 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   oa.ngal = (double*)ngal2->ptr;
   oa.occupation = occupation_device;
   {
-    const dim3 grid((unsigned)(ldb / 64), (unsigned)splits), block(tc::kOccWaves * 64);
+    const dim3 grid((unsigned)grid_blocks), block(tc::kOccWaves * 64);
     const bool assembias = (flags & TC_FLAG_ASSEMBIAS) != 0;
-    if (n_gauss == 10 && !assembias)
-      hipLaunchKernelGGL((tc::occ_zheng07_kernel<10, false>), grid, block, 0, stream, oa);
-    else if (n_gauss == 10)
-      hipLaunchKernelGGL((tc::occ_zheng07_kernel<10, true>), grid, block, 0, stream, oa);
-    else if (!assembias)
-      hipLaunchKernelGGL((tc::occ_zheng07_kernel<0, false>), grid, block, 0, stream, oa);
-    else
-      hipLaunchKernelGGL((tc::occ_zheng07_kernel<0, true>), grid, block, 0, stream, oa);
+    const bool modulate = (flags & TC_FLAG_MODULATE_WITH_CENOCC) != 0;
+#define TC_OCC(NG, AB, MO)                                                           \
+  hipLaunchKernelGGL((tc::occ_zheng07_kernel<NG, AB, MO>), grid, block, 0, stream, oa)
+#ifdef TC_DEVELOPER_KNOBS
+    // diagnosis only (tools/ab.sh): reuse the densities of the previous call
+    static int occ_calls = 0;
+    if (env_int("TC_SKIP_OCC", 0) && ++occ_calls > 8) return TC_OK;
+#endif
+    if (n_gauss == 10) {
+      if (!assembias && !modulate) TC_OCC(10, false, false);
+      else if (!assembias) TC_OCC(10, false, true);
+      else if (!modulate) TC_OCC(10, true, false);
+      else TC_OCC(10, true, true);
+    } else {
+      if (!assembias && !modulate) TC_OCC(0, false, false);
+      else if (!assembias) TC_OCC(0, false, true);
+      else if (!modulate) TC_OCC(0, true, false);
+      else TC_OCC(0, true, true);
+    }
+#undef TC_OCC
   }
   TC_HIP(hipGetLastError());
   return TC_OK;

@@ -106,16 +106,18 @@ int tc_gauss_legendre(int n, double* x, double* w) {
 }
 
 int tc_debug_fastmath(int kind, int64_t n, const double* x, double* y) {
-  TC_CHECK(kind >= 0 && kind <= 2 && n >= 0 && x && y, "invalid arguments");
+  TC_CHECK(kind >= 0 && kind <= 3 && n >= 0 && x && y, "invalid arguments");
   static std::vector<double> table;
   if (table.empty()) {
     table.resize(tc::fm::kTableDoubles);
     tc::fm::build_tables(table.data());
   }
+  const tc::fm::Consts k = tc::fm::make_consts();
   for (int64_t i = 0; i < n; ++i) {
-    if (kind == 0) y[i] = tc::fm::erf_fast(table.data(), x[i]);
-    if (kind == 1) y[i] = tc::fm::log_fast(table.data(), x[i]);
-    if (kind == 2) y[i] = tc::fm::exp_fast(table.data(), x[i]);
+    if (kind == 0) y[i] = tc::fm::erf_fast(table.data(), k, x[i]);
+    if (kind == 1) y[i] = tc::fm::log2_fast(table.data(), k, x[i]);
+    if (kind == 2) y[i] = tc::fm::exp2_fast(table.data(), k, x[i]);
+    if (kind == 3) y[i] = tc::fm::exp10_fast(table.data(), k, x[i]);
   }
   return TC_OK;
 }

@@ -368,3 +368,35 @@ def test_read_reference_interpolator_file_and_round_trip(tmp_path):
     npz = str(tmp_path / 'interp.npz')
     interp.write(npz)
     assert np.array_equal(Interpolator.read(npz).points, interp.points)
+
+
+def test_fastmath_accuracy_on_host():
+    """The table-driven erf / log2 / exp2 / exp10 of the occupation kernel (same inline
+    code on the host) against scipy / numpy."""
+    import ctypes
+    from scipy import special
+    from tabcorr_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+
+    def run(kind, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        _lib.check(lib.tc_debug_fastmath(
+            kind, x.size, x.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+            y.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        return y
+
+    x = np.concatenate([rng.uniform(-7, 7, 200000), np.arange(0, 769) / 128.0,
+                        (np.arange(0, 768) + 0.5) / 128.0, [0.0, -0.0, 1e-300, 50.0, -50.0]])
+    assert np.max(np.abs(run(0, x) - special.erf(x))) < 4e-16
+    y = np.concatenate([10**rng.uniform(-290, 290, 100000), rng.uniform(0.5, 2.0, 100000),
+                        1.0 + np.arange(257) / 256.0, [1.0, 2.0, 0.5, 1e-300]])
+    expect = np.log2(y)
+    assert np.max(np.abs(run(1, y) - expect) / np.maximum(1.0, np.abs(expect))) < 4e-16
+    z = np.concatenate([rng.uniform(-900, 900, 200000), rng.uniform(-1, 1, 50000),
+                        np.arange(-512, 512) / 256.0])
+    assert np.max(np.abs(run(2, z) / np.exp2(z) - 1.0)) < 4e-16
+    assert run(2, np.array([-5000.0]))[0] < 1e-300
+    w = rng.uniform(9.0, 16.0, 100000)
+    assert np.max(np.abs(run(3, w) / 10.0**w - 1.0)) < 6e-16

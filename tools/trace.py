@@ -62,3 +62,19 @@ order = np.argsort(ts[:, 4])
 for frac in [0.1, 0.3, 0.5, 0.7, 0.9, 1.0]:
     k = order[int(frac * (len(order) - 1))]
     print('wave finishing at %5.1f us: start %.1f quarters %s' % (ts[k, 4], ts[k, 0], np.round(q[k], 1)))
+
+# ---- wave placement: how many waves of the launch share each SIMD ---------------------
+w_all = np.zeros((nw.value, 6), dtype=np.uint64)
+_lib.check(dev.lib.tc_debug_wave_trace(dev.handle, w_all.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), nw.value, ctypes.byref(nw)))
+waves_per_block = nw.value // n.value
+valid = w_all[:, 0] > 0
+block_of = np.arange(nw.value) // waves_per_block
+hw_w = w_all[:, 5].astype(np.int64)
+key = (xcc[block_of] * 100000 + ((hw_w >> 13) & 7) * 10000 + ((hw_w >> 12) & 1) * 1000 +
+       ((hw_w >> 8) & 0xf) * 10 + ((hw_w >> 4) & 3))[valid]
+simds, inverse, per_simd = np.unique(key, return_inverse=True, return_counts=True)
+print('SIMDs used', len(simds), 'waves per SIMD histogram', np.bincount(per_simd))
+finish = (w_all[valid, 4].astype(np.int64) - int(t0)) / 100.0
+for count in np.unique(per_simd):
+    sel = per_simd[inverse] == count
+    print('  waves on SIMDs holding %d: finish median %.1f us (n=%d)' % (count, np.median(finish[sel]), sel.sum()))
