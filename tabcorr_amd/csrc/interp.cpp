@@ -139,6 +139,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   ca.trace = nullptr;
   ca.wave_trace = nullptr;
   ca.pos_ij = nullptr;
+  ca.pos_off = (const int32_t*)t0->d_pos_off;
   ca.partial = (double*)it->partial.ptr;
   ca.n_tables = it->n_tables;
   ca.k_splits = k_splits;
@@ -200,7 +201,7 @@ int tc_interp_create(tc_table* const* tables, int n_tables, int n_dim,
     if (t->compute_dtype != TC_DTYPE_F64)
       return fail(TC_ERR_UNSUPPORTED, "interpolation of float32 tables is not built");
     TC_CHECK(t->mode == t0->mode && t->n_bins == t0->n_bins && t->n_r == t0->n_r &&
-                 t->plan.perm == t0->plan.perm,
+                 t->plan.perm == t0->plan.perm && t->f64_mfma == t0->f64_mfma,
              "table %d differs from table 0 in mode, shape or gal_type layout", k);
   }
   // abscissae: sorted unique values per dimension (interpolator.py:41-43)

@@ -56,6 +56,7 @@ struct ContractArgs {
   int n_tiles;              // draw tiles (grid.x covers 8 * ceil(n_tiles / 8) * slabs)
   int n_slabs;              // groups * table splits per draw tile
   const int32_t* pos_ij;    // float32 kernel: packed bin pairs of every position
+  const int32_t* pos_off;   // FP64 matrix kernel: (i, j) * 512 (LDS row bytes) per position
   unsigned long long* trace;  // developer timeline (TC_TRACE): 6 words per block, or NULL
   unsigned long long* wave_trace;  // TC_TRACE: 6 words per wave (progress stamps)
   double* partial;          // (n_groups * k_splits, r_stride, ldb)

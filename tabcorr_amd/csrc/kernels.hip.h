@@ -479,6 +479,259 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
   }
 }
 
+// ---- FP64 matrix-core contraction -----------------------------------------------------
+//
+// Same decomposition, staging, reduction and output as contract_kernel, but the inner
+// product runs on v_mfma_f64_4x4x4_4b_f64: 4 blocks of D(4x4) += A(4x4) B(4x4).  The FP64
+// matrix rate equals the FP64 vector rate on gfx950, but the vector FMAs are power
+// throttled under sustained load (tools/micro/sustained.hip: 63-67 TFLOP/s against 75
+// for this instruction), and the matrix form needs a fifth of the vector work around it.
+//
+// Operand mapping (probed with tools/micro/mfma_map.hip): lane l holds A[i][k] and
+// B[k][j] with i or j = l % 4, block = (l / 4) % 4, k = l / 16, and D[i][j] with
+// j = l % 4, block = (l / 4) % 4, i = l / 16.  One instruction covers 4 consecutive
+// table positions (k), 4 r values (i) and 16 draws (block, j):
+//   A (per r sub-tile u): T[position q0 + l / 16][r = 4 u + l % 4], the same in all blocks;
+//     table layout [q0 / 8][u][k][i][step parity]: one 16-byte load per lane serves two
+//     consecutive steps;
+//   B (per draw set s): w[draw 16 s + l % 16][position q0 + l / 16] = n_i n_j, formed from
+//     two LDS gathers per set at row offsets the lane gets from pos_off[q0 + l / 16];
+//   D (per set s and sub-tile u): draw 16 s + l % 16, r = 4 u + l / 16.
+// Per 4 positions: (RT / 4 + 1) / 2 vector loads, 8 LDS reads (4 ds_read2_b64), 4 v_mul_f64
+// and RT MFMAs -- against 4 * (RT + 1) vector instructions and RT / 4 loads.
+template <int RT, bool INTERP>
+__global__ __launch_bounds__(512) void contract_mfma_kernel(ContractArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int NT = RT / 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n_waves = blockDim.x >> 6;
+  const int xcd = blockIdx.x & 7;
+  const int rest = blockIdx.x >> 3;
+  const int tile = (rest / a.n_slabs) * 8 + xcd;
+  const int slab = rest % a.n_slabs;
+  if (tile >= a.n_tiles) return;
+  const int64_t col = (int64_t)tile * kLanes;
+
+  constexpr bool interp = INTERP;
+  unsigned long long t_start = 0, t_staged = 0, t_main = 0, c_staged = 0, c_main = 0;
+  if (a.trace) t_start = __builtin_amdgcn_s_memrealtime();
+  const int k_splits = interp ? a.k_splits : 1;
+  const Group group = a.groups[slab / k_splits];
+  const int n_rows_j = group.j_hi - group.j_lo;
+  const int n_rows = n_rows_j + (group.i_hi - group.i_lo);
+  int k_begin = 0, k_end = 1;
+  if (interp) {
+    const int split = slab % k_splits;
+    k_begin = (int)((int64_t)a.n_tables * split / k_splits);
+    k_end = (int)((int64_t)a.n_tables * (split + 1) / k_splits);
+  }
+
+  double acc[4][NT];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int u = 0; u < NT; ++u) acc[s][u] = 0.0;
+
+  int staged_class = -1;
+  for (int k = k_begin; k < k_end; ++k) {
+    const int density_class = interp ? a.table_class[k] : 0;
+    if (density_class != staged_class) {
+      if (staged_class >= 0) __syncthreads();
+      typedef double __attribute__((ext_vector_type(2))) double2v;
+      typedef const __attribute__((address_space(1))) double2v* gl_f64x2;
+      const int n_items = n_rows * (kLanes / 2);
+      gl_f64 src = (gl_f64)(interp ? a.nbufs[density_class] : a.nbuf) + col;
+      auto source = [&](int id) {
+        const int row = id >> 5;
+        const int bin = row < n_rows_j ? group.j_lo + row : group.i_lo + row - n_rows_j;
+        return (gl_f64x2)(src + (int64_t)bin * a.ldb + (id & 31) * 2);
+      };
+      const int nthreads = blockDim.x;
+      int it = threadIdx.x;
+      for (; it + 3 * nthreads < n_items; it += 4 * nthreads) {
+        double2v v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *source(it + u * nthreads);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int id = it + u * nthreads;
+          *(double2v*)(lds + (id >> 5) * kLanes + (id & 31) * 2) = v[u];
+        }
+      }
+      for (; it < n_items; it += nthreads)
+        *(double2v*)(lds + (it >> 5) * kLanes + (it & 31) * 2) = *source(it);
+      // mode cross has no row bin: its "n_i" is a row of ones behind the staged rows
+      if (a.mode != 0 && threadIdx.x < kLanes) lds[n_rows * kLanes + threadIdx.x] = 1.0;
+      __syncthreads();
+      staged_class = density_class;
+      if (a.trace) {
+        t_staged = __builtin_amdgcn_s_memrealtime();
+        c_staged = __builtin_amdgcn_s_memtime();
+      }
+    }
+
+    if (wave < group.n_chunks) {
+      const Chunk chunk = a.chunks[group.chunk_begin + wave];
+      // Steps of 4 positions, loaded two at a time: the vector-memory pipe costs ~17
+      // cycles per load INSTRUCTION per CU whatever its width (tools/micro/ta_rate.hip),
+      // so every load is 16 bytes per lane: the table values of a lane for two
+      // consecutive steps, and the LDS offsets of its position in both steps.
+      const int n_pairs = (chunk.q_end - chunk.q_begin) / 8;
+      const int last = n_pairs > 0 ? n_pairs - 1 : 0;
+      typedef double __attribute__((ext_vector_type(2))) double2v;
+      typedef const __attribute__((address_space(1))) double2v* gl_f64x2;
+      typedef int __attribute__((ext_vector_type(4))) int4v;
+      typedef const __attribute__((address_space(1))) int4v* gl_i32x4;
+      // A operand: k = lane / 16, i = lane % 4 inside the [u][k][i][step parity] block
+      gl_f64x2 table =
+          (gl_f64x2)((interp ? a.tables[k] : (const double*)a.table) +
+                     ((int64_t)blockIdx.z * a.n_positions + chunk.q_begin) * RT) +
+          (lane >> 4) * 4 + (lane & 3);
+      gl_i32x4 pos_base = (gl_i32x4)a.pos_off + (chunk.q_begin / 8) * 4 + (lane >> 4);
+      auto pos = [&](int pair) { return pos_base[(int64_t)pair * 4]; };
+      // byte offsets of this lane's first draw (set 0) in LDS rows i and j
+      const int lane_col = (lane & 15) * 8;
+      const int base_j = lane_col - group.j_lo * (kLanes * 8);
+      const int base_i =
+          lane_col + (a.mode == 0 ? group.i_shift : n_rows) * (kLanes * 8);
+      double scale[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        scale[s] = interp ? a.coef[(int64_t)k * a.ldb + col + 16 * s + (lane & 15)] : 1.0;
+
+      auto load_table = [&](double2v (&t)[NT], int pair) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) t[u] = table[(int64_t)pair * 4 * RT + u * 16];
+      };
+      // densities of the step's position in this lane's four draws
+      auto gather = [&](double (&ni)[4], double (&nj)[4], int off_i, int off_j) {
+        const double* rj = (const double*)((const char*)lds + (off_j + base_j));
+        const double* ri = (const double*)((const char*)lds + (off_i + base_i));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) nj[s] = rj[16 * s];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ni[s] = ri[16 * s];
+      };
+      auto weights = [&](double (&w)[4], const double (&ni)[4], const double (&nj)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          w[s] = ni[s] * nj[s];
+          if (interp) w[s] *= scale[s];
+        }
+      };
+      auto multiply = [&](const double2v (&t)[NT], int parity, const double (&w)[4]) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            acc[s][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(parity ? t[u].y : t[u].x, w[s],
+                                                           acc[s][u], 0, 0, 0);
+      };
+
+      double2v ta[NT], tb[NT];
+      double ni[4], nj[4], w[4];
+      unsigned long long stamps[5] = {0, 0, 0, 0, 0};
+      if (a.wave_trace) stamps[0] = __builtin_amdgcn_s_memrealtime();
+      if (n_pairs > 0) {
+        load_table(ta, 0);
+        int4v pa = pos(0), pb;
+        gather(ni, nj, pa.x, pa.y);
+        const int quarter = (n_pairs / 8) * 2 > 0 ? (n_pairs / 8) * 2 : 2;
+        int pair = 0;
+        // two pairs per iteration so that the two register sets swap roles without
+        // moves; every prefetch is unconditional (clamped to the last pair)
+        for (; pair + 2 <= n_pairs; pair += 2) {
+          load_table(tb, pair + 1);
+          pb = pos(pair + 1);
+          weights(w, ni, nj);
+          gather(ni, nj, pa.z, pa.w);
+          multiply(ta, 0, w);
+          weights(w, ni, nj);
+          gather(ni, nj, pb.x, pb.y);
+          multiply(ta, 1, w);
+          const int next = pair + 2 < last ? pair + 2 : last;
+          load_table(ta, next);
+          pa = pos(next);
+          weights(w, ni, nj);
+          gather(ni, nj, pb.z, pb.w);
+          multiply(tb, 0, w);
+          weights(w, ni, nj);
+          gather(ni, nj, pa.x, pa.y);
+          multiply(tb, 1, w);
+          if (a.wave_trace && (pair + 2) % quarter == 0 && (pair + 2) / quarter <= 3)
+            stamps[(pair + 2) / quarter] = __builtin_amdgcn_s_memrealtime();
+        }
+        if (pair < n_pairs) {
+          weights(w, ni, nj);
+          gather(ni, nj, pa.z, pa.w);
+          multiply(ta, 0, w);
+          weights(w, ni, nj);
+          multiply(ta, 1, w);
+        }
+      }
+      if (a.wave_trace) {
+        stamps[4] = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+          unsigned long long* rec =
+              a.wave_trace + 6 * (((unsigned long long)tile * a.n_slabs + slab) * n_waves + wave);
+          for (int q = 0; q < 5; ++q) rec[q] = stamps[q];
+          rec[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        }
+      }
+    }
+  }
+  if (a.trace) {
+    t_main = __builtin_amdgcn_s_memrealtime();
+    c_main = __builtin_amdgcn_s_memtime();
+  }
+  __syncthreads();  // the staged densities are dead; reuse LDS for the sums
+
+  // deterministic tree reduction over the waves (any layout: all waves share it)
+  int span = 1;
+  while (span < n_waves) span <<= 1;
+  for (int half = span >> 1; half >= 1; half >>= 1) {
+    if (wave >= half && wave < 2 * half) {
+      double* slot = lds + (wave - half) * RT * kLanes + lane;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) slot[(s * NT + u) * kLanes] = acc[s][u];
+    }
+    __syncthreads();
+    if (wave < half && wave + half < n_waves) {
+      const double* slot = lds + wave * RT * kLanes + lane;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[s][u] += slot[(s * NT + u) * kLanes];
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    // D layout: draw = 16 s + lane % 16, r = 4 u + lane / 16
+    double* out = a.partial +
+                  ((int64_t)slab * a.r_stride + (int64_t)blockIdx.z * RT + (lane >> 4)) *
+                      a.ldb + col + (lane & 15);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int u = 0; u < NT; ++u) out[(int64_t)(4 * u) * a.ldb + 16 * s] = acc[s][u];
+  }
+  if (a.trace && threadIdx.x == 0) {
+    const unsigned long long block =
+        tile + (unsigned long long)a.n_tiles * (slab + a.n_slabs * blockIdx.z);
+    unsigned long long* rec = a.trace + 6 * block;
+    rec[0] = t_start;
+    rec[1] = t_staged;
+    rec[2] = t_main;
+    rec[3] = __builtin_amdgcn_s_memrealtime();
+    rec[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+    rec[5] = (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf) |
+             ((c_main - c_staged) << 4);   // XCC_ID, shader cycles of the main loop
+  }
+}
+
 // ---- float32 variant for tables with many correlation-function bins -------------------
 //
 // BASELINE configs[4]: R = 760 (rp x pi), G ~ 200.  With hundreds of r values the

@@ -69,7 +69,8 @@ int get_chunking(tc_table* t, int n_chunks, int waves, DeviceChunking** out) {
 int lds_bytes_for(const tc::Chunking& chunking, int rt, int elem) {
   int span = 1;
   while (span < chunking.waves_per_group) span <<= 1;
-  return std::max(chunking.max_rows, (span / 2) * rt) * 64 * elem;
+  // + 1: the row of ones the matrix kernel uses as "n_i" in mode cross
+  return std::max(chunking.max_rows + 1, (span / 2) * rt) * 64 * elem;
 }
 
 // Workgroups of this kernel that fit on one CU: LDS (160 KiB) and wave slots (the
@@ -163,6 +164,25 @@ int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
 
 int launch_contract_rt(int rt, dim3 grid, dim3 block, int lds, hipStream_t stream,
                        const tc::ContractArgs& args) {
+  if (args.pos_off != nullptr) {
+    switch (rt) {
+#define TC_CASE(N)                                                            \
+  case N:                                                                     \
+    if (args.n_tables > 0)                                                    \
+      hipLaunchKernelGGL((tc::contract_mfma_kernel<N, true>), grid, block,    \
+                         lds, stream, args);                                  \
+    else                                                                      \
+      hipLaunchKernelGGL((tc::contract_mfma_kernel<N, false>), grid, block,   \
+                         lds, stream, args);                                  \
+    break;
+      TC_RT_CASES
+#undef TC_CASE
+      default:
+        return fail(TC_ERR_UNSUPPORTED, "no kernel for r tile %d", rt);
+    }
+    TC_HIP(hipGetLastError());
+    return TC_OK;
+  }
   switch (rt) {
 #define TC_CASE(N)                                                            \
   case N:                                                                     \
@@ -191,6 +211,12 @@ int set_lds_limit_rt(int rt, int lds) {
         hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \
     TC_HIP(hipFuncSetAttribute(                                               \
         reinterpret_cast<const void*>(&tc::contract_kernel<N, true>),         \
+        hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \
+    TC_HIP(hipFuncSetAttribute(                                               \
+        reinterpret_cast<const void*>(&tc::contract_mfma_kernel<N, false>),   \
+        hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \
+    TC_HIP(hipFuncSetAttribute(                                               \
+        reinterpret_cast<const void*>(&tc::contract_mfma_kernel<N, true>),    \
         hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \
     break;
     TC_RT_CASES
@@ -231,6 +257,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   ca.trace = nullptr;
   ca.wave_trace = nullptr;
   ca.pos_ij = nullptr;
+  ca.pos_off = (const int32_t*)t->d_pos_off;
   if (env_int("TC_TRACE", 0)) {
     t->trace_blocks = (size_t)(ldb / 64) * n_groups * t->n_rtiles;
     status = t->trace.reserve(t->trace_blocks * 6 * sizeof(unsigned long long), stream);

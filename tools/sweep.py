@@ -109,6 +109,12 @@ if __name__ == '__main__':
         run(50, 1, (19, ), 64, 50, 'cfg2 64')
         run(50, 1, (19, ), 100000, 10, 'cfg2 1e5')
         run(30, 1, (19, ), 10000, 50, 'bolplanck-like G=60')
+    elif which == 'mfma':
+        for nw in [4]:
+            for ng in [6, 8, 10, 12, 13, 14, 16, 20, 26]:
+                os.environ['TC_NWAVES'] = str(nw)
+                os.environ['TC_NGROUPS'] = str(ng)
+                run(50, 1, (19, ), 10000, 50, 'cfg2 nw=%d ngroups=%d' % (nw, ng))
     elif which == 'waves':
         for nw, ng in [(4, 8), (5, 6), (6, 5), (6, 6), (7, 5), (8, 4), (6, 7), (5, 8)]:
             os.environ['TC_NWAVES'] = str(nw)
