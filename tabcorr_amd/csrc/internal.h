@@ -204,7 +204,8 @@ constexpr int64_t kMaxSlab = 1 << 18;
 int get_quadrature(tc_table* t, int n_gauss, Quadrature** out);
 int get_chunking(tc_table* t, int n_chunks, int waves, DeviceChunking** out);
 int lds_bytes_for(const Chunking& chunking, int rt, int elem = 8);
-int blocks_per_cu(int lds_bytes, int waves);
+int wave_slots(const tc_table* t, bool interp);
+int blocks_per_cu(int lds_bytes, int waves, int slots);
 int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out, DeviceChunking** out,
                     int* lds_bytes);
 int launch_contract_rt(int rt, dim3 grid, dim3 block, int lds, hipStream_t stream,

@@ -111,7 +111,8 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   int k_splits = 1;
   {
     const int64_t blocks = n_tiles * t0->n_rtiles * (int64_t)c->host.groups.size();
-    const int64_t want = 256 * (int64_t)blocks_per_cu(lds, c->host.waves_per_group);
+    const int64_t want = 256 * (int64_t)blocks_per_cu(lds, c->host.waves_per_group,
+                                                        wave_slots(t0, true));
     if (blocks * 2 <= want)
       k_splits = (int)std::min<int64_t>(it->n_tables, want / std::max<int64_t>(1, blocks));
     k_splits = std::max(1, env_int("TC_KSPLITS", k_splits));

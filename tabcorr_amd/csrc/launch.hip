@@ -73,11 +73,20 @@ int lds_bytes_for(const tc::Chunking& chunking, int rt, int elem) {
   return std::max(chunking.max_rows + 1, (span / 2) * rt) * 64 * elem;
 }
 
-// Workgroups of this kernel that fit on one CU: LDS (160 KiB) and wave slots (the
-// kernel needs ~70 VGPRs: 7 waves per SIMD).
-int blocks_per_cu(int lds_bytes, int waves) {
+// Waves of the contraction kernel one SIMD holds, from the kernels' register counts
+// (vector kernel ~72 VGPRs; matrix kernel 72-170 growing with the r tile, more with the
+// interpolator's table loop; float32 kernel ~100).
+int wave_slots(const tc_table* t, bool interp) {
+  if (t->compute_dtype == TC_DTYPE_F32) return 4;
+  if (!t->f64_mfma) return 7;
+  if (interp) return t->rt <= 8 ? 4 : t->rt <= 20 ? 3 : 2;
+  return t->rt <= 12 ? 6 : t->rt <= 20 ? 4 : t->rt <= 28 ? 3 : 2;
+}
+
+// Workgroups of the contraction kernel that fit on one CU: LDS (160 KiB) and wave slots.
+int blocks_per_cu(int lds_bytes, int waves, int slots) {
   const int by_lds = kMaxLdsBytes / std::max(lds_bytes, 1);
-  const int by_waves = 28 / waves;
+  const int by_waves = slots * 4 / waves;
   return std::max(1, std::min(std::min(by_lds, by_waves), 8));
 }
 
@@ -130,7 +139,7 @@ int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
       int longest = 1;
       for (const tc::Chunk& chunk : trial.chunks)
         longest = std::max(longest, chunk.q_end - chunk.q_begin);
-      const int fit = blocks_per_cu(bytes + 1024, use_waves);
+      const int fit = blocks_per_cu(bytes + 1024, use_waves, wave_slots(t, false));
       const double blocks = (double)n_tiles * actual_groups;
       const double per_cu = std::ceil(blocks / n_cus);
       const double resident = std::min<double>(per_cu, fit) * use_waves / 4.0;

@@ -37,3 +37,9 @@ print('cfg4  5x5 interpolator, 12500 draws/GPU  : %8.1f us/batch  %.3g calls/s' 
 t5 = make(synthetic.synthetic_table(100, 1, (19, 40), 'auto', seed=9), compute_dtype='float32')
 dt = timeit(lambda: t5.predict_batch(theta), 5)
 print('cfg5  G=200 R=760 float32 MFMA           : %8.1f us/batch  %.3g calls/s' % (dt * 1e6, 1e4 / dt))
+t5d = make(synthetic.synthetic_table(100, 1, (19, 40), 'auto', seed=9))
+dt = timeit(lambda: t5d.predict_batch(theta), 3)
+print('cfg5 f64  G=200 R=760 float64            : %8.1f us/batch  %.3g calls/s' % (dt * 1e6, 1e4 / dt))
+tc = make(synthetic.synthetic_table(50, 1, (19, ), 'cross', seed=2))
+dt = timeit(lambda: tc.predict_batch(theta), 50)
+print('cross G=100 R=19  10^4 draws             : %8.1f us/batch  %.3g calls/s' % (dt * 1e6, 1e4 / dt))
