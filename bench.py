@@ -243,7 +243,7 @@ def main():
                 'gather_every_steps': every,
             },
             'roofline': {
-                'kernel': 'tc::contract_kernel<20, false>',
+                'kernel': 'tc::contract_mfma_kernel<20, false>',
                 'bound': 'mfma',
                 'achieved': achieved,
                 'peak': FP64_PEAK_TFLOPS,

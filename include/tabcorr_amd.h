@@ -94,8 +94,9 @@ int tc_spline_interpolation_matrix(int n, const double* xp, double* a);
  * the first n_central (after the library's stable sort by gal_type) are centrals, cut into
  * n_chunks wave-sized pieces.  Outputs one record per packed column, in processing order:
  * entry_pair[e] = packed column p (auto) or bin (cross), entry_chunk[e], entry_class[e]
- * (0 cen-cen / cen, 1 cen-sat, 2 sat-sat / sat).  Lets CPU tests check the kernel's
- * traversal covers every column exactly once. */
+ * (0 cen-cen / cen, 1 cen-sat, 2 sat-sat / sat).  Lets CPU tests check that the kernel's
+ * traversal covers every column exactly once and only gathers density rows its workgroup
+ * stages (padding positions included). */
 int tc_plan_debug(int mode, int n_bins, const uint8_t* is_central, int n_chunks,
                   int64_t* n_entries, int32_t* entry_pair, int32_t* entry_chunk,
                   int32_t* entry_class);

@@ -156,16 +156,6 @@ void build_tables(double* table) {
 
 }  // namespace fm
 
-int block_entries(int rt) {
-  int g = 16, r = rt;
-  while (r != 0) {
-    int t = g % r;
-    g = r;
-    r = t;
-  }
-  return 16 / g;   // g = gcd(rt, 16)
-}
-
 namespace {
 
 void add_triangle(std::vector<Segment>& out, int component, int lo, int hi, int budget) {
@@ -304,12 +294,7 @@ void build_chunking(const Plan& plan, int n_chunks, int waves_per_group,
       chunk.q_begin = (int32_t)(seg.q_begin + b0 * eb);
       chunk.q_end = (int32_t)(seg.q_begin + b1 * eb);
       chunk.n_real = (int32_t)(std::min<int64_t>(n_real, b1 * eb) - b0 * eb);
-      chunk.i0 = plan.pos_i[chunk.q_begin];
-      chunk.j0 = plan.pos_j[chunk.q_begin];
       chunk.component = seg.component;
-      chunk.j_lo = seg.j_lo;
-      chunk.j_last = plan.mode != 0 ? 0x7fffffff
-                                    : (seg.rectangular ? seg.j_hi - 1 : -1);
       out.chunks.push_back(chunk);
       chunk_segment.push_back((int)si);
     }

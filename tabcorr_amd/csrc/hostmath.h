@@ -44,18 +44,12 @@ struct Segment {
 };
 
 // The work of one wavefront: positions [q_begin, q_end) of one segment, of which the
-// first n_real are real entries; (i0, j0) is the bin pair of position q_begin.  The
-// walk steps j -> j + 1 and wraps to (i + 1, j_lo) after column `j_last` (rectangle)
-// or after the diagonal (j_last < 0).
+// first n_real are real entries.
 struct Chunk {
   int32_t q_begin;
   int32_t q_end;
   int32_t n_real;
-  int32_t i0;
-  int32_t j0;
   int32_t component;
-  int32_t j_lo;
-  int32_t j_last;
 };
 
 // The work of one workgroup: chunks [chunk_begin, chunk_begin + n_chunks), all of one
@@ -78,9 +72,9 @@ struct Plan {
   int n_bins = 0;
   int n_central = 0;
   int n_components = 0;          // 3 (auto) or 2 (cross)
-  int block = 1;                 // EB: entries per 128-byte aligned block
+  int block = 1;                 // positions per block of the table layout
   int64_t n_entries = 0;         // = P
-  int64_t n_positions = 0;       // padded, multiple of EB per segment
+  int64_t n_positions = 0;       // padded, multiple of `block` per segment
   std::vector<int32_t> perm;     // library bin g' -> reference row
   std::vector<Segment> segments;
   // Position order of the re-laid-out table: reference column (-1 = padding),
@@ -97,9 +91,6 @@ struct Chunking {
   int max_rows = 0;              // max over groups of the LDS rows staged
 };
 
-// Entries per aligned block for an r tile of width rt: EB * rt % 16 == 0.
-int block_entries(int rt);
-
 // Bin permutation (stable sort, centrals first), segmentation (no workgroup will need
 // more than about `row_budget` density rows) and position order.
 void build_plan(int mode, int n_bins, const uint8_t* is_central, int block,
@@ -111,8 +102,8 @@ void build_plan(int mode, int n_bins, const uint8_t* is_central, int block,
 void build_chunking(const Plan& plan, int n_chunks, int waves_per_group,
                     Chunking& out);
 
-// The rule by which the kernel steps from one entry to the next inside a segment
-// (shared by the kernel, the planner and the CPU tests).
+// Position order inside a segment: j -> j + 1, wrapping to (i + 1, j_lo) after column
+// `j_last` (rectangle) or after the diagonal (j_last < 0).
 inline void advance_pair(int j_lo, int j_last, int& i, int& j) {
   const int last = j_last >= 0 ? j_last : i;
   if (++j > last) {

@@ -156,8 +156,7 @@ struct tc_table {
   void* d_perm = nullptr;
   void* d_math_table = nullptr;  // fastmath.h tables
   void* d_pos_ij = nullptr;      // float32 variant: packed bin pairs per position
-  void* d_pos_off = nullptr;     // FP64 matrix kernel: LDS row byte offsets per position
-  bool f64_mfma = false;         // FP64 table laid out for contract_mfma_kernel
+  void* d_pos_off = nullptr;     // FP64 kernel: LDS row byte offsets per position
   std::map<int, tc::host::Quadrature> quadrature;
   std::map<std::pair<int, int>, std::unique_ptr<tc::host::DeviceChunking>> chunkings;
   std::map<int64_t, tc::host::DeviceChunking*> choices;   // decomposition chosen per tile count

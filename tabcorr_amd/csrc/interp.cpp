@@ -202,7 +202,7 @@ int tc_interp_create(tc_table* const* tables, int n_tables, int n_dim,
     if (t->compute_dtype != TC_DTYPE_F64)
       return fail(TC_ERR_UNSUPPORTED, "interpolation of float32 tables is not built");
     TC_CHECK(t->mode == t0->mode && t->n_bins == t0->n_bins && t->n_r == t0->n_r &&
-                 t->plan.perm == t0->plan.perm && t->f64_mfma == t0->f64_mfma,
+                 t->plan.perm == t0->plan.perm,
              "table %d differs from table 0 in mode, shape or gal_type layout", k);
   }
   // abscissae: sorted unique values per dimension (interpolator.py:41-43)

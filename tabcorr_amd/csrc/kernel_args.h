@@ -14,6 +14,7 @@ constexpr unsigned kFlagModulate = 2u;
 constexpr unsigned kFlagAssembias = 4u;
 constexpr int kOccWaves = 4;
 constexpr int kF32Block = 8;    // entries per block
+constexpr int kF64Block = 8;    // positions per block of the FP64 table layout (two steps)
 constexpr int kF32Tile = 32;    // r values per tile
 constexpr int kFinalizeRows = 32;   // (component, r) rows per LDS pass
 constexpr int kMaxInterpDim = 8;

@@ -1,11 +1,11 @@
 // Device kernels of libtabcorr_hip.so (gfx950 / CDNA4 only).
 //
-// Common layout: one LANE per parameter draw.  A wavefront owns 64 consecutive
-// draws ("draw tile"); everything that does not depend on the draw -- table
-// values, quadrature constants, work descriptors -- is wave-uniform, is read
-// through the scalar data cache (s_load_*) and enters the FP64 FMAs as an SGPR
-// operand.  Per-draw values live in VGPRs / LDS with the draw index fastest, so
-// every vector access is a contiguous 512-byte row.
+// Common layout: a workgroup owns 64 consecutive draws ("draw tile").  In the occupation
+// and finalisation kernels one LANE is one draw and everything that does not depend on
+// the draw (quadrature constants, work descriptors) is wave-uniform and read through the
+// scalar data cache.  The contraction runs on the FP64 matrix cores with the draws as one
+// matrix dimension.  Per-draw values live in global memory / LDS with the draw index
+// fastest, so every vector access is a contiguous 512-byte row.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -203,289 +203,20 @@ __global__ __launch_bounds__(256) void occ_from_array_kernel(
   ngal[ldb + b0] = sum_sat;
 }
 
-// acc += t[lane N of my 16-lane row] * w.  The DP-only DPP control row_newbcast
-// lets the 16 table values held by the 16 lanes of a row feed 16 FMAs without
-// ever leaving the vector register file.
-template <int N>
-__device__ __forceinline__ void fmac_row_bcast(double& acc, double t, double w) {
-  asm volatile(
-      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-      : "+v"(acc)
-      : "v"(t), "v"(w), "n"(N));
-}
-
-template <int RT>
-struct ContractGeometry {
-  static constexpr int gcd16 = (RT % 16 == 0) ? 16 : (RT % 8 == 0) ? 8
-                               : (RT % 4 == 0) ? 4 : (RT % 2 == 0) ? 2 : 1;
-  static constexpr int EB = 16 / gcd16;       // entries per block
-  static constexpr int NG = EB * RT / 16;     // 16-value register groups per block
-};
-
-template <int RT, int E, int... Rs>
-__device__ __forceinline__ void entry_fma(
-    double (&acc)[RT], const double (&t)[ContractGeometry<RT>::NG], double w,
-    std::integer_sequence<int, Rs...>) {
-  (fmac_row_bcast<((E * RT + Rs) & 15)>(acc[Rs], t[(E * RT + Rs) >> 4], w), ...);
-}
-
-// Per-wave walk state over the entries of one component.
-struct WalkState {
-  int i, j, remaining, row_lo, i_shift, j_lo, j_last;
-  double ni;      // density of row i times `scale`
-  double scale;   // per-draw weight of the current table (1 without interpolation)
-};
-
-// Weight of the walk's current entry, then step to the next real entry (padding keeps
-// the last real pair: its table rows are zero).
-__device__ __forceinline__ double next_weight(WalkState& st, const double* lds, int lane) {
-  const double nj = lds[(st.j - st.row_lo) * kLanes + lane];
-  const double w = st.ni * nj;
-  if (--st.remaining > 0) {
-    const int last = st.j_last >= 0 ? st.j_last : st.i;
-    if (++st.j > last) {
-      ++st.i;
-      st.j = st.j_lo;
-      st.ni = lds[(st.i + st.i_shift) * kLanes + lane] * st.scale;
-    }
-  }
-  return w;
-}
-
-template <int RT, int... Es>
-__device__ __forceinline__ void block_compute(
-    double (&acc)[RT], const double (&t)[ContractGeometry<RT>::NG],
-    WalkState& st, const double* lds, int lane,
-    std::integer_sequence<int, Es...>) {
-  // all weights of the block first (one LDS round trip per block instead of one per
-  // entry), then the FMAs
-  constexpr int EB = (int)sizeof...(Es);
-  double w[EB];
-  const int last = st.j_last >= 0 ? st.j_last : st.i;
-  if (st.remaining > EB && st.j + EB - 1 <= last) {
-    // common case: the block lies inside one row -- one LDS address, the column
-    // densities at immediate offsets, one multiplication per entry
-    const double* p = lds + (st.j - st.row_lo) * kLanes + lane;
-    ((w[Es] = st.ni * p[Es * kLanes]), ...);
-    st.j += EB;
-    st.remaining -= EB;
-    if (st.j > last) {
-      ++st.i;
-      st.j = st.j_lo;
-      st.ni = lds[(st.i + st.i_shift) * kLanes + lane] * st.scale;
-    }
-  } else {
-    ((w[Es] = next_weight(st, lds, lane)), ...);
-  }
-  (entry_fma<RT, Es>(acc, t, w[Es], std::make_integer_sequence<int, RT>()), ...);
-}
-
-// Contraction of the re-laid-out table with the pair weights of 64 draws:
-// tabcorr.py:641-649 (total) and :652-683 (per component), without the final
-// division.  grid = (draw tiles, groups, r tiles); wave w of a block works on
-// chunk w of its group.  The per-draw densities of the rows the group touches
-// are staged once in LDS.  Table values stream from L2 through the vector
-// memory path, 16 doubles per 128-byte line replicated over the 4 rows of the
-// wave; each of them feeds one v_fmac_f64_dpp row_newbcast.  Per table entry a
-// wave issues one ds_read_b64 (n_j), one v_mul_f64 (n_i n_j) and RT FMAs; the
-// loads of the next block are in flight while the current one is consumed.
-template <int RT, bool INTERP>
-__global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  typedef ContractGeometry<RT> Geo;
-  constexpr int EB = Geo::EB, NG = Geo::NG;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n_waves = blockDim.x >> 6;
-  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with its
-  // own L2), so linear id b runs on XCD b % 8.  All slabs (groups x table splits) of a
-  // draw tile are given ids with the same b % 8, next to each other in dispatch order:
-  // the tile's density rows, re-read by every slab, then come from that XCD's L2.
-  const int xcd = blockIdx.x & 7;
-  const int rest = blockIdx.x >> 3;
-  const int tile = (rest / a.n_slabs) * 8 + xcd;
-  const int slab = rest % a.n_slabs;
-  if (tile >= a.n_tiles) return;
-  const int64_t col = (int64_t)tile * kLanes;
-
-  constexpr bool interp = INTERP;
-  unsigned long long t_start = 0, t_staged = 0, t_main = 0, c_staged = 0, c_main = 0;
-  if (a.trace) t_start = __builtin_amdgcn_s_memrealtime();
-  const int k_splits = interp ? a.k_splits : 1;
-  const Group group = a.groups[slab / k_splits];
-  const int n_rows_j = group.j_hi - group.j_lo;
-  const int n_rows = n_rows_j + (group.i_hi - group.i_lo);
-  int k_begin = 0, k_end = 1;
-  if (interp) {
-    const int split = slab % k_splits;
-    k_begin = (int)((int64_t)a.n_tables * split / k_splits);
-    k_end = (int)((int64_t)a.n_tables * (split + 1) / k_splits);
-  }
-
-  double acc[RT];
-#pragma unroll
-  for (int r = 0; r < RT; ++r) acc[r] = 0.0;
-
-  int staged_class = -1;
-  for (int k = k_begin; k < k_end; ++k) {
-    const int density_class = interp ? a.table_class[k] : 0;
-    if (density_class != staged_class) {
-      if (staged_class >= 0) __syncthreads();   // everyone is done with the old rows
-      // stage the column bins [j_lo, j_hi) and, behind them, the row bins [i_lo, i_hi)
-      // of this draw tile: 16 bytes per lane, four independent loads in flight
-      typedef double __attribute__((ext_vector_type(2))) double2v;
-      typedef const __attribute__((address_space(1))) double2v* gl_f64x2;
-      const int n_items = n_rows * (kLanes / 2);
-      gl_f64 src = (gl_f64)(interp ? a.nbufs[density_class] : a.nbuf) + col;
-      auto source = [&](int id) {
-        const int row = id >> 5;
-        const int bin = row < n_rows_j ? group.j_lo + row : group.i_lo + row - n_rows_j;
-        return (gl_f64x2)(src + (int64_t)bin * a.ldb + (id & 31) * 2);
-      };
-      const int nthreads = blockDim.x;
-      int it = threadIdx.x;
-      for (; it + 3 * nthreads < n_items; it += 4 * nthreads) {
-        double2v v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *source(it + u * nthreads);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int id = it + u * nthreads;
-          *(double2v*)(lds + (id >> 5) * kLanes + (id & 31) * 2) = v[u];
-        }
-      }
-      for (; it < n_items; it += nthreads)
-        *(double2v*)(lds + (it >> 5) * kLanes + (it & 31) * 2) = *source(it);
-      __syncthreads();
-      staged_class = density_class;
-      if (a.trace) {
-        t_staged = __builtin_amdgcn_s_memrealtime();
-        c_staged = __builtin_amdgcn_s_memtime();
-      }
-    }
-
-    if (wave < group.n_chunks) {
-      const Chunk chunk = a.chunks[group.chunk_begin + wave];
-      WalkState st;
-      st.i = chunk.i0;
-      st.j = chunk.j0;
-      st.remaining = chunk.n_real;
-      st.row_lo = group.j_lo;
-      st.i_shift = group.i_shift;
-      st.j_lo = chunk.j_lo;
-      st.j_last = chunk.j_last;
-      st.scale = interp ? a.coef[(int64_t)k * a.ldb + col + lane] : 1.0;
-      st.ni = a.mode == 0
-                  ? lds[(chunk.i0 + group.i_shift) * kLanes + lane] * st.scale
-                  : st.scale;
-
-      gl_f64 table = (gl_f64)(interp ? a.tables[k] : (const double*)a.table) +
-                     ((int64_t)blockIdx.z * a.n_positions + chunk.q_begin) * RT +
-                     (lane & 15);
-      const int n_blocks = (chunk.q_end - chunk.q_begin) / EB;
-      double ta[NG], tb[NG];
-#pragma unroll
-      for (int g = 0; g < NG; ++g) ta[g] = table[g * 16];
-      unsigned long long stamps[5] = {0, 0, 0, 0, 0};
-      if (a.wave_trace) stamps[0] = __builtin_amdgcn_s_memrealtime();
-      // The SIMD's arbiter serves the oldest waves first and a single wave can use only
-      // ~40 % of the FP64 issue slots, so without help two or three waves run while the
-      // younger ones starve and then finish one after the other at the single-wave rate
-      // (tools/trace.py).  Each wave therefore lowers its own priority as it advances
-      // (3 in its first quarter ... 0 in its last): laggards overtake, the waves progress
-      // together and the pipe stays full until the end.
-      const int quarter = (n_blocks / 8) * 2 > 0 ? (n_blocks / 8) * 2 : 2;
-      __builtin_amdgcn_s_setprio(3);
-      int blk = 0;
-      // two blocks per iteration so that the two register sets swap roles
-      // without moves; the prefetch is unconditional (clamped to the last block) so
-      // that the compiler can count the loads in flight exactly
-      const int last = n_blocks > 0 ? n_blocks - 1 : 0;
-      for (; blk + 2 <= n_blocks; blk += 2) {
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-          tb[g] = table[(int64_t)(blk + 1) * EB * RT + g * 16];
-        block_compute<RT>(acc, ta, st, lds, lane, std::make_integer_sequence<int, EB>());
-        const int next = blk + 2 < last ? blk + 2 : last;
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-          ta[g] = table[(int64_t)next * EB * RT + g * 16];
-        block_compute<RT>(acc, tb, st, lds, lane, std::make_integer_sequence<int, EB>());
-        if ((blk + 2) % quarter == 0) {
-          const int done = (blk + 2) / quarter;
-          if (done == 1) __builtin_amdgcn_s_setprio(2);
-          if (done == 2) __builtin_amdgcn_s_setprio(1);
-          if (done == 3) __builtin_amdgcn_s_setprio(0);
-          if (a.wave_trace && done <= 3) stamps[done] = __builtin_amdgcn_s_memrealtime();
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
-      if (a.wave_trace) {
-        stamps[4] = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) {
-          unsigned long long* rec =
-              a.wave_trace + 6 * (((unsigned long long)tile * a.n_slabs + slab) * n_waves + wave);
-          for (int q = 0; q < 5; ++q) rec[q] = stamps[q];
-          rec[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-        }
-      }
-      if (blk < n_blocks)
-        block_compute<RT>(acc, ta, st, lds, lane, std::make_integer_sequence<int, EB>());
-    }
-  }
-  if (a.trace) {
-    t_main = __builtin_amdgcn_s_memrealtime();
-    c_main = __builtin_amdgcn_s_memtime();
-  }
-  __syncthreads();  // the staged densities are dead; reuse LDS for the sums
-
-  // Deterministic tree reduction over the waves of the block (all of one
-  // component): the upper half parks its accumulators in LDS, the lower half
-  // adds them in registers.
-  int span = 1;
-  while (span < n_waves) span <<= 1;
-  for (int half = span >> 1; half >= 1; half >>= 1) {
-    if (wave >= half && wave < 2 * half) {
-      double* slot = lds + (wave - half) * RT * kLanes + lane;
-#pragma unroll
-      for (int r = 0; r < RT; ++r) slot[r * kLanes] = acc[r];
-    }
-    __syncthreads();
-    if (wave < half && wave + half < n_waves) {
-      const double* slot = lds + wave * RT * kLanes + lane;
-#pragma unroll
-      for (int r = 0; r < RT; ++r) acc[r] += slot[r * kLanes];
-    }
-    __syncthreads();
-  }
-  if (wave == 0) {
-    double* out = a.partial +
-                  ((int64_t)slab * a.r_stride + (int64_t)blockIdx.z * RT) * a.ldb + col +
-                  lane;
-#pragma unroll
-    for (int r = 0; r < RT; ++r) out[(int64_t)r * a.ldb] = acc[r];
-  }
-  if (a.trace && threadIdx.x == 0) {
-    const unsigned long long block =
-        tile + (unsigned long long)a.n_tiles * (slab + a.n_slabs * blockIdx.z);
-    unsigned long long* rec = a.trace + 6 * block;
-    rec[0] = t_start;
-    rec[1] = t_staged;
-    rec[2] = t_main;
-    rec[3] = __builtin_amdgcn_s_memrealtime();
-    rec[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
-    rec[5] = (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf) |
-             ((c_main - c_staged) << 4);   // XCC_ID, shader cycles of the main loop
-  }
-}
-
 // ---- FP64 matrix-core contraction -----------------------------------------------------
 //
-// Same decomposition, staging, reduction and output as contract_kernel, but the inner
-// product runs on v_mfma_f64_4x4x4_4b_f64: 4 blocks of D(4x4) += A(4x4) B(4x4).  The FP64
-// matrix rate equals the FP64 vector rate on gfx950, but the vector FMAs are power
+// partial[slab][r][draw] = sum over the slab's table positions q of T[q][r] w[q][draw],
+// w = n_i n_j of the position's bin pair (tabcorr.py:626-655 with the pair prefactor
+// folded into T).  grid = (8 * ceil(tiles / 8) * slabs, 1, r tiles); a workgroup stages
+// the density rows of its group's bins for its draw tile in LDS, each wave walks one
+// chunk of positions, the waves' sums are combined by a fixed-order tree in LDS.
+//
+// The inner product runs on v_mfma_f64_4x4x4_4b_f64: 4 blocks of D(4x4) += A(4x4) B(4x4).
+// The FP64 matrix rate equals the FP64 vector rate on gfx950, but vector FMAs are power
 // throttled under sustained load (tools/micro/sustained.hip: 63-67 TFLOP/s against 75
-// for this instruction), and the matrix form needs a fifth of the vector work around it.
+// for this instruction), and the matrix form needs a fifth of the vector work around it
+// (the first version of this kernel, vector FMAs with DPP row broadcasts of the table
+// values, reached 45.7 TFLOP/s: profiles/r01_notes.md).
 //
 // Operand mapping (probed with tools/micro/mfma_map.hip): lane l holds A[i][k] and
 // B[k][j] with i or j = l % 4, block = (l / 4) % 4, k = l / 16, and D[i][j] with
@@ -498,7 +229,7 @@ __global__ __launch_bounds__(1024) void contract_kernel(ContractArgs a) {
 //     two LDS gathers per set at row offsets the lane gets from pos_off[q0 + l / 16];
 //   D (per set s and sub-tile u): draw 16 s + l % 16, r = 4 u + l / 16.
 // Per 4 positions: (RT / 4 + 1) / 2 vector loads, 8 LDS reads (4 ds_read2_b64), 4 v_mul_f64
-// and RT MFMAs -- against 4 * (RT + 1) vector instructions and RT / 4 loads.
+// and RT MFMAs.
 template <int RT, bool INTERP>
 __global__ __launch_bounds__(512) void contract_mfma_kernel(ContractArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];

@@ -74,11 +74,10 @@ int lds_bytes_for(const tc::Chunking& chunking, int rt, int elem) {
 }
 
 // Waves of the contraction kernel one SIMD holds, from the kernels' register counts
-// (vector kernel ~72 VGPRs; matrix kernel 72-170 growing with the r tile, more with the
-// interpolator's table loop; float32 kernel ~100).
+// (FP64 matrix kernel 72-170 VGPRs growing with the r tile, more with the interpolator's
+// table loop; float32 kernel ~100).
 int wave_slots(const tc_table* t, bool interp) {
   if (t->compute_dtype == TC_DTYPE_F32) return 4;
-  if (!t->f64_mfma) return 7;
   if (interp) return t->rt <= 8 ? 4 : t->rt <= 20 ? 3 : 2;
   return t->rt <= 12 ? 6 : t->rt <= 20 ? 4 : t->rt <= 28 ? 3 : 2;
 }
@@ -173,8 +172,7 @@ int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
 
 int launch_contract_rt(int rt, dim3 grid, dim3 block, int lds, hipStream_t stream,
                        const tc::ContractArgs& args) {
-  if (args.pos_off != nullptr) {
-    switch (rt) {
+  switch (rt) {
 #define TC_CASE(N)                                                            \
   case N:                                                                     \
     if (args.n_tables > 0)                                                    \
@@ -183,24 +181,6 @@ int launch_contract_rt(int rt, dim3 grid, dim3 block, int lds, hipStream_t strea
     else                                                                      \
       hipLaunchKernelGGL((tc::contract_mfma_kernel<N, false>), grid, block,   \
                          lds, stream, args);                                  \
-    break;
-      TC_RT_CASES
-#undef TC_CASE
-      default:
-        return fail(TC_ERR_UNSUPPORTED, "no kernel for r tile %d", rt);
-    }
-    TC_HIP(hipGetLastError());
-    return TC_OK;
-  }
-  switch (rt) {
-#define TC_CASE(N)                                                            \
-  case N:                                                                     \
-    if (args.n_tables > 0)                                                    \
-      hipLaunchKernelGGL((tc::contract_kernel<N, true>), grid, block, lds,    \
-                         stream, args);                                       \
-    else                                                                      \
-      hipLaunchKernelGGL((tc::contract_kernel<N, false>), grid, block, lds,   \
-                         stream, args);                                       \
     break;
     TC_RT_CASES
 #undef TC_CASE
@@ -215,12 +195,6 @@ int set_lds_limit_rt(int rt, int lds) {
   switch (rt) {
 #define TC_CASE(N)                                                            \
   case N:                                                                     \
-    TC_HIP(hipFuncSetAttribute(                                               \
-        reinterpret_cast<const void*>(&tc::contract_kernel<N, false>),        \
-        hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \
-    TC_HIP(hipFuncSetAttribute(                                               \
-        reinterpret_cast<const void*>(&tc::contract_kernel<N, true>),         \
-        hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \
     TC_HIP(hipFuncSetAttribute(                                               \
         reinterpret_cast<const void*>(&tc::contract_mfma_kernel<N, false>),   \
         hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \

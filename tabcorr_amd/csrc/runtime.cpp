@@ -153,34 +153,49 @@ int tc_plan_debug(int mode, int n_bins, const uint8_t* is_central, int n_chunks,
   TC_CHECK(mode == TC_MODE_AUTO || mode == TC_MODE_CROSS, "invalid mode");
   TC_CHECK(n_bins >= 1 && is_central && n_entries, "invalid arguments");
   tc::Plan plan;
-  tc::build_plan(mode, n_bins, is_central, 4, env_int("TC_ROW_BUDGET", 56), plan);
+  tc::build_plan(mode, n_bins, is_central, tc::kF64Block, env_int("TC_ROW_BUDGET", 56),
+                 plan);
   tc::Chunking chunking;
-  tc::build_chunking(plan, n_chunks, 8, chunking);
+  tc::build_chunking(plan, n_chunks, 4, chunking);
   *n_entries = plan.n_entries;
   if (entry_pair == nullptr) return TC_OK;
-  // Walk every chunk exactly as the kernel does and record what it visits.
+  // Visit every chunk as the kernel does: all positions of the chunk, bin pair from the
+  // position tables, density rows from the rows its workgroup stages.
   std::vector<int> seen((size_t)plan.n_positions, 0);
   int64_t e = 0;
-  for (size_t c = 0; c < chunking.chunks.size(); ++c) {
-    const tc::Chunk& chunk = chunking.chunks[c];
-    if ((chunk.q_begin % plan.block) != 0 || (chunk.q_end % plan.block) != 0)
-      return fail(TC_ERR_INVALID, "chunk %zu is not block aligned", c);
-    int i = chunk.i0, j = chunk.j0, remaining = chunk.n_real;
-    for (int q = chunk.q_begin; q < chunk.q_end; ++q) {
-      if (seen[q]++) return fail(TC_ERR_INVALID, "position %d covered twice", q);
-      if (plan.column[q] >= 0) {
+  for (size_t g = 0; g < chunking.groups.size(); ++g) {
+    const tc::Group& group = chunking.groups[g];
+    const int n_rows_j = group.j_hi - group.j_lo;
+    const int n_rows = n_rows_j + (group.i_hi - group.i_lo);
+    if (n_rows > chunking.max_rows) return fail(TC_ERR_INVALID, "group %zu: max_rows", g);
+    for (int c = group.chunk_begin; c < group.chunk_begin + group.n_chunks; ++c) {
+      const tc::Chunk& chunk = chunking.chunks[c];
+      if ((chunk.q_begin % plan.block) != 0 || (chunk.q_end % plan.block) != 0)
+        return fail(TC_ERR_INVALID, "chunk %d is not block aligned", c);
+      for (int q = chunk.q_begin; q < chunk.q_end; ++q) {
+        if (seen[q]++) return fail(TC_ERR_INVALID, "position %d covered twice", q);
+        // the rows gathered for this position (padding included) must be staged
+        const int row_j = plan.pos_j[q] - group.j_lo;
+        if (row_j < 0 || row_j >= n_rows_j)
+          return fail(TC_ERR_INVALID, "position %d: column bin not staged", q);
+        if (mode == TC_MODE_AUTO) {
+          const int row_i = plan.pos_i[q] + group.i_shift;
+          if (row_i < 0 || row_i >= n_rows)
+            return fail(TC_ERR_INVALID, "position %d: row bin not staged", q);
+        }
+        if (plan.column[q] < 0) continue;
         const int64_t column =
-            mode == TC_MODE_AUTO ? tc::packed_index(plan.perm[i], plan.perm[j])
-                                 : plan.perm[j];
-        if (column != plan.column[q] || q >= chunk.q_begin + chunk.n_real)
-          return fail(TC_ERR_INVALID, "walk mismatch at position %d", q);
+            mode == TC_MODE_AUTO
+                ? tc::packed_index(plan.perm[plan.pos_i[q]], plan.perm[plan.pos_j[q]])
+                : plan.perm[plan.pos_j[q]];
+        if (column != plan.column[q])
+          return fail(TC_ERR_INVALID, "bin pair mismatch at position %d", q);
         if (e >= plan.n_entries) return fail(TC_ERR_INVALID, "too many entries");
         entry_pair[e] = (int32_t)column;
-        entry_chunk[e] = (int32_t)c;
+        entry_chunk[e] = c;
         entry_class[e] = chunk.component;
         ++e;
       }
-      if (--remaining > 0) tc::advance_pair(chunk.j_lo, chunk.j_last, i, j);
     }
   }
   for (int64_t q = 0; q < plan.n_positions; ++q)

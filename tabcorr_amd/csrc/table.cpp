@@ -51,14 +51,10 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
   } else {
     int rt = (n_r + t->n_rtiles - 1) / t->n_rtiles;
     t->rt = (rt + 3) / 4 * 4;
-    // matrix-core kernel (default) or the vector kernel (TC_F64_KERNEL=valu)
-    const char* kind = getenv("TC_F64_KERNEL");
-    t->f64_mfma = !(kind != nullptr && strcmp(kind, "valu") == 0);
     // LDS rows a workgroup may stage: half the bins (one triangle or one column block
     // of the cen-sat rectangle) plus a few rows, within 28..66 KB
     const int budget = std::max(56, std::min(128, n_bins / 2 + 6));
-    tc::build_plan(mode, n_bins, is_central,
-                   t->f64_mfma ? 8 : tc::block_entries(t->rt),
+    tc::build_plan(mode, n_bins, is_central, tc::kF64Block,
                    env_int("TC_ROW_BUDGET", budget), t->plan);
   }
 
@@ -83,7 +79,7 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
   std::vector<float> tmp32;
   std::vector<int32_t> pos_ij;
   if (compute_dtype == TC_DTYPE_F64) {
-    // Re-laid-out matrix: [r tile][position][r in tile] with the pair prefactor
+    // Re-laid-out matrix, per r tile and position, with the pair prefactor
     // (tabcorr.py:638-642) folded in (a multiplication by 2 is exact) and zero
     // rows at the padding positions.
     t->table_bytes = count * sizeof(double);
@@ -93,23 +89,20 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
       for (int64_t q = 0; q < n_positions; ++q) {
         const int64_t column = t->plan.column[q];
         if (column < 0) continue;
-        // vector kernel: [position][r]; matrix kernel: blocks of 8 positions (two steps of
-        // 4) as [r sub-tile of 4][position in step][r in sub-tile][step] (kernels.hip.h)
-        const size_t index =
-            t->f64_mfma ? ((size_t)tile * n_positions + q / 8 * 8) * rt +
-                              (((rr / 4) * 16 + (q % 4) * 4 + rr % 4) * 2 + (q / 4) % 2)
-                        : ((size_t)tile * n_positions + q) * rt + rr;
+        // blocks of 8 positions (two steps of 4) as [r sub-tile of 4][position in step]
+        // [r in sub-tile][step] (kernels.hip.h)
+        const size_t index = ((size_t)tile * n_positions + q / 8 * 8) * rt +
+                             (((rr / 4) * 16 + (q % 4) * 4 + rr % 4) * 2 + (q / 4) % 2);
         tmp64[index] = source(r, column) * t->plan.prefactor[q];
       }
     }
-    if (t->f64_mfma) {
-      // per pair of steps and position in step: (i, j of step 0, i, j of step 1) * 512
-      pos_ij.assign((size_t)n_positions * 2, 0);
-      for (int64_t q = 0; q < n_positions; ++q) {
-        const size_t slot = ((size_t)(q / 8) * 4 + q % 4) * 4 + ((q / 4) % 2) * 2;
-        pos_ij[slot] = std::max(t->plan.pos_i[q], 0) * 512;
-        pos_ij[slot + 1] = t->plan.pos_j[q] * 512;
-      }
+    // LDS row offsets per pair of steps and position in step: (i, j of step 0, i, j of
+    // step 1) * 512 bytes
+    pos_ij.assign((size_t)n_positions * 2, 0);
+    for (int64_t q = 0; q < n_positions; ++q) {
+      const size_t slot = ((size_t)(q / 8) * 4 + q % 4) * 4 + ((q / 4) % 2) * 2;
+      pos_ij[slot] = std::max(t->plan.pos_i[q], 0) * 512;
+      pos_ij[slot + 1] = t->plan.pos_j[q] * 512;
     }
   } else {
     // float32 MFMA layout: [r tile][block of 8 positions][k][r][k-step] (kernels.hip.h)
@@ -147,7 +140,8 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
                                              : upload(tmp32, &t->d_table);
   if (status == TC_OK && compute_dtype == TC_DTYPE_F32)
     status = upload(pos_ij, &t->d_pos_ij);
-  if (status == TC_OK && t->f64_mfma) status = upload(pos_ij, &t->d_pos_off);
+  if (status == TC_OK && compute_dtype == TC_DTYPE_F64)
+    status = upload(pos_ij, &t->d_pos_off);
   if (status == TC_OK) status = upload(t->n_h, &t->d_n_h);
   if (status == TC_OK) status = upload(t->percentile, &t->d_percentile);
   if (status == TC_OK) status = upload(t->plan.perm, &t->d_perm);

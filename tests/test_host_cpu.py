@@ -126,7 +126,8 @@ def test_plan_covers_every_column_once(lib, mode):
     from tabcorr_amd import _lib
     rng = np.random.default_rng(mode)
     cases = [(1, 'half'), (2, 'half'), (7, 'half'), (12, 'half'), (9, 'rand'),
-             (5, 'allcen'), (6, 'allsat'), (100, 'half'), (61, 'rand')]
+             (5, 'allcen'), (6, 'allsat'), (100, 'half'), (61, 'rand'), (200, 'half'),
+             (333, 'rand')]
     for n_bins, pattern in cases:
         if pattern == 'half':
             central = np.arange(n_bins) < n_bins // 2
