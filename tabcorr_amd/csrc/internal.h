@@ -183,6 +183,7 @@ struct tc_table {
   size_t wave_trace_count = 0;
   tc::host::PinnedBuffer h_in, h_out;
   size_t trace_blocks = 0;
+  size_t trace_launches = 0;
 
   // measurement
   bool profile_kernels = false;

@@ -241,18 +241,23 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   ca.wave_trace = nullptr;
   ca.pos_ij = nullptr;
   ca.pos_off = (const int32_t*)t->d_pos_off;
-  if (env_int("TC_TRACE", 0)) {
-    t->trace_blocks = (size_t)(ldb / 64) * n_groups * t->n_rtiles;
+  if (const int ring = env_int("TC_TRACE", 0)) {
+    // developer timelines: ring > 1 keeps the block records of the last `ring` launches
+    // (tools/occupancy.py) and skips the per-wave stamps
+    const size_t blocks = (size_t)(ldb / 64) * n_groups * t->n_rtiles;
+    t->trace_blocks = blocks * ring;
     status = t->trace.reserve(t->trace_blocks * 6 * sizeof(unsigned long long), stream);
     if (status != TC_OK) return status;
-    ca.trace = (unsigned long long*)t->trace.ptr;
-    t->wave_trace_count = t->trace_blocks * c->host.waves_per_group;
-    status = t->wave_trace.reserve(t->wave_trace_count * 6 * sizeof(unsigned long long),
-                                   stream);
-    if (status != TC_OK) return status;
-    TC_HIP(hipMemsetAsync(t->wave_trace.ptr, 0,
-                          t->wave_trace_count * 6 * sizeof(unsigned long long), stream));
-    ca.wave_trace = (unsigned long long*)t->wave_trace.ptr;
+    ca.trace = (unsigned long long*)t->trace.ptr + (t->trace_launches++ % ring) * blocks * 6;
+    if (ring == 1) {
+      t->wave_trace_count = blocks * c->host.waves_per_group;
+      status = t->wave_trace.reserve(
+          t->wave_trace_count * 6 * sizeof(unsigned long long), stream);
+      if (status != TC_OK) return status;
+      TC_HIP(hipMemsetAsync(t->wave_trace.ptr, 0,
+                            t->wave_trace_count * 6 * sizeof(unsigned long long), stream));
+      ca.wave_trace = (unsigned long long*)t->wave_trace.ptr;
+    }
   }
   ca.n_tables = 0;
   ca.k_splits = 1;
