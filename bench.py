@@ -44,11 +44,11 @@ sys.path.insert(0, REPO)
 # (v_fma_f64, clock-limited) TFLOP/s.
 FP64_PEAK_TFLOPS = 78.6
 # HBM-side traffic of one contraction launch of the default workload (10^4 draws) from the
-# committed PMC passes (profiles/r01_pmc_hbm_traffic.txt: separate rocprofv3 --pmc
+# committed PMC passes (profiles/r01_pmc_counters.txt: separate rocprofv3 --pmc
 # FETCH_SIZE / WRITE_SIZE runs of this script; FETCH_SIZE doubled per the gfx950
-# correction): 2 x 7145.5 KB + 12560 KB.  Compulsory bytes: table 0.81 MB + densities
+# correction): 2 x 7308 KB + 12560 KB.  Compulsory bytes: table 0.83 MB + densities
 # 8.0 MB + group partials 12.9 MB.  PMC counters cannot be read inside this process.
-PMC_TRAFFIC_BYTES_DEFAULT_WORKLOAD = (2 * 7145.5 + 12560.0) * 1024
+PMC_TRAFFIC_BYTES_DEFAULT_WORKLOAD = (2 * 7308.0 + 12560.0) * 1024
 
 N_PRIM, N_SEC, N_R = 50, 1, 19
 N_GAUSS = 10
@@ -250,7 +250,7 @@ def main():
                 'unit': 'TFLOP/s',
                 'frac': achieved / FP64_PEAK_TFLOPS,
                 'traffic': PMC_TRAFFIC_BYTES_DEFAULT_WORKLOAD if n_draws == 10000 else None,
-                'traffic_source': 'profiles/r01_pmc_hbm_traffic.txt (offline PMC passes)',
+                'traffic_source': 'profiles/r01_pmc_counters.txt (offline PMC passes)',
                 'flop_per_launch': flop_contract,
                 'mean_launch_ms': isolated_ms.value,
                 'launches_timed': n_launch.value,
