@@ -161,8 +161,8 @@ struct tc_table {
   std::map<std::pair<int, int>, std::unique_ptr<tc::host::DeviceChunking>> chunkings;
   std::map<int64_t, tc::host::DeviceChunking*> choices;   // decomposition chosen per tile count
 
-  // Two independent "lanes" (stream + workspaces).  Consecutive device-pointer
-  // predict calls alternate between them, so that the occupation kernel of batch k + 1
+  // Independent "lanes" (stream + workspaces; four by default, TC_LANES).  Consecutive
+  // device-pointer predict calls alternate between them, so that the occupation kernel of batch k + 1
   // overlaps the contraction of batch k (both are FP64-issue bound and the contraction
   // leaves issue slots free at its ramp-down); results are still produced in call order
   // (the finalisation kernels are chained by events).  Host-buffer calls use lane 0.

@@ -351,54 +351,41 @@ __global__ __launch_bounds__(512) void contract_mfma_kernel(ContractArgs a) {
           if (interp) w[s] *= scale[s];
         }
       };
-      auto multiply = [&](const double2v (&t)[NT], int parity, const double (&w)[4]) {
-#pragma unroll
-        for (int u = 0; u < NT; ++u)
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-            acc[s][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(parity ? t[u].y : t[u].x, w[s],
-                                                           acc[s][u], 0, 0, 0);
-      };
-
-      double2v ta[NT], tb[NT];
+      double2v t[NT];
       double ni[4], nj[4], w[4];
       unsigned long long stamps[5] = {0, 0, 0, 0, 0};
       if (a.wave_trace) stamps[0] = __builtin_amdgcn_s_memrealtime();
       if (n_pairs > 0) {
-        load_table(ta, 0);
-        int4v pa = pos(0), pb;
+        load_table(t, 0);
+        int4v pa = pos(0);
         gather(ni, nj, pa.x, pa.y);
-        const int quarter = (n_pairs / 8) * 2 > 0 ? (n_pairs / 8) * 2 : 2;
-        int pair = 0;
-        // two pairs per iteration so that the two register sets swap roles without
-        // moves; every prefetch is unconditional (clamped to the last pair)
-        for (; pair + 2 <= n_pairs; pair += 2) {
-          load_table(tb, pair + 1);
-          pb = pos(pair + 1);
+        const int quarter = (n_pairs / 4) > 0 ? (n_pairs / 4) : 1;
+        // One register set for the table values: each sub-tile's 16 bytes are reloaded for
+        // the next pair of steps right after their last use; the other resident waves of
+        // the SIMD cover the latency (the registers saved buy a fifth wave per SIMD).
+        // Every prefetch is unconditional (clamped to the last pair).
+        for (int pair = 0; pair < n_pairs; ++pair) {
+          const int next = pair + 1 < last ? pair + 1 : last;
+          const int4v pn = pos(next);
           weights(w, ni, nj);
           gather(ni, nj, pa.z, pa.w);
-          multiply(ta, 0, w);
+#pragma unroll
+          for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              acc[s][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(t[u].x, w[s], acc[s][u], 0, 0, 0);
           weights(w, ni, nj);
-          gather(ni, nj, pb.x, pb.y);
-          multiply(ta, 1, w);
-          const int next = pair + 2 < last ? pair + 2 : last;
-          load_table(ta, next);
-          pa = pos(next);
-          weights(w, ni, nj);
-          gather(ni, nj, pb.z, pb.w);
-          multiply(tb, 0, w);
-          weights(w, ni, nj);
-          gather(ni, nj, pa.x, pa.y);
-          multiply(tb, 1, w);
-          if (a.wave_trace && (pair + 2) % quarter == 0 && (pair + 2) / quarter <= 3)
-            stamps[(pair + 2) / quarter] = __builtin_amdgcn_s_memrealtime();
-        }
-        if (pair < n_pairs) {
-          weights(w, ni, nj);
-          gather(ni, nj, pa.z, pa.w);
-          multiply(ta, 0, w);
-          weights(w, ni, nj);
-          multiply(ta, 1, w);
+          gather(ni, nj, pn.x, pn.y);
+#pragma unroll
+          for (int u = 0; u < NT; ++u) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              acc[s][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(t[u].y, w[s], acc[s][u], 0, 0, 0);
+            t[u] = table[(int64_t)next * 4 * RT + u * 16];
+          }
+          pa = pn;
+          if (a.wave_trace && (pair + 1) % quarter == 0 && (pair + 1) / quarter <= 3)
+            stamps[(pair + 1) / quarter] = __builtin_amdgcn_s_memrealtime();
         }
       }
       if (a.wave_trace) {

@@ -74,12 +74,13 @@ int lds_bytes_for(const tc::Chunking& chunking, int rt, int elem) {
 }
 
 // Waves of the contraction kernel one SIMD holds, from the kernels' register counts
-// (FP64 matrix kernel 72-170 VGPRs growing with the r tile, more with the interpolator's
-// table loop; float32 kernel ~100).
+// (FP64 matrix kernel: 54 ... 128 VGPRs growing with the r tile, 76 ... 160 with the
+// interpolator's table loop; float32 kernel ~100).
 int wave_slots(const tc_table* t, bool interp) {
   if (t->compute_dtype == TC_DTYPE_F32) return 4;
-  if (interp) return t->rt <= 8 ? 4 : t->rt <= 20 ? 3 : 2;
-  return t->rt <= 12 ? 6 : t->rt <= 20 ? 4 : t->rt <= 28 ? 3 : 2;
+  const int rt = t->rt;
+  if (interp) return rt <= 4 ? 6 : rt <= 8 ? 5 : rt <= 20 ? 4 : 3;
+  return rt <= 8 ? 8 : rt <= 12 ? 7 : rt <= 16 ? 6 : rt <= 20 ? 5 : 4;
 }
 
 // Workgroups of the contraction kernel that fit on one CU: LDS (160 KiB) and wave slots.

@@ -133,7 +133,7 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
     TC_HIP(hipEventCreateWithFlags(&lane.finished, hipEventDisableTiming));
   }
   t->stream = t->lanes[0].stream;
-  t->n_lanes = std::max(1, std::min(env_int("TC_LANES", 3), (int)tc_table::kMaxLanes));
+  t->n_lanes = std::max(1, std::min(env_int("TC_LANES", 4), (int)tc_table::kMaxLanes));
   TC_HIP(hipEventCreate(&t->ev_begin));
   TC_HIP(hipEventCreate(&t->ev_end));
   int status = compute_dtype == TC_DTYPE_F64 ? upload(tmp64, &t->d_table)
