@@ -46,9 +46,9 @@ FP64_PEAK_TFLOPS = 78.6
 # HBM-side traffic of one contraction launch of the default workload (10^4 draws) from the
 # committed PMC passes (profiles/r01_pmc_counters.txt: separate rocprofv3 --pmc
 # FETCH_SIZE / WRITE_SIZE runs of this script; FETCH_SIZE doubled per the gfx950
-# correction): 2 x 7308 KB + 12560 KB.  Compulsory bytes: table 0.83 MB + densities
+# correction): 2 x 7299 KB + 12560 KB.  Compulsory bytes: table 0.83 MB + densities
 # 8.0 MB + group partials 12.9 MB.  PMC counters cannot be read inside this process.
-PMC_TRAFFIC_BYTES_DEFAULT_WORKLOAD = (2 * 7308.0 + 12560.0) * 1024
+PMC_TRAFFIC_BYTES_DEFAULT_WORKLOAD = (2 * 7299.0 + 12560.0) * 1024
 
 N_PRIM, N_SEC, N_R = 50, 1, 19
 N_GAUSS = 10
