@@ -100,6 +100,16 @@ inline size_t stage_limit() {
   return limit;
 }
 
+// Calls moving at most this many bytes skip the copy commands: the kernels address the
+// page-locked staging buffers directly (TC_ZERO_COPY_KB overrides, 0 disables).
+inline size_t zero_copy_limit() {
+  static const size_t limit = [] {
+    const char* value = getenv("TC_ZERO_COPY_KB");
+    return (size_t)(value && *value ? atoi(value) : 16) << 10;
+  }();
+  return limit;
+}
+
 template <typename T>
 int upload(const std::vector<T>& host, void** device) {
   size_t bytes = std::max<size_t>(1, host.size()) * sizeof(T);

@@ -295,12 +295,30 @@ int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
   const int n_comp = separate ? t->plan.n_components : 1;
   const size_t ngal_count = (size_t)n_draws * (separate ? 2 : 1);
   const size_t xi_count = (size_t)n_draws * n_comp * t->n_r;
-  status = t->theta.reserve((size_t)n_draws * n_theta * sizeof(double), t->stream);
+  const size_t theta_bytes = (size_t)n_draws * n_theta * sizeof(double);
+  const size_t out_bytes = (ngal_count + xi_count) * sizeof(double);
+  // Small calls (the un-batched predict() of an MCMC step): no copy commands at all.  The
+  // kernels read the draws from and write the results to page-locked host memory, which
+  // the device addresses directly; two API calls and two copy-engine round trips less.
+  if (theta_bytes + out_bytes <= zero_copy_limit() && t->h_in.reserve(theta_bytes) == TC_OK &&
+      t->h_out.reserve(out_bytes) == TC_OK) {
+    memcpy(t->h_in.ptr, theta, theta_bytes);
+    double* h = (double*)t->h_out.ptr;
+    t->force_lane = 0;
+    status = tc_predict_zheng07_batch_device(t, (const double*)t->h_in.ptr, n_theta,
+                                             n_draws, n_gauss, flags, h, h + ngal_count);
+    t->force_lane = -1;
+    if (status != TC_OK) return status;
+    TC_HIP(hipStreamSynchronize(t->stream));
+    memcpy(ngal, h, ngal_count * 8);
+    memcpy(xi, h + ngal_count, xi_count * 8);
+    return TC_OK;
+  }
+  status = t->theta.reserve(theta_bytes, t->stream);
   if (status == TC_OK) status = t->out_ngal.reserve(ngal_count * 8, t->stream);
   if (status == TC_OK) status = t->out_xi.reserve(xi_count * 8, t->stream);
   if (status != TC_OK) return status;
-  status = copy_in(&t->h_in, t->theta.ptr, theta, (size_t)n_draws * n_theta * 8,
-                   t->stream);
+  status = copy_in(&t->h_in, t->theta.ptr, theta, theta_bytes, t->stream);
   if (status != TC_OK) return status;
   t->force_lane = 0;
   status = tc_predict_zheng07_batch_device(
