@@ -477,3 +477,51 @@ print("sharded ok")
                             capture_output=True, text=True, timeout=900)
     assert result.returncode == 0, result.stdout[-2000:] + result.stderr[-2000:]
     assert 'sharded ok' in result.stdout
+
+
+def test_random_shapes_against_oracle():
+    """Seeded sweep over table shapes the fixtures do not cover: every r tile width
+    (R = 1 .. 70: sub-tiles of 4, one to three r tiles), odd bin counts, both modes,
+    shuffled gal_type rows, batch sizes around the 64-draw tile -- float64 HIP path against
+    the NumPy oracle."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+    from oracle import tabcorr_oracle as oracle
+    from tabcorr_amd import synthetic
+    rng = np.random.default_rng(2024)
+    cases = [(1, 1, (1, ), 'auto'), (1, 1, (3, ), 'cross'), (3, 1, (4, ), 'auto'),
+             (5, 1, (5, ), 'auto'), (7, 1, (8, ), 'cross'), (9, 1, (11, ), 'auto'),
+             (11, 1, (13, ), 'auto'), (6, 2, (16, ), 'auto'), (13, 1, (17, ), 'cross'),
+             (8, 1, (21, ), 'auto'), (10, 1, (24, ), 'auto'), (4, 3, (27, ), 'auto'),
+             (12, 1, (29, ), 'cross'), (9, 1, (32, ), 'auto'), (7, 1, (33, ), 'auto'),
+             (5, 2, (6, 7), 'auto'), (17, 1, (64, ), 'auto'), (6, 1, (7, 10), 'cross'),
+             (40, 1, (19, ), 'auto'), (33, 2, (10, ), 'auto')]
+    for index, (n_prim, n_sec, shape, mode) in enumerate(cases):
+        table = synthetic.synthetic_table(n_prim, n_sec, shape, mode, seed=100 + index)
+        n_bins = len(table['gal_type'])
+        if index % 2 == 1 and mode == 'auto' and n_bins > 2:
+            # arbitrary row order: permute rows and the packed matrix consistently
+            perm = rng.permutation(n_bins)
+            full = np.zeros((table['tpcf_matrix'].shape[0], n_bins, n_bins))
+            rows, cols = np.tril_indices(n_bins)
+            full[:, rows, cols] = table['tpcf_matrix']
+            full[:, cols, rows] = table['tpcf_matrix']
+            full = full[:, perm][:, :, perm]
+            table['gal_type'] = table['gal_type'][perm]
+            table['tpcf_matrix'] = np.ascontiguousarray(full[:, rows, cols])
+        n_draws = int(rng.choice([1, 2, 37, 64, 65, 130]))
+        theta = synthetic.zheng07_draws(n_draws, seed=500 + index)
+        halotab = make_tabcorr(table)
+        expect_ngal, expect_xi = oracle.predict_zheng07_batch(table, theta)
+        ngal, xi = halotab.predict_batch(theta)
+        assert xi.shape == (n_draws, ) + tuple(shape)
+        assert_rel(ngal, expect_ngal, RTOL)
+        assert_rel(xi, expect_xi, RTOL)
+        if index % 3 == 0:
+            expect_n, expect_x = oracle.predict_zheng07_batch(
+                table, theta, separate_gal_type=True)
+            ngal_sep, xi_sep = halotab.predict_batch(theta, separate_gal_type=True)
+            for key in expect_x:
+                assert_rel(xi_sep[key], expect_x[key], RTOL)
+            for key in expect_n:
+                assert_rel(ngal_sep[key], expect_n[key], RTOL)
