@@ -105,7 +105,7 @@ inline size_t stage_limit() {
 inline size_t zero_copy_limit() {
   static const size_t limit = [] {
     const char* value = getenv("TC_ZERO_COPY_KB");
-    return (size_t)(value && *value ? atoi(value) : 16) << 10;
+    return (size_t)(value && *value ? atoi(value) : 1024) << 10;
   }();
   return limit;
 }

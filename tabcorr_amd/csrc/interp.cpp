@@ -26,6 +26,7 @@ struct tc_interp {
   std::vector<DeviceBuffer> nbuf, ngal2;    // per class
   std::vector<void*> nbuf_ptrs, ngal_ptrs;  // last uploaded pointer values
   DeviceBuffer theta, x, coef, partial, out_ngal, out_xi;
+  PinnedBuffer h_in, h_out;
   std::map<std::pair<int, int>, std::unique_ptr<DeviceChunking>> chunkings;
 };
 
@@ -299,6 +300,8 @@ int tc_interp_destroy(tc_interp* it) {
   for (DeviceBuffer* b : {&it->theta, &it->x, &it->coef, &it->partial, &it->out_ngal,
                           &it->out_xi})
     b->release();
+  it->h_in.release();
+  it->h_out.release();
   if (it->stream) (void)hipStreamDestroy(it->stream);
   delete it;
   return TC_OK;
@@ -356,6 +359,25 @@ int tc_interp_predict_zheng07_batch(tc_interp* it, const double* theta, int n_th
   const int n_comp = separate ? it->tables[0]->plan.n_components : 1;
   const size_t ngal_count = (size_t)n_draws * (separate ? 2 : 1);
   const size_t xi_count = (size_t)n_draws * n_comp * it->tables[0]->n_r;
+  const size_t theta_count = (size_t)n_draws * n_theta, x_count = (size_t)n_draws * it->n_dim;
+  // small and medium calls: the kernels address page-locked host buffers directly
+  // (table.cpp: tc_predict_zheng07_batch)
+  if ((theta_count + x_count + ngal_count + xi_count) * 8 <= zero_copy_limit() &&
+      it->h_in.reserve((theta_count + x_count) * 8) == TC_OK &&
+      it->h_out.reserve((ngal_count + xi_count) * 8) == TC_OK) {
+    double* in = (double*)it->h_in.ptr;
+    double* out = (double*)it->h_out.ptr;
+    memcpy(in, theta, theta_count * 8);
+    memcpy(in + theta_count, x, x_count * 8);
+    status = tc_interp_predict_zheng07_batch_device(it, in, n_theta, in + theta_count,
+                                                    n_draws, n_gauss, flags, out,
+                                                    out + ngal_count);
+    if (status != TC_OK) return status;
+    TC_HIP(hipStreamSynchronize(it->stream));
+    memcpy(ngal, out, ngal_count * 8);
+    memcpy(xi, out + ngal_count, xi_count * 8);
+    return TC_OK;
+  }
   status = it->theta.reserve((size_t)n_draws * n_theta * 8, it->stream);
   if (status == TC_OK) status = it->x.reserve((size_t)n_draws * it->n_dim * 8, it->stream);
   if (status == TC_OK) status = it->out_ngal.reserve(ngal_count * 8, it->stream);

@@ -297,9 +297,11 @@ int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
   const size_t xi_count = (size_t)n_draws * n_comp * t->n_r;
   const size_t theta_bytes = (size_t)n_draws * n_theta * sizeof(double);
   const size_t out_bytes = (ngal_count + xi_count) * sizeof(double);
-  // Small calls (the un-batched predict() of an MCMC step): no copy commands at all.  The
-  // kernels read the draws from and write the results to page-locked host memory, which
-  // the device addresses directly; two API calls and two copy-engine round trips less.
+  // Small and medium calls (the un-batched predict() of an MCMC step, an ensemble of a few
+  // thousand walkers): no copy commands at all.  The kernels read the draws from and write
+  // the results to page-locked host memory, which the device addresses directly; two API
+  // calls and two copy-engine round trips less (1 draw 45 -> 40 us, 1000 draws 72 -> 54 us;
+  // beyond ~1 MB the copy engines win).
   if (theta_bytes + out_bytes <= zero_copy_limit() && t->h_in.reserve(theta_bytes) == TC_OK &&
       t->h_out.reserve(out_bytes) == TC_OK) {
     memcpy(t->h_in.ptr, theta, theta_bytes);
