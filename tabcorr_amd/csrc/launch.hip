@@ -452,8 +452,12 @@ int check_predict_args(const tc_table* t, const void* theta, int n_theta,
 }
 
 int launch_finalize(const FinalizeArgs& args, hipStream_t stream) {
-  hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)(args.ldb / 64)),
-                     dim3(env_int("TC_FINALIZE_THREADS", 256)), 0, stream, args);
+  // one block per draw tile; a wave sums one (component, r) row at a time over the slabs,
+  // so small batches (few blocks, latency-bound) get 16 waves per block instead of 4
+  const int64_t n_tiles = args.ldb / 64;
+  const int threads = env_int("TC_FINALIZE_THREADS", n_tiles < 128 ? 1024 : 256);
+  hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)n_tiles), dim3(threads), 0, stream,
+                     args);
   TC_HIP(hipGetLastError());
   return TC_OK;
 }
