@@ -30,3 +30,17 @@ for n_draws in (10000, 100000, 200000):
     print('%7d draws: %8.1f us per launch = %.1f us per 10^4 draws = %.1f TFLOP/s' % (
         n_draws, dt * 1e6, dt * 1e6 * 1e4 / n_draws, n_draws * 2.0705e5 / dt / 1e12))
     lib.tc_device_free(d_theta); lib.tc_device_free(d_out)
+if os.environ.get('TC_TRACE'):
+    n = ctypes.c_int64()
+    _lib.check(lib.tc_debug_trace(dev.handle, None, 0, ctypes.byref(n)))
+    rec = np.zeros((n.value, 6), dtype=np.uint64)
+    _lib.check(lib.tc_debug_trace(dev.handle, rec.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n.value, ctypes.byref(n)))
+    rec = rec[rec[:, 0] > 0]
+    staged = rec[:, 1].astype(np.int64); main = rec[:, 2].astype(np.int64)
+    cycles = (rec[:, 5] >> np.uint64(4)).astype(np.float64)
+    ok = main > staged
+    clock = cycles[ok] / ((main[ok] - staged[ok]) * 10.0)
+    print('shader clock during the main loops of the last launch: median %.3f GHz (10%% %.3f, 90%% %.3f)' % tuple(np.percentile(clock, [50, 10, 90])))
+    print('block phases (us): stage %.2f main %.2f tail %.2f' % (
+        np.median(staged - rec[:, 0].astype(np.int64)) / 100.0, np.median(main - staged) / 100.0,
+        np.median(rec[:, 3].astype(np.int64) - main) / 100.0))
