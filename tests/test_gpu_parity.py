@@ -212,6 +212,17 @@ def test_ragged_and_empty_batches():
         expect = oracle.predict_zheng07_batch(table, theta)
         assert_rel(ngal, expect[0], RTOL)
         assert_rel(xi, expect[1], RTOL)
+    # either side of the 1 MB limit below which a call uses no copy commands (the kernels
+    # address page-locked host buffers): same draws, same results (up to the summation
+    # order of a different launch decomposition)
+    theta = synthetic.zheng07_draws(5400, seed=7)
+    ngal_copy, xi_copy = halotab.predict_batch(theta)              # 1.08 MB: copy engines
+    ngal_direct, xi_direct = halotab.predict_batch(theta[:5200])   # 1.04 MB: direct
+    assert_rel(ngal_copy[:5200], ngal_direct, 1e-13)
+    assert_rel(xi_copy[:5200], xi_direct, 1e-13)
+    expect = oracle.predict_zheng07_batch(table, theta[::270])
+    assert_rel(ngal_copy[::270], expect[0], RTOL)
+    assert_rel(xi_copy[::270], expect[1], RTOL)
 
 
 # -- Interpolator -------------------------------------------------------------------
