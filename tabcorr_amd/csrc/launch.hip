@@ -105,11 +105,13 @@ int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
   const int elem = t->compute_dtype == TC_DTYPE_F32 ? 4 : 8;
   const int forced_groups = env_int("TC_NGROUPS", 0);
   const int forced_waves = env_int("TC_NWAVES", 0);
-  if (forced_groups == 0 && forced_waves == 0) {
-    auto cached = t->choices.find(n_tiles);
+  // (the developer overrides are part of the key: sweeps stay cheap on the host)
+  const int64_t key = n_tiles * 4096 + forced_groups * 64 + forced_waves;
+  {
+    auto cached = t->choices.find(key);
     if (cached != t->choices.end()) {
       *out = cached->second;
-      *lds_bytes = lds_bytes_for((*out)->host, t->rt, elem);
+      *lds_bytes = std::max(lds_bytes_for((*out)->host, t->rt, elem), env_int("TC_LDS_MIN", 0));
       return TC_OK;
     }
   }
@@ -161,7 +163,7 @@ int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
   DeviceChunking* c = nullptr;
   int status = get_chunking(t, best_chunks, best_waves, &c);
   if (status != TC_OK) return status;
-  if (forced_groups == 0 && forced_waves == 0) t->choices[n_tiles] = c;
+  t->choices[key] = c;
   *out = c;
   *lds_bytes = std::max(lds_bytes_for(c->host, t->rt, elem), env_int("TC_LDS_MIN", 0));
   return TC_OK;
