@@ -189,7 +189,7 @@ struct tc_table {
   int cur = 0;                       // lane of the current / last predict call
   int force_lane = -1;               // host-buffer entry points pin lane 0
   uint64_t device_calls = 0;
-  tc::host::DeviceBuffer theta, out_ngal, out_xi, occupation, trace, wave_trace;
+  tc::host::DeviceBuffer theta, out_ngal, out_xi, occupation, trace, wave_trace, single_ws;
   size_t wave_trace_count = 0;
   tc::host::PinnedBuffer h_in, h_out;
   size_t trace_blocks = 0;
@@ -233,6 +233,9 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
 int check_predict_args(const tc_table* t, const void* theta, int n_theta, int64_t n_draws,
                        int n_gauss, unsigned flags);
 int launch_finalize(const FinalizeArgs& args, hipStream_t stream);
+bool single_draw_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags);
+int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_gauss,
+                       unsigned flags, double* ngal, double* xi, hipStream_t stream);
 int launch_interp_coef(const InterpArgs& args, hipStream_t stream);
 int launch_occ_from_array(tc_table* t, const double* occupation_device, int64_t n_draws,
                           int64_t ldb, double* nbuf, double* ngal2, hipStream_t stream);

@@ -44,6 +44,33 @@ struct OccArgs {
   double* occupation;      // optional (n_draws, n_bins) in reference order
 };
 
+// Un-batched predict(): one draw through one launch (single_draw_kernel).
+struct SingleArgs {
+  double theta_value[7];     // the draw, by value
+  int n_theta;
+  int n_bins;
+  int n_central;
+  int n_gauss;
+  unsigned flags;
+  double split;
+  const double* log_m;       // quadrature constants as in OccArgs
+  const double* m;
+  const double* weight;
+  const double* n_h;
+  const double* percentile;
+  const double* math_table;
+  const double* table;       // re-laid-out matrix of the single r tile
+  const int32_t* pos_off;
+  int64_t n_positions;
+  int rt;
+  int n_r;
+  int mode;
+  double* partial;           // (blocks, rt)
+  unsigned* counter;         // workgroups that have delivered their partial sums
+  double* ngal;              // (1), may live in page-locked host memory
+  double* xi;                // (n_r)
+};
+
 struct ContractArgs {
   const double* nbuf;       // (n_bins, ldb)
   int64_t ldb;

@@ -450,6 +450,154 @@ __global__ __launch_bounds__(512) void contract_mfma_kernel(ContractArgs a) {
   }
 }
 
+// ---- un-batched predict(): one draw, one launch ---------------------------------------
+//
+// The reference's usage is one predict() per MCMC step.  Three launches for one draw are
+// latency, not work (7 + 8 + 5 us of kernels back to back), so a single draw goes
+// through one kernel: every workgroup evaluates all G * n_gauss occupation nodes (one
+// node per thread and pass, per-bin sums in fixed order), contracts its share of the table
+// positions (thread = r value x slice of positions), and the last workgroup to deliver its
+// partial sums (device-scope fence + counter) adds them in fixed order, normalises and
+// writes the result -- deterministic like the batched path.  Total correlation function
+// only, one r tile, G * n_gauss <= kSingleMaxNodes.
+constexpr int kSingleThreads = 1024;
+constexpr int kSingleMaxNodes = 4096;
+constexpr int kSingleMaxBins = 1024;
+
+__global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs a) {
+  __shared__ double node_value[kSingleMaxNodes];
+  __shared__ double density[kSingleMaxBins];
+  __shared__ double slice_sum[kSingleThreads];
+  __shared__ __attribute__((aligned(16))) double table[fm::kTableDoubles];
+  __shared__ double ngal_sum[2];
+  __shared__ int is_last;
+  const int tid = threadIdx.x;
+  const fm::Consts kc = fm::make_consts();
+
+  // everything here is latency: the draw arrives in the kernel arguments, the math tables
+  // are staged in LDS
+  const double log_m_min = a.theta_value[0], sigma = a.theta_value[1];
+  const double log_m0 = a.theta_value[2], log_m1 = a.theta_value[3];
+  const double alpha = a.theta_value[4];
+  const bool assembias = (a.flags & kFlagAssembias) != 0;
+  const bool modulate = (a.flags & kFlagModulate) != 0;
+  const double a_cen = assembias ? a.theta_value[5] : 0.0;
+  const double a_sat = assembias ? a.theta_value[6] : 0.0;
+  const int n_nodes = a.n_bins * a.n_gauss;
+  {
+    typedef double __attribute__((ext_vector_type(2))) double2v;
+    const double2v* src = (const double2v*)a.math_table;
+    double2v* dst = (double2v*)table;
+    for (int i = tid; i < fm::kTableDoubles / 2; i += kSingleThreads) dst[i] = src[i];
+  }
+  __syncthreads();
+  const double inv_sigma = 1.0 / sigma;
+  const double m0 = fm::exp10_fast(table, kc, log_m0);
+  const double log2_m1 = log_m1 * fm::kLog2Of10Hi;
+  const double log2_m1_lo =
+      fma(log_m1, fm::kLog2Of10Hi, -log2_m1) + log_m1 * fm::kLog2Of10Lo;
+  const double sat_scale = fma(-alpha * fm::kLn2, log2_m1_lo, 1.0);
+  const double f1 = (1.0 - a.split) / a.split, f2 = a.split / (1.0 - a.split);
+
+  for (int idx = tid; idx < n_nodes; idx += kSingleThreads) {
+    const int g = idx / a.n_gauss;
+    const double lm = a.log_m[idx], mass = a.m[idx], wk = a.weight[idx];
+    const bool above = a.percentile[g] > a.split;
+    double n;
+    if (g < a.n_central) {
+      n = fma(0.5, fm::erf_fast(table, kc, (lm - log_m_min) * inv_sigma), 0.5);
+      if (assembias) n = heaviside_assembias(n, a_cen, above, f2, f1, true);
+    } else {
+      const double x = mass - m0;
+      n = fm::exp2_fast(
+          table, kc,
+          alpha * fm::log2_fast_offset(table, kc, x > 1e-300 ? x : 1e-300, log2_m1),
+          x > 0.0);
+      n *= sat_scale;
+      if (modulate)
+        n *= fma(0.5, fm::erf_fast(table, kc, (lm - log_m_min) * inv_sigma), 0.5);
+      if (assembias) n = heaviside_assembias(n, a_sat, above, f2, f1, false);
+    }
+    node_value[idx] = wk * n;
+  }
+  __syncthreads();
+  for (int g = tid; g < a.n_bins; g += kSingleThreads) {
+    double acc = 0.0;
+    for (int k = 0; k < a.n_gauss; ++k) acc += node_value[g * a.n_gauss + k];
+    density[g] = acc * a.n_h[g];
+  }
+  __syncthreads();
+  if (tid < 128) {   // centrals / satellites totals: one wave each, fixed order
+    const int which = tid >> 6, lane = tid & 63;
+    const int lo = which == 0 ? 0 : a.n_central, hi = which == 0 ? a.n_central : a.n_bins;
+    double total = 0.0;
+    for (int g = lo + lane; g < hi; g += 64) total += density[g];
+#pragma unroll
+    for (int offset = 32; offset >= 1; offset >>= 1) total += __shfl_down(total, offset, 64);
+    if (lane == 0) ngal_sum[which] = total;
+  }
+
+  // contraction of this workgroup's positions: thread = (slice, r); eight positions per
+  // pass, their loads issued together
+  const int rt = a.rt;
+  const int n_slices = kSingleThreads / rt;
+  const int r = tid % rt, slice = tid / rt;
+  const int64_t per_block = (a.n_positions + gridDim.x - 1) / gridDim.x;
+  const int64_t q_begin = per_block * blockIdx.x;
+  const int64_t q_end = q_begin + per_block < a.n_positions ? q_begin + per_block
+                                                             : a.n_positions;
+  double acc = 0.0;
+  if (slice < n_slices && q_begin < q_end) {
+    for (int64_t q0 = q_begin + slice; q0 < q_end; q0 += 8 * n_slices) {
+      int off_i[8], off_j[8];
+      double value[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t qu = q0 + (int64_t)u * n_slices;
+        const int64_t q = qu < q_end ? qu : q_begin;
+        // layouts of table.cpp: blocks of 8 positions, LDS row offsets per position
+        const int64_t slot = ((q >> 3) * 4 + (q & 3)) * 4 + ((q >> 2) & 1) * 2;
+        off_i[u] = a.pos_off[slot];
+        off_j[u] = a.pos_off[slot + 1];
+        const int64_t index = (q >> 3) * 8 * rt +
+                              ((((r >> 2) * 16 + (q & 3) * 4 + (r & 3)) << 1) + ((q >> 2) & 1));
+        value[u] = qu < q_end ? a.table[index] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        double w = density[off_j[u] >> 9];
+        if (a.mode == 0) w *= density[off_i[u] >> 9];
+        acc = fma(value[u], w, acc);
+      }
+    }
+  }
+  slice_sum[tid] = acc;
+  __syncthreads();
+  if (tid < rt) {
+    double total = 0.0;
+    for (int s = 0; s < n_slices; ++s) total += slice_sum[s * rt + tid];
+    a.partial[(int64_t)blockIdx.x * rt + tid] = total;
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) is_last = atomicAdd(a.counter, 1u) == gridDim.x - 1 ? 1 : 0;
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  const double n_total = ngal_sum[0] + ngal_sum[1];
+  const double norm = a.mode == 0 ? n_total * n_total : n_total;
+  if (tid < a.n_r) {
+    double total = 0.0;
+    for (unsigned b = 0; b < gridDim.x; ++b)
+      total += __builtin_nontemporal_load(a.partial + (int64_t)b * rt + tid);
+    a.xi[tid] = total / norm;
+  }
+  if (tid == 0) {
+    a.ngal[0] = n_total;
+    *a.counter = 0u;
+  }
+}
+
 // ---- float32 variant for tables with many correlation-function bins -------------------
 //
 // BASELINE configs[4]: R = 760 (rp x pi), G ~ 200.  With hundreds of r values the

@@ -453,6 +453,58 @@ int check_predict_args(const tc_table* t, const void* theta, int n_theta,
   return TC_OK;
 }
 
+// Un-batched predict(): one draw through single_draw_kernel, or TC_ERR_UNSUPPORTED when
+// the call does not qualify (the caller then takes the batched path).
+bool single_draw_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags) {
+  return n_draws == 1 && t->compute_dtype == TC_DTYPE_F64 && t->n_rtiles == 1 &&
+         !(flags & TC_FLAG_SEPARATE_GAL_TYPE) && t->n_bins <= tc::kSingleMaxBins &&
+         (int64_t)t->n_bins * n_gauss <= tc::kSingleMaxNodes && env_int("TC_SINGLE_DRAW", 1);
+}
+
+int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_gauss,
+                       unsigned flags, double* ngal, double* xi, hipStream_t stream) {
+  Quadrature* q = nullptr;
+  int status = get_quadrature(t, n_gauss, &q);
+  if (status != TC_OK) return status;
+  const int blocks =
+      (int)std::max<int64_t>(1, std::min<int64_t>(48, t->plan.n_positions / 400));
+  const size_t partial_bytes = (size_t)blocks * t->rt * sizeof(double);
+  if (t->single_ws.ptr == nullptr) {
+    status = t->single_ws.reserve(48 * 32 * sizeof(double) + 64, stream);
+    if (status != TC_OK) return status;
+    TC_HIP(hipMemsetAsync(t->single_ws.ptr, 0, t->single_ws.bytes, stream));
+  }
+  (void)partial_bytes;
+  tc::SingleArgs sa;
+  for (int i = 0; i < 7; ++i) sa.theta_value[i] = i < n_theta ? theta[i] : 0.0;
+  sa.n_theta = n_theta;
+  sa.n_bins = t->n_bins;
+  sa.n_central = t->plan.n_central;
+  sa.n_gauss = n_gauss;
+  sa.flags = flags;
+  sa.split = 0.5;
+  sa.log_m = (const double*)q->log_m;
+  sa.m = (const double*)q->m;
+  sa.weight = (const double*)q->weight;
+  sa.n_h = (const double*)t->d_n_h;
+  sa.percentile = (const double*)t->d_percentile;
+  sa.math_table = (const double*)t->d_math_table;
+  sa.table = (const double*)t->d_table;
+  sa.pos_off = (const int32_t*)t->d_pos_off;
+  sa.n_positions = t->plan.n_positions;
+  sa.rt = t->rt;
+  sa.n_r = t->n_r;
+  sa.mode = t->mode;
+  sa.partial = (double*)t->single_ws.ptr;
+  sa.counter = (unsigned*)((char*)t->single_ws.ptr + 48 * 32 * sizeof(double));
+  sa.ngal = ngal;
+  sa.xi = xi;
+  hipLaunchKernelGGL(tc::single_draw_kernel, dim3((unsigned)blocks),
+                     dim3(tc::kSingleThreads), 0, stream, sa);
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+
 int launch_finalize(const FinalizeArgs& args, hipStream_t stream) {
   // one block per draw tile; a wave sums one (component, r) row at a time over the slabs,
   // so small batches (few blocks, latency-bound) get 16 waves per block instead of 4

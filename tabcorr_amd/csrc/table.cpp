@@ -173,7 +173,7 @@ int tc_table_destroy(tc_table* t) {
     for (void* p : {kv.second->chunks, kv.second->groups})
       if (p) (void)hipFree(p);
   for (DeviceBuffer* b : {&t->theta, &t->out_ngal, &t->out_xi, &t->occupation,
-                          &t->trace, &t->wave_trace})
+                          &t->trace, &t->wave_trace, &t->single_ws})
     b->release();
   for (tc_table::Lane& lane : t->lanes) {
     lane.nbuf.release();
@@ -306,10 +306,16 @@ int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
       t->h_out.reserve(out_bytes) == TC_OK) {
     memcpy(t->h_in.ptr, theta, theta_bytes);
     double* h = (double*)t->h_out.ptr;
-    t->force_lane = 0;
-    status = tc_predict_zheng07_batch_device(t, (const double*)t->h_in.ptr, n_theta,
-                                             n_draws, n_gauss, flags, h, h + ngal_count);
-    t->force_lane = -1;
+    if (single_draw_eligible(t, n_draws, n_gauss, flags)) {
+      // one draw: one launch (kernels.hip.h: single_draw_kernel)
+      status = launch_single_draw(t, theta, n_theta, n_gauss, flags, h, h + ngal_count,
+                                  t->stream);
+    } else {
+      t->force_lane = 0;
+      status = tc_predict_zheng07_batch_device(t, (const double*)t->h_in.ptr, n_theta,
+                                               n_draws, n_gauss, flags, h, h + ngal_count);
+      t->force_lane = -1;
+    }
     if (status != TC_OK) return status;
     TC_HIP(hipStreamSynchronize(t->stream));
     memcpy(ngal, h, ngal_count * 8);

@@ -30,6 +30,11 @@ def check_against_golden(halotab, data, table, suffix='', prefix='',
     ngal, xi = halotab.predict_batch(theta, **kwargs)
     assert_rel(ngal, data[prefix + 'ngal' + suffix], RTOL, 'ngal')
     assert_rel(xi, data[prefix + 'xi' + suffix], RTOL, 'xi')
+    # one draw at a time: the un-batched path (a single fused launch where it applies)
+    for index in range(min(3, len(theta))):
+        ngal_1, xi_1 = halotab.predict_batch(theta[index:index + 1], **kwargs)
+        assert_rel(ngal_1[0], data[prefix + 'ngal' + suffix][index], RTOL, 'ngal')
+        assert_rel(xi_1[0], data[prefix + 'xi' + suffix][index], RTOL, 'xi')
     ngal_sep, xi_sep = halotab.predict_batch(
         theta, separate_gal_type=True, **kwargs)
     assert list(ngal_sep.keys()) == ['centrals', 'satellites']
