@@ -151,7 +151,8 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   ca.coef = (const double*)it->coef.ptr;
   ca.n_tiles = (int)n_tiles;
   ca.n_slabs = n_groups * k_splits;
-  dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * n_groups * k_splits), 1,
+  const int64_t padded_tiles = n_tiles >= 8 ? (n_tiles + 7) / 8 * 8 : n_tiles;
+  dim3 grid((unsigned)(padded_tiles * n_groups * k_splits), 1,
             (unsigned)t0->n_rtiles);
   dim3 block(64 * c->host.waves_per_group);
   if (lds > 64 * 1024) {

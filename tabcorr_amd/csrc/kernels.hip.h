@@ -207,7 +207,10 @@ __global__ __launch_bounds__(256) void occ_from_array_kernel(
 //
 // partial[slab][r][draw] = sum over the slab's table positions q of T[q][r] w[q][draw],
 // w = n_i n_j of the position's bin pair (tabcorr.py:626-655 with the pair prefactor
-// folded into T).  grid = (8 * ceil(tiles / 8) * slabs, 1, r tiles); a workgroup stages
+// folded into T).  grid = (8 * ceil(tiles / 8) * slabs, 1, r tiles), XCD-aware: linear
+// block id b runs on XCD b % 8 (each with its own L2) and all slabs of a draw tile get
+// ids with the same b % 8, so the tile's density rows, re-read by every slab, come from
+// that XCD's L2.  A workgroup stages
 // the density rows of its group's bins for its draw tile in LDS, each wave walks one
 // chunk of positions, the waves' sums are combined by a fixed-order tree in LDS.
 //
@@ -237,10 +240,16 @@ __global__ __launch_bounds__(512) void contract_mfma_kernel(ContractArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_waves = blockDim.x >> 6;
-  const int xcd = blockIdx.x & 7;
-  const int rest = blockIdx.x >> 3;
-  const int tile = (rest / a.n_slabs) * 8 + xcd;
-  const int slab = rest % a.n_slabs;
+  int tile, slab;
+  if (a.n_tiles >= 8) {
+    const int xcd = blockIdx.x & 7;
+    const int rest = blockIdx.x >> 3;
+    tile = (rest / a.n_slabs) * 8 + xcd;
+    slab = rest % a.n_slabs;
+  } else {   // fewer draw tiles than XCDs: no padding of the grid
+    tile = blockIdx.x / a.n_slabs;
+    slab = blockIdx.x % a.n_slabs;
+  }
   if (tile >= a.n_tiles) return;
   const int64_t col = (int64_t)tile * kLanes;
 
@@ -623,10 +632,16 @@ __global__ __launch_bounds__(512) void contract_f32_kernel(ContractArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_waves = blockDim.x >> 6;
-  const int xcd = blockIdx.x & 7;
-  const int rest = blockIdx.x >> 3;
-  const int tile = (rest / a.n_slabs) * 8 + xcd;
-  const int slab = rest % a.n_slabs;
+  int tile, slab;
+  if (a.n_tiles >= 8) {
+    const int xcd = blockIdx.x & 7;
+    const int rest = blockIdx.x >> 3;
+    tile = (rest / a.n_slabs) * 8 + xcd;
+    slab = rest % a.n_slabs;
+  } else {   // fewer draw tiles than XCDs: no padding of the grid
+    tile = blockIdx.x / a.n_slabs;
+    slab = blockIdx.x % a.n_slabs;
+  }
   if (tile >= a.n_tiles) return;
   const int64_t col = (int64_t)tile * kLanes;
   const Group group = a.groups[slab];
@@ -730,6 +745,7 @@ __global__ __launch_bounds__(512) void contract_f32_kernel(ContractArgs a) {
 // goes through LDS.
 __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
   __shared__ double tile[kFinalizeRows][kLanes + 1];
+  __shared__ double part_sum[16][kLanes];
   __shared__ double norm_inv[kLanes];
   __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63;
@@ -746,7 +762,7 @@ __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
     }
     const double total = n_cen + n_sat;
     norm_inv[lane] = a.mode == 0 ? total * total : total;
-    if (lane < n_valid) {
+    if (lane < n_valid && blockIdx.y == 0) {
       if (a.n_comp == 1) {
         a.ngal[col + lane] = total;
       } else {
@@ -761,27 +777,52 @@ __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
   const int n_rows = a.n_comp * a.n_r;
   const int n_waves = blockDim.x >> 6;
   const int n_slabs = a.n_groups * a.k_splits;
-  for (int row0 = 0; row0 < n_rows; row0 += kFinalizeRows) {
-    const int rows = n_rows - row0 < kFinalizeRows ? n_rows - row0 : kFinalizeRows;
-    for (int rr = wave; rr < rows; rr += n_waves) {
-      const int c = (row0 + rr) / a.n_r, r = (row0 + rr) % a.n_r;
-      const double* src = a.partial + (int64_t)r * a.ldb + col + lane;
-      const int64_t slab = (int64_t)a.r_stride * a.ldb;
-      double sum = 0.0;
-      // eight independent loads in flight; the additions keep the slab order
-      for (int g0 = 0; g0 < n_slabs; g0 += 8) {
-        double v[8];
+  // rows of this block (grid.y row blocks; one for large batches)
+  const int rows_per_block = (n_rows + gridDim.y - 1) / gridDim.y;
+  const int row_begin = blockIdx.y * rows_per_block;
+  const int row_end = row_begin + rows_per_block < n_rows ? row_begin + rows_per_block : n_rows;
+  const int64_t slab = (int64_t)a.r_stride * a.ldb;
+  // sum of the slabs [g_begin, g_end) of one row, eight independent loads in flight, the
+  // additions in slab order
+  auto sum_slabs = [&](int row, int g_begin, int g_end) {
+    const int c = row / a.n_r, r = row % a.n_r;
+    const double* src = a.partial + (int64_t)r * a.ldb + col + lane;
+    double sum = 0.0;
+    for (int g0 = g_begin; g0 < g_end; g0 += 8) {
+      double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int g = g0 + u;
-          const bool use = g < n_slabs &&
-                           (a.n_comp == 1 || a.groups[g / a.k_splits].component == c);
-          v[u] = use ? src[g * slab] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) sum += v[u];
+      for (int u = 0; u < 8; ++u) {
+        const int g = g0 + u;
+        const bool use = g < g_end &&
+                         (a.n_comp == 1 || a.groups[g / a.k_splits].component == c);
+        v[u] = use ? src[g * slab] : 0.0;
       }
-      tile[rr][lane] = sum / norm;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    return sum;
+  };
+  for (int row0 = row_begin; row0 < row_end; row0 += kFinalizeRows) {
+    const int rows = row_end - row0 < kFinalizeRows ? row_end - row0 : kFinalizeRows;
+    if (rows * 2 <= n_waves) {
+      // few rows (small batches, split over row blocks): several waves per row, each
+      // over a contiguous range of slabs, combined in fixed order
+      const int parts = n_waves / rows;
+      const int rr = wave / parts, part = wave % parts;
+      if (rr < rows) {
+        const int g_begin = (int)((int64_t)n_slabs * part / parts);
+        const int g_end = (int)((int64_t)n_slabs * (part + 1) / parts);
+        part_sum[wave][lane] = sum_slabs(row0 + rr, g_begin, g_end);
+      }
+      __syncthreads();
+      if (wave < rows) {
+        double sum = 0.0;
+        for (int p = 0; p < parts; ++p) sum += part_sum[wave * parts + p][lane];
+        tile[wave][lane] = sum / norm;
+      }
+    } else {
+      for (int rr = wave; rr < rows; rr += n_waves)
+        tile[rr][lane] = sum_slabs(row0 + rr, 0, n_slabs) / norm;
     }
     __syncthreads();
     // out[(col + d) * n_rows + row0 + rr]
@@ -818,15 +859,24 @@ __global__ __launch_bounds__(64) void interp_coef_kernel(InterpArgs a) {
       weight[d][j][lane] = m[j] + m[n + j] * x + m[2 * n + j] * x2 + m[3 * n + j] * x3;
   }
   double n_cen = 0.0, n_sat = 0.0;
+  int summed_class = -1;
+  double cen = 0.0, sat = 0.0;
   for (int k = 0; k < a.n_tables; ++k) {
     double c = 1.0;
     for (int d = 0; d < a.n_dim; ++d)
       c *= weight[d][a.table_node[k * a.n_dim + d]][lane];
-    const double* parts = a.ngal_parts[a.table_class[k]];
-    double cen = 0.0, sat = 0.0;
-    for (int p = 0; p < a.n_ngal_parts; ++p) {
-      cen += parts[((int64_t)p * 2 + 0) * a.ldb + b0];
-      sat += parts[((int64_t)p * 2 + 1) * a.ldb + b0];
+    // the densities of a class of identical halo tables are summed once (tables of one
+    // class are usually all of them)
+    const int density_class = a.table_class[k];
+    if (density_class != summed_class) {
+      const double* parts = a.ngal_parts[density_class];
+      cen = 0.0;
+      sat = 0.0;
+      for (int p = 0; p < a.n_ngal_parts; ++p) {
+        cen += parts[((int64_t)p * 2 + 0) * a.ldb + b0];
+        sat += parts[((int64_t)p * 2 + 1) * a.ldb + b0];
+      }
+      summed_class = density_class;
     }
     const double total = cen + sat;
     a.coef[(int64_t)k * a.ldb + b0] = c / (a.mode == 0 ? total * total : total);

@@ -273,7 +273,8 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   const int n_tiles = (int)(ldb / 64);
   ca.n_tiles = n_tiles;
   ca.n_slabs = n_groups;
-  dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * n_groups), 1, (unsigned)t->n_rtiles);
+  const int padded_tiles = n_tiles >= 8 ? (n_tiles + 7) / 8 * 8 : n_tiles;
+  dim3 grid((unsigned)(padded_tiles * n_groups), 1, (unsigned)t->n_rtiles);
   dim3 block(64 * c->host.waves_per_group);
   if (lds > 64 * 1024) {
     status = set_lds_limit_rt(t->rt, lds);
@@ -508,10 +509,14 @@ int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_gaus
 int launch_finalize(const FinalizeArgs& args, hipStream_t stream) {
   // one block per draw tile; a wave sums one (component, r) row at a time over the slabs,
   // so small batches (few blocks, latency-bound) get 16 waves per block instead of 4
+  // and split the rows over several blocks (up to ~512 blocks in all)
   const int64_t n_tiles = args.ldb / 64;
   const int threads = env_int("TC_FINALIZE_THREADS", n_tiles < 128 ? 1024 : 256);
-  hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)n_tiles), dim3(threads), 0, stream,
-                     args);
+  const int n_rows = args.n_comp * args.n_r;
+  const int row_blocks =
+      n_tiles < 128 ? (int)std::max<int64_t>(1, std::min<int64_t>(n_rows, 512 / n_tiles)) : 1;
+  hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)n_tiles, (unsigned)row_blocks),
+                     dim3(threads), 0, stream, args);
   TC_HIP(hipGetLastError());
   return TC_OK;
 }
