@@ -513,8 +513,9 @@ int launch_finalize(const FinalizeArgs& args, hipStream_t stream) {
   const int64_t n_tiles = args.ldb / 64;
   const int threads = env_int("TC_FINALIZE_THREADS", n_tiles < 128 ? 1024 : 256);
   const int n_rows = args.n_comp * args.n_r;
-  const int row_blocks =
-      n_tiles < 128 ? (int)std::max<int64_t>(1, std::min<int64_t>(n_rows, 512 / n_tiles)) : 1;
+  const int row_blocks = std::min(
+      n_rows, env_int("TC_FINALIZE_ROW_BLOCKS",
+                      n_tiles < 128 ? (int)std::max<int64_t>(1, 512 / n_tiles) : 1));
   hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)n_tiles, (unsigned)row_blocks),
                      dim3(threads), 0, stream, args);
   TC_HIP(hipGetLastError());

@@ -48,7 +48,11 @@ __global__ __launch_bounds__(256) void bench(const double* table, double* out, i
       const double* rj = rows + ((it * 7 + (lane >> 4)) & 63) * 64 + (lane & 15);
       const double* ri = rows + ((it * 3) & 63) * 64 + (lane & 15);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) { nj[s] = rj[16 * s]; ni[s] = ri[16 * s]; }
+      for (int s = 0; s < 4; ++s) nj[s] = rj[16 * s];
+      if (LDS == 1) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ni[s] = ri[16 * s];
+      }
     }
     if (LOADS) {
 #pragma unroll
@@ -86,7 +90,8 @@ int main() {
   run<1, 0, 0>("20 MFMA + 4 v_mul_f64", table);
   run<1, 1, 0>("20 MFMA + 4 mul + 8 LDS reads", table);
   run<1, 1, 3>("20 MFMA + 4 mul + 8 LDS reads + 3 loads", table);
-  run<0, 1, 0>("20 MFMA + 8 LDS reads", table);
+  run<1, 2, 0>("20 MFMA + 4 mul + 4 LDS reads (n_i kept)", table);
+  run<1, 2, 3>("20 MFMA + 4 mul + 4 LDS reads + 3 loads", table);
   run<0, 0, 3>("20 MFMA + 3 loads", table);
   run<0, 0, 5>("20 MFMA + 5 loads", table);
   run<1, 1, 0, 1>("mul ahead: 20 MFMA + 4 mul + 8 LDS", table);
