@@ -190,6 +190,8 @@ struct tc_table {
   int force_lane = -1;               // host-buffer entry points pin lane 0
   uint64_t device_calls = 0;
   tc::host::DeviceBuffer theta, out_ngal, out_xi, occupation, trace, wave_trace, single_ws;
+  tc::host::DeviceBuffer chi2_data;          // data vector + precision matrix of chi2 calls
+  std::vector<double> chi2_host;             // host copy of what chi2_data holds
   size_t wave_trace_count = 0;
   tc::host::PinnedBuffer h_in, h_out;
   size_t trace_blocks = 0;

@@ -173,7 +173,7 @@ int tc_table_destroy(tc_table* t) {
     for (void* p : {kv.second->chunks, kv.second->groups})
       if (p) (void)hipFree(p);
   for (DeviceBuffer* b : {&t->theta, &t->out_ngal, &t->out_xi, &t->occupation,
-                          &t->trace, &t->wave_trace, &t->single_ws})
+                          &t->trace, &t->wave_trace, &t->single_ws, &t->chi2_data})
     b->release();
   for (tc_table::Lane& lane : t->lanes) {
     lane.nbuf.release();
@@ -351,32 +351,58 @@ int tc_chi2_zheng07_batch(tc_table* t, const double* theta, int n_theta,
   TC_HIP(hipSetDevice(t->device));
   const int n_r = t->n_r;
   const size_t xi_count = (size_t)n_draws * n_r;
-  status = t->theta.reserve((size_t)n_draws * n_theta * sizeof(double), t->stream);
-  if (status == TC_OK) status = t->out_ngal.reserve((size_t)n_draws * 2 * 8, t->stream);
-  if (status == TC_OK) status = t->out_xi.reserve(xi_count * 8, t->stream);
-  if (status == TC_OK)
-    status = t->occupation.reserve((size_t)(n_r + 1) * n_r * 8, t->stream);
+  const size_t theta_bytes = (size_t)n_draws * n_theta * sizeof(double);
+  status = t->out_xi.reserve(xi_count * 8, t->stream);
+  if (status == TC_OK) status = t->chi2_data.reserve((size_t)(n_r + 1) * n_r * 8, t->stream);
   if (status != TC_OK) return status;
-  status = copy_in(&t->h_in, t->theta.ptr, theta, (size_t)n_draws * n_theta * 8,
-                   t->stream);
-  if (status != TC_OK) return status;
-  // data vector and precision matrix behind each other in a scratch buffer
-  double* d_data = (double*)t->occupation.ptr;
+  // the data vector and the precision matrix of a likelihood do not change between calls:
+  // they are uploaded when they differ from the host copy of the last upload
+  double* d_data = (double*)t->chi2_data.ptr;
   double* d_precision = d_data + n_r;
-  TC_HIP(hipMemcpyAsync(d_data, data, (size_t)n_r * 8, hipMemcpyHostToDevice, t->stream));
-  TC_HIP(hipMemcpyAsync(d_precision, precision, (size_t)n_r * n_r * 8,
-                        hipMemcpyHostToDevice, t->stream));
-  double* d_ngal = (double*)t->out_ngal.ptr;
+  const size_t data_count = (size_t)(n_r + 1) * n_r;
+  if (t->chi2_host.size() != data_count ||
+      memcmp(t->chi2_host.data(), data, (size_t)n_r * 8) != 0 ||
+      memcmp(t->chi2_host.data() + n_r, precision, (size_t)n_r * n_r * 8) != 0) {
+    t->chi2_host.assign(data, data + n_r);
+    t->chi2_host.insert(t->chi2_host.end(), precision, precision + (size_t)n_r * n_r);
+    TC_HIP(hipMemcpyAsync(d_data, t->chi2_host.data(), data_count * 8,
+                          hipMemcpyHostToDevice, t->stream));
+    TC_HIP(hipStreamSynchronize(t->stream));
+  }
+  // small calls: draws read from and results written to page-locked host memory directly
+  const bool direct = theta_bytes + (size_t)n_draws * 16 <= zero_copy_limit() &&
+                      t->h_in.reserve(theta_bytes) == TC_OK &&
+                      t->h_out.reserve((size_t)n_draws * 16) == TC_OK;
+  const double* theta_device = nullptr;
+  double* d_ngal = nullptr;
+  if (direct) {
+    memcpy(t->h_in.ptr, theta, theta_bytes);
+    theta_device = (const double*)t->h_in.ptr;
+    d_ngal = (double*)t->h_out.ptr;
+  } else {
+    status = t->theta.reserve(theta_bytes, t->stream);
+    if (status == TC_OK) status = t->out_ngal.reserve((size_t)n_draws * 2 * 8, t->stream);
+    if (status != TC_OK) return status;
+    status = copy_in(&t->h_in, t->theta.ptr, theta, theta_bytes, t->stream);
+    if (status != TC_OK) return status;
+    theta_device = (const double*)t->theta.ptr;
+    d_ngal = (double*)t->out_ngal.ptr;
+  }
   double* d_chi2 = d_ngal + n_draws;
   t->force_lane = 0;
-  status = tc_predict_zheng07_batch_device(t, (const double*)t->theta.ptr, n_theta,
-                                           n_draws, n_gauss, flags, d_ngal,
-                                           (double*)t->out_xi.ptr);
+  status = tc_predict_zheng07_batch_device(t, theta_device, n_theta, n_draws, n_gauss, flags,
+                                           d_ngal, (double*)t->out_xi.ptr);
   t->force_lane = -1;
   if (status != TC_OK) return status;
   status = launch_chi2((const double*)t->out_xi.ptr, n_draws, n_r, d_data, d_precision,
                        d_chi2, t->stream);
   if (status != TC_OK) return status;
+  if (direct) {
+    TC_HIP(hipStreamSynchronize(t->stream));
+    memcpy(ngal, d_ngal, (size_t)n_draws * 8);
+    memcpy(chi2, d_chi2, (size_t)n_draws * 8);
+    return TC_OK;
+  }
   return copy_out(&t->h_out, ngal, (size_t)n_draws, d_ngal, chi2, (size_t)n_draws,
                   d_chi2, t->stream);
 }

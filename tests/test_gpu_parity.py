@@ -460,6 +460,19 @@ def test_chi2_fused_likelihood():
     expect = np.einsum('bi,ij,bj->b', delta, precision, delta)
     assert_rel(ngal, data['ngal'], RTOL)
     assert_rel(chi2, expect, 1e-9)
+    # again (cached data vector), one draw at a time, a changed data vector, a large batch
+    ngal, chi2 = halotab.chi2_batch(data['theta'], observed, precision)
+    assert_rel(chi2, expect, 1e-9)
+    ngal_1, chi2_1 = halotab.chi2_batch(data['theta'][2:3], observed, precision)
+    assert_rel(chi2_1[0], expect[2], 1e-9)
+    shifted = observed * 1.01
+    ngal, chi2 = halotab.chi2_batch(data['theta'], shifted, precision)
+    delta = data['xi'] - shifted
+    assert_rel(chi2, np.einsum('bi,ij,bj->b', delta, precision, delta), 1e-9)
+    big = np.tile(data['theta'], (1 + 70000 // len(data['theta']), 1))
+    ngal, chi2 = halotab.chi2_batch(big, shifted, precision)
+    assert_rel(chi2[:len(data['theta'])],
+               np.einsum('bi,ij,bj->b', delta, precision, delta), 1e-9)
     with pytest.raises(ValueError):
         halotab.chi2_batch(data['theta'], observed[:5], precision)
 
