@@ -893,6 +893,61 @@ __global__ __launch_bounds__(64) void interp_coef_kernel(InterpArgs a) {
   }
 }
 
+// The same for a handful of draws (the un-batched Interpolator.predict of an MCMC step):
+// one block per draw, the LANES over the tables, instead of one lane per draw looping over
+// all tables -- 18 -> ~5 us for a 5 x 5 grid.  Table weights land in LDS and are summed
+// in table order by one thread (deterministic).
+constexpr int kCoefSmallTables = 1024;
+
+__global__ __launch_bounds__(64) void interp_coef_small_kernel(InterpArgs a) {
+  __shared__ double weight[kMaxInterpDim][kMaxInterpAxis];
+  __shared__ double part_cen[kCoefSmallTables], part_sat[kCoefSmallTables];
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  for (int d = 0; d < a.n_dim; ++d) {
+    const int n = a.n_axis[d];
+    const double* xp = a.xp + a.axis_offset[d];
+    const double x = a.x[b * a.n_dim + d];
+    int seg = -1;
+    for (int i = 0; i < n; ++i) seg += xp[i] <= x ? 1 : 0;   // np.digitize(x, xp) - 1
+    if (x == xp[n - 1]) seg = n - 2;
+    seg = seg < 0 ? 0 : (seg > n - 2 ? n - 2 : seg);
+    const double* m = a.a + a.a_offset[d] + (int64_t)seg * 4 * n;
+    const double x2 = x * x, x3 = x2 * x;
+    if (lane < n)
+      weight[d][lane] = m[lane] + m[n + lane] * x + m[2 * n + lane] * x2 + m[3 * n + lane] * x3;
+  }
+  __syncthreads();
+  for (int k = lane; k < a.n_tables; k += kLanes) {
+    double c = 1.0;
+    for (int d = 0; d < a.n_dim; ++d) c *= weight[d][a.table_node[k * a.n_dim + d]];
+    const double* parts = a.ngal_parts[a.table_class[k]];
+    double cen = 0.0, sat = 0.0;
+    for (int p = 0; p < a.n_ngal_parts; ++p) {
+      cen += parts[((int64_t)p * 2 + 0) * a.ldb + b];
+      sat += parts[((int64_t)p * 2 + 1) * a.ldb + b];
+    }
+    const double total = cen + sat;
+    a.coef[(int64_t)k * a.ldb + b] = c / (a.mode == 0 ? total * total : total);
+    part_cen[k] = c * cen;
+    part_sat[k] = c * sat;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    double n_cen = 0.0, n_sat = 0.0;
+    for (int k = 0; k < a.n_tables; ++k) {
+      n_cen += part_cen[k];
+      n_sat += part_sat[k];
+    }
+    if (a.separate) {
+      a.ngal[2 * b] = n_cen;
+      a.ngal[2 * b + 1] = n_sat;
+    } else {
+      a.ngal[b] = n_cen + n_sat;
+    }
+  }
+}
+
 // Gaussian likelihood fused behind predict(): chi2[b] = (xi_b - d)^T P (xi_b - d) with the
 // data vector d and precision matrix P in the scalar cache; one lane per draw.  This is
 // the step every MCMC likelihood performs on the host right after predict()

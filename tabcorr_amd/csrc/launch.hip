@@ -523,8 +523,12 @@ int launch_finalize(const FinalizeArgs& args, hipStream_t stream) {
 }
 
 int launch_interp_coef(const InterpArgs& args, hipStream_t stream) {
-  hipLaunchKernelGGL(tc::interp_coef_kernel, dim3((unsigned)(args.ldb / 64)), dim3(64), 0,
-                     stream, args);
+  if (args.n_draws <= 16 && args.n_tables <= tc::kCoefSmallTables)
+    hipLaunchKernelGGL(tc::interp_coef_small_kernel, dim3((unsigned)args.n_draws), dim3(64),
+                       0, stream, args);
+  else
+    hipLaunchKernelGGL(tc::interp_coef_kernel, dim3((unsigned)(args.ldb / 64)), dim3(64), 0,
+                       stream, args);
   TC_HIP(hipGetLastError());
   return TC_OK;
 }
