@@ -57,8 +57,11 @@ N_GAUSS = 10
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument('--gpus', type=int, default=1)
-    parser.add_argument('--steps', type=int, default=200)
-    parser.add_argument('--warmup', type=int, default=20)
+    # defaults: about one second of timed steps -- the chip's power management needs tens of
+    # milliseconds of load to settle (tools/ramp.py: 10-ms regions started from idle run
+    # 10-20 % slower than the sustained rate)
+    parser.add_argument('--steps', type=int, default=20000)
+    parser.add_argument('--warmup', type=int, default=2000)
     parser.add_argument('--draws', type=int, default=10000,
                         help='draws per GPU per step')
     parser.add_argument('--gather-every', type=int, default=8,
@@ -178,7 +181,7 @@ def main():
     def kernel_pass():
         ms = ctypes.c_float()
         _lib.check(lib.tc_table_timer_begin(handle, 1))
-        for index in range(min(args.steps, 200)):
+        for index in range(min(args.steps, 1000)):
             _lib.check(lib.tc_predict_zheng07_batch_device(
                 handle, d_theta, 5, n_draws, N_GAUSS, 0, out_ptr(index % n_slots),
                 out_ptr(index % n_slots, n_draws)))

@@ -6,11 +6,11 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 OUT=gpurun_out/profile
 rm -rf $OUT; mkdir -p $OUT
-python bench.py --steps 400 --warmup 40 > $OUT/bench.json 2> $OUT/bench.err
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
 TC_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lanes1 -- \
-  python3 bench.py --steps 300 --warmup 30 --cpu-seconds 0 > $OUT/bench_under_rocprof_lanes1.log 2>&1
+  python3 bench.py --steps 2000 --warmup 200 --cpu-seconds 0 > $OUT/bench_under_rocprof_lanes1.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pipelined -- \
-  python3 bench.py --steps 300 --warmup 30 --cpu-seconds 0 > $OUT/bench_under_rocprof_pipelined.log 2>&1
+  python3 bench.py --steps 2000 --warmup 200 --cpu-seconds 0 > $OUT/bench_under_rocprof_pipelined.log 2>&1
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64" \
