@@ -21,7 +21,10 @@ for n_draws in (10000, 100000, 200000):
     for _ in range(12):
         step()
     _lib.check(lib.tc_table_synchronize(dev.handle))
-    steps = 20
+    steps = max(20, int(0.6e5 * 1e4 / n_draws / 5))      # about 0.6 s of work
+    for _ in range(steps // 4):
+        step()
+    _lib.check(lib.tc_table_synchronize(dev.handle))
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
