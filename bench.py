@@ -64,7 +64,7 @@ def main():
     parser.add_argument('--warmup', type=int, default=2000)
     parser.add_argument('--draws', type=int, default=10000,
                         help='draws per GPU per step')
-    parser.add_argument('--gather-every', type=int, default=8,
+    parser.add_argument('--gather-every', type=int, default=32,
                         help='multi-GPU: steps per RCCL gather of the results')
     parser.add_argument('--cpu-seconds', type=float, default=12.0,
                         help='budget of the CPU baseline sample (0: skip)')
