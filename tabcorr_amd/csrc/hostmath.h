@@ -31,9 +31,8 @@ bool spline_interpolation_matrix(int n, const double* xp, std::vector<double>& a
 // uses one-row "rectangles" without a row bin (i = -1).  Segments are sized so that the
 // density rows a workgroup has to stage (its column range plus its row range) fit in
 // LDS, which also lifts any limit on the number of bins.  Inside a segment the entries
-// are row-major and are followed by zero padding up to a multiple of the block size EB,
-// so that every block of EB entries starts on a 128-byte boundary of the re-laid-out
-// table.
+// are row-major and are followed by zero padding up to a multiple of the block size of
+// the table layout (8 positions: two matrix-core steps, kernels.hip.h).
 struct Segment {
   int32_t component;
   int32_t rectangular;   // 0: triangle (row i ends at column i), 1: rectangle
