@@ -218,7 +218,7 @@ int get_chunking(tc_table* t, int n_chunks, int waves, DeviceChunking** out);
 int lds_bytes_for(const Chunking& chunking, int rt, int elem = 8);
 int wave_slots(const tc_table* t, bool interp);
 int blocks_per_cu(int lds_bytes, int waves, int slots);
-int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out, DeviceChunking** out,
+int choose_chunking(tc_table* t, int64_t n_draws, int tables_per_block, DeviceChunking** out,
                     int* lds_bytes);
 int launch_contract_rt(int rt, dim3 grid, dim3 block, int lds, hipStream_t stream,
                        const ContractArgs& args);

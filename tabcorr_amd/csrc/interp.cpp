@@ -106,7 +106,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   int lds = 0;
   {
     // the table handle caches the chunkings; all tables share table 0's plan
-    status = choose_chunking(t0, n_draws, n_comp, &c, &lds);
+    status = choose_chunking(t0, n_draws, std::min(it->n_tables, 1000), &c, &lds);
     if (status != TC_OK) return status;
   }
   int k_splits = 1;

@@ -98,15 +98,15 @@ int blocks_per_cu(int lds_bytes, int waves, int slots) {
 // several scheduling rounds -- calibrated on per-workgroup timelines (tools/trace.py):
 // the main loop issues one FP64 VALU instruction per 4 cycles per SIMD as long as >= 4
 // waves per SIMD are resident, and idle time comes from uneven workgroup counts per CU.
-int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
+int choose_chunking(tc_table* t, int64_t n_draws, int tables_per_block,
                     DeviceChunking** out, int* lds_bytes) {
-  (void)n_comp_out;
   const int64_t n_tiles = (n_draws + 63) / 64 * t->n_rtiles;
   const int elem = t->compute_dtype == TC_DTYPE_F32 ? 4 : 8;
   const int forced_groups = env_int("TC_NGROUPS", 0);
   const int forced_waves = env_int("TC_NWAVES", 0);
   // (the developer overrides are part of the key: sweeps stay cheap on the host)
-  const int64_t key = n_tiles * 4096 + forced_groups * 64 + forced_waves;
+  const int64_t key =
+      (n_tiles * 4096 + forced_groups * 64 + forced_waves) * 1024 + tables_per_block;
   {
     auto cached = t->choices.find(key);
     if (cached != t->choices.end()) {
@@ -116,6 +116,7 @@ int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
     }
   }
   const int64_t min_entries = env_int("TC_MIN_CHUNK_ENTRIES", 32);
+  // fixed cost of a workgroup (staging, reduction) in units of table entries
   const double overhead_entries = 24.0;
   const int n_cus = 256;
   double best_cost = 0.0;
@@ -141,7 +142,8 @@ int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
       int longest = 1;
       for (const tc::Chunk& chunk : trial.chunks)
         longest = std::max(longest, chunk.q_end - chunk.q_begin);
-      const int fit = blocks_per_cu(bytes + 1024, use_waves, wave_slots(t, false));
+      const int fit =
+          blocks_per_cu(bytes + 1024, use_waves, wave_slots(t, tables_per_block > 1));
       const double blocks = (double)n_tiles * actual_groups;
       const double per_cu = std::ceil(blocks / n_cus);
       const double resident = std::min<double>(per_cu, fit) * use_waves / 4.0;
@@ -149,6 +151,13 @@ int choose_chunking(tc_table* t, int64_t n_draws, int n_comp_out,
       double cost = per_cu * use_waves * (longest + overhead_entries);
       if (resident < 4.0) cost *= 4.0 / resident;
       cost *= 1.0 + 0.1 * (rounds - 1.0);
+      if (tables_per_block > 1 && n_tiles >= 64) {
+        // interpolator: workgroups are long (all tables of a split), so what counts is
+        // the half-empty last scheduling round against the staging of finer groups
+        // (measured, 25 tables: 196 tiles best with 16-20 groups, 1563 tiles with 8)
+        cost = (rounds + 0.5) * std::min<double>(per_cu, fit) * use_waves *
+               (longest + 14.0);
+      }
       if (best_chunks == 0 || cost < best_cost) {
         best_cost = cost;
         best_chunks = (int)n_chunks;
@@ -220,7 +229,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   const int n_comp = separate ? t->plan.n_components : 1;
   DeviceChunking* c = nullptr;
   int lds = 0;
-  int status = choose_chunking(t, n_draws, n_comp, &c, &lds);
+  int status = choose_chunking(t, n_draws, 1, &c, &lds);
   if (status != TC_OK) return status;
   tc_table::Lane& lane = t->lanes[t->cur];
   hipStream_t stream = lane.stream;
