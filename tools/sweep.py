@@ -110,7 +110,7 @@ if __name__ == '__main__':
         run(50, 1, (19, ), 100000, 10, 'cfg2 1e5')
         run(30, 1, (19, ), 10000, 50, 'bolplanck-like G=60')
     elif which == 'cfg3one':
-        run(50, 2, (19, ), 10000, 20, 'cfg3 splits=%s' % os.environ.get('TC_OCC_SPLITS'), flags=1)
+        run(50, 2, (19, ), 10000, 2000, 'cfg3 splits=%s nw=%s ng=%s' % (os.environ.get('TC_OCC_SPLITS'), os.environ.get('TC_NWAVES'), os.environ.get('TC_NGROUPS')), flags=1)
     elif which == 'cfg5one':
         run(100, 1, (19, 40), 10000, 3, 'cfg5 float32', dtype='float32')
     elif which == 'f32':
