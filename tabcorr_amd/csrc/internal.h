@@ -223,6 +223,8 @@ int choose_chunking(tc_table* t, int64_t n_draws, int tables_per_block, DeviceCh
 int launch_contract_rt(int rt, dim3 grid, dim3 block, int lds, hipStream_t stream,
                        const ContractArgs& args);
 int set_lds_limit_rt(int rt, int lds);
+int launch_contract_f32(dim3 grid, dim3 block, int lds, hipStream_t stream,
+                        const ContractArgs& args);
 // Occupation kernel for a slab of draws: densities into (nbuf, ngal2) -- the current
 // lane's by default -- and optionally the occupations in reference order.
 int run_occupation(tc_table* t, const double* theta_device, int n_theta, int64_t n_draws,

@@ -158,11 +158,16 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   dim3 grid((unsigned)(padded_tiles * n_groups * k_splits), 1,
             (unsigned)t0->n_rtiles);
   dim3 block(64 * c->host.waves_per_group);
-  if (lds > 64 * 1024) {
-    status = set_lds_limit_rt(t0->rt, lds);
-    if (status != TC_OK) return status;
+  if (t0->compute_dtype == TC_DTYPE_F32) {
+    ca.pos_ij = (const int32_t*)t0->d_pos_ij;
+    status = launch_contract_f32(grid, block, lds, it->stream, ca);
+  } else {
+    if (lds > 64 * 1024) {
+      status = set_lds_limit_rt(t0->rt, lds);
+      if (status != TC_OK) return status;
+    }
+    status = launch_contract_rt(t0->rt, grid, block, lds, it->stream, ca);
   }
-  status = launch_contract_rt(t0->rt, grid, block, lds, it->stream, ca);
   if (status != TC_OK) return status;
 
   tc::FinalizeArgs fa;
@@ -204,8 +209,8 @@ int tc_interp_create(tc_table* const* tables, int n_tables, int n_dim,
     tc_table* t = tables[k];
     TC_CHECK(t != nullptr, "table %d is NULL", k);
     TC_CHECK(t->device == it->device, "table %d lives on another device", k);
-    if (t->compute_dtype != TC_DTYPE_F64)
-      return fail(TC_ERR_UNSUPPORTED, "interpolation of float32 tables is not built");
+    TC_CHECK(t->compute_dtype == t0->compute_dtype,
+             "table %d differs from table 0 in compute dtype", k);
     TC_CHECK(t->mode == t0->mode && t->n_bins == t0->n_bins && t->n_r == t0->n_r &&
                  t->plan.perm == t0->plan.perm,
              "table %d differs from table 0 in mode, shape or gal_type layout", k);

@@ -627,6 +627,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+template <bool INTERP>
 __global__ __launch_bounds__(512) void contract_f32_kernel(ContractArgs a) {
   extern __shared__ __attribute__((aligned(16))) float ldsf[];
   const int lane = threadIdx.x & 63;
@@ -644,58 +645,82 @@ __global__ __launch_bounds__(512) void contract_f32_kernel(ContractArgs a) {
   }
   if (tile >= a.n_tiles) return;
   const int64_t col = (int64_t)tile * kLanes;
-  const Group group = a.groups[slab];
+  constexpr bool interp = INTERP;
+  const int k_splits = interp ? a.k_splits : 1;
+  const Group group = a.groups[slab / k_splits];
   const int n_rows_j = group.j_hi - group.j_lo;
   const int n_rows = n_rows_j + (group.i_hi - group.i_lo);
-
-  // stage the density rows as float
-  {
-    gl_f64 src = (gl_f64)a.nbuf + col;
-    for (int id = threadIdx.x; id < n_rows * kLanes; id += blockDim.x) {
-      const int row = id >> 6;
-      const int bin = row < n_rows_j ? group.j_lo + row : group.i_lo + row - n_rows_j;
-      ldsf[id] = (float)src[(int64_t)bin * a.ldb + (id & 63)];
-    }
+  int k_begin = 0, k_end = 1;
+  if (interp) {
+    const int split = slab % k_splits;
+    k_begin = (int)((int64_t)a.n_tables * split / k_splits);
+    k_end = (int)((int64_t)a.n_tables * (split + 1) / k_splits);
   }
-  __syncthreads();
 
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
 
-  if (wave < group.n_chunks) {
-    const Chunk chunk = a.chunks[group.chunk_begin + wave];
-    const int n_blocks = (chunk.q_end - chunk.q_begin) / kF32Block;
-    typedef const __attribute__((address_space(1))) f32x4* gl_f32x4;
-    typedef const __attribute__((address_space(1))) i32x4* gl_i32x4;
-    gl_f32x4 table = (gl_f32x4)((const float*)a.table +
-                                ((int64_t)blockIdx.z * a.n_positions + chunk.q_begin) *
-                                    kF32Tile) + lane;
-    gl_i32x4 pairs = (gl_i32x4)(a.pos_ij + chunk.q_begin) + (lane >> 5);
-    const int draw = lane & 31;
-    const bool auto_mode = a.mode == 0;
-    f32x4 ta = table[0];
-    i32x4 pa = pairs[0];
-    for (int blk = 0; blk < n_blocks; ++blk) {
-      const int next = blk + 1 < n_blocks ? blk + 1 : blk;
-      const f32x4 tn = table[(int64_t)next * 64];
-      const i32x4 pn = pairs[(int64_t)next * 2];
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int jj = (pa[p] & 0xffff) - group.j_lo;
-        const int ii = (pa[p] >> 16) + group.i_shift;
-        const float* rj = ldsf + jj * kLanes + draw;
-        float w0 = rj[0], w1 = rj[32];
-        if (auto_mode) {
-          const float* ri = ldsf + ii * kLanes + draw;
-          w0 *= ri[0];
-          w1 *= ri[32];
-        }
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[p], w0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[p], w1, acc1, 0, 0, 0);
+  int staged_class = -1;
+  for (int k = k_begin; k < k_end; ++k) {
+    // interpolator: the block loops over the tables of its split (as contract_mfma_kernel)
+    const int density_class = interp ? a.table_class[k] : 0;
+    if (density_class != staged_class) {
+      if (staged_class >= 0) __syncthreads();
+      // stage the density rows as float
+      gl_f64 src = (gl_f64)(interp ? a.nbufs[density_class] : a.nbuf) + col;
+      for (int id = threadIdx.x; id < n_rows * kLanes; id += blockDim.x) {
+        const int row = id >> 6;
+        const int bin = row < n_rows_j ? group.j_lo + row : group.i_lo + row - n_rows_j;
+        ldsf[id] = (float)src[(int64_t)bin * a.ldb + (id & 63)];
       }
-      ta = tn;
-      pa = pn;
+      __syncthreads();
+      staged_class = density_class;
+    }
+
+    if (wave < group.n_chunks) {
+      const Chunk chunk = a.chunks[group.chunk_begin + wave];
+      const int n_blocks = (chunk.q_end - chunk.q_begin) / kF32Block;
+      typedef const __attribute__((address_space(1))) f32x4* gl_f32x4;
+      typedef const __attribute__((address_space(1))) i32x4* gl_i32x4;
+      gl_f32x4 table =
+          (gl_f32x4)((const float*)(interp ? (const void*)a.tables[k] : a.table) +
+                     ((int64_t)blockIdx.z * a.n_positions + chunk.q_begin) * kF32Tile) +
+          lane;
+      gl_i32x4 pairs = (gl_i32x4)(a.pos_ij + chunk.q_begin) + (lane >> 5);
+      const int draw = lane & 31;
+      const bool auto_mode = a.mode == 0;
+      // spline weight / pair-weight norm of this table for the lane's two draws
+      const float scale0 = interp ? (float)a.coef[(int64_t)k * a.ldb + col + draw] : 1.0f;
+      const float scale1 =
+          interp ? (float)a.coef[(int64_t)k * a.ldb + col + draw + 32] : 1.0f;
+      f32x4 ta = table[0];
+      i32x4 pa = pairs[0];
+      for (int blk = 0; blk < n_blocks; ++blk) {
+        const int next = blk + 1 < n_blocks ? blk + 1 : blk;
+        const f32x4 tn = table[(int64_t)next * 64];
+        const i32x4 pn = pairs[(int64_t)next * 2];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int jj = (pa[p] & 0xffff) - group.j_lo;
+          const int ii = (pa[p] >> 16) + group.i_shift;
+          const float* rj = ldsf + jj * kLanes + draw;
+          float w0 = rj[0], w1 = rj[32];
+          if (auto_mode) {
+            const float* ri = ldsf + ii * kLanes + draw;
+            w0 *= ri[0];
+            w1 *= ri[32];
+          }
+          if (interp) {
+            w0 *= scale0;
+            w1 *= scale1;
+          }
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[p], w0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[p], w1, acc1, 0, 0, 0);
+        }
+        ta = tn;
+        pa = pn;
+      }
     }
   }
   __syncthreads();

@@ -203,6 +203,25 @@ int launch_contract_rt(int rt, dim3 grid, dim3 block, int lds, hipStream_t strea
   return TC_OK;
 }
 
+// float32 variant (one kernel for every r tile: always 32 wide)
+int launch_contract_f32(dim3 grid, dim3 block, int lds, hipStream_t stream,
+                        const tc::ContractArgs& args) {
+  if (lds > 64 * 1024) {
+    TC_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&tc::contract_f32_kernel<false>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    TC_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&tc::contract_f32_kernel<true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  }
+  if (args.n_tables > 0)
+    hipLaunchKernelGGL(tc::contract_f32_kernel<true>, grid, block, lds, stream, args);
+  else
+    hipLaunchKernelGGL(tc::contract_f32_kernel<false>, grid, block, lds, stream, args);
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+
 int set_lds_limit_rt(int rt, int lds) {
   switch (rt) {
 #define TC_CASE(N)                                                            \
@@ -304,12 +323,8 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   }
   if (t->compute_dtype == TC_DTYPE_F32) {
     ca.pos_ij = (const int32_t*)t->d_pos_ij;
-    if (lds > 64 * 1024)
-      TC_HIP(hipFuncSetAttribute(
-          reinterpret_cast<const void*>(&tc::contract_f32_kernel),
-          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(tc::contract_f32_kernel, grid, block, lds, stream, ca);
-    TC_HIP(hipGetLastError());
+    status = launch_contract_f32(grid, block, lds, stream, ca);
+    if (status != TC_OK) return status;
   } else {
     status = launch_contract_rt(t->rt, grid, block, lds, stream, ca);
     if (status != TC_OK) return status;

@@ -223,6 +223,39 @@ def test_config5_float32_mfma():
     assert np.max(np.abs(xi / xi64 - 1)) < RTOL_F32
 
 
+@pytest.mark.parametrize('shape,tpcf_shape,mode', [((4, 4), (40, ), 'auto'),
+                                                   ((5, ), (7, 9), 'cross'),
+                                                   ((4, 5), (19, ), 'auto')])
+def test_float32_interpolator(shape, tpcf_shape, mode):
+    """Interpolation over float32 tables (matrix-core kernel with the table loop) against
+    the float64 interpolator and, for a few draws, the oracle."""
+    from tabcorr_amd import Interpolator, synthetic
+    from oracle import tabcorr_oracle as oracle
+    tables, keys, points = synthetic.synthetic_interpolator(
+        shape, 14, 1, tpcf_shape, mode, seed=61)
+    param_dict = {key: points[:, d] for d, key in enumerate(keys)}
+    interp64 = Interpolator([make(t) for t in tables], param_dict)
+    interp32 = Interpolator([make(t, compute_dtype='float32') for t in tables], param_dict)
+    rng = np.random.default_rng(62)
+    for n_draws in (3, 700):
+        theta = synthetic.zheng07_draws(n_draws, seed=63)
+        x = np.stack([rng.uniform(xp[0], xp[-1], size=n_draws) for xp in interp64.xp], axis=-1)
+        ngal64, xi64 = interp64.predict_batch(theta, x)
+        ngal32, xi32 = interp32.predict_batch(theta, x)
+        assert_rel(ngal32, ngal64, 1e-12)
+        scale = np.max(np.abs(xi64), axis=tuple(range(1, xi64.ndim)), keepdims=True)
+        np.testing.assert_allclose(xi32, xi64, rtol=RTOL_F32, atol=RTOL_F32 * scale.max())
+        sep64 = interp64.predict_batch(theta, x, separate_gal_type=True)[1]
+        sep32 = interp32.predict_batch(theta, x, separate_gal_type=True)[1]
+        for key in sep64:
+            np.testing.assert_allclose(sep32[key], sep64[key], rtol=RTOL_F32,
+                                       atol=RTOL_F32 * np.max(np.abs(sep64[key])))
+    setup = oracle.interpolator_setup(tables, points)
+    expect = oracle.interpolator_predict_zheng07_batch(tables, setup, theta[:4], x[:4])
+    np.testing.assert_allclose(xi32[:4], expect[1], rtol=RTOL_F32,
+                               atol=RTOL_F32 * np.max(np.abs(expect[1])))
+
+
 def test_more_draws_than_one_slab():
     """Batches beyond the internal slab size (2^18 draws) are processed in pieces."""
     from tabcorr_amd import synthetic
