@@ -6,12 +6,14 @@ batched call.
     python examples/example_wp.py tests/golden/bolplanck_wp.hdf5
 """
 
+import os
 import sys
 import time
 
 import numpy as np
 
-from tabcorr_amd import TabCorr, Zheng07Model
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from tabcorr_amd import TabCorr, Zheng07Model  # noqa: E402
 
 fname = sys.argv[1] if len(sys.argv) > 1 else 'tests/golden/bolplanck_wp.hdf5'
 halotab = TabCorr.read(fname)
