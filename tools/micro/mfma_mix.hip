@@ -17,7 +17,31 @@ __global__ __launch_bounds__(256) void bench(const double* table, double* out, i
   const double* p = table + (size_t)(blockIdx.x % 64) * 4096 + lane;
   double ni[4] = {1, 1, 1, 1}, nj[4] = {1, 1, 1, 1};
   double w2[4] = {1.0, 1.0, 1.0, 1.0};
-  if (AHEAD) {
+  if (AHEAD == 2) {
+    // gathers two steps ahead: two density register sets
+    double ni2[4] = {1, 1, 1, 1}, nj2[4] = {1, 1, 1, 1};
+    for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        double (&ci)[4] = half ? ni2 : ni;
+        double (&cj)[4] = half ? nj2 : nj;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("v_mul_f64 %0, %1, %2" : "=v"(w[s]) : "v"(ci[s]), "v"(cj[s]));
+        const double* rj = rows + (((it + half) * 7 + (lane >> 4)) & 63) * 64 + (lane & 15);
+        const double* ri = rows + (((it + half) * 3) & 63) * 64 + (lane & 15);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { cj[s] = rj[16 * s]; ci[s] = ri[16 * s]; }
+#pragma unroll
+        for (int u = 0; u < LOADS; ++u) a[u] = p[(size_t)(((it + half) * 5 + u) & 63) * 64];
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            acc[u * 4 + s] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[u], w[s], acc[u * 4 + s], 0, 0, 0);
+      }
+    }
+    w2[0] += ni2[0] + nj2[0];
+  } else if (AHEAD) {
     for (int it = 0; it < iters; it += 2) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -98,6 +122,9 @@ int main() {
   run<1, 1, 3, 1>("mul ahead: 20 MFMA + 4 mul + 8 LDS + 3 loads", table);
   run<1, 1, 3, 1>("mul ahead, 4 waves/SIMD: full mix", table, 4);
   run<1, 1, 3, 0>("4 waves/SIMD: full mix", table, 4);
+  run<1, 1, 0, 2>("gathers 2 steps ahead: 20 MFMA + 4 mul + 8 LDS", table);
+  run<1, 1, 3, 2>("gathers 2 steps ahead: full mix", table);
+  run<1, 1, 3, 2>("gathers 2 steps ahead: full mix, 4 waves", table, 4);
   run<1, 1, 2, 1>("mul ahead: 20 MFMA + 4 mul + 8 LDS + 2 loads", table);
   run<1, 1, 1, 1>("mul ahead: 20 MFMA + 4 mul + 8 LDS + 1 load", table);
   return 0;
