@@ -101,6 +101,25 @@ int tc_plan_debug(int mode, int n_bins, const uint8_t* is_central, int n_chunks,
                   int64_t* n_entries, int32_t* entry_pair, int32_t* entry_chunk,
                   int32_t* entry_class);
 
+/* Quadratic-form contraction kernel (mode auto, float64; tabcorr_amd/csrc/hostmath.h):
+ * builds the schedule for a table of n_bins bins (the first n_central centrals) and checks
+ * that it covers every (draw tile, r tile, component, table, unit) exactly once with
+ * consecutive slabs per output group; returns its size and the smallest / largest number
+ * of units any wave gets. */
+int tc_debug_quad_schedule(int n_bins, int n_central, int by_type, int n_tiles, int n_rtiles,
+                           int n_tables, int separate, int max_waves, int min_units,
+                           int* n_waves, int* n_runs, int* n_slabs, int64_t* units_min,
+                           int64_t* units_max);
+/* TEST INFRASTRUCTURE, never called by the product: executes the kernel's table layout,
+ * schedule and slab grouping on the host, lane by lane, for densities (n_bins, ldb) given
+ * in the reference's bin order; out (n_draws, 1 | 3, n_r) = sum_p c_p T[r][p] n_i n_j
+ * before the normalisation (tabcorr.py:641-655).  Lets CPU tests check the index logic of
+ * contract_quad_kernel / finalize_quad_kernel without a GPU. */
+int tc_debug_quad_emulate(int n_bins, int n_r, const double* tpcf_matrix,
+                          const uint8_t* is_central, int by_type, int separate,
+                          const double* densities, int64_t ldb, int64_t n_draws,
+                          int max_waves, int min_units, double* out);
+
 /* ---- one tabulated table (replaces the state of a `TabCorr` instance) ----------------
  *
  * tc_table_create uploads everything predict() needs from a TabCorr object

@@ -266,6 +266,249 @@ void build_plan(int mode, int n_bins, const uint8_t* is_central, int block,
   plan.n_positions = (int64_t)plan.column.size();
 }
 
+void build_quad_layout(int n_bins, int n_central, bool by_type, QuadLayout& out) {
+  out.n_bins = n_bins;
+  out.n_central = n_central;
+  out.by_type = by_type;
+  out.comps.clear();
+  out.n_units = 0;
+  // (an empty component -- a table without centrals or without satellites -- keeps its
+  // slot: the component index is the output component)
+  auto add = [&](int component, bool triangular, int i0, int ni, int j0, int nj) {
+    if (ni <= 0 || nj <= 0) ni = nj = 0;
+    QuadComp comp;
+    comp.component = component;
+    comp.triangular = triangular ? 1 : 0;
+    comp.i_bin0 = i0;
+    comp.i_count = ni;
+    comp.j_bin0 = j0;
+    comp.j_count = nj;
+    comp.n_rb = (ni + 3) / 4;
+    comp.n_cb = triangular ? comp.n_rb : (nj + 3) / 4;
+    comp.unit_base = out.n_units;
+    comp.n_units = triangular ? (int64_t)comp.n_rb * (comp.n_rb + 1) / 2
+                              : (int64_t)comp.n_rb * comp.n_cb;
+    out.n_units += comp.n_units;
+    out.comps.push_back(comp);
+  };
+  if (!by_type) {
+    add(0, true, 0, n_bins, 0, n_bins);
+  } else {
+    const int n_sat = n_bins - n_central;
+    add(0, true, 0, n_central, 0, n_central);
+    add(1, false, n_central, n_sat, 0, n_central);
+    add(2, true, n_central, n_sat, n_central, n_sat);
+  }
+}
+
+void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, int n_tables,
+                         bool separate, int max_waves, int min_units_per_wave,
+                         QuadSchedule& out) {
+  out.runs.clear();
+  out.wave_runs.clear();
+  out.group_begin.clear();
+  n_tables = std::max(1, n_tables);
+  const int n_comps = (int)layout.comps.size();
+  const int groups_per_rtile = separate ? n_comps : 1;
+  out.n_groups = n_tiles * n_rtiles * groups_per_rtile;
+  const int64_t per_rtile = layout.n_units * n_tables;          // units of one (tile, r tile)
+  const int64_t total = per_rtile * n_rtiles * n_tiles;
+  int64_t n_waves = std::min<int64_t>(max_waves, total / std::max(1, min_units_per_wave));
+  n_waves = std::max<int64_t>(1, std::min<int64_t>(n_waves, total));
+  if (total == 0) n_waves = 0;
+  out.n_waves = (int)n_waves;
+  out.group_begin.assign((size_t)out.n_groups + 1, 0);
+
+  // position -> (tile, rtile, comp, table, unit in component)
+  int slab = 0;
+  std::vector<int32_t> slab_group;
+  for (int64_t w = 0; w < n_waves; ++w) {
+    out.wave_runs.push_back((int32_t)out.runs.size());
+    // (128-bit product: total * w can exceed 63 bits for huge batches of huge tables)
+    int64_t begin = (int64_t)((__int128)total * w / n_waves);
+    const int64_t end = (int64_t)((__int128)total * (w + 1) / n_waves);
+    const size_t first_run = out.runs.size();
+    while (begin < end) {
+      const int64_t tile_rtile = begin / per_rtile;
+      int64_t rest = begin % per_rtile;
+      // inside a (tile, rtile): components, then tables, then the component's units
+      int comp = 0;
+      while (rest >= layout.comps[comp].n_units * n_tables) {
+        rest -= layout.comps[comp].n_units * n_tables;
+        ++comp;
+      }
+      const QuadComp& qc = layout.comps[comp];
+      const int table = (int)(rest / qc.n_units);
+      const int64_t unit = rest % qc.n_units;
+      const int64_t stop = std::min<int64_t>(end, begin + (qc.n_units - unit));
+      QuadRun run;
+      run.tile = (int32_t)(tile_rtile / n_rtiles);
+      run.rtile = (int32_t)(tile_rtile % n_rtiles);
+      run.comp = comp;
+      run.table = table;
+      if (qc.triangular) {
+        int64_t rb = (int64_t)((std::sqrt(8.0 * (double)unit + 1.0) - 1.0) / 2.0);
+        while ((rb + 1) * (rb + 2) / 2 <= unit) ++rb;
+        while (rb * (rb + 1) / 2 > unit) --rb;
+        run.rb0 = (int32_t)rb;
+        run.cb0 = (int32_t)(unit - rb * (rb + 1) / 2);
+      } else {
+        run.rb0 = (int32_t)(unit / qc.n_cb);
+        run.cb0 = (int32_t)(unit % qc.n_cb);
+      }
+      run.count = (int32_t)(stop - begin);
+      run.slab = -1;
+      out.runs.push_back(run);
+      begin = stop;
+    }
+    // flush after the last run of every output group this wave touches
+    auto group_of = [&](const QuadRun& run) {
+      return ((int64_t)run.tile * n_rtiles + run.rtile) * groups_per_rtile +
+             (separate ? run.comp : 0);
+    };
+    for (size_t k = first_run; k < out.runs.size(); ++k) {
+      const bool last = k + 1 == out.runs.size();
+      if (last || group_of(out.runs[k + 1]) != group_of(out.runs[k])) {
+        out.runs[k].slab = slab++;
+        slab_group.push_back((int32_t)group_of(out.runs[k]));
+      }
+    }
+  }
+  out.wave_runs.push_back((int32_t)out.runs.size());
+  out.n_slabs = slab;
+  // slabs are in group order: group_begin by counting
+  for (int32_t g : slab_group) ++out.group_begin[(size_t)g + 1];
+  for (int g = 0; g < out.n_groups; ++g) out.group_begin[g + 1] += out.group_begin[g];
+}
+
+QuadTiling quad_tiling(int n_r) {
+  QuadTiling tiling;
+  tiling.n_rtiles = (n_r + 19) / 20;
+  tiling.r_per_tile = (n_r + tiling.n_rtiles - 1) / tiling.n_rtiles;
+  tiling.n_u = (tiling.r_per_tile + 3) / 4;
+  return tiling;
+}
+
+void fill_quad_table(const QuadLayout& layout, const std::vector<int32_t>& perm, int n_r,
+                     int64_t n_pairs, const void* matrix, bool matrix_is_f32,
+                     const QuadTiling& tiling, std::vector<double>& out) {
+  const int up = (tiling.n_u + 1) / 2;
+  const size_t per_unit = (size_t)up * 128;
+  out.assign((size_t)tiling.n_rtiles * layout.n_units * per_unit, 0.0);
+  auto source = [&](int r, int64_t column) {
+    return matrix_is_f32 ? (double)((const float*)matrix)[(size_t)r * n_pairs + column]
+                         : ((const double*)matrix)[(size_t)r * n_pairs + column];
+  };
+  for (const QuadComp& comp : layout.comps) {
+    for (int rb = 0; rb < comp.n_rb; ++rb) {
+      for (int cb = 0; cb < quad_row_length(comp, rb); ++cb) {
+        const int64_t unit =
+            comp.unit_base + (comp.triangular ? (int64_t)rb * (rb + 1) / 2 + cb
+                                              : (int64_t)rb * comp.n_cb + cb);
+        for (int lane = 0; lane < 64; ++lane) {
+          const int m = lane & 15, k = lane >> 4;
+          const int i_local = 4 * rb + (m >> 2), j_local = 4 * cb + k;
+          if (i_local >= comp.i_count || j_local >= comp.j_count) continue;
+          const int i = comp.i_bin0 + i_local, j = comp.j_bin0 + j_local;
+          if (comp.triangular && j > i) continue;
+          const int64_t column = packed_index(perm[i], perm[j]);
+          const double prefactor = i == j ? 1.0 : 2.0;
+          for (int z = 0; z < tiling.n_rtiles; ++z) {
+            for (int u = 0; u < tiling.n_u; ++u) {
+              const int r_local = 4 * u + (m & 3);
+              const int r = z * tiling.r_per_tile + r_local;
+              if (r_local >= tiling.r_per_tile || r >= n_r) continue;
+              out[((size_t)z * layout.n_units + unit) * per_unit +
+                  ((size_t)(u / 2) * 64 + lane) * 2 + (u & 1)] = source(r, column) * prefactor;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+void quad_emulate(const QuadLayout& layout, const QuadSchedule& schedule,
+                  const QuadTiling& tiling, const std::vector<double>& table,
+                  const double* densities, int64_t ldb, int64_t n_draws, int n_r,
+                  bool separate, double* out) {
+  const int n_u = tiling.n_u, up = (n_u + 1) / 2, rt = 4 * n_u;
+  const size_t per_unit = (size_t)up * 128;
+  const int n_comp_out = separate ? (int)layout.comps.size() : 1;
+  std::vector<double> partial((size_t)schedule.n_slabs * rt * 32, 0.0);
+  // densities of bin `bin` (zero beyond the last one, as the buffer resource returns)
+  auto density = [&](int bin, int64_t draw) {
+    return bin < layout.n_bins ? densities[(size_t)bin * ldb + draw] : 0.0;
+  };
+  for (int w = 0; w < schedule.n_waves; ++w) {
+    std::vector<double> f((size_t)n_u * 2 * 64, 0.0);      // F[u][set] per lane
+    for (int ri = schedule.wave_runs[w]; ri < schedule.wave_runs[w + 1]; ++ri) {
+      const QuadRun& run = schedule.runs[ri];
+      const QuadComp& comp = layout.comps[run.comp];
+      int rb = run.rb0, cb = run.cb0, left = run.count;
+      int64_t unit = comp.unit_base + (comp.triangular ? (int64_t)rb * (rb + 1) / 2 + cb
+                                                       : (int64_t)rb * comp.n_cb + cb);
+      while (left > 0) {
+        const int n = std::min(quad_row_length(comp, rb) - cb, left);
+        left -= n;
+        // D[u][set][v] per lane: r = 4 u + l / 16, i = i0 + v, draw = 2 (l % 16) + set
+        std::vector<double> d((size_t)n_u * 2 * 4 * 64, 0.0);
+        for (int t = 0; t < n; ++t, ++unit) {
+          const double* a_unit =
+              table.data() + ((size_t)run.rtile * layout.n_units + unit) * per_unit;
+          for (int u = 0; u < n_u; ++u)
+            for (int set = 0; set < 2; ++set)
+              for (int l = 0; l < 64; ++l)      // output lane
+                for (int v = 0; v < 4; ++v) {
+                  const int m = (l >> 4) + 4 * v, col = l & 15;
+                  double sum = d[(((size_t)u * 2 + set) * 4 + v) * 64 + l];
+                  for (int k = 0; k < 4; ++k) {
+                    const int lane_a = k * 16 + m, lane_b = k * 16 + col;
+                    const double av = a_unit[((size_t)(u / 2) * 64 + lane_a) * 2 + (u & 1)];
+                    const double bv = density(comp.j_bin0 + 4 * (cb + t) + (lane_b >> 4),
+                                              (int64_t)run.tile * 32 + 2 * (lane_b & 15) + set);
+                    sum = std::fma(av, bv, sum);
+                  }
+                  d[(((size_t)u * 2 + set) * 4 + v) * 64 + l] = sum;
+                }
+        }
+        for (int u = 0; u < n_u; ++u)
+          for (int set = 0; set < 2; ++set)
+            for (int l = 0; l < 64; ++l)
+              for (int v = 0; v < 4; ++v)
+                f[((size_t)u * 2 + set) * 64 + l] = std::fma(
+                    d[(((size_t)u * 2 + set) * 4 + v) * 64 + l],
+                    density(comp.i_bin0 + 4 * rb + v, (int64_t)run.tile * 32 + 2 * (l & 15) + set),
+                    f[((size_t)u * 2 + set) * 64 + l]);
+        ++rb;
+        cb = 0;
+      }
+      if (run.slab >= 0) {
+        for (int u = 0; u < n_u; ++u)
+          for (int set = 0; set < 2; ++set)
+            for (int l = 0; l < 64; ++l) {
+              partial[((size_t)run.slab * rt + 4 * u + (l >> 4)) * 32 + 2 * (l & 15) + set] =
+                  f[((size_t)u * 2 + set) * 64 + l];
+              f[((size_t)u * 2 + set) * 64 + l] = 0.0;
+            }
+      }
+    }
+  }
+  // finalize_quad_kernel's grouping
+  for (int64_t b = 0; b < n_draws; ++b) {
+    const int64_t tile32 = b / 32;
+    for (int c = 0; c < n_comp_out; ++c)
+      for (int r = 0; r < n_r; ++r) {
+        const int z = r / tiling.r_per_tile, r_local = r % tiling.r_per_tile;
+        const int64_t group = (tile32 * tiling.n_rtiles + z) * n_comp_out + c;
+        double sum = 0.0;
+        for (int s = schedule.group_begin[group]; s < schedule.group_begin[group + 1]; ++s)
+          sum += partial[((size_t)s * rt + r_local) * 32 + b % 32];
+        out[((size_t)b * n_comp_out + c) * n_r + r] = sum;
+      }
+  }
+}
+
 void build_chunking(const Plan& plan, int n_chunks, int waves_per_group,
                     Chunking& out) {
   out.waves_per_group = waves_per_group;

@@ -101,6 +101,104 @@ void build_plan(int mode, int n_bins, const uint8_t* is_central, int block,
 void build_chunking(const Plan& plan, int n_chunks, int waves_per_group,
                     Chunking& out);
 
+// ---- quadratic-form contraction (mode auto, float64) ------------------------------------
+//
+// sum_p T[r][p] c_p n_i n_j = sum_i n_i (sum_{j <= i} c_ij T_r[i][j] n_j): the inner sum is a
+// matrix product over j with the density rows themselves as one operand (no pair weights
+// to form), the outer factor n_i is applied once per row of 4 x 4 bin blocks.  The work
+// is cut into UNITS: one 4 x 4 block of bin pairs (block row rb, block column cb of one
+// component) x all r values of one r tile x one tile of 32 draws = 2 U matrix-core
+// instructions (U = r sub-tiles of 4 per r tile, <= 5).  A layout lists the components
+// (the whole triangle, or cen-cen triangle / cen-sat rectangle / sat-sat triangle when
+// the output is separated by galaxy type: each type is then padded to whole blocks) and
+// numbers their units row-major; the table is stored per r tile and unit as
+// [u pair][lane = k * 16 + r_local + 4 i_local][2] doubles (kernels.hip.h).
+struct QuadComp {
+  int32_t component;     // 0 cen-cen (or everything), 1 cen-sat, 2 sat-sat
+  int32_t triangular;    // block columns 0 .. rb of block row rb, else all n_cb
+  int32_t i_bin0;        // first row bin (library order)
+  int32_t i_count;
+  int32_t j_bin0;        // first column bin
+  int32_t j_count;
+  int32_t n_rb;          // block rows
+  int32_t n_cb;          // block columns (triangle: n_rb)
+  int64_t unit_base;     // first unit of the component in the layout
+  int64_t n_units;
+};
+
+struct QuadLayout {
+  int n_bins = 0;
+  int n_central = 0;
+  bool by_type = false;
+  std::vector<QuadComp> comps;   // 1 (whole triangle) or 3
+  int64_t n_units = 0;
+};
+
+void build_quad_layout(int n_bins, int n_central, bool by_type, QuadLayout& out);
+
+// Units of block row rb of a component.
+inline int quad_row_length(const QuadComp& comp, int rb) {
+  return comp.triangular ? rb + 1 : comp.n_cb;
+}
+
+// The work of one wavefront is a list of RUNS: `count` consecutive units of one (draw
+// tile, r tile, component, table), starting at block (rb0, cb0).  After a run with
+// slab >= 0 the wave writes its sums to that slab of the partial buffer and clears them.
+struct QuadRun {
+  int32_t tile;      // tile of 32 draws
+  int32_t rtile;
+  int32_t comp;      // index into the layout's components
+  int32_t table;     // interpolator: table index, else 0
+  int32_t rb0;
+  int32_t cb0;
+  int32_t count;
+  int32_t slab;
+};
+
+// The linearised unit space (draw tile, r tile, component, table, unit), cut into equal
+// contiguous ranges, one per wave -- every wave gets the same number of matrix-core
+// instructions whatever the batch size.  Slabs are numbered in run order, so the slabs of
+// one output group (draw tile, r tile[, component when `separate`]) are consecutive:
+// group g owns slabs [group_begin[g], group_begin[g + 1]).
+struct QuadSchedule {
+  int n_waves = 0;
+  int n_slabs = 0;
+  int n_groups = 0;
+  std::vector<QuadRun> runs;
+  std::vector<int32_t> wave_runs;     // n_waves + 1
+  std::vector<int32_t> group_begin;   // n_groups + 1
+};
+
+void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, int n_tables,
+                         bool separate, int max_waves, int min_units_per_wave,
+                         QuadSchedule& out);
+
+// r tiling of the quadratic-form kernel: n_rtiles tiles of r_per_tile values (the last one
+// may hold fewer), n_u = ceil(r_per_tile / 4) <= 5 sub-tiles of 4.
+struct QuadTiling {
+  int n_rtiles = 1;
+  int r_per_tile = 0;
+  int n_u = 0;
+};
+QuadTiling quad_tiling(int n_r);
+
+// The re-laid-out matrix of a layout: (n_rtiles, n_units, (n_u + 1) / 2, 64 lanes, 2)
+// doubles with the pair prefactor folded in; `matrix` is the reference's (n_r, n_pairs)
+// tpcf_matrix in float64 or float32, `perm` the library's bin order.
+void fill_quad_table(const QuadLayout& layout, const std::vector<int32_t>& perm, int n_r,
+                     int64_t n_pairs, const void* matrix, bool matrix_is_f32,
+                     const QuadTiling& tiling, std::vector<double>& out);
+
+// TEST INFRASTRUCTURE (never called by the product): executes a schedule on the host the
+// way contract_quad_kernel + finalize_quad_kernel do -- same operand lanes, same unit
+// walk, same slab grouping -- so that the layout, the schedule and the grouping can be
+// checked without a GPU.  densities: (n_bins, ldb); out: (n_draws, n_comp_out, n_r) sums
+// before the normalisation.
+void quad_emulate(const QuadLayout& layout, const QuadSchedule& schedule,
+                  const QuadTiling& tiling, const std::vector<double>& table,
+                  const double* densities, int64_t ldb, int64_t n_draws, int n_r,
+                  bool separate, double* out);
+
 // Position order inside a segment: j -> j + 1, wrapping to (i + 1, j_lo) after column
 // `j_last` (rectangle) or after the diagonal (j_last < 0).
 inline void advance_pair(int j_lo, int j_last, int& i, int& j) {

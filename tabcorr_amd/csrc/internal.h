@@ -133,6 +133,29 @@ struct Quadrature {
   void* weight = nullptr;
 };
 
+// A schedule of the quadratic-form kernel on the device (hostmath.h: QuadSchedule).
+struct DeviceQuadSchedule {
+  int n_waves = 0;
+  int n_slabs = 0;
+  int n_groups = 0;
+  int n_runs = 0;
+  void* runs = nullptr;
+  void* wave_runs = nullptr;
+  void* group_begin = nullptr;
+};
+
+// One layout of a table for the quadratic-form kernel: the re-laid-out matrix, the
+// components, and the schedules built so far, keyed by (draw tiles, separate, tables).
+struct QuadTable {
+  tc::QuadLayout layout;
+  void* d_table = nullptr;      // (n_rtiles, n_units, (n_u + 1) / 2, 64, 2) doubles
+  void* d_comps = nullptr;      // QuadCompArgs per component
+  size_t rtile_bytes = 0;
+  size_t bytes = 0;
+  std::map<std::vector<int64_t>, std::unique_ptr<DeviceQuadSchedule>> schedules;
+  void release();
+};
+
 inline int env_int(const char* name, int fallback) {
   const char* value = getenv(name);
   if (value == nullptr || *value == 0) return fallback;
@@ -167,6 +190,15 @@ struct tc_table {
   void* d_math_table = nullptr;  // fastmath.h tables
   void* d_pos_ij = nullptr;      // float32 variant: packed bin pairs per position
   void* d_pos_off = nullptr;     // FP64 kernel: LDS row byte offsets per position
+  // Mode auto in float64 runs the quadratic-form kernel (kernels.hip.h): the matrix by
+  // galaxy type (cen-cen / cen-sat / sat-sat, each type padded to whole 4 x 4 blocks; also
+  // serves the total when the number of centrals is a multiple of 4) and, otherwise, the
+  // unpadded whole triangle for the total prediction.
+  bool quad = false;
+  tc::QuadTiling quad_tiling;
+  tc::host::QuadTable quad_by_type, quad_total;
+  int n_cus = 256;               // compute units of the device
+  int quad_waves_per_simd = 2;   // resident waves of the contraction per SIMD
   std::map<int, tc::host::Quadrature> quadrature;
   std::map<std::pair<int, int>, std::unique_ptr<tc::host::DeviceChunking>> chunkings;
   std::map<int64_t, tc::host::DeviceChunking*> choices;   // decomposition chosen per tile count
@@ -237,6 +269,16 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
 int check_predict_args(const tc_table* t, const void* theta, int n_theta, int64_t n_draws,
                        int n_gauss, unsigned flags);
 int launch_finalize(const FinalizeArgs& args, hipStream_t stream);
+// Quadratic-form path: layout upload, schedules, launches.
+int build_quad_table(tc_table* t, bool by_type, const void* matrix, int matrix_dtype,
+                     QuadTable* out);
+int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, bool separate,
+                      DeviceQuadSchedule** out);
+int launch_contract_quad(int n_u, bool interp, const QuadArgs& args, hipStream_t stream);
+int launch_finalize_quad(const FinalizeQuadArgs& args, hipStream_t stream);
+// Largest number of draws one slab may hold (workspaces bounded; 32-bit scalar offsets of
+// the quadratic-form kernel: n_bins * ldb * 8 < 2^32).
+int64_t max_slab(const tc_table* t);
 bool single_draw_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags);
 int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_gauss,
                        unsigned flags, double* ngal, double* xi, hipStream_t stream);

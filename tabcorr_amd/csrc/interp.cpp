@@ -20,6 +20,8 @@ struct tc_interp {
   void* d_table_node = nullptr;
   void* d_table_class = nullptr;
   void* d_tables = nullptr;                 // (K) device pointers
+  void* d_quad_by_type = nullptr;           // (K) matrices of the quadratic-form kernel
+  void* d_quad_total = nullptr;             // (K) ... unpadded triangle, if the tables have it
   void* d_nbufs = nullptr;                  // (V) device pointers
   void* d_ngal_parts = nullptr;             // (V) device pointers
   std::vector<int> axis_offset, a_offset;
@@ -97,6 +99,57 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   ia.ngal = ngal_device;
   status = launch_interp_coef(ia, it->stream);
   if (status != TC_OK) return status;
+
+  if (t0->quad) {
+    // quadratic-form kernel: the unit space (draw tile, r tile, component, TABLE, unit) in
+    // equal shares per wave; a table's spline weight scales the outer factor n_i
+    const bool by_type = separate || t0->quad_total.d_table == nullptr;
+    QuadTable* q = by_type ? &t0->quad_by_type : &t0->quad_total;
+    const tc::QuadTiling& tiling = t0->quad_tiling;
+    DeviceQuadSchedule* schedule = nullptr;
+    status = get_quad_schedule(t0, q, ldb / tc::kQuadTile, it->n_tables, separate, &schedule);
+    if (status != TC_OK) return status;
+    const int rt = 4 * tiling.n_u;
+    status = it->partial.reserve(
+        (size_t)schedule->n_slabs * rt * tc::kQuadTile * sizeof(double), it->stream);
+    if (status != TC_OK) return status;
+    tc::QuadArgs qa;
+    qa.nbuf = nullptr;
+    qa.nbufs = (const double* const*)it->d_nbufs;
+    qa.ldb = ldb;
+    qa.n_bins = t0->n_bins;
+    qa.table = nullptr;
+    qa.tables = (const double* const*)(by_type ? it->d_quad_by_type : it->d_quad_total);
+    qa.table_class = (const int32_t*)it->d_table_class;
+    qa.coef = (const double*)it->coef.ptr;
+    qa.rtile_bytes = (uint32_t)q->rtile_bytes;
+    qa.runs = (const tc::QuadRun*)schedule->runs;
+    qa.comps = (const tc::QuadCompArgs*)q->d_comps;
+    qa.wave_runs = (const int32_t*)schedule->wave_runs;
+    qa.n_waves = schedule->n_waves;
+    qa.partial = (double*)it->partial.ptr;
+    qa.priority = 1;
+    status = launch_contract_quad(tiling.n_u, true, qa, it->stream);
+    if (status != TC_OK) return status;
+    tc::FinalizeQuadArgs fq;
+    fq.partial = (const double*)it->partial.ptr;
+    fq.group_begin = (const int32_t*)schedule->group_begin;
+    fq.ngal_part = nullptr;      // already normalised; ngal written by the coef kernel
+    fq.n_ngal_parts = 0;
+    fq.n_rtiles = tiling.n_rtiles;
+    fq.r_per_tile = tiling.r_per_tile;
+    fq.rt = rt;
+    fq.groups_per_rtile = separate ? (int)q->layout.comps.size() : 1;
+    fq.priority = 3;
+    fq.n_comp = n_comp;
+    fq.n_r = t0->n_r;
+    fq.mode = t0->mode;
+    fq.ldb = ldb;
+    fq.n_draws = n_draws;
+    fq.ngal = ngal_device;
+    fq.xi = xi_device;
+    return launch_finalize_quad(fq, it->stream);
+  }
 
   // decomposition: as for one table (choose_chunking), with the tables looped inside
   // the block; the tables are split over blocks only when one pass would leave the chip
@@ -199,7 +252,10 @@ int tc_interp_create(tc_table* const* tables, int n_tables, int n_dim,
   TC_CHECK(tables != nullptr && points != nullptr, "NULL argument");
   TC_CHECK(n_tables >= 1 && n_dim >= 1 && n_dim <= tc::kMaxInterpDim,
            "invalid number of tables or dimensions");
-  std::unique_ptr<tc_interp> it(new tc_interp);
+  struct Destroy {
+    void operator()(tc_interp* interp) const { tc_interp_destroy(interp); }
+  };
+  std::unique_ptr<tc_interp, Destroy> it(new tc_interp);
   TC_HIP(hipGetDevice(&it->device));
   it->n_tables = n_tables;
   it->n_dim = n_dim;
@@ -279,17 +335,21 @@ int tc_interp_create(tc_table* const* tables, int n_tables, int n_dim,
   std::vector<void*> table_ptrs;
   for (int k = 0; k < n_tables; ++k) table_ptrs.push_back(tables[k]->d_table);
   std::vector<void*> zeros(n_classes, nullptr);
+  std::vector<void*> quad_by_type, quad_total;
+  for (int k = 0; k < n_tables; ++k) {
+    quad_by_type.push_back(tables[k]->quad_by_type.d_table);
+    quad_total.push_back(tables[k]->quad_total.d_table);
+  }
   int status = upload(xp_all, &it->d_xp);
+  if (status == TC_OK) status = upload(quad_by_type, &it->d_quad_by_type);
+  if (status == TC_OK) status = upload(quad_total, &it->d_quad_total);
   if (status == TC_OK) status = upload(a_all, &it->d_a);
   if (status == TC_OK) status = upload(it->table_node, &it->d_table_node);
   if (status == TC_OK) status = upload(it->table_class, &it->d_table_class);
   if (status == TC_OK) status = upload(table_ptrs, &it->d_tables);
   if (status == TC_OK) status = upload(zeros, &it->d_nbufs);
   if (status == TC_OK) status = upload(zeros, &it->d_ngal_parts);
-  if (status != TC_OK) {
-    tc_interp_destroy(it.release());
-    return status;
-  }
+  if (status != TC_OK) return status;
   *out = it.release();
   return TC_OK;
 }
@@ -299,7 +359,7 @@ int tc_interp_destroy(tc_interp* it) {
   (void)hipSetDevice(it->device);
   if (it->stream) (void)hipStreamSynchronize(it->stream);
   for (void* p : {it->d_xp, it->d_a, it->d_table_node, it->d_table_class, it->d_tables,
-                  it->d_nbufs, it->d_ngal_parts})
+                  it->d_nbufs, it->d_ngal_parts, it->d_quad_by_type, it->d_quad_total})
     if (p) (void)hipFree(p);
   for (auto& kv : it->chunkings)
     for (void* p : {kv.second->chunks, kv.second->groups})
@@ -344,8 +404,9 @@ int tc_interp_predict_zheng07_batch_device(tc_interp* it, const double* theta_de
   TC_HIP(hipSetDevice(it->device));
   const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
   const int n_comp = separate ? it->tables[0]->plan.n_components : 1;
-  for (int64_t begin = 0; begin < n_draws; begin += kMaxSlab) {
-    const int64_t n = std::min(kMaxSlab, n_draws - begin);
+  const int64_t slab = max_slab(it->tables[0]);
+  for (int64_t begin = 0; begin < n_draws; begin += slab) {
+    const int64_t n = std::min(slab, n_draws - begin);
     status = interp_predict_device(
         it, theta_device + begin * n_theta, n_theta, x_device + begin * it->n_dim, n,
         n_gauss, flags, ngal_device + begin * (separate ? 2 : 1),

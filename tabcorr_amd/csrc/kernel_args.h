@@ -98,6 +98,58 @@ struct ContractArgs {
   const double* coef;       // (n_tables, ldb) spline weight / pair-weight norm
 };
 
+// ---- quadratic-form contraction (contract_quad_kernel, mode auto, float64) --------------
+constexpr int kQuadMaxU = 5;          // r sub-tiles of 4 per r tile: at most 20 r values
+constexpr int kQuadTile = 32;         // draws per tile (two matrix-core column sets of 16)
+constexpr int kQuadWavesPerBlock = 4;
+
+// Device copy of a QuadComp: what the kernel needs to walk a component (32 bytes).
+struct QuadCompArgs {
+  int32_t triangular;
+  int32_t i_bin0;
+  int32_t j_bin0;
+  int32_t n_cb;
+  uint32_t unit_base;       // first unit of the component inside an r tile
+  int32_t pad[3];
+};
+
+struct QuadArgs {
+  const double* nbuf;              // (n_bins, ldb); interpolator: NULL
+  const double* const* nbufs;      // interpolator: density buffer of each class
+  int64_t ldb;
+  int n_bins;
+  const void* table;               // (n_rtiles, n_units, UP, 64, 2) doubles; interpolator: NULL
+  const double* const* tables;     // interpolator: one such matrix per table
+  const int32_t* table_class;      // interpolator: density class of each table
+  const double* coef;              // interpolator: (n_tables, ldb) spline weight / norm
+  uint32_t rtile_bytes;            // bytes of one r tile of a table
+  const QuadRun* runs;
+  const QuadCompArgs* comps;
+  const int32_t* wave_runs;        // (n_waves + 1)
+  int n_waves;
+  int priority;                    // wave priority (0..3)
+  double* partial;                 // (n_slabs, 4 U, 32)
+};
+
+struct FinalizeQuadArgs {
+  const double* partial;        // (n_slabs, rt, 32)
+  const int32_t* group_begin;   // (n_groups + 1): slabs of each (draw tile, r tile[, component])
+  const double* ngal_part;      // as FinalizeArgs
+  int n_ngal_parts;
+  int n_rtiles;
+  int r_per_tile;               // r values per r tile (the last tile may hold fewer)
+  int rt;                       // 4 U: rows of a slab
+  int groups_per_rtile;         // 1, or the number of components when separated
+  int n_comp;                   // output components
+  int n_r;
+  int mode;
+  int priority;
+  int64_t ldb;
+  int64_t n_draws;
+  double* ngal;
+  double* xi;
+};
+
 struct FinalizeArgs {
   const double* partial;   // (n_groups, r_stride, ldb)
   const Group* groups;     // component of each group

@@ -19,6 +19,8 @@
 
 namespace tc {
 
+static_assert(sizeof(QuadRun) == 32 && sizeof(QuadCompArgs) == 32, "read as 8 x int32");
+
 // Pointers whose loads must go through the scalar cache.
 typedef const __attribute__((address_space(4))) double* sc_f64;
 typedef const __attribute__((address_space(4))) float* sc_f32;
@@ -26,6 +28,16 @@ typedef const __attribute__((address_space(4))) int32_t* sc_i32;
 // Pointers that were themselves loaded from memory are generic to the compiler; this
 // tells it they point to global memory (global_load with counted vmcnt, not flat_load).
 typedef const __attribute__((address_space(1))) double* gl_f64;
+
+// wave priority chosen at run time (experiments: who wins the FP64 pipe)
+__device__ inline void set_priority(int priority) {
+  switch (priority) {
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    default: __builtin_amdgcn_s_setprio(0); break;
+  }
+}
 
 __device__ inline double heaviside_assembias(double n, double strength,
                                              bool above, double f2_over_f1,
@@ -58,7 +70,7 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
   const fm::Consts kc = fm::make_consts();
   // short kernel on the critical path of its lane: run ahead of the contraction waves
   // of neighbouring batches it shares the CUs with
-  __builtin_amdgcn_s_setprio(3);
+  set_priority((int)(a.flags >> 8) & 3);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_gauss = NGAUSS > 0 ? NGAUSS : a.n_gauss;
@@ -456,6 +468,264 @@ __global__ __launch_bounds__(512) void contract_mfma_kernel(ContractArgs a) {
     rec[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
     rec[5] = (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf) |
              ((c_main - c_staged) << 4);   // XCC_ID, shader cycles of the main loop
+  }
+}
+
+// ---- contraction as a quadratic form (mode auto, float64) -----------------------------
+//
+//   sum_p c_p T[r][p] n_i n_j = sum_i n_i ( sum_{j <= i} c_ij T_r[i][j] n_j )
+//
+// (tabcorr.py:626-655 regrouped).  The inner sum is a matrix product over j whose second
+// operand is the density row itself: no pair weights to form, no gathers.  One
+// v_mfma_f64_16x16x4_f64 covers a 4 x 4 block of bin pairs (4 i x 4 j), 4 r values and 16
+// draws; operand lanes (MI355X programming guide, f64 forms): A[m = l % 16][k = l / 16],
+// B[k = l / 16][n = l % 16], D[m = l / 16 + 4 v][n = l % 16] in register v = 0..3.  With
+// m = r_local + 4 i_local, k = j_local and n = draw:
+//   A = c_ij T[r = 4 u + m % 4][i = i0 + m / 4][j = j0 + k]   one double per lane from the
+//       re-laid-out table, two r sub-tiles u per 16-byte load;
+//   B = n[j0 + l / 16][draws 2 (l % 16), 2 (l % 16) + 1]       one 16-byte load serves the
+//       wave's two column sets (even / odd draws of its 32-draw tile);
+//   D[u][set][v]: r = 4 u + l / 16, i = i0 + v, draw = 2 (l % 16) + set.
+// After the last block of a block row: F[u][set] += sum_v D[u][set][v] n[i0 + v][draw]
+// (40 FMAs per ~13 x 10 matrix instructions).  Per unit (4 x 4 bin block, all U sub-tiles,
+// 32 draws): 2 U matrix instructions, (U + 1) / 2 + 1 loads, nothing else: every address
+// is a buffer resource + constant lane offset + scalar offset, so the vector ALU (which
+// shares the FP64 pipe with the matrix instructions) stays idle.  Reads past the end of a
+// resource return zero: bins beyond the last one need no padding.
+//
+// No workgroup structure, no LDS, no barriers: the (draw tile, r tile, component, table,
+// unit) space is cut into equal contiguous ranges, one per resident wave (hostmath.h:
+// QuadSchedule), so every SIMD retires the same number of matrix instructions whatever
+// the batch size; a wave writes its sums to a slab of the partial buffer whenever it
+// leaves an output group, finalize_quad_kernel adds the slabs in fixed order.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const double* f64_ptr;
+typedef const __attribute__((address_space(4))) f64_ptr* sc_ptrs;   // array of pointers
+
+constexpr unsigned kBufferFlags = 0x00020000;   // raw buffer, 32-bit data format (gfx9 family)
+
+template <int IMM>
+__device__ inline f64x2 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_offset,
+                                      unsigned wave_offset) {
+  return __builtin_bit_cast(
+      f64x2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_offset + IMM, wave_offset, 0));
+}
+
+template <int U, bool INTERP>
+__global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_kernel(QuadArgs a) {
+  constexpr int UP = (U + 1) / 2;
+  constexpr bool interp = INTERP;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(
+      (int)blockIdx.x * kQuadWavesPerBlock + (int)(threadIdx.x >> 6));
+  if (wave >= a.n_waves) return;
+  set_priority(a.priority);
+  sc_i32 wave_runs = (sc_i32)a.wave_runs;
+  sc_i32 runs = (sc_i32)a.runs;       // QuadRun = 8 x int32
+  sc_i32 comps = (sc_i32)a.comps;     // QuadCompArgs = 8 x int32
+  const int run_begin = wave_runs[wave], run_end = wave_runs[wave + 1];
+  const int c = lane & 15, kq = lane >> 4;
+  const unsigned row_bytes = (unsigned)(a.ldb * 8);
+  const unsigned off_a = lane * 16;                    // table: (unit, u pair, lane) x 16 B
+  const unsigned off_e = c * 16;                       // densities of draws 2 c, 2 c + 1
+  const unsigned off_b = kq * row_bytes + c * 16;      // ... of bin j0 + l / 16
+  double F[U][2];
+#pragma unroll
+  for (int u = 0; u < U; ++u) F[u][0] = F[u][1] = 0.0;
+
+  for (int ri = run_begin; ri < run_end; ++ri) {
+    const int tile = runs[ri * 8 + 0], rtile = runs[ri * 8 + 1], comp = runs[ri * 8 + 2];
+    const int table = runs[ri * 8 + 3], rb0 = runs[ri * 8 + 4], cb0 = runs[ri * 8 + 5];
+    const int count = runs[ri * 8 + 6], slab = runs[ri * 8 + 7];
+    const bool triangular = comps[comp * 8 + 0] != 0;
+    const int i_bin0 = comps[comp * 8 + 1], j_bin0 = comps[comp * 8 + 2];
+    const int n_cb = comps[comp * 8 + 3];
+    const unsigned unit_base = (unsigned)comps[comp * 8 + 4];
+
+    const double* densities =
+        interp ? ((sc_ptrs)a.nbufs)[((sc_i32)a.table_class)[table]] : a.nbuf;
+    const char* matrix = (const char*)(interp ? (const void*)((sc_ptrs)a.tables)[table]
+                                              : a.table) + (int64_t)rtile * a.rtile_bytes;
+    // the tile's 32 draws of every bin; rows past the last bin read as zero
+    const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(densities + (int64_t)tile * kQuadTile), 0,
+        (unsigned)a.n_bins * row_bytes - (unsigned)tile * (kQuadTile * 8), kBufferFlags);
+    const __amdgpu_buffer_rsrc_t rs_t =
+        __builtin_amdgcn_make_buffer_rsrc((void*)matrix, 0, a.rtile_bytes, kBufferFlags);
+    f64x2 cf = {1.0, 1.0};
+    if (interp)   // spline weight / pair-weight norm of this table for the lane's two draws
+      cf = *(const __attribute__((address_space(1))) f64x2*)(
+          a.coef + (int64_t)table * a.ldb + (int64_t)tile * kQuadTile + 2 * c);
+
+    int rb = rb0, cb = cb0, left = count;
+    unsigned ua = (unit_base + (unsigned)(triangular ? rb * (rb + 1) / 2 + cb : rb * n_cb + cb)) *
+                  (UP * 1024);
+    f64x2 t0[UP], t1[UP], b0, b1;
+    f64x4 D[U][2];
+    // Operands of the unit at table offset `ua` and block column `col`.  Unconditional
+    // (one basic block per phase keeps every prefetch where it is written); at worst a
+    // wave reads one unit nobody uses.
+    auto fetch = [&](f64x2 (&t)[UP], f64x2& b, int col) {
+      t[0] = buffer_load16<0>(rs_t, off_a, ua);
+      if (UP > 1) t[1] = buffer_load16<1024>(rs_t, off_a, ua);
+      if (UP > 2) t[2] = buffer_load16<2048>(rs_t, off_a, ua);
+      b = buffer_load16<0>(rs_n, off_b, (unsigned)(j_bin0 + 4 * col) * row_bytes);
+      ua += UP * 1024;
+    };
+    auto mma = [&](const f64x2 (&t)[UP], const f64x2& b, bool first) {
+      if (first) {
+        const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const double av = (u & 1) ? t[u >> 1].y : t[u >> 1].x;
+          D[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b.x, zero, 0, 0, 0);
+          D[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b.y, zero, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const double av = (u & 1) ? t[u >> 1].y : t[u >> 1].x;
+          D[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b.x, D[u][0], 0, 0, 0);
+          D[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b.y, D[u][1], 0, 0, 0);
+        }
+      }
+    };
+    fetch(t0, b0, cb);
+    while (left > 0) {
+      // the units of one block row inside this run: n >= 1; on entry the first one is
+      // in (t0, b0)
+      const int row_length = triangular ? rb + 1 : n_cb;
+      const int n = row_length - cb < left ? row_length - cb : left;
+      left -= n;
+      f64x2 e[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        e[v] = buffer_load16<0>(rs_n, off_e, (unsigned)(i_bin0 + 4 * rb + v) * row_bytes);
+      // (the scheduling barriers keep the compiler from sinking a prefetch next to its
+      // use: the loads of unit t + 1 are in flight while unit t runs on the matrix core)
+      fetch(t1, b1, n > 1 ? cb + 1 : 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(t0, b0, true);
+      __builtin_amdgcn_sched_barrier(0);
+      int t = 1;
+      for (; t + 1 < n; t += 2) {
+        fetch(t0, b0, cb + t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(t1, b1, false);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(t1, b1, t + 2 < n ? cb + t + 2 : 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(t0, b0, false);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (t < n) {
+        // one unit left, in (t1, b1); the next row's first unit goes to (t0, b0)
+        fetch(t0, b0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(t1, b1, false);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        // the next row's first unit sits in (t1, b1)
+#pragma unroll
+        for (int p = 0; p < UP; ++p) t0[p] = t1[p];
+        b0 = b1;
+      }
+      // the row's outer factor: F += D n_i (x the table's spline weight)
+      if (interp) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) e[v] *= cf;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          F[u][0] = fma(D[u][0][v], e[v].x, F[u][0]);
+          F[u][1] = fma(D[u][1][v], e[v].y, F[u][1]);
+        }
+      ++rb;
+      cb = 0;
+    }
+    if (slab >= 0) {
+      // r = 4 u + l / 16, draws 2 c and 2 c + 1 of the tile
+      double* out = a.partial + ((int64_t)slab * (4 * U) + kq) * kQuadTile + 2 * c;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const f64x2 value = {F[u][0], F[u][1]};
+        *(f64x2*)(out + (4 * u) * kQuadTile) = value;
+        F[u][0] = F[u][1] = 0.0;
+      }
+    }
+  }
+}
+
+// Sums the slabs of every output group in slab order, normalises and writes the results
+// in the reference's order: finalize_kernel for the partial layout of contract_quad_kernel.
+// One block per 64 draws (two 32-draw tiles, each with its own slab lists).
+__global__ __launch_bounds__(1024) void finalize_quad_kernel(FinalizeQuadArgs a) {
+  __shared__ double tile[kFinalizeRows][kLanes + 1];
+  __shared__ double norm_inv[kLanes];
+  set_priority(a.priority);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t col = (int64_t)blockIdx.x * kLanes;
+  const int64_t n_valid = a.n_draws - col < kLanes ? a.n_draws - col : kLanes;
+
+  if (wave == 0 && a.ngal_part == nullptr) norm_inv[lane] = 1.0;
+  if (wave == 0 && a.ngal_part != nullptr) {
+    double n_cen = 0.0, n_sat = 0.0;
+    for (int p = 0; p < a.n_ngal_parts; ++p) {
+      n_cen += a.ngal_part[((int64_t)p * 2 + 0) * a.ldb + col + lane];
+      n_sat += a.ngal_part[((int64_t)p * 2 + 1) * a.ldb + col + lane];
+    }
+    const double total = n_cen + n_sat;
+    norm_inv[lane] = a.mode == 0 ? total * total : total;
+    if (lane < n_valid && blockIdx.y == 0) {
+      if (a.n_comp == 1) {
+        a.ngal[col + lane] = total;
+      } else {
+        a.ngal[2 * (col + lane)] = n_cen;
+        a.ngal[2 * (col + lane) + 1] = n_sat;
+      }
+    }
+  }
+  __syncthreads();
+  const double norm = norm_inv[lane];
+
+  const int n_rows = a.n_comp * a.n_r;
+  const int n_waves = blockDim.x >> 6;
+  const int rows_per_block = (n_rows + gridDim.y - 1) / gridDim.y;
+  const int row_begin = blockIdx.y * rows_per_block;
+  const int row_end = row_begin + rows_per_block < n_rows ? row_begin + rows_per_block : n_rows;
+  const int64_t tile32 = (int64_t)blockIdx.x * 2 + (lane >> 5);
+  const int64_t slab_stride = (int64_t)a.rt * kQuadTile;
+  auto sum_slabs = [&](int row) {
+    const int comp = row / a.n_r, r = row % a.n_r;
+    const int rtile = r / a.r_per_tile, r_local = r % a.r_per_tile;
+    const int64_t group = (tile32 * a.n_rtiles + rtile) * a.groups_per_rtile +
+                          (a.groups_per_rtile > 1 ? comp : 0);
+    const int begin = a.group_begin[group], end = a.group_begin[group + 1];
+    const double* src = a.partial + ((int64_t)begin * a.rt + r_local) * kQuadTile + (lane & 31);
+    double sum = 0.0;
+    for (int s0 = begin; s0 < end; s0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = s0 + u < end ? src[(s0 - begin + u) * slab_stride] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    return sum;
+  };
+  for (int row0 = row_begin; row0 < row_end; row0 += kFinalizeRows) {
+    const int rows = row_end - row0 < kFinalizeRows ? row_end - row0 : kFinalizeRows;
+    for (int rr = wave; rr < rows; rr += n_waves) tile[rr][lane] = sum_slabs(row0 + rr) / norm;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < rows * kLanes; idx += blockDim.x) {
+      const int d = idx / rows, rr = idx % rows;
+      if (d < n_valid) a.xi[(col + d) * (int64_t)n_rows + row0 + rr] = tile[rr][d];
+    }
+    __syncthreads();
   }
 }
 

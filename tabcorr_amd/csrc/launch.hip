@@ -178,6 +178,205 @@ int choose_chunking(tc_table* t, int64_t n_draws, int tables_per_block,
   return TC_OK;
 }
 
+// ---- quadratic-form path -------------------------------------------------------------------
+
+void QuadTable::release() {
+  for (void* p : {d_table, d_comps})
+    if (p) (void)hipFree(p);
+  d_table = d_comps = nullptr;
+  for (auto& kv : schedules)
+    for (void* p : {kv.second->runs, kv.second->wave_runs, kv.second->group_begin})
+      if (p) (void)hipFree(p);
+  schedules.clear();
+}
+
+int64_t max_slab(const tc_table* t) {
+  // scalar offsets into the density buffer are 32 bits: n_bins * ldb * 8 < 2^32
+  const int64_t by_offset = ((int64_t)0xff000000 / (8 * (int64_t)std::max(1, t->n_bins))) / 64 * 64;
+  return std::max<int64_t>(64, std::min<int64_t>(kMaxSlab, by_offset));
+}
+
+int build_quad_table(tc_table* t, bool by_type, const void* matrix, int matrix_dtype,
+                     QuadTable* out) {
+  tc::build_quad_layout(t->n_bins, t->plan.n_central, by_type, out->layout);
+  std::vector<double> host;
+  tc::fill_quad_table(out->layout, t->plan.perm, t->n_r, t->n_pairs, matrix,
+                      matrix_dtype == TC_DTYPE_F32, t->quad_tiling, host);
+  const int up = (t->quad_tiling.n_u + 1) / 2;
+  out->rtile_bytes = (size_t)out->layout.n_units * up * 1024;
+  if (out->rtile_bytes >= ((size_t)1 << 32) - (1 << 24))
+    return fail(TC_ERR_UNSUPPORTED, "table with %d bins is too large for the float64 kernel",
+                t->n_bins);
+  out->bytes = host.size() * sizeof(double);
+  int status = upload(host, &out->d_table);
+  if (status != TC_OK) return status;
+  std::vector<tc::QuadCompArgs> comps;
+  for (const tc::QuadComp& comp : out->layout.comps) {
+    tc::QuadCompArgs c;
+    c.triangular = comp.triangular;
+    c.i_bin0 = comp.i_bin0;
+    c.j_bin0 = comp.j_bin0;
+    c.n_cb = comp.n_cb;
+    c.unit_base = (uint32_t)comp.unit_base;
+    c.pad[0] = c.pad[1] = c.pad[2] = 0;
+    comps.push_back(c);
+  }
+  return upload(comps, &out->d_comps);
+}
+
+int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, bool separate,
+                      DeviceQuadSchedule** out) {
+  const std::vector<int64_t> key = {n_tiles, (int64_t)n_tables, separate ? 1 : 0};
+  auto it = q->schedules.find(key);
+  if (it != q->schedules.end()) {
+    *out = it->second.get();
+    return TC_OK;
+  }
+  // every SIMD gets `quad_waves_per_simd` waves with equal shares of the matrix-core work;
+  // small batches use fewer waves (at least 8 units = 16 n_u instructions each)
+  const int max_waves = t->n_cus * 4 * t->quad_waves_per_simd;
+  tc::QuadSchedule schedule;
+  tc::build_quad_schedule(q->layout, (int)n_tiles, t->quad_tiling.n_rtiles, n_tables, separate,
+                          max_waves, 8, schedule);
+  std::unique_ptr<DeviceQuadSchedule> d(new DeviceQuadSchedule);
+  d->n_waves = schedule.n_waves;
+  d->n_slabs = schedule.n_slabs;
+  d->n_groups = schedule.n_groups;
+  d->n_runs = (int)schedule.runs.size();
+  int status = upload(schedule.runs, &d->runs);
+  if (status == TC_OK) status = upload(schedule.wave_runs, &d->wave_runs);
+  if (status == TC_OK) status = upload(schedule.group_begin, &d->group_begin);
+  if (status != TC_OK) {
+    for (void* p : {d->runs, d->wave_runs, d->group_begin})
+      if (p) (void)hipFree(p);
+    return status;
+  }
+  *out = d.get();
+  q->schedules[key] = std::move(d);
+  return TC_OK;
+}
+
+int launch_contract_quad(int n_u, bool interp, const tc::QuadArgs& args, hipStream_t stream) {
+  const dim3 grid((unsigned)((args.n_waves + tc::kQuadWavesPerBlock - 1) /
+                             tc::kQuadWavesPerBlock));
+  const dim3 block(64 * tc::kQuadWavesPerBlock);
+  if (args.n_waves == 0) return TC_OK;
+  switch (n_u) {
+#define TC_CASE(N)                                                                          \
+  case N:                                                                                   \
+    if (interp)                                                                             \
+      hipLaunchKernelGGL((tc::contract_quad_kernel<N, true>), grid, block, 0, stream, args); \
+    else                                                                                    \
+      hipLaunchKernelGGL((tc::contract_quad_kernel<N, false>), grid, block, 0, stream, args); \
+    break;
+    TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4) TC_CASE(5)
+#undef TC_CASE
+    default:
+      return fail(TC_ERR_UNSUPPORTED, "no kernel for %d r sub-tiles", n_u);
+  }
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+
+int launch_finalize_quad(const tc::FinalizeQuadArgs& args, hipStream_t stream) {
+  // geometry as launch_finalize: one block per 64 draws, small batches split the rows
+  const int64_t n_tiles = args.ldb / 64;
+  const int threads = env_int("TC_FINALIZE_THREADS", n_tiles < 128 ? 1024 : 256);
+  const int n_rows = args.n_comp * args.n_r;
+  const int row_blocks =
+      std::min(n_rows, env_int("TC_FINALIZE_ROW_BLOCKS",
+                               n_tiles < 128 ? (int)std::max<int64_t>(1, 512 / n_tiles) : 1));
+  hipLaunchKernelGGL(tc::finalize_quad_kernel, dim3((unsigned)n_tiles, (unsigned)row_blocks),
+                     dim3(threads), 0, stream, args);
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+
+// Contraction + finalisation through the quadratic-form kernel (mode auto, float64).
+static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
+                                double* ngal_device, double* xi_device) {
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  QuadTable* q = separate || t->quad_total.d_table == nullptr ? &t->quad_by_type
+                                                              : &t->quad_total;
+  const tc::QuadTiling& tiling = t->quad_tiling;
+  DeviceQuadSchedule* schedule = nullptr;
+  int status = get_quad_schedule(t, q, ldb / tc::kQuadTile, 1, separate, &schedule);
+  if (status != TC_OK) return status;
+  tc_table::Lane& lane = t->lanes[t->cur];
+  hipStream_t stream = lane.stream;
+  const int rt = 4 * tiling.n_u;
+  status = lane.partial.reserve(
+      (size_t)schedule->n_slabs * rt * tc::kQuadTile * sizeof(double), stream);
+  if (status != TC_OK) return status;
+
+  tc::QuadArgs qa;
+  qa.nbuf = (const double*)lane.nbuf.ptr;
+  qa.nbufs = nullptr;
+  qa.ldb = ldb;
+  qa.n_bins = t->n_bins;
+  qa.table = q->d_table;
+  qa.tables = nullptr;
+  qa.table_class = nullptr;
+  qa.coef = nullptr;
+  qa.rtile_bytes = (uint32_t)q->rtile_bytes;
+  qa.runs = (const tc::QuadRun*)schedule->runs;
+  qa.comps = (const tc::QuadCompArgs*)q->d_comps;
+  qa.wave_runs = (const int32_t*)schedule->wave_runs;
+  qa.n_waves = schedule->n_waves;
+  qa.partial = (double*)lane.partial.ptr;
+  qa.priority = env_int("TC_PRIO_C", 1);
+
+  hipEvent_t k0 = nullptr, k1 = nullptr;
+  if (t->profile_kernels) {
+    if (t->kernel_events_used == t->kernel_events.size()) {
+      hipEvent_t e0, e1;
+      TC_HIP(hipEventCreate(&e0));
+      TC_HIP(hipEventCreate(&e1));
+      t->kernel_events.emplace_back(e0, e1);
+    }
+    k0 = t->kernel_events[t->kernel_events_used].first;
+    k1 = t->kernel_events[t->kernel_events_used].second;
+    ++t->kernel_events_used;
+    TC_HIP(hipEventRecord(k0, stream));
+  }
+  status = launch_contract_quad(tiling.n_u, false, qa, stream);
+  if (status != TC_OK) return status;
+  if (t->profile_kernels) TC_HIP(hipEventRecord(k1, stream));
+  t->last_workgroups = (schedule->n_waves + tc::kQuadWavesPerBlock - 1) / tc::kQuadWavesPerBlock;
+  t->last_waves = tc::kQuadWavesPerBlock;
+  t->last_splits = schedule->n_slabs;
+  t->last_lds = 0;
+
+  tc::FinalizeQuadArgs fa;
+  fa.partial = (const double*)lane.partial.ptr;
+  fa.group_begin = (const int32_t*)schedule->group_begin;
+  fa.ngal_part = (const double*)lane.ngal2.ptr;
+  fa.n_ngal_parts = lane.ngal_parts;
+  fa.n_rtiles = tiling.n_rtiles;
+  fa.r_per_tile = tiling.r_per_tile;
+  fa.rt = rt;
+  fa.groups_per_rtile = separate ? (int)q->layout.comps.size() : 1;
+  fa.priority = env_int("TC_PRIO_F", 3);
+  fa.n_comp = separate ? t->plan.n_components : 1;
+  fa.n_r = t->n_r;
+  fa.mode = t->mode;
+  fa.ldb = ldb;
+  fa.n_draws = n_draws;
+  fa.ngal = ngal_device;
+  fa.xi = xi_device;
+  if (t->prev >= 0 && t->prev != t->cur)
+    TC_HIP(hipStreamWaitEvent(stream, t->lanes[t->prev].finished, 0));
+  status = launch_finalize_quad(fa, stream);
+  if (status != TC_OK) return status;
+  if (t->force_lane >= 0) {
+    t->prev = -1;
+  } else {
+    TC_HIP(hipEventRecord(lane.finished, stream));
+    t->prev = t->cur;
+  }
+  return TC_OK;
+}
+
 #define TC_RT_CASES                                                           \
   TC_CASE(4) TC_CASE(8) TC_CASE(12) TC_CASE(16) TC_CASE(20) TC_CASE(24)       \
   TC_CASE(28) TC_CASE(32)
@@ -244,6 +443,7 @@ int set_lds_limit_rt(int rt, int lds) {
 // Contraction + finalisation of draws whose densities are already in nbuf / ngal2.
 int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
                     double* ngal_device, double* xi_device) {
+  if (t->quad) return run_contraction_quad(t, n_draws, ldb, flags, ngal_device, xi_device);
   const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
   const int n_comp = separate ? t->plan.n_components : 1;
   DeviceChunking* c = nullptr;
@@ -434,7 +634,7 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   oa.n_gauss = n_gauss;
   oa.n_tiles = (int)n_tiles;
   oa.n_splits = splits;
-  oa.flags = flags;
+  oa.flags = flags | ((unsigned)env_int("TC_PRIO_O", 0) << 8);
   oa.split = 0.5;
   oa.log_m = (const double*)q->log_m;
   oa.m = (const double*)q->m;

@@ -204,4 +204,100 @@ int tc_plan_debug(int mode, int n_bins, const uint8_t* is_central, int n_chunks,
   return TC_OK;
 }
 
+int tc_debug_quad_schedule(int n_bins, int n_central, int by_type, int n_tiles, int n_rtiles,
+                           int n_tables, int separate, int max_waves, int min_units,
+                           int* n_waves, int* n_runs, int* n_slabs, int64_t* units_min,
+                           int64_t* units_max) {
+  TC_CHECK(n_bins >= 1 && n_central >= 0 && n_central <= n_bins && n_tiles >= 1 &&
+               n_rtiles >= 1 && max_waves >= 1,
+           "invalid arguments");
+  tc::QuadLayout layout;
+  tc::build_quad_layout(n_bins, n_central, by_type != 0, layout);
+  tc::QuadSchedule schedule;
+  tc::build_quad_schedule(layout, n_tiles, n_rtiles, n_tables, separate != 0, max_waves,
+                          min_units, schedule);
+  const int tables = std::max(1, n_tables);
+  // every (tile, r tile, component, table, unit) exactly once; runs stay inside one block
+  // row sequence of their component; slabs of a group consecutive and in order
+  std::vector<uint8_t> seen((size_t)n_tiles * n_rtiles * tables * layout.n_units, 0);
+  const int groups_per_rtile = separate ? (int)layout.comps.size() : 1;
+  int64_t lo = -1, hi = 0;
+  int next_slab = 0;
+  for (int w = 0; w < schedule.n_waves; ++w) {
+    int64_t units = 0;
+    for (int ri = schedule.wave_runs[w]; ri < schedule.wave_runs[w + 1]; ++ri) {
+      const tc::QuadRun& run = schedule.runs[ri];
+      if (run.comp < 0 || run.comp >= (int)layout.comps.size())
+        return fail(TC_ERR_INVALID, "run %d: component", ri);
+      const tc::QuadComp& comp = layout.comps[run.comp];
+      int rb = run.rb0, cb = run.cb0;
+      for (int k = 0; k < run.count; ++k) {
+        if (rb >= comp.n_rb || cb >= tc::quad_row_length(comp, rb))
+          return fail(TC_ERR_INVALID, "run %d leaves its component", ri);
+        const int64_t unit = comp.unit_base + (comp.triangular ? (int64_t)rb * (rb + 1) / 2 + cb
+                                                                : (int64_t)rb * comp.n_cb + cb);
+        const size_t index =
+            ((((size_t)run.tile * n_rtiles + run.rtile) * tables + run.table) * layout.n_units) +
+            unit;
+        if (seen[index]++) return fail(TC_ERR_INVALID, "unit covered twice (run %d)", ri);
+        if (++cb == tc::quad_row_length(comp, rb)) {
+          ++rb;
+          cb = 0;
+        }
+      }
+      units += run.count;
+      if (run.slab >= 0) {
+        if (run.slab != next_slab) return fail(TC_ERR_INVALID, "slab order (run %d)", ri);
+        const int64_t group = ((int64_t)run.tile * n_rtiles + run.rtile) * groups_per_rtile +
+                              (separate ? run.comp : 0);
+        if (run.slab < schedule.group_begin[group] || run.slab >= schedule.group_begin[group + 1])
+          return fail(TC_ERR_INVALID, "slab %d outside its group", run.slab);
+        ++next_slab;
+      }
+    }
+    if (schedule.wave_runs[w + 1] > schedule.wave_runs[w] &&
+        schedule.runs[schedule.wave_runs[w + 1] - 1].slab < 0)
+      return fail(TC_ERR_INVALID, "wave %d does not flush its sums", w);
+    lo = lo < 0 ? units : std::min(lo, units);
+    hi = std::max(hi, units);
+  }
+  for (size_t k = 0; k < seen.size(); ++k)
+    if (!seen[k]) return fail(TC_ERR_INVALID, "unit %zu not covered", k);
+  if (next_slab != schedule.n_slabs) return fail(TC_ERR_INVALID, "slab count");
+  if (n_waves) *n_waves = schedule.n_waves;
+  if (n_runs) *n_runs = (int)schedule.runs.size();
+  if (n_slabs) *n_slabs = schedule.n_slabs;
+  if (units_min) *units_min = lo;
+  if (units_max) *units_max = hi;
+  return TC_OK;
+}
+
+int tc_debug_quad_emulate(int n_bins, int n_r, const double* tpcf_matrix,
+                          const uint8_t* is_central, int by_type, int separate,
+                          const double* densities, int64_t ldb, int64_t n_draws,
+                          int max_waves, int min_units, double* out) {
+  TC_CHECK(n_bins >= 1 && n_r >= 1 && tpcf_matrix && is_central && densities && out &&
+               ldb % 64 == 0 && n_draws >= 1 && n_draws <= ldb,
+           "invalid arguments");
+  tc::Plan plan;
+  tc::build_plan(TC_MODE_AUTO, n_bins, is_central, tc::kF64Block, 56, plan);
+  tc::QuadLayout layout;
+  tc::build_quad_layout(n_bins, plan.n_central, by_type != 0, layout);
+  const tc::QuadTiling tiling = tc::quad_tiling(n_r);
+  std::vector<double> table;
+  tc::fill_quad_table(layout, plan.perm, n_r, (int64_t)n_bins * (n_bins + 1) / 2, tpcf_matrix,
+                      false, tiling, table);
+  tc::QuadSchedule schedule;
+  tc::build_quad_schedule(layout, (int)(ldb / 32), tiling.n_rtiles, 1, separate != 0,
+                          max_waves, min_units, schedule);
+  // densities arrive in the reference's bin order; the kernel sees library order
+  std::vector<double> ordered((size_t)n_bins * ldb);
+  for (int g = 0; g < n_bins; ++g)
+    std::copy(densities + (size_t)plan.perm[g] * ldb, densities + (size_t)(plan.perm[g] + 1) * ldb,
+              ordered.begin() + (size_t)g * ldb);
+  tc::quad_emulate(layout, schedule, tiling, table, ordered.data(), ldb, n_draws, n_r,
+                   separate != 0, out);
+  return TC_OK;
+}
+
 }  // extern "C"

@@ -30,9 +30,20 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
            "invalid matrix dtype");
   TC_CHECK(compute_dtype == TC_DTYPE_F64 || compute_dtype == TC_DTYPE_F32,
            "invalid compute dtype");
+  TC_CHECK(compute_dtype != TC_DTYPE_F32 || n_bins < 65535,
+           "too many bins for the float32 variant");
 
-  std::unique_ptr<tc_table> t(new tc_table);
+  // (tc_table_destroy releases whatever exists when a later step fails)
+  struct Destroy {
+    void operator()(tc_table* table) const { tc_table_destroy(table); }
+  };
+  std::unique_ptr<tc_table, Destroy> t(new tc_table);
   TC_HIP(hipGetDevice(&t->device));
+  {
+    hipDeviceProp_t prop;
+    TC_HIP(hipGetDeviceProperties(&prop, t->device));
+    t->n_cus = std::max(1, prop.multiProcessorCount);
+  }
   t->mode = mode;
   t->n_bins = n_bins;
   t->n_r = n_r;
@@ -119,7 +130,6 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
             (float)(source(r, column) * t->plan.prefactor[q]);
       }
     }
-    TC_CHECK(n_bins < 65535, "too many bins for the float32 variant");
     pos_ij.assign((size_t)n_positions, 0);
     for (int64_t q = 0; q < n_positions; ++q) {
       const int64_t block = q / 8;
@@ -150,10 +160,18 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
     tc::fm::build_tables(math_table.data());
     status = upload(math_table, &t->d_math_table);
   }
-  if (status != TC_OK) {
-    tc_table_destroy(t.release());
-    return status;
+  if (status == TC_OK && mode == TC_MODE_AUTO && compute_dtype == TC_DTYPE_F64) {
+    // quadratic-form kernel: the matrix by galaxy type and, when the centrals do not fill
+    // whole 4 x 4 blocks, the unpadded triangle for the total prediction
+    t->quad = true;
+    t->quad_tiling = tc::quad_tiling(n_r);
+    t->quad_waves_per_simd = std::max(1, std::min(3, env_int("TC_QUAD_WAVES", 2)));
+    status = build_quad_table(t.get(), true, tpcf_matrix, matrix_dtype, &t->quad_by_type);
+    const int n_central = t->plan.n_central;
+    if (status == TC_OK && n_central % 4 != 0 && n_central < n_bins)
+      status = build_quad_table(t.get(), false, tpcf_matrix, matrix_dtype, &t->quad_total);
   }
+  if (status != TC_OK) return status;
   *out = t.release();
   return TC_OK;
 }
@@ -172,6 +190,8 @@ int tc_table_destroy(tc_table* t) {
   for (auto& kv : t->chunkings)
     for (void* p : {kv.second->chunks, kv.second->groups})
       if (p) (void)hipFree(p);
+  t->quad_by_type.release();
+  t->quad_total.release();
   for (DeviceBuffer* b : {&t->theta, &t->out_ngal, &t->out_xi, &t->occupation,
                           &t->trace, &t->wave_trace, &t->single_ws, &t->chi2_data})
     b->release();
@@ -228,8 +248,9 @@ int tc_predict_zheng07_batch_device(tc_table* t, const double* theta_device,
     t->cur = t->force_lane;
   else
     t->cur = env_int("TC_PIPELINE", 1) ? (int)(t->device_calls++ % t->n_lanes) : 0;
-  for (int64_t begin = 0; begin < n_draws; begin += kMaxSlab) {
-    const int64_t n = std::min(kMaxSlab, n_draws - begin);
+  const int64_t slab = max_slab(t);
+  for (int64_t begin = 0; begin < n_draws; begin += slab) {
+    const int64_t n = std::min(slab, n_draws - begin);
     const int64_t ldb = (n + 63) / 64 * 64;
     status = run_occupation(t, theta_device + begin * n_theta, n_theta, n, ldb,
                             n_gauss, flags, nullptr);
@@ -415,8 +436,9 @@ int tc_mean_occupation_zheng07_batch(tc_table* t, const double* theta, int n_the
   if (n_draws == 0) return TC_OK;
   TC_CHECK(occupation != nullptr, "output pointer is NULL");
   TC_HIP(hipSetDevice(t->device));
-  for (int64_t begin = 0; begin < n_draws; begin += kMaxSlab) {
-    const int64_t n = std::min(kMaxSlab, n_draws - begin);
+  const int64_t slab = max_slab(t);
+  for (int64_t begin = 0; begin < n_draws; begin += slab) {
+    const int64_t n = std::min(slab, n_draws - begin);
     const int64_t ldb = (n + 63) / 64 * 64;
     const size_t occ_bytes = (size_t)n * t->n_bins * 8;
     status = t->theta.reserve((size_t)n * n_theta * 8, t->stream);
@@ -445,8 +467,9 @@ int tc_predict_occupation_batch(tc_table* t, const double* occupation,
   TC_HIP(hipSetDevice(t->device));
   const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
   const int n_comp = separate ? t->plan.n_components : 1;
-  for (int64_t begin = 0; begin < n_draws; begin += kMaxSlab) {
-    const int64_t n = std::min(kMaxSlab, n_draws - begin);
+  const int64_t slab = max_slab(t);
+  for (int64_t begin = 0; begin < n_draws; begin += slab) {
+    const int64_t n = std::min(slab, n_draws - begin);
     const int64_t ldb = (n + 63) / 64 * 64;
     const size_t occ_bytes = (size_t)n * t->n_bins * 8;
     const size_t ngal_count = (size_t)n * (separate ? 2 : 1);

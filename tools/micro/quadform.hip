@@ -43,6 +43,7 @@ struct Args {
   int n_waves;
   int skip;            // ablation bits: 1 no A loads, 2 no B loads, 4 no E loads
   double* partial;      // [slab][4 U][32]
+  unsigned long long* stamps;   // per wave: start, after first row, end (100 MHz), or NULL
 };
 
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
@@ -60,6 +61,8 @@ __global__ __launch_bounds__(256, 2) void quad_kernel(Args a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   if (wave >= a.n_waves) return;
+  unsigned long long s0 = 0, s1 = 0;
+  if (a.stamps) s0 = __builtin_amdgcn_s_memrealtime();
   typedef const __attribute__((address_space(4))) int* sc_int;
   typedef const __attribute__((address_space(4))) Run* sc_run;
   const int run_begin = ((sc_int)a.wave_runs)[wave], run_end = ((sc_int)a.wave_runs)[wave + 1];
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(256, 2) void quad_kernel(Args a) {
         }
       ++row;
       cj = 0;
+      if (a.stamps && s1 == 0) s1 = __builtin_amdgcn_s_memrealtime();
     }
     if (run.slab >= 0) {
       double* out = a.partial + ((long)run.slab * (4 * U) + kq) * 32 + 2 * c;
@@ -173,6 +177,13 @@ __global__ __launch_bounds__(256, 2) void quad_kernel(Args a) {
         F[u][0] = F[u][1] = 0.0;
       }
     }
+  }
+  if (a.stamps && lane == 0) {
+    a.stamps[wave * 3] = s0;
+    a.stamps[wave * 3 + 1] = s1;
+    a.stamps[wave * 3 + 2] = __builtin_amdgcn_s_memrealtime();
+    a.stamps[a.n_waves * 3 + wave] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+        ((unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf) << 32);
   }
 }
 
@@ -278,6 +289,7 @@ int main(int argc, char** argv) {
   args.n_waves = n_waves;
   args.partial = d_partial;
   args.skip = skip;
+  args.stamps = nullptr;
   const int blocks = (n_waves + 3) / 4;
   quad_kernel<U><<<blocks, 256>>>(args);
   if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }
@@ -303,6 +315,54 @@ int main(int argc, char** argv) {
   }
   printf("max rel deviation from the packed sum: %.3g\n", worst);
 
+  {
+    // per-wave timeline of one launch in the middle of a train of launches
+    unsigned long long* d_stamps;
+    hipMalloc(&d_stamps, (size_t)n_waves * 32);
+    for (int it = 0; it < 200; ++it) quad_kernel<U><<<blocks, 256>>>(args);
+    args.stamps = d_stamps;
+    quad_kernel<U><<<blocks, 256>>>(args);
+    args.stamps = nullptr;
+    for (int it = 0; it < 20; ++it) quad_kernel<U><<<blocks, 256>>>(args);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> st((size_t)n_waves * 4);
+    hipMemcpy(st.data(), d_stamps, st.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull;
+    for (int w = 0; w < n_waves; ++w) t0 = std::min(t0, st[w * 3]);
+    std::vector<double> start, first, end;
+    for (int w = 0; w < n_waves; ++w) {
+      start.push_back((st[w * 3] - t0) * 0.01);
+      first.push_back((st[w * 3 + 1] - st[w * 3]) * 0.01);
+      end.push_back((st[w * 3 + 2] - t0) * 0.01);
+    }
+    auto pct = [](std::vector<double> v, double p) { std::sort(v.begin(), v.end()); return v[(size_t)(p * (v.size() - 1))]; };
+    printf("wave start (us after the first): p10 %.2f p50 %.2f p90 %.2f max %.2f\n", pct(start, .1), pct(start, .5), pct(start, .9), pct(start, 1));
+    printf("start -> end of first block row: p10 %.2f p50 %.2f p90 %.2f max %.2f\n", pct(first, .1), pct(first, .5), pct(first, .9), pct(first, 1));
+    printf("wave end: p0 %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f\n", pct(end, 0), pct(end, .1), pct(end, .5), pct(end, .9), pct(end, 1));
+    // waves per SIMD
+    std::vector<int> per_simd;
+    {
+      std::vector<long> keys;
+      for (int w = 0; w < n_waves; ++w) {
+        const unsigned long long h = st[(size_t)n_waves * 3 + w];
+        const long hw = (long)(h & 0xffffffff), xcc = (long)(h >> 32);
+        keys.push_back(xcc * 100000 + ((hw >> 13) & 7) * 10000 + ((hw >> 12) & 1) * 1000 + ((hw >> 8) & 0xf) * 10 + ((hw >> 4) & 3));
+      }
+      std::sort(keys.begin(), keys.end());
+      int hist[16] = {0}, simds = 0;
+      for (size_t k = 0; k < keys.size();) {
+        size_t e = k;
+        while (e < keys.size() && keys[e] == keys[k]) ++e;
+        hist[std::min<size_t>(15, e - k)]++;
+        ++simds;
+        k = e;
+      }
+      printf("SIMDs used %d; waves per SIMD histogram:", simds);
+      for (int k = 1; k < 10; ++k) printf(" %d:%d", k, hist[k]);
+      printf("\n");
+    }
+    hipFree(d_stamps);
+  }
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
