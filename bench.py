@@ -5,32 +5,47 @@ Metric (BASELINE.json): predict() calls per second -- Zheng07 HOD, 50 mass bins 
 {centrals, satellites} (G = 100 halo/galaxy bins, P = 5050 packed pair columns), 19
 r_p bins, float64.  One *step* is one pass of the hot path over one batch of 10^4
 parameter draws against the resident synthetic table (BASELINE configs[1]): occupation
-kernel -> contraction kernel -> finalisation kernel, with the draws already resident
-in HBM and the results left in HBM.
+kernel -> contraction kernel -> finalisation kernel.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
+``value`` is the DEVICE-RESIDENT rate: draws already in HBM when the timed region starts,
+results left in HBM (multi-GPU: gathered on rank 0 over RCCL).  The rate SURVEY.md section
+8d defines -- theta on the host to (ngal, xi) on the host, PCIe included -- is reported
+next to it as ``host_to_host`` and is never ``value``.
+
 Multi-GPU: weak scaling, one process per GPU, every rank runs its own 10^4 draws per
 step against its own replica of the table (the path shards over draws without any
 data-path collective); the results of all steps are collected on rank 0 by one RCCL
 gather over xGMI per block of --gather-every steps, on a second stream, overlapped with
-the following steps.  PyTorch is only used for the gloo control plane (rendezvous,
-barrier, max over ranks).
+the following steps (``--gather chi2``: the fused likelihood, 16 bytes per draw instead
+of 160).  ``--workload interp5x5`` is BASELINE configs[3]: ``Interpolator.predict`` over a
+5 x 5 grid of such tables, 10^5 draws per step sharded round-robin over the ranks (strong
+scaling), gathered the same way.  PyTorch is only used for the gloo control plane.
 
-Rank 0 prints ONE JSON line.  Extra objects: ``roofline`` (contraction kernel:
-algorithmic flop per launch / mean launch duration from HIP events on the kernel's
-own stream, against the FP64 matrix/vector peak; measured with the batches serialised
-(`TC_PIPELINE=0`, what `TC_LANES=1 rocprofv3 --kernel-trace --stats` shows), next to the
-stretched duration in the overlapped timed region and the whole-step fraction) and ``cpu_baseline`` (the NumPy port
-of the reference's predict(), oracle/tabcorr_oracle.py, timed on one host core).
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline       contraction kernel: algorithmic flop per launch / mean launch duration.
+                 Always measured the same way, whatever --steps is: kernels serialised
+                 (one lane), >= 150 ms of load first, then 1000 launches each carrying its
+                 own start / stop events (hipExtLaunchKernelGGL: the dispatch's begin and
+                 end, the interval `rocprofv3 --kernel-trace --stats` reports).
+                 ``traffic``: HBM bytes per launch from the committed PMC passes.
+  host_to_host   the SURVEY 8d rate through tc_predict_zheng07_batch (host arrays).
+  unbatched_us   one predict(model) / Interpolator.predict(model) call, as in the
+                 reference's usage (README.md:72-75).
+  other_configs  BASELINE configs[2], [3] (one GPU's share), [4] in float32 and float64:
+                 device rate, host rate, dominant kernel, roofline fraction, CPU port.
+  cpu_baseline   the NumPy port of the reference's predict() (oracle/tabcorr_oracle.py),
+                 timed on one host core and with one walker per core.
 """
 
 import argparse
 import ctypes
 import json
 import os
+import re
 import sys
 import time
 
@@ -39,19 +54,139 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-# FP64 peak of MI355X: 78.6 TFLOP/s (AMD datasheet, vector = matrix); the local
-# microbenchmarks (tools/micro) measure 78.0 (v_mfma_f64_16x16x4) and 61
-# (v_fma_f64, clock-limited) TFLOP/s.
+# FP64 peak of MI355X: 78.6 TFLOP/s (AMD datasheet, vector = matrix; the local
+# microbenchmarks in tools/micro measure 78.0 for v_mfma_f64_16x16x4); FP32 matrix peak
+# 157.3 TFLOP/s (/opt/skills/guides/MI355X_MICROARCH.md).
 FP64_PEAK_TFLOPS = 78.6
-# HBM-side traffic of one contraction launch of the default workload (10^4 draws) from the
-# committed PMC passes (profiles/r01_pmc_counters.txt: separate rocprofv3 --pmc
-# FETCH_SIZE / WRITE_SIZE runs of this script; FETCH_SIZE doubled per the gfx950
-# correction): 2 x 7299 KB + 12560 KB.  Compulsory bytes: table 0.83 MB + densities
-# 8.0 MB + group partials 12.9 MB.  PMC counters cannot be read inside this process.
-PMC_TRAFFIC_BYTES_DEFAULT_WORKLOAD = (2 * 7299.0 + 12560.0) * 1024
+FP32_PEAK_TFLOPS = 157.3
+PMC_FILE = os.path.join(REPO, 'profiles', 'r02_pmc_counters.txt')
 
 N_PRIM, N_SEC, N_R = 50, 1, 19
 N_GAUSS = 10
+FLAG_SEPARATE, FLAG_ASSEMBIAS = 1, 4
+ROOFLINE_LAUNCHES = 1000
+ROOFLINE_WARM_SECONDS = 0.25
+
+
+def pair_flops(n_bins, n_r):
+    """Algorithmic flop of one draw's contraction: 2 R P + 3 P."""
+    n_pairs = n_bins * (n_bins + 1) // 2
+    return 2.0 * n_r * n_pairs + 3.0 * n_pairs
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE and WRITE_SIZE in KB; FETCH_SIZE doubled per the gfx950 correction of the
+    MI355X guide).  None when the file does not hold that kernel."""
+    try:
+        text = open(PMC_FILE).read()
+    except OSError:
+        return None
+    values = {}
+    prefix = kernel[:40]
+    for line in text.splitlines():
+        match = re.match(r'(.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+\s+mean=([0-9.e+]+)', line)
+        if match and prefix in match.group(1).replace('void ', ''):
+            values[match.group(2)] = float(match.group(3))
+    if len(values) != 2:
+        return None
+    return (2.0 * values['FETCH_SIZE'] + values['WRITE_SIZE']) * 1024.0
+
+
+class Device:
+    """Thin helper over the C ABI for device-resident arrays."""
+
+    def __init__(self, lib, _lib):
+        self.lib = lib
+        self._lib = _lib
+        self.allocations = []
+
+    def malloc(self, count):
+        ptr = ctypes.c_void_p()
+        self._lib.check(self.lib.tc_device_malloc(ctypes.byref(ptr), max(1, count) * 8))
+        self.allocations.append(ptr)
+        return ptr
+
+    def upload(self, array):
+        array = np.ascontiguousarray(array, dtype=np.float64)
+        ptr = self.malloc(array.size)
+        self._lib.check(self.lib.tc_memcpy_h2d(
+            ptr, array.ctypes.data_as(ctypes.c_void_p), array.nbytes))
+        return ptr
+
+    def download(self, ptr, count):
+        host = np.empty(count)
+        self._lib.check(self.lib.tc_memcpy_d2h(
+            host.ctypes.data_as(ctypes.c_void_p), ptr, host.nbytes))
+        return host
+
+    def free_all(self):
+        for ptr in self.allocations:
+            if ptr.value:
+                self.lib.tc_device_free(ptr)
+        self.allocations = []
+
+
+def kernel_time(lib, _lib, timer_handle, launch, synchronize, warm_seconds=ROOFLINE_WARM_SECONDS,
+                n_launches=ROOFLINE_LAUNCHES, max_seconds=1.0):
+    """Mean duration (ms) of the contraction kernel inside `launch()`, serialised: load the
+    chip for `warm_seconds` first (the power management needs tens of milliseconds to
+    settle), then time `n_launches` launches (fewer when they would take more than
+    `max_seconds`) with per-launch start / stop events."""
+    launch()
+    synchronize()
+    t0 = time.perf_counter()
+    launch()
+    synchronize()
+    per_call = max(time.perf_counter() - t0, 1e-6)
+    for _ in range(int(warm_seconds / per_call) + 1):
+        launch()
+    n = max(10, min(n_launches, int(max_seconds / per_call)))
+    synchronize()
+    _lib.check(lib.tc_table_timer_begin(timer_handle, 1))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        launch()
+    synchronize()
+    wall_ms = (time.perf_counter() - t0) / n * 1e3
+    ms = ctypes.c_float()
+    _lib.check(lib.tc_table_timer_end(timer_handle, ctypes.byref(ms)))
+    count = ctypes.c_int()
+    kernel_ms = ctypes.c_float()
+    _lib.check(lib.tc_table_kernel_time(timer_handle, ctypes.byref(count), ctypes.byref(kernel_ms)))
+    return kernel_ms.value, count.value, wall_ms
+
+
+def sustained(launch, synchronize, seconds=0.4, warm_seconds=0.15):
+    """Seconds per `launch()` in a sustained stream of calls."""
+    launch()
+    synchronize()
+    t0 = time.perf_counter()
+    launch()
+    synchronize()
+    per_call = max(time.perf_counter() - t0, 1e-6)
+    for _ in range(int(warm_seconds / per_call) + 1):
+        launch()
+    synchronize()
+    n = max(5, int(seconds / per_call))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        launch()
+    synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def time_calls(call, seconds=0.5, warm=3):
+    for _ in range(warm):
+        call()
+    t0 = time.perf_counter()
+    call()
+    per_call = max(time.perf_counter() - t0, 1e-6)
+    n = max(3, int(seconds / per_call))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        call()
+    return (time.perf_counter() - t0) / n
 
 
 def main():
@@ -60,19 +195,34 @@ def main():
     # defaults: about one second of timed steps -- the chip's power management needs tens of
     # milliseconds of load to settle (tools/ramp.py: 10-ms regions started from idle run
     # 10-20 % slower than the sustained rate)
-    parser.add_argument('--steps', type=int, default=20000)
-    parser.add_argument('--warmup', type=int, default=2000)
-    parser.add_argument('--draws', type=int, default=10000,
-                        help='draws per GPU per step')
+    parser.add_argument('--steps', type=int, default=None)
+    parser.add_argument('--warmup', type=int, default=None)
+    parser.add_argument('--workload', choices=['cfg2', 'interp5x5'], default='cfg2')
+    parser.add_argument('--draws', type=int, default=None,
+                        help='cfg2: draws per GPU per step (10^4); interp5x5: draws per '
+                             'step over ALL GPUs (10^5)')
+    parser.add_argument('--gather', choices=['full', 'chi2'], default='full',
+                        help='multi-GPU: gather (ngal, xi) of every draw, or the fused '
+                             'likelihood (ngal, chi2)')
     parser.add_argument('--gather-every', type=int, default=32,
                         help='multi-GPU: steps per RCCL gather of the results')
+    parser.add_argument('--lanes', type=int, default=0,
+                        help='pipelining lanes of the timed region (default: library '
+                             'default, 4); 1 serialises the kernels, e.g. under rocprofv3')
     parser.add_argument('--cpu-seconds', type=float, default=12.0,
                         help='budget of the CPU baseline sample (0: skip)')
     parser.add_argument('--cpu-all-cores', type=int, default=1,
                         help='also time one independent CPU walker per host core')
+    parser.add_argument('--other-configs', type=int, default=1,
+                        help='measure BASELINE configs[2..4] as well (single GPU only)')
     args = parser.parse_args()
+    interp_mode = args.workload == 'interp5x5'
+    if args.steps is None:
+        args.steps = 200 if interp_mode else 20000
+    if args.warmup is None:
+        args.warmup = 20 if interp_mode else 2000
 
-    from tabcorr_amd import TabCorr, synthetic, _lib
+    from tabcorr_amd import TabCorr, Interpolator, synthetic, _lib
     from tabcorr_amd.parallel import Communicator
 
     world_size = int(os.environ.get('WORLD_SIZE', '1'))
@@ -84,7 +234,7 @@ def main():
     # The all-cores CPU baseline forks its workers, so it runs before this process
     # touches the GPU.
     cpu_all = None
-    if world_size == 1 and args.cpu_seconds > 0 and args.cpu_all_cores:
+    if world_size == 1 and args.cpu_seconds > 0 and args.cpu_all_cores and not interp_mode:
         cpu_all = cpu_baseline_all_cores(args.cpu_seconds / 2)
     lib = _lib.load()
     _lib.require_device()
@@ -92,50 +242,92 @@ def main():
     _lib.check(lib.tc_set_device(local_rank))
     comm = Communicator.from_env()
     rank = comm.rank
+    dev = Device(lib, _lib)
 
+    def make(table, **kwargs):
+        return TabCorr.from_arrays(table['gal_type'], table['tpcf_matrix'],
+                                   table['tpcf_shape'], table['attrs'], **kwargs)
+
+    # ---- workload -------------------------------------------------------------------------
     table = synthetic.synthetic_table(N_PRIM, N_SEC, (N_R, ), 'auto', seed=0)
-    halotab = TabCorr.from_arrays(table['gal_type'], table['tpcf_matrix'],
-                                  table['tpcf_shape'], table['attrs'])
-    device = halotab.to_device()
-    handle = device.handle
-    n_draws = args.draws
-    theta = synthetic.zheng07_draws(n_draws, seed=1 + rank)
-    n_out = n_draws * (1 + N_R)        # ngal (B) followed by xi (B, R)
+    interp = None
+    if interp_mode:
+        tables, keys, points = synthetic.synthetic_interpolator((5, 5), N_PRIM, N_SEC, (N_R, ),
+                                                                'auto', seed=7)
+        interp = Interpolator([make(t) for t in tables],
+                              {k: points[:, d] for d, k in enumerate(keys)})
+        total_draws = args.draws or 100000
+        # round-robin shard of this rank (BASELINE configs[3]); equal shares per rank
+        n_draws = (total_draws + world_size - 1) // world_size
+        theta_all = synthetic.zheng07_draws(n_draws * world_size, seed=5)
+        rng = np.random.default_rng(6)
+        x_all = np.stack([rng.uniform(xp[0], xp[-1], size=len(theta_all))
+                          for xp in interp.xp], axis=-1)
+        theta = np.ascontiguousarray(theta_all[rank::world_size])
+        x = np.ascontiguousarray(x_all[rank::world_size])
+        device = interp.to_device()
+        handle = device.handle
+        timer_handle = device.tables[0].handle
+        n_tables = 25
+    else:
+        halotab = make(table)
+        device = halotab.to_device()
+        handle = timer_handle = device.handle
+        n_draws = args.draws or 10000
+        theta = synthetic.zheng07_draws(n_draws, seed=1 + rank)
+        x = None
+        n_tables = 1
+    if args.lanes > 0:
+        _lib.check(lib.tc_table_set_option(timer_handle, b'lanes', args.lanes))
+    chi2_mode = args.gather == 'chi2' and not interp_mode
+    n_out = n_draws * (2 if chi2_mode else 1 + N_R)     # ngal | xi (B, R), or ngal | chi2
+    d_theta = dev.upload(theta)
+    d_x = dev.upload(x) if interp_mode else None
+    data_vector = np.full(N_R, 50.0)
+    precision = np.eye(N_R) * 1e-2
+    data_p, precision_p = _lib.as_double_p(data_vector), _lib.as_double_p(precision)
 
-    def dmalloc(count):
-        ptr = ctypes.c_void_p()
-        _lib.check(lib.tc_device_malloc(ctypes.byref(ptr), count * 8))
-        return ptr
-
-    d_theta = dmalloc(theta.size)
-    _lib.check(lib.tc_memcpy_h2d(d_theta, theta.ctypes.data_as(ctypes.c_void_p),
-                                 theta.nbytes))
     # Results ring: 2 blocks of `every` steps.  A block is gathered on rank 0 (RCCL, own
     # stream) once its last step is queued; the other block keeps filling meanwhile.
     every = max(1, args.gather_every)
     n_slots = 2 * every
-    d_out = dmalloc(n_slots * n_out)
+    d_out = dev.malloc(n_slots * n_out)
     use_rccl = comm.comm is not None
-    d_recv = dmalloc(2 * comm.world_size * every * n_out) if (
+    d_recv = dev.malloc(2 * comm.world_size * every * n_out) if (
         use_rccl and comm.is_root) else ctypes.c_void_p()
+    interp_handle = handle if interp_mode else None
 
     def out_ptr(slot, offset=0):
         return ctypes.c_void_p(d_out.value + (slot * n_out + offset) * 8)
+
+    def predict(slot):
+        if interp_mode:
+            _lib.check(lib.tc_interp_predict_zheng07_batch_device(
+                handle, d_theta, 5, d_x, n_draws, N_GAUSS, 0, out_ptr(slot),
+                out_ptr(slot, n_draws)))
+        elif chi2_mode:
+            _lib.check(lib.tc_chi2_zheng07_batch_device(
+                handle, d_theta, 5, n_draws, N_GAUSS, 0, data_p, precision_p,
+                out_ptr(slot), out_ptr(slot, n_draws)))
+        else:
+            _lib.check(lib.tc_predict_zheng07_batch_device(
+                handle, d_theta, 5, n_draws, N_GAUSS, 0, out_ptr(slot),
+                out_ptr(slot, n_draws)))
 
     def gather_block(block, n_steps):
         recv = ctypes.c_void_p(
             d_recv.value + block * comm.world_size * every * n_out * 8) if (
                 comm.is_root) else None
-        comm.gather_device(handle, out_ptr(block * every), recv, n_steps * n_out, block)
+        comm.gather_device(timer_handle, out_ptr(block * every), recv, n_steps * n_out, block,
+                           interp_handle=interp_handle)
 
     def step(index):
         slot = index % n_slots
         block = slot // every
         if use_rccl and index >= n_slots and slot % every == 0:
-            comm.release(handle, block)         # the block's previous gather is done
-        _lib.check(lib.tc_predict_zheng07_batch_device(
-            handle, d_theta, 5, n_draws, N_GAUSS, 0, out_ptr(slot),
-            out_ptr(slot, n_draws)))
+            # the block's previous gather is done before it is overwritten
+            comm.release(timer_handle, block, interp_handle=interp_handle)
+        predict(slot)
         if use_rccl and slot % every == every - 1:
             gather_block(block, every)
 
@@ -144,8 +336,14 @@ def main():
         if use_rccl and n_steps % every:
             gather_block(((n_steps - 1) % n_slots) // every, n_steps % every)
 
+    def synchronize():
+        if interp_mode:
+            _lib.check(lib.tc_interp_synchronize(handle))
+        else:
+            _lib.check(lib.tc_table_synchronize(handle))
+
     def drain():
-        _lib.check(lib.tc_table_synchronize(handle))
+        synchronize()
         comm.synchronize()
         _lib.check(lib.tc_device_synchronize())
 
@@ -168,99 +366,112 @@ def main():
     if comm.dist is not None and not use_rccl:
         # RCCL unavailable: collect the last batch over gloo so that the job still
         # ends with the results on rank 0 (reported as "gather": "gloo").
-        host = np.empty(n_out)
-        _lib.check(lib.tc_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p),
-                                     out_ptr((args.steps - 1) % n_slots), host.nbytes))
+        host = dev.download(out_ptr((args.steps - 1) % n_slots), n_out)
         comm.gather_host(host)
 
-    # ---- dominant kernel: contraction, HIP events on its own stream --------------------
+    # ---- dominant kernel: contraction, per-launch start / stop events -------------------
     n_bins = 2 * N_PRIM * N_SEC
     n_pairs = n_bins * (n_bins + 1) // 2
-    flop_contract = n_draws * (2.0 * N_R * n_pairs + 3.0 * n_pairs)
+    flop_contract = n_draws * n_tables * pair_flops(n_bins, N_R)
     drain()
-    def kernel_pass():
-        ms = ctypes.c_float()
-        _lib.check(lib.tc_table_timer_begin(handle, 1))
-        for index in range(min(args.steps, 1000)):
-            _lib.check(lib.tc_predict_zheng07_batch_device(
-                handle, d_theta, 5, n_draws, N_GAUSS, 0, out_ptr(index % n_slots),
-                out_ptr(index % n_slots, n_draws)))
-        _lib.check(lib.tc_table_timer_end(handle, ctypes.byref(ms)))
-        n_launch = ctypes.c_int()
-        kernel_ms = ctypes.c_float()
-        _lib.check(lib.tc_table_kernel_time(handle, ctypes.byref(n_launch),
-                                            ctypes.byref(kernel_ms)))
-        return n_launch, kernel_ms
-
-    # as in the timed region: consecutive batches overlap on the table's two lanes, so
-    # the contraction shares the chip with the next batch's occupation kernel
-    n_launch, kernel_ms = kernel_pass()
-    # the kernel alone (batches serialised), for reference
-    os.environ['TC_PIPELINE'] = '0'
-    _, isolated_ms = kernel_pass()
-    os.environ['TC_PIPELINE'] = '1'
+    _lib.check(lib.tc_table_set_option(timer_handle, b'pipeline', 0))
+    isolated_ms, n_launch, serial_step_ms = kernel_time(
+        lib, _lib, timer_handle, lambda: predict(0), synchronize)
+    _lib.check(lib.tc_table_set_option(timer_handle, b'pipeline', 1))
+    # ... and stretched by the kernels of neighbouring batches in the overlapped regime of
+    # the timed region
+    overlapped_ms, _, _ = kernel_time(lib, _lib, timer_handle, lambda: predict(0), synchronize)
     launch = [ctypes.c_int() for _ in range(4)]
-    lib.tc_table_last_launch(handle, *[ctypes.byref(v) for v in launch])
+    lib.tc_table_last_launch(timer_handle, *[ctypes.byref(v) for v in launch])
 
     result = None
     if comm.is_root:
-        # spot check against the CPU oracle (4 draws)
-        host = np.empty(n_out)
-        _lib.check(lib.tc_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p), out_ptr(0),
-                                     host.nbytes))
         from oracle import tabcorr_oracle as oracle
-        expect = oracle.predict_zheng07_batch(table, theta[:4])
-        xi = host[n_draws:].reshape(n_draws, N_R)
-        parity = float(max(np.max(np.abs(host[:4] / expect[0] - 1)),
-                           np.max(np.abs(xi[:4] / expect[1] - 1))))
+        # spot check against the CPU oracle (4 draws)
+        predict(0)
+        drain()
+        host = dev.download(out_ptr(0), n_out)
+        if interp_mode:
+            setup = oracle.interpolator_setup(tables, points)
+            expect = oracle.interpolator_predict_zheng07_batch(tables, setup, theta[:2], x[:2])
+            xi = host[n_draws:].reshape(n_draws, N_R)
+            parity = float(max(np.max(np.abs(host[:2] / expect[0] - 1)),
+                               np.max(np.abs(xi[:2] / expect[1] - 1))))
+        else:
+            expect = oracle.predict_zheng07_batch(table, theta[:4])
+            if chi2_mode:
+                delta = expect[1] - data_vector
+                chi2 = np.einsum('bi,ij,bj->b', delta, precision, delta)
+                parity = float(max(np.max(np.abs(host[:4] / expect[0] - 1)),
+                                   np.max(np.abs(host[n_draws:n_draws + 4] / chi2 - 1))))
+            else:
+                xi = host[n_draws:].reshape(n_draws, N_R)
+                parity = float(max(np.max(np.abs(host[:4] / expect[0] - 1)),
+                                   np.max(np.abs(xi[:4] / expect[1] - 1))))
 
-        # the kernel's own roofline: launches serialised (TC_PIPELINE=0 pass above); in the
-        # timed region kernels of neighbouring batches share the chip, which stretches
-        # every launch (reported as overlapped_*)
-        achieved = flop_contract / (isolated_ms.value * 1e-3) / 1e12
-        overlapped = flop_contract / (kernel_ms.value * 1e-3) / 1e12
+        kernel_name = ('tc::contract_quad_kernel<5, true>' if interp_mode
+                       else 'tc::contract_quad_kernel<5, false>')
+        achieved = flop_contract / (isolated_ms * 1e-3) / 1e12
         total_draws = comm.world_size * n_draws * args.steps
+        if interp_mode:
+            workload = ('BASELINE configs[3]: Interpolator.predict() over a 5 x 5 grid of '
+                        'synthetic auto tables (each 50 mass bins x {cen,sat}, G=100, P=5050, 19 '
+                        'rp bins), Zheng07, n_gauss_prim=10; %d draws per step sharded '
+                        'round-robin over %d GPU(s), draws resident in HBM, results gathered on '
+                        'rank 0' % (n_draws * comm.world_size, comm.world_size))
+        else:
+            workload = ('BASELINE configs[1]: Zheng07 predict(), synthetic auto '
+                        'table 50 mass bins x {cen,sat} (G=100, P=5050), 19 rp '
+                        'bins, n_gauss_prim=10, batch of %d draws per GPU per '
+                        'step, draws and results resident in HBM' % n_draws)
         result = {
             'metric': 'predict_calls_per_sec',
             'value': total_draws / elapsed,
+            'value_is': 'device-resident rate (draws and results in HBM); the host-to-host '
+                        'rate of SURVEY.md 8d is host_to_host.value',
             'unit': 'calls/s',
             'n_gpus': comm.world_size,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': 'strong' if interp_mode else 'weak',
             'vs_baseline': None,
             'dtype': 'f64',
             'data': 'synthetic',
             'config': {
-                'workload': 'BASELINE configs[1]: Zheng07 predict(), synthetic auto '
-                            'table 50 mass bins x {cen,sat} (G=100, P=5050), 19 rp '
-                            'bins, n_gauss_prim=10, batch of %d draws per GPU per '
-                            'step, draws and results resident in HBM' % n_draws,
+                'workload': workload,
                 'draws_per_gpu_per_step': n_draws,
-                'n_bins': n_bins, 'n_pairs': n_pairs, 'n_r': N_R,
-                'parallelism': 'draws sharded over %d GPU(s), table replicated' %
-                               comm.world_size,
+                'n_bins': n_bins, 'n_pairs': n_pairs, 'n_r': N_R, 'n_tables': n_tables,
+                'parallelism': 'draws sharded over %d GPU(s), table%s replicated' %
+                               (comm.world_size, 's' if interp_mode else ''),
                 'gather': comm.gather_backend,
+                'gather_payload': 'ngal + chi2 (16 B per draw)' if chi2_mode
+                                  else 'ngal + xi (%d B per draw)' % (8 * (1 + N_R)),
                 'gather_every_steps': every,
             },
             'roofline': {
-                'kernel': 'tc::contract_mfma_kernel<20, false>',
+                'kernel': kernel_name,
                 'bound': 'mfma',
                 'achieved': achieved,
                 'peak': FP64_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': achieved / FP64_PEAK_TFLOPS,
-                'traffic': PMC_TRAFFIC_BYTES_DEFAULT_WORKLOAD if n_draws == 10000 else None,
-                'traffic_source': 'profiles/r01_pmc_counters.txt (offline PMC passes)',
+                'traffic': pmc_traffic(kernel_name) if n_draws == 10000 and not interp_mode
+                           else None,
+                'traffic_source': 'profiles/r02_pmc_counters.txt (separate rocprofv3 --pmc '
+                                  'FETCH_SIZE / WRITE_SIZE passes of this script; FETCH_SIZE x 2 '
+                                  'per the gfx950 correction)',
                 'flop_per_launch': flop_contract,
-                'mean_launch_ms': isolated_ms.value,
-                'launches_timed': n_launch.value,
-                'overlapped_launch_ms': kernel_ms.value,
-                'overlapped_frac': overlapped / FP64_PEAK_TFLOPS,
-                'step_frac': flop_contract / (elapsed / args.steps) / 1e12 /
-                             FP64_PEAK_TFLOPS,
+                'mean_launch_ms': isolated_ms,
+                'launches_timed': n_launch,
+                'method': 'kernels serialised (pipeline off), >= 150 ms of load, then %d '
+                          'launches with hipExtLaunchKernelGGL start/stop events' % n_launch,
+                'serialised_step_ms': serial_step_ms,
+                'overlapped_launch_ms': overlapped_ms,
+                'overlapped_frac': flop_contract / (overlapped_ms * 1e-3) / 1e12 /
+                                   FP64_PEAK_TFLOPS,
+                'step_frac': flop_contract / (elapsed / args.steps) / 1e12 / FP64_PEAK_TFLOPS,
                 'workgroups': launch[0].value,
                 'waves_per_workgroup': launch[1].value,
                 'lds_bytes': launch[3].value,
@@ -270,17 +481,178 @@ def main():
         }
         if comm.rccl_error:
             result['config']['rccl_error'] = comm.rccl_error
-        if comm.world_size == 1 and args.cpu_seconds > 0:
+
+    # ---- SURVEY 8d metric, latency mode, the other BASELINE configurations (1 GPU) ---------
+    if comm.world_size == 1 and not interp_mode:
+        ngal_host = np.empty(n_draws)
+        xi_host = np.empty((n_draws, N_R))
+
+        def host_call():
+            _lib.check(lib.tc_predict_zheng07_batch(
+                handle, _lib.as_double_p(theta), 5, n_draws, N_GAUSS, 0,
+                _lib.as_double_p(ngal_host), _lib.as_double_p(xi_host)))
+        seconds = time_calls(host_call, seconds=0.5, warm=5)
+        result['host_to_host'] = {
+            'value': n_draws / seconds, 'unit': 'calls/s', 'ms_per_call': seconds * 1e3,
+            'what': 'tc_predict_zheng07_batch: %d draws in pageable host memory -> (ngal, xi) '
+                    'in host memory, synchronous, PCIe included (SURVEY.md 8d)' % n_draws}
+        result['unbatched_us'] = unbatched(make, table, synthetic, Interpolator)
+        if args.other_configs:
+            result['other_configs'] = other_configs(
+                lib, _lib, make, synthetic, Interpolator, args.cpu_seconds)
+    if result is not None:
+        if comm.world_size == 1 and args.cpu_seconds > 0 and not interp_mode:
             result['cpu_baseline'] = cpu_baseline(table, args.cpu_seconds)
             if cpu_all is not None:
                 result['cpu_baseline']['all_cores'] = cpu_all
         print(json.dumps(result), flush=True)
 
-    for ptr in (d_theta, d_out, d_recv):
-        if ptr.value:
-            lib.tc_device_free(ptr)
+    dev.free_all()
     comm.barrier()
     comm.close()
+
+
+# ---- latency mode --------------------------------------------------------------------------
+
+def unbatched(make, table, synthetic, Interpolator):
+    """One predict(model) per call, the reference's usage pattern (README.md:72-75)."""
+    from tabcorr_amd import Zheng07Model
+    halotab = make(table)
+    model = Zheng07Model()
+    halotab.predict(model)
+    count = [0]
+
+    def call():
+        count[0] += 1
+        model.param_dict['logMmin'] = 12.0 + 1e-5 * (count[0] % 1000)
+        halotab.predict(model)
+    single = time_calls(call, seconds=0.3, warm=50)
+    tables, keys, points = synthetic.synthetic_interpolator((5, 5), N_PRIM, N_SEC, (N_R, ),
+                                                            'auto', seed=7)
+    interp = Interpolator([make(t) for t in tables],
+                          {k: points[:, d] for d, k in enumerate(keys)})
+    for d, key in enumerate(keys):
+        model.param_dict[key] = float(np.mean(points[:, d]))
+    interp.predict(model)
+
+    def call_interp():
+        count[0] += 1
+        model.param_dict['logMmin'] = 12.0 + 1e-5 * (count[0] % 1000)
+        interp.predict(model)
+    grid = time_calls(call_interp, seconds=0.3, warm=20)
+    return {'predict_model': single * 1e6, 'interpolator_5x5_predict_model': grid * 1e6,
+            'unit': 'us per call (Python API, host model -> host results)'}
+
+
+# ---- BASELINE configs[2], [3], [4] ----------------------------------------------------------
+
+def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds):
+    from oracle import tabcorr_oracle as oracle
+    out = {}
+    dev = Device(lib, _lib)
+    theta = synthetic.zheng07_draws(10000, seed=1)
+    cpu_budget = min(3.0, cpu_seconds / 4) if cpu_seconds > 0 else 0.0
+
+    def cpu_rate(call, n_max=100000):
+        if cpu_budget <= 0:
+            return None
+        call(0)
+        start = time.perf_counter()
+        count = 0
+        while time.perf_counter() - start < cpu_budget and count < n_max:
+            call(count)
+            count += 1
+        spent = time.perf_counter() - start
+        return {'value': count / spent, 'unit': 'calls/s', 'cores': 1, 'kind': 'port',
+                'sample': '%d sequential predict() calls in %.1f s' % (count, spent)}
+
+    def measure(name, what, handle, timer_handle, launch, synchronize, host_call, n_draws, flop,
+                peak, kernel, dtype, cpu):
+        device_seconds = sustained(launch, synchronize)
+        _lib.check(lib.tc_table_set_option(timer_handle, b'pipeline', 0))
+        kernel_ms, n_launch, _ = kernel_time(lib, _lib, timer_handle, launch, synchronize,
+                                             n_launches=300, max_seconds=0.6)
+        _lib.check(lib.tc_table_set_option(timer_handle, b'pipeline', 1))
+        host_seconds = time_calls(host_call, seconds=0.4, warm=3)
+        achieved = flop / (kernel_ms * 1e-3) / 1e12
+        out[name] = {
+            'workload': what, 'dtype': dtype, 'draws_per_call': n_draws,
+            'device_calls_per_sec': n_draws / device_seconds,
+            'host_to_host_calls_per_sec': n_draws / host_seconds,
+            'kernel': kernel, 'kernel_us': kernel_ms * 1e3, 'launches_timed': n_launch,
+            'flop_per_launch': flop, 'achieved_tflops': achieved, 'peak_tflops': peak,
+            'frac': achieved / peak, 'cpu_baseline': cpu}
+
+    # configs[2]: separate_gal_type + assembly bias on a 2-D halo-bin grid
+    table3 = synthetic.synthetic_table(50, 2, (N_R, ), 'auto', seed=3)
+    theta7 = np.hstack([theta, np.random.default_rng(0).uniform(-1, 1, (10000, 2))])
+    tab3 = make(table3)
+    h3 = tab3.to_device().handle
+    d_theta7 = dev.upload(theta7)
+    d_ngal, d_xi = dev.malloc(2 * 10000), dev.malloc(3 * N_R * 10000)
+    flags3 = FLAG_SEPARATE | FLAG_ASSEMBIAS
+    cache3 = {}
+    measure('configs[2]', 'separate_gal_type=True + Heaviside assembly bias, 50 x 2 x {cen,sat} '
+            'bins (G=200, P=20100), 19 rp bins, 10^4 draws', h3, h3,
+            lambda: _lib.check(lib.tc_predict_zheng07_batch_device(
+                h3, d_theta7, 7, 10000, N_GAUSS, flags3, d_ngal, d_xi)),
+            lambda: _lib.check(lib.tc_table_synchronize(h3)),
+            lambda: tab3.predict_batch(theta7, separate_gal_type=True, assembias=True),
+            10000, 10000 * pair_flops(200, N_R), FP64_PEAK_TFLOPS,
+            'tc::contract_quad_kernel<5, false>', 'f64',
+            cpu_rate(lambda i: oracle.predict_zheng07(
+                table3, theta7[i % 10000, :5], separate_gal_type=True,
+                assembias=theta7[i % 10000, 5:], cache=cache3)))
+    del tab3
+
+    # configs[3]: one GPU's share (12 500 draws) of the 5 x 5 interpolator
+    tables, keys, points = synthetic.synthetic_interpolator((5, 5), N_PRIM, N_SEC, (N_R, ),
+                                                            'auto', seed=7)
+    interp = Interpolator([make(t) for t in tables],
+                          {k: points[:, d] for d, k in enumerate(keys)})
+    n4 = 12500
+    theta4 = synthetic.zheng07_draws(n4, seed=5)
+    rng = np.random.default_rng(6)
+    x4 = np.ascontiguousarray(np.stack(
+        [rng.uniform(xp[0], xp[-1], size=n4) for xp in interp.xp], axis=-1))
+    idev = interp.to_device()
+    d_theta4, d_x4 = dev.upload(theta4), dev.upload(x4)
+    d_ngal4, d_xi4 = dev.malloc(n4), dev.malloc(n4 * N_R)
+    setup = oracle.interpolator_setup(tables, points)
+    measure('configs[3]', 'Interpolator.predict over a 5 x 5 grid of configs[1] tables, one '
+            "GPU's share of 10^5 draws (12 500)", idev.handle, idev.tables[0].handle,
+            lambda: _lib.check(lib.tc_interp_predict_zheng07_batch_device(
+                idev.handle, d_theta4, 5, d_x4, n4, N_GAUSS, 0, d_ngal4, d_xi4)),
+            lambda: _lib.check(lib.tc_interp_synchronize(idev.handle)),
+            lambda: interp.predict_batch(theta4, x4), n4,
+            n4 * 25 * pair_flops(100, N_R), FP64_PEAK_TFLOPS,
+            'tc::contract_quad_kernel<5, true>', 'f64',
+            cpu_rate(lambda i: oracle.interpolator_predict(
+                tables, setup, oracle.Zheng07(theta4[i % n4]), x4[i % n4])))
+    del interp, idev
+
+    # configs[4]: AbacusSummit-scale table, rp_pi (19 x 40), float32 MFMA variant and float64
+    table5 = synthetic.synthetic_table(100, 1, (19, 40), 'auto', seed=9)
+    n_r5 = 760
+    d_ngal5, d_xi5 = dev.malloc(10000), dev.malloc(10000 * n_r5)
+    d_theta5 = dev.upload(theta)
+    cache5 = {}
+    cpu5 = cpu_rate(lambda i: oracle.predict_zheng07(table5, theta[i % 10000], cache=cache5))
+    for dtype, peak, kernel in (('float32', FP32_PEAK_TFLOPS, 'tc::contract_f32_kernel<false>'),
+                                ('float64', FP64_PEAK_TFLOPS,
+                                 'tc::contract_quad_kernel<5, false>')):
+        tab5 = make(table5, compute_dtype=dtype)
+        h5 = tab5.to_device().handle
+        measure('configs[4] ' + dtype, 'rp_pi table 19 x 40 (R=760), 100 x {cen,sat} bins (G=200, '
+                'P=20100), 10^4 draws, %s table and contraction' % dtype, h5, h5,
+                lambda: _lib.check(lib.tc_predict_zheng07_batch_device(
+                    h5, d_theta5, 5, 10000, N_GAUSS, 0, d_ngal5, d_xi5)),
+                lambda: _lib.check(lib.tc_table_synchronize(h5)),
+                lambda: tab5.predict_batch(theta), 10000, 10000 * pair_flops(200, n_r5), peak,
+                kernel, 'f32' if dtype == 'float32' else 'f64', cpu5)
+        del tab5
+    dev.free_all()
+    return out
 
 
 def cpu_baseline(table, seconds):

@@ -180,6 +180,15 @@ int tc_chi2_zheng07_batch(tc_table* table, const double* theta, int n_theta,
                           const double* data, const double* precision, double* ngal,
                           double* chi2);
 
+/* The same with the draws and the results (ngal, chi2: n_draws doubles each) resident on
+ * the device; data / precision are host arrays (uploaded when they change).  Enqueues and
+ * returns; at most 2^18 draws per call.  Lets a multi-GPU run gather 16 bytes per draw
+ * instead of 8 (1 + n_r). */
+int tc_chi2_zheng07_batch_device(tc_table* table, const double* theta_device, int n_theta,
+                                 int64_t n_draws, int n_gauss_prim, unsigned flags,
+                                 const double* data, const double* precision,
+                                 double* ngal_device, double* chi2_device);
+
 /* TabCorr.predict(ndarray): the operator seam of tabcorr.py:616-621 for arbitrary
  * occupation models evaluated by the caller.  occupation: (n_draws, n_bins). */
 int tc_predict_occupation_batch(tc_table* table, const double* occupation,
@@ -215,10 +224,20 @@ int tc_interp_predict_zheng07_batch_device(tc_interp* interp, const double* thet
                                            unsigned flags, double* ngal_device,
                                            double* xi_device);
 
+/* Run-time options of a table handle (the library never reads the environment):
+ *   "pipeline"    1 (default): consecutive device-pointer calls rotate over the handle's
+ *                 lanes (stream + workspaces) so that kernels of neighbouring batches
+ *                 overlap; 0: every call on lane 0, kernels strictly serialised.
+ *   "lanes"       number of lanes, 1..4 (default 4).
+ *   "single_draw" 1 (default): an un-batched predict() goes through one launch. */
+int tc_table_set_option(tc_table* table, const char* name, int value);
+
 /* ---- measurement -------------------------------------------------------------------
  * HIP events on the handle's own stream (torch.cuda.Event would only see torch's).
  * tc_table_timer_begin/end bracket a region; with profile = 1 every launch of the
- * contraction kernel is additionally bracketed by its own event pair and
+ * contraction kernel -- of this table, or of an interpolator whose first table this is --
+ * additionally carries its own start / stop events (hipExtLaunchKernelGGL: the dispatch's
+ * own begin and end, the interval rocprofv3 --kernel-trace reports) and
  * tc_table_kernel_time reports the count and mean duration since timer_begin. */
 int tc_table_timer_begin(tc_table* table, int profile_kernels);
 int tc_table_timer_end(tc_table* table, float* elapsed_ms);
@@ -250,6 +269,11 @@ int tc_comm_destroy(tc_comm* comm);
 int tc_comm_gather(tc_comm* comm, tc_table* table, const double* send_device,
                    double* recv_device, int64_t count, int root, int slot);
 int tc_comm_release(tc_comm* comm, tc_table* table, int slot);
+/* The same for results produced by an interpolator handle (Interpolator.predict sharded
+ * over the GPUs: BASELINE configs[3], interpolator.py:124-216). */
+int tc_comm_gather_interp(tc_comm* comm, tc_interp* interp, const double* send_device,
+                          double* recv_device, int64_t count, int root, int slot);
+int tc_comm_release_interp(tc_comm* comm, tc_interp* interp, int slot);
 int tc_comm_barrier(tc_comm* comm);
 int tc_comm_synchronize(tc_comm* comm);
 

@@ -75,10 +75,15 @@ def heaviside_assembias(baseline, percentile, strength, lower, upper,
 
     Bins above the percentile ``split`` receive ``+d``, the others
     ``-d f1 / f2`` (f1 = 1 - split), with ``d = strength * d_max`` and
-    ``d_max`` the largest shift that keeps both inside ``[lower, upper]``.
+    ``d_max`` the largest shift that keeps both inside ``[lower, upper]``;
+    ``strength`` is limited to [-1, 1].
     """
     f1 = 1.0 - split
     f2 = split
+    # halotools' HeavisideAssembias.assembias_strength clips to [-1, 1] (two
+    # np.where calls, so a NaN strength stays NaN)
+    strength = 1.0 if strength > 1 else strength
+    strength = -1.0 if strength < -1 else strength
     if strength >= 0:
         dmax = np.minimum(upper - baseline, (baseline - lower) * f2 / f1)
     else:

@@ -83,6 +83,10 @@ SIGNATURES = {
         ctypes.c_void_p, c_double_p, ctypes.c_int, ctypes.c_int64,
         ctypes.c_int, ctypes.c_uint, c_double_p, c_double_p, c_double_p,
         c_double_p],
+    'tc_chi2_zheng07_batch_device': [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+        ctypes.c_int, ctypes.c_uint, c_double_p, c_double_p, ctypes.c_void_p,
+        ctypes.c_void_p],
     'tc_predict_occupation_batch': [
         ctypes.c_void_p, c_double_p, ctypes.c_int64, ctypes.c_uint,
         c_double_p, c_double_p],
@@ -99,6 +103,7 @@ SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
         ctypes.c_int64, ctypes.c_int, ctypes.c_uint, ctypes.c_void_p,
         ctypes.c_void_p],
+    'tc_table_set_option': [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int],
     'tc_table_timer_begin': [ctypes.c_void_p, ctypes.c_int],
     'tc_table_timer_end': [ctypes.c_void_p, c_float_p],
     'tc_table_kernel_time': [ctypes.c_void_p, c_int_p, c_float_p],
@@ -116,6 +121,11 @@ SIGNATURES = {
                        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
                        ctypes.c_int],
     'tc_comm_release': [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int],
+    'tc_comm_gather_interp': [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                              ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                              ctypes.c_int],
+    'tc_comm_release_interp': [ctypes.c_void_p, ctypes.c_void_p,
+                               ctypes.c_int],
     'tc_comm_barrier': [ctypes.c_void_p],
     'tc_comm_synchronize': [ctypes.c_void_p],
 }

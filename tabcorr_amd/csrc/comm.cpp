@@ -128,23 +128,42 @@ int tc_comm_destroy(tc_comm* c) {
   return TC_OK;
 }
 
-int tc_comm_gather(tc_comm* c, tc_table* t, const double* send_device,
-                   double* recv_device, int64_t count, int root, int slot) {
+namespace {
+
+// Gather on the communicator's stream once the work queued so far on `producer` is done,
+// without blocking the host: later batches overlap with the transfer.
+int gather_after(tc_comm* c, hipStream_t producer, const double* send_device,
+                 double* recv_device, int64_t count, int root, int slot) {
   TC_CHECK(slot >= 0 && slot < 4, "slot must be in [0, 4)");
   TC_CHECK(c != nullptr && send_device != nullptr, "NULL argument");
   TC_CHECK(count >= 0 && root >= 0 && root < c->n_ranks, "invalid count or root");
   TC_CHECK(c->rank != root || recv_device != nullptr, "recv buffer is NULL on the root");
   TC_HIP(hipSetDevice(c->device));
-  if (t != nullptr) {
-    // the gather starts once the predictions queued on the table's stream are done,
-    // without blocking the host: later batches overlap with the transfer
-    TC_HIP(hipEventRecord(c->ready, t->lanes[t->cur].stream));
+  if (producer != nullptr) {
+    TC_HIP(hipEventRecord(c->ready, producer));
     TC_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
   }
-  TC_RCCL(g_rccl.Gather(send_device, recv_device, (size_t)count, kNcclFloat64, root,
-                        c->comm, c->stream));
+  tc::host::range_push("rccl gather");
+  const int status = g_rccl.Gather(send_device, recv_device, (size_t)count, kNcclFloat64,
+                                   root, c->comm, c->stream);
+  tc::host::range_pop();
+  TC_RCCL(status);
   TC_HIP(hipEventRecord(c->done[slot], c->stream));
   return TC_OK;
+}
+
+}  // namespace
+
+int tc_comm_gather(tc_comm* c, tc_table* t, const double* send_device,
+                   double* recv_device, int64_t count, int root, int slot) {
+  return gather_after(c, t != nullptr ? t->lanes[t->cur].stream : nullptr, send_device,
+                      recv_device, count, root, slot);
+}
+
+int tc_comm_gather_interp(tc_comm* c, tc_interp* interp, const double* send_device,
+                          double* recv_device, int64_t count, int root, int slot) {
+  return gather_after(c, interp != nullptr ? tc::host::interp_stream(interp) : nullptr,
+                      send_device, recv_device, count, root, slot);
 }
 
 int tc_comm_release(tc_comm* c, tc_table* t, int slot) {
@@ -153,6 +172,14 @@ int tc_comm_release(tc_comm* c, tc_table* t, int slot) {
   TC_HIP(hipSetDevice(c->device));
   for (tc_table::Lane& lane : t->lanes)
     TC_HIP(hipStreamWaitEvent(lane.stream, c->done[slot], 0));
+  return TC_OK;
+}
+
+int tc_comm_release_interp(tc_comm* c, tc_interp* interp, int slot) {
+  TC_CHECK(c != nullptr && interp != nullptr, "NULL argument");
+  TC_CHECK(slot >= 0 && slot < 4, "slot must be in [0, 4)");
+  TC_HIP(hipSetDevice(c->device));
+  TC_HIP(hipStreamWaitEvent(tc::host::interp_stream(interp), c->done[slot], 0));
   return TC_OK;
 }
 

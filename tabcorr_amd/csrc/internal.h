@@ -5,6 +5,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -29,6 +30,18 @@ namespace host {
 // Records the message tc_last_error() returns on this thread; returns `code`.
 int fail(int code, const char* format, ...);
 const char* last_error();
+
+// roctx ranges around the stages of a call (upload, occupation, contraction, finalisation,
+// download, gather), visible with `rocprofv3 --marker-trace`.  The marker library is
+// resolved at run time; without it the calls do nothing.
+void range_push(const char* name);
+void range_pop();
+struct Range {
+  explicit Range(const char* name) { range_push(name); }
+  ~Range() { range_pop(); }
+  Range(const Range&) = delete;
+  Range& operator=(const Range&) = delete;
+};
 
 #define TC_HIP(call)                                                          \
   do {                                                                        \
@@ -91,22 +104,25 @@ struct PinnedBuffer {
     bytes = 0;
   }
 };
-// Larger transfers go directly (TC_STAGE_LIMIT_MB overrides).
+// (developer builds only: environment overrides)
+inline int env_int_early(const char* name, int fallback) {
+#ifdef TC_DEVELOPER_KNOBS
+  const char* value = getenv(name);
+  if (value != nullptr && *value != 0) return atoi(value);
+#endif
+  (void)name;
+  return fallback;
+}
+// Larger transfers go directly.
 inline size_t stage_limit() {
-  static const size_t limit = [] {
-    const char* value = getenv("TC_STAGE_LIMIT_MB");
-    return (size_t)(value && *value ? atoi(value) : 1) << 20;
-  }();
+  static const size_t limit = (size_t)env_int_early("TC_STAGE_LIMIT_MB", 1) << 20;
   return limit;
 }
 
 // Calls moving at most this many bytes skip the copy commands: the kernels address the
-// page-locked staging buffers directly (TC_ZERO_COPY_KB overrides, 0 disables).
+// page-locked staging buffers directly (1 MB).
 inline size_t zero_copy_limit() {
-  static const size_t limit = [] {
-    const char* value = getenv("TC_ZERO_COPY_KB");
-    return (size_t)(value && *value ? atoi(value) : 1024) << 10;
-  }();
+  static const size_t limit = (size_t)env_int_early("TC_ZERO_COPY_KB", 1024) << 10;
   return limit;
 }
 
@@ -156,11 +172,57 @@ struct QuadTable {
   void release();
 };
 
+// Developer knobs.  The release build never reads the environment: tuning values are the
+// defaults of `Tuning` below (read once per handle in developer builds, -DTC_DEVELOPER_KNOBS,
+// so that parameter sweeps stay possible) and the few run-time options a caller may
+// legitimately change go through tc_table_set_option().
 inline int env_int(const char* name, int fallback) {
+#ifdef TC_DEVELOPER_KNOBS
   const char* value = getenv(name);
   if (value == nullptr || *value == 0) return fallback;
   return atoi(value);
+#else
+  (void)name;
+  return fallback;
+#endif
 }
+
+struct Tuning {
+  int lanes = 4;              // pipelining lanes of device-pointer calls (1..4)
+  int pipeline = 1;           // 0: every device-pointer call on lane 0 (kernels serialised)
+  int single_draw = 1;        // one-launch path for un-batched predict()
+  int quad_waves = 2;         // resident contraction waves per SIMD (quadratic-form kernel)
+  int prio_occ = 0, prio_contract = 1, prio_finalize = 3;   // wave priorities
+  int finalize_threads = 0;   // 0: chosen per batch size
+  int finalize_row_blocks = 0;
+  int occ_splits = 0;         // 0: chosen per batch size
+  int occ_per_cu = 4;
+  int n_groups = 0, n_waves = 0, lds_min = 0, min_chunk_entries = 32;   // segment kernels
+  int k_splits = 0;           // interpolator, segment kernels: table splits (0: chosen)
+  int trace = 0;              // developer timelines
+  int skip_occ = 0, skip_finalize = 0;   // diagnosis (developer builds only)
+  void load() {
+    lanes = env_int("TC_LANES", lanes);
+    pipeline = env_int("TC_PIPELINE", pipeline);
+    single_draw = env_int("TC_SINGLE_DRAW", single_draw);
+    quad_waves = env_int("TC_QUAD_WAVES", quad_waves);
+    prio_occ = env_int("TC_PRIO_O", prio_occ);
+    prio_contract = env_int("TC_PRIO_C", prio_contract);
+    prio_finalize = env_int("TC_PRIO_F", prio_finalize);
+    finalize_threads = env_int("TC_FINALIZE_THREADS", finalize_threads);
+    finalize_row_blocks = env_int("TC_FINALIZE_ROW_BLOCKS", finalize_row_blocks);
+    occ_splits = env_int("TC_OCC_SPLITS", occ_splits);
+    occ_per_cu = env_int("TC_OCC_PER_CU", occ_per_cu);
+    n_groups = env_int("TC_NGROUPS", n_groups);
+    n_waves = env_int("TC_NWAVES", n_waves);
+    lds_min = env_int("TC_LDS_MIN", lds_min);
+    min_chunk_entries = env_int("TC_MIN_CHUNK_ENTRIES", min_chunk_entries);
+    k_splits = env_int("TC_KSPLITS", k_splits);
+    trace = env_int("TC_TRACE", trace);
+    skip_occ = env_int("TC_SKIP_OCC", skip_occ);
+    skip_finalize = env_int("TC_SKIP_FINALIZE", skip_finalize);
+  }
+};
 
 }  // namespace host
 }  // namespace tc
@@ -198,7 +260,8 @@ struct tc_table {
   tc::QuadTiling quad_tiling;
   tc::host::QuadTable quad_by_type, quad_total;
   int n_cus = 256;               // compute units of the device
-  int quad_waves_per_simd = 2;   // resident waves of the contraction per SIMD
+  int n_xcds = 8;                // accelerator complexes (each with its own L2)
+  tc::host::Tuning tuning;
   std::map<int, tc::host::Quadrature> quadrature;
   std::map<std::pair<int, int>, std::unique_ptr<tc::host::DeviceChunking>> chunkings;
   std::map<int64_t, tc::host::DeviceChunking*> choices;   // decomposition chosen per tile count
@@ -212,6 +275,7 @@ struct tc_table {
     hipStream_t stream = nullptr;
     hipEvent_t finished = nullptr;   // recorded after the lane's last finalisation
     tc::host::DeviceBuffer nbuf, ngal2, partial;
+    tc::host::DeviceBuffer xi;       // chi2 device calls: the correlation functions
     int ngal_parts = 1;              // partial sums the occupation step left in ngal2
   };
   static constexpr int kMaxLanes = 4;
@@ -253,10 +317,12 @@ int blocks_per_cu(int lds_bytes, int waves, int slots);
 int choose_chunking(tc_table* t, int64_t n_draws, int tables_per_block, DeviceChunking** out,
                     int* lds_bytes);
 int launch_contract_rt(int rt, dim3 grid, dim3 block, int lds, hipStream_t stream,
-                       const ContractArgs& args);
+                       const ContractArgs& args, hipEvent_t start = nullptr,
+                       hipEvent_t stop = nullptr);
 int set_lds_limit_rt(int rt, int lds);
 int launch_contract_f32(dim3 grid, dim3 block, int lds, hipStream_t stream,
-                        const ContractArgs& args);
+                        const ContractArgs& args, hipEvent_t start = nullptr,
+                        hipEvent_t stop = nullptr);
 // Occupation kernel for a slab of draws: densities into (nbuf, ngal2) -- the current
 // lane's by default -- and optionally the occupations in reference order.
 int run_occupation(tc_table* t, const double* theta_device, int n_theta, int64_t n_draws,
@@ -268,14 +334,19 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
                     double* ngal_device, double* xi_device);
 int check_predict_args(const tc_table* t, const void* theta, int n_theta, int64_t n_draws,
                        int n_gauss, unsigned flags);
-int launch_finalize(const FinalizeArgs& args, hipStream_t stream);
+int launch_finalize(const FinalizeArgs& args, const Tuning& tuning, hipStream_t stream);
 // Quadratic-form path: layout upload, schedules, launches.
 int build_quad_table(tc_table* t, bool by_type, const void* matrix, int matrix_dtype,
                      QuadTable* out);
 int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, bool separate,
                       DeviceQuadSchedule** out);
-int launch_contract_quad(int n_u, bool interp, const QuadArgs& args, hipStream_t stream);
-int launch_finalize_quad(const FinalizeQuadArgs& args, hipStream_t stream);
+int launch_contract_quad(int n_u, bool interp, const QuadArgs& args, hipStream_t stream,
+                         hipEvent_t start, hipEvent_t stop);
+int launch_finalize_quad(const FinalizeQuadArgs& args, const Tuning& tuning, hipStream_t stream);
+// Stream an interpolator's work is queued on (interp.cpp).
+hipStream_t interp_stream(tc_interp* interp);
+// Events for hipExtLaunchKernelGGL while the table's kernel timer is on, else NULLs.
+int next_kernel_events(tc_table* t, hipEvent_t* start, hipEvent_t* stop);
 // Largest number of draws one slab may hold (workspaces bounded; 32-bit scalar offsets of
 // the quadratic-form kernel: n_bins * ldb * 8 < 2^32).
 int64_t max_slab(const tc_table* t);

@@ -97,8 +97,12 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   ia.n_draws = n_draws;
   ia.coef = (double*)it->coef.ptr;
   ia.ngal = ngal_device;
-  status = launch_interp_coef(ia, it->stream);
+  {
+    Range range("spline weights");
+    status = launch_interp_coef(ia, it->stream);
+  }
   if (status != TC_OK) return status;
+  Range range("contraction + finalisation (all tables)");
 
   if (t0->quad) {
     // quadratic-form kernel: the unit space (draw tile, r tile, component, TABLE, unit) in
@@ -128,8 +132,11 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
     qa.wave_runs = (const int32_t*)schedule->wave_runs;
     qa.n_waves = schedule->n_waves;
     qa.partial = (double*)it->partial.ptr;
-    qa.priority = 1;
-    status = launch_contract_quad(tiling.n_u, true, qa, it->stream);
+    qa.priority = t0->tuning.prio_contract;
+    hipEvent_t k0 = nullptr, k1 = nullptr;     // timed through the first table's timer
+    status = next_kernel_events(t0, &k0, &k1);
+    if (status != TC_OK) return status;
+    status = launch_contract_quad(tiling.n_u, true, qa, it->stream, k0, k1);
     if (status != TC_OK) return status;
     tc::FinalizeQuadArgs fq;
     fq.partial = (const double*)it->partial.ptr;
@@ -140,7 +147,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
     fq.r_per_tile = tiling.r_per_tile;
     fq.rt = rt;
     fq.groups_per_rtile = separate ? (int)q->layout.comps.size() : 1;
-    fq.priority = 3;
+    fq.priority = t0->tuning.prio_finalize;
     fq.n_comp = n_comp;
     fq.n_r = t0->n_r;
     fq.mode = t0->mode;
@@ -148,7 +155,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
     fq.n_draws = n_draws;
     fq.ngal = ngal_device;
     fq.xi = xi_device;
-    return launch_finalize_quad(fq, it->stream);
+    return launch_finalize_quad(fq, t0->tuning, it->stream);
   }
 
   // decomposition: as for one table (choose_chunking), with the tables looped inside
@@ -165,14 +172,14 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   int k_splits = 1;
   {
     const int64_t blocks = n_tiles * t0->n_rtiles * (int64_t)c->host.groups.size();
-    const int64_t want = 256 * (int64_t)blocks_per_cu(lds, c->host.waves_per_group,
+    const int64_t want = t0->n_cus * (int64_t)blocks_per_cu(lds, c->host.waves_per_group,
                                                         wave_slots(t0, true));
     // about two scheduling rounds of blocks (measured optimum for 16 tiles x 20 groups x
     // 25 tables: 3 splits); every split adds a slab the finalisation has to sum
     if (blocks < want)
       k_splits = (int)std::min<int64_t>(
           it->n_tables, std::max<int64_t>(1, 2 * want / std::max<int64_t>(1, blocks)));
-    k_splits = std::max(1, env_int("TC_KSPLITS", k_splits));
+    if (t0->tuning.k_splits > 0) k_splits = t0->tuning.k_splits;
     k_splits = std::min(k_splits, it->n_tables);
   }
   if (lds > kMaxLdsBytes)
@@ -207,19 +214,23 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   ca.coef = (const double*)it->coef.ptr;
   ca.n_tiles = (int)n_tiles;
   ca.n_slabs = n_groups * k_splits;
-  const int64_t padded_tiles = n_tiles >= 8 ? (n_tiles + 7) / 8 * 8 : n_tiles;
+  ca.xcd_map = t0->n_xcds == 8 && n_tiles >= 8;
+  const int64_t padded_tiles = ca.xcd_map ? (n_tiles + 7) / 8 * 8 : n_tiles;
   dim3 grid((unsigned)(padded_tiles * n_groups * k_splits), 1,
             (unsigned)t0->n_rtiles);
   dim3 block(64 * c->host.waves_per_group);
+  hipEvent_t k0 = nullptr, k1 = nullptr;       // timed through the first table's timer
+  status = next_kernel_events(t0, &k0, &k1);
+  if (status != TC_OK) return status;
   if (t0->compute_dtype == TC_DTYPE_F32) {
     ca.pos_ij = (const int32_t*)t0->d_pos_ij;
-    status = launch_contract_f32(grid, block, lds, it->stream, ca);
+    status = launch_contract_f32(grid, block, lds, it->stream, ca, k0, k1);
   } else {
     if (lds > 64 * 1024) {
       status = set_lds_limit_rt(t0->rt, lds);
       if (status != TC_OK) return status;
     }
-    status = launch_contract_rt(t0->rt, grid, block, lds, it->stream, ca);
+    status = launch_contract_rt(t0->rt, grid, block, lds, it->stream, ca, k0, k1);
   }
   if (status != TC_OK) return status;
 
@@ -238,10 +249,16 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   fa.n_draws = n_draws;
   fa.ngal = ngal_device;
   fa.xi = xi_device;
-  return launch_finalize(fa, it->stream);
+  return launch_finalize(fa, t0->tuning, it->stream);
 }
 
 }  // namespace
+
+namespace tc {
+namespace host {
+hipStream_t interp_stream(tc_interp* interp) { return interp->stream; }
+}  // namespace host
+}  // namespace tc
 
 extern "C" {
 

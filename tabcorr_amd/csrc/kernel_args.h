@@ -81,7 +81,9 @@ struct ContractArgs {
   int mode;
   int n_central;
   int r_stride;             // n_rtiles * RT: padded number of r values
-  int n_tiles;              // draw tiles (grid.x covers 8 * ceil(n_tiles / 8) * slabs)
+  int n_tiles;              // draw tiles (grid.x covers 8 * ceil(n_tiles / 8) * slabs
+                            // with xcd_map, else n_tiles * slabs)
+  int xcd_map;              // 1: block b runs on XCD b % 8 (whole MI355X, 8 XCDs x 32 CUs)
   int n_slabs;              // groups * table splits per draw tile
   const int32_t* pos_ij;    // float32 kernel: packed bin pairs of every position
   const int32_t* pos_off;   // FP64 matrix kernel: (i, j) * 512 (LDS row bytes) per position

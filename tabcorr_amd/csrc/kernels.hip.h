@@ -51,6 +51,65 @@ __device__ inline double heaviside_assembias(double n, double strength,
   return above ? n + d1 : n - d1 * f1_over_f2;
 }
 
+// Per-draw constants of the Zheng07 occupation functions and the flags of draws the fast
+// node loop cannot represent.  The table-driven erf / log2 / exp2 clamp their arguments, so
+// a NaN parameter would come out as a finite occupation where the reference's NumPy
+// callbacks (tabcorr.py:556-563; oracle/tabcorr_oracle.py) return NaN -- and an MCMC
+// likelihood relies on that NaN to reject the draw.  Such parameters are replaced by
+// harmless finite ones here and the affected bins are set to NaN after their node loop:
+//   kBadCen  logMmin or sigma_logM is NaN (or both infinite): every <N_cen> is NaN;
+//   kBadSat  logM1 or alpha is NaN: <N_sat> is NaN at every node with M > M0, 0 elsewhere
+//            (a NaN logM0 makes "M - M0 > 0" false everywhere: <N_sat> = 0);
+//   kTieCen  sigma_logM == 0: a step function, NaN (0 / 0) at a node with log M == logMmin.
+// Assembly-bias strengths are clipped to [-1, 1] as halotools' HeavisideAssembias does (a
+// NaN strength stays NaN and propagates through the decoration by itself).
+constexpr int kBadCen = 1, kBadSat = 2, kTieCen = 4;
+
+struct DrawSetup {
+  double log_m_min, inv_sigma, m0, log2_m1, sat_scale, alpha, a_cen, a_sat;
+  int bad;
+};
+
+__device__ inline double clip_strength(double a) {
+  a = a > 1.0 ? 1.0 : a;
+  return a < -1.0 ? -1.0 : a;
+}
+
+__device__ inline DrawSetup prepare_draw(const double* table, const fm::Consts& kc,
+                                         double log_m_min, double sigma, double log_m0,
+                                         double log_m1, double alpha, double a_cen,
+                                         double a_sat) {
+  DrawSetup d;
+  d.bad = 0;
+  if (log_m_min != log_m_min || sigma != sigma ||
+      (__builtin_isinf(log_m_min) && __builtin_isinf(sigma))) {
+    d.bad |= kBadCen;
+    log_m_min = 12.0;
+    sigma = 1.0;
+  }
+  if (sigma == 0.0) d.bad |= kTieCen;
+  if (log_m1 != log_m1 || alpha != alpha) {
+    d.bad |= kBadSat;
+    log_m1 = 13.0;
+    alpha = 1.0;
+  }
+  d.log_m_min = log_m_min;
+  d.inv_sigma = 1.0 / sigma;
+  d.m0 = log_m0 != log_m0 ? 1e300 : fm::exp10_fast(table, kc, log_m0);
+  // ((M - M0) / M1)^alpha = 2^(alpha (log2(M - M0) - log2 M1)); log2 M1 is carried in two
+  // parts, the low one applied to the finished bin sum as 2^(-alpha lo)
+  const double hi = log_m1 * fm::kLog2Of10Hi;
+  const double lo = __builtin_isinf(log_m1)
+                        ? 0.0
+                        : fma(log_m1, fm::kLog2Of10Hi, -hi) + log_m1 * fm::kLog2Of10Lo;
+  d.log2_m1 = hi;
+  d.sat_scale = fma(-alpha * fm::kLn2, lo, 1.0);
+  d.alpha = alpha;
+  d.a_cen = clip_strength(a_cen);
+  d.a_sat = clip_strength(a_sat);
+  return d;
+}
+
 // Mean occupation of every bin for every draw: tabcorr/tabcorr.py:537-578 with
 // the two halotools callbacks of :556-563 evaluated inline (Zheng et al. 2007
 // eqs. 1 and 3).  Work items = (draw tile, bin split); the kOccWaves waves of a
@@ -65,7 +124,7 @@ template <int NGAUSS, bool ASSEMBIAS, bool MODULATE>
 __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     OccArgs a) {
   __shared__ double red[2][kOccWaves][kLanes];
-  __shared__ double prm[8][kLanes];
+  __shared__ double prm[9][kLanes];
   __shared__ __attribute__((aligned(16))) double table[fm::kTableDoubles];
   const fm::Consts kc = fm::make_consts();
   // short kernel on the critical path of its lane: run ahead of the contraction waves
@@ -120,19 +179,17 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     // per-draw quantities: computed by wave 0, shared with the other waves through LDS
     if (wave == 0) {
       const double* th = a.theta + b * a.n_theta;
-      const double log_m1 = th[3], alpha_0 = th[4];
-      // ((M - M0) / M1)^alpha = 2^(alpha (log2(M - M0) - log2 M1)); log2 M1 is carried
-      // in two parts, the low one applied to the finished bin sum as 2^(-alpha lo)
-      const double hi = log_m1 * fm::kLog2Of10Hi;
-      const double lo = fma(log_m1, fm::kLog2Of10Hi, -hi) + log_m1 * fm::kLog2Of10Lo;
-      prm[0][lane] = th[0];
-      prm[1][lane] = 1.0 / th[1];
-      prm[2][lane] = fm::exp10_fast(table, kc, th[2]);
-      prm[3][lane] = hi;
-      prm[4][lane] = fma(-alpha_0 * fm::kLn2, lo, 1.0);
-      prm[5][lane] = alpha_0;
-      prm[6][lane] = assembias ? th[5] : 0.0;
-      prm[7][lane] = assembias ? th[6] : 0.0;
+      const DrawSetup d = prepare_draw(table, kc, th[0], th[1], th[2], th[3], th[4],
+                                       assembias ? th[5] : 0.0, assembias ? th[6] : 0.0);
+      prm[0][lane] = d.log_m_min;
+      prm[1][lane] = d.inv_sigma;
+      prm[2][lane] = d.m0;
+      prm[3][lane] = d.log2_m1;
+      prm[4][lane] = d.sat_scale;
+      prm[5][lane] = d.alpha;
+      prm[6][lane] = d.a_cen;
+      prm[7][lane] = d.a_sat;
+      prm[8][lane] = (double)d.bad;
     }
     __syncthreads();
     const double log_m_min = prm[0][lane];
@@ -143,6 +200,9 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     const double alpha = prm[5][lane];
     const double a_cen = assembias ? prm[6][lane] : 0.0;
     const double a_sat = assembias ? prm[7][lane] : 0.0;
+    const int bad = (int)prm[8][lane];
+    // wave-uniform: does any draw of this tile need the NaN fix-ups after a bin's node loop?
+    const bool any_bad = __builtin_amdgcn_ballot_w64(bad != 0) != 0;
 
     double sum_cen = 0.0, sum_sat = 0.0;
     for (int g = g_begin + wave; g < g_end; g += kOccWaves) {
@@ -176,6 +236,14 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
           acc = fma(weight[g * n_gauss + k], n, acc);
         }
         if (!assembias) acc *= sat_scale;
+      }
+      if (any_bad) {
+        bool tie = false;
+        if ((bad & kTieCen) && (central || modulate))
+          for (int k = 0; k < n_gauss; ++k) tie = tie || log_m[g * n_gauss + k] == log_m_min;
+        const bool cen_nan = (bad & kBadCen) || tie;
+        if (central ? cen_nan : (((bad & kBadSat) && acc != 0.0) || (modulate && cen_nan)))
+          acc = __builtin_nan("");
       }
       if (a.occupation != nullptr && b0 < a.n_draws)
         a.occupation[b0 * a.n_bins + perm[g]] = acc;
@@ -253,12 +321,12 @@ __global__ __launch_bounds__(512) void contract_mfma_kernel(ContractArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_waves = blockDim.x >> 6;
   int tile, slab;
-  if (a.n_tiles >= 8) {
+  if (a.xcd_map) {   // full chip (8 XCDs) and at least 8 draw tiles
     const int xcd = blockIdx.x & 7;
     const int rest = blockIdx.x >> 3;
     tile = (rest / a.n_slabs) * 8 + xcd;
     slab = rest % a.n_slabs;
-  } else {   // fewer draw tiles than XCDs: no padding of the grid
+  } else {   // fewer draw tiles than XCDs, or a partitioned device: plain order
     tile = blockIdx.x / a.n_slabs;
     slab = blockIdx.x % a.n_slabs;
   }
@@ -755,13 +823,8 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
 
   // everything here is latency: the draw arrives in the kernel arguments, the math tables
   // are staged in LDS
-  const double log_m_min = a.theta_value[0], sigma = a.theta_value[1];
-  const double log_m0 = a.theta_value[2], log_m1 = a.theta_value[3];
-  const double alpha = a.theta_value[4];
   const bool assembias = (a.flags & kFlagAssembias) != 0;
   const bool modulate = (a.flags & kFlagModulate) != 0;
-  const double a_cen = assembias ? a.theta_value[5] : 0.0;
-  const double a_sat = assembias ? a.theta_value[6] : 0.0;
   const int n_nodes = a.n_bins * a.n_gauss;
   {
     typedef double __attribute__((ext_vector_type(2))) double2v;
@@ -770,12 +833,13 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
     for (int i = tid; i < fm::kTableDoubles / 2; i += kSingleThreads) dst[i] = src[i];
   }
   __syncthreads();
-  const double inv_sigma = 1.0 / sigma;
-  const double m0 = fm::exp10_fast(table, kc, log_m0);
-  const double log2_m1 = log_m1 * fm::kLog2Of10Hi;
-  const double log2_m1_lo =
-      fma(log_m1, fm::kLog2Of10Hi, -log2_m1) + log_m1 * fm::kLog2Of10Lo;
-  const double sat_scale = fma(-alpha * fm::kLn2, log2_m1_lo, 1.0);
+  const DrawSetup d = prepare_draw(table, kc, a.theta_value[0], a.theta_value[1],
+                                   a.theta_value[2], a.theta_value[3], a.theta_value[4],
+                                   assembias ? a.theta_value[5] : 0.0,
+                                   assembias ? a.theta_value[6] : 0.0);
+  const double log_m_min = d.log_m_min, inv_sigma = d.inv_sigma, m0 = d.m0;
+  const double log2_m1 = d.log2_m1, sat_scale = d.sat_scale, alpha = d.alpha;
+  const double a_cen = d.a_cen, a_sat = d.a_sat;
   const double f1 = (1.0 - a.split) / a.split, f2 = a.split / (1.0 - a.split);
 
   for (int idx = tid; idx < n_nodes; idx += kSingleThreads) {
@@ -796,6 +860,12 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
       if (modulate)
         n *= fma(0.5, fm::erf_fast(table, kc, (lm - log_m_min) * inv_sigma), 0.5);
       if (assembias) n = heaviside_assembias(n, a_sat, above, f2, f1, false);
+    }
+    if (d.bad) {   // (prepare_draw: parameters the fast path cannot represent)
+      const bool cen_nan = (d.bad & kBadCen) || ((d.bad & kTieCen) && lm == log_m_min);
+      if (g < a.n_central ? cen_nan
+                          : (((d.bad & kBadSat) && n != 0.0) || (modulate && cen_nan)))
+        n = __builtin_nan("");
     }
     node_value[idx] = wk * n;
   }
@@ -904,12 +974,12 @@ __global__ __launch_bounds__(512) void contract_f32_kernel(ContractArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_waves = blockDim.x >> 6;
   int tile, slab;
-  if (a.n_tiles >= 8) {
+  if (a.xcd_map) {   // full chip (8 XCDs) and at least 8 draw tiles
     const int xcd = blockIdx.x & 7;
     const int rest = blockIdx.x >> 3;
     tile = (rest / a.n_slabs) * 8 + xcd;
     slab = rest % a.n_slabs;
-  } else {   // fewer draw tiles than XCDs: no padding of the grid
+  } else {   // fewer draw tiles than XCDs, or a partitioned device: plain order
     tile = blockIdx.x / a.n_slabs;
     slab = blockIdx.x % a.n_slabs;
   }

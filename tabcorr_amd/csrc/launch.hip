@@ -102,8 +102,8 @@ int choose_chunking(tc_table* t, int64_t n_draws, int tables_per_block,
                     DeviceChunking** out, int* lds_bytes) {
   const int64_t n_tiles = (n_draws + 63) / 64 * t->n_rtiles;
   const int elem = t->compute_dtype == TC_DTYPE_F32 ? 4 : 8;
-  const int forced_groups = env_int("TC_NGROUPS", 0);
-  const int forced_waves = env_int("TC_NWAVES", 0);
+  const int forced_groups = t->tuning.n_groups;
+  const int forced_waves = t->tuning.n_waves;
   // (the developer overrides are part of the key: sweeps stay cheap on the host)
   const int64_t key =
       (n_tiles * 4096 + forced_groups * 64 + forced_waves) * 1024 + tables_per_block;
@@ -111,14 +111,14 @@ int choose_chunking(tc_table* t, int64_t n_draws, int tables_per_block,
     auto cached = t->choices.find(key);
     if (cached != t->choices.end()) {
       *out = cached->second;
-      *lds_bytes = std::max(lds_bytes_for((*out)->host, t->rt, elem), env_int("TC_LDS_MIN", 0));
+      *lds_bytes = std::max(lds_bytes_for((*out)->host, t->rt, elem), t->tuning.lds_min);
       return TC_OK;
     }
   }
-  const int64_t min_entries = env_int("TC_MIN_CHUNK_ENTRIES", 32);
+  const int64_t min_entries = t->tuning.min_chunk_entries;
   // fixed cost of a workgroup (staging, reduction) in units of table entries
   const double overhead_entries = 24.0;
-  const int n_cus = 256;
+  const int n_cus = t->n_cus;
   double best_cost = 0.0;
   int best_chunks = 0, best_waves = 0;
   tc::Chunking trial;
@@ -174,7 +174,7 @@ int choose_chunking(tc_table* t, int64_t n_draws, int tables_per_block,
   if (status != TC_OK) return status;
   t->choices[key] = c;
   *out = c;
-  *lds_bytes = std::max(lds_bytes_for(c->host, t->rt, elem), env_int("TC_LDS_MIN", 0));
+  *lds_bytes = std::max(lds_bytes_for(c->host, t->rt, elem), t->tuning.lds_min);
   return TC_OK;
 }
 
@@ -232,9 +232,9 @@ int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, 
     *out = it->second.get();
     return TC_OK;
   }
-  // every SIMD gets `quad_waves_per_simd` waves with equal shares of the matrix-core work;
+  // every SIMD gets `tuning.quad_waves` waves with equal shares of the matrix-core work;
   // small batches use fewer waves (at least 8 units = 16 n_u instructions each)
-  const int max_waves = t->n_cus * 4 * t->quad_waves_per_simd;
+  const int max_waves = t->n_cus * 4 * std::max(1, std::min(3, t->tuning.quad_waves));
   tc::QuadSchedule schedule;
   tc::build_quad_schedule(q->layout, (int)n_tiles, t->quad_tiling.n_rtiles, n_tables, separate,
                           max_waves, 8, schedule);
@@ -256,7 +256,28 @@ int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, 
   return TC_OK;
 }
 
-int launch_contract_quad(int n_u, bool interp, const tc::QuadArgs& args, hipStream_t stream) {
+// Event pair of the next contraction launch while tc_table_timer_begin(profile = 1) is in
+// effect, else NULLs.  The events are handed to hipExtLaunchKernelGGL, which stamps them
+// with the dispatch's own begin / end -- the interval rocprofv3 --kernel-trace reports
+// (tools/micro/event_timing.hip: 35.8 us against the profiler's 35.95 for a 35 us kernel;
+// hipEventRecord before / after the launch reads 38.6).
+int next_kernel_events(tc_table* t, hipEvent_t* start, hipEvent_t* stop) {
+  *start = *stop = nullptr;
+  if (!t->profile_kernels) return TC_OK;
+  if (t->kernel_events_used == t->kernel_events.size()) {
+    hipEvent_t e0, e1;
+    TC_HIP(hipEventCreate(&e0));
+    TC_HIP(hipEventCreate(&e1));
+    t->kernel_events.emplace_back(e0, e1);
+  }
+  *start = t->kernel_events[t->kernel_events_used].first;
+  *stop = t->kernel_events[t->kernel_events_used].second;
+  ++t->kernel_events_used;
+  return TC_OK;
+}
+
+int launch_contract_quad(int n_u, bool interp, const tc::QuadArgs& args, hipStream_t stream,
+                         hipEvent_t start, hipEvent_t stop) {
   const dim3 grid((unsigned)((args.n_waves + tc::kQuadWavesPerBlock - 1) /
                              tc::kQuadWavesPerBlock));
   const dim3 block(64 * tc::kQuadWavesPerBlock);
@@ -265,9 +286,11 @@ int launch_contract_quad(int n_u, bool interp, const tc::QuadArgs& args, hipStre
 #define TC_CASE(N)                                                                          \
   case N:                                                                                   \
     if (interp)                                                                             \
-      hipLaunchKernelGGL((tc::contract_quad_kernel<N, true>), grid, block, 0, stream, args); \
+      hipExtLaunchKernelGGL((tc::contract_quad_kernel<N, true>), grid, block, 0, stream,  \
+                            start, stop, 0, args);                                        \
     else                                                                                    \
-      hipLaunchKernelGGL((tc::contract_quad_kernel<N, false>), grid, block, 0, stream, args); \
+      hipExtLaunchKernelGGL((tc::contract_quad_kernel<N, false>), grid, block, 0, stream, \
+                            start, stop, 0, args);                                        \
     break;
     TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4) TC_CASE(5)
 #undef TC_CASE
@@ -278,14 +301,17 @@ int launch_contract_quad(int n_u, bool interp, const tc::QuadArgs& args, hipStre
   return TC_OK;
 }
 
-int launch_finalize_quad(const tc::FinalizeQuadArgs& args, hipStream_t stream) {
+int launch_finalize_quad(const tc::FinalizeQuadArgs& args, const Tuning& tuning,
+                         hipStream_t stream) {
   // geometry as launch_finalize: one block per 64 draws, small batches split the rows
   const int64_t n_tiles = args.ldb / 64;
-  const int threads = env_int("TC_FINALIZE_THREADS", n_tiles < 128 ? 1024 : 256);
+  const int threads =
+      tuning.finalize_threads > 0 ? tuning.finalize_threads : n_tiles < 128 ? 1024 : 256;
   const int n_rows = args.n_comp * args.n_r;
-  const int row_blocks =
-      std::min(n_rows, env_int("TC_FINALIZE_ROW_BLOCKS",
-                               n_tiles < 128 ? (int)std::max<int64_t>(1, 512 / n_tiles) : 1));
+  const int row_blocks = std::min(
+      n_rows, tuning.finalize_row_blocks > 0
+                  ? tuning.finalize_row_blocks
+                  : n_tiles < 128 ? (int)std::max<int64_t>(1, 512 / n_tiles) : 1);
   hipLaunchKernelGGL(tc::finalize_quad_kernel, dim3((unsigned)n_tiles, (unsigned)row_blocks),
                      dim3(threads), 0, stream, args);
   TC_HIP(hipGetLastError());
@@ -295,6 +321,7 @@ int launch_finalize_quad(const tc::FinalizeQuadArgs& args, hipStream_t stream) {
 // Contraction + finalisation through the quadratic-form kernel (mode auto, float64).
 static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
                                 double* ngal_device, double* xi_device) {
+  Range range("contraction + finalisation");
   const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
   QuadTable* q = separate || t->quad_total.d_table == nullptr ? &t->quad_by_type
                                                               : &t->quad_total;
@@ -324,24 +351,13 @@ static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsig
   qa.wave_runs = (const int32_t*)schedule->wave_runs;
   qa.n_waves = schedule->n_waves;
   qa.partial = (double*)lane.partial.ptr;
-  qa.priority = env_int("TC_PRIO_C", 1);
+  qa.priority = t->tuning.prio_contract;
 
   hipEvent_t k0 = nullptr, k1 = nullptr;
-  if (t->profile_kernels) {
-    if (t->kernel_events_used == t->kernel_events.size()) {
-      hipEvent_t e0, e1;
-      TC_HIP(hipEventCreate(&e0));
-      TC_HIP(hipEventCreate(&e1));
-      t->kernel_events.emplace_back(e0, e1);
-    }
-    k0 = t->kernel_events[t->kernel_events_used].first;
-    k1 = t->kernel_events[t->kernel_events_used].second;
-    ++t->kernel_events_used;
-    TC_HIP(hipEventRecord(k0, stream));
-  }
-  status = launch_contract_quad(tiling.n_u, false, qa, stream);
+  status = next_kernel_events(t, &k0, &k1);
   if (status != TC_OK) return status;
-  if (t->profile_kernels) TC_HIP(hipEventRecord(k1, stream));
+  status = launch_contract_quad(tiling.n_u, false, qa, stream, k0, k1);
+  if (status != TC_OK) return status;
   t->last_workgroups = (schedule->n_waves + tc::kQuadWavesPerBlock - 1) / tc::kQuadWavesPerBlock;
   t->last_waves = tc::kQuadWavesPerBlock;
   t->last_splits = schedule->n_slabs;
@@ -356,7 +372,7 @@ static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsig
   fa.r_per_tile = tiling.r_per_tile;
   fa.rt = rt;
   fa.groups_per_rtile = separate ? (int)q->layout.comps.size() : 1;
-  fa.priority = env_int("TC_PRIO_F", 3);
+  fa.priority = t->tuning.prio_finalize;
   fa.n_comp = separate ? t->plan.n_components : 1;
   fa.n_r = t->n_r;
   fa.mode = t->mode;
@@ -366,7 +382,7 @@ static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsig
   fa.xi = xi_device;
   if (t->prev >= 0 && t->prev != t->cur)
     TC_HIP(hipStreamWaitEvent(stream, t->lanes[t->prev].finished, 0));
-  status = launch_finalize_quad(fa, stream);
+  status = launch_finalize_quad(fa, t->tuning, stream);
   if (status != TC_OK) return status;
   if (t->force_lane >= 0) {
     t->prev = -1;
@@ -382,16 +398,16 @@ static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsig
   TC_CASE(28) TC_CASE(32)
 
 int launch_contract_rt(int rt, dim3 grid, dim3 block, int lds, hipStream_t stream,
-                       const tc::ContractArgs& args) {
+                       const tc::ContractArgs& args, hipEvent_t start, hipEvent_t stop) {
   switch (rt) {
 #define TC_CASE(N)                                                            \
   case N:                                                                     \
     if (args.n_tables > 0)                                                    \
-      hipLaunchKernelGGL((tc::contract_mfma_kernel<N, true>), grid, block,    \
-                         lds, stream, args);                                  \
+      hipExtLaunchKernelGGL((tc::contract_mfma_kernel<N, true>), grid, block, \
+                            lds, stream, start, stop, 0, args);               \
     else                                                                      \
-      hipLaunchKernelGGL((tc::contract_mfma_kernel<N, false>), grid, block,   \
-                         lds, stream, args);                                  \
+      hipExtLaunchKernelGGL((tc::contract_mfma_kernel<N, false>), grid, block, \
+                            lds, stream, start, stop, 0, args);               \
     break;
     TC_RT_CASES
 #undef TC_CASE
@@ -404,7 +420,7 @@ int launch_contract_rt(int rt, dim3 grid, dim3 block, int lds, hipStream_t strea
 
 // float32 variant (one kernel for every r tile: always 32 wide)
 int launch_contract_f32(dim3 grid, dim3 block, int lds, hipStream_t stream,
-                        const tc::ContractArgs& args) {
+                        const tc::ContractArgs& args, hipEvent_t start, hipEvent_t stop) {
   if (lds > 64 * 1024) {
     TC_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&tc::contract_f32_kernel<false>),
@@ -414,9 +430,11 @@ int launch_contract_f32(dim3 grid, dim3 block, int lds, hipStream_t stream,
         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
   if (args.n_tables > 0)
-    hipLaunchKernelGGL(tc::contract_f32_kernel<true>, grid, block, lds, stream, args);
+    hipExtLaunchKernelGGL(tc::contract_f32_kernel<true>, grid, block, lds, stream, start, stop,
+                          0, args);
   else
-    hipLaunchKernelGGL(tc::contract_f32_kernel<false>, grid, block, lds, stream, args);
+    hipExtLaunchKernelGGL(tc::contract_f32_kernel<false>, grid, block, lds, stream, start, stop,
+                          0, args);
   TC_HIP(hipGetLastError());
   return TC_OK;
 }
@@ -444,6 +462,7 @@ int set_lds_limit_rt(int rt, int lds) {
 int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
                     double* ngal_device, double* xi_device) {
   if (t->quad) return run_contraction_quad(t, n_draws, ldb, flags, ngal_device, xi_device);
+  Range range("contraction + finalisation");
   const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
   const int n_comp = separate ? t->plan.n_components : 1;
   DeviceChunking* c = nullptr;
@@ -472,7 +491,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   ca.wave_trace = nullptr;
   ca.pos_ij = nullptr;
   ca.pos_off = (const int32_t*)t->d_pos_off;
-  if (const int ring = env_int("TC_TRACE", 0)) {
+  if (const int ring = t->tuning.trace) {
     // developer timelines: ring > 1 keeps the block records of the last `ring` launches
     // (tools/occupancy.py) and skips the per-wave stamps
     const size_t blocks = (size_t)(ldb / 64) * n_groups * t->n_rtiles;
@@ -501,7 +520,8 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   const int n_tiles = (int)(ldb / 64);
   ca.n_tiles = n_tiles;
   ca.n_slabs = n_groups;
-  const int padded_tiles = n_tiles >= 8 ? (n_tiles + 7) / 8 * 8 : n_tiles;
+  ca.xcd_map = t->n_xcds == 8 && n_tiles >= 8;
+  const int padded_tiles = ca.xcd_map ? (n_tiles + 7) / 8 * 8 : n_tiles;
   dim3 grid((unsigned)(padded_tiles * n_groups), 1, (unsigned)t->n_rtiles);
   dim3 block(64 * c->host.waves_per_group);
   if (lds > 64 * 1024) {
@@ -509,27 +529,16 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
     if (status != TC_OK) return status;
   }
   hipEvent_t k0 = nullptr, k1 = nullptr;
-  if (t->profile_kernels) {
-    if (t->kernel_events_used == t->kernel_events.size()) {
-      hipEvent_t e0, e1;
-      TC_HIP(hipEventCreate(&e0));
-      TC_HIP(hipEventCreate(&e1));
-      t->kernel_events.emplace_back(e0, e1);
-    }
-    k0 = t->kernel_events[t->kernel_events_used].first;
-    k1 = t->kernel_events[t->kernel_events_used].second;
-    ++t->kernel_events_used;
-    TC_HIP(hipEventRecord(k0, stream));
-  }
+  status = next_kernel_events(t, &k0, &k1);
+  if (status != TC_OK) return status;
   if (t->compute_dtype == TC_DTYPE_F32) {
     ca.pos_ij = (const int32_t*)t->d_pos_ij;
-    status = launch_contract_f32(grid, block, lds, stream, ca);
+    status = launch_contract_f32(grid, block, lds, stream, ca, k0, k1);
     if (status != TC_OK) return status;
   } else {
-    status = launch_contract_rt(t->rt, grid, block, lds, stream, ca);
+    status = launch_contract_rt(t->rt, grid, block, lds, stream, ca, k0, k1);
     if (status != TC_OK) return status;
   }
-  if (t->profile_kernels) TC_HIP(hipEventRecord(k1, stream));
   t->last_workgroups = n_tiles * n_groups * t->n_rtiles;
   t->last_waves = c->host.waves_per_group;
   t->last_splits = n_groups;
@@ -554,10 +563,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   // (host-buffer calls synchronise before returning and need no chaining)
   if (t->prev >= 0 && t->prev != t->cur)
     TC_HIP(hipStreamWaitEvent(stream, t->lanes[t->prev].finished, 0));
-#ifdef TC_DEVELOPER_KNOBS
-  if (!env_int("TC_SKIP_FINALIZE", 0))
-#endif
-  status = launch_finalize(fa, stream);
+  if (!t->tuning.skip_finalize) status = launch_finalize(fa, t->tuning, stream);
   if (status != TC_OK) return status;
   if (t->force_lane >= 0) {
     t->prev = -1;
@@ -572,6 +578,7 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
                    int64_t n_draws, int64_t ldb, int n_gauss, unsigned flags,
                    double* occupation_device, DeviceBuffer* nbuf, DeviceBuffer* ngal2,
                    hipStream_t stream, int* ngal_parts) {
+  Range range("occupation");
   tc_table::Lane& lane = t->lanes[t->cur];
   if (nbuf == nullptr) nbuf = &lane.nbuf;
   if (ngal2 == nullptr) ngal2 = &lane.ngal2;
@@ -588,7 +595,7 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   const int64_t n_tiles = ldb / 64;
   int splits = 1, grid_blocks = 1;
   {
-    const int n_cus = 256;
+    const int n_cus = t->n_cus;
     const int64_t slots = (int64_t)n_cus * 4;
     const int max_splits = (t->n_bins + tc::kOccWaves - 1) / tc::kOccWaves;
     double best = 0.0;
@@ -611,12 +618,12 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
         grid_blocks = (int)std::min<int64_t>(items, slots);
       }
     }
-    const int forced = env_int("TC_OCC_SPLITS", 0);
+    const int forced = t->tuning.occ_splits;
     if (forced > 0) {
       const int per_block = (t->n_bins + forced - 1) / forced;
       splits = (t->n_bins + per_block - 1) / per_block;
       grid_blocks = (int)std::min<int64_t>(
-          n_tiles * splits, (int64_t)n_cus * std::max(1, env_int("TC_OCC_PER_CU", 4)));
+          n_tiles * splits, (int64_t)n_cus * std::max(1, t->tuning.occ_per_cu));
     }
   }
   status = nbuf->reserve((size_t)t->n_bins * ldb * sizeof(double), stream);
@@ -634,7 +641,7 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   oa.n_gauss = n_gauss;
   oa.n_tiles = (int)n_tiles;
   oa.n_splits = splits;
-  oa.flags = flags | ((unsigned)env_int("TC_PRIO_O", 0) << 8);
+  oa.flags = flags | ((unsigned)(t->tuning.prio_occ & 3) << 8);
   oa.split = 0.5;
   oa.log_m = (const double*)q->log_m;
   oa.m = (const double*)q->m;
@@ -652,11 +659,9 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
     const bool modulate = (flags & TC_FLAG_MODULATE_WITH_CENOCC) != 0;
 #define TC_OCC(NG, AB, MO)                                                           \
   hipLaunchKernelGGL((tc::occ_zheng07_kernel<NG, AB, MO>), grid, block, 0, stream, oa)
-#ifdef TC_DEVELOPER_KNOBS
-    // diagnosis only (tools/ab.sh): reuse the densities of the previous call
+    // diagnosis only (developer builds, tools/ab.sh): reuse the densities of the previous call
     static int occ_calls = 0;
-    if (env_int("TC_SKIP_OCC", 0) && ++occ_calls > 8) return TC_OK;
-#endif
+    if (t->tuning.skip_occ && ++occ_calls > 8) return TC_OK;
     if (n_gauss == 10) {
       if (!assembias && !modulate) TC_OCC(10, false, false);
       else if (!assembias) TC_OCC(10, false, true);
@@ -690,7 +695,7 @@ int check_predict_args(const tc_table* t, const void* theta, int n_theta,
 bool single_draw_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags) {
   return n_draws == 1 && t->compute_dtype == TC_DTYPE_F64 && t->n_rtiles == 1 &&
          !(flags & TC_FLAG_SEPARATE_GAL_TYPE) && t->n_bins <= tc::kSingleMaxBins &&
-         (int64_t)t->n_bins * n_gauss <= tc::kSingleMaxNodes && env_int("TC_SINGLE_DRAW", 1);
+         (int64_t)t->n_bins * n_gauss <= tc::kSingleMaxNodes && t->tuning.single_draw;
 }
 
 int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_gauss,
@@ -737,16 +742,18 @@ int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_gaus
   return TC_OK;
 }
 
-int launch_finalize(const FinalizeArgs& args, hipStream_t stream) {
+int launch_finalize(const FinalizeArgs& args, const Tuning& tuning, hipStream_t stream) {
   // one block per draw tile; a wave sums one (component, r) row at a time over the slabs,
   // so small batches (few blocks, latency-bound) get 16 waves per block instead of 4
   // and split the rows over several blocks (up to ~512 blocks in all)
   const int64_t n_tiles = args.ldb / 64;
-  const int threads = env_int("TC_FINALIZE_THREADS", n_tiles < 128 ? 1024 : 256);
+  const int threads =
+      tuning.finalize_threads > 0 ? tuning.finalize_threads : n_tiles < 128 ? 1024 : 256;
   const int n_rows = args.n_comp * args.n_r;
   const int row_blocks = std::min(
-      n_rows, env_int("TC_FINALIZE_ROW_BLOCKS",
-                      n_tiles < 128 ? (int)std::max<int64_t>(1, 512 / n_tiles) : 1));
+      n_rows, tuning.finalize_row_blocks > 0
+                  ? tuning.finalize_row_blocks
+                  : n_tiles < 128 ? (int)std::max<int64_t>(1, 512 / n_tiles) : 1);
   hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)n_tiles, (unsigned)row_blocks),
                      dim3(threads), 0, stream, args);
   TC_HIP(hipGetLastError());

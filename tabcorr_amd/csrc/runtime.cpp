@@ -1,6 +1,8 @@
 // Runtime and host-side helper entry points of the C ABI (include/tabcorr_amd.h):
 // error reporting, device management, and the pure host functions (quadrature nodes,
 // pair indices, spline matrices, plan self-check) that are testable without a GPU.
+#include <dlfcn.h>
+
 #include "internal.h"
 
 namespace tc {
@@ -8,6 +10,52 @@ namespace host {
 
 namespace {
 thread_local std::string g_last_error;
+}
+
+// roctx: librocprofiler-sdk-roctx is what rocprofv3 --marker-trace listens to; the older
+// roctracer library is the fallback.  Resolved on first use, never required.
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+};
+const Roctx& roctx() {
+  static const Roctx table = [] {
+    Roctx r;
+    // only when a profiler is in the process (rocprofv3 preloads its tool library) or the
+    // application itself already uses roctx: a plain run never loads anything
+    bool profiled = false;
+    for (const char* name : {"librocprofiler-sdk-tool.so", "librocprofiler-sdk-tool.so.1",
+                             "librocprofiler-sdk-roctx.so.1", "libroctx64.so.4"})
+      if (void* handle = dlopen(name, RTLD_NOLOAD | RTLD_NOW)) {
+        profiled = true;
+        (void)handle;
+      }
+    if (!profiled) return r;
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so",
+                             "libroctx64.so.4", "libroctx64.so"}) {
+      void* handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (handle == nullptr) continue;
+      *(void**)(&r.push) = dlsym(handle, "roctxRangePushA");
+      *(void**)(&r.pop) = dlsym(handle, "roctxRangePop");
+      if (r.push != nullptr && r.pop != nullptr) break;
+      r.push = nullptr;
+      r.pop = nullptr;
+    }
+    return r;
+  }();
+  return table;
+}
+}  // namespace
+
+void range_push(const char* name) {
+  const Roctx& r = roctx();
+  if (r.push != nullptr) (void)r.push(name);
+}
+
+void range_pop() {
+  const Roctx& r = roctx();
+  if (r.pop != nullptr) (void)r.pop();
 }
 
 int fail(int code, const char* format, ...) {
@@ -153,7 +201,7 @@ int tc_plan_debug(int mode, int n_bins, const uint8_t* is_central, int n_chunks,
   TC_CHECK(mode == TC_MODE_AUTO || mode == TC_MODE_CROSS, "invalid mode");
   TC_CHECK(n_bins >= 1 && is_central && n_entries, "invalid arguments");
   tc::Plan plan;
-  tc::build_plan(mode, n_bins, is_central, tc::kF64Block, env_int("TC_ROW_BUDGET", 56),
+  tc::build_plan(mode, n_bins, is_central, tc::kF64Block, 56,
                  plan);
   tc::Chunking chunking;
   tc::build_chunking(plan, n_chunks, 4, chunking);

@@ -43,7 +43,10 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
     hipDeviceProp_t prop;
     TC_HIP(hipGetDeviceProperties(&prop, t->device));
     t->n_cus = std::max(1, prop.multiProcessorCount);
+    // MI355X: 8 accelerator complexes (XCDs) of 32 CUs; a compute partition exposes fewer
+    t->n_xcds = std::max(1, t->n_cus / 32);
   }
+  t->tuning.load();
   t->mode = mode;
   t->n_bins = n_bins;
   t->n_r = n_r;
@@ -58,7 +61,7 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
   if (compute_dtype == TC_DTYPE_F32) {
     t->rt = tc::kF32Tile;
     tc::build_plan(mode, n_bins, is_central, tc::kF32Block,
-                   env_int("TC_ROW_BUDGET_F32", 128), t->plan);
+                   env_int("TC_ROW_BUDGET_F32", 128), t->plan);   // (developer builds)
   } else {
     int rt = (n_r + t->n_rtiles - 1) / t->n_rtiles;
     t->rt = (rt + 3) / 4 * 4;
@@ -143,7 +146,7 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
     TC_HIP(hipEventCreateWithFlags(&lane.finished, hipEventDisableTiming));
   }
   t->stream = t->lanes[0].stream;
-  t->n_lanes = std::max(1, std::min(env_int("TC_LANES", 4), (int)tc_table::kMaxLanes));
+  t->n_lanes = std::max(1, std::min(t->tuning.lanes, (int)tc_table::kMaxLanes));
   TC_HIP(hipEventCreate(&t->ev_begin));
   TC_HIP(hipEventCreate(&t->ev_end));
   int status = compute_dtype == TC_DTYPE_F64 ? upload(tmp64, &t->d_table)
@@ -165,7 +168,6 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
     // whole 4 x 4 blocks, the unpadded triangle for the total prediction
     t->quad = true;
     t->quad_tiling = tc::quad_tiling(n_r);
-    t->quad_waves_per_simd = std::max(1, std::min(3, env_int("TC_QUAD_WAVES", 2)));
     status = build_quad_table(t.get(), true, tpcf_matrix, matrix_dtype, &t->quad_by_type);
     const int n_central = t->plan.n_central;
     if (status == TC_OK && n_central % 4 != 0 && n_central < n_bins)
@@ -199,6 +201,7 @@ int tc_table_destroy(tc_table* t) {
     lane.nbuf.release();
     lane.ngal2.release();
     lane.partial.release();
+    lane.xi.release();
     if (lane.finished) (void)hipEventDestroy(lane.finished);
   }
   t->h_in.release();
@@ -247,7 +250,7 @@ int tc_predict_zheng07_batch_device(tc_table* t, const double* theta_device,
   if (t->force_lane >= 0)
     t->cur = t->force_lane;
   else
-    t->cur = env_int("TC_PIPELINE", 1) ? (int)(t->device_calls++ % t->n_lanes) : 0;
+    t->cur = t->tuning.pipeline ? (int)(t->device_calls++ % t->n_lanes) : 0;
   const int64_t slab = max_slab(t);
   for (int64_t begin = 0; begin < n_draws; begin += slab) {
     const int64_t n = std::min(slab, n_draws - begin);
@@ -271,6 +274,7 @@ namespace host {
 // Host -> device copy of a small input through the pinned staging buffer.
 int copy_in(PinnedBuffer* stage, void* device, const void* host, size_t bytes,
             hipStream_t stream) {
+  Range range("upload");
   if (bytes <= stage_limit() && stage->reserve(bytes) == TC_OK) {
     memcpy(stage->ptr, host, bytes);
     host = stage->ptr;
@@ -282,6 +286,7 @@ int copy_in(PinnedBuffer* stage, void* device, const void* host, size_t bytes,
 // Device -> host copy of [ngal | xi], synchronising the stream.
 int copy_out(PinnedBuffer* stage, double* ngal, size_t ngal_count, const void* d_ngal,
              double* xi, size_t xi_count, const void* d_xi, hipStream_t stream) {
+  Range range("download");
   const size_t bytes = (ngal_count + xi_count) * sizeof(double);
   if (bytes <= stage_limit() && stage->reserve(bytes) == TC_OK) {
     double* h = (double*)stage->ptr;
@@ -359,6 +364,66 @@ int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
                   t->out_xi.ptr, t->stream);
 }
 
+namespace {
+
+// The data vector and the precision matrix of a likelihood do not change between calls:
+// they are uploaded when they differ from the host copy of the last upload.
+int upload_chi2_data(tc_table* t, const double* data, const double* precision) {
+  const int n_r = t->n_r;
+  int status = t->chi2_data.reserve((size_t)(n_r + 1) * n_r * 8, t->stream);
+  if (status != TC_OK) return status;
+  const size_t data_count = (size_t)(n_r + 1) * n_r;
+  if (t->chi2_host.size() != data_count ||
+      memcmp(t->chi2_host.data(), data, (size_t)n_r * 8) != 0 ||
+      memcmp(t->chi2_host.data() + n_r, precision, (size_t)n_r * n_r * 8) != 0) {
+    // (kernels of earlier calls may still be reading the old values)
+    for (tc_table::Lane& lane : t->lanes) TC_HIP(hipStreamSynchronize(lane.stream));
+    t->chi2_host.assign(data, data + n_r);
+    t->chi2_host.insert(t->chi2_host.end(), precision, precision + (size_t)n_r * n_r);
+    TC_HIP(hipMemcpyAsync(t->chi2_data.ptr, t->chi2_host.data(), data_count * 8,
+                          hipMemcpyHostToDevice, t->stream));
+    TC_HIP(hipStreamSynchronize(t->stream));
+  }
+  return TC_OK;
+}
+
+}  // namespace
+
+int tc_chi2_zheng07_batch_device(tc_table* t, const double* theta_device, int n_theta,
+                                 int64_t n_draws, int n_gauss, unsigned flags,
+                                 const double* data, const double* precision,
+                                 double* ngal_device, double* chi2_device) {
+  int status = check_predict_args(t, theta_device, n_theta, n_draws, n_gauss, flags);
+  if (status != TC_OK) return status;
+  TC_CHECK(!(flags & TC_FLAG_SEPARATE_GAL_TYPE),
+           "chi2 is defined for the total correlation function only");
+  if (n_draws == 0) return TC_OK;
+  TC_CHECK(data && precision && ngal_device && chi2_device, "NULL pointer");
+  TC_CHECK(n_draws <= max_slab(t), "at most %lld draws per call",
+           (long long)max_slab(t));
+  TC_HIP(hipSetDevice(t->device));
+  status = upload_chi2_data(t, data, precision);
+  if (status != TC_OK) return status;
+  // xi stays in a workspace of the lane the call runs on; the lane's `finished` event is
+  // re-recorded behind the chi2 kernel, so the next call on this lane (whose finalisation
+  // waits for that event through the chain of lanes) cannot overwrite it early
+  const int lane_index =
+      t->force_lane >= 0 ? t->force_lane
+                         : t->tuning.pipeline ? (int)(t->device_calls % t->n_lanes) : 0;
+  tc_table::Lane& lane = t->lanes[lane_index];
+  status = lane.xi.reserve((size_t)n_draws * t->n_r * 8, lane.stream);
+  if (status != TC_OK) return status;
+  status = tc_predict_zheng07_batch_device(t, theta_device, n_theta, n_draws, n_gauss, flags,
+                                           ngal_device, (double*)lane.xi.ptr);
+  if (status != TC_OK) return status;
+  const double* d_data = (const double*)t->chi2_data.ptr;
+  status = launch_chi2((const double*)lane.xi.ptr, n_draws, t->n_r, d_data, d_data + t->n_r,
+                       chi2_device, lane.stream);
+  if (status != TC_OK) return status;
+  if (t->force_lane < 0) TC_HIP(hipEventRecord(lane.finished, lane.stream));
+  return TC_OK;
+}
+
 int tc_chi2_zheng07_batch(tc_table* t, const double* theta, int n_theta,
                           int64_t n_draws, int n_gauss, unsigned flags,
                           const double* data, const double* precision, double* ngal,
@@ -374,22 +439,10 @@ int tc_chi2_zheng07_batch(tc_table* t, const double* theta, int n_theta,
   const size_t xi_count = (size_t)n_draws * n_r;
   const size_t theta_bytes = (size_t)n_draws * n_theta * sizeof(double);
   status = t->out_xi.reserve(xi_count * 8, t->stream);
-  if (status == TC_OK) status = t->chi2_data.reserve((size_t)(n_r + 1) * n_r * 8, t->stream);
+  if (status == TC_OK) status = upload_chi2_data(t, data, precision);
   if (status != TC_OK) return status;
-  // the data vector and the precision matrix of a likelihood do not change between calls:
-  // they are uploaded when they differ from the host copy of the last upload
   double* d_data = (double*)t->chi2_data.ptr;
   double* d_precision = d_data + n_r;
-  const size_t data_count = (size_t)(n_r + 1) * n_r;
-  if (t->chi2_host.size() != data_count ||
-      memcmp(t->chi2_host.data(), data, (size_t)n_r * 8) != 0 ||
-      memcmp(t->chi2_host.data() + n_r, precision, (size_t)n_r * n_r * 8) != 0) {
-    t->chi2_host.assign(data, data + n_r);
-    t->chi2_host.insert(t->chi2_host.end(), precision, precision + (size_t)n_r * n_r);
-    TC_HIP(hipMemcpyAsync(d_data, t->chi2_host.data(), data_count * 8,
-                          hipMemcpyHostToDevice, t->stream));
-    TC_HIP(hipStreamSynchronize(t->stream));
-  }
   // small calls: draws read from and results written to page-locked host memory directly
   const bool direct = theta_bytes + (size_t)n_draws * 16 <= zero_copy_limit() &&
                       t->h_in.reserve(theta_bytes) == TC_OK &&
@@ -498,6 +551,25 @@ int tc_predict_occupation_batch(tc_table* t, const double* occupation,
                       t->out_ngal.ptr, xi + begin * n_comp * t->n_r, xi_count,
                       t->out_xi.ptr, t->stream);
     if (status != TC_OK) return status;
+  }
+  return TC_OK;
+}
+
+int tc_table_set_option(tc_table* t, const char* name, int value) {
+  TC_CHECK(t != nullptr && name != nullptr, "NULL argument");
+  const std::string key(name);
+  if (key == "pipeline") {
+    t->tuning.pipeline = value != 0;
+  } else if (key == "lanes") {
+    TC_CHECK(value >= 1 && value <= (int)tc_table::kMaxLanes, "lanes must be in [1, %d]",
+             (int)tc_table::kMaxLanes);
+    for (tc_table::Lane& lane : t->lanes) TC_HIP(hipStreamSynchronize(lane.stream));
+    t->tuning.lanes = t->n_lanes = value;
+    t->prev = -1;
+  } else if (key == "single_draw") {
+    t->tuning.single_draw = value != 0;
+  } else {
+    return fail(TC_ERR_INVALID, "unknown option '%s'", name);
   }
   return TC_OK;
 }

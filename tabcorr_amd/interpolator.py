@@ -19,6 +19,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
+from .galtable import GalTypeTable
 from .models import device_spec
 from .tabcorr import TabCorr, XI_KEYS, NGAL_KEYS, _flags, _unbatch
 
@@ -109,9 +110,12 @@ class Interpolator:
         # Grid order (lexicographic in the keys), as the sorted table with its
         # tabcorr_index column in the reference (interpolator.py:59-61).
         self.order = np.lexsort(self.points.T[::-1])
-        self.param_dict_table = {
-            key: self.points[self.order, d] for d, key in enumerate(self.keys)}
-        self.param_dict_table['tabcorr_index'] = self.order.copy()
+        columns = {key: self.points[self.order, d]
+                   for d, key in enumerate(self.keys)}
+        columns['tabcorr_index'] = self.order.copy()
+        # (a column table with ``colnames`` / ``[name]`` / ``len`` like the
+        # astropy Table of the reference)
+        self.param_dict_table = GalTypeTable(columns)
         self._device = None
         self._a = None
 
@@ -157,7 +161,9 @@ class Interpolator:
             return
         x = np.atleast_2d(x)
         for d, xp in enumerate(self.xp):
-            if np.any(x[:, d] < xp[0]) or np.any(x[:, d] > xp[-1]):
+            # (NaN fails the test, as np.digitize puts it past the last node:
+            # interpolator.py:318-326)
+            if not np.all((x[:, d] >= xp[0]) & (x[:, d] <= xp[-1])):
                 raise ValueError(OUT_OF_RANGE)
 
     # -- predict -------------------------------------------------------------------

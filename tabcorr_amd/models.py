@@ -112,6 +112,9 @@ class Zheng07Model:
 
 def _heaviside(baseline, percentile, strength, upper, split):
     f1, f2 = 1.0 - split, split
+    # halotools clips the strength to [-1, 1] (NaN stays NaN)
+    strength = 1.0 if strength > 1 else strength
+    strength = -1.0 if strength < -1 else strength
     if strength >= 0:
         dmax = np.minimum(upper - baseline, baseline * f2 / f1)
     else:
@@ -132,9 +135,26 @@ class DeviceSpec:
 
 def device_spec(model):
     """Return a `DeviceSpec` if the kernel can evaluate ``model``, else None.
+
+    The test is strict: the kernel implements exactly the plain Zheng07
+    centrals / satellites and their Heaviside assembly-bias decoration with
+    one constant strength per galaxy type and a split at the median.  A model
+    that merely *looks* like one of those (same class names, but several
+    strength abscissae, another split, an overridden occupation method, a
+    satellite model modulated by something other than Zheng07 centrals)
+    takes the generic route -- callbacks on the host, contraction on the
+    device -- which is always correct.
     """
-    kind = getattr(model, '_tabcorr_amd_device_model', None)
-    if kind == 'zheng07':
+    if getattr(model, '_tabcorr_amd_device_model', None) == 'zheng07':
+        cls = type(model)
+        if (getattr(cls, 'mean_occupation_centrals', None) is not
+                Zheng07Model.mean_occupation_centrals or
+                getattr(cls, 'mean_occupation_satellites', None) is not
+                Zheng07Model.mean_occupation_satellites or
+                'mean_occupation_centrals' in vars(model) or
+                'mean_occupation_satellites' in vars(model) or
+                getattr(model, 'split', 0.5) != 0.5):
+            return None
         return _spec_from(model, model.modulate_with_cenocc, model.assembias)
 
     components = getattr(model, '_input_model_dictionary', None)
@@ -145,19 +165,60 @@ def device_spec(model):
         sats = components['satellites_occupation']
     except KeyError:
         return None
-    names = (type(cens).__name__, type(sats).__name__)
-    if names == ('Zheng07Cens', 'Zheng07Sats'):
+    if _halotools_name(cens) == 'Zheng07Cens' and \
+            _halotools_name(sats) == 'Zheng07Sats':
         assembias = False
-    elif names == ('AssembiasZheng07Cens', 'AssembiasZheng07Sats'):
+    elif _halotools_name(cens) == 'AssembiasZheng07Cens' and \
+            _halotools_name(sats) == 'AssembiasZheng07Sats':
         assembias = True
-        # Only the default single split at the median maps onto the kernel.
         for component in (cens, sats):
-            if getattr(component, '_split_abscissa', [0.5]) != [0.5]:
+            if not _plain_heaviside(component):
                 return None
     else:
         return None
-    return _spec_from(model, getattr(sats, 'modulate_with_cenocc', False),
-                      assembias)
+    for component in (cens, sats):
+        # an instance-level override of the occupation function
+        if 'mean_occupation' in vars(component):
+            return None
+    modulate = bool(getattr(sats, 'modulate_with_cenocc', False))
+    if modulate:
+        # <N_sat> is multiplied by the occupation of
+        # ``sats.central_occupation_model``: only plain Zheng07 centrals
+        # (sharing logMmin / sigma_logM through the composite param_dict)
+        # are what the kernel multiplies with
+        if _halotools_name(getattr(sats, 'central_occupation_model',
+                                   None)) != 'Zheng07Cens':
+            return None
+    param_dict = getattr(model, 'param_dict', {})
+    allowed = set(ASSEMBIAS_KEYS) if assembias else set()
+    for key in param_dict:
+        if 'assembias' in str(key) and key not in allowed:
+            return None      # e.g. ..._assembias_param2: mass-dependent strength
+    return _spec_from(model, modulate, assembias)
+
+
+def _halotools_name(component):
+    """Class name of a halotools component, or None for anything that is not
+    an instance of a class defined by halotools itself (a user subclass may
+    override what the kernel assumes)."""
+    cls = type(component)
+    if not str(getattr(cls, '__module__', '')).startswith('halotools.'):
+        return None
+    return cls.__name__
+
+
+def _plain_heaviside(component):
+    """True if a HeavisideAssembias-decorated component has the only shape
+    the kernel implements: one strength abscissa (constant strength) and a
+    constant split at the median."""
+    try:
+        if len(component._assembias_strength_abscissa) != 1:
+            return False
+        ordinates = np.atleast_1d(np.asarray(
+            component._split_ordinates, dtype=np.float64))
+    except (AttributeError, TypeError, ValueError):
+        return False
+    return len(ordinates) >= 1 and bool(np.all(ordinates == 0.5))
 
 
 def _spec_from(model, modulate, assembias):

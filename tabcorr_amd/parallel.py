@@ -11,8 +11,9 @@ Control plane (rendezvous, barrier, scalar reductions, exchange of the RCCL
 unique id): ``torch.distributed`` with the ``gloo`` backend on CPU tensors --
 PyTorch never touches the GPU here.  Data plane: ``ncclGather`` of RCCL over
 xGMI through the C ABI (``tc_comm_*``), on device buffers owned by this
-library.  When RCCL is unavailable (e.g. the CPU-only tests) the gather falls
-back to gloo on host arrays; the result is identical.
+library, for every sharded variant (single table or interpolator, total or
+separated by galaxy type).  When RCCL is unavailable (e.g. the CPU-only
+tests) the gather falls back to gloo on host arrays; the result is identical.
 """
 
 import ctypes
@@ -103,46 +104,53 @@ class Communicator:
         return 'rccl' if self.comm is not None else 'gloo'
 
     def _init_rccl(self):
+        """Create the RCCL communicator, or fall back to gloo on EVERY rank.
+
+        Every local failure (library missing, no device, librccl not
+        loadable) becomes this rank's ``ok = 0`` contribution to the first
+        all_reduce, so that all ranks run the same sequence of gloo
+        collectives and agree on the outcome -- a rank that cannot use RCCL
+        must not leave the others waiting in ncclCommInitRank.
+        """
         import torch
+        lib = None
+        error = None
+        buffer = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
         try:
             lib = _lib.load()
             if _lib.device_count() < 1:
                 raise _lib.TabCorrHipError('no HIP device')
             _lib.check(lib.tc_set_device(self.local_rank))
-            # Every rank probes librccl (ncclGetUniqueId) before any rank enters the
-            # blocking ncclCommInitRank: a rank that cannot load RCCL must not leave
-            # the others waiting for it.
-            unique = torch.zeros(_lib.UNIQUE_ID_BYTES, dtype=torch.uint8)
-            buffer = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
-            ok = torch.tensor(
-                [1 if lib.tc_comm_unique_id(buffer) == _lib.TC_OK else 0],
-                dtype=torch.int32)
-            if self.rank == 0 and ok.item() == 1:
-                unique = torch.frombuffer(
-                    bytearray(buffer.raw), dtype=torch.uint8).clone()
-            self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
-            if ok.item() == 0:
-                raise _lib.TabCorrHipError(
-                    'RCCL is not usable on every rank: ' +
-                    lib.tc_last_error().decode(errors='replace'))
-            self.dist.broadcast(unique, 0)
-            handle = ctypes.c_void_p()
-            raw = bytes(unique.numpy().tobytes())
-            status = lib.tc_comm_create(raw, self.world_size, self.rank,
-                                        ctypes.byref(handle))
-            good = torch.tensor([1 if status == _lib.TC_OK else 0],
-                                dtype=torch.int32)
-            self.dist.all_reduce(good, op=self.dist.ReduceOp.MIN)
-            if good.item() == 0:
-                if status == _lib.TC_OK:
-                    lib.tc_comm_destroy(handle)
-                raise _lib.TabCorrHipError(
-                    'ncclCommInitRank failed on some rank: ' +
-                    lib.tc_last_error().decode(errors='replace'))
-            self.comm = handle
-        except (_lib.TabCorrHipError, OSError) as error:
-            self.comm = None
-            self.rccl_error = str(error)
+            _lib.check(lib.tc_comm_unique_id(buffer))
+        except (_lib.TabCorrHipError, OSError, ValueError,
+                NotImplementedError) as exc:
+            error = str(exc)
+        ok = torch.tensor([0 if error else 1], dtype=torch.int32)
+        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
+        unique = torch.zeros(_lib.UNIQUE_ID_BYTES, dtype=torch.uint8)
+        if self.rank == 0 and error is None:
+            unique = torch.frombuffer(
+                bytearray(buffer.raw), dtype=torch.uint8).clone()
+        self.dist.broadcast(unique, 0)
+        if ok.item() == 0:
+            self.rccl_error = error or 'RCCL is not usable on every rank'
+            return
+        handle = ctypes.c_void_p()
+        raw = bytes(unique.numpy().tobytes())
+        status = lib.tc_comm_create(raw, self.world_size, self.rank,
+                                    ctypes.byref(handle))
+        if status != _lib.TC_OK:
+            error = lib.tc_last_error().decode(errors='replace')
+        good = torch.tensor([1 if status == _lib.TC_OK else 0],
+                            dtype=torch.int32)
+        self.dist.all_reduce(good, op=self.dist.ReduceOp.MIN)
+        if good.item() == 0:
+            if status == _lib.TC_OK:
+                lib.tc_comm_destroy(handle)
+            self.rccl_error = ('ncclCommInitRank failed on some rank' +
+                               (': ' + error if error else ''))
+            return
+        self.comm = handle
 
     # -- control plane -----------------------------------------------------
 
@@ -183,16 +191,28 @@ class Communicator:
         self.dist.gather(tensor, None, dst=0)
         return None
 
-    def gather_device(self, table_handle, send_ptr, recv_ptr, count, slot=0):
+    def gather_device(self, table_handle, send_ptr, recv_ptr, count, slot=0,
+                      interp_handle=None):
         """ncclGather of ``count`` doubles per rank from ``send_ptr`` into
-        ``recv_ptr`` (root), queued behind the work on the table's stream."""
-        _lib.check(_lib.load().tc_comm_gather(
-            self.comm, table_handle, send_ptr, recv_ptr, count, 0, slot))
+        ``recv_ptr`` (root), queued behind the work on the table's (or the
+        interpolator's) stream."""
+        lib = _lib.load()
+        if interp_handle is not None:
+            _lib.check(lib.tc_comm_gather_interp(
+                self.comm, interp_handle, send_ptr, recv_ptr, count, 0, slot))
+        else:
+            _lib.check(lib.tc_comm_gather(
+                self.comm, table_handle, send_ptr, recv_ptr, count, 0, slot))
 
-    def release(self, table_handle, slot=0):
-        """Device-side wait of the table's stream for the gather of ``slot``.
-        """
-        _lib.check(_lib.load().tc_comm_release(self.comm, table_handle, slot))
+    def release(self, table_handle, slot=0, interp_handle=None):
+        """Device-side wait of the producer's stream for the gather of
+        ``slot``."""
+        lib = _lib.load()
+        if interp_handle is not None:
+            _lib.check(lib.tc_comm_release_interp(self.comm, interp_handle,
+                                                  slot))
+        else:
+            _lib.check(lib.tc_comm_release(self.comm, table_handle, slot))
 
     def synchronize(self):
         if self.comm is not None:
@@ -237,38 +257,63 @@ class _DeviceArray:
             self.ptr = ctypes.c_void_p()
 
 
-def _predict_sharded_rccl(halotab, theta, communicator, n_gauss_prim=10,
-                          modulate_with_cenocc=False, assembias=False):
-    """Total prediction of a single table with the results gathered on the
-    root over RCCL: device buffers end to end, one ``ncclGather``."""
+def _predict_sharded_rccl(predictor, theta, communicator, x=None,
+                          separate_gal_type=False, n_gauss_prim=10,
+                          modulate_with_cenocc=False, assembias=False,
+                          extrapolate=False):
+    """Device buffers end to end, one ``ncclGather``: every rank evaluates its
+    round-robin share (``TabCorr`` or, with ``x``, ``Interpolator``; total or
+    per-galaxy-type prediction) into ``[ngal | xi]`` on its GPU, RCCL collects
+    the blocks on the root, the root downloads once and undoes the
+    round-robin split."""
     from .tabcorr import _flags
     n_draws = len(theta)
-    shard = local_shard(theta, communicator.rank, communicator.world_size)
-    device = halotab.to_device()
-    n_local, n_r = len(shard), device.n_r
-    count = n_local * (1 + n_r)
+    rank, world = communicator.rank, communicator.world_size
+    shard = local_shard(theta, rank, world)
+    device = predictor.to_device()
+    lib = device.lib
+    if x is not None:
+        predictor._check_range(x, extrapolate)     # same outcome on every rank
+        x_shard = local_shard(x, rank, world)
+        table = device.tables[0]
+        first = predictor.tabcorr_list[0]
+    else:
+        table = device
+        first = predictor
+    n_local, n_r = len(shard), table.n_r
+    n_ngal = 2 if separate_gal_type else 1
+    n_comp = table.n_components if separate_gal_type else 1
+    count = n_local * (n_ngal + n_comp * n_r)
+    flags = _flags(separate_gal_type, modulate_with_cenocc, assembias)
     d_theta = _DeviceArray(shard.size)
     d_theta.upload(shard)
     d_out = _DeviceArray(count)
-    d_recv = _DeviceArray(count * communicator.world_size
-                          if communicator.is_root else 0)
-    _lib.check(device.lib.tc_predict_zheng07_batch_device(
-        device.handle, d_theta.ptr, shard.shape[1], n_local, n_gauss_prim,
-        _flags(False, modulate_with_cenocc, assembias), d_out.ptr,
-        d_out.offset(n_local)))
-    communicator.gather_device(
-        device.handle, d_out.ptr,
-        d_recv.ptr if communicator.is_root else None, count, 0)
+    d_recv = _DeviceArray(count * world if communicator.is_root else 0)
+    if x is not None:
+        d_x = _DeviceArray(x_shard.size)
+        d_x.upload(x_shard)
+        _lib.check(lib.tc_interp_predict_zheng07_batch_device(
+            device.handle, d_theta.ptr, shard.shape[1], d_x.ptr, n_local,
+            n_gauss_prim, flags, d_out.ptr, d_out.offset(n_local * n_ngal)))
+        communicator.gather_device(
+            None, d_out.ptr, d_recv.ptr if communicator.is_root else None,
+            count, 0, interp_handle=device.handle)
+    else:
+        _lib.check(lib.tc_predict_zheng07_batch_device(
+            device.handle, d_theta.ptr, shard.shape[1], n_local, n_gauss_prim,
+            flags, d_out.ptr, d_out.offset(n_local * n_ngal)))
+        communicator.gather_device(
+            device.handle, d_out.ptr,
+            d_recv.ptr if communicator.is_root else None, count, 0)
     communicator.synchronize()
     if not communicator.is_root:
         return None
-    flat = d_recv.download().reshape(communicator.world_size, count)
-    parts = [np.concatenate([part[:n_local, np.newaxis],
-                             part[n_local:].reshape(n_local, n_r)], axis=1)
-             for part in flat]
-    full = assemble(parts, n_draws)
-    return full[:, 0], full[:, 1:].reshape((n_draws, ) + tuple(
-        halotab.tpcf_shape))
+    flat = d_recv.download().reshape(world, count)
+    ngal = assemble([part[:n_local * n_ngal].reshape(n_local, n_ngal)
+                     for part in flat], n_draws)
+    xi = assemble([part[n_local * n_ngal:].reshape(n_local, n_comp, n_r)
+                   for part in flat], n_draws)
+    return first._package(ngal, xi, separate_gal_type)
 
 
 def predict_batch_sharded(halotab, theta, communicator, x=None, **kwargs):
@@ -276,20 +321,20 @@ def predict_batch_sharded(halotab, theta, communicator, x=None, **kwargs):
     parameters ``x`` are given) with the draws sharded round-robin over the
     ranks of ``communicator``.  Every rank passes the same ``theta`` (and
     ``x``); the root returns the assembled ``(ngal, xi)`` (or dicts), other
-    ranks ``None``.  With an RCCL communicator the total prediction of a
-    single table stays on the devices until one ``ncclGather`` has collected
-    it on the root; the other cases gather host arrays over gloo.
+    ranks ``None``.  With an RCCL communicator the results of every variant
+    (single table or interpolator, total or separated by galaxy type) stay on
+    the devices until one ``ncclGather`` has collected them on the root; without
+    RCCL (CPU-only tests, RCCL unusable) host arrays are gathered over gloo.
     """
     theta = np.atleast_2d(np.asarray(theta, dtype=np.float64))
     n_draws = len(theta)
-    if (communicator.comm is not None and x is None and
-            hasattr(halotab, 'to_device') and
-            not kwargs.get('separate_gal_type', False)):
-        kwargs.pop('separate_gal_type', None)
-        return _predict_sharded_rccl(halotab, theta, communicator, **kwargs)
-    shard = local_shard(theta, communicator.rank, communicator.world_size)
     if x is not None:
         x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+    if communicator.comm is not None and hasattr(halotab, 'to_device'):
+        return _predict_sharded_rccl(halotab, theta, communicator, x=x,
+                                     **kwargs)
+    shard = local_shard(theta, communicator.rank, communicator.world_size)
+    if x is not None:
         x_shard = local_shard(x, communicator.rank, communicator.world_size)
         ngal, xi = halotab.predict_batch(shard, x_shard, **kwargs)
     else:

@@ -293,3 +293,138 @@ def test_degenerate_parameters_do_not_fault():
     # the device is still healthy afterwards
     ngal2, xi2 = halotab.predict_batch(theta[good])
     assert_rel(xi2, xi[good], 1e-13)
+
+
+def _occupation_oracle(table, theta, **kwargs):
+    from oracle import tabcorr_oracle as oracle
+    out = []
+    with np.errstate(all='ignore'):
+        for i, t in enumerate(theta):
+            assembias = kwargs.get('assembias')
+            model = oracle.Zheng07(t[:5], kwargs.get('modulate_with_cenocc', False),
+                                   None if assembias is None else assembias[i])
+            out.append(oracle.mean_occupation(table, model))
+    return np.array(out)
+
+
+@pytest.mark.parametrize('variant', ['plain', 'modulate', 'assembias'])
+def test_degenerate_parameters_match_the_oracle(variant):
+    """NaN parameters, sigma_logM = 0, all satellites below M0 and draws without any
+    galaxies give what the reference's NumPy arithmetic gives (NaN where it gives NaN:
+    an MCMC likelihood relies on that to reject the draw) -- batched and un-batched."""
+    import warnings
+    from tabcorr_amd import synthetic, Zheng07Model
+    from tabcorr_amd.models import ASSEMBIAS_KEYS, ZHENG07_KEYS
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(8, 2, (4, ), 'auto', seed=23)
+    halotab = make(table)
+    base = np.array([12.4, 0.35, 11.9, 13.3, 1.1])
+    rows, names = [], []
+    def case(name, **changes):
+        theta = base.copy()
+        for key, value in changes.items():
+            theta[ZHENG07_KEYS.index(key)] = value
+        rows.append(theta)
+        names.append(name)
+    case('regular')
+    case('sigma = 0: step function', sigma_logM=0.0)
+    case('sigma = -0', sigma_logM=-0.0)
+    case('sigma tiny', sigma_logM=1e-12)
+    case('NaN logMmin', logMmin=np.nan)
+    case('NaN sigma', sigma_logM=np.nan)
+    case('NaN logM0: no satellites', logM0=np.nan)
+    case('NaN logM1', logM1=np.nan)
+    case('NaN alpha', alpha=np.nan)
+    case('all NaN', logMmin=np.nan, sigma_logM=np.nan, logM0=np.nan, logM1=np.nan,
+         alpha=np.nan)
+    case('every satellite bin below M0', logM0=15.5)
+    case('NaN alpha with every satellite bin below M0', logM0=15.5, alpha=np.nan)
+    case('no galaxies at all: 0 / 0', logMmin=30.0, sigma_logM=0.01, logM0=15.5)
+    case('no centrals', logMmin=30.0, sigma_logM=0.01)
+    case('logMmin = +inf', logMmin=np.inf)
+    case('logMmin = -inf', logMmin=-np.inf)
+    case('M1 underflows', logM1=-400.0)
+    case('M0 overflows', logM0=400.0)
+    theta = np.array(rows)
+    kwargs = {}
+    if variant == 'modulate':
+        kwargs['modulate_with_cenocc'] = True
+    if variant == 'assembias':
+        strengths = np.tile([[0.6, -0.4]], (len(theta), 1))
+        strengths[0] = [1.8, -3.0]              # clipped to [-1, 1]
+        strengths[3] = [np.nan, 0.2]            # NaN strength: every central bin NaN
+        strengths[6] = [0.2, np.nan]
+        kwargs['assembias'] = strengths
+    with np.errstate(all='ignore'), warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        expect_occ = _occupation_oracle(table, theta, **kwargs)
+        expect = oracle.predict_zheng07_batch(table, theta, **kwargs)
+        expect_sep = oracle.predict_zheng07_batch(table, theta, separate_gal_type=True,
+                                                  **kwargs)
+    call = dict(kwargs)
+    batch = theta
+    if variant == 'assembias':
+        call['assembias'] = True
+        batch = np.hstack([theta, strengths])
+    occupation = halotab.mean_occupation_batch(batch, **call)
+    ngal, xi = halotab.predict_batch(batch, **call)
+    ngal_sep, xi_sep = halotab.predict_batch(batch, separate_gal_type=True, **call)
+    for i, name in enumerate(names):
+        what = '%s / %s' % (variant, name)
+        assert np.array_equal(np.isnan(occupation[i]), np.isnan(expect_occ[i])), what
+        assert_rel(np.nan_to_num(occupation[i]), np.nan_to_num(expect_occ[i]), RTOL, what)
+        np.testing.assert_allclose(ngal[i], expect[0][i], rtol=RTOL, err_msg=what)
+        np.testing.assert_allclose(xi[i], expect[1][i], rtol=RTOL, err_msg=what)
+        for key in ngal_sep:
+            np.testing.assert_allclose(ngal_sep[key][i], expect_sep[0][key][i], rtol=RTOL,
+                                       err_msg=what)
+        for key in xi_sep:
+            np.testing.assert_allclose(xi_sep[key][i], expect_sep[1][key][i], rtol=RTOL,
+                                       atol=1e-14 * np.nanmax(np.abs(np.nan_to_num(
+                                           expect[1][i]))), err_msg=what)
+    # the step function really is one, and the rejected draws are NaN
+    cen = oracle.is_centrals(table['gal_type'])
+    if variant == 'plain':
+        assert np.all((occupation[1][cen] >= 0) & (occupation[1][cen] <= 1))
+        assert np.all(np.isnan(xi[4])) and np.isnan(ngal[4])
+        assert np.all(np.isnan(xi[12]))          # 0 / 0
+        assert ngal[12] == 0.0
+    # un-batched calls (one launch for one draw) agree with the batched path bit for bit
+    # in their NaN pattern and to rounding elsewhere
+    for i, name in enumerate(names):
+        model = Zheng07Model(modulate_with_cenocc=variant == 'modulate',
+                             sec_haloprop_key='halo_nfw_conc' if variant == 'assembias'
+                             else None)
+        for k, key in enumerate(ZHENG07_KEYS):
+            model.param_dict[key] = theta[i, k]
+        if variant == 'assembias':
+            model.param_dict[ASSEMBIAS_KEYS[0]] = strengths[i, 0]
+            model.param_dict[ASSEMBIAS_KEYS[1]] = strengths[i, 1]
+        n1, x1 = halotab.predict(model, check_consistency=False)
+        np.testing.assert_allclose(n1, ngal[i], rtol=1e-12, err_msg=name)
+        np.testing.assert_allclose(x1, xi[i], rtol=1e-12, err_msg=name)
+
+
+def test_sigma_zero_tie_is_nan():
+    """sigma_logM = 0 and logMmin exactly on a quadrature node: the reference divides
+    0 by 0 there (tabcorr.py:556-559 -> erf(nan)), so that bin is NaN."""
+    import ctypes
+    from tabcorr_amd import synthetic, _lib
+    table = synthetic.synthetic_table(6, 1, (3, ), 'auto', seed=29)
+    halotab = make(table)
+    lib = _lib.load()
+    x = np.zeros(10)
+    w = np.zeros(10)
+    _lib.check(lib.tc_gauss_legendre(10, _lib.as_double_p(x), _lib.as_double_p(w)))
+    gal_type = table['gal_type']
+    lo, hi = gal_type['log_prim_haloprop_min'][2], gal_type['log_prim_haloprop_max'][2]
+    node = np.log10(10.0**(lo + (hi - lo) * x[4]))     # as the library forms it
+    theta = np.array([[node, 0.0, 11.9, 13.3, 1.1], [node + 1e-9, 0.0, 11.9, 13.3, 1.1]])
+    occupation = halotab.mean_occupation_batch(theta)
+    assert np.isnan(occupation[0, 2]) and np.sum(np.isnan(occupation[0])) == 1
+    assert not np.any(np.isnan(occupation[1]))
+    ngal, xi = halotab.predict_batch(theta)
+    assert np.isnan(ngal[0]) and np.all(np.isnan(xi[0]))
+    assert np.all(np.isfinite(xi[1]))
+    occupation = halotab.mean_occupation_batch(theta, modulate_with_cenocc=True)
+    assert np.isnan(occupation[0, 2])

@@ -497,6 +497,32 @@ np.testing.assert_allclose(ngal, data["ngal"], rtol=1e-10)
 np.testing.assert_allclose(xi, data["xi"], rtol=1e-10)
 ngal_sep, xi_sep = parallel.predict_batch_sharded(halotab, data["theta"], comm, separate_gal_type=True)
 np.testing.assert_allclose(sum(xi_sep.values()), data["xi"], rtol=1e-10)
+for key in xi_sep:
+    np.testing.assert_allclose(xi_sep[key], data["xi_sep_" + key], rtol=1e-10,
+                               atol=1e-14 * np.max(np.abs(data["xi"])))
+for key in ngal_sep:
+    np.testing.assert_allclose(ngal_sep[key], data["ngal_sep_" + key], rtol=1e-10)
+# Interpolator.predict sharded: device buffers + ncclGather as well (BASELINE configs[3])
+from util import interpolator_tables_from_golden
+from tabcorr_amd import Interpolator
+idata = load_golden("interp_2d_auto")
+tabs = [TabCorr.from_arrays(t["gal_type"], t["tpcf_matrix"], t["tpcf_shape"], t["attrs"])
+        for t in interpolator_tables_from_golden(idata)]
+keys = [str(k) for k in idata["keys"]]
+interp = Interpolator(tabs, {k: idata["points"][:, d] for d, k in enumerate(keys)})
+ngal, xi = parallel.predict_batch_sharded(interp, idata["theta"], comm, x=idata["x"])
+np.testing.assert_allclose(ngal, idata["ngal"], rtol=1e-10)
+np.testing.assert_allclose(xi, idata["xi"], rtol=1e-10, atol=1e-13 * np.max(np.abs(idata["xi"])))
+ngal_sep, xi_sep = parallel.predict_batch_sharded(interp, idata["theta"], comm, x=idata["x"],
+                                                  separate_gal_type=True)
+np.testing.assert_allclose(sum(xi_sep.values()), idata["xi"], rtol=1e-9,
+                           atol=1e-12 * np.max(np.abs(idata["xi"])))
+bad = idata["x"].copy(); bad[3, 0] = np.nan
+try:
+    parallel.predict_batch_sharded(interp, idata["theta"], comm, x=bad)
+    raise SystemExit("NaN x accepted")
+except ValueError:
+    pass
 comm.close()
 print("sharded ok")
 ''' % {'repo': REPO}

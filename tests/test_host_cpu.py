@@ -277,6 +277,17 @@ out = parallel.predict_batch_sharded(OracleInterp(), idata['theta'][:9], comm, x
 if comm.is_root:
     assert np.array_equal(out[0], idata['ngal'][:9]) or np.allclose(out[0], idata['ngal'][:9], rtol=1e-11, atol=0)
     assert np.allclose(out[1], idata['xi'][:9], rtol=1e-10, atol=0)
+out = parallel.predict_batch_sharded(OracleInterp(), idata['theta'][:9], comm, x=idata['x'][:9],
+                                     separate_gal_type=True)
+if comm.is_root:
+    for key in ('centrals-centrals', 'centrals-satellites', 'satellites-satellites'):
+        assert out[1][key].shape == idata['xi'][:9].shape
+        assert np.allclose(out[1][key], idata['xi_sep_' + key][:9], rtol=1e-10,
+                           atol=1e-14 * np.max(np.abs(idata['xi'])))
+    for key in ('centrals', 'satellites'):
+        assert np.allclose(out[0][key], idata['ngal_sep_' + key][:9], rtol=1e-11, atol=0)
+else:
+    assert out is None
 assert comm.max(comm.rank + 1.0) == 2.0
 assert comm.sum(1.0) == 2.0
 comm.barrier()
@@ -401,3 +412,156 @@ def test_fastmath_accuracy_on_host():
     assert run(2, np.array([-5000.0]))[0] < 1e-300
     w = rng.uniform(9.0, 16.0, 100000)
     assert np.max(np.abs(run(3, w) / 10.0**w - 1.0)) < 6e-16
+
+
+# ---- model recognition (tabcorr.py:556-563 call sites; halotools itself is not installed) --
+
+def _fake_halotools(name, **attributes):
+    """An object whose class carries a halotools class name and module, as the
+    components of a HodModelFactory do."""
+    cls = type(name, (), {'__module__': 'halotools.empirical_models.occupation_models'})
+    component = cls()
+    component.prim_haloprop_key = 'halo_mvir'
+    for key, value in attributes.items():
+        setattr(component, key, value)
+    return component
+
+
+class _FakeFactory:
+    def __init__(self, cens, sats, **param_dict):
+        self.gal_types = ['centrals', 'satellites']
+        self.redshift = 0.0
+        self._input_model_dictionary = {'centrals_occupation': cens,
+                                        'satellites_occupation': sats}
+        self.param_dict = {'logMmin': 12.1, 'sigma_logM': 0.3, 'logM0': 11.5,
+                           'logM1': 13.2, 'alpha': 1.1}
+        self.param_dict.update(param_dict)
+
+
+def _assembias_pair(**overrides):
+    attributes = {'_assembias_strength_abscissa': [2.0], '_split_ordinates': [0.5],
+                  '_split_abscissa': [2.0], 'sec_haloprop_key': 'halo_nfw_conc'}
+    attributes.update(overrides)
+    return (_fake_halotools('AssembiasZheng07Cens', **attributes),
+            _fake_halotools('AssembiasZheng07Sats', **attributes))
+
+
+def test_device_spec_accepts_only_what_the_kernel_implements():
+    from tabcorr_amd import Zheng07Model
+    from tabcorr_amd.models import device_spec, ASSEMBIAS_KEYS
+    strengths = {ASSEMBIAS_KEYS[0]: 0.4, ASSEMBIAS_KEYS[1]: -0.7}
+
+    # plain zheng07 composite, extra (interpolator) keys in param_dict are fine
+    spec = device_spec(_FakeFactory(_fake_halotools('Zheng07Cens'),
+                                    _fake_halotools('Zheng07Sats'), log_eta=0.1))
+    assert spec is not None and not spec.assembias and not spec.modulate_with_cenocc
+    np.testing.assert_array_equal(spec.theta, [12.1, 0.3, 11.5, 13.2, 1.1])
+    # modulate_with_cenocc with Zheng07 centrals
+    sats = _fake_halotools('Zheng07Sats', modulate_with_cenocc=True,
+                           central_occupation_model=_fake_halotools('Zheng07Cens'))
+    spec = device_spec(_FakeFactory(_fake_halotools('Zheng07Cens'), sats))
+    assert spec is not None and spec.modulate_with_cenocc
+    # decorated pair with one constant strength and the median split
+    spec = device_spec(_FakeFactory(*_assembias_pair(), **strengths))
+    assert spec is not None and spec.assembias
+    np.testing.assert_array_equal(spec.theta[5:], [0.4, -0.7])
+    # this package's own model
+    assert device_spec(Zheng07Model()) is not None
+
+    # ---- everything below must take the host route ----
+    # mass-dependent strength: two abscissae and a _param2 key
+    cens, sats = _assembias_pair(_assembias_strength_abscissa=[1e12, 1e14])
+    assert device_spec(_FakeFactory(cens, sats, **strengths)) is None
+    two = dict(strengths)
+    two['mean_occupation_centrals_assembias_param2'] = 0.1
+    assert device_spec(_FakeFactory(*_assembias_pair(), **two)) is None
+    # a split away from the median, or split information missing altogether
+    assert device_spec(_FakeFactory(*_assembias_pair(_split_ordinates=[0.3]),
+                                    **strengths)) is None
+    cens, sats = _assembias_pair()
+    del cens._split_ordinates
+    assert device_spec(_FakeFactory(cens, sats, **strengths)) is None
+    # strengths missing from param_dict
+    assert device_spec(_FakeFactory(*_assembias_pair())) is None
+    # assembly-bias keys on an undecorated model
+    assert device_spec(_FakeFactory(_fake_halotools('Zheng07Cens'),
+                                    _fake_halotools('Zheng07Sats'), **strengths)) is None
+    # a user class with halotools' name (may override anything), a subclass defined
+    # elsewhere, another occupation family, mixed pairs
+    user = type('Zheng07Cens', (), {'__module__': 'my_models'})()
+    assert device_spec(_FakeFactory(user, _fake_halotools('Zheng07Sats'))) is None
+    assert device_spec(_FakeFactory(_fake_halotools('Leauthaud11Cens'),
+                                    _fake_halotools('Leauthaud11Sats'))) is None
+    assert device_spec(_FakeFactory(_fake_halotools('Zheng07Cens'),
+                                    _assembias_pair()[1], **strengths)) is None
+    # instance-level override of the occupation function
+    cens = _fake_halotools('Zheng07Cens', mean_occupation=lambda **kw: 1.0)
+    assert device_spec(_FakeFactory(cens, _fake_halotools('Zheng07Sats'))) is None
+    # satellites modulated by something that is not Zheng07 centrals
+    sats = _fake_halotools('Zheng07Sats', modulate_with_cenocc=True,
+                           central_occupation_model=_fake_halotools('Leauthaud11Cens'))
+    assert device_spec(_FakeFactory(_fake_halotools('Zheng07Cens'), sats)) is None
+    sats = _fake_halotools('Zheng07Sats', modulate_with_cenocc=True)
+    assert device_spec(_FakeFactory(_fake_halotools('Zheng07Cens'), sats)) is None
+    # subclasses of this package's model that change the occupation functions or the split
+    class Steeper(Zheng07Model):
+        def mean_occupation_satellites(self, **kwargs):
+            return 2.0 * super().mean_occupation_satellites(**kwargs)
+    assert device_spec(Steeper()) is None
+    shifted = Zheng07Model(sec_haloprop_key='halo_nfw_conc')
+    shifted.split = 0.3
+    assert device_spec(shifted) is None
+    # no components at all
+    assert device_spec(object()) is None
+
+
+def test_heaviside_strength_is_clipped_like_halotools():
+    """halotools' HeavisideAssembias.assembias_strength clips to [-1, 1]; the oracle, the
+    host model and (GPU tests) the kernel do the same."""
+    from tabcorr_amd import Zheng07Model
+    from tabcorr_amd.models import ASSEMBIAS_KEYS
+    from oracle import tabcorr_oracle as oracle
+    mass = np.logspace(11, 15, 50)
+    percentile = np.tile([0.25, 0.75], 25)
+    theta = [12.3, 0.4, 11.8, 13.1, 1.05]
+    for strength in (1.7, -2.5, np.nan):
+        clipped = np.clip(strength, -1, 1)
+        model = oracle.Zheng07(theta, assembias=(strength, strength))
+        expect = oracle.Zheng07(theta, assembias=(clipped, clipped))
+        for name in ('mean_occupation_centrals', 'mean_occupation_satellites'):
+            np.testing.assert_array_equal(getattr(model, name)(mass, percentile),
+                                          getattr(expect, name)(mass, percentile))
+        host = Zheng07Model(sec_haloprop_key='halo_nfw_conc', logMmin=theta[0],
+                            sigma_logM=theta[1], logM0=theta[2], logM1=theta[3],
+                            alpha=theta[4], **{ASSEMBIAS_KEYS[0]: strength,
+                                               ASSEMBIAS_KEYS[1]: strength})
+        np.testing.assert_allclose(
+            host.mean_occupation_centrals(prim_haloprop=mass,
+                                          sec_haloprop_percentile=percentile),
+            expect.mean_occupation_centrals(mass, percentile), rtol=1e-14, equal_nan=True)
+        np.testing.assert_allclose(
+            host.mean_occupation_satellites(prim_haloprop=mass,
+                                            sec_haloprop_percentile=percentile),
+            expect.mean_occupation_satellites(mass, percentile), rtol=1e-13,
+            equal_nan=True)
+        occupation = expect.mean_occupation_centrals(mass, percentile)
+        if not np.isnan(strength):
+            assert np.all((occupation >= 0) & (occupation <= 1))
+
+
+def test_interpolator_param_table_and_nan_range():
+    from tabcorr_amd import Interpolator, TabCorr, synthetic
+    tables, keys, points = synthetic.synthetic_interpolator((4, 4), 5, 1, (3, ), 'auto',
+                                                            seed=3)
+    tabs = [TabCorr.from_arrays(t['gal_type'], t['tpcf_matrix'], t['tpcf_shape'], t['attrs'])
+            for t in tables]
+    interp = Interpolator(tabs, {k: points[:, d] for d, k in enumerate(keys)})
+    table = interp.param_dict_table
+    assert table.colnames == list(keys) + ['tabcorr_index']      # interpolator.py:59-61
+    assert len(table) == 16
+    assert np.all(np.diff(table[keys[0]]) >= 0)
+    # NaN is outside of the interpolation range (np.digitize sorts it past the last node)
+    x = np.array([[points[0, 0], np.nan]])
+    with pytest.raises(ValueError, match='outside of the interpolation'):
+        interp._check_range(x, False)
+    interp._check_range(x, True)

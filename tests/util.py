@@ -48,13 +48,14 @@ def xi_keys(table):
     return XI_KEYS_AUTO if table['attrs']['mode'] == 'auto' else XI_KEYS_CROSS
 
 
-def assert_rel(actual, desired, rtol, what=''):
-    """Relative agreement measured against the largest |desired| of each row
-    of the last axis would hide small elements; use elementwise rtol with a
-    tiny absolute floor tied to the scale of the row."""
+def assert_rel(actual, desired, rtol, what='', floor=1e-14):
+    """Elementwise relative agreement, with an absolute floor of ``floor`` x
+    the largest |desired| (a few ulp of the scale of the array: elements more
+    than ~1e4 below the largest one are sums whose rounding is set by their
+    larger neighbours' scale)."""
     actual = np.asarray(actual, dtype=np.float64)
     desired = np.asarray(desired, dtype=np.float64)
     assert actual.shape == desired.shape, (what, actual.shape, desired.shape)
     scale = np.max(np.abs(desired)) if desired.size else 0.0
     np.testing.assert_allclose(actual, desired, rtol=rtol,
-                               atol=rtol * 1e-3 * scale, err_msg=what)
+                               atol=floor * scale, err_msg=what)
