@@ -640,7 +640,7 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds):
     cpu5 = cpu_rate(lambda i: oracle.predict_zheng07(table5, theta[i % 10000], cache=cache5))
     for dtype, peak, kernel in (('float32', FP32_PEAK_TFLOPS, 'tc::contract_f32_kernel<false>'),
                                 ('float64', FP64_PEAK_TFLOPS,
-                                 'tc::contract_quad_kernel<5, false>')):
+                                 'tc::contract_mfma_kernel<32, false>')):
         tab5 = make(table5, compute_dtype=dtype)
         h5 = tab5.to_device().handle
         measure('configs[4] ' + dtype, 'rp_pi table 19 x 40 (R=760), 100 x {cen,sat} bins (G=200, '

@@ -254,6 +254,32 @@ int tc_debug_wave_trace(tc_table* table, uint64_t* out, int64_t capacity,
 int tc_table_last_launch(const tc_table* table, int* n_workgroups, int* waves_per_workgroup,
                          int* n_splits, int* lds_bytes);
 
+/* ---- tabulation: pair counting ---------------------------------
+ *
+ * tc_pair_count_rppi replaces one Corrfunc.theory.DDrppi call of tabcorr/corrfunc.py:62-84
+ * (the pair count behind `wp` for one pair of halo bins): ORDERED pair counts between the
+ * points pos1 (n1, 3) and pos2 (n2, 3) -- pos2 = NULL: of pos1 with itself, every pair then
+ * counted twice as Corrfunc's autocorr = 1 does -- in a periodic box `boxsize` (3), per
+ * projected-separation bin (rp_bins: n_rp + 1 increasing edges) and line-of-sight bin
+ * (n_pi equal bins on [0, pi_max)): npairs (n_rp, n_pi), row-major.  Separations are
+ * minimum-image; r_p^2 = dx dx + dy dy is compared with rp_bins^2; a pair with i == j only
+ * counts when rp_bins[0] == 0.  Integer counters: the result is exact and independent of
+ * the execution order.
+ *
+ * tc_pair_count_rppi_labelled is the loop of tabcorr/tabcorr.py:846-922
+ * (compute_tpcf_matrix: one pair count per pair of halo bins, from a process pool) in ONE
+ * pass: label1 / label2 give the halo bin of every point (0 <= label < n_labels) and
+ * counts (n_rp, n_labels, n_labels) receives, for every pair of bins (a, b), the ordered
+ * pair counts between the points of bin a in set 1 and of bin b in set 2 (pos2 = NULL:
+ * set 1 with itself), summed over |pi| < pi_max.  Positions must lie in [0, boxsize]. */
+int tc_pair_count_rppi(const double* pos1, int64_t n1, const double* pos2, int64_t n2,
+                       const double* boxsize, const double* rp_bins, int n_rp, double pi_max,
+                       int n_pi, uint64_t* npairs);
+int tc_pair_count_rppi_labelled(const double* pos1, const int32_t* label1, int64_t n1,
+                                const double* pos2, const int32_t* label2, int64_t n2,
+                                int n_labels, const double* boxsize, const double* rp_bins,
+                                int n_rp, double pi_max, uint64_t* counts);
+
 /* ---- multi-GPU: one process per GPU, results collected with one RCCL gather ---------- */
 
 #define TC_UNIQUE_ID_BYTES 128

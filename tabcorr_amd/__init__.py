@@ -10,7 +10,8 @@ from .interpolator import Interpolator
 from .models import Zheng07Model
 from .galtable import GalTypeTable
 from . import synthetic
+from . import corrfunc
 
 __version__ = '0.1.0'
 __all__ = ['TabCorr', 'Interpolator', 'Zheng07Model', 'GalTypeTable',
-           'symmetric_matrix_to_array', 'synthetic']
+           'symmetric_matrix_to_array', 'synthetic', 'corrfunc']

@@ -16,9 +16,10 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBRARY = os.path.join(HERE, 'libtabcorr_hip.so')
-# launch.hip holds all device code; the other units are host-only C++
-SOURCES = ['launch.hip', 'table.cpp', 'interp.cpp', 'comm.cpp', 'runtime.cpp',
-           'hostmath.cpp']
+# launch.hip (prediction) and paircount.hip (tabulation) hold the device code; the other
+# units are host-only C++
+SOURCES = ['launch.hip', 'paircount.hip', 'table.cpp', 'interp.cpp', 'comm.cpp',
+           'runtime.cpp', 'hostmath.cpp']
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-gpu-rdc',
          '-Wall', '-Wno-unused-function']
 

@@ -1,0 +1,162 @@
+"""Two-point functions for the tabulation step, counted on the GPU.
+
+Mirrors ``tabcorr/corrfunc.py`` of johannesulf/TabCorr v1.2.0, whose functions
+wrap the Corrfunc pair counters so that they can be handed to
+``TabCorr.tabulate`` in the place of the halotools two-point functions.  Here
+the pair counts come from this package's HIP kernel
+(``tabcorr_amd/csrc/paircount.hip`` through ``tc_pair_count_rppi``): same
+signature, same arithmetic around the counts, no Corrfunc.
+
+`compute_tpcf_matrix` is the MI355X-native form of the reference's
+``compute_tpcf_matrix`` (``tabcorr/tabcorr.py:846-922``) for ``tpcf = wp``:
+instead of one pair count per pair of halo bins from a pool of processes, every
+point is labelled with its halo bin and ONE pass over the box fills the counts
+of all bin pairs.
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def _period(period):
+    if period is None:
+        raise ValueError('A periodic box (period) is required.')
+    if isinstance(period, (float, int)):
+        period = (period, period, period)
+    return _lib.contiguous(np.asarray(period, dtype=np.float64).reshape(3))
+
+
+def _positions(sample):
+    sample = _lib.contiguous(np.asarray(sample, dtype=np.float64))
+    if sample.ndim != 2 or sample.shape[1] != 3:
+        raise ValueError('positions must have shape (n, 3).')
+    return sample
+
+
+def pair_count_rppi(sample1, rp_bins, pi_max, sample2=None, period=None,
+                    n_pi=None):
+    """Ordered pair counts ``(n_rp, n_pi)`` (uint64) between ``sample1`` and
+    ``sample2`` -- ``None``: of ``sample1`` with itself, every pair counted
+    twice -- as ``Corrfunc.theory.DDrppi(autocorr, 1, pi_max, rp_bins, ...,
+    periodic=True)`` reports them in ``npairs``
+    (``tabcorr/corrfunc.py:62-84``)."""
+    lib = _lib.load()
+    _lib.require_device()
+    sample1 = _positions(sample1)
+    rp_bins = _lib.contiguous(np.asarray(rp_bins, dtype=np.float64))
+    if n_pi is None:
+        n_pi = int(pi_max)
+    box = _period(period)
+    npairs = np.zeros((len(rp_bins) - 1, n_pi), dtype=np.uint64)
+    if sample2 is not None:
+        sample2 = _positions(sample2)
+    _lib.check(lib.tc_pair_count_rppi(
+        _lib.as_double_p(sample1), len(sample1),
+        _lib.as_double_p(sample2) if sample2 is not None else None,
+        len(sample2) if sample2 is not None else 0, _lib.as_double_p(box),
+        _lib.as_double_p(rp_bins), len(rp_bins) - 1, float(pi_max), n_pi,
+        npairs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+    return npairs
+
+
+def wp(sample1, rp_bins, pi_max, sample2=None, period=None, do_auto=True,
+       do_cross=False):
+    """Drop-in for ``tabcorr.corrfunc.wp`` (``tabcorr/corrfunc.py:6-95``,
+    itself a stand-in for ``halotools.mock_observables.wp``): the projected
+    correlation function of ``sample1`` (``do_auto``) or between ``sample1``
+    and ``sample2`` (``do_cross``) in a periodic box.
+
+    Raises
+    ------
+    ValueError
+        If ``do_auto`` and ``do_cross`` have the same value.
+    """
+    if (do_auto and do_cross) or (not do_auto and not do_cross):
+        raise ValueError("'do_auto' and 'do_cross' cannot both be True or " +
+                         "False.")
+    rp_bins = np.asarray(rp_bins, dtype=np.float64)
+    box = _period(period)
+    if do_auto:
+        npairs = pair_count_rppi(sample1, rp_bins, pi_max, None, box)
+        n_exp = (len(sample1) * len(sample1) / np.prod(box) * np.pi *
+                 np.diff(rp_bins**2) * 2 * pi_max)
+    else:
+        npairs = pair_count_rppi(sample1, rp_bins, pi_max, sample2, box)
+        n_exp = (len(sample1) * len(sample2) / np.prod(box) * np.pi *
+                 np.diff(rp_bins**2) * 2 * pi_max)
+    npairs = np.sum(npairs, axis=1).astype(np.float64)
+    return (npairs / n_exp - 1) * 2 * pi_max
+
+
+def pair_count_matrix(pos, rp_bins, pi_max, period, sample2=None):
+    """Pair counts between all bins in one pass.
+
+    ``pos`` is the list of per-bin position arrays ``TabCorr.tabulate`` builds
+    (``tabcorr/tabcorr.py:318-330``).  Returns ``(n_rp, G, G)`` ordered pair
+    counts between the points of every pair of bins (``sample2`` given:
+    ``(n_rp, G)`` counts of every bin against that sample), summed over
+    ``|pi| < pi_max``."""
+    lib = _lib.load()
+    _lib.require_device()
+    n_bins = len(pos)
+    sizes = np.array([len(p) for p in pos], dtype=np.int64)
+    points = _positions(np.concatenate(
+        [np.asarray(p, dtype=np.float64).reshape(-1, 3) for p in pos]))
+    label = np.ascontiguousarray(
+        np.repeat(np.arange(n_bins, dtype=np.int32), sizes))
+    rp_bins = _lib.contiguous(np.asarray(rp_bins, dtype=np.float64))
+    box = _period(period)
+    n_rp = len(rp_bins) - 1
+    counts = np.zeros((n_rp, n_bins, n_bins), dtype=np.uint64)
+    int32_p = ctypes.POINTER(ctypes.c_int32)
+    if sample2 is None:
+        pos2 = label2 = None
+        n2 = 0
+    else:
+        sample2 = _positions(sample2)
+        label2 = np.zeros(len(sample2), dtype=np.int32)
+        pos2, n2 = _lib.as_double_p(sample2), len(sample2)
+        label2 = label2.ctypes.data_as(int32_p)
+    _lib.check(lib.tc_pair_count_rppi_labelled(
+        _lib.as_double_p(points), label.ctypes.data_as(int32_p), len(points),
+        pos2, label2, n2, max(n_bins, 1), _lib.as_double_p(box),
+        _lib.as_double_p(rp_bins), n_rp, float(pi_max),
+        counts.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+    if sample2 is not None:
+        return counts[:, :, 0]
+    return counts
+
+
+def compute_tpcf_matrix(mode, pos, period, rp_bins, pi_max, sample2=None):
+    """``compute_tpcf_matrix`` of the reference (``tabcorr/tabcorr.py:846-922``)
+    for ``tpcf = wp``: the correlation functions between all pairs of bins
+    (mode ``'auto'``: ``(n_rp, G, G)``, symmetric) or of every bin with
+    ``sample2`` (mode ``'cross'``: ``(n_rp, G)``), and the shape ``(n_rp, )``
+    of one of them.  Empty bins give zeros, as in the reference."""
+    rp_bins = np.asarray(rp_bins, dtype=np.float64)
+    box = _period(period)
+    sizes = np.array([len(p) for p in pos], dtype=np.float64)
+    d_rp_sqr = np.diff(rp_bins**2)
+    volume = np.prod(box)
+    # (the products in the reference's order, tabcorr/corrfunc.py:72-73, 83-84)
+    if mode == 'auto':
+        counts = pair_count_matrix(pos, rp_bins, pi_max, box).astype(
+            np.float64)
+        n_exp = ((sizes[:, None] * sizes[None, :] / volume * np.pi)[None] *
+                 d_rp_sqr[:, None, None] * 2 * pi_max)
+    elif mode == 'cross':
+        if sample2 is None:
+            raise ValueError("mode 'cross' needs a second sample.")
+        counts = pair_count_matrix(pos, rp_bins, pi_max, box,
+                                   sample2=sample2).astype(np.float64)
+        n_exp = ((sizes * len(sample2) / volume * np.pi)[None] *
+                 d_rp_sqr[:, None] * 2 * pi_max)
+    else:
+        raise ValueError("mode must be 'auto' or 'cross'.")
+    with np.errstate(divide='ignore', invalid='ignore'):
+        matrix = (counts / n_exp - 1) * 2 * pi_max
+    matrix[n_exp == 0] = 0.0          # bins without points: tabcorr.py:888
+    return matrix, (len(rp_bins) - 1, )

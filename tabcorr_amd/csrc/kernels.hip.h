@@ -60,10 +60,12 @@ __device__ inline double heaviside_assembias(double n, double strength,
 //   kBadCen  logMmin or sigma_logM is NaN (or both infinite): every <N_cen> is NaN;
 //   kBadSat  logM1 or alpha is NaN: <N_sat> is NaN at every node with M > M0, 0 elsewhere
 //            (a NaN logM0 makes "M - M0 > 0" false everywhere: <N_sat> = 0);
-//   kTieCen  sigma_logM == 0: a step function, NaN (0 / 0) at a node with log M == logMmin.
+//   kTieCen  sigma_logM == 0: a step function, NaN (0 / 0) at a node with log M == logMmin;
+//   kInfSat  M1 = 10^logM1 underflows (logM1 < -290 is treated as M1 = 0) with alpha > 0:
+//            <N_sat> is infinite at every node with M > M0.
 // Assembly-bias strengths are clipped to [-1, 1] as halotools' HeavisideAssembias does (a
 // NaN strength stays NaN and propagates through the decoration by itself).
-constexpr int kBadCen = 1, kBadSat = 2, kTieCen = 4;
+constexpr int kBadCen = 1, kBadSat = 2, kTieCen = 4, kInfSat = 8;
 
 struct DrawSetup {
   double log_m_min, inv_sigma, m0, log2_m1, sat_scale, alpha, a_cen, a_sat;
@@ -93,9 +95,15 @@ __device__ inline DrawSetup prepare_draw(const double* table, const fm::Consts& 
     log_m1 = 13.0;
     alpha = 1.0;
   }
+  bool no_satellites = log_m0 != log_m0;   // "M - M0 > 0" is false for every node
+  if (log_m1 < -290.0) {                   // M1 = 0: (x / 0)^alpha = inf, 1 or 0
+    if (alpha > 0.0) d.bad |= kInfSat;
+    if (alpha < 0.0) no_satellites = true;
+    log_m1 = 13.0;
+  }
   d.log_m_min = log_m_min;
   d.inv_sigma = 1.0 / sigma;
-  d.m0 = log_m0 != log_m0 ? 1e300 : fm::exp10_fast(table, kc, log_m0);
+  d.m0 = no_satellites ? 1e300 : fm::exp10_fast(table, kc, log_m0);
   // ((M - M0) / M1)^alpha = 2^(alpha (log2(M - M0) - log2 M1)); log2 M1 is carried in two
   // parts, the low one applied to the finished bin sum as 2^(-alpha lo)
   const double hi = log_m1 * fm::kLog2Of10Hi;
@@ -242,6 +250,7 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
         if ((bad & kTieCen) && (central || modulate))
           for (int k = 0; k < n_gauss; ++k) tie = tie || log_m[g * n_gauss + k] == log_m_min;
         const bool cen_nan = (bad & kBadCen) || tie;
+        if (!central && (bad & kInfSat) && acc != 0.0) acc = __builtin_huge_val();
         if (central ? cen_nan : (((bad & kBadSat) && acc != 0.0) || (modulate && cen_nan)))
           acc = __builtin_nan("");
       }
@@ -863,6 +872,7 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
     }
     if (d.bad) {   // (prepare_draw: parameters the fast path cannot represent)
       const bool cen_nan = (d.bad & kBadCen) || ((d.bad & kTieCen) && lm == log_m_min);
+      if (g >= a.n_central && (d.bad & kInfSat) && n != 0.0) n = __builtin_huge_val();
       if (g < a.n_central ? cen_nan
                           : (((d.bad & kBadSat) && n != 0.0) || (modulate && cen_nan)))
         n = __builtin_nan("");

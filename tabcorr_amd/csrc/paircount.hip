@@ -1,0 +1,369 @@
+// Pair counting for the tabulation step: DD(r_p, pi) in a periodic
+// box on the GPU.
+//
+// In the reference, TabCorr.tabulate fills the correlation matrix by calling the two-point
+// function once per pair of halo bins from a multiprocessing pool (tabcorr/tabcorr.py:846-922)
+// and, with the Corrfunc backend, every such call is one Corrfunc.theory.DDrppi pair count
+// (tabcorr/corrfunc.py:62-84).  Here:
+//   * tc_pair_count_rppi is that one call: ordered pair counts per (r_p, pi) bin between two
+//     point sets (or of one set with itself);
+//   * tc_pair_count_rppi_labelled is the whole loop in one launch: every point carries the
+//     index of its halo bin and ONE pass over the box fills count[r_p bin][label 1][label 2]
+//     for all bin pairs at once -- the points of all bins share one cell grid and every
+//     close pair is visited once, instead of G (G + 1) / 2 separate pair counts.
+//
+// Pair definition (Corrfunc 2.x DDrppi, restated from its documentation -- Corrfunc is a
+// third-party dependency that is not vendored in the reference; oracle/paircount_oracle.py
+// is the executable statement of these rules and the kernel is bit-exact against it):
+//   dx, dy, dz = minimum-image separations in the periodic box (each coordinate difference
+//   d -> d - L if d > L / 2, d + L if d < -L / 2); r_p^2 = dx dx + dy dy with each product and
+//   the sum rounded separately (no fused multiply-add); a pair counts if |dz| < pi_max and
+//   rp_bins[0]^2 <= r_p^2 < rp_bins[-1]^2; its r_p bin is the last k with rp_bins[k]^2 <=
+//   r_p^2, its pi bin int(|dz| * (n_pi / pi_max)).  All ORDERED pairs (i, j) are counted, so
+//   an auto-count holds every pair twice; i == j is a pair like any other (it only counts
+//   when rp_bins[0] == 0).
+//
+// Layout: the host sorts the points into a grid of cells at least r_p,max (x, y) and pi_max
+// (z) wide, so that the partners of a point lie in the 27 cells around it (a dimension with
+// fewer than three cells has one cell and no neighbour offsets: the minimum image does the
+// wrapping).  A workgroup owns up to 256 consecutive points of one cell -- one per lane --
+// and streams the points of the neighbouring cells through LDS in tiles of 256 (the classic
+// all-pairs tiling: one global load per point and tile, 256 distance tests per load).
+// Counters are integers: per-workgroup LDS histograms (r_p x pi bins) flushed with 64-bit
+// global atomics, or 64-bit global atomics directly for the labelled matrix (its
+// n_rp x G x G counters do not fit LDS; neighbouring lanes mostly hit different counters).
+// The result does not depend on the order of the atomics.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "internal.h"
+
+namespace tc {
+
+constexpr int kPairThreads = 256;
+constexpr int kMaxRpBins = 64;
+
+struct PairArgs {
+  // set 1 ("i", one lane each) and set 2 ("j", streamed): positions sorted by cell
+  const double* x1;
+  const double* y1;
+  const double* z1;
+  const int32_t* label1;
+  const double* x2;
+  const double* y2;
+  const double* z2;
+  const int32_t* label2;
+  const int32_t* cell_start2;   // (n_cells + 1) offsets into set 2
+  const int32_t* item_cell;     // per workgroup: its cell ...
+  const int32_t* item_begin;    // ... and its range of set-1 points
+  const int32_t* item_end;
+  int nx, ny, nz;               // cells per dimension
+  int reach_x, reach_y, reach_z;   // neighbour offsets per dimension: 1, or 0 for one cell
+  double lx, ly, lz;            // box size
+  double edge_sqr[kMaxRpBins + 1];
+  int n_rp;
+  int n_pi;
+  double pi_max;
+  double inv_dpi;               // n_pi / pi_max
+  int n_labels;
+  unsigned long long* counts;   // (n_rp, n_pi) or (n_rp, n_labels, n_labels)
+};
+
+__device__ inline double min_image(double d, double box, double half) {
+  d = d > half ? d - box : d;
+  return d < -half ? d + box : d;
+}
+
+template <bool LABELLED>
+__global__ __launch_bounds__(kPairThreads) void pair_count_kernel(PairArgs a) {
+  __shared__ double sx[kPairThreads], sy[kPairThreads], sz[kPairThreads];
+  __shared__ int32_t sl[kPairThreads];
+  extern __shared__ unsigned hist[];   // unlabelled: n_rp * n_pi counters
+  const int tid = threadIdx.x;
+  const int n_hist = LABELLED ? 0 : a.n_rp * a.n_pi;
+  for (int k = tid; k < n_hist; k += kPairThreads) hist[k] = 0u;
+
+  const int cell = a.item_cell[blockIdx.x];
+  const int begin = a.item_begin[blockIdx.x], end = a.item_end[blockIdx.x];
+  const int i = begin + tid;
+  const bool active = i < end;
+  const double xi = active ? a.x1[i] : 0.0, yi = active ? a.y1[i] : 0.0;
+  const double zi = active ? a.z1[i] : 0.0;
+  const int li = LABELLED && active ? a.label1[i] : 0;
+  const int cz = cell % a.nz, cy = (cell / a.nz) % a.ny, cx = cell / (a.nz * a.ny);
+  const double hx = 0.5 * a.lx, hy = 0.5 * a.ly, hz = 0.5 * a.lz;
+  const double lo_sqr = a.edge_sqr[0], hi_sqr = a.edge_sqr[a.n_rp];
+  __syncthreads();
+
+  for (int ox = -a.reach_x; ox <= a.reach_x; ++ox)
+    for (int oy = -a.reach_y; oy <= a.reach_y; ++oy)
+      for (int oz = -a.reach_z; oz <= a.reach_z; ++oz) {
+        const int nxc = (cx + ox + a.nx) % a.nx, nyc = (cy + oy + a.ny) % a.ny;
+        const int nzc = (cz + oz + a.nz) % a.nz;
+        const int other = (nxc * a.ny + nyc) * a.nz + nzc;
+        const int j_begin = a.cell_start2[other], j_end = a.cell_start2[other + 1];
+        for (int j0 = j_begin; j0 < j_end; j0 += kPairThreads) {
+          const int n_tile = j_end - j0 < kPairThreads ? j_end - j0 : kPairThreads;
+          __syncthreads();
+          if (tid < n_tile) {
+            sx[tid] = a.x2[j0 + tid];
+            sy[tid] = a.y2[j0 + tid];
+            sz[tid] = a.z2[j0 + tid];
+            if (LABELLED) sl[tid] = a.label2[j0 + tid];
+          }
+          __syncthreads();
+          if (!active) continue;
+          for (int t = 0; t < n_tile; ++t) {
+            const double dz = fabs(min_image(zi - sz[t], a.lz, hz));
+            if (!(dz < a.pi_max)) continue;
+            const double dx = min_image(xi - sx[t], a.lx, hx);
+            const double dy = min_image(yi - sy[t], a.ly, hy);
+            // (separately rounded products and sum: the oracle's arithmetic)
+            const double r_sqr = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+            if (!(r_sqr >= lo_sqr && r_sqr < hi_sqr)) continue;
+            int bin = 0;
+            for (int k = 1; k < a.n_rp; ++k) bin += r_sqr >= a.edge_sqr[k] ? 1 : 0;
+            if (LABELLED) {
+              atomicAdd(a.counts + ((size_t)bin * a.n_labels + li) * a.n_labels + sl[t], 1ull);
+            } else {
+              const int pi_bin = (int)(dz * a.inv_dpi);
+              if (pi_bin < a.n_pi) atomicAdd(&hist[bin * a.n_pi + pi_bin], 1u);
+            }
+          }
+        }
+      }
+  __syncthreads();
+  for (int k = tid; k < n_hist; k += kPairThreads)
+    if (hist[k] != 0u) atomicAdd(a.counts + k, (unsigned long long)hist[k]);
+}
+
+namespace host {
+
+namespace {
+
+// Points of one set sorted by cell.
+struct CellSort {
+  std::vector<double> x, y, z;
+  std::vector<int32_t> label, cell_start;
+};
+
+struct Grid {
+  int nx = 1, ny = 1, nz = 1;
+  int reach_x = 0, reach_y = 0, reach_z = 0;
+  double lx = 0, ly = 0, lz = 0;
+  int n_cells() const { return nx * ny * nz; }
+};
+
+int cells_along(double box, double reach, int64_t n_points) {
+  // cells at least `reach` wide; fewer than three cells cannot tell a cell from its
+  // periodic image, so such a dimension gets one cell.  No more cells than the points
+  // warrant (about 8 points per cell at least).
+  int n = (int)std::floor(box / reach);
+  const int cap = (int)std::max<double>(1.0, std::cbrt((double)std::max<int64_t>(n_points, 1) / 8.0));
+  n = std::min(n, std::max(cap, 3));
+  n = std::min(n, 256);
+  return n < 3 ? 1 : n;
+}
+
+int sort_into_cells(const Grid& grid, const double* pos, const int32_t* label, int64_t n,
+                    CellSort& out) {
+  std::vector<int32_t> cell((size_t)n);
+  out.cell_start.assign((size_t)grid.n_cells() + 1, 0);
+  for (int64_t p = 0; p < n; ++p) {
+    const double x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
+    if (!(x >= 0.0 && x <= grid.lx && y >= 0.0 && y <= grid.ly && z >= 0.0 && z <= grid.lz))
+      return fail(TC_ERR_INVALID, "point %lld lies outside of the periodic box",
+                  (long long)p);
+    const int cx = std::min(grid.nx - 1, (int)(x / grid.lx * grid.nx));
+    const int cy = std::min(grid.ny - 1, (int)(y / grid.ly * grid.ny));
+    const int cz = std::min(grid.nz - 1, (int)(z / grid.lz * grid.nz));
+    cell[p] = (cx * grid.ny + cy) * grid.nz + cz;
+    ++out.cell_start[cell[p] + 1];
+  }
+  for (int c = 0; c < grid.n_cells(); ++c) out.cell_start[c + 1] += out.cell_start[c];
+  std::vector<int32_t> cursor(out.cell_start.begin(), out.cell_start.end() - 1);
+  out.x.resize(n);
+  out.y.resize(n);
+  out.z.resize(n);
+  if (label != nullptr) out.label.resize(n);
+  for (int64_t p = 0; p < n; ++p) {
+    const int32_t slot = cursor[cell[p]]++;
+    out.x[slot] = pos[3 * p];
+    out.y[slot] = pos[3 * p + 1];
+    out.z[slot] = pos[3 * p + 2];
+    if (label != nullptr) out.label[slot] = label[p];
+  }
+  return TC_OK;
+}
+
+struct DeviceArrays {
+  std::vector<void*> pointers;
+  ~DeviceArrays() {
+    for (void* p : pointers)
+      if (p) (void)hipFree(p);
+  }
+  template <typename T>
+  int put(const std::vector<T>& host, const T** out) {
+    void* device = nullptr;
+    int status = upload(host, &device);
+    if (status != TC_OK) return status;
+    pointers.push_back(device);
+    *out = (const T*)device;
+    return TC_OK;
+  }
+};
+
+int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const double* pos2,
+               const int32_t* label2, int64_t n2, int n_labels, const double* boxsize,
+               const double* rp_bins, int n_rp, double pi_max, int n_pi, uint64_t* counts) {
+  TC_CHECK(pos1 != nullptr && boxsize != nullptr && rp_bins != nullptr && counts != nullptr,
+           "NULL argument");
+  TC_CHECK(n1 >= 0 && n2 >= 0 && n1 < (1LL << 31) && n2 < (1LL << 31), "invalid point count");
+  TC_CHECK(n_rp >= 1 && n_rp <= kMaxRpBins, "between 1 and %d r_p bins are supported",
+           kMaxRpBins);
+  TC_CHECK(pi_max > 0.0 && n_pi >= 1, "pi_max and the number of pi bins must be positive");
+  for (int k = 0; k <= n_rp; ++k)
+    TC_CHECK(rp_bins[k] >= 0.0 && (k == 0 || rp_bins[k] > rp_bins[k - 1]),
+             "rp_bins must be non-negative and increasing");
+  const bool labelled = n_labels > 0;
+  const bool autocorr = pos2 == nullptr;
+  if (autocorr) {
+    pos2 = pos1;
+    label2 = label1;
+    n2 = n1;
+  }
+  Grid grid;
+  grid.lx = boxsize[0];
+  grid.ly = boxsize[1];
+  grid.lz = boxsize[2];
+  const double rp_max = rp_bins[n_rp];
+  TC_CHECK(grid.lx > 0 && grid.ly > 0 && grid.lz > 0, "box size must be positive");
+  // the minimum image is only the nearest image below half a box
+  TC_CHECK(rp_max < 0.5 * std::min(grid.lx, grid.ly) && pi_max < 0.5 * grid.lz,
+           "the largest separation must be smaller than half the box size");
+  const size_t n_counts =
+      labelled ? (size_t)n_rp * n_labels * n_labels : (size_t)n_rp * n_pi;
+  std::fill(counts, counts + n_counts, (uint64_t)0);
+  if (n1 == 0 || n2 == 0) return TC_OK;
+  if (labelled) {
+    TC_CHECK(label1 != nullptr && label2 != nullptr, "labels are NULL");
+    for (int64_t p = 0; p < n1; ++p)
+      TC_CHECK(label1[p] >= 0 && label1[p] < n_labels, "label of point %lld out of range",
+               (long long)p);
+    if (!autocorr)
+      for (int64_t p = 0; p < n2; ++p)
+        TC_CHECK(label2[p] >= 0 && label2[p] < n_labels, "label of point %lld out of range",
+                 (long long)p);
+  }
+  const int64_t n_max = std::max(n1, n2);
+  grid.nx = cells_along(grid.lx, rp_max, n_max);
+  grid.ny = cells_along(grid.ly, rp_max, n_max);
+  grid.nz = cells_along(grid.lz, pi_max, n_max);
+  grid.reach_x = grid.nx > 1 ? 1 : 0;
+  grid.reach_y = grid.ny > 1 ? 1 : 0;
+  grid.reach_z = grid.nz > 1 ? 1 : 0;
+
+  Range range("pair count");
+  CellSort set1, set2;
+  int status = sort_into_cells(grid, pos1, labelled ? label1 : nullptr, n1, set1);
+  if (status != TC_OK) return status;
+  if (!autocorr) {
+    status = sort_into_cells(grid, pos2, labelled ? label2 : nullptr, n2, set2);
+    if (status != TC_OK) return status;
+  }
+  // work items: up to 256 consecutive set-1 points of one cell
+  std::vector<int32_t> item_cell, item_begin, item_end;
+  for (int c = 0; c < grid.n_cells(); ++c)
+    for (int32_t b = set1.cell_start[c]; b < set1.cell_start[c + 1]; b += kPairThreads) {
+      item_cell.push_back(c);
+      item_begin.push_back(b);
+      item_end.push_back(std::min<int32_t>(b + kPairThreads, set1.cell_start[c + 1]));
+    }
+
+  DeviceArrays device;
+  PairArgs a;
+  status = device.put(set1.x, &a.x1);
+  if (status == TC_OK) status = device.put(set1.y, &a.y1);
+  if (status == TC_OK) status = device.put(set1.z, &a.z1);
+  a.label1 = nullptr;
+  if (status == TC_OK && labelled) status = device.put(set1.label, &a.label1);
+  const CellSort& second = autocorr ? set1 : set2;
+  if (autocorr) {
+    a.x2 = a.x1;
+    a.y2 = a.y1;
+    a.z2 = a.z1;
+    a.label2 = a.label1;
+  } else {
+    if (status == TC_OK) status = device.put(set2.x, &a.x2);
+    if (status == TC_OK) status = device.put(set2.y, &a.y2);
+    if (status == TC_OK) status = device.put(set2.z, &a.z2);
+    a.label2 = nullptr;
+    if (status == TC_OK && labelled) status = device.put(set2.label, &a.label2);
+  }
+  if (status == TC_OK) status = device.put(second.cell_start, &a.cell_start2);
+  if (status == TC_OK) status = device.put(item_cell, &a.item_cell);
+  if (status == TC_OK) status = device.put(item_begin, &a.item_begin);
+  if (status == TC_OK) status = device.put(item_end, &a.item_end);
+  if (status != TC_OK) return status;
+  a.nx = grid.nx;
+  a.ny = grid.ny;
+  a.nz = grid.nz;
+  a.reach_x = grid.reach_x;
+  a.reach_y = grid.reach_y;
+  a.reach_z = grid.reach_z;
+  a.lx = grid.lx;
+  a.ly = grid.ly;
+  a.lz = grid.lz;
+  for (int k = 0; k <= n_rp; ++k) a.edge_sqr[k] = rp_bins[k] * rp_bins[k];
+  a.n_rp = n_rp;
+  a.n_pi = n_pi;
+  a.pi_max = pi_max;
+  a.inv_dpi = (double)n_pi / pi_max;
+  a.n_labels = n_labels;
+  void* d_counts = nullptr;
+  TC_HIP(hipMalloc(&d_counts, n_counts * sizeof(uint64_t)));
+  device.pointers.push_back(d_counts);
+  TC_HIP(hipMemset(d_counts, 0, n_counts * sizeof(uint64_t)));
+  a.counts = (unsigned long long*)d_counts;
+
+  const dim3 grid_dim((unsigned)item_cell.size()), block(kPairThreads);
+  if (labelled) {
+    hipLaunchKernelGGL(pair_count_kernel<true>, grid_dim, block, 0, nullptr, a);
+  } else {
+    const size_t lds = (size_t)n_rp * n_pi * sizeof(unsigned);
+    TC_CHECK(lds <= 48 * 1024, "at most %d (r_p, pi) bins are supported", 48 * 1024 / 4);
+    hipLaunchKernelGGL(pair_count_kernel<false>, grid_dim, block, lds, nullptr, a);
+  }
+  TC_HIP(hipGetLastError());
+  TC_HIP(hipMemcpy(counts, d_counts, n_counts * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return TC_OK;
+}
+
+}  // namespace
+}  // namespace host
+}  // namespace tc
+
+extern "C" {
+
+int tc_pair_count_rppi(const double* pos1, int64_t n1, const double* pos2, int64_t n2,
+                       const double* boxsize, const double* rp_bins, int n_rp, double pi_max,
+                       int n_pi, uint64_t* npairs) {
+  return tc::host::pair_count(pos1, nullptr, n1, pos2, nullptr, n2, 0, boxsize, rp_bins, n_rp,
+                              pi_max, n_pi, npairs);
+}
+
+int tc_pair_count_rppi_labelled(const double* pos1, const int32_t* label1, int64_t n1,
+                                const double* pos2, const int32_t* label2, int64_t n2,
+                                int n_labels, const double* boxsize, const double* rp_bins,
+                                int n_rp, double pi_max, uint64_t* counts) {
+  using tc::host::fail;
+  TC_CHECK(n_labels >= 1 && n_labels <= 4096, "between 1 and 4096 labels are supported");
+  return tc::host::pair_count(pos1, label1, n1, pos2, label2, n2, n_labels, boxsize, rp_bins,
+                              n_rp, pi_max, 1, counts);
+}
+
+}  // extern "C"

@@ -163,11 +163,22 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
     tc::fm::build_tables(math_table.data());
     status = upload(math_table, &t->d_math_table);
   }
-  if (status == TC_OK && mode == TC_MODE_AUTO && compute_dtype == TC_DTYPE_F64) {
+  // The quadratic-form kernel's equal-share schedule walks the matrix once per tile of 32
+  // draws: fine while the matrix stays in the L2s (cfg2 0.8 MB, cfg3 3.2 MB, 25 tables of an
+  // interpolator 21 MB), but a matrix with hundreds of r values (BASELINE configs[4] in
+  // float64: 38 r tiles, 155 MB) would be streamed from the Infinity Cache 313 times per
+  // 10^4 draws (measured 8.2 ms against 4.9 ms for the segment kernel, whose workgroups
+  // share their matrix slice).  Such tables stay on the segment kernel.
+  const tc::QuadTiling quad_tiling = tc::quad_tiling(n_r);
+  const double quad_blocks = (n_bins / 4.0 + 1.0) * (n_bins / 4.0 + 2.0) / 2.0;
+  const double quad_bytes =
+      quad_blocks * ((quad_tiling.n_u + 1) / 2) * 1024.0 * quad_tiling.n_rtiles;
+  if (status == TC_OK && mode == TC_MODE_AUTO && compute_dtype == TC_DTYPE_F64 &&
+      quad_bytes <= 32.0 * 1024 * 1024) {
     // quadratic-form kernel: the matrix by galaxy type and, when the centrals do not fill
     // whole 4 x 4 blocks, the unpadded triangle for the total prediction
     t->quad = true;
-    t->quad_tiling = tc::quad_tiling(n_r);
+    t->quad_tiling = quad_tiling;
     status = build_quad_table(t.get(), true, tpcf_matrix, matrix_dtype, &t->quad_by_type);
     const int n_central = t->plan.n_central;
     if (status == TC_OK && n_central % 4 != 0 && n_central < n_bins)

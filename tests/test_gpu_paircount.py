@@ -1,0 +1,135 @@
+"""GPU pair counting (tabcorr_amd/csrc/paircount.hip through the C ABI) against the
+brute-force oracle (oracle/paircount_oracle.py): integer counts, so the bar is bit-exact.
+Seeded point sets: uniform and strongly clustered, cubic and non-cubic boxes, grids with one
+cell in a dimension, points on the box faces, auto / cross / labelled counts, and the
+tabulation wrappers of tabcorr/corrfunc.py:6-95 and tabcorr/tabcorr.py:846-922."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+
+pytestmark = pytest.mark.gpu
+
+
+def clustered(rng, n, box, n_centres=40, scale=1.5):
+    centres = rng.uniform(0, 1, (n_centres, 3)) * box
+    pos = centres[rng.integers(0, n_centres, n)] + rng.normal(0, scale, (n, 3))
+    return np.mod(pos, box)
+
+
+@pytest.mark.parametrize('case', ['uniform', 'clustered', 'flat box', 'faces'])
+def test_pair_counts_are_exact(case):
+    from tabcorr_amd import corrfunc
+    from oracle import paircount_oracle as oracle
+    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    box = np.array([120.0, 120.0, 120.0])
+    rp_bins = np.logspace(-1, np.log10(25.0), 13)
+    pi_max = 40.0
+    if case == 'uniform':
+        pos1, pos2 = rng.uniform(0, 1, (5000, 3)) * box, rng.uniform(0, 1, (3000, 3)) * box
+    elif case == 'clustered':
+        pos1, pos2 = clustered(rng, 6000, box), clustered(rng, 2500, box)
+    elif case == 'flat box':
+        # fewer than three cells along y and z: one cell there, minimum image only
+        box = np.array([200.0, 60.0, 90.0])
+        pos1, pos2 = clustered(rng, 4000, box, 25), rng.uniform(0, 1, (2000, 3)) * box
+    else:
+        pos1 = rng.uniform(0, 1, (3000, 3)) * box
+        pos1[:500, 0] = 0.0
+        pos1[500:1000, 1] = box[1]          # exactly on the upper face
+        pos1[1000:1500, 2] = 0.0
+        pos1[1500:1600] = pos1[1400:1500]   # duplicates: separation exactly 0
+        pos2 = pos1[::3] + 0.0
+    for a, b in ((pos1, None), (pos1, pos2), (pos2, pos1)):
+        got = corrfunc.pair_count_rppi(a, rp_bins, pi_max, b, box)
+        expect = oracle.pair_count_rppi(a, b, box, rp_bins, pi_max)
+        assert got.dtype == np.uint64 and got.shape == (12, 40)
+        assert np.array_equal(got, expect), (case, int(np.abs(
+            got.astype(np.int64) - expect.astype(np.int64)).sum()))
+    # first edge 0: self pairs and exact duplicates count
+    edges0 = np.array([0.0, 0.5, 2.0, 10.0])
+    assert np.array_equal(corrfunc.pair_count_rppi(pos1, edges0, 5.0, None, box, n_pi=3),
+                          oracle.pair_count_rppi(pos1, None, box, edges0, 5.0, 3))
+
+
+def test_empty_and_tiny_samples_and_errors():
+    from tabcorr_amd import corrfunc
+    box = 50.0
+    rp_bins = np.array([1.0, 2.0, 4.0])
+    empty = np.zeros((0, 3))
+    one = np.array([[1.0, 2.0, 3.0]])
+    assert corrfunc.pair_count_rppi(empty, rp_bins, 5.0, None, box).sum() == 0
+    assert corrfunc.pair_count_rppi(one, rp_bins, 5.0, None, box).sum() == 0
+    assert corrfunc.pair_count_rppi(one, rp_bins, 5.0, empty, box).sum() == 0
+    two = np.array([[1.0, 2.0, 3.0], [2.5, 2.0, 49.5]])     # rp = 1.5, dz = 3.5 (wrapped)
+    assert corrfunc.pair_count_rppi(two, rp_bins, 5.0, None, box)[:, 3].tolist() == [2, 0]
+    with pytest.raises(ValueError, match='half the box'):
+        corrfunc.pair_count_rppi(two, np.array([1.0, 30.0]), 5.0, None, box)
+    with pytest.raises(ValueError, match='outside'):
+        corrfunc.pair_count_rppi(two + 60.0, rp_bins, 5.0, None, box)
+    with pytest.raises(ValueError, match='increasing'):
+        corrfunc.pair_count_rppi(two, np.array([2.0, 1.0]), 5.0, None, box)
+    with pytest.raises(ValueError):
+        corrfunc.wp(two, rp_bins, 5.0, period=box, do_auto=False, do_cross=False)
+
+
+def test_wp_and_the_tabulation_matrix():
+    """corrfunc.wp and compute_tpcf_matrix against the reference's loop structure run with
+    the brute-force counter: identical counts, identical arithmetic -> identical floats."""
+    from tabcorr_amd import corrfunc
+    from oracle import paircount_oracle as oracle
+    rng = np.random.default_rng(77)
+    box = 150.0
+    rp_bins = np.logspace(-1, 1.3, 11)
+    pi_max = 40.0
+    halos = clustered(rng, 7000, np.full(3, box), 60, 2.0)
+    # halo bins of very different sizes, one of them empty (tabcorr.py:888 skips it)
+    cuts = [0, 40, 40, 400, 1500, 3500, 7000]
+    pos = [halos[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    matrix, shape = corrfunc.compute_tpcf_matrix('auto', pos, box, rp_bins, pi_max)
+    expect, expect_shape = oracle.compute_tpcf_matrix_wp('auto', pos, box, rp_bins, pi_max)
+    assert shape == expect_shape == (10, )
+    assert np.array_equal(matrix, expect)
+    assert np.all(matrix[:, 1] == 0)
+    particles = rng.uniform(0, box, (4000, 3))
+    cross, _ = corrfunc.compute_tpcf_matrix('cross', pos, box, rp_bins, pi_max,
+                                            sample2=particles)
+    expect, _ = oracle.compute_tpcf_matrix_wp('cross', pos, box, rp_bins, pi_max,
+                                              sample2=particles)
+    assert np.array_equal(cross, expect)
+    # the single-pair entry point, as TabCorr.tabulate would call it through the pool
+    assert np.array_equal(corrfunc.wp(pos[3], rp_bins, pi_max, period=box), matrix[:, 3, 3])
+    assert np.array_equal(
+        corrfunc.wp(pos[2], rp_bins, pi_max, sample2=pos[4], period=box, do_auto=False,
+                    do_cross=True), matrix[:, 2, 4])
+
+
+def test_labelled_counts_at_tabulation_scale():
+    """2 x 10^5 halos in 100 bins (the shape of BASELINE configs[1]'s table): properties that
+    do not need the O(N^2) oracle -- symmetry, even diagonal, the sum over bin pairs equals
+    the unlabelled count, invariance under a relabelling -- plus the oracle on a sub-box."""
+    from tabcorr_amd import corrfunc
+    rng = np.random.default_rng(3)
+    box = 250.0
+    n = 200000
+    pos = clustered(rng, n, np.full(3, box), 3000, 3.0)
+    label = rng.integers(0, 100, n)
+    rp_bins = np.logspace(-1, np.log10(30.0), 20)
+    order = np.argsort(label, kind='stable')
+    bins = np.split(pos[order], np.cumsum(np.bincount(label, minlength=100))[:-1])
+    counts = corrfunc.pair_count_matrix(bins, rp_bins, 40.0, box)
+    assert counts.shape == (19, 100, 100)
+    assert np.array_equal(counts, counts.transpose(0, 2, 1))
+    diagonal = counts[:, np.arange(100), np.arange(100)]
+    assert np.all(diagonal % 2 == 0)
+    total = corrfunc.pair_count_rppi(pos, rp_bins, 40.0, None, box).sum(axis=1)
+    assert np.array_equal(counts.sum(axis=(1, 2)), total)
+    assert total.sum() > 1e7
+    # merging bins adds their blocks
+    merged = [np.concatenate(bins[2 * k:2 * k + 2]) for k in range(50)]
+    coarse = corrfunc.pair_count_matrix(merged, rp_bins, 40.0, box)
+    assert np.array_equal(coarse, counts.reshape(19, 50, 2, 50, 2).sum(axis=(2, 4)))

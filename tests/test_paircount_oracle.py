@@ -1,0 +1,87 @@
+"""CPU tests of the pair-count oracle (oracle/paircount_oracle.py): known answers on
+hand-made point sets, invariants of the counts, and the wrapper arithmetic of
+tabcorr/corrfunc.py:6-95 / tabcorr/tabcorr.py:846-922."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+from oracle import paircount_oracle as oracle  # noqa: E402
+
+
+def test_known_answers_on_hand_made_points():
+    box = (10.0, 10.0, 10.0)
+    rp_bins = np.array([0.5, 1.5, 3.0])
+    # two points 1 apart in x, 0.2 apart in z; a third one across the periodic boundary
+    pos = np.array([[1.0, 1.0, 1.0], [2.0, 1.0, 1.2], [9.5, 1.0, 9.9]])
+    counts = oracle.pair_count_rppi(pos, None, box, rp_bins, pi_max=2.0, n_pi=2)
+    # pairs (ordered): 0-1: rp = 1, dz = 0.2 -> bin (0, 0), twice;
+    # 0-2: dx = 1.5 (wrapped), dz = 1.1 (wrapped) -> rp bin 1, pi bin 1, twice;
+    # 1-2: dx = 2.5, dz = 1.3 -> rp bin 1, pi bin 1, twice
+    expect = np.array([[2, 0], [0, 4]], dtype=np.uint64)
+    assert np.array_equal(counts, expect)
+    # self pairs only when the first edge is 0
+    counts0 = oracle.pair_count_rppi(pos, None, box, np.array([0.0, 1.5, 3.0]), 2.0, 2)
+    assert counts0[0, 0] == 2 + 3
+    # pimax cuts: dz = 1.1 and 1.3 fall out
+    assert oracle.pair_count_rppi(pos, None, box, rp_bins, 1.0, 1).sum() == 2
+    # edges are half-open: rp exactly on an inner edge goes up, on the last edge out
+    pos = np.array([[0.0, 0.0, 5.0], [1.5, 0.0, 5.0], [3.0, 0.0, 5.0]])
+    counts = oracle.pair_count_rppi(pos, None, box, rp_bins, 1.0, 1)
+    assert counts[:, 0].tolist() == [0, 4]          # 0-1 and 1-2 at rp = 1.5; 0-2 at 3.0 out
+
+
+def test_count_invariants():
+    rng = np.random.default_rng(5)
+    box = np.array([40.0, 50.0, 60.0])
+    pos1 = rng.uniform(0, 1, (300, 3)) * box
+    pos2 = rng.uniform(0, 1, (200, 3)) * box
+    rp_bins = np.logspace(-0.5, 1.0, 8)
+    auto = oracle.pair_count_rppi(pos1, None, box, rp_bins, 12.0)
+    assert auto.shape == (7, 12) and np.all(auto % 2 == 0)          # every pair twice
+    cross = oracle.pair_count_rppi(pos1, pos2, box, rp_bins, 12.0)
+    swapped = oracle.pair_count_rppi(pos2, pos1, box, rp_bins, 12.0)
+    assert np.array_equal(cross, swapped)
+    # a rigid shift through the periodic boundary moves no pair across an edge here
+    shifted = (pos1 + np.array([17.0, 33.0, 41.0])) % box
+    assert np.abs(oracle.pair_count_rppi(shifted, None, box, rp_bins, 12.0).astype(int)
+                  - auto.astype(int)).sum() <= 4
+    # labelled counts: the bin-pair blocks are the pair counts of the sub-samples
+    label = rng.integers(0, 4, len(pos1))
+    matrix = oracle.pair_count_rppi(pos1, None, box, rp_bins, 12.0, label1=label,
+                                    n_labels=4)
+    assert matrix.shape == (7, 4, 4)
+    assert np.array_equal(matrix, matrix.transpose(0, 2, 1))
+    assert np.array_equal(matrix.sum(axis=(1, 2)), auto.sum(axis=1))
+    for a in range(4):
+        for b in range(4):
+            sub = oracle.pair_count_rppi(pos1[label == a], None if a == b else pos1[label == b],
+                                         box, rp_bins, 12.0)
+            assert np.array_equal(sub.sum(axis=1), matrix[:, a, b])
+
+
+def test_wp_of_a_poisson_sample_is_zero_and_matrix_matches_pairwise_calls():
+    rng = np.random.default_rng(11)
+    box = 100.0
+    pos = rng.uniform(0, box, (3000, 3))
+    rp_bins = np.array([2.0, 5.0, 10.0, 20.0])
+    wp = oracle.wp(pos, rp_bins, 20.0, period=box)
+    # (npairs / n_exp - 1) 2 pi_max with ~1e4 .. 2e5 pairs per bin
+    assert np.all(np.abs(wp) < 40.0 * 5.0 / np.sqrt(3000 * 3000 / box**3 * np.pi *
+                                                   np.diff(rp_bins**2) * 40.0))
+    with pytest.raises(ValueError):
+        oracle.wp(pos, rp_bins, 20.0, period=box, do_auto=True, do_cross=True)
+    bins = [pos[:100], pos[100:100], pos[100:700], pos[700:1000]]      # one empty bin
+    matrix, shape = oracle.compute_tpcf_matrix_wp('auto', bins, box, rp_bins, 20.0)
+    assert shape == (3, ) and matrix.shape == (3, 4, 4)
+    assert np.all(matrix[:, 1, :] == 0) and np.all(matrix[:, :, 1] == 0)
+    assert np.array_equal(matrix, matrix.transpose(0, 2, 1))
+    assert np.array_equal(matrix[:, 2, 2], oracle.wp(bins[2], rp_bins, 20.0, period=box))
+    assert np.array_equal(matrix[:, 0, 3], oracle.wp(bins[0], rp_bins, 20.0, sample2=bins[3],
+                                                    period=box, do_auto=False, do_cross=True))
+    cross, _ = oracle.compute_tpcf_matrix_wp('cross', bins, box, rp_bins, 20.0,
+                                             sample2=pos[1000:])
+    assert cross.shape == (3, 4) and np.all(cross[:, 1] == 0)
