@@ -742,6 +742,7 @@ __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_kern
 // One block per 64 draws (two 32-draw tiles, each with its own slab lists).
 __global__ __launch_bounds__(1024) void finalize_quad_kernel(FinalizeQuadArgs a) {
   __shared__ double tile[kFinalizeRows][kLanes + 1];
+  __shared__ double part_sum[16][kLanes];
   __shared__ double norm_inv[kLanes];
   set_priority(a.priority);
   const int lane = threadIdx.x & 63;
@@ -769,6 +770,11 @@ __global__ __launch_bounds__(1024) void finalize_quad_kernel(FinalizeQuadArgs a)
   }
   __syncthreads();
   const double norm = norm_inv[lane];
+  // Separated by galaxy type the reference forms every term / sum first and masks
+  // afterwards (tabcorr.py:653-681): with a non-finite sum some term is inf / inf = NaN
+  // and NaN x False = NaN reaches every component.
+  const bool poisoned = a.n_comp > 1 && !(fabs(norm) <= 1.79769313486231570815e308);
+  auto normalise = [&](double sum) { return poisoned ? __builtin_nan("") : sum / norm; };
 
   const int n_rows = a.n_comp * a.n_r;
   const int n_waves = blockDim.x >> 6;
@@ -777,12 +783,16 @@ __global__ __launch_bounds__(1024) void finalize_quad_kernel(FinalizeQuadArgs a)
   const int row_end = row_begin + rows_per_block < n_rows ? row_begin + rows_per_block : n_rows;
   const int64_t tile32 = (int64_t)blockIdx.x * 2 + (lane >> 5);
   const int64_t slab_stride = (int64_t)a.rt * kQuadTile;
-  auto sum_slabs = [&](int row) {
+  // sum of part `part` of `parts` equal ranges of a row's slabs, eight independent loads
+  // in flight, the additions in slab order
+  auto sum_slabs = [&](int row, int part, int parts) {
     const int comp = row / a.n_r, r = row % a.n_r;
     const int rtile = r / a.r_per_tile, r_local = r % a.r_per_tile;
     const int64_t group = (tile32 * a.n_rtiles + rtile) * a.groups_per_rtile +
                           (a.groups_per_rtile > 1 ? comp : 0);
-    const int begin = a.group_begin[group], end = a.group_begin[group + 1];
+    const int first = a.group_begin[group], count = a.group_begin[group + 1] - first;
+    const int begin = first + (int)((int64_t)count * part / parts);
+    const int end = first + (int)((int64_t)count * (part + 1) / parts);
     const double* src = a.partial + ((int64_t)begin * a.rt + r_local) * kQuadTile + (lane & 31);
     double sum = 0.0;
     for (int s0 = begin; s0 < end; s0 += 8) {
@@ -796,7 +806,23 @@ __global__ __launch_bounds__(1024) void finalize_quad_kernel(FinalizeQuadArgs a)
   };
   for (int row0 = row_begin; row0 < row_end; row0 += kFinalizeRows) {
     const int rows = row_end - row0 < kFinalizeRows ? row_end - row0 : kFinalizeRows;
-    for (int rr = wave; rr < rows; rr += n_waves) tile[rr][lane] = sum_slabs(row0 + rr) / norm;
+    if (rows * 2 <= n_waves) {
+      // few rows (small batches, split over row blocks; an un-batched interpolator call
+      // leaves ~1000 slabs per row): several waves per row, each over a contiguous range
+      // of slabs, combined in fixed order
+      const int parts = n_waves / rows;
+      const int rr = wave / parts, part = wave % parts;
+      if (rr < rows) part_sum[wave][lane] = sum_slabs(row0 + rr, part, parts);
+      __syncthreads();
+      if (wave < rows) {
+        double sum = 0.0;
+        for (int p = 0; p < parts; ++p) sum += part_sum[wave * parts + p][lane];
+        tile[wave][lane] = normalise(sum);
+      }
+    } else {
+      for (int rr = wave; rr < rows; rr += n_waves)
+        tile[rr][lane] = normalise(sum_slabs(row0 + rr, 0, 1));
+    }
     __syncthreads();
     for (int idx = threadIdx.x; idx < rows * kLanes; idx += blockDim.x) {
       const int d = idx / rows, rr = idx % rows;
@@ -1147,7 +1173,11 @@ __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
     }
   }
   __syncthreads();
-  const double norm = norm_inv[lane];
+  // (separated by galaxy type a non-finite sum poisons every component: see
+  // finalize_quad_kernel)
+  const double norm = a.n_comp > 1 && !(fabs(norm_inv[lane]) <= 1.79769313486231570815e308)
+                          ? __builtin_nan("")
+                          : norm_inv[lane];
 
   const int n_rows = a.n_comp * a.n_r;
   const int n_waves = blockDim.x >> 6;
