@@ -127,7 +127,7 @@ struct QuadArgs {
   uint32_t rtile_bytes;            // bytes of one r tile of a table
   const QuadRun* runs;
   const QuadCompArgs* comps;
-  const int32_t* wave_runs;        // (n_waves + 1)
+  const int32_t* wave_runs;        // (n_waves, 2): first run and end run of every wave
   int n_waves;
   int priority;                    // wave priority (0..3)
   double* partial;                 // (n_slabs, 4 U, 32)

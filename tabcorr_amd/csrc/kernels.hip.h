@@ -250,7 +250,10 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
         if ((bad & kTieCen) && (central || modulate))
           for (int k = 0; k < n_gauss; ++k) tie = tie || log_m[g * n_gauss + k] == log_m_min;
         const bool cen_nan = (bad & kBadCen) || tie;
-        if (!central && (bad & kInfSat) && acc != 0.0) acc = __builtin_huge_val();
+        if (!central && (bad & kInfSat) && acc != 0.0) {
+          // (decorated: the shift limit is inf - inf = NaN in the reference's arithmetic)
+          acc = assembias ? __builtin_nan("") : __builtin_huge_val();
+        }
         if (central ? cen_nan : (((bad & kBadSat) && acc != 0.0) || (modulate && cen_nan)))
           acc = __builtin_nan("");
       }
@@ -602,7 +605,7 @@ __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_kern
   sc_i32 wave_runs = (sc_i32)a.wave_runs;
   sc_i32 runs = (sc_i32)a.runs;       // QuadRun = 8 x int32
   sc_i32 comps = (sc_i32)a.comps;     // QuadCompArgs = 8 x int32
-  const int run_begin = wave_runs[wave], run_end = wave_runs[wave + 1];
+  const int run_begin = wave_runs[2 * wave], run_end = wave_runs[2 * wave + 1];
   const int c = lane & 15, kq = lane >> 4;
   const unsigned row_bytes = (unsigned)(a.ldb * 8);
   const unsigned off_a = lane * 16;                    // table: (unit, u pair, lane) x 16 B
@@ -898,7 +901,9 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
     }
     if (d.bad) {   // (prepare_draw: parameters the fast path cannot represent)
       const bool cen_nan = (d.bad & kBadCen) || ((d.bad & kTieCen) && lm == log_m_min);
-      if (g >= a.n_central && (d.bad & kInfSat) && n != 0.0) n = __builtin_huge_val();
+      if (g >= a.n_central && (d.bad & kInfSat) && n != 0.0) {
+        n = assembias ? __builtin_nan("") : __builtin_huge_val();
+      }
       if (g < a.n_central ? cen_nan
                           : (((d.bad & kBadSat) && n != 0.0) || (modulate && cen_nan)))
         n = __builtin_nan("");

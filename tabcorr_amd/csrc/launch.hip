@@ -244,7 +244,29 @@ int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, 
   d->n_groups = schedule.n_groups;
   d->n_runs = (int)schedule.runs.size();
   int status = upload(schedule.runs, &d->runs);
-  if (status == TC_OK) status = upload(schedule.wave_runs, &d->wave_runs);
+  // The k-th share of the unit space goes to a wave on XCD k * 8 / n_waves: workgroup b
+  // runs on XCD b % 8 and each XCD has its own L2, so the waves that walk one draw tile
+  // (consecutive shares) read its density rows through ONE L2 instead of eight.  Per wave
+  // the kernel gets [first run, end run).
+  std::vector<int32_t> wave_range((size_t)schedule.n_waves * 2);
+  {
+    const int per_block = tc::kQuadWavesPerBlock;
+    const int n_blocks = schedule.n_waves / per_block;
+    const bool by_xcd = t->n_xcds == 8 && schedule.n_waves % (8 * per_block) == 0;
+    for (int share = 0; share < schedule.n_waves; ++share) {
+      int wave = share;
+      if (by_xcd) {
+        const int per_xcd = schedule.n_waves / 8;
+        const int xcd = share / per_xcd, local = share % per_xcd;
+        const int block = xcd + 8 * (local / per_block);
+        wave = block * per_block + local % per_block;
+        (void)n_blocks;
+      }
+      wave_range[2 * (size_t)wave] = schedule.wave_runs[share];
+      wave_range[2 * (size_t)wave + 1] = schedule.wave_runs[share + 1];
+    }
+  }
+  if (status == TC_OK) status = upload(wave_range, &d->wave_runs);
   if (status == TC_OK) status = upload(schedule.group_begin, &d->group_begin);
   if (status != TC_OK) {
     for (void* p : {d->runs, d->wave_runs, d->group_begin})
