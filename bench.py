@@ -209,6 +209,8 @@ def main():
     parser.add_argument('--lanes', type=int, default=0,
                         help='pipelining lanes of the timed region (default: library '
                              'default, 4); 1 serialises the kernels, e.g. under rocprofv3')
+    parser.add_argument('--settle-seconds', type=float, default=0.3,
+                        help='untimed load before the warm-up steps (power management)')
     parser.add_argument('--cpu-seconds', type=float, default=12.0,
                         help='budget of the CPU baseline sample (0: skip)')
     parser.add_argument('--cpu-all-cores', type=int, default=1,
@@ -347,6 +349,25 @@ def main():
         comm.synchronize()
         _lib.check(lib.tc_device_synchronize())
 
+    # Untimed: load the chip until its power management has settled (tools/ramp.py: a
+    # region started from idle runs 10-20 % slower for the first tens of milliseconds),
+    # then the W warm-up steps.  The driver's short runs (--steps 20) would otherwise time
+    # the ramp, not the path.
+    settle_steps = 0
+    if args.settle_seconds > 0:
+        probe = 100 if not interp_mode else 5
+        t_probe = time.perf_counter()
+        for index in range(probe):
+            step(index)
+        flush(probe)
+        drain()
+        per_step = max((time.perf_counter() - t_probe) / probe, 1e-6)
+        settle_steps = int(args.settle_seconds / per_step) + 1
+        for index in range(settle_steps):
+            step(index)
+        flush(settle_steps)
+        drain()
+        settle_steps += probe
     for index in range(args.warmup):
         step(index)
     flush(args.warmup)
@@ -433,6 +454,7 @@ def main():
             'n_gpus': comm.world_size,
             'steps': args.steps,
             'warmup': args.warmup,
+            'settle_steps': settle_steps,
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True,
             'scaling': 'strong' if interp_mode else 'weak',

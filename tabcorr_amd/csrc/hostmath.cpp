@@ -596,4 +596,64 @@ void build_chunking(const Plan& plan, int n_chunks, int waves_per_group,
   }
 }
 
+// ---- pair counting: cell grid ----------------------------------------------------------------
+
+namespace {
+int cells_along(double box, double reach, int64_t n_points) {
+  // no more cells than the points warrant (about 8 points per cell at least), at most 256
+  int n = (int)std::floor(box / reach);
+  const int cap =
+      (int)std::max<double>(1.0, std::cbrt((double)std::max<int64_t>(n_points, 1) / 8.0));
+  n = std::min(n, std::max(cap, 3));
+  n = std::min(n, 256);
+  return n < 3 ? 1 : n;
+}
+}  // namespace
+
+CellGrid make_cell_grid(const double* boxsize, double reach_xy, double reach_z,
+                        int64_t n_points) {
+  CellGrid grid;
+  grid.lx = boxsize[0];
+  grid.ly = boxsize[1];
+  grid.lz = boxsize[2];
+  grid.nx = cells_along(grid.lx, reach_xy, n_points);
+  grid.ny = cells_along(grid.ly, reach_xy, n_points);
+  grid.nz = cells_along(grid.lz, reach_z, n_points);
+  grid.reach_x = grid.nx > 1 ? 1 : 0;
+  grid.reach_y = grid.ny > 1 ? 1 : 0;
+  grid.reach_z = grid.nz > 1 ? 1 : 0;
+  return grid;
+}
+
+int64_t sort_into_cells(const CellGrid& grid, const double* pos, const int32_t* label,
+                        int64_t n, CellSort& out) {
+  std::vector<int32_t> cell((size_t)n);
+  out.cell_start.assign((size_t)grid.n_cells() + 1, 0);
+  for (int64_t p = 0; p < n; ++p) {
+    const double x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
+    if (!(x >= 0.0 && x <= grid.lx && y >= 0.0 && y <= grid.ly && z >= 0.0 && z <= grid.lz))
+      return p;
+    const int cx = std::min(grid.nx - 1, (int)(x / grid.lx * grid.nx));
+    const int cy = std::min(grid.ny - 1, (int)(y / grid.ly * grid.ny));
+    const int cz = std::min(grid.nz - 1, (int)(z / grid.lz * grid.nz));
+    cell[p] = (cx * grid.ny + cy) * grid.nz + cz;
+    ++out.cell_start[cell[p] + 1];
+  }
+  for (int c = 0; c < grid.n_cells(); ++c) out.cell_start[c + 1] += out.cell_start[c];
+  std::vector<int32_t> cursor(out.cell_start.begin(), out.cell_start.end() - 1);
+  out.x.resize(n);
+  out.y.resize(n);
+  out.z.resize(n);
+  out.label.clear();
+  if (label != nullptr) out.label.resize(n);
+  for (int64_t p = 0; p < n; ++p) {
+    const int32_t slot = cursor[cell[p]]++;
+    out.x[slot] = pos[3 * p];
+    out.y[slot] = pos[3 * p + 1];
+    out.z[slot] = pos[3 * p + 2];
+    if (label != nullptr) out.label[slot] = label[p];
+  }
+  return -1;
+}
+
 }  // namespace tc

@@ -199,6 +199,29 @@ void quad_emulate(const QuadLayout& layout, const QuadSchedule& schedule,
                   const double* densities, int64_t ldb, int64_t n_draws, int n_r,
                   bool separate, double* out);
 
+// ---- pair counting (paircount.hip): cell grid of a periodic box ----------------------------
+//
+// Cells at least `reach` wide, so that the partners of a point lie in the 27 cells around
+// its own; a dimension that cannot hold three such cells gets ONE cell and no neighbour
+// offsets (the minimum image does the wrapping there).
+struct CellGrid {
+  int nx = 1, ny = 1, nz = 1;
+  int reach_x = 0, reach_y = 0, reach_z = 0;   // neighbour offsets per dimension: 1 or 0
+  double lx = 0, ly = 0, lz = 0;               // box size
+  int n_cells() const { return nx * ny * nz; }
+};
+CellGrid make_cell_grid(const double* boxsize, double reach_xy, double reach_z,
+                        int64_t n_points);
+
+// Points of one set sorted by cell (counting sort): coordinates, labels (if given) and the
+// cell offsets.  Returns -1, or the index of the first point outside [0, box].
+struct CellSort {
+  std::vector<double> x, y, z;
+  std::vector<int32_t> label, cell_start;   // cell_start: n_cells + 1
+};
+int64_t sort_into_cells(const CellGrid& grid, const double* pos, const int32_t* label,
+                        int64_t n, CellSort& out);
+
 // Position order inside a segment: j -> j + 1, wrapping to (i + 1, j_lo) after column
 // `j_last` (rectangle) or after the diagonal (j_last < 0).
 inline void advance_pair(int j_lo, int j_last, int& i, int& j) {

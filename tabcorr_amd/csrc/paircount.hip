@@ -145,61 +145,6 @@ namespace host {
 
 namespace {
 
-// Points of one set sorted by cell.
-struct CellSort {
-  std::vector<double> x, y, z;
-  std::vector<int32_t> label, cell_start;
-};
-
-struct Grid {
-  int nx = 1, ny = 1, nz = 1;
-  int reach_x = 0, reach_y = 0, reach_z = 0;
-  double lx = 0, ly = 0, lz = 0;
-  int n_cells() const { return nx * ny * nz; }
-};
-
-int cells_along(double box, double reach, int64_t n_points) {
-  // cells at least `reach` wide; fewer than three cells cannot tell a cell from its
-  // periodic image, so such a dimension gets one cell.  No more cells than the points
-  // warrant (about 8 points per cell at least).
-  int n = (int)std::floor(box / reach);
-  const int cap = (int)std::max<double>(1.0, std::cbrt((double)std::max<int64_t>(n_points, 1) / 8.0));
-  n = std::min(n, std::max(cap, 3));
-  n = std::min(n, 256);
-  return n < 3 ? 1 : n;
-}
-
-int sort_into_cells(const Grid& grid, const double* pos, const int32_t* label, int64_t n,
-                    CellSort& out) {
-  std::vector<int32_t> cell((size_t)n);
-  out.cell_start.assign((size_t)grid.n_cells() + 1, 0);
-  for (int64_t p = 0; p < n; ++p) {
-    const double x = pos[3 * p], y = pos[3 * p + 1], z = pos[3 * p + 2];
-    if (!(x >= 0.0 && x <= grid.lx && y >= 0.0 && y <= grid.ly && z >= 0.0 && z <= grid.lz))
-      return fail(TC_ERR_INVALID, "point %lld lies outside of the periodic box",
-                  (long long)p);
-    const int cx = std::min(grid.nx - 1, (int)(x / grid.lx * grid.nx));
-    const int cy = std::min(grid.ny - 1, (int)(y / grid.ly * grid.ny));
-    const int cz = std::min(grid.nz - 1, (int)(z / grid.lz * grid.nz));
-    cell[p] = (cx * grid.ny + cy) * grid.nz + cz;
-    ++out.cell_start[cell[p] + 1];
-  }
-  for (int c = 0; c < grid.n_cells(); ++c) out.cell_start[c + 1] += out.cell_start[c];
-  std::vector<int32_t> cursor(out.cell_start.begin(), out.cell_start.end() - 1);
-  out.x.resize(n);
-  out.y.resize(n);
-  out.z.resize(n);
-  if (label != nullptr) out.label.resize(n);
-  for (int64_t p = 0; p < n; ++p) {
-    const int32_t slot = cursor[cell[p]]++;
-    out.x[slot] = pos[3 * p];
-    out.y[slot] = pos[3 * p + 1];
-    out.z[slot] = pos[3 * p + 2];
-    if (label != nullptr) out.label[slot] = label[p];
-  }
-  return TC_OK;
-}
-
 struct DeviceArrays {
   std::vector<void*> pointers;
   ~DeviceArrays() {
@@ -236,14 +181,10 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
     label2 = label1;
     n2 = n1;
   }
-  Grid grid;
-  grid.lx = boxsize[0];
-  grid.ly = boxsize[1];
-  grid.lz = boxsize[2];
   const double rp_max = rp_bins[n_rp];
-  TC_CHECK(grid.lx > 0 && grid.ly > 0 && grid.lz > 0, "box size must be positive");
+  TC_CHECK(boxsize[0] > 0 && boxsize[1] > 0 && boxsize[2] > 0, "box size must be positive");
   // the minimum image is only the nearest image below half a box
-  TC_CHECK(rp_max < 0.5 * std::min(grid.lx, grid.ly) && pi_max < 0.5 * grid.lz,
+  TC_CHECK(rp_max < 0.5 * std::min(boxsize[0], boxsize[1]) && pi_max < 0.5 * boxsize[2],
            "the largest separation must be smaller than half the box size");
   const size_t n_counts =
       labelled ? (size_t)n_rp * n_labels * n_labels : (size_t)n_rp * n_pi;
@@ -259,21 +200,17 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
         TC_CHECK(label2[p] >= 0 && label2[p] < n_labels, "label of point %lld out of range",
                  (long long)p);
   }
-  const int64_t n_max = std::max(n1, n2);
-  grid.nx = cells_along(grid.lx, rp_max, n_max);
-  grid.ny = cells_along(grid.ly, rp_max, n_max);
-  grid.nz = cells_along(grid.lz, pi_max, n_max);
-  grid.reach_x = grid.nx > 1 ? 1 : 0;
-  grid.reach_y = grid.ny > 1 ? 1 : 0;
-  grid.reach_z = grid.nz > 1 ? 1 : 0;
+  const CellGrid grid = make_cell_grid(boxsize, rp_max, pi_max, std::max(n1, n2));
 
   Range range("pair count");
   CellSort set1, set2;
-  int status = sort_into_cells(grid, pos1, labelled ? label1 : nullptr, n1, set1);
-  if (status != TC_OK) return status;
+  int64_t outside = sort_into_cells(grid, pos1, labelled ? label1 : nullptr, n1, set1);
+  TC_CHECK(outside < 0, "point %lld of the first sample lies outside of the periodic box",
+           (long long)outside);
   if (!autocorr) {
-    status = sort_into_cells(grid, pos2, labelled ? label2 : nullptr, n2, set2);
-    if (status != TC_OK) return status;
+    outside = sort_into_cells(grid, pos2, labelled ? label2 : nullptr, n2, set2);
+    TC_CHECK(outside < 0, "point %lld of the second sample lies outside of the periodic box",
+             (long long)outside);
   }
   // work items: up to 256 consecutive set-1 points of one cell
   std::vector<int32_t> item_cell, item_begin, item_end;
@@ -286,7 +223,7 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
 
   DeviceArrays device;
   PairArgs a;
-  status = device.put(set1.x, &a.x1);
+  int status = device.put(set1.x, &a.x1);
   if (status == TC_OK) status = device.put(set1.y, &a.y1);
   if (status == TC_OK) status = device.put(set1.z, &a.z1);
   a.label1 = nullptr;

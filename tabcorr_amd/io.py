@@ -102,9 +102,13 @@ def read_tabcorr(cls, fname):
     try:
         attrs = {key: _plain(value) for key, value in node.attrs().items()}
         matrix = np.asarray(node.read('tpcf_matrix')).astype(np.float64)
-        args_group = node.group('tpcf_args')
-        args = tuple(args_group.read(key) for key in args_group.keys())
-        args_group.close()
+        # (a table written without positional arguments has no such group; the reference's
+        # reader raises KeyError there -- tabcorr.py:401-404 -- this one returns ())
+        args = ()
+        if 'tpcf_args' in node:
+            args_group = node.group('tpcf_args')
+            args = tuple(args_group.read(key) for key in args_group.keys())
+            args_group.close()
         kwargs = {}
         if 'tpcf_kwargs' in node:
             kwargs_group = node.group('tpcf_kwargs')

@@ -565,3 +565,30 @@ def test_interpolator_param_table_and_nan_range():
     with pytest.raises(ValueError, match='outside of the interpolation'):
         interp._check_range(x, False)
     interp._check_range(x, True)
+
+
+def test_host_logic_under_address_and_undefined_sanitizers(tmp_path):
+    """the library's host logic (planner, schedules, table layouts, spline
+    and quadrature setup, the pair counter's cell sort) built with
+    -fsanitize=address,undefined and run over a sweep of shapes (tools/sanitize)."""
+    import shutil
+    if shutil.which('g++') is None or shutil.which('make') is None:
+        pytest.skip('g++ / make not available')
+    work = tmp_path / 'sanitize'
+    shutil.copytree(os.path.join(REPO, 'tools', 'sanitize'), work,
+                    ignore=shutil.ignore_patterns('host_driver'))
+    makefile = (work / 'Makefile').read_text().replace(
+        'SRC = ../../tabcorr_amd/csrc', 'SRC = ' + os.path.join(REPO, 'tabcorr_amd', 'csrc'))
+    (work / 'Makefile').write_text(makefile)
+    source = (work / 'host_driver.cpp').read_text().replace(
+        '../../tabcorr_amd/csrc', os.path.join(REPO, 'tabcorr_amd', 'csrc'))
+    (work / 'host_driver.cpp').write_text(source)
+    build = subprocess.run(['make', '-C', str(work)], capture_output=True, text=True,
+                           timeout=600)
+    if build.returncode != 0 and 'sanitize' in build.stderr and 'cannot find' in build.stderr:
+        pytest.skip('sanitizer runtime libraries not installed')
+    assert build.returncode == 0, build.stdout + build.stderr
+    run = subprocess.run([str(work / 'host_driver')], capture_output=True, text=True,
+                         timeout=600)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
+    assert 'all checks passed' in run.stdout
