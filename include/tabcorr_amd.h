@@ -49,6 +49,14 @@ extern "C" {
 #define TC_FLAG_MODULATE_WITH_CENOCC 2u /* <N_sat> *= <N_cen> (halotools Zheng07Sats option) */
 #define TC_FLAG_ASSEMBIAS 4u          /* theta carries 2 extra Heaviside assembly-bias strengths */
 #define TC_FLAG_LEGACY_NO_DIST_INDEX 8u /* table without prim_haloprop_dist_index, tabcorr.py:571-574 */
+/* Occupation family of the theta columns (default: Zheng et al. 2007).  With
+ * TC_FLAG_LEAUTHAUD11 every entry point named *_zheng07_* evaluates the Leauthaud et al.
+ * (2011) centrals / satellites on the Behroozi et al. (2010) stellar-to-halo mass relation
+ * instead; theta then has 13 columns: logm0, logm1, beta, delta, gamma (the relation at the
+ * model's redshift), scatter, alphasat, bsat, betasat, bcut, betacut, threshold (log10 of
+ * the stellar mass threshold), littleh.  TC_FLAG_MODULATE_WITH_CENOCC applies as for
+ * Zheng07; TC_FLAG_ASSEMBIAS is not available for this family. */
+#define TC_FLAG_LEAUTHAUD11 16u
 
 typedef struct tc_table tc_table;
 typedef struct tc_interp tc_interp;

@@ -18,7 +18,8 @@ Parity status
   ``tests/test_oracle_golden.py`` against ``tests/golden/*.npz``, which were
   recorded by running the unmodified reference (``tests/golden/make_golden.py``).
 * PARITY UNPINNED: the Zheng07 occupation functions themselves
-  (`zheng07_centrals`, `zheng07_satellites`, `heaviside_assembias`).  In the
+  (`zheng07_centrals`, `zheng07_satellites`, `heaviside_assembias`, and the
+  Leauthaud et al. 2011 family `Leauthaud11`).  In the
   reference they are halotools callbacks (call sites
   ``tabcorr/tabcorr.py:556-563``); halotools (unpinned dependency,
   ``pyproject.toml:12``) is not available, so they restate Zheng et al. (2007)
@@ -120,6 +121,79 @@ class Zheng07:
                                     self.assembias[1], 0.0, np.inf,
                                     self.split)
         return n
+
+
+# -- Leauthaud et al. (2011) family (halotools callbacks; PARITY UNPINNED) ----------
+#
+# Restated from the literature, not from halotools' source: Behroozi, Conroy &
+# Wechsler (2010) eq. 21 for the stellar-to-halo mass relation and Leauthaud et
+# al. (2011) eqs. 8 and 12 for the occupations, with halotools' parameter
+# conventions (knee mass 1e12, littleh = 0.72, scatter sqrt(2) sigma).  halotools
+# inverts the relation by cubic-spline interpolation of a 100-point table; here
+# the inverse is exact (bisection to the last bit), so agreement with halotools
+# is limited by ITS table, and these functions are pinned only against the duck
+# model of ``tests/golden/make_golden.py`` (an independent root finder).
+# theta: logm0, logm1, beta, delta, gamma, scatter, alphasat, bsat, betasat,
+# bcut, betacut, threshold, littleh.
+
+def behroozi10_log_halo_mass(log_stellar_mass, theta):
+    x = log_stellar_mass + 2.0 * np.log10(theta[12]) - theta[0]
+    return (theta[1] + theta[2] * x +
+            10.0**(theta[3] * x) / (1.0 + 10.0**(-theta[4] * x)) - 0.5 -
+            np.log10(theta[12]))
+
+
+def behroozi10_log_stellar_mass(log_halo_mass, theta):
+    """Inverse of `behroozi10_log_halo_mass` by bisection (the relation is
+    increasing for positive beta, delta, gamma)."""
+    log_halo_mass = np.atleast_1d(np.asarray(log_halo_mass, dtype=np.float64))
+    lo = np.full(log_halo_mass.shape, -60.0)
+    hi = np.full(log_halo_mass.shape, 60.0)
+    with np.errstate(all='ignore'):
+        for _ in range(200):
+            mid = 0.5 * (lo + hi)
+            below = behroozi10_log_halo_mass(mid, theta) < log_halo_mass
+            lo = np.where(below, mid, lo)
+            hi = np.where(below, hi, mid)
+    return 0.5 * (lo + hi)
+
+
+class Leauthaud11:
+    """Callbacks with the signature used at ``tabcorr/tabcorr.py:556-563``."""
+
+    def __init__(self, theta, modulate_with_cenocc=True):
+        self.theta = np.asarray(theta, dtype=np.float64)
+        self.modulate_with_cenocc = modulate_with_cenocc
+
+    def mean_occupation_centrals(self, prim_haloprop,
+                                 sec_haloprop_percentile=None):
+        t = self.theta
+        log_mstar = behroozi10_log_stellar_mass(np.log10(prim_haloprop), t)
+        return 0.5 * (1.0 - _erf((t[11] - log_mstar) / (np.sqrt(2.0) * t[5])))
+
+    def mean_occupation_satellites(self, prim_haloprop,
+                                   sec_haloprop_percentile=None):
+        t = self.theta
+        prim_haloprop = np.asarray(prim_haloprop, dtype=np.float64)
+        knee = 10.0**behroozi10_log_halo_mass(t[11], t) * t[12]
+        m_sat = 1e12 * t[7] * (knee / 1e12)**t[8]
+        m_cut = 1e12 * t[9] * (knee / 1e12)**t[10]
+        n = (np.exp(-m_cut / (prim_haloprop * t[12])) *
+             (prim_haloprop * t[12] / m_sat)**t[6])
+        if self.modulate_with_cenocc:
+            n = n * self.mean_occupation_centrals(prim_haloprop)
+        return n
+
+
+def predict_leauthaud11_batch(table, theta, separate_gal_type=False,
+                              n_gauss_prim=10, modulate_with_cenocc=True):
+    """`predict` for a batch of Leauthaud11 parameter vectors (13 columns)."""
+    theta = np.atleast_2d(theta)
+    cache = {}
+    results = [predict(table, mean_occupation(
+        table, Leauthaud11(t, modulate_with_cenocc), n_gauss_prim),
+        separate_gal_type, cache) for t in theta]
+    return _stack(results, separate_gal_type)
 
 
 # -- tabcorr/tabcorr.py ---------------------------------------------------------

@@ -7,11 +7,12 @@ the arithmetic runs in hand-written HIP kernels behind a C ABI
 
 from .tabcorr import TabCorr, symmetric_matrix_to_array
 from .interpolator import Interpolator
-from .models import Zheng07Model
+from .models import Zheng07Model, Leauthaud11Model
 from .galtable import GalTypeTable
 from . import synthetic
 from . import corrfunc
 
 __version__ = '0.1.0'
-__all__ = ['TabCorr', 'Interpolator', 'Zheng07Model', 'GalTypeTable',
+__all__ = ['TabCorr', 'Interpolator', 'Zheng07Model', 'Leauthaud11Model',
+           'GalTypeTable',
            'symmetric_matrix_to_array', 'synthetic', 'corrfunc']

@@ -26,6 +26,7 @@ DTYPE_F32 = 1
 FLAG_SEPARATE_GAL_TYPE = 1
 FLAG_MODULATE_WITH_CENOCC = 2
 FLAG_ASSEMBIAS = 4
+FLAG_LEAUTHAUD11 = 16
 
 UNIQUE_ID_BYTES = 128
 

@@ -276,6 +276,176 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
   }
 }
 
+// ---- Leauthaud et al. (2011) occupation family ------------------------------------------
+//
+// The second family evaluated on the device (the callbacks the
+// reference would get from halotools' Leauthaud11Cens / Leauthaud11Sats at
+// tabcorr.py:556-563), restated from the papers:
+//   stellar-to-halo mass relation (Behroozi, Conroy & Wechsler 2010, eq. 21), h = littleh:
+//     log10 M_h(M*) = logm1 + beta x + 10^(delta x) / (1 + 10^(-gamma x)) - 1/2 - log10 h,
+//     x = log10 M* + 2 log10 h - logm0
+//   centrals (Leauthaud et al. 2011, eq. 8):
+//     <N_cen>(M_h) = 1/2 [1 - erf((threshold - log10 M*(M_h)) / (sqrt 2 scatter))]
+//     with M*(M_h) the INVERSE of the relation above;
+//   satellites (eq. 12): <N_sat>(M_h) = [<N_cen>] (M_h h / M_sat)^alphasat exp(-M_cut / (M_h h)),
+//     M_sat = 1e12 bsat (M_knee / 1e12)^betasat, M_cut = 1e12 bcut (M_knee / 1e12)^betacut,
+//     M_knee = h M_h(M* = 10^threshold).
+// theta columns: logm0, logm1, beta, delta, gamma, scatter, alphasat, bsat, betasat, bcut,
+// betacut, threshold, littleh.  The inverse relation is solved per quadrature node by
+// Newton's method on g(x) = beta x + 10^(delta x) / (1 + 10^(-gamma x)) = log10(M_h h) + 1/2
+// - logm1, started right of the root (x0 = min(T / beta, log10(2 T) / delta)), to the last
+// bit (<= 11 iterations over the prior box, 5 typically); halotools itself interpolates a
+// 100-point table of the relation with a cubic spline, which is NOT reproduced here: only
+// this package's own Leauthaud11Model is routed to this kernel (models.device_spec).
+constexpr int kLeauthaudTheta = 13;
+constexpr unsigned kFlagLeauthaud11 = 16u;
+
+struct SmhmSetup {
+  double log_m0, beta, delta, gamma, offset;   // offset: log10 h + 1/2 - logm1
+  double two_log_h;
+};
+
+// log10 M* (in h = 1 units) of a halo of log10 mass `log_mh`.
+__device__ inline double smhm_log_mstar(const double* table, const fm::Consts& kc,
+                                        const SmhmSetup& s, double log_mh) {
+  const double target = log_mh + s.offset;
+  double x = target / s.beta;
+  if (target > 0.5) {
+    const double alt = fm::log2_fast(table, kc, 2.0 * target) * (0.30102999566398119521 / s.delta);
+    x = alt < x ? alt : x;
+  }
+  constexpr double kLn10 = 2.30258509299404568402;
+  for (int iteration = 0; iteration < 24; ++iteration) {
+    const double a = fm::exp10_fast(table, kc, s.delta * x);
+    const double b = fm::exp10_fast(table, kc, -s.gamma * x);
+    const double inv = 1.0 / (1.0 + b);
+    const double g = fma(s.beta, x, a * inv);
+    const double slope = fma(kLn10 * a * inv, fma(s.gamma * b, inv, s.delta), s.beta);
+    const double step = (g - target) / slope;
+    x -= step;
+    const double scale = fabs(x) > 1.0 ? fabs(x) : 1.0;
+    // wave-uniform exit: every lane within one part in 10^15 (NaN lanes never hold it up)
+    if (__builtin_amdgcn_ballot_w64(fabs(step) > 1e-15 * scale) == 0) break;
+  }
+  return x + s.log_m0 - s.two_log_h;
+}
+
+// Same work decomposition, outputs and launch geometry as occ_zheng07_kernel.
+template <bool MODULATE>
+__global__ __launch_bounds__(kOccWaves * kLanes) void occ_leauthaud11_kernel(OccArgs a) {
+  __shared__ double red[2][kOccWaves][kLanes];
+  __shared__ double prm[12][kLanes];
+  __shared__ __attribute__((aligned(16))) double table[fm::kTableDoubles];
+  const fm::Consts kc = fm::make_consts();
+  set_priority((int)(a.flags >> 8) & 3);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n_gauss = a.n_gauss;
+  const int n_items = a.n_tiles * a.n_splits;
+  const int per_block = (a.n_bins + a.n_splits - 1) / a.n_splits;
+  for (int i = threadIdx.x; i < fm::kTableDoubles; i += blockDim.x) table[i] = a.math_table[i];
+  __syncthreads();
+  sc_f64 log_m = (sc_f64)a.log_m;
+  sc_f64 mass = (sc_f64)a.m;
+  sc_f64 weight = (sc_f64)a.weight;
+  sc_f64 n_h = (sc_f64)a.n_h;
+  sc_i32 perm = (sc_i32)a.perm;
+  constexpr bool modulate = MODULATE;
+  constexpr double kLog2Of10 = 3.32192809488736234787, kLog10Of2 = 0.30102999566398119521;
+  constexpr double kLog2E = 1.44269504088896340736;
+
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int tile = item % a.n_tiles, split = item / a.n_tiles;
+    const int64_t b0 = (int64_t)tile * kLanes + lane;
+    const int64_t b = b0 < a.n_draws ? b0 : a.n_draws - 1;
+    const int g_begin = split * per_block;
+    const int g_end = g_begin + per_block < a.n_bins ? g_begin + per_block : a.n_bins;
+    if (wave == 0) {
+      const double* th = a.theta + b * a.n_theta;
+      const double log_m0 = th[0], log_m1 = th[1], beta = th[2], delta = th[3], gamma = th[4];
+      const double scatter = th[5], alphasat = th[6], bsat = th[7], betasat = th[8];
+      const double bcut = th[9], betacut = th[10], threshold = th[11], h = th[12];
+      const double log_h = fm::log2_fast(table, kc, h > 1e-300 ? h : 1e-300) * kLog10Of2;
+      // halo mass of the threshold: the forward relation, then the knee in units of 1e12
+      const double x_t = threshold + 2.0 * log_h - log_m0;
+      const double a_t = fm::exp10_fast(table, kc, delta * x_t);
+      const double b_t = fm::exp10_fast(table, kc, -gamma * x_t);
+      const double log_knee = log_m1 + beta * x_t + a_t / (1.0 + b_t) - 0.5 - 12.0;
+      // log2 M_sat and M_cut * log2 e (bsat <= 0 or bcut < 0 have no real power law: NaN)
+      const double log2_msat =
+          bsat > 0.0 ? fm::log2_fast(table, kc, bsat) + (12.0 + betasat * log_knee) * kLog2Of10
+                     : __builtin_nan("");
+      const double mcut =
+          bcut > 0.0 ? fm::exp2_fast(table, kc, fm::log2_fast(table, kc, bcut) +
+                                                    (12.0 + betacut * log_knee) * kLog2Of10)
+                     : (bcut == 0.0 ? 0.0 : __builtin_nan(""));
+      prm[0][lane] = log_m0;
+      prm[1][lane] = beta;
+      prm[2][lane] = delta;
+      prm[3][lane] = gamma;
+      prm[4][lane] = log_h + 0.5 - log_m1;
+      prm[5][lane] = 2.0 * log_h;
+      prm[6][lane] = 1.0 / (1.41421356237309504880 * scatter);
+      prm[7][lane] = threshold;
+      prm[8][lane] = alphasat;
+      prm[9][lane] = log2_msat - log_h * kLog2Of10;      // (M h / M_sat): log2 M - this
+      prm[10][lane] = -mcut * kLog2E / h;                 // exp(-M_cut / (M h)) = 2^(this / M)
+      prm[11][lane] = h;
+    }
+    __syncthreads();
+    SmhmSetup smhm;
+    smhm.log_m0 = prm[0][lane];
+    smhm.beta = prm[1][lane];
+    smhm.delta = prm[2][lane];
+    smhm.gamma = prm[3][lane];
+    smhm.offset = prm[4][lane];
+    smhm.two_log_h = prm[5][lane];
+    const double inv_scatter = prm[6][lane], threshold = prm[7][lane];
+    const double alphasat = prm[8][lane], log2_msat = prm[9][lane], cut = prm[10][lane];
+
+    double sum_cen = 0.0, sum_sat = 0.0;
+    for (int g = g_begin + wave; g < g_end; g += kOccWaves) {
+      const bool central = g < a.n_central;
+      double acc = 0.0;
+      for (int k = 0; k < n_gauss; ++k) {
+        const double lm = log_m[g * n_gauss + k];
+        double n_cen = 1.0;
+        if (central || modulate) {
+          const double log_mstar = smhm_log_mstar(table, kc, smhm, lm);
+          const double za = (threshold - log_mstar) * inv_scatter;
+          n_cen = fma(-0.5, fm::erf_fast(table, kc, za), 0.5);
+          n_cen = za != za ? za : n_cen;      // NaN parameters stay NaN (erf_fast clamps)
+        }
+        double n = n_cen;
+        if (!central) {
+          const double m = mass[g * n_gauss + k];
+          // (M h / M_sat)^alphasat exp(-M_cut / (M h)) as one power of two
+          const double z = fma(alphasat, lm * kLog2Of10 - log2_msat, cut / m);
+          n = fm::exp2_fast(table, kc, z);
+          n = z != z ? z : n;                 // NaN parameters stay NaN (exp2_fast clamps)
+          if (modulate) n *= n_cen;
+        }
+        acc = fma(weight[g * n_gauss + k], n, acc);
+      }
+      if (a.occupation != nullptr && b0 < a.n_draws)
+        a.occupation[b0 * a.n_bins + perm[g]] = acc;
+      const double dens = acc * n_h[g];
+      a.nbuf[(int64_t)g * a.ldb + (int64_t)tile * kLanes + lane] = dens;
+      if (central) sum_cen += dens; else sum_sat += dens;
+    }
+    red[0][wave][lane] = sum_cen;
+    red[1][wave][lane] = sum_sat;
+    __syncthreads();
+    if (wave < 2) {
+      double total = 0.0;
+#pragma unroll
+      for (int w = 0; w < kOccWaves; ++w) total += red[wave][w][lane];
+      a.ngal[((int64_t)split * 2 + wave) * a.ldb + (int64_t)tile * kLanes + lane] = total;
+    }
+    __syncthreads();
+  }
+}
+
 // Occupations supplied by the caller (the ndarray seam, tabcorr.py:616-623):
 // nbuf[g'][b] = occupation[b][perm[g']] * n_h[g'] and the two sums.
 __global__ __launch_bounds__(256) void occ_from_array_kernel(

@@ -684,7 +684,12 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
     // diagnosis only (developer builds, tools/ab.sh): reuse the densities of the previous call
     static int occ_calls = 0;
     if (t->tuning.skip_occ && ++occ_calls > 8) return TC_OK;
-    if (n_gauss == 10) {
+    if (flags & TC_FLAG_LEAUTHAUD11) {
+      if (modulate)
+        hipLaunchKernelGGL(tc::occ_leauthaud11_kernel<true>, grid, block, 0, stream, oa);
+      else
+        hipLaunchKernelGGL(tc::occ_leauthaud11_kernel<false>, grid, block, 0, stream, oa);
+    } else if (n_gauss == 10) {
       if (!assembias && !modulate) TC_OCC(10, false, false);
       else if (!assembias) TC_OCC(10, false, true);
       else if (!modulate) TC_OCC(10, true, false);
@@ -707,7 +712,10 @@ int check_predict_args(const tc_table* t, const void* theta, int n_theta,
   TC_CHECK(n_draws >= 0, "n_draws must be non-negative");
   TC_CHECK(n_draws == 0 || theta != nullptr, "theta is NULL");
   TC_CHECK(n_gauss >= 1 && n_gauss <= 4096, "n_gauss_prim must be in [1, 4096]");
-  const int need = (flags & TC_FLAG_ASSEMBIAS) ? 7 : 5;
+  TC_CHECK(!(flags & TC_FLAG_LEAUTHAUD11) || !(flags & TC_FLAG_ASSEMBIAS),
+           "assembly bias is implemented for the Zheng07 family only");
+  const int need = (flags & TC_FLAG_LEAUTHAUD11) ? tc::kLeauthaudTheta
+                                                 : (flags & TC_FLAG_ASSEMBIAS) ? 7 : 5;
   TC_CHECK(n_theta == need, "theta must have %d columns, got %d", need, n_theta);
   return TC_OK;
 }
@@ -716,7 +724,7 @@ int check_predict_args(const tc_table* t, const void* theta, int n_theta,
 // the call does not qualify (the caller then takes the batched path).
 bool single_draw_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags) {
   return n_draws == 1 && t->compute_dtype == TC_DTYPE_F64 && t->n_rtiles == 1 &&
-         !(flags & TC_FLAG_SEPARATE_GAL_TYPE) && t->n_bins <= tc::kSingleMaxBins &&
+         !(flags & (TC_FLAG_SEPARATE_GAL_TYPE | TC_FLAG_LEAUTHAUD11)) && t->n_bins <= tc::kSingleMaxBins &&
          (int64_t)t->n_bins * n_gauss <= tc::kSingleMaxNodes && t->tuning.single_draw;
 }
 

@@ -193,11 +193,12 @@ class Interpolator:
             separate_gal_type=separate_gal_type, n_gauss_prim=n_gauss_prim,
             extrapolate=extrapolate,
             modulate_with_cenocc=spec.modulate_with_cenocc,
-            assembias=spec.assembias))
+            assembias=spec.assembias, family=spec.family))
 
     def predict_batch(self, theta, x, separate_gal_type=False,
                       n_gauss_prim=10, extrapolate=False,
-                      modulate_with_cenocc=False, assembias=False):
+                      modulate_with_cenocc=False, assembias=False,
+                      family='zheng07'):
         """`predict` for ``(n_draws, 5 | 7)`` Zheng07 parameters ``theta`` and
         ``(n_draws, n_dim)`` values ``x`` of the extra parameters (columns in
         the order of ``self.keys``)."""
@@ -209,7 +210,8 @@ class Interpolator:
         self._check_range(x, extrapolate)
         device = self.to_device()
         table = device.tables[0]
-        flags = _flags(separate_gal_type, modulate_with_cenocc, assembias)
+        flags = _flags(separate_gal_type, modulate_with_cenocc, assembias,
+                       family)
         n_draws = len(theta)
         n_comp = table.n_components if separate_gal_type else 1
         ngal = np.empty((n_draws, 2 if separate_gal_type else 1))

@@ -110,6 +110,136 @@ class Zheng07Model:
         return n
 
 
+LEAUTHAUD11_KEYS = ('smhm_m0_0', 'smhm_m0_a', 'smhm_m1_0', 'smhm_m1_a',
+                    'smhm_beta_0', 'smhm_beta_a', 'smhm_delta_0',
+                    'smhm_delta_a', 'smhm_gamma_0', 'smhm_gamma_a',
+                    'scatter_model_param1', 'alphasat', 'bsat', 'betasat',
+                    'bcut', 'betacut')
+
+
+def behroozi10_log_halo_mass(log_stellar_mass, log_m0, log_m1, beta, delta,
+                             gamma, littleh):
+    """Behroozi, Conroy & Wechsler (2010), eq. 21: log10 of the halo mass (in
+    1 / h units) of galaxies of stellar mass ``10**log_stellar_mass`` (in
+    1 / h^2 units)."""
+    x = log_stellar_mass + 2.0 * np.log10(littleh) - log_m0
+    return (log_m1 + beta * x + 10.0**(delta * x) / (1.0 + 10.0**(-gamma * x))
+            - 0.5 - np.log10(littleh))
+
+
+def behroozi10_log_stellar_mass(log_halo_mass, log_m0, log_m1, beta, delta,
+                                gamma, littleh):
+    """Inverse of `behroozi10_log_halo_mass`, solved to rounding by Newton's
+    method from the right of the root."""
+    log_halo_mass = np.asarray(log_halo_mass, dtype=np.float64)
+    target = log_halo_mass + np.log10(littleh) + 0.5 - log_m1
+    x = target / beta
+    with np.errstate(all='ignore'):
+        alt = np.log10(np.maximum(2.0 * target, 1e-300)) / delta
+        x = np.where(target > 0.5, np.minimum(x, alt), x)
+        for _ in range(60):
+            a = 10.0**(delta * x)
+            b = 10.0**(-gamma * x)
+            g = beta * x + a / (1.0 + b)
+            slope = beta + np.log(10.0) * a / (1.0 + b) * (
+                delta + gamma * b / (1.0 + b))
+            step = (g - target) / slope
+            x = x - step
+            if not np.any(np.abs(step) > 1e-15 * np.maximum(1.0, np.abs(x))):
+                break
+    return x + log_m0 - 2.0 * np.log10(littleh)
+
+
+class Leauthaud11Model:
+    """Leauthaud et al. (2011) HOD on the Behroozi et al. (2010)
+    stellar-to-halo mass relation, with halotools' parameter names
+    (``PrebuiltHodModelFactory('leauthaud11')``: ``smhm_*``,
+    ``scatter_model_param1``, ``alphasat``, ``bsat``, ``betasat``, ``bcut``,
+    ``betacut``) and defaults.
+
+    The occupation functions are restated from the papers; unlike halotools,
+    which inverts the stellar-to-halo mass relation by spline interpolation of
+    a 100-point table, the inverse is solved exactly -- the two agree to the
+    accuracy of that table, not to rounding, which is why only THIS class
+    (not a halotools ``Leauthaud11Cens`` / ``Leauthaud11Sats`` composite) is
+    evaluated by the device kernel.
+
+    Parameters
+    ----------
+    threshold : float
+        log10 of the stellar mass threshold of the sample.
+    redshift : float
+    modulate_with_cenocc : bool
+        Multiply <N_sat> by <N_cen> (halotools' default for this family).
+    """
+
+    _tabcorr_amd_device_model = 'leauthaud11'
+    littleh = 0.72
+
+    def __init__(self, threshold=10.5, prim_haloprop_key='halo_mvir',
+                 redshift=0.0, modulate_with_cenocc=True, **param_dict):
+        self.gal_types = ['centrals', 'satellites']
+        self.threshold = threshold
+        self.redshift = redshift
+        self.modulate_with_cenocc = modulate_with_cenocc
+        self._input_model_dictionary = {
+            'centrals_occupation': _OccupationComponent(prim_haloprop_key),
+            'satellites_occupation': _OccupationComponent(prim_haloprop_key)}
+        self.param_dict = {
+            'smhm_m0_0': 10.72, 'smhm_m0_a': 0.59, 'smhm_m1_0': 12.35,
+            'smhm_m1_a': 0.3, 'smhm_beta_0': 0.43, 'smhm_beta_a': 0.18,
+            'smhm_delta_0': 0.56, 'smhm_delta_a': 0.18, 'smhm_gamma_0': 1.54,
+            'smhm_gamma_a': 2.52, 'scatter_model_param1': 0.2,
+            'alphasat': 1.0, 'bsat': 10.62, 'betasat': 0.859, 'bcut': 1.47,
+            'betacut': -0.13}
+        self.param_dict.update(param_dict)
+
+    def device_theta(self):
+        """The 13 columns the kernel reads (``include/tabcorr_amd.h``,
+        TC_FLAG_LEAUTHAUD11): the relation at the model's redshift,
+        a = 1 / (1 + z), X = X_0 + X_a (a - 1)."""
+        p = self.param_dict
+        a = 1.0 / (1.0 + self.redshift)
+        smhm = [p['smhm_%s_0' % k] + p['smhm_%s_a' % k] * (a - 1.0)
+                for k in ('m0', 'm1', 'beta', 'delta', 'gamma')]
+        return np.array(smhm + [p['scatter_model_param1'], p['alphasat'],
+                                p['bsat'], p['betasat'], p['bcut'],
+                                p['betacut'], self.threshold, self.littleh],
+                        dtype=np.float64)
+
+    def mean_occupation_centrals(self, prim_haloprop=None, **kwargs):
+        return leauthaud11_centrals(prim_haloprop, self.device_theta())
+
+    def mean_occupation_satellites(self, prim_haloprop=None, **kwargs):
+        return leauthaud11_satellites(prim_haloprop, self.device_theta(),
+                                      self.modulate_with_cenocc)
+
+
+def leauthaud11_centrals(prim_haloprop, theta):
+    """Leauthaud et al. (2011), eq. 8."""
+    log_mstar = behroozi10_log_stellar_mass(
+        np.log10(prim_haloprop), theta[0], theta[1], theta[2], theta[3],
+        theta[4], theta[12])
+    return 0.5 * (1.0 - _erf((theta[11] - log_mstar) /
+                             (np.sqrt(2.0) * theta[5])))
+
+
+def leauthaud11_satellites(prim_haloprop, theta, modulate_with_cenocc=True):
+    """Leauthaud et al. (2011), eq. 12 (knee mass 1e12)."""
+    prim_haloprop = np.asarray(prim_haloprop, dtype=np.float64)
+    littleh = theta[12]
+    knee = 10.0**behroozi10_log_halo_mass(
+        theta[11], theta[0], theta[1], theta[2], theta[3], theta[4],
+        littleh) * littleh
+    m_sat = 1e12 * theta[7] * (knee / 1e12)**theta[8]
+    m_cut = 1e12 * theta[9] * (knee / 1e12)**theta[10]
+    n = (np.exp(-m_cut / (prim_haloprop * littleh)) *
+         (prim_haloprop * littleh / m_sat)**theta[6])
+    if modulate_with_cenocc:
+        n = n * leauthaud11_centrals(prim_haloprop, theta)
+    return n
+
+
 def _heaviside(baseline, percentile, strength, upper, split):
     f1, f2 = 1.0 - split, split
     # halotools clips the strength to [-1, 1] (NaN stays NaN)
@@ -127,10 +257,12 @@ def _heaviside(baseline, percentile, strength, upper, split):
 class DeviceSpec:
     """What the occupation kernel needs to know about one model."""
 
-    def __init__(self, theta, modulate_with_cenocc=False, assembias=False):
+    def __init__(self, theta, modulate_with_cenocc=False, assembias=False,
+                 family='zheng07'):
         self.theta = np.asarray(theta, dtype=np.float64)
         self.modulate_with_cenocc = bool(modulate_with_cenocc)
         self.assembias = bool(assembias)
+        self.family = family
 
 
 def device_spec(model):
@@ -156,6 +288,24 @@ def device_spec(model):
                 getattr(model, 'split', 0.5) != 0.5):
             return None
         return _spec_from(model, model.modulate_with_cenocc, model.assembias)
+
+    if getattr(model, '_tabcorr_amd_device_model', None) == 'leauthaud11':
+        cls = type(model)
+        if (getattr(cls, 'mean_occupation_centrals', None) is not
+                Leauthaud11Model.mean_occupation_centrals or
+                getattr(cls, 'mean_occupation_satellites', None) is not
+                Leauthaud11Model.mean_occupation_satellites or
+                getattr(cls, 'device_theta', None) is not
+                Leauthaud11Model.device_theta or
+                'mean_occupation_centrals' in vars(model) or
+                'mean_occupation_satellites' in vars(model)):
+            return None
+        try:
+            theta = model.device_theta()
+        except KeyError:
+            return None
+        return DeviceSpec(theta, model.modulate_with_cenocc, False,
+                          family='leauthaud11')
 
     components = getattr(model, '_input_model_dictionary', None)
     if not isinstance(components, dict):

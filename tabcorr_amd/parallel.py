@@ -260,7 +260,7 @@ class _DeviceArray:
 def _predict_sharded_rccl(predictor, theta, communicator, x=None,
                           separate_gal_type=False, n_gauss_prim=10,
                           modulate_with_cenocc=False, assembias=False,
-                          extrapolate=False):
+                          extrapolate=False, family='zheng07'):
     """Device buffers end to end, one ``ncclGather``: every rank evaluates its
     round-robin share (``TabCorr`` or, with ``x``, ``Interpolator``; total or
     per-galaxy-type prediction) into ``[ngal | xi]`` on its GPU, RCCL collects
@@ -284,7 +284,7 @@ def _predict_sharded_rccl(predictor, theta, communicator, x=None,
     n_ngal = 2 if separate_gal_type else 1
     n_comp = table.n_components if separate_gal_type else 1
     count = n_local * (n_ngal + n_comp * n_r)
-    flags = _flags(separate_gal_type, modulate_with_cenocc, assembias)
+    flags = _flags(separate_gal_type, modulate_with_cenocc, assembias, family)
     d_theta = _DeviceArray(shard.size)
     d_theta.upload(shard)
     d_out = _DeviceArray(count)

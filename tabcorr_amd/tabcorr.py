@@ -278,16 +278,19 @@ class TabCorr:
         return self.mean_occupation_batch(
             spec.theta[np.newaxis], n_gauss_prim=n_gauss_prim,
             modulate_with_cenocc=spec.modulate_with_cenocc,
-            assembias=spec.assembias)[0]
+            assembias=spec.assembias, family=spec.family)[0]
 
     def mean_occupation_batch(self, theta, n_gauss_prim=10,
-                              modulate_with_cenocc=False, assembias=False):
+                              modulate_with_cenocc=False, assembias=False,
+                              family='zheng07'):
         """`mean_occupation` for a ``(n_draws, 5 | 7)`` array of Zheng07
         parameters (columns: logMmin, sigma_logM, logM0, logM1, alpha
-        [, A_cen, A_sat]).  Returns ``(n_draws, n_bins)``."""
+        [, A_cen, A_sat]) -- or, with ``family='leauthaud11'``, the 13 columns
+        of `models.Leauthaud11Model.device_theta`.  Returns
+        ``(n_draws, n_bins)``."""
         device = self.to_device()
         theta = _lib.contiguous(np.atleast_2d(theta))
-        flags = _flags(False, modulate_with_cenocc, assembias)
+        flags = _flags(False, modulate_with_cenocc, assembias, family)
         occupation = np.empty((len(theta), device.n_bins))
         _lib.check(device.lib.tc_mean_occupation_zheng07_batch(
             device.handle, _lib.as_double_p(theta), theta.shape[1],
@@ -330,11 +333,13 @@ class TabCorr:
             spec.theta[np.newaxis], separate_gal_type=separate_gal_type,
             n_gauss_prim=n_gauss_prim,
             modulate_with_cenocc=spec.modulate_with_cenocc,
-            assembias=spec.assembias))
+            assembias=spec.assembias, family=spec.family))
 
     def predict_batch(self, theta, separate_gal_type=False, n_gauss_prim=10,
-                      modulate_with_cenocc=False, assembias=False):
-        """`predict` for a ``(n_draws, 5 | 7)`` array of Zheng07 parameters.
+                      modulate_with_cenocc=False, assembias=False,
+                      family='zheng07'):
+        """`predict` for a ``(n_draws, 5 | 7)`` array of Zheng07 parameters
+        (``family='leauthaud11'``: 13 columns, see `mean_occupation_batch`).
 
         Returns
         -------
@@ -343,7 +348,8 @@ class TabCorr:
         """
         device = self.to_device()
         theta = _lib.contiguous(np.atleast_2d(theta))
-        flags = _flags(separate_gal_type, modulate_with_cenocc, assembias)
+        flags = _flags(separate_gal_type, modulate_with_cenocc, assembias,
+                       family)
         n_draws = len(theta)
         n_comp = device.n_components if separate_gal_type else 1
         ngal = np.empty((n_draws, 2 if separate_gal_type else 1))
@@ -355,7 +361,8 @@ class TabCorr:
         return self._package(ngal, xi, separate_gal_type)
 
     def chi2_batch(self, theta, data, precision, n_gauss_prim=10,
-                   modulate_with_cenocc=False, assembias=False):
+                   modulate_with_cenocc=False, assembias=False,
+                   family='zheng07'):
         """Gaussian ``chi^2 = (xi - data)^T precision (xi - data)`` of every draw,
         evaluated on the device right after the prediction (extension: the
         reference leaves this to the user's likelihood, ``README.md:7``).
@@ -382,7 +389,8 @@ class TabCorr:
         chi2 = np.empty(len(theta))
         _lib.check(device.lib.tc_chi2_zheng07_batch(
             device.handle, _lib.as_double_p(theta), theta.shape[1], len(theta),
-            n_gauss_prim, _flags(False, modulate_with_cenocc, assembias),
+            n_gauss_prim,
+            _flags(False, modulate_with_cenocc, assembias, family),
             _lib.as_double_p(data), _lib.as_double_p(precision),
             _lib.as_double_p(ngal), _lib.as_double_p(chi2)))
         return ngal, chi2
@@ -418,10 +426,13 @@ class TabCorr:
 
 
 def _flags(separate_gal_type=False, modulate_with_cenocc=False,
-           assembias=False):
+           assembias=False, family='zheng07'):
+    if family not in ('zheng07', 'leauthaud11'):
+        raise ValueError("family must be 'zheng07' or 'leauthaud11'.")
     return ((_lib.FLAG_SEPARATE_GAL_TYPE if separate_gal_type else 0) |
             (_lib.FLAG_MODULATE_WITH_CENOCC if modulate_with_cenocc else 0) |
-            (_lib.FLAG_ASSEMBIAS if assembias else 0))
+            (_lib.FLAG_ASSEMBIAS if assembias else 0) |
+            (_lib.FLAG_LEAUTHAUD11 if family == 'leauthaud11' else 0))
 
 
 def _unbatch(ngal, xi):

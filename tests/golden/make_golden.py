@@ -199,6 +199,75 @@ class DuckAssembiasZheng07(DuckZheng07):
             0.0, np.inf)
 
 
+class DuckLeauthaud11:
+    """Leauthaud et al. (2011) HOD on the Behroozi, Conroy & Wechsler (2010)
+    stellar-to-halo mass relation (eq. 21), with halotools' parameter names:
+
+      log10 M_h(M*) = logm1 + beta x + 10^(delta x) / (1 + 10^(-gamma x)) - 1/2
+                      - log10 h,   x = log10 M* + 2 log10 h - logm0,
+      <N_cen> = 1/2 [1 - erf((threshold - log10 M*(M_h)) / (sqrt 2 scatter))],
+      <N_sat> = [<N_cen>] (M_h h / M_sat)^alphasat exp(-M_cut / (M_h h)),
+      M_sat = 1e12 bsat (M_knee / 1e12)^betasat, M_cut likewise, M_knee = h
+      M_h(10^threshold).
+
+    The inverse relation M*(M_h) is found per node with scipy's ``brentq`` (an
+    independent root finder: the library uses Newton's method, the oracle
+    bisection).  halotools' own table + spline inversion is not reproduced.
+    ``theta``: logm0, logm1, beta, delta, gamma, scatter, alphasat, bsat,
+    betasat, bcut, betacut, threshold, littleh."""
+
+    def __init__(self, theta, prim_haloprop_key='halo_mvir', redshift=0.0,
+                 modulate_with_cenocc=True):
+        self.gal_types = ['centrals', 'satellites']
+        self.redshift = redshift
+        self.modulate_with_cenocc = modulate_with_cenocc
+        self.theta = np.asarray(theta, dtype=np.float64)
+        self._input_model_dictionary = {
+            'centrals_occupation': _Occupation(prim_haloprop_key),
+            'satellites_occupation': _Occupation(prim_haloprop_key)}
+        self.param_dict = {}
+
+    def log_halo_mass(self, log_mstar):
+        t = self.theta
+        x = log_mstar + 2.0 * np.log10(t[12]) - t[0]
+        return (t[1] + t[2] * x + 10.0**(t[3] * x) / (1.0 + 10.0**(-t[4] * x))
+                - 0.5 - np.log10(t[12]))
+
+    def log_stellar_mass(self, prim_haloprop):
+        from scipy.optimize import brentq
+        return np.array([brentq(lambda s: self.log_halo_mass(s) - lm, -40.0,
+                                40.0, xtol=1e-15, rtol=8.9e-16, maxiter=500)
+                         for lm in np.log10(prim_haloprop)])
+
+    def mean_occupation_centrals(self, prim_haloprop=None, **kwargs):
+        t = self.theta
+        return 0.5 * (1.0 - erf((t[11] - self.log_stellar_mass(prim_haloprop))
+                                / (np.sqrt(2.0) * t[5])))
+
+    def mean_occupation_satellites(self, prim_haloprop=None, **kwargs):
+        t = self.theta
+        knee = 10.0**self.log_halo_mass(t[11]) * t[12]
+        m_sat = 1e12 * t[7] * (knee / 1e12)**t[8]
+        m_cut = 1e12 * t[9] * (knee / 1e12)**t[10]
+        n = (np.exp(-m_cut / (prim_haloprop * t[12])) *
+             (prim_haloprop * t[12] / m_sat)**t[6])
+        if self.modulate_with_cenocc:
+            n = n * self.mean_occupation_centrals(prim_haloprop)
+        return n
+
+
+def leauthaud11_draws(n_draws, seed):
+    """Parameter vectors around halotools' ``leauthaud11`` defaults."""
+    rng = np.random.default_rng(seed)
+    centre = np.array([10.72, 12.35, 0.43, 0.56, 1.54, 0.2, 1.0, 10.62, 0.859,
+                       1.47, -0.13, 10.5, 0.72])
+    width = np.array([0.3, 0.3, 0.08, 0.1, 0.4, 0.08, 0.2, 3.0, 0.1, 0.5,
+                      0.1, 0.5, 0.0])
+    theta = centre + width * rng.uniform(-1, 1, size=(n_draws, 13))
+    theta[0] = centre
+    return theta
+
+
 # -- helpers -------------------------------------------------------------------
 
 def make_reference_tabcorr(table):
@@ -453,6 +522,30 @@ def golden_synthetic():
         save(name, **arrays)
 
 
+def golden_leauthaud11():
+    """The second occupation family the device evaluates:
+    the reference's mean_occupation / predict driven by `DuckLeauthaud11` on
+    the real wp table of the reference and on a synthetic 2-D table."""
+    fname = os.path.join(REFERENCE, 'docs', 'examples', 'bolplanck_wp.hdf5')
+    cases = [('leauthaud11_bolplanck_wp',
+              table_from_reference(tabcorr.TabCorr.read(fname)), 12),
+             ('leauthaud11_synthetic',
+              synthetic.synthetic_table(9, 1, (6, 2), 'auto', seed=31), 10)]
+    for name, table, n_draws in cases:
+        halotab = make_reference_tabcorr(table)
+        theta = leauthaud11_draws(n_draws, seed=len(name))
+        arrays = pack_table(table)
+        arrays['theta'] = theta
+        for modulate in (True, False):
+            models = [DuckLeauthaud11(t, redshift=table['attrs']['redshift'],
+                                      modulate_with_cenocc=modulate)
+                      for t in theta]
+            out = run_draws(halotab, models)
+            for key in out:
+                arrays[key + ('' if modulate else '_nomodulate')] = out[key]
+        save(name, **arrays)
+
+
 # -- 4. synthetic interpolators -------------------------------------------------------
 
 def make_reference_interpolator(tables, keys, points):
@@ -612,8 +705,12 @@ def golden_helpers():
 
 
 if __name__ == '__main__':
+    if '--only-leauthaud11' in sys.argv:
+        golden_leauthaud11()
+        sys.exit(0)
     golden_helpers()
     golden_real_tables()
     golden_abacus()
     golden_synthetic()
     golden_interpolators()
+    golden_leauthaud11()

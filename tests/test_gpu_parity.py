@@ -50,6 +50,48 @@ def check_against_golden(halotab, data, table, suffix='', prefix='',
     assert_rel(sum(xi_sep.values()), xi, 1e-12)
 
 
+@pytest.mark.parametrize('name', ['leauthaud11_bolplanck_wp', 'leauthaud11_synthetic'])
+def test_leauthaud11_family_on_device(name):
+    """Second occupation family on the device: Leauthaud et al. (2011) on
+    the Behroozi et al. (2010) relation, its inverse solved per quadrature node in the
+    kernel, against fixtures recorded by running the reference with a duck model."""
+    from tabcorr_amd import Leauthaud11Model
+    from tabcorr_amd.models import LEAUTHAUD11_KEYS
+    data = load_golden(name)
+    table = table_from_golden(data)
+    halotab = make_tabcorr(table)
+    for modulate, suffix in ((True, ''), (False, '_nomodulate')):
+        check_against_golden(halotab, data, table, suffix, family='leauthaud11',
+                             modulate_with_cenocc=modulate)
+        occupation = halotab.mean_occupation_batch(
+            data['theta'], family='leauthaud11', modulate_with_cenocc=modulate)
+        assert_rel(occupation, data['mean_occupation' + suffix], RTOL, floor=1e-13)
+    # the model class (halotools' parameter names) through the scalar API
+    theta = data['theta'][3]
+    model = Leauthaud11Model(threshold=theta[11], redshift=table['attrs']['redshift'])
+    for key, value in zip(('smhm_m0_0', 'smhm_m1_0', 'smhm_beta_0', 'smhm_delta_0',
+                           'smhm_gamma_0'), theta[:5]):
+        model.param_dict[key] = value
+        model.param_dict[key[:-1] + 'a'] = 0.0
+    for key, value in zip(LEAUTHAUD11_KEYS[10:], theta[5:11]):
+        model.param_dict[key] = value
+    ngal, xi = halotab.predict(model)
+    assert_rel(ngal, data['ngal'][3], RTOL)
+    assert_rel(xi, data['xi'][3], RTOL)
+    assert_rel(halotab.mean_occupation(model), data['mean_occupation'][3], RTOL, floor=1e-13)
+    # a NaN parameter rejects the draw, as the reference's NumPy arithmetic would
+    bad = data['theta'][:4].copy()
+    bad[1, 5] = np.nan        # scatter: centrals (and modulated satellites) NaN
+    bad[2, 6] = np.nan        # alphasat: satellites NaN
+    ngal, xi = halotab.predict_batch(bad, family='leauthaud11', modulate_with_cenocc=True)
+    assert np.isnan(ngal[1]) and np.isnan(ngal[2]) and np.all(np.isnan(xi[1:3]))
+    assert_rel(xi[[0, 3]], data['xi'][[0, 3]], RTOL)
+    with pytest.raises(ValueError, match='13 columns'):
+        halotab.predict_batch(data['theta'][:, :5], family='leauthaud11')
+    with pytest.raises(ValueError):
+        halotab.predict_batch(data['theta'], family='leauthaud11', assembias=True)
+
+
 @pytest.mark.parametrize('name', ['bolplanck_wp', 'bolplanck_ds'])
 def test_real_tables(name):
     data = load_golden(name)

@@ -232,3 +232,58 @@ def test_spline_matches_scipy():
         y = oracle.spline_interpolate(x, xp, a, yp)
         y_scipy = [interp1d(xp, yp[:, i], kind='cubic')(x) for i in range(4)]
         assert np.allclose(y, y_scipy)
+
+
+@pytest.mark.parametrize('name', ['leauthaud11_bolplanck_wp', 'leauthaud11_synthetic'])
+def test_leauthaud11_family(name):
+    """The Leauthaud et al. (2011) occupation family: the oracle's bisection inverse of the
+    stellar-to-halo mass relation against fixtures recorded by running the reference with
+    a duck model that uses scipy's brentq (tests/golden/make_golden.py)."""
+    data = load_golden(name)
+    table = table_from_golden(data)
+    for modulate, suffix in ((True, ''), (False, '_nomodulate')):
+        ngal, xi = oracle.predict_leauthaud11_batch(table, data['theta'],
+                                                    modulate_with_cenocc=modulate)
+        assert_rel(ngal, data['ngal' + suffix], RTOL)
+        assert_rel(xi, data['xi' + suffix], RTOL)
+        ngal_sep, xi_sep = oracle.predict_leauthaud11_batch(
+            table, data['theta'], separate_gal_type=True, modulate_with_cenocc=modulate)
+        for key in xi_sep:
+            assert_rel(xi_sep[key], data['xi_sep_' + key + suffix], RTOL, key)
+        occupation = np.array([oracle.mean_occupation(
+            table, oracle.Leauthaud11(t, modulate)) for t in data['theta']])
+        # (tiny central occupations 1/2 [1 - erf(z)] lose relative accuracy to cancellation)
+        assert_rel(occupation, data['mean_occupation' + suffix], 1e-10, floor=1e-13)
+
+
+def test_leauthaud11_host_model_matches_the_oracle():
+    """tabcorr_amd.Leauthaud11Model (Newton inverse, halotools' parameter names and
+    redshift dependence) against the oracle's callbacks."""
+    from tabcorr_amd import Leauthaud11Model
+    from tabcorr_amd.models import device_spec
+    mass = np.logspace(10.6, 15.2, 300)
+    for redshift, extra in ((0.0, {}), (0.4, {'bsat': 8.0, 'smhm_beta_0': 0.5}),
+                            (1.0, {'scatter_model_param1': 0.35, 'alphasat': 1.2})):
+        for modulate in (True, False):
+            model = Leauthaud11Model(threshold=10.8, redshift=redshift,
+                                     modulate_with_cenocc=modulate, **extra)
+            theta = model.device_theta()
+            a = 1.0 / (1.0 + redshift)
+            assert theta[0] == model.param_dict['smhm_m0_0'] + model.param_dict[
+                'smhm_m0_a'] * (a - 1.0)
+            callbacks = oracle.Leauthaud11(theta, modulate)
+            expect_cen = callbacks.mean_occupation_centrals(mass)
+            expect_sat = callbacks.mean_occupation_satellites(mass)
+            assert_rel(model.mean_occupation_centrals(prim_haloprop=mass), expect_cen, 1e-10,
+                       floor=1e-13)
+            assert_rel(model.mean_occupation_satellites(prim_haloprop=mass), expect_sat, 1e-10,
+                       floor=1e-13)
+            assert np.all(np.diff(expect_cen) >= 0) and 0.99 < expect_cen[-1] <= 1.0
+            spec = device_spec(model)
+            assert spec is not None and spec.family == 'leauthaud11'
+            assert spec.modulate_with_cenocc == modulate and len(spec.theta) == 13
+
+    class Tweaked(Leauthaud11Model):
+        def mean_occupation_centrals(self, **kwargs):
+            return 0.9 * super().mean_occupation_centrals(**kwargs)
+    assert device_spec(Tweaked()) is None
