@@ -285,7 +285,7 @@ struct tc_table {
   int cur = 0;                       // lane of the current / last predict call
   int force_lane = -1;               // host-buffer entry points pin lane 0
   uint64_t device_calls = 0;
-  tc::host::DeviceBuffer theta, out_ngal, out_xi, occupation, trace, wave_trace, single_ws;
+  tc::host::DeviceBuffer theta, out_ngal, out_xi, occupation, trace, wave_trace;
   tc::host::DeviceBuffer chi2_data;          // data vector + precision matrix of chi2 calls
   std::vector<double> chi2_host;             // host copy of what chi2_data holds
   size_t wave_trace_count = 0;
@@ -351,8 +351,15 @@ int next_kernel_events(tc_table* t, hipEvent_t* start, hipEvent_t* stop);
 // the quadratic-form kernel: n_bins * ldb * 8 < 2^32).
 int64_t max_slab(const tc_table* t);
 bool single_draw_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags);
+constexpr int kSingleMaxBlocks = 64;
+constexpr size_t kSingleWsDoubles = 2 + (size_t)kSingleMaxBlocks * 32;
 int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_gauss,
-                       unsigned flags, double* ngal, double* xi, hipStream_t stream);
+                       unsigned flags, double* host_ws, int* n_blocks, hipStream_t stream);
+void combine_single_draw(const tc_table* t, const double* host_ws, int n_blocks, double* ngal,
+                         double* xi);
+int single_draw_blocks(const tc_table* t);
+int launch_single_draw_tables(tc_table* t0, const SingleArgs& prepared, int n_tables,
+                              int blocks_per_table, hipStream_t stream);
 int launch_interp_coef(const InterpArgs& args, hipStream_t stream);
 int launch_occ_from_array(tc_table* t, const double* occupation_device, int64_t n_draws,
                           int64_t ldb, double* nbuf, double* ngal2, hipStream_t stream);

@@ -25,6 +25,16 @@ struct tc_interp {
   void* d_nbufs = nullptr;                  // (V) device pointers
   void* d_ngal_parts = nullptr;             // (V) device pointers
   std::vector<int> axis_offset, a_offset;
+  std::vector<double> a_host;               // spline matrices of all dimensions
+  // un-batched calls: per n_gauss the per-class pointer arrays of single_draw_kernel
+  struct SinglePointers {
+    void* log_m = nullptr;
+    void* m = nullptr;
+    void* weight = nullptr;
+    void* n_h = nullptr;
+    void* percentile = nullptr;
+  };
+  std::map<int, SinglePointers> single_pointers;
   std::vector<DeviceBuffer> nbuf, ngal2;    // per class
   std::vector<void*> nbuf_ptrs, ngal_ptrs;  // last uploaded pointer values
   DeviceBuffer theta, x, coef, partial, out_ngal, out_xi;
@@ -360,6 +370,7 @@ int tc_interp_create(tc_table* const* tables, int n_tables, int n_dim,
   int status = upload(xp_all, &it->d_xp);
   if (status == TC_OK) status = upload(quad_by_type, &it->d_quad_by_type);
   if (status == TC_OK) status = upload(quad_total, &it->d_quad_total);
+  it->a_host = a_all;
   if (status == TC_OK) status = upload(a_all, &it->d_a);
   if (status == TC_OK) status = upload(it->table_node, &it->d_table_node);
   if (status == TC_OK) status = upload(it->table_class, &it->d_table_class);
@@ -380,6 +391,10 @@ int tc_interp_destroy(tc_interp* it) {
     if (p) (void)hipFree(p);
   for (auto& kv : it->chunkings)
     for (void* p : {kv.second->chunks, kv.second->groups})
+      if (p) (void)hipFree(p);
+  for (auto& kv : it->single_pointers)
+    for (void* p : {kv.second.log_m, kv.second.m, kv.second.weight, kv.second.n_h,
+                    kv.second.percentile})
       if (p) (void)hipFree(p);
   for (DeviceBuffer& b : it->nbuf) b.release();
   for (DeviceBuffer& b : it->ngal2) b.release();
@@ -433,6 +448,116 @@ int tc_interp_predict_zheng07_batch_device(tc_interp* it, const double* theta_de
   return TC_OK;
 }
 
+namespace {
+
+// Un-batched Interpolator.predict: ONE launch evaluates every table (single_draw_kernel
+// with grid = tables x workgroups per table, each workgroup computing the occupations of
+// its table's class itself), the partial sums land in page-locked host memory, and the
+// host normalises each table, forms the tensor-product spline weights
+// (interpolator.py:275-331) and adds the tables in list order.  No device-side
+// combination, no second launch: ~25 us against ~70 us for the four-launch batched path.
+int interp_predict_one(tc_interp* it, const double* theta, int n_theta, const double* x,
+                       int n_gauss, unsigned flags, double* ngal, double* xi) {
+  tc_table* t0 = it->tables[0];
+  const int n_classes = (int)it->class_table.size();
+  auto found = it->single_pointers.find(n_gauss);
+  if (found == it->single_pointers.end()) {
+    std::vector<void*> log_m, m, weight, n_h, percentile;
+    for (int v = 0; v < n_classes; ++v) {
+      tc_table* t = it->tables[it->class_table[v]];
+      Quadrature* q = nullptr;
+      int status = get_quadrature(t, n_gauss, &q);
+      if (status != TC_OK) return status;
+      log_m.push_back(q->log_m);
+      m.push_back(q->m);
+      weight.push_back(q->weight);
+      n_h.push_back(t->d_n_h);
+      percentile.push_back(t->d_percentile);
+    }
+    tc_interp::SinglePointers p;
+    int status = upload(log_m, &p.log_m);
+    if (status == TC_OK) status = upload(m, &p.m);
+    if (status == TC_OK) status = upload(weight, &p.weight);
+    if (status == TC_OK) status = upload(n_h, &p.n_h);
+    if (status == TC_OK) status = upload(percentile, &p.percentile);
+    if (status != TC_OK) return status;
+    found = it->single_pointers.emplace(n_gauss, p).first;
+  }
+  const tc_interp::SinglePointers& p = found->second;
+  const int blocks = single_draw_blocks(t0);
+  const int rt = t0->rt, n_tables = it->n_tables;
+  const size_t ws_doubles = (size_t)n_tables * (2 + (size_t)blocks * rt);
+  int status = it->h_out.reserve(ws_doubles * sizeof(double));
+  if (status != TC_OK) return status;
+  double* ws = (double*)it->h_out.ptr;
+  tc::SingleArgs sa;
+  for (int i = 0; i < 7; ++i) sa.theta_value[i] = i < n_theta ? theta[i] : 0.0;
+  sa.n_theta = n_theta;
+  sa.n_bins = t0->n_bins;
+  sa.n_central = t0->plan.n_central;
+  sa.n_gauss = n_gauss;
+  sa.flags = flags;
+  sa.split = 0.5;
+  sa.log_m = sa.m = sa.weight = sa.n_h = sa.percentile = nullptr;
+  sa.math_table = (const double*)t0->d_math_table;
+  sa.table = nullptr;
+  sa.pos_off = (const int32_t*)t0->d_pos_off;
+  sa.n_positions = t0->plan.n_positions;
+  sa.rt = rt;
+  sa.n_r = t0->n_r;
+  sa.mode = t0->mode;
+  sa.ngal = ws;
+  sa.partial = ws + 2 * (size_t)n_tables;
+  sa.tables = (const double* const*)it->d_tables;
+  sa.table_class = (const int32_t*)it->d_table_class;
+  sa.class_log_m = (const double* const*)p.log_m;
+  sa.class_m = (const double* const*)p.m;
+  sa.class_weight = (const double* const*)p.weight;
+  sa.class_n_h = (const double* const*)p.n_h;
+  sa.class_percentile = (const double* const*)p.percentile;
+  status = launch_single_draw_tables(t0, sa, n_tables, blocks, it->stream);
+  if (status != TC_OK) return status;
+
+  // spline weights while the kernel runs
+  double weight[tc::kMaxInterpDim][tc::kMaxInterpAxis];
+  for (int d = 0; d < it->n_dim; ++d) {
+    const std::vector<double>& xp = it->xp[d];
+    const int n = (int)xp.size();
+    const double xv = x[d];
+    int seg = -1;
+    for (int i = 0; i < n; ++i) seg += xp[i] <= xv ? 1 : 0;   // np.digitize(x, xp) - 1
+    if (xv == xp[n - 1]) seg = n - 2;
+    seg = seg < 0 ? 0 : (seg > n - 2 ? n - 2 : seg);
+    const double* m = it->a_host.data() + it->a_offset[d] + (size_t)seg * 4 * n;
+    const double x2 = xv * xv, x3 = x2 * xv;
+    for (int j = 0; j < n; ++j)
+      weight[d][j] = m[j] + m[n + j] * xv + m[2 * n + j] * x2 + m[3 * n + j] * x3;
+  }
+  TC_HIP(hipStreamSynchronize(it->stream));
+  const double* partial = ws + 2 * (size_t)n_tables;
+  double n_cen = 0.0, n_sat = 0.0;
+  for (int r = 0; r < t0->n_r; ++r) xi[r] = 0.0;
+  for (int k = 0; k < n_tables; ++k) {
+    double c = 1.0;
+    for (int d = 0; d < it->n_dim; ++d) c *= weight[d][it->table_node[(size_t)k * it->n_dim + d]];
+    const double cen = ws[2 * k], sat = ws[2 * k + 1];
+    const double total = cen + sat;
+    const double coef = c / (t0->mode == TC_MODE_AUTO ? total * total : total);
+    n_cen += c * cen;
+    n_sat += c * sat;
+    const double* rows = partial + (size_t)k * blocks * rt;
+    for (int r = 0; r < t0->n_r; ++r) {
+      double sum = 0.0;
+      for (int b = 0; b < blocks; ++b) sum += rows[(size_t)b * rt + r];
+      xi[r] += coef * sum;
+    }
+  }
+  ngal[0] = n_cen + n_sat;
+  return TC_OK;
+}
+
+}  // namespace
+
 int tc_interp_predict_zheng07_batch(tc_interp* it, const double* theta, int n_theta,
                                     const double* x, int64_t n_draws, int n_gauss,
                                     unsigned flags, double* ngal, double* xi) {
@@ -442,6 +567,9 @@ int tc_interp_predict_zheng07_batch(tc_interp* it, const double* theta, int n_th
   if (n_draws == 0) return TC_OK;
   TC_CHECK(x && ngal && xi, "NULL pointer");
   TC_HIP(hipSetDevice(it->device));
+  if (single_draw_eligible(it->tables[0], n_draws, n_gauss, flags) &&
+      (int64_t)it->n_tables * single_draw_blocks(it->tables[0]) <= 8192)
+    return interp_predict_one(it, theta, n_theta, x, n_gauss, flags, ngal, xi);
   const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
   const int n_comp = separate ? it->tables[0]->plan.n_components : 1;
   const size_t ngal_count = (size_t)n_draws * (separate ? 2 : 1);

@@ -65,10 +65,22 @@ struct SingleArgs {
   int rt;
   int n_r;
   int mode;
-  double* partial;           // (blocks, rt)
-  unsigned* counter;         // workgroups that have delivered their partial sums
-  double* ngal;              // (1), may live in page-locked host memory
-  double* xi;                // (n_r)
+  double* partial;           // (blocks, rt) partial sums, page-locked host memory
+  double* ngal;              // (2) centrals / satellites number density, host memory
+  // Interpolator (un-batched Interpolator.predict): grid = n_tables x blocks_per_table;
+  // workgroup b serves table b / blocks_per_table with the bins of that table's class.
+  // n_tables == 0: one table, the direct pointers above.  Per table the host memory holds
+  // partial (n_tables, blocks_per_table, rt) and ngal (n_tables, 2).
+  int n_tables;
+  int blocks_per_table;
+  const double* const* tables;       // (n_tables) re-laid-out matrices
+  const int32_t* table_class;        // (n_tables)
+  const double* const* class_log_m;  // (n_classes) quadrature constants and bin columns
+  const double* const* class_m;
+  const double* const* class_weight;
+  const double* const* class_n_h;
+  const double* const* class_percentile;
+  unsigned long long* stamps;   // developer timeline: 8 x 100 MHz stamps per block, or NULL
 };
 
 struct ContractArgs {

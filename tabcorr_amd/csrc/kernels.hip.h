@@ -1008,13 +1008,17 @@ __global__ __launch_bounds__(1024) void finalize_quad_kernel(FinalizeQuadArgs a)
 // ---- un-batched predict(): one draw, one launch ---------------------------------------
 //
 // The reference's usage is one predict() per MCMC step.  Three launches for one draw are
-// latency, not work (7 + 8 + 5 us of kernels back to back), so a single draw goes
-// through one kernel: every workgroup evaluates all G * n_gauss occupation nodes (one
-// node per thread and pass, per-bin sums in fixed order), contracts its share of the table
-// positions (thread = r value x slice of positions), and the last workgroup to deliver its
-// partial sums (device-scope fence + counter) adds them in fixed order, normalises and
-// writes the result -- deterministic like the batched path.  Total correlation function
-// only, one r tile, G * n_gauss <= kSingleMaxNodes.
+// latency, not work, so a single draw goes through one kernel: every workgroup evaluates
+// all G * n_gauss occupation nodes (one node per thread and pass, per-bin sums in fixed
+// order), contracts its share of the table positions (thread = r value x slice of
+// positions, all of a thread's loads in flight at once) and writes its partial sums
+// STRAIGHT INTO PAGE-LOCKED HOST MEMORY; the host adds the workgroups' partial sums in
+// fixed order and normalises (table.cpp) -- deterministic like the batched path.  There is
+// no inter-workgroup step on the device: the first version combined the partial sums in
+// the last workgroup to arrive (device-scope fence + counter), and per-phase stamps
+// (tools/single_trace.py) showed that this tail -- fence 2.6 us, atomic 1.7 us, re-read and
+// write-out 6.3 us -- was 10 of the kernel's 17 us.  Total correlation function only, one r
+// tile, G * n_gauss <= kSingleMaxNodes.
 constexpr int kSingleThreads = 1024;
 constexpr int kSingleMaxNodes = 4096;
 constexpr int kSingleMaxBins = 1024;
@@ -1024,16 +1028,35 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
   __shared__ double density[kSingleMaxBins];
   __shared__ double slice_sum[kSingleThreads];
   __shared__ __attribute__((aligned(16))) double table[fm::kTableDoubles];
-  __shared__ double ngal_sum[2];
-  __shared__ int is_last;
   const int tid = threadIdx.x;
   const fm::Consts kc = fm::make_consts();
+  auto stamp = [&](int phase) {
+    if (a.stamps != nullptr && tid == 0)
+      a.stamps[blockIdx.x * 8 + phase] = __builtin_amdgcn_s_memrealtime();
+  };
+  stamp(0);
 
   // everything here is latency: the draw arrives in the kernel arguments, the math tables
   // are staged in LDS
   const bool assembias = (a.flags & kFlagAssembias) != 0;
   const bool modulate = (a.flags & kFlagModulate) != 0;
   const int n_nodes = a.n_bins * a.n_gauss;
+  // which table and which part of it (one table: everything direct)
+  int part = blockIdx.x, n_parts = gridDim.x, which_table = 0;
+  if (a.n_tables > 0) {
+    which_table = blockIdx.x / a.blocks_per_table;
+    part = blockIdx.x % a.blocks_per_table;
+    n_parts = a.blocks_per_table;
+    const int cls = a.table_class[which_table];
+    a.table = a.tables[which_table];
+    a.log_m = a.class_log_m[cls];
+    a.m = a.class_m[cls];
+    a.weight = a.class_weight[cls];
+    a.n_h = a.class_n_h[cls];
+    a.percentile = a.class_percentile[cls];
+    a.ngal += 2 * which_table;
+    a.partial += (int64_t)which_table * a.blocks_per_table * a.rt;
+  }
   {
     typedef double __attribute__((ext_vector_type(2))) double2v;
     const double2v* src = (const double2v*)a.math_table;
@@ -1041,6 +1064,7 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
     for (int i = tid; i < fm::kTableDoubles / 2; i += kSingleThreads) dst[i] = src[i];
   }
   __syncthreads();
+  stamp(1);
   const DrawSetup d = prepare_draw(table, kc, a.theta_value[0], a.theta_value[1],
                                    a.theta_value[2], a.theta_value[3], a.theta_value[4],
                                    assembias ? a.theta_value[5] : 0.0,
@@ -1081,6 +1105,7 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
     node_value[idx] = wk * n;
   }
   __syncthreads();
+  stamp(2);
   for (int g = tid; g < a.n_bins; g += kSingleThreads) {
     double acc = 0.0;
     for (int k = 0; k < a.n_gauss; ++k) acc += node_value[g * a.n_gauss + k];
@@ -1094,16 +1119,17 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
     for (int g = lo + lane; g < hi; g += 64) total += density[g];
 #pragma unroll
     for (int offset = 32; offset >= 1; offset >>= 1) total += __shfl_down(total, offset, 64);
-    if (lane == 0) ngal_sum[which] = total;
+    // (every workgroup holds the same sums; the first one reports them)
+    if (lane == 0 && part == 0) a.ngal[which] = total;
   }
 
   // contraction of this workgroup's positions: thread = (slice, r); eight positions per
-  // pass, their loads issued together
+  // pass, their loads issued together (the launch sizes the grid for a single pass)
   const int rt = a.rt;
   const int n_slices = kSingleThreads / rt;
   const int r = tid % rt, slice = tid / rt;
-  const int64_t per_block = (a.n_positions + gridDim.x - 1) / gridDim.x;
-  const int64_t q_begin = per_block * blockIdx.x;
+  const int64_t per_block = (a.n_positions + n_parts - 1) / n_parts;
+  const int64_t q_begin = per_block * part;
   const int64_t q_end = q_begin + per_block < a.n_positions ? q_begin + per_block
                                                              : a.n_positions;
   double acc = 0.0;
@@ -1133,29 +1159,13 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
   }
   slice_sum[tid] = acc;
   __syncthreads();
+  stamp(3);
   if (tid < rt) {
     double total = 0.0;
     for (int s = 0; s < n_slices; ++s) total += slice_sum[s * rt + tid];
-    a.partial[(int64_t)blockIdx.x * rt + tid] = total;
+    a.partial[(int64_t)part * rt + tid] = total;     // host memory
   }
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) is_last = atomicAdd(a.counter, 1u) == gridDim.x - 1 ? 1 : 0;
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
-  const double n_total = ngal_sum[0] + ngal_sum[1];
-  const double norm = a.mode == 0 ? n_total * n_total : n_total;
-  if (tid < a.n_r) {
-    double total = 0.0;
-    for (unsigned b = 0; b < gridDim.x; ++b)
-      total += __builtin_nontemporal_load(a.partial + (int64_t)b * rt + tid);
-    a.xi[tid] = total / norm;
-  }
-  if (tid == 0) {
-    a.ngal[0] = n_total;
-    *a.counter = 0u;
-  }
+  stamp(4);
 }
 
 // ---- float32 variant for tables with many correlation-function bins -------------------

@@ -728,20 +728,20 @@ bool single_draw_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsig
          (int64_t)t->n_bins * n_gauss <= tc::kSingleMaxNodes && t->tuning.single_draw;
 }
 
+// `host_ws`: page-locked host memory the kernel writes to, kSingleWsDoubles doubles:
+// [0] centrals, [1] satellites number density, then (workgroups, rt) partial sums of the
+// contraction.  combine_single_draw() turns it into (ngal, xi) after the stream is idle.
 int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_gauss,
-                       unsigned flags, double* ngal, double* xi, hipStream_t stream) {
+                       unsigned flags, double* host_ws, int* n_blocks, hipStream_t stream) {
   Quadrature* q = nullptr;
   int status = get_quadrature(t, n_gauss, &q);
   if (status != TC_OK) return status;
-  const int blocks =
-      (int)std::max<int64_t>(1, std::min<int64_t>(48, t->plan.n_positions / 400));
-  const size_t partial_bytes = (size_t)blocks * t->rt * sizeof(double);
-  if (t->single_ws.ptr == nullptr) {
-    status = t->single_ws.reserve(48 * 32 * sizeof(double) + 64, stream);
-    if (status != TC_OK) return status;
-    TC_HIP(hipMemsetAsync(t->single_ws.ptr, 0, t->single_ws.bytes, stream));
-  }
-  (void)partial_bytes;
+  // one pass of eight positions per thread: all of a thread's table loads are in flight
+  // together (a second pass costs another memory round trip, ~1.5 us)
+  const int n_slices = tc::kSingleThreads / t->rt;
+  const int blocks = (int)std::max<int64_t>(
+      1, std::min<int64_t>(kSingleMaxBlocks,
+                           (t->plan.n_positions + 8 * n_slices - 1) / (8 * n_slices)));
   tc::SingleArgs sa;
   for (int i = 0; i < 7; ++i) sa.theta_value[i] = i < n_theta ? theta[i] : 0.0;
   sa.n_theta = n_theta;
@@ -762,14 +762,64 @@ int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_gaus
   sa.rt = t->rt;
   sa.n_r = t->n_r;
   sa.mode = t->mode;
-  sa.partial = (double*)t->single_ws.ptr;
-  sa.counter = (unsigned*)((char*)t->single_ws.ptr + 48 * 32 * sizeof(double));
-  sa.ngal = ngal;
-  sa.xi = xi;
+  sa.ngal = host_ws;
+  sa.partial = host_ws + 2;
+  sa.n_tables = 0;
+  sa.blocks_per_table = blocks;
+  sa.tables = nullptr;
+  sa.table_class = nullptr;
+  sa.class_log_m = sa.class_m = sa.class_weight = sa.class_n_h = sa.class_percentile = nullptr;
+  sa.stamps = nullptr;
+  if (t->tuning.trace) {
+    // developer timeline (tc_table_set_option "trace"): 8 stamps per workgroup
+    status = t->trace.reserve(kSingleMaxBlocks * 8 * sizeof(unsigned long long), stream);
+    if (status != TC_OK) return status;
+    t->trace_blocks = (size_t)blocks;
+    sa.stamps = (unsigned long long*)t->trace.ptr;
+  }
   hipLaunchKernelGGL(tc::single_draw_kernel, dim3((unsigned)blocks),
                      dim3(tc::kSingleThreads), 0, stream, sa);
   TC_HIP(hipGetLastError());
+  *n_blocks = blocks;
   return TC_OK;
+}
+
+// The same for every table of an interpolator in one launch (interp.cpp fills the per-class
+// pointer arrays): host_ws holds (n_tables, 2) densities, then (n_tables, blocks, rt)
+// partial sums.
+int launch_single_draw_tables(tc_table* t0, const tc::SingleArgs& prepared, int n_tables,
+                              int blocks_per_table, hipStream_t stream) {
+  tc::SingleArgs sa = prepared;
+  sa.n_tables = n_tables;
+  sa.blocks_per_table = blocks_per_table;
+  sa.stamps = nullptr;
+  (void)t0;
+  hipLaunchKernelGGL(tc::single_draw_kernel, dim3((unsigned)(n_tables * blocks_per_table)),
+                     dim3(tc::kSingleThreads), 0, stream, sa);
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+
+int single_draw_blocks(const tc_table* t) {
+  const int n_slices = tc::kSingleThreads / t->rt;
+  return (int)std::max<int64_t>(
+      1, std::min<int64_t>(kSingleMaxBlocks,
+                           (t->plan.n_positions + 8 * n_slices - 1) / (8 * n_slices)));
+}
+
+// Host half of the un-batched path: the workgroups' partial sums in workgroup order,
+// divided by the total pair weight (tabcorr.py:646-650).
+void combine_single_draw(const tc_table* t, const double* host_ws, int n_blocks, double* ngal,
+                         double* xi) {
+  const double total = host_ws[0] + host_ws[1];
+  const double norm = t->mode == TC_MODE_AUTO ? total * total : total;
+  const double* partial = host_ws + 2;
+  for (int r = 0; r < t->n_r; ++r) {
+    double sum = 0.0;
+    for (int b = 0; b < n_blocks; ++b) sum += partial[(size_t)b * t->rt + r];
+    xi[r] = sum / norm;
+  }
+  ngal[0] = total;
 }
 
 int launch_finalize(const FinalizeArgs& args, const Tuning& tuning, hipStream_t stream) {

@@ -206,7 +206,7 @@ int tc_table_destroy(tc_table* t) {
   t->quad_by_type.release();
   t->quad_total.release();
   for (DeviceBuffer* b : {&t->theta, &t->out_ngal, &t->out_xi, &t->occupation,
-                          &t->trace, &t->wave_trace, &t->single_ws, &t->chi2_data})
+                          &t->trace, &t->wave_trace, &t->chi2_data})
     b->release();
   for (tc_table::Lane& lane : t->lanes) {
     lane.nbuf.release();
@@ -339,20 +339,26 @@ int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
   // the results to page-locked host memory, which the device addresses directly; two API
   // calls and two copy-engine round trips less (1 draw 45 -> 40 us, 1000 draws 72 -> 54 us;
   // beyond ~1 MB the copy engines win).
+  if (single_draw_eligible(t, n_draws, n_gauss, flags) &&
+      t->h_out.reserve(kSingleWsDoubles * sizeof(double)) == TC_OK) {
+    // one draw: one launch, the device-side combination replaced by a few hundred additions
+    // here (kernels.hip.h: single_draw_kernel)
+    int n_blocks = 0;
+    status = launch_single_draw(t, theta, n_theta, n_gauss, flags, (double*)t->h_out.ptr,
+                                &n_blocks, t->stream);
+    if (status != TC_OK) return status;
+    TC_HIP(hipStreamSynchronize(t->stream));
+    combine_single_draw(t, (const double*)t->h_out.ptr, n_blocks, ngal, xi);
+    return TC_OK;
+  }
   if (theta_bytes + out_bytes <= zero_copy_limit() && t->h_in.reserve(theta_bytes) == TC_OK &&
       t->h_out.reserve(out_bytes) == TC_OK) {
     memcpy(t->h_in.ptr, theta, theta_bytes);
     double* h = (double*)t->h_out.ptr;
-    if (single_draw_eligible(t, n_draws, n_gauss, flags)) {
-      // one draw: one launch (kernels.hip.h: single_draw_kernel)
-      status = launch_single_draw(t, theta, n_theta, n_gauss, flags, h, h + ngal_count,
-                                  t->stream);
-    } else {
-      t->force_lane = 0;
-      status = tc_predict_zheng07_batch_device(t, (const double*)t->h_in.ptr, n_theta,
-                                               n_draws, n_gauss, flags, h, h + ngal_count);
-      t->force_lane = -1;
-    }
+    t->force_lane = 0;
+    status = tc_predict_zheng07_batch_device(t, (const double*)t->h_in.ptr, n_theta,
+                                             n_draws, n_gauss, flags, h, h + ngal_count);
+    t->force_lane = -1;
     if (status != TC_OK) return status;
     TC_HIP(hipStreamSynchronize(t->stream));
     memcpy(ngal, h, ngal_count * 8);
@@ -579,6 +585,8 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     t->prev = -1;
   } else if (key == "single_draw") {
     t->tuning.single_draw = value != 0;
+  } else if (key == "trace") {
+    t->tuning.trace = value;
   } else {
     return fail(TC_ERR_INVALID, "unknown option '%s'", name);
   }

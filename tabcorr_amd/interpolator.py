@@ -60,6 +60,26 @@ class _DeviceInterpolator:
         self.handle = handle
         self.lib = lib
         self.tables = devices          # keep the table handles alive
+        # scratch of the un-batched predict(model) path (see
+        # tabcorr._DeviceTable.predict_one)
+        self._one_theta = np.zeros(16)
+        self._one_x = np.zeros(points.shape[1])
+        self._one_ngal = np.zeros(1)
+        self._one_xi = np.zeros(devices[0].n_r)
+        self._one_pointers = tuple(_lib.as_double_p(a) for a in (
+            self._one_theta, self._one_x, self._one_ngal, self._one_xi))
+        self._one_call = lib.tc_interp_predict_zheng07_batch
+
+    def predict_one(self, theta, x, n_gauss_prim, flags):
+        n_theta = len(theta)
+        self._one_theta[:n_theta] = theta
+        self._one_x[:] = x
+        p_theta, p_x, p_ngal, p_xi = self._one_pointers
+        status = self._one_call(self.handle, p_theta, n_theta, p_x, 1,
+                                n_gauss_prim, flags, p_ngal, p_xi)
+        if status:
+            _lib.check(status)
+        return self._one_ngal[0], self._one_xi.copy()
 
     def __del__(self):
         handle = getattr(self, 'handle', None)
@@ -188,6 +208,13 @@ class Interpolator:
             return self._predict_generic(model, x, separate_gal_type,
                                          n_gauss_prim, extrapolate,
                                          **occ_kwargs)
+        if not separate_gal_type:
+            self._check_range(x, extrapolate)
+            ngal, xi = self.to_device().predict_one(
+                spec.theta, x, n_gauss_prim,
+                _flags(False, spec.modulate_with_cenocc, spec.assembias,
+                       spec.family))
+            return ngal, xi.reshape(self.tabcorr_list[0].tpcf_shape)
         return _unbatch(*self.predict_batch(
             spec.theta[np.newaxis], x[np.newaxis],
             separate_gal_type=separate_gal_type, n_gauss_prim=n_gauss_prim,

@@ -85,6 +85,28 @@ class _DeviceTable:
         self.n_r = matrix.shape[0]
         self.n_components = 3 if mode == 'auto' else 2
         self.compute_dtype = compute_dtype
+        # scratch of the un-batched predict(model) path: one draw in, one
+        # (ngal, xi) out, with the ctypes pointers made once
+        self._one_theta = np.zeros(16)
+        self._one_ngal = np.zeros(1)
+        self._one_xi = np.zeros(self.n_r)
+        self._one_pointers = (_lib.as_double_p(self._one_theta),
+                              _lib.as_double_p(self._one_ngal),
+                              _lib.as_double_p(self._one_xi))
+        self._one_call = lib.tc_predict_zheng07_batch
+
+    def predict_one(self, theta, n_gauss_prim, flags):
+        """Total prediction of ONE parameter vector (the reference's usage:
+        one ``predict`` per MCMC step, ``README.md:72-75``) with as little
+        Python between the caller and the C ABI as possible."""
+        n_theta = len(theta)
+        self._one_theta[:n_theta] = theta
+        p_theta, p_ngal, p_xi = self._one_pointers
+        status = self._one_call(self.handle, p_theta, n_theta, 1, n_gauss_prim,
+                                flags, p_ngal, p_xi)
+        if status:
+            _lib.check(status)
+        return self._one_ngal[0], self._one_xi.copy()
 
     def __del__(self):
         handle = getattr(self, 'handle', None)
@@ -329,6 +351,12 @@ class TabCorr:
                 model, n_gauss_prim, **occ_kwargs)
             return _unbatch(*self._predict_occupation(
                 occupation[np.newaxis], separate_gal_type))
+        if not separate_gal_type:
+            ngal, xi = self.to_device().predict_one(
+                spec.theta, n_gauss_prim,
+                _flags(False, spec.modulate_with_cenocc, spec.assembias,
+                       spec.family))
+            return ngal, xi.reshape(self.tpcf_shape)
         return _unbatch(*self.predict_batch(
             spec.theta[np.newaxis], separate_gal_type=separate_gal_type,
             n_gauss_prim=n_gauss_prim,
