@@ -446,19 +446,25 @@ def test_rccl_communicator_single_rank():
     _lib.check(lib.tc_comm_destroy(comm))
 
 
-def test_bench_under_torchrun_single_rank():
+@pytest.mark.parametrize('mode', ['default', 'chi2 gather', 'interp5x5'])
+def test_bench_under_torchrun_single_rank(mode):
     """bench.py as the driver launches it (torch.distributed.run), one rank, with the
-    communicator forced on: gloo control plane next to the HIP library, RCCL gather
-    per step."""
+    communicator forced on: gloo control plane next to the HIP library, RCCL gather per
+    block of steps -- the default workload, the 16-bytes-per-draw likelihood gather, and
+    BASELINE configs[3] (Interpolator over a 5 x 5 grid, results gathered over RCCL)."""
     import json
     import subprocess
     from util import REPO
     env = dict(os.environ, TABCORR_AMD_FORCE_COMM='1', MASTER_ADDR='127.0.0.1')
+    extra = {'default': ['--steps', '20', '--warmup', '3'],
+             'chi2 gather': ['--steps', '20', '--warmup', '3', '--gather', 'chi2'],
+             'interp5x5': ['--workload', 'interp5x5', '--draws', '12500', '--steps', '6',
+                           '--warmup', '2', '--gather-every', '2']}[mode]
     result = subprocess.run(
         [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
          '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port',
-         '29533', os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '20',
-         '--warmup', '3', '--cpu-seconds', '0'],
+         '29533', os.path.join(REPO, 'bench.py'), '--gpus', '1', '--cpu-seconds', '0',
+         '--settle-seconds', '0.05', '--other-configs', '0'] + extra,
         env=env, capture_output=True, text=True, timeout=900)
     assert result.returncode == 0, result.stdout[-2000:] + result.stderr[-2000:]
     line = [l for l in result.stdout.splitlines() if l.startswith('{')][-1]
@@ -466,6 +472,12 @@ def test_bench_under_torchrun_single_rank():
     assert record['n_gpus'] == 1 and record['value'] > 1e6
     assert record['config']['gather'] == 'rccl', record['config']
     assert record['parity_max_rel_vs_oracle'] < 1e-10
+    assert 0.1 < record['roofline']['frac'] < 1.0
+    if mode == 'interp5x5':
+        assert record['scaling'] == 'strong' and record['config']['n_tables'] == 25
+        assert record['roofline']['kernel'] == 'tc::contract_quad_kernel<5, true>'
+    if mode == 'chi2 gather':
+        assert '16 B' in record['config']['gather_payload']
 
 
 def test_read_hdf5_and_predict():
