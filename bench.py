@@ -363,10 +363,16 @@ def main():
         drain()
         per_step = max((time.perf_counter() - t_probe) / probe, 1e-6)
         settle_steps = int(args.settle_seconds / per_step) + 1
-        for index in range(settle_steps):
-            step(index)
-        flush(settle_steps)
-        drain()
+        # in chunks with a drain after each: the runtime retires finished commands lazily, and
+        # thousands of them left over from one long burst make later launches stall
+        # (tools/stall.py: 60-100 us per launch for a while, as long as 10 steps)
+        chunk = 4 * n_slots
+        for begin in range(0, settle_steps, chunk):
+            count = min(chunk, settle_steps - begin)
+            for index in range(count):
+                step(index)
+            flush(count)
+            drain()
         settle_steps += probe
     for index in range(args.warmup):
         step(index)
@@ -374,15 +380,24 @@ def main():
     drain()
 
     # ---- timed region: exactly `steps` steps between barrier + device sync -----------
+    # (no garbage collection inside it: a full collection pass of the interpreter stalls
+    # the enqueueing thread for hundreds of microseconds, longer than 10 steps)
+    import gc
+    gc.disable()
     comm.barrier()
     drain()
     t0 = time.perf_counter()
     for index in range(args.steps):
         step(index)
+    t_queued = time.perf_counter()
     flush(args.steps)
     drain()
+    t_drained = time.perf_counter()
     comm.barrier()
     elapsed = comm.max(time.perf_counter() - t0)
+    breakdown = {'enqueue': (t_queued - t0) * 1e6, 'drain': (t_drained - t_queued) * 1e6,
+                 'barrier': (time.perf_counter() - t_drained) * 1e6}
+    gc.enable()
 
     if comm.dist is not None and not use_rccl:
         # RCCL unavailable: collect the last batch over gloo so that the job still
@@ -455,6 +470,7 @@ def main():
             'steps': args.steps,
             'warmup': args.warmup,
             'settle_steps': settle_steps,
+            'timed_region_breakdown_us': breakdown,
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True,
             'scaling': 'strong' if interp_mode else 'weak',
