@@ -209,6 +209,8 @@ def main():
     parser.add_argument('--lanes', type=int, default=0,
                         help='pipelining lanes of the timed region (default: library '
                              'default, 4); 1 serialises the kernels, e.g. under rocprofv3')
+    parser.add_argument('--option', action='append', default=[],
+                        help='developer A/B: tc_table_set_option name=value (repeatable)')
     parser.add_argument('--settle-seconds', type=float, default=0.3,
                         help='untimed load before the warm-up steps (power management)')
     parser.add_argument('--cpu-seconds', type=float, default=12.0,
@@ -281,6 +283,9 @@ def main():
         n_tables = 1
     if args.lanes > 0:
         _lib.check(lib.tc_table_set_option(timer_handle, b'lanes', args.lanes))
+    for option in args.option:
+        name, value = option.split('=')
+        _lib.check(lib.tc_table_set_option(timer_handle, name.encode(), int(value)))
     chi2_mode = args.gather == 'chi2' and not interp_mode
     n_out = n_draws * (2 if chi2_mode else 1 + N_R)     # ngal | xi (B, R), or ngal | chi2
     d_theta = dev.upload(theta)

@@ -381,6 +381,53 @@ void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, in
   for (int g = 0; g < out.n_groups; ++g) out.group_begin[g + 1] += out.group_begin[g];
 }
 
+void merge_quad_schedule(const QuadLayout& layout, int n_rtiles, bool separate,
+                         int waves_per_block, int max_slots, QuadSchedule& schedule,
+                         QuadMergePlan& plan) {
+  const int groups_per_rtile = separate ? (int)layout.comps.size() : 1;
+  auto group_of = [&](const QuadRun& run) {
+    return ((int64_t)run.tile * n_rtiles + run.rtile) * groups_per_rtile +
+           (separate ? run.comp : 0);
+  };
+  plan.waves_per_block = waves_per_block;
+  plan.n_blocks = (schedule.n_waves + waves_per_block - 1) / waves_per_block;
+  plan.lds_slots = 0;
+  plan.block_begin.assign((size_t)plan.n_blocks + 1, 0);
+  plan.merges.clear();
+  std::vector<int32_t> slab_group;
+  int next_slab = 0;
+  for (int block = 0; block < plan.n_blocks; ++block) {
+    const int w_begin = block * waves_per_block;
+    const int w_end = std::min(schedule.n_waves, w_begin + waves_per_block);
+    std::vector<int> flushes;      // runs of this workgroup that flush, in order
+    for (int ri = schedule.wave_runs[w_begin]; ri < schedule.wave_runs[w_end]; ++ri)
+      if (schedule.runs[ri].slab >= 0) flushes.push_back(ri);
+    if ((int)flushes.size() > max_slots || flushes.size() < 2) {
+      for (int ri : flushes) {      // direct form, renumbered
+        schedule.runs[ri].slab = next_slab++;
+        slab_group.push_back((int32_t)group_of(schedule.runs[ri]));
+      }
+    } else {
+      plan.lds_slots = std::max(plan.lds_slots, (int)flushes.size());
+      for (size_t k = 0; k < flushes.size(); ++k) {
+        const int64_t group = group_of(schedule.runs[flushes[k]]);
+        if (k == 0 || group != group_of(schedule.runs[flushes[k - 1]])) {
+          plan.merges.push_back({next_slab++, (int32_t)k, 0, 0});
+          slab_group.push_back((int32_t)group);
+        }
+        ++plan.merges.back().count;
+        schedule.runs[flushes[k]].slab = -2 - (int32_t)k;
+      }
+    }
+    plan.block_begin[(size_t)block + 1] = (int32_t)plan.merges.size();
+  }
+  schedule.n_slabs = next_slab;
+  schedule.group_begin.assign((size_t)schedule.n_groups + 1, 0);
+  for (int32_t g : slab_group) ++schedule.group_begin[(size_t)g + 1];
+  for (int g = 0; g < schedule.n_groups; ++g)
+    schedule.group_begin[g + 1] += schedule.group_begin[g];
+}
+
 QuadTiling quad_tiling(int n_r) {
   QuadTiling tiling;
   tiling.n_rtiles = (n_r + 19) / 20;
@@ -431,7 +478,7 @@ void fill_quad_table(const QuadLayout& layout, const std::vector<int32_t>& perm,
 void quad_emulate(const QuadLayout& layout, const QuadSchedule& schedule,
                   const QuadTiling& tiling, const std::vector<double>& table,
                   const double* densities, int64_t ldb, int64_t n_draws, int n_r,
-                  bool separate, double* out) {
+                  bool separate, double* out, const QuadMergePlan* merge) {
   const int n_u = tiling.n_u, up = (n_u + 1) / 2, rt = 4 * n_u;
   const size_t per_unit = (size_t)up * 128;
   const int n_comp_out = separate ? (int)layout.comps.size() : 1;
@@ -440,6 +487,8 @@ void quad_emulate(const QuadLayout& layout, const QuadSchedule& schedule,
   auto density = [&](int bin, int64_t draw) {
     return bin < layout.n_bins ? densities[(size_t)bin * ldb + draw] : 0.0;
   };
+  // LDS slots of the workgroup being emulated (merge plan)
+  std::vector<double> stage(merge ? (size_t)std::max(1, merge->lds_slots) * rt * 32 : 0, 0.0);
   for (int w = 0; w < schedule.n_waves; ++w) {
     std::vector<double> f((size_t)n_u * 2 * 64, 0.0);      // F[u][set] per lane
     for (int ri = schedule.wave_runs[w]; ri < schedule.wave_runs[w + 1]; ++ri) {
@@ -483,14 +532,30 @@ void quad_emulate(const QuadLayout& layout, const QuadSchedule& schedule,
         ++rb;
         cb = 0;
       }
-      if (run.slab >= 0) {
+      if (run.slab >= 0 || run.slab <= -2) {
+        double* target = run.slab >= 0 ? partial.data() + (size_t)run.slab * rt * 32
+                                       : stage.data() + (size_t)(-2 - run.slab) * rt * 32;
         for (int u = 0; u < n_u; ++u)
           for (int set = 0; set < 2; ++set)
             for (int l = 0; l < 64; ++l) {
-              partial[((size_t)run.slab * rt + 4 * u + (l >> 4)) * 32 + 2 * (l & 15) + set] =
+              target[((size_t)4 * u + (l >> 4)) * 32 + 2 * (l & 15) + set] =
                   f[((size_t)u * 2 + set) * 64 + l];
               f[((size_t)u * 2 + set) * 64 + l] = 0.0;
             }
+      }
+    }
+    // end of a workgroup: its merges, LDS slots added in slot order
+    if (merge != nullptr &&
+        ((w + 1) % merge->waves_per_block == 0 || w + 1 == schedule.n_waves)) {
+      const int block = w / merge->waves_per_block;
+      for (int e = merge->block_begin[block]; e < merge->block_begin[block + 1]; ++e) {
+        const QuadMerge& m = merge->merges[e];
+        for (int k = 0; k < rt * 32; ++k) {
+          double sum = 0.0;
+          for (int slot = m.first_slot; slot < m.first_slot + m.count; ++slot)
+            sum += stage[(size_t)slot * rt * 32 + k];
+          partial[(size_t)m.slab * rt * 32 + k] = sum;
+        }
       }
     }
   }

@@ -173,6 +173,31 @@ void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, in
                          bool separate, int max_waves, int min_units_per_wave,
                          QuadSchedule& out);
 
+// Workgroup-level merging of the slabs.  Consecutive waves walk consecutive ranges, so the
+// waves of one workgroup mostly end / start inside the same output group and each would
+// write its own slab of it.  After this pass a run's `slab` is
+//   >= 0   a slab of the partial buffer the wave writes itself (workgroups with more
+//          flushes than `max_slots` keep this direct form), or
+//   <= -2  LDS slot -2 - slab of its workgroup,
+// and per workgroup a list of merges says which consecutive LDS slots are added (in slot
+// order) into which slab of the partial buffer.  Slabs stay numbered in group order.
+struct QuadMerge {
+  int32_t slab;         // destination in the partial buffer
+  int32_t first_slot;   // LDS slots first_slot .. first_slot + count - 1
+  int32_t count;
+  int32_t pad;
+};
+struct QuadMergePlan {
+  int waves_per_block = 0;
+  int n_blocks = 0;
+  int lds_slots = 0;                       // most LDS slots any workgroup needs
+  std::vector<int32_t> block_begin;        // (n_blocks + 1) into merges
+  std::vector<QuadMerge> merges;
+};
+void merge_quad_schedule(const QuadLayout& layout, int n_rtiles, bool separate,
+                         int waves_per_block, int max_slots, QuadSchedule& schedule,
+                         QuadMergePlan& plan);
+
 // r tiling of the quadratic-form kernel: n_rtiles tiles of r_per_tile values (the last one
 // may hold fewer), n_u = ceil(r_per_tile / 4) <= 5 sub-tiles of 4.
 struct QuadTiling {
@@ -197,7 +222,7 @@ void fill_quad_table(const QuadLayout& layout, const std::vector<int32_t>& perm,
 void quad_emulate(const QuadLayout& layout, const QuadSchedule& schedule,
                   const QuadTiling& tiling, const std::vector<double>& table,
                   const double* densities, int64_t ldb, int64_t n_draws, int n_r,
-                  bool separate, double* out);
+                  bool separate, double* out, const QuadMergePlan* merge = nullptr);
 
 // ---- pair counting (paircount.hip): cell grid of a periodic box ----------------------------
 //

@@ -158,6 +158,9 @@ struct DeviceQuadSchedule {
   void* runs = nullptr;
   void* wave_runs = nullptr;
   void* group_begin = nullptr;
+  void* merge_range = nullptr;   // (workgroups, 2)
+  void* merges = nullptr;        // QuadMerge per merge
+  int lds_bytes = 0;             // merge slots of the busiest workgroup
 };
 
 // One layout of a table for the quadratic-form kernel: the re-laid-out matrix, the
@@ -192,6 +195,7 @@ struct Tuning {
   int pipeline = 1;           // 0: every device-pointer call on lane 0 (kernels serialised)
   int single_draw = 1;        // one-launch path for un-batched predict()
   int quad_waves = 2;         // resident contraction waves per SIMD (quadratic-form kernel)
+  int quad_merge = 1;         // workgroup-level merging of the partial slabs (hostmath.h)
   int prio_occ = 0, prio_contract = 1, prio_finalize = 3;   // wave priorities
   int finalize_threads = 0;   // 0: chosen per batch size
   int finalize_row_blocks = 0;
@@ -206,6 +210,7 @@ struct Tuning {
     pipeline = env_int("TC_PIPELINE", pipeline);
     single_draw = env_int("TC_SINGLE_DRAW", single_draw);
     quad_waves = env_int("TC_QUAD_WAVES", quad_waves);
+    quad_merge = env_int("TC_QUAD_MERGE", quad_merge);
     prio_occ = env_int("TC_PRIO_O", prio_occ);
     prio_contract = env_int("TC_PRIO_C", prio_contract);
     prio_finalize = env_int("TC_PRIO_F", prio_finalize);
@@ -340,8 +345,8 @@ int build_quad_table(tc_table* t, bool by_type, const void* matrix, int matrix_d
                      QuadTable* out);
 int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, bool separate,
                       DeviceQuadSchedule** out);
-int launch_contract_quad(int n_u, bool interp, const QuadArgs& args, hipStream_t stream,
-                         hipEvent_t start, hipEvent_t stop);
+int launch_contract_quad(int n_u, bool interp, const QuadArgs& args, int lds_bytes,
+                         hipStream_t stream, hipEvent_t start, hipEvent_t stop);
 int launch_finalize_quad(const FinalizeQuadArgs& args, const Tuning& tuning, hipStream_t stream);
 // Stream an interpolator's work is queued on (interp.cpp).
 hipStream_t interp_stream(tc_interp* interp);

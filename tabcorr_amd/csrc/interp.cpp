@@ -85,7 +85,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
 
   status = it->coef.reserve((size_t)it->n_tables * ldb * sizeof(double), it->stream);
   if (status != TC_OK) return status;
-  tc::InterpArgs ia;
+  tc::InterpArgs ia{};
   ia.n_dim = it->n_dim;
   ia.n_tables = it->n_tables;
   ia.n_classes = n_classes;
@@ -127,7 +127,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
     status = it->partial.reserve(
         (size_t)schedule->n_slabs * rt * tc::kQuadTile * sizeof(double), it->stream);
     if (status != TC_OK) return status;
-    tc::QuadArgs qa;
+    tc::QuadArgs qa{};
     qa.nbuf = nullptr;
     qa.nbufs = (const double* const*)it->d_nbufs;
     qa.ldb = ldb;
@@ -143,12 +143,15 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
     qa.n_waves = schedule->n_waves;
     qa.partial = (double*)it->partial.ptr;
     qa.priority = t0->tuning.prio_contract;
+    qa.merge_range = (const int32_t*)schedule->merge_range;
+    qa.merges = (const int32_t*)schedule->merges;
+    qa.stamps = nullptr;
     hipEvent_t k0 = nullptr, k1 = nullptr;     // timed through the first table's timer
     status = next_kernel_events(t0, &k0, &k1);
     if (status != TC_OK) return status;
-    status = launch_contract_quad(tiling.n_u, true, qa, it->stream, k0, k1);
+    status = launch_contract_quad(tiling.n_u, true, qa, schedule->lds_bytes, it->stream, k0, k1);
     if (status != TC_OK) return status;
-    tc::FinalizeQuadArgs fq;
+    tc::FinalizeQuadArgs fq{};
     fq.partial = (const double*)it->partial.ptr;
     fq.group_begin = (const int32_t*)schedule->group_begin;
     fq.ngal_part = nullptr;      // already normalised; ngal written by the coef kernel
@@ -201,7 +204,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
       (size_t)n_groups * k_splits * r_stride * ldb * sizeof(double), it->stream);
   if (status != TC_OK) return status;
 
-  tc::ContractArgs ca;
+  tc::ContractArgs ca{};
   ca.nbuf = nullptr;
   ca.ldb = ldb;
   ca.table = nullptr;
@@ -244,7 +247,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   }
   if (status != TC_OK) return status;
 
-  tc::FinalizeArgs fa;
+  tc::FinalizeArgs fa{};
   fa.partial = (const double*)it->partial.ptr;
   fa.groups = (const tc::Group*)c->groups;
   fa.ngal_part = nullptr;      // already normalised; ngal written by the coef kernel
@@ -490,7 +493,7 @@ int interp_predict_one(tc_interp* it, const double* theta, int n_theta, const do
   int status = it->h_out.reserve(ws_doubles * sizeof(double));
   if (status != TC_OK) return status;
   double* ws = (double*)it->h_out.ptr;
-  tc::SingleArgs sa;
+  tc::SingleArgs sa{};
   for (int i = 0; i < 7; ++i) sa.theta_value[i] = i < n_theta ? theta[i] : 0.0;
   sa.n_theta = n_theta;
   sa.n_bins = t0->n_bins;

@@ -143,6 +143,9 @@ struct QuadArgs {
   int n_waves;
   int priority;                    // wave priority (0..3)
   double* partial;                 // (n_slabs, 4 U, 32)
+  const int32_t* merge_range;      // (workgroups, 2): first and end merge of every workgroup
+  const int32_t* merges;           // QuadMerge = 4 x int32: slab, first LDS slot, count, -
+  unsigned long long* stamps;      // developer timeline: 6 words per wave, or NULL
 };
 
 struct FinalizeQuadArgs {

@@ -767,15 +767,21 @@ template <int U, bool INTERP>
 __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_kernel(QuadArgs a) {
   constexpr int UP = (U + 1) / 2;
   constexpr bool interp = INTERP;
+  extern __shared__ __attribute__((aligned(16))) double stage[];   // merge slots (4 U, 32) each
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(
-      (int)blockIdx.x * kQuadWavesPerBlock + (int)(threadIdx.x >> 6));
-  if (wave >= a.n_waves) return;
+  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave = (int)blockIdx.x * kQuadWavesPerBlock + wave_in_block;
   set_priority(a.priority);
   sc_i32 wave_runs = (sc_i32)a.wave_runs;
   sc_i32 runs = (sc_i32)a.runs;       // QuadRun = 8 x int32
   sc_i32 comps = (sc_i32)a.comps;     // QuadCompArgs = 8 x int32
-  const int run_begin = wave_runs[2 * wave], run_end = wave_runs[2 * wave + 1];
+  // (a workgroup beyond the last wave has no runs but still meets the others at the barrier)
+  // developer timeline: entry, first operands in, last matrix instruction issued, sums
+  // written, end (100 MHz) and the shader clock cycles between the second and the third
+  unsigned long long t_entry = 0, t_first = 0, t_main = 0, t_flushed = 0, c_first = 0, c_main = 0;
+  if (a.stamps) t_entry = __builtin_amdgcn_s_memrealtime();
+  const int run_begin = wave < a.n_waves ? wave_runs[2 * wave] : 0;
+  const int run_end = wave < a.n_waves ? wave_runs[2 * wave + 1] : 0;
   const int c = lane & 15, kq = lane >> 4;
   const unsigned row_bytes = (unsigned)(a.ldb * 8);
   const unsigned off_a = lane * 16;                    // table: (unit, u pair, lane) x 16 B
@@ -843,6 +849,12 @@ __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_kern
       }
     };
     fetch(t0, b0, cb);
+    if (a.stamps && ri == run_begin) {
+      // (waits for the first operands: reading them forces the loads to land)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      t_first = __builtin_amdgcn_s_memrealtime();
+      c_first = __builtin_amdgcn_s_memtime();
+    }
     while (left > 0) {
       // the units of one block row inside this run: n >= 1; on entry the first one is
       // in (t0, b0)
@@ -897,9 +909,15 @@ __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_kern
       ++rb;
       cb = 0;
     }
-    if (slab >= 0) {
-      // r = 4 u + l / 16, draws 2 c and 2 c + 1 of the tile
-      double* out = a.partial + ((int64_t)slab * (4 * U) + kq) * kQuadTile + 2 * c;
+    if (a.stamps) {
+      t_main = __builtin_amdgcn_s_memrealtime();
+      c_main = __builtin_amdgcn_s_memtime();
+    }
+    if (slab != -1) {
+      // r = 4 u + l / 16, draws 2 c and 2 c + 1 of the tile: to a slab of the partial buffer,
+      // or to an LDS slot of the workgroup that is merged with its neighbours below
+      double* out = slab >= 0 ? a.partial + ((int64_t)slab * (4 * U) + kq) * kQuadTile + 2 * c
+                              : stage + ((-2 - slab) * (4 * U) + kq) * kQuadTile + 2 * c;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const f64x2 value = {F[u][0], F[u][1]};
@@ -908,6 +926,42 @@ __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_kern
       }
     }
   }
+  // Workgroup-level merge (hostmath.h: QuadMergePlan): the waves of a workgroup mostly end
+  // and start inside the same output group; their sums are added here, in slot order, and
+  // leave as ONE slab -- a third of the partial-buffer traffic of one slab per wave.
+  if (a.stamps) t_flushed = __builtin_amdgcn_s_memrealtime();
+  auto write_stamps = [&]() {
+    if (a.stamps && lane == 0 && wave < a.n_waves) {
+      unsigned long long* out = a.stamps + (size_t)wave * 6;
+      out[0] = t_entry;
+      out[1] = t_first;
+      out[2] = t_main;
+      out[3] = t_flushed;
+      out[4] = __builtin_amdgcn_s_memrealtime();
+      out[5] = c_main - c_first;     // shader clock cycles of the main loop(s)
+    }
+  };
+  sc_i32 merge_range = (sc_i32)a.merge_range;
+  const int merge_begin = merge_range[2 * blockIdx.x], merge_end = merge_range[2 * blockIdx.x + 1];
+  if (merge_begin == merge_end) {          // (uniform over the workgroup)
+    write_stamps();
+    return;
+  }
+  __syncthreads();
+  sc_i32 merges = (sc_i32)a.merges;
+  for (int e = merge_begin + wave_in_block; e < merge_end; e += kQuadWavesPerBlock) {
+    const int slab = merges[4 * e], first = merges[4 * e + 1], count = merges[4 * e + 2];
+    double* out = a.partial + ((int64_t)slab * (4 * U) + kq) * kQuadTile + 2 * c;
+    const double* in = stage + (first * (4 * U) + kq) * kQuadTile + 2 * c;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      f64x2 sum = *(const f64x2*)(in + (4 * u) * kQuadTile);
+      for (int s = 1; s < count; ++s)
+        sum += *(const f64x2*)(in + (s * (4 * U) + 4 * u) * kQuadTile);
+      *(f64x2*)(out + (4 * u) * kQuadTile) = sum;
+    }
+  }
+  write_stamps();
 }
 
 // Sums the slabs of every output group in slab order, normalises and writes the results

@@ -185,7 +185,8 @@ void QuadTable::release() {
     if (p) (void)hipFree(p);
   d_table = d_comps = nullptr;
   for (auto& kv : schedules)
-    for (void* p : {kv.second->runs, kv.second->wave_runs, kv.second->group_begin})
+    for (void* p : {kv.second->runs, kv.second->wave_runs, kv.second->group_begin,
+                    kv.second->merge_range, kv.second->merges})
       if (p) (void)hipFree(p);
   schedules.clear();
 }
@@ -238,8 +239,14 @@ int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, 
   tc::QuadSchedule schedule;
   tc::build_quad_schedule(q->layout, (int)n_tiles, t->quad_tiling.n_rtiles, n_tables, separate,
                           max_waves, 8, schedule);
+  // workgroup-level merging of the slabs: at most 12 LDS slots (60 KB for 20 r values) per
+  // workgroup of kQuadWavesPerBlock waves, two workgroups per CU
+  tc::QuadMergePlan merge;
+  tc::merge_quad_schedule(q->layout, t->quad_tiling.n_rtiles, separate, tc::kQuadWavesPerBlock,
+                          t->tuning.quad_merge ? 12 : 0, schedule, merge);
   std::unique_ptr<DeviceQuadSchedule> d(new DeviceQuadSchedule);
   d->n_waves = schedule.n_waves;
+  d->lds_bytes = merge.lds_slots * 4 * t->quad_tiling.n_u * tc::kQuadTile * (int)sizeof(double);
   d->n_slabs = schedule.n_slabs;
   d->n_groups = schedule.n_groups;
   d->n_runs = (int)schedule.runs.size();
@@ -249,9 +256,9 @@ int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, 
   // (consecutive shares) read its density rows through ONE L2 instead of eight.  Per wave
   // the kernel gets [first run, end run).
   std::vector<int32_t> wave_range((size_t)schedule.n_waves * 2);
+  std::vector<int32_t> merge_range((size_t)merge.n_blocks * 2, 0);
   {
     const int per_block = tc::kQuadWavesPerBlock;
-    const int n_blocks = schedule.n_waves / per_block;
     const bool by_xcd = t->n_xcds == 8 && schedule.n_waves % (8 * per_block) == 0;
     for (int share = 0; share < schedule.n_waves; ++share) {
       int wave = share;
@@ -260,16 +267,22 @@ int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, 
         const int xcd = share / per_xcd, local = share % per_xcd;
         const int block = xcd + 8 * (local / per_block);
         wave = block * per_block + local % per_block;
-        (void)n_blocks;
       }
       wave_range[2 * (size_t)wave] = schedule.wave_runs[share];
       wave_range[2 * (size_t)wave + 1] = schedule.wave_runs[share + 1];
+      if (share % per_block == 0) {      // the workgroup of these shares
+        const int block = wave / per_block, share_block = share / per_block;
+        merge_range[2 * (size_t)block] = merge.block_begin[share_block];
+        merge_range[2 * (size_t)block + 1] = merge.block_begin[share_block + 1];
+      }
     }
   }
   if (status == TC_OK) status = upload(wave_range, &d->wave_runs);
+  if (status == TC_OK) status = upload(merge_range, &d->merge_range);
+  if (status == TC_OK) status = upload(merge.merges, &d->merges);
   if (status == TC_OK) status = upload(schedule.group_begin, &d->group_begin);
   if (status != TC_OK) {
-    for (void* p : {d->runs, d->wave_runs, d->group_begin})
+    for (void* p : {d->runs, d->wave_runs, d->group_begin, d->merge_range, d->merges})
       if (p) (void)hipFree(p);
     return status;
   }
@@ -298,8 +311,8 @@ int next_kernel_events(tc_table* t, hipEvent_t* start, hipEvent_t* stop) {
   return TC_OK;
 }
 
-int launch_contract_quad(int n_u, bool interp, const tc::QuadArgs& args, hipStream_t stream,
-                         hipEvent_t start, hipEvent_t stop) {
+int launch_contract_quad(int n_u, bool interp, const tc::QuadArgs& args, int lds_bytes,
+                         hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
   const dim3 grid((unsigned)((args.n_waves + tc::kQuadWavesPerBlock - 1) /
                              tc::kQuadWavesPerBlock));
   const dim3 block(64 * tc::kQuadWavesPerBlock);
@@ -308,11 +321,11 @@ int launch_contract_quad(int n_u, bool interp, const tc::QuadArgs& args, hipStre
 #define TC_CASE(N)                                                                          \
   case N:                                                                                   \
     if (interp)                                                                             \
-      hipExtLaunchKernelGGL((tc::contract_quad_kernel<N, true>), grid, block, 0, stream,  \
-                            start, stop, 0, args);                                        \
+      hipExtLaunchKernelGGL((tc::contract_quad_kernel<N, true>), grid, block, lds_bytes,  \
+                            stream, start, stop, 0, args);                                \
     else                                                                                    \
-      hipExtLaunchKernelGGL((tc::contract_quad_kernel<N, false>), grid, block, 0, stream, \
-                            start, stop, 0, args);                                        \
+      hipExtLaunchKernelGGL((tc::contract_quad_kernel<N, false>), grid, block, lds_bytes, \
+                            stream, start, stop, 0, args);                                \
     break;
     TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4) TC_CASE(5)
 #undef TC_CASE
@@ -358,7 +371,7 @@ static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsig
       (size_t)schedule->n_slabs * rt * tc::kQuadTile * sizeof(double), stream);
   if (status != TC_OK) return status;
 
-  tc::QuadArgs qa;
+  tc::QuadArgs qa{};
   qa.nbuf = (const double*)lane.nbuf.ptr;
   qa.nbufs = nullptr;
   qa.ldb = ldb;
@@ -374,18 +387,28 @@ static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsig
   qa.n_waves = schedule->n_waves;
   qa.partial = (double*)lane.partial.ptr;
   qa.priority = t->tuning.prio_contract;
+  qa.merge_range = (const int32_t*)schedule->merge_range;
+  qa.merges = (const int32_t*)schedule->merges;
+  qa.stamps = nullptr;
+  if (t->tuning.trace) {
+    // developer timeline of the last launch: 6 words per wave (tc_debug_wave_trace)
+    t->wave_trace_count = (size_t)schedule->n_waves;
+    status = t->wave_trace.reserve(t->wave_trace_count * 6 * sizeof(unsigned long long), stream);
+    if (status != TC_OK) return status;
+    qa.stamps = (unsigned long long*)t->wave_trace.ptr;
+  }
 
   hipEvent_t k0 = nullptr, k1 = nullptr;
   status = next_kernel_events(t, &k0, &k1);
   if (status != TC_OK) return status;
-  status = launch_contract_quad(tiling.n_u, false, qa, stream, k0, k1);
+  status = launch_contract_quad(tiling.n_u, false, qa, schedule->lds_bytes, stream, k0, k1);
   if (status != TC_OK) return status;
   t->last_workgroups = (schedule->n_waves + tc::kQuadWavesPerBlock - 1) / tc::kQuadWavesPerBlock;
   t->last_waves = tc::kQuadWavesPerBlock;
   t->last_splits = schedule->n_slabs;
   t->last_lds = 0;
 
-  tc::FinalizeQuadArgs fa;
+  tc::FinalizeQuadArgs fa{};
   fa.partial = (const double*)lane.partial.ptr;
   fa.group_begin = (const int32_t*)schedule->group_begin;
   fa.ngal_part = (const double*)lane.ngal2.ptr;
@@ -499,7 +522,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
       (size_t)n_groups * r_stride * ldb * sizeof(double), stream);
   if (status != TC_OK) return status;
 
-  tc::ContractArgs ca;
+  tc::ContractArgs ca{};
   ca.nbuf = (const double*)lane.nbuf.ptr;
   ca.ldb = ldb;
   ca.table = t->d_table;
@@ -566,7 +589,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   t->last_splits = n_groups;
   t->last_lds = lds;
 
-  tc::FinalizeArgs fa;
+  tc::FinalizeArgs fa{};
   fa.partial = (const double*)lane.partial.ptr;
   fa.groups = (const tc::Group*)c->groups;
   fa.ngal_part = (const double*)lane.ngal2.ptr;
@@ -653,7 +676,7 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
     status = ngal2->reserve((size_t)splits * 2 * ldb * sizeof(double), stream);
   if (status != TC_OK) return status;
   if (ngal_parts != nullptr) *ngal_parts = splits; else lane.ngal_parts = splits;
-  tc::OccArgs oa;
+  tc::OccArgs oa{};
   oa.theta = theta_device;
   oa.n_theta = n_theta;
   oa.n_draws = n_draws;
@@ -742,7 +765,7 @@ int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_gaus
   const int blocks = (int)std::max<int64_t>(
       1, std::min<int64_t>(kSingleMaxBlocks,
                            (t->plan.n_positions + 8 * n_slices - 1) / (8 * n_slices)));
-  tc::SingleArgs sa;
+  tc::SingleArgs sa{};
   for (int i = 0; i < 7; ++i) sa.theta_value[i] = i < n_theta ? theta[i] : 0.0;
   sa.n_theta = n_theta;
   sa.n_bins = t->n_bins;

@@ -222,7 +222,7 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
     }
 
   DeviceArrays device;
-  PairArgs a;
+  PairArgs a{};
   int status = device.put(set1.x, &a.x1);
   if (status == TC_OK) status = device.put(set1.y, &a.y1);
   if (status == TC_OK) status = device.put(set1.z, &a.z1);

@@ -343,8 +343,12 @@ int tc_debug_quad_emulate(int n_bins, int n_r, const double* tpcf_matrix,
   for (int g = 0; g < n_bins; ++g)
     std::copy(densities + (size_t)plan.perm[g] * ldb, densities + (size_t)(plan.perm[g] + 1) * ldb,
               ordered.begin() + (size_t)g * ldb);
+  // (the workgroup-level merge of the slabs as the launch layer applies it)
+  tc::QuadMergePlan merge;
+  tc::merge_quad_schedule(layout, tiling.n_rtiles, separate != 0, tc::kQuadWavesPerBlock, 12,
+                          schedule, merge);
   tc::quad_emulate(layout, schedule, tiling, table, ordered.data(), ldb, n_draws, n_r,
-                   separate != 0, out);
+                   separate != 0, out, &merge);
   return TC_OK;
 }
 

@@ -587,6 +587,18 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     t->tuning.single_draw = value != 0;
   } else if (key == "trace") {
     t->tuning.trace = value;
+  } else if (key == "quad_merge" || key == "quad_waves") {
+    // developer A/B of the quadratic-form schedule: schedules are rebuilt on demand
+    for (tc_table::Lane& lane : t->lanes) TC_HIP(hipStreamSynchronize(lane.stream));
+    if (key == "quad_merge") t->tuning.quad_merge = value != 0;
+    else t->tuning.quad_waves = value;
+    for (tc::host::QuadTable* q : {&t->quad_by_type, &t->quad_total}) {
+      for (auto& kv : q->schedules)
+        for (void* p : {kv.second->runs, kv.second->wave_runs, kv.second->group_begin,
+                        kv.second->merge_range, kv.second->merges})
+          if (p) (void)hipFree(p);
+      q->schedules.clear();
+    }
   } else {
     return fail(TC_ERR_INVALID, "unknown option '%s'", name);
   }

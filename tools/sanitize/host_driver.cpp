@@ -140,8 +140,14 @@ static void check_quad() {
                                   max_waves, 8, schedule);
           const int n_comp = separate ? 3 : 1;
           std::vector<double> out((size_t)n_draws * n_comp * n_r, 0.0);
+          // with and without the workgroup-level merge of the slabs
+          tc::QuadMergePlan merge;
+          if (max_waves != 7)
+            tc::merge_quad_schedule(layout, tiling.n_rtiles, separate != 0, tc::kQuadWavesPerBlock,
+                                    max_waves == 64 ? 3 : 12, schedule, merge);
           tc::quad_emulate(layout, schedule, tiling, table, densities.data(), ldb, n_draws, n_r,
-                           separate != 0, out.data());
+                           separate != 0, out.data(), max_waves != 7 ? &merge : nullptr);
+          EXPECT(schedule.group_begin.back() == schedule.n_slabs, "slab count after the merge");
           // direct evaluation: sum_p c_p T[r][p] n_i n_j over the packed columns
           for (int64_t b = 0; b < n_draws; b += 23)
             for (int r = 0; r < n_r; ++r) {
