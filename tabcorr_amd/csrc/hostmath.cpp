@@ -301,9 +301,25 @@ void build_quad_layout(int n_bins, int n_central, bool by_type, QuadLayout& out)
   }
 }
 
+namespace {
+// Number the slabs so that those of one output group are consecutive: `slab_group[s]` is the
+// group of provisional slab s; returns the new id of every provisional slab (stable: inside a
+// group the provisional order is kept) and fills group_begin.
+std::vector<int32_t> number_slabs_by_group(const std::vector<int32_t>& slab_group, int n_groups,
+                                           std::vector<int32_t>& group_begin) {
+  group_begin.assign((size_t)n_groups + 1, 0);
+  for (int32_t g : slab_group) ++group_begin[(size_t)g + 1];
+  for (int g = 0; g < n_groups; ++g) group_begin[g + 1] += group_begin[g];
+  std::vector<int32_t> cursor(group_begin.begin(), group_begin.end() - 1);
+  std::vector<int32_t> renumbered(slab_group.size());
+  for (size_t s = 0; s < slab_group.size(); ++s) renumbered[s] = cursor[slab_group[s]]++;
+  return renumbered;
+}
+}  // namespace
+
 void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, int n_tables,
                          bool separate, int max_waves, int min_units_per_wave,
-                         QuadSchedule& out) {
+                         QuadSchedule& out, bool table_major) {
   out.runs.clear();
   out.wave_runs.clear();
   out.group_begin.clear();
@@ -329,17 +345,32 @@ void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, in
     const int64_t end = (int64_t)((__int128)total * (w + 1) / n_waves);
     const size_t first_run = out.runs.size();
     while (begin < end) {
-      const int64_t tile_rtile = begin / per_rtile;
-      int64_t rest = begin % per_rtile;
-      // inside a (tile, rtile): components, then tables, then the component's units
-      int comp = 0;
-      while (rest >= layout.comps[comp].n_units * n_tables) {
-        rest -= layout.comps[comp].n_units * n_tables;
-        ++comp;
+      int64_t tile_rtile, unit;
+      int comp = 0, table;
+      if (table_major) {
+        // tables, then (tile, rtile), then the components' units
+        const int64_t per_table = layout.n_units * n_rtiles * n_tiles;
+        table = (int)(begin / per_table);
+        int64_t rest = begin % per_table;
+        tile_rtile = rest / layout.n_units;
+        rest %= layout.n_units;
+        while (rest >= layout.comps[comp].n_units) {
+          rest -= layout.comps[comp].n_units;
+          ++comp;
+        }
+        unit = rest;
+      } else {
+        tile_rtile = begin / per_rtile;
+        int64_t rest = begin % per_rtile;
+        // inside a (tile, rtile): components, then tables, then the component's units
+        while (rest >= layout.comps[comp].n_units * n_tables) {
+          rest -= layout.comps[comp].n_units * n_tables;
+          ++comp;
+        }
+        table = (int)(rest / layout.comps[comp].n_units);
+        unit = rest % layout.comps[comp].n_units;
       }
       const QuadComp& qc = layout.comps[comp];
-      const int table = (int)(rest / qc.n_units);
-      const int64_t unit = rest % qc.n_units;
       const int64_t stop = std::min<int64_t>(end, begin + (qc.n_units - unit));
       QuadRun run;
       run.tile = (int32_t)(tile_rtile / n_rtiles);
@@ -376,9 +407,11 @@ void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, in
   }
   out.wave_runs.push_back((int32_t)out.runs.size());
   out.n_slabs = slab;
-  // slabs are in group order: group_begin by counting
-  for (int32_t g : slab_group) ++out.group_begin[(size_t)g + 1];
-  for (int g = 0; g < out.n_groups; ++g) out.group_begin[g + 1] += out.group_begin[g];
+  // slabs of a group consecutive (they already are unless the order is table-major)
+  const std::vector<int32_t> renumbered =
+      number_slabs_by_group(slab_group, out.n_groups, out.group_begin);
+  for (QuadRun& run : out.runs)
+    if (run.slab >= 0) run.slab = renumbered[run.slab];
 }
 
 void merge_quad_schedule(const QuadLayout& layout, int n_rtiles, bool separate,
@@ -422,10 +455,11 @@ void merge_quad_schedule(const QuadLayout& layout, int n_rtiles, bool separate,
     plan.block_begin[(size_t)block + 1] = (int32_t)plan.merges.size();
   }
   schedule.n_slabs = next_slab;
-  schedule.group_begin.assign((size_t)schedule.n_groups + 1, 0);
-  for (int32_t g : slab_group) ++schedule.group_begin[(size_t)g + 1];
-  for (int g = 0; g < schedule.n_groups; ++g)
-    schedule.group_begin[g + 1] += schedule.group_begin[g];
+  const std::vector<int32_t> renumbered =
+      number_slabs_by_group(slab_group, schedule.n_groups, schedule.group_begin);
+  for (QuadRun& run : schedule.runs)
+    if (run.slab >= 0) run.slab = renumbered[run.slab];
+  for (QuadMerge& m : plan.merges) m.slab = renumbered[m.slab];
 }
 
 QuadTiling quad_tiling(int n_r) {

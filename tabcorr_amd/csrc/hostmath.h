@@ -169,9 +169,15 @@ struct QuadSchedule {
   std::vector<int32_t> group_begin;   // n_groups + 1
 };
 
+// `table_major` (interpolators): the linearised space is (table, draw tile, r tile, component,
+// unit) instead of (draw tile, r tile, component, table, unit) -- consecutive shares then
+// walk the SAME matrix over consecutive draw tiles, so that with an eighth of the shares per
+// XCD every L2 holds the ~K / 8 matrices its waves use instead of streaming all K through it
+// once per draw tile.  An output group then receives slabs from K tables; slabs are numbered
+// so that those of one group stay consecutive (in table order).
 void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, int n_tables,
                          bool separate, int max_waves, int min_units_per_wave,
-                         QuadSchedule& out);
+                         QuadSchedule& out, bool table_major = false);
 
 // Workgroup-level merging of the slabs.  Consecutive waves walk consecutive ranges, so the
 // waves of one workgroup mostly end / start inside the same output group and each would

@@ -263,7 +263,7 @@ int tc_debug_quad_schedule(int n_bins, int n_central, int by_type, int n_tiles, 
   tc::build_quad_layout(n_bins, n_central, by_type != 0, layout);
   tc::QuadSchedule schedule;
   tc::build_quad_schedule(layout, n_tiles, n_rtiles, n_tables, separate != 0, max_waves,
-                          min_units, schedule);
+                          min_units, schedule, n_tables > 1);
   const int tables = std::max(1, n_tables);
   // every (tile, r tile, component, table, unit) exactly once; runs stay inside one block
   // row sequence of their component; slabs of a group consecutive and in order
@@ -271,6 +271,7 @@ int tc_debug_quad_schedule(int n_bins, int n_central, int by_type, int n_tiles, 
   const int groups_per_rtile = separate ? (int)layout.comps.size() : 1;
   int64_t lo = -1, hi = 0;
   int next_slab = 0;
+  std::vector<uint8_t> slab_seen((size_t)std::max(schedule.n_slabs, 0), 0);
   for (int w = 0; w < schedule.n_waves; ++w) {
     int64_t units = 0;
     for (int ri = schedule.wave_runs[w]; ri < schedule.wave_runs[w + 1]; ++ri) {
@@ -295,7 +296,12 @@ int tc_debug_quad_schedule(int n_bins, int n_central, int by_type, int n_tiles, 
       }
       units += run.count;
       if (run.slab >= 0) {
-        if (run.slab != next_slab) return fail(TC_ERR_INVALID, "slab order (run %d)", ri);
+        // every slab written exactly once (in run order unless the order is table-major)
+        if (run.slab >= schedule.n_slabs || slab_seen[run.slab]++)
+          return fail(TC_ERR_INVALID, "slab %d written twice or out of range (run %d)",
+                      run.slab, ri);
+        if (n_tables <= 1 && run.slab != next_slab)
+          return fail(TC_ERR_INVALID, "slab order (run %d)", ri);
         const int64_t group = ((int64_t)run.tile * n_rtiles + run.rtile) * groups_per_rtile +
                               (separate ? run.comp : 0);
         if (run.slab < schedule.group_begin[group] || run.slab >= schedule.group_begin[group + 1])

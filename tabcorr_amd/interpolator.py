@@ -138,6 +138,7 @@ class Interpolator:
         self.param_dict_table = GalTypeTable(columns)
         self._device = None
         self._a = None
+        self._checked = None       # signature of the last consistent model
 
     # -- I/O ------------------------------------------------------------------
 
@@ -201,8 +202,21 @@ class Interpolator:
         """
         x = self._x_model(model)
         if check_consistency:
-            for halotab in self.tabcorr_list:
-                halotab._check_consistency(model)
+            # the checks of tabcorr.py:496-535 read a handful of model
+            # attributes; they are repeated for every table only when those
+            # attributes (or the tables) have changed since the last call
+            components = model._input_model_dictionary
+            signature = (
+                id(self.tabcorr_list[0]), len(self.tabcorr_list),
+                tuple(model.gal_types), model.redshift,
+                tuple((components[name].prim_haloprop_key,
+                       getattr(components[name], 'sec_haloprop_key', None))
+                      for name in ('centrals_occupation',
+                                   'satellites_occupation')))
+            if signature != self._checked:
+                for halotab in self.tabcorr_list:
+                    halotab._check_consistency(model)
+                self._checked = signature
         spec = None if occ_kwargs else device_spec(model)
         if spec is None:
             return self._predict_generic(model, x, separate_gal_type,

@@ -592,3 +592,81 @@ def test_host_logic_under_address_and_undefined_sanitizers(tmp_path):
                          timeout=600)
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
     assert 'all checks passed' in run.stdout
+
+
+# ---- quadratic-form contraction: layout, equal-share schedule, merge (no GPU needed) --------
+
+@pytest.mark.parametrize('n_bins,n_central,by_type,n_tiles,n_rtiles,n_tables,separate,max_waves', [
+    (100, 50, 1, 313, 1, 1, 0, 2048),      # BASELINE configs[1]
+    (200, 100, 1, 313, 1, 1, 1, 2048),     # configs[2]
+    (100, 50, 1, 391, 1, 25, 0, 2048),     # configs[3]: table-major order
+    (100, 50, 1, 7, 1, 25, 1, 2048),
+    (13, 5, 0, 3, 2, 1, 0, 64),
+    (13, 5, 1, 3, 2, 4, 1, 64),
+    (1, 1, 1, 1, 1, 1, 0, 2048),
+    (60, 30, 1, 1, 1, 1, 0, 2048),         # un-batched call
+])
+def test_quad_schedule_covers_every_unit_once(lib, n_bins, n_central, by_type, n_tiles, n_rtiles,
+                                              n_tables, separate, max_waves):
+    """Every (draw tile, r tile, component, table, unit) in exactly one run, every slab
+    written once and inside its group's range, equal shares (tc_debug_quad_schedule)."""
+    n_waves, n_runs, n_slabs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    from tabcorr_amd import _lib
+    _lib.check(lib.tc_debug_quad_schedule(
+        n_bins, n_central, by_type, n_tiles, n_rtiles, n_tables, separate, max_waves, 8,
+        ctypes.byref(n_waves), ctypes.byref(n_runs), ctypes.byref(n_slabs), ctypes.byref(lo),
+        ctypes.byref(hi)))
+    assert 1 <= n_waves.value <= max_waves
+    assert hi.value - lo.value <= 1                      # equal shares
+    assert n_slabs.value >= 1 and n_runs.value >= n_waves.value
+
+
+@pytest.mark.parametrize('n_prim,n_sec,n_r,separate,n_draws', [
+    (7, 1, 5, 0, 70), (7, 1, 5, 1, 70), (6, 2, 23, 1, 33), (25, 1, 19, 0, 200),
+    (3, 1, 1, 1, 64), (10, 1, 45, 0, 40)])
+def test_quad_emulation_matches_the_oracle(lib, n_prim, n_sec, n_r, separate, n_draws):
+    """The kernel's table layout, unit walk, operand lanes, equal-share schedule, the
+    workgroup-level merge of the slabs and the finalisation's grouping, executed on the host
+    lane by lane (tc_debug_quad_emulate), against the oracle's packed sums
+    (tabcorr.py:641-655)."""
+    from tabcorr_amd import _lib, synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(n_prim, n_sec, (n_r, ), 'auto', seed=n_prim + n_r)
+    gal_type = table['gal_type']
+    rng = np.random.default_rng(n_draws)
+    shuffle = rng.permutation(len(gal_type))               # any row order is accepted
+    gal_type = gal_type[shuffle]
+    n_bins = len(gal_type)
+    # the packed matrix of the shuffled rows
+    index_1, index_2, _ = oracle.pair_indices(n_bins)
+    full = np.zeros((n_r, n_bins, n_bins))
+    lower = np.tril_indices(n_bins)
+    full[:, lower[0], lower[1]] = table['tpcf_matrix']
+    full = full + np.transpose(np.tril(full, -1), (0, 2, 1))
+    full = full[:, shuffle][:, :, shuffle]
+    matrix = np.ascontiguousarray(full[:, index_1, index_2])
+    densities = np.exp(rng.normal(size=(n_bins, n_draws)))
+    ldb = (n_draws + 63) // 64 * 64
+    padded = np.zeros((n_bins, ldb))
+    padded[:, :n_draws] = densities
+    is_central = np.ascontiguousarray(oracle.is_centrals(gal_type), dtype=np.uint8)
+    n_comp = 3 if separate else 1
+    for max_waves in (5, 2048):
+        out = np.zeros((n_draws, n_comp, n_r))
+        _lib.check(lib.tc_debug_quad_emulate(
+            n_bins, n_r, _lib.as_double_p(matrix), is_central.ctypes.data_as(_lib.c_uint8_p),
+            1, separate, _lib.as_double_p(padded), ldb, n_draws, max_waves, 8,
+            _lib.as_double_p(out)))
+        prefactor = np.where(index_1 == index_2, 1.0, 2.0)
+        weights = prefactor[None] * densities[index_1].T * densities[index_2].T   # (B, P)
+        if separate:
+            cen = is_central.astype(bool)
+            kind = (~cen[index_1]).astype(int) + (~cen[index_2]).astype(int)
+            for c in range(3):
+                expect = np.einsum('rp,bp->br', matrix[:, kind == c], weights[:, kind == c])
+                np.testing.assert_allclose(out[:, c], expect, rtol=1e-12,
+                                           atol=1e-13 * np.max(np.abs(expect)) + 1e-300)
+        else:
+            expect = np.einsum('rp,bp->br', matrix, weights)
+            np.testing.assert_allclose(out[:, 0], expect, rtol=1e-12)
