@@ -284,6 +284,13 @@ int tc_table_last_launch(const tc_table* table, int* n_workgroups, int* waves_pe
 int tc_pair_count_rppi(const double* pos1, int64_t n1, const double* pos2, int64_t n2,
                        const double* boxsize, const double* rp_bins, int n_rp, double pi_max,
                        int n_pi, uint64_t* npairs);
+/* tc_pair_count_smu replaces one Corrfunc.theory.DDsmu call of tabcorr/corrfunc.py:141-163
+ * (the pair count behind `s_mu_tpcf`): ordered pair counts per bin of the three-dimensional
+ * separation s (s_bins: n_s + 1 increasing edges, compared squared) and of mu = |dz| / s
+ * (n_mu equal bins on [0, 1); a pair with mu == 1 is not counted): npairs (n_s, n_mu). */
+int tc_pair_count_smu(const double* pos1, int64_t n1, const double* pos2, int64_t n2,
+                      const double* boxsize, const double* s_bins, int n_s, int n_mu,
+                      uint64_t* npairs);
 int tc_pair_count_rppi_labelled(const double* pos1, const int32_t* label1, int64_t n1,
                                 const double* pos2, const int32_t* label2, int64_t n2,
                                 int n_labels, const double* boxsize, const double* rp_bins,

@@ -81,6 +81,66 @@ def pair_count_rppi(pos1, pos2, boxsize, rp_bins, pi_max, n_pi=None,
     return counts.reshape(n_rp, n_pi)
 
 
+def pair_count_smu(pos1, pos2, boxsize, s_bins, n_mu, chunk=512):
+    """Ordered pair counts ``(n_s, n_mu)`` in bins of the separation ``s`` and
+    of ``mu = |dz| / s`` on ``[0, 1)`` -- ``Corrfunc.theory.DDsmu`` as called at
+    ``tabcorr/corrfunc.py:141-155``: ``s_bins[0]^2 <= s^2 < s_bins[-1]^2`` with
+    ``s^2 = (dx^2 + dy^2) + dz^2``, ``mu < 1``, mu bin ``int(mu n_mu)``; a pair at
+    zero separation (self-pairs when ``s_bins[0] == 0``) goes to mu bin 0."""
+    pos1 = np.asarray(pos1, dtype=np.float64).reshape(-1, 3)
+    if pos2 is None:
+        pos2 = pos1
+    pos2 = np.asarray(pos2, dtype=np.float64).reshape(-1, 3)
+    boxsize = np.broadcast_to(np.asarray(boxsize, dtype=np.float64), (3, ))
+    s_bins = np.asarray(s_bins, dtype=np.float64)
+    n_s = len(s_bins) - 1
+    edge_sqr = s_bins * s_bins
+    counts = np.zeros(n_s * n_mu, dtype=np.uint64)
+    for begin in range(0, len(pos1), chunk):
+        a = pos1[begin:begin + chunk]
+        dz = np.abs(_min_image(a[:, None, 2] - pos2[None, :, 2], boxsize[2]))
+        dx = _min_image(a[:, None, 0] - pos2[None, :, 0], boxsize[0])
+        dy = _min_image(a[:, None, 1] - pos2[None, :, 1], boxsize[1])
+        s_sqr = (dx * dx + dy * dy) + dz * dz
+        keep = (s_sqr >= edge_sqr[0]) & (s_sqr < edge_sqr[-1])
+        s_sqr, dz = s_sqr[keep], dz[keep]
+        with np.errstate(invalid='ignore', divide='ignore'):
+            mu = np.where(s_sqr > 0, dz / np.sqrt(s_sqr), 0.0)
+        inside = mu < 1.0
+        s_bin = np.searchsorted(edge_sqr, s_sqr[inside], side='right') - 1
+        mu_bin = (mu[inside] * float(n_mu)).astype(np.int64)
+        ok = mu_bin < n_mu
+        counts += np.bincount(s_bin[ok] * n_mu + mu_bin[ok],
+                              minlength=len(counts)).astype(np.uint64)
+    return counts.reshape(n_s, n_mu)
+
+
+def s_mu_tpcf(sample1, s_bins, mu_bins, sample2=None, period=None,
+              do_auto=True, do_cross=False):
+    """``tabcorr/corrfunc.py:98-175`` with `pair_count_smu` in the place of
+    ``Corrfunc.theory.DDsmu``."""
+    if (do_auto and do_cross) or (not do_auto and not do_cross):
+        raise ValueError("'do_auto' and 'do_cross' cannot both be True or " +
+                         "False.")
+    mu_bins = np.asarray(mu_bins, dtype=np.float64)
+    if not np.all(np.isclose(mu_bins, np.linspace(0, 1, len(mu_bins)))):
+        raise ValueError('Bins in mu must be uniform from 0 to 1.')  # :135-138
+    s_bins = np.asarray(s_bins, dtype=np.float64)
+    if isinstance(period, (float, int)):
+        period = (period, period, period)
+    period = tuple(np.asarray(period, dtype=np.float64))
+    n_mu = len(mu_bins) - 1
+    if do_auto:                                                    # :146-153
+        npairs = pair_count_smu(sample1, None, period, s_bins, n_mu)
+        n_exp = (len(sample1) * len(sample1) / np.prod(period) * 4 *
+                 np.pi / 3 * np.diff(s_bins**3) / n_mu)
+    else:                                                          # :155-163
+        npairs = pair_count_smu(sample1, sample2, period, s_bins, n_mu)
+        n_exp = (len(sample1) * len(sample2) / np.prod(period) * 4 *
+                 np.pi / 3 * np.diff(s_bins**3) / n_mu)
+    return npairs.astype(np.float64) / n_exp[:, np.newaxis] - 1     # :165-166
+
+
 def wp(sample1, rp_bins, pi_max, sample2=None, period=None, do_auto=True,
        do_cross=False):
     """``tabcorr/corrfunc.py:6-95`` with `pair_count_rppi` in the place of

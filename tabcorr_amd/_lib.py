@@ -118,6 +118,9 @@ SIGNATURES = {
                            ctypes.c_int64, c_double_p, c_double_p, ctypes.c_int,
                            ctypes.c_double, ctypes.c_int,
                            ctypes.POINTER(ctypes.c_uint64)],
+    'tc_pair_count_smu': [c_double_p, ctypes.c_int64, c_double_p,
+                          ctypes.c_int64, c_double_p, c_double_p, ctypes.c_int,
+                          ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)],
     'tc_pair_count_rppi_labelled': [c_double_p, c_int32_p, ctypes.c_int64,
                                     c_double_p, c_int32_p, ctypes.c_int64,
                                     ctypes.c_int, c_double_p, c_double_p,

@@ -1,7 +1,7 @@
 """Two-point functions for the tabulation step, counted on the GPU.
 
-Mirrors ``tabcorr/corrfunc.py`` of johannesulf/TabCorr v1.2.0, whose functions
-wrap the Corrfunc pair counters so that they can be handed to
+Mirrors ``tabcorr/corrfunc.py`` of johannesulf/TabCorr v1.2.0 (`wp`,
+`s_mu_tpcf`), whose functions wrap the Corrfunc pair counters so that they can be handed to
 ``TabCorr.tabulate`` in the place of the halotools two-point functions.  Here
 the pair counts come from this package's HIP kernel
 (``tabcorr_amd/csrc/paircount.hip`` through ``tc_pair_count_rppi``): same
@@ -91,6 +91,61 @@ def wp(sample1, rp_bins, pi_max, sample2=None, period=None, do_auto=True,
     return (npairs / n_exp - 1) * 2 * pi_max
 
 
+def pair_count_smu(sample1, s_bins, n_mu, sample2=None, period=None):
+    """Ordered pair counts ``(n_s, n_mu)`` (uint64) in bins of the separation
+    ``s`` and of ``mu = |dz| / s`` on ``[0, 1)``, as
+    ``Corrfunc.theory.DDsmu(autocorr, 1, s_bins, 1, n_mu, ..., periodic=True)``
+    reports them (``tabcorr/corrfunc.py:141-155``)."""
+    lib = _lib.load()
+    _lib.require_device()
+    sample1 = _positions(sample1)
+    s_bins = _lib.contiguous(np.asarray(s_bins, dtype=np.float64))
+    box = _period(period)
+    npairs = np.zeros((len(s_bins) - 1, int(n_mu)), dtype=np.uint64)
+    if sample2 is not None:
+        sample2 = _positions(sample2)
+    _lib.check(lib.tc_pair_count_smu(
+        _lib.as_double_p(sample1), len(sample1),
+        _lib.as_double_p(sample2) if sample2 is not None else None,
+        len(sample2) if sample2 is not None else 0, _lib.as_double_p(box),
+        _lib.as_double_p(s_bins), len(s_bins) - 1, int(n_mu),
+        npairs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+    return npairs
+
+
+def s_mu_tpcf(sample1, s_bins, mu_bins, sample2=None, period=None,
+              do_auto=True, do_cross=False):
+    """Drop-in for ``tabcorr.corrfunc.s_mu_tpcf``
+    (``tabcorr/corrfunc.py:98-175``, itself a stand-in for
+    ``halotools.mock_observables.s_mu_tpcf``): the redshift-space correlation
+    function in bins of ``s`` and ``mu``.
+
+    Raises
+    ------
+    ValueError
+        If ``do_auto`` and ``do_cross`` have the same value or if ``mu_bins``
+        are not uniform bins from 0 to 1.
+    """
+    if (do_auto and do_cross) or (not do_auto and not do_cross):
+        raise ValueError("'do_auto' and 'do_cross' cannot both be True or " +
+                         "False.")
+    mu_bins = np.asarray(mu_bins, dtype=np.float64)
+    if not np.all(np.isclose(mu_bins, np.linspace(0, 1, len(mu_bins)))):
+        raise ValueError('Bins in mu must be uniform from 0 to 1.')
+    s_bins = np.asarray(s_bins, dtype=np.float64)
+    box = _period(period)
+    n_mu = len(mu_bins) - 1
+    if do_auto:
+        npairs = pair_count_smu(sample1, s_bins, n_mu, None, box)
+        n_exp = (len(sample1) * len(sample1) / np.prod(box) * 4 * np.pi / 3 *
+                 np.diff(s_bins**3) / n_mu)
+    else:
+        npairs = pair_count_smu(sample1, s_bins, n_mu, sample2, box)
+        n_exp = (len(sample1) * len(sample2) / np.prod(box) * 4 * np.pi / 3 *
+                 np.diff(s_bins**3) / n_mu)
+    return npairs.astype(np.float64) / n_exp[:, np.newaxis] - 1
+
+
 def pair_count_matrix(pos, rp_bins, pi_max, period, sample2=None):
     """Pair counts between all bins in one pass.
 
@@ -160,3 +215,17 @@ def compute_tpcf_matrix(mode, pos, period, rp_bins, pi_max, sample2=None):
         matrix = (counts / n_exp - 1) * 2 * pi_max
     matrix[n_exp == 0] = 0.0          # bins without points: tabcorr.py:888
     return matrix, (len(rp_bins) - 1, )
+
+
+def reference_compute_tpcf_matrix(mode, pos, tpcf, period, tpcf_args,
+                                  tpcf_kwargs, num_threads=1, verbose=False):
+    """`compute_tpcf_matrix` with the reference's own signature
+    (``tabcorr/tabcorr.py:846-848``) for ``tpcf = wp``: what
+    ``TabCorr.tabulate`` swaps in for the reference's pool of per-pair calls.
+    ``tpcf_args`` are ``(rp_bins, pi_max)``; mode ``'cross'`` takes ``sample2``
+    from ``tpcf_kwargs`` as the reference's call at ``:841-844`` would."""
+    if tpcf is not wp:
+        raise ValueError('Only tabcorr_amd.corrfunc.wp is counted on the GPU.')
+    rp_bins, pi_max = tpcf_args[0], tpcf_args[1]
+    return compute_tpcf_matrix(mode, pos, period, rp_bins, pi_max,
+                               sample2=tpcf_kwargs.get('sample2'))

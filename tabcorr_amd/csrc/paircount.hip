@@ -78,7 +78,12 @@ __device__ inline double min_image(double d, double box, double half) {
   return d < -half ? d + box : d;
 }
 
-template <bool LABELLED>
+// SMU: bins in the three-dimensional separation s and mu = |dz| / s (Corrfunc DDsmu, the pair
+// count behind s_mu_tpcf, tabcorr/corrfunc.py:141-163): s^2 = (dx dx + dy dy) + dz dz, a pair
+// counts if s_bins[0]^2 <= s^2 < s_bins[-1]^2 and mu < 1, its mu bin is int(mu n_mu) with
+// mu = |dz| / sqrt(s^2) (correctly rounded square root and division, as NumPy's); s = 0
+// (i == j with s_bins[0] == 0) goes to mu bin 0.
+template <bool LABELLED, bool SMU>
 __global__ __launch_bounds__(kPairThreads) void pair_count_kernel(PairArgs a) {
   __shared__ double sx[kPairThreads], sy[kPairThreads], sz[kPairThreads];
   __shared__ int32_t sl[kPairThreads];
@@ -122,13 +127,18 @@ __global__ __launch_bounds__(kPairThreads) void pair_count_kernel(PairArgs a) {
             if (!(dz < a.pi_max)) continue;
             const double dx = min_image(xi - sx[t], a.lx, hx);
             const double dy = min_image(yi - sy[t], a.ly, hy);
-            // (separately rounded products and sum: the oracle's arithmetic)
-            const double r_sqr = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+            // (separately rounded products and sums: the oracle's arithmetic)
+            double r_sqr = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+            if (SMU) r_sqr = __dadd_rn(r_sqr, __dmul_rn(dz, dz));
             if (!(r_sqr >= lo_sqr && r_sqr < hi_sqr)) continue;
             int bin = 0;
             for (int k = 1; k < a.n_rp; ++k) bin += r_sqr >= a.edge_sqr[k] ? 1 : 0;
             if (LABELLED) {
               atomicAdd(a.counts + ((size_t)bin * a.n_labels + li) * a.n_labels + sl[t], 1ull);
+            } else if (SMU) {
+              const double mu = r_sqr > 0.0 ? __ddiv_rn(dz, __dsqrt_rn(r_sqr)) : 0.0;
+              const int mu_bin = (int)(mu * a.inv_dpi);
+              if (mu < 1.0 && mu_bin < a.n_pi) atomicAdd(&hist[bin * a.n_pi + mu_bin], 1u);
             } else {
               const int pi_bin = (int)(dz * a.inv_dpi);
               if (pi_bin < a.n_pi) atomicAdd(&hist[bin * a.n_pi + pi_bin], 1u);
@@ -162,15 +172,19 @@ struct DeviceArrays {
   }
 };
 
+// smu: rp_bins are the s bins, n_pi the number of mu bins on [0, 1), pi_max is ignored (the
+// line-of-sight reach is the largest s).
 int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const double* pos2,
                const int32_t* label2, int64_t n2, int n_labels, const double* boxsize,
-               const double* rp_bins, int n_rp, double pi_max, int n_pi, uint64_t* counts) {
+               const double* rp_bins, int n_rp, double pi_max, int n_pi, uint64_t* counts,
+               bool smu = false) {
   TC_CHECK(pos1 != nullptr && boxsize != nullptr && rp_bins != nullptr && counts != nullptr,
            "NULL argument");
   TC_CHECK(n1 >= 0 && n2 >= 0 && n1 < (1LL << 31) && n2 < (1LL << 31), "invalid point count");
   TC_CHECK(n_rp >= 1 && n_rp <= kMaxRpBins, "between 1 and %d r_p bins are supported",
            kMaxRpBins);
-  TC_CHECK(pi_max > 0.0 && n_pi >= 1, "pi_max and the number of pi bins must be positive");
+  if (smu) pi_max = rp_bins[n_rp];
+  TC_CHECK(pi_max > 0.0 && n_pi >= 1, "pi_max and the number of pi / mu bins must be positive");
   for (int k = 0; k <= n_rp; ++k)
     TC_CHECK(rp_bins[k] >= 0.0 && (k == 0 || rp_bins[k] > rp_bins[k - 1]),
              "rp_bins must be non-negative and increasing");
@@ -259,7 +273,7 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
   a.n_rp = n_rp;
   a.n_pi = n_pi;
   a.pi_max = pi_max;
-  a.inv_dpi = (double)n_pi / pi_max;
+  a.inv_dpi = smu ? (double)n_pi : (double)n_pi / pi_max;
   a.n_labels = n_labels;
   void* d_counts = nullptr;
   TC_HIP(hipMalloc(&d_counts, n_counts * sizeof(uint64_t)));
@@ -269,11 +283,14 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
 
   const dim3 grid_dim((unsigned)item_cell.size()), block(kPairThreads);
   if (labelled) {
-    hipLaunchKernelGGL(pair_count_kernel<true>, grid_dim, block, 0, nullptr, a);
+    hipLaunchKernelGGL((pair_count_kernel<true, false>), grid_dim, block, 0, nullptr, a);
   } else {
     const size_t lds = (size_t)n_rp * n_pi * sizeof(unsigned);
-    TC_CHECK(lds <= 48 * 1024, "at most %d (r_p, pi) bins are supported", 48 * 1024 / 4);
-    hipLaunchKernelGGL(pair_count_kernel<false>, grid_dim, block, lds, nullptr, a);
+    TC_CHECK(lds <= 48 * 1024, "at most %d two-dimensional bins are supported", 48 * 1024 / 4);
+    if (smu)
+      hipLaunchKernelGGL((pair_count_kernel<false, true>), grid_dim, block, lds, nullptr, a);
+    else
+      hipLaunchKernelGGL((pair_count_kernel<false, false>), grid_dim, block, lds, nullptr, a);
   }
   TC_HIP(hipGetLastError());
   TC_HIP(hipMemcpy(counts, d_counts, n_counts * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -291,6 +308,13 @@ int tc_pair_count_rppi(const double* pos1, int64_t n1, const double* pos2, int64
                        int n_pi, uint64_t* npairs) {
   return tc::host::pair_count(pos1, nullptr, n1, pos2, nullptr, n2, 0, boxsize, rp_bins, n_rp,
                               pi_max, n_pi, npairs);
+}
+
+int tc_pair_count_smu(const double* pos1, int64_t n1, const double* pos2, int64_t n2,
+                      const double* boxsize, const double* s_bins, int n_s, int n_mu,
+                      uint64_t* npairs) {
+  return tc::host::pair_count(pos1, nullptr, n1, pos2, nullptr, n2, 0, boxsize, s_bins, n_s, 1.0,
+                              n_mu, npairs, true);
 }
 
 int tc_pair_count_rppi_labelled(const double* pos1, const int32_t* label1, int64_t n1,

@@ -18,6 +18,7 @@ Extensions beyond the reference (the reason to use a GPU at all):
 """
 
 import ctypes
+import sys
 import itertools
 import json
 import os
@@ -162,9 +163,11 @@ class TabCorr:
     def tabulate(cls, halocat, tpcf, *tpcf_args, **kwargs):
         """Tabulate halo correlation functions (``tabcorr/tabcorr.py:23-372``).
 
-        Tabulation is an offline, halotools-bound step outside the scope of
-        this package; it is delegated to the reference package when that (and
-        halotools) is installed and the result is adopted.
+        Populating the mock and binning the halos is halotools-bound and
+        delegated to the reference package when that (and halotools) is
+        installed; with ``tpcf=tabcorr_amd.corrfunc.wp`` the pair counting
+        inside it (``compute_tpcf_matrix``, ``tabcorr/tabcorr.py:846-922``)
+        runs on the GPU, all bin pairs in one pass.
         """
         try:
             import tabcorr as reference
@@ -173,8 +176,23 @@ class TabCorr:
                 'TabCorr.tabulate needs the reference `tabcorr` package and '
                 'halotools; tabcorr_amd accelerates predict() only.'
             ) from error
-        tabulated = reference.TabCorr.tabulate(
-            halocat, tpcf, *tpcf_args, **kwargs)
+        from . import corrfunc
+        if tpcf is corrfunc.wp:
+            # the pair counts of ALL bin pairs in one pass on the GPU instead of
+            # one two-point function call per pair of bins from a process pool
+            # (tabcorr/tabcorr.py:846-922; a pool would also fork a process
+            # that has initialised the GPU)
+            module = sys.modules[reference.TabCorr.__module__]
+            original = module.compute_tpcf_matrix
+            module.compute_tpcf_matrix = corrfunc.reference_compute_tpcf_matrix
+            try:
+                tabulated = reference.TabCorr.tabulate(
+                    halocat, tpcf, *tpcf_args, **kwargs)
+            finally:
+                module.compute_tpcf_matrix = original
+        else:
+            tabulated = reference.TabCorr.tabulate(
+                halocat, tpcf, *tpcf_args, **kwargs)
         return cls.from_arrays(
             tabulated.gal_type, tabulated.tpcf_matrix, tabulated.tpcf_shape,
             tabulated.attrs, tabulated.tpcf_args, tabulated.tpcf_kwargs)

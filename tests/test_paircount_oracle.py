@@ -85,3 +85,36 @@ def test_wp_of_a_poisson_sample_is_zero_and_matrix_matches_pairwise_calls():
     cross, _ = oracle.compute_tpcf_matrix_wp('cross', bins, box, rp_bins, 20.0,
                                              sample2=pos[1000:])
     assert cross.shape == (3, 4) and np.all(cross[:, 1] == 0)
+
+
+def test_s_mu_counts():
+    box = (20.0, 20.0, 20.0)
+    s_bins = np.array([0.5, 2.0, 5.0])
+    # s = 1 along x (mu = 0); s = 5 along z (mu = 1: never counted, and on the last edge);
+    # (3, 0, 4) from the first point: s = 5 out; (0.6, 0, 0.8): s = 1, mu = 0.8
+    pos = np.array([[1.0, 1.0, 1.0], [2.0, 1.0, 1.0], [1.0, 1.0, 19.5], [1.6, 1.0, 1.8]])
+    counts = oracle.pair_count_smu(pos, None, box, s_bins, 5)
+    assert counts.shape == (2, 5)
+    # pairs: 0-1 (s 1, mu 0) bin (0, 0); 0-3 (s 1, mu .8) bin (0, 4); 1-3: d = (.4, 0, .8),
+    # s = .894, mu = .894 -> (0, 4); 0-2: dz = 1.5 wrapped, s = 1.5, mu = 1 -> out;
+    # 1-2: d = (1, 0, 1.5), s = 1.80, mu = .83 -> (0, 4); 2-3: d = (.6, 0, 2.3 wrapped): s = 2.38,
+    # mu = .968 -> (1, 4)
+    expect = np.zeros((2, 5), dtype=np.uint64)
+    expect[0, 0] = 2
+    expect[0, 4] = 6
+    expect[1, 4] = 2
+    assert np.array_equal(counts, expect)
+    rng = np.random.default_rng(8)
+    box = 60.0
+    pos1, pos2 = rng.uniform(0, box, (400, 3)), rng.uniform(0, box, (300, 3))
+    s_bins = np.logspace(-0.3, 1.2, 7)
+    auto = oracle.pair_count_smu(pos1, None, box, s_bins, 10)
+    assert np.all(auto % 2 == 0)
+    assert np.array_equal(oracle.pair_count_smu(pos1, pos2, box, s_bins, 10),
+                          oracle.pair_count_smu(pos2, pos1, box, s_bins, 10))
+    # summed over mu the counts are those of spherical shells: a Poisson sample has xi ~ 0
+    xi = oracle.s_mu_tpcf(rng.uniform(0, box, (2500, 3)), s_bins, np.linspace(0, 1, 5),
+                          period=box)
+    assert xi.shape == (6, 4) and np.all(np.abs(xi[3:]) < 0.2)
+    with pytest.raises(ValueError, match='uniform'):
+        oracle.s_mu_tpcf(pos1, s_bins, np.array([0.0, 0.3, 1.0]), period=box)
