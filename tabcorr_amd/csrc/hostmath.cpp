@@ -755,4 +755,53 @@ int64_t sort_into_cells(const CellGrid& grid, const double* pos, const int32_t* 
   return -1;
 }
 
+void sort_cells_by_label(CellSort& cells) {
+  if (cells.label.empty()) return;
+  const size_t n = cells.x.size();
+  std::vector<int32_t> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  for (size_t c = 0; c + 1 < cells.cell_start.size(); ++c)
+    std::stable_sort(order.begin() + cells.cell_start[c], order.begin() + cells.cell_start[c + 1],
+                     [&](int32_t a, int32_t b) { return cells.label[a] < cells.label[b]; });
+  CellSort sorted;
+  sorted.cell_start = cells.cell_start;
+  sorted.x.resize(n);
+  sorted.y.resize(n);
+  sorted.z.resize(n);
+  sorted.label.resize(n);
+  for (size_t p = 0; p < n; ++p) {
+    sorted.x[p] = cells.x[order[p]];
+    sorted.y[p] = cells.y[order[p]];
+    sorted.z[p] = cells.z[order[p]];
+    sorted.label[p] = cells.label[order[p]];
+  }
+  cells = std::move(sorted);
+}
+
+void build_label_items(const CellSort& cells, int max_points, int max_slots, LabelItems& out) {
+  out = LabelItems();
+  out.slot.assign(cells.x.size(), 0);
+  for (size_t c = 0; c + 1 < cells.cell_start.size(); ++c) {
+    int32_t p = cells.cell_start[c];
+    const int32_t cell_end = cells.cell_start[c + 1];
+    while (p < cell_end) {
+      const int32_t begin = p;
+      std::vector<int32_t> labels;
+      while (p < cell_end && p - begin < max_points) {
+        if (labels.empty() || labels.back() != cells.label[p]) {
+          if ((int)labels.size() == max_slots) break;
+          labels.push_back(cells.label[p]);
+        }
+        out.slot[p] = (int32_t)labels.size() - 1;
+        ++p;
+      }
+      out.cell.push_back((int32_t)c);
+      out.begin.push_back(begin);
+      out.end.push_back(p);
+      labels.resize((size_t)max_slots, 0);
+      out.item_labels.insert(out.item_labels.end(), labels.begin(), labels.end());
+    }
+  }
+}
+
 }  // namespace tc

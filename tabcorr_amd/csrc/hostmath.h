@@ -252,6 +252,17 @@ struct CellSort {
 };
 int64_t sort_into_cells(const CellGrid& grid, const double* pos, const int32_t* label,
                         int64_t n, CellSort& out);
+// Inside every cell, order the points by label (stable).
+void sort_cells_by_label(CellSort& cells);
+
+// Work items of the labelled pair count: consecutive points of one cell (sorted by label), at
+// most `max_points` of them and at most `max_slots` distinct labels, so that a workgroup can
+// keep private counters for (r bin, its label slots, every partner label) in LDS.  slot[p] is
+// the label slot of point p inside its item, item_labels (items, max_slots) the labels.
+struct LabelItems {
+  std::vector<int32_t> cell, begin, end, slot, item_labels;
+};
+void build_label_items(const CellSort& cells, int max_points, int max_slots, LabelItems& out);
 
 // Position order inside a segment: j -> j + 1, wrapping to (i + 1, j_lo) after column
 // `j_last` (rectangle) or after the diagonal (j_last < 0).

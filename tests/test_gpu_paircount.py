@@ -180,3 +180,27 @@ def test_s_mu_pair_counts_are_exact(case):
     edges0 = np.array([0.0, 1.0, 4.0])
     assert np.array_equal(corrfunc.pair_count_smu(pos1, edges0, 4, None, box),
                           oracle.pair_count_smu(pos1, None, box, edges0, 4))
+
+
+def test_labelled_counts_with_private_counters():
+    """Many points per (cell, label): the labelled count keeps per-workgroup counters in LDS
+    (points sorted by label inside the cells, at most 8 labels per workgroup).  Against the
+    brute-force oracle, auto and cross, with a label that has no points at all."""
+    from tabcorr_amd import corrfunc
+    from oracle import paircount_oracle as oracle
+    rng = np.random.default_rng(21)
+    box = np.array([100.0, 100.0, 100.0])
+    rp_bins = np.logspace(-0.5, np.log10(20.0), 8)
+    pos = clustered(rng, 12000, box, 30, 2.5)
+    label = rng.choice([0, 1, 3], size=len(pos), p=[0.5, 0.3, 0.2])      # label 2 is empty
+    order = np.argsort(label, kind='stable')
+    bins = np.split(pos[order], np.cumsum(np.bincount(label, minlength=4))[:-1])
+    counts = corrfunc.pair_count_matrix(bins, rp_bins, 40.0, box)
+    expect = oracle.pair_count_rppi(pos, None, box, rp_bins, 40.0, label1=label, n_labels=4)
+    assert np.array_equal(counts, expect)
+    assert counts[:, 2].sum() == 0 and counts[:, :, 2].sum() == 0 and counts.sum() > 1e6
+    other = rng.uniform(0, 1, (5000, 3)) * box
+    cross = corrfunc.pair_count_matrix(bins, rp_bins, 40.0, box, sample2=other)
+    expect = oracle.pair_count_rppi(pos, other, box, rp_bins, 40.0, label1=label,
+                                    label2=np.zeros(len(other), dtype=int), n_labels=4)
+    assert np.array_equal(cross, expect[:, :, 0])

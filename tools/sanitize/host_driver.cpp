@@ -229,6 +229,28 @@ static void check_cells() {
           const int cx = std::min(grid.nx - 1, (int)(sorted.x[s] / grid.lx * grid.nx));
           EXPECT(cx == c / (grid.ny * grid.nz), "point in the wrong cell");
         }
+      // labelled work items: sorted by label inside the cells, bounded points and labels
+      tc::sort_cells_by_label(sorted);
+      for (int c = 0; c < grid.n_cells(); ++c)
+        for (int32_t s = sorted.cell_start[c] + 1; s < sorted.cell_start[c + 1]; ++s)
+          EXPECT(sorted.label[s - 1] <= sorted.label[s], "labels not sorted inside a cell");
+      for (int max_slots : {1, 3, 8}) {
+        tc::LabelItems items;
+        tc::build_label_items(sorted, 256, max_slots, items);
+        int64_t covered = 0;
+        for (size_t k = 0; k < items.cell.size(); ++k) {
+          EXPECT(items.end[k] - items.begin[k] >= 1 && items.end[k] - items.begin[k] <= 256,
+                 "item size");
+          covered += items.end[k] - items.begin[k];
+          for (int32_t p = items.begin[k]; p < items.end[k]; ++p) {
+            EXPECT(items.slot[p] >= 0 && items.slot[p] < max_slots, "label slot out of range");
+            EXPECT(items.item_labels[k * max_slots + items.slot[p]] == sorted.label[p],
+                   "label slot does not name the point's label");
+          }
+        }
+        EXPECT(covered == n, "label items cover %lld of %lld points", (long long)covered,
+               (long long)n);
+      }
       if (n > 0) {
         pos[2] = -1.0;
         EXPECT(tc::sort_into_cells(grid, pos.data(), nullptr, n, sorted) == 0,
