@@ -367,7 +367,8 @@ def main():
         flush(probe)
         drain()
         per_step = max((time.perf_counter() - t_probe) / probe, 1e-6)
-        settle_steps = int(args.settle_seconds / per_step) + 1
+        # (the same count on every rank: the gathers inside step() are collectives)
+        settle_steps = int(comm.max(int(args.settle_seconds / per_step) + 1))
         # in chunks with a drain after each: the runtime retires finished commands lazily, and
         # thousands of them left over from one long burst make later launches stall
         # (tools/stall.py: 60-100 us per launch for a while, as long as 10 steps)
