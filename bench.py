@@ -35,6 +35,9 @@ Rank 0 prints ONE JSON line.  Extra objects:
   host_to_host   the SURVEY 8d rate through tc_predict_zheng07_batch (host arrays).
   unbatched_us   one predict(model) / Interpolator.predict(model) call, as in the
                  reference's usage (README.md:72-75).
+  tabulation     SURVEY 8f.4: DD(r_p, pi) pair counts on the GPU (single pair of samples, and
+                 all 100 x 100 halo-bin pairs in one pass) with the brute-force oracle as
+                 the CPU baseline.
   other_configs  BASELINE configs[2], [3] (one GPU's share), [4] in float32 and float64:
                  device rate, host rate, dominant kernel, roofline fraction, CPU port.
   cpu_baseline   the NumPy port of the reference's predict() (oracle/tabcorr_oracle.py),
@@ -541,6 +544,7 @@ def main():
             'what': 'tc_predict_zheng07_batch: %d draws in pageable host memory -> (ngal, xi) '
                     'in host memory, synchronous, PCIe included (SURVEY.md 8d)' % n_draws}
         result['unbatched_us'] = unbatched(make, table, synthetic, Interpolator)
+        result['tabulation'] = tabulation(args.cpu_seconds)
         if args.other_configs:
             result['other_configs'] = other_configs(
                 lib, _lib, make, synthetic, Interpolator, args.cpu_seconds)
@@ -586,6 +590,52 @@ def unbatched(make, table, synthetic, Interpolator):
     grid = time_calls(call_interp, seconds=0.3, warm=20)
     return {'predict_model': single * 1e6, 'interpolator_5x5_predict_model': grid * 1e6,
             'unit': 'us per call (Python API, host model -> host results)'}
+
+
+# ---- pair counting for the tabulation step ---------------------------------------
+
+def tabulation(cpu_seconds):
+    """DD(r_p, pi) on the GPU (tabcorr/corrfunc.py:62-84, tabcorr/tabcorr.py:846-922): a
+    clustered sample in a 250 Mpc/h box, 19 r_p bins up to 30, pi_max = 40; the single pair
+    count, all 100 x 100 halo-bin pairs in one pass, and the brute-force NumPy oracle on a
+    subsample as the CPU baseline (bit-exact check included)."""
+    from tabcorr_amd import corrfunc
+    from oracle import paircount_oracle
+    rng = np.random.default_rng(3)
+    box, n = 250.0, 400000
+    rp_bins = np.logspace(-1, np.log10(30.0), 20)
+    centres = rng.uniform(0, box, (n // 60, 3))
+    pos = np.mod(centres[rng.integers(0, len(centres), n)] + rng.normal(0, 3.0, (n, 3)), box)
+    label = rng.integers(0, 100, n)
+    corrfunc.pair_count_rppi(pos[:1000], rp_bins, 40.0, None, box)
+    t0 = time.perf_counter()
+    counts = corrfunc.pair_count_rppi(pos, rp_bins, 40.0, None, box)
+    auto_seconds = time.perf_counter() - t0
+    pairs = int(counts.sum())
+    order = np.argsort(label, kind='stable')
+    bins = np.split(pos[order], np.cumsum(np.bincount(label, minlength=100))[:-1])
+    t0 = time.perf_counter()
+    matrix = corrfunc.pair_count_matrix(bins, rp_bins, 40.0, box)
+    matrix_seconds = time.perf_counter() - t0
+    out = {'workload': '%d clustered points, box 250, 19 rp bins to 30, pi_max 40, host arrays '
+                       'in, counts out (cell sort on the host included)' % n,
+           'pairs_counted': pairs,
+           'auto_count_ms': auto_seconds * 1e3, 'auto_pairs_per_sec': pairs / auto_seconds,
+           'all_100x100_bin_pairs_ms': matrix_seconds * 1e3,
+           'all_bin_pairs_pairs_per_sec': pairs / matrix_seconds,
+           'all_bin_pairs_consistent': bool(int(matrix.sum()) == pairs)}
+    if cpu_seconds > 0:
+        sub = pos[:6000]
+        t0 = time.perf_counter()
+        expect = paircount_oracle.pair_count_rppi(sub, None, box, rp_bins, 40.0)
+        spent = time.perf_counter() - t0
+        got = corrfunc.pair_count_rppi(sub, rp_bins, 40.0, None, box)
+        out['cpu_baseline'] = {
+            'value': len(sub)**2 / spent, 'unit': 'pair tests/s', 'cores': 1, 'kind': 'port',
+            'sample': 'brute-force NumPy oracle on %d points (%.1f s)' % (len(sub), spent),
+            'gpu_bit_exact': bool(np.array_equal(got, expect))}
+        out['gpu_pair_tests_per_sec_equivalent'] = float(n)**2 / auto_seconds
+    return out
 
 
 # ---- BASELINE configs[2], [3], [4] ----------------------------------------------------------
