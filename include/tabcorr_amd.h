@@ -116,6 +116,7 @@ int tc_plan_debug(int mode, int n_bins, const uint8_t* is_central, int n_chunks,
  * of units any wave gets. */
 int tc_debug_quad_schedule(int n_bins, int n_central, int by_type, int n_tiles, int n_rtiles,
                            int n_tables, int separate, int max_waves, int min_units,
+                           int order /* 0 draw-tile-major, 1 table-major, 2 r-tile-major */,
                            int* n_waves, int* n_runs, int* n_slabs, int64_t* units_min,
                            int64_t* units_max);
 /* TEST INFRASTRUCTURE, never called by the product: executes the kernel's table layout,
@@ -126,7 +127,7 @@ int tc_debug_quad_schedule(int n_bins, int n_central, int by_type, int n_tiles, 
 int tc_debug_quad_emulate(int n_bins, int n_r, const double* tpcf_matrix,
                           const uint8_t* is_central, int by_type, int separate,
                           const double* densities, int64_t ldb, int64_t n_draws,
-                          int max_waves, int min_units, double* out);
+                          int max_waves, int min_units, int order, double* out);
 
 /* ---- one tabulated table (replaces the state of a `TabCorr` instance) ----------------
  *

@@ -319,7 +319,9 @@ std::vector<int32_t> number_slabs_by_group(const std::vector<int32_t>& slab_grou
 
 void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, int n_tables,
                          bool separate, int max_waves, int min_units_per_wave,
-                         QuadSchedule& out, bool table_major) {
+                         QuadSchedule& out, int order) {
+  const bool table_major = order == kQuadTableMajor;
+  const bool rtile_major = order == kQuadRtileMajor && n_rtiles > 1;
   out.runs.clear();
   out.wave_runs.clear();
   out.group_begin.clear();
@@ -329,8 +331,11 @@ void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, in
   out.n_groups = n_tiles * n_rtiles * groups_per_rtile;
   const int64_t per_rtile = layout.n_units * n_tables;          // units of one (tile, r tile)
   const int64_t total = per_rtile * n_rtiles * n_tiles;
-  int64_t n_waves = std::min<int64_t>(max_waves, total / std::max(1, min_units_per_wave));
-  n_waves = std::max<int64_t>(1, std::min<int64_t>(n_waves, total));
+  // (r-tile-major: the shares are cut per r tile)
+  const int64_t span = rtile_major ? per_rtile * n_tiles : total;
+  const int n_passes = rtile_major ? n_rtiles : 1;
+  int64_t n_waves = std::min<int64_t>(max_waves, span / std::max(1, min_units_per_wave));
+  n_waves = std::max<int64_t>(1, std::min<int64_t>(n_waves, span));
   if (total == 0) n_waves = 0;
   out.n_waves = (int)n_waves;
   out.group_begin.assign((size_t)out.n_groups + 1, 0);
@@ -340,14 +345,26 @@ void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, in
   std::vector<int32_t> slab_group;
   for (int64_t w = 0; w < n_waves; ++w) {
     out.wave_runs.push_back((int32_t)out.runs.size());
-    // (128-bit product: total * w can exceed 63 bits for huge batches of huge tables)
-    int64_t begin = (int64_t)((__int128)total * w / n_waves);
-    const int64_t end = (int64_t)((__int128)total * (w + 1) / n_waves);
     const size_t first_run = out.runs.size();
+    for (int pass = 0; pass < n_passes; ++pass) {
+    // (128-bit product: span * w can exceed 63 bits for huge batches of huge tables)
+    int64_t begin = (int64_t)((__int128)span * w / n_waves);
+    const int64_t end = (int64_t)((__int128)span * (w + 1) / n_waves);
     while (begin < end) {
       int64_t tile_rtile, unit;
       int comp = 0, table;
-      if (table_major) {
+      if (rtile_major) {
+        // inside r tile `pass`: draw tiles, then components, tables, units
+        const int64_t tile = begin / per_rtile;
+        int64_t rest = begin % per_rtile;
+        tile_rtile = tile * n_rtiles + pass;
+        while (rest >= layout.comps[comp].n_units * n_tables) {
+          rest -= layout.comps[comp].n_units * n_tables;
+          ++comp;
+        }
+        table = (int)(rest / layout.comps[comp].n_units);
+        unit = rest % layout.comps[comp].n_units;
+      } else if (table_major) {
         // tables, then (tile, rtile), then the components' units
         const int64_t per_table = layout.n_units * n_rtiles * n_tiles;
         table = (int)(begin / per_table);
@@ -391,6 +408,7 @@ void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, in
       run.slab = -1;
       out.runs.push_back(run);
       begin = stop;
+    }
     }
     // flush after the last run of every output group this wave touches
     auto group_of = [&](const QuadRun& run) {

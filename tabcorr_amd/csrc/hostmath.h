@@ -175,9 +175,15 @@ struct QuadSchedule {
 // XCD every L2 holds the ~K / 8 matrices its waves use instead of streaming all K through it
 // once per draw tile.  An output group then receives slabs from K tables; slabs are numbered
 // so that those of one group stay consecutive (in table order).
+// kQuadRtileMajor (matrices beyond one L2: hundreds of r values): the r tiles are walked one
+// after the other by ALL waves, each taking an equal share of that r tile's (draw tile,
+// component, unit) space -- with an eighth of the shares per XCD every L2 holds the slice of
+// the matrix of the r tile in flight (1 / n_rtiles of it) instead of streaming the whole
+// matrix once per draw tile.
+constexpr int kQuadTileMajor = 0, kQuadTableMajor = 1, kQuadRtileMajor = 2;
 void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, int n_tables,
                          bool separate, int max_waves, int min_units_per_wave,
-                         QuadSchedule& out, bool table_major = false);
+                         QuadSchedule& out, int order = kQuadTileMajor);
 
 // Workgroup-level merging of the slabs.  Consecutive waves walk consecutive ranges, so the
 // waves of one workgroup mostly end / start inside the same output group and each would

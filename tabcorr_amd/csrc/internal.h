@@ -196,6 +196,7 @@ struct Tuning {
   int single_draw = 1;        // one-launch path for un-batched predict()
   int quad_waves = 2;         // resident contraction waves per SIMD (quadratic-form kernel)
   int quad_merge = 1;         // workgroup-level merging of the partial slabs (hostmath.h)
+  int quad_order = -1;        // schedule order of one table (-1: chosen by matrix size)
   int prio_occ = 0, prio_contract = 1, prio_finalize = 3;   // wave priorities
   int finalize_threads = 0;   // 0: chosen per batch size
   int finalize_row_blocks = 0;

@@ -237,9 +237,15 @@ int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, 
   // small batches use fewer waves (at least 8 units = 16 n_u instructions each)
   const int max_waves = t->n_cus * 4 * std::max(1, std::min(3, t->tuning.quad_waves));
   tc::QuadSchedule schedule;
-  // (interpolators: table-major order, see hostmath.h)
+  // (interpolators: table-major order; one matrix larger than an L2: r-tile-major; see
+  // hostmath.h)
+  const int order = n_tables > 1 ? tc::kQuadTableMajor
+                    : t->tuning.quad_order >= 0 ? t->tuning.quad_order
+                    : (t->quad_tiling.n_rtiles > 1 && q->bytes > ((size_t)4 << 20))
+                        ? tc::kQuadRtileMajor
+                        : tc::kQuadTileMajor;
   tc::build_quad_schedule(q->layout, (int)n_tiles, t->quad_tiling.n_rtiles, n_tables, separate,
-                          max_waves, 8, schedule, n_tables > 1);
+                          max_waves, 8, schedule, order);
   // workgroup-level merging of the slabs: at most 12 LDS slots (60 KB for 20 r values) per
   // workgroup of kQuadWavesPerBlock waves, two workgroups per CU
   tc::QuadMergePlan merge;

@@ -253,7 +253,7 @@ int tc_plan_debug(int mode, int n_bins, const uint8_t* is_central, int n_chunks,
 }
 
 int tc_debug_quad_schedule(int n_bins, int n_central, int by_type, int n_tiles, int n_rtiles,
-                           int n_tables, int separate, int max_waves, int min_units,
+                           int n_tables, int separate, int max_waves, int min_units, int order,
                            int* n_waves, int* n_runs, int* n_slabs, int64_t* units_min,
                            int64_t* units_max) {
   TC_CHECK(n_bins >= 1 && n_central >= 0 && n_central <= n_bins && n_tiles >= 1 &&
@@ -263,7 +263,7 @@ int tc_debug_quad_schedule(int n_bins, int n_central, int by_type, int n_tiles, 
   tc::build_quad_layout(n_bins, n_central, by_type != 0, layout);
   tc::QuadSchedule schedule;
   tc::build_quad_schedule(layout, n_tiles, n_rtiles, n_tables, separate != 0, max_waves,
-                          min_units, schedule, n_tables > 1);
+                          min_units, schedule, order);
   const int tables = std::max(1, n_tables);
   // every (tile, r tile, component, table, unit) exactly once; runs stay inside one block
   // row sequence of their component; slabs of a group consecutive and in order
@@ -300,7 +300,7 @@ int tc_debug_quad_schedule(int n_bins, int n_central, int by_type, int n_tiles, 
         if (run.slab >= schedule.n_slabs || slab_seen[run.slab]++)
           return fail(TC_ERR_INVALID, "slab %d written twice or out of range (run %d)",
                       run.slab, ri);
-        if (n_tables <= 1 && run.slab != next_slab)
+        if (order == tc::kQuadTileMajor && run.slab != next_slab)
           return fail(TC_ERR_INVALID, "slab order (run %d)", ri);
         const int64_t group = ((int64_t)run.tile * n_rtiles + run.rtile) * groups_per_rtile +
                               (separate ? run.comp : 0);
@@ -329,7 +329,7 @@ int tc_debug_quad_schedule(int n_bins, int n_central, int by_type, int n_tiles, 
 int tc_debug_quad_emulate(int n_bins, int n_r, const double* tpcf_matrix,
                           const uint8_t* is_central, int by_type, int separate,
                           const double* densities, int64_t ldb, int64_t n_draws,
-                          int max_waves, int min_units, double* out) {
+                          int max_waves, int min_units, int order, double* out) {
   TC_CHECK(n_bins >= 1 && n_r >= 1 && tpcf_matrix && is_central && densities && out &&
                ldb % 64 == 0 && n_draws >= 1 && n_draws <= ldb,
            "invalid arguments");
@@ -343,7 +343,7 @@ int tc_debug_quad_emulate(int n_bins, int n_r, const double* tpcf_matrix,
                       false, tiling, table);
   tc::QuadSchedule schedule;
   tc::build_quad_schedule(layout, (int)(ldb / 32), tiling.n_rtiles, 1, separate != 0,
-                          max_waves, min_units, schedule);
+                          max_waves, min_units, schedule, order);
   // densities arrive in the reference's bin order; the kernel sees library order
   std::vector<double> ordered((size_t)n_bins * ldb);
   for (int g = 0; g < n_bins; ++g)

@@ -163,12 +163,13 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
     tc::fm::build_tables(math_table.data());
     status = upload(math_table, &t->d_math_table);
   }
-  // The quadratic-form kernel's equal-share schedule walks the matrix once per tile of 32
-  // draws: fine while the matrix stays in the L2s (cfg2 0.8 MB, cfg3 3.2 MB, 25 tables of an
-  // interpolator 21 MB), but a matrix with hundreds of r values (BASELINE configs[4] in
-  // float64: 38 r tiles, 155 MB) would be streamed from the Infinity Cache 313 times per
-  // 10^4 draws (measured 8.2 ms against 4.9 ms for the segment kernel, whose workgroups
-  // share their matrix slice).  Such tables stay on the segment kernel.
+  // The quadratic-form kernel serves mode auto in float64 up to 32 MB of matrix.  While the
+  // matrix fits an L2 (cfg2 0.8 MB, cfg3 3.2 MB) the shares walk it once per tile of 32 draws;
+  // larger ones are walked r tile by r tile by all waves (hostmath.h: kQuadRtileMajor),
+  // interpolators table by table.  Beyond that (BASELINE configs[4] in float64: 38 r tiles of
+  // 4 MB each, more than an L2 per r tile) every wave would still stream its slice from the
+  // Infinity Cache per draw tile (measured 8.2 ms tile-major, 7.2 ms r-tile-major) where the
+  // segment kernel's workgroups share theirs through LDS (4.7 ms): those stay there.
   const tc::QuadTiling quad_tiling = tc::quad_tiling(n_r);
   const double quad_blocks = (n_bins / 4.0 + 1.0) * (n_bins / 4.0 + 2.0) / 2.0;
   const double quad_bytes =
@@ -587,10 +588,11 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     t->tuning.single_draw = value != 0;
   } else if (key == "trace") {
     t->tuning.trace = value;
-  } else if (key == "quad_merge" || key == "quad_waves") {
+  } else if (key == "quad_merge" || key == "quad_waves" || key == "quad_order") {
     // developer A/B of the quadratic-form schedule: schedules are rebuilt on demand
     for (tc_table::Lane& lane : t->lanes) TC_HIP(hipStreamSynchronize(lane.stream));
     if (key == "quad_merge") t->tuning.quad_merge = value != 0;
+    else if (key == "quad_order") t->tuning.quad_order = value;
     else t->tuning.quad_waves = value;
     for (tc::host::QuadTable* q : {&t->quad_by_type, &t->quad_total}) {
       for (auto& kv : q->schedules)

@@ -596,29 +596,33 @@ def test_host_logic_under_address_and_undefined_sanitizers(tmp_path):
 
 # ---- quadratic-form contraction: layout, equal-share schedule, merge (no GPU needed) --------
 
-@pytest.mark.parametrize('n_bins,n_central,by_type,n_tiles,n_rtiles,n_tables,separate,max_waves', [
-    (100, 50, 1, 313, 1, 1, 0, 2048),      # BASELINE configs[1]
-    (200, 100, 1, 313, 1, 1, 1, 2048),     # configs[2]
-    (100, 50, 1, 391, 1, 25, 0, 2048),     # configs[3]: table-major order
-    (100, 50, 1, 7, 1, 25, 1, 2048),
-    (13, 5, 0, 3, 2, 1, 0, 64),
-    (13, 5, 1, 3, 2, 4, 1, 64),
-    (1, 1, 1, 1, 1, 1, 0, 2048),
-    (60, 30, 1, 1, 1, 1, 0, 2048),         # un-batched call
-])
+@pytest.mark.parametrize(
+    'n_bins,n_central,by_type,n_tiles,n_rtiles,n_tables,separate,max_waves,order', [
+        (100, 50, 1, 313, 1, 1, 0, 2048, 0),      # BASELINE configs[1]
+        (200, 100, 1, 313, 1, 1, 1, 2048, 0),     # configs[2]
+        (100, 50, 1, 391, 1, 25, 0, 2048, 1),     # configs[3]: table-major order
+        (100, 50, 1, 7, 1, 25, 1, 2048, 1),
+        (200, 100, 1, 40, 38, 1, 0, 2048, 2),     # configs[4] in float64: r-tile-major order
+        (13, 5, 0, 3, 2, 1, 0, 64, 0),
+        (13, 5, 0, 3, 3, 1, 1, 64, 2),
+        (13, 5, 1, 3, 2, 4, 1, 64, 1),
+        (1, 1, 1, 1, 1, 1, 0, 2048, 0),
+        (60, 30, 1, 1, 1, 1, 0, 2048, 0),         # un-batched call
+    ])
 def test_quad_schedule_covers_every_unit_once(lib, n_bins, n_central, by_type, n_tiles, n_rtiles,
-                                              n_tables, separate, max_waves):
+                                              n_tables, separate, max_waves, order):
     """Every (draw tile, r tile, component, table, unit) in exactly one run, every slab
     written once and inside its group's range, equal shares (tc_debug_quad_schedule)."""
     n_waves, n_runs, n_slabs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     lo, hi = ctypes.c_int64(), ctypes.c_int64()
     from tabcorr_amd import _lib
     _lib.check(lib.tc_debug_quad_schedule(
-        n_bins, n_central, by_type, n_tiles, n_rtiles, n_tables, separate, max_waves, 8,
+        n_bins, n_central, by_type, n_tiles, n_rtiles, n_tables, separate, max_waves, 8, order,
         ctypes.byref(n_waves), ctypes.byref(n_runs), ctypes.byref(n_slabs), ctypes.byref(lo),
         ctypes.byref(hi)))
     assert 1 <= n_waves.value <= max_waves
-    assert hi.value - lo.value <= 1                      # equal shares
+    # equal shares (per r tile in r-tile-major order: a unit of slack per pass)
+    assert hi.value - lo.value <= (n_rtiles if order == 2 else 1)
     assert n_slabs.value >= 1 and n_runs.value >= n_waves.value
 
 
@@ -652,11 +656,11 @@ def test_quad_emulation_matches_the_oracle(lib, n_prim, n_sec, n_r, separate, n_
     padded[:, :n_draws] = densities
     is_central = np.ascontiguousarray(oracle.is_centrals(gal_type), dtype=np.uint8)
     n_comp = 3 if separate else 1
-    for max_waves in (5, 2048):
+    for max_waves, order in ((5, 0), (2048, 0), (5, 2), (2048, 2)):
         out = np.zeros((n_draws, n_comp, n_r))
         _lib.check(lib.tc_debug_quad_emulate(
             n_bins, n_r, _lib.as_double_p(matrix), is_central.ctypes.data_as(_lib.c_uint8_p),
-            1, separate, _lib.as_double_p(padded), ldb, n_draws, max_waves, 8,
+            1, separate, _lib.as_double_p(padded), ldb, n_draws, max_waves, 8, order,
             _lib.as_double_p(out)))
         prefactor = np.where(index_1 == index_2, 1.0, 2.0)
         weights = prefactor[None] * densities[index_1].T * densities[index_2].T   # (B, P)
