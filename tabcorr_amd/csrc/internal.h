@@ -197,7 +197,12 @@ struct Tuning {
   int quad_waves = 2;         // resident contraction waves per SIMD (quadratic-form kernel)
   int quad_merge = 1;         // workgroup-level merging of the partial slabs (hostmath.h)
   int quad_order = -1;        // schedule order of one table (-1: chosen by matrix size)
-  int prio_occ = 0, prio_contract = 1, prio_finalize = 3;   // wave priorities
+  // wave priorities.  The occupation kernel heads each lane's chain (occupation ->
+  // contraction -> finalisation); below the contraction's priority its dependent chains of
+  // FP64 instructions wait behind 64-cycle matrix instructions and the kernel takes 85-95 us
+  // in the pipeline (25 us alone), which the lane's next two kernels then wait for: 44.2 us
+  // per step with priority 0, 43.2 with 1, 42.6 with 2, 48.1 with 3 (tools/r02_sweep.sh)
+  int prio_occ = 2, prio_contract = 1, prio_finalize = 3;
   int finalize_threads = 0;   // 0: chosen per batch size
   int finalize_row_blocks = 0;
   int occ_splits = 0;         // 0: chosen per batch size
@@ -284,7 +289,7 @@ struct tc_table {
     tc::host::DeviceBuffer xi;       // chi2 device calls: the correlation functions
     int ngal_parts = 1;              // partial sums the occupation step left in ngal2
   };
-  static constexpr int kMaxLanes = 4;
+  static constexpr int kMaxLanes = 8;
   Lane lanes[kMaxLanes];
   int n_lanes = 2;
   int prev = -1;                     // lane of the previous finalisation

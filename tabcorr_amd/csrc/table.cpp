@@ -588,6 +588,12 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     t->tuning.single_draw = value != 0;
   } else if (key == "trace") {
     t->tuning.trace = value;
+  } else if (key == "prio_occ" || key == "prio_contract" || key == "prio_finalize") {
+    // developer A/B: wave priorities (0..3) of the three kernels
+    TC_CHECK(value >= 0 && value <= 3, "priorities are 0..3");
+    (key == "prio_occ" ? t->tuning.prio_occ
+                       : key == "prio_contract" ? t->tuning.prio_contract
+                                                : t->tuning.prio_finalize) = value;
   } else if (key == "quad_merge" || key == "quad_waves" || key == "quad_order") {
     // developer A/B of the quadratic-form schedule: schedules are rebuilt on demand
     for (tc_table::Lane& lane : t->lanes) TC_HIP(hipStreamSynchronize(lane.stream));
