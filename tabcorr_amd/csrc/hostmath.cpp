@@ -527,6 +527,52 @@ void fill_quad_table(const QuadLayout& layout, const std::vector<int32_t>& perm,
   }
 }
 
+QuadTiling quad_tiling_f32(int n_r) {
+  QuadTiling tiling;
+  tiling.n_rtiles = (n_r + 15) / 16;
+  tiling.r_per_tile = (n_r + tiling.n_rtiles - 1) / tiling.n_rtiles;
+  tiling.n_u = (tiling.r_per_tile + 3) / 4;
+  return tiling;
+}
+
+void fill_quad_table_f32(const QuadLayout& layout, const std::vector<int32_t>& perm, int n_r,
+                         int64_t n_pairs, const void* matrix, bool matrix_is_f32,
+                         const QuadTiling& tiling, std::vector<float>& out) {
+  const size_t per_unit = 256;       // 64 lanes x 4 sub-tiles
+  out.assign((size_t)tiling.n_rtiles * layout.n_units * per_unit, 0.0f);
+  auto source = [&](int r, int64_t column) {
+    return matrix_is_f32 ? (double)((const float*)matrix)[(size_t)r * n_pairs + column]
+                         : ((const double*)matrix)[(size_t)r * n_pairs + column];
+  };
+  for (const QuadComp& comp : layout.comps) {
+    for (int rb = 0; rb < comp.n_rb; ++rb) {
+      for (int cb = 0; cb < quad_row_length(comp, rb); ++cb) {
+        const int64_t unit =
+            comp.unit_base + (comp.triangular ? (int64_t)rb * (rb + 1) / 2 + cb
+                                              : (int64_t)rb * comp.n_cb + cb);
+        for (int lane = 0; lane < 64; ++lane) {
+          const int m = lane & 15, k = lane >> 4;
+          const int i_local = 4 * rb + (m & 3), j_local = 4 * cb + k;
+          if (i_local >= comp.i_count || j_local >= comp.j_count) continue;
+          const int i = comp.i_bin0 + i_local, j = comp.j_bin0 + j_local;
+          if (comp.triangular && j > i) continue;
+          const int64_t column = packed_index(perm[i], perm[j]);
+          const double prefactor = i == j ? 1.0 : 2.0;
+          for (int z = 0; z < tiling.n_rtiles; ++z) {
+            for (int u = 0; u < tiling.n_u; ++u) {
+              const int r_local = 4 * u + (m >> 2);
+              const int r = z * tiling.r_per_tile + r_local;
+              if (r_local >= tiling.r_per_tile || r >= n_r) continue;
+              out[((size_t)z * layout.n_units + unit) * per_unit + (size_t)lane * 4 + u] =
+                  (float)(source(r, column) * prefactor);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 void quad_emulate(const QuadLayout& layout, const QuadSchedule& schedule,
                   const QuadTiling& tiling, const std::vector<double>& table,
                   const double* densities, int64_t ldb, int64_t n_draws, int n_r,

@@ -226,6 +226,15 @@ void fill_quad_table(const QuadLayout& layout, const std::vector<int32_t>& perm,
                      int64_t n_pairs, const void* matrix, bool matrix_is_f32,
                      const QuadTiling& tiling, std::vector<double>& out);
 
+// float32 variant (contract_quad_f32_kernel, v_mfma_f32_16x16x4_f32): r tiles of 16 values
+// (n_u <= 4 sub-tiles of 4), draw tiles of 64 (four column sets of 16); per r tile and unit
+// [lane = k * 16 + i_local + 4 r_local][u] floats -- one 16-byte load per lane carries the A
+// operand of all four sub-tiles.
+QuadTiling quad_tiling_f32(int n_r);
+void fill_quad_table_f32(const QuadLayout& layout, const std::vector<int32_t>& perm, int n_r,
+                         int64_t n_pairs, const void* matrix, bool matrix_is_f32,
+                         const QuadTiling& tiling, std::vector<float>& out);
+
 // TEST INFRASTRUCTURE (never called by the product): executes a schedule on the host the
 // way contract_quad_kernel + finalize_quad_kernel do -- same operand lanes, same unit
 // walk, same slab grouping -- so that the layout, the schedule and the grouping can be

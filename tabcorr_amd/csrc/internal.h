@@ -286,6 +286,7 @@ struct tc_table {
     hipStream_t stream = nullptr;
     hipEvent_t finished = nullptr;   // recorded after the lane's last finalisation
     tc::host::DeviceBuffer nbuf, ngal2, partial;
+    tc::host::DeviceBuffer nbuf32;   // float copy of nbuf (float32 quadratic-form kernel)
     tc::host::DeviceBuffer xi;       // chi2 device calls: the correlation functions
     int ngal_parts = 1;              // partial sums the occupation step left in ngal2
   };
@@ -353,7 +354,10 @@ int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, 
                       DeviceQuadSchedule** out);
 int launch_contract_quad(int n_u, bool interp, const QuadArgs& args, int lds_bytes,
                          hipStream_t stream, hipEvent_t start, hipEvent_t stop);
-int launch_finalize_quad(const FinalizeQuadArgs& args, const Tuning& tuning, hipStream_t stream);
+int launch_finalize_quad(const FinalizeQuadArgs& args, const Tuning& tuning, hipStream_t stream,
+                         bool f32 = false);
+int launch_contract_quad_f32(int n_u, const QuadArgs& args, int lds_bytes, hipStream_t stream,
+                             hipEvent_t start, hipEvent_t stop);
 // Stream an interpolator's work is queued on (interp.cpp).
 hipStream_t interp_stream(tc_interp* interp);
 // Events for hipExtLaunchKernelGGL while the table's kernel timer is on, else NULLs.

@@ -114,7 +114,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   if (status != TC_OK) return status;
   Range range("contraction + finalisation (all tables)");
 
-  if (t0->quad) {
+  if (t0->quad && t0->compute_dtype == TC_DTYPE_F64) {
     // quadratic-form kernel: the unit space (draw tile, r tile, component, TABLE, unit) in
     // equal shares per wave; a table's spline weight scales the outer factor n_i
     const bool by_type = separate || t0->quad_total.d_table == nullptr;
@@ -141,7 +141,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
     qa.comps = (const tc::QuadCompArgs*)q->d_comps;
     qa.wave_runs = (const int32_t*)schedule->wave_runs;
     qa.n_waves = schedule->n_waves;
-    qa.partial = (double*)it->partial.ptr;
+    qa.partial = it->partial.ptr;
     qa.priority = t0->tuning.prio_contract;
     qa.merge_range = (const int32_t*)schedule->merge_range;
     qa.merges = (const int32_t*)schedule->merges;
@@ -152,7 +152,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
     status = launch_contract_quad(tiling.n_u, true, qa, schedule->lds_bytes, it->stream, k0, k1);
     if (status != TC_OK) return status;
     tc::FinalizeQuadArgs fq{};
-    fq.partial = (const double*)it->partial.ptr;
+    fq.partial = it->partial.ptr;
     fq.group_begin = (const int32_t*)schedule->group_begin;
     fq.ngal_part = nullptr;      // already normalised; ngal written by the coef kernel
     fq.n_ngal_parts = 0;

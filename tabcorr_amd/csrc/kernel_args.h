@@ -40,6 +40,7 @@ struct OccArgs {
   const int32_t* perm;     // library bin -> reference row
   const double* math_table;  // fm::kTableDoubles doubles (fastmath.h)
   double* nbuf;            // (n_bins, ldb) number density per bin and draw
+  float* nbuf32;           // optional float copy of it (float32 quadratic-form kernel)
   double* ngal;            // (bin splits, 2, ldb) partial cen / sat densities
   double* occupation;      // optional (n_draws, n_bins) in reference order
 };
@@ -127,7 +128,11 @@ struct QuadCompArgs {
   int32_t pad[3];
 };
 
+constexpr int kQuadTileF32 = 64;       // draws per tile of the float32 kernel (four column sets)
+constexpr int kQuadMaxUF32 = 4;        // r sub-tiles per r tile: at most 16 r values
+
 struct QuadArgs {
+  const float* nbuf32;             // float32 kernel: (n_bins, ldb) densities in float
   const double* nbuf;              // (n_bins, ldb); interpolator: NULL
   const double* const* nbufs;      // interpolator: density buffer of each class
   int64_t ldb;
@@ -142,14 +147,14 @@ struct QuadArgs {
   const int32_t* wave_runs;        // (n_waves, 2): first run and end run of every wave
   int n_waves;
   int priority;                    // wave priority (0..3)
-  double* partial;                 // (n_slabs, 4 U, 32)
+  void* partial;                   // (n_slabs, 4 U, 32) doubles / (n_slabs, 4 U, 64) floats
   const int32_t* merge_range;      // (workgroups, 2): first and end merge of every workgroup
   const int32_t* merges;           // QuadMerge = 4 x int32: slab, first LDS slot, count, -
   unsigned long long* stamps;      // developer timeline: 6 words per wave, or NULL
 };
 
 struct FinalizeQuadArgs {
-  const double* partial;        // (n_slabs, rt, 32)
+  const void* partial;          // (n_slabs, rt, 32) doubles or (n_slabs, rt, 64) floats
   const int32_t* group_begin;   // (n_groups + 1): slabs of each (draw tile, r tile[, component])
   const double* ngal_part;      // as FinalizeArgs
   int n_ngal_parts;

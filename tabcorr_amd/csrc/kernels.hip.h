@@ -261,6 +261,8 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
         a.occupation[b0 * a.n_bins + perm[g]] = acc;
       const double dens = acc * n_h[g];
       a.nbuf[(int64_t)g * a.ldb + (int64_t)tile * kLanes + lane] = dens;
+      if (a.nbuf32 != nullptr)
+        a.nbuf32[(int64_t)g * a.ldb + (int64_t)tile * kLanes + lane] = (float)dens;
       if (central) sum_cen += dens; else sum_sat += dens;
     }
     red[0][wave][lane] = sum_cen;
@@ -431,6 +433,8 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_leauthaud11_kernel(Occ
         a.occupation[b0 * a.n_bins + perm[g]] = acc;
       const double dens = acc * n_h[g];
       a.nbuf[(int64_t)g * a.ldb + (int64_t)tile * kLanes + lane] = dens;
+      if (a.nbuf32 != nullptr)
+        a.nbuf32[(int64_t)g * a.ldb + (int64_t)tile * kLanes + lane] = (float)dens;
       if (central) sum_cen += dens; else sum_sat += dens;
     }
     red[0][wave][lane] = sum_cen;
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_leauthaud11_kernel(Occ
 __global__ __launch_bounds__(256) void occ_from_array_kernel(
     const double* occupation, int64_t n_draws, int64_t ldb, int n_bins,
     int n_central, const double* n_h, const int32_t* perm, double* nbuf,
-    double* ngal) {
+    double* ngal, float* nbuf32) {
   const int64_t b0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b0 >= ldb) return;
   const int64_t b = b0 < n_draws ? b0 : n_draws - 1;
@@ -459,6 +463,7 @@ __global__ __launch_bounds__(256) void occ_from_array_kernel(
   for (int g = 0; g < n_bins; ++g) {
     const double dens = occupation[b * n_bins + perm[g]] * n_h[g];
     nbuf[(int64_t)g * ldb + b0] = dens;
+    if (nbuf32 != nullptr) nbuf32[(int64_t)g * ldb + b0] = (float)dens;
     if (g < n_central) sum_cen += dens; else sum_sat += dens;
   }
   ngal[b0] = sum_cen;
@@ -916,8 +921,9 @@ __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_kern
     if (slab != -1) {
       // r = 4 u + l / 16, draws 2 c and 2 c + 1 of the tile: to a slab of the partial buffer,
       // or to an LDS slot of the workgroup that is merged with its neighbours below
-      double* out = slab >= 0 ? a.partial + ((int64_t)slab * (4 * U) + kq) * kQuadTile + 2 * c
-                              : stage + ((-2 - slab) * (4 * U) + kq) * kQuadTile + 2 * c;
+      double* out = slab >= 0
+                        ? (double*)a.partial + ((int64_t)slab * (4 * U) + kq) * kQuadTile + 2 * c
+                        : stage + ((-2 - slab) * (4 * U) + kq) * kQuadTile + 2 * c;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const f64x2 value = {F[u][0], F[u][1]};
@@ -951,7 +957,7 @@ __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_kern
   sc_i32 merges = (sc_i32)a.merges;
   for (int e = merge_begin + wave_in_block; e < merge_end; e += kQuadWavesPerBlock) {
     const int slab = merges[4 * e], first = merges[4 * e + 1], count = merges[4 * e + 2];
-    double* out = a.partial + ((int64_t)slab * (4 * U) + kq) * kQuadTile + 2 * c;
+    double* out = (double*)a.partial + ((int64_t)slab * (4 * U) + kq) * kQuadTile + 2 * c;
     const double* in = stage + (first * (4 * U) + kq) * kQuadTile + 2 * c;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -964,9 +970,162 @@ __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_kern
   write_stamps();
 }
 
+// ---- the same in float32 (BASELINE configs[4]: hundreds of r values, tolerance 1e-5) ------
+//
+// v_mfma_f32_16x16x4_f32 (probed: tools/micro/mfma_map_f32.hip): A[m = l % 16][k = l / 16],
+// B[k = l / 16][n = l % 16], D[m = 4 (l / 16) + v][n = l % 16] in register v.  With
+// m = i_local + 4 r_local, k = j_local, n = draw: register v is bin i0 + v and the lane group
+// l / 16 the r value, so the outer factor is applied per register as in the float64 kernel.
+// The matrix instruction is twice as fast as the float64 one, so a wave owns 64 draws (four
+// column sets: draws 4 c + s of its tile, one 16-byte density load per lane serves all four)
+// and an r tile holds 16 values (four sub-tiles in ONE 16-byte table load per lane): 16
+// matrix instructions per two loads.  Densities arrive as floats (the occupation kernel
+// writes a float copy), sums stay in float, slabs are (4 U, 64) floats.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int IMM>
+__device__ inline f32x4 buffer_load16f(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_offset,
+                                       unsigned wave_offset) {
+  return __builtin_bit_cast(
+      f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_offset + IMM, wave_offset, 0));
+}
+
+template <int U>
+__global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_f32_kernel(QuadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float stage32[];   // merge slots (4 U, 64)
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave = (int)blockIdx.x * kQuadWavesPerBlock + wave_in_block;
+  set_priority(a.priority);
+  sc_i32 wave_runs = (sc_i32)a.wave_runs;
+  sc_i32 runs = (sc_i32)a.runs;
+  sc_i32 comps = (sc_i32)a.comps;
+  const int run_begin = wave < a.n_waves ? wave_runs[2 * wave] : 0;
+  const int run_end = wave < a.n_waves ? wave_runs[2 * wave + 1] : 0;
+  const int c = lane & 15, kq = lane >> 4;
+  const unsigned row_bytes = (unsigned)(a.ldb * 4);
+  const unsigned off_a = lane * 16;                    // table: (unit, lane) x 16 B
+  const unsigned off_e = c * 16;                       // densities of draws 4 c .. 4 c + 3
+  const unsigned off_b = kq * row_bytes + c * 16;      // ... of bin j0 + l / 16
+  float F[U][4];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) F[u][s] = 0.0f;
+
+  for (int ri = run_begin; ri < run_end; ++ri) {
+    const int tile = runs[ri * 8 + 0], rtile = runs[ri * 8 + 1], comp = runs[ri * 8 + 2];
+    const int rb0 = runs[ri * 8 + 4], cb0 = runs[ri * 8 + 5];
+    const int count = runs[ri * 8 + 6], slab = runs[ri * 8 + 7];
+    const bool triangular = comps[comp * 8 + 0] != 0;
+    const int i_bin0 = comps[comp * 8 + 1], j_bin0 = comps[comp * 8 + 2];
+    const int n_cb = comps[comp * 8 + 3];
+    const unsigned unit_base = (unsigned)comps[comp * 8 + 4];
+    const char* matrix = (const char*)a.table + (int64_t)rtile * a.rtile_bytes;
+    const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.nbuf32 + (int64_t)tile * kQuadTileF32), 0,
+        (unsigned)a.n_bins * row_bytes - (unsigned)tile * (kQuadTileF32 * 4), kBufferFlags);
+    const __amdgpu_buffer_rsrc_t rs_t =
+        __builtin_amdgcn_make_buffer_rsrc((void*)matrix, 0, a.rtile_bytes, kBufferFlags);
+
+    int rb = rb0, cb = cb0, left = count;
+    unsigned ua = (unit_base + (unsigned)(triangular ? rb * (rb + 1) / 2 + cb : rb * n_cb + cb)) *
+                  1024u;
+    f32x4 t0, t1, b0, b1;
+    f32x4 D[U][4];
+    auto fetch = [&](f32x4& t, f32x4& b, int col) {
+      t = buffer_load16f<0>(rs_t, off_a, ua);
+      b = buffer_load16f<0>(rs_n, off_b, (unsigned)(j_bin0 + 4 * col) * row_bytes);
+      ua += 1024u;
+    };
+    auto mma = [&](const f32x4& t, const f32x4& b, bool first) {
+      const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          D[u][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[u], b[s], first ? zero : D[u][s], 0, 0, 0);
+    };
+    fetch(t0, b0, cb);
+    while (left > 0) {
+      const int row_length = triangular ? rb + 1 : n_cb;
+      const int n = row_length - cb < left ? row_length - cb : left;
+      left -= n;
+      f32x4 e[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        e[v] = buffer_load16f<0>(rs_n, off_e, (unsigned)(i_bin0 + 4 * rb + v) * row_bytes);
+      fetch(t1, b1, n > 1 ? cb + 1 : 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(t0, b0, true);
+      __builtin_amdgcn_sched_barrier(0);
+      int t = 1;
+      for (; t + 1 < n; t += 2) {
+        fetch(t0, b0, cb + t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(t1, b1, false);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(t1, b1, t + 2 < n ? cb + t + 2 : 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(t0, b0, false);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (t < n) {
+        fetch(t0, b0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(t1, b1, false);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        t0 = t1;
+        b0 = b1;
+      }
+      // the row's outer factor: F += D n_i
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) F[u][s] = fmaf(D[u][s][v], e[v][s], F[u][s]);
+      ++rb;
+      cb = 0;
+    }
+    if (slab != -1) {
+      // r = 4 u + l / 16, draws 4 c .. 4 c + 3 of the tile
+      float* out = slab >= 0
+                       ? (float*)a.partial + ((int64_t)slab * (4 * U) + kq) * kQuadTileF32 + 4 * c
+                       : stage32 + ((-2 - slab) * (4 * U) + kq) * kQuadTileF32 + 4 * c;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const f32x4 value = {F[u][0], F[u][1], F[u][2], F[u][3]};
+        *(f32x4*)(out + (4 * u) * kQuadTileF32) = value;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) F[u][s] = 0.0f;
+      }
+    }
+  }
+  sc_i32 merge_range = (sc_i32)a.merge_range;
+  const int merge_begin = merge_range[2 * blockIdx.x], merge_end = merge_range[2 * blockIdx.x + 1];
+  if (merge_begin == merge_end) return;          // (uniform over the workgroup)
+  __syncthreads();
+  sc_i32 merges = (sc_i32)a.merges;
+  for (int e = merge_begin + wave_in_block; e < merge_end; e += kQuadWavesPerBlock) {
+    const int slab = merges[4 * e], first = merges[4 * e + 1], n_slots = merges[4 * e + 2];
+    float* out = (float*)a.partial + ((int64_t)slab * (4 * U) + kq) * kQuadTileF32 + 4 * c;
+    const float* in = stage32 + (first * (4 * U) + kq) * kQuadTileF32 + 4 * c;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      f32x4 sum = *(const f32x4*)(in + (4 * u) * kQuadTileF32);
+      for (int s = 1; s < n_slots; ++s)
+        sum += *(const f32x4*)(in + (s * (4 * U) + 4 * u) * kQuadTileF32);
+      *(f32x4*)(out + (4 * u) * kQuadTileF32) = sum;
+    }
+  }
+}
+
 // Sums the slabs of every output group in slab order, normalises and writes the results
 // in the reference's order: finalize_kernel for the partial layout of contract_quad_kernel.
 // One block per 64 draws (two 32-draw tiles, each with its own slab lists).
+template <typename P, int TILE>
 __global__ __launch_bounds__(1024) void finalize_quad_kernel(FinalizeQuadArgs a) {
   __shared__ double tile[kFinalizeRows][kLanes + 1];
   __shared__ double part_sum[16][kLanes];
@@ -1008,8 +1167,9 @@ __global__ __launch_bounds__(1024) void finalize_quad_kernel(FinalizeQuadArgs a)
   const int rows_per_block = (n_rows + gridDim.y - 1) / gridDim.y;
   const int row_begin = blockIdx.y * rows_per_block;
   const int row_end = row_begin + rows_per_block < n_rows ? row_begin + rows_per_block : n_rows;
-  const int64_t tile32 = (int64_t)blockIdx.x * 2 + (lane >> 5);
-  const int64_t slab_stride = (int64_t)a.rt * kQuadTile;
+  // (a block serves 64 draws: two tiles of 32, or one of 64)
+  const int64_t tile32 = TILE == 32 ? (int64_t)blockIdx.x * 2 + (lane >> 5) : (int64_t)blockIdx.x;
+  const int64_t slab_stride = (int64_t)a.rt * TILE;
   // sum of part `part` of `parts` equal ranges of a row's slabs, eight independent loads
   // in flight, the additions in slab order
   auto sum_slabs = [&](int row, int part, int parts) {
@@ -1020,12 +1180,13 @@ __global__ __launch_bounds__(1024) void finalize_quad_kernel(FinalizeQuadArgs a)
     const int first = a.group_begin[group], count = a.group_begin[group + 1] - first;
     const int begin = first + (int)((int64_t)count * part / parts);
     const int end = first + (int)((int64_t)count * (part + 1) / parts);
-    const double* src = a.partial + ((int64_t)begin * a.rt + r_local) * kQuadTile + (lane & 31);
+    const P* src = (const P*)a.partial + ((int64_t)begin * a.rt + r_local) * TILE + (lane & (TILE - 1));
     double sum = 0.0;
     for (int s0 = begin; s0 < end; s0 += 8) {
       double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = s0 + u < end ? src[(s0 - begin + u) * slab_stride] : 0.0;
+      for (int u = 0; u < 8; ++u)
+        v[u] = s0 + u < end ? (double)src[(s0 - begin + u) * slab_stride] : 0.0;
 #pragma unroll
       for (int u = 0; u < 8; ++u) sum += v[u];
     }

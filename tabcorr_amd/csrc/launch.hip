@@ -200,16 +200,26 @@ int64_t max_slab(const tc_table* t) {
 int build_quad_table(tc_table* t, bool by_type, const void* matrix, int matrix_dtype,
                      QuadTable* out) {
   tc::build_quad_layout(t->n_bins, t->plan.n_central, by_type, out->layout);
-  std::vector<double> host;
-  tc::fill_quad_table(out->layout, t->plan.perm, t->n_r, t->n_pairs, matrix,
-                      matrix_dtype == TC_DTYPE_F32, t->quad_tiling, host);
-  const int up = (t->quad_tiling.n_u + 1) / 2;
-  out->rtile_bytes = (size_t)out->layout.n_units * up * 1024;
+  int status;
+  if (t->compute_dtype == TC_DTYPE_F32) {
+    std::vector<float> host;
+    tc::fill_quad_table_f32(out->layout, t->plan.perm, t->n_r, t->n_pairs, matrix,
+                            matrix_dtype == TC_DTYPE_F32, t->quad_tiling, host);
+    out->rtile_bytes = (size_t)out->layout.n_units * 1024;
+    out->bytes = host.size() * sizeof(float);
+    status = upload(host, &out->d_table);
+  } else {
+    std::vector<double> host;
+    tc::fill_quad_table(out->layout, t->plan.perm, t->n_r, t->n_pairs, matrix,
+                        matrix_dtype == TC_DTYPE_F32, t->quad_tiling, host);
+    const int up = (t->quad_tiling.n_u + 1) / 2;
+    out->rtile_bytes = (size_t)out->layout.n_units * up * 1024;
+    out->bytes = host.size() * sizeof(double);
+    status = upload(host, &out->d_table);
+  }
   if (out->rtile_bytes >= ((size_t)1 << 32) - (1 << 24))
-    return fail(TC_ERR_UNSUPPORTED, "table with %d bins is too large for the float64 kernel",
-                t->n_bins);
-  out->bytes = host.size() * sizeof(double);
-  int status = upload(host, &out->d_table);
+    return fail(TC_ERR_UNSUPPORTED, "table with %d bins is too large for the quadratic-form "
+                "kernel", t->n_bins);
   if (status != TC_OK) return status;
   std::vector<tc::QuadCompArgs> comps;
   for (const tc::QuadComp& comp : out->layout.comps) {
@@ -241,8 +251,11 @@ int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, 
   // hostmath.h)
   const int order = n_tables > 1 ? tc::kQuadTableMajor
                     : t->tuning.quad_order >= 0 ? t->tuning.quad_order
-                    : (t->quad_tiling.n_rtiles > 1 && q->bytes > ((size_t)4 << 20))
+                    : (t->compute_dtype == TC_DTYPE_F64 && t->quad_tiling.n_rtiles > 1 &&
+                       q->bytes > ((size_t)4 << 20))
                         ? tc::kQuadRtileMajor
+                        // (float32, BASELINE configs[4]: 2.42 ms draw-tile-major against 2.80 --
+                        // half the bytes per flop, and 48 passes cost 13 slabs per group)
                         : tc::kQuadTileMajor;
   tc::build_quad_schedule(q->layout, (int)n_tiles, t->quad_tiling.n_rtiles, n_tables, separate,
                           max_waves, 8, schedule, order);
@@ -253,7 +266,9 @@ int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, 
                           t->tuning.quad_merge ? 12 : 0, schedule, merge);
   std::unique_ptr<DeviceQuadSchedule> d(new DeviceQuadSchedule);
   d->n_waves = schedule.n_waves;
-  d->lds_bytes = merge.lds_slots * 4 * t->quad_tiling.n_u * tc::kQuadTile * (int)sizeof(double);
+  d->lds_bytes = merge.lds_slots * 4 * t->quad_tiling.n_u *
+                 (t->compute_dtype == TC_DTYPE_F32 ? tc::kQuadTileF32 * (int)sizeof(float)
+                                                   : tc::kQuadTile * (int)sizeof(double));
   d->n_slabs = schedule.n_slabs;
   d->n_groups = schedule.n_groups;
   d->n_runs = (int)schedule.runs.size();
@@ -343,19 +358,50 @@ int launch_contract_quad(int n_u, bool interp, const tc::QuadArgs& args, int lds
   return TC_OK;
 }
 
+int launch_contract_quad_f32(int n_u, const tc::QuadArgs& args, int lds_bytes,
+                             hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+  const dim3 grid((unsigned)((args.n_waves + tc::kQuadWavesPerBlock - 1) /
+                             tc::kQuadWavesPerBlock));
+  const dim3 block(64 * tc::kQuadWavesPerBlock);
+  if (args.n_waves == 0) return TC_OK;
+  switch (n_u) {
+#define TC_CASE(N)                                                                        \
+  case N:                                                                                 \
+    hipExtLaunchKernelGGL((tc::contract_quad_f32_kernel<N>), grid, block, lds_bytes,      \
+                          stream, start, stop, 0, args);                                  \
+    break;
+    TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4)
+#undef TC_CASE
+    default:
+      return fail(TC_ERR_UNSUPPORTED, "no float32 kernel for %d r sub-tiles", n_u);
+  }
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+
 int launch_finalize_quad(const tc::FinalizeQuadArgs& args, const Tuning& tuning,
-                         hipStream_t stream) {
+                         hipStream_t stream, bool f32) {
   // geometry as launch_finalize: one block per 64 draws, small batches split the rows
   const int64_t n_tiles = args.ldb / 64;
   const int threads =
       tuning.finalize_threads > 0 ? tuning.finalize_threads : n_tiles < 128 ? 1024 : 256;
   const int n_rows = args.n_comp * args.n_r;
+  // (many rows -- hundreds of r values -- are split over row blocks of at least 16 rows until
+  // the grid has ~2048 blocks: one block per draw tile walked 760 rows serially, 2.4 ms)
   const int row_blocks = std::min(
       n_rows, tuning.finalize_row_blocks > 0
                   ? tuning.finalize_row_blocks
-                  : n_tiles < 128 ? (int)std::max<int64_t>(1, 512 / n_tiles) : 1);
-  hipLaunchKernelGGL(tc::finalize_quad_kernel, dim3((unsigned)n_tiles, (unsigned)row_blocks),
-                     dim3(threads), 0, stream, args);
+                  : n_tiles < 128 ? (int)std::max<int64_t>(1, 512 / n_tiles)
+                                  : (int)std::max<int64_t>(
+                                        1, std::min<int64_t>(n_rows / 16, 2048 / n_tiles)));
+  if (f32)
+    hipLaunchKernelGGL((tc::finalize_quad_kernel<float, tc::kQuadTileF32>),
+                       dim3((unsigned)n_tiles, (unsigned)row_blocks), dim3(threads), 0, stream,
+                       args);
+  else
+    hipLaunchKernelGGL((tc::finalize_quad_kernel<double, tc::kQuadTile>),
+                       dim3((unsigned)n_tiles, (unsigned)row_blocks), dim3(threads), 0, stream,
+                       args);
   TC_HIP(hipGetLastError());
   return TC_OK;
 }
@@ -368,18 +414,23 @@ static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsig
   QuadTable* q = separate || t->quad_total.d_table == nullptr ? &t->quad_by_type
                                                               : &t->quad_total;
   const tc::QuadTiling& tiling = t->quad_tiling;
+  const bool f32 = t->compute_dtype == TC_DTYPE_F32;
   DeviceQuadSchedule* schedule = nullptr;
-  int status = get_quad_schedule(t, q, ldb / tc::kQuadTile, 1, separate, &schedule);
+  int status = get_quad_schedule(t, q, ldb / (f32 ? tc::kQuadTileF32 : tc::kQuadTile), 1,
+                                 separate, &schedule);
   if (status != TC_OK) return status;
   tc_table::Lane& lane = t->lanes[t->cur];
   hipStream_t stream = lane.stream;
   const int rt = 4 * tiling.n_u;
   status = lane.partial.reserve(
-      (size_t)schedule->n_slabs * rt * tc::kQuadTile * sizeof(double), stream);
+      (size_t)schedule->n_slabs * rt *
+          (f32 ? tc::kQuadTileF32 * sizeof(float) : tc::kQuadTile * sizeof(double)),
+      stream);
   if (status != TC_OK) return status;
 
   tc::QuadArgs qa{};
   qa.nbuf = (const double*)lane.nbuf.ptr;
+  qa.nbuf32 = (const float*)lane.nbuf32.ptr;
   qa.nbufs = nullptr;
   qa.ldb = ldb;
   qa.n_bins = t->n_bins;
@@ -392,7 +443,7 @@ static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsig
   qa.comps = (const tc::QuadCompArgs*)q->d_comps;
   qa.wave_runs = (const int32_t*)schedule->wave_runs;
   qa.n_waves = schedule->n_waves;
-  qa.partial = (double*)lane.partial.ptr;
+  qa.partial = lane.partial.ptr;
   qa.priority = t->tuning.prio_contract;
   qa.merge_range = (const int32_t*)schedule->merge_range;
   qa.merges = (const int32_t*)schedule->merges;
@@ -408,7 +459,8 @@ static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsig
   hipEvent_t k0 = nullptr, k1 = nullptr;
   status = next_kernel_events(t, &k0, &k1);
   if (status != TC_OK) return status;
-  status = launch_contract_quad(tiling.n_u, false, qa, schedule->lds_bytes, stream, k0, k1);
+  status = f32 ? launch_contract_quad_f32(tiling.n_u, qa, schedule->lds_bytes, stream, k0, k1)
+               : launch_contract_quad(tiling.n_u, false, qa, schedule->lds_bytes, stream, k0, k1);
   if (status != TC_OK) return status;
   t->last_workgroups = (schedule->n_waves + tc::kQuadWavesPerBlock - 1) / tc::kQuadWavesPerBlock;
   t->last_waves = tc::kQuadWavesPerBlock;
@@ -416,7 +468,7 @@ static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsig
   t->last_lds = 0;
 
   tc::FinalizeQuadArgs fa{};
-  fa.partial = (const double*)lane.partial.ptr;
+  fa.partial = lane.partial.ptr;
   fa.group_begin = (const int32_t*)schedule->group_begin;
   fa.ngal_part = (const double*)lane.ngal2.ptr;
   fa.n_ngal_parts = lane.ngal_parts;
@@ -434,7 +486,7 @@ static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsig
   fa.xi = xi_device;
   if (t->prev >= 0 && t->prev != t->cur)
     TC_HIP(hipStreamWaitEvent(stream, t->lanes[t->prev].finished, 0));
-  status = launch_finalize_quad(fa, t->tuning, stream);
+  status = launch_finalize_quad(fa, t->tuning, stream, f32);
   if (status != TC_OK) return status;
   if (t->force_lane >= 0) {
     t->prev = -1;
@@ -678,6 +730,11 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
           n_tiles * splits, (int64_t)n_cus * std::max(1, t->tuning.occ_per_cu));
     }
   }
+  const bool want_f32 = t->quad && t->compute_dtype == TC_DTYPE_F32 && nbuf == &lane.nbuf;
+  if (want_f32) {
+    status = lane.nbuf32.reserve((size_t)t->n_bins * ldb * sizeof(float), stream);
+    if (status != TC_OK) return status;
+  }
   status = nbuf->reserve((size_t)t->n_bins * ldb * sizeof(double), stream);
   if (status == TC_OK)
     status = ngal2->reserve((size_t)splits * 2 * ldb * sizeof(double), stream);
@@ -703,6 +760,7 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   oa.perm = (const int32_t*)t->d_perm;
   oa.math_table = (const double*)t->d_math_table;
   oa.nbuf = (double*)nbuf->ptr;
+  oa.nbuf32 = want_f32 ? (float*)lane.nbuf32.ptr : nullptr;
   oa.ngal = (double*)ngal2->ptr;
   oa.occupation = occupation_device;
   {
@@ -883,10 +941,17 @@ int launch_interp_coef(const InterpArgs& args, hipStream_t stream) {
 
 int launch_occ_from_array(tc_table* t, const double* occupation_device, int64_t n_draws,
                           int64_t ldb, double* nbuf, double* ngal2, hipStream_t stream) {
+  // (the float32 quadratic-form kernel reads a float copy of the densities of lane 0)
+  float* nbuf32 = nullptr;
+  if (t->quad && t->compute_dtype == TC_DTYPE_F32 && nbuf == (double*)t->lanes[0].nbuf.ptr) {
+    int status = t->lanes[0].nbuf32.reserve((size_t)t->n_bins * ldb * sizeof(float), stream);
+    if (status != TC_OK) return status;
+    nbuf32 = (float*)t->lanes[0].nbuf32.ptr;
+  }
   hipLaunchKernelGGL(tc::occ_from_array_kernel, dim3((unsigned)((ldb + 255) / 256)),
                      dim3(256), 0, stream, occupation_device, n_draws, ldb, t->n_bins,
                      t->plan.n_central, (const double*)t->d_n_h, (const int32_t*)t->d_perm,
-                     nbuf, ngal2);
+                     nbuf, ngal2, nbuf32);
   TC_HIP(hipGetLastError());
   return TC_OK;
 }

@@ -174,12 +174,16 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
   const double quad_blocks = (n_bins / 4.0 + 1.0) * (n_bins / 4.0 + 2.0) / 2.0;
   const double quad_bytes =
       quad_blocks * ((quad_tiling.n_u + 1) / 2) * 1024.0 * quad_tiling.n_rtiles;
-  if (status == TC_OK && mode == TC_MODE_AUTO && compute_dtype == TC_DTYPE_F64 &&
-      quad_bytes <= 32.0 * 1024 * 1024) {
+  // float32: r tiles of 16 values, 1 KB per unit; an r tile's slice must stay in an L2
+  // (r-tile-major order): up to 3 MB per r tile, i.e. about 300 bins
+  const tc::QuadTiling quad_tiling_f32 = tc::quad_tiling_f32(n_r);
+  const bool quad_f32 = compute_dtype == TC_DTYPE_F32 && quad_blocks * 1024.0 <= 3.0 * 1024 * 1024;
+  if (status == TC_OK && mode == TC_MODE_AUTO &&
+      ((compute_dtype == TC_DTYPE_F64 && quad_bytes <= 32.0 * 1024 * 1024) || quad_f32)) {
     // quadratic-form kernel: the matrix by galaxy type and, when the centrals do not fill
     // whole 4 x 4 blocks, the unpadded triangle for the total prediction
     t->quad = true;
-    t->quad_tiling = quad_tiling;
+    t->quad_tiling = quad_f32 ? quad_tiling_f32 : quad_tiling;
     status = build_quad_table(t.get(), true, tpcf_matrix, matrix_dtype, &t->quad_by_type);
     const int n_central = t->plan.n_central;
     if (status == TC_OK && n_central % 4 != 0 && n_central < n_bins)
@@ -214,6 +218,7 @@ int tc_table_destroy(tc_table* t) {
     lane.ngal2.release();
     lane.partial.release();
     lane.xi.release();
+    lane.nbuf32.release();
     if (lane.finished) (void)hipEventDestroy(lane.finished);
   }
   t->h_in.release();
@@ -588,6 +593,14 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     t->tuning.single_draw = value != 0;
   } else if (key == "trace") {
     t->tuning.trace = value;
+  } else if (key == "occ_splits" || key == "occ_per_cu" || key == "finalize_threads" ||
+             key == "finalize_row_blocks") {
+    // developer A/B: launch geometry of the occupation / finalisation kernels (0: chosen)
+    TC_CHECK(value >= 0 && value <= 4096, "invalid value");
+    (key == "occ_splits" ? t->tuning.occ_splits
+     : key == "occ_per_cu" ? t->tuning.occ_per_cu
+     : key == "finalize_threads" ? t->tuning.finalize_threads
+                                 : t->tuning.finalize_row_blocks) = value;
   } else if (key == "prio_occ" || key == "prio_contract" || key == "prio_finalize") {
     // developer A/B: wave priorities (0..3) of the three kernels
     TC_CHECK(value >= 0 && value <= 3, "priorities are 0..3");

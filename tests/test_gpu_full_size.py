@@ -205,6 +205,13 @@ def test_float32_variant_small(case):
         scale = np.max(np.abs(expect[1][key]))
         np.testing.assert_allclose(xi_sep[key][:10], expect[1][key],
                                    rtol=RTOL_F32, atol=RTOL_F32 * scale)
+    # the ndarray seam (tabcorr.py:616-621) and ragged batch sizes through the float32 path
+    occupation = halotab.mean_occupation_batch(theta[:70])
+    ngal_occ, xi_occ = halotab.predict(occupation)
+    assert_rel(xi_occ, xi[:70], 1e-6)
+    for n_draws in (1, 63, 65):
+        ngal_n, xi_n = halotab.predict_batch(theta[:n_draws])
+        assert_rel(xi_n, xi[:n_draws], 1e-6)
 
 
 def test_config5_float32_mfma():

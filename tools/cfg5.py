@@ -12,10 +12,14 @@ def dmalloc(a):
     _lib.check(lib.tc_memcpy_h2d(p, a.ctypes.data_as(ctypes.c_void_p), a.nbytes)); return p
 d_theta = dmalloc(theta); d_ngal = dmalloc(np.zeros(10000)); d_xi = dmalloc(np.zeros((10000, 760)))
 flop = 10000 * (2.0 * 760 * 20100 + 3 * 20100)
-for dtype in sys.argv[1:] or ['float64', 'float32']:
+options = [a for a in sys.argv[1:] if '=' in a]
+for dtype in [a for a in sys.argv[1:] if '=' not in a] or ['float64', 'float32']:
     t0 = time.perf_counter()
     tab = TabCorr.from_arrays(table['gal_type'], table['tpcf_matrix'], table['tpcf_shape'], table['attrs'], compute_dtype=dtype)
     h = tab.to_device().handle
+    for option in options:
+        name, value = option.split('=')
+        _lib.check(lib.tc_table_set_option(h, name.encode(), int(value)))
     print('%s: table upload %.1f s' % (dtype, time.perf_counter() - t0))
     def step():
         _lib.check(lib.tc_predict_zheng07_batch_device(h, d_theta, 5, 10000, 10, 0, d_ngal, d_xi))
