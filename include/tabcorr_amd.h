@@ -237,7 +237,7 @@ int tc_interp_predict_zheng07_batch_device(tc_interp* interp, const double* thet
  *   "pipeline"    1 (default): consecutive device-pointer calls rotate over the handle's
  *                 lanes (stream + workspaces) so that kernels of neighbouring batches
  *                 overlap; 0: every call on lane 0, kernels strictly serialised.
- *   "lanes"       number of lanes, 1..8 (default 4).
+ *   "lanes"       number of lanes, 1..4 (default 4; more lose 20 %: four hardware queues).
  *   "single_draw" 1 (default): an un-batched predict() goes through one launch.
  *   "trace"       developer timelines (tc_debug_trace): 0 (default) off. */
 int tc_table_set_option(tc_table* table, const char* name, int value);

@@ -290,7 +290,7 @@ struct tc_table {
     tc::host::DeviceBuffer xi;       // chi2 device calls: the correlation functions
     int ngal_parts = 1;              // partial sums the occupation step left in ngal2
   };
-  static constexpr int kMaxLanes = 8;
+  static constexpr int kMaxLanes = 4;
   Lane lanes[kMaxLanes];
   int n_lanes = 2;
   int prev = -1;                     // lane of the previous finalisation

@@ -634,3 +634,46 @@ def test_random_shapes_against_oracle():
                 assert_rel(xi_sep[key], expect_x[key], RTOL)
             for key in expect_n:
                 assert_rel(ngal_sep[key], expect_n[key], RTOL)
+
+
+def test_leauthaud11_through_the_interpolator_and_chi2():
+    """The occupation family flag travels through every entry point: Interpolator (batched
+    and un-batched) and the fused likelihood, against the oracle."""
+    from tabcorr_amd import Interpolator, Leauthaud11Model
+    from oracle import tabcorr_oracle as oracle
+    from util import interpolator_tables_from_golden
+    data = load_golden('interp_2d_auto')
+    tables = interpolator_tables_from_golden(data)
+    keys = [str(k) for k in data['keys']]
+    interp = make_interpolator(tables, keys, data['points'])
+    theta = load_golden('leauthaud11_synthetic')['theta'][:6]
+    x = data['x'][:6]
+    ngal, xi = interp.predict_batch(theta, x, family='leauthaud11', modulate_with_cenocc=True)
+    setup = oracle.interpolator_setup(tables, data['points'])
+    for i in range(6):
+        expect = oracle.interpolator_predict(tables, setup, oracle.Leauthaud11(theta[i]), x[i])
+        assert_rel(ngal[i], expect[0], RTOL)
+        assert_rel(xi[i], expect[1], RTOL, floor=1e-12)
+    # un-batched: the model object through Interpolator.predict (one launch for all tables)
+    model = Leauthaud11Model(threshold=theta[2, 11], redshift=0.0)
+    for key, value in zip(('smhm_m0_0', 'smhm_m1_0', 'smhm_beta_0', 'smhm_delta_0',
+                           'smhm_gamma_0', 'scatter_model_param1', 'alphasat', 'bsat', 'betasat',
+                           'bcut', 'betacut'), theta[2, :11]):
+        model.param_dict[key] = value
+    for key, value in zip(keys, x[2]):
+        model.param_dict[key] = value
+    n1, x1 = interp.predict(model, check_consistency=False)
+    assert_rel(n1, ngal[2], 1e-12)
+    assert_rel(x1, xi[2], 1e-10, floor=1e-12)
+    # fused likelihood on a single table
+    table = tables[0]
+    halotab = make_tabcorr(table)
+    n_r = halotab.to_device().n_r
+    observed = np.full(n_r, 30.0)
+    precision = np.eye(n_r) * 0.01
+    ngal_t, xi_t = halotab.predict_batch(theta, family='leauthaud11', modulate_with_cenocc=True)
+    ngal_c, chi2 = halotab.chi2_batch(theta, observed, precision, family='leauthaud11',
+                                      modulate_with_cenocc=True)
+    delta = xi_t.reshape(len(theta), -1) - observed
+    assert_rel(ngal_c, ngal_t, 1e-13)
+    assert_rel(chi2, np.einsum('bi,ij,bj->b', delta, precision, delta), 1e-9)
