@@ -762,29 +762,39 @@ void build_chunking(const Plan& plan, int n_chunks, int waves_per_group,
 // ---- pair counting: cell grid ----------------------------------------------------------------
 
 namespace {
-int cells_along(double box, double reach, int64_t n_points) {
-  // no more cells than the points warrant (about 8 points per cell at least), at most 256
-  int n = (int)std::floor(box / reach);
-  const int cap =
-      (int)std::max<double>(1.0, std::cbrt((double)std::max<int64_t>(n_points, 1) / 8.0));
-  n = std::min(n, std::max(cap, 3));
-  n = std::min(n, 256);
-  return n < 3 ? 1 : n;
+// Cells along one dimension and how many neighbour cells to each side hold the partners of a
+// point.  Preferred: cells at least reach / 2 wide, two neighbours per side (5 x 5 x 5 cells
+// of an eighth of the volume: 15.6 instead of 27 cell volumes of candidates per point); with
+// fewer than five such cells: cells at least `reach` wide, one neighbour per side; with
+// fewer than three of those: ONE cell (the minimum image does the wrapping).  No more cells
+// than the points warrant (about 8 points per cell at least), at most 256.
+int cells_along(double box, double reach, int64_t n_points, bool allow_fine, int* neighbours) {
+  const int cap = std::max(
+      3, (int)std::max<double>(1.0, std::cbrt((double)std::max<int64_t>(n_points, 1) / 8.0)));
+  const int fine = std::min(std::min((int)std::floor(2.0 * box / reach), cap), 256);
+  if (allow_fine && fine >= 5) {
+    *neighbours = 2;
+    return fine;
+  }
+  const int coarse = std::min(std::min((int)std::floor(box / reach), cap), 256);
+  if (coarse >= 3) {
+    *neighbours = 1;
+    return coarse;
+  }
+  *neighbours = 0;
+  return 1;
 }
 }  // namespace
 
 CellGrid make_cell_grid(const double* boxsize, double reach_xy, double reach_z,
-                        int64_t n_points) {
+                        int64_t n_points, bool allow_fine) {
   CellGrid grid;
   grid.lx = boxsize[0];
   grid.ly = boxsize[1];
   grid.lz = boxsize[2];
-  grid.nx = cells_along(grid.lx, reach_xy, n_points);
-  grid.ny = cells_along(grid.ly, reach_xy, n_points);
-  grid.nz = cells_along(grid.lz, reach_z, n_points);
-  grid.reach_x = grid.nx > 1 ? 1 : 0;
-  grid.reach_y = grid.ny > 1 ? 1 : 0;
-  grid.reach_z = grid.nz > 1 ? 1 : 0;
+  grid.nx = cells_along(grid.lx, reach_xy, n_points, allow_fine, &grid.reach_x);
+  grid.ny = cells_along(grid.ly, reach_xy, n_points, allow_fine, &grid.reach_y);
+  grid.nz = cells_along(grid.lz, reach_z, n_points, allow_fine, &grid.reach_z);
   return grid;
 }
 

@@ -247,17 +247,18 @@ void quad_emulate(const QuadLayout& layout, const QuadSchedule& schedule,
 
 // ---- pair counting (paircount.hip): cell grid of a periodic box ----------------------------
 //
-// Cells at least `reach` wide, so that the partners of a point lie in the 27 cells around
-// its own; a dimension that cannot hold three such cells gets ONE cell and no neighbour
-// offsets (the minimum image does the wrapping there).
+// Per dimension: cells at least reach / 2 wide with two neighbour cells per side, or (fewer
+// than five of those) at least `reach` wide with one, or ONE cell and no neighbour offsets
+// (the minimum image does the wrapping there) -- the partners of a point always lie in the
+// neighbour cells around its own.
 struct CellGrid {
   int nx = 1, ny = 1, nz = 1;
-  int reach_x = 0, reach_y = 0, reach_z = 0;   // neighbour offsets per dimension: 1 or 0
+  int reach_x = 0, reach_y = 0, reach_z = 0;   // neighbour cells per side: 2, 1 or 0
   double lx = 0, ly = 0, lz = 0;               // box size
   int n_cells() const { return nx * ny * nz; }
 };
 CellGrid make_cell_grid(const double* boxsize, double reach_xy, double reach_z,
-                        int64_t n_points);
+                        int64_t n_points, bool allow_fine = true);
 
 // Points of one set sorted by cell (counting sort): coordinates, labels (if given) and the
 // cell offsets.  Returns -1, or the index of the first point outside [0, box].

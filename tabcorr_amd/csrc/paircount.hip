@@ -237,7 +237,23 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
         TC_CHECK(label2[p] >= 0 && label2[p] < n_labels, "label of point %lld out of range",
                  (long long)p);
   }
-  const CellGrid grid = make_cell_grid(boxsize, rp_max, pi_max, std::max(n1, n2));
+  // Labelled counts with enough points per (cell, label) keep private counters per workgroup
+  // (below); they need full workgroups, i.e. the coarse grid.  Everything else takes the fine
+  // grid (an eighth of the cell volume, 5 x 5 x 5 neighbours: 42 % fewer candidate pairs).
+  int label_slots = 0;
+  CellGrid grid = make_cell_grid(boxsize, rp_max, pi_max, std::max(n1, n2), !labelled);
+  if (labelled) {
+    label_slots =
+        (int)std::min<size_t>(8, (56 * 1024) / ((size_t)n_rp * n_labels * sizeof(unsigned)));
+    // with few points per (cell, label) such workgroups would hold a handful of points each,
+    // every one of them streaming all neighbour tiles (10^5 points in 100 bins: 48 ms against
+    // 13 ms with global atomics; 10^6 points: 645 ms against 790 ms)
+    const double per_cell_label = (double)n1 / ((double)grid.n_cells() * n_labels);
+    if (label_slots * per_cell_label < 128.0) {
+      label_slots = 0;
+      grid = make_cell_grid(boxsize, rp_max, pi_max, std::max(n1, n2), true);
+    }
+  }
 
   Range range("pair count");
   CellSort set1, set2;
@@ -254,19 +270,9 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
   // as keep its private counters within 56 KB of LDS (none fit: global atomics per pair)
   std::vector<int32_t> item_cell, item_begin, item_end;
   LabelItems label_items;
-  int label_slots = 0;
-  if (labelled) {
-    label_slots = (int)std::min<size_t>(8, (56 * 1024) / ((size_t)n_rp * n_labels * sizeof(unsigned)));
-    // ... and only when such workgroups stay reasonably full: with few points per (cell,
-    // label) they would hold a handful of points each and every one of them streams all
-    // neighbour tiles (10^5 points in 100 bins: 48 ms against 13 ms with global atomics;
-    // 10^6 points: 647 ms against 820 ms)
-    const double per_cell_label = (double)n1 / ((double)grid.n_cells() * n_labels);
-    if (label_slots * per_cell_label < 128.0) label_slots = 0;
-    if (label_slots > 0) {
-      sort_cells_by_label(set1);
-      if (!autocorr) sort_cells_by_label(set2);
-    }
+  if (label_slots > 0) {
+    sort_cells_by_label(set1);
+    if (!autocorr) sort_cells_by_label(set2);
   }
   if (label_slots > 0) {
     build_label_items(set1, kPairThreads, label_slots, label_items);

@@ -220,6 +220,11 @@ static void check_cells() {
       const tc::CellGrid grid = tc::make_cell_grid(box, 20.0, 40.0, n);
       EXPECT(grid.nx >= 1 && grid.ny >= 1 && grid.nz >= 1, "empty grid");
       EXPECT((grid.ny == 1) == (grid.reach_y == 0), "reach does not match the cell count");
+      // neighbour cells to each side are distinct cells and cover the reach
+      EXPECT(grid.nx >= 2 * grid.reach_x + 1 && grid.ny >= 2 * grid.reach_y + 1 &&
+                 grid.nz >= 2 * grid.reach_z + 1, "neighbour cells alias");
+      EXPECT(grid.reach_x == 0 || grid.lx / grid.nx * grid.reach_x >= 20.0, "x cells too narrow");
+      EXPECT(grid.reach_z == 0 || grid.lz / grid.nz * grid.reach_z >= 40.0, "z cells too narrow");
       tc::CellSort sorted;
       EXPECT(tc::sort_into_cells(grid, pos.data(), label.data(), n, sorted) == -1,
              "points reported outside the box");
