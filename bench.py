@@ -207,8 +207,10 @@ def main():
     parser.add_argument('--gather', choices=['full', 'chi2'], default='full',
                         help='multi-GPU: gather (ngal, xi) of every draw, or the fused '
                              'likelihood (ngal, chi2)')
-    parser.add_argument('--gather-every', type=int, default=32,
-                        help='multi-GPU: steps per RCCL gather of the results')
+    parser.add_argument('--gather-every', type=int, default=0,
+                        help='multi-GPU: steps per RCCL gather of the results (default: 32, or '
+                             'a quarter of --steps for short runs so that the gathers overlap '
+                             'the steps instead of trailing them)')
     parser.add_argument('--lanes', type=int, default=0,
                         help='pipelining lanes of the timed region (default: library '
                              'default, 4); 1 serialises the kernels, e.g. under rocprofv3')
@@ -297,13 +299,15 @@ def main():
     precision = np.eye(N_R) * 1e-2
     data_p, precision_p = _lib.as_double_p(data_vector), _lib.as_double_p(precision)
 
-    # Results ring: 2 blocks of `every` steps.  A block is gathered on rank 0 (RCCL, own
-    # stream) once its last step is queued; the other block keeps filling meanwhile.
-    every = max(1, args.gather_every)
-    n_slots = 2 * every
+    # Results ring: 4 blocks of `every` steps.  A block is gathered on rank 0 (RCCL, own
+    # stream) once its last step is queued; the other blocks keep filling meanwhile.
+    every = args.gather_every if args.gather_every > 0 else (
+        32 if args.steps >= 128 else max(2, args.steps // 4))
+    n_blocks = 4                        # (the communicator has four send-buffer slots)
+    n_slots = n_blocks * every
     d_out = dev.malloc(n_slots * n_out)
     use_rccl = comm.comm is not None
-    d_recv = dev.malloc(2 * comm.world_size * every * n_out) if (
+    d_recv = dev.malloc(n_blocks * comm.world_size * every * n_out) if (
         use_rccl and comm.is_root) else ctypes.c_void_p()
     interp_handle = handle if interp_mode else None
 

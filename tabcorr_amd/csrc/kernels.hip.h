@@ -1753,27 +1753,45 @@ __global__ __launch_bounds__(64) void interp_coef_small_kernel(InterpArgs a) {
   }
 }
 
-// Gaussian likelihood fused behind predict(): chi2[b] = (xi_b - d)^T P (xi_b - d) with the
-// data vector d and precision matrix P in the scalar cache; one lane per draw.  This is
-// the step every MCMC likelihood performs on the host right after predict()
-// (README.md:7 of the reference); doing it here leaves one double per draw to copy back.
+// Gaussian likelihood fused behind predict(): chi2[b] = (xi_b - d)^T P (xi_b - d).  This is
+// the step every MCMC likelihood performs on the host right after predict() (README.md:7 of
+// the reference); doing it here leaves one double per draw to copy back / gather.  32 lanes
+// per draw (two draws per wave): lane i forms delta_i (sum_j P_ij delta_j) for the rows
+// i = lane, lane + 32, ..., a fixed-order butterfly adds the 32 lanes.  The deviations of the
+// block's draws and (for up to 64 r values) the precision matrix sit in LDS.  (The first
+// version used one lane per draw: 40 workgroups for 10^4 draws, 30-50 us of a chain that the
+// next batch's kernels wait for.)
+constexpr int kChi2DrawsPerBlock = 8;      // 256 threads
+constexpr int kChi2LdsMatrix = 64;         // largest n_r whose precision matrix is staged
+
 __global__ __launch_bounds__(256) void chi2_kernel(const double* xi, int64_t n_draws,
                                                    int n_r, const double* data,
                                                    const double* precision,
                                                    double* chi2) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n_draws) return;
-  sc_f64 d = (sc_f64)data;
-  sc_f64 p = (sc_f64)precision;
-  const double* row = xi + b * n_r;
-  double total = 0.0;
-  for (int i = 0; i < n_r; ++i) {
-    const double di = row[i] - d[i];
-    double inner = 0.0;
-    for (int j = 0; j < n_r; ++j) inner = fma(p[i * n_r + j], row[j] - d[j], inner);
-    total = fma(di, inner, total);
+  extern __shared__ double chi2_lds[];     // (8, n_r) deviations [+ (n_r, n_r) matrix]
+  double* delta = chi2_lds;
+  double* matrix = chi2_lds + kChi2DrawsPerBlock * n_r;
+  const bool staged = n_r <= kChi2LdsMatrix;
+  const int64_t first = (int64_t)blockIdx.x * kChi2DrawsPerBlock;
+  for (int idx = threadIdx.x; idx < kChi2DrawsPerBlock * n_r; idx += blockDim.x) {
+    const int64_t b = first + idx / n_r;
+    delta[idx] = b < n_draws ? xi[b * n_r + idx % n_r] - data[idx % n_r] : 0.0;
   }
-  chi2[b] = total;
+  if (staged)
+    for (int idx = threadIdx.x; idx < n_r * n_r; idx += blockDim.x) matrix[idx] = precision[idx];
+  __syncthreads();
+  const int local = threadIdx.x >> 5, lane = threadIdx.x & 31;
+  const double* d = delta + local * n_r;
+  const double* p = staged ? matrix : precision;
+  double total = 0.0;
+  for (int i = lane; i < n_r; i += 32) {
+    double inner = 0.0;
+    for (int j = 0; j < n_r; ++j) inner = fma(p[(int64_t)i * n_r + j], d[j], inner);
+    total = fma(d[i], inner, total);
+  }
+#pragma unroll
+  for (int offset = 16; offset >= 1; offset >>= 1) total += __shfl_xor(total, offset, 32);
+  if (lane == 0 && first + local < n_draws) chi2[first + local] = total;
 }
 
 }  // namespace tc

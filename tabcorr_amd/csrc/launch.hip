@@ -958,8 +958,12 @@ int launch_occ_from_array(tc_table* t, const double* occupation_device, int64_t 
 
 int launch_chi2(const double* xi, int64_t n_draws, int n_r, const double* data,
                 const double* precision, double* chi2, hipStream_t stream) {
-  hipLaunchKernelGGL(tc::chi2_kernel, dim3((unsigned)((n_draws + 255) / 256)), dim3(256),
-                     0, stream, xi, n_draws, n_r, data, precision, chi2);
+  const size_t lds = ((size_t)tc::kChi2DrawsPerBlock * n_r +
+                      (n_r <= tc::kChi2LdsMatrix ? (size_t)n_r * n_r : 0)) * sizeof(double);
+  hipLaunchKernelGGL(tc::chi2_kernel,
+                     dim3((unsigned)((n_draws + tc::kChi2DrawsPerBlock - 1) /
+                                     tc::kChi2DrawsPerBlock)),
+                     dim3(256), lds, stream, xi, n_draws, n_r, data, precision, chi2);
   TC_HIP(hipGetLastError());
   return TC_OK;
 }

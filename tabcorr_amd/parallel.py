@@ -155,7 +155,12 @@ class Communicator:
     # -- control plane -----------------------------------------------------
 
     def barrier(self):
-        if self.dist is not None:
+        """All ranks: over RCCL when the communicator exists (one all-reduce of a double on
+        its stream, tens of microseconds), else gloo (a TCP round trip, 0.2-0.3 ms -- a
+        quarter of a 20-step timed region)."""
+        if self.comm is not None:
+            _lib.check(_lib.load().tc_comm_barrier(self.comm))
+        elif self.dist is not None:
             self.dist.barrier()
 
     def max(self, value):
