@@ -296,6 +296,12 @@ int tc_pair_count_rppi_labelled(const double* pos1, const int32_t* label1, int64
                                 const double* pos2, const int32_t* label2, int64_t n2,
                                 int n_labels, const double* boxsize, const double* rp_bins,
                                 int n_rp, double pi_max, uint64_t* counts);
+/* The same one-pass form for `s_mu_tpcf` tables (tabcorr/tabcorr.py:846-922 with
+ * tpcf = tabcorr/corrfunc.py:98-175): counts (n_s, n_mu, n_labels, n_labels). */
+int tc_pair_count_smu_labelled(const double* pos1, const int32_t* label1, int64_t n1,
+                               const double* pos2, const int32_t* label2, int64_t n2,
+                               int n_labels, const double* boxsize, const double* s_bins,
+                               int n_s, int n_mu, uint64_t* counts);
 
 /* ---- multi-GPU: one process per GPU, results collected with one RCCL gather ---------- */
 

@@ -189,3 +189,32 @@ def compute_tpcf_matrix_wp(mode, pos, period, rp_bins, pi_max, sample2=None):
             matrix[:, i] += wp(pos[i], rp_bins, pi_max, sample2=sample2,
                                do_auto=False, do_cross=True, period=period)
     return matrix, (n_r, )
+
+
+def compute_tpcf_matrix_smu(mode, pos, period, s_bins, mu_bins, sample2=None):
+    """``tabcorr/tabcorr.py:846-922`` for ``tpcf = s_mu_tpcf``
+    (``tabcorr/corrfunc.py:98-175``): one call per pair of non-empty bins, the
+    ``(n_s, n_mu)`` results flattened as the reference's ``xi.ravel()`` does
+    (``:900-915``)."""
+    shape = (len(s_bins) - 1, len(mu_bins) - 1)
+    tasks = [i for i in range(len(pos)) if len(pos[i]) > 0]        # :888
+    if mode == 'auto':
+        matrix = np.zeros((shape[0] * shape[1], len(pos), len(pos)))
+        for a, i_1 in enumerate(tasks):
+            for i_2 in tasks[a:]:                                  # :890-891
+                j_1, j_2 = i_1, i_2
+                if len(pos[j_1]) > len(pos[j_2]):                  # :838-839
+                    j_1, j_2 = j_2, j_1
+                xi = s_mu_tpcf(pos[j_1], s_bins, mu_bins,
+                               sample2=pos[j_2] if j_1 != j_2 else None,
+                               do_auto=(j_1 == j_2), do_cross=(j_1 != j_2),
+                               period=period)                      # :840-843
+                matrix[:, i_1, i_2] += xi.ravel()                  # :910-912
+                matrix[:, i_2, i_1] = matrix[:, i_1, i_2]
+    else:
+        matrix = np.zeros((shape[0] * shape[1], len(pos)))
+        for i in tasks:
+            matrix[:, i] += s_mu_tpcf(pos[i], s_bins, mu_bins, sample2=sample2,
+                                      do_auto=False, do_cross=True,
+                                      period=period).ravel()
+    return matrix, shape

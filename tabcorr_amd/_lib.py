@@ -126,6 +126,11 @@ SIGNATURES = {
                                     ctypes.c_int, c_double_p, c_double_p,
                                     ctypes.c_int, ctypes.c_double,
                                     ctypes.POINTER(ctypes.c_uint64)],
+    'tc_pair_count_smu_labelled': [c_double_p, c_int32_p, ctypes.c_int64,
+                                   c_double_p, c_int32_p, ctypes.c_int64,
+                                   ctypes.c_int, c_double_p, c_double_p,
+                                   ctypes.c_int, ctypes.c_int,
+                                   ctypes.POINTER(ctypes.c_uint64)],
     'tc_comm_unique_id': [ctypes.c_void_p],
     'tc_comm_create': [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                        c_void_pp],

@@ -146,6 +146,28 @@ def s_mu_tpcf(sample1, s_bins, mu_bins, sample2=None, period=None,
     return npairs.astype(np.float64) / n_exp[:, np.newaxis] - 1
 
 
+def _labelled_points(pos, sample2):
+    n_bins = len(pos)
+    sizes = np.array([len(p) for p in pos], dtype=np.int64)
+    points = _positions(np.concatenate(
+        [np.asarray(p, dtype=np.float64).reshape(-1, 3) for p in pos]))
+    label = np.ascontiguousarray(
+        np.repeat(np.arange(n_bins, dtype=np.int32), sizes))
+    int32_p = ctypes.POINTER(ctypes.c_int32)
+    if sample2 is None:
+        second = (None, None, 0)
+        keep = ()
+    else:
+        sample2 = _positions(sample2)
+        label2 = np.zeros(len(sample2), dtype=np.int32)
+        second = (_lib.as_double_p(sample2), label2.ctypes.data_as(int32_p),
+                  len(sample2))
+        keep = (sample2, label2)
+    first = (_lib.as_double_p(points), label.ctypes.data_as(int32_p),
+             len(points))
+    return first, second, (points, label) + keep
+
+
 def pair_count_matrix(pos, rp_bins, pi_max, period, sample2=None):
     """Pair counts between all bins in one pass.
 
@@ -157,31 +179,39 @@ def pair_count_matrix(pos, rp_bins, pi_max, period, sample2=None):
     lib = _lib.load()
     _lib.require_device()
     n_bins = len(pos)
-    sizes = np.array([len(p) for p in pos], dtype=np.int64)
-    points = _positions(np.concatenate(
-        [np.asarray(p, dtype=np.float64).reshape(-1, 3) for p in pos]))
-    label = np.ascontiguousarray(
-        np.repeat(np.arange(n_bins, dtype=np.int32), sizes))
     rp_bins = _lib.contiguous(np.asarray(rp_bins, dtype=np.float64))
     box = _period(period)
     n_rp = len(rp_bins) - 1
     counts = np.zeros((n_rp, n_bins, n_bins), dtype=np.uint64)
-    int32_p = ctypes.POINTER(ctypes.c_int32)
-    if sample2 is None:
-        pos2 = label2 = None
-        n2 = 0
-    else:
-        sample2 = _positions(sample2)
-        label2 = np.zeros(len(sample2), dtype=np.int32)
-        pos2, n2 = _lib.as_double_p(sample2), len(sample2)
-        label2 = label2.ctypes.data_as(int32_p)
+    first, second, keep = _labelled_points(pos, sample2)
     _lib.check(lib.tc_pair_count_rppi_labelled(
-        _lib.as_double_p(points), label.ctypes.data_as(int32_p), len(points),
-        pos2, label2, n2, max(n_bins, 1), _lib.as_double_p(box),
+        *first, *second, max(n_bins, 1), _lib.as_double_p(box),
         _lib.as_double_p(rp_bins), n_rp, float(pi_max),
         counts.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+    del keep
     if sample2 is not None:
         return counts[:, :, 0]
+    return counts
+
+
+def pair_count_matrix_smu(pos, s_bins, n_mu, period, sample2=None):
+    """`pair_count_matrix` in bins of ``s`` and ``mu``: ``(n_s, n_mu, G, G)``
+    ordered pair counts (``sample2`` given: ``(n_s, n_mu, G)``)."""
+    lib = _lib.load()
+    _lib.require_device()
+    n_bins = len(pos)
+    s_bins = _lib.contiguous(np.asarray(s_bins, dtype=np.float64))
+    box = _period(period)
+    n_s = len(s_bins) - 1
+    counts = np.zeros((n_s, int(n_mu), n_bins, n_bins), dtype=np.uint64)
+    first, second, keep = _labelled_points(pos, sample2)
+    _lib.check(lib.tc_pair_count_smu_labelled(
+        *first, *second, max(n_bins, 1), _lib.as_double_p(box),
+        _lib.as_double_p(s_bins), n_s, int(n_mu),
+        counts.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+    del keep
+    if sample2 is not None:
+        return counts[:, :, :, 0]
     return counts
 
 
@@ -217,15 +247,57 @@ def compute_tpcf_matrix(mode, pos, period, rp_bins, pi_max, sample2=None):
     return matrix, (len(rp_bins) - 1, )
 
 
+def compute_tpcf_matrix_smu(mode, pos, period, s_bins, mu_bins, sample2=None):
+    """`compute_tpcf_matrix` for ``tpcf = s_mu_tpcf``: ``(n_s n_mu, G, G)``
+    (mode ``'auto'``) or ``(n_s n_mu, G)`` (mode ``'cross'``) and the shape
+    ``(n_s, n_mu)``, flattened as the reference's ``xi.ravel()``
+    (``tabcorr/tabcorr.py:900-915``)."""
+    mu_bins = np.asarray(mu_bins, dtype=np.float64)
+    if not np.all(np.isclose(mu_bins, np.linspace(0, 1, len(mu_bins)))):
+        raise ValueError('Bins in mu must be uniform from 0 to 1.')
+    s_bins = np.asarray(s_bins, dtype=np.float64)
+    box = _period(period)
+    n_mu = len(mu_bins) - 1
+    n_s = len(s_bins) - 1
+    sizes = np.array([len(p) for p in pos], dtype=np.float64)
+    # (the products in the reference's order, tabcorr/corrfunc.py:151-153, 161-163)
+    shell = np.diff(s_bins**3)
+    volume = np.prod(box)
+    if mode == 'auto':
+        counts = pair_count_matrix_smu(pos, s_bins, n_mu, box).astype(
+            np.float64)
+        n_exp = ((sizes[:, None] * sizes[None, :] / volume * 4 * np.pi /
+                  3)[None] * shell[:, None, None] / n_mu)[:, None]
+    elif mode == 'cross':
+        if sample2 is None:
+            raise ValueError("mode 'cross' needs a second sample.")
+        counts = pair_count_matrix_smu(pos, s_bins, n_mu, box,
+                                       sample2=sample2).astype(np.float64)
+        n_exp = ((sizes * len(sample2) / volume * 4 * np.pi / 3)[None] *
+                 shell[:, None] / n_mu)[:, None]
+    else:
+        raise ValueError("mode must be 'auto' or 'cross'.")
+    with np.errstate(divide='ignore', invalid='ignore'):
+        matrix = counts / n_exp - 1
+    matrix[np.broadcast_to(n_exp == 0, matrix.shape)] = 0.0   # empty bins
+    return matrix.reshape((n_s * n_mu, ) + matrix.shape[2:]), (n_s, n_mu)
+
+
 def reference_compute_tpcf_matrix(mode, pos, tpcf, period, tpcf_args,
                                   tpcf_kwargs, num_threads=1, verbose=False):
     """`compute_tpcf_matrix` with the reference's own signature
-    (``tabcorr/tabcorr.py:846-848``) for ``tpcf = wp``: what
+    (``tabcorr/tabcorr.py:846-848``) for ``tpcf = wp`` or ``s_mu_tpcf``: what
     ``TabCorr.tabulate`` swaps in for the reference's pool of per-pair calls.
-    ``tpcf_args`` are ``(rp_bins, pi_max)``; mode ``'cross'`` takes ``sample2``
-    from ``tpcf_kwargs`` as the reference's call at ``:841-844`` would."""
+    ``tpcf_args`` are ``(rp_bins, pi_max)`` / ``(s_bins, mu_bins)``; mode
+    ``'cross'`` takes ``sample2`` from ``tpcf_kwargs`` as the reference's call
+    at ``:841-844`` would."""
+    if tpcf is s_mu_tpcf:
+        return compute_tpcf_matrix_smu(mode, pos, period, tpcf_args[0],
+                                       tpcf_args[1],
+                                       sample2=tpcf_kwargs.get('sample2'))
     if tpcf is not wp:
-        raise ValueError('Only tabcorr_amd.corrfunc.wp is counted on the GPU.')
+        raise ValueError('Only tabcorr_amd.corrfunc.wp and s_mu_tpcf are '
+                         'counted on the GPU.')
     rp_bins, pi_max = tpcf_args[0], tpcf_args[1]
     return compute_tpcf_matrix(mode, pos, period, rp_bins, pi_max,
                                sample2=tpcf_kwargs.get('sample2'))

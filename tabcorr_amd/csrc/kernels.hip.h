@@ -1761,19 +1761,21 @@ __global__ __launch_bounds__(64) void interp_coef_small_kernel(InterpArgs a) {
 // block's draws and (for up to 64 r values) the precision matrix sit in LDS.  (The first
 // version used one lane per draw: 40 workgroups for 10^4 draws, 30-50 us of a chain that the
 // next batch's kernels wait for.)
-constexpr int kChi2DrawsPerBlock = 8;      // 256 threads
+constexpr int kChi2DrawsPerBlock = 8;      // 256 threads; fewer when n_r is large (LDS)
 constexpr int kChi2LdsMatrix = 64;         // largest n_r whose precision matrix is staged
+constexpr int kChi2LdsBytes = 48 * 1024;
 
 __global__ __launch_bounds__(256) void chi2_kernel(const double* xi, int64_t n_draws,
                                                    int n_r, const double* data,
                                                    const double* precision,
                                                    double* chi2) {
-  extern __shared__ double chi2_lds[];     // (8, n_r) deviations [+ (n_r, n_r) matrix]
+  extern __shared__ double chi2_lds[];     // (draws per block, n_r) deviations [+ matrix]
+  const int per_block = blockDim.x >> 5;
   double* delta = chi2_lds;
-  double* matrix = chi2_lds + kChi2DrawsPerBlock * n_r;
+  double* matrix = chi2_lds + per_block * n_r;
   const bool staged = n_r <= kChi2LdsMatrix;
-  const int64_t first = (int64_t)blockIdx.x * kChi2DrawsPerBlock;
-  for (int idx = threadIdx.x; idx < kChi2DrawsPerBlock * n_r; idx += blockDim.x) {
+  const int64_t first = (int64_t)blockIdx.x * per_block;
+  for (int idx = threadIdx.x; idx < per_block * n_r; idx += blockDim.x) {
     const int64_t b = first + idx / n_r;
     delta[idx] = b < n_draws ? xi[b * n_r + idx % n_r] - data[idx % n_r] : 0.0;
   }
@@ -1783,11 +1785,12 @@ __global__ __launch_bounds__(256) void chi2_kernel(const double* xi, int64_t n_d
   const int local = threadIdx.x >> 5, lane = threadIdx.x & 31;
   const double* d = delta + local * n_r;
   const double* p = staged ? matrix : precision;
+  // lanes over the columns (consecutive addresses), rows in order: sum_j d_j sum_i d_i P_ij
   double total = 0.0;
-  for (int i = lane; i < n_r; i += 32) {
+  for (int j = lane; j < n_r; j += 32) {
     double inner = 0.0;
-    for (int j = 0; j < n_r; ++j) inner = fma(p[(int64_t)i * n_r + j], d[j], inner);
-    total = fma(d[i], inner, total);
+    for (int i = 0; i < n_r; ++i) inner = fma(d[i], p[(int64_t)i * n_r + j], inner);
+    total = fma(d[j], inner, total);
   }
 #pragma unroll
   for (int offset = 16; offset >= 1; offset >>= 1) total += __shfl_xor(total, offset, 32);

@@ -958,12 +958,16 @@ int launch_occ_from_array(tc_table* t, const double* occupation_device, int64_t 
 
 int launch_chi2(const double* xi, int64_t n_draws, int n_r, const double* data,
                 const double* precision, double* chi2, hipStream_t stream) {
-  const size_t lds = ((size_t)tc::kChi2DrawsPerBlock * n_r +
-                      (n_r <= tc::kChi2LdsMatrix ? (size_t)n_r * n_r : 0)) * sizeof(double);
-  hipLaunchKernelGGL(tc::chi2_kernel,
-                     dim3((unsigned)((n_draws + tc::kChi2DrawsPerBlock - 1) /
-                                     tc::kChi2DrawsPerBlock)),
-                     dim3(256), lds, stream, xi, n_draws, n_r, data, precision, chi2);
+  // draws per workgroup: 8 unless their deviations would not fit the LDS budget
+  const size_t row = (size_t)n_r * sizeof(double);
+  TC_CHECK(n_r >= 1 && row <= (size_t)tc::kChi2LdsBytes, "chi2: too many r bins");
+  const int per_block =
+      (int)std::min<size_t>(tc::kChi2DrawsPerBlock, (size_t)tc::kChi2LdsBytes / row);
+  const size_t lds =
+      per_block * row + (n_r <= tc::kChi2LdsMatrix ? (size_t)n_r * row : (size_t)0);
+  hipLaunchKernelGGL(tc::chi2_kernel, dim3((unsigned)((n_draws + per_block - 1) / per_block)),
+                     dim3(32 * per_block), lds, stream, xi, n_draws, n_r, data, precision,
+                     chi2);
   TC_HIP(hipGetLastError());
   return TC_OK;
 }

@@ -74,11 +74,11 @@ struct PairArgs {
   int n_labels;
   // labelled counts with private counters: the workgroup's points carry at most label_slots
   // distinct labels (slot1: the slot of every set-1 point, item_labels: (items, label_slots))
-  // and LDS holds (n_rp, label_slots, n_labels) counters; 0: 64-bit global atomics per pair
+  // and LDS holds (n_rp [* n_mu], label_slots, n_labels) counters; 0: 64-bit global atomics
   int label_slots;
   const int32_t* slot1;
   const int32_t* item_labels;
-  unsigned long long* counts;   // (n_rp, n_pi) or (n_rp, n_labels, n_labels)
+  unsigned long long* counts;   // (n_rp, n_pi) or (n_rp [, n_mu], n_labels, n_labels)
 };
 
 __device__ inline double min_image(double d, double box, double half) {
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kPairThreads) void pair_count_kernel(PairArgs a) {
   __shared__ int32_t sl[kPairThreads];
   extern __shared__ unsigned hist[];   // n_rp * n_pi, or n_rp * label_slots * n_labels counters
   const int tid = threadIdx.x;
-  const int n_hist = LABELLED ? a.n_rp * a.label_slots * a.n_labels : a.n_rp * a.n_pi;
+  const int n_hist = (LABELLED ? a.label_slots * a.n_labels : 1) * a.n_rp * a.n_pi;
   for (int k = tid; k < n_hist; k += kPairThreads) hist[k] = 0u;
 
   const int cell = a.item_cell[blockIdx.x];
@@ -142,15 +142,22 @@ __global__ __launch_bounds__(kPairThreads) void pair_count_kernel(PairArgs a) {
             if (!(r_sqr >= lo_sqr && r_sqr < hi_sqr)) continue;
             int bin = 0;
             for (int k = 1; k < a.n_rp; ++k) bin += r_sqr >= a.edge_sqr[k] ? 1 : 0;
-            if (LABELLED) {
-              if (a.label_slots > 0)
-                atomicAdd(&hist[(bin * a.label_slots + slot) * a.n_labels + sl[t]], 1u);
-              else
-                atomicAdd(a.counts + ((size_t)bin * a.n_labels + li) * a.n_labels + sl[t], 1ull);
-            } else if (SMU) {
+            int mu_bin = 0;
+            if (SMU) {
               const double mu = r_sqr > 0.0 ? __ddiv_rn(dz, __dsqrt_rn(r_sqr)) : 0.0;
-              const int mu_bin = (int)(mu * a.inv_dpi);
-              if (mu < 1.0 && mu_bin < a.n_pi) atomicAdd(&hist[bin * a.n_pi + mu_bin], 1u);
+              mu_bin = (int)(mu * a.inv_dpi);
+              if (!(mu < 1.0 && mu_bin < a.n_pi)) continue;
+            }
+            if (LABELLED) {
+              // (labelled r_p counts are summed over pi: n_pi == 1 there)
+              const int cell_bin = SMU ? bin * a.n_pi + mu_bin : bin;
+              if (a.label_slots > 0)
+                atomicAdd(&hist[(cell_bin * a.label_slots + slot) * a.n_labels + sl[t]], 1u);
+              else
+                atomicAdd(a.counts + ((size_t)cell_bin * a.n_labels + li) * a.n_labels + sl[t],
+                          1ull);
+            } else if (SMU) {
+              atomicAdd(&hist[bin * a.n_pi + mu_bin], 1u);
             } else {
               const int pi_bin = (int)(dz * a.inv_dpi);
               if (pi_bin < a.n_pi) atomicAdd(&hist[bin * a.n_pi + pi_bin], 1u);
@@ -223,8 +230,8 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
   // the minimum image is only the nearest image below half a box
   TC_CHECK(rp_max < 0.5 * std::min(boxsize[0], boxsize[1]) && pi_max < 0.5 * boxsize[2],
            "the largest separation must be smaller than half the box size");
-  const size_t n_counts =
-      labelled ? (size_t)n_rp * n_labels * n_labels : (size_t)n_rp * n_pi;
+  // (labelled r_p counts arrive with n_pi == 1: summed over the line of sight)
+  const size_t n_counts = (size_t)n_rp * n_pi * (labelled ? (size_t)n_labels * n_labels : 1);
   std::fill(counts, counts + n_counts, (uint64_t)0);
   if (n1 == 0 || n2 == 0) return TC_OK;
   if (labelled) {
@@ -244,7 +251,7 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
   CellGrid grid = make_cell_grid(boxsize, rp_max, pi_max, std::max(n1, n2), !labelled);
   if (labelled) {
     label_slots =
-        (int)std::min<size_t>(8, (56 * 1024) / ((size_t)n_rp * n_labels * sizeof(unsigned)));
+        (int)std::min<size_t>(8, (56 * 1024) / ((size_t)n_rp * n_pi * n_labels * sizeof(unsigned)));
     // with few points per (cell, label) such workgroups would hold a handful of points each,
     // every one of them streaming all neighbour tiles (10^5 points in 100 bins: 48 ms against
     // 13 ms with global atomics; 10^6 points: 645 ms against 790 ms)
@@ -342,8 +349,11 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
 
   const dim3 grid_dim((unsigned)item_cell.size()), block(kPairThreads);
   if (labelled) {
-    const size_t lds = (size_t)n_rp * label_slots * n_labels * sizeof(unsigned);
-    hipLaunchKernelGGL((pair_count_kernel<true, false>), grid_dim, block, lds, nullptr, a);
+    const size_t lds = (size_t)n_rp * n_pi * label_slots * n_labels * sizeof(unsigned);
+    if (smu)
+      hipLaunchKernelGGL((pair_count_kernel<true, true>), grid_dim, block, lds, nullptr, a);
+    else
+      hipLaunchKernelGGL((pair_count_kernel<true, false>), grid_dim, block, lds, nullptr, a);
   } else {
     const size_t lds = (size_t)n_rp * n_pi * sizeof(unsigned);
     TC_CHECK(lds <= 48 * 1024, "at most %d two-dimensional bins are supported", 48 * 1024 / 4);
@@ -385,6 +395,19 @@ int tc_pair_count_rppi_labelled(const double* pos1, const int32_t* label1, int64
   TC_CHECK(n_labels >= 1 && n_labels <= 4096, "between 1 and 4096 labels are supported");
   return tc::host::pair_count(pos1, label1, n1, pos2, label2, n2, n_labels, boxsize, rp_bins,
                               n_rp, pi_max, 1, counts);
+}
+
+int tc_pair_count_smu_labelled(const double* pos1, const int32_t* label1, int64_t n1,
+                               const double* pos2, const int32_t* label2, int64_t n2,
+                               int n_labels, const double* boxsize, const double* s_bins,
+                               int n_s, int n_mu, uint64_t* counts) {
+  using tc::host::fail;
+  TC_CHECK(n_labels >= 1 && n_labels <= 4096, "between 1 and 4096 labels are supported");
+  TC_CHECK(n_s >= 1 && n_mu >= 1 &&
+               (double)n_s * n_mu * n_labels * n_labels * sizeof(uint64_t) <= 8e9,
+           "the (n_s, n_mu, n_labels, n_labels) counters exceed 8 GB");
+  return tc::host::pair_count(pos1, label1, n1, pos2, label2, n2, n_labels, boxsize, s_bins, n_s,
+                              1.0, n_mu, counts, true);
 }
 
 }  // extern "C"

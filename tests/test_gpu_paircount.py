@@ -204,3 +204,64 @@ def test_labelled_counts_with_private_counters():
     expect = oracle.pair_count_rppi(pos, other, box, rp_bins, 40.0, label1=label,
                                     label2=np.zeros(len(other), dtype=int), n_labels=4)
     assert np.array_equal(cross, expect[:, :, 0])
+
+
+def test_s_mu_tabulation_matrix():
+    """compute_tpcf_matrix for tpcf = s_mu_tpcf (tabcorr/tabcorr.py:846-922 with
+    tabcorr/corrfunc.py:98-175): all bin pairs in one labelled pass against the reference's
+    loop of per-pair calls run with the brute-force counter.  Counts are integers (exact);
+    the float arithmetic behind them is the same sequence of operations -> identical."""
+    from tabcorr_amd import corrfunc
+    from oracle import paircount_oracle as oracle
+    rng = np.random.default_rng(91)
+    box = 140.0
+    s_bins = np.logspace(-0.5, np.log10(30.0), 9)
+    mu_bins = np.linspace(0, 1, 7)
+    halos = clustered(rng, 6000, np.full(3, box), 50, 2.0)
+    cuts = [0, 30, 30, 300, 1300, 3000, 6000]               # one empty bin
+    pos = [halos[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    # global 64-bit atomics (few points per cell and label) ...
+    counts = corrfunc.pair_count_matrix_smu(pos, s_bins, 6, box)
+    assert counts.shape == (8, 6, 6, 6) and counts.dtype == np.uint64
+    for a in (0, 2, 3, 5):
+        for b in (2, 4, 5):
+            expect = oracle.pair_count_smu(pos[a], pos[b] if a != b else None,
+                                           np.full(3, box), s_bins, 6)
+            assert np.array_equal(counts[:, :, a, b], expect), (a, b)
+    assert np.array_equal(counts, counts.transpose(0, 1, 3, 2))
+    assert np.array_equal(counts.sum(axis=(2, 3)),
+                          corrfunc.pair_count_smu(halos, s_bins, 6, None, box))
+    matrix, shape = corrfunc.compute_tpcf_matrix_smu('auto', pos, box, s_bins, mu_bins)
+    expect, expect_shape = oracle.compute_tpcf_matrix_smu('auto', pos, box, s_bins, mu_bins)
+    assert shape == expect_shape == (8, 6) and matrix.shape == (48, 6, 6)
+    assert np.array_equal(matrix, expect)
+    assert np.all(matrix[:, 1] == 0)
+    particles = rng.uniform(0, box, (3000, 3))
+    cross, _ = corrfunc.compute_tpcf_matrix_smu('cross', pos, box, s_bins, mu_bins,
+                                                sample2=particles)
+    expect, _ = oracle.compute_tpcf_matrix_smu('cross', pos, box, s_bins, mu_bins,
+                                               sample2=particles)
+    assert cross.shape == (48, 6) and np.array_equal(cross, expect)
+    swapped, swapped_shape = corrfunc.reference_compute_tpcf_matrix(
+        'auto', pos, corrfunc.s_mu_tpcf, np.full(3, box), (s_bins, mu_bins), {})
+    assert swapped_shape == (8, 6) and np.array_equal(swapped, matrix)
+    assert np.array_equal(
+        corrfunc.s_mu_tpcf(pos[3], s_bins, mu_bins, period=box).ravel(), matrix[:, 3, 3])
+    assert np.array_equal(
+        corrfunc.s_mu_tpcf(pos[2], s_bins, mu_bins, sample2=pos[4], period=box,
+                           do_auto=False, do_cross=True).ravel(), matrix[:, 2, 4])
+    with pytest.raises(ValueError):
+        corrfunc.compute_tpcf_matrix_smu('auto', pos, box, s_bins, np.array([0, 0.3, 1.0]))
+    # ... and per-workgroup private counters (many points per cell and label)
+    dense = clustered(rng, 12000, np.full(3, 100.0), 30, 2.5)
+    label = rng.choice([0, 2], size=len(dense), p=[0.6, 0.4])
+    order = np.argsort(label, kind='stable')
+    bins = np.split(dense[order], np.cumsum(np.bincount(label, minlength=3))[:-1])
+    few_s = np.array([0.5, 2.0, 8.0, 20.0])
+    counts = corrfunc.pair_count_matrix_smu(bins, few_s, 4, 100.0)
+    for a in (0, 2):
+        for b in (0, 2):
+            expect = oracle.pair_count_smu(bins[a], bins[b] if a != b else None,
+                                           np.full(3, 100.0), few_s, 4)
+            assert np.array_equal(counts[:, :, a, b], expect), (a, b)
+    assert counts[:, :, 1].sum() == 0 and counts.sum() > 1e6

@@ -531,6 +531,30 @@ def test_chi2_fused_likelihood():
         halotab.chi2_batch(data['theta'], observed[:5], precision)
 
 
+@pytest.mark.parametrize('shape', [(64, ), (70, ), (13, 40), (1500, )])
+def test_chi2_wide_tables(shape):
+    """Fused likelihood beyond the staged-matrix size (n_r > 64), with a non-symmetric
+    weight matrix, ragged batch sizes and the reduced draws-per-workgroup geometry."""
+    from tabcorr_amd import synthetic
+    table = synthetic.synthetic_table(6, 1, shape, 'auto', seed=77)
+    halotab = make_tabcorr(table)
+    n_r = int(np.prod(shape))
+    rng = np.random.default_rng(n_r)
+    for n_draws in (1, 7, 8, 9, 203):
+        theta = synthetic.zheng07_draws(n_draws, seed=n_draws)
+        ngal_p, xi = halotab.predict_batch(theta)
+        xi = xi.reshape(n_draws, n_r)
+        observed = xi[0] * (1 + 0.05 * rng.normal(size=n_r))
+        weight = rng.normal(size=(n_r, n_r)) / np.outer(np.abs(observed), np.abs(observed))
+        ngal, chi2 = halotab.chi2_batch(theta, observed, weight)
+        delta = xi - observed
+        expect = np.einsum('bi,ij,bj->b', delta, weight, delta)
+        scale = np.einsum('bi,ij,bj->b', np.abs(delta), np.abs(weight), np.abs(delta))
+        assert np.array_equal(ngal, ngal_p)
+        # a quadratic form with mixed signs cancels: error relative to the sum of magnitudes
+        assert np.all(np.abs(chi2 - expect) <= 1e-12 * scale)
+
+
 def test_sharded_predict_over_rccl_single_rank():
     """Product API for sharded prediction with the RCCL data plane (one rank here)."""
     import subprocess
