@@ -486,7 +486,7 @@ static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsig
   fa.xi = xi_device;
   if (t->prev >= 0 && t->prev != t->cur)
     TC_HIP(hipStreamWaitEvent(stream, t->lanes[t->prev].finished, 0));
-  status = launch_finalize_quad(fa, t->tuning, stream, f32);
+  if (!t->tuning.skip_finalize) status = launch_finalize_quad(fa, t->tuning, stream, f32);
   if (status != TC_OK) return status;
   if (t->force_lane >= 0) {
     t->prev = -1;
