@@ -157,6 +157,7 @@ struct DeviceQuadSchedule {
   int n_runs = 0;
   void* runs = nullptr;
   void* wave_runs = nullptr;
+  void* wave_head = nullptr;     // (n_waves, 16): QuadArgs::wave_head
   void* group_begin = nullptr;
   void* merge_range = nullptr;   // (workgroups, 2)
   void* merges = nullptr;        // QuadMerge per merge

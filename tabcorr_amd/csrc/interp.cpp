@@ -140,6 +140,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
     qa.runs = (const tc::QuadRun*)schedule->runs;
     qa.comps = (const tc::QuadCompArgs*)q->d_comps;
     qa.wave_runs = (const int32_t*)schedule->wave_runs;
+    qa.wave_head = (const int32_t*)schedule->wave_head;
     qa.n_waves = schedule->n_waves;
     qa.partial = it->partial.ptr;
     qa.priority = t0->tuning.prio_contract;

@@ -145,6 +145,10 @@ struct QuadArgs {
   const QuadRun* runs;
   const QuadCompArgs* comps;
   const int32_t* wave_runs;        // (n_waves, 2): first run and end run of every wave
+  // (n_waves, 16): the same two numbers, the wave's first QuadRun (8) and the first five
+  // words of that run's QuadCompArgs: ONE scalar load at the start of a wave instead of
+  // three dependent ones (float64 kernel)
+  const int32_t* wave_head;
   int n_waves;
   int priority;                    // wave priority (0..3)
   void* partial;                   // (n_slabs, 4 U, 32) doubles / (n_slabs, 4 U, 64) floats

@@ -785,8 +785,12 @@ __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_kern
   // written, end (100 MHz) and the shader clock cycles between the second and the third
   unsigned long long t_entry = 0, t_first = 0, t_main = 0, t_flushed = 0, c_first = 0, c_main = 0;
   if (a.stamps) t_entry = __builtin_amdgcn_s_memrealtime();
-  const int run_begin = wave < a.n_waves ? wave_runs[2 * wave] : 0;
-  const int run_end = wave < a.n_waves ? wave_runs[2 * wave + 1] : 0;
+  // (one 64-byte record per wave: its range of runs, its first run and that run's component;
+  // three dependent scalar loads at the start of every wave otherwise)
+  sc_i32 head = (sc_i32)a.wave_head + 16 * (wave < a.n_waves ? wave : 0);
+  const bool have_head = a.wave_head != nullptr;
+  const int run_begin = wave >= a.n_waves ? 0 : have_head ? head[0] : wave_runs[2 * wave];
+  const int run_end = wave >= a.n_waves ? 0 : have_head ? head[1] : wave_runs[2 * wave + 1];
   const int c = lane & 15, kq = lane >> 4;
   const unsigned row_bytes = (unsigned)(a.ldb * 8);
   const unsigned off_a = lane * 16;                    // table: (unit, u pair, lane) x 16 B
@@ -797,13 +801,16 @@ __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_kern
   for (int u = 0; u < U; ++u) F[u][0] = F[u][1] = 0.0;
 
   for (int ri = run_begin; ri < run_end; ++ri) {
-    const int tile = runs[ri * 8 + 0], rtile = runs[ri * 8 + 1], comp = runs[ri * 8 + 2];
-    const int table = runs[ri * 8 + 3], rb0 = runs[ri * 8 + 4], cb0 = runs[ri * 8 + 5];
-    const int count = runs[ri * 8 + 6], slab = runs[ri * 8 + 7];
-    const bool triangular = comps[comp * 8 + 0] != 0;
-    const int i_bin0 = comps[comp * 8 + 1], j_bin0 = comps[comp * 8 + 2];
-    const int n_cb = comps[comp * 8 + 3];
-    const unsigned unit_base = (unsigned)comps[comp * 8 + 4];
+    const bool first_run = have_head && ri == run_begin;
+    sc_i32 run = first_run ? head + 2 : runs + ri * 8;
+    const int tile = run[0], rtile = run[1], comp = run[2];
+    const int table = run[3], rb0 = run[4], cb0 = run[5];
+    const int count = run[6], slab = run[7];
+    sc_i32 cmp = first_run ? head + 10 : comps + comp * 8;
+    const bool triangular = cmp[0] != 0;
+    const int i_bin0 = cmp[1], j_bin0 = cmp[2];
+    const int n_cb = cmp[3];
+    const unsigned unit_base = (unsigned)cmp[4];
 
     const double* densities =
         interp ? ((sc_ptrs)a.nbufs)[((sc_i32)a.table_class)[table]] : a.nbuf;

@@ -185,7 +185,8 @@ void QuadTable::release() {
     if (p) (void)hipFree(p);
   d_table = d_comps = nullptr;
   for (auto& kv : schedules)
-    for (void* p : {kv.second->runs, kv.second->wave_runs, kv.second->group_begin,
+    for (void* p : {kv.second->runs, kv.second->wave_runs, kv.second->wave_head,
+                    kv.second->group_begin,
                     kv.second->merge_range, kv.second->merges})
       if (p) (void)hipFree(p);
   schedules.clear();
@@ -299,12 +300,31 @@ int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, 
       }
     }
   }
+  // per wave: its range, its first run and that run's component in one 64-byte record
+  std::vector<int32_t> wave_head((size_t)schedule.n_waves * 16, 0);
+  for (int wave = 0; wave < schedule.n_waves; ++wave) {
+    int32_t* head = wave_head.data() + (size_t)wave * 16;
+    head[0] = wave_range[2 * (size_t)wave];
+    head[1] = wave_range[2 * (size_t)wave + 1];
+    if (head[0] >= head[1]) continue;
+    static_assert(sizeof(tc::QuadRun) == 32 && sizeof(tc::QuadCompArgs) == 32, "record sizes");
+    const tc::QuadRun& run = schedule.runs[(size_t)head[0]];
+    memcpy(head + 2, &run, sizeof(run));
+    const tc::QuadComp& comp = q->layout.comps[(size_t)run.comp];
+    head[10] = comp.triangular;
+    head[11] = comp.i_bin0;
+    head[12] = comp.j_bin0;
+    head[13] = comp.n_cb;
+    head[14] = (int32_t)(uint32_t)comp.unit_base;
+  }
   if (status == TC_OK) status = upload(wave_range, &d->wave_runs);
+  if (status == TC_OK) status = upload(wave_head, &d->wave_head);
   if (status == TC_OK) status = upload(merge_range, &d->merge_range);
   if (status == TC_OK) status = upload(merge.merges, &d->merges);
   if (status == TC_OK) status = upload(schedule.group_begin, &d->group_begin);
   if (status != TC_OK) {
-    for (void* p : {d->runs, d->wave_runs, d->group_begin, d->merge_range, d->merges})
+    for (void* p : {d->runs, d->wave_runs, d->wave_head, d->group_begin, d->merge_range,
+                    d->merges})
       if (p) (void)hipFree(p);
     return status;
   }
@@ -442,6 +462,7 @@ static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsig
   qa.runs = (const tc::QuadRun*)schedule->runs;
   qa.comps = (const tc::QuadCompArgs*)q->d_comps;
   qa.wave_runs = (const int32_t*)schedule->wave_runs;
+  qa.wave_head = (const int32_t*)schedule->wave_head;
   qa.n_waves = schedule->n_waves;
   qa.partial = lane.partial.ptr;
   qa.priority = t->tuning.prio_contract;
