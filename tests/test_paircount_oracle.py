@@ -118,3 +118,33 @@ def test_s_mu_counts():
     assert xi.shape == (6, 4) and np.all(np.abs(xi[3:]) < 0.2)
     with pytest.raises(ValueError, match='uniform'):
         oracle.s_mu_tpcf(pos1, s_bins, np.array([0.0, 0.3, 1.0]), period=box)
+
+
+def test_s_mu_matrix_matches_pairwise_calls():
+    """compute_tpcf_matrix_smu (tabcorr/tabcorr.py:846-922 with tpcf = s_mu_tpcf): symmetric,
+    zero rows for empty bins, entries equal to the single-pair calls, flattened as
+    xi.ravel()."""
+    rng = np.random.default_rng(12)
+    box = 50.0
+    s_bins = np.array([0.5, 2.0, 6.0, 15.0])
+    mu_bins = np.linspace(0, 1, 4)
+    points = rng.uniform(0, box, (900, 3))
+    pos = [points[:200], points[200:200], points[200:500], points[500:]]
+    matrix, shape = oracle.compute_tpcf_matrix_smu('auto', pos, box, s_bins, mu_bins)
+    assert shape == (3, 3) and matrix.shape == (9, 4, 4)
+    assert np.array_equal(matrix, matrix.transpose(0, 2, 1))
+    assert np.all(matrix[:, 1] == 0) and np.all(matrix[:, :, 1] == 0)
+    assert np.array_equal(matrix[:, 2, 2],
+                          oracle.s_mu_tpcf(pos[2], s_bins, mu_bins, period=box).ravel())
+    assert np.array_equal(
+        matrix[:, 0, 3],
+        oracle.s_mu_tpcf(pos[0], s_bins, mu_bins, sample2=pos[3], period=box,
+                         do_auto=False, do_cross=True).ravel())
+    other = rng.uniform(0, box, (300, 3))
+    cross, shape = oracle.compute_tpcf_matrix_smu('cross', pos, box, s_bins, mu_bins,
+                                                  sample2=other)
+    assert shape == (3, 3) and cross.shape == (9, 4) and np.all(cross[:, 1] == 0)
+    assert np.array_equal(
+        cross[:, 3],
+        oracle.s_mu_tpcf(pos[3], s_bins, mu_bins, sample2=other, period=box,
+                         do_auto=False, do_cross=True).ravel())
