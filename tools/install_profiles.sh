@@ -5,6 +5,7 @@ cd "$(dirname "$0")/.." || exit 1
 R=${1:-r02}
 P=gpurun_out/profile
 cp $P/bench.json profiles/${R}_bench.json
+cp $P/bench_driver_command.json profiles/${R}_bench_driver_command.json
 cp $P/kernel_stats_lanes1.csv profiles/${R}_bench_kernel_stats_lanes1.csv
 cp $P/kernel_stats_pipelined.csv profiles/${R}_bench_kernel_stats_pipelined.csv
 cp $P/bench_under_rocprof_lanes1.log profiles/${R}_bench_under_rocprof_lanes1.log

@@ -8,6 +8,10 @@ export TMPDIR=/tmp
 OUT=gpurun_out/profile
 rm -rf $OUT; mkdir -p $OUT
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+# the driver's own command (short timed region), three times
+for i in 1 2 3; do
+  python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 >> $OUT/bench_driver_command.json
+done
 FAST="--cpu-seconds 0 --other-configs 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lanes1 -- \
   python3 bench.py --lanes 1 --steps 2000 --warmup 200 $FAST > $OUT/bench_under_rocprof_lanes1.log 2>&1
