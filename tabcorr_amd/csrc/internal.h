@@ -120,9 +120,11 @@ inline size_t stage_limit() {
 }
 
 // Calls moving at most this many bytes skip the copy commands: the kernels address the
-// page-locked staging buffers directly (1 MB).
+// page-locked staging buffers directly.  512 KB (2000-2500 draws of a 19-bin table: 67 us per
+// call against 83 with copies); beyond it the finalisation kernel's transposed stores over
+// PCIe lose to the copy engines (3000 draws: 125 us against 105, tools/r02_host_limits.sh).
 inline size_t zero_copy_limit() {
-  static const size_t limit = (size_t)env_int_early("TC_ZERO_COPY_KB", 1024) << 10;
+  static const size_t limit = (size_t)env_int_early("TC_ZERO_COPY_KB", 512) << 10;
   return limit;
 }
 

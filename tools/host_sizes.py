@@ -6,7 +6,8 @@ from tabcorr_amd import TabCorr, synthetic
 
 table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
 halotab = TabCorr.from_arrays(table['gal_type'], table['tpcf_matrix'], table['tpcf_shape'], table['attrs'])
-for n in (1, 64, 256, 1000, 4000, 10000, 40000):
+sizes = [int(v) for v in sys.argv[1:]] or [1, 64, 256, 1000, 4000, 10000, 40000]
+for n in sizes:
     theta = synthetic.zheng07_draws(n, seed=1)
     for _ in range(8):
         halotab.predict_batch(theta)
