@@ -729,9 +729,14 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
       if ((t->n_bins + per_block - 1) / per_block != trial) continue;
       const int64_t items = n_tiles * trial;
       if (n_tiles >= 64) {
+        // pipelined calls: throughput, the fewest ranges that give every CU an item; calls
+        // that run alone on their lane (host-buffer API, pipeline off) wait for this kernel:
+        // twice as many, shorter items (10^4 draws: 25 -> 20 us, host-to-host 158 -> 149 us;
+        // in the pipeline they cost 0.7 us per step)
+        const bool alone = t->force_lane >= 0 || !t->tuning.pipeline || t->n_lanes == 1;
         splits = trial;
         grid_blocks = (int)std::min<int64_t>(items, slots);
-        if (items >= n_cus) break;
+        if (items >= (alone ? 2 : 1) * (int64_t)n_cus) break;
         continue;
       }
       const int64_t rounds = (items + slots - 1) / slots;
