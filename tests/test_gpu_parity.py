@@ -701,3 +701,58 @@ def test_leauthaud11_through_the_interpolator_and_chi2():
     delta = xi_t.reshape(len(theta), -1) - observed
     assert_rel(ngal_c, ngal_t, 1e-13)
     assert_rel(chi2, np.einsum('bi,ij,bj->b', delta, precision, delta), 1e-9)
+
+
+def test_flag_sweep_matches_the_oracle():
+    """Every combination of the prediction flags (separate_gal_type, modulate_with_cenocc,
+    Heaviside assembly bias, the Leauthaud11 family), several n_gauss_prim (compile-time
+    unrolled 10 and the general loop), mode auto and cross, one- and two-dimensional
+    tpcf_shape, primary x secondary bins, batch sizes around the tile sizes: seeded tables and
+    draws against the NumPy oracle (`tabcorr/tabcorr.py:465-683`)."""
+    from oracle import tabcorr_oracle as oracle
+    from tabcorr_amd import synthetic
+    rng = np.random.default_rng(77)
+    leauthaud = load_golden('leauthaud11_synthetic')['theta']
+    shapes = [(9, 1, (7, ), 'auto'), (6, 2, (19, ), 'auto'), (12, 1, (5, 6), 'auto'),
+              (10, 2, (9, ), 'cross'), (21, 1, (23, ), 'auto')]
+    n_cases = 0
+    for index, (n_prim, n_sec, shape, mode) in enumerate(shapes):
+        table = synthetic.synthetic_table(n_prim, n_sec, shape, mode, seed=300 + index)
+        halotab = make_tabcorr(table)
+        for family in ('zheng07', 'leauthaud11'):
+            for modulate in (False, True):
+                for assembias in ((False, True) if family == 'zheng07' else (False, )):
+                    for separate in (False, True):
+                        n_gauss = int(rng.choice([1, 3, 10, 17]))
+                        n_draws = int(rng.choice([1, 5, 33, 64, 97]))
+                        if family == 'zheng07':
+                            theta = synthetic.zheng07_draws(n_draws, seed=900 + n_cases)
+                            strengths = rng.uniform(-1.2, 1.2, (n_draws, 2))
+                            expect = oracle.predict_zheng07_batch(
+                                table, theta, separate_gal_type=separate, n_gauss_prim=n_gauss,
+                                modulate_with_cenocc=modulate,
+                                assembias=strengths if assembias else None)
+                            batch = np.hstack([theta, strengths]) if assembias else theta
+                        else:
+                            batch = leauthaud[rng.integers(0, len(leauthaud), n_draws)]
+                            expect = oracle.predict_leauthaud11_batch(
+                                table, batch, separate_gal_type=separate, n_gauss_prim=n_gauss,
+                                modulate_with_cenocc=modulate)
+                        ngal, xi = halotab.predict_batch(
+                            batch, separate_gal_type=separate, n_gauss_prim=n_gauss,
+                            modulate_with_cenocc=modulate, assembias=assembias, family=family)
+                        what = '%s %s n_gauss=%d modulate=%s assembias=%s separate=%s B=%d' % (
+                            mode, shape, n_gauss, modulate, assembias, separate, n_draws)
+                        if separate:
+                            assert list(xi.keys()) == list(expect[1].keys()), what
+                            for key in expect[0]:
+                                assert_rel(ngal[key], expect[0][key], RTOL, what)
+                            for key in expect[1]:
+                                assert xi[key].shape == (n_draws, ) + tuple(shape), what
+                                assert_rel(xi[key], expect[1][key], RTOL, what, floor=1e-13)
+                        else:
+                            assert xi.shape == (n_draws, ) + tuple(shape), what
+                            assert_rel(ngal, expect[0], RTOL, what)
+                            assert_rel(xi, expect[1], RTOL, what)
+                        n_cases += 1
+    assert n_cases == 5 * (8 + 4)
