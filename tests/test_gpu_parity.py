@@ -756,3 +756,60 @@ def test_flag_sweep_matches_the_oracle():
                             assert_rel(xi, expect[1], RTOL, what)
                         n_cases += 1
     assert n_cases == 5 * (8 + 4)
+
+
+def test_interpolator_flag_sweep_matches_the_oracle():
+    """The same sweep through `Interpolator.predict_batch` (`tabcorr/interpolator.py:124-216`):
+    grids of one to three dimensions, mode auto and cross, every flag combination, batch sizes
+    of 1 (the one-launch path) to a few tiles, extrapolation beyond the grid."""
+    from oracle import tabcorr_oracle as oracle
+    from tabcorr_amd import synthetic
+    rng = np.random.default_rng(5)
+    leauthaud = load_golden('leauthaud11_synthetic')['theta']
+    grids = [((4, ), 7, 1, (6, ), 'auto'), ((4, 5), 5, 2, (9, ), 'auto'),
+             ((4, 4, 4), 4, 1, (3, 4), 'auto'), ((5, 4), 6, 1, (11, ), 'cross')]
+    n_cases = 0
+    for index, (grid, n_prim, n_sec, shape, mode) in enumerate(grids):
+        tables, keys, points = synthetic.synthetic_interpolator(
+            grid, n_prim, n_sec, shape, mode, seed=40 + index)
+        interp = make_interpolator(tables, keys, points)
+        setup = oracle.interpolator_setup(tables, points)
+        low, high = points.min(axis=0), points.max(axis=0)
+        for family in ('zheng07', 'leauthaud11'):
+            for modulate in (False, True):
+                for assembias in ((False, True) if family == 'zheng07' else (False, )):
+                    separate = bool(n_cases % 2)
+                    extrapolate = n_cases % 3 == 0
+                    n_draws = int(rng.choice([1, 3, 40, 70]))
+                    span = 0.15 if extrapolate else 0.0
+                    x = rng.uniform(low - span * (high - low), high + span * (high - low),
+                                    (n_draws, len(grid)))
+                    strengths = rng.uniform(-1, 1, (n_draws, 2))
+                    if family == 'zheng07':
+                        theta = synthetic.zheng07_draws(n_draws, seed=70 + n_cases)
+                        models = [oracle.Zheng07(theta[i], modulate,
+                                                 strengths[i] if assembias else None)
+                                  for i in range(n_draws)]
+                        batch = np.hstack([theta, strengths]) if assembias else theta
+                    else:
+                        batch = leauthaud[rng.integers(0, len(leauthaud), n_draws)]
+                        models = [oracle.Leauthaud11(batch[i], modulate) for i in range(n_draws)]
+                    ngal, xi = interp.predict_batch(
+                        batch, x, separate_gal_type=separate, extrapolate=extrapolate,
+                        modulate_with_cenocc=modulate, assembias=assembias, family=family)
+                    what = '%s grid %s modulate=%s assembias=%s separate=%s B=%d' % (
+                        family, grid, modulate, assembias, separate, n_draws)
+                    for i in range(n_draws):
+                        expect = oracle.interpolator_predict(
+                            tables, setup, models[i], x[i], separate_gal_type=separate,
+                            extrapolate=extrapolate)
+                        if separate:
+                            for key in expect[0]:
+                                assert_rel(ngal[key][i], expect[0][key], RTOL, what)
+                            for key in expect[1]:
+                                assert_rel(xi[key][i], expect[1][key], RTOL, what, floor=1e-11)
+                        else:
+                            assert_rel(ngal[i], expect[0], RTOL, what)
+                            assert_rel(xi[i], expect[1], RTOL, what, floor=1e-11)
+                    n_cases += 1
+    assert n_cases == 4 * 6
