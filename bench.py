@@ -291,7 +291,7 @@ def main():
     for option in args.option:
         name, value = option.split('=')
         _lib.check(lib.tc_table_set_option(timer_handle, name.encode(), int(value)))
-    chi2_mode = args.gather == 'chi2' and not interp_mode
+    chi2_mode = args.gather == 'chi2'
     n_out = n_draws * (2 if chi2_mode else 1 + N_R)     # ngal | xi (B, R), or ngal | chi2
     d_theta = dev.upload(theta)
     d_x = dev.upload(x) if interp_mode else None
@@ -315,7 +315,11 @@ def main():
         return ctypes.c_void_p(d_out.value + (slot * n_out + offset) * 8)
 
     def predict(slot):
-        if interp_mode:
+        if interp_mode and chi2_mode:
+            _lib.check(lib.tc_interp_chi2_zheng07_batch_device(
+                handle, d_theta, 5, d_x, n_draws, N_GAUSS, 0, data_p, precision_p,
+                out_ptr(slot), out_ptr(slot, n_draws)))
+        elif interp_mode:
             _lib.check(lib.tc_interp_predict_zheng07_batch_device(
                 handle, d_theta, 5, d_x, n_draws, N_GAUSS, 0, out_ptr(slot),
                 out_ptr(slot, n_draws)))
@@ -449,9 +453,15 @@ def main():
         if interp_mode:
             setup = oracle.interpolator_setup(tables, points)
             expect = oracle.interpolator_predict_zheng07_batch(tables, setup, theta[:2], x[:2])
-            xi = host[n_draws:].reshape(n_draws, N_R)
-            parity = float(max(np.max(np.abs(host[:2] / expect[0] - 1)),
-                               np.max(np.abs(xi[:2] / expect[1] - 1))))
+            if chi2_mode:
+                delta = expect[1] - data_vector
+                chi2 = np.einsum('bi,ij,bj->b', delta, precision, delta)
+                parity = float(max(np.max(np.abs(host[:2] / expect[0] - 1)),
+                                   np.max(np.abs(host[n_draws:n_draws + 2] / chi2 - 1))))
+            else:
+                xi = host[n_draws:].reshape(n_draws, N_R)
+                parity = float(max(np.max(np.abs(host[:2] / expect[0] - 1)),
+                                   np.max(np.abs(xi[:2] / expect[1] - 1))))
         else:
             expect = oracle.predict_zheng07_batch(table, theta[:4])
             if chi2_mode:

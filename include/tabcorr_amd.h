@@ -233,6 +233,21 @@ int tc_interp_predict_zheng07_batch_device(tc_interp* interp, const double* thet
                                            unsigned flags, double* ngal_device,
                                            double* xi_device);
 
+/* The fused Gaussian likelihood (tc_chi2_zheng07_batch) behind Interpolator.predict: what an
+ * MCMC over interpolated tables (cosmology / phase-space parameters next to the HOD) needs per
+ * draw.  Host arrays in, ngal (n_draws) and chi2 (n_draws) out; the `_device` form keeps the
+ * draws, x and the results on the device (data / precision are host arrays, uploaded when
+ * they change), enqueues and returns. */
+int tc_interp_chi2_zheng07_batch(tc_interp* interp, const double* theta, int n_theta,
+                                 const double* x, int64_t n_draws, int n_gauss_prim,
+                                 unsigned flags, const double* data, const double* precision,
+                                 double* ngal, double* chi2);
+int tc_interp_chi2_zheng07_batch_device(tc_interp* interp, const double* theta_device,
+                                        int n_theta, const double* x_device, int64_t n_draws,
+                                        int n_gauss_prim, unsigned flags, const double* data,
+                                        const double* precision, double* ngal_device,
+                                        double* chi2_device);
+
 /* Run-time options of a table handle (the library never reads the environment):
  *   "pipeline"    1 (default): consecutive device-pointer calls rotate over the handle's
  *                 lanes (stream + workspaces) so that kernels of neighbouring batches

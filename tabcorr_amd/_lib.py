@@ -104,6 +104,14 @@ SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
         ctypes.c_int64, ctypes.c_int, ctypes.c_uint, ctypes.c_void_p,
         ctypes.c_void_p],
+    'tc_interp_chi2_zheng07_batch': [
+        ctypes.c_void_p, c_double_p, ctypes.c_int, c_double_p,
+        ctypes.c_int64, ctypes.c_int, ctypes.c_uint, c_double_p, c_double_p,
+        c_double_p, c_double_p],
+    'tc_interp_chi2_zheng07_batch_device': [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_int64, ctypes.c_int, ctypes.c_uint, c_double_p, c_double_p,
+        ctypes.c_void_p, ctypes.c_void_p],
     'tc_table_set_option': [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int],
     'tc_table_timer_begin': [ctypes.c_void_p, ctypes.c_int],
     'tc_table_timer_end': [ctypes.c_void_p, c_float_p],

@@ -38,6 +38,8 @@ struct tc_interp {
   std::vector<DeviceBuffer> nbuf, ngal2;    // per class
   std::vector<void*> nbuf_ptrs, ngal_ptrs;  // last uploaded pointer values
   DeviceBuffer theta, x, coef, partial, out_ngal, out_xi;
+  DeviceBuffer chi2_xi, chi2_data;          // fused likelihood: xi workspace, data + precision
+  std::vector<double> chi2_host;            // host copy of what chi2_data holds
   PinnedBuffer h_in, h_out;
   std::map<std::pair<int, int>, std::unique_ptr<DeviceChunking>> chunkings;
 };
@@ -403,7 +405,7 @@ int tc_interp_destroy(tc_interp* it) {
   for (DeviceBuffer& b : it->nbuf) b.release();
   for (DeviceBuffer& b : it->ngal2) b.release();
   for (DeviceBuffer* b : {&it->theta, &it->x, &it->coef, &it->partial, &it->out_ngal,
-                          &it->out_xi})
+                          &it->out_xi, &it->chi2_xi, &it->chi2_data})
     b->release();
   it->h_in.release();
   it->h_out.release();
@@ -614,6 +616,73 @@ int tc_interp_predict_zheng07_batch(tc_interp* it, const double* theta, int n_th
                         it->stream));
   TC_HIP(hipMemcpyAsync(xi, it->out_xi.ptr, xi_count * 8, hipMemcpyDeviceToHost,
                         it->stream));
+  TC_HIP(hipStreamSynchronize(it->stream));
+  return TC_OK;
+}
+
+int tc_interp_chi2_zheng07_batch_device(tc_interp* it, const double* theta_device,
+                                        int n_theta, const double* x_device, int64_t n_draws,
+                                        int n_gauss, unsigned flags, const double* data,
+                                        const double* precision, double* ngal_device,
+                                        double* chi2_device) {
+  TC_CHECK(it != nullptr, "interp handle is NULL");
+  TC_CHECK(!(flags & TC_FLAG_SEPARATE_GAL_TYPE),
+           "chi2 is defined for the total correlation function only");
+  if (n_draws == 0) return TC_OK;
+  TC_CHECK(data && precision && ngal_device && chi2_device, "NULL pointer");
+  TC_HIP(hipSetDevice(it->device));
+  const int n_r = it->tables[0]->n_r;
+  // data vector and precision matrix: uploaded when they differ from the last upload
+  const size_t data_count = (size_t)(n_r + 1) * n_r;
+  int status = it->chi2_data.reserve(data_count * 8, it->stream);
+  if (status != TC_OK) return status;
+  if (it->chi2_host.size() != data_count ||
+      memcmp(it->chi2_host.data(), data, (size_t)n_r * 8) != 0 ||
+      memcmp(it->chi2_host.data() + n_r, precision, (size_t)n_r * n_r * 8) != 0) {
+    TC_HIP(hipStreamSynchronize(it->stream));   // (earlier kernels may still read the old ones)
+    it->chi2_host.assign(data, data + n_r);
+    it->chi2_host.insert(it->chi2_host.end(), precision, precision + (size_t)n_r * n_r);
+    TC_HIP(hipMemcpyAsync(it->chi2_data.ptr, it->chi2_host.data(), data_count * 8,
+                          hipMemcpyHostToDevice, it->stream));
+    TC_HIP(hipStreamSynchronize(it->stream));
+  }
+  status = it->chi2_xi.reserve((size_t)n_draws * n_r * 8, it->stream);
+  if (status != TC_OK) return status;
+  status = tc_interp_predict_zheng07_batch_device(it, theta_device, n_theta, x_device, n_draws,
+                                                  n_gauss, flags, ngal_device,
+                                                  (double*)it->chi2_xi.ptr);
+  if (status != TC_OK) return status;
+  const double* d_data = (const double*)it->chi2_data.ptr;
+  return launch_chi2((const double*)it->chi2_xi.ptr, n_draws, n_r, d_data, d_data + n_r,
+                     chi2_device, it->stream);
+}
+
+int tc_interp_chi2_zheng07_batch(tc_interp* it, const double* theta, int n_theta,
+                                 const double* x, int64_t n_draws, int n_gauss,
+                                 unsigned flags, const double* data, const double* precision,
+                                 double* ngal, double* chi2) {
+  TC_CHECK(it != nullptr, "interp handle is NULL");
+  int status = check_predict_args(it->tables[0], theta, n_theta, n_draws, n_gauss, flags);
+  if (status != TC_OK) return status;
+  if (n_draws == 0) return TC_OK;
+  TC_CHECK(x && data && precision && ngal && chi2, "NULL pointer");
+  TC_HIP(hipSetDevice(it->device));
+  const size_t theta_bytes = (size_t)n_draws * n_theta * 8;
+  const size_t x_bytes = (size_t)n_draws * it->n_dim * 8;
+  status = it->theta.reserve(theta_bytes, it->stream);
+  if (status == TC_OK) status = it->x.reserve(x_bytes, it->stream);
+  if (status == TC_OK) status = it->out_ngal.reserve((size_t)n_draws * 2 * 8, it->stream);
+  if (status != TC_OK) return status;
+  TC_HIP(hipMemcpyAsync(it->theta.ptr, theta, theta_bytes, hipMemcpyHostToDevice, it->stream));
+  TC_HIP(hipMemcpyAsync(it->x.ptr, x, x_bytes, hipMemcpyHostToDevice, it->stream));
+  double* d_ngal = (double*)it->out_ngal.ptr;
+  double* d_chi2 = d_ngal + n_draws;
+  status = tc_interp_chi2_zheng07_batch_device(it, (const double*)it->theta.ptr, n_theta,
+                                               (const double*)it->x.ptr, n_draws, n_gauss,
+                                               flags, data, precision, d_ngal, d_chi2);
+  if (status != TC_OK) return status;
+  TC_HIP(hipMemcpyAsync(ngal, d_ngal, (size_t)n_draws * 8, hipMemcpyDeviceToHost, it->stream));
+  TC_HIP(hipMemcpyAsync(chi2, d_chi2, (size_t)n_draws * 8, hipMemcpyDeviceToHost, it->stream));
   TC_HIP(hipStreamSynchronize(it->stream));
   return TC_OK;
 }

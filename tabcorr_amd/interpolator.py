@@ -263,6 +263,41 @@ class Interpolator:
             _lib.as_double_p(ngal), _lib.as_double_p(xi)))
         return self.tabcorr_list[0]._package(ngal, xi, separate_gal_type)
 
+    def chi2_batch(self, theta, x, data, precision, n_gauss_prim=10,
+                   extrapolate=False, modulate_with_cenocc=False,
+                   assembias=False, family='zheng07'):
+        """Gaussian ``chi^2 = (xi - data)^T precision (xi - data)`` of every
+        draw of `predict_batch`, evaluated on the device right behind the
+        interpolated prediction (extension, as `TabCorr.chi2_batch`: the
+        reference leaves the likelihood to the user, ``README.md:7``).
+
+        Returns
+        -------
+        ngal, chi2 : numpy.ndarray ``(n_draws, )``
+        """
+        theta = _lib.contiguous(np.atleast_2d(theta))
+        x = _lib.contiguous(np.atleast_2d(x))
+        if x.shape != (len(theta), len(self.keys)):
+            raise ValueError('x must have shape (n_draws, {}).'.format(
+                len(self.keys)))
+        self._check_range(x, extrapolate)
+        device = self.to_device()
+        n_r = device.tables[0].n_r
+        data = _lib.contiguous(np.ravel(data))
+        precision = _lib.contiguous(precision)
+        if data.shape != (n_r, ) or precision.shape != (n_r, n_r):
+            raise ValueError('data must have {0} entries and precision shape '
+                             '({0}, {0}).'.format(n_r))
+        ngal = np.empty(len(theta))
+        chi2 = np.empty(len(theta))
+        _lib.check(device.lib.tc_interp_chi2_zheng07_batch(
+            device.handle, _lib.as_double_p(theta), theta.shape[1],
+            _lib.as_double_p(x), len(theta), n_gauss_prim,
+            _flags(False, modulate_with_cenocc, assembias, family),
+            _lib.as_double_p(data), _lib.as_double_p(precision),
+            _lib.as_double_p(ngal), _lib.as_double_p(chi2)))
+        return ngal, chi2
+
     # -- generic models: host callbacks + device contraction per table -----------------
 
     def _spline_matrices(self):

@@ -446,7 +446,7 @@ def test_rccl_communicator_single_rank():
     _lib.check(lib.tc_comm_destroy(comm))
 
 
-@pytest.mark.parametrize('mode', ['default', 'chi2 gather', 'interp5x5'])
+@pytest.mark.parametrize('mode', ['default', 'chi2 gather', 'interp5x5', 'interp5x5 chi2'])
 def test_bench_under_torchrun_single_rank(mode):
     """bench.py as the driver launches it (torch.distributed.run), one rank, with the
     communicator forced on: gloo control plane next to the HIP library, RCCL gather per
@@ -459,7 +459,10 @@ def test_bench_under_torchrun_single_rank(mode):
     extra = {'default': ['--steps', '20', '--warmup', '3'],
              'chi2 gather': ['--steps', '20', '--warmup', '3', '--gather', 'chi2'],
              'interp5x5': ['--workload', 'interp5x5', '--draws', '12500', '--steps', '6',
-                           '--warmup', '2', '--gather-every', '2']}[mode]
+                           '--warmup', '2', '--gather-every', '2'],
+             'interp5x5 chi2': ['--workload', 'interp5x5', '--draws', '12500', '--steps', '6',
+                                '--warmup', '2', '--gather-every', '2', '--gather',
+                                'chi2']}[mode]
     result = subprocess.run(
         [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
          '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port',
@@ -473,10 +476,10 @@ def test_bench_under_torchrun_single_rank(mode):
     assert record['config']['gather'] == 'rccl', record['config']
     assert record['parity_max_rel_vs_oracle'] < 1e-10
     assert 0.1 < record['roofline']['frac'] < 1.0
-    if mode == 'interp5x5':
+    if mode.startswith('interp5x5'):
         assert record['scaling'] == 'strong' and record['config']['n_tables'] == 25
         assert record['roofline']['kernel'] == 'tc::contract_quad_kernel<5, true>'
-    if mode == 'chi2 gather':
+    if mode.endswith('chi2') or mode == 'chi2 gather':
         assert '16 B' in record['config']['gather_payload']
 
 
@@ -813,3 +816,39 @@ def test_interpolator_flag_sweep_matches_the_oracle():
                             assert_rel(xi[i], expect[1], RTOL, what, floor=1e-11)
                     n_cases += 1
     assert n_cases == 4 * 6
+
+
+def test_interpolator_chi2_fused_likelihood():
+    """`Interpolator.chi2_batch`: the fused likelihood behind the interpolated prediction
+    (C ABI: tc_interp_chi2_zheng07_batch), against einsum on `predict_batch`'s results."""
+    from util import interpolator_tables_from_golden
+    data = load_golden('interp_2d_auto')
+    tables = interpolator_tables_from_golden(data)
+    keys = [str(k) for k in data['keys']]
+    interp = make_interpolator(tables, keys, data['points'])
+    theta, x = data['theta'], data['x']
+    n_r = data['xi'].shape[1]
+    rng = np.random.default_rng(9)
+    observed = data['xi'][2] * (1 + 0.05 * rng.normal(size=n_r))
+    a = rng.normal(size=(n_r, n_r))
+    precision = a @ a.T / np.outer(observed, observed)
+    expect_delta = data['xi'] - observed
+    expect = np.einsum('bi,ij,bj->b', expect_delta, precision, expect_delta)
+    for _ in range(2):                   # (the second call finds the data vector cached)
+        ngal, chi2 = interp.chi2_batch(theta, x, observed, precision)
+        assert_rel(ngal, data['ngal'], RTOL)
+        assert_rel(chi2, expect, 1e-8)
+    ngal_1, chi2_1 = interp.chi2_batch(theta[3:4], x[3:4], observed, precision)
+    assert_rel(chi2_1[0], expect[3], 1e-8)
+    shifted = observed * 0.98
+    delta = data['xi'] - shifted
+    ngal, chi2 = interp.chi2_batch(theta, x, shifted, precision, modulate_with_cenocc=False)
+    assert_rel(chi2, np.einsum('bi,ij,bj->b', delta, precision, delta), 1e-8)
+    big = 1 + 3000 // len(theta)
+    ngal, chi2 = interp.chi2_batch(np.tile(theta, (big, 1)), np.tile(x, (big, 1)), shifted,
+                                   precision)
+    assert_rel(chi2[:len(theta)], np.einsum('bi,ij,bj->b', delta, precision, delta), 1e-8)
+    with pytest.raises(ValueError):
+        interp.chi2_batch(theta, x, observed[:3], precision)
+    with pytest.raises(ValueError):
+        interp.chi2_batch(theta, x[:, :1], observed, precision)
