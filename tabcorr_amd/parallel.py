@@ -368,3 +368,77 @@ def predict_batch_sharded(halotab, theta, communicator, x=None, **kwargs):
             xi_out[k] = full[:, lo:lo + n_r].reshape(shape)
         return ngal_out, xi_out
     return full[:, 0], full[:, 1:].reshape(shape)
+
+
+def chi2_batch_sharded(predictor, theta, data, precision, communicator, x=None,
+                       n_gauss_prim=10, modulate_with_cenocc=False,
+                       assembias=False, extrapolate=False, family='zheng07'):
+    """``chi2_batch`` of a ``TabCorr`` (or, with ``x``, an ``Interpolator``) with
+    the draws sharded round-robin over the ranks: every rank evaluates
+    ``(ngal, chi2)`` of its share on its GPU and 16 bytes per draw are gathered
+    on the root (one ``ncclGather`` with an RCCL communicator, gloo otherwise).
+    Every rank passes the same arguments; the root returns ``(ngal, chi2)``,
+    each ``(n_draws, )``, the other ranks ``None``."""
+    from .tabcorr import _flags
+    theta = np.atleast_2d(np.asarray(theta, dtype=np.float64))
+    n_draws = len(theta)
+    rank, world = communicator.rank, communicator.world_size
+    shard = local_shard(theta, rank, world)
+    kwargs = dict(n_gauss_prim=n_gauss_prim, modulate_with_cenocc=modulate_with_cenocc,
+                  assembias=assembias, family=family)
+    if x is not None:
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        x_shard = local_shard(x, rank, world)
+    if communicator.comm is None or not hasattr(predictor, 'to_device'):
+        if x is not None:
+            ngal, chi2 = predictor.chi2_batch(shard, x_shard, data, precision,
+                                              extrapolate=extrapolate, **kwargs)
+        else:
+            ngal, chi2 = predictor.chi2_batch(shard, data, precision, **kwargs)
+        parts = communicator.gather_host(np.stack([ngal, chi2], axis=1))
+        if parts is None:
+            return None
+        full = assemble(parts, n_draws)
+        return full[:, 0], full[:, 1]
+    device = predictor.to_device()
+    lib = device.lib
+    n_r = (device.tables[0] if x is not None else device).n_r
+    data = _lib.contiguous(np.ravel(data))
+    precision = _lib.contiguous(precision)
+    if data.shape != (n_r, ) or precision.shape != (n_r, n_r):
+        raise ValueError('data must have {0} entries and precision shape '
+                         '({0}, {0}).'.format(n_r))
+    if x is not None:
+        predictor._check_range(x, extrapolate)     # same outcome on every rank
+    n_local = len(shard)
+    count = 2 * n_local
+    flags = _flags(False, modulate_with_cenocc, assembias, family)
+    d_theta = _DeviceArray(shard.size)
+    d_theta.upload(shard)
+    d_out = _DeviceArray(count)
+    d_recv = _DeviceArray(count * world if communicator.is_root else 0)
+    if x is not None:
+        d_x = _DeviceArray(x_shard.size)
+        d_x.upload(x_shard)
+        _lib.check(lib.tc_interp_chi2_zheng07_batch_device(
+            device.handle, d_theta.ptr, shard.shape[1], d_x.ptr, n_local,
+            n_gauss_prim, flags, _lib.as_double_p(data),
+            _lib.as_double_p(precision), d_out.ptr, d_out.offset(n_local)))
+        communicator.gather_device(
+            None, d_out.ptr, d_recv.ptr if communicator.is_root else None,
+            count, 0, interp_handle=device.handle)
+    else:
+        _lib.check(lib.tc_chi2_zheng07_batch_device(
+            device.handle, d_theta.ptr, shard.shape[1], n_local, n_gauss_prim,
+            flags, _lib.as_double_p(data), _lib.as_double_p(precision),
+            d_out.ptr, d_out.offset(n_local)))
+        communicator.gather_device(
+            device.handle, d_out.ptr,
+            d_recv.ptr if communicator.is_root else None, count, 0)
+    communicator.synchronize()
+    if not communicator.is_root:
+        return None
+    flat = d_recv.download().reshape(world, 2, n_local)
+    return (assemble([part[0] for part in flat], n_draws),
+            assemble([part[1] for part in flat], n_draws))
+

@@ -604,6 +604,20 @@ try:
     raise SystemExit("NaN x accepted")
 except ValueError:
     pass
+# the fused likelihood sharded: 16 bytes per draw through the gather
+observed = data["xi"][1] * 1.02
+weight = np.eye(19) / observed**2
+ngal, chi2 = parallel.chi2_batch_sharded(halotab, data["theta"], observed, weight, comm)
+delta = data["xi"] - observed
+np.testing.assert_allclose(ngal, data["ngal"], rtol=1e-10)
+np.testing.assert_allclose(chi2, np.einsum("bi,ij,bj->b", delta, weight, delta), rtol=1e-8)
+n_r = idata["xi"].shape[1]
+observed = idata["xi"][1] * 0.97
+weight = np.eye(n_r) / observed**2
+ngal, chi2 = parallel.chi2_batch_sharded(interp, idata["theta"], observed, weight, comm, x=idata["x"])
+delta = idata["xi"] - observed
+np.testing.assert_allclose(ngal, idata["ngal"], rtol=1e-10)
+np.testing.assert_allclose(chi2, np.einsum("bi,ij,bj->b", delta, weight, delta), rtol=1e-8)
 comm.close()
 print("sharded ok")
 ''' % {'repo': REPO}

@@ -288,6 +288,23 @@ if comm.is_root:
         assert np.allclose(out[0][key], idata['ngal_sep_' + key][:9], rtol=1e-11, atol=0)
 else:
     assert out is None
+# the fused likelihood: 16 bytes per draw gathered
+class OracleChi2(OracleTab):
+    def chi2_batch(self, theta, data, precision, **kwargs):
+        kwargs.pop('family')
+        assert kwargs.pop('assembias', False) is False
+        ngal, xi = oracle.predict_zheng07_batch(self.table, theta, **kwargs)
+        delta = xi.reshape(len(theta), -1) - data
+        return ngal, np.einsum('bi,ij,bj->b', delta, precision, delta)
+observed = np.full(40, 3.0)
+weight = np.eye(40) * 0.5
+out = parallel.chi2_batch_sharded(OracleChi2(table), theta, observed, weight, comm)
+if comm.is_root:
+    expect = OracleChi2(table).chi2_batch(theta, observed, weight, family='zheng07')
+    assert out[0].shape == (15, ) and np.array_equal(out[0], expect[0])
+    assert np.array_equal(out[1], expect[1])
+else:
+    assert out is None
 assert comm.max(comm.rank + 1.0) == 2.0
 assert comm.sum(1.0) == 2.0
 comm.barrier()
