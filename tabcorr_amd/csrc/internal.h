@@ -299,6 +299,11 @@ struct tc_table {
   int prev = -1;                     // lane of the previous finalisation
   int cur = 0;                       // lane of the current / last predict call
   int force_lane = -1;               // host-buffer entry points pin lane 0
+  // chi2 calls: where the finalisation may put the fused likelihood (data | precision on
+  // the device, output); run_contraction sets chi2_fused when it did
+  const double* fuse_chi2_data = nullptr;
+  double* fuse_chi2_out = nullptr;
+  bool chi2_fused = false;
   uint64_t device_calls = 0;
   tc::host::DeviceBuffer theta, out_ngal, out_xi, occupation, trace, wave_trace;
   tc::host::DeviceBuffer chi2_data;          // data vector + precision matrix of chi2 calls

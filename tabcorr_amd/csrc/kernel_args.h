@@ -174,6 +174,11 @@ struct FinalizeQuadArgs {
   int64_t n_draws;
   double* ngal;
   double* xi;
+  // Fused Gaussian likelihood (total prediction, all rows of a draw in one LDS pass, one row
+  // block): chi2[b] = (xi_b - data)^T P (xi_b - data) straight from the tile, xi itself is
+  // not written.  chi2_data = data (n_r) followed by P (n_r, n_r); NULL: off.
+  const double* chi2_data;
+  double* chi2;
 };
 
 struct FinalizeArgs {

@@ -1137,7 +1137,13 @@ __global__ __launch_bounds__(1024) void finalize_quad_kernel(FinalizeQuadArgs a)
   __shared__ double tile[kFinalizeRows][kLanes + 1];
   __shared__ double part_sum[16][kLanes];
   __shared__ double norm_inv[kLanes];
+  // fused likelihood: the data vector and the weight matrix, staged once per workgroup
+  __shared__ double chi2_lds[kFinalizeRows * (kFinalizeRows + 1)];
   set_priority(a.priority);
+  if (a.chi2 != nullptr) {
+    const int count = a.n_r * (a.n_r + 1);
+    for (int idx = threadIdx.x; idx < count; idx += blockDim.x) chi2_lds[idx] = a.chi2_data[idx];
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t col = (int64_t)blockIdx.x * kLanes;
@@ -1219,6 +1225,29 @@ __global__ __launch_bounds__(1024) void finalize_quad_kernel(FinalizeQuadArgs a)
         tile[rr][lane] = normalise(sum_slabs(row0 + rr, 0, 1));
     }
     __syncthreads();
+    if (a.chi2 != nullptr) {
+      // (host side: every row of the draws is in `tile` now -- one pass, one row block)
+      // wave w sums the rows i = w, w + n_waves, ... of delta_i (P delta)_i for its lane's
+      // draw; the matrix from LDS (every lane reads the same word: a broadcast)
+      const double* data = chi2_lds;
+      const double* matrix = chi2_lds + rows;
+      double part = 0.0;
+      for (int i = wave; i < rows; i += n_waves) {
+        double inner = 0.0;
+        for (int j = 0; j < rows; ++j)
+          inner = fma(matrix[i * rows + j], tile[j][lane] - data[j], inner);
+        part = fma(tile[i][lane] - data[i], inner, part);
+      }
+      part_sum[wave][lane] = part;
+      __syncthreads();
+      if (wave == 0 && lane < n_valid) {
+        double total = 0.0;
+        for (int w = 0; w < n_waves; ++w) total += part_sum[w][lane];
+        a.chi2[col + lane] = total;
+      }
+      __syncthreads();
+      continue;
+    }
     for (int idx = threadIdx.x; idx < rows * kLanes; idx += blockDim.x) {
       const int d = idx / rows, rr = idx % rows;
       if (d < n_valid) a.xi[(col + d) * (int64_t)n_rows + row0 + rr] = tile[rr][d];

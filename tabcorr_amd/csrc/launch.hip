@@ -403,17 +403,22 @@ int launch_finalize_quad(const tc::FinalizeQuadArgs& args, const Tuning& tuning,
                          hipStream_t stream, bool f32) {
   // geometry as launch_finalize: one block per 64 draws, small batches split the rows
   const int64_t n_tiles = args.ldb / 64;
-  const int threads =
-      tuning.finalize_threads > 0 ? tuning.finalize_threads : n_tiles < 128 ? 1024 : 256;
+  // (fused likelihood: 16 waves share the rows of the quadratic form -- next to a
+  // contraction every vector instruction of a wave waits for a matrix instruction)
+  const int threads = tuning.finalize_threads > 0 ? tuning.finalize_threads
+                      : n_tiles < 128 || args.chi2 != nullptr ? 1024 : 256;
   const int n_rows = args.n_comp * args.n_r;
   // (many rows -- hundreds of r values -- are split over row blocks of at least 16 rows until
   // the grid has ~2048 blocks: one block per draw tile walked 760 rows serially, 2.4 ms)
-  const int row_blocks = std::min(
-      n_rows, tuning.finalize_row_blocks > 0
-                  ? tuning.finalize_row_blocks
-                  : n_tiles < 128 ? (int)std::max<int64_t>(1, 512 / n_tiles)
-                                  : (int)std::max<int64_t>(
-                                        1, std::min<int64_t>(n_rows / 16, 2048 / n_tiles)));
+  const int row_blocks =
+      args.chi2 != nullptr
+          ? 1   // (the fused likelihood needs every row of a draw in one workgroup)
+          : std::min(n_rows, tuning.finalize_row_blocks > 0
+                                 ? tuning.finalize_row_blocks
+                                 : n_tiles < 128
+                                       ? (int)std::max<int64_t>(1, 512 / n_tiles)
+                                       : (int)std::max<int64_t>(
+                                             1, std::min<int64_t>(n_rows / 16, 2048 / n_tiles)));
   if (f32)
     hipLaunchKernelGGL((tc::finalize_quad_kernel<float, tc::kQuadTileF32>),
                        dim3((unsigned)n_tiles, (unsigned)row_blocks), dim3(threads), 0, stream,
@@ -505,6 +510,15 @@ static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsig
   fa.n_draws = n_draws;
   fa.ngal = ngal_device;
   fa.xi = xi_device;
+  t->chi2_fused = false;
+  if (t->fuse_chi2_out != nullptr && !separate && t->n_r <= tc::kFinalizeRows) {
+    // the likelihood straight from the finalisation's LDS tile: no xi round trip, one
+    // launch (and one gap in the lane's chain) less
+    fa.chi2_data = t->fuse_chi2_data;
+    fa.chi2 = t->fuse_chi2_out;
+    fa.xi = nullptr;
+    t->chi2_fused = true;
+  }
   if (t->prev >= 0 && t->prev != t->cur)
     TC_HIP(hipStreamWaitEvent(stream, t->lanes[t->prev].finished, 0));
   if (!t->tuning.skip_finalize) status = launch_finalize_quad(fa, t->tuning, stream, f32);

@@ -436,10 +436,14 @@ int tc_chi2_zheng07_batch_device(tc_table* t, const double* theta_device, int n_
   tc_table::Lane& lane = t->lanes[lane_index];
   status = lane.xi.reserve((size_t)n_draws * t->n_r * 8, lane.stream);
   if (status != TC_OK) return status;
+  const double* d_data = (const double*)t->chi2_data.ptr;
+  t->fuse_chi2_data = d_data;
+  t->fuse_chi2_out = chi2_device;
   status = tc_predict_zheng07_batch_device(t, theta_device, n_theta, n_draws, n_gauss, flags,
                                            ngal_device, (double*)lane.xi.ptr);
+  t->fuse_chi2_out = nullptr;
   if (status != TC_OK) return status;
-  const double* d_data = (const double*)t->chi2_data.ptr;
+  if (t->chi2_fused) return TC_OK;      // (the finalisation kernel wrote chi2 itself)
   status = launch_chi2((const double*)lane.xi.ptr, n_draws, t->n_r, d_data, d_data + t->n_r,
                        chi2_device, lane.stream);
   if (status != TC_OK) return status;
@@ -486,13 +490,19 @@ int tc_chi2_zheng07_batch(tc_table* t, const double* theta, int n_theta,
     d_ngal = (double*)t->out_ngal.ptr;
   }
   double* d_chi2 = d_ngal + n_draws;
+  // (one slab: the finalisation kernel may write the likelihood itself)
+  const bool fuse = n_draws <= max_slab(t);
   t->force_lane = 0;
+  t->fuse_chi2_data = d_data;
+  t->fuse_chi2_out = fuse ? d_chi2 : nullptr;
   status = tc_predict_zheng07_batch_device(t, theta_device, n_theta, n_draws, n_gauss, flags,
                                            d_ngal, (double*)t->out_xi.ptr);
+  t->fuse_chi2_out = nullptr;
   t->force_lane = -1;
   if (status != TC_OK) return status;
-  status = launch_chi2((const double*)t->out_xi.ptr, n_draws, n_r, d_data, d_precision,
-                       d_chi2, t->stream);
+  if (!(fuse && t->chi2_fused))
+    status = launch_chi2((const double*)t->out_xi.ptr, n_draws, n_r, d_data, d_precision,
+                         d_chi2, t->stream);
   if (status != TC_OK) return status;
   if (direct) {
     TC_HIP(hipStreamSynchronize(t->stream));
