@@ -171,6 +171,14 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
     fq.n_draws = n_draws;
     fq.ngal = ngal_device;
     fq.xi = xi_device;
+    t0->chi2_fused = false;
+    if (t0->fuse_chi2_out != nullptr && !separate && t0->n_r <= tc::kFinalizeRows) {
+      // (launch.hip, run_contraction_quad: the likelihood from the finalisation's LDS tile)
+      fq.chi2_data = t0->fuse_chi2_data;
+      fq.chi2 = t0->fuse_chi2_out;
+      fq.xi = nullptr;
+      t0->chi2_fused = true;
+    }
     return launch_finalize_quad(fq, t0->tuning, it->stream);
   }
 
@@ -648,11 +656,18 @@ int tc_interp_chi2_zheng07_batch_device(tc_interp* it, const double* theta_devic
   }
   status = it->chi2_xi.reserve((size_t)n_draws * n_r * 8, it->stream);
   if (status != TC_OK) return status;
+  const double* d_data = (const double*)it->chi2_data.ptr;
+  tc_table* t0 = it->tables[0];
+  t0->chi2_fused = false;
+  t0->fuse_chi2_data = d_data;
+  t0->fuse_chi2_out = n_draws <= max_slab(t0) ? chi2_device : nullptr;   // (one slab)
   status = tc_interp_predict_zheng07_batch_device(it, theta_device, n_theta, x_device, n_draws,
                                                   n_gauss, flags, ngal_device,
                                                   (double*)it->chi2_xi.ptr);
+  const bool fused = t0->fuse_chi2_out != nullptr && t0->chi2_fused;
+  t0->fuse_chi2_out = nullptr;
   if (status != TC_OK) return status;
-  const double* d_data = (const double*)it->chi2_data.ptr;
+  if (fused) return TC_OK;
   return launch_chi2((const double*)it->chi2_xi.ptr, n_draws, n_r, d_data, d_data + n_r,
                      chi2_device, it->stream);
 }
