@@ -307,6 +307,15 @@ def main():
     n_slots = n_blocks * every
     d_out = dev.malloc(n_slots * n_out)
     use_rccl = comm.comm is not None
+    lanes_used = args.lanes if args.lanes > 0 else 4
+    if use_rccl and args.lanes == 0 and not interp_mode and every < 16:
+        # Frequent gathers: the communicator's stream is a fifth stream on the runtime's four
+        # hardware queues and shares one with a lane, whose kernels then wait behind the
+        # gather (and the other way round).  Three lanes leave it a queue of its own: 51.5
+        # against 58 us per step in the short run with a gather every 5 steps (one rank,
+        # tools/r02_forced_comm.sh); with a gather every 32 steps four lanes stay ahead.
+        lanes_used = 3
+        _lib.check(lib.tc_table_set_option(timer_handle, b'lanes', lanes_used))
     d_recv = dev.malloc(n_blocks * comm.world_size * every * n_out) if (
         use_rccl and comm.is_root) else ctypes.c_void_p()
     interp_handle = handle if interp_mode else None
@@ -516,6 +525,7 @@ def main():
                 'gather_payload': 'ngal + chi2 (16 B per draw)' if chi2_mode
                                   else 'ngal + xi (%d B per draw)' % (8 * (1 + N_R)),
                 'gather_every_steps': every,
+                'lanes': lanes_used,
             },
             'roofline': {
                 'kernel': kernel_name,
