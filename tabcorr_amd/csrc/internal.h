@@ -176,6 +176,8 @@ struct QuadTable {
   size_t bytes = 0;
   std::map<std::vector<int64_t>, std::unique_ptr<DeviceQuadSchedule>> schedules;
   void release();
+  // Frees every cached schedule (the caller makes sure no kernel still reads them).
+  void drop_schedules();
 };
 
 // Developer knobs.  The release build never reads the environment: tuning values are the

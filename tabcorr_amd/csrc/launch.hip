@@ -184,10 +184,13 @@ void QuadTable::release() {
   for (void* p : {d_table, d_comps})
     if (p) (void)hipFree(p);
   d_table = d_comps = nullptr;
+  drop_schedules();
+}
+
+void QuadTable::drop_schedules() {
   for (auto& kv : schedules)
     for (void* p : {kv.second->runs, kv.second->wave_runs, kv.second->wave_head,
-                    kv.second->group_begin,
-                    kv.second->merge_range, kv.second->merges})
+                    kv.second->group_begin, kv.second->merge_range, kv.second->merges})
       if (p) (void)hipFree(p);
   schedules.clear();
 }
@@ -243,6 +246,13 @@ int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, 
   if (it != q->schedules.end()) {
     *out = it->second.get();
     return TC_OK;
+  }
+  // One schedule per distinct number of draw tiles (~0.3 MB each): a caller sweeping the
+  // batch size must not grow the cache without bound.
+  constexpr size_t kMaxCachedSchedules = 64;
+  if (q->schedules.size() >= kMaxCachedSchedules) {
+    TC_HIP(hipDeviceSynchronize());      // (kernels in flight may still read them)
+    q->drop_schedules();
   }
   // every SIMD gets `tuning.quad_waves` waves with equal shares of the matrix-core work;
   // small batches use fewer waves (at least 8 units = 16 n_u instructions each)

@@ -623,14 +623,7 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     if (key == "quad_merge") t->tuning.quad_merge = value != 0;
     else if (key == "quad_order") t->tuning.quad_order = value;
     else t->tuning.quad_waves = value;
-    for (tc::host::QuadTable* q : {&t->quad_by_type, &t->quad_total}) {
-      for (auto& kv : q->schedules)
-        for (void* p : {kv.second->runs, kv.second->wave_runs, kv.second->wave_head,
-                    kv.second->group_begin,
-                        kv.second->merge_range, kv.second->merges})
-          if (p) (void)hipFree(p);
-      q->schedules.clear();
-    }
+    for (tc::host::QuadTable* q : {&t->quad_by_type, &t->quad_total}) q->drop_schedules();
   } else {
     return fail(TC_ERR_INVALID, "unknown option '%s'", name);
   }

@@ -435,3 +435,23 @@ def test_sigma_zero_tie_is_nan():
     assert np.all(np.isfinite(xi[1]))
     occupation = halotab.mean_occupation_batch(theta, modulate_with_cenocc=True)
     assert np.isnan(occupation[0, 2])
+
+
+def test_many_batch_sizes_do_not_grow_the_schedule_cache_without_bound():
+    """A caller sweeping the batch size: one cached schedule per distinct number of draw tiles,
+    capped (the cache is flushed behind a device synchronisation); results stay right across
+    the flush and device memory does not keep growing."""
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(6, 1, (5, ), 'auto', seed=4)
+    halotab = make(table)
+    theta = synthetic.zheng07_draws(32 * 150, seed=2)
+    expect = oracle.predict_zheng07_batch(table, theta[:40])
+    for n_tiles in range(2, 150):                       # 148 distinct schedules
+        ngal, xi = halotab.predict_batch(theta[:32 * n_tiles])
+        if n_tiles % 37 == 0:
+            assert_rel(ngal[:40], expect[0], RTOL)
+            assert_rel(xi[:40], expect[1], RTOL)
+    ngal, xi = halotab.predict_batch(theta[:64])
+    assert_rel(ngal[:40], expect[0][:40], RTOL)
+    assert_rel(xi[:40], expect[1][:40], RTOL)
