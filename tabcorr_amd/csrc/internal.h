@@ -350,7 +350,8 @@ int launch_contract_f32(dim3 grid, dim3 block, int lds, hipStream_t stream,
 int run_occupation(tc_table* t, const double* theta_device, int n_theta, int64_t n_draws,
                    int64_t ldb, int n_gauss, unsigned flags, double* occupation_device,
                    DeviceBuffer* nbuf = nullptr, DeviceBuffer* ngal2 = nullptr,
-                   hipStream_t stream = nullptr, int* ngal_parts = nullptr);
+                   hipStream_t stream = nullptr, int* ngal_parts = nullptr,
+                   DeviceBuffer* nbuf32 = nullptr);
 // Contraction + finalisation of draws whose densities are already in the current lane.
 int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
                     double* ngal_device, double* xi_device);
@@ -366,6 +367,8 @@ int launch_contract_quad(int n_u, bool interp, const QuadArgs& args, int lds_byt
                          hipStream_t stream, hipEvent_t start, hipEvent_t stop);
 int launch_finalize_quad(const FinalizeQuadArgs& args, const Tuning& tuning, hipStream_t stream,
                          bool f32 = false);
+int launch_contract_quad_f32_interp(int n_u, const tc::QuadArgs& args, int lds_bytes,
+                                    hipStream_t stream, hipEvent_t start, hipEvent_t stop);
 int launch_contract_quad_f32(int n_u, const QuadArgs& args, int lds_bytes, hipStream_t stream,
                              hipEvent_t start, hipEvent_t stop);
 // Stream an interpolator's work is queued on (interp.cpp).

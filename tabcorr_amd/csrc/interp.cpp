@@ -24,6 +24,7 @@ struct tc_interp {
   void* d_quad_total = nullptr;             // (K) ... unpadded triangle, if the tables have it
   void* d_nbufs = nullptr;                  // (V) device pointers
   void* d_ngal_parts = nullptr;             // (V) device pointers
+  void* d_nbufs32 = nullptr;                // (V) ... float copies of the densities
   std::vector<int> axis_offset, a_offset;
   std::vector<double> a_host;               // spline matrices of all dimensions
   // un-batched calls: per n_gauss the per-class pointer arrays of single_draw_kernel
@@ -36,7 +37,8 @@ struct tc_interp {
   };
   std::map<int, SinglePointers> single_pointers;
   std::vector<DeviceBuffer> nbuf, ngal2;    // per class
-  std::vector<void*> nbuf_ptrs, ngal_ptrs;  // last uploaded pointer values
+  std::vector<DeviceBuffer> nbuf32;         // per class: float copies (float32 quadratic form)
+  std::vector<void*> nbuf_ptrs, ngal_ptrs, nbuf32_ptrs;   // last uploaded pointer values
   DeviceBuffer theta, x, coef, partial, out_ngal, out_xi;
   DeviceBuffer chi2_xi, chi2_data;          // fused likelihood: xi workspace, data + precision
   std::vector<double> chi2_host;            // host copy of what chi2_data holds
@@ -64,20 +66,25 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
 
   // occupations once per class of identical halo tables (interpolator.py:181-184)
   int ngal_parts = 1;
+  const bool quad_f32 = t0->quad && t0->compute_dtype == TC_DTYPE_F32;
   for (int v = 0; v < n_classes; ++v) {
     status = run_occupation(it->tables[it->class_table[v]], theta_device, n_theta,
                             n_draws, ldb, n_gauss, flags, nullptr, &it->nbuf[v],
-                            &it->ngal2[v], it->stream, &ngal_parts);
+                            &it->ngal2[v], it->stream, &ngal_parts,
+                            quad_f32 ? &it->nbuf32[v] : nullptr);
     if (status != TC_OK) return status;
   }
   bool moved = false;
   for (int v = 0; v < n_classes; ++v) {
     moved = moved || it->nbuf_ptrs[v] != it->nbuf[v].ptr ||
-            it->ngal_ptrs[v] != it->ngal2[v].ptr;
+            it->ngal_ptrs[v] != it->ngal2[v].ptr || it->nbuf32_ptrs[v] != it->nbuf32[v].ptr;
     it->nbuf_ptrs[v] = it->nbuf[v].ptr;
     it->ngal_ptrs[v] = it->ngal2[v].ptr;
+    it->nbuf32_ptrs[v] = it->nbuf32[v].ptr;
   }
   if (moved) {
+    TC_HIP(hipMemcpyAsync(it->d_nbufs32, it->nbuf32_ptrs.data(), n_classes * sizeof(void*),
+                          hipMemcpyHostToDevice, it->stream));
     TC_HIP(hipMemcpyAsync(it->d_nbufs, it->nbuf_ptrs.data(), n_classes * sizeof(void*),
                           hipMemcpyHostToDevice, it->stream));
     TC_HIP(hipMemcpyAsync(it->d_ngal_parts, it->ngal_ptrs.data(),
@@ -116,22 +123,25 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   if (status != TC_OK) return status;
   Range range("contraction + finalisation (all tables)");
 
-  if (t0->quad && t0->compute_dtype == TC_DTYPE_F64) {
+  if (t0->quad) {
     // quadratic-form kernel: the unit space (draw tile, r tile, component, TABLE, unit) in
     // equal shares per wave; a table's spline weight scales the outer factor n_i
     const bool by_type = separate || t0->quad_total.d_table == nullptr;
     QuadTable* q = by_type ? &t0->quad_by_type : &t0->quad_total;
     const tc::QuadTiling& tiling = t0->quad_tiling;
     DeviceQuadSchedule* schedule = nullptr;
-    status = get_quad_schedule(t0, q, ldb / tc::kQuadTile, it->n_tables, separate, &schedule);
+    const int tile_draws = quad_f32 ? tc::kQuadTileF32 : tc::kQuadTile;
+    status = get_quad_schedule(t0, q, ldb / tile_draws, it->n_tables, separate, &schedule);
     if (status != TC_OK) return status;
     const int rt = 4 * tiling.n_u;
-    status = it->partial.reserve(
-        (size_t)schedule->n_slabs * rt * tc::kQuadTile * sizeof(double), it->stream);
+    status = it->partial.reserve((size_t)schedule->n_slabs * rt * tile_draws *
+                                     (quad_f32 ? sizeof(float) : sizeof(double)),
+                                 it->stream);
     if (status != TC_OK) return status;
     tc::QuadArgs qa{};
     qa.nbuf = nullptr;
     qa.nbufs = (const double* const*)it->d_nbufs;
+    qa.nbufs32 = (const float* const*)it->d_nbufs32;
     qa.ldb = ldb;
     qa.n_bins = t0->n_bins;
     qa.table = nullptr;
@@ -152,7 +162,10 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
     hipEvent_t k0 = nullptr, k1 = nullptr;     // timed through the first table's timer
     status = next_kernel_events(t0, &k0, &k1);
     if (status != TC_OK) return status;
-    status = launch_contract_quad(tiling.n_u, true, qa, schedule->lds_bytes, it->stream, k0, k1);
+    status = quad_f32 ? launch_contract_quad_f32_interp(tiling.n_u, qa, schedule->lds_bytes,
+                                                        it->stream, k0, k1)
+                      : launch_contract_quad(tiling.n_u, true, qa, schedule->lds_bytes,
+                                             it->stream, k0, k1);
     if (status != TC_OK) return status;
     tc::FinalizeQuadArgs fq{};
     fq.partial = it->partial.ptr;
@@ -179,7 +192,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
       fq.xi = nullptr;
       t0->chi2_fused = true;
     }
-    return launch_finalize_quad(fq, t0->tuning, it->stream);
+    return launch_finalize_quad(fq, t0->tuning, it->stream, quad_f32);
   }
 
   // decomposition: as for one table (choose_chunking), with the tables looped inside
@@ -369,8 +382,10 @@ int tc_interp_create(tc_table* const* tables, int n_tables, int n_dim,
   const size_t n_classes = it->class_table.size();
   it->nbuf.resize(n_classes);
   it->ngal2.resize(n_classes);
+  it->nbuf32.resize(n_classes);
   it->nbuf_ptrs.assign(n_classes, nullptr);
   it->ngal_ptrs.assign(n_classes, nullptr);
+  it->nbuf32_ptrs.assign(n_classes, nullptr);
 
   TC_HIP(hipStreamCreateWithFlags(&it->stream, hipStreamNonBlocking));
   std::vector<void*> table_ptrs;
@@ -390,6 +405,7 @@ int tc_interp_create(tc_table* const* tables, int n_tables, int n_dim,
   if (status == TC_OK) status = upload(it->table_class, &it->d_table_class);
   if (status == TC_OK) status = upload(table_ptrs, &it->d_tables);
   if (status == TC_OK) status = upload(zeros, &it->d_nbufs);
+  if (status == TC_OK) status = upload(zeros, &it->d_nbufs32);
   if (status == TC_OK) status = upload(zeros, &it->d_ngal_parts);
   if (status != TC_OK) return status;
   *out = it.release();
@@ -401,7 +417,8 @@ int tc_interp_destroy(tc_interp* it) {
   (void)hipSetDevice(it->device);
   if (it->stream) (void)hipStreamSynchronize(it->stream);
   for (void* p : {it->d_xp, it->d_a, it->d_table_node, it->d_table_class, it->d_tables,
-                  it->d_nbufs, it->d_ngal_parts, it->d_quad_by_type, it->d_quad_total})
+                  it->d_nbufs, it->d_nbufs32, it->d_ngal_parts, it->d_quad_by_type,
+                  it->d_quad_total})
     if (p) (void)hipFree(p);
   for (auto& kv : it->chunkings)
     for (void* p : {kv.second->chunks, kv.second->groups})
@@ -412,6 +429,7 @@ int tc_interp_destroy(tc_interp* it) {
       if (p) (void)hipFree(p);
   for (DeviceBuffer& b : it->nbuf) b.release();
   for (DeviceBuffer& b : it->ngal2) b.release();
+  for (DeviceBuffer& b : it->nbuf32) b.release();
   for (DeviceBuffer* b : {&it->theta, &it->x, &it->coef, &it->partial, &it->out_ngal,
                           &it->out_xi, &it->chi2_xi, &it->chi2_data})
     b->release();

@@ -135,6 +135,7 @@ struct QuadArgs {
   const float* nbuf32;             // float32 kernel: (n_bins, ldb) densities in float
   const double* nbuf;              // (n_bins, ldb); interpolator: NULL
   const double* const* nbufs;      // interpolator: density buffer of each class
+  const float* const* nbufs32;     // ... float copies (float32 kernel)
   int64_t ldb;
   int n_bins;
   const void* table;               // (n_rtiles, n_units, UP, 64, 2) doubles; interpolator: NULL

@@ -997,8 +997,9 @@ __device__ inline f32x4 buffer_load16f(__amdgpu_buffer_rsrc_t rsrc, unsigned lan
       f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_offset + IMM, wave_offset, 0));
 }
 
-template <int U>
+template <int U, bool INTERP>
 __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_f32_kernel(QuadArgs a) {
+  constexpr bool interp = INTERP;   // (the unit space gains a table dimension, as in float64)
   extern __shared__ __attribute__((aligned(16))) float stage32[];   // merge slots (4 U, 64)
   const int lane = threadIdx.x & 63;
   const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1022,15 +1023,27 @@ __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_f32_
 
   for (int ri = run_begin; ri < run_end; ++ri) {
     const int tile = runs[ri * 8 + 0], rtile = runs[ri * 8 + 1], comp = runs[ri * 8 + 2];
+    const int table = runs[ri * 8 + 3];
     const int rb0 = runs[ri * 8 + 4], cb0 = runs[ri * 8 + 5];
     const int count = runs[ri * 8 + 6], slab = runs[ri * 8 + 7];
     const bool triangular = comps[comp * 8 + 0] != 0;
     const int i_bin0 = comps[comp * 8 + 1], j_bin0 = comps[comp * 8 + 2];
     const int n_cb = comps[comp * 8 + 3];
     const unsigned unit_base = (unsigned)comps[comp * 8 + 4];
-    const char* matrix = (const char*)a.table + (int64_t)rtile * a.rtile_bytes;
+    typedef const float* f32_ptr;
+    typedef const __attribute__((address_space(4))) f32_ptr* sc_f32_ptrs;
+    const float* densities =
+        interp ? ((sc_f32_ptrs)a.nbufs32)[((sc_i32)a.table_class)[table]] : a.nbuf32;
+    const char* matrix = (const char*)(interp ? (const void*)((sc_ptrs)a.tables)[table]
+                                              : a.table) + (int64_t)rtile * a.rtile_bytes;
+    (void)table;
+    f32x4 cf = {1.0f, 1.0f, 1.0f, 1.0f};
+    if (interp) {   // spline weight / pair-weight norm of this table for the lane's four draws
+      const double* w = a.coef + (int64_t)table * a.ldb + (int64_t)tile * kQuadTileF32 + 4 * c;
+      cf = f32x4{(float)w[0], (float)w[1], (float)w[2], (float)w[3]};
+    }
     const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.nbuf32 + (int64_t)tile * kQuadTileF32), 0,
+        (void*)(densities + (int64_t)tile * kQuadTileF32), 0,
         (unsigned)a.n_bins * row_bytes - (unsigned)tile * (kQuadTileF32 * 4), kBufferFlags);
     const __amdgpu_buffer_rsrc_t rs_t =
         __builtin_amdgcn_make_buffer_rsrc((void*)matrix, 0, a.rtile_bytes, kBufferFlags);
@@ -1086,7 +1099,11 @@ __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_f32_
         t0 = t1;
         b0 = b1;
       }
-      // the row's outer factor: F += D n_i
+      // the row's outer factor: F += D n_i (x the table's spline weight)
+      if (interp) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) e[v] *= cf;
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll

@@ -388,6 +388,27 @@ int launch_contract_quad(int n_u, bool interp, const tc::QuadArgs& args, int lds
   return TC_OK;
 }
 
+int launch_contract_quad_f32_interp(int n_u, const tc::QuadArgs& args, int lds_bytes,
+                                    hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+  const dim3 grid((unsigned)((args.n_waves + tc::kQuadWavesPerBlock - 1) /
+                             tc::kQuadWavesPerBlock));
+  const dim3 block(64 * tc::kQuadWavesPerBlock);
+  if (args.n_waves == 0) return TC_OK;
+  switch (n_u) {
+#define TC_CASE(N)                                                                          \
+  case N:                                                                                   \
+    hipExtLaunchKernelGGL((tc::contract_quad_f32_kernel<N, true>), grid, block, lds_bytes, \
+                          stream, start, stop, 0, args);                                  \
+    break;
+    TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4)
+#undef TC_CASE
+    default:
+      return fail(TC_ERR_UNSUPPORTED, "no float32 kernel for %d r sub-tiles", n_u);
+  }
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+
 int launch_contract_quad_f32(int n_u, const tc::QuadArgs& args, int lds_bytes,
                              hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
   const dim3 grid((unsigned)((args.n_waves + tc::kQuadWavesPerBlock - 1) /
@@ -397,7 +418,8 @@ int launch_contract_quad_f32(int n_u, const tc::QuadArgs& args, int lds_bytes,
   switch (n_u) {
 #define TC_CASE(N)                                                                        \
   case N:                                                                                 \
-    hipExtLaunchKernelGGL((tc::contract_quad_f32_kernel<N>), grid, block, lds_bytes,      \
+    hipExtLaunchKernelGGL((tc::contract_quad_f32_kernel<N, false>), grid, block,          \
+                          lds_bytes,                                                      \
                           stream, start, stop, 0, args);                                  \
     break;
     TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4)
@@ -726,7 +748,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
 int run_occupation(tc_table* t, const double* theta_device, int n_theta,
                    int64_t n_draws, int64_t ldb, int n_gauss, unsigned flags,
                    double* occupation_device, DeviceBuffer* nbuf, DeviceBuffer* ngal2,
-                   hipStream_t stream, int* ngal_parts) {
+                   hipStream_t stream, int* ngal_parts, DeviceBuffer* nbuf32) {
   Range range("occupation");
   tc_table::Lane& lane = t->lanes[t->cur];
   if (nbuf == nullptr) nbuf = &lane.nbuf;
@@ -780,9 +802,13 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
           n_tiles * splits, (int64_t)n_cus * std::max(1, t->tuning.occ_per_cu));
     }
   }
-  const bool want_f32 = t->quad && t->compute_dtype == TC_DTYPE_F32 && nbuf == &lane.nbuf;
+  // float copy of the densities for the float32 quadratic-form kernel: the lane's own, or
+  // the caller's (interpolators: one per class of halo tables)
+  if (nbuf32 == nullptr && t->quad && t->compute_dtype == TC_DTYPE_F32 && nbuf == &lane.nbuf)
+    nbuf32 = &lane.nbuf32;
+  const bool want_f32 = nbuf32 != nullptr;
   if (want_f32) {
-    status = lane.nbuf32.reserve((size_t)t->n_bins * ldb * sizeof(float), stream);
+    status = nbuf32->reserve((size_t)t->n_bins * ldb * sizeof(float), stream);
     if (status != TC_OK) return status;
   }
   status = nbuf->reserve((size_t)t->n_bins * ldb * sizeof(double), stream);
@@ -810,7 +836,7 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   oa.perm = (const int32_t*)t->d_perm;
   oa.math_table = (const double*)t->d_math_table;
   oa.nbuf = (double*)nbuf->ptr;
-  oa.nbuf32 = want_f32 ? (float*)lane.nbuf32.ptr : nullptr;
+  oa.nbuf32 = want_f32 ? (float*)nbuf32->ptr : nullptr;
   oa.ngal = (double*)ngal2->ptr;
   oa.occupation = occupation_device;
   {
