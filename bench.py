@@ -763,7 +763,7 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds):
     d_theta5 = dev.upload(theta)
     cache5 = {}
     cpu5 = cpu_rate(lambda i: oracle.predict_zheng07(table5, theta[i % 10000], cache=cache5))
-    for dtype, peak, kernel in (('float32', FP32_PEAK_TFLOPS, 'tc::contract_quad_f32_kernel<4>'),
+    for dtype, peak, kernel in (('float32', FP32_PEAK_TFLOPS, 'tc::contract_quad_f32_kernel<4, false>'),
                                 ('float64', FP64_PEAK_TFLOPS,
                                  'tc::contract_mfma_kernel<32, false>')):
         tab5 = make(table5, compute_dtype=dtype)
