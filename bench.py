@@ -574,6 +574,7 @@ def main():
             'value': n_draws / seconds, 'unit': 'calls/s', 'ms_per_call': seconds * 1e3,
             'what': 'tc_predict_zheng07_batch: %d draws in pageable host memory -> (ngal, xi) '
                     'in host memory, synchronous, PCIe included (SURVEY.md 8d)' % n_draws}
+        result.update(host_pipelined(lib, _lib, handle, table, n_draws, data_vector, precision))
         result['unbatched_us'] = unbatched(make, table, synthetic, Interpolator)
         result['tabulation'] = tabulation(args.cpu_seconds)
         if args.other_configs:
@@ -589,6 +590,71 @@ def main():
     dev.free_all()
     comm.barrier()
     comm.close()
+
+
+# ---- SURVEY 8d metric through the asynchronous entry points ------------------------------------
+
+def host_pipelined(lib, _lib, handle, table, n_draws, data_vector, precision, seconds=0.5,
+                   depth=6, ring=8):
+    """theta in page-locked host memory -> (ngal, xi) / (ngal, chi2) in page-locked host memory
+    through tc_predict_zheng07_batch_async / tc_chi2_zheng07_batch_async + tc_table_wait:
+    `depth` calls in flight over a ring of `ring` distinct buffer sets, every call with its
+    own draws; each ticket is waited for before its buffers are reused.  The last ring's
+    results are checked against the CPU oracle."""
+    from tabcorr_amd import synthetic, pinned_array, pinned_empty
+    from oracle import tabcorr_oracle as oracle
+    thetas = [pinned_array(synthetic.zheng07_draws(n_draws, seed=500 + i)) for i in range(ring)]
+    ngals = [pinned_empty(n_draws) for _ in range(ring)]
+    xis = [pinned_empty((n_draws, N_R)) for _ in range(ring)]
+    chis = [pinned_empty(n_draws) for _ in range(ring)]
+    p_theta = [_lib.as_double_p(a) for a in thetas]
+    p_ngal = [_lib.as_double_p(a) for a in ngals]
+    p_xi = [_lib.as_double_p(a) for a in xis]
+    p_chi = [_lib.as_double_p(a) for a in chis]
+    data_p, precision_p = _lib.as_double_p(data_vector), _lib.as_double_p(precision)
+    ticket = ctypes.c_int64()
+    ref = ctypes.byref(ticket)
+
+    def run(chi2, total):
+        tickets = [None] * ring
+        start = time.perf_counter()
+        for k in range(total):
+            s = k % ring
+            if k >= depth:
+                _lib.check(lib.tc_table_wait(handle, tickets[(k - depth) % ring]))
+            if chi2:
+                _lib.check(lib.tc_chi2_zheng07_batch_async(
+                    handle, p_theta[s], 5, n_draws, N_GAUSS, 0, data_p, precision_p, p_ngal[s],
+                    p_chi[s], ref))
+            else:
+                _lib.check(lib.tc_predict_zheng07_batch_async(
+                    handle, p_theta[s], 5, n_draws, N_GAUSS, 0, p_ngal[s], p_xi[s], ref))
+            tickets[s] = ticket.value
+        for k in range(max(0, total - depth), total):
+            _lib.check(lib.tc_table_wait(handle, tickets[k % ring]))
+        return (time.perf_counter() - start) / total
+
+    out = {}
+    for chi2, name, payload in ((False, 'host_to_host_pipelined', '%d B out' % (8 * (1 + N_R))),
+                                (True, 'host_to_host_chi2', '16 B out')):
+        run(chi2, 300)
+        per = run(chi2, 100)
+        per = run(chi2, max(100, int(seconds / per)))
+        check = ring - 1
+        expect = oracle.predict_zheng07_batch(table, thetas[check][:2])
+        if chi2:
+            delta = expect[1] - data_vector
+            want = np.einsum('bi,ij,bj->b', delta, precision, delta)
+            parity = float(np.max(np.abs(chis[check][:2] / want - 1)))
+        else:
+            parity = float(np.max(np.abs(xis[check][:2] / expect[1] - 1)))
+        out[name] = {
+            'value': n_draws / per, 'unit': 'calls/s', 'us_per_call': per * 1e6,
+            'calls_in_flight': depth, 'parity_max_rel_vs_oracle': parity,
+            'what': 'tc_%s_zheng07_batch_async + tc_table_wait: %d draws per call (40 B in, %s '
+                    'per draw), page-locked caller buffers, PCIe included (SURVEY.md 8d)'
+                    % ('chi2' if chi2 else 'predict', n_draws, payload)}
+    return out
 
 
 # ---- latency mode --------------------------------------------------------------------------

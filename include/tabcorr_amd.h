@@ -80,6 +80,17 @@ int tc_device_free(void* ptr);
 int tc_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes);
 int tc_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes);
 
+/* Page-locked host memory for the asynchronous entry points (tc_*_async): caller-owned,
+ * released with tc_host_free.  tc_host_register pins memory the caller already owns (e.g.
+ * the coordinate array of an ensemble sampler) until tc_host_unregister.  The library keeps
+ * a registry of these ranges; tc_host_is_pinned reports whether [ptr, ptr + bytes) lies
+ * inside one (no HIP call, usable without a device). */
+int tc_host_alloc(void** ptr, size_t bytes);
+int tc_host_free(void* ptr);
+int tc_host_register(void* ptr, size_t bytes);
+int tc_host_unregister(void* ptr);
+int tc_host_is_pinned(const void* ptr, size_t bytes, int* pinned);
+
 /* ---- helpers exported for the host-side tests (pure host code, no GPU needed) ------- */
 
 /* Gauss-Legendre nodes mapped to (0, 1) and weights, as tabcorr.py:543-546
@@ -198,6 +209,30 @@ int tc_chi2_zheng07_batch_device(tc_table* table, const double* theta_device, in
                                  const double* data, const double* precision,
                                  double* ngal_device, double* chi2_device);
 
+/* Asynchronous host-to-host form of the two calls above -- the SURVEY.md section 8d metric
+ * (theta on the host -> (ngal, xi) on the host) at the device rate.  What it replaces in the
+ * reference is the user's loop of predict() calls (README.md:72-75): an ensemble sampler
+ * enqueues the batch of walker positions of step k + 1 while the results of step k are still
+ * on their way back.
+ *
+ * theta, ngal, xi (chi2) must lie in page-locked memory (tc_host_alloc / tc_host_register),
+ * else TC_ERR_INVALID.  The call enqueues upload -> occupation -> contraction ->
+ * finalisation -> download on the next lane of the handle (stream + workspaces + staging,
+ * rotating as the _device entry points do) and returns a ticket without synchronising;
+ * copies run on the lane's stream, so the kernels of call k + 1 overlap the download of call
+ * k.  The caller must not touch theta / ngal / xi of a ticket before tc_table_wait(ticket)
+ * returned (tc_table_query: non-blocking test).  Tickets complete in any order; results of
+ * a ticket land only in the buffers passed with it.  At most 64 tickets may be pending. */
+int tc_predict_zheng07_batch_async(tc_table* table, const double* theta_pinned, int n_theta,
+                                   int64_t n_draws, int n_gauss_prim, unsigned flags,
+                                   double* ngal_pinned, double* xi_pinned, int64_t* ticket);
+int tc_chi2_zheng07_batch_async(tc_table* table, const double* theta_pinned, int n_theta,
+                                int64_t n_draws, int n_gauss_prim, unsigned flags,
+                                const double* data, const double* precision,
+                                double* ngal_pinned, double* chi2_pinned, int64_t* ticket);
+int tc_table_wait(tc_table* table, int64_t ticket);
+int tc_table_query(tc_table* table, int64_t ticket, int* done);
+
 /* TabCorr.predict(ndarray): the operator seam of tabcorr.py:616-621 for arbitrary
  * occupation models evaluated by the caller.  occupation: (n_draws, n_bins). */
 int tc_predict_occupation_batch(tc_table* table, const double* occupation,
@@ -247,6 +282,21 @@ int tc_interp_chi2_zheng07_batch_device(tc_interp* interp, const double* theta_d
                                         int n_gauss_prim, unsigned flags, const double* data,
                                         const double* precision, double* ngal_device,
                                         double* chi2_device);
+
+/* Asynchronous host-to-host forms (page-locked theta, x, outputs; see
+ * tc_predict_zheng07_batch_async): upload and kernels on the interpolator's stream, the
+ * download of call k on a second stream behind it, overlapping the kernels of call k + 1
+ * (results double-buffered on the device). */
+int tc_interp_predict_zheng07_batch_async(tc_interp* interp, const double* theta_pinned,
+                                          int n_theta, const double* x_pinned, int64_t n_draws,
+                                          int n_gauss_prim, unsigned flags, double* ngal_pinned,
+                                          double* xi_pinned, int64_t* ticket);
+int tc_interp_chi2_zheng07_batch_async(tc_interp* interp, const double* theta_pinned,
+                                       int n_theta, const double* x_pinned, int64_t n_draws,
+                                       int n_gauss_prim, unsigned flags, const double* data,
+                                       const double* precision, double* ngal_pinned,
+                                       double* chi2_pinned, int64_t* ticket);
+int tc_interp_wait(tc_interp* interp, int64_t ticket);
 
 /* Run-time options of a table handle (the library never reads the environment):
  *   "pipeline"    1 (default): consecutive device-pointer calls rotate over the handle's

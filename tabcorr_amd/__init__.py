@@ -9,10 +9,11 @@ from .tabcorr import TabCorr, symmetric_matrix_to_array
 from .interpolator import Interpolator
 from .models import Zheng07Model, Leauthaud11Model
 from .galtable import GalTypeTable
+from .pinned import pinned_empty, pinned_array, is_pinned, pin
 from . import synthetic
 from . import corrfunc
 
 __version__ = '0.1.0'
 __all__ = ['TabCorr', 'Interpolator', 'Zheng07Model', 'Leauthaud11Model',
-           'GalTypeTable',
+           'GalTypeTable', 'pinned_empty', 'pinned_array', 'is_pinned', 'pin',
            'symmetric_matrix_to_array', 'synthetic', 'corrfunc']

@@ -50,6 +50,11 @@ SIGNATURES = {
     'tc_device_free': [ctypes.c_void_p],
     'tc_memcpy_h2d': [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t],
     'tc_memcpy_d2h': [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t],
+    'tc_host_alloc': [c_void_pp, ctypes.c_size_t],
+    'tc_host_free': [ctypes.c_void_p],
+    'tc_host_register': [ctypes.c_void_p, ctypes.c_size_t],
+    'tc_host_unregister': [ctypes.c_void_p],
+    'tc_host_is_pinned': [ctypes.c_void_p, ctypes.c_size_t, c_int_p],
     'tc_gauss_legendre': [ctypes.c_int, c_double_p, c_double_p],
     'tc_debug_fastmath': [ctypes.c_int, ctypes.c_int64, c_double_p,
                           c_double_p],
@@ -88,6 +93,24 @@ SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
         ctypes.c_int, ctypes.c_uint, c_double_p, c_double_p, ctypes.c_void_p,
         ctypes.c_void_p],
+    'tc_predict_zheng07_batch_async': [
+        ctypes.c_void_p, c_double_p, ctypes.c_int, ctypes.c_int64,
+        ctypes.c_int, ctypes.c_uint, c_double_p, c_double_p, c_int64_p],
+    'tc_chi2_zheng07_batch_async': [
+        ctypes.c_void_p, c_double_p, ctypes.c_int, ctypes.c_int64,
+        ctypes.c_int, ctypes.c_uint, c_double_p, c_double_p, c_double_p,
+        c_double_p, c_int64_p],
+    'tc_table_wait': [ctypes.c_void_p, ctypes.c_int64],
+    'tc_table_query': [ctypes.c_void_p, ctypes.c_int64, c_int_p],
+    'tc_interp_predict_zheng07_batch_async': [
+        ctypes.c_void_p, c_double_p, ctypes.c_int, c_double_p,
+        ctypes.c_int64, ctypes.c_int, ctypes.c_uint, c_double_p, c_double_p,
+        c_int64_p],
+    'tc_interp_chi2_zheng07_batch_async': [
+        ctypes.c_void_p, c_double_p, ctypes.c_int, c_double_p,
+        ctypes.c_int64, ctypes.c_int, ctypes.c_uint, c_double_p, c_double_p,
+        c_double_p, c_double_p, c_int64_p],
+    'tc_interp_wait': [ctypes.c_void_p, ctypes.c_int64],
     'tc_predict_occupation_batch': [
         ctypes.c_void_p, c_double_p, ctypes.c_int64, ctypes.c_uint,
         c_double_p, c_double_p],

@@ -156,6 +156,13 @@ int gather_after(tc_comm* c, hipStream_t producer, const double* send_device,
 
 int tc_comm_gather(tc_comm* c, tc_table* t, const double* send_device,
                    double* recv_device, int64_t count, int root, int slot) {
+  if (c != nullptr && t != nullptr && !t->chain) {
+    // unordered finalisations (tc_table_set_option "ordered" 0): the results of earlier
+    // calls are not implied by the current lane's stream, wait for every lane's last one
+    TC_HIP(hipSetDevice(c->device));
+    for (int l = 0; l < t->n_lanes; ++l)
+      if (l != t->cur) TC_HIP(hipStreamWaitEvent(c->stream, t->lanes[l].finished, 0));
+  }
   return gather_after(c, t != nullptr ? t->lanes[t->cur].stream : nullptr, send_device,
                       recv_device, count, root, slot);
 }
@@ -171,7 +178,7 @@ int tc_comm_release(tc_comm* c, tc_table* t, int slot) {
   TC_CHECK(slot >= 0 && slot < 4, "slot must be in [0, 4)");
   TC_HIP(hipSetDevice(c->device));
   for (tc_table::Lane& lane : t->lanes)
-    TC_HIP(hipStreamWaitEvent(lane.stream, c->done[slot], 0));
+    if (lane.stream) TC_HIP(hipStreamWaitEvent(lane.stream, c->done[slot], 0));
   return TC_OK;
 }
 

@@ -104,6 +104,11 @@ struct PinnedBuffer {
     bytes = 0;
   }
 };
+// Whether [ptr, ptr + bytes) lies in page-locked memory known to the library
+// (tc_host_alloc / tc_host_register; runtime.cpp).
+// `device_ptr` receives the address the device sees the range at (NULL when it has none).
+bool is_pinned(const void* ptr, size_t bytes, void** device_ptr = nullptr);
+
 // (developer builds only: environment overrides)
 inline int env_int_early(const char* name, int fallback) {
 #ifdef TC_DEVELOPER_KNOBS
@@ -215,6 +220,16 @@ struct Tuning {
   int n_groups = 0, n_waves = 0, lds_min = 0, min_chunk_entries = 32;   // segment kernels
   int k_splits = 0;           // interpolator, segment kernels: table splits (0: chosen)
   int trace = 0;              // developer timelines
+  // Asynchronous host calls (10^4 draws per call, four lanes, tools/r03_async_sweep.sh): with
+  // copy commands both ways 64-68 us per call; the occupation kernel reading the draws from
+  // the caller's page-locked memory itself (one command and one engine hop of ~10 us less in
+  // the lane's chain) 58; small results (number densities, chi2) stored by the finalisation
+  // kernel directly 57 / the likelihood 47.5; ALL results stored directly 66 (1.5 MB of
+  // 64-byte writes over PCIe from the shader cores lose to the copy engine); downloads on a
+  // stream of their own 91-105 (cross-stream events), more lanes 72-80 (four hardware queues).
+  int async_direct_in = 1;    // 1: kernels read the draws from the caller's pinned memory
+  int async_direct_out = 2;   // 0: copy commands, 1: kernels store everything, 2: kernels
+                              // store arrays up to kDirectOutBytes, copy commands beyond
   int skip_occ = 0, skip_finalize = 0;   // diagnosis (developer builds only)
   void load() {
     lanes = env_int("TC_LANES", lanes);
@@ -293,14 +308,29 @@ struct tc_table {
     tc::host::DeviceBuffer nbuf, ngal2, partial;
     tc::host::DeviceBuffer nbuf32;   // float copy of nbuf (float32 quadratic-form kernel)
     tc::host::DeviceBuffer xi;       // chi2 device calls: the correlation functions
+    tc::host::DeviceBuffer in_theta, out;   // asynchronous host calls: staging of draws / results
     int ngal_parts = 1;              // partial sums the occupation step left in ngal2
   };
-  static constexpr int kMaxLanes = 4;
+  static constexpr int kMaxLanes = 8;
   Lane lanes[kMaxLanes];
   int n_lanes = 2;
   int prev = -1;                     // lane of the previous finalisation
   int cur = 0;                       // lane of the current / last predict call
   int force_lane = -1;               // host-buffer entry points pin lane 0
+  int async_lane = -1;               // asynchronous host calls: the lane already chosen
+  // Results of consecutive device-pointer calls appear in call order (the finalisations are
+  // chained by events) unless this is off: asynchronous host calls deliver every ticket into
+  // its own buffers, and tc_comm_gather waits for every lane.
+  bool chain = true;
+  // Tickets of the asynchronous host calls (tc_*_async): a ring of events; a ticket whose
+  // slot was reused is older than every lane's current work.
+  struct Ticket {
+    hipEvent_t done = nullptr;
+    int64_t id = -1;
+  };
+  static constexpr int kMaxTickets = 64;
+  Ticket tickets[kMaxTickets];
+  int64_t next_ticket = 0;
   // chi2 calls: where the finalisation may put the fused likelihood (data | precision on
   // the device, output); run_contraction sets chi2_fused when it did
   const double* fuse_chi2_data = nullptr;
@@ -325,6 +355,9 @@ struct tc_table {
 namespace tc {
 namespace host {
 
+// Asynchronous host calls: result arrays up to this size are stored by the kernels into the
+// caller's page-locked memory, larger ones travel by copy command.
+constexpr size_t kDirectOutBytes = 256 * 1024;
 // Largest dynamic LDS allocation a workgroup may ask for (160 KiB per CU).
 constexpr int kMaxLdsBytes = 160 * 1024;
 // Draws are processed in slabs so that the workspaces stay bounded.

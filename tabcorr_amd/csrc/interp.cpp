@@ -44,6 +44,14 @@ struct tc_interp {
   std::vector<double> chi2_host;            // host copy of what chi2_data holds
   PinnedBuffer h_in, h_out;
   std::map<std::pair<int, int>, std::unique_ptr<DeviceChunking>> chunkings;
+  // asynchronous host calls (tc_interp_*_async): uploads and kernels on `stream`, the
+  // download of call k on `out_stream` behind it (results double-buffered), tickets as for
+  // a table handle
+  hipStream_t out_stream = nullptr;
+  hipEvent_t computed[2] = {nullptr, nullptr}, downloaded[2] = {nullptr, nullptr};
+  DeviceBuffer stage_in, stage_out[2];
+  tc_table::Ticket tickets[tc_table::kMaxTickets];
+  int64_t next_ticket = 0;
 };
 
 namespace {
@@ -435,6 +443,15 @@ int tc_interp_destroy(tc_interp* it) {
     b->release();
   it->h_in.release();
   it->h_out.release();
+  if (it->out_stream) (void)hipStreamSynchronize(it->out_stream);
+  it->stage_in.release();
+  for (DeviceBuffer& b : it->stage_out) b.release();
+  for (hipEvent_t event : {it->computed[0], it->computed[1], it->downloaded[0],
+                           it->downloaded[1]})
+    if (event) (void)hipEventDestroy(event);
+  for (tc_table::Ticket& ticket : it->tickets)
+    if (ticket.done) (void)hipEventDestroy(ticket.done);
+  if (it->out_stream) (void)hipStreamDestroy(it->out_stream);
   if (it->stream) (void)hipStreamDestroy(it->stream);
   delete it;
   return TC_OK;
@@ -443,6 +460,7 @@ int tc_interp_destroy(tc_interp* it) {
 int tc_interp_synchronize(tc_interp* it) {
   TC_CHECK(it != nullptr, "interp handle is NULL");
   TC_HIP(hipStreamSynchronize(it->stream));
+  if (it->out_stream) TC_HIP(hipStreamSynchronize(it->out_stream));
   return TC_OK;
 }
 
@@ -717,6 +735,113 @@ int tc_interp_chi2_zheng07_batch(tc_interp* it, const double* theta, int n_theta
   TC_HIP(hipMemcpyAsync(ngal, d_ngal, (size_t)n_draws * 8, hipMemcpyDeviceToHost, it->stream));
   TC_HIP(hipMemcpyAsync(chi2, d_chi2, (size_t)n_draws * 8, hipMemcpyDeviceToHost, it->stream));
   TC_HIP(hipStreamSynchronize(it->stream));
+  return TC_OK;
+}
+
+namespace {
+
+int interp_async(tc_interp* it, const double* theta, int n_theta, const double* x,
+                 int64_t n_draws, int n_gauss, unsigned flags, const double* data,
+                 const double* precision, double* ngal, double* second, bool chi2,
+                 int64_t* ticket_out) {
+  TC_CHECK(it != nullptr, "interp handle is NULL");
+  tc_table* t0 = it->tables[0];
+  int status = check_predict_args(t0, theta, n_theta, n_draws, n_gauss, flags);
+  if (status != TC_OK) return status;
+  TC_CHECK(ticket_out != nullptr, "ticket is NULL");
+  TC_CHECK(n_draws == 0 || (x && ngal && second), "NULL pointer");
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  TC_CHECK(!(chi2 && separate), "chi2 is defined for the total correlation function only");
+  TC_CHECK(!chi2 || (data && precision), "NULL pointer");
+  const int n_comp = separate ? t0->plan.n_components : 1;
+  const size_t ngal_count = (size_t)n_draws * (separate ? 2 : 1);
+  const size_t second_count = chi2 ? (size_t)n_draws : (size_t)n_draws * n_comp * t0->n_r;
+  const size_t theta_count = (size_t)n_draws * n_theta, x_count = (size_t)n_draws * it->n_dim;
+  TC_CHECK(n_draws == 0 ||
+               (is_pinned(theta, theta_count * 8) && is_pinned(x, x_count * 8) &&
+                is_pinned(ngal, ngal_count * 8) && is_pinned(second, second_count * 8)),
+           "asynchronous calls need page-locked buffers (tc_host_alloc / tc_host_register)");
+  TC_HIP(hipSetDevice(it->device));
+  if (it->out_stream == nullptr) {
+    TC_HIP(hipStreamCreateWithFlags(&it->out_stream, hipStreamNonBlocking));
+    for (hipEvent_t* event : {&it->computed[0], &it->computed[1], &it->downloaded[0],
+                              &it->downloaded[1]})
+      TC_HIP(hipEventCreateWithFlags(event, hipEventDisableTiming));
+  }
+  const int s = (int)(it->next_ticket % 2);
+  hipStream_t last = it->stream;
+  if (n_draws > 0) {
+    DeviceBuffer& out = it->stage_out[s];
+    if ((ngal_count + second_count) * 8 > out.bytes)
+      TC_HIP(hipStreamSynchronize(it->out_stream));    // (a download may still read it)
+    status = out.reserve((ngal_count + second_count) * 8, it->stream);
+    if (status == TC_OK) status = it->stage_in.reserve((theta_count + x_count) * 8, it->stream);
+    if (status != TC_OK) return status;
+    double* d_theta = (double*)it->stage_in.ptr;
+    double* d_x = d_theta + theta_count;
+    double* d_ngal = (double*)out.ptr;
+    double* d_second = d_ngal + ngal_count;
+    {
+      Range range("upload");
+      TC_HIP(hipMemcpyAsync(d_theta, theta, theta_count * 8, hipMemcpyHostToDevice, it->stream));
+      TC_HIP(hipMemcpyAsync(d_x, x, x_count * 8, hipMemcpyHostToDevice, it->stream));
+    }
+    // the download of the call before last read this half of the results
+    TC_HIP(hipStreamWaitEvent(it->stream, it->downloaded[s], 0));
+    status = chi2 ? tc_interp_chi2_zheng07_batch_device(it, d_theta, n_theta, d_x, n_draws,
+                                                        n_gauss, flags, data, precision, d_ngal,
+                                                        d_second)
+                  : tc_interp_predict_zheng07_batch_device(it, d_theta, n_theta, d_x, n_draws,
+                                                           n_gauss, flags, d_ngal, d_second);
+    if (status != TC_OK) return status;
+    TC_HIP(hipEventRecord(it->computed[s], it->stream));
+    TC_HIP(hipStreamWaitEvent(it->out_stream, it->computed[s], 0));
+    Range range("download");
+    TC_HIP(hipMemcpyAsync(ngal, d_ngal, ngal_count * 8, hipMemcpyDeviceToHost, it->out_stream));
+    TC_HIP(hipMemcpyAsync(second, d_second, second_count * 8, hipMemcpyDeviceToHost,
+                          it->out_stream));
+    TC_HIP(hipEventRecord(it->downloaded[s], it->out_stream));
+    last = it->out_stream;
+  }
+  tc_table::Ticket& slot = it->tickets[it->next_ticket % tc_table::kMaxTickets];
+  if (slot.done == nullptr)
+    TC_HIP(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+  slot.id = it->next_ticket++;
+  TC_HIP(hipEventRecord(slot.done, last));
+  *ticket_out = slot.id;
+  return TC_OK;
+}
+
+}  // namespace
+
+int tc_interp_predict_zheng07_batch_async(tc_interp* it, const double* theta, int n_theta,
+                                          const double* x, int64_t n_draws, int n_gauss,
+                                          unsigned flags, double* ngal, double* xi,
+                                          int64_t* ticket) {
+  return interp_async(it, theta, n_theta, x, n_draws, n_gauss, flags, nullptr, nullptr, ngal, xi,
+                      false, ticket);
+}
+
+int tc_interp_chi2_zheng07_batch_async(tc_interp* it, const double* theta, int n_theta,
+                                       const double* x, int64_t n_draws, int n_gauss,
+                                       unsigned flags, const double* data,
+                                       const double* precision, double* ngal, double* chi2,
+                                       int64_t* ticket) {
+  return interp_async(it, theta, n_theta, x, n_draws, n_gauss, flags, data, precision, ngal,
+                      chi2, true, ticket);
+}
+
+int tc_interp_wait(tc_interp* it, int64_t ticket) {
+  TC_CHECK(it != nullptr, "interp handle is NULL");
+  TC_CHECK(ticket >= 0 && ticket < it->next_ticket, "unknown ticket %lld", (long long)ticket);
+  const tc_table::Ticket& slot = it->tickets[ticket % tc_table::kMaxTickets];
+  if (slot.id == ticket) {
+    TC_HIP(hipEventSynchronize(slot.done));
+    return TC_OK;
+  }
+  // the slot was reused: the ticket is older than everything queued now
+  TC_HIP(hipStreamSynchronize(it->stream));
+  if (it->out_stream) TC_HIP(hipStreamSynchronize(it->out_stream));
   return TC_OK;
 }
 

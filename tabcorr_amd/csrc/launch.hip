@@ -551,7 +551,7 @@ static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsig
     fa.xi = nullptr;
     t->chi2_fused = true;
   }
-  if (t->prev >= 0 && t->prev != t->cur)
+  if (t->chain && t->prev >= 0 && t->prev != t->cur)
     TC_HIP(hipStreamWaitEvent(stream, t->lanes[t->prev].finished, 0));
   if (!t->tuning.skip_finalize) status = launch_finalize_quad(fa, t->tuning, stream, f32);
   if (status != TC_OK) return status;
@@ -732,7 +732,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   fa.xi = xi_device;
   // results appear in call order: wait for the previous call's finalisation
   // (host-buffer calls synchronise before returning and need no chaining)
-  if (t->prev >= 0 && t->prev != t->cur)
+  if (t->chain && t->prev >= 0 && t->prev != t->cur)
     TC_HIP(hipStreamWaitEvent(stream, t->lanes[t->prev].finished, 0));
   if (!t->tuning.skip_finalize) status = launch_finalize(fa, t->tuning, stream);
   if (status != TC_OK) return status;

@@ -3,6 +3,8 @@
 // pair indices, spline matrices, plan self-check) that are testable without a GPU.
 #include <dlfcn.h>
 
+#include <mutex>
+
 #include "internal.h"
 
 namespace tc {
@@ -69,6 +71,32 @@ int fail(int code, const char* format, ...) {
 }
 
 const char* last_error() { return g_last_error.c_str(); }
+
+// Page-locked host ranges handed out by tc_host_alloc or pinned by tc_host_register:
+// begin -> (bytes, allocated by us).  The asynchronous entry points look their buffers up
+// here (a map lookup under a mutex; hipPointerGetAttributes costs microseconds per call).
+namespace {
+struct PinnedRange {
+  size_t bytes = 0;
+  bool owned = false;
+  uintptr_t device = 0;      // address of the range as the device sees it
+};
+std::mutex g_pinned_mutex;
+std::map<uintptr_t, PinnedRange> g_pinned;
+}  // namespace
+
+bool is_pinned(const void* ptr, size_t bytes, void** device_ptr) {
+  if (device_ptr != nullptr) *device_ptr = nullptr;
+  if (ptr == nullptr) return false;
+  const uintptr_t begin = (uintptr_t)ptr;
+  std::lock_guard<std::mutex> lock(g_pinned_mutex);
+  auto it = g_pinned.upper_bound(begin);
+  if (it == g_pinned.begin()) return false;
+  --it;
+  if (begin < it->first || begin + bytes > it->first + it->second.bytes) return false;
+  if (device_ptr != nullptr) *device_ptr = (void*)(it->second.device + (begin - it->first));
+  return true;
+}
 
 }  // namespace host
 }  // namespace tc
@@ -141,6 +169,60 @@ int tc_memcpy_h2d(void* dst, const void* src, size_t bytes) {
 
 int tc_memcpy_d2h(void* dst, const void* src, size_t bytes) {
   TC_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return TC_OK;
+}
+
+int tc_host_alloc(void** ptr, size_t bytes) {
+  TC_CHECK(ptr != nullptr, "ptr is NULL");
+  *ptr = nullptr;
+  const size_t size = std::max<size_t>(bytes, 1);
+  TC_HIP(hipHostMalloc(ptr, size, hipHostMallocDefault));
+  void* device = nullptr;
+  if (hipHostGetDevicePointer(&device, *ptr, 0) != hipSuccess) device = *ptr;
+  std::lock_guard<std::mutex> lock(g_pinned_mutex);
+  g_pinned[(uintptr_t)*ptr] = PinnedRange{size, true, (uintptr_t)device};
+  return TC_OK;
+}
+
+int tc_host_free(void* ptr) {
+  if (ptr == nullptr) return TC_OK;
+  {
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    auto it = g_pinned.find((uintptr_t)ptr);
+    TC_CHECK(it != g_pinned.end() && it->second.owned,
+             "tc_host_free: not a pointer returned by tc_host_alloc");
+    g_pinned.erase(it);
+  }
+  TC_HIP(hipHostFree(ptr));
+  return TC_OK;
+}
+
+int tc_host_register(void* ptr, size_t bytes) {
+  TC_CHECK(ptr != nullptr && bytes > 0, "invalid range");
+  TC_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  void* device = nullptr;
+  if (hipHostGetDevicePointer(&device, ptr, 0) != hipSuccess) device = nullptr;
+  std::lock_guard<std::mutex> lock(g_pinned_mutex);
+  g_pinned[(uintptr_t)ptr] = PinnedRange{bytes, false, (uintptr_t)device};
+  return TC_OK;
+}
+
+int tc_host_unregister(void* ptr) {
+  if (ptr == nullptr) return TC_OK;
+  {
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    auto it = g_pinned.find((uintptr_t)ptr);
+    TC_CHECK(it != g_pinned.end() && !it->second.owned,
+             "tc_host_unregister: not a range pinned by tc_host_register");
+    g_pinned.erase(it);
+  }
+  TC_HIP(hipHostUnregister(ptr));
+  return TC_OK;
+}
+
+int tc_host_is_pinned(const void* ptr, size_t bytes, int* pinned) {
+  TC_CHECK(pinned != nullptr, "pinned is NULL");
+  *pinned = is_pinned(ptr, bytes) ? 1 : 0;
   return TC_OK;
 }
 

@@ -141,12 +141,13 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
       pos_ij[(size_t)block * 8 + k * 4 + p] = (i << 16) | t->plan.pos_j[q];
     }
   }
-  for (tc_table::Lane& lane : t->lanes) {
-    TC_HIP(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
-    TC_HIP(hipEventCreateWithFlags(&lane.finished, hipEventDisableTiming));
+  // (streams of the lanes in use; tc_table_set_option "lanes" creates further ones)
+  t->n_lanes = std::max(1, std::min(t->tuning.lanes, (int)tc_table::kMaxLanes));
+  for (int l = 0; l < t->n_lanes; ++l) {
+    TC_HIP(hipStreamCreateWithFlags(&t->lanes[l].stream, hipStreamNonBlocking));
+    TC_HIP(hipEventCreateWithFlags(&t->lanes[l].finished, hipEventDisableTiming));
   }
   t->stream = t->lanes[0].stream;
-  t->n_lanes = std::max(1, std::min(t->tuning.lanes, (int)tc_table::kMaxLanes));
   TC_HIP(hipEventCreate(&t->ev_begin));
   TC_HIP(hipEventCreate(&t->ev_end));
   int status = compute_dtype == TC_DTYPE_F64 ? upload(tmp64, &t->d_table)
@@ -219,8 +220,12 @@ int tc_table_destroy(tc_table* t) {
     lane.partial.release();
     lane.xi.release();
     lane.nbuf32.release();
+    lane.in_theta.release();
+    lane.out.release();
     if (lane.finished) (void)hipEventDestroy(lane.finished);
   }
+  for (tc_table::Ticket& ticket : t->tickets)
+    if (ticket.done) (void)hipEventDestroy(ticket.done);
   t->h_in.release();
   t->h_out.release();
   for (auto& ev : t->kernel_events) {
@@ -237,7 +242,8 @@ int tc_table_destroy(tc_table* t) {
 
 int tc_table_synchronize(tc_table* t) {
   TC_CHECK(t != nullptr, "table handle is NULL");
-  for (tc_table::Lane& lane : t->lanes) TC_HIP(hipStreamSynchronize(lane.stream));
+  for (tc_table::Lane& lane : t->lanes)
+    if (lane.stream) TC_HIP(hipStreamSynchronize(lane.stream));
   return TC_OK;
 }
 
@@ -266,6 +272,8 @@ int tc_predict_zheng07_batch_device(tc_table* t, const double* theta_device,
   const int n_comp = separate ? t->plan.n_components : 1;
   if (t->force_lane >= 0)
     t->cur = t->force_lane;
+  else if (t->async_lane >= 0)
+    t->cur = t->async_lane;
   else
     t->cur = t->tuning.pipeline ? (int)(t->device_calls++ % t->n_lanes) : 0;
   const int64_t slab = max_slab(t);
@@ -400,7 +408,8 @@ int upload_chi2_data(tc_table* t, const double* data, const double* precision) {
       memcmp(t->chi2_host.data(), data, (size_t)n_r * 8) != 0 ||
       memcmp(t->chi2_host.data() + n_r, precision, (size_t)n_r * n_r * 8) != 0) {
     // (kernels of earlier calls may still be reading the old values)
-    for (tc_table::Lane& lane : t->lanes) TC_HIP(hipStreamSynchronize(lane.stream));
+    for (tc_table::Lane& lane : t->lanes)
+      if (lane.stream) TC_HIP(hipStreamSynchronize(lane.stream));
     t->chi2_host.assign(data, data + n_r);
     t->chi2_host.insert(t->chi2_host.end(), precision, precision + (size_t)n_r * n_r);
     TC_HIP(hipMemcpyAsync(t->chi2_data.ptr, t->chi2_host.data(), data_count * 8,
@@ -431,8 +440,10 @@ int tc_chi2_zheng07_batch_device(tc_table* t, const double* theta_device, int n_
   // re-recorded behind the chi2 kernel, so the next call on this lane (whose finalisation
   // waits for that event through the chain of lanes) cannot overwrite it early
   const int lane_index =
-      t->force_lane >= 0 ? t->force_lane
-                         : t->tuning.pipeline ? (int)(t->device_calls % t->n_lanes) : 0;
+      t->force_lane >= 0   ? t->force_lane
+      : t->async_lane >= 0 ? t->async_lane
+      : t->tuning.pipeline ? (int)(t->device_calls % t->n_lanes)
+                           : 0;
   tc_table::Lane& lane = t->lanes[lane_index];
   status = lane.xi.reserve((size_t)n_draws * t->n_r * 8, lane.stream);
   if (status != TC_OK) return status;
@@ -512,6 +523,155 @@ int tc_chi2_zheng07_batch(tc_table* t, const double* theta, int n_theta,
   }
   return copy_out(&t->h_out, ngal, (size_t)n_draws, d_ngal, chi2, (size_t)n_draws,
                   d_chi2, t->stream);
+}
+
+namespace {
+
+// Next ticket of the handle: its event (created on first use of the slot) and its number.
+int next_ticket(tc_table* t, tc_table::Ticket** out) {
+  tc_table::Ticket& slot = t->tickets[t->next_ticket % tc_table::kMaxTickets];
+  if (slot.done == nullptr)
+    TC_HIP(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+  slot.id = t->next_ticket++;
+  *out = &slot;
+  return TC_OK;
+}
+
+// Asynchronous host-to-host prediction or likelihood on the handle's next lane: everything
+// (upload, three kernels, download, the ticket's event) is queued on that lane's stream, so
+// lanes overlap each other's copies and kernels and nothing orders one ticket against
+// another.
+int predict_async(tc_table* t, const double* theta, int n_theta, int64_t n_draws, int n_gauss,
+                  unsigned flags, const double* data, const double* precision, double* ngal,
+                  double* second, bool chi2, int64_t* ticket_out) {
+  int status = check_predict_args(t, theta, n_theta, n_draws, n_gauss, flags);
+  if (status != TC_OK) return status;
+  TC_CHECK(ticket_out != nullptr, "ticket is NULL");
+  TC_CHECK(n_draws == 0 || (ngal && second), "output pointer is NULL");
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  TC_CHECK(!(chi2 && separate), "chi2 is defined for the total correlation function only");
+  TC_CHECK(!chi2 || (data && precision), "NULL pointer");
+  TC_CHECK(!chi2 || n_draws <= max_slab(t), "at most %lld draws per call",
+           (long long)max_slab(t));
+  const int n_comp = separate ? t->plan.n_components : 1;
+  const size_t ngal_count = (size_t)n_draws * (separate ? 2 : 1);
+  const size_t second_count = chi2 ? (size_t)n_draws : (size_t)n_draws * n_comp * t->n_r;
+  const size_t theta_bytes = (size_t)n_draws * n_theta * sizeof(double);
+  void *theta_seen = nullptr, *ngal_seen = nullptr, *second_seen = nullptr;
+  TC_CHECK(n_draws == 0 || (is_pinned(theta, theta_bytes, &theta_seen) &&
+                            is_pinned(ngal, ngal_count * 8, &ngal_seen) &&
+                            is_pinned(second, second_count * 8, &second_seen)),
+           "asynchronous calls need page-locked buffers (tc_host_alloc / tc_host_register)");
+  TC_HIP(hipSetDevice(t->device));
+  tc_table::Ticket* ticket = nullptr;
+  const int lane_index = t->tuning.pipeline ? (int)(t->device_calls++ % t->n_lanes) : 0;
+  tc_table::Lane& lane = t->lanes[lane_index];
+  if (n_draws > 0) {
+    // Which arrays the kernels address in the caller's page-locked memory themselves and
+    // which travel by copy command: see Tuning::async_direct_in / async_direct_out.
+    const int mode = t->tuning.async_direct_out;
+    auto direct = [mode](void* seen, size_t count) {
+      return seen != nullptr && (mode == 1 || (mode == 2 && count * 8 <= kDirectOutBytes));
+    };
+    const bool direct_in = t->tuning.async_direct_in && theta_seen != nullptr;
+    const bool direct_ngal = direct(ngal_seen, ngal_count);
+    const bool direct_second = direct(second_seen, second_count);
+    if (!direct_in) status = lane.in_theta.reserve(theta_bytes, lane.stream);
+    if (status == TC_OK && !(direct_ngal && direct_second))
+      status = lane.out.reserve((ngal_count + second_count) * 8, lane.stream);
+    if (status != TC_OK) return status;
+    const double* d_theta = direct_in ? (const double*)theta_seen
+                                      : (const double*)lane.in_theta.ptr;
+    double* d_ngal = direct_ngal ? (double*)ngal_seen : (double*)lane.out.ptr;
+    double* d_second = direct_second ? (double*)second_seen
+                                     : (double*)lane.out.ptr + ngal_count;
+    if (!direct_in) {
+      Range range("upload");
+      TC_HIP(hipMemcpyAsync(lane.in_theta.ptr, theta, theta_bytes, hipMemcpyHostToDevice,
+                            lane.stream));
+    }
+    const bool saved_chain = t->chain;
+    t->async_lane = lane_index;
+    t->chain = false;
+    status = chi2 ? tc_chi2_zheng07_batch_device(t, d_theta, n_theta, n_draws, n_gauss, flags,
+                                                 data, precision, d_ngal, d_second)
+                  : tc_predict_zheng07_batch_device(t, d_theta, n_theta, n_draws, n_gauss,
+                                                    flags, d_ngal, d_second);
+    t->async_lane = -1;
+    t->chain = saved_chain;
+    if (status != TC_OK) return status;
+    Range range("download");
+    if (!direct_ngal && !direct_second && second == ngal + ngal_count) {
+      // (adjacent in the caller's memory as in the staging buffer: one command)
+      TC_HIP(hipMemcpyAsync(ngal, d_ngal, (ngal_count + second_count) * 8,
+                            hipMemcpyDeviceToHost, lane.stream));
+    } else {
+      if (!direct_ngal)
+        TC_HIP(hipMemcpyAsync(ngal, d_ngal, ngal_count * 8, hipMemcpyDeviceToHost,
+                              lane.stream));
+      if (!direct_second)
+        TC_HIP(hipMemcpyAsync(second, d_second, second_count * 8, hipMemcpyDeviceToHost,
+                              lane.stream));
+    }
+  }
+  status = next_ticket(t, &ticket);
+  if (status != TC_OK) return status;
+  TC_HIP(hipEventRecord(ticket->done, lane.stream));
+  *ticket_out = ticket->id;
+  return TC_OK;
+}
+
+}  // namespace
+
+int tc_predict_zheng07_batch_async(tc_table* t, const double* theta, int n_theta,
+                                   int64_t n_draws, int n_gauss, unsigned flags, double* ngal,
+                                   double* xi, int64_t* ticket) {
+  return predict_async(t, theta, n_theta, n_draws, n_gauss, flags, nullptr, nullptr, ngal, xi,
+                       false, ticket);
+}
+
+int tc_chi2_zheng07_batch_async(tc_table* t, const double* theta, int n_theta, int64_t n_draws,
+                                int n_gauss, unsigned flags, const double* data,
+                                const double* precision, double* ngal, double* chi2,
+                                int64_t* ticket) {
+  return predict_async(t, theta, n_theta, n_draws, n_gauss, flags, data, precision, ngal, chi2,
+                       true, ticket);
+}
+
+int tc_table_wait(tc_table* t, int64_t ticket) {
+  TC_CHECK(t != nullptr, "table handle is NULL");
+  TC_CHECK(ticket >= 0 && ticket < t->next_ticket, "unknown ticket %lld", (long long)ticket);
+  const tc_table::Ticket& slot = t->tickets[ticket % tc_table::kMaxTickets];
+  if (slot.id == ticket) {
+    TC_HIP(hipEventSynchronize(slot.done));
+    return TC_OK;
+  }
+  // the slot was reused: the ticket is older than the work now queued on every lane
+  return tc_table_synchronize(t);
+}
+
+int tc_table_query(tc_table* t, int64_t ticket, int* done) {
+  TC_CHECK(t != nullptr && done != nullptr, "NULL argument");
+  TC_CHECK(ticket >= 0 && ticket < t->next_ticket, "unknown ticket %lld", (long long)ticket);
+  const tc_table::Ticket& slot = t->tickets[ticket % tc_table::kMaxTickets];
+  *done = 0;
+  if (slot.id == ticket) {
+    const hipError_t state = hipEventQuery(slot.done);
+    if (state == hipSuccess) *done = 1;
+    else if (state != hipErrorNotReady)
+      return fail(TC_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(state));
+    return TC_OK;
+  }
+  // a reused slot: done once every lane has passed its own later tickets
+  *done = 1;
+  for (tc_table::Lane& lane : t->lanes) {
+    if (lane.stream == nullptr) continue;
+    const hipError_t state = hipStreamQuery(lane.stream);
+    if (state == hipErrorNotReady) *done = 0;
+    else if (state != hipSuccess)
+      return fail(TC_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(state));
+  }
+  return TC_OK;
 }
 
 int tc_mean_occupation_zheng07_batch(tc_table* t, const double* theta, int n_theta,
@@ -596,9 +756,30 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
   } else if (key == "lanes") {
     TC_CHECK(value >= 1 && value <= (int)tc_table::kMaxLanes, "lanes must be in [1, %d]",
              (int)tc_table::kMaxLanes);
-    for (tc_table::Lane& lane : t->lanes) TC_HIP(hipStreamSynchronize(lane.stream));
+    for (tc_table::Lane& lane : t->lanes)
+      if (lane.stream) TC_HIP(hipStreamSynchronize(lane.stream));
+    for (int l = 0; l < value; ++l) {
+      if (t->lanes[l].stream != nullptr) continue;
+      TC_HIP(hipStreamCreateWithFlags(&t->lanes[l].stream, hipStreamNonBlocking));
+      TC_HIP(hipEventCreateWithFlags(&t->lanes[l].finished, hipEventDisableTiming));
+    }
     t->tuning.lanes = t->n_lanes = value;
     t->prev = -1;
+  } else if (key == "ordered") {
+    // 1 (default): results of consecutive device-pointer calls appear in call order (the
+    // finalisations of the lanes are chained by events); 0: every call only orders its own
+    // kernels -- callers that give every call its own output buffers (bench.py's results
+    // ring) lose nothing, and tc_comm_gather then waits for every lane
+    for (tc_table::Lane& lane : t->lanes)
+      if (lane.stream) TC_HIP(hipStreamSynchronize(lane.stream));
+    t->chain = value != 0;
+    t->prev = -1;
+  } else if (key == "async_direct_in" || key == "async_direct_out") {
+    // asynchronous host calls: 1 = the kernels read the draws from / write the results to
+    // the caller's page-locked buffers themselves; 0 = copy commands on the lane's stream
+    // (async_direct_out 2: only the number densities directly, xi by copy command)
+    (key == "async_direct_in" ? t->tuning.async_direct_in : t->tuning.async_direct_out) =
+        value;
   } else if (key == "single_draw") {
     t->tuning.single_draw = value != 0;
   } else if (key == "trace") {
@@ -619,7 +800,8 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
                                                 : t->tuning.prio_finalize) = value;
   } else if (key == "quad_merge" || key == "quad_waves" || key == "quad_order") {
     // developer A/B of the quadratic-form schedule: schedules are rebuilt on demand
-    for (tc_table::Lane& lane : t->lanes) TC_HIP(hipStreamSynchronize(lane.stream));
+    for (tc_table::Lane& lane : t->lanes)
+      if (lane.stream) TC_HIP(hipStreamSynchronize(lane.stream));
     if (key == "quad_merge") t->tuning.quad_merge = value != 0;
     else if (key == "quad_order") t->tuning.quad_order = value;
     else t->tuning.quad_waves = value;
@@ -642,7 +824,7 @@ int tc_table_timer_begin(tc_table* t, int profile_kernels) {
 int tc_table_timer_end(tc_table* t, float* elapsed_ms) {
   TC_CHECK(t != nullptr && elapsed_ms != nullptr, "NULL argument");
   for (int l = 1; l < tc_table::kMaxLanes; ++l)
-    TC_HIP(hipStreamSynchronize(t->lanes[l].stream));
+    if (t->lanes[l].stream) TC_HIP(hipStreamSynchronize(t->lanes[l].stream));
   TC_HIP(hipEventRecord(t->ev_end, t->stream));
   TC_HIP(hipEventSynchronize(t->ev_end));
   TC_HIP(hipEventElapsedTime(elapsed_ms, t->ev_begin, t->ev_end));
@@ -669,7 +851,8 @@ int tc_debug_trace(tc_table* t, uint64_t* out, int64_t capacity, int64_t* n_bloc
   TC_CHECK(t != nullptr && n_blocks != nullptr, "NULL argument");
   *n_blocks = (int64_t)t->trace_blocks;
   if (out == nullptr || t->trace.ptr == nullptr) return TC_OK;
-  for (tc_table::Lane& lane : t->lanes) TC_HIP(hipStreamSynchronize(lane.stream));
+  for (tc_table::Lane& lane : t->lanes)
+      if (lane.stream) TC_HIP(hipStreamSynchronize(lane.stream));
   const int64_t n = std::min<int64_t>(capacity, (int64_t)t->trace_blocks);
   TC_HIP(hipMemcpy(out, t->trace.ptr, (size_t)n * 6 * sizeof(uint64_t),
                    hipMemcpyDeviceToHost));
@@ -680,7 +863,8 @@ int tc_debug_wave_trace(tc_table* t, uint64_t* out, int64_t capacity, int64_t* n
   TC_CHECK(t != nullptr && n_waves != nullptr, "NULL argument");
   *n_waves = (int64_t)t->wave_trace_count;
   if (out == nullptr || t->wave_trace.ptr == nullptr) return TC_OK;
-  for (tc_table::Lane& lane : t->lanes) TC_HIP(hipStreamSynchronize(lane.stream));
+  for (tc_table::Lane& lane : t->lanes)
+      if (lane.stream) TC_HIP(hipStreamSynchronize(lane.stream));
   const int64_t n = std::min<int64_t>(capacity, (int64_t)t->wave_trace_count);
   TC_HIP(hipMemcpy(out, t->wave_trace.ptr, (size_t)n * 6 * sizeof(uint64_t),
                    hipMemcpyDeviceToHost));

@@ -15,10 +15,12 @@ reference's scalar signature.
 """
 
 import ctypes
+import threading
 
 import numpy as np
 
 from . import _lib
+from . import pinned
 from .galtable import GalTypeTable
 from .models import device_spec
 from .tabcorr import TabCorr, XI_KEYS, NGAL_KEYS, _flags, _unbatch
@@ -60,6 +62,8 @@ class _DeviceInterpolator:
         self.handle = handle
         self.lib = lib
         self.tables = devices          # keep the table handles alive
+        # one host thread at a time per handle (see tabcorr._DeviceTable)
+        self.lock = threading.Lock()
         # scratch of the un-batched predict(model) path (see
         # tabcorr._DeviceTable.predict_one)
         self._one_theta = np.zeros(16)
@@ -72,14 +76,15 @@ class _DeviceInterpolator:
 
     def predict_one(self, theta, x, n_gauss_prim, flags):
         n_theta = len(theta)
-        self._one_theta[:n_theta] = theta
-        self._one_x[:] = x
-        p_theta, p_x, p_ngal, p_xi = self._one_pointers
-        status = self._one_call(self.handle, p_theta, n_theta, p_x, 1,
-                                n_gauss_prim, flags, p_ngal, p_xi)
-        if status:
-            _lib.check(status)
-        return self._one_ngal[0], self._one_xi.copy()
+        with self.lock:
+            self._one_theta[:n_theta] = theta
+            self._one_x[:] = x
+            p_theta, p_x, p_ngal, p_xi = self._one_pointers
+            status = self._one_call(self.handle, p_theta, n_theta, p_x, 1,
+                                    n_gauss_prim, flags, p_ngal, p_xi)
+            if status:
+                _lib.check(status)
+            return self._one_ngal[0], self._one_xi.copy()
 
     def __del__(self):
         handle = getattr(self, 'handle', None)
@@ -239,10 +244,17 @@ class Interpolator:
     def predict_batch(self, theta, x, separate_gal_type=False,
                       n_gauss_prim=10, extrapolate=False,
                       modulate_with_cenocc=False, assembias=False,
-                      family='zheng07'):
+                      family='zheng07', out=None):
         """`predict` for ``(n_draws, 5 | 7)`` Zheng07 parameters ``theta`` and
         ``(n_draws, n_dim)`` values ``x`` of the extra parameters (columns in
-        the order of ``self.keys``)."""
+        the order of ``self.keys``).  ``out=(ngal, xi)``: page-locked arrays
+        that receive the results (see `TabCorr.predict_batch`)."""
+        if out is not None:
+            return self.predict_batch_async(
+                theta, x, separate_gal_type=separate_gal_type,
+                n_gauss_prim=n_gauss_prim, extrapolate=extrapolate,
+                modulate_with_cenocc=modulate_with_cenocc,
+                assembias=assembias, family=family, out=out).wait()
         theta = _lib.contiguous(np.atleast_2d(theta))
         x = _lib.contiguous(np.atleast_2d(x))
         if x.shape != (len(theta), len(self.keys)):
@@ -257,11 +269,82 @@ class Interpolator:
         n_comp = table.n_components if separate_gal_type else 1
         ngal = np.empty((n_draws, 2 if separate_gal_type else 1))
         xi = np.empty((n_draws, n_comp, table.n_r))
-        _lib.check(device.lib.tc_interp_predict_zheng07_batch(
-            device.handle, _lib.as_double_p(theta), theta.shape[1],
-            _lib.as_double_p(x), n_draws, n_gauss_prim, flags,
-            _lib.as_double_p(ngal), _lib.as_double_p(xi)))
+        with device.lock:
+            _lib.check(device.lib.tc_interp_predict_zheng07_batch(
+                device.handle, _lib.as_double_p(theta), theta.shape[1],
+                _lib.as_double_p(x), n_draws, n_gauss_prim, flags,
+                _lib.as_double_p(ngal), _lib.as_double_p(xi)))
         return self.tabcorr_list[0]._package(ngal, xi, separate_gal_type)
+
+    def _async_inputs(self, theta, x, extrapolate):
+        theta = _lib.contiguous(np.atleast_2d(theta))
+        x = _lib.contiguous(np.atleast_2d(x))
+        if x.shape != (len(theta), len(self.keys)):
+            raise ValueError('x must have shape (n_draws, {}).'.format(
+                len(self.keys)))
+        self._check_range(x, extrapolate)
+        return theta, x
+
+    def predict_batch_async(self, theta, x, separate_gal_type=False,
+                            n_gauss_prim=10, extrapolate=False,
+                            modulate_with_cenocc=False, assembias=False,
+                            family='zheng07', out=None):
+        """`predict_batch` without waiting for the device (see
+        `TabCorr.predict_batch_async`): returns a
+        `tabcorr_amd.pinned.PendingPrediction`."""
+        theta, x = self._async_inputs(theta, x, extrapolate)
+        device = self.to_device()
+        table = device.tables[0]
+        flags = _flags(separate_gal_type, modulate_with_cenocc, assembias,
+                       family)
+        n_draws = len(theta)
+        n_comp = table.n_components if separate_gal_type else 1
+        shapes = [(n_draws, 2 if separate_gal_type else 1),
+                  (n_draws, n_comp, table.n_r)]
+        (ngal, xi), pooled_out = pinned.stage_outputs(shapes, out)
+        (theta_p, x_p), pooled_in = pinned.stage_inputs([theta, x])
+        ticket = ctypes.c_int64(-1)
+        with device.lock:
+            _lib.check(device.lib.tc_interp_predict_zheng07_batch_async(
+                device.handle, _lib.as_double_p(theta_p), theta.shape[1],
+                _lib.as_double_p(x_p), n_draws, n_gauss_prim, flags,
+                _lib.as_double_p(ngal), _lib.as_double_p(xi),
+                ctypes.byref(ticket)))
+        first = self.tabcorr_list[0]
+        return pinned.PendingPrediction(
+            device, device.lib.tc_interp_wait, None, ticket.value,
+            [theta_p, x_p], [ngal, xi], pooled_in, pooled_out,
+            lambda n, v: first._package(n, v, separate_gal_type))
+
+    def chi2_batch_async(self, theta, x, data, precision, n_gauss_prim=10,
+                         extrapolate=False, modulate_with_cenocc=False,
+                         assembias=False, family='zheng07', out=None):
+        """`chi2_batch` without waiting for the device."""
+        theta, x = self._async_inputs(theta, x, extrapolate)
+        device = self.to_device()
+        n_r = device.tables[0].n_r
+        data = _lib.contiguous(np.ravel(data))
+        precision = _lib.contiguous(precision)
+        if data.shape != (n_r, ) or precision.shape != (n_r, n_r):
+            raise ValueError('data must have {0} entries and precision shape '
+                             '({0}, {0}).'.format(n_r))
+        n_draws = len(theta)
+        (ngal, chi2), pooled_out = pinned.stage_outputs(
+            [(n_draws, ), (n_draws, )], out)
+        (theta_p, x_p), pooled_in = pinned.stage_inputs([theta, x])
+        ticket = ctypes.c_int64(-1)
+        with device.lock:
+            _lib.check(device.lib.tc_interp_chi2_zheng07_batch_async(
+                device.handle, _lib.as_double_p(theta_p), theta.shape[1],
+                _lib.as_double_p(x_p), n_draws, n_gauss_prim,
+                _flags(False, modulate_with_cenocc, assembias, family),
+                _lib.as_double_p(data), _lib.as_double_p(precision),
+                _lib.as_double_p(ngal), _lib.as_double_p(chi2),
+                ctypes.byref(ticket)))
+        return pinned.PendingPrediction(
+            device, device.lib.tc_interp_wait, None, ticket.value,
+            [theta_p, x_p], [ngal, chi2], pooled_in, pooled_out,
+            lambda n, c: (n, c))
 
     def chi2_batch(self, theta, x, data, precision, n_gauss_prim=10,
                    extrapolate=False, modulate_with_cenocc=False,
@@ -290,12 +373,13 @@ class Interpolator:
                              '({0}, {0}).'.format(n_r))
         ngal = np.empty(len(theta))
         chi2 = np.empty(len(theta))
-        _lib.check(device.lib.tc_interp_chi2_zheng07_batch(
-            device.handle, _lib.as_double_p(theta), theta.shape[1],
-            _lib.as_double_p(x), len(theta), n_gauss_prim,
-            _flags(False, modulate_with_cenocc, assembias, family),
-            _lib.as_double_p(data), _lib.as_double_p(precision),
-            _lib.as_double_p(ngal), _lib.as_double_p(chi2)))
+        with device.lock:
+            _lib.check(device.lib.tc_interp_chi2_zheng07_batch(
+                device.handle, _lib.as_double_p(theta), theta.shape[1],
+                _lib.as_double_p(x), len(theta), n_gauss_prim,
+                _flags(False, modulate_with_cenocc, assembias, family),
+                _lib.as_double_p(data), _lib.as_double_p(precision),
+                _lib.as_double_p(ngal), _lib.as_double_p(chi2)))
         return ngal, chi2
 
     # -- generic models: host callbacks + device contraction per table -----------------

@@ -19,13 +19,12 @@ Extensions beyond the reference (the reason to use a GPU at all):
 
 import ctypes
 import sys
-import itertools
-import json
-import os
+import threading
 
 import numpy as np
 
 from . import _lib
+from . import pinned
 from .galtable import GalTypeTable
 from .models import device_spec
 
@@ -86,6 +85,10 @@ class _DeviceTable:
         self.n_r = matrix.shape[0]
         self.n_components = 3 if mode == 'auto' else 2
         self.compute_dtype = compute_dtype
+        # A handle serves one host thread at a time (include/tabcorr_amd.h);
+        # ctypes releases the GIL during a call, so every call on this handle
+        # -- and the scratch arrays of predict_one -- sits behind this lock.
+        self.lock = threading.Lock()
         # scratch of the un-batched predict(model) path: one draw in, one
         # (ngal, xi) out, with the ctypes pointers made once
         self._one_theta = np.zeros(16)
@@ -101,13 +104,14 @@ class _DeviceTable:
         one ``predict`` per MCMC step, ``README.md:72-75``) with as little
         Python between the caller and the C ABI as possible."""
         n_theta = len(theta)
-        self._one_theta[:n_theta] = theta
-        p_theta, p_ngal, p_xi = self._one_pointers
-        status = self._one_call(self.handle, p_theta, n_theta, 1, n_gauss_prim,
-                                flags, p_ngal, p_xi)
-        if status:
-            _lib.check(status)
-        return self._one_ngal[0], self._one_xi.copy()
+        with self.lock:
+            self._one_theta[:n_theta] = theta
+            p_theta, p_ngal, p_xi = self._one_pointers
+            status = self._one_call(self.handle, p_theta, n_theta, 1,
+                                    n_gauss_prim, flags, p_ngal, p_xi)
+            if status:
+                _lib.check(status)
+            return self._one_ngal[0], self._one_xi.copy()
 
     def __del__(self):
         handle = getattr(self, 'handle', None)
@@ -333,9 +337,11 @@ class TabCorr:
         theta = _lib.contiguous(np.atleast_2d(theta))
         flags = _flags(False, modulate_with_cenocc, assembias, family)
         occupation = np.empty((len(theta), device.n_bins))
-        _lib.check(device.lib.tc_mean_occupation_zheng07_batch(
-            device.handle, _lib.as_double_p(theta), theta.shape[1],
-            len(theta), n_gauss_prim, flags, _lib.as_double_p(occupation)))
+        with device.lock:
+            _lib.check(device.lib.tc_mean_occupation_zheng07_batch(
+                device.handle, _lib.as_double_p(theta), theta.shape[1],
+                len(theta), n_gauss_prim, flags,
+                _lib.as_double_p(occupation)))
         return occupation
 
     # -- predict ---------------------------------------------------------------------
@@ -384,15 +390,26 @@ class TabCorr:
 
     def predict_batch(self, theta, separate_gal_type=False, n_gauss_prim=10,
                       modulate_with_cenocc=False, assembias=False,
-                      family='zheng07'):
+                      family='zheng07', out=None):
         """`predict` for a ``(n_draws, 5 | 7)`` array of Zheng07 parameters
         (``family='leauthaud11'``: 13 columns, see `mean_occupation_batch`).
+
+        ``out=(ngal, xi)``: page-locked float64 arrays
+        (`tabcorr_amd.pinned_empty`) of ``n_draws [* 2]`` and
+        ``n_draws * n_components * n_r`` elements that receive the results
+        without an intermediate copy; the returned arrays are views of them.
 
         Returns
         -------
         ngal : numpy.ndarray ``(n_draws, )`` or dict of such
         xi : numpy.ndarray ``(n_draws, ) + tpcf_shape`` or dict of such
         """
+        if out is not None:
+            return self.predict_batch_async(
+                theta, separate_gal_type=separate_gal_type,
+                n_gauss_prim=n_gauss_prim,
+                modulate_with_cenocc=modulate_with_cenocc,
+                assembias=assembias, family=family, out=out).wait()
         device = self.to_device()
         theta = _lib.contiguous(np.atleast_2d(theta))
         flags = _flags(separate_gal_type, modulate_with_cenocc, assembias,
@@ -401,11 +418,49 @@ class TabCorr:
         n_comp = device.n_components if separate_gal_type else 1
         ngal = np.empty((n_draws, 2 if separate_gal_type else 1))
         xi = np.empty((n_draws, n_comp, device.n_r))
-        _lib.check(device.lib.tc_predict_zheng07_batch(
-            device.handle, _lib.as_double_p(theta), theta.shape[1], n_draws,
-            n_gauss_prim, flags, _lib.as_double_p(ngal),
-            _lib.as_double_p(xi)))
+        with device.lock:
+            _lib.check(device.lib.tc_predict_zheng07_batch(
+                device.handle, _lib.as_double_p(theta), theta.shape[1],
+                n_draws, n_gauss_prim, flags, _lib.as_double_p(ngal),
+                _lib.as_double_p(xi)))
         return self._package(ngal, xi, separate_gal_type)
+
+    def predict_batch_async(self, theta, separate_gal_type=False,
+                            n_gauss_prim=10, modulate_with_cenocc=False,
+                            assembias=False, family='zheng07', out=None):
+        """`predict_batch` without waiting for the device: the upload of the
+        draws, the kernels and the download of the results are queued on one
+        of the handle's lanes and a `tabcorr_amd.pinned.PendingPrediction` is
+        returned; ``.wait()`` gives what `predict_batch` returns.  Calls made
+        before the previous ones were waited for overlap on the device
+        (transfers of one call with kernels of the next).
+
+        For the full rate keep ``theta`` and ``out`` in page-locked arrays
+        (`tabcorr_amd.pinned_empty`): pageable ``theta`` is copied to a pooled
+        pinned block first, and without ``out`` the results are copied out of
+        one at ``wait()``.  Do not modify a pinned ``theta`` or read ``out``
+        before ``wait()`` returned.
+        """
+        device = self.to_device()
+        theta = _lib.contiguous(np.atleast_2d(theta))
+        flags = _flags(separate_gal_type, modulate_with_cenocc, assembias,
+                       family)
+        n_draws = len(theta)
+        n_comp = device.n_components if separate_gal_type else 1
+        shapes = [(n_draws, 2 if separate_gal_type else 1),
+                  (n_draws, n_comp, device.n_r)]
+        (ngal, xi), pooled_out = pinned.stage_outputs(shapes, out)
+        (theta_pinned, ), pooled_in = pinned.stage_inputs([theta])
+        ticket = ctypes.c_int64(-1)
+        with device.lock:
+            _lib.check(device.lib.tc_predict_zheng07_batch_async(
+                device.handle, _lib.as_double_p(theta_pinned), theta.shape[1],
+                n_draws, n_gauss_prim, flags, _lib.as_double_p(ngal),
+                _lib.as_double_p(xi), ctypes.byref(ticket)))
+        return pinned.PendingPrediction(
+            device, device.lib.tc_table_wait, device.lib.tc_table_query,
+            ticket.value, [theta_pinned], [ngal, xi], pooled_in, pooled_out,
+            lambda n, x: self._package(n, x, separate_gal_type))
 
     def chi2_batch(self, theta, data, precision, n_gauss_prim=10,
                    modulate_with_cenocc=False, assembias=False,
@@ -434,13 +489,46 @@ class TabCorr:
                              '({0}, {0}).'.format(device.n_r))
         ngal = np.empty(len(theta))
         chi2 = np.empty(len(theta))
-        _lib.check(device.lib.tc_chi2_zheng07_batch(
-            device.handle, _lib.as_double_p(theta), theta.shape[1], len(theta),
-            n_gauss_prim,
-            _flags(False, modulate_with_cenocc, assembias, family),
-            _lib.as_double_p(data), _lib.as_double_p(precision),
-            _lib.as_double_p(ngal), _lib.as_double_p(chi2)))
+        with device.lock:
+            _lib.check(device.lib.tc_chi2_zheng07_batch(
+                device.handle, _lib.as_double_p(theta), theta.shape[1],
+                len(theta), n_gauss_prim,
+                _flags(False, modulate_with_cenocc, assembias, family),
+                _lib.as_double_p(data), _lib.as_double_p(precision),
+                _lib.as_double_p(ngal), _lib.as_double_p(chi2)))
         return ngal, chi2
+
+    def chi2_batch_async(self, theta, data, precision, n_gauss_prim=10,
+                         modulate_with_cenocc=False, assembias=False,
+                         family='zheng07', out=None):
+        """`chi2_batch` without waiting (see `predict_batch_async`): 8 bytes
+        per parameter go to the device and 16 bytes per draw come back.
+        ``out=(ngal, chi2)``: page-locked arrays of ``n_draws`` elements."""
+        device = self.to_device()
+        theta = _lib.contiguous(np.atleast_2d(theta))
+        data = _lib.contiguous(np.ravel(data))
+        precision = _lib.contiguous(precision)
+        if data.shape != (device.n_r, ) or precision.shape != (device.n_r,
+                                                               device.n_r):
+            raise ValueError('data must have {0} entries and precision shape '
+                             '({0}, {0}).'.format(device.n_r))
+        n_draws = len(theta)
+        (ngal, chi2), pooled_out = pinned.stage_outputs(
+            [(n_draws, ), (n_draws, )], out)
+        (theta_pinned, ), pooled_in = pinned.stage_inputs([theta])
+        ticket = ctypes.c_int64(-1)
+        with device.lock:
+            _lib.check(device.lib.tc_chi2_zheng07_batch_async(
+                device.handle, _lib.as_double_p(theta_pinned), theta.shape[1],
+                n_draws, n_gauss_prim,
+                _flags(False, modulate_with_cenocc, assembias, family),
+                _lib.as_double_p(data), _lib.as_double_p(precision),
+                _lib.as_double_p(ngal), _lib.as_double_p(chi2),
+                ctypes.byref(ticket)))
+        return pinned.PendingPrediction(
+            device, device.lib.tc_table_wait, device.lib.tc_table_query,
+            ticket.value, [theta_pinned], [ngal, chi2], pooled_in, pooled_out,
+            lambda n, c: (n, c))
 
     def _predict_occupation(self, occupation, separate_gal_type):
         device = self.to_device()
@@ -454,10 +542,11 @@ class TabCorr:
         n_comp = device.n_components if separate_gal_type else 1
         ngal = np.empty((n_draws, 2 if separate_gal_type else 1))
         xi = np.empty((n_draws, n_comp, device.n_r))
-        _lib.check(device.lib.tc_predict_occupation_batch(
-            device.handle, _lib.as_double_p(occupation), n_draws,
-            _flags(separate_gal_type), _lib.as_double_p(ngal),
-            _lib.as_double_p(xi)))
+        with device.lock:
+            _lib.check(device.lib.tc_predict_occupation_batch(
+                device.handle, _lib.as_double_p(occupation), n_draws,
+                _flags(separate_gal_type), _lib.as_double_p(ngal),
+                _lib.as_double_p(xi)))
         return self._package(ngal, xi, separate_gal_type)
 
     def _package(self, ngal, xi, separate_gal_type):

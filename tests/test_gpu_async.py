@@ -1,0 +1,210 @@
+"""The asynchronous host-to-host entry points (tc_*_async, tc_table_wait, page-locked
+buffers): parity with the synchronous path, the golden vectors and the oracle; results land
+in the buffers of the right ticket whatever the order of the waits.  Needs an MI355X."""
+
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+from util import load_golden, table_from_golden, interpolator_tables_from_golden, assert_rel
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+def make_tabcorr(table, **kwargs):
+    from tabcorr_amd import TabCorr
+    return TabCorr.from_arrays(table['gal_type'], table['tpcf_matrix'],
+                               table['tpcf_shape'], table['attrs'], **kwargs)
+
+
+def test_pinned_arrays():
+    from tabcorr_amd import pinned_empty, pinned_array, is_pinned, pin
+    a = pinned_empty((7, 3))
+    assert a.shape == (7, 3) and a.dtype == np.float64 and a.flags.c_contiguous
+    assert is_pinned(a) and is_pinned(a[2:5])
+    assert not is_pinned(np.zeros(4))
+    b = pinned_array(np.arange(12.0).reshape(3, 4))
+    assert is_pinned(b) and np.array_equal(b, np.arange(12.0).reshape(3, 4))
+    own = np.zeros((1000, 5))
+    with pin(own) as same:
+        assert same is own and is_pinned(own)
+    assert not is_pinned(own)
+    view = a[1]
+    del a                      # views keep the allocation alive
+    view[:] = 1.0
+    assert is_pinned(view)
+
+
+def test_async_matches_golden_and_sync():
+    from tabcorr_amd import pinned_array, pinned_empty
+    data = load_golden('synthetic_cfg2')
+    table = table_from_golden(data)
+    halotab = make_tabcorr(table)
+    theta = pinned_array(data['theta'])
+    n = len(theta)
+    n_r = int(np.prod(table['tpcf_shape']))
+    ngal, xi = pinned_empty(n), pinned_empty((n, n_r))
+    pending = halotab.predict_batch_async(theta, out=(ngal, xi))
+    got_ngal, got_xi = pending.wait()
+    assert pending.done()
+    assert np.shares_memory(got_xi, xi) and np.shares_memory(got_ngal, ngal)
+    assert_rel(got_ngal, data['ngal'], RTOL, 'ngal')
+    assert_rel(got_xi, data['xi'], RTOL, 'xi')
+    # out= through the synchronous signature
+    ngal[:] = 0
+    xi[:] = 0
+    again = halotab.predict_batch(theta, out=(ngal, xi))
+    assert_rel(again[1], data['xi'], RTOL)
+    # separated by galaxy type
+    ngal2, xi3 = pinned_empty((n, 2)), pinned_empty((n, 3, n_r))
+    n_sep, x_sep = halotab.predict_batch_async(theta, separate_gal_type=True,
+                                               out=(ngal2, xi3)).wait()
+    for key in n_sep:
+        assert_rel(n_sep[key], data['ngal_sep_' + key], RTOL, key)
+    for key in x_sep:
+        assert_rel(x_sep[key], data['xi_sep_' + key], RTOL, key)
+    # pageable theta, no out: pooled pinned staging, results copied out
+    plain = halotab.predict_batch_async(np.array(data['theta'])).wait()
+    assert_rel(plain[0], data['ngal'], RTOL)
+    assert_rel(plain[1], data['xi'], RTOL)
+    # the likelihood
+    rng = np.random.default_rng(0)
+    vector = data['xi'][0] * 1.1
+    a = rng.normal(size=(n_r, n_r))
+    precision = a @ a.T / np.mean(vector)**2
+    expect = np.einsum('bi,ij,bj->b', data['xi'] - vector, precision, data['xi'] - vector)
+    n_chi, chi2 = halotab.chi2_batch_async(theta, vector, precision).wait()
+    assert_rel(n_chi, data['ngal'], RTOL)
+    assert_rel(chi2, expect, 1e-9)
+    sync = halotab.chi2_batch(theta, vector, precision)
+    assert_rel(chi2, sync[1], 1e-12)
+
+
+def test_tickets_deliver_into_their_own_buffers():
+    """Many calls in flight with different draws and batch sizes, waited for in reverse and
+    in shuffled order: every ticket's buffers hold that ticket's results (compared with the
+    oracle), and more than 64 pending tickets still resolve."""
+    from tabcorr_amd import pinned_array, pinned_empty, synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(12, 2, (7, ), 'auto', seed=5)
+    halotab = make_tabcorr(table)
+    sizes = [1, 64, 65, 700, 3, 1000, 129, 256, 31, 2048, 5, 77]
+    thetas = [pinned_array(synthetic.zheng07_draws(size, seed=40 + i))
+              for i, size in enumerate(sizes)]
+    outs = [(pinned_empty(size), pinned_empty((size, 7))) for size in sizes]
+    for ngal, xi in outs:
+        ngal[:] = np.nan
+        xi[:] = np.nan
+    pending = [halotab.predict_batch_async(theta, out=out)
+               for theta, out in zip(thetas, outs)]
+    order = list(reversed(range(len(sizes))))
+    for index in order:
+        ngal, xi = pending[index].wait()
+        expect = oracle.predict_zheng07_batch(table, thetas[index])
+        assert_rel(ngal, expect[0], RTOL, 'ngal of ticket %d' % index)
+        assert_rel(xi, expect[1], RTOL, 'xi of ticket %d' % index)
+    # second round: shuffled waits, then 100 small calls without waiting in between
+    pending = [halotab.predict_batch_async(theta, out=out)
+               for theta, out in zip(thetas, outs)]
+    for index in np.random.default_rng(1).permutation(len(sizes)):
+        ngal, xi = pending[index].wait()
+        expect = oracle.predict_zheng07_batch(table, thetas[index][:4])
+        assert_rel(xi[:4], expect[1], RTOL)
+    many_theta = [pinned_array(synthetic.zheng07_draws(3, seed=100 + i)) for i in range(100)]
+    many_out = [(pinned_empty(3), pinned_empty((3, 7))) for _ in range(100)]
+    many = [halotab.predict_batch_async(t, out=o) for t, o in zip(many_theta, many_out)]
+    for index in (0, 99, 50, 1, 98):
+        ngal, xi = many[index].wait()
+        expect = oracle.predict_zheng07_batch(table, many_theta[index])
+        assert_rel(xi, expect[1], RTOL, 'ticket %d of 100' % index)
+    for item in many:
+        item.wait()
+
+
+def test_async_rejects_pageable_buffers_and_bad_tickets():
+    from tabcorr_amd import _lib, pinned_array, pinned_empty, synthetic
+    table = synthetic.synthetic_table(6, 1, (5, ), 'auto', seed=2)
+    halotab = make_tabcorr(table)
+    device = halotab.to_device()
+    lib = device.lib
+    theta = synthetic.zheng07_draws(10, seed=3)
+    ngal, xi = np.empty(10), np.empty((10, 5))
+    ticket = ctypes.c_int64(-1)
+    status = lib.tc_predict_zheng07_batch_async(
+        device.handle, _lib.as_double_p(theta), 5, 10, 10, 0, _lib.as_double_p(ngal),
+        _lib.as_double_p(xi), ctypes.byref(ticket))
+    assert status == _lib.TC_ERR_INVALID
+    assert b'page-locked' in lib.tc_last_error()
+    with pytest.raises(ValueError, match='page-locked'):
+        halotab.predict_batch_async(theta, out=(ngal, xi))
+    with pytest.raises(ValueError, match='elements'):
+        halotab.predict_batch_async(theta, out=(pinned_empty(9), pinned_empty((10, 5))))
+    assert lib.tc_table_wait(device.handle, 12345) == _lib.TC_ERR_INVALID
+    # an empty batch gives a ticket that completes
+    empty = halotab.predict_batch_async(pinned_empty((0, 5)),
+                                        out=(pinned_empty(0), pinned_empty((0, 5))))
+    assert empty.wait()[1].shape == (0, 5)
+    # wrong number of columns
+    with pytest.raises(ValueError, match='columns'):
+        halotab.predict_batch_async(pinned_array(theta[:, :4]))
+
+
+def test_async_interpolator_matches_golden():
+    from tabcorr_amd import Interpolator, pinned_array, pinned_empty
+    data = load_golden('interp_2d_auto')
+    tables = interpolator_tables_from_golden(data)
+    keys = [str(k) for k in data['keys']]
+    interp = Interpolator([make_tabcorr(t) for t in tables],
+                          {k: data['points'][:, d] for d, k in enumerate(keys)})
+    theta, x = pinned_array(data['theta']), pinned_array(data['x'])
+    n = len(theta)
+    n_r = data['xi'].shape[1]
+    outs = [(pinned_empty(n), pinned_empty((n, n_r))) for _ in range(3)]
+    pending = [interp.predict_batch_async(theta, x, out=out) for out in outs]
+    for item in reversed(pending):
+        ngal, xi = item.wait()
+        assert_rel(ngal, data['ngal'], RTOL, 'ngal')
+        assert_rel(xi, data['xi'], RTOL, 'xi', floor=1e-12)
+    sync = interp.predict_batch(theta, x)
+    assert_rel(outs[0][1], sync[1], 1e-12)
+    vector = data['xi'][0] * 0.9
+    precision = np.eye(n_r) / np.mean(vector)**2
+    expect = np.einsum('bi,ij,bj->b', data['xi'] - vector, precision, data['xi'] - vector)
+    n_chi, chi2 = interp.chi2_batch_async(theta, x, vector, precision).wait()
+    assert_rel(chi2, expect, 1e-8)
+    assert_rel(n_chi, data['ngal'], RTOL)
+    with pytest.raises(ValueError):
+        interp.predict_batch_async(theta, x + 100.0)
+
+
+def test_threads_share_one_table():
+    """predict() from several threads on the same instance (a threaded sampler
+    pool): the handle and its scratch arrays sit behind a lock."""
+    from tabcorr_amd import Zheng07Model, synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(10, 1, (6, ), 'auto', seed=8)
+    halotab = make_tabcorr(table)
+    draws = synthetic.zheng07_draws(64, seed=9)
+    expect = oracle.predict_zheng07_batch(table, draws)
+    errors = []
+
+    def work(offset):
+        model = Zheng07Model()
+        for index in range(offset, 64, 4):
+            for key, value in zip(synthetic.ZHENG07_KEYS, draws[index]):
+                model.param_dict[key] = value
+            ngal, xi = halotab.predict(model)
+            if not (np.allclose(xi, expect[1][index], rtol=1e-10, atol=0) and
+                    np.isclose(ngal, expect[0][index], rtol=1e-10)):
+                errors.append(index)
+
+    threads = [threading.Thread(target=work, args=(k, )) for k in range(4)]
+    for thread in threads:
+        thread.start()
+    for thread in threads:
+        thread.join()
+    assert errors == []
