@@ -704,9 +704,158 @@ def golden_helpers():
     save('helpers', **arrays)
 
 
+# -- pair-count wrappers ------------------------------------------
+# Corrfunc is not installed anywhere in the image, so a stub ``Corrfunc.theory``
+# with an independent brute-force counter is injected; what the fixture pins is
+# the REFERENCE's own wrapper arithmetic (tabcorr/corrfunc.py:6-175: argument
+# handling, expected pair counts, the (npairs / n_exp - 1) forms) and its matrix
+# assembly (tabcorr/tabcorr.py:809-922: task list, the swap of the two samples
+# by size, symmetrisation, empty bins), driven through
+# ``tabcorr.corrfunc.wp`` / ``s_mu_tpcf`` / ``tabcorr.tabcorr.compute_tpcf_matrix``.
+
+def _stub_corrfunc():
+    """``Corrfunc.theory.DDrppi`` / ``DDsmu`` as documented (Corrfunc 2.x): ordered
+    pair counts in a periodic box -- an auto-count holds every pair twice --
+    per (rp, pi) or (s, mu) bin, rp / s edges compared squared, ``int(pimax)``
+    line-of-sight bins, result rows rp-major / s-major with a field
+    ``npairs``.  Written independently of oracle/paircount_oracle.py: one
+    point against all others, coordinate differences wrapped with the modulo
+    form, bins found with np.digitize."""
+    def wrap(d, box):
+        return (d + 0.5 * box) % box - 0.5 * box
+
+    def setup(x1, y1, z1, x2, y2, z2, boxsize):
+        a = np.stack([x1, y1, z1], axis=1).astype(np.float64)
+        b = a if x2 is None else np.stack([x2, y2, z2], axis=1).astype(
+            np.float64)
+        return a, b, np.broadcast_to(np.asarray(boxsize, np.float64), (3, ))
+
+    def ddrppi(autocorr, nthreads, pimax, binfile, X1, Y1, Z1, weights1=None,
+               periodic=True, boxsize=None, X2=None, Y2=None, Z2=None,
+               **kwargs):
+        assert periodic and (autocorr == 1) == (X2 is None)
+        a, b, box = setup(X1, Y1, Z1, X2, Y2, Z2, boxsize)
+        edges = np.asarray(binfile, dtype=np.float64)
+        n_rp, n_pi = len(edges) - 1, int(pimax)
+        counts = np.zeros((n_rp, n_pi), dtype=np.uint64)
+        for k in range(len(a)):
+            d = wrap(a[k] - b, box)
+            rp = np.sqrt(d[:, 0]**2 + d[:, 1]**2)
+            dz = np.abs(d[:, 2])
+            i_rp = np.digitize(rp, edges) - 1
+            i_pi = np.floor(dz * (n_pi / pimax)).astype(int)
+            good = (i_rp >= 0) & (i_rp < n_rp) & (dz < pimax) & (i_pi < n_pi)
+            if autocorr == 1 and edges[0] > 0:
+                good[k] = False
+            np.add.at(counts, (i_rp[good], i_pi[good]), 1)
+        out = np.zeros(n_rp * n_pi, dtype=[('rmin', 'f8'), ('rmax', 'f8'),
+                                           ('pimax', 'f8'), ('npairs', 'u8')])
+        out['npairs'] = counts.ravel()
+        return out
+
+    def ddsmu(autocorr, nthreads, binfile, mu_max, nmu_bins, X1, Y1, Z1,
+              weights1=None, periodic=True, boxsize=None, X2=None, Y2=None,
+              Z2=None, **kwargs):
+        assert periodic and mu_max == 1 and (autocorr == 1) == (X2 is None)
+        a, b, box = setup(X1, Y1, Z1, X2, Y2, Z2, boxsize)
+        edges = np.asarray(binfile, dtype=np.float64)
+        n_s = len(edges) - 1
+        counts = np.zeros((n_s, nmu_bins), dtype=np.uint64)
+        for k in range(len(a)):
+            d = wrap(a[k] - b, box)
+            sep = np.sqrt(np.sum(d**2, axis=1))
+            with np.errstate(invalid='ignore', divide='ignore'):
+                mu = np.where(sep > 0, np.abs(d[:, 2]) / sep, 0.0)
+            i_s = np.digitize(sep, edges) - 1
+            i_mu = np.floor(mu * nmu_bins).astype(int)
+            good = (i_s >= 0) & (i_s < n_s) & (mu < 1.0) & (i_mu < nmu_bins)
+            if autocorr == 1 and edges[0] > 0:
+                good[k] = False
+            np.add.at(counts, (i_s[good], i_mu[good]), 1)
+        out = np.zeros(n_s * nmu_bins, dtype=[('smin', 'f8'), ('smax', 'f8'),
+                                              ('npairs', 'u8')])
+        out['npairs'] = counts.ravel()
+        return out
+
+    package = types.ModuleType('Corrfunc')
+    theory = types.ModuleType('Corrfunc.theory')
+    theory.DDrppi = ddrppi
+    theory.DDsmu = ddsmu
+    package.theory = theory
+    sys.modules['Corrfunc'] = package
+    sys.modules['Corrfunc.theory'] = theory
+
+
+def golden_paircount():
+    _stub_corrfunc()
+    from tabcorr import corrfunc as ref_corrfunc
+    from tabcorr.tabcorr import compute_tpcf_matrix
+    rng = np.random.default_rng(77)
+    period = np.array([60.0, 70.0, 80.0])
+    # clustered points: a pair-count signal in every bin
+    centres = rng.uniform(0, 1, (40, 3)) * period
+    def sample(n):
+        return np.mod(centres[rng.integers(0, len(centres), n)] +
+                      rng.normal(0, 2.5, (n, 3)), period)
+    # halo/galaxy bins of unequal size (the swap at tabcorr.py:837-838 is hit
+    # in both directions) and one empty bin (dropped from the task list, :888)
+    sizes = [150, 40, 0, 220, 90]
+    pos = [sample(n) for n in sizes]
+    particles = sample(400)
+    rp_bins = np.array([0.4, 1.0, 2.2, 4.5, 9.0])
+    pi_max = 12.0
+    s_bins = np.array([0.5, 1.5, 3.5, 8.0])
+    mu_bins = np.linspace(0, 1, 6)
+    arrays = {'period': period, 'sizes': np.array(sizes),
+              'pos': np.concatenate(pos), 'particles': particles,
+              'rp_bins': rp_bins, 'pi_max': np.array(pi_max),
+              's_bins': s_bins, 'mu_bins': mu_bins}
+    # the wrappers themselves: auto, cross, scalar period
+    arrays['wp_auto'] = ref_corrfunc.wp(pos[0], rp_bins, pi_max,
+                                        period=period)
+    arrays['wp_cross'] = ref_corrfunc.wp(
+        pos[0], rp_bins, pi_max, sample2=pos[3], period=period,
+        do_auto=False, do_cross=True)
+    cube = np.mod(pos[3], 60.0)
+    arrays['wp_auto_scalar_period'] = ref_corrfunc.wp(cube, rp_bins, pi_max,
+                                                      period=60.0)
+    arrays['smu_auto'] = ref_corrfunc.s_mu_tpcf(pos[0], s_bins, mu_bins,
+                                                period=period)
+    arrays['smu_cross'] = ref_corrfunc.s_mu_tpcf(
+        pos[0], s_bins, mu_bins, sample2=pos[3], period=period,
+        do_auto=False, do_cross=True)
+    for call in (lambda: ref_corrfunc.wp(pos[0], rp_bins, pi_max,
+                                         period=period, do_cross=True),
+                 lambda: ref_corrfunc.s_mu_tpcf(pos[0], s_bins,
+                                                np.array([0, 0.3, 1.0]),
+                                                period=period)):
+        try:
+            call()
+            raise RuntimeError('expected ValueError')
+        except ValueError:
+            pass
+    # the matrix assembly, as TabCorr.tabulate calls it (tabcorr.py:322-325)
+    cross_kwargs = dict(sample2=particles, do_auto=False, do_cross=True)
+    for name, tpcf, args in (
+            ('wp', ref_corrfunc.wp, (rp_bins, pi_max)),
+            ('smu', ref_corrfunc.s_mu_tpcf, (s_bins, mu_bins))):
+        matrix, shape = compute_tpcf_matrix('auto', pos, tpcf, period, args,
+                                            {}, num_threads=1)
+        arrays['matrix_auto_' + name] = matrix
+        arrays['shape_auto_' + name] = np.array(shape)
+        matrix, shape = compute_tpcf_matrix('cross', pos, tpcf, period, args,
+                                            cross_kwargs, num_threads=1)
+        arrays['matrix_cross_' + name] = matrix
+        arrays['shape_cross_' + name] = np.array(shape)
+    save('paircount_wrappers', **arrays)
+
+
 if __name__ == '__main__':
     if '--only-leauthaud11' in sys.argv:
         golden_leauthaud11()
+        sys.exit(0)
+    if '--only-paircount' in sys.argv:
+        golden_paircount()
         sys.exit(0)
     golden_helpers()
     golden_real_tables()
@@ -714,3 +863,4 @@ if __name__ == '__main__':
     golden_synthetic()
     golden_interpolators()
     golden_leauthaud11()
+    golden_paircount()

@@ -265,3 +265,43 @@ def test_s_mu_tabulation_matrix():
                                            np.full(3, 100.0), few_s, 4)
             assert np.array_equal(counts[:, :, a, b], expect), (a, b)
     assert counts[:, :, 1].sum() == 0 and counts.sum() > 1e6
+
+
+def test_wrappers_match_the_reference_fixture():
+    """HIP path against tests/golden/paircount_wrappers.npz, recorded from the REFERENCE's
+    tabcorr.corrfunc.wp / s_mu_tpcf / tabcorr.tabcorr.compute_tpcf_matrix over a stub
+    Corrfunc counter (make_golden.py: golden_paircount): the drop-in wrappers, and the
+    one-pass form of the matrix the tabulation swaps in for the reference's per-pair loop
+    (unequal bin sizes, an empty bin, auto and cross)."""
+    from tabcorr_amd import corrfunc
+    from util import load_golden
+    data = load_golden('paircount_wrappers')
+    offsets = np.concatenate([[0], np.cumsum(data['sizes'])])
+    pos = [data['pos'][a:b] for a, b in zip(offsets[:-1], offsets[1:])]
+    period, rp_bins, pi_max = data['period'], data['rp_bins'], float(data['pi_max'])
+    s_bins, mu_bins = data['s_bins'], data['mu_bins']
+    close = dict(rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(corrfunc.wp(pos[0], rp_bins, pi_max, period=period),
+                               data['wp_auto'], **close)
+    np.testing.assert_allclose(
+        corrfunc.wp(pos[0], rp_bins, pi_max, sample2=pos[3], period=period, do_auto=False,
+                    do_cross=True), data['wp_cross'], **close)
+    np.testing.assert_allclose(
+        corrfunc.wp(np.mod(pos[3], 60.0), rp_bins, pi_max, period=60.0),
+        data['wp_auto_scalar_period'], **close)
+    np.testing.assert_allclose(corrfunc.s_mu_tpcf(pos[0], s_bins, mu_bins, period=period),
+                               data['smu_auto'], **close)
+    np.testing.assert_allclose(
+        corrfunc.s_mu_tpcf(pos[0], s_bins, mu_bins, sample2=pos[3], period=period,
+                           do_auto=False, do_cross=True), data['smu_cross'], **close)
+    cross_kwargs = dict(sample2=data['particles'], do_auto=False, do_cross=True)
+    for name, tpcf, args in (('wp', corrfunc.wp, (rp_bins, pi_max)),
+                             ('smu', corrfunc.s_mu_tpcf, (s_bins, mu_bins))):
+        matrix, shape = corrfunc.reference_compute_tpcf_matrix(
+            'auto', pos, tpcf, period, args, {})
+        assert tuple(shape) == tuple(data['shape_auto_' + name])
+        np.testing.assert_allclose(matrix, data['matrix_auto_' + name], **close)
+        matrix, shape = corrfunc.reference_compute_tpcf_matrix(
+            'cross', pos, tpcf, period, args, cross_kwargs)
+        assert tuple(shape) == tuple(data['shape_cross_' + name])
+        np.testing.assert_allclose(matrix, data['matrix_cross_' + name], **close)

@@ -148,3 +148,54 @@ def test_s_mu_matrix_matches_pairwise_calls():
         cross[:, 3],
         oracle.s_mu_tpcf(pos[3], s_bins, mu_bins, sample2=other, period=box,
                          do_auto=False, do_cross=True).ravel())
+
+
+# ---- pinned against the reference's own wrappers -------------------------------------------
+
+def _wrapper_fixture():
+    from util import load_golden
+    data = load_golden('paircount_wrappers')
+    offsets = np.concatenate([[0], np.cumsum(data['sizes'])])
+    pos = [data['pos'][a:b] for a, b in zip(offsets[:-1], offsets[1:])]
+    return data, pos
+
+
+def test_oracle_wrappers_match_the_reference_fixture():
+    """tests/golden/paircount_wrappers.npz was recorded by running the reference's
+    tabcorr.corrfunc.wp / s_mu_tpcf and tabcorr.tabcorr.compute_tpcf_matrix (unmodified,
+    imported from /root/reference) over a stub Corrfunc.theory with an independent
+    brute-force counter (tests/golden/make_golden.py: golden_paircount).  The oracle's
+    restatement of the wrapper arithmetic and of the matrix assembly -- task list, swap of
+    the samples by size, symmetrisation, empty bin -- must reproduce it."""
+    data, pos = _wrapper_fixture()
+    period, rp_bins, pi_max = data['period'], data['rp_bins'], float(data['pi_max'])
+    s_bins, mu_bins = data['s_bins'], data['mu_bins']
+    close = dict(rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(oracle.wp(pos[0], rp_bins, pi_max, period=period),
+                               data['wp_auto'], **close)
+    np.testing.assert_allclose(
+        oracle.wp(pos[0], rp_bins, pi_max, sample2=pos[3], period=period, do_auto=False,
+                  do_cross=True), data['wp_cross'], **close)
+    np.testing.assert_allclose(
+        oracle.wp(np.mod(pos[3], 60.0), rp_bins, pi_max, period=60.0),
+        data['wp_auto_scalar_period'], **close)
+    np.testing.assert_allclose(oracle.s_mu_tpcf(pos[0], s_bins, mu_bins, period=period),
+                               data['smu_auto'], **close)
+    np.testing.assert_allclose(
+        oracle.s_mu_tpcf(pos[0], s_bins, mu_bins, sample2=pos[3], period=period,
+                         do_auto=False, do_cross=True), data['smu_cross'], **close)
+    matrix, shape = oracle.compute_tpcf_matrix_wp('auto', pos, period, rp_bins, pi_max)
+    assert tuple(shape) == tuple(data['shape_auto_wp'])
+    np.testing.assert_allclose(matrix, data['matrix_auto_wp'], **close)
+    assert np.all(matrix[:, 2] == 0) and np.all(matrix[:, :, 2] == 0)      # the empty bin
+    matrix, shape = oracle.compute_tpcf_matrix_wp('cross', pos, period, rp_bins, pi_max,
+                                                  sample2=data['particles'])
+    assert tuple(shape) == tuple(data['shape_cross_wp'])
+    np.testing.assert_allclose(matrix, data['matrix_cross_wp'], **close)
+    matrix, shape = oracle.compute_tpcf_matrix_smu('auto', pos, period, s_bins, mu_bins)
+    assert tuple(shape) == tuple(data['shape_auto_smu'])
+    np.testing.assert_allclose(matrix, data['matrix_auto_smu'], **close)
+    matrix, shape = oracle.compute_tpcf_matrix_smu('cross', pos, period, s_bins, mu_bins,
+                                                   sample2=data['particles'])
+    assert tuple(shape) == tuple(data['shape_cross_smu'])
+    np.testing.assert_allclose(matrix, data['matrix_cross_smu'], **close)
