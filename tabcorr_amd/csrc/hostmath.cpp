@@ -852,30 +852,68 @@ void sort_cells_by_label(CellSort& cells) {
   cells = std::move(sorted);
 }
 
-void build_label_items(const CellSort& cells, int max_points, int max_slots, LabelItems& out) {
-  out = LabelItems();
-  out.slot.assign(cells.x.size(), 0);
-  for (size_t c = 0; c + 1 < cells.cell_start.size(); ++c) {
+void build_label_blocks(const CellSort& cells, int n_labels, int block, LabelBlocks& out) {
+  out.block = std::max(1, block);
+  out.n_blocks = std::max(1, (n_labels + out.block - 1) / out.block);
+  const size_t n_cells = cells.cell_start.empty() ? 0 : cells.cell_start.size() - 1;
+  const size_t stride = (size_t)out.n_blocks + 1;
+  out.start.assign(n_cells * stride, 0);
+  for (size_t c = 0; c < n_cells; ++c) {
     int32_t p = cells.cell_start[c];
-    const int32_t cell_end = cells.cell_start[c + 1];
-    while (p < cell_end) {
-      const int32_t begin = p;
-      std::vector<int32_t> labels;
-      while (p < cell_end && p - begin < max_points) {
-        if (labels.empty() || labels.back() != cells.label[p]) {
-          if ((int)labels.size() == max_slots) break;
-          labels.push_back(cells.label[p]);
-        }
-        out.slot[p] = (int32_t)labels.size() - 1;
-        ++p;
-      }
-      out.cell.push_back((int32_t)c);
-      out.begin.push_back(begin);
-      out.end.push_back(p);
-      labels.resize((size_t)max_slots, 0);
-      out.item_labels.insert(out.item_labels.end(), labels.begin(), labels.end());
+    const int32_t end = cells.cell_start[c + 1];
+    for (int k = 0; k <= out.n_blocks; ++k) {
+      // (labels are sorted inside the cell: advance to the first label of block k)
+      while (k < out.n_blocks && p < end && cells.label[p] < k * out.block) ++p;
+      out.start[c * stride + k] = k < out.n_blocks ? p : end;
     }
   }
+}
+
+void build_pair_units(const CellGrid& grid, const CellSort& set1, const CellSort& set2,
+                      int n_blocks1, int n_blocks2, int target_units, PairUnits& out) {
+  out = PairUnits();
+  const int n_cells = grid.n_cells();
+  // candidate pairs per cell: its set-1 points x the set-2 points of the cells around it
+  std::vector<double> weight((size_t)n_cells, 0.0);
+  double total = 0.0;
+  for (int cx = 0; cx < grid.nx; ++cx)
+    for (int cy = 0; cy < grid.ny; ++cy)
+      for (int cz = 0; cz < grid.nz; ++cz) {
+        const int c = (cx * grid.ny + cy) * grid.nz + cz;
+        const double n1 = set1.cell_start[c + 1] - set1.cell_start[c];
+        if (n1 == 0.0) continue;
+        double n2 = 0.0;
+        for (int ox = -grid.reach_x; ox <= grid.reach_x; ++ox)
+          for (int oy = -grid.reach_y; oy <= grid.reach_y; ++oy)
+            for (int oz = -grid.reach_z; oz <= grid.reach_z; ++oz) {
+              const int other = (((cx + ox + grid.nx) % grid.nx) * grid.ny +
+                                 (cy + oy + grid.ny) % grid.ny) * grid.nz +
+                                (cz + oz + grid.nz) % grid.nz;
+              n2 += set2.cell_start[other + 1] - set2.cell_start[other];
+            }
+        // (+ a fixed cost per visited cell: the neighbour ranges are set up per cell)
+        weight[c] = n1 * n2 + 256.0;
+        total += weight[c];
+      }
+  const int pairs = std::max(1, n_blocks1 * n_blocks2);
+  const int ranges = std::max(1, std::min(n_cells, (target_units + pairs - 1) / pairs));
+  std::vector<int32_t> cut(1, 0);
+  double running = 0.0;
+  for (int c = 0; c < n_cells; ++c) {
+    running += weight[c];
+    if ((int)cut.size() < ranges && running >= total * (double)cut.size() / ranges)
+      cut.push_back(c + 1);
+  }
+  if (cut.back() != n_cells) cut.push_back(n_cells);
+  for (int a = 0; a < n_blocks1; ++a)
+    for (int b = 0; b < n_blocks2; ++b)
+      for (size_t r = 0; r + 1 < cut.size(); ++r) {
+        if (cut[r] == cut[r + 1]) continue;
+        out.block1.push_back(a);
+        out.block2.push_back(b);
+        out.cell_begin.push_back(cut[r]);
+        out.cell_end.push_back(cut[r + 1]);
+      }
 }
 
 }  // namespace tc

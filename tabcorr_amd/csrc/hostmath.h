@@ -271,14 +271,25 @@ int64_t sort_into_cells(const CellGrid& grid, const double* pos, const int32_t* 
 // Inside every cell, order the points by label (stable).
 void sort_cells_by_label(CellSort& cells);
 
-// Work items of the labelled pair count: consecutive points of one cell (sorted by label), at
-// most `max_points` of them and at most `max_slots` distinct labels, so that a workgroup can
-// keep private counters for (r bin, its label slots, every partner label) in LDS.  slot[p] is
-// the label slot of point p inside its item, item_labels (items, max_slots) the labels.
-struct LabelItems {
-  std::vector<int32_t> cell, begin, end, slot, item_labels;
+// Labelled pair count (paircount.hip: pair_count_blocks_kernel): the labels are cut into blocks
+// of `block` consecutive values; with the points sorted by (cell, label), start[(cell,
+// k)] = first point of `cell` whose label is >= k * block, k = 0 .. n_blocks (the last entry
+// is the end of the cell): the points of one cell and one label block are contiguous.
+struct LabelBlocks {
+  int block = 1;
+  int n_blocks = 1;
+  std::vector<int32_t> start;   // (n_cells, n_blocks + 1)
 };
-void build_label_items(const CellSort& cells, int max_points, int max_slots, LabelItems& out);
+void build_label_blocks(const CellSort& cells, int n_labels, int block, LabelBlocks& out);
+
+// Work units of that kernel: (set-1 label block, set-2 label block, range of cells), the cell
+// ranges cut so that every unit holds about the same number of candidate pairs (points of a
+// cell x points in the cells around it) and all blocks together give ~`target_units` units.
+struct PairUnits {
+  std::vector<int32_t> block1, block2, cell_begin, cell_end;
+};
+void build_pair_units(const CellGrid& grid, const CellSort& set1, const CellSort& set2,
+                      int n_blocks1, int n_blocks2, int target_units, PairUnits& out);
 
 // Position order inside a segment: j -> j + 1, wrapping to (i + 1, j_lo) after column
 // `j_last` (rectangle) or after the diagonal (j_last < 0).

@@ -23,18 +23,28 @@
 //   an auto-count holds every pair twice; i == j is a pair like any other (it only counts
 //   when rp_bins[0] == 0).
 //
-// Layout: the host sorts the points into a grid of cells at least r_p,max (x, y) and pi_max
-// (z) wide, so that the partners of a point lie in the 27 cells around it (a dimension with
-// fewer than three cells has one cell and no neighbour offsets: the minimum image does the
-// wrapping).  A workgroup owns up to 256 consecutive points of one cell -- one per lane --
-// and streams the points of the neighbouring cells through LDS in tiles of 256 (the classic
-// all-pairs tiling: one global load per point and tile, 256 distance tests per load).
-// Counters are integers: per-workgroup LDS histograms flushed with 64-bit global atomics --
-// (r_p, pi) bins, or, for the labelled matrix, (r_p bin, label slot, partner label): the points
-// are sorted by label inside the cells and a workgroup takes at most 8 distinct labels, so its
-// private counters fit 56 KB (64-bit global atomics per pair only when not even one label
-// slot fits: 4x slower).
-// The result does not depend on the order of the atomics.
+// Layout: the host sorts the points into a grid of cells at least half of r_p,max (x, y) and
+// pi_max (z) wide, so that the partners of a point lie in the 5 x 5 x 5 cells around it (or, in
+// small boxes, cells a full reach wide and 27 neighbours; a dimension with fewer than three cells
+// has one cell and no neighbour offsets: the minimum image does the wrapping).
+//   * pair_count_kernel (one pair of samples): a workgroup owns up to 256 consecutive points of
+//     one cell -- one per lane -- and streams the points of the neighbouring cells through LDS in
+//     tiles of 256 (one global load per point and tile, 256 distance tests per load); (r_p, pi)
+//     counters in LDS, flushed once per workgroup.
+//   * pair_count_blocks_kernel (all bin pairs): counters for every (r_p bin, label 1, label 2)
+//     would be 19 x 100 x 100 words, and with a handful of points per cell and label a
+//     workgroup's pairs scatter over all of them -- one 64-bit global atomic per pair, each a
+//     fabric transaction (round 2: 2.3e9 atomics = 73 GB of WRITE_SIZE per 10^6 points).  So the
+//     labels are cut into blocks (all labels of sample 1 x 4 labels of sample 2 while that fits
+//     30 KB), the points are sorted by (cell, label), and a workgroup owns ONE pair of label
+//     blocks over a range of cells: for every cell it gathers the block-2 points of the
+//     surrounding cells -- 125 short ranges compacted through a prefix sum, one point per lane --
+//     and walks the cell's block-1 points (uniform addresses: they arrive through the scalar
+//     cache as SGPR operands, no staging, no barrier).  Its private LDS histogram (r bin, label
+//     1, label 2 in block) collects hundreds of pairs per counter before ONE flush: ~1e7 global
+//     atomics instead of one per pair.  10^6 points, 100 x 100 bin pairs: 642 -> 180 ms, 1.2x
+//     the count of the same points without labels.
+// Counters are integers: the result does not depend on the order of the atomics.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -72,13 +82,16 @@ struct PairArgs {
   double pi_max;
   double inv_dpi;               // n_pi / pi_max
   int n_labels;
-  // labelled counts with private counters: the workgroup's points carry at most label_slots
-  // distinct labels (slot1: the slot of every set-1 point, item_labels: (items, label_slots))
-  // and LDS holds (n_rp [* n_mu], label_slots, n_labels) counters; 0: 64-bit global atomics
-  int label_slots;
-  const int32_t* slot1;
-  const int32_t* item_labels;
   unsigned long long* counts;   // (n_rp, n_pi) or (n_rp [, n_mu], n_labels, n_labels)
+  // pair_count_blocks_kernel: label blocks of both sets (hostmath.h: LabelBlocks, PairUnits)
+  const int32_t* block_start1;  // (n_cells, n_blocks1 + 1)
+  const int32_t* block_start2;  // (n_cells, n_blocks2 + 1)
+  int block1, block2;           // labels per block
+  int n_blocks1, n_blocks2;
+  const int32_t* unit_block1;   // per workgroup: its pair of label blocks ...
+  const int32_t* unit_block2;
+  const int32_t* unit_cell_begin;   // ... and its range of cells
+  const int32_t* unit_cell_end;
 };
 
 __device__ inline double min_image(double d, double box, double half) {
@@ -91,13 +104,12 @@ __device__ inline double min_image(double d, double box, double half) {
 // counts if s_bins[0]^2 <= s^2 < s_bins[-1]^2 and mu < 1, its mu bin is int(mu n_mu) with
 // mu = |dz| / sqrt(s^2) (correctly rounded square root and division, as NumPy's); s = 0
 // (i == j with s_bins[0] == 0) goes to mu bin 0.
-template <bool LABELLED, bool SMU>
+template <bool SMU>
 __global__ __launch_bounds__(kPairThreads) void pair_count_kernel(PairArgs a) {
   __shared__ double sx[kPairThreads], sy[kPairThreads], sz[kPairThreads];
-  __shared__ int32_t sl[kPairThreads];
-  extern __shared__ unsigned hist[];   // n_rp * n_pi, or n_rp * label_slots * n_labels counters
+  extern __shared__ unsigned hist[];   // n_rp * n_pi counters
   const int tid = threadIdx.x;
-  const int n_hist = (LABELLED ? a.label_slots * a.n_labels : 1) * a.n_rp * a.n_pi;
+  const int n_hist = a.n_rp * a.n_pi;
   for (int k = tid; k < n_hist; k += kPairThreads) hist[k] = 0u;
 
   const int cell = a.item_cell[blockIdx.x];
@@ -106,8 +118,6 @@ __global__ __launch_bounds__(kPairThreads) void pair_count_kernel(PairArgs a) {
   const bool active = i < end;
   const double xi = active ? a.x1[i] : 0.0, yi = active ? a.y1[i] : 0.0;
   const double zi = active ? a.z1[i] : 0.0;
-  const int li = LABELLED && active ? a.label1[i] : 0;
-  const int slot = LABELLED && active && a.label_slots > 0 ? a.slot1[i] : 0;
   const int cz = cell % a.nz, cy = (cell / a.nz) % a.ny, cx = cell / (a.nz * a.ny);
   const double hx = 0.5 * a.lx, hy = 0.5 * a.ly, hz = 0.5 * a.lz;
   const double lo_sqr = a.edge_sqr[0], hi_sqr = a.edge_sqr[a.n_rp];
@@ -127,7 +137,6 @@ __global__ __launch_bounds__(kPairThreads) void pair_count_kernel(PairArgs a) {
             sx[tid] = a.x2[j0 + tid];
             sy[tid] = a.y2[j0 + tid];
             sz[tid] = a.z2[j0 + tid];
-            if (LABELLED) sl[tid] = a.label2[j0 + tid];
           }
           __syncthreads();
           if (!active) continue;
@@ -142,21 +151,10 @@ __global__ __launch_bounds__(kPairThreads) void pair_count_kernel(PairArgs a) {
             if (!(r_sqr >= lo_sqr && r_sqr < hi_sqr)) continue;
             int bin = 0;
             for (int k = 1; k < a.n_rp; ++k) bin += r_sqr >= a.edge_sqr[k] ? 1 : 0;
-            int mu_bin = 0;
             if (SMU) {
               const double mu = r_sqr > 0.0 ? __ddiv_rn(dz, __dsqrt_rn(r_sqr)) : 0.0;
-              mu_bin = (int)(mu * a.inv_dpi);
+              const int mu_bin = (int)(mu * a.inv_dpi);
               if (!(mu < 1.0 && mu_bin < a.n_pi)) continue;
-            }
-            if (LABELLED) {
-              // (labelled r_p counts are summed over pi: n_pi == 1 there)
-              const int cell_bin = SMU ? bin * a.n_pi + mu_bin : bin;
-              if (a.label_slots > 0)
-                atomicAdd(&hist[(cell_bin * a.label_slots + slot) * a.n_labels + sl[t]], 1u);
-              else
-                atomicAdd(a.counts + ((size_t)cell_bin * a.n_labels + li) * a.n_labels + sl[t],
-                          1ull);
-            } else if (SMU) {
               atomicAdd(&hist[bin * a.n_pi + mu_bin], 1u);
             } else {
               const int pi_bin = (int)(dz * a.inv_dpi);
@@ -168,17 +166,145 @@ __global__ __launch_bounds__(kPairThreads) void pair_count_kernel(PairArgs a) {
   __syncthreads();
   for (int k = tid; k < n_hist; k += kPairThreads) {
     const unsigned value = hist[k];
-    if (value == 0u) continue;
-    if (LABELLED) {
-      const int lj = k % a.n_labels, s = (k / a.n_labels) % a.label_slots;
-      const int bin = k / (a.n_labels * a.label_slots);
-      const int label = a.item_labels[blockIdx.x * a.label_slots + s];
-      atomicAdd(a.counts + ((size_t)bin * a.n_labels + label) * a.n_labels + lj,
+    if (value != 0u) atomicAdd(a.counts + k, (unsigned long long)value);
+  }
+}
+
+// All pairs of labels in one pass (see the top of this file).  Workgroup = (label block of set
+// 1, label block of set 2, range of cells); LDS: (n_rp [* n_mu], block1, block2) counters.
+constexpr int kMaxNeighbours = 125;
+
+// (x1 ... label1 = a.x1 ... a.label1 once more as restrict-qualified kernel arguments: nothing
+// the kernel writes aliases them, which lets the compiler fetch the block-1 point of an
+// iteration with scalar loads)
+template <bool SMU, int UNROLL>
+__global__ __launch_bounds__(kPairThreads) void pair_count_blocks_kernel(
+    PairArgs a, const double* __restrict__ x1, const double* __restrict__ y1,
+    const double* __restrict__ z1, const int32_t* __restrict__ label1) {
+  extern __shared__ unsigned hist[];
+  __shared__ int32_t nb_start[128];
+  __shared__ int32_t nb_prefix[129];     // [128]: all block-2 points around the cell
+  const int tid = threadIdx.x;
+  const int n_bin = a.n_rp * a.n_pi;             // (labelled r_p counts: n_pi == 1)
+  const int n_hist = n_bin * a.block1 * a.block2;
+  const int ba = a.unit_block1[blockIdx.x], bb = a.unit_block2[blockIdx.x];
+  const int c_begin = a.unit_cell_begin[blockIdx.x], c_end = a.unit_cell_end[blockIdx.x];
+  const int label_lo1 = ba * a.block1, label_lo2 = bb * a.block2;
+  const int stride1 = a.n_blocks1 + 1, stride2 = a.n_blocks2 + 1;
+  const int wx = 2 * a.reach_x + 1, wy = 2 * a.reach_y + 1, wz = 2 * a.reach_z + 1;
+  const int n_nb = wx * wy * wz;
+  const double hx = 0.5 * a.lx, hy = 0.5 * a.ly, hz = 0.5 * a.lz;
+  const double lo_sqr = a.edge_sqr[0], hi_sqr = a.edge_sqr[a.n_rp];
+
+  auto flush = [&]() {
+    __syncthreads();
+    for (int k = tid; k < n_hist; k += kPairThreads) {
+      const unsigned value = hist[k];
+      hist[k] = 0u;
+      if (value == 0u) continue;
+      const int lj = k % a.block2, li = (k / a.block2) % a.block1, bin = k / (a.block1 * a.block2);
+      atomicAdd(a.counts + ((size_t)bin * a.n_labels + label_lo1 + li) * a.n_labels +
+                    label_lo2 + lj,
                 (unsigned long long)value);
-    } else {
-      atomicAdd(a.counts + k, (unsigned long long)value);
+    }
+    __syncthreads();
+  };
+  for (int k = tid; k < n_hist; k += kPairThreads) hist[k] = 0u;
+  // candidate pairs since the last flush: the 32-bit counters cannot overflow below 2^32
+  unsigned long long pending = 0;
+
+  for (int cell = c_begin; cell < c_end; ++cell) {
+    const int p_begin = a.block_start1[cell * stride1 + ba];
+    const int p_end = a.block_start1[cell * stride1 + ba + 1];
+    if (p_begin == p_end) continue;              // (uniform over the workgroup)
+    const int cz = cell % a.nz, cy = (cell / a.nz) % a.ny, cx = cell / (a.nz * a.ny);
+    __syncthreads();                             // the previous cell's ranges are no longer read
+    // ranges of the block-2 points in the cells around this one, compacted by a prefix sum
+    // (wave 0: two ranges per lane, inclusive scan across the lanes)
+    if (tid < 64) {
+      int len[2], start[2];
+      for (int h = 0; h < 2; ++h) {
+        const int k = 2 * tid + h;
+        len[h] = 0;
+        start[h] = 0;
+        if (k < n_nb) {
+          const int oz = k % wz - a.reach_z, oy = (k / wz) % wy - a.reach_y;
+          const int ox = k / (wz * wy) - a.reach_x;
+          const int other = (((cx + ox + a.nx) % a.nx) * a.ny + (cy + oy + a.ny) % a.ny) * a.nz +
+                            (cz + oz + a.nz) % a.nz;
+          start[h] = a.block_start2[other * stride2 + bb];
+          len[h] = a.block_start2[other * stride2 + bb + 1] - start[h];
+        }
+      }
+      int sum = len[0] + len[1];
+      for (int shift = 1; shift < 64; shift <<= 1) {
+        const int up = __shfl_up(sum, shift, 64);
+        if (tid >= shift) sum += up;
+      }
+      // nb_prefix[k] = points before range k; nb_prefix[n_nb ...] = total
+      const int before = sum - len[0] - len[1];
+      nb_prefix[2 * tid] = before;
+      nb_prefix[2 * tid + 1] = before + len[0];
+      nb_start[2 * tid] = start[0];
+      nb_start[2 * tid + 1] = start[1];
+      if (tid == 63) nb_prefix[128] = sum;
+    }
+    __syncthreads();
+    const int total = nb_prefix[128];
+    pending += (unsigned long long)(p_end - p_begin) * (unsigned long long)total;
+    if (pending >= (1ull << 31)) {
+      flush();
+      pending = (unsigned long long)(p_end - p_begin) * (unsigned long long)total;
+    }
+    for (int g0 = 0; g0 < total; g0 += kPairThreads) {
+      const int g = g0 + tid;
+      if (g >= total) continue;
+      // range of point g: the last k with nb_prefix[k] <= g (ranges of length 0 are skipped
+      // because their successor has the same prefix)
+      int k = 0;
+      for (int step = 64; step >= 1; step >>= 1)
+        if (k + step < 128 && nb_prefix[k + step] <= g) k += step;
+      const int j = nb_start[k] + (g - nb_prefix[k]);
+      const double xj = a.x2[j], yj = a.y2[j], zj = a.z2[j];
+      const int lj = a.label2[j] - label_lo2;
+      // block-1 points four at a time: p is uniform over the wave, so the coordinates come by
+      // scalar loads, issued together ahead of the four tests
+      auto test = [&](double xi, double yi, double zi, int li) {
+        const double dz = fabs(min_image(zi - zj, a.lz, hz));
+        if (!(dz < a.pi_max)) return;
+        const double dx = min_image(xi - xj, a.lx, hx);
+        const double dy = min_image(yi - yj, a.ly, hy);
+        double r_sqr = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+        if (SMU) r_sqr = __dadd_rn(r_sqr, __dmul_rn(dz, dz));
+        if (!(r_sqr >= lo_sqr && r_sqr < hi_sqr)) return;
+        int bin = 0;
+        for (int e = 1; e < a.n_rp; ++e) bin += r_sqr >= a.edge_sqr[e] ? 1 : 0;
+        if (SMU) {
+          const double mu = r_sqr > 0.0 ? __ddiv_rn(dz, __dsqrt_rn(r_sqr)) : 0.0;
+          const int mu_bin = (int)(mu * a.inv_dpi);
+          if (!(mu < 1.0 && mu_bin < a.n_pi)) return;
+          bin = bin * a.n_pi + mu_bin;
+        }
+        atomicAdd(&hist[(bin * a.block1 + (li - label_lo1)) * a.block2 + lj], 1u);
+      };
+      for (int p = p_begin; p < p_end; p += UNROLL) {
+        double xs[UNROLL], ys[UNROLL], zs[UNROLL];
+        int ls[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+          const int q = p + u < p_end ? p + u : p_end - 1;
+          xs[u] = x1[q];
+          ys[u] = y1[q];
+          zs[u] = z1[q];
+          ls[u] = label1[q];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+          if (p + u < p_end) test(xs[u], ys[u], zs[u], ls[u]);
+      }
     }
   }
+  flush();
 }
 
 namespace host {
@@ -244,23 +370,9 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
         TC_CHECK(label2[p] >= 0 && label2[p] < n_labels, "label of point %lld out of range",
                  (long long)p);
   }
-  // Labelled counts with enough points per (cell, label) keep private counters per workgroup
-  // (below); they need full workgroups, i.e. the coarse grid.  Everything else takes the fine
-  // grid (an eighth of the cell volume, 5 x 5 x 5 neighbours: 42 % fewer candidate pairs).
-  int label_slots = 0;
-  CellGrid grid = make_cell_grid(boxsize, rp_max, pi_max, std::max(n1, n2), !labelled);
-  if (labelled) {
-    label_slots =
-        (int)std::min<size_t>(8, (56 * 1024) / ((size_t)n_rp * n_pi * n_labels * sizeof(unsigned)));
-    // with few points per (cell, label) such workgroups would hold a handful of points each,
-    // every one of them streaming all neighbour tiles (10^5 points in 100 bins: 48 ms against
-    // 13 ms with global atomics; 10^6 points: 645 ms against 790 ms)
-    const double per_cell_label = (double)n1 / ((double)grid.n_cells() * n_labels);
-    if (label_slots * per_cell_label < 128.0) {
-      label_slots = 0;
-      grid = make_cell_grid(boxsize, rp_max, pi_max, std::max(n1, n2), true);
-    }
-  }
+  // Cells half the reach wide with 5 x 5 x 5 neighbours where the box allows (an eighth of
+  // the cell volume: 42 % fewer candidate pairs than 27 full-size cells).
+  CellGrid grid = make_cell_grid(boxsize, rp_max, pi_max, std::max(n1, n2), true);
 
   Range range("pair count");
   CellSort set1, set2;
@@ -272,20 +384,34 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
     TC_CHECK(outside < 0, "point %lld of the second sample lies outside of the periodic box",
              (long long)outside);
   }
-  // work items: up to 256 consecutive set-1 points of one cell; labelled: sorted by label
-  // inside the cells and cut so that a workgroup sees at most `label_slots` labels, as many
-  // as keep its private counters within 56 KB of LDS (none fit: global atomics per pair)
+  const CellSort& second = autocorr ? set1 : set2;
+  // work items of the unlabelled kernel: up to 256 consecutive set-1 points of one cell;
+  // labelled: label blocks and (block, block, cell range) units of the blocks kernel
   std::vector<int32_t> item_cell, item_begin, item_end;
-  LabelItems label_items;
-  if (label_slots > 0) {
+  LabelBlocks blocks1, blocks2;
+  PairUnits units;
+  const int n_bin = n_rp * n_pi;
+  int lds_counters = n_bin;
+  if (labelled) {
+    // LDS counters (bins, labels of block 1, labels of block 2): about 30 KB per workgroup
+    // keep five workgroups on a CU, which the scalar-load latency of the inner loop needs
+    // (19 bins x 100 labels, 10^6 points: 8 labels of set 2 = 60 KB 276 ms, 4 = 30 KB 180 ms,
+    // 2 = 15 KB 190 ms: tools/r03_pc_knobs.sh); set 1 keeps all its labels while that fits
+    const int limit = 60 * 1024 / (int)sizeof(unsigned);
+    const int budget = env_int("TC_PAIR_LDS_KB", 30) * 1024 / (int)sizeof(unsigned);
+    TC_CHECK(n_bin <= limit, "at most %d (separation, mu) bins are supported", limit);
+    int b1 = n_labels, b2 = std::min(n_labels, 8);
+    while (n_bin * b1 * b2 > budget && b2 > 2) --b2;
+    while (n_bin * b1 * b2 > budget && b1 > 1) b1 = (b1 + 1) / 2;
+    while (n_bin * b1 * b2 > limit && b2 > 1) --b2;
     sort_cells_by_label(set1);
     if (!autocorr) sort_cells_by_label(set2);
-  }
-  if (label_slots > 0) {
-    build_label_items(set1, kPairThreads, label_slots, label_items);
-    item_cell = label_items.cell;
-    item_begin = label_items.begin;
-    item_end = label_items.end;
+    build_label_blocks(set1, n_labels, b1, blocks1);
+    build_label_blocks(second, n_labels, b2, blocks2);
+    // ~16 units per CU: the cell ranges differ in weight by the clustering of the points
+    build_pair_units(grid, set1, second, blocks1.n_blocks, blocks2.n_blocks,
+                     env_int("TC_PAIR_UNITS", 4096), units);
+    lds_counters = n_bin * b1 * b2;
   } else {
     for (int c = 0; c < grid.n_cells(); ++c)
       for (int32_t b = set1.cell_start[c]; b < set1.cell_start[c + 1]; b += kPairThreads) {
@@ -302,7 +428,6 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
   if (status == TC_OK) status = device.put(set1.z, &a.z1);
   a.label1 = nullptr;
   if (status == TC_OK && labelled) status = device.put(set1.label, &a.label1);
-  const CellSort& second = autocorr ? set1 : set2;
   if (autocorr) {
     a.x2 = a.x1;
     a.y2 = a.y1;
@@ -316,15 +441,22 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
     if (status == TC_OK && labelled) status = device.put(set2.label, &a.label2);
   }
   if (status == TC_OK) status = device.put(second.cell_start, &a.cell_start2);
-  if (status == TC_OK) status = device.put(item_cell, &a.item_cell);
-  if (status == TC_OK) status = device.put(item_begin, &a.item_begin);
-  if (status == TC_OK) status = device.put(item_end, &a.item_end);
-  a.label_slots = label_slots;
-  a.slot1 = nullptr;
-  a.item_labels = nullptr;
-  if (status == TC_OK && label_slots > 0) status = device.put(label_items.slot, &a.slot1);
-  if (status == TC_OK && label_slots > 0)
-    status = device.put(label_items.item_labels, &a.item_labels);
+  if (labelled) {
+    if (status == TC_OK) status = device.put(blocks1.start, &a.block_start1);
+    if (status == TC_OK) status = device.put(blocks2.start, &a.block_start2);
+    if (status == TC_OK) status = device.put(units.block1, &a.unit_block1);
+    if (status == TC_OK) status = device.put(units.block2, &a.unit_block2);
+    if (status == TC_OK) status = device.put(units.cell_begin, &a.unit_cell_begin);
+    if (status == TC_OK) status = device.put(units.cell_end, &a.unit_cell_end);
+    a.block1 = blocks1.block;
+    a.block2 = blocks2.block;
+    a.n_blocks1 = blocks1.n_blocks;
+    a.n_blocks2 = blocks2.n_blocks;
+  } else {
+    if (status == TC_OK) status = device.put(item_cell, &a.item_cell);
+    if (status == TC_OK) status = device.put(item_begin, &a.item_begin);
+    if (status == TC_OK) status = device.put(item_end, &a.item_end);
+  }
   if (status != TC_OK) return status;
   a.nx = grid.nx;
   a.ny = grid.ny;
@@ -347,20 +479,28 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
   TC_HIP(hipMemset(d_counts, 0, n_counts * sizeof(uint64_t)));
   a.counts = (unsigned long long*)d_counts;
 
-  const dim3 grid_dim((unsigned)item_cell.size()), block(kPairThreads);
+  const dim3 block(kPairThreads);
+  const size_t lds = (size_t)lds_counters * sizeof(unsigned);
   if (labelled) {
-    const size_t lds = (size_t)n_rp * n_pi * label_slots * n_labels * sizeof(unsigned);
-    if (smu)
-      hipLaunchKernelGGL((pair_count_kernel<true, true>), grid_dim, block, lds, nullptr, a);
-    else
-      hipLaunchKernelGGL((pair_count_kernel<true, false>), grid_dim, block, lds, nullptr, a);
+    const dim3 grid_dim((unsigned)units.block1.size());
+    if (grid_dim.x == 0) return TC_OK;
+    const int unroll = env_int("TC_PAIR_UNROLL", 8);                  // (developer builds)
+#define TC_LAUNCH(SMU, U)                                                                     \
+  hipLaunchKernelGGL((pair_count_blocks_kernel<SMU, U>), grid_dim, block, lds, nullptr, a,  \
+                     a.x1, a.y1, a.z1, a.label1)
+    if (smu) {
+      if (unroll == 4) TC_LAUNCH(true, 4); else if (unroll == 2) TC_LAUNCH(true, 2); else TC_LAUNCH(true, 8);
+    } else {
+      if (unroll == 4) TC_LAUNCH(false, 4); else if (unroll == 2) TC_LAUNCH(false, 2); else TC_LAUNCH(false, 8);
+    }
+#undef TC_LAUNCH
   } else {
-    const size_t lds = (size_t)n_rp * n_pi * sizeof(unsigned);
+    const dim3 grid_dim((unsigned)item_cell.size());
     TC_CHECK(lds <= 48 * 1024, "at most %d two-dimensional bins are supported", 48 * 1024 / 4);
     if (smu)
-      hipLaunchKernelGGL((pair_count_kernel<false, true>), grid_dim, block, lds, nullptr, a);
+      hipLaunchKernelGGL(pair_count_kernel<true>, grid_dim, block, lds, nullptr, a);
     else
-      hipLaunchKernelGGL((pair_count_kernel<false, false>), grid_dim, block, lds, nullptr, a);
+      hipLaunchKernelGGL(pair_count_kernel<false>, grid_dim, block, lds, nullptr, a);
   }
   TC_HIP(hipGetLastError());
   TC_HIP(hipMemcpy(counts, d_counts, n_counts * sizeof(uint64_t), hipMemcpyDeviceToHost));

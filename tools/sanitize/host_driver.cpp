@@ -239,22 +239,43 @@ static void check_cells() {
       for (int c = 0; c < grid.n_cells(); ++c)
         for (int32_t s = sorted.cell_start[c] + 1; s < sorted.cell_start[c + 1]; ++s)
           EXPECT(sorted.label[s - 1] <= sorted.label[s], "labels not sorted inside a cell");
-      for (int max_slots : {1, 3, 8}) {
-        tc::LabelItems items;
-        tc::build_label_items(sorted, 256, max_slots, items);
+      for (int block : {1, 3, 8}) {
+        tc::LabelBlocks blocks;
+        tc::build_label_blocks(sorted, 7, block, blocks);
+        EXPECT(blocks.n_blocks == (7 + block - 1) / block, "number of label blocks");
+        const size_t stride = (size_t)blocks.n_blocks + 1;
         int64_t covered = 0;
-        for (size_t k = 0; k < items.cell.size(); ++k) {
-          EXPECT(items.end[k] - items.begin[k] >= 1 && items.end[k] - items.begin[k] <= 256,
-                 "item size");
-          covered += items.end[k] - items.begin[k];
-          for (int32_t p = items.begin[k]; p < items.end[k]; ++p) {
-            EXPECT(items.slot[p] >= 0 && items.slot[p] < max_slots, "label slot out of range");
-            EXPECT(items.item_labels[k * max_slots + items.slot[p]] == sorted.label[p],
-                   "label slot does not name the point's label");
+        for (int c = 0; c < grid.n_cells(); ++c) {
+          EXPECT(blocks.start[c * stride] == sorted.cell_start[c] &&
+                     blocks.start[c * stride + blocks.n_blocks] == sorted.cell_start[c + 1],
+                 "label blocks do not span the cell");
+          for (int k = 0; k < blocks.n_blocks; ++k) {
+            EXPECT(blocks.start[c * stride + k] <= blocks.start[c * stride + k + 1],
+                   "label block offsets decrease");
+            for (int32_t p = blocks.start[c * stride + k]; p < blocks.start[c * stride + k + 1];
+                 ++p) {
+              EXPECT(sorted.label[p] / block == k, "point in the wrong label block");
+              ++covered;
+            }
           }
         }
-        EXPECT(covered == n, "label items cover %lld of %lld points", (long long)covered,
+        EXPECT(covered == n, "label blocks cover %lld of %lld points", (long long)covered,
                (long long)n);
+        // work units: every (block, block, cell) exactly once
+        for (int target : {1, 40, 4096}) {
+          tc::PairUnits units;
+          tc::build_pair_units(grid, sorted, sorted, blocks.n_blocks, blocks.n_blocks, target,
+                               units);
+          std::vector<int> seen((size_t)blocks.n_blocks * blocks.n_blocks * grid.n_cells(), 0);
+          for (size_t u = 0; u < units.block1.size(); ++u) {
+            EXPECT(units.cell_begin[u] < units.cell_end[u] && units.cell_end[u] <= grid.n_cells(),
+                   "unit cell range");
+            for (int c = units.cell_begin[u]; c < units.cell_end[u]; ++c)
+              ++seen[((size_t)units.block1[u] * blocks.n_blocks + units.block2[u]) *
+                         grid.n_cells() + c];
+          }
+          for (int v : seen) EXPECT(v == 1, "a (block, block, cell) is covered %d times", v);
+        }
       }
       if (n > 0) {
         pos[2] = -1.0;
