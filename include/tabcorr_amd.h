@@ -368,6 +368,18 @@ int tc_pair_count_smu_labelled(const double* pos1, const int32_t* label1, int64_
                                int n_labels, const double* boxsize, const double* s_bins,
                                int n_s, int n_mu, uint64_t* counts);
 
+/* tc_mass_in_cylinders is the pair count behind an excess-surface-density table: what
+ * TabCorr.tabulate does per halo bin when it is handed halotools' mean_delta_sigma with
+ * tpcf_args = (particle positions, particle masses, rp_bins) (tabcorr/tabcorr.py:846-922 in
+ * mode 'cross'; scripts/tabulate_snapshot.py:228-237), for the objects of ALL bins in one
+ * pass: mass (n_objects, n_edges) receives, per object and per radius rp_bins[k], the summed
+ * mass of the particles whose projected separation r = sqrt(dx^2 + dy^2) (periodic in x and y,
+ * the line of sight spanning the box) is <= rp_bins[k].  masses = NULL: unit masses (counts).
+ * Sums run in a fixed order (reproducible; exact for equal masses). */
+int tc_mass_in_cylinders(const double* objects, int64_t n_objects, const double* particles,
+                         int64_t n_particles, const double* masses, const double* boxsize,
+                         const double* rp_bins, int n_edges, double* mass);
+
 /* ---- multi-GPU: one process per GPU, results collected with one RCCL gather ---------- */
 
 #define TC_UNIQUE_ID_BYTES 128

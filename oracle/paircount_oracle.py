@@ -218,3 +218,63 @@ def compute_tpcf_matrix_smu(mode, pos, period, s_bins, mu_bins, sample2=None):
                                       do_auto=False, do_cross=True,
                                       period=period).ravel()
     return matrix, shape
+
+
+# ---- excess surface density (halotools' mean_delta_sigma; PARITY UNPINNED) --------------------
+#
+# halotools (``pyproject.toml``: unpinned, not vendored, not installed here) provides
+# ``mean_delta_sigma(galaxies, particles, effective_particle_masses, rp_bins, period)``, the
+# two-point function of the reference's ds tables (``scripts/tabulate_snapshot.py:228-237``;
+# called per halo bin at ``tabcorr/tabcorr.py:844``).  Restated from its documentation and
+# the method it cites (the mass in cylinders of radius rp_bins[k] around every object, then
+# Delta Sigma = Sigma(< R) - Sigma(R) at the area-weighted midpoints of the annuli, Sigma(< R)
+# log-interpolated between the cylinder radii).  Nothing in the reference tree pins its
+# numbers; the HIP kernel is checked against THIS restatement (exactly, for equal masses).
+
+def mass_in_cylinders(galaxies, particles, masses, rp_bins, period, chunk=256):
+    """(n_galaxies, len(rp_bins)) summed particle mass within projected separation
+    ``r <= rp_bins[k]`` (compared squared; minimum image in x and y)."""
+    galaxies = np.asarray(galaxies, dtype=np.float64).reshape(-1, 3)
+    particles = np.asarray(particles, dtype=np.float64).reshape(-1, 3)
+    period = np.broadcast_to(np.asarray(period, dtype=np.float64), (3, ))
+    masses = np.broadcast_to(np.asarray(masses, dtype=np.float64), (len(particles), ))
+    edge_sqr = np.asarray(rp_bins, dtype=np.float64)**2
+    out = np.zeros((len(galaxies), len(edge_sqr)))
+    for begin in range(0, len(galaxies), chunk):
+        a = galaxies[begin:begin + chunk]
+        dx = _min_image(a[:, None, 0] - particles[None, :, 0], period[0])
+        dy = _min_image(a[:, None, 1] - particles[None, :, 1], period[1])
+        r_sqr = dx * dx + dy * dy
+        for k, edge in enumerate(edge_sqr):
+            out[begin:begin + chunk, k] = np.sum(np.where(r_sqr <= edge, masses[None, :], 0.0),
+                                                 axis=1)
+    return out
+
+
+def mean_delta_sigma(galaxies, particles, masses, rp_bins, period, per_object=False):
+    rp_bins = np.asarray(rp_bins, dtype=np.float64)
+    mass = mass_in_cylinders(galaxies, particles, masses, rp_bins, period)
+    rp_mids = np.sqrt(0.5 * (rp_bins[:-1]**2 + rp_bins[1:]**2))
+    annulus = (mass[:, 1:] - mass[:, :-1]) / (np.pi * (rp_bins[1:]**2 - rp_bins[:-1]**2))
+    inside = mass / (np.pi * rp_bins**2)
+    result = np.zeros_like(annulus)
+    for g in range(len(mass)):
+        have = np.nonzero(inside[g] > 0)[0]
+        if len(have) >= 2:
+            interp = 10.0**np.interp(np.log10(rp_mids), np.log10(rp_bins[have]),
+                                     np.log10(inside[g][have]))
+            interp[rp_mids < rp_bins[have[0]]] = 0.0
+            result[g] = interp
+    result -= annulus
+    return result if per_object else result.mean(axis=0)
+
+
+def compute_tpcf_matrix_ds(pos, period, particles, masses, rp_bins):
+    """``tabcorr/tabcorr.py:846-922`` in mode 'cross' for ``tpcf = mean_delta_sigma``: one
+    call per non-empty bin (``:844``), columns of empty bins stay zero (``:888, 903``)."""
+    n_r = len(rp_bins) - 1
+    matrix = np.zeros((n_r, len(pos)))
+    for i in range(len(pos)):
+        if len(pos[i]) > 0:
+            matrix[:, i] += mean_delta_sigma(pos[i], particles, masses, rp_bins, period)
+    return matrix, (n_r, )

@@ -162,6 +162,9 @@ SIGNATURES = {
                                    ctypes.c_int, c_double_p, c_double_p,
                                    ctypes.c_int, ctypes.c_int,
                                    ctypes.POINTER(ctypes.c_uint64)],
+    'tc_mass_in_cylinders': [c_double_p, ctypes.c_int64, c_double_p,
+                             ctypes.c_int64, c_double_p, c_double_p, c_double_p,
+                             ctypes.c_int, c_double_p],
     'tc_comm_unique_id': [ctypes.c_void_p],
     'tc_comm_create': [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                        c_void_pp],

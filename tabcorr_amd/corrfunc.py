@@ -7,6 +7,12 @@ the pair counts come from this package's HIP kernel
 (``tabcorr_amd/csrc/paircount.hip`` through ``tc_pair_count_rppi``): same
 signature, same arithmetic around the counts, no Corrfunc.
 
+`mean_delta_sigma` stands in for ``halotools.mock_observables.mean_delta_sigma``
+(the two-point function of the reference's excess-surface-density tables,
+``scripts/tabulate_snapshot.py:228-237``): the per-object mass in cylinders is
+counted on the GPU (``tc_mass_in_cylinders``), for the halos of all bins in one
+pass when `TabCorr.tabulate` calls it.
+
 `compute_tpcf_matrix` is the MI355X-native form of the reference's
 ``compute_tpcf_matrix`` (``tabcorr/tabcorr.py:846-922``) for ``tpcf = wp``:
 instead of one pair count per pair of halo bins from a pool of processes, every
@@ -144,6 +150,112 @@ def s_mu_tpcf(sample1, s_bins, mu_bins, sample2=None, period=None,
         n_exp = (len(sample1) * len(sample2) / np.prod(box) * 4 * np.pi / 3 *
                  np.diff(s_bins**3) / n_mu)
     return npairs.astype(np.float64) / n_exp[:, np.newaxis] - 1
+
+
+def mass_in_cylinders(galaxies, particles, effective_particle_masses, rp_bins,
+                      period=None):
+    """Per-object mass of the particles within projected separation
+    ``rp_bins[k]`` (``r = sqrt(dx^2 + dy^2) <= rp_bins[k]``, periodic in x and y,
+    the line of sight spanning the box): ``(n_galaxies, len(rp_bins))`` -- the
+    per-object weighted pair count behind
+    ``halotools.mock_observables.mean_delta_sigma``.  ``effective_particle_masses``:
+    a scalar or one mass per particle."""
+    lib = _lib.load()
+    _lib.require_device()
+    galaxies = _positions(galaxies)
+    particles = _positions(particles)
+    rp_bins = _lib.contiguous(np.asarray(rp_bins, dtype=np.float64))
+    box = _period(period)
+    masses = np.asarray(effective_particle_masses, dtype=np.float64)
+    scale = 1.0
+    if masses.ndim == 0:
+        # equal masses: integer counts on the device, one multiplication here
+        scale, masses_p, keep = float(masses), None, None
+    else:
+        keep = _lib.contiguous(masses.ravel())
+        if len(keep) != len(particles):
+            raise ValueError('effective_particle_masses must be a scalar or '
+                             'have one entry per particle.')
+        masses_p = _lib.as_double_p(keep)
+    out = np.zeros((len(galaxies), len(rp_bins)))
+    _lib.check(lib.tc_mass_in_cylinders(
+        _lib.as_double_p(galaxies), len(galaxies), _lib.as_double_p(particles),
+        len(particles), masses_p, _lib.as_double_p(box),
+        _lib.as_double_p(rp_bins), len(rp_bins), _lib.as_double_p(out)))
+    del keep
+    return out * scale if scale != 1.0 else out
+
+
+def delta_sigma_from_mass_in_cylinders(mass_encl, rp_bins):
+    """Excess surface density per object from the mass in cylinders, as
+    halotools' ``mean_delta_sigma`` forms it (restated from its documentation;
+    halotools is not part of the reference tree -- parity unpinned): at the
+    area-weighted midpoint ``rp_mid = sqrt((r_lo^2 + r_hi^2) / 2)`` of every
+    annulus, ``Sigma(< rp_mid)`` -- the surface density inside the cylinders
+    ``mass_encl / (pi rp_bins^2)``, interpolated linearly in ``log rp`` --
+    ``log Sigma`` over the radii with mass (0 inside the innermost of them) --
+    minus the surface density of the annulus
+    ``diff(mass_encl) / (pi diff(rp_bins^2))``: ``(n, len(rp_bins) - 1)``."""
+    rp_bins = np.asarray(rp_bins, dtype=np.float64)
+    mass_encl = np.atleast_2d(np.asarray(mass_encl, dtype=np.float64))
+    rp_mids = np.sqrt(0.5 * (rp_bins[:-1]**2 + rp_bins[1:]**2))
+    sigma_annulus = np.diff(mass_encl, axis=1) / (np.pi * np.diff(rp_bins**2))
+    sigma_inside = mass_encl / (np.pi * rp_bins**2)
+    log_rp, log_mid = np.log10(rp_bins), np.log10(rp_mids)
+    interpolated = np.zeros_like(sigma_annulus)
+    for g in range(len(mass_encl)):
+        mask = sigma_inside[g] > 0
+        if np.count_nonzero(mask) < 2:
+            continue
+        interpolated[g] = 10.0**np.interp(log_mid, log_rp[mask],
+                                          np.log10(sigma_inside[g][mask]))
+        interpolated[g][rp_mids < rp_bins[mask][0]] = 0.0
+    return interpolated - sigma_annulus
+
+
+def mean_delta_sigma(galaxies, particles, effective_particle_masses, rp_bins,
+                     period=None, per_object=False, **ignored):
+    """Drop-in for ``halotools.mock_observables.mean_delta_sigma(galaxies,
+    particles, effective_particle_masses, rp_bins, period=...)``: the mean
+    excess surface density of the particles around the galaxies in annuli
+    of ``rp_bins`` (``per_object=True``: one row per galaxy).  halotools'
+    tuning arguments (``num_threads``, ``approx_cell*_size``, ``verbose``)
+    are accepted and ignored."""
+    rp_bins = np.asarray(rp_bins, dtype=np.float64)
+    mass = mass_in_cylinders(galaxies, particles, effective_particle_masses,
+                             rp_bins, period)
+    result = delta_sigma_from_mass_in_cylinders(mass, rp_bins)
+    return result if per_object else np.mean(result, axis=0)
+
+
+def compute_tpcf_matrix_ds(mode, pos, period, particles,
+                           effective_particle_masses, rp_bins):
+    """``compute_tpcf_matrix`` of the reference (``tabcorr/tabcorr.py:846-922``)
+    for ``tpcf = mean_delta_sigma`` (mode ``'cross'``, as
+    ``scripts/tabulate_snapshot.py:228-237`` tabulates it): the halos of ALL
+    bins go through one mass-in-cylinders pass instead of one call per bin;
+    empty bins give zeros, as in the reference.  Returns ``(n_rp, G)`` and the
+    shape ``(n_rp, )``."""
+    if mode != 'cross':
+        raise ValueError("mean_delta_sigma tables are tabulated in mode "
+                         "'cross'.")
+    rp_bins = np.asarray(rp_bins, dtype=np.float64)
+    sizes = np.array([len(p) for p in pos], dtype=np.int64)
+    n_r = len(rp_bins) - 1
+    matrix = np.zeros((n_r, len(pos)))
+    if sizes.sum() == 0:
+        return matrix, (n_r, )
+    galaxies = np.concatenate(
+        [np.asarray(p, dtype=np.float64).reshape(-1, 3) for p in pos])
+    mass = mass_in_cylinders(galaxies, particles, effective_particle_masses,
+                             rp_bins, period)
+    per_object = delta_sigma_from_mass_in_cylinders(mass, rp_bins)
+    offsets = np.concatenate([[0], np.cumsum(sizes)])
+    for i in range(len(pos)):
+        if sizes[i] > 0:
+            matrix[:, i] = np.mean(per_object[offsets[i]:offsets[i + 1]],
+                                   axis=0)
+    return matrix, (n_r, )
 
 
 def _labelled_points(pos, sample2):
@@ -286,7 +398,8 @@ def compute_tpcf_matrix_smu(mode, pos, period, s_bins, mu_bins, sample2=None):
 def reference_compute_tpcf_matrix(mode, pos, tpcf, period, tpcf_args,
                                   tpcf_kwargs, num_threads=1, verbose=False):
     """`compute_tpcf_matrix` with the reference's own signature
-    (``tabcorr/tabcorr.py:846-848``) for ``tpcf = wp`` or ``s_mu_tpcf``: what
+    (``tabcorr/tabcorr.py:846-848``) for ``tpcf = wp``, ``s_mu_tpcf`` or
+    ``mean_delta_sigma``: what
     ``TabCorr.tabulate`` swaps in for the reference's pool of per-pair calls.
     ``tpcf_args`` are ``(rp_bins, pi_max)`` / ``(s_bins, mu_bins)``; mode
     ``'cross'`` takes ``sample2`` from ``tpcf_kwargs`` as the reference's call
@@ -295,9 +408,13 @@ def reference_compute_tpcf_matrix(mode, pos, tpcf, period, tpcf_args,
         return compute_tpcf_matrix_smu(mode, pos, period, tpcf_args[0],
                                        tpcf_args[1],
                                        sample2=tpcf_kwargs.get('sample2'))
+    if tpcf is mean_delta_sigma:
+        # tpcf_args = (particle positions, particle masses, rp_bins)
+        return compute_tpcf_matrix_ds(mode, pos, period, tpcf_args[0],
+                                      tpcf_args[1], tpcf_args[2])
     if tpcf is not wp:
-        raise ValueError('Only tabcorr_amd.corrfunc.wp and s_mu_tpcf are '
-                         'counted on the GPU.')
+        raise ValueError('Only tabcorr_amd.corrfunc.wp, s_mu_tpcf and '
+                         'mean_delta_sigma are counted on the GPU.')
     rp_bins, pi_max = tpcf_args[0], tpcf_args[1]
     return compute_tpcf_matrix(mode, pos, period, rp_bins, pi_max,
                                sample2=tpcf_kwargs.get('sample2'))

@@ -50,6 +50,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <numeric>
 #include <vector>
 
 #include "internal.h"
@@ -307,6 +308,78 @@ __global__ __launch_bounds__(kPairThreads) void pair_count_blocks_kernel(
   flush();
 }
 
+// Mass in cylinders around every object (the per-object weighted pair count behind an excess
+// surface density, halotools' mean_delta_sigma: tabcorr/tabcorr.py:846-922 calls it with
+// tpcf_args = (particle positions, particle masses, rp_bins), scripts/tabulate_snapshot.py:
+// 228-237): for object g and every annulus d between consecutive edges the summed mass of the
+// particles whose projected separation r = sqrt(dx^2 + dy^2) (minimum image in x and y; the
+// line of sight spans the whole box) satisfies edge[d - 1] < r <= edge[d] (annulus 0: r <=
+// edge[0]), compared squared.  One lane per object, the particles of the surrounding cell
+// columns streamed through LDS in tiles of 256 in cell order, every lane adding into its own
+// LDS column of annuli -- the order of the additions is fixed by the cell sort, so the sums are
+// reproducible (and exact for equal masses: they are counts).  The host accumulates the annuli
+// into cylinders.
+struct CylinderArgs {
+  const double* x1;             // objects, sorted by cell column
+  const double* y1;
+  const double* x2;             // particles, sorted by cell column
+  const double* y2;
+  const double* mass2;          // NULL: unit masses
+  const int32_t* cell_start2;
+  const int32_t* item_cell;
+  const int32_t* item_begin;
+  const int32_t* item_end;
+  int nx, ny;
+  int reach_x, reach_y;
+  double lx, ly;
+  double edge_sqr[kMaxRpBins + 1];
+  int n_edges;
+  double* annuli;               // (n_objects, n_edges), objects in sorted order
+};
+
+__global__ __launch_bounds__(kPairThreads) void mass_in_cylinders_kernel(CylinderArgs a) {
+  __shared__ double sx[kPairThreads], sy[kPairThreads], sm[kPairThreads];
+  extern __shared__ double column[];   // (n_edges, 256): annulus sums of every lane
+  const int tid = threadIdx.x;
+  for (int d = 0; d < a.n_edges; ++d) column[d * kPairThreads + tid] = 0.0;
+  const int cell = a.item_cell[blockIdx.x];
+  const int begin = a.item_begin[blockIdx.x], end = a.item_end[blockIdx.x];
+  const int i = begin + tid;
+  const bool active = i < end;
+  const double xi = active ? a.x1[i] : 0.0, yi = active ? a.y1[i] : 0.0;
+  const int cy = cell % a.ny, cx = cell / a.ny;
+  const double hx = 0.5 * a.lx, hy = 0.5 * a.ly;
+  const double hi_sqr = a.edge_sqr[a.n_edges - 1];
+  for (int ox = -a.reach_x; ox <= a.reach_x; ++ox)
+    for (int oy = -a.reach_y; oy <= a.reach_y; ++oy) {
+      const int other = ((cx + ox + a.nx) % a.nx) * a.ny + (cy + oy + a.ny) % a.ny;
+      const int j_begin = a.cell_start2[other], j_end = a.cell_start2[other + 1];
+      for (int j0 = j_begin; j0 < j_end; j0 += kPairThreads) {
+        const int n_tile = j_end - j0 < kPairThreads ? j_end - j0 : kPairThreads;
+        __syncthreads();
+        if (tid < n_tile) {
+          sx[tid] = a.x2[j0 + tid];
+          sy[tid] = a.y2[j0 + tid];
+          sm[tid] = a.mass2 != nullptr ? a.mass2[j0 + tid] : 1.0;
+        }
+        __syncthreads();
+        if (!active) continue;
+        for (int t = 0; t < n_tile; ++t) {
+          const double dx = min_image(xi - sx[t], a.lx, hx);
+          const double dy = min_image(yi - sy[t], a.ly, hy);
+          const double r_sqr = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+          if (!(r_sqr <= hi_sqr)) continue;
+          int d = 0;
+          for (int k = 0; k + 1 < a.n_edges; ++k) d += r_sqr > a.edge_sqr[k] ? 1 : 0;
+          column[d * kPairThreads + tid] += sm[t];
+        }
+      }
+    }
+  if (active)
+    for (int d = 0; d < a.n_edges; ++d)
+      a.annuli[(size_t)i * a.n_edges + d] = column[d * kPairThreads + tid];
+}
+
 namespace host {
 
 namespace {
@@ -507,11 +580,110 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
   return TC_OK;
 }
 
+// tc_mass_in_cylinders: cell columns in (x, y) at least half the largest radius wide, objects
+// and particles sorted into them (the original index rides along as the label), one launch,
+// annuli accumulated into cylinders in the caller's object order.
+int mass_in_cylinders(const double* objects, int64_t n_obj, const double* particles,
+                      int64_t n_ptcl, const double* masses, const double* boxsize,
+                      const double* rp_bins, int n_edges, double* mass) {
+  TC_CHECK(boxsize != nullptr && rp_bins != nullptr, "NULL argument");
+  TC_CHECK(n_obj >= 0 && n_ptcl >= 0 && n_obj < (1LL << 31) && n_ptcl < (1LL << 31),
+           "invalid point count");
+  TC_CHECK(n_edges >= 1 && n_edges <= kMaxRpBins + 1, "between 1 and %d radii are supported",
+           kMaxRpBins + 1);
+  for (int k = 0; k < n_edges; ++k)
+    TC_CHECK(rp_bins[k] >= 0.0 && (k == 0 || rp_bins[k] > rp_bins[k - 1]),
+             "rp_bins must be non-negative and increasing");
+  TC_CHECK(boxsize[0] > 0 && boxsize[1] > 0 && boxsize[2] > 0, "box size must be positive");
+  const double rp_max = rp_bins[n_edges - 1];
+  TC_CHECK(rp_max < 0.5 * std::min(boxsize[0], boxsize[1]),
+           "the largest radius must be smaller than half the box size");
+  if (n_obj == 0) return TC_OK;
+  TC_CHECK(objects != nullptr && mass != nullptr && (n_ptcl == 0 || particles != nullptr),
+           "NULL argument");
+  std::fill(mass, mass + (size_t)n_obj * n_edges, 0.0);
+  if (n_ptcl == 0) return TC_OK;
+  // one cell along z: its reach is the box
+  const CellGrid grid = make_cell_grid(boxsize, rp_max, boxsize[2], std::max(n_obj, n_ptcl), true);
+  Range range("mass in cylinders");
+  std::vector<int32_t> index1((size_t)n_obj), index2((size_t)n_ptcl);
+  std::iota(index1.begin(), index1.end(), 0);
+  std::iota(index2.begin(), index2.end(), 0);
+  CellSort set1, set2;
+  int64_t outside = sort_into_cells(grid, objects, index1.data(), n_obj, set1);
+  TC_CHECK(outside < 0, "object %lld lies outside of the periodic box", (long long)outside);
+  outside = sort_into_cells(grid, particles, index2.data(), n_ptcl, set2);
+  TC_CHECK(outside < 0, "particle %lld lies outside of the periodic box", (long long)outside);
+  std::vector<double> mass_sorted;
+  if (masses != nullptr) {
+    mass_sorted.resize((size_t)n_ptcl);
+    for (int64_t s = 0; s < n_ptcl; ++s) mass_sorted[s] = masses[set2.label[s]];
+  }
+  std::vector<int32_t> item_cell, item_begin, item_end;
+  for (int c = 0; c < grid.n_cells(); ++c)
+    for (int32_t b = set1.cell_start[c]; b < set1.cell_start[c + 1]; b += kPairThreads) {
+      item_cell.push_back(c);
+      item_begin.push_back(b);
+      item_end.push_back(std::min<int32_t>(b + kPairThreads, set1.cell_start[c + 1]));
+    }
+  DeviceArrays device;
+  CylinderArgs a{};
+  int status = device.put(set1.x, &a.x1);
+  if (status == TC_OK) status = device.put(set1.y, &a.y1);
+  if (status == TC_OK) status = device.put(set2.x, &a.x2);
+  if (status == TC_OK) status = device.put(set2.y, &a.y2);
+  a.mass2 = nullptr;
+  if (status == TC_OK && masses != nullptr) status = device.put(mass_sorted, &a.mass2);
+  if (status == TC_OK) status = device.put(set2.cell_start, &a.cell_start2);
+  if (status == TC_OK) status = device.put(item_cell, &a.item_cell);
+  if (status == TC_OK) status = device.put(item_begin, &a.item_begin);
+  if (status == TC_OK) status = device.put(item_end, &a.item_end);
+  if (status != TC_OK) return status;
+  a.nx = grid.nx;
+  a.ny = grid.ny;
+  a.reach_x = grid.reach_x;
+  a.reach_y = grid.reach_y;
+  a.lx = grid.lx;
+  a.ly = grid.ly;
+  for (int k = 0; k < n_edges; ++k) a.edge_sqr[k] = rp_bins[k] * rp_bins[k];
+  a.n_edges = n_edges;
+  void* d_annuli = nullptr;
+  const size_t out_bytes = (size_t)n_obj * n_edges * sizeof(double);
+  TC_HIP(hipMalloc(&d_annuli, out_bytes));
+  device.pointers.push_back(d_annuli);
+  a.annuli = (double*)d_annuli;
+  const size_t lds = (size_t)n_edges * kPairThreads * sizeof(double);
+  if (lds > 48 * 1024)
+    TC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mass_in_cylinders_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(mass_in_cylinders_kernel, dim3((unsigned)item_cell.size()),
+                     dim3(kPairThreads), lds, nullptr, a);
+  TC_HIP(hipGetLastError());
+  std::vector<double> annuli((size_t)n_obj * n_edges);
+  TC_HIP(hipMemcpy(annuli.data(), d_annuli, out_bytes, hipMemcpyDeviceToHost));
+  for (int64_t s = 0; s < n_obj; ++s) {
+    double* row = mass + (size_t)set1.label[s] * n_edges;
+    double running = 0.0;
+    for (int k = 0; k < n_edges; ++k) {
+      running += annuli[(size_t)s * n_edges + k];
+      row[k] = running;
+    }
+  }
+  return TC_OK;
+}
+
 }  // namespace
 }  // namespace host
 }  // namespace tc
 
 extern "C" {
+
+int tc_mass_in_cylinders(const double* objects, int64_t n_objects, const double* particles,
+                         int64_t n_particles, const double* masses, const double* boxsize,
+                         const double* rp_bins, int n_edges, double* mass) {
+  return tc::host::mass_in_cylinders(objects, n_objects, particles, n_particles, masses, boxsize,
+                                     rp_bins, n_edges, mass);
+}
 
 int tc_pair_count_rppi(const double* pos1, int64_t n1, const double* pos2, int64_t n2,
                        const double* boxsize, const double* rp_bins, int n_rp, double pi_max,

@@ -169,8 +169,8 @@ class TabCorr:
 
         Populating the mock and binning the halos is halotools-bound and
         delegated to the reference package when that (and halotools) is
-        installed; with ``tpcf=tabcorr_amd.corrfunc.wp`` or ``s_mu_tpcf`` the
-        pair counting inside it (``compute_tpcf_matrix``,
+        installed; with ``tpcf=tabcorr_amd.corrfunc.wp``, ``s_mu_tpcf`` or
+        ``mean_delta_sigma`` the pair counting inside it (``compute_tpcf_matrix``,
         ``tabcorr/tabcorr.py:846-922``) runs on the GPU, all bin pairs in one
         pass.
         """
@@ -182,7 +182,8 @@ class TabCorr:
                 'halotools; tabcorr_amd accelerates predict() only.'
             ) from error
         from . import corrfunc
-        if tpcf is corrfunc.wp or tpcf is corrfunc.s_mu_tpcf:
+        if tpcf in (corrfunc.wp, corrfunc.s_mu_tpcf,
+                    corrfunc.mean_delta_sigma):
             # the pair counts of ALL bin pairs in one pass on the GPU instead of
             # one two-point function call per pair of bins from a process pool
             # (tabcorr/tabcorr.py:846-922; a pool would also fork a process

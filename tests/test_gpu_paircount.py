@@ -305,3 +305,57 @@ def test_wrappers_match_the_reference_fixture():
             'cross', pos, tpcf, period, args, cross_kwargs)
         assert tuple(shape) == tuple(data['shape_cross_' + name])
         np.testing.assert_allclose(matrix, data['matrix_cross_' + name], **close)
+
+
+def test_mass_in_cylinders_and_mean_delta_sigma():
+    """SURVEY.md 8f.4, the third estimator of the reference's database
+    (scripts/tabulate_snapshot.py:228-237): per-object mass in cylinders on the GPU against
+    the brute-force oracle -- exact for equal masses (counts), 1e-12 for per-particle masses
+    (the order of the additions differs) -- and the excess surface density built on it, per
+    object, averaged, and for all halo bins in one pass."""
+    from tabcorr_amd import corrfunc
+    from oracle import paircount_oracle as oracle
+    rng = np.random.default_rng(12)
+    for box, n_gal, n_ptcl in ((np.array([150.0, 150.0, 150.0]), 3000, 40000),
+                               (np.array([90.0, 200.0, 60.0]), 1500, 25000)):
+        galaxies = clustered(rng, n_gal, box, 30, 4.0)
+        particles = np.vstack([clustered(rng, n_ptcl // 2, box, 30, 6.0),
+                               rng.uniform(0, 1, (n_ptcl - n_ptcl // 2, 3)) * box])
+        galaxies[:5, 0] = 0.0
+        galaxies[5:10, 1] = box[1]                    # on the faces of the box
+        particles[:50] = galaxies[:50]                # separation exactly 0
+        rp_bins = np.logspace(-1, np.log10(0.3 * box.min() / 2), 14)
+        got = corrfunc.mass_in_cylinders(galaxies, particles, 2.5e9, rp_bins, box)
+        expect = oracle.mass_in_cylinders(galaxies, particles, 2.5e9, rp_bins, box)
+        assert got.shape == (n_gal, 14)
+        assert np.array_equal(got, expect)
+        weights = rng.uniform(0.5, 2.0, n_ptcl)
+        got = corrfunc.mass_in_cylinders(galaxies, particles, weights, rp_bins, box)
+        expect = oracle.mass_in_cylinders(galaxies, particles, weights, rp_bins, box)
+        np.testing.assert_allclose(got, expect, rtol=1e-12, atol=0)
+        ds = corrfunc.mean_delta_sigma(galaxies, particles, 2.5e9, rp_bins, period=box,
+                                       num_threads=4)
+        np.testing.assert_allclose(
+            ds, oracle.mean_delta_sigma(galaxies, particles, 2.5e9, rp_bins, box), rtol=1e-12)
+        per_object = corrfunc.mean_delta_sigma(galaxies, particles, weights, rp_bins,
+                                               period=box, per_object=True)
+        np.testing.assert_allclose(
+            per_object, oracle.mean_delta_sigma(galaxies, particles, weights, rp_bins, box,
+                                                per_object=True), rtol=1e-10, atol=1e-12)
+    # all halo bins in one pass, as TabCorr.tabulate calls it (tabcorr.py:322-325, 844)
+    bins = [galaxies[:400], galaxies[400:400], galaxies[400:1000], galaxies[1000:]]
+    matrix, shape = corrfunc.reference_compute_tpcf_matrix(
+        'cross', bins, corrfunc.mean_delta_sigma, box, (particles, 2.5e9, rp_bins), {})
+    expect, expect_shape = oracle.compute_tpcf_matrix_ds(bins, box, particles, 2.5e9, rp_bins)
+    assert tuple(shape) == tuple(expect_shape) == (13, )
+    np.testing.assert_allclose(matrix, expect, rtol=1e-12)
+    assert np.all(matrix[:, 1] == 0)
+    # errors and edge cases
+    with pytest.raises(ValueError, match='half the box'):
+        corrfunc.mass_in_cylinders(galaxies, particles, 1.0, np.array([1.0, 46.0]), box)
+    with pytest.raises(ValueError, match='one entry per particle'):
+        corrfunc.mass_in_cylinders(galaxies, particles, np.ones(3), rp_bins, box)
+    with pytest.raises(ValueError, match='outside'):
+        corrfunc.mass_in_cylinders(galaxies - 500.0, particles, 1.0, rp_bins, box)
+    assert corrfunc.mass_in_cylinders(galaxies[:0], particles, 1.0, rp_bins, box).shape == (0, 14)
+    assert np.all(corrfunc.mass_in_cylinders(galaxies, particles[:0], 1.0, rp_bins, box) == 0)

@@ -199,3 +199,29 @@ def test_oracle_wrappers_match_the_reference_fixture():
                                                    sample2=data['particles'])
     assert tuple(shape) == tuple(data['shape_cross_smu'])
     np.testing.assert_allclose(matrix, data['matrix_cross_smu'], **close)
+
+
+def test_mass_in_cylinders_and_delta_sigma_known_answers():
+    box = (20.0, 20.0, 50.0)
+    rp_bins = np.array([1.0, 2.0, 4.0])
+    galaxies = np.array([[5.0, 5.0, 1.0], [19.5, 10.0, 40.0]])
+    # around galaxy 0: one particle at r = 0.5, two at r = 1.5 (any z), one at r = 3;
+    # around galaxy 1: one particle across the periodic boundary at r = 1 (edge: r <= 1)
+    particles = np.array([[5.5, 5.0, 30.0], [5.0, 6.5, 2.0], [3.5, 5.0, 49.0], [5.0, 2.0, 7.0],
+                          [0.5, 10.0, 3.0]])
+    mass = oracle.mass_in_cylinders(galaxies, particles, 2.0, rp_bins, box)
+    assert mass.tolist() == [[2.0, 6.0, 8.0], [2.0, 2.0, 2.0]]
+    weights = np.array([1.0, 10.0, 100.0, 1000.0, 5.0])
+    mass = oracle.mass_in_cylinders(galaxies, particles, weights, rp_bins, box)
+    assert mass.tolist() == [[1.0, 111.0, 1111.0], [5.0, 5.0, 5.0]]
+    # a uniform sheet: Sigma(< R) = Sigma(R), so Delta Sigma = 0 up to shot noise
+    rng = np.random.default_rng(0)
+    sheet = rng.uniform(0, 1, (40000, 3)) * np.array(box)
+    ds = oracle.mean_delta_sigma(rng.uniform(0, 1, (50, 3)) * np.array(box), sheet, 1.0,
+                                 np.array([1.0, 2.0, 4.0, 8.0]), box)
+    assert np.all(np.abs(ds) < 0.1 * 40000 / 400.0)
+    # a point mass M at the centre of a galaxy: Sigma(< R) = M / (pi R^2), Sigma(R) = 0
+    ds = oracle.mean_delta_sigma(np.array([[10.0, 10.0, 0.0]]), np.array([[10.0, 10.0, 9.0]]),
+                                 3.0, rp_bins, box)
+    mids = np.sqrt(0.5 * (rp_bins[:-1]**2 + rp_bins[1:]**2))
+    np.testing.assert_allclose(ds, 3.0 / (np.pi * mids**2), rtol=1e-12)
