@@ -359,3 +359,70 @@ def test_mass_in_cylinders_and_mean_delta_sigma():
         corrfunc.mass_in_cylinders(galaxies - 500.0, particles, 1.0, rp_bins, box)
     assert corrfunc.mass_in_cylinders(galaxies[:0], particles, 1.0, rp_bins, box).shape == (0, 14)
     assert np.all(corrfunc.mass_in_cylinders(galaxies, particles[:0], 1.0, rp_bins, box) == 0)
+
+
+def test_tabulate_swaps_in_the_one_pass_pair_count(monkeypatch):
+    """TabCorr.tabulate delegates mock population to the reference package (halotools-bound,
+    absent here) and swaps the reference's per-pair process pool (tabcorr.py:846-922) for the
+    GPU's one-pass count.  A stand-in `tabcorr` package whose tabulate() drives
+    module.compute_tpcf_matrix exactly as the reference does (tabcorr.py:318-344: call,
+    symmetric packing) executes that glue end to end: matrix = oracle's, the reference's
+    function restored afterwards, and the tabulated object predicts."""
+    import types
+    from tabcorr_amd import TabCorr, corrfunc, synthetic, symmetric_matrix_to_array
+    from oracle import paircount_oracle as oracle
+
+    def reference_compute_tpcf_matrix(*args, **kwargs):
+        raise AssertionError('the process-pool loop must have been swapped out')
+
+    module = types.ModuleType('tabcorr.tabcorr')
+    module.compute_tpcf_matrix = reference_compute_tpcf_matrix
+
+    class ReferenceTabCorr:
+        @classmethod
+        def tabulate(cls, halocat, tpcf, *tpcf_args, mode='auto', **kwargs):
+            matrix, shape = module.compute_tpcf_matrix(
+                mode, halocat['pos'], tpcf, halocat['period'], tpcf_args,
+                halocat.get('tpcf_kwargs', {}), num_threads=kwargs.get('num_threads', 1))
+            if mode == 'auto':
+                matrix = np.array([symmetric_matrix_to_array(m) for m in matrix])
+            out = cls()
+            out.gal_type, out.tpcf_matrix, out.tpcf_shape = halocat['gal_type'], matrix, shape
+            out.attrs, out.tpcf_args, out.tpcf_kwargs = halocat['attrs'], tpcf_args, {}
+            return out
+    ReferenceTabCorr.__module__ = 'tabcorr.tabcorr'
+    package = types.ModuleType('tabcorr')
+    package.TabCorr = ReferenceTabCorr
+    package.tabcorr = module
+    monkeypatch.setitem(sys.modules, 'tabcorr', package)
+    monkeypatch.setitem(sys.modules, 'tabcorr.tabcorr', module)
+
+    table = synthetic.synthetic_table(4, 1, (5, ), 'auto', seed=3)      # 8 halo/galaxy bins
+    rng = np.random.default_rng(21)
+    period = np.array([80.0, 80.0, 80.0])
+    pos = [clustered(rng, n, period, 20, 3.0) for n in (300, 120, 260, 90, 400, 150, 60, 220)]
+    rp_bins = np.array([0.3, 0.8, 2.0, 5.0, 9.0, 15.0])
+    halocat = {'pos': pos, 'period': period, 'gal_type': table['gal_type'],
+               'attrs': table['attrs']}
+    halotab = TabCorr.tabulate(halocat, corrfunc.wp, rp_bins, 20.0, mode='auto')
+    assert module.compute_tpcf_matrix is reference_compute_tpcf_matrix      # restored
+    expect, shape = oracle.compute_tpcf_matrix_wp('auto', pos, period, rp_bins, 20.0)
+    expect = np.array([symmetric_matrix_to_array(m) for m in expect])
+    assert tuple(halotab.tpcf_shape) == tuple(shape) == (5, )
+    np.testing.assert_allclose(halotab.tpcf_matrix, expect, rtol=1e-13, atol=1e-13)
+    ngal, xi = halotab.predict_batch(synthetic.zheng07_draws(8, seed=4))
+    assert xi.shape == (8, 5) and np.all(np.isfinite(xi)) and np.all(ngal > 0)
+    # the excess surface density, mode 'cross' (scripts/tabulate_snapshot.py:228-237)
+    particles = clustered(rng, 20000, period, 20, 5.0)
+    halocat['attrs'] = dict(table['attrs'], mode='cross')
+    ds_bins = np.logspace(-0.5, 1.2, 7)
+    halotab = TabCorr.tabulate(halocat, corrfunc.mean_delta_sigma, particles, 1.5e10, ds_bins,
+                               mode='cross')
+    expect, shape = oracle.compute_tpcf_matrix_ds(pos, period, particles, 1.5e10, ds_bins)
+    np.testing.assert_allclose(halotab.tpcf_matrix, expect, rtol=1e-12)
+    ngal, ds = halotab.predict_batch(synthetic.zheng07_draws(8, seed=5))
+    assert ds.shape == (8, 6) and np.all(np.isfinite(ds))
+    # any other two-point function stays with the reference's own loop
+    with pytest.raises(AssertionError, match='swapped out'):
+        TabCorr.tabulate(halocat, lambda *a, **k: None, rp_bins, mode='cross')
+    assert module.compute_tpcf_matrix is reference_compute_tpcf_matrix
