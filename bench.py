@@ -204,9 +204,13 @@ def main():
     parser.add_argument('--draws', type=int, default=None,
                         help='cfg2: draws per GPU per step (10^4); interp5x5: draws per '
                              'step over ALL GPUs (10^5)')
-    parser.add_argument('--gather', choices=['full', 'chi2'], default='full',
-                        help='multi-GPU: gather (ngal, xi) of every draw, or the fused '
-                             'likelihood (ngal, chi2)')
+    parser.add_argument('--gather', choices=['full', 'chi2'], default=None,
+                        help='what every step leaves behind / multi-GPU: what is gathered on '
+                             'rank 0: (ngal, xi) of every draw (160 B per draw; default for '
+                             'one GPU, the configuration BASELINE.json names), or the fused '
+                             'likelihood (ngal, chi2) (16 B per draw; default for --gpus > 1: '
+                             'what an MCMC needs back, and 8 ranks of full results would put '
+                             '~260 GB/s on rank 0)')
     parser.add_argument('--gather-every', type=int, default=0,
                         help='multi-GPU: steps per RCCL gather of the results (default: 32, or '
                              'a quarter of --steps for short runs so that the gathers overlap '
@@ -226,13 +230,15 @@ def main():
                         help='measure BASELINE configs[2..4] as well (single GPU only)')
     args = parser.parse_args()
     interp_mode = args.workload == 'interp5x5'
+    if args.gather is None:
+        args.gather = 'chi2' if args.gpus > 1 else 'full'
     if args.steps is None:
         args.steps = 200 if interp_mode else 20000
     if args.warmup is None:
         args.warmup = 20 if interp_mode else 2000
 
     from tabcorr_amd import TabCorr, Interpolator, synthetic, _lib
-    from tabcorr_amd.parallel import Communicator
+    from tabcorr_amd.parallel import Communicator, ResultRing
 
     world_size = int(os.environ.get('WORLD_SIZE', '1'))
     if world_size != args.gpus:
@@ -299,14 +305,26 @@ def main():
     precision = np.eye(N_R) * 1e-2
     data_p, precision_p = _lib.as_double_p(data_vector), _lib.as_double_p(precision)
 
-    # Results ring: 4 blocks of `every` steps.  A block is gathered on rank 0 (RCCL, own
-    # stream) once its last step is queued; the other blocks keep filling meanwhile.
+    # Results ring (tabcorr_amd.parallel.ResultRing): 4 blocks of `every` steps.  A block is
+    # gathered on rank 0 (RCCL, own stream) once its last step is queued; the other blocks
+    # keep filling meanwhile.
     every = args.gather_every if args.gather_every > 0 else (
         32 if args.steps >= 128 else max(2, args.steps // 4))
-    n_blocks = 4                        # (the communicator has four send-buffer slots)
-    n_slots = n_blocks * every
-    d_out = dev.malloc(n_slots * n_out)
     use_rccl = comm.comm is not None
+    interp_handle = handle if interp_mode else None
+
+    def ring_gather(block, send_offset, recv_offset, count):
+        recv = ctypes.c_void_p(d_recv.value + recv_offset * 8) if comm.is_root else None
+        comm.gather_device(timer_handle, ctypes.c_void_p(d_out.value + send_offset * 8), recv,
+                           count, block, interp_handle=interp_handle)
+
+    ring = ResultRing(n_out, every, comm.world_size,
+                      gather=ring_gather if use_rccl else (lambda *a: None),
+                      release=(lambda block: comm.release(
+                          timer_handle, block, interp_handle=interp_handle)) if use_rccl
+                      else None)               # (the communicator has four send-buffer slots)
+    n_slots = ring.n_slots
+    d_out = dev.malloc(ring.ring_elements)
     lanes_used = args.lanes if args.lanes > 0 else 4
     if use_rccl and args.lanes == 0 and not interp_mode and every < 16:
         # Frequent gathers: the communicator's stream is a fifth stream on the runtime's four
@@ -316,9 +334,7 @@ def main():
         # tools/r02_forced_comm.sh); with a gather every 32 steps four lanes stay ahead.
         lanes_used = 3
         _lib.check(lib.tc_table_set_option(timer_handle, b'lanes', lanes_used))
-    d_recv = dev.malloc(n_blocks * comm.world_size * every * n_out) if (
-        use_rccl and comm.is_root) else ctypes.c_void_p()
-    interp_handle = handle if interp_mode else None
+    d_recv = dev.malloc(ring.recv_elements) if (use_rccl and comm.is_root) else ctypes.c_void_p()
 
     def out_ptr(slot, offset=0):
         return ctypes.c_void_p(d_out.value + (slot * n_out + offset) * 8)
@@ -341,27 +357,14 @@ def main():
                 handle, d_theta, 5, n_draws, N_GAUSS, 0, out_ptr(slot),
                 out_ptr(slot, n_draws)))
 
-    def gather_block(block, n_steps):
-        recv = ctypes.c_void_p(
-            d_recv.value + block * comm.world_size * every * n_out * 8) if (
-                comm.is_root) else None
-        comm.gather_device(timer_handle, out_ptr(block * every), recv, n_steps * n_out, block,
-                           interp_handle=interp_handle)
-
     def step(index):
-        slot = index % n_slots
-        block = slot // every
-        if use_rccl and index >= n_slots and slot % every == 0:
-            # the block's previous gather is done before it is overwritten
-            comm.release(timer_handle, block, interp_handle=interp_handle)
-        predict(slot)
-        if use_rccl and slot % every == every - 1:
-            gather_block(block, every)
+        ring.before_step(index)
+        predict(ring.slot(index))
+        ring.after_step(index)
 
     def flush(n_steps):
         """Gather the steps of a trailing, partly filled block."""
-        if use_rccl and n_steps % every:
-            gather_block(((n_steps - 1) % n_slots) // every, n_steps % every)
+        ring.flush(n_steps)
 
     def synchronize():
         if interp_mode:
@@ -524,6 +527,11 @@ def main():
                 'gather': comm.gather_backend,
                 'gather_payload': 'ngal + chi2 (16 B per draw)' if chi2_mode
                                   else 'ngal + xi (%d B per draw)' % (8 * (1 + N_R)),
+                'gather_payload_options': {
+                    'chi2': '16 B per draw = %.2f MB per rank per gather' %
+                            (16e-6 * n_draws * every),
+                    'full': '%d B per draw = %.2f MB per rank per gather' %
+                            (8 * (1 + N_R), 8e-6 * (1 + N_R) * n_draws * every)},
                 'gather_every_steps': every,
                 'lanes': lanes_used,
             },

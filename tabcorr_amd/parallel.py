@@ -122,9 +122,11 @@ class Communicator:
                 raise _lib.TabCorrHipError('no HIP device')
             _lib.check(lib.tc_set_device(self.local_rank))
             _lib.check(lib.tc_comm_unique_id(buffer))
-        except (_lib.TabCorrHipError, OSError, ValueError,
-                NotImplementedError) as exc:
-            error = str(exc)
+        except Exception as exc:   # noqa: BLE001 -- every failure is a vote
+            # (also e.g. subprocess.CalledProcessError of an on-demand build:
+            # whatever goes wrong here, this rank must still reach the
+            # all_reduce below or the others would wait for it)
+            error = '{}: {}'.format(type(exc).__name__, exc)
         ok = torch.tensor([0 if error else 1], dtype=torch.int32)
         self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
         unique = torch.zeros(_lib.UNIQUE_ID_BYTES, dtype=torch.uint8)
@@ -229,6 +231,123 @@ class Communicator:
             self.comm = None
 
 
+def packed_count(n_local, n_ngal, n_comp, n_r):
+    """Doubles one rank contributes to the gather: ``[ngal (n_local, n_ngal) |
+    xi (n_local, n_comp, n_r)]``."""
+    return n_local * (n_ngal + n_comp * n_r)
+
+
+def unpack_gathered(flat, world_size, n_local, n_ngal, n_comp, n_r, n_draws):
+    """Undo the gather of `packed_count` blocks: ``flat`` holds the blocks of
+    all ranks, rank-major, as ``ncclGather`` delivers them; returns ``ngal
+    (n_draws, n_ngal)`` and ``xi (n_draws, n_comp, n_r)`` in the caller's
+    draw order (round-robin undone, padding rows dropped)."""
+    count = packed_count(n_local, n_ngal, n_comp, n_r)
+    flat = np.asarray(flat).reshape(world_size, count)
+    ngal = assemble([part[:n_local * n_ngal].reshape(n_local, n_ngal)
+                     for part in flat], n_draws)
+    xi = assemble([part[n_local * n_ngal:].reshape(n_local, n_comp, n_r)
+                   for part in flat], n_draws)
+    return ngal, xi
+
+
+class ResultRing:
+    """Bookkeeping of a ring of per-step result slots that is drained to the
+    root block by block (``bench.py --gpus N``; any producer that keeps the
+    results of many steps on the device and gathers them in the background).
+
+    The ring holds ``n_blocks`` blocks of ``every`` slots of ``n_out`` doubles.
+    Step ``k`` writes slot ``k % (n_blocks * every)``.  When the last slot of
+    a block has been written the block is gathered (``gather`` -- injectable:
+    RCCL on device buffers in production, gloo on host arrays in the CPU
+    tests); before the first slot of a block is written again the producer
+    waits for that block's previous gather (``release``).  `flush` gathers a
+    trailing, partly filled block.
+
+    ``gather(block, send_offset, recv_offset, count)`` must collect ``count``
+    doubles starting at element ``send_offset`` of every rank's ring into the
+    root's receive buffer at ``recv_offset``, rank-major (rank ``r`` at
+    ``recv_offset + r * count``): the layout of ``ncclGather``.  The receive
+    buffer has ``n_blocks * world_size * every * n_out`` elements; block ``b``
+    owns ``[b, b + 1) * world_size * every * n_out``.
+
+    Every gather is recorded in ``self.log`` as ``(block, first_step,
+    n_steps, recv_offset, count)`` so that a consumer on the root knows which
+    steps a region holds (`steps_in`).
+    """
+
+    def __init__(self, n_out, every, world_size, gather, release=None,
+                 n_blocks=4):
+        if every < 1 or n_blocks < 1:
+            raise ValueError('every and n_blocks must be positive.')
+        self.n_out = n_out
+        self.every = every
+        self.world_size = world_size
+        self.n_blocks = n_blocks
+        self.n_slots = n_blocks * every
+        self._gather = gather
+        self._release = release
+        self.log = []
+        self._gathers_of_block = [0] * n_blocks
+
+    @property
+    def ring_elements(self):
+        return self.n_slots * self.n_out
+
+    @property
+    def recv_elements(self):
+        return self.n_blocks * self.world_size * self.every * self.n_out
+
+    def slot(self, index):
+        return index % self.n_slots
+
+    def slot_offset(self, index):
+        """Element offset of the slot step ``index`` writes."""
+        return self.slot(index) * self.n_out
+
+    def recv_offset(self, block):
+        return block * self.world_size * self.every * self.n_out
+
+    def _gather_block(self, block, first_step, n_steps):
+        count = n_steps * self.n_out
+        self._gather(block, block * self.every * self.n_out,
+                     self.recv_offset(block), count)
+        self._gathers_of_block[block] += 1
+        self.log.append((block, first_step, n_steps, self.recv_offset(block),
+                         count))
+
+    def before_step(self, index):
+        """Call before the producer of step ``index`` is queued."""
+        slot = self.slot(index)
+        block = slot // self.every
+        if (slot % self.every == 0 and self._release is not None and
+                self._gathers_of_block[block] > 0):
+            # the block's previous gather is done before it is overwritten
+            self._release(block)
+
+    def after_step(self, index):
+        """Call after the producer of step ``index`` is queued."""
+        slot = self.slot(index)
+        if slot % self.every == self.every - 1:
+            self._gather_block(slot // self.every, index - self.every + 1,
+                               self.every)
+
+    def flush(self, n_steps):
+        """Gather the trailing, partly filled block after ``n_steps`` steps
+        (counted from a multiple of the ring size)."""
+        rest = n_steps % self.every
+        if rest:
+            self._gather_block(self.slot(n_steps - 1) // self.every,
+                               n_steps - rest, rest)
+
+    def steps_in(self, entry, rank):
+        """For a log entry: ``[(step, offset)]`` of rank ``rank``'s steps inside
+        the root's receive buffer."""
+        block, first_step, n_steps, recv_offset, count = entry
+        return [(first_step + k, recv_offset + rank * count + k * self.n_out)
+                for k in range(n_steps)]
+
+
 class _DeviceArray:
     """A device allocation of doubles owned through the C ABI."""
 
@@ -288,7 +407,7 @@ def _predict_sharded_rccl(predictor, theta, communicator, x=None,
     n_local, n_r = len(shard), table.n_r
     n_ngal = 2 if separate_gal_type else 1
     n_comp = table.n_components if separate_gal_type else 1
-    count = n_local * (n_ngal + n_comp * n_r)
+    count = packed_count(n_local, n_ngal, n_comp, n_r)
     flags = _flags(separate_gal_type, modulate_with_cenocc, assembias, family)
     d_theta = _DeviceArray(shard.size)
     d_theta.upload(shard)
@@ -313,11 +432,8 @@ def _predict_sharded_rccl(predictor, theta, communicator, x=None,
     communicator.synchronize()
     if not communicator.is_root:
         return None
-    flat = d_recv.download().reshape(world, count)
-    ngal = assemble([part[:n_local * n_ngal].reshape(n_local, n_ngal)
-                     for part in flat], n_draws)
-    xi = assemble([part[n_local * n_ngal:].reshape(n_local, n_comp, n_r)
-                   for part in flat], n_draws)
+    ngal, xi = unpack_gathered(d_recv.download(), world, n_local, n_ngal,
+                               n_comp, n_r, n_draws)
     return first._package(ngal, xi, separate_gal_type)
 
 

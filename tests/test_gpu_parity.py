@@ -15,6 +15,13 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-10
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]
+
+
 def make_tabcorr(table, **kwargs):
     from tabcorr_amd import TabCorr
     return TabCorr.from_arrays(table['gal_type'], table['tpcf_matrix'],
@@ -466,7 +473,7 @@ def test_bench_under_torchrun_single_rank(mode):
     result = subprocess.run(
         [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
          '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port',
-         '29533', os.path.join(REPO, 'bench.py'), '--gpus', '1', '--cpu-seconds', '0',
+         str(_free_port()), os.path.join(REPO, 'bench.py'), '--gpus', '1', '--cpu-seconds', '0',
          '--settle-seconds', '0.05', '--other-configs', '0'] + extra,
         env=env, capture_output=True, text=True, timeout=900)
     assert result.returncode == 0, result.stdout[-2000:] + result.stderr[-2000:]
@@ -622,7 +629,7 @@ comm.close()
 print("sharded ok")
 ''' % {'repo': REPO}
     env = dict(os.environ, TABCORR_AMD_FORCE_COMM='1', MASTER_ADDR='127.0.0.1',
-               MASTER_PORT='29547', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+               MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     result = subprocess.run([sys.executable, '-c', script], env=env,
                             capture_output=True, text=True, timeout=900)
     assert result.returncode == 0, result.stdout[-2000:] + result.stderr[-2000:]

@@ -312,6 +312,13 @@ print('rank', comm.rank, 'ok')
 '''
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]
+
+
 def test_sharded_predict_world_size_2_gloo(tmp_path):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER % {'repo': REPO})
@@ -319,10 +326,146 @@ def test_sharded_predict_world_size_2_gloo(tmp_path):
     result = subprocess.run(
         [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
          '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-         '--master-port', '29517', str(script)],
+         '--master-port', str(_free_port()), str(script)],
         env=env, capture_output=True, text=True, timeout=600)
     assert result.returncode == 0, result.stdout + result.stderr
     assert result.stdout.count('ok') == 2
+
+
+RING_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(repo)r)
+sys.path.insert(0, os.path.join(%(repo)r, 'tests'))
+from util import load_golden, table_from_golden
+from oracle import tabcorr_oracle as oracle
+from tabcorr_amd import parallel
+
+comm = parallel.Communicator.from_env(use_rccl=False)
+world, rank = comm.world_size, comm.rank
+assert world == int(os.environ['EXPECT_WORLD'])
+
+# ---- the result ring of bench.py, drained over a fake data plane (gloo on host arrays) ----
+n_out = 6
+for every, n_blocks, steps in ((4, 4, 37), (3, 4, 12), (5, 2, 23), (1, 4, 9), (7, 4, 5)):
+    ring_buffer = np.full(n_blocks * every * n_out, np.nan)
+    recv = np.full(n_blocks * world * every * n_out, np.nan) if comm.is_root else None
+    seen = {}
+    released = []
+
+    def gather(block, send_offset, recv_offset, count):
+        parts = comm.gather_host(ring_buffer[send_offset:send_offset + count].copy())
+        if comm.is_root:
+            # rank-major, as ncclGather delivers it
+            recv[recv_offset:recv_offset + world * count] = np.concatenate(parts)
+
+    ring = parallel.ResultRing(n_out, every, world, gather, released.append, n_blocks)
+    assert ring.ring_elements == ring_buffer.size
+    assert not comm.is_root or ring.recv_elements == recv.size
+    consumed = 0
+    for index in range(steps):
+        ring.before_step(index)
+        offset = ring.slot_offset(index)
+        # the "prediction" of step `index` on this rank: a signature per element
+        ring_buffer[offset:offset + n_out] = 1000.0 * rank + index + 0.01 * np.arange(n_out)
+        ring.after_step(index)
+        # the root consumes every gather as soon as it is logged
+        while consumed < len(ring.log):
+            if comm.is_root:
+                for r in range(world):
+                    for step, where in ring.steps_in(ring.log[consumed], r):
+                        assert (r, step) not in seen, (r, step)
+                        seen[(r, step)] = recv[where:where + n_out].copy()
+            consumed += 1
+    ring.flush(steps)
+    while consumed < len(ring.log):
+        if comm.is_root:
+            for r in range(world):
+                for step, where in ring.steps_in(ring.log[consumed], r):
+                    assert (r, step) not in seen, (r, step)
+                    seen[(r, step)] = recv[where:where + n_out].copy()
+        consumed += 1
+    if comm.is_root:
+        # every rank's every step exactly once, with that rank's and step's values
+        assert sorted(seen) == [(r, k) for r in range(world) for k in range(steps)], (every, steps)
+        for (r, k), values in seen.items():
+            assert np.array_equal(values, 1000.0 * r + k + 0.01 * np.arange(n_out)), (r, k)
+    # a block is released exactly when it is about to be rewritten after a gather
+    expect_released = [(k %% (n_blocks * every)) // every for k in range(steps)
+                       if k %% every == 0 and k >= n_blocks * every]
+    assert released == expect_released, (released, expect_released)
+    # the gathers are collectives: every rank logged the same sequence
+    assert comm.max(len(ring.log)) == len(ring.log)
+
+# ---- pack / gather / unpack arithmetic of the RCCL route, over the same fake --------------
+data = load_golden('synthetic_rp_pi')
+table = table_from_golden(data)
+n_r = int(np.prod(table['tpcf_shape']))
+for n_draws in (1, 7, 15, 16):
+    theta = data['theta'][:n_draws]
+    shard = parallel.local_shard(theta, rank, world)
+    n_local = len(shard)
+    for separate in (False, True):
+        n_ngal, n_comp = (2, 3) if separate else (1, 1)
+        ngal, xi = oracle.predict_zheng07_batch(table, shard, separate_gal_type=separate)
+        if separate:
+            ngal = np.stack([ngal['centrals'], ngal['satellites']], axis=1)
+            xi = np.stack([xi[k].reshape(n_local, n_r) for k in
+                           ('centrals-centrals', 'centrals-satellites',
+                            'satellites-satellites')], axis=1)
+        # what the device leaves in d_out: [ngal (n_local, n_ngal) | xi (n_local, n_comp, n_r)]
+        packed = np.concatenate([np.ravel(ngal), np.ravel(xi)])
+        assert packed.size == parallel.packed_count(n_local, n_ngal, n_comp, n_r)
+        parts = comm.gather_host(packed)
+        if comm.is_root:
+            got_ngal, got_xi = parallel.unpack_gathered(
+                np.concatenate(parts), world, n_local, n_ngal, n_comp, n_r, n_draws)
+            e_ngal, e_xi = oracle.predict_zheng07_batch(table, theta, separate_gal_type=separate)
+            if separate:
+                assert np.array_equal(got_ngal[:, 1], e_ngal['satellites'])
+                assert np.array_equal(got_xi[:, 1].reshape(e_xi['centrals-satellites'].shape),
+                                      e_xi['centrals-satellites'])
+            else:
+                assert np.array_equal(got_ngal[:, 0], e_ngal)
+                assert np.array_equal(got_xi[:, 0].reshape(e_xi.shape), e_xi)
+comm.barrier()
+print('rank', rank, 'ok')
+'''
+
+
+@pytest.mark.parametrize('world_size', [2, 3])
+def test_result_ring_and_rccl_route_arithmetic_over_gloo(tmp_path, world_size):
+    """bench.py's result ring (slots, blocks, releases, the partial flush, receive offsets) and
+    the pack / unpack arithmetic of the RCCL route of predict_batch_sharded, driven with
+    `steps` not divisible by `every` over a fake data plane: rank 0 must hold every rank's
+    every step exactly once."""
+    script = tmp_path / 'ring_worker.py'
+    script.write_text(RING_WORKER % {'repo': REPO})
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', EXPECT_WORLD=str(world_size))
+    result = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+         '--nproc-per-node', str(world_size), '--master-addr', '127.0.0.1',
+         '--master-port', str(port), str(script)],
+        env=env, capture_output=True, text=True, timeout=600)
+    assert result.returncode == 0, result.stdout + result.stderr
+    assert result.stdout.count('ok') == world_size
+
+
+def test_result_ring_single_rank_bookkeeping():
+    from tabcorr_amd.parallel import ResultRing
+    calls = []
+    ring = ResultRing(10, 3, 2, lambda *a: calls.append(a), n_blocks=4)
+    for index in range(8):
+        ring.before_step(index)
+        ring.after_step(index)
+    ring.flush(8)
+    # blocks 0 and 1 complete, block 2 holds steps 6 and 7
+    assert calls == [(0, 0, 0, 30), (1, 30, 60, 30), (2, 60, 120, 20)]
+    assert [entry[:3] for entry in ring.log] == [(0, 0, 3), (1, 3, 3), (2, 6, 2)]
+    assert ring.steps_in(ring.log[2], 1) == [(6, 120 + 20), (7, 120 + 30)]
+    with pytest.raises(ValueError):
+        ResultRing(10, 0, 2, None)
 
 
 # -- HDF5 through the C library (no h5py / astropy) -------------------------------------

@@ -17,6 +17,6 @@ print("calls/s %.4g  ms/step %.4f  contract %.4f ms  parity %.2g" % (
 PY
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof_l1
-TC_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_l1 -- \
-  python3 bench.py --steps 300 --warmup 30 --cpu-seconds 0 > gpurun_out/prof_l1.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_l1 -- \
+  python3 bench.py --lanes 1 --steps 300 --warmup 30 --cpu-seconds 0 > gpurun_out/prof_l1.log 2>&1
 cat gpurun_out/prof_l1/*/*kernel_stats.csv | cut -d, -f1-4 | cut -c1-110 | head -6

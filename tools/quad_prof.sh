@@ -3,8 +3,8 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 rm -rf gpurun_out/qp_l1 gpurun_out/qp_l4
-TC_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/qp_l1 -- \
-  python3 bench.py --steps 1500 --warmup 200 --cpu-seconds 0 > gpurun_out/qp_l1.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/qp_l1 -- \
+  python3 bench.py --lanes 1 --steps 1500 --warmup 200 --cpu-seconds 0 > gpurun_out/qp_l1.log 2>&1
 cat gpurun_out/qp_l1/*/*kernel_stats.csv | cut -d, -f1-4 | cut -c1-110 | head -6
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/qp_l4 -- \
   python3 bench.py --steps 600 --warmup 100 --cpu-seconds 0 > gpurun_out/qp_l4.log 2>&1
