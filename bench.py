@@ -693,7 +693,15 @@ def unbatched(make, table, synthetic, Interpolator):
         model.param_dict['logMmin'] = 12.0 + 1e-5 * (count[0] % 1000)
         interp.predict(model)
     grid = time_calls(call_interp, seconds=0.3, warm=20)
+    # an ensemble sampler's step: n independent walkers per call, one launch
+    # (tc_predict_zheng07_many behind predict_batch)
+    walkers = {}
+    for n in (1, 16, 64):
+        theta = synthetic.zheng07_draws(n, seed=70 + n)
+        seconds = time_calls(lambda: halotab.predict_batch(theta), seconds=0.2, warm=50)
+        walkers['%d' % n] = {'us_per_call': seconds * 1e6, 'us_per_walker': seconds * 1e6 / n}
     return {'predict_model': single * 1e6, 'interpolator_5x5_predict_model': grid * 1e6,
+            'predict_batch_walkers': walkers,
             'unit': 'us per call (Python API, host model -> host results)'}
 
 

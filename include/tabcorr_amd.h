@@ -209,6 +209,18 @@ int tc_chi2_zheng07_batch_device(tc_table* table, const double* theta_device, in
                                  const double* data, const double* precision,
                                  double* ngal_device, double* chi2_device);
 
+/* A handful of independent draws in ONE launch (the proposals of an ensemble sampler's step,
+ * or the reference's un-batched predict(), README.md:72-75, for n_walkers = 1): every
+ * workgroup evaluates the occupations of its draw itself, contracts its share of the table
+ * and stores its partial sums and a completion word into page-locked host memory, which the
+ * host polls -- no device-side combination, no stream synchronisation.  theta (n_walkers,
+ * n_theta), ngal (n_walkers), xi (n_walkers, n_r): host arrays.  Total prediction only;
+ * calls the path cannot serve (TC_FLAG_SEPARATE_GAL_TYPE, more than 64 walkers, several r
+ * tiles, float32 tables, TC_FLAG_LEAUTHAUD11) are forwarded to tc_predict_zheng07_batch,
+ * which in turn routes small eligible batches here. */
+int tc_predict_zheng07_many(tc_table* table, const double* theta, int n_theta, int n_walkers,
+                            int n_gauss_prim, unsigned flags, double* ngal, double* xi);
+
 /* Asynchronous host-to-host form of the two calls above -- the SURVEY.md section 8d metric
  * (theta on the host -> (ngal, xi) on the host) at the device rate.  What it replaces in the
  * reference is the user's loop of predict() calls (README.md:72-75): an ensemble sampler

@@ -93,6 +93,9 @@ SIGNATURES = {
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
         ctypes.c_int, ctypes.c_uint, c_double_p, c_double_p, ctypes.c_void_p,
         ctypes.c_void_p],
+    'tc_predict_zheng07_many': [
+        ctypes.c_void_p, c_double_p, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_uint, c_double_p, c_double_p],
     'tc_predict_zheng07_batch_async': [
         ctypes.c_void_p, c_double_p, ctypes.c_int, ctypes.c_int64,
         ctypes.c_int, ctypes.c_uint, c_double_p, c_double_p, c_int64_p],

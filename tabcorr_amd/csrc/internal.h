@@ -133,6 +133,22 @@ inline size_t zero_copy_limit() {
   return limit;
 }
 
+// Page-locked workspace of the un-batched path (launch.hip: launch_single_draw): the kernel
+// stores its results and one completion word per workgroup here, the host polls the words.
+struct SingleWorkspace {
+  PinnedBuffer buffer;
+  unsigned long long epoch = 0;
+  int jobs = 0, blocks = 0;
+  size_t partial_offset = 0, theta_offset = 0, done_offset = 0;   // in doubles
+  int prepare(int n_jobs, int n_blocks, int rt, int extra_doubles);
+  double* ngal() const { return (double*)buffer.ptr; }
+  double* partial() const { return (double*)buffer.ptr + partial_offset; }
+  double* theta() const { return (double*)buffer.ptr + theta_offset; }
+  unsigned long long* done() const {
+    return (unsigned long long*)((double*)buffer.ptr + done_offset);
+  }
+};
+
 template <typename T>
 int upload(const std::vector<T>& host, void** device) {
   size_t bytes = std::max<size_t>(1, host.size()) * sizeof(T);
@@ -204,6 +220,7 @@ struct Tuning {
   int lanes = 4;              // pipelining lanes of device-pointer calls (1..4)
   int pipeline = 1;           // 0: every device-pointer call on lane 0 (kernels serialised)
   int single_draw = 1;        // one-launch path for un-batched predict()
+  int poll_done = 1;          // ... completed by polling its completion words in host memory
   int quad_waves = 2;         // resident contraction waves per SIMD (quadratic-form kernel)
   int quad_merge = 1;         // workgroup-level merging of the partial slabs (hostmath.h)
   int quad_order = -1;        // schedule order of one table (-1: chosen by matrix size)
@@ -342,6 +359,7 @@ struct tc_table {
   std::vector<double> chi2_host;             // host copy of what chi2_data holds
   size_t wave_trace_count = 0;
   tc::host::PinnedBuffer h_in, h_out;
+  tc::host::SingleWorkspace single_ws;       // un-batched path
   size_t trace_blocks = 0;
   size_t trace_launches = 0;
 
@@ -413,10 +431,18 @@ int next_kernel_events(tc_table* t, hipEvent_t* start, hipEvent_t* stop);
 int64_t max_slab(const tc_table* t);
 bool single_draw_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags);
 constexpr int kSingleMaxBlocks = 64;
-constexpr size_t kSingleWsDoubles = 2 + (size_t)kSingleMaxBlocks * 32;
-int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_gauss,
-                       unsigned flags, double* host_ws, int* n_blocks, hipStream_t stream);
-void combine_single_draw(const tc_table* t, const double* host_ws, int n_blocks, double* ngal,
+constexpr int kSingleMaxWalkers = 64;
+// Batches of at most this many draws take the one-launch path (tools/r03_latency.py: 1 draw
+// 15 us, 16 draws 25 us, 64 draws 35 us against 36-37 us for the three-kernel path).
+inline int64_t many_walkers_limit() {
+  static const int64_t limit =
+      std::min<int64_t>(kSingleMaxWalkers, env_int_early("TC_MANY_WALKERS", 64));
+  return limit;
+}
+int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_walkers, int n_gauss,
+                       unsigned flags, SingleWorkspace* ws, hipStream_t stream);
+int wait_single_done(SingleWorkspace* ws, hipStream_t stream, bool poll = true);
+void combine_single_draw(const tc_table* t, const SingleWorkspace& ws, int walker, double* ngal,
                          double* xi);
 int single_draw_blocks(const tc_table* t);
 int launch_single_draw_tables(tc_table* t0, const SingleArgs& prepared, int n_tables,

@@ -43,6 +43,7 @@ struct tc_interp {
   DeviceBuffer chi2_xi, chi2_data;          // fused likelihood: xi workspace, data + precision
   std::vector<double> chi2_host;            // host copy of what chi2_data holds
   PinnedBuffer h_in, h_out;
+  SingleWorkspace single_ws;                // un-batched calls
   std::map<std::pair<int, int>, std::unique_ptr<DeviceChunking>> chunkings;
   // asynchronous host calls (tc_interp_*_async): uploads and kernels on `stream`, the
   // download of call k on `out_stream` behind it (results double-buffered), tickets as for
@@ -443,6 +444,7 @@ int tc_interp_destroy(tc_interp* it) {
     b->release();
   it->h_in.release();
   it->h_out.release();
+  it->single_ws.buffer.release();
   if (it->out_stream) (void)hipStreamSynchronize(it->out_stream);
   it->stage_in.release();
   for (DeviceBuffer& b : it->stage_out) b.release();
@@ -536,10 +538,10 @@ int interp_predict_one(tc_interp* it, const double* theta, int n_theta, const do
   const tc_interp::SinglePointers& p = found->second;
   const int blocks = single_draw_blocks(t0);
   const int rt = t0->rt, n_tables = it->n_tables;
-  const size_t ws_doubles = (size_t)n_tables * (2 + (size_t)blocks * rt);
-  int status = it->h_out.reserve(ws_doubles * sizeof(double));
+  SingleWorkspace& workspace = it->single_ws;
+  int status = workspace.prepare(n_tables, blocks, rt, 0);
   if (status != TC_OK) return status;
-  double* ws = (double*)it->h_out.ptr;
+  double* ws = workspace.ngal();
   tc::SingleArgs sa{};
   for (int i = 0; i < 7; ++i) sa.theta_value[i] = i < n_theta ? theta[i] : 0.0;
   sa.n_theta = n_theta;
@@ -557,7 +559,9 @@ int interp_predict_one(tc_interp* it, const double* theta, int n_theta, const do
   sa.n_r = t0->n_r;
   sa.mode = t0->mode;
   sa.ngal = ws;
-  sa.partial = ws + 2 * (size_t)n_tables;
+  sa.partial = workspace.partial();
+  sa.done = workspace.done();
+  sa.epoch = workspace.epoch;
   sa.tables = (const double* const*)it->d_tables;
   sa.table_class = (const int32_t*)it->d_table_class;
   sa.class_log_m = (const double* const*)p.log_m;
@@ -583,8 +587,9 @@ int interp_predict_one(tc_interp* it, const double* theta, int n_theta, const do
     for (int j = 0; j < n; ++j)
       weight[d][j] = m[j] + m[n + j] * xv + m[2 * n + j] * x2 + m[3 * n + j] * x3;
   }
-  TC_HIP(hipStreamSynchronize(it->stream));
-  const double* partial = ws + 2 * (size_t)n_tables;
+  status = wait_single_done(&workspace, it->stream, t0->tuning.poll_done != 0);
+  if (status != TC_OK) return status;
+  const double* partial = workspace.partial();
   double n_cen = 0.0, n_sat = 0.0;
   for (int r = 0; r < t0->n_r; ++r) xi[r] = 0.0;
   for (int k = 0; k < n_tables; ++k) {

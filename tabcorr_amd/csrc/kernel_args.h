@@ -82,6 +82,17 @@ struct SingleArgs {
   const double* const* class_n_h;
   const double* const* class_percentile;
   unsigned long long* stamps;   // developer timeline: 8 x 100 MHz stamps per block, or NULL
+  // Several independent draws in one launch (an ensemble sampler proposes many points per
+  // step): grid = n_walkers x blocks_per_table, workgroup b serves draw b / blocks_per_table
+  // whose parameters are theta_many[draw][n_theta] (page-locked host memory); partial
+  // (n_walkers, blocks_per_table, rt) and ngal (n_walkers, 2).  n_walkers == 0: one draw,
+  // theta_value.
+  const double* theta_many;
+  int n_walkers;
+  // Completion without a stream synchronisation: every workgroup, after its last store to
+  // host memory, sets done[workgroup] = epoch (system-scope release); the host polls.
+  unsigned long long* done;
+  unsigned long long epoch;
 };
 
 struct ContractArgs {

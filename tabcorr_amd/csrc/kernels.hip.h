@@ -1295,12 +1295,17 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
   __shared__ double node_value[kSingleMaxNodes];
   __shared__ double density[kSingleMaxBins];
   __shared__ double slice_sum[kSingleThreads];
+  __shared__ double totals[2];
   __shared__ __attribute__((aligned(16))) double table[fm::kTableDoubles];
   const int tid = threadIdx.x;
   const fm::Consts kc = fm::make_consts();
   auto stamp = [&](int phase) {
+#ifdef TC_DEVELOPER_KNOBS
     if (a.stamps != nullptr && tid == 0)
       a.stamps[blockIdx.x * 8 + phase] = __builtin_amdgcn_s_memrealtime();
+#else
+    (void)phase;
+#endif
   };
   stamp(0);
 
@@ -1324,6 +1329,14 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
     a.percentile = a.class_percentile[cls];
     a.ngal += 2 * which_table;
     a.partial += (int64_t)which_table * a.blocks_per_table * a.rt;
+  } else if (a.n_walkers > 0) {
+    const int walker = blockIdx.x / a.blocks_per_table;
+    part = blockIdx.x % a.blocks_per_table;
+    n_parts = a.blocks_per_table;
+    for (int i = 0; i < 7; ++i)
+      a.theta_value[i] = i < a.n_theta ? a.theta_many[walker * a.n_theta + i] : 0.0;
+    a.ngal += 2 * walker;
+    a.partial += (int64_t)walker * a.blocks_per_table * a.rt;
   }
   {
     typedef double __attribute__((ext_vector_type(2))) double2v;
@@ -1387,8 +1400,8 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
     for (int g = lo + lane; g < hi; g += 64) total += density[g];
 #pragma unroll
     for (int offset = 32; offset >= 1; offset >>= 1) total += __shfl_down(total, offset, 64);
-    // (every workgroup holds the same sums; the first one reports them)
-    if (lane == 0 && part == 0) a.ngal[which] = total;
+    // (every workgroup holds the same sums; the first one reports them, below)
+    if (lane == 0) totals[which] = total;
   }
 
   // contraction of this workgroup's positions: thread = (slice, r); eight positions per
@@ -1428,10 +1441,33 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
   slice_sum[tid] = acc;
   __syncthreads();
   stamp(3);
-  if (tid < rt) {
-    double total = 0.0;
-    for (int s = 0; s < n_slices; ++s) total += slice_sum[s * rt + tid];
-    a.partial[(int64_t)part * rt + tid] = total;     // host memory
+  // all stores to host memory come from wave 0 (rt <= 32): the partial sums, the number
+  // densities, then -- behind a system-scope fence -- the workgroup's completion word
+  // the slices of every r value are added in two levels (eight partial sums per r value, then
+  // one: 51 dependent LDS reads by 20 threads cost 1.4 us of a 7 us kernel), in fixed order
+  constexpr int kFan = 8;
+  double level = 0.0;
+  if (tid < rt * kFan) {
+    const int rr = tid % rt;
+    for (int s = tid / rt; s < n_slices; s += kFan) level += slice_sum[s * rt + rr];
+  }
+  __syncthreads();
+  if (tid < rt * kFan) slice_sum[tid] = level;
+  __syncthreads();
+  if (tid < 64) {
+    if (tid < rt) {
+      double total = 0.0;
+      for (int s = 0; s < kFan; ++s) total += slice_sum[s * rt + tid];
+      a.partial[(int64_t)part * rt + tid] = total;     // host memory
+    } else if (tid < rt + 2 && part == 0) {
+      a.ngal[tid - rt] = totals[tid - rt];
+    }
+    if (a.done != nullptr) {
+      __threadfence_system();
+      if (tid == 0)
+        __hip_atomic_store(a.done + blockIdx.x, a.epoch, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   stamp(4);
 }

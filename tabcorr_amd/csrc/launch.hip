@@ -892,20 +892,23 @@ bool single_draw_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsig
          (int64_t)t->n_bins * n_gauss <= tc::kSingleMaxNodes && t->tuning.single_draw;
 }
 
-// `host_ws`: page-locked host memory the kernel writes to, kSingleWsDoubles doubles:
-// [0] centrals, [1] satellites number density, then (workgroups, rt) partial sums of the
-// contraction.  combine_single_draw() turns it into (ngal, xi) after the stream is idle.
-int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_gauss,
-                       unsigned flags, double* host_ws, int* n_blocks, hipStream_t stream) {
+// Workspace of the un-batched path in page-locked host memory (SingleWorkspace, internal.h):
+// per draw [0] centrals, [1] satellites number density and (workgroups, rt) partial sums of
+// the contraction, then one completion word per workgroup.  n_walkers draws (1 ..
+// kSingleMaxWalkers) go through ONE launch; combine_single_draw() turns a draw's part into
+// (ngal, xi) once wait_single_done() has seen every workgroup's word.
+int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_walkers, int n_gauss,
+                       unsigned flags, SingleWorkspace* ws, hipStream_t stream) {
   Quadrature* q = nullptr;
   int status = get_quadrature(t, n_gauss, &q);
   if (status != TC_OK) return status;
-  // one pass of eight positions per thread: all of a thread's table loads are in flight
-  // together (a second pass costs another memory round trip, ~1.5 us)
-  const int n_slices = tc::kSingleThreads / t->rt;
-  const int blocks = (int)std::max<int64_t>(
-      1, std::min<int64_t>(kSingleMaxBlocks,
-                           (t->plan.n_positions + 8 * n_slices - 1) / (8 * n_slices)));
+  // workgroups per draw: a single pass over the table positions for a few draws; fewer (each
+  // evaluates all occupation nodes of its draw, and the host polls one word per workgroup)
+  // when many draws share the launch
+  const int blocks = std::max(1, std::min(single_draw_blocks(t),
+                                          std::max(2, env_int("TC_MANY_BLOCKS", 128) / n_walkers)));
+  status = ws->prepare(n_walkers, blocks, t->rt, n_walkers > 1 ? n_walkers * n_theta : 0);
+  if (status != TC_OK) return status;
   tc::SingleArgs sa{};
   for (int i = 0; i < 7; ++i) sa.theta_value[i] = i < n_theta ? theta[i] : 0.0;
   sa.n_theta = n_theta;
@@ -926,25 +929,35 @@ int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_gaus
   sa.rt = t->rt;
   sa.n_r = t->n_r;
   sa.mode = t->mode;
-  sa.ngal = host_ws;
-  sa.partial = host_ws + 2;
+  sa.ngal = ws->ngal();
+  sa.partial = ws->partial();
   sa.n_tables = 0;
   sa.blocks_per_table = blocks;
   sa.tables = nullptr;
   sa.table_class = nullptr;
   sa.class_log_m = sa.class_m = sa.class_weight = sa.class_n_h = sa.class_percentile = nullptr;
+  sa.theta_many = nullptr;
+  sa.n_walkers = 0;
+  if (n_walkers > 1) {
+    // the draws travel through page-locked memory the kernel reads itself
+    memcpy(ws->theta(), theta, (size_t)n_walkers * n_theta * sizeof(double));
+    sa.theta_many = ws->theta();
+    sa.n_walkers = n_walkers;
+  }
+  sa.done = ws->done();
+  sa.epoch = ws->epoch;
   sa.stamps = nullptr;
   if (t->tuning.trace) {
     // developer timeline (tc_table_set_option "trace"): 8 stamps per workgroup
-    status = t->trace.reserve(kSingleMaxBlocks * 8 * sizeof(unsigned long long), stream);
+    status = t->trace.reserve((size_t)n_walkers * kSingleMaxBlocks * 8 *
+                                  sizeof(unsigned long long), stream);
     if (status != TC_OK) return status;
     t->trace_blocks = (size_t)blocks;
     sa.stamps = (unsigned long long*)t->trace.ptr;
   }
-  hipLaunchKernelGGL(tc::single_draw_kernel, dim3((unsigned)blocks),
+  hipLaunchKernelGGL(tc::single_draw_kernel, dim3((unsigned)(blocks * n_walkers)),
                      dim3(tc::kSingleThreads), 0, stream, sa);
   TC_HIP(hipGetLastError());
-  *n_blocks = blocks;
   return TC_OK;
 }
 
@@ -957,6 +970,8 @@ int launch_single_draw_tables(tc_table* t0, const tc::SingleArgs& prepared, int 
   sa.n_tables = n_tables;
   sa.blocks_per_table = blocks_per_table;
   sa.stamps = nullptr;
+  sa.theta_many = nullptr;
+  sa.n_walkers = 0;
   (void)t0;
   hipLaunchKernelGGL(tc::single_draw_kernel, dim3((unsigned)(n_tables * blocks_per_table)),
                      dim3(tc::kSingleThreads), 0, stream, sa);
@@ -971,19 +986,83 @@ int single_draw_blocks(const tc_table* t) {
                            (t->plan.n_positions + 8 * n_slices - 1) / (8 * n_slices)));
 }
 
-// Host half of the un-batched path: the workgroups' partial sums in workgroup order,
+// Host half of the un-batched path: the partial sums of draw `walker` in workgroup order,
 // divided by the total pair weight (tabcorr.py:646-650).
-void combine_single_draw(const tc_table* t, const double* host_ws, int n_blocks, double* ngal,
+void combine_single_draw(const tc_table* t, const SingleWorkspace& ws, int walker, double* ngal,
                          double* xi) {
-  const double total = host_ws[0] + host_ws[1];
+  const double* densities = ws.ngal() + 2 * (size_t)walker;
+  const double total = densities[0] + densities[1];
   const double norm = t->mode == TC_MODE_AUTO ? total * total : total;
-  const double* partial = host_ws + 2;
+  const double* partial = ws.partial() + (size_t)walker * ws.blocks * t->rt;
   for (int r = 0; r < t->n_r; ++r) {
     double sum = 0.0;
-    for (int b = 0; b < n_blocks; ++b) sum += partial[(size_t)b * t->rt + r];
+    for (int b = 0; b < ws.blocks; ++b) sum += partial[(size_t)b * t->rt + r];
     xi[r] = sum / norm;
   }
   ngal[0] = total;
+}
+
+// Page-locked workspace of the un-batched path: [ngal (jobs, 2) | partial (jobs, blocks, rt) |
+// theta (extra doubles) | done (jobs x blocks words)].  Every call gets a new epoch; a
+// workgroup's completion word carries the epoch of the call it belongs to.
+int SingleWorkspace::prepare(int n_jobs, int n_blocks, int rt, int extra_doubles) {
+  const size_t doubles = (size_t)n_jobs * (2 + (size_t)n_blocks * rt) + extra_doubles;
+  const size_t bytes = (doubles + (size_t)n_jobs * n_blocks) * sizeof(double);
+  if (bytes > buffer.bytes) {
+    int status = buffer.reserve(bytes);
+    if (status != TC_OK) return status;
+    memset(buffer.ptr, 0, buffer.bytes);     // (no stale completion words)
+    epoch = 0;
+  }
+  jobs = n_jobs;
+  blocks = n_blocks;
+  partial_offset = 2 * (size_t)n_jobs;
+  theta_offset = partial_offset + (size_t)n_jobs * n_blocks * rt;
+  done_offset = theta_offset + extra_doubles;
+  ++epoch;
+  return TC_OK;
+}
+
+// Wait until every workgroup of the launch has stored its completion word (written behind
+// its results with a system-scope release): polling host memory costs the PCIe write latency
+// where hipStreamSynchronize adds the runtime's signal path (~5 us per call).  Falls back to
+// the stream synchronisation -- which also reports a failed launch -- after 2 ms, and joins the
+// stream every 256 calls so that the runtime retires its finished commands.
+int wait_single_done(SingleWorkspace* ws, hipStream_t stream, bool poll) {
+  const volatile unsigned long long* done = ws->done();
+  const int n = ws->jobs * ws->blocks;
+  const unsigned long long epoch = ws->epoch;
+  bool joined = false;
+  if (!poll) {
+    TC_HIP(hipStreamSynchronize(stream));
+    joined = true;
+  }
+  for (int b = 0; b < n && !joined; ++b) {
+    unsigned spins = 0;
+    timespec start{};
+    while (done[b] != epoch) {
+      __builtin_ia32_pause();
+      if ((++spins & 0x3ff) != 0) continue;
+      timespec now{};
+      clock_gettime(CLOCK_MONOTONIC, &now);
+      if (start.tv_sec == 0 && start.tv_nsec == 0) start = now;
+      if ((now.tv_sec - start.tv_sec) * 1000000000LL + (now.tv_nsec - start.tv_nsec) > 2000000LL) {
+        TC_HIP(hipStreamSynchronize(stream));
+        joined = true;
+        break;
+      }
+    }
+  }
+  if (joined) {
+    for (int b = 0; b < n; ++b)
+      if (done[b] != epoch)
+        return fail(TC_ERR_HIP, "the un-batched kernel finished without reporting workgroup %d",
+                    b);
+  } else if ((ws->epoch & 0xff) == 0) {
+    TC_HIP(hipStreamSynchronize(stream));
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return TC_OK;
 }
 
 int launch_finalize(const FinalizeArgs& args, const Tuning& tuning, hipStream_t stream) {

@@ -228,6 +228,7 @@ int tc_table_destroy(tc_table* t) {
     if (ticket.done) (void)hipEventDestroy(ticket.done);
   t->h_in.release();
   t->h_out.release();
+  t->single_ws.buffer.release();
   for (auto& ev : t->kernel_events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -334,6 +335,30 @@ int copy_out(PinnedBuffer* stage, double* ngal, size_t ngal_count, const void* d
 
 extern "C" {
 
+int tc_predict_zheng07_many(tc_table* t, const double* theta, int n_theta, int n_walkers,
+                            int n_gauss, unsigned flags, double* ngal, double* xi) {
+  int status = check_predict_args(t, theta, n_theta, n_walkers, n_gauss, flags);
+  if (status != TC_OK) return status;
+  if (n_walkers == 0) return TC_OK;
+  TC_CHECK(ngal && xi, "output pointer is NULL");
+  if (n_walkers > kSingleMaxWalkers || !single_draw_eligible(t, 1, n_gauss, flags)) {
+    // (separated by galaxy type, several r tiles, float32 tables, the Leauthaud11 family, more
+    // walkers than one launch takes: the batched path serves them)
+    TC_CHECK(n_walkers > many_walkers_limit() || !single_draw_eligible(t, 1, n_gauss, flags),
+             "internal: un-batched routing");
+    return tc_predict_zheng07_batch(t, theta, n_theta, n_walkers, n_gauss, flags, ngal, xi);
+  }
+  TC_HIP(hipSetDevice(t->device));
+  status = launch_single_draw(t, theta, n_theta, n_walkers, n_gauss, flags, &t->single_ws,
+                              t->stream);
+  if (status != TC_OK) return status;
+  status = wait_single_done(&t->single_ws, t->stream, t->tuning.poll_done != 0);
+  if (status != TC_OK) return status;
+  for (int w = 0; w < n_walkers; ++w)
+    combine_single_draw(t, t->single_ws, w, ngal + w, xi + (size_t)w * t->n_r);
+  return TC_OK;
+}
+
 int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
                              int64_t n_draws, int n_gauss, unsigned flags,
                              double* ngal, double* xi) {
@@ -353,17 +378,10 @@ int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
   // the results to page-locked host memory, which the device addresses directly; two API
   // calls and two copy-engine round trips less (1 draw 45 -> 40 us, 1000 draws 72 -> 54 us;
   // beyond ~1 MB the copy engines win).
-  if (single_draw_eligible(t, n_draws, n_gauss, flags) &&
-      t->h_out.reserve(kSingleWsDoubles * sizeof(double)) == TC_OK) {
-    // one draw: one launch, the device-side combination replaced by a few hundred additions
-    // here (kernels.hip.h: single_draw_kernel)
-    int n_blocks = 0;
-    status = launch_single_draw(t, theta, n_theta, n_gauss, flags, (double*)t->h_out.ptr,
-                                &n_blocks, t->stream);
-    if (status != TC_OK) return status;
-    TC_HIP(hipStreamSynchronize(t->stream));
-    combine_single_draw(t, (const double*)t->h_out.ptr, n_blocks, ngal, xi);
-    return TC_OK;
+  if (n_draws <= many_walkers_limit() && single_draw_eligible(t, 1, n_gauss, flags)) {
+    // one draw -- or a handful (an ensemble sampler's proposals): ONE launch, the device-side
+    // combination replaced by a few hundred additions here (kernels.hip.h: single_draw_kernel)
+    return tc_predict_zheng07_many(t, theta, n_theta, (int)n_draws, n_gauss, flags, ngal, xi);
   }
   if (theta_bytes + out_bytes <= zero_copy_limit() && t->h_in.reserve(theta_bytes) == TC_OK &&
       t->h_out.reserve(out_bytes) == TC_OK) {
@@ -782,6 +800,10 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
         value;
   } else if (key == "single_draw") {
     t->tuning.single_draw = value != 0;
+  } else if (key == "poll_done") {
+    // un-batched calls: 1 (default) poll the kernel's completion words in page-locked host
+    // memory, 0 wait with hipStreamSynchronize
+    t->tuning.poll_done = value != 0;
   } else if (key == "trace") {
     t->tuning.trace = value;
   } else if (key == "occ_splits" || key == "occ_per_cu" || key == "finalize_threads" ||

@@ -208,3 +208,62 @@ def test_threads_share_one_table():
     for thread in threads:
         thread.join()
     assert errors == []
+
+
+def test_many_walkers_in_one_launch():
+    """tc_predict_zheng07_many: n independent draws through ONE launch of the un-batched
+    kernel, completion polled in host memory -- against the golden vectors, the oracle and
+    the three-kernel path, for every n up to the limit and beyond it (forwarded)."""
+    from tabcorr_amd import _lib, synthetic
+    from oracle import tabcorr_oracle as oracle
+    data = load_golden('bolplanck_wp')
+    table = table_from_golden(data)
+    halotab = make_tabcorr(table)
+    device = halotab.to_device()
+    lib = device.lib
+    theta = np.ascontiguousarray(data['theta'])
+    for n in (1, 2, 3, 7, 16, len(theta)):
+        ngal, xi = np.full(n, np.nan), np.full((n, device.n_r), np.nan)
+        _lib.check(lib.tc_predict_zheng07_many(
+            device.handle, _lib.as_double_p(theta), 5, n, 10, 0, _lib.as_double_p(ngal),
+            _lib.as_double_p(xi)))
+        assert_rel(ngal, data['ngal'][:n], RTOL, 'ngal, %d walkers' % n)
+        assert_rel(xi, data['xi'][:n], RTOL, 'xi, %d walkers' % n)
+    # modulate_with_cenocc and n_gauss_prim through the same path; repeated calls (epochs)
+    for _ in range(300):
+        ngal, xi = halotab.predict_batch(theta[:5], modulate_with_cenocc=True)
+    assert_rel(xi, data['xi_modulate'][:5], RTOL)
+    ngal, xi = halotab.predict_batch(theta[:9], n_gauss_prim=100)
+    assert_rel(xi, data['xi_ng100'][:9], RTOL)
+    # the same draws through the three-kernel path and through the oracle
+    draws = synthetic.zheng07_draws(64, seed=12)
+    _lib.check(lib.tc_table_set_option(device.handle, b'single_draw', 0))
+    batch = halotab.predict_batch(draws)
+    _lib.check(lib.tc_table_set_option(device.handle, b'single_draw', 1))
+    many = halotab.predict_batch(draws)
+    assert_rel(many[1], batch[1], 1e-12)
+    expect = oracle.predict_zheng07_batch(table, draws)
+    assert_rel(many[0], expect[0], RTOL)
+    assert_rel(many[1], expect[1], RTOL)
+    # stream synchronisation instead of polling gives the same
+    _lib.check(lib.tc_table_set_option(device.handle, b'poll_done', 0))
+    assert_rel(halotab.predict_batch(draws)[1], many[1], 0.0, floor=0.0)
+    _lib.check(lib.tc_table_set_option(device.handle, b'poll_done', 1))
+    # more walkers than one launch takes, and a request the path cannot serve: forwarded
+    big = synthetic.zheng07_draws(100, seed=13)
+    ngal, xi = np.empty(100), np.empty((100, device.n_r))
+    _lib.check(lib.tc_predict_zheng07_many(
+        device.handle, _lib.as_double_p(big), 5, 100, 10, 0, _lib.as_double_p(ngal),
+        _lib.as_double_p(xi)))
+    assert_rel(xi, oracle.predict_zheng07_batch(table, big)[1], RTOL)
+    ngal2, xi3 = np.empty((4, 2)), np.empty((4, 3, device.n_r))
+    _lib.check(lib.tc_predict_zheng07_many(
+        device.handle, _lib.as_double_p(theta), 5, 4, 10, _lib.FLAG_SEPARATE_GAL_TYPE,
+        _lib.as_double_p(ngal2), _lib.as_double_p(xi3)))
+    assert_rel(xi3[:, 1], data['xi_sep_centrals-satellites'][:4], RTOL)
+    # NaN parameters reject the draw only
+    bad = theta[:6].copy()
+    bad[2, 1] = np.nan
+    ngal, xi = halotab.predict_batch(bad)
+    assert np.isnan(ngal[2]) and np.all(np.isnan(xi[2]))
+    assert_rel(xi[[0, 1, 3, 4, 5]], data['xi'][[0, 1, 3, 4, 5]], RTOL)
