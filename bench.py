@@ -62,8 +62,6 @@ sys.path.insert(0, REPO)
 # 157.3 TFLOP/s (/opt/skills/guides/MI355X_MICROARCH.md).
 FP64_PEAK_TFLOPS = 78.6
 FP32_PEAK_TFLOPS = 157.3
-PMC_FILE = os.path.join(REPO, 'profiles', 'r02_pmc_counters.txt')
-
 N_PRIM, N_SEC, N_R = 50, 1, 19
 N_GAUSS = 10
 FLAG_SEPARATE, FLAG_ASSEMBIAS = 1, 4
@@ -77,23 +75,33 @@ def pair_flops(n_bins, n_r):
     return 2.0 * n_r * n_pairs + 3.0 * n_pairs
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE and WRITE_SIZE in KB; FETCH_SIZE doubled per the gfx950 correction of the
-    MI355X guide).  None when the file does not hold that kernel."""
-    try:
-        text = open(PMC_FILE).read()
-    except OSError:
-        return None
+def pmc_file(tag):
+    """Newest committed PMC summary of a configuration: profiles/rNN_pmc_counters[_tag].txt
+    (tools/profile_round.sh; tag '' = the headline configuration)."""
+    import glob
+    suffix = '_pmc_counters%s.txt' % ('_' + tag if tag else '')
+    files = sorted(f for f in glob.glob(os.path.join(REPO, 'profiles', 'r[0-9][0-9]' + suffix)))
+    return files[-1] if files else None
+
+
+def pmc_traffic(kernel, tag=''):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of
+    configuration `tag` (FETCH_SIZE and WRITE_SIZE in KB; FETCH_SIZE doubled per the gfx950
+    correction of the MI355X guide) and the file they come from; (None, None) when no
+    committed file holds that kernel."""
+    path = pmc_file(tag)
+    if path is None:
+        return None, None
     values = {}
     prefix = kernel[:40]
-    for line in text.splitlines():
+    for line in open(path).read().splitlines():
         match = re.match(r'(.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+\s+mean=([0-9.e+]+)', line)
         if match and prefix in match.group(1).replace('void ', ''):
             values[match.group(2)] = float(match.group(3))
     if len(values) != 2:
-        return None
-    return (2.0 * values['FETCH_SIZE'] + values['WRITE_SIZE']) * 1024.0
+        return None, None
+    return ((2.0 * values['FETCH_SIZE'] + values['WRITE_SIZE']) * 1024.0,
+            os.path.relpath(path, REPO))
 
 
 class Device:
@@ -228,6 +236,9 @@ def main():
                         help='also time one independent CPU walker per host core')
     parser.add_argument('--other-configs', type=int, default=1,
                         help='measure BASELINE configs[2..4] as well (single GPU only)')
+    parser.add_argument('--only-config', choices=CONFIG_TAGS, default=None,
+                        help='measure ONLY that configuration of other_configs and print its '
+                             'record (for rocprofv3 runs: tools/profile_round.sh)')
     args = parser.parse_args()
     interp_mode = args.workload == 'interp5x5'
     if args.gather is None:
@@ -255,6 +266,14 @@ def main():
     _lib.require_device()
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     _lib.check(lib.tc_set_device(local_rank))
+    if args.only_config:
+        def make_only(table, **kwargs):
+            return TabCorr.from_arrays(table['gal_type'], table['tpcf_matrix'],
+                                       table['tpcf_shape'], table['attrs'], **kwargs)
+        print(json.dumps(other_configs(lib, _lib, make_only, synthetic, Interpolator,
+                                       args.cpu_seconds, only=args.only_config,
+                                       lanes=args.lanes)), flush=True)
+        return
     comm = Communicator.from_env()
     rank = comm.rank
     dev = Device(lib, _lib)
@@ -488,6 +507,10 @@ def main():
 
         kernel_name = ('tc::contract_quad_kernel<5, true>' if interp_mode
                        else 'tc::contract_quad_kernel<5, false>')
+        headline_traffic = (pmc_traffic(kernel_name, 'interp5x5' if interp_mode else '')
+                            if n_draws == (100000 if interp_mode else 10000) // (
+                                comm.world_size if interp_mode else 1)
+                            else (None, None))
         achieved = flop_contract / (isolated_ms * 1e-3) / 1e12
         total_draws = comm.world_size * n_draws * args.steps
         if interp_mode:
@@ -542,11 +565,11 @@ def main():
                 'peak': FP64_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': achieved / FP64_PEAK_TFLOPS,
-                'traffic': pmc_traffic(kernel_name) if n_draws == 10000 and not interp_mode
-                           else None,
-                'traffic_source': 'profiles/r02_pmc_counters.txt (separate rocprofv3 --pmc '
-                                  'FETCH_SIZE / WRITE_SIZE passes of this script; FETCH_SIZE x 2 '
-                                  'per the gfx950 correction)',
+                'traffic': headline_traffic[0],
+                'traffic_source': '%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '
+                                  'of this script, tools/profile_round.sh; FETCH_SIZE x 2 per '
+                                  'the gfx950 correction)' % headline_traffic[1]
+                                  if headline_traffic[1] else None,
                 'flop_per_launch': flop_contract,
                 'mean_launch_ms': isolated_ms,
                 'launches_timed': n_launch,
@@ -753,12 +776,24 @@ def tabulation(cpu_seconds):
 
 # ---- BASELINE configs[2], [3], [4] ----------------------------------------------------------
 
-def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds):
+CONFIG_TAGS = ('cfg3', 'cfg4', 'cfg5f32', 'cfg5f64')
+
+
+def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=None, lanes=0):
+    """BASELINE configs[2] ('cfg3': separate + assembly bias), configs[3] ('cfg4': one GPU's
+    share of the 5 x 5 interpolator), configs[4] in float32 and float64 ('cfg5f32',
+    'cfg5f64'): device rate, host rate, the dominant kernel serialised with per-launch
+    events, its roofline fraction and committed traffic, the whole step's fraction, an oracle
+    spot check of the first and last draws of the timed batch, the CPU port.  `only`: one
+    tag (what tools/profile_round.sh wraps in rocprofv3)."""
     from oracle import tabcorr_oracle as oracle
     out = {}
     dev = Device(lib, _lib)
     theta = synthetic.zheng07_draws(10000, seed=1)
     cpu_budget = min(3.0, cpu_seconds / 4) if cpu_seconds > 0 else 0.0
+
+    def wanted(tag):
+        return only is None or only == tag
 
     def cpu_rate(call, n_max=100000):
         if cpu_budget <= 0:
@@ -773,8 +808,10 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds):
         return {'value': count / spent, 'unit': 'calls/s', 'cores': 1, 'kind': 'port',
                 'sample': '%d sequential predict() calls in %.1f s' % (count, spent)}
 
-    def measure(name, what, handle, timer_handle, launch, synchronize, host_call, n_draws, flop,
-                peak, kernel, dtype, cpu):
+    def measure(name, tag, what, timer_handle, launch, synchronize, host_call, n_draws, flop,
+                peak, kernel, dtype, cpu, parity):
+        if lanes > 0:
+            _lib.check(lib.tc_table_set_option(timer_handle, b'lanes', lanes))
         device_seconds = sustained(launch, synchronize)
         _lib.check(lib.tc_table_set_option(timer_handle, b'pipeline', 0))
         kernel_ms, n_launch, _ = kernel_time(lib, _lib, timer_handle, launch, synchronize,
@@ -782,82 +819,124 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds):
         _lib.check(lib.tc_table_set_option(timer_handle, b'pipeline', 1))
         host_seconds = time_calls(host_call, seconds=0.4, warm=3)
         achieved = flop / (kernel_ms * 1e-3) / 1e12
+        traffic, source = pmc_traffic(kernel, tag)
+        launch()
+        synchronize()
         out[name] = {
-            'workload': what, 'dtype': dtype, 'draws_per_call': n_draws,
+            'workload': what, 'tag': tag, 'dtype': dtype, 'draws_per_call': n_draws,
             'device_calls_per_sec': n_draws / device_seconds,
             'host_to_host_calls_per_sec': n_draws / host_seconds,
             'kernel': kernel, 'kernel_us': kernel_ms * 1e3, 'launches_timed': n_launch,
             'flop_per_launch': flop, 'achieved_tflops': achieved, 'peak_tflops': peak,
-            'frac': achieved / peak, 'cpu_baseline': cpu}
+            'frac': achieved / peak,
+            'step_frac': flop / device_seconds / 1e12 / peak,
+            'traffic': traffic, 'traffic_source': source,
+            'parity_max_rel_vs_oracle': parity(), 'cpu_baseline': cpu}
+
+    def rel(actual, expect, floor=1e-14):
+        scale = floor * np.max(np.abs(expect))
+        return float(np.max(np.abs(actual - expect) / np.maximum(np.abs(expect), scale)))
 
     # configs[2]: separate_gal_type + assembly bias on a 2-D halo-bin grid
-    table3 = synthetic.synthetic_table(50, 2, (N_R, ), 'auto', seed=3)
-    theta7 = np.hstack([theta, np.random.default_rng(0).uniform(-1, 1, (10000, 2))])
-    tab3 = make(table3)
-    h3 = tab3.to_device().handle
-    d_theta7 = dev.upload(theta7)
-    d_ngal, d_xi = dev.malloc(2 * 10000), dev.malloc(3 * N_R * 10000)
-    flags3 = FLAG_SEPARATE | FLAG_ASSEMBIAS
-    cache3 = {}
-    measure('configs[2]', 'separate_gal_type=True + Heaviside assembly bias, 50 x 2 x {cen,sat} '
-            'bins (G=200, P=20100), 19 rp bins, 10^4 draws', h3, h3,
-            lambda: _lib.check(lib.tc_predict_zheng07_batch_device(
-                h3, d_theta7, 7, 10000, N_GAUSS, flags3, d_ngal, d_xi)),
-            lambda: _lib.check(lib.tc_table_synchronize(h3)),
-            lambda: tab3.predict_batch(theta7, separate_gal_type=True, assembias=True),
-            10000, 10000 * pair_flops(200, N_R), FP64_PEAK_TFLOPS,
-            'tc::contract_quad_kernel<5, false>', 'f64',
-            cpu_rate(lambda i: oracle.predict_zheng07(
-                table3, theta7[i % 10000, :5], separate_gal_type=True,
-                assembias=theta7[i % 10000, 5:], cache=cache3)))
-    del tab3
+    if wanted('cfg3'):
+        table3 = synthetic.synthetic_table(50, 2, (N_R, ), 'auto', seed=3)
+        theta7 = np.hstack([theta, np.random.default_rng(0).uniform(-1, 1, (10000, 2))])
+        tab3 = make(table3)
+        h3 = tab3.to_device().handle
+        d_theta7 = dev.upload(theta7)
+        d_ngal, d_xi = dev.malloc(2 * 10000), dev.malloc(3 * N_R * 10000)
+        flags3 = FLAG_SEPARATE | FLAG_ASSEMBIAS
+        cache3 = {}
+        ends = np.r_[0:2, 9998:10000]
+
+        def parity3():
+            ngal = dev.download(d_ngal, 2 * 10000).reshape(10000, 2)
+            xi = dev.download(d_xi, 3 * N_R * 10000).reshape(10000, 3, N_R)
+            expect = oracle.predict_zheng07_batch(table3, theta7[ends, :5],
+                                                  separate_gal_type=True,
+                                                  assembias=theta7[ends, 5:])
+            worst = max(rel(ngal[ends, i], expect[0][key])
+                        for i, key in enumerate(('centrals', 'satellites')))
+            return max([worst] + [rel(xi[ends, i], expect[1][key]) for i, key in enumerate(
+                ('centrals-centrals', 'centrals-satellites', 'satellites-satellites'))])
+        measure('configs[2]', 'cfg3', 'separate_gal_type=True + Heaviside assembly bias, 50 x 2 x '
+                '{cen,sat} bins (G=200, P=20100), 19 rp bins, 10^4 draws', h3,
+                lambda: _lib.check(lib.tc_predict_zheng07_batch_device(
+                    h3, d_theta7, 7, 10000, N_GAUSS, flags3, d_ngal, d_xi)),
+                lambda: _lib.check(lib.tc_table_synchronize(h3)),
+                lambda: tab3.predict_batch(theta7, separate_gal_type=True, assembias=True),
+                10000, 10000 * pair_flops(200, N_R), FP64_PEAK_TFLOPS,
+                'tc::contract_quad_kernel<5, false>', 'f64',
+                cpu_rate(lambda i: oracle.predict_zheng07(
+                    table3, theta7[i % 10000, :5], separate_gal_type=True,
+                    assembias=theta7[i % 10000, 5:], cache=cache3)), parity3)
+        del tab3
 
     # configs[3]: one GPU's share (12 500 draws) of the 5 x 5 interpolator
-    tables, keys, points = synthetic.synthetic_interpolator((5, 5), N_PRIM, N_SEC, (N_R, ),
-                                                            'auto', seed=7)
-    interp = Interpolator([make(t) for t in tables],
-                          {k: points[:, d] for d, k in enumerate(keys)})
-    n4 = 12500
-    theta4 = synthetic.zheng07_draws(n4, seed=5)
-    rng = np.random.default_rng(6)
-    x4 = np.ascontiguousarray(np.stack(
-        [rng.uniform(xp[0], xp[-1], size=n4) for xp in interp.xp], axis=-1))
-    idev = interp.to_device()
-    d_theta4, d_x4 = dev.upload(theta4), dev.upload(x4)
-    d_ngal4, d_xi4 = dev.malloc(n4), dev.malloc(n4 * N_R)
-    setup = oracle.interpolator_setup(tables, points)
-    measure('configs[3]', 'Interpolator.predict over a 5 x 5 grid of configs[1] tables, one '
-            "GPU's share of 10^5 draws (12 500)", idev.handle, idev.tables[0].handle,
-            lambda: _lib.check(lib.tc_interp_predict_zheng07_batch_device(
-                idev.handle, d_theta4, 5, d_x4, n4, N_GAUSS, 0, d_ngal4, d_xi4)),
-            lambda: _lib.check(lib.tc_interp_synchronize(idev.handle)),
-            lambda: interp.predict_batch(theta4, x4), n4,
-            n4 * 25 * pair_flops(100, N_R), FP64_PEAK_TFLOPS,
-            'tc::contract_quad_kernel<5, true>', 'f64',
-            cpu_rate(lambda i: oracle.interpolator_predict(
-                tables, setup, oracle.Zheng07(theta4[i % n4]), x4[i % n4])))
-    del interp, idev
+    if wanted('cfg4'):
+        tables, keys, points = synthetic.synthetic_interpolator((5, 5), N_PRIM, N_SEC, (N_R, ),
+                                                                'auto', seed=7)
+        interp = Interpolator([make(t) for t in tables],
+                              {k: points[:, d] for d, k in enumerate(keys)})
+        n4 = 12500
+        theta4 = synthetic.zheng07_draws(n4, seed=5)
+        rng = np.random.default_rng(6)
+        x4 = np.ascontiguousarray(np.stack(
+            [rng.uniform(xp[0], xp[-1], size=n4) for xp in interp.xp], axis=-1))
+        idev = interp.to_device()
+        d_theta4, d_x4 = dev.upload(theta4), dev.upload(x4)
+        d_ngal4, d_xi4 = dev.malloc(n4), dev.malloc(n4 * N_R)
+        setup = oracle.interpolator_setup(tables, points)
+        ends4 = np.r_[0:2, n4 - 2:n4]
+
+        def parity4():
+            expect = oracle.interpolator_predict_zheng07_batch(tables, setup, theta4[ends4],
+                                                               x4[ends4])
+            return max(rel(dev.download(d_ngal4, n4)[ends4], expect[0]),
+                       rel(dev.download(d_xi4, n4 * N_R).reshape(n4, N_R)[ends4], expect[1],
+                           floor=1e-12))
+        measure('configs[3]', 'cfg4', 'Interpolator.predict over a 5 x 5 grid of configs[1] '
+                "tables, one GPU's share of 10^5 draws (12 500)", idev.tables[0].handle,
+                lambda: _lib.check(lib.tc_interp_predict_zheng07_batch_device(
+                    idev.handle, d_theta4, 5, d_x4, n4, N_GAUSS, 0, d_ngal4, d_xi4)),
+                lambda: _lib.check(lib.tc_interp_synchronize(idev.handle)),
+                lambda: interp.predict_batch(theta4, x4), n4,
+                n4 * 25 * pair_flops(100, N_R), FP64_PEAK_TFLOPS,
+                'tc::contract_quad_kernel<5, true>', 'f64',
+                cpu_rate(lambda i: oracle.interpolator_predict(
+                    tables, setup, oracle.Zheng07(theta4[i % n4]), x4[i % n4])), parity4)
+        del interp, idev
 
     # configs[4]: AbacusSummit-scale table, rp_pi (19 x 40), float32 MFMA variant and float64
-    table5 = synthetic.synthetic_table(100, 1, (19, 40), 'auto', seed=9)
-    n_r5 = 760
-    d_ngal5, d_xi5 = dev.malloc(10000), dev.malloc(10000 * n_r5)
-    d_theta5 = dev.upload(theta)
-    cache5 = {}
-    cpu5 = cpu_rate(lambda i: oracle.predict_zheng07(table5, theta[i % 10000], cache=cache5))
-    for dtype, peak, kernel in (('float32', FP32_PEAK_TFLOPS, 'tc::contract_quad_f32_kernel<4, false>'),
-                                ('float64', FP64_PEAK_TFLOPS,
-                                 'tc::contract_mfma_kernel<32, false>')):
-        tab5 = make(table5, compute_dtype=dtype)
-        h5 = tab5.to_device().handle
-        measure('configs[4] ' + dtype, 'rp_pi table 19 x 40 (R=760), 100 x {cen,sat} bins (G=200, '
-                'P=20100), 10^4 draws, %s table and contraction' % dtype, h5, h5,
-                lambda: _lib.check(lib.tc_predict_zheng07_batch_device(
-                    h5, d_theta5, 5, 10000, N_GAUSS, 0, d_ngal5, d_xi5)),
-                lambda: _lib.check(lib.tc_table_synchronize(h5)),
-                lambda: tab5.predict_batch(theta), 10000, 10000 * pair_flops(200, n_r5), peak,
-                kernel, 'f32' if dtype == 'float32' else 'f64', cpu5)
-        del tab5
+    if wanted('cfg5f32') or wanted('cfg5f64'):
+        table5 = synthetic.synthetic_table(100, 1, (19, 40), 'auto', seed=9)
+        n_r5 = 760
+        d_ngal5, d_xi5 = dev.malloc(10000), dev.malloc(10000 * n_r5)
+        d_theta5 = dev.upload(theta)
+        cache5 = {}
+        cpu5 = cpu_rate(lambda i: oracle.predict_zheng07(table5, theta[i % 10000], cache=cache5))
+        ends5 = np.r_[0, 9999]
+        expect5 = oracle.predict_zheng07_batch(table5, theta[ends5])
+
+        def parity5():
+            xi = dev.download(d_xi5, 10000 * n_r5).reshape((10000, ) + expect5[1].shape[1:])
+            return max(rel(dev.download(d_ngal5, 10000)[ends5], expect5[0]),
+                       rel(xi[ends5], expect5[1]))
+        for dtype, tag, peak, kernel in (
+                ('float32', 'cfg5f32', FP32_PEAK_TFLOPS, 'tc::contract_quad_f32_kernel<4, false>'),
+                ('float64', 'cfg5f64', FP64_PEAK_TFLOPS, 'tc::contract_mfma_kernel<32, false>')):
+            if not wanted(tag):
+                continue
+            tab5 = make(table5, compute_dtype=dtype)
+            h5 = tab5.to_device().handle
+            measure('configs[4] ' + dtype, tag, 'rp_pi table 19 x 40 (R=760), 100 x {cen,sat} '
+                    'bins (G=200, P=20100), 10^4 draws, %s table and contraction' % dtype, h5,
+                    lambda: _lib.check(lib.tc_predict_zheng07_batch_device(
+                        h5, d_theta5, 5, 10000, N_GAUSS, 0, d_ngal5, d_xi5)),
+                    lambda: _lib.check(lib.tc_table_synchronize(h5)),
+                    lambda: tab5.predict_batch(theta), 10000, 10000 * pair_flops(200, n_r5),
+                    peak, kernel, 'f32' if dtype == 'float32' else 'f64', cpu5, parity5)
+            del tab5
     dev.free_all()
     return out
 

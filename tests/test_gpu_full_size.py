@@ -131,19 +131,25 @@ def test_config4_interpolator_5x5():
     assert_rel(sum(xi_sep.values()), xi[:3000], 1e-11)
 
 
+# draws the oracle checks in a batch of 10^4: both ends, the boundaries of the 32- and 64-draw
+# tiles of the contraction kernels, the middle, and the last (partly filled) tile
+BENCH_DRAWS = 10000
+BENCH_INDEX = np.r_[0:2, 31:34, 63:66, 4999:5001, 9983:9985, 9998:10000]
+
+
 def test_config5_rp_pi_table_float64():
-    """AbacusSummit-scale table: 100 mass bins x {cen, sat}, tpcf_shape (19, 40);
-    R = 760 exercises the r tiling.  (The float32 variant of configs[4] is not built
-    yet; float64 is the stricter computation.)"""
+    """AbacusSummit-scale table at the batch size bench.py times (BASELINE configs[4] in
+    float64): 100 mass bins x {cen, sat}, tpcf_shape (19, 40); R = 760 exercises the r
+    tiling, 10^4 draws the schedule of the benchmark."""
     from tabcorr_amd import synthetic
     table = synthetic.synthetic_table(100, 1, (19, 40), 'auto', seed=9)
-    theta = synthetic.zheng07_draws(512, seed=8)
+    theta = synthetic.zheng07_draws(BENCH_DRAWS, seed=8)
     halotab = make(table)
     ngal, xi = halotab.predict_batch(theta)
-    assert xi.shape == (512, 19, 40)
-    oracle_check(table, theta, ngal, xi, np.r_[0:2, 510:512])
-    ngal_sep, xi_sep = halotab.predict_batch(theta, separate_gal_type=True)
-    assert_rel(sum(xi_sep.values()), xi, 1e-12)
+    assert xi.shape == (BENCH_DRAWS, 19, 40)
+    oracle_check(table, theta, ngal, xi, BENCH_INDEX)
+    ngal_sep, xi_sep = halotab.predict_batch(theta[:512], separate_gal_type=True)
+    assert_rel(sum(xi_sep.values()), xi[:512], 1e-12)
 
 
 def test_many_bins_auto_mode():
@@ -215,22 +221,63 @@ def test_float32_variant_small(case):
 
 
 def test_config5_float32_mfma():
-    """BASELINE configs[4] at full size: 100 mass bins x {cen, sat}, tpcf_shape
-    (19, 40), float32 table and accumulation on the matrix cores."""
+    """BASELINE configs[4] at full size AND at the batch size bench.py times (10^4 draws: 157
+    draw tiles of 64, the equal-share schedule of the benchmark): 100 mass bins x {cen, sat},
+    tpcf_shape (19, 40), float32 table and accumulation on the matrix cores -- against the
+    oracle on draws at both ends, across tile boundaries and in the last tile, and against
+    the float64 kernel on all draws."""
     from tabcorr_amd import synthetic
     from oracle import tabcorr_oracle as oracle
     table = synthetic.synthetic_table(100, 1, (19, 40), 'auto', seed=9)
-    theta = synthetic.zheng07_draws(2000, seed=8)
+    theta = synthetic.zheng07_draws(BENCH_DRAWS, seed=8)
     halotab32 = make(table, compute_dtype='float32')
     ngal, xi = halotab32.predict_batch(theta)
-    assert xi.shape == (2000, 19, 40)
-    expect = oracle.predict_zheng07_batch(table, theta[:3])
-    assert_rel(ngal[:3], expect[0], 1e-12)
-    assert_rel(xi[:3], expect[1], RTOL_F32)
+    assert xi.shape == (BENCH_DRAWS, 19, 40)
+    expect = oracle.predict_zheng07_batch(table, theta[BENCH_INDEX])
+    assert_rel(ngal[BENCH_INDEX], expect[0], 1e-12)
+    assert_rel(xi[BENCH_INDEX], expect[1], RTOL_F32)
     # against the float64 kernel on all draws
     ngal64, xi64 = make(table).predict_batch(theta)
+    assert_rel(ngal, ngal64, 1e-12)
     assert_rel(xi, xi64, RTOL_F32)
     assert np.max(np.abs(xi / xi64 - 1)) < RTOL_F32
+
+
+def test_configs_1_to_3_at_the_benchmarked_batch_size():
+    """The batch bench.py times (10^4 draws per call; 12 500 for the interpolator share)
+    against the oracle at both ends, across tile boundaries and in the last tile:
+    configs[1] total, configs[2] separated with assembly bias, configs[3] interpolated."""
+    from tabcorr_amd import Interpolator, synthetic
+    from oracle import tabcorr_oracle as oracle
+    theta = synthetic.zheng07_draws(BENCH_DRAWS, seed=1)
+    table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    ngal, xi = make(table).predict_batch(theta)
+    oracle_check(table, theta, ngal, xi, BENCH_INDEX)
+    table3 = synthetic.synthetic_table(50, 2, (19, ), 'auto', seed=3)
+    theta7 = np.hstack([theta, np.random.default_rng(0).uniform(-1, 1, (BENCH_DRAWS, 2))])
+    ngal_sep, xi_sep = make(table3).predict_batch(theta7, separate_gal_type=True,
+                                                  assembias=True)
+    expect = oracle.predict_zheng07_batch(table3, theta7[BENCH_INDEX, :5],
+                                          separate_gal_type=True,
+                                          assembias=theta7[BENCH_INDEX, 5:])
+    for key in expect[0]:
+        assert_rel(ngal_sep[key][BENCH_INDEX], expect[0][key], RTOL, key)
+    for key in expect[1]:
+        assert_rel(xi_sep[key][BENCH_INDEX], expect[1][key], RTOL, key)
+    tables, keys, points = synthetic.synthetic_interpolator((5, 5), 50, 1, (19, ), 'auto',
+                                                            seed=7)
+    interp = Interpolator([make(t) for t in tables],
+                          {k: points[:, d] for d, k in enumerate(keys)})
+    n4 = 12500
+    theta4 = synthetic.zheng07_draws(n4, seed=5)
+    rng = np.random.default_rng(6)
+    x4 = np.stack([rng.uniform(xp[0], xp[-1], size=n4) for xp in interp.xp], axis=-1)
+    ngal4, xi4 = interp.predict_batch(theta4, x4)
+    index = np.r_[0:2, 31:33, 6249:6251, n4 - 2:n4]
+    setup = oracle.interpolator_setup(tables, points)
+    expect = oracle.interpolator_predict_zheng07_batch(tables, setup, theta4[index], x4[index])
+    assert_rel(ngal4[index], expect[0], RTOL)
+    assert_rel(xi4[index], expect[1], RTOL, floor=1e-12)
 
 
 @pytest.mark.parametrize('shape,tpcf_shape,mode', [((4, 4), (40, ), 'auto'),
@@ -260,10 +307,28 @@ def test_float32_interpolator(shape, tpcf_shape, mode):
         for key in sep64:
             np.testing.assert_allclose(sep32[key], sep64[key], rtol=RTOL_F32,
                                        atol=RTOL_F32 * np.max(np.abs(sep64[key])))
+    # the oracle on 48 draws spread over the batch (first and last tiles included)
     setup = oracle.interpolator_setup(tables, points)
-    expect = oracle.interpolator_predict_zheng07_batch(tables, setup, theta[:4], x[:4])
-    np.testing.assert_allclose(xi32[:4], expect[1], rtol=RTOL_F32,
+    index = np.r_[0:16, 342:358, 684:700]
+    expect = oracle.interpolator_predict_zheng07_batch(tables, setup, theta[index], x[index])
+    assert_rel(ngal32[index], expect[0], 1e-11)
+    np.testing.assert_allclose(xi32[index], expect[1], rtol=RTOL_F32,
                                atol=RTOL_F32 * np.max(np.abs(expect[1])))
+    # a NaN coordinate with extrapolate=True: np.digitize puts it past the last node, the
+    # clamp keeps the segment, the polynomial is NaN (interpolator.py:318-329) -- that draw only
+    x_nan = x[:6].copy()
+    x_nan[2, 0] = np.nan
+    for interp in (interp64, interp32):
+        ngal_nan, xi_nan = interp.predict_batch(theta[:6], x_nan, extrapolate=True)
+        expect = oracle.interpolator_predict_zheng07_batch(tables, setup, theta[:6], x_nan,
+                                                           extrapolate=True)
+        assert np.isnan(expect[0][2]) and np.all(np.isnan(expect[1][2]))
+        assert np.isnan(ngal_nan[2]) and np.all(np.isnan(xi_nan[2]))
+        keep = [0, 1, 3, 4, 5]
+        np.testing.assert_allclose(xi_nan[keep], expect[1][keep], rtol=RTOL_F32,
+                                   atol=RTOL_F32 * np.max(np.abs(expect[1][keep])))
+    with pytest.raises(ValueError):
+        interp64.predict_batch(theta[:6], x_nan)
 
 
 def test_more_draws_than_one_slab():
