@@ -52,9 +52,10 @@ extern "C" {
 /* Occupation family of the theta columns (default: Zheng et al. 2007).  With
  * TC_FLAG_LEAUTHAUD11 every entry point named *_zheng07_* evaluates the Leauthaud et al.
  * (2011) centrals / satellites on the Behroozi et al. (2010) stellar-to-halo mass relation
- * instead; theta then has 13 columns: logm0, logm1, beta, delta, gamma (the relation at the
+ * instead; theta then has 14 columns: logm0, logm1, beta, delta, gamma (the relation at the
  * model's redshift), scatter, alphasat, bsat, betasat, bcut, betacut, threshold (log10 of
- * the stellar mass threshold), littleh.  TC_FLAG_MODULATE_WITH_CENOCC applies as for
+ * the stellar mass threshold), the Hubble parameter inside the relation (halotools'
+ * Behroozi10SmHm: 0.7) and that of the satellite terms (halotools' Leauthaud11Sats: 0.72).  TC_FLAG_MODULATE_WITH_CENOCC applies as for
  * Zheng07; TC_FLAG_ASSEMBIAS is not available for this family. */
 #define TC_FLAG_LEAUTHAUD11 16u
 
@@ -101,44 +102,8 @@ int tc_gauss_legendre(int n, double* x, double* w);
  * row index i1, column index i2 (i2 <= i1) and prefactor (1 on the diagonal, else 2). */
 int tc_pair_indices(int n_bins, int32_t* index_1, int32_t* index_2, int32_t* prefactor);
 
-/* Host evaluation of the table-driven FP64 functions the occupation kernel uses in place
- * of the device libm (tabcorr_amd/csrc/fastmath.h): kind 0 erf, 1 log2 (x > 0 normal),
- * 2 exp2, 3 exp10. */
-int tc_debug_fastmath(int kind, int64_t n, const double* x, double* y);
-
 /* Not-a-knot cubic spline matrix a[(n-1)][4][n] of interpolator.py:219-272. */
 int tc_spline_interpolation_matrix(int n, const double* xp, double* a);
-
-/* Work decomposition used by the contraction kernel for a table with n_bins rows of which
- * the first n_central (after the library's stable sort by gal_type) are centrals, cut into
- * n_chunks wave-sized pieces.  Outputs one record per packed column, in processing order:
- * entry_pair[e] = packed column p (auto) or bin (cross), entry_chunk[e], entry_class[e]
- * (0 cen-cen / cen, 1 cen-sat, 2 sat-sat / sat).  Lets CPU tests check that the kernel's
- * traversal covers every column exactly once and only gathers density rows its workgroup
- * stages (padding positions included). */
-int tc_plan_debug(int mode, int n_bins, const uint8_t* is_central, int n_chunks,
-                  int64_t* n_entries, int32_t* entry_pair, int32_t* entry_chunk,
-                  int32_t* entry_class);
-
-/* Quadratic-form contraction kernel (mode auto, float64; tabcorr_amd/csrc/hostmath.h):
- * builds the schedule for a table of n_bins bins (the first n_central centrals) and checks
- * that it covers every (draw tile, r tile, component, table, unit) exactly once with
- * consecutive slabs per output group; returns its size and the smallest / largest number
- * of units any wave gets. */
-int tc_debug_quad_schedule(int n_bins, int n_central, int by_type, int n_tiles, int n_rtiles,
-                           int n_tables, int separate, int max_waves, int min_units,
-                           int order /* 0 draw-tile-major, 1 table-major, 2 r-tile-major */,
-                           int* n_waves, int* n_runs, int* n_slabs, int64_t* units_min,
-                           int64_t* units_max);
-/* TEST INFRASTRUCTURE, never called by the product: executes the kernel's table layout,
- * schedule and slab grouping on the host, lane by lane, for densities (n_bins, ldb) given
- * in the reference's bin order; out (n_draws, 1 | 3, n_r) = sum_p c_p T[r][p] n_i n_j
- * before the normalisation (tabcorr.py:641-655).  Lets CPU tests check the index logic of
- * contract_quad_kernel / finalize_quad_kernel without a GPU. */
-int tc_debug_quad_emulate(int n_bins, int n_r, const double* tpcf_matrix,
-                          const uint8_t* is_central, int by_type, int separate,
-                          const double* densities, int64_t ldb, int64_t n_draws,
-                          int max_waves, int min_units, int order, double* out);
 
 /* ---- one tabulated table (replaces the state of a `TabCorr` instance) ----------------
  *
@@ -316,7 +281,7 @@ int tc_interp_wait(tc_interp* interp, int64_t ticket);
  *                 overlap; 0: every call on lane 0, kernels strictly serialised.
  *   "lanes"       number of lanes, 1..4 (default 4; more lose 20 %: four hardware queues).
  *   "single_draw" 1 (default): an un-batched predict() goes through one launch.
- *   "trace"       developer timelines (tc_debug_trace): 0 (default) off. */
+ *   "trace"       developer timelines (developer builds only, tabcorr_amd_testing.h). */
 int tc_table_set_option(tc_table* table, const char* name, int value);
 
 /* ---- measurement -------------------------------------------------------------------
@@ -329,14 +294,6 @@ int tc_table_set_option(tc_table* table, const char* name, int value);
 int tc_table_timer_begin(tc_table* table, int profile_kernels);
 int tc_table_timer_end(tc_table* table, float* elapsed_ms);
 int tc_table_kernel_time(tc_table* table, int* n_launches, float* mean_ms);
-/* Developer timeline (environment TC_TRACE=1): per workgroup of the last contraction
- * launch six words: 100 MHz timestamps at start / after staging / after the main loop /
- * at the end, HW_ID and XCC_ID.  Copies min(capacity, n_blocks) records. */
-int tc_debug_trace(tc_table* table, uint64_t* out, int64_t capacity, int64_t* n_blocks);
-/* Same run, per wavefront: timestamps at the start of the main loop, after 1/4, 1/2 and
- * 3/4 of its blocks and at the end, and HW_ID (wave slot / SIMD / CU). */
-int tc_debug_wave_trace(tc_table* table, uint64_t* out, int64_t capacity,
-                        int64_t* n_waves);
 /* Launch geometry of the last predict call (for DESIGN.md / bench.py reporting). */
 int tc_table_last_launch(const tc_table* table, int* n_workgroups, int* waves_per_workgroup,
                          int* n_splits, int* lds_bytes);

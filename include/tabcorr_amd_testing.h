@@ -1,0 +1,66 @@
+/*
+ * tabcorr_amd_testing.h -- test-infrastructure and developer hooks of libtabcorr_hip.so.
+ *
+ * NOT part of the drop-in boundary (include/tabcorr_amd.h): nothing here is called by the
+ * product's host classes.  The CPU tests (tests/test_host_cpu.py) use the tc_debug_* helpers
+ * to check host-side planning code and the table-driven math without a GPU; the timeline
+ * readers return data only from developer builds (-DTC_DEVELOPER_KNOBS, tools/build_dev.sh).
+ */
+#ifndef TABCORR_AMD_TESTING_H
+#define TABCORR_AMD_TESTING_H
+
+#include "tabcorr_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Host evaluation of the table-driven FP64 functions the occupation kernel uses in place
+ * of the device libm (tabcorr_amd/csrc/fastmath.h): kind 0 erf, 1 log2 (x > 0 normal),
+ * 2 exp2, 3 exp10. */
+int tc_debug_fastmath(int kind, int64_t n, const double* x, double* y);
+
+/* Work decomposition used by the contraction kernel for a table with n_bins rows of which
+ * the first n_central (after the library's stable sort by gal_type) are centrals, cut into
+ * n_chunks wave-sized pieces.  Outputs one record per packed column, in processing order:
+ * entry_pair[e] = packed column p (auto) or bin (cross), entry_chunk[e], entry_class[e]
+ * (0 cen-cen / cen, 1 cen-sat, 2 sat-sat / sat).  Lets CPU tests check that the kernel's
+ * traversal covers every column exactly once and only gathers density rows its workgroup
+ * stages (padding positions included). */
+int tc_plan_debug(int mode, int n_bins, const uint8_t* is_central, int n_chunks,
+                  int64_t* n_entries, int32_t* entry_pair, int32_t* entry_chunk,
+                  int32_t* entry_class);
+
+/* Quadratic-form contraction kernel (mode auto, float64; tabcorr_amd/csrc/hostmath.h):
+ * builds the schedule for a table of n_bins bins (the first n_central centrals) and checks
+ * that it covers every (draw tile, r tile, component, table, unit) exactly once with
+ * consecutive slabs per output group; returns its size and the smallest / largest number
+ * of units any wave gets. */
+int tc_debug_quad_schedule(int n_bins, int n_central, int by_type, int n_tiles, int n_rtiles,
+                           int n_tables, int separate, int max_waves, int min_units,
+                           int order /* 0 draw-tile-major, 1 table-major, 2 r-tile-major */,
+                           int* n_waves, int* n_runs, int* n_slabs, int64_t* units_min,
+                           int64_t* units_max);
+/* TEST INFRASTRUCTURE, never called by the product: executes the kernel's table layout,
+ * schedule and slab grouping on the host, lane by lane, for densities (n_bins, ldb) given
+ * in the reference's bin order; out (n_draws, 1 | 3, n_r) = sum_p c_p T[r][p] n_i n_j
+ * before the normalisation (tabcorr.py:641-655).  Lets CPU tests check the index logic of
+ * contract_quad_kernel / finalize_quad_kernel without a GPU. */
+int tc_debug_quad_emulate(int n_bins, int n_r, const double* tpcf_matrix,
+                          const uint8_t* is_central, int by_type, int separate,
+                          const double* densities, int64_t ldb, int64_t n_draws,
+                          int max_waves, int min_units, int order, double* out);
+
+/* Developer timeline (environment TC_TRACE=1): per workgroup of the last contraction
+ * launch six words: 100 MHz timestamps at start / after staging / after the main loop /
+ * at the end, HW_ID and XCC_ID.  Copies min(capacity, n_blocks) records. */
+int tc_debug_trace(tc_table* table, uint64_t* out, int64_t capacity, int64_t* n_blocks);
+/* Same run, per wavefront: timestamps at the start of the main loop, after 1/4, 1/2 and
+ * 3/4 of its blocks and at the end, and HW_ID (wave slot / SIMD / CU). */
+int tc_debug_wave_trace(tc_table* table, uint64_t* out, int64_t capacity,
+                        int64_t* n_waves);
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* TABCORR_AMD_TESTING_H */

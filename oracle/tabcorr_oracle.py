@@ -128,13 +128,14 @@ class Zheng07:
 # Restated from the literature, not from halotools' source: Behroozi, Conroy &
 # Wechsler (2010) eq. 21 for the stellar-to-halo mass relation and Leauthaud et
 # al. (2011) eqs. 8 and 12 for the occupations, with halotools' parameter
-# conventions (knee mass 1e12, littleh = 0.72, scatter sqrt(2) sigma).  halotools
+# conventions (knee mass 1e12, h = 0.7 inside the stellar-to-halo mass relation and
+# h = 0.72 in the satellite terms, scatter sqrt(2) sigma).  halotools
 # inverts the relation by cubic-spline interpolation of a 100-point table; here
 # the inverse is exact (bisection to the last bit), so agreement with halotools
 # is limited by ITS table, and these functions are pinned only against the duck
 # model of ``tests/golden/make_golden.py`` (an independent root finder).
 # theta: logm0, logm1, beta, delta, gamma, scatter, alphasat, bsat, betasat,
-# bcut, betacut, threshold, littleh.
+# bcut, betacut, threshold, h of the relation, h of the satellite terms.
 
 def behroozi10_log_halo_mass(log_stellar_mass, theta):
     x = log_stellar_mass + 2.0 * np.log10(theta[12]) - theta[0]
@@ -175,11 +176,11 @@ class Leauthaud11:
                                    sec_haloprop_percentile=None):
         t = self.theta
         prim_haloprop = np.asarray(prim_haloprop, dtype=np.float64)
-        knee = 10.0**behroozi10_log_halo_mass(t[11], t) * t[12]
+        knee = 10.0**behroozi10_log_halo_mass(t[11], t) * t[13]
         m_sat = 1e12 * t[7] * (knee / 1e12)**t[8]
         m_cut = 1e12 * t[9] * (knee / 1e12)**t[10]
-        n = (np.exp(-m_cut / (prim_haloprop * t[12])) *
-             (prim_haloprop * t[12] / m_sat)**t[6])
+        n = (np.exp(-m_cut / (prim_haloprop * t[13])) *
+             (prim_haloprop * t[13] / m_sat)**t[6])
         if self.modulate_with_cenocc:
             n = n * self.mean_occupation_centrals(prim_haloprop)
         return n
@@ -187,7 +188,7 @@ class Leauthaud11:
 
 def predict_leauthaud11_batch(table, theta, separate_gal_type=False,
                               n_gauss_prim=10, modulate_with_cenocc=True):
-    """`predict` for a batch of Leauthaud11 parameter vectors (13 columns)."""
+    """`predict` for a batch of Leauthaud11 parameter vectors (14 columns)."""
     theta = np.atleast_2d(theta)
     cache = {}
     results = [predict(table, mean_occupation(

@@ -35,7 +35,7 @@ def hipcc():
 def dependencies():
     files = [os.path.join(CSRC, f) for f in SOURCES]
     files += glob.glob(os.path.join(CSRC, '*.h'))
-    files.append(os.path.join(HERE, '..', 'include', 'tabcorr_amd.h'))
+    files += glob.glob(os.path.join(HERE, '..', 'include', '*.h'))
     return files
 
 

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/tabcorr_amd.h"
+#include "../../include/tabcorr_amd_testing.h"
 #include "fastmath.h"
 #include "hostmath.h"
 #include "kernel_args.h"

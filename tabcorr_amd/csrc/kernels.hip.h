@@ -17,6 +17,15 @@
 #include "hostmath.h"
 #include "kernel_args.h"
 
+// Developer timelines (per-workgroup / per-wave time stamps behind tc_table_set_option
+// "trace") exist only in developer builds (-DTC_DEVELOPER_KNOBS, tools/build_dev.sh); the
+// release kernels carry none of their branches.
+#ifdef TC_DEVELOPER_KNOBS
+#define TC_TRACE(pointer) ((pointer) != nullptr)
+#else
+#define TC_TRACE(pointer) false
+#endif
+
 namespace tc {
 
 static_assert(sizeof(QuadRun) == 32 && sizeof(QuadCompArgs) == 32, "read as 8 x int32");
@@ -283,23 +292,25 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
 // The second family evaluated on the device (the callbacks the
 // reference would get from halotools' Leauthaud11Cens / Leauthaud11Sats at
 // tabcorr.py:556-563), restated from the papers:
-//   stellar-to-halo mass relation (Behroozi, Conroy & Wechsler 2010, eq. 21), h = littleh:
+//   stellar-to-halo mass relation (Behroozi, Conroy & Wechsler 2010, eq. 21), h = the Hubble
+//   parameter of the relation (halotools' Behroozi10SmHm: 0.7), h_s that of the satellite
+//   terms (halotools' Leauthaud11Sats: 0.72):
 //     log10 M_h(M*) = logm1 + beta x + 10^(delta x) / (1 + 10^(-gamma x)) - 1/2 - log10 h,
 //     x = log10 M* + 2 log10 h - logm0
 //   centrals (Leauthaud et al. 2011, eq. 8):
 //     <N_cen>(M_h) = 1/2 [1 - erf((threshold - log10 M*(M_h)) / (sqrt 2 scatter))]
 //     with M*(M_h) the INVERSE of the relation above;
-//   satellites (eq. 12): <N_sat>(M_h) = [<N_cen>] (M_h h / M_sat)^alphasat exp(-M_cut / (M_h h)),
-//     M_sat = 1e12 bsat (M_knee / 1e12)^betasat, M_cut = 1e12 bcut (M_knee / 1e12)^betacut,
-//     M_knee = h M_h(M* = 10^threshold).
+//   satellites (eq. 12): <N_sat>(M_h) = [<N_cen>] (M_h h_s / M_sat)^alphasat
+//     exp(-M_cut / (M_h h_s)), M_sat = 1e12 bsat (M_knee / 1e12)^betasat, M_cut = 1e12 bcut
+//     (M_knee / 1e12)^betacut, M_knee = h_s M_h(M* = 10^threshold).
 // theta columns: logm0, logm1, beta, delta, gamma, scatter, alphasat, bsat, betasat, bcut,
-// betacut, threshold, littleh.  The inverse relation is solved per quadrature node by
+// betacut, threshold, h, h_s.  The inverse relation is solved per quadrature node by
 // Newton's method on g(x) = beta x + 10^(delta x) / (1 + 10^(-gamma x)) = log10(M_h h) + 1/2
 // - logm1, started right of the root (x0 = min(T / beta, log10(2 T) / delta)), to the last
 // bit (<= 11 iterations over the prior box, 5 typically); halotools itself interpolates a
 // 100-point table of the relation with a cubic spline, which is NOT reproduced here: only
 // this package's own Leauthaud11Model is routed to this kernel (models.device_spec).
-constexpr int kLeauthaudTheta = 13;
+constexpr int kLeauthaudTheta = 14;
 constexpr unsigned kFlagLeauthaud11 = 16u;
 
 struct SmhmSetup {
@@ -367,12 +378,16 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_leauthaud11_kernel(Occ
       const double log_m0 = th[0], log_m1 = th[1], beta = th[2], delta = th[3], gamma = th[4];
       const double scatter = th[5], alphasat = th[6], bsat = th[7], betasat = th[8];
       const double bcut = th[9], betacut = th[10], threshold = th[11], h = th[12];
+      const double h_sat = th[13];
       const double log_h = fm::log2_fast(table, kc, h > 1e-300 ? h : 1e-300) * kLog10Of2;
+      const double log_hs =
+          fm::log2_fast(table, kc, h_sat > 1e-300 ? h_sat : 1e-300) * kLog10Of2;
       // halo mass of the threshold: the forward relation, then the knee in units of 1e12
       const double x_t = threshold + 2.0 * log_h - log_m0;
       const double a_t = fm::exp10_fast(table, kc, delta * x_t);
       const double b_t = fm::exp10_fast(table, kc, -gamma * x_t);
-      const double log_knee = log_m1 + beta * x_t + a_t / (1.0 + b_t) - 0.5 - 12.0;
+      const double log_knee =
+          log_m1 + beta * x_t + a_t / (1.0 + b_t) - 0.5 - log_h + log_hs - 12.0;
       // log2 M_sat and M_cut * log2 e (bsat <= 0 or bcut < 0 have no real power law: NaN)
       const double log2_msat =
           bsat > 0.0 ? fm::log2_fast(table, kc, bsat) + (12.0 + betasat * log_knee) * kLog2Of10
@@ -390,9 +405,9 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_leauthaud11_kernel(Occ
       prm[6][lane] = 1.0 / (1.41421356237309504880 * scatter);
       prm[7][lane] = threshold;
       prm[8][lane] = alphasat;
-      prm[9][lane] = log2_msat - log_h * kLog2Of10;      // (M h / M_sat): log2 M - this
-      prm[10][lane] = -mcut * kLog2E / h;                 // exp(-M_cut / (M h)) = 2^(this / M)
-      prm[11][lane] = h;
+      prm[9][lane] = log2_msat - log_hs * kLog2Of10;     // (M h_s / M_sat): log2 M - this
+      prm[10][lane] = -mcut * kLog2E / h_sat;             // exp(-M_cut / (M h_s)) = 2^(this / M)
+      prm[11][lane] = h_sat;
     }
     __syncthreads();
     SmhmSetup smhm;
@@ -522,7 +537,7 @@ __global__ __launch_bounds__(512) void contract_mfma_kernel(ContractArgs a) {
 
   constexpr bool interp = INTERP;
   unsigned long long t_start = 0, t_staged = 0, t_main = 0, c_staged = 0, c_main = 0;
-  if (a.trace) t_start = __builtin_amdgcn_s_memrealtime();
+  if (TC_TRACE(a.trace)) t_start = __builtin_amdgcn_s_memrealtime();
   const int k_splits = interp ? a.k_splits : 1;
   const Group group = a.groups[slab / k_splits];
   const int n_rows_j = group.j_hi - group.j_lo;
@@ -572,7 +587,7 @@ __global__ __launch_bounds__(512) void contract_mfma_kernel(ContractArgs a) {
       if (a.mode != 0 && threadIdx.x < kLanes) lds[n_rows * kLanes + threadIdx.x] = 1.0;
       __syncthreads();
       staged_class = density_class;
-      if (a.trace) {
+      if (TC_TRACE(a.trace)) {
         t_staged = __builtin_amdgcn_s_memrealtime();
         c_staged = __builtin_amdgcn_s_memtime();
       }
@@ -630,7 +645,7 @@ __global__ __launch_bounds__(512) void contract_mfma_kernel(ContractArgs a) {
       double2v t[NT];
       double ni[4], nj[4], w[4];
       unsigned long long stamps[5] = {0, 0, 0, 0, 0};
-      if (a.wave_trace) stamps[0] = __builtin_amdgcn_s_memrealtime();
+      if (TC_TRACE(a.wave_trace)) stamps[0] = __builtin_amdgcn_s_memrealtime();
       if (n_pairs > 0) {
         load_table(t, 0);
         int4v pa = pos(0);
@@ -660,11 +675,11 @@ __global__ __launch_bounds__(512) void contract_mfma_kernel(ContractArgs a) {
             t[u] = table[(int64_t)next * 4 * RT + u * 16];
           }
           pa = pn;
-          if (a.wave_trace && (pair + 1) % quarter == 0 && (pair + 1) / quarter <= 3)
+          if (TC_TRACE(a.wave_trace) && (pair + 1) % quarter == 0 && (pair + 1) / quarter <= 3)
             stamps[(pair + 1) / quarter] = __builtin_amdgcn_s_memrealtime();
         }
       }
-      if (a.wave_trace) {
+      if (TC_TRACE(a.wave_trace)) {
         stamps[4] = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
           unsigned long long* rec =
@@ -675,7 +690,7 @@ __global__ __launch_bounds__(512) void contract_mfma_kernel(ContractArgs a) {
       }
     }
   }
-  if (a.trace) {
+  if (TC_TRACE(a.trace)) {
     t_main = __builtin_amdgcn_s_memrealtime();
     c_main = __builtin_amdgcn_s_memtime();
   }
@@ -712,7 +727,7 @@ __global__ __launch_bounds__(512) void contract_mfma_kernel(ContractArgs a) {
 #pragma unroll
       for (int u = 0; u < NT; ++u) out[(int64_t)(4 * u) * a.ldb + 16 * s] = acc[s][u];
   }
-  if (a.trace && threadIdx.x == 0) {
+  if (TC_TRACE(a.trace) && threadIdx.x == 0) {
     const unsigned long long block =
         tile + (unsigned long long)a.n_tiles * (slab + a.n_slabs * blockIdx.z);
     unsigned long long* rec = a.trace + 6 * block;
@@ -784,7 +799,7 @@ __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_kern
   // developer timeline: entry, first operands in, last matrix instruction issued, sums
   // written, end (100 MHz) and the shader clock cycles between the second and the third
   unsigned long long t_entry = 0, t_first = 0, t_main = 0, t_flushed = 0, c_first = 0, c_main = 0;
-  if (a.stamps) t_entry = __builtin_amdgcn_s_memrealtime();
+  if (TC_TRACE(a.stamps)) t_entry = __builtin_amdgcn_s_memrealtime();
   // (one 64-byte record per wave: its range of runs, its first run and that run's component;
   // three dependent scalar loads at the start of every wave otherwise)
   sc_i32 head = (sc_i32)a.wave_head + 16 * (wave < a.n_waves ? wave : 0);
@@ -861,7 +876,7 @@ __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_kern
       }
     };
     fetch(t0, b0, cb);
-    if (a.stamps && ri == run_begin) {
+    if (TC_TRACE(a.stamps) && ri == run_begin) {
       // (waits for the first operands: reading them forces the loads to land)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       t_first = __builtin_amdgcn_s_memrealtime();
@@ -921,7 +936,7 @@ __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_kern
       ++rb;
       cb = 0;
     }
-    if (a.stamps) {
+    if (TC_TRACE(a.stamps)) {
       t_main = __builtin_amdgcn_s_memrealtime();
       c_main = __builtin_amdgcn_s_memtime();
     }
@@ -942,9 +957,9 @@ __global__ __launch_bounds__(64 * kQuadWavesPerBlock, 2) void contract_quad_kern
   // Workgroup-level merge (hostmath.h: QuadMergePlan): the waves of a workgroup mostly end
   // and start inside the same output group; their sums are added here, in slot order, and
   // leave as ONE slab -- a third of the partial-buffer traffic of one slab per wave.
-  if (a.stamps) t_flushed = __builtin_amdgcn_s_memrealtime();
+  if (TC_TRACE(a.stamps)) t_flushed = __builtin_amdgcn_s_memrealtime();
   auto write_stamps = [&]() {
-    if (a.stamps && lane == 0 && wave < a.n_waves) {
+    if (TC_TRACE(a.stamps) && lane == 0 && wave < a.n_waves) {
       unsigned long long* out = a.stamps + (size_t)wave * 6;
       out[0] = t_entry;
       out[1] = t_first;

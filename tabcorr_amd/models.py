@@ -157,7 +157,9 @@ class Leauthaud11Model:
     ``scatter_model_param1``, ``alphasat``, ``bsat``, ``betasat``, ``bcut``,
     ``betacut``) and defaults.
 
-    The occupation functions are restated from the papers; unlike halotools,
+    The occupation functions are restated from the papers with halotools'
+    conventions (h = 0.7 inside the Behroozi et al. relation, h = 0.72 in the
+    satellite terms, knee mass 1e12, scatter sqrt(2) sigma); unlike halotools,
     which inverts the stellar-to-halo mass relation by spline interpolation of
     a 100-point table, the inverse is solved exactly -- the two agree to the
     accuracy of that table, not to rounding, which is why only THIS class
@@ -174,7 +176,11 @@ class Leauthaud11Model:
     """
 
     _tabcorr_amd_device_model = 'leauthaud11'
-    littleh = 0.72
+    # halotools' composite carries two Hubble parameters: the stellar-to-halo
+    # mass relation (Behroozi10SmHm) was calibrated with h = 0.7, the satellite
+    # terms of Leauthaud11Sats use h = 0.72
+    littleh_smhm = 0.7
+    littleh_sats = 0.72
 
     def __init__(self, threshold=10.5, prim_haloprop_key='halo_mvir',
                  redshift=0.0, modulate_with_cenocc=True, **param_dict):
@@ -195,16 +201,18 @@ class Leauthaud11Model:
         self.param_dict.update(param_dict)
 
     def device_theta(self):
-        """The 13 columns the kernel reads (``include/tabcorr_amd.h``,
+        """The 14 columns the kernel reads (``include/tabcorr_amd.h``,
         TC_FLAG_LEAUTHAUD11): the relation at the model's redshift,
-        a = 1 / (1 + z), X = X_0 + X_a (a - 1)."""
+        a = 1 / (1 + z), X = X_0 + X_a (a - 1), ..., the Hubble parameter of
+        the relation and that of the satellite terms."""
         p = self.param_dict
         a = 1.0 / (1.0 + self.redshift)
         smhm = [p['smhm_%s_0' % k] + p['smhm_%s_a' % k] * (a - 1.0)
                 for k in ('m0', 'm1', 'beta', 'delta', 'gamma')]
         return np.array(smhm + [p['scatter_model_param1'], p['alphasat'],
                                 p['bsat'], p['betasat'], p['bcut'],
-                                p['betacut'], self.threshold, self.littleh],
+                                p['betacut'], self.threshold,
+                                self.littleh_smhm, self.littleh_sats],
                         dtype=np.float64)
 
     def mean_occupation_centrals(self, prim_haloprop=None, **kwargs):
@@ -227,10 +235,10 @@ def leauthaud11_centrals(prim_haloprop, theta):
 def leauthaud11_satellites(prim_haloprop, theta, modulate_with_cenocc=True):
     """Leauthaud et al. (2011), eq. 12 (knee mass 1e12)."""
     prim_haloprop = np.asarray(prim_haloprop, dtype=np.float64)
-    littleh = theta[12]
+    littleh = theta[13]
     knee = 10.0**behroozi10_log_halo_mass(
         theta[11], theta[0], theta[1], theta[2], theta[3], theta[4],
-        littleh) * littleh
+        theta[12]) * littleh
     m_sat = 1e12 * theta[7] * (knee / 1e12)**theta[8]
     m_cut = 1e12 * theta[9] * (knee / 1e12)**theta[10]
     n = (np.exp(-m_cut / (prim_haloprop * littleh)) *

@@ -331,7 +331,7 @@ class TabCorr:
                               family='zheng07'):
         """`mean_occupation` for a ``(n_draws, 5 | 7)`` array of Zheng07
         parameters (columns: logMmin, sigma_logM, logM0, logM1, alpha
-        [, A_cen, A_sat]) -- or, with ``family='leauthaud11'``, the 13 columns
+        [, A_cen, A_sat]) -- or, with ``family='leauthaud11'``, the 14 columns
         of `models.Leauthaud11Model.device_theta`.  Returns
         ``(n_draws, n_bins)``."""
         device = self.to_device()
@@ -393,7 +393,7 @@ class TabCorr:
                       modulate_with_cenocc=False, assembias=False,
                       family='zheng07', out=None):
         """`predict` for a ``(n_draws, 5 | 7)`` array of Zheng07 parameters
-        (``family='leauthaud11'``: 13 columns, see `mean_occupation_batch`).
+        (``family='leauthaud11'``: 14 columns, see `mean_occupation_batch`).
 
         ``out=(ngal, xi)``: page-locked float64 arrays
         (`tabcorr_amd.pinned_empty`) of ``n_draws [* 2]`` and

@@ -206,15 +206,16 @@ class DuckLeauthaud11:
       log10 M_h(M*) = logm1 + beta x + 10^(delta x) / (1 + 10^(-gamma x)) - 1/2
                       - log10 h,   x = log10 M* + 2 log10 h - logm0,
       <N_cen> = 1/2 [1 - erf((threshold - log10 M*(M_h)) / (sqrt 2 scatter))],
-      <N_sat> = [<N_cen>] (M_h h / M_sat)^alphasat exp(-M_cut / (M_h h)),
-      M_sat = 1e12 bsat (M_knee / 1e12)^betasat, M_cut likewise, M_knee = h
-      M_h(10^threshold).
+      <N_sat> = [<N_cen>] (M_h h_s / M_sat)^alphasat exp(-M_cut / (M_h h_s)),
+      M_sat = 1e12 bsat (M_knee / 1e12)^betasat, M_cut likewise, M_knee = h_s
+      M_h(10^threshold); h = 0.7 (halotools' Behroozi10SmHm), h_s = 0.72
+      (halotools' Leauthaud11Sats).
 
     The inverse relation M*(M_h) is found per node with scipy's ``brentq`` (an
     independent root finder: the library uses Newton's method, the oracle
     bisection).  halotools' own table + spline inversion is not reproduced.
     ``theta``: logm0, logm1, beta, delta, gamma, scatter, alphasat, bsat,
-    betasat, bcut, betacut, threshold, littleh."""
+    betasat, bcut, betacut, threshold, h, h_s."""
 
     def __init__(self, theta, prim_haloprop_key='halo_mvir', redshift=0.0,
                  modulate_with_cenocc=True):
@@ -246,11 +247,11 @@ class DuckLeauthaud11:
 
     def mean_occupation_satellites(self, prim_haloprop=None, **kwargs):
         t = self.theta
-        knee = 10.0**self.log_halo_mass(t[11]) * t[12]
+        knee = 10.0**self.log_halo_mass(t[11]) * t[13]
         m_sat = 1e12 * t[7] * (knee / 1e12)**t[8]
         m_cut = 1e12 * t[9] * (knee / 1e12)**t[10]
-        n = (np.exp(-m_cut / (prim_haloprop * t[12])) *
-             (prim_haloprop * t[12] / m_sat)**t[6])
+        n = (np.exp(-m_cut / (prim_haloprop * t[13])) *
+             (prim_haloprop * t[13] / m_sat)**t[6])
         if self.modulate_with_cenocc:
             n = n * self.mean_occupation_centrals(prim_haloprop)
         return n
@@ -260,10 +261,10 @@ def leauthaud11_draws(n_draws, seed):
     """Parameter vectors around halotools' ``leauthaud11`` defaults."""
     rng = np.random.default_rng(seed)
     centre = np.array([10.72, 12.35, 0.43, 0.56, 1.54, 0.2, 1.0, 10.62, 0.859,
-                       1.47, -0.13, 10.5, 0.72])
+                       1.47, -0.13, 10.5, 0.7, 0.72])
     width = np.array([0.3, 0.3, 0.08, 0.1, 0.4, 0.08, 0.2, 3.0, 0.1, 0.5,
-                      0.1, 0.5, 0.0])
-    theta = centre + width * rng.uniform(-1, 1, size=(n_draws, 13))
+                      0.1, 0.5, 0.0, 0.0])
+    theta = centre + width * rng.uniform(-1, 1, size=(n_draws, 14))
     theta[0] = centre
     return theta
 

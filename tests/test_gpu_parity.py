@@ -93,7 +93,7 @@ def test_leauthaud11_family_on_device(name):
     ngal, xi = halotab.predict_batch(bad, family='leauthaud11', modulate_with_cenocc=True)
     assert np.isnan(ngal[1]) and np.isnan(ngal[2]) and np.all(np.isnan(xi[1:3]))
     assert_rel(xi[[0, 3]], data['xi'][[0, 3]], RTOL)
-    with pytest.raises(ValueError, match='13 columns'):
+    with pytest.raises(ValueError, match='14 columns'):
         halotab.predict_batch(data['theta'][:, :5], family='leauthaud11')
     with pytest.raises(ValueError):
         halotab.predict_batch(data['theta'], family='leauthaud11', assembias=True)

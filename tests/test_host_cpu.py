@@ -18,9 +18,14 @@ sys.path.insert(0, REPO)
 
 
 def declared_symbols():
-    header = open(os.path.join(REPO, 'include', 'tabcorr_amd.h')).read()
-    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
-    return sorted(set(re.findall(r'\b(tc_[a-z0-9_]+)\s*\(', header)))
+    """Functions declared in include/*.h: the boundary (tabcorr_amd.h) and the test hooks
+    (tabcorr_amd_testing.h)."""
+    import glob
+    names = set()
+    for path in glob.glob(os.path.join(REPO, 'include', '*.h')):
+        header = re.sub(r'/\*.*?\*/', '', open(path).read(), flags=re.S)
+        names.update(re.findall(r'\b(tc_[a-z0-9_]+)\s*\(', header))
+    return sorted(names)
 
 
 @pytest.fixture(scope='module')
@@ -33,9 +38,12 @@ def lib():
 def test_library_exports_every_declared_symbol(lib):
     from tabcorr_amd import _lib
     names = declared_symbols()
-    assert len(names) >= 35
+    assert len(names) >= 60
     for name in names:
         assert hasattr(lib, name), name
+    # the boundary header declares no debug hooks
+    boundary = open(os.path.join(REPO, 'include', 'tabcorr_amd.h')).read()
+    assert 'tc_debug' not in boundary and 'tc_plan_debug' not in boundary
     # and the ctypes table covers them all
     assert set(names) == set(_lib.SIGNATURES) | {'tc_last_error'}
 

@@ -281,7 +281,7 @@ def test_leauthaud11_host_model_matches_the_oracle():
             assert np.all(np.diff(expect_cen) >= 0) and 0.99 < expect_cen[-1] <= 1.0
             spec = device_spec(model)
             assert spec is not None and spec.family == 'leauthaud11'
-            assert spec.modulate_with_cenocc == modulate and len(spec.theta) == 13
+            assert spec.modulate_with_cenocc == modulate and len(spec.theta) == 14 and spec.theta[12] == 0.7 and spec.theta[13] == 0.72
 
     class Tweaked(Leauthaud11Model):
         def mean_occupation_centrals(self, **kwargs):
