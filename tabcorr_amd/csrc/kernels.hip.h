@@ -226,7 +226,29 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
       const bool central = g < a.n_central;
       const bool above = percentile[g] > a.split;
       double acc = 0.0;
-      if (central) {
+      // Wave-uniform shortcuts (the draws of a sampler's ensemble cluster around the posterior,
+      // so whole bins sit on the plateaus for all 64 draws of a tile): a bin whose nodes all
+      // have |z| >= 6 evaluates to erf = +-1 exactly (erf_fast clamps there), a satellite bin
+      // below every draw's M0 to 0.  Same bits as the node loop, none of its instructions.
+      int shortcut = 0;      // 1: all ones, 2: all zeros
+#ifndef TC_NO_OCC_SHORTCUTS
+      if (!assembias && !any_bad) {
+        if (central) {
+          const double z_a = (log_m[g * n_gauss] - log_m_min) * inv_sigma;
+          const double z_b = (log_m[g * n_gauss + n_gauss - 1] - log_m_min) * inv_sigma;
+          const double z_lo = z_a < z_b ? z_a : z_b, z_hi = z_a < z_b ? z_b : z_a;
+          if (__builtin_amdgcn_ballot_w64(!(z_lo >= 6.0)) == 0) shortcut = 1;
+          else if (__builtin_amdgcn_ballot_w64(!(z_hi <= -6.0)) == 0) shortcut = 2;
+        } else {
+          const double m_a = mass[g * n_gauss], m_b = mass[g * n_gauss + n_gauss - 1];
+          if (__builtin_amdgcn_ballot_w64((m_a > m_b ? m_a : m_b) > m0) == 0) shortcut = 2;
+        }
+      }
+#endif
+      if (shortcut != 0) {
+        if (shortcut == 1)
+          for (int k = 0; k < n_gauss; ++k) acc = fma(weight[g * n_gauss + k], 1.0, acc);
+      } else if (central) {
 #pragma unroll
         for (int k = 0; k < n_gauss; ++k) {
           const double lm = log_m[g * n_gauss + k];

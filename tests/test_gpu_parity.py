@@ -873,3 +873,34 @@ def test_interpolator_chi2_fused_likelihood():
         interp.chi2_batch(theta, x, observed[:3], precision)
     with pytest.raises(ValueError):
         interp.chi2_batch(theta, x[:, :1], observed, precision)
+
+
+def test_occupation_shortcuts_on_clustered_draws():
+    """Posterior-like ensembles (all 64 draws of a tile close together) take the occupation
+    kernel's wave-uniform shortcuts -- bins on the erf plateaus, satellite bins below every
+    M0 -- which must give what the node loop and the oracle give, also next to tiles that
+    do not qualify and with modulate_with_cenocc."""
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    halotab = make_tabcorr(table)
+    rng = np.random.default_rng(31)
+    centre = np.array([12.3, 0.12, 13.4, 13.9, 1.05])
+    tight = centre + rng.normal(0, 1, (192, 5)) * np.array([0.02, 0.005, 0.03, 0.03, 0.02])
+    wide = synthetic.zheng07_draws(64, seed=32)
+    theta = np.vstack([tight[:64], wide, tight[64:]])       # shortcut, no shortcut, shortcut
+    for modulate in (False, True):
+        occupation = halotab.mean_occupation_batch(theta, modulate_with_cenocc=modulate)
+        ngal, xi = halotab.predict_batch(theta, modulate_with_cenocc=modulate)
+        expect_occ = np.array([oracle.mean_occupation(table, oracle.Zheng07(t, modulate))
+                               for t in theta[[0, 63, 64, 127, 128, 255]]])
+        assert_rel(occupation[[0, 63, 64, 127, 128, 255]], expect_occ, RTOL, floor=1e-13)
+        # the plateaus are exact: whole bins at 0 and at 1 for the tight draws
+        assert np.any(occupation[0, :50] == 1.0) and np.any(occupation[0, 50:] == 0.0)
+        expect = oracle.predict_zheng07_batch(table, theta[[0, 63, 64, 127, 128, 255]],
+                                              modulate_with_cenocc=modulate)
+        assert_rel(ngal[[0, 63, 64, 127, 128, 255]], expect[0], RTOL)
+        assert_rel(xi[[0, 63, 64, 127, 128, 255]], expect[1], RTOL)
+    # one draw at a time goes through the un-batched kernel (no shortcuts): same numbers
+    single = halotab.predict_batch(theta[:1])
+    assert_rel(single[1][0], halotab.predict_batch(theta)[1][0], 1e-12)

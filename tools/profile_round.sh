@@ -2,34 +2,63 @@
 # Collect the round's profile artefacts on a GPU box into gpurun_out/profile/ (copied to
 # profiles/ afterwards by tools/install_profiles.sh): bench line, rocprofv3 kernel stats
 # (kernels serialised with --lanes 1, and pipelined), PMC passes (each in its own run, with
-# --kernel-trace only).
+# --kernel-trace only) -- for the headline configuration and, with the same recipe, for
+# BASELINE configs[2], [3], [4] float32 / float64 (bench.py --only-config TAG).
+# The program always follows `--` directly (python3 bench.py ...).
+#   gpurun --timeout 1200 -- bash tools/profile_round.sh [main|configs|all]
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
+WHAT=${1:-all}
 OUT=gpurun_out/profile
-rm -rf $OUT; mkdir -p $OUT
-python bench.py > $OUT/bench.json 2> $OUT/bench.err
-# the driver's own command (short timed region), three times
-for i in 1 2 3; do
-  python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 >> $OUT/bench_driver_command.json
-done
+mkdir -p $OUT
 FAST="--cpu-seconds 0 --other-configs 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lanes1 -- \
-  python3 bench.py --lanes 1 --steps 2000 --warmup 200 $FAST > $OUT/bench_under_rocprof_lanes1.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pipelined -- \
-  python3 bench.py --steps 2000 --warmup 200 $FAST > $OUT/bench_under_rocprof_pipelined.log 2>&1
-i=0
-for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
-           "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64" \
-           "TA_TA_BUSY_sum SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" \
-           "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
-  i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_$i -- \
-    python3 bench.py --lanes 1 --steps 50 --warmup 5 $FAST > $OUT/pmc_$i.log 2>&1
-done
-python3 tools/pmc_summary.py $OUT/pmc_1 $OUT/pmc_2 $OUT/pmc_3 $OUT/pmc_4 $OUT/pmc_5 $OUT/pmc_6 > $OUT/pmc_summary.txt
-cp $OUT/lanes1/*/*kernel_stats.csv $OUT/kernel_stats_lanes1.csv
-cp $OUT/pipelined/*/*kernel_stats.csv $OUT/kernel_stats_pipelined.csv
-grep -h '"metric"' $OUT/bench_under_rocprof_lanes1.log > $OUT/l1.json; mv $OUT/l1.json $OUT/bench_under_rocprof_lanes1.log
-grep -h '"metric"' $OUT/bench_under_rocprof_pipelined.log > $OUT/p.json; mv $OUT/p.json $OUT/bench_under_rocprof_pipelined.log
-rm -rf $OUT/lanes1 $OUT/pipelined $OUT/pmc_[0-9] $OUT/pmc_[0-9].log
-cat $OUT/bench.json; cut -c1-140 $OUT/kernel_stats_lanes1.csv | head -6; cat $OUT/pmc_summary.txt
+
+pmc_passes() {   # $1 = output stem, rest = bench arguments
+  local stem=$1; shift
+  local i=0
+  for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
+             "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64" \
+             "TA_TA_BUSY_sum SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" \
+             "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
+    i=$((i+1))
+    [ "$PMC_SHORT" = 1 ] && [ $i -gt 4 ] && break
+    rm -rf $OUT/pmc_$i
+    rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_$i -- \
+      python3 bench.py "$@" > $OUT/pmc_$i.log 2>&1
+    echo "pmc pass $i of $stem done"
+  done
+  python3 tools/pmc_summary.py $OUT/pmc_[0-9] > $OUT/${stem}.txt
+  rm -rf $OUT/pmc_[0-9] $OUT/pmc_[0-9].log
+}
+
+kernel_stats() {   # $1 = output stem, rest = bench arguments
+  local stem=$1; shift
+  rm -rf $OUT/trace
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- \
+    python3 bench.py "$@" > $OUT/${stem}.log 2>&1
+  cp $OUT/trace/*/*kernel_stats.csv $OUT/${stem}.csv
+  grep -h -E '^\{' $OUT/${stem}.log | tail -1 > $OUT/${stem}.json
+  rm -rf $OUT/trace $OUT/${stem}.log
+  echo "kernel stats $stem done"
+}
+
+if [ $WHAT = main ] || [ $WHAT = all ]; then
+  python bench.py > $OUT/bench.json 2> $OUT/bench.err
+  echo "default bench done"
+  # the driver's own command (short timed region), three times
+  : > $OUT/bench_driver_command.json
+  for i in 1 2 3; do
+    python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 >> $OUT/bench_driver_command.json
+  done
+  kernel_stats kernel_stats_lanes1 --lanes 1 --steps 2000 --warmup 200 $FAST
+  kernel_stats kernel_stats_pipelined --steps 2000 --warmup 200 $FAST
+  pmc_passes pmc_summary --lanes 1 --steps 50 --warmup 5 $FAST
+fi
+if [ $WHAT = configs ] || [ $WHAT = all ]; then
+  for tag in cfg3 cfg4 cfg5f32 cfg5f64; do
+    kernel_stats kernel_stats_${tag}_lanes1 --only-config $tag --lanes 1 --cpu-seconds 0
+    kernel_stats kernel_stats_${tag}_pipelined --only-config $tag --cpu-seconds 0
+    PMC_SHORT=1 pmc_passes pmc_summary_${tag} --only-config $tag --lanes 1 --cpu-seconds 0
+  done
+fi
+ls -la $OUT
