@@ -157,7 +157,7 @@ int gather_after(tc_comm* c, hipStream_t producer, const double* send_device,
 int tc_comm_gather(tc_comm* c, tc_table* t, const double* send_device,
                    double* recv_device, int64_t count, int root, int slot) {
   if (c != nullptr && t != nullptr && !t->chain) {
-    // unordered finalisations (tc_table_set_option "ordered" 0): the results of earlier
+    // unordered finalisations (the default; tc_table_set_option "ordered"): the results of earlier
     // calls are not implied by the current lane's stream, wait for every lane's last one
     TC_HIP(hipSetDevice(c->device));
     for (int l = 0; l < t->n_lanes; ++l)

@@ -336,10 +336,12 @@ struct tc_table {
   int cur = 0;                       // lane of the current / last predict call
   int force_lane = -1;               // host-buffer entry points pin lane 0
   int async_lane = -1;               // asynchronous host calls: the lane already chosen
-  // Results of consecutive device-pointer calls appear in call order (the finalisations are
-  // chained by events) unless this is off: asynchronous host calls deliver every ticket into
-  // its own buffers, and tc_comm_gather waits for every lane.
-  bool chain = true;
+  // Option "ordered": the finalisations of consecutive device-pointer calls are chained by
+  // events so that their results appear in call order.  Off by default: every call only orders
+  // its own kernels, tc_table_synchronize / tc_comm_gather wait for every lane (the chain
+  // costs 0.3 us per step on prior draws and 3 us on posterior-like ones, whose short
+  // occupation kernels then wait for a neighbour's finalisation: tools/r03_clustered.py).
+  bool chain = false;
   // Tickets of the asynchronous host calls (tc_*_async): a ring of events; a ticket whose
   // slot was reused is older than every lane's current work.
   struct Ticket {

@@ -784,10 +784,10 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     t->tuning.lanes = t->n_lanes = value;
     t->prev = -1;
   } else if (key == "ordered") {
-    // 1 (default): results of consecutive device-pointer calls appear in call order (the
-    // finalisations of the lanes are chained by events); 0: every call only orders its own
-    // kernels -- callers that give every call its own output buffers (bench.py's results
-    // ring) lose nothing, and tc_comm_gather then waits for every lane
+    // 0 (default): every call only orders its own kernels (results land in the buffers the
+    // caller passed; tc_table_synchronize and tc_comm_gather wait for every lane);
+    // 1: the finalisations of consecutive device-pointer calls are chained by events, so
+    // that a consumer waiting for the LAST call finds the earlier ones complete as well
     for (tc_table::Lane& lane : t->lanes)
       if (lane.stream) TC_HIP(hipStreamSynchronize(lane.stream));
     t->chain = value != 0;

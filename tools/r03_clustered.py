@@ -25,6 +25,10 @@ sets = {'uniform prior': synthetic.zheng07_draws(n, seed=1),
 d_theta, d_ngal, d_xi = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
 for ptr, count in ((d_theta, n * 5), (d_ngal, 4 * n), (d_xi, 4 * n * 19)):
     _lib.check(lib.tc_device_malloc(ctypes.byref(ptr), count * 8))
+import itertools
+options = [o.split('=') for o in sys.argv[1:]]
+for name, value in options:
+    _lib.check(lib.tc_table_set_option(handle, name.encode(), int(value)))
 for name, theta in sets.items():
     theta = np.ascontiguousarray(theta)
     _lib.check(lib.tc_memcpy_h2d(d_theta, theta.ctypes.data_as(ctypes.c_void_p), theta.nbytes))
