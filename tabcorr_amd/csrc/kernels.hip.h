@@ -699,6 +699,13 @@ __global__ __launch_bounds__(512) void contract_mfma_kernel(ContractArgs a) {
           pa = pn;
           if (TC_TRACE(a.wave_trace) && (pair + 1) % quarter == 0 && (pair + 1) / quarter <= 3)
             stamps[(pair + 1) / quarter] = __builtin_amdgcn_s_memrealtime();
+#ifndef TC_DEVELOPER_KNOBS
+          // Keep the iterations apart for the instruction scheduler: with the whole loop body
+          // as one region it interleaves the next pair's loads differently and the kernel
+          // takes 6.15 instead of 4.65 ms on BASELINE configs[4] (float64).  (The developer
+          // build's time-stamp branch at this place had the same effect.)
+          __builtin_amdgcn_sched_barrier(0);
+#endif
         }
       }
       if (TC_TRACE(a.wave_trace)) {
