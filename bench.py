@@ -272,7 +272,7 @@ def main():
                                        table['tpcf_shape'], table['attrs'], **kwargs)
         print(json.dumps(other_configs(lib, _lib, make_only, synthetic, Interpolator,
                                        args.cpu_seconds, only=args.only_config,
-                                       lanes=args.lanes)), flush=True)
+                                       lanes=args.lanes, options=args.option)), flush=True)
         return
     comm = Communicator.from_env()
     rank = comm.rank
@@ -779,7 +779,8 @@ def tabulation(cpu_seconds):
 CONFIG_TAGS = ('cfg3', 'cfg4', 'cfg5f32', 'cfg5f64')
 
 
-def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=None, lanes=0):
+def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=None, lanes=0,
+                  options=()):
     """BASELINE configs[2] ('cfg3': separate + assembly bias), configs[3] ('cfg4': one GPU's
     share of the 5 x 5 interpolator), configs[4] in float32 and float64 ('cfg5f32',
     'cfg5f64'): device rate, host rate, the dominant kernel serialised with per-launch
@@ -812,6 +813,9 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
                 peak, kernel, dtype, cpu, parity):
         if lanes > 0:
             _lib.check(lib.tc_table_set_option(timer_handle, b'lanes', lanes))
+        for option in options:          # (developer A/B: --option name=value)
+            key, value = option.split('=')
+            _lib.check(lib.tc_table_set_option(timer_handle, key.encode(), int(value)))
         device_seconds = sustained(launch, synchronize)
         _lib.check(lib.tc_table_set_option(timer_handle, b'pipeline', 0))
         kernel_ms, n_launch, _ = kernel_time(lib, _lib, timer_handle, launch, synchronize,

@@ -322,6 +322,7 @@ void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, in
                          QuadSchedule& out, int order) {
   const bool table_major = order == kQuadTableMajor;
   const bool rtile_major = order == kQuadRtileMajor && n_rtiles > 1;
+  const bool unit_major = order == kQuadUnitMajor && std::max(1, n_tables) == 1;
   out.runs.clear();
   out.wave_runs.clear();
   out.group_begin.clear();
@@ -353,7 +354,30 @@ void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, in
     while (begin < end) {
       int64_t tile_rtile, unit;
       int comp = 0, table;
-      if (rtile_major) {
+      int64_t part_stop = end;        // (unit-major: a run stays inside its part)
+      if (unit_major) {
+        // parts of the unit range, then (tile, rtile), then the part's units (across the
+        // components in layout order)
+        const int64_t n_tr = (int64_t)n_tiles * n_rtiles;
+        int part = 0;
+        int64_t offset = 0, lo = 0, hi = per_rtile / kQuadUnitParts;
+        while (part + 1 < kQuadUnitParts && begin >= offset + (hi - lo) * n_tr) {
+          offset += (hi - lo) * n_tr;
+          ++part;
+          lo = hi;
+          hi = per_rtile * (part + 1) / kQuadUnitParts;
+        }
+        const int64_t size = hi - lo, inside = (begin - offset) % size;
+        tile_rtile = (begin - offset) / size;
+        part_stop = begin + (size - inside);
+        int64_t rest = lo + inside;
+        while (rest >= layout.comps[comp].n_units) {
+          rest -= layout.comps[comp].n_units;
+          ++comp;
+        }
+        table = 0;
+        unit = rest;
+      } else if (rtile_major) {
         // inside r tile `pass`: draw tiles, then components, tables, units
         const int64_t tile = begin / per_rtile;
         int64_t rest = begin % per_rtile;
@@ -388,7 +412,8 @@ void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, in
         unit = rest % layout.comps[comp].n_units;
       }
       const QuadComp& qc = layout.comps[comp];
-      const int64_t stop = std::min<int64_t>(end, begin + (qc.n_units - unit));
+      const int64_t stop =
+          std::min<int64_t>(std::min<int64_t>(end, part_stop), begin + (qc.n_units - unit));
       QuadRun run;
       run.tile = (int32_t)(tile_rtile / n_rtiles);
       run.rtile = (int32_t)(tile_rtile % n_rtiles);

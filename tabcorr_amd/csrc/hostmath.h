@@ -180,7 +180,14 @@ struct QuadSchedule {
 // component, unit) space -- with an eighth of the shares per XCD every L2 holds the slice of
 // the matrix of the r tile in flight (1 / n_rtiles of it) instead of streaming the whole
 // matrix once per draw tile.
-constexpr int kQuadTileMajor = 0, kQuadTableMajor = 1, kQuadRtileMajor = 2;
+// kQuadUnitMajor (one table of 2 - 4 MB, e.g. BASELINE configs[2]'s 3.2 MB by-type matrix, which
+// does not stay in a 4 MB L2 next to the streaming density rows: 56 % of the passes re-read it
+// from the Infinity Cache): the units of a (draw tile, r tile) are cut into eight parts and the
+// linearised space is (part, draw tile, r tile, units of the part) -- with an eighth of the
+// shares per XCD every L2 keeps ONE eighth of the matrix for all draw tiles.  An output group
+// then receives slabs from all eight parts.
+constexpr int kQuadTileMajor = 0, kQuadTableMajor = 1, kQuadRtileMajor = 2, kQuadUnitMajor = 3;
+constexpr int kQuadUnitParts = 8;
 void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, int n_tables,
                          bool separate, int max_waves, int min_units_per_wave,
                          QuadSchedule& out, int order = kQuadTileMajor);

@@ -771,6 +771,9 @@ def test_host_logic_under_address_and_undefined_sanitizers(tmp_path):
         (100, 50, 1, 391, 1, 25, 0, 2048, 1),     # configs[3]: table-major order
         (100, 50, 1, 7, 1, 25, 1, 2048, 1),
         (200, 100, 1, 40, 38, 1, 0, 2048, 2),     # configs[4] in float64: r-tile-major order
+        (200, 100, 1, 313, 1, 1, 1, 2048, 3),     # configs[2]: unit-major order, separated
+        (200, 100, 1, 313, 1, 1, 0, 2048, 3),     # ... and the total
+        (37, 20, 1, 5, 2, 1, 1, 64, 3),           # unit-major with parts smaller than a share
         (13, 5, 0, 3, 2, 1, 0, 64, 0),
         (13, 5, 0, 3, 3, 1, 1, 64, 2),
         (13, 5, 1, 3, 2, 4, 1, 64, 1),
@@ -824,7 +827,7 @@ def test_quad_emulation_matches_the_oracle(lib, n_prim, n_sec, n_r, separate, n_
     padded[:, :n_draws] = densities
     is_central = np.ascontiguousarray(oracle.is_centrals(gal_type), dtype=np.uint8)
     n_comp = 3 if separate else 1
-    for max_waves, order in ((5, 0), (2048, 0), (5, 2), (2048, 2)):
+    for max_waves, order in ((5, 0), (2048, 0), (5, 2), (2048, 2), (5, 3), (2048, 3)):
         out = np.zeros((n_draws, n_comp, n_r))
         _lib.check(lib.tc_debug_quad_emulate(
             n_bins, n_r, _lib.as_double_p(matrix), is_central.ctypes.data_as(_lib.c_uint8_p),
