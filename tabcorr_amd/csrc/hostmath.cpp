@@ -919,6 +919,7 @@ void build_pair_units(const CellGrid& grid, const CellSort& set1, const CellSort
         // (+ a fixed cost per visited cell: the neighbour ranges are set up per cell)
         weight[c] = n1 * n2 + 256.0;
         total += weight[c];
+        out.max_cell_candidates = std::max(out.max_cell_candidates, n1 * n2);
       }
   const int pairs = std::max(1, n_blocks1 * n_blocks2);
   const int ranges = std::max(1, std::min(n_cells, (target_units + pairs - 1) / pairs));

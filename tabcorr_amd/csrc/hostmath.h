@@ -294,6 +294,7 @@ void build_label_blocks(const CellSort& cells, int n_labels, int block, LabelBlo
 // cell x points in the cells around it) and all blocks together give ~`target_units` units.
 struct PairUnits {
   std::vector<int32_t> block1, block2, cell_begin, cell_end;
+  double max_cell_candidates = 0.0;   // largest (points of a cell) x (points around it)
 };
 void build_pair_units(const CellGrid& grid, const CellSort& set1, const CellSort& set2,
                       int n_blocks1, int n_blocks2, int target_units, PairUnits& out);

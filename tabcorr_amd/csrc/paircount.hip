@@ -485,6 +485,11 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
     build_pair_units(grid, set1, second, blocks1.n_blocks, blocks2.n_blocks,
                      env_int("TC_PAIR_UNITS", 4096), units);
     lds_counters = n_bin * b1 * b2;
+    // (the workgroup's 32-bit LDS counters are flushed between cells, not inside one)
+    if (units.max_cell_candidates >= 4.0e9)
+      return fail(TC_ERR_UNSUPPORTED, "a cell and its surroundings hold %.3g candidate pairs; "
+                  "more than the labelled pair counter's 32-bit counters take",
+                  units.max_cell_candidates);
   } else {
     for (int c = 0; c < grid.n_cells(); ++c)
       for (int32_t b = set1.cell_start[c]; b < set1.cell_start[c + 1]; b += kPairThreads) {
