@@ -345,12 +345,14 @@ def main():
     n_slots = ring.n_slots
     d_out = dev.malloc(ring.ring_elements)
     lanes_used = args.lanes if args.lanes > 0 else 4
-    if use_rccl and args.lanes == 0 and not interp_mode and every < 16:
-        # Frequent gathers: the communicator's stream is a fifth stream on the runtime's four
-        # hardware queues and shares one with a lane, whose kernels then wait behind the
-        # gather (and the other way round).  Three lanes leave it a queue of its own: 51.5
-        # against 58 us per step in the short run with a gather every 5 steps (one rank,
-        # tools/r02_forced_comm.sh); with a gather every 32 steps four lanes stay ahead.
+    if use_rccl and args.lanes == 0 and not interp_mode and every < 16 and not chi2_mode:
+        # Frequent gathers of the full results: the communicator's stream is a fifth stream on
+        # the runtime's four hardware queues and shares one with a lane, whose kernels then
+        # wait behind the gather (and the other way round).  Three lanes leave it a queue of
+        # its own: 51.5 against 58 us per step in the short run with a gather every 5 steps
+        # (one rank, tools/r02_forced_comm.sh); with a gather every 32 steps four lanes stay
+        # ahead, and so they do with the likelihood payload (16 B per draw: the gather kernel
+        # is short; 49.4-52.0 against 53.2-53.5 us per step, tools/r03_forced_comm.sh).
         lanes_used = 3
         _lib.check(lib.tc_table_set_option(timer_handle, b'lanes', lanes_used))
     d_recv = dev.malloc(ring.recv_elements) if (use_rccl and comm.is_root) else ctypes.c_void_p()
