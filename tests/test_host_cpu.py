@@ -66,6 +66,31 @@ def test_no_gpu_fails_loudly(lib):
                                   table['tpcf_shape'], table['attrs'])
     with pytest.raises(_lib.TabCorrHipError):
         halotab.predict_batch(data['theta'])
+    # the round-3 entry points have no fallback either
+    from tabcorr_amd import corrfunc, pinned_empty, is_pinned
+    with pytest.raises(_lib.TabCorrHipError):
+        halotab.predict_batch_async(data['theta'])
+    with pytest.raises(_lib.TabCorrHipError):
+        pinned_empty(8)
+    assert not is_pinned(np.zeros(4))            # (the registry needs no device)
+    points = np.random.default_rng(0).uniform(0, 50, (20, 3))
+    with pytest.raises(_lib.TabCorrHipError):
+        corrfunc.mean_delta_sigma(points, points, 1.0, np.array([1.0, 2.0]), period=50.0)
+    with pytest.raises(_lib.TabCorrHipError):
+        corrfunc.wp(points, np.array([1.0, 2.0]), 10.0, period=50.0)
+
+
+def test_result_of_async_validation_without_a_device():
+    """Argument checks of the asynchronous Python layer that do not need a device."""
+    from tabcorr_amd import pinned
+    with pytest.raises(ValueError, match='out must hold 2 arrays'):
+        pinned.stage_outputs([(3, ), (3, 4)], [np.zeros(3)])
+    with pytest.raises(ValueError, match='page-locked'):
+        pinned.stage_outputs([(3, )], [np.zeros(3)])
+    with pytest.raises(ValueError, match='C-contiguous'):
+        pinned.stage_outputs([(3, )], [np.zeros((3, 2))[:, 0]])
+    with pytest.raises(ValueError, match='C-contiguous numpy array'):
+        pinned.pin([1.0, 2.0])
 
 
 def test_gauss_legendre(lib):
