@@ -267,3 +267,17 @@ def test_many_walkers_in_one_launch():
     ngal, xi = halotab.predict_batch(bad)
     assert np.isnan(ngal[2]) and np.all(np.isnan(xi[2]))
     assert_rel(xi[[0, 1, 3, 4, 5]], data['xi'][[0, 1, 3, 4, 5]], RTOL)
+
+
+def test_random_interleaving_of_all_host_paths():
+    """tools/r03_stress.py for a few seconds: synchronous, un-batched, many-walker,
+    asynchronous (random waits) and device-pointer calls of random sizes on ONE table, every
+    result against a reference -- workspaces, tickets and completion epochs under reuse."""
+    import os
+    import subprocess
+    import sys
+    from util import REPO
+    result = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'r03_stress.py'), '4'],
+                            capture_output=True, text=True, timeout=300)
+    assert result.returncode == 0, result.stdout[-2000:] + result.stderr[-2000:]
+    assert 'stress ok' in result.stdout
