@@ -67,6 +67,13 @@ def test_async_matches_golden_and_sync():
         assert_rel(n_sep[key], data['ngal_sep_' + key], RTOL, key)
     for key in x_sep:
         assert_rel(x_sep[key], data['xi_sep_' + key], RTOL, key)
+    # polling instead of waiting (tc_table_query)
+    import time
+    polled = halotab.predict_batch_async(theta, out=(ngal, xi))
+    deadline = time.time() + 10.0
+    while not polled.done():
+        assert time.time() < deadline
+    assert_rel(polled.wait()[1], data['xi'], RTOL)
     # pageable theta, no out: pooled pinned staging, results copied out
     plain = halotab.predict_batch_async(np.array(data['theta'])).wait()
     assert_rel(plain[0], data['ngal'], RTOL)
