@@ -203,7 +203,16 @@ def delta_sigma_from_mass_in_cylinders(mass_encl, rp_bins):
     sigma_inside = mass_encl / (np.pi * rp_bins**2)
     log_rp, log_mid = np.log10(rp_bins), np.log10(rp_mids)
     interpolated = np.zeros_like(sigma_annulus)
-    for g in range(len(mass_encl)):
+    # objects with mass inside every cylinder (almost all): the midpoint of annulus k lies
+    # between radii k and k + 1, so the interpolation is one vectorised expression
+    full = np.all(sigma_inside > 0, axis=1)
+    if np.any(full):
+        log_sigma = np.log10(sigma_inside[full])
+        slope = ((log_sigma[:, 1:] - log_sigma[:, :-1]) /
+                 (log_rp[1:] - log_rp[:-1]))
+        interpolated[full] = 10.0**(slope * (log_mid - log_rp[:-1]) +
+                                    log_sigma[:, :-1])
+    for g in np.nonzero(~full)[0]:
         mask = sigma_inside[g] > 0
         if np.count_nonzero(mask) < 2:
             continue

@@ -32,6 +32,21 @@ int main() {
   CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
   volatile unsigned long long* flags = out;
   unsigned long long epoch = 0;
+  // launch-path floor against the launch geometry (plain launch, polling)
+  for (int geometry = 0; geometry < 6; ++geometry) {
+    const int nb = geometry < 3 ? 1 : 13, nt = geometry % 3 == 0 ? 64 : geometry % 3 == 1 ? 256 : 1024;
+    const int n = 20000;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < n; ++k) {
+      *in = ++epoch;
+      hipLaunchKernelGGL(probe, dim3(nb), dim3(nt), 0, stream, in, out);
+      for (int b = 0; b < nb; ++b) while (flags[b] != epoch) __builtin_ia32_pause();
+      if ((k & 255) == 0) CHECK(hipStreamSynchronize(stream));
+    }
+    CHECK(hipStreamSynchronize(stream));
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / n;
+    printf("%2d workgroups x %4d threads, poll: %6.2f us per call\n", nb, nt, us);
+  }
   for (int mode = 0; mode < 4; ++mode) {
     const int n = 20000;
     auto t0 = std::chrono::steady_clock::now();
