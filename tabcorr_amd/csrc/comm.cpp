@@ -159,9 +159,14 @@ int tc_comm_gather(tc_comm* c, tc_table* t, const double* send_device,
   if (c != nullptr && t != nullptr && !t->chain) {
     // unordered finalisations (the default; tc_table_set_option "ordered"): the results of earlier
     // calls are not implied by the current lane's stream, wait for every lane's last one
+    // (the events are recorded here, behind everything queued so far on each lane, not per
+    // call: a marker after every finalisation costs the lane a bubble)
     TC_HIP(hipSetDevice(c->device));
-    for (int l = 0; l < t->n_lanes; ++l)
-      if (l != t->cur) TC_HIP(hipStreamWaitEvent(c->stream, t->lanes[l].finished, 0));
+    for (int l = 0; l < t->n_lanes; ++l) {
+      if (l == t->cur) continue;
+      TC_HIP(hipEventRecord(t->lanes[l].finished, t->lanes[l].stream));
+      TC_HIP(hipStreamWaitEvent(c->stream, t->lanes[l].finished, 0));
+    }
   }
   return gather_after(c, t != nullptr ? t->lanes[t->cur].stream : nullptr, send_device,
                       recv_device, count, root, slot);

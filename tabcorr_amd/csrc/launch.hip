@@ -558,7 +558,11 @@ static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsig
   if (t->force_lane >= 0) {
     t->prev = -1;
   } else {
-    TC_HIP(hipEventRecord(lane.finished, stream));
+    // (the lane's `finished` event orders the next lane's finalisation behind this one; with
+    // unordered finalisations nobody waits for it -- tc_comm_gather records its own -- and the
+    // marker would only put a 7-25 us bubble between this finalisation and the lane's next
+    // occupation kernel: profiles/r03_notes.md)
+    if (t->chain) TC_HIP(hipEventRecord(lane.finished, stream));
     t->prev = t->cur;
   }
   return TC_OK;
@@ -739,7 +743,11 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   if (t->force_lane >= 0) {
     t->prev = -1;
   } else {
-    TC_HIP(hipEventRecord(lane.finished, stream));
+    // (the lane's `finished` event orders the next lane's finalisation behind this one; with
+    // unordered finalisations nobody waits for it -- tc_comm_gather records its own -- and the
+    // marker would only put a 7-25 us bubble between this finalisation and the lane's next
+    // occupation kernel: profiles/r03_notes.md)
+    if (t->chain) TC_HIP(hipEventRecord(lane.finished, stream));
     t->prev = t->cur;
   }
   return TC_OK;

@@ -476,7 +476,7 @@ int tc_chi2_zheng07_batch_device(tc_table* t, const double* theta_device, int n_
   status = launch_chi2((const double*)lane.xi.ptr, n_draws, t->n_r, d_data, d_data + t->n_r,
                        chi2_device, lane.stream);
   if (status != TC_OK) return status;
-  if (t->force_lane < 0) TC_HIP(hipEventRecord(lane.finished, lane.stream));
+  if (t->force_lane < 0 && t->chain) TC_HIP(hipEventRecord(lane.finished, lane.stream));
   return TC_OK;
 }
 
