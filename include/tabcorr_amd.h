@@ -274,6 +274,7 @@ int tc_interp_chi2_zheng07_batch_async(tc_interp* interp, const double* theta_pi
                                        const double* precision, double* ngal_pinned,
                                        double* chi2_pinned, int64_t* ticket);
 int tc_interp_wait(tc_interp* interp, int64_t ticket);
+int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
 
 /* Run-time options of a table handle (the library never reads the environment):
  *   "pipeline"    1 (default): consecutive device-pointer calls rotate over the handle's

@@ -114,6 +114,7 @@ SIGNATURES = {
         ctypes.c_int64, ctypes.c_int, ctypes.c_uint, c_double_p, c_double_p,
         c_double_p, c_double_p, c_int64_p],
     'tc_interp_wait': [ctypes.c_void_p, ctypes.c_int64],
+    'tc_interp_query': [ctypes.c_void_p, ctypes.c_int64, c_int_p],
     'tc_predict_occupation_batch': [
         ctypes.c_void_p, c_double_p, ctypes.c_int64, ctypes.c_uint,
         c_double_p, c_double_p],

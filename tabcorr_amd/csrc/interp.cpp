@@ -850,4 +850,21 @@ int tc_interp_wait(tc_interp* it, int64_t ticket) {
   return TC_OK;
 }
 
+int tc_interp_query(tc_interp* it, int64_t ticket, int* done) {
+  TC_CHECK(it != nullptr && done != nullptr, "NULL argument");
+  TC_CHECK(ticket >= 0 && ticket < it->next_ticket, "unknown ticket %lld", (long long)ticket);
+  const tc_table::Ticket& slot = it->tickets[ticket % tc_table::kMaxTickets];
+  *done = 0;
+  // (a reused slot: the ticket is done once both streams have passed their later work)
+  const hipError_t state =
+      slot.id == ticket ? hipEventQuery(slot.done)
+      : hipStreamQuery(it->stream) == hipSuccess && it->out_stream != nullptr
+          ? hipStreamQuery(it->out_stream)
+          : hipStreamQuery(it->stream);
+  if (state == hipSuccess) *done = 1;
+  else if (state != hipErrorNotReady)
+    return fail(TC_ERR_HIP, "query failed: %s", hipGetErrorString(state));
+  return TC_OK;
+}
+
 }  // extern "C"

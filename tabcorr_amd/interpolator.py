@@ -312,7 +312,8 @@ class Interpolator:
                 ctypes.byref(ticket)))
         first = self.tabcorr_list[0]
         return pinned.PendingPrediction(
-            device, device.lib.tc_interp_wait, None, ticket.value,
+            device, device.lib.tc_interp_wait, device.lib.tc_interp_query,
+            ticket.value,
             [theta_p, x_p], [ngal, xi], pooled_in, pooled_out,
             lambda n, v: first._package(n, v, separate_gal_type))
 
@@ -342,7 +343,8 @@ class Interpolator:
                 _lib.as_double_p(ngal), _lib.as_double_p(chi2),
                 ctypes.byref(ticket)))
         return pinned.PendingPrediction(
-            device, device.lib.tc_interp_wait, None, ticket.value,
+            device, device.lib.tc_interp_wait, device.lib.tc_interp_query,
+            ticket.value,
             [theta_p, x_p], [ngal, chi2], pooled_in, pooled_out,
             lambda n, c: (n, c))
 

@@ -172,6 +172,10 @@ def test_async_interpolator_matches_golden():
     n_r = data['xi'].shape[1]
     outs = [(pinned_empty(n), pinned_empty((n, n_r))) for _ in range(3)]
     pending = [interp.predict_batch_async(theta, x, out=out) for out in outs]
+    import time
+    deadline = time.time() + 10.0
+    while not pending[-1].done():          # tc_interp_query
+        assert time.time() < deadline
     for item in reversed(pending):
         ngal, xi = item.wait()
         assert_rel(ngal, data['ngal'], RTOL, 'ngal')
