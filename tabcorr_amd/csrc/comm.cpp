@@ -174,8 +174,13 @@ int tc_comm_gather(tc_comm* c, tc_table* t, const double* send_device,
 
 int tc_comm_gather_interp(tc_comm* c, tc_interp* interp, const double* send_device,
                           double* recv_device, int64_t count, int root, int slot) {
-  return gather_after(c, interp != nullptr ? tc::host::interp_stream(interp) : nullptr,
-                      send_device, recv_device, count, root, slot);
+  if (c != nullptr && interp != nullptr) {
+    // results of earlier calls sit behind the interpolator's other lane
+    TC_HIP(hipSetDevice(c->device));
+    const int status = tc::host::interp_join_lanes(interp, c->stream);
+    if (status != TC_OK) return status;
+  }
+  return gather_after(c, nullptr, send_device, recv_device, count, root, slot);
 }
 
 int tc_comm_release(tc_comm* c, tc_table* t, int slot) {
@@ -191,8 +196,7 @@ int tc_comm_release_interp(tc_comm* c, tc_interp* interp, int slot) {
   TC_CHECK(c != nullptr && interp != nullptr, "NULL argument");
   TC_CHECK(slot >= 0 && slot < 4, "slot must be in [0, 4)");
   TC_HIP(hipSetDevice(c->device));
-  TC_HIP(hipStreamWaitEvent(tc::host::interp_stream(interp), c->done[slot], 0));
-  return TC_OK;
+  return tc::host::interp_lanes_wait(interp, c->done[slot]);
 }
 
 int tc_comm_barrier(tc_comm* c) {

@@ -427,6 +427,8 @@ int launch_contract_quad_f32(int n_u, const QuadArgs& args, int lds_bytes, hipSt
                              hipEvent_t start, hipEvent_t stop);
 // Stream an interpolator's work is queued on (interp.cpp).
 hipStream_t interp_stream(tc_interp* interp);
+int interp_join_lanes(tc_interp* interp, hipStream_t stream);
+int interp_lanes_wait(tc_interp* interp, hipEvent_t event);
 // Events for hipExtLaunchKernelGGL while the table's kernel timer is on, else NULLs.
 int next_kernel_events(tc_table* t, hipEvent_t* start, hipEvent_t* stop);
 // Largest number of draws one slab may hold (workspaces bounded; 32-bit scalar offsets of

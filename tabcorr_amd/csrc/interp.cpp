@@ -14,7 +14,6 @@ struct tc_interp {
   std::vector<int32_t> table_node;          // (K, D)
   std::vector<int32_t> table_class;         // (K)
   std::vector<int> class_table;             // representative table of each class
-  hipStream_t stream = nullptr;
   void* d_xp = nullptr;
   void* d_a = nullptr;
   void* d_table_node = nullptr;
@@ -22,9 +21,6 @@ struct tc_interp {
   void* d_tables = nullptr;                 // (K) device pointers
   void* d_quad_by_type = nullptr;           // (K) matrices of the quadratic-form kernel
   void* d_quad_total = nullptr;             // (K) ... unpadded triangle, if the tables have it
-  void* d_nbufs = nullptr;                  // (V) device pointers
-  void* d_ngal_parts = nullptr;             // (V) device pointers
-  void* d_nbufs32 = nullptr;                // (V) ... float copies of the densities
   std::vector<int> axis_offset, a_offset;
   std::vector<double> a_host;               // spline matrices of all dimensions
   // un-batched calls: per n_gauss the per-class pointer arrays of single_draw_kernel
@@ -36,21 +32,36 @@ struct tc_interp {
     void* percentile = nullptr;
   };
   std::map<int, SinglePointers> single_pointers;
-  std::vector<DeviceBuffer> nbuf, ngal2;    // per class
-  std::vector<DeviceBuffer> nbuf32;         // per class: float copies (float32 quadratic form)
-  std::vector<void*> nbuf_ptrs, ngal_ptrs, nbuf32_ptrs;   // last uploaded pointer values
-  DeviceBuffer theta, x, coef, partial, out_ngal, out_xi;
-  DeviceBuffer chi2_xi, chi2_data;          // fused likelihood: xi workspace, data + precision
+  // Lanes (stream + workspaces), as for a table handle: consecutive device-pointer and
+  // asynchronous calls alternate between them, so that the occupation / spline-weight /
+  // finalisation kernels and the ramps of one call's contraction hide behind the
+  // neighbour's (BASELINE configs[3], 12 500 draws: 992 -> 929 us per call).  Host-buffer
+  // calls use lane 0.
+  struct Lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t finished = nullptr;            // recorded by the gather, not per call
+    std::vector<DeviceBuffer> nbuf, ngal2;    // per class
+    std::vector<DeviceBuffer> nbuf32;         // per class: float copies (float32 quadratic form)
+    std::vector<void*> nbuf_ptrs, ngal_ptrs, nbuf32_ptrs;   // last uploaded pointer values
+    void* d_nbufs = nullptr;                  // (V) device pointers
+    void* d_ngal_parts = nullptr;             // (V) device pointers
+    void* d_nbufs32 = nullptr;                // (V) ... float copies of the densities
+    DeviceBuffer coef, partial, chi2_xi;
+    DeviceBuffer stage_in, stage_out;         // asynchronous host calls
+  };
+  static constexpr int kLanes = 2;
+  Lane lanes[kLanes];
+  int force_lane = -1;                        // host-buffer entry points pin lane 0
+  int cur = 0;                                // lane of the current / last call
+  uint64_t device_calls = 0;
+  hipStream_t stream = nullptr;               // = lanes[0].stream
+  DeviceBuffer theta, x, out_ngal, out_xi;  // host-buffer calls
+  DeviceBuffer chi2_data;                   // fused likelihood: data + precision
   std::vector<double> chi2_host;            // host copy of what chi2_data holds
   PinnedBuffer h_in, h_out;
   SingleWorkspace single_ws;                // un-batched calls
   std::map<std::pair<int, int>, std::unique_ptr<DeviceChunking>> chunkings;
-  // asynchronous host calls (tc_interp_*_async): uploads and kernels on `stream`, the
-  // download of call k on `out_stream` behind it (results double-buffered), tickets as for
-  // a table handle
-  hipStream_t out_stream = nullptr;
-  hipEvent_t computed[2] = {nullptr, nullptr}, downloaded[2] = {nullptr, nullptr};
-  DeviceBuffer stage_in, stage_out[2];
+  // asynchronous host calls (tc_interp_*_async): tickets as for a table handle
   tc_table::Ticket tickets[tc_table::kMaxTickets];
   int64_t next_ticket = 0;
 };
@@ -67,6 +78,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
                           const double* x_device, int64_t n_draws, int n_gauss,
                           unsigned flags, double* ngal_device, double* xi_device) {
   tc_table* t0 = it->tables[0];
+  tc_interp::Lane& L = it->lanes[it->cur];
   const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
   const int n_comp = separate ? t0->plan.n_components : 1;
   const int n_classes = (int)it->class_table.size();
@@ -78,30 +90,30 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   const bool quad_f32 = t0->quad && t0->compute_dtype == TC_DTYPE_F32;
   for (int v = 0; v < n_classes; ++v) {
     status = run_occupation(it->tables[it->class_table[v]], theta_device, n_theta,
-                            n_draws, ldb, n_gauss, flags, nullptr, &it->nbuf[v],
-                            &it->ngal2[v], it->stream, &ngal_parts,
-                            quad_f32 ? &it->nbuf32[v] : nullptr);
+                            n_draws, ldb, n_gauss, flags, nullptr, &L.nbuf[v],
+                            &L.ngal2[v], L.stream, &ngal_parts,
+                            quad_f32 ? &L.nbuf32[v] : nullptr);
     if (status != TC_OK) return status;
   }
   bool moved = false;
   for (int v = 0; v < n_classes; ++v) {
-    moved = moved || it->nbuf_ptrs[v] != it->nbuf[v].ptr ||
-            it->ngal_ptrs[v] != it->ngal2[v].ptr || it->nbuf32_ptrs[v] != it->nbuf32[v].ptr;
-    it->nbuf_ptrs[v] = it->nbuf[v].ptr;
-    it->ngal_ptrs[v] = it->ngal2[v].ptr;
-    it->nbuf32_ptrs[v] = it->nbuf32[v].ptr;
+    moved = moved || L.nbuf_ptrs[v] != L.nbuf[v].ptr ||
+            L.ngal_ptrs[v] != L.ngal2[v].ptr || L.nbuf32_ptrs[v] != L.nbuf32[v].ptr;
+    L.nbuf_ptrs[v] = L.nbuf[v].ptr;
+    L.ngal_ptrs[v] = L.ngal2[v].ptr;
+    L.nbuf32_ptrs[v] = L.nbuf32[v].ptr;
   }
   if (moved) {
-    TC_HIP(hipMemcpyAsync(it->d_nbufs32, it->nbuf32_ptrs.data(), n_classes * sizeof(void*),
-                          hipMemcpyHostToDevice, it->stream));
-    TC_HIP(hipMemcpyAsync(it->d_nbufs, it->nbuf_ptrs.data(), n_classes * sizeof(void*),
-                          hipMemcpyHostToDevice, it->stream));
-    TC_HIP(hipMemcpyAsync(it->d_ngal_parts, it->ngal_ptrs.data(),
-                          n_classes * sizeof(void*), hipMemcpyHostToDevice, it->stream));
-    TC_HIP(hipStreamSynchronize(it->stream));   // the host vectors may change later
+    TC_HIP(hipMemcpyAsync(L.d_nbufs32, L.nbuf32_ptrs.data(), n_classes * sizeof(void*),
+                          hipMemcpyHostToDevice, L.stream));
+    TC_HIP(hipMemcpyAsync(L.d_nbufs, L.nbuf_ptrs.data(), n_classes * sizeof(void*),
+                          hipMemcpyHostToDevice, L.stream));
+    TC_HIP(hipMemcpyAsync(L.d_ngal_parts, L.ngal_ptrs.data(),
+                          n_classes * sizeof(void*), hipMemcpyHostToDevice, L.stream));
+    TC_HIP(hipStreamSynchronize(L.stream));   // the host vectors may change later
   }
 
-  status = it->coef.reserve((size_t)it->n_tables * ldb * sizeof(double), it->stream);
+  status = L.coef.reserve((size_t)it->n_tables * ldb * sizeof(double), L.stream);
   if (status != TC_OK) return status;
   tc::InterpArgs ia{};
   ia.n_dim = it->n_dim;
@@ -119,15 +131,15 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   ia.table_node = (const int32_t*)it->d_table_node;
   ia.table_class = (const int32_t*)it->d_table_class;
   ia.x = x_device;
-  ia.ngal_parts = (const double* const*)it->d_ngal_parts;
+  ia.ngal_parts = (const double* const*)L.d_ngal_parts;
   ia.n_ngal_parts = ngal_parts;
   ia.ldb = ldb;
   ia.n_draws = n_draws;
-  ia.coef = (double*)it->coef.ptr;
+  ia.coef = (double*)L.coef.ptr;
   ia.ngal = ngal_device;
   {
     Range range("spline weights");
-    status = launch_interp_coef(ia, it->stream);
+    status = launch_interp_coef(ia, L.stream);
   }
   if (status != TC_OK) return status;
   Range range("contraction + finalisation (all tables)");
@@ -143,27 +155,27 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
     status = get_quad_schedule(t0, q, ldb / tile_draws, it->n_tables, separate, &schedule);
     if (status != TC_OK) return status;
     const int rt = 4 * tiling.n_u;
-    status = it->partial.reserve((size_t)schedule->n_slabs * rt * tile_draws *
+    status = L.partial.reserve((size_t)schedule->n_slabs * rt * tile_draws *
                                      (quad_f32 ? sizeof(float) : sizeof(double)),
-                                 it->stream);
+                                 L.stream);
     if (status != TC_OK) return status;
     tc::QuadArgs qa{};
     qa.nbuf = nullptr;
-    qa.nbufs = (const double* const*)it->d_nbufs;
-    qa.nbufs32 = (const float* const*)it->d_nbufs32;
+    qa.nbufs = (const double* const*)L.d_nbufs;
+    qa.nbufs32 = (const float* const*)L.d_nbufs32;
     qa.ldb = ldb;
     qa.n_bins = t0->n_bins;
     qa.table = nullptr;
     qa.tables = (const double* const*)(by_type ? it->d_quad_by_type : it->d_quad_total);
     qa.table_class = (const int32_t*)it->d_table_class;
-    qa.coef = (const double*)it->coef.ptr;
+    qa.coef = (const double*)L.coef.ptr;
     qa.rtile_bytes = (uint32_t)q->rtile_bytes;
     qa.runs = (const tc::QuadRun*)schedule->runs;
     qa.comps = (const tc::QuadCompArgs*)q->d_comps;
     qa.wave_runs = (const int32_t*)schedule->wave_runs;
     qa.wave_head = (const int32_t*)schedule->wave_head;
     qa.n_waves = schedule->n_waves;
-    qa.partial = it->partial.ptr;
+    qa.partial = L.partial.ptr;
     qa.priority = t0->tuning.prio_contract;
     qa.merge_range = (const int32_t*)schedule->merge_range;
     qa.merges = (const int32_t*)schedule->merges;
@@ -172,12 +184,12 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
     status = next_kernel_events(t0, &k0, &k1);
     if (status != TC_OK) return status;
     status = quad_f32 ? launch_contract_quad_f32_interp(tiling.n_u, qa, schedule->lds_bytes,
-                                                        it->stream, k0, k1)
+                                                        L.stream, k0, k1)
                       : launch_contract_quad(tiling.n_u, true, qa, schedule->lds_bytes,
-                                             it->stream, k0, k1);
+                                             L.stream, k0, k1);
     if (status != TC_OK) return status;
     tc::FinalizeQuadArgs fq{};
-    fq.partial = it->partial.ptr;
+    fq.partial = L.partial.ptr;
     fq.group_begin = (const int32_t*)schedule->group_begin;
     fq.ngal_part = nullptr;      // already normalised; ngal written by the coef kernel
     fq.n_ngal_parts = 0;
@@ -201,7 +213,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
       fq.xi = nullptr;
       t0->chi2_fused = true;
     }
-    return launch_finalize_quad(fq, t0->tuning, it->stream, quad_f32);
+    return launch_finalize_quad(fq, t0->tuning, L.stream, quad_f32);
   }
 
   // decomposition: as for one table (choose_chunking), with the tables looped inside
@@ -233,8 +245,8 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
                 t0->n_bins, lds);
   const int n_groups = (int)c->host.groups.size();
   const int r_stride = t0->rt * t0->n_rtiles;
-  status = it->partial.reserve(
-      (size_t)n_groups * k_splits * r_stride * ldb * sizeof(double), it->stream);
+  status = L.partial.reserve(
+      (size_t)n_groups * k_splits * r_stride * ldb * sizeof(double), L.stream);
   if (status != TC_OK) return status;
 
   tc::ContractArgs ca{};
@@ -251,13 +263,13 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   ca.wave_trace = nullptr;
   ca.pos_ij = nullptr;
   ca.pos_off = (const int32_t*)t0->d_pos_off;
-  ca.partial = (double*)it->partial.ptr;
+  ca.partial = (double*)L.partial.ptr;
   ca.n_tables = it->n_tables;
   ca.k_splits = k_splits;
   ca.tables = (const double* const*)it->d_tables;
-  ca.nbufs = (const double* const*)it->d_nbufs;
+  ca.nbufs = (const double* const*)L.d_nbufs;
   ca.table_class = (const int32_t*)it->d_table_class;
-  ca.coef = (const double*)it->coef.ptr;
+  ca.coef = (const double*)L.coef.ptr;
   ca.n_tiles = (int)n_tiles;
   ca.n_slabs = n_groups * k_splits;
   ca.xcd_map = t0->n_xcds == 8 && n_tiles >= 8;
@@ -270,18 +282,18 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   if (status != TC_OK) return status;
   if (t0->compute_dtype == TC_DTYPE_F32) {
     ca.pos_ij = (const int32_t*)t0->d_pos_ij;
-    status = launch_contract_f32(grid, block, lds, it->stream, ca, k0, k1);
+    status = launch_contract_f32(grid, block, lds, L.stream, ca, k0, k1);
   } else {
     if (lds > 64 * 1024) {
       status = set_lds_limit_rt(t0->rt, lds);
       if (status != TC_OK) return status;
     }
-    status = launch_contract_rt(t0->rt, grid, block, lds, it->stream, ca, k0, k1);
+    status = launch_contract_rt(t0->rt, grid, block, lds, L.stream, ca, k0, k1);
   }
   if (status != TC_OK) return status;
 
   tc::FinalizeArgs fa{};
-  fa.partial = (const double*)it->partial.ptr;
+  fa.partial = (const double*)L.partial.ptr;
   fa.groups = (const tc::Group*)c->groups;
   fa.ngal_part = nullptr;      // already normalised; ngal written by the coef kernel
   fa.n_ngal_parts = 0;
@@ -295,14 +307,30 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   fa.n_draws = n_draws;
   fa.ngal = ngal_device;
   fa.xi = xi_device;
-  return launch_finalize(fa, t0->tuning, it->stream);
+  return launch_finalize(fa, t0->tuning, L.stream);
 }
 
 }  // namespace
 
 namespace tc {
 namespace host {
-hipStream_t interp_stream(tc_interp* interp) { return interp->stream; }
+hipStream_t interp_stream(tc_interp* interp) { return interp->lanes[interp->cur].stream; }
+// Everything queued so far on every lane of the interpolator precedes what is queued on
+// `stream` afterwards (tc_comm_gather_interp) / every lane waits for `event`
+// (tc_comm_release_interp).
+int interp_join_lanes(tc_interp* interp, hipStream_t stream) {
+  for (tc_interp::Lane& lane : interp->lanes) {
+    if (lane.stream == nullptr) continue;
+    TC_HIP(hipEventRecord(lane.finished, lane.stream));
+    TC_HIP(hipStreamWaitEvent(stream, lane.finished, 0));
+  }
+  return TC_OK;
+}
+int interp_lanes_wait(tc_interp* interp, hipEvent_t event) {
+  for (tc_interp::Lane& lane : interp->lanes)
+    if (lane.stream != nullptr) TC_HIP(hipStreamWaitEvent(lane.stream, event, 0));
+  return TC_OK;
+}
 }  // namespace host
 }  // namespace tc
 
@@ -389,14 +417,17 @@ int tc_interp_create(tc_table* const* tables, int n_tables, int n_dim,
     }
   }
   const size_t n_classes = it->class_table.size();
-  it->nbuf.resize(n_classes);
-  it->ngal2.resize(n_classes);
-  it->nbuf32.resize(n_classes);
-  it->nbuf_ptrs.assign(n_classes, nullptr);
-  it->ngal_ptrs.assign(n_classes, nullptr);
-  it->nbuf32_ptrs.assign(n_classes, nullptr);
-
-  TC_HIP(hipStreamCreateWithFlags(&it->stream, hipStreamNonBlocking));
+  for (tc_interp::Lane& lane : it->lanes) {
+    lane.nbuf.resize(n_classes);
+    lane.ngal2.resize(n_classes);
+    lane.nbuf32.resize(n_classes);
+    lane.nbuf_ptrs.assign(n_classes, nullptr);
+    lane.ngal_ptrs.assign(n_classes, nullptr);
+    lane.nbuf32_ptrs.assign(n_classes, nullptr);
+    TC_HIP(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
+    TC_HIP(hipEventCreateWithFlags(&lane.finished, hipEventDisableTiming));
+  }
+  it->stream = it->lanes[0].stream;
   std::vector<void*> table_ptrs;
   for (int k = 0; k < n_tables; ++k) table_ptrs.push_back(tables[k]->d_table);
   std::vector<void*> zeros(n_classes, nullptr);
@@ -413,9 +444,11 @@ int tc_interp_create(tc_table* const* tables, int n_tables, int n_dim,
   if (status == TC_OK) status = upload(it->table_node, &it->d_table_node);
   if (status == TC_OK) status = upload(it->table_class, &it->d_table_class);
   if (status == TC_OK) status = upload(table_ptrs, &it->d_tables);
-  if (status == TC_OK) status = upload(zeros, &it->d_nbufs);
-  if (status == TC_OK) status = upload(zeros, &it->d_nbufs32);
-  if (status == TC_OK) status = upload(zeros, &it->d_ngal_parts);
+  for (tc_interp::Lane& lane : it->lanes) {
+    if (status == TC_OK) status = upload(zeros, &lane.d_nbufs);
+    if (status == TC_OK) status = upload(zeros, &lane.d_nbufs32);
+    if (status == TC_OK) status = upload(zeros, &lane.d_ngal_parts);
+  }
   if (status != TC_OK) return status;
   *out = it.release();
   return TC_OK;
@@ -424,10 +457,10 @@ int tc_interp_create(tc_table* const* tables, int n_tables, int n_dim,
 int tc_interp_destroy(tc_interp* it) {
   if (it == nullptr) return TC_OK;
   (void)hipSetDevice(it->device);
-  if (it->stream) (void)hipStreamSynchronize(it->stream);
+  for (tc_interp::Lane& lane : it->lanes)
+    if (lane.stream) (void)hipStreamSynchronize(lane.stream);
   for (void* p : {it->d_xp, it->d_a, it->d_table_node, it->d_table_class, it->d_tables,
-                  it->d_nbufs, it->d_nbufs32, it->d_ngal_parts, it->d_quad_by_type,
-                  it->d_quad_total})
+                  it->d_quad_by_type, it->d_quad_total})
     if (p) (void)hipFree(p);
   for (auto& kv : it->chunkings)
     for (void* p : {kv.second->chunks, kv.second->groups})
@@ -436,33 +469,34 @@ int tc_interp_destroy(tc_interp* it) {
     for (void* p : {kv.second.log_m, kv.second.m, kv.second.weight, kv.second.n_h,
                     kv.second.percentile})
       if (p) (void)hipFree(p);
-  for (DeviceBuffer& b : it->nbuf) b.release();
-  for (DeviceBuffer& b : it->ngal2) b.release();
-  for (DeviceBuffer& b : it->nbuf32) b.release();
-  for (DeviceBuffer* b : {&it->theta, &it->x, &it->coef, &it->partial, &it->out_ngal,
-                          &it->out_xi, &it->chi2_xi, &it->chi2_data})
+  for (tc_interp::Lane& lane : it->lanes) {
+    for (void* p : {lane.d_nbufs, lane.d_nbufs32, lane.d_ngal_parts})
+      if (p) (void)hipFree(p);
+    for (DeviceBuffer& b : lane.nbuf) b.release();
+    for (DeviceBuffer& b : lane.ngal2) b.release();
+    for (DeviceBuffer& b : lane.nbuf32) b.release();
+    for (DeviceBuffer* b : {&lane.coef, &lane.partial, &lane.chi2_xi, &lane.stage_in,
+                            &lane.stage_out})
+      b->release();
+    if (lane.finished) (void)hipEventDestroy(lane.finished);
+  }
+  for (DeviceBuffer* b : {&it->theta, &it->x, &it->out_ngal, &it->out_xi, &it->chi2_data})
     b->release();
   it->h_in.release();
   it->h_out.release();
   it->single_ws.buffer.release();
-  if (it->out_stream) (void)hipStreamSynchronize(it->out_stream);
-  it->stage_in.release();
-  for (DeviceBuffer& b : it->stage_out) b.release();
-  for (hipEvent_t event : {it->computed[0], it->computed[1], it->downloaded[0],
-                           it->downloaded[1]})
-    if (event) (void)hipEventDestroy(event);
   for (tc_table::Ticket& ticket : it->tickets)
     if (ticket.done) (void)hipEventDestroy(ticket.done);
-  if (it->out_stream) (void)hipStreamDestroy(it->out_stream);
-  if (it->stream) (void)hipStreamDestroy(it->stream);
+  for (tc_interp::Lane& lane : it->lanes)
+    if (lane.stream) (void)hipStreamDestroy(lane.stream);
   delete it;
   return TC_OK;
 }
 
 int tc_interp_synchronize(tc_interp* it) {
   TC_CHECK(it != nullptr, "interp handle is NULL");
-  TC_HIP(hipStreamSynchronize(it->stream));
-  if (it->out_stream) TC_HIP(hipStreamSynchronize(it->out_stream));
+  for (tc_interp::Lane& lane : it->lanes)
+    if (lane.stream) TC_HIP(hipStreamSynchronize(lane.stream));
   return TC_OK;
 }
 
@@ -488,6 +522,9 @@ int tc_interp_predict_zheng07_batch_device(tc_interp* it, const double* theta_de
   TC_HIP(hipSetDevice(it->device));
   const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
   const int n_comp = separate ? it->tables[0]->plan.n_components : 1;
+  it->cur = it->force_lane >= 0 ? it->force_lane
+            : it->tables[0]->tuning.pipeline ? (int)(it->device_calls++ % tc_interp::kLanes)
+                                             : 0;
   const int64_t slab = max_slab(it->tables[0]);
   for (int64_t begin = 0; begin < n_draws; begin += slab) {
     const int64_t n = std::min(slab, n_draws - begin);
@@ -639,9 +676,11 @@ int tc_interp_predict_zheng07_batch(tc_interp* it, const double* theta, int n_th
     double* out = (double*)it->h_out.ptr;
     memcpy(in, theta, theta_count * 8);
     memcpy(in + theta_count, x, x_count * 8);
+    it->force_lane = 0;
     status = tc_interp_predict_zheng07_batch_device(it, in, n_theta, in + theta_count,
                                                     n_draws, n_gauss, flags, out,
                                                     out + ngal_count);
+    it->force_lane = -1;
     if (status != TC_OK) return status;
     TC_HIP(hipStreamSynchronize(it->stream));
     memcpy(ngal, out, ngal_count * 8);
@@ -657,9 +696,11 @@ int tc_interp_predict_zheng07_batch(tc_interp* it, const double* theta, int n_th
                         hipMemcpyHostToDevice, it->stream));
   TC_HIP(hipMemcpyAsync(it->x.ptr, x, (size_t)n_draws * it->n_dim * 8,
                         hipMemcpyHostToDevice, it->stream));
+  it->force_lane = 0;
   status = tc_interp_predict_zheng07_batch_device(
       it, (const double*)it->theta.ptr, n_theta, (const double*)it->x.ptr, n_draws,
       n_gauss, flags, (double*)it->out_ngal.ptr, (double*)it->out_xi.ptr);
+  it->force_lane = -1;
   if (status != TC_OK) return status;
   TC_HIP(hipMemcpyAsync(ngal, it->out_ngal.ptr, ngal_count * 8, hipMemcpyDeviceToHost,
                         it->stream));
@@ -681,6 +722,12 @@ int tc_interp_chi2_zheng07_batch_device(tc_interp* it, const double* theta_devic
   TC_CHECK(data && precision && ngal_device && chi2_device, "NULL pointer");
   TC_HIP(hipSetDevice(it->device));
   const int n_r = it->tables[0]->n_r;
+  tc_table* t0 = it->tables[0];
+  // the lane tc_interp_predict_zheng07_batch_device is about to pick
+  const int lane_index = it->force_lane >= 0 ? it->force_lane
+                         : t0->tuning.pipeline ? (int)(it->device_calls % tc_interp::kLanes)
+                                               : 0;
+  tc_interp::Lane& L = it->lanes[lane_index];
   // data vector and precision matrix: uploaded when they differ from the last upload
   const size_t data_count = (size_t)(n_r + 1) * n_r;
   int status = it->chi2_data.reserve(data_count * 8, it->stream);
@@ -688,29 +735,30 @@ int tc_interp_chi2_zheng07_batch_device(tc_interp* it, const double* theta_devic
   if (it->chi2_host.size() != data_count ||
       memcmp(it->chi2_host.data(), data, (size_t)n_r * 8) != 0 ||
       memcmp(it->chi2_host.data() + n_r, precision, (size_t)n_r * n_r * 8) != 0) {
-    TC_HIP(hipStreamSynchronize(it->stream));   // (earlier kernels may still read the old ones)
+    // (earlier kernels of any lane may still read the old ones)
+    status = tc_interp_synchronize(it);
+    if (status != TC_OK) return status;
     it->chi2_host.assign(data, data + n_r);
     it->chi2_host.insert(it->chi2_host.end(), precision, precision + (size_t)n_r * n_r);
     TC_HIP(hipMemcpyAsync(it->chi2_data.ptr, it->chi2_host.data(), data_count * 8,
                           hipMemcpyHostToDevice, it->stream));
     TC_HIP(hipStreamSynchronize(it->stream));
   }
-  status = it->chi2_xi.reserve((size_t)n_draws * n_r * 8, it->stream);
+  status = L.chi2_xi.reserve((size_t)n_draws * n_r * 8, L.stream);
   if (status != TC_OK) return status;
   const double* d_data = (const double*)it->chi2_data.ptr;
-  tc_table* t0 = it->tables[0];
   t0->chi2_fused = false;
   t0->fuse_chi2_data = d_data;
   t0->fuse_chi2_out = n_draws <= max_slab(t0) ? chi2_device : nullptr;   // (one slab)
   status = tc_interp_predict_zheng07_batch_device(it, theta_device, n_theta, x_device, n_draws,
                                                   n_gauss, flags, ngal_device,
-                                                  (double*)it->chi2_xi.ptr);
+                                                  (double*)L.chi2_xi.ptr);
   const bool fused = t0->fuse_chi2_out != nullptr && t0->chi2_fused;
   t0->fuse_chi2_out = nullptr;
   if (status != TC_OK) return status;
   if (fused) return TC_OK;
-  return launch_chi2((const double*)it->chi2_xi.ptr, n_draws, n_r, d_data, d_data + n_r,
-                     chi2_device, it->stream);
+  return launch_chi2((const double*)L.chi2_xi.ptr, n_draws, n_r, d_data, d_data + n_r,
+                     chi2_device, L.stream);
 }
 
 int tc_interp_chi2_zheng07_batch(tc_interp* it, const double* theta, int n_theta,
@@ -733,9 +781,11 @@ int tc_interp_chi2_zheng07_batch(tc_interp* it, const double* theta, int n_theta
   TC_HIP(hipMemcpyAsync(it->x.ptr, x, x_bytes, hipMemcpyHostToDevice, it->stream));
   double* d_ngal = (double*)it->out_ngal.ptr;
   double* d_chi2 = d_ngal + n_draws;
+  it->force_lane = 0;
   status = tc_interp_chi2_zheng07_batch_device(it, (const double*)it->theta.ptr, n_theta,
                                                (const double*)it->x.ptr, n_draws, n_gauss,
                                                flags, data, precision, d_ngal, d_chi2);
+  it->force_lane = -1;
   if (status != TC_OK) return status;
   TC_HIP(hipMemcpyAsync(ngal, d_ngal, (size_t)n_draws * 8, hipMemcpyDeviceToHost, it->stream));
   TC_HIP(hipMemcpyAsync(chi2, d_chi2, (size_t)n_draws * 8, hipMemcpyDeviceToHost, it->stream));
@@ -767,46 +817,36 @@ int interp_async(tc_interp* it, const double* theta, int n_theta, const double* 
                 is_pinned(ngal, ngal_count * 8) && is_pinned(second, second_count * 8)),
            "asynchronous calls need page-locked buffers (tc_host_alloc / tc_host_register)");
   TC_HIP(hipSetDevice(it->device));
-  if (it->out_stream == nullptr) {
-    TC_HIP(hipStreamCreateWithFlags(&it->out_stream, hipStreamNonBlocking));
-    for (hipEvent_t* event : {&it->computed[0], &it->computed[1], &it->downloaded[0],
-                              &it->downloaded[1]})
-      TC_HIP(hipEventCreateWithFlags(event, hipEventDisableTiming));
-  }
-  const int s = (int)(it->next_ticket % 2);
-  hipStream_t last = it->stream;
+  // everything of a call -- upload, kernels, download, the ticket's event -- on the next lane's
+  // stream: the lanes overlap each other's transfers and kernels
+  const int lane_index =
+      t0->tuning.pipeline ? (int)(it->device_calls % tc_interp::kLanes) : 0;
+  tc_interp::Lane& L = it->lanes[lane_index];
+  hipStream_t last = L.stream;
   if (n_draws > 0) {
-    DeviceBuffer& out = it->stage_out[s];
-    if ((ngal_count + second_count) * 8 > out.bytes)
-      TC_HIP(hipStreamSynchronize(it->out_stream));    // (a download may still read it)
-    status = out.reserve((ngal_count + second_count) * 8, it->stream);
-    if (status == TC_OK) status = it->stage_in.reserve((theta_count + x_count) * 8, it->stream);
+    status = L.stage_out.reserve((ngal_count + second_count) * 8, L.stream);
+    if (status == TC_OK) status = L.stage_in.reserve((theta_count + x_count) * 8, L.stream);
     if (status != TC_OK) return status;
-    double* d_theta = (double*)it->stage_in.ptr;
+    double* d_theta = (double*)L.stage_in.ptr;
     double* d_x = d_theta + theta_count;
-    double* d_ngal = (double*)out.ptr;
+    double* d_ngal = (double*)L.stage_out.ptr;
     double* d_second = d_ngal + ngal_count;
     {
       Range range("upload");
-      TC_HIP(hipMemcpyAsync(d_theta, theta, theta_count * 8, hipMemcpyHostToDevice, it->stream));
-      TC_HIP(hipMemcpyAsync(d_x, x, x_count * 8, hipMemcpyHostToDevice, it->stream));
+      TC_HIP(hipMemcpyAsync(d_theta, theta, theta_count * 8, hipMemcpyHostToDevice, L.stream));
+      TC_HIP(hipMemcpyAsync(d_x, x, x_count * 8, hipMemcpyHostToDevice, L.stream));
     }
-    // the download of the call before last read this half of the results
-    TC_HIP(hipStreamWaitEvent(it->stream, it->downloaded[s], 0));
     status = chi2 ? tc_interp_chi2_zheng07_batch_device(it, d_theta, n_theta, d_x, n_draws,
                                                         n_gauss, flags, data, precision, d_ngal,
                                                         d_second)
                   : tc_interp_predict_zheng07_batch_device(it, d_theta, n_theta, d_x, n_draws,
                                                            n_gauss, flags, d_ngal, d_second);
     if (status != TC_OK) return status;
-    TC_HIP(hipEventRecord(it->computed[s], it->stream));
-    TC_HIP(hipStreamWaitEvent(it->out_stream, it->computed[s], 0));
     Range range("download");
-    TC_HIP(hipMemcpyAsync(ngal, d_ngal, ngal_count * 8, hipMemcpyDeviceToHost, it->out_stream));
-    TC_HIP(hipMemcpyAsync(second, d_second, second_count * 8, hipMemcpyDeviceToHost,
-                          it->out_stream));
-    TC_HIP(hipEventRecord(it->downloaded[s], it->out_stream));
-    last = it->out_stream;
+    TC_HIP(hipMemcpyAsync(ngal, d_ngal, ngal_count * 8, hipMemcpyDeviceToHost, L.stream));
+    TC_HIP(hipMemcpyAsync(second, d_second, second_count * 8, hipMemcpyDeviceToHost, L.stream));
+  } else if (t0->tuning.pipeline) {
+    ++it->device_calls;
   }
   tc_table::Ticket& slot = it->tickets[it->next_ticket % tc_table::kMaxTickets];
   if (slot.done == nullptr)
@@ -845,9 +885,7 @@ int tc_interp_wait(tc_interp* it, int64_t ticket) {
     return TC_OK;
   }
   // the slot was reused: the ticket is older than everything queued now
-  TC_HIP(hipStreamSynchronize(it->stream));
-  if (it->out_stream) TC_HIP(hipStreamSynchronize(it->out_stream));
-  return TC_OK;
+  return tc_interp_synchronize(it);
 }
 
 int tc_interp_query(tc_interp* it, int64_t ticket, int* done) {
@@ -855,12 +893,16 @@ int tc_interp_query(tc_interp* it, int64_t ticket, int* done) {
   TC_CHECK(ticket >= 0 && ticket < it->next_ticket, "unknown ticket %lld", (long long)ticket);
   const tc_table::Ticket& slot = it->tickets[ticket % tc_table::kMaxTickets];
   *done = 0;
-  // (a reused slot: the ticket is done once both streams have passed their later work)
-  const hipError_t state =
-      slot.id == ticket ? hipEventQuery(slot.done)
-      : hipStreamQuery(it->stream) == hipSuccess && it->out_stream != nullptr
-          ? hipStreamQuery(it->out_stream)
-          : hipStreamQuery(it->stream);
+  // (a reused slot: the ticket is done once both lanes have passed their later work)
+  hipError_t state = hipSuccess;
+  if (slot.id == ticket) {
+    state = hipEventQuery(slot.done);
+  } else {
+    for (tc_interp::Lane& lane : it->lanes) {
+      const hipError_t lane_state = hipStreamQuery(lane.stream);
+      if (lane_state != hipSuccess) state = lane_state;
+    }
+  }
   if (state == hipSuccess) *done = 1;
   else if (state != hipErrorNotReady)
     return fail(TC_ERR_HIP, "query failed: %s", hipGetErrorString(state));
