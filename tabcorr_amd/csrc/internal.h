@@ -248,8 +248,27 @@ struct Tuning {
   int async_direct_in = 1;    // 1: kernels read the draws from the caller's pinned memory
   int async_direct_out = 2;   // 0: copy commands, 1: kernels store everything, 2: kernels
                               // store arrays up to kDirectOutBytes, copy commands beyond
+  // One launch per batch (predict_fused_kernel) for the calls it covers: 0 never, 1 the
+  // pipelined device-pointer and asynchronous calls of fused_min_draws .. fused_max_draws
+  // draws, 2 every call of that size.  Sustained device-resident rate on four lanes
+  // (tools/r03_fused_scan.py, BASELINE configs[1]'s table; three kernels / one launch, us per
+  // call): 4096 draws 23.6 / 30.7, 8192 35.6 / 33.0, 10^4 42.7 / 39.6, 16384 66.7 / 63.5,
+  // 40000 151.8 / 156.3 -- both designs approach the same 38 us per 10^4 draws for huge
+  // batches (matrix + vector instructions on one FP64 pipe); the one-launch form gets there
+  // with the batch sizes an ensemble sampler has, the three kernels spread small batches
+  // over the whole chip.
+  int fused = 1;
+  int fused_min_draws = 6144;
+  int fused_max_draws = 32768;
+  int prio_fused = 1, prio_fused_occ = 2, prio_fused_out = 3;   // phases 2, 1, 3
   int skip_occ = 0, skip_finalize = 0;   // diagnosis (developer builds only)
   void load() {
+    fused = env_int("TC_FUSED", fused);
+    fused_min_draws = env_int("TC_FUSED_MIN_DRAWS", fused_min_draws);
+    fused_max_draws = env_int("TC_FUSED_MAX_DRAWS", fused_max_draws);
+    prio_fused = env_int("TC_PRIO_FUSED", prio_fused);
+    prio_fused_occ = env_int("TC_PRIO_FUSED_OCC", prio_fused_occ);
+    prio_fused_out = env_int("TC_PRIO_FUSED_OUT", prio_fused_out);
     lanes = env_int("TC_LANES", lanes);
     pipeline = env_int("TC_PIPELINE", pipeline);
     single_draw = env_int("TC_SINGLE_DRAW", single_draw);
@@ -409,6 +428,12 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta, int64_t
 // Contraction + finalisation of draws whose densities are already in the current lane.
 int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
                     double* ngal_device, double* xi_device);
+// One launch per slab (predict_fused_kernel) for the calls it covers; ngal and xi (or the
+// likelihood, t->fuse_chi2_out) as run_contraction leaves them.
+bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags);
+int fused_lds_bytes(const tc_table* t);
+int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_draws, int n_gauss,
+              double* ngal_device, double* xi_device);
 int check_predict_args(const tc_table* t, const void* theta, int n_theta, int64_t n_draws,
                        int n_gauss, unsigned flags);
 int launch_finalize(const FinalizeArgs& args, const Tuning& tuning, hipStream_t stream);

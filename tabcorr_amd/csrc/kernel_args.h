@@ -193,6 +193,38 @@ struct FinalizeQuadArgs {
   double* chi2;
 };
 
+// ---- one launch per batch (predict_fused_kernel): occupation -> quadratic form -> results ---
+// A workgroup of kFusedWaves waves owns 64 draws from theta to (ngal, xi[, chi2]): the
+// densities live in LDS ((dens_rows, 64) doubles, rows beyond n_bins zero), nothing is handed
+// over through memory.  Mode auto, total correlation function, one r tile.
+constexpr int kFusedWaves = 8;
+
+struct FusedArgs {
+  const double* theta;       // (n_draws, n_theta)
+  int n_theta;
+  int n_bins;
+  int n_central;
+  int n_gauss;
+  int dens_rows;             // 4 x block rows of the triangle
+  int part_rb0[4];           // the four quarters of the triangle's units: first block row,
+  int part_cb0[4];           // ... block column
+  int part_count[4];         // ... units
+  int n_r;
+  int priority;              // wave priorities: phase 2 | phase 1 << 2 | phase 3 << 4
+  int64_t n_draws;
+  const double* log_m;       // quadrature constants as in OccArgs
+  const double* m;
+  const double* weight;
+  const double* n_h;
+  const double* math_table;
+  const void* table;         // re-laid-out matrix of the whole triangle (one r tile)
+  uint32_t table_bytes;
+  double* ngal;              // (n_draws)
+  double* xi;                // (n_draws, n_r), or NULL when the likelihood is fused
+  const double* chi2_data;   // as FinalizeQuadArgs
+  double* chi2;
+};
+
 struct FinalizeArgs {
   const double* partial;   // (n_groups, r_stride, ldb)
   const Group* groups;     // component of each group

@@ -127,6 +127,92 @@ __device__ inline DrawSetup prepare_draw(const double* table, const fm::Consts& 
   return d;
 }
 
+// Mean occupation of bin g for the lane's draw (Zheng et al. 2007 eqs. 1 and 3 averaged over
+// the bin's quadrature nodes): the body shared by occ_zheng07_kernel and predict_fused_kernel.
+struct DrawParams {
+  double log_m_min, inv_sigma, m0, log2_m1, sat_scale, alpha, a_cen, a_sat;
+  int bad;
+  bool any_bad;    // wave-uniform: does any draw of the tile need the NaN fix-ups?
+};
+
+template <int NGAUSS, bool ASSEMBIAS, bool MODULATE>
+__device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm::Consts& kc,
+                                                  int g, int n_gauss, bool central, bool above,
+                                                  sc_f64 log_m, sc_f64 mass, sc_f64 weight,
+                                                  const DrawParams& d, double f1, double f2) {
+  constexpr bool assembias = ASSEMBIAS;
+  constexpr bool modulate = MODULATE;
+  const double log_m_min = d.log_m_min, inv_sigma = d.inv_sigma, m0 = d.m0;
+  const double log2_m1 = d.log2_m1, sat_scale = d.sat_scale, alpha = d.alpha;
+  const double a_cen = d.a_cen, a_sat = d.a_sat;
+  const int bad = d.bad;
+  const bool any_bad = d.any_bad;
+  double acc = 0.0;
+  // Wave-uniform shortcuts (the draws of a sampler's ensemble cluster around the posterior,
+  // so whole bins sit on the plateaus for all 64 draws of a tile): a bin whose nodes all
+  // have |z| >= 6 evaluates to erf = +-1 exactly (erf_fast clamps there), a satellite bin
+  // below every draw's M0 to 0.  Same bits as the node loop, none of its instructions.
+  int shortcut = 0;      // 1: all ones, 2: all zeros
+#ifndef TC_NO_OCC_SHORTCUTS
+  if (!assembias && !any_bad) {
+    if (central) {
+      const double z_a = (log_m[g * n_gauss] - log_m_min) * inv_sigma;
+      const double z_b = (log_m[g * n_gauss + n_gauss - 1] - log_m_min) * inv_sigma;
+      const double z_lo = z_a < z_b ? z_a : z_b, z_hi = z_a < z_b ? z_b : z_a;
+      if (__builtin_amdgcn_ballot_w64(!(z_lo >= 6.0)) == 0) shortcut = 1;
+      else if (__builtin_amdgcn_ballot_w64(!(z_hi <= -6.0)) == 0) shortcut = 2;
+    } else {
+      const double m_a = mass[g * n_gauss], m_b = mass[g * n_gauss + n_gauss - 1];
+      if (__builtin_amdgcn_ballot_w64((m_a > m_b ? m_a : m_b) > m0) == 0) shortcut = 2;
+    }
+  }
+#endif
+  if (shortcut != 0) {
+    if (shortcut == 1)
+      for (int k = 0; k < n_gauss; ++k) acc = fma(weight[g * n_gauss + k], 1.0, acc);
+  } else if (central) {
+#pragma unroll
+    for (int k = 0; k < n_gauss; ++k) {
+      const double lm = log_m[g * n_gauss + k];
+      double n = fma(0.5, fm::erf_fast(table, kc, (lm - log_m_min) * inv_sigma), 0.5);
+      if (assembias) n = heaviside_assembias(n, a_cen, above, f2, f1, true);
+      acc = fma(weight[g * n_gauss + k], n, acc);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < n_gauss; ++k) {
+      const double x = mass[g * n_gauss + k] - m0;
+      // 1e-300 keeps log2's input a positive normal number on the lanes with
+      // M <= M0, whose result the scaling step of exp2 then sets to exactly 0
+      double n = fm::exp2_fast(
+          table, kc,
+          alpha * fm::log2_fast_offset(table, kc, x > 1e-300 ? x : 1e-300, log2_m1),
+          x > 0.0);
+      if (assembias) n *= sat_scale;   // (the Heaviside decoration is not linear)
+      if (modulate) {
+        const double lm = log_m[g * n_gauss + k];
+        n *= fma(0.5, fm::erf_fast(table, kc, (lm - log_m_min) * inv_sigma), 0.5);
+      }
+      if (assembias) n = heaviside_assembias(n, a_sat, above, f2, f1, false);
+      acc = fma(weight[g * n_gauss + k], n, acc);
+    }
+    if (!assembias) acc *= sat_scale;
+  }
+  if (any_bad) {
+    bool tie = false;
+    if ((bad & kTieCen) && (central || modulate))
+      for (int k = 0; k < n_gauss; ++k) tie = tie || log_m[g * n_gauss + k] == log_m_min;
+    const bool cen_nan = (bad & kBadCen) || tie;
+    if (!central && (bad & kInfSat) && acc != 0.0) {
+      // (decorated: the shift limit is inf - inf = NaN in the reference's arithmetic)
+      acc = assembias ? __builtin_nan("") : __builtin_huge_val();
+    }
+    if (central ? cen_nan : (((bad & kBadSat) && acc != 0.0) || (modulate && cen_nan)))
+      acc = __builtin_nan("");
+  }
+  return acc;
+}
+
 // Mean occupation of every bin for every draw: tabcorr/tabcorr.py:537-578 with
 // the two halotools callbacks of :556-563 evaluated inline (Zheng et al. 2007
 // eqs. 1 and 3).  Work items = (draw tile, bin split); the kOccWaves waves of a
@@ -209,85 +295,25 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
       prm[8][lane] = (double)d.bad;
     }
     __syncthreads();
-    const double log_m_min = prm[0][lane];
-    const double inv_sigma = prm[1][lane];
-    const double m0 = prm[2][lane];
-    const double log2_m1 = prm[3][lane];
-    const double sat_scale = prm[4][lane];
-    const double alpha = prm[5][lane];
-    const double a_cen = assembias ? prm[6][lane] : 0.0;
-    const double a_sat = assembias ? prm[7][lane] : 0.0;
-    const int bad = (int)prm[8][lane];
+    DrawParams dp;
+    dp.log_m_min = prm[0][lane];
+    dp.inv_sigma = prm[1][lane];
+    dp.m0 = prm[2][lane];
+    dp.log2_m1 = prm[3][lane];
+    dp.sat_scale = prm[4][lane];
+    dp.alpha = prm[5][lane];
+    dp.a_cen = assembias ? prm[6][lane] : 0.0;
+    dp.a_sat = assembias ? prm[7][lane] : 0.0;
+    dp.bad = (int)prm[8][lane];
     // wave-uniform: does any draw of this tile need the NaN fix-ups after a bin's node loop?
-    const bool any_bad = __builtin_amdgcn_ballot_w64(bad != 0) != 0;
+    dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
 
     double sum_cen = 0.0, sum_sat = 0.0;
     for (int g = g_begin + wave; g < g_end; g += kOccWaves) {
       const bool central = g < a.n_central;
       const bool above = percentile[g] > a.split;
-      double acc = 0.0;
-      // Wave-uniform shortcuts (the draws of a sampler's ensemble cluster around the posterior,
-      // so whole bins sit on the plateaus for all 64 draws of a tile): a bin whose nodes all
-      // have |z| >= 6 evaluates to erf = +-1 exactly (erf_fast clamps there), a satellite bin
-      // below every draw's M0 to 0.  Same bits as the node loop, none of its instructions.
-      int shortcut = 0;      // 1: all ones, 2: all zeros
-#ifndef TC_NO_OCC_SHORTCUTS
-      if (!assembias && !any_bad) {
-        if (central) {
-          const double z_a = (log_m[g * n_gauss] - log_m_min) * inv_sigma;
-          const double z_b = (log_m[g * n_gauss + n_gauss - 1] - log_m_min) * inv_sigma;
-          const double z_lo = z_a < z_b ? z_a : z_b, z_hi = z_a < z_b ? z_b : z_a;
-          if (__builtin_amdgcn_ballot_w64(!(z_lo >= 6.0)) == 0) shortcut = 1;
-          else if (__builtin_amdgcn_ballot_w64(!(z_hi <= -6.0)) == 0) shortcut = 2;
-        } else {
-          const double m_a = mass[g * n_gauss], m_b = mass[g * n_gauss + n_gauss - 1];
-          if (__builtin_amdgcn_ballot_w64((m_a > m_b ? m_a : m_b) > m0) == 0) shortcut = 2;
-        }
-      }
-#endif
-      if (shortcut != 0) {
-        if (shortcut == 1)
-          for (int k = 0; k < n_gauss; ++k) acc = fma(weight[g * n_gauss + k], 1.0, acc);
-      } else if (central) {
-#pragma unroll
-        for (int k = 0; k < n_gauss; ++k) {
-          const double lm = log_m[g * n_gauss + k];
-          double n = fma(0.5, fm::erf_fast(table, kc, (lm - log_m_min) * inv_sigma), 0.5);
-          if (assembias) n = heaviside_assembias(n, a_cen, above, f2, f1, true);
-          acc = fma(weight[g * n_gauss + k], n, acc);
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < n_gauss; ++k) {
-          const double x = mass[g * n_gauss + k] - m0;
-          // 1e-300 keeps log2's input a positive normal number on the lanes with
-          // M <= M0, whose result the scaling step of exp2 then sets to exactly 0
-          double n = fm::exp2_fast(
-              table, kc,
-              alpha * fm::log2_fast_offset(table, kc, x > 1e-300 ? x : 1e-300, log2_m1),
-              x > 0.0);
-          if (assembias) n *= sat_scale;   // (the Heaviside decoration is not linear)
-          if (modulate) {
-            const double lm = log_m[g * n_gauss + k];
-            n *= fma(0.5, fm::erf_fast(table, kc, (lm - log_m_min) * inv_sigma), 0.5);
-          }
-          if (assembias) n = heaviside_assembias(n, a_sat, above, f2, f1, false);
-          acc = fma(weight[g * n_gauss + k], n, acc);
-        }
-        if (!assembias) acc *= sat_scale;
-      }
-      if (any_bad) {
-        bool tie = false;
-        if ((bad & kTieCen) && (central || modulate))
-          for (int k = 0; k < n_gauss; ++k) tie = tie || log_m[g * n_gauss + k] == log_m_min;
-        const bool cen_nan = (bad & kBadCen) || tie;
-        if (!central && (bad & kInfSat) && acc != 0.0) {
-          // (decorated: the shift limit is inf - inf = NaN in the reference's arithmetic)
-          acc = assembias ? __builtin_nan("") : __builtin_huge_val();
-        }
-        if (central ? cen_nan : (((bad & kBadSat) && acc != 0.0) || (modulate && cen_nan)))
-          acc = __builtin_nan("");
-      }
+      const double acc = occ_bin_zheng07<NGAUSS, ASSEMBIAS, MODULATE>(
+          table, kc, g, n_gauss, central, above, log_m, mass, weight, dp, f1, f2);
       if (a.occupation != nullptr && b0 < a.n_draws)
         a.occupation[b0 * a.n_bins + perm[g]] = acc;
       const double dens = acc * n_h[g];
@@ -1314,6 +1340,262 @@ __global__ __launch_bounds__(1024) void finalize_quad_kernel(FinalizeQuadArgs a)
       if (d < n_valid) a.xi[(col + d) * (int64_t)n_rows + row0 + rr] = tile[rr][d];
     }
     __syncthreads();
+  }
+}
+
+// ---- one launch per batch: theta -> (ngal, xi[, chi2]) inside a workgroup ------------------
+//
+// tabcorr.py:537-578 + :623-650 for 64 draws per workgroup, nothing handed over through
+// memory.  The three-kernel path pays for its hand-offs twice: 8 MB of densities and ~5 MB of
+// partial sums per 10^4 draws travel through the L2, and -- what costs the time -- every lane's
+// chain has three stages that each wait for the previous one to DRAIN (a lane's cycle is
+// occupation 75 us, contraction 68 us, finalisation 26 us with four lanes in flight:
+// profiles/r03_notes.md).  Here a workgroup of kFusedWaves waves
+//   1. evaluates the occupations of its 64 draws (lane = draw, bins strided over the waves,
+//      occ_bin_zheng07 as in occ_zheng07_kernel) into an LDS array dens[bin][64],
+//   2. contracts: wave w takes the 32-draw tile w / 4 and quarter w % 4 of the triangle's
+//      units -- the loop of contract_quad_kernel with the density operands read from LDS (the
+//      matrix still streams from the L2 through buffer loads), walked once per PAIR of r
+//      sub-tiles: 32 accumulator registers instead of 80, so that four waves per SIMD fit
+//      (two workgroups per CU: whatever phase the neighbour is in, a SIMD has two waves
+//      issuing matrix instructions),
+//   3. adds the four quarters through LDS, normalises and writes ngal, xi (or the likelihood).
+// Workgroups of different launches share a CU, so one's occupation phase (vector ALU) runs
+// under the other's matrix instructions; there is no inter-workgroup step.
+// Mode auto, total correlation function, one r tile, plain Zheng07.
+constexpr int kFusedSlotDoubles = kFusedWaves * 4 * kQuadMaxU * kQuadTile;   // phase 3
+constexpr int kFusedScratchDoubles = fm::kTableDoubles + 2 * kFusedWaves * kLanes;
+static_assert(kFusedWaves == 8, "two 32-draw tiles x four quarters of the triangle");
+static_assert(20 * (kLanes + 1) + 20 * 21 <= fm::kTableDoubles,
+              "results tile + likelihood data in the place of the math table");
+
+// One pass over `count` units from block (rb, cb) on: UU (1 or 2) r sub-tiles whose table
+// operands are the pair at lane offset off_a; F[uu][set] += ... as in contract_quad_kernel.
+template <int UU>
+__device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, unsigned off_a,
+                                                unsigned unit_bytes, const double* dens_b,
+                                                const double* dens_e, int rb, int cb, int left,
+                                                double (&F)[2][2]) {
+  unsigned ua = (unsigned)(rb * (rb + 1) / 2 + cb) * unit_bytes;
+  f64x2 t0, t1, b0, b1;
+  f64x4 D[UU][2];
+  auto fetch = [&](f64x2& t, f64x2& b, int column) {
+    t = buffer_load16<0>(rs_t, off_a, ua);
+    b = *(const f64x2*)(dens_b + 4 * column * kLanes);
+    ua += unit_bytes;
+  };
+  auto mma = [&](const f64x2& t, const f64x2& b, bool first) {
+    if (first) {
+      const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < UU; ++u) {
+        const double av = u ? t.y : t.x;
+        D[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b.x, zero, 0, 0, 0);
+        D[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b.y, zero, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < UU; ++u) {
+        const double av = u ? t.y : t.x;
+        D[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b.x, D[u][0], 0, 0, 0);
+        D[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b.y, D[u][1], 0, 0, 0);
+      }
+    }
+  };
+  fetch(t0, b0, cb);
+  while (left > 0) {
+    const int row_length = rb + 1;
+    const int n = row_length - cb < left ? row_length - cb : left;
+    left -= n;
+    f64x2 e[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) e[v] = *(const f64x2*)(dens_e + (4 * rb + v) * kLanes);
+    fetch(t1, b1, n > 1 ? cb + 1 : 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(t0, b0, true);
+    __builtin_amdgcn_sched_barrier(0);
+    int t = 1;
+    for (; t + 1 < n; t += 2) {
+      fetch(t0, b0, cb + t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(t1, b1, false);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(t1, b1, t + 2 < n ? cb + t + 2 : 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(t0, b0, false);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (t < n) {
+      fetch(t0, b0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(t1, b1, false);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      t0 = t1;
+      b0 = b1;
+    }
+#pragma unroll
+    for (int u = 0; u < UU; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        F[u][0] = fma(D[u][0][v], e[v].x, F[u][0]);
+        F[u][1] = fma(D[u][1][v], e[v].y, F[u][1]);
+      }
+    ++rb;
+    cb = 0;
+  }
+}
+
+template <int NGAUSS, int U>
+__global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(FusedArgs a) {
+  constexpr int UP = (U + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) double fused_lds[];
+  // region B: densities, later the waves' sums; region A: math table, later the results tile
+  // and the likelihood's data | ngal sums
+  const int region_b =
+      a.dens_rows * kLanes > kFusedSlotDoubles ? a.dens_rows * kLanes : kFusedSlotDoubles;
+  double* dens = fused_lds;
+  double* table = fused_lds + region_b;
+  double(*red)[kFusedWaves][kLanes] =
+      (double(*)[kFusedWaves][kLanes])(table + fm::kTableDoubles);
+  const fm::Consts kc = fm::make_consts();
+  set_priority((a.priority >> 2) & 3);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n_gauss = NGAUSS > 0 ? NGAUSS : a.n_gauss;
+  {
+    typedef double __attribute__((ext_vector_type(2))) double2v;
+    const int hi = fm::kTableDoubles / 2;
+    const double2v* src = (const double2v*)a.math_table;
+    double2v* dst = (double2v*)table;
+    for (int i = threadIdx.x; i < hi; i += blockDim.x) dst[i] = src[i];
+  }
+  for (int idx = a.n_bins * kLanes + threadIdx.x; idx < a.dens_rows * kLanes; idx += blockDim.x)
+    dens[idx] = 0.0;
+  __syncthreads();
+
+  // ---- 1. occupations ----
+  const int64_t col = (int64_t)blockIdx.x * kLanes;
+  const int64_t b0 = col + lane;
+  const int64_t b = b0 < a.n_draws ? b0 : a.n_draws - 1;
+  double norm;
+  {
+    // (every wave sets up its lanes' draws itself: cheaper than a hand-over through LDS)
+    const double* th = a.theta + b * a.n_theta;
+    const DrawSetup d = prepare_draw(table, kc, th[0], th[1], th[2], th[3], th[4], 0.0, 0.0);
+    DrawParams dp;
+    dp.log_m_min = d.log_m_min;
+    dp.inv_sigma = d.inv_sigma;
+    dp.m0 = d.m0;
+    dp.log2_m1 = d.log2_m1;
+    dp.sat_scale = d.sat_scale;
+    dp.alpha = d.alpha;
+    dp.a_cen = dp.a_sat = 0.0;
+    dp.bad = d.bad;
+    dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
+    sc_f64 log_m = (sc_f64)a.log_m;
+    sc_f64 mass = (sc_f64)a.m;
+    sc_f64 weight = (sc_f64)a.weight;
+    sc_f64 n_h = (sc_f64)a.n_h;
+    double sum_cen = 0.0, sum_sat = 0.0;
+    for (int g = wave; g < a.n_bins; g += kFusedWaves) {
+      const bool central = g < a.n_central;
+      const double acc = occ_bin_zheng07<NGAUSS, false, false>(
+          table, kc, g, n_gauss, central, false, log_m, mass, weight, dp, 1.0, 1.0);
+      const double value = acc * n_h[g];
+      dens[g * kLanes + lane] = value;
+      if (central) sum_cen += value; else sum_sat += value;
+    }
+    red[0][wave][lane] = sum_cen;
+    red[1][wave][lane] = sum_sat;
+    __syncthreads();
+    double n_cen = 0.0, n_sat = 0.0;
+#pragma unroll
+    for (int w = 0; w < kFusedWaves; ++w) {
+      n_cen += red[0][w][lane];
+      n_sat += red[1][w][lane];
+    }
+    const double total = n_cen + n_sat;
+    norm = total * total;
+    if (wave == 0 && b0 < a.n_draws) a.ngal[b0] = total;
+  }
+
+  // ---- 2. quadratic form ----
+  set_priority(a.priority & 3);
+  const int c = lane & 15, kq = lane >> 4;
+  double F[UP][2][2];
+  {
+    const int sub = wave >> 2, part = wave & 3;
+    const unsigned off_a = lane * 16;
+    const double* dens_b = dens + kq * kLanes + sub * kQuadTile + 2 * c;   // + 4 col rows
+    const double* dens_e = dens + sub * kQuadTile + 2 * c;                  // + row i
+    const __amdgpu_buffer_rsrc_t rs_t =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.table, 0, a.table_bytes, kBufferFlags);
+    const int rb = a.part_rb0[part], cb = a.part_cb0[part], count = a.part_count[part];
+#pragma unroll
+    for (int p = 0; p < UP; ++p) {
+      F[p][0][0] = F[p][0][1] = F[p][1][0] = F[p][1][1] = 0.0;
+      if (2 * p + 1 < U)
+        fused_quad_pass<2>(rs_t, off_a + p * 1024, UP * 1024, dens_b, dens_e, rb, cb, count, F[p]);
+      else
+        fused_quad_pass<1>(rs_t, off_a + p * 1024, UP * 1024, dens_b, dens_e, rb, cb, count, F[p]);
+    }
+  }
+  __syncthreads();       // the densities are dead: their place takes the waves' sums
+  {
+    // r = 4 u + l / 16, draws 2 c and 2 c + 1 of the wave's tile
+    double* out = dens + (wave * (4 * U) + kq) * kQuadTile + 2 * c;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const f64x2 value = {F[u >> 1][u & 1][0], F[u >> 1][u & 1][1]};
+      *(f64x2*)(out + (4 * u) * kQuadTile) = value;
+    }
+  }
+  // ---- 3. the four quarters of every tile, normalisation, results ----
+  set_priority((a.priority >> 4) & 3);
+  double(*tile)[kLanes + 1] = (double(*)[kLanes + 1])table;
+  double* chi2_lds = table + 20 * (kLanes + 1);
+  if (a.chi2 != nullptr) {
+    const int count = a.n_r * (a.n_r + 1);
+    for (int idx = threadIdx.x; idx < count; idx += blockDim.x) chi2_lds[idx] = a.chi2_data[idx];
+  }
+  __syncthreads();
+  {
+    const int sub = lane >> 5, d = lane & 31;
+    for (int rr = wave; rr < a.n_r; rr += kFusedWaves) {
+      const double* first = dens + ((4 * sub) * (4 * U) + rr) * kQuadTile + d;
+      double sum = first[0];
+#pragma unroll
+      for (int part = 1; part < 4; ++part) sum += first[part * (4 * U) * kQuadTile];
+      tile[rr][lane] = sum / norm;
+    }
+  }
+  __syncthreads();
+  const int64_t n_valid = a.n_draws - col < kLanes ? a.n_draws - col : kLanes;
+  if (a.chi2 != nullptr) {
+    // chi2 = delta^T P delta for the lane's draw (finalize_quad_kernel's fused likelihood)
+    const int rows = a.n_r;
+    const double* data = chi2_lds;
+    const double* matrix = chi2_lds + rows;
+    double part = 0.0;
+    for (int i = wave; i < rows; i += kFusedWaves) {
+      double inner = 0.0;
+      for (int j = 0; j < rows; ++j)
+        inner = fma(matrix[i * rows + j], tile[j][lane] - data[j], inner);
+      part = fma(tile[i][lane] - data[i], inner, part);
+    }
+    red[0][wave][lane] = part;
+    __syncthreads();
+    if (wave == 0 && lane < n_valid) {
+      double total = 0.0;
+      for (int w = 0; w < kFusedWaves; ++w) total += red[0][w][lane];
+      a.chi2[col + lane] = total;
+    }
+    return;
+  }
+  for (int idx = threadIdx.x; idx < a.n_r * kLanes; idx += blockDim.x) {
+    const int d = idx / a.n_r, rr = idx % a.n_r;
+    if (d < n_valid) a.xi[(col + d) * (int64_t)a.n_r + rr] = tile[rr][d];
   }
 }
 

@@ -878,6 +878,120 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   return TC_OK;
 }
 
+// One launch per slab of draws (predict_fused_kernel): plain Zheng07, total correlation
+// function, float64 quadratic form with one r tile, densities of 64 draws within the LDS.
+bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags) {
+  if (t->tuning.fused == 0 || n_draws < t->tuning.fused_min_draws ||
+      n_draws > t->tuning.fused_max_draws)
+    return false;
+  if (!t->quad || t->compute_dtype != TC_DTYPE_F64 || t->quad_total.d_table == nullptr)
+    return false;
+  if (t->quad_tiling.n_rtiles != 1 || t->n_r > 20 || t->chain || t->tuning.trace) return false;
+  if (flags & (TC_FLAG_SEPARATE_GAL_TYPE | TC_FLAG_ASSEMBIAS | TC_FLAG_MODULATE_WITH_CENOCC |
+               TC_FLAG_LEAUTHAUD11))
+    return false;
+  if (t->quad_total.layout.comps.size() != 1 || !t->quad_total.layout.comps[0].triangular)
+    return false;
+  if (fused_lds_bytes(t) > 160 * 1024 || n_gauss < 1) return false;
+  // calls that run alone on their lane (host-buffer API, pipeline off) keep the three kernels,
+  // which spread one batch over the whole chip
+  const bool alone = t->force_lane >= 0 || !t->tuning.pipeline || t->n_lanes == 1;
+  return t->tuning.fused >= 2 || !alone;
+}
+
+int fused_lds_bytes(const tc_table* t) {
+  const int dens_rows = 4 * t->quad_total.layout.comps[0].n_rb;
+  return (std::max(dens_rows * 64, tc::kFusedSlotDoubles) + tc::kFusedScratchDoubles) * 8;
+}
+
+int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_draws,
+              int n_gauss, double* ngal_device, double* xi_device) {
+  Range range("occupation + contraction + finalisation (one launch)");
+  tc_table::Lane& lane = t->lanes[t->cur];
+  hipStream_t stream = lane.stream;
+  Quadrature* q = nullptr;
+  int status = get_quadrature(t, n_gauss, &q);
+  if (status != TC_OK) return status;
+  const tc::QuadComp& comp = t->quad_total.layout.comps[0];
+  tc::FusedArgs fa{};
+  fa.theta = theta_device;
+  fa.n_theta = n_theta;
+  fa.n_bins = t->n_bins;
+  fa.n_central = t->plan.n_central;
+  fa.n_gauss = n_gauss;
+  fa.dens_rows = 4 * comp.n_rb;
+  for (int part = 0; part < 4; ++part) {
+    const int64_t begin = comp.n_units * part / 4, end = comp.n_units * (part + 1) / 4;
+    int64_t rb = (int64_t)((std::sqrt(8.0 * (double)begin + 1.0) - 1.0) / 2.0);
+    while ((rb + 1) * (rb + 2) / 2 <= begin) ++rb;
+    while (rb * (rb + 1) / 2 > begin) --rb;
+    fa.part_rb0[part] = (int)rb;
+    fa.part_cb0[part] = (int)(begin - rb * (rb + 1) / 2);
+    fa.part_count[part] = (int)(end - begin);
+  }
+  fa.n_r = t->n_r;
+  fa.priority = (t->tuning.prio_fused & 3) | ((t->tuning.prio_fused_occ & 3) << 2) |
+                ((t->tuning.prio_fused_out & 3) << 4);
+  fa.n_draws = n_draws;
+  fa.log_m = (const double*)q->log_m;
+  fa.m = (const double*)q->m;
+  fa.weight = (const double*)q->weight;
+  fa.n_h = (const double*)t->d_n_h;
+  fa.math_table = (const double*)t->d_math_table;
+  fa.table = (const char*)t->quad_total.d_table + (size_t)comp.unit_base *
+                 (size_t)((t->quad_tiling.n_u + 1) / 2) * 1024;
+  fa.table_bytes = (uint32_t)t->quad_total.rtile_bytes;
+  fa.ngal = ngal_device;
+  fa.xi = xi_device;
+  t->chi2_fused = false;
+  if (t->fuse_chi2_out != nullptr) {
+    fa.chi2_data = t->fuse_chi2_data;
+    fa.chi2 = t->fuse_chi2_out;
+    fa.xi = nullptr;
+    t->chi2_fused = true;
+  }
+  const int lds = fused_lds_bytes(t);
+  const dim3 grid((unsigned)((n_draws + 63) / 64)), block(64 * tc::kFusedWaves);
+  hipEvent_t k0 = nullptr, k1 = nullptr;
+  status = next_kernel_events(t, &k0, &k1);
+  if (status != TC_OK) return status;
+  switch (t->quad_tiling.n_u) {
+#define TC_CASE(N)                                                                           \
+  case N: {                                                                                  \
+    static bool limit_set_10 = false, limit_set_0 = false;                                   \
+    if (n_gauss == 10) {                                                                     \
+      if (lds > 64 * 1024 && !limit_set_10) {                                                \
+        TC_HIP(hipFuncSetAttribute((const void*)tc::predict_fused_kernel<10, N>,             \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        limit_set_10 = true;                                                                 \
+      }                                                                                      \
+      hipExtLaunchKernelGGL((tc::predict_fused_kernel<10, N>), grid, block, lds, stream, k0, \
+                            k1, 0, fa);                                                      \
+    } else {                                                                                 \
+      if (lds > 64 * 1024 && !limit_set_0) {                                                 \
+        TC_HIP(hipFuncSetAttribute((const void*)tc::predict_fused_kernel<0, N>,              \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        limit_set_0 = true;                                                                  \
+      }                                                                                      \
+      hipExtLaunchKernelGGL((tc::predict_fused_kernel<0, N>), grid, block, lds, stream, k0,  \
+                            k1, 0, fa);                                                      \
+    }                                                                                        \
+    break;                                                                                   \
+  }
+    TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4) TC_CASE(5)
+#undef TC_CASE
+    default:
+      return fail(TC_ERR_UNSUPPORTED, "no fused kernel for %d r sub-tiles", t->quad_tiling.n_u);
+  }
+  TC_HIP(hipGetLastError());
+  t->last_workgroups = (int)grid.x;
+  t->last_waves = tc::kFusedWaves;
+  t->last_splits = 0;
+  t->last_lds = lds;
+  t->prev = t->force_lane >= 0 ? -1 : t->cur;
+  return TC_OK;
+}
+
 int check_predict_args(const tc_table* t, const void* theta, int n_theta,
                        int64_t n_draws, int n_gauss, unsigned flags) {
   TC_CHECK(t != nullptr, "table handle is NULL");

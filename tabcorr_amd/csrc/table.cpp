@@ -187,7 +187,10 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
     t->quad_tiling = quad_f32 ? quad_tiling_f32 : quad_tiling;
     status = build_quad_table(t.get(), true, tpcf_matrix, matrix_dtype, &t->quad_by_type);
     const int n_central = t->plan.n_central;
-    if (status == TC_OK && n_central % 4 != 0 && n_central < n_bins)
+    // (... and for every float64 table with a single r tile: predict_fused_kernel walks the
+    // whole triangle as one component)
+    const bool fusable = !quad_f32 && quad_tiling.n_rtiles == 1;
+    if (status == TC_OK && ((n_central % 4 != 0 && n_central < n_bins) || fusable))
       status = build_quad_table(t.get(), false, tpcf_matrix, matrix_dtype, &t->quad_total);
   }
   if (status != TC_OK) return status;
@@ -281,6 +284,12 @@ int tc_predict_zheng07_batch_device(tc_table* t, const double* theta_device,
   for (int64_t begin = 0; begin < n_draws; begin += slab) {
     const int64_t n = std::min(slab, n_draws - begin);
     const int64_t ldb = (n + 63) / 64 * 64;
+    if (fused_eligible(t, n, n_gauss, flags)) {
+      status = run_fused(t, theta_device + begin * n_theta, n_theta, n, n_gauss,
+                         ngal_device + begin, xi_device + begin * t->n_r);
+      if (status != TC_OK) return status;
+      continue;
+    }
     status = run_occupation(t, theta_device + begin * n_theta, n_theta, n, ldb,
                             n_gauss, flags, nullptr);
     if (status != TC_OK) return status;
@@ -798,6 +807,22 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     // (async_direct_out 2: only the number densities directly, xi by copy command)
     (key == "async_direct_in" ? t->tuning.async_direct_in : t->tuning.async_direct_out) =
         value;
+  } else if (key == "fused") {
+    // 0: always the three-kernel path; 1 (default): one launch per batch
+    // (predict_fused_kernel) for pipelined device-pointer and asynchronous calls of
+    // "fused_min_draws" .. "fused_max_draws" draws that it covers; 2: for every such call, also
+    // those that run alone
+    TC_CHECK(value >= 0 && value <= 2, "fused must be 0, 1 or 2");
+    t->tuning.fused = value;
+  } else if (key == "fused_min_draws" || key == "fused_max_draws") {
+    TC_CHECK(value >= 1, "%s must be positive", name);
+    (key == "fused_min_draws" ? t->tuning.fused_min_draws : t->tuning.fused_max_draws) = value;
+  } else if (key == "prio_fused") {
+    t->tuning.prio_fused = value & 3;
+  } else if (key == "prio_fused_occ") {
+    t->tuning.prio_fused_occ = value & 3;
+  } else if (key == "prio_fused_out") {
+    t->tuning.prio_fused_out = value & 3;
   } else if (key == "single_draw") {
     t->tuning.single_draw = value != 0;
   } else if (key == "poll_done") {

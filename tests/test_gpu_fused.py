@@ -1,0 +1,218 @@
+"""predict_fused_kernel (one launch per batch: occupation -> quadratic form -> results inside a
+workgroup) against the golden vectors, the oracle and the three-kernel path, through every
+entry point that may take it.  Needs an MI355X."""
+
+import numpy as np
+import pytest
+
+from util import load_golden, table_from_golden, assert_rel
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+def make_tabcorr(table, **kwargs):
+    from tabcorr_amd import TabCorr
+    return TabCorr.from_arrays(table['gal_type'], table['tpcf_matrix'],
+                               table['tpcf_shape'], table['attrs'], **kwargs)
+
+
+def set_option(halotab, name, value):
+    from tabcorr_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.tc_table_set_option(halotab.to_device().handle, name.encode(), value))
+
+
+def force_fused(halotab, on=True):
+    set_option(halotab, 'fused', 2 if on else 0)
+    set_option(halotab, 'fused_min_draws', 1)
+    set_option(halotab, 'single_draw', 0)      # (small batches: the batched path, not the
+                                               # one-launch path of un-batched calls)
+
+
+def last_launch(halotab):
+    """(workgroups, waves per workgroup, slabs, LDS bytes) of the last contraction launch."""
+    import ctypes
+    from tabcorr_amd import _lib
+    lib = _lib.load()
+    values = [ctypes.c_int() for _ in range(4)]
+    _lib.check(lib.tc_table_last_launch(halotab.to_device().handle, *[ctypes.byref(v) for v in values]))
+    return tuple(v.value for v in values)
+
+
+def test_fused_matches_golden():
+    data = load_golden('synthetic_cfg2')
+    table = table_from_golden(data)
+    halotab = make_tabcorr(table)
+    force_fused(halotab)
+    ngal, xi = halotab.predict_batch(data['theta'])
+    workgroups, waves, slabs, lds = last_launch(halotab)
+    assert waves == 8 and slabs == 0 and workgroups == (len(data['theta']) + 63) // 64
+    assert_rel(ngal, data['ngal'], RTOL, 'ngal')
+    assert_rel(xi, data['xi'], RTOL, 'xi')
+    # the three-kernel path gives the same to rounding
+    force_fused(halotab, False)
+    ngal3, xi3 = halotab.predict_batch(data['theta'])
+    assert last_launch(halotab)[2] > 0
+    assert_rel(ngal, ngal3, 1e-13)
+    assert_rel(xi, xi3, 1e-12)
+
+
+@pytest.mark.parametrize('n_prim, n_sec, n_r, n_gauss, n_draws', [
+    (7, 1, 1, 10, 1),          # 14 bins (padded to 16 rows), one r value, one draw
+    (5, 2, 3, 10, 63),         # 20 bins
+    (13, 1, 4, 10, 64),        # 26 bins -> 28 rows
+    (10, 1, 5, 7, 65),         # any n_gauss, two r sub-tiles
+    (25, 1, 9, 10, 200),
+    (12, 2, 13, 3, 129),
+    (50, 1, 19, 10, 1000),     # BASELINE configs[1]'s table
+    (33, 1, 20, 10, 333),
+    (60, 1, 17, 10, 150),      # 120 bins: 88 KB of LDS, one workgroup per CU
+    (3, 1, 2, 100, 40),
+])
+def test_fused_matches_oracle(n_prim, n_sec, n_r, n_gauss, n_draws):
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(n_prim, n_sec, (n_r, ), 'auto', seed=n_prim + n_r)
+    theta = synthetic.zheng07_draws(n_draws, seed=n_draws)
+    halotab = make_tabcorr(table)
+    force_fused(halotab)
+    ngal, xi = halotab.predict_batch(theta, n_gauss_prim=n_gauss)
+    assert last_launch(halotab)[1:3] == (8, 0), 'the fused kernel did not run'
+    expect = oracle.predict_zheng07_batch(table, theta, n_gauss_prim=n_gauss)
+    assert_rel(ngal, expect[0], RTOL, 'ngal')
+    assert_rel(xi, expect[1], RTOL, 'xi')
+
+
+def test_fused_likelihood_and_async():
+    from tabcorr_amd import pinned_array, pinned_empty, synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    halotab = make_tabcorr(table)
+    set_option(halotab, 'fused_min_draws', 1)       # fused = 1: pipelined calls only
+    set_option(halotab, 'single_draw', 0)
+    theta = pinned_array(synthetic.zheng07_draws(777, seed=3))
+    expect = oracle.predict_zheng07_batch(table, theta)
+    ngal, xi = pinned_empty(777), pinned_empty((777, 19))
+    got = halotab.predict_batch_async(theta, out=(ngal, xi)).wait()
+    assert last_launch(halotab)[1:3] == (8, 0), 'the fused kernel did not run'
+    assert_rel(got[0], expect[0], RTOL)
+    assert_rel(got[1], expect[1], RTOL)
+    rng = np.random.default_rng(0)
+    vector = expect[1][0] * 1.1
+    a = rng.normal(size=(19, 19))
+    precision = a @ a.T / np.mean(vector)**2
+    want = np.einsum('bi,ij,bj->b', expect[1] - vector, precision, expect[1] - vector)
+    n_chi, chi2 = halotab.chi2_batch_async(theta, vector, precision).wait()
+    assert last_launch(halotab)[1:3] == (8, 0)
+    assert_rel(n_chi, expect[0], RTOL)
+    assert_rel(chi2, want, 1e-9)
+    # the synchronous calls run alone on their lane: three kernels unless forced
+    sync = halotab.chi2_batch(theta, vector, precision)
+    assert last_launch(halotab)[2] > 0
+    assert_rel(sync[1], chi2, 1e-11)
+    force_fused(halotab)
+    forced = halotab.chi2_batch(theta, vector, precision)
+    assert last_launch(halotab)[1:3] == (8, 0)
+    assert_rel(forced[1], chi2, 1e-13)
+    # many calls in flight, different sizes
+    sizes = [64, 1, 300, 65, 2048, 127]
+    thetas = [pinned_array(synthetic.zheng07_draws(size, seed=70 + i))
+              for i, size in enumerate(sizes)]
+    outs = [(pinned_empty(size), pinned_empty((size, 19))) for size in sizes]
+    pending = [halotab.predict_batch_async(t, out=o) for t, o in zip(thetas, outs)]
+    for index in reversed(range(len(sizes))):
+        got = pending[index].wait()
+        want = oracle.predict_zheng07_batch(table, thetas[index][:5])
+        assert_rel(got[0][:5], want[0], RTOL)
+        assert_rel(got[1][:5], want[1], RTOL)
+        full = oracle.predict_zheng07_batch(table, thetas[index][-3:])
+        assert_rel(got[1][-3:], full[1], RTOL)
+
+
+def test_fused_degenerate_parameters():
+    """NaN / infinite / tied parameters: the same values (NaN for NaN) as the three-kernel path,
+    which test_gpu_full_size.py compares with the oracle."""
+    from tabcorr_amd import synthetic
+    table = synthetic.synthetic_table(20, 1, (6, ), 'auto', seed=2)
+    theta = synthetic.zheng07_draws(200, seed=5)
+    theta[3, 0] = np.nan
+    theta[10, 1] = 0.0
+    theta[11, 1] = np.inf
+    theta[20, 2] = np.nan
+    theta[30, 3] = np.nan
+    theta[40, 4] = np.nan
+    theta[50, 3] = -np.inf
+    theta[60, 2] = np.inf
+    theta[70, 0] = np.inf
+    theta[80, 0] = -np.inf
+    theta[90, 4] = 0.0
+    theta[100, 4] = -1.0
+    theta[110, 3] = -400.0
+    theta[120] = [11.0, 0.0, 11.0, 13.0, 1.0]
+    halotab = make_tabcorr(table)
+    force_fused(halotab, False)
+    with np.errstate(all='ignore'):
+        ngal3, xi3 = halotab.predict_batch(theta)
+        force_fused(halotab)
+        ngal, xi = halotab.predict_batch(theta)
+    assert last_launch(halotab)[1:3] == (8, 0)
+    assert np.array_equal(np.isnan(ngal), np.isnan(ngal3))
+    assert np.array_equal(np.isnan(xi), np.isnan(xi3))
+    assert np.array_equal(np.isinf(xi), np.isinf(xi3))
+    good = np.isfinite(xi3)
+    assert_rel(xi[good], xi3[good], 1e-12)
+    good = np.isfinite(ngal3)
+    assert_rel(ngal[good], ngal3[good], 1e-13)
+
+
+def test_fused_is_not_taken_where_it_does_not_apply():
+    from tabcorr_amd import synthetic
+    table = synthetic.synthetic_table(10, 2, (25, ), 'auto', seed=1)    # two r tiles
+    theta = synthetic.zheng07_draws(100, seed=1)
+    halotab = make_tabcorr(table)
+    force_fused(halotab)
+    halotab.predict_batch(theta)
+    assert last_launch(halotab)[2] > 0
+    table = synthetic.synthetic_table(10, 2, (5, ), 'auto', seed=1)
+    halotab = make_tabcorr(table)
+    force_fused(halotab)
+    halotab.predict_batch(theta)
+    assert last_launch(halotab)[1:3] == (8, 0)
+    halotab.predict_batch(theta, separate_gal_type=True)
+    assert last_launch(halotab)[2] > 0
+
+
+def test_fused_at_the_benchmarked_batch_size():
+    """10^4 draws of BASELINE configs[1] through the asynchronous entry points with default
+    options (the one-launch path is taken by itself), against the oracle on draws from both
+    ends and the middle of the batch and against the three-kernel path on all of them."""
+    from tabcorr_amd import pinned_array, pinned_empty, synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    n = 10000
+    theta = pinned_array(synthetic.zheng07_draws(n, seed=1))
+    halotab = make_tabcorr(table)
+    ngal, xi = pinned_empty(n), pinned_empty((n, 19))
+    pending = [halotab.predict_batch_async(theta, out=(ngal, xi)) for _ in range(3)]
+    for item in pending:
+        item.wait()
+    assert last_launch(halotab)[1:3] == (8, 0), 'the fused kernel did not run'
+    index = np.r_[0:40, 4990:5030, 9960:10000]
+    expect = oracle.predict_zheng07_batch(table, theta[index])
+    assert_rel(ngal[index], expect[0], RTOL)
+    assert_rel(xi[index], expect[1], RTOL)
+    ngal3, xi3 = halotab.predict_batch(theta)          # synchronous: three kernels
+    assert last_launch(halotab)[2] > 0
+    assert_rel(ngal, ngal3, 1e-13)
+    assert_rel(xi, xi3, 1e-12)
+    rng = np.random.default_rng(0)
+    vector = expect[1][0] * 1.1
+    a = rng.normal(size=(19, 19))
+    precision = a @ a.T / np.mean(vector)**2
+    want = np.einsum('bi,ij,bj->b', xi3 - vector, precision, xi3 - vector)
+    n_chi, chi2 = halotab.chi2_batch_async(theta, vector, precision).wait()
+    assert last_launch(halotab)[1:3] == (8, 0)
+    assert_rel(n_chi, ngal3, 1e-13)
+    assert_rel(chi2, want, 1e-9)
