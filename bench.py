@@ -472,9 +472,24 @@ def main():
     drain()
     # (the serialised pass ran before the timed region, see above) ... and stretched by the
     # kernels of neighbouring batches in the overlapped regime of the timed region
-    overlapped_ms, _, _ = kernel_time(lib, _lib, timer_handle, lambda: predict(0), synchronize)
+    overlapped_ms, _, overlapped_wall_ms = kernel_time(
+        lib, _lib, timer_handle, lambda: predict(0), synchronize)
     launch = [ctypes.c_int() for _ in range(4)]
     lib.tc_table_last_launch(timer_handle, *[ctypes.byref(v) for v in launch])
+    # One launch per step (predict_fused_kernel: occupation -> quadratic form -> results inside a
+    # workgroup) when the library chose it for this batch size: the dominant kernel of the timed
+    # region is then that one, and its launches overlap by design (one per lane).  Also timed:
+    # the same kernel alone on the chip.
+    fused_active = not interp_mode and launch[1].value == 8 and launch[2].value == 0
+    fused_alone_ms = None
+    if fused_active:
+        user_fused = dict(o.split('=') for o in args.option).get('fused', '1')
+        _lib.check(lib.tc_table_set_option(timer_handle, b'pipeline', 0))
+        _lib.check(lib.tc_table_set_option(timer_handle, b'fused', 2))
+        fused_alone_ms, _, _ = kernel_time(lib, _lib, timer_handle, lambda: predict(0),
+                                           synchronize, n_launches=300, max_seconds=0.3)
+        _lib.check(lib.tc_table_set_option(timer_handle, b'fused', int(user_fused)))
+        _lib.check(lib.tc_table_set_option(timer_handle, b'pipeline', 1))
 
     result = None
     if comm.is_root:
@@ -507,13 +522,21 @@ def main():
                 parity = float(max(np.max(np.abs(host[:4] / expect[0] - 1)),
                                    np.max(np.abs(xi[:4] / expect[1] - 1))))
 
-        kernel_name = ('tc::contract_quad_kernel<5, true>' if interp_mode
-                       else 'tc::contract_quad_kernel<5, false>')
+        three_kernel_name = ('tc::contract_quad_kernel<5, true>' if interp_mode
+                             else 'tc::contract_quad_kernel<5, false>')
+        kernel_name = 'tc::predict_fused_kernel<10, 5>' if fused_active else three_kernel_name
         headline_traffic = (pmc_traffic(kernel_name, 'interp5x5' if interp_mode else '')
                             if n_draws == (100000 if interp_mode else 10000) // (
                                 comm.world_size if interp_mode else 1)
                             else (None, None))
-        achieved = flop_contract / (isolated_ms * 1e-3) / 1e12
+        if fused_active:
+            # launches of different lanes share the chip: a launch's share of it is its
+            # duration divided by the mean number of launches running at once
+            concurrency = overlapped_ms / overlapped_wall_ms
+            achieved = flop_contract / (overlapped_ms / concurrency * 1e-3) / 1e12
+        else:
+            concurrency = None
+            achieved = flop_contract / (isolated_ms * 1e-3) / 1e12
         total_draws = comm.world_size * n_draws * args.steps
         if interp_mode:
             workload = ('BASELINE configs[3]: Interpolator.predict() over a 5 x 5 grid of '
@@ -573,15 +596,37 @@ def main():
                                   'the gfx950 correction)' % headline_traffic[1]
                                   if headline_traffic[1] else None,
                 'flop_per_launch': flop_contract,
-                'mean_launch_ms': isolated_ms,
+                'mean_launch_ms': overlapped_ms if fused_active else isolated_ms,
+                'concurrent_launches': concurrency,
                 'launches_timed': n_launch,
-                'method': 'before the timed region: kernels serialised (pipeline off), '
+                'method': ('after the timed region, same stream of calls: %d launches with '
+                           'hipExtLaunchKernelGGL start/stop events; one launch per step and '
+                           'lane, the launches of the %d lanes overlap (that is the design: a '
+                           'workgroup carries 64 draws from theta to the results, workgroups '
+                           'of different launches share a CU), so achieved = flop_per_launch '
+                           '/ (mean_launch_ms / concurrent_launches), concurrent_launches = '
+                           'mean_launch_ms / wall time per launch' % (n_launch, lanes_used))
+                          if fused_active else
+                          'before the timed region: kernels serialised (pipeline off), '
                           '>= 150 ms of load, then %d launches with hipExtLaunchKernelGGL '
                           'start/stop events' % n_launch,
-                'serialised_step_ms': serial_step_ms,
-                'overlapped_launch_ms': overlapped_ms,
-                'overlapped_frac': flop_contract / (overlapped_ms * 1e-3) / 1e12 /
-                                   FP64_PEAK_TFLOPS,
+                'alone': {
+                    'mean_launch_ms': fused_alone_ms,
+                    'frac': flop_contract / (fused_alone_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                    'note': 'the same kernel with nothing else on the chip (pipeline off): '
+                            '%d workgroups, one per CU on %d of the 256 CUs, the occupation '
+                            'phase not overlapped by a neighbour\'s matrix phase -- not how it '
+                            'is used; calls that run alone (synchronous host API) keep the '
+                            'three kernels' % (launch[0].value, min(256, launch[0].value))}
+                if fused_active else None,
+                'three_kernel_path': {
+                    'kernel': three_kernel_name,
+                    'mean_launch_ms': isolated_ms,
+                    'frac': flop_contract / (isolated_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                    'serialised_step_ms': serial_step_ms,
+                    'note': 'contraction kernel of the three-kernel path (option fused=0, and '
+                            'every call that runs alone on its lane), kernels serialised, '
+                            'measured before the timed region'},
                 'step_frac': flop_contract / (elapsed / args.steps) / 1e12 / FP64_PEAK_TFLOPS,
                 'workgroups': launch[0].value,
                 'waves_per_workgroup': launch[1].value,

@@ -50,9 +50,15 @@ if [ $WHAT = main ] || [ $WHAT = all ]; then
   for i in 1 2 3; do
     python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 >> $OUT/bench_driver_command.json
   done
+  # --lanes 1: every call alone on its lane = the three-kernel path, kernels serialised;
+  # default lanes: predict_fused_kernel, one launch per step, four launches overlapping;
+  # fused=2 with one lane: that kernel alone on the chip
   kernel_stats kernel_stats_lanes1 --lanes 1 --steps 2000 --warmup 200 $FAST
   kernel_stats kernel_stats_pipelined --steps 2000 --warmup 200 $FAST
-  pmc_passes pmc_summary --lanes 1 --steps 50 --warmup 5 $FAST
+  kernel_stats kernel_stats_fused_alone --lanes 1 --option fused=2 --steps 2000 --warmup 200 $FAST
+  # (default lanes: the profiler serialises the dispatches itself; the timed region then runs
+  # predict_fused_kernel, bench.py's serialised pass the three kernels -- both are counted)
+  pmc_passes pmc_summary --steps 50 --warmup 5 $FAST
 fi
 if [ $WHAT = configs ] || [ $WHAT = all ]; then
   for tag in cfg3 cfg4 cfg5f32 cfg5f64; do
