@@ -433,7 +433,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
 bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags);
 int fused_lds_bytes(const tc_table* t);
 int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_draws, int n_gauss,
-              double* ngal_device, double* xi_device);
+              unsigned flags, double* ngal_device, double* xi_device);
 int check_predict_args(const tc_table* t, const void* theta, int n_theta, int64_t n_draws,
                        int n_gauss, unsigned flags);
 int launch_finalize(const FinalizeArgs& args, const Tuning& tuning, hipStream_t stream);

@@ -216,6 +216,8 @@ struct FusedArgs {
   const double* m;
   const double* weight;
   const double* n_h;
+  const double* percentile;  // (n_bins) sec_haloprop_percentile (assembly bias)
+  double split;
   const double* math_table;
   const void* table;         // re-laid-out matrix of the whole triangle (one r tile)
   uint32_t table_bytes;

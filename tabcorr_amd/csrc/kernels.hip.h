@@ -1362,7 +1362,8 @@ __global__ __launch_bounds__(1024) void finalize_quad_kernel(FinalizeQuadArgs a)
 //   3. adds the four quarters through LDS, normalises and writes ngal, xi (or the likelihood).
 // Workgroups of different launches share a CU, so one's occupation phase (vector ALU) runs
 // under the other's matrix instructions; there is no inter-workgroup step.
-// Mode auto, total correlation function, one r tile, plain Zheng07.
+// Mode auto, total correlation function, one r tile, the Zheng07 family (with its Heaviside
+// assembly bias / modulate_with_cenocc variants).
 constexpr int kFusedSlotDoubles = kFusedWaves * 4 * kQuadMaxU * kQuadTile;   // phase 3
 constexpr int kFusedScratchDoubles = fm::kTableDoubles + 2 * kFusedWaves * kLanes;
 static_assert(kFusedWaves == 8, "two 32-draw tiles x four quarters of the triangle");
@@ -1446,7 +1447,7 @@ __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, uns
   }
 }
 
-template <int NGAUSS, int U>
+template <int NGAUSS, int U, bool ASSEMBIAS, bool MODULATE>
 __global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(FusedArgs a) {
   constexpr int UP = (U + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) double fused_lds[];
@@ -1482,7 +1483,8 @@ __global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(Fuse
   {
     // (every wave sets up its lanes' draws itself: cheaper than a hand-over through LDS)
     const double* th = a.theta + b * a.n_theta;
-    const DrawSetup d = prepare_draw(table, kc, th[0], th[1], th[2], th[3], th[4], 0.0, 0.0);
+    const DrawSetup d = prepare_draw(table, kc, th[0], th[1], th[2], th[3], th[4],
+                                     ASSEMBIAS ? th[5] : 0.0, ASSEMBIAS ? th[6] : 0.0);
     DrawParams dp;
     dp.log_m_min = d.log_m_min;
     dp.inv_sigma = d.inv_sigma;
@@ -1490,18 +1492,22 @@ __global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(Fuse
     dp.log2_m1 = d.log2_m1;
     dp.sat_scale = d.sat_scale;
     dp.alpha = d.alpha;
-    dp.a_cen = dp.a_sat = 0.0;
+    dp.a_cen = d.a_cen;
+    dp.a_sat = d.a_sat;
     dp.bad = d.bad;
     dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
     sc_f64 log_m = (sc_f64)a.log_m;
     sc_f64 mass = (sc_f64)a.m;
     sc_f64 weight = (sc_f64)a.weight;
     sc_f64 n_h = (sc_f64)a.n_h;
+    sc_f64 percentile = (sc_f64)a.percentile;
+    const double f1 = (1.0 - a.split) / a.split, f2 = a.split / (1.0 - a.split);
     double sum_cen = 0.0, sum_sat = 0.0;
     for (int g = wave; g < a.n_bins; g += kFusedWaves) {
       const bool central = g < a.n_central;
-      const double acc = occ_bin_zheng07<NGAUSS, false, false>(
-          table, kc, g, n_gauss, central, false, log_m, mass, weight, dp, 1.0, 1.0);
+      const bool above = ASSEMBIAS ? percentile[g] > a.split : false;
+      const double acc = occ_bin_zheng07<NGAUSS, ASSEMBIAS, MODULATE>(
+          table, kc, g, n_gauss, central, above, log_m, mass, weight, dp, f1, f2);
       const double value = acc * n_h[g];
       dens[g * kLanes + lane] = value;
       if (central) sum_cen += value; else sum_sat += value;

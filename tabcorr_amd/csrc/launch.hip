@@ -887,9 +887,9 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
   if (!t->quad || t->compute_dtype != TC_DTYPE_F64 || t->quad_total.d_table == nullptr)
     return false;
   if (t->quad_tiling.n_rtiles != 1 || t->n_r > 20 || t->chain || t->tuning.trace) return false;
-  if (flags & (TC_FLAG_SEPARATE_GAL_TYPE | TC_FLAG_ASSEMBIAS | TC_FLAG_MODULATE_WITH_CENOCC |
-               TC_FLAG_LEAUTHAUD11))
-    return false;
+  if (flags & (TC_FLAG_SEPARATE_GAL_TYPE | TC_FLAG_LEAUTHAUD11)) return false;
+  // (the decorated variants are compiled for the reference's default n_gauss_prim only)
+  if ((flags & (TC_FLAG_ASSEMBIAS | TC_FLAG_MODULATE_WITH_CENOCC)) && n_gauss != 10) return false;
   if (t->quad_total.layout.comps.size() != 1 || !t->quad_total.layout.comps[0].triangular)
     return false;
   if (fused_lds_bytes(t) > 160 * 1024 || n_gauss < 1) return false;
@@ -904,8 +904,35 @@ int fused_lds_bytes(const tc_table* t) {
   return (std::max(dens_rows * 64, tc::kFusedSlotDoubles) + tc::kFusedScratchDoubles) * 8;
 }
 
+namespace {
+template <int NG, bool AB, bool MO>
+int launch_fused(int n_u, dim3 grid, dim3 block, int lds, hipStream_t stream, hipEvent_t k0,
+                 hipEvent_t k1, const tc::FusedArgs& fa) {
+  switch (n_u) {
+#define TC_CASE(N)                                                                            \
+  case N: {                                                                                   \
+    static bool limit_set = false;                                                            \
+    if (lds > 64 * 1024 && !limit_set) {                                                      \
+      TC_HIP(hipFuncSetAttribute((const void*)tc::predict_fused_kernel<NG, N, AB, MO>,        \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));    \
+      limit_set = true;                                                                       \
+    }                                                                                         \
+    hipExtLaunchKernelGGL((tc::predict_fused_kernel<NG, N, AB, MO>), grid, block, lds,        \
+                          stream, k0, k1, 0, fa);                                             \
+    break;                                                                                    \
+  }
+    TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4) TC_CASE(5)
+#undef TC_CASE
+    default:
+      return fail(TC_ERR_UNSUPPORTED, "no fused kernel for %d r sub-tiles", n_u);
+  }
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+}  // namespace
+
 int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_draws,
-              int n_gauss, double* ngal_device, double* xi_device) {
+              int n_gauss, unsigned flags, double* ngal_device, double* xi_device) {
   Range range("occupation + contraction + finalisation (one launch)");
   tc_table::Lane& lane = t->lanes[t->cur];
   hipStream_t stream = lane.stream;
@@ -937,6 +964,8 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   fa.m = (const double*)q->m;
   fa.weight = (const double*)q->weight;
   fa.n_h = (const double*)t->d_n_h;
+  fa.percentile = (const double*)t->d_percentile;
+  fa.split = 0.5;
   fa.math_table = (const double*)t->d_math_table;
   fa.table = (const char*)t->quad_total.d_table + (size_t)comp.unit_base *
                  (size_t)((t->quad_tiling.n_u + 1) / 2) * 1024;
@@ -955,35 +984,19 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   hipEvent_t k0 = nullptr, k1 = nullptr;
   status = next_kernel_events(t, &k0, &k1);
   if (status != TC_OK) return status;
-  switch (t->quad_tiling.n_u) {
-#define TC_CASE(N)                                                                           \
-  case N: {                                                                                  \
-    static bool limit_set_10 = false, limit_set_0 = false;                                   \
-    if (n_gauss == 10) {                                                                     \
-      if (lds > 64 * 1024 && !limit_set_10) {                                                \
-        TC_HIP(hipFuncSetAttribute((const void*)tc::predict_fused_kernel<10, N>,             \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        limit_set_10 = true;                                                                 \
-      }                                                                                      \
-      hipExtLaunchKernelGGL((tc::predict_fused_kernel<10, N>), grid, block, lds, stream, k0, \
-                            k1, 0, fa);                                                      \
-    } else {                                                                                 \
-      if (lds > 64 * 1024 && !limit_set_0) {                                                 \
-        TC_HIP(hipFuncSetAttribute((const void*)tc::predict_fused_kernel<0, N>,              \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        limit_set_0 = true;                                                                  \
-      }                                                                                      \
-      hipExtLaunchKernelGGL((tc::predict_fused_kernel<0, N>), grid, block, lds, stream, k0,  \
-                            k1, 0, fa);                                                      \
-    }                                                                                        \
-    break;                                                                                   \
-  }
-    TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4) TC_CASE(5)
-#undef TC_CASE
-    default:
-      return fail(TC_ERR_UNSUPPORTED, "no fused kernel for %d r sub-tiles", t->quad_tiling.n_u);
-  }
-  TC_HIP(hipGetLastError());
+  const bool assembias = (flags & TC_FLAG_ASSEMBIAS) != 0;
+  const bool modulate = (flags & TC_FLAG_MODULATE_WITH_CENOCC) != 0;
+  if (n_gauss != 10)
+    status = launch_fused<0, false, false>(t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+  else if (!assembias && !modulate)
+    status = launch_fused<10, false, false>(t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+  else if (!assembias)
+    status = launch_fused<10, false, true>(t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+  else if (!modulate)
+    status = launch_fused<10, true, false>(t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+  else
+    status = launch_fused<10, true, true>(t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+  if (status != TC_OK) return status;
   t->last_workgroups = (int)grid.x;
   t->last_waves = tc::kFusedWaves;
   t->last_splits = 0;

@@ -216,3 +216,29 @@ def test_fused_at_the_benchmarked_batch_size():
     assert last_launch(halotab)[1:3] == (8, 0)
     assert_rel(n_chi, ngal3, 1e-13)
     assert_rel(chi2, want, 1e-9)
+
+
+@pytest.mark.parametrize('modulate, assembias', [(True, False), (False, True), (True, True)])
+def test_fused_decorated_variants(modulate, assembias):
+    """modulate_with_cenocc / Heaviside assembly bias (two percentile bins, strengths beyond
+    [-1, 1] clipped) through the one-launch path, against the oracle."""
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    rng = np.random.default_rng(11)
+    table = synthetic.synthetic_table(11, 2, (9, ), 'auto', seed=21)
+    n_draws = 150
+    theta = synthetic.zheng07_draws(n_draws, seed=8)
+    strengths = rng.uniform(-1.2, 1.2, (n_draws, 2))
+    expect = oracle.predict_zheng07_batch(table, theta, modulate_with_cenocc=modulate,
+                                          assembias=strengths if assembias else None)
+    batch = np.hstack([theta, strengths]) if assembias else theta
+    halotab = make_tabcorr(table)
+    force_fused(halotab)
+    ngal, xi = halotab.predict_batch(batch, modulate_with_cenocc=modulate, assembias=assembias)
+    assert last_launch(halotab)[1:3] == (8, 0), 'the fused kernel did not run'
+    assert_rel(ngal, expect[0], RTOL, 'ngal')
+    assert_rel(xi, expect[1], RTOL, 'xi')
+    # any other n_gauss_prim: the three kernels serve the decorated variants
+    halotab.predict_batch(batch, modulate_with_cenocc=modulate, assembias=assembias,
+                          n_gauss_prim=7)
+    assert last_launch(halotab)[2] > 0
