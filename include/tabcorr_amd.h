@@ -261,9 +261,8 @@ int tc_interp_chi2_zheng07_batch_device(tc_interp* interp, const double* theta_d
                                         double* chi2_device);
 
 /* Asynchronous host-to-host forms (page-locked theta, x, outputs; see
- * tc_predict_zheng07_batch_async): upload and kernels on the interpolator's stream, the
- * download of call k on a second stream behind it, overlapping the kernels of call k + 1
- * (results double-buffered on the device). */
+ * tc_predict_zheng07_batch_async): upload, kernels and download of a call on one of the
+ * interpolator's two lanes (stream + workspaces), consecutive calls alternating between them. */
 int tc_interp_predict_zheng07_batch_async(tc_interp* interp, const double* theta_pinned,
                                           int n_theta, const double* x_pinned, int64_t n_draws,
                                           int n_gauss_prim, unsigned flags, double* ngal_pinned,
@@ -285,6 +284,12 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 tc_table_synchronize (or gather with tc_comm_gather, which waits for every
  *                 lane); 1: their finalisations are chained so that results appear in call
  *                 order (0.3 - 3 us per 10^4-draw step).
+ *   "fused"       1 (default): pipelined device-pointer and asynchronous calls of
+ *                 "fused_min_draws" .. "fused_max_draws" draws (6144 .. 32768) that qualify
+ *                 (mode auto, total correlation function, at most 20 r values, Zheng07 family)
+ *                 run as ONE launch per batch, a workgroup carrying 64 draws from the
+ *                 parameters to the results; 0: always occupation, contraction, finalisation
+ *                 kernels; 2: one launch also for calls that run alone on their lane.
  *   "single_draw" 1 (default): an un-batched predict() goes through one launch.
  *   "trace"       developer timelines (developer builds only, tabcorr_amd_testing.h). */
 int tc_table_set_option(tc_table* table, const char* name, int value);
