@@ -969,7 +969,7 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   fa.math_table = (const double*)t->d_math_table;
   fa.table = (const char*)t->quad_total.d_table + (size_t)comp.unit_base *
                  (size_t)((t->quad_tiling.n_u + 1) / 2) * 1024;
-  fa.table_bytes = (uint32_t)t->quad_total.rtile_bytes;
+  fa.table_bytes = (uint32_t)((size_t)comp.n_units * (size_t)((t->quad_tiling.n_u + 1) / 2) * 1024);
   fa.ngal = ngal_device;
   fa.xi = xi_device;
   t->chi2_fused = false;
