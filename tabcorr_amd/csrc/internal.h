@@ -256,9 +256,10 @@ struct Tuning {
   // 40000 151.8 / 156.3 -- both designs approach the same 38 us per 10^4 draws for huge
   // batches (matrix + vector instructions on one FP64 pipe); the one-launch form gets there
   // with the batch sizes an ensemble sampler has, the three kernels spread small batches
-  // over the whole chip.
+  // over the whole chip.  Asynchronous host calls (us per call, tools/r03_async.py): 6144 draws
+  // 38.8 / 41.6, 10^4 58 / 47.6, 20 000 93.7 / 82.6, 40 000 176 / 162: no upper bound there.
   int fused = 1;
-  int fused_min_draws = 6144;
+  int fused_min_draws = 8192;
   int fused_max_draws = 32768;
   int prio_fused = 1, prio_fused_occ = 2, prio_fused_out = 3;   // phases 2, 1, 3
   int skip_occ = 0, skip_finalize = 0;   // diagnosis (developer builds only)
