@@ -84,6 +84,32 @@ def pmc_file(tag):
     return files[-1] if files else None
 
 
+def matrix_pipe_busy(kernel, step_seconds, simds=1024, clock_hz=2.4e9):
+    """Share of the timed region in which a SIMD's matrix pipe was busy: the counter
+    SQ_VALU_MFMA_BUSY_CYCLES per launch of `kernel` (committed PMC passes) over the SIMD cycles
+    of one step at the nominal clock (one launch per step)."""
+    cycles = pmc_counter(kernel, 'SQ_VALU_MFMA_BUSY_CYCLES')
+    if cycles is None:
+        return None
+    return {'value': cycles / (simds * step_seconds * clock_hz),
+            'what': 'SQ_VALU_MFMA_BUSY_CYCLES per launch (%s) / (%d SIMDs x step time x %.1f GHz)'
+                    % (os.path.relpath(pmc_file(''), REPO), simds, clock_hz * 1e-9)}
+
+
+def pmc_counter(kernel, counter, tag=''):
+    """Mean of one raw counter per launch of `kernel` from the committed rocprofv3 --pmc passes
+    of configuration `tag`, or None."""
+    path = pmc_file(tag)
+    if path is None:
+        return None
+    prefix = kernel[:40]
+    for line in open(path).read().splitlines():
+        match = re.match(r'(.*?)\s+(\w+)\s+n=\s*\d+\s+mean=([0-9.e+]+)', line)
+        if match and match.group(2) == counter and prefix in match.group(1).replace('void ', ''):
+            return float(match.group(3))
+    return None
+
+
 def pmc_traffic(kernel, tag=''):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of
     configuration `tag` (FETCH_SIZE and WRITE_SIZE in KB; FETCH_SIZE doubled per the gfx950
@@ -628,6 +654,8 @@ def main():
                             'every call that runs alone on its lane), kernels serialised, '
                             'measured before the timed region'},
                 'step_frac': flop_contract / (elapsed / args.steps) / 1e12 / FP64_PEAK_TFLOPS,
+                'matrix_pipe_busy': matrix_pipe_busy(kernel_name, elapsed / args.steps)
+                                    if fused_active else None,
                 'workgroups': launch[0].value,
                 'waves_per_workgroup': launch[1].value,
                 'lds_bytes': launch[3].value,
