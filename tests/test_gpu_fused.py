@@ -242,3 +242,24 @@ def test_fused_decorated_variants(modulate, assembias):
     halotab.predict_batch(batch, modulate_with_cenocc=modulate, assembias=assembias,
                           n_gauss_prim=7)
     assert last_launch(halotab)[2] > 0
+
+
+def test_a_draws_result_does_not_depend_on_its_place_in_the_batch():
+    """Size-independent property at the benchmarked size: reversing / re-batching 10^4 draws
+    permutes the results bit for bit (every lane does the same arithmetic whatever tile it
+    sits in; the split of the triangle over the waves is fixed)."""
+    from tabcorr_amd import pinned_array, synthetic
+    table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    n = 10000
+    theta = synthetic.zheng07_draws(n, seed=21)
+    halotab = make_tabcorr(table)
+    force_fused(halotab)
+    ngal, xi = halotab.predict_batch(theta)
+    assert last_launch(halotab)[1:3] == (8, 0)
+    ngal_r, xi_r = halotab.predict_batch(theta[::-1].copy())
+    assert np.array_equal(ngal_r[::-1], ngal)
+    assert np.array_equal(xi_r[::-1], xi)
+    # a batch of another size, other neighbours in the tile
+    ngal_p, xi_p = halotab.predict_batch(theta[3000:3777])
+    assert np.array_equal(ngal_p, ngal[3000:3777])
+    assert np.array_equal(xi_p, xi[3000:3777])
