@@ -105,11 +105,26 @@ __device__ inline double min_image(double d, double box, double half) {
 // counts if s_bins[0]^2 <= s^2 < s_bins[-1]^2 and mu < 1, its mu bin is int(mu n_mu) with
 // mu = |dz| / sqrt(s^2) (correctly rounded square root and division, as NumPy's); s = 0
 // (i == j with s_bins[0] == 0) goes to mu bin 0.
+// Candidates that pass the distance cuts are COMPACTED before they are binned: with one point
+// i per lane and the same point j for all lanes, ~15 % of the lanes pass a test, but a wave
+// pays for the r_p bin search and the histogram update whenever any lane does.  So the passing
+// lanes append (r^2, |dz|) to a queue of their wave in LDS (ballot + mbcnt), and whenever 64
+// entries are there the wave bins 64 real pairs at once: the search and the atomics run at full
+// lane occupancy, ~7 tests per binning pass.  Neighbour cells that do not wrap around the box
+// skip the minimum image (uniform per cell pair; with at least seven cells per dimension the
+// separations inside the 5 x 5 x 5 neighbourhood stay below half the box, so the oracle's
+// conditional shifts never fire there).  Counters are integers: the order does not matter.
+// (Point j through scalar loads instead of the LDS tiles -- the labelled kernel's way for its
+// block-1 points -- is slower here: 122 against 101 ms for 10^6 points.)
 template <bool SMU>
 __global__ __launch_bounds__(kPairThreads) void pair_count_kernel(PairArgs a) {
   __shared__ double sx[kPairThreads], sy[kPairThreads], sz[kPairThreads];
+  __shared__ double queue_r[kPairThreads / 64][128], queue_z[kPairThreads / 64][128];
   extern __shared__ unsigned hist[];   // n_rp * n_pi counters
   const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  double* qr = queue_r[tid >> 6];
+  double* qz = queue_z[tid >> 6];
   const int n_hist = a.n_rp * a.n_pi;
   for (int k = tid; k < n_hist; k += kPairThreads) hist[k] = 0u;
 
@@ -124,13 +139,76 @@ __global__ __launch_bounds__(kPairThreads) void pair_count_kernel(PairArgs a) {
   const double lo_sqr = a.edge_sqr[0], hi_sqr = a.edge_sqr[a.n_rp];
   __syncthreads();
 
+  // bins the first n entries of the wave's queue (n <= 64)
+  auto bin_entries = [&](int n) {
+    if (lane < n) {
+      const double r_sqr = qr[lane], dz = qz[lane];
+      int bin = 0;
+      for (int k = 1; k < a.n_rp; ++k) bin += r_sqr >= a.edge_sqr[k] ? 1 : 0;
+      if (SMU) {
+        const double mu = r_sqr > 0.0 ? __ddiv_rn(dz, __dsqrt_rn(r_sqr)) : 0.0;
+        const int mu_bin = (int)(mu * a.inv_dpi);
+        if (mu < 1.0 && mu_bin < a.n_pi) atomicAdd(&hist[bin * a.n_pi + mu_bin], 1u);
+      } else {
+        const int pi_bin = (int)(dz * a.inv_dpi);
+        if (pi_bin < a.n_pi) atomicAdd(&hist[bin * a.n_pi + pi_bin], 1u);
+      }
+    }
+  };
+  int queued = 0;      // entries in the wave's queue (uniform over the wave)
+
   for (int ox = -a.reach_x; ox <= a.reach_x; ++ox)
     for (int oy = -a.reach_y; oy <= a.reach_y; ++oy)
       for (int oz = -a.reach_z; oz <= a.reach_z; ++oz) {
         const int nxc = (cx + ox + a.nx) % a.nx, nyc = (cy + oy + a.ny) % a.ny;
         const int nzc = (cz + oz + a.nz) % a.nz;
         const int other = (nxc * a.ny + nyc) * a.nz + nzc;
+        const bool wrap_x = a.nx < 7 || cx + ox < 0 || cx + ox >= a.nx;
+        const bool wrap_y = a.ny < 7 || cy + oy < 0 || cy + oy >= a.ny;
+        const bool wrap_z = a.nz < 7 || cz + oz < 0 || cz + oz >= a.nz;
         const int j_begin = a.cell_start2[other], j_end = a.cell_start2[other + 1];
+        auto test = [&](double xj, double yj, double zj, bool in_range) {
+          double dz = zi - zj;
+          if (wrap_z) dz = min_image(dz, a.lz, hz);
+          dz = fabs(dz);
+          bool pass = active && in_range && dz < a.pi_max;
+          if (__builtin_amdgcn_ballot_w64(pass) == 0) return;
+          double dx = xi - xj, dy = yi - yj;
+          if (wrap_x) dx = min_image(dx, a.lx, hx);
+          if (wrap_y) dy = min_image(dy, a.ly, hy);
+          // (separately rounded products and sums: the oracle's arithmetic)
+          double r_sqr = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+          if (SMU) r_sqr = __dadd_rn(r_sqr, __dmul_rn(dz, dz));
+          pass = pass && r_sqr >= lo_sqr && r_sqr < hi_sqr;
+          const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+          if (mask == 0) return;
+          if (pass) {
+            const int slot =
+                queued + (int)__builtin_amdgcn_mbcnt_hi(
+                             (unsigned)(mask >> 32),
+                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            qr[slot] = r_sqr;
+            qz[slot] = dz;
+          }
+          queued += __builtin_popcountll(mask);
+          if (queued >= 64) {
+            __builtin_amdgcn_wave_barrier();
+            bin_entries(64);
+            // the rest (fewer than 64 entries) moves to the front
+            queued -= 64;
+            double rest_r = 0.0, rest_z = 0.0;
+            if (lane < queued) {
+              rest_r = qr[64 + lane];
+              rest_z = qz[64 + lane];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < queued) {
+              qr[lane] = rest_r;
+              qz[lane] = rest_z;
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        };
         for (int j0 = j_begin; j0 < j_end; j0 += kPairThreads) {
           const int n_tile = j_end - j0 < kPairThreads ? j_end - j0 : kPairThreads;
           __syncthreads();
@@ -140,30 +218,11 @@ __global__ __launch_bounds__(kPairThreads) void pair_count_kernel(PairArgs a) {
             sz[tid] = a.z2[j0 + tid];
           }
           __syncthreads();
-          if (!active) continue;
-          for (int t = 0; t < n_tile; ++t) {
-            const double dz = fabs(min_image(zi - sz[t], a.lz, hz));
-            if (!(dz < a.pi_max)) continue;
-            const double dx = min_image(xi - sx[t], a.lx, hx);
-            const double dy = min_image(yi - sy[t], a.ly, hy);
-            // (separately rounded products and sums: the oracle's arithmetic)
-            double r_sqr = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
-            if (SMU) r_sqr = __dadd_rn(r_sqr, __dmul_rn(dz, dz));
-            if (!(r_sqr >= lo_sqr && r_sqr < hi_sqr)) continue;
-            int bin = 0;
-            for (int k = 1; k < a.n_rp; ++k) bin += r_sqr >= a.edge_sqr[k] ? 1 : 0;
-            if (SMU) {
-              const double mu = r_sqr > 0.0 ? __ddiv_rn(dz, __dsqrt_rn(r_sqr)) : 0.0;
-              const int mu_bin = (int)(mu * a.inv_dpi);
-              if (!(mu < 1.0 && mu_bin < a.n_pi)) continue;
-              atomicAdd(&hist[bin * a.n_pi + mu_bin], 1u);
-            } else {
-              const int pi_bin = (int)(dz * a.inv_dpi);
-              if (pi_bin < a.n_pi) atomicAdd(&hist[bin * a.n_pi + pi_bin], 1u);
-            }
-          }
+          for (int t = 0; t < n_tile; ++t) test(sx[t], sy[t], sz[t], true);
         }
       }
+  __builtin_amdgcn_wave_barrier();
+  bin_entries(queued);
   __syncthreads();
   for (int k = tid; k < n_hist; k += kPairThreads) {
     const unsigned value = hist[k];
@@ -197,6 +256,32 @@ __global__ __launch_bounds__(kPairThreads) void pair_count_blocks_kernel(
   const double hx = 0.5 * a.lx, hy = 0.5 * a.ly, hz = 0.5 * a.lz;
   const double lo_sqr = a.edge_sqr[0], hi_sqr = a.edge_sqr[a.n_rp];
 
+  // passing pairs wait in a queue of their wave and are binned 64 at a time (see
+  // pair_count_kernel): (r^2 [, |dz|], (label 1 in block) * block2 + label 2 in block)
+  __shared__ double queue_r[kPairThreads / 64][128];
+  __shared__ double queue_z[SMU ? kPairThreads / 64 : 1][128];
+  __shared__ int32_t queue_c[kPairThreads / 64][128];
+  const int lane = tid & 63;
+  double* qr = queue_r[tid >> 6];
+  double* qz = queue_z[SMU ? tid >> 6 : 0];
+  int32_t* qc = queue_c[tid >> 6];
+  int queued = 0;      // (uniform over the wave)
+  auto bin_entries = [&](int n) {
+    if (lane < n) {
+      const double r_sqr = qr[lane];
+      int bin = 0;
+      for (int e = 1; e < a.n_rp; ++e) bin += r_sqr >= a.edge_sqr[e] ? 1 : 0;
+      bool counts = true;
+      if (SMU) {
+        const double dz = qz[lane];
+        const double mu = r_sqr > 0.0 ? __ddiv_rn(dz, __dsqrt_rn(r_sqr)) : 0.0;
+        const int mu_bin = (int)(mu * a.inv_dpi);
+        counts = mu < 1.0 && mu_bin < a.n_pi;
+        bin = bin * a.n_pi + mu_bin;
+      }
+      if (counts) atomicAdd(&hist[bin * a.block1 * a.block2 + qc[lane]], 1u);
+    }
+  };
   auto flush = [&]() {
     __syncthreads();
     for (int k = tid; k < n_hist; k += kPairThreads) {
@@ -258,8 +343,9 @@ __global__ __launch_bounds__(kPairThreads) void pair_count_blocks_kernel(
       pending = (unsigned long long)(p_end - p_begin) * (unsigned long long)total;
     }
     for (int g0 = 0; g0 < total; g0 += kPairThreads) {
-      const int g = g0 + tid;
-      if (g >= total) continue;
+      // (no lane leaves the loop early: the wave's queue is drained by all of its lanes)
+      const bool valid = g0 + tid < total;
+      const int g = valid ? g0 + tid : total - 1;
       // range of point g: the last k with nb_prefix[k] <= g (ranges of length 0 are skipped
       // because their successor has the same prefix)
       int k = 0;
@@ -268,25 +354,61 @@ __global__ __launch_bounds__(kPairThreads) void pair_count_blocks_kernel(
       const int j = nb_start[k] + (g - nb_prefix[k]);
       const double xj = a.x2[j], yj = a.y2[j], zj = a.z2[j];
       const int lj = a.label2[j] - label_lo2;
-      // block-1 points four at a time: p is uniform over the wave, so the coordinates come by
-      // scalar loads, issued together ahead of the four tests
-      auto test = [&](double xi, double yi, double zi, int li) {
-        const double dz = fabs(min_image(zi - zj, a.lz, hz));
-        if (!(dz < a.pi_max)) return;
-        const double dx = min_image(xi - xj, a.lx, hx);
-        const double dy = min_image(yi - yj, a.ly, hy);
+      // does any lane's neighbour cell wrap around the box?  (uniform over the wave; without a
+      // wrap the minimum image is the identity: see pair_count_kernel)
+      const int oz = k % wz - a.reach_z, oy = (k / wz) % wy - a.reach_y;
+      const int ox = k / (wz * wy) - a.reach_x;
+      const bool wrap_x =
+          __builtin_amdgcn_ballot_w64(a.nx < 7 || cx + ox < 0 || cx + ox >= a.nx) != 0;
+      const bool wrap_y =
+          __builtin_amdgcn_ballot_w64(a.ny < 7 || cy + oy < 0 || cy + oy >= a.ny) != 0;
+      const bool wrap_z =
+          __builtin_amdgcn_ballot_w64(a.nz < 7 || cz + oz < 0 || cz + oz >= a.nz) != 0;
+      // block-1 points several at a time: p is uniform over the wave, so the coordinates come
+      // by scalar loads, issued together ahead of the tests; passing pairs are queued and
+      // binned 64 at a time
+      auto test = [&](double xi, double yi, double zi, int li, bool in_range) {
+        double dz = zi - zj;
+        if (wrap_z) dz = min_image(dz, a.lz, hz);
+        dz = fabs(dz);
+        bool pass = valid && in_range && dz < a.pi_max;
+        if (__builtin_amdgcn_ballot_w64(pass) == 0) return;
+        double dx = xi - xj, dy = yi - yj;
+        if (wrap_x) dx = min_image(dx, a.lx, hx);
+        if (wrap_y) dy = min_image(dy, a.ly, hy);
         double r_sqr = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
         if (SMU) r_sqr = __dadd_rn(r_sqr, __dmul_rn(dz, dz));
-        if (!(r_sqr >= lo_sqr && r_sqr < hi_sqr)) return;
-        int bin = 0;
-        for (int e = 1; e < a.n_rp; ++e) bin += r_sqr >= a.edge_sqr[e] ? 1 : 0;
-        if (SMU) {
-          const double mu = r_sqr > 0.0 ? __ddiv_rn(dz, __dsqrt_rn(r_sqr)) : 0.0;
-          const int mu_bin = (int)(mu * a.inv_dpi);
-          if (!(mu < 1.0 && mu_bin < a.n_pi)) return;
-          bin = bin * a.n_pi + mu_bin;
+        pass = pass && r_sqr >= lo_sqr && r_sqr < hi_sqr;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+        if (mask == 0) return;
+        if (pass) {
+          const int slot = queued + (int)__builtin_amdgcn_mbcnt_hi(
+                                        (unsigned)(mask >> 32),
+                                        __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+          qr[slot] = r_sqr;
+          if (SMU) qz[slot] = dz;
+          qc[slot] = (li - label_lo1) * a.block2 + lj;
         }
-        atomicAdd(&hist[(bin * a.block1 + (li - label_lo1)) * a.block2 + lj], 1u);
+        queued += __builtin_popcountll(mask);
+        if (queued >= 64) {
+          __builtin_amdgcn_wave_barrier();
+          bin_entries(64);
+          queued -= 64;
+          double rest_r = 0.0, rest_z = 0.0;
+          int rest_c = 0;
+          if (lane < queued) {
+            rest_r = qr[64 + lane];
+            if (SMU) rest_z = qz[64 + lane];
+            rest_c = qc[64 + lane];
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (lane < queued) {
+            qr[lane] = rest_r;
+            if (SMU) qz[lane] = rest_z;
+            qc[lane] = rest_c;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
       };
       for (int p = p_begin; p < p_end; p += UNROLL) {
         double xs[UNROLL], ys[UNROLL], zs[UNROLL];
@@ -300,11 +422,12 @@ __global__ __launch_bounds__(kPairThreads) void pair_count_blocks_kernel(
           ls[u] = label1[q];
         }
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-          if (p + u < p_end) test(xs[u], ys[u], zs[u], ls[u]);
+        for (int u = 0; u < UNROLL; ++u) test(xs[u], ys[u], zs[u], ls[u], p + u < p_end);
       }
     }
   }
+  __builtin_amdgcn_wave_barrier();
+  bin_entries(queued);
   flush();
 }
 
