@@ -267,7 +267,6 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
   sc_f64 percentile = (sc_f64)a.percentile;
   sc_i32 perm = (sc_i32)a.perm;
   constexpr bool assembias = ASSEMBIAS;
-  constexpr bool modulate = MODULATE;
   const double f1 = (1.0 - a.split) / a.split, f2 = a.split / (1.0 - a.split);
   // (f1 = f1/f2 and f2 = f2/f1 of Hearin et al.'s population fractions)
 
