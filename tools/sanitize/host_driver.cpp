@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <numeric>
 #include <vector>
 
 #include "../../tabcorr_amd/csrc/fastmath.h"
@@ -203,7 +204,8 @@ static void check_fastmath() {
 static void check_cells() {
   std::mt19937_64 rng(4);
   std::uniform_real_distribution<double> uniform(0.0, 1.0);
-  for (int64_t n : {0, 1, 17, 5000})
+  // (250 000 points: the sorts run on several host threads)
+  for (int64_t n : {0, 1, 17, 5000, 250000})
     for (int shape = 0; shape < 3; ++shape) {
       const double box[3] = {100.0, shape == 1 ? 45.0 : 100.0, shape == 2 ? 70.0 : 130.0};
       std::vector<double> pos((size_t)n * 3);
@@ -234,8 +236,38 @@ static void check_cells() {
           const int cx = std::min(grid.nx - 1, (int)(sorted.x[s] / grid.lx * grid.nx));
           EXPECT(cx == c / (grid.ny * grid.nz), "point in the wrong cell");
         }
+      {
+        // stable: with the input index as label, the points of a cell keep their input order
+        // (whatever the number of threads), and sorting by that label changes nothing
+        std::vector<int32_t> index((size_t)n);
+        std::iota(index.begin(), index.end(), 0);
+        tc::CellSort by_index;
+        EXPECT(tc::sort_into_cells(grid, pos.data(), index.data(), n, by_index) == -1,
+               "points reported outside the box");
+        EXPECT(by_index.cell_start == sorted.cell_start && by_index.x == sorted.x,
+               "cell sort depends on the labels");
+        for (int c = 0; c < grid.n_cells(); ++c)
+          for (int32_t s = by_index.cell_start[c] + 1; s < by_index.cell_start[c + 1]; ++s)
+            EXPECT(by_index.label[s - 1] < by_index.label[s], "cell sort is not stable");
+        const std::vector<double> before = by_index.z;
+        tc::sort_cells_by_label(by_index);
+        EXPECT(by_index.z == before, "label sort moved points that were in order");
+      }
       // labelled work items: sorted by label inside the cells, bounded points and labels
+      const tc::CellSort unsorted = sorted;
       tc::sort_cells_by_label(sorted);
+      for (int c = 0; c < grid.n_cells(); ++c) {
+        // (stable inside a label: equal labels keep the order they had in the cell)
+        std::vector<int32_t> order((size_t)(sorted.cell_start[c + 1] - sorted.cell_start[c]));
+        std::iota(order.begin(), order.end(), sorted.cell_start[c]);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+          return unsorted.label[a] < unsorted.label[b];
+        });
+        for (size_t k = 0; k < order.size(); ++k)
+          EXPECT(sorted.x[sorted.cell_start[c] + k] == unsorted.x[order[k]] &&
+                     sorted.label[sorted.cell_start[c] + k] == unsorted.label[order[k]],
+                 "label sort differs from a stable sort");
+      }
       for (int c = 0; c < grid.n_cells(); ++c)
         for (int32_t s = sorted.cell_start[c] + 1; s < sorted.cell_start[c + 1]; ++s)
           EXPECT(sorted.label[s - 1] <= sorted.label[s], "labels not sorted inside a cell");
