@@ -55,7 +55,19 @@
 
 #include "internal.h"
 
+// The separations are formed exactly as the oracle (NumPy) forms them: every product and every
+// sum rounded on its own.  hipcc contracts a * b + c * d into a fused multiply-add by default
+// (the toolchain's __dmul_rn / __dadd_rn are plain operators compiled with contraction
+// allowed), which changes r^2 in the last bit and with it the bin of a pair that sits within
+// an ulp of a bin edge (tests/test_gpu_paircount.py constructs such pairs).
+#pragma clang fp contract(off)
+
 namespace tc {
+
+// (operators of THIS file, i.e. without the contraction flag the toolchain's own __dmul_rn /
+// __dadd_rn inline functions carry)
+__device__ __forceinline__ double mul_rn(double a, double b) { return a * b; }
+__device__ __forceinline__ double add_rn(double a, double b) { return a + b; }
 
 constexpr int kPairThreads = 256;
 constexpr int kMaxRpBins = 64;
@@ -177,8 +189,8 @@ __global__ __launch_bounds__(kPairThreads) void pair_count_kernel(PairArgs a) {
           if (wrap_x) dx = min_image(dx, a.lx, hx);
           if (wrap_y) dy = min_image(dy, a.ly, hy);
           // (separately rounded products and sums: the oracle's arithmetic)
-          double r_sqr = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
-          if (SMU) r_sqr = __dadd_rn(r_sqr, __dmul_rn(dz, dz));
+          double r_sqr = add_rn(mul_rn(dx, dx), mul_rn(dy, dy));
+          if (SMU) r_sqr = add_rn(r_sqr, mul_rn(dz, dz));
           pass = pass && r_sqr >= lo_sqr && r_sqr < hi_sqr;
           const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
           if (mask == 0) return;
@@ -376,8 +388,8 @@ __global__ __launch_bounds__(kPairThreads) void pair_count_blocks_kernel(
         double dx = xi - xj, dy = yi - yj;
         if (wrap_x) dx = min_image(dx, a.lx, hx);
         if (wrap_y) dy = min_image(dy, a.ly, hy);
-        double r_sqr = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
-        if (SMU) r_sqr = __dadd_rn(r_sqr, __dmul_rn(dz, dz));
+        double r_sqr = add_rn(mul_rn(dx, dx), mul_rn(dy, dy));
+        if (SMU) r_sqr = add_rn(r_sqr, mul_rn(dz, dz));
         pass = pass && r_sqr >= lo_sqr && r_sqr < hi_sqr;
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
         if (mask == 0) return;
@@ -490,7 +502,7 @@ __global__ __launch_bounds__(kPairThreads) void mass_in_cylinders_kernel(Cylinde
         for (int t = 0; t < n_tile; ++t) {
           const double dx = min_image(xi - sx[t], a.lx, hx);
           const double dy = min_image(yi - sy[t], a.ly, hy);
-          const double r_sqr = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+          const double r_sqr = add_rn(mul_rn(dx, dx), mul_rn(dy, dy));
           if (!(r_sqr <= hi_sqr)) continue;
           int d = 0;
           for (int k = 0; k + 1 < a.n_edges; ++k) d += r_sqr > a.edge_sqr[k] ? 1 : 0;
@@ -614,12 +626,40 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
                   "more than the labelled pair counter's 32-bit counters take",
                   units.max_cell_candidates);
   } else {
+    // heaviest items first: the candidates of an item are its points x the points of the
+    // cells around its cell, and clustered points make that vary by orders of magnitude -- in
+    // cell order the launch ended with a few workgroups of dense cells on an otherwise idle
+    // chip (1.4 resident waves per SIMD on average)
+    std::vector<int64_t> around((size_t)grid.n_cells(), 0);
+    for (int cx = 0; cx < grid.nx; ++cx)
+      for (int cy = 0; cy < grid.ny; ++cy)
+        for (int cz = 0; cz < grid.nz; ++cz) {
+          int64_t sum = 0;
+          for (int ox = -grid.reach_x; ox <= grid.reach_x; ++ox)
+            for (int oy = -grid.reach_y; oy <= grid.reach_y; ++oy)
+              for (int oz = -grid.reach_z; oz <= grid.reach_z; ++oz) {
+                const int other = (((cx + ox + grid.nx) % grid.nx) * grid.ny +
+                                   (cy + oy + grid.ny) % grid.ny) * grid.nz +
+                                  (cz + oz + grid.nz) % grid.nz;
+                sum += second.cell_start[other + 1] - second.cell_start[other];
+              }
+          around[(size_t)(cx * grid.ny + cy) * grid.nz + cz] = sum;
+        }
+    struct Item { int32_t cell, begin, end; int64_t cost; };
+    std::vector<Item> items;
     for (int c = 0; c < grid.n_cells(); ++c)
       for (int32_t b = set1.cell_start[c]; b < set1.cell_start[c + 1]; b += kPairThreads) {
-        item_cell.push_back(c);
-        item_begin.push_back(b);
-        item_end.push_back(std::min<int32_t>(b + kPairThreads, set1.cell_start[c + 1]));
+        const int32_t e = std::min<int32_t>(b + kPairThreads, set1.cell_start[c + 1]);
+        // (a wave tests 64 points at once: a partial item costs what its waves cost)
+        items.push_back({c, b, e, (int64_t)((e - b + 63) / 64) * around[c]});
       }
+    std::stable_sort(items.begin(), items.end(),
+                     [](const Item& u, const Item& v) { return u.cost > v.cost; });
+    for (const Item& item : items) {
+      item_cell.push_back(item.cell);
+      item_begin.push_back(item.begin);
+      item_end.push_back(item.end);
+    }
   }
 
   DeviceArrays device;

@@ -426,3 +426,54 @@ def test_tabulate_swaps_in_the_one_pass_pair_count(monkeypatch):
     with pytest.raises(AssertionError, match='swapped out'):
         TabCorr.tabulate(halocat, lambda *a, **k: None, rp_bins, mode='cross')
     assert module.compute_tpcf_matrix is reference_compute_tpcf_matrix
+
+
+def _pairs_on_a_bin_edge(n_cases, seed=5):
+    """Separations (dx, dy) and a bin edge e such that r^2 = dx dx + dy dy formed with
+    separately rounded products and sum equals fl(e e) exactly, while a fused multiply-add
+    (dx dx + fl(dy dy) rounded once) falls on the other side of it."""
+    import math
+    rng = np.random.default_rng(seed)
+    cases = []
+    scale = 2.0**-30
+    while len(cases) < n_cases:
+        dx = float(rng.integers(1, 2**30)) * scale * 4.0        # < 4, exact in the box below
+        dy = float(rng.integers(1, 2**30)) * scale * 4.0
+        separate = dx * dx + dy * dy                             # NumPy / the oracle
+        fused = math.fma(dx, dx, dy * dy) if hasattr(math, 'fma') else None
+        if fused is None:
+            # (Python < 3.13: exact rational arithmetic)
+            from fractions import Fraction
+            exact = Fraction(dx) * Fraction(dx) + Fraction(dy * dy)
+            fused = float(exact)
+        if fused == separate:
+            continue
+        upper = max(separate, fused)
+        edge = math.sqrt(upper)
+        for candidate in (edge, np.nextafter(edge, 0.0), np.nextafter(edge, 10.0)):
+            if candidate * candidate == upper:
+                cases.append((dx, dy, float(candidate), separate >= upper))
+                break
+    return cases
+
+
+def test_products_and_sums_are_rounded_separately():
+    """r_p^2 exactly on a bin edge with the oracle's arithmetic, on the other side of it with a
+    fused multiply-add: the pair must land in the oracle's bin (the toolchain contracts
+    a * b + c * d by default)."""
+    from tabcorr_amd import corrfunc
+    from oracle import paircount_oracle as oracle
+    period = np.array([64.0, 64.0, 64.0])
+    for dx, dy, edge, in_upper_bin in _pairs_on_a_bin_edge(24):
+        rp_bins = np.array([0.5 * edge, edge, 1.5 * edge])
+        if rp_bins[-1] >= 0.5 * period[0]:
+            continue
+        pos = np.array([[16.0, 24.0, 8.0], [16.0 + dx, 24.0 + dy, 8.5]])
+        assert pos[1, 0] - pos[0, 0] == dx and pos[1, 1] - pos[0, 1] == dy
+        expect = oracle.pair_count_rppi(pos, None, period, rp_bins, 4.0)
+        assert expect.sum() == 2 and (expect[1].sum() == 2) == in_upper_bin
+        got = corrfunc.pair_count_rppi(pos, rp_bins, 4.0, None, period)
+        assert np.array_equal(got, expect), (dx, dy, edge)
+        labelled = corrfunc.pair_count_matrix([pos[:1], pos[1:]], rp_bins, 4.0, period)
+        assert labelled[1 if in_upper_bin else 0, 0, 1] == 1
+        assert labelled.sum() == 2
