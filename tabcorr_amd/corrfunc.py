@@ -212,13 +212,32 @@ def delta_sigma_from_mass_in_cylinders(mass_encl, rp_bins):
                  (log_rp[1:] - log_rp[:-1]))
         interpolated[full] = 10.0**(slope * (log_mid - log_rp[:-1]) +
                                     log_sigma[:, :-1])
-    for g in np.nonzero(~full)[0]:
-        mask = sigma_inside[g] > 0
-        if np.count_nonzero(mask) < 2:
-            continue
-        interpolated[g] = 10.0**np.interp(log_mid, log_rp[mask],
-                                          np.log10(sigma_inside[g][mask]))
-        interpolated[g][rp_mids < rp_bins[mask][0]] = 0.0
+    rest = np.nonzero(~full)[0]
+    if len(rest):
+        # objects with empty inner cylinders: linear interpolation in log-log between the
+        # nearest radii WITH mass on either side of the midpoint (numpy.interp over the
+        # masked radii, for all of them at once): the value at the last radius with mass
+        # beyond it, 0 inside the first one or with fewer than two such radii
+        mask = sigma_inside[rest] > 0
+        n_radii = mask.shape[1]
+        index = np.arange(n_radii)
+        with np.errstate(divide='ignore'):
+            log_sigma = np.where(mask, np.log10(np.where(mask, sigma_inside[rest], 1.0)),
+                                 0.0)
+        # midpoint k lies between radii k and k + 1
+        left = np.maximum.accumulate(np.where(mask, index, -1), axis=1)[:, :-1]
+        right = np.minimum.accumulate(np.where(mask, index, n_radii)[:, ::-1],
+                                      axis=1)[:, ::-1][:, 1:]
+        rows = np.arange(len(rest))[:, None]
+        lo, hi = np.clip(left, 0, n_radii - 1), np.clip(right, 0, n_radii - 1)
+        x_lo, x_hi = log_rp[lo], log_rp[hi]
+        y_lo, y_hi = log_sigma[rows, lo], log_sigma[rows, hi]
+        with np.errstate(divide='ignore', invalid='ignore'):
+            slope = (y_hi - y_lo) / (x_hi - x_lo)
+            value = 10.0**np.where(right < n_radii,
+                                   slope * (log_mid - x_lo) + y_lo, y_lo)
+        value[(left < 0) | (np.count_nonzero(mask, axis=1) < 2)[:, None]] = 0.0
+        interpolated[rest] = value
     return interpolated - sigma_annulus
 
 
