@@ -41,6 +41,10 @@ int tc_debug_quad_schedule(int n_bins, int n_central, int by_type, int n_tiles, 
                            int order /* 0 draw-tile-major, 1 table-major, 2 r-tile-major */,
                            int* n_waves, int* n_runs, int* n_slabs, int64_t* units_min,
                            int64_t* units_max);
+/* The equal contiguous parts of a triangle of n_rb block rows that the waves of
+ * predict_fused_kernel walk (hostmath.h: triangle_parts): first block row, block column and
+ * number of units of each of the n_parts parts. */
+int tc_debug_triangle_parts(int n_rb, int n_parts, int32_t* rb0, int32_t* cb0, int32_t* count);
 /* TEST INFRASTRUCTURE, never called by the product: executes the kernel's table layout,
  * schedule and slab grouping on the host, lane by lane, for densities (n_bins, ldb) given
  * in the reference's bin order; out (n_draws, 1 | 3, n_r) = sum_p c_p T[r][p] n_i n_j

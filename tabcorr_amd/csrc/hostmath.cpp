@@ -507,6 +507,19 @@ void merge_quad_schedule(const QuadLayout& layout, int n_rtiles, bool separate,
   for (QuadMerge& m : plan.merges) m.slab = renumbered[m.slab];
 }
 
+void triangle_parts(int n_rb, int n_parts, int32_t* rb0, int32_t* cb0, int32_t* count) {
+  const int64_t n_units = (int64_t)n_rb * (n_rb + 1) / 2;
+  for (int part = 0; part < n_parts; ++part) {
+    const int64_t begin = n_units * part / n_parts, end = n_units * (part + 1) / n_parts;
+    int64_t rb = (int64_t)((std::sqrt(8.0 * (double)begin + 1.0) - 1.0) / 2.0);
+    while ((rb + 1) * (rb + 2) / 2 <= begin) ++rb;
+    while (rb * (rb + 1) / 2 > begin) --rb;
+    rb0[part] = (int32_t)rb;
+    cb0[part] = (int32_t)(begin - rb * (rb + 1) / 2);
+    count[part] = (int32_t)(end - begin);
+  }
+}
+
 QuadTiling quad_tiling(int n_r) {
   QuadTiling tiling;
   tiling.n_rtiles = (n_r + 19) / 20;

@@ -217,6 +217,11 @@ void merge_quad_schedule(const QuadLayout& layout, int n_rtiles, bool separate,
                          int waves_per_block, int max_slots, QuadSchedule& schedule,
                          QuadMergePlan& plan);
 
+// The units of a triangular component (block rows rb = 0 .. n_rb - 1 with rb + 1 units each,
+// row-major) cut into `n_parts` equal contiguous parts -- the quarters the waves of
+// predict_fused_kernel walk: first block row, block column and number of units of every part.
+void triangle_parts(int n_rb, int n_parts, int32_t* rb0, int32_t* cb0, int32_t* count);
+
 // r tiling of the quadratic-form kernel: n_rtiles tiles of r_per_tile values (the last one
 // may hold fewer), n_u = ceil(r_per_tile / 4) <= 5 sub-tiles of 4.
 struct QuadTiling {

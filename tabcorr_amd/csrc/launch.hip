@@ -949,15 +949,7 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   fa.n_central = t->plan.n_central;
   fa.n_gauss = n_gauss;
   fa.dens_rows = 4 * comp.n_rb;
-  for (int part = 0; part < 4; ++part) {
-    const int64_t begin = comp.n_units * part / 4, end = comp.n_units * (part + 1) / 4;
-    int64_t rb = (int64_t)((std::sqrt(8.0 * (double)begin + 1.0) - 1.0) / 2.0);
-    while ((rb + 1) * (rb + 2) / 2 <= begin) ++rb;
-    while (rb * (rb + 1) / 2 > begin) --rb;
-    fa.part_rb0[part] = (int)rb;
-    fa.part_cb0[part] = (int)(begin - rb * (rb + 1) / 2);
-    fa.part_count[part] = (int)(end - begin);
-  }
+  tc::triangle_parts(comp.n_rb, 4, fa.part_rb0, fa.part_cb0, fa.part_count);
   fa.n_r = t->n_r;
   fa.priority = (t->tuning.prio_fused & 3) | ((t->tuning.prio_fused_occ & 3) << 2) |
                 ((t->tuning.prio_fused_out & 3) << 4);

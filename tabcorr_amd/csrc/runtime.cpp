@@ -334,6 +334,12 @@ int tc_plan_debug(int mode, int n_bins, const uint8_t* is_central, int n_chunks,
   return TC_OK;
 }
 
+int tc_debug_triangle_parts(int n_rb, int n_parts, int32_t* rb0, int32_t* cb0, int32_t* count) {
+  TC_CHECK(n_rb >= 1 && n_parts >= 1 && rb0 && cb0 && count, "invalid argument");
+  tc::triangle_parts(n_rb, n_parts, rb0, cb0, count);
+  return TC_OK;
+}
+
 int tc_debug_quad_schedule(int n_bins, int n_central, int by_type, int n_tiles, int n_rtiles,
                            int n_tables, int separate, int max_waves, int min_units, int order,
                            int* n_waves, int* n_runs, int* n_slabs, int64_t* units_min,

@@ -870,3 +870,27 @@ def test_quad_emulation_matches_the_oracle(lib, n_prim, n_sec, n_r, separate, n_
         else:
             expect = np.einsum('rp,bp->br', matrix, weights)
             np.testing.assert_allclose(out[:, 0], expect, rtol=1e-12)
+
+
+def test_triangle_parts_of_the_one_launch_kernel():
+    """The equal contiguous parts of the unit triangle that the waves of predict_fused_kernel
+    walk: every unit exactly once, in row-major order, parts within one unit of equal size."""
+    import ctypes
+    from tabcorr_amd import _lib
+    lib = _lib.load()
+    for n_rb in (1, 2, 3, 4, 7, 25, 26, 50, 251):
+        for n_parts in (1, 2, 4, 8, 16):
+            arrays = [(ctypes.c_int * n_parts)() for _ in range(3)]
+            _lib.check(lib.tc_debug_triangle_parts(n_rb, n_parts, *arrays))
+            rb0, cb0, count = (list(a) for a in arrays)
+            n_units = n_rb * (n_rb + 1) // 2
+            assert sum(count) == n_units
+            assert max(count) - min(count) <= 1
+            position = 0
+            for part in range(n_parts):
+                if count[part] == 0:
+                    continue
+                assert 0 <= cb0[part] <= rb0[part] < n_rb
+                assert rb0[part] * (rb0[part] + 1) // 2 + cb0[part] == position
+                position += count[part]
+            assert position == n_units
