@@ -223,6 +223,7 @@ struct Tuning {
   int single_draw = 1;        // one-launch path for un-batched predict()
   int poll_done = 1;          // ... completed by polling its completion words in host memory
   int quad_waves = 2;         // resident contraction waves per SIMD (quadratic-form kernel)
+  int quad_waves_f32 = 3;     // ... of the float32 kernel
   int quad_merge = 1;         // workgroup-level merging of the partial slabs (hostmath.h)
   int quad_order = -1;        // schedule order of one table (-1: chosen by matrix size)
   // wave priorities.  The occupation kernel heads each lane's chain (occupation ->
@@ -274,6 +275,7 @@ struct Tuning {
     pipeline = env_int("TC_PIPELINE", pipeline);
     single_draw = env_int("TC_SINGLE_DRAW", single_draw);
     quad_waves = env_int("TC_QUAD_WAVES", quad_waves);
+    quad_waves_f32 = env_int("TC_QUAD_WAVES_F32", quad_waves_f32);
     quad_merge = env_int("TC_QUAD_MERGE", quad_merge);
     prio_occ = env_int("TC_PRIO_O", prio_occ);
     prio_contract = env_int("TC_PRIO_C", prio_contract);

@@ -851,7 +851,7 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
       if (lane.stream) TC_HIP(hipStreamSynchronize(lane.stream));
     if (key == "quad_merge") t->tuning.quad_merge = value != 0;
     else if (key == "quad_order") t->tuning.quad_order = value;
-    else t->tuning.quad_waves = value;
+    else t->tuning.quad_waves = t->tuning.quad_waves_f32 = value;
     for (tc::host::QuadTable* q : {&t->quad_by_type, &t->quad_total}) q->drop_schedules();
   } else {
     return fail(TC_ERR_INVALID, "unknown option '%s'", name);
