@@ -222,7 +222,8 @@ struct Tuning {
   int pipeline = 1;           // 0: every device-pointer call on lane 0 (kernels serialised)
   int single_draw = 1;        // one-launch path for un-batched predict()
   int poll_done = 1;          // ... completed by polling its completion words in host memory
-  int quad_waves = 2;         // resident contraction waves per SIMD (quadratic-form kernel)
+  int quad_waves = 0;         // resident contraction waves per SIMD (quadratic-form kernel;
+                              // 0: chosen by the matrix work per draw tile, launch.hip)
   int quad_waves_f32 = 3;     // ... of the float32 kernel
   int quad_merge = 1;         // workgroup-level merging of the partial slabs (hostmath.h)
   int quad_order = -1;        // schedule order of one table (-1: chosen by matrix size)

@@ -259,8 +259,13 @@ int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, 
   // (float32: three -- the matrix instruction is half as long, a third wave covers more of the
   // issue gaps: configs[4] 2327 -> 2253 us per launch, 0.836 -> 0.864; float64: three waves are
   // no faster alone and 8 % slower in the pipeline)
+  // float64, default: two for tables of BASELINE configs[1]'s size, three where a draw tile
+  // carries more matrix work -- more bins or an interpolator's tables (configs[2] 125.6 -> 124.7
+  // us per launch and +1.5 % per step, configs[3] 936 -> 921 us and +0.4 %)
   const int per_simd = t->compute_dtype == TC_DTYPE_F32 ? t->tuning.quad_waves_f32
-                                                        : t->tuning.quad_waves;
+                       : t->tuning.quad_waves > 0       ? t->tuning.quad_waves
+                       : q->layout.n_units * std::max(1, n_tables) >= 1000 ? 3
+                                                                           : 2;
   const int max_waves = t->n_cus * 4 * std::max(1, std::min(3, per_simd));
   tc::QuadSchedule schedule;
   // (interpolators: table-major order; one matrix larger than an L2: r-tile-major; see
