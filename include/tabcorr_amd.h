@@ -285,7 +285,7 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 lane); 1: their finalisations are chained so that results appear in call
  *                 order (0.3 - 3 us per 10^4-draw step).
  *   "fused"       1 (default): pipelined device-pointer and asynchronous calls of
- *                 "fused_min_draws" .. "fused_max_draws" draws (8192 .. 32768; asynchronous
+ *                 "fused_min_draws" .. "fused_max_draws" draws (7168 .. 30720; asynchronous
  *                 calls: no upper bound) that qualify
  *                 (mode auto, total correlation function, at most 20 r values, Zheng07 family)
  *                 run as ONE launch per batch, a workgroup carrying 64 draws from the

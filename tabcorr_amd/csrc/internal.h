@@ -254,15 +254,16 @@ struct Tuning {
   // pipelined device-pointer and asynchronous calls of fused_min_draws .. fused_max_draws
   // draws, 2 every call of that size.  Sustained device-resident rate on four lanes
   // (tools/r03_fused_scan.py, BASELINE configs[1]'s table; three kernels / one launch, us per
-  // call): 4096 draws 23.6 / 30.7, 8192 35.6 / 33.0, 10^4 42.7 / 39.6, 16384 66.7 / 63.5,
+  // call): 4096 draws 23.6 / 30.7, 6144 31.4 / 31.5, 7168 34.9 / 32.0, 8192 35.6 / 33.0, 10^4
+  // 42.7 / 39.6, 16384 66.7 / 63.5, 28672 111.7 / 111.0, 32768 126.3 / 126.6,
   // 40000 151.8 / 156.3 -- both designs approach the same 38 us per 10^4 draws for huge
   // batches (matrix + vector instructions on one FP64 pipe); the one-launch form gets there
   // with the batch sizes an ensemble sampler has, the three kernels spread small batches
   // over the whole chip.  Asynchronous host calls (us per call, tools/r03_async.py): 6144 draws
   // 38.8 / 41.6, 10^4 58 / 47.6, 20 000 93.7 / 82.6, 40 000 176 / 162: no upper bound there.
   int fused = 1;
-  int fused_min_draws = 8192;
-  int fused_max_draws = 32768;
+  int fused_min_draws = 7168;
+  int fused_max_draws = 30720;
   int prio_fused = 1, prio_fused_occ = 2, prio_fused_out = 3;   // phases 2, 1, 3
   int skip_occ = 0, skip_finalize = 0;   // diagnosis (developer builds only)
   void load() {

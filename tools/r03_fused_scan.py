@@ -24,8 +24,11 @@ for ptr, count in ((d_theta, n_max * 5), (d_ngal, 4 * n_max), (d_xi, 4 * n_max *
     _lib.check(lib.tc_device_malloc(ctypes.byref(ptr), count * 8))
 _lib.check(lib.tc_memcpy_h2d(d_theta, theta.ctypes.data_as(ctypes.c_void_p), theta.nbytes))
 _lib.check(lib.tc_table_set_option(handle, b'fused_min_draws', 1))
+_lib.check(lib.tc_table_set_option(handle, b'fused_max_draws', 10000000))
 print('%8s %14s %14s' % ('draws', 'three kernels', 'one launch'))
-for n in (65, 256, 512, 1024, 2048, 4096, 8192, 10000, 16384, 40000, 100000):
+sizes = [int(v) for v in sys.argv[1:]] or [65, 256, 512, 1024, 2048, 4096, 8192, 10000, 16384,
+                                           40000, 100000]
+for n in sizes:
     row = []
     for fused in (0, 1):
         _lib.check(lib.tc_table_set_option(handle, b'fused', fused))
