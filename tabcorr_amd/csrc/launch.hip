@@ -918,16 +918,17 @@ int fused_lds_bytes(const tc_table* t) {
 
 namespace {
 template <int NG, bool AB, bool MO>
-int launch_fused(int n_u, dim3 grid, dim3 block, int lds, hipStream_t stream, hipEvent_t k0,
-                 hipEvent_t k1, const tc::FusedArgs& fa) {
+int launch_fused(int device, int n_u, dim3 grid, dim3 block, int lds, hipStream_t stream,
+                 hipEvent_t k0, hipEvent_t k1, const tc::FusedArgs& fa) {
   switch (n_u) {
 #define TC_CASE(N)                                                                            \
   case N: {                                                                                   \
-    static bool limit_set = false;                                                            \
-    if (lds > 64 * 1024 && !limit_set) {                                                      \
+    /* (the attribute belongs to the function ON a device: once per device) */                \
+    static bool limit_set[64] = {};                                                           \
+    if (lds > 64 * 1024 && !(device >= 0 && device < 64 && limit_set[device])) {              \
       TC_HIP(hipFuncSetAttribute((const void*)tc::predict_fused_kernel<NG, N, AB, MO>,        \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));    \
-      limit_set = true;                                                                       \
+      if (device >= 0 && device < 64) limit_set[device] = true;                               \
     }                                                                                         \
     hipExtLaunchKernelGGL((tc::predict_fused_kernel<NG, N, AB, MO>), grid, block, lds,        \
                           stream, k0, k1, 0, fa);                                             \
@@ -991,15 +992,15 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   const bool assembias = (flags & TC_FLAG_ASSEMBIAS) != 0;
   const bool modulate = (flags & TC_FLAG_MODULATE_WITH_CENOCC) != 0;
   if (n_gauss != 10)
-    status = launch_fused<0, false, false>(t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+    status = launch_fused<0, false, false>(t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
   else if (!assembias && !modulate)
-    status = launch_fused<10, false, false>(t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+    status = launch_fused<10, false, false>(t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
   else if (!assembias)
-    status = launch_fused<10, false, true>(t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+    status = launch_fused<10, false, true>(t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
   else if (!modulate)
-    status = launch_fused<10, true, false>(t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+    status = launch_fused<10, true, false>(t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
   else
-    status = launch_fused<10, true, true>(t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+    status = launch_fused<10, true, true>(t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
   if (status != TC_OK) return status;
   t->last_workgroups = (int)grid.x;
   t->last_waves = tc::kFusedWaves;
