@@ -905,6 +905,11 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
   if (t->quad_total.layout.comps.size() != 1 || !t->quad_total.layout.comps[0].triangular)
     return false;
   if (fused_lds_bytes(t) > 160 * 1024 || n_gauss < 1) return false;
+  // two workgroups per CU or not at all: with more than 80 KB of LDS each (more than 104 bins)
+  // a CU holds one, its phases no longer overlap with a neighbour's, and the three kernels are
+  // 10 % ahead (tools/r03_fused_bins.py, 10^4 draws, three kernels / one launch: G = 80 31.3 /
+  // 27.7 us, 104 45.2 / 42.2, 112 50.7 / 56.0, 128 62.8 / 69.4, 200 135.5 / 149.3)
+  if (fused_lds_bytes(t) > 80 * 1024 && t->tuning.fused < 2) return false;
   // calls that run alone on their lane (host-buffer API, pipeline off) keep the three kernels,
   // which spread one batch over the whole chip
   const bool alone = t->force_lane >= 0 || !t->tuning.pipeline || t->n_lanes == 1;
