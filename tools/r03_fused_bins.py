@@ -15,13 +15,17 @@ from tabcorr_amd import TabCorr, synthetic, _lib   # noqa: E402
 lib = _lib.load()
 n = 10000
 theta = np.ascontiguousarray(synthetic.zheng07_draws(n, seed=1))
-for n_prim in (40, 50, 52, 56, 64, 80, 100):
-    table = synthetic.synthetic_table(n_prim, 1, (19, ), 'auto', seed=0)
+cases = [(n_prim, 19, 10) for n_prim in (40, 50, 52, 56, 64, 80, 100)]
+if len(sys.argv) > 1 and sys.argv[1] == 'shapes':
+    # (fewer r values, another n_gauss_prim)
+    cases = [(50, 3, 10), (50, 8, 10), (50, 12, 10), (50, 19, 7), (50, 19, 20), (25, 19, 10)]
+for n_prim, n_r, n_gauss in cases:
+    table = synthetic.synthetic_table(n_prim, 1, (n_r, ), 'auto', seed=0)
     halotab = TabCorr.from_arrays(table['gal_type'], table['tpcf_matrix'], table['tpcf_shape'],
                                   table['attrs'])
     handle = halotab.to_device().handle
     d_theta, d_ngal, d_xi = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
-    for ptr, count in ((d_theta, n * 5), (d_ngal, 4 * n), (d_xi, 4 * n * 19)):
+    for ptr, count in ((d_theta, n * 5), (d_ngal, 4 * n), (d_xi, 4 * n * n_r)):
         _lib.check(lib.tc_device_malloc(ctypes.byref(ptr), count * 8))
     _lib.check(lib.tc_memcpy_h2d(d_theta, theta.ctypes.data_as(ctypes.c_void_p), theta.nbytes))
     row = []
@@ -31,8 +35,8 @@ for n_prim in (40, 50, 52, 56, 64, 80, 100):
         def step(k):
             s = k % 4
             _lib.check(lib.tc_predict_zheng07_batch_device(
-                handle, d_theta, 5, n, 10, 0, ctypes.c_void_p(d_ngal.value + s * n * 8),
-                ctypes.c_void_p(d_xi.value + s * n * 19 * 8)))
+                handle, d_theta, 5, n, n_gauss, 0, ctypes.c_void_p(d_ngal.value + s * n * 8),
+                ctypes.c_void_p(d_xi.value + s * n * n_r * 8)))
         for k in range(500):
             step(k)
         _lib.check(lib.tc_table_synchronize(handle))
@@ -43,8 +47,8 @@ for n_prim in (40, 50, 52, 56, 64, 80, 100):
         row.append((time.perf_counter() - t0) / 2000 * 1e6)
     launch = [ctypes.c_int() for _ in range(4)]
     lib.tc_table_last_launch(handle, *[ctypes.byref(v) for v in launch])
-    print('G = %3d: three kernels %7.2f us, one launch %7.2f us per step (LDS %d bytes, %s)' %
-          (2 * n_prim, row[0], row[1], launch[3].value,
+    print('G = %3d, R = %2d, n_gauss %2d: three kernels %7.2f us, one launch %7.2f us per step '
+          '(LDS %d bytes, %s)' % (2 * n_prim, n_r, n_gauss, row[0], row[1], launch[3].value,
            'one launch taken' if launch[2].value == 0 else 'NOT taken'))
     for ptr in (d_theta, d_ngal, d_xi):
         lib.tc_device_free(ptr)
