@@ -263,3 +263,44 @@ def test_a_draws_result_does_not_depend_on_its_place_in_the_batch():
     ngal_p, xi_p = halotab.predict_batch(theta[3000:3777])
     assert np.array_equal(ngal_p, ngal[3000:3777])
     assert np.array_equal(xi_p, xi[3000:3777])
+
+
+def test_fused_matches_the_references_own_tables():
+    """The reference's example table (docs/examples/bolplanck_wp.hdf5: 60 bins, 19 r_p bins) and
+    the other fixtures recorded by running the reference, through the one-launch path: any
+    n_gauss_prim, modulate_with_cenocc, one r value, tables without prim_haloprop_dist_index,
+    assembly bias on the 200-bin table (one workgroup per CU: forced)."""
+    data = load_golden('bolplanck_wp')
+    halotab = make_tabcorr(table_from_golden(data))
+    force_fused(halotab)
+    for suffix, kwargs in (('', {}), ('_ng1', {'n_gauss_prim': 1}),
+                           ('_ng100', {'n_gauss_prim': 100}),
+                           ('_modulate', {'modulate_with_cenocc': True})):
+        ngal, xi = halotab.predict_batch(data['theta'], **kwargs)
+        assert last_launch(halotab)[1:3] == (8, 0), suffix
+        assert_rel(ngal, data['ngal' + suffix], RTOL, 'ngal' + suffix)
+        assert_rel(xi, data['xi' + suffix], RTOL, 'xi' + suffix)
+    for name, prefixes in (('synthetic_r1', ('', )), ('synthetic_small_auto', ('', 'legacy_'))):
+        data = load_golden(name)
+        for prefix in prefixes:
+            table = table_from_golden(data)
+            if prefix == 'legacy_':      # (a table without prim_haloprop_dist_index)
+                names = [n for n in table['gal_type'].dtype.names
+                         if n != 'prim_haloprop_dist_index']
+                table = dict(table, gal_type=table['gal_type'][names])
+            halotab = make_tabcorr(table)
+            force_fused(halotab)
+            ngal, xi = halotab.predict_batch(data['theta'])
+            assert last_launch(halotab)[1:3] == (8, 0), name + prefix
+            assert_rel(ngal, data[prefix + 'ngal'], RTOL, name)
+            assert_rel(xi, data[prefix + 'xi'], RTOL, name)
+    data = load_golden('synthetic_cfg3')
+    halotab = make_tabcorr(table_from_golden(data))
+    force_fused(halotab)
+    ngal, xi = halotab.predict_batch(np.hstack([data['theta'], data['assembias']]),
+                                     assembias=True)
+    assert last_launch(halotab)[1:3] == (8, 0)
+    assert_rel(ngal, data['ngal'], RTOL)
+    assert_rel(xi, data['xi'], RTOL)
+    ngal, xi = halotab.predict_batch(data['theta'])
+    assert_rel(xi, data['plain_xi'], RTOL)
