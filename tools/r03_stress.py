@@ -43,7 +43,7 @@ start = time.time()
 while time.time() - start < seconds:
     kind = rng.choice(['sync', 'many', 'one', 'async', 'async_chi2', 'wait', 'device', 'chi2'])
     counts[kind] = counts.get(kind, 0) + 1
-    n = int(rng.choice([1, 3, 17, 64, 65, 200, 1000, 2500, 10000]))
+    n = int(rng.choice([1, 3, 17, 64, 65, 200, 1000, 2500, 7167, 7168, 10000, 16001]))
     lo = int(rng.integers(0, len(pool) - n))
     if kind == 'sync':
         ngal, xi = halotab.predict_batch(pool[lo:lo + n])
