@@ -287,7 +287,8 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *   "fused"       1 (default): pipelined device-pointer and asynchronous calls of
  *                 "fused_min_draws" .. "fused_max_draws" draws (7168 .. 30720; asynchronous
  *                 calls: no upper bound) that qualify
- *                 (mode auto, total correlation function, at most 20 r values, Zheng07 family)
+ *                 (mode auto, at most 20 r values and 104 bins, Zheng07 family, total or
+ *                 separated by galaxy type)
  *                 run as ONE launch per batch, a workgroup carrying 64 draws from the
  *                 parameters to the results; 0: always occupation, contraction, finalisation
  *                 kernels; 2: one launch also for calls that run alone on their lane.

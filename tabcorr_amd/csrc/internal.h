@@ -436,7 +436,8 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
 // One launch per slab (predict_fused_kernel) for the calls it covers; ngal and xi (or the
 // likelihood, t->fuse_chi2_out) as run_contraction leaves them.
 bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags);
-int fused_lds_bytes(const tc_table* t);
+int fused_dens_rows(const tc_table* t, bool separate);
+int fused_lds_bytes(const tc_table* t, bool separate);
 int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_draws, int n_gauss,
               unsigned flags, double* ngal_device, double* xi_device);
 int check_predict_args(const tc_table* t, const void* theta, int n_theta, int64_t n_draws,

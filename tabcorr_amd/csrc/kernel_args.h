@@ -205,10 +205,19 @@ struct FusedArgs {
   int n_bins;
   int n_central;
   int n_gauss;
-  int dens_rows;             // 4 x block rows of the triangle
-  int part_rb0[4];           // the four quarters of the triangle's units: first block row,
-  int part_cb0[4];           // ... block column
-  int part_count[4];         // ... units
+  int dens_rows;             // rows of the LDS density array (whole blocks of four)
+  // the work of the four waves of a 32-draw tile: `count` units of one component from block
+  // (rb0, cb0) on.  Total: the four quarters of the triangle.  Separated by galaxy type: the
+  // cen-cen triangle, the two halves of the cen-sat rectangle, the sat-sat triangle.
+  int part_rb0[4];
+  int part_cb0[4];
+  int part_count[4];
+  int part_triangular[4];    // block columns 0 .. rb of block row rb, else all part_n_cb
+  int part_n_cb[4];
+  int part_i_row0[4];        // first density row of the component's rows / columns
+  int part_j_row0[4];
+  int part_unit_base[4];     // first unit of the component in the table
+  int separate;              // 1: ngal (n_draws, 2), xi (n_draws, 3, n_r): cc, cs, ss
   int n_r;
   int priority;              // wave priorities: phase 2 | phase 1 << 2 | phase 3 << 4
   int64_t n_draws;
@@ -221,8 +230,8 @@ struct FusedArgs {
   const double* math_table;
   const void* table;         // re-laid-out matrix of the whole triangle (one r tile)
   uint32_t table_bytes;
-  double* ngal;              // (n_draws)
-  double* xi;                // (n_draws, n_r), or NULL when the likelihood is fused
+  double* ngal;              // (n_draws) or (n_draws, 2)
+  double* xi;                // (n_draws, n_r) or (n_draws, 3, n_r); NULL: the likelihood is fused
   const double* chi2_data;   // as FinalizeQuadArgs
   double* chi2;
 };

@@ -1386,8 +1386,10 @@ template <int UU>
 __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, unsigned off_a,
                                                 unsigned unit_bytes, const double* dens_b,
                                                 const double* dens_e, int rb, int cb, int left,
+                                                bool triangular, int n_cb, unsigned unit_base,
                                                 double (&F)[2][2]) {
-  unsigned ua = (unsigned)(rb * (rb + 1) / 2 + cb) * unit_bytes;
+  unsigned ua = (unit_base + (unsigned)(triangular ? rb * (rb + 1) / 2 + cb : rb * n_cb + cb)) *
+                unit_bytes;
   f64x2 t0, t1, b0, b1;
   f64x4 D[UU][2];
   auto fetch = [&](f64x2& t, f64x2& b, int column) {
@@ -1415,7 +1417,7 @@ __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, uns
   };
   fetch(t0, b0, cb);
   while (left > 0) {
-    const int row_length = rb + 1;
+    const int row_length = triangular ? rb + 1 : n_cb;
     const int n = row_length - cb < left ? row_length - cb : left;
     left -= n;
     f64x2 e[4];
@@ -1533,7 +1535,14 @@ __global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(Fuse
     }
     const double total = n_cen + n_sat;
     norm = total * total;
-    if (wave == 0 && b0 < a.n_draws) a.ngal[b0] = total;
+    if (wave == 0 && b0 < a.n_draws) {
+      if (a.separate) {
+        a.ngal[2 * b0] = n_cen;
+        a.ngal[2 * b0 + 1] = n_sat;
+      } else {
+        a.ngal[b0] = total;
+      }
+    }
   }
 
   // ---- 2. quadratic form ----
@@ -1543,18 +1552,25 @@ __global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(Fuse
   {
     const int sub = wave >> 2, part = wave & 3;
     const unsigned off_a = lane * 16;
-    const double* dens_b = dens + kq * kLanes + sub * kQuadTile + 2 * c;   // + 4 col rows
-    const double* dens_e = dens + sub * kQuadTile + 2 * c;                  // + row i
+    // (the component's columns are density rows j_row0 ..., its rows i_row0 ...)
+    const double* dens_b =
+        dens + (a.part_j_row0[part] + kq) * kLanes + sub * kQuadTile + 2 * c;   // + 4 col rows
+    const double* dens_e = dens + a.part_i_row0[part] * kLanes + sub * kQuadTile + 2 * c;
     const __amdgpu_buffer_rsrc_t rs_t =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.table, 0, a.table_bytes, kBufferFlags);
     const int rb = a.part_rb0[part], cb = a.part_cb0[part], count = a.part_count[part];
+    const bool triangular = a.part_triangular[part] != 0;
+    const int n_cb = a.part_n_cb[part];
+    const unsigned unit_base = (unsigned)a.part_unit_base[part];
 #pragma unroll
     for (int p = 0; p < UP; ++p) {
       F[p][0][0] = F[p][0][1] = F[p][1][0] = F[p][1][1] = 0.0;
       if (2 * p + 1 < U)
-        fused_quad_pass<2>(rs_t, off_a + p * 1024, UP * 1024, dens_b, dens_e, rb, cb, count, F[p]);
+        fused_quad_pass<2>(rs_t, off_a + p * 1024, UP * 1024, dens_b, dens_e, rb, cb, count,
+                           triangular, n_cb, unit_base, F[p]);
       else
-        fused_quad_pass<1>(rs_t, off_a + p * 1024, UP * 1024, dens_b, dens_e, rb, cb, count, F[p]);
+        fused_quad_pass<1>(rs_t, off_a + p * 1024, UP * 1024, dens_b, dens_e, rb, cb, count,
+                           triangular, n_cb, unit_base, F[p]);
     }
   }
   __syncthreads();       // the densities are dead: their place takes the waves' sums
@@ -1570,6 +1586,31 @@ __global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(Fuse
   // ---- 3. the four quarters of every tile, normalisation, results ----
   set_priority((a.priority >> 4) & 3);
   double(*tile)[kLanes + 1] = (double(*)[kLanes + 1])table;
+  if (a.separate) {
+    // cen-cen = wave 0 of the tile, cen-sat = waves 1 + 2, sat-sat = wave 3, one component
+    // after the other through the results tile.  The reference forms every term / sum first
+    // and masks afterwards (tabcorr.py:653-681): with a non-finite pair-weight sum some term
+    // is inf / inf = NaN and NaN x False = NaN reaches every component.
+    const bool poisoned = !(fabs(norm) <= 1.79769313486231570815e308);
+    const int64_t n_valid = a.n_draws - col < kLanes ? a.n_draws - col : kLanes;
+    const int sub = lane >> 5, d = lane & 31;
+    for (int comp = 0; comp < 3; ++comp) {
+      __syncthreads();
+      for (int rr = wave; rr < a.n_r; rr += kFusedWaves) {
+        const double* first =
+            dens + ((4 * sub + (comp == 0 ? 0 : comp == 1 ? 1 : 3)) * (4 * U) + rr) * kQuadTile + d;
+        double sum = first[0];
+        if (comp == 1) sum += first[(4 * U) * kQuadTile];
+        tile[rr][lane] = poisoned ? __builtin_nan("") : sum / norm;
+      }
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < a.n_r * kLanes; idx += blockDim.x) {
+        const int dd = idx / a.n_r, rr = idx % a.n_r;
+        if (dd < n_valid) a.xi[((col + dd) * 3 + comp) * (int64_t)a.n_r + rr] = tile[rr][dd];
+      }
+    }
+    return;
+  }
   double* chi2_lds = table + 20 * (kLanes + 1);
   if (a.chi2 != nullptr) {
     const int count = a.n_r * (a.n_r + 1);

@@ -899,25 +899,46 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
   if (!t->quad || t->compute_dtype != TC_DTYPE_F64 || t->quad_total.d_table == nullptr)
     return false;
   if (t->quad_tiling.n_rtiles != 1 || t->n_r > 20 || t->chain || t->tuning.trace) return false;
-  if (flags & (TC_FLAG_SEPARATE_GAL_TYPE | TC_FLAG_LEAUTHAUD11)) return false;
+  if (flags & TC_FLAG_LEAUTHAUD11) return false;
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  if (separate) {
+    // cen-cen | two halves of cen-sat | sat-sat on the four waves of a 32-draw tile: both
+    // galaxy types present (equal numbers of bins, as a TabCorr table has them, balance the
+    // waves to within a block row); no likelihood of separated components
+    const tc::QuadLayout& layout = t->quad_by_type.layout;
+    if (t->quad_by_type.d_table == nullptr || layout.comps.size() != 3 ||
+        t->fuse_chi2_out != nullptr)
+      return false;
+    for (const tc::QuadComp& comp : layout.comps)
+      if (comp.n_units <= 0) return false;
+  }
   // (the decorated variants are compiled for the reference's default n_gauss_prim only)
   if ((flags & (TC_FLAG_ASSEMBIAS | TC_FLAG_MODULATE_WITH_CENOCC)) && n_gauss != 10) return false;
   if (t->quad_total.layout.comps.size() != 1 || !t->quad_total.layout.comps[0].triangular)
     return false;
-  if (fused_lds_bytes(t) > 160 * 1024 || n_gauss < 1) return false;
+  if (fused_lds_bytes(t, separate) > 160 * 1024 || n_gauss < 1) return false;
   // two workgroups per CU or not at all: with more than 80 KB of LDS each (more than 104 bins)
   // a CU holds one, its phases no longer overlap with a neighbour's, and the three kernels are
   // 10 % ahead (tools/r03_fused_bins.py, 10^4 draws, three kernels / one launch: G = 80 31.3 /
   // 27.7 us, 104 45.2 / 42.2, 112 50.7 / 56.0, 128 62.8 / 69.4, 200 135.5 / 149.3)
-  if (fused_lds_bytes(t) > 80 * 1024 && t->tuning.fused < 2) return false;
+  if (fused_lds_bytes(t, separate) > 80 * 1024 && t->tuning.fused < 2) return false;
   // calls that run alone on their lane (host-buffer API, pipeline off) keep the three kernels,
   // which spread one batch over the whole chip
   const bool alone = t->force_lane >= 0 || !t->tuning.pipeline || t->n_lanes == 1;
   return t->tuning.fused >= 2 || !alone;
 }
 
-int fused_lds_bytes(const tc_table* t) {
-  const int dens_rows = 4 * t->quad_total.layout.comps[0].n_rb;
+// Rows of the LDS density array: whole blocks of four covering every row a component reads.
+int fused_dens_rows(const tc_table* t, bool separate) {
+  if (!separate) return 4 * t->quad_total.layout.comps[0].n_rb;
+  int rows = 0;
+  for (const tc::QuadComp& comp : t->quad_by_type.layout.comps)
+    rows = std::max(rows, std::max(comp.i_bin0 + 4 * comp.n_rb, comp.j_bin0 + 4 * comp.n_cb));
+  return (rows + 3) / 4 * 4;
+}
+
+int fused_lds_bytes(const tc_table* t, bool separate) {
+  const int dens_rows = fused_dens_rows(t, separate);
   return (std::max(dens_rows * 64, tc::kFusedSlotDoubles) + tc::kFusedScratchDoubles) * 8;
 }
 
@@ -957,15 +978,45 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   Quadrature* q = nullptr;
   int status = get_quadrature(t, n_gauss, &q);
   if (status != TC_OK) return status;
-  const tc::QuadComp& comp = t->quad_total.layout.comps[0];
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  const QuadTable& q_table = separate ? t->quad_by_type : t->quad_total;
   tc::FusedArgs fa{};
   fa.theta = theta_device;
   fa.n_theta = n_theta;
   fa.n_bins = t->n_bins;
   fa.n_central = t->plan.n_central;
   fa.n_gauss = n_gauss;
-  fa.dens_rows = 4 * comp.n_rb;
-  tc::triangle_parts(comp.n_rb, 4, fa.part_rb0, fa.part_cb0, fa.part_count);
+  fa.dens_rows = fused_dens_rows(t, separate);
+  fa.separate = separate ? 1 : 0;
+  if (!separate) {
+    const tc::QuadComp& comp = q_table.layout.comps[0];
+    tc::triangle_parts(comp.n_rb, 4, fa.part_rb0, fa.part_cb0, fa.part_count);
+    for (int part = 0; part < 4; ++part) {
+      fa.part_triangular[part] = 1;
+      fa.part_n_cb[part] = comp.n_cb;
+      fa.part_i_row0[part] = comp.i_bin0;
+      fa.part_j_row0[part] = comp.j_bin0;
+      fa.part_unit_base[part] = (int)comp.unit_base;
+    }
+  } else {
+    // wave 0: cen-cen, waves 1 and 2: the halves of cen-sat (whole units, row-major), wave 3:
+    // sat-sat
+    const int comp_of[4] = {0, 1, 1, 2};
+    for (int part = 0; part < 4; ++part) {
+      const tc::QuadComp& comp = q_table.layout.comps[comp_of[part]];
+      int64_t begin = 0, end = comp.n_units;
+      if (part == 1) end = comp.n_units / 2;
+      if (part == 2) begin = comp.n_units / 2;
+      fa.part_triangular[part] = comp.triangular;
+      fa.part_n_cb[part] = comp.n_cb;
+      fa.part_i_row0[part] = comp.i_bin0;
+      fa.part_j_row0[part] = comp.j_bin0;
+      fa.part_unit_base[part] = (int)comp.unit_base;
+      fa.part_rb0[part] = comp.triangular ? 0 : (int)(begin / comp.n_cb);
+      fa.part_cb0[part] = comp.triangular ? 0 : (int)(begin % comp.n_cb);
+      fa.part_count[part] = (int)(end - begin);
+    }
+  }
   fa.n_r = t->n_r;
   fa.priority = (t->tuning.prio_fused & 3) | ((t->tuning.prio_fused_occ & 3) << 2) |
                 ((t->tuning.prio_fused_out & 3) << 4);
@@ -977,9 +1028,9 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   fa.percentile = (const double*)t->d_percentile;
   fa.split = 0.5;
   fa.math_table = (const double*)t->d_math_table;
-  fa.table = (const char*)t->quad_total.d_table + (size_t)comp.unit_base *
-                 (size_t)((t->quad_tiling.n_u + 1) / 2) * 1024;
-  fa.table_bytes = (uint32_t)((size_t)comp.n_units * (size_t)((t->quad_tiling.n_u + 1) / 2) * 1024);
+  fa.table = q_table.d_table;
+  fa.table_bytes =
+      (uint32_t)((size_t)q_table.layout.n_units * (size_t)((t->quad_tiling.n_u + 1) / 2) * 1024);
   fa.ngal = ngal_device;
   fa.xi = xi_device;
   t->chi2_fused = false;
@@ -989,7 +1040,7 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
     fa.xi = nullptr;
     t->chi2_fused = true;
   }
-  const int lds = fused_lds_bytes(t);
+  const int lds = fused_lds_bytes(t, separate);
   const dim3 grid((unsigned)((n_draws + 63) / 64)), block(64 * tc::kFusedWaves);
   hipEvent_t k0 = nullptr, k1 = nullptr;
   status = next_kernel_events(t, &k0, &k1);

@@ -286,7 +286,8 @@ int tc_predict_zheng07_batch_device(tc_table* t, const double* theta_device,
     const int64_t ldb = (n + 63) / 64 * 64;
     if (fused_eligible(t, n, n_gauss, flags)) {
       status = run_fused(t, theta_device + begin * n_theta, n_theta, n, n_gauss, flags,
-                         ngal_device + begin, xi_device + begin * t->n_r);
+                         ngal_device + begin * (separate ? 2 : 1),
+                         xi_device + begin * n_comp * t->n_r);
       if (status != TC_OK) return status;
       continue;
     }

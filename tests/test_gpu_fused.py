@@ -180,7 +180,10 @@ def test_fused_is_not_taken_where_it_does_not_apply():
     force_fused(halotab)
     halotab.predict_batch(theta)
     assert last_launch(halotab)[1:3] == (8, 0)
-    halotab.predict_batch(theta, separate_gal_type=True)
+    # (the Leauthaud11 family keeps the three kernels)
+    from tabcorr_amd import Leauthaud11Model
+    draws = np.tile(Leauthaud11Model().device_theta(), (100, 1))
+    halotab.predict_batch(draws, family='leauthaud11')
     assert last_launch(halotab)[2] > 0
 
 
@@ -304,3 +307,65 @@ def test_fused_matches_the_references_own_tables():
     assert_rel(xi, data['xi'], RTOL)
     ngal, xi = halotab.predict_batch(data['theta'])
     assert_rel(xi, data['plain_xi'], RTOL)
+
+
+@pytest.mark.parametrize('n_prim, n_sec, n_r, n_draws, kwargs', [
+    (50, 1, 19, 1000, {}),                                  # BASELINE configs[1]'s table
+    (7, 1, 3, 65, {}),                                      # 7 + 7 bins: padded blocks
+    (13, 2, 12, 129, {'modulate_with_cenocc': True}),
+    (9, 1, 20, 64, {'n_gauss_prim': 5}),
+    (6, 2, 5, 200, {'assembias': True}),
+])
+def test_fused_separate_gal_type(n_prim, n_sec, n_r, n_draws, kwargs):
+    """cen-cen / cen-sat / sat-sat through the one-launch path (wave 0 of a tile the cen-cen
+    triangle, waves 1 and 2 the halves of the cen-sat rectangle, wave 3 the sat-sat triangle)
+    against the oracle; the components add up to the total."""
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    rng = np.random.default_rng(n_draws)
+    table = synthetic.synthetic_table(n_prim, n_sec, (n_r, ), 'auto', seed=n_prim)
+    theta = synthetic.zheng07_draws(n_draws, seed=n_draws)
+    kwargs = dict(kwargs)
+    strengths = rng.uniform(-1.2, 1.2, (n_draws, 2)) if kwargs.pop('assembias', False) else None
+    expect = oracle.predict_zheng07_batch(
+        table, theta, separate_gal_type=True, n_gauss_prim=kwargs.get('n_gauss_prim', 10),
+        modulate_with_cenocc=kwargs.get('modulate_with_cenocc', False), assembias=strengths)
+    batch = theta if strengths is None else np.hstack([theta, strengths])
+    if strengths is not None:
+        kwargs['assembias'] = True
+    halotab = make_tabcorr(table)
+    force_fused(halotab)
+    ngal, xi = halotab.predict_batch(batch, separate_gal_type=True, **kwargs)
+    assert last_launch(halotab)[1:3] == (8, 0), 'the fused kernel did not run'
+    assert list(xi.keys()) == list(expect[1].keys())
+    scale = max(np.max(np.abs(v)) for v in expect[1].values())
+    for key in expect[0]:
+        assert_rel(ngal[key], expect[0][key], RTOL, key)
+    for key in expect[1]:
+        np.testing.assert_allclose(xi[key], expect[1][key], rtol=RTOL, atol=1e-13 * scale,
+                                   err_msg=key)
+    total_ngal, total_xi = halotab.predict_batch(batch, **kwargs)
+    assert_rel(sum(ngal.values()), total_ngal, 1e-12)
+    np.testing.assert_allclose(sum(xi.values()), total_xi, rtol=1e-11, atol=1e-13 * scale)
+
+
+def test_fused_separate_matches_golden():
+    data = load_golden('bolplanck_wp')
+    halotab = make_tabcorr(table_from_golden(data))
+    force_fused(halotab)
+    ngal, xi = halotab.predict_batch(data['theta'], separate_gal_type=True)
+    assert last_launch(halotab)[1:3] == (8, 0)
+    for key in ngal:
+        assert_rel(ngal[key], data['ngal_sep_' + key], RTOL, key)
+    for key in xi:
+        assert_rel(xi[key], data['xi_sep_' + key], RTOL, key)
+    # NaN parameters poison every component, as the reference's arithmetic does
+    theta = np.array(data['theta'][:8])
+    theta[3, 0] = np.nan
+    with np.errstate(all='ignore'):
+        ngal, xi = halotab.predict_batch(theta, separate_gal_type=True)
+        force_fused(halotab, False)
+        ngal3, xi3 = halotab.predict_batch(theta, separate_gal_type=True)
+    for key in xi:
+        assert np.array_equal(np.isnan(xi[key]), np.isnan(xi3[key])), key
+        assert np.all(np.isnan(xi[key][3]))
