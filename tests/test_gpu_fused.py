@@ -219,6 +219,17 @@ def test_fused_at_the_benchmarked_batch_size():
     assert last_launch(halotab)[1:3] == (8, 0)
     assert_rel(n_chi, ngal3, 1e-13)
     assert_rel(chi2, want, 1e-9)
+    # separated by galaxy type, asynchronously: one launch as well
+    n_sep, x_sep = halotab.predict_batch_async(theta, separate_gal_type=True).wait()
+    assert last_launch(halotab)[1:3] == (8, 0)
+    n_sep3, x_sep3 = halotab.predict_batch(theta, separate_gal_type=True)
+    assert last_launch(halotab)[2] > 0
+    scale = np.max(np.abs(xi3))
+    for key in x_sep3:
+        np.testing.assert_allclose(x_sep[key], x_sep3[key], rtol=1e-11, atol=1e-13 * scale)
+    for key in n_sep3:
+        assert_rel(n_sep[key], n_sep3[key], 1e-13)
+    np.testing.assert_allclose(sum(x_sep.values()), xi3, rtol=1e-11, atol=1e-13 * scale)
 
 
 @pytest.mark.parametrize('modulate, assembias', [(True, False), (False, True), (True, True)])
