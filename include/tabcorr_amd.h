@@ -284,13 +284,13 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 tc_table_synchronize (or gather with tc_comm_gather, which waits for every
  *                 lane); 1: their finalisations are chained so that results appear in call
  *                 order (0.3 - 3 us per 10^4-draw step).
- *   "fused"       1 (default): pipelined device-pointer and asynchronous calls of
- *                 "fused_min_draws" .. "fused_max_draws" draws (7168 .. 30720; asynchronous
- *                 calls: no upper bound) that qualify
+ *   "fused"       1 (default): pipelined device-pointer and asynchronous calls that qualify
  *                 (mode auto, at most 20 r values and 104 bins, Zheng07 family, total or
- *                 separated by galaxy type)
- *                 run as ONE launch per batch, a workgroup carrying 64 draws from the
- *                 parameters to the results; 0: always occupation, contraction, finalisation
+ *                 separated by galaxy type) run as ONE launch per batch, a workgroup carrying
+ *                 64 draws from the parameters to the results, for batches of
+ *                 "fused_min_draws" .. "fused_max_draws" draws (default 0 = chosen per table:
+ *                 512 for small tables, ~7000 for 100 bins x 19 r values; 30720; asynchronous
+ *                 calls: no upper bound); 0: always occupation, contraction, finalisation
  *                 kernels; 2: one launch also for calls that run alone on their lane.
  *   "single_draw" 1 (default): an un-batched predict() goes through one launch.
  *   "trace"       developer timelines (developer builds only, tabcorr_amd_testing.h). */

@@ -262,7 +262,7 @@ struct Tuning {
   // over the whole chip.  Asynchronous host calls (us per call, tools/r03_async.py): 6144 draws
   // 38.8 / 41.6, 10^4 58 / 47.6, 20 000 93.7 / 82.6, 40 000 176 / 162: no upper bound there.
   int fused = 1;
-  int fused_min_draws = 7168;
+  int fused_min_draws = 0;      // 0: chosen per table (launch.hip: fused_eligible)
   int fused_max_draws = 30720;
   int prio_fused = 1, prio_fused_occ = 2, prio_fused_out = 3;   // phases 2, 1, 3
   int skip_occ = 0, skip_finalize = 0;   // diagnosis (developer builds only)

@@ -893,8 +893,7 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
 bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags) {
   // (asynchronous host calls: one command per call in the lane's chain pays for any size from
   // the lower bound on -- 20 000 draws 93.7 -> 82.6 us, 40 000 176 -> 162 us per call)
-  if (t->tuning.fused == 0 || n_draws < t->tuning.fused_min_draws ||
-      (n_draws > t->tuning.fused_max_draws && t->async_lane < 0))
+  if (t->tuning.fused == 0 || (n_draws > t->tuning.fused_max_draws && t->async_lane < 0))
     return false;
   if (!t->quad || t->compute_dtype != TC_DTYPE_F64 || t->quad_total.d_table == nullptr)
     return false;
@@ -922,6 +921,26 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
   // 10 % ahead (tools/r03_fused_bins.py, 10^4 draws, three kernels / one launch: G = 80 31.3 /
   // 27.7 us, 104 45.2 / 42.2, 112 50.7 / 56.0, 128 62.8 / 69.4, 200 135.5 / 149.3)
   if (fused_lds_bytes(t, separate) > 80 * 1024 && t->tuning.fused < 2) return false;
+  // Smallest batch: a launch lasts as long as one workgroup does, whatever the batch, so the
+  // one-launch form pays from the batch size on at which four lanes of such launches beat the
+  // three kernels (which spread any batch over the whole chip).  Estimated duration of a
+  // workgroup alone on its CU (us): 5 + 10 (G / 100) (n_gauss / 10) [occupations] + 60 (units /
+  // 325) (U / 5) [matrix work]: 75 for BASELINE configs[1]'s table, 33 for the reference's
+  // example table (G = 60), 27 for G = 100 with three r values.  Measured crossovers
+  // (tools/r03_fused_scan.py with N_PRIM / N_R): estimates up to 28 us win from 512 draws on
+  // (G = 40: 5.8 against 11.0 us per call at 512 draws; G = 100 with three r values: 8.5 /
+  // 12.0), longer workgroups from ~90 draws per estimated microsecond (G = 60: 3000-4000;
+  // G = 100, R = 8: 4096; G = 80: 5000; G = 100, R = 19: 6500-7000) -- below that both forms
+  // are bound by the host thread that queues them (10-13 us per call) and differ by noise.
+  {
+    const tc::QuadLayout& layout = separate ? t->quad_by_type.layout : t->quad_total.layout;
+    const double estimate = 5.0 + 10.0 * (t->n_bins / 100.0) * (n_gauss / 10.0) +
+                            60.0 * ((double)layout.n_units / 325.0) * (t->quad_tiling.n_u / 5.0);
+    const int64_t min_draws = t->tuning.fused_min_draws > 0 ? t->tuning.fused_min_draws
+                              : estimate <= 28.0            ? 512
+                                                            : (int64_t)(90.0 * estimate);
+    if (n_draws < min_draws) return false;
+  }
   // calls that run alone on their lane (host-buffer API, pipeline off) keep the three kernels,
   // which spread one batch over the whole chip
   const bool alone = t->force_lane >= 0 || !t->tuning.pipeline || t->n_lanes == 1;

@@ -816,7 +816,7 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     TC_CHECK(value >= 0 && value <= 2, "fused must be 0, 1 or 2");
     t->tuning.fused = value;
   } else if (key == "fused_min_draws" || key == "fused_max_draws") {
-    TC_CHECK(value >= 1, "%s must be positive", name);
+    TC_CHECK(value >= (key == "fused_min_draws" ? 0 : 1), "%s must be positive", name);
     (key == "fused_min_draws" ? t->tuning.fused_min_draws : t->tuning.fused_max_draws) = value;
   } else if (key == "prio_fused") {
     t->tuning.prio_fused = value & 3;
