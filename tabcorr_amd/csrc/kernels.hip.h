@@ -401,6 +401,81 @@ __device__ inline double smhm_log_mstar(const double* table, const fm::Consts& k
   return x + s.log_m0 - s.two_log_h;
 }
 
+// Per-draw constants of the Leauthaud11 occupation functions (theta columns: see above) and
+// the mean occupation of one bin: shared by occ_leauthaud11_kernel and predict_fused_kernel.
+struct LeauthaudDraw {
+  SmhmSetup smhm;
+  double inv_scatter, threshold, alphasat, log2_msat, cut;
+};
+
+__device__ inline LeauthaudDraw prepare_leauthaud(const double* table, const fm::Consts& kc,
+                                                  const double* th) {
+  constexpr double kLog2Of10 = 3.32192809488736234787, kLog10Of2 = 0.30102999566398119521;
+  constexpr double kLog2E = 1.44269504088896340736;
+  const double log_m0 = th[0], log_m1 = th[1], beta = th[2], delta = th[3], gamma = th[4];
+  const double scatter = th[5], alphasat = th[6], bsat = th[7], betasat = th[8];
+  const double bcut = th[9], betacut = th[10], threshold = th[11], h = th[12];
+  const double h_sat = th[13];
+  const double log_h = fm::log2_fast(table, kc, h > 1e-300 ? h : 1e-300) * kLog10Of2;
+  const double log_hs = fm::log2_fast(table, kc, h_sat > 1e-300 ? h_sat : 1e-300) * kLog10Of2;
+  // halo mass of the threshold: the forward relation, then the knee in units of 1e12
+  const double x_t = threshold + 2.0 * log_h - log_m0;
+  const double a_t = fm::exp10_fast(table, kc, delta * x_t);
+  const double b_t = fm::exp10_fast(table, kc, -gamma * x_t);
+  const double log_knee = log_m1 + beta * x_t + a_t / (1.0 + b_t) - 0.5 - log_h + log_hs - 12.0;
+  // log2 M_sat and M_cut * log2 e (bsat <= 0 or bcut < 0 have no real power law: NaN)
+  const double log2_msat =
+      bsat > 0.0 ? fm::log2_fast(table, kc, bsat) + (12.0 + betasat * log_knee) * kLog2Of10
+                 : __builtin_nan("");
+  const double mcut =
+      bcut > 0.0 ? fm::exp2_fast(table, kc, fm::log2_fast(table, kc, bcut) +
+                                                (12.0 + betacut * log_knee) * kLog2Of10)
+                 : (bcut == 0.0 ? 0.0 : __builtin_nan(""));
+  LeauthaudDraw d;
+  d.smhm.log_m0 = log_m0;
+  d.smhm.beta = beta;
+  d.smhm.delta = delta;
+  d.smhm.gamma = gamma;
+  d.smhm.offset = log_h + 0.5 - log_m1;
+  d.smhm.two_log_h = 2.0 * log_h;
+  d.inv_scatter = 1.0 / (1.41421356237309504880 * scatter);
+  d.threshold = threshold;
+  d.alphasat = alphasat;
+  d.log2_msat = log2_msat - log_hs * kLog2Of10;     // (M h_s / M_sat): log2 M - this
+  d.cut = -mcut * kLog2E / h_sat;                   // exp(-M_cut / (M h_s)) = 2^(this / M)
+  return d;
+}
+
+template <bool MODULATE>
+__device__ __forceinline__ double occ_bin_leauthaud11(const double* table, const fm::Consts& kc,
+                                                      int g, int n_gauss, bool central,
+                                                      sc_f64 log_m, sc_f64 mass, sc_f64 weight,
+                                                      const LeauthaudDraw& d) {
+  constexpr double kLog2Of10 = 3.32192809488736234787;
+  double acc = 0.0;
+  for (int k = 0; k < n_gauss; ++k) {
+    const double lm = log_m[g * n_gauss + k];
+    double n_cen = 1.0;
+    if (central || MODULATE) {
+      const double log_mstar = smhm_log_mstar(table, kc, d.smhm, lm);
+      const double za = (d.threshold - log_mstar) * d.inv_scatter;
+      n_cen = fma(-0.5, fm::erf_fast(table, kc, za), 0.5);
+      n_cen = za != za ? za : n_cen;      // NaN parameters stay NaN (erf_fast clamps)
+    }
+    double n = n_cen;
+    if (!central) {
+      const double m = mass[g * n_gauss + k];
+      // (M h / M_sat)^alphasat exp(-M_cut / (M h)) as one power of two
+      const double z = fma(d.alphasat, lm * kLog2Of10 - d.log2_msat, d.cut / m);
+      n = fm::exp2_fast(table, kc, z);
+      n = z != z ? z : n;                 // NaN parameters stay NaN (exp2_fast clamps)
+      if (MODULATE) n *= n_cen;
+    }
+    acc = fma(weight[g * n_gauss + k], n, acc);
+  }
+  return acc;
+}
+
 // Same work decomposition, outputs and launch geometry as occ_zheng07_kernel.
 template <bool MODULATE>
 __global__ __launch_bounds__(kOccWaves * kLanes) void occ_leauthaud11_kernel(OccArgs a) {
@@ -432,76 +507,38 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_leauthaud11_kernel(Occ
     const int g_begin = split * per_block;
     const int g_end = g_begin + per_block < a.n_bins ? g_begin + per_block : a.n_bins;
     if (wave == 0) {
-      const double* th = a.theta + b * a.n_theta;
-      const double log_m0 = th[0], log_m1 = th[1], beta = th[2], delta = th[3], gamma = th[4];
-      const double scatter = th[5], alphasat = th[6], bsat = th[7], betasat = th[8];
-      const double bcut = th[9], betacut = th[10], threshold = th[11], h = th[12];
-      const double h_sat = th[13];
-      const double log_h = fm::log2_fast(table, kc, h > 1e-300 ? h : 1e-300) * kLog10Of2;
-      const double log_hs =
-          fm::log2_fast(table, kc, h_sat > 1e-300 ? h_sat : 1e-300) * kLog10Of2;
-      // halo mass of the threshold: the forward relation, then the knee in units of 1e12
-      const double x_t = threshold + 2.0 * log_h - log_m0;
-      const double a_t = fm::exp10_fast(table, kc, delta * x_t);
-      const double b_t = fm::exp10_fast(table, kc, -gamma * x_t);
-      const double log_knee =
-          log_m1 + beta * x_t + a_t / (1.0 + b_t) - 0.5 - log_h + log_hs - 12.0;
-      // log2 M_sat and M_cut * log2 e (bsat <= 0 or bcut < 0 have no real power law: NaN)
-      const double log2_msat =
-          bsat > 0.0 ? fm::log2_fast(table, kc, bsat) + (12.0 + betasat * log_knee) * kLog2Of10
-                     : __builtin_nan("");
-      const double mcut =
-          bcut > 0.0 ? fm::exp2_fast(table, kc, fm::log2_fast(table, kc, bcut) +
-                                                    (12.0 + betacut * log_knee) * kLog2Of10)
-                     : (bcut == 0.0 ? 0.0 : __builtin_nan(""));
-      prm[0][lane] = log_m0;
-      prm[1][lane] = beta;
-      prm[2][lane] = delta;
-      prm[3][lane] = gamma;
-      prm[4][lane] = log_h + 0.5 - log_m1;
-      prm[5][lane] = 2.0 * log_h;
-      prm[6][lane] = 1.0 / (1.41421356237309504880 * scatter);
-      prm[7][lane] = threshold;
-      prm[8][lane] = alphasat;
-      prm[9][lane] = log2_msat - log_hs * kLog2Of10;     // (M h_s / M_sat): log2 M - this
-      prm[10][lane] = -mcut * kLog2E / h_sat;             // exp(-M_cut / (M h_s)) = 2^(this / M)
-      prm[11][lane] = h_sat;
+      const LeauthaudDraw d = prepare_leauthaud(table, kc, a.theta + b * a.n_theta);
+      prm[0][lane] = d.smhm.log_m0;
+      prm[1][lane] = d.smhm.beta;
+      prm[2][lane] = d.smhm.delta;
+      prm[3][lane] = d.smhm.gamma;
+      prm[4][lane] = d.smhm.offset;
+      prm[5][lane] = d.smhm.two_log_h;
+      prm[6][lane] = d.inv_scatter;
+      prm[7][lane] = d.threshold;
+      prm[8][lane] = d.alphasat;
+      prm[9][lane] = d.log2_msat;
+      prm[10][lane] = d.cut;
     }
     __syncthreads();
-    SmhmSetup smhm;
-    smhm.log_m0 = prm[0][lane];
-    smhm.beta = prm[1][lane];
-    smhm.delta = prm[2][lane];
-    smhm.gamma = prm[3][lane];
-    smhm.offset = prm[4][lane];
-    smhm.two_log_h = prm[5][lane];
-    const double inv_scatter = prm[6][lane], threshold = prm[7][lane];
-    const double alphasat = prm[8][lane], log2_msat = prm[9][lane], cut = prm[10][lane];
+    LeauthaudDraw draw;
+    draw.smhm.log_m0 = prm[0][lane];
+    draw.smhm.beta = prm[1][lane];
+    draw.smhm.delta = prm[2][lane];
+    draw.smhm.gamma = prm[3][lane];
+    draw.smhm.offset = prm[4][lane];
+    draw.smhm.two_log_h = prm[5][lane];
+    draw.inv_scatter = prm[6][lane];
+    draw.threshold = prm[7][lane];
+    draw.alphasat = prm[8][lane];
+    draw.log2_msat = prm[9][lane];
+    draw.cut = prm[10][lane];
 
     double sum_cen = 0.0, sum_sat = 0.0;
     for (int g = g_begin + wave; g < g_end; g += kOccWaves) {
       const bool central = g < a.n_central;
-      double acc = 0.0;
-      for (int k = 0; k < n_gauss; ++k) {
-        const double lm = log_m[g * n_gauss + k];
-        double n_cen = 1.0;
-        if (central || modulate) {
-          const double log_mstar = smhm_log_mstar(table, kc, smhm, lm);
-          const double za = (threshold - log_mstar) * inv_scatter;
-          n_cen = fma(-0.5, fm::erf_fast(table, kc, za), 0.5);
-          n_cen = za != za ? za : n_cen;      // NaN parameters stay NaN (erf_fast clamps)
-        }
-        double n = n_cen;
-        if (!central) {
-          const double m = mass[g * n_gauss + k];
-          // (M h / M_sat)^alphasat exp(-M_cut / (M h)) as one power of two
-          const double z = fma(alphasat, lm * kLog2Of10 - log2_msat, cut / m);
-          n = fm::exp2_fast(table, kc, z);
-          n = z != z ? z : n;                 // NaN parameters stay NaN (exp2_fast clamps)
-          if (modulate) n *= n_cen;
-        }
-        acc = fma(weight[g * n_gauss + k], n, acc);
-      }
+      const double acc = occ_bin_leauthaud11<MODULATE>(table, kc, g, n_gauss, central, log_m,
+                                                       mass, weight, draw);
       if (a.occupation != nullptr && b0 < a.n_draws)
         a.occupation[b0 * a.n_bins + perm[g]] = acc;
       const double dens = acc * n_h[g];
