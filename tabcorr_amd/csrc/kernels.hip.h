@@ -1409,8 +1409,9 @@ __global__ __launch_bounds__(1024) void finalize_quad_kernel(FinalizeQuadArgs a)
 //   3. adds the four quarters through LDS, normalises and writes ngal, xi (or the likelihood).
 // Workgroups of different launches share a CU, so one's occupation phase (vector ALU) runs
 // under the other's matrix instructions; there is no inter-workgroup step.
-// Mode auto, total correlation function, one r tile, the Zheng07 family (with its Heaviside
-// assembly bias / modulate_with_cenocc variants).
+// Mode auto, total correlation function or its three components, one r tile; the Zheng07
+// family (with its Heaviside assembly bias / modulate_with_cenocc variants) or, LEAUTHAUD, the
+// Leauthaud11 family.
 constexpr int kFusedSlotDoubles = kFusedWaves * 4 * kQuadMaxU * kQuadTile;   // phase 3
 constexpr int kFusedScratchDoubles = fm::kTableDoubles + 2 * kFusedWaves * kLanes;
 static_assert(kFusedWaves == 8, "two 32-draw tiles x four quarters of the triangle");
@@ -1496,8 +1497,9 @@ __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, uns
   }
 }
 
-template <int NGAUSS, int U, bool ASSEMBIAS, bool MODULATE>
+template <int NGAUSS, int U, bool ASSEMBIAS, bool MODULATE, bool LEAUTHAUD = false>
 __global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(FusedArgs a) {
+  static_assert(!LEAUTHAUD || (NGAUSS == 0 && !ASSEMBIAS), "Leauthaud11: any n_gauss, undecorated");
   constexpr int UP = (U + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) double fused_lds[];
   // region B: densities, later the waves' sums; region A: math table, later the results tile
@@ -1532,8 +1534,14 @@ __global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(Fuse
   {
     // (every wave sets up its lanes' draws itself: cheaper than a hand-over through LDS)
     const double* th = a.theta + b * a.n_theta;
-    const DrawSetup d = prepare_draw(table, kc, th[0], th[1], th[2], th[3], th[4],
-                                     ASSEMBIAS ? th[5] : 0.0, ASSEMBIAS ? th[6] : 0.0);
+    // (Leauthaud11: the draw's constants in the place of the Zheng07 ones, which are then
+    // harmless finite numbers the compiler drops with the unused branch)
+    LeauthaudDraw ld;
+    if (LEAUTHAUD) ld = prepare_leauthaud(table, kc, th);
+    const DrawSetup d =
+        LEAUTHAUD ? prepare_draw(table, kc, 12.0, 1.0, 12.0, 13.0, 1.0, 0.0, 0.0)
+                  : prepare_draw(table, kc, th[0], th[1], th[2], th[3], th[4],
+                                 ASSEMBIAS ? th[5] : 0.0, ASSEMBIAS ? th[6] : 0.0);
     DrawParams dp;
     dp.log_m_min = d.log_m_min;
     dp.inv_sigma = d.inv_sigma;
@@ -1555,8 +1563,11 @@ __global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(Fuse
     for (int g = wave; g < a.n_bins; g += kFusedWaves) {
       const bool central = g < a.n_central;
       const bool above = ASSEMBIAS ? percentile[g] > a.split : false;
-      const double acc = occ_bin_zheng07<NGAUSS, ASSEMBIAS, MODULATE>(
-          table, kc, g, n_gauss, central, above, log_m, mass, weight, dp, f1, f2);
+      const double acc =
+          LEAUTHAUD ? occ_bin_leauthaud11<MODULATE>(table, kc, g, n_gauss, central, log_m, mass,
+                                                    weight, ld)
+                    : occ_bin_zheng07<NGAUSS, ASSEMBIAS, MODULATE>(
+                          table, kc, g, n_gauss, central, above, log_m, mass, weight, dp, f1, f2);
       const double value = acc * n_h[g];
       dens[g * kLanes + lane] = value;
       if (central) sum_cen += value; else sum_sat += value;

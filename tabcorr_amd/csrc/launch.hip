@@ -888,8 +888,8 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   return TC_OK;
 }
 
-// One launch per slab of draws (predict_fused_kernel): plain Zheng07, total correlation
-// function, float64 quadratic form with one r tile, densities of 64 draws within the LDS.
+// One launch per slab of draws (predict_fused_kernel): float64 quadratic form with one r tile,
+// densities of 64 draws within the LDS.
 bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags) {
   // (asynchronous host calls: one command per call in the lane's chain pays for any size from
   // the lower bound on -- 20 000 draws 93.7 -> 82.6 us, 40 000 176 -> 162 us per call)
@@ -898,7 +898,7 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
   if (!t->quad || t->compute_dtype != TC_DTYPE_F64 || t->quad_total.d_table == nullptr)
     return false;
   if (t->quad_tiling.n_rtiles != 1 || t->n_r > 20 || t->chain || t->tuning.trace) return false;
-  if (flags & TC_FLAG_LEAUTHAUD11) return false;
+  const bool leauthaud = (flags & TC_FLAG_LEAUTHAUD11) != 0;
   const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
   if (separate) {
     // cen-cen | two halves of cen-sat | sat-sat on the four waves of a 32-draw tile: both
@@ -912,7 +912,8 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
       if (comp.n_units <= 0) return false;
   }
   // (the decorated variants are compiled for the reference's default n_gauss_prim only)
-  if ((flags & (TC_FLAG_ASSEMBIAS | TC_FLAG_MODULATE_WITH_CENOCC)) && n_gauss != 10) return false;
+  if (!leauthaud && (flags & (TC_FLAG_ASSEMBIAS | TC_FLAG_MODULATE_WITH_CENOCC)) && n_gauss != 10)
+    return false;
   if (t->quad_total.layout.comps.size() != 1 || !t->quad_total.layout.comps[0].triangular)
     return false;
   if (fused_lds_bytes(t, separate) > 160 * 1024 || n_gauss < 1) return false;
@@ -936,7 +937,15 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
     const tc::QuadLayout& layout = separate ? t->quad_by_type.layout : t->quad_total.layout;
     const double estimate = 5.0 + 10.0 * (t->n_bins / 100.0) * (n_gauss / 10.0) +
                             60.0 * ((double)layout.n_units / 325.0) * (t->quad_tiling.n_u / 5.0);
+    // Leauthaud11 (a Newton inverse of the stellar-to-halo mass relation per central node: the
+    // occupations outweigh the matrix work and spread better over the chip as a kernel of their
+    // own): tools/r03_fused_leauthaud.py, us per step, three kernels / one launch: G = 100: 4000
+    // draws 57.3 / 88.7, 10^4 126.0 / 114.5; G = 60: 4000 38.4 / 49.9, 10^4 73.0 / 65.2; with
+    // modulate_with_cenocc (the inverse at the satellites' nodes too) never ahead: 10^4 draws
+    // 183.4 / 188.1 and 106.0 / 106.0 -- only when forced.
+    if (leauthaud && (flags & TC_FLAG_MODULATE_WITH_CENOCC) && t->tuning.fused < 2) return false;
     const int64_t min_draws = t->tuning.fused_min_draws > 0 ? t->tuning.fused_min_draws
+                              : leauthaud                   ? 8192
                               : estimate <= 28.0            ? 512
                                                             : (int64_t)(90.0 * estimate);
     if (n_draws < min_draws) return false;
@@ -962,7 +971,7 @@ int fused_lds_bytes(const tc_table* t, bool separate) {
 }
 
 namespace {
-template <int NG, bool AB, bool MO>
+template <int NG, bool AB, bool MO, bool LE = false>
 int launch_fused(int device, int n_u, dim3 grid, dim3 block, int lds, hipStream_t stream,
                  hipEvent_t k0, hipEvent_t k1, const tc::FusedArgs& fa) {
   switch (n_u) {
@@ -971,11 +980,11 @@ int launch_fused(int device, int n_u, dim3 grid, dim3 block, int lds, hipStream_
     /* (the attribute belongs to the function ON a device: once per device) */                \
     static bool limit_set[64] = {};                                                           \
     if (lds > 64 * 1024 && !(device >= 0 && device < 64 && limit_set[device])) {              \
-      TC_HIP(hipFuncSetAttribute((const void*)tc::predict_fused_kernel<NG, N, AB, MO>,        \
+      TC_HIP(hipFuncSetAttribute((const void*)tc::predict_fused_kernel<NG, N, AB, MO, LE>,    \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));    \
       if (device >= 0 && device < 64) limit_set[device] = true;                               \
     }                                                                                         \
-    hipExtLaunchKernelGGL((tc::predict_fused_kernel<NG, N, AB, MO>), grid, block, lds,        \
+    hipExtLaunchKernelGGL((tc::predict_fused_kernel<NG, N, AB, MO, LE>), grid, block, lds,    \
                           stream, k0, k1, 0, fa);                                             \
     break;                                                                                    \
   }
@@ -1066,7 +1075,10 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   if (status != TC_OK) return status;
   const bool assembias = (flags & TC_FLAG_ASSEMBIAS) != 0;
   const bool modulate = (flags & TC_FLAG_MODULATE_WITH_CENOCC) != 0;
-  if (n_gauss != 10)
+  if (flags & TC_FLAG_LEAUTHAUD11)
+    status = modulate ? launch_fused<0, false, true, true>(t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa)
+                      : launch_fused<0, false, false, true>(t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+  else if (n_gauss != 10)
     status = launch_fused<0, false, false>(t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
   else if (!assembias && !modulate)
     status = launch_fused<10, false, false>(t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);

@@ -180,11 +180,90 @@ def test_fused_is_not_taken_where_it_does_not_apply():
     force_fused(halotab)
     halotab.predict_batch(theta)
     assert last_launch(halotab)[1:3] == (8, 0)
-    # (the Leauthaud11 family keeps the three kernels)
-    from tabcorr_amd import Leauthaud11Model
-    draws = np.tile(Leauthaud11Model().device_theta(), (100, 1))
-    halotab.predict_batch(draws, family='leauthaud11')
+    # (Heaviside assembly bias with another n_gauss_prim than the reference's default keeps the
+    # three kernels)
+    decorated = np.hstack([theta, np.full((100, 2), 0.3)])
+    halotab.predict_batch(decorated, assembias=True, n_gauss_prim=7)
     assert last_launch(halotab)[2] > 0
+
+
+@pytest.mark.parametrize('name', ['leauthaud11_bolplanck_wp', 'leauthaud11_synthetic'])
+def test_fused_leauthaud11(name):
+    """The Leauthaud11 family (Newton inverse of the stellar-to-halo mass relation per central
+    node) in the one-launch form: fixtures recorded from the reference with a duck model,
+    with and without modulate_with_cenocc; more draws than a tile (jittered fixture draws)
+    against the oracle, total and separated by galaxy type, any n_gauss_prim; the fused
+    likelihood; NaN parameters."""
+    from oracle import tabcorr_oracle as oracle
+    data = load_golden(name)
+    table = table_from_golden(data)
+    halotab = make_tabcorr(table)
+    force_fused(halotab)
+    theta = data['theta']
+    n_r = int(np.prod(data['xi'].shape[1:]))
+    rng = np.random.default_rng(len(theta))
+    many = theta[rng.integers(0, len(theta), 140)].copy()
+    many[:, :12] *= 1.0 + 0.003 * rng.normal(size=(140, 12))
+    for modulate, suffix in ((True, ''), (False, '_nomodulate')):
+        ngal, xi = halotab.predict_batch(theta, family='leauthaud11',
+                                         modulate_with_cenocc=modulate)
+        assert last_launch(halotab)[1:3] == (8, 0), 'the fused kernel did not run'
+        assert_rel(ngal, data['ngal' + suffix], RTOL, 'ngal' + suffix)
+        assert_rel(xi, data['xi' + suffix], RTOL, 'xi' + suffix)
+        # more than two tiles: oracle, and the three-kernel path to rounding
+        ngal, xi = halotab.predict_batch(many, family='leauthaud11',
+                                         modulate_with_cenocc=modulate)
+        assert last_launch(halotab)[:3] == (3, 8, 0)
+        want = oracle.predict_leauthaud11_batch(table, many, modulate_with_cenocc=modulate)
+        assert_rel(ngal, want[0], RTOL, 'ngal, 140 draws')
+        assert_rel(xi, want[1], RTOL, 'xi, 140 draws')
+        force_fused(halotab, False)
+        ngal3, xi3 = halotab.predict_batch(many, family='leauthaud11',
+                                           modulate_with_cenocc=modulate)
+        assert last_launch(halotab)[2] > 0
+        force_fused(halotab)
+        assert_rel(ngal, ngal3, 1e-13)
+        assert_rel(xi, xi3, 1e-12)
+        # separated by galaxy type
+        ngal_s, xi_s = halotab.predict_batch(many[:70], family='leauthaud11',
+                                             modulate_with_cenocc=modulate,
+                                             separate_gal_type=True)
+        assert last_launch(halotab)[1:3] == (8, 0)
+        want = oracle.predict_leauthaud11_batch(table, many[:70], separate_gal_type=True,
+                                                modulate_with_cenocc=modulate)
+        for key in want[0]:
+            assert_rel(ngal_s[key], want[0][key], RTOL, 'ngal ' + key)
+        for key in want[1]:
+            assert_rel(xi_s[key], want[1][key], RTOL, 'xi ' + key, floor=1e-13)
+    # any n_gauss_prim
+    for n_gauss in (3, 16):
+        ngal, xi = halotab.predict_batch(many[:65], family='leauthaud11', n_gauss_prim=n_gauss,
+                                         modulate_with_cenocc=True)
+        assert last_launch(halotab)[1:3] == (8, 0)
+        want = oracle.predict_leauthaud11_batch(table, many[:65], n_gauss_prim=n_gauss)
+        assert_rel(ngal, want[0], RTOL)
+        assert_rel(xi, want[1], RTOL)
+    # the fused likelihood (tables with up to 20 r values)
+    expect = data['xi'].reshape(len(theta), n_r)
+    vector = expect[0] * 1.05
+    a = rng.normal(size=(n_r, n_r))
+    precision = a @ a.T / np.mean(np.abs(vector))**2
+    delta = expect - vector
+    n_chi, chi2 = halotab.chi2_batch(theta, vector, precision, family='leauthaud11',
+                                     modulate_with_cenocc=True)
+    assert last_launch(halotab)[1:3] == (8, 0)
+    assert_rel(n_chi, data['ngal'], RTOL)
+    assert_rel(chi2, np.einsum('bi,ij,bj->b', delta, precision, delta), 1e-9)
+    # NaN parameters reject the draw and no other
+    bad = many.copy()
+    bad[1, 5] = np.nan        # scatter
+    bad[66, 6] = np.nan       # alphasat
+    ngal, xi = halotab.predict_batch(bad, family='leauthaud11', modulate_with_cenocc=True)
+    assert last_launch(halotab)[1:3] == (8, 0)
+    assert np.isnan(ngal[1]) and np.isnan(ngal[66]) and np.all(np.isnan(xi[[1, 66]]))
+    keep = np.setdiff1d(np.arange(140), [1, 66])
+    want = oracle.predict_leauthaud11_batch(table, many[keep], modulate_with_cenocc=True)
+    assert_rel(xi[keep], want[1], RTOL)
 
 
 def test_fused_at_the_benchmarked_batch_size():
