@@ -12,8 +12,9 @@
 //             Taylor coefficients around c are Hermite polynomials in c evaluated on the
 //             fly: erf(c + h) = E + G h (1 - c h + (2c^2-1)/3 h^2 + c(3-2c^2)/6 h^3 +
 //             (4c^4-12c^2+3)/30 h^4), |h| <= 1/256, truncation 2e-16.
-//   log2(y) : exponent and the top 8 mantissa bits straight from the bit pattern; 256
-//             rows {1/c, log2 c}; log2(1 + r) to degree 5 with |r| <= 2^-9.
+//   log2(y) : the top 8 mantissa bits straight from the bit pattern, mantissa and exponent
+//             from the frexp instructions; 256 rows {2/c, log2 c - 1}; log2(1 + r) to degree
+//             5 with |r| <= 2^-9.
 //   exp2(z) : z = k / 256 + r; 256 rows 2^(j/256); 2^r to degree 4, |r| <= 2^-9.
 //
 // Accurate to a few 1e-16 (erf, exp2 relative; log2 absolute) -- far inside the 1e-10
@@ -43,6 +44,7 @@ constexpr int kExpOffset = kLogOffset + 2 * kLogRows;        // 2050
 constexpr int kTableDoubles = kExpOffset + kExpRows;         // 2306 doubles = 18.4 KB
 
 constexpr double kMagic = 6755399441055744.0;   // 1.5 * 2^52: ulp 1, low dword = integer
+constexpr double kMagicErf = kMagic / 128.0;    // 1.5 * 2^45: ulp 1 / 128
 constexpr double kLog2Of10Hi = 3.321928094887362182;      // fl(log2 10)
 constexpr double kLog2Of10Lo = 1.661617516973592e-16;     // log2 10 - kLog2Of10Hi
 constexpr double kLn2 = 0.6931471805599453094;
@@ -61,7 +63,7 @@ TC_HD double pin(double value) {
 }
 
 struct Consts {
-  double erf_p5_1, erf_p3_0, log_l4, exp_c3, magic, c128, c256;
+  double erf_p5_1, erf_p3_0, log_l4, exp_c3, magic, c256;
 };
 
 TC_HD Consts make_consts() {
@@ -71,7 +73,6 @@ TC_HD Consts make_consts() {
   k.log_l4 = pin(-1.4426950408889634074 / 4.0);
   k.exp_c3 = pin(kLn2 * kLn2 * kLn2 / 6.0);
   k.magic = pin(kMagic);
-  k.c128 = pin(128.0);
   k.c256 = pin(256.0);
   return k;
 }
@@ -91,10 +92,11 @@ TC_HD int low_word(double x) { return (int)(uint32_t)bits_of(x); }
 TC_HD double erf_fast(const double* table, const Consts& k, double x) {
   double t = fabs(x);
   t = t < 6.0 ? t : 6.0;                       // erf(6) = 1 - 2e-17
-  const double u = fma(t, k.c128, k.magic);     // nearest row
-  const double d = u - kMagic;
-  const double h = fma(d, -0.0078125, t);      // exact, |h| <= 1/256
-  const double c = d * 0.0078125;
+  // 1.5 * 2^45 has ulp 1 / 128: the sum IS t rounded to the nearest row centre, the row
+  // number in its low dword (three additions; scaling by 128 first took four instructions)
+  const double u = t + kMagicErf;
+  const double c = u - kMagicErf;
+  const double h = t - c;                      // exact, |h| <= 1/256
   const double* row = table + kErfOffset + 2 * low_word(u);
   const double c2 = c * c;
   double p5 = fma(c2, 4.0 / 30.0, k.erf_p5_1);
@@ -113,13 +115,20 @@ TC_HD double log2_fast_offset(const double* table, const Consts& k, double y,
                               double offset) {
   const uint64_t bits = bits_of(y);
   const uint32_t hi = (uint32_t)(bits >> 32);
-  const int idx = (int)((hi >> 12) & 0xffu);
-  // mantissa in [0.5, 1); the rows hold 2 / c for c in [1, 2)
+  // mantissa in [0.5, 1) and its exponent (one more than the IEEE one: the rows' second
+  // entries are log2 c - 1); the rows hold 2 / c for c in [1, 2)
 #if defined(__HIP_DEVICE_COMPILE__)
+  // (one v_bfe_u32; hidden from the optimiser, which would otherwise fold the field into the
+  // address arithmetic as a shift and a mask)
+  int idx = (int)__builtin_amdgcn_ubfe(hi, 12u, 8u);
+  asm volatile("" : "+v"(idx));
   const double m = __builtin_amdgcn_frexp_mant(y);
+  const double e = (double)__builtin_amdgcn_frexp_exp(y);
 #else
-  int unused;
-  const double m = frexp(y, &unused);
+  const int idx = (int)((hi >> 12) & 0xffu);
+  int exponent;
+  const double m = frexp(y, &exponent);
+  const double e = (double)exponent;
 #endif
   const double* row = table + kLogOffset + 2 * idx;
   const double r = fma(m, row[0], -1.0);       // 2 m / c - 1, |r| <= 2^-9
@@ -129,7 +138,6 @@ TC_HD double log2_fast_offset(const double* table, const Consts& k, double y,
   p = fma(p, r, -kInvLn2 / 2.0);
   p = fma(p, r, kInvLn2);
   p = p * r;                                   // log2(1 + r)
-  const double e = (double)((int)(hi >> 20) - 1023);
   return ((e - offset) + row[1]) + p;
 }
 

@@ -150,7 +150,8 @@ void build_tables(double* table) {
     const double inv = (double)(2.0L / c);
     table[kLogOffset + 2 * i] = inv;
     // log2 of the reciprocal actually stored, so that r = m * inv - 1 is consistent
-    table[kLogOffset + 2 * i + 1] = (double)(1.0L - log2l((long double)inv));
+    // (minus one: the exponent of a mantissa in [0.5, 1) is one more than the IEEE exponent)
+    table[kLogOffset + 2 * i + 1] = (double)(-log2l((long double)inv));
   }
   for (int j = 0; j < kExpRows; ++j)
     table[kExpOffset + j] = (double)exp2l(j / 256.0L);

@@ -19,8 +19,9 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
   std::vector<double> x, w;
   tc::gauss_legendre(n_gauss, x, w);
   const int g = t->n_bins;
+  // (behind the weights: every bin's sum of them, added in node order as the kernels would)
   std::vector<double> log_m((size_t)g * n_gauss), m((size_t)g * n_gauss),
-      weight((size_t)g * n_gauss);
+      weight((size_t)g * n_gauss + g);
   for (int i = 0; i < g; ++i) {
     const double d_log = t->log_max[i] - t->log_min[i];
     const double exponent = t->legacy ? 0.0 : t->dist_index[i] + 1.0;
@@ -35,8 +36,12 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
                powl((long double)mass / (long double)m_ref, (long double)exponent);
       norm += raw[k];
     }
-    for (int k = 0; k < n_gauss; ++k)
+    double sum = 0.0;
+    for (int k = 0; k < n_gauss; ++k) {
       weight[(size_t)i * n_gauss + k] = (double)(raw[k] / norm);
+      sum += weight[(size_t)i * n_gauss + k];
+    }
+    weight[(size_t)g * n_gauss + i] = sum;
   }
   Quadrature q;
   q.n_gauss = n_gauss;
