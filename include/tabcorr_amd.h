@@ -291,7 +291,11 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 "fused_min_draws" .. "fused_max_draws" draws (default 0 = chosen per table:
  *                 512 for small tables, ~7000 for 100 bins x 19 r values; 30720; asynchronous
  *                 calls: no upper bound); 0: always occupation, contraction, finalisation
- *                 kernels; 2: one launch also for calls that run alone on their lane.
+ *                 kernels; 2: one launch also for calls that run alone on their lane and for
+ *                 tables of 105 .. 248 bins (one 16-wave workgroup per CU: level with the
+ *                 three kernels).
+ *   "fused_waves" 0 (default): 8 waves per workgroup where two workgroups fit a CU; 8 / 16:
+ *                 that many where the table fits.
  *   "single_draw" 1 (default): an un-batched predict() goes through one launch.
  *   "trace"       developer timelines (developer builds only, tabcorr_amd_testing.h). */
 int tc_table_set_option(tc_table* table, const char* name, int value);

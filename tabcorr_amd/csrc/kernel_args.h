@@ -197,7 +197,8 @@ struct FinalizeQuadArgs {
 // A workgroup of kFusedWaves waves owns 64 draws from theta to (ngal, xi[, chi2]): the
 // densities live in LDS ((dens_rows, 64) doubles, rows beyond n_bins zero), nothing is handed
 // over through memory.  Mode auto, total correlation function, one r tile.
-constexpr int kFusedWaves = 8;
+constexpr int kFusedWaves = 8;       // (default; 16 where one workgroup per CU is all that fits)
+constexpr int kFusedMaxParts = 8;    // parts of the units per 32-draw tile: waves / 2
 
 struct FusedArgs {
   const double* theta;       // (n_draws, n_theta)
@@ -206,17 +207,18 @@ struct FusedArgs {
   int n_central;
   int n_gauss;
   int dens_rows;             // rows of the LDS density array (whole blocks of four)
-  // the work of the four waves of a 32-draw tile: `count` units of one component from block
-  // (rb0, cb0) on.  Total: the four quarters of the triangle.  Separated by galaxy type: the
-  // cen-cen triangle, the two halves of the cen-sat rectangle, the sat-sat triangle.
-  int part_rb0[4];
-  int part_cb0[4];
-  int part_count[4];
-  int part_triangular[4];    // block columns 0 .. rb of block row rb, else all part_n_cb
-  int part_n_cb[4];
-  int part_i_row0[4];        // first density row of the component's rows / columns
-  int part_j_row0[4];
-  int part_unit_base[4];     // first unit of the component in the table
+  // the work of the 4 (8) waves of a 32-draw tile: `count` units of one component from block
+  // (rb0, cb0) on.  Total: equal parts of the triangle.  Separated by galaxy type: the cen-cen
+  // triangle (one quarter of the waves), the cen-sat rectangle (two quarters), the sat-sat
+  // triangle (one quarter).
+  int part_rb0[kFusedMaxParts];
+  int part_cb0[kFusedMaxParts];
+  int part_count[kFusedMaxParts];
+  int part_triangular[kFusedMaxParts];    // block columns 0 .. rb of block row rb, else all part_n_cb
+  int part_n_cb[kFusedMaxParts];
+  int part_i_row0[kFusedMaxParts];        // first density row of the component's rows / columns
+  int part_j_row0[kFusedMaxParts];
+  int part_unit_base[kFusedMaxParts];     // first unit of the component in the table
   int separate;              // 1: ngal (n_draws, 2), xi (n_draws, 3, n_r): cc, cs, ss
   int n_r;
   int priority;              // wave priorities: phase 2 | phase 1 << 2 | phase 3 << 4

@@ -1422,9 +1422,12 @@ __global__ __launch_bounds__(1024) void finalize_quad_kernel(FinalizeQuadArgs a)
 // Mode auto, total correlation function or its three components, one r tile; the Zheng07
 // family (with its Heaviside assembly bias / modulate_with_cenocc variants) or, LEAUTHAUD, the
 // Leauthaud11 family.
-constexpr int kFusedSlotDoubles = kFusedWaves * 4 * kQuadMaxU * kQuadTile;   // phase 3
-constexpr int kFusedScratchDoubles = fm::kTableDoubles + 2 * kFusedWaves * kLanes;
-static_assert(kFusedWaves == 8, "two 32-draw tiles x four quarters of the triangle");
+// (W waves per workgroup: 8 = two 32-draw tiles x four parts of the units, two workgroups per
+// CU; 16 = eight parts per tile, one workgroup with up to 160 KB of LDS per CU -- tables of
+// more than 104 bins)
+constexpr int fused_slot_doubles(int waves) { return waves * 4 * kQuadMaxU * kQuadTile; }
+constexpr int fused_scratch_doubles(int waves) { return fm::kTableDoubles + 2 * waves * kLanes; }
+static_assert(kFusedWaves == 8 && kFusedMaxParts == 8, "8 or 16 waves: 4 or 8 parts per tile");
 static_assert(20 * (kLanes + 1) + 20 * 21 <= fm::kTableDoubles,
               "results tile + likelihood data in the place of the math table");
 
@@ -1507,19 +1510,21 @@ __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, uns
   }
 }
 
-template <int NGAUSS, int U, bool ASSEMBIAS, bool MODULATE, bool LEAUTHAUD = false>
-__global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(FusedArgs a) {
+template <int NGAUSS, int U, bool ASSEMBIAS, bool MODULATE, bool LEAUTHAUD = false,
+          int W = kFusedWaves>
+__global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(FusedArgs a) {
+  static_assert(W == 8 || W == 16, "waves per workgroup");
+  constexpr int PARTS = W / 2;       // waves per 32-draw tile
   static_assert(!LEAUTHAUD || (NGAUSS == 0 && !ASSEMBIAS), "Leauthaud11: any n_gauss, undecorated");
   constexpr int UP = (U + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) double fused_lds[];
   // region B: densities, later the waves' sums; region A: math table, later the results tile
   // and the likelihood's data | ngal sums
-  const int region_b =
-      a.dens_rows * kLanes > kFusedSlotDoubles ? a.dens_rows * kLanes : kFusedSlotDoubles;
+  constexpr int kSlotDoubles = fused_slot_doubles(W);
+  const int region_b = a.dens_rows * kLanes > kSlotDoubles ? a.dens_rows * kLanes : kSlotDoubles;
   double* dens = fused_lds;
   double* table = fused_lds + region_b;
-  double(*red)[kFusedWaves][kLanes] =
-      (double(*)[kFusedWaves][kLanes])(table + fm::kTableDoubles);
+  double(*red)[W][kLanes] = (double(*)[W][kLanes])(table + fm::kTableDoubles);
   const fm::Consts kc = fm::make_consts();
   set_priority((a.priority >> 2) & 3);
   const int lane = threadIdx.x & 63;
@@ -1571,7 +1576,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(Fuse
     sc_f64 percentile = (sc_f64)a.percentile;
     const double f1 = (1.0 - a.split) / a.split, f2 = a.split / (1.0 - a.split);
     double sum_cen = 0.0, sum_sat = 0.0;
-    for (int g = wave; g < a.n_bins; g += kFusedWaves) {
+    for (int g = wave; g < a.n_bins; g += W) {
       const bool central = g < a.n_central;
       const bool above = ASSEMBIAS ? percentile[g] > a.split : false;
       const double acc =
@@ -1589,7 +1594,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(Fuse
     __syncthreads();
     double n_cen = 0.0, n_sat = 0.0;
 #pragma unroll
-    for (int w = 0; w < kFusedWaves; ++w) {
+    for (int w = 0; w < W; ++w) {
       n_cen += red[0][w][lane];
       n_sat += red[1][w][lane];
     }
@@ -1610,7 +1615,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(Fuse
   const int c = lane & 15, kq = lane >> 4;
   double F[UP][2][2];
   {
-    const int sub = wave >> 2, part = wave & 3;
+    const int sub = wave / PARTS, part = wave % PARTS;
     const unsigned off_a = lane * 16;
     // (the component's columns are density rows j_row0 ..., its rows i_row0 ...)
     const double* dens_b =
@@ -1647,8 +1652,8 @@ __global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(Fuse
   set_priority((a.priority >> 4) & 3);
   double(*tile)[kLanes + 1] = (double(*)[kLanes + 1])table;
   if (a.separate) {
-    // cen-cen = wave 0 of the tile, cen-sat = waves 1 + 2, sat-sat = wave 3, one component
-    // after the other through the results tile.  The reference forms every term / sum first
+    // cen-cen = the first quarter of the tile's waves, cen-sat = the two middle quarters,
+    // sat-sat = the last quarter, one component after the other through the results tile.  The reference forms every term / sum first
     // and masks afterwards (tabcorr.py:653-681): with a non-finite pair-weight sum some term
     // is inf / inf = NaN and NaN x False = NaN reaches every component.
     const bool poisoned = !(fabs(norm) <= 1.79769313486231570815e308);
@@ -1656,11 +1661,13 @@ __global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(Fuse
     const int sub = lane >> 5, d = lane & 31;
     for (int comp = 0; comp < 3; ++comp) {
       __syncthreads();
-      for (int rr = wave; rr < a.n_r; rr += kFusedWaves) {
-        const double* first =
-            dens + ((4 * sub + (comp == 0 ? 0 : comp == 1 ? 1 : 3)) * (4 * U) + rr) * kQuadTile + d;
+      constexpr int Q = PARTS / 4;
+      const int p_begin = comp == 0 ? 0 : comp == 1 ? Q : 3 * Q;
+      const int p_count = comp == 1 ? 2 * Q : Q;
+      for (int rr = wave; rr < a.n_r; rr += W) {
+        const double* first = dens + ((PARTS * sub + p_begin) * (4 * U) + rr) * kQuadTile + d;
         double sum = first[0];
-        if (comp == 1) sum += first[(4 * U) * kQuadTile];
+        for (int p = 1; p < p_count; ++p) sum += first[p * (4 * U) * kQuadTile];
         tile[rr][lane] = poisoned ? __builtin_nan("") : sum / norm;
       }
       __syncthreads();
@@ -1679,11 +1686,11 @@ __global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(Fuse
   __syncthreads();
   {
     const int sub = lane >> 5, d = lane & 31;
-    for (int rr = wave; rr < a.n_r; rr += kFusedWaves) {
-      const double* first = dens + ((4 * sub) * (4 * U) + rr) * kQuadTile + d;
+    for (int rr = wave; rr < a.n_r; rr += W) {
+      const double* first = dens + ((PARTS * sub) * (4 * U) + rr) * kQuadTile + d;
       double sum = first[0];
 #pragma unroll
-      for (int part = 1; part < 4; ++part) sum += first[part * (4 * U) * kQuadTile];
+      for (int part = 1; part < PARTS; ++part) sum += first[part * (4 * U) * kQuadTile];
       tile[rr][lane] = sum / norm;
     }
   }
@@ -1695,7 +1702,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(Fuse
     const double* data = chi2_lds;
     const double* matrix = chi2_lds + rows;
     double part = 0.0;
-    for (int i = wave; i < rows; i += kFusedWaves) {
+    for (int i = wave; i < rows; i += W) {
       double inner = 0.0;
       for (int j = 0; j < rows; ++j)
         inner = fma(matrix[i * rows + j], tile[j][lane] - data[j], inner);
@@ -1705,7 +1712,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, 2) void predict_fused_kernel(Fuse
     __syncthreads();
     if (wave == 0 && lane < n_valid) {
       double total = 0.0;
-      for (int w = 0; w < kFusedWaves; ++w) total += red[0][w][lane];
+      for (int w = 0; w < W; ++w) total += red[0][w][lane];
       a.chi2[col + lane] = total;
     }
     return;

@@ -921,12 +921,14 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
     return false;
   if (t->quad_total.layout.comps.size() != 1 || !t->quad_total.layout.comps[0].triangular)
     return false;
-  if (fused_lds_bytes(t, separate) > 160 * 1024 || n_gauss < 1) return false;
-  // two workgroups per CU or not at all: with more than 80 KB of LDS each (more than 104 bins)
-  // a CU holds one, its phases no longer overlap with a neighbour's, and the three kernels are
-  // 10 % ahead (tools/r03_fused_bins.py, 10^4 draws, three kernels / one launch: G = 80 31.3 /
-  // 27.7 us, 104 45.2 / 42.2, 112 50.7 / 56.0, 128 62.8 / 69.4, 200 135.5 / 149.3)
-  if (fused_lds_bytes(t, separate) > 80 * 1024 && t->tuning.fused < 2) return false;
+  // Two workgroups of 8 waves per CU (up to 80 KB of LDS each: 104 bins) or not at all: larger
+  // tables fit ONE workgroup per CU, whose phases no neighbour covers.  With 8 waves the three
+  // kernels are then 8-13 % ahead, with 16 waves (eight parts of the units per tile, four waves
+  // per SIMD again) level -- tools/r03_fused_waves.py, 10^4 draws, us per step, three kernels /
+  // 8 waves / 16 waves: G = 112 51.8 / 55.6 / 51.5, 128 64.2 / 69.2 / 64.3, 200 137.0 / 150.9 /
+  // 138.7, 240 189.6 / 215.0 / 192.3; G = 100: 43.5 / 39.4 / 43.2 -- so beyond 104 bins the
+  // one-launch form (16 waves, up to 160 KB: 248 bins) is taken only when forced.
+  if (n_gauss < 1 || fused_waves(t, separate) == 0) return false;
   // Smallest batch: a launch lasts as long as one workgroup does, whatever the batch, so the
   // one-launch form pays from the batch size on at which four lanes of such launches beat the
   // three kernels (which spread any batch over the whole chip).  Estimated duration of a
@@ -940,8 +942,9 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
   // are bound by the host thread that queues them (10-13 us per call) and differ by noise.
   {
     const tc::QuadLayout& layout = separate ? t->quad_by_type.layout : t->quad_total.layout;
-    const double estimate = 5.0 + 10.0 * (t->n_bins / 100.0) * (n_gauss / 10.0) +
-                            60.0 * ((double)layout.n_units / 325.0) * (t->quad_tiling.n_u / 5.0);
+    const double estimate = (5.0 + 10.0 * (t->n_bins / 100.0) * (n_gauss / 10.0) +
+                             60.0 * ((double)layout.n_units / 325.0) * (t->quad_tiling.n_u / 5.0)) *
+                            8.0 / fused_waves(t, separate);
     // Leauthaud11 (a Newton inverse of the stellar-to-halo mass relation per central node: the
     // occupations outweigh the matrix work and spread better over the chip as a kernel of their
     // own): tools/r03_fused_leauthaud.py, us per step, three kernels / one launch: G = 100: 4000
@@ -970,13 +973,23 @@ int fused_dens_rows(const tc_table* t, bool separate) {
   return (rows + 3) / 4 * 4;
 }
 
-int fused_lds_bytes(const tc_table* t, bool separate) {
+int fused_lds_bytes(const tc_table* t, bool separate, int waves) {
   const int dens_rows = fused_dens_rows(t, separate);
-  return (std::max(dens_rows * 64, tc::kFusedSlotDoubles) + tc::kFusedScratchDoubles) * 8;
+  return (std::max(dens_rows * 64, tc::fused_slot_doubles(waves)) +
+          tc::fused_scratch_doubles(waves)) * 8;
+}
+
+// Waves per workgroup of the one-launch form for this table: 8, 16, or 0 (does not fit).
+int fused_waves(const tc_table* t, bool separate) {
+  const bool fits8 = fused_lds_bytes(t, separate, 8) <= 80 * 1024;
+  const bool fits16 = fused_lds_bytes(t, separate, 16) <= 160 * 1024;
+  if (t->tuning.fused_waves == 8 && fused_lds_bytes(t, separate, 8) <= 160 * 1024) return 8;
+  if (t->tuning.fused_waves == 16 && fits16) return 16;
+  return fits8 ? 8 : (fits16 && t->tuning.fused >= 2) ? 16 : 0;
 }
 
 namespace {
-template <int NG, bool AB, bool MO, bool LE = false>
+template <int NG, bool AB, bool MO, bool LE = false, int W = tc::kFusedWaves>
 int launch_fused(int device, int n_u, dim3 grid, dim3 block, int lds, hipStream_t stream,
                  hipEvent_t k0, hipEvent_t k1, const tc::FusedArgs& fa) {
   switch (n_u) {
@@ -985,11 +998,11 @@ int launch_fused(int device, int n_u, dim3 grid, dim3 block, int lds, hipStream_
     /* (the attribute belongs to the function ON a device: once per device) */                \
     static bool limit_set[64] = {};                                                           \
     if (lds > 64 * 1024 && !(device >= 0 && device < 64 && limit_set[device])) {              \
-      TC_HIP(hipFuncSetAttribute((const void*)tc::predict_fused_kernel<NG, N, AB, MO, LE>,    \
+      TC_HIP(hipFuncSetAttribute((const void*)tc::predict_fused_kernel<NG, N, AB, MO, LE, W>, \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));    \
       if (device >= 0 && device < 64) limit_set[device] = true;                               \
     }                                                                                         \
-    hipExtLaunchKernelGGL((tc::predict_fused_kernel<NG, N, AB, MO, LE>), grid, block, lds,    \
+    hipExtLaunchKernelGGL((tc::predict_fused_kernel<NG, N, AB, MO, LE, W>), grid, block, lds, \
                           stream, k0, k1, 0, fa);                                             \
     break;                                                                                    \
   }
@@ -1021,10 +1034,12 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   fa.n_gauss = n_gauss;
   fa.dens_rows = fused_dens_rows(t, separate);
   fa.separate = separate ? 1 : 0;
+  const int waves = fused_waves(t, separate);
+  const int n_parts = waves / 2;
   if (!separate) {
     const tc::QuadComp& comp = q_table.layout.comps[0];
-    tc::triangle_parts(comp.n_rb, 4, fa.part_rb0, fa.part_cb0, fa.part_count);
-    for (int part = 0; part < 4; ++part) {
+    tc::triangle_parts(comp.n_rb, n_parts, fa.part_rb0, fa.part_cb0, fa.part_count);
+    for (int part = 0; part < n_parts; ++part) {
       fa.part_triangular[part] = 1;
       fa.part_n_cb[part] = comp.n_cb;
       fa.part_i_row0[part] = comp.i_bin0;
@@ -1032,22 +1047,32 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
       fa.part_unit_base[part] = (int)comp.unit_base;
     }
   } else {
-    // wave 0: cen-cen, waves 1 and 2: the halves of cen-sat (whole units, row-major), wave 3:
-    // sat-sat
-    const int comp_of[4] = {0, 1, 1, 2};
-    for (int part = 0; part < 4; ++part) {
-      const tc::QuadComp& comp = q_table.layout.comps[comp_of[part]];
-      int64_t begin = 0, end = comp.n_units;
-      if (part == 1) end = comp.n_units / 2;
-      if (part == 2) begin = comp.n_units / 2;
+    // first quarter of a tile's waves: cen-cen, the two middle quarters: cen-sat (whole units,
+    // row-major), last quarter: sat-sat; equal shares of a component's units within its waves
+    const int quarter = n_parts / 4;
+    for (int part = 0; part < n_parts; ++part) {
+      const int c = part < quarter ? 0 : part < 3 * quarter ? 1 : 2;
+      const int first = c == 0 ? 0 : c == 1 ? quarter : 3 * quarter;
+      const int pieces = c == 1 ? 2 * quarter : quarter, piece = part - first;
+      const tc::QuadComp& comp = q_table.layout.comps[c];
       fa.part_triangular[part] = comp.triangular;
       fa.part_n_cb[part] = comp.n_cb;
       fa.part_i_row0[part] = comp.i_bin0;
       fa.part_j_row0[part] = comp.j_bin0;
       fa.part_unit_base[part] = (int)comp.unit_base;
-      fa.part_rb0[part] = comp.triangular ? 0 : (int)(begin / comp.n_cb);
-      fa.part_cb0[part] = comp.triangular ? 0 : (int)(begin % comp.n_cb);
-      fa.part_count[part] = (int)(end - begin);
+      if (comp.triangular) {
+        int32_t rb0[tc::kFusedMaxParts], cb0[tc::kFusedMaxParts], count[tc::kFusedMaxParts];
+        tc::triangle_parts(comp.n_rb, pieces, rb0, cb0, count);
+        fa.part_rb0[part] = rb0[piece];
+        fa.part_cb0[part] = cb0[piece];
+        fa.part_count[part] = count[piece];
+      } else {
+        const int64_t begin = comp.n_units * piece / pieces;
+        const int64_t end = comp.n_units * (piece + 1) / pieces;
+        fa.part_rb0[part] = (int)(begin / comp.n_cb);
+        fa.part_cb0[part] = (int)(begin % comp.n_cb);
+        fa.part_count[part] = (int)(end - begin);
+      }
     }
   }
   fa.n_r = t->n_r;
@@ -1073,29 +1098,34 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
     fa.xi = nullptr;
     t->chi2_fused = true;
   }
-  const int lds = fused_lds_bytes(t, separate);
-  const dim3 grid((unsigned)((n_draws + 63) / 64)), block(64 * tc::kFusedWaves);
+  const int lds = fused_lds_bytes(t, separate, waves);
+  const dim3 grid((unsigned)((n_draws + 63) / 64)), block(64 * waves);
   hipEvent_t k0 = nullptr, k1 = nullptr;
   status = next_kernel_events(t, &k0, &k1);
   if (status != TC_OK) return status;
   const bool assembias = (flags & TC_FLAG_ASSEMBIAS) != 0;
   const bool modulate = (flags & TC_FLAG_MODULATE_WITH_CENOCC) != 0;
+#define TC_FUSED(NG, AB, MO, LE)                                                              \
+  (waves == 16 ? launch_fused<NG, AB, MO, LE, 16>(t->device, t->quad_tiling.n_u, grid, block,  \
+                                                  lds, stream, k0, k1, fa)                     \
+               : launch_fused<NG, AB, MO, LE, 8>(t->device, t->quad_tiling.n_u, grid, block,   \
+                                                 lds, stream, k0, k1, fa))
   if (flags & TC_FLAG_LEAUTHAUD11)
-    status = modulate ? launch_fused<0, false, true, true>(t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa)
-                      : launch_fused<0, false, false, true>(t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+    status = modulate ? TC_FUSED(0, false, true, true) : TC_FUSED(0, false, false, true);
   else if (n_gauss != 10)
-    status = launch_fused<0, false, false>(t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+    status = TC_FUSED(0, false, false, false);
   else if (!assembias && !modulate)
-    status = launch_fused<10, false, false>(t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+    status = TC_FUSED(10, false, false, false);
   else if (!assembias)
-    status = launch_fused<10, false, true>(t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+    status = TC_FUSED(10, false, true, false);
   else if (!modulate)
-    status = launch_fused<10, true, false>(t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+    status = TC_FUSED(10, true, false, false);
   else
-    status = launch_fused<10, true, true>(t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+    status = TC_FUSED(10, true, true, false);
+#undef TC_FUSED
   if (status != TC_OK) return status;
   t->last_workgroups = (int)grid.x;
-  t->last_waves = tc::kFusedWaves;
+  t->last_waves = waves;
   t->last_splits = 0;
   t->last_lds = lds;
   t->prev = t->force_lane >= 0 ? -1 : t->cur;

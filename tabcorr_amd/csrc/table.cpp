@@ -818,6 +818,9 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
   } else if (key == "fused_min_draws" || key == "fused_max_draws") {
     TC_CHECK(value >= (key == "fused_min_draws" ? 0 : 1), "%s must be positive", name);
     (key == "fused_min_draws" ? t->tuning.fused_min_draws : t->tuning.fused_max_draws) = value;
+  } else if (key == "fused_waves") {
+    TC_CHECK(value == 0 || value == 8 || value == 16, "fused_waves must be 0, 8 or 16");
+    t->tuning.fused_waves = value;
   } else if (key == "prio_fused") {
     t->tuning.prio_fused = value & 3;
   } else if (key == "prio_fused_occ") {

@@ -41,6 +41,13 @@ def last_launch(halotab):
     return tuple(v.value for v in values)
 
 
+def fused_ran(halotab, waves=(8, 16)):
+    """Was the last launch predict_fused_kernel (8 waves per workgroup where two workgroups fit
+    a CU, 16 for tables of more than 104 bins; no slabs of partial sums)?"""
+    launch = last_launch(halotab)
+    return launch[1] in waves and launch[2] == 0
+
+
 def test_fused_matches_golden():
     data = load_golden('synthetic_cfg2')
     table = table_from_golden(data)
@@ -79,7 +86,7 @@ def test_fused_matches_oracle(n_prim, n_sec, n_r, n_gauss, n_draws):
     halotab = make_tabcorr(table)
     force_fused(halotab)
     ngal, xi = halotab.predict_batch(theta, n_gauss_prim=n_gauss)
-    assert last_launch(halotab)[1:3] == (8, 0), 'the fused kernel did not run'
+    assert fused_ran(halotab), 'the fused kernel did not run'
     expect = oracle.predict_zheng07_batch(table, theta, n_gauss_prim=n_gauss)
     assert_rel(ngal, expect[0], RTOL, 'ngal')
     assert_rel(xi, expect[1], RTOL, 'xi')
@@ -96,7 +103,7 @@ def test_fused_likelihood_and_async():
     expect = oracle.predict_zheng07_batch(table, theta)
     ngal, xi = pinned_empty(777), pinned_empty((777, 19))
     got = halotab.predict_batch_async(theta, out=(ngal, xi)).wait()
-    assert last_launch(halotab)[1:3] == (8, 0), 'the fused kernel did not run'
+    assert fused_ran(halotab), 'the fused kernel did not run'
     assert_rel(got[0], expect[0], RTOL)
     assert_rel(got[1], expect[1], RTOL)
     rng = np.random.default_rng(0)
@@ -105,7 +112,7 @@ def test_fused_likelihood_and_async():
     precision = a @ a.T / np.mean(vector)**2
     want = np.einsum('bi,ij,bj->b', expect[1] - vector, precision, expect[1] - vector)
     n_chi, chi2 = halotab.chi2_batch_async(theta, vector, precision).wait()
-    assert last_launch(halotab)[1:3] == (8, 0)
+    assert fused_ran(halotab)
     assert_rel(n_chi, expect[0], RTOL)
     assert_rel(chi2, want, 1e-9)
     # the synchronous calls run alone on their lane: three kernels unless forced
@@ -114,7 +121,7 @@ def test_fused_likelihood_and_async():
     assert_rel(sync[1], chi2, 1e-11)
     force_fused(halotab)
     forced = halotab.chi2_batch(theta, vector, precision)
-    assert last_launch(halotab)[1:3] == (8, 0)
+    assert fused_ran(halotab)
     assert_rel(forced[1], chi2, 1e-13)
     # many calls in flight, different sizes
     sizes = [64, 1, 300, 65, 2048, 127]
@@ -157,7 +164,7 @@ def test_fused_degenerate_parameters():
         ngal3, xi3 = halotab.predict_batch(theta)
         force_fused(halotab)
         ngal, xi = halotab.predict_batch(theta)
-    assert last_launch(halotab)[1:3] == (8, 0)
+    assert fused_ran(halotab)
     assert np.array_equal(np.isnan(ngal), np.isnan(ngal3))
     assert np.array_equal(np.isnan(xi), np.isnan(xi3))
     assert np.array_equal(np.isinf(xi), np.isinf(xi3))
@@ -179,7 +186,7 @@ def test_fused_is_not_taken_where_it_does_not_apply():
     halotab = make_tabcorr(table)
     force_fused(halotab)
     halotab.predict_batch(theta)
-    assert last_launch(halotab)[1:3] == (8, 0)
+    assert fused_ran(halotab)
     # (Heaviside assembly bias with another n_gauss_prim than the reference's default keeps the
     # three kernels)
     decorated = np.hstack([theta, np.full((100, 2), 0.3)])
@@ -207,7 +214,7 @@ def test_fused_leauthaud11(name):
     for modulate, suffix in ((True, ''), (False, '_nomodulate')):
         ngal, xi = halotab.predict_batch(theta, family='leauthaud11',
                                          modulate_with_cenocc=modulate)
-        assert last_launch(halotab)[1:3] == (8, 0), 'the fused kernel did not run'
+        assert fused_ran(halotab), 'the fused kernel did not run'
         assert_rel(ngal, data['ngal' + suffix], RTOL, 'ngal' + suffix)
         assert_rel(xi, data['xi' + suffix], RTOL, 'xi' + suffix)
         # more than two tiles: oracle, and the three-kernel path to rounding
@@ -228,7 +235,7 @@ def test_fused_leauthaud11(name):
         ngal_s, xi_s = halotab.predict_batch(many[:70], family='leauthaud11',
                                              modulate_with_cenocc=modulate,
                                              separate_gal_type=True)
-        assert last_launch(halotab)[1:3] == (8, 0)
+        assert fused_ran(halotab)
         want = oracle.predict_leauthaud11_batch(table, many[:70], separate_gal_type=True,
                                                 modulate_with_cenocc=modulate)
         for key in want[0]:
@@ -239,7 +246,7 @@ def test_fused_leauthaud11(name):
     for n_gauss in (3, 16):
         ngal, xi = halotab.predict_batch(many[:65], family='leauthaud11', n_gauss_prim=n_gauss,
                                          modulate_with_cenocc=True)
-        assert last_launch(halotab)[1:3] == (8, 0)
+        assert fused_ran(halotab)
         want = oracle.predict_leauthaud11_batch(table, many[:65], n_gauss_prim=n_gauss)
         assert_rel(ngal, want[0], RTOL)
         assert_rel(xi, want[1], RTOL)
@@ -251,7 +258,7 @@ def test_fused_leauthaud11(name):
     delta = expect - vector
     n_chi, chi2 = halotab.chi2_batch(theta, vector, precision, family='leauthaud11',
                                      modulate_with_cenocc=True)
-    assert last_launch(halotab)[1:3] == (8, 0)
+    assert fused_ran(halotab)
     assert_rel(n_chi, data['ngal'], RTOL)
     assert_rel(chi2, np.einsum('bi,ij,bj->b', delta, precision, delta), 1e-9)
     # NaN parameters reject the draw and no other
@@ -259,7 +266,7 @@ def test_fused_leauthaud11(name):
     bad[1, 5] = np.nan        # scatter
     bad[66, 6] = np.nan       # alphasat
     ngal, xi = halotab.predict_batch(bad, family='leauthaud11', modulate_with_cenocc=True)
-    assert last_launch(halotab)[1:3] == (8, 0)
+    assert fused_ran(halotab)
     assert np.isnan(ngal[1]) and np.isnan(ngal[66]) and np.all(np.isnan(xi[[1, 66]]))
     keep = np.setdiff1d(np.arange(140), [1, 66])
     want = oracle.predict_leauthaud11_batch(table, many[keep], modulate_with_cenocc=True)
@@ -280,7 +287,7 @@ def test_fused_at_the_benchmarked_batch_size():
     pending = [halotab.predict_batch_async(theta, out=(ngal, xi)) for _ in range(3)]
     for item in pending:
         item.wait()
-    assert last_launch(halotab)[1:3] == (8, 0), 'the fused kernel did not run'
+    assert fused_ran(halotab), 'the fused kernel did not run'
     index = np.r_[0:40, 4990:5030, 9960:10000]
     expect = oracle.predict_zheng07_batch(table, theta[index])
     assert_rel(ngal[index], expect[0], RTOL)
@@ -295,12 +302,12 @@ def test_fused_at_the_benchmarked_batch_size():
     precision = a @ a.T / np.mean(vector)**2
     want = np.einsum('bi,ij,bj->b', xi3 - vector, precision, xi3 - vector)
     n_chi, chi2 = halotab.chi2_batch_async(theta, vector, precision).wait()
-    assert last_launch(halotab)[1:3] == (8, 0)
+    assert fused_ran(halotab)
     assert_rel(n_chi, ngal3, 1e-13)
     assert_rel(chi2, want, 1e-9)
     # separated by galaxy type, asynchronously: one launch as well
     n_sep, x_sep = halotab.predict_batch_async(theta, separate_gal_type=True).wait()
-    assert last_launch(halotab)[1:3] == (8, 0)
+    assert fused_ran(halotab)
     n_sep3, x_sep3 = halotab.predict_batch(theta, separate_gal_type=True)
     assert last_launch(halotab)[2] > 0
     scale = np.max(np.abs(xi3))
@@ -328,7 +335,7 @@ def test_fused_decorated_variants(modulate, assembias):
     halotab = make_tabcorr(table)
     force_fused(halotab)
     ngal, xi = halotab.predict_batch(batch, modulate_with_cenocc=modulate, assembias=assembias)
-    assert last_launch(halotab)[1:3] == (8, 0), 'the fused kernel did not run'
+    assert fused_ran(halotab), 'the fused kernel did not run'
     assert_rel(ngal, expect[0], RTOL, 'ngal')
     assert_rel(xi, expect[1], RTOL, 'xi')
     # any other n_gauss_prim: the three kernels serve the decorated variants
@@ -348,7 +355,7 @@ def test_a_draws_result_does_not_depend_on_its_place_in_the_batch():
     halotab = make_tabcorr(table)
     force_fused(halotab)
     ngal, xi = halotab.predict_batch(theta)
-    assert last_launch(halotab)[1:3] == (8, 0)
+    assert fused_ran(halotab)
     ngal_r, xi_r = halotab.predict_batch(theta[::-1].copy())
     assert np.array_equal(ngal_r[::-1], ngal)
     assert np.array_equal(xi_r[::-1], xi)
@@ -370,7 +377,7 @@ def test_fused_matches_the_references_own_tables():
                            ('_ng100', {'n_gauss_prim': 100}),
                            ('_modulate', {'modulate_with_cenocc': True})):
         ngal, xi = halotab.predict_batch(data['theta'], **kwargs)
-        assert last_launch(halotab)[1:3] == (8, 0), suffix
+        assert fused_ran(halotab), suffix
         assert_rel(ngal, data['ngal' + suffix], RTOL, 'ngal' + suffix)
         assert_rel(xi, data['xi' + suffix], RTOL, 'xi' + suffix)
     for name, prefixes in (('synthetic_r1', ('', )), ('synthetic_small_auto', ('', 'legacy_'))):
@@ -384,7 +391,7 @@ def test_fused_matches_the_references_own_tables():
             halotab = make_tabcorr(table)
             force_fused(halotab)
             ngal, xi = halotab.predict_batch(data['theta'])
-            assert last_launch(halotab)[1:3] == (8, 0), name + prefix
+            assert fused_ran(halotab), name + prefix
             assert_rel(ngal, data[prefix + 'ngal'], RTOL, name)
             assert_rel(xi, data[prefix + 'xi'], RTOL, name)
     data = load_golden('synthetic_cfg3')
@@ -392,7 +399,7 @@ def test_fused_matches_the_references_own_tables():
     force_fused(halotab)
     ngal, xi = halotab.predict_batch(np.hstack([data['theta'], data['assembias']]),
                                      assembias=True)
-    assert last_launch(halotab)[1:3] == (8, 0)
+    assert fused_ran(halotab)
     assert_rel(ngal, data['ngal'], RTOL)
     assert_rel(xi, data['xi'], RTOL)
     ngal, xi = halotab.predict_batch(data['theta'])
@@ -426,7 +433,7 @@ def test_fused_separate_gal_type(n_prim, n_sec, n_r, n_draws, kwargs):
     halotab = make_tabcorr(table)
     force_fused(halotab)
     ngal, xi = halotab.predict_batch(batch, separate_gal_type=True, **kwargs)
-    assert last_launch(halotab)[1:3] == (8, 0), 'the fused kernel did not run'
+    assert fused_ran(halotab), 'the fused kernel did not run'
     assert list(xi.keys()) == list(expect[1].keys())
     scale = max(np.max(np.abs(v)) for v in expect[1].values())
     for key in expect[0]:
@@ -444,7 +451,7 @@ def test_fused_separate_matches_golden():
     halotab = make_tabcorr(table_from_golden(data))
     force_fused(halotab)
     ngal, xi = halotab.predict_batch(data['theta'], separate_gal_type=True)
-    assert last_launch(halotab)[1:3] == (8, 0)
+    assert fused_ran(halotab)
     for key in ngal:
         assert_rel(ngal[key], data['ngal_sep_' + key], RTOL, key)
     for key in xi:
@@ -459,3 +466,53 @@ def test_fused_separate_matches_golden():
     for key in xi:
         assert np.array_equal(np.isnan(xi[key]), np.isnan(xi3[key])), key
         assert np.all(np.isnan(xi[key][3]))
+
+
+@pytest.mark.parametrize('n_prim, n_sec, n_r, n_draws, kwargs', [
+    (50, 1, 19, 1000, {}),                                    # forced on BASELINE configs[1]'s table
+    (50, 2, 19, 300, {}),                                     # 200 bins: BASELINE configs[2]'s table
+    (50, 2, 19, 200, {'assembias': True}),
+    (50, 2, 7, 130, {'modulate_with_cenocc': True}),
+    (60, 2, 19, 100, {}),                                     # 240 bins: 158 KB of LDS
+    (31, 2, 13, 65, {'n_gauss_prim': 4}),                     # 124 bins
+    (7, 1, 3, 65, {}),                                        # forced: fewer block rows than parts
+])
+def test_fused_sixteen_waves(n_prim, n_sec, n_r, n_draws, kwargs):
+    """One workgroup of 16 waves per CU (eight parts of the units per 32-draw tile, up to 160 KB
+    of LDS: tables of 105 ... 248 bins, where two 8-wave workgroups do not fit a CU), total and
+    separated by galaxy type, against the oracle; forced on small tables too."""
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    rng = np.random.default_rng(n_draws)
+    table = synthetic.synthetic_table(n_prim, n_sec, (n_r, ), 'auto', seed=n_prim)
+    theta = synthetic.zheng07_draws(n_draws, seed=n_draws)
+    kwargs = dict(kwargs)
+    strengths = rng.uniform(-1.2, 1.2, (n_draws, 2)) if kwargs.pop('assembias', False) else None
+    halotab = make_tabcorr(table)
+    force_fused(halotab)
+    set_option(halotab, 'fused_waves', 16)
+    batch = theta if strengths is None else np.hstack([theta, strengths])
+    flags = dict(kwargs, assembias=True) if strengths is not None else kwargs
+    for separate in (False, True):
+        expect = oracle.predict_zheng07_batch(
+            table, theta, separate_gal_type=separate, assembias=strengths, **kwargs)
+        ngal, xi = halotab.predict_batch(batch, separate_gal_type=separate, **flags)
+        assert fused_ran(halotab, (16, )), 'the 16-wave kernel did not run'
+        if separate:
+            for key in expect[0]:
+                assert_rel(ngal[key], expect[0][key], RTOL, 'ngal ' + key)
+            for key in expect[1]:
+                assert_rel(xi[key], expect[1][key], RTOL, 'xi ' + key, floor=1e-13)
+        else:
+            assert_rel(ngal, expect[0], RTOL, 'ngal')
+            assert_rel(xi, expect[1], RTOL, 'xi')
+            total = xi
+    # the fused likelihood
+    if n_r <= 20 and strengths is None:
+        vector = total[0] * 1.1
+        a = rng.normal(size=(n_r, n_r))
+        precision = a @ a.T / np.mean(vector)**2
+        delta = total - vector
+        n_chi, chi2 = halotab.chi2_batch(theta, vector, precision, **kwargs)
+        assert fused_ran(halotab, (16, ))
+        assert_rel(chi2, np.einsum('bi,ij,bj->b', delta, precision, delta), 1e-9)
