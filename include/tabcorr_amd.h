@@ -297,6 +297,16 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *   "fused_waves" 0 (default): 8 waves per workgroup where two workgroups fit a CU; 8 / 16:
  *                 that many where the table fits.
  *   "single_draw" 1 (default): an un-batched predict() goes through one launch.
+ *   "resident"    1: un-batched calls (tc_predict_zheng07_batch with one draw; total
+ *                 correlation function, Zheng07 family) are served by ONE resident launch:
+ *                 the call writes its parameters into a mailbox in page-locked memory, the
+ *                 workgroups answer through page-locked partial sums -- no launch per call.
+ *                 The kernel leaves when no call has arrived for "resident_idle_us"
+ *                 microseconds (default 2000, 10 .. 10^6; the next call launches it again),
+ *                 after 10 s, and before any other kind of call on the handle and
+ *                 tc_table_destroy.  Device-wide synchronisations by the caller
+ *                 (hipDeviceSynchronize, hipFree) wait for it at most that idle time.
+ *                 0 (default): one launch per call.
  *   "trace"       developer timelines (developer builds only, tabcorr_amd_testing.h). */
 int tc_table_set_option(tc_table* table, const char* name, int value);
 

@@ -63,6 +63,9 @@ int tc_debug_trace(tc_table* table, uint64_t* out, int64_t capacity, int64_t* n_
  * 3/4 of its blocks and at the end, and HW_ID (wave slot / SIMD / CU). */
 int tc_debug_wave_trace(tc_table* table, uint64_t* out, int64_t capacity,
                         int64_t* n_waves);
+/* Resident un-batched path (option "resident"): per workgroup the 100 MHz ticks the last call
+ * took from the sight of its parameters to the store of its completion word. */
+int tc_debug_resident_ticks(tc_table* table, uint64_t* out, int64_t capacity, int64_t* n_blocks);
 #ifdef __cplusplus
 }
 #endif

@@ -388,6 +388,22 @@ struct tc_table {
   size_t wave_trace_count = 0;
   tc::host::PinnedBuffer h_in, h_out;
   tc::host::SingleWorkspace single_ws;       // un-batched path
+  // Resident un-batched path (launch.hip: resident_predict; option "resident"): one launch of
+  // resident_draw_kernel on a stream of its own serves the calls until it is told to stop or
+  // none has arrived for idle_us; mailbox = [call number | 7 parameters | one word per
+  // workgroup: the launch it has left] in page-locked memory.
+  struct Resident {
+    int enabled = 0;
+    int idle_us = 2000;
+    int poll_waves = 1;
+    bool running = false;
+    unsigned long long launch_id = 0;
+    hipStream_t stream = nullptr;
+    tc::host::PinnedBuffer mailbox;
+    tc::host::SingleWorkspace ws;
+    int n_theta = 0, n_gauss = 0, blocks = 0;
+    unsigned flags = 0;
+  } resident;
   size_t trace_blocks = 0;
   size_t trace_launches = 0;
 
@@ -477,6 +493,10 @@ inline int64_t many_walkers_limit() {
       std::min<int64_t>(kSingleMaxWalkers, env_int_early("TC_MANY_WALKERS", 64));
   return limit;
 }
+int resident_predict(tc_table* t, const double* theta, int n_theta, int n_gauss, unsigned flags,
+                     double* ngal, double* xi);
+int resident_stop(tc_table* t);
+bool resident_eligible(const tc_table* t, int n_gauss);
 int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_walkers, int n_gauss,
                        unsigned flags, SingleWorkspace* ws, hipStream_t stream);
 int wait_single_done(SingleWorkspace* ws, hipStream_t stream, bool poll = true);

@@ -93,7 +93,21 @@ struct SingleArgs {
   // host memory, sets done[workgroup] = epoch (system-scope release); the host polls.
   unsigned long long* done;
   unsigned long long epoch;
+  // Resident form (resident_draw_kernel: the launch itself is the larger part of an un-batched
+  // call): the workgroups stay on the chip between calls and take every draw from a mailbox
+  // in page-locked host memory -- seven 16-byte entries {parameter, number of the call it
+  // belongs to} (the host writes the number behind the parameter; kResidentStop: leave),
+  // `epoch` = the first call to serve.  A workgroup leaves when told to, when no call has arrived for
+  // idle_ticks, or after life_ticks (100 MHz ticks), and then sets exited[workgroup] =
+  // launch_id behind its last store.
+  const unsigned long long* mailbox;
+  unsigned long long* exited;
+  unsigned long long launch_id;
+  unsigned long long idle_ticks, life_ticks;
+  int poll_waves;            // waves per workgroup that poll the mailbox (1 .. 4)
 };
+constexpr unsigned long long kResidentStop = ~0ull;
+constexpr int kResidentBusyOffset = 64;   // exited[64 + workgroup]: ticks the last call took
 
 struct ContractArgs {
   const double* nbuf;       // (n_bins, ldb)

@@ -1741,14 +1741,18 @@ constexpr int kSingleThreads = 1024;
 constexpr int kSingleMaxNodes = 4096;
 constexpr int kSingleMaxBins = 1024;
 
-__global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs a) {
-  __shared__ double node_value[kSingleMaxNodes];
+template <bool RESIDENT>
+__device__ __forceinline__ void single_draw_body(SingleArgs a) {
+  // (resident: one node per thread; what a thread reads from the table between the calls
+  // stays in LDS -- registers would not hold it next to the body's own 80)
+  __shared__ double node_value[RESIDENT ? kSingleThreads : kSingleMaxNodes];
+  __shared__ unsigned kept_bins[RESIDENT ? 8 : 1][RESIDENT ? kSingleThreads : 1];
+  __shared__ double kept_value[RESIDENT ? 8 : 1][RESIDENT ? kSingleThreads : 1];
   __shared__ double density[kSingleMaxBins];
   __shared__ double slice_sum[kSingleThreads];
   __shared__ double totals[2];
   __shared__ __attribute__((aligned(16))) double table[fm::kTableDoubles];
   const int tid = threadIdx.x;
-  const fm::Consts kc = fm::make_consts();
   auto stamp = [&](int phase) {
 #ifdef TC_DEVELOPER_KNOBS
     if (a.stamps != nullptr && tid == 0)
@@ -1796,6 +1800,118 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
   }
   __syncthreads();
   stamp(1);
+  // Resident form: the rest of the body once per call, the calls taken from the mailbox.
+  // Wave 0 polls it (uncached loads over PCIe; a.poll_waves > 1: that many waves, started a
+  // fraction of a round trip apart -- more samples per round trip, but every reader of the
+  // mailbox's two cache lines delays the host's next stores to them: 13 workgroups x 4 waves
+  // 25 us per call against 14.5 with one wave each) and the others sleep at the barrier; every
+  // path out of the polling loop is bounded by the two time limits.
+  __shared__ volatile int resident_decided;
+  __shared__ int resident_leave;
+  __shared__ double resident_theta[7];
+  __shared__ unsigned long long resident_seen;
+  unsigned long long serving = a.epoch;
+  unsigned long long t_begin = 0, t_last = 0;
+  if (RESIDENT) {
+    t_begin = t_last = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) resident_decided = 0;
+    __syncthreads();
+  }
+  // What a thread reads from memory does not change between the calls of a resident launch:
+  // its quadrature node stays in registers, its eight table positions in LDS (tables of up to
+  // 1024 nodes and launches sized for a single pass: launch.hip, resident_eligible).
+  const int rt = a.rt;
+  const int n_slices = kSingleThreads / rt;
+  const int r = tid % rt, slice = tid / rt;
+  const int64_t per_block = (a.n_positions + n_parts - 1) / n_parts;
+  const int64_t q_begin = per_block * part;
+  const int64_t q_end = q_begin + per_block < a.n_positions ? q_begin + per_block
+                                                             : a.n_positions;
+  auto load_positions = [&](int64_t q0, int (&off_i)[8], int (&off_j)[8], double (&value)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t qu = q0 + (int64_t)u * n_slices;
+      const int64_t q = qu < q_end ? qu : q_begin;
+      // layouts of table.cpp: blocks of 8 positions, LDS row offsets per position
+      const int64_t slot = ((q >> 3) * 4 + (q & 3)) * 4 + ((q >> 2) & 1) * 2;
+      off_i[u] = a.pos_off[slot];
+      off_j[u] = a.pos_off[slot + 1];
+      const int64_t index = (q >> 3) * 8 * rt +
+                            ((((r >> 2) * 16 + (q & 3) * 4 + (r & 3)) << 1) + ((q >> 2) & 1));
+      value[u] = qu < q_end ? a.table[index] : 0.0;
+    }
+  };
+  double kept_lm = 0.0, kept_mass = 0.0, kept_wk = 0.0, kept_n_h = 0.0;
+  bool kept_above = false;
+  if (RESIDENT) {
+    if (tid < n_nodes) {
+      kept_lm = a.log_m[tid];
+      kept_mass = a.m[tid];
+      kept_wk = a.weight[tid];
+      kept_above = a.percentile[tid / a.n_gauss] > a.split;
+    }
+    if (tid < a.n_bins) kept_n_h = a.n_h[tid];
+    if (slice < n_slices && q_begin < q_end) {
+      int off_i[8], off_j[8];
+      double value[8];
+      load_positions(q_begin + slice, off_i, off_j, value);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        // (the positions' bins, 16 bits each)
+        kept_bins[u][tid] = (unsigned)(off_i[u] >> 9) | ((unsigned)(off_j[u] >> 9) << 16);
+        kept_value[u][tid] = value[u];
+      }
+    }
+  }
+  for (;;) {
+  if (RESIDENT) {
+    // One 16-byte entry {value, call number} per parameter, written by the host in that
+    // order: lane i of a polling wave reads entry i with ONE uncached load (a 16-byte read
+    // inside a cache line is a snapshot of it), so a single PCIe round trip both detects the
+    // call and fetches its parameters; the call is there when all seven entries carry its
+    // number.  The first wave to decide publishes the parameters and the decision.
+    if (tid < 64 * a.poll_waves) {
+      typedef unsigned long long __attribute__((ext_vector_type(2))) u64x2;
+      const int lane = tid & 63;
+      const u64x2* entry = (const u64x2*)a.mailbox + (lane < 7 ? lane : 0);
+      u64x2 word = {0ull, 0ull};
+      for (int i = 0; i < (tid >> 6); ++i) __builtin_amdgcn_s_sleep(24);
+      while (resident_decided == 0) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=v"(word) : "v"(entry) : "memory");
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        const bool here = word.y == serving;
+        const bool stop = word.y == kResidentStop;
+        int leave = -1;
+        if (__builtin_amdgcn_ballot_w64(!here) == 0) leave = 0;
+        else if (__builtin_amdgcn_ballot_w64(stop) != 0 || now - t_last > a.idle_ticks ||
+                 now - t_begin > a.life_ticks) leave = 1;
+        if (leave >= 0) {
+          // (several waves may decide at once: a call that is there is there for all of them,
+          // and "leave" can only lose against "go" -- the later writer -- when the call
+          // arrived in between, which the host handles like any workgroup that has left)
+          if (lane < 7) resident_theta[lane] = __builtin_bit_cast(double, word.x);
+          if (lane == 0) {
+            resident_leave = leave;
+            resident_seen = now;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) resident_decided = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __syncthreads();
+    const int leave = resident_leave;
+    for (int i = 0; i < 7; ++i) a.theta_value[i] = i < a.n_theta ? resident_theta[i] : 0.0;
+    __syncthreads();
+    if (tid == 0) resident_decided = 0;
+    if (leave != 0) break;
+    a.epoch = serving;
+  }
+  // (made per call: the resident form would otherwise hold their registers while it waits)
+  const fm::Consts kc = fm::make_consts();
   const DrawSetup d = prepare_draw(table, kc, a.theta_value[0], a.theta_value[1],
                                    a.theta_value[2], a.theta_value[3], a.theta_value[4],
                                    assembias ? a.theta_value[5] : 0.0,
@@ -1805,10 +1921,14 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
   const double a_cen = d.a_cen, a_sat = d.a_sat;
   const double f1 = (1.0 - a.split) / a.split, f2 = a.split / (1.0 - a.split);
 
-  for (int idx = tid; idx < n_nodes; idx += kSingleThreads) {
+  // (resident: one node per thread, its constants in registers -- launch.hip admits only
+  // tables of up to kSingleThreads nodes and launches sized for a single pass)
+  const int node_end = RESIDENT ? (tid < n_nodes ? tid + 1 : 0) : n_nodes;
+  for (int idx = tid; idx < node_end; idx += kSingleThreads) {
     const int g = idx / a.n_gauss;
-    const double lm = a.log_m[idx], mass = a.m[idx], wk = a.weight[idx];
-    const bool above = a.percentile[g] > a.split;
+    const double lm = RESIDENT ? kept_lm : a.log_m[idx], mass = RESIDENT ? kept_mass : a.m[idx];
+    const double wk = RESIDENT ? kept_wk : a.weight[idx];
+    const bool above = RESIDENT ? kept_above : a.percentile[g] > a.split;
     double n;
     if (g < a.n_central) {
       n = fma(0.5, fm::erf_fast(table, kc, (lm - log_m_min) * inv_sigma), 0.5);
@@ -1840,7 +1960,7 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
   for (int g = tid; g < a.n_bins; g += kSingleThreads) {
     double acc = 0.0;
     for (int k = 0; k < a.n_gauss; ++k) acc += node_value[g * a.n_gauss + k];
-    density[g] = acc * a.n_h[g];
+    density[g] = acc * (RESIDENT ? kept_n_h : a.n_h[g]);
   }
   __syncthreads();
   if (tid < 128) {   // centrals / satellites totals: one wave each, fixed order
@@ -1856,29 +1976,22 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
 
   // contraction of this workgroup's positions: thread = (slice, r); eight positions per
   // pass, their loads issued together (the launch sizes the grid for a single pass)
-  const int rt = a.rt;
-  const int n_slices = kSingleThreads / rt;
-  const int r = tid % rt, slice = tid / rt;
-  const int64_t per_block = (a.n_positions + n_parts - 1) / n_parts;
-  const int64_t q_begin = per_block * part;
-  const int64_t q_end = q_begin + per_block < a.n_positions ? q_begin + per_block
-                                                             : a.n_positions;
   double acc = 0.0;
   if (slice < n_slices && q_begin < q_end) {
-    for (int64_t q0 = q_begin + slice; q0 < q_end; q0 += 8 * n_slices) {
+    const int64_t q_last = RESIDENT ? q_begin + slice + 1 : q_end;
+    for (int64_t q0 = q_begin + slice; q0 < q_last; q0 += 8 * n_slices) {
       int off_i[8], off_j[8];
       double value[8];
+      if (RESIDENT) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int64_t qu = q0 + (int64_t)u * n_slices;
-        const int64_t q = qu < q_end ? qu : q_begin;
-        // layouts of table.cpp: blocks of 8 positions, LDS row offsets per position
-        const int64_t slot = ((q >> 3) * 4 + (q & 3)) * 4 + ((q >> 2) & 1) * 2;
-        off_i[u] = a.pos_off[slot];
-        off_j[u] = a.pos_off[slot + 1];
-        const int64_t index = (q >> 3) * 8 * rt +
-                              ((((r >> 2) * 16 + (q & 3) * 4 + (r & 3)) << 1) + ((q >> 2) & 1));
-        value[u] = qu < q_end ? a.table[index] : 0.0;
+        for (int u = 0; u < 8; ++u) {
+          const unsigned bins = kept_bins[u][tid];
+          off_i[u] = (int)(bins & 0xffffu) << 9;
+          off_j[u] = (int)(bins >> 16) << 9;
+          value[u] = kept_value[u][tid];
+        }
+      } else {
+        load_positions(q0, off_i, off_j, value);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -1920,6 +2033,30 @@ __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs 
     }
   }
   stamp(4);
+  if (!RESIDENT) break;
+  ++serving;
+  {
+    // (diagnosis, tools/r03_resident.py: 100 MHz ticks from the sight of the call to here)
+    t_last = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) a.exited[kResidentBusyOffset + blockIdx.x] = t_last - resident_seen;
+  }
+  }   // (calls of the resident form)
+  if (RESIDENT && tid == 0) {
+    __threadfence_system();
+    __hip_atomic_store(a.exited + blockIdx.x, a.launch_id, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+__global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs a) {
+  single_draw_body<false>(a);
+}
+
+// The same body, resident: one launch serves every un-batched call until the host says stop,
+// none has arrived for a.idle_ticks, or a.life_ticks have passed (SingleArgs, kernel_args.h).
+// One table, one draw per call (a.n_tables == 0, a.n_walkers == 0).
+__global__ __launch_bounds__(kSingleThreads) void resident_draw_kernel(SingleArgs a) {
+  single_draw_body<true>(a);
 }
 
 // ---- float32 variant for tables with many correlation-function bins -------------------

@@ -1159,6 +1159,10 @@ bool single_draw_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsig
 // the contraction, then one completion word per workgroup.  n_walkers draws (1 ..
 // kSingleMaxWalkers) go through ONE launch; combine_single_draw() turns a draw's part into
 // (ngal, xi) once wait_single_done() has seen every workgroup's word.
+void fill_single_args(const tc_table* t, const Quadrature* q, const double* theta, int n_theta,
+                      int n_gauss, unsigned flags, int blocks, const SingleWorkspace& ws,
+                      tc::SingleArgs* out);
+
 int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_walkers, int n_gauss,
                        unsigned flags, SingleWorkspace* ws, hipStream_t stream) {
   Quadrature* q = nullptr;
@@ -1172,6 +1176,32 @@ int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_walk
   status = ws->prepare(n_walkers, blocks, t->rt, n_walkers > 1 ? n_walkers * n_theta : 0);
   if (status != TC_OK) return status;
   tc::SingleArgs sa{};
+  fill_single_args(t, q, theta, n_theta, n_gauss, flags, blocks, *ws, &sa);
+  if (n_walkers > 1) {
+    // the draws travel through page-locked memory the kernel reads itself
+    memcpy(ws->theta(), theta, (size_t)n_walkers * n_theta * sizeof(double));
+    sa.theta_many = ws->theta();
+    sa.n_walkers = n_walkers;
+  }
+  if (t->tuning.trace) {
+    // developer timeline (tc_table_set_option "trace"): 8 stamps per workgroup
+    status = t->trace.reserve((size_t)n_walkers * kSingleMaxBlocks * 8 *
+                                  sizeof(unsigned long long), stream);
+    if (status != TC_OK) return status;
+    t->trace_blocks = (size_t)blocks;
+    sa.stamps = (unsigned long long*)t->trace.ptr;
+  }
+  hipLaunchKernelGGL(tc::single_draw_kernel, dim3((unsigned)(blocks * n_walkers)),
+                     dim3(tc::kSingleThreads), 0, stream, sa);
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+
+// The argument block of one draw against one table (results and completion words in `ws`).
+void fill_single_args(const tc_table* t, const Quadrature* q, const double* theta, int n_theta,
+                      int n_gauss, unsigned flags, int blocks, const SingleWorkspace& ws,
+                      tc::SingleArgs* out) {
+  tc::SingleArgs& sa = *out;
   for (int i = 0; i < 7; ++i) sa.theta_value[i] = i < n_theta ? theta[i] : 0.0;
   sa.n_theta = n_theta;
   sa.n_bins = t->n_bins;
@@ -1191,8 +1221,8 @@ int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_walk
   sa.rt = t->rt;
   sa.n_r = t->n_r;
   sa.mode = t->mode;
-  sa.ngal = ws->ngal();
-  sa.partial = ws->partial();
+  sa.ngal = ws.ngal();
+  sa.partial = ws.partial();
   sa.n_tables = 0;
   sa.blocks_per_table = blocks;
   sa.tables = nullptr;
@@ -1200,27 +1230,146 @@ int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_walk
   sa.class_log_m = sa.class_m = sa.class_weight = sa.class_n_h = sa.class_percentile = nullptr;
   sa.theta_many = nullptr;
   sa.n_walkers = 0;
-  if (n_walkers > 1) {
-    // the draws travel through page-locked memory the kernel reads itself
-    memcpy(ws->theta(), theta, (size_t)n_walkers * n_theta * sizeof(double));
-    sa.theta_many = ws->theta();
-    sa.n_walkers = n_walkers;
-  }
-  sa.done = ws->done();
-  sa.epoch = ws->epoch;
+  sa.done = ws.done();
+  sa.epoch = ws.epoch;
   sa.stamps = nullptr;
-  if (t->tuning.trace) {
-    // developer timeline (tc_table_set_option "trace"): 8 stamps per workgroup
-    status = t->trace.reserve((size_t)n_walkers * kSingleMaxBlocks * 8 *
-                                  sizeof(unsigned long long), stream);
-    if (status != TC_OK) return status;
-    t->trace_blocks = (size_t)blocks;
-    sa.stamps = (unsigned long long*)t->trace.ptr;
+}
+
+// ---- resident un-batched path ---------------------------------------------------------------
+//
+// Of the 15 us of an un-batched call 10 are the launch path (an empty kernel whose completion
+// word the host polls: tools/micro/graph_launch.hip).  With option "resident" the workgroups
+// of ONE launch of resident_draw_kernel stay on the chip: every call writes its parameters and
+// its number into a mailbox in page-locked memory, the workgroups (polling it over PCIe)
+// evaluate the draw and answer through the same page-locked partial sums and completion words
+// as single_draw_kernel.  The kernel leaves by itself when no call has arrived for
+// resident.idle_us (or after 10 s), so that nothing ever waits for it longer than that; a call
+// that finds it gone (a workgroup's `exited` word carries the launch's number) launches it
+// again.  Every other entry point of the handle stops it first (it would otherwise hold a
+// hardware queue that a lane's kernels may share).
+namespace {
+constexpr size_t kMailboxEntryWords = 16;     // seven entries {parameter, call number}, padded
+constexpr size_t kMailboxWords = kMailboxEntryWords + 2 * kSingleMaxBlocks;
+static_assert(tc::kResidentBusyOffset == kSingleMaxBlocks, "busy ticks behind the exited words");
+
+// (the parameter before the call number of every entry: x86 keeps the order of the stores)
+void publish(unsigned long long* mailbox, const double* theta, int n_theta,
+             unsigned long long call) {
+  for (int i = 0; i < 7; ++i) {
+    const double value = i < n_theta ? theta[i] : 0.0;
+    unsigned long long bits;
+    memcpy(&bits, &value, 8);
+    __atomic_store_n(mailbox + 2 * i, bits, __ATOMIC_RELAXED);
+    __atomic_store_n(mailbox + 2 * i + 1, call, __ATOMIC_RELEASE);
   }
-  hipLaunchKernelGGL(tc::single_draw_kernel, dim3((unsigned)(blocks * n_walkers)),
-                     dim3(tc::kSingleThreads), 0, stream, sa);
-  TC_HIP(hipGetLastError());
+}
+
+// 0: every workgroup has answered call `epoch`; 1: one has left before it did.
+int resident_wait(tc_table* t, int* left) {
+  tc_table::Resident& r = t->resident;
+  const volatile unsigned long long* done = r.ws.done();
+  const volatile unsigned long long* exited =
+      (unsigned long long*)r.mailbox.ptr + kMailboxEntryWords;
+  const unsigned long long epoch = r.ws.epoch;
+  *left = 0;
+  timespec start{};
+  for (int b = 0; b < r.blocks; ++b) {
+    unsigned spins = 0;
+    while (done[b] != epoch) {
+      if (exited[b] == r.launch_id) {
+        *left = 1;
+        return TC_OK;
+      }
+      __builtin_ia32_pause();
+      if ((++spins & 0x3ff) != 0) continue;
+      timespec now{};
+      clock_gettime(CLOCK_MONOTONIC, &now);
+      if (start.tv_sec == 0 && start.tv_nsec == 0) start = now;
+      if ((now.tv_sec - start.tv_sec) * 1000000000LL + (now.tv_nsec - start.tv_nsec) >
+          500000000LL) {
+        (void)resident_stop(t);
+        return fail(TC_ERR_HIP, "the resident kernel did not answer (workgroup %d)", b);
+      }
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
   return TC_OK;
+}
+}  // namespace
+
+int resident_stop(tc_table* t) {
+  tc_table::Resident& r = t->resident;
+  if (!r.running) return TC_OK;
+  for (int i = 0; i < 7; ++i)
+    __atomic_store_n((unsigned long long*)r.mailbox.ptr + 2 * i + 1, tc::kResidentStop,
+                     __ATOMIC_RELEASE);
+  r.running = false;
+  TC_HIP(hipStreamSynchronize(r.stream));
+  return TC_OK;
+}
+
+// One node per thread and a single pass over the workgroup's positions (what the resident
+// kernel keeps in registers between the calls).
+bool resident_eligible(const tc_table* t, int n_gauss) {
+  const int n_slices = tc::kSingleThreads / t->rt;
+  return (int64_t)t->n_bins * n_gauss <= tc::kSingleThreads &&
+         t->plan.n_positions <= (int64_t)single_draw_blocks(t) * 8 * n_slices;
+}
+
+int resident_predict(tc_table* t, const double* theta, int n_theta, int n_gauss, unsigned flags,
+                     double* ngal, double* xi) {
+  tc_table::Resident& r = t->resident;
+  Quadrature* q = nullptr;
+  int status = get_quadrature(t, n_gauss, &q);
+  if (status != TC_OK) return status;
+  const int blocks = single_draw_blocks(t);
+  if (r.running && (r.n_theta != n_theta || r.n_gauss != n_gauss || r.flags != flags ||
+                    r.blocks != blocks)) {
+    status = resident_stop(t);        // (another kind of call: its own launch)
+    if (status != TC_OK) return status;
+  }
+  if (r.stream == nullptr) TC_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+  if (r.mailbox.ptr == nullptr) {
+    status = r.mailbox.reserve(kMailboxWords * 8);
+    if (status != TC_OK) return status;
+    memset(r.mailbox.ptr, 0, r.mailbox.bytes);
+  }
+  status = r.ws.prepare(1, blocks, t->rt, 0);       // (a new call number: r.ws.epoch)
+  if (status != TC_OK) return status;
+  unsigned long long* mailbox = (unsigned long long*)r.mailbox.ptr;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    publish(mailbox, theta, n_theta, r.ws.epoch);
+    if (!r.running) {
+      tc::SingleArgs sa{};
+      fill_single_args(t, q, theta, n_theta, n_gauss, flags, blocks, r.ws, &sa);
+      sa.mailbox = mailbox;
+      sa.exited = mailbox + kMailboxEntryWords;
+      sa.launch_id = ++r.launch_id;
+      sa.idle_ticks = (unsigned long long)std::max(1, r.idle_us) * 100ull;   // 100 MHz
+      sa.life_ticks = 1000000000ull;                                          // 10 s
+      sa.poll_waves = std::max(1, std::min(4, r.poll_waves));
+      hipLaunchKernelGGL(tc::resident_draw_kernel, dim3((unsigned)blocks),
+                         dim3(tc::kSingleThreads), 0, r.stream, sa);
+      TC_HIP(hipGetLastError());
+      r.running = true;
+      r.n_theta = n_theta;
+      r.n_gauss = n_gauss;
+      r.flags = flags;
+      r.blocks = blocks;
+    }
+    int left = 0;
+    status = resident_wait(t, &left);
+    if (status != TC_OK) return status;
+    if (!left) {
+      combine_single_draw(t, r.ws, 0, ngal, xi);
+      return TC_OK;
+    }
+    // a workgroup has left (idle or life time) before it saw this call: all of them out, then
+    // a new launch serves it
+    status = resident_stop(t);
+    if (status != TC_OK) return status;
+  }
+  return fail(TC_ERR_HIP, "the resident kernel keeps leaving before it answers");
 }
 
 // The same for every table of an interpolator in one launch (interp.cpp fills the per-class

@@ -201,6 +201,10 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
 int tc_table_destroy(tc_table* t) {
   if (t == nullptr) return TC_OK;
   (void)hipSetDevice(t->device);
+  (void)resident_stop(t);
+  if (t->resident.stream) (void)hipStreamDestroy(t->resident.stream);
+  t->resident.mailbox.release();
+  t->resident.ws.buffer.release();
   for (tc_table::Lane& lane : t->lanes)
     if (lane.stream) (void)hipStreamSynchronize(lane.stream);
   for (void* p : {t->d_table, t->d_n_h, t->d_percentile, t->d_perm, t->d_math_table,
@@ -272,6 +276,7 @@ int tc_predict_zheng07_batch_device(tc_table* t, const double* theta_device,
   if (n_draws == 0) return TC_OK;
   TC_CHECK(ngal_device && xi_device, "output pointer is NULL");
   TC_HIP(hipSetDevice(t->device));
+  if (t->resident.running && (status = resident_stop(t)) != TC_OK) return status;
   const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
   const int n_comp = separate ? t->plan.n_components : 1;
   if (t->force_lane >= 0)
@@ -359,6 +364,9 @@ int tc_predict_zheng07_many(tc_table* t, const double* theta, int n_theta, int n
     return tc_predict_zheng07_batch(t, theta, n_theta, n_walkers, n_gauss, flags, ngal, xi);
   }
   TC_HIP(hipSetDevice(t->device));
+  if (n_walkers == 1 && t->resident.enabled && resident_eligible(t, n_gauss))
+    return resident_predict(t, theta, n_theta, n_gauss, flags, ngal, xi);
+  if (t->resident.running && (status = resident_stop(t)) != TC_OK) return status;
   status = launch_single_draw(t, theta, n_theta, n_walkers, n_gauss, flags, &t->single_ws,
                               t->stream);
   if (status != TC_OK) return status;
@@ -462,6 +470,10 @@ int tc_chi2_zheng07_batch_device(tc_table* t, const double* theta_device, int n_
   TC_CHECK(n_draws <= max_slab(t), "at most %lld draws per call",
            (long long)max_slab(t));
   TC_HIP(hipSetDevice(t->device));
+  if (t->resident.running) {
+    const int stopped = resident_stop(t);
+    if (stopped != TC_OK) return stopped;
+  }
   status = upload_chi2_data(t, data, precision);
   if (status != TC_OK) return status;
   // xi stays in a workspace of the lane the call runs on; the lane's `finished` event is
@@ -591,6 +603,10 @@ int predict_async(tc_table* t, const double* theta, int n_theta, int64_t n_draws
                             is_pinned(second, second_count * 8, &second_seen)),
            "asynchronous calls need page-locked buffers (tc_host_alloc / tc_host_register)");
   TC_HIP(hipSetDevice(t->device));
+  if (t->resident.running) {
+    const int stopped = resident_stop(t);
+    if (stopped != TC_OK) return stopped;
+  }
   tc_table::Ticket* ticket = nullptr;
   const int lane_index = t->tuning.pipeline ? (int)(t->device_calls++ % t->n_lanes) : 0;
   tc_table::Lane& lane = t->lanes[lane_index];
@@ -710,6 +726,10 @@ int tc_mean_occupation_zheng07_batch(tc_table* t, const double* theta, int n_the
   if (n_draws == 0) return TC_OK;
   TC_CHECK(occupation != nullptr, "output pointer is NULL");
   TC_HIP(hipSetDevice(t->device));
+  if (t->resident.running) {
+    const int stopped = resident_stop(t);
+    if (stopped != TC_OK) return stopped;
+  }
   const int64_t slab = max_slab(t);
   for (int64_t begin = 0; begin < n_draws; begin += slab) {
     const int64_t n = std::min(slab, n_draws - begin);
@@ -739,6 +759,10 @@ int tc_predict_occupation_batch(tc_table* t, const double* occupation,
   if (n_draws == 0) return TC_OK;
   TC_CHECK(occupation && ngal && xi, "NULL array");
   TC_HIP(hipSetDevice(t->device));
+  if (t->resident.running) {
+    const int stopped = resident_stop(t);
+    if (stopped != TC_OK) return stopped;
+  }
   const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
   const int n_comp = separate ? t->plan.n_components : 1;
   const int64_t slab = max_slab(t);
@@ -818,6 +842,24 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
   } else if (key == "fused_min_draws" || key == "fused_max_draws") {
     TC_CHECK(value >= (key == "fused_min_draws" ? 0 : 1), "%s must be positive", name);
     (key == "fused_min_draws" ? t->tuning.fused_min_draws : t->tuning.fused_max_draws) = value;
+  } else if (key == "resident") {
+    // 1: un-batched calls (one draw, total correlation function, Zheng07 family) are served by
+    // ONE resident launch that takes them from a mailbox in page-locked memory (launch.hip:
+    // resident_predict); it leaves when idle for "resident_idle_us" and before any other kind
+    // of call on this handle.  0 (default): one launch per call.
+    TC_CHECK(value == 0 || value == 1, "resident must be 0 or 1");
+    t->resident.enabled = value;
+    if (value == 0) return resident_stop(t);
+  } else if (key == "resident_poll_waves") {
+    TC_CHECK(value >= 1 && value <= 4, "resident_poll_waves must be in [1, 4]");
+    const int status = resident_stop(t);
+    if (status != TC_OK) return status;
+    t->resident.poll_waves = value;
+  } else if (key == "resident_idle_us") {
+    TC_CHECK(value >= 10 && value <= 1000000, "resident_idle_us must be in [10, 1000000]");
+    const int status = resident_stop(t);
+    if (status != TC_OK) return status;
+    t->resident.idle_us = value;
   } else if (key == "fused_waves") {
     TC_CHECK(value == 0 || value == 8 || value == 16, "fused_waves must be 0, 8 or 16");
     t->tuning.fused_waves = value;
@@ -919,6 +961,16 @@ int tc_debug_wave_trace(tc_table* t, uint64_t* out, int64_t capacity, int64_t* n
   const int64_t n = std::min<int64_t>(capacity, (int64_t)t->wave_trace_count);
   TC_HIP(hipMemcpy(out, t->wave_trace.ptr, (size_t)n * 6 * sizeof(uint64_t),
                    hipMemcpyDeviceToHost));
+  return TC_OK;
+}
+
+int tc_debug_resident_ticks(tc_table* t, uint64_t* out, int64_t capacity, int64_t* n_blocks) {
+  TC_CHECK(t != nullptr && n_blocks != nullptr, "NULL argument");
+  *n_blocks = t->resident.mailbox.ptr != nullptr ? t->resident.blocks : 0;
+  if (out == nullptr || t->resident.mailbox.ptr == nullptr) return TC_OK;
+  const unsigned long long* words = (const unsigned long long*)t->resident.mailbox.ptr;
+  for (int64_t b = 0; b < std::min<int64_t>(capacity, *n_blocks); ++b)
+    out[b] = words[16 + kSingleMaxBlocks + b];
   return TC_OK;
 }
 

@@ -241,6 +241,23 @@ class TabCorr:
     def invalidate(self):
         self._device = None
 
+    def set_resident(self, enabled=True, idle_us=None):
+        """Serve un-batched ``predict(model)`` calls (one per MCMC step,
+        ``README.md:72-75``) from ONE resident kernel launch instead of one
+        launch per call: the launch path is 10 of the 15 us of such a call.
+        The kernel takes every draw from a mailbox in page-locked memory and
+        leaves by itself when no call has arrived for ``idle_us`` microseconds
+        (default 2000; the next call launches it again) or when any other kind
+        of call is made on this table.  Results are bit-identical to the
+        one-launch-per-call path."""
+        device = self.to_device()
+        with device.lock:
+            if idle_us is not None:
+                _lib.check(device.lib.tc_table_set_option(
+                    device.handle, b'resident_idle_us', int(idle_us)))
+            _lib.check(device.lib.tc_table_set_option(
+                device.handle, b'resident', 1 if enabled else 0))
+
     # -- consistency checks ---------------------------------------------------
 
     def _check_consistency(self, model):

@@ -292,3 +292,77 @@ def test_random_interleaving_of_all_host_paths():
                             capture_output=True, text=True, timeout=300)
     assert result.returncode == 0, result.stdout[-2000:] + result.stderr[-2000:]
     assert 'stress ok' in result.stdout
+
+
+def test_resident_kernel_serves_unbatched_calls():
+    """Option "resident": ONE launch of resident_draw_kernel answers the un-batched calls from a
+    mailbox in page-locked memory -- the same results as one launch per call to the last bits, against the oracle, across
+    idle time-outs (the kernel leaves, the next call launches it again), other kinds of calls
+    in between (they stop it), other flags, and a handle destroyed while it runs."""
+    import time
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    theta = synthetic.zheng07_draws(300, seed=8)
+    halotab = make_tabcorr(table)
+    plain = [halotab.predict_batch(theta[i:i + 1]) for i in range(300)]
+    halotab.set_resident(True)
+    first = []
+    for i in range(300):
+        ngal, xi = halotab.predict_batch(theta[i:i + 1])
+        # (another instantiation of the same body: the compiler contracts a few products and
+        # sums differently -- the last bits may differ, nothing else)
+        assert_rel(ngal, plain[i][0], 1e-14)
+        assert_rel(xi, plain[i][1], 1e-14)
+        first.append((ngal, xi))
+    plain = first           # from here on bit for bit: the same kernel, whatever happens around
+    want = oracle.predict_zheng07_batch(table, theta[:5])
+    for i in range(5):
+        assert_rel(plain[i][0], want[0][i:i + 1], RTOL)
+        assert_rel(plain[i][1], want[1][i:i + 1], RTOL)
+    # idle time-out: the kernel leaves after 50 us without a call
+    halotab.set_resident(True, idle_us=50)
+    for i in range(40):
+        ngal, xi = halotab.predict_batch(theta[i:i + 1])
+        assert np.array_equal(xi, plain[i][1]), i
+        time.sleep(0.0002 * (i % 4))
+    halotab.set_resident(True, idle_us=2000)
+    # a batch, several walkers, the likelihood, other flags in between
+    batch = halotab.predict_batch(theta[:100])
+    assert_rel(batch[1][:5], want[1], RTOL)
+    ngal, xi = halotab.predict_batch(theta[7:8])
+    assert np.array_equal(xi, plain[7][1])
+    several = halotab.predict_batch(theta[:3])
+    assert_rel(several[1], want[1][:3], RTOL)
+    ngal, xi = halotab.predict_batch(theta[9:10], modulate_with_cenocc=True)
+    expect = oracle.predict_zheng07_batch(table, theta[9:10], modulate_with_cenocc=True)
+    assert_rel(xi, expect[1], RTOL)
+    ngal, xi = halotab.predict_batch(theta[9:10])
+    assert np.array_equal(xi, plain[9][1])
+    # separated by galaxy type is not a resident call: served by the batched path
+    ngal_s, xi_s = halotab.predict_batch(theta[9:10], separate_gal_type=True)
+    total = sum(xi_s[key] for key in xi_s)
+    assert_rel(total, plain[9][1], 1e-12)
+    # NaN parameters
+    bad = theta[11:12].copy()
+    bad[0, 1] = np.nan
+    ngal, xi = halotab.predict_batch(bad)
+    assert np.isnan(ngal[0]) and np.all(np.isnan(xi))
+    ngal, xi = halotab.predict_batch(theta[11:12])
+    assert np.array_equal(xi, plain[11][1])
+    # switched off: stops it; a table deleted while its kernel runs stops it too
+    halotab.set_resident(False)
+    ngal, xi = halotab.predict_batch(theta[12:13])
+    assert_rel(xi, plain[12][1], 1e-14)
+    other = make_tabcorr(table)
+    other.set_resident(True)
+    other.predict_batch(theta[:1])
+    del other
+    # the model interface (the reference's usage)
+    from tabcorr_amd import Zheng07Model
+    model = Zheng07Model(redshift=table['attrs']['redshift'])
+    for key, value in zip(('logMmin', 'sigma_logM', 'logM0', 'logM1', 'alpha'), theta[3]):
+        model.param_dict[key] = value
+    halotab.set_resident(True)
+    ngal, xi = halotab.predict(model)
+    assert np.array_equal(xi, plain[3][1][0])
