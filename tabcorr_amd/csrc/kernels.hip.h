@@ -180,7 +180,7 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
   } else if (central && !assembias) {
     // sum_k w_k (1 + erf_k) / 2 = (W + sum_k w_k erf_k) / 2 with W = sum_k w_k from the host
     // (get_quadrature): one instruction per node less than forming every <N_cen> first
-#pragma unroll
+#pragma unroll NGAUSS > 0 ? NGAUSS : 1
     for (int k = 0; k < n_gauss; ++k) {
       const double lm = log_m[g * n_gauss + k];
       acc = fma(weight[g * n_gauss + k],
@@ -188,7 +188,7 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
     }
     acc = fma(0.5, acc, 0.5 * weight_sum[g]);
   } else if (central) {
-#pragma unroll
+#pragma unroll NGAUSS > 0 ? NGAUSS : 1
     for (int k = 0; k < n_gauss; ++k) {
       const double lm = log_m[g * n_gauss + k];
       double n = fma(0.5, fm::erf_fast(table, kc, (lm - log_m_min) * inv_sigma), 0.5);
@@ -197,7 +197,7 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
       acc = fma(weight[g * n_gauss + k], n, acc);
     }
   } else {
-#pragma unroll
+#pragma unroll NGAUSS > 0 ? NGAUSS : 1
     for (int k = 0; k < n_gauss; ++k) {
       const double x = mass[g * n_gauss + k] - m0;
       // 1e-300 keeps log2's input a positive normal number on the lanes with
@@ -506,9 +506,6 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_leauthaud11_kernel(Occ
   sc_f64 weight = (sc_f64)a.weight;
   sc_f64 n_h = (sc_f64)a.n_h;
   sc_i32 perm = (sc_i32)a.perm;
-  constexpr bool modulate = MODULATE;
-  constexpr double kLog2Of10 = 3.32192809488736234787, kLog10Of2 = 0.30102999566398119521;
-  constexpr double kLog2E = 1.44269504088896340736;
 
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int tile = item % a.n_tiles, split = item / a.n_tiles;
