@@ -2015,17 +2015,26 @@ __device__ __forceinline__ void single_draw_body(SingleArgs a) {
   if (tid < rt * kFan) slice_sum[tid] = level;
   __syncthreads();
   if (tid < 64) {
+    // Write-through stores to the page-locked results (system scope, no cache holds them), the
+    // wave waits until all of them are acknowledged, then the completion word the same way:
+    // what a system-scope fence + release store would add -- two write-backs and an
+    // invalidation of the whole L2 -- has nothing to write back here and costs ~1 us per call.
+    auto store_host = [](double* address, double value) {
+      __hip_atomic_store((unsigned long long*)address,
+                         __builtin_bit_cast(unsigned long long, value), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    };
     if (tid < rt) {
       double total = 0.0;
       for (int s = 0; s < kFan; ++s) total += slice_sum[s * rt + tid];
-      a.partial[(int64_t)part * rt + tid] = total;     // host memory
+      store_host(a.partial + (int64_t)part * rt + tid, total);
     } else if (tid < rt + 2 && part == 0) {
-      a.ngal[tid - rt] = totals[tid - rt];
+      store_host(a.ngal + (tid - rt), totals[tid - rt]);
     }
     if (a.done != nullptr) {
-      __threadfence_system();
+      __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0): the wave's stores have arrived
       if (tid == 0)
-        __hip_atomic_store(a.done + blockIdx.x, a.epoch, __ATOMIC_RELEASE,
+        __hip_atomic_store(a.done + blockIdx.x, a.epoch, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
