@@ -871,6 +871,10 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     t->tuning.prio_fused_out = value & 3;
   } else if (key == "single_draw") {
     t->tuning.single_draw = value != 0;
+  } else if (key == "single_round") {
+    // (first table of an interpolator) 1: its un-batched call is sized so that all tables'
+    // workgroups are on the chip at once; 0: one pass over the positions per workgroup
+    t->tuning.single_round = value != 0;
   } else if (key == "poll_done") {
     // un-batched calls: 1 (default) poll the kernel's completion words in page-locked host
     // memory, 0 wait with hipStreamSynchronize
