@@ -221,6 +221,8 @@ struct Tuning {
   int lanes = 4;              // pipelining lanes of device-pointer calls (1..4)
   int pipeline = 1;           // 0: every device-pointer call on lane 0 (kernels serialised)
   int single_draw = 1;        // one-launch path for un-batched predict()
+  int many_blocks = 256;      // workgroups of a launch that several walkers share: one round
+                              // (64 walkers 41 -> 37 us per call against 128, 512: 44)
   int single_round = 1;       // un-batched Interpolator.predict: all tables' workgroups at once
   int poll_done = 1;          // ... completed by polling its completion words in host memory
   int quad_waves = 0;         // resident contraction waves per SIMD (quadratic-form kernel;

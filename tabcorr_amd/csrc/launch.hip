@@ -1172,7 +1172,7 @@ int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_walk
   // evaluates all occupation nodes of its draw, and the host polls one word per workgroup)
   // when many draws share the launch
   const int blocks = std::max(1, std::min(single_draw_blocks(t),
-                                          std::max(2, env_int("TC_MANY_BLOCKS", 128) / n_walkers)));
+                                          std::max(2, t->tuning.many_blocks / n_walkers)));
   status = ws->prepare(n_walkers, blocks, t->rt, n_walkers > 1 ? n_walkers * n_theta : 0);
   if (status != TC_OK) return status;
   tc::SingleArgs sa{};

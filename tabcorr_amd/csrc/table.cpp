@@ -871,6 +871,9 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     t->tuning.prio_fused_out = value & 3;
   } else if (key == "single_draw") {
     t->tuning.single_draw = value != 0;
+  } else if (key == "many_blocks") {
+    TC_CHECK(value >= 2 && value <= 4096, "many_blocks must be in [2, 4096]");
+    t->tuning.many_blocks = value;
   } else if (key == "single_round") {
     // (first table of an interpolator) 1: its un-batched call is sized so that all tables'
     // workgroups are on the chip at once; 0: one pass over the positions per workgroup
