@@ -366,3 +366,40 @@ def test_resident_kernel_serves_unbatched_calls():
     halotab.set_resident(True)
     ngal, xi = halotab.predict(model)
     assert np.array_equal(xi, plain[3][1][0])
+
+
+@pytest.mark.parametrize('shape, n_prim', [((5, 5), 50), ((4, 4, 4), 50), ((4, 7), 50), ((4, 4, 4), 6)])
+def test_unbatched_interpolator_in_one_round_of_workgroups(shape, n_prim):
+    """Un-batched Interpolator.predict(model): the launch sized so that all tables' workgroups
+    are on the chip at once (250 workgroups of two passes for 5 x 5 tables of 100 bins, 256 of
+    four passes for the 64 tables of a 4 x 4 x 4 grid) gives what one pass per workgroup gives,
+    and what the oracle gives."""
+    from tabcorr_amd import Interpolator, Zheng07Model, synthetic, _lib
+    from oracle import tabcorr_oracle as oracle
+    lib = _lib.load()
+    tables, keys, points = synthetic.synthetic_interpolator(shape, n_prim, 1, (19, ), 'auto',
+                                                            seed=len(shape) + n_prim)
+    interp = Interpolator([make_tabcorr(t) for t in tables],
+                          {k: points[:, d] for d, k in enumerate(keys)})
+    rng = np.random.default_rng(5)
+    theta = synthetic.zheng07_draws(3, seed=9)
+    setup = oracle.interpolator_setup(tables, points)
+    handle = interp.to_device().tables[0].handle
+    for i in range(3):
+        model = Zheng07Model(redshift=tables[0]['attrs']['redshift'])
+        for key, value in zip(('logMmin', 'sigma_logM', 'logM0', 'logM1', 'alpha'), theta[i]):
+            model.param_dict[key] = value
+        x = np.array([rng.uniform(points[:, d].min(), points[:, d].max())
+                      for d in range(len(keys))])
+        for d, key in enumerate(keys):
+            model.param_dict[key] = x[d]
+        results = []
+        for single_round in (1, 0):
+            _lib.check(lib.tc_table_set_option(handle, b'single_round', single_round))
+            results.append(interp.predict(model))
+        _lib.check(lib.tc_table_set_option(handle, b'single_round', 1))
+        assert_rel(results[0][0], results[1][0], 1e-13)
+        assert_rel(results[0][1], results[1][1], 1e-12)
+        want = oracle.interpolator_predict_zheng07_batch(tables, setup, theta[i:i + 1], x[None, :])
+        assert_rel(results[0][0], want[0][0], RTOL)
+        assert_rel(results[0][1], want[1][0], RTOL)
