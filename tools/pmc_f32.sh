@@ -1,7 +1,8 @@
 #!/bin/bash
 # Developer PMC passes for the float32 contraction (cfg5).
 cd "$GRAFT_REPO_ROOT" || exit 1
-export TMPDIR=/tmp TC_LANES=1
+# (the TC_* knobs are read by developer builds only: tools/build_dev.sh)
+export TMPDIR=/tmp TC_LANES=1 TABCORR_AMD_LIBRARY=$PWD/build/ab/dev.so
 rm -rf gpurun_out/pmc_*
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32" \
