@@ -268,6 +268,9 @@ struct Tuning {
   int fused_min_draws = 0;      // 0: chosen per table (launch.hip: fused_eligible)
   int fused_max_draws = 30720;
   int fused_waves = 0;          // 0: 8 where two workgroups fit a CU, else 16; 8 / 16: forced
+  int fused_draws = 0;          // draws per workgroup of the one-launch form: 0 = 32 for batches
+                                // below 8192 draws where that form applies, else 64
+                                // (launch.hip: fused_half_tiles); 32 / 64: forced
   int prio_fused = 1, prio_fused_occ = 2, prio_fused_out = 3;   // phases 2, 1, 3
   int skip_occ = 0, skip_finalize = 0;   // diagnosis (developer builds only)
   void load() {
@@ -457,8 +460,10 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
 // likelihood, t->fuse_chi2_out) as run_contraction leaves them.
 bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags);
 int fused_dens_rows(const tc_table* t, bool separate);
-int fused_lds_bytes(const tc_table* t, bool separate, int waves);
+int fused_lds_bytes(const tc_table* t, bool separate, int waves, int draws);
 int fused_waves(const tc_table* t, bool separate);
+bool fused_half_tiles(const tc_table* t, bool separate, int64_t n_draws, int n_gauss,
+                      unsigned flags);
 int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_draws, int n_gauss,
               unsigned flags, double* ngal_device, double* xi_device);
 int check_predict_args(const tc_table* t, const void* theta, int n_theta, int64_t n_draws,

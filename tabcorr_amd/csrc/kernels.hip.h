@@ -233,6 +233,57 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
   return acc;
 }
 
+// The same for workgroups of 32 draws (predict_fused_kernel<..., DL = 32>): lane = (draw, half),
+// each half of the wave takes five of the bin's ten nodes -- their constants come from memory
+// by vector loads, two addresses per wave, instead of scalar registers -- and the halves are
+// added through a lane exchange; then the bin's affine map / scale and the fix-ups of draws the
+// node loop cannot represent, as in occ_bin_zheng07 (same values to the last bits or two: five
+// + five nodes are added instead of ten in a row).  Undecorated, n_gauss_prim = 10.
+template <bool MODULATE>
+__device__ __forceinline__ double occ_bin_zheng07_halves(const double* table, const fm::Consts& kc,
+                                                         int g, bool central, int half,
+                                                         const double* log_m_v,
+                                                         const double* mass_v,
+                                                         const double* weight_v, sc_f64 log_m,
+                                                         sc_f64 weight_sum,
+                                                         const DrawParams& d) {
+  constexpr int kNodes = 10, kHalf = 5;
+  const double* lm_p = log_m_v + g * kNodes + half * kHalf;
+  const double* m_p = mass_v + g * kNodes + half * kHalf;
+  const double* w_p = weight_v + g * kNodes + half * kHalf;
+  double acc = 0.0;
+  if (central) {
+#pragma unroll
+    for (int k = 0; k < kHalf; ++k)
+      acc = fma(w_p[k], fm::erf_fast(table, kc, (lm_p[k] - d.log_m_min) * d.inv_sigma), acc);
+  } else {
+#pragma unroll
+    for (int k = 0; k < kHalf; ++k) {
+      const double x = m_p[k] - d.m0;
+      double n = fm::exp2_fast(
+          table, kc,
+          d.alpha * fm::log2_fast_offset(table, kc, x > 1e-300 ? x : 1e-300, d.log2_m1),
+          x > 0.0);
+      if (MODULATE)
+        n *= fma(0.5, fm::erf_fast(table, kc, (lm_p[k] - d.log_m_min) * d.inv_sigma), 0.5);
+      acc = fma(w_p[k], n, acc);
+    }
+  }
+  acc += __shfl_xor(acc, 32, 64);            // both halves hold the bin's sum
+  acc = central ? fma(0.5, acc, 0.5 * weight_sum[g]) : acc * d.sat_scale;
+  if (d.any_bad) {
+    const int bad = d.bad;
+    bool tie = false;
+    if ((bad & kTieCen) && (central || MODULATE))
+      for (int k = 0; k < kNodes; ++k) tie = tie || log_m[g * kNodes + k] == d.log_m_min;
+    const bool cen_nan = (bad & kBadCen) || tie;
+    if (!central && (bad & kInfSat) && acc != 0.0) acc = __builtin_huge_val();
+    if (central ? cen_nan : (((bad & kBadSat) && acc != 0.0) || (MODULATE && cen_nan)))
+      acc = __builtin_nan("");
+  }
+  return acc;
+}
+
 // Mean occupation of every bin for every draw: tabcorr/tabcorr.py:537-578 with
 // the two halotools callbacks of :556-563 evaluated inline (Zheng et al. 2007
 // eqs. 1 and 3).  Work items = (draw tile, bin split); the kOccWaves waves of a
@@ -1430,7 +1481,7 @@ static_assert(20 * (kLanes + 1) + 20 * 21 <= fm::kTableDoubles,
 
 // One pass over `count` units from block (rb, cb) on: UU (1 or 2) r sub-tiles whose table
 // operands are the pair at lane offset off_a; F[uu][set] += ... as in contract_quad_kernel.
-template <int UU>
+template <int UU, int DL>
 __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, unsigned off_a,
                                                 unsigned unit_bytes, const double* dens_b,
                                                 const double* dens_e, int rb, int cb, int left,
@@ -1442,7 +1493,7 @@ __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, uns
   f64x4 D[UU][2];
   auto fetch = [&](f64x2& t, f64x2& b, int column) {
     t = buffer_load16<0>(rs_t, off_a, ua);
-    b = *(const f64x2*)(dens_b + 4 * column * kLanes);
+    b = *(const f64x2*)(dens_b + 4 * column * DL);
     ua += unit_bytes;
   };
   auto mma = [&](const f64x2& t, const f64x2& b, bool first) {
@@ -1470,7 +1521,7 @@ __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, uns
     left -= n;
     f64x2 e[4];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) e[v] = *(const f64x2*)(dens_e + (4 * rb + v) * kLanes);
+    for (int v = 0; v < 4; ++v) e[v] = *(const f64x2*)(dens_e + (4 * rb + v) * DL);
     fetch(t1, b1, n > 1 ? cb + 1 : 0);
     __builtin_amdgcn_sched_barrier(0);
     mma(t0, b0, true);
@@ -1508,17 +1559,22 @@ __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, uns
 }
 
 template <int NGAUSS, int U, bool ASSEMBIAS, bool MODULATE, bool LEAUTHAUD = false,
-          int W = kFusedWaves>
-__global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(FusedArgs a) {
-  static_assert(W == 8 || W == 16, "waves per workgroup");
-  constexpr int PARTS = W / 2;       // waves per 32-draw tile
+          int W = kFusedWaves, int DL = 64>
+__global__ __launch_bounds__(64 * W, DL == 32 ? 3 : W == 8 ? 2 : 1) void predict_fused_kernel(
+    FusedArgs a) {
+  // DL = draws per workgroup: 64 (two 32-draw tiles, W = 8 or 16 waves), or 32 (one tile, four
+  // waves, three workgroups per CU: half the lifetime of a workgroup -- lanes = (draw, half
+  // of a bin's nodes) in the occupation phase, occ_bin_zheng07_halves)
+  static_assert((DL == 64 && (W == 8 || W == 16)) || (DL == 32 && W == 4), "workgroup shape");
+  static_assert(DL == 64 || (NGAUSS == 10 && !ASSEMBIAS && !LEAUTHAUD), "32 draws: plain Zheng07");
+  constexpr int PARTS = W * 32 / DL;       // waves per 32-draw tile
   static_assert(!LEAUTHAUD || (NGAUSS == 0 && !ASSEMBIAS), "Leauthaud11: any n_gauss, undecorated");
   constexpr int UP = (U + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) double fused_lds[];
   // region B: densities, later the waves' sums; region A: math table, later the results tile
   // and the likelihood's data | ngal sums
   constexpr int kSlotDoubles = fused_slot_doubles(W);
-  const int region_b = a.dens_rows * kLanes > kSlotDoubles ? a.dens_rows * kLanes : kSlotDoubles;
+  const int region_b = a.dens_rows * DL > kSlotDoubles ? a.dens_rows * DL : kSlotDoubles;
   double* dens = fused_lds;
   double* table = fused_lds + region_b;
   double(*red)[W][kLanes] = (double(*)[W][kLanes])(table + fm::kTableDoubles);
@@ -1534,13 +1590,15 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
     double2v* dst = (double2v*)table;
     for (int i = threadIdx.x; i < hi; i += blockDim.x) dst[i] = src[i];
   }
-  for (int idx = a.n_bins * kLanes + threadIdx.x; idx < a.dens_rows * kLanes; idx += blockDim.x)
+  for (int idx = a.n_bins * DL + threadIdx.x; idx < a.dens_rows * DL; idx += blockDim.x)
     dens[idx] = 0.0;
   __syncthreads();
 
   // ---- 1. occupations ----
-  const int64_t col = (int64_t)blockIdx.x * kLanes;
-  const int64_t b0 = col + lane;
+  const int draw = DL == 64 ? lane : (lane & 31);
+  const int half = DL == 64 ? 0 : (lane >> 5);
+  const int64_t col = (int64_t)blockIdx.x * DL;
+  const int64_t b0 = col + draw;
   const int64_t b = b0 < a.n_draws ? b0 : a.n_draws - 1;
   double norm;
   {
@@ -1577,13 +1635,15 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
       const bool central = g < a.n_central;
       const bool above = ASSEMBIAS ? percentile[g] > a.split : false;
       const double acc =
-          LEAUTHAUD ? occ_bin_leauthaud11<MODULATE>(table, kc, g, n_gauss, central, log_m, mass,
-                                                    weight, ld)
-                    : occ_bin_zheng07<NGAUSS, ASSEMBIAS, MODULATE>(
-                          table, kc, g, n_gauss, central, above, log_m, mass, weight,
-                          weight_sum, dp, f1, f2);
+          DL == 32    ? occ_bin_zheng07_halves<MODULATE>(table, kc, g, central, half, a.log_m, a.m,
+                                                         a.weight, log_m, weight_sum, dp)
+          : LEAUTHAUD ? occ_bin_leauthaud11<MODULATE>(table, kc, g, n_gauss, central, log_m, mass,
+                                                      weight, ld)
+                      : occ_bin_zheng07<NGAUSS, ASSEMBIAS, MODULATE>(
+                            table, kc, g, n_gauss, central, above, log_m, mass, weight,
+                            weight_sum, dp, f1, f2);
       const double value = acc * n_h[g];
-      dens[g * kLanes + lane] = value;
+      if (half == 0) dens[g * DL + draw] = value;
       if (central) sum_cen += value; else sum_sat += value;
     }
     red[0][wave][lane] = sum_cen;
@@ -1597,7 +1657,7 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
     }
     const double total = n_cen + n_sat;
     norm = total * total;
-    if (wave == 0 && b0 < a.n_draws) {
+    if (wave == 0 && half == 0 && b0 < a.n_draws) {
       if (a.separate) {
         a.ngal[2 * b0] = n_cen;
         a.ngal[2 * b0 + 1] = n_sat;
@@ -1616,8 +1676,8 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
     const unsigned off_a = lane * 16;
     // (the component's columns are density rows j_row0 ..., its rows i_row0 ...)
     const double* dens_b =
-        dens + (a.part_j_row0[part] + kq) * kLanes + sub * kQuadTile + 2 * c;   // + 4 col rows
-    const double* dens_e = dens + a.part_i_row0[part] * kLanes + sub * kQuadTile + 2 * c;
+        dens + (a.part_j_row0[part] + kq) * DL + sub * kQuadTile + 2 * c;   // + 4 col rows
+    const double* dens_e = dens + a.part_i_row0[part] * DL + sub * kQuadTile + 2 * c;
     const __amdgpu_buffer_rsrc_t rs_t =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.table, 0, a.table_bytes, kBufferFlags);
     const int rb = a.part_rb0[part], cb = a.part_cb0[part], count = a.part_count[part];
@@ -1628,11 +1688,11 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
     for (int p = 0; p < UP; ++p) {
       F[p][0][0] = F[p][0][1] = F[p][1][0] = F[p][1][1] = 0.0;
       if (2 * p + 1 < U)
-        fused_quad_pass<2>(rs_t, off_a + p * 1024, UP * 1024, dens_b, dens_e, rb, cb, count,
-                           triangular, n_cb, unit_base, F[p]);
+        fused_quad_pass<2, DL>(rs_t, off_a + p * 1024, UP * 1024, dens_b, dens_e, rb, cb, count,
+                               triangular, n_cb, unit_base, F[p]);
       else
-        fused_quad_pass<1>(rs_t, off_a + p * 1024, UP * 1024, dens_b, dens_e, rb, cb, count,
-                           triangular, n_cb, unit_base, F[p]);
+        fused_quad_pass<1, DL>(rs_t, off_a + p * 1024, UP * 1024, dens_b, dens_e, rb, cb, count,
+                               triangular, n_cb, unit_base, F[p]);
     }
   }
   __syncthreads();       // the densities are dead: their place takes the waves' sums
@@ -1654,21 +1714,21 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
     // and masks afterwards (tabcorr.py:653-681): with a non-finite pair-weight sum some term
     // is inf / inf = NaN and NaN x False = NaN reaches every component.
     const bool poisoned = !(fabs(norm) <= 1.79769313486231570815e308);
-    const int64_t n_valid = a.n_draws - col < kLanes ? a.n_draws - col : kLanes;
+    const int64_t n_valid = a.n_draws - col < DL ? a.n_draws - col : DL;
     const int sub = lane >> 5, d = lane & 31;
     for (int comp = 0; comp < 3; ++comp) {
       __syncthreads();
       constexpr int Q = PARTS / 4;
       const int p_begin = comp == 0 ? 0 : comp == 1 ? Q : 3 * Q;
       const int p_count = comp == 1 ? 2 * Q : Q;
-      for (int rr = wave; rr < a.n_r; rr += W) {
+      for (int rr = wave; rr < a.n_r && lane < DL; rr += W) {
         const double* first = dens + ((PARTS * sub + p_begin) * (4 * U) + rr) * kQuadTile + d;
         double sum = first[0];
         for (int p = 1; p < p_count; ++p) sum += first[p * (4 * U) * kQuadTile];
         tile[rr][lane] = poisoned ? __builtin_nan("") : sum / norm;
       }
       __syncthreads();
-      for (int idx = threadIdx.x; idx < a.n_r * kLanes; idx += blockDim.x) {
+      for (int idx = threadIdx.x; idx < a.n_r * DL; idx += blockDim.x) {
         const int dd = idx / a.n_r, rr = idx % a.n_r;
         if (dd < n_valid) a.xi[((col + dd) * 3 + comp) * (int64_t)a.n_r + rr] = tile[rr][dd];
       }
@@ -1683,7 +1743,7 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
   __syncthreads();
   {
     const int sub = lane >> 5, d = lane & 31;
-    for (int rr = wave; rr < a.n_r; rr += W) {
+    for (int rr = wave; rr < a.n_r && lane < DL; rr += W) {
       const double* first = dens + ((PARTS * sub) * (4 * U) + rr) * kQuadTile + d;
       double sum = first[0];
 #pragma unroll
@@ -1692,7 +1752,7 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
     }
   }
   __syncthreads();
-  const int64_t n_valid = a.n_draws - col < kLanes ? a.n_draws - col : kLanes;
+  const int64_t n_valid = a.n_draws - col < DL ? a.n_draws - col : DL;
   if (a.chi2 != nullptr) {
     // chi2 = delta^T P delta for the lane's draw (finalize_quad_kernel's fused likelihood)
     const int rows = a.n_r;
@@ -1714,7 +1774,7 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
     }
     return;
   }
-  for (int idx = threadIdx.x; idx < a.n_r * kLanes; idx += blockDim.x) {
+  for (int idx = threadIdx.x; idx < a.n_r * DL; idx += blockDim.x) {
     const int d = idx / a.n_r, rr = idx % a.n_r;
     if (d < n_valid) a.xi[(col + d) * (int64_t)a.n_r + rr] = tile[rr][d];
   }

@@ -942,9 +942,11 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
   // are bound by the host thread that queues them (10-13 us per call) and differ by noise.
   {
     const tc::QuadLayout& layout = separate ? t->quad_by_type.layout : t->quad_total.layout;
+    // (workgroups of 32 draws last half as long)
     const double estimate = (5.0 + 10.0 * (t->n_bins / 100.0) * (n_gauss / 10.0) +
                              60.0 * ((double)layout.n_units / 325.0) * (t->quad_tiling.n_u / 5.0)) *
-                            8.0 / fused_waves(t, separate);
+                            8.0 / fused_waves(t, separate) *
+                            (fused_half_tiles(t, separate, n_draws, n_gauss, flags) ? 0.5 : 1.0);
     // Leauthaud11 (a Newton inverse of the stellar-to-halo mass relation per central node: the
     // occupations outweigh the matrix work and spread better over the chip as a kernel of their
     // own): tools/r03_fused_leauthaud.py, us per step, three kernels / one launch: G = 100: 4000
@@ -973,23 +975,40 @@ int fused_dens_rows(const tc_table* t, bool separate) {
   return (rows + 3) / 4 * 4;
 }
 
-int fused_lds_bytes(const tc_table* t, bool separate, int waves) {
+int fused_lds_bytes(const tc_table* t, bool separate, int waves, int draws) {
   const int dens_rows = fused_dens_rows(t, separate);
-  return (std::max(dens_rows * 64, tc::fused_slot_doubles(waves)) +
+  return (std::max(dens_rows * draws, tc::fused_slot_doubles(waves)) +
           tc::fused_scratch_doubles(waves)) * 8;
+}
+
+// Workgroups of 32 draws (four waves, three per CU): plain Zheng07 with the reference's default
+// n_gauss_prim, tables whose 32-draw workgroup fits a third of a CU's LDS.
+// A workgroup then lasts half as long, and a batch has twice as many: ahead for medium batches,
+// where the 64-draw workgroups of four launches do not fill the chip, behind by 4-7 % once they
+// do (three workgroups of four waves per CU leave a SIMD three waves) -- tools/r03_fused_half.py,
+// us per step, three kernels / 64 / 32 draws: G = 100: 2048 draws 19.1 / 28.5 / 22.1, 4096
+// 24.0 / 30.5 / 21.0, 6144 31.4 / 30.9 / 26.1, 10^4 43.6 / 39.5 / 41.1; G = 60: 1024 10.3 / 12.2 /
+// 9.3, 4096 15.3 / 13.4 / 10.7, 6144 18.6 / 14.3 / 12.2, 10^4 21.6 / 17.7 / 19.0: below 8192 draws.
+bool fused_half_tiles(const tc_table* t, bool separate, int64_t n_draws, int n_gauss,
+                      unsigned flags) {
+  if (t->tuning.fused_draws == 64 || (t->tuning.fused_draws == 0 && n_draws >= 8192))
+    return false;
+  if (n_gauss != 10 || (flags & (TC_FLAG_ASSEMBIAS | TC_FLAG_LEAUTHAUD11))) return false;
+  if (t->tuning.fused_waves != 0) return false;
+  return fused_lds_bytes(t, separate, 4, 32) <= 53 * 1024;
 }
 
 // Waves per workgroup of the one-launch form for this table: 8, 16, or 0 (does not fit).
 int fused_waves(const tc_table* t, bool separate) {
-  const bool fits8 = fused_lds_bytes(t, separate, 8) <= 80 * 1024;
-  const bool fits16 = fused_lds_bytes(t, separate, 16) <= 160 * 1024;
-  if (t->tuning.fused_waves == 8 && fused_lds_bytes(t, separate, 8) <= 160 * 1024) return 8;
+  const bool fits8 = fused_lds_bytes(t, separate, 8, 64) <= 80 * 1024;
+  const bool fits16 = fused_lds_bytes(t, separate, 16, 64) <= 160 * 1024;
+  if (t->tuning.fused_waves == 8 && fused_lds_bytes(t, separate, 8, 64) <= 160 * 1024) return 8;
   if (t->tuning.fused_waves == 16 && fits16) return 16;
   return fits8 ? 8 : (fits16 && t->tuning.fused >= 2) ? 16 : 0;
 }
 
 namespace {
-template <int NG, bool AB, bool MO, bool LE = false, int W = tc::kFusedWaves>
+template <int NG, bool AB, bool MO, bool LE = false, int W = tc::kFusedWaves, int DL = 64>
 int launch_fused(int device, int n_u, dim3 grid, dim3 block, int lds, hipStream_t stream,
                  hipEvent_t k0, hipEvent_t k1, const tc::FusedArgs& fa) {
   switch (n_u) {
@@ -998,12 +1017,13 @@ int launch_fused(int device, int n_u, dim3 grid, dim3 block, int lds, hipStream_
     /* (the attribute belongs to the function ON a device: once per device) */                \
     static bool limit_set[64] = {};                                                           \
     if (lds > 64 * 1024 && !(device >= 0 && device < 64 && limit_set[device])) {              \
-      TC_HIP(hipFuncSetAttribute((const void*)tc::predict_fused_kernel<NG, N, AB, MO, LE, W>, \
+      TC_HIP(hipFuncSetAttribute(                                                             \
+          (const void*)tc::predict_fused_kernel<NG, N, AB, MO, LE, W, DL>,                    \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));    \
       if (device >= 0 && device < 64) limit_set[device] = true;                               \
     }                                                                                         \
-    hipExtLaunchKernelGGL((tc::predict_fused_kernel<NG, N, AB, MO, LE, W>), grid, block, lds, \
-                          stream, k0, k1, 0, fa);                                             \
+    hipExtLaunchKernelGGL((tc::predict_fused_kernel<NG, N, AB, MO, LE, W, DL>), grid, block,  \
+                          lds, stream, k0, k1, 0, fa);                                        \
     break;                                                                                    \
   }
     TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4) TC_CASE(5)
@@ -1034,8 +1054,10 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   fa.n_gauss = n_gauss;
   fa.dens_rows = fused_dens_rows(t, separate);
   fa.separate = separate ? 1 : 0;
-  const int waves = fused_waves(t, separate);
-  const int n_parts = waves / 2;
+  const bool half_tiles = fused_half_tiles(t, separate, n_draws, n_gauss, flags);
+  const int waves = half_tiles ? 4 : fused_waves(t, separate);
+  const int draws = half_tiles ? 32 : 64;
+  const int n_parts = waves * 32 / draws;
   if (!separate) {
     const tc::QuadComp& comp = q_table.layout.comps[0];
     tc::triangle_parts(comp.n_rb, n_parts, fa.part_rb0, fa.part_cb0, fa.part_count);
@@ -1098,8 +1120,8 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
     fa.xi = nullptr;
     t->chi2_fused = true;
   }
-  const int lds = fused_lds_bytes(t, separate, waves);
-  const dim3 grid((unsigned)((n_draws + 63) / 64)), block(64 * waves);
+  const int lds = fused_lds_bytes(t, separate, waves, draws);
+  const dim3 grid((unsigned)((n_draws + draws - 1) / draws)), block(64 * waves);
   hipEvent_t k0 = nullptr, k1 = nullptr;
   status = next_kernel_events(t, &k0, &k1);
   if (status != TC_OK) return status;
@@ -1110,7 +1132,12 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
                                                   lds, stream, k0, k1, fa)                     \
                : launch_fused<NG, AB, MO, LE, 8>(t->device, t->quad_tiling.n_u, grid, block,   \
                                                  lds, stream, k0, k1, fa))
-  if (flags & TC_FLAG_LEAUTHAUD11)
+  if (half_tiles)
+    status = modulate ? launch_fused<10, false, true, false, 4, 32>(
+                            t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa)
+                      : launch_fused<10, false, false, false, 4, 32>(
+                            t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+  else if (flags & TC_FLAG_LEAUTHAUD11)
     status = modulate ? TC_FUSED(0, false, true, true) : TC_FUSED(0, false, false, true);
   else if (n_gauss != 10)
     status = TC_FUSED(0, false, false, false);

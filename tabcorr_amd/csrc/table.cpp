@@ -860,6 +860,9 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     const int status = resident_stop(t);
     if (status != TC_OK) return status;
     t->resident.idle_us = value;
+  } else if (key == "fused_draws") {
+    TC_CHECK(value == 0 || value == 32 || value == 64, "fused_draws must be 0, 32 or 64");
+    t->tuning.fused_draws = value;
   } else if (key == "fused_waves") {
     TC_CHECK(value == 0 || value == 8 || value == 16, "fused_waves must be 0, 8 or 16");
     t->tuning.fused_waves = value;

@@ -41,9 +41,10 @@ def last_launch(halotab):
     return tuple(v.value for v in values)
 
 
-def fused_ran(halotab, waves=(8, 16)):
-    """Was the last launch predict_fused_kernel (8 waves per workgroup where two workgroups fit
-    a CU, 16 for tables of more than 104 bins; no slabs of partial sums)?"""
+def fused_ran(halotab, waves=(4, 8, 16)):
+    """Was the last launch predict_fused_kernel (8 waves per workgroup of 64 draws where two
+    workgroups fit a CU, 4 waves per workgroup of 32 draws for batches below 8192 draws of the
+    plain Zheng07 family, 16 for tables of more than 104 bins; no slabs of partial sums)?"""
     launch = last_launch(halotab)
     return launch[1] in waves and launch[2] == 0
 
@@ -55,7 +56,7 @@ def test_fused_matches_golden():
     force_fused(halotab)
     ngal, xi = halotab.predict_batch(data['theta'])
     workgroups, waves, slabs, lds = last_launch(halotab)
-    assert waves == 8 and slabs == 0 and workgroups == (len(data['theta']) + 63) // 64
+    assert waves == 4 and slabs == 0 and workgroups == (len(data['theta']) + 31) // 32
     assert_rel(ngal, data['ngal'], RTOL, 'ngal')
     assert_rel(xi, data['xi'], RTOL, 'xi')
     # the three-kernel path gives the same to rounding
@@ -354,8 +355,9 @@ def test_a_draws_result_does_not_depend_on_its_place_in_the_batch():
     theta = synthetic.zheng07_draws(n, seed=21)
     halotab = make_tabcorr(table)
     force_fused(halotab)
+    set_option(halotab, 'fused_draws', 64)     # (one shape of workgroup for every batch size)
     ngal, xi = halotab.predict_batch(theta)
-    assert fused_ran(halotab)
+    assert fused_ran(halotab, (8, ))
     ngal_r, xi_r = halotab.predict_batch(theta[::-1].copy())
     assert np.array_equal(ngal_r[::-1], ngal)
     assert np.array_equal(xi_r[::-1], xi)
@@ -516,3 +518,91 @@ def test_fused_sixteen_waves(n_prim, n_sec, n_r, n_draws, kwargs):
         n_chi, chi2 = halotab.chi2_batch(theta, vector, precision, **kwargs)
         assert fused_ran(halotab, (16, ))
         assert_rel(chi2, np.einsum('bi,ij,bj->b', delta, precision, delta), 1e-9)
+
+
+@pytest.mark.parametrize('n_prim, n_sec, n_r, n_draws, kwargs', [
+    (50, 1, 19, 1000, {}),                                  # BASELINE configs[1]'s table
+    (30, 1, 19, 333, {}),                                   # the reference's example table size
+    (7, 1, 1, 1, {}),
+    (5, 2, 3, 31, {}),
+    (13, 1, 4, 32, {}),
+    (10, 1, 5, 33, {'modulate_with_cenocc': True}),
+    (25, 1, 9, 200, {}),
+    (26, 2, 20, 97, {'modulate_with_cenocc': True}),        # 104 bins
+])
+def test_fused_workgroups_of_32_draws(n_prim, n_sec, n_r, n_draws, kwargs):
+    """predict_fused_kernel<..., W = 4, DL = 32>: lanes = (draw, half of a bin's nodes) in the
+    occupation phase, one 32-draw tile per workgroup -- total, separated by galaxy type and the
+    fused likelihood against the oracle; equal to the 64-draw form to rounding; NaN / tied
+    parameters as the 64-draw form; a draw's result does not depend on its place in the batch."""
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    rng = np.random.default_rng(n_draws)
+    table = synthetic.synthetic_table(n_prim, n_sec, (n_r, ), 'auto', seed=n_prim + 1)
+    theta = synthetic.zheng07_draws(n_draws, seed=n_draws + 3)
+    halotab = make_tabcorr(table)
+    force_fused(halotab)
+    set_option(halotab, 'fused_draws', 32)
+    for separate in (False, True):
+        expect = oracle.predict_zheng07_batch(table, theta, separate_gal_type=separate, **kwargs)
+        ngal, xi = halotab.predict_batch(theta, separate_gal_type=separate, **kwargs)
+        launch = last_launch(halotab)
+        assert launch[:3] == ((n_draws + 31) // 32, 4, 0), 'the 32-draw kernel did not run'
+        if separate:
+            for key in expect[0]:
+                assert_rel(ngal[key], expect[0][key], RTOL, 'ngal ' + key)
+            for key in expect[1]:
+                assert_rel(xi[key], expect[1][key], RTOL, 'xi ' + key, floor=1e-13)
+        else:
+            assert_rel(ngal, expect[0], RTOL, 'ngal')
+            assert_rel(xi, expect[1], RTOL, 'xi')
+            total = (ngal, xi)
+    set_option(halotab, 'fused_draws', 64)
+    ngal64, xi64 = halotab.predict_batch(theta, **kwargs)
+    assert last_launch(halotab)[1] == 8
+    assert_rel(total[0], ngal64, 1e-13)
+    assert_rel(total[1], xi64, 1e-12)
+    set_option(halotab, 'fused_draws', 32)
+    # the fused likelihood
+    vector = total[1][0] * 1.1
+    a = rng.normal(size=(n_r, n_r))
+    precision = a @ a.T / np.mean(vector)**2
+    delta = total[1] - vector
+    n_chi, chi2 = halotab.chi2_batch(theta, vector, precision, **kwargs)
+    assert last_launch(halotab)[1] == 4
+    assert_rel(n_chi, total[0], 1e-13)
+    assert_rel(chi2, np.einsum('bi,ij,bj->b', delta, precision, delta), 1e-9)
+    # reversed / re-batched: bit for bit
+    ngal_r, xi_r = halotab.predict_batch(theta[::-1].copy(), **kwargs)
+    assert np.array_equal(ngal_r[::-1], total[0]) and np.array_equal(xi_r[::-1], total[1])
+    if n_draws > 40:
+        ngal_p, xi_p = halotab.predict_batch(theta[7:40], **kwargs)
+        assert np.array_equal(xi_p, total[1][7:40])
+    # parameters the node loop cannot represent: the same NaN / inf pattern as the 64-draw form
+    bad = np.tile(theta[:1], (70, 1)) if n_draws < 70 else theta[:70].copy()
+    bad[3, 0] = np.nan                         # logMmin
+    bad[5, 3] = np.nan                         # logM1
+    bad[9, 1] = 0.0                            # sigma_logM = 0: a step function
+    bad[34, 4] = np.nan                        # alpha
+    bad[40, 2] = np.nan                        # logM0: no satellites
+    bad[41, 3] = -300.0                        # M1 = 0
+    got = halotab.predict_batch(bad, **kwargs)
+    set_option(halotab, 'fused_draws', 64)
+    want = halotab.predict_batch(bad, **kwargs)
+    assert np.array_equal(np.isnan(got[0]), np.isnan(want[0]))
+    assert np.array_equal(np.isnan(got[1]), np.isnan(want[1]))
+    assert np.array_equal(np.isinf(got[1]), np.isinf(want[1]))
+    good = np.isfinite(want[1])
+    assert_rel(got[1][good], want[1][good], 1e-12)
+
+
+def test_workgroups_of_32_draws_are_taken_below_8192_draws():
+    from tabcorr_amd import pinned_array, pinned_empty, synthetic
+    table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    halotab = make_tabcorr(table)
+    for n, waves in ((4096, 4), (8191, 4), (8192, 8), (10000, 8)):
+        theta = pinned_array(synthetic.zheng07_draws(n, seed=1))
+        out = (pinned_empty(n), pinned_empty((n, 19)))
+        halotab.predict_batch_async(theta, out=out).wait()
+        launch = last_launch(halotab)
+        assert launch[2] == 0 and launch[1] == waves, (n, launch)
