@@ -913,6 +913,13 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
             key, value = option.split('=')
             _lib.check(lib.tc_table_set_option(timer_handle, key.encode(), int(value)))
         device_seconds = sustained(launch, synchronize)
+        shape = [ctypes.c_int() for _ in range(4)]
+        lib.tc_table_last_launch(timer_handle, *[ctypes.byref(v) for v in shape])
+        # (the pipelined calls of device_calls_per_sec: one launch per call where the library
+        # chose predict_fused_kernel -- no slabs of partial sums --, else the three kernels)
+        pipelined = ('one launch per call: predict_fused_kernel, %d workgroups of %d waves'
+                     % (shape[0].value, shape[1].value) if shape[2].value == 0
+                     else 'occupation, contraction, finalisation kernels')
         _lib.check(lib.tc_table_set_option(timer_handle, b'pipeline', 0))
         kernel_ms, n_launch, _ = kernel_time(lib, _lib, timer_handle, launch, synchronize,
                                              n_launches=300, max_seconds=0.6)
@@ -925,6 +932,7 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
         out[name] = {
             'workload': what, 'tag': tag, 'dtype': dtype, 'draws_per_call': n_draws,
             'device_calls_per_sec': n_draws / device_seconds,
+            'device_calls_run_as': pipelined,
             'host_to_host_calls_per_sec': n_draws / host_seconds,
             'kernel': kernel, 'kernel_us': kernel_ms * 1e3, 'launches_timed': n_launch,
             'flop_per_launch': flop, 'achieved_tflops': achieved, 'peak_tflops': peak,

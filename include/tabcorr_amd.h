@@ -285,9 +285,10 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 lane); 1: their finalisations are chained so that results appear in call
  *                 order (0.3 - 3 us per 10^4-draw step).
  *   "fused"       1 (default): pipelined device-pointer and asynchronous calls that qualify
- *                 (mode auto, at most 20 r values and 104 bins, Zheng07 family, total or
- *                 separated by galaxy type) run as ONE launch per batch, a workgroup carrying
- *                 64 draws from the parameters to the results, for batches of
+ *                 (mode auto, at most 20 r values; 104 bins, or 208 for the Zheng07 family with
+ *                 n_gauss_prim = 10; total or separated by galaxy type) run as ONE launch per
+ *                 batch, a workgroup carrying 64 (32) draws from the parameters to the results,
+ *                 for batches of
  *                 "fused_min_draws" .. "fused_max_draws" draws (default 0 = chosen per table:
  *                 512 for small tables, ~7000 for 100 bins x 19 r values; 30720; asynchronous
  *                 calls: no upper bound); 0: always occupation, contraction, finalisation

@@ -464,6 +464,7 @@ int fused_lds_bytes(const tc_table* t, bool separate, int waves, int draws);
 int fused_waves(const tc_table* t, bool separate);
 bool fused_half_tiles(const tc_table* t, bool separate, int64_t n_draws, int n_gauss,
                       unsigned flags);
+bool fused_wide_tables(const tc_table* t, bool separate, int n_gauss, unsigned flags);
 int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_draws, int n_gauss,
               unsigned flags, double* ngal_device, double* xi_device);
 int check_predict_args(const tc_table* t, const void* theta, int n_theta, int64_t n_draws,

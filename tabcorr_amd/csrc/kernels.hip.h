@@ -239,9 +239,9 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
 // added through a lane exchange; then the bin's affine map / scale and the fix-ups of draws the
 // node loop cannot represent, as in occ_bin_zheng07 (same values to the last bits or two: five
 // + five nodes are added instead of ten in a row).  Undecorated, n_gauss_prim = 10.
-template <bool MODULATE>
+template <bool ASSEMBIAS, bool MODULATE>
 __device__ __forceinline__ double occ_bin_zheng07_halves(const double* table, const fm::Consts& kc,
-                                                         int g, bool central, int half,
+                                                         int g, bool central, bool above, int half,
                                                          const double* log_m_v,
                                                          const double* mass_v,
                                                          const double* weight_v, sc_f64 log_m,
@@ -251,8 +251,18 @@ __device__ __forceinline__ double occ_bin_zheng07_halves(const double* table, co
   const double* lm_p = log_m_v + g * kNodes + half * kHalf;
   const double* m_p = mass_v + g * kNodes + half * kHalf;
   const double* w_p = weight_v + g * kNodes + half * kHalf;
+  // (Heaviside assembly bias at the median split, as occ_bin_zheng07: n + s min(n, 1 - n) per
+  // central node, the factor 1 + s on a satellite bin's sum, s = +-strength above / below)
+  const double s_cen = above ? d.a_cen : -d.a_cen, s_sat = above ? d.a_sat : -d.a_sat;
   double acc = 0.0;
-  if (central) {
+  if (central && ASSEMBIAS) {
+#pragma unroll
+    for (int k = 0; k < kHalf; ++k) {
+      const double n =
+          fma(0.5, fm::erf_fast(table, kc, (lm_p[k] - d.log_m_min) * d.inv_sigma), 0.5);
+      acc = fma(w_p[k], fma(s_cen, fmin(n, 1.0 - n), n), acc);
+    }
+  } else if (central) {
 #pragma unroll
     for (int k = 0; k < kHalf; ++k)
       acc = fma(w_p[k], fm::erf_fast(table, kc, (lm_p[k] - d.log_m_min) * d.inv_sigma), acc);
@@ -270,14 +280,17 @@ __device__ __forceinline__ double occ_bin_zheng07_halves(const double* table, co
     }
   }
   acc += __shfl_xor(acc, 32, 64);            // both halves hold the bin's sum
-  acc = central ? fma(0.5, acc, 0.5 * weight_sum[g]) : acc * d.sat_scale;
+  if (!central) acc *= d.sat_scale;
+  else if (!ASSEMBIAS) acc = fma(0.5, acc, 0.5 * weight_sum[g]);
+  if (!central && ASSEMBIAS) acc = fma(s_sat, acc, acc);
   if (d.any_bad) {
     const int bad = d.bad;
     bool tie = false;
     if ((bad & kTieCen) && (central || MODULATE))
       for (int k = 0; k < kNodes; ++k) tie = tie || log_m[g * kNodes + k] == d.log_m_min;
     const bool cen_nan = (bad & kBadCen) || tie;
-    if (!central && (bad & kInfSat) && acc != 0.0) acc = __builtin_huge_val();
+    if (!central && (bad & kInfSat) && acc != 0.0)
+      acc = ASSEMBIAS ? __builtin_nan("") : __builtin_huge_val();
     if (central ? cen_nan : (((bad & kBadSat) && acc != 0.0) || (MODULATE && cen_nan)))
       acc = __builtin_nan("");
   }
@@ -1560,13 +1573,16 @@ __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, uns
 
 template <int NGAUSS, int U, bool ASSEMBIAS, bool MODULATE, bool LEAUTHAUD = false,
           int W = kFusedWaves, int DL = 64>
-__global__ __launch_bounds__(64 * W, DL == 32 ? 3 : W == 8 ? 2 : 1) void predict_fused_kernel(
-    FusedArgs a) {
-  // DL = draws per workgroup: 64 (two 32-draw tiles, W = 8 or 16 waves), or 32 (one tile, four
-  // waves, three workgroups per CU: half the lifetime of a workgroup -- lanes = (draw, half
-  // of a bin's nodes) in the occupation phase, occ_bin_zheng07_halves)
-  static_assert((DL == 64 && (W == 8 || W == 16)) || (DL == 32 && W == 4), "workgroup shape");
-  static_assert(DL == 64 || (NGAUSS == 10 && !ASSEMBIAS && !LEAUTHAUD), "32 draws: plain Zheng07");
+__global__ __launch_bounds__(64 * W, DL == 32 && W == 4 ? 3 : W == 8 ? 2 : 1) void
+predict_fused_kernel(FusedArgs a) {
+  // DL = draws per workgroup: 64 (two 32-draw tiles, W = 8 or 16 waves), or 32 (one tile --
+  // lanes = (draw, half of a bin's nodes) in the occupation phase, occ_bin_zheng07_halves):
+  // four waves, three workgroups per CU, half the lifetime of a workgroup (medium batches), or
+  // eight waves = eight parts of the units, two workgroups of up to 80 KB per CU: tables of
+  // 105-230 bins with the wave count per SIMD of the 64-draw form
+  static_assert((DL == 64 && (W == 8 || W == 16)) || (DL == 32 && (W == 4 || W == 8)),
+                "workgroup shape");
+  static_assert(DL == 64 || (NGAUSS == 10 && !LEAUTHAUD), "32 draws: the Zheng07 family");
   constexpr int PARTS = W * 32 / DL;       // waves per 32-draw tile
   static_assert(!LEAUTHAUD || (NGAUSS == 0 && !ASSEMBIAS), "Leauthaud11: any n_gauss, undecorated");
   constexpr int UP = (U + 1) / 2;
@@ -1635,8 +1651,9 @@ __global__ __launch_bounds__(64 * W, DL == 32 ? 3 : W == 8 ? 2 : 1) void predict
       const bool central = g < a.n_central;
       const bool above = ASSEMBIAS ? percentile[g] > a.split : false;
       const double acc =
-          DL == 32    ? occ_bin_zheng07_halves<MODULATE>(table, kc, g, central, half, a.log_m, a.m,
-                                                         a.weight, log_m, weight_sum, dp)
+          DL == 32    ? occ_bin_zheng07_halves<ASSEMBIAS, MODULATE>(table, kc, g, central, above,
+                                                                    half, a.log_m, a.m, a.weight,
+                                                                    log_m, weight_sum, dp)
           : LEAUTHAUD ? occ_bin_leauthaud11<MODULATE>(table, kc, g, n_gauss, central, log_m, mass,
                                                       weight, ld)
                       : occ_bin_zheng07<NGAUSS, ASSEMBIAS, MODULATE>(

@@ -928,7 +928,8 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
   // 8 waves / 16 waves: G = 112 51.8 / 55.6 / 51.5, 128 64.2 / 69.2 / 64.3, 200 137.0 / 150.9 /
   // 138.7, 240 189.6 / 215.0 / 192.3; G = 100: 43.5 / 39.4 / 43.2 -- so beyond 104 bins the
   // one-launch form (16 waves, up to 160 KB: 248 bins) is taken only when forced.
-  if (n_gauss < 1 || fused_waves(t, separate) == 0) return false;
+  const bool wide = fused_wide_tables(t, separate, n_gauss, flags);
+  if (n_gauss < 1 || (!wide && fused_waves(t, separate) == 0)) return false;
   // Smallest batch: a launch lasts as long as one workgroup does, whatever the batch, so the
   // one-launch form pays from the batch size on at which four lanes of such launches beat the
   // three kernels (which spread any batch over the whole chip).  Estimated duration of a
@@ -945,7 +946,7 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
     // (workgroups of 32 draws last half as long)
     const double estimate = (5.0 + 10.0 * (t->n_bins / 100.0) * (n_gauss / 10.0) +
                              60.0 * ((double)layout.n_units / 325.0) * (t->quad_tiling.n_u / 5.0)) *
-                            8.0 / fused_waves(t, separate) *
+                            8.0 / (wide ? 16 : fused_waves(t, separate)) *
                             (fused_half_tiles(t, separate, n_draws, n_gauss, flags) ? 0.5 : 1.0);
     // Leauthaud11 (a Newton inverse of the stellar-to-halo mass relation per central node: the
     // occupations outweigh the matrix work and spread better over the chip as a kernel of their
@@ -954,7 +955,13 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
     // modulate_with_cenocc (the inverse at the satellites' nodes too) never ahead: 10^4 draws
     // 183.4 / 188.1 and 106.0 / 106.0 -- only when forced.
     if (leauthaud && (flags & TC_FLAG_MODULATE_WITH_CENOCC) && t->tuning.fused < 2) return false;
+    // Wide tables (eight waves x 32 draws; tools/r03_fused_wide.py, us per step, three kernels /
+    // one launch: G = 112: 1024 draws 14.9 / 18.6, 2048 21.4 / 19.1, 4096 27.2 / 20.3, 10^4 52.3 /
+    // 50.2, 20 000 98.6 / 99.0; G = 200: 2048 38.6 / 49.1, 4096 61.2 / 54.6, 6144 90.1 / 81.6,
+    // 10^4 137.3 / 134.8; separated + assembly bias: 4096 66.5 / 57.0, 10^4 146.9 / 140.8): from
+    // 15 draws per bin on.
     const int64_t min_draws = t->tuning.fused_min_draws > 0 ? t->tuning.fused_min_draws
+                              : wide                        ? 15 * (int64_t)t->n_bins
                               : leauthaud                   ? 8192
                               : estimate <= 28.0            ? 512
                                                             : (int64_t)(90.0 * estimate);
@@ -993,9 +1000,20 @@ bool fused_half_tiles(const tc_table* t, bool separate, int64_t n_draws, int n_g
                       unsigned flags) {
   if (t->tuning.fused_draws == 64 || (t->tuning.fused_draws == 0 && n_draws >= 8192))
     return false;
-  if (n_gauss != 10 || (flags & (TC_FLAG_ASSEMBIAS | TC_FLAG_LEAUTHAUD11))) return false;
+  if (n_gauss != 10 || (flags & TC_FLAG_LEAUTHAUD11)) return false;
   if (t->tuning.fused_waves != 0) return false;
   return fused_lds_bytes(t, separate, 4, 32) <= 53 * 1024;
+}
+
+// Tables whose 64-draw workgroup does not fit half a CU (more than 104 bins): ONE 32-draw tile
+// per workgroup of eight waves (eight parts of the units), two workgroups of up to 80 KB per
+// CU -- four waves per SIMD like the 64-draw form of smaller tables.  Zheng07 family with the
+// default n_gauss_prim, up to 230 bins.
+bool fused_wide_tables(const tc_table* t, bool separate, int n_gauss, unsigned flags) {
+  if (t->tuning.fused_draws == 64 || t->tuning.fused_waves != 0) return false;
+  if (n_gauss != 10 || (flags & TC_FLAG_LEAUTHAUD11)) return false;
+  return fused_lds_bytes(t, separate, 8, 64) > 80 * 1024 &&
+         fused_lds_bytes(t, separate, 8, 32) <= 80 * 1024;
 }
 
 // Waves per workgroup of the one-launch form for this table: 8, 16, or 0 (does not fit).
@@ -1054,9 +1072,10 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   fa.n_gauss = n_gauss;
   fa.dens_rows = fused_dens_rows(t, separate);
   fa.separate = separate ? 1 : 0;
-  const bool half_tiles = fused_half_tiles(t, separate, n_draws, n_gauss, flags);
-  const int waves = half_tiles ? 4 : fused_waves(t, separate);
-  const int draws = half_tiles ? 32 : 64;
+  const bool wide = fused_wide_tables(t, separate, n_gauss, flags);
+  const bool half_tiles = !wide && fused_half_tiles(t, separate, n_draws, n_gauss, flags);
+  const int waves = wide ? 8 : half_tiles ? 4 : fused_waves(t, separate);
+  const int draws = wide || half_tiles ? 32 : 64;
   const int n_parts = waves * 32 / draws;
   if (!separate) {
     const tc::QuadComp& comp = q_table.layout.comps[0];
@@ -1132,11 +1151,14 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
                                                   lds, stream, k0, k1, fa)                     \
                : launch_fused<NG, AB, MO, LE, 8>(t->device, t->quad_tiling.n_u, grid, block,   \
                                                  lds, stream, k0, k1, fa))
-  if (half_tiles)
-    status = modulate ? launch_fused<10, false, true, false, 4, 32>(
-                            t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa)
-                      : launch_fused<10, false, false, false, 4, 32>(
-                            t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+#define TC_FUSED32(AB, MO)                                                                    \
+  (wide ? launch_fused<10, AB, MO, false, 8, 32>(t->device, t->quad_tiling.n_u, grid, block,   \
+                                                 lds, stream, k0, k1, fa)                      \
+        : launch_fused<10, AB, MO, false, 4, 32>(t->device, t->quad_tiling.n_u, grid, block,   \
+                                                 lds, stream, k0, k1, fa))
+  if (wide || half_tiles)
+    status = assembias ? (modulate ? TC_FUSED32(true, true) : TC_FUSED32(true, false))
+                       : (modulate ? TC_FUSED32(false, true) : TC_FUSED32(false, false));
   else if (flags & TC_FLAG_LEAUTHAUD11)
     status = modulate ? TC_FUSED(0, false, true, true) : TC_FUSED(0, false, false, true);
   else if (n_gauss != 10)
@@ -1150,6 +1172,7 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   else
     status = TC_FUSED(10, true, true, false);
 #undef TC_FUSED
+#undef TC_FUSED32
   if (status != TC_OK) return status;
   t->last_workgroups = (int)grid.x;
   t->last_waves = waves;

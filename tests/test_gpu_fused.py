@@ -529,6 +529,9 @@ def test_fused_sixteen_waves(n_prim, n_sec, n_r, n_draws, kwargs):
     (10, 1, 5, 33, {'modulate_with_cenocc': True}),
     (25, 1, 9, 200, {}),
     (26, 2, 20, 97, {'modulate_with_cenocc': True}),        # 104 bins
+    (50, 2, 19, 100, {}),                                   # 200 bins: eight waves per workgroup
+    (52, 2, 7, 65, {"modulate_with_cenocc": True}),         # 208 bins
+    (28, 2, 12, 40, {}),                                    # 112 bins
 ])
 def test_fused_workgroups_of_32_draws(n_prim, n_sec, n_r, n_draws, kwargs):
     """predict_fused_kernel<..., W = 4, DL = 32>: lanes = (draw, half of a bin's nodes) in the
@@ -547,7 +550,9 @@ def test_fused_workgroups_of_32_draws(n_prim, n_sec, n_r, n_draws, kwargs):
         expect = oracle.predict_zheng07_batch(table, theta, separate_gal_type=separate, **kwargs)
         ngal, xi = halotab.predict_batch(theta, separate_gal_type=separate, **kwargs)
         launch = last_launch(halotab)
-        assert launch[:3] == ((n_draws + 31) // 32, 4, 0), 'the 32-draw kernel did not run'
+        wide = 2 * n_prim * n_sec > 104
+        assert launch[:3] == ((n_draws + 31) // 32, 8 if wide else 4, 0), \
+            'the 32-draw kernel did not run'
         if separate:
             for key in expect[0]:
                 assert_rel(ngal[key], expect[0][key], RTOL, 'ngal ' + key)
@@ -559,7 +564,7 @@ def test_fused_workgroups_of_32_draws(n_prim, n_sec, n_r, n_draws, kwargs):
             total = (ngal, xi)
     set_option(halotab, 'fused_draws', 64)
     ngal64, xi64 = halotab.predict_batch(theta, **kwargs)
-    assert last_launch(halotab)[1] == 8
+    assert last_launch(halotab)[:2] == ((n_draws + 63) // 64, 16 if wide else 8)
     assert_rel(total[0], ngal64, 1e-13)
     assert_rel(total[1], xi64, 1e-12)
     set_option(halotab, 'fused_draws', 32)
@@ -569,7 +574,7 @@ def test_fused_workgroups_of_32_draws(n_prim, n_sec, n_r, n_draws, kwargs):
     precision = a @ a.T / np.mean(vector)**2
     delta = total[1] - vector
     n_chi, chi2 = halotab.chi2_batch(theta, vector, precision, **kwargs)
-    assert last_launch(halotab)[1] == 4
+    assert last_launch(halotab)[:2] == ((n_draws + 31) // 32, 8 if wide else 4)
     assert_rel(n_chi, total[0], 1e-13)
     assert_rel(chi2, np.einsum('bi,ij,bj->b', delta, precision, delta), 1e-9)
     # reversed / re-batched: bit for bit
@@ -606,3 +611,47 @@ def test_workgroups_of_32_draws_are_taken_below_8192_draws():
         halotab.predict_batch_async(theta, out=out).wait()
         launch = last_launch(halotab)
         assert launch[2] == 0 and launch[1] == waves, (n, launch)
+
+
+@pytest.mark.parametrize('n_prim, n_sec, n_r, n_draws, modulate', [
+    (50, 2, 19, 200, False),        # BASELINE configs[2]'s table: 200 bins, eight waves
+    (20, 2, 6, 70, True),           # 80 bins: four waves
+    (13, 2, 3, 33, False),
+])
+def test_fused_32_draws_with_assembly_bias(n_prim, n_sec, n_r, n_draws, modulate):
+    """Heaviside assembly bias (median split) in the halves of the 32-draw workgroups, total and
+    separated by galaxy type, against the oracle; strengths beyond [-1, 1] are clipped."""
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    rng = np.random.default_rng(n_draws)
+    table = synthetic.synthetic_table(n_prim, n_sec, (n_r, ), 'auto', seed=n_prim)
+    theta = synthetic.zheng07_draws(n_draws, seed=n_draws)
+    strengths = rng.uniform(-1.2, 1.2, (n_draws, 2))
+    halotab = make_tabcorr(table)
+    force_fused(halotab)
+    set_option(halotab, 'fused_draws', 32)
+    batch = np.hstack([theta, strengths])
+    wide = 2 * n_prim * n_sec > 104
+    for separate in (False, True):
+        expect = oracle.predict_zheng07_batch(table, theta, separate_gal_type=separate,
+                                              assembias=strengths, modulate_with_cenocc=modulate)
+        ngal, xi = halotab.predict_batch(batch, separate_gal_type=separate, assembias=True,
+                                         modulate_with_cenocc=modulate)
+        assert last_launch(halotab)[:3] == ((n_draws + 31) // 32, 8 if wide else 4, 0)
+        if separate:
+            for key in expect[0]:
+                assert_rel(ngal[key], expect[0][key], RTOL, 'ngal ' + key)
+            for key in expect[1]:
+                assert_rel(xi[key], expect[1][key], RTOL, 'xi ' + key, floor=1e-13)
+        else:
+            assert_rel(ngal, expect[0], RTOL, 'ngal')
+            assert_rel(xi, expect[1], RTOL, 'xi')
+    bad = batch.copy()
+    bad[2, 5] = np.nan                  # a NaN strength: the centrals of that draw
+    bad[3, 3] = -300.0                  # M1 = 0 with a decorated satellite occupation
+    got = halotab.predict_batch(bad, assembias=True, modulate_with_cenocc=modulate)
+    force_fused(halotab, False)
+    want = halotab.predict_batch(bad, assembias=True, modulate_with_cenocc=modulate)
+    assert np.array_equal(np.isnan(got[1]), np.isnan(want[1]))
+    good = np.isfinite(want[1])
+    assert_rel(got[1][good], want[1][good], 1e-12)

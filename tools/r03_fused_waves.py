@@ -15,8 +15,8 @@ from tabcorr_amd import TabCorr, synthetic, _lib   # noqa: E402
 
 lib = _lib.load()
 n = 10000
-cases = [(50, 1, 0), (52, 1, 0), (56, 1, 0), (64, 1, 0), (80, 1, 0), (50, 2, 0), (50, 2, 1),
-         (50, 2, 5), (60, 2, 0)]
+cases = [(50, 1, 0), (56, 1, 0), (64, 1, 0), (80, 1, 0), (50, 2, 0), (50, 2, 1),
+         (50, 2, 5), (57, 2, 0)]
 for n_prim, n_sec, flags in cases:
     n_theta = 7 if flags & 4 else 5
     theta = synthetic.zheng07_draws(n, seed=1)
@@ -38,7 +38,8 @@ for n_prim, n_sec, flags in cases:
             handle, d_theta, n_theta, n, 10, flags, ctypes.c_void_p(d_ngal.value + s * n * 16),
             ctypes.c_void_p(d_xi.value + s * n * 19 * 3 * 8)))
     text = []
-    for label, fused, waves in (('three kernels', 0, 0), ('8 waves', 1, 8), ('16 waves', 1, 16)):
+    for label, fused, waves in (('three kernels', 0, 0), ('8 waves', 1, 8), ('16 waves', 1, 16),
+                                ('default shape', 1, 0)):
         _lib.check(lib.tc_table_set_option(handle, b'fused', fused))
         _lib.check(lib.tc_table_set_option(handle, b'fused_min_draws', 1))
         _lib.check(lib.tc_table_set_option(handle, b'fused_waves', waves))
@@ -47,7 +48,7 @@ for n_prim, n_sec, flags in cases:
         _lib.check(lib.tc_table_synchronize(handle))
         launch = [ctypes.c_int() for _ in range(4)]
         lib.tc_table_last_launch(handle, *[ctypes.byref(v) for v in launch])
-        if fused and (launch[2].value != 0 or launch[1].value != waves):
+        if fused and (launch[2].value != 0 or (waves and launch[1].value != waves)):
             text.append('%s: -' % label)
             continue
         t0 = time.perf_counter()
@@ -63,7 +64,9 @@ for n_prim, n_sec, flags in cases:
                 step(k)
             _lib.check(lib.tc_table_synchronize(handle))
             bursts.append((time.perf_counter() - t0) / 20 * 1e6)
-        text.append('%s: %.2f (burst of 20: %.2f)' % (label, steady, float(np.median(bursts))))
+        text.append('%s%s: %.2f (burst of 20: %.2f)' % (
+            label, '' if waves else ' = %d waves, %d workgroups' % (launch[1].value, launch[0].value),
+            steady, float(np.median(bursts))))
     print('G = %3d, flags %d, us per step: %s' % (2 * n_prim * n_sec, flags, ' | '.join(text)),
           flush=True)
     for ptr in (d_theta, d_ngal, d_xi):
