@@ -918,7 +918,8 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
         # (the pipelined calls of device_calls_per_sec: one launch per call where the library
         # chose predict_fused_kernel -- no slabs of partial sums --, else the three kernels)
         pipelined = ('one launch per call: predict_fused_kernel, %d workgroups of %d waves'
-                     % (shape[0].value, shape[1].value) if shape[2].value == 0
+                     % (shape[0].value, shape[1].value)
+                     if shape[2].value == 0 and shape[1].value > 0
                      else 'occupation, contraction, finalisation kernels')
         _lib.check(lib.tc_table_set_option(timer_handle, b'pipeline', 0))
         kernel_ms, n_launch, _ = kernel_time(lib, _lib, timer_handle, launch, synchronize,
