@@ -19,8 +19,10 @@ for n_prim in (20, 30, 50):
     for n in (200, 1000, 4000, 10000):
         theta = synthetic.zheng07_draws(n, seed=1)
         row = []
-        for fused in (1, 2):
+        for fused, draws in ((1, 0), (2, 64), (2, 32)):
             _lib.check(lib.tc_table_set_option(handle, b'fused', fused))
+            _lib.check(lib.tc_table_set_option(handle, b'fused_draws', draws))
             _lib.check(lib.tc_table_set_option(handle, b'fused_min_draws', 1 if fused == 2 else 0))
             row.append(timeit(lambda: halotab.predict_batch(theta)))
-        print('G = %3d, %5d draws, synchronous host call: three kernels %7.1f us, one launch %7.1f us' % (2 * n_prim, n, row[0], row[1]))
+        print('G = %3d, %5d draws, synchronous host call: three kernels %7.1f us, one launch %7.1f us '
+              '(64 draws per workgroup), %7.1f us (32)' % (2 * n_prim, n, row[0], row[1], row[2]))
