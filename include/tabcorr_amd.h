@@ -297,10 +297,11 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 three kernels).
  *   "fused_waves" 0 (default): 8 waves per workgroup where two workgroups fit a CU; 8 / 16:
  *                 that many where the table fits.
- *   "fused_draws" 0 (default): workgroups of 32 draws (four waves, three per CU) for batches
- *                 below 8192 draws of the plain Zheng07 family with n_gauss_prim = 10 --
- *                 a third faster there, and the one-launch form then pays from half the batch
- *                 size --, of 64 draws otherwise; 32 / 64: forced.
+ *   "fused_draws" 0 (default): workgroups of 32 draws (one tile, eight waves, two per CU) for
+ *                 batches below 8192 draws of the Zheng07 family with n_gauss_prim = 10 --
+ *                 a third faster there, and the one-launch form then pays from 12 draws per
+ *                 bin on -- and for tables of 105 .. 208 bins, of 64 draws otherwise; 32 / 64:
+ *                 forced.
  *   "single_draw" 1 (default): an un-batched predict() goes through one launch.
  *   "resident"    1: un-batched calls (tc_predict_zheng07_batch with one draw; total
  *                 correlation function, Zheng07 family) are served by ONE resident launch:

@@ -1573,15 +1573,13 @@ __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, uns
 
 template <int NGAUSS, int U, bool ASSEMBIAS, bool MODULATE, bool LEAUTHAUD = false,
           int W = kFusedWaves, int DL = 64>
-__global__ __launch_bounds__(64 * W, DL == 32 && W == 4 ? 3 : W == 8 ? 2 : 1) void
-predict_fused_kernel(FusedArgs a) {
-  // DL = draws per workgroup: 64 (two 32-draw tiles, W = 8 or 16 waves), or 32 (one tile --
-  // lanes = (draw, half of a bin's nodes) in the occupation phase, occ_bin_zheng07_halves):
-  // four waves, three workgroups per CU, half the lifetime of a workgroup (medium batches), or
-  // eight waves = eight parts of the units, two workgroups of up to 80 KB per CU: tables of
-  // 105-230 bins with the wave count per SIMD of the 64-draw form
-  static_assert((DL == 64 && (W == 8 || W == 16)) || (DL == 32 && (W == 4 || W == 8)),
-                "workgroup shape");
+__global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(FusedArgs a) {
+  // DL = draws per workgroup: 64 (two 32-draw tiles, W = 8 or 16 waves), or 32 (ONE tile, eight
+  // waves = eight parts of the units, lanes = (draw, half of a bin's nodes) in the occupation
+  // phase, occ_bin_zheng07_halves; two workgroups of up to 80 KB per CU): a quarter of the
+  // 64-draw workgroup's lifetime -- batches below 8192 draws --, and tables of 105-208 bins
+  // with the wave count per SIMD of the 64-draw form
+  static_assert((DL == 64 && (W == 8 || W == 16)) || (DL == 32 && W == 8), "workgroup shape");
   static_assert(DL == 64 || (NGAUSS == 10 && !LEAUTHAUD), "32 draws: the Zheng07 family");
   constexpr int PARTS = W * 32 / DL;       // waves per 32-draw tile
   static_assert(!LEAUTHAUD || (NGAUSS == 0 && !ASSEMBIAS), "Leauthaud11: any n_gauss, undecorated");

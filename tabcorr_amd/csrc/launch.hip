@@ -943,11 +943,9 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
   // are bound by the host thread that queues them (10-13 us per call) and differ by noise.
   {
     const tc::QuadLayout& layout = separate ? t->quad_by_type.layout : t->quad_total.layout;
-    // (workgroups of 32 draws last half as long)
     const double estimate = (5.0 + 10.0 * (t->n_bins / 100.0) * (n_gauss / 10.0) +
                              60.0 * ((double)layout.n_units / 325.0) * (t->quad_tiling.n_u / 5.0)) *
-                            8.0 / (wide ? 16 : fused_waves(t, separate)) *
-                            (fused_half_tiles(t, separate, n_draws, n_gauss, flags) ? 0.5 : 1.0);
+                            8.0 / (wide ? 16 : fused_waves(t, separate));
     // Leauthaud11 (a Newton inverse of the stellar-to-halo mass relation per central node: the
     // occupations outweigh the matrix work and spread better over the chip as a kernel of their
     // own): tools/r03_fused_leauthaud.py, us per step, three kernels / one launch: G = 100: 4000
@@ -962,6 +960,8 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
     // 15 draws per bin on.
     const int64_t min_draws = t->tuning.fused_min_draws > 0 ? t->tuning.fused_min_draws
                               : wide                        ? 15 * (int64_t)t->n_bins
+                              : fused_half_tiles(t, separate, n_draws, n_gauss, flags)
+                                  ? 12 * (int64_t)t->n_bins
                               : leauthaud                   ? 8192
                               : estimate <= 28.0            ? 512
                                                             : (int64_t)(90.0 * estimate);
@@ -988,30 +988,29 @@ int fused_lds_bytes(const tc_table* t, bool separate, int waves, int draws) {
           tc::fused_scratch_doubles(waves)) * 8;
 }
 
-// Workgroups of 32 draws (four waves, three per CU): plain Zheng07 with the reference's default
-// n_gauss_prim, tables whose 32-draw workgroup fits a third of a CU's LDS.
-// A workgroup then lasts half as long, and a batch has twice as many: ahead for medium batches,
-// where the 64-draw workgroups of four launches do not fill the chip, behind by 4-7 % once they
-// do (three workgroups of four waves per CU leave a SIMD three waves) -- tools/r03_fused_half.py,
-// us per step, three kernels / 64 / 32 draws: G = 100: 2048 draws 19.1 / 28.5 / 22.1, 4096
-// 24.0 / 30.5 / 21.0, 6144 31.4 / 30.9 / 26.1, 10^4 43.6 / 39.5 / 41.1; G = 60: 1024 10.3 / 12.2 /
-// 9.3, 4096 15.3 / 13.4 / 10.7, 6144 18.6 / 14.3 / 12.2, 10^4 21.6 / 17.7 / 19.0: below 8192 draws.
+// Workgroups of ONE 32-draw tile and eight waves (eight parts of the units; up to 80 KB of LDS,
+// two per CU), Zheng07 family with the default n_gauss_prim.
+// * Batches below 8192 draws of tables up to 104 bins: a workgroup lasts a quarter as long as
+//   the 64-draw one and a batch has twice as many -- what batches need that do not fill the
+//   chip's 512 places with four launches of 64-draw workgroups (tools/r03_fused_half.py, us per
+//   step, three kernels / 64 draws x 8 waves / 32 x 4 / 32 x 8: G = 100: 1024 draws 12.8 / 23.4 /
+//   19.3 / 15.1, 2048 19.0 / 29.0 / 21.7 / 16.0, 4096 23.9 / 30.2 / 22.3 / 16.9, 6144 31.6 / 31.1 /
+//   26.2 / 25.1, 10^4 43.5 / 39.4 / 41.0 / 41.4; G = 60: 1024 10.2 / 12.3 / 9.7 / 7.4, 4096 15.3 /
+//   13.4 / 11.0 / 8.2, 6144 18.6 / 14.2 / 12.2 / 11.9, 10^4 21.5 / 17.7 / 19.0 / 19.5): once the
+//   chip is full the 64-draw form's fixed costs per draw win by 4-7 %.
+// * Tables of 105-208 bins, whose 64-draw workgroup does not fit half a CU: any batch size.
 bool fused_half_tiles(const tc_table* t, bool separate, int64_t n_draws, int n_gauss,
                       unsigned flags) {
   if (t->tuning.fused_draws == 64 || (t->tuning.fused_draws == 0 && n_draws >= 8192))
     return false;
   if (n_gauss != 10 || (flags & TC_FLAG_LEAUTHAUD11)) return false;
-  if (t->tuning.fused_waves != 0) return false;
-  return fused_lds_bytes(t, separate, 4, 32) <= 53 * 1024;
+  if (t->tuning.fused_waves != 0 && t->tuning.fused_waves != 8) return false;
+  return fused_lds_bytes(t, separate, 8, 32) <= 80 * 1024;
 }
 
-// Tables whose 64-draw workgroup does not fit half a CU (more than 104 bins): ONE 32-draw tile
-// per workgroup of eight waves (eight parts of the units), two workgroups of up to 80 KB per
-// CU -- four waves per SIMD like the 64-draw form of smaller tables.  Zheng07 family with the
-// default n_gauss_prim, up to 230 bins.
 bool fused_wide_tables(const tc_table* t, bool separate, int n_gauss, unsigned flags) {
-  if (t->tuning.fused_draws == 64 || t->tuning.fused_waves != 0) return false;
   if (n_gauss != 10 || (flags & TC_FLAG_LEAUTHAUD11)) return false;
+  if (t->tuning.fused_draws == 64 || t->tuning.fused_waves != 0) return false;
   return fused_lds_bytes(t, separate, 8, 64) > 80 * 1024 &&
          fused_lds_bytes(t, separate, 8, 32) <= 80 * 1024;
 }
@@ -1074,7 +1073,7 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   fa.separate = separate ? 1 : 0;
   const bool wide = fused_wide_tables(t, separate, n_gauss, flags);
   const bool half_tiles = !wide && fused_half_tiles(t, separate, n_draws, n_gauss, flags);
-  const int waves = wide ? 8 : half_tiles ? 4 : fused_waves(t, separate);
+  const int waves = wide || half_tiles ? 8 : fused_waves(t, separate);
   const int draws = wide || half_tiles ? 32 : 64;
   const int n_parts = waves * 32 / draws;
   if (!separate) {
@@ -1152,10 +1151,8 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
                : launch_fused<NG, AB, MO, LE, 8>(t->device, t->quad_tiling.n_u, grid, block,   \
                                                  lds, stream, k0, k1, fa))
 #define TC_FUSED32(AB, MO)                                                                    \
-  (wide ? launch_fused<10, AB, MO, false, 8, 32>(t->device, t->quad_tiling.n_u, grid, block,   \
-                                                 lds, stream, k0, k1, fa)                      \
-        : launch_fused<10, AB, MO, false, 4, 32>(t->device, t->quad_tiling.n_u, grid, block,   \
-                                                 lds, stream, k0, k1, fa))
+  launch_fused<10, AB, MO, false, 8, 32>(t->device, t->quad_tiling.n_u, grid, block, lds,      \
+                                         stream, k0, k1, fa)
   if (wide || half_tiles)
     status = assembias ? (modulate ? TC_FUSED32(true, true) : TC_FUSED32(true, false))
                        : (modulate ? TC_FUSED32(false, true) : TC_FUSED32(false, false));

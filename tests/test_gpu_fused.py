@@ -41,10 +41,10 @@ def last_launch(halotab):
     return tuple(v.value for v in values)
 
 
-def fused_ran(halotab, waves=(4, 8, 16)):
-    """Was the last launch predict_fused_kernel (8 waves per workgroup of 64 draws where two
-    workgroups fit a CU, 4 waves per workgroup of 32 draws for batches below 8192 draws of the
-    plain Zheng07 family, 16 for tables of more than 104 bins; no slabs of partial sums)?"""
+def fused_ran(halotab, waves=(8, 16)):
+    """Was the last launch predict_fused_kernel (8 waves per workgroup -- of 64 draws, or of 32
+    for batches below 8192 draws and for tables of 105-208 bins --, 16 when forced for larger
+    tables; no slabs of partial sums)?"""
     launch = last_launch(halotab)
     return launch[1] in waves and launch[2] == 0
 
@@ -56,7 +56,7 @@ def test_fused_matches_golden():
     force_fused(halotab)
     ngal, xi = halotab.predict_batch(data['theta'])
     workgroups, waves, slabs, lds = last_launch(halotab)
-    assert waves == 4 and slabs == 0 and workgroups == (len(data['theta']) + 31) // 32
+    assert waves == 8 and slabs == 0 and workgroups == (len(data['theta']) + 31) // 32
     assert_rel(ngal, data['ngal'], RTOL, 'ngal')
     assert_rel(xi, data['xi'], RTOL, 'xi')
     # the three-kernel path gives the same to rounding
@@ -534,7 +534,7 @@ def test_fused_sixteen_waves(n_prim, n_sec, n_r, n_draws, kwargs):
     (28, 2, 12, 40, {}),                                    # 112 bins
 ])
 def test_fused_workgroups_of_32_draws(n_prim, n_sec, n_r, n_draws, kwargs):
-    """predict_fused_kernel<..., W = 4, DL = 32>: lanes = (draw, half of a bin's nodes) in the
+    """predict_fused_kernel<..., W = 8, DL = 32>: lanes = (draw, half of a bin's nodes) in the
     occupation phase, one 32-draw tile per workgroup -- total, separated by galaxy type and the
     fused likelihood against the oracle; equal to the 64-draw form to rounding; NaN / tied
     parameters as the 64-draw form; a draw's result does not depend on its place in the batch."""
@@ -551,8 +551,7 @@ def test_fused_workgroups_of_32_draws(n_prim, n_sec, n_r, n_draws, kwargs):
         ngal, xi = halotab.predict_batch(theta, separate_gal_type=separate, **kwargs)
         launch = last_launch(halotab)
         wide = 2 * n_prim * n_sec > 104
-        assert launch[:3] == ((n_draws + 31) // 32, 8 if wide else 4, 0), \
-            'the 32-draw kernel did not run'
+        assert launch[:3] == ((n_draws + 31) // 32, 8, 0), 'the 32-draw kernel did not run'
         if separate:
             for key in expect[0]:
                 assert_rel(ngal[key], expect[0][key], RTOL, 'ngal ' + key)
@@ -574,7 +573,7 @@ def test_fused_workgroups_of_32_draws(n_prim, n_sec, n_r, n_draws, kwargs):
     precision = a @ a.T / np.mean(vector)**2
     delta = total[1] - vector
     n_chi, chi2 = halotab.chi2_batch(theta, vector, precision, **kwargs)
-    assert last_launch(halotab)[:2] == ((n_draws + 31) // 32, 8 if wide else 4)
+    assert last_launch(halotab)[:2] == ((n_draws + 31) // 32, 8)
     assert_rel(n_chi, total[0], 1e-13)
     assert_rel(chi2, np.einsum('bi,ij,bj->b', delta, precision, delta), 1e-9)
     # reversed / re-batched: bit for bit
@@ -605,17 +604,17 @@ def test_workgroups_of_32_draws_are_taken_below_8192_draws():
     from tabcorr_amd import pinned_array, pinned_empty, synthetic
     table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
     halotab = make_tabcorr(table)
-    for n, waves in ((4096, 4), (8191, 4), (8192, 8), (10000, 8)):
+    for n, draws in ((1200, 32), (4096, 32), (8191, 32), (8192, 64), (10000, 64)):
         theta = pinned_array(synthetic.zheng07_draws(n, seed=1))
         out = (pinned_empty(n), pinned_empty((n, 19)))
         halotab.predict_batch_async(theta, out=out).wait()
         launch = last_launch(halotab)
-        assert launch[2] == 0 and launch[1] == waves, (n, launch)
+        assert launch[:3] == ((n + draws - 1) // draws, 8, 0), (n, launch)
 
 
 @pytest.mark.parametrize('n_prim, n_sec, n_r, n_draws, modulate', [
-    (50, 2, 19, 200, False),        # BASELINE configs[2]'s table: 200 bins, eight waves
-    (20, 2, 6, 70, True),           # 80 bins: four waves
+    (50, 2, 19, 200, False),        # BASELINE configs[2]'s table: 200 bins
+    (20, 2, 6, 70, True),           # 80 bins
     (13, 2, 3, 33, False),
 ])
 def test_fused_32_draws_with_assembly_bias(n_prim, n_sec, n_r, n_draws, modulate):
@@ -631,13 +630,12 @@ def test_fused_32_draws_with_assembly_bias(n_prim, n_sec, n_r, n_draws, modulate
     force_fused(halotab)
     set_option(halotab, 'fused_draws', 32)
     batch = np.hstack([theta, strengths])
-    wide = 2 * n_prim * n_sec > 104
     for separate in (False, True):
         expect = oracle.predict_zheng07_batch(table, theta, separate_gal_type=separate,
                                               assembias=strengths, modulate_with_cenocc=modulate)
         ngal, xi = halotab.predict_batch(batch, separate_gal_type=separate, assembias=True,
                                          modulate_with_cenocc=modulate)
-        assert last_launch(halotab)[:3] == ((n_draws + 31) // 32, 8 if wide else 4, 0)
+        assert last_launch(halotab)[:3] == ((n_draws + 31) // 32, 8, 0)
         if separate:
             for key in expect[0]:
                 assert_rel(ngal[key], expect[0][key], RTOL, 'ngal ' + key)

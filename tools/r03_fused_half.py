@@ -20,6 +20,7 @@ for n_prim in (50, 30):
                                   table['attrs'])
     handle = halotab.to_device().handle
     _lib.check(lib.tc_table_set_option(handle, b'fused', 2))
+    _lib.check(lib.tc_table_set_option(handle, b'fused_waves', 0))
     _lib.check(lib.tc_table_set_option(handle, b'fused_min_draws', 1))
     _lib.check(lib.tc_table_set_option(handle, b'single_draw', 0))
     theta = synthetic.zheng07_draws(333, seed=2)
@@ -43,9 +44,11 @@ for n_prim in (50, 30):
                 handle, d_theta, 5, n, 10, 0, ctypes.c_void_p(d_ngal.value + s * n * 8),
                 ctypes.c_void_p(d_xi.value + s * n * 19 * 8)))
         text = []
-        for label, fused, draws in (('three kernels', 0, 64), ('64 draws', 1, 64), ('32 draws', 1, 32)):
+        for label, fused, draws, waves in (('three kernels', 0, 64, 0), ('64 draws', 1, 64, 0),
+                                           ('32 draws', 1, 32, 0), ('32 draws x 8 waves', 1, 32, 8)):
             _lib.check(lib.tc_table_set_option(handle, b'fused', fused))
             _lib.check(lib.tc_table_set_option(handle, b'fused_draws', draws))
+            _lib.check(lib.tc_table_set_option(handle, b'fused_waves', waves))
             for k in range(300):
                 step(k)
             _lib.check(lib.tc_table_synchronize(handle))
@@ -67,3 +70,4 @@ for n_prim in (50, 30):
         for ptr in (d_theta, d_ngal, d_xi):
             lib.tc_device_free(ptr)
     _lib.check(lib.tc_table_set_option(handle, b'fused', 2))
+    _lib.check(lib.tc_table_set_option(handle, b'fused_waves', 0))
