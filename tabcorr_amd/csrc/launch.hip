@@ -961,7 +961,12 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
     const int64_t min_draws = t->tuning.fused_min_draws > 0 ? t->tuning.fused_min_draws
                               : wide                        ? 15 * (int64_t)t->n_bins
                               : fused_half_tiles(t, separate, n_draws, n_gauss, flags)
-                                  ? 12 * (int64_t)t->n_bins
+                                  // (tools/r03_fused_low.py, us per step, three kernels / one
+                                  // launch: a step of small batches costs a fifth of the
+                                  // estimate -- G = 40: 256 draws 14.0 / 5.6; G = 60: 256 8.7 /
+                                  // 5.5, 1024 8.6 / 7.6; G = 100, R = 3: 256 13.4 / 6.3; G = 100,
+                                  // R = 19: 1024 15.0 / 15.4, 1280 16.3 / 15.6, 2048 19.3 / 16.4)
+                                  ? (estimate <= 50.0 ? 256 : 12 * (int64_t)t->n_bins)
                               : leauthaud                   ? 8192
                               : estimate <= 28.0            ? 512
                                                             : (int64_t)(90.0 * estimate);
