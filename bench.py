@@ -681,6 +681,35 @@ def main():
             'what': 'tc_predict_zheng07_batch: %d draws in pageable host memory -> (ngal, xi) '
                     'in host memory, synchronous, PCIe included (SURVEY.md 8d)' % n_draws}
         result.update(host_pipelined(lib, _lib, handle, table, n_draws, data_vector, precision))
+        # other batch sizes of the same table (an ensemble sampler's 10^2 ... 10^4 walkers per
+        # step), device-resident, the form the library chooses and -- by option -- the three
+        # kernels; first draws of every batch against the oracle
+        sizes = {}
+        from oracle import tabcorr_oracle as oracle
+        for size in (256, 1024, 4096):
+            row = {}
+            for name, fused in (('chosen', 1), ('three_kernels', 0)):
+                _lib.check(lib.tc_table_set_option(handle, b'fused', fused))
+                seconds = sustained(
+                    lambda: lib.tc_predict_zheng07_batch_device(
+                        handle, d_theta, 5, size, N_GAUSS, 0, out_ptr(0), out_ptr(0, size)),
+                    synchronize, seconds=0.15, warm_seconds=0.05)
+                row[name + '_us_per_call'] = seconds * 1e6
+                row[name + '_calls_per_sec'] = size / seconds
+                if fused:
+                    shape = [ctypes.c_int() for _ in range(4)]
+                    lib.tc_table_last_launch(handle, *[ctypes.byref(v) for v in shape])
+                    row['chosen_form'] = (
+                        'one launch: %d workgroups of %d waves' % (shape[0].value, shape[1].value)
+                        if shape[2].value == 0 else 'three kernels')
+                    host = dev.download(out_ptr(0), size * (1 + N_R))
+                    expect = oracle.predict_zheng07_batch(table, theta[:3])
+                    row['parity_max_rel_vs_oracle'] = float(max(
+                        np.max(np.abs(host[:3] / expect[0] - 1)),
+                        np.max(np.abs(host[size:size + 3 * N_R].reshape(3, N_R) / expect[1] - 1))))
+            sizes[str(size)] = row
+        _lib.check(lib.tc_table_set_option(handle, b'fused', 1))
+        result['batch_sizes'] = sizes
         result['unbatched_us'] = unbatched(make, table, synthetic, Interpolator)
         result['tabulation'] = tabulation(args.cpu_seconds)
         if args.other_configs:
