@@ -550,6 +550,43 @@ __device__ __forceinline__ double occ_bin_leauthaud11(const double* table, const
   return acc;
 }
 
+// The same for the 32-draw workgroups of predict_fused_kernel: lane = (draw, half), five of the
+// bin's ten nodes per half (constants by vector loads), the halves added by a lane exchange.
+template <bool MODULATE>
+__device__ __forceinline__ double occ_bin_leauthaud11_halves(const double* table,
+                                                             const fm::Consts& kc, int g,
+                                                             bool central, int half,
+                                                             const double* log_m_v,
+                                                             const double* mass_v,
+                                                             const double* weight_v,
+                                                             const LeauthaudDraw& d) {
+  constexpr double kLog2Of10 = 3.32192809488736234787;
+  constexpr int kNodes = 10, kHalf = 5;
+  const double* lm_p = log_m_v + g * kNodes + half * kHalf;
+  const double* m_p = mass_v + g * kNodes + half * kHalf;
+  const double* w_p = weight_v + g * kNodes + half * kHalf;
+  double acc = 0.0;
+  for (int k = 0; k < kHalf; ++k) {
+    const double lm = lm_p[k];
+    double n_cen = 1.0;
+    if (central || MODULATE) {
+      const double log_mstar = smhm_log_mstar(table, kc, d.smhm, lm);
+      const double za = (d.threshold - log_mstar) * d.inv_scatter;
+      n_cen = fma(-0.5, fm::erf_fast(table, kc, za), 0.5);
+      n_cen = za != za ? za : n_cen;
+    }
+    double n = n_cen;
+    if (!central) {
+      const double z = fma(d.alphasat, lm * kLog2Of10 - d.log2_msat, d.cut / m_p[k]);
+      n = fm::exp2_fast(table, kc, z);
+      n = z != z ? z : n;
+      if (MODULATE) n *= n_cen;
+    }
+    acc = fma(w_p[k], n, acc);
+  }
+  return acc + __shfl_xor(acc, 32, 64);
+}
+
 // Same work decomposition, outputs and launch geometry as occ_zheng07_kernel.
 template <bool MODULATE>
 __global__ __launch_bounds__(kOccWaves * kLanes) void occ_leauthaud11_kernel(OccArgs a) {
@@ -1580,7 +1617,7 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
   // 64-draw workgroup's lifetime -- batches below 8192 draws --, and tables of 105-208 bins
   // with the wave count per SIMD of the 64-draw form
   static_assert((DL == 64 && (W == 8 || W == 16)) || (DL == 32 && W == 8), "workgroup shape");
-  static_assert(DL == 64 || (NGAUSS == 10 && !LEAUTHAUD), "32 draws: the Zheng07 family");
+  static_assert(DL == 64 || NGAUSS == 10 || LEAUTHAUD, "32 draws: ten nodes per bin");
   constexpr int PARTS = W * 32 / DL;       // waves per 32-draw tile
   static_assert(!LEAUTHAUD || (NGAUSS == 0 && !ASSEMBIAS), "Leauthaud11: any n_gauss, undecorated");
   constexpr int UP = (U + 1) / 2;
@@ -1649,7 +1686,10 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
       const bool central = g < a.n_central;
       const bool above = ASSEMBIAS ? percentile[g] > a.split : false;
       const double acc =
-          DL == 32    ? occ_bin_zheng07_halves<ASSEMBIAS, MODULATE>(table, kc, g, central, above,
+          DL == 32 && LEAUTHAUD
+              ? occ_bin_leauthaud11_halves<MODULATE>(table, kc, g, central, half, a.log_m, a.m,
+                                                     a.weight, ld)
+          : DL == 32  ? occ_bin_zheng07_halves<ASSEMBIAS, MODULATE>(table, kc, g, central, above,
                                                                     half, a.log_m, a.m, a.weight,
                                                                     log_m, weight_sum, dp)
           : LEAUTHAUD ? occ_bin_leauthaud11<MODULATE>(table, kc, g, n_gauss, central, log_m, mass,

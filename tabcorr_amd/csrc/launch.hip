@@ -960,6 +960,11 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
     // 15 draws per bin on.
     const int64_t min_draws = t->tuning.fused_min_draws > 0 ? t->tuning.fused_min_draws
                               : wide                        ? 15 * (int64_t)t->n_bins
+                              // (Leauthaud11 in 32-draw workgroups, tools/r03_fused_leauthaud.py,
+                              // three kernels / one launch: G = 60: 2000 draws 20.7 / 25.6, 4000
+                              // 37.4 / 28.7; G = 100: 2000 33.9 / 39.6, 4000 56.5 / 50.3)
+                              : leauthaud && fused_half_tiles(t, separate, n_draws, n_gauss, flags)
+                                  ? 3000
                               : fused_half_tiles(t, separate, n_draws, n_gauss, flags)
                                   // (tools/r03_fused_low.py, us per step, three kernels / one
                                   // launch: a step of small batches costs a fifth of the
@@ -1008,13 +1013,13 @@ bool fused_half_tiles(const tc_table* t, bool separate, int64_t n_draws, int n_g
                       unsigned flags) {
   if (t->tuning.fused_draws == 64 || (t->tuning.fused_draws == 0 && n_draws >= 8192))
     return false;
-  if (n_gauss != 10 || (flags & TC_FLAG_LEAUTHAUD11)) return false;
+  if (n_gauss != 10) return false;
   if (t->tuning.fused_waves != 0 && t->tuning.fused_waves != 8) return false;
   return fused_lds_bytes(t, separate, 8, 32) <= 80 * 1024;
 }
 
 bool fused_wide_tables(const tc_table* t, bool separate, int n_gauss, unsigned flags) {
-  if (n_gauss != 10 || (flags & TC_FLAG_LEAUTHAUD11)) return false;
+  if (n_gauss != 10) return false;
   if (t->tuning.fused_draws == 64 || t->tuning.fused_waves != 0) return false;
   return fused_lds_bytes(t, separate, 8, 64) > 80 * 1024 &&
          fused_lds_bytes(t, separate, 8, 32) <= 80 * 1024;
@@ -1158,7 +1163,12 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
 #define TC_FUSED32(AB, MO)                                                                    \
   launch_fused<10, AB, MO, false, 8, 32>(t->device, t->quad_tiling.n_u, grid, block, lds,      \
                                          stream, k0, k1, fa)
-  if (wide || half_tiles)
+  if ((wide || half_tiles) && (flags & TC_FLAG_LEAUTHAUD11))
+    status = modulate ? launch_fused<0, false, true, true, 8, 32>(
+                            t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa)
+                      : launch_fused<0, false, false, true, 8, 32>(
+                            t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
+  else if (wide || half_tiles)
     status = assembias ? (modulate ? TC_FUSED32(true, true) : TC_FUSED32(true, false))
                        : (modulate ? TC_FUSED32(false, true) : TC_FUSED32(false, false));
   else if (flags & TC_FLAG_LEAUTHAUD11)

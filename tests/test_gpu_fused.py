@@ -195,8 +195,9 @@ def test_fused_is_not_taken_where_it_does_not_apply():
     assert last_launch(halotab)[2] > 0
 
 
+@pytest.mark.parametrize('draws', [64, 32])
 @pytest.mark.parametrize('name', ['leauthaud11_bolplanck_wp', 'leauthaud11_synthetic'])
-def test_fused_leauthaud11(name):
+def test_fused_leauthaud11(name, draws):
     """The Leauthaud11 family (Newton inverse of the stellar-to-halo mass relation per central
     node) in the one-launch form: fixtures recorded from the reference with a duck model,
     with and without modulate_with_cenocc; more draws than a tile (jittered fixture draws)
@@ -207,6 +208,7 @@ def test_fused_leauthaud11(name):
     table = table_from_golden(data)
     halotab = make_tabcorr(table)
     force_fused(halotab)
+    set_option(halotab, 'fused_draws', draws)     # (workgroups of 64 draws, or of one 32-draw tile)
     theta = data['theta']
     n_r = int(np.prod(data['xi'].shape[1:]))
     rng = np.random.default_rng(len(theta))
@@ -221,7 +223,7 @@ def test_fused_leauthaud11(name):
         # more than two tiles: oracle, and the three-kernel path to rounding
         ngal, xi = halotab.predict_batch(many, family='leauthaud11',
                                          modulate_with_cenocc=modulate)
-        assert last_launch(halotab)[:3] == (3, 8, 0)
+        assert last_launch(halotab)[:3] == ((140 + draws - 1) // draws, 8, 0)
         want = oracle.predict_leauthaud11_batch(table, many, modulate_with_cenocc=modulate)
         assert_rel(ngal, want[0], RTOL, 'ngal, 140 draws')
         assert_rel(xi, want[1], RTOL, 'xi, 140 draws')

@@ -24,7 +24,7 @@ for n_prim in (30, 50):
         _lib.check(lib.tc_memcpy_h2d(d_theta, theta.ctypes.data_as(ctypes.c_void_p), theta.nbytes))
         for flags in (16, 18):
             row = []
-            for fused in (0, 1):
+            for fused in (0, 2):
                 _lib.check(lib.tc_table_set_option(handle, b'fused', fused))
                 _lib.check(lib.tc_table_set_option(handle, b'fused_min_draws', 1))
                 def step(k):
