@@ -948,10 +948,12 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
                             8.0 / (wide ? 16 : fused_waves(t, separate));
     // Leauthaud11 (a Newton inverse of the stellar-to-halo mass relation per central node: the
     // occupations outweigh the matrix work and spread better over the chip as a kernel of their
-    // own): tools/r03_fused_leauthaud.py, us per step, three kernels / one launch: G = 100: 4000
-    // draws 57.3 / 88.7, 10^4 126.0 / 114.5; G = 60: 4000 38.4 / 49.9, 10^4 73.0 / 65.2; with
-    // modulate_with_cenocc (the inverse at the satellites' nodes too) never ahead: 10^4 draws
-    // 183.4 / 188.1 and 106.0 / 106.0 -- only when forced.
+    // own): tools/r03_fused_leauthaud.py, us per step, three kernels / one launch of 64-draw
+    // workgroups: G = 100: 4000 draws 57.3 / 88.7, 10^4 126.0 / 114.5; G = 60: 4000 38.4 / 49.9,
+    // 10^4 73.0 / 65.2 (32-draw workgroups below 8192 draws: further down); with
+    // modulate_with_cenocc (the inverse at the satellites' nodes too) never clearly ahead: 10^4
+    // draws 183.4 / 188.1 and 106.0 / 106.0, 4000 draws in 32-draw workgroups 80.2 / 80.6 and
+    // 51.5 / 45.9 -- only when forced.
     if (leauthaud && (flags & TC_FLAG_MODULATE_WITH_CENOCC) && t->tuning.fused < 2) return false;
     // Wide tables (eight waves x 32 draws; tools/r03_fused_wide.py, us per step, three kernels /
     // one launch: G = 112: 1024 draws 14.9 / 18.6, 2048 21.4 / 19.1, 4096 27.2 / 20.3, 10^4 52.3 /
