@@ -302,6 +302,13 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 a third faster there, and the one-launch form then pays from 12 draws per
  *                 bin on -- and for tables of 105 .. 208 bins, of 64 draws otherwise; 32 / 64:
  *                 forced.
+ *   "grouped"     1 (default): bins with identical log_prim_haloprop_min / max and galaxy type
+ *                 -- the secondary-percentile bins of one mass bin (tabcorr/tabcorr.py:186-205)
+ *                 -- share their Gauss-Legendre nodes (:548-549); the occupation functions are
+ *                 evaluated once per node of such a GROUP and every member bin accumulates
+ *                 them with its own weights (Zheng07 family, n_gauss_prim = 10).  No effect on
+ *                 tables without such bins.  0: every bin by itself (same occupations per bin
+ *                 to the last bit; sums over bins may differ in the last bits).
  *   "single_draw" 1 (default): an un-batched predict() goes through one launch.
  *   "resident"    1: un-batched calls (tc_predict_zheng07_batch with one draw; total
  *                 correlation function, Zheng07 family) are served by ONE resident launch:

@@ -45,6 +45,13 @@ int tc_debug_quad_schedule(int n_bins, int n_central, int by_type, int n_tiles, 
  * predict_fused_kernel walk (hostmath.h: triangle_parts): first block row, block column and
  * number of units of each of the n_parts parts. */
 int tc_debug_triangle_parts(int n_rb, int n_parts, int32_t* rb0, int32_t* cb0, int32_t* count);
+/* Groups of bins that share their Gauss-Legendre nodes (tabcorr_amd/csrc/hostmath.h:
+ * find_node_groups; identical log_prim_haloprop_min / max and galaxy type), for n_bins bins in
+ * library order of which the first n_central are centrals: group i = member[begin[i] ..
+ * begin[i + 1]).  begin holds n_groups + 1 entries (capacity n_bins + 1), member n_bins. */
+int tc_debug_node_groups(int n_bins, int n_central, const double* log_min,
+                         const double* log_max, int32_t* begin, int32_t* member,
+                         int* n_groups, int* n_central_groups);
 /* TEST INFRASTRUCTURE, never called by the product: executes the kernel's table layout,
  * schedule and slab grouping on the host, lane by lane, for densities (n_bins, ldb) given
  * in the reference's bin order; out (n_draws, 1 | 3, n_r) = sum_p c_p T[r][p] n_i n_j

@@ -5,7 +5,10 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstring>
+#include <map>
 #include <numeric>
+#include <tuple>
 #include <thread>
 
 namespace tc {
@@ -196,6 +199,39 @@ void add_rectangle(std::vector<Segment>& out, int component, int i_lo, int i_hi,
 }
 
 }  // namespace
+
+void find_node_groups(int n_bins, int n_central, const double* log_min, const double* log_max,
+                      NodeGroups& out) {
+  out = NodeGroups();
+  // (exact comparison of the bin edges: members of a group must have bit-identical nodes)
+  std::map<std::tuple<int, uint64_t, uint64_t>, int> seen;
+  std::vector<std::vector<int32_t>> groups;
+  auto bits = [](double x) {
+    uint64_t u;
+    std::memcpy(&u, &x, sizeof(u));
+    return u;
+  };
+  for (int g = 0; g < n_bins; ++g) {
+    if (g == n_central) out.n_central_groups = (int)groups.size();
+    const auto key = std::make_tuple(g < n_central ? 0 : 1, bits(log_min[g]), bits(log_max[g]));
+    auto it = seen.find(key);
+    // (a NaN edge never equals anything: such a bin stays alone)
+    if (it == seen.end() || log_min[g] != log_min[g] || log_max[g] != log_max[g]) {
+      seen[key] = (int)groups.size();
+      groups.emplace_back(1, g);
+    } else {
+      groups[it->second].push_back(g);
+    }
+  }
+  if (n_central >= n_bins) out.n_central_groups = (int)groups.size();
+  out.n_groups = (int)groups.size();
+  out.begin.push_back(0);
+  for (const std::vector<int32_t>& members : groups) {
+    out.member.insert(out.member.end(), members.begin(), members.end());
+    out.begin.push_back((int32_t)out.member.size());
+    out.largest = std::max(out.largest, (int)members.size());
+  }
+}
 
 void build_plan(int mode, int n_bins, const uint8_t* is_central, int block,
                 int row_budget, Plan& plan) {

@@ -95,6 +95,21 @@ struct Chunking {
 void build_plan(int mode, int n_bins, const uint8_t* is_central, int block,
                 int row_budget, Plan& plan);
 
+// Groups of bins that share their Gauss-Legendre nodes: the same log_prim_haloprop_min / max
+// (tabcorr.py:548-549: the nodes depend on nothing else) and the same galaxy type -- the
+// secondary-percentile bins of one mass bin (tabcorr.py:186-205).  Bins are in library order
+// (centrals first: the first n_central); group i = member[begin[i] .. begin[i + 1]), groups in
+// the order of their first member, members ascending; groups of centrals come first.
+struct NodeGroups {
+  std::vector<int32_t> begin;    // n_groups + 1
+  std::vector<int32_t> member;   // n_bins
+  int n_groups = 0;
+  int n_central_groups = 0;
+  int largest = 0;               // members of the largest group
+};
+void find_node_groups(int n_bins, int n_central, const double* log_min, const double* log_max,
+                      NodeGroups& out);
+
 // Cut the positions into about n_chunks wave-sized chunks (multiples of the
 // block size, never crossing a segment) and pack them waves_per_group at a
 // time into workgroups.

@@ -171,6 +171,11 @@ struct Quadrature {
   void* log_m = nullptr;
   void* m = nullptr;
   void* weight = nullptr;
+  // the same constants for the GROUPED kernels (n_gauss = 10, tables with groups of bins):
+  // nodes per group, weights (+ their sums) per member in group order (kernel_args.h: GroupArgs)
+  void* group_log_m = nullptr;
+  void* group_m = nullptr;
+  void* group_weight = nullptr;
 };
 
 // A schedule of the quadratic-form kernel on the device (hostmath.h: QuadSchedule).
@@ -329,6 +334,15 @@ struct tc_table {
   void* d_n_h = nullptr;
   void* d_percentile = nullptr;
   void* d_perm = nullptr;
+  // Groups of bins with the same quadrature nodes (hostmath.h: find_node_groups).  `grouped`:
+  // some group has more than one member and the option "grouped" is on -- the occupation
+  // kernels then evaluate every group's nodes once (kernels.hip.h: occ_group_zheng07).
+  tc::NodeGroups node_groups;
+  void* d_group_begin = nullptr;
+  void* d_group_member = nullptr;
+  void* d_group_n_h = nullptr;         // n_h and sec_haloprop_percentile in member order
+  void* d_group_percentile = nullptr;
+  bool grouped = false;
   void* d_math_table = nullptr;  // fastmath.h tables
   void* d_pos_ij = nullptr;      // float32 variant: packed bin pairs per position
   void* d_pos_off = nullptr;     // FP64 kernel: LDS row byte offsets per position
@@ -433,6 +447,8 @@ constexpr int64_t kMaxSlab = 1 << 18;
 
 // ---- launch layer (launch.hip) --------------------------------------------------------
 int get_quadrature(tc_table* t, int n_gauss, Quadrature** out);
+// The GroupArgs of a table's groups of bins (n_gauss = 10).
+tc::GroupArgs group_args(const tc_table* t, const Quadrature& q);
 int get_chunking(tc_table* t, int n_chunks, int waves, DeviceChunking** out);
 int lds_bytes_for(const Chunking& chunking, int rt, int elem = 8);
 int wave_slots(const tc_table* t, bool interp);

@@ -20,6 +20,18 @@ constexpr int kFinalizeRows = 32;   // (component, r) rows per LDS pass
 constexpr int kMaxInterpDim = 8;
 constexpr int kMaxInterpAxis = 32;
 
+// Constants of the GROUPED occupation kernels (kernels.hip.h: occ_group_zheng07): the nodes per
+// group, everything else per member in group order (launch.hip: get_quadrature).
+struct GroupArgs {
+  const int32_t* begin;      // (n_groups + 1) first member index of every group
+  const int32_t* member;     // (n_bins) library bin of every member index
+  const double* log_m;       // (n_groups, 10) log10 of the node masses
+  const double* m;           // (n_groups, 10) node masses
+  const double* weight;      // (n_bins, 10) weights in member order, then (n_bins) their sums
+  const double* n_h;         // (n_bins) in member order
+  const double* percentile;  // (n_bins) in member order
+};
+
 struct OccArgs {
   const double* theta;     // (n_draws, n_theta) row-major
   int n_theta;
@@ -43,6 +55,13 @@ struct OccArgs {
   float* nbuf32;           // optional float copy of it (float32 quadratic-form kernel)
   double* ngal;            // (bin splits, 2, ldb) partial cen / sat densities
   double* occupation;      // optional (n_draws, n_bins) in reference order
+  // Groups of bins with the same quadrature nodes (the secondary-percentile bins of one mass
+  // bin; table.cpp: find_node_groups): group i = bins group_member[group_begin[i] ..
+  // group_begin[i + 1]) in library order, the groups of centrals first.  Used by the GROUPED
+  // kernels only, which split the groups -- not the bins -- into n_splits ranges.
+  int n_groups;
+  int n_central_groups;
+  GroupArgs group;
 };
 
 // Un-batched predict(): one draw through one launch (single_draw_kernel).
@@ -250,6 +269,10 @@ struct FusedArgs {
   double* xi;                // (n_draws, n_r) or (n_draws, 3, n_r); NULL: the likelihood is fused
   const double* chi2_data;   // as FinalizeQuadArgs
   double* chi2;
+  // groups of bins with the same quadrature nodes (OccArgs; GROUPED instances only)
+  int n_groups;
+  int n_central_groups;
+  GroupArgs group;
 };
 
 struct FinalizeArgs {

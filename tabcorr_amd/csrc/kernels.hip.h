@@ -297,6 +297,215 @@ __device__ __forceinline__ double occ_bin_zheng07_halves(const double* table, co
   return acc;
 }
 
+// ---- bins that share their quadrature nodes ------------------------------------------------
+//
+// The secondary-percentile bins of one mass bin (tabcorr.py:186-205: the reference cuts every
+// log_prim_haloprop bin into sec_haloprop_percentile bins -- two in its AbacusSummit database,
+// scripts/tabulate_snapshot.py:193) have the same log_prim_haloprop_min / max and galaxy type,
+// hence the same ten nodes M_gk (tabcorr.py:548-549); only the weights W_gk (through
+// prim_haloprop_dist_index) and the side of the assembly-bias split differ.  The expensive part
+// of a node -- one erf, or one log2 + exp2 -- is therefore evaluated ONCE per group of such
+// bins (table.cpp finds the groups at upload) and every member accumulates it with its own
+// weights: per member and node one FMA (undecorated), or the four instructions of the
+// Heaviside decoration.  For every bin the instructions and their order are those of
+// occ_bin_zheng07: same bits.  n_gauss_prim = 10 (the default) only.
+//
+// Constants (launch.hip: get_quadrature): the nodes per GROUP (log_m, mass: [group][10]), the
+// weights, their sums, n_h and the percentile per MEMBER in group order ([member index][10],
+// ...), so that no address depends on a loaded bin index; member[mi] = the library bin of
+// member index mi (only the results' row needs it).  Members are processed in pairs: the
+// constants of both are in flight together and their two FMA chains interleave.
+//
+// emit(mi, g, acc): called once per member with its index, its bin g and its mean occupation.
+struct GroupConsts {
+  sc_f64 log_m, mass;          // (n_groups, 10)
+  sc_f64 weight, weight_sum;   // (n_bins, 10), (n_bins) in member order
+  sc_f64 percentile;           // (n_bins) in member order
+  sc_i32 member;               // (n_bins)
+};
+
+template <bool ASSEMBIAS, bool MODULATE, typename Emit>
+__device__ __forceinline__ void occ_group_zheng07(const double* table, const fm::Consts& kc,
+                                                  int group, int m_begin, int m_end,
+                                                  bool central, const GroupConsts& q,
+                                                  double split, const DrawParams& d,
+                                                  Emit&& emit) {
+  constexpr int kNodes = 10;
+  constexpr bool assembias = ASSEMBIAS;
+  constexpr bool modulate = MODULATE;
+  const double log_m_min = d.log_m_min, inv_sigma = d.inv_sigma, m0 = d.m0;
+  const double log2_m1 = d.log2_m1, sat_scale = d.sat_scale, alpha = d.alpha;
+  const int bad = d.bad;
+  const bool any_bad = d.any_bad;
+  // (the split at the median, f1 = f2 = 1: the only one the device path is given,
+  // models.device_spec -- the decoration is n + s min(n, 1 - n) resp. n (1 + s))
+  constexpr bool median = assembias;
+  sc_f64 log_m = q.log_m + group * kNodes, mass = q.mass + group * kNodes;
+  int shortcut = 0;                    // as occ_bin_zheng07: 1 all ones, 2 all zeros
+#ifndef TC_NO_OCC_SHORTCUTS
+  if (!assembias && !any_bad) {
+    if (central) {
+      const double z_a = (log_m[0] - log_m_min) * inv_sigma;
+      const double z_b = (log_m[kNodes - 1] - log_m_min) * inv_sigma;
+      const double z_lo = z_a < z_b ? z_a : z_b, z_hi = z_a < z_b ? z_b : z_a;
+      if (__builtin_amdgcn_ballot_w64(!(z_lo >= 6.0)) == 0) shortcut = 1;
+      else if (__builtin_amdgcn_ballot_w64(!(z_hi <= -6.0)) == 0) shortcut = 2;
+    } else {
+      const double m_a = mass[0], m_b = mass[kNodes - 1];
+      if (__builtin_amdgcn_ballot_w64((m_a > m_b ? m_a : m_b) > m0) == 0) shortcut = 2;
+    }
+  }
+#endif
+  // v[k]: centrals erf(z_k) (decorated: <N_cen> itself), satellites <N_sat> before the scale
+  double v[kNodes];
+  if (shortcut == 0) {
+    if (central) {
+#pragma unroll
+      for (int k = 0; k < kNodes; ++k) {
+        const double e = fm::erf_fast(table, kc, (log_m[k] - log_m_min) * inv_sigma);
+        v[k] = assembias ? fma(0.5, e, 0.5) : e;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kNodes; ++k) {
+        const double x = mass[k] - m0;
+        double n = fm::exp2_fast(
+            table, kc,
+            alpha * fm::log2_fast_offset(table, kc, x > 1e-300 ? x : 1e-300, log2_m1),
+            x > 0.0);
+        if (modulate)
+          n *= fma(0.5, fm::erf_fast(table, kc, (log_m[k] - log_m_min) * inv_sigma), 0.5);
+        v[k] = n;
+      }
+    }
+  }
+  bool tie = false;
+  if (any_bad && (bad & kTieCen) && (central || modulate))
+    for (int k = 0; k < kNodes; ++k) tie = tie || log_m[k] == log_m_min;
+  // one member's sum over the nodes, from its weights on (the arithmetic of occ_bin_zheng07)
+  auto member_sum = [&](int mi) {
+    sc_f64 weight = q.weight + mi * kNodes;
+    const bool above = assembias ? q.percentile[mi] > split : false;
+    const double s_cen = above ? d.a_cen : -d.a_cen, s_sat = above ? d.a_sat : -d.a_sat;
+    double acc = 0.0;
+    if (shortcut != 0) {
+      if (shortcut == 1) acc = q.weight_sum[mi];
+    } else if (central && !assembias) {
+#pragma unroll
+      for (int k = 0; k < kNodes; ++k) acc = fma(weight[k], v[k], acc);
+      acc = fma(0.5, acc, 0.5 * q.weight_sum[mi]);
+    } else if (central) {
+#pragma unroll
+      for (int k = 0; k < kNodes; ++k)
+        acc = fma(weight[k], fma(s_cen, fmin(v[k], 1.0 - v[k]), v[k]), acc);
+    } else {
+#pragma unroll
+      for (int k = 0; k < kNodes; ++k) acc = fma(weight[k], v[k], acc);
+      acc *= sat_scale;
+      if (median) acc = fma(s_sat, acc, acc);
+    }
+    if (any_bad) {
+      const bool cen_nan = (bad & kBadCen) || tie;
+      if (!central && (bad & kInfSat) && acc != 0.0)
+        acc = assembias ? __builtin_nan("") : __builtin_huge_val();
+      if (central ? cen_nan : (((bad & kBadSat) && acc != 0.0) || (modulate && cen_nan)))
+        acc = __builtin_nan("");
+    }
+    return acc;
+  };
+  for (int mi = m_begin; mi < m_end; mi += 2) {
+    const int mj = mi + 1 < m_end ? mi + 1 : mi;       // (clamped: a single member twice)
+    const double acc_i = member_sum(mi), acc_j = member_sum(mj);
+    emit(mi, q.member[mi], acc_i);
+    if (mj != mi) emit(mj, q.member[mj], acc_j);
+  }
+}
+
+// The same for the 32-draw workgroups (lane = (draw, half of the nodes), occ_bin_zheng07_halves):
+// five node values per lane, every member's weights by vector loads -- those of a pair of
+// members requested BEFORE the nodes are evaluated, so that they arrive under that arithmetic
+// --, the halves added through one lane exchange per member.
+template <bool ASSEMBIAS, bool MODULATE, typename Emit>
+__device__ __forceinline__ void occ_group_zheng07_halves(
+    const double* table, const fm::Consts& kc, int group, int m_begin, int m_end, bool central,
+    int half, const double* log_m_v, const double* mass_v, const double* weight_v,
+    const GroupConsts& q, double split, const DrawParams& d, Emit&& emit) {
+  constexpr int kNodes = 10, kHalf = 5;
+  const double* lm_p = log_m_v + group * kNodes + half * kHalf;
+  const double* m_p = mass_v + group * kNodes + half * kHalf;
+  double v[kHalf];
+  bool tie = false;
+  if (d.any_bad && (d.bad & kTieCen) && (central || MODULATE))
+    for (int k = 0; k < kNodes; ++k) tie = tie || q.log_m[group * kNodes + k] == d.log_m_min;
+  auto finish = [&](int mi, double acc) {
+    const bool above = ASSEMBIAS ? q.percentile[mi] > split : false;
+    const double s_sat = above ? d.a_sat : -d.a_sat;
+    acc += __shfl_xor(acc, 32, 64);            // both halves hold the bin's sum
+    if (!central) acc *= d.sat_scale;
+    else if (!ASSEMBIAS) acc = fma(0.5, acc, 0.5 * q.weight_sum[mi]);
+    if (!central && ASSEMBIAS) acc = fma(s_sat, acc, acc);
+    if (d.any_bad) {
+      const int bad = d.bad;
+      const bool cen_nan = (bad & kBadCen) || tie;
+      if (!central && (bad & kInfSat) && acc != 0.0)
+        acc = ASSEMBIAS ? __builtin_nan("") : __builtin_huge_val();
+      if (central ? cen_nan : (((bad & kBadSat) && acc != 0.0) || (MODULATE && cen_nan)))
+        acc = __builtin_nan("");
+    }
+    return acc;
+  };
+  for (int mi = m_begin; mi < m_end; mi += 2) {
+    const int mj = mi + 1 < m_end ? mi + 1 : mi;
+    double w_i[kHalf], w_j[kHalf];
+#pragma unroll
+    for (int k = 0; k < kHalf; ++k) {
+      w_i[k] = weight_v[mi * kNodes + half * kHalf + k];
+      w_j[k] = weight_v[mj * kNodes + half * kHalf + k];
+    }
+    if (mi == m_begin) {
+      if (central) {
+#pragma unroll
+        for (int k = 0; k < kHalf; ++k) {
+          const double e = fm::erf_fast(table, kc, (lm_p[k] - d.log_m_min) * d.inv_sigma);
+          v[k] = ASSEMBIAS ? fma(0.5, e, 0.5) : e;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < kHalf; ++k) {
+          const double x = m_p[k] - d.m0;
+          double n = fm::exp2_fast(
+              table, kc,
+              d.alpha * fm::log2_fast_offset(table, kc, x > 1e-300 ? x : 1e-300, d.log2_m1),
+              x > 0.0);
+          if (MODULATE)
+            n *= fma(0.5, fm::erf_fast(table, kc, (lm_p[k] - d.log_m_min) * d.inv_sigma), 0.5);
+          v[k] = n;
+        }
+      }
+    }
+    double acc_i = 0.0, acc_j = 0.0;
+    if (central && ASSEMBIAS) {
+      const double s_i = q.percentile[mi] > split ? d.a_cen : -d.a_cen;
+      const double s_j = q.percentile[mj] > split ? d.a_cen : -d.a_cen;
+#pragma unroll
+      for (int k = 0; k < kHalf; ++k) {
+        const double low = fmin(v[k], 1.0 - v[k]);
+        acc_i = fma(w_i[k], fma(s_i, low, v[k]), acc_i);
+        acc_j = fma(w_j[k], fma(s_j, low, v[k]), acc_j);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kHalf; ++k) {
+        acc_i = fma(w_i[k], v[k], acc_i);
+        acc_j = fma(w_j[k], v[k], acc_j);
+      }
+    }
+    acc_i = finish(mi, acc_i);
+    emit(mi, q.member[mi], acc_i);
+    if (mj != mi) emit(mj, q.member[mj], finish(mj, acc_j));
+  }
+}
+
 // Mean occupation of every bin for every draw: tabcorr/tabcorr.py:537-578 with
 // the two halotools callbacks of :556-563 evaluated inline (Zheng et al. 2007
 // eqs. 1 and 3).  Work items = (draw tile, bin split); the kOccWaves waves of a
@@ -307,9 +516,12 @@ __device__ __forceinline__ double occ_bin_zheng07_halves(const double* table, co
 // NGAUSS > 0: n_gauss known at compile time, node loop fully unrolled (the scalar loads
 // of a bin's constants are batched and the independent polynomial chains interleave);
 // NGAUSS == 0: any n_gauss.
-template <int NGAUSS, bool ASSEMBIAS, bool MODULATE>
+// GROUPED (NGAUSS == 10): the work items are ranges of GROUPS of bins that share their nodes
+// (occ_group_zheng07); a.n_groups / a.n_central_groups take the place of the bin counts.
+template <int NGAUSS, bool ASSEMBIAS, bool MODULATE, bool GROUPED = false>
 __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     OccArgs a) {
+  static_assert(!GROUPED || NGAUSS == 10, "groups of bins: ten nodes per bin");
   __shared__ double red[2][kOccWaves][kLanes];
   __shared__ double prm[9][kLanes];
   __shared__ __attribute__((aligned(16))) double table[fm::kTableDoubles];
@@ -321,13 +533,16 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_gauss = NGAUSS > 0 ? NGAUSS : a.n_gauss;
   const int n_items = a.n_tiles * a.n_splits;
-  const int per_block = (a.n_bins + a.n_splits - 1) / a.n_splits;
+  // (ranges of bins, or of groups of bins)
+  const int n_units = GROUPED ? a.n_groups : a.n_bins;
+  const int n_central_units = GROUPED ? a.n_central_groups : a.n_central;
+  const int per_block = (n_units + a.n_splits - 1) / a.n_splits;
   {
     typedef double __attribute__((ext_vector_type(2))) double2v;
     // a block with a single all-satellites item does not need the erf rows (the exp2
     // table is always needed: 10^logM0)
     const bool need_erf = (int)gridDim.x < n_items || MODULATE ||
-                          ((int)blockIdx.x / a.n_tiles) * per_block < a.n_central;
+                          ((int)blockIdx.x / a.n_tiles) * per_block < n_central_units;
     const int lo = need_erf ? 0 : fm::kLogOffset / 2;
     const int hi = fm::kTableDoubles / 2;
     const double2v* src = (const double2v*)a.math_table;
@@ -362,7 +577,7 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     const int64_t b0 = (int64_t)tile * kLanes + lane;
     const int64_t b = b0 < a.n_draws ? b0 : a.n_draws - 1;
     const int g_begin = split * per_block;
-    const int g_end = g_begin + per_block < a.n_bins ? g_begin + per_block : a.n_bins;
+    const int g_end = g_begin + per_block < n_units ? g_begin + per_block : n_units;
     // per-draw quantities: computed by wave 0, shared with the other waves through LDS
     if (wave == 0) {
       const double* th = a.theta + b * a.n_theta;
@@ -393,18 +608,35 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
 
     double sum_cen = 0.0, sum_sat = 0.0;
-    for (int g = g_begin + wave; g < g_end; g += kOccWaves) {
-      const bool central = g < a.n_central;
-      const bool above = percentile[g] > a.split;
-      const double acc = occ_bin_zheng07<NGAUSS, ASSEMBIAS, MODULATE>(
-          table, kc, g, n_gauss, central, above, log_m, mass, weight, weight_sum, dp, f1, f2);
+    auto emit = [&](int g, bool central, double acc, double n_h_g) {
       if (a.occupation != nullptr && b0 < a.n_draws)
         a.occupation[b0 * a.n_bins + perm[g]] = acc;
-      const double dens = acc * n_h[g];
+      const double dens = acc * n_h_g;
       a.nbuf[(int64_t)g * a.ldb + (int64_t)tile * kLanes + lane] = dens;
       if (a.nbuf32 != nullptr)
         a.nbuf32[(int64_t)g * a.ldb + (int64_t)tile * kLanes + lane] = (float)dens;
       if (central) sum_cen += dens; else sum_sat += dens;
+    };
+    for (int g = g_begin + wave; g < g_end; g += kOccWaves) {
+      if (GROUPED) {
+        sc_i32 group_begin = (sc_i32)a.group.begin;
+        sc_f64 n_h_m = (sc_f64)a.group.n_h;
+        const GroupConsts gq{(sc_f64)a.group.log_m, (sc_f64)a.group.m, (sc_f64)a.group.weight,
+                             (sc_f64)a.group.weight + a.n_bins * 10,
+                             (sc_f64)a.group.percentile, (sc_i32)a.group.member};
+        const bool central = g < a.n_central_groups;
+        occ_group_zheng07<ASSEMBIAS, MODULATE>(
+            table, kc, g, group_begin[g], group_begin[g + 1], central, gq, a.split, dp,
+            [&](int mi, int bin, double acc) { emit(bin, central, acc, n_h_m[mi]); });
+      } else {
+        const bool central = g < a.n_central;
+        const bool above = percentile[g] > a.split;
+        emit(g, central,
+             occ_bin_zheng07<NGAUSS, ASSEMBIAS, MODULATE>(table, kc, g, n_gauss, central, above,
+                                                          log_m, mass, weight, weight_sum, dp,
+                                                          f1, f2),
+             n_h[g]);
+      }
     }
     red[0][wave][lane] = sum_cen;
     red[1][wave][lane] = sum_sat;
@@ -1609,8 +1841,10 @@ __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, uns
 }
 
 template <int NGAUSS, int U, bool ASSEMBIAS, bool MODULATE, bool LEAUTHAUD = false,
-          int W = kFusedWaves, int DL = 64>
+          int W = kFusedWaves, int DL = 64, bool GROUPED = false>
 __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(FusedArgs a) {
+  // GROUPED: the waves stride over the groups of bins that share their nodes (occ_group_zheng07)
+  static_assert(!GROUPED || (NGAUSS == 10 && !LEAUTHAUD), "groups of bins: Zheng07, ten nodes");
   // DL = draws per workgroup: 64 (two 32-draw tiles, W = 8 or 16 waves), or 32 (ONE tile, eight
   // waves = eight parts of the units, lanes = (draw, half of a bin's nodes) in the occupation
   // phase, occ_bin_zheng07_halves; two workgroups of up to 80 KB per CU): a quarter of the
@@ -1682,7 +1916,30 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
     sc_f64 percentile = (sc_f64)a.percentile;
     const double f1 = (1.0 - a.split) / a.split, f2 = a.split / (1.0 - a.split);
     double sum_cen = 0.0, sum_sat = 0.0;
-    for (int g = wave; g < a.n_bins; g += W) {
+    if (GROUPED) {
+      sc_i32 group_begin = (sc_i32)a.group.begin;
+      sc_f64 n_h_m = (sc_f64)a.group.n_h;
+      const GroupConsts gq{(sc_f64)a.group.log_m, (sc_f64)a.group.m, (sc_f64)a.group.weight,
+                           (sc_f64)a.group.weight + a.n_bins * 10, (sc_f64)a.group.percentile,
+                           (sc_i32)a.group.member};
+      for (int gr = wave; gr < a.n_groups; gr += W) {
+        const bool central = gr < a.n_central_groups;
+        auto emit = [&](int mi, int g, double acc) {
+          const double value = acc * n_h_m[mi];
+          if (half == 0) dens[g * DL + draw] = value;
+          if (central) sum_cen += value; else sum_sat += value;
+        };
+        if (DL == 32)
+          occ_group_zheng07_halves<ASSEMBIAS, MODULATE>(
+              table, kc, gr, group_begin[gr], group_begin[gr + 1], central, half, a.group.log_m,
+              a.group.m, a.group.weight, gq, a.split, dp, emit);
+        else
+          occ_group_zheng07<ASSEMBIAS, MODULATE>(table, kc, gr, group_begin[gr],
+                                                 group_begin[gr + 1], central, gq, a.split, dp,
+                                                 emit);
+      }
+    }
+    for (int g = wave; g < (GROUPED ? 0 : a.n_bins); g += W) {
       const bool central = g < a.n_central;
       const bool above = ASSEMBIAS ? percentile[g] > a.split : false;
       const double acc =

@@ -48,10 +48,45 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
   int status = upload(log_m, &q.log_m);
   if (status == TC_OK) status = upload(m, &q.m);
   if (status == TC_OK) status = upload(weight, &q.weight);
+  if (status == TC_OK && n_gauss == 10 && t->node_groups.largest > 1) {
+    // GROUPED kernels: the nodes of every group (= those of its first member), the weights and
+    // their sums per member in group order
+    const tc::NodeGroups& groups = t->node_groups;
+    std::vector<double> g_log_m((size_t)groups.n_groups * n_gauss),
+        g_m((size_t)groups.n_groups * n_gauss), g_weight((size_t)g * n_gauss + g);
+    for (int i = 0; i < groups.n_groups; ++i) {
+      const int first = groups.member[groups.begin[i]];
+      for (int k = 0; k < n_gauss; ++k) {
+        g_log_m[(size_t)i * n_gauss + k] = log_m[(size_t)first * n_gauss + k];
+        g_m[(size_t)i * n_gauss + k] = m[(size_t)first * n_gauss + k];
+      }
+    }
+    for (int mi = 0; mi < g; ++mi) {
+      const int bin = groups.member[mi];
+      for (int k = 0; k < n_gauss; ++k)
+        g_weight[(size_t)mi * n_gauss + k] = weight[(size_t)bin * n_gauss + k];
+      g_weight[(size_t)g * n_gauss + mi] = weight[(size_t)g * n_gauss + bin];
+    }
+    status = upload(g_log_m, &q.group_log_m);
+    if (status == TC_OK) status = upload(g_m, &q.group_m);
+    if (status == TC_OK) status = upload(g_weight, &q.group_weight);
+  }
   if (status != TC_OK) return status;
   t->quadrature[n_gauss] = q;
   *out = &t->quadrature[n_gauss];
   return TC_OK;
+}
+
+tc::GroupArgs group_args(const tc_table* t, const Quadrature& q) {
+  tc::GroupArgs ga{};
+  ga.begin = (const int32_t*)t->d_group_begin;
+  ga.member = (const int32_t*)t->d_group_member;
+  ga.log_m = (const double*)q.group_log_m;
+  ga.m = (const double*)q.group_m;
+  ga.weight = (const double*)q.group_weight;
+  ga.n_h = (const double*)t->d_group_n_h;
+  ga.percentile = (const double*)t->d_group_percentile;
+  return ga;
 }
 
 int get_chunking(tc_table* t, int n_chunks, int waves, DeviceChunking** out) {
@@ -787,15 +822,19 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   // with 2 ranges, 43.4 with 5, 45.0 with 13, 44.6 with 1); small batches (latency, not
   // throughput) minimise rounds x (bins per wave per item + per-item overhead).
   const int64_t n_tiles = ldb / 64;
+  // groups of bins that share their nodes (Zheng07 family, default n_gauss_prim): the work
+  // items are ranges of groups
+  const bool grouped = t->grouped && n_gauss == 10 && !(flags & TC_FLAG_LEAUTHAUD11);
+  const int n_units = grouped ? t->node_groups.n_groups : t->n_bins;
   int splits = 1, grid_blocks = 1;
   {
     const int n_cus = t->n_cus;
     const int64_t slots = (int64_t)n_cus * 4;
-    const int max_splits = (t->n_bins + tc::kOccWaves - 1) / tc::kOccWaves;
+    const int max_splits = (n_units + tc::kOccWaves - 1) / tc::kOccWaves;
     double best = 0.0;
     for (int trial = 1; trial <= max_splits; ++trial) {
-      const int per_block = (t->n_bins + trial - 1) / trial;
-      if ((t->n_bins + per_block - 1) / per_block != trial) continue;
+      const int per_block = (n_units + trial - 1) / trial;
+      if ((n_units + per_block - 1) / per_block != trial) continue;
       const int64_t items = n_tiles * trial;
       if (n_tiles >= 64) {
         // pipelined calls: throughput, the fewest ranges that give every CU an item; calls
@@ -819,8 +858,8 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
     }
     const int forced = t->tuning.occ_splits;
     if (forced > 0) {
-      const int per_block = (t->n_bins + forced - 1) / forced;
-      splits = (t->n_bins + per_block - 1) / per_block;
+      const int per_block = (n_units + forced - 1) / forced;
+      splits = (n_units + per_block - 1) / per_block;
       grid_blocks = (int)std::min<int64_t>(
           n_tiles * splits, (int64_t)n_cus * std::max(1, t->tuning.occ_per_cu));
     }
@@ -862,6 +901,9 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   oa.nbuf32 = want_f32 ? (float*)nbuf32->ptr : nullptr;
   oa.ngal = (double*)ngal2->ptr;
   oa.occupation = occupation_device;
+  oa.n_groups = t->node_groups.n_groups;
+  oa.n_central_groups = t->node_groups.n_central_groups;
+  oa.group = group_args(t, *q);
   {
     const dim3 grid((unsigned)grid_blocks), block(tc::kOccWaves * 64);
     const bool assembias = (flags & TC_FLAG_ASSEMBIAS) != 0;
@@ -876,6 +918,14 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
         hipLaunchKernelGGL(tc::occ_leauthaud11_kernel<true>, grid, block, 0, stream, oa);
       else
         hipLaunchKernelGGL(tc::occ_leauthaud11_kernel<false>, grid, block, 0, stream, oa);
+    } else if (grouped) {
+#define TC_OCC_GROUPED(AB, MO)                                                        \
+  hipLaunchKernelGGL((tc::occ_zheng07_kernel<10, AB, MO, true>), grid, block, 0, stream, oa)
+      if (!assembias && !modulate) TC_OCC_GROUPED(false, false);
+      else if (!assembias) TC_OCC_GROUPED(false, true);
+      else if (!modulate) TC_OCC_GROUPED(true, false);
+      else TC_OCC_GROUPED(true, true);
+#undef TC_OCC_GROUPED
     } else if (n_gauss == 10) {
       if (!assembias && !modulate) TC_OCC(10, false, false);
       else if (!assembias) TC_OCC(10, false, true);
@@ -1037,7 +1087,8 @@ int fused_waves(const tc_table* t, bool separate) {
 }
 
 namespace {
-template <int NG, bool AB, bool MO, bool LE = false, int W = tc::kFusedWaves, int DL = 64>
+template <int NG, bool AB, bool MO, bool LE = false, int W = tc::kFusedWaves, int DL = 64,
+          bool GR = false>
 int launch_fused(int device, int n_u, dim3 grid, dim3 block, int lds, hipStream_t stream,
                  hipEvent_t k0, hipEvent_t k1, const tc::FusedArgs& fa) {
   switch (n_u) {
@@ -1047,12 +1098,12 @@ int launch_fused(int device, int n_u, dim3 grid, dim3 block, int lds, hipStream_
     static bool limit_set[64] = {};                                                           \
     if (lds > 64 * 1024 && !(device >= 0 && device < 64 && limit_set[device])) {              \
       TC_HIP(hipFuncSetAttribute(                                                             \
-          (const void*)tc::predict_fused_kernel<NG, N, AB, MO, LE, W, DL>,                    \
+          (const void*)tc::predict_fused_kernel<NG, N, AB, MO, LE, W, DL, GR>,                \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));    \
       if (device >= 0 && device < 64) limit_set[device] = true;                               \
     }                                                                                         \
-    hipExtLaunchKernelGGL((tc::predict_fused_kernel<NG, N, AB, MO, LE, W, DL>), grid, block,  \
-                          lds, stream, k0, k1, 0, fa);                                        \
+    hipExtLaunchKernelGGL((tc::predict_fused_kernel<NG, N, AB, MO, LE, W, DL, GR>), grid,     \
+                          block, lds, stream, k0, k1, 0, fa);                                 \
     break;                                                                                    \
   }
     TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4) TC_CASE(5)
@@ -1131,6 +1182,9 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   fa.priority = (t->tuning.prio_fused & 3) | ((t->tuning.prio_fused_occ & 3) << 2) |
                 ((t->tuning.prio_fused_out & 3) << 4);
   fa.n_draws = n_draws;
+  fa.n_groups = t->node_groups.n_groups;
+  fa.n_central_groups = t->node_groups.n_central_groups;
+  fa.group = group_args(t, *q);
   fa.log_m = (const double*)q->log_m;
   fa.m = (const double*)q->m;
   fa.weight = (const double*)q->weight;
@@ -1165,7 +1219,22 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
 #define TC_FUSED32(AB, MO)                                                                    \
   launch_fused<10, AB, MO, false, 8, 32>(t->device, t->quad_tiling.n_u, grid, block, lds,      \
                                          stream, k0, k1, fa)
-  if ((wide || half_tiles) && (flags & TC_FLAG_LEAUTHAUD11))
+  // bins that share their nodes (Zheng07 family, ten nodes): the GROUPED instances
+  const bool grouped = t->grouped && n_gauss == 10 && !(flags & TC_FLAG_LEAUTHAUD11);
+#define TC_FUSED_GROUPED(AB, MO)                                                              \
+  (wide || half_tiles                                                                         \
+       ? launch_fused<10, AB, MO, false, 8, 32, true>(t->device, t->quad_tiling.n_u, grid,    \
+                                                      block, lds, stream, k0, k1, fa)         \
+   : waves == 16                                                                              \
+       ? launch_fused<10, AB, MO, false, 16, 64, true>(t->device, t->quad_tiling.n_u, grid,   \
+                                                       block, lds, stream, k0, k1, fa)        \
+       : launch_fused<10, AB, MO, false, 8, 64, true>(t->device, t->quad_tiling.n_u, grid,    \
+                                                      block, lds, stream, k0, k1, fa))
+  if (grouped)
+    status = assembias ? (modulate ? TC_FUSED_GROUPED(true, true) : TC_FUSED_GROUPED(true, false))
+                       : (modulate ? TC_FUSED_GROUPED(false, true)
+                                   : TC_FUSED_GROUPED(false, false));
+  else if ((wide || half_tiles) && (flags & TC_FLAG_LEAUTHAUD11))
     status = modulate ? launch_fused<0, false, true, true, 8, 32>(
                             t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa)
                       : launch_fused<0, false, false, true, 8, 32>(
@@ -1187,6 +1256,7 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
     status = TC_FUSED(10, true, true, false);
 #undef TC_FUSED
 #undef TC_FUSED32
+#undef TC_FUSED_GROUPED
   if (status != TC_OK) return status;
   t->last_workgroups = (int)grid.x;
   t->last_waves = waves;

@@ -277,6 +277,21 @@ int tc_spline_interpolation_matrix(int n, const double* xp, double* a) {
   return TC_OK;
 }
 
+int tc_debug_node_groups(int n_bins, int n_central, const double* log_min,
+                         const double* log_max, int32_t* begin, int32_t* member,
+                         int* n_groups, int* n_central_groups) {
+  TC_CHECK(n_bins >= 1 && n_central >= 0 && n_central <= n_bins, "invalid bin counts");
+  TC_CHECK(log_min && log_max && begin && member && n_groups && n_central_groups,
+           "NULL argument");
+  tc::NodeGroups groups;
+  tc::find_node_groups(n_bins, n_central, log_min, log_max, groups);
+  std::copy(groups.begin.begin(), groups.begin.end(), begin);
+  std::copy(groups.member.begin(), groups.member.end(), member);
+  *n_groups = groups.n_groups;
+  *n_central_groups = groups.n_central_groups;
+  return TC_OK;
+}
+
 int tc_plan_debug(int mode, int n_bins, const uint8_t* is_central, int n_chunks,
                   int64_t* n_entries, int32_t* entry_pair, int32_t* entry_chunk,
                   int32_t* entry_class) {

@@ -159,6 +159,20 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
   if (status == TC_OK) status = upload(t->n_h, &t->d_n_h);
   if (status == TC_OK) status = upload(t->percentile, &t->d_percentile);
   if (status == TC_OK) status = upload(t->plan.perm, &t->d_perm);
+  tc::find_node_groups(n_bins, t->plan.n_central, t->log_min.data(), t->log_max.data(),
+                       t->node_groups);
+  t->grouped = t->node_groups.largest > 1;
+  if (status == TC_OK) status = upload(t->node_groups.begin, &t->d_group_begin);
+  if (status == TC_OK) status = upload(t->node_groups.member, &t->d_group_member);
+  {
+    std::vector<double> n_h_m, percentile_m;
+    for (int32_t g : t->node_groups.member) {
+      n_h_m.push_back(t->n_h[g]);
+      percentile_m.push_back(t->percentile[g]);
+    }
+    if (status == TC_OK) status = upload(n_h_m, &t->d_group_n_h);
+    if (status == TC_OK) status = upload(percentile_m, &t->d_group_percentile);
+  }
   if (status == TC_OK) {
     std::vector<double> math_table(tc::fm::kTableDoubles);
     tc::fm::build_tables(math_table.data());
@@ -208,10 +222,12 @@ int tc_table_destroy(tc_table* t) {
   for (tc_table::Lane& lane : t->lanes)
     if (lane.stream) (void)hipStreamSynchronize(lane.stream);
   for (void* p : {t->d_table, t->d_n_h, t->d_percentile, t->d_perm, t->d_math_table,
-                  t->d_pos_ij, t->d_pos_off})
+                  t->d_pos_ij, t->d_pos_off, t->d_group_begin, t->d_group_member,
+                  t->d_group_n_h, t->d_group_percentile})
     if (p) (void)hipFree(p);
   for (auto& kv : t->quadrature)
-    for (void* p : {kv.second.log_m, kv.second.m, kv.second.weight})
+    for (void* p : {kv.second.log_m, kv.second.m, kv.second.weight, kv.second.group_log_m,
+                    kv.second.group_m, kv.second.group_weight})
       if (p) (void)hipFree(p);
   for (auto& kv : t->chunkings)
     for (void* p : {kv.second->chunks, kv.second->groups})
@@ -802,9 +818,18 @@ int tc_predict_occupation_batch(tc_table* t, const double* occupation,
 
 int tc_table_set_option(tc_table* t, const char* name, int value) {
   TC_CHECK(t != nullptr && name != nullptr, "NULL argument");
+  // (streams and events created below, and the resident kernel stopped, belong to the table's
+  // device whatever device is current in the calling thread)
+  TC_HIP(hipSetDevice(t->device));
   const std::string key(name);
   if (key == "pipeline") {
     t->tuning.pipeline = value != 0;
+  } else if (key == "grouped") {
+    // 1 (default): bins that share their quadrature nodes -- the secondary-percentile bins of a
+    // mass bin -- have the nodes' occupations evaluated once per group (kernels.hip.h:
+    // occ_group_zheng07); 0: every bin by itself (A/B and tests: rounding-level differences
+    // only in the sums over bins, none per bin)
+    t->grouped = value != 0 && t->node_groups.largest > 1;
   } else if (key == "lanes") {
     TC_CHECK(value >= 1 && value <= (int)tc_table::kMaxLanes, "lanes must be in [1, %d]",
              (int)tc_table::kMaxLanes);

@@ -538,7 +538,7 @@ def test_read_reference_interpolator_file_and_round_trip(tmp_path):
     _need_hdf5()
     from tabcorr_amd import Interpolator, TabCorr
     from util import GOLDEN
-    interp = Interpolator.read(os.path.join(GOLDEN, 'ds_efficient.hdf5'))
+    interp = Interpolator.read(os.path.join(REPO, 'tests', 'golden', 'ds_efficient.hdf5'))
     data = load_golden('ds_efficient')
     assert interp.keys == ['log_eta']
     assert np.array_equal(interp.points, data['points'])
@@ -894,3 +894,75 @@ def test_triangle_parts_of_the_one_launch_kernel():
                 assert rb0[part] * (rb0[part] + 1) // 2 + cb0[part] == position
                 position += count[part]
             assert position == n_units
+
+
+def test_node_groups_of_bins_that_share_their_quadrature_nodes():
+    """hostmath.h: find_node_groups -- the secondary-percentile bins of a mass bin
+    (tabcorr/tabcorr.py:186-205: same log_prim_haloprop_min / max, same galaxy type) form one
+    group; every bin is in exactly one group, members ascending, groups ordered by their first
+    member, the groups of centrals first; the real AbacusSummit fixture of the reference
+    (cross, 1104 bins = 280 mass bins x 2 percentile bins x 2 types minus empty bins)."""
+    import ctypes
+    from tabcorr_amd import _lib, Interpolator
+    lib = _lib.load()
+
+    def groups_of(log_min, log_max, n_central):
+        n = len(log_min)
+        begin = np.zeros(n + 1, dtype=np.int32)
+        member = np.zeros(n, dtype=np.int32)
+        n_groups, n_cen = ctypes.c_int(), ctypes.c_int()
+        _lib.check(lib.tc_debug_node_groups(
+            n, n_central, _lib.as_double_p(np.ascontiguousarray(log_min, dtype=float)),
+            _lib.as_double_p(np.ascontiguousarray(log_max, dtype=float)),
+            begin.ctypes.data_as(_lib.c_int32_p), member.ctypes.data_as(_lib.c_int32_p),
+            ctypes.byref(n_groups), ctypes.byref(n_cen)))
+        begin = begin[:n_groups.value + 1]
+        return [list(member[a:b]) for a, b in zip(begin[:-1], begin[1:])], n_cen.value
+
+    def check(log_min, log_max, n_central):
+        groups, n_cen = groups_of(log_min, log_max, n_central)
+        assert sorted(g for group in groups for g in group) == list(range(len(log_min)))
+        firsts = [group[0] for group in groups]
+        assert firsts == sorted(firsts)
+        assert all(group == sorted(group) for group in groups)
+        assert all((group[0] < n_central) == (i < n_cen) for i, group in enumerate(groups))
+        for group in groups:
+            for g in group:
+                assert (g < n_central) == (group[0] < n_central)
+                assert log_min[g] == log_min[group[0]] and log_max[g] == log_max[group[0]]
+        keys = {(g < n_central, log_min[g], log_max[g]) for g in range(len(log_min))}
+        assert len(groups) == len(keys)
+        return groups, n_cen
+
+    # no secondary bins: every bin alone
+    edges = np.linspace(10.5, 15.0, 13)
+    lo, hi = np.tile(edges[:-1], 2), np.tile(edges[1:], 2)
+    groups, n_cen = check(lo, hi, 12)
+    assert [len(g) for g in groups] == [1] * 24 and n_cen == 12
+    # three percentile bins per mass bin, secondary index slowest (the reference's row order)
+    lo, hi = np.tile(edges[:-1], 6), np.tile(edges[1:], 6)
+    groups, n_cen = check(lo, hi, 36)
+    assert len(groups) == 24 and n_cen == 12
+    assert groups[0] == [0, 12, 24] and groups[12] == [36, 48, 60]
+    # only centrals / only satellites; a NaN edge stays alone
+    assert check(lo[:36], hi[:36], 36)[1] == 12
+    assert check(lo[:36], hi[:36], 0)[1] == 0
+    bad = lo.copy()
+    bad[[0, 12]] = np.nan
+    groups, _ = groups_of(bad, hi, 36)
+    assert [0] in groups and [12] in groups and len(groups) == 26
+    # shuffled rows, ragged groups
+    rng = np.random.default_rng(3)
+    keep = np.sort(rng.permutation(72)[:55])
+    cen = keep < 36
+    order = np.concatenate([rng.permutation(keep[cen]), rng.permutation(keep[~cen])])
+    check(lo[order], hi[order], int(np.sum(cen)))
+    # the reference's AbacusSummit table
+    table = Interpolator.read(os.path.join(REPO, 'tests', 'golden', 'ds_efficient.hdf5')).tabcorr_list[0]
+    gal_type = table.gal_type
+    central = np.asarray(gal_type['gal_type']) == 'centrals'
+    order = np.concatenate([np.flatnonzero(central), np.flatnonzero(~central)])
+    lo = np.asarray(gal_type['log_prim_haloprop_min'])[order]
+    hi = np.asarray(gal_type['log_prim_haloprop_max'])[order]
+    groups, n_cen = check(lo, hi, int(np.sum(central)))
+    assert len(lo) == 1104 and len(groups) == 560 and max(len(g) for g in groups) == 2
