@@ -207,6 +207,22 @@ struct QuadTable {
   void drop_schedules();
 };
 
+// Coefficients of predict_cross_fused_kernel (mode cross, one launch per batch) for one table
+// or for the K tables of an interpolator: per member bin (group order of the first table) the
+// rows T_k[r][g] n_h,k[g] and n_h,k[g]; built at the first call that may use them.
+struct CrossFused {
+  bool tried = false;
+  int rows = 0;              // ROWS of the kernel instance; 0: not available for this handle
+  int n_tables = 0;
+  void* d_rows = nullptr;
+  void release() {
+    if (d_rows != nullptr) (void)hipFree(d_rows);
+    d_rows = nullptr;
+    rows = 0;
+    tried = false;
+  }
+};
+
 // Developer knobs.  The release build never reads the environment: tuning values are the
 // defaults of `Tuning` below (read once per handle in developer builds, -DTC_DEVELOPER_KNOBS,
 // so that parameter sweeps stay possible) and the few run-time options a caller may
@@ -350,6 +366,10 @@ struct tc_table {
   // galaxy type (cen-cen / cen-sat / sat-sat, each type padded to whole 4 x 4 blocks; also
   // serves the total when the number of centrals is a multiple of 4) and, otherwise, the
   // unpadded whole triangle for the total prediction.
+  // mode cross in float64: the matrix as (n_bins in library order, n_r), kept on the host for
+  // the coefficient rows of predict_cross_fused_kernel (also those of interpolators)
+  std::vector<double> cross_host;
+  tc::host::CrossFused cross_fused;
   bool quad = false;
   tc::QuadTiling quad_tiling;
   tc::host::QuadTable quad_by_type, quad_total;
@@ -485,6 +505,15 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
               unsigned flags, double* ngal_device, double* xi_device);
 int check_predict_args(const tc_table* t, const void* theta, int n_theta, int64_t n_draws,
                        int n_gauss, unsigned flags);
+// Mode cross, one launch per batch (predict_cross_fused_kernel): the coefficient rows of one
+// table / K tables with common mass bins (cf->rows == 0 afterwards: not available), whether a
+// call takes that form, and the launch (`interp`: the spline part of the arguments, or NULL).
+int build_cross_fused(tc_table* const* tables, int n_tables, CrossFused* cf);
+bool cross_fused_eligible(const tc_table* t0, const CrossFused& cf, int64_t n_draws, int n_gauss,
+                          unsigned flags, bool alone);
+int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs* interp,
+                    const double* theta_device, int n_theta, int64_t n_draws, unsigned flags,
+                    double* ngal_device, double* xi_device, hipStream_t stream);
 int launch_finalize(const FinalizeArgs& args, const Tuning& tuning, hipStream_t stream);
 // Quadratic-form path: layout upload, schedules, launches.
 int build_quad_table(tc_table* t, bool by_type, const void* matrix, int matrix_dtype,

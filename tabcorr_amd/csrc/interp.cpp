@@ -61,6 +61,7 @@ struct tc_interp {
   PinnedBuffer h_in, h_out;
   SingleWorkspace single_ws;                // un-batched calls
   std::map<std::pair<int, int>, std::unique_ptr<DeviceChunking>> chunkings;
+  CrossFused cross_fused;                   // mode cross: one launch per batch (launch.hip)
   // asynchronous host calls (tc_interp_*_async): tickets as for a table handle
   tc_table::Ticket tickets[tc_table::kMaxTickets];
   int64_t next_ticket = 0;
@@ -84,6 +85,30 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
   const int n_classes = (int)it->class_table.size();
   const int64_t ldb = (n_draws + 63) / 64 * 64;
   int status = TC_OK;
+
+  // mode cross: everything in one launch where it pays (predict_cross_fused_kernel)
+  if (t0->mode == TC_MODE_CROSS && !t0->cross_host.empty() && t0->tuning.fused != 0) {
+    if (!it->cross_fused.tried) {
+      status = build_cross_fused(it->tables.data(), it->n_tables, &it->cross_fused);
+      if (status != TC_OK) return status;
+    }
+    const bool alone = it->force_lane >= 0 || !t0->tuning.pipeline;
+    if (cross_fused_eligible(t0, it->cross_fused, n_draws, n_gauss, flags, alone)) {
+      tc::CrossFusedArgs ca{};
+      ca.n_dim = it->n_dim;
+      for (int d = 0; d < it->n_dim; ++d) {
+        ca.n_axis[d] = (int)it->xp[d].size();
+        ca.axis_offset[d] = it->axis_offset[d];
+        ca.a_offset[d] = it->a_offset[d];
+      }
+      ca.xp = (const double*)it->d_xp;
+      ca.a = (const double*)it->d_a;
+      ca.table_node = (const int32_t*)it->d_table_node;
+      ca.x = x_device;
+      return run_cross_fused(t0, it->cross_fused, &ca, theta_device, n_theta, n_draws, flags,
+                             ngal_device, xi_device, L.stream);
+    }
+  }
 
   // occupations once per class of identical halo tables (interpolator.py:181-184)
   int ngal_parts = 1;
@@ -188,6 +213,10 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
                       : launch_contract_quad(tiling.n_u, true, qa, schedule->lds_bytes,
                                              L.stream, k0, k1);
     if (status != TC_OK) return status;
+    t0->last_workgroups = (schedule->n_waves + tc::kQuadWavesPerBlock - 1) / tc::kQuadWavesPerBlock;
+    t0->last_waves = tc::kQuadWavesPerBlock;
+    t0->last_splits = schedule->n_slabs;
+    t0->last_lds = schedule->lds_bytes;
     tc::FinalizeQuadArgs fq{};
     fq.partial = L.partial.ptr;
     fq.group_begin = (const int32_t*)schedule->group_begin;
@@ -291,6 +320,10 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
     status = launch_contract_rt(t0->rt, grid, block, lds, L.stream, ca, k0, k1);
   }
   if (status != TC_OK) return status;
+  t0->last_workgroups = (int)(grid.x * grid.z);
+  t0->last_waves = c->host.waves_per_group;
+  t0->last_splits = n_groups * k_splits;
+  t0->last_lds = lds;
 
   tc::FinalizeArgs fa{};
   fa.partial = (const double*)L.partial.ptr;
@@ -482,6 +515,7 @@ int tc_interp_destroy(tc_interp* it) {
   }
   for (DeviceBuffer* b : {&it->theta, &it->x, &it->out_ngal, &it->out_xi, &it->chi2_data})
     b->release();
+  it->cross_fused.release();
   it->h_in.release();
   it->h_out.release();
   it->single_ws.buffer.release();

@@ -275,6 +275,46 @@ struct FusedArgs {
   GroupArgs group;
 };
 
+// ---- mode cross, one launch per batch (predict_cross_fused_kernel, kernels.hip.h) ----------
+constexpr int kCrossWaves = 8;
+constexpr int kCrossChunk = 8;       // rows per pass of the waves' sums through LDS
+constexpr int kCrossMaxRows = 64;    // K (R + 1) of the largest instance
+// LDS doubles of an instance: math table | stage (waves, chunk, 64) | sums (components, ROWS, 64)
+constexpr int cross_stage_doubles() { return kCrossWaves * kCrossChunk * kLanes; }
+constexpr int cross_lds_doubles(int rows, int n_comp) {
+  return 2306 + cross_stage_doubles() + n_comp * rows * kLanes;
+}
+
+struct CrossFusedArgs {
+  const double* theta;       // (n_draws, n_theta)
+  int n_theta;
+  int64_t n_draws;
+  int n_bins;
+  int n_groups, n_central_groups;
+  GroupArgs group;
+  const double* math_table;
+  const double* rows;        // (n_bins in member order, ROWS)
+  int n_tables;              // K
+  int n_r;
+  int separate;              // 1: ngal (n_draws, 2), xi (n_draws, 2, n_r): centrals, satellites
+  int cen_waves;             // separate: waves [0, cen_waves) take the groups of centrals
+  int interp;                // 1: spline weights from x (else one table, c = 1)
+  int n_dim;
+  int n_axis[kMaxInterpDim];
+  int axis_offset[kMaxInterpDim];
+  int a_offset[kMaxInterpDim];
+  const double* xp;
+  const double* a;
+  const int32_t* table_node;   // (K, n_dim)
+  const double* x;             // (n_draws, n_dim)
+  double split;
+  int priority;
+  double* ngal;
+  double* xi;                // NULL: the likelihood is fused
+  const double* chi2_data;   // as FinalizeQuadArgs
+  double* chi2;
+};
+
 struct FinalizeArgs {
   const double* partial;   // (n_groups, r_stride, ldb)
   const Group* groups;     // component of each group

@@ -48,7 +48,8 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
   int status = upload(log_m, &q.log_m);
   if (status == TC_OK) status = upload(m, &q.m);
   if (status == TC_OK) status = upload(weight, &q.weight);
-  if (status == TC_OK && n_gauss == 10 && t->node_groups.largest > 1) {
+  if (status == TC_OK && n_gauss == 10 &&
+      (t->node_groups.largest > 1 || t->mode == TC_MODE_CROSS)) {
     // GROUPED kernels: the nodes of every group (= those of its first member), the weights and
     // their sums per member in group order
     const tc::NodeGroups& groups = t->node_groups;
@@ -1263,6 +1264,163 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   t->last_splits = 0;
   t->last_lds = lds;
   t->prev = t->force_lane >= 0 ? -1 : t->cur;
+  return TC_OK;
+}
+
+// ---- mode cross, one launch per batch -----------------------------------------------------
+
+int build_cross_fused(tc_table* const* tables, int n_tables, CrossFused* cf) {
+  cf->tried = true;
+  cf->rows = 0;
+  cf->n_tables = n_tables;
+  const tc_table* t0 = tables[0];
+  if (t0->mode != TC_MODE_CROSS || t0->compute_dtype != TC_DTYPE_F64) return TC_OK;
+  const int per_table = t0->n_r + 1;
+  if ((int64_t)n_tables * per_table > tc::kCrossMaxRows) return TC_OK;
+  for (int k = 0; k < n_tables; ++k) {
+    const tc_table* t = tables[k];
+    // the tables share the nodes and the weights of every bin (n_h may differ: it is folded
+    // into the rows)
+    if (t->cross_host.empty() || t->n_bins != t0->n_bins || t->n_r != t0->n_r ||
+        t->plan.perm != t0->plan.perm || t->log_min != t0->log_min ||
+        t->log_max != t0->log_max || t->percentile != t0->percentile ||
+        t->dist_index != t0->dist_index || t->legacy != t0->legacy)
+      return TC_OK;
+  }
+  const int rows = (n_tables * per_table + tc::kCrossChunk - 1) / tc::kCrossChunk *
+                   tc::kCrossChunk;
+  // (instances: 16, 32, 48, 64 rows)
+  const int instance = (rows + 15) / 16 * 16;
+  const tc::NodeGroups& groups = t0->node_groups;
+  std::vector<double> host((size_t)t0->n_bins * instance, 0.0);
+  for (int mi = 0; mi < t0->n_bins; ++mi) {
+    const int g = groups.member[mi];
+    for (int k = 0; k < n_tables; ++k) {
+      const tc_table* t = tables[k];
+      double* row = host.data() + (size_t)mi * instance + (size_t)k * per_table;
+      for (int r = 0; r < t->n_r; ++r) row[r] = t->cross_host[(size_t)g * t->n_r + r] * t->n_h[g];
+      row[t->n_r] = t->n_h[g];
+    }
+  }
+  const int status = upload(host, &cf->d_rows);
+  if (status != TC_OK) return status;
+  cf->rows = instance;
+  return TC_OK;
+}
+
+bool cross_fused_eligible(const tc_table* t0, const CrossFused& cf, int64_t n_draws, int n_gauss,
+                          unsigned flags, bool alone) {
+  if (cf.rows == 0 || t0->tuning.fused == 0 || n_gauss != 10 || t0->chain || t0->tuning.trace)
+    return false;
+  if (flags & TC_FLAG_LEAUTHAUD11) return false;
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  const tc::NodeGroups& groups = t0->node_groups;
+  if (separate && (groups.n_central_groups == 0 || groups.n_central_groups == groups.n_groups ||
+                   t0->fuse_chi2_out != nullptr))
+    return false;
+  // the spline weights / norms and the results tile take the place of the stage
+  if (cf.n_tables * 64 + (separate ? 2 : 1) * t0->n_r * 65 > tc::cross_stage_doubles())
+    return false;
+  if (t0->fuse_chi2_out != nullptr && t0->n_r > 32) return false;
+  // A workgroup carries 64 draws through ALL bins (one per CU): batches of fewer than ~64
+  // workgroups leave most of the chip idle even with four launches in flight, where the three
+  // kernels spread any batch over the bins as well.
+  // (tools/r04_cross_scan.py, the reference's AbacusSummit table, us per step one launch / three
+  // kernels: 4096 draws 48.6 / 44.0, 6144 47.4 / 59.0, 10^4 57.9 / 90.7, 32768 185 / 290)
+  const int64_t min_draws = t0->tuning.fused_min_draws > 0 ? t0->tuning.fused_min_draws : 6144;
+  if (n_draws < min_draws) return false;
+  return t0->tuning.fused >= 2 || !alone;
+}
+
+namespace {
+template <bool AB, bool MO>
+int launch_cross_fused(int device, int rows, dim3 grid, dim3 block, int lds, hipStream_t stream,
+                       hipEvent_t k0, hipEvent_t k1, const tc::CrossFusedArgs& ca) {
+  switch (rows) {
+#define TC_CASE(N)                                                                            \
+  case N: {                                                                                   \
+    static bool limit_set[64] = {};                                                           \
+    if (lds > 64 * 1024 && !(device >= 0 && device < 64 && limit_set[device])) {              \
+      TC_HIP(hipFuncSetAttribute((const void*)tc::predict_cross_fused_kernel<N, AB, MO>,      \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));    \
+      if (device >= 0 && device < 64) limit_set[device] = true;                               \
+    }                                                                                         \
+    hipExtLaunchKernelGGL((tc::predict_cross_fused_kernel<N, AB, MO>), grid, block, lds,      \
+                          stream, k0, k1, 0, ca);                                             \
+    break;                                                                                    \
+  }
+    TC_CASE(16) TC_CASE(32) TC_CASE(48) TC_CASE(64)
+#undef TC_CASE
+    default:
+      return fail(TC_ERR_UNSUPPORTED, "no cross kernel for %d rows", rows);
+  }
+  TC_HIP(hipGetLastError());
+  return TC_OK;
+}
+}  // namespace
+
+int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs* interp,
+                    const double* theta_device, int n_theta, int64_t n_draws, unsigned flags,
+                    double* ngal_device, double* xi_device, hipStream_t stream) {
+  Range range("occupation + contraction + finalisation (mode cross, one launch)");
+  Quadrature* q = nullptr;
+  int status = get_quadrature(t0, 10, &q);
+  if (status != TC_OK) return status;
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  tc::CrossFusedArgs ca{};
+  if (interp != nullptr) ca = *interp;
+  ca.theta = theta_device;
+  ca.n_theta = n_theta;
+  ca.n_draws = n_draws;
+  ca.n_bins = t0->n_bins;
+  ca.n_groups = t0->node_groups.n_groups;
+  ca.n_central_groups = t0->node_groups.n_central_groups;
+  ca.group = group_args(t0, *q);
+  ca.math_table = (const double*)t0->d_math_table;
+  ca.rows = (const double*)cf.d_rows;
+  ca.n_tables = cf.n_tables;
+  ca.n_r = t0->n_r;
+  ca.separate = separate ? 1 : 0;
+  if (separate) {
+    // waves for the groups of centrals in proportion to their cost (a node of the centrals
+    // takes ~21 instructions, one of the satellites ~33)
+    const double cen = 21.0 * ca.n_central_groups, sat = 33.0 * (ca.n_groups - ca.n_central_groups);
+    ca.cen_waves = std::max(1, std::min(tc::kCrossWaves - 1,
+                                        (int)std::lround(tc::kCrossWaves * cen / (cen + sat))));
+  }
+  ca.interp = interp != nullptr ? 1 : 0;
+  ca.split = 0.5;
+  ca.priority = (t0->tuning.prio_fused_occ & 3) | ((t0->tuning.prio_fused_out & 3) << 4);
+  ca.ngal = ngal_device;
+  ca.xi = xi_device;
+  t0->chi2_fused = false;
+  if (t0->fuse_chi2_out != nullptr) {
+    ca.chi2_data = t0->fuse_chi2_data;
+    ca.chi2 = t0->fuse_chi2_out;
+    ca.xi = nullptr;
+    t0->chi2_fused = true;
+  }
+  const int lds = tc::cross_lds_doubles(cf.rows, separate ? 2 : 1) * 8;
+  const dim3 grid((unsigned)((n_draws + 63) / 64)), block(64 * tc::kCrossWaves);
+  hipEvent_t k0 = nullptr, k1 = nullptr;
+  status = next_kernel_events(t0, &k0, &k1);
+  if (status != TC_OK) return status;
+  const bool assembias = (flags & TC_FLAG_ASSEMBIAS) != 0;
+  const bool modulate = (flags & TC_FLAG_MODULATE_WITH_CENOCC) != 0;
+  status = assembias ? (modulate ? launch_cross_fused<true, true>(t0->device, cf.rows, grid, block,
+                                                                  lds, stream, k0, k1, ca)
+                                 : launch_cross_fused<true, false>(t0->device, cf.rows, grid,
+                                                                   block, lds, stream, k0, k1, ca))
+                     : (modulate ? launch_cross_fused<false, true>(t0->device, cf.rows, grid,
+                                                                   block, lds, stream, k0, k1, ca)
+                                 : launch_cross_fused<false, false>(t0->device, cf.rows, grid,
+                                                                    block, lds, stream, k0, k1,
+                                                                    ca));
+  if (status != TC_OK) return status;
+  t0->last_workgroups = (int)grid.x;
+  t0->last_waves = tc::kCrossWaves;
+  t0->last_splits = 0;
+  t0->last_lds = lds;
   return TC_OK;
 }
 

@@ -141,6 +141,13 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
       pos_ij[(size_t)block * 8 + k * 4 + p] = (i << 16) | t->plan.pos_j[q];
     }
   }
+  if (mode == TC_MODE_CROSS && compute_dtype == TC_DTYPE_F64 &&
+      (int64_t)n_r + 1 <= tc::kCrossMaxRows) {
+    t->cross_host.resize((size_t)n_bins * n_r);
+    for (int g = 0; g < n_bins; ++g)
+      for (int r = 0; r < n_r; ++r)
+        t->cross_host[(size_t)g * n_r + r] = source(r, t->plan.perm[g]);
+  }
   // (streams of the lanes in use; tc_table_set_option "lanes" creates further ones)
   t->n_lanes = std::max(1, std::min(t->tuning.lanes, (int)tc_table::kMaxLanes));
   for (int l = 0; l < t->n_lanes; ++l) {
@@ -234,6 +241,7 @@ int tc_table_destroy(tc_table* t) {
       if (p) (void)hipFree(p);
   t->quad_by_type.release();
   t->quad_total.release();
+  t->cross_fused.release();
   for (DeviceBuffer* b : {&t->theta, &t->out_ngal, &t->out_xi, &t->occupation,
                           &t->trace, &t->wave_trace, &t->chi2_data})
     b->release();
@@ -295,6 +303,7 @@ int tc_predict_zheng07_batch_device(tc_table* t, const double* theta_device,
   if (t->resident.running && (status = resident_stop(t)) != TC_OK) return status;
   const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
   const int n_comp = separate ? t->plan.n_components : 1;
+  t->chi2_fused = false;     // (set by whichever form writes the likelihood itself)
   if (t->force_lane >= 0)
     t->cur = t->force_lane;
   else if (t->async_lane >= 0)
@@ -305,6 +314,23 @@ int tc_predict_zheng07_batch_device(tc_table* t, const double* theta_device,
   for (int64_t begin = 0; begin < n_draws; begin += slab) {
     const int64_t n = std::min(slab, n_draws - begin);
     const int64_t ldb = (n + 63) / 64 * 64;
+    if (t->mode == TC_MODE_CROSS && !t->cross_host.empty() && t->tuning.fused != 0) {
+      // mode cross: one launch per batch where it pays (launch.hip)
+      if (!t->cross_fused.tried) {
+        tc_table* self = t;
+        status = build_cross_fused(&self, 1, &t->cross_fused);
+        if (status != TC_OK) return status;
+      }
+      const bool alone = t->force_lane >= 0 || !t->tuning.pipeline || t->n_lanes == 1;
+      if (cross_fused_eligible(t, t->cross_fused, n, n_gauss, flags, alone)) {
+        status = run_cross_fused(t, t->cross_fused, nullptr, theta_device + begin * n_theta,
+                                 n_theta, n, flags, ngal_device + begin * (separate ? 2 : 1),
+                                 xi_device + begin * n_comp * t->n_r, t->lanes[t->cur].stream);
+        if (status != TC_OK) return status;
+        t->prev = t->force_lane >= 0 ? -1 : t->cur;
+        continue;
+      }
+    }
     if (fused_eligible(t, n, n_gauss, flags)) {
       status = run_fused(t, theta_device + begin * n_theta, n_theta, n, n_gauss, flags,
                          ngal_device + begin * (separate ? 2 : 1),
