@@ -215,9 +215,13 @@ struct CrossFused {
   int rows = 0;              // ROWS of the kernel instance; 0: not available for this handle
   int n_tables = 0;
   void* d_rows = nullptr;
+  // chunks of whole groups of at most kCrossChunkBins bins (kernel_args.h: CrossFusedArgs)
+  void* d_chunk_group = nullptr;
+  int n_chunks = 0, n_central_chunks = 0;
   void release() {
     if (d_rows != nullptr) (void)hipFree(d_rows);
-    d_rows = nullptr;
+    if (d_chunk_group != nullptr) (void)hipFree(d_chunk_group);
+    d_rows = d_chunk_group = nullptr;
     rows = 0;
     tried = false;
   }

@@ -49,8 +49,13 @@ struct tc_interp {
     DeviceBuffer coef, partial, chi2_xi;
     DeviceBuffer stage_in, stage_out;         // asynchronous host calls
   };
-  static constexpr int kLanes = 2;
+  static constexpr int kLanes = 4;
   Lane lanes[kLanes];
+  // Lanes in use: two for the three-kernel forms (their contraction fills the chip by itself),
+  // four in mode cross, where a launch of predict_cross_fused_kernel is one workgroup per 64
+  // draws and only several launches in flight fill the CUs (the reference's AbacusSummit
+  // interpolator, 10^4 draws per call: 143 us per call with two lanes)
+  int n_lanes = 2;
   int force_lane = -1;                        // host-buffer entry points pin lane 0
   int cur = 0;                                // lane of the current / last call
   uint64_t device_calls = 0;
@@ -461,6 +466,7 @@ int tc_interp_create(tc_table* const* tables, int n_tables, int n_dim,
     TC_HIP(hipEventCreateWithFlags(&lane.finished, hipEventDisableTiming));
   }
   it->stream = it->lanes[0].stream;
+  it->n_lanes = t0->mode == TC_MODE_CROSS ? tc_interp::kLanes : 2;
   std::vector<void*> table_ptrs;
   for (int k = 0; k < n_tables; ++k) table_ptrs.push_back(tables[k]->d_table);
   std::vector<void*> zeros(n_classes, nullptr);
@@ -557,7 +563,7 @@ int tc_interp_predict_zheng07_batch_device(tc_interp* it, const double* theta_de
   const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
   const int n_comp = separate ? it->tables[0]->plan.n_components : 1;
   it->cur = it->force_lane >= 0 ? it->force_lane
-            : it->tables[0]->tuning.pipeline ? (int)(it->device_calls++ % tc_interp::kLanes)
+            : it->tables[0]->tuning.pipeline ? (int)(it->device_calls++ % it->n_lanes)
                                              : 0;
   const int64_t slab = max_slab(it->tables[0]);
   for (int64_t begin = 0; begin < n_draws; begin += slab) {
@@ -768,7 +774,7 @@ int tc_interp_chi2_zheng07_batch_device(tc_interp* it, const double* theta_devic
   tc_table* t0 = it->tables[0];
   // the lane tc_interp_predict_zheng07_batch_device is about to pick
   const int lane_index = it->force_lane >= 0 ? it->force_lane
-                         : t0->tuning.pipeline ? (int)(it->device_calls % tc_interp::kLanes)
+                         : t0->tuning.pipeline ? (int)(it->device_calls % it->n_lanes)
                                                : 0;
   tc_interp::Lane& L = it->lanes[lane_index];
   // data vector and precision matrix: uploaded when they differ from the last upload
@@ -863,7 +869,7 @@ int interp_async(tc_interp* it, const double* theta, int n_theta, const double* 
   // everything of a call -- upload, kernels, download, the ticket's event -- on the next lane's
   // stream: the lanes overlap each other's transfers and kernels
   const int lane_index =
-      t0->tuning.pipeline ? (int)(it->device_calls % tc_interp::kLanes) : 0;
+      t0->tuning.pipeline ? (int)(it->device_calls % it->n_lanes) : 0;
   tc_interp::Lane& L = it->lanes[lane_index];
   hipStream_t last = L.stream;
   if (n_draws > 0) {

@@ -277,12 +277,24 @@ struct FusedArgs {
 
 // ---- mode cross, one launch per batch (predict_cross_fused_kernel, kernels.hip.h) ----------
 constexpr int kCrossWaves = 8;
-constexpr int kCrossChunk = 8;       // rows per pass of the waves' sums through LDS
-constexpr int kCrossMaxRows = 64;    // K (R + 1) of the largest instance
-// LDS doubles of an instance: math table | stage (waves, chunk, 64) | sums (components, ROWS, 64)
-constexpr int cross_stage_doubles() { return kCrossWaves * kCrossChunk * kLanes; }
-constexpr int cross_lds_doubles(int rows, int n_comp) {
-  return 2306 + cross_stage_doubles() + n_comp * rows * kLanes;
+constexpr int kCrossChunkBins = 32;  // bins whose mean occupations one LDS buffer holds
+constexpr int kCrossMaxRows = 128;   // K (R + 1) of the largest instance (16 rows per wave)
+// LDS layout in doubles (launch.hip: run_cross_fused fills the offsets): math table, later the
+// spline weights / norms (K, 64) and the results tile (rows out, 65) when they fit there | two
+// chunk buffers (kCrossChunkBins, 64), later the row sums (ROWS, 64) | separated by galaxy
+// type: the row sums of the centrals (ROWS, 64) | the tile when it does not fit the first part
+constexpr int kCrossTableDoubles = 2306;       // = fm::kTableDoubles (fastmath.h)
+// predict_cross_small_kernel (up to 16 rows, the sums in every wave's registers): math table |
+// stage (waves, 8 rows, 64): the waves' sums of half the rows, later the spline weights and the
+// results tile | sums (components, 16, 64)
+constexpr int kCrossSmallRows = 16, kCrossSmallChunk = 8;
+constexpr int cross_small_lds_doubles(int n_comp) {
+  return kCrossTableDoubles + kCrossWaves * kCrossSmallChunk * kLanes +
+         n_comp * kCrossSmallRows * kLanes;
+}
+constexpr int cross_buffer_doubles(int rows) {
+  return 2 * kCrossChunkBins * kLanes > rows * kLanes ? 2 * kCrossChunkBins * kLanes
+                                                      : rows * kLanes;
 }
 
 struct CrossFusedArgs {
@@ -293,11 +305,19 @@ struct CrossFusedArgs {
   int n_groups, n_central_groups;
   GroupArgs group;
   const double* math_table;
-  const double* rows;        // (n_bins in member order, ROWS)
+  const double* rows;        // (n_bins in member order, ROWS): wave w owns rows w RW .. + RW
+  // chunks of whole groups with at most kCrossChunkBins members, none across the boundary
+  // between centrals and satellites: chunk c = groups chunk_group[c] .. chunk_group[c + 1]
+  const int32_t* chunk_group;    // (n_chunks + 1)
+  int n_chunks, n_central_chunks;
   int n_tables;              // K
   int n_r;
   int separate;              // 1: ngal (n_draws, 2), xi (n_draws, 2, n_r): centrals, satellites
-  int cen_waves;             // separate: waves [0, cen_waves) take the groups of centrals
+  int row_stride;            // doubles between the rows of consecutive members (= ROWS)
+  int cen_waves;             // predict_cross_small_kernel, separate: waves [0, cen_waves) take
+                             // the groups of centrals
+  int lds_res0;              // offsets (doubles) into the dynamic LDS: sums of the centrals,
+  int lds_tile;              // spline weights + results tile
   int interp;                // 1: spline weights from x (else one table, c = 1)
   int n_dim;
   int n_axis[kMaxInterpDim];

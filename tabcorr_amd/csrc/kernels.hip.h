@@ -2095,33 +2095,214 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
 // ---- mode cross, one launch per batch: theta -> (ngal, xi[, chi2]) ------------------------
 //
 // tabcorr.py:537-578 + :623-683 for tables with mode = 'cross' (excess surface density, any
-// galaxy-matter statistic: tabcorr_matrix has one column per halo bin, xi = T n / sum n), and
+// galaxy-matter statistic: tpcf_matrix has one column per halo bin, xi = T n / sum n), and
 // interpolator.py:124-216 over K such tables whose bins share their mass edges.  Per draw the
 // contraction is 2 K R G flop against G x n_gauss occupation nodes -- the step is ALL vector
 // arithmetic, and the three-kernel path spends as much time moving the G x draws density array
 // through memory (AbacusSummit fixture, G = 1104: 87 MB written + 89 MB read per 10^4 draws) as
-// computing.  Here a workgroup owns 64 draws (lane = draw), its eight waves stride over the
-// groups of bins (occ_group_zheng07: nodes once per group), and every member's mean
-// occupation N goes straight into the wave's row sums
-//     acc[k (R + 1) + r] += N T_k[r][g] n_h,k[g]      (r < R),
-//     acc[k (R + 1) + R] += N n_h,k[g]                (the number density of table k)
-// -- one FMA per row with the coefficient as a scalar operand; the coefficients lie per member
-// in group order, (n_bins, ROWS) doubles, rows beyond K (R + 1) zero.  Nothing but theta comes
-// in and nothing but the results go out.  The waves' sums are added in wave order through LDS,
-// kCrossChunk rows at a time; then per draw xi[r] = sum_k c_k acc[k][r] / ngal_k with the spline weights
-// c_k of the draw's extra parameters (interpolator.py:275-331; one table: c = 1).  Separated by
-// galaxy type the first `cen_waves` waves take the groups of centrals, the others the
-// satellites', and the two components are reduced apart.
-template <int ROWS, bool ASSEMBIAS, bool MODULATE>
-__global__ __launch_bounds__(64 * kCrossWaves) void predict_cross_fused_kernel(CrossFusedArgs a) {
-  static_assert(ROWS % kCrossChunk == 0 && ROWS <= kCrossMaxRows, "whole chunks of rows");
-  static_assert(fm::kTableDoubles == 2306, "cross_lds_doubles (kernel_args.h)");
+// computing.  Here a workgroup of eight waves owns 64 draws (lane = draw) and walks the bins in
+// chunks of whole groups (<= 32 bins):
+//   A. the waves stride over the chunk's groups (occ_group_zheng07: nodes once per group) and
+//      put every member's mean occupation N into an LDS buffer (bin in chunk, draw);
+//   B. wave w owns rows w RW .. w RW + RW - 1 of the K (R + 1) row sums
+//          acc[k (R + 1) + r] += N T_k[r][g] n_h,k[g]      (r < R),
+//          acc[k (R + 1) + R] += N n_h,k[g]                (the number density of table k)
+//      and adds every bin of the chunk: one LDS read (conflict-free: a row per bin) and RW FMAs
+//      with the coefficients as scalar operands ((n_bins in group order, ROWS) doubles, rows
+//      beyond K (R + 1) zero).
+// Two buffers, so that one barrier per chunk is enough: a wave that writes chunk c + 1 has
+// passed the barrier of chunk c, which every wave reaches only after reading chunk c - 1.
+// No wave ever holds more than RW sums (16 VGPRs for 64 rows): four waves per SIMD, two
+// workgroups per CU.  Nothing but theta comes in and nothing but the results go out.  Then per
+// draw xi[r] = sum_k c_k acc[k][r] / ngal_k with the spline weights c_k of the draw's extra
+// parameters (interpolator.py:275-331; one table: c = 1).  Separated by galaxy type the sums
+// of the centrals are set aside after their last chunk (no chunk holds both types).
+template <int RW, bool ASSEMBIAS, bool MODULATE>
+__global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_fused_kernel(
+    CrossFusedArgs a) {
+  constexpr int W = kCrossWaves, ROWS = W * RW;
+  static_assert(ROWS <= kCrossMaxRows && fm::kTableDoubles == kCrossTableDoubles, "kernel_args.h");
+  extern __shared__ __attribute__((aligned(16))) double cross_lds[];
+  double* table = cross_lds;
+  double* buffers = cross_lds + kCrossTableDoubles;    // 2 x (kCrossChunkBins, 64); then the sums
+  const fm::Consts kc = fm::make_consts();
+  set_priority(a.priority & 3);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  {
+    typedef double __attribute__((ext_vector_type(2))) double2v;
+    const double2v* src = (const double2v*)a.math_table;
+    double2v* dst = (double2v*)table;
+    for (int i = threadIdx.x; i < fm::kTableDoubles / 2; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int64_t col = (int64_t)blockIdx.x * kLanes;
+  const int64_t b0 = col + lane;
+  const int64_t b = b0 < a.n_draws ? b0 : a.n_draws - 1;
+
+  double acc[RW];
+#pragma unroll
+  for (int j = 0; j < RW; ++j) acc[j] = 0.0;
+  {
+    const double* th = a.theta + b * a.n_theta;
+    const DrawSetup d = prepare_draw(table, kc, th[0], th[1], th[2], th[3], th[4],
+                                     ASSEMBIAS ? th[5] : 0.0, ASSEMBIAS ? th[6] : 0.0);
+    DrawParams dp;
+    dp.log_m_min = d.log_m_min;
+    dp.inv_sigma = d.inv_sigma;
+    dp.m0 = d.m0;
+    dp.log2_m1 = d.log2_m1;
+    dp.sat_scale = d.sat_scale;
+    dp.alpha = d.alpha;
+    dp.a_cen = d.a_cen;
+    dp.a_sat = d.a_sat;
+    dp.bad = d.bad;
+    dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
+    sc_i32 group_begin = (sc_i32)a.group.begin;
+    sc_i32 chunk_group = (sc_i32)a.chunk_group;
+    const GroupConsts gq{(sc_f64)a.group.log_m, (sc_f64)a.group.m, (sc_f64)a.group.weight,
+                         (sc_f64)a.group.weight + a.n_bins * 10, (sc_f64)a.group.percentile,
+                         (sc_i32)a.group.member};
+    sc_f64 rows = (sc_f64)a.rows + wave * RW;
+    for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+      if (a.separate && chunk == a.n_central_chunks) {
+        // (the sums of the centrals are complete: set them aside; nobody reads them before the
+        // barrier behind the last chunk)
+        double* res0 = cross_lds + a.lds_res0;
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+          res0[(wave * RW + j) * kLanes + lane] = acc[j];
+          acc[j] = 0.0;
+        }
+      }
+      double* buffer = buffers + (chunk & 1) * (kCrossChunkBins * kLanes);
+      const int g0 = chunk_group[chunk], g1 = chunk_group[chunk + 1];
+      const int m0 = group_begin[g0], m1 = group_begin[g1];
+      // A. mean occupations of the chunk's bins
+      for (int gr = g0 + wave; gr < g1; gr += W)
+        occ_group_zheng07<ASSEMBIAS, MODULATE>(
+            table, kc, gr, group_begin[gr], group_begin[gr + 1], gr < a.n_central_groups, gq,
+            a.split, dp, [&](int mi, int, double nbar) { buffer[(mi - m0) * kLanes + lane] = nbar; });
+      __syncthreads();
+      // B. this wave's rows over every bin of the chunk
+#pragma unroll 4
+      for (int mi = m0; mi < m1; ++mi) {
+        const double nbar = buffer[(mi - m0) * kLanes + lane];
+        sc_f64 coefficient = rows + (int64_t)mi * ROWS;
+#pragma unroll
+        for (int j = 0; j < RW; ++j) acc[j] = fma(coefficient[j], nbar, acc[j]);
+      }
+    }
+  }
+  __syncthreads();      // every wave has read the last chunk: the buffers take the sums
+  double* res1 = buffers;                               // all bins, or the satellites
+  double* res0 = a.separate ? cross_lds + a.lds_res0 : buffers;
+#pragma unroll
+  for (int j = 0; j < RW; ++j) res1[(wave * RW + j) * kLanes + lane] = acc[j];
+  __syncthreads();
+
+  // ---- per draw: spline weights / norms of the tables, number densities ----
+  set_priority((a.priority >> 4) & 3);
+  const int n_comp = a.separate ? 2 : 1;
+  const int per_table = a.n_r + 1;
+  double* coef = cross_lds + a.lds_tile;        // (K, 64): c_k / ngal_k
+  double* tile = coef + a.n_tables * kLanes;    // (n_comp n_r, 65)
+  if (wave == 0) {
+    double n_cen = 0.0, n_sat = 0.0;
+    for (int k = 0; k < a.n_tables; ++k) {
+      double c = 1.0;
+      if (a.interp) {
+        for (int dim = 0; dim < a.n_dim; ++dim) {
+          const int n = a.n_axis[dim];
+          const double* xp = a.xp + a.axis_offset[dim];
+          const double x = a.x[b * a.n_dim + dim];
+          int seg = -1;
+          for (int i = 0; i < n; ++i) seg += xp[i] <= x ? 1 : 0;   // np.digitize(x, xp) - 1
+          if (x == xp[n - 1]) seg = n - 2;
+          seg = seg < 0 ? 0 : (seg > n - 2 ? n - 2 : seg);
+          const double* m = a.a + a.a_offset[dim] + (int64_t)seg * 4 * n;
+          const int j = a.table_node[k * a.n_dim + dim];
+          const double x2 = x * x, x3 = x2 * x;
+          c *= m[j] + m[n + j] * x + m[2 * n + j] * x2 + m[3 * n + j] * x3;
+        }
+      }
+      const double cen = res0[(k * per_table + a.n_r) * kLanes + lane];
+      const double sat = a.separate ? res1[(k * per_table + a.n_r) * kLanes + lane] : 0.0;
+      const double total = cen + sat;
+      // (separated by galaxy type a non-finite sum poisons both components of the table, as
+      // the reference's mask-after-divide does: tabcorr.py:653-681, finalize_kernel)
+      const bool poisoned = a.separate && !(fabs(total) <= 1.79769313486231570815e308);
+      coef[k * kLanes + lane] = c / (poisoned ? __builtin_nan("") : total);
+      n_cen += c * cen;
+      n_sat += c * sat;
+    }
+    if (b0 < a.n_draws) {
+      if (a.separate) {
+        a.ngal[2 * b0] = n_cen;
+        a.ngal[2 * b0 + 1] = n_sat;
+      } else {
+        a.ngal[b0] = n_cen + n_sat;
+      }
+    }
+  }
+  __syncthreads();
+  const int n_rows = n_comp * a.n_r;
+  for (int row = wave; row < n_rows; row += W) {
+    const int comp = row / a.n_r, r = row % a.n_r;
+    const double* res = comp == 0 ? res0 : res1;
+    double sum = 0.0;
+    for (int k = 0; k < a.n_tables; ++k)
+      sum = fma(coef[k * kLanes + lane], res[(k * per_table + r) * kLanes + lane], sum);
+    tile[row * (kLanes + 1) + lane] = sum;
+  }
+  __syncthreads();
+  const int64_t n_valid = a.n_draws - col < kLanes ? a.n_draws - col : kLanes;
+  if (a.chi2 != nullptr) {
+    // chi2 = delta^T P delta for the lane's draw (total prediction; finalize_quad_kernel)
+    const int rows_r = a.n_r;
+    const double* data = a.chi2_data;
+    const double* matrix = a.chi2_data + rows_r;
+    double part = 0.0;
+    for (int i = wave; i < rows_r; i += W) {
+      double inner = 0.0;
+      for (int j = 0; j < rows_r; ++j)
+        inner = fma(matrix[i * rows_r + j], tile[j * (kLanes + 1) + lane] - data[j], inner);
+      part = fma(tile[i * (kLanes + 1) + lane] - data[i], inner, part);
+    }
+    res1[wave * kLanes + lane] = part;           // (the sums are dead: all in the tile)
+    __syncthreads();
+    if (wave == 0 && lane < n_valid) {
+      double total = 0.0;
+      for (int w = 0; w < W; ++w) total += res1[w * kLanes + lane];
+      a.chi2[col + lane] = total;
+    }
+    return;
+  }
+  for (int idx = threadIdx.x; idx < n_rows * kLanes; idx += blockDim.x) {
+    const int dd = idx / n_rows, row = idx % n_rows;
+    if (dd < n_valid) a.xi[(col + dd) * (int64_t)n_rows + row] = tile[row * (kLanes + 1) + dd];
+  }
+}
+
+// The same for up to 16 rows (one table with up to 15 r values -- the reference's excess surface
+// density tables have 13 --, a few tables with a handful): the row sums fit every wave's
+// registers next to the occupation arithmetic (two workgroups per CU all the same), so the waves
+// simply stride over the groups, a member's mean occupation goes straight into the wave's 16
+// sums, and the waves' sums meet ONCE, at the end, through LDS -- no buffer, no barrier per
+// chunk: the AbacusSummit table takes 57.9 us per 10^4 draws this way against 73.7 through the
+// chunks above (where the 2 rows per wave make phase B mostly LDS reads and scalar loads).
+// Separated by galaxy type the first `cen_waves` waves take the groups of centrals.
+template <bool ASSEMBIAS, bool MODULATE>
+__global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kernel(
+    CrossFusedArgs a) {
+  constexpr int ROWS = kCrossSmallRows, kCrossChunk = kCrossSmallChunk;
+  static_assert(fm::kTableDoubles == kCrossTableDoubles, "kernel_args.h");
   constexpr int W = kCrossWaves;
   extern __shared__ __attribute__((aligned(16))) double cross_lds[];
   // math table | stage (W, kCrossChunk, 64): the waves' sums of one chunk of rows, later the spline
   // weights / norms (K, 64) and the results tile | res (n_comp, ROWS, 64)
   double* table = cross_lds;
-  double* stage = cross_lds + fm::kTableDoubles + (fm::kTableDoubles & 1);
+  double* stage = cross_lds + kCrossTableDoubles;
   double* res = stage + W * kCrossChunk * kLanes;
   const fm::Consts kc = fm::make_consts();
   set_priority(a.priority & 3);
@@ -2163,7 +2344,7 @@ __global__ __launch_bounds__(64 * kCrossWaves) void predict_cross_fused_kernel(C
                          (sc_i32)a.group.member};
     sc_f64 rows = (sc_f64)a.rows;
     auto emit = [&](int mi, int, double nbar) {
-      sc_f64 coefficient = rows + (int64_t)mi * ROWS;
+      sc_f64 coefficient = rows + (int64_t)mi * a.row_stride;
 #pragma unroll
       for (int j = 0; j < ROWS; ++j) acc[j] = fma(coefficient[j], nbar, acc[j]);
     };

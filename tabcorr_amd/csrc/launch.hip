@@ -1287,11 +1287,27 @@ int build_cross_fused(tc_table* const* tables, int n_tables, CrossFused* cf) {
         t->dist_index != t0->dist_index || t->legacy != t0->legacy)
       return TC_OK;
   }
-  const int rows = (n_tables * per_table + tc::kCrossChunk - 1) / tc::kCrossChunk *
-                   tc::kCrossChunk;
-  // (instances: 16, 32, 48, 64 rows)
-  const int instance = (rows + 15) / 16 * 16;
+  // (instances: 2, 4, 8, 16 rows per wave)
+  const int rows = n_tables * per_table;
+  const int instance = rows <= 16 ? 16 : rows <= 32 ? 32 : rows <= 64 ? 64 : 128;
   const tc::NodeGroups& groups = t0->node_groups;
+  if (groups.largest > tc::kCrossChunkBins) return TC_OK;
+  // chunks: whole groups, at most kCrossChunkBins bins, centrals and satellites apart
+  std::vector<int32_t> chunk_group{0};
+  cf->n_central_chunks = 0;
+  for (int g = 0, members = 0; g < groups.n_groups; ++g) {
+    const int size = groups.begin[g + 1] - groups.begin[g];
+    if (g > chunk_group.back() &&
+        (members + size > tc::kCrossChunkBins || g == groups.n_central_groups)) {
+      chunk_group.push_back(g);
+      members = 0;
+    }
+    if (g == groups.n_central_groups) cf->n_central_chunks = (int)chunk_group.size() - 1;
+    members += size;
+  }
+  if (groups.n_central_groups == groups.n_groups) cf->n_central_chunks = (int)chunk_group.size();
+  chunk_group.push_back(groups.n_groups);
+  cf->n_chunks = (int)chunk_group.size() - 1;
   std::vector<double> host((size_t)t0->n_bins * instance, 0.0);
   for (int mi = 0; mi < t0->n_bins; ++mi) {
     const int g = groups.member[mi];
@@ -1302,11 +1318,36 @@ int build_cross_fused(tc_table* const* tables, int n_tables, CrossFused* cf) {
       row[t->n_r] = t->n_h[g];
     }
   }
-  const int status = upload(host, &cf->d_rows);
+  int status = upload(host, &cf->d_rows);
+  if (status == TC_OK) status = upload(chunk_group, &cf->d_chunk_group);
   if (status != TC_OK) return status;
   cf->rows = instance;
   return TC_OK;
 }
+
+namespace {
+// LDS layout of predict_cross_fused_kernel (kernel_args.h): offsets in doubles, total in bytes.
+struct CrossLds {
+  int res0 = 0, tile = 0, bytes = 0;
+};
+CrossLds cross_lds_layout(const CrossFused& cf, int n_r, bool separate) {
+  CrossLds lds;
+  int end = tc::kCrossTableDoubles + tc::cross_buffer_doubles(cf.rows);
+  if (separate) {
+    lds.res0 = end;
+    end += cf.rows * 64;
+  }
+  const int tile = cf.n_tables * 64 + (separate ? 2 : 1) * n_r * 65;
+  if (tile <= tc::kCrossTableDoubles) {
+    lds.tile = 0;
+  } else {
+    lds.tile = end;
+    end += tile;
+  }
+  lds.bytes = end * 8;
+  return lds;
+}
+}  // namespace
 
 bool cross_fused_eligible(const tc_table* t0, const CrossFused& cf, int64_t n_draws, int n_gauss,
                           unsigned flags, bool alone) {
@@ -1318,8 +1359,8 @@ bool cross_fused_eligible(const tc_table* t0, const CrossFused& cf, int64_t n_dr
   if (separate && (groups.n_central_groups == 0 || groups.n_central_groups == groups.n_groups ||
                    t0->fuse_chi2_out != nullptr))
     return false;
-  // the spline weights / norms and the results tile take the place of the stage
-  if (cf.n_tables * 64 + (separate ? 2 : 1) * t0->n_r * 65 > tc::cross_stage_doubles())
+  if (cf.rows > tc::kCrossSmallRows &&
+      cross_lds_layout(cf, t0->n_r, separate).bytes > kMaxLdsBytes)
     return false;
   if (t0->fuse_chi2_out != nullptr && t0->n_r > 32) return false;
   // A workgroup carries 64 draws through ALL bins (one per CU): batches of fewer than ~64
@@ -1336,7 +1377,7 @@ namespace {
 template <bool AB, bool MO>
 int launch_cross_fused(int device, int rows, dim3 grid, dim3 block, int lds, hipStream_t stream,
                        hipEvent_t k0, hipEvent_t k1, const tc::CrossFusedArgs& ca) {
-  switch (rows) {
+  switch (rows / tc::kCrossWaves) {      // rows per wave
 #define TC_CASE(N)                                                                            \
   case N: {                                                                                   \
     static bool limit_set[64] = {};                                                           \
@@ -1349,8 +1390,12 @@ int launch_cross_fused(int device, int rows, dim3 grid, dim3 block, int lds, hip
                           stream, k0, k1, 0, ca);                                             \
     break;                                                                                    \
   }
-    TC_CASE(16) TC_CASE(32) TC_CASE(48) TC_CASE(64)
+    TC_CASE(4) TC_CASE(8) TC_CASE(16)
 #undef TC_CASE
+    case 2:     // up to 16 rows: the sums in every wave's registers
+      hipExtLaunchKernelGGL((tc::predict_cross_small_kernel<AB, MO>), grid, block, lds, stream,
+                            k0, k1, 0, ca);
+      break;
     default:
       return fail(TC_ERR_UNSUPPORTED, "no cross kernel for %d rows", rows);
   }
@@ -1381,12 +1426,23 @@ int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs
   ca.n_tables = cf.n_tables;
   ca.n_r = t0->n_r;
   ca.separate = separate ? 1 : 0;
-  if (separate) {
-    // waves for the groups of centrals in proportion to their cost (a node of the centrals
-    // takes ~21 instructions, one of the satellites ~33)
-    const double cen = 21.0 * ca.n_central_groups, sat = 33.0 * (ca.n_groups - ca.n_central_groups);
-    ca.cen_waves = std::max(1, std::min(tc::kCrossWaves - 1,
-                                        (int)std::lround(tc::kCrossWaves * cen / (cen + sat))));
+  ca.chunk_group = (const int32_t*)cf.d_chunk_group;
+  ca.n_chunks = cf.n_chunks;
+  ca.n_central_chunks = cf.n_central_chunks;
+  CrossLds layout = cross_lds_layout(cf, t0->n_r, separate);
+  ca.lds_res0 = layout.res0;
+  ca.lds_tile = layout.tile;
+  ca.row_stride = cf.rows;
+  if (cf.rows <= tc::kCrossSmallRows) {
+    layout.bytes = tc::cross_small_lds_doubles(separate ? 2 : 1) * 8;
+    if (separate) {
+      // waves for the groups of centrals in proportion to their cost (a node of the centrals
+      // takes ~21 instructions, one of the satellites ~33)
+      const double cen = 21.0 * ca.n_central_groups,
+                   sat = 33.0 * (ca.n_groups - ca.n_central_groups);
+      ca.cen_waves = std::max(1, std::min(tc::kCrossWaves - 1,
+                                          (int)std::lround(tc::kCrossWaves * cen / (cen + sat))));
+    }
   }
   ca.interp = interp != nullptr ? 1 : 0;
   ca.split = 0.5;
@@ -1400,7 +1456,7 @@ int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs
     ca.xi = nullptr;
     t0->chi2_fused = true;
   }
-  const int lds = tc::cross_lds_doubles(cf.rows, separate ? 2 : 1) * 8;
+  const int lds = layout.bytes;
   const dim3 grid((unsigned)((n_draws + 63) / 64)), block(64 * tc::kCrossWaves);
   hipEvent_t k0 = nullptr, k1 = nullptr;
   status = next_kernel_events(t0, &k0, &k1);

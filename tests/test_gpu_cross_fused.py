@@ -60,11 +60,12 @@ def compare(got, expect, separate, rtol, what, floor=1e-14):
 
 
 @pytest.mark.parametrize('n_prim, n_sec, n_r, n_draws, kwargs', [
-    (20, 1, 13, 200, {}),                                   # 14 rows -> the 16-row instance
+    (20, 1, 13, 200, {}),                                   # 14 rows -> 16 (2 per wave)
     (20, 2, 13, 333, {'assembias': True}),
     (9, 3, 19, 64, {'modulate_with_cenocc': True}),         # 20 rows -> 32
     (30, 2, 40, 129, {}),                                   # 41 rows -> 48
     (12, 2, 62, 65, {'assembias': True, 'modulate_with_cenocc': True}),   # 63 rows -> 64
+    (10, 2, 100, 70, {}),                                   # 101 rows -> 128
     (40, 2, 1, 1000, {}),                                   # one r value
     (3, 1, 5, 1, {}),                                       # one draw
 ])
@@ -83,8 +84,8 @@ def test_cross_table_against_oracle_and_three_kernels(n_prim, n_sec, n_r, n_draw
     halotab = make_tabcorr(table)
     handle = halotab.to_device().handle
     for separate in (False, True):
-        if separate and n_r > 31:
-            continue        # (the results tile of two components does not fit: three kernels)
+        if separate and n_r > 62:
+            continue        # (two components of 100 r values do not fit the LDS: three kernels)
         expect = oracle.predict_zheng07_batch(table, theta, separate_gal_type=separate,
                                               **oracle_kwargs)
         force(handle, True)
@@ -180,6 +181,7 @@ def synthetic_cross_interpolator(shape, n_prim, n_sec, n_r, seed, vary_n_h=False
     ((4, ), 20, 2, 13, False),            # 56 rows: the shape of the reference's fixture
     ((4, ), 16, 1, 7, True),              # 32 rows, every table its own n_h
     ((4, 4), 10, 2, 3, True),             # 16 tables x 4 rows
+    ((4, 4), 8, 1, 6, False),             # 16 tables x 7 rows = 112 -> 128
     ((5, ), 12, 2, 11, False),            # 60 rows
 ])
 def test_cross_interpolator(shape, n_prim, n_sec, n_r, vary_n_h):
