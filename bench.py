@@ -20,8 +20,10 @@ Multi-GPU: weak scaling, one process per GPU, every rank runs its own 10^4 draws
 step against its own replica of the table (the path shards over draws without any
 data-path collective); the results of all steps are collected on rank 0 by one RCCL
 gather over xGMI per block of --gather-every steps, on a second stream, overlapped with
-the following steps (``--gather chi2``: the fused likelihood, 16 bytes per draw instead
-of 160).  ``--workload interp5x5`` is BASELINE configs[3]: ``Interpolator.predict`` over a
+the following steps.  The SAME workload and payload for every N: (ngal, xi) of every draw,
+160 bytes; with --gpus > 1 the fused likelihood (``--gather chi2``: 16 bytes per draw, what
+an MCMC needs back) is timed as well, in a second region of the same run
+(``second_payload``).  ``--workload interp5x5`` is BASELINE configs[3]: ``Interpolator.predict`` over a
 5 x 5 grid of such tables, 10^5 draws per step sharded round-robin over the ranks (strong
 scaling), gathered the same way.  PyTorch is only used for the gloo control plane.
 
@@ -240,11 +242,15 @@ def main():
                              'step over ALL GPUs (10^5)')
     parser.add_argument('--gather', choices=['full', 'chi2'], default=None,
                         help='what every step leaves behind / multi-GPU: what is gathered on '
-                             'rank 0: (ngal, xi) of every draw (160 B per draw; default for '
-                             'one GPU, the configuration BASELINE.json names), or the fused '
-                             'likelihood (ngal, chi2) (16 B per draw; default for --gpus > 1: '
-                             'what an MCMC needs back, and 8 ranks of full results would put '
-                             '~260 GB/s on rank 0)')
+                             'rank 0 in the region `value` is timed on: (ngal, xi) of every '
+                             'draw (160 B per draw; default for every N: the configuration '
+                             'BASELINE.json names), or the fused likelihood (ngal, chi2) (16 B '
+                             'per draw: what an MCMC needs back).  With --gpus > 1 the other '
+                             'payload is timed as well, in a second region of the same run '
+                             '(`second_payload`)')
+    parser.add_argument('--second-payload', type=int, default=None,
+                        help='time the other payload in a second region (default: 1 for '
+                             '--gpus > 1, else 0)')
     parser.add_argument('--gather-every', type=int, default=0,
                         help='multi-GPU: steps per RCCL gather of the results (default: 32, or '
                              'a quarter of --steps for short runs so that the gathers overlap '
@@ -268,7 +274,7 @@ def main():
     args = parser.parse_args()
     interp_mode = args.workload == 'interp5x5'
     if args.gather is None:
-        args.gather = 'chi2' if args.gpus > 1 else 'full'
+        args.gather = 'full'      # the same workload and payload for every N
     if args.steps is None:
         args.steps = 200 if interp_mode else 20000
     if args.warmup is None:
@@ -342,34 +348,73 @@ def main():
     for option in args.option:
         name, value = option.split('=')
         _lib.check(lib.tc_table_set_option(timer_handle, name.encode(), int(value)))
-    chi2_mode = args.gather == 'chi2'
-    n_out = n_draws * (2 if chi2_mode else 1 + N_R)     # ngal | xi (B, R), or ngal | chi2
     d_theta = dev.upload(theta)
     d_x = dev.upload(x) if interp_mode else None
     data_vector = np.full(N_R, 50.0)
     precision = np.eye(N_R) * 1e-2
     data_p, precision_p = _lib.as_double_p(data_vector), _lib.as_double_p(precision)
-
-    # Results ring (tabcorr_amd.parallel.ResultRing): 4 blocks of `every` steps.  A block is
-    # gathered on rank 0 (RCCL, own stream) once its last step is queued; the other blocks
-    # keep filling meanwhile.
     every = args.gather_every if args.gather_every > 0 else (
         32 if args.steps >= 128 else max(2, args.steps // 4))
     use_rccl = comm.comm is not None
     interp_handle = handle if interp_mode else None
 
-    def ring_gather(block, send_offset, recv_offset, count):
-        recv = ctypes.c_void_p(d_recv.value + recv_offset * 8) if comm.is_root else None
-        comm.gather_device(timer_handle, ctypes.c_void_p(d_out.value + send_offset * 8), recv,
-                           count, block, interp_handle=interp_handle)
+    class Region:
+        """One payload: the ring of result slots (tabcorr_amd.parallel.ResultRing: 4 blocks of
+        `every` steps; a block is gathered on rank 0 -- RCCL, own stream -- once its last step
+        is queued, the other blocks keep filling meanwhile), the step and its gathers."""
 
-    ring = ResultRing(n_out, every, comm.world_size,
-                      gather=ring_gather if use_rccl else (lambda *a: None),
-                      release=(lambda block: comm.release(
-                          timer_handle, block, interp_handle=interp_handle)) if use_rccl
-                      else None)               # (the communicator has four send-buffer slots)
-    n_slots = ring.n_slots
-    d_out = dev.malloc(ring.ring_elements)
+        def __init__(self, chi2_mode):
+            self.chi2_mode = chi2_mode
+            self.n_out = n_draws * (2 if chi2_mode else 1 + N_R)   # ngal | chi2, or ngal | xi
+            self.ring = ResultRing(
+                self.n_out, every, comm.world_size,
+                gather=self.gather if use_rccl else (lambda *a: None),
+                release=(lambda block: comm.release(
+                    timer_handle, block, interp_handle=interp_handle)) if use_rccl
+                else None)               # (the communicator has four send-buffer slots)
+            self.n_slots = self.ring.n_slots
+            self.d_out = dev.malloc(self.ring.ring_elements)
+            self.d_recv = (dev.malloc(self.ring.recv_elements)
+                           if (use_rccl and comm.is_root) else ctypes.c_void_p())
+
+        def gather(self, block, send_offset, recv_offset, count):
+            recv = (ctypes.c_void_p(self.d_recv.value + recv_offset * 8)
+                    if comm.is_root else None)
+            comm.gather_device(timer_handle,
+                               ctypes.c_void_p(self.d_out.value + send_offset * 8), recv,
+                               count, block, interp_handle=interp_handle)
+
+        def out_ptr(self, slot, offset=0):
+            return ctypes.c_void_p(self.d_out.value + (slot * self.n_out + offset) * 8)
+
+        def predict(self, slot):
+            out, second = self.out_ptr(slot), self.out_ptr(slot, n_draws)
+            if interp_mode and self.chi2_mode:
+                _lib.check(lib.tc_interp_chi2_zheng07_batch_device(
+                    handle, d_theta, 5, d_x, n_draws, N_GAUSS, 0, data_p, precision_p,
+                    out, second))
+            elif interp_mode:
+                _lib.check(lib.tc_interp_predict_zheng07_batch_device(
+                    handle, d_theta, 5, d_x, n_draws, N_GAUSS, 0, out, second))
+            elif self.chi2_mode:
+                _lib.check(lib.tc_chi2_zheng07_batch_device(
+                    handle, d_theta, 5, n_draws, N_GAUSS, 0, data_p, precision_p, out, second))
+            else:
+                _lib.check(lib.tc_predict_zheng07_batch_device(
+                    handle, d_theta, 5, n_draws, N_GAUSS, 0, out, second))
+
+        def step(self, index):
+            self.ring.before_step(index)
+            self.predict(self.ring.slot(index))
+            self.ring.after_step(index)
+
+        def flush(self, n_steps):
+            """Gather the steps of a trailing, partly filled block."""
+            self.ring.flush(n_steps)
+
+    region = Region(args.gather == 'chi2')
+    chi2_mode, n_out, n_slots = region.chi2_mode, region.n_out, region.n_slots
+    predict, step, flush, out_ptr = region.predict, region.step, region.flush, region.out_ptr
     lanes_used = args.lanes if args.lanes > 0 else 4
     if use_rccl and args.lanes == 0 and not interp_mode and every < 16 and not chi2_mode:
         # Frequent gathers of the full results: the communicator's stream is a fifth stream on
@@ -381,37 +426,6 @@ def main():
         # is short; 49.4-52.0 against 53.2-53.5 us per step, tools/r03_forced_comm.sh).
         lanes_used = 3
         _lib.check(lib.tc_table_set_option(timer_handle, b'lanes', lanes_used))
-    d_recv = dev.malloc(ring.recv_elements) if (use_rccl and comm.is_root) else ctypes.c_void_p()
-
-    def out_ptr(slot, offset=0):
-        return ctypes.c_void_p(d_out.value + (slot * n_out + offset) * 8)
-
-    def predict(slot):
-        if interp_mode and chi2_mode:
-            _lib.check(lib.tc_interp_chi2_zheng07_batch_device(
-                handle, d_theta, 5, d_x, n_draws, N_GAUSS, 0, data_p, precision_p,
-                out_ptr(slot), out_ptr(slot, n_draws)))
-        elif interp_mode:
-            _lib.check(lib.tc_interp_predict_zheng07_batch_device(
-                handle, d_theta, 5, d_x, n_draws, N_GAUSS, 0, out_ptr(slot),
-                out_ptr(slot, n_draws)))
-        elif chi2_mode:
-            _lib.check(lib.tc_chi2_zheng07_batch_device(
-                handle, d_theta, 5, n_draws, N_GAUSS, 0, data_p, precision_p,
-                out_ptr(slot), out_ptr(slot, n_draws)))
-        else:
-            _lib.check(lib.tc_predict_zheng07_batch_device(
-                handle, d_theta, 5, n_draws, N_GAUSS, 0, out_ptr(slot),
-                out_ptr(slot, n_draws)))
-
-    def step(index):
-        ring.before_step(index)
-        predict(ring.slot(index))
-        ring.after_step(index)
-
-    def flush(n_steps):
-        """Gather the steps of a trailing, partly filled block."""
-        ring.flush(n_steps)
 
     def synchronize():
         if interp_mode:
@@ -469,21 +483,48 @@ def main():
     # (no garbage collection inside it: a full collection pass of the interpreter stalls
     # the enqueueing thread for hundreds of microseconds, longer than 10 steps)
     import gc
-    gc.disable()
-    comm.barrier()
-    drain()
-    t0 = time.perf_counter()
-    for index in range(args.steps):
-        step(index)
-    t_queued = time.perf_counter()
-    flush(args.steps)
-    drain()
-    t_drained = time.perf_counter()
-    comm.barrier()
-    elapsed = comm.max(time.perf_counter() - t0)
-    breakdown = {'enqueue': (t_queued - t0) * 1e6, 'drain': (t_drained - t_queued) * 1e6,
-                 'barrier': (time.perf_counter() - t_drained) * 1e6}
-    gc.enable()
+
+    def timed(payload):
+        gc.disable()
+        comm.barrier()
+        drain()
+        t0 = time.perf_counter()
+        for index in range(args.steps):
+            payload.step(index)
+        t_queued = time.perf_counter()
+        payload.flush(args.steps)
+        drain()
+        t_drained = time.perf_counter()
+        comm.barrier()
+        seconds = comm.max(time.perf_counter() - t0)
+        gc.enable()
+        return seconds, {'enqueue': (t_queued - t0) * 1e6, 'drain': (t_drained - t_queued) * 1e6,
+                         'barrier': (time.perf_counter() - t_drained) * 1e6}
+
+    elapsed, breakdown = timed(region)
+
+    # The other payload, same workload, same steps: a second region of the same run (default
+    # for --gpus > 1, where what travels to rank 0 is the difference between the two).
+    second = None
+    want_second = (args.second_payload if args.second_payload is not None
+                   else int(comm.world_size > 1))
+    if want_second:
+        other = Region(not chi2_mode)
+        for index in range(args.warmup):
+            other.step(index)
+        other.flush(args.warmup)
+        drain()
+        second_elapsed, second_breakdown = timed(other)
+        second = {
+            'gather_payload': 'ngal + chi2 (16 B per draw)' if other.chi2_mode
+                              else 'ngal + xi (%d B per draw)' % (8 * (1 + N_R)),
+            'value': comm.world_size * n_draws * args.steps / second_elapsed,
+            'unit': 'calls/s', 'ms_per_step': second_elapsed / args.steps * 1e3,
+            'steps': args.steps, 'warmup': args.warmup,
+            'timed_region_breakdown_us': second_breakdown,
+            'what': 'the same workload and steps with the other payload, timed right after '
+                    'the region of `value` (barrier + device sync on both sides, max over '
+                    'ranks)'}
 
     if comm.dist is not None and not use_rccl:
         # RCCL unavailable: collect the last batch over gloo so that the job still
@@ -550,7 +591,8 @@ def main():
 
         three_kernel_name = ('tc::contract_quad_kernel<5, true>' if interp_mode
                              else 'tc::contract_quad_kernel<5, false>')
-        kernel_name = 'tc::predict_fused_kernel<10, 5, false, false, false, 8, 64>' if fused_active else three_kernel_name
+        kernel_name = ('tc::predict_fused_kernel<10, 5, false, false, false, 8, 64, false>'
+                       if fused_active else three_kernel_name)
         headline_traffic = (pmc_traffic(kernel_name, 'interp5x5' if interp_mode else '')
                             if n_draws == (100000 if interp_mode else 10000) // (
                                 comm.world_size if interp_mode else 1)
@@ -578,8 +620,10 @@ def main():
         result = {
             'metric': 'predict_calls_per_sec',
             'value': total_draws / elapsed,
-            'value_is': 'device-resident rate (draws and results in HBM); the host-to-host '
-                        'rate of SURVEY.md 8d is host_to_host.value',
+            'value_definition': 'device-resident',
+            'value_is': 'device-resident rate (draws and results in HBM; multi-GPU: results '
+                        'gathered on rank 0); the host-to-host rate of SURVEY.md 8d is '
+                        'value_host_to_host (= host_to_host_pipelined.value)',
             'unit': 'calls/s',
             'n_gpus': comm.world_size,
             'steps': args.steps,
@@ -616,6 +660,16 @@ def main():
                 'peak': FP64_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': achieved / FP64_PEAK_TFLOPS,
+                'frac_method': ('flop_per_launch / (mean_launch_ms / concurrent_launches) / '
+                                "peak: a launch's share of the chip while "
+                                'concurrent_launches of them overlap') if fused_active
+                               else 'flop_per_launch / mean_launch_ms / peak (kernels serialised)',
+                'frac_by_duration': flop_contract / ((overlapped_ms if fused_active
+                                                      else isolated_ms) * 1e-3) / 1e12
+                                    / FP64_PEAK_TFLOPS,
+                'frac_by_duration_method': 'flop_per_launch / mean_launch_ms / peak: by the raw '
+                                           'duration of a launch (what rocprofv3 reports per '
+                                           'dispatch), whatever else runs beside it',
                 'traffic': headline_traffic[0],
                 'traffic_source': '%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '
                                   'of this script, tools/profile_round.sh; FETCH_SIZE x 2 per '
@@ -665,6 +719,8 @@ def main():
         }
         if comm.rccl_error:
             result['config']['rccl_error'] = comm.rccl_error
+        if second is not None:
+            result['second_payload'] = second
 
     # ---- SURVEY 8d metric, latency mode, the other BASELINE configurations (1 GPU) ---------
     if comm.world_size == 1 and not interp_mode:
@@ -681,6 +737,7 @@ def main():
             'what': 'tc_predict_zheng07_batch: %d draws in pageable host memory -> (ngal, xi) '
                     'in host memory, synchronous, PCIe included (SURVEY.md 8d)' % n_draws}
         result.update(host_pipelined(lib, _lib, handle, table, n_draws, data_vector, precision))
+        result['value_host_to_host'] = result['host_to_host_pipelined']['value']
         # other batch sizes of the same table (an ensemble sampler's 10^2 ... 10^4 walkers per
         # step), device-resident, the form the library chooses and -- by option -- the three
         # kernels; first draws of every batch against the oracle
@@ -901,7 +958,7 @@ def tabulation(cpu_seconds):
 
 # ---- BASELINE configs[2], [3], [4] ----------------------------------------------------------
 
-CONFIG_TAGS = ('cfg3', 'cfg4', 'cfg5f32', 'cfg5f64')
+CONFIG_TAGS = ('cfg3', 'cfg4', 'cfg5f32', 'cfg5f64', 'ds4', 'ds1', 'wp', 'db')
 
 
 def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=None, lanes=0,
@@ -935,41 +992,89 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
                 'sample': '%d sequential predict() calls in %.1f s' % (count, spent)}
 
     def measure(name, tag, what, timer_handle, launch, synchronize, host_call, n_draws, flop,
-                peak, kernel, dtype, cpu, parity):
+                peak, kernel, dtype, cpu, parity, fused_kernel=None, bound='mfma',
+                set_options=None):
+        """`kernel`: the dominant kernel of the three-kernel form; `fused_kernel`: the one-launch
+        kernel the library may choose for the pipelined calls of this configuration (its name
+        as rocprofv3 prints it).  The record's `kernel` is the one that ran in the timed
+        region; the serialised three-kernel figures sit under `three_kernel_path`.
+        `set_options(name, value)`: sets an option on every table handle of the workload."""
+        if set_options is None:
+            def set_options(key, value):
+                _lib.check(lib.tc_table_set_option(timer_handle, key, value))
         if lanes > 0:
             _lib.check(lib.tc_table_set_option(timer_handle, b'lanes', lanes))
         for option in options:          # (developer A/B: --option name=value)
             key, value = option.split('=')
-            _lib.check(lib.tc_table_set_option(timer_handle, key.encode(), int(value)))
+            set_options(key.encode(), int(value))
         device_seconds = sustained(launch, synchronize)
         shape = [ctypes.c_int() for _ in range(4)]
         lib.tc_table_last_launch(timer_handle, *[ctypes.byref(v) for v in shape])
         # (the pipelined calls of device_calls_per_sec: one launch per call where the library
-        # chose predict_fused_kernel -- no slabs of partial sums --, else the three kernels)
-        pipelined = ('one launch per call: predict_fused_kernel, %d workgroups of %d waves'
-                     % (shape[0].value, shape[1].value)
-                     if shape[2].value == 0 and shape[1].value > 0
-                     else 'occupation, contraction, finalisation kernels')
+        # chose a one-launch form -- no slabs of partial sums --, else the three kernels)
+        one_launch = shape[2].value == 0 and shape[1].value > 0
+        pipelined = ('one launch per call: %s, %d workgroups of %d waves'
+                     % (fused_kernel or 'one-launch kernel', shape[0].value, shape[1].value)
+                     if one_launch else 'occupation, contraction, finalisation kernels')
+        # the dominant kernel of THAT stream of calls: per-launch start / stop events, launches
+        # of different lanes overlapping as in the timed region
+        pipelined_ms, n_pipelined, pipelined_wall_ms = kernel_time(
+            lib, _lib, timer_handle, launch, synchronize, n_launches=300, max_seconds=0.6)
+        # ... and the three-kernel form, kernels serialised (one lane, one-launch forms off)
         _lib.check(lib.tc_table_set_option(timer_handle, b'pipeline', 0))
+        user_fused = dict(o.split('=') for o in options).get('fused', '1')
+        set_options(b'fused', 0)
         kernel_ms, n_launch, _ = kernel_time(lib, _lib, timer_handle, launch, synchronize,
                                              n_launches=300, max_seconds=0.6)
+        set_options(b'fused', int(user_fused))
         _lib.check(lib.tc_table_set_option(timer_handle, b'pipeline', 1))
         host_seconds = time_calls(host_call, seconds=0.4, warm=3)
-        achieved = flop / (kernel_ms * 1e-3) / 1e12
-        traffic, source = pmc_traffic(kernel, tag)
         launch()
         synchronize()
-        out[name] = {
+        ran = fused_kernel if one_launch and fused_kernel else kernel
+        traffic, source = pmc_traffic(ran, tag)
+        concurrency = pipelined_ms / pipelined_wall_ms
+        record = {
             'workload': what, 'tag': tag, 'dtype': dtype, 'draws_per_call': n_draws,
             'device_calls_per_sec': n_draws / device_seconds,
+            'us_per_step': device_seconds * 1e6,
             'device_calls_run_as': pipelined,
             'host_to_host_calls_per_sec': n_draws / host_seconds,
-            'kernel': kernel, 'kernel_us': kernel_ms * 1e3, 'launches_timed': n_launch,
-            'flop_per_launch': flop, 'achieved_tflops': achieved, 'peak_tflops': peak,
-            'frac': achieved / peak,
+            'kernel': ran,
+            'kernel_us': pipelined_ms * 1e3, 'launches_timed': n_pipelined,
+            'concurrent_launches': concurrency,
+            'kernel_method': 'per-launch start/stop events (hipExtLaunchKernelGGL) in the '
+                             'pipelined stream of calls of device_calls_per_sec; launches of '
+                             'different lanes overlap: concurrent_launches = kernel_us / wall '
+                             'time per launch',
+            'flop_per_launch': flop, 'peak_tflops': peak,
+            'frac_by_duration': flop / (pipelined_ms * 1e-3) / 1e12 / peak,
+            'frac': flop / (pipelined_ms / max(concurrency, 1.0) * 1e-3) / 1e12 / peak,
+            'frac_method': 'flop_per_launch / (kernel_us / concurrent_launches) / peak: a '
+                           "launch's share of the chip; frac_by_duration = flop_per_launch / "
+                           'kernel_us / peak',
             'step_frac': flop / device_seconds / 1e12 / peak,
+            'three_kernel_path': {
+                'kernel': kernel, 'kernel_us': kernel_ms * 1e3, 'launches_timed': n_launch,
+                'frac': flop / (kernel_ms * 1e-3) / 1e12 / peak,
+                'note': 'dominant kernel of the three-kernel form, kernels serialised (one '
+                        'lane, one-launch forms off): flop_per_launch / kernel_us / peak'},
             'traffic': traffic, 'traffic_source': source,
             'parity_max_rel_vs_oracle': parity(), 'cpu_baseline': cpu}
+        insts = pmc_counter(ran, 'SQ_INSTS_VALU', tag)
+        if insts is not None:
+            # vector-ALU issue: one wave instruction occupies its SIMD for 4 cycles
+            record['valu'] = {
+                'wave_instructions_per_launch': insts,
+                'frac': insts * 4.0 / (1024 * device_seconds * 2.4e9),
+                'what': 'SQ_INSTS_VALU per launch of %s (%s) x 4 cycles / (1024 SIMDs x step '
+                        'time x 2.4 GHz): share of the vector issue slots of the timed region '
+                        'this kernel fills' % (ran, os.path.relpath(pmc_file(tag), REPO))}
+            mfma = pmc_counter(ran, 'SQ_VALU_MFMA_BUSY_CYCLES', tag)
+            if mfma is not None:
+                record['valu']['matrix_pipe_busy'] = mfma / (1024 * device_seconds * 2.4e9)
+        record['bound'] = bound
+        out[name] = record
 
     def rel(actual, expect, floor=1e-14):
         scale = floor * np.max(np.abs(expect))
@@ -1007,7 +1112,8 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
                 'tc::contract_quad_kernel<5, false>', 'f64',
                 cpu_rate(lambda i: oracle.predict_zheng07(
                     table3, theta7[i % 10000, :5], separate_gal_type=True,
-                    assembias=theta7[i % 10000, 5:], cache=cache3)), parity3)
+                    assembias=theta7[i % 10000, 5:], cache=cache3)), parity3,
+                fused_kernel='tc::predict_fused_kernel<10, 5, true, false, false, 8, 32, true>')
         del tab3
 
     # configs[3]: one GPU's share (12 500 draws) of the 5 x 5 interpolator
@@ -1044,6 +1150,158 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
                 cpu_rate(lambda i: oracle.interpolator_predict(
                     tables, setup, oracle.Zheng07(theta4[i % n4]), x4[i % n4])), parity4)
         del interp, idev
+
+    # ---- the reference's own table shapes (throughput evidence on them) ----------
+    golden = os.path.join(REPO, 'tests', 'golden')
+    valu_peak = 1024 * 2.4e9 / 4 * 1e-12     # wave instructions per second (x 1e-12)
+
+    # the reference's AbacusSummit fixture (tests/AbacusSummit/.../ds_efficient.hdf5): mode
+    # cross, G = 1104 (280 mass bins x 2 percentile bins x {cen, sat}), 13 r values, a 4-table
+    # interpolator over log_eta -- the step is all occupations (vector ALU), one launch per call
+    if wanted('ds4') or wanted('ds1'):
+        from tabcorr_amd import TabCorr
+        interp = Interpolator.read(os.path.join(golden, 'ds_efficient.hdf5'))
+        rng = np.random.default_rng(0)
+        theta_ds = theta.copy()
+        theta_ds[:, 0] = rng.uniform(12.5, 13.3, 10000)     # (a sample this table resolves)
+        theta_ds[:, 3] = rng.uniform(13.6, 14.4, 10000)
+        x_ds = np.ascontiguousarray(np.stack(
+            [rng.uniform(xp[0], xp[-1], size=10000) for xp in interp.xp], axis=-1))
+        ds_tables = [{'gal_type': t.gal_type.as_array(), 'tpcf_matrix': t.tpcf_matrix,
+                      'tpcf_shape': t.tpcf_shape, 'attrs': t.attrs}
+                     for t in interp.tabcorr_list]
+        n_bins_ds, n_r_ds = len(ds_tables[0]['gal_type']), 13
+        d_theta_ds, d_x_ds = dev.upload(theta_ds), dev.upload(x_ds)
+        d_ngal_ds, d_xi_ds = dev.malloc(10000), dev.malloc(10000 * n_r_ds)
+        ends_ds = np.r_[0:2, 9998:10000]
+        # (the survey's accounting: contraction 2 R G + G per table, occupations 4 G n_gauss)
+        flop_table = 2.0 * n_r_ds * n_bins_ds + n_bins_ds
+        flop_occ = 4.0 * n_bins_ds * N_GAUSS
+        if wanted('ds4'):
+            idev = interp.to_device()
+            # (row k of the grid table describes tabcorr_list[tabcorr_index[k]])
+            points = np.zeros((len(ds_tables), len(interp.keys)))
+            index = np.asarray(interp.param_dict_table['tabcorr_index'], dtype=int)
+            for d, key in enumerate(interp.keys):
+                points[index, d] = np.asarray(interp.param_dict_table[key], dtype=float)
+            setup = oracle.interpolator_setup(ds_tables, points)
+
+            def parity_ds4():
+                expect = oracle.interpolator_predict_zheng07_batch(
+                    ds_tables, setup, theta_ds[ends_ds], x_ds[ends_ds])
+                return max(rel(dev.download(d_ngal_ds, 10000)[ends_ds], expect[0]),
+                           rel(dev.download(d_xi_ds, 10000 * n_r_ds).reshape(
+                               10000, n_r_ds)[ends_ds], expect[1], floor=1e-12))
+            measure('reference fixture: AbacusSummit interpolator', 'ds4',
+                    "the reference's tests/AbacusSummit/base_c000_ph000/0p50/ds_efficient.hdf5: "
+                    'Interpolator over 4 tables, mode cross, G=1104 (280 mass x 2 percentile '
+                    'bins x {cen,sat}), 13 r values, 10^4 draws', idev.tables[0].handle,
+                    lambda: _lib.check(lib.tc_interp_predict_zheng07_batch_device(
+                        idev.handle, d_theta_ds, 5, d_x_ds, 10000, N_GAUSS, 0, d_ngal_ds,
+                        d_xi_ds)),
+                    lambda: _lib.check(lib.tc_interp_synchronize(idev.handle)),
+                    lambda: interp.predict_batch(theta_ds, x_ds), 10000,
+                    10000 * (4 * flop_table + flop_occ), FP64_PEAK_TFLOPS,
+                    'tc::occ_zheng07_kernel<10, false, false, true>', 'f64',
+                    cpu_rate(lambda i: oracle.interpolator_predict(
+                        ds_tables, setup, oracle.Zheng07(theta_ds[i % 10000]),
+                        x_ds[i % 10000])), parity_ds4,
+                    fused_kernel='tc::predict_cross_fused_kernel<8, false, false>',
+                    bound='valu')
+            del idev
+        if wanted('ds1'):
+            tab_ds = interp.tabcorr_list[0]
+            h_ds = tab_ds.to_device().handle
+            cache_ds = {}
+
+            def parity_ds1():
+                expect = oracle.predict_zheng07_batch(ds_tables[0], theta_ds[ends_ds])
+                return max(rel(dev.download(d_ngal_ds, 10000)[ends_ds], expect[0]),
+                           rel(dev.download(d_xi_ds, 10000 * n_r_ds).reshape(
+                               10000, n_r_ds)[ends_ds], expect[1]))
+            measure('reference fixture: AbacusSummit table', 'ds1',
+                    'the first table of that file by itself: mode cross, G=1104, 13 r values, '
+                    '10^4 draws', h_ds,
+                    lambda: _lib.check(lib.tc_predict_zheng07_batch_device(
+                        h_ds, d_theta_ds, 5, 10000, N_GAUSS, 0, d_ngal_ds, d_xi_ds)),
+                    lambda: _lib.check(lib.tc_table_synchronize(h_ds)),
+                    lambda: tab_ds.predict_batch(theta_ds), 10000,
+                    10000 * (flop_table + flop_occ), FP64_PEAK_TFLOPS,
+                    'tc::occ_zheng07_kernel<10, false, false, true>', 'f64',
+                    cpu_rate(lambda i: oracle.predict_zheng07(
+                        ds_tables[0], theta_ds[i % 10000], cache=cache_ds)), parity_ds1,
+                    fused_kernel='tc::predict_cross_small_kernel<false, false>', bound='valu')
+        del interp
+
+    # the reference's example table (docs/examples/bolplanck_wp.hdf5: G = 60, 19 r values)
+    if wanted('wp'):
+        from tabcorr_amd import TabCorr
+        tab_wp = TabCorr.read(os.path.join(golden, 'bolplanck_wp.hdf5'))
+        table_wp = {'gal_type': tab_wp.gal_type.as_array(), 'tpcf_matrix': tab_wp.tpcf_matrix,
+                    'tpcf_shape': tab_wp.tpcf_shape, 'attrs': tab_wp.attrs}
+        h_wp = tab_wp.to_device().handle
+        d_theta_wp = dev.upload(theta)
+        d_ngal_wp, d_xi_wp = dev.malloc(10000), dev.malloc(10000 * N_R)
+        ends_wp = np.r_[0:2, 9998:10000]
+        cache_wp = {}
+
+        def parity_wp():
+            expect = oracle.predict_zheng07_batch(table_wp, theta[ends_wp])
+            return max(rel(dev.download(d_ngal_wp, 10000)[ends_wp], expect[0]),
+                       rel(dev.download(d_xi_wp, 10000 * N_R).reshape(10000, N_R)[ends_wp],
+                           expect[1]))
+        measure('reference example: bolplanck wp table', 'wp',
+                "the reference's docs/examples/bolplanck_wp.hdf5 (BASELINE configs[0]'s table): "
+                '30 mass bins x {cen,sat} (G=60, P=1830), 19 rp bins, 10^4 draws', h_wp,
+                lambda: _lib.check(lib.tc_predict_zheng07_batch_device(
+                    h_wp, d_theta_wp, 5, 10000, N_GAUSS, 0, d_ngal_wp, d_xi_wp)),
+                lambda: _lib.check(lib.tc_table_synchronize(h_wp)),
+                lambda: tab_wp.predict_batch(theta), 10000, 10000 * pair_flops(60, N_R),
+                FP64_PEAK_TFLOPS, 'tc::contract_quad_kernel<5, false>', 'f64',
+                cpu_rate(lambda i: oracle.predict_zheng07(table_wp, theta[i % 10000],
+                                                          cache=cache_wp)), parity_wp,
+                fused_kernel='tc::predict_fused_kernel<10, 5, false, false, false, 8, 64, false>')
+        del tab_wp
+
+    # the layout of the reference's database (scripts/tabulate_snapshot.py:179-193: 30 mass bins x
+    # 2 percentile bins; tabcorr/database.py:56-59: grids of up to 4 x 4 x 4 tables)
+    if wanted('db'):
+        tables_db, keys_db, points_db = synthetic.synthetic_interpolator(
+            (4, 4, 4), 30, 2, (N_R, ), 'auto', seed=11)
+        interp_db = Interpolator([make(t) for t in tables_db],
+                                 {k: points_db[:, d] for d, k in enumerate(keys_db)})
+        n_db = 10000
+        rng = np.random.default_rng(12)
+        x_db = np.ascontiguousarray(np.stack(
+            [rng.uniform(xp[0], xp[-1], size=n_db) for xp in interp_db.xp], axis=-1))
+        idev_db = interp_db.to_device()
+        d_theta_db, d_x_db = dev.upload(theta), dev.upload(x_db)
+        d_ngal_db, d_xi_db = dev.malloc(n_db), dev.malloc(n_db * N_R)
+        setup_db = oracle.interpolator_setup(tables_db, points_db)
+        ends_db = np.r_[0:1, n_db - 1:n_db]
+
+        def parity_db():
+            expect = oracle.interpolator_predict_zheng07_batch(tables_db, setup_db,
+                                                               theta[ends_db], x_db[ends_db])
+            return max(rel(dev.download(d_ngal_db, n_db)[ends_db], expect[0]),
+                       rel(dev.download(d_xi_db, n_db * N_R).reshape(n_db, N_R)[ends_db],
+                           expect[1], floor=1e-12))
+        measure('reference database layout', 'db',
+                'Interpolator over a 4 x 4 x 4 grid (tabcorr/database.py:56-59) of synthetic auto '
+                'tables with 30 mass x 2 percentile bins x {cen,sat} (G=120, P=7260; '
+                'scripts/tabulate_snapshot.py:179-193), 19 rp bins, 10^4 draws',
+                idev_db.tables[0].handle,
+                lambda: _lib.check(lib.tc_interp_predict_zheng07_batch_device(
+                    idev_db.handle, d_theta_db, 5, d_x_db, n_db, N_GAUSS, 0, d_ngal_db,
+                    d_xi_db)),
+                lambda: _lib.check(lib.tc_interp_synchronize(idev_db.handle)),
+                lambda: interp_db.predict_batch(theta, x_db), n_db,
+                n_db * 64 * pair_flops(120, N_R), FP64_PEAK_TFLOPS,
+                'tc::contract_quad_kernel<5, true>', 'f64',
+                cpu_rate(lambda i: oracle.interpolator_predict(
+                    tables_db, setup_db, oracle.Zheng07(theta[i % n_db]), x_db[i % n_db])),
+                parity_db)
+        del interp_db, idev_db
 
     # configs[4]: AbacusSummit-scale table, rp_pi (19 x 40), float32 MFMA variant and float64
     if wanted('cfg5f32') or wanted('cfg5f64'):

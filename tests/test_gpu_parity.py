@@ -453,7 +453,8 @@ def test_rccl_communicator_single_rank():
     _lib.check(lib.tc_comm_destroy(comm))
 
 
-@pytest.mark.parametrize('mode', ['default', 'chi2 gather', 'interp5x5', 'interp5x5 chi2'])
+@pytest.mark.parametrize('mode', ['default', 'both payloads', 'chi2 gather', 'interp5x5',
+                                  'interp5x5 chi2'])
 def test_bench_under_torchrun_single_rank(mode):
     """bench.py as the driver launches it (torch.distributed.run), one rank, with the
     communicator forced on: gloo control plane next to the HIP library, RCCL gather per
@@ -464,6 +465,8 @@ def test_bench_under_torchrun_single_rank(mode):
     from util import REPO
     env = dict(os.environ, TABCORR_AMD_FORCE_COMM='1', MASTER_ADDR='127.0.0.1')
     extra = {'default': ['--steps', '20', '--warmup', '3'],
+             'both payloads': ['--steps', '20', '--warmup', '3', '--second-payload', '1',
+                               '--gather-every', '5'],
              'chi2 gather': ['--steps', '20', '--warmup', '3', '--gather', 'chi2'],
              'interp5x5': ['--workload', 'interp5x5', '--draws', '12500', '--steps', '6',
                            '--warmup', '2', '--gather-every', '2'],
@@ -488,6 +491,16 @@ def test_bench_under_torchrun_single_rank(mode):
         assert record['roofline']['kernel'] == 'tc::contract_quad_kernel<5, true>'
     if mode.endswith('chi2') or mode == 'chi2 gather':
         assert '16 B' in record['config']['gather_payload']
+    else:
+        assert '160 B' in record['config']['gather_payload']
+    assert record['value_definition'] == 'device-resident'
+    assert 0.05 < record['roofline']['frac_by_duration'] <= record['roofline']['frac'] * 1.001
+    if mode == 'both payloads':
+        # (what --gpus > 1 times by default: the full results, then the likelihood payload in a
+        # second region of the same run)
+        second = record['second_payload']
+        assert '16 B' in second['gather_payload'] and second['value'] > 1e6
+        assert second['steps'] == record['steps']
 
 
 def test_read_hdf5_and_predict():

@@ -2,7 +2,7 @@
 # Copy the artefacts tools/profile_round.sh collected (gpurun_out/profile) into profiles/.
 # Usage: tools/install_profiles.sh [round tag, default r03]
 cd "$(dirname "$0")/.." || exit 1
-R=${1:-r03}
+R=${1:-r04}
 P=gpurun_out/profile
 HEAD1="# rocprofv3 --pmc passes (separate runs, --kernel-trace only; tools/profile_round.sh): python3 bench.py"
 HEAD2="# FETCH_SIZE / WRITE_SIZE in KB per launch (FETCH_SIZE under-reports wide coalesced reads 2x on gfx950); other counters raw"
@@ -16,13 +16,13 @@ if [ -f $P/pmc_summary.txt ]; then
   (echo "$HEAD1 --steps 50 --warmup 5 --cpu-seconds 0 --other-configs 0"; echo "$HEAD2"
    grep -v copyBuffer $P/pmc_summary.txt) > profiles/${R}_pmc_counters.txt
 fi
-for tag in cfg3 cfg4 cfg5f32 cfg5f64; do
+for tag in cfg3 cfg4 cfg5f32 cfg5f64 ds4 ds1 wp db; do
   for mode in lanes1 pipelined; do
     [ -f $P/kernel_stats_${tag}_$mode.csv ] && cp $P/kernel_stats_${tag}_$mode.csv profiles/${R}_${tag}_kernel_stats_$mode.csv
     [ -f $P/kernel_stats_${tag}_$mode.json ] && cp $P/kernel_stats_${tag}_$mode.json profiles/${R}_${tag}_under_rocprof_$mode.json
   done
   if [ -f $P/pmc_summary_${tag}.txt ]; then
-    (echo "$HEAD1 --only-config $tag --lanes 1 --cpu-seconds 0"; echo "$HEAD2"
+    (echo "$HEAD1 --only-config $tag --cpu-seconds 0"; echo "$HEAD2"
      grep -v copyBuffer $P/pmc_summary_${tag}.txt) > profiles/${R}_pmc_counters_${tag}.txt
   fi
 done

@@ -16,12 +16,13 @@ FAST="--cpu-seconds 0 --other-configs 0"
 pmc_passes() {   # $1 = output stem, rest = bench arguments
   local stem=$1; shift
   local i=0
-  for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
-             "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64" \
+  for set in "FETCH_SIZE" "WRITE_SIZE" \
+             "SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES" \
+             "TCC_HIT_sum TCC_MISS_sum" \
              "TA_TA_BUSY_sum SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" \
-             "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
+             "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU"; do
     i=$((i+1))
-    [ "$PMC_SHORT" = 1 ] && [ $i -gt 4 ] && break
+    [ "$PMC_SHORT" = 1 ] && [ $i -gt 3 ] && break
     rm -rf $OUT/pmc_$i
     rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_$i -- \
       python3 bench.py "$@" > $OUT/pmc_$i.log 2>&1
@@ -61,10 +62,13 @@ if [ $WHAT = main ] || [ $WHAT = all ]; then
   pmc_passes pmc_summary --steps 50 --warmup 5 $FAST
 fi
 if [ $WHAT = configs ] || [ $WHAT = all ]; then
-  for tag in cfg3 cfg4 cfg5f32 cfg5f64; do
+  # (TAGS="cfg3 ds4" ... selects; the PMC passes run with the default lanes so that the
+  # one-launch forms are what the pipelined calls take -- the profiler serialises the
+  # dispatches itself --, and bench.py's own serialised pass adds the three kernels)
+  for tag in ${TAGS:-cfg3 cfg4 cfg5f32 cfg5f64 ds4 ds1 wp db}; do
     kernel_stats kernel_stats_${tag}_lanes1 --only-config $tag --lanes 1 --cpu-seconds 0
     kernel_stats kernel_stats_${tag}_pipelined --only-config $tag --cpu-seconds 0
-    PMC_SHORT=1 pmc_passes pmc_summary_${tag} --only-config $tag --lanes 1 --cpu-seconds 0
+    PMC_SHORT=1 pmc_passes pmc_summary_${tag} --only-config $tag --cpu-seconds 0
   done
 fi
 ls -la $OUT
