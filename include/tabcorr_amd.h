@@ -16,7 +16,11 @@
  *   - functions with the suffix _device take DEVICE pointers, enqueue work on the
  *     handle's stream and return without synchronising (tc_*_synchronize waits).
  *   - a handle is bound to the HIP device that was current when it was created and
- *     must be used by one host thread at a time.
+ *     must be used by one host thread at a time.  An interpolator handle works THROUGH the
+ *     table handles it was created from (their caches, lanes, timers and fused-likelihood
+ *     state): a call on the interpolator must not run concurrently with a call on any of
+ *     its tables either (the Python classes take the tables' locks with the
+ *     interpolator's).
  *   - there is no CPU fallback: every compute entry point fails with TC_ERR_HIP when
  *     no gfx950 device is usable.
  */

@@ -94,7 +94,10 @@ bool is_pinned(const void* ptr, size_t bytes, void** device_ptr) {
   if (it == g_pinned.begin()) return false;
   --it;
   if (begin < it->first || begin + bytes > it->first + it->second.bytes) return false;
-  if (device_ptr != nullptr) *device_ptr = (void*)(it->second.device + (begin - it->first));
+  // (a range without a device address -- hipHostGetDevicePointer failed at registration -- has
+  // none anywhere inside it: the callers then fall back to copy commands)
+  if (device_ptr != nullptr && it->second.device != 0)
+    *device_ptr = (void*)(it->second.device + (begin - it->first));
   return true;
 }
 
@@ -199,6 +202,22 @@ int tc_host_free(void* ptr) {
 
 int tc_host_register(void* ptr, size_t bytes) {
   TC_CHECK(ptr != nullptr && bytes > 0, "invalid range");
+  {
+    // ranges must not overlap one another: a second registration of the same memory would
+    // silently replace the first entry (and its unregistration strand the other)
+    const uintptr_t begin = (uintptr_t)ptr;
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    auto next = g_pinned.lower_bound(begin);
+    if (next != g_pinned.end() && next->first < begin + bytes)
+      return fail(TC_ERR_INVALID, "tc_host_register: the range overlaps a page-locked range "
+                  "the library already knows");
+    if (next != g_pinned.begin()) {
+      auto previous = std::prev(next);
+      if (previous->first + previous->second.bytes > begin)
+        return fail(TC_ERR_INVALID, "tc_host_register: the range overlaps a page-locked range "
+                    "the library already knows");
+    }
+  }
   TC_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
   void* device = nullptr;
   if (hipHostGetDevicePointer(&device, ptr, 0) != hipSuccess) device = nullptr;

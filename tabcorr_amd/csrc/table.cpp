@@ -210,7 +210,9 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
     const int n_central = t->plan.n_central;
     // (... and for every float64 table with a single r tile: predict_fused_kernel walks the
     // whole triangle as one component)
-    const bool fusable = !quad_f32 && quad_tiling.n_rtiles == 1;
+    // (only where that kernel can ever take the table -- launch.hip: fused_eligible --: up to
+    // 20 r values, up to 248 bins; a second copy of the matrix otherwise serves nobody)
+    const bool fusable = !quad_f32 && quad_tiling.n_rtiles == 1 && n_r <= 20 && n_bins <= 248;
     if (status == TC_OK && ((n_central % 4 != 0 && n_central < n_bins) || fusable))
       status = build_quad_table(t.get(), false, tpcf_matrix, matrix_dtype, &t->quad_total);
   }

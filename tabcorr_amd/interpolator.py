@@ -47,6 +47,45 @@ def _columns(param_dict_table):
     return names, [np.asarray(array[n], dtype=np.float64) for n in names]
 
 
+class _HandleLocks:
+    """The lock of an interpolator handle: its own and those of its tables.
+
+    ``tc_interp_*`` calls use the table handles they were created from (the
+    quadrature and schedule caches, the fused-likelihood state and the kernel
+    timer of the first table, the lanes of every class representative), so a
+    call on the interpolator must exclude calls on any of its tables
+    (``include/tabcorr_amd.h``).  The table locks are taken in a fixed global
+    order, so that two interpolators sharing tables cannot deadlock."""
+
+    def __init__(self, tables):
+        unique = {id(t.lock): t.lock for t in tables}
+        self._locks = [threading.RLock()] + [unique[k] for k in sorted(unique)]
+
+    def __enter__(self):
+        for lock in self._locks:
+            lock.acquire()
+        return self
+
+    def __exit__(self, *exc):
+        for lock in reversed(self._locks):
+            lock.release()
+        return False
+
+    def acquire(self, blocking=True):
+        taken = []
+        for lock in self._locks:
+            if not lock.acquire(blocking):
+                for held in reversed(taken):
+                    held.release()
+                return False
+            taken.append(lock)
+        return True
+
+    def release(self):
+        for lock in reversed(self._locks):
+            lock.release()
+
+
 class _DeviceInterpolator:
 
     def __init__(self, interpolator):
@@ -62,8 +101,9 @@ class _DeviceInterpolator:
         self.handle = handle
         self.lib = lib
         self.tables = devices          # keep the table handles alive
-        # one host thread at a time per handle (see tabcorr._DeviceTable)
-        self.lock = threading.Lock()
+        # one host thread at a time per handle (see tabcorr._DeviceTable),
+        # the handles of the tables included
+        self.lock = _HandleLocks(devices)
         # scratch of the un-batched predict(model) path (see
         # tabcorr._DeviceTable.predict_one)
         self._one_theta = np.zeros(16)

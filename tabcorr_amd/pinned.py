@@ -110,7 +110,8 @@ class _Pool:
 
     def __init__(self):
         self.free = {}
-        self.lock = threading.Lock()
+        self.lock = threading.RLock()     # (re-entrant: PendingPrediction.__del__ may run
+                                          # inside take / give on the same thread)
 
     def take(self, shape):
         count = int(np.prod(shape, dtype=np.int64))

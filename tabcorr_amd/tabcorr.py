@@ -87,8 +87,10 @@ class _DeviceTable:
         self.compute_dtype = compute_dtype
         # A handle serves one host thread at a time (include/tabcorr_amd.h);
         # ctypes releases the GIL during a call, so every call on this handle
-        # -- and the scratch arrays of predict_one -- sits behind this lock.
-        self.lock = threading.Lock()
+        # -- and the scratch arrays of predict_one -- sits behind this lock
+        # (re-entrant: a pending asynchronous call finalised by the garbage
+        # collector inside a locked region waits on the same thread).
+        self.lock = threading.RLock()
         # scratch of the un-batched predict(model) path: one draw in, one
         # (ngal, xi) out, with the ctypes pointers made once
         self._one_theta = np.zeros(16)

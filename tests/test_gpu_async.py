@@ -221,6 +221,62 @@ def test_threads_share_one_table():
     assert errors == []
 
 
+def test_threads_share_a_table_with_its_interpolator():
+    """an interpolator works through the handles of its tables (the fused-likelihood
+    state and caches of the first one): its lock includes theirs, so chi2 calls on the
+    interpolator and predictions on its first table from other threads do not mix."""
+    from tabcorr_amd import Interpolator, synthetic
+    from oracle import tabcorr_oracle as oracle
+    tables, keys, points = synthetic.synthetic_interpolator((4, ), 12, 1, (7, ), 'auto', seed=3)
+    tabs = [make_tabcorr(t) for t in tables]
+    interp = Interpolator(tabs, {k: points[:, d] for d, k in enumerate(keys)})
+    theta = synthetic.zheng07_draws(300, seed=4)
+    x = np.random.default_rng(5).uniform(points.min(), points.max(), (300, 1))
+    setup = oracle.interpolator_setup(tables, points)
+    expect_interp = oracle.interpolator_predict_zheng07_batch(tables, setup, theta[:40], x[:40])
+    expect_table = oracle.predict_zheng07_batch(tables[0], theta[:40])
+    vector = np.full(7, float(np.mean(expect_interp[1])))
+    precision = np.eye(7) / np.mean(vector)**2
+    want = np.einsum('bi,ij,bj->b', expect_interp[1] - vector, precision,
+                     expect_interp[1] - vector)
+    errors = []
+
+    def chi2_calls():
+        for _ in range(30):
+            ngal, chi2 = interp.chi2_batch(theta, x, vector, precision)
+            if not np.allclose(chi2[:40], want, rtol=1e-8):
+                errors.append('interpolator chi2')
+
+    def table_calls():
+        for _ in range(30):
+            ngal, xi = tabs[0].predict_batch(theta)
+            if not np.allclose(xi[:40], expect_table[1], rtol=1e-10):
+                errors.append('table xi')
+
+    threads = [threading.Thread(target=f) for f in (chi2_calls, table_calls, chi2_calls)]
+    for thread in threads:
+        thread.start()
+    for thread in threads:
+        thread.join()
+    assert errors == []
+
+
+def test_overlapping_registrations_are_rejected():
+    """a second tc_host_register of memory the registry already knows would replace
+    the first entry; it is refused instead."""
+    from tabcorr_amd import pin, is_pinned
+    own = np.zeros(4096)
+    with pin(own):
+        for view in (own, own[100:200], own[-8:]):
+            with pytest.raises(ValueError):
+                with pin(view):
+                    pass
+        assert is_pinned(own)
+    assert not is_pinned(own)
+    with pin(own[:2048]), pin(own[2048:]):          # adjacent ranges are fine
+        assert is_pinned(own[:2048]) and is_pinned(own[2048:])
+
+
 def test_many_walkers_in_one_launch():
     """tc_predict_zheng07_many: n independent draws through ONE launch of the un-batched
     kernel, completion polled in host memory -- against the golden vectors, the oracle and

@@ -966,3 +966,52 @@ def test_node_groups_of_bins_that_share_their_quadrature_nodes():
     hi = np.asarray(gal_type['log_prim_haloprop_max'])[order]
     groups, n_cen = check(lo, hi, int(np.sum(central)))
     assert len(lo) == 1104 and len(groups) == 560 and max(len(g) for g in groups) == 2
+
+
+def test_interpolator_lock_includes_its_tables():
+    """the lock of an interpolator handle takes the locks of its tables as well, in
+    one global order (two interpolators sharing tables cannot deadlock), and is re-entrant."""
+    import threading
+    from tabcorr_amd.interpolator import _HandleLocks
+
+    class Table:
+        def __init__(self):
+            self.lock = threading.RLock()
+
+    a, b, c = Table(), Table(), Table()
+    first, second = _HandleLocks([a, b, a]), _HandleLocks([b, c, a])
+    assert len(first._locks) == 3 and len(second._locks) == 4
+    with first:
+        with first:                                  # re-entrant on the same thread
+            pass
+        got = []
+        thread = threading.Thread(target=lambda: got.append(a.lock.acquire(False)))
+        thread.start()
+        thread.join()
+        assert got == [False]                        # a table of the interpolator is locked
+        thread = threading.Thread(target=lambda: got.append(second.acquire(False)))
+        thread.start()
+        thread.join()
+        assert got == [False, False]
+        def try_unrelated():
+            got.append(c.lock.acquire(False))
+            c.lock.release()
+        thread = threading.Thread(target=try_unrelated)
+        thread.start()
+        thread.join()
+        assert got == [False, False, True]           # (an unrelated table is not)
+    order = [id(lock) for lock in second._locks[1:]]
+    assert order == sorted(order)
+    done = []
+
+    def hammer(locks):
+        for _ in range(2000):
+            with locks:
+                pass
+        done.append(1)
+    threads = [threading.Thread(target=hammer, args=(l, )) for l in (first, second, first)]
+    for thread in threads:
+        thread.start()
+    for thread in threads:
+        thread.join(timeout=60)
+    assert len(done) == 3
