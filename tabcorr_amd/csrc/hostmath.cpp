@@ -359,7 +359,8 @@ std::vector<int32_t> number_slabs_by_group(const std::vector<int32_t>& slab_grou
 void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, int n_tables,
                          bool separate, int max_waves, int min_units_per_wave,
                          QuadSchedule& out, int order) {
-  const bool table_major = order == kQuadTableMajor;
+  bool table_sync = order == kQuadTableSync && std::max(1, n_tables) > 1;
+  const bool table_major = order == kQuadTableMajor || order == kQuadTableSync;
   const bool rtile_major = order == kQuadRtileMajor && n_rtiles > 1;
   const bool unit_major = order == kQuadUnitMajor && std::max(1, n_tables) == 1;
   out.runs.clear();
@@ -379,6 +380,10 @@ void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, in
   if (total == 0) n_waves = 0;
   out.n_waves = (int)n_waves;
   out.group_begin.assign((size_t)out.n_groups + 1, 0);
+  // table-synchronous: needs whole eighths of the waves (else plain table-major)
+  table_sync = table_sync && n_waves >= 8 && n_waves % 8 == 0;
+  const int64_t per_xcd = table_sync ? n_waves / 8 : 1;
+  const int64_t per_table_span = layout.n_units * n_rtiles * (int64_t)n_tiles;
 
   // position -> (tile, rtile, comp, table, unit in component)
   int slab = 0;
@@ -386,10 +391,29 @@ void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, in
   for (int64_t w = 0; w < n_waves; ++w) {
     out.wave_runs.push_back((int32_t)out.runs.size());
     const size_t first_run = out.runs.size();
-    for (int pass = 0; pass < n_passes; ++pass) {
-    // (128-bit product: span * w can exceed 63 bits for huge batches of huge tables)
-    int64_t begin = (int64_t)((__int128)span * w / n_waves);
-    const int64_t end = (int64_t)((__int128)span * (w + 1) / n_waves);
+    // the wave's intervals of the linearised space: one (per r tile in r-tile-major order), or
+    // -- table-synchronous -- its slice of every table piece of its XCD's range
+    std::vector<std::pair<int64_t, int64_t>> intervals;
+    if (table_sync) {
+      const int64_t xcd = w / per_xcd, local = w % per_xcd;
+      const int64_t lo = (int64_t)((__int128)total * xcd / 8);
+      const int64_t hi = (int64_t)((__int128)total * (xcd + 1) / 8);
+      for (int64_t a = lo; a < hi;) {
+        const int64_t b = std::min(hi, (a / per_table_span + 1) * per_table_span);
+        intervals.emplace_back(a + (int64_t)((__int128)(b - a) * local / per_xcd),
+                               a + (int64_t)((__int128)(b - a) * (local + 1) / per_xcd));
+        a = b;
+      }
+    } else {
+      // (128-bit product: span * w can exceed 63 bits for huge batches of huge tables)
+      for (int pass = 0; pass < n_passes; ++pass)
+        intervals.emplace_back((int64_t)((__int128)span * w / n_waves),
+                               (int64_t)((__int128)span * (w + 1) / n_waves));
+    }
+    for (size_t pass_index = 0; pass_index < intervals.size(); ++pass_index) {
+    const int pass = (int)pass_index;
+    int64_t begin = intervals[pass_index].first;
+    const int64_t end = intervals[pass_index].second;
     while (begin < end) {
       int64_t tile_rtile, unit;
       int comp = 0, table;

@@ -201,7 +201,14 @@ struct QuadSchedule {
 // linearised space is (part, draw tile, r tile, units of the part) -- with an eighth of the
 // shares per XCD every L2 keeps ONE eighth of the matrix for all draw tiles.  An output group
 // then receives slabs from all eight parts.
-constexpr int kQuadTileMajor = 0, kQuadTableMajor = 1, kQuadRtileMajor = 2, kQuadUnitMajor = 3;
+// kQuadTableSync (interpolators whose matrices do not fit the L2s next to each other: the
+// reference's database grids of up to 4 x 4 x 4 tables): table-major, but the waves of an XCD
+// -- an eighth of the shares, `n_waves` a multiple of 8 -- walk the tables of that XCD's range ONE
+// AFTER THE OTHER, each wave taking an equal slice of every table's (draw tile, r tile, unit)
+// space in turn: at any time the XCD's waves read one matrix instead of all K / 8 of them
+// (64 tables of 120 bins: 12 MB per L2 of 4 MB, 23 GB of fabric reads per 10^4 draws).
+constexpr int kQuadTileMajor = 0, kQuadTableMajor = 1, kQuadRtileMajor = 2, kQuadUnitMajor = 3,
+              kQuadTableSync = 4;
 constexpr int kQuadUnitParts = 8;
 void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, int n_tables,
                          bool separate, int max_waves, int min_units_per_wave,

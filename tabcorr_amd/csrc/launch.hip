@@ -311,7 +311,14 @@ int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, 
   tc::QuadSchedule schedule;
   // (interpolators: table-major order; one matrix larger than an L2: r-tile-major; see
   // hostmath.h)
-  const int order = n_tables > 1 ? tc::kQuadTableMajor
+  // (interpolators: the waves of an XCD share its K / 8 matrices -- all at once while those fit
+  // its L2 next to the density rows, one after the other beyond ~3 MB: kQuadTableSync)
+  const bool many_matrices = (double)n_tables * (double)q->bytes / 8.0 > 3.0 * 1024 * 1024;
+  const int order = n_tables > 1 ? ((t->tuning.quad_order == tc::kQuadTableMajor ||
+                                     t->tuning.quad_order == tc::kQuadTableSync)
+                                        ? t->tuning.quad_order
+                                    : many_matrices ? tc::kQuadTableSync
+                                                    : tc::kQuadTableMajor)
                     : t->tuning.quad_order >= 0 ? t->tuning.quad_order
                     : (t->compute_dtype == TC_DTYPE_F64 && t->quad_tiling.n_rtiles > 1 &&
                        q->bytes > ((size_t)4 << 20))

@@ -208,3 +208,43 @@ def test_grouped_real_abacus_table_in_mode_cross():
         expect = oracle.predict_zheng07_batch(table, theta[:40], **oracle_kwargs)
         assert_rel(ngal[:40], expect[0], RTOL)
         assert_rel(xi[:40], expect[1], RTOL)
+
+
+@pytest.mark.parametrize('shape, n_prim, n_sec, n_r, n_draws, separate', [
+    ((4, 4), 12, 1, 7, 700, False),
+    ((4, 4, 4), 6, 2, 19, 300, False),       # the database's grid shape, 64 tables
+    ((5, ), 9, 1, 5, 4000, True),            # tables not a multiple of 8, separated
+])
+def test_interpolator_table_synchronous_schedule(shape, n_prim, n_sec, n_r, n_draws, separate):
+    """hostmath.h: kQuadTableSync -- the waves of an XCD walk its tables one after the other
+    (chosen for interpolators whose matrices do not fit the L2s side by side; forced here)
+    against the oracle and the table-major order."""
+    from tabcorr_amd import Interpolator, synthetic
+    from oracle import tabcorr_oracle as oracle
+    tables, keys, points = synthetic.synthetic_interpolator(shape, n_prim, n_sec, (n_r, ), 'auto',
+                                                            seed=n_prim)
+    interp = Interpolator([make_tabcorr(t) for t in tables],
+                          {k: points[:, d] for d, k in enumerate(keys)})
+    theta = synthetic.zheng07_draws(n_draws, seed=n_r)
+    rng = np.random.default_rng(n_draws)
+    x = np.stack([rng.uniform(xp[0], xp[-1], n_draws) for xp in interp.xp], axis=-1)
+    first = interp.to_device().tables[0]
+    results = {}
+    for order in (4, 1):
+        from tabcorr_amd import _lib
+        _lib.check(_lib.load().tc_table_set_option(first.handle, b'quad_order', order))
+        results[order] = interp.predict_batch(theta, x, separate_gal_type=separate)
+    setup = oracle.interpolator_setup(tables, points)
+    index = np.r_[0:6, n_draws - 6:n_draws]
+    expect = oracle.interpolator_predict_zheng07_batch(tables, setup, theta[index], x[index],
+                                                       separate_gal_type=separate)
+    if separate:
+        for key in expect[1]:
+            assert_rel(results[4][1][key][index], expect[1][key], RTOL, key, floor=1e-12)
+            assert_rel(results[4][1][key], results[1][1][key], 1e-11, key, floor=1e-12)
+        for key in expect[0]:
+            assert_rel(results[4][0][key][index], expect[0][key], RTOL, key)
+    else:
+        assert_rel(results[4][0][index], expect[0], RTOL)
+        assert_rel(results[4][1][index], expect[1], RTOL, floor=1e-12)
+        assert_rel(results[4][1], results[1][1], 1e-11, floor=1e-12)

@@ -797,6 +797,10 @@ def test_host_logic_under_address_and_undefined_sanitizers(tmp_path):
         (100, 50, 1, 7, 1, 25, 1, 2048, 1),
         (200, 100, 1, 40, 38, 1, 0, 2048, 2),     # configs[4] in float64: r-tile-major order
         (200, 100, 1, 313, 1, 1, 1, 2048, 3),     # configs[2]: unit-major order, separated
+        (120, 60, 0, 313, 1, 64, 0, 3072, 4),     # database grid 4 x 4 x 4: table-synchronous
+        (60, 30, 1, 37, 1, 25, 1, 1024, 4),       # ... tables not a multiple of 8, separated
+        (20, 10, 0, 3, 2, 5, 0, 64, 4),           # ... fewer tables than XCDs, two r tiles
+        (20, 10, 0, 3, 1, 5, 0, 30, 4),           # ... waves not a multiple of 8: table-major
         (200, 100, 1, 313, 1, 1, 0, 2048, 3),     # ... and the total
         (37, 20, 1, 5, 2, 1, 1, 64, 3),           # unit-major with parts smaller than a share
         (13, 5, 0, 3, 2, 1, 0, 64, 0),
@@ -818,7 +822,9 @@ def test_quad_schedule_covers_every_unit_once(lib, n_bins, n_central, by_type, n
         ctypes.byref(hi)))
     assert 1 <= n_waves.value <= max_waves
     # equal shares (per r tile in r-tile-major order: a unit of slack per pass)
-    assert hi.value - lo.value <= (n_rtiles if order == 2 else 1)
+    # (table-synchronous: a unit per table piece of an XCD's range)
+    assert hi.value - lo.value <= (n_rtiles if order == 2 else
+                                   n_tables // 8 + 2 if order == 4 else 1)
     assert n_slabs.value >= 1 and n_runs.value >= n_waves.value
 
 
