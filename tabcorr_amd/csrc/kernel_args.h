@@ -277,7 +277,7 @@ struct FusedArgs {
 
 // ---- mode cross, one launch per batch (predict_cross_fused_kernel, kernels.hip.h) ----------
 constexpr int kCrossWaves = 8;
-constexpr int kCrossChunkBins = 32;  // bins whose mean occupations one LDS buffer holds
+constexpr int kCrossChunkBins = 48;  // bins whose mean occupations one LDS buffer holds
 constexpr int kCrossMaxRows = 128;   // K (R + 1) of the largest instance (16 rows per wave)
 // LDS layout in doubles (launch.hip: run_cross_fused fills the offsets): math table, later the
 // spline weights / norms (K, 64) and the results tile (rows out, 65) when they fit there | two

@@ -2185,7 +2185,7 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_fused_kerne
             a.split, dp, [&](int mi, int, double nbar) { buffer[(mi - m0) * kLanes + lane] = nbar; });
       __syncthreads();
       // B. this wave's rows over every bin of the chunk
-#pragma unroll 4
+#pragma unroll 8
       for (int mi = m0; mi < m1; ++mi) {
         const double nbar = buffer[(mi - m0) * kLanes + lane];
         sc_f64 coefficient = rows + (int64_t)mi * ROWS;
