@@ -306,6 +306,15 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 a third faster there, and the one-launch form then pays from 12 draws per
  *                 bin on -- and for tables of 105 .. 208 bins, of 64 draws otherwise; 32 / 64:
  *                 forced.
+ *   "autotune"    value = the predict flags to tune for (a combination of TC_FLAG_*; 0 = the
+ *                 total prediction of plain Zheng07), n_gauss_prim = 10: MEASURES on this table,
+ *                 for batch sizes 256 .. 65536 (x 2 steps), which form serves a batch fastest in
+ *                 the pipelined regime -- three kernels, one launch with 64-draw or with 32-draw
+ *                 workgroups -- and keeps the choice in the handle (~0.5 s; draws from a wide
+ *                 prior box on scratch buffers).  Pipelined device-pointer and asynchronous
+ *                 calls with these flags then take the measured form of the nearest batch size
+ *                 instead of the built-in estimate (fitted on a handful of table shapes).  -1:
+ *                 forget every measurement.  tc_table_autotune_result reads it back.
  *   "grouped"     1 (default): bins with identical log_prim_haloprop_min / max and galaxy type
  *                 -- the secondary-percentile bins of one mass bin (tabcorr/tabcorr.py:186-205)
  *                 -- share their Gauss-Legendre nodes (:548-549); the occupation functions are
@@ -326,6 +335,12 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 0 (default): one launch per call.
  *   "trace"       developer timelines (developer builds only, tabcorr_amd_testing.h). */
 int tc_table_set_option(tc_table* table, const char* name, int value);
+/* What option "autotune" measured for `flags`: per batch size (`count` of them, at most
+ * `capacity`: 9) the form chosen (0 three kernels, 64 / 32: draws per workgroup of the
+ * one-launch form) and the microseconds per call of the three forms in that order, us
+ * (count, 3) (0: form not available). */
+int tc_table_autotune_result(const tc_table* table, unsigned flags, int capacity, int* count,
+                             int64_t* sizes, int* forms, float* us);
 
 /* ---- measurement -------------------------------------------------------------------
  * HIP events on the handle's own stream (torch.cuda.Event would only see torch's).

@@ -76,6 +76,8 @@ SIGNATURES = {
         ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p, c_double_p,
         c_double_p, c_double_p, c_uint8_p, ctypes.c_int, c_void_pp],
     'tc_table_destroy': [ctypes.c_void_p],
+    'tc_table_autotune_result': [ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, c_int_p,
+                                 c_int64_p, c_int_p, c_float_p],
     'tc_table_synchronize': [ctypes.c_void_p],
     'tc_table_info': [ctypes.c_void_p, c_int_p, c_int_p, c_int_p, c_int64_p,
                       c_int_p, c_int64_p],

@@ -8,6 +8,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -332,6 +333,40 @@ struct Tuning {
 }  // namespace host
 }  // namespace tc
 
+// Measured choice of the form a batch takes (option "autotune"; table.cpp: autotune): for a
+// grid of batch sizes the fastest of {three kernels, one launch with 64-draw workgroups, one
+// launch with 32-draw workgroups} in the pipelined regime, per combination of predict flags.
+// launch.hip: fused_eligible / fused_half_tiles ask it before their formula.
+struct AutoChoice {
+  static constexpr int kSizes = 9;
+  // batch sizes measured (geometric: a batch takes the choice of the nearest one)
+  static constexpr int64_t size(int i) { return (int64_t)256 << i; }      // 256 .. 65536
+  int form[kSizes] = {};         // 0 three kernels, 32 / 64 draws per workgroup of one launch
+  float us[kSizes][3] = {};      // measured us per call: three kernels, 64 draws, 32 draws
+  // The form for a batch of n draws: every form's time interpolated linearly between the two
+  // measured sizes around n (a form that is missing at either end is out; beyond the grid the
+  // nearest end decides), the fastest wins, a one-launch form only by 2 %.
+  int form_for(int64_t n_draws) const {
+    if (n_draws <= size(0)) return form[0];
+    if (n_draws >= size(kSizes - 1)) return form[kSizes - 1];
+    int i = 0;
+    while (size(i + 1) < n_draws) ++i;
+    const double w = (double)(n_draws - size(i)) / (double)(size(i + 1) - size(i));
+    static const int shape[3] = {0, 64, 32};
+    int best = 0;
+    double best_us = (1.0 - w) * us[i][0] + w * us[i + 1][0];
+    for (int k = 1; k < 3; ++k) {
+      if (us[i][k] <= 0.0f || us[i + 1][k] <= 0.0f) continue;
+      const double value = (1.0 - w) * us[i][k] + w * us[i + 1][k];
+      if (value < (best == 0 ? 0.98 : 1.0) * best_us) {
+        best_us = value;
+        best = shape[k];
+      }
+    }
+    return best;
+  }
+};
+
 struct tc_table {
   int device = 0;
   int mode = 0;
@@ -380,6 +415,7 @@ struct tc_table {
   int n_cus = 256;               // compute units of the device
   int n_xcds = 8;                // accelerator complexes (each with its own L2)
   tc::host::Tuning tuning;
+  std::map<unsigned, AutoChoice> autotuned;      // by predict flags (n_gauss_prim = 10)
   std::map<int, tc::host::Quadrature> quadrature;
   std::map<std::pair<int, int>, std::unique_ptr<tc::host::DeviceChunking>> chunkings;
   std::map<int64_t, tc::host::DeviceChunking*> choices;   // decomposition chosen per tile count

@@ -956,8 +956,11 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
 bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags) {
   // (asynchronous host calls: one command per call in the lane's chain pays for any size from
   // the lower bound on -- 20 000 draws 93.7 -> 82.6 us, 40 000 176 -> 162 us per call)
-  if (t->tuning.fused == 0 || (n_draws > t->tuning.fused_max_draws && t->async_lane < 0))
-    return false;
+  if (t->tuning.fused == 0) return false;
+  // (a measured choice -- option "autotune" -- knows where the one-launch form stops paying)
+  const bool tuned_flags = n_gauss == 10 && t->tuning.fused == 1 &&
+                           t->tuning.fused_min_draws == 0 && t->autotuned.count(flags) != 0;
+  if (n_draws > t->tuning.fused_max_draws && t->async_lane < 0 && !tuned_flags) return false;
   if (!t->quad || t->compute_dtype != TC_DTYPE_F64 || t->quad_total.d_table == nullptr)
     return false;
   if (t->quad_tiling.n_rtiles != 1 || t->n_r > 20 || t->chain || t->tuning.trace) return false;
@@ -988,6 +991,13 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
   // one-launch form (16 waves, up to 160 KB: 248 bins) is taken only when forced.
   const bool wide = fused_wide_tables(t, separate, n_gauss, flags);
   if (n_gauss < 1 || (!wide && fused_waves(t, separate) == 0)) return false;
+  // a measured choice for this table and these flags (option "autotune") replaces the formula
+  // below for the calls it was measured on: pipelined device-pointer and asynchronous calls
+  if (n_gauss == 10 && t->tuning.fused == 1 && t->tuning.fused_min_draws == 0) {
+    auto tuned = t->autotuned.find(flags);
+    const bool alone = t->force_lane >= 0 || !t->tuning.pipeline || t->n_lanes == 1;
+    if (tuned != t->autotuned.end() && !alone) return tuned->second.form_for(n_draws) != 0;
+  }
   // Smallest batch: a launch lasts as long as one workgroup does, whatever the batch, so the
   // one-launch form pays from the batch size on at which four lanes of such launches beat the
   // three kernels (which spread any batch over the whole chip).  Estimated duration of a
@@ -1071,6 +1081,13 @@ int fused_lds_bytes(const tc_table* t, bool separate, int waves, int draws) {
 // * Tables of 105-208 bins, whose 64-draw workgroup does not fit half a CU: any batch size.
 bool fused_half_tiles(const tc_table* t, bool separate, int64_t n_draws, int n_gauss,
                       unsigned flags) {
+  if (t->tuning.fused_draws == 0 && n_gauss == 10 && t->tuning.fused == 1 &&
+      t->tuning.fused_min_draws == 0) {
+    auto tuned = t->autotuned.find(flags);      // (measured: option "autotune")
+    if (tuned != t->autotuned.end() && tuned->second.form_for(n_draws) != 0)
+      return tuned->second.form_for(n_draws) == 32 &&
+             fused_lds_bytes(t, separate, 8, 32) <= 80 * 1024;
+  }
   if (t->tuning.fused_draws == 64 || (t->tuning.fused_draws == 0 && n_draws >= 8192))
     return false;
   if (n_gauss != 10) return false;

@@ -844,6 +844,141 @@ int tc_predict_occupation_batch(tc_table* t, const double* occupation,
   return TC_OK;
 }
 
+namespace {
+
+// Option "autotune": which form serves a batch of n draws fastest on THIS table in the
+// pipelined regime -- three kernels, one launch with 64-draw workgroups, one launch with
+// 32-draw workgroups --, measured for a grid of batch sizes with draws from a wide prior box and
+// kept in the handle (internal.h: AutoChoice).  `flags`: the predict flags to tune for.
+int autotune(tc_table* t, unsigned flags) {
+  TC_CHECK(!(flags & ~(TC_FLAG_SEPARATE_GAL_TYPE | TC_FLAG_MODULATE_WITH_CENOCC |
+                       TC_FLAG_ASSEMBIAS | TC_FLAG_LEAUTHAUD11)),
+           "autotune: the value is a combination of predict flags");
+  TC_CHECK(!((flags & TC_FLAG_LEAUTHAUD11) && (flags & TC_FLAG_ASSEMBIAS)),
+           "autotune: no assembly bias for the Leauthaud11 family");
+  int status = tc_table_synchronize(t);
+  if (status != TC_OK) return status;
+  if (t->resident.running && (status = resident_stop(t)) != TC_OK) return status;
+  t->autotuned.erase(flags);
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  const bool leauthaud = (flags & TC_FLAG_LEAUTHAUD11) != 0;
+  const int n_theta = leauthaud ? 14 : (flags & TC_FLAG_ASSEMBIAS) ? 7 : 5;
+  const int n_comp = separate ? t->plan.n_components : 1;
+  const int64_t n_max = AutoChoice::size(AutoChoice::kSizes - 1);
+  // draws: uniform in the box of tabcorr_amd.synthetic.zheng07_draws (/ the defaults of the
+  // Leauthaud11 model with a little scatter), a fixed multiplicative generator
+  std::vector<double> theta((size_t)n_max * n_theta);
+  uint64_t state = 0x9E3779B97F4A7C15ull;
+  auto uniform = [&state]() {
+    state = state * 6364136223846793005ull + 1442695040888963407ull;
+    return (double)(state >> 11) * (1.0 / 9007199254740992.0);
+  };
+  static const double lo[7] = {11.5, 0.1, 11.0, 12.5, 0.7, -1.0, -1.0};
+  static const double hi[7] = {13.5, 0.8, 13.0, 14.5, 1.4, 1.0, 1.0};
+  static const double leauthaud_mid[14] = {10.72, 12.35, 0.43, 0.56, 1.54, 0.2,  1.0,
+                                           10.62, 0.859, 1.47, -0.13, 10.5, 0.7, 0.72};
+  for (int64_t b = 0; b < n_max; ++b)
+    for (int i = 0; i < n_theta; ++i)
+      theta[(size_t)b * n_theta + i] =
+          leauthaud ? leauthaud_mid[i] * (i < 12 ? 1.0 + 0.02 * (uniform() - 0.5) : 1.0)
+                    : lo[i] + (hi[i] - lo[i]) * uniform();
+  DeviceBuffer d_theta, d_ngal, d_xi;
+  struct Release {
+    DeviceBuffer *a, *b, *c;
+    ~Release() {
+      a->release();
+      b->release();
+      c->release();
+    }
+  } release{&d_theta, &d_ngal, &d_xi};
+  status = d_theta.reserve(theta.size() * 8, t->stream);
+  if (status == TC_OK) status = d_ngal.reserve((size_t)n_max * 2 * 8, t->stream);
+  if (status == TC_OK) status = d_xi.reserve((size_t)n_max * n_comp * t->n_r * 8, t->stream);
+  if (status != TC_OK) return status;
+  TC_HIP(hipMemcpy(d_theta.ptr, theta.data(), theta.size() * 8, hipMemcpyHostToDevice));
+
+  const Tuning saved = t->tuning;
+  struct Restore {
+    tc_table* t;
+    Tuning saved;
+    ~Restore() { t->tuning = saved; }
+  } restore{t, saved};
+  t->tuning.fused_min_draws = 1;
+  t->tuning.fused_max_draws = 1 << 30;
+  auto time_form = [&](int64_t n, float* us) -> int {
+    auto call = [&]() {
+      return tc_predict_zheng07_batch_device(t, (const double*)d_theta.ptr, n_theta, n, 10, flags,
+                                             (double*)d_ngal.ptr, (double*)d_xi.ptr);
+    };
+    int st = TC_OK;
+    for (int k = 0; k < 4 && st == TC_OK; ++k) st = call();          // warm (schedules, lanes)
+    if (st == TC_OK) st = tc_table_synchronize(t);
+    if (st != TC_OK) return st;
+    // at least 4 ms and 8 calls, at most 200
+    int calls = 8;
+    double seconds = 0.0;
+    for (;;) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int k = 0; k < calls && st == TC_OK; ++k) st = call();
+      if (st == TC_OK) st = tc_table_synchronize(t);
+      if (st != TC_OK) return st;
+      seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (seconds >= 4e-3 || calls >= 200) break;
+      calls = (int)std::min<double>(200.0, std::max<double>(calls * 2.0,
+                                                            calls * 5e-3 / std::max(seconds, 1e-6)));
+    }
+    *us = (float)(seconds / calls * 1e6);
+    return TC_OK;
+  };
+  AutoChoice choice;
+  for (int i = 0; i < AutoChoice::kSizes; ++i) {
+    const int64_t n = AutoChoice::size(i);
+    t->tuning.fused = 0;
+    status = time_form(n, &choice.us[i][0]);
+    if (status != TC_OK) return status;
+    choice.form[i] = 0;
+    float best = choice.us[i][0];
+    const int shapes[2] = {64, 32};
+    for (int k = 0; k < 2; ++k) {
+      t->tuning.fused = 2;
+      t->tuning.fused_draws = shapes[k];
+      choice.us[i][1 + k] = 0.0f;
+      if (!fused_eligible(t, n, 10, flags)) continue;
+      // (the shape asked for is the one that would run?)
+      const bool half = fused_wide_tables(t, separate, 10, flags) ||
+                        fused_half_tiles(t, separate, n, 10, flags);
+      if (half != (shapes[k] == 32)) continue;
+      status = time_form(n, &choice.us[i][1 + k]);
+      if (status != TC_OK) return status;
+      // (a one-launch form must win by 2 %: ties go to the three kernels)
+      if (choice.us[i][1 + k] < 0.98f * best) {
+        best = choice.us[i][1 + k];
+        choice.form[i] = shapes[k];
+      }
+    }
+  }
+  t->autotuned[flags] = choice;
+  return TC_OK;
+}
+
+}  // namespace
+
+int tc_table_autotune_result(const tc_table* t, unsigned flags, int capacity, int* count,
+                             int64_t* sizes, int* forms, float* us) {
+  TC_CHECK(t != nullptr && count && sizes && forms && us, "NULL argument");
+  *count = 0;
+  auto it = t->autotuned.find(flags);
+  TC_CHECK(it != t->autotuned.end(), "no autotune result for these flags");
+  TC_CHECK(capacity >= AutoChoice::kSizes, "capacity below %d", (int)AutoChoice::kSizes);
+  for (int i = 0; i < AutoChoice::kSizes; ++i) {
+    sizes[i] = AutoChoice::size(i);
+    forms[i] = it->second.form[i];
+    for (int k = 0; k < 3; ++k) us[3 * i + k] = it->second.us[i][k];
+  }
+  *count = AutoChoice::kSizes;
+  return TC_OK;
+}
+
 int tc_table_set_option(tc_table* t, const char* name, int value) {
   TC_CHECK(t != nullptr && name != nullptr, "NULL argument");
   // (streams and events created below, and the resident kernel stopped, belong to the table's
@@ -852,6 +987,14 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
   const std::string key(name);
   if (key == "pipeline") {
     t->tuning.pipeline = value != 0;
+  } else if (key == "autotune") {
+    // value = the predict flags to tune for (TC_FLAG_*; n_gauss_prim = 10), or -1: forget
+    // every measured choice (back to the formula of launch.hip: fused_eligible)
+    if (value < 0) {
+      t->autotuned.clear();
+      return TC_OK;
+    }
+    return autotune(t, (unsigned)value);
   } else if (key == "grouped") {
     // 1 (default): bins that share their quadrature nodes -- the secondary-percentile bins of a
     // mass bin -- have the nodes' occupations evaluated once per group (kernels.hip.h:

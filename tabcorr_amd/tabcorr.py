@@ -240,6 +240,42 @@ class TabCorr:
             self._device = _DeviceTable(self, self.compute_dtype)
         return self._device
 
+    def autotune(self, separate_gal_type=False, modulate_with_cenocc=False,
+                 assembias=False, family='zheng07'):
+        """Measure which form of the batched path -- three kernels, or one
+        launch with 64-draw / 32-draw workgroups -- serves this table fastest
+        at batch sizes 256 ... 65536, and let the pipelined and asynchronous
+        calls with these options take the measured form (about half a second;
+        ``tc_table_set_option "autotune"``).  Without it the library estimates
+        the crossovers from the table's shape.
+
+        Returns
+        -------
+        result : dict
+            ``sizes`` (draws per call), ``forms`` (0: three kernels, 64 / 32:
+            draws per workgroup of the one-launch form) and ``us_per_call``
+            ``(n_sizes, 3)`` for (three kernels, 64 draws, 32 draws; 0 where
+            a form is not available).
+        """
+        device = self.to_device()
+        flags = _flags(separate_gal_type, modulate_with_cenocc, assembias,
+                       family)
+        sizes = np.zeros(16, dtype=np.int64)
+        forms = np.zeros(16, dtype=np.int32)
+        us = np.zeros((16, 3), dtype=np.float32)
+        with device.lock:
+            _lib.check(device.lib.tc_table_set_option(
+                device.handle, b'autotune', flags))
+            count = ctypes.c_int(0)
+            _lib.check(device.lib.tc_table_autotune_result(
+                device.handle, flags, 16, ctypes.byref(count),
+                sizes.ctypes.data_as(_lib.c_int64_p),
+                forms.ctypes.data_as(_lib.c_int_p),
+                us.ctypes.data_as(_lib.c_float_p)))
+        count = count.value
+        return {'sizes': sizes[:count].copy(), 'forms': forms[:count].copy(),
+                'us_per_call': us[:count].astype(float)}
+
     def invalidate(self):
         self._device = None
 

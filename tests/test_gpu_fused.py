@@ -655,3 +655,64 @@ def test_fused_32_draws_with_assembly_bias(n_prim, n_sec, n_r, n_draws, modulate
     assert np.array_equal(np.isnan(got[1]), np.isnan(want[1]))
     good = np.isfinite(want[1])
     assert_rel(got[1][good], want[1][good], 1e-12)
+
+
+@pytest.mark.parametrize('n_prim, n_r', [(20, 3), (100, 19), (50, 19)])
+def test_autotune_picks_the_fastest_form(n_prim, n_r):
+    """Option "autotune" (TabCorr.autotune): the measured choice between three kernels and the
+    one-launch forms is never far behind the best forced form -- the built-in estimate, fitted
+    on a handful of shapes, is up to 40 % behind on others (tools/r04_autotune.py) -- and the
+    results do not depend on it."""
+    import ctypes
+    import time
+    from tabcorr_amd import synthetic, _lib
+    from oracle import tabcorr_oracle as oracle
+    lib = _lib.load()
+    table = synthetic.synthetic_table(n_prim, 1, (n_r, ), 'auto', seed=n_prim)
+    halotab = make_tabcorr(table)
+    handle = halotab.to_device().handle
+    theta = synthetic.zheng07_draws(20000, seed=2)
+    pointers = [ctypes.c_void_p() for _ in range(3)]
+    for ptr, count in zip(pointers, (theta.size, 20000, 20000 * n_r)):
+        _lib.check(lib.tc_device_malloc(ctypes.byref(ptr), count * 8))
+    d_theta, d_ngal, d_xi = pointers
+    _lib.check(lib.tc_memcpy_h2d(d_theta, theta.ctypes.data_as(ctypes.c_void_p), theta.nbytes))
+
+    def us_per_call(n, seconds=0.12):
+        def call():
+            _lib.check(lib.tc_predict_zheng07_batch_device(handle, d_theta, 5, n, 10, 0, d_ngal,
+                                                           d_xi))
+        for _ in range(200):
+            call()
+        _lib.check(lib.tc_table_synchronize(handle))
+        count, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(20):
+                call()
+            count += 20
+        _lib.check(lib.tc_table_synchronize(handle))
+        return (time.perf_counter() - t0) / count * 1e6
+
+    result = halotab.autotune()
+    assert list(result['sizes']) == [256 << i for i in range(9)]
+    assert set(result['forms']) <= {0, 32, 64} and np.all(result['us_per_call'][:, 0] > 0)
+    sizes = (700, 3000, 12000)
+    tuned = {n: us_per_call(n) for n in sizes}
+    ngal, xi = halotab.predict_batch_async(theta[:3000]).wait()
+    expect = oracle.predict_zheng07_batch(table, theta[:8])
+    assert_rel(ngal[:8], expect[0], RTOL)
+    assert_rel(xi[:8], expect[1], RTOL)
+    set_option(halotab, 'autotune', -1)
+    set_option(halotab, 'fused_min_draws', 1)
+    set_option(halotab, 'fused_max_draws', 1 << 30)
+    for n in sizes:
+        forced = []
+        for fused, shape in ((0, 0), (2, 64), (2, 32)):
+            set_option(halotab, 'fused', fused)
+            set_option(halotab, 'fused_draws', shape)
+            forced.append(us_per_call(n))
+        assert tuned[n] <= 1.15 * min(forced), (n, tuned[n], forced)
+    for ptr in pointers:
+        lib.tc_device_free(ptr)
+    with pytest.raises(ValueError):
+        set_option(halotab, 'autotune', 64)         # not a combination of predict flags
