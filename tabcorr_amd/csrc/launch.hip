@@ -1108,7 +1108,9 @@ int fused_waves(const tc_table* t, bool separate) {
   const bool fits16 = fused_lds_bytes(t, separate, 16, 64) <= 160 * 1024;
   if (t->tuning.fused_waves == 8 && fused_lds_bytes(t, separate, 8, 64) <= 160 * 1024) return 8;
   if (t->tuning.fused_waves == 16 && fits16) return 16;
-  return fits8 ? 8 : (fits16 && t->tuning.fused >= 2) ? 16 : 0;
+  // (16 waves: level with the three kernels on the shapes swept by hand, so only when forced --
+  // or when option "autotune" has measured this table: its choice then decides)
+  return fits8 ? 8 : (fits16 && (t->tuning.fused >= 2 || !t->autotuned.empty())) ? 16 : 0;
 }
 
 namespace {

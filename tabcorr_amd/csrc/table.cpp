@@ -914,7 +914,7 @@ int autotune(tc_table* t, unsigned flags) {
     for (int k = 0; k < 4 && st == TC_OK; ++k) st = call();          // warm (schedules, lanes)
     if (st == TC_OK) st = tc_table_synchronize(t);
     if (st != TC_OK) return st;
-    // at least 4 ms and 8 calls, at most 200
+    // at least 8 ms and 8 calls, at most 400
     int calls = 8;
     double seconds = 0.0;
     for (;;) {
@@ -923,9 +923,9 @@ int autotune(tc_table* t, unsigned flags) {
       if (st == TC_OK) st = tc_table_synchronize(t);
       if (st != TC_OK) return st;
       seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (seconds >= 4e-3 || calls >= 200) break;
-      calls = (int)std::min<double>(200.0, std::max<double>(calls * 2.0,
-                                                            calls * 5e-3 / std::max(seconds, 1e-6)));
+      if (seconds >= 8e-3 || calls >= 400) break;
+      calls = (int)std::min<double>(400.0, std::max<double>(calls * 2.0,
+                                                            calls * 1e-2 / std::max(seconds, 1e-6)));
     }
     *us = (float)(seconds / calls * 1e6);
     return TC_OK;
