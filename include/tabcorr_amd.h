@@ -315,6 +315,13 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 calls with these flags then take the measured form of the nearest batch size
  *                 instead of the built-in estimate (fitted on a handful of table shapes).  -1:
  *                 forget every measurement.  tc_table_autotune_result reads it back.
+ *   "series"      1 (default): the Gauss-Legendre sum of an undecorated central bin
+ *                 (tabcorr/tabcorr.py:556-578) is evaluated by its moment expansion around the
+ *                 bin centre -- the same sum re-ordered, one erf and 8 .. 24 short terms instead
+ *                 of n_gauss_prim erf evaluations, tabcorr_amd/csrc/series.h -- wherever every
+ *                 draw of a wavefront has sigma_logM above about a bin width (truncation below
+ *                 1e-16; otherwise, and for decorated centrals, the node loop).  0: always the
+ *                 node loop.
  *   "grouped"     1 (default): bins with identical log_prim_haloprop_min / max and galaxy type
  *                 -- the secondary-percentile bins of one mass bin (tabcorr/tabcorr.py:186-205)
  *                 -- share their Gauss-Legendre nodes (:548-549); the occupation functions are

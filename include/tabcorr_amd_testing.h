@@ -17,8 +17,18 @@ extern "C" {
 
 /* Host evaluation of the table-driven FP64 functions the occupation kernel uses in place
  * of the device libm (tabcorr_amd/csrc/fastmath.h): kind 0 erf, 1 log2 (x > 0 normal),
- * 2 exp2, 3 exp10. */
+ * 2 exp2, 3 exp10, 4 erf and 5 its derivative 2/sqrt(pi) exp(-x^2) from erf_gauss_fast. */
 int tc_debug_fastmath(int kind, int64_t n, const double* x, double* y);
+
+/* The moment expansion of a central bin's node sum (tabcorr_amd/csrc/series.h) on the host,
+ * next to the node loop it replaces: for one bin [log_min, log_max] with
+ * prim_haloprop_dist_index `dist_index` and n_gauss nodes, and n draws (log_m_min, sigma):
+ * series[i] = the expansion with the number of terms the kernel would take for a wave whose
+ * smallest |sigma| is that draw's (terms[i]; 0: the expansion does not apply, series[i] is
+ * then the node loop's value), nodes[i] = sum_k W_k erf_fast((log M_k - log_m_min) / sigma). */
+int tc_debug_central_series(int n_gauss, double log_min, double log_max, double dist_index,
+                            int64_t n, const double* log_m_min, const double* sigma,
+                            double* series, double* nodes, int32_t* terms);
 
 /* Work decomposition used by the contraction kernel for a table with n_bins rows of which
  * the first n_central (after the library's stable sort by gal_type) are centrals, cut into

@@ -63,6 +63,9 @@ SIGNATURES = {
     'tc_plan_debug': [ctypes.c_int, ctypes.c_int, c_uint8_p, ctypes.c_int,
                       c_int64_p, c_int32_p, c_int32_p, c_int32_p],
     'tc_debug_triangle_parts': [ctypes.c_int, ctypes.c_int, c_int_p, c_int_p, c_int_p],
+    'tc_debug_central_series': [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                ctypes.c_int64, c_double_p, c_double_p, c_double_p, c_double_p,
+                                c_int32_p],
     'tc_debug_node_groups': [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
                              c_int32_p, c_int32_p, c_int_p, c_int_p],
     'tc_debug_quad_schedule': [ctypes.c_int] * 10 + [c_int_p, c_int_p, c_int_p,

@@ -110,6 +110,43 @@ TC_HD double erf_fast(const double* table, const Consts& k, double x) {
   return copysign(fma(row[1] * h, s, row[0]), x);
 }
 
+// erf(x) (x clamped to [-6, 6] as in erf_fast) and its derivative 2/sqrt(pi) exp(-x^2) (0 from
+// |x| = 6 on): the row
+// holds the derivative at the row centre c, and exp(-(c + h)^2) = exp(-c^2) exp(-(2 c + h) h)
+// with |(2 c + h) h| <= 0.047: Taylor to degree 9 (3e-18).  For the moment expansion of a
+// bin's node sum (kernels.hip.h: central_series).
+TC_HD double erf_gauss_fast(const double* table, const Consts& k, double x, double* gauss) {
+  double t = fabs(x);
+  t = t < 6.0 ? t : 6.0;
+  const double u = t + kMagicErf;
+  const double c = u - kMagicErf;
+  const double h = t - c;
+  const double* row = table + kErfOffset + 2 * low_word(u);
+  const double c2 = c * c;
+  double p5 = fma(c2, 4.0 / 30.0, k.erf_p5_1);
+  p5 = fma(p5, c2, 0.1);
+  const double p4 = fma(c2, -1.0 / 3.0, 0.5) * c;
+  const double p3 = fma(c2, 2.0 / 3.0, k.erf_p3_0);
+  double s = fma(p5, h, p4);
+  s = fma(s, h, p3);
+  s = fma(s, h, -c);
+  s = fma(s, h, 1.0);
+  const double g = row[1];
+  const double e = -fma(2.0, c, h) * h;        // -(2 c + h) h
+  double q = fma(e, 1.0 / 362880.0, 1.0 / 40320.0);
+  q = fma(q, e, 1.0 / 5040.0);
+  q = fma(q, e, 1.0 / 720.0);
+  q = fma(q, e, 1.0 / 120.0);
+  q = fma(q, e, 1.0 / 24.0);
+  q = fma(q, e, 1.0 / 6.0);
+  q = fma(q, e, 0.5);
+  q = fma(q, e, 1.0);
+  // (beyond the clamp the derivative is below 3e-16 and counts as zero: the expansion around
+  // such a point is the constant +-1 its nodes evaluate to)
+  *gauss = fabs(x) < 6.0 ? fma(g * e, q, g) : 0.0;      // g exp(e)
+  return copysign(fma(g * h, s, row[0]), x);
+}
+
 // log2(y) - offset for a positive normal y.
 TC_HD double log2_fast_offset(const double* table, const Consts& k, double y,
                               double offset) {

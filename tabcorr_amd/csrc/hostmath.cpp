@@ -1,6 +1,7 @@
 // Host-side mathematics and work planning (see hostmath.h).
 #include "hostmath.h"
 #include "fastmath.h"
+#include "series.h"
 
 #include <algorithm>
 #include <atomic>
@@ -199,6 +200,59 @@ void add_rectangle(std::vector<Segment>& out, int component, int i_lo, int i_hi,
 }
 
 }  // namespace
+
+namespace series {
+
+double h_max(int n_terms) {
+  // tail of the expansion beyond n_terms: sum_n 1.23 2^((n-1)/2) h^n / sqrt(n! n) (series.h)
+  auto tail = [n_terms](double h) {
+    long double sum = 0.0L, factorial = 1.0L;
+    for (int n = 1; n <= n_terms + 60; ++n) {
+      factorial *= n;
+      if (n > n_terms)
+        sum += 1.23L * powl(2.0L, 0.5L * (n - 1)) * powl((long double)h, n) /
+               sqrtl(factorial * n);
+    }
+    return (double)sum;
+  };
+  double lo = 0.0, hi = 4.0;
+  for (int i = 0; i < 80; ++i) {
+    const double mid = 0.5 * (lo + hi);
+    (tail(mid) < kTolerance ? lo : hi) = mid;
+  }
+  return lo;
+}
+
+void bin_consts(int n_gauss, const double* log_m, const double* weight, double log_min,
+                double log_max, double* consts, int32_t* thresholds) {
+  for (int i = 0; i < kStride; ++i) consts[i] = 0.0;
+  for (int i = 0; i < kThresholds; ++i) thresholds[i] = 0;
+  const double centre = 0.5 * (log_min + log_max), half = 0.5 * std::fabs(log_max - log_min);
+  if (!std::isfinite(centre) || !std::isfinite(half)) return;
+  consts[0] = centre;
+  long double factorial = 1.0L;
+  for (int n = 1; n <= kMaxTerms; ++n) {
+    factorial *= n;
+    long double moment = 0.0L;
+    for (int k = 0; k < n_gauss; ++k)
+      moment += (long double)weight[k] * powl((long double)log_m[k] - (long double)centre, n);
+    consts[1 + n] = (double)((n % 2 ? 1.0L : -1.0L) * moment / factorial);
+  }
+  // (the nodes may lie a rounding error outside the edges: the bound uses the farthest one)
+  double reach = half;
+  for (int k = 0; k < n_gauss; ++k) reach = std::max(reach, std::fabs(log_m[k] - centre));
+  static const double h_of_step[kSteps] = {h_max(8), h_max(12), h_max(16), h_max(20),
+                                           h_max(24)};
+  for (int s = 0; s < kSteps; ++s) {
+    // |1 / sigma| < h / reach; compared through the high dwords (strictly below suffices)
+    const double limit = reach > 0.0 ? h_of_step[s] / reach : 1e300;
+    uint64_t bits;
+    std::memcpy(&bits, &limit, sizeof(bits));
+    thresholds[s] = std::isfinite(limit) ? (int32_t)(bits >> 32) : 0x7fe00000;
+  }
+}
+
+}  // namespace series
 
 void find_node_groups(int n_bins, int n_central, const double* log_min, const double* log_max,
                       NodeGroups& out) {

@@ -177,6 +177,11 @@ struct Quadrature {
   void* group_log_m = nullptr;
   void* group_m = nullptr;
   void* group_weight = nullptr;
+  // moment expansion of the central bins (series.h): per bin, and per member in group order
+  void* series = nullptr;
+  void* series_thr = nullptr;
+  void* group_series = nullptr;
+  void* group_series_thr = nullptr;
 };
 
 // A schedule of the quadratic-form kernel on the device (hostmath.h: QuadSchedule).
@@ -290,6 +295,7 @@ struct Tuning {
   // with the batch sizes an ensemble sampler has, the three kernels spread small batches
   // over the whole chip.  Asynchronous host calls (us per call, tools/r03_async.py): 6144 draws
   // 38.8 / 41.6, 10^4 58 / 47.6, 20 000 93.7 / 82.6, 40 000 176 / 162: no upper bound there.
+  int series = 1;               // moment expansion of the central bins' node sums (series.h)
   int fused = 1;
   int fused_min_draws = 0;      // 0: chosen per table (launch.hip: fused_eligible)
   int fused_max_draws = 30720;

@@ -30,6 +30,10 @@ struct GroupArgs {
   const double* weight;      // (n_bins, 10) weights in member order, then (n_bins) their sums
   const double* n_h;         // (n_bins) in member order
   const double* percentile;  // (n_bins) in member order
+  // moment expansion of the central bins' node sums (series.h), per member in group order:
+  // (n_bins, series::kStride) doubles and (n_bins, series::kThresholds) int32; NULL: off
+  const double* series;
+  const int32_t* series_thr;
 };
 
 struct OccArgs {
@@ -62,6 +66,9 @@ struct OccArgs {
   int n_groups;
   int n_central_groups;
   GroupArgs group;
+  // moment expansion of the central bins' node sums (series.h), per bin: NULL: off
+  const double* series;
+  const int32_t* series_thr;
 };
 
 // Un-batched predict(): one draw through one launch (single_draw_kernel).
@@ -273,6 +280,8 @@ struct FusedArgs {
   int n_groups;
   int n_central_groups;
   GroupArgs group;
+  const double* series;        // moment expansion (OccArgs), 64-draw workgroups only
+  const int32_t* series_thr;
 };
 
 // ---- mode cross, one launch per batch (predict_cross_fused_kernel, kernels.hip.h) ----------

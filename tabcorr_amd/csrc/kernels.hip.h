@@ -16,6 +16,7 @@
 #include "fastmath.h"
 #include "hostmath.h"
 #include "kernel_args.h"
+#include "series.h"
 
 // Developer timelines (per-workgroup / per-wave time stamps behind tc_table_set_option
 // "trace") exist only in developer builds (-DTC_DEVELOPER_KNOBS, tools/build_dev.sh); the
@@ -133,14 +134,37 @@ struct DrawParams {
   double log_m_min, inv_sigma, m0, log2_m1, sat_scale, alpha, a_cen, a_sat;
   int bad;
   bool any_bad;    // wave-uniform: does any draw of the tile need the NaN fix-ups?
+  // wave-uniform: high dword of the wave's largest |1 / sigma| -- what decides how many terms
+  // the moment expansion of a central bin needs (series.h); INT_MAX: expansion off
+  int series_hi = 0x7fffffff;
 };
+
+// Constants of the moment expansion (launch.hip: get_quadrature): per bin (or member, in group
+// order) series::kStride doubles and series::kThresholds int32.  consts == nullptr: off.
+struct SeriesConsts {
+  sc_f64 consts = nullptr;
+  sc_i32 thresholds = nullptr;
+};
+
+// High dword of the largest |value| of the wave's lanes (non-negative doubles order like their
+// high dwords; NaN and infinity come out above every threshold of series.h).
+__device__ inline int wave_max_high_dword(double value) {
+  int hi = (int)(fm::bits_of(fabs(value)) >> 32);
+#pragma unroll
+  for (int offset = 32; offset >= 1; offset >>= 1) {
+    const int other = __shfl_xor(hi, offset, 64);
+    hi = other > hi ? other : hi;
+  }
+  return __builtin_amdgcn_readfirstlane(hi);
+}
 
 template <int NGAUSS, bool ASSEMBIAS, bool MODULATE>
 __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm::Consts& kc,
                                                   int g, int n_gauss, bool central, bool above,
                                                   sc_f64 log_m, sc_f64 mass, sc_f64 weight,
                                                   sc_f64 weight_sum, const DrawParams& d,
-                                                  double f1, double f2) {
+                                                  double f1, double f2,
+                                                  const SeriesConsts& sr = SeriesConsts()) {
   constexpr bool assembias = ASSEMBIAS;
   constexpr bool modulate = MODULATE;
   const double log_m_min = d.log_m_min, inv_sigma = d.inv_sigma, m0 = d.m0;
@@ -175,8 +199,17 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
     }
   }
 #endif
+  // the node sum of an undecorated central bin by its moment expansion (series.h) where every
+  // draw of the wave allows it: (half bin width) / sigma small enough, no draw to fix up
+  int n_terms = 0;
+  if (central && !assembias && shortcut == 0 && sr.consts != nullptr && n_gauss >= 4)
+    n_terms = series::terms_for(sr.thresholds + g * series::kThresholds, d.series_hi);
   if (shortcut != 0) {
     if (shortcut == 1) acc = weight_sum[g];
+  } else if (n_terms != 0) {
+    acc = series::central_sum(table, kc, log_m_min, inv_sigma, sr.consts + g * series::kStride,
+                              weight_sum[g], n_terms);
+    acc = fma(0.5, acc, 0.5 * weight_sum[g]);
   } else if (central && !assembias) {
     // sum_k w_k (1 + erf_k) / 2 = (W + sum_k w_k erf_k) / 2 with W = sum_k w_k from the host
     // (get_quadrature): one instruction per node less than forming every <N_cen> first
@@ -322,9 +355,10 @@ struct GroupConsts {
   sc_f64 weight, weight_sum;   // (n_bins, 10), (n_bins) in member order
   sc_f64 percentile;           // (n_bins) in member order
   sc_i32 member;               // (n_bins)
+  SeriesConsts series;         // moment expansion, per member in group order (or off)
 };
 
-template <bool ASSEMBIAS, bool MODULATE, typename Emit>
+template <bool ASSEMBIAS, bool MODULATE, bool SERIES = true, typename Emit>
 __device__ __forceinline__ void occ_group_zheng07(const double* table, const fm::Consts& kc,
                                                   int group, int m_begin, int m_end,
                                                   bool central, const GroupConsts& q,
@@ -356,6 +390,29 @@ __device__ __forceinline__ void occ_group_zheng07(const double* table, const fm:
     }
   }
 #endif
+  // (undecorated centrals: the moment expansion where the wave's draws allow it -- series.h;
+  // the members share the recurrence, each adds its own moments)
+  // (SERIES = false: compiled without it -- predict_cross_small_kernel, whose 16 row sums per
+  // wave leave no registers for it: 142 with it, one workgroup per CU)
+  int n_terms = 0;
+  if (SERIES && central && !assembias && shortcut == 0 && q.series.consts != nullptr)
+    n_terms = series::terms_for(q.series.thresholds + m_begin * series::kThresholds,
+                                d.series_hi);
+  if (SERIES && n_terms != 0) {
+    // (a path of its own, so that the node path below stays one straight line whose scalar
+    // loads the compiler can start early)
+    for (int mi = m_begin; mi < m_end; mi += 2) {
+      const int mj = mi + 1 < m_end ? mi + 1 : mi;
+      double acc_i, acc_j;
+      series::central_sum_pair(table, kc, log_m_min, inv_sigma,
+                               q.series.consts + mi * series::kStride,
+                               q.series.consts + mj * series::kStride, q.weight_sum[mi],
+                               q.weight_sum[mj], n_terms, &acc_i, &acc_j);
+      emit(mi, q.member[mi], fma(0.5, acc_i, 0.5 * q.weight_sum[mi]));
+      if (mj != mi) emit(mj, q.member[mj], fma(0.5, acc_j, 0.5 * q.weight_sum[mj]));
+    }
+    return;
+  }
   // v[k]: centrals erf(z_k) (decorated: <N_cen> itself), satellites <N_sat> before the scale
   double v[kNodes];
   if (shortcut == 0) {
@@ -606,6 +663,7 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     dp.bad = (int)prm[8][lane];
     // wave-uniform: does any draw of this tile need the NaN fix-ups after a bin's node loop?
     dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
+    dp.series_hi = ((GROUPED ? a.group.series : a.series) != nullptr) ? wave_max_high_dword(dp.inv_sigma) : 0x7fffffff;
 
     double sum_cen = 0.0, sum_sat = 0.0;
     auto emit = [&](int g, bool central, double acc, double n_h_g) {
@@ -623,7 +681,8 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
         sc_f64 n_h_m = (sc_f64)a.group.n_h;
         const GroupConsts gq{(sc_f64)a.group.log_m, (sc_f64)a.group.m, (sc_f64)a.group.weight,
                              (sc_f64)a.group.weight + a.n_bins * 10,
-                             (sc_f64)a.group.percentile, (sc_i32)a.group.member};
+                             (sc_f64)a.group.percentile, (sc_i32)a.group.member,
+                             SeriesConsts{(sc_f64)a.group.series, (sc_i32)a.group.series_thr}};
         const bool central = g < a.n_central_groups;
         occ_group_zheng07<ASSEMBIAS, MODULATE>(
             table, kc, g, group_begin[g], group_begin[g + 1], central, gq, a.split, dp,
@@ -632,9 +691,9 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
         const bool central = g < a.n_central;
         const bool above = percentile[g] > a.split;
         emit(g, central,
-             occ_bin_zheng07<NGAUSS, ASSEMBIAS, MODULATE>(table, kc, g, n_gauss, central, above,
-                                                          log_m, mass, weight, weight_sum, dp,
-                                                          f1, f2),
+             occ_bin_zheng07<NGAUSS, ASSEMBIAS, MODULATE>(
+                 table, kc, g, n_gauss, central, above, log_m, mass, weight, weight_sum, dp, f1,
+                 f2, SeriesConsts{(sc_f64)a.series, (sc_i32)a.series_thr}),
              n_h[g]);
       }
     }
@@ -1908,6 +1967,7 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
     dp.a_sat = d.a_sat;
     dp.bad = d.bad;
     dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
+    dp.series_hi = ((GROUPED ? a.group.series : a.series) != nullptr && DL == 64) ? wave_max_high_dword(dp.inv_sigma) : 0x7fffffff;
     sc_f64 log_m = (sc_f64)a.log_m;
     sc_f64 mass = (sc_f64)a.m;
     sc_f64 weight = (sc_f64)a.weight;
@@ -1921,7 +1981,8 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
       sc_f64 n_h_m = (sc_f64)a.group.n_h;
       const GroupConsts gq{(sc_f64)a.group.log_m, (sc_f64)a.group.m, (sc_f64)a.group.weight,
                            (sc_f64)a.group.weight + a.n_bins * 10, (sc_f64)a.group.percentile,
-                           (sc_i32)a.group.member};
+                           (sc_i32)a.group.member,
+                             SeriesConsts{(sc_f64)a.group.series, (sc_i32)a.group.series_thr}};
       for (int gr = wave; gr < a.n_groups; gr += W) {
         const bool central = gr < a.n_central_groups;
         auto emit = [&](int mi, int g, double acc) {
@@ -1953,7 +2014,8 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
                                                       weight, ld)
                       : occ_bin_zheng07<NGAUSS, ASSEMBIAS, MODULATE>(
                             table, kc, g, n_gauss, central, above, log_m, mass, weight,
-                            weight_sum, dp, f1, f2);
+                            weight_sum, dp, f1, f2,
+                            SeriesConsts{(sc_f64)a.series, (sc_i32)a.series_thr});
       const double value = acc * n_h[g];
       if (half == 0) dens[g * DL + draw] = value;
       if (central) sum_cen += value; else sum_sat += value;
@@ -2118,7 +2180,7 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
 // parameters (interpolator.py:275-331; one table: c = 1).  Separated by galaxy type the sums
 // of the centrals are set aside after their last chunk (no chunk holds both types).
 template <int RW, bool ASSEMBIAS, bool MODULATE>
-__global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_fused_kernel(
+__global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 2 : 4) void predict_cross_fused_kernel(
     CrossFusedArgs a) {
   constexpr int W = kCrossWaves, ROWS = W * RW;
   static_assert(ROWS <= kCrossMaxRows && fm::kTableDoubles == kCrossTableDoubles, "kernel_args.h");
@@ -2158,11 +2220,13 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_fused_kerne
     dp.a_sat = d.a_sat;
     dp.bad = d.bad;
     dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
+    dp.series_hi = (a.group.series != nullptr) ? wave_max_high_dword(dp.inv_sigma) : 0x7fffffff;
     sc_i32 group_begin = (sc_i32)a.group.begin;
     sc_i32 chunk_group = (sc_i32)a.chunk_group;
     const GroupConsts gq{(sc_f64)a.group.log_m, (sc_f64)a.group.m, (sc_f64)a.group.weight,
                          (sc_f64)a.group.weight + a.n_bins * 10, (sc_f64)a.group.percentile,
-                         (sc_i32)a.group.member};
+                         (sc_i32)a.group.member,
+                             SeriesConsts{(sc_f64)a.group.series, (sc_i32)a.group.series_thr}};
     sc_f64 rows = (sc_f64)a.rows + wave * RW;
     for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
       if (a.separate && chunk == a.n_central_chunks) {
@@ -2292,6 +2356,9 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_fused_kerne
 // chunk: the AbacusSummit table takes 57.9 us per 10^4 draws this way against 73.7 through the
 // chunks above (where the 2 rows per wave make phase B mostly LDS reads and scalar loads).
 // Separated by galaxy type the first `cen_waves` waves take the groups of centrals.
+// (four waves per SIMD = two workgroups per CU -- the second launch bound is waves per SIMD in
+// HIP: left to itself the register allocator takes 130 registers since the moment expansion
+// joined, and one workgroup per CU costs 58 -> 94 us per 10^4 draws of the AbacusSummit table)
 template <bool ASSEMBIAS, bool MODULATE>
 __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kernel(
     CrossFusedArgs a) {
@@ -2338,10 +2405,12 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kerne
     dp.a_sat = d.a_sat;
     dp.bad = d.bad;
     dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
+    dp.series_hi = 0x7fffffff;       // (compiled without the moment expansion)
     sc_i32 group_begin = (sc_i32)a.group.begin;
     const GroupConsts gq{(sc_f64)a.group.log_m, (sc_f64)a.group.m, (sc_f64)a.group.weight,
                          (sc_f64)a.group.weight + a.n_bins * 10, (sc_f64)a.group.percentile,
-                         (sc_i32)a.group.member};
+                         (sc_i32)a.group.member,
+                             SeriesConsts{(sc_f64)a.group.series, (sc_i32)a.group.series_thr}};
     sc_f64 rows = (sc_f64)a.rows;
     auto emit = [&](int mi, int, double nbar) {
       sc_f64 coefficient = rows + (int64_t)mi * a.row_stride;
@@ -2356,7 +2425,7 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kerne
       stride = cen ? a.cen_waves : W - a.cen_waves;
     }
     for (int gr = first; gr < end; gr += stride)
-      occ_group_zheng07<ASSEMBIAS, MODULATE>(table, kc, gr, group_begin[gr], group_begin[gr + 1],
+      occ_group_zheng07<ASSEMBIAS, MODULATE, false>(table, kc, gr, group_begin[gr], group_begin[gr + 1],
                                              gr < a.n_central_groups, gq, a.split, dp, emit);
   }
 

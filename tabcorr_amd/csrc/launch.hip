@@ -3,6 +3,7 @@
 // table's lanes (internal.h).
 #include "internal.h"
 #include "kernels.hip.h"
+#include "series.h"
 
 namespace tc {
 namespace host {
@@ -48,6 +49,16 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
   int status = upload(log_m, &q.log_m);
   if (status == TC_OK) status = upload(m, &q.m);
   if (status == TC_OK) status = upload(weight, &q.weight);
+  // moment expansion of the central bins' node sums (series.h)
+  std::vector<double> series((size_t)g * tc::series::kStride);
+  std::vector<int32_t> series_thr((size_t)g * tc::series::kThresholds);
+  for (int i = 0; i < g; ++i)
+    tc::series::bin_consts(n_gauss, log_m.data() + (size_t)i * n_gauss,
+                           weight.data() + (size_t)i * n_gauss, t->log_min[i], t->log_max[i],
+                           series.data() + (size_t)i * tc::series::kStride,
+                           series_thr.data() + (size_t)i * tc::series::kThresholds);
+  if (status == TC_OK) status = upload(series, &q.series);
+  if (status == TC_OK) status = upload(series_thr, &q.series_thr);
   if (status == TC_OK && n_gauss == 10 &&
       (t->node_groups.largest > 1 || t->mode == TC_MODE_CROSS)) {
     // GROUPED kernels: the nodes of every group (= those of its first member), the weights and
@@ -68,9 +79,21 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
         g_weight[(size_t)mi * n_gauss + k] = weight[(size_t)bin * n_gauss + k];
       g_weight[(size_t)g * n_gauss + mi] = weight[(size_t)g * n_gauss + bin];
     }
+    std::vector<double> g_series((size_t)g * tc::series::kStride);
+    std::vector<int32_t> g_series_thr((size_t)g * tc::series::kThresholds);
+    for (int mi = 0; mi < g; ++mi) {
+      const int bin = groups.member[mi];
+      std::copy_n(series.data() + (size_t)bin * tc::series::kStride, tc::series::kStride,
+                  g_series.data() + (size_t)mi * tc::series::kStride);
+      std::copy_n(series_thr.data() + (size_t)bin * tc::series::kThresholds,
+                  tc::series::kThresholds,
+                  g_series_thr.data() + (size_t)mi * tc::series::kThresholds);
+    }
     status = upload(g_log_m, &q.group_log_m);
     if (status == TC_OK) status = upload(g_m, &q.group_m);
     if (status == TC_OK) status = upload(g_weight, &q.group_weight);
+    if (status == TC_OK) status = upload(g_series, &q.group_series);
+    if (status == TC_OK) status = upload(g_series_thr, &q.group_series_thr);
   }
   if (status != TC_OK) return status;
   t->quadrature[n_gauss] = q;
@@ -87,6 +110,8 @@ tc::GroupArgs group_args(const tc_table* t, const Quadrature& q) {
   ga.weight = (const double*)q.group_weight;
   ga.n_h = (const double*)t->d_group_n_h;
   ga.percentile = (const double*)t->d_group_percentile;
+  ga.series = t->tuning.series ? (const double*)q.group_series : nullptr;
+  ga.series_thr = (const int32_t*)q.group_series_thr;
   return ga;
 }
 
@@ -912,6 +937,8 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   oa.n_groups = t->node_groups.n_groups;
   oa.n_central_groups = t->node_groups.n_central_groups;
   oa.group = group_args(t, *q);
+  oa.series = t->tuning.series ? (const double*)q->series : nullptr;
+  oa.series_thr = (const int32_t*)q->series_thr;
   {
     const dim3 grid((unsigned)grid_blocks), block(tc::kOccWaves * 64);
     const bool assembias = (flags & TC_FLAG_ASSEMBIAS) != 0;
@@ -1212,6 +1239,8 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   fa.n_groups = t->node_groups.n_groups;
   fa.n_central_groups = t->node_groups.n_central_groups;
   fa.group = group_args(t, *q);
+  fa.series = t->tuning.series ? (const double*)q->series : nullptr;
+  fa.series_thr = (const int32_t*)q->series_thr;
   fa.log_m = (const double*)q->log_m;
   fa.m = (const double*)q->m;
   fa.weight = (const double*)q->weight;

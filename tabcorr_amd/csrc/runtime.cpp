@@ -6,6 +6,7 @@
 #include <mutex>
 
 #include "internal.h"
+#include "series.h"
 
 namespace tc {
 namespace host {
@@ -255,7 +256,7 @@ int tc_gauss_legendre(int n, double* x, double* w) {
 }
 
 int tc_debug_fastmath(int kind, int64_t n, const double* x, double* y) {
-  TC_CHECK(kind >= 0 && kind <= 3 && n >= 0 && x && y, "invalid arguments");
+  TC_CHECK(kind >= 0 && kind <= 5 && n >= 0 && x && y, "invalid arguments");
   static std::vector<double> table;
   if (table.empty()) {
     table.resize(tc::fm::kTableDoubles);
@@ -267,6 +268,64 @@ int tc_debug_fastmath(int kind, int64_t n, const double* x, double* y) {
     if (kind == 1) y[i] = tc::fm::log2_fast(table.data(), k, x[i]);
     if (kind == 2) y[i] = tc::fm::exp2_fast(table.data(), k, x[i]);
     if (kind == 3) y[i] = tc::fm::exp10_fast(table.data(), k, x[i]);
+    if (kind >= 4) {
+      double gauss;
+      const double value = tc::fm::erf_gauss_fast(table.data(), k, x[i], &gauss);
+      y[i] = kind == 4 ? value : gauss;
+    }
+  }
+  return TC_OK;
+}
+
+int tc_debug_central_series(int n_gauss, double log_min, double log_max, double dist_index,
+                            int64_t n, const double* log_m_min, const double* sigma,
+                            double* series, double* nodes, int32_t* terms) {
+  TC_CHECK(n_gauss >= 1 && n_gauss <= 4096 && n >= 0, "invalid arguments");
+  TC_CHECK(log_m_min && sigma && series && nodes && terms, "NULL argument");
+  static std::vector<double> table;
+  if (table.empty()) {
+    table.resize(tc::fm::kTableDoubles);
+    tc::fm::build_tables(table.data());
+  }
+  const tc::fm::Consts kc = tc::fm::make_consts();
+  // nodes and normalised weights as launch.hip: get_quadrature
+  std::vector<double> x, w;
+  tc::gauss_legendre(n_gauss, x, w);
+  std::vector<double> log_m(n_gauss), weight(n_gauss);
+  std::vector<long double> raw(n_gauss);
+  long double norm = 0.0L;
+  double m_ref = 0.0;
+  for (int k = 0; k < n_gauss; ++k) {
+    const double mass = std::pow(10.0, log_min + (log_max - log_min) * x[k]);
+    if (k == 0) m_ref = mass;
+    log_m[k] = std::log10(mass);
+    raw[k] = (long double)w[k] * powl((long double)mass / (long double)m_ref,
+                                      (long double)(dist_index + 1.0));
+    norm += raw[k];
+  }
+  double m0 = 0.0;
+  for (int k = 0; k < n_gauss; ++k) {
+    weight[k] = (double)(raw[k] / norm);
+    m0 += weight[k];
+  }
+  std::vector<double> consts(tc::series::kStride);
+  std::vector<int32_t> thresholds(tc::series::kThresholds);
+  tc::series::bin_consts(n_gauss, log_m.data(), weight.data(), log_min, log_max, consts.data(),
+                         thresholds.data());
+  for (int64_t i = 0; i < n; ++i) {
+    const double inv_sigma = 1.0 / sigma[i];
+    double sum = 0.0;
+    for (int k = 0; k < n_gauss; ++k)
+      sum = fma(weight[k], tc::fm::erf_fast(table.data(), kc, (log_m[k] - log_m_min[i]) * inv_sigma),
+                sum);
+    nodes[i] = sum;
+    const double magnitude = std::fabs(inv_sigma);
+    uint64_t bits;
+    memcpy(&bits, &magnitude, sizeof(bits));
+    terms[i] = tc::series::terms_for(thresholds.data(), (int)(bits >> 32));
+    series[i] = terms[i] > 0 ? tc::series::central_sum(table.data(), kc, log_m_min[i], inv_sigma,
+                                                       consts.data(), m0, terms[i])
+                             : sum;
   }
   return TC_OK;
 }

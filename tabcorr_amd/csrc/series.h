@@ -1,0 +1,142 @@
+// Moment expansion of a central bin's Gauss-Legendre sum (host + device).
+//
+// tabcorr.py:556-578 averages <N_cen>(M) = (1 + erf((log M - logMmin) / sigma)) / 2 over the
+// nodes of a bin with the weights W_k.  The nodes lie within half a bin width of the bin's
+// centre c, so with z0 = (c - logMmin) / sigma and d_k = log M_k - c
+//
+//   sum_k W_k erf(z0 + d_k / sigma)
+//       = m_0 erf(z0) + 2/sqrt(pi) exp(-z0^2) sum_{n >= 1} (-1)^(n-1) H_{n-1}(z0) sigma^-n m_n / n!
+//
+// (Taylor series of erf around z0; H: physicists' Hermite polynomials) with the bin's moments
+// m_n = sum_k W_k d_k^n, which do not depend on the draw: the SAME sum over the nodes,
+// re-ordered, truncated where the tail is below 1e-16 -- Cramer's bound
+// |H_n(z) exp(-z^2 / 2)| <= 1.09 2^(n/2) sqrt(n!) gives the number of terms from
+// h = (half bin width) / sigma alone.  One erf, its derivative and four instructions per term
+// (the recurrence p_n = H_n(z0) sigma^-(n+1): p_(n+1) = (2 z0 / sigma) p_n - (2 n / sigma^2)
+// p_(n-1), and one FMA with the moment as a scalar operand) replace n_gauss erf evaluations:
+// 8 terms serve h <= 0.027, 12 h <= 0.11, 16 h <= 0.24, 20 h <= 0.39, 24 h <= 0.55; beyond
+// that (sigma below a tenth of a bin width ...) the node loop runs as before.
+#pragma once
+
+#include <cstdint>
+
+#include "fastmath.h"
+
+namespace tc {
+namespace series {
+
+constexpr int kMaxTerms = 24;
+constexpr int kSteps = 5;                    // 8, 12, 16, 20, 24 terms
+constexpr int kStride = 2 + kMaxTerms;       // per bin: centre, (unused), M_1 .. M_24
+constexpr int kThresholds = 8;               // int32 per bin (kSteps used)
+constexpr double kTolerance = 1e-16;
+
+// Largest h = (half bin width) / sigma for which `n_terms` terms leave a tail below kTolerance.
+double h_max(int n_terms);
+
+// Per-bin constants from the bin's nodes (log10 M_k) and normalised weights: consts[0] = centre,
+// consts[2 + n - 1] = (-1)^(n-1) m_n / n!; thresholds[s] = high dword of the largest
+// |1 / sigma| for which 8 + 4 s terms suffice (0: never).
+void bin_consts(int n_gauss, const double* log_m, const double* weight, double log_min,
+                double log_max, double* consts, int32_t* thresholds);
+
+// Number of terms for a wave whose largest |1 / sigma| has the high dword `inv_sigma_hi`
+// (0: the expansion does not apply, run the node loop).
+template <typename IntPtr>
+TC_HD int terms_for(IntPtr thresholds, int inv_sigma_hi) {
+  int n = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int s = kSteps - 1; s >= 0; --s)
+    if (inv_sigma_hi < thresholds[s]) n = 8 + 4 * s;
+  return n;
+}
+
+// sum_k W_k erf((log M_k - log_m_min) inv_sigma) of the bin whose constants are `consts`, by
+// n_terms (a multiple of 4) terms of the expansion; m0 = sum_k W_k.  Uniform steps from
+// (p_-1, p_0) = (0, 1 / sigma): term n adds p_(n-1) M_n, then p_n = a p_(n-1) + (n - 1) b p_(n-2).
+// Four terms per pass of a loop that is NOT unrolled (the unrolled forms took 150-200 vector
+// registers in the kernels); the next pass's four moments are requested -- one scalar load --
+// before the current ones are used.
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+
+template <typename Ptr>
+TC_HD f64x4_t load_moments(Ptr consts, int block) {
+  f64x4_t m;
+  m.x = consts[2 + 4 * block];
+  m.y = consts[3 + 4 * block];
+  m.z = consts[4 + 4 * block];
+  m.w = consts[5 + 4 * block];
+  return m;
+}
+
+template <typename Ptr>
+TC_HD double central_sum(const double* table, const fm::Consts& kc, double log_m_min,
+                         double inv_sigma, Ptr consts, double m0, int n_terms) {
+  const double z0 = (consts[0] - log_m_min) * inv_sigma;
+  double g0;
+  const double e = fm::erf_gauss_fast(table, kc, z0, &g0);
+  const double a = 2.0 * z0 * inv_sigma, b = -2.0 * inv_sigma * inv_sigma;
+  double p_prev = 0.0, p = inv_sigma, nb = -b, sum = 0.0;
+  const int n_blocks = n_terms >> 2;
+  f64x4_t m = load_moments(consts, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int block = 0; block < n_blocks; ++block) {
+    const f64x4_t next_m = load_moments(consts, block + 1 < n_blocks ? block + 1 : block);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; ++k) {
+      sum = fma(p, m[k], sum);
+      nb += b;
+      const double next = fma(a, p, nb * p_prev);
+      p_prev = p;
+      p = next;
+    }
+    m = next_m;
+  }
+  return fma(g0, sum, m0 * e);
+}
+
+// The same for two bins with the same nodes (one group: same centre, different moments): the
+// recurrence once, one FMA per term and bin.
+template <typename Ptr>
+TC_HD void central_sum_pair(const double* table, const fm::Consts& kc, double log_m_min,
+                            double inv_sigma, Ptr consts_i, Ptr consts_j, double m0_i,
+                            double m0_j, int n_terms, double* out_i, double* out_j) {
+  const double z0 = (consts_i[0] - log_m_min) * inv_sigma;
+  double g0;
+  const double e = fm::erf_gauss_fast(table, kc, z0, &g0);
+  const double a = 2.0 * z0 * inv_sigma, b = -2.0 * inv_sigma * inv_sigma;
+  double p_prev = 0.0, p = inv_sigma, nb = -b, sum_i = 0.0, sum_j = 0.0;
+  const int n_blocks = n_terms >> 2;
+  f64x4_t mi = load_moments(consts_i, 0), mj = load_moments(consts_j, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int block = 0; block < n_blocks; ++block) {
+    const int ahead = block + 1 < n_blocks ? block + 1 : block;
+    const f64x4_t next_i = load_moments(consts_i, ahead), next_j = load_moments(consts_j, ahead);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; ++k) {
+      sum_i = fma(p, mi[k], sum_i);
+      sum_j = fma(p, mj[k], sum_j);
+      nb += b;
+      const double next = fma(a, p, nb * p_prev);
+      p_prev = p;
+      p = next;
+    }
+    mi = next_i;
+    mj = next_j;
+  }
+  *out_i = fma(g0, sum_i, m0_i * e);
+  *out_j = fma(g0, sum_j, m0_j * e);
+}
+
+}  // namespace series
+}  // namespace tc

@@ -236,7 +236,8 @@ int tc_table_destroy(tc_table* t) {
     if (p) (void)hipFree(p);
   for (auto& kv : t->quadrature)
     for (void* p : {kv.second.log_m, kv.second.m, kv.second.weight, kv.second.group_log_m,
-                    kv.second.group_m, kv.second.group_weight})
+                    kv.second.group_m, kv.second.group_weight, kv.second.series,
+                    kv.second.series_thr, kv.second.group_series, kv.second.group_series_thr})
       if (p) (void)hipFree(p);
   for (auto& kv : t->chunkings)
     for (void* p : {kv.second->chunks, kv.second->groups})
@@ -995,6 +996,10 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
       return TC_OK;
     }
     return autotune(t, (unsigned)value);
+  } else if (key == "series") {
+    // 1 (default): the node sum of an undecorated central bin by its moment expansion
+    // (csrc/series.h) wherever every draw of a wave allows it; 0: always the node loop
+    t->tuning.series = value != 0;
   } else if (key == "grouped") {
     // 1 (default): bins that share their quadrature nodes -- the secondary-percentile bins of a
     // mass bin -- have the nodes' occupations evaluated once per group (kernels.hip.h:

@@ -657,7 +657,7 @@ def test_fused_32_draws_with_assembly_bias(n_prim, n_sec, n_r, n_draws, modulate
     assert_rel(got[1][good], want[1][good], 1e-12)
 
 
-@pytest.mark.parametrize('n_prim, n_r', [(20, 3), (100, 19), (50, 19)])
+@pytest.mark.parametrize('n_prim, n_r', [(40, 8), (100, 19), (50, 19)])
 def test_autotune_picks_the_fastest_form(n_prim, n_r):
     """Option "autotune" (TabCorr.autotune): the measured choice between three kernels and the
     one-launch forms is never far behind the best forced form -- the built-in estimate, fitted

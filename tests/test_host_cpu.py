@@ -1021,3 +1021,56 @@ def test_interpolator_lock_includes_its_tables():
     for thread in threads:
         thread.join(timeout=60)
     assert len(done) == 3
+
+
+def test_central_moment_expansion_reproduces_the_node_loop():
+    """csrc/series.h: the Taylor / Hermite re-ordering of a central bin's Gauss-Legendre sum
+    (same inline code as the kernels, run on the host) against the node loop it replaces: to
+    rounding wherever the expansion applies, with the term counts 8 ... 24 chosen from
+    (half bin width) / sigma; and erf_gauss_fast's derivative against exp(-x^2)."""
+    import ctypes
+    from tabcorr_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(-7, 7, 20000), [0.0, -0.0, 6.0, -6.0, 5.999, 1e-300, 30.0]])
+    out = np.empty_like(x)
+    _lib.check(lib.tc_debug_fastmath(5, len(x), _lib.as_double_p(x), _lib.as_double_p(out)))
+    exact = (2 / np.sqrt(np.pi, dtype=np.longdouble) *
+             np.exp(-x.astype(np.longdouble)**2)).astype(float)
+    exact[np.abs(x) >= 6.0] = 0.0               # (zero from the clamp of erf_fast on)
+    np.testing.assert_allclose(out, exact, rtol=1e-15)
+    _lib.check(lib.tc_debug_fastmath(4, len(x), _lib.as_double_p(x), _lib.as_double_p(out)))
+    from scipy.special import erf
+    np.testing.assert_allclose(out, erf(x), rtol=0, atol=4.5e-16)
+
+    used = {}
+    for width, dist_index, n_gauss, sigma_range in (
+            (0.09, -2.1, 10, (0.08, 0.9)),        # BASELINE configs[1]: 50 bins over 4.5 dex
+            (0.09, -1.6, 10, (0.3, 0.9)),
+            (0.0121, 7.5, 10, (0.05, 0.9)),       # the reference's AbacusSummit table
+            (0.0121, -10.0, 10, (0.02, 0.2)),
+            (0.15, -2.0, 10, (0.1, 0.9)),         # bolplanck wp table: 30 bins
+            (0.09, -2.0, 100, (0.1, 0.9)),        # any n_gauss_prim: the moments are the bin's
+            (0.09, -2.0, 3, (0.1, 0.9)),
+            (0.3, -2.0, 10, (0.05, 0.5))):        # wide bins: mostly the node loop
+        n = 4000
+        log_min = rng.uniform(10.5, 15.0 - width)
+        log_m_min = rng.uniform(log_min - 4.0, log_min + 4.0, n)
+        sigma = rng.uniform(*sigma_range, n) * rng.choice([1.0, 1.0, 1.0, -1.0], n)
+        series, nodes = np.empty(n), np.empty(n)
+        terms = np.zeros(n, dtype=np.int32)
+        _lib.check(lib.tc_debug_central_series(
+            n_gauss, log_min, log_min + width, dist_index, n, _lib.as_double_p(log_m_min),
+            _lib.as_double_p(sigma), _lib.as_double_p(series), _lib.as_double_p(nodes),
+            terms.ctypes.data_as(_lib.c_int32_p)))
+        assert set(terms) <= {0, 8, 12, 16, 20, 24}
+        np.testing.assert_allclose(series, nodes, rtol=0, atol=1.5e-15,
+                                   err_msg='width %g, %d nodes' % (width, n_gauss))
+        # the number of terms follows (half width) / |sigma|
+        h = 0.5 * width / np.abs(sigma)
+        for count, limit in ((8, 0.0275), (12, 0.1100), (16, 0.2366), (20, 0.3879), (24, 0.5506)):
+            assert np.all(h[terms == count] < limit * 1.001)
+        assert np.all(h[terms == 0] > 0.5506 * 0.99)
+        used.setdefault((width, n_gauss), set()).update(int(t) for t in terms)
+    assert {0, 16, 20, 24} <= used[0.09, 10]
+    assert {8, 12} <= used[0.0121, 10] and 0 in used[0.3, 10]
