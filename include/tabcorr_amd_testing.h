@@ -30,6 +30,15 @@ int tc_debug_central_series(int n_gauss, double log_min, double log_max, double 
                             int64_t n, const double* log_m_min, const double* sigma,
                             double* series, double* nodes, int32_t* terms);
 
+/* The same for a satellite bin (series.h, namespace sat): the binomial expansion of
+ * sum_k W_k ((M_k - M0) / M1)^alpha around the bin's reference mass next to the node loop;
+ * terms[i] from that draw's M0 (0: the expansion does not apply -- the bin is too close to M0 or
+ * alpha outside [0, 4] --, series[i] is then the node loop's value). */
+int tc_debug_satellite_series(int n_gauss, double log_min, double log_max, double dist_index,
+                              int64_t n, const double* log_m0, const double* log_m1,
+                              const double* alpha, double* series, double* nodes,
+                              int32_t* terms);
+
 /* Work decomposition used by the contraction kernel for a table with n_bins rows of which
  * the first n_central (after the library's stable sort by gal_type) are centrals, cut into
  * n_chunks wave-sized pieces.  Outputs one record per packed column, in processing order:

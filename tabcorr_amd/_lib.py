@@ -66,6 +66,9 @@ SIGNATURES = {
     'tc_debug_central_series': [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                 ctypes.c_int64, c_double_p, c_double_p, c_double_p, c_double_p,
                                 c_int32_p],
+    'tc_debug_satellite_series': [ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                  ctypes.c_double, ctypes.c_int64, c_double_p, c_double_p,
+                                  c_double_p, c_double_p, c_double_p, c_int32_p],
     'tc_debug_node_groups': [ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
                              c_int32_p, c_int32_p, c_int_p, c_int_p],
     'tc_debug_quad_schedule': [ctypes.c_int] * 10 + [c_int_p, c_int_p, c_int_p,

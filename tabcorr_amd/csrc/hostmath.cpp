@@ -252,6 +252,51 @@ void bin_consts(int n_gauss, const double* log_m, const double* weight, double l
   }
 }
 
+namespace sat {
+
+double r_max(int n_terms) {
+  // tail beyond n_terms of sum_n 16 r^n: 16 r^(n_terms + 1) / (1 - r) (series.h)
+  double lo = 0.0, hi = 0.9;
+  for (int i = 0; i < 80; ++i) {
+    const double mid = 0.5 * (lo + hi);
+    (16.0 * std::pow(mid, n_terms + 1) / (1.0 - mid) < kTolerance ? lo : hi) = mid;
+  }
+  return lo;
+}
+
+void bin_consts(int n_gauss, const double* mass, const double* weight, double log_min,
+                double log_max, double* consts, int32_t* thresholds) {
+  for (int i = 0; i < kStride; ++i) consts[i] = 0.0;
+  for (int i = 0; i < kThresholds; ++i) thresholds[i] = 0;
+  const double centre = std::pow(10.0, 0.5 * (log_min + log_max));
+  if (!std::isfinite(centre) || !(centre > 0.0)) return;
+  consts[0] = centre;
+  double y_max = 0.0;
+  for (int k = 0; k < n_gauss; ++k) y_max = std::max(y_max, std::fabs(mass[k] / centre - 1.0));
+  consts[1] = y_max;
+  long double factorial = 1.0L;
+  for (int n = 0; n <= kMaxTerms; ++n) {
+    if (n > 0) factorial *= n;
+    long double moment = 0.0L;
+    for (int k = 0; k < n_gauss; ++k)
+      moment += (long double)weight[k] *
+                powl((long double)mass[k] / (long double)centre - 1.0L, n);
+    consts[2 + n] = (double)(moment / factorial);
+  }
+  if (!std::isfinite(y_max)) return;
+  for (int s = 0; s < kSteps; ++s) {
+    // eps y_max <= r  <=>  M0 <= Mc (1 - y_max / r); through the high dwords, strictly below
+    const double r = r_max(12 + 4 * s);
+    const double limit = centre * (1.0 - y_max / r);
+    if (!(limit > 0.0) || !std::isfinite(limit)) continue;
+    uint64_t bits;
+    std::memcpy(&bits, &limit, sizeof(bits));
+    thresholds[s] = (int32_t)(bits >> 32);
+  }
+}
+
+}  // namespace sat
+
 }  // namespace series
 
 void find_node_groups(int n_bins, int n_central, const double* log_min, const double* log_max,

@@ -182,6 +182,10 @@ struct Quadrature {
   void* series_thr = nullptr;
   void* group_series = nullptr;
   void* group_series_thr = nullptr;
+  void* sat_series = nullptr;          // satellites (series.h, namespace sat), as above
+  void* sat_series_thr = nullptr;
+  void* group_sat_series = nullptr;
+  void* group_sat_series_thr = nullptr;
 };
 
 // A schedule of the quadratic-form kernel on the device (hostmath.h: QuadSchedule).

@@ -34,6 +34,10 @@ struct GroupArgs {
   // (n_bins, series::kStride) doubles and (n_bins, series::kThresholds) int32; NULL: off
   const double* series;
   const int32_t* series_thr;
+  // ... of the satellite bins (series.h, namespace sat): (n_bins, sat::kStride) doubles and
+  // (n_bins, sat::kThresholds) int32
+  const double* sat_series;
+  const int32_t* sat_series_thr;
 };
 
 struct OccArgs {
@@ -69,6 +73,8 @@ struct OccArgs {
   // moment expansion of the central bins' node sums (series.h), per bin: NULL: off
   const double* series;
   const int32_t* series_thr;
+  const double* sat_series;     // ... of the satellite bins (namespace sat)
+  const int32_t* sat_series_thr;
 };
 
 // Un-batched predict(): one draw through one launch (single_draw_kernel).
@@ -282,6 +288,8 @@ struct FusedArgs {
   GroupArgs group;
   const double* series;        // moment expansion (OccArgs), 64-draw workgroups only
   const int32_t* series_thr;
+  const double* sat_series;
+  const int32_t* sat_series_thr;
 };
 
 // ---- mode cross, one launch per batch (predict_cross_fused_kernel, kernels.hip.h) ----------

@@ -137,6 +137,9 @@ struct DrawParams {
   // wave-uniform: high dword of the wave's largest |1 / sigma| -- what decides how many terms
   // the moment expansion of a central bin needs (series.h); INT_MAX: expansion off
   int series_hi = 0x7fffffff;
+  // ... and of the wave's largest M0: the binomial expansion of a satellite bin (series.h,
+  // namespace sat); INT_MAX: off (also when some draw's alpha lies outside [0, 4])
+  int sat_hi = 0x7fffffff;
 };
 
 // Constants of the moment expansion (launch.hip: get_quadrature): per bin (or member, in group
@@ -144,6 +147,8 @@ struct DrawParams {
 struct SeriesConsts {
   sc_f64 consts = nullptr;
   sc_i32 thresholds = nullptr;
+  sc_f64 sat_consts = nullptr;         // series::sat::kStride doubles per bin / member
+  sc_i32 sat_thresholds = nullptr;
 };
 
 // High dword of the largest |value| of the wave's lanes (non-negative doubles order like their
@@ -157,6 +162,28 @@ __device__ inline int wave_max_high_dword(double value) {
   }
   return __builtin_amdgcn_readfirstlane(hi);
 }
+
+// dp.series_hi / dp.sat_hi of a wave (series.h): what the expansions' term counts follow.
+template <bool MODULATE>
+__device__ inline void series_setup(DrawParams& dp, bool on) {
+  dp.series_hi = on ? wave_max_high_dword(dp.inv_sigma) : 0x7fffffff;
+  const bool alpha_ok =
+      __builtin_amdgcn_ballot_w64(!(dp.alpha >= 0.0 && dp.alpha <= 4.0)) == 0;
+  dp.sat_hi = on && !MODULATE && alpha_ok && !dp.any_bad ? wave_max_high_dword(dp.m0)
+                                                          : 0x7fffffff;
+}
+
+// (Mc - M0)^alpha / M1^alpha times the binomial sum of a satellite bin's moments.
+__device__ __forceinline__ double sat_series_value(const double* table, const fm::Consts& kc,
+                                                   sc_f64 consts, const DrawParams& d,
+                                                   int n_terms) {
+  const double base = consts[0] - d.m0;
+  const double eps = consts[0] * series::sat::reciprocal(base);
+  const double sum = series::sat::binomial_sum(consts, eps, d.alpha, n_terms);
+  return sum * fm::exp2_fast(table, kc,
+                             d.alpha * fm::log2_fast_offset(table, kc, base, d.log2_m1));
+}
+
 
 template <int NGAUSS, bool ASSEMBIAS, bool MODULATE>
 __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm::Consts& kc,
@@ -229,6 +256,16 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
                  : heaviside_assembias(n, a_cen, above, f2, f1, true);
       acc = fma(weight[g * n_gauss + k], n, acc);
     }
+  } else if (!central && !modulate && (!assembias || median) && shortcut == 0 &&
+             sr.sat_consts != nullptr && n_gauss >= 4 &&
+             series::sat::terms_for(sr.sat_thresholds + g * series::sat::kThresholds,
+                                    d.sat_hi) != 0) {
+    // a satellite bin well above every draw's M0: the binomial expansion of its node sum
+    acc = sat_series_value(table, kc, sr.sat_consts + g * series::sat::kStride, d,
+                           series::sat::terms_for(
+                               sr.sat_thresholds + g * series::sat::kThresholds, d.sat_hi));
+    acc *= sat_scale;
+    if (median) acc = fma(s_sat, acc, acc);
   } else {
 #pragma unroll NGAUSS > 0 ? NGAUSS : 1
     for (int k = 0; k < n_gauss; ++k) {
@@ -398,6 +435,37 @@ __device__ __forceinline__ void occ_group_zheng07(const double* table, const fm:
   if (SERIES && central && !assembias && shortcut == 0 && q.series.consts != nullptr)
     n_terms = series::terms_for(q.series.thresholds + m_begin * series::kThresholds,
                                 d.series_hi);
+  if (SERIES && !central && !modulate && shortcut == 0 && q.series.sat_consts != nullptr) {
+    const int sat_terms = series::sat::terms_for(
+        q.series.sat_thresholds + m_begin * series::sat::kThresholds, d.sat_hi);
+    if (sat_terms != 0) {
+      // a group of satellite bins well above every draw's M0: the binomial expansion; the
+      // members share Mc, eps and the coefficients
+      sc_f64 first = q.series.sat_consts + m_begin * series::sat::kStride;
+      const double base = first[0] - m0;
+      const double eps = first[0] * series::sat::reciprocal(base);
+      const double power = fm::exp2_fast(
+          table, kc, alpha * fm::log2_fast_offset(table, kc, base, log2_m1));
+      for (int mi = m_begin; mi < m_end; mi += 2) {
+        const int mj = mi + 1 < m_end ? mi + 1 : mi;
+        double acc_i, acc_j;
+        series::sat::binomial_sum_pair(q.series.sat_consts + mi * series::sat::kStride,
+                                       q.series.sat_consts + mj * series::sat::kStride, eps,
+                                       alpha, sat_terms, &acc_i, &acc_j);
+        acc_i = acc_i * power * sat_scale;
+        acc_j = acc_j * power * sat_scale;
+        if (median) {
+          const double s_i = q.percentile[mi] > split ? d.a_sat : -d.a_sat;
+          const double s_j = q.percentile[mj] > split ? d.a_sat : -d.a_sat;
+          acc_i = fma(s_i, acc_i, acc_i);
+          acc_j = fma(s_j, acc_j, acc_j);
+        }
+        emit(mi, q.member[mi], acc_i);
+        if (mj != mi) emit(mj, q.member[mj], acc_j);
+      }
+      return;
+    }
+  }
   if (SERIES && n_terms != 0) {
     // (a path of its own, so that the node path below stays one straight line whose scalar
     // loads the compiler can start early)
@@ -663,7 +731,7 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     dp.bad = (int)prm[8][lane];
     // wave-uniform: does any draw of this tile need the NaN fix-ups after a bin's node loop?
     dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
-    dp.series_hi = ((GROUPED ? a.group.series : a.series) != nullptr) ? wave_max_high_dword(dp.inv_sigma) : 0x7fffffff;
+    series_setup<MODULATE>(dp, (GROUPED ? a.group.series : a.series) != nullptr);
 
     double sum_cen = 0.0, sum_sat = 0.0;
     auto emit = [&](int g, bool central, double acc, double n_h_g) {
@@ -682,7 +750,8 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
         const GroupConsts gq{(sc_f64)a.group.log_m, (sc_f64)a.group.m, (sc_f64)a.group.weight,
                              (sc_f64)a.group.weight + a.n_bins * 10,
                              (sc_f64)a.group.percentile, (sc_i32)a.group.member,
-                             SeriesConsts{(sc_f64)a.group.series, (sc_i32)a.group.series_thr}};
+                             SeriesConsts{(sc_f64)a.group.series, (sc_i32)a.group.series_thr,
+                                          (sc_f64)a.group.sat_series, (sc_i32)a.group.sat_series_thr}};
         const bool central = g < a.n_central_groups;
         occ_group_zheng07<ASSEMBIAS, MODULATE>(
             table, kc, g, group_begin[g], group_begin[g + 1], central, gq, a.split, dp,
@@ -693,7 +762,8 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
         emit(g, central,
              occ_bin_zheng07<NGAUSS, ASSEMBIAS, MODULATE>(
                  table, kc, g, n_gauss, central, above, log_m, mass, weight, weight_sum, dp, f1,
-                 f2, SeriesConsts{(sc_f64)a.series, (sc_i32)a.series_thr}),
+                 f2, SeriesConsts{(sc_f64)a.series, (sc_i32)a.series_thr, (sc_f64)a.sat_series,
+                              (sc_i32)a.sat_series_thr}),
              n_h[g]);
       }
     }
@@ -1967,7 +2037,7 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
     dp.a_sat = d.a_sat;
     dp.bad = d.bad;
     dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
-    dp.series_hi = ((GROUPED ? a.group.series : a.series) != nullptr && DL == 64) ? wave_max_high_dword(dp.inv_sigma) : 0x7fffffff;
+    series_setup<MODULATE>(dp, (GROUPED ? a.group.series : a.series) != nullptr && DL == 64);
     sc_f64 log_m = (sc_f64)a.log_m;
     sc_f64 mass = (sc_f64)a.m;
     sc_f64 weight = (sc_f64)a.weight;
@@ -1982,7 +2052,8 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
       const GroupConsts gq{(sc_f64)a.group.log_m, (sc_f64)a.group.m, (sc_f64)a.group.weight,
                            (sc_f64)a.group.weight + a.n_bins * 10, (sc_f64)a.group.percentile,
                            (sc_i32)a.group.member,
-                             SeriesConsts{(sc_f64)a.group.series, (sc_i32)a.group.series_thr}};
+                             SeriesConsts{(sc_f64)a.group.series, (sc_i32)a.group.series_thr,
+                                          (sc_f64)a.group.sat_series, (sc_i32)a.group.sat_series_thr}};
       for (int gr = wave; gr < a.n_groups; gr += W) {
         const bool central = gr < a.n_central_groups;
         auto emit = [&](int mi, int g, double acc) {
@@ -2015,7 +2086,8 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
                       : occ_bin_zheng07<NGAUSS, ASSEMBIAS, MODULATE>(
                             table, kc, g, n_gauss, central, above, log_m, mass, weight,
                             weight_sum, dp, f1, f2,
-                            SeriesConsts{(sc_f64)a.series, (sc_i32)a.series_thr});
+                            SeriesConsts{(sc_f64)a.series, (sc_i32)a.series_thr, (sc_f64)a.sat_series,
+                              (sc_i32)a.sat_series_thr});
       const double value = acc * n_h[g];
       if (half == 0) dens[g * DL + draw] = value;
       if (central) sum_cen += value; else sum_sat += value;
@@ -2220,13 +2292,14 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 2 : 4) void predict_cro
     dp.a_sat = d.a_sat;
     dp.bad = d.bad;
     dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
-    dp.series_hi = (a.group.series != nullptr) ? wave_max_high_dword(dp.inv_sigma) : 0x7fffffff;
+    series_setup<MODULATE>(dp, a.group.series != nullptr);
     sc_i32 group_begin = (sc_i32)a.group.begin;
     sc_i32 chunk_group = (sc_i32)a.chunk_group;
     const GroupConsts gq{(sc_f64)a.group.log_m, (sc_f64)a.group.m, (sc_f64)a.group.weight,
                          (sc_f64)a.group.weight + a.n_bins * 10, (sc_f64)a.group.percentile,
                          (sc_i32)a.group.member,
-                             SeriesConsts{(sc_f64)a.group.series, (sc_i32)a.group.series_thr}};
+                             SeriesConsts{(sc_f64)a.group.series, (sc_i32)a.group.series_thr,
+                                          (sc_f64)a.group.sat_series, (sc_i32)a.group.sat_series_thr}};
     sc_f64 rows = (sc_f64)a.rows + wave * RW;
     for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
       if (a.separate && chunk == a.n_central_chunks) {
@@ -2410,7 +2483,8 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kerne
     const GroupConsts gq{(sc_f64)a.group.log_m, (sc_f64)a.group.m, (sc_f64)a.group.weight,
                          (sc_f64)a.group.weight + a.n_bins * 10, (sc_f64)a.group.percentile,
                          (sc_i32)a.group.member,
-                             SeriesConsts{(sc_f64)a.group.series, (sc_i32)a.group.series_thr}};
+                             SeriesConsts{(sc_f64)a.group.series, (sc_i32)a.group.series_thr,
+                                          (sc_f64)a.group.sat_series, (sc_i32)a.group.sat_series_thr}};
     sc_f64 rows = (sc_f64)a.rows;
     auto emit = [&](int mi, int, double nbar) {
       sc_f64 coefficient = rows + (int64_t)mi * a.row_stride;

@@ -59,6 +59,16 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
                            series_thr.data() + (size_t)i * tc::series::kThresholds);
   if (status == TC_OK) status = upload(series, &q.series);
   if (status == TC_OK) status = upload(series_thr, &q.series_thr);
+  std::vector<double> sat_series((size_t)g * tc::series::sat::kStride);
+  std::vector<int32_t> sat_series_thr((size_t)g * tc::series::sat::kThresholds);
+  for (int i = 0; i < g; ++i)
+    tc::series::sat::bin_consts(n_gauss, m.data() + (size_t)i * n_gauss,
+                                weight.data() + (size_t)i * n_gauss, t->log_min[i],
+                                t->log_max[i],
+                                sat_series.data() + (size_t)i * tc::series::sat::kStride,
+                                sat_series_thr.data() + (size_t)i * tc::series::sat::kThresholds);
+  if (status == TC_OK) status = upload(sat_series, &q.sat_series);
+  if (status == TC_OK) status = upload(sat_series_thr, &q.sat_series_thr);
   if (status == TC_OK && n_gauss == 10 &&
       (t->node_groups.largest > 1 || t->mode == TC_MODE_CROSS)) {
     // GROUPED kernels: the nodes of every group (= those of its first member), the weights and
@@ -81,8 +91,15 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
     }
     std::vector<double> g_series((size_t)g * tc::series::kStride);
     std::vector<int32_t> g_series_thr((size_t)g * tc::series::kThresholds);
+    std::vector<double> g_sat((size_t)g * tc::series::sat::kStride);
+    std::vector<int32_t> g_sat_thr((size_t)g * tc::series::sat::kThresholds);
     for (int mi = 0; mi < g; ++mi) {
       const int bin = groups.member[mi];
+      std::copy_n(sat_series.data() + (size_t)bin * tc::series::sat::kStride,
+                  tc::series::sat::kStride, g_sat.data() + (size_t)mi * tc::series::sat::kStride);
+      std::copy_n(sat_series_thr.data() + (size_t)bin * tc::series::sat::kThresholds,
+                  tc::series::sat::kThresholds,
+                  g_sat_thr.data() + (size_t)mi * tc::series::sat::kThresholds);
       std::copy_n(series.data() + (size_t)bin * tc::series::kStride, tc::series::kStride,
                   g_series.data() + (size_t)mi * tc::series::kStride);
       std::copy_n(series_thr.data() + (size_t)bin * tc::series::kThresholds,
@@ -94,6 +111,8 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
     if (status == TC_OK) status = upload(g_weight, &q.group_weight);
     if (status == TC_OK) status = upload(g_series, &q.group_series);
     if (status == TC_OK) status = upload(g_series_thr, &q.group_series_thr);
+    if (status == TC_OK) status = upload(g_sat, &q.group_sat_series);
+    if (status == TC_OK) status = upload(g_sat_thr, &q.group_sat_series_thr);
   }
   if (status != TC_OK) return status;
   t->quadrature[n_gauss] = q;
@@ -112,6 +131,8 @@ tc::GroupArgs group_args(const tc_table* t, const Quadrature& q) {
   ga.percentile = (const double*)t->d_group_percentile;
   ga.series = t->tuning.series ? (const double*)q.group_series : nullptr;
   ga.series_thr = (const int32_t*)q.group_series_thr;
+  ga.sat_series = t->tuning.series ? (const double*)q.group_sat_series : nullptr;
+  ga.sat_series_thr = (const int32_t*)q.group_sat_series_thr;
   return ga;
 }
 
@@ -939,6 +960,8 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   oa.group = group_args(t, *q);
   oa.series = t->tuning.series ? (const double*)q->series : nullptr;
   oa.series_thr = (const int32_t*)q->series_thr;
+  oa.sat_series = t->tuning.series ? (const double*)q->sat_series : nullptr;
+  oa.sat_series_thr = (const int32_t*)q->sat_series_thr;
   {
     const dim3 grid((unsigned)grid_blocks), block(tc::kOccWaves * 64);
     const bool assembias = (flags & TC_FLAG_ASSEMBIAS) != 0;
@@ -1241,6 +1264,8 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   fa.group = group_args(t, *q);
   fa.series = t->tuning.series ? (const double*)q->series : nullptr;
   fa.series_thr = (const int32_t*)q->series_thr;
+  fa.sat_series = t->tuning.series ? (const double*)q->sat_series : nullptr;
+  fa.sat_series_thr = (const int32_t*)q->sat_series_thr;
   fa.log_m = (const double*)q->log_m;
   fa.m = (const double*)q->m;
   fa.weight = (const double*)q->weight;

@@ -370,6 +370,70 @@ int tc_debug_node_groups(int n_bins, int n_central, const double* log_min,
   return TC_OK;
 }
 
+int tc_debug_satellite_series(int n_gauss, double log_min, double log_max, double dist_index,
+                              int64_t n, const double* log_m0, const double* log_m1,
+                              const double* alpha, double* series, double* nodes,
+                              int32_t* terms) {
+  TC_CHECK(n_gauss >= 1 && n_gauss <= 4096 && n >= 0, "invalid arguments");
+  TC_CHECK(log_m0 && log_m1 && alpha && series && nodes && terms, "NULL argument");
+  static std::vector<double> table;
+  if (table.empty()) {
+    table.resize(tc::fm::kTableDoubles);
+    tc::fm::build_tables(table.data());
+  }
+  const tc::fm::Consts kc = tc::fm::make_consts();
+  std::vector<double> x, w;
+  tc::gauss_legendre(n_gauss, x, w);
+  std::vector<double> mass(n_gauss), weight(n_gauss);
+  std::vector<long double> raw(n_gauss);
+  long double norm = 0.0L;
+  for (int k = 0; k < n_gauss; ++k) {
+    mass[k] = std::pow(10.0, log_min + (log_max - log_min) * x[k]);
+    raw[k] = (long double)w[k] * powl((long double)mass[k] / (long double)mass[0],
+                                      (long double)(dist_index + 1.0));
+    norm += raw[k];
+  }
+  for (int k = 0; k < n_gauss; ++k) weight[k] = (double)(raw[k] / norm);
+  std::vector<double> consts(tc::series::sat::kStride);
+  std::vector<int32_t> thresholds(tc::series::sat::kThresholds);
+  tc::series::sat::bin_consts(n_gauss, mass.data(), weight.data(), log_min, log_max,
+                              consts.data(), thresholds.data());
+  for (int64_t i = 0; i < n; ++i) {
+    // (kernels.hip.h: prepare_draw)
+    const double m0 = tc::fm::exp10_fast(table.data(), kc, log_m0[i]);
+    const double hi = log_m1[i] * tc::fm::kLog2Of10Hi;
+    const double lo = fma(log_m1[i], tc::fm::kLog2Of10Hi, -hi) + log_m1[i] * tc::fm::kLog2Of10Lo;
+    const double sat_scale = fma(-alpha[i] * tc::fm::kLn2, lo, 1.0);
+    double sum = 0.0;
+    for (int k = 0; k < n_gauss; ++k) {
+      const double xk = mass[k] - m0;
+      sum = fma(weight[k],
+                tc::fm::exp2_fast(table.data(), kc,
+                                  alpha[i] * tc::fm::log2_fast_offset(
+                                                 table.data(), kc, xk > 1e-300 ? xk : 1e-300, hi),
+                                  xk > 0.0),
+                sum);
+    }
+    nodes[i] = sum * sat_scale;
+    uint64_t bits;
+    memcpy(&bits, &m0, sizeof(bits));
+    terms[i] = alpha[i] >= 0.0 && alpha[i] <= 4.0
+                   ? tc::series::sat::terms_for(thresholds.data(), (int)(bits >> 32))
+                   : 0;
+    if (terms[i] > 0) {
+      const double base = consts[0] - m0;
+      const double eps = consts[0] * tc::series::sat::reciprocal(base);
+      const double s = tc::series::sat::binomial_sum(consts.data(), eps, alpha[i], terms[i]);
+      series[i] = s * tc::fm::exp2_fast(table.data(), kc,
+                                        alpha[i] * tc::fm::log2_fast_offset(table.data(), kc, base,
+                                                                            hi)) * sat_scale;
+    } else {
+      series[i] = nodes[i];
+    }
+  }
+  return TC_OK;
+}
+
 int tc_plan_debug(int mode, int n_bins, const uint8_t* is_central, int n_chunks,
                   int64_t* n_entries, int32_t* entry_pair, int32_t* entry_chunk,
                   int32_t* entry_class) {

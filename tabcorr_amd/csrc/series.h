@@ -59,16 +59,25 @@ TC_HD int terms_for(IntPtr thresholds, int inv_sigma_hi) {
 // Four terms per pass of a loop that is NOT unrolled (the unrolled forms took 150-200 vector
 // registers in the kernels); the next pass's four moments are requested -- one scalar load --
 // before the current ones are used.
-typedef double f64x4_t __attribute__((ext_vector_type(4)));
+struct f64x4_t {
+  double v[4];
+  TC_HD double operator[](int k) const { return v[k]; }
+};
+
+// Four consecutive constants from consts[first + 4 block] on.
+template <typename Ptr>
+TC_HD f64x4_t load_four(Ptr consts, int first, int block) {
+  f64x4_t m;
+  m.v[0] = consts[first + 4 * block];
+  m.v[1] = consts[first + 1 + 4 * block];
+  m.v[2] = consts[first + 2 + 4 * block];
+  m.v[3] = consts[first + 3 + 4 * block];
+  return m;
+}
 
 template <typename Ptr>
 TC_HD f64x4_t load_moments(Ptr consts, int block) {
-  f64x4_t m;
-  m.x = consts[2 + 4 * block];
-  m.y = consts[3 + 4 * block];
-  m.z = consts[4 + 4 * block];
-  m.w = consts[5 + 4 * block];
-  return m;
+  return load_four(consts, 2, block);
 }
 
 template <typename Ptr>
@@ -137,6 +146,114 @@ TC_HD void central_sum_pair(const double* table, const fm::Consts& kc, double lo
   *out_i = fma(g0, sum_i, m0_i * e);
   *out_j = fma(g0, sum_j, m0_j * e);
 }
+
+// ---- satellites ---------------------------------------------------------------------------
+//
+// <N_sat>(M) = ((M - M0) / M1)^alpha above M0 (Zheng et al. 2007, eq. 3; tabcorr.py:560-563).
+// With the bin's reference mass Mc (its geometric centre), y_k = M_k / Mc - 1 and
+// eps = Mc / (Mc - M0):
+//
+//   sum_k W_k (M_k - M0)^alpha = (Mc - M0)^alpha sum_n C(alpha, n) eps^n mu_n,   mu_n = sum_k W_k y_k^n
+//
+// (binomial series of (1 + eps y)^alpha; the moments mu_n do not depend on the draw): one
+// log2 + exp2 for (Mc - M0)^alpha / M1^alpha and three instructions per term -- d_(n+1) = d_n eps
+// (alpha - n) with the 1 / n! folded into the moments -- instead of ten log2 + exp2.  For
+// 0 <= alpha <= 4 the coefficients stay below 16, so n terms leave a tail below 1e-16 when
+// r = eps max|y_k| <= 0.047 (12 terms), 0.097 (16), 0.15 (20), 0.20 (24), 0.25 (28), 0.30 (32):
+// bins far enough above M0 (M0 <= Mc (1 - max|y| / r)); the others run their node loop.
+namespace sat {
+
+constexpr int kMaxTerms = 32;
+constexpr int kSteps = 6;                    // 12, 16, ..., 32 terms
+constexpr int kStride = 2 + kMaxTerms + 2;   // per bin: Mc, max|y|, mu_0 / 0! .. mu_32 / 32!, pad
+constexpr int kThresholds = 8;               // int32 per bin (kSteps used)
+
+// Largest r = eps max|y| for which `n_terms` terms leave a tail below kTolerance.
+double r_max(int n_terms);
+
+// Per-bin constants from the bin's node masses and normalised weights: consts[0] = Mc,
+// consts[2 + n] = mu_n / n!; thresholds[s] = high dword of the largest M0 for which 12 + 4 s
+// terms suffice (0: never).
+void bin_consts(int n_gauss, const double* mass, const double* weight, double log_min,
+                double log_max, double* consts, int32_t* thresholds);
+
+template <typename IntPtr>
+TC_HD int terms_for(IntPtr thresholds, int m0_hi) {
+  int n = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int s = kSteps - 1; s >= 0; --s)
+    if (m0_hi < thresholds[s]) n = 12 + 4 * s;
+  return n;
+}
+
+// 1 / x to rounding (hardware estimate + two Newton steps on the device).
+TC_HD double reciprocal(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return fma(fma(-x, r, 1.0), r, r);
+#else
+  return 1.0 / x;
+#endif
+}
+
+// sum_k W_k (1 + eps y_k)^alpha by n_terms (a multiple of 4) terms + the n = 0 term.
+template <typename Ptr>
+TC_HD double binomial_sum(Ptr consts, double eps, double alpha, int n_terms) {
+  double d = 1.0, g = eps * alpha, sum = consts[2];         // n = 0: mu_0
+  const int n_blocks = n_terms >> 2;
+  // moments mu_n / n! for n >= 1 start at consts[3]: blocks of four from there
+  f64x4_t cur = load_four(consts, 3, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int block = 0; block < n_blocks; ++block) {
+    const f64x4_t next = load_four(consts, 3, block + 1 < n_blocks ? block + 1 : block);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; ++k) {
+      d *= g;                       // d_n = d_(n-1) eps (alpha - (n - 1))
+      g -= eps;
+      sum = fma(d, cur[k], sum);
+    }
+    cur = next;
+  }
+  return sum;
+}
+
+// The same for two bins with the same nodes (same Mc, eps): the coefficients once.
+template <typename Ptr>
+TC_HD void binomial_sum_pair(Ptr consts_i, Ptr consts_j, double eps, double alpha, int n_terms,
+                             double* out_i, double* out_j) {
+  double d = 1.0, g = eps * alpha, sum_i = consts_i[2], sum_j = consts_j[2];
+  const int n_blocks = n_terms >> 2;
+  f64x4_t cur_i = load_four(consts_i, 3, 0), cur_j = load_four(consts_j, 3, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int block = 0; block < n_blocks; ++block) {
+    const int ahead = block + 1 < n_blocks ? block + 1 : block;
+    const f64x4_t next_i = load_four(consts_i, 3, ahead), next_j = load_four(consts_j, 3, ahead);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; ++k) {
+      d *= g;
+      g -= eps;
+      sum_i = fma(d, cur_i[k], sum_i);
+      sum_j = fma(d, cur_j[k], sum_j);
+    }
+    cur_i = next_i;
+    cur_j = next_j;
+  }
+  *out_i = sum_i;
+  *out_j = sum_j;
+}
+
+}  // namespace sat
 
 }  // namespace series
 }  // namespace tc

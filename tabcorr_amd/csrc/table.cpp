@@ -237,7 +237,9 @@ int tc_table_destroy(tc_table* t) {
   for (auto& kv : t->quadrature)
     for (void* p : {kv.second.log_m, kv.second.m, kv.second.weight, kv.second.group_log_m,
                     kv.second.group_m, kv.second.group_weight, kv.second.series,
-                    kv.second.series_thr, kv.second.group_series, kv.second.group_series_thr})
+                    kv.second.series_thr, kv.second.group_series, kv.second.group_series_thr,
+                    kv.second.sat_series, kv.second.sat_series_thr, kv.second.group_sat_series,
+                    kv.second.group_sat_series_thr})
       if (p) (void)hipFree(p);
   for (auto& kv : t->chunkings)
     for (void* p : {kv.second->chunks, kv.second->groups})

@@ -1074,3 +1074,41 @@ def test_central_moment_expansion_reproduces_the_node_loop():
         used.setdefault((width, n_gauss), set()).update(int(t) for t in terms)
     assert {0, 16, 20, 24} <= used[0.09, 10]
     assert {8, 12} <= used[0.0121, 10] and 0 in used[0.3, 10]
+
+
+def test_satellite_binomial_expansion_reproduces_the_node_loop():
+    """csrc/series.h (namespace sat): the binomial re-ordering of a satellite bin's node sum
+    around the bin's reference mass, on the host with the kernels' inline code, against the node
+    loop: to rounding of the log2 / exp2 chain wherever it applies (bins well above M0,
+    0 <= alpha <= 4), with 12 ... 32 terms chosen from M0 alone."""
+    from tabcorr_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    seen = {}
+    for width, lo_range, dist_index, n_gauss in (
+            (0.09, (10.5, 14.9), -2.0, 10),          # BASELINE configs[1]
+            (0.0121, (11.8, 15.4), 7.0, 10),         # the reference's AbacusSummit table
+            (0.0121, (11.8, 15.4), -10.0, 10),
+            (0.15, (10.5, 14.8), -1.6, 10),          # bolplanck wp table
+            (0.09, (10.5, 14.9), -2.0, 100),
+            (0.09, (10.5, 14.9), -2.0, 4)):
+        for trial in range(12):
+            log_min = rng.uniform(*lo_range)
+            n = 1500
+            log_m0 = rng.uniform(10.5, 13.5, n)
+            log_m1 = rng.uniform(12.5, 14.5, n)
+            alpha = rng.uniform(-0.5, 4.5, n)
+            series, nodes = np.empty(n), np.empty(n)
+            terms = np.zeros(n, dtype=np.int32)
+            _lib.check(lib.tc_debug_satellite_series(
+                n_gauss, log_min, log_min + width, dist_index, n, _lib.as_double_p(log_m0),
+                _lib.as_double_p(log_m1), _lib.as_double_p(alpha), _lib.as_double_p(series),
+                _lib.as_double_p(nodes), terms.ctypes.data_as(_lib.c_int32_p)))
+            assert set(terms) <= {0, 12, 16, 20, 24, 28, 32}
+            assert np.all(terms[(alpha < 0) | (alpha > 4)] == 0)
+            used = terms > 0
+            assert np.all(10.0**log_m0[used] < 10.0**(log_min + 0.5 * width))
+            np.testing.assert_allclose(series[used], nodes[used], rtol=2e-14)
+            assert np.array_equal(series[~used], nodes[~used])
+            seen.setdefault(width, set()).update(int(t) for t in terms)
+    assert {0, 20, 24} <= seen[0.09] and {0, 12} <= seen[0.0121]
