@@ -359,7 +359,12 @@ int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, 
   // hostmath.h)
   // (interpolators: the waves of an XCD share its K / 8 matrices -- all at once while those fit
   // its L2 next to the density rows, one after the other beyond ~3 MB: kQuadTableSync)
-  const bool many_matrices = (double)n_tables * (double)q->bytes / 8.0 > 3.0 * 1024 * 1024;
+  // (from eight tables on: every XCD then owns whole tables.  BASELINE configs[3], 25 tables of
+  // 0.83 MB: 937 -> 930 us per 12 500 draws and 4.08 -> 3.14 GB of fabric reads; the database's
+  // 64 tables of 1.5 MB: 3547 -> 2730 us.  Tried and dropped: tile by tile inside every XCD's
+  // tables -- consecutive waves share a tile's density rows but cycle through the XCD's three
+  // matrices: 5.9 GB, 948 us; profiles/r04_notes.md)
+  const bool many_matrices = n_tables >= 8;
   const int order = n_tables > 1 ? ((t->tuning.quad_order == tc::kQuadTableMajor ||
                                      t->tuning.quad_order == tc::kQuadTableSync)
                                         ? t->tuning.quad_order
