@@ -1320,7 +1320,7 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
                        rel(xi[ends5], expect5[1]))
         for dtype, tag, peak, kernel in (
                 ('float32', 'cfg5f32', FP32_PEAK_TFLOPS, 'tc::contract_quad_f32_kernel<4, false>'),
-                ('float64', 'cfg5f64', FP64_PEAK_TFLOPS, 'tc::contract_mfma_kernel<32, false>')):
+                ('float64', 'cfg5f64', FP64_PEAK_TFLOPS, 'tc::contract_quad_kernel<5, false>')):
             if not wanted(tag):
                 continue
             tab5 = make(table5, compute_dtype=dtype)

@@ -481,7 +481,29 @@ void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, in
   out.group_begin.assign((size_t)out.n_groups + 1, 0);
   // table-synchronous: needs whole eighths of the waves (else plain table-major)
   table_sync = table_sync && n_waves >= 8 && n_waves % 8 == 0;
-  const int64_t per_xcd = table_sync ? n_waves / 8 : 1;
+  bool unit_sync = order == kQuadUnitSync && n_tables == 1 && n_waves >= 8 &&
+                   n_waves % 8 == 0 && layout.n_units >= 64;
+  // kQuadUnitSync: S sub-ranges per (draw tile, r tile) such that the rounds of an XCD fill
+  int unit_parts = 1;
+  int64_t n_items = 0;
+  if (unit_sync) {
+    double best = -1.0;
+    for (int parts = 1; parts <= 8 && layout.n_units / parts >= 64; ++parts) {
+      const double per = (double)n_tiles * n_rtiles * parts / (double)n_waves;
+      const double fill = per / std::ceil(per);
+      if (fill > best + 1e-9) {
+        best = fill;
+        unit_parts = parts;
+      }
+    }
+    n_items = (int64_t)n_tiles * n_rtiles * unit_parts;
+    // (fewer items than waves: as many waves as whole eighths of the items)
+    if (n_items < n_waves) n_waves = n_items / 8 * 8;
+    unit_sync = n_waves >= 8;
+    if (!unit_sync) n_waves = std::max<int64_t>(1, std::min<int64_t>(max_waves, n_items));
+    out.n_waves = (int)n_waves;
+  }
+  const int64_t per_xcd = table_sync || unit_sync ? n_waves / 8 : 1;
   const int64_t per_table_span = layout.n_units * n_rtiles * (int64_t)n_tiles;
 
   // position -> (tile, rtile, comp, table, unit in component)
@@ -502,6 +524,18 @@ void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, in
         intervals.emplace_back(a + (int64_t)((__int128)(b - a) * local / per_xcd),
                                a + (int64_t)((__int128)(b - a) * (local + 1) / per_xcd));
         a = b;
+      }
+    } else if (unit_sync) {
+      // items in (r tile, sub-range, draw tile) order; XCD x owns items [n x / 8, n (x + 1) / 8),
+      // its wave `local` takes every per_xcd-th of them
+      const int64_t xcd = w / per_xcd, local = w % per_xcd;
+      const int64_t lo = n_items * xcd / 8, hi = n_items * (xcd + 1) / 8;
+      for (int64_t item = lo + local; item < hi; item += per_xcd) {
+        const int64_t tile = item % n_tiles, rest = item / n_tiles;
+        const int64_t part = rest % unit_parts, rtile = rest / unit_parts;
+        const int64_t base = (tile * n_rtiles + rtile) * per_rtile;
+        intervals.emplace_back(base + layout.n_units * part / unit_parts,
+                               base + layout.n_units * (part + 1) / unit_parts);
       }
     } else {
       // (128-bit product: span * w can exceed 63 bits for huge batches of huge tables)

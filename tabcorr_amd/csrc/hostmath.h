@@ -207,8 +207,14 @@ struct QuadSchedule {
 // AFTER THE OTHER, each wave taking an equal slice of every table's (draw tile, r tile, unit)
 // space in turn: at any time the XCD's waves read one matrix instead of all K / 8 of them
 // (64 tables of 120 bins: 12 MB per L2 of 4 MB, 23 GB of fabric reads per 10^4 draws).
+// kQuadUnitSync (one table whose matrix is far beyond the L2s: BASELINE configs[4], 38 r tiles of
+// 4 MB in float64): the (r tile, sub-range of the units, draw tile) items -- S sub-ranges per
+// (draw tile, r tile), S chosen so that the rounds fill -- are dealt to the XCDs in that order
+// and inside an XCD round-robin to its waves, so that at any time the 256 waves of an XCD walk
+// the SAME units of the same r tile for different draw tiles: the matrix streams through every
+// L2 once per round instead of once per wave.  Shares differ by one item (a few per cent).
 constexpr int kQuadTileMajor = 0, kQuadTableMajor = 1, kQuadRtileMajor = 2, kQuadUnitMajor = 3,
-              kQuadTableSync = 4;
+              kQuadTableSync = 4, kQuadUnitSync = 5;
 constexpr int kQuadUnitParts = 8;
 void build_quad_schedule(const QuadLayout& layout, int n_tiles, int n_rtiles, int n_tables,
                          bool separate, int max_waves, int min_units_per_wave,

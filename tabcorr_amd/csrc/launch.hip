@@ -371,6 +371,12 @@ int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, 
                                     : many_matrices ? tc::kQuadTableSync
                                                     : tc::kQuadTableMajor)
                     : t->tuning.quad_order >= 0 ? t->tuning.quad_order
+                    // (one matrix far beyond the L2s, BASELINE configs[4]: the waves of an XCD
+                    // walk the same units for different draw tiles -- float64 7.3 ms draw-tile-
+                    // major / 7.0 r-tile-major / 4.40 this way, against 4.76 for the segment
+                    // kernel that served it until round 3; float32 2.23 -> 2.24 ms with 3.2 GB
+                    // of fabric reads instead of 9.9)
+                    : q->bytes > ((size_t)32 << 20) ? tc::kQuadUnitSync
                     : (t->compute_dtype == TC_DTYPE_F64 && t->quad_tiling.n_rtiles > 1 &&
                        q->bytes > ((size_t)4 << 20))
                         ? tc::kQuadRtileMajor

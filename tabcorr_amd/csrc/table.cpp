@@ -185,13 +185,13 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
     tc::fm::build_tables(math_table.data());
     status = upload(math_table, &t->d_math_table);
   }
-  // The quadratic-form kernel serves mode auto in float64 up to 32 MB of matrix.  While the
+  // The quadratic-form kernel serves mode auto in float64 up to 256 MB of matrix.  While the
   // matrix fits an L2 (cfg2 0.8 MB, cfg3 3.2 MB) the shares walk it once per tile of 32 draws;
   // larger ones are walked r tile by r tile by all waves (hostmath.h: kQuadRtileMajor),
-  // interpolators table by table.  Beyond that (BASELINE configs[4] in float64: 38 r tiles of
-  // 4 MB each, more than an L2 per r tile) every wave would still stream its slice from the
-  // Infinity Cache per draw tile (measured 8.2 ms tile-major, 7.2 ms r-tile-major) where the
-  // segment kernel's workgroups share theirs through LDS (4.7 ms): those stay there.
+  // interpolators table by table, and matrices far beyond the L2s (BASELINE configs[4] in
+  // float64: 38 r tiles of 4 MB) unit-synchronously: the waves of an XCD read the same units at
+  // the same time (kQuadUnitSync: 4.40 ms per 10^4 draws against 4.76 for the segment kernel,
+  // whose workgroups share their slice through LDS, and 7.0-7.3 in the other orders).
   const tc::QuadTiling quad_tiling = tc::quad_tiling(n_r);
   const double quad_blocks = (n_bins / 4.0 + 1.0) * (n_bins / 4.0 + 2.0) / 2.0;
   const double quad_bytes =
@@ -201,7 +201,7 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
   const tc::QuadTiling quad_tiling_f32 = tc::quad_tiling_f32(n_r);
   const bool quad_f32 = compute_dtype == TC_DTYPE_F32 && quad_blocks * 1024.0 <= 3.0 * 1024 * 1024;
   if (status == TC_OK && mode == TC_MODE_AUTO &&
-      ((compute_dtype == TC_DTYPE_F64 && quad_bytes <= 32.0 * 1024 * 1024) || quad_f32)) {
+      ((compute_dtype == TC_DTYPE_F64 && quad_bytes <= 256.0 * 1024 * 1024) || quad_f32)) {
     // quadratic-form kernel: the matrix by galaxy type and, when the centrals do not fill
     // whole 4 x 4 blocks, the unpadded triangle for the total prediction
     t->quad = true;

@@ -801,6 +801,9 @@ def test_host_logic_under_address_and_undefined_sanitizers(tmp_path):
         (60, 30, 1, 37, 1, 25, 1, 1024, 4),       # ... tables not a multiple of 8, separated
         (20, 10, 0, 3, 2, 5, 0, 64, 4),           # ... fewer tables than XCDs, two r tiles
         (20, 10, 0, 3, 1, 5, 0, 30, 4),           # ... waves not a multiple of 8: table-major
+        (200, 100, 0, 313, 38, 1, 0, 2048, 5),    # configs[4] in float64: unit-synchronous
+        (200, 100, 1, 40, 3, 1, 1, 2048, 5),      # ... separated by galaxy type
+        (24, 12, 0, 5, 2, 1, 0, 64, 5),           # ... few units: one part per (tile, r tile)
         (200, 100, 1, 313, 1, 1, 0, 2048, 3),     # ... and the total
         (37, 20, 1, 5, 2, 1, 1, 64, 3),           # unit-major with parts smaller than a share
         (13, 5, 0, 3, 2, 1, 0, 64, 0),
@@ -823,8 +826,11 @@ def test_quad_schedule_covers_every_unit_once(lib, n_bins, n_central, by_type, n
     assert 1 <= n_waves.value <= max_waves
     # equal shares (per r tile in r-tile-major order: a unit of slack per pass)
     # (table-synchronous: a unit per table piece of an XCD's range)
+    # (unit-synchronous: whole items of up to all units of a (draw tile, r tile); a few per cent)
+    n_units = (n_bins // 4 + 1) * (n_bins // 4 + 2) // 2 + 8
     assert hi.value - lo.value <= (n_rtiles if order == 2 else
-                                   n_tables // 8 + 2 if order == 4 else 1)
+                                   n_tables // 8 + 2 if order == 4 else
+                                   n_units if order == 5 else 1)
     assert n_slabs.value >= 1 and n_runs.value >= n_waves.value
 
 
@@ -858,7 +864,8 @@ def test_quad_emulation_matches_the_oracle(lib, n_prim, n_sec, n_r, separate, n_
     padded[:, :n_draws] = densities
     is_central = np.ascontiguousarray(oracle.is_centrals(gal_type), dtype=np.uint8)
     n_comp = 3 if separate else 1
-    for max_waves, order in ((5, 0), (2048, 0), (5, 2), (2048, 2), (5, 3), (2048, 3)):
+    for max_waves, order in ((5, 0), (2048, 0), (5, 2), (2048, 2), (5, 3), (2048, 3), (16, 5),
+                             (2048, 5)):
         out = np.zeros((n_draws, n_comp, n_r))
         _lib.check(lib.tc_debug_quad_emulate(
             n_bins, n_r, _lib.as_double_p(matrix), is_central.ctypes.data_as(_lib.c_uint8_p),
