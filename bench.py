@@ -232,7 +232,7 @@ def main():
     parser = argparse.ArgumentParser()
     parser.add_argument('--gpus', type=int, default=1)
     # defaults: about one second of timed steps -- the chip's power management needs tens of
-    # milliseconds of load to settle (tools/ramp.py: 10-ms regions started from idle run
+    # milliseconds of load to settle (tools/archive/ramp.py: 10-ms regions started from idle run
     # 10-20 % slower than the sustained rate)
     parser.add_argument('--steps', type=int, default=None)
     parser.add_argument('--warmup', type=int, default=None)
@@ -421,9 +421,9 @@ def main():
         # the runtime's four hardware queues and shares one with a lane, whose kernels then
         # wait behind the gather (and the other way round).  Three lanes leave it a queue of
         # its own: 51.5 against 58 us per step in the short run with a gather every 5 steps
-        # (one rank, tools/r02_forced_comm.sh); with a gather every 32 steps four lanes stay
+        # (one rank, tools/archive/r02_forced_comm.sh); with a gather every 32 steps four lanes stay
         # ahead, and so they do with the likelihood payload (16 B per draw: the gather kernel
-        # is short; 49.4-52.0 against 53.2-53.5 us per step, tools/r03_forced_comm.sh).
+        # is short; 49.4-52.0 against 53.2-53.5 us per step, tools/archive/r03_forced_comm.sh).
         lanes_used = 3
         _lib.check(lib.tc_table_set_option(timer_handle, b'lanes', lanes_used))
 
@@ -448,7 +448,7 @@ def main():
         lib, _lib, timer_handle, lambda: predict(0), synchronize)
     _lib.check(lib.tc_table_set_option(timer_handle, b'pipeline', 1))
 
-    # Untimed: load the chip until its power management has settled (tools/ramp.py: a
+    # Untimed: load the chip until its power management has settled (tools/archive/ramp.py: a
     # region started from idle runs 10-20 % slower for the first tens of milliseconds),
     # then the W warm-up steps.  The driver's short runs (--steps 20) would otherwise time
     # the ramp, not the path.
@@ -465,7 +465,7 @@ def main():
         settle_steps = int(comm.max(int(args.settle_seconds / per_step) + 1))
         # in chunks with a drain after each: the runtime retires finished commands lazily, and
         # thousands of them left over from one long burst make later launches stall
-        # (tools/stall.py: 60-100 us per launch for a while, as long as 10 steps)
+        # (tools/archive/stall.py: 60-100 us per launch for a while, as long as 10 steps)
         chunk = 4 * n_slots
         for begin in range(0, settle_steps, chunk):
             count = min(chunk, settle_steps - begin)

@@ -129,7 +129,7 @@ inline size_t stage_limit() {
 // Calls moving at most this many bytes skip the copy commands: the kernels address the
 // page-locked staging buffers directly.  512 KB (2000-2500 draws of a 19-bin table: 67 us per
 // call against 83 with copies); beyond it the finalisation kernel's transposed stores over
-// PCIe lose to the copy engines (3000 draws: 125 us against 105, tools/r02_host_limits.sh).
+// PCIe lose to the copy engines (3000 draws: 125 us against 105, tools/archive/r02_host_limits.sh).
 inline size_t zero_copy_limit() {
   static const size_t limit = (size_t)env_int_early("TC_ZERO_COPY_KB", 512) << 10;
   return limit;
@@ -269,7 +269,7 @@ struct Tuning {
   // contraction -> finalisation); below the contraction's priority its dependent chains of
   // FP64 instructions wait behind 64-cycle matrix instructions and the kernel takes 85-95 us
   // in the pipeline (25 us alone), which the lane's next two kernels then wait for: 44.2 us
-  // per step with priority 0, 43.2 with 1, 42.6 with 2, 48.1 with 3 (tools/r02_sweep.sh)
+  // per step with priority 0, 43.2 with 1, 42.6 with 2, 48.1 with 3 (tools/archive/r02_sweep.sh)
   int prio_occ = 2, prio_contract = 1, prio_finalize = 3;
   int finalize_threads = 0;   // 0: chosen per batch size
   int finalize_row_blocks = 0;
@@ -278,7 +278,7 @@ struct Tuning {
   int n_groups = 0, n_waves = 0, lds_min = 0, min_chunk_entries = 32;   // segment kernels
   int k_splits = 0;           // interpolator, segment kernels: table splits (0: chosen)
   int trace = 0;              // developer timelines
-  // Asynchronous host calls (10^4 draws per call, four lanes, tools/r03_async_sweep.sh): with
+  // Asynchronous host calls (10^4 draws per call, four lanes, tools/archive/r03_async_sweep.sh): with
   // copy commands both ways 64-68 us per call; the occupation kernel reading the draws from
   // the caller's page-locked memory itself (one command and one engine hop of ~10 us less in
   // the lane's chain) 58; small results (number densities, chi2) stored by the finalisation
@@ -291,13 +291,13 @@ struct Tuning {
   // One launch per batch (predict_fused_kernel) for the calls it covers: 0 never, 1 the
   // pipelined device-pointer and asynchronous calls of fused_min_draws .. fused_max_draws
   // draws, 2 every call of that size.  Sustained device-resident rate on four lanes
-  // (tools/r03_fused_scan.py, BASELINE configs[1]'s table; three kernels / one launch, us per
+  // (tools/archive/r03_fused_scan.py, BASELINE configs[1]'s table; three kernels / one launch, us per
   // call): 4096 draws 23.6 / 30.7, 6144 31.4 / 31.5, 7168 34.9 / 32.0, 8192 35.6 / 33.0, 10^4
   // 42.7 / 39.6, 16384 66.7 / 63.5, 28672 111.7 / 111.0, 32768 126.3 / 126.6,
   // 40000 151.8 / 156.3 -- both designs approach the same 38 us per 10^4 draws for huge
   // batches (matrix + vector instructions on one FP64 pipe); the one-launch form gets there
   // with the batch sizes an ensemble sampler has, the three kernels spread small batches
-  // over the whole chip.  Asynchronous host calls (us per call, tools/r03_async.py): 6144 draws
+  // over the whole chip.  Asynchronous host calls (us per call, tools/archive/r03_async.py): 6144 draws
   // 38.8 / 41.6, 10^4 58 / 47.6, 20 000 93.7 / 82.6, 40 000 176 / 162: no upper bound there.
   int series = 1;               // moment expansion of the central bins' node sums (series.h)
   int fused = 1;
@@ -455,7 +455,7 @@ struct tc_table {
   // events so that their results appear in call order.  Off by default: every call only orders
   // its own kernels, tc_table_synchronize / tc_comm_gather wait for every lane (the chain
   // costs 0.3 us per step on prior draws and 3 us on posterior-like ones, whose short
-  // occupation kernels then wait for a neighbour's finalisation: tools/r03_clustered.py).
+  // occupation kernels then wait for a neighbour's finalisation: tools/archive/r03_clustered.py).
   bool chain = false;
   // Tickets of the asynchronous host calls (tc_*_async): a ring of events; a ticket whose
   // slot was reused is older than every lane's current work.
@@ -590,7 +590,7 @@ int64_t max_slab(const tc_table* t);
 bool single_draw_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags);
 constexpr int kSingleMaxBlocks = 64;
 constexpr int kSingleMaxWalkers = 64;
-// Batches of at most this many draws take the one-launch path (tools/r03_latency.py: 1 draw
+// Batches of at most this many draws take the one-launch path (tools/archive/r03_latency.py: 1 draw
 // 15 us, 16 draws 25 us, 64 draws 35 us against 36-37 us for the three-kernel path).
 inline int64_t many_walkers_limit() {
   static const int64_t limit =

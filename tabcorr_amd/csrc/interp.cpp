@@ -617,7 +617,7 @@ int interp_predict_one(tc_interp* it, const double* theta, int n_theta, const do
   // One workgroup of 1024 threads per CU at a time (16 of the 24 wave slots its registers
   // allow): all tables' workgroups in ONE round where that leaves each of them at most four
   // passes over its positions -- a workgroup that waits for a CU costs more than more passes
-  // (tools/r03_interp_one.py, un-batched predict(model), us per call, one pass per workgroup /
+  // (tools/archive/r03_interp_one.py, un-batched predict(model), us per call, one pass per workgroup /
   // one round: 5 x 5 tables of 100 bins 35.0 / 31.3 (325 / 250 workgroups), 6 x 6 37.5 / 31.9,
   // 4 x 4 x 4 58.8 / 41.0 (832 / 256 workgroups); 4 x 4 fits anyway: 28.8)
   int blocks = single_draw_blocks(t0);

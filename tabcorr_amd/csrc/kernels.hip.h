@@ -2615,7 +2615,7 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kerne
 // fixed order and normalises (table.cpp) -- deterministic like the batched path.  There is
 // no inter-workgroup step on the device: the first version combined the partial sums in
 // the last workgroup to arrive (device-scope fence + counter), and per-phase stamps
-// (tools/single_trace.py) showed that this tail -- fence 2.6 us, atomic 1.7 us, re-read and
+// (tools/archive/single_trace.py) showed that this tail -- fence 2.6 us, atomic 1.7 us, re-read and
 // write-out 6.3 us -- was 10 of the kernel's 17 us.  Total correlation function only, one r
 // tile, G * n_gauss <= kSingleMaxNodes.
 constexpr int kSingleThreads = 1024;
@@ -2926,7 +2926,7 @@ __device__ __forceinline__ void single_draw_body(SingleArgs a) {
   if (!RESIDENT) break;
   ++serving;
   {
-    // (diagnosis, tools/r03_resident.py: 100 MHz ticks from the sight of the call to here)
+    // (diagnosis, tools/archive/r03_resident.py: 100 MHz ticks from the sight of the call to here)
     t_last = __builtin_amdgcn_s_memrealtime();
     if (tid == 0) a.exited[kResidentBusyOffset + blockIdx.x] = t_last - resident_seen;
   }

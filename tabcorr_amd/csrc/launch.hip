@@ -182,7 +182,7 @@ int blocks_per_cu(int lds_bytes, int waves, int slots) {
 // Candidates (4 or 8 waves per workgroup, 1..32 groups) are ranked by a small cost model
 // of the busiest CU -- workgroups per CU x waves x (entries per wave + fixed overhead),
 // penalised when fewer than four waves per SIMD are resident or when the workgroups need
-// several scheduling rounds -- calibrated on per-workgroup timelines (tools/trace.py):
+// several scheduling rounds -- calibrated on per-workgroup timelines (tools/archive/trace.py):
 // the main loop issues one FP64 VALU instruction per 4 cycles per SIMD as long as >= 4
 // waves per SIMD are resident, and idle time comes from uneven workgroup counts per CU.
 int choose_chunking(tc_table* t, int64_t n_draws, int tables_per_block,
@@ -783,7 +783,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
   ca.pos_off = (const int32_t*)t->d_pos_off;
   if (const int ring = t->tuning.trace) {
     // developer timelines: ring > 1 keeps the block records of the last `ring` launches
-    // (tools/occupancy.py) and skips the per-wave stamps
+    // (tools/archive/occupancy.py) and skips the per-wave stamps
     const size_t blocks = (size_t)(ldb / 64) * n_groups * t->n_rtiles;
     t->trace_blocks = blocks * ring;
     status = t->trace.reserve(t->trace_blocks * 6 * sizeof(unsigned long long), stream);
@@ -979,7 +979,7 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
     const bool modulate = (flags & TC_FLAG_MODULATE_WITH_CENOCC) != 0;
 #define TC_OCC(NG, AB, MO)                                                           \
   hipLaunchKernelGGL((tc::occ_zheng07_kernel<NG, AB, MO>), grid, block, 0, stream, oa)
-    // diagnosis only (developer builds, tools/ab.sh): reuse the densities of the previous call
+    // diagnosis only (developer builds, tools/archive/ab.sh): reuse the densities of the previous call
     static int occ_calls = 0;
     if (t->tuning.skip_occ && ++occ_calls > 8) return TC_OK;
     if (flags & TC_FLAG_LEAUTHAUD11) {
@@ -1046,7 +1046,7 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
   // Two workgroups of 8 waves per CU (up to 80 KB of LDS each: 104 bins) or not at all: larger
   // tables fit ONE workgroup per CU, whose phases no neighbour covers.  With 8 waves the three
   // kernels are then 8-13 % ahead, with 16 waves (eight parts of the units per tile, four waves
-  // per SIMD again) level -- tools/r03_fused_waves.py, 10^4 draws, us per step, three kernels /
+  // per SIMD again) level -- tools/archive/r03_fused_waves.py, 10^4 draws, us per step, three kernels /
   // 8 waves / 16 waves: G = 112 51.8 / 55.6 / 51.5, 128 64.2 / 69.2 / 64.3, 200 137.0 / 150.9 /
   // 138.7, 240 189.6 / 215.0 / 192.3; G = 100: 43.5 / 39.4 / 43.2 -- so beyond 104 bins the
   // one-launch form (16 waves, up to 160 KB: 248 bins) is taken only when forced.
@@ -1065,7 +1065,7 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
   // workgroup alone on its CU (us): 5 + 10 (G / 100) (n_gauss / 10) [occupations] + 60 (units /
   // 325) (U / 5) [matrix work]: 75 for BASELINE configs[1]'s table, 33 for the reference's
   // example table (G = 60), 27 for G = 100 with three r values.  Measured crossovers
-  // (tools/r03_fused_scan.py with N_PRIM / N_R): estimates up to 28 us win from 512 draws on
+  // (tools/archive/r03_fused_scan.py with N_PRIM / N_R): estimates up to 28 us win from 512 draws on
   // (G = 40: 5.8 against 11.0 us per call at 512 draws; G = 100 with three r values: 8.5 /
   // 12.0), longer workgroups from ~90 draws per estimated microsecond (G = 60: 3000-4000;
   // G = 100, R = 8: 4096; G = 80: 5000; G = 100, R = 19: 6500-7000) -- below that both forms
@@ -1077,27 +1077,27 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
                             8.0 / (wide ? 16 : fused_waves(t, separate));
     // Leauthaud11 (a Newton inverse of the stellar-to-halo mass relation per central node: the
     // occupations outweigh the matrix work and spread better over the chip as a kernel of their
-    // own): tools/r03_fused_leauthaud.py, us per step, three kernels / one launch of 64-draw
+    // own): tools/archive/r03_fused_leauthaud.py, us per step, three kernels / one launch of 64-draw
     // workgroups: G = 100: 4000 draws 57.3 / 88.7, 10^4 126.0 / 114.5; G = 60: 4000 38.4 / 49.9,
     // 10^4 73.0 / 65.2 (32-draw workgroups below 8192 draws: further down); with
     // modulate_with_cenocc (the inverse at the satellites' nodes too) never clearly ahead: 10^4
     // draws 183.4 / 188.1 and 106.0 / 106.0, 4000 draws in 32-draw workgroups 80.2 / 80.6 and
     // 51.5 / 45.9 -- only when forced.
     if (leauthaud && (flags & TC_FLAG_MODULATE_WITH_CENOCC) && t->tuning.fused < 2) return false;
-    // Wide tables (eight waves x 32 draws; tools/r03_fused_wide.py, us per step, three kernels /
+    // Wide tables (eight waves x 32 draws; tools/archive/r03_fused_wide.py, us per step, three kernels /
     // one launch: G = 112: 1024 draws 14.9 / 18.6, 2048 21.4 / 19.1, 4096 27.2 / 20.3, 10^4 52.3 /
     // 50.2, 20 000 98.6 / 99.0; G = 200: 2048 38.6 / 49.1, 4096 61.2 / 54.6, 6144 90.1 / 81.6,
     // 10^4 137.3 / 134.8; separated + assembly bias: 4096 66.5 / 57.0, 10^4 146.9 / 140.8): from
     // 15 draws per bin on.
     const int64_t min_draws = t->tuning.fused_min_draws > 0 ? t->tuning.fused_min_draws
                               : wide                        ? 15 * (int64_t)t->n_bins
-                              // (Leauthaud11 in 32-draw workgroups, tools/r03_fused_leauthaud.py,
+                              // (Leauthaud11 in 32-draw workgroups, tools/archive/r03_fused_leauthaud.py,
                               // three kernels / one launch: G = 60: 2000 draws 20.7 / 25.6, 4000
                               // 37.4 / 28.7; G = 100: 2000 33.9 / 39.6, 4000 56.5 / 50.3)
                               : leauthaud && fused_half_tiles(t, separate, n_draws, n_gauss, flags)
                                   ? 3000
                               : fused_half_tiles(t, separate, n_draws, n_gauss, flags)
-                                  // (tools/r03_fused_low.py, us per step, three kernels / one
+                                  // (tools/archive/r03_fused_low.py, us per step, three kernels / one
                                   // launch: a step of small batches costs a fifth of the
                                   // estimate -- G = 40: 256 draws 14.0 / 5.6; G = 60: 256 8.7 /
                                   // 5.5, 1024 8.6 / 7.6; G = 100, R = 3: 256 13.4 / 6.3; G = 100,
@@ -1133,7 +1133,7 @@ int fused_lds_bytes(const tc_table* t, bool separate, int waves, int draws) {
 // two per CU), Zheng07 family with the default n_gauss_prim.
 // * Batches below 8192 draws of tables up to 104 bins: a workgroup lasts a quarter as long as
 //   the 64-draw one and a batch has twice as many -- what batches need that do not fill the
-//   chip's 512 places with four launches of 64-draw workgroups (tools/r03_fused_half.py, us per
+//   chip's 512 places with four launches of 64-draw workgroups (tools/archive/r03_fused_half.py, us per
 //   step, three kernels / 64 draws x 8 waves / 32 x 4 / 32 x 8: G = 100: 1024 draws 12.8 / 23.4 /
 //   19.3 / 15.1, 2048 19.0 / 29.0 / 21.7 / 16.0, 4096 23.9 / 30.2 / 22.3 / 16.9, 6144 31.6 / 31.1 /
 //   26.2 / 25.1, 10^4 43.5 / 39.4 / 41.0 / 41.4; G = 60: 1024 10.2 / 12.3 / 9.7 / 7.4, 4096 15.3 /

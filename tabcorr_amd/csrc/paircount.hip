@@ -604,7 +604,7 @@ int pair_count(const double* pos1, const int32_t* label1, int64_t n1, const doub
     // LDS counters (bins, labels of block 1, labels of block 2): about 30 KB per workgroup
     // keep five workgroups on a CU, which the scalar-load latency of the inner loop needs
     // (19 bins x 100 labels, 10^6 points: 8 labels of set 2 = 60 KB 276 ms, 4 = 30 KB 180 ms,
-    // 2 = 15 KB 190 ms: tools/r03_pc_knobs.sh); set 1 keeps all its labels while that fits
+    // 2 = 15 KB 190 ms: tools/archive/r03_pc_knobs.sh); set 1 keeps all its labels while that fits
     const int limit = 60 * 1024 / (int)sizeof(unsigned);
     const int budget = env_int("TC_PAIR_LDS_KB", 30) * 1024 / (int)sizeof(unsigned);
     TC_CHECK(n_bin <= limit, "at most %d (separation, mu) bins are supported", limit);
