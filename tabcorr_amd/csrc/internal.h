@@ -135,6 +135,14 @@ inline size_t zero_copy_limit() {
   return limit;
 }
 
+// The streams of a handle's lanes.  Whether their kernels overlap depends on which hardware
+// queues the runtime gives them (four per process): created while one to three other streams
+// exist -- the null stream after a first hipMemcpy is enough -- two of four lanes end up on one
+// queue and a 10^4-draw step of the AbacusSummit table takes 77 us instead of 60
+// (tools/r04_streams.py).  With none or at least four streams present the four lanes land on
+// four queues: so four short-lived ballast streams are created first and destroyed afterwards.
+int create_lane_streams(int count, hipStream_t* streams);
+
 // Page-locked workspace of the un-batched path (launch.hip: launch_single_draw): the kernel
 // stores its results and one completion word per workgroup here, the host polls the words.
 struct SingleWorkspace {
@@ -300,6 +308,8 @@ struct Tuning {
   // over the whole chip.  Asynchronous host calls (us per call, tools/archive/r03_async.py): 6144 draws
   // 38.8 / 41.6, 10^4 58 / 47.6, 20 000 93.7 / 82.6, 40 000 176 / 162: no upper bound there.
   int series = 1;               // moment expansion of the central bins' node sums (series.h)
+  int cross_target = 160;       // mode cross, <= 16 rows: workgroups a launch should have at
+                                // least (several per tile of 64 draws below that)
   int fused = 1;
   int fused_min_draws = 0;      // 0: chosen per table (launch.hip: fused_eligible)
   int fused_max_draws = 30720;
@@ -442,6 +452,7 @@ struct tc_table {
     tc::host::DeviceBuffer nbuf32;   // float copy of nbuf (float32 quadratic-form kernel)
     tc::host::DeviceBuffer xi;       // chi2 device calls: the correlation functions
     tc::host::DeviceBuffer in_theta, out;   // asynchronous host calls: staging of draws / results
+    tc::host::DeviceBuffer cross_counters;  // mode cross, several workgroups per tile: arrivals
     int ngal_parts = 1;              // partial sums the occupation step left in ngal2
   };
   static constexpr int kMaxLanes = 8;
@@ -563,7 +574,8 @@ bool cross_fused_eligible(const tc_table* t0, const CrossFused& cf, int64_t n_dr
                           unsigned flags, bool alone);
 int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs* interp,
                     const double* theta_device, int n_theta, int64_t n_draws, unsigned flags,
-                    double* ngal_device, double* xi_device, hipStream_t stream);
+                    double* ngal_device, double* xi_device, hipStream_t stream,
+                    DeviceBuffer* partial, DeviceBuffer* counters);
 int launch_finalize(const FinalizeArgs& args, const Tuning& tuning, hipStream_t stream);
 // Quadratic-form path: layout upload, schedules, launches.
 int build_quad_table(tc_table* t, bool by_type, const void* matrix, int matrix_dtype,

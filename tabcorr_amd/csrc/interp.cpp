@@ -47,6 +47,7 @@ struct tc_interp {
     void* d_ngal_parts = nullptr;             // (V) device pointers
     void* d_nbufs32 = nullptr;                // (V) ... float copies of the densities
     DeviceBuffer coef, partial, chi2_xi;
+    DeviceBuffer cross_counters;              // mode cross, several workgroups per tile
     DeviceBuffer stage_in, stage_out;         // asynchronous host calls
   };
   static constexpr int kLanes = 4;
@@ -111,7 +112,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
       ca.table_node = (const int32_t*)it->d_table_node;
       ca.x = x_device;
       return run_cross_fused(t0, it->cross_fused, &ca, theta_device, n_theta, n_draws, flags,
-                             ngal_device, xi_device, L.stream);
+                             ngal_device, xi_device, L.stream, &L.partial, &L.cross_counters);
     }
   }
 
@@ -462,8 +463,13 @@ int tc_interp_create(tc_table* const* tables, int n_tables, int n_dim,
     lane.nbuf_ptrs.assign(n_classes, nullptr);
     lane.ngal_ptrs.assign(n_classes, nullptr);
     lane.nbuf32_ptrs.assign(n_classes, nullptr);
-    TC_HIP(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
     TC_HIP(hipEventCreateWithFlags(&lane.finished, hipEventDisableTiming));
+  }
+  {
+    hipStream_t streams[tc_interp::kLanes] = {};
+    const int created = create_lane_streams(tc_interp::kLanes, streams);
+    for (int l = 0; l < tc_interp::kLanes; ++l) it->lanes[l].stream = streams[l];
+    if (created != TC_OK) return created;
   }
   it->stream = it->lanes[0].stream;
   it->n_lanes = t0->mode == TC_MODE_CROSS ? tc_interp::kLanes : 2;
@@ -515,7 +521,7 @@ int tc_interp_destroy(tc_interp* it) {
     for (DeviceBuffer& b : lane.ngal2) b.release();
     for (DeviceBuffer& b : lane.nbuf32) b.release();
     for (DeviceBuffer* b : {&lane.coef, &lane.partial, &lane.chi2_xi, &lane.stage_in,
-                            &lane.stage_out})
+                            &lane.stage_out, &lane.cross_counters})
       b->release();
     if (lane.finished) (void)hipEventDestroy(lane.finished);
   }

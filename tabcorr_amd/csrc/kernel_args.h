@@ -305,6 +305,7 @@ constexpr int kCrossTableDoubles = 2306;       // = fm::kTableDoubles (fastmath.
 // stage (waves, 8 rows, 64): the waves' sums of half the rows, later the spline weights and the
 // results tile | sums (components, 16, 64)
 constexpr int kCrossSmallRows = 16, kCrossSmallChunk = 8;
+constexpr int kCrossMaxSplits = 8;
 constexpr int cross_small_lds_doubles(int n_comp) {
   return kCrossTableDoubles + kCrossWaves * kCrossSmallChunk * kLanes +
          n_comp * kCrossSmallRows * kLanes;
@@ -333,6 +334,15 @@ struct CrossFusedArgs {
   int row_stride;            // doubles between the rows of consecutive members (= ROWS)
   int cen_waves;             // predict_cross_small_kernel, separate: waves [0, cen_waves) take
                              // the groups of centrals
+  // predict_cross_small_kernel, medium batches: n_splits workgroups per tile of 64 draws, each
+  // with a share of the groups (split_*[s] .. split_*[s + 1]: all groups / the centrals' / the
+  // satellites'); partial (tiles, n_splits, n_comp, 16, 64) doubles, counters (tiles) ints, zero
+  // between launches
+  int n_splits;
+  int split_all[kCrossMaxSplits + 1], split_cen[kCrossMaxSplits + 1],
+      split_sat[kCrossMaxSplits + 1];
+  double* partial;
+  int* counters;
   int lds_res0;              // offsets (doubles) into the dynamic LDS: sums of the centrals,
   int lds_tile;              // spline weights + results tile
   int interp;                // 1: spline weights from x (else one table, c = 1)

@@ -2455,7 +2455,11 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kerne
     for (int i = threadIdx.x; i < fm::kTableDoubles / 2; i += blockDim.x) dst[i] = src[i];
   }
   __syncthreads();
-  const int64_t col = (int64_t)blockIdx.x * kLanes;
+  // (medium batches: n_splits workgroups per tile of 64 draws, each with a share of the groups;
+  // the last one to arrive adds the shares in split order and finishes the tile)
+  const int n_splits = a.n_splits > 1 ? a.n_splits : 1;
+  const int tile_index = (int)blockIdx.x / n_splits, split = (int)blockIdx.x % n_splits;
+  const int64_t col = (int64_t)tile_index * kLanes;
   const int64_t b0 = col + lane;
   const int64_t b = b0 < a.n_draws ? b0 : a.n_draws - 1;
 
@@ -2491,11 +2495,14 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kerne
 #pragma unroll
       for (int j = 0; j < ROWS; ++j) acc[j] = fma(coefficient[j], nbar, acc[j]);
     };
-    int first = wave, end = a.n_groups, stride = W;
+    // this workgroup's groups: [split_all[s], split_all[s + 1]), or -- separated by galaxy
+    // type -- that share of the centrals for the first cen_waves waves and of the satellites
+    // for the others
+    int first = a.split_all[split] + wave, end = a.split_all[split + 1], stride = W;
     if (a.separate) {
       const bool cen = wave < a.cen_waves;
-      first = cen ? wave : a.n_central_groups + (wave - a.cen_waves);
-      end = cen ? a.n_central_groups : a.n_groups;
+      first = cen ? a.split_cen[split] + wave : a.split_sat[split] + (wave - a.cen_waves);
+      end = cen ? a.split_cen[split + 1] : a.split_sat[split + 1];
       stride = cen ? a.cen_waves : W - a.cen_waves;
     }
     for (int gr = first; gr < end; gr += stride)
@@ -2518,6 +2525,45 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kerne
       double sum = 0.0;
       for (int w = w_begin; w < w_end; ++w) sum += stage[w * kCrossChunk * kLanes + rest];
       res[(comp * ROWS + chunk * kCrossChunk) * kLanes + rest] = sum;
+    }
+    __syncthreads();
+  }
+
+  if (n_splits > 1) {
+    // this workgroup's share goes to the tile's slot `split` of the partial buffer; the last
+    // of the tile's workgroups to get here (a counter per tile, which it resets for the next
+    // launch on this lane) adds the shares in split order: deterministic
+    // (the shares travel as device-scope write-through stores / loads and the wave waits until
+    // its stores are acknowledged: a release fence by 128 workgroups -- a write-back and an
+    // invalidation of the whole L2 each -- cost 40 us per 1024 draws)
+    __shared__ int is_last;
+    const int count = n_comp * ROWS * kLanes;
+    unsigned long long* mine =
+        (unsigned long long*)a.partial + ((int64_t)tile_index * n_splits + split) * count;
+    for (int idx = threadIdx.x; idx < count; idx += blockDim.x)
+      __hip_atomic_store(mine + idx, __builtin_bit_cast(unsigned long long, res[idx]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): the wave's stores have arrived
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int arrived = __hip_atomic_fetch_add(a.counters + tile_index, 1, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+      is_last = arrived == n_splits - 1;
+      if (is_last)
+        __hip_atomic_store(a.counters + tile_index, 0, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    const unsigned long long* shares =
+        (const unsigned long long*)a.partial + (int64_t)tile_index * n_splits * count;
+    for (int idx = threadIdx.x; idx < count; idx += blockDim.x) {
+      double sum = 0.0;
+      for (int part = 0; part < n_splits; ++part)
+        sum += __builtin_bit_cast(
+            double, __hip_atomic_load(shares + (int64_t)part * count + idx, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT));
+      res[idx] = sum;
     }
     __syncthreads();
   }

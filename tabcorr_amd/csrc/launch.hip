@@ -1459,7 +1459,12 @@ bool cross_fused_eligible(const tc_table* t0, const CrossFused& cf, int64_t n_dr
   // kernels spread any batch over the bins as well.
   // (tools/r04_cross_scan.py, the reference's AbacusSummit table, us per step one launch / three
   // kernels: 4096 draws 48.6 / 44.0, 6144 47.4 / 59.0, 10^4 57.9 / 90.7, 32768 185 / 290)
-  const int64_t min_draws = t0->tuning.fused_min_draws > 0 ? t0->tuning.fused_min_draws : 6144;
+  // The register form (<= 16 rows) gives a tile several workgroups below ~120 tiles and wins
+  // from the smallest batches on (256 draws 8.7 us against 13.4 for the three kernels, 1024: 9.3 /
+  // 19.4, 4096: 25.6 / 55.7).
+  const int64_t min_draws = t0->tuning.fused_min_draws > 0 ? t0->tuning.fused_min_draws
+                            : cf.rows <= tc::kCrossSmallRows ? 192
+                                                             : 6144;
   if (n_draws < min_draws) return false;
   return t0->tuning.fused >= 2 || !alone;
 }
@@ -1497,7 +1502,8 @@ int launch_cross_fused(int device, int rows, dim3 grid, dim3 block, int lds, hip
 
 int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs* interp,
                     const double* theta_device, int n_theta, int64_t n_draws, unsigned flags,
-                    double* ngal_device, double* xi_device, hipStream_t stream) {
+                    double* ngal_device, double* xi_device, hipStream_t stream,
+                    DeviceBuffer* partial, DeviceBuffer* counters) {
   Range range("occupation + contraction + finalisation (mode cross, one launch)");
   Quadrature* q = nullptr;
   int status = get_quadrature(t0, 10, &q);
@@ -1548,7 +1554,49 @@ int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs
     t0->chi2_fused = true;
   }
   const int lds = layout.bytes;
-  const dim3 grid((unsigned)((n_draws + 63) / 64)), block(64 * tc::kCrossWaves);
+  const int64_t n_tiles = (n_draws + 63) / 64;
+  // Medium batches of the register form (<= 16 rows): a workgroup carries 64 draws through ALL
+  // bins, so few tiles leave most CUs idle -- several workgroups per tile, each with a share of
+  // the groups (by cost: a node of the centrals ~21 instructions, of the satellites ~33), the
+  // last to arrive adds the shares.  About two workgroups per CU over four lanes in flight.
+  int n_splits = 1;
+  if (cf.rows <= tc::kCrossSmallRows) {
+    // (tools/r04_cross_splits.py, AbacusSummit table, us per call, one workgroup per tile /
+    // this rule: 256 draws 36.9 / 8.7, 1024 43.3 / 9.3, 4096 49.4 / 25.6, 6144 48.1 / 37.1,
+    // 8192 47.7, 10^4 59.0 -- from ~120 tiles on a second workgroup per tile only costs)
+    n_splits = (int)std::min<int64_t>(
+        tc::kCrossMaxSplits,
+        std::max<int64_t>(1, (2 * t0->tuning.cross_target + n_tiles) / (2 * n_tiles)));
+    const int n_cen = ca.n_central_groups, n_sat = ca.n_groups - ca.n_central_groups;
+    n_splits = std::max(1, std::min(n_splits, std::min(std::max(n_cen, 1), std::max(n_sat, 1))));
+    const double cost_cen = 21.0, cost_sat = 33.0;
+    const double total_cost = cost_cen * n_cen + cost_sat * n_sat;
+    for (int k = 0; k <= n_splits; ++k) {
+      ca.split_cen[k] = (int)((int64_t)n_cen * k / n_splits);
+      ca.split_sat[k] = n_cen + (int)((int64_t)n_sat * k / n_splits);
+      // all groups, equal cost per split: centrals first
+      const double target = total_cost * k / n_splits;
+      ca.split_all[k] = target <= cost_cen * n_cen
+                            ? (int)std::lround(target / cost_cen)
+                            : n_cen + (int)std::lround((target - cost_cen * n_cen) / cost_sat);
+    }
+    ca.split_all[0] = 0;
+    ca.split_all[n_splits] = ca.n_groups;
+    ca.n_splits = n_splits;
+    if (n_splits > 1) {
+      const size_t count = (size_t)(separate ? 2 : 1) * tc::kCrossSmallRows * 64;
+      status = partial->reserve((size_t)n_tiles * n_splits * count * sizeof(double), stream);
+      if (status != TC_OK) return status;
+      const size_t had = counters->bytes;
+      status = counters->reserve((size_t)n_tiles * sizeof(int), stream);
+      if (status != TC_OK) return status;
+      // (zero once: the last workgroup of a tile resets its counter)
+      if (counters->bytes != had) TC_HIP(hipMemsetAsync(counters->ptr, 0, counters->bytes, stream));
+      ca.partial = (double*)partial->ptr;
+      ca.counters = (int*)counters->ptr;
+    }
+  }
+  const dim3 grid((unsigned)(n_tiles * n_splits)), block(64 * tc::kCrossWaves);
   hipEvent_t k0 = nullptr, k1 = nullptr;
   status = next_kernel_events(t0, &k0, &k1);
   if (status != TC_OK) return status;

@@ -73,6 +73,21 @@ int fail(int code, const char* format, ...) {
 
 const char* last_error() { return g_last_error.c_str(); }
 
+int create_lane_streams(int count, hipStream_t* streams) {
+  hipStream_t ballast[4] = {nullptr, nullptr, nullptr, nullptr};
+  int status = TC_OK;
+  for (hipStream_t& stream : ballast)
+    if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) stream = nullptr;
+  for (int l = 0; l < count && status == TC_OK; ++l) {
+    const hipError_t error = hipStreamCreateWithFlags(&streams[l], hipStreamNonBlocking);
+    if (error != hipSuccess)
+      status = fail(TC_ERR_HIP, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(error));
+  }
+  for (hipStream_t stream : ballast)
+    if (stream != nullptr) (void)hipStreamDestroy(stream);
+  return status;
+}
+
 // Page-locked host ranges handed out by tc_host_alloc or pinned by tc_host_register:
 // begin -> (bytes, allocated by us).  The asynchronous entry points look their buffers up
 // here (a map lookup under a mutex; hipPointerGetAttributes costs microseconds per call).

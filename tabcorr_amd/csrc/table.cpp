@@ -150,9 +150,13 @@ int tc_table_create(int mode, int n_bins, int n_r, int64_t n_pairs,
   }
   // (streams of the lanes in use; tc_table_set_option "lanes" creates further ones)
   t->n_lanes = std::max(1, std::min(t->tuning.lanes, (int)tc_table::kMaxLanes));
-  for (int l = 0; l < t->n_lanes; ++l) {
-    TC_HIP(hipStreamCreateWithFlags(&t->lanes[l].stream, hipStreamNonBlocking));
-    TC_HIP(hipEventCreateWithFlags(&t->lanes[l].finished, hipEventDisableTiming));
+  {
+    hipStream_t streams[tc_table::kMaxLanes] = {};
+    const int created = create_lane_streams(t->n_lanes, streams);
+    for (int l = 0; l < t->n_lanes; ++l) t->lanes[l].stream = streams[l];
+    if (created != TC_OK) return created;
+    for (int l = 0; l < t->n_lanes; ++l)
+      TC_HIP(hipEventCreateWithFlags(&t->lanes[l].finished, hipEventDisableTiming));
   }
   t->stream = t->lanes[0].stream;
   TC_HIP(hipEventCreate(&t->ev_begin));
@@ -258,6 +262,7 @@ int tc_table_destroy(tc_table* t) {
     lane.nbuf32.release();
     lane.in_theta.release();
     lane.out.release();
+    lane.cross_counters.release();
     if (lane.finished) (void)hipEventDestroy(lane.finished);
   }
   for (tc_table::Ticket& ticket : t->tickets)
@@ -330,7 +335,8 @@ int tc_predict_zheng07_batch_device(tc_table* t, const double* theta_device,
       if (cross_fused_eligible(t, t->cross_fused, n, n_gauss, flags, alone)) {
         status = run_cross_fused(t, t->cross_fused, nullptr, theta_device + begin * n_theta,
                                  n_theta, n, flags, ngal_device + begin * (separate ? 2 : 1),
-                                 xi_device + begin * n_comp * t->n_r, t->lanes[t->cur].stream);
+                                 xi_device + begin * n_comp * t->n_r, t->lanes[t->cur].stream,
+                                 &t->lanes[t->cur].partial, &t->lanes[t->cur].cross_counters);
         if (status != TC_OK) return status;
         t->prev = t->force_lane >= 0 ? -1 : t->cur;
         continue;
@@ -998,6 +1004,10 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
       return TC_OK;
     }
     return autotune(t, (unsigned)value);
+  } else if (key == "cross_target") {
+    // developer A/B: workgroups a launch of predict_cross_small_kernel should have at least
+    TC_CHECK(value >= 1 && value <= 4096, "cross_target must be in [1, 4096]");
+    t->tuning.cross_target = value;
   } else if (key == "series") {
     // 1 (default): the node sum of an undecorated central bin by its moment expansion
     // (csrc/series.h) wherever every draw of a wave allows it; 0: always the node loop

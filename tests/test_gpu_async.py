@@ -337,7 +337,7 @@ def test_many_walkers_in_one_launch():
 
 
 def test_random_interleaving_of_all_host_paths():
-    """tools/archive/r03_stress.py for a few seconds: synchronous, un-batched, many-walker,
+    """tools/r03_stress.py for a few seconds: synchronous, un-batched, many-walker,
     asynchronous (random waits) and device-pointer calls of random sizes on ONE table, every
     result against a reference -- workspaces, tickets and completion epochs under reuse."""
     import os

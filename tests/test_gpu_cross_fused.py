@@ -44,7 +44,11 @@ def force(handle, on):
 
 
 def cross_ran(handle, n_draws):
-    return last_launch(handle)[:3] == ((n_draws + 63) // 64, 8, 0)
+    """One launch of eight-wave workgroups, one per 64 draws -- or, for tables of up to 16 rows,
+    up to eight per tile (each a share of the groups) --, no slabs of partial sums."""
+    workgroups, waves, slabs, _ = last_launch(handle)
+    tiles = (n_draws + 63) // 64
+    return waves == 8 and slabs == 0 and workgroups % tiles == 0 and 1 <= workgroups // tiles <= 8
 
 
 def compare(got, expect, separate, rtol, what, floor=1e-14):
@@ -136,7 +140,7 @@ def test_cross_likelihood_async_and_threshold():
     halotab = make_tabcorr(table)
     handle = halotab.to_device().handle
     set_option(handle, 'single_draw', 0)
-    n = 6500                                             # (default threshold: 6144 draws)
+    n = 6500
     theta = pinned_array(synthetic.zheng07_draws(n, seed=3))
     index = np.r_[0:3, 4000:4003, n - 3:n]
     expect = oracle.predict_zheng07_batch(table, theta[index])
@@ -154,8 +158,18 @@ def test_cross_likelihood_async_and_threshold():
     assert cross_ran(handle, n)
     assert_rel(n_chi[index], expect[0], RTOL)
     assert_rel(chi2[index], want, 1e-9)
-    # smaller batches and calls that run alone keep the three kernels
-    halotab.predict_batch_async(theta[:2000], out=(ngal[:2000], xi[:2000])).wait()
+    # a medium batch: several workgroups per tile of 64 draws (each a share of the groups, the
+    # last to arrive adds the shares in order); identical from call to call
+    got_small = halotab.predict_batch_async(theta[:2000], out=(ngal[:2000], xi[:2000])).wait()
+    launch = last_launch(handle)
+    assert cross_ran(handle, 2000) and launch[0] > 32, launch
+    small = oracle.predict_zheng07_batch(table, theta[:6])
+    assert_rel(got_small[1][:6], small[1], RTOL)
+    again = halotab.predict_batch_async(theta[:2000]).wait()
+    assert np.array_equal(again[1], got_small[1][:2000]) and np.array_equal(again[0],
+                                                                           got_small[0][:2000])
+    # tiny batches and calls that run alone keep the three kernels
+    halotab.predict_batch_async(theta[:100], out=(ngal[:100], xi[:100])).wait()
     assert last_launch(handle)[2] > 0
     halotab.predict_batch(theta)
     assert last_launch(handle)[2] > 0

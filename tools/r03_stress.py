@@ -4,7 +4,7 @@ un-batched / many-walker, asynchronous (prediction and likelihood, random waits)
 device-pointer calls with random batch sizes, every result checked against a reference
 computed once through the synchronous path.  Catches workspace / ticket / epoch hazards.
 
-    gpurun -- python3 tools/archive/r03_stress.py [seconds]
+    gpurun -- python3 tools/r03_stress.py [seconds]
 """
 import ctypes
 import os
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tabcorr_amd import TabCorr, synthetic, _lib, pinned_array, pinned_empty   # noqa: E402
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0

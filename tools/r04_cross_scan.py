@@ -24,7 +24,7 @@ for n in (2048, 4096, 6144, 8192, 10000, 16384, 32768):
         row.append((s * 1e6, last(h0)))
     print('K=4 %6d draws: fused %8.1f us %s   three kernels %8.1f us %s' % (n, row[0][0], row[0][1], row[1][0], row[1][1]), flush=True)
 t = interp.tabcorr_list[0]; ht = t.to_device().handle
-for n in (2048, 4096, 6144, 8192, 10000, 16384, 32768):
+for n in (256, 512, 1024, 2048, 4096, 6144, 8192, 10000, 16384, 32768):
     row = []
     for fused in (2, 0):
         _lib.check(lib.tc_table_set_option(ht, b'fused', fused))
