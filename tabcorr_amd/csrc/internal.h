@@ -235,6 +235,7 @@ struct CrossFused {
   void* d_rows = nullptr;
   // chunks of whole groups of at most kCrossChunkBins bins (kernel_args.h: CrossFusedArgs)
   void* d_chunk_group = nullptr;
+  std::vector<int32_t> chunk_group_host;
   int n_chunks = 0, n_central_chunks = 0;
   void release() {
     if (d_rows != nullptr) (void)hipFree(d_rows);
@@ -308,8 +309,12 @@ struct Tuning {
   // over the whole chip.  Asynchronous host calls (us per call, tools/archive/r03_async.py): 6144 draws
   // 38.8 / 41.6, 10^4 58 / 47.6, 20 000 93.7 / 82.6, 40 000 176 / 162: no upper bound there.
   int series = 1;               // moment expansion of the central bins' node sums (series.h)
-  int cross_target = 160;       // mode cross, <= 16 rows: workgroups a launch should have at
-                                // least (several per tile of 64 draws below that)
+  int cross_target = 160;       // mode cross: workgroups a launch should have at least
+                                // (several per tile of 64 draws below that)
+  int cross_min_draws = 192;    // ... smallest batch of the chunked form (17 - 128 rows;
+                                // tools/r04_cross_scan.py, AbacusSummit interpolator, us per call
+                                // one launch / three kernels: 256 draws 15.7 / 20.6, 1024 20.6 /
+                                // 26.0, 4096 35.1 / 68.1, 10^4 79.6 / 164.6)
   int fused = 1;
   int fused_min_draws = 0;      // 0: chosen per table (launch.hip: fused_eligible)
   int fused_max_draws = 30720;

@@ -2270,7 +2270,14 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 2 : 4) void predict_cro
     for (int i = threadIdx.x; i < fm::kTableDoubles / 2; i += blockDim.x) dst[i] = src[i];
   }
   __syncthreads();
-  const int64_t col = (int64_t)blockIdx.x * kLanes;
+  // (medium batches: n_splits workgroups per tile of 64 draws, each with a range of the chunks;
+  // the last one to arrive adds the shares in split order and finishes the tile -- as
+  // predict_cross_small_kernel)
+  const int n_splits = a.n_splits > 1 ? a.n_splits : 1;
+  const int tile_index = (int)blockIdx.x / n_splits, split = (int)blockIdx.x % n_splits;
+  const int chunk_begin = a.n_splits > 1 ? a.split_all[split] : 0;
+  const int chunk_end = a.n_splits > 1 ? a.split_all[split + 1] : a.n_chunks;
+  const int64_t col = (int64_t)tile_index * kLanes;
   const int64_t b0 = col + lane;
   const int64_t b = b0 < a.n_draws ? b0 : a.n_draws - 1;
 
@@ -2301,8 +2308,14 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 2 : 4) void predict_cro
                              SeriesConsts{(sc_f64)a.group.series, (sc_i32)a.group.series_thr,
                                           (sc_f64)a.group.sat_series, (sc_i32)a.group.sat_series_thr}};
     sc_f64 rows = (sc_f64)a.rows + wave * RW;
-    for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
-      if (a.separate && chunk == a.n_central_chunks) {
+    if (a.separate && chunk_begin >= a.n_central_chunks) {
+      // (a share without centrals: their sums are zero)
+      double* res0 = cross_lds + a.lds_res0;
+#pragma unroll
+      for (int j = 0; j < RW; ++j) res0[(wave * RW + j) * kLanes + lane] = 0.0;
+    }
+    for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
+      if (a.separate && chunk == a.n_central_chunks && chunk > chunk_begin) {
         // (the sums of the centrals are complete: set them aside; nobody reads them before the
         // barrier behind the last chunk)
         double* res0 = cross_lds + a.lds_res0;
@@ -2334,9 +2347,53 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 2 : 4) void predict_cro
   __syncthreads();      // every wave has read the last chunk: the buffers take the sums
   double* res1 = buffers;                               // all bins, or the satellites
   double* res0 = a.separate ? cross_lds + a.lds_res0 : buffers;
+  {
+    // (a share that ends before the satellites begin holds sums of centrals only)
+    const bool only_centrals = a.separate && chunk_end <= a.n_central_chunks;
 #pragma unroll
-  for (int j = 0; j < RW; ++j) res1[(wave * RW + j) * kLanes + lane] = acc[j];
+    for (int j = 0; j < RW; ++j) {
+      if (only_centrals) res0[(wave * RW + j) * kLanes + lane] = acc[j];
+      res1[(wave * RW + j) * kLanes + lane] = only_centrals ? 0.0 : acc[j];
+    }
+  }
   __syncthreads();
+  if (n_splits > 1) {
+    // the shares of the tile's workgroups: device-scope write-through stores, the last arrival
+    // (a counter per tile, reset for the next launch on this lane) adds them in split order
+    __shared__ int is_last;
+    const int n_comp_rows = (a.separate ? 2 : 1) * ROWS;
+    const int count = n_comp_rows * kLanes;
+    unsigned long long* mine =
+        (unsigned long long*)a.partial + ((int64_t)tile_index * n_splits + split) * count;
+    for (int idx = threadIdx.x; idx < count; idx += blockDim.x) {
+      const double value = idx < ROWS * kLanes ? res0[idx] : res1[idx - ROWS * kLanes];
+      __hip_atomic_store(mine + idx, __builtin_bit_cast(unsigned long long, value),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): the wave's stores have arrived
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int arrived = __hip_atomic_fetch_add(a.counters + tile_index, 1, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+      is_last = arrived == n_splits - 1;
+      if (is_last)
+        __hip_atomic_store(a.counters + tile_index, 0, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    const unsigned long long* shares =
+        (const unsigned long long*)a.partial + (int64_t)tile_index * n_splits * count;
+    for (int idx = threadIdx.x; idx < count; idx += blockDim.x) {
+      double sum = 0.0;
+      for (int part = 0; part < n_splits; ++part)
+        sum += __builtin_bit_cast(
+            double, __hip_atomic_load(shares + (int64_t)part * count + idx, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT));
+      if (idx < ROWS * kLanes) res0[idx] = sum; else res1[idx - ROWS * kLanes] = sum;
+    }
+    __syncthreads();
+  }
 
   // ---- per draw: spline weights / norms of the tables, number densities ----
   set_priority((a.priority >> 4) & 3);

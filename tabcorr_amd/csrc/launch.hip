@@ -1399,6 +1399,7 @@ int build_cross_fused(tc_table* const* tables, int n_tables, CrossFused* cf) {
   if (groups.n_central_groups == groups.n_groups) cf->n_central_chunks = (int)chunk_group.size();
   chunk_group.push_back(groups.n_groups);
   cf->n_chunks = (int)chunk_group.size() - 1;
+  cf->chunk_group_host = chunk_group;
   std::vector<double> host((size_t)t0->n_bins * instance, 0.0);
   for (int mi = 0; mi < t0->n_bins; ++mi) {
     const int g = groups.member[mi];
@@ -1451,12 +1452,11 @@ bool cross_fused_eligible(const tc_table* t0, const CrossFused& cf, int64_t n_dr
                    t0->fuse_chi2_out != nullptr))
     return false;
   if (cf.rows > tc::kCrossSmallRows &&
-      cross_lds_layout(cf, t0->n_r, separate).bytes > kMaxLdsBytes)
+      cross_lds_layout(cf, t0->n_r, separate).bytes > kMaxLdsBytes - 256)
     return false;
   if (t0->fuse_chi2_out != nullptr && t0->n_r > 32) return false;
-  // A workgroup carries 64 draws through ALL bins (one per CU): batches of fewer than ~64
-  // workgroups leave most of the chip idle even with four launches in flight, where the three
-  // kernels spread any batch over the bins as well.
+  // A workgroup carries 64 draws through the bins; batches of few tiles get several workgroups
+  // per tile (run_cross_fused), so that the one-launch forms pay from a few hundred draws on.
   // (tools/r04_cross_scan.py, the reference's AbacusSummit table, us per step one launch / three
   // kernels: 4096 draws 48.6 / 44.0, 6144 47.4 / 59.0, 10^4 57.9 / 90.7, 32768 185 / 290)
   // The register form (<= 16 rows) gives a tile several workgroups below ~120 tiles and wins
@@ -1464,7 +1464,7 @@ bool cross_fused_eligible(const tc_table* t0, const CrossFused& cf, int64_t n_dr
   // 19.4, 4096: 25.6 / 55.7).
   const int64_t min_draws = t0->tuning.fused_min_draws > 0 ? t0->tuning.fused_min_draws
                             : cf.rows <= tc::kCrossSmallRows ? 192
-                                                             : 6144;
+                                                             : t0->tuning.cross_min_draws;
   if (n_draws < min_draws) return false;
   return t0->tuning.fused >= 2 || !alone;
 }
@@ -1478,8 +1478,10 @@ int launch_cross_fused(int device, int rows, dim3 grid, dim3 block, int lds, hip
   case N: {                                                                                   \
     static bool limit_set[64] = {};                                                           \
     if (lds > 64 * 1024 && !(device >= 0 && device < 64 && limit_set[device])) {              \
+      /* (the kernel holds a few bytes of static LDS besides) */                               \
       TC_HIP(hipFuncSetAttribute((const void*)tc::predict_cross_fused_kernel<N, AB, MO>,      \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));    \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize,                  \
+                                 160 * 1024 - 256));                                          \
       if (device >= 0 && device < 64) limit_set[device] = true;                               \
     }                                                                                         \
     hipExtLaunchKernelGGL((tc::predict_cross_fused_kernel<N, AB, MO>), grid, block, lds,      \
@@ -1591,6 +1593,42 @@ int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs
       status = counters->reserve((size_t)n_tiles * sizeof(int), stream);
       if (status != TC_OK) return status;
       // (zero once: the last workgroup of a tile resets its counter)
+      if (counters->bytes != had) TC_HIP(hipMemsetAsync(counters->ptr, 0, counters->bytes, stream));
+      ca.partial = (double*)partial->ptr;
+      ca.counters = (int*)counters->ptr;
+    }
+  } else {
+    // the chunked form likewise: ranges of chunks of about equal cost (per group a node
+    // evaluation, per member bin its row FMAs)
+    n_splits = (int)std::min<int64_t>(
+        tc::kCrossMaxSplits,
+        std::max<int64_t>(1, (2 * t0->tuning.cross_target + n_tiles) / (2 * n_tiles)));
+    n_splits = std::max(1, std::min(n_splits, cf.n_chunks));
+    if (n_splits > 1) {
+      const tc::NodeGroups& groups = t0->node_groups;
+      std::vector<double> cost(cf.n_chunks + 1, 0.0);
+      for (int c = 0; c < cf.n_chunks; ++c) {
+        double value = 0.0;
+        for (int g = cf.chunk_group_host[c]; g < cf.chunk_group_host[c + 1]; ++g)
+          value += (g < groups.n_central_groups ? 210.0 : 330.0) +
+                   (groups.begin[g + 1] - groups.begin[g]) * (10.0 + cf.rows);
+        cost[c + 1] = cost[c] + value;
+      }
+      ca.split_all[0] = 0;
+      for (int k = 1; k < n_splits; ++k) {
+        const double target = cost[cf.n_chunks] * k / n_splits;
+        int c = ca.split_all[k - 1] + 1;
+        while (c < cf.n_chunks - (n_splits - k) && cost[c] < target) ++c;
+        ca.split_all[k] = c;
+      }
+      ca.split_all[n_splits] = cf.n_chunks;
+      ca.n_splits = n_splits;
+      const size_t count = (size_t)(separate ? 2 : 1) * cf.rows * 64;
+      status = partial->reserve((size_t)n_tiles * n_splits * count * sizeof(double), stream);
+      if (status != TC_OK) return status;
+      const size_t had = counters->bytes;
+      status = counters->reserve((size_t)n_tiles * sizeof(int), stream);
+      if (status != TC_OK) return status;
       if (counters->bytes != had) TC_HIP(hipMemsetAsync(counters->ptr, 0, counters->bytes, stream));
       ca.partial = (double*)partial->ptr;
       ca.counters = (int*)counters->ptr;

@@ -15,7 +15,8 @@ d_ngal, d_xi = dev.malloc(len(theta)), dev.malloc(13 * len(theta))
 def last(hh):
     v = [ctypes.c_int() for _ in range(4)]
     lib.tc_table_last_launch(hh, *[ctypes.byref(q) for q in v]); return tuple(q.value for q in v)
-for n in (2048, 4096, 6144, 8192, 10000, 16384, 32768):
+_lib.check(lib.tc_table_set_option(h0, b'cross_min_draws', int(os.environ.get('CROSS_MIN', 6144))))
+for n in (256, 1024, 2048, 4096, 6144, 8192, 10000, 16384, 32768):
     row = []
     for fused in (1, 0):
         _lib.check(lib.tc_table_set_option(h0, b'fused', fused))

@@ -56,7 +56,7 @@ if 'destroy' in sys.argv:
 n_r = int(np.prod(halotab.tpcf_shape))
 d_theta = dev.upload(theta)
 d_ngal, d_xi = dev.malloc(len(theta)), dev.malloc(n_r * len(theta))
-for n in (10000, ):
+for n in (256, 1024, 10000):
     s = sustained(lambda: _lib.check(lib.tc_predict_zheng07_batch_device(h, d_theta, 5, n, 10, 0,
                                                                          d_ngal, d_xi)),
                   lambda: _lib.check(lib.tc_table_synchronize(h)), seconds=0.3)
