@@ -509,6 +509,14 @@ struct tc_table {
     tc::host::SingleWorkspace ws;
     int n_theta = 0, n_gauss = 0, blocks = 0;
     unsigned flags = 0;
+    // the ensemble form (launch.hip: ensemble_predict; kernel_args.h: EnsembleArgs): which of
+    // the two kernels the launch runs, its call counter, its page-locked results and the
+    // device memory the phases hand their data on through
+    bool ensemble = false;
+    unsigned long long ens_epoch = 0;
+    int ens_grid = 0;
+    tc::host::PinnedBuffer ens_mailbox, ens_out;
+    tc::host::DeviceBuffer ens_device;
   } resident;
   size_t trace_blocks = 0;
   size_t trace_launches = 0;
@@ -618,6 +626,10 @@ int resident_predict(tc_table* t, const double* theta, int n_theta, int n_gauss,
                      double* ngal, double* xi);
 int resident_stop(tc_table* t);
 bool resident_eligible(const tc_table* t, int n_gauss);
+// 2 .. kEnsembleMaxWalkers draws through the resident ensemble kernel, host to host.
+bool ensemble_eligible(const tc_table* t, int64_t n_walkers, int n_gauss, unsigned flags);
+int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walkers, int n_gauss,
+                     unsigned flags, double* ngal, double* xi);
 int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_walkers, int n_gauss,
                        unsigned flags, SingleWorkspace* ws, hipStream_t stream);
 int wait_single_done(SingleWorkspace* ws, hipStream_t stream, bool poll = true);

@@ -141,6 +141,69 @@ struct SingleArgs {
 constexpr unsigned long long kResidentStop = ~0ull;
 constexpr int kResidentBusyOffset = 64;   // exited[64 + workgroup]: ticks the last call took
 
+// Resident form for ENSEMBLES (resident_ensemble_kernel; launch.hip: ensemble_predict): 2 ..
+// kEnsembleMaxWalkers draws per call, host memory to host memory, no launch and no stream
+// synchronisation per call.  The grid is 4 * n_slices workgroups of 1024 threads that stay on
+// the chip (one per CU); workgroup b = 4 * slice + c.  A call runs in three phases that hand
+// their data on through device memory (write-through stores, a flag per producer that carries
+// the number of the call; nothing is ever reset):
+//   A  workgroup w < n_walkers: the occupation of walker w (one quadrature node per thread),
+//      its G number densities and the two totals -> dens[w], flag_a[w];
+//   B  the table's positions are cut into n_slices slices of four quarters, kept in LDS for
+//      the life of the launch; lane = walker of a group of 64.  With one group the four
+//      workgroups of a slice take a quarter each, with two groups half a slice for a group
+//      each, with three or four the whole slice for group c.  Every quarter is summed by itself
+//      and the quarters of a slice are added as (q0 + q1) + (q2 + q3) -- by the workgroup or by
+//      the reader of its partial sums -- so that a walker's result does not depend on the size
+//      of the ensemble.  -> partial[b] (rt, 64), flag_b[b];
+//   C  workgroup (row, group): the sum over the slices of one row of one group in fixed
+//      order (rows rt, rt + 1: the two totals of the group's walkers) -> 64 contiguous doubles
+//      of out (groups, rt + 2, 64) in page-locked memory, then done[b].
+// The host writes one 128-byte line per walker -- eight 16-byte entries {value, number of the
+// call}: seven parameters and the number of walkers -- and workgroup w polls line w and the
+// device word that workgroup 0 forwards {call number, walkers} through, which is how the
+// workgroups without a walker learn of a call.  Every wait is bounded: idle_ticks / life_ticks
+// as for the single draw, call_ticks for a wait inside a call; a workgroup that gives up sets
+// exited[b] = launch_id and the host serves the call another way.
+struct EnsembleArgs {
+  int n_theta;
+  int n_bins;
+  int n_central;
+  int n_gauss;
+  unsigned flags;
+  double split;
+  const double* log_m;
+  const double* m;
+  const double* weight;
+  const double* n_h;
+  const double* percentile;
+  const double* math_table;
+  const double* table;          // re-laid-out matrix of the single r tile (as SingleArgs)
+  const int32_t* pos_off;
+  int64_t n_positions;
+  int rt;
+  int mode;
+  int n_slices;                 // grid = 4 * n_slices
+  int per_quarter;              // positions per quarter of a slice
+  int dens_stride;              // doubles per walker in dens (n_bins + 2, padded)
+  double* dens;                 // device memory
+  unsigned long long* flag_a;   // (kEnsembleMaxWalkers)
+  double* partial;              // (grid, rt, 64)
+  unsigned long long* flag_b;   // (grid)
+  unsigned long long* callword; // call number << 10 | walkers
+  const unsigned long long* mailbox;   // page-locked: (walkers) lines of 16 words
+  double* out;                  // page-locked: (4, rt + 2, 64)
+  unsigned long long* done;     // page-locked: (grid)
+  unsigned long long* exited;   // page-locked: (grid), then 8 phase stamps of workgroup 0
+  unsigned long long epoch;     // first call to serve
+  unsigned long long launch_id;
+  unsigned long long idle_ticks, life_ticks, call_ticks;
+  int lds_area, lds_dens, lds_t, lds_ij;   // byte offsets into the dynamic LDS
+};
+constexpr int kEnsembleThreads = 1024;
+constexpr int kEnsembleMaxWalkers = 256;
+constexpr int kEnsembleDensPad = 65;      // doubles per bin row of the densities in LDS
+
 struct ContractArgs {
   const double* nbuf;       // (n_bins, ldb)
   int64_t ldb;

@@ -3052,6 +3052,391 @@ __global__ __launch_bounds__(kSingleThreads) void resident_draw_kernel(SingleArg
   single_draw_body<true>(a);
 }
 
+// ---- ensembles without a launch: the resident ensemble kernel ---------------------------
+//
+// kernel_args.h (EnsembleArgs) describes the phases and the protocol.  Every loop that waits
+// for another workgroup or for the host is bounded by a time limit, after which the workgroup
+// leaves and says so: the grid drains whatever happens to the others.
+namespace ens {
+__device__ __forceinline__ void store_agent(double* address, double value) {
+  __hip_atomic_store((unsigned long long*)address, __builtin_bit_cast(unsigned long long, value),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_agent(const double* address) {
+  return __builtin_bit_cast(double,
+                            __hip_atomic_load((const unsigned long long*)address,
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void store_host(double* address, double value) {
+  __hip_atomic_store((unsigned long long*)address, __builtin_bit_cast(unsigned long long, value),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void wait_stores() { __builtin_amdgcn_s_waitcnt(0x0f70); }  // vmcnt(0)
+}  // namespace ens
+
+__global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(EnsembleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ens_lds[];
+  double* table = (double*)ens_lds;
+  // phase A: node_value[1024] | density[1024]; phase B: red[3][rt][64]; phase C: red16[16][64]
+  double* area = (double*)(ens_lds + a.lds_area);
+  double* node_value = area;
+  double* density = area + kEnsembleThreads;
+  double* dens_lds = (double*)(ens_lds + a.lds_dens);     // (n_bins + 2, 65)
+  double* t_lds = (double*)(ens_lds + a.lds_t);           // (4 * per_quarter, rt)
+  unsigned* ij_lds = (unsigned*)(ens_lds + a.lds_ij);     // (4 * per_quarter)
+  __shared__ volatile int s_abort;
+  __shared__ int s_leave, s_walkers, s_is_walker;
+  __shared__ unsigned long long s_epoch, s_seen;
+  __shared__ double s_theta[7];
+  __shared__ double s_totals[2];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  const int c = b & 3, slice = b >> 2;
+  const int rt = a.rt;
+  const int pq = a.per_quarter;
+  const bool assembias = (a.flags & kFlagAssembias) != 0;
+  const bool modulate = (a.flags & kFlagModulate) != 0;
+  const int n_nodes = a.n_bins * a.n_gauss;
+
+  // once per launch: the math tables, this slice's positions, this thread's node
+  {
+    typedef double __attribute__((ext_vector_type(2))) double2v;
+    const double2v* src = (const double2v*)a.math_table;
+    double2v* dst = (double2v*)table;
+    for (int i = tid; i < fm::kTableDoubles / 2; i += kEnsembleThreads) dst[i] = src[i];
+  }
+  const int64_t slice_begin = (int64_t)slice * 4 * pq;
+  for (int idx = tid; idx < 4 * pq * rt; idx += kEnsembleThreads) {
+    const int pl = idx / rt, r = idx % rt;
+    const int64_t q = slice_begin + pl;
+    // layouts of table.cpp, as single_draw_body reads them
+    const int64_t index = (q >> 3) * 8 * rt +
+                          ((((r >> 2) * 16 + (q & 3) * 4 + (r & 3)) << 1) + ((q >> 2) & 1));
+    t_lds[idx] = q < a.n_positions ? a.table[index] : 0.0;
+  }
+  for (int pl = tid; pl < 4 * pq; pl += kEnsembleThreads) {
+    const int64_t q = slice_begin + pl;
+    unsigned bins = 0;
+    if (q < a.n_positions) {
+      const int64_t slot = ((q >> 3) * 4 + (q & 3)) * 4 + ((q >> 2) & 1) * 2;
+      bins = (unsigned)(a.pos_off[slot] >> 9) | ((unsigned)(a.pos_off[slot + 1] >> 9) << 16);
+    }
+    ij_lds[pl] = bins;
+  }
+  double kept_lm = 0.0, kept_mass = 0.0, kept_wk = 0.0, kept_n_h = 0.0;
+  bool kept_above = false;
+  if (tid < n_nodes) {
+    kept_lm = a.log_m[tid];
+    kept_mass = a.m[tid];
+    kept_wk = a.weight[tid];
+    kept_above = a.percentile[tid / a.n_gauss] > a.split;
+  }
+  if (tid < a.n_bins) kept_n_h = a.n_h[tid];
+  if (tid == 0) s_abort = 0;
+  __syncthreads();
+
+  unsigned long long serving = a.epoch;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+  unsigned long long t_last = t_begin;
+  // (a wait inside a call: until `ready` holds for every lane of the wave, or the time is up)
+  auto timed_out = [&](unsigned long long since) {
+    return __builtin_amdgcn_s_memrealtime() - since > a.call_ticks;
+  };
+
+  for (;;) {
+    // ---- the call: own line of the mailbox (walker b) or the forwarded word ---------------
+    if (wave == 0) {
+      typedef unsigned long long __attribute__((ext_vector_type(2))) u64x2;
+      const u64x2* entry = (const u64x2*)a.mailbox + (size_t)b * 8 + (lane & 7);
+      u64x2 word = {0ull, 0ull};
+      for (;;) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=v"(word) : "v"(entry) : "memory");
+        const unsigned long long forwarded =
+            __hip_atomic_load(a.callword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        const unsigned first_lo = __builtin_amdgcn_readfirstlane((unsigned)word.y);
+        const unsigned first_hi = __builtin_amdgcn_readfirstlane((unsigned)(word.y >> 32));
+        const unsigned long long first = ((unsigned long long)first_hi << 32) | first_lo;
+        const bool same = __builtin_amdgcn_ballot_w64(word.y != first) == 0;
+        const bool stop = __builtin_amdgcn_ballot_w64(word.y == kResidentStop) != 0;
+        int leave = -1, walkers = 0, is_walker = 0;
+        unsigned long long epoch = 0;
+        if (stop) {
+          leave = 1;
+        } else if (same && first >= serving && first >= (forwarded >> 10)) {
+          // (a line older than the forwarded call is a stale one, or about to be replaced;
+          // entry 7: the number of walkers)
+          const unsigned count = __builtin_amdgcn_readlane((unsigned)word.x, 7);
+          leave = 0;
+          walkers = (int)count;
+          is_walker = 1;
+          epoch = first;
+        } else if ((forwarded >> 10) >= serving && (int)(forwarded & 1023) <= b) {
+          leave = 0;
+          walkers = (int)(forwarded & 1023);
+          epoch = forwarded >> 10;
+        } else if (now - t_last > a.idle_ticks || now - t_begin > a.life_ticks) {
+          leave = 1;
+        }
+        if (leave >= 0) {
+          if (lane < 7) s_theta[lane] = __builtin_bit_cast(double, word.x);
+          if (lane == 0) {
+            s_leave = leave;
+            s_walkers = walkers;
+            s_is_walker = is_walker;
+            s_epoch = epoch;
+            s_seen = now;
+            if (b == 0 && leave == 0)
+              __hip_atomic_store(a.callword, (epoch << 10) | (unsigned long long)walkers,
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __syncthreads();
+    if (s_leave != 0) break;
+    const int n_walkers = s_walkers;
+    const unsigned long long epoch = s_epoch;
+    const bool is_walker = s_is_walker != 0 && b < n_walkers;
+    const unsigned long long t_call = s_seen;
+    if (b == 0 && tid == 0) a.exited[gridDim.x + 0] = t_call;
+
+    // ---- A: the occupation of walker b ----------------------------------------------------
+    if (is_walker) {
+      const fm::Consts kc = fm::make_consts();
+      const DrawSetup d = prepare_draw(table, kc, s_theta[0], s_theta[1], s_theta[2], s_theta[3],
+                                       s_theta[4], assembias ? s_theta[5] : 0.0,
+                                       assembias ? s_theta[6] : 0.0);
+      const double f1 = (1.0 - a.split) / a.split, f2 = a.split / (1.0 - a.split);
+      if (tid < n_nodes) {
+        const int g = tid / a.n_gauss;
+        const double lm = kept_lm, mass = kept_mass;
+        double n;
+        if (g < a.n_central) {
+          n = fma(0.5, fm::erf_fast(table, kc, (lm - d.log_m_min) * d.inv_sigma), 0.5);
+          if (assembias) n = heaviside_assembias(n, d.a_cen, kept_above, f2, f1, true);
+        } else {
+          const double x = mass - d.m0;
+          n = fm::exp2_fast(
+              table, kc,
+              d.alpha * fm::log2_fast_offset(table, kc, x > 1e-300 ? x : 1e-300, d.log2_m1),
+              x > 0.0);
+          n *= d.sat_scale;
+          if (modulate)
+            n *= fma(0.5, fm::erf_fast(table, kc, (lm - d.log_m_min) * d.inv_sigma), 0.5);
+          if (assembias) n = heaviside_assembias(n, d.a_sat, kept_above, f2, f1, false);
+        }
+        if (d.bad) {   // (prepare_draw: parameters the fast path cannot represent)
+          const bool cen_nan = (d.bad & kBadCen) || ((d.bad & kTieCen) && lm == d.log_m_min);
+          if (g >= a.n_central && (d.bad & kInfSat) && n != 0.0)
+            n = assembias ? __builtin_nan("") : __builtin_huge_val();
+          if (g < a.n_central ? cen_nan
+                              : (((d.bad & kBadSat) && n != 0.0) || (modulate && cen_nan)))
+            n = __builtin_nan("");
+        }
+        node_value[tid] = kept_wk * n;
+      }
+      __syncthreads();
+      if (tid < a.n_bins) {
+        double acc = 0.0;
+        for (int k = 0; k < a.n_gauss; ++k) acc += node_value[tid * a.n_gauss + k];
+        density[tid] = acc * kept_n_h;
+      }
+      __syncthreads();
+      if (tid < 128) {   // centrals / satellites totals: one wave each, fixed order
+        const int which = tid >> 6;
+        const int lo = which == 0 ? 0 : a.n_central, hi = which == 0 ? a.n_central : a.n_bins;
+        double total = 0.0;
+        for (int g = lo + lane; g < hi; g += 64) total += density[g];
+#pragma unroll
+        for (int offset = 32; offset >= 1; offset >>= 1) total += __shfl_down(total, offset, 64);
+        if (lane == 0) s_totals[which] = total;
+      }
+      __syncthreads();
+      if (tid < a.n_bins + 2) {
+        const double value = tid < a.n_bins ? density[tid] : s_totals[tid - a.n_bins];
+        ens::store_agent(a.dens + (size_t)b * a.dens_stride + tid, value);
+      }
+      ens::wait_stores();
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_store(a.flag_a + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (b == 0 && tid == 0) a.exited[gridDim.x + 1] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- B: this workgroup's part of its slice for one group of 64 walkers ----------------
+    const int n_wg = (n_walkers + 63) >> 6;
+    int grp, q_first, q_count;
+    if (n_wg == 1) {
+      grp = 0; q_first = c; q_count = 1;
+    } else if (n_wg == 2) {
+      grp = c & 1; q_first = 2 * (c >> 1); q_count = 2;
+    } else {
+      grp = c; q_first = 0; q_count = 4;
+    }
+    const bool active = grp < n_wg;
+    if (active) {
+      if (wave == 0) {
+        const int walker = grp * 64 + lane;
+        const unsigned long long since = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+          const unsigned long long flag =
+              walker < n_walkers ? __hip_atomic_load(a.flag_a + walker, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)
+                                 : epoch;
+          if (__builtin_amdgcn_ballot_w64(flag != epoch) == 0) break;
+          if (timed_out(since)) {
+            s_abort = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+      if (s_abort) break;
+      const int stride = a.dens_stride;
+      for (int idx = tid; idx < 64 * stride; idx += kEnsembleThreads) {
+        const int w = idx / stride, g = idx % stride;
+        const int walker = grp * 64 + w;
+        if (g < a.n_bins + 2)
+          dens_lds[g * kEnsembleDensPad + w] =
+              walker < n_walkers ? ens::load_agent(a.dens + (size_t)walker * stride + g) : 0.0;
+      }
+      __syncthreads();
+      if (b == 0 && tid == 0) a.exited[gridDim.x + 2] = __builtin_amdgcn_s_memrealtime();
+
+      // waves = 4 shares of a quarter's positions x 4 groups of rows
+      const int ps = wave & 3, rg = wave >> 2;
+      const int rpw = (rt + 3) >> 2;                       // rows per group (<= 8)
+      const int row0 = rg * rpw;
+      const int rows = row0 < rt ? (rt - row0 < rpw ? rt - row0 : rpw) : 0;
+      double total[8], hold[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) total[k] = hold[k] = 0.0;
+      for (int qi = 0; qi < q_count; ++qi) {
+        const int base = (q_first + qi) * pq;
+        double acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+        for (int p = base + ps; p < base + pq; p += 4) {
+          const unsigned bins = ij_lds[p];
+          double w = dens_lds[(bins >> 16) * kEnsembleDensPad + lane];
+          if (a.mode == 0) w *= dens_lds[(bins & 0xffffu) * kEnsembleDensPad + lane];
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (k < rows) acc[k] = fma(t_lds[p * rt + row0 + k], w, acc[k]);
+        }
+        if (ps > 0) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (k < rows) area[((ps - 1) * rt + row0 + k) * 64 + lane] = acc[k];
+        }
+        __syncthreads();
+        if (ps == 0) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (k < rows) {
+              double quarter = acc[k];
+              for (int other = 0; other < 3; ++other)
+                quarter += area[(other * rt + row0 + k) * 64 + lane];
+              // the quarters of a slice: (q0 + q1) + (q2 + q3)
+              if ((qi & 1) == 0) hold[k] = quarter;
+              else if (qi == 1) total[k] = hold[k] + quarter;
+              else total[k] = total[k] + (hold[k] + quarter);
+            }
+          }
+        }
+        __syncthreads();
+      }
+      if (ps == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k < rows)
+            ens::store_agent(a.partial + ((size_t)b * rt + row0 + k) * 64 + lane,
+                             q_count == 1 ? hold[k] : total[k]);
+      }
+      ens::wait_stores();
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_store(a.flag_b + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (b == 0 && tid == 0) a.exited[gridDim.x + 3] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- C: one row of one group over all slices ------------------------------------------
+    if (c < n_wg && slice < rt + 2) {
+      const int row = slice;
+      double* out = a.out + ((size_t)c * (rt + 2) + row) * 64;
+      if (row < rt) {
+        const int spw = (a.n_slices + 15) >> 4;            // slices per wave
+        const int first = wave * spw;
+        // the flags of the workgroups this wave reads from
+        {
+          const int from = 4 * first + lane;
+          const bool needed = lane < 4 * spw && (from >> 2) < a.n_slices &&
+                              (n_wg == 1 ? true : n_wg == 2 ? (lane & 1) == c : (lane & 3) == c);
+          const unsigned long long since = __builtin_amdgcn_s_memrealtime();
+          for (;;) {
+            const unsigned long long flag =
+                needed ? __hip_atomic_load(a.flag_b + from, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT)
+                       : epoch;
+            if (__builtin_amdgcn_ballot_w64(flag != epoch) == 0) break;
+            if (timed_out(since)) {
+              s_abort = 1;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        double sum = 0.0;
+        if (!s_abort) {
+          for (int s = first; s < first + spw && s < a.n_slices; ++s) {
+            auto part = [&](int which) {
+              return ens::load_agent(a.partial + ((size_t)(4 * s + which) * rt + row) * 64 + lane);
+            };
+            double value;
+            if (n_wg == 1) value = (part(0) + part(1)) + (part(2) + part(3));
+            else if (n_wg == 2) value = part(c) + part(2 + c);
+            else value = part(c);
+            sum = s == first ? value : sum + value;
+          }
+        }
+        area[wave * 64 + lane] = sum;
+        __syncthreads();
+        if (s_abort) break;
+        if (wave == 0) {
+          double total = area[lane];
+          for (int w = 1; w < 16; ++w) total += area[w * 64 + lane];
+          ens::store_host(out + lane, total);
+        }
+      } else if (wave == 0) {
+        ens::store_host(out + lane, dens_lds[(a.n_bins + row - rt) * kEnsembleDensPad + lane]);
+      }
+      if (wave == 0) {
+        ens::wait_stores();
+        if (lane == 0)
+          __hip_atomic_store(a.done + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    __syncthreads();    // (area and dens_lds are free again)
+    serving = epoch + 1;
+    t_last = __builtin_amdgcn_s_memrealtime();
+    if (b == 0 && tid == 0) {
+      a.exited[gridDim.x + 4] = t_last;
+    }
+  }
+  if (tid == 0) {
+    __threadfence_system();
+    __hip_atomic_store(a.exited + b, a.launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // ---- float32 variant for tables with many correlation-function bins -------------------
 //
 // BASELINE configs[4]: R = 760 (rp x pi), G ~ 200.  With hundreds of r values the

@@ -1825,10 +1825,19 @@ int resident_wait(tc_table* t, int* left) {
 int resident_stop(tc_table* t) {
   tc_table::Resident& r = t->resident;
   if (!r.running) return TC_OK;
-  for (int i = 0; i < 7; ++i)
-    __atomic_store_n((unsigned long long*)r.mailbox.ptr + 2 * i + 1, tc::kResidentStop,
-                     __ATOMIC_RELEASE);
+  if (r.ensemble) {
+    // (every workgroup polls its own line)
+    unsigned long long* lines = (unsigned long long*)r.ens_mailbox.ptr;
+    for (int b = 0; b < r.ens_grid; ++b)
+      for (int i = 0; i < 8; ++i)
+        __atomic_store_n(lines + (size_t)b * 16 + 2 * i + 1, tc::kResidentStop, __ATOMIC_RELEASE);
+  } else {
+    for (int i = 0; i < 7; ++i)
+      __atomic_store_n((unsigned long long*)r.mailbox.ptr + 2 * i + 1, tc::kResidentStop,
+                       __ATOMIC_RELEASE);
+  }
   r.running = false;
+  r.ensemble = false;
   TC_HIP(hipStreamSynchronize(r.stream));
   return TC_OK;
 }
@@ -1848,8 +1857,8 @@ int resident_predict(tc_table* t, const double* theta, int n_theta, int n_gauss,
   int status = get_quadrature(t, n_gauss, &q);
   if (status != TC_OK) return status;
   const int blocks = single_draw_blocks(t);
-  if (r.running && (r.n_theta != n_theta || r.n_gauss != n_gauss || r.flags != flags ||
-                    r.blocks != blocks)) {
+  if (r.running && (r.ensemble || r.n_theta != n_theta || r.n_gauss != n_gauss ||
+                    r.flags != flags || r.blocks != blocks)) {
     status = resident_stop(t);        // (another kind of call: its own launch)
     if (status != TC_OK) return status;
   }
@@ -1895,6 +1904,226 @@ int resident_predict(tc_table* t, const double* theta, int n_theta, int n_gauss,
     if (status != TC_OK) return status;
   }
   return fail(TC_ERR_HIP, "the resident kernel keeps leaving before it answers");
+}
+
+// ---- resident ensemble path -------------------------------------------------------------------
+//
+// kernel_args.h (EnsembleArgs) has the protocol.  Page-locked: mailbox = (grid) lines of 16
+// words, then (grid) exited words and 8 stamps; out = (4, rt + 2, 64) doubles, then (grid)
+// completion words.  Device: dens | flag_a | partial | flag_b | callword, zeroed once.
+namespace {
+struct EnsembleLayout {
+  int grid = 0, n_slices = 0, per_quarter = 0, dens_stride = 0;
+  int lds_area = 0, lds_dens = 0, lds_t = 0, lds_ij = 0, lds_bytes = 0;
+  size_t dev_flag_a = 0, dev_partial = 0, dev_flag_b = 0, dev_callword = 0, dev_bytes = 0;
+};
+
+bool ensemble_layout(const tc_table* t, int n_gauss, EnsembleLayout* out) {
+  static const int n_cus = [] {
+    hipDeviceProp_t prop{};
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return 0;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+    return prop.multiProcessorCount;
+  }();
+  EnsembleLayout l;
+  l.n_slices = std::min(64, n_cus / 4);
+  l.grid = 4 * l.n_slices;
+  const int rt = t->rt;
+  if (l.n_slices < rt + 2 || rt > 32) return false;
+  if ((int64_t)t->n_bins * n_gauss > tc::kEnsembleThreads || t->n_bins + 2 > 1022) return false;
+  l.per_quarter = (int)((t->plan.n_positions + l.grid - 1) / l.grid);
+  l.dens_stride = (t->n_bins + 2 + 7) / 8 * 8;
+  auto align = [](size_t v) { return (v + 255) / 256 * 256; };
+  size_t at = align((size_t)tc::fm::kTableDoubles * 8);
+  l.lds_area = (int)at;
+  at = align(at + std::max<size_t>(2 * tc::kEnsembleThreads * 8, (size_t)3 * rt * 64 * 8));
+  l.lds_dens = (int)at;
+  at = align(at + (size_t)(t->n_bins + 2) * tc::kEnsembleDensPad * 8);
+  l.lds_t = (int)at;
+  at = align(at + (size_t)4 * l.per_quarter * rt * 8);
+  l.lds_ij = (int)at;
+  at = align(at + (size_t)4 * l.per_quarter * 4);
+  l.lds_bytes = (int)at;
+  if (at > 150 * 1024) return false;
+  size_t dev = align((size_t)tc::kEnsembleMaxWalkers * l.dens_stride * 8);
+  l.dev_flag_a = dev;
+  dev = align(dev + (size_t)tc::kEnsembleMaxWalkers * 8);
+  l.dev_partial = dev;
+  dev = align(dev + (size_t)l.grid * rt * 64 * 8);
+  l.dev_flag_b = dev;
+  dev = align(dev + (size_t)l.grid * 8);
+  l.dev_callword = dev;
+  l.dev_bytes = dev + 256;
+  *out = l;
+  return true;
+}
+}  // namespace
+
+bool ensemble_eligible(const tc_table* t, int64_t n_walkers, int n_gauss, unsigned flags) {
+  EnsembleLayout l;
+  return n_walkers >= 2 && n_walkers <= tc::kEnsembleMaxWalkers &&
+         single_draw_eligible(t, 1, n_gauss, flags) && ensemble_layout(t, n_gauss, &l);
+}
+
+int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walkers, int n_gauss,
+                     unsigned flags, double* ngal, double* xi) {
+  tc_table::Resident& r = t->resident;
+  Quadrature* q = nullptr;
+  int status = get_quadrature(t, n_gauss, &q);
+  if (status != TC_OK) return status;
+  EnsembleLayout l;
+  TC_CHECK(ensemble_layout(t, n_gauss, &l), "internal: ensemble routing");
+  if (r.running && (!r.ensemble || r.n_theta != n_theta || r.n_gauss != n_gauss ||
+                    r.flags != flags)) {
+    status = resident_stop(t);        // (another kind of call: its own launch)
+    if (status != TC_OK) return status;
+  }
+  if (r.stream == nullptr) TC_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+  const int rt = t->rt;
+  const size_t mailbox_words = (size_t)l.grid * 16 + l.grid + 8;
+  const size_t out_doubles = (size_t)4 * (rt + 2) * 64;
+  if (r.ens_mailbox.ptr == nullptr || r.ens_grid != l.grid) {
+    status = r.ens_mailbox.reserve(mailbox_words * 8);
+    if (status != TC_OK) return status;
+    memset(r.ens_mailbox.ptr, 0, r.ens_mailbox.bytes);
+    status = r.ens_out.reserve((out_doubles + l.grid) * 8);
+    if (status != TC_OK) return status;
+    memset(r.ens_out.ptr, 0, r.ens_out.bytes);
+    status = r.ens_device.reserve(l.dev_bytes, r.stream);
+    if (status != TC_OK) return status;
+    TC_HIP(hipMemset(r.ens_device.ptr, 0, r.ens_device.bytes));
+    r.ens_grid = l.grid;
+  }
+  unsigned long long* lines = (unsigned long long*)r.ens_mailbox.ptr;
+  volatile unsigned long long* exited = lines + (size_t)l.grid * 16;
+  double* out = (double*)r.ens_out.ptr;
+  volatile unsigned long long* done = (unsigned long long*)(out + out_doubles);
+  const unsigned long long epoch = ++r.ens_epoch;
+  const int n_wg = (n_walkers + 63) / 64;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    // eight entries {value, call number} per walker, the value before the number (x86 keeps
+    // the order of the stores)
+    for (int w = 0; w < n_walkers; ++w) {
+      unsigned long long* line = lines + (size_t)w * 16;
+      for (int i = 0; i < 8; ++i) {
+        unsigned long long bits = (unsigned long long)n_walkers;
+        if (i < 7) {
+          const double value = i < n_theta ? theta[(size_t)w * n_theta + i] : 0.0;
+          memcpy(&bits, &value, 8);
+        }
+        __atomic_store_n(line + 2 * i, bits, __ATOMIC_RELAXED);
+        __atomic_store_n(line + 2 * i + 1, epoch, __ATOMIC_RELEASE);
+      }
+    }
+    if (!r.running) {
+      tc::EnsembleArgs ea{};
+      ea.n_theta = n_theta;
+      ea.n_bins = t->n_bins;
+      ea.n_central = t->plan.n_central;
+      ea.n_gauss = n_gauss;
+      ea.flags = flags;
+      ea.split = 0.5;
+      ea.log_m = (const double*)q->log_m;
+      ea.m = (const double*)q->m;
+      ea.weight = (const double*)q->weight;
+      ea.n_h = (const double*)t->d_n_h;
+      ea.percentile = (const double*)t->d_percentile;
+      ea.math_table = (const double*)t->d_math_table;
+      ea.table = (const double*)t->d_table;
+      ea.pos_off = (const int32_t*)t->d_pos_off;
+      ea.n_positions = t->plan.n_positions;
+      ea.rt = rt;
+      ea.mode = t->mode;
+      ea.n_slices = l.n_slices;
+      ea.per_quarter = l.per_quarter;
+      ea.dens_stride = l.dens_stride;
+      char* device = (char*)r.ens_device.ptr;
+      ea.dens = (double*)device;
+      ea.flag_a = (unsigned long long*)(device + l.dev_flag_a);
+      ea.partial = (double*)(device + l.dev_partial);
+      ea.flag_b = (unsigned long long*)(device + l.dev_flag_b);
+      ea.callword = (unsigned long long*)(device + l.dev_callword);
+      ea.mailbox = lines;
+      ea.out = out;
+      ea.done = (unsigned long long*)done;
+      ea.exited = (unsigned long long*)exited;
+      ea.epoch = epoch;
+      ea.launch_id = ++r.launch_id;
+      ea.idle_ticks = (unsigned long long)std::max(1, r.idle_us) * 100ull;   // 100 MHz
+      ea.life_ticks = 1000000000ull;                                          // 10 s
+      ea.call_ticks = 2000000ull;                                             // 20 ms
+      ea.lds_area = l.lds_area;
+      ea.lds_dens = l.lds_dens;
+      ea.lds_t = l.lds_t;
+      ea.lds_ij = l.lds_ij;
+      static int attribute_device = -1;
+      if (attribute_device != t->device) {
+        TC_HIP(hipFuncSetAttribute((const void*)tc::resident_ensemble_kernel,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attribute_device = t->device;
+      }
+      hipLaunchKernelGGL(tc::resident_ensemble_kernel, dim3((unsigned)l.grid),
+                         dim3(tc::kEnsembleThreads), (size_t)l.lds_bytes, r.stream, ea);
+      TC_HIP(hipGetLastError());
+      r.running = true;
+      r.ensemble = true;
+      r.n_theta = n_theta;
+      r.n_gauss = n_gauss;
+      r.flags = flags;
+    }
+    // the completion words of the (row, group) workgroups
+    bool left = false;
+    {
+      timespec start{};
+      unsigned spins = 0;
+      for (int row = 0; row < rt + 2 && !left; ++row) {
+        for (int grp = 0; grp < n_wg && !left; ++grp) {
+          const int b = row * 4 + grp;
+          while (done[b] != epoch) {
+            __builtin_ia32_pause();
+            if ((++spins & 0x3ff) != 0) continue;
+            for (int other = 0; other < l.grid; ++other)
+              if (exited[other] == r.launch_id) left = true;
+            if (left) break;
+            timespec now{};
+            clock_gettime(CLOCK_MONOTONIC, &now);
+            if (start.tv_sec == 0 && start.tv_nsec == 0) start = now;
+            if ((now.tv_sec - start.tv_sec) * 1000000000LL + (now.tv_nsec - start.tv_nsec) >
+                500000000LL) {
+              (void)resident_stop(t);
+              return fail(TC_ERR_HIP, "the resident ensemble kernel did not answer (workgroup %d)",
+                          b);
+            }
+          }
+        }
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    if (!left) {
+      // tabcorr.py:646-650, row by row (the rows are contiguous in `out`)
+      double norm[tc::kEnsembleMaxWalkers];
+      for (int w = 0; w < n_walkers; ++w) {
+        const double* group = out + (size_t)(w >> 6) * (rt + 2) * 64;
+        const double total = group[(size_t)rt * 64 + (w & 63)] + group[(size_t)(rt + 1) * 64 + (w & 63)];
+        ngal[w] = total;
+        norm[w] = t->mode == TC_MODE_AUTO ? total * total : total;
+      }
+      for (int grp = 0; grp < n_wg; ++grp) {
+        const double* group = out + (size_t)grp * (rt + 2) * 64;
+        const int count = std::min(64, n_walkers - 64 * grp);
+        for (int row = 0; row < t->n_r; ++row)
+          for (int w = 0; w < count; ++w)
+            xi[(size_t)(64 * grp + w) * t->n_r + row] = group[(size_t)row * 64 + w] / norm[64 * grp + w];
+      }
+      return TC_OK;
+    }
+    // a workgroup has left (idle, life time or a wait that ran out): all of them out, then a
+    // new launch serves the call
+    status = resident_stop(t);
+    if (status != TC_OK) return status;
+  }
+  return fail(TC_ERR_HIP, "the resident ensemble kernel keeps leaving before it answers");
 }
 
 // The same for every table of an interpolator in one launch (interp.cpp fills the per-class

@@ -231,6 +231,9 @@ int tc_table_destroy(tc_table* t) {
   (void)resident_stop(t);
   if (t->resident.stream) (void)hipStreamDestroy(t->resident.stream);
   t->resident.mailbox.release();
+  t->resident.ens_mailbox.release();
+  t->resident.ens_out.release();
+  t->resident.ens_device.release();
   t->resident.ws.buffer.release();
   for (tc_table::Lane& lane : t->lanes)
     if (lane.stream) (void)hipStreamSynchronize(lane.stream);
@@ -419,6 +422,8 @@ int tc_predict_zheng07_many(tc_table* t, const double* theta, int n_theta, int n
   TC_HIP(hipSetDevice(t->device));
   if (n_walkers == 1 && t->resident.enabled && resident_eligible(t, n_gauss))
     return resident_predict(t, theta, n_theta, n_gauss, flags, ngal, xi);
+  if (t->resident.enabled && ensemble_eligible(t, n_walkers, n_gauss, flags))
+    return ensemble_predict(t, theta, n_theta, n_walkers, n_gauss, flags, ngal, xi);
   if (t->resident.running && (status = resident_stop(t)) != TC_OK) return status;
   status = launch_single_draw(t, theta, n_theta, n_walkers, n_gauss, flags, &t->single_ws,
                               t->stream);
@@ -449,6 +454,10 @@ int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
   // the results to page-locked host memory, which the device addresses directly; two API
   // calls and two copy-engine round trips less (1 draw 45 -> 40 us, 1000 draws 72 -> 54 us;
   // beyond ~1 MB the copy engines win).
+  if (t->resident.enabled && ensemble_eligible(t, n_draws, n_gauss, flags)) {
+    // an ensemble of up to 256 walkers with option "resident": no launch at all
+    return ensemble_predict(t, theta, n_theta, (int)n_draws, n_gauss, flags, ngal, xi);
+  }
   if (n_draws <= many_walkers_limit() && single_draw_eligible(t, 1, n_gauss, flags)) {
     // one draw -- or a handful (an ensemble sampler's proposals): ONE launch, the device-side
     // combination replaced by a few hundred additions here (kernels.hip.h: single_draw_kernel)
