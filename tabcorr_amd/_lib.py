@@ -160,6 +160,8 @@ SIGNATURES = {
                             ctypes.c_int64, c_int64_p],
     'tc_debug_resident_ticks': [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64),
                                 ctypes.c_int64, c_int64_p],
+    'tc_debug_ensemble_stamps': [ctypes.c_void_p,
+                                 ctypes.POINTER(ctypes.c_uint64)],
     'tc_table_last_launch': [ctypes.c_void_p, c_int_p, c_int_p, c_int_p,
                              c_int_p],
     'tc_pair_count_rppi': [c_double_p, ctypes.c_int64, c_double_p,

@@ -311,6 +311,8 @@ struct Tuning {
   int series = 1;               // moment expansion of the central bins' node sums (series.h)
   int cross_target = 160;       // mode cross: workgroups a launch should have at least
                                 // (several per tile of 64 draws below that)
+  int resident_aperture = 1;    // resident ensemble kernel: the mailbox in device memory that
+                                // the host writes through the PCIe aperture (large BAR only)
   int cross_min_draws = 192;    // ... smallest batch of the chunked form (17 - 128 rows;
                                 // tools/r04_cross_scan.py, AbacusSummit interpolator, us per call
                                 // one launch / three kernels: 256 draws 15.7 / 20.6, 1024 20.6 /
@@ -517,6 +519,8 @@ struct tc_table {
     int ens_grid = 0;
     tc::host::PinnedBuffer ens_mailbox, ens_out;
     tc::host::DeviceBuffer ens_device;
+    tc::host::DeviceBuffer ens_aperture;    // the mailbox in device memory (large BAR), or none
+    unsigned long long ens_host_ns[3] = {0, 0, 0};   // last call: published, answered, combined
   } resident;
   size_t trace_blocks = 0;
   size_t trace_launches = 0;

@@ -143,11 +143,11 @@ constexpr int kResidentBusyOffset = 64;   // exited[64 + workgroup]: ticks the l
 
 // Resident form for ENSEMBLES (resident_ensemble_kernel; launch.hip: ensemble_predict): 2 ..
 // kEnsembleMaxWalkers draws per call, host memory to host memory, no launch and no stream
-// synchronisation per call.  The grid is 4 * n_slices workgroups of 1024 threads that stay on
+// synchronisation per call.  The grid is 4 * n_slices workgroups of 512 threads that stay on
 // the chip (one per CU); workgroup b = 4 * slice + c.  A call runs in three phases that hand
 // their data on through device memory (write-through stores, a flag per producer that carries
 // the number of the call; nothing is ever reset):
-//   A  workgroup w < n_walkers: the occupation of walker w (one quadrature node per thread),
+//   A  workgroup w < n_walkers: the occupation of walker w (two quadrature nodes per thread),
 //      its G number densities and the two totals -> dens[w], flag_a[w];
 //   B  the table's positions are cut into n_slices slices of four quarters, kept in LDS for
 //      the life of the launch; lane = walker of a group of 64.  With one group the four
@@ -158,11 +158,16 @@ constexpr int kResidentBusyOffset = 64;   // exited[64 + workgroup]: ticks the l
 //      of the ensemble.  -> partial[b] (rt, 64), flag_b[b];
 //   C  workgroup (row, group): the sum over the slices of one row of one group in fixed
 //      order (rows rt, rt + 1: the two totals of the group's walkers) -> 64 contiguous doubles
-//      of out (groups, rt + 2, 64) in page-locked memory, then done[b].
-// The host writes one 128-byte line per walker -- eight 16-byte entries {value, number of the
-// call}: seven parameters and the number of walkers -- and workgroup w polls line w and the
-// device word that workgroup 0 forwards {call number, walkers} through, which is how the
-// workgroups without a walker learn of a call.  Every wait is bounded: idle_ticks / life_ticks
+//      of out (groups, rt + 2, 64) in page-locked memory, then done[group][row].
+// The host writes the walkers' parameters (8 doubles each) and then the header (number of the
+// call << 10 | walkers) into the mailbox.  On a large-BAR system the mailbox is DEVICE memory
+// that the host stores into through the PCIe aperture (tools/micro/bar_write.hip: a host ->
+// device -> host round trip 1.8 us against 2.45 us with the mailbox in page-locked memory,
+// and polling it costs no PCIe reads): every workgroup polls the header itself.  Otherwise
+// the mailbox is page-locked host memory, workgroup 0 alone polls the header and passes it on
+// through a word in device memory.  (First version: every workgroup polled a line of its own
+// in host memory -- 256 pollers keep the link so busy that a call took 22 - 38 us.)
+// Every wait is bounded: idle_ticks / life_ticks
 // as for the single draw, call_ticks for a wait inside a call; a workgroup that gives up sets
 // exited[b] = launch_id and the host serves the call another way.
 struct EnsembleArgs {
@@ -190,17 +195,19 @@ struct EnsembleArgs {
   unsigned long long* flag_a;   // (kEnsembleMaxWalkers)
   double* partial;              // (grid, rt, 64)
   unsigned long long* flag_b;   // (grid)
-  unsigned long long* callword; // call number << 10 | walkers
-  const unsigned long long* mailbox;   // page-locked: (walkers) lines of 16 words
+  unsigned long long* callword; // the header, forwarded by workgroup 0 (direct == 0)
+  const unsigned long long* mailbox;   // header (8 words), 8 doubles per walker
+  int direct;                   // 1: the mailbox is device memory, every workgroup polls it
   double* out;                  // page-locked: (4, rt + 2, 64)
-  unsigned long long* done;     // page-locked: (grid)
+  unsigned long long* done;     // page-locked: (4, rt + 2) completion words
   unsigned long long* exited;   // page-locked: (grid), then 8 phase stamps of workgroup 0
   unsigned long long epoch;     // first call to serve
   unsigned long long launch_id;
   unsigned long long idle_ticks, life_ticks, call_ticks;
   int lds_area, lds_dens, lds_t, lds_ij;   // byte offsets into the dynamic LDS
+  int skip;                     // developer A/B (TC_ENS_SKIP): phases left out, results wrong
 };
-constexpr int kEnsembleThreads = 1024;
+constexpr int kEnsembleThreads = 512;
 constexpr int kEnsembleMaxWalkers = 256;
 constexpr int kEnsembleDensPad = 65;      // doubles per bin row of the densities in LDS
 

@@ -3075,19 +3075,21 @@ __device__ __forceinline__ void wait_stores() { __builtin_amdgcn_s_waitcnt(0x0f7
 }  // namespace ens
 
 __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(EnsembleArgs a) {
+  // (512 threads: eight waves with 256 registers each keep the loads of a phase in flight
+  // together; sixteen waves of 128 registers spilled and walked the LDS one read at a time)
   extern __shared__ __attribute__((aligned(16))) unsigned char ens_lds[];
   double* table = (double*)ens_lds;
-  // phase A: node_value[1024] | density[1024]; phase B: red[3][rt][64]; phase C: red16[16][64]
+  // phase A: node_value[1024] | density[1024]; phase B: other[32][64]; phase C: sums[8][64]
   double* area = (double*)(ens_lds + a.lds_area);
   double* node_value = area;
-  double* density = area + kEnsembleThreads;
+  double* density = area + 1024;
   double* dens_lds = (double*)(ens_lds + a.lds_dens);     // (n_bins + 2, 65)
-  double* t_lds = (double*)(ens_lds + a.lds_t);           // (4 * per_quarter, rt)
+  double* t_lds = (double*)(ens_lds + a.lds_t);           // (4 * per_quarter, 32)
   unsigned* ij_lds = (unsigned*)(ens_lds + a.lds_ij);     // (4 * per_quarter)
-  __shared__ volatile int s_abort;
-  __shared__ int s_leave, s_walkers, s_is_walker;
+  __shared__ int s_abort;
+  __shared__ int s_leave, s_walkers;
   __shared__ unsigned long long s_epoch, s_seen;
-  __shared__ double s_theta[7];
+  __shared__ double s_theta[8];
   __shared__ double s_totals[2];
 
   const int tid = threadIdx.x;
@@ -3101,7 +3103,7 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
   const bool modulate = (a.flags & kFlagModulate) != 0;
   const int n_nodes = a.n_bins * a.n_gauss;
 
-  // once per launch: the math tables, this slice's positions, this thread's node
+  // once per launch: the math tables, this slice's positions, this thread's two nodes
   {
     typedef double __attribute__((ext_vector_type(2))) double2v;
     const double2v* src = (const double2v*)a.math_table;
@@ -3109,144 +3111,169 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
     for (int i = tid; i < fm::kTableDoubles / 2; i += kEnsembleThreads) dst[i] = src[i];
   }
   const int64_t slice_begin = (int64_t)slice * 4 * pq;
-  for (int idx = tid; idx < 4 * pq * rt; idx += kEnsembleThreads) {
-    const int pl = idx / rt, r = idx % rt;
+  for (int idx = tid; idx < 4 * pq * 32; idx += kEnsembleThreads) {
+    const int pl = idx >> 5, r = idx & 31;
     const int64_t q = slice_begin + pl;
-    // layouts of table.cpp, as single_draw_body reads them
+    // layouts of table.cpp, as single_draw_body reads them; 32 rows per position here, zeros
+    // beyond rt
     const int64_t index = (q >> 3) * 8 * rt +
                           ((((r >> 2) * 16 + (q & 3) * 4 + (r & 3)) << 1) + ((q >> 2) & 1));
-    t_lds[idx] = q < a.n_positions ? a.table[index] : 0.0;
+    t_lds[idx] = q < a.n_positions && r < rt ? a.table[index] : 0.0;
   }
   for (int pl = tid; pl < 4 * pq; pl += kEnsembleThreads) {
     const int64_t q = slice_begin + pl;
-    unsigned bins = 0;
+    unsigned bins = 0xffffffffu;            // (no position)
     if (q < a.n_positions) {
       const int64_t slot = ((q >> 3) * 4 + (q & 3)) * 4 + ((q >> 2) & 1) * 2;
       bins = (unsigned)(a.pos_off[slot] >> 9) | ((unsigned)(a.pos_off[slot + 1] >> 9) << 16);
     }
     ij_lds[pl] = bins;
   }
-  double kept_lm = 0.0, kept_mass = 0.0, kept_wk = 0.0, kept_n_h = 0.0;
-  bool kept_above = false;
-  if (tid < n_nodes) {
-    kept_lm = a.log_m[tid];
-    kept_mass = a.m[tid];
-    kept_wk = a.weight[tid];
-    kept_above = a.percentile[tid / a.n_gauss] > a.split;
+  double kept_lm[2] = {0.0, 0.0}, kept_mass[2] = {0.0, 0.0}, kept_wk[2] = {0.0, 0.0};
+  bool kept_above[2] = {false, false};
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int node = tid + u * kEnsembleThreads;
+    if (node < n_nodes) {
+      kept_lm[u] = a.log_m[node];
+      kept_mass[u] = a.m[node];
+      kept_wk[u] = a.weight[node];
+      kept_above[u] = a.percentile[node / a.n_gauss] > a.split;
+    }
   }
-  if (tid < a.n_bins) kept_n_h = a.n_h[tid];
+  double kept_n_h[2] = {0.0, 0.0};
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (tid + u * kEnsembleThreads < a.n_bins) kept_n_h[u] = a.n_h[tid + u * kEnsembleThreads];
   if (tid == 0) s_abort = 0;
   __syncthreads();
 
   unsigned long long serving = a.epoch;
   const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
   unsigned long long t_last = t_begin;
-  // (a wait inside a call: until `ready` holds for every lane of the wave, or the time is up)
+  // (a wait inside a call is over when its time is up)
   auto timed_out = [&](unsigned long long since) {
     return __builtin_amdgcn_s_memrealtime() - since > a.call_ticks;
   };
+  // (diagnosis, tools/r04_ensemble.py: 100 MHz stamps of workgroup 0 in page-locked memory)
+  auto stamp = [&](int which, unsigned long long value) {
+    if (b == 0 && tid == 0)
+      __hip_atomic_store(a.exited + gridDim.x + which, value, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  auto stamp_any = [&](int which, unsigned long long value) {
+    if (b == 0 && lane == 0)
+      __hip_atomic_store(a.exited + gridDim.x + which, value, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  };
 
   for (;;) {
-    // ---- the call: own line of the mailbox (walker b) or the forwarded word ---------------
+    // ---- the call.  a.direct: the mailbox lies in device memory that the host writes through
+    // the PCIe aperture, every workgroup polls its header there (local reads) and a walker's
+    // workgroup takes its parameters from behind it.  Otherwise the mailbox is page-locked
+    // host memory: workgroup 0 alone polls the header and passes it on through a word in
+    // device memory that the others poll (256 pollers of host memory keep the link so busy
+    // that the host's own stores take tens of microseconds), and the parameters cross the link
+    // when a workgroup asks for them.  The header is written behind the parameters.
     if (wave == 0) {
-      typedef unsigned long long __attribute__((ext_vector_type(2))) u64x2;
-      const u64x2* entry = (const u64x2*)a.mailbox + (size_t)b * 8 + (lane & 7);
-      u64x2 word = {0ull, 0ull};
+      // (the header and the forwarded word: number of the call << 10 | walkers)
+      const unsigned long long* source = b == 0 || a.direct ? a.mailbox : a.callword;
+      int leave = -1, walkers = 0;
+      unsigned long long epoch = 0, now = 0;
       for (;;) {
-        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
-                     : "=v"(word) : "v"(entry) : "memory");
-        const unsigned long long forwarded =
-            __hip_atomic_load(a.callword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-        const unsigned first_lo = __builtin_amdgcn_readfirstlane((unsigned)word.y);
-        const unsigned first_hi = __builtin_amdgcn_readfirstlane((unsigned)(word.y >> 32));
-        const unsigned long long first = ((unsigned long long)first_hi << 32) | first_lo;
-        const bool same = __builtin_amdgcn_ballot_w64(word.y != first) == 0;
-        const bool stop = __builtin_amdgcn_ballot_w64(word.y == kResidentStop) != 0;
-        int leave = -1, walkers = 0, is_walker = 0;
-        unsigned long long epoch = 0;
-        if (stop) {
+        unsigned long long word;
+        asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=v"(word) : "v"(source) : "memory");
+        now = __builtin_amdgcn_s_memrealtime();
+        if (word == kResidentStop) {
           leave = 1;
-        } else if (same && first >= serving && first >= (forwarded >> 10)) {
-          // (a line older than the forwarded call is a stale one, or about to be replaced;
-          // entry 7: the number of walkers)
-          const unsigned count = __builtin_amdgcn_readlane((unsigned)word.x, 7);
+        } else if ((word >> 10) >= serving) {
           leave = 0;
-          walkers = (int)count;
-          is_walker = 1;
-          epoch = first;
-        } else if ((forwarded >> 10) >= serving && (int)(forwarded & 1023) <= b) {
-          leave = 0;
-          walkers = (int)(forwarded & 1023);
-          epoch = forwarded >> 10;
+          walkers = (int)(word & 1023);
+          epoch = word >> 10;
         } else if (now - t_last > a.idle_ticks || now - t_begin > a.life_ticks) {
           leave = 1;
         }
-        if (leave >= 0) {
-          if (lane < 7) s_theta[lane] = __builtin_bit_cast(double, word.x);
-          if (lane == 0) {
-            s_leave = leave;
-            s_walkers = walkers;
-            s_is_walker = is_walker;
-            s_epoch = epoch;
-            s_seen = now;
-            if (b == 0 && leave == 0)
-              __hip_atomic_store(a.callword, (epoch << 10) | (unsigned long long)walkers,
-                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          break;
-        }
-        __builtin_amdgcn_s_sleep(2);
+        if (leave >= 0) break;
+        if (b == 0) __builtin_amdgcn_s_sleep(2);
+        else __builtin_amdgcn_s_sleep(4);
+      }
+      if (b == 0 && !a.direct && lane == 0)
+        __hip_atomic_store(a.callword,
+                           leave != 0 ? kResidentStop : (epoch << 10) | (unsigned long long)walkers,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (leave == 0 && b < walkers && lane < 7) {
+        // (parameters: 8 doubles per walker behind the header's line)
+        const double* theta = (const double*)a.mailbox + 8 + (size_t)b * 8 + lane;
+        double value;
+        asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=v"(value) : "v"(theta) : "memory");
+        s_theta[lane] = value;
+      }
+      if (lane == 0) {
+        s_leave = leave;
+        s_walkers = walkers;
+        s_epoch = epoch;
+        s_seen = now;
       }
     }
     __syncthreads();
     if (s_leave != 0) break;
     const int n_walkers = s_walkers;
     const unsigned long long epoch = s_epoch;
-    const bool is_walker = s_is_walker != 0 && b < n_walkers;
-    const unsigned long long t_call = s_seen;
-    if (b == 0 && tid == 0) a.exited[gridDim.x + 0] = t_call;
+    const bool is_walker = b < n_walkers;
+    stamp(0, s_seen);
 
     // ---- A: the occupation of walker b ----------------------------------------------------
-    if (is_walker) {
+    if (is_walker && (a.skip & 1)) {
+      if (tid == 0) __hip_atomic_store(a.flag_a + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (is_walker) {
       const fm::Consts kc = fm::make_consts();
       const DrawSetup d = prepare_draw(table, kc, s_theta[0], s_theta[1], s_theta[2], s_theta[3],
                                        s_theta[4], assembias ? s_theta[5] : 0.0,
                                        assembias ? s_theta[6] : 0.0);
       const double f1 = (1.0 - a.split) / a.split, f2 = a.split / (1.0 - a.split);
-      if (tid < n_nodes) {
-        const int g = tid / a.n_gauss;
-        const double lm = kept_lm, mass = kept_mass;
-        double n;
-        if (g < a.n_central) {
-          n = fma(0.5, fm::erf_fast(table, kc, (lm - d.log_m_min) * d.inv_sigma), 0.5);
-          if (assembias) n = heaviside_assembias(n, d.a_cen, kept_above, f2, f1, true);
-        } else {
-          const double x = mass - d.m0;
-          n = fm::exp2_fast(
-              table, kc,
-              d.alpha * fm::log2_fast_offset(table, kc, x > 1e-300 ? x : 1e-300, d.log2_m1),
-              x > 0.0);
-          n *= d.sat_scale;
-          if (modulate)
-            n *= fma(0.5, fm::erf_fast(table, kc, (lm - d.log_m_min) * d.inv_sigma), 0.5);
-          if (assembias) n = heaviside_assembias(n, d.a_sat, kept_above, f2, f1, false);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int node = tid + u * kEnsembleThreads;
+        if (node < n_nodes) {
+          const int g = node / a.n_gauss;
+          const double lm = kept_lm[u], mass = kept_mass[u];
+          double n;
+          if (g < a.n_central) {
+            n = fma(0.5, fm::erf_fast(table, kc, (lm - d.log_m_min) * d.inv_sigma), 0.5);
+            if (assembias) n = heaviside_assembias(n, d.a_cen, kept_above[u], f2, f1, true);
+          } else {
+            const double x = mass - d.m0;
+            n = fm::exp2_fast(
+                table, kc,
+                d.alpha * fm::log2_fast_offset(table, kc, x > 1e-300 ? x : 1e-300, d.log2_m1),
+                x > 0.0);
+            n *= d.sat_scale;
+            if (modulate)
+              n *= fma(0.5, fm::erf_fast(table, kc, (lm - d.log_m_min) * d.inv_sigma), 0.5);
+            if (assembias) n = heaviside_assembias(n, d.a_sat, kept_above[u], f2, f1, false);
+          }
+          if (d.bad) {   // (prepare_draw: parameters the fast path cannot represent)
+            const bool cen_nan = (d.bad & kBadCen) || ((d.bad & kTieCen) && lm == d.log_m_min);
+            if (g >= a.n_central && (d.bad & kInfSat) && n != 0.0)
+              n = assembias ? __builtin_nan("") : __builtin_huge_val();
+            if (g < a.n_central ? cen_nan
+                                : (((d.bad & kBadSat) && n != 0.0) || (modulate && cen_nan)))
+              n = __builtin_nan("");
+          }
+          node_value[node] = kept_wk[u] * n;
         }
-        if (d.bad) {   // (prepare_draw: parameters the fast path cannot represent)
-          const bool cen_nan = (d.bad & kBadCen) || ((d.bad & kTieCen) && lm == d.log_m_min);
-          if (g >= a.n_central && (d.bad & kInfSat) && n != 0.0)
-            n = assembias ? __builtin_nan("") : __builtin_huge_val();
-          if (g < a.n_central ? cen_nan
-                              : (((d.bad & kBadSat) && n != 0.0) || (modulate && cen_nan)))
-            n = __builtin_nan("");
-        }
-        node_value[tid] = kept_wk * n;
       }
       __syncthreads();
-      if (tid < a.n_bins) {
-        double acc = 0.0;
-        for (int k = 0; k < a.n_gauss; ++k) acc += node_value[tid * a.n_gauss + k];
-        density[tid] = acc * kept_n_h;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int g = tid + u * kEnsembleThreads;
+        if (g < a.n_bins) {
+          double acc = 0.0;
+          for (int k = 0; k < a.n_gauss; ++k) acc += node_value[g * a.n_gauss + k];
+          density[g] = acc * kept_n_h[u];
+        }
       }
       __syncthreads();
       if (tid < 128) {   // centrals / satellites totals: one wave each, fixed order
@@ -3258,17 +3285,17 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
         for (int offset = 32; offset >= 1; offset >>= 1) total += __shfl_down(total, offset, 64);
         if (lane == 0) s_totals[which] = total;
       }
+      // the densities go out while the totals are formed; the totals behind them
+      for (int g = tid; g < a.n_bins; g += kEnsembleThreads)
+        ens::store_agent(a.dens + (size_t)b * a.dens_stride + g, density[g]);
       __syncthreads();
-      if (tid < a.n_bins + 2) {
-        const double value = tid < a.n_bins ? density[tid] : s_totals[tid - a.n_bins];
-        ens::store_agent(a.dens + (size_t)b * a.dens_stride + tid, value);
-      }
+      if (tid < 2) ens::store_agent(a.dens + (size_t)b * a.dens_stride + a.n_bins + tid, s_totals[tid]);
       ens::wait_stores();
       __syncthreads();
       if (tid == 0)
         __hip_atomic_store(a.flag_a + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (b == 0 && tid == 0) a.exited[gridDim.x + 1] = __builtin_amdgcn_s_memrealtime();
+    stamp(1, __builtin_amdgcn_s_memrealtime());
 
     // ---- B: this workgroup's part of its slice for one group of 64 walkers ----------------
     const int n_wg = (n_walkers + 63) >> 6;
@@ -3300,22 +3327,39 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
       }
       __syncthreads();
       if (s_abort) break;
-      const int stride = a.dens_stride;
-      for (int idx = tid; idx < 64 * stride; idx += kEnsembleThreads) {
-        const int w = idx / stride, g = idx % stride;
-        const int walker = grp * 64 + w;
-        if (g < a.n_bins + 2)
-          dens_lds[g * kEnsembleDensPad + w] =
-              walker < n_walkers ? ens::load_agent(a.dens + (size_t)walker * stride + g) : 0.0;
+      stamp(2, __builtin_amdgcn_s_memrealtime());
+      if (!(a.skip & 4)) {
+        // the group's densities, (walker, bin) in memory -> (bin, walker) in LDS; eight loads
+        // in flight per thread
+        const int stride = a.dens_stride;
+        const int count = 64 * stride;
+        for (int idx0 = tid; idx0 < count; idx0 += 8 * kEnsembleThreads) {
+          double value[8];
+          int at[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int idx = idx0 + u * kEnsembleThreads;
+            const int w = idx / stride, g = idx - w * stride;
+            const int walker = grp * 64 + w;
+            const bool valid = idx < count && g < a.n_bins + 2;
+            at[u] = valid ? g * kEnsembleDensPad + w : -1;
+            value[u] = valid && walker < n_walkers
+                           ? ens::load_agent(a.dens + (size_t)walker * stride + g) : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (at[u] >= 0) dens_lds[at[u]] = value[u];
+        }
       }
       __syncthreads();
-      if (b == 0 && tid == 0) a.exited[gridDim.x + 2] = __builtin_amdgcn_s_memrealtime();
+      stamp(3, __builtin_amdgcn_s_memrealtime());
 
-      // waves = 4 shares of a quarter's positions x 4 groups of rows
-      const int ps = wave & 3, rg = wave >> 2;
-      const int rpw = (rt + 3) >> 2;                       // rows per group (<= 8)
-      const int row0 = rg * rpw;
-      const int rows = row0 < rt ? (rt - row0 < rpw ? rt - row0 : rpw) : 0;
+      // waves = 2 shares of a quarter's positions x 4 groups of 8 rows (the rows beyond rt
+      // are zeros in t_lds)
+      // (ps and the rows as per-lane values: with wave-uniform ones the compiler moves the
+      // positions' bins into scalar registers one LDS read, one wait and one branch at a time)
+      const int ps = (tid >> 6) & 1, row0 = (tid >> 7) * 8;
+      const bool rows_used = (wave >> 1) * 8 < rt;
       double total[8], hold[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) total[k] = hold[k] = 0.0;
@@ -3324,40 +3368,61 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
         double acc[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] = 0.0;
-        for (int p = base + ps; p < base + pq; p += 4) {
-          const unsigned bins = ij_lds[p];
-          double w = dens_lds[(bins >> 16) * kEnsembleDensPad + lane];
-          if (a.mode == 0) w *= dens_lds[(bins & 0xffffu) * kEnsembleDensPad + lane];
+        if (rows_used && !(a.skip & 2)) {
+          // the wave's positions of this quarter (at most 16: launch.hip, ensemble_layout):
+          // their bins first, then the products of the densities, then the rows
+          double w[16];
+          unsigned bins[16];
+          // (2 * u < pq: wave-uniform, what lies beyond costs nothing)
 #pragma unroll
-          for (int k = 0; k < 8; ++k)
-            if (k < rows) acc[k] = fma(t_lds[p * rt + row0 + k], w, acc[k]);
-        }
-        if (ps > 0) {
+          for (int u = 0; u < 16; ++u) {
+            const int p = base + ps + 2 * u;
+            bins[u] = 0xffffffffu;
+            if (2 * u < pq) bins[u] = p < base + pq ? ij_lds[p] : 0xffffffffu;
+          }
 #pragma unroll
-          for (int k = 0; k < 8; ++k)
-            if (k < rows) area[((ps - 1) * rt + row0 + k) * 64 + lane] = acc[k];
-        }
-        __syncthreads();
-        if (ps == 0) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            if (k < rows) {
-              double quarter = acc[k];
-              for (int other = 0; other < 3; ++other)
-                quarter += area[(other * rt + row0 + k) * 64 + lane];
-              // the quarters of a slice: (q0 + q1) + (q2 + q3)
-              if ((qi & 1) == 0) hold[k] = quarter;
-              else if (qi == 1) total[k] = hold[k] + quarter;
-              else total[k] = total[k] + (hold[k] + quarter);
+          for (int u = 0; u < 16; ++u) {
+            w[u] = 0.0;
+            if (2 * u < pq) {
+              const bool valid = bins[u] != 0xffffffffu;
+              const unsigned bi = valid ? bins[u] & 0xffffu : 0u, bj = valid ? bins[u] >> 16 : 0u;
+              double value = dens_lds[bj * kEnsembleDensPad + lane];
+              if (a.mode == 0) value *= dens_lds[bi * kEnsembleDensPad + lane];
+              w[u] = valid ? value : 0.0;
             }
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            // (a position beyond the quarter: w = 0 times a finite row of the first position)
+            const int p = base + ps + 2 * u < base + pq ? base + ps + 2 * u : base;
+            if (2 * u < pq) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) acc[k] = fma(t_lds[p * 32 + row0 + k], w[u], acc[k]);
+            }
+          }
+          if (ps == 1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) area[(row0 + k) * 64 + lane] = acc[k];
           }
         }
         __syncthreads();
+        if (ps == 0 && rows_used) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const double quarter = acc[k] + area[(row0 + k) * 64 + lane];
+            // the quarters of a slice: (q0 + q1) + (q2 + q3)
+            if ((qi & 1) == 0) hold[k] = quarter;
+            else if (qi == 1) total[k] = hold[k] + quarter;
+            else total[k] = total[k] + (hold[k] + quarter);
+          }
+        }
+        if (qi + 1 < q_count) __syncthreads();
       }
+      stamp(4, __builtin_amdgcn_s_memrealtime());
       if (ps == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-          if (k < rows)
+          if (row0 + k < rt)
             ens::store_agent(a.partial + ((size_t)b * rt + row0 + k) * 64 + lane,
                              q_count == 1 ? hold[k] : total[k]);
       }
@@ -3366,19 +3431,19 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
       if (tid == 0)
         __hip_atomic_store(a.flag_b + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (b == 0 && tid == 0) a.exited[gridDim.x + 3] = __builtin_amdgcn_s_memrealtime();
+    stamp(5, __builtin_amdgcn_s_memrealtime());
 
     // ---- C: one row of one group over all slices ------------------------------------------
     if (c < n_wg && slice < rt + 2) {
       const int row = slice;
       double* out = a.out + ((size_t)c * (rt + 2) + row) * 64;
       if (row < rt) {
-        const int spw = (a.n_slices + 15) >> 4;            // slices per wave
-        const int first = wave * spw;
-        // the flags of the workgroups this wave reads from
+        // a wave = eight slices: the flags of the 32 workgroups it reads from, then their
+        // partial sums, all loads in flight together
+        const int first = wave * 8;
         {
           const int from = 4 * first + lane;
-          const bool needed = lane < 4 * spw && (from >> 2) < a.n_slices &&
+          const bool needed = lane < 32 && (from >> 2) < a.n_slices &&
                               (n_wg == 1 ? true : n_wg == 2 ? (lane & 1) == c : (lane & 3) == c);
           const unsigned long long since = __builtin_amdgcn_s_memrealtime();
           for (;;) {
@@ -3394,25 +3459,42 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
             __builtin_amdgcn_s_sleep(1);
           }
         }
-        double sum = 0.0;
-        if (!s_abort) {
-          for (int s = first; s < first + spw && s < a.n_slices; ++s) {
-            auto part = [&](int which) {
-              return ens::load_agent(a.partial + ((size_t)(4 * s + which) * rt + row) * 64 + lane);
-            };
-            double value;
-            if (n_wg == 1) value = (part(0) + part(1)) + (part(2) + part(3));
-            else if (n_wg == 2) value = part(c) + part(2 + c);
-            else value = part(c);
-            sum = s == first ? value : sum + value;
+        if (wave == 7) stamp_any(6, __builtin_amdgcn_s_memrealtime());
+        const int n_parts = n_wg == 1 ? 4 : n_wg == 2 ? 2 : 1;
+        double part[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int s = first + u;
+            const int which = n_wg == 1 ? v : n_wg == 2 ? c + 2 * v : c;
+            part[u][v] =
+                s < a.n_slices && v < n_parts && !(a.skip & 8)
+                    ? ens::load_agent(a.partial + ((size_t)(4 * s + which) * rt + row) * 64 + lane)
+                    : 0.0;
           }
+        }
+        double sum = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          double value;
+          if (n_wg == 1) value = (part[u][0] + part[u][1]) + (part[u][2] + part[u][3]);
+          else if (n_wg == 2) value = part[u][0] + part[u][1];
+          else value = part[u][0];
+          if (first + u < a.n_slices) sum = u == 0 ? value : sum + value;
         }
         area[wave * 64 + lane] = sum;
         __syncthreads();
         if (s_abort) break;
         if (wave == 0) {
-          double total = area[lane];
-          for (int w = 1; w < 16; ++w) total += area[w * 64 + lane];
+          double each[8];
+#pragma unroll
+          for (int w = 0; w < 8; ++w) each[w] = area[w * 64 + lane];
+          double total = each[0];
+          const int n_waves = (a.n_slices + 7) >> 3;
+#pragma unroll
+          for (int w = 1; w < 8; ++w)
+            if (w < n_waves) total += each[w];
           ens::store_host(out + lane, total);
         }
       } else if (wave == 0) {
@@ -3421,15 +3503,14 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
       if (wave == 0) {
         ens::wait_stores();
         if (lane == 0)
-          __hip_atomic_store(a.done + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(a.done + c * (rt + 2) + row, epoch, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
     __syncthreads();    // (area and dens_lds are free again)
     serving = epoch + 1;
     t_last = __builtin_amdgcn_s_memrealtime();
-    if (b == 0 && tid == 0) {
-      a.exited[gridDim.x + 4] = t_last;
-    }
+    stamp(7, t_last);
   }
   if (tid == 0) {
     __threadfence_system();

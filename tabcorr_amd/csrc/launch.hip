@@ -1,6 +1,8 @@
 // Launch layer: the only translation unit that contains device code.  Chooses the
 // decomposition of a batch, fills the kernels' argument blocks and launches them on the
 // table's lanes (internal.h).
+#include <immintrin.h>
+
 #include "internal.h"
 #include "kernels.hip.h"
 #include "series.h"
@@ -1826,11 +1828,12 @@ int resident_stop(tc_table* t) {
   tc_table::Resident& r = t->resident;
   if (!r.running) return TC_OK;
   if (r.ensemble) {
-    // (every workgroup polls its own line)
-    unsigned long long* lines = (unsigned long long*)r.ens_mailbox.ptr;
-    for (int b = 0; b < r.ens_grid; ++b)
-      for (int i = 0; i < 8; ++i)
-        __atomic_store_n(lines + (size_t)b * 16 + 2 * i + 1, tc::kResidentStop, __ATOMIC_RELEASE);
+    // (the header; without the aperture workgroup 0 passes the word on)
+    unsigned long long* header = r.ens_aperture.ptr != nullptr
+                                     ? (unsigned long long*)r.ens_aperture.ptr
+                                     : (unsigned long long*)r.ens_mailbox.ptr;
+    __atomic_store_n(header, tc::kResidentStop, __ATOMIC_RELEASE);
+    _mm_sfence();
   } else {
     for (int i = 0; i < 7; ++i)
       __atomic_store_n((unsigned long long*)r.mailbox.ptr + 2 * i + 1, tc::kResidentStop,
@@ -1908,8 +1911,8 @@ int resident_predict(tc_table* t, const double* theta, int n_theta, int n_gauss,
 
 // ---- resident ensemble path -------------------------------------------------------------------
 //
-// kernel_args.h (EnsembleArgs) has the protocol.  Page-locked: mailbox = (grid) lines of 16
-// words, then (grid) exited words and 8 stamps; out = (4, rt + 2, 64) doubles, then (grid)
+// kernel_args.h (EnsembleArgs) has the protocol.  Page-locked: mailbox = the header {walkers,
+// call number} on a line of its own, 8 doubles per walker, (grid) exited words and 8 stamps; out = (4, rt + 2, 64) doubles, then (grid)
 // completion words.  Device: dens | flag_a | partial | flag_b | callword, zeroed once.
 namespace {
 struct EnsembleLayout {
@@ -1931,17 +1934,18 @@ bool ensemble_layout(const tc_table* t, int n_gauss, EnsembleLayout* out) {
   l.grid = 4 * l.n_slices;
   const int rt = t->rt;
   if (l.n_slices < rt + 2 || rt > 32) return false;
-  if ((int64_t)t->n_bins * n_gauss > tc::kEnsembleThreads || t->n_bins + 2 > 1022) return false;
+  if ((int64_t)t->n_bins * n_gauss > 1024 || t->n_bins > 1022) return false;
   l.per_quarter = (int)((t->plan.n_positions + l.grid - 1) / l.grid);
+  if (l.per_quarter > 32) return false;        // (sixteen positions per wave and quarter)
   l.dens_stride = (t->n_bins + 2 + 7) / 8 * 8;
   auto align = [](size_t v) { return (v + 255) / 256 * 256; };
   size_t at = align((size_t)tc::fm::kTableDoubles * 8);
   l.lds_area = (int)at;
-  at = align(at + std::max<size_t>(2 * tc::kEnsembleThreads * 8, (size_t)3 * rt * 64 * 8));
+  at = align(at + (size_t)2 * 1024 * 8);         // (phase A; phases B and C need as much)
   l.lds_dens = (int)at;
   at = align(at + (size_t)(t->n_bins + 2) * tc::kEnsembleDensPad * 8);
   l.lds_t = (int)at;
-  at = align(at + (size_t)4 * l.per_quarter * rt * 8);
+  at = align(at + (size_t)4 * l.per_quarter * 32 * 8);
   l.lds_ij = (int)at;
   at = align(at + (size_t)4 * l.per_quarter * 4);
   l.lds_bytes = (int)at;
@@ -1981,8 +1985,9 @@ int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walker
   }
   if (r.stream == nullptr) TC_HIP(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
   const int rt = t->rt;
-  const size_t mailbox_words = (size_t)l.grid * 16 + l.grid + 8;
-  const size_t out_doubles = (size_t)4 * (rt + 2) * 64;
+  const size_t exited_offset = 8 + (size_t)tc::kEnsembleMaxWalkers * 8;
+  const size_t mailbox_words = exited_offset + l.grid + 8;
+  const size_t out_doubles = (size_t)4 * (rt + 2) * 64;      // (then 4 x (rt + 2) words)
   if (r.ens_mailbox.ptr == nullptr || r.ens_grid != l.grid) {
     status = r.ens_mailbox.reserve(mailbox_words * 8);
     if (status != TC_OK) return status;
@@ -1993,29 +1998,52 @@ int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walker
     status = r.ens_device.reserve(l.dev_bytes, r.stream);
     if (status != TC_OK) return status;
     TC_HIP(hipMemset(r.ens_device.ptr, 0, r.ens_device.bytes));
+    // With a large BAR the runtime maps device memory into the host's address space: the
+    // mailbox goes there (option "resident_aperture" = 0: page-locked host memory instead).
+    int large_bar = 0;
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, t->device) != hipSuccess) {
+      (void)hipGetLastError();
+      large_bar = 0;
+    }
+    if (large_bar && t->tuning.resident_aperture) {
+      status = r.ens_aperture.reserve(exited_offset * 8, r.stream);
+      if (status != TC_OK) return status;
+      TC_HIP(hipMemset(r.ens_aperture.ptr, 0, r.ens_aperture.bytes));
+      TC_HIP(hipDeviceSynchronize());
+    } else {
+      r.ens_aperture.release();
+    }
     r.ens_grid = l.grid;
   }
-  unsigned long long* lines = (unsigned long long*)r.ens_mailbox.ptr;
-  volatile unsigned long long* exited = lines + (size_t)l.grid * 16;
+  const bool direct = r.ens_aperture.ptr != nullptr;
+  unsigned long long* lines =
+      direct ? (unsigned long long*)r.ens_aperture.ptr : (unsigned long long*)r.ens_mailbox.ptr;
+  volatile unsigned long long* exited = (unsigned long long*)r.ens_mailbox.ptr + exited_offset;
   double* out = (double*)r.ens_out.ptr;
   volatile unsigned long long* done = (unsigned long long*)(out + out_doubles);
   const unsigned long long epoch = ++r.ens_epoch;
   const int n_wg = (n_walkers + 63) / 64;
+  auto now_ns = [] {
+    timespec ts{};
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (unsigned long long)ts.tv_sec * 1000000000ull + (unsigned long long)ts.tv_nsec;
+  };
+  const unsigned long long host_begin = now_ns();
   for (int attempt = 0; attempt < 4; ++attempt) {
-    // eight entries {value, call number} per walker, the value before the number (x86 keeps
-    // the order of the stores)
-    for (int w = 0; w < n_walkers; ++w) {
-      unsigned long long* line = lines + (size_t)w * 16;
-      for (int i = 0; i < 8; ++i) {
-        unsigned long long bits = (unsigned long long)n_walkers;
-        if (i < 7) {
-          const double value = i < n_theta ? theta[(size_t)w * n_theta + i] : 0.0;
-          memcpy(&bits, &value, 8);
-        }
-        __atomic_store_n(line + 2 * i, bits, __ATOMIC_RELAXED);
-        __atomic_store_n(line + 2 * i + 1, epoch, __ATOMIC_RELEASE);
-      }
+    // the parameters (8 doubles per walker), then the header (call number << 10 | walkers): a
+    // workgroup reads its parameters only after the header has been seen
+    {
+      double* slots = (double*)(lines + 8);
+      for (int w = 0; w < n_walkers; ++w)
+        for (int i = 0; i < 7; ++i)
+          slots[(size_t)w * 8 + i] = i < n_theta ? theta[(size_t)w * n_theta + i] : 0.0;
+      // (the aperture is write-combining memory: the parameters leave the buffers before
+      // the header, and the header at once)
+      if (direct) _mm_sfence();
+      __atomic_store_n(lines + 0, (epoch << 10) | (unsigned long long)n_walkers, __ATOMIC_RELEASE);
+      if (direct) _mm_sfence();
     }
+    r.ens_host_ns[0] = now_ns() - host_begin;       // (published)
     if (!r.running) {
       tc::EnsembleArgs ea{};
       ea.n_theta = n_theta;
@@ -2045,6 +2073,8 @@ int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walker
       ea.flag_b = (unsigned long long*)(device + l.dev_flag_b);
       ea.callword = (unsigned long long*)(device + l.dev_callword);
       ea.mailbox = lines;
+      ea.direct = direct ? 1 : 0;
+      ea.skip = env_int_early("TC_ENS_SKIP", 0);
       ea.out = out;
       ea.done = (unsigned long long*)done;
       ea.exited = (unsigned long long*)exited;
@@ -2057,6 +2087,8 @@ int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walker
       ea.lds_dens = l.lds_dens;
       ea.lds_t = l.lds_t;
       ea.lds_ij = l.lds_ij;
+      // (the word a previous launch's workgroup 0 left behind)
+      TC_HIP(hipMemsetAsync(ea.callword, 0, 8, r.stream));
       static int attribute_device = -1;
       if (attribute_device != t->device) {
         TC_HIP(hipFuncSetAttribute((const void*)tc::resident_ensemble_kernel,
@@ -2072,15 +2104,26 @@ int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walker
       r.n_gauss = n_gauss;
       r.flags = flags;
     }
-    // the completion words of the (row, group) workgroups
+    // The completion words of the (group, row) workgroups, the two rows of totals first; every
+    // row goes to the caller's arrays as soon as it is there (tabcorr.py:646-650), the lines of
+    // the next rows on their way from memory meanwhile (the device's writes land in DRAM: a
+    // first read of a line costs ~100 ns).
     bool left = false;
     {
       timespec start{};
       unsigned spins = 0;
-      for (int row = 0; row < rt + 2 && !left; ++row) {
-        for (int grp = 0; grp < n_wg && !left; ++grp) {
-          const int b = row * 4 + grp;
-          while (done[b] != epoch) {
+      double norm[64];
+      for (int grp = 0; grp < n_wg && !left; ++grp) {
+        const double* group = out + (size_t)grp * (rt + 2) * 64;
+        const int count = std::min(64, n_walkers - 64 * grp);
+        for (int step = 0; step < rt + 2 && !left; ++step) {
+          auto row_of = [rt](int s) { return s < 2 ? rt + s : s - 2; };
+          const int row = row_of(step);
+          for (int s = step == 0 ? 0 : step + 3; s <= step + 3 && s < rt + 2; ++s)
+            for (int line = 0; line < count * 8; line += 64)
+              __builtin_prefetch((const char*)(group + (size_t)row_of(s) * 64) + line, 0, 0);
+          volatile unsigned long long* word = done + (size_t)grp * (rt + 2) + row;
+          while (*word != epoch) {
             __builtin_ia32_pause();
             if ((++spins & 0x3ff) != 0) continue;
             for (int other = 0; other < l.grid; ++other)
@@ -2092,30 +2135,31 @@ int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walker
             if ((now.tv_sec - start.tv_sec) * 1000000000LL + (now.tv_nsec - start.tv_nsec) >
                 500000000LL) {
               (void)resident_stop(t);
-              return fail(TC_ERR_HIP, "the resident ensemble kernel did not answer (workgroup %d)",
-                          b);
+              return fail(TC_ERR_HIP,
+                          "the resident ensemble kernel did not answer (group %d, row %d)", grp, row);
             }
+          }
+          if (left) break;
+          __atomic_thread_fence(__ATOMIC_ACQUIRE);
+          const double* values = group + (size_t)row * 64;
+          if (row == rt) {
+            for (int w = 0; w < count; ++w) norm[w] = values[w];
+          } else if (row == rt + 1) {
+            for (int w = 0; w < count; ++w) {
+              const double total = norm[w] + values[w];
+              ngal[64 * grp + w] = total;
+              norm[w] = t->mode == TC_MODE_AUTO ? total * total : total;
+            }
+          } else if (row < t->n_r) {
+            for (int w = 0; w < count; ++w)
+              xi[(size_t)(64 * grp + w) * t->n_r + row] = values[w] / norm[w];
           }
         }
       }
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
+    r.ens_host_ns[1] = now_ns() - host_begin;       // (every row seen and combined)
     if (!left) {
-      // tabcorr.py:646-650, row by row (the rows are contiguous in `out`)
-      double norm[tc::kEnsembleMaxWalkers];
-      for (int w = 0; w < n_walkers; ++w) {
-        const double* group = out + (size_t)(w >> 6) * (rt + 2) * 64;
-        const double total = group[(size_t)rt * 64 + (w & 63)] + group[(size_t)(rt + 1) * 64 + (w & 63)];
-        ngal[w] = total;
-        norm[w] = t->mode == TC_MODE_AUTO ? total * total : total;
-      }
-      for (int grp = 0; grp < n_wg; ++grp) {
-        const double* group = out + (size_t)grp * (rt + 2) * 64;
-        const int count = std::min(64, n_walkers - 64 * grp);
-        for (int row = 0; row < t->n_r; ++row)
-          for (int w = 0; w < count; ++w)
-            xi[(size_t)(64 * grp + w) * t->n_r + row] = group[(size_t)row * 64 + w] / norm[64 * grp + w];
-      }
+      r.ens_host_ns[2] = r.ens_host_ns[1];
       return TC_OK;
     }
     // a workgroup has left (idle, life time or a wait that ran out): all of them out, then a

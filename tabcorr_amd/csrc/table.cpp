@@ -234,6 +234,7 @@ int tc_table_destroy(tc_table* t) {
   t->resident.ens_mailbox.release();
   t->resident.ens_out.release();
   t->resident.ens_device.release();
+  t->resident.ens_aperture.release();
   t->resident.ws.buffer.release();
   for (tc_table::Lane& lane : t->lanes)
     if (lane.stream) (void)hipStreamSynchronize(lane.stream);
@@ -1013,6 +1014,14 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
       return TC_OK;
     }
     return autotune(t, (unsigned)value);
+  } else if (key == "resident_aperture") {
+    // 1 (default): the resident ensemble kernel's mailbox lies in device memory (large-BAR
+    // systems; the host writes it through the PCIe aperture); 0: in page-locked host memory
+    TC_CHECK(value == 0 || value == 1, "resident_aperture must be 0 or 1");
+    const int status = resident_stop(t);
+    if (status != TC_OK) return status;
+    t->tuning.resident_aperture = value;
+    t->resident.ens_grid = 0;          // (the buffers are chosen again at the next call)
   } else if (key == "cross_min_draws") {
     TC_CHECK(value >= 1, "cross_min_draws must be positive");
     t->tuning.cross_min_draws = value;
@@ -1206,6 +1215,20 @@ int tc_debug_resident_ticks(tc_table* t, uint64_t* out, int64_t capacity, int64_
   const unsigned long long* words = (const unsigned long long*)t->resident.mailbox.ptr;
   for (int64_t b = 0; b < std::min<int64_t>(capacity, *n_blocks); ++b)
     out[b] = words[16 + kSingleMaxBlocks + b];
+  return TC_OK;
+}
+
+// Phase stamps of workgroup 0 in the last call of the resident ensemble kernel (100 MHz ticks:
+// call seen, occupation stored, the group's occupations seen, densities in LDS, quarters summed,
+// partial sums stored, the slices' partial sums seen, call finished), then three host times of
+// that call in ns from its begin: published, every completion word seen, results combined.
+int tc_debug_ensemble_stamps(tc_table* t, uint64_t* out) {
+  TC_CHECK(t != nullptr && out != nullptr, "NULL argument");
+  TC_CHECK(t->resident.ens_mailbox.ptr != nullptr, "no ensemble call has been made");
+  const unsigned long long* words = (const unsigned long long*)t->resident.ens_mailbox.ptr;
+  const size_t offset = 8 + (size_t)tc::kEnsembleMaxWalkers * 8 + t->resident.ens_grid;
+  for (int i = 0; i < 8; ++i) out[i] = words[offset + i];
+  for (int i = 0; i < 3; ++i) out[8 + i] = t->resident.ens_host_ns[i];
   return TC_OK;
 }
 

@@ -459,3 +459,92 @@ def test_unbatched_interpolator_in_one_round_of_workgroups(shape, n_prim):
         want = oracle.interpolator_predict_zheng07_batch(tables, setup, theta[i:i + 1], x[None, :])
         assert_rel(results[0][0], want[0][0], RTOL)
         assert_rel(results[0][1], want[1][0], RTOL)
+
+
+@pytest.mark.parametrize('aperture', [1, 0])
+def test_resident_kernel_serves_ensembles(aperture):
+    """Option "resident", 2 .. 256 walkers per synchronous call: resident_ensemble_kernel answers
+    without a launch (mailbox in device memory behind the PCIe aperture, or in page-locked
+    memory) -- the batched path's results to rounding, the oracle's within the tolerance, a
+    walker's result bit for bit the same in an ensemble of any size and from call to call;
+    across idle time-outs, other kinds of calls in between, other flags, NaN parameters, more
+    walkers than it takes, the reference's table, and a handle destroyed while it runs."""
+    import time
+    from tabcorr_amd import synthetic, _lib
+    from oracle import tabcorr_oracle as oracle
+    lib = _lib.load()
+    table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    theta = synthetic.zheng07_draws(300, seed=21)
+    halotab = make_tabcorr(table)
+    handle = halotab.to_device().handle
+    _lib.check(lib.tc_table_set_option(handle, b'resident_aperture', aperture))
+    plain = halotab.predict_batch(theta[:256])
+    want = oracle.predict_zheng07_batch(table, theta[:6])
+    halotab.set_resident(True)
+    full = halotab.predict_batch(theta[:256])
+    assert_rel(full[0], plain[0], 1e-12)
+    assert_rel(full[1], plain[1], 1e-12)
+    assert_rel(full[1][:6], want[1], RTOL)
+    assert_rel(full[0][:6], want[0], RTOL)
+    for n in (2, 3, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256):
+        ngal, xi = halotab.predict_batch(theta[:n])
+        assert np.array_equal(xi, full[1][:n]) and np.array_equal(ngal, full[0][:n]), n
+    # a walker's place in the ensemble does not matter either
+    order = np.random.default_rng(3).permutation(200)
+    ngal, xi = halotab.predict_batch(theta[order])
+    assert np.array_equal(xi, full[1][order])
+    # idle time-out: the kernel leaves after 50 us without a call, the next call launches it
+    halotab.set_resident(True, idle_us=50)
+    for i in range(30):
+        n = 2 + 8 * i
+        ngal, xi = halotab.predict_batch(theta[:n])
+        assert np.array_equal(xi, full[1][:n]), n
+        time.sleep(0.0002 * (i % 4))
+    halotab.set_resident(True, idle_us=2000)
+    # one walker (the other resident kernel), more than 256 (the batched path), the
+    # asynchronous path, other flags in between
+    single = halotab.predict_batch(theta[5:6])
+    assert_rel(single[1], full[1][5:6], 1e-13)
+    ngal, xi = halotab.predict_batch(theta[:70])
+    assert np.array_equal(xi, full[1][:70])
+    many = halotab.predict_batch(theta[:300])
+    assert_rel(many[1][:256], plain[1], 1e-12)
+    ngal, xi = halotab.predict_batch(theta[:130])
+    assert np.array_equal(xi, full[1][:130])
+    ngal, xi = halotab.predict_batch(theta[:40], modulate_with_cenocc=True)
+    expect = oracle.predict_zheng07_batch(table, theta[:40], modulate_with_cenocc=True)
+    assert_rel(xi, expect[1], RTOL)
+    ngal_s, xi_s = halotab.predict_batch(theta[:40], separate_gal_type=True)
+    assert_rel(sum(xi_s[key] for key in xi_s), full[1][:40], 1e-12)
+    ngal, xi = halotab.predict_batch(theta[:40])
+    assert np.array_equal(xi, full[1][:40])
+    # NaN parameters reject their walker only
+    bad = theta[:20].copy()
+    bad[7, 1] = np.nan
+    ngal, xi = halotab.predict_batch(bad)
+    assert np.isnan(ngal[7]) and np.all(np.isnan(xi[7]))
+    keep = [i for i in range(20) if i != 7]
+    assert np.array_equal(xi[keep], full[1][keep])
+    # decorated occupations
+    strengths = np.random.default_rng(11).uniform(-1.2, 1.2, (90, 2))
+    table_ab = synthetic.synthetic_table(30, 2, (12, ), 'auto', seed=2)
+    decorated = make_tabcorr(table_ab)
+    _lib.check(lib.tc_table_set_option(decorated.to_device().handle, b'resident_aperture',
+                                       aperture))
+    decorated.set_resident(True)
+    ngal, xi = decorated.predict_batch(np.hstack([theta[:90], strengths]), assembias=True,
+                                       modulate_with_cenocc=True)
+    expect = oracle.predict_zheng07_batch(table_ab, theta[:90], modulate_with_cenocc=True,
+                                          assembias=strengths)
+    assert_rel(xi, expect[1], RTOL)
+    assert_rel(ngal, expect[0], RTOL)
+    # the reference's own table (G = 60), and a handle deleted while its kernel runs
+    golden = make_tabcorr(table_from_golden(load_golden('bolplanck_wp')))
+    reference = golden.predict_batch(theta[:100])
+    golden.set_resident(True)
+    ngal, xi = golden.predict_batch(theta[:100])
+    assert_rel(xi, reference[1], 1e-12)
+    del golden, decorated
+    halotab.set_resident(False)
+    ngal, xi = halotab.predict_batch(theta[:50])
+    assert_rel(xi, plain[1][:50], 1e-15)
