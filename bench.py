@@ -902,8 +902,32 @@ def unbatched(make, table, synthetic, Interpolator):
         theta = synthetic.zheng07_draws(n, seed=70 + n)
         seconds = time_calls(lambda: halotab.predict_batch(theta), seconds=0.2, warm=50)
         walkers['%d' % n] = {'us_per_call': seconds * 1e6, 'us_per_walker': seconds * 1e6 / n}
+    # the same steps served by the resident ENSEMBLE kernel (2 .. 256 walkers per call, no
+    # launch; checked against the launched result)
+    resident_walkers = {}
+    try:
+        for n in (64, 256):
+            theta = synthetic.zheng07_draws(n, seed=70 + n)
+            halotab.set_resident(False)
+            expect = halotab.predict_batch(theta)
+            launched = time_calls(lambda: halotab.predict_batch(theta), seconds=0.2, warm=50)
+            halotab.set_resident(True)
+            got = halotab.predict_batch(theta)
+            served = time_calls(lambda: halotab.predict_batch(theta), seconds=0.2, warm=50)
+            resident_walkers['%d' % n] = {
+                'us_per_call': served * 1e6, 'us_per_call_launched': launched * 1e6,
+                'max_rel_vs_launched': float(max(np.max(np.abs(got[0] / expect[0] - 1)),
+                                                 np.max(np.abs(got[1] / expect[1] - 1))))}
+    except Exception as error:   # noqa: BLE001 -- a secondary measurement must not end the bench
+        resident_walkers['failed'] = str(error)
+    finally:
+        try:
+            halotab.set_resident(False)
+        except Exception:   # noqa: BLE001
+            pass
     return {'predict_model': single * 1e6,
             'predict_model_resident': None if resident is None else resident * 1e6,
+            'predict_batch_walkers_resident': resident_walkers,
             'predict_model_resident_max_rel_vs_one_launch_per_call': resident_parity,
             'interpolator_5x5_predict_model': grid * 1e6,
             'predict_batch_walkers': walkers,

@@ -340,6 +340,15 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 tc_table_destroy.  Device-wide synchronisations by the caller
  *                 (hipDeviceSynchronize, hipFree) wait for it at most that idle time.
  *                 0 (default): one launch per call.
+ *                 Calls with 2 .. 256 draws in host arrays (an ensemble sampler's step) are
+ *                 served the same way by a second resident kernel of one workgroup per CU
+ *                 (kernel_args.h: EnsembleArgs): no launch, no copy command, no stream
+ *                 synchronisation per call; a draw's result does not depend on the number of
+ *                 draws in the call or its place among them.
+ *   "resident_aperture"  1 (default): on large-BAR systems the mailbox of the resident
+ *                 ensemble kernel lies in device memory that the host stores into through
+ *                 the PCIe aperture (no PCIe reads while the kernel polls); 0: in page-locked
+ *                 host memory, as on systems without a large BAR.
  *   "trace"       developer timelines (developer builds only, tabcorr_amd_testing.h). */
 int tc_table_set_option(tc_table* table, const char* name, int value);
 /* What option "autotune" measured for `flags`: per batch size (`count` of them, at most
