@@ -1,0 +1,311 @@
+// VERDICT r03 item 9, the gate itself: BASELINE configs[4] in float64 (G = 200, P = 20100 pairs,
+// R = 760, 10^4 draws) contracted on the INTEGER matrix cores at float64 accuracy, with real
+// operand traffic -- table slices from memory, densities from memory, the pair weights formed
+// and cut into slices per draw inside the kernel -- against the product's float64 quadratic
+// form (4.4 - 4.6 ms per 10^4 draws, 0.86 - 0.89 of the float64 matrix peak).
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/ozaki_kernel.hip -o tools/micro/ozaki_kernel
+// Scheme (tools/micro/ozaki_accuracy.py): per block of 256 pairs the table row / the draw's
+// pair weights are scaled by a power of two and cut into six signed 7-bit slices; the 21 slice
+// products with i + j < 6 go through v_mfma_i32_16x16x64_i8 (four K steps per block), the
+// products of one diagonal into one int32 tile; per block and row tile the six tiles become
+// one double (Horner in 2^-7) times 2^(eT + eW - 14).  The table is float32-exact
+// (tabcorr.py:335 stores it as float32), so six slices hold it with room for the spread of
+// magnitudes inside a block.
+// Work item = 16 draws x a quarter of the blocks; eight waves = eight groups of six row tiles;
+// the weights of the next block are cut (two draws per wave) while this one is consumed, one
+// barrier per block.  (32 draws x 12 row tiles per wave: 96 registers of sums next to the
+// operands of two steps -- spills; 3.5 ms.)
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#define CHECK(call)                                                             \
+  do {                                                                          \
+    hipError_t status_ = (call);                                                \
+    if (status_ != hipSuccess) {                                                \
+      fprintf(stderr, "%s: %s\n", #call, hipGetErrorString(status_));           \
+      exit(1);                                                                  \
+    }                                                                           \
+  } while (0)
+
+constexpr int kBins = 200;
+constexpr int kPairs = kBins * (kBins + 1) / 2;          // 20100
+constexpr int kBlock = 256;
+constexpr int kBlocks = (kPairs + kBlock - 1) / kBlock;   // 79
+constexpr int kRows = 760;
+constexpr int kRowTiles = 48;                             // 768 rows
+constexpr int kSlices = 6;
+constexpr int kParts = 4;                                 // K parts per group of draws
+constexpr int kDraws = 16;                                // draws per workgroup
+constexpr int kTilesPerWave = 6;
+
+struct Args {
+  const i32x4* table_slices;     // (block, row tile, slice, K step, lane)
+  const int* table_exponents;    // (block, row tile, 16 rows) one byte each
+  const unsigned* pairs;         // (block, 256) i | j << 16
+  const double* densities;       // (bin, ld)
+  int64_t ld;
+  double* partial;               // (part, draw, 768)
+  int n_draws;
+  int skip;                      // diagnosis: 1 no cutting after the first block, 4 no conversions
+};
+
+__global__ __launch_bounds__(512) void contract_i8(Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  double* dens = (double*)lds;                                      // (bin, 32)
+  i32x4* wbuf = (i32x4*)(lds + kBins * kDraws * 8);                 // (2, slices, 4, 64)
+  int* wexp = (int*)(lds + kBins * kDraws * 8 + 2 * kSlices * 4 * 64 * 16);       // (2, 16)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int group = blockIdx.x / kParts, part = blockIdx.x % kParts;
+  const int draw0 = group * kDraws;
+  const int per_part = (kBlocks + kParts - 1) / kParts;
+  const int b_begin = part * per_part, b_end = min(kBlocks, b_begin + per_part);
+
+  for (int idx = tid; idx < kBins * kDraws; idx += 512) {
+    const int bin = idx / kDraws, d = idx % kDraws;
+    dens[idx] = draw0 + d < a.n_draws ? a.densities[(int64_t)bin * a.ld + draw0 + d] : 0.0;
+  }
+  __syncthreads();
+
+  // the pair weights of four draws of block b -> slices in buffer `buf`
+  auto cut = [&](int b, int buf) {
+    const uint4 four = ((const uint4*)(a.pairs + (size_t)b * kBlock))[lane];
+    const unsigned ij[4] = {four.x, four.y, four.z, four.w};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int d = wave * 2 + u;
+      double w[4], top = 0.0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        w[e] = dens[(ij[e] & 0xffffu) * kDraws + d] * dens[(ij[e] >> 16) * kDraws + d];
+        top = fmax(top, fabs(w[e]));
+      }
+#pragma unroll
+      for (int offset = 32; offset >= 1; offset >>= 1) top = fmax(top, __shfl_xor(top, offset, 64));
+      int exponent = 0;
+      (void)frexp(top, &exponent);
+      exponent = top > 0.0 ? exponent + 1 : 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = ldexp(w[e], -exponent);       // |w| < 1/2
+      // lane l holds pairs 4 l .. 4 l + 3 of the block: K step l / 16, bytes 4 (l % 4) .. of the
+      // 16-byte operand of lane (l % 16) / 4 * 16 + draw
+      const int ks = lane >> 4, target = ((lane & 15) >> 2) * 16 + (d & 15);
+      int* word = (int*)(wbuf + ((buf * kSlices) * 4 + ks) * 64 + target) + (lane & 3);
+#pragma unroll
+      for (int s = 0; s < kSlices; ++s) {
+        int packed = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          w[e] *= 128.0;
+          const double piece = __builtin_rint(w[e]);
+          w[e] -= piece;
+          packed |= ((int)piece & 0xff) << (8 * e);
+        }
+        word[(size_t)s * 4 * 64 * 4] = packed;
+      }
+      if (lane == 0) wexp[buf * 16 + d] = exponent;
+    }
+  };
+
+  const int rg = wave;
+  double total[kTilesPerWave][4];
+#pragma unroll
+  for (int rt = 0; rt < kTilesPerWave; ++rt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) total[rt][v] = 0.0;
+
+  cut(b_begin, b_begin & 1);
+  __syncthreads();
+  for (int b = b_begin; b < b_end; ++b) {
+    const int buf = b & 1;
+    if (b + 1 < b_end && !(a.skip & 1)) cut(b + 1, buf ^ 1);
+    const int e_w = wexp[buf * 16 + (lane & 15)];
+    const i32x4* b_base = wbuf + (buf * kSlices) * 4 * 64 + lane;
+    // 48 steps (row tile, K step), the operands of the next step requested before this
+    // step's matrix instructions
+    const i32x4* a_block = a.table_slices +
+        ((size_t)(b * kRowTiles + rg * kTilesPerWave) * kSlices) * 4 * 64 + lane;
+    const int* e_block = a.table_exponents + ((size_t)b * kRowTiles + rg * kTilesPerWave) * 4 + (lane >> 4);
+    // (the block's weights stay in registers for all row tiles of the wave: read from the LDS
+    // step by step they put an LDS latency in front of every 21 matrix instructions)
+    i32x4 ta[2][kSlices], wb[4][kSlices];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int s = 0; s < kSlices; ++s) wb[ks][s] = b_base[(s * 4 + ks) * 64];
+    int e_t4[2] = {0, 0};
+    auto request = [&](int step, int slot) {
+      const int rt = step >> 2, ks = step & 3;
+#pragma unroll
+      for (int s = 0; s < kSlices; ++s)
+        ta[slot][s] = a_block[((size_t)rt * kSlices * 4 + s * 4 + ks) * 64];
+      if (ks == 0) e_t4[(step >> 2) & 1] = e_block[rt * 4];
+    };
+    request(0, 0);
+    i32x4 acc[kSlices];
+#pragma unroll
+    for (int step = 0; step < 4 * kTilesPerWave; ++step) {
+      const int rt = step >> 2, ks = step & 3, slot = step & 1;
+      if (step + 1 < 4 * kTilesPerWave) request(step + 1, slot ^ 1);
+      if (ks == 0) {
+#pragma unroll
+        for (int d = 0; d < kSlices; ++d) acc[d] = i32x4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int d = 0; d < kSlices; ++d)
+#pragma unroll
+        for (int i = 0; i <= d; ++i)
+          acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ta[slot][i], wb[ks][d - i], acc[d], 0, 0, 0);
+      if (ks == 3 && !(a.skip & 4)) {
+        const int word = e_t4[rt & 1];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          double sum = (double)acc[kSlices - 1][v];
+#pragma unroll
+          for (int d = kSlices - 2; d >= 0; --d) sum = fma(sum, 0.0078125, (double)acc[d][v]);
+          const int e_t = (int)(signed char)((word >> (8 * v)) & 0xff);
+          total[rt][v] += ldexp(sum, e_t + e_w - 14);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int draw = draw0 + (lane & 15);
+  if (draw < a.n_draws) {
+#pragma unroll
+    for (int rt = 0; rt < kTilesPerWave; ++rt) {
+      const int row = (rg * kTilesPerWave + rt) * 16 + 4 * (lane >> 4);
+      double* out = a.partial + ((size_t)part * a.n_draws + draw) * (kRowTiles * 16) + row;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) out[v] = total[rt][v];
+    }
+  }
+}
+
+int main(int argc, char** argv) {
+  const int n_draws = argc > 1 ? atoi(argv[1]) : 10000;
+  const int skip = argc > 2 ? atoi(argv[2]) : 0;
+  std::mt19937_64 rng(5);
+  std::uniform_real_distribution<double> uniform(0.0, 1.0);
+  // a float32-exact table with four decades of magnitudes and both signs, the packed pairs
+  std::vector<double> table((size_t)kRows * kBlocks * kBlock, 0.0);
+  for (int r = 0; r < kRows; ++r)
+    for (int p = 0; p < kPairs; ++p) {
+      const double magnitude = std::pow(10.0, -3.0 + 4.0 * uniform(rng));
+      table[(size_t)r * kBlocks * kBlock + p] = (double)(float)(uniform(rng) < 0.3 ? -magnitude : magnitude);
+    }
+  std::vector<unsigned> pairs((size_t)kBlocks * kBlock, 0u);
+  {
+    int p = 0;
+    for (int i = 0; i < kBins; ++i)
+      for (int j = i; j < kBins; ++j) pairs[p++] = (unsigned)i | ((unsigned)j << 16);
+  }
+  const int64_t ld = (n_draws + 31) / 32 * 32;      // (a multiple of kDraws)
+  std::vector<double> densities((size_t)kBins * ld, 0.0);
+  for (int g = 0; g < kBins; ++g)
+    for (int d = 0; d < n_draws; ++d)
+      densities[(size_t)g * ld + d] = std::pow(10.0, -6.0 + 4.0 * uniform(rng));
+  // slices of the table: per (block, row) a power of two above twice the largest magnitude
+  std::vector<int8_t> slices((size_t)kBlocks * kRowTiles * kSlices * 4 * 64 * 16, 0);
+  std::vector<int8_t> exponents((size_t)kBlocks * kRowTiles * 16, 0);
+  for (int b = 0; b < kBlocks; ++b)
+    for (int row = 0; row < kRows; ++row) {
+      const double* values = &table[(size_t)row * kBlocks * kBlock + (size_t)b * kBlock];
+      double top = 0.0;
+      for (int k = 0; k < kBlock; ++k) top = std::max(top, std::fabs(values[k]));
+      int exponent = 0;
+      (void)std::frexp(top, &exponent);
+      exponent = top > 0.0 ? exponent + 1 : 0;
+      const int tile = row / 16, m = row % 16;
+      exponents[((size_t)b * kRowTiles + tile) * 16 + m] = (int8_t)exponent;
+      for (int k = 0; k < kBlock; ++k) {
+        double rest = std::ldexp(values[k], -exponent);
+        const int ks = k / 64, lane = ((k % 64) / 16) * 16 + m, byte = k % 16;
+        for (int s = 0; s < kSlices; ++s) {
+          rest *= 128.0;
+          const double piece = std::nearbyint(rest);
+          rest -= piece;
+          slices[((((size_t)(b * kRowTiles + tile) * kSlices + s) * 4 + ks) * 64 + lane) * 16 + byte] =
+              (int8_t)(int)piece;
+        }
+      }
+    }
+  // (the exponents of the four rows 4 (l / 16) + v of a lane in one word)
+  Args args{};
+  void *d_slices, *d_exponents, *d_pairs, *d_densities, *d_partial;
+  CHECK(hipMalloc(&d_slices, slices.size()));
+  CHECK(hipMalloc(&d_exponents, exponents.size()));
+  CHECK(hipMalloc(&d_pairs, pairs.size() * 4));
+  CHECK(hipMalloc(&d_densities, densities.size() * 8));
+  const size_t partial_doubles = (size_t)kParts * n_draws * kRowTiles * 16;
+  CHECK(hipMalloc(&d_partial, partial_doubles * 8));
+  CHECK(hipMemcpy(d_slices, slices.data(), slices.size(), hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_exponents, exponents.data(), exponents.size(), hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_pairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_densities, densities.data(), densities.size() * 8, hipMemcpyHostToDevice));
+  args.table_slices = (const i32x4*)d_slices;
+  args.table_exponents = (const int*)d_exponents;
+  args.pairs = (const unsigned*)d_pairs;
+  args.densities = (const double*)d_densities;
+  args.ld = ld;
+  args.partial = (double*)d_partial;
+  args.n_draws = n_draws;
+  args.skip = skip;
+  const size_t lds_bytes = (size_t)kBins * kDraws * 8 + 2 * kSlices * 4 * 64 * 16 + 2 * 16 * 4;
+  CHECK(hipFuncSetAttribute((const void*)contract_i8, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_bytes));
+  const int groups = (n_draws + kDraws - 1) / kDraws;
+  hipEvent_t start, stop;
+  CHECK(hipEventCreate(&start));
+  CHECK(hipEventCreate(&stop));
+  float best = 1e30f;
+  for (int repeat = 0; repeat < 5; ++repeat) {
+    CHECK(hipEventRecord(start));
+    hipLaunchKernelGGL(contract_i8, dim3(groups * kParts), dim3(512), lds_bytes, 0, args);
+    CHECK(hipEventRecord(stop));
+    CHECK(hipEventSynchronize(stop));
+    CHECK(hipGetLastError());
+    float ms = 0.0f;
+    CHECK(hipEventElapsedTime(&ms, start, stop));
+    best = std::min(best, ms);
+    printf("launch %d: %.3f ms\n", repeat, ms);
+  }
+  const double flop = 2.0 * kRows * (double)kPairs * n_draws;
+  printf("%d draws: %.3f ms = %.1f TFLOP/s float64-equivalent (x%.2f the 78.6 TFLOP/s float64 matrix "
+         "peak; the product's float64 quadratic form: 4.4 - 4.6 ms per 10^4 draws)\n",
+         n_draws, best, flop / best * 1e-9, flop / best * 1e-9 / 78.6);
+  // accuracy on a sample of draws against float64 on the host
+  std::vector<double> partial(partial_doubles);
+  CHECK(hipMemcpy(partial.data(), d_partial, partial_doubles * 8, hipMemcpyDeviceToHost));
+  double worst_scaled = 0.0, worst_element = 0.0;
+  const int sample[6] = {0, 1, 17, 31, n_draws / 2, n_draws - 1};
+  for (int d : sample) {
+    std::vector<double> exact(kRows, 0.0), weight(kPairs);
+    for (int p = 0; p < kPairs; ++p)
+      weight[p] = densities[(size_t)(pairs[p] & 0xffffu) * ld + d] * densities[(size_t)(pairs[p] >> 16) * ld + d];
+    double largest = 0.0;
+    for (int r = 0; r < kRows; ++r) {
+      long double sum = 0.0L;
+      for (int p = 0; p < kPairs; ++p) sum += (long double)table[(size_t)r * kBlocks * kBlock + p] * weight[p];
+      exact[r] = (double)sum;
+      largest = std::max(largest, std::fabs(exact[r]));
+    }
+    for (int r = 0; r < kRows; ++r) {
+      double got = 0.0;
+      for (int q = 0; q < kParts; ++q) got += partial[((size_t)q * n_draws + d) * (kRowTiles * 16) + r];
+      worst_scaled = std::max(worst_scaled, std::fabs(got - exact[r]) / largest);
+      worst_element = std::max(worst_element, std::fabs(got - exact[r]) / std::fabs(exact[r]));
+    }
+  }
+  printf("against float64 (six draws, all rows): error / largest |xi| of the draw %.1e, largest "
+         "elementwise relative error %.1e\n", worst_scaled, worst_element);
+  return 0;
+}
