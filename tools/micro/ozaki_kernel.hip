@@ -11,10 +11,10 @@
 // one double (Horner in 2^-7) times 2^(eT + eW - 14).  The table is float32-exact
 // (tabcorr.py:335 stores it as float32), so six slices hold it with room for the spread of
 // magnitudes inside a block.
-// Work item = 16 draws x a quarter of the blocks; eight waves = eight groups of six row tiles;
-// the weights of the next block are cut (two draws per wave) while this one is consumed, one
-// barrier per block.  (32 draws x 12 row tiles per wave: 96 registers of sums next to the
-// operands of two steps -- spills; 3.5 ms.)
+// Work item = 32 draws x a quarter of the blocks; eight waves = eight groups of six row tiles,
+// every wave feeds BOTH draw tiles from one load of the table slices (one tile of 16 draws per
+// load needs 73 bytes per clock and CU at the full integer rate: 3.43 ms); the weights of the
+// next block are cut (four draws per wave) while this one is consumed, one barrier per block.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -43,7 +43,7 @@ constexpr int kRows = 760;
 constexpr int kRowTiles = 48;                             // 768 rows
 constexpr int kSlices = 6;
 constexpr int kParts = 4;                                 // K parts per group of draws
-constexpr int kDraws = 16;                                // draws per workgroup
+constexpr int kDraws = 32;                                // draws per workgroup
 constexpr int kTilesPerWave = 6;
 
 struct Args {
@@ -60,8 +60,8 @@ struct Args {
 __global__ __launch_bounds__(512) void contract_i8(Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   double* dens = (double*)lds;                                      // (bin, 32)
-  i32x4* wbuf = (i32x4*)(lds + kBins * kDraws * 8);                 // (2, slices, 4, 64)
-  int* wexp = (int*)(lds + kBins * kDraws * 8 + 2 * kSlices * 4 * 64 * 16);       // (2, 16)
+  i32x4* wbuf = (i32x4*)(lds + kBins * kDraws * 8);                 // (2, 2, slices, 4, 64)
+  int* wexp = (int*)(lds + kBins * kDraws * 8 + 2 * 2 * kSlices * 4 * 64 * 16);   // (2, 32)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int group = blockIdx.x / kParts, part = blockIdx.x % kParts;
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(512) void contract_i8(Args a) {
     const uint4 four = ((const uint4*)(a.pairs + (size_t)b * kBlock))[lane];
     const unsigned ij[4] = {four.x, four.y, four.z, four.w};
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int d = wave * 2 + u;
+    for (int u = 0; u < 4; ++u) {
+      const int d = wave * 4 + u;
       double w[4], top = 0.0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(512) void contract_i8(Args a) {
       // lane l holds pairs 4 l .. 4 l + 3 of the block: K step l / 16, bytes 4 (l % 4) .. of the
       // 16-byte operand of lane (l % 16) / 4 * 16 + draw
       const int ks = lane >> 4, target = ((lane & 15) >> 2) * 16 + (d & 15);
-      int* word = (int*)(wbuf + ((buf * kSlices) * 4 + ks) * 64 + target) + (lane & 3);
+      int* word = (int*)(wbuf + (((buf * 2 + (d >> 4)) * kSlices) * 4 + ks) * 64 + target) + (lane & 3);
 #pragma unroll
       for (int s = 0; s < kSlices; ++s) {
         int packed = 0;
@@ -111,36 +111,32 @@ __global__ __launch_bounds__(512) void contract_i8(Args a) {
         }
         word[(size_t)s * 4 * 64 * 4] = packed;
       }
-      if (lane == 0) wexp[buf * 16 + d] = exponent;
+      if (lane == 0) wexp[buf * 32 + d] = exponent;
     }
   };
 
   const int rg = wave;
-  double total[kTilesPerWave][4];
+  double total[2][kTilesPerWave][4];
 #pragma unroll
-  for (int rt = 0; rt < kTilesPerWave; ++rt)
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) total[rt][v] = 0.0;
+    for (int rt = 0; rt < kTilesPerWave; ++rt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) total[t][rt][v] = 0.0;
 
   cut(b_begin, b_begin & 1);
   __syncthreads();
   for (int b = b_begin; b < b_end; ++b) {
     const int buf = b & 1;
     if (b + 1 < b_end && !(a.skip & 1)) cut(b + 1, buf ^ 1);
-    const int e_w = wexp[buf * 16 + (lane & 15)];
-    const i32x4* b_base = wbuf + (buf * kSlices) * 4 * 64 + lane;
-    // 48 steps (row tile, K step), the operands of the next step requested before this
-    // step's matrix instructions
+    const int e_w[2] = {wexp[buf * 32 + (lane & 15)], wexp[buf * 32 + 16 + (lane & 15)]};
+    const i32x4* b_base = wbuf + (buf * 2 * kSlices) * 4 * 64 + lane;
+    // 24 steps (row tile, K step): the table slices of the next step requested before this
+    // step's matrix instructions, the weight slices of both draw tiles from the LDS
     const i32x4* a_block = a.table_slices +
         ((size_t)(b * kRowTiles + rg * kTilesPerWave) * kSlices) * 4 * 64 + lane;
     const int* e_block = a.table_exponents + ((size_t)b * kRowTiles + rg * kTilesPerWave) * 4 + (lane >> 4);
-    // (the block's weights stay in registers for all row tiles of the wave: read from the LDS
-    // step by step they put an LDS latency in front of every 21 matrix instructions)
-    i32x4 ta[2][kSlices], wb[4][kSlices];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int s = 0; s < kSlices; ++s) wb[ks][s] = b_base[(s * 4 + ks) * 64];
+    i32x4 ta[2][kSlices];
     int e_t4[2] = {0, 0};
     auto request = [&](int step, int slot) {
       const int rt = step >> 2, ks = step & 3;
@@ -150,42 +146,51 @@ __global__ __launch_bounds__(512) void contract_i8(Args a) {
       if (ks == 0) e_t4[(step >> 2) & 1] = e_block[rt * 4];
     };
     request(0, 0);
-    i32x4 acc[kSlices];
+    i32x4 acc[2][kSlices];
 #pragma unroll
     for (int step = 0; step < 4 * kTilesPerWave; ++step) {
       const int rt = step >> 2, ks = step & 3, slot = step & 1;
       if (step + 1 < 4 * kTilesPerWave) request(step + 1, slot ^ 1);
-      if (ks == 0) {
 #pragma unroll
-        for (int d = 0; d < kSlices; ++d) acc[d] = i32x4{0, 0, 0, 0};
-      }
+      for (int t = 0; t < 2; ++t) {
+        i32x4 wb[kSlices];
 #pragma unroll
-      for (int d = 0; d < kSlices; ++d)
+        for (int s = 0; s < kSlices; ++s) wb[s] = b_base[((t * kSlices + s) * 4 + ks) * 64];
+        if (ks == 0) {
 #pragma unroll
-        for (int i = 0; i <= d; ++i)
-          acc[d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ta[slot][i], wb[ks][d - i], acc[d], 0, 0, 0);
-      if (ks == 3 && !(a.skip & 4)) {
-        const int word = e_t4[rt & 1];
+          for (int d = 0; d < kSlices; ++d) acc[t][d] = i32x4{0, 0, 0, 0};
+        }
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          double sum = (double)acc[kSlices - 1][v];
+        for (int d = 0; d < kSlices; ++d)
 #pragma unroll
-          for (int d = kSlices - 2; d >= 0; --d) sum = fma(sum, 0.0078125, (double)acc[d][v]);
-          const int e_t = (int)(signed char)((word >> (8 * v)) & 0xff);
-          total[rt][v] += ldexp(sum, e_t + e_w - 14);
+          for (int i = 0; i <= d; ++i)
+            acc[t][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ta[slot][i], wb[d - i], acc[t][d], 0, 0, 0);
+        if (ks == 3 && !(a.skip & 4)) {
+          const int word = e_t4[rt & 1];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            double sum = (double)acc[t][kSlices - 1][v];
+#pragma unroll
+            for (int d = kSlices - 2; d >= 0; --d) sum = fma(sum, 0.0078125, (double)acc[t][d][v]);
+            const int e_t = (int)(signed char)((word >> (8 * v)) & 0xff);
+            total[t][rt][v] += ldexp(sum, e_t + e_w[t] - 14);
+          }
         }
       }
     }
     __syncthreads();
   }
-  const int draw = draw0 + (lane & 15);
-  if (draw < a.n_draws) {
 #pragma unroll
-    for (int rt = 0; rt < kTilesPerWave; ++rt) {
-      const int row = (rg * kTilesPerWave + rt) * 16 + 4 * (lane >> 4);
-      double* out = a.partial + ((size_t)part * a.n_draws + draw) * (kRowTiles * 16) + row;
+  for (int t = 0; t < 2; ++t) {
+    const int draw = draw0 + t * 16 + (lane & 15);
+    if (draw < a.n_draws) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) out[v] = total[rt][v];
+      for (int rt = 0; rt < kTilesPerWave; ++rt) {
+        const int row = (rg * kTilesPerWave + rt) * 16 + 4 * (lane >> 4);
+        double* out = a.partial + ((size_t)part * a.n_draws + draw) * (kRowTiles * 16) + row;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) out[v] = total[t][rt][v];
+      }
     }
   }
 }
@@ -259,7 +264,7 @@ int main(int argc, char** argv) {
   args.partial = (double*)d_partial;
   args.n_draws = n_draws;
   args.skip = skip;
-  const size_t lds_bytes = (size_t)kBins * kDraws * 8 + 2 * kSlices * 4 * 64 * 16 + 2 * 16 * 4;
+  const size_t lds_bytes = (size_t)kBins * kDraws * 8 + 2 * 2 * kSlices * 4 * 64 * 16 + 2 * 32 * 4;
   CHECK(hipFuncSetAttribute((const void*)contract_i8, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_bytes));
   const int groups = (n_draws + kDraws - 1) / kDraws;
