@@ -92,9 +92,10 @@ int tc_debug_wave_trace(tc_table* table, uint64_t* out, int64_t capacity,
 /* Resident un-batched path (option "resident"): per workgroup the 100 MHz ticks the last call
  * took from the sight of its parameters to the store of its completion word. */
 int tc_debug_resident_ticks(tc_table* table, uint64_t* out, int64_t capacity, int64_t* n_blocks);
-/* Resident ensemble kernel: eight 100 MHz stamps of workgroup 0 in the last call (call seen,
- * occupation stored, the group's occupations seen, densities in LDS, quarters summed, partial
- * sums stored, the slices' partial sums seen, finished), then three host times of that call in
+/* Resident ensemble kernel: eight words of workgroup 0 in the last call (developer builds;
+ * 100 MHz stamps: call seen, occupation stored, the group's occupations seen, densities in LDS,
+ * quarters summed, partial sums stored; [6] shader cycles of the quarter sums; [7] finished),
+ * then three host times of that call in
  * ns from its begin (published, every completion word seen, results combined): 11 words. */
 int tc_debug_ensemble_stamps(tc_table* table, uint64_t* out);
 #ifdef __cplusplus

@@ -3156,15 +3156,17 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
     return __builtin_amdgcn_s_memrealtime() - since > a.call_ticks;
   };
   // (diagnosis, tools/r04_ensemble.py: 100 MHz stamps of workgroup 0 in page-locked memory)
+  // (developer builds only: a store to host memory in front of a phase's `s_waitcnt vmcnt(0)`
+  // makes workgroup 0 -- walker 0, reducer of row 0 -- wait for the link: 2 us per call)
   auto stamp = [&](int which, unsigned long long value) {
+#ifdef TC_DEVELOPER_KNOBS
     if (b == 0 && tid == 0)
       __hip_atomic_store(a.exited + gridDim.x + which, value, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
-  };
-  auto stamp_any = [&](int which, unsigned long long value) {
-    if (b == 0 && lane == 0)
-      __hip_atomic_store(a.exited + gridDim.x + which, value, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    (void)which;
+    (void)value;
+#endif
   };
 
   for (;;) {
@@ -3353,78 +3355,99 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
       }
       __syncthreads();
       stamp(3, __builtin_amdgcn_s_memrealtime());
+      const unsigned long long cycles_begin = __builtin_amdgcn_s_memtime();
 
-      // waves = 2 shares of a quarter's positions x 4 groups of 8 rows (the rows beyond rt
-      // are zeros in t_lds)
-      // (ps and the rows as per-lane values: with wave-uniform ones the compiler moves the
+      // Waves = 2 x 4 groups of 8 rows (the rows beyond rt are zeros in t_lds).  A quarter is
+      // ALWAYS summed as (its even positions) + (its odd positions), each half in position
+      // order: with one quarter per workgroup the two waves of a row group take a half each
+      // and meet through the LDS; with two or four quarters a wave sums whole quarters (both
+      // halves, two accumulators) -- one exchange per call instead of one per quarter.
+      // (sel and the rows as per-lane values: with wave-uniform ones the compiler moves the
       // positions' bins into scalar registers one LDS read, one wait and one branch at a time)
-      const int ps = (tid >> 6) & 1, row0 = (tid >> 7) * 8;
+      const int sel = (tid >> 6) & 1, row0 = (tid >> 7) * 8;
       const bool rows_used = (wave >> 1) * 8 < rt;
-      double total[8], hold[8];
+      // (one instance of the inner code, real loops: unrolled over 16 guarded positions and
+      // inlined five times the phase was 7000 instructions, more than the instruction cache
+      // holds, with a spilled scalar condition per position: 4100 cycles per half)
+      auto quarter_sum = [&](int base, int parity_begin, int parity_end, double (&out)[8]) {
+#pragma unroll 1
+        for (int parity = parity_begin; parity < parity_end; ++parity) {
+          double acc[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) total[k] = hold[k] = 0.0;
-      for (int qi = 0; qi < q_count; ++qi) {
-        const int base = (q_first + qi) * pq;
-        double acc[8];
+          for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+          const int n_half = (pq - parity + 1) >> 1;
+#pragma unroll 1
+          for (int u0 = 0; u0 < n_half; u0 += 4) {
+            int p[4];
+            unsigned bins[4];
+            double w[4];
+            // (a slot beyond the quarter: w = 0 times a finite row of the first position)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = 0.0;
-        if (rows_used && !(a.skip & 2)) {
-          // the wave's positions of this quarter (at most 16: launch.hip, ensemble_layout):
-          // their bins first, then the products of the densities, then the rows
-          double w[16];
-          unsigned bins[16];
-          // (2 * u < pq: wave-uniform, what lies beyond costs nothing)
+            for (int u = 0; u < 4; ++u) {
+              const int at = base + parity + 2 * (u0 + u);
+              p[u] = at < base + pq ? at : base;
+              bins[u] = at < base + pq ? ij_lds[p[u]] : 0xffffffffu;
+            }
+            // (the rows of all four positions requested before anything waits for them: left
+            // to itself the compiler reads two values, waits, multiplies, reads the next two)
+            double t[4][8];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) {
-            const int p = base + ps + 2 * u;
-            bins[u] = 0xffffffffu;
-            if (2 * u < pq) bins[u] = p < base + pq ? ij_lds[p] : 0xffffffffu;
-          }
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int u = 0; u < 16; ++u) {
-            w[u] = 0.0;
-            if (2 * u < pq) {
+              for (int k = 0; k < 8; ++k) t[u][k] = t_lds[p[u] * 32 + row0 + k];
+            double first[4], second[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
               const bool valid = bins[u] != 0xffffffffu;
               const unsigned bi = valid ? bins[u] & 0xffffu : 0u, bj = valid ? bins[u] >> 16 : 0u;
-              double value = dens_lds[bj * kEnsembleDensPad + lane];
-              if (a.mode == 0) value *= dens_lds[bi * kEnsembleDensPad + lane];
-              w[u] = valid ? value : 0.0;
+              first[u] = dens_lds[bj * kEnsembleDensPad + lane];
+              second[u] = a.mode == 0 ? dens_lds[bi * kEnsembleDensPad + lane] : 1.0;
             }
-          }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-          for (int u = 0; u < 16; ++u) {
-            // (a position beyond the quarter: w = 0 times a finite row of the first position)
-            const int p = base + ps + 2 * u < base + pq ? base + ps + 2 * u : base;
-            if (2 * u < pq) {
-#pragma unroll
-              for (int k = 0; k < 8; ++k) acc[k] = fma(t_lds[p * 32 + row0 + k], w[u], acc[k]);
+            for (int u = 0; u < 4; ++u) {
+              double value = first[u];
+              if (a.mode == 0) value *= second[u];
+              w[u] = bins[u] != 0xffffffffu ? value : 0.0;
             }
-          }
-          if (ps == 1) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) area[(row0 + k) * 64 + lane] = acc[k];
-          }
-        }
-        __syncthreads();
-        if (ps == 0 && rows_used) {
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const double quarter = acc[k] + area[(row0 + k) * 64 + lane];
-            // the quarters of a slice: (q0 + q1) + (q2 + q3)
-            if ((qi & 1) == 0) hold[k] = quarter;
-            else if (qi == 1) total[k] = hold[k] + quarter;
-            else total[k] = total[k] + (hold[k] + quarter);
+              for (int k = 0; k < 8; ++k) acc[k] = fma(t[u][k], w[u], acc[k]);
           }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) out[k] = parity == parity_begin ? acc[k] : out[k] + acc[k];
         }
-        if (qi + 1 < q_count) __syncthreads();
+      };
+      double mine[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) mine[k] = 0.0;
+      if (rows_used && !(a.skip & 2)) {
+        // one quarter: wave `sel` sums its half; two quarters: wave `sel` sums quarter sel;
+        // four: quarters 2 sel and 2 sel + 1, added at once -- (q0 + q1) and (q2 + q3)
+        const int n_mine = q_count == 1 ? 1 : q_count >> 1;
+#pragma unroll 1
+        for (int j = 0; j < n_mine; ++j) {
+          double quarter[8];
+          const int base = (q_first + (q_count == 1 ? 0 : sel * n_mine) + j) * pq;
+          quarter_sum(base, q_count == 1 ? sel : 0, q_count == 1 ? sel + 1 : 2, quarter);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) mine[k] = j == 0 ? quarter[k] : mine[k] + quarter[k];
+        }
+        if (sel == 1) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) area[(row0 + k) * 64 + lane] = mine[k];
+        }
       }
+      __syncthreads();
       stamp(4, __builtin_amdgcn_s_memrealtime());
-      if (ps == 0) {
+      stamp(6, __builtin_amdgcn_s_memtime() - cycles_begin);    // (shader cycles of the sums)
+      if (sel == 0 && rows_used) {
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           if (row0 + k < rt)
             ens::store_agent(a.partial + ((size_t)b * rt + row0 + k) * 64 + lane,
-                             q_count == 1 ? hold[k] : total[k]);
+                             mine[k] + area[(row0 + k) * 64 + lane]);
       }
       ens::wait_stores();
       __syncthreads();
@@ -3459,7 +3482,6 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
             __builtin_amdgcn_s_sleep(1);
           }
         }
-        if (wave == 7) stamp_any(6, __builtin_amdgcn_s_memrealtime());
         const int n_parts = n_wg == 1 ? 4 : n_wg == 2 ? 2 : 1;
         double part[8][4];
 #pragma unroll

@@ -1218,9 +1218,10 @@ int tc_debug_resident_ticks(tc_table* t, uint64_t* out, int64_t capacity, int64_
   return TC_OK;
 }
 
-// Phase stamps of workgroup 0 in the last call of the resident ensemble kernel (100 MHz ticks:
-// call seen, occupation stored, the group's occupations seen, densities in LDS, quarters summed,
-// partial sums stored, the slices' partial sums seen, call finished), then three host times of
+// Phase stamps of workgroup 0 in the last call of the resident ensemble kernel (developer
+// builds; 100 MHz ticks: call seen, occupation stored, the group's occupations seen, densities
+// in LDS, quarters summed, partial sums stored, [6] shader cycles of the quarter sums, call
+// finished), then three host times of
 // that call in ns from its begin: published, every completion word seen, results combined.
 int tc_debug_ensemble_stamps(tc_table* t, uint64_t* out) {
   TC_CHECK(t != nullptr && out != nullptr, "NULL argument");

@@ -293,9 +293,10 @@ class TabCorr:
         draws in host arrays goes to a second resident kernel (one workgroup
         per CU: the walkers' occupations, slices of the table and the rows of
         the results in three phases that hand their data on through device
-        memory) -- 64 walkers 33 -> 20 us, 256 walkers 45 -> 30 us per call; a
-        walker's result does not depend on the size of the ensemble or its
-        place in it, and equals the batched path's to rounding (1e-14)."""
+        memory) -- 64 walkers 34 -> 25 us, 256 walkers 45 -> 33 us per call on
+        the reference's 60-bin table; a walker's result does not depend on the
+        size of the ensemble or its place in it, and equals the batched path's
+        to rounding (1e-14)."""
         device = self.to_device()
         with device.lock:
             if idle_us is not None:

@@ -9,6 +9,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 WHAT=${1:-all}
+ROUND=${ROUND:-r04}
 OUT=gpurun_out/profile
 mkdir -p $OUT
 FAST="--cpu-seconds 0 --other-configs 0"
@@ -30,6 +31,12 @@ pmc_passes() {   # $1 = output stem, rest = bench arguments
   done
   python3 tools/pmc_summary.py $OUT/pmc_[0-9] > $OUT/${stem}.txt
   rm -rf $OUT/pmc_[0-9] $OUT/pmc_[0-9].log
+  # into profiles/ of THIS copy of the tree as well (as tools/install_profiles.sh will at home):
+  # the bench runs that follow quote `traffic` from these passes, not from last round's
+  local tag=${stem#pmc_summary}
+  (echo "# rocprofv3 --pmc passes (separate runs, --kernel-trace only; tools/profile_round.sh): python3 bench.py $*"
+   echo "# FETCH_SIZE / WRITE_SIZE in KB per launch (FETCH_SIZE under-reports wide coalesced reads 2x on gfx950); other counters raw"
+   grep -v copyBuffer $OUT/${stem}.txt) > profiles/${ROUND}_pmc_counters${tag}.txt
 }
 
 kernel_stats() {   # $1 = output stem, rest = bench arguments
@@ -44,6 +51,9 @@ kernel_stats() {   # $1 = output stem, rest = bench arguments
 }
 
 if [ $WHAT = main ] || [ $WHAT = all ]; then
+  # (default lanes: the profiler serialises the dispatches itself; the timed region then runs
+  # predict_fused_kernel, bench.py's serialised pass the three kernels -- both are counted)
+  pmc_passes pmc_summary --steps 50 --warmup 5 $FAST
   python bench.py > $OUT/bench.json 2> $OUT/bench.err
   echo "default bench done"
   # the driver's own command (short timed region), three times
@@ -57,18 +67,15 @@ if [ $WHAT = main ] || [ $WHAT = all ]; then
   kernel_stats kernel_stats_lanes1 --lanes 1 --steps 2000 --warmup 200 $FAST
   kernel_stats kernel_stats_pipelined --steps 2000 --warmup 200 $FAST
   kernel_stats kernel_stats_fused_alone --lanes 1 --option fused=2 --steps 2000 --warmup 200 $FAST
-  # (default lanes: the profiler serialises the dispatches itself; the timed region then runs
-  # predict_fused_kernel, bench.py's serialised pass the three kernels -- both are counted)
-  pmc_passes pmc_summary --steps 50 --warmup 5 $FAST
 fi
 if [ $WHAT = configs ] || [ $WHAT = all ]; then
   # (TAGS="cfg3 ds4" ... selects; the PMC passes run with the default lanes so that the
   # one-launch forms are what the pipelined calls take -- the profiler serialises the
   # dispatches itself --, and bench.py's own serialised pass adds the three kernels)
   for tag in ${TAGS:-cfg3 cfg4 cfg5f32 cfg5f64 ds4 ds1 wp db}; do
+    PMC_SHORT=1 pmc_passes pmc_summary_${tag} --only-config $tag --cpu-seconds 0
     kernel_stats kernel_stats_${tag}_lanes1 --only-config $tag --lanes 1 --cpu-seconds 0
     kernel_stats kernel_stats_${tag}_pipelined --only-config $tag --cpu-seconds 0
-    PMC_SHORT=1 pmc_passes pmc_summary_${tag} --only-config $tag --cpu-seconds 0
   done
 fi
 ls -la $OUT

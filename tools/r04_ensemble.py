@@ -102,6 +102,6 @@ for name, halotab in (
         print('%-6s %4d walkers: C call %6.1f -> %6.1f us, predict_batch %6.1f -> %6.1f us; '
               'workgroup 0, us after the sight of the call (medians): occupation stored %.1f, '
               'group seen %.1f, densities in LDS %.1f, quarters summed %.1f, partial sums '
-              'stored %.1f, slices seen %.1f, finished %.1f'
-              % (name, n, row[0], row[2], row[1], row[3], *phases), flush=True)
+              'stored %.1f, finished %.1f (developer build; zeros otherwise)'
+              % (name, n, row[0], row[2], row[1], row[3], *phases[:5], phases[6]), flush=True)
     _lib.check(lib.tc_table_set_option(h, b'resident', 0))
