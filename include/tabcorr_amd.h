@@ -344,7 +344,10 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 served the same way by a second resident kernel of one workgroup per CU
  *                 (kernel_args.h: EnsembleArgs): no launch, no copy command, no stream
  *                 synchronisation per call; a draw's result does not depend on the number of
- *                 draws in the call or its place among them.
+ *                 draws in the call or its place among them.  The kernel holds every CU's
+ *                 LDS while it waits: the ensemble kernel of another handle starts when this
+ *                 one has left (its idle time), so alternate between handles with a short
+ *                 "resident_idle_us" or keep the option to the one table of the sampler.
  *   "resident_aperture"  1 (default): on large-BAR systems the mailbox of the resident
  *                 ensemble kernel lies in device memory that the host stores into through
  *                 the PCIe aperture (no PCIe reads while the kernel polls); 0: in page-locked
