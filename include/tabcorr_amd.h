@@ -344,7 +344,10 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 served the same way by a second resident kernel of one workgroup per CU
  *                 (kernel_args.h: EnsembleArgs): no launch, no copy command, no stream
  *                 synchronisation per call; a draw's result does not depend on the number of
- *                 draws in the call or its place among them.  The kernel holds every CU's
+ *                 draws in the call or its place among them.  When its workgroups do not
+ *                 all find a place on the chip (other work running) the launched path serves
+ *                 the call -- after three such calls all of them, until the option is set
+ *                 again.  The kernel holds every CU's
  *                 LDS while it waits: the ensemble kernel of another handle starts when this
  *                 one has left (its idle time), so alternate between handles with a short
  *                 "resident_idle_us" or keep the option to the one table of the sampler.

@@ -1966,7 +1966,7 @@ bool ensemble_layout(const tc_table* t, int n_gauss, EnsembleLayout* out) {
 
 bool ensemble_eligible(const tc_table* t, int64_t n_walkers, int n_gauss, unsigned flags) {
   EnsembleLayout l;
-  return n_walkers >= 2 && n_walkers <= tc::kEnsembleMaxWalkers &&
+  return !t->resident.ens_disabled && n_walkers >= 2 && n_walkers <= tc::kEnsembleMaxWalkers &&
          single_draw_eligible(t, 1, n_gauss, flags) && ensemble_layout(t, n_gauss, &l);
 }
 
@@ -2029,7 +2029,7 @@ int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walker
     return (unsigned long long)ts.tv_sec * 1000000000ull + (unsigned long long)ts.tv_nsec;
   };
   const unsigned long long host_begin = now_ns();
-  for (int attempt = 0; attempt < 4; ++attempt) {
+  for (int attempt = 0; attempt < 2; ++attempt) {
     // the parameters (8 doubles per walker), then the header (call number << 10 | walkers): a
     // workgroup reads its parameters only after the header has been seen
     {
@@ -2160,6 +2160,7 @@ int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walker
     r.ens_host_ns[1] = now_ns() - host_begin;       // (every row seen and combined)
     if (!left) {
       r.ens_host_ns[2] = r.ens_host_ns[1];
+      r.ens_failures = 0;
       return TC_OK;
     }
     // a workgroup has left (idle, life time or a wait that ran out): all of them out, then a
@@ -2167,7 +2168,10 @@ int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walker
     status = resident_stop(t);
     if (status != TC_OK) return status;
   }
-  return fail(TC_ERR_HIP, "the resident ensemble kernel keeps leaving before it answers");
+  // (its workgroups do not all find a place -- the chip is shared with other work: the launched
+  // path serves this call, and after three such calls every call until the option is set again)
+  if (++r.ens_failures >= 3) r.ens_disabled = true;
+  return TC_ERR_UNSUPPORTED;
 }
 
 // The same for every table of an interpolator in one launch (interp.cpp fills the per-class

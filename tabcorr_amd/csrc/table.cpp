@@ -423,8 +423,10 @@ int tc_predict_zheng07_many(tc_table* t, const double* theta, int n_theta, int n
   TC_HIP(hipSetDevice(t->device));
   if (n_walkers == 1 && t->resident.enabled && resident_eligible(t, n_gauss))
     return resident_predict(t, theta, n_theta, n_gauss, flags, ngal, xi);
-  if (t->resident.enabled && ensemble_eligible(t, n_walkers, n_gauss, flags))
-    return ensemble_predict(t, theta, n_theta, n_walkers, n_gauss, flags, ngal, xi);
+  if (t->resident.enabled && ensemble_eligible(t, n_walkers, n_gauss, flags)) {
+    status = ensemble_predict(t, theta, n_theta, n_walkers, n_gauss, flags, ngal, xi);
+    if (status != TC_ERR_UNSUPPORTED) return status;     // (else: the launched path below)
+  }
   if (t->resident.running && (status = resident_stop(t)) != TC_OK) return status;
   status = launch_single_draw(t, theta, n_theta, n_walkers, n_gauss, flags, &t->single_ws,
                               t->stream);
@@ -456,8 +458,10 @@ int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
   // calls and two copy-engine round trips less (1 draw 45 -> 40 us, 1000 draws 72 -> 54 us;
   // beyond ~1 MB the copy engines win).
   if (t->resident.enabled && ensemble_eligible(t, n_draws, n_gauss, flags)) {
-    // an ensemble of up to 256 walkers with option "resident": no launch at all
-    return ensemble_predict(t, theta, n_theta, (int)n_draws, n_gauss, flags, ngal, xi);
+    // an ensemble of up to 256 walkers with option "resident": no launch at all (unless its
+    // workgroups do not all find a place on the chip: the launched path below)
+    status = ensemble_predict(t, theta, n_theta, (int)n_draws, n_gauss, flags, ngal, xi);
+    if (status != TC_ERR_UNSUPPORTED) return status;
   }
   if (n_draws <= many_walkers_limit() && single_draw_eligible(t, 1, n_gauss, flags)) {
     // one draw -- or a handful (an ensemble sampler's proposals): ONE launch, the device-side
@@ -1083,6 +1087,8 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     // of call on this handle.  0 (default): one launch per call.
     TC_CHECK(value == 0 || value == 1, "resident must be 0 or 1");
     t->resident.enabled = value;
+    t->resident.ens_disabled = false;
+    t->resident.ens_failures = 0;
     if (value == 0) return resident_stop(t);
   } else if (key == "resident_poll_waves") {
     TC_CHECK(value >= 1 && value <= 4, "resident_poll_waves must be in [1, 4]");
