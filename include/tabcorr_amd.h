@@ -351,6 +351,8 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 LDS while it waits: the ensemble kernel of another handle starts when this
  *                 one has left (its idle time), so alternate between handles with a short
  *                 "resident_idle_us" or keep the option to the one table of the sampler.
+ *   "resident_wait_us"  how long a workgroup of the resident ensemble kernel waits for another
+ *                 one inside a call before it gives up (default 20 000, 1 .. 10^6).
  *   "resident_aperture"  1 (default): on large-BAR systems the mailbox of the resident
  *                 ensemble kernel lies in device memory that the host stores into through
  *                 the PCIe aperture (no PCIe reads while the kernel polls); 0: in page-locked

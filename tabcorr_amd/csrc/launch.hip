@@ -2082,7 +2082,7 @@ int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walker
       ea.launch_id = ++r.launch_id;
       ea.idle_ticks = (unsigned long long)std::max(1, r.idle_us) * 100ull;   // 100 MHz
       ea.life_ticks = 1000000000ull;                                          // 10 s
-      ea.call_ticks = 2000000ull;                                             // 20 ms
+      ea.call_ticks = (unsigned long long)std::max(1, r.wait_us) * 100ull;
       ea.lds_area = l.lds_area;
       ea.lds_dens = l.lds_dens;
       ea.lds_t = l.lds_t;

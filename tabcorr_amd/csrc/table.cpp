@@ -1018,6 +1018,13 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
       return TC_OK;
     }
     return autotune(t, (unsigned)value);
+  } else if (key == "resident_wait_us") {
+    // how long a workgroup of the resident ensemble kernel waits for another one inside a call
+    // before it gives up (default 20 000; tests use 1 to exercise that path)
+    TC_CHECK(value >= 1 && value <= 1000000, "resident_wait_us must be in [1, 1000000]");
+    const int status = resident_stop(t);
+    if (status != TC_OK) return status;
+    t->resident.wait_us = value;
   } else if (key == "resident_aperture") {
     // 1 (default): the resident ensemble kernel's mailbox lies in device memory (large-BAR
     // systems; the host writes it through the PCIe aperture); 0: in page-locked host memory

@@ -548,3 +548,31 @@ def test_resident_kernel_serves_ensembles(aperture):
     halotab.set_resident(False)
     ngal, xi = halotab.predict_batch(theta[:50])
     assert_rel(xi, plain[1][:50], 1e-15)
+
+
+def test_resident_ensemble_kernel_gives_up_cleanly():
+    """Workgroups of the resident ensemble kernel that wait in vain (here: a wait limit of 1 us)
+    leave and say so; the launched path serves the call, after three such calls all of them,
+    and setting the option again brings the kernel back."""
+    from tabcorr_amd import synthetic, _lib
+    lib = _lib.load()
+    table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    theta = synthetic.zheng07_draws(200, seed=5)
+    halotab = make_tabcorr(table)
+    handle = halotab.to_device().handle
+    plain = halotab.predict_batch(theta)
+    halotab.set_resident(True)
+    served = halotab.predict_batch(theta)
+    assert_rel(served[1], plain[1], 1e-12)
+    _lib.check(lib.tc_table_set_option(handle, b'resident_wait_us', 1))
+    for n in (200, 64, 130, 7, 200):
+        ngal, xi = halotab.predict_batch(theta[:n])
+        # (served by the launched path, or -- when every wait happened to be over in time --
+        # by the kernel)
+        assert_rel(xi, plain[1][:n], 1e-12)
+        assert_rel(ngal, plain[0][:n], 1e-12)
+    _lib.check(lib.tc_table_set_option(handle, b'resident_wait_us', 20000))
+    halotab.set_resident(True)
+    ngal, xi = halotab.predict_batch(theta)
+    assert np.array_equal(xi, served[1])
+    halotab.set_resident(False)
