@@ -41,7 +41,10 @@ constexpr int kBlock = 256;
 constexpr int kBlocks = (kPairs + kBlock - 1) / kBlock;   // 79
 constexpr int kRows = 760;
 constexpr int kRowTiles = 48;                             // 768 rows
-constexpr int kSlices = 6;
+#ifndef SLICES
+#define SLICES 6
+#endif
+constexpr int kSlices = SLICES;      // (-DSLICES=3: float32 tolerance, 6 products)
 constexpr int kParts = 4;                                 // K parts per group of draws
 constexpr int kDraws = 32;                                // draws per workgroup
 constexpr int kTilesPerWave = 6;
