@@ -508,6 +508,8 @@ struct tc_table {
     unsigned long long launch_id = 0;
     hipStream_t stream = nullptr;
     tc::host::PinnedBuffer mailbox;
+    tc::host::DeviceBuffer single_aperture;   // the seven entries in device memory (large BAR)
+    bool single_aperture_decided = false;
     tc::host::SingleWorkspace ws;
     int n_theta = 0, n_gauss = 0, blocks = 0;
     unsigned flags = 0;

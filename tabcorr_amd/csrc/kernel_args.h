@@ -168,8 +168,9 @@ constexpr int kResidentBusyOffset = 64;   // exited[64 + workgroup]: ticks the l
 // through a word in device memory.  (First version: every workgroup polled a line of its own
 // in host memory -- 256 pollers keep the link so busy that a call took 22 - 38 us.)
 // Every wait is bounded: idle_ticks / life_ticks
-// as for the single draw, call_ticks for a wait inside a call; a workgroup that gives up sets
-// exited[b] = launch_id and the host serves the call another way.
+// as for the single draw, call_ticks (or the host's stop) for a wait inside a call; a workgroup
+// that leaves sets exited[b] = launch_id << 40 | the call it would have served next, and when
+// that is the current one or an earlier one the host serves the call another way.
 struct EnsembleArgs {
   int n_theta;
   int n_bins;

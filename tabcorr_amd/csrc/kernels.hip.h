@@ -3151,8 +3151,22 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
   unsigned long long serving = a.epoch;
   const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
   unsigned long long t_last = t_begin;
-  // (a wait inside a call is over when its time is up)
+  // (a wait inside a call is over when its time is up or the host says stop -- it does when it
+  // has seen a workgroup leave that this call needed; workgroup 0 passes the word on where the
+  // others cannot see the header)
+  const unsigned long long* source = b == 0 || a.direct ? a.mailbox : a.callword;
+  unsigned waited = 0;       // (the stop word every 16th look: a look costs a trip to memory)
   auto timed_out = [&](unsigned long long since) {
+    if ((++waited & 15u) == 0) {
+      unsigned long long word;
+      asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                   : "=v"(word) : "v"(source) : "memory");
+      if (word == kResidentStop) {
+        if (b == 0 && !a.direct)
+          __hip_atomic_store(a.callword, kResidentStop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+      }
+    }
     return __builtin_amdgcn_s_memrealtime() - since > a.call_ticks;
   };
   // (diagnosis, tools/r04_ensemble.py: 100 MHz stamps of workgroup 0 in page-locked memory)
@@ -3179,7 +3193,6 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
     // when a workgroup asks for them.  The header is written behind the parameters.
     if (wave == 0) {
       // (the header and the forwarded word: number of the call << 10 | walkers)
-      const unsigned long long* source = b == 0 || a.direct ? a.mailbox : a.callword;
       int leave = -1, walkers = 0;
       unsigned long long epoch = 0, now = 0;
       for (;;) {
@@ -3534,9 +3547,12 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
     t_last = __builtin_amdgcn_s_memrealtime();
     stamp(7, t_last);
   }
+  // (with the number of the first call this workgroup has NOT served: one that leaves -- idle --
+  // behind its part of a call that slower workgroups are still working on has not failed it)
   if (tid == 0) {
     __threadfence_system();
-    __hip_atomic_store(a.exited + b, a.launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(a.exited + b, (a.launch_id << 40) | serving, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

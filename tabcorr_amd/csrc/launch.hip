@@ -1835,9 +1835,12 @@ int resident_stop(tc_table* t) {
     __atomic_store_n(header, tc::kResidentStop, __ATOMIC_RELEASE);
     _mm_sfence();
   } else {
+    unsigned long long* entries = r.single_aperture.ptr != nullptr
+                                      ? (unsigned long long*)r.single_aperture.ptr
+                                      : (unsigned long long*)r.mailbox.ptr;
     for (int i = 0; i < 7; ++i)
-      __atomic_store_n((unsigned long long*)r.mailbox.ptr + 2 * i + 1, tc::kResidentStop,
-                       __ATOMIC_RELEASE);
+      __atomic_store_n(entries + 2 * i + 1, tc::kResidentStop, __ATOMIC_RELEASE);
+    _mm_sfence();
   }
   r.running = false;
   r.ensemble = false;
@@ -1871,15 +1874,39 @@ int resident_predict(tc_table* t, const double* theta, int n_theta, int n_gauss,
     if (status != TC_OK) return status;
     memset(r.mailbox.ptr, 0, r.mailbox.bytes);
   }
+  if (!r.single_aperture_decided) {
+    // On a large-BAR system the seven entries live in device memory that the host stores into
+    // through the PCIe aperture (tools/micro/bar_write.hip): the polling wave reads local
+    // memory instead of crossing the link.  The exited words stay in page-locked memory.
+    int large_bar = 0;
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, t->device) != hipSuccess) {
+      (void)hipGetLastError();
+      large_bar = 0;
+    }
+    if (large_bar && t->tuning.resident_aperture) {
+      status = r.single_aperture.reserve(256, r.stream);
+      if (status != TC_OK) return status;
+      TC_HIP(hipMemset(r.single_aperture.ptr, 0, r.single_aperture.bytes));
+      TC_HIP(hipDeviceSynchronize());
+    } else {
+      r.single_aperture.release();
+    }
+    r.single_aperture_decided = true;
+  }
   status = r.ws.prepare(1, blocks, t->rt, 0);       // (a new call number: r.ws.epoch)
   if (status != TC_OK) return status;
   unsigned long long* mailbox = (unsigned long long*)r.mailbox.ptr;
+  const bool direct = r.single_aperture.ptr != nullptr;
+  unsigned long long* entries = direct ? (unsigned long long*)r.single_aperture.ptr : mailbox;
   for (int attempt = 0; attempt < 4; ++attempt) {
-    publish(mailbox, theta, n_theta, r.ws.epoch);
+    // (the aperture is write-combining memory: an entry's two words share a line and leave in
+    // program order, the fence sends them off at once)
+    publish(entries, theta, n_theta, r.ws.epoch);
+    if (direct) _mm_sfence();
     if (!r.running) {
       tc::SingleArgs sa{};
       fill_single_args(t, q, theta, n_theta, n_gauss, flags, blocks, r.ws, &sa);
-      sa.mailbox = mailbox;
+      sa.mailbox = entries;
       sa.exited = mailbox + kMailboxEntryWords;
       sa.launch_id = ++r.launch_id;
       sa.idle_ticks = (unsigned long long)std::max(1, r.idle_us) * 100ull;   // 100 MHz
@@ -2126,8 +2153,11 @@ int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walker
           while (*word != epoch) {
             __builtin_ia32_pause();
             if ((++spins & 0x3ff) != 0) continue;
-            for (int other = 0; other < l.grid; ++other)
-              if (exited[other] == r.launch_id) left = true;
+            // (a workgroup that has left says which call it would have served next)
+            for (int other = 0; other < l.grid; ++other) {
+              const unsigned long long word = exited[other];
+              if ((word >> 40) == r.launch_id && (word & ((1ull << 40) - 1)) <= epoch) left = true;
+            }
             if (left) break;
             timespec now{};
             clock_gettime(CLOCK_MONOTONIC, &now);

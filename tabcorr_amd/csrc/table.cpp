@@ -235,6 +235,7 @@ int tc_table_destroy(tc_table* t) {
   t->resident.ens_out.release();
   t->resident.ens_device.release();
   t->resident.ens_aperture.release();
+  t->resident.single_aperture.release();
   t->resident.ws.buffer.release();
   for (tc_table::Lane& lane : t->lanes)
     if (lane.stream) (void)hipStreamSynchronize(lane.stream);
@@ -1033,6 +1034,7 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     if (status != TC_OK) return status;
     t->tuning.resident_aperture = value;
     t->resident.ens_grid = 0;          // (the buffers are chosen again at the next call)
+    t->resident.single_aperture_decided = false;
   } else if (key == "cross_min_draws") {
     TC_CHECK(value >= 1, "cross_min_draws must be positive");
     t->tuning.cross_min_draws = value;
