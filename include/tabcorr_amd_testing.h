@@ -96,7 +96,7 @@ int tc_debug_resident_ticks(tc_table* table, uint64_t* out, int64_t capacity, in
  * 100 MHz stamps: call seen, occupation stored, the group's occupations seen, densities in LDS,
  * quarters summed, partial sums stored; [6] shader cycles of the quarter sums; [7] finished),
  * then three host times of that call in
- * ns from its begin (published, every completion word seen, results combined): 11 words. */
+ * ns (published, every row combined -- from its begin --, time spent on the rows): 11 words. */
 int tc_debug_ensemble_stamps(tc_table* table, uint64_t* out);
 #ifdef __cplusplus
 }

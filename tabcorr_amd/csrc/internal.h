@@ -522,7 +522,7 @@ struct tc_table {
     tc::host::PinnedBuffer ens_mailbox, ens_out;
     tc::host::DeviceBuffer ens_device;
     tc::host::DeviceBuffer ens_aperture;    // the mailbox in device memory (large BAR), or none
-    unsigned long long ens_host_ns[3] = {0, 0, 0};   // last call: published, answered, combined
+    unsigned long long ens_host_ns[3] = {0, 0, 0};   // last call: published, all rows combined, time spent on rows
     int wait_us = 20000;         // ensemble kernel: limit of a wait for another workgroup
     int ens_failures = 0;        // consecutive calls the kernel left before it answered
     bool ens_disabled = false;   // ... three of them: the launched path until "resident" is set again

@@ -2171,6 +2171,8 @@ int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walker
           }
           if (left) break;
           __atomic_thread_fence(__ATOMIC_ACQUIRE);
+          const unsigned long long seen_ns = now_ns();
+          if (grp == 0 && step == 0) r.ens_host_ns[2] = 0;
           const double* values = group + (size_t)row * 64;
           if (row == rt) {
             for (int w = 0; w < count; ++w) norm[w] = values[w];
@@ -2184,12 +2186,12 @@ int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walker
             for (int w = 0; w < count; ++w)
               xi[(size_t)(64 * grp + w) * t->n_r + row] = values[w] / norm[w];
           }
+          r.ens_host_ns[2] += now_ns() - seen_ns;      // (time spent on the rows)
         }
       }
     }
     r.ens_host_ns[1] = now_ns() - host_begin;       // (every row seen and combined)
     if (!left) {
-      r.ens_host_ns[2] = r.ens_host_ns[1];
       r.ens_failures = 0;
       return TC_OK;
     }

@@ -1237,7 +1237,7 @@ int tc_debug_resident_ticks(tc_table* t, uint64_t* out, int64_t capacity, int64_
 // builds; 100 MHz ticks: call seen, occupation stored, the group's occupations seen, densities
 // in LDS, quarters summed, partial sums stored, [6] shader cycles of the quarter sums, call
 // finished), then three host times of
-// that call in ns from its begin: published, every completion word seen, results combined.
+// that call in ns: published, every row combined (from its begin), time spent on the rows.
 int tc_debug_ensemble_stamps(tc_table* t, uint64_t* out) {
   TC_CHECK(t != nullptr && out != nullptr, "NULL argument");
   TC_CHECK(t->resident.ens_mailbox.ptr != nullptr, "no ensemble call has been made");

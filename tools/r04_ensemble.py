@@ -96,9 +96,8 @@ for name, halotab in (
             rows.append([(stamps[i] - stamps[0]) / 100.0 for i in range(1, 8)])
             host.append([stamps[8 + i] / 1000.0 for i in range(3)])
         phases = np.median(np.array(rows), axis=0)
-        print('    host, us from the begin of the call (medians): published %.2f, answered %.2f, '
-              'combined %.2f; raw stamps of the last call %s'
-              % (*np.median(np.array(host), axis=0), list(stamps)[:8]))
+        print('    host, us from the begin of the call (medians): published %.2f, every row '
+              'combined %.2f, of which spent on rows that were there %.2f' % tuple(np.median(np.array(host), axis=0)))
         print('%-6s %4d walkers: C call %6.1f -> %6.1f us, predict_batch %6.1f -> %6.1f us; '
               'workgroup 0, us after the sight of the call (medians): occupation stored %.1f, '
               'group seen %.1f, densities in LDS %.1f, quarters summed %.1f, partial sums '
