@@ -34,7 +34,7 @@ for halotab in halotabs:
 bad = []
 t0 = time.time()
 counts = {'resident': 0, 'batch': 0, 'walkers': 0, 'modulate': 0, 'toggle': 0, 'pause': 0}
-for call in range(30000):
+for call in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30000):
     k = int(rng.integers(0, len(halotabs)))
     halotab = halotabs[k]
     what = rng.random()
@@ -66,6 +66,6 @@ for call in range(30000):
     else:
         time.sleep(float(rng.uniform(0, 0.0004)))
         counts['pause'] += 1
-    if call % 5000 == 0:
+    if call % 50000 == 0:
         print(call, 'calls, %.1f s' % (time.time() - t0), flush=True)
 print('all results as recorded:', counts, '%.1f s' % (time.time() - t0))
