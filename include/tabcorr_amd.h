@@ -340,7 +340,7 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 tc_table_destroy.  Device-wide synchronisations by the caller
  *                 (hipDeviceSynchronize, hipFree) wait for it at most that idle time.
  *                 0 (default): one launch per call.
- *                 Calls with 2 .. 256 draws in host arrays (an ensemble sampler's step) are
+ *                 Calls with 24 .. 256 draws in host arrays (an ensemble sampler's step) are
  *                 served the same way by a second resident kernel of one workgroup per CU
  *                 (kernel_args.h: EnsembleArgs): no launch, no copy command, no stream
  *                 synchronisation per call; a draw's result does not depend on the number of
@@ -351,6 +351,9 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 LDS while it waits: the ensemble kernel of another handle starts when this
  *                 one has left (its idle time), so alternate between handles with a short
  *                 "resident_idle_us" or keep the option to the one table of the sampler.
+ *   "resident_min_walkers"  smallest number of draws per call the resident ensemble kernel
+ *                 takes (default 24, 2 .. 256): for fewer, one launch of the un-batched kernel
+ *                 is faster.
  *   "resident_wait_us"  how long a workgroup of the resident ensemble kernel waits for another
  *                 one inside a call before it gives up (default 20 000, 1 .. 10^6).
  *   "resident_aperture"  1 (default): on large-BAR systems the mailbox of the resident

@@ -524,6 +524,10 @@ struct tc_table {
     tc::host::DeviceBuffer ens_aperture;    // the mailbox in device memory (large BAR), or none
     unsigned long long ens_host_ns[3] = {0, 0, 0};   // last call: published, all rows combined, time spent on rows
     int wait_us = 20000;         // ensemble kernel: limit of a wait for another workgroup
+    int min_walkers = 24;        // ... smallest ensemble it takes (fewer walkers: one launch of
+                                 // single_draw_kernel is faster -- G = 60: 2 walkers 17.8 against
+                                 // 20.3 us, 32: 22.5 / 22.5, 64: 26.4 / 23.3; G = 100: 16 walkers
+                                 // 30.1 / 26.4 -- tools/r04_ensemble.py)
     int ens_failures = 0;        // consecutive calls the kernel left before it answered
     bool ens_disabled = false;   // ... three of them: the launched path until "resident" is set again
   } resident;

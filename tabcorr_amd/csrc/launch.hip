@@ -1993,7 +1993,7 @@ bool ensemble_layout(const tc_table* t, int n_gauss, EnsembleLayout* out) {
 
 bool ensemble_eligible(const tc_table* t, int64_t n_walkers, int n_gauss, unsigned flags) {
   EnsembleLayout l;
-  return !t->resident.ens_disabled && n_walkers >= 2 && n_walkers <= tc::kEnsembleMaxWalkers &&
+  return !t->resident.ens_disabled && n_walkers >= std::max(2, t->resident.min_walkers) && n_walkers <= tc::kEnsembleMaxWalkers &&
          single_draw_eligible(t, 1, n_gauss, flags) && ensemble_layout(t, n_gauss, &l);
 }
 

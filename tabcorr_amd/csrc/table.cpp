@@ -1019,6 +1019,11 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
       return TC_OK;
     }
     return autotune(t, (unsigned)value);
+  } else if (key == "resident_min_walkers") {
+    // smallest ensemble the resident ensemble kernel takes (default 24; smaller ones go through
+    // one launch of single_draw_kernel, which is faster for them)
+    TC_CHECK(value >= 2 && value <= 256, "resident_min_walkers must be in [2, 256]");
+    t->resident.min_walkers = value;
   } else if (key == "resident_wait_us") {
     // how long a workgroup of the resident ensemble kernel waits for another one inside a call
     // before it gives up (default 20 000; tests use 1 to exercise that path)

@@ -289,8 +289,9 @@ class TabCorr:
         of call is made on this table.  Results are bit-identical to the
         one-launch-per-call path.
 
-        Ensembles are served the same way: ``predict_batch`` with 2 to 256
-        draws in host arrays goes to a second resident kernel (one workgroup
+        Ensembles are served the same way: ``predict_batch`` with 24 to 256
+        draws in host arrays (fewer: one launch is faster; option
+        ``"resident_min_walkers"``) goes to a second resident kernel (one workgroup
         per CU: the walkers' occupations, slices of the table and the rows of
         the results in three phases that hand their data on through device
         memory) -- 64 walkers 34 -> 25 us, 256 walkers 45 -> 33 us per call on

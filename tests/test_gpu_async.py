@@ -478,6 +478,8 @@ def test_resident_kernel_serves_ensembles(aperture):
     halotab = make_tabcorr(table)
     handle = halotab.to_device().handle
     _lib.check(lib.tc_table_set_option(handle, b'resident_aperture', aperture))
+    # (by default ensembles of fewer than 24 walkers take one launch: here every size the kernel)
+    _lib.check(lib.tc_table_set_option(handle, b'resident_min_walkers', 2))
     plain = halotab.predict_batch(theta[:256])
     want = oracle.predict_zheng07_batch(table, theta[:6])
     halotab.set_resident(True)
@@ -531,6 +533,7 @@ def test_resident_kernel_serves_ensembles(aperture):
     decorated = make_tabcorr(table_ab)
     _lib.check(lib.tc_table_set_option(decorated.to_device().handle, b'resident_aperture',
                                        aperture))
+    _lib.check(lib.tc_table_set_option(decorated.to_device().handle, b'resident_min_walkers', 2))
     decorated.set_resident(True)
     ngal, xi = decorated.predict_batch(np.hstack([theta[:90], strengths]), assembias=True,
                                        modulate_with_cenocc=True)
@@ -545,6 +548,12 @@ def test_resident_kernel_serves_ensembles(aperture):
     ngal, xi = golden.predict_batch(theta[:100])
     assert_rel(xi, reference[1], 1e-12)
     del golden, decorated
+    # the default: fewer than 24 walkers go through one launch of the un-batched kernel
+    _lib.check(lib.tc_table_set_option(handle, b'resident_min_walkers', 24))
+    ngal, xi = halotab.predict_batch(theta[:10])
+    assert_rel(xi, full[1][:10], 1e-12)
+    ngal, xi = halotab.predict_batch(theta[:24])
+    assert np.array_equal(xi, full[1][:24])
     halotab.set_resident(False)
     ngal, xi = halotab.predict_batch(theta[:50])
     assert_rel(xi, plain[1][:50], 1e-15)
@@ -565,7 +574,7 @@ def test_resident_ensemble_kernel_gives_up_cleanly():
     served = halotab.predict_batch(theta)
     assert_rel(served[1], plain[1], 1e-12)
     _lib.check(lib.tc_table_set_option(handle, b'resident_wait_us', 1))
-    for n in (200, 64, 130, 7, 200):
+    for n in (200, 64, 130, 30, 200):
         ngal, xi = halotab.predict_batch(theta[:n])
         # (served by the launched path, or -- when every wait happened to be over in time --
         # by the kernel)

@@ -42,6 +42,7 @@ for name, halotab in (
         ('G=100', table_g100()),
         ('G=60', TabCorr.read(os.path.join(REPO, 'tests', 'golden', 'bolplanck_wp.hdf5')))):
     h = halotab.to_device().handle
+    _lib.check(lib.tc_table_set_option(h, b'resident_min_walkers', 2))
     n_r = halotab.predict_batch(synthetic.zheng07_draws(2, seed=1))[1].shape[1]
 
     def call(theta, resident):
@@ -73,7 +74,7 @@ for name, halotab in (
         _lib.check(lib.tc_table_set_option(h, b'resident', 0))
         continue
     for aperture, n in [(a, n) for a in ((1, ) if ONLY_TIME else (0, 1))
-                        for n in ((2, 64, 256) if ONLY_TIME else (2, 16, 64, 128, 192, 256))]:
+                        for n in ((2, 8, 16, 32, 48, 64, 128, 256) if ONLY_TIME else (2, 16, 64, 128, 192, 256))]:
         _lib.check(lib.tc_table_set_option(h, b'resident_aperture', aperture))
         print('mailbox in %s' % ('device memory' if aperture else 'page-locked memory'))
         theta = np.ascontiguousarray(big[:n])

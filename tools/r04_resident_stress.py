@@ -23,6 +23,9 @@ halotabs = [TabCorr.from_arrays(t['gal_type'], t['tpcf_matrix'], t['tpcf_shape']
 theta = synthetic.zheng07_draws(512, seed=3)
 expect = []
 for halotab in halotabs:
+    from tabcorr_amd import _lib
+    _lib.check(_lib.load().tc_table_set_option(halotab.to_device().handle,
+                                               b'resident_min_walkers', 2))
     halotab.set_resident(True, idle_us=100)
     expect.append([halotab.predict_batch(theta[i:i + 1]) for i in range(512)])
 batch = [halotab.predict_batch(theta[:200]) for halotab in halotabs]
