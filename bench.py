@@ -4,8 +4,8 @@
 Metric (BASELINE.json): predict() calls per second -- Zheng07 HOD, 50 mass bins x
 {centrals, satellites} (G = 100 halo/galaxy bins, P = 5050 packed pair columns), 19
 r_p bins, float64.  One *step* is one pass of the hot path over one batch of 10^4
-parameter draws against the resident synthetic table (BASELINE configs[1]): occupation
-kernel -> contraction kernel -> finalisation kernel.
+parameter draws against the resident synthetic table (BASELINE configs[1]): one
+launch of predict_fused_kernel (occupations -> quadratic form -> results in a workgroup).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
@@ -27,30 +27,38 @@ an MCMC needs back) is timed as well, in a second region of the same run
 5 x 5 grid of such tables, 10^5 draws per step sharded round-robin over the ranks (strong
 scaling), gathered the same way.  PyTorch is only used for the gloo control plane.
 
-Rank 0 prints ONE JSON line.  Extra objects:
-  roofline       contraction kernel: algorithmic flop per launch / mean launch duration.
-                 Always measured the same way, whatever --steps is: kernels serialised
-                 (one lane), >= 150 ms of load first, then 1000 launches each carrying its
-                 own start / stop events (hipExtLaunchKernelGGL: the dispatch's begin and
-                 end, the interval `rocprofv3 --kernel-trace --stats` reports).
-                 ``traffic``: HBM bytes per launch from the committed PMC passes.
-  host_to_host   the SURVEY 8d rate through tc_predict_zheng07_batch (host arrays).
-  unbatched_us   one predict(model) / Interpolator.predict(model) call, as in the
-                 reference's usage (README.md:72-75).
-  tabulation     SURVEY 8f.4: DD(r_p, pi) pair counts on the GPU (single pair of samples, and
-                 all 100 x 100 halo-bin pairs in one pass) with the brute-force oracle as
-                 the CPU baseline.
-  other_configs  BASELINE configs[2], [3] (one GPU's share), [4] in float32 and float64:
-                 device rate, host rate, dominant kernel, roofline fraction, CPU port.
+Rank 0 prints ONE short JSON line (< 4 KB) as the LAST line of stdout:
+
+  metric, value, unit, n_gpus, steps, warmup, ms_per_step, dtype, config, ...
+  roofline       the kernel of the timed region.  ``frac`` = algorithmic flop of one step /
+                 (elapsed / steps) / peak OF THE TIMED REGION (reproducible from
+                 ``ms_per_step``: flop_per_launch / ms_per_step / peak; one launch per step).
+                 ``mean_launch_ms``: that kernel's launches with their own start / stop events
+                 (hipExtLaunchKernelGGL: the dispatch's begin and end, the interval
+                 `rocprofv3 --kernel-trace --stats` reports) -- over the timed region itself
+                 when it has <= 1024 steps (the driver's command), else over 1000 launches of
+                 the same stream of calls right after it (``launch_ms_source`` says which);
+                 launches of the four lanes overlap by design, ``concurrent_launches`` =
+                 mean_launch_ms / ms_per_step and ``frac_by_duration`` = flop_per_launch /
+                 mean_launch_ms / peak.  ``traffic``: HBM bytes per launch from the committed
+                 PMC passes.
   cpu_baseline   the NumPy port of the reference's predict() (oracle/tabcorr_oracle.py),
                  timed on one host core and with one walker per core.
+  value_host_to_host   the SURVEY 8d rate (PCIe included), never ``value``.
+
+Everything else goes to the sidecar ``bench_detail.json`` (next to this file, and a copy under
+gpurun_out/ when that directory exists) and to ``detail ...`` lines printed BEFORE the final
+one: the full roofline record (kernel alone, three-kernel path, methods), host_to_host*,
+batch_sizes, unbatched_us (one predict(model) per call, README.md:72-75), tabulation (SURVEY
+8f.4), other_configs (BASELINE configs[2], [3], [4] and the reference's own table shapes; the
+legs live in bench_legs.py).  A secondary leg that fails is recorded there and never costs the
+headline line.
 """
 
 import argparse
 import ctypes
 import json
 import os
-import re
 import sys
 import time
 
@@ -59,173 +67,77 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-# FP64 peak of MI355X: 78.6 TFLOP/s (AMD datasheet, vector = matrix; the local
-# microbenchmarks in tools/micro measure 78.0 for v_mfma_f64_16x16x4); FP32 matrix peak
-# 157.3 TFLOP/s (/opt/skills/guides/MI355X_MICROARCH.md).
-FP64_PEAK_TFLOPS = 78.6
-FP32_PEAK_TFLOPS = 157.3
-N_PRIM, N_SEC, N_R = 50, 1, 19
-N_GAUSS = 10
-FLAG_SEPARATE, FLAG_ASSEMBIAS = 1, 4
-ROOFLINE_LAUNCHES = 1000
-ROOFLINE_WARM_SECONDS = 0.25
+from bench_legs import (CONFIG_TAGS, FP64_PEAK_TFLOPS, N_GAUSS, N_PRIM, N_R, N_SEC,   # noqa: E402
+                        Device, cpu_baseline, cpu_baseline_all_cores, host_pipelined,
+                        kernel_time, matrix_pipe_busy, other_configs, pair_flops, pmc_traffic,
+                        sustained, tabulation, time_calls, unbatched)
 
 
-def pair_flops(n_bins, n_r):
-    """Algorithmic flop of one draw's contraction: 2 R P + 3 P."""
-    n_pairs = n_bins * (n_bins + 1) // 2
-    return 2.0 * n_r * n_pairs + 3.0 * n_pairs
+HEADLINE_KEYS = ('metric', 'value', 'value_definition', 'unit', 'n_gpus', 'steps', 'warmup',
+                 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')
+ROOFLINE_KEYS = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'frac_by_duration',
+                 'flop_per_launch', 'mean_launch_ms', 'launch_ms_source', 'concurrent_launches',
+                 'traffic', 'traffic_source')
+CONFIG_KEYS = ('workload', 'draws_per_gpu_per_step', 'n_tables', 'gather', 'gather_payload',
+               'gather_every_steps', 'lanes', 'rccl_ranks', 'rccl_error')
+MAX_LINE = 4096
 
 
-def pmc_file(tag):
-    """Newest committed PMC summary of a configuration: profiles/rNN_pmc_counters[_tag].txt
-    (tools/profile_round.sh; tag '' = the headline configuration)."""
-    import glob
-    suffix = '_pmc_counters%s.txt' % ('_' + tag if tag else '')
-    files = sorted(f for f in glob.glob(os.path.join(REPO, 'profiles', 'r[0-9][0-9]' + suffix)))
-    return files[-1] if files else None
+def headline(result, detail_path):
+    """The short record: what the driver parses and cross-checks (< MAX_LINE bytes)."""
+    line = {key: result[key] for key in HEADLINE_KEYS}
+    line['config'] = {key: result['config'][key] for key in CONFIG_KEYS
+                      if key in result['config']}
+    roofline = {key: result['roofline'][key] for key in ROOFLINE_KEYS}
+    if roofline.get('traffic_source'):
+        roofline['traffic_source'] = roofline['traffic_source'].split(' ')[0]
+    line['roofline'] = roofline
+    cpu = result.get('cpu_baseline')
+    if cpu is not None:
+        line['cpu_baseline'] = {key: cpu[key] for key in ('value', 'unit', 'cores', 'kind',
+                                                          'sample')}
+        if cpu.get('all_cores'):
+            line['cpu_baseline']['all_cores'] = {key: cpu['all_cores'][key]
+                                                 for key in ('value', 'cores')}
+    else:
+        line['cpu_baseline'] = None
+    line['value_host_to_host'] = result.get('value_host_to_host')
+    line['parity_max_rel_vs_oracle'] = result['parity_max_rel_vs_oracle']
+    if 'second_payload' in result:
+        line['second_payload'] = {key: result['second_payload'][key]
+                                  for key in ('gather_payload', 'value', 'ms_per_step')}
+    if result.get('failed_legs'):
+        line['failed_legs'] = sorted(result['failed_legs'])
+    line['detail'] = detail_path
+    text = json.dumps(line)
+    if len(text) >= MAX_LINE:          # (cannot happen with the keys above; never lose the line)
+        line['config'] = {'workload': line['config']['workload'][:200]}
+        line['roofline'].pop('launch_ms_source', None)
+        text = json.dumps(line)
+    return text
 
 
-def matrix_pipe_busy(kernel, step_seconds, simds=1024, clock_hz=2.4e9):
-    """Share of the timed region in which a SIMD's matrix pipe was busy: the counter
-    SQ_VALU_MFMA_BUSY_CYCLES per launch of `kernel` (committed PMC passes) over the SIMD cycles
-    of one step at the nominal clock (one launch per step)."""
-    cycles = pmc_counter(kernel, 'SQ_VALU_MFMA_BUSY_CYCLES')
-    if cycles is None:
-        return None
-    return {'value': cycles / (simds * step_seconds * clock_hz),
-            'what': 'SQ_VALU_MFMA_BUSY_CYCLES per launch (%s) / (%d SIMDs x step time x %.1f GHz)'
-                    % (os.path.relpath(pmc_file(''), REPO), simds, clock_hz * 1e-9)}
-
-
-def pmc_counter(kernel, counter, tag=''):
-    """Mean of one raw counter per launch of `kernel` from the committed rocprofv3 --pmc passes
-    of configuration `tag`, or None."""
-    path = pmc_file(tag)
-    if path is None:
-        return None
-    prefix = kernel[:40]
-    for line in open(path).read().splitlines():
-        match = re.match(r'(.*?)\s+(\w+)\s+n=\s*\d+\s+mean=([0-9.e+]+)', line)
-        if match and match.group(2) == counter and prefix in match.group(1).replace('void ', ''):
-            return float(match.group(3))
-    return None
-
-
-def pmc_traffic(kernel, tag=''):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of
-    configuration `tag` (FETCH_SIZE and WRITE_SIZE in KB; FETCH_SIZE doubled per the gfx950
-    correction of the MI355X guide) and the file they come from; (None, None) when no
-    committed file holds that kernel."""
-    path = pmc_file(tag)
-    if path is None:
-        return None, None
-    values = {}
-    prefix = kernel[:40]
-    for line in open(path).read().splitlines():
-        match = re.match(r'(.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+\s+mean=([0-9.e+]+)', line)
-        if match and prefix in match.group(1).replace('void ', ''):
-            values[match.group(2)] = float(match.group(3))
-    if len(values) != 2:
-        return None, None
-    return ((2.0 * values['FETCH_SIZE'] + values['WRITE_SIZE']) * 1024.0,
-            os.path.relpath(path, REPO))
-
-
-class Device:
-    """Thin helper over the C ABI for device-resident arrays."""
-
-    def __init__(self, lib, _lib):
-        self.lib = lib
-        self._lib = _lib
-        self.allocations = []
-
-    def malloc(self, count):
-        ptr = ctypes.c_void_p()
-        self._lib.check(self.lib.tc_device_malloc(ctypes.byref(ptr), max(1, count) * 8))
-        self.allocations.append(ptr)
-        return ptr
-
-    def upload(self, array):
-        array = np.ascontiguousarray(array, dtype=np.float64)
-        ptr = self.malloc(array.size)
-        self._lib.check(self.lib.tc_memcpy_h2d(
-            ptr, array.ctypes.data_as(ctypes.c_void_p), array.nbytes))
-        return ptr
-
-    def download(self, ptr, count):
-        host = np.empty(count)
-        self._lib.check(self.lib.tc_memcpy_d2h(
-            host.ctypes.data_as(ctypes.c_void_p), ptr, host.nbytes))
-        return host
-
-    def free_all(self):
-        for ptr in self.allocations:
-            if ptr.value:
-                self.lib.tc_device_free(ptr)
-        self.allocations = []
-
-
-def kernel_time(lib, _lib, timer_handle, launch, synchronize, warm_seconds=ROOFLINE_WARM_SECONDS,
-                n_launches=ROOFLINE_LAUNCHES, max_seconds=1.0):
-    """Mean duration (ms) of the contraction kernel inside `launch()`, serialised: load the
-    chip for `warm_seconds` first (the power management needs tens of milliseconds to
-    settle), then time `n_launches` launches (fewer when they would take more than
-    `max_seconds`) with per-launch start / stop events."""
-    launch()
-    synchronize()
-    t0 = time.perf_counter()
-    launch()
-    synchronize()
-    per_call = max(time.perf_counter() - t0, 1e-6)
-    for _ in range(int(warm_seconds / per_call) + 1):
-        launch()
-    n = max(10, min(n_launches, int(max_seconds / per_call)))
-    synchronize()
-    _lib.check(lib.tc_table_timer_begin(timer_handle, 1))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        launch()
-    synchronize()
-    wall_ms = (time.perf_counter() - t0) / n * 1e3
-    ms = ctypes.c_float()
-    _lib.check(lib.tc_table_timer_end(timer_handle, ctypes.byref(ms)))
-    count = ctypes.c_int()
-    kernel_ms = ctypes.c_float()
-    _lib.check(lib.tc_table_kernel_time(timer_handle, ctypes.byref(count), ctypes.byref(kernel_ms)))
-    return kernel_ms.value, count.value, wall_ms
-
-
-def sustained(launch, synchronize, seconds=0.4, warm_seconds=0.15):
-    """Seconds per `launch()` in a sustained stream of calls."""
-    launch()
-    synchronize()
-    t0 = time.perf_counter()
-    launch()
-    synchronize()
-    per_call = max(time.perf_counter() - t0, 1e-6)
-    for _ in range(int(warm_seconds / per_call) + 1):
-        launch()
-    synchronize()
-    n = max(5, int(seconds / per_call))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        launch()
-    synchronize()
-    return (time.perf_counter() - t0) / n
-
-
-def time_calls(call, seconds=0.5, warm=3):
-    for _ in range(warm):
-        call()
-    t0 = time.perf_counter()
-    call()
-    per_call = max(time.perf_counter() - t0, 1e-6)
-    n = max(3, int(seconds / per_call))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        call()
-    return (time.perf_counter() - t0) / n
+def emit(result):
+    """Sidecar with everything, `detail` lines, then the ONE short JSON line (last on stdout)."""
+    detail_path = None
+    for directory in (REPO, os.path.join(REPO, 'gpurun_out')):
+        if not os.path.isdir(directory):
+            continue
+        try:
+            with open(os.path.join(directory, 'bench_detail.json'), 'w') as stream:
+                json.dump(result, stream, indent=1)
+            detail_path = detail_path or 'bench_detail.json'
+        except OSError:
+            pass
+    for key, value in result.items():
+        if isinstance(value, dict) and key not in ('config', ):
+            if key == 'other_configs':
+                for name, record in value.items():
+                    print('detail other_configs[%s] %s' % (name, json.dumps(record)))
+            else:
+                print('detail %s %s' % (key, json.dumps(value)))
+    sys.stdout.flush()
+    print(headline(result, detail_path), flush=True)
 
 
 def main():
@@ -268,6 +180,9 @@ def main():
                         help='also time one independent CPU walker per host core')
     parser.add_argument('--other-configs', type=int, default=1,
                         help='measure BASELINE configs[2..4] as well (single GPU only)')
+    parser.add_argument('--detail', type=int, default=1,
+                        help='0 = headline only: skip the secondary legs (host-to-host, batch '
+                             'sizes, un-batched calls, tabulation, other configurations)')
     parser.add_argument('--only-config', choices=CONFIG_TAGS, default=None,
                         help='measure ONLY that configuration of other_configs and print its '
                              'record (for rocprofv3 runs: tools/profile_round.sh)')
@@ -484,10 +399,30 @@ def main():
     # the enqueueing thread for hundreds of microseconds, longer than 10 steps)
     import gc
 
+    # Per-launch start / stop events INSIDE the timed region when it is short (the driver's
+    # --steps 20): the mean launch duration of the roofline record then belongs to the very
+    # launches `value` times.  (20 000 event pairs in the default run would cost more than they
+    # tell: there the same stream of calls is sampled right after the region.)  The event pairs
+    # are created beforehand.
+    events_in_region = args.steps <= 1024
+
+    def region_events(begin):
+        if not events_in_region:
+            return None
+        if begin:
+            _lib.check(lib.tc_table_timer_begin(timer_handle, 1))
+            return None
+        ms, count, mean = ctypes.c_float(), ctypes.c_int(), ctypes.c_float()
+        _lib.check(lib.tc_table_timer_end(timer_handle, ctypes.byref(ms)))
+        _lib.check(lib.tc_table_kernel_time(timer_handle, ctypes.byref(count),
+                                            ctypes.byref(mean)))
+        return (mean.value, count.value) if count.value else None
+
     def timed(payload):
         gc.disable()
         comm.barrier()
         drain()
+        region_events(True)
         t0 = time.perf_counter()
         for index in range(args.steps):
             payload.step(index)
@@ -498,10 +433,18 @@ def main():
         comm.barrier()
         seconds = comm.max(time.perf_counter() - t0)
         gc.enable()
+        launches = region_events(False)
         return seconds, {'enqueue': (t_queued - t0) * 1e6, 'drain': (t_drained - t_queued) * 1e6,
-                         'barrier': (time.perf_counter() - t_drained) * 1e6}
+                         'barrier': (time.perf_counter() - t_drained) * 1e6}, launches
 
-    elapsed, breakdown = timed(region)
+    if events_in_region:
+        region_events(True)
+        for index in range(args.steps):
+            step(index)
+        flush(args.steps)
+        drain()
+        region_events(False)
+    elapsed, breakdown, region_launches = timed(region)
 
     # The other payload, same workload, same steps: a second region of the same run (default
     # for --gpus > 1, where what travels to rank 0 is the difference between the two).
@@ -514,7 +457,7 @@ def main():
             other.step(index)
         other.flush(args.warmup)
         drain()
-        second_elapsed, second_breakdown = timed(other)
+        second_elapsed, second_breakdown, _ = timed(other)
         second = {
             'gather_payload': 'ngal + chi2 (16 B per draw)' if other.chi2_mode
                               else 'ngal + xi (%d B per draw)' % (8 * (1 + N_R)),
@@ -597,14 +540,26 @@ def main():
                             if n_draws == (100000 if interp_mode else 10000) // (
                                 comm.world_size if interp_mode else 1)
                             else (None, None))
-        if fused_active:
-            # launches of different lanes share the chip: a launch's share of it is its
-            # duration divided by the mean number of launches running at once
-            concurrency = overlapped_ms / overlapped_wall_ms
-            achieved = flop_contract / (overlapped_ms / concurrency * 1e-3) / 1e12
+        step_seconds = elapsed / args.steps
+        # The dominant kernel's launch durations: events inside the timed region when it is
+        # short, else a sample of the same stream of calls right after it (one launch per step:
+        # predict_fused_kernel, launches of different lanes sharing the chip) or -- three
+        # kernels per step -- the contraction kernel serialised before the region
+        sample_concurrency = overlapped_ms / overlapped_wall_ms
+        if region_launches is not None:
+            launch_ms, n_launch = region_launches
+            launch_source = 'events on the %d launches of the timed region' % n_launch
+        elif fused_active:
+            launch_ms = overlapped_ms
+            launch_source = ('events on %d launches of the same stream of calls right after '
+                             'the timed region (its %d steps carry none)' % (n_launch, args.steps))
         else:
-            concurrency = None
-            achieved = flop_contract / (isolated_ms * 1e-3) / 1e12
+            launch_ms = isolated_ms
+            launch_source = ('kernels serialised (pipeline off) before the timed region: %d '
+                             'launches with events' % n_launch)
+        concurrency = launch_ms / (step_seconds * 1e3)
+        # THE fraction: algorithmic flop of one step over the step time of the timed region
+        achieved = flop_contract / step_seconds / 1e12
         total_draws = comm.world_size * n_draws * args.steps
         if interp_mode:
             workload = ('BASELINE configs[3]: Interpolator.predict() over a 5 x 5 grid of '
@@ -643,6 +598,7 @@ def main():
                 'parallelism': 'draws sharded over %d GPU(s), table%s replicated' %
                                (comm.world_size, 's' if interp_mode else ''),
                 'gather': comm.gather_backend,
+                'rccl_ranks': comm.world_size if comm.comm is not None else 0,
                 'gather_payload': 'ngal + chi2 (16 B per draw)' if chi2_mode
                                   else 'ngal + xi (%d B per draw)' % (8 * (1 + N_R)),
                 'gather_payload_options': {
@@ -660,13 +616,9 @@ def main():
                 'peak': FP64_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': achieved / FP64_PEAK_TFLOPS,
-                'frac_method': ('flop_per_launch / (mean_launch_ms / concurrent_launches) / '
-                                "peak: a launch's share of the chip while "
-                                'concurrent_launches of them overlap') if fused_active
-                               else 'flop_per_launch / mean_launch_ms / peak (kernels serialised)',
-                'frac_by_duration': flop_contract / ((overlapped_ms if fused_active
-                                                      else isolated_ms) * 1e-3) / 1e12
-                                    / FP64_PEAK_TFLOPS,
+                'frac_method': 'flop_per_launch x launches per step (1) / (elapsed / steps) / '
+                               'peak, of the timed region: = flop_per_launch / ms_per_step / peak',
+                'frac_by_duration': flop_contract / (launch_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                 'frac_by_duration_method': 'flop_per_launch / mean_launch_ms / peak: by the raw '
                                            'duration of a launch (what rocprofv3 reports per '
                                            'dispatch), whatever else runs beside it',
@@ -676,20 +628,17 @@ def main():
                                   'the gfx950 correction)' % headline_traffic[1]
                                   if headline_traffic[1] else None,
                 'flop_per_launch': flop_contract,
-                'mean_launch_ms': overlapped_ms if fused_active else isolated_ms,
+                'mean_launch_ms': launch_ms,
+                'launch_ms_source': launch_source,
                 'concurrent_launches': concurrency,
                 'launches_timed': n_launch,
-                'method': ('after the timed region, same stream of calls: %d launches with '
-                           'hipExtLaunchKernelGGL start/stop events; one launch per step and '
-                           'lane, the launches of the %d lanes overlap (that is the design: a '
-                           'workgroup carries 64 draws from theta to the results, workgroups '
-                           'of different launches share a CU), so achieved = flop_per_launch '
-                           '/ (mean_launch_ms / concurrent_launches), concurrent_launches = '
-                           'mean_launch_ms / wall time per launch' % (n_launch, lanes_used))
-                          if fused_active else
-                          'before the timed region: kernels serialised (pipeline off), '
-                          '>= 150 ms of load, then %d launches with hipExtLaunchKernelGGL '
-                          'start/stop events' % n_launch,
+                'sample_after_region': {
+                    'mean_launch_ms': overlapped_ms, 'wall_ms_per_launch': overlapped_wall_ms,
+                    'concurrent_launches': sample_concurrency,
+                    'frac_share_of_chip': flop_contract / (overlapped_wall_ms * 1e-3) / 1e12
+                                          / FP64_PEAK_TFLOPS,
+                    'note': '1000 launches of the same stream of calls with per-launch events, '
+                            'right after the timed region (rounds 3-4 quoted this as frac)'},
                 'alone': {
                     'mean_launch_ms': fused_alone_ms,
                     'frac': flop_contract / (fused_alone_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
@@ -707,8 +656,7 @@ def main():
                     'note': 'contraction kernel of the three-kernel path (option fused=0, and '
                             'every call that runs alone on its lane), kernels serialised, '
                             'measured before the timed region'},
-                'step_frac': flop_contract / (elapsed / args.steps) / 1e12 / FP64_PEAK_TFLOPS,
-                'matrix_pipe_busy': matrix_pipe_busy(kernel_name, elapsed / args.steps)
+                'matrix_pipe_busy': matrix_pipe_busy(kernel_name, step_seconds)
                                     if fused_active else None,
                 'workgroups': launch[0].value,
                 'waves_per_workgroup': launch[1].value,
@@ -722,696 +670,91 @@ def main():
         if second is not None:
             result['second_payload'] = second
 
-    # ---- SURVEY 8d metric, latency mode, the other BASELINE configurations (1 GPU) ---------
-    if comm.world_size == 1 and not interp_mode:
+    # ---- CPU baseline (the headline line needs it), then the secondary legs (1 GPU) ----------
+    if result is not None and comm.world_size == 1 and args.cpu_seconds > 0 and not interp_mode:
+        result['cpu_baseline'] = cpu_baseline(table, args.cpu_seconds)
+        if cpu_all is not None:
+            result['cpu_baseline']['all_cores'] = cpu_all
+
+    def leg(name, measure):
+        """A secondary measurement: its record (or its failure) goes to the sidecar; it never
+        costs the headline line."""
+        try:
+            value = measure()
+        except Exception as error:   # noqa: BLE001
+            import traceback
+            result.setdefault('failed_legs', {})[name] = '%s: %s' % (type(error).__name__, error)
+            traceback.print_exc(file=sys.stderr)
+            return None
+        if isinstance(value, dict) and name is None:
+            result.update(value)
+        elif name is not None:
+            result[name] = value
+        return value
+
+    if comm.world_size == 1 and not interp_mode and args.detail:
         ngal_host = np.empty(n_draws)
         xi_host = np.empty((n_draws, N_R))
 
-        def host_call():
-            _lib.check(lib.tc_predict_zheng07_batch(
-                handle, _lib.as_double_p(theta), 5, n_draws, N_GAUSS, 0,
-                _lib.as_double_p(ngal_host), _lib.as_double_p(xi_host)))
-        seconds = time_calls(host_call, seconds=0.5, warm=5)
-        result['host_to_host'] = {
-            'value': n_draws / seconds, 'unit': 'calls/s', 'ms_per_call': seconds * 1e3,
-            'what': 'tc_predict_zheng07_batch: %d draws in pageable host memory -> (ngal, xi) '
-                    'in host memory, synchronous, PCIe included (SURVEY.md 8d)' % n_draws}
-        result.update(host_pipelined(lib, _lib, handle, table, n_draws, data_vector, precision))
-        result['value_host_to_host'] = result['host_to_host_pipelined']['value']
-        # other batch sizes of the same table (an ensemble sampler's 10^2 ... 10^4 walkers per
-        # step), device-resident, the form the library chooses and -- by option -- the three
-        # kernels; first draws of every batch against the oracle
-        sizes = {}
-        from oracle import tabcorr_oracle as oracle
-        for size in (256, 1024, 4096):
-            row = {}
-            for name, fused in (('chosen', 1), ('three_kernels', 0)):
-                _lib.check(lib.tc_table_set_option(handle, b'fused', fused))
-                seconds = sustained(
-                    lambda: lib.tc_predict_zheng07_batch_device(
-                        handle, d_theta, 5, size, N_GAUSS, 0, out_ptr(0), out_ptr(0, size)),
-                    synchronize, seconds=0.15, warm_seconds=0.05)
-                row[name + '_us_per_call'] = seconds * 1e6
-                row[name + '_calls_per_sec'] = size / seconds
-                if fused:
-                    shape = [ctypes.c_int() for _ in range(4)]
-                    lib.tc_table_last_launch(handle, *[ctypes.byref(v) for v in shape])
-                    row['chosen_form'] = (
-                        'one launch: %d workgroups of %d waves' % (shape[0].value, shape[1].value)
-                        if shape[2].value == 0 else 'three kernels')
-                    host = dev.download(out_ptr(0), size * (1 + N_R))
-                    expect = oracle.predict_zheng07_batch(table, theta[:3])
-                    row['parity_max_rel_vs_oracle'] = float(max(
-                        np.max(np.abs(host[:3] / expect[0] - 1)),
-                        np.max(np.abs(host[size:size + 3 * N_R].reshape(3, N_R) / expect[1] - 1))))
-            sizes[str(size)] = row
-        _lib.check(lib.tc_table_set_option(handle, b'fused', 1))
-        result['batch_sizes'] = sizes
-        result['unbatched_us'] = unbatched(make, table, synthetic, Interpolator)
-        result['tabulation'] = tabulation(args.cpu_seconds)
+        def host_to_host():
+            def host_call():
+                _lib.check(lib.tc_predict_zheng07_batch(
+                    handle, _lib.as_double_p(theta), 5, n_draws, N_GAUSS, 0,
+                    _lib.as_double_p(ngal_host), _lib.as_double_p(xi_host)))
+            seconds = time_calls(host_call, seconds=0.5, warm=5)
+            return {
+                'value': n_draws / seconds, 'unit': 'calls/s', 'ms_per_call': seconds * 1e3,
+                'what': 'tc_predict_zheng07_batch: %d draws in pageable host memory -> (ngal, '
+                        'xi) in host memory, synchronous, PCIe included (SURVEY.md 8d)' % n_draws}
+        leg('host_to_host', host_to_host)
+        if leg(None, lambda: host_pipelined(lib, _lib, handle, table, n_draws, data_vector,
+                                            precision)):
+            result['value_host_to_host'] = result['host_to_host_pipelined']['value']
+
+        def batch_sizes():
+            # other batch sizes of the same table (an ensemble sampler's 10^2 ... 10^4 walkers
+            # per step), device-resident, the form the library chooses and -- by option -- the
+            # three kernels; first draws of every batch against the oracle
+            sizes = {}
+            from oracle import tabcorr_oracle as oracle
+            for size in (256, 1024, 4096):
+                row = {}
+                for name, fused in (('chosen', 1), ('three_kernels', 0)):
+                    _lib.check(lib.tc_table_set_option(handle, b'fused', fused))
+                    seconds = sustained(
+                        lambda: lib.tc_predict_zheng07_batch_device(
+                            handle, d_theta, 5, size, N_GAUSS, 0, out_ptr(0), out_ptr(0, size)),
+                        synchronize, seconds=0.15, warm_seconds=0.05)
+                    row[name + '_us_per_call'] = seconds * 1e6
+                    row[name + '_calls_per_sec'] = size / seconds
+                    if fused:
+                        shape = [ctypes.c_int() for _ in range(4)]
+                        lib.tc_table_last_launch(handle, *[ctypes.byref(v) for v in shape])
+                        row['chosen_form'] = (
+                            'one launch: %d workgroups of %d waves'
+                            % (shape[0].value, shape[1].value)
+                            if shape[2].value == 0 else 'three kernels')
+                        host = dev.download(out_ptr(0), size * (1 + N_R))
+                        expect = oracle.predict_zheng07_batch(table, theta[:3])
+                        row['parity_max_rel_vs_oracle'] = float(max(
+                            np.max(np.abs(host[:3] / expect[0] - 1)),
+                            np.max(np.abs(host[size:size + 3 * N_R].reshape(3, N_R)
+                                          / expect[1] - 1))))
+                sizes[str(size)] = row
+            _lib.check(lib.tc_table_set_option(handle, b'fused', 1))
+            return sizes
+        leg('batch_sizes', batch_sizes)
+        leg('unbatched_us', lambda: unbatched(make, table, synthetic, Interpolator))
+        leg('tabulation', lambda: tabulation(args.cpu_seconds))
         if args.other_configs:
-            result['other_configs'] = other_configs(
-                lib, _lib, make, synthetic, Interpolator, args.cpu_seconds)
+            leg('other_configs', lambda: other_configs(
+                lib, _lib, make, synthetic, Interpolator, args.cpu_seconds))
     if result is not None:
-        if comm.world_size == 1 and args.cpu_seconds > 0 and not interp_mode:
-            result['cpu_baseline'] = cpu_baseline(table, args.cpu_seconds)
-            if cpu_all is not None:
-                result['cpu_baseline']['all_cores'] = cpu_all
-        print(json.dumps(result), flush=True)
+        emit(result)
 
     dev.free_all()
     comm.barrier()
     comm.close()
-
-
-# ---- SURVEY 8d metric through the asynchronous entry points ------------------------------------
-
-def host_pipelined(lib, _lib, handle, table, n_draws, data_vector, precision, seconds=0.5,
-                   depth=6, ring=8):
-    """theta in page-locked host memory -> (ngal, xi) / (ngal, chi2) in page-locked host memory
-    through tc_predict_zheng07_batch_async / tc_chi2_zheng07_batch_async + tc_table_wait:
-    `depth` calls in flight over a ring of `ring` distinct buffer sets, every call with its
-    own draws; each ticket is waited for before its buffers are reused.  The last ring's
-    results are checked against the CPU oracle."""
-    from tabcorr_amd import synthetic, pinned_array, pinned_empty
-    from oracle import tabcorr_oracle as oracle
-    thetas = [pinned_array(synthetic.zheng07_draws(n_draws, seed=500 + i)) for i in range(ring)]
-    ngals = [pinned_empty(n_draws) for _ in range(ring)]
-    xis = [pinned_empty((n_draws, N_R)) for _ in range(ring)]
-    chis = [pinned_empty(n_draws) for _ in range(ring)]
-    p_theta = [_lib.as_double_p(a) for a in thetas]
-    p_ngal = [_lib.as_double_p(a) for a in ngals]
-    p_xi = [_lib.as_double_p(a) for a in xis]
-    p_chi = [_lib.as_double_p(a) for a in chis]
-    data_p, precision_p = _lib.as_double_p(data_vector), _lib.as_double_p(precision)
-    ticket = ctypes.c_int64()
-    ref = ctypes.byref(ticket)
-
-    def run(chi2, total):
-        tickets = [None] * ring
-        start = time.perf_counter()
-        for k in range(total):
-            s = k % ring
-            if k >= depth:
-                _lib.check(lib.tc_table_wait(handle, tickets[(k - depth) % ring]))
-            if chi2:
-                _lib.check(lib.tc_chi2_zheng07_batch_async(
-                    handle, p_theta[s], 5, n_draws, N_GAUSS, 0, data_p, precision_p, p_ngal[s],
-                    p_chi[s], ref))
-            else:
-                _lib.check(lib.tc_predict_zheng07_batch_async(
-                    handle, p_theta[s], 5, n_draws, N_GAUSS, 0, p_ngal[s], p_xi[s], ref))
-            tickets[s] = ticket.value
-        for k in range(max(0, total - depth), total):
-            _lib.check(lib.tc_table_wait(handle, tickets[k % ring]))
-        return (time.perf_counter() - start) / total
-
-    out = {}
-    for chi2, name, payload in ((False, 'host_to_host_pipelined', '%d B out' % (8 * (1 + N_R))),
-                                (True, 'host_to_host_chi2', '16 B out')):
-        run(chi2, 300)
-        per = run(chi2, 100)
-        per = run(chi2, max(100, int(seconds / per)))
-        check = ring - 1
-        expect = oracle.predict_zheng07_batch(table, thetas[check][:2])
-        if chi2:
-            delta = expect[1] - data_vector
-            want = np.einsum('bi,ij,bj->b', delta, precision, delta)
-            parity = float(np.max(np.abs(chis[check][:2] / want - 1)))
-        else:
-            parity = float(np.max(np.abs(xis[check][:2] / expect[1] - 1)))
-        out[name] = {
-            'value': n_draws / per, 'unit': 'calls/s', 'us_per_call': per * 1e6,
-            'calls_in_flight': depth, 'parity_max_rel_vs_oracle': parity,
-            'what': 'tc_%s_zheng07_batch_async + tc_table_wait: %d draws per call (40 B in, %s '
-                    'per draw), page-locked caller buffers, PCIe included (SURVEY.md 8d)'
-                    % ('chi2' if chi2 else 'predict', n_draws, payload)}
-    return out
-
-
-# ---- latency mode --------------------------------------------------------------------------
-
-def unbatched(make, table, synthetic, Interpolator):
-    """One predict(model) per call, the reference's usage pattern (README.md:72-75)."""
-    from tabcorr_amd import Zheng07Model
-    halotab = make(table)
-    model = Zheng07Model()
-    halotab.predict(model)
-    count = [0]
-
-    def call():
-        count[0] += 1
-        model.param_dict['logMmin'] = 12.0 + 1e-5 * (count[0] % 1000)
-        halotab.predict(model)
-    single = time_calls(call, seconds=0.3, warm=50)
-    # the same calls served by ONE resident launch (TabCorr.set_resident: the call writes its
-    # parameters into a mailbox in page-locked memory, no launch per call), checked against
-    # the one-launch-per-call result
-    expect = halotab.predict(model)
-    resident, resident_parity = None, None
-    try:
-        halotab.set_resident(True)
-        got = halotab.predict(model)
-        resident_parity = float(max(abs(got[0] / expect[0] - 1),
-                                    np.max(np.abs(got[1] / expect[1] - 1))))
-        resident = time_calls(call, seconds=0.3, warm=50)
-    except Exception as error:   # noqa: BLE001 -- a secondary measurement must not end the bench
-        resident_parity = 'failed: %s' % error
-    finally:
-        try:
-            halotab.set_resident(False)
-        except Exception:   # noqa: BLE001
-            pass
-    tables, keys, points = synthetic.synthetic_interpolator((5, 5), N_PRIM, N_SEC, (N_R, ),
-                                                            'auto', seed=7)
-    interp = Interpolator([make(t) for t in tables],
-                          {k: points[:, d] for d, k in enumerate(keys)})
-    for d, key in enumerate(keys):
-        model.param_dict[key] = float(np.mean(points[:, d]))
-    interp.predict(model)
-
-    def call_interp():
-        count[0] += 1
-        model.param_dict['logMmin'] = 12.0 + 1e-5 * (count[0] % 1000)
-        interp.predict(model)
-    grid = time_calls(call_interp, seconds=0.3, warm=20)
-    # an ensemble sampler's step: n independent walkers per call, one launch
-    # (tc_predict_zheng07_many behind predict_batch)
-    walkers = {}
-    for n in (1, 16, 64):
-        theta = synthetic.zheng07_draws(n, seed=70 + n)
-        seconds = time_calls(lambda: halotab.predict_batch(theta), seconds=0.2, warm=50)
-        walkers['%d' % n] = {'us_per_call': seconds * 1e6, 'us_per_walker': seconds * 1e6 / n}
-    # the same steps served by the resident ENSEMBLE kernel (2 .. 256 walkers per call, no
-    # launch; checked against the launched result)
-    resident_walkers = {}
-    try:
-        for n in (64, 256):
-            theta = synthetic.zheng07_draws(n, seed=70 + n)
-            halotab.set_resident(False)
-            expect = halotab.predict_batch(theta)
-            launched = time_calls(lambda: halotab.predict_batch(theta), seconds=0.2, warm=50)
-            halotab.set_resident(True)
-            got = halotab.predict_batch(theta)
-            served = time_calls(lambda: halotab.predict_batch(theta), seconds=0.2, warm=50)
-            resident_walkers['%d' % n] = {
-                'us_per_call': served * 1e6, 'us_per_call_launched': launched * 1e6,
-                'max_rel_vs_launched': float(max(np.max(np.abs(got[0] / expect[0] - 1)),
-                                                 np.max(np.abs(got[1] / expect[1] - 1))))}
-    except Exception as error:   # noqa: BLE001 -- a secondary measurement must not end the bench
-        resident_walkers['failed'] = str(error)
-    finally:
-        try:
-            halotab.set_resident(False)
-        except Exception:   # noqa: BLE001
-            pass
-    return {'predict_model': single * 1e6,
-            'predict_model_resident': None if resident is None else resident * 1e6,
-            'predict_batch_walkers_resident': resident_walkers,
-            'predict_model_resident_max_rel_vs_one_launch_per_call': resident_parity,
-            'interpolator_5x5_predict_model': grid * 1e6,
-            'predict_batch_walkers': walkers,
-            'unit': 'us per call (Python API, host model -> host results)'}
-
-
-# ---- SURVEY 8f.4: pair counting for the tabulation step ---------------------------------------
-
-def tabulation(cpu_seconds):
-    """DD(r_p, pi) on the GPU (tabcorr/corrfunc.py:62-84, tabcorr/tabcorr.py:846-922): a
-    clustered sample in a 250 Mpc/h box, 19 r_p bins up to 30, pi_max = 40; the single pair
-    count, all 100 x 100 halo-bin pairs in one pass, and the brute-force NumPy oracle on a
-    subsample as the CPU baseline (bit-exact check included)."""
-    from tabcorr_amd import corrfunc
-    from oracle import paircount_oracle
-    rng = np.random.default_rng(3)
-    box, n = 250.0, 400000
-    rp_bins = np.logspace(-1, np.log10(30.0), 20)
-    centres = rng.uniform(0, box, (n // 60, 3))
-    pos = np.mod(centres[rng.integers(0, len(centres), n)] + rng.normal(0, 3.0, (n, 3)), box)
-    label = rng.integers(0, 100, n)
-    corrfunc.pair_count_rppi(pos[:1000], rp_bins, 40.0, None, box)
-    t0 = time.perf_counter()
-    counts = corrfunc.pair_count_rppi(pos, rp_bins, 40.0, None, box)
-    auto_seconds = time.perf_counter() - t0
-    pairs = int(counts.sum())
-    order = np.argsort(label, kind='stable')
-    bins = np.split(pos[order], np.cumsum(np.bincount(label, minlength=100))[:-1])
-    t0 = time.perf_counter()
-    matrix = corrfunc.pair_count_matrix(bins, rp_bins, 40.0, box)
-    matrix_seconds = time.perf_counter() - t0
-    out = {'workload': '%d clustered points, box 250, 19 rp bins to 30, pi_max 40, host arrays '
-                       'in, counts out (cell sort on the host included)' % n,
-           'pairs_counted': pairs,
-           'auto_count_ms': auto_seconds * 1e3, 'auto_pairs_per_sec': pairs / auto_seconds,
-           'all_100x100_bin_pairs_ms': matrix_seconds * 1e3,
-           'all_bin_pairs_pairs_per_sec': pairs / matrix_seconds,
-           'all_bin_pairs_consistent': bool(int(matrix.sum()) == pairs)}
-    if cpu_seconds > 0:
-        sub = pos[:6000]
-        t0 = time.perf_counter()
-        expect = paircount_oracle.pair_count_rppi(sub, None, box, rp_bins, 40.0)
-        spent = time.perf_counter() - t0
-        got = corrfunc.pair_count_rppi(sub, rp_bins, 40.0, None, box)
-        out['cpu_baseline'] = {
-            'value': len(sub)**2 / spent, 'unit': 'pair tests/s', 'cores': 1, 'kind': 'port',
-            'sample': 'brute-force NumPy oracle on %d points (%.1f s)' % (len(sub), spent),
-            'gpu_bit_exact': bool(np.array_equal(got, expect))}
-        out['gpu_pair_tests_per_sec_equivalent'] = float(n)**2 / auto_seconds
-    return out
-
-
-# ---- BASELINE configs[2], [3], [4] ----------------------------------------------------------
-
-CONFIG_TAGS = ('cfg3', 'cfg4', 'cfg5f32', 'cfg5f64', 'ds4', 'ds1', 'wp', 'db')
-
-
-def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=None, lanes=0,
-                  options=()):
-    """BASELINE configs[2] ('cfg3': separate + assembly bias), configs[3] ('cfg4': one GPU's
-    share of the 5 x 5 interpolator), configs[4] in float32 and float64 ('cfg5f32',
-    'cfg5f64'): device rate, host rate, the dominant kernel serialised with per-launch
-    events, its roofline fraction and committed traffic, the whole step's fraction, an oracle
-    spot check of the first and last draws of the timed batch, the CPU port.  `only`: one
-    tag (what tools/profile_round.sh wraps in rocprofv3)."""
-    from oracle import tabcorr_oracle as oracle
-    out = {}
-    dev = Device(lib, _lib)
-    theta = synthetic.zheng07_draws(10000, seed=1)
-    cpu_budget = min(3.0, cpu_seconds / 4) if cpu_seconds > 0 else 0.0
-
-    def wanted(tag):
-        return only is None or only == tag
-
-    def cpu_rate(call, n_max=100000):
-        if cpu_budget <= 0:
-            return None
-        call(0)
-        start = time.perf_counter()
-        count = 0
-        while time.perf_counter() - start < cpu_budget and count < n_max:
-            call(count)
-            count += 1
-        spent = time.perf_counter() - start
-        return {'value': count / spent, 'unit': 'calls/s', 'cores': 1, 'kind': 'port',
-                'sample': '%d sequential predict() calls in %.1f s' % (count, spent)}
-
-    def measure(name, tag, what, timer_handle, launch, synchronize, host_call, n_draws, flop,
-                peak, kernel, dtype, cpu, parity, fused_kernel=None, bound='mfma',
-                set_options=None):
-        """`kernel`: the dominant kernel of the three-kernel form; `fused_kernel`: the one-launch
-        kernel the library may choose for the pipelined calls of this configuration (its name
-        as rocprofv3 prints it).  The record's `kernel` is the one that ran in the timed
-        region; the serialised three-kernel figures sit under `three_kernel_path`.
-        `set_options(name, value)`: sets an option on every table handle of the workload."""
-        if set_options is None:
-            def set_options(key, value):
-                _lib.check(lib.tc_table_set_option(timer_handle, key, value))
-        if lanes > 0:
-            _lib.check(lib.tc_table_set_option(timer_handle, b'lanes', lanes))
-        for option in options:          # (developer A/B: --option name=value)
-            key, value = option.split('=')
-            set_options(key.encode(), int(value))
-        device_seconds = sustained(launch, synchronize)
-        shape = [ctypes.c_int() for _ in range(4)]
-        lib.tc_table_last_launch(timer_handle, *[ctypes.byref(v) for v in shape])
-        # (the pipelined calls of device_calls_per_sec: one launch per call where the library
-        # chose a one-launch form -- no slabs of partial sums --, else the three kernels)
-        one_launch = shape[2].value == 0 and shape[1].value > 0
-        pipelined = ('one launch per call: %s, %d workgroups of %d waves'
-                     % (fused_kernel or 'one-launch kernel', shape[0].value, shape[1].value)
-                     if one_launch else 'occupation, contraction, finalisation kernels')
-        # the dominant kernel of THAT stream of calls: per-launch start / stop events, launches
-        # of different lanes overlapping as in the timed region
-        pipelined_ms, n_pipelined, pipelined_wall_ms = kernel_time(
-            lib, _lib, timer_handle, launch, synchronize, n_launches=300, max_seconds=0.6)
-        # ... and the three-kernel form, kernels serialised (one lane, one-launch forms off)
-        _lib.check(lib.tc_table_set_option(timer_handle, b'pipeline', 0))
-        user_fused = dict(o.split('=') for o in options).get('fused', '1')
-        set_options(b'fused', 0)
-        kernel_ms, n_launch, _ = kernel_time(lib, _lib, timer_handle, launch, synchronize,
-                                             n_launches=300, max_seconds=0.6)
-        set_options(b'fused', int(user_fused))
-        _lib.check(lib.tc_table_set_option(timer_handle, b'pipeline', 1))
-        host_seconds = time_calls(host_call, seconds=0.4, warm=3)
-        launch()
-        synchronize()
-        ran = fused_kernel if one_launch and fused_kernel else kernel
-        traffic, source = pmc_traffic(ran, tag)
-        concurrency = pipelined_ms / pipelined_wall_ms
-        record = {
-            'workload': what, 'tag': tag, 'dtype': dtype, 'draws_per_call': n_draws,
-            'device_calls_per_sec': n_draws / device_seconds,
-            'us_per_step': device_seconds * 1e6,
-            'device_calls_run_as': pipelined,
-            'host_to_host_calls_per_sec': n_draws / host_seconds,
-            'kernel': ran,
-            'kernel_us': pipelined_ms * 1e3, 'launches_timed': n_pipelined,
-            'concurrent_launches': concurrency,
-            'kernel_method': 'per-launch start/stop events (hipExtLaunchKernelGGL) in the '
-                             'pipelined stream of calls of device_calls_per_sec; launches of '
-                             'different lanes overlap: concurrent_launches = kernel_us / wall '
-                             'time per launch',
-            'flop_per_launch': flop, 'peak_tflops': peak,
-            'frac_by_duration': flop / (pipelined_ms * 1e-3) / 1e12 / peak,
-            'frac': flop / (pipelined_ms / max(concurrency, 1.0) * 1e-3) / 1e12 / peak,
-            'frac_method': 'flop_per_launch / (kernel_us / concurrent_launches) / peak: a '
-                           "launch's share of the chip; frac_by_duration = flop_per_launch / "
-                           'kernel_us / peak',
-            'step_frac': flop / device_seconds / 1e12 / peak,
-            'three_kernel_path': {
-                'kernel': kernel, 'kernel_us': kernel_ms * 1e3, 'launches_timed': n_launch,
-                'frac': flop / (kernel_ms * 1e-3) / 1e12 / peak,
-                'note': 'dominant kernel of the three-kernel form, kernels serialised (one '
-                        'lane, one-launch forms off): flop_per_launch / kernel_us / peak'},
-            'traffic': traffic, 'traffic_source': source,
-            'parity_max_rel_vs_oracle': parity(), 'cpu_baseline': cpu}
-        insts = pmc_counter(ran, 'SQ_INSTS_VALU', tag)
-        if insts is not None:
-            # vector-ALU issue: one wave instruction occupies its SIMD for 4 cycles
-            record['valu'] = {
-                'wave_instructions_per_launch': insts,
-                'frac': insts * 4.0 / (1024 * device_seconds * 2.4e9),
-                'what': 'SQ_INSTS_VALU per launch of %s (%s) x 4 cycles / (1024 SIMDs x step '
-                        'time x 2.4 GHz): share of the vector issue slots of the timed region '
-                        'this kernel fills' % (ran, os.path.relpath(pmc_file(tag), REPO))}
-            mfma = pmc_counter(ran, 'SQ_VALU_MFMA_BUSY_CYCLES', tag)
-            if mfma is not None:
-                record['valu']['matrix_pipe_busy'] = mfma / (1024 * device_seconds * 2.4e9)
-        record['bound'] = bound
-        out[name] = record
-
-    def rel(actual, expect, floor=1e-14):
-        scale = floor * np.max(np.abs(expect))
-        return float(np.max(np.abs(actual - expect) / np.maximum(np.abs(expect), scale)))
-
-    # configs[2]: separate_gal_type + assembly bias on a 2-D halo-bin grid
-    if wanted('cfg3'):
-        table3 = synthetic.synthetic_table(50, 2, (N_R, ), 'auto', seed=3)
-        theta7 = np.hstack([theta, np.random.default_rng(0).uniform(-1, 1, (10000, 2))])
-        tab3 = make(table3)
-        h3 = tab3.to_device().handle
-        d_theta7 = dev.upload(theta7)
-        d_ngal, d_xi = dev.malloc(2 * 10000), dev.malloc(3 * N_R * 10000)
-        flags3 = FLAG_SEPARATE | FLAG_ASSEMBIAS
-        cache3 = {}
-        ends = np.r_[0:2, 9998:10000]
-
-        def parity3():
-            ngal = dev.download(d_ngal, 2 * 10000).reshape(10000, 2)
-            xi = dev.download(d_xi, 3 * N_R * 10000).reshape(10000, 3, N_R)
-            expect = oracle.predict_zheng07_batch(table3, theta7[ends, :5],
-                                                  separate_gal_type=True,
-                                                  assembias=theta7[ends, 5:])
-            worst = max(rel(ngal[ends, i], expect[0][key])
-                        for i, key in enumerate(('centrals', 'satellites')))
-            return max([worst] + [rel(xi[ends, i], expect[1][key]) for i, key in enumerate(
-                ('centrals-centrals', 'centrals-satellites', 'satellites-satellites'))])
-        measure('configs[2]', 'cfg3', 'separate_gal_type=True + Heaviside assembly bias, 50 x 2 x '
-                '{cen,sat} bins (G=200, P=20100), 19 rp bins, 10^4 draws', h3,
-                lambda: _lib.check(lib.tc_predict_zheng07_batch_device(
-                    h3, d_theta7, 7, 10000, N_GAUSS, flags3, d_ngal, d_xi)),
-                lambda: _lib.check(lib.tc_table_synchronize(h3)),
-                lambda: tab3.predict_batch(theta7, separate_gal_type=True, assembias=True),
-                10000, 10000 * pair_flops(200, N_R), FP64_PEAK_TFLOPS,
-                'tc::contract_quad_kernel<5, false>', 'f64',
-                cpu_rate(lambda i: oracle.predict_zheng07(
-                    table3, theta7[i % 10000, :5], separate_gal_type=True,
-                    assembias=theta7[i % 10000, 5:], cache=cache3)), parity3,
-                fused_kernel='tc::predict_fused_kernel<10, 5, true, false, false, 8, 32, true>')
-        del tab3
-
-    # configs[3]: one GPU's share (12 500 draws) of the 5 x 5 interpolator
-    if wanted('cfg4'):
-        tables, keys, points = synthetic.synthetic_interpolator((5, 5), N_PRIM, N_SEC, (N_R, ),
-                                                                'auto', seed=7)
-        interp = Interpolator([make(t) for t in tables],
-                              {k: points[:, d] for d, k in enumerate(keys)})
-        n4 = 12500
-        theta4 = synthetic.zheng07_draws(n4, seed=5)
-        rng = np.random.default_rng(6)
-        x4 = np.ascontiguousarray(np.stack(
-            [rng.uniform(xp[0], xp[-1], size=n4) for xp in interp.xp], axis=-1))
-        idev = interp.to_device()
-        d_theta4, d_x4 = dev.upload(theta4), dev.upload(x4)
-        d_ngal4, d_xi4 = dev.malloc(n4), dev.malloc(n4 * N_R)
-        setup = oracle.interpolator_setup(tables, points)
-        ends4 = np.r_[0:2, n4 - 2:n4]
-
-        def parity4():
-            expect = oracle.interpolator_predict_zheng07_batch(tables, setup, theta4[ends4],
-                                                               x4[ends4])
-            return max(rel(dev.download(d_ngal4, n4)[ends4], expect[0]),
-                       rel(dev.download(d_xi4, n4 * N_R).reshape(n4, N_R)[ends4], expect[1],
-                           floor=1e-12))
-        measure('configs[3]', 'cfg4', 'Interpolator.predict over a 5 x 5 grid of configs[1] '
-                "tables, one GPU's share of 10^5 draws (12 500)", idev.tables[0].handle,
-                lambda: _lib.check(lib.tc_interp_predict_zheng07_batch_device(
-                    idev.handle, d_theta4, 5, d_x4, n4, N_GAUSS, 0, d_ngal4, d_xi4)),
-                lambda: _lib.check(lib.tc_interp_synchronize(idev.handle)),
-                lambda: interp.predict_batch(theta4, x4), n4,
-                n4 * 25 * pair_flops(100, N_R), FP64_PEAK_TFLOPS,
-                'tc::contract_quad_kernel<5, true>', 'f64',
-                cpu_rate(lambda i: oracle.interpolator_predict(
-                    tables, setup, oracle.Zheng07(theta4[i % n4]), x4[i % n4])), parity4)
-        del interp, idev
-
-    # ---- the reference's own table shapes (VERDICT r03: throughput evidence on them) ----------
-    golden = os.path.join(REPO, 'tests', 'golden')
-    valu_peak = 1024 * 2.4e9 / 4 * 1e-12     # wave instructions per second (x 1e-12)
-
-    # the reference's AbacusSummit fixture (tests/AbacusSummit/.../ds_efficient.hdf5): mode
-    # cross, G = 1104 (280 mass bins x 2 percentile bins x {cen, sat}), 13 r values, a 4-table
-    # interpolator over log_eta -- the step is all occupations (vector ALU), one launch per call
-    if wanted('ds4') or wanted('ds1'):
-        from tabcorr_amd import TabCorr
-        interp = Interpolator.read(os.path.join(golden, 'ds_efficient.hdf5'))
-        rng = np.random.default_rng(0)
-        theta_ds = theta.copy()
-        theta_ds[:, 0] = rng.uniform(12.5, 13.3, 10000)     # (a sample this table resolves)
-        theta_ds[:, 3] = rng.uniform(13.6, 14.4, 10000)
-        x_ds = np.ascontiguousarray(np.stack(
-            [rng.uniform(xp[0], xp[-1], size=10000) for xp in interp.xp], axis=-1))
-        ds_tables = [{'gal_type': t.gal_type.as_array(), 'tpcf_matrix': t.tpcf_matrix,
-                      'tpcf_shape': t.tpcf_shape, 'attrs': t.attrs}
-                     for t in interp.tabcorr_list]
-        n_bins_ds, n_r_ds = len(ds_tables[0]['gal_type']), 13
-        d_theta_ds, d_x_ds = dev.upload(theta_ds), dev.upload(x_ds)
-        d_ngal_ds, d_xi_ds = dev.malloc(10000), dev.malloc(10000 * n_r_ds)
-        ends_ds = np.r_[0:2, 9998:10000]
-        # (the survey's accounting: contraction 2 R G + G per table, occupations 4 G n_gauss)
-        flop_table = 2.0 * n_r_ds * n_bins_ds + n_bins_ds
-        flop_occ = 4.0 * n_bins_ds * N_GAUSS
-        if wanted('ds4'):
-            idev = interp.to_device()
-            # (row k of the grid table describes tabcorr_list[tabcorr_index[k]])
-            points = np.zeros((len(ds_tables), len(interp.keys)))
-            index = np.asarray(interp.param_dict_table['tabcorr_index'], dtype=int)
-            for d, key in enumerate(interp.keys):
-                points[index, d] = np.asarray(interp.param_dict_table[key], dtype=float)
-            setup = oracle.interpolator_setup(ds_tables, points)
-
-            def parity_ds4():
-                expect = oracle.interpolator_predict_zheng07_batch(
-                    ds_tables, setup, theta_ds[ends_ds], x_ds[ends_ds])
-                return max(rel(dev.download(d_ngal_ds, 10000)[ends_ds], expect[0]),
-                           rel(dev.download(d_xi_ds, 10000 * n_r_ds).reshape(
-                               10000, n_r_ds)[ends_ds], expect[1], floor=1e-12))
-            measure('reference fixture: AbacusSummit interpolator', 'ds4',
-                    "the reference's tests/AbacusSummit/base_c000_ph000/0p50/ds_efficient.hdf5: "
-                    'Interpolator over 4 tables, mode cross, G=1104 (280 mass x 2 percentile '
-                    'bins x {cen,sat}), 13 r values, 10^4 draws', idev.tables[0].handle,
-                    lambda: _lib.check(lib.tc_interp_predict_zheng07_batch_device(
-                        idev.handle, d_theta_ds, 5, d_x_ds, 10000, N_GAUSS, 0, d_ngal_ds,
-                        d_xi_ds)),
-                    lambda: _lib.check(lib.tc_interp_synchronize(idev.handle)),
-                    lambda: interp.predict_batch(theta_ds, x_ds), 10000,
-                    10000 * (4 * flop_table + flop_occ), FP64_PEAK_TFLOPS,
-                    'tc::occ_zheng07_kernel<10, false, false, true>', 'f64',
-                    cpu_rate(lambda i: oracle.interpolator_predict(
-                        ds_tables, setup, oracle.Zheng07(theta_ds[i % 10000]),
-                        x_ds[i % 10000])), parity_ds4,
-                    fused_kernel='tc::predict_cross_fused_kernel<8, false, false>',
-                    bound='valu')
-            del idev
-        if wanted('ds1'):
-            tab_ds = interp.tabcorr_list[0]
-            h_ds = tab_ds.to_device().handle
-            cache_ds = {}
-
-            def parity_ds1():
-                expect = oracle.predict_zheng07_batch(ds_tables[0], theta_ds[ends_ds])
-                return max(rel(dev.download(d_ngal_ds, 10000)[ends_ds], expect[0]),
-                           rel(dev.download(d_xi_ds, 10000 * n_r_ds).reshape(
-                               10000, n_r_ds)[ends_ds], expect[1]))
-            measure('reference fixture: AbacusSummit table', 'ds1',
-                    'the first table of that file by itself: mode cross, G=1104, 13 r values, '
-                    '10^4 draws', h_ds,
-                    lambda: _lib.check(lib.tc_predict_zheng07_batch_device(
-                        h_ds, d_theta_ds, 5, 10000, N_GAUSS, 0, d_ngal_ds, d_xi_ds)),
-                    lambda: _lib.check(lib.tc_table_synchronize(h_ds)),
-                    lambda: tab_ds.predict_batch(theta_ds), 10000,
-                    10000 * (flop_table + flop_occ), FP64_PEAK_TFLOPS,
-                    'tc::occ_zheng07_kernel<10, false, false, true>', 'f64',
-                    cpu_rate(lambda i: oracle.predict_zheng07(
-                        ds_tables[0], theta_ds[i % 10000], cache=cache_ds)), parity_ds1,
-                    fused_kernel='tc::predict_cross_small_kernel<false, false>', bound='valu')
-        del interp
-
-    # the reference's example table (docs/examples/bolplanck_wp.hdf5: G = 60, 19 r values)
-    if wanted('wp'):
-        from tabcorr_amd import TabCorr
-        tab_wp = TabCorr.read(os.path.join(golden, 'bolplanck_wp.hdf5'))
-        table_wp = {'gal_type': tab_wp.gal_type.as_array(), 'tpcf_matrix': tab_wp.tpcf_matrix,
-                    'tpcf_shape': tab_wp.tpcf_shape, 'attrs': tab_wp.attrs}
-        h_wp = tab_wp.to_device().handle
-        d_theta_wp = dev.upload(theta)
-        d_ngal_wp, d_xi_wp = dev.malloc(10000), dev.malloc(10000 * N_R)
-        ends_wp = np.r_[0:2, 9998:10000]
-        cache_wp = {}
-
-        def parity_wp():
-            expect = oracle.predict_zheng07_batch(table_wp, theta[ends_wp])
-            return max(rel(dev.download(d_ngal_wp, 10000)[ends_wp], expect[0]),
-                       rel(dev.download(d_xi_wp, 10000 * N_R).reshape(10000, N_R)[ends_wp],
-                           expect[1]))
-        measure('reference example: bolplanck wp table', 'wp',
-                "the reference's docs/examples/bolplanck_wp.hdf5 (BASELINE configs[0]'s table): "
-                '30 mass bins x {cen,sat} (G=60, P=1830), 19 rp bins, 10^4 draws', h_wp,
-                lambda: _lib.check(lib.tc_predict_zheng07_batch_device(
-                    h_wp, d_theta_wp, 5, 10000, N_GAUSS, 0, d_ngal_wp, d_xi_wp)),
-                lambda: _lib.check(lib.tc_table_synchronize(h_wp)),
-                lambda: tab_wp.predict_batch(theta), 10000, 10000 * pair_flops(60, N_R),
-                FP64_PEAK_TFLOPS, 'tc::contract_quad_kernel<5, false>', 'f64',
-                cpu_rate(lambda i: oracle.predict_zheng07(table_wp, theta[i % 10000],
-                                                          cache=cache_wp)), parity_wp,
-                fused_kernel='tc::predict_fused_kernel<10, 5, false, false, false, 8, 64, false>')
-        del tab_wp
-
-    # the layout of the reference's database (scripts/tabulate_snapshot.py:179-193: 30 mass bins x
-    # 2 percentile bins; tabcorr/database.py:56-59: grids of up to 4 x 4 x 4 tables)
-    if wanted('db'):
-        tables_db, keys_db, points_db = synthetic.synthetic_interpolator(
-            (4, 4, 4), 30, 2, (N_R, ), 'auto', seed=11)
-        interp_db = Interpolator([make(t) for t in tables_db],
-                                 {k: points_db[:, d] for d, k in enumerate(keys_db)})
-        n_db = 10000
-        rng = np.random.default_rng(12)
-        x_db = np.ascontiguousarray(np.stack(
-            [rng.uniform(xp[0], xp[-1], size=n_db) for xp in interp_db.xp], axis=-1))
-        idev_db = interp_db.to_device()
-        d_theta_db, d_x_db = dev.upload(theta), dev.upload(x_db)
-        d_ngal_db, d_xi_db = dev.malloc(n_db), dev.malloc(n_db * N_R)
-        setup_db = oracle.interpolator_setup(tables_db, points_db)
-        ends_db = np.r_[0:1, n_db - 1:n_db]
-
-        def parity_db():
-            expect = oracle.interpolator_predict_zheng07_batch(tables_db, setup_db,
-                                                               theta[ends_db], x_db[ends_db])
-            return max(rel(dev.download(d_ngal_db, n_db)[ends_db], expect[0]),
-                       rel(dev.download(d_xi_db, n_db * N_R).reshape(n_db, N_R)[ends_db],
-                           expect[1], floor=1e-12))
-        measure('reference database layout', 'db',
-                'Interpolator over a 4 x 4 x 4 grid (tabcorr/database.py:56-59) of synthetic auto '
-                'tables with 30 mass x 2 percentile bins x {cen,sat} (G=120, P=7260; '
-                'scripts/tabulate_snapshot.py:179-193), 19 rp bins, 10^4 draws',
-                idev_db.tables[0].handle,
-                lambda: _lib.check(lib.tc_interp_predict_zheng07_batch_device(
-                    idev_db.handle, d_theta_db, 5, d_x_db, n_db, N_GAUSS, 0, d_ngal_db,
-                    d_xi_db)),
-                lambda: _lib.check(lib.tc_interp_synchronize(idev_db.handle)),
-                lambda: interp_db.predict_batch(theta, x_db), n_db,
-                n_db * 64 * pair_flops(120, N_R), FP64_PEAK_TFLOPS,
-                'tc::contract_quad_kernel<5, true>', 'f64',
-                cpu_rate(lambda i: oracle.interpolator_predict(
-                    tables_db, setup_db, oracle.Zheng07(theta[i % n_db]), x_db[i % n_db])),
-                parity_db)
-        del interp_db, idev_db
-
-    # configs[4]: AbacusSummit-scale table, rp_pi (19 x 40), float32 MFMA variant and float64
-    if wanted('cfg5f32') or wanted('cfg5f64'):
-        table5 = synthetic.synthetic_table(100, 1, (19, 40), 'auto', seed=9)
-        n_r5 = 760
-        d_ngal5, d_xi5 = dev.malloc(10000), dev.malloc(10000 * n_r5)
-        d_theta5 = dev.upload(theta)
-        cache5 = {}
-        cpu5 = cpu_rate(lambda i: oracle.predict_zheng07(table5, theta[i % 10000], cache=cache5))
-        ends5 = np.r_[0, 9999]
-        expect5 = oracle.predict_zheng07_batch(table5, theta[ends5])
-
-        def parity5():
-            xi = dev.download(d_xi5, 10000 * n_r5).reshape((10000, ) + expect5[1].shape[1:])
-            return max(rel(dev.download(d_ngal5, 10000)[ends5], expect5[0]),
-                       rel(xi[ends5], expect5[1]))
-        for dtype, tag, peak, kernel in (
-                ('float32', 'cfg5f32', FP32_PEAK_TFLOPS, 'tc::contract_quad_f32_kernel<4, false>'),
-                ('float64', 'cfg5f64', FP64_PEAK_TFLOPS, 'tc::contract_quad_kernel<5, false>')):
-            if not wanted(tag):
-                continue
-            tab5 = make(table5, compute_dtype=dtype)
-            h5 = tab5.to_device().handle
-            measure('configs[4] ' + dtype, tag, 'rp_pi table 19 x 40 (R=760), 100 x {cen,sat} '
-                    'bins (G=200, P=20100), 10^4 draws, %s table and contraction' % dtype, h5,
-                    lambda: _lib.check(lib.tc_predict_zheng07_batch_device(
-                        h5, d_theta5, 5, 10000, N_GAUSS, 0, d_ngal5, d_xi5)),
-                    lambda: _lib.check(lib.tc_table_synchronize(h5)),
-                    lambda: tab5.predict_batch(theta), 10000, 10000 * pair_flops(200, n_r5),
-                    peak, kernel, 'f32' if dtype == 'float32' else 'f64', cpu5, parity5)
-            del tab5
-    dev.free_all()
-    return out
-
-
-def cpu_baseline(table, seconds):
-    """The NumPy port of the reference's predict() (oracle), one call per draw as
-    in the reference's usage (README.md:72-75), on one host core."""
-    from oracle import tabcorr_oracle as oracle
-    from tabcorr_amd import synthetic
-    theta = synthetic.zheng07_draws(200000, seed=99)
-    cache = {}
-    oracle.predict_zheng07(table, theta[0], cache=cache)       # builds the caches
-    start = time.perf_counter()
-    count = 0
-    while True:
-        for t in theta[count:count + 200]:
-            oracle.predict_zheng07(table, t, cache=cache)
-        count += 200
-        spent = time.perf_counter() - start
-        if spent >= seconds or count >= len(theta):
-            break
-    return {'value': count / spent, 'unit': 'calls/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d sequential predict() calls of the same workload (same '
-                      'table, draws from the same prior) in %.1f s' % (count, spent)}
-
-
-def _cpu_walker(job):
-    """One independent MCMC-style walker: sequential predict() calls for `seconds`."""
-    seed, seconds = job
-    from oracle import tabcorr_oracle as oracle
-    from tabcorr_amd import synthetic
-    table = synthetic.synthetic_table(N_PRIM, N_SEC, (N_R, ), 'auto', seed=0)
-    theta = synthetic.zheng07_draws(100000, seed=seed)
-    cache = {}
-    oracle.predict_zheng07(table, theta[0], cache=cache)
-    start = time.perf_counter()
-    count = 0
-    while time.perf_counter() - start < seconds and count < len(theta):
-        for t in theta[count:count + 100]:
-            oracle.predict_zheng07(table, t, cache=cache)
-        count += 100
-    return count, time.perf_counter() - start
-
-
-def cpu_baseline_all_cores(seconds):
-    """predict() is single-threaded in the reference, so "all host
-    cores" means one independent walker process per core."""
-    import multiprocessing
-    cores = min(len(os.sched_getaffinity(0)), 256)
-    with multiprocessing.get_context('fork').Pool(cores) as pool:
-        done = pool.map(_cpu_walker, [(1000 + i, seconds) for i in range(cores)])
-    return {'value': sum(count / spent for count, spent in done), 'unit': 'calls/s',
-            'cores': cores, 'kind': 'port',
-            'sample': '%d walker processes x %.1f s of sequential predict() calls'
-                      % (cores, seconds)}
 
 
 if __name__ == '__main__':
