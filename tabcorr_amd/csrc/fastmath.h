@@ -115,9 +115,11 @@ TC_HD double erf_fast(const double* table, const Consts& k, double x) {
 // holds the derivative at the row centre c, and exp(-(c + h)^2) = exp(-c^2) exp(-(2 c + h) h)
 // with |(2 c + h) h| <= 0.047: Taylor to degree 9 (3e-18).  For the moment expansion of a
 // bin's node sum (kernels.hip.h: central_series).
-TC_HD double erf_gauss_fast(const double* table, const Consts& k, double x, double* gauss) {
+TC_HD double erf_gauss_fast(const double* table, const Consts& k, double x, double* gauss,
+                            double* clamped = nullptr) {
   double t = fabs(x);
   t = t < 6.0 ? t : 6.0;
+  if (clamped != nullptr) *clamped = copysign(t, x);      // x within [-6, 6] (an infinite x too)
   const double u = t + kMagicErf;
   const double c = u - kMagicErf;
   const double h = t - c;

@@ -308,7 +308,11 @@ struct Tuning {
   // with the batch sizes an ensemble sampler has, the three kernels spread small batches
   // over the whole chip.  Asynchronous host calls (us per call, tools/archive/r03_async.py): 6144 draws
   // 38.8 / 41.6, 10^4 58 / 47.6, 20 000 93.7 / 82.6, 40 000 176 / 162: no upper bound there.
-  int series = 1;               // moment expansion of the central bins' node sums (series.h)
+  // moment expansions of the node sums (series.h): bit 0 central bins, bit 1 satellite bins.
+  // Off by default since round 5: a draw's bits must not depend on its neighbours in the
+  // batch, so every lane takes the terms ITS draw needs -- and on wide priors a wave then runs
+  // the expansion AND the node loop for most bins (measured: no gain; profiles/r05_notes.md)
+  int series = 0;
   int cross_target = 160;       // mode cross: workgroups a launch should have at least
                                 // (several per tile of 64 draws below that)
   int resident_aperture = 1;    // resident ensemble kernel: the mailbox in device memory that

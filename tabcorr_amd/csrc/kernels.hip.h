@@ -134,12 +134,12 @@ struct DrawParams {
   double log_m_min, inv_sigma, m0, log2_m1, sat_scale, alpha, a_cen, a_sat;
   int bad;
   bool any_bad;    // wave-uniform: does any draw of the tile need the NaN fix-ups?
-  // wave-uniform: high dword of the wave's largest |1 / sigma| -- what decides how many terms
-  // the moment expansion of a central bin needs (series.h); INT_MAX: expansion off
-  int series_hi = 0x7fffffff;
-  // ... and of the wave's largest M0: the binomial expansion of a satellite bin (series.h,
-  // namespace sat); INT_MAX: off (also when some draw's alpha lies outside [0, 4])
-  int sat_hi = 0x7fffffff;
+  // The moment expansions (series.h).  A LANE adds as many terms as its own draw needs --
+  // inv_sigma_hi: high dword of the draw's |1 / sigma| (central bins); m0_hi: of its M0, or
+  // INT_MAX where the expansion does not apply to the draw (centrals to fix up; satellites: alpha
+  // outside [0, 4], any fix-up) -- so that a draw's result does not depend on its neighbours in
+  // the wave.  INT_MAX: off.
+  int inv_sigma_hi = 0x7fffffff, m0_hi = 0x7fffffff;
 };
 
 // Constants of the moment expansion (launch.hip: get_quadrature): per bin (or member, in group
@@ -151,35 +151,26 @@ struct SeriesConsts {
   sc_i32 sat_thresholds = nullptr;
 };
 
-// High dword of the largest |value| of the wave's lanes (non-negative doubles order like their
-// high dwords; NaN and infinity come out above every threshold of series.h).
-__device__ inline int wave_max_high_dword(double value) {
-  int hi = (int)(fm::bits_of(fabs(value)) >> 32);
-#pragma unroll
-  for (int offset = 32; offset >= 1; offset >>= 1) {
-    const int other = __shfl_xor(hi, offset, 64);
-    hi = other > hi ? other : hi;
-  }
-  return __builtin_amdgcn_readfirstlane(hi);
-}
-
-// dp.series_hi / dp.sat_hi of a wave (series.h): what the expansions' term counts follow.
+// The expansions' per-lane keys (series.h): what a draw's term counts follow (non-negative
+// doubles order like their high dwords; NaN and infinity come out above every threshold).
 template <bool MODULATE>
-__device__ inline void series_setup(DrawParams& dp, bool on) {
-  dp.series_hi = on ? wave_max_high_dword(dp.inv_sigma) : 0x7fffffff;
-  const bool alpha_ok =
-      __builtin_amdgcn_ballot_w64(!(dp.alpha >= 0.0 && dp.alpha <= 4.0)) == 0;
-  dp.sat_hi = on && !MODULATE && alpha_ok && !dp.any_bad ? wave_max_high_dword(dp.m0)
-                                                          : 0x7fffffff;
+__device__ inline void series_setup(DrawParams& dp, bool on, bool sat_on) {
+  const bool sat_ok = sat_on && !MODULATE && dp.alpha >= 0.0 && dp.alpha <= 4.0 && dp.bad == 0;
+  // (a draw whose centrals are to be fixed up -- kBadCen: its parameters were replaced -- takes
+  // the node path, where the fix-ups are)
+  dp.inv_sigma_hi = on && !(dp.bad & kBadCen) ? (int)(fm::bits_of(fabs(dp.inv_sigma)) >> 32)
+                                              : 0x7fffffff;
+  // (fabs: a NaN M0 -- 10^inf from the table-driven exp10 -- may carry a sign bit)
+  dp.m0_hi = sat_ok ? (int)(fm::bits_of(fabs(dp.m0)) >> 32) : 0x7fffffff;
 }
 
 // (Mc - M0)^alpha / M1^alpha times the binomial sum of a satellite bin's moments.
 __device__ __forceinline__ double sat_series_value(const double* table, const fm::Consts& kc,
-                                                   sc_f64 consts, const DrawParams& d,
-                                                   int n_terms) {
+                                                   sc_f64 consts, sc_i32 thresholds,
+                                                   const DrawParams& d) {
   const double base = consts[0] - d.m0;
   const double eps = consts[0] * series::sat::reciprocal(base);
-  const double sum = series::sat::binomial_sum(consts, eps, d.alpha, n_terms);
+  const double sum = series::sat::binomial_sum(consts, eps, d.alpha, thresholds, d.m0_hi);
   return sum * fm::exp2_fast(table, kc,
                              d.alpha * fm::log2_fast_offset(table, kc, base, d.log2_m1));
 }
@@ -226,16 +217,22 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
     }
   }
 #endif
-  // the node sum of an undecorated central bin by its moment expansion (series.h) where every
-  // draw of the wave allows it: (half bin width) / sigma small enough, no draw to fix up
-  int n_terms = 0;
+  // the node sum of an undecorated central bin by its moment expansion (series.h) on the lanes
+  // whose own draw allows it -- (half bin width) / sigma small enough; the others run the node
+  // loop (both paths in a wave that holds both kinds of draws).  Per lane, so that a draw's
+  // bits do not depend on its neighbours.
+  bool series_cen = false, series_sat = false;     // this lane takes the expansion
   if (central && !assembias && shortcut == 0 && sr.consts != nullptr && n_gauss >= 4)
-    n_terms = series::terms_for(sr.thresholds + g * series::kThresholds, d.series_hi);
+    series_cen = series::eligible(sr.thresholds + g * series::kThresholds, d.inv_sigma_hi);
+  if (!central && !modulate && (!assembias || median) && shortcut == 0 &&
+      sr.sat_consts != nullptr && n_gauss >= 4)
+    series_sat = series::sat::eligible(sr.sat_thresholds + g * series::sat::kThresholds, d.m0_hi);
   if (shortcut != 0) {
     if (shortcut == 1) acc = weight_sum[g];
-  } else if (n_terms != 0) {
+  } else if (series_cen) {
     acc = series::central_sum(table, kc, log_m_min, inv_sigma, sr.consts + g * series::kStride,
-                              weight_sum[g], n_terms);
+                              weight_sum[g], sr.thresholds + g * series::kThresholds,
+                              d.inv_sigma_hi);
     acc = fma(0.5, acc, 0.5 * weight_sum[g]);
   } else if (central && !assembias) {
     // sum_k w_k (1 + erf_k) / 2 = (W + sum_k w_k erf_k) / 2 with W = sum_k w_k from the host
@@ -256,14 +253,10 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
                  : heaviside_assembias(n, a_cen, above, f2, f1, true);
       acc = fma(weight[g * n_gauss + k], n, acc);
     }
-  } else if (!central && !modulate && (!assembias || median) && shortcut == 0 &&
-             sr.sat_consts != nullptr && n_gauss >= 4 &&
-             series::sat::terms_for(sr.sat_thresholds + g * series::sat::kThresholds,
-                                    d.sat_hi) != 0) {
-    // a satellite bin well above every draw's M0: the binomial expansion of its node sum
-    acc = sat_series_value(table, kc, sr.sat_consts + g * series::sat::kStride, d,
-                           series::sat::terms_for(
-                               sr.sat_thresholds + g * series::sat::kThresholds, d.sat_hi));
+  } else if (series_sat) {
+    // a satellite bin well above the draw's M0: the binomial expansion of its node sum
+    acc = sat_series_value(table, kc, sr.sat_consts + g * series::sat::kStride,
+                           sr.sat_thresholds + g * series::sat::kThresholds, d);
     acc *= sat_scale;
     if (median) acc = fma(s_sat, acc, acc);
   } else {
@@ -431,15 +424,13 @@ __device__ __forceinline__ void occ_group_zheng07(const double* table, const fm:
   // the members share the recurrence, each adds its own moments)
   // (SERIES = false: compiled without it -- predict_cross_small_kernel, whose 16 row sums per
   // wave leave no registers for it: 142 with it, one workgroup per CU)
-  int n_terms = 0;
-  if (SERIES && central && !assembias && shortcut == 0 && q.series.consts != nullptr)
-    n_terms = series::terms_for(q.series.thresholds + m_begin * series::kThresholds,
-                                d.series_hi);
+  // Per LANE (series.h): a lane whose own draw allows the expansion takes it, the others the node
+  // path below -- `done` marks the former; a wave of both kinds runs both.
+  bool done = false;
   if (SERIES && !central && !modulate && shortcut == 0 && q.series.sat_consts != nullptr) {
-    const int sat_terms = series::sat::terms_for(
-        q.series.sat_thresholds + m_begin * series::sat::kThresholds, d.sat_hi);
-    if (sat_terms != 0) {
-      // a group of satellite bins well above every draw's M0: the binomial expansion; the
+    sc_i32 thresholds = q.series.sat_thresholds + m_begin * series::sat::kThresholds;
+    if (series::sat::eligible(thresholds, d.m0_hi)) {
+      // a group of satellite bins well above the draw's M0: the binomial expansion; the
       // members share Mc, eps and the coefficients
       sc_f64 first = q.series.sat_consts + m_begin * series::sat::kStride;
       const double base = first[0] - m0;
@@ -451,7 +442,7 @@ __device__ __forceinline__ void occ_group_zheng07(const double* table, const fm:
         double acc_i, acc_j;
         series::sat::binomial_sum_pair(q.series.sat_consts + mi * series::sat::kStride,
                                        q.series.sat_consts + mj * series::sat::kStride, eps,
-                                       alpha, sat_terms, &acc_i, &acc_j);
+                                       alpha, thresholds, d.m0_hi, &acc_i, &acc_j);
         acc_i = acc_i * power * sat_scale;
         acc_j = acc_j * power * sat_scale;
         if (median) {
@@ -463,24 +454,28 @@ __device__ __forceinline__ void occ_group_zheng07(const double* table, const fm:
         emit(mi, q.member[mi], acc_i);
         if (mj != mi) emit(mj, q.member[mj], acc_j);
       }
-      return;
+      done = true;
     }
   }
-  if (SERIES && n_terms != 0) {
-    // (a path of its own, so that the node path below stays one straight line whose scalar
-    // loads the compiler can start early)
-    for (int mi = m_begin; mi < m_end; mi += 2) {
-      const int mj = mi + 1 < m_end ? mi + 1 : mi;
-      double acc_i, acc_j;
-      series::central_sum_pair(table, kc, log_m_min, inv_sigma,
-                               q.series.consts + mi * series::kStride,
-                               q.series.consts + mj * series::kStride, q.weight_sum[mi],
-                               q.weight_sum[mj], n_terms, &acc_i, &acc_j);
-      emit(mi, q.member[mi], fma(0.5, acc_i, 0.5 * q.weight_sum[mi]));
-      if (mj != mi) emit(mj, q.member[mj], fma(0.5, acc_j, 0.5 * q.weight_sum[mj]));
+  if (SERIES && central && !assembias && shortcut == 0 && q.series.consts != nullptr) {
+    sc_i32 thresholds = q.series.thresholds + m_begin * series::kThresholds;
+    if (series::eligible(thresholds, d.inv_sigma_hi)) {
+      // (a path of its own, so that the node path below stays one straight line whose scalar
+      // loads the compiler can start early)
+      for (int mi = m_begin; mi < m_end; mi += 2) {
+        const int mj = mi + 1 < m_end ? mi + 1 : mi;
+        double acc_i, acc_j;
+        series::central_sum_pair(table, kc, log_m_min, inv_sigma,
+                                 q.series.consts + mi * series::kStride,
+                                 q.series.consts + mj * series::kStride, q.weight_sum[mi],
+                                 q.weight_sum[mj], thresholds, d.inv_sigma_hi, &acc_i, &acc_j);
+        emit(mi, q.member[mi], fma(0.5, acc_i, 0.5 * q.weight_sum[mi]));
+        if (mj != mi) emit(mj, q.member[mj], fma(0.5, acc_j, 0.5 * q.weight_sum[mj]));
+      }
+      done = true;
     }
-    return;
   }
+  if (done) return;
   // v[k]: centrals erf(z_k) (decorated: <N_cen> itself), satellites <N_sat> before the scale
   double v[kNodes];
   if (shortcut == 0) {
@@ -731,7 +726,8 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_zheng07_kernel(
     dp.bad = (int)prm[8][lane];
     // wave-uniform: does any draw of this tile need the NaN fix-ups after a bin's node loop?
     dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
-    series_setup<MODULATE>(dp, (GROUPED ? a.group.series : a.series) != nullptr);
+    series_setup<MODULATE>(dp, (GROUPED ? a.group.series : a.series) != nullptr,
+                           (GROUPED ? a.group.sat_series : a.sat_series) != nullptr);
 
     double sum_cen = 0.0, sum_sat = 0.0;
     auto emit = [&](int g, bool central, double acc, double n_h_g) {
@@ -2037,7 +2033,8 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
     dp.a_sat = d.a_sat;
     dp.bad = d.bad;
     dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
-    series_setup<MODULATE>(dp, (GROUPED ? a.group.series : a.series) != nullptr && DL == 64);
+    series_setup<MODULATE>(dp, (GROUPED ? a.group.series : a.series) != nullptr && DL == 64,
+                           (GROUPED ? a.group.sat_series : a.sat_series) != nullptr && DL == 64);
     sc_f64 log_m = (sc_f64)a.log_m;
     sc_f64 mass = (sc_f64)a.m;
     sc_f64 weight = (sc_f64)a.weight;
@@ -2299,7 +2296,7 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 2 : 4) void predict_cro
     dp.a_sat = d.a_sat;
     dp.bad = d.bad;
     dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
-    series_setup<MODULATE>(dp, a.group.series != nullptr);
+    series_setup<MODULATE>(dp, a.group.series != nullptr, a.group.sat_series != nullptr);
     sc_i32 group_begin = (sc_i32)a.group.begin;
     sc_i32 chunk_group = (sc_i32)a.chunk_group;
     const GroupConsts gq{(sc_f64)a.group.log_m, (sc_f64)a.group.m, (sc_f64)a.group.weight,
@@ -2539,7 +2536,7 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kerne
     dp.a_sat = d.a_sat;
     dp.bad = d.bad;
     dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
-    dp.series_hi = 0x7fffffff;       // (compiled without the moment expansion)
+    // (compiled without the moment expansion: dp's keys stay at INT_MAX)
     sc_i32 group_begin = (sc_i32)a.group.begin;
     const GroupConsts gq{(sc_f64)a.group.log_m, (sc_f64)a.group.m, (sc_f64)a.group.weight,
                          (sc_f64)a.group.weight + a.n_bins * 10, (sc_f64)a.group.percentile,

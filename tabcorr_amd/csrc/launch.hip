@@ -131,9 +131,9 @@ tc::GroupArgs group_args(const tc_table* t, const Quadrature& q) {
   ga.weight = (const double*)q.group_weight;
   ga.n_h = (const double*)t->d_group_n_h;
   ga.percentile = (const double*)t->d_group_percentile;
-  ga.series = t->tuning.series ? (const double*)q.group_series : nullptr;
+  ga.series = (t->tuning.series & 1) ? (const double*)q.group_series : nullptr;
   ga.series_thr = (const int32_t*)q.group_series_thr;
-  ga.sat_series = t->tuning.series ? (const double*)q.group_sat_series : nullptr;
+  ga.sat_series = (t->tuning.series & 2) ? (const double*)q.group_sat_series : nullptr;
   ga.sat_series_thr = (const int32_t*)q.group_sat_series_thr;
   return ga;
 }
@@ -971,9 +971,9 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   oa.n_groups = t->node_groups.n_groups;
   oa.n_central_groups = t->node_groups.n_central_groups;
   oa.group = group_args(t, *q);
-  oa.series = t->tuning.series ? (const double*)q->series : nullptr;
+  oa.series = (t->tuning.series & 1) ? (const double*)q->series : nullptr;
   oa.series_thr = (const int32_t*)q->series_thr;
-  oa.sat_series = t->tuning.series ? (const double*)q->sat_series : nullptr;
+  oa.sat_series = (t->tuning.series & 2) ? (const double*)q->sat_series : nullptr;
   oa.sat_series_thr = (const int32_t*)q->sat_series_thr;
   {
     const dim3 grid((unsigned)grid_blocks), block(tc::kOccWaves * 64);
@@ -1275,9 +1275,9 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   fa.n_groups = t->node_groups.n_groups;
   fa.n_central_groups = t->node_groups.n_central_groups;
   fa.group = group_args(t, *q);
-  fa.series = t->tuning.series ? (const double*)q->series : nullptr;
+  fa.series = (t->tuning.series & 1) ? (const double*)q->series : nullptr;
   fa.series_thr = (const int32_t*)q->series_thr;
-  fa.sat_series = t->tuning.series ? (const double*)q->sat_series : nullptr;
+  fa.sat_series = (t->tuning.series & 2) ? (const double*)q->sat_series : nullptr;
   fa.sat_series_thr = (const int32_t*)q->sat_series_thr;
   fa.log_m = (const double*)q->log_m;
   fa.m = (const double*)q->m;

@@ -339,7 +339,8 @@ int tc_debug_central_series(int n_gauss, double log_min, double log_max, double 
     memcpy(&bits, &magnitude, sizeof(bits));
     terms[i] = tc::series::terms_for(thresholds.data(), (int)(bits >> 32));
     series[i] = terms[i] > 0 ? tc::series::central_sum(table.data(), kc, log_m_min[i], inv_sigma,
-                                                       consts.data(), m0, terms[i])
+                                                       consts.data(), m0, thresholds.data(),
+                                                       (int)(bits >> 32))
                              : sum;
   }
   return TC_OK;
@@ -438,7 +439,8 @@ int tc_debug_satellite_series(int n_gauss, double log_min, double log_max, doubl
     if (terms[i] > 0) {
       const double base = consts[0] - m0;
       const double eps = consts[0] * tc::series::sat::reciprocal(base);
-      const double s = tc::series::sat::binomial_sum(consts.data(), eps, alpha[i], terms[i]);
+      const double s = tc::series::sat::binomial_sum(consts.data(), eps, alpha[i],
+                                                     thresholds.data(), (int)(bits >> 32));
       series[i] = s * tc::fm::exp2_fast(table.data(), kc,
                                         alpha[i] * tc::fm::log2_fast_offset(table.data(), kc, base,
                                                                             hi)) * sat_scale;

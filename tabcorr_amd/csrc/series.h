@@ -40,8 +40,14 @@ double h_max(int n_terms);
 void bin_consts(int n_gauss, const double* log_m, const double* weight, double log_min,
                 double log_max, double* consts, int32_t* thresholds);
 
-// Number of terms for a wave whose largest |1 / sigma| has the high dword `inv_sigma_hi`
-// (0: the expansion does not apply, run the node loop).
+// Number of terms for a draw whose |1 / sigma| has the high dword `inv_sigma_hi` (0: the
+// expansion does not apply, run the node loop).
+//
+// In the kernels a LANE adds the terms its OWN draw asks for, so that a draw's result depends
+// on nothing but the draw -- the same bits wherever it sits in whatever batch: a lane takes
+// the expansion when eligible(thresholds, its key) and leaves the loop of passes (four terms
+// each) when its key is below the next pass's threshold; the wave's loop ends with its last
+// lane.  The thresholds increase with the number of terms (0: never); keys are non-negative.
 template <typename IntPtr>
 TC_HD int terms_for(IntPtr thresholds, int inv_sigma_hi) {
   int n = 0;
@@ -53,12 +59,28 @@ TC_HD int terms_for(IntPtr thresholds, int inv_sigma_hi) {
   return n;
 }
 
+template <typename IntPtr>
+TC_HD bool eligible(IntPtr thresholds, int inv_sigma_hi) {
+  return inv_sigma_hi < thresholds[kSteps - 1];
+}
+
+// A draw with the key `hi` adds the terms of pass `block` when hi >= pass_threshold(thresholds,
+// block) -- that is, block < terms_for(...) / 4; the first two passes are the fewest any draw
+// takes, and an eligible draw fails the test at block = kMaxTerms / 4 at the latest.  The loops
+// below request a pass's moments one pass and its threshold TWO passes ahead (the exit test of a
+// pass must not wait for a load issued in that pass).
+template <typename IntPtr>
+TC_HD int pass_threshold(IntPtr thresholds, int block) {
+  const int value = thresholds[block > 2 ? block - 2 : 0];      // (no branch: load + select)
+  return block < 2 ? 0 : value;
+}
+
 // sum_k W_k erf((log M_k - log_m_min) inv_sigma) of the bin whose constants are `consts`, by
-// n_terms (a multiple of 4) terms of the expansion; m0 = sum_k W_k.  Uniform steps from
+// the terms of the expansion an ELIGIBLE draw needs; m0 = sum_k W_k.  Uniform steps from
 // (p_-1, p_0) = (0, 1 / sigma): term n adds p_(n-1) M_n, then p_n = a p_(n-1) + (n - 1) b p_(n-2).
 // Four terms per pass of a loop that is NOT unrolled (the unrolled forms took 150-200 vector
-// registers in the kernels); the next pass's four moments are requested -- one scalar load --
-// before the current ones are used.
+// registers in the kernels); the next pass's four moments and its threshold are requested --
+// scalar loads -- before the current ones are used.
 struct f64x4_t {
   double v[4];
   TC_HD double operator[](int k) const { return v[k]; }
@@ -80,21 +102,27 @@ TC_HD f64x4_t load_moments(Ptr consts, int block) {
   return load_four(consts, 2, block);
 }
 
-template <typename Ptr>
+template <typename Ptr, typename IntPtr>
 TC_HD double central_sum(const double* table, const fm::Consts& kc, double log_m_min,
-                         double inv_sigma, Ptr consts, double m0, int n_terms) {
-  const double z0 = (consts[0] - log_m_min) * inv_sigma;
-  double g0;
-  const double e = fm::erf_gauss_fast(table, kc, z0, &g0);
+                         double inv_sigma, Ptr consts, double m0, IntPtr thresholds,
+                         int inv_sigma_hi) {
+  constexpr int kLastBlock = kMaxTerms / 4 - 1;
+  // (the recurrence runs on z0 clamped to [-6, 6]: beyond, on the plateaus, g0 = 0 and the sum
+  // is m0 erf(z0) = -+m0 whatever the terms are -- but they must stay finite: with an infinite
+  // or huge logMmin the unclamped recurrence overflows and 0 x inf would be NaN where the node
+  // loop and the reference give -+1, N_cen = 0 or 1)
+  double g0, z0;
+  const double e = fm::erf_gauss_fast(table, kc, (consts[0] - log_m_min) * inv_sigma, &g0, &z0);
   const double a = 2.0 * z0 * inv_sigma, b = -2.0 * inv_sigma * inv_sigma;
   double p_prev = 0.0, p = inv_sigma, nb = -b, sum = 0.0;
-  const int n_blocks = n_terms >> 2;
   f64x4_t m = load_moments(consts, 0);
+  int threshold = 0, next_threshold = 0, block = 0;     // (of passes 0 and 1)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-  for (int block = 0; block < n_blocks; ++block) {
-    const f64x4_t next_m = load_moments(consts, block + 1 < n_blocks ? block + 1 : block);
+  while (inv_sigma_hi >= threshold) {
+    const f64x4_t next_m = load_moments(consts, block < kLastBlock ? block + 1 : block);
+    const int after_next = pass_threshold(thresholds, block + 2);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -106,29 +134,35 @@ TC_HD double central_sum(const double* table, const fm::Consts& kc, double log_m
       p = next;
     }
     m = next_m;
+    threshold = next_threshold;
+    next_threshold = after_next;
+    ++block;
   }
   return fma(g0, sum, m0 * e);
 }
 
 // The same for two bins with the same nodes (one group: same centre, different moments): the
 // recurrence once, one FMA per term and bin.
-template <typename Ptr>
+template <typename Ptr, typename IntPtr>
 TC_HD void central_sum_pair(const double* table, const fm::Consts& kc, double log_m_min,
                             double inv_sigma, Ptr consts_i, Ptr consts_j, double m0_i,
-                            double m0_j, int n_terms, double* out_i, double* out_j) {
-  const double z0 = (consts_i[0] - log_m_min) * inv_sigma;
-  double g0;
-  const double e = fm::erf_gauss_fast(table, kc, z0, &g0);
+                            double m0_j, IntPtr thresholds, int inv_sigma_hi, double* out_i,
+                            double* out_j) {
+  constexpr int kLastBlock = kMaxTerms / 4 - 1;
+  double g0, z0;
+  const double e =
+      fm::erf_gauss_fast(table, kc, (consts_i[0] - log_m_min) * inv_sigma, &g0, &z0);
   const double a = 2.0 * z0 * inv_sigma, b = -2.0 * inv_sigma * inv_sigma;
   double p_prev = 0.0, p = inv_sigma, nb = -b, sum_i = 0.0, sum_j = 0.0;
-  const int n_blocks = n_terms >> 2;
   f64x4_t mi = load_moments(consts_i, 0), mj = load_moments(consts_j, 0);
+  int threshold = 0, next_threshold = 0, block = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-  for (int block = 0; block < n_blocks; ++block) {
-    const int ahead = block + 1 < n_blocks ? block + 1 : block;
+  while (inv_sigma_hi >= threshold) {
+    const int ahead = block < kLastBlock ? block + 1 : block;
     const f64x4_t next_i = load_moments(consts_i, ahead), next_j = load_moments(consts_j, ahead);
+    const int after_next = pass_threshold(thresholds, block + 2);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -142,6 +176,9 @@ TC_HD void central_sum_pair(const double* table, const fm::Consts& kc, double lo
     }
     mi = next_i;
     mj = next_j;
+    threshold = next_threshold;
+    next_threshold = after_next;
+    ++block;
   }
   *out_i = fma(g0, sum_i, m0_i * e);
   *out_j = fma(g0, sum_j, m0_j * e);
@@ -188,6 +225,19 @@ TC_HD int terms_for(IntPtr thresholds, int m0_hi) {
   return n;
 }
 
+// Per lane, as for the centrals: does the expansion apply to a draw with this key, and does
+// the draw add the terms of pass `block` (the first three passes are the fewest any draw takes)?
+template <typename IntPtr>
+TC_HD bool eligible(IntPtr thresholds, int m0_hi) {
+  return m0_hi < thresholds[kSteps - 1];
+}
+
+template <typename IntPtr>
+TC_HD int pass_threshold(IntPtr thresholds, int block) {
+  const int value = thresholds[block > 3 ? block - 3 : 0];
+  return block < 3 ? 0 : value;
+}
+
 // 1 / x to rounding (hardware estimate + two Newton steps on the device).
 TC_HD double reciprocal(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -199,18 +249,21 @@ TC_HD double reciprocal(double x) {
 #endif
 }
 
-// sum_k W_k (1 + eps y_k)^alpha by n_terms (a multiple of 4) terms + the n = 0 term.
-template <typename Ptr>
-TC_HD double binomial_sum(Ptr consts, double eps, double alpha, int n_terms) {
+// sum_k W_k (1 + eps y_k)^alpha by the terms an ELIGIBLE draw needs + the n = 0 term (the loop
+// of passes as central_sum).
+template <typename Ptr, typename IntPtr>
+TC_HD double binomial_sum(Ptr consts, double eps, double alpha, IntPtr thresholds, int m0_hi) {
+  constexpr int kLastBlock = kMaxTerms / 4 - 1;
   double d = 1.0, g = eps * alpha, sum = consts[2];         // n = 0: mu_0
-  const int n_blocks = n_terms >> 2;
   // moments mu_n / n! for n >= 1 start at consts[3]: blocks of four from there
   f64x4_t cur = load_four(consts, 3, 0);
+  int threshold = 0, next_threshold = 0, block = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-  for (int block = 0; block < n_blocks; ++block) {
-    const f64x4_t next = load_four(consts, 3, block + 1 < n_blocks ? block + 1 : block);
+  while (m0_hi >= threshold) {
+    const f64x4_t next = load_four(consts, 3, block < kLastBlock ? block + 1 : block);
+    const int after_next = pass_threshold(thresholds, block + 2);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -220,23 +273,28 @@ TC_HD double binomial_sum(Ptr consts, double eps, double alpha, int n_terms) {
       sum = fma(d, cur[k], sum);
     }
     cur = next;
+    threshold = next_threshold;
+    next_threshold = after_next;
+    ++block;
   }
   return sum;
 }
 
 // The same for two bins with the same nodes (same Mc, eps): the coefficients once.
-template <typename Ptr>
-TC_HD void binomial_sum_pair(Ptr consts_i, Ptr consts_j, double eps, double alpha, int n_terms,
-                             double* out_i, double* out_j) {
+template <typename Ptr, typename IntPtr>
+TC_HD void binomial_sum_pair(Ptr consts_i, Ptr consts_j, double eps, double alpha,
+                             IntPtr thresholds, int m0_hi, double* out_i, double* out_j) {
+  constexpr int kLastBlock = kMaxTerms / 4 - 1;
   double d = 1.0, g = eps * alpha, sum_i = consts_i[2], sum_j = consts_j[2];
-  const int n_blocks = n_terms >> 2;
   f64x4_t cur_i = load_four(consts_i, 3, 0), cur_j = load_four(consts_j, 3, 0);
+  int threshold = 0, next_threshold = 0, block = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-  for (int block = 0; block < n_blocks; ++block) {
-    const int ahead = block + 1 < n_blocks ? block + 1 : block;
+  while (m0_hi >= threshold) {
+    const int ahead = block < kLastBlock ? block + 1 : block;
     const f64x4_t next_i = load_four(consts_i, 3, ahead), next_j = load_four(consts_j, 3, ahead);
+    const int after_next = pass_threshold(thresholds, block + 2);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -248,6 +306,9 @@ TC_HD void binomial_sum_pair(Ptr consts_i, Ptr consts_j, double eps, double alph
     }
     cur_i = next_i;
     cur_j = next_j;
+    threshold = next_threshold;
+    next_threshold = after_next;
+    ++block;
   }
   *out_i = sum_i;
   *out_j = sum_j;

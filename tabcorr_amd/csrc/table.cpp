@@ -1048,9 +1048,12 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     TC_CHECK(value >= 1 && value <= 4096, "cross_target must be in [1, 4096]");
     t->tuning.cross_target = value;
   } else if (key == "series") {
-    // 1 (default): the node sum of an undecorated central bin by its moment expansion
-    // (csrc/series.h) wherever every draw of a wave allows it; 0: always the node loop
-    t->tuning.series = value != 0;
+    // bit 0: the node sum of an undecorated central bin by its moment expansion (csrc/series.h)
+    // for every draw that allows it; bit 1: the binomial expansion of the satellite bins well
+    // above a draw's M0; 0: always the node loops.  Per draw either way (a draw's bits do not
+    // depend on its neighbours in the batch).
+    TC_CHECK(value >= 0 && value <= 3, "series must be 0 .. 3");
+    t->tuning.series = value;
   } else if (key == "grouped") {
     // 1 (default): bins that share their quadrature nodes -- the secondary-percentile bins of a
     // mass bin -- have the nodes' occupations evaluated once per group (kernels.hip.h:

@@ -29,3 +29,29 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(REPO, 'tests', 'golden')
+
+
+# The moment expansions of csrc/series.h are off by default (option "series"): the tests of the
+# occupation paths run twice, with the node loops and with both expansions on.
+SERIES_MODULES = {'test_gpu_fused', 'test_gpu_grouped', 'test_gpu_cross_fused'}
+
+
+@pytest.fixture(autouse=True)
+def expansions(request, monkeypatch):
+    value = getattr(request, 'param', None)
+    if value is None:
+        return
+    from tabcorr_amd import tabcorr, _lib
+    original = tabcorr._DeviceTable.__init__
+
+    def init(self, *args, **kwargs):
+        original(self, *args, **kwargs)
+        _lib.check(self.lib.tc_table_set_option(self.handle, b'series', value))
+    monkeypatch.setattr(tabcorr._DeviceTable, '__init__', init)
+
+
+def pytest_generate_tests(metafunc):
+    if (metafunc.module.__name__ in SERIES_MODULES
+            and 'expansions' in metafunc.fixturenames):
+        metafunc.parametrize('expansions', [0, 3], indirect=True,
+                             ids=['nodes', 'expansions'])

@@ -45,22 +45,23 @@ def test_config2_batch_of_1e4():
     assert_rel(sum(xi_sep.values()), xi, 1e-12)
 
     # deterministic: same bits on a second call.  A draw's position in the batch decides
-    # where the equal-share schedule cuts its sums (hostmath.h: QuadSchedule) and -- since the
-    # node sums may be taken by their moment expansions, whose number of terms follows the
-    # narrowest sigma_logM / largest M0 of the 64 draws of a wavefront (csrc/series.h) -- which
-    # re-ordering of a bin's node sum it gets: reordering / splitting changes last bits only
+    # where the equal-share schedule cuts its sums (hostmath.h: QuadSchedule): reordering /
+    # splitting changes last bits of xi only; the number densities -- per draw arithmetic, also
+    # with the moment expansions of csrc/series.h, which take the terms each draw needs -- not
     ngal2, xi2 = halotab.predict_batch(theta)
     assert np.array_equal(xi, xi2) and np.array_equal(ngal, ngal2)
     perm = np.random.default_rng(0).permutation(len(theta))
     ngal3, xi3 = halotab.predict_batch(theta[perm])
     assert_rel(ngal3, ngal[perm], 1e-14)
     assert_rel(xi3, xi[perm], 1e-13)
-    # ... with the expansions off a draw's number densities do not depend on its neighbours
+    # ... a draw's number densities do not depend on its neighbours, expansions off or on
     from tabcorr_amd import _lib
     _lib.check(_lib.load().tc_table_set_option(halotab.to_device().handle, b'series', 0))
     assert np.array_equal(halotab.predict_batch(theta[perm])[0],
                           halotab.predict_batch(theta)[0][perm])
-    _lib.check(_lib.load().tc_table_set_option(halotab.to_device().handle, b'series', 1))
+    _lib.check(_lib.load().tc_table_set_option(halotab.to_device().handle, b'series', 3))
+    assert np.array_equal(halotab.predict_batch(theta[perm])[0],
+                          halotab.predict_batch(theta)[0][perm])
     ngal4, xi4 = halotab.predict_batch(theta[:777])
     assert_rel(xi4, xi[:777], 1e-13)
 

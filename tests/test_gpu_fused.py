@@ -358,10 +358,9 @@ def test_a_draws_result_does_not_depend_on_its_place_in_the_batch():
     halotab = make_tabcorr(table)
     force_fused(halotab)
     set_option(halotab, 'fused_draws', 64)     # (one shape of workgroup for every batch size)
-    # (the node sums by their own loop: the moment expansions of csrc/series.h take as many
-    # terms as the narrowest sigma_logM / largest M0 of a wavefront's 64 draws asks for, so
-    # with them a draw's last bits depend on its neighbours -- checked to rounding below)
-    set_option(halotab, 'series', 0)
+    # (with the moment expansions of csrc/series.h ON -- the default: a lane adds the terms its
+    # OWN draw asks for, whatever the narrowest sigma_logM / largest M0 of its wavefront is)
+    set_option(halotab, 'series', 3)
     ngal, xi = halotab.predict_batch(theta)
     assert fused_ran(halotab, (8, ))
     ngal_r, xi_r = halotab.predict_batch(theta[::-1].copy())
@@ -371,14 +370,75 @@ def test_a_draws_result_does_not_depend_on_its_place_in_the_batch():
     ngal_p, xi_p = halotab.predict_batch(theta[3000:3777])
     assert np.array_equal(ngal_p, ngal[3000:3777])
     assert np.array_equal(xi_p, xi[3000:3777])
-    set_option(halotab, 'series', 1)
-    ngal_s, xi_s = halotab.predict_batch(theta)
+    # draws whose neighbours force every path of the wave: a narrow sigma_logM (node loop for
+    # that lane, expansion for the others), alpha outside [0, 4], draws to fix up
+    mixed = theta[:640].copy()
+    mixed[5::64, 1] = 1e-3
+    mixed[9::64, 4] = 5.5
+    mixed[17::64, 0] = np.inf
+    mixed[33::64, 3] = np.nan
+    ngal_m, xi_m = halotab.predict_batch(mixed)
+    untouched = np.ones(640, dtype=bool)
+    for first in (5, 9, 17, 33):
+        untouched[first::64] = False
+    assert np.array_equal(ngal_m[untouched], ngal[:640][untouched])
+    assert np.array_equal(xi_m[untouched], xi[:640][untouched])
+    # ... and the three-kernel path (occ_zheng07_kernel)
+    force_fused(halotab, False)
+    ngal_3, xi_3 = halotab.predict_batch(theta[:640])
+    ngal_3m, xi_3m = halotab.predict_batch(mixed)
+    assert np.array_equal(ngal_3m[untouched], ngal_3[untouched])
+    assert np.array_equal(xi_3m[untouched], xi_3[untouched])
+    occ = halotab.mean_occupation_batch(theta[:640])
+    occ_m = halotab.mean_occupation_batch(mixed)
+    assert np.array_equal(occ_m[untouched], occ[untouched])
+    # the expansions against the node loops: rounding
+    set_option(halotab, 'series', 0)
+    force_fused(halotab)
+    set_option(halotab, 'fused_draws', 64)
+    ngal_n, xi_n = halotab.predict_batch(theta)
     assert fused_ran(halotab, (8, ))
-    assert_rel(ngal_s, ngal, 1e-14)
-    assert_rel(xi_s, xi, 1e-13)
-    ngal_r, xi_r = halotab.predict_batch(theta[::-1].copy())
-    assert_rel(ngal_r[::-1], ngal_s, 1e-14)
-    assert_rel(xi_r[::-1], xi_s, 1e-13)
+    assert_rel(ngal, ngal_n, 1e-14)
+    assert_rel(xi, xi_n, 1e-13)
+
+
+@pytest.mark.parametrize('form', ['occupation', 'three kernels', 'one launch'])
+def test_infinite_log_m_min_next_to_regular_draws(form):
+    """a draw with logMmin = +-inf (or huge) and a regular sigma_logM in a wave of
+    regular draws takes the moment expansion, whose recurrence overflows there; the result is
+    the plateau's -+m_0 (N_cen = 0 or 1) as in the node loop and the reference, not NaN."""
+    import warnings
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    halotab = make_tabcorr(table)
+    set_option(halotab, 'series', 3)
+    theta = synthetic.zheng07_draws(128, seed=31)
+    theta[:, 1] = np.random.default_rng(2).uniform(0.3, 0.8, 128)
+    special = {3: np.inf, 40: -np.inf, 70: 1e15, 101: -1e15, 127: 1e300}
+    for row, value in special.items():
+        theta[row, 0] = value
+    rows = sorted(special) + [0, 1, 64]
+    with np.errstate(all='ignore'), warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        expect = oracle.predict_zheng07_batch(table, theta[rows])
+    if form == 'occupation':
+        occupation = halotab.mean_occupation_batch(theta)
+        with np.errstate(all='ignore'):
+            want = np.array([oracle.mean_occupation(table, oracle.Zheng07(theta[r]))
+                             for r in rows])
+        assert np.all(np.isfinite(occupation[rows]))
+        assert_rel(occupation[rows], want, RTOL, 'occupation')
+        return
+    force_fused(halotab, form == 'one launch')
+    if form == 'one launch':
+        set_option(halotab, 'fused_draws', 64)
+    ngal, xi = halotab.predict_batch(theta)
+    assert fused_ran(halotab, (8, )) == (form == 'one launch')
+    # (logMmin = +inf: no centrals, satellites only; -inf: every halo hosts a central)
+    assert np.all(np.isfinite(ngal[rows])) and np.all(np.isfinite(xi[rows]))
+    assert_rel(ngal[rows], expect[0], RTOL, 'ngal')
+    assert_rel(xi[rows], expect[1], RTOL, 'xi')
 
 
 def test_fused_matches_the_references_own_tables():

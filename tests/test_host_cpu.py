@@ -1063,6 +1063,9 @@ def test_central_moment_expansion_reproduces_the_node_loop():
         n = 4000
         log_min = rng.uniform(10.5, 15.0 - width)
         log_m_min = rng.uniform(log_min - 4.0, log_min + 4.0, n)
+        # (an infinite or huge logMmin with a regular sigma sits on a plateau --
+        # erf = -+1 -- where the recurrence overflows: the expansion must return -+m_0, not NaN)
+        log_m_min[:8] = [np.inf, -np.inf, 1e15, -1e15, 1e300, -1e300, 1e12, -1e12]
         sigma = rng.uniform(*sigma_range, n) * rng.choice([1.0, 1.0, 1.0, -1.0], n)
         series, nodes = np.empty(n), np.empty(n)
         terms = np.zeros(n, dtype=np.int32)
@@ -1073,6 +1076,7 @@ def test_central_moment_expansion_reproduces_the_node_loop():
         assert set(terms) <= {0, 8, 12, 16, 20, 24}
         np.testing.assert_allclose(series, nodes, rtol=0, atol=1.5e-15,
                                    err_msg='width %g, %d nodes' % (width, n_gauss))
+        assert np.all(np.isfinite(series[:8])) and np.all(np.abs(nodes[:8]) > 0.99)
         # the number of terms follows (half width) / |sigma|
         h = 0.5 * width / np.abs(sigma)
         for count, limit in ((8, 0.0275), (12, 0.1100), (16, 0.2366), (20, 0.3879), (24, 0.5506)):
