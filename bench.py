@@ -105,7 +105,7 @@ def headline(result, detail_path):
     line['parity_max_rel_vs_oracle'] = result['parity_max_rel_vs_oracle']
     if 'second_payload' in result:
         line['second_payload'] = {key: result['second_payload'][key]
-                                  for key in ('gather_payload', 'value', 'ms_per_step')}
+                                  for key in ('gather_payload', 'value', 'ms_per_step', 'steps')}
     if result.get('failed_legs'):
         line['failed_legs'] = sorted(result['failed_legs'])
     line['detail'] = detail_path

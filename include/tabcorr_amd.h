@@ -315,19 +315,19 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 calls with these flags then take the measured form of the nearest batch size
  *                 instead of the built-in estimate (fitted on a handful of table shapes).  -1:
  *                 forget every measurement.  tc_table_autotune_result reads it back.
- *   "series"      0 (default): every bin's Gauss-Legendre sum (tabcorr/tabcorr.py:556-578) by
- *                 its node loop.  Bit 0: the sum of an undecorated central bin by its moment
- *                 expansion around the bin centre -- the same sum re-ordered, one erf and 8 ..
- *                 24 short terms instead of n_gauss_prim erf evaluations,
- *                 tabcorr_amd/csrc/series.h -- for every draw whose sigma_logM is above about a
- *                 bin width (truncation below 1e-16); bit 1: the binomial expansion of a
- *                 satellite bin well above the draw's M0.  Each draw takes the terms IT needs:
- *                 with any value of this option a draw's result is bit for bit the same
- *                 wherever it sits in whatever batch (round 4 chose the term count per
- *                 wavefront, which was faster on wide priors and made the last bits depend on
- *                 the neighbouring draws).  Ensembles of similar draws (an MCMC's walkers)
- *                 gain from 3; a wide prior box does not (a wavefront then runs the expansion
- *                 and the node loop for most bins).
+ *   "series"      bit mask, default 1.  Bit 0: the Gauss-Legendre sum of an undecorated
+ *                 central bin (tabcorr/tabcorr.py:556-578) by its moment expansion around the
+ *                 bin centre -- the same sum re-ordered, one erf and 8 .. 24 short terms instead
+ *                 of n_gauss_prim erf evaluations, tabcorr_amd/csrc/series.h -- for every draw
+ *                 whose sigma_logM is above about a bin width (truncation below 1e-16;
+ *                 otherwise, and for decorated centrals, the node loop); bit 1: the binomial
+ *                 expansion of a satellite bin well above the draw's M0.  0: always the node
+ *                 loops.  Each draw takes the terms IT needs: with any value of this option a
+ *                 draw's result is bit for bit the same wherever it sits in whatever batch
+ *                 (round 4 chose the term count per wavefront, which was faster on wide priors
+ *                 and made the last bits depend on the neighbouring draws).  Ensembles of
+ *                 similar draws (an MCMC's walkers) gain from 3; on a wide prior box a
+ *                 wavefront runs the satellites' expansion AND their node loop for most bins.
  *   "grouped"     1 (default): bins with identical log_prim_haloprop_min / max and galaxy type
  *                 -- the secondary-percentile bins of one mass bin (tabcorr/tabcorr.py:186-205)
  *                 -- share their Gauss-Legendre nodes (:548-549); the occupation functions are

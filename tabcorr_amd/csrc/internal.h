@@ -235,12 +235,14 @@ struct CrossFused {
   void* d_rows = nullptr;
   // chunks of whole groups of at most kCrossChunkBins bins (kernel_args.h: CrossFusedArgs)
   void* d_chunk_group = nullptr;
+  void* d_chunk_block = nullptr;     // first 4-bin step of every chunk (matrix-operand layout)
   std::vector<int32_t> chunk_group_host;
   int n_chunks = 0, n_central_chunks = 0;
   void release() {
     if (d_rows != nullptr) (void)hipFree(d_rows);
     if (d_chunk_group != nullptr) (void)hipFree(d_chunk_group);
-    d_rows = d_chunk_group = nullptr;
+    if (d_chunk_block != nullptr) (void)hipFree(d_chunk_block);
+    d_rows = d_chunk_group = d_chunk_block = nullptr;
     rows = 0;
     tried = false;
   }
@@ -309,10 +311,13 @@ struct Tuning {
   // over the whole chip.  Asynchronous host calls (us per call, tools/archive/r03_async.py): 6144 draws
   // 38.8 / 41.6, 10^4 58 / 47.6, 20 000 93.7 / 82.6, 40 000 176 / 162: no upper bound there.
   // moment expansions of the node sums (series.h): bit 0 central bins, bit 1 satellite bins.
-  // Off by default since round 5: a draw's bits must not depend on its neighbours in the
-  // batch, so every lane takes the terms ITS draw needs -- and on wide priors a wave then runs
-  // the expansion AND the node loop for most bins (measured: no gain; profiles/r05_notes.md)
-  int series = 0;
+  // Every lane takes the terms ITS draw needs (a draw's bits must not depend on its neighbours
+  // in the batch), and a wave runs the node loop as well wherever one of its draws needs it.
+  // Centrals: nearly every draw qualifies for every bin -- on by default (the reference's
+  // AbacusSummit interpolator 85.4 -> 80.3 us per 10^4 draws; the headline table level).
+  // Satellites: on a wide prior most bins hold both kinds of draws and cost both paths
+  // (headline 39.9 -> 40.5 us) -- off by default (profiles/r05_notes.md)
+  int series = 1;
   int cross_target = 160;       // mode cross: workgroups a launch should have at least
                                 // (several per tile of 64 draws below that)
   int resident_aperture = 1;    // resident ensemble kernel: the mailbox in device memory that

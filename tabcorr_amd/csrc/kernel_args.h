@@ -394,7 +394,12 @@ struct CrossFusedArgs {
   int n_groups, n_central_groups;
   GroupArgs group;
   const double* math_table;
-  const double* rows;        // (n_bins in member order, ROWS): wave w owns rows w RW .. + RW
+  // predict_cross_small_kernel: (n_bins in member order, 16) doubles.  predict_cross_fused_kernel:
+  // the A operands of its matrix instructions -- per chunk (the bins padded with zero rows to a
+  // multiple of 4), 4-bin step and block of 16 rows 64 doubles, [l] = coefficient of bin
+  // 4 step + l / 16, row 16 block + l % 16; chunk c starts at step chunk_block[c]
+  const double* rows;
+  const int32_t* chunk_block;    // (n_chunks + 1)
   // chunks of whole groups with at most kCrossChunkBins members, none across the boundary
   // between centrals and satellites: chunk c = groups chunk_group[c] .. chunk_group[c + 1]
   const int32_t* chunk_group;    // (n_chunks + 1)

@@ -2243,16 +2243,36 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
 //      beyond K (R + 1) zero).
 // Two buffers, so that one barrier per chunk is enough: a wave that writes chunk c + 1 has
 // passed the barrier of chunk c, which every wave reaches only after reading chunk c - 1.
-// No wave ever holds more than RW sums (16 VGPRs for 64 rows): four waves per SIMD, two
-// workgroups per CU.  Nothing but theta comes in and nothing but the results go out.  Then per
+// Nothing but theta comes in and nothing but the results go out.  Then per
 // draw xi[r] = sum_k c_k acc[k][r] / ngal_k with the spline weights c_k of the draw's extra
 // parameters (interpolator.py:275-331; one table: c = 1).  Separated by galaxy type the sums
 // of the centrals are set aside after their last chunk (no chunk holds both types).
+//
+// B on the matrix pipe (round 5).  acc[row][draw] += sum_bin coefficient[bin][row] N[bin][draw]
+// is a (ROWS x bins) x (bins x 64 draws) product: one v_mfma_f64_16x16x4_f64 takes 16 rows x 4
+// bins (A: one double per lane from the rows re-laid out per (4-bin block, 16-row block), one
+// coalesced 512-byte load) and 4 bins x 16 draws (B: one ds_read_b64 per lane from the chunk
+// buffer).  The ROWS / 16 x 4 output tiles are dealt to the eight waves (RW / 4 each: 1, 2 or
+// 4; two tiles of a wave share their A operand).  Round 4 issued per bin and wave one LDS read,
+// one 64-byte SCALAR load of coefficients (from a 565 KB table the 16 KB scalar cache cannot
+// hold) and RW FMAs, and spilled 61 scalar registers around the unrolled loads: 79.4 us per 10^4
+// draws of the reference's AbacusSummit interpolator against 45 us of vector issue.  The same
+// flop on the same pipe (matrix and vector FP64 share it), an eighth of the instructions, no
+// scalar loads.  The buffer's rows are skewed by 16 draws per bin (row r holds draw d at column
+// (d + 16 (r % 4)) % 64) so that the four bins a B operand spans fall into different banks.
 template <int RW, bool ASSEMBIAS, bool MODULATE>
-__global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 2 : 4) void predict_cross_fused_kernel(
+// (second launch bound = waves per SIMD: four -- two workgroups per CU, 128 vector registers --
+// for up to 8 rows per wave; the 16-row instances (65 - 128 rows: 32 registers of sums live across
+// the occupation arithmetic) would spill there and take one workgroup per CU instead)
+__global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cross_fused_kernel(
     CrossFusedArgs a) {
   constexpr int W = kCrossWaves, ROWS = W * RW;
+  constexpr int NT = ROWS / 16;                       // row blocks of 16
+  constexpr int N_RB = RW >= 16 ? 2 : 1;              // row blocks per wave
+  constexpr int N_DB = RW >= 8 ? 2 : 1;               // blocks of 16 draws per wave
+  constexpr int PF = 4;                               // A operands in flight (4-bin steps)
   static_assert(ROWS <= kCrossMaxRows && fm::kTableDoubles == kCrossTableDoubles, "kernel_args.h");
+  static_assert(N_RB * N_DB * 4 == RW && kCrossChunkBins % 4 == 0, "tiles per wave");
   extern __shared__ __attribute__((aligned(16))) double cross_lds[];
   double* table = cross_lds;
   double* buffers = cross_lds + kCrossTableDoubles;    // 2 x (kCrossChunkBins, 64); then the sums
@@ -2278,9 +2298,19 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 2 : 4) void predict_cro
   const int64_t b0 = col + lane;
   const int64_t b = b0 < a.n_draws ? b0 : a.n_draws - 1;
 
-  double acc[RW];
+  // this wave's output tiles: row blocks rb0 (+ 4), draw blocks db0 (+ 1); D[m = l / 16 + 4 v]
+  // [n = l % 16] in register v (the lane map of contract_quad_kernel)
+  const int rb0 = RW == 4 ? (wave & 1) : (wave >> 1);
+  const int db0 = RW == 4 ? (wave >> 1) : 2 * (wave & 1);
+  f64x4 acc[N_RB][N_DB];
 #pragma unroll
-  for (int j = 0; j < RW; ++j) acc[j] = 0.0;
+  for (int j = 0; j < N_RB; ++j)
+#pragma unroll
+    for (int i = 0; i < N_DB; ++i) acc[j][i] = f64x4{0.0, 0.0, 0.0, 0.0};
+  // element (j, i, v) of the wave's sums sits at [row][draw] of a (ROWS, 64) array
+  auto sum_index = [&](int j, int i, int v) {
+    return (16 * (rb0 + 4 * j) + (lane >> 4) + 4 * v) * kLanes + 16 * (db0 + i) + (lane & 15);
+  };
   {
     const double* th = a.theta + b * a.n_theta;
     const DrawSetup d = prepare_draw(table, kc, th[0], th[1], th[2], th[3], th[4],
@@ -2299,17 +2329,21 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 2 : 4) void predict_cro
     series_setup<MODULATE>(dp, a.group.series != nullptr, a.group.sat_series != nullptr);
     sc_i32 group_begin = (sc_i32)a.group.begin;
     sc_i32 chunk_group = (sc_i32)a.chunk_group;
+    sc_i32 chunk_block = (sc_i32)a.chunk_block;
     const GroupConsts gq{(sc_f64)a.group.log_m, (sc_f64)a.group.m, (sc_f64)a.group.weight,
                          (sc_f64)a.group.weight + a.n_bins * 10, (sc_f64)a.group.percentile,
                          (sc_i32)a.group.member,
                              SeriesConsts{(sc_f64)a.group.series, (sc_i32)a.group.series_thr,
                                           (sc_f64)a.group.sat_series, (sc_i32)a.group.sat_series_thr}};
-    sc_f64 rows = (sc_f64)a.rows + wave * RW;
     if (a.separate && chunk_begin >= a.n_central_chunks) {
       // (a share without centrals: their sums are zero)
       double* res0 = cross_lds + a.lds_res0;
 #pragma unroll
-      for (int j = 0; j < RW; ++j) res0[(wave * RW + j) * kLanes + lane] = 0.0;
+      for (int j = 0; j < N_RB; ++j)
+#pragma unroll
+        for (int i = 0; i < N_DB; ++i)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) res0[sum_index(j, i, v)] = 0.0;
     }
     for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
       if (a.separate && chunk == a.n_central_chunks && chunk > chunk_begin) {
@@ -2317,27 +2351,67 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 2 : 4) void predict_cro
         // barrier behind the last chunk)
         double* res0 = cross_lds + a.lds_res0;
 #pragma unroll
-        for (int j = 0; j < RW; ++j) {
-          res0[(wave * RW + j) * kLanes + lane] = acc[j];
-          acc[j] = 0.0;
-        }
+        for (int j = 0; j < N_RB; ++j)
+#pragma unroll
+          for (int i = 0; i < N_DB; ++i)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              res0[sum_index(j, i, v)] = acc[j][i][v];
+              acc[j][i][v] = 0.0;
+            }
       }
       double* buffer = buffers + (chunk & 1) * (kCrossChunkBins * kLanes);
       const int g0 = chunk_group[chunk], g1 = chunk_group[chunk + 1];
       const int m0 = group_begin[g0], m1 = group_begin[g1];
-      // A. mean occupations of the chunk's bins
+      const int n_steps = (m1 - m0 + 3) >> 2;        // 4-bin steps of phase B
+      // A. mean occupations of the chunk's bins (row = bin in chunk, skewed columns)
       for (int gr = g0 + wave; gr < g1; gr += W)
         occ_group_zheng07<ASSEMBIAS, MODULATE>(
             table, kc, gr, group_begin[gr], group_begin[gr + 1], gr < a.n_central_groups, gq,
-            a.split, dp, [&](int mi, int, double nbar) { buffer[(mi - m0) * kLanes + lane] = nbar; });
-      __syncthreads();
-      // B. this wave's rows over every bin of the chunk
-#pragma unroll 8
-      for (int mi = m0; mi < m1; ++mi) {
-        const double nbar = buffer[(mi - m0) * kLanes + lane];
-        sc_f64 coefficient = rows + (int64_t)mi * ROWS;
+            a.split, dp, [&](int mi, int, double nbar) {
+              const int row = mi - m0;
+              buffer[row * kLanes + ((lane + 16 * (row & 3)) & 63)] = nbar;
+            });
+      // (the rows that fill the last step: zero, whatever an earlier chunk left there)
+      for (int row = m1 - m0 + wave; row < 4 * n_steps; row += W) buffer[row * kLanes + lane] = 0.0;
+      // B. this wave's tiles over every bin of the chunk; the first A operands are requested
+      // before the barrier.  (The lane's offsets are formed here, per chunk, from a lane index
+      // the optimiser cannot see through: hoisted out of the chunk loop they would cost six
+      // registers across phase A, which has none to spare at four waves per SIMD.)
+      int l = lane;
+      asm volatile("" : "+v"(l));
+      // B operand: bins 4 q + l / 16 of the chunk buffer, draws 16 (db0 + i) + l % 16, skewed
+      int b_col[N_DB];
 #pragma unroll
-        for (int j = 0; j < RW; ++j) acc[j] = fma(coefficient[j], nbar, acc[j]);
+      for (int i = 0; i < N_DB; ++i)
+        b_col[i] = (l >> 4) * kLanes + ((16 * (db0 + i) + (l & 15) + 16 * (l >> 4)) & 63);
+      const double* a_lane = a.rows + ((int64_t)chunk_block[chunk] * NT + rb0) * 64 + l;
+      double av[PF][N_RB];
+#pragma unroll
+      for (int s = 0; s < PF; ++s)
+#pragma unroll
+        for (int j = 0; j < N_RB; ++j)
+          av[s][j] = s < n_steps ? a_lane[(s * NT + 4 * j) * 64] : 0.0;
+      __syncthreads();
+      for (int q = 0; q < n_steps; q += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+          if (q + s < n_steps) {
+            double bv[N_DB];
+#pragma unroll
+            for (int i = 0; i < N_DB; ++i) bv[i] = buffer[(q + s) * 4 * kLanes + b_col[i]];
+#pragma unroll
+            for (int j = 0; j < N_RB; ++j)
+#pragma unroll
+              for (int i = 0; i < N_DB; ++i)
+                acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s][j], bv[i], acc[j][i], 0, 0, 0);
+            if (q + s + PF < n_steps) {
+#pragma unroll
+              for (int j = 0; j < N_RB; ++j)
+                av[s][j] = a_lane[((q + s + PF) * NT + 4 * j) * 64];
+            }
+          }
+        }
       }
     }
   }
@@ -2348,10 +2422,15 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 2 : 4) void predict_cro
     // (a share that ends before the satellites begin holds sums of centrals only)
     const bool only_centrals = a.separate && chunk_end <= a.n_central_chunks;
 #pragma unroll
-    for (int j = 0; j < RW; ++j) {
-      if (only_centrals) res0[(wave * RW + j) * kLanes + lane] = acc[j];
-      res1[(wave * RW + j) * kLanes + lane] = only_centrals ? 0.0 : acc[j];
-    }
+    for (int j = 0; j < N_RB; ++j)
+#pragma unroll
+      for (int i = 0; i < N_DB; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int index = sum_index(j, i, v);
+          if (only_centrals) res0[index] = acc[j][i][v];
+          res1[index] = only_centrals ? 0.0 : acc[j][i][v];
+        }
   }
   __syncthreads();
   if (n_splits > 1) {

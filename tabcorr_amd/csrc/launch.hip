@@ -1412,8 +1412,30 @@ int build_cross_fused(tc_table* const* tables, int n_tables, CrossFused* cf) {
       row[t->n_r] = t->n_h[g];
     }
   }
+  // predict_cross_fused_kernel (more than 16 rows) multiplies on the matrix pipe: its A operands
+  // per (chunk, 4-bin step, block of 16 rows) -- kernel_args.h: CrossFusedArgs::rows
+  std::vector<int32_t> chunk_block(cf->n_chunks + 1, 0);
+  if (instance > tc::kCrossSmallRows) {
+    const int row_blocks = instance / 16;
+    for (int c = 0; c < cf->n_chunks; ++c) {
+      const int bins = groups.begin[chunk_group[c + 1]] - groups.begin[chunk_group[c]];
+      chunk_block[c + 1] = chunk_block[c] + (bins + 3) / 4;
+    }
+    std::vector<double> operands((size_t)chunk_block[cf->n_chunks] * row_blocks * 64, 0.0);
+    for (int c = 0; c < cf->n_chunks; ++c) {
+      const int m0 = groups.begin[chunk_group[c]], m1 = groups.begin[chunk_group[c + 1]];
+      for (int mi = m0; mi < m1; ++mi) {
+        const int step = chunk_block[c] + (mi - m0) / 4, k = (mi - m0) % 4;
+        for (int row = 0; row < instance; ++row)
+          operands[((size_t)step * row_blocks + row / 16) * 64 + k * 16 + row % 16] =
+              host[(size_t)mi * instance + row];
+      }
+    }
+    host.swap(operands);
+  }
   int status = upload(host, &cf->d_rows);
   if (status == TC_OK) status = upload(chunk_group, &cf->d_chunk_group);
+  if (status == TC_OK) status = upload(chunk_block, &cf->d_chunk_block);
   if (status != TC_OK) return status;
   cf->rows = instance;
   return TC_OK;
@@ -1528,6 +1550,7 @@ int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs
   ca.n_r = t0->n_r;
   ca.separate = separate ? 1 : 0;
   ca.chunk_group = (const int32_t*)cf.d_chunk_group;
+  ca.chunk_block = (const int32_t*)cf.d_chunk_block;
   ca.n_chunks = cf.n_chunks;
   ca.n_central_chunks = cf.n_central_chunks;
   CrossLds layout = cross_lds_layout(cf, t0->n_r, separate);
