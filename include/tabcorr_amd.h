@@ -306,6 +306,17 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 a third faster there, and the one-launch form then pays from 12 draws per
  *                 bin on -- and for tables of 105 .. 208 bins, of 64 draws otherwise; 32 / 64:
  *                 forced.
+ *   "sync_chunks" synchronous host-array calls (tc_predict_zheng07_batch, tc_chi2_zheng07_batch
+ *                 beyond the zero-copy size): 0 (default) batches of 2048 draws and more are cut
+ *                 into 2 .. 8 chunks of draws (about a megabyte of results each) whose staging,
+ *                 kernels, transfers and copies into the caller's arrays overlap; N >= 1: N
+ *                 chunks for every batch; -1: the serial path (upload, the kernels alone on one
+ *                 lane, download).  "sync_form" (default 32): draws per workgroup of the
+ *                 one-launch form the chunks take where it serves the table -- a draw's result
+ *                 then does not depend on the number of chunks; 0: whatever a pipelined call of
+ *                 the chunk's size takes.  "sync_direct_out": as "async_direct_out" for the
+ *                 chunks' staging area (2, default: arrays up to 1 MB are stored by the kernels
+ *                 themselves, larger ones travel by copy command).
  *   "autotune"    value = the predict flags to tune for (a combination of TC_FLAG_*; 0 = the
  *                 total prediction of plain Zheng07), n_gauss_prim = 10: MEASURES on this table,
  *                 for batch sizes 256 .. 65536 (x 2 steps), which form serves a batch fastest in

@@ -110,6 +110,9 @@ struct PinnedBuffer {
 // (tc_host_alloc / tc_host_register; runtime.cpp).
 // `device_ptr` receives the address the device sees the range at (NULL when it has none).
 bool is_pinned(const void* ptr, size_t bytes, void** device_ptr = nullptr);
+// memcpy shared with a few helper threads from 256 KB on (runtime.cpp: CopyPool): the results'
+// way out of the staging areas at the end of a synchronous host call.
+void parallel_copy(void* dst, const void* src, size_t bytes);
 
 // (developer builds only: environment overrides)
 inline int env_int_early(const char* name, int fallback) {
@@ -296,6 +299,14 @@ struct Tuning {
   // kernel directly 57 / the likelihood 47.5; ALL results stored directly 66 (1.5 MB of
   // 64-byte writes over PCIe from the shader cores lose to the copy engine); downloads on a
   // stream of their own 91-105 (cross-stream events), more lanes 72-80 (four hardware queues).
+  // synchronous host calls as overlapping chunks of draws (table.cpp: predict_chunked):
+  // sync_chunks 0 auto (from 2048 draws on), -1 never, N >= 1 that many; sync_form: draws per
+  // workgroup of the one-launch form the chunks take where it serves the table (so that the
+  // result does not depend on the number of chunks; 0: whatever a pipelined call of the chunk's
+  // size would take); sync_direct_out as async_direct_out, for the staging area of the chunks
+  int sync_chunks = 0;
+  int sync_form = 32;
+  int sync_direct_out = 2;
   int async_direct_in = 1;    // 1: kernels read the draws from the caller's pinned memory
   int async_direct_out = 2;   // 0: copy commands, 1: kernels store everything, 2: kernels
                               // store arrays up to kDirectOutBytes, copy commands beyond
@@ -556,6 +567,7 @@ namespace host {
 // Asynchronous host calls: result arrays up to this size are stored by the kernels into the
 // caller's page-locked memory, larger ones travel by copy command.
 constexpr size_t kDirectOutBytes = 256 * 1024;
+constexpr size_t kSyncDirectOutBytes = 1024 * 1024;   // (per array and chunk of a synchronous call)
 // Largest dynamic LDS allocation a workgroup may ask for (160 KiB per CU).
 constexpr int kMaxLdsBytes = 160 * 1024;
 // Draws are processed in slabs so that the workspaces stay bounded.

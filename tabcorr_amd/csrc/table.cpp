@@ -394,7 +394,7 @@ int copy_out(PinnedBuffer* stage, double* ngal, size_t ngal_count, const void* d
                           stream));
     TC_HIP(hipStreamSynchronize(stream));
     memcpy(ngal, h, ngal_count * 8);
-    memcpy(xi, h + ngal_count, xi_count * 8);
+    parallel_copy(xi, h + ngal_count, xi_count * 8);
     return TC_OK;
   }
   TC_HIP(hipMemcpyAsync(ngal, d_ngal, ngal_count * 8, hipMemcpyDeviceToHost, stream));
@@ -439,6 +439,88 @@ int tc_predict_zheng07_many(tc_table* t, const double* theta, int n_theta, int n
   return TC_OK;
 }
 
+namespace {
+int predict_async(tc_table* t, const double* theta, int n_theta, int64_t n_draws, int n_gauss,
+                  unsigned flags, const double* data, const double* precision, double* ngal,
+                  double* second, bool chi2, int64_t* ticket_out, bool staging);
+
+// How many chunks a synchronous host call of n_draws with out_bytes of results is cut into
+// (0: not chunked -- the serial path).
+int sync_chunks(const tc_table* t, int64_t n_draws, size_t out_bytes) {
+  if (t->tuning.sync_chunks < 0 || !t->tuning.pipeline || t->n_lanes < 2 || t->chain) return 0;
+  if (t->tuning.sync_chunks >= 1)
+    return (int)std::min<int64_t>(t->tuning.sync_chunks, (n_draws + 63) / 64);
+  // auto: about a megabyte of results per chunk, 2 .. 8 chunks of at least 1024 draws.  (All
+  // chunks' kernels share the chip and finish together, so more chunks buy nothing for small
+  // results -- 10^4 draws x 19 r values: 2 chunks 128 us, 3: 130, 4: 134, serial 150 -- while
+  // the 61 MB of a (19, 40) table's 10^4 draws travel and are copied under the kernels.)
+  if (n_draws < 2048) return 0;
+  const int64_t by_bytes = std::max<int64_t>(2, (int64_t)(out_bytes >> 20));
+  return (int)std::min<int64_t>(std::min<int64_t>(8, n_draws / 1024), by_bytes);
+}
+
+// A synchronous host-to-host call as overlapping chunks of draws: the draws
+// of chunk k are staged and queued on lane k % lanes while chunk k - 1 computes; the results of
+// chunk k are copied to the caller's arrays (on four host threads: parallel_copy) while later
+// chunks compute and travel.  Before: upload -> all kernels alone on one lane -> whole download
+// -> synchronise, strictly in series.  Every chunk takes the form the library picks for a
+// PIPELINED call -- for tables the one-launch form serves, workgroups of 32 draws (option
+// "sync_form"), whose results do not depend on where a draw sits in which batch: there the
+// call returns the same bits for any number of chunks (tests/test_gpu_async.py); elsewhere the
+// chunks differ from one piece by rounding (the schedule of the three-kernel path cuts a
+// draw's sums where the batch size puts them).
+int predict_chunked(tc_table* t, const double* theta, int n_theta, int64_t n_draws, int n_gauss,
+                    unsigned flags, const double* data, const double* precision, double* ngal,
+                    double* second, bool chi2, int n_chunks) {
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  const int n_comp = separate ? t->plan.n_components : 1;
+  const size_t ngal_cols = separate ? 2 : 1;
+  const size_t second_cols = chi2 ? 1 : (size_t)n_comp * t->n_r;
+  const size_t theta_bytes = (size_t)n_draws * n_theta * sizeof(double);
+  const size_t out_bytes = (size_t)n_draws * (ngal_cols + second_cols) * sizeof(double);
+  int status = t->h_in.reserve(theta_bytes);
+  if (status == TC_OK) status = t->h_out.reserve(out_bytes);
+  if (status != TC_OK) return status;
+  const int64_t chunk = ((n_draws + n_chunks - 1) / n_chunks + 63) / 64 * 64;
+  n_chunks = (int)((n_draws + chunk - 1) / chunk);
+  int64_t tickets[64];
+  TC_CHECK(n_chunks <= 64, "internal: too many chunks");
+  double* h_theta = (double*)t->h_in.ptr;
+  double* h_out = (double*)t->h_out.ptr;
+  // (one form for every chunk size: the one-launch form with sync_form draws per workgroup
+  // wherever it serves the table at all, not only from the batch size on where it pays)
+  const int saved_draws = t->tuning.fused_draws, saved_min = t->tuning.fused_min_draws;
+  if (t->tuning.sync_form != 0 && saved_draws == 0 && t->tuning.fused == 1) {
+    t->tuning.fused_draws = t->tuning.sync_form;
+    if (saved_min == 0) t->tuning.fused_min_draws = 1;
+  }
+  for (int k = 0; k < n_chunks && status == TC_OK; ++k) {
+    const int64_t begin = k * chunk, n = std::min(chunk, n_draws - begin);
+    memcpy(h_theta + begin * n_theta, theta + begin * n_theta, (size_t)n * n_theta * 8);
+    // (the chunk's results side by side in the staging area: [ngal | xi] -- one copy command)
+    double* out = h_out + begin * (ngal_cols + second_cols);
+    status = predict_async(t, h_theta + begin * n_theta, n_theta, n, n_gauss, flags, data,
+                           precision, out, out + n * ngal_cols, chi2, &tickets[k], true);
+    if (status != TC_OK) n_chunks = k;       // (wait for what was queued, then report)
+  }
+  t->tuning.fused_draws = saved_draws;
+  t->tuning.fused_min_draws = saved_min;
+  for (int k = 0; k < n_chunks; ++k) {
+    const int64_t begin = k * chunk, n = std::min(chunk, n_draws - begin);
+    const int waited = tc_table_wait(t, tickets[k]);
+    if (waited != TC_OK) {
+      (void)tc_table_synchronize(t);
+      return waited;
+    }
+    if (status != TC_OK) continue;
+    const double* out = h_out + begin * (ngal_cols + second_cols);
+    memcpy(ngal + begin * ngal_cols, out, (size_t)n * ngal_cols * 8);
+    parallel_copy(second + begin * second_cols, out + n * ngal_cols, (size_t)n * second_cols * 8);
+  }
+  return status;
+}
+}  // namespace
+
 int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
                              int64_t n_draws, int n_gauss, unsigned flags,
                              double* ngal, double* xi) {
@@ -480,9 +562,12 @@ int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
     if (status != TC_OK) return status;
     TC_HIP(hipStreamSynchronize(t->stream));
     memcpy(ngal, h, ngal_count * 8);
-    memcpy(xi, h + ngal_count, xi_count * 8);
+    parallel_copy(xi, h + ngal_count, xi_count * 8);
     return TC_OK;
   }
+  if (const int n_chunks = sync_chunks(t, n_draws, out_bytes))
+    return predict_chunked(t, theta, n_theta, n_draws, n_gauss, flags, nullptr, nullptr, ngal, xi,
+                           false, n_chunks);
   status = t->theta.reserve(theta_bytes, t->stream);
   if (status == TC_OK) status = t->out_ngal.reserve(ngal_count * 8, t->stream);
   if (status == TC_OK) status = t->out_xi.reserve(xi_count * 8, t->stream);
@@ -649,9 +734,11 @@ int next_ticket(tc_table* t, tc_table::Ticket** out) {
 // (upload, three kernels, download, the ticket's event) is queued on that lane's stream, so
 // lanes overlap each other's copies and kernels and nothing orders one ticket against
 // another.
+// `staging`: the buffers are the library's own page-locked staging areas (hipHostMalloc: the
+// device sees them at the same addresses) -- the chunks of a synchronous call, predict_chunked.
 int predict_async(tc_table* t, const double* theta, int n_theta, int64_t n_draws, int n_gauss,
                   unsigned flags, const double* data, const double* precision, double* ngal,
-                  double* second, bool chi2, int64_t* ticket_out) {
+                  double* second, bool chi2, int64_t* ticket_out, bool staging) {
   int status = check_predict_args(t, theta, n_theta, n_draws, n_gauss, flags);
   if (status != TC_OK) return status;
   TC_CHECK(ticket_out != nullptr, "ticket is NULL");
@@ -666,10 +753,16 @@ int predict_async(tc_table* t, const double* theta, int n_theta, int64_t n_draws
   const size_t second_count = chi2 ? (size_t)n_draws : (size_t)n_draws * n_comp * t->n_r;
   const size_t theta_bytes = (size_t)n_draws * n_theta * sizeof(double);
   void *theta_seen = nullptr, *ngal_seen = nullptr, *second_seen = nullptr;
-  TC_CHECK(n_draws == 0 || (is_pinned(theta, theta_bytes, &theta_seen) &&
-                            is_pinned(ngal, ngal_count * 8, &ngal_seen) &&
-                            is_pinned(second, second_count * 8, &second_seen)),
-           "asynchronous calls need page-locked buffers (tc_host_alloc / tc_host_register)");
+  if (staging) {
+    theta_seen = (void*)theta;
+    ngal_seen = ngal;
+    second_seen = second;
+  } else {
+    TC_CHECK(n_draws == 0 || (is_pinned(theta, theta_bytes, &theta_seen) &&
+                              is_pinned(ngal, ngal_count * 8, &ngal_seen) &&
+                              is_pinned(second, second_count * 8, &second_seen)),
+             "asynchronous calls need page-locked buffers (tc_host_alloc / tc_host_register)");
+  }
   TC_HIP(hipSetDevice(t->device));
   if (t->resident.running) {
     const int stopped = resident_stop(t);
@@ -681,9 +774,13 @@ int predict_async(tc_table* t, const double* theta, int n_theta, int64_t n_draws
   if (n_draws > 0) {
     // Which arrays the kernels address in the caller's page-locked memory themselves and
     // which travel by copy command: see Tuning::async_direct_in / async_direct_out.
-    const int mode = t->tuning.async_direct_out;
-    auto direct = [mode](void* seen, size_t count) {
-      return seen != nullptr && (mode == 1 || (mode == 2 && count * 8 <= kDirectOutBytes));
+    // (the chunks of a synchronous call: the kernels store up to 1 MB per array themselves --
+    // one call's 10^4 draws of 19 r values in two chunks 128 us against 151 with copy commands;
+    // larger chunks, e.g. of a (19, 40) table, go through the copy engines)
+    const int mode = staging ? t->tuning.sync_direct_out : t->tuning.async_direct_out;
+    const size_t direct_bytes = staging ? kSyncDirectOutBytes : kDirectOutBytes;
+    auto direct = [mode, direct_bytes](void* seen, size_t count) {
+      return seen != nullptr && (mode == 1 || (mode == 2 && count * 8 <= direct_bytes));
     };
     const bool direct_in = t->tuning.async_direct_in && theta_seen != nullptr;
     const bool direct_ngal = direct(ngal_seen, ngal_count);
@@ -739,7 +836,7 @@ int tc_predict_zheng07_batch_async(tc_table* t, const double* theta, int n_theta
                                    int64_t n_draws, int n_gauss, unsigned flags, double* ngal,
                                    double* xi, int64_t* ticket) {
   return predict_async(t, theta, n_theta, n_draws, n_gauss, flags, nullptr, nullptr, ngal, xi,
-                       false, ticket);
+                       false, ticket, false);
 }
 
 int tc_chi2_zheng07_batch_async(tc_table* t, const double* theta, int n_theta, int64_t n_draws,
@@ -747,7 +844,7 @@ int tc_chi2_zheng07_batch_async(tc_table* t, const double* theta, int n_theta, i
                                 const double* precision, double* ngal, double* chi2,
                                 int64_t* ticket) {
   return predict_async(t, theta, n_theta, n_draws, n_gauss, flags, data, precision, ngal, chi2,
-                       true, ticket);
+                       true, ticket, false);
 }
 
 int tc_table_wait(tc_table* t, int64_t ticket) {
@@ -1081,6 +1178,19 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
       if (lane.stream) TC_HIP(hipStreamSynchronize(lane.stream));
     t->chain = value != 0;
     t->prev = -1;
+  } else if (key == "sync_chunks") {
+    // synchronous host calls (tc_predict_zheng07_batch, ...): 0 (default) cut batches of 2048
+    // draws and more into up to 8 chunks whose uploads, kernels, downloads and host copies
+    // overlap; N >= 1: N chunks for every batch (1: the same machinery, one piece); -1: the
+    // serial path of rounds 1-4 (upload, kernels alone on one lane, download, copy)
+    TC_CHECK(value >= -1 && value <= 64, "sync_chunks must be in [-1, 64]");
+    t->tuning.sync_chunks = value;
+  } else if (key == "sync_form") {
+    TC_CHECK(value == 0 || value == 32 || value == 64, "sync_form must be 0, 32 or 64");
+    t->tuning.sync_form = value;
+  } else if (key == "sync_direct_out") {
+    TC_CHECK(value >= 0 && value <= 2, "sync_direct_out must be 0, 1 or 2");
+    t->tuning.sync_direct_out = value;
   } else if (key == "async_direct_in" || key == "async_direct_out") {
     // asynchronous host calls: 1 = the kernels read the draws from / write the results to
     // the caller's page-locked buffers themselves; 0 = copy commands on the lane's stream

@@ -585,3 +585,72 @@ def test_resident_ensemble_kernel_gives_up_cleanly():
     ngal, xi = halotab.predict_batch(theta)
     assert np.array_equal(xi, served[1])
     halotab.set_resident(False)
+
+
+@pytest.mark.parametrize('case', ['configs[1] table', 'separate', 'wide table: three kernels',
+                                  'float32 rp-pi table', 'mode cross'])
+def test_synchronous_calls_in_chunks(case):
+    """a synchronous host-array call is cut into chunks of draws whose
+    staging, kernels, transfers and copies overlap (table.cpp: predict_chunked).  Against the
+    oracle on draws of every chunk and around the chunk boundaries; the same bits for any
+    number of chunks where the one-launch form serves the table (its workgroups of 32 draws do
+    not care where a draw sits), rounding elsewhere; ragged sizes; the serial path agrees."""
+    from tabcorr_amd import synthetic, _lib
+    from oracle import tabcorr_oracle as oracle
+    lib = _lib.load()
+    kwargs, make_kwargs, exact, rtol = {}, {}, True, RTOL
+    if case == 'configs[1] table':
+        table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    elif case == 'separate':
+        table = synthetic.synthetic_table(30, 1, (19, ), 'auto', seed=2)
+        kwargs = {'separate_gal_type': True}
+    elif case == 'wide table: three kernels':
+        table = synthetic.synthetic_table(120, 1, (7, ), 'auto', seed=3)
+        exact = False
+    elif case == 'float32 rp-pi table':
+        table = synthetic.synthetic_table(20, 1, (6, 10), 'auto', seed=4)
+        make_kwargs = {'compute_dtype': 'float32'}
+        exact, rtol = False, 1e-5
+    else:
+        table = synthetic.synthetic_table(40, 2, (13, ), 'cross', seed=5)
+        exact = False
+    halotab = make_tabcorr(table, **make_kwargs)
+    handle = halotab.to_device().handle
+
+    def option(name, value):
+        _lib.check(lib.tc_table_set_option(handle, name, value))
+    n = 9000 + 37                       # (not a multiple of anything)
+    theta = synthetic.zheng07_draws(n, seed=17)
+
+    def parts(result, count):
+        """(ngal, xi) as two 2-D arrays, one row per draw."""
+        ngal, xi = result
+        if isinstance(ngal, dict):
+            return (np.stack([ngal[k] for k in ngal], -1).reshape(count, -1),
+                    np.stack([xi[k] for k in xi], 1).reshape(count, -1))
+        return np.asarray(ngal).reshape(count, 1), np.asarray(xi).reshape(count, -1)
+    loose = 10 * rtol if rtol > 1e-8 else 1e-12
+    results = {}
+    for chunks in (0, 1, 3, 8, -1):
+        option(b'sync_chunks', chunks)
+        results[chunks] = parts(halotab.predict_batch(theta, **kwargs), n)
+    # the oracle on draws of every chunk and at the boundaries of 3 and 8 chunks
+    index = np.unique(np.r_[0:2, 1150:1154, 3070:3074, 4500:4502, 6142:6146, n - 2:n])
+    want = parts(oracle.predict_zheng07_batch(table, theta[index], **kwargs), len(index))
+    for chunks, got in results.items():
+        for part in (0, 1):
+            assert_rel(got[part][index], want[part], rtol, 'chunks %d vs oracle' % chunks,
+                       floor=1e-13)
+            assert_rel(got[part], results[1][part], loose, 'chunks %d vs one piece' % chunks,
+                       floor=1e-13)
+    if exact:
+        for chunks in (0, 3, 8):
+            for part in (0, 1):
+                assert np.array_equal(results[chunks][part], results[1][part]), chunks
+    # a small call with more chunks requested than it has tiles of 64 draws
+    option(b'sync_chunks', 64)
+    few = parts(halotab.predict_batch(theta[:100], **kwargs), 100)
+    option(b'sync_chunks', 0)
+    ref = parts(halotab.predict_batch(theta[:100], **kwargs), 100)
+    for part in (0, 1):
+        assert_rel(few[part], ref[part], loose, floor=1e-13)
