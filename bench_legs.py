@@ -268,8 +268,12 @@ def unbatched(make, table, synthetic, Interpolator):
         count[0] += 1
         model.param_dict['logMmin'] = 12.0 + 1e-5 * (count[0] % 1000)
         halotab.predict(model)
+    # the library's default: a loop of un-batched calls is moved to the resident kernel by
+    # itself (option "resident" = 2); then one launch per call (set_resident(False)) ...
+    default = time_calls(call, seconds=0.3, warm=50)
+    halotab.set_resident(False)
     single = time_calls(call, seconds=0.3, warm=50)
-    # the same calls served by ONE resident launch (TabCorr.set_resident: the call writes its
+    # ... and the resident launch asked for (TabCorr.set_resident(True): the call writes its
     # parameters into a mailbox in page-locked memory, no launch per call), checked against
     # the one-launch-per-call result
     expect = halotab.predict(model)
@@ -330,7 +334,9 @@ def unbatched(make, table, synthetic, Interpolator):
             halotab.set_resident(False)
         except Exception:   # noqa: BLE001
             pass
-    return {'predict_model': single * 1e6,
+    return {'predict_model': default * 1e6,
+            'predict_model_calls_per_sec': 1.0 / default,
+            'predict_model_one_launch_per_call': single * 1e6,
             'predict_model_resident': None if resident is None else resident * 1e6,
             'predict_batch_walkers_resident': resident_walkers,
             'predict_model_resident_max_rel_vs_one_launch_per_call': resident_parity,

@@ -356,7 +356,14 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 after 10 s, and before any other kind of call on the handle and
  *                 tc_table_destroy.  Device-wide synchronisations by the caller
  *                 (hipDeviceSynchronize, hipFree) wait for it at most that idle time.
- *                 0 (default): one launch per call.
+ *                 2 (default): the library moves a loop of un-batched calls to the resident
+ *                 kernel by itself -- from the eighth call on that follows its predecessor
+ *                 within 300 us, with the idle time "resident_auto_idle_us" (default 250: the
+ *                 caller's device-wide synchronisations wait at most that long) -- and goes
+ *                 back to one launch per call for 4096 calls when more than a quarter of 32
+ *                 such calls found the kernel gone (a caller that pauses or synchronises the
+ *                 device between its calls).  Single draws only; ensembles need 1.
+ *                 0: one launch per call, always.
  *                 Calls with 24 .. 256 draws in host arrays (an ensemble sampler's step) are
  *                 served the same way by a second resident kernel of one workgroup per CU
  *                 (kernel_args.h: EnsembleArgs): no launch, no copy command, no stream

@@ -523,6 +523,20 @@ struct tc_table {
   struct Resident {
     int enabled = 0;
     int idle_us = 2000;
+    // Automatic mode (default; option "resident" = 2; table.cpp: resident_auto_*): un-batched
+    // calls that follow one another within auto_gap_us -- an MCMC's predict(model) loop -- are
+    // served by the resident kernel from the auto_streak_min-th on, with the short idle time
+    // auto_idle_us (a device-wide synchronisation by the caller waits for the kernel at most
+    // that long); when more than a quarter of 32 such calls find the kernel gone (the caller
+    // pauses or synchronises between calls: every call would pay a launch AND a stop), the
+    // launched path serves the next auto_backoff_calls calls.
+    int auto_mode = 1;
+    int auto_idle_us = 250, auto_gap_us = 300, auto_streak_min = 8, auto_backoff_calls = 4096;
+    int auto_streak = 0, auto_backoff = 0, auto_window = 0, auto_relaunches = 0;
+    long long auto_last_ns = 0;          // when the last un-batched call returned
+    bool auto_serving = false;           // the running launch was started by the automatic mode
+    unsigned long long relaunches = 0;   // calls that found the kernel gone (all modes)
+    int running_idle_us = 0;             // idle time of the launch that is running
     int poll_waves = 1;
     bool running = false;
     unsigned long long launch_id = 0;

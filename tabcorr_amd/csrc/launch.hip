@@ -1886,8 +1886,9 @@ int resident_predict(tc_table* t, const double* theta, int n_theta, int n_gauss,
   int status = get_quadrature(t, n_gauss, &q);
   if (status != TC_OK) return status;
   const int blocks = single_draw_blocks(t);
+  const int idle_us = r.enabled ? r.idle_us : std::min(r.idle_us, r.auto_idle_us);
   if (r.running && (r.ensemble || r.n_theta != n_theta || r.n_gauss != n_gauss ||
-                    r.flags != flags || r.blocks != blocks)) {
+                    r.flags != flags || r.blocks != blocks || r.running_idle_us != idle_us)) {
     status = resident_stop(t);        // (another kind of call: its own launch)
     if (status != TC_OK) return status;
   }
@@ -1932,7 +1933,9 @@ int resident_predict(tc_table* t, const double* theta, int n_theta, int n_gauss,
       sa.mailbox = entries;
       sa.exited = mailbox + kMailboxEntryWords;
       sa.launch_id = ++r.launch_id;
-      sa.idle_ticks = (unsigned long long)std::max(1, r.idle_us) * 100ull;   // 100 MHz
+      sa.idle_ticks = (unsigned long long)std::max(1, idle_us) * 100ull;     // 100 MHz
+      r.running_idle_us = idle_us;
+      r.auto_serving = !r.enabled;
       sa.life_ticks = 1000000000ull;                                          // 10 s
       sa.poll_waves = std::max(1, std::min(4, r.poll_waves));
       hipLaunchKernelGGL(tc::resident_draw_kernel, dim3((unsigned)blocks),
@@ -1953,6 +1956,7 @@ int resident_predict(tc_table* t, const double* theta, int n_theta, int n_gauss,
     }
     // a workgroup has left (idle or life time) before it saw this call: all of them out, then
     // a new launch serves it
+    ++r.relaunches;
     status = resident_stop(t);
     if (status != TC_OK) return status;
   }

@@ -406,6 +406,44 @@ int copy_out(PinnedBuffer* stage, double* ngal, size_t ngal_count, const void* d
 }  // namespace host
 }  // namespace tc
 
+namespace {
+long long monotonic_ns() {
+  timespec now{};
+  clock_gettime(CLOCK_MONOTONIC, &now);
+  return (long long)now.tv_sec * 1000000000LL + now.tv_nsec;
+}
+
+// Should this un-batched call go to the resident kernel although nobody asked for it?  From the
+// auto_streak_min-th call on that follows its predecessor within auto_gap_us, unless the mode
+// is backing off.
+bool resident_auto_wants(tc_table* t) {
+  tc_table::Resident& r = t->resident;
+  const long long now = monotonic_ns();
+  const bool close = r.auto_last_ns != 0 && now - r.auto_last_ns < (long long)r.auto_gap_us * 1000;
+  r.auto_streak = close ? std::min(r.auto_streak + 1, 1 << 20) : 0;
+  if (r.auto_backoff > 0) {
+    --r.auto_backoff;
+    return false;
+  }
+  return r.auto_streak >= r.auto_streak_min;
+}
+
+// Bookkeeping behind a call the automatic mode served: a window of 32 calls of which more than
+// a quarter found the kernel gone ends the mode for auto_backoff_calls calls.
+void resident_auto_served(tc_table* t, bool relaunched) {
+  tc_table::Resident& r = t->resident;
+  r.auto_last_ns = monotonic_ns();
+  r.auto_relaunches += relaunched ? 1 : 0;
+  if (++r.auto_window < 32) return;
+  if (r.auto_relaunches > 8) {
+    r.auto_backoff = r.auto_backoff_calls;
+    r.auto_streak = 0;
+    (void)resident_stop(t);
+  }
+  r.auto_window = r.auto_relaunches = 0;
+}
+}  // namespace
+
 extern "C" {
 
 int tc_predict_zheng07_many(tc_table* t, const double* theta, int n_theta, int n_walkers,
@@ -424,6 +462,15 @@ int tc_predict_zheng07_many(tc_table* t, const double* theta, int n_theta, int n
   TC_HIP(hipSetDevice(t->device));
   if (n_walkers == 1 && t->resident.enabled && resident_eligible(t, n_gauss))
     return resident_predict(t, theta, n_theta, n_gauss, flags, ngal, xi);
+  // the resident kernel by itself for loops of un-batched calls (internal.h: Resident::auto_*)
+  const bool auto_candidate = n_walkers == 1 && t->resident.auto_mode && !t->resident.enabled &&
+                              resident_eligible(t, n_gauss);
+  if (auto_candidate && resident_auto_wants(t)) {
+    const unsigned long long before = t->resident.relaunches;
+    status = resident_predict(t, theta, n_theta, n_gauss, flags, ngal, xi);
+    resident_auto_served(t, t->resident.relaunches != before);
+    return status;
+  }
   if (t->resident.enabled && ensemble_eligible(t, n_walkers, n_gauss, flags)) {
     status = ensemble_predict(t, theta, n_theta, n_walkers, n_gauss, flags, ngal, xi);
     if (status != TC_ERR_UNSUPPORTED) return status;     // (else: the launched path below)
@@ -436,6 +483,7 @@ int tc_predict_zheng07_many(tc_table* t, const double* theta, int n_theta, int n
   if (status != TC_OK) return status;
   for (int w = 0; w < n_walkers; ++w)
     combine_single_draw(t, t->single_ws, w, ngal + w, xi + (size_t)w * t->n_r);
+  if (auto_candidate) t->resident.auto_last_ns = monotonic_ns();
   return TC_OK;
 }
 
@@ -1212,11 +1260,22 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     // ONE resident launch that takes them from a mailbox in page-locked memory (launch.hip:
     // resident_predict); it leaves when idle for "resident_idle_us" and before any other kind
     // of call on this handle.  0 (default): one launch per call.
-    TC_CHECK(value == 0 || value == 1, "resident must be 0 or 1");
-    t->resident.enabled = value;
+    // 2 (default): by itself for loops of un-batched calls -- from the eighth call on that
+    // follows its predecessor within 300 us, with an idle time of 250 us, backing off when the
+    // caller's pauses or device-wide synchronisations keep ending the launch.
+    TC_CHECK(value >= 0 && value <= 2, "resident must be 0, 1 or 2");
+    t->resident.enabled = value == 1;
+    t->resident.auto_mode = value == 2;
+    t->resident.auto_streak = t->resident.auto_backoff = 0;
+    t->resident.auto_window = t->resident.auto_relaunches = 0;
     t->resident.ens_disabled = false;
     t->resident.ens_failures = 0;
-    if (value == 0) return resident_stop(t);
+    if (value != 1) return resident_stop(t);
+  } else if (key == "resident_auto_idle_us") {
+    TC_CHECK(value >= 10 && value <= 100000, "resident_auto_idle_us must be in [10, 100000]");
+    const int status = resident_stop(t);
+    if (status != TC_OK) return status;
+    t->resident.auto_idle_us = value;
   } else if (key == "resident_poll_waves") {
     TC_CHECK(value >= 1 && value <= 4, "resident_poll_waves must be in [1, 4]");
     const int status = resident_stop(t);

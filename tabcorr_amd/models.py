@@ -267,10 +267,16 @@ class DeviceSpec:
 
     def __init__(self, theta, modulate_with_cenocc=False, assembias=False,
                  family='zheng07'):
-        self.theta = np.asarray(theta, dtype=np.float64)
+        # (a list of floats: the un-batched path copies it straight into its
+        # staging array; `theta` makes the array the batched paths want)
+        self.values = theta
         self.modulate_with_cenocc = bool(modulate_with_cenocc)
         self.assembias = bool(assembias)
         self.family = family
+
+
+DeviceSpec.theta = property(
+    lambda self: np.asarray(self.values, dtype=np.float64))
 
 
 def device_spec(model):

@@ -361,6 +361,7 @@ def test_resident_kernel_serves_unbatched_calls():
     table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
     theta = synthetic.zheng07_draws(300, seed=8)
     halotab = make_tabcorr(table)
+    halotab.set_resident(False)         # (one launch per call, not the automatic mode)
     plain = [halotab.predict_batch(theta[i:i + 1]) for i in range(300)]
     halotab.set_resident(True)
     first = []
@@ -422,6 +423,83 @@ def test_resident_kernel_serves_unbatched_calls():
     halotab.set_resident(True)
     ngal, xi = halotab.predict(model)
     assert np.array_equal(xi, plain[3][1][0])
+
+
+def test_resident_kernel_by_itself_for_loops_of_unbatched_calls():
+    """The default (option "resident" = 2): a plain loop of predict(model) is moved to the
+    resident kernel by the library -- same bits as with the option set, faster than one launch
+    per call --, a caller that synchronises the device between its calls never waits for the
+    kernel longer than its short idle time and is served by launches again after a while, and
+    random pauses, other kinds of calls and device-wide synchronisations in between change no
+    result (tools/r04_resident_stress.py with nothing switched on)."""
+    import time
+    from tabcorr_amd import synthetic, Zheng07Model, _lib
+    lib = _lib.load()
+    table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    theta = synthetic.zheng07_draws(400, seed=8)
+    halotab = make_tabcorr(table)
+    halotab.set_resident(False)
+    launched = [halotab.predict_batch(theta[i:i + 1]) for i in range(400)]
+    halotab.set_resident(True)
+    resident = [halotab.predict_batch(theta[i:i + 1]) for i in range(400)]
+    halotab.set_resident('auto')
+    model = Zheng07Model(redshift=table['attrs']['redshift'])
+    keys = ('logMmin', 'sigma_logM', 'logM0', 'logM1', 'alpha')
+
+    def loop(n):
+        t0 = time.perf_counter()
+        for call in range(n):
+            i = call % 400
+            for key, value in zip(keys, theta[i]):
+                model.param_dict[key] = value
+            ngal, xi = halotab.predict(model)
+            # the first calls are launches, the later ones the resident kernel's
+            assert (np.array_equal(xi, launched[i][1][0]) or
+                    np.array_equal(xi, resident[i][1][0])), call
+            if call >= 16:
+                assert np.array_equal(xi, resident[i][1][0]), call
+        return (time.perf_counter() - t0) / n
+    per_call_auto = loop(3000)
+    halotab.set_resident(False)
+    t0 = time.perf_counter()
+    for call in range(3000):
+        halotab.predict_batch(theta[call % 400:call % 400 + 1])
+    per_call_launched = (time.perf_counter() - t0) / 3000
+    assert per_call_auto < 0.9 * per_call_launched, (per_call_auto, per_call_launched)
+    # a caller that synchronises the device after every call: never more than the automatic
+    # idle time (250 us) + the synchronisation's own cost, and launches again after the window
+    halotab.set_resident('auto')
+    waits = []
+    for call in range(400):
+        ngal, xi = halotab.predict_batch(theta[call % 400:call % 400 + 1])
+        t0 = time.perf_counter()
+        _lib.check(lib.tc_device_synchronize())
+        waits.append(time.perf_counter() - t0)
+        assert (np.array_equal(xi, launched[call % 400][1]) or
+                np.array_equal(xi, resident[call % 400][1])), call
+    assert max(waits) < 600e-6, max(waits)
+    assert np.median(waits[-200:]) < 100e-6, np.median(waits[-200:])      # (backed off)
+    # random interleaving, nothing switched on
+    halotab.set_resident('auto')
+    rng = np.random.default_rng(5)
+    batch = halotab.predict_batch(theta[:200])
+    for call in range(6000):
+        what = rng.random()
+        i = int(rng.integers(0, 400))
+        if what < 0.93:
+            ngal, xi = halotab.predict_batch(theta[i:i + 1])
+            assert (np.array_equal(xi, launched[i][1]) or
+                    np.array_equal(xi, resident[i][1])), (call, i)
+        elif what < 0.95:
+            again = halotab.predict_batch(theta[:200])
+            assert np.array_equal(again[1], batch[1])
+        elif what < 0.97:
+            _lib.check(lib.tc_device_synchronize())
+        elif what < 0.98:
+            halotab.predict_batch(theta[i:i + 1], modulate_with_cenocc=True)
+        else:
+            time.sleep(float(rng.uniform(0, 0.0006)))
+    del halotab          # (a table deleted while the kernel it started by itself runs)
 
 
 @pytest.mark.parametrize('shape, n_prim', [((5, 5), 50), ((4, 4, 4), 50), ((4, 7), 50), ((4, 4, 4), 6)])
