@@ -326,6 +326,11 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 calls with these flags then take the measured form of the nearest batch size
  *                 instead of the built-in estimate (fitted on a handful of table shapes).  -1:
  *                 forget every measurement.  tc_table_autotune_result reads it back.
+ *   "autotune_after"  default 256: the N-th pipelined device-pointer or asynchronous call
+ *                 with one combination of predict flags (tables the one-launch forms can serve)
+ *                 runs "autotune" for that combination by itself -- about half a second, once
+ *                 -- so that a loop of calls gets the measured form without asking; the
+ *                 built-in estimate serves the calls before it.  0: never.
  *   "series"      bit mask, default 1.  Bit 0: the Gauss-Legendre sum of an undecorated
  *                 central bin (tabcorr/tabcorr.py:556-578) by its moment expansion around the
  *                 bin centre -- the same sum re-ordered, one erf and 8 .. 24 short terms instead

@@ -304,6 +304,9 @@ struct Tuning {
   // workgroup of the one-launch form the chunks take where it serves the table (so that the
   // result does not depend on the number of chunks; 0: whatever a pipelined call of the chunk's
   // size would take); sync_direct_out as async_direct_out, for the staging area of the chunks
+  // the dispatch measures itself (option "autotune") at this many pipelined / asynchronous
+  // calls with one combination of predict flags (0: never by itself)
+  int autotune_after = 256;
   int sync_chunks = 0;
   int sync_form = 32;
   int sync_direct_out = 2;
@@ -463,6 +466,10 @@ struct tc_table {
   int n_xcds = 8;                // accelerator complexes (each with its own L2)
   tc::host::Tuning tuning;
   std::map<unsigned, AutoChoice> autotuned;      // by predict flags (n_gauss_prim = 10)
+  // pipelined / asynchronous calls seen per predict flags: the autotune_after-th one measures
+  // the forms by itself (table.cpp: maybe_autotune)
+  std::map<unsigned, int> pipelined_calls;
+  bool autotuning = false;
   std::map<int, tc::host::Quadrature> quadrature;
   std::map<std::pair<int, int>, std::unique_ptr<tc::host::DeviceChunking>> chunkings;
   std::map<int64_t, tc::host::DeviceChunking*> choices;   // decomposition chosen per tile count
@@ -619,7 +626,7 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
 bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags);
 int fused_dens_rows(const tc_table* t, bool separate);
 int fused_lds_bytes(const tc_table* t, bool separate, int waves, int draws);
-int fused_waves(const tc_table* t, bool separate);
+int fused_waves(const tc_table* t, bool separate, unsigned flags);
 bool fused_half_tiles(const tc_table* t, bool separate, int64_t n_draws, int n_gauss,
                       unsigned flags);
 bool fused_wide_tables(const tc_table* t, bool separate, int n_gauss, unsigned flags);

@@ -176,6 +176,83 @@ __device__ __forceinline__ double sat_series_value(const double* table, const fm
 }
 
 
+// The node loop of bin g (tabcorr.py:556-578 with the Zheng07 callbacks inline) and the fix-ups
+// of draws it cannot represent: what occ_bin_zheng07 runs where no shortcut or expansion
+// applies.  Ptr = scalar-cache pointers with a wave-uniform g (the constants are scalar
+// operands), or plain pointers with a bin PER LANE -- the deferred (bin, draw) pairs of
+// predict_fused_kernel, whose constants come by vector loads; `central`, `above` and d.any_bad
+// are per lane resp. recomputed by the caller there.
+template <int NGAUSS, bool ASSEMBIAS, bool MODULATE, typename Ptr>
+__device__ __forceinline__ double occ_nodes_zheng07(const double* table, const fm::Consts& kc,
+                                                    int g, int n_gauss, bool central, bool above,
+                                                    Ptr log_m, Ptr mass, Ptr weight,
+                                                    Ptr weight_sum, const DrawParams& d,
+                                                    double f1, double f2) {
+  constexpr bool assembias = ASSEMBIAS;
+  constexpr bool modulate = MODULATE;
+  const double log_m_min = d.log_m_min, inv_sigma = d.inv_sigma, m0 = d.m0;
+  const double log2_m1 = d.log2_m1, sat_scale = d.sat_scale, alpha = d.alpha;
+  const double a_cen = d.a_cen, a_sat = d.a_sat;
+  const int bad = d.bad;
+  const bool median = assembias && f1 == 1.0 && f2 == 1.0;
+  const double s_cen = above ? a_cen : -a_cen, s_sat = above ? a_sat : -a_sat;
+  double acc = 0.0;
+  if (central && !assembias) {
+    // sum_k w_k (1 + erf_k) / 2 = (W + sum_k w_k erf_k) / 2 with W = sum_k w_k from the host
+    // (get_quadrature): one instruction per node less than forming every <N_cen> first
+#pragma unroll NGAUSS > 0 ? NGAUSS : 1
+    for (int k = 0; k < n_gauss; ++k) {
+      const double lm = log_m[g * n_gauss + k];
+      acc = fma(weight[g * n_gauss + k],
+                fm::erf_fast(table, kc, (lm - log_m_min) * inv_sigma), acc);
+    }
+    acc = fma(0.5, acc, 0.5 * weight_sum[g]);
+  } else if (central) {
+#pragma unroll NGAUSS > 0 ? NGAUSS : 1
+    for (int k = 0; k < n_gauss; ++k) {
+      const double lm = log_m[g * n_gauss + k];
+      double n = fma(0.5, fm::erf_fast(table, kc, (lm - log_m_min) * inv_sigma), 0.5);
+      n = median ? fma(s_cen, fmin(n, 1.0 - n), n)
+                 : heaviside_assembias(n, a_cen, above, f2, f1, true);
+      acc = fma(weight[g * n_gauss + k], n, acc);
+    }
+  } else {
+#pragma unroll NGAUSS > 0 ? NGAUSS : 1
+    for (int k = 0; k < n_gauss; ++k) {
+      const double x = mass[g * n_gauss + k] - m0;
+      // 1e-300 keeps log2's input a positive normal number on the lanes with
+      // M <= M0, whose result the scaling step of exp2 then sets to exactly 0
+      double n = fm::exp2_fast(
+          table, kc,
+          alpha * fm::log2_fast_offset(table, kc, x > 1e-300 ? x : 1e-300, log2_m1),
+          x > 0.0);
+      // (another split: the decoration is not linear in n, everything per node)
+      if (assembias && !median) n *= sat_scale;
+      if (modulate) {
+        const double lm = log_m[g * n_gauss + k];
+        n *= fma(0.5, fm::erf_fast(table, kc, (lm - log_m_min) * inv_sigma), 0.5);
+      }
+      if (assembias && !median) n = heaviside_assembias(n, a_sat, above, f2, f1, false);
+      acc = fma(weight[g * n_gauss + k], n, acc);
+    }
+    if (!assembias || median) acc *= sat_scale;
+    if (median) acc = fma(s_sat, acc, acc);
+  }
+  if (d.any_bad) {
+    bool tie = false;
+    if ((bad & kTieCen) && (central || modulate))
+      for (int k = 0; k < n_gauss; ++k) tie = tie || log_m[g * n_gauss + k] == log_m_min;
+    const bool cen_nan = (bad & kBadCen) || tie;
+    if (!central && (bad & kInfSat) && acc != 0.0) {
+      // (decorated: the shift limit is inf - inf = NaN in the reference's arithmetic)
+      acc = assembias ? __builtin_nan("") : __builtin_huge_val();
+    }
+    if (central ? cen_nan : (((bad & kBadSat) && acc != 0.0) || (modulate && cen_nan)))
+      acc = __builtin_nan("");
+  }
+  return acc;
+}
+
 template <int NGAUSS, bool ASSEMBIAS, bool MODULATE>
 __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm::Consts& kc,
                                                   int g, int n_gauss, bool central, bool above,
@@ -186,9 +263,7 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
   constexpr bool assembias = ASSEMBIAS;
   constexpr bool modulate = MODULATE;
   const double log_m_min = d.log_m_min, inv_sigma = d.inv_sigma, m0 = d.m0;
-  const double log2_m1 = d.log2_m1, sat_scale = d.sat_scale, alpha = d.alpha;
-  const double a_cen = d.a_cen, a_sat = d.a_sat;
-  const int bad = d.bad;
+  const double sat_scale = d.sat_scale, a_sat = d.a_sat;
   const bool any_bad = d.any_bad;
   // Split at the median (f1 = f2 = 1, what the device path is given: models.device_spec): the
   // limit of the shift is min(n, 1 - n) for either sign of the strength (centrals) and n itself
@@ -196,7 +271,7 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
   // s = +-strength above / below the split -- three instructions per central node instead of
   // ten, and for the satellites one factor on the finished bin sum.
   const bool median = assembias && f1 == 1.0 && f2 == 1.0;
-  const double s_cen = above ? a_cen : -a_cen, s_sat = above ? a_sat : -a_sat;
+  const double s_sat = above ? a_sat : -a_sat;
   double acc = 0.0;
   // Wave-uniform shortcuts (the draws of a sampler's ensemble cluster around the posterior,
   // so whole bins sit on the plateaus for all 64 draws of a tile): a bin whose nodes all
@@ -234,25 +309,6 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
                               weight_sum[g], sr.thresholds + g * series::kThresholds,
                               d.inv_sigma_hi);
     acc = fma(0.5, acc, 0.5 * weight_sum[g]);
-  } else if (central && !assembias) {
-    // sum_k w_k (1 + erf_k) / 2 = (W + sum_k w_k erf_k) / 2 with W = sum_k w_k from the host
-    // (get_quadrature): one instruction per node less than forming every <N_cen> first
-#pragma unroll NGAUSS > 0 ? NGAUSS : 1
-    for (int k = 0; k < n_gauss; ++k) {
-      const double lm = log_m[g * n_gauss + k];
-      acc = fma(weight[g * n_gauss + k],
-                fm::erf_fast(table, kc, (lm - log_m_min) * inv_sigma), acc);
-    }
-    acc = fma(0.5, acc, 0.5 * weight_sum[g]);
-  } else if (central) {
-#pragma unroll NGAUSS > 0 ? NGAUSS : 1
-    for (int k = 0; k < n_gauss; ++k) {
-      const double lm = log_m[g * n_gauss + k];
-      double n = fma(0.5, fm::erf_fast(table, kc, (lm - log_m_min) * inv_sigma), 0.5);
-      n = median ? fma(s_cen, fmin(n, 1.0 - n), n)
-                 : heaviside_assembias(n, a_cen, above, f2, f1, true);
-      acc = fma(weight[g * n_gauss + k], n, acc);
-    }
   } else if (series_sat) {
     // a satellite bin well above the draw's M0: the binomial expansion of its node sum
     acc = sat_series_value(table, kc, sr.sat_consts + g * series::sat::kStride,
@@ -260,38 +316,11 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
     acc *= sat_scale;
     if (median) acc = fma(s_sat, acc, acc);
   } else {
-#pragma unroll NGAUSS > 0 ? NGAUSS : 1
-    for (int k = 0; k < n_gauss; ++k) {
-      const double x = mass[g * n_gauss + k] - m0;
-      // 1e-300 keeps log2's input a positive normal number on the lanes with
-      // M <= M0, whose result the scaling step of exp2 then sets to exactly 0
-      double n = fm::exp2_fast(
-          table, kc,
-          alpha * fm::log2_fast_offset(table, kc, x > 1e-300 ? x : 1e-300, log2_m1),
-          x > 0.0);
-      // (another split: the decoration is not linear in n, everything per node)
-      if (assembias && !median) n *= sat_scale;
-      if (modulate) {
-        const double lm = log_m[g * n_gauss + k];
-        n *= fma(0.5, fm::erf_fast(table, kc, (lm - log_m_min) * inv_sigma), 0.5);
-      }
-      if (assembias && !median) n = heaviside_assembias(n, a_sat, above, f2, f1, false);
-      acc = fma(weight[g * n_gauss + k], n, acc);
-    }
-    if (!assembias || median) acc *= sat_scale;
-    if (median) acc = fma(s_sat, acc, acc);
-  }
-  if (any_bad) {
-    bool tie = false;
-    if ((bad & kTieCen) && (central || modulate))
-      for (int k = 0; k < n_gauss; ++k) tie = tie || log_m[g * n_gauss + k] == log_m_min;
-    const bool cen_nan = (bad & kBadCen) || tie;
-    if (!central && (bad & kInfSat) && acc != 0.0) {
-      // (decorated: the shift limit is inf - inf = NaN in the reference's arithmetic)
-      acc = assembias ? __builtin_nan("") : __builtin_huge_val();
-    }
-    if (central ? cen_nan : (((bad & kBadSat) && acc != 0.0) || (modulate && cen_nan)))
-      acc = __builtin_nan("");
+    // (no shortcut, no expansion for this lane's draw: the node loop, and the fix-ups of the
+    // draws it cannot represent -- such draws never qualify for an expansion, series_setup)
+    acc = occ_nodes_zheng07<NGAUSS, ASSEMBIAS, MODULATE>(table, kc, g, n_gauss, central, above,
+                                                        log_m, mass, weight, weight_sum, d, f1,
+                                                        f2);
   }
   return acc;
 }

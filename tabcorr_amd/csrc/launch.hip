@@ -1053,7 +1053,7 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
   // 138.7, 240 189.6 / 215.0 / 192.3; G = 100: 43.5 / 39.4 / 43.2 -- so beyond 104 bins the
   // one-launch form (16 waves, up to 160 KB: 248 bins) is taken only when forced.
   const bool wide = fused_wide_tables(t, separate, n_gauss, flags);
-  if (n_gauss < 1 || (!wide && fused_waves(t, separate) == 0)) return false;
+  if (n_gauss < 1 || (!wide && fused_waves(t, separate, flags) == 0)) return false;
   // a measured choice for this table and these flags (option "autotune") replaces the formula
   // below for the calls it was measured on: pipelined device-pointer and asynchronous calls
   if (n_gauss == 10 && t->tuning.fused == 1 && t->tuning.fused_min_draws == 0) {
@@ -1076,7 +1076,7 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
     const tc::QuadLayout& layout = separate ? t->quad_by_type.layout : t->quad_total.layout;
     const double estimate = (5.0 + 10.0 * (t->n_bins / 100.0) * (n_gauss / 10.0) +
                              60.0 * ((double)layout.n_units / 325.0) * (t->quad_tiling.n_u / 5.0)) *
-                            8.0 / (wide ? 16 : fused_waves(t, separate));
+                            8.0 / (wide ? 16 : fused_waves(t, separate, flags));
     // Leauthaud11 (a Newton inverse of the stellar-to-halo mass relation per central node: the
     // occupations outweigh the matrix work and spread better over the chip as a kernel of their
     // own): tools/archive/r03_fused_leauthaud.py, us per step, three kernels / one launch of 64-draw
@@ -1166,14 +1166,16 @@ bool fused_wide_tables(const tc_table* t, bool separate, int n_gauss, unsigned f
 }
 
 // Waves per workgroup of the one-launch form for this table: 8, 16, or 0 (does not fit).
-int fused_waves(const tc_table* t, bool separate) {
+int fused_waves(const tc_table* t, bool separate, unsigned flags) {
   const bool fits8 = fused_lds_bytes(t, separate, 8, 64) <= 80 * 1024;
   const bool fits16 = fused_lds_bytes(t, separate, 16, 64) <= 160 * 1024;
   if (t->tuning.fused_waves == 8 && fused_lds_bytes(t, separate, 8, 64) <= 160 * 1024) return 8;
   if (t->tuning.fused_waves == 16 && fits16) return 16;
   // (16 waves: level with the three kernels on the shapes swept by hand, so only when forced --
-  // or when option "autotune" has measured this table: its choice then decides)
-  return fits8 ? 8 : (fits16 && (t->tuning.fused >= 2 || !t->autotuned.empty())) ? 16 : 0;
+  // or when the table has been measured with THESE flags (option "autotune"): that choice then
+  // decides; a measurement with other flags says nothing about this LDS footprint)
+  return fits8 ? 8
+               : (fits16 && (t->tuning.fused >= 2 || t->autotuned.count(flags) != 0)) ? 16 : 0;
 }
 
 namespace {
@@ -1226,7 +1228,7 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   fa.separate = separate ? 1 : 0;
   const bool wide = fused_wide_tables(t, separate, n_gauss, flags);
   const bool half_tiles = !wide && fused_half_tiles(t, separate, n_draws, n_gauss, flags);
-  const int waves = wide || half_tiles ? 8 : fused_waves(t, separate);
+  const int waves = wide || half_tiles ? 8 : fused_waves(t, separate, flags);
   const int draws = wide || half_tiles ? 32 : 64;
   const int n_parts = waves * 32 / draws;
   if (!separate) {

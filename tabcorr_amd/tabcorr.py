@@ -242,13 +242,17 @@ class TabCorr:
         return self._device
 
     def autotune(self, separate_gal_type=False, modulate_with_cenocc=False,
-                 assembias=False, family='zheng07'):
+                 assembias=False, family='zheng07', measure=True):
         """Measure which form of the batched path -- three kernels, or one
         launch with 64-draw / 32-draw workgroups -- serves this table fastest
         at batch sizes 256 ... 65536, and let the pipelined and asynchronous
         calls with these options take the measured form (about half a second;
         ``tc_table_set_option "autotune"``).  Without it the library estimates
-        the crossovers from the table's shape.
+        the crossovers from the table's shape -- until it has seen 256
+        pipelined or asynchronous calls with one combination of options: that
+        call runs this measurement by itself (option ``"autotune_after"``).
+        ``measure=False`` only reads the stored result (``None`` if there is
+        none yet).
 
         Returns
         -------
@@ -265,9 +269,18 @@ class TabCorr:
         forms = np.zeros(16, dtype=np.int32)
         us = np.zeros((16, 3), dtype=np.float32)
         with device.lock:
-            _lib.check(device.lib.tc_table_set_option(
-                device.handle, b'autotune', flags))
+            if measure:
+                _lib.check(device.lib.tc_table_set_option(
+                    device.handle, b'autotune', flags))
             count = ctypes.c_int(0)
+            status = device.lib.tc_table_autotune_result(
+                device.handle, flags, 16, ctypes.byref(count),
+                sizes.ctypes.data_as(_lib.c_int64_p),
+                forms.ctypes.data_as(_lib.c_int_p),
+                us.ctypes.data_as(_lib.c_float_p))
+            if status != 0 and not measure:
+                return None
+            _lib.check(status)
             _lib.check(device.lib.tc_table_autotune_result(
                 device.handle, flags, 16, ctypes.byref(count),
                 sizes.ctypes.data_as(_lib.c_int64_p),

@@ -295,7 +295,8 @@ def test_fused_at_the_benchmarked_batch_size():
     expect = oracle.predict_zheng07_batch(table, theta[index])
     assert_rel(ngal[index], expect[0], RTOL)
     assert_rel(xi[index], expect[1], RTOL)
-    ngal3, xi3 = halotab.predict_batch(theta)          # synchronous: three kernels
+    set_option(halotab, 'sync_chunks', -1)             # (the serial path: ...
+    ngal3, xi3 = halotab.predict_batch(theta)          # ... synchronous, three kernels)
     assert last_launch(halotab)[2] > 0
     assert_rel(ngal, ngal3, 1e-13)
     assert_rel(xi, xi3, 1e-12)
@@ -729,12 +730,14 @@ def test_fused_32_draws_with_assembly_bias(n_prim, n_sec, n_r, n_draws, modulate
     assert_rel(got[1][good], want[1][good], 1e-12)
 
 
+@pytest.mark.parametrize('how', ['asked', 'by itself'])
 @pytest.mark.parametrize('n_prim, n_r', [(40, 8), (100, 19), (50, 19)])
-def test_autotune_picks_the_fastest_form(n_prim, n_r):
+def test_autotune_picks_the_fastest_form(n_prim, n_r, how):
     """Option "autotune" (TabCorr.autotune): the measured choice between three kernels and the
     one-launch forms is never far behind the best forced form -- the built-in estimate, fitted
     on a handful of shapes, is up to 40 % behind on others (tools/r04_autotune.py) -- and the
-    results do not depend on it."""
+    results do not depend on it.  'by itself' (VERDICT r04 item 5): nobody calls autotune();
+    the 256th pipelined call with these flags measures (option "autotune_after")."""
     import ctypes
     import time
     from tabcorr_amd import synthetic, _lib
@@ -765,7 +768,16 @@ def test_autotune_picks_the_fastest_form(n_prim, n_r):
         _lib.check(lib.tc_table_synchronize(handle))
         return (time.perf_counter() - t0) / count * 1e6
 
-    result = halotab.autotune()
+    if how == 'asked':
+        result = halotab.autotune()
+    else:
+        assert halotab.autotune(measure=False) is None
+        for _ in range(300):
+            _lib.check(lib.tc_predict_zheng07_batch_device(handle, d_theta, 5, 3000, 10, 0, d_ngal,
+                                                           d_xi))
+        _lib.check(lib.tc_table_synchronize(handle))
+        result = halotab.autotune(measure=False)
+        assert result is not None, 'the 256th pipelined call did not measure'
     assert list(result['sizes']) == [256 << i for i in range(9)]
     assert set(result['forms']) <= {0, 32, 64} and np.all(result['us_per_call'][:, 0] > 0)
     sizes = (3000, 12000)          # (device-bound; below ~1000 draws the host thread binds)
