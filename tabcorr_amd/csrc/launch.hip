@@ -3,6 +3,8 @@
 // table's lanes (internal.h).
 #include <immintrin.h>
 
+#include <mutex>
+
 #include "internal.h"
 #include "kernels.hip.h"
 #include "series.h"
@@ -1978,13 +1980,7 @@ struct EnsembleLayout {
 };
 
 bool ensemble_layout(const tc_table* t, int n_gauss, EnsembleLayout* out) {
-  static const int n_cus = [] {
-    hipDeviceProp_t prop{};
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess) return 0;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
-    return prop.multiProcessorCount;
-  }();
+  const int n_cus = t->n_cus;       // (of the handle's device, not of whichever is current)
   EnsembleLayout l;
   l.n_slices = std::min(64, n_cus / 4);
   l.grid = 4 * l.n_slices;
@@ -2021,9 +2017,13 @@ bool ensemble_layout(const tc_table* t, int n_gauss, EnsembleLayout* out) {
 }  // namespace
 
 bool ensemble_eligible(const tc_table* t, int64_t n_walkers, int n_gauss, unsigned flags) {
+  // (walker b is served by workgroup b: on a device with fewer than 256 CUs the grid -- 4 x
+  // min(64, CUs / 4) workgroups -- bounds the ensemble, or walkers beyond it would never be
+  // computed and every such call would wait out its time limits before falling back)
   EnsembleLayout l;
-  return !t->resident.ens_disabled && n_walkers >= std::max(2, t->resident.min_walkers) && n_walkers <= tc::kEnsembleMaxWalkers &&
-         single_draw_eligible(t, 1, n_gauss, flags) && ensemble_layout(t, n_gauss, &l);
+  return !t->resident.ens_disabled && n_walkers >= std::max(2, t->resident.min_walkers) &&
+         n_walkers <= tc::kEnsembleMaxWalkers && single_draw_eligible(t, 1, n_gauss, flags) &&
+         ensemble_layout(t, n_gauss, &l) && n_walkers <= l.grid;
 }
 
 int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walkers, int n_gauss,
@@ -2145,11 +2145,17 @@ int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walker
       ea.lds_ij = l.lds_ij;
       // (the word a previous launch's workgroup 0 left behind)
       TC_HIP(hipMemsetAsync(ea.callword, 0, 8, r.stream));
-      static int attribute_device = -1;
-      if (attribute_device != t->device) {
-        TC_HIP(hipFuncSetAttribute((const void*)tc::resident_ensemble_kernel,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attribute_device = t->device;
+      {
+        // (the attribute belongs to the function ON a device: once per device, and handles may
+        // be used from different threads)
+        static std::mutex attribute_mutex;
+        static bool attribute_set[64] = {};
+        std::lock_guard<std::mutex> lock(attribute_mutex);
+        if (!(t->device >= 0 && t->device < 64 && attribute_set[t->device])) {
+          TC_HIP(hipFuncSetAttribute((const void*)tc::resident_ensemble_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+          if (t->device >= 0 && t->device < 64) attribute_set[t->device] = true;
+        }
       }
       hipLaunchKernelGGL(tc::resident_ensemble_kernel, dim3((unsigned)l.grid),
                          dim3(tc::kEnsembleThreads), (size_t)l.lds_bytes, r.stream, ea);

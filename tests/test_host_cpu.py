@@ -1123,3 +1123,44 @@ def test_satellite_binomial_expansion_reproduces_the_node_loop():
             assert np.array_equal(series[~used], nodes[~used])
             seen.setdefault(width, set()).update(int(t) for t in terms)
     assert {0, 20, 24} <= seen[0.09] and {0, 12} <= seen[0.0121]
+
+
+def test_no_kernel_spills_vector_registers():
+    """every shipped instance of the prediction kernels compiles without
+    vector-register spills and scratch (hipcc's kernel-resource-usage remarks of launch.hip,
+    tools/kernel_resources.py) -- except the two resident kernels, whose known counts may only
+    go down (latency paths: one workgroup per CU resp. a handful of workgroups)."""
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(REPO, 'tools'))
+    import kernel_resources
+    from tabcorr_amd import build
+    compiler = build.hipcc()
+    if shutil.which('c++filt') is None:
+        pytest.skip('c++filt not found')
+    with tempfile.TemporaryDirectory() as tmp:
+        out = subprocess.run(
+            [compiler] + build.FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-c',
+                                        os.path.join(REPO, 'tabcorr_amd', 'csrc', 'launch.hip'),
+                                        '-o', os.path.join(tmp, 'launch.o')],
+            capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    kernels = kernel_resources.parse(out.stderr)
+    names = kernel_resources.demangle(list(kernels))
+    assert len(kernels) > 150
+    allowed = {'tc::resident_draw_kernel': 1, 'tc::resident_ensemble_kernel': 19}
+    spilling = {}
+    for mangled, usage in kernels.items():
+        name = names[mangled].replace('void ', '').split('(')[0]
+        spills = usage.get('VGPRs Spill', 0)
+        if spills > allowed.get(name, 0):
+            spilling[names[mangled]] = (spills, usage.get('ScratchSize', 0))
+        if name not in allowed:
+            assert usage.get('ScratchSize', 0) == 0, (names[mangled], usage)
+    assert not spilling, spilling
+    # the instances whose two workgroups per CU need four waves per SIMD stay within 128
+    for mangled, usage in kernels.items():
+        name = names[mangled]
+        if ('predict_fused_kernel<10, 5, false, false, false, 8, 64, false>' in name or
+                'predict_cross_fused_kernel<8,' in name or 'predict_cross_small_kernel' in name):
+            assert usage['VGPRs'] <= 128, (name, usage['VGPRs'])

@@ -9,10 +9,10 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 WHAT=${1:-all}
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 OUT=gpurun_out/profile
 mkdir -p $OUT
-FAST="--cpu-seconds 0 --other-configs 0"
+FAST="--cpu-seconds 0 --detail 0"
 
 pmc_passes() {   # $1 = output stem, rest = bench arguments
   local stem=$1; shift
@@ -54,7 +54,10 @@ if [ $WHAT = main ] || [ $WHAT = all ]; then
   # (default lanes: the profiler serialises the dispatches itself; the timed region then runs
   # predict_fused_kernel, bench.py's serialised pass the three kernels -- both are counted)
   pmc_passes pmc_summary --steps 50 --warmup 5 $FAST
-  python bench.py > $OUT/bench.json 2> $OUT/bench.err
+  # (the last line of stdout is the record; everything else sits in the sidecar)
+  python bench.py > $OUT/bench.log 2> $OUT/bench.err
+  tail -1 $OUT/bench.log > $OUT/bench.json
+  cp bench_detail.json $OUT/bench_detail.json
   echo "default bench done"
   # the driver's own command (short timed region), three times
   : > $OUT/bench_driver_command.json
