@@ -236,7 +236,7 @@ void bin_consts(int n_gauss, const double* log_m, const double* weight, double l
     long double moment = 0.0L;
     for (int k = 0; k < n_gauss; ++k)
       moment += (long double)weight[k] * powl((long double)log_m[k] - (long double)centre, n);
-    consts[1 + n] = (double)((n % 2 ? 1.0L : -1.0L) * moment / factorial);
+    consts[kFirst + n - 1] = (double)((n % 2 ? 1.0L : -1.0L) * moment / factorial);
   }
   // (the nodes may lie a rounding error outside the edges: the bound uses the farthest one)
   double reach = half;
@@ -281,7 +281,7 @@ void bin_consts(int n_gauss, const double* mass, const double* weight, double lo
     for (int k = 0; k < n_gauss; ++k)
       moment += (long double)weight[k] *
                 powl((long double)mass[k] / (long double)centre - 1.0L, n);
-    consts[2 + n] = (double)(moment / factorial);
+    consts[n == 0 ? 3 : kFirst + n - 1] = (double)(moment / factorial);
   }
   if (!std::isfinite(y_max)) return;
   for (int s = 0; s < kSteps; ++s) {

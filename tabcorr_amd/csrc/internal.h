@@ -239,13 +239,15 @@ struct CrossFused {
   // chunks of whole groups of at most kCrossChunkBins bins (kernel_args.h: CrossFusedArgs)
   void* d_chunk_group = nullptr;
   void* d_chunk_block = nullptr;     // first 4-bin step of every chunk (matrix-operand layout)
+  void* d_bin_operand = nullptr;     // where a member bin's operands start (deferred pairs)
   std::vector<int32_t> chunk_group_host;
   int n_chunks = 0, n_central_chunks = 0;
   void release() {
     if (d_rows != nullptr) (void)hipFree(d_rows);
     if (d_chunk_group != nullptr) (void)hipFree(d_chunk_group);
     if (d_chunk_block != nullptr) (void)hipFree(d_chunk_block);
-    d_rows = d_chunk_group = d_chunk_block = nullptr;
+    if (d_bin_operand != nullptr) (void)hipFree(d_bin_operand);
+    d_rows = d_chunk_group = d_chunk_block = d_bin_operand = nullptr;
     rows = 0;
     tried = false;
   }
@@ -332,6 +334,7 @@ struct Tuning {
   // Satellites: on a wide prior most bins hold both kinds of draws and cost both paths
   // (headline 39.9 -> 40.5 us) -- off by default (profiles/r05_notes.md)
   int series = 1;
+  int cross_defer = 1;          // mode cross, one launch: deferred (group, draw) pairs (kernel_args.h)
   int cross_target = 160;       // mode cross: workgroups a launch should have at least
                                 // (several per tile of 64 draws below that)
   int resident_aperture = 1;    // resident ensemble kernel: the mailbox in device memory that

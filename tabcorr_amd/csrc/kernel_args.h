@@ -400,6 +400,15 @@ struct CrossFusedArgs {
   // 4 step + l / 16, row 16 block + l % 16; chunk c starts at step chunk_block[c]
   const double* rows;
   const int32_t* chunk_block;    // (n_chunks + 1)
+  // Deferred (group, draw) pairs of predict_cross_fused_kernel (undecorated, up to 64 rows): 1 =
+  // lanes that no shortcut and no expansion serves do not run the node loop in place; their
+  // pairs are marked in a bitmap in LDS (one 64-bit word per group, at lds_bitmap doubles) and
+  // evaluated after the chunks, 64 pairs per wave at a time, from lists at lds_list (512 words
+  // per wave); bin_operand[mi] = where member bin mi's 16-row blocks start in `rows`
+  // (doubles: + 64 per block of 16 rows, + row % 16).
+  int defer;
+  int lds_bitmap, lds_list;
+  const int32_t* bin_operand;    // (n_bins)
   // chunks of whole groups with at most kCrossChunkBins members, none across the boundary
   // between centrals and satellites: chunk c = groups chunk_group[c] .. chunk_group[c + 1]
   const int32_t* chunk_group;    // (n_chunks + 1)

@@ -417,12 +417,45 @@ struct GroupConsts {
   SeriesConsts series;         // moment expansion, per member in group order (or off)
 };
 
-template <bool ASSEMBIAS, bool MODULATE, bool SERIES = true, typename Emit>
+// Defer (predict_cross_fused_kernel, round 5): what happens to the lanes of a group that neither a
+// shortcut nor an expansion serves.  NoDefer: they run the node path here, under their part of
+// the execution mask -- a wave that holds one such lane pays the whole node loop.  A deferring
+// hook (active, on) gets a call under that mask instead and the members' occupations are
+// emitted as 0 for those lanes: the caller evaluates the (group, draw) pairs later, whole waves
+// of them at a time.
+// A double of lane `lane` (wave-uniform index) as a scalar.
+__device__ __forceinline__ double readlane_f64(double value, int lane) {
+  const unsigned long long bits = fm::bits_of(value);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(bits & 0xffffffffu), lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(bits >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+struct NoDefer {
+  static constexpr bool active = false;
+  bool on = false;
+  __device__ void operator()(int) const {}
+};
+
+// ... the hook of predict_cross_fused_kernel: a word per group in LDS takes the mask of the
+// lanes (draws) it is called under (a group is one wave's).
+template <bool ACTIVE>
+struct MarkPairs {
+  static constexpr bool active = ACTIVE;
+  bool on;
+  unsigned long long* bitmap;
+  __device__ void operator()(int group) const {
+    bitmap[group] = __builtin_amdgcn_ballot_w64(true);
+  }
+};
+
+template <bool ASSEMBIAS, bool MODULATE, bool SERIES = true, typename Emit,
+          typename Defer = NoDefer>
 __device__ __forceinline__ void occ_group_zheng07(const double* table, const fm::Consts& kc,
                                                   int group, int m_begin, int m_end,
                                                   bool central, const GroupConsts& q,
                                                   double split, const DrawParams& d,
-                                                  Emit&& emit) {
+                                                  Emit&& emit, Defer defer = Defer()) {
   constexpr int kNodes = 10;
   constexpr bool assembias = ASSEMBIAS;
   constexpr bool modulate = MODULATE;
@@ -505,6 +538,15 @@ __device__ __forceinline__ void occ_group_zheng07(const double* table, const fm:
     }
   }
   if (done) return;
+  if (Defer::active && defer.on && shortcut == 0) {
+    // a satellite group at or below the draw's M0: every node gives 0, as the node loop would;
+    // everything else goes to the caller's list of pairs
+    const bool zero = !central && bad == 0 &&
+                      !((mass[0] > mass[kNodes - 1] ? mass[0] : mass[kNodes - 1]) > m0);
+    if (!zero) defer(group);
+    for (int mi = m_begin; mi < m_end; ++mi) emit(mi, q.member[mi], 0.0);
+    return;
+  }
   // v[k]: centrals erf(z_k) (decorated: <N_cen> itself), satellites <N_sat> before the scale
   double v[kNodes];
   if (shortcut == 0) {
@@ -2315,6 +2357,12 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
     double2v* dst = (double2v*)table;
     for (int i = threadIdx.x; i < fm::kTableDoubles / 2; i += blockDim.x) dst[i] = src[i];
   }
+  // (the deferred pairs: compiled for the undecorated instances of up to 64 rows)
+  constexpr bool kDeferrable = !ASSEMBIAS && !MODULATE && ROWS <= 64;
+  const bool deferring = kDeferrable && a.defer != 0;
+  unsigned long long* bitmap = (unsigned long long*)(cross_lds + a.lds_bitmap);
+  if (deferring)
+    for (int i = threadIdx.x; i < a.n_groups; i += blockDim.x) bitmap[i] = 0;
   __syncthreads();
   // (medium batches: n_splits workgroups per tile of 64 draws, each with a range of the chunks;
   // the last one to arrive adds the shares in split order and finishes the tile -- as
@@ -2326,6 +2374,7 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
   const int64_t col = (int64_t)tile_index * kLanes;
   const int64_t b0 = col + lane;
   const int64_t b = b0 < a.n_draws ? b0 : a.n_draws - 1;
+  DrawParams dp;              // (the lane's draw: also what the deferred pairs fetch)
 
   // this wave's output tiles: row blocks rb0 (+ 4), draw blocks db0 (+ 1); D[m = l / 16 + 4 v]
   // [n = l % 16] in register v (the lane map of contract_quad_kernel)
@@ -2344,7 +2393,6 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
     const double* th = a.theta + b * a.n_theta;
     const DrawSetup d = prepare_draw(table, kc, th[0], th[1], th[2], th[3], th[4],
                                      ASSEMBIAS ? th[5] : 0.0, ASSEMBIAS ? th[6] : 0.0);
-    DrawParams dp;
     dp.log_m_min = d.log_m_min;
     dp.inv_sigma = d.inv_sigma;
     dp.m0 = d.m0;
@@ -2359,6 +2407,7 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
     sc_i32 group_begin = (sc_i32)a.group.begin;
     sc_i32 chunk_group = (sc_i32)a.chunk_group;
     sc_i32 chunk_block = (sc_i32)a.chunk_block;
+    const MarkPairs<kDeferrable> mark{deferring, bitmap};
     const GroupConsts gq{(sc_f64)a.group.log_m, (sc_f64)a.group.m, (sc_f64)a.group.weight,
                          (sc_f64)a.group.weight + a.n_bins * 10, (sc_f64)a.group.percentile,
                          (sc_i32)a.group.member,
@@ -2400,7 +2449,7 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
             a.split, dp, [&](int mi, int, double nbar) {
               const int row = mi - m0;
               buffer[row * kLanes + ((lane + 16 * (row & 3)) & 63)] = nbar;
-            });
+            }, mark);
       // (the rows that fill the last step: zero, whatever an earlier chunk left there)
       for (int row = m1 - m0 + wave; row < 4 * n_steps; row += W) buffer[row * kLanes + lane] = 0.0;
       // B. this wave's tiles over every bin of the chunk; the first A operands are requested
@@ -2462,6 +2511,128 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
         }
   }
   __syncthreads();
+  if (kDeferrable && deferring) {
+    // ---- the deferred (group, draw) pairs ----
+    // Wave w owns the draws w, w + 8, ...: it collects their pairs from the bitmap in group
+    // order (64 groups at a time: a prefix sum over the lanes), evaluates 64 pairs per pass of
+    // the node loop (lane = pair: the draw's constants from the lane that holds the draw, the
+    // group's by vector loads) and adds coefficient x occupation to ITS draws' sums, lane =
+    // row, in that order -- a fixed order per draw, whatever the rest of the batch is.
+    sc_i32 chunk_groups = (sc_i32)a.chunk_group;
+    const int g_first = chunk_groups[chunk_begin], g_last = chunk_groups[chunk_end];
+    unsigned* list = (unsigned*)(cross_lds + a.lds_list) + wave * 512;
+    const unsigned long long owner = 0x0101010101010101ull << wave;
+    sc_i32 bin_operand = (sc_i32)a.bin_operand;
+    // (separated by galaxy type: the pairs of the centrals in a first pass, the satellites' in
+    // a second -- eight sums per lane at a time)
+    for (int pass = 0; pass < (a.separate ? 2 : 1); ++pass) {
+    double extra[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) extra[j] = 0.0;
+    for (int gb = g_first; gb < g_last; gb += 64) {
+      const int g_lane = gb + lane;
+      unsigned long long word = g_lane < g_last ? bitmap[g_lane] & owner : 0ull;
+      const int count = __builtin_popcountll(word);
+      int inclusive = count;
+#pragma unroll
+      for (int offset = 1; offset < 64; offset <<= 1) {
+        const int other = __shfl_up(inclusive, offset, 64);
+        if (lane >= offset) inclusive += other;
+      }
+      const int total = __builtin_amdgcn_readlane(inclusive, 63);
+      int slot = inclusive - count;
+      while (word != 0) {
+        list[slot++] = (unsigned)(g_lane << 6) | (unsigned)__builtin_ctzll(word);
+        word &= word - 1;
+      }
+      for (int e0 = 0; e0 < total; e0 += 64) {
+        const int n = total - e0 < 64 ? total - e0 : 64;
+        const bool active = lane < n;
+        const unsigned entry = list[e0 + (active ? lane : 0)];
+        const int g = (int)(entry >> 6), draw = (int)(entry & 63);
+        const bool central = g < a.n_central_groups;
+        const int m_begin = a.group.begin[g], m_end = a.group.begin[g + 1];
+        const double log_m_min = __shfl(dp.log_m_min, draw, 64);
+        const double inv_sigma = __shfl(dp.inv_sigma, draw, 64);
+        const double m0 = __shfl(dp.m0, draw, 64);
+        const double log2_m1 = __shfl(dp.log2_m1, draw, 64);
+        const double sat_scale = __shfl(dp.sat_scale, draw, 64);
+        const double alpha = __shfl(dp.alpha, draw, 64);
+        const int bad = __shfl(dp.bad, draw, 64);
+        // member by member: the occupation (the nodes of the lane's group for the lane's draw,
+        // evaluated per member -- a handful of pairs per tile, and twenty registers less than
+        // keeping the node values), then its row contributions to the owner's sums
+        for (int t = 0; __builtin_amdgcn_ballot_w64(active && m_begin + t < m_end) != 0; ++t) {
+          const int mi = m_begin + t;
+          const bool valid = active && mi < m_end && (!a.separate || central == (pass == 0));
+          const int mi_safe = valid ? mi : m_begin;
+          const double* weight = a.group.weight + (int64_t)mi_safe * 10;
+          double acc = 0.0;
+          bool tie = false;
+          // (five nodes at a time: their constants requested together, then evaluated)
+#pragma unroll 1
+          for (int k0 = 0; k0 < 10; k0 += 5) {
+            double node[5], w[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+              node[k] = central ? a.group.log_m[g * 10 + k0 + k] : a.group.m[g * 10 + k0 + k];
+              w[k] = weight[k0 + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+              double value;
+              if (central) {
+                value = fm::erf_fast(table, kc, (node[k] - log_m_min) * inv_sigma);
+                tie = tie || node[k] == log_m_min;
+              } else {
+                const double x = node[k] - m0;
+                value = fm::exp2_fast(
+                    table, kc,
+                    alpha * fm::log2_fast_offset(table, kc, x > 1e-300 ? x : 1e-300, log2_m1),
+                    x > 0.0);
+              }
+              acc = fma(w[k], value, acc);
+            }
+          }
+          const bool cen_nan = (bad & kBadCen) || ((bad & kTieCen) && tie);
+          if (central) acc = fma(0.5, acc, 0.5 * a.group.weight[(int64_t)a.n_bins * 10 + mi_safe]);
+          else acc *= sat_scale;
+          if (bad != 0) {
+            if (!central && (bad & kInfSat) && acc != 0.0) acc = __builtin_huge_val();
+            if (central ? cen_nan : ((bad & kBadSat) && acc != 0.0)) acc = __builtin_nan("");
+          }
+          // (eight pairs at a time: their coefficients requested together; a pair that is not
+          // valid -- beyond the batch, beyond its group's members, the other galaxy type --
+          // adds coefficient x 0)
+          const double nbar_lane = valid ? acc : 0.0;
+          const int row_offset = lane < ROWS ? (lane >> 4) * 64 + (lane & 15) : 0;
+          for (int p0 = 0; p0 < n; p0 += 8) {
+            double coefficient[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int bin = __builtin_amdgcn_readlane(mi_safe, (p0 + u) & 63);
+              coefficient[u] = a.rows[bin_operand[bin] + row_offset];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const double nbar = readlane_f64(nbar_lane, (p0 + u) & 63);
+              const int j = __builtin_amdgcn_readlane(draw, (p0 + u) & 63) >> 3;
+#pragma unroll
+              for (int jj = 0; jj < 8; ++jj)
+                extra[jj] = fma(coefficient[u], jj == j ? nbar : 0.0, extra[jj]);
+            }
+          }
+        }
+      }
+    }
+    if (lane < ROWS) {
+      double* res = pass == 0 ? res0 : res1;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) res[lane * kLanes + wave + 8 * jj] += extra[jj];
+    }
+    }
+    __syncthreads();
+  }
   if (n_splits > 1) {
     // the shares of the tile's workgroups: device-scope write-through stores, the last arrival
     // (a counter per tile, reset for the next launch on this lane) adds them in split order
@@ -2502,6 +2673,12 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
 
   // ---- per draw: spline weights / norms of the tables, number densities ----
   set_priority((a.priority >> 4) & 3);
+  // (the draw's index once more, from a lane index the optimiser cannot trace back: kept from
+  // the top of the kernel it would sit in three registers across every phase -- spilled)
+  int lane_again = lane;
+  asm volatile("" : "+v"(lane_again));
+  const int64_t b0_end = col + lane_again;
+  const int64_t b_end = b0_end < a.n_draws ? b0_end : a.n_draws - 1;
   const int n_comp = a.separate ? 2 : 1;
   const int per_table = a.n_r + 1;
   double* coef = cross_lds + a.lds_tile;        // (K, 64): c_k / ngal_k
@@ -2514,7 +2691,7 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
         for (int dim = 0; dim < a.n_dim; ++dim) {
           const int n = a.n_axis[dim];
           const double* xp = a.xp + a.axis_offset[dim];
-          const double x = a.x[b * a.n_dim + dim];
+          const double x = a.x[b_end * a.n_dim + dim];
           int seg = -1;
           for (int i = 0; i < n; ++i) seg += xp[i] <= x ? 1 : 0;   // np.digitize(x, xp) - 1
           if (x == xp[n - 1]) seg = n - 2;
@@ -2535,12 +2712,12 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
       n_cen += c * cen;
       n_sat += c * sat;
     }
-    if (b0 < a.n_draws) {
+    if (b0_end < a.n_draws) {
       if (a.separate) {
-        a.ngal[2 * b0] = n_cen;
-        a.ngal[2 * b0 + 1] = n_sat;
+        a.ngal[2 * b0_end] = n_cen;
+        a.ngal[2 * b0_end + 1] = n_sat;
       } else {
-        a.ngal[b0] = n_cen + n_sat;
+        a.ngal[b0_end] = n_cen + n_sat;
       }
     }
   }

@@ -54,7 +54,7 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
   if (status == TC_OK) status = upload(m, &q.m);
   if (status == TC_OK) status = upload(weight, &q.weight);
   // moment expansion of the central bins' node sums (series.h)
-  std::vector<double> series((size_t)g * tc::series::kStride);
+  std::vector<double> series((size_t)g * tc::series::kStride + tc::series::kPad);
   std::vector<int32_t> series_thr((size_t)g * tc::series::kThresholds);
   for (int i = 0; i < g; ++i)
     tc::series::bin_consts(n_gauss, log_m.data() + (size_t)i * n_gauss,
@@ -63,7 +63,7 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
                            series_thr.data() + (size_t)i * tc::series::kThresholds);
   if (status == TC_OK) status = upload(series, &q.series);
   if (status == TC_OK) status = upload(series_thr, &q.series_thr);
-  std::vector<double> sat_series((size_t)g * tc::series::sat::kStride);
+  std::vector<double> sat_series((size_t)g * tc::series::sat::kStride + tc::series::kPad);
   std::vector<int32_t> sat_series_thr((size_t)g * tc::series::sat::kThresholds);
   for (int i = 0; i < g; ++i)
     tc::series::sat::bin_consts(n_gauss, m.data() + (size_t)i * n_gauss,
@@ -93,9 +93,9 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
         g_weight[(size_t)mi * n_gauss + k] = weight[(size_t)bin * n_gauss + k];
       g_weight[(size_t)g * n_gauss + mi] = weight[(size_t)g * n_gauss + bin];
     }
-    std::vector<double> g_series((size_t)g * tc::series::kStride);
+    std::vector<double> g_series((size_t)g * tc::series::kStride + tc::series::kPad);
     std::vector<int32_t> g_series_thr((size_t)g * tc::series::kThresholds);
-    std::vector<double> g_sat((size_t)g * tc::series::sat::kStride);
+    std::vector<double> g_sat((size_t)g * tc::series::sat::kStride + tc::series::kPad);
     std::vector<int32_t> g_sat_thr((size_t)g * tc::series::sat::kThresholds);
     for (int mi = 0; mi < g; ++mi) {
       const int bin = groups.member[mi];
@@ -1436,6 +1436,15 @@ int build_cross_fused(tc_table* const* tables, int n_tables, CrossFused* cf) {
       }
     }
     host.swap(operands);
+    // (where a member bin's blocks of 16 rows start: the deferred pairs' coefficients)
+    std::vector<int32_t> bin_operand(t0->n_bins, 0);
+    for (int c = 0; c < cf->n_chunks; ++c) {
+      const int m0 = groups.begin[chunk_group[c]], m1 = groups.begin[chunk_group[c + 1]];
+      for (int mi = m0; mi < m1; ++mi)
+        bin_operand[mi] = ((chunk_block[c] + (mi - m0) / 4) * row_blocks) * 64 + ((mi - m0) % 4) * 16;
+    }
+    const int uploaded = upload(bin_operand, &cf->d_bin_operand);
+    if (uploaded != TC_OK) return uploaded;
   }
   int status = upload(host, &cf->d_rows);
   if (status == TC_OK) status = upload(chunk_group, &cf->d_chunk_group);
@@ -1448,11 +1457,19 @@ int build_cross_fused(tc_table* const* tables, int n_tables, CrossFused* cf) {
 namespace {
 // LDS layout of predict_cross_fused_kernel (kernel_args.h): offsets in doubles, total in bytes.
 struct CrossLds {
-  int res0 = 0, tile = 0, bytes = 0;
+  int res0 = 0, tile = 0, bitmap = 0, list = 0, bytes = 0;
 };
-CrossLds cross_lds_layout(const CrossFused& cf, int n_r, bool separate) {
+// `defer_groups` > 0: the deferred pairs' bitmap (one word per group) behind the buffers; their
+// lists (8 waves x 512 words = 2048 doubles) lie in the buffers' area behind the row sums, which
+// take rows x 64 of its 2 x 48 x 64 doubles once the chunks are done (up to 64 rows).
+CrossLds cross_lds_layout(const CrossFused& cf, int n_r, bool separate, int defer_groups = 0) {
   CrossLds lds;
   int end = tc::kCrossTableDoubles + tc::cross_buffer_doubles(cf.rows);
+  if (defer_groups > 0) {
+    lds.list = tc::kCrossTableDoubles + cf.rows * 64;
+    lds.bitmap = end;
+    end += (defer_groups + 1) / 2 * 2;
+  }
   if (separate) {
     lds.res0 = end;
     end += cf.rows * 64;
@@ -1557,7 +1574,28 @@ int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs
   ca.chunk_block = (const int32_t*)cf.d_chunk_block;
   ca.n_chunks = cf.n_chunks;
   ca.n_central_chunks = cf.n_central_chunks;
-  CrossLds layout = cross_lds_layout(cf, t0->n_r, separate);
+  // The deferred pairs (kernel_args.h): undecorated, 17 .. 64 rows, the centrals' expansion on
+  // -- the satellites' then comes with it whatever bit 1 of "series" says: its cost on wide
+  // priors was the node loop a wave ran NEXT to it for a single draw, which is what goes away.
+  const bool defer = t0->tuning.cross_defer != 0 && cf.rows > tc::kCrossSmallRows &&
+                     cf.rows <= 64 && cf.d_bin_operand != nullptr &&
+                     !(flags & (TC_FLAG_ASSEMBIAS | TC_FLAG_MODULATE_WITH_CENOCC)) &&
+                     (t0->tuning.series & 1) != 0 && q->group_sat_series != nullptr &&
+                     tc::cross_buffer_doubles(cf.rows) >= cf.rows * 64 + 2048;
+  CrossLds layout = cross_lds_layout(cf, t0->n_r, separate, defer ? ca.n_groups : 0);
+  if (defer && layout.bytes > kMaxLdsBytes / 2 - 256) {
+    // (not at the price of the second workgroup per CU)
+    layout = cross_lds_layout(cf, t0->n_r, separate);
+    ca.defer = 0;
+  } else {
+    ca.defer = defer ? 1 : 0;
+  }
+  if (ca.defer) {
+    ca.group.sat_series = (const double*)q->group_sat_series;
+    ca.lds_bitmap = layout.bitmap;
+    ca.lds_list = layout.list;
+    ca.bin_operand = (const int32_t*)cf.d_bin_operand;
+  }
   ca.lds_res0 = layout.res0;
   ca.lds_tile = layout.tile;
   ca.row_stride = cf.rows;

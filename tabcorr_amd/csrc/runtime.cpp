@@ -447,7 +447,7 @@ int tc_debug_central_series(int n_gauss, double log_min, double log_max, double 
     weight[k] = (double)(raw[k] / norm);
     m0 += weight[k];
   }
-  std::vector<double> consts(tc::series::kStride);
+  std::vector<double> consts(tc::series::kStride + tc::series::kPad);
   std::vector<int32_t> thresholds(tc::series::kThresholds);
   tc::series::bin_consts(n_gauss, log_m.data(), weight.data(), log_min, log_max, consts.data(),
                          thresholds.data());
@@ -534,7 +534,7 @@ int tc_debug_satellite_series(int n_gauss, double log_min, double log_max, doubl
     norm += raw[k];
   }
   for (int k = 0; k < n_gauss; ++k) weight[k] = (double)(raw[k] / norm);
-  std::vector<double> consts(tc::series::sat::kStride);
+  std::vector<double> consts(tc::series::sat::kStride + tc::series::kPad);
   std::vector<int32_t> thresholds(tc::series::sat::kThresholds);
   tc::series::sat::bin_consts(n_gauss, mass.data(), weight.data(), log_min, log_max,
                               consts.data(), thresholds.data());

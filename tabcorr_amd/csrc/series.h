@@ -27,7 +27,12 @@ namespace series {
 
 constexpr int kMaxTerms = 24;
 constexpr int kSteps = 5;                    // 8, 12, 16, 20, 24 terms
-constexpr int kStride = 2 + kMaxTerms;       // per bin: centre, (unused), M_1 .. M_24
+constexpr int kFirst = 4;                    // the moments start at consts[kFirst]: blocks of
+                                             // four, 32 bytes each, 32-byte aligned
+constexpr int kStride = kFirst + kMaxTerms;  // per bin: centre, (3 unused), M_1 .. M_24
+// (the loops request the block behind the one they use, also behind the last: arrays of
+// constants end with kPad more doubles)
+constexpr int kPad = 4;
 constexpr int kThresholds = 8;               // int32 per bin (kSteps used)
 constexpr double kTolerance = 1e-16;
 
@@ -35,7 +40,7 @@ constexpr double kTolerance = 1e-16;
 double h_max(int n_terms);
 
 // Per-bin constants from the bin's nodes (log10 M_k) and normalised weights: consts[0] = centre,
-// consts[2 + n - 1] = (-1)^(n-1) m_n / n!; thresholds[s] = high dword of the largest
+// consts[kFirst + n - 1] = (-1)^(n-1) m_n / n!; thresholds[s] = high dword of the largest
 // |1 / sigma| for which 8 + 4 s terms suffice (0: never).
 void bin_consts(int n_gauss, const double* log_m, const double* weight, double log_min,
                 double log_max, double* consts, int32_t* thresholds);
@@ -64,65 +69,95 @@ TC_HD bool eligible(IntPtr thresholds, int inv_sigma_hi) {
   return inv_sigma_hi < thresholds[kSteps - 1];
 }
 
-// A draw with the key `hi` adds the terms of pass `block` when hi >= pass_threshold(thresholds,
-// block) -- that is, block < terms_for(...) / 4; the first two passes are the fewest any draw
-// takes, and an eligible draw fails the test at block = kMaxTerms / 4 at the latest.  The loops
-// below request a pass's moments one pass and its threshold TWO passes ahead (the exit test of a
-// pass must not wait for a load issued in that pass).
-template <typename IntPtr>
-TC_HD int pass_threshold(IntPtr thresholds, int block) {
-  const int value = thresholds[block > 2 ? block - 2 : 0];      // (no branch: load + select)
-  return block < 2 ? 0 : value;
-}
-
-// sum_k W_k erf((log M_k - log_m_min) inv_sigma) of the bin whose constants are `consts`, by
-// the terms of the expansion an ELIGIBLE draw needs; m0 = sum_k W_k.  Uniform steps from
-// (p_-1, p_0) = (0, 1 / sigma): term n adds p_(n-1) M_n, then p_n = a p_(n-1) + (n - 1) b p_(n-2).
-// Four terms per pass of a loop that is NOT unrolled (the unrolled forms took 150-200 vector
-// registers in the kernels); the next pass's four moments and its threshold are requested --
-// scalar loads -- before the current ones are used.
+// The loops below: passes of four terms, NOT unrolled (the unrolled forms take 135-205 vector
+// registers in the kernels).  The moments of a pass are ONE aligned 32-byte scalar load through
+// a pointer that advances by a block per pass (requested one pass ahead; the arrays end with a
+// block of padding); the thresholds are eight scalar registers from one load before the first
+// pass, from which a lane counts its passes (`passes`): the loop ends with the wave's last
+// lane.  Round 4's loop recomputed its addresses from the pass number -- clamped, so that eight
+// separate 8-byte loads and three scalar instructions per vector instruction came out.
 struct f64x4_t {
   double v[4];
   TC_HD double operator[](int k) const { return v[k]; }
 };
 
-// Four consecutive constants from consts[first + 4 block] on.
+// Four consecutive constants from consts[first + 4 block] on (first + 4 block a multiple of 4:
+// one 32-byte load on the device).
 template <typename Ptr>
 TC_HD f64x4_t load_four(Ptr consts, int first, int block) {
   f64x4_t m;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef double __attribute__((ext_vector_type(4))) f64x4v;
+  typedef const __attribute__((address_space(4))) f64x4v* sc_f64x4v;
+  const f64x4v value = *(sc_f64x4v)(consts + first + 4 * block);
+  m.v[0] = value.x;
+  m.v[1] = value.y;
+  m.v[2] = value.z;
+  m.v[3] = value.w;
+#else
   m.v[0] = consts[first + 4 * block];
   m.v[1] = consts[first + 1 + 4 * block];
   m.v[2] = consts[first + 2 + 4 * block];
   m.v[3] = consts[first + 3 + 4 * block];
+#endif
   return m;
 }
 
-template <typename Ptr>
-TC_HD f64x4_t load_moments(Ptr consts, int block) {
-  return load_four(consts, 2, block);
+// The bin's thresholds (kThresholds = 8 int32: one 32-byte load on the device).
+struct Thresholds {
+  int v[kThresholds];
+};
+template <typename IntPtr>
+TC_HD Thresholds load_thresholds(IntPtr thresholds) {
+  Thresholds t;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef int __attribute__((ext_vector_type(8))) i32x8v;
+  typedef const __attribute__((address_space(4))) i32x8v* sc_i32x8v;
+  const i32x8v value = *(sc_i32x8v)thresholds;
+#pragma unroll
+  for (int i = 0; i < kThresholds; ++i) t.v[i] = value[i];
+#else
+  for (int i = 0; i < kThresholds; ++i) t.v[i] = thresholds[i];
+#endif
+  return t;
 }
 
+// Passes of an ELIGIBLE draw with the key `hi`: `fewest`, plus one per threshold it reaches
+// (= terms_for(...) / 4).
+template <int STEPS>
+TC_HD int passes(const Thresholds& limit, int hi, int fewest) {
+  int n = fewest;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int s = 0; s < STEPS - 1; ++s) n += hi >= limit.v[s] ? 1 : 0;
+  return n;
+}
+
+// sum_k W_k erf((log M_k - log_m_min) inv_sigma) of the bin whose constants are `consts`, by
+// the terms of the expansion an ELIGIBLE draw needs; m0 = sum_k W_k.  Uniform steps from
+// (p_-1, p_0) = (0, 1 / sigma): term n adds p_(n-1) M_n, then p_n = a p_(n-1) + (n - 1) b p_(n-2).
 template <typename Ptr, typename IntPtr>
 TC_HD double central_sum(const double* table, const fm::Consts& kc, double log_m_min,
                          double inv_sigma, Ptr consts, double m0, IntPtr thresholds,
                          int inv_sigma_hi) {
-  constexpr int kLastBlock = kMaxTerms / 4 - 1;
   // (the recurrence runs on z0 clamped to [-6, 6]: beyond, on the plateaus, g0 = 0 and the sum
   // is m0 erf(z0) = -+m0 whatever the terms are -- but they must stay finite: with an infinite
   // or huge logMmin the unclamped recurrence overflows and 0 x inf would be NaN where the node
   // loop and the reference give -+1, N_cen = 0 or 1)
+  const int n_blocks = passes<kSteps>(load_thresholds(thresholds), inv_sigma_hi, 2);
+  Ptr block_ptr = consts + kFirst;
+  f64x4_t m = load_four(block_ptr, 0, 0);
   double g0, z0;
   const double e = fm::erf_gauss_fast(table, kc, (consts[0] - log_m_min) * inv_sigma, &g0, &z0);
   const double a = 2.0 * z0 * inv_sigma, b = -2.0 * inv_sigma * inv_sigma;
   double p_prev = 0.0, p = inv_sigma, nb = -b, sum = 0.0;
-  f64x4_t m = load_moments(consts, 0);
-  int threshold = 0, next_threshold = 0, block = 0;     // (of passes 0 and 1)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-  while (inv_sigma_hi >= threshold) {
-    const f64x4_t next_m = load_moments(consts, block < kLastBlock ? block + 1 : block);
-    const int after_next = pass_threshold(thresholds, block + 2);
+  for (int block = 0; block < n_blocks; ++block) {
+    block_ptr += 4;
+    const f64x4_t next_m = load_four(block_ptr, 0, 0);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -134,9 +169,6 @@ TC_HD double central_sum(const double* table, const fm::Consts& kc, double log_m
       p = next;
     }
     m = next_m;
-    threshold = next_threshold;
-    next_threshold = after_next;
-    ++block;
   }
   return fma(g0, sum, m0 * e);
 }
@@ -148,21 +180,22 @@ TC_HD void central_sum_pair(const double* table, const fm::Consts& kc, double lo
                             double inv_sigma, Ptr consts_i, Ptr consts_j, double m0_i,
                             double m0_j, IntPtr thresholds, int inv_sigma_hi, double* out_i,
                             double* out_j) {
-  constexpr int kLastBlock = kMaxTerms / 4 - 1;
+  const int n_blocks = passes<kSteps>(load_thresholds(thresholds), inv_sigma_hi, 2);
+  Ptr ptr_i = consts_i + kFirst, ptr_j = consts_j + kFirst;
+  f64x4_t mi = load_four(ptr_i, 0, 0), mj = load_four(ptr_j, 0, 0);
   double g0, z0;
   const double e =
       fm::erf_gauss_fast(table, kc, (consts_i[0] - log_m_min) * inv_sigma, &g0, &z0);
   const double a = 2.0 * z0 * inv_sigma, b = -2.0 * inv_sigma * inv_sigma;
   double p_prev = 0.0, p = inv_sigma, nb = -b, sum_i = 0.0, sum_j = 0.0;
-  f64x4_t mi = load_moments(consts_i, 0), mj = load_moments(consts_j, 0);
-  int threshold = 0, next_threshold = 0, block = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-  while (inv_sigma_hi >= threshold) {
-    const int ahead = block < kLastBlock ? block + 1 : block;
-    const f64x4_t next_i = load_moments(consts_i, ahead), next_j = load_moments(consts_j, ahead);
-    const int after_next = pass_threshold(thresholds, block + 2);
+  for (int block = 0; block < n_blocks; ++block) {
+    ptr_i += 4;
+    ptr_j += 4;
+    const f64x4_t next_i = load_four(ptr_i, 0, 0);
+    const f64x4_t next_j = load_four(ptr_j, 0, 0);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -176,9 +209,6 @@ TC_HD void central_sum_pair(const double* table, const fm::Consts& kc, double lo
     }
     mi = next_i;
     mj = next_j;
-    threshold = next_threshold;
-    next_threshold = after_next;
-    ++block;
   }
   *out_i = fma(g0, sum_i, m0_i * e);
   *out_j = fma(g0, sum_j, m0_j * e);
@@ -202,15 +232,17 @@ namespace sat {
 
 constexpr int kMaxTerms = 32;
 constexpr int kSteps = 6;                    // 12, 16, ..., 32 terms
-constexpr int kStride = 2 + kMaxTerms + 2;   // per bin: Mc, max|y|, mu_0 / 0! .. mu_32 / 32!, pad
+constexpr int kFirst = 4;                    // mu_1 sits at consts[kFirst]: 32-byte blocks of four
+constexpr int kStride = kFirst + kMaxTerms;  // per bin: Mc, max|y|, (unused), mu_0, mu_1 / 1! ..
+                                             // mu_32 / 32!
 constexpr int kThresholds = 8;               // int32 per bin (kSteps used)
 
 // Largest r = eps max|y| for which `n_terms` terms leave a tail below kTolerance.
 double r_max(int n_terms);
 
 // Per-bin constants from the bin's node masses and normalised weights: consts[0] = Mc,
-// consts[2 + n] = mu_n / n!; thresholds[s] = high dword of the largest M0 for which 12 + 4 s
-// terms suffice (0: never).
+// consts[3] = mu_0, consts[kFirst + n - 1] = mu_n / n!; thresholds[s] = high dword of the
+// largest M0 for which 12 + 4 s terms suffice (0: never).
 void bin_consts(int n_gauss, const double* mass, const double* weight, double log_min,
                 double log_max, double* consts, int32_t* thresholds);
 
@@ -232,12 +264,6 @@ TC_HD bool eligible(IntPtr thresholds, int m0_hi) {
   return m0_hi < thresholds[kSteps - 1];
 }
 
-template <typename IntPtr>
-TC_HD int pass_threshold(IntPtr thresholds, int block) {
-  const int value = thresholds[block > 3 ? block - 3 : 0];
-  return block < 3 ? 0 : value;
-}
-
 // 1 / x to rounding (hardware estimate + two Newton steps on the device).
 TC_HD double reciprocal(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -249,21 +275,20 @@ TC_HD double reciprocal(double x) {
 #endif
 }
 
-// sum_k W_k (1 + eps y_k)^alpha by the terms an ELIGIBLE draw needs + the n = 0 term (the loop
-// of passes as central_sum).
+// sum_k W_k (1 + eps y_k)^alpha by the terms an ELIGIBLE draw needs + the n = 0 term (the
+// unrolled passes of central_sum; the first three are the fewest any draw takes).
 template <typename Ptr, typename IntPtr>
 TC_HD double binomial_sum(Ptr consts, double eps, double alpha, IntPtr thresholds, int m0_hi) {
-  constexpr int kLastBlock = kMaxTerms / 4 - 1;
-  double d = 1.0, g = eps * alpha, sum = consts[2];         // n = 0: mu_0
-  // moments mu_n / n! for n >= 1 start at consts[3]: blocks of four from there
-  f64x4_t cur = load_four(consts, 3, 0);
-  int threshold = 0, next_threshold = 0, block = 0;
+  const int n_blocks = series::passes<kSteps>(series::load_thresholds(thresholds), m0_hi, 3);
+  Ptr block_ptr = consts + kFirst;
+  f64x4_t cur = load_four(block_ptr, 0, 0);
+  double d = 1.0, g = eps * alpha, sum = consts[3];         // n = 0: mu_0
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-  while (m0_hi >= threshold) {
-    const f64x4_t next = load_four(consts, 3, block < kLastBlock ? block + 1 : block);
-    const int after_next = pass_threshold(thresholds, block + 2);
+  for (int block = 0; block < n_blocks; ++block) {
+    block_ptr += 4;
+    const f64x4_t next = load_four(block_ptr, 0, 0);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -273,9 +298,6 @@ TC_HD double binomial_sum(Ptr consts, double eps, double alpha, IntPtr threshold
       sum = fma(d, cur[k], sum);
     }
     cur = next;
-    threshold = next_threshold;
-    next_threshold = after_next;
-    ++block;
   }
   return sum;
 }
@@ -284,17 +306,18 @@ TC_HD double binomial_sum(Ptr consts, double eps, double alpha, IntPtr threshold
 template <typename Ptr, typename IntPtr>
 TC_HD void binomial_sum_pair(Ptr consts_i, Ptr consts_j, double eps, double alpha,
                              IntPtr thresholds, int m0_hi, double* out_i, double* out_j) {
-  constexpr int kLastBlock = kMaxTerms / 4 - 1;
-  double d = 1.0, g = eps * alpha, sum_i = consts_i[2], sum_j = consts_j[2];
-  f64x4_t cur_i = load_four(consts_i, 3, 0), cur_j = load_four(consts_j, 3, 0);
-  int threshold = 0, next_threshold = 0, block = 0;
+  const int n_blocks = series::passes<kSteps>(series::load_thresholds(thresholds), m0_hi, 3);
+  Ptr ptr_i = consts_i + kFirst, ptr_j = consts_j + kFirst;
+  f64x4_t cur_i = load_four(ptr_i, 0, 0), cur_j = load_four(ptr_j, 0, 0);
+  double d = 1.0, g = eps * alpha, sum_i = consts_i[3], sum_j = consts_j[3];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-  while (m0_hi >= threshold) {
-    const int ahead = block < kLastBlock ? block + 1 : block;
-    const f64x4_t next_i = load_four(consts_i, 3, ahead), next_j = load_four(consts_j, 3, ahead);
-    const int after_next = pass_threshold(thresholds, block + 2);
+  for (int block = 0; block < n_blocks; ++block) {
+    ptr_i += 4;
+    ptr_j += 4;
+    const f64x4_t next_i = load_four(ptr_i, 0, 0);
+    const f64x4_t next_j = load_four(ptr_j, 0, 0);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -306,9 +329,6 @@ TC_HD void binomial_sum_pair(Ptr consts_i, Ptr consts_j, double eps, double alph
     }
     cur_i = next_i;
     cur_j = next_j;
-    threshold = next_threshold;
-    next_threshold = after_next;
-    ++block;
   }
   *out_i = sum_i;
   *out_j = sum_j;

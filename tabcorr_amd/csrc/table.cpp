@@ -1241,6 +1241,9 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
   } else if (key == "cross_min_draws") {
     TC_CHECK(value >= 1, "cross_min_draws must be positive");
     t->tuning.cross_min_draws = value;
+  } else if (key == "cross_defer") {
+    // developer A/B: 0 = predict_cross_fused_kernel runs every lane's node loop in place
+    t->tuning.cross_defer = value != 0;
   } else if (key == "cross_target") {
     // developer A/B: workgroups a launch of predict_cross_small_kernel should have at least
     TC_CHECK(value >= 1 && value <= 4096, "cross_target must be in [1, 4096]");

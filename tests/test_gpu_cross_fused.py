@@ -171,6 +171,7 @@ def test_cross_likelihood_async_and_threshold():
     # tiny batches and calls that run alone keep the three kernels
     halotab.predict_batch_async(theta[:100], out=(ngal[:100], xi[:100])).wait()
     assert last_launch(handle)[2] > 0
+    set_option(handle, 'sync_chunks', -1)       # (the serial path)
     halotab.predict_batch(theta)
     assert last_launch(handle)[2] > 0
     sync = halotab.chi2_batch(theta, vector, precision)
