@@ -331,7 +331,10 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 runs "autotune" for that combination by itself -- about half a second, once
  *                 -- so that a loop of calls gets the measured form without asking; the
  *                 built-in estimate serves the calls before it.  0: never.
- *   "series"      bit mask, default 1.  Bit 0: the Gauss-Legendre sum of an undecorated
+ *   "series"      bit mask; default -1 = by the table: bit 0 for tables whose widest central
+ *                 bin is at most 0.1 dex (with wider bins nearly every wavefront of a wide prior
+ *                 holds a draw whose sigma_logM is below a bin width and runs the expansion AND
+ *                 the node loop), bit 1 off.  Bit 0: the Gauss-Legendre sum of an undecorated
  *                 central bin (tabcorr/tabcorr.py:556-578) by its moment expansion around the
  *                 bin centre -- the same sum re-ordered, one erf and 8 .. 24 short terms instead
  *                 of n_gauss_prim erf evaluations, tabcorr_amd/csrc/series.h -- for every draw

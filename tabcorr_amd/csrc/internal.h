@@ -326,14 +326,11 @@ struct Tuning {
   // with the batch sizes an ensemble sampler has, the three kernels spread small batches
   // over the whole chip.  Asynchronous host calls (us per call, tools/archive/r03_async.py): 6144 draws
   // 38.8 / 41.6, 10^4 58 / 47.6, 20 000 93.7 / 82.6, 40 000 176 / 162: no upper bound there.
-  // moment expansions of the node sums (series.h): bit 0 central bins, bit 1 satellite bins.
-  // Every lane takes the terms ITS draw needs (a draw's bits must not depend on its neighbours
-  // in the batch), and a wave runs the node loop as well wherever one of its draws needs it.
-  // Centrals: nearly every draw qualifies for every bin -- on by default (the reference's
-  // AbacusSummit interpolator 85.4 -> 80.3 us per 10^4 draws; the headline table level).
-  // Satellites: on a wide prior most bins hold both kinds of draws and cost both paths
-  // (headline 39.9 -> 40.5 us) -- off by default (profiles/r05_notes.md)
-  int series = 1;
+  // moment expansions of the node sums (series.h): bit 0 central bins, bit 1 satellite bins;
+  // -1 (default): the centrals' for tables with narrow bins (launch.hip: series_mask).  Every
+  // lane takes the terms ITS draw needs (a draw's bits must not depend on its neighbours in
+  // the batch), and a wave runs the node loop as well wherever one of its draws needs it.
+  int series = -1;
   int cross_defer = 1;          // mode cross, one launch: deferred (group, draw) pairs (kernel_args.h)
   int cross_target = 160;       // mode cross: workgroups a launch should have at least
                                 // (several per tile of 64 draws below that)
@@ -630,6 +627,7 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
 int fused_dens_rows(const tc_table* t, bool separate);
 int fused_lds_bytes(const tc_table* t, bool separate, int waves, int draws);
 int fused_waves(const tc_table* t, bool separate, unsigned flags);
+int series_mask(const tc_table* t);
 bool fused_half_tiles(const tc_table* t, bool separate, int64_t n_draws, int n_gauss,
                       unsigned flags);
 bool fused_wide_tables(const tc_table* t, bool separate, int n_gauss, unsigned flags);

@@ -124,6 +124,23 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
   return TC_OK;
 }
 
+
+// Which expansions of series.h the occupation kernels take (option "series": bit 0 centrals,
+// bit 1 satellites; -1, the default: by the table).  Every lane takes the path ITS draw asks
+// for, so a wave that holds draws with sigma_logM below about a bin width runs the expansion
+// AND the node loop of a central bin: with bins of 0.15 dex (the reference's example table)
+// that is nearly every wave of a wide prior and costs 8 % of the step (19.6 against 18.1 us per
+// 10^4 draws); with 0.09 dex (BASELINE configs[1]) every draw above sigma_logM = 0.08
+// qualifies (39.4 against 40.0 us), with 0.012 dex (AbacusSummit) everything does (80 against
+// 85 us).  So: the centrals' expansion for tables whose widest central bin is at most 0.1 dex.
+int series_mask(const tc_table* t) {
+  if (t->tuning.series >= 0) return t->tuning.series;
+  double widest = 0.0;
+  for (int g = 0; g < t->plan.n_central; ++g)       // (library order: centrals first)
+    widest = std::max(widest, std::fabs(t->log_max[g] - t->log_min[g]));
+  return widest <= 0.1 ? 1 : 0;
+}
+
 tc::GroupArgs group_args(const tc_table* t, const Quadrature& q) {
   tc::GroupArgs ga{};
   ga.begin = (const int32_t*)t->d_group_begin;
@@ -133,9 +150,9 @@ tc::GroupArgs group_args(const tc_table* t, const Quadrature& q) {
   ga.weight = (const double*)q.group_weight;
   ga.n_h = (const double*)t->d_group_n_h;
   ga.percentile = (const double*)t->d_group_percentile;
-  ga.series = (t->tuning.series & 1) ? (const double*)q.group_series : nullptr;
+  ga.series = (series_mask(t) & 1) ? (const double*)q.group_series : nullptr;
   ga.series_thr = (const int32_t*)q.group_series_thr;
-  ga.sat_series = (t->tuning.series & 2) ? (const double*)q.group_sat_series : nullptr;
+  ga.sat_series = (series_mask(t) & 2) ? (const double*)q.group_sat_series : nullptr;
   ga.sat_series_thr = (const int32_t*)q.group_sat_series_thr;
   return ga;
 }
@@ -973,9 +990,9 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   oa.n_groups = t->node_groups.n_groups;
   oa.n_central_groups = t->node_groups.n_central_groups;
   oa.group = group_args(t, *q);
-  oa.series = (t->tuning.series & 1) ? (const double*)q->series : nullptr;
+  oa.series = (series_mask(t) & 1) ? (const double*)q->series : nullptr;
   oa.series_thr = (const int32_t*)q->series_thr;
-  oa.sat_series = (t->tuning.series & 2) ? (const double*)q->sat_series : nullptr;
+  oa.sat_series = (series_mask(t) & 2) ? (const double*)q->sat_series : nullptr;
   oa.sat_series_thr = (const int32_t*)q->sat_series_thr;
   {
     const dim3 grid((unsigned)grid_blocks), block(tc::kOccWaves * 64);
@@ -1279,9 +1296,9 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   fa.n_groups = t->node_groups.n_groups;
   fa.n_central_groups = t->node_groups.n_central_groups;
   fa.group = group_args(t, *q);
-  fa.series = (t->tuning.series & 1) ? (const double*)q->series : nullptr;
+  fa.series = (series_mask(t) & 1) ? (const double*)q->series : nullptr;
   fa.series_thr = (const int32_t*)q->series_thr;
-  fa.sat_series = (t->tuning.series & 2) ? (const double*)q->sat_series : nullptr;
+  fa.sat_series = (series_mask(t) & 2) ? (const double*)q->sat_series : nullptr;
   fa.sat_series_thr = (const int32_t*)q->sat_series_thr;
   fa.log_m = (const double*)q->log_m;
   fa.m = (const double*)q->m;
@@ -1580,7 +1597,7 @@ int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs
   const bool defer = t0->tuning.cross_defer != 0 && cf.rows > tc::kCrossSmallRows &&
                      cf.rows <= 64 && cf.d_bin_operand != nullptr &&
                      !(flags & (TC_FLAG_ASSEMBIAS | TC_FLAG_MODULATE_WITH_CENOCC)) &&
-                     (t0->tuning.series & 1) != 0 && q->group_sat_series != nullptr &&
+                     (series_mask(t0) & 1) != 0 && q->group_sat_series != nullptr &&
                      tc::cross_buffer_doubles(cf.rows) >= cf.rows * 64 + 2048;
   CrossLds layout = cross_lds_layout(cf, t0->n_r, separate, defer ? ca.n_groups : 0);
   if (defer && layout.bytes > kMaxLdsBytes / 2 - 256) {

@@ -1253,7 +1253,7 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     // for every draw that allows it; bit 1: the binomial expansion of the satellite bins well
     // above a draw's M0; 0: always the node loops.  Per draw either way (a draw's bits do not
     // depend on its neighbours in the batch).
-    TC_CHECK(value >= 0 && value <= 3, "series must be 0 .. 3");
+    TC_CHECK(value >= -1 && value <= 3, "series must be -1 .. 3");
     t->tuning.series = value;
   } else if (key == "grouped") {
     // 1 (default): bins that share their quadrature nodes -- the secondary-percentile bins of a
