@@ -420,7 +420,7 @@ struct GroupConsts {
 // Defer (predict_cross_fused_kernel, round 5): what happens to the lanes of a group that neither a
 // shortcut nor an expansion serves.  NoDefer: they run the node path here, under their part of
 // the execution mask -- a wave that holds one such lane pays the whole node loop.  A deferring
-// hook (active, on) gets a call under that mask instead and the members' occupations are
+// hook (active) gets a call under that mask instead and the members' occupations are
 // emitted as 0 for those lanes: the caller evaluates the (group, draw) pairs later, whole waves
 // of them at a time.
 // A double of lane `lane` (wave-uniform index) as a scalar.
@@ -433,7 +433,6 @@ __device__ __forceinline__ double readlane_f64(double value, int lane) {
 
 struct NoDefer {
   static constexpr bool active = false;
-  bool on = false;
   __device__ void operator()(int) const {}
 };
 
@@ -442,7 +441,6 @@ struct NoDefer {
 template <bool ACTIVE>
 struct MarkPairs {
   static constexpr bool active = ACTIVE;
-  bool on;
   unsigned long long* bitmap;
   __device__ void operator()(int group) const {
     bitmap[group] = __builtin_amdgcn_ballot_w64(true);
@@ -538,7 +536,7 @@ __device__ __forceinline__ void occ_group_zheng07(const double* table, const fm:
     }
   }
   if (done) return;
-  if (Defer::active && defer.on && shortcut == 0) {
+  if (Defer::active && shortcut == 0) {
     // a satellite group at or below the draw's M0: every node gives 0, as the node loop would;
     // everything else goes to the caller's list of pairs
     const bool zero = !central && bad == 0 &&
@@ -2294,6 +2292,128 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
   }
 }
 
+// The deferred (group, draw) pairs of the mode-cross kernels (round 5): lanes that neither a
+// shortcut nor an expansion served are marked in `bitmap` (one word per group: MarkPairs) and
+// entered the row sums as 0.  Wave w owns the draws w, w + 8, ...: it collects their pairs of
+// the groups [g_first, g_last) from the bitmap in group order (64 groups at a time: a prefix
+// sum over the lanes, into `list`: 512 words of this wave), evaluates 64 pairs per pass of the
+// node loop (lane = pair: the draw's constants from the lane that holds the draw, the group's
+// by vector loads, five nodes at a time) and adds coefficient x occupation to ITS draws' sums
+// in `res` ((rows, 64) doubles) -- lane = (row, share of the eight draws), eight pairs'
+// coefficients requested together --, in that order: a fixed order per draw, whatever the
+// rest of the batch is.  `type`: -1 every pair, 0 / 1 only the pairs of centrals / satellites
+// (separated by galaxy type: one call per component).  coefficient(bin, row): the row's
+// coefficient of member bin `bin`.  ROW_LANES: 16, 32 or 64 rows (lanes beyond: further draws).
+template <int ROW_LANES, typename Coefficient>
+__device__ __forceinline__ void cross_deferred_pairs(
+    const CrossFusedArgs& a, const double* table, const fm::Consts& kc, const DrawParams& dp,
+    const unsigned long long* bitmap, unsigned* list, int wave, int lane, int g_first, int g_last,
+    int type, Coefficient&& coefficient, double* res) {
+  constexpr int SHARES = 64 / ROW_LANES;        // lanes per row: shares of the wave's 8 draws
+  constexpr int SLOTS = 8 / SHARES;             // draws per lane: j = share + SHARES slot
+  const int row = lane % ROW_LANES, share = lane / ROW_LANES;
+  const unsigned long long owner = 0x0101010101010101ull << wave;
+  double extra[SLOTS];
+#pragma unroll
+  for (int slot = 0; slot < SLOTS; ++slot) extra[slot] = 0.0;
+  for (int gb = g_first; gb < g_last; gb += 64) {
+    const int g_lane = gb + lane;
+    unsigned long long word = g_lane < g_last ? bitmap[g_lane] & owner : 0ull;
+    const int count = __builtin_popcountll(word);
+    int inclusive = count;
+#pragma unroll
+    for (int offset = 1; offset < 64; offset <<= 1) {
+      const int other = __shfl_up(inclusive, offset, 64);
+      if (lane >= offset) inclusive += other;
+    }
+    const int total = __builtin_amdgcn_readlane(inclusive, 63);
+    int slot_out = inclusive - count;
+    while (word != 0) {
+      list[slot_out++] = (unsigned)(g_lane << 6) | (unsigned)__builtin_ctzll(word);
+      word &= word - 1;
+    }
+    for (int e0 = 0; e0 < total; e0 += 64) {
+      const int n = total - e0 < 64 ? total - e0 : 64;
+      const bool active = lane < n;
+      const unsigned entry = list[e0 + (active ? lane : 0)];
+      const int g = (int)(entry >> 6), draw = (int)(entry & 63);
+      const bool central = g < a.n_central_groups;
+      const int m_begin = a.group.begin[g], m_end = a.group.begin[g + 1];
+      const double log_m_min = __shfl(dp.log_m_min, draw, 64);
+      const double inv_sigma = __shfl(dp.inv_sigma, draw, 64);
+      const double m0 = __shfl(dp.m0, draw, 64);
+      const double log2_m1 = __shfl(dp.log2_m1, draw, 64);
+      const double sat_scale = __shfl(dp.sat_scale, draw, 64);
+      const double alpha = __shfl(dp.alpha, draw, 64);
+      const int bad = __shfl(dp.bad, draw, 64);
+      // member by member: the occupation (the nodes of the lane's group for the lane's draw,
+      // evaluated per member -- a handful of pairs per tile, and twenty registers less than
+      // keeping the node values), then its row contributions to the owner's sums
+      for (int t = 0; __builtin_amdgcn_ballot_w64(active && m_begin + t < m_end) != 0; ++t) {
+        const int mi = m_begin + t;
+        const bool valid = active && mi < m_end && (type < 0 || central == (type == 0));
+        const int mi_safe = valid ? mi : m_begin;
+        const double* weight = a.group.weight + (int64_t)mi_safe * 10;
+        double acc = 0.0;
+        bool tie = false;
+        // (five nodes at a time: their constants requested together, then evaluated)
+#pragma unroll 1
+        for (int k0 = 0; k0 < 10; k0 += 5) {
+          double node[5], w[5];
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            node[k] = central ? a.group.log_m[g * 10 + k0 + k] : a.group.m[g * 10 + k0 + k];
+            w[k] = weight[k0 + k];
+          }
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            double value;
+            if (central) {
+              value = fm::erf_fast(table, kc, (node[k] - log_m_min) * inv_sigma);
+              tie = tie || node[k] == log_m_min;
+            } else {
+              const double x = node[k] - m0;
+              value = fm::exp2_fast(
+                  table, kc,
+                  alpha * fm::log2_fast_offset(table, kc, x > 1e-300 ? x : 1e-300, log2_m1),
+                  x > 0.0);
+            }
+            acc = fma(w[k], value, acc);
+          }
+        }
+        const bool cen_nan = (bad & kBadCen) || ((bad & kTieCen) && tie);
+        if (central) acc = fma(0.5, acc, 0.5 * a.group.weight[(int64_t)a.n_bins * 10 + mi_safe]);
+        else acc *= sat_scale;
+        if (bad != 0) {
+          if (!central && (bad & kInfSat) && acc != 0.0) acc = __builtin_huge_val();
+          if (central ? cen_nan : ((bad & kBadSat) && acc != 0.0)) acc = __builtin_nan("");
+        }
+        // (eight pairs at a time: their coefficients requested together; a pair that is not
+        // valid -- beyond the batch, beyond its group's members, the other galaxy type --
+        // adds coefficient x 0)
+        const double nbar_lane = valid ? acc : 0.0;
+        for (int p0 = 0; p0 < n; p0 += 8) {
+          double c[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            c[u] = coefficient(__builtin_amdgcn_readlane(mi_safe, (p0 + u) & 63), row);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const double nbar = readlane_f64(nbar_lane, (p0 + u) & 63);
+            const int j = __builtin_amdgcn_readlane(draw, (p0 + u) & 63) >> 3;
+#pragma unroll
+            for (int slot = 0; slot < SLOTS; ++slot)
+              extra[slot] = fma(c[u], share + SHARES * slot == j ? nbar : 0.0, extra[slot]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int slot = 0; slot < SLOTS; ++slot)
+    res[row * kLanes + wave + 8 * (share + SHARES * slot)] += extra[slot];
+}
+
 // ---- mode cross, one launch per batch: theta -> (ngal, xi[, chi2]) ------------------------
 //
 // tabcorr.py:537-578 + :623-683 for tables with mode = 'cross' (excess surface density, any
@@ -2331,7 +2451,7 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
 // flop on the same pipe (matrix and vector FP64 share it), an eighth of the instructions, no
 // scalar loads.  The buffer's rows are skewed by 16 draws per bin (row r holds draw d at column
 // (d + 16 (r % 4)) % 64) so that the four bins a B operand spans fall into different banks.
-template <int RW, bool ASSEMBIAS, bool MODULATE>
+template <int RW, bool ASSEMBIAS, bool MODULATE, bool DEFER = false>
 // (second launch bound = waves per SIMD: four -- two workgroups per CU, 128 vector registers --
 // for up to 8 rows per wave; the 16-row instances (65 - 128 rows: 32 registers of sums live across
 // the occupation arithmetic) would spill there and take one workgroup per CU instead)
@@ -2357,9 +2477,10 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
     double2v* dst = (double2v*)table;
     for (int i = threadIdx.x; i < fm::kTableDoubles / 2; i += blockDim.x) dst[i] = src[i];
   }
-  // (the deferred pairs: compiled for the undecorated instances of up to 64 rows)
-  constexpr bool kDeferrable = !ASSEMBIAS && !MODULATE && ROWS <= 64;
-  const bool deferring = kDeferrable && a.defer != 0;
+  // (the deferred pairs: instances of their own -- undecorated, up to 64 rows)
+  static_assert(!DEFER || (!ASSEMBIAS && !MODULATE && ROWS <= 64), "deferred pairs");
+  constexpr bool kDeferrable = DEFER;
+  constexpr bool deferring = DEFER;
   unsigned long long* bitmap = (unsigned long long*)(cross_lds + a.lds_bitmap);
   if (deferring)
     for (int i = threadIdx.x; i < a.n_groups; i += blockDim.x) bitmap[i] = 0;
@@ -2407,7 +2528,7 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
     sc_i32 group_begin = (sc_i32)a.group.begin;
     sc_i32 chunk_group = (sc_i32)a.chunk_group;
     sc_i32 chunk_block = (sc_i32)a.chunk_block;
-    const MarkPairs<kDeferrable> mark{deferring, bitmap};
+    const MarkPairs<kDeferrable> mark{bitmap};
     const GroupConsts gq{(sc_f64)a.group.log_m, (sc_f64)a.group.m, (sc_f64)a.group.weight,
                          (sc_f64)a.group.weight + a.n_bins * 10, (sc_f64)a.group.percentile,
                          (sc_i32)a.group.member,
@@ -2512,125 +2633,18 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
   }
   __syncthreads();
   if (kDeferrable && deferring) {
-    // ---- the deferred (group, draw) pairs ----
-    // Wave w owns the draws w, w + 8, ...: it collects their pairs from the bitmap in group
-    // order (64 groups at a time: a prefix sum over the lanes), evaluates 64 pairs per pass of
-    // the node loop (lane = pair: the draw's constants from the lane that holds the draw, the
-    // group's by vector loads) and adds coefficient x occupation to ITS draws' sums, lane =
-    // row, in that order -- a fixed order per draw, whatever the rest of the batch is.
+    // ---- the deferred (group, draw) pairs (cross_deferred_pairs) ----
     sc_i32 chunk_groups = (sc_i32)a.chunk_group;
-    const int g_first = chunk_groups[chunk_begin], g_last = chunk_groups[chunk_end];
-    unsigned* list = (unsigned*)(cross_lds + a.lds_list) + wave * 512;
-    const unsigned long long owner = 0x0101010101010101ull << wave;
     sc_i32 bin_operand = (sc_i32)a.bin_operand;
-    // (separated by galaxy type: the pairs of the centrals in a first pass, the satellites' in
-    // a second -- eight sums per lane at a time)
-    for (int pass = 0; pass < (a.separate ? 2 : 1); ++pass) {
-    double extra[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) extra[j] = 0.0;
-    for (int gb = g_first; gb < g_last; gb += 64) {
-      const int g_lane = gb + lane;
-      unsigned long long word = g_lane < g_last ? bitmap[g_lane] & owner : 0ull;
-      const int count = __builtin_popcountll(word);
-      int inclusive = count;
-#pragma unroll
-      for (int offset = 1; offset < 64; offset <<= 1) {
-        const int other = __shfl_up(inclusive, offset, 64);
-        if (lane >= offset) inclusive += other;
-      }
-      const int total = __builtin_amdgcn_readlane(inclusive, 63);
-      int slot = inclusive - count;
-      while (word != 0) {
-        list[slot++] = (unsigned)(g_lane << 6) | (unsigned)__builtin_ctzll(word);
-        word &= word - 1;
-      }
-      for (int e0 = 0; e0 < total; e0 += 64) {
-        const int n = total - e0 < 64 ? total - e0 : 64;
-        const bool active = lane < n;
-        const unsigned entry = list[e0 + (active ? lane : 0)];
-        const int g = (int)(entry >> 6), draw = (int)(entry & 63);
-        const bool central = g < a.n_central_groups;
-        const int m_begin = a.group.begin[g], m_end = a.group.begin[g + 1];
-        const double log_m_min = __shfl(dp.log_m_min, draw, 64);
-        const double inv_sigma = __shfl(dp.inv_sigma, draw, 64);
-        const double m0 = __shfl(dp.m0, draw, 64);
-        const double log2_m1 = __shfl(dp.log2_m1, draw, 64);
-        const double sat_scale = __shfl(dp.sat_scale, draw, 64);
-        const double alpha = __shfl(dp.alpha, draw, 64);
-        const int bad = __shfl(dp.bad, draw, 64);
-        // member by member: the occupation (the nodes of the lane's group for the lane's draw,
-        // evaluated per member -- a handful of pairs per tile, and twenty registers less than
-        // keeping the node values), then its row contributions to the owner's sums
-        for (int t = 0; __builtin_amdgcn_ballot_w64(active && m_begin + t < m_end) != 0; ++t) {
-          const int mi = m_begin + t;
-          const bool valid = active && mi < m_end && (!a.separate || central == (pass == 0));
-          const int mi_safe = valid ? mi : m_begin;
-          const double* weight = a.group.weight + (int64_t)mi_safe * 10;
-          double acc = 0.0;
-          bool tie = false;
-          // (five nodes at a time: their constants requested together, then evaluated)
-#pragma unroll 1
-          for (int k0 = 0; k0 < 10; k0 += 5) {
-            double node[5], w[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-              node[k] = central ? a.group.log_m[g * 10 + k0 + k] : a.group.m[g * 10 + k0 + k];
-              w[k] = weight[k0 + k];
-            }
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-              double value;
-              if (central) {
-                value = fm::erf_fast(table, kc, (node[k] - log_m_min) * inv_sigma);
-                tie = tie || node[k] == log_m_min;
-              } else {
-                const double x = node[k] - m0;
-                value = fm::exp2_fast(
-                    table, kc,
-                    alpha * fm::log2_fast_offset(table, kc, x > 1e-300 ? x : 1e-300, log2_m1),
-                    x > 0.0);
-              }
-              acc = fma(w[k], value, acc);
-            }
-          }
-          const bool cen_nan = (bad & kBadCen) || ((bad & kTieCen) && tie);
-          if (central) acc = fma(0.5, acc, 0.5 * a.group.weight[(int64_t)a.n_bins * 10 + mi_safe]);
-          else acc *= sat_scale;
-          if (bad != 0) {
-            if (!central && (bad & kInfSat) && acc != 0.0) acc = __builtin_huge_val();
-            if (central ? cen_nan : ((bad & kBadSat) && acc != 0.0)) acc = __builtin_nan("");
-          }
-          // (eight pairs at a time: their coefficients requested together; a pair that is not
-          // valid -- beyond the batch, beyond its group's members, the other galaxy type --
-          // adds coefficient x 0)
-          const double nbar_lane = valid ? acc : 0.0;
-          const int row_offset = lane < ROWS ? (lane >> 4) * 64 + (lane & 15) : 0;
-          for (int p0 = 0; p0 < n; p0 += 8) {
-            double coefficient[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int bin = __builtin_amdgcn_readlane(mi_safe, (p0 + u) & 63);
-              coefficient[u] = a.rows[bin_operand[bin] + row_offset];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const double nbar = readlane_f64(nbar_lane, (p0 + u) & 63);
-              const int j = __builtin_amdgcn_readlane(draw, (p0 + u) & 63) >> 3;
-#pragma unroll
-              for (int jj = 0; jj < 8; ++jj)
-                extra[jj] = fma(coefficient[u], jj == j ? nbar : 0.0, extra[jj]);
-            }
-          }
-        }
-      }
-    }
-    if (lane < ROWS) {
-      double* res = pass == 0 ? res0 : res1;
-#pragma unroll
-      for (int jj = 0; jj < 8; ++jj) res[lane * kLanes + wave + 8 * jj] += extra[jj];
-    }
-    }
+    unsigned* list = (unsigned*)(cross_lds + a.lds_list) + wave * 512;
+    for (int pass = 0; pass < (a.separate ? 2 : 1); ++pass)
+      cross_deferred_pairs<ROWS <= 32 ? 32 : 64>(
+          a, table, kc, dp, bitmap, list, wave, lane, chunk_groups[chunk_begin],
+          chunk_groups[chunk_end], a.separate ? pass : -1,
+          [&](int bin, int row) {
+            return a.rows[bin_operand[bin] + (row >> 4) * 64 + (row & 15)];
+          },
+          pass == 0 ? res0 : res1);
     __syncthreads();
   }
   if (n_splits > 1) {
@@ -2771,8 +2785,8 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
 // (four waves per SIMD = two workgroups per CU -- the second launch bound is waves per SIMD in
 // HIP: left to itself the register allocator takes 130 registers since the moment expansion
 // joined, and one workgroup per CU costs 58 -> 94 us per 10^4 draws of the AbacusSummit table)
-template <bool ASSEMBIAS, bool MODULATE>
-__global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kernel(
+template <bool ASSEMBIAS, bool MODULATE, bool DEFER = false>
+__global__ __launch_bounds__(64 * kCrossWaves, DEFER ? 4 : 2) void predict_cross_small_kernel(
     CrossFusedArgs a) {
   constexpr int ROWS = kCrossSmallRows, kCrossChunk = kCrossSmallChunk;
   static_assert(fm::kTableDoubles == kCrossTableDoubles, "kernel_args.h");
@@ -2793,6 +2807,15 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kerne
     double2v* dst = (double2v*)table;
     for (int i = threadIdx.x; i < fm::kTableDoubles / 2; i += blockDim.x) dst[i] = src[i];
   }
+  // (the deferred pairs of cross_deferred_pairs: compiled for the undecorated instance, which
+  // then also takes the expansions of series.h -- without the node loop in its main loop the
+  // registers suffice)
+  static_assert(!DEFER || (!ASSEMBIAS && !MODULATE), "deferred pairs");
+  constexpr bool kDeferrable = DEFER;
+  constexpr bool deferring = DEFER;
+  unsigned long long* bitmap = (unsigned long long*)(cross_lds + a.lds_bitmap);
+  if (deferring)
+    for (int i = threadIdx.x; i < a.n_groups; i += blockDim.x) bitmap[i] = 0;
   __syncthreads();
   // (medium batches: n_splits workgroups per tile of 64 draws, each with a share of the groups;
   // the last one to arrive adds the shares in split order and finishes the tile)
@@ -2806,11 +2829,11 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kerne
   double acc[ROWS];
 #pragma unroll
   for (int j = 0; j < ROWS; ++j) acc[j] = 0.0;
+  DrawParams dp;
   {
     const double* th = a.theta + b * a.n_theta;
     const DrawSetup d = prepare_draw(table, kc, th[0], th[1], th[2], th[3], th[4],
                                      ASSEMBIAS ? th[5] : 0.0, ASSEMBIAS ? th[6] : 0.0);
-    DrawParams dp;
     dp.log_m_min = d.log_m_min;
     dp.inv_sigma = d.inv_sigma;
     dp.m0 = d.m0;
@@ -2821,7 +2844,12 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kerne
     dp.a_sat = d.a_sat;
     dp.bad = d.bad;
     dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
-    // (compiled without the moment expansion: dp's keys stay at INT_MAX)
+    // (the decorated instances are compiled without the moment expansions: dp's keys stay at
+    // INT_MAX there)
+    if (kDeferrable)
+      series_setup<MODULATE>(dp, deferring && a.group.series != nullptr,
+                             deferring && a.group.sat_series != nullptr);
+    const MarkPairs<kDeferrable> mark{bitmap};
     sc_i32 group_begin = (sc_i32)a.group.begin;
     const GroupConsts gq{(sc_f64)a.group.log_m, (sc_f64)a.group.m, (sc_f64)a.group.weight,
                          (sc_f64)a.group.weight + a.n_bins * 10, (sc_f64)a.group.percentile,
@@ -2845,8 +2873,9 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kerne
       stride = cen ? a.cen_waves : W - a.cen_waves;
     }
     for (int gr = first; gr < end; gr += stride)
-      occ_group_zheng07<ASSEMBIAS, MODULATE, false>(table, kc, gr, group_begin[gr], group_begin[gr + 1],
-                                             gr < a.n_central_groups, gq, a.split, dp, emit);
+      occ_group_zheng07<ASSEMBIAS, MODULATE, kDeferrable>(
+          table, kc, gr, group_begin[gr], group_begin[gr + 1], gr < a.n_central_groups, gq,
+          a.split, dp, emit, mark);
   }
 
   // ---- the waves' sums, kCrossChunk rows at a time, in wave order ----
@@ -2864,6 +2893,22 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kerne
       double sum = 0.0;
       for (int w = w_begin; w < w_end; ++w) sum += stage[w * kCrossChunk * kLanes + rest];
       res[(comp * ROWS + chunk * kCrossChunk) * kLanes + rest] = sum;
+    }
+    __syncthreads();
+  }
+
+  if (kDeferrable && deferring) {
+    // ---- the deferred (group, draw) pairs of this workgroup's groups (cross_deferred_pairs) ----
+    unsigned* list = (unsigned*)stage + wave * 512;         // (the stage is free again)
+    auto coefficient = [&](int bin, int row) { return a.rows[(int64_t)bin * a.row_stride + row]; };
+    if (a.separate) {
+      cross_deferred_pairs<ROWS>(a, table, kc, dp, bitmap, list, wave, lane, a.split_cen[split],
+                                 a.split_cen[split + 1], -1, coefficient, res);
+      cross_deferred_pairs<ROWS>(a, table, kc, dp, bitmap, list, wave, lane, a.split_sat[split],
+                                 a.split_sat[split + 1], -1, coefficient, res + ROWS * kLanes);
+    } else {
+      cross_deferred_pairs<ROWS>(a, table, kc, dp, bitmap, list, wave, lane, a.split_all[split],
+                                 a.split_all[split + 1], -1, coefficient, res);
     }
     __syncthreads();
   }
@@ -2909,6 +2954,12 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kerne
 
   // ---- per draw: spline weights / norms of the tables, number densities ----
   set_priority((a.priority >> 4) & 3);
+  // (the draw's index once more, from a lane index the optimiser cannot trace back: kept from
+  // the top of the kernel it would sit in registers across every phase)
+  int lane_again = lane;
+  asm volatile("" : "+v"(lane_again));
+  const int64_t b0_end = col + lane_again;
+  const int64_t b_end = b0_end < a.n_draws ? b0_end : a.n_draws - 1;
   const int per_table = a.n_r + 1;
   double* coef = stage;                         // (K, 64): c_k / ngal_k
   double* tile = stage + a.n_tables * kLanes;   // (n_comp n_r, 65)
@@ -2920,7 +2971,7 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kerne
         for (int dim = 0; dim < a.n_dim; ++dim) {
           const int n = a.n_axis[dim];
           const double* xp = a.xp + a.axis_offset[dim];
-          const double x = a.x[b * a.n_dim + dim];
+          const double x = a.x[b_end * a.n_dim + dim];
           int seg = -1;
           for (int i = 0; i < n; ++i) seg += xp[i] <= x ? 1 : 0;   // np.digitize(x, xp) - 1
           if (x == xp[n - 1]) seg = n - 2;
@@ -2941,12 +2992,12 @@ __global__ __launch_bounds__(64 * kCrossWaves, 2) void predict_cross_small_kerne
       n_cen += c * cen;
       n_sat += c * sat;
     }
-    if (b0 < a.n_draws) {
+    if (b0_end < a.n_draws) {
       if (a.separate) {
-        a.ngal[2 * b0] = n_cen;
-        a.ngal[2 * b0 + 1] = n_sat;
+        a.ngal[2 * b0_end] = n_cen;
+        a.ngal[2 * b0_end + 1] = n_sat;
       } else {
-        a.ngal[b0] = n_cen + n_sat;
+        a.ngal[b0_end] = n_cen + n_sat;
       }
     }
   }

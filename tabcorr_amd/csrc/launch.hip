@@ -1532,29 +1532,31 @@ bool cross_fused_eligible(const tc_table* t0, const CrossFused& cf, int64_t n_dr
 }
 
 namespace {
-template <bool AB, bool MO>
+template <bool AB, bool MO, bool DE = false>
 int launch_cross_fused(int device, int rows, dim3 grid, dim3 block, int lds, hipStream_t stream,
                        hipEvent_t k0, hipEvent_t k1, const tc::CrossFusedArgs& ca) {
   switch (rows / tc::kCrossWaves) {      // rows per wave
-#define TC_CASE(N)                                                                            \
+#define TC_CASE(N, DEFER)                                                                     \
   case N: {                                                                                   \
     static bool limit_set[64] = {};                                                           \
     if (lds > 64 * 1024 && !(device >= 0 && device < 64 && limit_set[device])) {              \
       /* (the kernel holds a few bytes of static LDS besides) */                               \
-      TC_HIP(hipFuncSetAttribute((const void*)tc::predict_cross_fused_kernel<N, AB, MO>,      \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize,                  \
-                                 160 * 1024 - 256));                                          \
+      TC_HIP(hipFuncSetAttribute(                                                             \
+          (const void*)tc::predict_cross_fused_kernel<N, AB, MO, DEFER>,                      \
+          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));                     \
       if (device >= 0 && device < 64) limit_set[device] = true;                               \
     }                                                                                         \
-    hipExtLaunchKernelGGL((tc::predict_cross_fused_kernel<N, AB, MO>), grid, block, lds,      \
-                          stream, k0, k1, 0, ca);                                             \
+    hipExtLaunchKernelGGL((tc::predict_cross_fused_kernel<N, AB, MO, DEFER>), grid, block,    \
+                          lds, stream, k0, k1, 0, ca);                                        \
     break;                                                                                    \
   }
-    TC_CASE(4) TC_CASE(8) TC_CASE(16)
+    TC_CASE(4, DE) TC_CASE(8, DE) TC_CASE(16, false)
 #undef TC_CASE
     case 2:     // up to 16 rows: the sums in every wave's registers
-      hipExtLaunchKernelGGL((tc::predict_cross_small_kernel<AB, MO>), grid, block, lds, stream,
-                            k0, k1, 0, ca);
+      // (the instance with the deferred pairs exists in the source and is not shipped: 59.2
+      // against 58.9 us per 10^4 draws of the AbacusSummit table, two registers spilled)
+      hipExtLaunchKernelGGL((tc::predict_cross_small_kernel<AB, MO, false>), grid, block, lds,
+                            stream, k0, k1, 0, ca);
       break;
     default:
       return fail(TC_ERR_UNSUPPORTED, "no cross kernel for %d rows", rows);
@@ -1594,8 +1596,9 @@ int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs
   // The deferred pairs (kernel_args.h): undecorated, 17 .. 64 rows, the centrals' expansion on
   // -- the satellites' then comes with it whatever bit 1 of "series" says: its cost on wide
   // priors was the node loop a wave ran NEXT to it for a single draw, which is what goes away.
-  const bool defer = t0->tuning.cross_defer != 0 && cf.rows > tc::kCrossSmallRows &&
-                     cf.rows <= 64 && cf.d_bin_operand != nullptr &&
+  const bool small = cf.rows <= tc::kCrossSmallRows;
+  const bool defer = t0->tuning.cross_defer != 0 && !small && cf.rows <= 64 &&
+                     cf.d_bin_operand != nullptr &&
                      !(flags & (TC_FLAG_ASSEMBIAS | TC_FLAG_MODULATE_WITH_CENOCC)) &&
                      (series_mask(t0) & 1) != 0 && q->group_sat_series != nullptr &&
                      tc::cross_buffer_doubles(cf.rows) >= cf.rows * 64 + 2048;
@@ -1618,6 +1621,11 @@ int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs
   ca.row_stride = cf.rows;
   if (cf.rows <= tc::kCrossSmallRows) {
     layout.bytes = tc::cross_small_lds_doubles(separate ? 2 : 1) * 8;
+    if (ca.defer) {
+      // (the bitmap behind the sums; the lists lie in the stage, which is free by then)
+      ca.lds_bitmap = tc::cross_small_lds_doubles(separate ? 2 : 1);
+      layout.bytes += (ca.n_groups + 1) / 2 * 2 * 8;
+    }
     if (separate) {
       // waves for the groups of centrals in proportion to their cost (a node of the centrals
       // takes ~21 instructions, one of the satellites ~33)
@@ -1724,6 +1732,10 @@ int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs
   if (status != TC_OK) return status;
   const bool assembias = (flags & TC_FLAG_ASSEMBIAS) != 0;
   const bool modulate = (flags & TC_FLAG_MODULATE_WITH_CENOCC) != 0;
+  if (ca.defer)        // (undecorated, up to 64 rows: the instances with the deferred pairs)
+    status = launch_cross_fused<false, false, true>(t0->device, cf.rows, grid, block, lds, stream,
+                                                    k0, k1, ca);
+  else
   status = assembias ? (modulate ? launch_cross_fused<true, true>(t0->device, cf.rows, grid, block,
                                                                   lds, stream, k0, k1, ca)
                                  : launch_cross_fused<true, false>(t0->device, cf.rows, grid,
