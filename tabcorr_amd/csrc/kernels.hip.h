@@ -3349,7 +3349,12 @@ __device__ __forceinline__ void single_draw_body(SingleArgs a) {
       for (int s = 0; s < kFan; ++s) total += slice_sum[s * rt + tid];
       store_host(a.partial + (int64_t)part * rt + tid, total);
     } else if (tid < rt + 2 && part == 0) {
-      store_host(a.ngal + (tid - rt), totals[tid - rt]);
+      // (the address formed here, from an index the optimiser cannot hoist out of the resident
+      // form's loop of calls: kept across the loop it was spilled, and every call of workgroup
+      // 0 waited for a scratch load in front of its number densities)
+      int which = tid - rt;
+      asm volatile("" : "+v"(which));
+      store_host(a.ngal + which, totals[which]);
     }
     if (a.done != nullptr) {
       __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0): the wave's stores have arrived
@@ -3517,6 +3522,13 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
   };
 
   for (;;) {
+    // (the thread's indices of THIS call, from a value the optimiser cannot trace back to
+    // threadIdx: addresses formed from it stay inside the loop of calls.  Hoisted out of
+    // it they filled 19 more registers than the 255 there are, and every call waited for
+    // their scratch loads in each of its phases)
+    int tid_call = tid;
+    asm volatile("" : "+v"(tid_call));
+    const int lane_call = tid_call & 63;
     // ---- the call.  a.direct: the mailbox lies in device memory that the host writes through
     // the PCIe aperture, every workgroup polls its header there (local reads) and a walker's
     // workgroup takes its parameters from behind it.  Otherwise the mailbox is page-locked
@@ -3546,19 +3558,19 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
         if (b == 0) __builtin_amdgcn_s_sleep(2);
         else __builtin_amdgcn_s_sleep(4);
       }
-      if (b == 0 && !a.direct && lane == 0)
+      if (b == 0 && !a.direct && lane_call == 0)
         __hip_atomic_store(a.callword,
                            leave != 0 ? kResidentStop : (epoch << 10) | (unsigned long long)walkers,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (leave == 0 && b < walkers && lane < 7) {
+      if (leave == 0 && b < walkers && lane_call < 7) {
         // (parameters: 8 doubles per walker behind the header's line)
-        const double* theta = (const double*)a.mailbox + 8 + (size_t)b * 8 + lane;
+        const double* theta = (const double*)a.mailbox + 8 + (size_t)b * 8 + lane_call;
         double value;
         asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
                      : "=v"(value) : "v"(theta) : "memory");
-        s_theta[lane] = value;
+        s_theta[lane_call] = value;
       }
-      if (lane == 0) {
+      if (lane_call == 0) {
         s_leave = leave;
         s_walkers = walkers;
         s_epoch = epoch;
@@ -3574,7 +3586,7 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
 
     // ---- A: the occupation of walker b ----------------------------------------------------
     if (is_walker && (a.skip & 1)) {
-      if (tid == 0) __hip_atomic_store(a.flag_a + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid_call == 0) __hip_atomic_store(a.flag_a + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (is_walker) {
       const fm::Consts kc = fm::make_consts();
       const DrawSetup d = prepare_draw(table, kc, s_theta[0], s_theta[1], s_theta[2], s_theta[3],
@@ -3583,7 +3595,7 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
       const double f1 = (1.0 - a.split) / a.split, f2 = a.split / (1.0 - a.split);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const int node = tid + u * kEnsembleThreads;
+        const int node = tid_call + u * kEnsembleThreads;
         if (node < n_nodes) {
           const int g = node / a.n_gauss;
           const double lm = kept_lm[u], mass = kept_mass[u];
@@ -3616,7 +3628,7 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
       __syncthreads();
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const int g = tid + u * kEnsembleThreads;
+        const int g = tid_call + u * kEnsembleThreads;
         if (g < a.n_bins) {
           double acc = 0.0;
           for (int k = 0; k < a.n_gauss; ++k) acc += node_value[g * a.n_gauss + k];
@@ -3624,23 +3636,23 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
         }
       }
       __syncthreads();
-      if (tid < 128) {   // centrals / satellites totals: one wave each, fixed order
-        const int which = tid >> 6;
+      if (tid_call < 128) {   // centrals / satellites totals: one wave each, fixed order
+        const int which = tid_call >> 6;
         const int lo = which == 0 ? 0 : a.n_central, hi = which == 0 ? a.n_central : a.n_bins;
         double total = 0.0;
-        for (int g = lo + lane; g < hi; g += 64) total += density[g];
+        for (int g = lo + lane_call; g < hi; g += 64) total += density[g];
 #pragma unroll
         for (int offset = 32; offset >= 1; offset >>= 1) total += __shfl_down(total, offset, 64);
-        if (lane == 0) s_totals[which] = total;
+        if (lane_call == 0) s_totals[which] = total;
       }
       // the densities go out while the totals are formed; the totals behind them
-      for (int g = tid; g < a.n_bins; g += kEnsembleThreads)
+      for (int g = tid_call; g < a.n_bins; g += kEnsembleThreads)
         ens::store_agent(a.dens + (size_t)b * a.dens_stride + g, density[g]);
       __syncthreads();
-      if (tid < 2) ens::store_agent(a.dens + (size_t)b * a.dens_stride + a.n_bins + tid, s_totals[tid]);
+      if (tid_call < 2) ens::store_agent(a.dens + (size_t)b * a.dens_stride + a.n_bins + tid_call, s_totals[tid_call]);
       ens::wait_stores();
       __syncthreads();
-      if (tid == 0)
+      if (tid_call == 0)
         __hip_atomic_store(a.flag_a + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     stamp(1, __builtin_amdgcn_s_memrealtime());
@@ -3658,7 +3670,7 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
     const bool active = grp < n_wg;
     if (active) {
       if (wave == 0) {
-        const int walker = grp * 64 + lane;
+        const int walker = grp * 64 + lane_call;
         const unsigned long long since = __builtin_amdgcn_s_memrealtime();
         for (;;) {
           const unsigned long long flag =
@@ -3681,7 +3693,7 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
         // in flight per thread
         const int stride = a.dens_stride;
         const int count = 64 * stride;
-        for (int idx0 = tid; idx0 < count; idx0 += 8 * kEnsembleThreads) {
+        for (int idx0 = tid_call; idx0 < count; idx0 += 8 * kEnsembleThreads) {
           double value[8];
           int at[8];
 #pragma unroll
@@ -3708,9 +3720,9 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
       // order: with one quarter per workgroup the two waves of a row group take a half each
       // and meet through the LDS; with two or four quarters a wave sums whole quarters (both
       // halves, two accumulators) -- one exchange per call instead of one per quarter.
-      // (sel and the rows as per-lane values: with wave-uniform ones the compiler moves the
+      // (sel and the rows as per-lane_call values: with wave-uniform ones the compiler moves the
       // positions' bins into scalar registers one LDS read, one wait and one branch at a time)
-      const int sel = (tid >> 6) & 1, row0 = (tid >> 7) * 8;
+      const int sel = (tid_call >> 6) & 1, row0 = (tid_call >> 7) * 8;
       const bool rows_used = (wave >> 1) * 8 < rt;
       // (one instance of the inner code, real loops: unrolled over 16 guarded positions and
       // inlined five times the phase was 7000 instructions, more than the instruction cache
@@ -3746,8 +3758,8 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
             for (int u = 0; u < 4; ++u) {
               const bool valid = bins[u] != 0xffffffffu;
               const unsigned bi = valid ? bins[u] & 0xffffu : 0u, bj = valid ? bins[u] >> 16 : 0u;
-              first[u] = dens_lds[bj * kEnsembleDensPad + lane];
-              second[u] = a.mode == 0 ? dens_lds[bi * kEnsembleDensPad + lane] : 1.0;
+              first[u] = dens_lds[bj * kEnsembleDensPad + lane_call];
+              second[u] = a.mode == 0 ? dens_lds[bi * kEnsembleDensPad + lane_call] : 1.0;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -3782,7 +3794,7 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
         }
         if (sel == 1) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) area[(row0 + k) * 64 + lane] = mine[k];
+          for (int k = 0; k < 8; ++k) area[(row0 + k) * 64 + lane_call] = mine[k];
         }
       }
       __syncthreads();
@@ -3792,12 +3804,12 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           if (row0 + k < rt)
-            ens::store_agent(a.partial + ((size_t)b * rt + row0 + k) * 64 + lane,
-                             mine[k] + area[(row0 + k) * 64 + lane]);
+            ens::store_agent(a.partial + ((size_t)b * rt + row0 + k) * 64 + lane_call,
+                             mine[k] + area[(row0 + k) * 64 + lane_call]);
       }
       ens::wait_stores();
       __syncthreads();
-      if (tid == 0)
+      if (tid_call == 0)
         __hip_atomic_store(a.flag_b + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     stamp(5, __builtin_amdgcn_s_memrealtime());
@@ -3811,9 +3823,9 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
         // partial sums, all loads in flight together
         const int first = wave * 8;
         {
-          const int from = 4 * first + lane;
-          const bool needed = lane < 32 && (from >> 2) < a.n_slices &&
-                              (n_wg == 1 ? true : n_wg == 2 ? (lane & 1) == c : (lane & 3) == c);
+          const int from = 4 * first + lane_call;
+          const bool needed = lane_call < 32 && (from >> 2) < a.n_slices &&
+                              (n_wg == 1 ? true : n_wg == 2 ? (lane_call & 1) == c : (lane_call & 3) == c);
           const unsigned long long since = __builtin_amdgcn_s_memrealtime();
           for (;;) {
             const unsigned long long flag =
@@ -3838,7 +3850,7 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
             const int which = n_wg == 1 ? v : n_wg == 2 ? c + 2 * v : c;
             part[u][v] =
                 s < a.n_slices && v < n_parts && !(a.skip & 8)
-                    ? ens::load_agent(a.partial + ((size_t)(4 * s + which) * rt + row) * 64 + lane)
+                    ? ens::load_agent(a.partial + ((size_t)(4 * s + which) * rt + row) * 64 + lane_call)
                     : 0.0;
           }
         }
@@ -3851,26 +3863,26 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
           else value = part[u][0];
           if (first + u < a.n_slices) sum = u == 0 ? value : sum + value;
         }
-        area[wave * 64 + lane] = sum;
+        area[wave * 64 + lane_call] = sum;
         __syncthreads();
         if (s_abort) break;
         if (wave == 0) {
           double each[8];
 #pragma unroll
-          for (int w = 0; w < 8; ++w) each[w] = area[w * 64 + lane];
+          for (int w = 0; w < 8; ++w) each[w] = area[w * 64 + lane_call];
           double total = each[0];
           const int n_waves = (a.n_slices + 7) >> 3;
 #pragma unroll
           for (int w = 1; w < 8; ++w)
             if (w < n_waves) total += each[w];
-          ens::store_host(out + lane, total);
+          ens::store_host(out + lane_call, total);
         }
       } else if (wave == 0) {
-        ens::store_host(out + lane, dens_lds[(a.n_bins + row - rt) * kEnsembleDensPad + lane]);
+        ens::store_host(out + lane_call, dens_lds[(a.n_bins + row - rt) * kEnsembleDensPad + lane_call]);
       }
       if (wave == 0) {
         ens::wait_stores();
-        if (lane == 0)
+        if (lane_call == 0)
           __hip_atomic_store(a.done + c * (rt + 2) + row, epoch, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_SYSTEM);
       }

@@ -1128,8 +1128,8 @@ def test_satellite_binomial_expansion_reproduces_the_node_loop():
 def test_no_kernel_spills_vector_registers():
     """every shipped instance of the prediction kernels compiles without
     vector-register spills and scratch (hipcc's kernel-resource-usage remarks of launch.hip,
-    tools/kernel_resources.py) -- except the two resident kernels, whose known counts may only
-    go down (latency paths: one workgroup per CU resp. a handful of workgroups)."""
+    tools/kernel_resources.py) -- the two resident kernels included since their per-call
+    address arithmetic stays inside the loop of calls (round 4: 1 and 19 spilled registers)."""
     import shutil
     import tempfile
     sys.path.insert(0, os.path.join(REPO, 'tools'))
@@ -1148,7 +1148,7 @@ def test_no_kernel_spills_vector_registers():
     kernels = kernel_resources.parse(out.stderr)
     names = kernel_resources.demangle(list(kernels))
     assert len(kernels) > 150
-    allowed = {'tc::resident_draw_kernel': 1, 'tc::resident_ensemble_kernel': 19}
+    allowed = {}
     spilling = {}
     for mangled, usage in kernels.items():
         name = names[mangled].replace('void ', '').split('(')[0]
