@@ -30,8 +30,8 @@ constexpr int kSteps = 5;                    // 8, 12, 16, 20, 24 terms
 constexpr int kFirst = 4;                    // the moments start at consts[kFirst]: blocks of
                                              // four, 32 bytes each, 32-byte aligned
 constexpr int kStride = kFirst + kMaxTerms;  // per bin: centre, (3 unused), M_1 .. M_24
-// (the loops request the block behind the one they use, also behind the last: arrays of
-// constants end with kPad more doubles)
+// (round 5's first loops requested the block behind the one they used, also behind the last:
+// arrays of constants still end with kPad more doubles)
 constexpr int kPad = 4;
 constexpr int kThresholds = 8;               // int32 per bin (kSteps used)
 constexpr double kTolerance = 1e-16;
@@ -71,11 +71,14 @@ TC_HD bool eligible(IntPtr thresholds, int inv_sigma_hi) {
 
 // The loops below: passes of four terms, NOT unrolled (the unrolled forms take 135-205 vector
 // registers in the kernels).  The moments of a pass are ONE aligned 32-byte scalar load through
-// a pointer that advances by a block per pass (requested one pass ahead; the arrays end with a
-// block of padding); the thresholds are eight scalar registers from one load before the first
-// pass, from which a lane counts its passes (`passes`): the loop ends with the wave's last
-// lane.  Round 4's loop recomputed its addresses from the pass number -- clamped, so that eight
-// separate 8-byte loads and three scalar instructions per vector instruction came out.
+// a pointer that advances by a block per pass, requested at the top of the pass (the other
+// waves of the SIMD cover its latency; requested a pass ahead, the rotation of the two register
+// sets cost eight scalar moves per pass of a pair of bins -- 39.4 -> 39.3 us per 10^4 draws of
+// the headline table, 75.8 -> 75.1 for the AbacusSummit interpolator); the thresholds are eight
+// scalar registers from one load before the first pass, from which a lane counts its passes
+// (`passes`): the loop ends with the wave's last lane.  Round 4's loop recomputed its
+// addresses from the pass number -- clamped, so that eight separate 8-byte loads and three scalar
+// instructions per vector instruction came out.
 struct f64x4_t {
   double v[4];
   TC_HD double operator[](int k) const { return v[k]; }
@@ -147,7 +150,6 @@ TC_HD double central_sum(const double* table, const fm::Consts& kc, double log_m
   // loop and the reference give -+1, N_cen = 0 or 1)
   const int n_blocks = passes<kSteps>(load_thresholds(thresholds), inv_sigma_hi, 2);
   Ptr block_ptr = consts + kFirst;
-  f64x4_t m = load_four(block_ptr, 0, 0);
   double g0, z0;
   const double e = fm::erf_gauss_fast(table, kc, (consts[0] - log_m_min) * inv_sigma, &g0, &z0);
   const double a = 2.0 * z0 * inv_sigma, b = -2.0 * inv_sigma * inv_sigma;
@@ -156,8 +158,8 @@ TC_HD double central_sum(const double* table, const fm::Consts& kc, double log_m
 #pragma unroll 1
 #endif
   for (int block = 0; block < n_blocks; ++block) {
+    const f64x4_t m = load_four(block_ptr, 0, 0);
     block_ptr += 4;
-    const f64x4_t next_m = load_four(block_ptr, 0, 0);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -168,7 +170,6 @@ TC_HD double central_sum(const double* table, const fm::Consts& kc, double log_m
       p_prev = p;
       p = next;
     }
-    m = next_m;
   }
   return fma(g0, sum, m0 * e);
 }
@@ -182,7 +183,6 @@ TC_HD void central_sum_pair(const double* table, const fm::Consts& kc, double lo
                             double* out_j) {
   const int n_blocks = passes<kSteps>(load_thresholds(thresholds), inv_sigma_hi, 2);
   Ptr ptr_i = consts_i + kFirst, ptr_j = consts_j + kFirst;
-  f64x4_t mi = load_four(ptr_i, 0, 0), mj = load_four(ptr_j, 0, 0);
   double g0, z0;
   const double e =
       fm::erf_gauss_fast(table, kc, (consts_i[0] - log_m_min) * inv_sigma, &g0, &z0);
@@ -192,10 +192,9 @@ TC_HD void central_sum_pair(const double* table, const fm::Consts& kc, double lo
 #pragma unroll 1
 #endif
   for (int block = 0; block < n_blocks; ++block) {
+    const f64x4_t mi = load_four(ptr_i, 0, 0), mj = load_four(ptr_j, 0, 0);
     ptr_i += 4;
     ptr_j += 4;
-    const f64x4_t next_i = load_four(ptr_i, 0, 0);
-    const f64x4_t next_j = load_four(ptr_j, 0, 0);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -207,8 +206,6 @@ TC_HD void central_sum_pair(const double* table, const fm::Consts& kc, double lo
       p_prev = p;
       p = next;
     }
-    mi = next_i;
-    mj = next_j;
   }
   *out_i = fma(g0, sum_i, m0_i * e);
   *out_j = fma(g0, sum_j, m0_j * e);
@@ -281,14 +278,13 @@ template <typename Ptr, typename IntPtr>
 TC_HD double binomial_sum(Ptr consts, double eps, double alpha, IntPtr thresholds, int m0_hi) {
   const int n_blocks = series::passes<kSteps>(series::load_thresholds(thresholds), m0_hi, 3);
   Ptr block_ptr = consts + kFirst;
-  f64x4_t cur = load_four(block_ptr, 0, 0);
   double d = 1.0, g = eps * alpha, sum = consts[3];         // n = 0: mu_0
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
   for (int block = 0; block < n_blocks; ++block) {
+    const f64x4_t cur = load_four(block_ptr, 0, 0);
     block_ptr += 4;
-    const f64x4_t next = load_four(block_ptr, 0, 0);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -297,7 +293,6 @@ TC_HD double binomial_sum(Ptr consts, double eps, double alpha, IntPtr threshold
       g -= eps;
       sum = fma(d, cur[k], sum);
     }
-    cur = next;
   }
   return sum;
 }
@@ -308,16 +303,14 @@ TC_HD void binomial_sum_pair(Ptr consts_i, Ptr consts_j, double eps, double alph
                              IntPtr thresholds, int m0_hi, double* out_i, double* out_j) {
   const int n_blocks = series::passes<kSteps>(series::load_thresholds(thresholds), m0_hi, 3);
   Ptr ptr_i = consts_i + kFirst, ptr_j = consts_j + kFirst;
-  f64x4_t cur_i = load_four(ptr_i, 0, 0), cur_j = load_four(ptr_j, 0, 0);
   double d = 1.0, g = eps * alpha, sum_i = consts_i[3], sum_j = consts_j[3];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
   for (int block = 0; block < n_blocks; ++block) {
+    const f64x4_t cur_i = load_four(ptr_i, 0, 0), cur_j = load_four(ptr_j, 0, 0);
     ptr_i += 4;
     ptr_j += 4;
-    const f64x4_t next_i = load_four(ptr_i, 0, 0);
-    const f64x4_t next_j = load_four(ptr_j, 0, 0);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -327,8 +320,6 @@ TC_HD void binomial_sum_pair(Ptr consts_i, Ptr consts_j, double eps, double alph
       sum_i = fma(d, cur_i[k], sum_i);
       sum_j = fma(d, cur_j[k], sum_j);
     }
-    cur_i = next_i;
-    cur_j = next_j;
   }
   *out_i = sum_i;
   *out_j = sum_j;
