@@ -705,6 +705,60 @@ int interp_predict_one(tc_interp* it, const double* theta, int n_theta, const do
 
 }  // namespace
 
+namespace {
+int interp_async(tc_interp* it, const double* theta, int n_theta, const double* x,
+                 int64_t n_draws, int n_gauss, unsigned flags, const double* data,
+                 const double* precision, double* ngal, double* second, bool chi2,
+                 int64_t* ticket_out, bool staging);
+
+// A synchronous host-array call as overlapping chunks of draws (table.cpp: predict_chunked has
+// the reasoning): chunk k's draws and extra parameters are staged and queued on lane k % lanes
+// while chunk k - 1 computes, its results are copied to the caller's arrays (on four host
+// threads) while later chunks compute and travel.  The interpolator's kernels cut a draw's
+// sums where the batch size puts them: chunks agree with one piece to rounding.
+int interp_chunked(tc_interp* it, const double* theta, int n_theta, const double* x,
+                   int64_t n_draws, int n_gauss, unsigned flags, double* ngal, double* xi,
+                   int n_chunks) {
+  tc_table* t0 = it->tables[0];
+  const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;
+  const size_t ngal_cols = separate ? 2 : 1;
+  const size_t xi_cols = (size_t)(separate ? t0->plan.n_components : 1) * t0->n_r;
+  const size_t in_cols = (size_t)n_theta + it->n_dim;
+  int status = it->h_in.reserve((size_t)n_draws * in_cols * 8);
+  if (status == TC_OK) status = it->h_out.reserve((size_t)n_draws * (ngal_cols + xi_cols) * 8);
+  if (status != TC_OK) return status;
+  const int64_t chunk = ((n_draws + n_chunks - 1) / n_chunks + 63) / 64 * 64;
+  n_chunks = (int)((n_draws + chunk - 1) / chunk);
+  TC_CHECK(n_chunks <= 64, "internal: too many chunks");
+  int64_t tickets[64];
+  double* h_in = (double*)it->h_in.ptr;
+  double* h_out = (double*)it->h_out.ptr;
+  for (int k = 0; k < n_chunks && status == TC_OK; ++k) {
+    const int64_t begin = k * chunk, n = std::min(chunk, n_draws - begin);
+    double* in = h_in + begin * in_cols;          // [theta | x] of the chunk
+    memcpy(in, theta + begin * n_theta, (size_t)n * n_theta * 8);
+    memcpy(in + n * n_theta, x + begin * it->n_dim, (size_t)n * it->n_dim * 8);
+    double* out = h_out + begin * (ngal_cols + xi_cols);
+    status = interp_async(it, in, n_theta, in + n * n_theta, n, n_gauss, flags, nullptr, nullptr,
+                          out, out + n * ngal_cols, false, &tickets[k], true);
+    if (status != TC_OK) n_chunks = k;
+  }
+  for (int k = 0; k < n_chunks; ++k) {
+    const int64_t begin = k * chunk, n = std::min(chunk, n_draws - begin);
+    const int waited = tc_interp_wait(it, tickets[k]);
+    if (waited != TC_OK) {
+      (void)tc_interp_synchronize(it);
+      return waited;
+    }
+    if (status != TC_OK) continue;
+    const double* out = h_out + begin * (ngal_cols + xi_cols);
+    memcpy(ngal + begin * ngal_cols, out, (size_t)n * ngal_cols * 8);
+    parallel_copy(xi + begin * xi_cols, out + n * ngal_cols, (size_t)n * xi_cols * 8);
+  }
+  return status;
+}
+}  // namespace
+
 int tc_interp_predict_zheng07_batch(tc_interp* it, const double* theta, int n_theta,
                                     const double* x, int64_t n_draws, int n_gauss,
                                     unsigned flags, double* ngal, double* xi) {
@@ -741,6 +795,22 @@ int tc_interp_predict_zheng07_batch(tc_interp* it, const double* theta, int n_th
     memcpy(ngal, out, ngal_count * 8);
     memcpy(xi, out + ngal_count, xi_count * 8);
     return TC_OK;
+  }
+  {
+    // (option "sync_chunks" of the first table: 0 = 2 .. 8 chunks of about a megabyte of results
+    // from 2048 draws on, N >= 1 that many, -1 the serial path below)
+    const tc_table* t0 = it->tables[0];
+    int n_chunks = 0;
+    if (t0->tuning.sync_chunks >= 0 && t0->tuning.pipeline && it->n_lanes >= 2) {
+      if (t0->tuning.sync_chunks >= 1)
+        n_chunks = (int)std::min<int64_t>(t0->tuning.sync_chunks, (n_draws + 63) / 64);
+      else if (n_draws >= 2048)
+        n_chunks = (int)std::min<int64_t>(
+            std::min<int64_t>(8, n_draws / 1024),
+            std::max<int64_t>(2, (int64_t)((ngal_count + xi_count) * 8 >> 20)));
+    }
+    if (n_chunks > 0)
+      return interp_chunked(it, theta, n_theta, x, n_draws, n_gauss, flags, ngal, xi, n_chunks);
   }
   status = it->theta.reserve((size_t)n_draws * n_theta * 8, it->stream);
   if (status == TC_OK) status = it->x.reserve((size_t)n_draws * it->n_dim * 8, it->stream);
@@ -853,7 +923,7 @@ namespace {
 int interp_async(tc_interp* it, const double* theta, int n_theta, const double* x,
                  int64_t n_draws, int n_gauss, unsigned flags, const double* data,
                  const double* precision, double* ngal, double* second, bool chi2,
-                 int64_t* ticket_out) {
+                 int64_t* ticket_out, bool staging) {
   TC_CHECK(it != nullptr, "interp handle is NULL");
   tc_table* t0 = it->tables[0];
   int status = check_predict_args(t0, theta, n_theta, n_draws, n_gauss, flags);
@@ -867,7 +937,8 @@ int interp_async(tc_interp* it, const double* theta, int n_theta, const double* 
   const size_t ngal_count = (size_t)n_draws * (separate ? 2 : 1);
   const size_t second_count = chi2 ? (size_t)n_draws : (size_t)n_draws * n_comp * t0->n_r;
   const size_t theta_count = (size_t)n_draws * n_theta, x_count = (size_t)n_draws * it->n_dim;
-  TC_CHECK(n_draws == 0 ||
+  // (staging: the library's own page-locked staging areas -- the chunks of a synchronous call)
+  TC_CHECK(n_draws == 0 || staging ||
                (is_pinned(theta, theta_count * 8) && is_pinned(x, x_count * 8) &&
                 is_pinned(ngal, ngal_count * 8) && is_pinned(second, second_count * 8)),
            "asynchronous calls need page-locked buffers (tc_host_alloc / tc_host_register)");
@@ -919,7 +990,7 @@ int tc_interp_predict_zheng07_batch_async(tc_interp* it, const double* theta, in
                                           unsigned flags, double* ngal, double* xi,
                                           int64_t* ticket) {
   return interp_async(it, theta, n_theta, x, n_draws, n_gauss, flags, nullptr, nullptr, ngal, xi,
-                      false, ticket);
+                      false, ticket, false);
 }
 
 int tc_interp_chi2_zheng07_batch_async(tc_interp* it, const double* theta, int n_theta,
@@ -928,7 +999,7 @@ int tc_interp_chi2_zheng07_batch_async(tc_interp* it, const double* theta, int n
                                        const double* precision, double* ngal, double* chi2,
                                        int64_t* ticket) {
   return interp_async(it, theta, n_theta, x, n_draws, n_gauss, flags, data, precision, ngal,
-                      chi2, true, ticket);
+                      chi2, true, ticket, false);
 }
 
 int tc_interp_wait(tc_interp* it, int64_t ticket) {

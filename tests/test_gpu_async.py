@@ -732,3 +732,39 @@ def test_synchronous_calls_in_chunks(case):
     ref = parts(halotab.predict_batch(theta[:100], **kwargs), 100)
     for part in (0, 1):
         assert_rel(few[part], ref[part], loose, floor=1e-13)
+
+
+@pytest.mark.parametrize('mode', ['auto', 'cross'])
+def test_synchronous_interpolator_calls_in_chunks(mode):
+    """Interpolator.predict_batch on host arrays in chunks (interp.cpp: interp_chunked): the
+    oracle on draws of every chunk, any number of chunks against one piece to rounding, ragged
+    sizes, separated by galaxy type."""
+    from tabcorr_amd import Interpolator, synthetic, _lib
+    from oracle import tabcorr_oracle as oracle
+    lib = _lib.load()
+    tables, keys, points = synthetic.synthetic_interpolator((4, 4), 12, 1, (7, ), mode, seed=3)
+    interp = Interpolator([make_tabcorr(t) for t in tables],
+                          {k: points[:, d] for d, k in enumerate(keys)})
+    n = 5000 + 13
+    theta = synthetic.zheng07_draws(n, seed=4)
+    rng = np.random.default_rng(5)
+    x = np.stack([rng.uniform(xp[0], xp[-1], size=n) for xp in interp.xp], axis=-1)
+    device = interp.to_device()
+    results = {}
+    for chunks in (0, 1, 3, 7, -1):
+        for table in device.tables:
+            _lib.check(lib.tc_table_set_option(table.handle, b'sync_chunks', chunks))
+        results[chunks] = interp.predict_batch(theta, x)
+    index = np.unique(np.r_[0:2, 1700:1703, 2500:2502, n - 2:n])
+    setup = oracle.interpolator_setup(tables, points)
+    expect = oracle.interpolator_predict_zheng07_batch(tables, setup, theta[index], x[index])
+    for chunks, (ngal, xi) in results.items():
+        assert_rel(ngal[index], expect[0], RTOL, 'chunks %d' % chunks)
+        assert_rel(xi[index], expect[1], RTOL, 'chunks %d' % chunks, floor=1e-12)
+        assert_rel(ngal, results[1][0], 1e-12, 'chunks %d vs one piece' % chunks)
+        assert_rel(xi, results[1][1], 1e-11, 'chunks %d vs one piece' % chunks, floor=1e-12)
+    for table in device.tables:
+        _lib.check(lib.tc_table_set_option(table.handle, b'sync_chunks', 0))
+    ngal_s, xi_s = interp.predict_batch(theta[:3000], x[:3000], separate_gal_type=True)
+    total = sum(xi_s[key] for key in xi_s)
+    assert_rel(total, results[1][1][:3000], 1e-10, floor=1e-12)
