@@ -428,12 +428,14 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
 
     def measure(name, tag, what, timer_handle, launch, synchronize, host_call, n_draws, flop,
                 peak, kernel, dtype, cpu, parity, fused_kernel=None, bound='mfma',
-                set_options=None):
+                set_options=None, host_call_kept=None):
         """`kernel`: the dominant kernel of the three-kernel form; `fused_kernel`: the one-launch
         kernel the library may choose for the pipelined calls of this configuration (its name
         as rocprofv3 prints it).  The record's `kernel` is the one that ran in the timed
         region; the serialised three-kernel figures sit under `three_kernel_path`.
-        `set_options(name, value)`: sets an option on every table handle of the workload."""
+        `set_options(name, value)`: sets an option on every table handle of the workload.
+        `host_call` returns fresh NumPy arrays, `host_call_kept` writes into arrays the caller
+        keeps (out=): a fresh 61 MB array is 4 ms of page faults per call."""
         if set_options is None:
             def set_options(key, value):
                 _lib.check(lib.tc_table_set_option(timer_handle, key, value))
@@ -508,6 +510,9 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
             mfma = pmc_counter(ran, 'SQ_VALU_MFMA_BUSY_CYCLES', tag)
             if mfma is not None:
                 record['valu']['matrix_pipe_busy'] = mfma / (1024 * device_seconds * 2.4e9)
+        if host_call_kept is not None:
+            record['host_to_host_kept_arrays_calls_per_sec'] = n_draws / time_calls(
+                host_call_kept, seconds=0.4, warm=3)
         record['bound'] = bound
         out[name] = record
 
@@ -760,13 +765,15 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
                 continue
             tab5 = make(table5, compute_dtype=dtype)
             h5 = tab5.to_device().handle
+            kept5 = np.zeros(10000), np.zeros((10000, n_r5))
             measure('configs[4] ' + dtype, tag, 'rp_pi table 19 x 40 (R=760), 100 x {cen,sat} '
                     'bins (G=200, P=20100), 10^4 draws, %s table and contraction' % dtype, h5,
                     lambda: _lib.check(lib.tc_predict_zheng07_batch_device(
                         h5, d_theta5, 5, 10000, N_GAUSS, 0, d_ngal5, d_xi5)),
                     lambda: _lib.check(lib.tc_table_synchronize(h5)),
                     lambda: tab5.predict_batch(theta), 10000, 10000 * pair_flops(200, n_r5),
-                    peak, kernel, 'f32' if dtype == 'float32' else 'f64', cpu5, parity5)
+                    peak, kernel, 'f32' if dtype == 'float32' else 'f64', cpu5, parity5,
+                    host_call_kept=lambda: tab5.predict_batch(theta, out=kept5))
             del tab5
     dev.free_all()
     return out

@@ -297,6 +297,38 @@ void bin_consts(int n_gauss, const double* mass, const double* weight, double lo
 
 }  // namespace sat
 
+namespace record {
+
+void group_record(bool central, const double* consts_i, const double* consts_j,
+                  const int32_t* thresholds, double sum_i, double sum_j, const double* log_m,
+                  const double* mass, int n_gauss, double* out) {
+  for (int i = 0; i < kStride; ++i) out[i] = 0.0;
+  int32_t head[6] = {0, 0, 0, 0, 0, 0};
+  const int n_steps = central ? series::kSteps : sat::kSteps;
+  for (int s = 0; s < n_steps; ++s) head[s] = thresholds[s];
+  std::memcpy(out, head, sizeof(head));
+  out[kCentre] = consts_i[0];
+  if (central) {
+    out[kLow] = log_m[0];
+    out[kHigh] = log_m[n_gauss - 1];
+    out[kFirstSum] = sum_i;
+    out[kFirstSum + 1] = sum_j;
+  } else {
+    out[kLow] = mass[0] > mass[n_gauss - 1] ? mass[0] : mass[n_gauss - 1];
+    out[kFirstSum] = consts_i[3];
+    out[kFirstSum + 1] = consts_j[3];
+  }
+  const int first = central ? series::kFirst : sat::kFirst;
+  const int n_terms = central ? series::kMaxTerms : sat::kMaxTerms;
+  for (int n = 0; n < n_terms; ++n) {
+    double* block = out + kHead + kBlock * (n / 4);
+    block[n % 4] = consts_i[first + n];
+    block[4 + n % 4] = consts_j[first + n];
+  }
+}
+
+}  // namespace record
+
 }  // namespace series
 
 void find_node_groups(int n_bins, int n_central, const double* log_min, const double* log_max,

@@ -197,6 +197,7 @@ struct Quadrature {
   void* sat_series_thr = nullptr;
   void* group_sat_series = nullptr;
   void* group_sat_series_thr = nullptr;
+  void* group_records = nullptr;       // series.h, namespace record (groups of <= 2 members)
 };
 
 // A schedule of the quadratic-form kernel on the device (hostmath.h: QuadSchedule).

@@ -38,6 +38,9 @@ struct GroupArgs {
   // (n_bins, sat::kThresholds) int32
   const double* sat_series;
   const int32_t* sat_series_thr;
+  // everything a group's expansions read in one record per group (series.h, namespace record:
+  // (n_groups, record::kStride) doubles); NULL: a group with more than two members exists
+  const double* records;
 };
 
 struct OccArgs {

@@ -610,6 +610,116 @@ __device__ __forceinline__ void occ_group_zheng07(const double* table, const fm:
   }
 }
 
+// A group of one or two undecorated bins from its record (series.h, namespace record) for the
+// kernels that defer what no expansion serves: the head and the passes every eligible draw
+// takes arrive with ONE round trip of scalar loads whose addresses depend on `group` alone; the
+// arithmetic per member is that of series::central_sum_pair / sat::binomial_sum_pair -- same bits.
+// emit(member index, 0, occupation) once per member; a lane that is neither on a plateau nor
+// eligible is handed to defer(group) and emits 0.
+template <typename Emit, typename Defer>
+__device__ __forceinline__ void occ_record_zheng07(const double* table, const fm::Consts& kc,
+                                                   int group, sc_f64 rec, int m_begin, int m_end,
+                                                   bool central, const DrawParams& d,
+                                                   Emit&& emit, Defer defer) {
+  namespace record = series::record;
+  const record::f64x8_t head = record::load_eight(rec);
+  const record::f64x8_t b0 = record::load_eight(rec + record::kHead);
+  const record::f64x8_t b1 = record::load_eight(rec + record::kHead + record::kBlock);
+  const series::Thresholds limit = record::thresholds_of(head);
+  const bool two = m_end - m_begin > 1;
+  double out_i = 0.0, out_j = 0.0;
+  if (central) {
+    if (!d.any_bad) {
+      // (the plateaus of occ_group_zheng07: every node of every lane at 1, or at 0)
+      const double z_a = (head.v[record::kLow] - d.log_m_min) * d.inv_sigma;
+      const double z_b = (head.v[record::kHigh] - d.log_m_min) * d.inv_sigma;
+      const double z_lo = z_a < z_b ? z_a : z_b, z_hi = z_a < z_b ? z_b : z_a;
+      const bool ones = __builtin_amdgcn_ballot_w64(!(z_lo >= 6.0)) == 0;
+      if (ones || __builtin_amdgcn_ballot_w64(!(z_hi <= -6.0)) == 0) {
+        emit(m_begin, 0, ones ? head.v[record::kFirstSum] : 0.0);
+        if (two) emit(m_begin + 1, 0, ones ? head.v[record::kFirstSum + 1] : 0.0);
+        return;
+      }
+    }
+    if (d.inv_sigma_hi < limit.v[series::kSteps - 1]) {
+      const int n_blocks = series::passes<series::kSteps>(limit, d.inv_sigma_hi, 2);
+      const double inv_sigma = d.inv_sigma;
+      double g0, z0;
+      const double e = fm::erf_gauss_fast(
+          table, kc, (head.v[record::kCentre] - d.log_m_min) * inv_sigma, &g0, &z0);
+      const double a = 2.0 * z0 * inv_sigma, b = -2.0 * inv_sigma * inv_sigma;
+      double p_prev = 0.0, p = inv_sigma, nb = -b, sum_i = 0.0, sum_j = 0.0;
+      auto pass = [&](const record::f64x8_t& m) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          sum_i = fma(p, m.v[k], sum_i);
+          sum_j = fma(p, m.v[4 + k], sum_j);
+          nb += b;
+          const double next = fma(a, p, nb * p_prev);
+          p_prev = p;
+          p = next;
+        }
+      };
+      pass(b0);
+      pass(b1);
+      sc_f64 further = rec + record::kHead + 2 * record::kBlock;
+#pragma unroll 1
+      for (int block = 2; block < n_blocks; ++block) {
+        pass(record::load_eight(further));
+        further += record::kBlock;
+      }
+      const double m0_i = head.v[record::kFirstSum], m0_j = head.v[record::kFirstSum + 1];
+      out_i = fma(0.5, fma(g0, sum_i, m0_i * e), 0.5 * m0_i);
+      out_j = fma(0.5, fma(g0, sum_j, m0_j * e), 0.5 * m0_j);
+    } else {
+      defer(group);
+    }
+  } else {
+    const record::f64x8_t b2 = record::load_eight(rec + record::kHead + 2 * record::kBlock);
+    const double m0 = d.m0, largest = head.v[record::kLow];
+    if (!d.any_bad && __builtin_amdgcn_ballot_w64(largest > m0) == 0) {
+      emit(m_begin, 0, 0.0);
+      if (two) emit(m_begin + 1, 0, 0.0);
+      return;
+    }
+    if (d.m0_hi < limit.v[series::sat::kSteps - 1]) {
+      const int n_blocks = series::passes<series::sat::kSteps>(limit, d.m0_hi, 3);
+      const double centre = head.v[record::kCentre], alpha = d.alpha;
+      const double base = centre - m0;
+      const double eps = centre * series::sat::reciprocal(base);
+      const double power = fm::exp2_fast(
+          table, kc, alpha * fm::log2_fast_offset(table, kc, base, d.log2_m1));
+      double c = 1.0, g = eps * alpha;
+      double sum_i = head.v[record::kFirstSum], sum_j = head.v[record::kFirstSum + 1];
+      auto pass = [&](const record::f64x8_t& m) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          c *= g;
+          g -= eps;
+          sum_i = fma(c, m.v[k], sum_i);
+          sum_j = fma(c, m.v[4 + k], sum_j);
+        }
+      };
+      pass(b0);
+      pass(b1);
+      pass(b2);
+      sc_f64 further = rec + record::kHead + 3 * record::kBlock;
+#pragma unroll 1
+      for (int block = 3; block < n_blocks; ++block) {
+        pass(record::load_eight(further));
+        further += record::kBlock;
+      }
+      out_i = sum_i * power * d.sat_scale;
+      out_j = sum_j * power * d.sat_scale;
+    } else if (!(d.bad == 0 && !(largest > m0))) {
+      // (at or below the draw's M0 every node gives 0, as the node loop would)
+      defer(group);
+    }
+  }
+  emit(m_begin, 0, out_i);
+  if (two) emit(m_begin + 1, 0, out_j);
+}
+
 // The same for the 32-draw workgroups (lane = (draw, half of the nodes), occ_bin_zheng07_halves):
 // five node values per lane, every member's weights by vector loads -- those of a pair of
 // members requested BEFORE the nodes are evaluated, so that they arrive under that arithmetic
@@ -2564,13 +2674,21 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
       const int m0 = group_begin[g0], m1 = group_begin[g1];
       const int n_steps = (m1 - m0 + 3) >> 2;        // 4-bin steps of phase B
       // A. mean occupations of the chunk's bins (row = bin in chunk, skewed columns)
-      for (int gr = g0 + wave; gr < g1; gr += W)
-        occ_group_zheng07<ASSEMBIAS, MODULATE>(
-            table, kc, gr, group_begin[gr], group_begin[gr + 1], gr < a.n_central_groups, gq,
-            a.split, dp, [&](int mi, int, double nbar) {
-              const int row = mi - m0;
-              buffer[row * kLanes + ((lane + 16 * (row & 3)) & 63)] = nbar;
-            }, mark);
+      auto emit = [&](int mi, int, double nbar) {
+        const int row = mi - m0;
+        buffer[row * kLanes + ((lane + 16 * (row & 3)) & 63)] = nbar;
+      };
+      for (int gr = g0 + wave; gr < g1; gr += W) {
+        if constexpr (kDeferrable)          // (launch.hip: only tables that have the records)
+          occ_record_zheng07(table, kc, gr,
+                             (sc_f64)a.group.records + (int64_t)gr * series::record::kStride,
+                             group_begin[gr], group_begin[gr + 1], gr < a.n_central_groups, dp,
+                             emit, mark);
+        else
+          occ_group_zheng07<ASSEMBIAS, MODULATE>(table, kc, gr, group_begin[gr],
+                                                 group_begin[gr + 1], gr < a.n_central_groups,
+                                                 gq, a.split, dp, emit, mark);
+      }
       // (the rows that fill the last step: zero, whatever an earlier chunk left there)
       for (int row = m1 - m0 + wave; row < 4 * n_steps; row += W) buffer[row * kLanes + lane] = 0.0;
       // B. this wave's tiles over every bin of the chunk; the first A operands are requested

@@ -110,7 +110,29 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
                   tc::series::kThresholds,
                   g_series_thr.data() + (size_t)mi * tc::series::kThresholds);
     }
-    status = upload(g_log_m, &q.group_log_m);
+    if (groups.largest <= 2) {
+      // one record per group (series.h, namespace record)
+      namespace rec = tc::series::record;
+      std::vector<double> records((size_t)groups.n_groups * rec::kStride);
+      for (int i = 0; i < groups.n_groups; ++i) {
+        const size_t mi = groups.begin[i];
+        const size_t mj = groups.begin[i + 1] - groups.begin[i] > 1 ? mi + 1 : mi;
+        const bool central = i < groups.n_central_groups;
+        rec::group_record(
+            central,
+            central ? g_series.data() + mi * tc::series::kStride
+                    : g_sat.data() + mi * tc::series::sat::kStride,
+            central ? g_series.data() + mj * tc::series::kStride
+                    : g_sat.data() + mj * tc::series::sat::kStride,
+            central ? g_series_thr.data() + mi * tc::series::kThresholds
+                    : g_sat_thr.data() + mi * tc::series::sat::kThresholds,
+            g_weight[(size_t)g * n_gauss + mi], g_weight[(size_t)g * n_gauss + mj],
+            g_log_m.data() + (size_t)i * n_gauss, g_m.data() + (size_t)i * n_gauss, n_gauss,
+            records.data() + (size_t)i * rec::kStride);
+      }
+      status = upload(records, &q.group_records);
+    }
+    if (status == TC_OK) status = upload(g_log_m, &q.group_log_m);
     if (status == TC_OK) status = upload(g_m, &q.group_m);
     if (status == TC_OK) status = upload(g_weight, &q.group_weight);
     if (status == TC_OK) status = upload(g_series, &q.group_series);
@@ -154,6 +176,7 @@ tc::GroupArgs group_args(const tc_table* t, const Quadrature& q) {
   ga.series_thr = (const int32_t*)q.group_series_thr;
   ga.sat_series = (series_mask(t) & 2) ? (const double*)q.group_sat_series : nullptr;
   ga.sat_series_thr = (const int32_t*)q.group_sat_series_thr;
+  ga.records = (const double*)q.group_records;
   return ga;
 }
 
@@ -1601,6 +1624,7 @@ int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs
                      cf.d_bin_operand != nullptr &&
                      !(flags & (TC_FLAG_ASSEMBIAS | TC_FLAG_MODULATE_WITH_CENOCC)) &&
                      (series_mask(t0) & 1) != 0 && q->group_sat_series != nullptr &&
+                     q->group_records != nullptr &&
                      tc::cross_buffer_doubles(cf.rows) >= cf.rows * 64 + 2048;
   CrossLds layout = cross_lds_layout(cf, t0->n_r, separate, defer ? ca.n_groups : 0);
   if (defer && layout.bytes > kMaxLdsBytes / 2 - 256) {

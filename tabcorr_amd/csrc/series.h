@@ -327,5 +327,71 @@ TC_HD void binomial_sum_pair(Ptr consts_i, Ptr consts_j, double eps, double alph
 
 }  // namespace sat
 
+// ---- one record per group of one or two bins (round 5) ---------------------------------------
+//
+// The loops above find a group's constants through a dozen arrays: per group of the reference's
+// AbacusSummit tables a wave issued ~20 scalar loads on 5 + (number of passes) dependent levels
+// (first member -> thresholds -> centre -> mu_0 -> the blocks of moments, each waited for where
+// it is used) against ~250 vector instructions, from half a megabyte of constants that a 16 KB
+// scalar cache does not hold: the occupations of predict_cross_fused_kernel were latency, not
+// arithmetic.  For tables whose groups have at most two members (secondary-percentile halves,
+// scripts/tabulate_snapshot.py:193, or no cut at all) everything a group's expansion reads sits in
+// ONE record of kStride doubles at records + group x kStride, 64-byte aligned:
+//
+//   [0, 3)  int32 x 6: the group's thresholds (series.h / namespace sat)
+//   [3]     centrals log10 M of the first node, satellites the larger of the end nodes' masses
+//   [4]     centre (log10) / Mc          [5], [6]  m_0 / mu_0 of the two members
+//   [7]     centrals log10 M of the last node
+//   [8 + 8 p, 16 + 8 p)  pass p: four moments of the first member, four of the second
+//                        (a single member: its own twice)
+//
+// so that the head and the passes every eligible draw takes (two for centrals, three for
+// satellites) are requested together, at addresses that depend on the group's number alone.
+namespace record {
+constexpr int kHead = 8;
+constexpr int kBlock = 8;
+constexpr int kStride = kHead + kBlock * (sat::kMaxTerms / 4);      // 72 doubles: nine lines
+constexpr int kLow = 3, kCentre = 4, kFirstSum = 5, kHigh = 7;
+
+struct f64x8_t {
+  double v[8];
+};
+
+// Eight consecutive doubles (64-byte aligned: one 64-byte scalar load on the device).
+template <typename Ptr>
+TC_HD f64x8_t load_eight(Ptr p) {
+  f64x8_t m;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef double __attribute__((ext_vector_type(8))) f64x8v;
+  typedef const __attribute__((address_space(4))) f64x8v* sc_f64x8v;
+  const f64x8v value = *(sc_f64x8v)p;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) m.v[i] = value[i];
+#else
+  for (int i = 0; i < 8; ++i) m.v[i] = p[i];
+#endif
+  return m;
+}
+
+// The thresholds out of a record's head.
+TC_HD Thresholds thresholds_of(const f64x8_t& head) {
+  Thresholds t;
+  for (int i = 0; i < 3; ++i) {
+    const unsigned long long bits = fm::bits_of(head.v[i]);
+    t.v[2 * i] = (int)(unsigned)(bits & 0xffffffffull);
+    t.v[2 * i + 1] = (int)(unsigned)(bits >> 32);
+  }
+  t.v[6] = t.v[7] = 0;
+  return t;
+}
+
+// A group's record from its members' per-bin constants (series::bin_consts / sat::bin_consts of
+// the first and the second member -- the same pointer twice for a single member --, their
+// thresholds = the first member's, m_0 of the centrals = the members' sums of weights).
+void group_record(bool central, const double* consts_i, const double* consts_j,
+                  const int32_t* thresholds, double sum_i, double sum_j, const double* log_m,
+                  const double* mass, int n_gauss, double* out);
+}  // namespace record
+
 }  // namespace series
 }  // namespace tc

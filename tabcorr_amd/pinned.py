@@ -206,11 +206,9 @@ def stage_inputs(arrays):
     return staged, True
 
 
-def stage_outputs(shapes, out):
-    """Output arrays: the caller's (``out``, which must be pinned float64
-    C-contiguous arrays of the right shapes) or pooled pinned blocks."""
-    if out is None:
-        return [POOL.take(shape) for shape in shapes], True
+def caller_outputs(shapes, out):
+    """The caller's ``out`` arrays (C-contiguous float64 of the right sizes,
+    pinned or not), reshaped to ``shapes``."""
     out = list(out)
     if len(out) != len(shapes):
         raise ValueError('out must hold {} arrays.'.format(len(shapes)))
@@ -221,7 +219,17 @@ def stage_outputs(shapes, out):
             raise ValueError(
                 'out arrays must be C-contiguous float64 with {} elements.'
                 .format(int(np.prod(shape, dtype=np.int64))))
-        if not is_pinned(array):
-            raise ValueError('out arrays must be page-locked: allocate them '
-                             'with tabcorr_amd.pinned_empty.')
-    return [a.reshape(shape) for a, shape in zip(out, shapes)], False
+    return [a.reshape(shape) for a, shape in zip(out, shapes)]
+
+
+def stage_outputs(shapes, out):
+    """Output arrays of an asynchronous call: the caller's (``out``, which
+    must be pinned float64 C-contiguous arrays of the right shapes) or pooled
+    pinned blocks."""
+    if out is None:
+        return [POOL.take(shape) for shape in shapes], True
+    arrays = caller_outputs(shapes, out)
+    if not all(is_pinned(array) for array in arrays):
+        raise ValueError('out arrays must be page-locked: allocate them '
+                         'with tabcorr_amd.pinned_empty.')
+    return arrays, False

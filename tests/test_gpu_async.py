@@ -59,6 +59,16 @@ def test_async_matches_golden_and_sync():
     xi[:] = 0
     again = halotab.predict_batch(theta, out=(ngal, xi))
     assert_rel(again[1], data['xi'], RTOL)
+    # ... and into ordinary arrays kept by the caller
+    kept = np.zeros(n), np.zeros((n, n_r))
+    into_kept = halotab.predict_batch(theta, out=kept)
+    assert np.shares_memory(into_kept[1], kept[1])
+    assert np.array_equal(kept[1], halotab.predict_batch(theta)[1])
+    assert np.array_equal(kept[0], halotab.predict_batch(theta)[0])
+    with pytest.raises(ValueError, match='elements'):
+        halotab.predict_batch(theta, out=(np.zeros(n), np.zeros((n, n_r + 1))))
+    with pytest.raises(ValueError, match='float64'):
+        halotab.predict_batch(theta, out=(np.zeros(n), np.zeros((n, n_r), dtype=np.float32)))
     # separated by galaxy type
     ngal2, xi3 = pinned_empty((n, 2)), pinned_empty((n, 3, n_r))
     n_sep, x_sep = halotab.predict_batch_async(theta, separate_gal_type=True,
