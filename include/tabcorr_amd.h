@@ -354,6 +354,14 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 them with its own weights (Zheng07 family, n_gauss_prim = 10).  No effect on
  *                 tables without such bins.  0: every bin by itself (same occupations per bin
  *                 to the last bit; sums over bins may differ in the last bits).
+ *   "cross_wide_min_draws"  default 5120.  Mode cross (tpcf_matrix with one column per halo
+ *                 bin), tables or interpolators of up to 16 result rows whose node groups have
+ *                 at most two members: undecorated batches of this many draws take the one-launch
+ *                 form that multiplies on the matrix pipe and reads a group's expansion
+ *                 constants from one record (csrc/series.h, namespace record) -- 52.4 against
+ *                 58.8 us per 10^4 draws of the reference's AbacusSummit table --, smaller ones
+ *                 the form that keeps the row sums in registers (faster below ~5000 draws);
+ *                 the two differ in the last bits.  0: always the register form.
  *   "single_draw" 1 (default): an un-batched predict() goes through one launch.
  *   "resident"    1: un-batched calls (tc_predict_zheng07_batch with one draw; total
  *                 correlation function, Zheng07 family) are served by ONE resident launch:

@@ -301,11 +301,14 @@ namespace record {
 
 void group_record(bool central, const double* consts_i, const double* consts_j,
                   const int32_t* thresholds, double sum_i, double sum_j, const double* log_m,
-                  const double* mass, int n_gauss, double* out) {
+                  const double* mass, int n_gauss, int first_member, bool two, double* out) {
   for (int i = 0; i < kStride; ++i) out[i] = 0.0;
   int32_t head[6] = {0, 0, 0, 0, 0, 0};
   const int n_steps = central ? series::kSteps : sat::kSteps;
   for (int s = 0; s < n_steps; ++s) head[s] = thresholds[s];
+  const int32_t members[2] = {2 * first_member + (two ? 1 : 0), 0};
+  if (central) head[5] = members[0];
+  else std::memcpy(out + kHigh, members, sizeof(members));
   std::memcpy(out, head, sizeof(head));
   out[kCentre] = consts_i[0];
   if (central) {

@@ -333,6 +333,7 @@ struct Tuning {
   // the batch), and a wave runs the node loop as well wherever one of its draws needs it.
   int series = -1;
   int cross_defer = 1;          // mode cross, one launch: deferred (group, draw) pairs (kernel_args.h)
+  int cross_wide_min_draws = 5120;   // launch.hip: choose_cross_fused (0: never the wide form)
   int cross_target = 160;       // mode cross: workgroups a launch should have at least
                                 // (several per tile of 64 draws below that)
   int resident_aperture = 1;    // resident ensemble kernel: the mailbox in device memory that
@@ -459,7 +460,7 @@ struct tc_table {
   // mode cross in float64: the matrix as (n_bins in library order, n_r), kept on the host for
   // the coefficient rows of predict_cross_fused_kernel (also those of interpolators)
   std::vector<double> cross_host;
-  tc::host::CrossFused cross_fused;
+  tc::host::CrossFused cross_fused, cross_fused_wide;
   bool quad = false;
   tc::QuadTiling quad_tiling;
   tc::host::QuadTable quad_by_type, quad_total;
@@ -639,7 +640,11 @@ int check_predict_args(const tc_table* t, const void* theta, int n_theta, int64_
 // Mode cross, one launch per batch (predict_cross_fused_kernel): the coefficient rows of one
 // table / K tables with common mass bins (cf->rows == 0 afterwards: not available), whether a
 // call takes that form, and the launch (`interp`: the spline part of the arguments, or NULL).
-int build_cross_fused(tc_table* const* tables, int n_tables, CrossFused* cf);
+int build_cross_fused(tc_table* const* tables, int n_tables, CrossFused* cf, bool wide = false);
+// ... and which of a handle's two sets a call takes: `narrow` (the instance the row count asks
+// for) or, for tables of up to 16 rows, `wide` (32 rows: the chunk form) -- built on first use.
+CrossFused* choose_cross_fused(tc_table* const* tables, int n_tables, CrossFused* narrow,
+                               CrossFused* wide, int64_t n_draws, unsigned flags, int* status);
 bool cross_fused_eligible(const tc_table* t0, const CrossFused& cf, int64_t n_draws, int n_gauss,
                           unsigned flags, bool alone);
 int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs* interp,

@@ -67,7 +67,7 @@ struct tc_interp {
   PinnedBuffer h_in, h_out;
   SingleWorkspace single_ws;                // un-batched calls
   std::map<std::pair<int, int>, std::unique_ptr<DeviceChunking>> chunkings;
-  CrossFused cross_fused;                   // mode cross: one launch per batch (launch.hip)
+  CrossFused cross_fused, cross_fused_wide; // mode cross: one launch per batch (launch.hip)
   // asynchronous host calls (tc_interp_*_async): tickets as for a table handle
   tc_table::Ticket tickets[tc_table::kMaxTickets];
   int64_t next_ticket = 0;
@@ -94,12 +94,12 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
 
   // mode cross: everything in one launch where it pays (predict_cross_fused_kernel)
   if (t0->mode == TC_MODE_CROSS && !t0->cross_host.empty() && t0->tuning.fused != 0) {
-    if (!it->cross_fused.tried) {
-      status = build_cross_fused(it->tables.data(), it->n_tables, &it->cross_fused);
-      if (status != TC_OK) return status;
-    }
+    const CrossFused& cf =
+        *choose_cross_fused(it->tables.data(), it->n_tables, &it->cross_fused,
+                            &it->cross_fused_wide, n_draws, flags, &status);
+    if (status != TC_OK) return status;
     const bool alone = it->force_lane >= 0 || !t0->tuning.pipeline;
-    if (cross_fused_eligible(t0, it->cross_fused, n_draws, n_gauss, flags, alone)) {
+    if (cross_fused_eligible(t0, cf, n_draws, n_gauss, flags, alone)) {
       tc::CrossFusedArgs ca{};
       ca.n_dim = it->n_dim;
       for (int d = 0; d < it->n_dim; ++d) {
@@ -111,7 +111,7 @@ int interp_predict_device(tc_interp* it, const double* theta_device, int n_theta
       ca.a = (const double*)it->d_a;
       ca.table_node = (const int32_t*)it->d_table_node;
       ca.x = x_device;
-      return run_cross_fused(t0, it->cross_fused, &ca, theta_device, n_theta, n_draws, flags,
+      return run_cross_fused(t0, cf, &ca, theta_device, n_theta, n_draws, flags,
                              ngal_device, xi_device, L.stream, &L.partial, &L.cross_counters);
     }
   }
@@ -528,6 +528,7 @@ int tc_interp_destroy(tc_interp* it) {
   for (DeviceBuffer* b : {&it->theta, &it->x, &it->out_ngal, &it->out_xi, &it->chi2_data})
     b->release();
   it->cross_fused.release();
+  it->cross_fused_wide.release();
   it->h_in.release();
   it->h_out.release();
   it->single_ws.buffer.release();

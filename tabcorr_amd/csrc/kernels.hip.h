@@ -618,15 +618,18 @@ __device__ __forceinline__ void occ_group_zheng07(const double* table, const fm:
 // eligible is handed to defer(group) and emits 0.
 template <typename Emit, typename Defer>
 __device__ __forceinline__ void occ_record_zheng07(const double* table, const fm::Consts& kc,
-                                                   int group, sc_f64 rec, int m_begin, int m_end,
-                                                   bool central, const DrawParams& d,
-                                                   Emit&& emit, Defer defer) {
+                                                   int group, sc_f64 rec, bool central,
+                                                   const DrawParams& d, Emit&& emit,
+                                                   Defer defer) {
   namespace record = series::record;
   const record::f64x8_t head = record::load_eight(rec);
   const record::f64x8_t b0 = record::load_eight(rec + record::kHead);
   const record::f64x8_t b1 = record::load_eight(rec + record::kHead + record::kBlock);
+  const record::f64x8_t b2 = record::load_eight(rec + record::kHead + 2 * record::kBlock);
   const series::Thresholds limit = record::thresholds_of(head);
-  const bool two = m_end - m_begin > 1;
+  const int members = record::members_of(central, limit, head);
+  const int m_begin = members >> 1;
+  const bool two = (members & 1) != 0;
   double out_i = 0.0, out_j = 0.0;
   if (central) {
     if (!d.any_bad) {
@@ -662,9 +665,10 @@ __device__ __forceinline__ void occ_record_zheng07(const double* table, const fm
       };
       pass(b0);
       pass(b1);
-      sc_f64 further = rec + record::kHead + 2 * record::kBlock;
+      if (n_blocks > 2) pass(b2);
+      sc_f64 further = rec + record::kHead + 3 * record::kBlock;
 #pragma unroll 1
-      for (int block = 2; block < n_blocks; ++block) {
+      for (int block = 3; block < n_blocks; ++block) {
         pass(record::load_eight(further));
         further += record::kBlock;
       }
@@ -675,7 +679,6 @@ __device__ __forceinline__ void occ_record_zheng07(const double* table, const fm
       defer(group);
     }
   } else {
-    const record::f64x8_t b2 = record::load_eight(rec + record::kHead + 2 * record::kBlock);
     const double m0 = d.m0, largest = head.v[record::kLow];
     if (!d.any_bad && __builtin_amdgcn_ballot_w64(largest > m0) == 0) {
       emit(m_begin, 0, 0.0);
@@ -2678,12 +2681,12 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
         const int row = mi - m0;
         buffer[row * kLanes + ((lane + 16 * (row & 3)) & 63)] = nbar;
       };
+      const bool central_chunk = chunk < a.n_central_chunks;     // (no chunk holds both types)
       for (int gr = g0 + wave; gr < g1; gr += W) {
         if constexpr (kDeferrable)          // (launch.hip: only tables that have the records)
           occ_record_zheng07(table, kc, gr,
                              (sc_f64)a.group.records + (int64_t)gr * series::record::kStride,
-                             group_begin[gr], group_begin[gr + 1], gr < a.n_central_groups, dp,
-                             emit, mark);
+                             central_chunk, dp, emit, mark);
         else
           occ_group_zheng07<ASSEMBIAS, MODULATE>(table, kc, gr, group_begin[gr],
                                                  group_begin[gr + 1], gr < a.n_central_groups,
@@ -2990,10 +2993,16 @@ __global__ __launch_bounds__(64 * kCrossWaves, DEFER ? 4 : 2) void predict_cross
       end = cen ? a.split_cen[split + 1] : a.split_sat[split + 1];
       stride = cen ? a.cen_waves : W - a.cen_waves;
     }
-    for (int gr = first; gr < end; gr += stride)
-      occ_group_zheng07<ASSEMBIAS, MODULATE, kDeferrable>(
-          table, kc, gr, group_begin[gr], group_begin[gr + 1], gr < a.n_central_groups, gq,
-          a.split, dp, emit, mark);
+    for (int gr = first; gr < end; gr += stride) {
+      if constexpr (kDeferrable)          // (launch.hip: only tables that have the records)
+        occ_record_zheng07(table, kc, gr,
+                           (sc_f64)a.group.records + (int64_t)gr * series::record::kStride,
+                           gr < a.n_central_groups, dp, emit, mark);
+      else
+        occ_group_zheng07<ASSEMBIAS, MODULATE, kDeferrable>(
+            table, kc, gr, group_begin[gr], group_begin[gr + 1], gr < a.n_central_groups, gq,
+            a.split, dp, emit, mark);
+    }
   }
 
   // ---- the waves' sums, kCrossChunk rows at a time, in wave order ----

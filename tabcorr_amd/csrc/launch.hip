@@ -128,7 +128,7 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
                     : g_sat_thr.data() + mi * tc::series::sat::kThresholds,
             g_weight[(size_t)g * n_gauss + mi], g_weight[(size_t)g * n_gauss + mj],
             g_log_m.data() + (size_t)i * n_gauss, g_m.data() + (size_t)i * n_gauss, n_gauss,
-            records.data() + (size_t)i * rec::kStride);
+            (int)mi, mj != mi, records.data() + (size_t)i * rec::kStride);
       }
       status = upload(records, &q.group_records);
     }
@@ -1406,7 +1406,28 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
 
 // ---- mode cross, one launch per batch -----------------------------------------------------
 
-int build_cross_fused(tc_table* const* tables, int n_tables, CrossFused* cf) {
+CrossFused* choose_cross_fused(tc_table* const* tables, int n_tables, CrossFused* narrow,
+                               CrossFused* wide, int64_t n_draws, unsigned flags, int* status) {
+  const tc_table* t0 = tables[0];
+  *status = TC_OK;
+  if (!narrow->tried) *status = build_cross_fused(tables, n_tables, narrow);
+  if (*status != TC_OK || narrow->rows == 0 || narrow->rows > tc::kCrossSmallRows) return narrow;
+  // Up to 16 rows.  Undecorated batches whose groups have records (series.h) take the chunk
+  // form with 32 rows -- products on the matrix pipe, expansions from the records, deferred
+  // pairs: 52.4 against 58.8 us per 10^4 draws of the reference's AbacusSummit table (13 rows)
+  // -- from cross_wide_min_draws draws on; below, the register form's several workgroups per
+  // tile win.
+  const bool undecorated =
+      !(flags & (TC_FLAG_ASSEMBIAS | TC_FLAG_MODULATE_WITH_CENOCC | TC_FLAG_LEAUTHAUD11));
+  if (!undecorated || t0->tuning.cross_defer == 0 || (series_mask(t0) & 1) == 0 ||
+      t0->node_groups.largest > 2 || t0->tuning.cross_wide_min_draws <= 0 ||
+      n_draws < t0->tuning.cross_wide_min_draws)
+    return narrow;
+  if (!wide->tried) *status = build_cross_fused(tables, n_tables, wide, true);
+  return *status == TC_OK && wide->rows > 0 ? wide : narrow;
+}
+
+int build_cross_fused(tc_table* const* tables, int n_tables, CrossFused* cf, bool wide) {
   cf->tried = true;
   cf->rows = 0;
   cf->n_tables = n_tables;
@@ -1426,7 +1447,7 @@ int build_cross_fused(tc_table* const* tables, int n_tables, CrossFused* cf) {
   }
   // (instances: 2, 4, 8, 16 rows per wave)
   const int rows = n_tables * per_table;
-  const int instance = rows <= 16 ? 16 : rows <= 32 ? 32 : rows <= 64 ? 64 : 128;
+  const int instance = rows <= 16 && !wide ? 16 : rows <= 32 ? 32 : rows <= 64 ? 64 : 128;
   const tc::NodeGroups& groups = t0->node_groups;
   if (groups.largest > tc::kCrossChunkBins) return TC_OK;
   // chunks: whole groups, at most kCrossChunkBins bins, centrals and satellites apart
@@ -1576,8 +1597,11 @@ int launch_cross_fused(int device, int rows, dim3 grid, dim3 block, int lds, hip
     TC_CASE(4, DE) TC_CASE(8, DE) TC_CASE(16, false)
 #undef TC_CASE
     case 2:     // up to 16 rows: the sums in every wave's registers
-      // (the instance with the deferred pairs exists in the source and is not shipped: 59.2
-      // against 58.9 us per 10^4 draws of the AbacusSummit table, two registers spilled)
+      // (the instance with the deferred pairs exists in the source and is not shipped: 16 row
+      // sums next to the expansions do not fit 128 registers -- 59.2 against 58.9 us per 10^4
+      // draws of the AbacusSummit table with the expansions of round 5's first half, 80 with the
+      // group records; undecorated batches go through the 32-row chunk form instead:
+      // choose_cross_fused)
       hipExtLaunchKernelGGL((tc::predict_cross_small_kernel<AB, MO, false>), grid, block, lds,
                             stream, k0, k1, 0, ca);
       break;

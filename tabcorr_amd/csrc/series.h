@@ -338,10 +338,12 @@ TC_HD void binomial_sum_pair(Ptr consts_i, Ptr consts_j, double eps, double alph
 // scripts/tabulate_snapshot.py:193, or no cut at all) everything a group's expansion reads sits in
 // ONE record of kStride doubles at records + group x kStride, 64-byte aligned:
 //
-//   [0, 3)  int32 x 6: the group's thresholds (series.h / namespace sat)
+//   [0, 3)  int32 x 6: the group's thresholds (series.h: five / namespace sat: six)
 //   [3]     centrals log10 M of the first node, satellites the larger of the end nodes' masses
 //   [4]     centre (log10) / Mc          [5], [6]  m_0 / mu_0 of the two members
 //   [7]     centrals log10 M of the last node
+//   2 x (index of the first member) + (1 if there is a second): centrals in the sixth int32 of
+//   [0, 3), satellites in the low half of [7]
 //   [8 + 8 p, 16 + 8 p)  pass p: four moments of the first member, four of the second
 //                        (a single member: its own twice)
 //
@@ -390,7 +392,12 @@ TC_HD Thresholds thresholds_of(const f64x8_t& head) {
 // thresholds = the first member's, m_0 of the centrals = the members' sums of weights).
 void group_record(bool central, const double* consts_i, const double* consts_j,
                   const int32_t* thresholds, double sum_i, double sum_j, const double* log_m,
-                  const double* mass, int n_gauss, double* out);
+                  const double* mass, int n_gauss, int first_member, bool two, double* out);
+
+// 2 x first member + second: see above.
+TC_HD int members_of(bool central, const Thresholds& limit, const f64x8_t& head) {
+  return central ? limit.v[5] : fm::low_word(head.v[kHigh]);
+}
 }  // namespace record
 
 }  // namespace series

@@ -256,6 +256,7 @@ int tc_table_destroy(tc_table* t) {
   t->quad_by_type.release();
   t->quad_total.release();
   t->cross_fused.release();
+  t->cross_fused_wide.release();
   for (DeviceBuffer* b : {&t->theta, &t->out_ngal, &t->out_xi, &t->occupation,
                           &t->trace, &t->wave_trace, &t->chi2_data})
     b->release();
@@ -379,14 +380,13 @@ int tc_predict_zheng07_batch_device(tc_table* t, const double* theta_device,
     const int64_t ldb = (n + 63) / 64 * 64;
     if (t->mode == TC_MODE_CROSS && !t->cross_host.empty() && t->tuning.fused != 0) {
       // mode cross: one launch per batch where it pays (launch.hip)
-      if (!t->cross_fused.tried) {
-        tc_table* self = t;
-        status = build_cross_fused(&self, 1, &t->cross_fused);
-        if (status != TC_OK) return status;
-      }
+      tc_table* self = t;
+      const CrossFused& cf = *choose_cross_fused(&self, 1, &t->cross_fused, &t->cross_fused_wide,
+                                                 n, flags, &status);
+      if (status != TC_OK) return status;
       const bool alone = t->force_lane >= 0 || !t->tuning.pipeline || t->n_lanes == 1;
-      if (cross_fused_eligible(t, t->cross_fused, n, n_gauss, flags, alone)) {
-        status = run_cross_fused(t, t->cross_fused, nullptr, theta_device + begin * n_theta,
+      if (cross_fused_eligible(t, cf, n, n_gauss, flags, alone)) {
+        status = run_cross_fused(t, cf, nullptr, theta_device + begin * n_theta,
                                  n_theta, n, flags, ngal_device + begin * (separate ? 2 : 1),
                                  xi_device + begin * n_comp * t->n_r, t->lanes[t->cur].stream,
                                  &t->lanes[t->cur].partial, &t->lanes[t->cur].cross_counters);
@@ -1244,6 +1244,11 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
   } else if (key == "cross_defer") {
     // developer A/B: 0 = predict_cross_fused_kernel runs every lane's node loop in place
     t->tuning.cross_defer = value != 0;
+  } else if (key == "cross_wide_min_draws") {
+    // mode cross, tables of up to 16 rows: undecorated batches of this many draws take the
+    // 32-row chunk form (launch.hip: choose_cross_fused); 0: never
+    TC_CHECK(value >= 0, "cross_wide_min_draws must not be negative");
+    t->tuning.cross_wide_min_draws = value;
   } else if (key == "cross_target") {
     // developer A/B: workgroups a launch of predict_cross_small_kernel should have at least
     TC_CHECK(value >= 1 && value <= 4096, "cross_target must be in [1, 4096]");

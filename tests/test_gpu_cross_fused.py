@@ -303,3 +303,52 @@ def test_cross_reference_fixture_interpolator():
     for key in ('centrals', 'satellites'):
         assert_rel(ngal[key], golden['table0_ngal_sep_' + key], RTOL)
         assert_rel(xi[key], golden['table0_xi_sep_' + key], RTOL, floor=1e-13)
+
+
+def test_tables_of_few_rows_in_the_chunk_form():
+    """Up to 16 rows: large undecorated batches leave the register form for the 32-row chunk
+    form (matrix pipe, group records, deferred pairs -- launch.hip: choose_cross_fused).  Forced
+    here for small batches: against the oracle, the register form, the reference's fixture, and
+    a draw's bits wherever it sits in the batch."""
+    from tabcorr_amd import Interpolator, synthetic
+    from oracle import tabcorr_oracle as oracle
+    from util import load_golden
+    table = synthetic.synthetic_table(40, 2, (13, ), 'cross', seed=7)
+    n = 700
+    theta = synthetic.zheng07_draws(n, seed=3)
+    theta[5, 1] = 1e-3              # (a step: no expansion serves it)
+    theta[6, 2] = 15.5              # (M0 above every bin)
+    halotab = make_tabcorr(table)
+    handle = halotab.to_device().handle
+    set_option(handle, 'series', 3)
+    force(handle, True)
+    narrow_launch = None
+    for separate in (False, True):
+        expect = oracle.predict_zheng07_batch(table, theta, separate_gal_type=separate)
+        set_option(handle, 'cross_wide_min_draws', 0)
+        narrow = halotab.predict_batch(theta, separate_gal_type=separate)
+        narrow_launch = narrow_launch if separate else last_launch(handle)
+        set_option(handle, 'cross_wide_min_draws', 1)
+        wide = halotab.predict_batch(theta, separate_gal_type=separate)
+        assert cross_ran(handle, n)
+        assert separate or last_launch(handle)[3] != narrow_launch[3]
+        compare(wide, expect, separate, RTOL, 'vs oracle')
+        compare(wide, narrow, separate, 1e-12, 'vs the register form')
+    order = np.random.default_rng(1).permutation(n)
+    ngal, xi = halotab.predict_batch(theta)
+    ngal_p, xi_p = halotab.predict_batch(theta[order][:333])
+    assert np.array_equal(xi_p, xi[order][:333]) and np.array_equal(ngal_p, ngal[order][:333])
+    # decorated calls keep the register form
+    strengths = np.random.default_rng(2).uniform(-1, 1, (n, 2))
+    halotab.predict_batch(np.hstack([theta, strengths]), assembias=True)
+    assert last_launch(handle)[3] == narrow_launch[3]
+    # the reference's AbacusSummit table (13 r values)
+    interp = Interpolator.read(os.path.join(REPO, 'tests', 'golden', 'ds_efficient.hdf5'))
+    golden = load_golden('ds_efficient')
+    first = interp.tabcorr_list[0]
+    handle0 = first.to_device().handle
+    force(handle0, True)
+    set_option(handle0, 'cross_wide_min_draws', 1)
+    ngal, xi = first.predict_batch(golden['theta'])
+    assert_rel(ngal, golden['table0_ngal'], RTOL)
+    assert_rel(xi, golden['table0_xi'], RTOL)
