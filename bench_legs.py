@@ -646,7 +646,7 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
                     cpu_rate(lambda i: oracle.interpolator_predict(
                         ds_tables, setup, oracle.Zheng07(theta_ds[i % 10000]),
                         x_ds[i % 10000])), parity_ds4,
-                    fused_kernel='tc::predict_cross_fused_kernel<8, false, false>',
+                    fused_kernel='tc::predict_cross_fused_kernel<8, false, false, true>',
                     bound='valu')
             del idev
         if wanted('ds1'):
@@ -670,7 +670,7 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
                     'tc::occ_zheng07_kernel<10, false, false, true>', 'f64',
                     cpu_rate(lambda i: oracle.predict_zheng07(
                         ds_tables[0], theta_ds[i % 10000], cache=cache_ds)), parity_ds1,
-                    fused_kernel='tc::predict_cross_small_kernel<false, false>', bound='valu')
+                    fused_kernel='tc::predict_cross_fused_kernel<4, false, false, true>', bound='valu')
         del interp
 
     # the reference's example table (docs/examples/bolplanck_wp.hdf5: G = 60, 19 r values)

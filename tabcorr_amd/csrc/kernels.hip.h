@@ -616,12 +616,12 @@ __device__ __forceinline__ void occ_group_zheng07(const double* table, const fm:
 // arithmetic per member is that of series::central_sum_pair / sat::binomial_sum_pair -- same bits.
 // emit(member index, 0, occupation) once per member; a lane that is neither on a plateau nor
 // eligible is handed to defer(group) and emits 0.
-template <typename Emit, typename Defer>
+template <bool CENTRAL, typename Emit, typename Defer>
 __device__ __forceinline__ void occ_record_zheng07(const double* table, const fm::Consts& kc,
-                                                   int group, sc_f64 rec, bool central,
-                                                   const DrawParams& d, Emit&& emit,
-                                                   Defer defer) {
+                                                   int group, sc_f64 rec, const DrawParams& d,
+                                                   Emit&& emit, Defer defer) {
   namespace record = series::record;
+  constexpr bool central = CENTRAL;
   const record::f64x8_t head = record::load_eight(rec);
   const record::f64x8_t b0 = record::load_eight(rec + record::kHead);
   const record::f64x8_t b1 = record::load_eight(rec + record::kHead + record::kBlock);
@@ -2681,13 +2681,23 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
         const int row = mi - m0;
         buffer[row * kLanes + ((lane + 16 * (row & 3)) & 63)] = nbar;
       };
-      const bool central_chunk = chunk < a.n_central_chunks;     // (no chunk holds both types)
-      for (int gr = g0 + wave; gr < g1; gr += W) {
-        if constexpr (kDeferrable)          // (launch.hip: only tables that have the records)
-          occ_record_zheng07(table, kc, gr,
-                             (sc_f64)a.group.records + (int64_t)gr * series::record::kStride,
-                             central_chunk, dp, emit, mark);
-        else
+      if constexpr (kDeferrable) {
+        // (launch.hip: only tables that have the records; no chunk holds both types: a loop
+        // per type)
+        sc_f64 records = (sc_f64)a.group.records;
+        if (chunk < a.n_central_chunks) {
+          for (int gr = g0 + wave; gr < g1; gr += W)
+            occ_record_zheng07<true>(table, kc, gr,
+                                     records + (int64_t)gr * series::record::kStride, dp, emit,
+                                     mark);
+        } else {
+          for (int gr = g0 + wave; gr < g1; gr += W)
+            occ_record_zheng07<false>(table, kc, gr,
+                                      records + (int64_t)gr * series::record::kStride, dp, emit,
+                                      mark);
+        }
+      } else {
+        for (int gr = g0 + wave; gr < g1; gr += W)
           occ_group_zheng07<ASSEMBIAS, MODULATE>(table, kc, gr, group_begin[gr],
                                                  group_begin[gr + 1], gr < a.n_central_groups,
                                                  gq, a.split, dp, emit, mark);
@@ -2994,11 +3004,11 @@ __global__ __launch_bounds__(64 * kCrossWaves, DEFER ? 4 : 2) void predict_cross
       stride = cen ? a.cen_waves : W - a.cen_waves;
     }
     for (int gr = first; gr < end; gr += stride) {
-      if constexpr (kDeferrable)          // (launch.hip: only tables that have the records)
-        occ_record_zheng07(table, kc, gr,
-                           (sc_f64)a.group.records + (int64_t)gr * series::record::kStride,
-                           gr < a.n_central_groups, dp, emit, mark);
-      else
+      if constexpr (kDeferrable) {        // (launch.hip: only tables that have the records)
+        sc_f64 rec = (sc_f64)a.group.records + (int64_t)gr * series::record::kStride;
+        if (gr < a.n_central_groups) occ_record_zheng07<true>(table, kc, gr, rec, dp, emit, mark);
+        else occ_record_zheng07<false>(table, kc, gr, rec, dp, emit, mark);
+      } else
         occ_group_zheng07<ASSEMBIAS, MODULATE, kDeferrable>(
             table, kc, gr, group_begin[gr], group_begin[gr + 1], gr < a.n_central_groups, gq,
             a.split, dp, emit, mark);
