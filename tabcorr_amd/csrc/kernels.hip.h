@@ -622,10 +622,8 @@ __device__ __forceinline__ void occ_record_zheng07(const double* table, const fm
                                                    Emit&& emit, Defer defer) {
   namespace record = series::record;
   constexpr bool central = CENTRAL;
-  const record::f64x8_t head = record::load_eight(rec);
-  const record::f64x8_t b0 = record::load_eight(rec + record::kHead);
-  const record::f64x8_t b1 = record::load_eight(rec + record::kHead + record::kBlock);
-  const record::f64x8_t b2 = record::load_eight(rec + record::kHead + 2 * record::kBlock);
+  record::f64x8_t head, b0, b1, b2;
+  record::load_record(rec, head, b0, b1, b2);
   const series::Thresholds limit = record::thresholds_of(head);
   const int members = record::members_of(central, limit, head);
   const int m_begin = members >> 1;
@@ -645,7 +643,6 @@ __device__ __forceinline__ void occ_record_zheng07(const double* table, const fm
       }
     }
     if (d.inv_sigma_hi < limit.v[series::kSteps - 1]) {
-      const int n_blocks = series::passes<series::kSteps>(limit, d.inv_sigma_hi, 2);
       const double inv_sigma = d.inv_sigma;
       double g0, z0;
       const double e = fm::erf_gauss_fast(
@@ -665,12 +662,16 @@ __device__ __forceinline__ void occ_record_zheng07(const double* table, const fm
       };
       pass(b0);
       pass(b1);
-      if (n_blocks > 2) pass(b2);
-      sc_f64 further = rec + record::kHead + 3 * record::kBlock;
+      // (most waves need no more: a lane's count of passes only where one of them does)
+      if (__builtin_amdgcn_ballot_w64(d.inv_sigma_hi >= limit.v[0]) != 0) {
+        const int n_blocks = series::passes<series::kSteps>(limit, d.inv_sigma_hi, 2);
+        if (n_blocks > 2) pass(b2);
+        sc_f64 further = rec + record::kHead + 3 * record::kBlock;
 #pragma unroll 1
-      for (int block = 3; block < n_blocks; ++block) {
-        pass(record::load_eight(further));
-        further += record::kBlock;
+        for (int block = 3; block < n_blocks; ++block) {
+          pass(record::load_eight(further));
+          further += record::kBlock;
+        }
       }
       const double m0_i = head.v[record::kFirstSum], m0_j = head.v[record::kFirstSum + 1];
       out_i = fma(0.5, fma(g0, sum_i, m0_i * e), 0.5 * m0_i);
@@ -686,7 +687,6 @@ __device__ __forceinline__ void occ_record_zheng07(const double* table, const fm
       return;
     }
     if (d.m0_hi < limit.v[series::sat::kSteps - 1]) {
-      const int n_blocks = series::passes<series::sat::kSteps>(limit, d.m0_hi, 3);
       const double centre = head.v[record::kCentre], alpha = d.alpha;
       const double base = centre - m0;
       const double eps = centre * series::sat::reciprocal(base);
@@ -706,11 +706,14 @@ __device__ __forceinline__ void occ_record_zheng07(const double* table, const fm
       pass(b0);
       pass(b1);
       pass(b2);
-      sc_f64 further = rec + record::kHead + 3 * record::kBlock;
+      if (__builtin_amdgcn_ballot_w64(d.m0_hi >= limit.v[0]) != 0) {
+        const int n_blocks = series::passes<series::sat::kSteps>(limit, d.m0_hi, 3);
+        sc_f64 further = rec + record::kHead + 3 * record::kBlock;
 #pragma unroll 1
-      for (int block = 3; block < n_blocks; ++block) {
-        pass(record::load_eight(further));
-        further += record::kBlock;
+        for (int block = 3; block < n_blocks; ++block) {
+          pass(record::load_eight(further));
+          further += record::kBlock;
+        }
       }
       out_i = sum_i * power * d.sat_scale;
       out_j = sum_j * power * d.sat_scale;

@@ -375,6 +375,38 @@ TC_HD f64x8_t load_eight(Ptr p) {
   return m;
 }
 
+// A record's head and first three passes, requested TOGETHER and waited for once.  Left to the
+// compiler the loads of the passes sink below the first branch that looks at the head (the
+// plateau test), the third pass's below the test that a draw needs it: three dependent round
+// trips to the L2 per group instead of one.
+template <typename Ptr>
+TC_HD void load_record(Ptr rec, f64x8_t& head, f64x8_t& b0, f64x8_t& b1, f64x8_t& b2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef double __attribute__((ext_vector_type(8))) f64x8v;
+  f64x8v h, x0, x1, x2;
+  asm volatile(
+      "s_load_dwordx16 %0, %4, 0x0\n\t"
+      "s_load_dwordx16 %1, %4, 0x40\n\t"
+      "s_load_dwordx16 %2, %4, 0x80\n\t"
+      "s_load_dwordx16 %3, %4, 0xc0\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(h), "=&s"(x0), "=&s"(x1), "=&s"(x2)
+      : "s"(rec));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    head.v[i] = h[i];
+    b0.v[i] = x0[i];
+    b1.v[i] = x1[i];
+    b2.v[i] = x2[i];
+  }
+#else
+  head = load_eight(rec);
+  b0 = load_eight(rec + kHead);
+  b1 = load_eight(rec + kHead + kBlock);
+  b2 = load_eight(rec + kHead + 2 * kBlock);
+#endif
+}
+
 // The thresholds out of a record's head.
 TC_HD Thresholds thresholds_of(const f64x8_t& head) {
   Thresholds t;
