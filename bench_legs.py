@@ -65,12 +65,21 @@ def pmc_counter(kernel, counter, tag=''):
     path = pmc_file(tag)
     if path is None:
         return None
-    prefix = kernel[:40]
     for line in open(path).read().splitlines():
         match = re.match(r'(.*?)\s+(\w+)\s+n=\s*\d+\s+mean=([0-9.e+]+)', line)
-        if match and match.group(2) == counter and prefix in match.group(1).replace('void ', ''):
+        if match and match.group(2) == counter and same_kernel(kernel, match.group(1)):
             return float(match.group(3))
     return None
+
+
+def same_kernel(kernel, printed):
+    """Whether a row of tools/pmc_summary.py (kernel names cut to 96 characters; 48 in the files
+    of earlier rounds) is `kernel`'s."""
+    printed = printed.replace('void ', '').strip()
+    name = kernel.split('(')[0]
+    if '(' in printed:                      # (whole up to the argument list)
+        return printed.split('(')[0] == name
+    return name.startswith(printed)
 
 
 def pmc_traffic(kernel, tag=''):
@@ -82,10 +91,9 @@ def pmc_traffic(kernel, tag=''):
     if path is None:
         return None, None
     values = {}
-    prefix = kernel[:40]
     for line in open(path).read().splitlines():
         match = re.match(r'(.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+\s+mean=([0-9.e+]+)', line)
-        if match and prefix in match.group(1).replace('void ', ''):
+        if match and same_kernel(kernel, match.group(1)):
             values[match.group(2)] = float(match.group(3))
     if len(values) != 2:
         return None, None
@@ -700,7 +708,7 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
                 FP64_PEAK_TFLOPS, 'tc::contract_quad_kernel<5, false>', 'f64',
                 cpu_rate(lambda i: oracle.predict_zheng07(table_wp, theta[i % 10000],
                                                           cache=cache_wp)), parity_wp,
-                fused_kernel='tc::predict_fused_kernel<10, 5, false, false, false, 8, 64, false>')
+                fused_kernel='tc::predict_fused_kernel<10, 5, false, false, false, 8, 64, false, false>')
         del tab_wp
 
     # the layout of the reference's database (scripts/tabulate_snapshot.py:179-193: 30 mass bins x

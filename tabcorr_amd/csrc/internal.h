@@ -333,6 +333,7 @@ struct Tuning {
   // the batch), and a wave runs the node loop as well wherever one of its draws needs it.
   int series = -1;
   int cross_defer = 1;          // mode cross, one launch: deferred (group, draw) pairs (kernel_args.h)
+  int fused_defer = 1;          // predict_fused_kernel: satellites' expansion + deferred pairs
   int cross_wide_min_draws = 5120;   // launch.hip: choose_cross_fused (0: never the wide form)
   int cross_target = 160;       // mode cross: workgroups a launch should have at least
                                 // (several per tile of 64 draws below that)

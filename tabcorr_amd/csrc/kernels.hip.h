@@ -179,9 +179,8 @@ __device__ __forceinline__ double sat_series_value(const double* table, const fm
 // The node loop of bin g (tabcorr.py:556-578 with the Zheng07 callbacks inline) and the fix-ups
 // of draws it cannot represent: what occ_bin_zheng07 runs where no shortcut or expansion
 // applies.  Ptr = scalar-cache pointers with a wave-uniform g (the constants are scalar
-// operands), or plain pointers with a bin PER LANE -- the deferred (bin, draw) pairs of
-// predict_fused_kernel, whose constants come by vector loads; `central`, `above` and d.any_bad
-// are per lane resp. recomputed by the caller there.
+// operands), or plain pointers with a bin PER LANE, whose constants then come by vector loads;
+// `central`, `above` and d.any_bad are per lane resp. recomputed by the caller there.
 template <int NGAUSS, bool ASSEMBIAS, bool MODULATE, typename Ptr>
 __device__ __forceinline__ double occ_nodes_zheng07(const double* table, const fm::Consts& kc,
                                                     int g, int n_gauss, bool central, bool above,
@@ -259,7 +258,8 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
                                                   sc_f64 log_m, sc_f64 mass, sc_f64 weight,
                                                   sc_f64 weight_sum, const DrawParams& d,
                                                   double f1, double f2,
-                                                  const SeriesConsts& sr = SeriesConsts()) {
+                                                  const SeriesConsts& sr = SeriesConsts(),
+                                                  bool* defer_sat = nullptr) {
   constexpr bool assembias = ASSEMBIAS;
   constexpr bool modulate = MODULATE;
   const double log_m_min = d.log_m_min, inv_sigma = d.inv_sigma, m0 = d.m0;
@@ -315,6 +315,12 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
                            sr.sat_thresholds + g * series::sat::kThresholds, d);
     acc *= sat_scale;
     if (median) acc = fma(s_sat, acc, acc);
+  } else if (defer_sat != nullptr && !central) {
+    // (predict_fused_kernel's deferred pairs: a satellite bin that no expansion serves for this
+    // lane's draw is evaluated later, whole waves of such (bin, draw) pairs at a time -- unless
+    // every node lies at or below the draw's M0: 0, as the node loop would give)
+    const double m_a = mass[g * n_gauss], m_b = mass[g * n_gauss + n_gauss - 1];
+    *defer_sat = !(d.bad == 0 && !((m_a > m_b ? m_a : m_b) > m0));
   } else {
     // (no shortcut, no expansion for this lane's draw: the node loop, and the fix-ups of the
     // draws it cannot represent -- such draws never qualify for an expansion, series_setup)
@@ -2151,8 +2157,13 @@ __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, uns
 }
 
 template <int NGAUSS, int U, bool ASSEMBIAS, bool MODULATE, bool LEAUTHAUD = false,
-          int W = kFusedWaves, int DL = 64, bool GROUPED = false>
+          int W = kFusedWaves, int DL = 64, bool GROUPED = false, bool SATDEFER = false>
 __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(FusedArgs a) {
+  // SATDEFER (round 5; undecorated Zheng07, ten nodes, 64 draws): the satellites' expansion for
+  // the lanes it serves, and the (bin, draw) pairs it does not serve evaluated after the
+  // wave's bins, 64 pairs per pass of the node loop -- see "deferred pairs" below
+  static_assert(!SATDEFER || (NGAUSS == 10 && !ASSEMBIAS && !MODULATE && !LEAUTHAUD && DL == 64 &&
+                              !GROUPED), "deferred pairs");
   // GROUPED: the waves stride over the groups of bins that share their nodes (occ_group_zheng07)
   static_assert(!GROUPED || (NGAUSS == 10 && !LEAUTHAUD), "groups of bins: Zheng07, ten nodes");
   // DL = draws per workgroup: 64 (two 32-draw tiles, W = 8 or 16 waves), or 32 (ONE tile, eight
@@ -2253,9 +2264,11 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
                                                  emit);
       }
     }
+    unsigned mine = 0;        // SATDEFER: bit j = this lane's draw defers the wave's j-th bin
     for (int g = wave; g < (GROUPED ? 0 : a.n_bins); g += W) {
       const bool central = g < a.n_central;
       const bool above = ASSEMBIAS ? percentile[g] > a.split : false;
+      bool deferred = false;
       const double acc =
           DL == 32 && LEAUTHAUD
               ? occ_bin_leauthaud11_halves<MODULATE>(table, kc, g, central, half, a.log_m, a.m,
@@ -2269,10 +2282,77 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
                             table, kc, g, n_gauss, central, above, log_m, mass, weight,
                             weight_sum, dp, f1, f2,
                             SeriesConsts{(sc_f64)a.series, (sc_i32)a.series_thr, (sc_f64)a.sat_series,
-                              (sc_i32)a.sat_series_thr});
+                              (sc_i32)a.sat_series_thr}, SATDEFER ? &deferred : nullptr);
+      if (SATDEFER && deferred) mine |= 1u << ((g - wave) / W);
       const double value = acc * n_h[g];
       if (half == 0) dens[g * DL + draw] = value;
       if (central) sum_cen += value; else sum_sat += value;
+    }
+    if (SATDEFER) {
+      // ---- deferred pairs: this wave's (bin, draw) pairs, 64 per pass (lane = pair) ----
+      // A lane marks in `mine` the bins of its wave its draw needs the node loop for; the
+      // pairs are numbered in (bin, draw) order through the waves' ballots, entry p goes to lane
+      // p of a pass: the draw's constants from the lane that holds the draw, the bin's by vector
+      // loads, the result to the bin's row of the densities (this wave's rows: no barrier), from
+      // where the draw's own lane adds it to its sum in bin order.  What a draw defers depends
+      // on the draw alone: the same bits wherever it sits in the batch.
+      unsigned* list = (unsigned*)&red[1][wave][0];
+      const int n_mine = (a.n_bins - wave + W - 1) / W;
+      int total = 0;
+      for (int j = 0; j < n_mine; ++j)
+        total += __builtin_popcountll(__builtin_amdgcn_ballot_w64((mine >> j) & 1u));
+      for (int base = 0; base < total; base += 64) {
+        int before = 0;
+        for (int j = 0; j < n_mine; ++j) {
+          const bool bit = (mine >> j) & 1u;
+          const unsigned long long mask = __builtin_amdgcn_ballot_w64(bit);
+          if (mask == 0) continue;
+          const int rank = before + __builtin_amdgcn_mbcnt_hi(
+                                        (unsigned)(mask >> 32),
+                                        __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+          if (bit && rank >= base && rank < base + 64)
+            list[rank - base] = ((unsigned)j << 6) | (unsigned)lane;
+          before += __builtin_popcountll(mask);
+        }
+        const int n = total - base < 64 ? total - base : 64;
+        const bool active = lane < n;
+        const unsigned entry = list[active ? lane : 0];
+        const int g = wave + W * (int)(entry >> 6), from = (int)(entry & 63);
+        const double m0 = __shfl(dp.m0, from, 64);
+        const double log2_m1 = __shfl(dp.log2_m1, from, 64);
+        const double sat_scale = __shfl(dp.sat_scale, from, 64);
+        const double alpha = __shfl(dp.alpha, from, 64);
+        const int bad = __shfl(dp.bad, from, 64);
+        double acc = 0.0;
+        // (five nodes at a time: their constants requested together, then evaluated)
+#pragma unroll 1
+        for (int k0 = 0; k0 < 10; k0 += 5) {
+          double node[5], w[5];
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            node[k] = a.m[g * 10 + k0 + k];
+            w[k] = a.weight[g * 10 + k0 + k];
+          }
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            const double x = node[k] - m0;
+            acc = fma(w[k],
+                      fm::exp2_fast(table, kc,
+                                    alpha * fm::log2_fast_offset(
+                                                table, kc, x > 1e-300 ? x : 1e-300, log2_m1),
+                                    x > 0.0),
+                      acc);
+          }
+        }
+        acc *= sat_scale;
+        if (bad != 0) {           // (occ_nodes_zheng07's fix-ups of an undecorated satellite bin)
+          if ((bad & kInfSat) && acc != 0.0) acc = __builtin_huge_val();
+          if ((bad & kBadSat) && acc != 0.0) acc = __builtin_nan("");
+        }
+        if (active) dens[g * DL + from] = acc * a.n_h[g];
+      }
+      for (int j = 0; j < n_mine; ++j)
+        if ((mine >> j) & 1u) sum_sat += dens[(wave + W * j) * DL + draw];
     }
     red[0][wave][lane] = sum_cen;
     red[1][wave][lane] = sum_sat;

@@ -1222,7 +1222,7 @@ int fused_waves(const tc_table* t, bool separate, unsigned flags) {
 
 namespace {
 template <int NG, bool AB, bool MO, bool LE = false, int W = tc::kFusedWaves, int DL = 64,
-          bool GR = false>
+          bool GR = false, bool SD = false>
 int launch_fused(int device, int n_u, dim3 grid, dim3 block, int lds, hipStream_t stream,
                  hipEvent_t k0, hipEvent_t k1, const tc::FusedArgs& fa) {
   switch (n_u) {
@@ -1232,11 +1232,11 @@ int launch_fused(int device, int n_u, dim3 grid, dim3 block, int lds, hipStream_
     static bool limit_set[64] = {};                                                           \
     if (lds > 64 * 1024 && !(device >= 0 && device < 64 && limit_set[device])) {              \
       TC_HIP(hipFuncSetAttribute(                                                             \
-          (const void*)tc::predict_fused_kernel<NG, N, AB, MO, LE, W, DL, GR>,                \
+          (const void*)tc::predict_fused_kernel<NG, N, AB, MO, LE, W, DL, GR, SD>,                \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));    \
       if (device >= 0 && device < 64) limit_set[device] = true;                               \
     }                                                                                         \
-    hipExtLaunchKernelGGL((tc::predict_fused_kernel<NG, N, AB, MO, LE, W, DL, GR>), grid,     \
+    hipExtLaunchKernelGGL((tc::predict_fused_kernel<NG, N, AB, MO, LE, W, DL, GR, SD>), grid,     \
                           block, lds, stream, k0, k1, 0, fa);                                 \
     break;                                                                                    \
   }
@@ -1349,6 +1349,14 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   if (status != TC_OK) return status;
   const bool assembias = (flags & TC_FLAG_ASSEMBIAS) != 0;
   const bool modulate = (flags & TC_FLAG_MODULATE_WITH_CENOCC) != 0;
+  // the satellites' expansion + deferred pairs (predict_fused_kernel, SATDEFER): undecorated
+  // Zheng07, ten nodes, eight waves x 64 draws, the centrals' expansion on
+  const bool sat_defer = t->tuning.fused_defer != 0 && !assembias && !modulate &&
+                         !(flags & TC_FLAG_LEAUTHAUD11) && n_gauss == 10 && !wide &&
+                         !half_tiles && waves == 8 &&
+                         !(t->grouped && n_gauss == 10) && (series_mask(t) & 1) != 0 &&
+                         q->sat_series != nullptr;
+  if (sat_defer) fa.sat_series = (const double*)q->sat_series;
 #define TC_FUSED(NG, AB, MO, LE)                                                              \
   (waves == 16 ? launch_fused<NG, AB, MO, LE, 16>(t->device, t->quad_tiling.n_u, grid, block,  \
                                                   lds, stream, k0, k1, fa)                     \
@@ -1384,6 +1392,9 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
     status = modulate ? TC_FUSED(0, false, true, true) : TC_FUSED(0, false, false, true);
   else if (n_gauss != 10)
     status = TC_FUSED(0, false, false, false);
+  else if (!assembias && !modulate && sat_defer)
+    status = launch_fused<10, false, false, false, 8, 64, false, true>(
+        t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
   else if (!assembias && !modulate)
     status = TC_FUSED(10, false, false, false);
   else if (!assembias)

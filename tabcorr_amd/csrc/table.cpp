@@ -1244,6 +1244,9 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
   } else if (key == "cross_defer") {
     // developer A/B: 0 = predict_cross_fused_kernel runs every lane's node loop in place
     t->tuning.cross_defer = value != 0;
+  } else if (key == "fused_defer") {
+    // developer A/B: 0 = predict_fused_kernel runs the satellites' node loops in place
+    t->tuning.fused_defer = value != 0;
   } else if (key == "cross_wide_min_draws") {
     // mode cross, tables of up to 16 rows: undecorated batches of this many draws take the
     // 32-row chunk form (launch.hip: choose_cross_fused); 0: never

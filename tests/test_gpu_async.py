@@ -458,16 +458,19 @@ def test_resident_kernel_by_itself_for_loops_of_unbatched_calls():
 
     def loop(n):
         t0 = time.perf_counter()
+        by_launch = 0
         for call in range(n):
             i = call % 400
             for key, value in zip(keys, theta[i]):
                 model.param_dict[key] = value
             ngal, xi = halotab.predict(model)
-            # the first calls are launches, the later ones the resident kernel's
+            # the first calls are launches, the later ones the resident kernel's -- but for the
+            # odd call after a hiccup of the host longer than the kernel's idle time
             assert (np.array_equal(xi, launched[i][1][0]) or
                     np.array_equal(xi, resident[i][1][0])), call
-            if call >= 16:
-                assert np.array_equal(xi, resident[i][1][0]), call
+            if call >= 16 and not np.array_equal(xi, resident[i][1][0]):
+                by_launch += 1
+        assert by_launch <= n // 100, by_launch
         return (time.perf_counter() - t0) / n
     per_call_auto = loop(3000)
     halotab.set_resident(False)

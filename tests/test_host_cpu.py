@@ -1161,6 +1161,6 @@ def test_no_kernel_spills_vector_registers():
     # the instances whose two workgroups per CU need four waves per SIMD stay within 128
     for mangled, usage in kernels.items():
         name = names[mangled]
-        if ('predict_fused_kernel<10, 5, false, false, false, 8, 64, false>' in name or
+        if ('predict_fused_kernel<10, 5, false, false, false, 8, 64, false, ' in name or
                 'predict_cross_fused_kernel<8,' in name or 'predict_cross_small_kernel' in name):
             assert usage['VGPRs'] <= 128, (name, usage['VGPRs'])

@@ -10,8 +10,8 @@ for root in sys.argv[1:]:
         sums = defaultdict(lambda: [0.0, 0])
         with open(path) as stream:
             for row in csv.DictReader(stream):
-                key = (row['Kernel_Name'][:48], row['Counter_Name'])
+                key = (row['Kernel_Name'][:96], row['Counter_Name'])
                 sums[key][0] += float(row['Counter_Value'])
                 sums[key][1] += 1
         for (kernel, counter), (total, n) in sorted(sums.items()):
-            print('%-50s %-24s n=%4d mean=%.5g' % (kernel, counter, n, total / n))
+            print('%-98s %-24s n=%4d mean=%.5g' % (kernel, counter, n, total / n))

@@ -75,10 +75,13 @@ if [ $WHAT = configs ] || [ $WHAT = all ]; then
   # (TAGS="cfg3 ds4" ... selects; the PMC passes run with the default lanes so that the
   # one-launch forms are what the pipelined calls take -- the profiler serialises the
   # dispatches itself --, and bench.py's own serialised pass adds the three kernels)
+  # (sync_chunks=-1: the host-call leg of these runs launches the same kernels for CHUNKS of the
+  # batch otherwise, and the per-launch means below would mix two launch sizes)
+  SERIAL="--option sync_chunks=-1"
   for tag in ${TAGS:-cfg3 cfg4 cfg5f32 cfg5f64 ds4 ds1 wp db}; do
-    PMC_SHORT=1 pmc_passes pmc_summary_${tag} --only-config $tag --cpu-seconds 0
-    kernel_stats kernel_stats_${tag}_lanes1 --only-config $tag --lanes 1 --cpu-seconds 0
-    kernel_stats kernel_stats_${tag}_pipelined --only-config $tag --cpu-seconds 0
+    PMC_SHORT=${PMC_SHORT:-1} pmc_passes pmc_summary_${tag} --only-config $tag --cpu-seconds 0 $SERIAL
+    kernel_stats kernel_stats_${tag}_lanes1 --only-config $tag --lanes 1 --cpu-seconds 0 $SERIAL
+    kernel_stats kernel_stats_${tag}_pipelined --only-config $tag --cpu-seconds 0 $SERIAL
   done
 fi
 ls -la $OUT
