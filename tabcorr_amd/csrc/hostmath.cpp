@@ -293,6 +293,9 @@ void bin_consts(int n_gauss, const double* mass, const double* weight, double lo
     std::memcpy(&bits, &limit, sizeof(bits));
     thresholds[s] = (int32_t)(bits >> 32);
   }
+  // (the limit of the SHORTEST expansion that serves the bin at all: kShortest)
+  for (int s = kSteps - 1; s >= 0; --s)
+    if (thresholds[s] != 0) thresholds[kShortest] = thresholds[s];
 }
 
 }  // namespace sat

@@ -364,6 +364,7 @@ struct FusedArgs {
   const int32_t* series_thr;
   const double* sat_series;
   const int32_t* sat_series_thr;
+  int sat_cap;                 // SATDEFER: longest expansion in place = 12 + 4 sat_cap terms
 };
 
 // ---- mode cross, one launch per batch (predict_cross_fused_kernel, kernels.hip.h) ----------

@@ -149,6 +149,9 @@ struct SeriesConsts {
   sc_i32 thresholds = nullptr;
   sc_f64 sat_consts = nullptr;         // series::sat::kStride doubles per bin / member
   sc_i32 sat_thresholds = nullptr;
+  // the longest satellite expansion a lane takes in place: 12 + 4 sat_cap terms (kernels that
+  // defer what is left: a wave pays for its longest lane)
+  int sat_cap = series::sat::kSteps - 1;
 };
 
 // The expansions' per-lane keys (series.h): what a draw's term counts follow (non-negative
@@ -301,7 +304,7 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
     series_cen = series::eligible(sr.thresholds + g * series::kThresholds, d.inv_sigma_hi);
   if (!central && !modulate && (!assembias || median) && shortcut == 0 &&
       sr.sat_consts != nullptr && n_gauss >= 4)
-    series_sat = series::sat::eligible(sr.sat_thresholds + g * series::sat::kThresholds, d.m0_hi);
+    series_sat = d.m0_hi < (sr.sat_thresholds + g * series::sat::kThresholds)[sr.sat_cap];
   if (shortcut != 0) {
     if (shortcut == 1) acc = weight_sum[g];
   } else if (series_cen) {
@@ -2282,7 +2285,9 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
                             table, kc, g, n_gauss, central, above, log_m, mass, weight,
                             weight_sum, dp, f1, f2,
                             SeriesConsts{(sc_f64)a.series, (sc_i32)a.series_thr, (sc_f64)a.sat_series,
-                              (sc_i32)a.sat_series_thr}, SATDEFER ? &deferred : nullptr);
+                              (sc_i32)a.sat_series_thr,
+                              SATDEFER ? a.sat_cap : series::sat::kSteps - 1},
+                            SATDEFER ? &deferred : nullptr);
       if (SATDEFER && deferred) mine |= 1u << ((g - wave) / W);
       const double value = acc * n_h[g];
       if (half == 0) dens[g * DL + draw] = value;

@@ -1357,6 +1357,7 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
                          !(t->grouped && n_gauss == 10) && (series_mask(t) & 1) != 0 &&
                          q->sat_series != nullptr;
   if (sat_defer) fa.sat_series = (const double*)q->sat_series;
+  fa.sat_cap = t->tuning.fused_sat_cap;
 #define TC_FUSED(NG, AB, MO, LE)                                                              \
   (waves == 16 ? launch_fused<NG, AB, MO, LE, 16>(t->device, t->quad_tiling.n_u, grid, block,  \
                                                   lds, stream, k0, k1, fa)                     \

@@ -1247,6 +1247,9 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
   } else if (key == "fused_defer") {
     // developer A/B: 0 = predict_fused_kernel runs the satellites' node loops in place
     t->tuning.fused_defer = value != 0;
+  } else if (key == "fused_sat_cap") {
+    TC_CHECK(value >= 0 && value <= 6, "fused_sat_cap must be in [0, 6]");
+    t->tuning.fused_sat_cap = value;
   } else if (key == "cross_wide_min_draws") {
     // mode cross, tables of up to 16 rows: undecorated batches of this many draws take the
     // 32-row chunk form (launch.hip: choose_cross_fused); 0: never
