@@ -335,6 +335,28 @@ void group_record(bool central, const double* consts_i, const double* consts_j,
 
 }  // namespace record
 
+namespace sat_record {
+
+void bin_record(const double* consts, const int32_t* thresholds, const double* mass, int n_gauss,
+                double* out) {
+  for (int i = 0; i < kStride; ++i) out[i] = 0.0;
+  int32_t head[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int shortest = 0;
+  for (int s = sat::kSteps - 1; s >= 0; --s) {
+    head[s] = thresholds[s];
+    if (thresholds[s] != 0) shortest = s;
+  }
+  head[6] = thresholds[sat::kShortest];
+  head[7] = 3 + shortest;
+  std::memcpy(out, head, sizeof(head));
+  out[kCentre] = consts[0];
+  out[kSum] = consts[3];
+  out[kLargest] = mass[0] > mass[n_gauss - 1] ? mass[0] : mass[n_gauss - 1];
+  for (int n = 0; n < sat::kMaxTerms; ++n) out[kHead + n] = consts[sat::kFirst + n];
+}
+
+}  // namespace sat_record
+
 }  // namespace series
 
 void find_node_groups(int n_bins, int n_central, const double* log_min, const double* log_max,

@@ -197,6 +197,7 @@ struct Quadrature {
   void* sat_series_thr = nullptr;
   void* group_sat_series = nullptr;
   void* group_sat_series_thr = nullptr;
+  void* sat_records = nullptr;         // series.h, namespace sat_record (satellite bins)
   void* group_records = nullptr;       // series.h, namespace record (groups of <= 2 members)
 };
 

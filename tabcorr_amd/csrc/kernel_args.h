@@ -365,6 +365,7 @@ struct FusedArgs {
   const double* sat_series;
   const int32_t* sat_series_thr;
   int sat_cap;                 // SATDEFER: longest expansion in place = 12 + 4 sat_cap terms
+  const double* sat_records;   // SATDEFER: series.h, namespace sat_record, by library bin
 };
 
 // ---- mode cross, one launch per batch (predict_cross_fused_kernel, kernels.hip.h) ----------

@@ -334,6 +334,57 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
   return acc;
 }
 
+// An undecorated satellite bin of predict_fused_kernel's deferring instance from its record
+// (series.h, namespace sat_record): head and the first sixteen moments with one round trip of
+// scalar loads.  In place only the draws the bin's SHORTEST expansion serves (the same number
+// of terms for all of them: the record's); *deferred for the others unless every node lies at
+// or below their M0.
+__device__ __forceinline__ double occ_sat_record(const double* table, const fm::Consts& kc,
+                                                 sc_f64 rec, const DrawParams& d,
+                                                 bool* deferred) {
+  namespace record = series::sat_record;
+  series::record::f64x8_t head, first, second;
+  record::load_record(rec, head, first, second);
+  const double m0 = d.m0, largest = head.v[record::kLargest];
+#ifndef TC_NO_OCC_SHORTCUTS
+  if (!d.any_bad && __builtin_amdgcn_ballot_w64(largest > m0) == 0) return 0.0;
+#endif
+  const unsigned long long word = fm::bits_of(head.v[record::kLimit]);
+  const int limit = (int)(unsigned)(word & 0xffffffffull), n_passes = (int)(word >> 32);
+  double acc = 0.0;
+  if (d.m0_hi < limit) {
+    const double centre = head.v[record::kCentre], alpha = d.alpha;
+    const double base = centre - m0;
+    const double eps = centre * series::sat::reciprocal(base);
+    const double power =
+        fm::exp2_fast(table, kc, alpha * fm::log2_fast_offset(table, kc, base, d.log2_m1));
+    double c = 1.0, g = eps * alpha, sum = head.v[record::kSum];
+    auto term = [&](double moment) {
+      c *= g;
+      g -= eps;
+      sum = fma(c, moment, sum);
+    };
+    // (sixteen terms whatever the bin asks for: more than needed only adds terms below the
+    // tolerance)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) term(first.v[k]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) term(second.v[k]);
+    sc_f64 further = rec + record::kHead + 4 * record::kBlock;
+#pragma unroll 1
+    for (int pass = 4; pass < n_passes; ++pass) {
+      const series::f64x4_t m = series::load_four(further, 0, 0);
+      further += record::kBlock;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) term(m[k]);
+    }
+    acc = sum * power * d.sat_scale;
+  } else {
+    *deferred = !(d.bad == 0 && !(largest > m0));
+  }
+  return acc;
+}
+
 // The same for workgroups of 32 draws (predict_fused_kernel<..., DL = 32>): lane = (draw, half),
 // each half of the wave takes five of the bin's ten nodes -- their constants come from memory
 // by vector loads, two addresses per wave, instead of scalar registers -- and the halves are
@@ -2273,6 +2324,10 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
       const bool above = ASSEMBIAS ? percentile[g] > a.split : false;
       bool deferred = false;
       const double acc =
+          SATDEFER && !central && a.sat_cap == series::sat::kShortest
+              ? occ_sat_record(table, kc,
+                               (sc_f64)a.sat_records + g * series::sat_record::kStride, dp,
+                               &deferred) :
           DL == 32 && LEAUTHAUD
               ? occ_bin_leauthaud11_halves<MODULATE>(table, kc, g, central, half, a.log_m, a.m,
                                                      a.weight, ld)

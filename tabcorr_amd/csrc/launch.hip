@@ -73,6 +73,18 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
                                 sat_series_thr.data() + (size_t)i * tc::series::sat::kThresholds);
   if (status == TC_OK) status = upload(sat_series, &q.sat_series);
   if (status == TC_OK) status = upload(sat_series_thr, &q.sat_series_thr);
+  if (n_gauss >= 4) {
+    // ... and a satellite bin's constants in one record (series.h, namespace sat_record), by
+    // library bin (the centrals' slots stay empty)
+    namespace rec = tc::series::sat_record;
+    std::vector<double> records((size_t)g * rec::kStride);
+    for (int i = t->plan.n_central; i < g; ++i)
+      rec::bin_record(sat_series.data() + (size_t)i * tc::series::sat::kStride,
+                      sat_series_thr.data() + (size_t)i * tc::series::sat::kThresholds,
+                      m.data() + (size_t)i * n_gauss, n_gauss,
+                      records.data() + (size_t)i * rec::kStride);
+    if (status == TC_OK) status = upload(records, &q.sat_records);
+  }
   if (status == TC_OK && n_gauss == 10 &&
       (t->node_groups.largest > 1 || t->mode == TC_MODE_CROSS)) {
     // GROUPED kernels: the nodes of every group (= those of its first member), the weights and
@@ -1355,8 +1367,9 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
                          !(flags & TC_FLAG_LEAUTHAUD11) && n_gauss == 10 && !wide &&
                          !half_tiles && waves == 8 &&
                          !(t->grouped && n_gauss == 10) && (series_mask(t) & 1) != 0 &&
-                         q->sat_series != nullptr;
+                         q->sat_series != nullptr && q->sat_records != nullptr;
   if (sat_defer) fa.sat_series = (const double*)q->sat_series;
+  fa.sat_records = (const double*)q->sat_records;
   fa.sat_cap = t->tuning.fused_sat_cap;
 #define TC_FUSED(NG, AB, MO, LE)                                                              \
   (waves == 16 ? launch_fused<NG, AB, MO, LE, 16>(t->device, t->quad_tiling.n_u, grid, block,  \

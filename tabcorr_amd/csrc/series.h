@@ -438,5 +438,48 @@ TC_HD int members_of(bool central, const Thresholds& limit, const f64x8_t& head)
 }
 }  // namespace record
 
+// ... and per satellite BIN, for predict_fused_kernel's deferring instance: kStride doubles,
+// 64-byte aligned --
+//   [0, 3)  int32 x 6: thresholds; [3] as int32 x 2: thresholds[kShortest], passes of the
+//   shortest expansion     [4] Mc     [5] mu_0     [6] the larger of the end nodes' masses
+//   [8 + 4 p, 12 + 4 p)    the four moments of pass p
+// head and the first four passes: three 64-byte loads, one round trip.
+namespace sat_record {
+constexpr int kHead = 8;
+constexpr int kBlock = 4;
+constexpr int kStride = kHead + kBlock * (sat::kMaxTerms / 4);      // 40 doubles: five lines
+constexpr int kLimit = 3, kCentre = 4, kSum = 5, kLargest = 6;
+
+template <typename Ptr>
+TC_HD void load_record(Ptr rec, record::f64x8_t& head, record::f64x8_t& first,
+                       record::f64x8_t& second) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef double __attribute__((ext_vector_type(8))) f64x8v;
+  f64x8v h, x, y;
+  asm volatile(
+      "s_load_dwordx16 %0, %3, 0x0\n\t"
+      "s_load_dwordx16 %1, %3, 0x40\n\t"
+      "s_load_dwordx16 %2, %3, 0x80\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(h), "=&s"(x), "=&s"(y)
+      : "s"(rec));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    head.v[i] = h[i];
+    first.v[i] = x[i];
+    second.v[i] = y[i];
+  }
+#else
+  head = record::load_eight(rec);
+  first = record::load_eight(rec + kHead);
+  second = record::load_eight(rec + kHead + 8);
+#endif
+}
+
+// A satellite bin's record from sat::bin_consts' output and its node masses.
+void bin_record(const double* consts, const int32_t* thresholds, const double* mass, int n_gauss,
+                double* out);
+}  // namespace sat_record
+
 }  // namespace series
 }  // namespace tc

@@ -248,7 +248,7 @@ int tc_table_destroy(tc_table* t) {
                     kv.second.group_m, kv.second.group_weight, kv.second.series,
                     kv.second.series_thr, kv.second.group_series, kv.second.group_series_thr,
                     kv.second.sat_series, kv.second.sat_series_thr, kv.second.group_sat_series,
-                    kv.second.group_sat_series_thr, kv.second.group_records})
+                    kv.second.group_sat_series_thr, kv.second.group_records, kv.second.sat_records})
       if (p) (void)hipFree(p);
   for (auto& kv : t->chunkings)
     for (void* p : {kv.second->chunks, kv.second->groups})
