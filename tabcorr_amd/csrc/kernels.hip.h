@@ -113,7 +113,9 @@ __device__ inline DrawSetup prepare_draw(const double* table, const fm::Consts& 
   }
   d.log_m_min = log_m_min;
   d.inv_sigma = 1.0 / sigma;
-  d.m0 = no_satellites ? 1e300 : fm::exp10_fast(table, kc, log_m0);
+  // (logM0 = -inf, or so low that 10^logM0 underflows: M0 = 0, as NumPy's 10**x gives -- the
+  // two-part product of exp10_fast would make inf - inf = NaN of it and lose every satellite)
+  d.m0 = no_satellites ? 1e300 : log_m0 < -300.0 ? 0.0 : fm::exp10_fast(table, kc, log_m0);
   // ((M - M0) / M1)^alpha = 2^(alpha (log2(M - M0) - log2 M1)); log2 M1 is carried in two
   // parts, the low one applied to the finished bin sum as 2^(-alpha lo)
   const double hi = log_m1 * fm::kLog2Of10Hi;

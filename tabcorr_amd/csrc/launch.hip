@@ -78,12 +78,18 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
     // library bin (the centrals' slots stay empty)
     namespace rec = tc::series::sat_record;
     std::vector<double> records((size_t)g * rec::kStride);
+    // (only where some expansion serves every bin: with none, all of a bin's pairs would be
+    // deferred -- the node loops in place are faster then)
+    bool served = g > t->plan.n_central;
     for (int i = t->plan.n_central; i < g; ++i)
+      served = served &&
+               sat_series_thr[(size_t)i * tc::series::sat::kThresholds + tc::series::sat::kShortest] != 0;
+    for (int i = t->plan.n_central; i < g && served; ++i)
       rec::bin_record(sat_series.data() + (size_t)i * tc::series::sat::kStride,
                       sat_series_thr.data() + (size_t)i * tc::series::sat::kThresholds,
                       m.data() + (size_t)i * n_gauss, n_gauss,
                       records.data() + (size_t)i * rec::kStride);
-    if (status == TC_OK) status = upload(records, &q.sat_records);
+    if (status == TC_OK && served) status = upload(records, &q.sat_records);
   }
   if (status == TC_OK && n_gauss == 10 &&
       (t->node_groups.largest > 1 || t->mode == TC_MODE_CROSS)) {

@@ -800,3 +800,61 @@ def test_autotune_picks_the_fastest_form(n_prim, n_r, how):
         lib.tc_device_free(ptr)
     with pytest.raises(ValueError):
         set_option(halotab, 'autotune', 64)         # not a combination of predict flags
+
+
+def test_satellites_by_expansion_with_deferred_pairs():
+    """predict_fused_kernel<..., SATDEFER>: undecorated Zheng07 on a table whose expansions
+    serve every bin (64-draw workgroups): the satellites' expansion from the bins' records for
+    the draws the shortest expansion serves, the other (bin, draw) pairs after the wave's bins
+    -- against the oracle, the same kernel with the node loops in place, separated by galaxy
+    type, with draws that need every exit, and wherever a draw sits in the batch."""
+    import warnings
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    n = 1500
+    theta = synthetic.zheng07_draws(n, seed=77)
+    rng = np.random.default_rng(3)
+    theta[:200, 2] = rng.uniform(12.9, 14.8, 200)       # M0 inside / above the upper bins
+    theta[200:260, 2] = 9.0                             # ... below all of them
+    theta[300, 4] = 5.5                                 # alpha outside [0, 4]: node loop
+    theta[301, 4] = -0.5
+    theta[302, 2] = np.inf
+    theta[303, 2] = -np.inf
+    theta[304, 3] = np.nan
+    theta[305, 1] = 1e-4
+    theta[306, 0] = np.inf
+    halotab = make_tabcorr(table)
+    force_fused(halotab)
+    set_option(halotab, 'fused_draws', 64)
+    set_option(halotab, 'series', 1)
+    results = {}
+    for defer in (1, 0):
+        set_option(halotab, 'fused_defer', defer)
+        for separate in (False, True):
+            results[defer, separate] = halotab.predict_batch(theta, separate_gal_type=separate)
+            assert fused_ran(halotab, (8, ))
+    with warnings.catch_warnings(), np.errstate(all='ignore'):
+        warnings.simplefilter('ignore')
+        expect = oracle.predict_zheng07_batch(table, theta)
+        expect_sep = oracle.predict_zheng07_batch(table, theta, separate_gal_type=True)
+    ngal, xi = results[1, False]
+    finite = np.isfinite(expect[0])
+    assert np.array_equal(np.isnan(ngal), np.isnan(expect[0]))
+    assert np.array_equal(np.isinf(ngal), np.isinf(expect[0]))
+    assert_rel(ngal[finite], expect[0][finite], 1e-12)
+    assert_rel(xi[finite], expect[1][finite], 1e-11)
+    assert_rel(ngal[finite], results[0, False][0][finite], 1e-13)
+    assert_rel(xi[finite], results[0, False][1][finite], 1e-12)
+    for key in expect_sep[0]:
+        good = np.isfinite(expect_sep[0][key]) & finite
+        assert_rel(results[1, True][0][key][good], expect_sep[0][key][good], 1e-12)
+    for key in expect_sep[1]:
+        assert_rel(results[1, True][1][key][finite], expect_sep[1][key][finite], 1e-11,
+                   floor=1e-13)
+    # the same bits wherever the draw sits, whatever its neighbours defer
+    set_option(halotab, 'fused_defer', 1)
+    order = rng.permutation(n)
+    ngal_p, xi_p = halotab.predict_batch(theta[order][:777])
+    assert np.array_equal(ngal_p, ngal[order][:777], equal_nan=True)
+    assert np.array_equal(xi_p, xi[order][:777], equal_nan=True)
