@@ -708,7 +708,7 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
                 FP64_PEAK_TFLOPS, 'tc::contract_quad_kernel<5, false>', 'f64',
                 cpu_rate(lambda i: oracle.predict_zheng07(table_wp, theta[i % 10000],
                                                           cache=cache_wp)), parity_wp,
-                fused_kernel='tc::predict_fused_kernel<10, 5, false, false, false, 8, 64, false, false>')
+                fused_kernel='tc::predict_fused_kernel<10, 5, false, false, false, 8, 64, false, true>')
         del tab_wp
 
     # the layout of the reference's database (scripts/tabulate_snapshot.py:179-193: 30 mass bins x
