@@ -561,7 +561,7 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
                 cpu_rate(lambda i: oracle.predict_zheng07(
                     table3, theta7[i % 10000, :5], separate_gal_type=True,
                     assembias=theta7[i % 10000, 5:], cache=cache3)), parity3,
-                fused_kernel='tc::predict_fused_kernel<10, 5, true, false, false, 8, 32, true>')
+                fused_kernel='tc::predict_fused_kernel<10, 5, true, false, false, 8, 32, true, false>')
         del tab3
 
     # configs[3]: one GPU's share (12 500 draws) of the 5 x 5 interpolator

@@ -364,13 +364,13 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 configs[1] 39.2 -> 37.5 us per 10^4 draws, the reference's example table 18.2 ->
  *                 17.5.  What a draw defers depends on the draw alone: same bits wherever it
  *                 sits in whatever batch.  0: the satellites' node loops in place.
- *   "cross_wide_min_draws"  default 5120.  Mode cross (tpcf_matrix with one column per halo
+ *   "cross_wide_min_draws"  default 4096.  Mode cross (tpcf_matrix with one column per halo
  *                 bin), tables or interpolators of up to 16 result rows whose node groups have
  *                 at most two members: undecorated batches of this many draws take the one-launch
  *                 form that multiplies on the matrix pipe and reads a group's expansion
- *                 constants from one record (csrc/series.h, namespace record) -- 52.4 against
- *                 58.8 us per 10^4 draws of the reference's AbacusSummit table --, smaller ones
- *                 the form that keeps the row sums in registers (faster below ~5000 draws);
+ *                 constants from one record (csrc/series.h, namespace record) -- 49.1 against
+ *                 59.1 us per 10^4 draws of the reference's AbacusSummit table --, smaller ones
+ *                 the form that keeps the row sums in registers (faster below ~3500 draws);
  *                 the two differ in the last bits.  0: always the register form.
  *   "single_draw" 1 (default): an un-batched predict() goes through one launch.
  *   "resident"    1: un-batched calls (tc_predict_zheng07_batch with one draw; total

@@ -337,7 +337,7 @@ struct Tuning {
   int fused_defer = 1;          // predict_fused_kernel: satellites' expansion + deferred pairs
   int fused_sat_cap = 6;        // ... in place up to 12 + 4 x this many terms (0 .. 5), or
                                 // 6 = series::sat::kShortest: the shortest that serves the bin
-  int cross_wide_min_draws = 5120;   // launch.hip: choose_cross_fused (0: never the wide form)
+  int cross_wide_min_draws = 4096;   // launch.hip: choose_cross_fused (0: never the wide form)
   int cross_target = 160;       // mode cross: workgroups a launch should have at least
                                 // (several per tile of 64 draws below that)
   int resident_aperture = 1;    // resident ensemble kernel: the mailbox in device memory that

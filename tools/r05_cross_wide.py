@@ -36,7 +36,7 @@ def main():
                     handle, d_theta, 5, n, 10, 0, d_ngal, d_xi)),
                 lambda: _lib.check(lib.tc_table_synchronize(handle)), seconds=0.3) * 1e6
             out[name] = dev.download(d_xi, n * 13)
-        _lib.check(lib.tc_table_set_option(handle, b'cross_wide_min_draws', 5120))
+        _lib.check(lib.tc_table_set_option(handle, b'cross_wide_min_draws', 4096))
         default = bench_legs.sustained(
             lambda: _lib.check(lib.tc_predict_zheng07_batch_device(
                 handle, d_theta, 5, n, 10, 0, d_ngal, d_xi)),
