@@ -2719,7 +2719,7 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
   constexpr int NT = ROWS / 16;                       // row blocks of 16
   constexpr int N_RB = RW >= 16 ? 2 : 1;              // row blocks per wave
   constexpr int N_DB = RW >= 8 ? 2 : 1;               // blocks of 16 draws per wave
-  constexpr int PF = 4;                               // A operands in flight (4-bin steps)
+  constexpr int PF = 6;                               // A operands in flight (4-bin steps; 4: +0.3–1 %, 8: level)
   static_assert(ROWS <= kCrossMaxRows && fm::kTableDoubles == kCrossTableDoubles, "kernel_args.h");
   static_assert(N_RB * N_DB * 4 == RW && kCrossChunkBins % 4 == 0, "tiles per wave");
   extern __shared__ __attribute__((aligned(16))) double cross_lds[];
