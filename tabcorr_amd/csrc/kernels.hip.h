@@ -2579,7 +2579,6 @@ __device__ __forceinline__ void cross_deferred_pairs(
   // defers a handful of groups, so a wave's pairs of ALL groups are usually one pass of the
   // node loop (evaluated per block of 64 groups they were ~5 nearly empty passes: a sixth of the
   // kernel's vector instructions on the AbacusSummit tables).
-  int filled = 0;
   auto evaluate = [&](int total) {
     for (int e0 = 0; e0 < total; e0 += 64) {
       const int n = total - e0 < 64 ? total - e0 : 64;
@@ -2658,30 +2657,32 @@ __device__ __forceinline__ void cross_deferred_pairs(
       }
     }
   };
-  for (int gb = g_first; gb < g_last; gb += 64) {
-    const int g_lane = gb + lane;
-    unsigned long long word = g_lane < g_last ? bitmap[g_lane] & owner : 0ull;
-    const int count = __builtin_popcountll(word);
-    int inclusive = count;
+  // (segments of blocks that fit the list; the evaluation stands in ONE place, outside the
+  // loop of blocks: inlined twice, or with a block's words alive across it, registers spill)
+  int gb = g_first;
+  while (gb < g_last) {
+    int filled = 0;
+    for (; gb < g_last; gb += 64) {
+      const int g_lane = gb + lane;
+      unsigned long long word = g_lane < g_last ? bitmap[g_lane] & owner : 0ull;
+      const int count = __builtin_popcountll(word);
+      int inclusive = count;
 #pragma unroll
-    for (int offset = 1; offset < 64; offset <<= 1) {
-      const int other = __shfl_up(inclusive, offset, 64);
-      if (lane >= offset) inclusive += other;
+      for (int offset = 1; offset < 64; offset <<= 1) {
+        const int other = __shfl_up(inclusive, offset, 64);
+        if (lane >= offset) inclusive += other;
+      }
+      const int total = __builtin_amdgcn_readlane(inclusive, 63);
+      if (filled + total > 512) break;            // (the next segment starts with this block)
+      int slot_out = filled + inclusive - count;
+      while (word != 0) {
+        list[slot_out++] = (unsigned)(g_lane << 6) | (unsigned)__builtin_ctzll(word);
+        word &= word - 1;
+      }
+      filled += total;
     }
-    const int total = __builtin_amdgcn_readlane(inclusive, 63);
-    if (total == 0) continue;
-    if (filled + total > 512) {
-      evaluate(filled);
-      filled = 0;
-    }
-    int slot_out = filled + inclusive - count;
-    while (word != 0) {
-      list[slot_out++] = (unsigned)(g_lane << 6) | (unsigned)__builtin_ctzll(word);
-      word &= word - 1;
-    }
-    filled += total;
+    evaluate(filled);
   }
-  evaluate(filled);
 #pragma unroll
   for (int slot = 0; slot < SLOTS; ++slot)
     res[row * kLanes + wave + 8 * (share + SHARES * slot)] += extra[slot];
