@@ -805,6 +805,14 @@ int tc_interp_predict_zheng07_batch(tc_interp* it, const double* theta, int n_th
     if (t0->tuning.sync_chunks >= 0 && t0->tuning.pipeline && it->n_lanes >= 2) {
       if (t0->tuning.sync_chunks >= 1)
         n_chunks = (int)std::min<int64_t>(t0->tuning.sync_chunks, (n_draws + 63) / 64);
+      else if (n_draws >= 2048 && t0->mode == TC_MODE_CROSS)
+        // (one piece through the asynchronous path: staging, kernels that store the results
+        // themselves, the copy on four threads.  Two and more chunks of an interpolator's
+        // one-launch form take 217-470 us per 10^4 draws of the AbacusSummit fixture from one
+        // batch of calls to the next -- the runtime's mapping of the lanes' streams to hardware
+        // queues is the suspect --, one chunk a steady 245; a single table's chunks are steady:
+        // 168 -> 143, tools/r05_sync_chunks.py)
+        n_chunks = 1;
       else if (n_draws >= 2048)
         n_chunks = (int)std::min<int64_t>(
             std::min<int64_t>(8, n_draws / 1024),
