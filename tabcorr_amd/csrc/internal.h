@@ -465,6 +465,12 @@ struct tc_table {
   // the coefficient rows of predict_cross_fused_kernel (also those of interpolators)
   std::vector<double> cross_host;
   tc::host::CrossFused cross_fused, cross_fused_wide;
+  // Set while the chunks of a synchronous host call are queued (0 otherwise): the workgroups a
+  // mode-cross launch should have at least, instead of Tuning::cross_target -- 512 / chunks, so
+  // that a call that has the chip to itself fills it once with shares of tiles (the
+  // AbacusSummit interpolator, one chunk: 242 -> 200 us per 10^4 draws host to host; its single
+  // table, two chunks: 149 -> 139; pipelined launches keep 160: they share the chip anyway).
+  int sync_cross_target = 0;
   bool quad = false;
   tc::QuadTiling quad_tiling;
   tc::host::QuadTable quad_by_type, quad_total;

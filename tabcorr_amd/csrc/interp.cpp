@@ -734,6 +734,7 @@ int interp_chunked(tc_interp* it, const double* theta, int n_theta, const double
   int64_t tickets[64];
   double* h_in = (double*)it->h_in.ptr;
   double* h_out = (double*)it->h_out.ptr;
+  it->tables[0]->sync_cross_target = 512 / n_chunks;       // (internal.h)
   for (int k = 0; k < n_chunks && status == TC_OK; ++k) {
     const int64_t begin = k * chunk, n = std::min(chunk, n_draws - begin);
     double* in = h_in + begin * in_cols;          // [theta | x] of the chunk
@@ -744,6 +745,7 @@ int interp_chunked(tc_interp* it, const double* theta, int n_theta, const double
                           out, out + n * ngal_cols, false, &tickets[k], true);
     if (status != TC_OK) n_chunks = k;
   }
+  it->tables[0]->sync_cross_target = 0;
   for (int k = 0; k < n_chunks; ++k) {
     const int64_t begin = k * chunk, n = std::min(chunk, n_draws - begin);
     const int waited = tc_interp_wait(it, tickets[k]);

@@ -1734,6 +1734,8 @@ int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs
   // bins, so few tiles leave most CUs idle -- several workgroups per tile, each with a share of
   // the groups (by cost: a node of the centrals ~21 instructions, of the satellites ~33), the
   // last to arrive adds the shares.  About two workgroups per CU over four lanes in flight.
+  const int cross_target =
+      t0->sync_cross_target > 0 ? t0->sync_cross_target : t0->tuning.cross_target;
   int n_splits = 1;
   if (cf.rows <= tc::kCrossSmallRows) {
     // (tools/r04_cross_splits.py, AbacusSummit table, us per call, one workgroup per tile /
@@ -1741,7 +1743,7 @@ int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs
     // 8192 47.7, 10^4 59.0 -- from ~120 tiles on a second workgroup per tile only costs)
     n_splits = (int)std::min<int64_t>(
         tc::kCrossMaxSplits,
-        std::max<int64_t>(1, (2 * t0->tuning.cross_target + n_tiles) / (2 * n_tiles)));
+        std::max<int64_t>(1, (2 * cross_target + n_tiles) / (2 * n_tiles)));
     const int n_cen = ca.n_central_groups, n_sat = ca.n_groups - ca.n_central_groups;
     n_splits = std::max(1, std::min(n_splits, std::min(std::max(n_cen, 1), std::max(n_sat, 1))));
     const double cost_cen = 21.0, cost_sat = 33.0;
@@ -1775,7 +1777,7 @@ int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs
     // evaluation, per member bin its row FMAs)
     n_splits = (int)std::min<int64_t>(
         tc::kCrossMaxSplits,
-        std::max<int64_t>(1, (2 * t0->tuning.cross_target + n_tiles) / (2 * n_tiles)));
+        std::max<int64_t>(1, (2 * cross_target + n_tiles) / (2 * n_tiles)));
     n_splits = std::max(1, std::min(n_splits, cf.n_chunks));
     if (n_splits > 1) {
       const tc::NodeGroups& groups = t0->node_groups;

@@ -585,6 +585,9 @@ int predict_chunked(tc_table* t, const double* theta, int n_theta, int64_t n_dra
   double* h_out = (double*)t->h_out.ptr;
   // (one form for every chunk size: the one-launch form with sync_form draws per workgroup
   // wherever it serves the table at all, not only from the batch size on where it pays)
+  // (mode cross: the workgroups of ALL chunks together should fill the chip once -- see
+  // tc_table::sync_cross_target)
+  t->sync_cross_target = 512 / n_chunks;
   const int saved_draws = t->tuning.fused_draws, saved_min = t->tuning.fused_min_draws;
   if (t->tuning.sync_form != 0 && saved_draws == 0 && t->tuning.fused == 1) {
     t->tuning.fused_draws = t->tuning.sync_form;
@@ -601,6 +604,7 @@ int predict_chunked(tc_table* t, const double* theta, int n_theta, int64_t n_dra
   }
   t->tuning.fused_draws = saved_draws;
   t->tuning.fused_min_draws = saved_min;
+  t->sync_cross_target = 0;
   for (int k = 0; k < n_chunks; ++k) {
     const int64_t begin = k * chunk, n = std::min(chunk, n_draws - begin);
     const int waited = tc_table_wait(t, tickets[k]);
