@@ -545,7 +545,7 @@ def main():
 
         three_kernel_name = ('tc::contract_quad_kernel<5, true>' if interp_mode
                              else 'tc::contract_quad_kernel<5, false>')
-        kernel_name = ('tc::predict_fused_kernel<10, 5, false, false, false, 8, 64, false, true>'
+        kernel_name = ('tc::predict_fused_kernel<10, 5, false, false, false, 8, 64, false, 2>'
                        if fused_active else three_kernel_name)
         headline_traffic = (pmc_traffic(kernel_name, 'interp5x5' if interp_mode else '')
                             if n_draws == (100000 if interp_mode else 10000) // (

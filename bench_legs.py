@@ -561,7 +561,7 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
                 cpu_rate(lambda i: oracle.predict_zheng07(
                     table3, theta7[i % 10000, :5], separate_gal_type=True,
                     assembias=theta7[i % 10000, 5:], cache=cache3)), parity3,
-                fused_kernel='tc::predict_fused_kernel<10, 5, true, false, false, 8, 32, true, false>')
+                fused_kernel='tc::predict_fused_kernel<10, 5, true, false, false, 8, 32, true, 0>')
         del tab3
 
     # configs[3]: one GPU's share (12 500 draws) of the 5 x 5 interpolator
@@ -708,7 +708,7 @@ def other_configs(lib, _lib, make, synthetic, Interpolator, cpu_seconds, only=No
                 FP64_PEAK_TFLOPS, 'tc::contract_quad_kernel<5, false>', 'f64',
                 cpu_rate(lambda i: oracle.predict_zheng07(table_wp, theta[i % 10000],
                                                           cache=cache_wp)), parity_wp,
-                fused_kernel='tc::predict_fused_kernel<10, 5, false, false, false, 8, 64, false, true>')
+                fused_kernel='tc::predict_fused_kernel<10, 5, false, false, false, 8, 64, false, 1>')
         del tab_wp
 
     # the layout of the reference's database (scripts/tabulate_snapshot.py:179-193: 30 mass bins x

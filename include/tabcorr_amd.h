@@ -354,7 +354,7 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 them with its own weights (Zheng07 family, n_gauss_prim = 10).  No effect on
  *                 tables without such bins.  0: every bin by itself (same occupations per bin
  *                 to the last bit; sums over bins may differ in the last bits).
- *   "fused_defer" 1 (default): pipelined / asynchronous batches of undecorated Zheng07
+ *   "fused_defer" 2 (default) / 1: pipelined / asynchronous batches of undecorated Zheng07
  *                 predictions with n_gauss_prim = 10 that take the one-launch form with 64-draw
  *                 workgroups evaluate a satellite bin by its binomial expansion for the draws
  *                 the bin's SHORTEST expansion serves (csrc/series.h; the same number of terms
@@ -363,7 +363,11 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 expansion (bins up to ~0.2 dex wide), unless "series" is 0.  BASELINE
  *                 configs[1] 39.2 -> 37.5 us per 10^4 draws, the reference's example table 18.2 ->
  *                 17.5.  What a draw defers depends on the draw alone: same bits wherever it
- *                 sits in whatever batch.  0: the satellites' node loops in place.
+ *                 sits in whatever batch.  2: where the centrals take their expansion
+ *                 (option "series"), a central bin comes from one record as well and the draws
+ *                 no expansion serves (sigma_logM below about a tenth of a bin width, parameters
+ *                 to fix up) join the deferred pairs: the node loops of BOTH galaxy types leave
+ *                 the loop of bins (configs[1] 37.8 -> 37.2 us).  0: the node loops in place.
  *   "cross_wide_min_draws"  default 4096.  Mode cross (tpcf_matrix with one column per halo
  *                 bin), tables or interpolators of up to 16 result rows whose node groups have
  *                 at most two members: undecorated batches of this many draws take the one-launch

@@ -335,6 +335,23 @@ void group_record(bool central, const double* consts_i, const double* consts_j,
 
 }  // namespace record
 
+namespace cen_record {
+
+void bin_record(const double* consts, const int32_t* thresholds, double weight_sum,
+                const double* log_m, int n_gauss, double* out) {
+  for (int i = 0; i < kStride; ++i) out[i] = 0.0;
+  int32_t head[6] = {0, 0, 0, 0, 0, 0};
+  for (int s = 0; s < series::kSteps; ++s) head[s] = thresholds[s];
+  std::memcpy(out, head, sizeof(head));
+  out[kLow] = log_m[0];
+  out[kHigh] = log_m[n_gauss - 1];
+  out[kCentre] = consts[0];
+  out[kSum] = weight_sum;
+  for (int n = 0; n < series::kMaxTerms; ++n) out[kHead + n] = consts[series::kFirst + n];
+}
+
+}  // namespace cen_record
+
 namespace sat_record {
 
 void bin_record(const double* consts, const int32_t* thresholds, const double* mass, int n_gauss,

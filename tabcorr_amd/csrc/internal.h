@@ -197,6 +197,7 @@ struct Quadrature {
   void* sat_series_thr = nullptr;
   void* group_sat_series = nullptr;
   void* group_sat_series_thr = nullptr;
+  void* cen_records = nullptr;         // series.h, namespace cen_record (central bins)
   void* sat_records = nullptr;         // series.h, namespace sat_record (satellite bins)
   void* group_records = nullptr;       // series.h, namespace record (groups of <= 2 members)
 };
@@ -334,7 +335,8 @@ struct Tuning {
   // the batch), and a wave runs the node loop as well wherever one of its draws needs it.
   int series = -1;
   int cross_defer = 1;          // mode cross, one launch: deferred (group, draw) pairs (kernel_args.h)
-  int fused_defer = 1;          // predict_fused_kernel: satellites' expansion + deferred pairs
+  int fused_defer = 2;          // predict_fused_kernel: 1 the satellites' expansion + deferred
+                                // pairs, 2 the centrals' likewise (where their expansion is on)
   int fused_sat_cap = 6;        // ... in place up to 12 + 4 x this many terms (0 .. 5), or
                                 // 6 = series::sat::kShortest: the shortest that serves the bin
   int cross_wide_min_draws = 4096;   // launch.hip: choose_cross_fused (0: never the wide form)

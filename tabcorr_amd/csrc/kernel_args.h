@@ -366,6 +366,7 @@ struct FusedArgs {
   const int32_t* sat_series_thr;
   int sat_cap;                 // SATDEFER: longest expansion in place = 12 + 4 sat_cap terms
   const double* sat_records;   // SATDEFER: series.h, namespace sat_record, by library bin
+  const double* cen_records;   // SATDEFER = 2: series.h, namespace cen_record, per central bin
 };
 
 // ---- mode cross, one launch per batch (predict_cross_fused_kernel, kernels.hip.h) ----------

@@ -336,6 +336,73 @@ __device__ __forceinline__ double occ_bin_zheng07(const double* table, const fm:
   return acc;
 }
 
+// An undecorated central bin of predict_fused_kernel's instance that defers the centrals too,
+// from its record (series.h, namespace cen_record): plateau nodes, thresholds, centre, m_0 and
+// all 24 moments with one round trip of scalar loads; a lane adds the passes ITS draw asks for
+// (the arithmetic of series::central_sum).  *deferred where no expansion serves the draw.
+__device__ __forceinline__ double occ_cen_record(const double* table, const fm::Consts& kc,
+                                                 sc_f64 rec, const DrawParams& d,
+                                                 bool* deferred) {
+  namespace record = series::cen_record;
+  series::record::f64x8_t head, m0, m1, m2;
+  record::load_record(rec, head, m0, m1, m2);
+  const double log_m_min = d.log_m_min, inv_sigma = d.inv_sigma;
+  const double weight_sum = head.v[record::kSum];
+#ifndef TC_NO_OCC_SHORTCUTS
+  if (!d.any_bad) {
+    const double z_a = (head.v[record::kLow] - log_m_min) * inv_sigma;
+    const double z_b = (head.v[record::kHigh] - log_m_min) * inv_sigma;
+    const double z_lo = z_a < z_b ? z_a : z_b, z_hi = z_a < z_b ? z_b : z_a;
+    if (__builtin_amdgcn_ballot_w64(!(z_lo >= 6.0)) == 0) return weight_sum;
+    if (__builtin_amdgcn_ballot_w64(!(z_hi <= -6.0)) == 0) return 0.0;
+  }
+#endif
+  const series::Thresholds limit = series::record::thresholds_of(head);
+  double acc = 0.0;
+  if (d.inv_sigma_hi < limit.v[series::kSteps - 1]) {
+    const int n_blocks = series::passes<series::kSteps>(limit, d.inv_sigma_hi, 2);
+    double g0, z0;
+    const double e = fm::erf_gauss_fast(
+        table, kc, (head.v[record::kCentre] - log_m_min) * inv_sigma, &g0, &z0);
+    const double a = 2.0 * z0 * inv_sigma;
+    // (b through a value the optimiser cannot see through: the multiples n b of all 24 unrolled
+    // terms would otherwise be formed once per draw, outside the loop of bins, and held in
+    // registers across it -- 129 of them in all)
+    double b = -2.0 * inv_sigma * inv_sigma;
+    asm volatile("" : "+v"(b));
+    double p_prev = 0.0, p = inv_sigma, nb = -b, sum = 0.0;
+    auto term = [&](double moment) {
+      sum = fma(p, moment, sum);
+      nb += b;
+      const double next = fma(a, p, nb * p_prev);
+      p_prev = p;
+      p = next;
+    };
+#pragma unroll
+    for (int k = 0; k < 8; ++k) term(m0.v[k]);
+    if (n_blocks > 2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) term(m1.v[k]);
+      if (n_blocks > 3) {
+#pragma unroll
+        for (int k = 4; k < 8; ++k) term(m1.v[k]);
+        if (n_blocks > 4) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) term(m2.v[k]);
+          if (n_blocks > 5) {
+#pragma unroll
+            for (int k = 4; k < 8; ++k) term(m2.v[k]);
+          }
+        }
+      }
+    }
+    acc = fma(0.5, fma(g0, sum, weight_sum * e), 0.5 * weight_sum);
+  } else {
+    *deferred = true;
+  }
+  return acc;
+}
+
 // An undecorated satellite bin of predict_fused_kernel's deferring instance from its record
 // (series.h, namespace sat_record): head and the first sixteen moments with one round trip of
 // scalar loads.  In place only the draws the bin's SHORTEST expansion serves (the same number
@@ -2213,11 +2280,14 @@ __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, uns
 }
 
 template <int NGAUSS, int U, bool ASSEMBIAS, bool MODULATE, bool LEAUTHAUD = false,
-          int W = kFusedWaves, int DL = 64, bool GROUPED = false, bool SATDEFER = false>
-__global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(FusedArgs a) {
+          int W = kFusedWaves, int DL = 64, bool GROUPED = false, int SATDEFER = 0>
+__global__ __launch_bounds__(64 * W, W == 8 ? (SATDEFER == 2 ? 4 : 2) : 1) void predict_fused_kernel(
+    FusedArgs a) {
   // SATDEFER (round 5; undecorated Zheng07, ten nodes, 64 draws): the satellites' expansion for
   // the lanes it serves, and the (bin, draw) pairs it does not serve evaluated after the
-  // wave's bins, 64 pairs per pass of the node loop -- see "deferred pairs" below
+  // wave's bins, 64 pairs per pass of the node loop -- see "deferred pairs" below.  2: the
+  // central bins likewise (records, the centrals no expansion serves deferred: the node loop of
+  // the centrals leaves the loop of bins as well)
   static_assert(!SATDEFER || (NGAUSS == 10 && !ASSEMBIAS && !MODULATE && !LEAUTHAUD && DL == 64 &&
                               !GROUPED), "deferred pairs");
   // GROUPED: the waves stride over the groups of bins that share their nodes (occ_group_zheng07)
@@ -2326,7 +2396,11 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
       const bool above = ASSEMBIAS ? percentile[g] > a.split : false;
       bool deferred = false;
       const double acc =
-          SATDEFER && !central && a.sat_cap == series::sat::kShortest
+          SATDEFER == 2 && central
+              ? occ_cen_record(table, kc,
+                               (sc_f64)a.cen_records + g * series::cen_record::kStride, dp,
+                               &deferred) :
+          SATDEFER && !central && (SATDEFER == 2 || a.sat_cap == series::sat::kShortest)
               ? occ_sat_record(table, kc,
                                (sc_f64)a.sat_records + g * series::sat_record::kStride, dp,
                                &deferred) :
@@ -2386,7 +2460,35 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
         const double alpha = __shfl(dp.alpha, from, 64);
         const int bad = __shfl(dp.bad, from, 64);
         double acc = 0.0;
+        const bool cen_pair = SATDEFER == 2 && g < a.n_central;
+        if (SATDEFER == 2 && __builtin_amdgcn_ballot_w64(active && cen_pair) != 0) {
+          // (pairs of centrals: draws no expansion serves -- a step-like sigma_logM, parameters
+          // to fix up; occ_nodes_zheng07's arithmetic)
+          const double log_m_min = __shfl(dp.log_m_min, from, 64);
+          const double inv_sigma = __shfl(dp.inv_sigma, from, 64);
+          double sum = 0.0;
+          bool tie = false;
+#pragma unroll 1
+          for (int k0 = 0; k0 < 10; k0 += 5) {
+            double node[5], w[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+              node[k] = a.log_m[g * 10 + k0 + k];
+              w[k] = a.weight[g * 10 + k0 + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+              sum = fma(w[k], fm::erf_fast(table, kc, (node[k] - log_m_min) * inv_sigma), sum);
+              tie = tie || node[k] == log_m_min;
+            }
+          }
+          sum = fma(0.5, sum, 0.5 * a.weight[a.n_bins * 10 + g]);
+          if ((bad & kBadCen) || ((bad & kTieCen) && tie)) sum = __builtin_nan("");
+          if (cen_pair) acc = sum;
+        }
         // (five nodes at a time: their constants requested together, then evaluated)
+        if (SATDEFER != 2 || __builtin_amdgcn_ballot_w64(active && !cen_pair) != 0) {
+        double sat = 0.0;
 #pragma unroll 1
         for (int k0 = 0; k0 < 10; k0 += 5) {
           double node[5], w[5];
@@ -2398,23 +2500,29 @@ __global__ __launch_bounds__(64 * W, W == 8 ? 2 : 1) void predict_fused_kernel(F
 #pragma unroll
           for (int k = 0; k < 5; ++k) {
             const double x = node[k] - m0;
-            acc = fma(w[k],
+            sat = fma(w[k],
                       fm::exp2_fast(table, kc,
                                     alpha * fm::log2_fast_offset(
                                                 table, kc, x > 1e-300 ? x : 1e-300, log2_m1),
                                     x > 0.0),
-                      acc);
+                      sat);
           }
         }
-        acc *= sat_scale;
+        sat *= sat_scale;
         if (bad != 0) {           // (occ_nodes_zheng07's fix-ups of an undecorated satellite bin)
-          if ((bad & kInfSat) && acc != 0.0) acc = __builtin_huge_val();
-          if ((bad & kBadSat) && acc != 0.0) acc = __builtin_nan("");
+          if ((bad & kInfSat) && sat != 0.0) sat = __builtin_huge_val();
+          if ((bad & kBadSat) && sat != 0.0) sat = __builtin_nan("");
+        }
+        if (!cen_pair) acc = sat;
         }
         if (active) dens[g * DL + from] = acc * a.n_h[g];
       }
       for (int j = 0; j < n_mine; ++j)
-        if ((mine >> j) & 1u) sum_sat += dens[(wave + W * j) * DL + draw];
+        if ((mine >> j) & 1u) {
+          const double value = dens[(wave + W * j) * DL + draw];
+          if (SATDEFER == 2 && wave + W * j < a.n_central) sum_cen += value;
+          else sum_sat += value;
+        }
     }
     red[0][wave][lane] = sum_cen;
     red[1][wave][lane] = sum_sat;

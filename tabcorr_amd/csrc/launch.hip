@@ -63,6 +63,17 @@ int get_quadrature(tc_table* t, int n_gauss, Quadrature** out) {
                            series_thr.data() + (size_t)i * tc::series::kThresholds);
   if (status == TC_OK) status = upload(series, &q.series);
   if (status == TC_OK) status = upload(series_thr, &q.series_thr);
+  if (n_gauss >= 4 && t->plan.n_central > 0) {
+    // ... and a central bin's constants in one record (series.h, namespace cen_record)
+    namespace rec = tc::series::cen_record;
+    std::vector<double> records((size_t)t->plan.n_central * rec::kStride);
+    for (int i = 0; i < t->plan.n_central; ++i)
+      rec::bin_record(series.data() + (size_t)i * tc::series::kStride,
+                      series_thr.data() + (size_t)i * tc::series::kThresholds,
+                      weight[(size_t)g * n_gauss + i], log_m.data() + (size_t)i * n_gauss,
+                      n_gauss, records.data() + (size_t)i * rec::kStride);
+    if (status == TC_OK) status = upload(records, &q.cen_records);
+  }
   std::vector<double> sat_series((size_t)g * tc::series::sat::kStride + tc::series::kPad);
   std::vector<int32_t> sat_series_thr((size_t)g * tc::series::sat::kThresholds);
   for (int i = 0; i < g; ++i)
@@ -1240,7 +1251,7 @@ int fused_waves(const tc_table* t, bool separate, unsigned flags) {
 
 namespace {
 template <int NG, bool AB, bool MO, bool LE = false, int W = tc::kFusedWaves, int DL = 64,
-          bool GR = false, bool SD = false>
+          bool GR = false, int SD = 0>
 int launch_fused(int device, int n_u, dim3 grid, dim3 block, int lds, hipStream_t stream,
                  hipEvent_t k0, hipEvent_t k1, const tc::FusedArgs& fa) {
   switch (n_u) {
@@ -1378,6 +1389,11 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
                          q->sat_series != nullptr && q->sat_records != nullptr;
   if (sat_defer) fa.sat_series = (const double*)q->sat_series;
   fa.sat_records = (const double*)q->sat_records;
+  fa.cen_records = (const double*)q->cen_records;
+  // (both galaxy types by their records, the centrals no expansion serves deferred as well,
+  // where the centrals' expansion is on)
+  const bool cen_defer = sat_defer && t->tuning.fused_defer >= 2 && (series_mask(t) & 1) != 0 &&
+                         q->cen_records != nullptr;
   fa.sat_cap = t->tuning.fused_sat_cap;
 #define TC_FUSED(NG, AB, MO, LE)                                                              \
   (waves == 16 ? launch_fused<NG, AB, MO, LE, 16>(t->device, t->quad_tiling.n_u, grid, block,  \
@@ -1414,8 +1430,11 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
     status = modulate ? TC_FUSED(0, false, true, true) : TC_FUSED(0, false, false, true);
   else if (n_gauss != 10)
     status = TC_FUSED(0, false, false, false);
+  else if (!assembias && !modulate && cen_defer)
+    status = launch_fused<10, false, false, false, 8, 64, false, 2>(
+        t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
   else if (!assembias && !modulate && sat_defer)
-    status = launch_fused<10, false, false, false, 8, 64, false, true>(
+    status = launch_fused<10, false, false, false, 8, 64, false, 1>(
         t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
   else if (!assembias && !modulate)
     status = TC_FUSED(10, false, false, false);

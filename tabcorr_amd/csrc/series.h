@@ -438,6 +438,25 @@ TC_HD int members_of(bool central, const Thresholds& limit, const f64x8_t& head)
 }
 }  // namespace record
 
+// ... per CENTRAL bin, for predict_fused_kernel's instance that defers the centrals no expansion
+// serves as well: 32 doubles = four 64-byte lines, ALL of which one batch of loads brings --
+//   [0, 3)  int32 x 5: thresholds   [3] log10 M of the first node   [4] centre   [5] m_0
+//   [7]     log10 M of the last node          [8 + n)  moment n + 1 of 24
+namespace cen_record {
+constexpr int kHead = 8;
+constexpr int kStride = kHead + series::kMaxTerms;      // 32 doubles
+constexpr int kLow = 3, kCentre = 4, kSum = 5, kHigh = 7;
+
+template <typename Ptr>
+TC_HD void load_record(Ptr rec, record::f64x8_t& head, record::f64x8_t& m0, record::f64x8_t& m1,
+                       record::f64x8_t& m2) {
+  record::load_record(rec, head, m0, m1, m2);     // (the same four 64-byte lines)
+}
+
+void bin_record(const double* consts, const int32_t* thresholds, double weight_sum,
+                const double* log_m, int n_gauss, double* out);
+}  // namespace cen_record
+
 // ... and per satellite BIN, for predict_fused_kernel's deferring instance: kStride doubles,
 // 64-byte aligned --
 //   [0, 3)  int32 x 6: thresholds; [3] as int32 x 2: thresholds[kShortest], passes of the

@@ -248,7 +248,7 @@ int tc_table_destroy(tc_table* t) {
                     kv.second.group_m, kv.second.group_weight, kv.second.series,
                     kv.second.series_thr, kv.second.group_series, kv.second.group_series_thr,
                     kv.second.sat_series, kv.second.sat_series_thr, kv.second.group_sat_series,
-                    kv.second.group_sat_series_thr, kv.second.group_records, kv.second.sat_records})
+                    kv.second.group_sat_series_thr, kv.second.group_records, kv.second.sat_records, kv.second.cen_records})
       if (p) (void)hipFree(p);
   for (auto& kv : t->chunkings)
     for (void* p : {kv.second->chunks, kv.second->groups})
@@ -1250,7 +1250,8 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     t->tuning.cross_defer = value != 0;
   } else if (key == "fused_defer") {
     // developer A/B: 0 = predict_fused_kernel runs the satellites' node loops in place
-    t->tuning.fused_defer = value != 0;
+    TC_CHECK(value >= 0 && value <= 2, "fused_defer must be 0, 1 or 2");
+    t->tuning.fused_defer = value;
   } else if (key == "fused_sat_cap") {
     TC_CHECK(value >= 0 && value <= 6, "fused_sat_cap must be in [0, 6]");
     t->tuning.fused_sat_cap = value;

@@ -829,7 +829,7 @@ def test_satellites_by_expansion_with_deferred_pairs():
     set_option(halotab, 'fused_draws', 64)
     set_option(halotab, 'series', 1)
     results = {}
-    for defer in (1, 0):
+    for defer in (2, 1, 0):
         set_option(halotab, 'fused_defer', defer)
         for separate in (False, True):
             results[defer, separate] = halotab.predict_batch(theta, separate_gal_type=separate)
@@ -838,7 +838,15 @@ def test_satellites_by_expansion_with_deferred_pairs():
         warnings.simplefilter('ignore')
         expect = oracle.predict_zheng07_batch(table, theta)
         expect_sep = oracle.predict_zheng07_batch(table, theta, separate_gal_type=True)
-    ngal, xi = results[1, False]
+    # (2, the default: the centrals by their records as well, those no expansion serves -- the
+    # step-like sigma_logM, the draws to fix up -- among the deferred pairs; 1: the satellites only)
+    for defer in (1, 2):
+        ngal, xi = results[defer, False]
+        good = np.isfinite(expect[0])
+        assert np.array_equal(np.isnan(ngal), np.isnan(expect[0]))
+        assert_rel(ngal[good], expect[0][good], 1e-12)
+        assert_rel(xi[good], expect[1][good], 1e-11)
+    ngal, xi = results[2, False]
     finite = np.isfinite(expect[0])
     assert np.array_equal(np.isnan(ngal), np.isnan(expect[0]))
     assert np.array_equal(np.isinf(ngal), np.isinf(expect[0]))
@@ -848,12 +856,12 @@ def test_satellites_by_expansion_with_deferred_pairs():
     assert_rel(xi[finite], results[0, False][1][finite], 1e-12)
     for key in expect_sep[0]:
         good = np.isfinite(expect_sep[0][key]) & finite
-        assert_rel(results[1, True][0][key][good], expect_sep[0][key][good], 1e-12)
+        assert_rel(results[2, True][0][key][good], expect_sep[0][key][good], 1e-12)
     for key in expect_sep[1]:
-        assert_rel(results[1, True][1][key][finite], expect_sep[1][key][finite], 1e-11,
+        assert_rel(results[2, True][1][key][finite], expect_sep[1][key][finite], 1e-11,
                    floor=1e-13)
     # the same bits wherever the draw sits, whatever its neighbours defer
-    set_option(halotab, 'fused_defer', 1)
+    set_option(halotab, 'fused_defer', 2)
     order = rng.permutation(n)
     ngal_p, xi_p = halotab.predict_batch(theta[order][:777])
     assert np.array_equal(ngal_p, ngal[order][:777], equal_nan=True)
