@@ -8,10 +8,11 @@ mkdir -p gpurun_out
 {
   echo "== headline (BASELINE configs[1], sustained): round-4 library / final"
   python tools/ab_bench.py --rounds 2 r04=tools/ab/libtabcorr_hip_r04.so final=tree | tail -2
-  echo "== headline: node loops of the satellites in place / expansion up to 12 + 4 cap terms in place (no records) / the bin's shortest from its record (default)"
-  python tools/ab_bench.py --rounds 2 nodefer=tree,fused_defer=0 cap5=tree,fused_sat_cap=5 \
-    cap4=tree,fused_sat_cap=4 cap3=tree,fused_sat_cap=3 cap2=tree,fused_sat_cap=2 \
-    cap1=tree,fused_sat_cap=1 default=tree | tail -7
+  echo "== headline: node loops in place / satellites: expansion up to 12 + 4 cap terms in place (no records) / the bin's shortest from its record / the centrals from records too (default)"
+  python tools/ab_bench.py --rounds 2 nodefer=tree,fused_defer=0 cap5=tree,fused_defer=1,fused_sat_cap=5 \
+    cap4=tree,fused_defer=1,fused_sat_cap=4 cap3=tree,fused_defer=1,fused_sat_cap=3 \
+    cap2=tree,fused_defer=1,fused_sat_cap=2 cap1=tree,fused_defer=1,fused_sat_cap=1 \
+    sats=tree,fused_defer=1 default=tree | tail -8
   for tag in ds4 ds1 wp cfg3; do
     echo "== $tag: round-4 library / final"
     python tools/ab_bench.py --rounds 2 --args "--only-config $tag --cpu-seconds 0 --detail 0" \
