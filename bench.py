@@ -389,17 +389,6 @@ def main():
             flush(count)
             drain()
         settle_steps += probe
-    # (the library measures which form serves which batch size at its 256th pipelined call
-    # with these flags -- option "autotune_after", half a second once: that call must not fall
-    # into the timed region of a short run with a short settling phase)
-    untimed = settle_steps + args.warmup
-    if not interp_mode and untimed < 320:
-        extra = 320 - untimed
-        for index in range(extra):
-            step(index)
-        flush(extra)
-        drain()
-        settle_steps += extra
     for index in range(args.warmup):
         step(index)
     flush(args.warmup)

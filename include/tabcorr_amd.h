@@ -326,11 +326,15 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 calls with these flags then take the measured form of the nearest batch size
  *                 instead of the built-in estimate (fitted on a handful of table shapes).  -1:
  *                 forget every measurement.  tc_table_autotune_result reads it back.
- *   "autotune_after"  default 256: the N-th pipelined device-pointer or asynchronous call
- *                 with one combination of predict flags (tables the one-launch forms can serve)
- *                 runs "autotune" for that combination by itself -- about half a second, once
- *                 -- so that a loop of calls gets the measured form without asking; the
- *                 built-in estimate serves the calls before it.  0: never.
+ *   "autotune_after"  default 0 = never (round 6; it was 256 in round 5).  N > 0: the N-th
+ *                 pipelined device-pointer or asynchronous call with one combination of predict
+ *                 flags (tables the one-launch forms can serve) runs "autotune" for that
+ *                 combination by itself -- that call BLOCKS for about half a second, once, and
+ *                 every lane is synchronised -- so that a loop of calls gets the measured form
+ *                 without asking; the built-in estimate serves the calls before it.  The
+ *                 measured choice depends on wall-clock timings: the last bits of a draw may
+ *                 differ before and after that call and from run to run, which is why it is
+ *                 opt-in (and refused while "deterministic" is set).
  *   "series"      bit mask; default -1 = by the table: bit 0 for tables whose widest central
  *                 bin is at most 0.1 dex (with wider bins nearly every wavefront of a wide prior
  *                 holds a draw whose sigma_logM is below a bin width and runs the expansion AND

@@ -16,10 +16,13 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBRARY = os.path.join(HERE, 'libtabcorr_hip.so')
-# launch.hip (prediction) and paircount.hip (tabulation) hold the device code; the other
-# units are host-only C++
-SOURCES = ['launch.hip', 'paircount.hip', 'table.cpp', 'interp.cpp', 'comm.cpp',
-           'runtime.cpp', 'hostmath.cpp']
+# inst_*.hip hold the kernel instances of the prediction path (one unit per kernel family: they
+# compile in parallel, the longest first), paircount.hip the tabulation kernels; launch.hip and
+# the .cpp units are host code
+SOURCES = ['inst_fused.hip', 'inst_fused32.hip', 'inst_fused16.hip', 'inst_cross.hip',
+           'inst_quad.hip', 'inst_single.hip', 'launch.hip', 'paircount.hip', 'table.cpp', 'interp.cpp', 'comm.cpp', 'runtime.cpp', 'hostmath.cpp']
+# per-unit flags (inst_single.hip: see its header)
+EXTRA_FLAGS = {'inst_single.hip': ['-ffp-contract=on']}
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-gpu-rdc',
          '-Wall', '-Wno-unused-function']
 
@@ -30,6 +33,31 @@ def hipcc():
         if candidate and os.path.exists(candidate):
             return candidate
     raise RuntimeError('hipcc not found; set HIPCC')
+
+
+def device_units():
+    """The translation units that hold kernels of the prediction path."""
+    return [f for f in SOURCES if f.startswith('inst_')]
+
+
+def kernel_resource_remarks():
+    """hipcc's kernel-resource-usage remarks (registers, spills, scratch, LDS per kernel) of
+    every device unit of the prediction path, as one text (tools/kernel_resources.py parses
+    it).  Compiles the units in parallel into a scratch directory."""
+    compiler = hipcc()
+
+    def remarks(unit):
+        with tempfile.TemporaryDirectory(prefix='tabcorr_amd_remarks_') as tmp:
+            out = subprocess.run(
+                [compiler] + FLAGS + EXTRA_FLAGS.get(unit, []) +
+                ['-Rpass-analysis=kernel-resource-usage', '-c', os.path.join(CSRC, unit), '-o',
+                 os.path.join(tmp, 'unit.o')], capture_output=True, text=True)
+        if out.returncode != 0:
+            raise RuntimeError('%s does not compile: %s' % (unit, out.stderr[-2000:]))
+        return out.stderr
+
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        return '\n'.join(pool.map(remarks, device_units()))
 
 
 def dependencies():
@@ -60,9 +88,10 @@ def build(force=False, verbose=False):
     with tempfile.TemporaryDirectory(prefix='tabcorr_amd_build_') as tmp:
         objects = [os.path.join(tmp, os.path.splitext(f)[0] + '.o')
                    for f in SOURCES]
-        commands = [[compiler] + FLAGS + ['-c', os.path.join(CSRC, f), '-o', o]
+        commands = [[compiler] + FLAGS + EXTRA_FLAGS.get(f, []) +
+                    ['-c', os.path.join(CSRC, f), '-o', o]
                     for f, o in zip(SOURCES, objects)]
-        with ThreadPoolExecutor(max_workers=min(4, len(commands))) as pool:
+        with ThreadPoolExecutor(max_workers=min(8, len(commands))) as pool:
             list(pool.map(run, commands))
         # bind every HIP symbol at load time to the ROCm runtime this library
         # was linked against, even if another copy is loaded later

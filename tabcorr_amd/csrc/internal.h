@@ -310,8 +310,11 @@ struct Tuning {
   // result does not depend on the number of chunks; 0: whatever a pipelined call of the chunk's
   // size would take); sync_direct_out as async_direct_out, for the staging area of the chunks
   // the dispatch measures itself (option "autotune") at this many pipelined / asynchronous
-  // calls with one combination of predict flags (0: never by itself)
-  int autotune_after = 256;
+  // calls with one combination of predict flags; 0 (default since round 6): never by itself --
+  // the measurement stalls a call documented as non-blocking for ~0.5 s and its outcome comes
+  // from wall-clock timings, so the same draws could return different last bits before and
+  // after it and from run to run: TabCorr.autotune() asks for it explicitly
+  int autotune_after = 0;
   int sync_chunks = 0;
   int sync_form = 32;
   int sync_direct_out = 2;
@@ -717,6 +720,33 @@ int launch_occ_from_array(tc_table* t, const double* occupation_device, int64_t 
                           int64_t ldb, double* nbuf, double* ngal2, hipStream_t stream);
 int launch_chi2(const double* xi, int64_t n_draws, int n_r, const double* data,
                 const double* precision, double* chi2, hipStream_t stream);
+
+// ---- kernel instances (inst_quad.hip, inst_fused.hip, inst_cross.hip, inst_single.hip) ----
+// The device code lives in these translation units; launch.hip fills the argument blocks and
+// says which instance it wants.
+int launch_occupation(const tc::OccArgs& oa, unsigned flags, int n_gauss, bool grouped,
+                      int64_t grid_blocks, hipStream_t stream);
+int launch_occ_from_array_kernel(const double* occupation_device, int64_t n_draws, int64_t ldb,
+                                 int n_bins, int n_central, const double* n_h,
+                                 const int32_t* perm, double* nbuf, double* ngal2, float* nbuf32,
+                                 hipStream_t stream);
+// predict_fused_kernel<n_gauss, U, assembias, modulate, leauthaud, waves, draws, grouped, defer>
+struct FusedInstance {
+  int n_gauss = 10;          // 10, or 0 = any number of nodes
+  bool assembias = false, modulate = false, leauthaud = false, grouped = false;
+  int waves = 8, draws = 64; // 8 x 64, 16 x 64, 8 x 32
+  int defer = 0;             // SATDEFER (8 x 64, undecorated Zheng07, ten nodes)
+};
+int launch_fused_instance(const FusedInstance& instance, int device, int n_u, dim3 grid,
+                          dim3 block, int lds, hipStream_t stream, hipEvent_t k0, hipEvent_t k1,
+                          const tc::FusedArgs& fa);
+int launch_cross_instance(bool assembias, bool modulate, bool defer, int device, int rows,
+                          dim3 grid, dim3 block, int lds, hipStream_t stream, hipEvent_t k0,
+                          hipEvent_t k1, const tc::CrossFusedArgs& ca);
+int launch_single_kernel(int blocks, hipStream_t stream, const tc::SingleArgs& sa);
+int launch_resident_kernel(int blocks, hipStream_t stream, const tc::SingleArgs& sa);
+int launch_ensemble_kernel(int device, int grid, int lds_bytes, hipStream_t stream,
+                           const tc::EnsembleArgs& ea);
 
 // ---- staging (table.cpp) --------------------------------------------------------------
 int copy_in(PinnedBuffer* stage, void* device, const void* host, size_t bytes,

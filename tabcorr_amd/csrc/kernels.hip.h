@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_leauthaud11_kernel(Occ
 
 // Occupations supplied by the caller (the ndarray seam, tabcorr.py:616-623):
 // nbuf[g'][b] = occupation[b][perm[g']] * n_h[g'] and the two sums.
-__global__ __launch_bounds__(256) void occ_from_array_kernel(
+static __global__ __launch_bounds__(256) void occ_from_array_kernel(
     const double* occupation, int64_t n_draws, int64_t ldb, int n_bins,
     int n_central, const double* n_h, const int32_t* perm, double* nbuf,
     double* ngal, float* nbuf32) {
@@ -3785,14 +3785,14 @@ __device__ __forceinline__ void single_draw_body(SingleArgs a) {
   }
 }
 
-__global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs a) {
+static __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs a) {
   single_draw_body<false>(a);
 }
 
 // The same body, resident: one launch serves every un-batched call until the host says stop,
 // none has arrived for a.idle_ticks, or a.life_ticks have passed (SingleArgs, kernel_args.h).
 // One table, one draw per call (a.n_tables == 0, a.n_walkers == 0).
-__global__ __launch_bounds__(kSingleThreads) void resident_draw_kernel(SingleArgs a) {
+static __global__ __launch_bounds__(kSingleThreads) void resident_draw_kernel(SingleArgs a) {
   single_draw_body<true>(a);
 }
 
@@ -3818,7 +3818,7 @@ __device__ __forceinline__ void store_host(double* address, double value) {
 __device__ __forceinline__ void wait_stores() { __builtin_amdgcn_s_waitcnt(0x0f70); }  // vmcnt(0)
 }  // namespace ens
 
-__global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(EnsembleArgs a) {
+static __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(EnsembleArgs a) {
   // (512 threads: eight waves with 256 registers each keep the loads of a phase in flight
   // together; sixteen waves of 128 registers spilled and walked the LDS one read at a time)
   extern __shared__ __attribute__((aligned(16))) unsigned char ens_lds[];
@@ -3837,7 +3837,6 @@ __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(Ens
   __shared__ double s_totals[2];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
   const int c = b & 3, slice = b >> 2;
@@ -4468,7 +4467,7 @@ __global__ __launch_bounds__(512) void contract_f32_kernel(ContractArgs a) {
 // write the results in the reference's output order.  One block per draw tile;
 // reads are coalesced over draws, the transposition to the draw-major output
 // goes through LDS.
-__global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
+static __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
   __shared__ double tile[kFinalizeRows][kLanes + 1];
   __shared__ double part_sum[16][kLanes];
   __shared__ double norm_inv[kLanes];
@@ -4569,7 +4568,7 @@ __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
 // edge special-cased, out-of-range clamped to the outermost segment), divided by the
 // table's total pair weight so that the contraction can accumulate all tables into
 // one sum (interpolation is linear in the per-table xi); and the interpolated ngal.
-__global__ __launch_bounds__(64) void interp_coef_kernel(InterpArgs a) {
+static __global__ __launch_bounds__(64) void interp_coef_kernel(InterpArgs a) {
   __shared__ double weight[kMaxInterpDim][kMaxInterpAxis][kLanes];
   const int lane = threadIdx.x;
   const int64_t b0 = (int64_t)blockIdx.x * kLanes + lane;
@@ -4628,7 +4627,7 @@ __global__ __launch_bounds__(64) void interp_coef_kernel(InterpArgs a) {
 // in table order by one thread (deterministic).
 constexpr int kCoefSmallTables = 1024;
 
-__global__ __launch_bounds__(64) void interp_coef_small_kernel(InterpArgs a) {
+static __global__ __launch_bounds__(64) void interp_coef_small_kernel(InterpArgs a) {
   __shared__ double weight[kMaxInterpDim][kMaxInterpAxis];
   __shared__ double part_cen[kCoefSmallTables], part_sat[kCoefSmallTables];
   const int lane = threadIdx.x;
@@ -4689,7 +4688,7 @@ constexpr int kChi2DrawsPerBlock = 8;      // 256 threads; fewer when n_r is lar
 constexpr int kChi2LdsMatrix = 64;         // largest n_r whose precision matrix is staged
 constexpr int kChi2LdsBytes = 48 * 1024;
 
-__global__ __launch_bounds__(256) void chi2_kernel(const double* xi, int64_t n_draws,
+static __global__ __launch_bounds__(256) void chi2_kernel(const double* xi, int64_t n_draws,
                                                    int n_r, const double* data,
                                                    const double* precision,
                                                    double* chi2) {

@@ -1,6 +1,7 @@
-// Launch layer: the only translation unit that contains device code.  Chooses the
-// decomposition of a batch, fills the kernels' argument blocks and launches them on the
-// table's lanes (internal.h).
+// Launch layer: chooses the decomposition of a batch, fills the kernels' argument blocks and
+// hands them to the kernel instances, which live in translation units of their own
+// (inst_quad.hip: the three-kernel path, inst_fused.hip / inst_cross.hip: the one-launch forms,
+// inst_single.hip: un-batched calls; internal.h declares their entry points).
 #include <immintrin.h>
 
 #include <mutex>
@@ -551,106 +552,6 @@ int next_kernel_events(tc_table* t, hipEvent_t* start, hipEvent_t* stop) {
   return TC_OK;
 }
 
-int launch_contract_quad(int n_u, bool interp, const tc::QuadArgs& args, int lds_bytes,
-                         hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
-  const dim3 grid((unsigned)((args.n_waves + tc::kQuadWavesPerBlock - 1) /
-                             tc::kQuadWavesPerBlock));
-  const dim3 block(64 * tc::kQuadWavesPerBlock);
-  if (args.n_waves == 0) return TC_OK;
-  switch (n_u) {
-#define TC_CASE(N)                                                                          \
-  case N:                                                                                   \
-    if (interp)                                                                             \
-      hipExtLaunchKernelGGL((tc::contract_quad_kernel<N, true>), grid, block, lds_bytes,  \
-                            stream, start, stop, 0, args);                                \
-    else                                                                                    \
-      hipExtLaunchKernelGGL((tc::contract_quad_kernel<N, false>), grid, block, lds_bytes, \
-                            stream, start, stop, 0, args);                                \
-    break;
-    TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4) TC_CASE(5)
-#undef TC_CASE
-    default:
-      return fail(TC_ERR_UNSUPPORTED, "no kernel for %d r sub-tiles", n_u);
-  }
-  TC_HIP(hipGetLastError());
-  return TC_OK;
-}
-
-int launch_contract_quad_f32_interp(int n_u, const tc::QuadArgs& args, int lds_bytes,
-                                    hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
-  const dim3 grid((unsigned)((args.n_waves + tc::kQuadWavesPerBlock - 1) /
-                             tc::kQuadWavesPerBlock));
-  const dim3 block(64 * tc::kQuadWavesPerBlock);
-  if (args.n_waves == 0) return TC_OK;
-  switch (n_u) {
-#define TC_CASE(N)                                                                          \
-  case N:                                                                                   \
-    hipExtLaunchKernelGGL((tc::contract_quad_f32_kernel<N, true>), grid, block, lds_bytes, \
-                          stream, start, stop, 0, args);                                  \
-    break;
-    TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4)
-#undef TC_CASE
-    default:
-      return fail(TC_ERR_UNSUPPORTED, "no float32 kernel for %d r sub-tiles", n_u);
-  }
-  TC_HIP(hipGetLastError());
-  return TC_OK;
-}
-
-int launch_contract_quad_f32(int n_u, const tc::QuadArgs& args, int lds_bytes,
-                             hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
-  const dim3 grid((unsigned)((args.n_waves + tc::kQuadWavesPerBlock - 1) /
-                             tc::kQuadWavesPerBlock));
-  const dim3 block(64 * tc::kQuadWavesPerBlock);
-  if (args.n_waves == 0) return TC_OK;
-  switch (n_u) {
-#define TC_CASE(N)                                                                        \
-  case N:                                                                                 \
-    hipExtLaunchKernelGGL((tc::contract_quad_f32_kernel<N, false>), grid, block,          \
-                          lds_bytes,                                                      \
-                          stream, start, stop, 0, args);                                  \
-    break;
-    TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4)
-#undef TC_CASE
-    default:
-      return fail(TC_ERR_UNSUPPORTED, "no float32 kernel for %d r sub-tiles", n_u);
-  }
-  TC_HIP(hipGetLastError());
-  return TC_OK;
-}
-
-int launch_finalize_quad(const tc::FinalizeQuadArgs& args, const Tuning& tuning,
-                         hipStream_t stream, bool f32) {
-  // geometry as launch_finalize: one block per 64 draws, small batches split the rows
-  const int64_t n_tiles = args.ldb / 64;
-  // (fused likelihood: 16 waves share the rows of the quadratic form -- next to a
-  // contraction every vector instruction of a wave waits for a matrix instruction)
-  const int threads = tuning.finalize_threads > 0 ? tuning.finalize_threads
-                      : n_tiles < 128 || args.chi2 != nullptr ? 1024 : 256;
-  const int n_rows = args.n_comp * args.n_r;
-  // (many rows -- hundreds of r values -- are split over row blocks of at least 16 rows until
-  // the grid has ~2048 blocks: one block per draw tile walked 760 rows serially, 2.4 ms)
-  const int row_blocks =
-      args.chi2 != nullptr
-          ? 1   // (the fused likelihood needs every row of a draw in one workgroup)
-          : std::min(n_rows, tuning.finalize_row_blocks > 0
-                                 ? tuning.finalize_row_blocks
-                                 : n_tiles < 128
-                                       ? (int)std::max<int64_t>(1, 512 / n_tiles)
-                                       : (int)std::max<int64_t>(
-                                             1, std::min<int64_t>(n_rows / 16, 2048 / n_tiles)));
-  if (f32)
-    hipLaunchKernelGGL((tc::finalize_quad_kernel<float, tc::kQuadTileF32>),
-                       dim3((unsigned)n_tiles, (unsigned)row_blocks), dim3(threads), 0, stream,
-                       args);
-  else
-    hipLaunchKernelGGL((tc::finalize_quad_kernel<double, tc::kQuadTile>),
-                       dim3((unsigned)n_tiles, (unsigned)row_blocks), dim3(threads), 0, stream,
-                       args);
-  TC_HIP(hipGetLastError());
-  return TC_OK;
-}
-
 // Contraction + finalisation through the quadratic-form kernel (mode auto, float64).
 static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
                                 double* ngal_device, double* xi_device) {
@@ -752,71 +653,6 @@ static int run_contraction_quad(tc_table* t, int64_t n_draws, int64_t ldb, unsig
     // occupation kernel: profiles/r03_notes.md)
     if (t->chain) TC_HIP(hipEventRecord(lane.finished, stream));
     t->prev = t->cur;
-  }
-  return TC_OK;
-}
-
-#define TC_RT_CASES                                                           \
-  TC_CASE(4) TC_CASE(8) TC_CASE(12) TC_CASE(16) TC_CASE(20) TC_CASE(24)       \
-  TC_CASE(28) TC_CASE(32)
-
-int launch_contract_rt(int rt, dim3 grid, dim3 block, int lds, hipStream_t stream,
-                       const tc::ContractArgs& args, hipEvent_t start, hipEvent_t stop) {
-  switch (rt) {
-#define TC_CASE(N)                                                            \
-  case N:                                                                     \
-    if (args.n_tables > 0)                                                    \
-      hipExtLaunchKernelGGL((tc::contract_mfma_kernel<N, true>), grid, block, \
-                            lds, stream, start, stop, 0, args);               \
-    else                                                                      \
-      hipExtLaunchKernelGGL((tc::contract_mfma_kernel<N, false>), grid, block, \
-                            lds, stream, start, stop, 0, args);               \
-    break;
-    TC_RT_CASES
-#undef TC_CASE
-    default:
-      return fail(TC_ERR_UNSUPPORTED, "no kernel for r tile %d", rt);
-  }
-  TC_HIP(hipGetLastError());
-  return TC_OK;
-}
-
-// float32 variant (one kernel for every r tile: always 32 wide)
-int launch_contract_f32(dim3 grid, dim3 block, int lds, hipStream_t stream,
-                        const tc::ContractArgs& args, hipEvent_t start, hipEvent_t stop) {
-  if (lds > 64 * 1024) {
-    TC_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&tc::contract_f32_kernel<false>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    TC_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&tc::contract_f32_kernel<true>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  }
-  if (args.n_tables > 0)
-    hipExtLaunchKernelGGL(tc::contract_f32_kernel<true>, grid, block, lds, stream, start, stop,
-                          0, args);
-  else
-    hipExtLaunchKernelGGL(tc::contract_f32_kernel<false>, grid, block, lds, stream, start, stop,
-                          0, args);
-  TC_HIP(hipGetLastError());
-  return TC_OK;
-}
-
-int set_lds_limit_rt(int rt, int lds) {
-  switch (rt) {
-#define TC_CASE(N)                                                            \
-  case N:                                                                     \
-    TC_HIP(hipFuncSetAttribute(                                               \
-        reinterpret_cast<const void*>(&tc::contract_mfma_kernel<N, false>),   \
-        hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \
-    TC_HIP(hipFuncSetAttribute(                                               \
-        reinterpret_cast<const void*>(&tc::contract_mfma_kernel<N, true>),    \
-        hipFuncAttributeMaxDynamicSharedMemorySize, lds));                    \
-    break;
-    TC_RT_CASES
-#undef TC_CASE
-    default:
-      break;
   }
   return TC_OK;
 }
@@ -1046,43 +882,10 @@ int run_occupation(tc_table* t, const double* theta_device, int n_theta,
   oa.series_thr = (const int32_t*)q->series_thr;
   oa.sat_series = (series_mask(t) & 2) ? (const double*)q->sat_series : nullptr;
   oa.sat_series_thr = (const int32_t*)q->sat_series_thr;
-  {
-    const dim3 grid((unsigned)grid_blocks), block(tc::kOccWaves * 64);
-    const bool assembias = (flags & TC_FLAG_ASSEMBIAS) != 0;
-    const bool modulate = (flags & TC_FLAG_MODULATE_WITH_CENOCC) != 0;
-#define TC_OCC(NG, AB, MO)                                                           \
-  hipLaunchKernelGGL((tc::occ_zheng07_kernel<NG, AB, MO>), grid, block, 0, stream, oa)
-    // diagnosis only (developer builds, tools/archive/ab.sh): reuse the densities of the previous call
-    static int occ_calls = 0;
-    if (t->tuning.skip_occ && ++occ_calls > 8) return TC_OK;
-    if (flags & TC_FLAG_LEAUTHAUD11) {
-      if (modulate)
-        hipLaunchKernelGGL(tc::occ_leauthaud11_kernel<true>, grid, block, 0, stream, oa);
-      else
-        hipLaunchKernelGGL(tc::occ_leauthaud11_kernel<false>, grid, block, 0, stream, oa);
-    } else if (grouped) {
-#define TC_OCC_GROUPED(AB, MO)                                                        \
-  hipLaunchKernelGGL((tc::occ_zheng07_kernel<10, AB, MO, true>), grid, block, 0, stream, oa)
-      if (!assembias && !modulate) TC_OCC_GROUPED(false, false);
-      else if (!assembias) TC_OCC_GROUPED(false, true);
-      else if (!modulate) TC_OCC_GROUPED(true, false);
-      else TC_OCC_GROUPED(true, true);
-#undef TC_OCC_GROUPED
-    } else if (n_gauss == 10) {
-      if (!assembias && !modulate) TC_OCC(10, false, false);
-      else if (!assembias) TC_OCC(10, false, true);
-      else if (!modulate) TC_OCC(10, true, false);
-      else TC_OCC(10, true, true);
-    } else {
-      if (!assembias && !modulate) TC_OCC(0, false, false);
-      else if (!assembias) TC_OCC(0, false, true);
-      else if (!modulate) TC_OCC(0, true, false);
-      else TC_OCC(0, true, true);
-    }
-#undef TC_OCC
-  }
-  TC_HIP(hipGetLastError());
-  return TC_OK;
+  // diagnosis only (developer builds, tools/archive/ab.sh): reuse the densities of the previous call
+  static int occ_calls = 0;
+  if (t->tuning.skip_occ && ++occ_calls > 8) return TC_OK;
+  return launch_occupation(oa, flags, n_gauss, grouped, grid_blocks, stream);
 }
 
 // One launch per slab of draws (predict_fused_kernel): float64 quadratic form with one r tile,
@@ -1249,36 +1052,6 @@ int fused_waves(const tc_table* t, bool separate, unsigned flags) {
                : (fits16 && (t->tuning.fused >= 2 || t->autotuned.count(flags) != 0)) ? 16 : 0;
 }
 
-namespace {
-template <int NG, bool AB, bool MO, bool LE = false, int W = tc::kFusedWaves, int DL = 64,
-          bool GR = false, int SD = 0>
-int launch_fused(int device, int n_u, dim3 grid, dim3 block, int lds, hipStream_t stream,
-                 hipEvent_t k0, hipEvent_t k1, const tc::FusedArgs& fa) {
-  switch (n_u) {
-#define TC_CASE(N)                                                                            \
-  case N: {                                                                                   \
-    /* (the attribute belongs to the function ON a device: once per device) */                \
-    static bool limit_set[64] = {};                                                           \
-    if (lds > 64 * 1024 && !(device >= 0 && device < 64 && limit_set[device])) {              \
-      TC_HIP(hipFuncSetAttribute(                                                             \
-          (const void*)tc::predict_fused_kernel<NG, N, AB, MO, LE, W, DL, GR, SD>,                \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));    \
-      if (device >= 0 && device < 64) limit_set[device] = true;                               \
-    }                                                                                         \
-    hipExtLaunchKernelGGL((tc::predict_fused_kernel<NG, N, AB, MO, LE, W, DL, GR, SD>), grid,     \
-                          block, lds, stream, k0, k1, 0, fa);                                 \
-    break;                                                                                    \
-  }
-    TC_CASE(1) TC_CASE(2) TC_CASE(3) TC_CASE(4) TC_CASE(5)
-#undef TC_CASE
-    default:
-      return fail(TC_ERR_UNSUPPORTED, "no fused kernel for %d r sub-tiles", n_u);
-  }
-  TC_HIP(hipGetLastError());
-  return TC_OK;
-}
-}  // namespace
-
 int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_draws,
               int n_gauss, unsigned flags, double* ngal_device, double* xi_device) {
   Range range("occupation + contraction + finalisation (one launch)");
@@ -1395,58 +1168,18 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   const bool cen_defer = sat_defer && t->tuning.fused_defer >= 2 && (series_mask(t) & 1) != 0 &&
                          q->cen_records != nullptr;
   fa.sat_cap = t->tuning.fused_sat_cap;
-#define TC_FUSED(NG, AB, MO, LE)                                                              \
-  (waves == 16 ? launch_fused<NG, AB, MO, LE, 16>(t->device, t->quad_tiling.n_u, grid, block,  \
-                                                  lds, stream, k0, k1, fa)                     \
-               : launch_fused<NG, AB, MO, LE, 8>(t->device, t->quad_tiling.n_u, grid, block,   \
-                                                 lds, stream, k0, k1, fa))
-#define TC_FUSED32(AB, MO)                                                                    \
-  launch_fused<10, AB, MO, false, 8, 32>(t->device, t->quad_tiling.n_u, grid, block, lds,      \
-                                         stream, k0, k1, fa)
+  tc::host::FusedInstance instance{};
+  instance.n_gauss = n_gauss == 10 ? 10 : 0;
+  instance.assembias = assembias;
+  instance.modulate = modulate;
+  instance.leauthaud = (flags & TC_FLAG_LEAUTHAUD11) != 0;
+  instance.waves = waves;
+  instance.draws = draws;
   // bins that share their nodes (Zheng07 family, ten nodes): the GROUPED instances
-  const bool grouped = t->grouped && n_gauss == 10 && !(flags & TC_FLAG_LEAUTHAUD11);
-#define TC_FUSED_GROUPED(AB, MO)                                                              \
-  (wide || half_tiles                                                                         \
-       ? launch_fused<10, AB, MO, false, 8, 32, true>(t->device, t->quad_tiling.n_u, grid,    \
-                                                      block, lds, stream, k0, k1, fa)         \
-   : waves == 16                                                                              \
-       ? launch_fused<10, AB, MO, false, 16, 64, true>(t->device, t->quad_tiling.n_u, grid,   \
-                                                       block, lds, stream, k0, k1, fa)        \
-       : launch_fused<10, AB, MO, false, 8, 64, true>(t->device, t->quad_tiling.n_u, grid,    \
-                                                      block, lds, stream, k0, k1, fa))
-  if (grouped)
-    status = assembias ? (modulate ? TC_FUSED_GROUPED(true, true) : TC_FUSED_GROUPED(true, false))
-                       : (modulate ? TC_FUSED_GROUPED(false, true)
-                                   : TC_FUSED_GROUPED(false, false));
-  else if ((wide || half_tiles) && (flags & TC_FLAG_LEAUTHAUD11))
-    status = modulate ? launch_fused<0, false, true, true, 8, 32>(
-                            t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa)
-                      : launch_fused<0, false, false, true, 8, 32>(
-                            t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
-  else if (wide || half_tiles)
-    status = assembias ? (modulate ? TC_FUSED32(true, true) : TC_FUSED32(true, false))
-                       : (modulate ? TC_FUSED32(false, true) : TC_FUSED32(false, false));
-  else if (flags & TC_FLAG_LEAUTHAUD11)
-    status = modulate ? TC_FUSED(0, false, true, true) : TC_FUSED(0, false, false, true);
-  else if (n_gauss != 10)
-    status = TC_FUSED(0, false, false, false);
-  else if (!assembias && !modulate && cen_defer)
-    status = launch_fused<10, false, false, false, 8, 64, false, 2>(
-        t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
-  else if (!assembias && !modulate && sat_defer)
-    status = launch_fused<10, false, false, false, 8, 64, false, 1>(
-        t->device, t->quad_tiling.n_u, grid, block, lds, stream, k0, k1, fa);
-  else if (!assembias && !modulate)
-    status = TC_FUSED(10, false, false, false);
-  else if (!assembias)
-    status = TC_FUSED(10, false, true, false);
-  else if (!modulate)
-    status = TC_FUSED(10, true, false, false);
-  else
-    status = TC_FUSED(10, true, true, false);
-#undef TC_FUSED
-#undef TC_FUSED32
-#undef TC_FUSED_GROUPED
+  instance.grouped = t->grouped && n_gauss == 10 && !(flags & TC_FLAG_LEAUTHAUD11);
+  instance.defer = cen_defer ? 2 : sat_defer ? 1 : 0;
+  status = launch_fused_instance(instance, t->device, t->quad_tiling.n_u, grid, block, lds, stream,
+                                 k0, k1, fa);
   if (status != TC_OK) return status;
   t->last_workgroups = (int)grid.x;
   t->last_waves = waves;
@@ -1627,44 +1360,6 @@ bool cross_fused_eligible(const tc_table* t0, const CrossFused& cf, int64_t n_dr
   return t0->tuning.fused >= 2 || !alone;
 }
 
-namespace {
-template <bool AB, bool MO, bool DE = false>
-int launch_cross_fused(int device, int rows, dim3 grid, dim3 block, int lds, hipStream_t stream,
-                       hipEvent_t k0, hipEvent_t k1, const tc::CrossFusedArgs& ca) {
-  switch (rows / tc::kCrossWaves) {      // rows per wave
-#define TC_CASE(N, DEFER)                                                                     \
-  case N: {                                                                                   \
-    static bool limit_set[64] = {};                                                           \
-    if (lds > 64 * 1024 && !(device >= 0 && device < 64 && limit_set[device])) {              \
-      /* (the kernel holds a few bytes of static LDS besides) */                               \
-      TC_HIP(hipFuncSetAttribute(                                                             \
-          (const void*)tc::predict_cross_fused_kernel<N, AB, MO, DEFER>,                      \
-          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));                     \
-      if (device >= 0 && device < 64) limit_set[device] = true;                               \
-    }                                                                                         \
-    hipExtLaunchKernelGGL((tc::predict_cross_fused_kernel<N, AB, MO, DEFER>), grid, block,    \
-                          lds, stream, k0, k1, 0, ca);                                        \
-    break;                                                                                    \
-  }
-    TC_CASE(4, DE) TC_CASE(8, DE) TC_CASE(16, false)
-#undef TC_CASE
-    case 2:     // up to 16 rows: the sums in every wave's registers
-      // (the instance with the deferred pairs exists in the source and is not shipped: 16 row
-      // sums next to the expansions do not fit 128 registers -- 59.2 against 58.9 us per 10^4
-      // draws of the AbacusSummit table with the expansions of round 5's first half, 80 with the
-      // group records; undecorated batches go through the 32-row chunk form instead:
-      // choose_cross_fused)
-      hipExtLaunchKernelGGL((tc::predict_cross_small_kernel<AB, MO, false>), grid, block, lds,
-                            stream, k0, k1, 0, ca);
-      break;
-    default:
-      return fail(TC_ERR_UNSUPPORTED, "no cross kernel for %d rows", rows);
-  }
-  TC_HIP(hipGetLastError());
-  return TC_OK;
-}
-}  // namespace
-
 int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs* interp,
                     const double* theta_device, int n_theta, int64_t n_draws, unsigned flags,
                     double* ngal_device, double* xi_device, hipStream_t stream,
@@ -1834,19 +1529,9 @@ int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs
   if (status != TC_OK) return status;
   const bool assembias = (flags & TC_FLAG_ASSEMBIAS) != 0;
   const bool modulate = (flags & TC_FLAG_MODULATE_WITH_CENOCC) != 0;
-  if (ca.defer)        // (undecorated, up to 64 rows: the instances with the deferred pairs)
-    status = launch_cross_fused<false, false, true>(t0->device, cf.rows, grid, block, lds, stream,
-                                                    k0, k1, ca);
-  else
-  status = assembias ? (modulate ? launch_cross_fused<true, true>(t0->device, cf.rows, grid, block,
-                                                                  lds, stream, k0, k1, ca)
-                                 : launch_cross_fused<true, false>(t0->device, cf.rows, grid,
-                                                                   block, lds, stream, k0, k1, ca))
-                     : (modulate ? launch_cross_fused<false, true>(t0->device, cf.rows, grid,
-                                                                   block, lds, stream, k0, k1, ca)
-                                 : launch_cross_fused<false, false>(t0->device, cf.rows, grid,
-                                                                    block, lds, stream, k0, k1,
-                                                                    ca));
+  // (ca.defer: undecorated, up to 64 rows -- the instances with the deferred pairs)
+  status = launch_cross_instance(assembias, modulate, ca.defer != 0, t0->device, cf.rows, grid,
+                                 block, lds, stream, k0, k1, ca);
   if (status != TC_OK) return status;
   t0->last_workgroups = (int)grid.x;
   t0->last_waves = tc::kCrossWaves;
@@ -1914,10 +1599,7 @@ int launch_single_draw(tc_table* t, const double* theta, int n_theta, int n_walk
     t->trace_blocks = (size_t)blocks;
     sa.stamps = (unsigned long long*)t->trace.ptr;
   }
-  hipLaunchKernelGGL(tc::single_draw_kernel, dim3((unsigned)(blocks * n_walkers)),
-                     dim3(tc::kSingleThreads), 0, stream, sa);
-  TC_HIP(hipGetLastError());
-  return TC_OK;
+  return launch_single_kernel(blocks * n_walkers, stream, sa);
 }
 
 // The argument block of one draw against one table (results and completion words in `ws`).
@@ -2111,9 +1793,8 @@ int resident_predict(tc_table* t, const double* theta, int n_theta, int n_gauss,
       r.auto_serving = !r.enabled;
       sa.life_ticks = 1000000000ull;                                          // 10 s
       sa.poll_waves = std::max(1, std::min(4, r.poll_waves));
-      hipLaunchKernelGGL(tc::resident_draw_kernel, dim3((unsigned)blocks),
-                         dim3(tc::kSingleThreads), 0, r.stream, sa);
-      TC_HIP(hipGetLastError());
+      status = launch_resident_kernel(blocks, r.stream, sa);
+      if (status != TC_OK) return status;
       r.running = true;
       r.n_theta = n_theta;
       r.n_gauss = n_gauss;
@@ -2314,21 +1995,8 @@ int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walker
       ea.lds_ij = l.lds_ij;
       // (the word a previous launch's workgroup 0 left behind)
       TC_HIP(hipMemsetAsync(ea.callword, 0, 8, r.stream));
-      {
-        // (the attribute belongs to the function ON a device: once per device, and handles may
-        // be used from different threads)
-        static std::mutex attribute_mutex;
-        static bool attribute_set[64] = {};
-        std::lock_guard<std::mutex> lock(attribute_mutex);
-        if (!(t->device >= 0 && t->device < 64 && attribute_set[t->device])) {
-          TC_HIP(hipFuncSetAttribute((const void*)tc::resident_ensemble_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-          if (t->device >= 0 && t->device < 64) attribute_set[t->device] = true;
-        }
-      }
-      hipLaunchKernelGGL(tc::resident_ensemble_kernel, dim3((unsigned)l.grid),
-                         dim3(tc::kEnsembleThreads), (size_t)l.lds_bytes, r.stream, ea);
-      TC_HIP(hipGetLastError());
+      status = launch_ensemble_kernel(t->device, l.grid, l.lds_bytes, r.stream, ea);
+      if (status != TC_OK) return status;
       r.running = true;
       r.ensemble = true;
       r.n_theta = n_theta;
@@ -2408,24 +2076,6 @@ int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walker
   // path serves this call, and after three such calls every call until the option is set again)
   if (++r.ens_failures >= 3) r.ens_disabled = true;
   return TC_ERR_UNSUPPORTED;
-}
-
-// The same for every table of an interpolator in one launch (interp.cpp fills the per-class
-// pointer arrays): host_ws holds (n_tables, 2) densities, then (n_tables, blocks, rt)
-// partial sums.
-int launch_single_draw_tables(tc_table* t0, const tc::SingleArgs& prepared, int n_tables,
-                              int blocks_per_table, hipStream_t stream) {
-  tc::SingleArgs sa = prepared;
-  sa.n_tables = n_tables;
-  sa.blocks_per_table = blocks_per_table;
-  sa.stamps = nullptr;
-  sa.theta_many = nullptr;
-  sa.n_walkers = 0;
-  (void)t0;
-  hipLaunchKernelGGL(tc::single_draw_kernel, dim3((unsigned)(n_tables * blocks_per_table)),
-                     dim3(tc::kSingleThreads), 0, stream, sa);
-  TC_HIP(hipGetLastError());
-  return TC_OK;
 }
 
 int single_draw_blocks(const tc_table* t) {
@@ -2514,35 +2164,6 @@ int wait_single_done(SingleWorkspace* ws, hipStream_t stream, bool poll) {
   return TC_OK;
 }
 
-int launch_finalize(const FinalizeArgs& args, const Tuning& tuning, hipStream_t stream) {
-  // one block per draw tile; a wave sums one (component, r) row at a time over the slabs,
-  // so small batches (few blocks, latency-bound) get 16 waves per block instead of 4
-  // and split the rows over several blocks (up to ~512 blocks in all)
-  const int64_t n_tiles = args.ldb / 64;
-  const int threads =
-      tuning.finalize_threads > 0 ? tuning.finalize_threads : n_tiles < 128 ? 1024 : 256;
-  const int n_rows = args.n_comp * args.n_r;
-  const int row_blocks = std::min(
-      n_rows, tuning.finalize_row_blocks > 0
-                  ? tuning.finalize_row_blocks
-                  : n_tiles < 128 ? (int)std::max<int64_t>(1, 512 / n_tiles) : 1);
-  hipLaunchKernelGGL(tc::finalize_kernel, dim3((unsigned)n_tiles, (unsigned)row_blocks),
-                     dim3(threads), 0, stream, args);
-  TC_HIP(hipGetLastError());
-  return TC_OK;
-}
-
-int launch_interp_coef(const InterpArgs& args, hipStream_t stream) {
-  if (args.n_draws <= 16 && args.n_tables <= tc::kCoefSmallTables)
-    hipLaunchKernelGGL(tc::interp_coef_small_kernel, dim3((unsigned)args.n_draws), dim3(64),
-                       0, stream, args);
-  else
-    hipLaunchKernelGGL(tc::interp_coef_kernel, dim3((unsigned)(args.ldb / 64)), dim3(64), 0,
-                       stream, args);
-  TC_HIP(hipGetLastError());
-  return TC_OK;
-}
-
 int launch_occ_from_array(tc_table* t, const double* occupation_device, int64_t n_draws,
                           int64_t ldb, double* nbuf, double* ngal2, hipStream_t stream) {
   // (the float32 quadratic-form kernel reads a float copy of the densities of lane 0)
@@ -2552,28 +2173,9 @@ int launch_occ_from_array(tc_table* t, const double* occupation_device, int64_t 
     if (status != TC_OK) return status;
     nbuf32 = (float*)t->lanes[0].nbuf32.ptr;
   }
-  hipLaunchKernelGGL(tc::occ_from_array_kernel, dim3((unsigned)((ldb + 255) / 256)),
-                     dim3(256), 0, stream, occupation_device, n_draws, ldb, t->n_bins,
-                     t->plan.n_central, (const double*)t->d_n_h, (const int32_t*)t->d_perm,
-                     nbuf, ngal2, nbuf32);
-  TC_HIP(hipGetLastError());
-  return TC_OK;
-}
-
-int launch_chi2(const double* xi, int64_t n_draws, int n_r, const double* data,
-                const double* precision, double* chi2, hipStream_t stream) {
-  // draws per workgroup: 8 unless their deviations would not fit the LDS budget
-  const size_t row = (size_t)n_r * sizeof(double);
-  TC_CHECK(n_r >= 1 && row <= (size_t)tc::kChi2LdsBytes, "chi2: too many r bins");
-  const int per_block =
-      (int)std::min<size_t>(tc::kChi2DrawsPerBlock, (size_t)tc::kChi2LdsBytes / row);
-  const size_t lds =
-      per_block * row + (n_r <= tc::kChi2LdsMatrix ? (size_t)n_r * row : (size_t)0);
-  hipLaunchKernelGGL(tc::chi2_kernel, dim3((unsigned)((n_draws + per_block - 1) / per_block)),
-                     dim3(32 * per_block), lds, stream, xi, n_draws, n_r, data, precision,
-                     chi2);
-  TC_HIP(hipGetLastError());
-  return TC_OK;
+  return launch_occ_from_array_kernel(occupation_device, n_draws, ldb, t->n_bins,
+                                      t->plan.n_central, (const double*)t->d_n_h,
+                                      (const int32_t*)t->d_perm, nbuf, ngal2, nbuf32, stream);
 }
 
 }  // namespace host

@@ -248,9 +248,11 @@ class TabCorr:
         at batch sizes 256 ... 65536, and let the pipelined and asynchronous
         calls with these options take the measured form (about half a second;
         ``tc_table_set_option "autotune"``).  Without it the library estimates
-        the crossovers from the table's shape -- until it has seen 256
-        pipelined or asynchronous calls with one combination of options: that
-        call runs this measurement by itself (option ``"autotune_after"``).
+        the crossovers from the table's shape.  (Option ``"autotune_after"``
+        = N makes the N-th pipelined or asynchronous call with one combination
+        of options run this measurement by itself; off by default, because
+        that call then blocks for half a second and the measured choice --
+        hence the last bits of the results -- may differ from run to run.)
         ``measure=False`` only reads the stored result (``None`` if there is
         none yet).
 

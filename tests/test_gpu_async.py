@@ -452,6 +452,12 @@ def test_resident_kernel_by_itself_for_loops_of_unbatched_calls():
     launched = [halotab.predict_batch(theta[i:i + 1]) for i in range(400)]
     halotab.set_resident(True)
     resident = [halotab.predict_batch(theta[i:i + 1]) for i in range(400)]
+    # round 6: the two kernels are instances of one body compiled with
+    # -ffp-contract=on (csrc/inst_single.hip), so which of them serves a call -- a matter of
+    # timing in the automatic mode -- does not show in the bits
+    for i in range(400):
+        assert np.array_equal(launched[i][0], resident[i][0]), i
+        assert np.array_equal(launched[i][1], resident[i][1]), i
     halotab.set_resident('auto')
     model = Zheng07Model(redshift=table['attrs']['redshift'])
     keys = ('logMmin', 'sigma_logM', 'logM0', 'logM1', 'alpha')

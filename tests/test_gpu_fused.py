@@ -737,7 +737,8 @@ def test_autotune_picks_the_fastest_form(n_prim, n_r, how):
     one-launch forms is never far behind the best forced form -- the built-in estimate, fitted
     on a handful of shapes, is up to 40 % behind on others (tools/r04_autotune.py) -- and the
     results do not depend on it.  'by itself' (VERDICT r04 item 5): nobody calls autotune();
-    the 256th pipelined call with these flags measures (option "autotune_after")."""
+    with option "autotune_after" = 256 (opt-in since round 6: ADVICE r05) the 256th pipelined
+    call with these flags measures."""
     import ctypes
     import time
     from tabcorr_amd import synthetic, _lib
@@ -772,6 +773,14 @@ def test_autotune_picks_the_fastest_form(n_prim, n_r, how):
         result = halotab.autotune()
     else:
         assert halotab.autotune(measure=False) is None
+        # (off by default since round 6: the loop of calls below must not measure ...)
+        for _ in range(300):
+            _lib.check(lib.tc_predict_zheng07_batch_device(handle, d_theta, 5, 3000, 10, 0, d_ngal,
+                                                           d_xi))
+        _lib.check(lib.tc_table_synchronize(handle))
+        assert halotab.autotune(measure=False) is None, 'autotune ran although nobody asked'
+        # (... until the caller opts in)
+        set_option(halotab, 'autotune_after', 256)
         for _ in range(300):
             _lib.check(lib.tc_predict_zheng07_batch_device(handle, d_theta, 5, 3000, 10, 0, d_ngal,
                                                            d_xi))

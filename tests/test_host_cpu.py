@@ -1127,7 +1127,7 @@ def test_satellite_binomial_expansion_reproduces_the_node_loop():
 
 def test_no_kernel_spills_vector_registers():
     """every shipped instance of the prediction kernels compiles without
-    vector-register spills and scratch (hipcc's kernel-resource-usage remarks of launch.hip,
+    vector-register spills and scratch (hipcc's kernel-resource-usage remarks of the inst_*.hip units,
     tools/kernel_resources.py) -- the two resident kernels included since their per-call
     address arithmetic stays inside the loop of calls (round 4: 1 and 19 spilled registers)."""
     import shutil
@@ -1135,17 +1135,9 @@ def test_no_kernel_spills_vector_registers():
     sys.path.insert(0, os.path.join(REPO, 'tools'))
     import kernel_resources
     from tabcorr_amd import build
-    compiler = build.hipcc()
     if shutil.which('c++filt') is None:
         pytest.skip('c++filt not found')
-    with tempfile.TemporaryDirectory() as tmp:
-        out = subprocess.run(
-            [compiler] + build.FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-c',
-                                        os.path.join(REPO, 'tabcorr_amd', 'csrc', 'launch.hip'),
-                                        '-o', os.path.join(tmp, 'launch.o')],
-            capture_output=True, text=True)
-    assert out.returncode == 0, out.stderr[-2000:]
-    kernels = kernel_resources.parse(out.stderr)
+    kernels = kernel_resources.parse(build.kernel_resource_remarks())
     names = kernel_resources.demangle(list(kernels))
     assert len(kernels) > 150
     allowed = {}

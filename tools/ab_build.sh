@@ -15,8 +15,10 @@ fi
 mkdir -p $ROOT/tools/ab
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -Wall -Wno-unused-function ${EXTRA_FLAGS}"
 cd $TMP/tabcorr_amd/csrc
-for f in launch.hip paircount.hip table.cpp interp.cpp comm.cpp runtime.cpp hostmath.cpp; do
-  /opt/rocm/bin/hipcc $FLAGS -c $f -o $TMP/${f%.*}.o &
+for f in $(ls *.hip *.cpp); do
+  # (inst_single.hip: see its header)
+  UNIT_FLAGS=$([ $f = inst_single.hip ] && echo -ffp-contract=on)
+  /opt/rocm/bin/hipcc $FLAGS $UNIT_FLAGS -c $f -o $TMP/${f%.*}.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fno-gpu-rdc -shared -Wl,-z,now -Wl,-rpath,/opt/rocm/lib \

@@ -2,8 +2,10 @@
 # Build build/ab/dev.so: the library with the developer knobs (TC_SKIP_OCC, TC_SKIP_FINALIZE).
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p build/ab/obj
-for f in launch.hip paircount.hip table.cpp interp.cpp comm.cpp runtime.cpp hostmath.cpp; do
-  hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -DTC_DEVELOPER_KNOBS -c tabcorr_amd/csrc/$f -o build/ab/obj/${f%.*}.o 2>/dev/null &
+for f in $(cd tabcorr_amd/csrc && ls *.hip *.cpp); do
+  # (inst_single.hip: see its header)
+  UNIT_FLAGS=$([ $f = inst_single.hip ] && echo -ffp-contract=on)
+  hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -DTC_DEVELOPER_KNOBS $UNIT_FLAGS -c tabcorr_amd/csrc/$f -o build/ab/obj/${f%.*}.o 2>/dev/null &
 done
 wait
 hipcc --offload-arch=gfx950 -fno-gpu-rdc -shared -Wl,-z,now -Wl,-rpath,/opt/rocm/lib -o build/ab/dev.so build/ab/obj/*.o

@@ -2,7 +2,8 @@
 """Per-kernel register / spill / LDS table from hipcc's -Rpass-analysis=kernel-resource-usage
 remarks (stdin or a file): one line per kernel, sorted by name.
 
-    hipcc ... -Rpass-analysis=kernel-resource-usage -c launch.hip -o /dev/null 2>&1 | tools/kernel_resources.py
+    python -c 'from tabcorr_amd import build; print(build.kernel_resource_remarks())' | tools/kernel_resources.py
+(the remarks of every inst_*.hip unit; or pipe one unit's hipcc ... -Rpass-analysis=kernel-resource-usage output)
 """
 import re
 import subprocess
