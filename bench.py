@@ -106,6 +106,9 @@ def headline(result, detail_path):
     if 'second_payload' in result:
         line['second_payload'] = {key: result['second_payload'][key]
                                   for key in ('gather_payload', 'value', 'ms_per_step', 'steps')}
+    if result.get('gather_check'):
+        line['gather_check'] = {key: result['gather_check'][key]
+                                for key in ('ranks', 'steps_checked', 'bit_equal')}
     if result.get('failed_legs'):
         line['failed_legs'] = sorted(result['failed_legs'])
     line['detail'] = detail_path
@@ -117,8 +120,66 @@ def headline(result, detail_path):
     return text
 
 
+def check_gathered(region, comm, lib, _lib, dev, handle, interp_mode, chi2_mode, n_draws, n_r,
+                   n_gauss, data_p, precision_p, synthetic, interp, synchronize):
+    """Rank 0: every step of every rank in the receive buffer == this rank's own evaluation of
+    that rank's draws (cfg2: seed 1 + rank; interp5x5: the rank's round-robin shard)."""
+    flat = region.gathered()
+    synchronize()
+    if not comm.is_root or flat is None:
+        return None
+    world = comm.world_size
+    if interp_mode:
+        theta_all = synthetic.zheng07_draws(n_draws * world, seed=5)
+        rng = np.random.default_rng(6)
+        x_all = np.stack([rng.uniform(xp[0], xp[-1], size=len(theta_all))
+                          for xp in interp.xp], axis=-1)
+    scratch = dev.malloc(region.n_out)
+    second = ctypes.c_void_p(scratch.value + n_draws * 8)
+    steps = mismatches = 0
+    # (the newest gather of every block: older entries of the log were overwritten)
+    newest = {}
+    for entry in region.ring.log:
+        newest[entry[0]] = entry
+    for r in range(world):
+        if interp_mode:
+            theta_r = np.ascontiguousarray(theta_all[r::world])
+            d_x = dev.upload(np.ascontiguousarray(x_all[r::world]))
+        else:
+            theta_r = synthetic.zheng07_draws(n_draws, seed=1 + r)
+        d_theta = dev.upload(theta_r)
+        if interp_mode and chi2_mode:
+            _lib.check(lib.tc_interp_chi2_zheng07_batch_device(
+                handle, d_theta, 5, d_x, n_draws, n_gauss, 0, data_p, precision_p, scratch,
+                second))
+        elif interp_mode:
+            _lib.check(lib.tc_interp_predict_zheng07_batch_device(
+                handle, d_theta, 5, d_x, n_draws, n_gauss, 0, scratch, second))
+        elif chi2_mode:
+            _lib.check(lib.tc_chi2_zheng07_batch_device(
+                handle, d_theta, 5, n_draws, n_gauss, 0, data_p, precision_p, scratch, second))
+        else:
+            _lib.check(lib.tc_predict_zheng07_batch_device(
+                handle, d_theta, 5, n_draws, n_gauss, 0, scratch, second))
+        synchronize()
+        own = dev.download(scratch, region.n_out)
+        for entry in newest.values():
+            for step, offset in region.ring.steps_in(entry, r):
+                steps += 1
+                if not np.array_equal(flat[offset:offset + region.n_out], own, equal_nan=True):
+                    mismatches += 1
+    return {'ranks': world, 'steps_checked': steps, 'steps_differing': mismatches,
+            'bit_equal': mismatches == 0 and steps > 0,
+            'what': 'every step of every rank held by rank 0 after the timed region against '
+                    'rank 0\'s own evaluation of that rank\'s draws'}
+
+
 def emit(result):
     """Sidecar with everything, `detail` lines, then the ONE short JSON line (last on stdout)."""
+    import bench_legs
+    if bench_legs.pmc_failures:
+        # (a committed PMC file that does not hold the kernel that was timed: say so)
+        result.setdefault('failed_legs', {})['pmc_counters'] = '; '.join(bench_legs.pmc_failures)
     detail_path = None
     for directory in (REPO, os.path.join(REPO, 'gpurun_out')):
         if not os.path.isdir(directory):
@@ -183,6 +244,10 @@ def main():
     parser.add_argument('--detail', type=int, default=1,
                         help='0 = headline only: skip the secondary legs (host-to-host, batch '
                              'sizes, un-batched calls, tabulation, other configurations)')
+    parser.add_argument('--check-gather', type=int, default=1,
+                        help='multi-rank: rank 0 compares every gathered step with its own '
+                             'evaluation of the sending rank\'s draws, bit for bit (after the '
+                             'timed region)')
     parser.add_argument('--only-config', choices=CONFIG_TAGS, default=None,
                         help='measure ONLY that configuration of other_configs and print its '
                              'record (for rocprofv3 runs: tools/profile_round.sh)')
@@ -212,7 +277,10 @@ def main():
     lib = _lib.load()
     _lib.require_device()
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    _lib.check(lib.tc_set_device(local_rank))
+    # (more ranks than devices -- two ranks rehearsing the multi-rank path on a one-GPU box --
+    # share devices round-robin; RCCL then refuses the communicator and the gather runs over
+    # gloo: Communicator._init_rccl)
+    _lib.check(lib.tc_set_device(local_rank % max(1, _lib.device_count())))
     if args.only_config:
         def make_only(table, **kwargs):
             return TabCorr.from_arrays(table['gal_type'], table['tpcf_matrix'],
@@ -281,9 +349,15 @@ def main():
         def __init__(self, chi2_mode):
             self.chi2_mode = chi2_mode
             self.n_out = n_draws * (2 if chi2_mode else 1 + N_R)   # ngal | chi2, or ngal | xi
+            # RCCL not usable on every rank (Communicator.rccl_error): the blocks travel over
+            # gloo on host arrays -- slower (a device synchronisation, a download and a TCP
+            # round trip per block), same layout on the root, "gather": "gloo" in the record
+            use_gloo = comm.dist is not None and not use_rccl
+            self.h_recv = None
             self.ring = ResultRing(
                 self.n_out, every, comm.world_size,
-                gather=self.gather if use_rccl else (lambda *a: None),
+                gather=self.gather if use_rccl else self.gather_gloo if use_gloo
+                else (lambda *a: None),
                 release=(lambda block: comm.release(
                     timer_handle, block, interp_handle=interp_handle)) if use_rccl
                 else None)               # (the communicator has four send-buffer slots)
@@ -291,6 +365,28 @@ def main():
             self.d_out = dev.malloc(self.ring.ring_elements)
             self.d_recv = (dev.malloc(self.ring.recv_elements)
                            if (use_rccl and comm.is_root) else ctypes.c_void_p())
+            if use_gloo and comm.is_root:
+                self.h_recv = np.zeros(self.ring.recv_elements)
+
+        def gather_gloo(self, block, send_offset, recv_offset, count):
+            synchronize()
+            host = dev.download(ctypes.c_void_p(self.d_out.value + send_offset * 8), count)
+            parts = comm.gather_host(host)
+            if comm.is_root:
+                for r, part in enumerate(parts):
+                    begin = recv_offset + r * count
+                    self.h_recv[begin:begin + count] = part
+
+        def gathered(self):
+            """The root's receive buffer as a host array (all blocks), or None."""
+            if not comm.is_root:
+                return None
+            if self.h_recv is not None:
+                return self.h_recv
+            if self.d_recv.value:
+                comm.synchronize()
+                return dev.download(self.d_recv, self.ring.recv_elements)
+            return None
 
         def gather(self, block, send_offset, recv_offset, count):
             recv = (ctypes.c_void_p(self.d_recv.value + recv_offset * 8)
@@ -469,11 +565,14 @@ def main():
                     'the region of `value` (barrier + device sync on both sides, max over '
                     'ranks)'}
 
-    if comm.dist is not None and not use_rccl:
-        # RCCL unavailable: collect the last batch over gloo so that the job still
-        # ends with the results on rank 0 (reported as "gather": "gloo").
-        host = dev.download(out_ptr((args.steps - 1) % n_slots), n_out)
-        comm.gather_host(host)
+    # What rank 0 holds at the end: every step of every rank that the ring's blocks still carry,
+    # against rank 0's OWN evaluation of that rank's draws (the same seeds: a single-rank run of
+    # that shard) -- bit for bit (the multi-rank path next to real kernels).
+    gather_check = None
+    if comm.dist is not None and args.check_gather:
+        gather_check = check_gathered(region, comm, lib, _lib, dev, handle, interp_mode,
+                                      chi2_mode, n_draws, N_R, N_GAUSS, data_p, precision_p,
+                                      synthetic, interp, synchronize)
 
     # ---- dominant kernel: contraction, per-launch start / stop events -------------------
     n_bins = 2 * N_PRIM * N_SEC
@@ -667,6 +766,8 @@ def main():
         }
         if comm.rccl_error:
             result['config']['rccl_error'] = comm.rccl_error
+        if gather_check is not None:
+            result['gather_check'] = gather_check
         if second is not None:
             result['second_payload'] = second
 

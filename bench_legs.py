@@ -59,16 +59,36 @@ def matrix_pipe_busy(kernel, step_seconds, simds=1024, clock_hz=2.4e9):
                     % (os.path.relpath(pmc_file(''), REPO), simds, clock_hz * 1e-9)}
 
 
+# Look-ups that found a committed PMC file for the configuration but NOT the kernel that was
+# timed (the profiles were taken with another build of the library): bench.py reports them under
+# `failed_legs` instead of quietly printing "traffic": null.
+pmc_failures = []
+
+
+def pmc_missing(kernel, what, path):
+    message = '%s of %s: not in %s (profiles of another build?)' % (
+        what, kernel, os.path.relpath(path, REPO))
+    if message not in pmc_failures:
+        pmc_failures.append(message)
+        print('detail pmc look-up failed: ' + message, file=sys.stderr)
+
+
 def pmc_counter(kernel, counter, tag=''):
     """Mean of one raw counter per launch of `kernel` from the committed rocprofv3 --pmc passes
-    of configuration `tag`, or None."""
+    of configuration `tag`; None when there is no committed file for the configuration, and
+    None + an entry in `pmc_failures` when the file does not hold the kernel."""
     path = pmc_file(tag)
     if path is None:
         return None
+    seen_counter = False
     for line in open(path).read().splitlines():
         match = re.match(r'(.*?)\s+(\w+)\s+n=\s*\d+\s+mean=([0-9.e+]+)', line)
-        if match and match.group(2) == counter and same_kernel(kernel, match.group(1)):
-            return float(match.group(3))
+        if match and match.group(2) == counter:
+            seen_counter = True
+            if same_kernel(kernel, match.group(1)):
+                return float(match.group(3))
+    if seen_counter:
+        pmc_missing(kernel, counter, path)
     return None
 
 
@@ -96,6 +116,7 @@ def pmc_traffic(kernel, tag=''):
         if match and same_kernel(kernel, match.group(1)):
             values[match.group(2)] = float(match.group(3))
     if len(values) != 2:
+        pmc_missing(kernel, 'FETCH_SIZE / WRITE_SIZE', path)
         return None, None
     return ((2.0 * values['FETCH_SIZE'] + values['WRITE_SIZE']) * 1024.0,
             os.path.relpath(path, REPO))

@@ -70,6 +70,13 @@ typedef struct tc_comm tc_comm;
 /* ---- runtime ---------------------------------------------------------------------- */
 
 const char* tc_last_error(void);
+/* The copies that end a synchronous host call (results from the page-locked staging area into
+ * the caller's arrays) are shared with `helpers` threads of the library (default 3, 0 .. 7; 0:
+ * the calling thread copies alone), which poll for the next job for `spin_us` microseconds
+ * (default 100, 0 .. 100000) before they sleep: set both to 0 where every core runs a rank of
+ * its own.  Process-wide; the threads are started by the first large copy, and a forked child
+ * starts its own. */
+int tc_set_copy_threads(int helpers, int spin_us);
 int tc_device_count(int* count);
 int tc_set_device(int device);
 int tc_get_device(int* device);
@@ -397,6 +404,11 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 back to one launch per call for 4096 calls when more than a quarter of 32
  *                 such calls found the kernel gone (a caller that pauses or synchronises the
  *                 device between its calls).  Single draws only; ensembles need 1.
+ *                 Whichever of the two kernels serves a call, the bits are the same (round 6:
+ *                 both are instances of one body compiled with -ffp-contract=on), and an error
+ *                 of the resident kernel in this mode never reaches the caller: the kernel is
+ *                 stopped, the call served by a launch, the mode suspended for 4096 calls
+ *                 and switched off after three such failures.
  *                 0: one launch per call, always.
  *                 Calls with 24 .. 256 draws in host arrays (an ensemble sampler's step) are
  *                 served the same way by a second resident kernel of one workgroup per CU
@@ -418,8 +430,37 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 ensemble kernel lies in device memory that the host stores into through
  *                 the PCIe aperture (no PCIe reads while the kernel polls); 0: in page-locked
  *                 host memory, as on systems without a large BAR.
+ *   "deterministic"  which of a call's possible kernel forms runs, and hence the LAST BITS of its
+ *                 results (every form agrees with the reference to ~1e-14; the reference itself,
+ *                 tabcorr/tabcorr.py:580-683, is deterministic).
+ *                 0 (default): the fastest form for the call -- a function of the table, the
+ *                 flags, the entry point (un-batched, host arrays, device pointers,
+ *                 asynchronous) and the batch size.  Never of timing or of the number of calls
+ *                 made so far (round 6: "autotune_after" is off by default and the two
+ *                 un-batched kernels give the same bits), so the same sequence of calls
+ *                 returns the same bits in every run; the same DRAW in batches of different
+ *                 sizes, or through different entry points, may differ in the last bits.
+ *                 1: the same, and "autotune" / "autotune_after" are refused (nothing
+ *                 measured can enter the choice).
+ *                 2: batch-invariant -- ONE form per (table, flags): the one-launch kernel
+ *                 (predict_fused_kernel with 64-draw workgroups, or the mode-cross one-launch
+ *                 kernel with one workgroup per 64 draws) for every entry point and every
+ *                 batch size, one draw included, so that a draw's (ngal, xi) depends on the
+ *                 draw alone: wherever it sits in whatever batch, synchronous or asynchronous,
+ *                 first call or millionth.  Where no one-launch form serves the table and the
+ *                 flags (tc_table_batch_invariant says: float32 tables, several r tiles, more
+ *                 than 248 bins, interpolators in mode auto, fused likelihood of separated
+ *                 components) the call runs as with 1.  What it costs: un-batched calls
+ *                 ~70 us instead of ~10-18 (a whole workgroup's latency for one draw); batches
+ *                 below ~8000 draws up to 2x (64-draw workgroups do not fill the chip);
+ *                 batches of 10^4 draws and more nothing (it is the default form there).
+ *                 Setting the option waits for the handle's work in flight.
  *   "trace"       developer timelines (developer builds only, tabcorr_amd_testing.h). */
 int tc_table_set_option(tc_table* table, const char* name, int value);
+/* *out = 1 when option "deterministic" = 2 is set AND a one-launch form serves this table with
+ * these predict flags and n_gauss_prim: every batched, un-batched and asynchronous call with
+ * them then runs that one form (a draw's bits depend on the draw alone); else 0. */
+int tc_table_batch_invariant(tc_table* table, int n_gauss, unsigned flags, int* out);
 /* What option "autotune" measured for `flags`: per batch size (`count` of them, at most
  * `capacity`: 9) the form chosen (0 three kernels, 64 / 32: draws per workgroup of the
  * one-launch form) and the microseconds per call of the three forms in that order, us

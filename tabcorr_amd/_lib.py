@@ -84,6 +84,8 @@ SIGNATURES = {
     'tc_table_destroy': [ctypes.c_void_p],
     'tc_table_autotune_result': [ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, c_int_p,
                                  c_int64_p, c_int_p, c_float_p],
+    'tc_table_batch_invariant': [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, c_int_p],
+    'tc_set_copy_threads': [ctypes.c_int, ctypes.c_int],
     'tc_table_synchronize': [ctypes.c_void_p],
     'tc_table_info': [ctypes.c_void_p, c_int_p, c_int_p, c_int_p, c_int64_p,
                       c_int_p, c_int64_p],

@@ -19,8 +19,9 @@ LIBRARY = os.path.join(HERE, 'libtabcorr_hip.so')
 # inst_*.hip hold the kernel instances of the prediction path (one unit per kernel family: they
 # compile in parallel, the longest first), paircount.hip the tabulation kernels; launch.hip and
 # the .cpp units are host code
-SOURCES = ['inst_fused.hip', 'inst_fused32.hip', 'inst_fused16.hip', 'inst_cross.hip',
-           'inst_quad.hip', 'inst_single.hip', 'launch.hip', 'paircount.hip', 'table.cpp', 'interp.cpp', 'comm.cpp', 'runtime.cpp', 'hostmath.cpp']
+SOURCES = ['inst_fused.hip', 'inst_fused32.hip', 'inst_fused16.hip', 'inst_fused40.hip',
+           'inst_cross.hip', 'inst_quad.hip', 'inst_single.hip', 'launch.hip', 'paircount.hip',
+           'table.cpp', 'interp.cpp', 'comm.cpp', 'runtime.cpp', 'hostmath.cpp']
 # per-unit flags (inst_single.hip: see its header)
 EXTRA_FLAGS = {'inst_single.hip': ['-ffp-contract=on']}
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-gpu-rdc',

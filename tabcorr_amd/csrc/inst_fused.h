@@ -37,8 +37,11 @@ int launch_fused(int device, int n_u, dim3 grid, dim3 block, int lds, hipStream_
 }  // namespace
 
 // (the parts of the family: 8 waves x 64 draws in inst_fused.hip, 8 x 32 in inst_fused32.hip,
-// 16 x 64 in inst_fused16.hip)
+// 16 x 64 in inst_fused16.hip, 8 x 40 -- the latency form -- in inst_fused40.hip)
 int launch_fused_instance_32(const FusedInstance& in, int device, int n_u, dim3 grid, dim3 block,
+                             int lds, hipStream_t stream, hipEvent_t k0, hipEvent_t k1,
+                             const tc::FusedArgs& fa);
+int launch_fused_instance_40(const FusedInstance& in, int device, int n_u, dim3 grid, dim3 block,
                              int lds, hipStream_t stream, hipEvent_t k0, hipEvent_t k1,
                              const tc::FusedArgs& fa);
 int launch_fused_instance_16(const FusedInstance& in, int device, int n_u, dim3 grid, dim3 block,

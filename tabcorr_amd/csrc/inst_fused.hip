@@ -10,6 +10,7 @@ int launch_fused_instance(const FusedInstance& in, int device, int n_u, dim3 gri
                        int lds, hipStream_t stream, hipEvent_t k0, hipEvent_t k1,
                        const tc::FusedArgs& fa) {
   const bool assembias = in.assembias, modulate = in.modulate;
+  if (in.draws == 40) return launch_fused_instance_40(in, TC_FUSED_ARGS);
   if (in.draws == 32) return launch_fused_instance_32(in, TC_FUSED_ARGS);
   if (in.waves == 16) return launch_fused_instance_16(in, TC_FUSED_ARGS);
 #define TC_FUSED(NG, AB, MO, LE) launch_fused<NG, AB, MO, LE, 8>(TC_FUSED_ARGS)

@@ -1,6 +1,7 @@
 // Kernels of the three-kernel path (occupations, contraction, finalisation), the segment
 // kernels, the interpolator's coefficients and the likelihood: their launches, in a translation
 // unit of their own.
+#define TC_UNIT_QUAD
 #include "internal.h"
 #include "kernels.hip.h"
 

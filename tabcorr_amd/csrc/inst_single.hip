@@ -5,6 +5,7 @@
 // out ~1e-14 apart depending on which of the two served it.
 #include <mutex>
 
+#define TC_UNIT_SINGLE
 #include "internal.h"
 #include "kernels.hip.h"
 

@@ -113,6 +113,9 @@ bool is_pinned(const void* ptr, size_t bytes, void** device_ptr = nullptr);
 // memcpy shared with a few helper threads from 256 KB on (runtime.cpp: CopyPool): the results'
 // way out of the staging areas at the end of a synchronous host call.
 void parallel_copy(void* dst, const void* src, size_t bytes);
+// Helper threads of that copy (0: none) and how long they poll for the next job before they
+// sleep (tc_set_copy_threads).
+void configure_copy_pool(int helpers, int spin_us);
 
 // (developer builds only: environment overrides)
 inline int env_int_early(const char* name, int fallback) {
@@ -358,7 +361,18 @@ struct Tuning {
   int fused_draws = 0;          // draws per workgroup of the one-launch form: 0 = 32 for batches
                                 // below 8192 draws where that form applies, else 64
                                 // (launch.hip: fused_half_tiles); 32 / 64: forced
+  // the latency form of the one-launch kernel (40 draws per workgroup, one workgroup per CU:
+  // launch.hip: fused_spread_eligible) for calls that run alone: 1 on; smallest batch; largest
+  // batch in rounds of one workgroup per CU
+  int fused_spread = 1, fused_spread_min = 8192, fused_spread_rounds = 1;
   int prio_fused = 1, prio_fused_occ = 2, prio_fused_out = 3;   // phases 2, 1, 3
+  // Reproducible bits on request (round 6).  0: the fastest form per call -- a function of the
+  // table, the flags, the entry point and the batch size (never of timing: autotune_after is
+  // off by default); 1: the same, and the measured dispatch ("autotune", "autotune_after") is
+  // refused; 2: BATCH-INVARIANT -- one kernel form per (table, flags) for every entry point and
+  // every batch size, one draw included, wherever a one-launch form serves the table
+  // (launch.hip: batch_invariant_form), so that a draw's (ngal, xi) depends on the draw alone
+  int deterministic = 0;
   int skip_occ = 0, skip_finalize = 0;   // diagnosis (developer builds only)
   void load() {
     fused = env_int("TC_FUSED", fused);
@@ -476,6 +490,10 @@ struct tc_table {
   // AbacusSummit interpolator, one chunk: 242 -> 200 us per 10^4 draws host to host; its single
   // table, two chunks: 149 -> 139; pipelined launches keep 160: they share the chip anyway).
   int sync_cross_target = 0;
+  // ... and that the chunks of such a call have the chip to themselves: where the latency form
+  // of the one-launch kernel serves the table, every chunk takes it when all chunks together
+  // have at most one workgroup of 40 draws per CU (launch.hip: fused_spread_eligible)
+  bool sync_spread = false;
   bool quad = false;
   tc::QuadTiling quad_tiling;
   tc::host::QuadTable quad_by_type, quad_total;
@@ -557,6 +575,8 @@ struct tc_table {
     int auto_mode = 1;
     int auto_idle_us = 250, auto_gap_us = 300, auto_streak_min = 8, auto_backoff_calls = 4096;
     int auto_streak = 0, auto_backoff = 0, auto_window = 0, auto_relaunches = 0;
+    int auto_failures = 0;               // calls the automatic mode had to hand back to a launch
+    int inject_failures = 0;             // test hook: the next calls of resident_predict fail
     long long auto_last_ns = 0;          // when the last un-batched call returned
     bool auto_serving = false;           // the running launch was started by the automatic mode
     unsigned long long relaunches = 0;   // calls that found the kernel gone (all modes)
@@ -641,6 +661,9 @@ int run_contraction(tc_table* t, int64_t n_draws, int64_t ldb, unsigned flags,
 // One launch per slab (predict_fused_kernel) for the calls it covers; ngal and xi (or the
 // likelihood, t->fuse_chi2_out) as run_contraction leaves them.
 bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags);
+// Option "deterministic" = 2: is there a one-launch form for this table and these flags (whose
+// bits do not depend on the batch)?  Every entry point then takes it for every batch size.
+bool batch_invariant_form(tc_table* t, int n_gauss, unsigned flags);
 int fused_dens_rows(const tc_table* t, bool separate);
 int fused_lds_bytes(const tc_table* t, bool separate, int waves, int draws);
 int fused_waves(const tc_table* t, bool separate, unsigned flags);
@@ -648,6 +671,7 @@ int series_mask(const tc_table* t);
 bool fused_half_tiles(const tc_table* t, bool separate, int64_t n_draws, int n_gauss,
                       unsigned flags);
 bool fused_wide_tables(const tc_table* t, bool separate, int n_gauss, unsigned flags);
+bool fused_spread_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags);
 int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_draws, int n_gauss,
               unsigned flags, double* ngal_device, double* xi_device);
 int check_predict_args(const tc_table* t, const void* theta, int n_theta, int64_t n_draws,
@@ -734,7 +758,7 @@ int launch_occ_from_array_kernel(const double* occupation_device, int64_t n_draw
 struct FusedInstance {
   int n_gauss = 10;          // 10, or 0 = any number of nodes
   bool assembias = false, modulate = false, leauthaud = false, grouped = false;
-  int waves = 8, draws = 64; // 8 x 64, 16 x 64, 8 x 32
+  int waves = 8, draws = 64; // 8 x 64, 16 x 64, 8 x 32, 8 x 40 (the latency form)
   int defer = 0;             // SATDEFER (8 x 64, undecorated Zheng07, ten nodes)
 };
 int launch_fused_instance(const FusedInstance& instance, int device, int n_u, dim3 grid,

@@ -771,7 +771,17 @@ int tc_interp_predict_zheng07_batch(tc_interp* it, const double* theta, int n_th
   if (n_draws == 0) return TC_OK;
   TC_CHECK(x && ngal && xi, "NULL pointer");
   TC_HIP(hipSetDevice(it->device));
-  if (single_draw_eligible(it->tables[0], n_draws, n_gauss, flags) &&
+  // (option "deterministic" = 2 of the first table, mode cross: the one-launch form for every
+  // batch size, one draw included)
+  bool invariant = false;
+  if (it->tables[0]->tuning.deterministic >= 2 && it->tables[0]->mode == TC_MODE_CROSS &&
+      !it->tables[0]->cross_host.empty() && it->tables[0]->tuning.fused != 0) {
+    const CrossFused& cf = *choose_cross_fused(it->tables.data(), it->n_tables, &it->cross_fused,
+                                               &it->cross_fused_wide, n_draws, flags, &status);
+    if (status != TC_OK) return status;
+    invariant = cross_fused_eligible(it->tables[0], cf, n_draws, n_gauss, flags, true);
+  }
+  if (!invariant && single_draw_eligible(it->tables[0], n_draws, n_gauss, flags) &&
       (int64_t)it->n_tables * single_draw_blocks(it->tables[0]) <= 8192)
     return interp_predict_one(it, theta, n_theta, x, n_gauss, flags, ngal, xi);
   const bool separate = (flags & TC_FLAG_SEPARATE_GAL_TYPE) != 0;

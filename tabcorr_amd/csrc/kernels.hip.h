@@ -484,9 +484,18 @@ __device__ __forceinline__ double occ_bin_zheng07_halves(const double* table, co
       acc = fma(w_p[k], fma(s_cen, fmin(n, 1.0 - n), n), acc);
     }
   } else if (central) {
+    // (each half closes its own affine map 0.5 (sum_k w_k erf_k + sum_k w_k) with the weights
+    // added in the order of the node sum: where every erf is -1 -- no centrals at all -- the
+    // two sums cancel EXACTLY, as the reference's 0.5 (1 + erf) = 0 per node does
+    // (tabcorr.py:556-578); against the bin's sum over all ten weights the halves' rounding
+    // left -4e-19 there, and 0 / 0 = NaN became a finite number)
+    double ws = 0.0;
 #pragma unroll
-    for (int k = 0; k < kHalf; ++k)
+    for (int k = 0; k < kHalf; ++k) {
       acc = fma(w_p[k], fm::erf_fast(table, kc, (lm_p[k] - d.log_m_min) * d.inv_sigma), acc);
+      ws += w_p[k];
+    }
+    acc = fma(0.5, acc, 0.5 * ws);
   } else {
 #pragma unroll
     for (int k = 0; k < kHalf; ++k) {
@@ -502,7 +511,6 @@ __device__ __forceinline__ double occ_bin_zheng07_halves(const double* table, co
   }
   acc += __shfl_xor(acc, 32, 64);            // both halves hold the bin's sum
   if (!central) acc *= d.sat_scale;
-  else if (!ASSEMBIAS) acc = fma(0.5, acc, 0.5 * weight_sum[g]);
   if (!central && ASSEMBIAS) acc = fma(s_sat, acc, acc);
   if (d.any_bad) {
     const int bad = d.bad;
@@ -876,7 +884,6 @@ __device__ __forceinline__ void occ_group_zheng07_halves(
     const double s_sat = above ? d.a_sat : -d.a_sat;
     acc += __shfl_xor(acc, 32, 64);            // both halves hold the bin's sum
     if (!central) acc *= d.sat_scale;
-    else if (!ASSEMBIAS) acc = fma(0.5, acc, 0.5 * q.weight_sum[mi]);
     if (!central && ASSEMBIAS) acc = fma(s_sat, acc, acc);
     if (d.any_bad) {
       const int bad = d.bad;
@@ -932,6 +939,18 @@ __device__ __forceinline__ void occ_group_zheng07_halves(
       for (int k = 0; k < kHalf; ++k) {
         acc_i = fma(w_i[k], v[k], acc_i);
         acc_j = fma(w_j[k], v[k], acc_j);
+      }
+      if (central) {
+        // (the half's own affine map, weights added in the order of its node sum: exact
+        // cancellation where every erf is -1 -- occ_bin_zheng07_halves)
+        double ws_i = 0.0, ws_j = 0.0;
+#pragma unroll
+        for (int k = 0; k < kHalf; ++k) {
+          ws_i += w_i[k];
+          ws_j += w_j[k];
+        }
+        acc_i = fma(0.5, acc_i, 0.5 * ws_i);
+        acc_j = fma(0.5, acc_j, 0.5 * ws_j);
       }
     }
     acc_i = finish(mi, acc_i);
@@ -1341,6 +1360,7 @@ __global__ __launch_bounds__(kOccWaves * kLanes) void occ_leauthaud11_kernel(Occ
 
 // Occupations supplied by the caller (the ndarray seam, tabcorr.py:616-623):
 // nbuf[g'][b] = occupation[b][perm[g']] * n_h[g'] and the two sums.
+#ifdef TC_UNIT_QUAD   // (emitted by the unit that launches it, which defines the macro)
 static __global__ __launch_bounds__(256) void occ_from_array_kernel(
     const double* occupation, int64_t n_draws, int64_t ldb, int n_bins,
     int n_central, const double* n_h, const int32_t* perm, double* nbuf,
@@ -1358,6 +1378,7 @@ static __global__ __launch_bounds__(256) void occ_from_array_kernel(
   ngal[b0] = sum_cen;
   ngal[ldb + b0] = sum_sat;
 }
+#endif
 
 // ---- FP64 matrix-core contraction -----------------------------------------------------
 //
@@ -2194,7 +2215,19 @@ __global__ __launch_bounds__(1024) void finalize_quad_kernel(FinalizeQuadArgs a)
 // (W waves per workgroup: 8 = two 32-draw tiles x four parts of the units, two workgroups per
 // CU; 16 = eight parts per tile, one workgroup with up to 160 KB of LDS per CU -- tables of
 // more than 104 bins)
-constexpr int fused_slot_doubles(int waves) { return waves * 4 * kQuadMaxU * kQuadTile; }
+constexpr int fused_slot_doubles(int waves, int draws = 64) {
+  // (the waves' sums: per wave 4 U rows of one 32-draw tile, or -- 40 draws per workgroup --
+  // of all its draws)
+  return waves * 4 * kQuadMaxU * (draws == 40 ? 40 : kQuadTile);
+}
+// 40 draws per workgroup (the latency form, below): where draw d of bin row `row` lies in the
+// LDS density array -- the ten draws d = 4 dg + j of one j side by side, so that a lane of
+// v_mfma_f64_4x4x4 (which wants dens[k][4 dg + j] for every dg) reads them as five 16-byte
+// words; the sixteen (row % 4, j) starts 320 row + 80 j bytes fall into sixteen different
+// 16-byte bank groups of the 256-byte LDS line: no conflicts.
+__device__ __forceinline__ constexpr int dens40(int row, int draw) {
+  return row * 40 + (draw & 3) * 10 + (draw >> 2);
+}
 constexpr int fused_scratch_doubles(int waves) { return fm::kTableDoubles + 2 * waves * kLanes; }
 static_assert(kFusedWaves == 8 && kFusedMaxParts == 8, "8 or 16 waves: 4 or 8 parts per tile");
 static_assert(20 * (kLanes + 1) + 20 * 21 <= fm::kTableDoubles,
@@ -2279,16 +2312,138 @@ __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, uns
   }
 }
 
+// The latency form's pass (40 draws per workgroup, v_mfma_f64_4x4x4_4b_f64): `count` units from
+// block (rb, cb) on for the NS r sub-tiles S0 .. S0 + NS - 1 and ALL 40 draws of the workgroup.
+// The table's unit layout serves this instruction as it stands: lane l = 16 k + 4 i + r holds
+// T[r][row 4 rb + i][column 4 cb + k] = A_block=i [r][k]; with B_block [k][j] = dens[4 cb + k][4
+// dg + j] (the same for every block) lane l receives D = sum_k T[r = l / 16][row i = (l / 4) %
+// 4][k] dens[k][draw j = l % 4] (lane <-> element map: tools/micro/mfma_map.hip), which times
+// dens[4 rb + i][4 dg + j] is the lane's share of F[r][draw]: the four i of a (r, j) are added
+// once, after the walk.  F[s][dg] += ... per lane.
+template <int S0, int NS>
+__device__ __forceinline__ void fused_quad_pass40(__amdgpu_buffer_rsrc_t rs_t, unsigned off_a,
+                                                  unsigned unit_bytes, const double* dens_b,
+                                                  const double* dens_e, int rb, int cb, int left,
+                                                  bool triangular, int n_cb, unsigned unit_base,
+                                                  double (&F)[NS][10]) {
+  unsigned ua = (unit_base + (unsigned)(triangular ? rb * (rb + 1) / 2 + cb : rb * n_cb + cb)) *
+                unit_bytes;
+  // (a unit holds the sub-tiles in pairs, 16 bytes per lane and pair: whole pairs come by one
+  // 16-byte load, a single sub-tile of a pair by an 8-byte load of its half -- a 16-byte load
+  // whose other half nobody reads invites the register allocator to reuse that half at once,
+  // and the wave then waits for the load where it writes the register)
+  double ta[2][NS];
+  f64x2 tb[2][5];
+  double D[NS][10];
+  auto fetch = [&](int set, int column) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      constexpr int kPairBytes = 1024;
+      const int sub = S0 + s;
+      const bool first_of_pair = (sub & 1) == 0 && s + 1 < NS;
+      const bool second_of_pair = (sub & 1) == 1 && s >= 1;
+      if (first_of_pair) {
+        const f64x2 word = __builtin_bit_cast(
+            f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs_t, off_a + (sub / 2) * kPairBytes, ua,
+                                                         0));
+        ta[set][s] = word.x;
+        ta[set][s + 1 < NS ? s + 1 : s] = word.y;
+      } else if (!second_of_pair) {
+        ta[set][s] = __builtin_bit_cast(
+            double, __builtin_amdgcn_raw_buffer_load_b64(
+                        rs_t, off_a + (sub / 2) * kPairBytes + (sub & 1) * 8, ua, 0));
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) tb[set][q] = *(const f64x2*)(dens_b + 4 * column * 40 + 2 * q);
+    ua += unit_bytes;
+  };
+  // (the first unit of a block row starts the sums: C = 0 instead of 30 register clears)
+  auto mma = [&](int set, bool first) {
+    if (first) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const double av = ta[set][s];
+          D[s][2 * q] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, tb[set][q].x, 0.0, 0, 0, 0);
+          D[s][2 * q + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, tb[set][q].y, 0.0, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const double av = ta[set][s];
+          D[s][2 * q] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, tb[set][q].x, D[s][2 * q], 0, 0, 0);
+          D[s][2 * q + 1] =
+              __builtin_amdgcn_mfma_f64_4x4x4f64(av, tb[set][q].y, D[s][2 * q + 1], 0, 0, 0);
+        }
+    }
+  };
+  fetch(0, cb);
+  while (left > 0) {
+    const int row_length = triangular ? rb + 1 : n_cb;
+    const int n = row_length - cb < left ? row_length - cb : left;
+    left -= n;
+    // (the row's own densities, requested here: they have arrived long before the row ends)
+    f64x2 e[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) e[q] = *(const f64x2*)(dens_e + 4 * rb * 40 + 2 * q);
+    int t = 0;
+    if (n > 1) {
+      fetch(1, cb + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(0, true);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(0, 2 < n ? cb + 2 : 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(1, false);
+      __builtin_amdgcn_sched_barrier(0);
+      t = 2;
+    }
+    for (; t + 1 < n; t += 2) {
+      fetch(1, cb + t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(0, false);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(0, t + 2 < n ? cb + t + 2 : 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(1, false);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (t < n) {
+      fetch(1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t == 0) mma(0, true); else mma(0, false);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) ta[0][s] = ta[1][s];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) tb[0][q] = tb[1][q];
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        F[s][2 * q] = fma(D[s][2 * q], e[q].x, F[s][2 * q]);
+        F[s][2 * q + 1] = fma(D[s][2 * q + 1], e[q].y, F[s][2 * q + 1]);
+      }
+    ++rb;
+    cb = 0;
+  }
+}
+
 template <int NGAUSS, int U, bool ASSEMBIAS, bool MODULATE, bool LEAUTHAUD = false,
           int W = kFusedWaves, int DL = 64, bool GROUPED = false, int SATDEFER = 0>
-__global__ __launch_bounds__(64 * W, W == 8 ? (SATDEFER == 2 ? 4 : 2) : 1) void predict_fused_kernel(
+__global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 : 2) : 1) void predict_fused_kernel(
     FusedArgs a) {
   // SATDEFER (round 5; undecorated Zheng07, ten nodes, 64 draws): the satellites' expansion for
   // the lanes it serves, and the (bin, draw) pairs it does not serve evaluated after the
   // wave's bins, 64 pairs per pass of the node loop -- see "deferred pairs" below.  2: the
   // central bins likewise (records, the centrals no expansion serves deferred: the node loop of
   // the centrals leaves the loop of bins as well)
-  static_assert(!SATDEFER || (NGAUSS == 10 && !ASSEMBIAS && !MODULATE && !LEAUTHAUD && DL == 64 &&
+  static_assert(!SATDEFER || (NGAUSS == 10 && !ASSEMBIAS && !MODULATE && !LEAUTHAUD && DL != 32 &&
                               !GROUPED), "deferred pairs");
   // GROUPED: the waves stride over the groups of bins that share their nodes (occ_group_zheng07)
   static_assert(!GROUPED || (NGAUSS == 10 && !LEAUTHAUD), "groups of bins: Zheng07, ten nodes");
@@ -2297,20 +2452,37 @@ __global__ __launch_bounds__(64 * W, W == 8 ? (SATDEFER == 2 ? 4 : 2) : 1) void 
   // phase, occ_bin_zheng07_halves; two workgroups of up to 80 KB per CU): a quarter of the
   // 64-draw workgroup's lifetime -- batches below 8192 draws --, and tables of 105-208 bins
   // with the wave count per SIMD of the 64-draw form
-  static_assert((DL == 64 && (W == 8 || W == 16)) || (DL == 32 && W == 8), "workgroup shape");
-  static_assert(DL == 64 || NGAUSS == 10 || LEAUTHAUD, "32 draws: ten nodes per bin");
-  constexpr int PARTS = W * 32 / DL;       // waves per 32-draw tile
+  // DL = 40 (round 6, the LATENCY form): ONE workgroup per CU and 250 of them for 10^4 draws,
+  // so that a launch that has the chip to itself fills it (64-draw workgroups: 157 of 256 CUs).
+  // Phase 1 as for 64 draws with lanes 40 .. 63 idle; phase 2 on v_mfma_f64_4x4x4_4b_f64, whose
+  // draw granularity is 4 instead of 16 (fused_quad_pass40): every wave takes an eighth of the
+  // units for all 40 draws.  Undecorated Zheng07, ten nodes, total correlation function.
+  static_assert((DL == 64 && (W == 8 || W == 16)) || ((DL == 32 || DL == 40) && W == 8),
+                "workgroup shape");
+  static_assert(DL == 64 || NGAUSS == 10 || LEAUTHAUD, "32 / 40 draws: ten nodes per bin");
+  static_assert(DL != 40 || (!ASSEMBIAS && !MODULATE && !LEAUTHAUD && !GROUPED), "latency form");
+  constexpr int PARTS = DL == 40 ? W : W * 32 / DL;       // waves per tile
   static_assert(!LEAUTHAUD || (NGAUSS == 0 && !ASSEMBIAS), "Leauthaud11: any n_gauss, undecorated");
   constexpr int UP = (U + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) double fused_lds[];
   // region B: densities, later the waves' sums; region A: math table, later the results tile
   // and the likelihood's data | ngal sums
-  constexpr int kSlotDoubles = fused_slot_doubles(W);
+  constexpr int kSlotDoubles = fused_slot_doubles(W, DL);
   const int region_b = a.dens_rows * DL > kSlotDoubles ? a.dens_rows * DL : kSlotDoubles;
   double* dens = fused_lds;
   double* table = fused_lds + region_b;
   double(*red)[W][kLanes] = (double(*)[W][kLanes])(table + fm::kTableDoubles);
   const fm::Consts kc = fm::make_consts();
+#ifdef TC_DEVELOPER_KNOBS
+  // (diagnosis, TC_FUSED_SKIP: 1 no occupations -- every density 1e-3 --, 2 no matrix phase)
+  const int skip = (a.priority >> 8) & 3;
+  const int n_bins_occ = (skip & 1) ? 0 : a.n_bins;
+  if (skip & 1)
+    for (int idx = threadIdx.x; idx < a.n_bins * DL; idx += blockDim.x) fused_lds[idx] = 1e-3;
+#else
+  constexpr int skip = 0;
+  const int n_bins_occ = a.n_bins;
+#endif
   set_priority((a.priority >> 2) & 3);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2327,8 +2499,14 @@ __global__ __launch_bounds__(64 * W, W == 8 ? (SATDEFER == 2 ? 4 : 2) : 1) void 
   __syncthreads();
 
   // ---- 1. occupations ----
-  const int draw = DL == 64 ? lane : (lane & 31);
-  const int half = DL == 64 ? 0 : (lane >> 5);
+  const int draw = DL != 32 ? lane : (lane & 31);
+  const int half = DL != 32 ? 0 : (lane >> 5);
+  // (40 draws: lanes 40 .. 63 evaluate draws of the next workgroup -- or the batch's last --
+  // and neither write nor defer anything)
+  const bool live = DL != 40 || lane < 40;
+  auto dens_at = [&](int row, int d) -> double& {
+    return dens[DL == 40 ? dens40(row, d) : row * DL + d];
+  };
   const int64_t col = (int64_t)blockIdx.x * DL;
   const int64_t b0 = col + draw;
   const int64_t b = b0 < a.n_draws ? b0 : a.n_draws - 1;
@@ -2355,8 +2533,8 @@ __global__ __launch_bounds__(64 * W, W == 8 ? (SATDEFER == 2 ? 4 : 2) : 1) void 
     dp.a_sat = d.a_sat;
     dp.bad = d.bad;
     dp.any_bad = __builtin_amdgcn_ballot_w64(dp.bad != 0) != 0;
-    series_setup<MODULATE>(dp, (GROUPED ? a.group.series : a.series) != nullptr && DL == 64,
-                           (GROUPED ? a.group.sat_series : a.sat_series) != nullptr && DL == 64);
+    series_setup<MODULATE>(dp, (GROUPED ? a.group.series : a.series) != nullptr && DL != 32,
+                           (GROUPED ? a.group.sat_series : a.sat_series) != nullptr && DL != 32);
     sc_f64 log_m = (sc_f64)a.log_m;
     sc_f64 mass = (sc_f64)a.m;
     sc_f64 weight = (sc_f64)a.weight;
@@ -2391,7 +2569,7 @@ __global__ __launch_bounds__(64 * W, W == 8 ? (SATDEFER == 2 ? 4 : 2) : 1) void 
       }
     }
     unsigned mine = 0;        // SATDEFER: bit j = this lane's draw defers the wave's j-th bin
-    for (int g = wave; g < (GROUPED ? 0 : a.n_bins); g += W) {
+    for (int g = wave; g < (GROUPED ? 0 : n_bins_occ); g += W) {
       const bool central = g < a.n_central;
       const bool above = ASSEMBIAS ? percentile[g] > a.split : false;
       bool deferred = false;
@@ -2419,9 +2597,9 @@ __global__ __launch_bounds__(64 * W, W == 8 ? (SATDEFER == 2 ? 4 : 2) : 1) void 
                               (sc_i32)a.sat_series_thr,
                               SATDEFER ? a.sat_cap : series::sat::kSteps - 1},
                             SATDEFER ? &deferred : nullptr);
-      if (SATDEFER && deferred) mine |= 1u << ((g - wave) / W);
+      if (SATDEFER && deferred && live) mine |= 1u << ((g - wave) / W);
       const double value = acc * n_h[g];
-      if (half == 0) dens[g * DL + draw] = value;
+      if (half == 0 && live) dens_at(g, draw) = value;
       if (central) sum_cen += value; else sum_sat += value;
     }
     if (SATDEFER) {
@@ -2433,7 +2611,7 @@ __global__ __launch_bounds__(64 * W, W == 8 ? (SATDEFER == 2 ? 4 : 2) : 1) void 
       // where the draw's own lane adds it to its sum in bin order.  What a draw defers depends
       // on the draw alone: the same bits wherever it sits in the batch.
       unsigned* list = (unsigned*)&red[1][wave][0];
-      const int n_mine = (a.n_bins - wave + W - 1) / W;
+      const int n_mine = (n_bins_occ - wave + W - 1) / W;
       int total = 0;
       for (int j = 0; j < n_mine; ++j)
         total += __builtin_popcountll(__builtin_amdgcn_ballot_w64((mine >> j) & 1u));
@@ -2515,11 +2693,11 @@ __global__ __launch_bounds__(64 * W, W == 8 ? (SATDEFER == 2 ? 4 : 2) : 1) void 
         }
         if (!cen_pair) acc = sat;
         }
-        if (active) dens[g * DL + from] = acc * a.n_h[g];
+        if (active) dens_at(g, from) = acc * a.n_h[g];
       }
       for (int j = 0; j < n_mine; ++j)
         if ((mine >> j) & 1u) {
-          const double value = dens[(wave + W * j) * DL + draw];
+          const double value = dens_at(wave + W * j, draw);
           if (SATDEFER == 2 && wave + W * j < a.n_central) sum_cen += value;
           else sum_sat += value;
         }
@@ -2533,9 +2711,9 @@ __global__ __launch_bounds__(64 * W, W == 8 ? (SATDEFER == 2 ? 4 : 2) : 1) void 
       n_cen += red[0][w][lane];
       n_sat += red[1][w][lane];
     }
-    const double total = n_cen + n_sat;
+    const double total = (skip & 1) ? 1.0 : n_cen + n_sat;
     norm = total * total;
-    if (wave == 0 && half == 0 && b0 < a.n_draws) {
+    if (wave == 0 && half == 0 && live && b0 < a.n_draws) {
       if (a.separate) {
         a.ngal[2 * b0] = n_cen;
         a.ngal[2 * b0 + 1] = n_sat;
@@ -2549,7 +2727,37 @@ __global__ __launch_bounds__(64 * W, W == 8 ? (SATDEFER == 2 ? 4 : 2) : 1) void 
   set_priority(a.priority & 3);
   const int c = lane & 15, kq = lane >> 4;
   double F[UP][2][2];
-  {
+  // (40 draws: three, then the other r sub-tiles -- accumulators and sums of up to 3 x 10
+  // (sub-tile, four draws) pairs per lane in either pass)
+  constexpr int UA = DL == 40 ? (U > 3 ? 3 : U) : 1, UB = DL == 40 && U > 3 ? U - 3 : 1;
+  double F40a[UA][10], F40b[UB][10];
+  if (DL == 40) {
+    const int part = wave;
+    const unsigned off_a = lane * 16;
+    const double* dens_b = dens + (a.part_j_row0[part] + (lane >> 4)) * 40 + (lane & 3) * 10;
+    const double* dens_e =
+        dens + (a.part_i_row0[part] + ((lane >> 2) & 3)) * 40 + (lane & 3) * 10;
+    const __amdgpu_buffer_rsrc_t rs_t =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.table, 0, a.table_bytes, kBufferFlags);
+    const int rb = a.part_rb0[part], cb = a.part_cb0[part], count = a.part_count[part];
+    const bool triangular = a.part_triangular[part] != 0;
+    const int n_cb = a.part_n_cb[part];
+    const unsigned unit_base = (unsigned)a.part_unit_base[part];
+#pragma unroll
+    for (int s = 0; s < UA; ++s)
+#pragma unroll
+      for (int g = 0; g < 10; ++g) F40a[s][g] = 0.0;
+#pragma unroll
+    for (int s = 0; s < UB; ++s)
+#pragma unroll
+      for (int g = 0; g < 10; ++g) F40b[s][g] = 0.0;
+    if (!(skip & 2))
+    fused_quad_pass40<0, UA>(rs_t, off_a, UP * 1024, dens_b, dens_e, rb, cb, count, triangular,
+                             n_cb, unit_base, F40a);
+    if (U > 3 && !(skip & 2))
+      fused_quad_pass40<(U > 3 ? 3 : 0), UB>(rs_t, off_a, UP * 1024, dens_b, dens_e, rb, cb,
+                                             count, triangular, n_cb, unit_base, F40b);
+  } else {
     const int sub = wave / PARTS, part = wave % PARTS;
     const unsigned off_a = lane * 16;
     // (the component's columns are density rows j_row0 ..., its rows i_row0 ...)
@@ -2565,6 +2773,7 @@ __global__ __launch_bounds__(64 * W, W == 8 ? (SATDEFER == 2 ? 4 : 2) : 1) void 
 #pragma unroll
     for (int p = 0; p < UP; ++p) {
       F[p][0][0] = F[p][0][1] = F[p][1][0] = F[p][1][1] = 0.0;
+      if (skip & 2) continue;
       if (2 * p + 1 < U)
         fused_quad_pass<2, DL>(rs_t, off_a + p * 1024, UP * 1024, dens_b, dens_e, rb, cb, count,
                                triangular, n_cb, unit_base, F[p]);
@@ -2574,7 +2783,47 @@ __global__ __launch_bounds__(64 * W, W == 8 ? (SATDEFER == 2 ? 4 : 2) : 1) void 
     }
   }
   __syncthreads();       // the densities are dead: their place takes the waves' sums
-  {
+  if (DL == 40) {
+    // lane l holds the share of row i = (l / 4) % 4 of F[r = 4 s + l / 16][draw 4 g + l % 4]:
+    // the four rows are added across the lanes (bits 2 and 3), and the lanes of row 0 store
+    // the wave's sums as (4 U, 40)
+    // (rotations inside the rows of 16 lanes -- data-parallel primitives, no LDS round trips:
+    // value + ror 4, then + ror 8 gives every lane of a (r, draw) the sum of its four rows)
+    double* out = dens + (wave * (4 * U) + kq) * 40 + (lane & 3);
+    auto rotate = [](double value, auto control) {
+      constexpr int kControl = decltype(control)::value;
+      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(value), kControl, 0xf, 0xf, false);
+      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(value), kControl, 0xf, 0xf, false);
+      return __hiloint2double(hi, lo);
+    };
+    auto reduce = [&](double value) {
+      value += rotate(value, std::integral_constant<int, 0x124>());     // row_ror:4
+      value += rotate(value, std::integral_constant<int, 0x128>());     // row_ror:8
+      return value;
+    };
+#pragma unroll
+    for (int s = 0; s < UA; ++s)
+#pragma unroll
+      for (int g = 0; g < 10; ++g) F40a[s][g] = reduce(F40a[s][g]);
+    if (U > 3) {
+#pragma unroll
+      for (int s = 0; s < UB; ++s)
+#pragma unroll
+        for (int g = 0; g < 10; ++g) F40b[s][g] = reduce(F40b[s][g]);
+    }
+    if (((lane >> 2) & 3) == 0) {
+#pragma unroll
+      for (int s = 0; s < UA; ++s)
+#pragma unroll
+        for (int g = 0; g < 10; ++g) out[(4 * s) * 40 + 4 * g] = F40a[s][g];
+      if (U > 3) {
+#pragma unroll
+        for (int s = 0; s < UB; ++s)
+#pragma unroll
+          for (int g = 0; g < 10; ++g) out[(4 * (3 + s)) * 40 + 4 * g] = F40b[s][g];
+      }
+    }
+  } else {
     // r = 4 u + l / 16, draws 2 c and 2 c + 1 of the wave's tile
     double* out = dens + (wave * (4 * U) + kq) * kQuadTile + 2 * c;
 #pragma unroll
@@ -2619,7 +2868,15 @@ __global__ __launch_bounds__(64 * W, W == 8 ? (SATDEFER == 2 ? 4 : 2) : 1) void 
     for (int idx = threadIdx.x; idx < count; idx += blockDim.x) chi2_lds[idx] = a.chi2_data[idx];
   }
   __syncthreads();
-  {
+  if (DL == 40) {
+    for (int rr = wave; rr < a.n_r && lane < DL; rr += W) {
+      const double* first = dens + rr * 40 + lane;
+      double sum = first[0];
+#pragma unroll
+      for (int part = 1; part < W; ++part) sum += first[part * (4 * U) * 40];
+      tile[rr][lane] = sum / norm;
+    }
+  } else {
     const int sub = lane >> 5, d = lane & 31;
     for (int rr = wave; rr < a.n_r && lane < DL; rr += W) {
       const double* first = dens + ((PARTS * sub) * (4 * U) + rr) * kQuadTile + d;
@@ -3785,16 +4042,20 @@ __device__ __forceinline__ void single_draw_body(SingleArgs a) {
   }
 }
 
+#ifdef TC_UNIT_SINGLE   // (emitted by the unit that launches it, which defines the macro)
 static __global__ __launch_bounds__(kSingleThreads) void single_draw_kernel(SingleArgs a) {
   single_draw_body<false>(a);
 }
+#endif
 
 // The same body, resident: one launch serves every un-batched call until the host says stop,
 // none has arrived for a.idle_ticks, or a.life_ticks have passed (SingleArgs, kernel_args.h).
 // One table, one draw per call (a.n_tables == 0, a.n_walkers == 0).
+#ifdef TC_UNIT_SINGLE   // (emitted by the unit that launches it, which defines the macro)
 static __global__ __launch_bounds__(kSingleThreads) void resident_draw_kernel(SingleArgs a) {
   single_draw_body<true>(a);
 }
+#endif
 
 // ---- ensembles without a launch: the resident ensemble kernel ---------------------------
 //
@@ -3818,6 +4079,7 @@ __device__ __forceinline__ void store_host(double* address, double value) {
 __device__ __forceinline__ void wait_stores() { __builtin_amdgcn_s_waitcnt(0x0f70); }  // vmcnt(0)
 }  // namespace ens
 
+#ifdef TC_UNIT_SINGLE   // (emitted by the unit that launches it, which defines the macro)
 static __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_kernel(EnsembleArgs a) {
   // (512 threads: eight waves with 256 registers each keep the loads of a phase in flight
   // together; sixteen waves of 128 registers spilled and walked the LDS one read at a time)
@@ -4305,6 +4567,7 @@ static __global__ __launch_bounds__(kEnsembleThreads) void resident_ensemble_ker
                        __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+#endif
 
 // ---- float32 variant for tables with many correlation-function bins -------------------
 //
@@ -4467,6 +4730,7 @@ __global__ __launch_bounds__(512) void contract_f32_kernel(ContractArgs a) {
 // write the results in the reference's output order.  One block per draw tile;
 // reads are coalesced over draws, the transposition to the draw-major output
 // goes through LDS.
+#ifdef TC_UNIT_QUAD   // (emitted by the unit that launches it, which defines the macro)
 static __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
   __shared__ double tile[kFinalizeRows][kLanes + 1];
   __shared__ double part_sum[16][kLanes];
@@ -4562,12 +4826,14 @@ static __global__ __launch_bounds__(1024) void finalize_kernel(FinalizeArgs a) {
     __syncthreads();
   }
 }
+#endif
 
 // Per draw: the tensor-product spline weight of every table at the draw's extra
 // parameters (interpolator.py:275-331; segment search as np.digitize with the right
 // edge special-cased, out-of-range clamped to the outermost segment), divided by the
 // table's total pair weight so that the contraction can accumulate all tables into
 // one sum (interpolation is linear in the per-table xi); and the interpolated ngal.
+#ifdef TC_UNIT_QUAD   // (emitted by the unit that launches it, which defines the macro)
 static __global__ __launch_bounds__(64) void interp_coef_kernel(InterpArgs a) {
   __shared__ double weight[kMaxInterpDim][kMaxInterpAxis][kLanes];
   const int lane = threadIdx.x;
@@ -4620,6 +4886,7 @@ static __global__ __launch_bounds__(64) void interp_coef_kernel(InterpArgs a) {
     }
   }
 }
+#endif
 
 // The same for a handful of draws (the un-batched Interpolator.predict of an MCMC step):
 // one block per draw, the LANES over the tables, instead of one lane per draw looping over
@@ -4627,6 +4894,7 @@ static __global__ __launch_bounds__(64) void interp_coef_kernel(InterpArgs a) {
 // in table order by one thread (deterministic).
 constexpr int kCoefSmallTables = 1024;
 
+#ifdef TC_UNIT_QUAD   // (emitted by the unit that launches it, which defines the macro)
 static __global__ __launch_bounds__(64) void interp_coef_small_kernel(InterpArgs a) {
   __shared__ double weight[kMaxInterpDim][kMaxInterpAxis];
   __shared__ double part_cen[kCoefSmallTables], part_sat[kCoefSmallTables];
@@ -4675,6 +4943,7 @@ static __global__ __launch_bounds__(64) void interp_coef_small_kernel(InterpArgs
     }
   }
 }
+#endif
 
 // Gaussian likelihood fused behind predict(): chi2[b] = (xi_b - d)^T P (xi_b - d).  This is
 // the step every MCMC likelihood performs on the host right after predict() (README.md:7 of
@@ -4688,6 +4957,7 @@ constexpr int kChi2DrawsPerBlock = 8;      // 256 threads; fewer when n_r is lar
 constexpr int kChi2LdsMatrix = 64;         // largest n_r whose precision matrix is staged
 constexpr int kChi2LdsBytes = 48 * 1024;
 
+#ifdef TC_UNIT_QUAD   // (emitted by the unit that launches it, which defines the macro)
 static __global__ __launch_bounds__(256) void chi2_kernel(const double* xi, int64_t n_draws,
                                                    int n_r, const double* data,
                                                    const double* precision,
@@ -4719,5 +4989,6 @@ static __global__ __launch_bounds__(256) void chi2_kernel(const double* xi, int6
   for (int offset = 16; offset >= 1; offset >>= 1) total += __shfl_xor(total, offset, 32);
   if (lane == 0 && first + local < n_draws) chi2[first + local] = total;
 }
+#endif
 
 }  // namespace tc

@@ -897,7 +897,9 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
   // (a measured choice -- option "autotune" -- knows where the one-launch form stops paying)
   const bool tuned_flags = n_gauss == 10 && t->tuning.fused == 1 &&
                            t->tuning.fused_min_draws == 0 && t->autotuned.count(flags) != 0;
-  if (n_draws > t->tuning.fused_max_draws && t->async_lane < 0 && !tuned_flags) return false;
+  const bool invariant = t->tuning.deterministic >= 2;     // (one form whatever the batch)
+  if (n_draws > t->tuning.fused_max_draws && t->async_lane < 0 && !tuned_flags && !invariant)
+    return false;
   if (!t->quad || t->compute_dtype != TC_DTYPE_F64 || t->quad_total.d_table == nullptr)
     return false;
   if (t->quad_tiling.n_rtiles != 1 || t->n_r > 20 || t->chain || t->tuning.trace) return false;
@@ -926,8 +928,13 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
   // 8 waves / 16 waves: G = 112 51.8 / 55.6 / 51.5, 128 64.2 / 69.2 / 64.3, 200 137.0 / 150.9 /
   // 138.7, 240 189.6 / 215.0 / 192.3; G = 100: 43.5 / 39.4 / 43.2 -- so beyond 104 bins the
   // one-launch form (16 waves, up to 160 KB: 248 bins) is taken only when forced.
+  // the latency form for calls that have the chip to themselves (fused_spread_eligible)
+  if (!invariant && fused_spread_eligible(t, n_draws, n_gauss, flags)) return true;
   const bool wide = fused_wide_tables(t, separate, n_gauss, flags);
   if (n_gauss < 1 || (!wide && fused_waves(t, separate, flags) == 0)) return false;
+  // option "deterministic" = 2: every call the form covers takes it, alone on its lane or not,
+  // one draw or a million (Leauthaud11 with modulate_with_cenocc included)
+  if (invariant) return true;
   // a measured choice for this table and these flags (option "autotune") replaces the formula
   // below for the calls it was measured on: pipelined device-pointer and asynchronous calls
   if (n_gauss == 10 && t->tuning.fused == 1 && t->tuning.fused_min_draws == 0) {
@@ -946,6 +953,8 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
   // 12.0), longer workgroups from ~90 draws per estimated microsecond (G = 60: 3000-4000;
   // G = 100, R = 8: 4096; G = 80: 5000; G = 100, R = 19: 6500-7000) -- below that both forms
   // are bound by the host thread that queues them (10-13 us per call) and differ by noise.
+  // calls that run alone on their lane (host-buffer API, one lane, pipeline off)
+  const bool alone = t->force_lane >= 0 || !t->tuning.pipeline || t->n_lanes == 1;
   {
     const tc::QuadLayout& layout = separate ? t->quad_by_type.layout : t->quad_total.layout;
     const double estimate = (5.0 + 10.0 * (t->n_bins / 100.0) * (n_gauss / 10.0) +
@@ -982,12 +991,42 @@ bool fused_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned fl
                               : leauthaud                   ? 8192
                               : estimate <= 28.0            ? 512
                                                             : (int64_t)(90.0 * estimate);
+    if (alone && t->tuning.fused < 2) {
+      // A call that has the chip to itself (round 6).  The three kernels spread any batch over
+      // the whole chip -- on BASELINE configs[1]'s table 26 us for 1024 draws, 66 us for 10^4:
+      // ~22 us + 4.4 us per 1000 draws, scaled with the table's work per draw --, a one-launch
+      // form lasts as long as ONE workgroup whatever the batch (0.56 / 0.95 of the estimate for
+      // 32 / 64 draws: 42 and 71 us there) for as long as one round of workgroups covers it:
+      // 32-draw workgroups up to 32 draws per CU, 64-draw ones from 40 to 64 draws per CU
+      // (in between: the latency form above; tools/r06_latency.py: 4096 draws 36.8 / 41.7,
+      // 6144: 46.0 / 41.8, 8192: 55.5 / 41.8; 12288: 73.9 / 71.5, 16384: 90.7 / 71.7 us).
+      if (leauthaud) return false;      // (its occupations spread better as a kernel of their own)
+      // (measured from 1024 draws on; below, both ways are a few launches' worth of latency)
+      if (n_draws < 2048) return false;
+      const double three = 22.0 + 0.0044 * (double)n_draws * estimate / 75.0;
+      if (n_draws <= (int64_t)32 * t->n_cus && t->tuning.fused_draws == 0 && !wide &&
+          fused_half_tiles(t, separate, n_draws, n_gauss, flags))
+        return 0.56 * estimate < three;
+      if (n_draws > (int64_t)40 * t->n_cus && n_draws <= (int64_t)64 * t->n_cus && !wide &&
+          t->tuning.fused_draws == 0 && fused_waves(t, separate, flags) == 8)
+        return 0.95 * estimate < three;
+      return false;
+    }
     if (n_draws < min_draws) return false;
   }
-  // calls that run alone on their lane (host-buffer API, pipeline off) keep the three kernels,
-  // which spread one batch over the whole chip
-  const bool alone = t->force_lane >= 0 || !t->tuning.pipeline || t->n_lanes == 1;
-  return t->tuning.fused >= 2 || !alone;
+  return true;
+}
+
+bool batch_invariant_form(tc_table* t, int n_gauss, unsigned flags) {
+  if (t->tuning.deterministic < 2) return false;
+  if (t->mode == TC_MODE_CROSS && !t->cross_host.empty() && t->tuning.fused != 0) {
+    int status = TC_OK;
+    tc_table* self = t;
+    const CrossFused& cf =
+        *choose_cross_fused(&self, 1, &t->cross_fused, &t->cross_fused_wide, 1, flags, &status);
+    return status == TC_OK && cross_fused_eligible(t, cf, 1, n_gauss, flags, true);
+  }
+  return fused_eligible(t, 1, n_gauss, flags);
 }
 
 // Rows of the LDS density array: whole blocks of four covering every row a component reads.
@@ -1001,8 +1040,38 @@ int fused_dens_rows(const tc_table* t, bool separate) {
 
 int fused_lds_bytes(const tc_table* t, bool separate, int waves, int draws) {
   const int dens_rows = fused_dens_rows(t, separate);
-  return (std::max(dens_rows * draws, tc::fused_slot_doubles(waves)) +
+  return (std::max(dens_rows * draws, tc::fused_slot_doubles(waves, draws)) +
           tc::fused_scratch_doubles(waves)) * 8;
+}
+
+// The latency form (predict_fused_kernel with 40 draws per workgroup, one workgroup per CU,
+// v_mfma_f64_4x4x4): for a call that has the chip to itself.  The 64-draw workgroups of the
+// throughput form put 10^4 draws on 157 of the 256 CUs (71 us alone on the chip, 0.37 of the
+// FP64 peak -- four such launches in flight are what fills it); 250 workgroups of 40 draws reach
+// every CU.  Undecorated Zheng07 with ten nodes, total correlation function (or its likelihood),
+// bins evaluated one by one; batches of up to one workgroup per CU.
+bool fused_spread_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsigned flags) {
+  if (t->tuning.fused_spread == 0 || n_gauss != 10 || t->tuning.deterministic >= 2) return false;
+  // (what every one-launch form of mode auto needs: the float64 quadratic-form layout of the
+  // whole triangle, one r tile, no chained finalisations, no developer timeline)
+  if (t->tuning.fused == 0 || !t->quad || t->compute_dtype != TC_DTYPE_F64 ||
+      t->quad_total.d_table == nullptr || t->quad_tiling.n_rtiles != 1 || t->n_r > 20 ||
+      t->chain || t->tuning.trace || t->quad_total.layout.comps.size() != 1 ||
+      !t->quad_total.layout.comps[0].triangular)
+    return false;
+  if (flags & (TC_FLAG_SEPARATE_GAL_TYPE | TC_FLAG_ASSEMBIAS | TC_FLAG_MODULATE_WITH_CENOCC |
+               TC_FLAG_LEAUTHAUD11))
+    return false;
+  if (t->grouped) return false;
+  if (t->tuning.fused_draws != 0 && t->tuning.fused_draws != 40) return false;
+  if (fused_lds_bytes(t, false, 8, 40) > kMaxLdsBytes) return false;
+  if (t->tuning.fused_draws == 40) return true;          // (forced: any batch)
+  // alone on the chip, between fused_spread_min and one workgroup per CU (the three kernels
+  // spread smaller batches over the chip in less than a 40-draw workgroup's lifetime)
+  const bool alone = t->force_lane >= 0 || !t->tuning.pipeline || t->n_lanes == 1 ||
+                     t->sync_spread;
+  return alone && n_draws >= t->tuning.fused_spread_min &&
+         n_draws <= (int64_t)40 * t->n_cus * std::max(1, t->tuning.fused_spread_rounds);
 }
 
 // Workgroups of ONE 32-draw tile and eight waves (eight parts of the units; up to 80 KB of LDS,
@@ -1018,6 +1087,12 @@ int fused_lds_bytes(const tc_table* t, bool separate, int waves, int draws) {
 // * Tables of 105-208 bins, whose 64-draw workgroup does not fit half a CU: any batch size.
 bool fused_half_tiles(const tc_table* t, bool separate, int64_t n_draws, int n_gauss,
                       unsigned flags) {
+  // (option "deterministic" = 2: the shape must not depend on the batch size -- 64 draws per
+  // workgroup unless 32 are forced)
+  if (t->tuning.deterministic >= 2)
+    return t->tuning.fused_draws == 32 && n_gauss == 10 &&
+           (t->tuning.fused_waves == 0 || t->tuning.fused_waves == 8) &&
+           fused_lds_bytes(t, separate, 8, 32) <= 80 * 1024;
   if (t->tuning.fused_draws == 0 && n_gauss == 10 && t->tuning.fused == 1 &&
       t->tuning.fused_min_draws == 0) {
     auto tuned = t->autotuned.find(flags);      // (measured: option "autotune")
@@ -1049,7 +1124,8 @@ int fused_waves(const tc_table* t, bool separate, unsigned flags) {
   // or when the table has been measured with THESE flags (option "autotune"): that choice then
   // decides; a measurement with other flags says nothing about this LDS footprint)
   return fits8 ? 8
-               : (fits16 && (t->tuning.fused >= 2 || t->autotuned.count(flags) != 0)) ? 16 : 0;
+               : (fits16 && (t->tuning.fused >= 2 || t->autotuned.count(flags) != 0 ||
+                             t->tuning.deterministic >= 2)) ? 16 : 0;
 }
 
 int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_draws,
@@ -1070,11 +1146,12 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   fa.n_gauss = n_gauss;
   fa.dens_rows = fused_dens_rows(t, separate);
   fa.separate = separate ? 1 : 0;
-  const bool wide = fused_wide_tables(t, separate, n_gauss, flags);
-  const bool half_tiles = !wide && fused_half_tiles(t, separate, n_draws, n_gauss, flags);
-  const int waves = wide || half_tiles ? 8 : fused_waves(t, separate, flags);
-  const int draws = wide || half_tiles ? 32 : 64;
-  const int n_parts = waves * 32 / draws;
+  const bool spread = fused_spread_eligible(t, n_draws, n_gauss, flags);
+  const bool wide = !spread && fused_wide_tables(t, separate, n_gauss, flags);
+  const bool half_tiles = !spread && !wide && fused_half_tiles(t, separate, n_draws, n_gauss, flags);
+  const int waves = spread || wide || half_tiles ? 8 : fused_waves(t, separate, flags);
+  const int draws = spread ? 40 : wide || half_tiles ? 32 : 64;
+  const int n_parts = spread ? 8 : waves * 32 / draws;
   if (!separate) {
     const tc::QuadComp& comp = q_table.layout.comps[0];
     tc::triangle_parts(comp.n_rb, n_parts, fa.part_rb0, fa.part_cb0, fa.part_count);
@@ -1116,7 +1193,8 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   }
   fa.n_r = t->n_r;
   fa.priority = (t->tuning.prio_fused & 3) | ((t->tuning.prio_fused_occ & 3) << 2) |
-                ((t->tuning.prio_fused_out & 3) << 4);
+                ((t->tuning.prio_fused_out & 3) << 4) |
+                ((env_int_early("TC_FUSED_SKIP", 0) & 3) << 8);   // (developer builds only)
   fa.n_draws = n_draws;
   fa.n_groups = t->node_groups.n_groups;
   fa.n_central_groups = t->node_groups.n_central_groups;
@@ -1157,7 +1235,7 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   // 17.5 us per 10^4 draws); option "series" = 0 switches every expansion off
   const bool sat_defer = t->tuning.fused_defer != 0 && !assembias && !modulate &&
                          !(flags & TC_FLAG_LEAUTHAUD11) && n_gauss == 10 && !wide &&
-                         !half_tiles && waves == 8 &&
+                         !half_tiles && waves == 8 && t->n_bins <= 256 &&
                          !(t->grouped && n_gauss == 10) && t->tuning.series != 0 &&
                          q->sat_series != nullptr && q->sat_records != nullptr;
   if (sat_defer) fa.sat_series = (const double*)q->sat_series;
@@ -1204,6 +1282,8 @@ CrossFused* choose_cross_fused(tc_table* const* tables, int n_tables, CrossFused
   // tile win.
   const bool undecorated =
       !(flags & (TC_FLAG_ASSEMBIAS | TC_FLAG_MODULATE_WITH_CENOCC | TC_FLAG_LEAUTHAUD11));
+  // (option "deterministic" = 2: the form must not depend on the batch size)
+  if (t0->tuning.deterministic >= 2) return narrow;
   if (!undecorated || t0->tuning.cross_defer == 0 || (series_mask(t0) & 1) == 0 ||
       t0->node_groups.largest > 2 || t0->tuning.cross_wide_min_draws <= 0 ||
       n_draws < t0->tuning.cross_wide_min_draws)
@@ -1353,6 +1433,7 @@ bool cross_fused_eligible(const tc_table* t0, const CrossFused& cf, int64_t n_dr
   // The register form (<= 16 rows) gives a tile several workgroups below ~120 tiles and wins
   // from the smallest batches on (256 draws 8.7 us against 13.4 for the three kernels, 1024: 9.3 /
   // 19.4, 4096: 25.6 / 55.7).
+  if (t0->tuning.deterministic >= 2) return true;        // (one form whatever the batch)
   const int64_t min_draws = t0->tuning.fused_min_draws > 0 ? t0->tuning.fused_min_draws
                             : cf.rows <= tc::kCrossSmallRows ? 192
                                                              : t0->tuning.cross_min_draws;
@@ -1448,8 +1529,11 @@ int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs
   // bins, so few tiles leave most CUs idle -- several workgroups per tile, each with a share of
   // the groups (by cost: a node of the centrals ~21 instructions, of the satellites ~33), the
   // last to arrive adds the shares.  About two workgroups per CU over four lanes in flight.
-  const int cross_target =
-      t0->sync_cross_target > 0 ? t0->sync_cross_target : t0->tuning.cross_target;
+  // (option "deterministic" = 2: ONE workgroup per tile whatever the batch -- the shares of a
+  // tile's groups, and with them the order of a draw's sums, follow the number of tiles)
+  const int cross_target = t0->tuning.deterministic >= 2 ? 0
+                           : t0->sync_cross_target > 0   ? t0->sync_cross_target
+                                                         : t0->tuning.cross_target;
   int n_splits = 1;
   if (cf.rows <= tc::kCrossSmallRows) {
     // (tools/r04_cross_splits.py, AbacusSummit table, us per call, one workgroup per tile /
@@ -1737,6 +1821,10 @@ bool resident_eligible(const tc_table* t, int n_gauss) {
 int resident_predict(tc_table* t, const double* theta, int n_theta, int n_gauss, unsigned flags,
                      double* ngal, double* xi) {
   tc_table::Resident& r = t->resident;
+  if (r.inject_failures > 0) {      // (option "resident_inject_failures": tests of the fallback)
+    --r.inject_failures;
+    return fail(TC_ERR_HIP, "the resident kernel keeps leaving before it answers (injected)");
+  }
   Quadrature* q = nullptr;
   int status = get_quadrature(t, n_gauss, &q);
   if (status != TC_OK) return status;

@@ -2,10 +2,12 @@
 // error reporting, device management, and the pure host functions (quadrature nodes,
 // pair indices, spline matrices, plan self-check) that are testable without a GPU.
 #include <dlfcn.h>
+#include <pthread.h>
 
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -105,94 +107,164 @@ int create_lane_streams(int count, hipStream_t* streams) {
 namespace {
 class CopyPool {
  public:
-  static constexpr int kHelpers = 3;
+  static constexpr int kMaxHelpers = 7;
   static constexpr size_t kSlice = 64 * 1024;
-  ~CopyPool() {
-    {
-      std::lock_guard<std::mutex> lock(mutex_);
-      stop_ = true;
+  // Everything the helper threads touch lives in one heap block: a forked child, in which those
+  // threads do not exist (and may have died holding the mutex), abandons the block and starts
+  // over -- joining or destroying what fork() did not copy would hang or abort.
+  struct State {
+    // A job's description.  Two slots, taken by the job number's parity: a helper that comes
+    // late for job J reads slot J & 1 while copy() fills the other one for job J + 1, and its
+    // ticket (which carries J) no longer matches by the time the slot is filled again.  The
+    // fields are atomics: a stale reader may see any mix of old and new values -- it is turned
+    // away by the ticket -- but never reads a field that is being written non-atomically.
+    struct Job {
+      std::atomic<size_t> n_slices{0}, bytes{0};
+      std::atomic<char*> dst{nullptr};
+      std::atomic<const char*> src{nullptr};
+    };
+    std::mutex mutex;
+    std::condition_variable wake;
+    std::vector<std::thread> threads;
+    std::atomic<uint64_t> job{0}, next{0};
+    std::atomic<size_t> done{0};
+    std::atomic<int> sleeping{0};
+    Job jobs[2];
+    bool stop = false;
+  };
+  CopyPool() {
+    static bool registered = false;
+    if (!registered) {
+      registered = true;
+      pthread_atfork(nullptr, nullptr, [] { instance().abandon(); });
     }
-    wake_.notify_all();
-    for (std::thread& thread : threads_)
-      if (thread.joinable()) thread.join();
+  }
+  ~CopyPool() { stop_and_join(); }
+  static CopyPool& instance() {
+    static CopyPool pool;
+    return pool;
+  }
+  // helpers: 0 .. kMaxHelpers threads beside the caller; spin_us: how long a helper polls for
+  // the next job before it sleeps (0: it sleeps at once -- one rank per core)
+  void configure(int helpers, int spin_us) {
+    std::lock_guard<std::mutex> call(call_mutex_);
+    stop_and_join();
+    helpers_ = std::max(0, std::min(kMaxHelpers, helpers));
+    spin_us_ = std::max(0, spin_us);
   }
   void copy(void* dst, const void* src, size_t bytes) {
     std::lock_guard<std::mutex> call(call_mutex_);       // one job at a time
-    if (threads_.empty())
-      for (int i = 0; i < kHelpers; ++i) threads_.emplace_back([this] { run(); });
-    dst_ = (char*)dst;
-    src_ = (const char*)src;
-    bytes_ = bytes;
-    n_slices_ = (bytes + kSlice - 1) / kSlice;
-    done_.store(0, std::memory_order_relaxed);
-    // the ticket counter carries the job's number in its high half: a helper that comes late
-    // for an earlier job finds another number and leaves; the fields above are published with it
-    const uint64_t job = job_.load(std::memory_order_relaxed) + 1;
-    next_.store(job << 32, std::memory_order_release);
-    job_.store(job, std::memory_order_release);
-    if (sleeping_.load(std::memory_order_acquire) > 0) {
-      std::lock_guard<std::mutex> lock(mutex_);
-      wake_.notify_all();
+    if (helpers_ == 0) {
+      memcpy(dst, src, bytes);
+      return;
     }
-    work(job);
+    if (state_ == nullptr) state_ = new State;
+    State& s = *state_;
+    if (s.threads.empty()) {
+      const int spins = spin_us_ * 200;                  // (~5 ns per pause)
+      for (int i = 0; i < helpers_; ++i) s.threads.emplace_back([&s, spins] { run(s, spins); });
+    }
+    const uint64_t job = s.job.load(std::memory_order_relaxed) + 1;
+    State::Job& slot = s.jobs[job & 1];
+    const size_t n_slices = (bytes + kSlice - 1) / kSlice;
+    slot.dst.store((char*)dst, std::memory_order_relaxed);
+    slot.src.store((const char*)src, std::memory_order_relaxed);
+    slot.bytes.store(bytes, std::memory_order_relaxed);
+    slot.n_slices.store(n_slices, std::memory_order_relaxed);
+    s.done.store(0, std::memory_order_relaxed);
+    // the ticket counter carries the job's number in its high half: a helper that comes late
+    // for an earlier job finds another number and leaves; the slot is published with it
+    s.next.store(job << 32, std::memory_order_release);
+    // (sequentially consistent on both sides of the wake-up handshake: with release / acquire
+    // alone the store below may pass the load of `sleeping` -- x86 reorders a store with a later
+    // load -- while a helper increments `sleeping` and still reads the old job number: it
+    // would sleep through the job)
+    s.job.store(job, std::memory_order_seq_cst);
+    if (s.sleeping.load(std::memory_order_seq_cst) > 0) {
+      std::lock_guard<std::mutex> lock(s.mutex);
+      s.wake.notify_all();
+    }
+    work(s, job);
     // (every slice that was handed out has been copied when this returns: nobody touches the
     // job's buffers afterwards)
-    while (done_.load(std::memory_order_acquire) < n_slices_) __builtin_ia32_pause();
+    while (s.done.load(std::memory_order_acquire) < n_slices) __builtin_ia32_pause();
   }
 
  private:
-  void work(uint64_t job) {
+  static void work(State& s, uint64_t job) {
+    const State::Job& slot = s.jobs[job & 1];
     for (;;) {
-      uint64_t ticket = next_.load(std::memory_order_acquire);
+      uint64_t ticket = s.next.load(std::memory_order_acquire);
       if ((ticket >> 32) != (job & 0xffffffffu)) return;
       const size_t slice = (size_t)(ticket & 0xffffffffu);
-      if (slice >= n_slices_) return;
-      if (!next_.compare_exchange_weak(ticket, ticket + 1, std::memory_order_acq_rel)) continue;
-      const size_t begin = slice * kSlice, n = std::min(kSlice, bytes_ - begin);
-      memcpy(dst_ + begin, src_ + begin, n);
-      done_.fetch_add(1, std::memory_order_release);
+      const size_t n_slices = slot.n_slices.load(std::memory_order_relaxed);
+      const size_t bytes = slot.bytes.load(std::memory_order_relaxed);
+      char* dst = slot.dst.load(std::memory_order_relaxed);
+      const char* src = slot.src.load(std::memory_order_relaxed);
+      if (slice >= n_slices) return;
+      // (the exchange succeeds only while the ticket still carries this job's number: what was
+      // read from the slot above then belongs to it)
+      if (!s.next.compare_exchange_weak(ticket, ticket + 1, std::memory_order_acq_rel)) continue;
+      const size_t begin = slice * kSlice, n = std::min(kSlice, bytes - begin);
+      memcpy(dst + begin, src + begin, n);
+      s.done.fetch_add(1, std::memory_order_release);
     }
   }
-  void run() {
+  static void run(State& s, int spins) {
     uint64_t seen = 0;
     for (;;) {
-      // spin ~100 us for the next job, then sleep
+      // poll for the next job for a while, then sleep
       bool have = false;
-      for (int spin = 0; spin < 20000 && !have; ++spin) {
-        have = job_.load(std::memory_order_acquire) != seen;
+      for (int spin = 0; spin < spins && !have; ++spin) {
+        have = s.job.load(std::memory_order_acquire) != seen;
         if (!have) __builtin_ia32_pause();
       }
       if (!have) {
-        std::unique_lock<std::mutex> lock(mutex_);
-        sleeping_.fetch_add(1, std::memory_order_release);
-        wake_.wait(lock, [&] { return stop_ || job_.load(std::memory_order_acquire) != seen; });
-        sleeping_.fetch_sub(1, std::memory_order_release);
-        if (stop_) return;
+        std::unique_lock<std::mutex> lock(s.mutex);
+        s.sleeping.fetch_add(1, std::memory_order_seq_cst);
+        s.wake.wait(lock, [&] { return s.stop || s.job.load(std::memory_order_seq_cst) != seen; });
+        s.sleeping.fetch_sub(1, std::memory_order_seq_cst);
+        if (s.stop) return;
       }
-      seen = job_.load(std::memory_order_acquire);
-      work(seen);
+      seen = s.job.load(std::memory_order_acquire);
+      work(s, seen);
     }
   }
-  std::mutex call_mutex_, mutex_;
-  std::condition_variable wake_;
-  std::vector<std::thread> threads_;
-  std::atomic<uint64_t> job_{0}, next_{0};
-  std::atomic<size_t> done_{0};
-  std::atomic<int> sleeping_{0};
-  size_t n_slices_ = 0, bytes_ = 0;
-  char* dst_ = nullptr;
-  const char* src_ = nullptr;
-  bool stop_ = false;
+  void stop_and_join() {
+    if (state_ == nullptr) return;
+    {
+      std::lock_guard<std::mutex> lock(state_->mutex);
+      state_->stop = true;
+    }
+    state_->wake.notify_all();
+    for (std::thread& thread : state_->threads)
+      if (thread.joinable()) thread.join();
+    delete state_;
+    state_ = nullptr;
+  }
+  // In the child of a fork(): the helper threads were not copied.  The block they lived in is
+  // left alone (its std::thread objects cannot be joined, its mutex may be locked for ever);
+  // the next large copy starts new ones.
+  void abandon() {
+    state_ = nullptr;
+    new (&call_mutex_) std::mutex;
+  }
+  std::mutex call_mutex_;
+  State* state_ = nullptr;
+  int helpers_ = 3, spin_us_ = 100;
 };
-CopyPool g_copy_pool;
 }  // namespace
+
+void configure_copy_pool(int helpers, int spin_us) {
+  CopyPool::instance().configure(helpers, spin_us);
+}
 
 void parallel_copy(void* dst, const void* src, size_t bytes) {
   if (bytes < 4 * CopyPool::kSlice) {
     memcpy(dst, src, bytes);
     return;
   }
-  g_copy_pool.copy(dst, src, bytes);
+  CopyPool::instance().copy(dst, src, bytes);
 }
 
 // Page-locked host ranges handed out by tc_host_alloc or pinned by tc_host_register:
@@ -232,6 +304,13 @@ using namespace tc::host;
 extern "C" {
 
 const char* tc_last_error(void) { return last_error(); }
+
+int tc_set_copy_threads(int helpers, int spin_us) {
+  TC_CHECK(helpers >= 0 && helpers <= 7, "helpers must be in [0, 7]");
+  TC_CHECK(spin_us >= 0 && spin_us <= 100000, "spin_us must be in [0, 100000]");
+  configure_copy_pool(helpers, spin_us);
+  return TC_OK;
+}
 
 int tc_device_count(int* count) {
   TC_CHECK(count != nullptr, "count is NULL");

@@ -317,7 +317,8 @@ int autotune(tc_table* t, unsigned flags);
 // 5).  So a handle that sees a LOOP of pipelined or asynchronous calls measures: the
 // autotune_after-th such call with one combination of flags runs option "autotune" for it.
 int maybe_autotune(tc_table* t, int n_gauss, unsigned flags) {
-  if (t->autotuning || t->tuning.autotune_after <= 0 || n_gauss != 10 || t->tuning.fused != 1 ||
+  if (t->autotuning || t->tuning.autotune_after <= 0 || t->tuning.deterministic != 0 ||
+      n_gauss != 10 || t->tuning.fused != 1 ||
       t->tuning.fused_min_draws != 0 || t->tuning.fused_draws != 0 || t->tuning.fused_waves != 0)
     return TC_OK;
   const bool pipelined = t->async_lane >= 0 || (t->force_lane < 0 && t->tuning.pipeline &&
@@ -500,6 +501,9 @@ int tc_predict_zheng07_many(tc_table* t, const double* theta, int n_theta, int n
   if (status != TC_OK) return status;
   if (n_walkers == 0) return TC_OK;
   TC_CHECK(ngal && xi, "output pointer is NULL");
+  // (option "deterministic" = 2: the batched path's one-launch form, whatever the batch size)
+  if (batch_invariant_form(t, n_gauss, flags))
+    return tc_predict_zheng07_batch(t, theta, n_theta, n_walkers, n_gauss, flags, ngal, xi);
   if (n_walkers > kSingleMaxWalkers || !single_draw_eligible(t, 1, n_gauss, flags)) {
     // (separated by galaxy type, several r tiles, float32 tables, the Leauthaud11 family, more
     // walkers than one launch takes: the batched path serves them)
@@ -516,8 +520,20 @@ int tc_predict_zheng07_many(tc_table* t, const double* theta, int n_theta, int n
   if (auto_candidate && resident_auto_wants(t)) {
     const unsigned long long before = t->resident.relaunches;
     status = resident_predict(t, theta, n_theta, n_gauss, flags, ngal, xi);
-    resident_auto_served(t, t->resident.relaunches != before);
-    return status;
+    if (status == TC_OK) {
+      resident_auto_served(t, t->resident.relaunches != before);
+      return status;
+    }
+    // Nobody asked for the resident kernel: whatever went wrong with it (it keeps leaving
+    // before it answers, its mailbox or aperture cannot be allocated, ...) is not the caller's
+    // business.  Stop it, stay away from it for a while -- for good after three such failures
+    // -- and serve THIS call by a launch.
+    (void)resident_stop(t);
+    (void)hipGetLastError();
+    tc_table::Resident& r = t->resident;
+    r.auto_backoff = r.auto_backoff_calls;
+    r.auto_streak = r.auto_window = r.auto_relaunches = 0;
+    if (++r.auto_failures >= 3) r.auto_mode = false;
   }
   if (t->resident.enabled && ensemble_eligible(t, n_walkers, n_gauss, flags)) {
     status = ensemble_predict(t, theta, n_theta, n_walkers, n_gauss, flags, ngal, xi);
@@ -588,8 +604,17 @@ int predict_chunked(tc_table* t, const double* theta, int n_theta, int64_t n_dra
   // (mode cross: the workgroups of ALL chunks together should fill the chip once -- see
   // tc_table::sync_cross_target)
   t->sync_cross_target = 512 / n_chunks;
+  // (the latency form for every chunk when the whole call fits one round of 40-draw workgroups:
+  // the chunks' launches then fill the chip together)
+  t->sync_spread = n_draws >= t->tuning.fused_spread_min &&
+                   (n_draws + 39) / 40 + n_chunks <= (int64_t)t->n_cus;
+  const bool spread = t->sync_spread && fused_spread_eligible(t, n_draws, n_gauss, flags);
+  t->sync_spread = spread;
   const int saved_draws = t->tuning.fused_draws, saved_min = t->tuning.fused_min_draws;
-  if (t->tuning.sync_form != 0 && saved_draws == 0 && t->tuning.fused == 1) {
+  if (spread) {
+    t->tuning.fused_draws = 40;
+  } else if (t->tuning.sync_form != 0 && saved_draws == 0 && t->tuning.fused == 1 &&
+      t->tuning.deterministic < 2) {
     t->tuning.fused_draws = t->tuning.sync_form;
     if (saved_min == 0) t->tuning.fused_min_draws = 1;
   }
@@ -605,6 +630,7 @@ int predict_chunked(tc_table* t, const double* theta, int n_theta, int64_t n_dra
   t->tuning.fused_draws = saved_draws;
   t->tuning.fused_min_draws = saved_min;
   t->sync_cross_target = 0;
+  t->sync_spread = false;
   for (int k = 0; k < n_chunks; ++k) {
     const int64_t begin = k * chunk, n = std::min(chunk, n_draws - begin);
     const int waited = tc_table_wait(t, tickets[k]);
@@ -640,13 +666,17 @@ int tc_predict_zheng07_batch(tc_table* t, const double* theta, int n_theta,
   // the results to page-locked host memory, which the device addresses directly; two API
   // calls and two copy-engine round trips less (1 draw 45 -> 40 us, 1000 draws 72 -> 54 us;
   // beyond ~1 MB the copy engines win).
-  if (t->resident.enabled && ensemble_eligible(t, n_draws, n_gauss, flags)) {
+  // (option "deterministic" = 2: neither of the un-batched kernels -- their sums are cut
+  // differently from the batched forms')
+  const bool invariant = batch_invariant_form(t, n_gauss, flags);
+  if (!invariant && t->resident.enabled && ensemble_eligible(t, n_draws, n_gauss, flags)) {
     // an ensemble of up to 256 walkers with option "resident": no launch at all (unless its
     // workgroups do not all find a place on the chip: the launched path below)
     status = ensemble_predict(t, theta, n_theta, (int)n_draws, n_gauss, flags, ngal, xi);
     if (status != TC_ERR_UNSUPPORTED) return status;
   }
-  if (n_draws <= many_walkers_limit() && single_draw_eligible(t, 1, n_gauss, flags)) {
+  if (!invariant && n_draws <= many_walkers_limit() &&
+      single_draw_eligible(t, 1, n_gauss, flags)) {
     // one draw -- or a handful (an ensemble sampler's proposals): ONE launch, the device-side
     // combination replaced by a few hundred additions here (kernels.hip.h: single_draw_kernel)
     return tc_predict_zheng07_many(t, theta, n_theta, (int)n_draws, n_gauss, flags, ngal, xi);
@@ -1200,6 +1230,13 @@ int tc_table_autotune_result(const tc_table* t, unsigned flags, int capacity, in
   return TC_OK;
 }
 
+int tc_table_batch_invariant(tc_table* t, int n_gauss, unsigned flags, int* out) {
+  TC_CHECK(t != nullptr && out != nullptr, "NULL argument");
+  TC_HIP(hipSetDevice(t->device));
+  *out = batch_invariant_form(t, n_gauss, flags) ? 1 : 0;
+  return TC_OK;
+}
+
 int tc_table_set_option(tc_table* t, const char* name, int value) {
   TC_CHECK(t != nullptr && name != nullptr, "NULL argument");
   // (streams and events created below, and the resident kernel stopped, belong to the table's
@@ -1208,7 +1245,25 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
   const std::string key(name);
   if (key == "pipeline") {
     t->tuning.pipeline = value != 0;
+  } else if (key == "deterministic") {
+    // 0 (default): the fastest form per call -- chosen from the table, the flags, the entry
+    // point and the batch size, never from timing (no self-measurement unless "autotune_after"
+    // or "autotune" ask for it); 1: the same, and the measured dispatch is refused; 2:
+    // batch-invariant -- ONE kernel form per (table, flags) for every entry point and batch
+    // size (internal.h: Tuning::deterministic)
+    TC_CHECK(value >= 0 && value <= 2, "deterministic must be 0, 1 or 2");
+    int status = resident_stop(t);
+    if (status != TC_OK) return status;
+    for (tc_table::Lane& lane : t->lanes)
+      if (lane.stream) TC_HIP(hipStreamSynchronize(lane.stream));
+    t->tuning.deterministic = value;
+    if (value != 0) {
+      t->autotuned.clear();
+      t->tuning.autotune_after = 0;
+    }
   } else if (key == "autotune_after") {
+    TC_CHECK(value == 0 || t->tuning.deterministic == 0,
+             "autotune_after: the measured dispatch is not available while \"deterministic\" is set");
     // the N-th pipelined / asynchronous call with one combination of predict flags measures the
     // forms by itself (option "autotune": ~0.5 s, once); 0: never
     TC_CHECK(value >= 0, "autotune_after must be non-negative");
@@ -1220,6 +1275,8 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
       t->autotuned.clear();
       return TC_OK;
     }
+    TC_CHECK(t->tuning.deterministic == 0,
+             "autotune: the measured dispatch is not available while \"deterministic\" is set");
     return autotune(t, (unsigned)value);
   } else if (key == "resident_min_walkers") {
     // smallest ensemble the resident ensemble kernel takes (default 24; smaller ones go through
@@ -1340,9 +1397,15 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     t->resident.auto_mode = value == 2;
     t->resident.auto_streak = t->resident.auto_backoff = 0;
     t->resident.auto_window = t->resident.auto_relaunches = 0;
+    t->resident.auto_failures = 0;
     t->resident.ens_disabled = false;
     t->resident.ens_failures = 0;
     if (value != 1) return resident_stop(t);
+  } else if (key == "resident_inject_failures") {
+    // test hook: the next `value` calls that reach the resident single-draw kernel fail as if
+    // the kernel kept leaving (the automatic mode must then serve them by launches)
+    TC_CHECK(value >= 0, "resident_inject_failures must not be negative");
+    t->resident.inject_failures = value;
   } else if (key == "resident_auto_idle_us") {
     TC_CHECK(value >= 10 && value <= 100000, "resident_auto_idle_us must be in [10, 100000]");
     const int status = resident_stop(t);
@@ -1359,8 +1422,20 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     if (status != TC_OK) return status;
     t->resident.idle_us = value;
   } else if (key == "fused_draws") {
-    TC_CHECK(value == 0 || value == 32 || value == 64, "fused_draws must be 0, 32 or 64");
+    // (40: the latency form -- launch.hip: fused_spread_eligible -- for every batch it serves)
+    TC_CHECK(value == 0 || value == 32 || value == 40 || value == 64,
+             "fused_draws must be 0, 32, 40 or 64");
     t->tuning.fused_draws = value;
+  } else if (key == "fused_spread") {
+    // 1 (default): calls that have the chip to themselves (host arrays, one lane, pipeline
+    // off) take the latency form of the one-launch kernel where it serves them; 0: never
+    t->tuning.fused_spread = value != 0;
+  } else if (key == "fused_spread_min") {
+    TC_CHECK(value >= 1, "fused_spread_min must be positive");
+    t->tuning.fused_spread_min = value;
+  } else if (key == "fused_spread_rounds") {
+    TC_CHECK(value >= 1 && value <= 64, "fused_spread_rounds must be in [1, 64]");
+    t->tuning.fused_spread_rounds = value;
   } else if (key == "fused_waves") {
     TC_CHECK(value == 0 || value == 8 || value == 16, "fused_waves must be 0, 8 or 16");
     t->tuning.fused_waves = value;

@@ -211,6 +211,21 @@ class Interpolator:
             self._device = _DeviceInterpolator(self)
         return self._device
 
+    def set_deterministic(self, level=True):
+        """``TabCorr.set_deterministic`` for every table of the grid (the
+        interpolator's calls read the option of the first one).  ``True``:
+        batch-invariant results where a one-launch form serves the grid (mode
+        cross with up to 128 rows, e.g. the reference's AbacusSummit
+        interpolator); grids in mode auto run three kernels whose sums are cut
+        where the batch size puts them -- there the option only refuses the
+        measured dispatch.  Returns whether the first table reports a
+        batch-invariant form."""
+        device = self.to_device()
+        invariant = [halotab.set_deterministic(level)
+                     for halotab in self.tabcorr_list]
+        del device
+        return invariant[0]
+
     def _x_model(self, model):
         x = np.empty(len(self.keys))
         for i, key in enumerate(self.keys):

@@ -120,7 +120,9 @@ class Communicator:
             lib = _lib.load()
             if _lib.device_count() < 1:
                 raise _lib.TabCorrHipError('no HIP device')
-            _lib.check(lib.tc_set_device(self.local_rank))
+            # (more ranks than devices: round-robin -- RCCL then refuses two ranks on one
+            # device below, and every rank falls back to gloo)
+            _lib.check(lib.tc_set_device(self.local_rank % _lib.device_count()))
             _lib.check(lib.tc_comm_unique_id(buffer))
         except Exception as exc:   # noqa: BLE001 -- every failure is a vote
             # (also e.g. subprocess.CalledProcessError of an on-demand build:

@@ -283,11 +283,6 @@ class TabCorr:
             if status != 0 and not measure:
                 return None
             _lib.check(status)
-            _lib.check(device.lib.tc_table_autotune_result(
-                device.handle, flags, 16, ctypes.byref(count),
-                sizes.ctypes.data_as(_lib.c_int64_p),
-                forms.ctypes.data_as(_lib.c_int_p),
-                us.ctypes.data_as(_lib.c_float_p)))
         count = count.value
         return {'sizes': sizes[:count].copy(), 'forms': forms[:count].copy(),
                 'us_per_call': us[:count].astype(float)}
@@ -332,6 +327,35 @@ class TabCorr:
             _lib.check(device.lib.tc_table_set_option(
                 device.handle, b'resident', value))
 
+    def set_deterministic(self, level=True):
+        """Reproducible bits on request (``tc_table_set_option
+        "deterministic"``).  Every kernel form agrees with the reference to
+        ~1e-14, but forms differ in their last bits, and by default the library
+        picks the fastest form per call -- from the table, the options, the
+        entry point and the batch size; never from timing, so a fixed-seed
+        chain is reproducible from run to run as it is.
+
+        ``level=True`` (2) makes the results *batch-invariant*: one kernel
+        form per table and combination of options for ``predict(model)``,
+        ``predict_batch`` of any size and the asynchronous calls, so that a
+        draw's ``(ngal, xi)`` depends on the draw alone.  It costs latency:
+        ``predict(model)`` ~70 us instead of ~10-18, batches below ~8000 draws
+        up to 2x; batches of 10^4 draws nothing.  ``level=1`` only refuses the
+        measured dispatch (``autotune``); ``False`` is the default behaviour.
+
+        Returns whether calls with default options are batch-invariant now
+        (``False`` for tables no one-launch form serves: float32, more than
+        248 bins, several r tiles)."""
+        device = self.to_device()
+        value = 2 if level is True else int(level)
+        with device.lock:
+            _lib.check(device.lib.tc_table_set_option(
+                device.handle, b'deterministic', value))
+            out = ctypes.c_int(0)
+            _lib.check(device.lib.tc_table_batch_invariant(
+                device.handle, 10, 0, ctypes.byref(out)))
+        return bool(out.value)
+
     # -- consistency checks ---------------------------------------------------
 
     def _check_consistency(self, model):
@@ -358,6 +382,34 @@ class TabCorr:
         if not abs(model.redshift - self.attrs['redshift']) < 0.05:
             raise ValueError('Mismatch in the redshift of the model and ' +
                              'the TabCorr instance.')
+
+    def _check_consistency_cached(self, model):
+        """`_check_consistency`, skipped while nothing it reads has changed:
+        the same model, component dictionary and ``gal_types`` objects, and
+        equal VALUES of everything the checks compare -- the components'
+        halo-property keys, the model's redshift and this table's three
+        attributes -- so that an in-place change of any of them after a first
+        successful call is checked again, as the reference does on every call
+        (``tabcorr/tabcorr.py:496-535``)."""
+        components = model._input_model_dictionary
+        try:
+            keys = tuple(
+                (components[name].prim_haloprop_key,
+                 getattr(components[name], 'sec_haloprop_key', None))
+                for name in ('centrals_occupation', 'satellites_occupation'))
+        except (KeyError, AttributeError, TypeError):
+            keys = None
+        attrs = self.attrs
+        seen = (model, components, model.gal_types,
+                (getattr(model, 'redshift', None), keys,
+                 attrs.get('prim_haloprop_key'), attrs.get('sec_haloprop_key'),
+                 attrs.get('redshift')))
+        last = self._checked_model
+        if (last is None or keys is None or last[0] is not seen[0] or
+                last[1] is not seen[1] or last[2] is not seen[2] or
+                last[3] != seen[3]):
+            self._check_consistency(model)
+            self._checked_model = seen
 
     # -- mean occupation ---------------------------------------------------------
 
@@ -411,14 +463,7 @@ class TabCorr:
             # (the checks read these attributes and nothing else: a model that
             # passed them is not checked again while they are the same
             # objects / values -- one predict() per MCMC step)
-            seen = (model, model._input_model_dictionary,
-                    getattr(model, 'redshift', None), model.gal_types)
-            last = self._checked_model
-            if (last is None or last[0] is not seen[0] or
-                    last[1] is not seen[1] or last[2] != seen[2] or
-                    last[3] is not seen[3]):
-                self._check_consistency(model)
-                self._checked_model = seen
+            self._check_consistency_cached(model)
         spec = None if occ_kwargs else device_spec(model)
         if spec is None:
             return self._host_mean_occupation(model, n_gauss_prim,
@@ -475,14 +520,7 @@ class TabCorr:
             # (the checks read these attributes and nothing else: a model that
             # passed them is not checked again while they are the same
             # objects / values -- one predict() per MCMC step)
-            seen = (model, model._input_model_dictionary,
-                    getattr(model, 'redshift', None), model.gal_types)
-            last = self._checked_model
-            if (last is None or last[0] is not seen[0] or
-                    last[1] is not seen[1] or last[2] != seen[2] or
-                    last[3] is not seen[3]):
-                self._check_consistency(model)
-                self._checked_model = seen
+            self._check_consistency_cached(model)
         spec = None if occ_kwargs else device_spec(model)
         if spec is None:
             occupation = self._host_mean_occupation(

@@ -521,6 +521,39 @@ def test_resident_kernel_by_itself_for_loops_of_unbatched_calls():
     del halotab          # (a table deleted while the kernel it started by itself runs)
 
 
+def test_automatic_resident_mode_keeps_its_failures_to_itself():
+    """with nothing switched on, an error of the resident kernel (it keeps leaving
+    before it answers, no memory for its mailbox, ...) must not reach a caller who never asked
+    for that kernel -- the call is served by a launch, the mode backs off, and after three
+    failures it stays off.  Option "resident_inject_failures" makes resident_predict fail."""
+    from tabcorr_amd import synthetic, _lib
+    lib = _lib.load()
+    table = synthetic.synthetic_table(30, 1, (19, ), 'auto', seed=3)
+    theta = synthetic.zheng07_draws(64, seed=4)
+    halotab = make_tabcorr(table)
+    halotab.set_resident(False)
+    launched = [halotab.predict_batch(theta[i:i + 1]) for i in range(64)]
+    halotab.set_resident('auto')
+    handle = halotab.to_device().handle
+    for failures in (1, 1, 1):
+        _lib.check(lib.tc_table_set_option(handle, b'resident_inject_failures', failures))
+        # (the mode engages at the eighth call of a tight loop; backed off, it needs 4096 more:
+        # set again, it starts afresh)
+        halotab.set_resident('auto')
+        _lib.check(lib.tc_table_set_option(handle, b'resident_inject_failures', failures))
+        for call in range(200):
+            ngal, xi = halotab.predict_batch(theta[call % 64:call % 64 + 1])
+            assert np.array_equal(ngal, launched[call % 64][0]), call
+            assert np.array_equal(xi, launched[call % 64][1]), call
+    # explicitly asked for, the error is the caller's to see
+    halotab.set_resident(True)
+    _lib.check(lib.tc_table_set_option(handle, b'resident_inject_failures', 1))
+    with pytest.raises(RuntimeError):
+        halotab.predict_batch(theta[:1])
+    ngal, xi = halotab.predict_batch(theta[:1])
+    assert np.array_equal(xi, launched[0][1])
+
+
 @pytest.mark.parametrize('shape, n_prim', [((5, 5), 50), ((4, 4, 4), 50), ((4, 7), 50), ((4, 4, 4), 6)])
 def test_unbatched_interpolator_in_one_round_of_workgroups(shape, n_prim):
     """Un-batched Interpolator.predict(model): the launch sized so that all tables' workgroups

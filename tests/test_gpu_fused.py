@@ -296,6 +296,7 @@ def test_fused_at_the_benchmarked_batch_size():
     assert_rel(ngal[index], expect[0], RTOL)
     assert_rel(xi[index], expect[1], RTOL)
     set_option(halotab, 'sync_chunks', -1)             # (the serial path: ...
+    set_option(halotab, 'fused_spread', 0)             # ... without the latency form ...
     ngal3, xi3 = halotab.predict_batch(theta)          # ... synchronous, three kernels)
     assert last_launch(halotab)[2] > 0
     assert_rel(ngal, ngal3, 1e-13)
@@ -875,3 +876,128 @@ def test_satellites_by_expansion_with_deferred_pairs():
     ngal_p, xi_p = halotab.predict_batch(theta[order][:777])
     assert np.array_equal(ngal_p, ngal[order][:777], equal_nan=True)
     assert np.array_equal(xi_p, xi[order][:777], equal_nan=True)
+
+
+# ---- the latency form: 40 draws per workgroup, one workgroup per CU (round 6) ----------------
+
+def force_latency_form(halotab, on=True):
+    set_option(halotab, 'fused_draws', 40 if on else 0)
+    set_option(halotab, 'single_draw', 0 if on else 1)
+    set_option(halotab, 'sync_chunks', 1 if on else 0)     # (host-array calls in one piece)
+
+
+def latency_form_ran(halotab, n_draws):
+    workgroups, waves, slabs, lds = last_launch(halotab)
+    return workgroups == (n_draws + 39) // 40 and waves == 8 and slabs == 0
+
+
+@pytest.mark.parametrize('n_prim, n_r, n_draws, options', [
+    (50, 19, 10000, {}),                 # BASELINE configs[1]: both galaxy types from records
+    (50, 19, 41, {'fused_defer': 1}),    # the satellites' records, centrals by their node loops
+    (50, 19, 777, {'series': 0}),        # node loops in place
+    (30, 19, 1000, {}),                  # the reference's example shape (bins 0.15 dex wide)
+    (50, 3, 39, {}),                     # one r sub-tile
+    (50, 7, 40, {}),                     # two
+    (50, 12, 1, {}),                     # three
+    (50, 16, 250, {}),                   # four
+    (104, 19, 300, {}),                  # 208 bins: 86 KB of LDS, one workgroup per CU anyway
+    (23, 9, 130, {}),                    # a ragged triangle (46 bins: the last block half full)
+])
+def test_latency_form_matches_oracle_and_three_kernels(n_prim, n_r, n_draws, options):
+    """predict_fused_kernel with 40 draws per workgroup (v_mfma_f64_4x4x4, every wave an eighth
+    of the units for all 40 draws): the oracle's values on a sample, the three-kernel path's on
+    every draw; tabcorr/tabcorr.py:580-650."""
+    from tabcorr_amd import synthetic
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(n_prim, 1, (n_r, ), 'auto', seed=n_prim + n_r)
+    theta = synthetic.zheng07_draws(n_draws, seed=3)
+    halotab = make_tabcorr(table)
+    force_fused(halotab, False)
+    ngal3, xi3 = halotab.predict_batch(theta)
+    force_fused(halotab)
+    force_latency_form(halotab)
+    for name, value in options.items():
+        set_option(halotab, name, value)
+    ngal, xi = halotab.predict_batch(theta)
+    assert latency_form_ran(halotab, n_draws), last_launch(halotab)
+    assert_rel(ngal, ngal3, 1e-13)
+    assert_rel(xi, xi3, 1e-12)
+    index = np.unique(np.r_[0:min(n_draws, 24), max(0, n_draws - 24):n_draws])
+    expect = oracle.predict_zheng07_batch(table, theta[index])
+    assert_rel(ngal[index], expect[0], RTOL)
+    assert_rel(xi[index], expect[1], RTOL)
+
+
+def test_latency_form_is_what_a_call_alone_on_the_chip_takes():
+    """Default options, BASELINE configs[1]: the synchronous predict_batch(theta) of 10^4 draws in
+    ordinary NumPy arrays runs as 40-draw workgroups -- 250 of them, one
+    per CU -- and so does a device-pointer call on a handle with one lane; pipelined calls keep
+    the 64-draw throughput form; smaller batches the three kernels.  Same values as the
+    throughput form to rounding, the oracle's on a sample, a draw's bits independent of its
+    place in the batch, degenerate parameters as everywhere else; the fused likelihood."""
+    from tabcorr_amd import synthetic, pinned_array
+    from oracle import tabcorr_oracle as oracle
+    table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    n = 10000
+    theta = synthetic.zheng07_draws(n, seed=1)
+    halotab = make_tabcorr(table)
+    ngal, xi = halotab.predict_batch(theta)
+    workgroups, waves, slabs, lds = last_launch(halotab)
+    assert waves == 8 and slabs == 0, last_launch(halotab)
+    assert workgroups in (250, 127, 124), last_launch(halotab)     # (one piece, or two chunks)
+    index = np.r_[0:40, 4990:5030, 9960:10000]
+    expect = oracle.predict_zheng07_batch(table, theta[index])
+    assert_rel(ngal[index], expect[0], RTOL)
+    assert_rel(xi[index], expect[1], RTOL)
+    # the throughput form (pipelined, asynchronous) on the same draws
+    ngal_t, xi_t = halotab.predict_batch_async(pinned_array(theta)).wait()
+    assert last_launch(halotab)[:3] == (157, 8, 0), last_launch(halotab)
+    assert_rel(ngal, ngal_t, 1e-14)
+    assert_rel(xi, xi_t, 1e-12)
+    # small batches that run alone: the three kernels spread them over the chip
+    halotab.predict_batch(theta[:1500])
+    assert last_launch(halotab)[2] > 0, last_launch(halotab)
+    # a draw's bits: reversed, and in another batch
+    force_latency_form(halotab)
+    ngal, xi = halotab.predict_batch(theta)
+    assert latency_form_ran(halotab, n)
+    ngal_r, xi_r = halotab.predict_batch(theta[::-1].copy())
+    assert np.array_equal(ngal_r[::-1], ngal) and np.array_equal(xi_r[::-1], xi)
+    ngal_p, xi_p = halotab.predict_batch(theta[3001:3778])
+    assert np.array_equal(ngal_p, ngal[3001:3778]) and np.array_equal(xi_p, xi[3001:3778])
+    # degenerate parameters next to regular draws: as the three-kernel path has them
+    mixed = theta[:400].copy()
+    mixed[5::40, 1] = 1e-3
+    mixed[9::40, 4] = 5.5
+    mixed[17::40, 0] = np.inf
+    mixed[21::40, 0] = -np.inf
+    mixed[33::40, 3] = np.nan
+    mixed[34::40, 2] = -np.inf
+    mixed[35::40, 1] = 0.0
+    with np.errstate(all='ignore'):
+        ngal_m, xi_m = halotab.predict_batch(mixed)
+        assert latency_form_ran(halotab, 400)
+        force_latency_form(halotab, False)
+        force_fused(halotab, False)
+        ngal_3, xi_3 = halotab.predict_batch(mixed)
+    assert np.array_equal(np.isnan(ngal_m), np.isnan(ngal_3))
+    assert np.array_equal(np.isnan(xi_m), np.isnan(xi_3))
+    assert np.array_equal(np.isinf(xi_m), np.isinf(xi_3))
+    good = np.isfinite(xi_3)
+    assert_rel(xi_m[good], xi_3[good], 1e-12)
+    untouched = np.ones(400, dtype=bool)
+    for first in (5, 9, 17, 21, 33, 34, 35):
+        untouched[first::40] = False
+    assert np.array_equal(xi_m[untouched], xi[:400][untouched])
+    # the fused likelihood
+    force_fused(halotab)
+    force_latency_form(halotab)
+    rng = np.random.default_rng(0)
+    vector = expect[1][0] * 1.1
+    a = rng.normal(size=(19, 19))
+    precision = a @ a.T / np.mean(vector)**2
+    want = np.einsum('bi,ij,bj->b', xi - vector, precision, xi - vector)
+    n_chi, chi2 = halotab.chi2_batch(theta, vector, precision)
+    assert latency_form_ran(halotab, n)
+    assert np.array_equal(n_chi, ngal)
+    assert_rel(chi2, want, 1e-9)

@@ -516,6 +516,53 @@ def test_bench_under_torchrun_single_rank(mode):
         assert second['steps'] == record['steps']
 
 
+@pytest.mark.parametrize('workload', ['cfg2', 'interp5x5'])
+def test_bench_with_two_ranks_on_one_device(workload):
+    """the >= 2-rank path of bench.py (ring of result blocks, barriers,
+    max over ranks, gather offsets) next to real kernels -- two ranks under
+    torch.distributed.run sharing the one device of this box (local_rank % device_count).  RCCL
+    refuses two ranks on one device, so the agreed fallback is the expected outcome: every rank
+    falls back to gloo ("gather": "gloo", `rccl_error` set) and the blocks travel on host
+    arrays; rank 0 then holds every step of both ranks and compares each with its own
+    evaluation of that rank's draws (a single-rank run of the same seeds): bit for bit
+    (`gather_check`).  BASELINE configs[1] (weak scaling) and configs[3] (Interpolator over a
+    5 x 5 grid, draws sharded round-robin: strong scaling)."""
+    import json
+    import subprocess
+    from util import REPO
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    extra = {'cfg2': ['--steps', '20', '--warmup', '3'],
+             'interp5x5': ['--workload', 'interp5x5', '--draws', '12500', '--steps', '6',
+                           '--warmup', '2', '--gather-every', '2']}[workload]
+    result = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+         '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
+         str(_free_port()), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--cpu-seconds', '0',
+         '--settle-seconds', '0.05', '--other-configs', '0'] + extra,
+        env=env, capture_output=True, text=True, timeout=900)
+    assert result.returncode == 0, result.stdout[-2000:] + result.stderr[-3000:]
+    line = result.stdout.strip().splitlines()[-1]
+    assert line.startswith('{') and len(line) < 4096, len(line)
+    record = json.loads(line)
+    assert record['n_gpus'] == 2 and record['steps'] == int(extra[extra.index('--steps') + 1])
+    config = record['config']
+    assert config['gather'] in ('gloo', 'rccl'), config
+    if config['gather'] == 'gloo':
+        assert config.get('rccl_error'), config
+        assert config['rccl_ranks'] == 0
+    else:                              # (should RCCL ever accept two ranks on one device)
+        assert config['rccl_ranks'] == 2
+    check = record['gather_check']
+    assert check['ranks'] == 2 and check['bit_equal'] and check['steps_checked'] >= 4, check
+    assert record['parity_max_rel_vs_oracle'] < 1e-10
+    assert record['scaling'] == ('strong' if workload == 'interp5x5' else 'weak')
+    # the whole-job rate counts both ranks' draws over the max of the ranks' times
+    per_step = 12500 if workload == 'interp5x5' else 2 * 10000
+    assert abs(record['value'] * record['ms_per_step'] * 1e-3 / per_step - 1) < 0.02, record
+    # the second payload (default for more than one rank) ran in the same job
+    assert '16 B' in record['second_payload']['gather_payload']
+
+
 def test_read_hdf5_and_predict():
     """End to end as a user of the reference would: read the reference's example file,
     predict with a model object."""

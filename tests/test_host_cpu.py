@@ -1156,3 +1156,35 @@ def test_no_kernel_spills_vector_registers():
         if ('predict_fused_kernel<10, 5, false, false, false, 8, 64, false, ' in name or
                 'predict_cross_fused_kernel<8,' in name or 'predict_cross_small_kernel' in name):
             assert usage['VGPRs'] <= 128, (name, usage['VGPRs'])
+
+
+def test_consistency_checks_notice_in_place_changes():
+    """the check a successful predict() lets later calls skip is keyed on the
+    VALUES the checks compare (tabcorr/tabcorr.py:496-535: the components' halo-property keys,
+    the redshifts), not only on object identities -- an in-place change is checked again."""
+    from tabcorr_amd import TabCorr, Zheng07Model, synthetic
+    table = synthetic.synthetic_table(6, 1, (4, ), 'auto', seed=1)
+    halotab = TabCorr.from_arrays(table['gal_type'], table['tpcf_matrix'], table['tpcf_shape'],
+                                  table['attrs'])
+    model = Zheng07Model(redshift=table['attrs']['redshift'])
+    calls = []
+    original = halotab._check_consistency
+    halotab._check_consistency = lambda m: (calls.append(1), original(m))
+    halotab._check_consistency_cached(model)
+    halotab._check_consistency_cached(model)
+    assert len(calls) == 1                              # (the second call is served by the cache)
+    component = model._input_model_dictionary['satellites_occupation']
+    component.prim_haloprop_key = 'halo_m200b'          # (same object, another value)
+    with pytest.raises(ValueError, match='primary halo properties'):
+        halotab._check_consistency_cached(model)
+    component.prim_haloprop_key = table['attrs']['prim_haloprop_key']
+    halotab._check_consistency_cached(model)
+    halotab.attrs['redshift'] = 2.0                     # (the table's side of the comparison)
+    with pytest.raises(ValueError, match='redshift'):
+        halotab._check_consistency_cached(model)
+    halotab.attrs['redshift'] = table['attrs']['redshift']
+    model.redshift = table['attrs']['redshift'] + 0.01
+    halotab._check_consistency_cached(model)
+    # (first call, the two failures, the model's new redshift; the restored values equal what
+    # last passed and are served by the cache)
+    assert len(calls) == 4
