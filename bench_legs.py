@@ -363,7 +363,9 @@ def unbatched(make, table, synthetic, Interpolator):
             halotab.set_resident(False)
         except Exception:   # noqa: BLE001
             pass
+    two = two_tables(Zheng07Model)
     return {'predict_model': default * 1e6,
+            'two_tables_per_step': two,
             'predict_model_calls_per_sec': 1.0 / default,
             'predict_model_one_launch_per_call': single * 1e6,
             'predict_model_resident': None if resident is None else resident * 1e6,
@@ -372,6 +374,55 @@ def unbatched(make, table, synthetic, Interpolator):
             'interpolator_5x5_predict_model': grid * 1e6,
             'predict_batch_walkers': walkers,
             'unit': 'us per call (Python API, host model -> host results)'}
+
+
+def two_tables(Zheng07Model):
+    """The reference's documented likelihood step: TWO tables per model evaluation
+    (docs/guides/overview.rst:86-92: halotab_wp.predict(model), then halotab_ds.predict(model))
+    -- its own example tables (tests/golden/bolplanck_{wp,ds}.hdf5: mode auto and mode cross),
+    default options: alternately, and posted together (TabCorr.predict_joint); us per PAIR."""
+    from tabcorr_amd import TabCorr
+    golden = os.path.join(REPO, 'tests', 'golden')
+    try:
+        wp = TabCorr.read(os.path.join(golden, 'bolplanck_wp.hdf5'))
+        ds = TabCorr.read(os.path.join(golden, 'bolplanck_ds.hdf5'))
+        model = Zheng07Model(redshift=wp.attrs['redshift'])
+        count = [0]
+
+        def step():
+            count[0] += 1
+            model.param_dict['logMmin'] = 12.0 + 1e-5 * (count[0] % 1000)
+
+        def alternately():
+            step()
+            wp.predict(model)
+            ds.predict(model)
+
+        def joint():
+            step()
+            TabCorr.predict_joint([wp, ds], model)
+        record = {}
+        for tab in (wp, ds):
+            tab.set_resident(False)
+        record['alternately_one_launch_per_call'] = time_calls(alternately, seconds=0.2,
+                                                               warm=50) * 1e6
+        record['predict_joint_one_launch_per_call'] = time_calls(joint, seconds=0.2,
+                                                                 warm=50) * 1e6
+        model.param_dict['logMmin'] = 12.3456
+        expect = (wp.predict(model), ds.predict(model))
+        for tab in (wp, ds):
+            tab.set_resident('auto')           # (= a new handle's state: nothing switched on)
+        record['alternately'] = time_calls(alternately, seconds=0.3, warm=200) * 1e6
+        record['predict_joint'] = time_calls(joint, seconds=0.3, warm=200) * 1e6
+        record['unit'] = 'us per pair of predictions (Python API, host model -> host results)'
+        # the model of `expect` again, posted together: the bits of one launch per call
+        model.param_dict['logMmin'] = 12.3456
+        both = TabCorr.predict_joint([wp, ds], model)
+        record['predict_joint_same_bits_as_predict'] = bool(
+            all(a[0] == b[0] and np.array_equal(a[1], b[1]) for a, b in zip(expect, both)))
+        return record
+    except Exception as error:   # noqa: BLE001 -- a secondary measurement must not end the bench
+        return {'failed': '%s: %s' % (type(error).__name__, error)}
 
 
 # ---- SURVEY 8f.4: pair counting for the tabulation step ---------------------------------------

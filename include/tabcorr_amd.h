@@ -196,6 +196,16 @@ int tc_chi2_zheng07_batch_device(tc_table* table, const double* theta_device, in
  * which in turn routes small eligible batches here. */
 int tc_predict_zheng07_many(tc_table* table, const double* theta, int n_theta, int n_walkers,
                             int n_gauss_prim, unsigned flags, double* ngal, double* xi);
+/* ONE draw against several tables in one call -- the reference's documented likelihood step
+ * evaluates two: halotab_wp.predict(model), then halotab_ds.predict(model)
+ * (docs/guides/overview.rst:86-92).  Every table's call is posted before the first answer is
+ * waited for (its resident kernel's mailbox, or one launch on the table's own stream), so the
+ * tables' round trips overlap; each table is served by the path tc_predict_zheng07_many would
+ * take for it, with the same bits.  tables: 1 .. 16 different handles (any mix of modes and
+ * shapes; all must accept the same theta and flags); ngal (n_tables); xi[k]: n_r(k) doubles. */
+int tc_predict_zheng07_joint(tc_table* const* tables, int n_tables, const double* theta,
+                             int n_theta, int n_gauss_prim, unsigned flags, double* ngal,
+                             double* const* xi);
 
 /* Asynchronous host-to-host form of the two calls above -- the SURVEY.md section 8d metric
  * (theta on the host -> (ngal, xi) on the host) at the device rate.  What it replaces in the
@@ -457,6 +467,12 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 Setting the option waits for the handle's work in flight.
  *   "trace"       developer timelines (developer builds only, tabcorr_amd_testing.h). */
 int tc_table_set_option(tc_table* table, const char* name, int value);
+/* The handle's resident kernels so far: launches (of either kernel), calls that found the
+ * single-draw kernel gone and launched it again, calls the automatic mode handed back to a
+ * launch after an error (it switches itself off at three), and whether one is running now
+ * (0 no, 1 the single-draw kernel, 2 the ensemble kernel).  Any pointer may be NULL. */
+int tc_table_resident_stats(const tc_table* table, int64_t* launches, int64_t* relaunches,
+                            int64_t* failures, int* running);
 /* *out = 1 when option "deterministic" = 2 is set AND a one-launch form serves this table with
  * these predict flags and n_gauss_prim: every batched, un-batched and asynchronous call with
  * them then runs that one form (a draw's bits depend on the draw alone); else 0. */

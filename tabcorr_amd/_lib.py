@@ -86,6 +86,7 @@ SIGNATURES = {
                                  c_int64_p, c_int_p, c_float_p],
     'tc_table_batch_invariant': [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, c_int_p],
     'tc_set_copy_threads': [ctypes.c_int, ctypes.c_int],
+    'tc_table_resident_stats': [ctypes.c_void_p, c_int64_p, c_int64_p, c_int64_p, c_int_p],
     'tc_table_synchronize': [ctypes.c_void_p],
     'tc_table_info': [ctypes.c_void_p, c_int_p, c_int_p, c_int_p, c_int64_p,
                       c_int_p, c_int64_p],
@@ -109,6 +110,9 @@ SIGNATURES = {
     'tc_predict_zheng07_many': [
         ctypes.c_void_p, c_double_p, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_uint, c_double_p, c_double_p],
+    'tc_predict_zheng07_joint': [
+        ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, c_double_p, ctypes.c_int,
+        ctypes.c_int, ctypes.c_uint, c_double_p, ctypes.POINTER(c_double_p)],
     'tc_predict_zheng07_batch_async': [
         ctypes.c_void_p, c_double_p, ctypes.c_int, ctypes.c_int64,
         ctypes.c_int, ctypes.c_uint, c_double_p, c_double_p, c_int64_p],

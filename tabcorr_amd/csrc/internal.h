@@ -725,8 +725,13 @@ inline int64_t many_walkers_limit() {
 }
 int resident_predict(tc_table* t, const double* theta, int n_theta, int n_gauss, unsigned flags,
                      double* ngal, double* xi);
+int resident_post(tc_table* t, const double* theta, int n_theta, int n_gauss, unsigned flags);
+int resident_collect(tc_table* t, const double* theta, int n_theta, int n_gauss, unsigned flags,
+                     double* ngal, double* xi);
 int resident_stop(tc_table* t);
 bool resident_eligible(const tc_table* t, int n_gauss);
+// Is a single-draw resident kernel of ANOTHER handle running on this handle's device?
+bool other_resident_running(const tc_table* t);
 // 2 .. kEnsembleMaxWalkers draws through the resident ensemble kernel, host to host.
 bool ensemble_eligible(const tc_table* t, int64_t n_walkers, int n_gauss, unsigned flags);
 int ensemble_predict(tc_table* t, const double* theta, int n_theta, int n_walkers, int n_gauss,

@@ -4,6 +4,7 @@
 // inst_single.hip: un-batched calls; internal.h declares their entry points).
 #include <immintrin.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "internal.h"
@@ -1786,6 +1787,22 @@ int resident_wait(tc_table* t, int* left) {
 }
 }  // namespace
 
+// Single-draw resident kernels running per device, over all handles of the process (as far as
+// the host knows: a kernel that has left by itself is noticed at its handle's next call).  A
+// handle whose un-batched call would be a LAUNCH while another handle's resident kernel runs
+// risks a place behind that kernel in a shared hardware queue -- it would wait out the other
+// kernel's idle time (250 us), the other handle's next call would find its kernel gone, and the
+// two would take turns like that until both streaks are long enough (the reference's two tables
+// per step: tools/r06_two_tables.py saw 8 relaunches and a 4.5 ms call on the way in).  With a
+// neighbour's kernel running, the automatic mode therefore engages at once.
+std::atomic<int> g_resident_single[64];
+
+bool other_resident_running(const tc_table* t) {
+  if (t->device < 0 || t->device >= 64) return false;
+  const int mine = t->resident.running && !t->resident.ensemble ? 1 : 0;
+  return g_resident_single[t->device].load(std::memory_order_relaxed) > mine;
+}
+
 int resident_stop(tc_table* t) {
   tc_table::Resident& r = t->resident;
   if (!r.running) return TC_OK;
@@ -1804,6 +1821,7 @@ int resident_stop(tc_table* t) {
       __atomic_store_n(entries + 2 * i + 1, tc::kResidentStop, __ATOMIC_RELEASE);
     _mm_sfence();
   }
+  if (!r.ensemble && t->device >= 0 && t->device < 64) g_resident_single[t->device].fetch_sub(1);
   r.running = false;
   r.ensemble = false;
   TC_HIP(hipStreamSynchronize(r.stream));
@@ -1818,8 +1836,50 @@ bool resident_eligible(const tc_table* t, int n_gauss) {
          t->plan.n_positions <= (int64_t)single_draw_blocks(t) * 8 * n_slices;
 }
 
-int resident_predict(tc_table* t, const double* theta, int n_theta, int n_gauss, unsigned flags,
-                     double* ngal, double* xi) {
+// One call of the resident single-draw kernel in two halves, so that a joint call over several
+// tables (tc_predict_zheng07_joint) can post every table's parameters before it waits for the
+// first answer: resident_post prepares the handle's buffers, publishes the parameters under a new
+// call number and launches the kernel unless it is running; resident_collect waits for the
+// workgroups' answers -- relaunching (and publishing again) when one of them had left before
+// it saw the call -- and combines them.  resident_predict = both.
+namespace {
+int resident_launch_and_publish(tc_table* t, Quadrature* q, const double* theta, int n_theta,
+                                int n_gauss, unsigned flags) {
+  tc_table::Resident& r = t->resident;
+  const int blocks = single_draw_blocks(t);
+  const int idle_us = r.enabled ? r.idle_us : std::min(r.idle_us, r.auto_idle_us);
+  unsigned long long* mailbox = (unsigned long long*)r.mailbox.ptr;
+  const bool direct = r.single_aperture.ptr != nullptr;
+  unsigned long long* entries = direct ? (unsigned long long*)r.single_aperture.ptr : mailbox;
+  // (the aperture is write-combining memory: an entry's two words share a line and leave in
+  // program order, the fence sends them off at once)
+  publish(entries, theta, n_theta, r.ws.epoch);
+  if (direct) _mm_sfence();
+  if (!r.running) {
+    tc::SingleArgs sa{};
+    fill_single_args(t, q, theta, n_theta, n_gauss, flags, blocks, r.ws, &sa);
+    sa.mailbox = entries;
+    sa.exited = mailbox + kMailboxEntryWords;
+    sa.launch_id = ++r.launch_id;
+    sa.idle_ticks = (unsigned long long)std::max(1, idle_us) * 100ull;     // 100 MHz
+    r.running_idle_us = idle_us;
+    r.auto_serving = !r.enabled;
+    sa.life_ticks = 1000000000ull;                                          // 10 s
+    sa.poll_waves = std::max(1, std::min(4, r.poll_waves));
+    const int status = launch_resident_kernel(blocks, r.stream, sa);
+    if (status != TC_OK) return status;
+    r.running = true;
+    if (t->device >= 0 && t->device < 64) g_resident_single[t->device].fetch_add(1);
+    r.n_theta = n_theta;
+    r.n_gauss = n_gauss;
+    r.flags = flags;
+    r.blocks = blocks;
+  }
+  return TC_OK;
+}
+}  // namespace
+
+int resident_post(tc_table* t, const double* theta, int n_theta, int n_gauss, unsigned flags) {
   tc_table::Resident& r = t->resident;
   if (r.inject_failures > 0) {      // (option "resident_inject_failures": tests of the fallback)
     --r.inject_failures;
@@ -1862,32 +1922,19 @@ int resident_predict(tc_table* t, const double* theta, int n_theta, int n_gauss,
   }
   status = r.ws.prepare(1, blocks, t->rt, 0);       // (a new call number: r.ws.epoch)
   if (status != TC_OK) return status;
-  unsigned long long* mailbox = (unsigned long long*)r.mailbox.ptr;
-  const bool direct = r.single_aperture.ptr != nullptr;
-  unsigned long long* entries = direct ? (unsigned long long*)r.single_aperture.ptr : mailbox;
+  return resident_launch_and_publish(t, q, theta, n_theta, n_gauss, flags);
+}
+
+int resident_collect(tc_table* t, const double* theta, int n_theta, int n_gauss, unsigned flags,
+                     double* ngal, double* xi) {
+  tc_table::Resident& r = t->resident;
+  Quadrature* q = nullptr;
+  int status = get_quadrature(t, n_gauss, &q);
+  if (status != TC_OK) return status;
   for (int attempt = 0; attempt < 4; ++attempt) {
-    // (the aperture is write-combining memory: an entry's two words share a line and leave in
-    // program order, the fence sends them off at once)
-    publish(entries, theta, n_theta, r.ws.epoch);
-    if (direct) _mm_sfence();
-    if (!r.running) {
-      tc::SingleArgs sa{};
-      fill_single_args(t, q, theta, n_theta, n_gauss, flags, blocks, r.ws, &sa);
-      sa.mailbox = entries;
-      sa.exited = mailbox + kMailboxEntryWords;
-      sa.launch_id = ++r.launch_id;
-      sa.idle_ticks = (unsigned long long)std::max(1, idle_us) * 100ull;     // 100 MHz
-      r.running_idle_us = idle_us;
-      r.auto_serving = !r.enabled;
-      sa.life_ticks = 1000000000ull;                                          // 10 s
-      sa.poll_waves = std::max(1, std::min(4, r.poll_waves));
-      status = launch_resident_kernel(blocks, r.stream, sa);
+    if (attempt > 0) {
+      status = resident_launch_and_publish(t, q, theta, n_theta, n_gauss, flags);
       if (status != TC_OK) return status;
-      r.running = true;
-      r.n_theta = n_theta;
-      r.n_gauss = n_gauss;
-      r.flags = flags;
-      r.blocks = blocks;
     }
     int left = 0;
     status = resident_wait(t, &left);
@@ -1903,6 +1950,13 @@ int resident_predict(tc_table* t, const double* theta, int n_theta, int n_gauss,
     if (status != TC_OK) return status;
   }
   return fail(TC_ERR_HIP, "the resident kernel keeps leaving before it answers");
+}
+
+int resident_predict(tc_table* t, const double* theta, int n_theta, int n_gauss, unsigned flags,
+                     double* ngal, double* xi) {
+  const int status = resident_post(t, theta, n_theta, n_gauss, flags);
+  if (status != TC_OK) return status;
+  return resident_collect(t, theta, n_theta, n_gauss, flags, ngal, xi);
 }
 
 // ---- resident ensemble path -------------------------------------------------------------------

@@ -474,6 +474,9 @@ bool resident_auto_wants(tc_table* t) {
     --r.auto_backoff;
     return false;
   }
+  // (a neighbour's resident kernel is running: this process is in a loop of un-batched calls,
+  // and a launch of this handle might queue behind that kernel -- launch.hip)
+  if (other_resident_running(t)) return true;
   return r.auto_streak >= r.auto_streak_min;
 }
 
@@ -549,6 +552,118 @@ int tc_predict_zheng07_many(tc_table* t, const double* theta, int n_theta, int n
     combine_single_draw(t, t->single_ws, w, ngal + w, xi + (size_t)w * t->n_r);
   if (auto_candidate) t->resident.auto_last_ns = monotonic_ns();
   return TC_OK;
+}
+
+// One draw against SEVERAL tables -- the reference's documented step evaluates two:
+// halotab_wp.predict(model), then halotab_ds.predict(model) (docs/guides/overview.rst:86-92,
+// tests/test_database.py:17-18).  Every table's call is posted first -- the parameters into the
+// mailbox of its resident kernel, or one launch of single_draw_kernel on the table's own stream
+// -- and only then are the answers waited for, in table order: the tables' round trips overlap
+// (two tables: 18.6 -> ~11 us per pair with the resident kernels, 33 -> ~20 us with launches).
+// Which path serves a table is decided as in tc_predict_zheng07_many, table by table, and the
+// results are those calls' bit for bit.
+int tc_predict_zheng07_joint(tc_table* const* tables, int n_tables, const double* theta,
+                             int n_theta, int n_gauss, unsigned flags, double* ngal,
+                             double* const* xi) {
+  constexpr int kMaxJoint = 16;
+  TC_CHECK(tables != nullptr && n_tables >= 1 && n_tables <= kMaxJoint,
+           "n_tables must be in [1, %d]", kMaxJoint);
+  TC_CHECK(ngal != nullptr && xi != nullptr, "output pointer is NULL");
+  enum Route { kGeneric, kResident, kLaunched };
+  Route route[kMaxJoint];
+  bool automatic[kMaxJoint];
+  unsigned long long relaunches[kMaxJoint];
+  for (int k = 0; k < n_tables; ++k) {
+    tc_table* t = tables[k];
+    int status = check_predict_args(t, theta, n_theta, 1, n_gauss, flags);
+    if (status != TC_OK) return status;
+    TC_CHECK(xi[k] != nullptr, "output pointer is NULL");
+    for (int j = 0; j < k; ++j) TC_CHECK(tables[j] != t, "a table appears twice");
+    route[k] = kGeneric;
+    automatic[k] = false;
+    if (batch_invariant_form(t, n_gauss, flags) || !single_draw_eligible(t, 1, n_gauss, flags))
+      continue;
+    TC_HIP(hipSetDevice(t->device));
+    tc_table::Resident& r = t->resident;
+    const bool eligible = resident_eligible(t, n_gauss);
+    const bool candidate = r.auto_mode && !r.enabled && eligible;
+    if (r.enabled && eligible) {
+      route[k] = kResident;
+    } else if (candidate && resident_auto_wants(t)) {
+      route[k] = kResident;
+      automatic[k] = true;
+    } else {
+      route[k] = kLaunched;
+      automatic[k] = candidate;
+    }
+  }
+  // post
+  int first_error = TC_OK;
+  for (int k = 0; k < n_tables; ++k) {
+    tc_table* t = tables[k];
+    if (route[k] == kGeneric) continue;
+    TC_HIP(hipSetDevice(t->device));
+    if (route[k] == kResident) {
+      relaunches[k] = t->resident.relaunches;
+      int status = resident_post(t, theta, n_theta, n_gauss, flags);
+      if (status == TC_OK) continue;
+      if (!automatic[k]) {
+        first_error = status;
+        n_tables = k;             // (collect what was posted, then report)
+        break;
+      }
+      // (nobody asked for the resident kernel: tc_predict_zheng07_many's fallback)
+      (void)resident_stop(t);
+      (void)hipGetLastError();
+      tc_table::Resident& r = t->resident;
+      r.auto_backoff = r.auto_backoff_calls;
+      r.auto_streak = r.auto_window = r.auto_relaunches = 0;
+      if (++r.auto_failures >= 3) r.auto_mode = false;
+      route[k] = kLaunched;
+    }
+    int status = TC_OK;
+    if (t->resident.running) status = resident_stop(t);
+    if (status == TC_OK)
+      status = launch_single_draw(t, theta, n_theta, 1, n_gauss, flags, &t->single_ws, t->stream);
+    if (status != TC_OK) {
+      first_error = status;
+      n_tables = k;
+      break;
+    }
+  }
+  // collect, in table order
+  for (int k = 0; k < n_tables; ++k) {
+    tc_table* t = tables[k];
+    TC_HIP(hipSetDevice(t->device));
+    int status = TC_OK;
+    if (route[k] == kGeneric) {
+      status = tc_predict_zheng07_many(t, theta, n_theta, 1, n_gauss, flags, ngal + k, xi[k]);
+    } else if (route[k] == kResident) {
+      status = resident_collect(t, theta, n_theta, n_gauss, flags, ngal + k, xi[k]);
+      if (status == TC_OK && automatic[k])
+        resident_auto_served(t, t->resident.relaunches != relaunches[k]);
+      if (status != TC_OK && automatic[k]) {
+        // (as above: stop, back off, serve this table by a launch)
+        (void)resident_stop(t);
+        (void)hipGetLastError();
+        tc_table::Resident& r = t->resident;
+        r.auto_backoff = r.auto_backoff_calls;
+        r.auto_streak = r.auto_window = r.auto_relaunches = 0;
+        if (++r.auto_failures >= 3) r.auto_mode = false;
+        status = launch_single_draw(t, theta, n_theta, 1, n_gauss, flags, &t->single_ws,
+                                    t->stream);
+        if (status == TC_OK)
+          status = wait_single_done(&t->single_ws, t->stream, t->tuning.poll_done != 0);
+        if (status == TC_OK) combine_single_draw(t, t->single_ws, 0, ngal + k, xi[k]);
+      }
+    } else {
+      status = wait_single_done(&t->single_ws, t->stream, t->tuning.poll_done != 0);
+      if (status == TC_OK) combine_single_draw(t, t->single_ws, 0, ngal + k, xi[k]);
+      if (automatic[k]) t->resident.auto_last_ns = monotonic_ns();
+    }
+    if (status != TC_OK && first_error == TC_OK) first_error = status;
+  }
+  return first_error;
 }
 
 namespace {
@@ -1227,6 +1342,17 @@ int tc_table_autotune_result(const tc_table* t, unsigned flags, int capacity, in
     for (int k = 0; k < 3; ++k) us[3 * i + k] = it->second.us[i][k];
   }
   *count = AutoChoice::kSizes;
+  return TC_OK;
+}
+
+int tc_table_resident_stats(const tc_table* t, int64_t* launches, int64_t* relaunches,
+                            int64_t* failures, int* running) {
+  TC_CHECK(t != nullptr, "table handle is NULL");
+  const tc_table::Resident& r = t->resident;
+  if (launches) *launches = (int64_t)r.launch_id;
+  if (relaunches) *relaunches = (int64_t)r.relaunches;
+  if (failures) *failures = (int64_t)r.auto_failures;
+  if (running) *running = r.running ? (r.ensemble ? 2 : 1) : 0;
   return TC_OK;
 }
 

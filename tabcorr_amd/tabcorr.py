@@ -539,6 +539,69 @@ class TabCorr:
             modulate_with_cenocc=spec.modulate_with_cenocc,
             assembias=spec.assembias, family=spec.family))
 
+    @staticmethod
+    def predict_joint(halotabs, model, n_gauss_prim=10, check_consistency=True):
+        """``[halotab.predict(model) for halotab in halotabs]`` in ONE call.
+
+        The reference's documented likelihood step evaluates two tables per
+        model (``docs/guides/overview.rst:86-92``: ``halotab_wp.predict(model)``,
+        then ``halotab_ds.predict(model)``).  Here every table's call is
+        posted before the first answer is waited for, so the tables' round
+        trips to the device overlap (``tc_predict_zheng07_joint``): two tables
+        take about as long as one and a half.  Total correlation functions
+        only; each table's result has the bits of its own ``predict(model)``.
+
+        Returns
+        -------
+        results : list of ``(ngal, xi)``, one per table, as `predict` returns
+            them.
+        """
+        halotabs = list(halotabs)
+        if check_consistency:
+            for halotab in halotabs:
+                halotab._check_consistency_cached(model)
+        spec = device_spec(model)
+        if spec is None or len(halotabs) < 2 or len(halotabs) > 16:
+            return [halotab.predict(model, n_gauss_prim=n_gauss_prim,
+                                    check_consistency=False)
+                    for halotab in halotabs]
+        devices = [halotab.to_device() for halotab in halotabs]
+        first = devices[0]
+        cache = getattr(first, '_joint', None)
+        if cache is None or cache[0] != [id(d) for d in devices]:
+            handles = (ctypes.c_void_p * len(devices))(
+                *[d.handle.value for d in devices])
+            theta = np.zeros(16)
+            ngal = np.zeros(len(devices))
+            xi = [np.zeros(d.n_r) for d in devices]
+            xi_p = (_lib.c_double_p * len(devices))(
+                *[a.ctypes.data_as(_lib.c_double_p) for a in xi])
+            # (every table's lock, in one fixed order whatever the order of
+            # the tables in the call)
+            locks = [d.lock for d in sorted(devices, key=id)]
+            cache = ([id(d) for d in devices], handles, theta,
+                     _lib.as_double_p(theta), ngal, _lib.as_double_p(ngal), xi,
+                     xi_p, locks, devices)
+            first._joint = cache
+        _, handles, theta, theta_p, ngal, ngal_p, xi, xi_p, locks, _ = cache
+        values = spec.values
+        flags = _flags(False, spec.modulate_with_cenocc, spec.assembias,
+                       spec.family)
+        for lock in locks:
+            lock.acquire()
+        try:
+            theta[:len(values)] = values
+            status = first.lib.tc_predict_zheng07_joint(
+                handles, len(devices), theta_p, len(values), n_gauss_prim,
+                flags, ngal_p, xi_p)
+            if status:
+                _lib.check(status)
+            return [(ngal[k], xi[k].reshape(halotab.tpcf_shape).copy())
+                    for k, halotab in enumerate(halotabs)]
+        finally:
+            for lock in reversed(locks):
+                lock.release()
+
     def predict_batch(self, theta, separate_gal_type=False, n_gauss_prim=10,
                       modulate_with_cenocc=False, assembias=False,
                       family='zheng07', out=None):

@@ -4,6 +4,7 @@ likelihood evaluation (docs/guides/overview.rst:86-92: halotab_wp.predict(model)
 halotab_ds.predict(model)) -- with default options: bolplanck_wp (mode auto) and bolplanck_ds
 (mode cross) alternately, per-pair time, per-call time distribution, agreement with the launched
 path, device-wide synchronisations in between.  gpurun -- python3 tools/r06_two_tables.py"""
+import ctypes
 import os
 import sys
 import time
@@ -56,6 +57,14 @@ def loop(n, label, joint=None):
                 np.array_equal(b[1], launched[i % 400][1][1])):
             bad += 1
     us = times * 1e6
+    stats = []
+    for tab in (wp, ds):
+        values = [ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()]
+        running = ctypes.c_int()
+        lib.tc_table_resident_stats(tab.to_device().handle, *[ctypes.byref(v) for v in values],
+                                    ctypes.byref(running))
+        stats.append(tuple(v.value for v in values) + (running.value, ))
+    print('    resident (launches, relaunches, fall-backs, running) wp %s ds %s' % tuple(stats))
     print('%-44s pair: median %6.2f us  mean %6.2f  p99 %7.1f  max %8.1f   results differing '
           'from the launched path: %d of %d' % (label, np.median(us), us.mean(),
                                                 np.percentile(us, 99), us.max(), bad, n), flush=True)
