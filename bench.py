@@ -633,7 +633,15 @@ def main():
 
         three_kernel_name = ('tc::contract_quad_kernel<5, true>' if interp_mode
                              else 'tc::contract_quad_kernel<5, false>')
-        kernel_name = ('tc::predict_fused_kernel<10, 5, false, false, false, 8, 64, false, 2>'
+        # (the one-launch kernel's instance from what the library reports about its last launch:
+        # draws per workgroup 64 -- the throughput form --, 32, or 40 -- the latency form, which
+        # calls that have the chip to themselves take; the deferring instance follows the
+        # option "fused_defer", 2 by default)
+        fused_draws = next((d for d in (64, 40, 32)
+                            if launch[0].value == (n_draws + d - 1) // d), 64)
+        fused_defer = dict(o.split('=') for o in args.option).get('fused_defer', '2')
+        kernel_name = ('tc::predict_fused_kernel<10, 5, false, false, false, 8, %d, false, %s>'
+                       % (fused_draws, fused_defer if fused_draws != 32 else '0')
                        if fused_active else three_kernel_name)
         headline_traffic = (pmc_traffic(kernel_name, 'interp5x5' if interp_mode else '')
                             if n_draws == (100000 if interp_mode else 10000) // (

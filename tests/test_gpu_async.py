@@ -924,3 +924,34 @@ def test_synchronous_interpolator_calls_in_chunks(mode):
     ngal_s, xi_s = interp.predict_batch(theta[:3000], x[:3000], separate_gal_type=True)
     total = sum(xi_s[key] for key in xi_s)
     assert_rel(total, results[1][1][:3000], 1e-10, floor=1e-12)
+
+
+def test_predict_joint_over_tables_of_every_kind():
+    """TabCorr.predict_joint with three tables -- mode auto, mode cross and a float32 table the
+    un-batched kernels cannot serve (it goes through the batched path inside the same call) --
+    returns what predict(model) returns for each, bit for bit; the same table twice is refused;
+    a model the device cannot evaluate falls back to one predict() per table."""
+    from tabcorr_amd import TabCorr, Zheng07Model, synthetic
+    tables = [synthetic.synthetic_table(20, 1, (9, ), 'auto', seed=1),
+              synthetic.synthetic_table(20, 1, (7, ), 'cross', seed=2),
+              synthetic.synthetic_table(12, 1, (6, 5), 'auto', seed=3)]
+    halotabs = [make_tabcorr(tables[0]), make_tabcorr(tables[1]),
+                make_tabcorr(tables[2], compute_dtype='float32')]
+    model = Zheng07Model(redshift=tables[0]['attrs']['redshift'])
+    theta = synthetic.zheng07_draws(40, seed=9)
+    keys = ('logMmin', 'sigma_logM', 'logM0', 'logM1', 'alpha')
+    for mode in (False, 'auto', True):
+        for tab in halotabs[:2]:
+            tab.set_resident(mode)
+        for i in range(40):
+            for key, value in zip(keys, theta[i]):
+                model.param_dict[key] = value
+            single = [tab.predict(model) for tab in halotabs]
+            joint = TabCorr.predict_joint(halotabs, model)
+            assert len(joint) == 3
+            for (n1, x1), (n2, x2), tab in zip(single, joint, halotabs):
+                assert n1 == n2 and np.array_equal(x1, x2), (mode, i)
+                assert x2.shape == tuple(tab.tpcf_shape)
+    with pytest.raises(ValueError):
+        TabCorr.predict_joint([halotabs[0], halotabs[0]], model)
+    assert len(TabCorr.predict_joint(halotabs[:1], model)) == 1

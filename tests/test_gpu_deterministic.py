@@ -196,3 +196,31 @@ def test_measured_dispatch_is_refused_and_default_is_timing_free():
     _lib.check(lib.tc_table_set_option(handle, b'autotune_after', 0))
     halotab.set_deterministic(False)
     _lib.check(lib.tc_table_set_option(handle, b'autotune_after', 256))
+
+
+def test_tables_without_a_batch_invariant_form_say_so():
+    """set_deterministic(True) returns False for a table no one-launch form serves (float32
+    storage): its calls then run as with level 1 -- reproducible from run to run, not
+    batch-invariant -- and tc_table_batch_invariant reports it per combination of flags."""
+    from tabcorr_amd import synthetic, _lib
+    from tabcorr_amd.tabcorr import _flags
+    lib = _lib.load()
+    table = synthetic.synthetic_table(12, 1, (6, 5), 'auto', seed=3)
+    halotab = make_tabcorr(table, compute_dtype='float32')
+    assert halotab.set_deterministic(True) is False
+    theta = synthetic.zheng07_draws(300, seed=4)
+    first = halotab.predict_batch(theta)
+    again = halotab.predict_batch(theta)
+    assert np.array_equal(first[1], again[1])
+    wide = make_tabcorr(synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0))
+    assert wide.set_deterministic(True) is True
+    out = ctypes.c_int(-1)
+    # the fused likelihood of separated components does not exist: no form for that combination
+    for separate, expect in ((False, 1), (True, 1)):
+        _lib.check(lib.tc_table_batch_invariant(wide.to_device().handle, 10,
+                                                _flags(separate, False, False, 'zheng07'),
+                                                ctypes.byref(out)))
+        assert out.value == expect
+    _lib.check(lib.tc_table_batch_invariant(wide.to_device().handle, 7, 0, ctypes.byref(out)))
+    assert out.value == 1                    # (any n_gauss_prim for the undecorated family)
+    assert wide.set_deterministic(False) is False

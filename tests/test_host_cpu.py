@@ -1188,3 +1188,39 @@ def test_consistency_checks_notice_in_place_changes():
     # (first call, the two failures, the model's new redshift; the restored values equal what
     # last passed and are served by the cache)
     assert len(calls) == 4
+
+
+def test_profiles_hold_the_kernels_they_quote():
+    """the newest committed bench record quotes memory traffic only from
+    PMC files that hold the very kernel it timed -- no `"traffic": null` for a configuration
+    whose PMC file exists, no stale file of another build (bench_legs.pmc_traffic reports such a
+    look-up under `failed_legs` instead of returning None quietly)."""
+    import glob
+    import json
+    import bench_legs
+    details = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r[0-9][0-9]_bench_detail.json')))
+    if not details:
+        pytest.skip('no committed bench detail')
+    detail = json.load(open(details[-1]))
+    round_tag = os.path.basename(details[-1])[:3]
+    assert 'pmc_counters' not in detail.get('failed_legs', {}), detail['failed_legs']
+    records = [('headline', detail['roofline'])]
+    records += [(record['tag'], record) for record in detail.get('other_configs', {}).values()]
+    checked = 0
+    for tag, record in records:
+        source = record.get('traffic_source')
+        assert record.get('traffic') is not None and source, (tag, 'no traffic quoted')
+        path = os.path.join(REPO, source.split(' ')[0])
+        assert os.path.basename(path).startswith(round_tag), (tag, source, 'another round')
+        rows = [line for line in open(path).read().splitlines()
+                if 'FETCH_SIZE' in line and not line.startswith('#')]
+        kernel = record['kernel']
+        assert any(bench_legs.same_kernel(kernel, row.split('FETCH_SIZE')[0]) for row in rows), (
+            tag, kernel, 'not in', source)
+        checked += 1
+    assert checked >= 8, checked
+    # ... and the look-up says so when a file does not hold a kernel
+    del bench_legs.pmc_failures[:]
+    assert bench_legs.pmc_traffic('tc::no_such_kernel<1>', '') == (None, None)
+    assert bench_legs.pmc_failures and 'no_such_kernel' in bench_legs.pmc_failures[0]
+    del bench_legs.pmc_failures[:]

@@ -2,7 +2,7 @@
 # Copy the artefacts tools/profile_round.sh collected (gpurun_out/profile) into profiles/.
 # Usage: tools/install_profiles.sh [round tag, default r03]
 cd "$(dirname "$0")/.." || exit 1
-R=${1:-r05}
+R=${1:-r06}
 P=gpurun_out/profile
 HEAD1="# rocprofv3 --pmc passes (separate runs, --kernel-trace only; tools/profile_round.sh): python3 bench.py"
 HEAD2="# FETCH_SIZE / WRITE_SIZE in KB per launch (FETCH_SIZE under-reports wide coalesced reads 2x on gfx950); other counters raw"

@@ -9,7 +9,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 WHAT=${1:-all}
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 OUT=gpurun_out/profile
 mkdir -p $OUT
 FAST="--cpu-seconds 0 --detail 0"
