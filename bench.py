@@ -124,9 +124,9 @@ def check_gathered(region, comm, lib, _lib, dev, handle, interp_mode, chi2_mode,
                    n_gauss, data_p, precision_p, synthetic, interp, synchronize):
     """Rank 0: every step of every rank in the receive buffer == this rank's own evaluation of
     that rank's draws (cfg2: seed 1 + rank; interp5x5: the rank's round-robin shard)."""
-    flat = region.gathered()
+    fetch = region.gathered()
     synchronize()
-    if not comm.is_root or flat is None:
+    if not comm.is_root or fetch is None:
         return None
     world = comm.world_size
     if interp_mode:
@@ -137,10 +137,12 @@ def check_gathered(region, comm, lib, _lib, dev, handle, interp_mode, chi2_mode,
     scratch = dev.malloc(region.n_out)
     second = ctypes.c_void_p(scratch.value + n_draws * 8)
     steps = mismatches = 0
-    # (the newest gather of every block: older entries of the log were overwritten)
+    # (the newest gather of every block: older entries of the log were overwritten; at most the
+    # two newest blocks -- a block of 32 steps of 8 ranks is 400 MB to bring to the host)
     newest = {}
     for entry in region.ring.log:
         newest[entry[0]] = entry
+    newest = dict(sorted(newest.items(), key=lambda item: item[1][1])[-2:])
     for r in range(world):
         if interp_mode:
             theta_r = np.ascontiguousarray(theta_all[r::world])
@@ -166,7 +168,7 @@ def check_gathered(region, comm, lib, _lib, dev, handle, interp_mode, chi2_mode,
         for entry in newest.values():
             for step, offset in region.ring.steps_in(entry, r):
                 steps += 1
-                if not np.array_equal(flat[offset:offset + region.n_out], own, equal_nan=True):
+                if not np.array_equal(fetch(offset, region.n_out), own, equal_nan=True):
                     mismatches += 1
     return {'ranks': world, 'steps_checked': steps, 'steps_differing': mismatches,
             'bit_equal': mismatches == 0 and steps > 0,
@@ -378,14 +380,16 @@ def main():
                     self.h_recv[begin:begin + count] = part
 
         def gathered(self):
-            """The root's receive buffer as a host array (all blocks), or None."""
+            """fetch(offset, count) -> that stretch of the root's receive buffer as a host
+            array, or None (not the root / nothing gathered)."""
             if not comm.is_root:
                 return None
             if self.h_recv is not None:
-                return self.h_recv
+                return lambda offset, count: self.h_recv[offset:offset + count]
             if self.d_recv.value:
                 comm.synchronize()
-                return dev.download(self.d_recv, self.ring.recv_elements)
+                return lambda offset, count: dev.download(
+                    ctypes.c_void_p(self.d_recv.value + offset * 8), count)
             return None
 
         def gather(self, block, send_offset, recv_offset, count):

@@ -334,6 +334,13 @@ int tc_interp_query(tc_interp* interp, int64_t ticket, int* done);
  *                 the chunk's size takes.  "sync_direct_out": as "async_direct_out" for the
  *                 chunks' staging area (2, default: arrays up to 1 MB are stored by the kernels
  *                 themselves, larger ones travel by copy command).
+ *   "sync_stagger"  synchronous host calls on float32 tables with 16 MB of results and more at
+ *                 2 KB per draw and more (a (19, 40) table's 10^4 draws are 61 MB): the chunks' kernels run one after the other -- each
+ *                 with the chip to itself, the previous chunk's results travelling and being
+ *                 copied meanwhile -- and the chunks shrink geometrically to this many per cent
+ *                 of the first (default 10, six chunks), so that only a small chunk's transfer
+ *                 is left behind the last kernel: 3.1e6 -> 3.6e6 calls/s into arrays the caller
+ *                 keeps.  0: equal chunks on all lanes, as for small results.
  *   "autotune"    value = the predict flags to tune for (a combination of TC_FLAG_*; 0 = the
  *                 total prediction of plain Zheng07), n_gauss_prim = 10: MEASURES on this table,
  *                 for batch sizes 256 .. 65536 (x 2 steps), which form serves a batch fastest in

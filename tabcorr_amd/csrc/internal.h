@@ -320,6 +320,8 @@ struct Tuning {
   int autotune_after = 0;
   int sync_chunks = 0;
   int sync_form = 32;
+  int sync_stagger = 10;      // large results: chunks one after the other, shrinking to this
+                              // many per cent of the first (0: off; table.cpp)
   int sync_direct_out = 2;
   int async_direct_in = 1;    // 1: kernels read the draws from the caller's pinned memory
   int async_direct_out = 2;   // 0: copy commands, 1: kernels store everything, 2: kernels
@@ -490,6 +492,7 @@ struct tc_table {
   // AbacusSummit interpolator, one chunk: 242 -> 200 us per 10^4 draws host to host; its single
   // table, two chunks: 149 -> 139; pipelined launches keep 160: they share the chip anyway).
   int sync_cross_target = 0;
+  std::vector<hipEvent_t> chunk_events;    // ... between the chunks of a call with large results
   // ... and that the chunks of such a call have the chip to themselves: where the latency form
   // of the one-launch kernel serves the table, every chunk takes it when all chunks together
   // have at most one workgroup of 40 draws per CU (launch.hip: fused_spread_eligible)

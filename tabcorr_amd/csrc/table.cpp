@@ -1,6 +1,8 @@
 // Table handle of the C ABI (include/tabcorr_amd.h): upload and re-layout of one
 // tabulated correlation matrix, the batched predict / chi2 / occupation entry points,
 // and the measurement hooks bench.py uses.
+#include <cmath>
+
 #include "internal.h"
 
 using namespace tc::host;
@@ -280,6 +282,7 @@ int tc_table_destroy(tc_table* t) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
   }
+  for (hipEvent_t event : t->chunk_events) (void)hipEventDestroy(event);
   if (t->ev_begin) (void)hipEventDestroy(t->ev_begin);
   if (t->ev_end) (void)hipEventDestroy(t->ev_end);
   for (tc_table::Lane& lane : t->lanes)
@@ -669,7 +672,8 @@ int tc_predict_zheng07_joint(tc_table* const* tables, int n_tables, const double
 namespace {
 int predict_async(tc_table* t, const double* theta, int n_theta, int64_t n_draws, int n_gauss,
                   unsigned flags, const double* data, const double* precision, double* ngal,
-                  double* second, bool chi2, int64_t* ticket_out, bool staging);
+                  double* second, bool chi2, int64_t* ticket_out, bool staging,
+                  hipEvent_t wait_for = nullptr, hipEvent_t kernels_done = nullptr);
 
 // How many chunks a synchronous host call of n_draws with out_bytes of results is cut into
 // (0: not chunked -- the serial path).
@@ -710,8 +714,50 @@ int predict_chunked(tc_table* t, const double* theta, int n_theta, int64_t n_dra
   if (status != TC_OK) return status;
   const int64_t chunk = ((n_draws + n_chunks - 1) / n_chunks + 63) / 64 * 64;
   n_chunks = (int)((n_draws + chunk - 1) / chunk);
-  int64_t tickets[64];
+  int64_t tickets[64], begins[65];
   TC_CHECK(n_chunks <= 64, "internal: too many chunks");
+  for (int k = 0; k <= n_chunks; ++k) begins[k] = std::min<int64_t>(n_draws, k * chunk);
+  // Large results (tens of megabytes: a (19, 40) table's 10^4 draws are 61 MB): equal chunks on
+  // four lanes finish in two groups of four, and the second group's downloads -- 145 us each,
+  // queued behind one another -- have no kernels left to hide under (0.6 of 3.2 ms).  Instead
+  // the chunks' kernels run ONE AFTER THE OTHER (events between the lanes), each with the chip
+  // to itself, chunk k - 1 travelling and being copied while chunk k computes, and the chunks
+  // SHRINK towards the end, so that what is left exposed behind the last kernel is a few
+  // hundred draws' worth of transfer and copy.
+  // (results of 2 KB per draw and more only: with a few values per draw the transfers are small
+  // beside the kernels, and a chunk's launch alone on the chip runs below the rate of four
+  // overlapping ones -- 4 x 10^5 draws of 19 values 2.48 against 2.19 ms, tools/r06_big_sync.py)
+  const bool staggered = t->tuning.sync_stagger != 0 && out_bytes >= ((size_t)16 << 20) &&
+                         second_cols * sizeof(double) >= 2048 && n_chunks >= 4 && !chi2 &&
+                         t->n_lanes >= 2 &&
+                         // (float32 tables: there the transfers are half of what the kernels
+                         // take; the same table in float64 computes twice as long and loses
+                         // more to small launches than the transfers cost: 2.0e6 -> 1.8e6)
+                         t->compute_dtype == TC_DTYPE_F32;
+  if (staggered) {
+    // (tools/r06_stagger.py, 10^4 draws of a (19, 40) float32 table into arrays the caller
+    // keeps, 1e6 calls/s: 6 chunks shrinking to 2 / 5 / 10 / 20 % of the first 3.44 / 3.58 / 3.62 /
+    // 3.49; 7 chunks 3.52 / 3.58 / 3.49 / 3.45; 8 chunks 3.34 / 3.38 / 3.51 / 3.39; equal chunks
+    // on four lanes 3.14)
+    if (t->tuning.sync_chunks == 0) n_chunks = std::min(n_chunks, 6);
+    double share[64];
+    const double ratio = std::pow(0.01 * t->tuning.sync_stagger, 1.0 / (n_chunks - 1));
+    double total = 0.0, done = 0.0;
+    for (int k = 0; k < n_chunks; ++k) total += share[k] = std::pow(ratio, k);
+    begins[0] = 0;
+    for (int k = 0; k < n_chunks; ++k) {
+      done += share[k];
+      const int64_t end = k + 1 == n_chunks
+                              ? n_draws
+                              : std::min<int64_t>(n_draws, ((int64_t)(n_draws * done / total) + 63) / 64 * 64);
+      begins[k + 1] = std::max(end, begins[k]);
+    }
+    while ((int)t->chunk_events.size() < n_chunks) {
+      hipEvent_t event;
+      TC_HIP(hipEventCreateWithFlags(&event, hipEventDisableTiming));
+      t->chunk_events.push_back(event);
+    }
+  }
   double* h_theta = (double*)t->h_in.ptr;
   double* h_out = (double*)t->h_out.ptr;
   // (one form for every chunk size: the one-launch form with sync_form draws per workgroup
@@ -734,12 +780,14 @@ int predict_chunked(tc_table* t, const double* theta, int n_theta, int64_t n_dra
     if (saved_min == 0) t->tuning.fused_min_draws = 1;
   }
   for (int k = 0; k < n_chunks && status == TC_OK; ++k) {
-    const int64_t begin = k * chunk, n = std::min(chunk, n_draws - begin);
+    const int64_t begin = begins[k], n = begins[k + 1] - begin;
     memcpy(h_theta + begin * n_theta, theta + begin * n_theta, (size_t)n * n_theta * 8);
     // (the chunk's results side by side in the staging area: [ngal | xi] -- one copy command)
     double* out = h_out + begin * (ngal_cols + second_cols);
     status = predict_async(t, h_theta + begin * n_theta, n_theta, n, n_gauss, flags, data,
-                           precision, out, out + n * ngal_cols, chi2, &tickets[k], true);
+                           precision, out, out + n * ngal_cols, chi2, &tickets[k], true,
+                           staggered && k > 0 ? t->chunk_events[k - 1] : nullptr,
+                           staggered ? t->chunk_events[k] : nullptr);
     if (status != TC_OK) n_chunks = k;       // (wait for what was queued, then report)
   }
   t->tuning.fused_draws = saved_draws;
@@ -747,7 +795,7 @@ int predict_chunked(tc_table* t, const double* theta, int n_theta, int64_t n_dra
   t->sync_cross_target = 0;
   t->sync_spread = false;
   for (int k = 0; k < n_chunks; ++k) {
-    const int64_t begin = k * chunk, n = std::min(chunk, n_draws - begin);
+    const int64_t begin = begins[k], n = begins[k + 1] - begin;
     const int waited = tc_table_wait(t, tickets[k]);
     if (waited != TC_OK) {
       (void)tc_table_synchronize(t);
@@ -981,9 +1029,14 @@ int next_ticket(tc_table* t, tc_table::Ticket** out) {
 // another.
 // `staging`: the buffers are the library's own page-locked staging areas (hipHostMalloc: the
 // device sees them at the same addresses) -- the chunks of a synchronous call, predict_chunked.
+// wait_for / kernels_done (the chunks of a synchronous call with large results): the call's
+// kernels start behind `wait_for`, and `kernels_done` is recorded between its kernels and its
+// download -- so that the chunks' kernels run one after the other, each with the chip to itself,
+// while the previous chunk's results travel.
 int predict_async(tc_table* t, const double* theta, int n_theta, int64_t n_draws, int n_gauss,
                   unsigned flags, const double* data, const double* precision, double* ngal,
-                  double* second, bool chi2, int64_t* ticket_out, bool staging) {
+                  double* second, bool chi2, int64_t* ticket_out, bool staging,
+                  hipEvent_t wait_for, hipEvent_t kernels_done) {
   int status = check_predict_args(t, theta, n_theta, n_draws, n_gauss, flags);
   if (status != TC_OK) return status;
   TC_CHECK(ticket_out != nullptr, "ticket is NULL");
@@ -1044,6 +1097,7 @@ int predict_async(tc_table* t, const double* theta, int n_theta, int64_t n_draws
       TC_HIP(hipMemcpyAsync(lane.in_theta.ptr, theta, theta_bytes, hipMemcpyHostToDevice,
                             lane.stream));
     }
+    if (wait_for != nullptr) TC_HIP(hipStreamWaitEvent(lane.stream, wait_for, 0));
     const bool saved_chain = t->chain;
     t->async_lane = lane_index;
     t->chain = false;
@@ -1054,6 +1108,7 @@ int predict_async(tc_table* t, const double* theta, int n_theta, int64_t n_draws
     t->async_lane = -1;
     t->chain = saved_chain;
     if (status != TC_OK) return status;
+    if (kernels_done != nullptr) TC_HIP(hipEventRecord(kernels_done, lane.stream));
     Range range("download");
     if (!direct_ngal && !direct_second && second == ngal + ngal_count) {
       // (adjacent in the caller's memory as in the staging buffer: one command)
@@ -1488,6 +1543,12 @@ int tc_table_set_option(tc_table* t, const char* name, int value) {
     // serial path of rounds 1-4 (upload, kernels alone on one lane, download, copy)
     TC_CHECK(value >= -1 && value <= 64, "sync_chunks must be in [-1, 64]");
     t->tuning.sync_chunks = value;
+  } else if (key == "sync_stagger") {
+    // synchronous host calls with 16 MB of results and more run their chunks' kernels one after
+    // the other, the chunks shrinking geometrically to this many per cent of the first
+    // (default 10; 0: equal chunks on all lanes as for small results; predict_chunked)
+    TC_CHECK(value >= 0 && value <= 100, "sync_stagger must be in [0, 100]");
+    t->tuning.sync_stagger = value;
   } else if (key == "sync_form") {
     TC_CHECK(value == 0 || value == 32 || value == 64, "sync_form must be 0, 32 or 64");
     t->tuning.sync_form = value;
