@@ -393,23 +393,23 @@ class TabCorr:
         (``tabcorr/tabcorr.py:496-535``)."""
         components = model._input_model_dictionary
         try:
-            keys = tuple(
-                (components[name].prim_haloprop_key,
-                 getattr(components[name], 'sec_haloprop_key', None))
-                for name in ('centrals_occupation', 'satellites_occupation'))
+            cen = components['centrals_occupation']
+            sat = components['satellites_occupation']
+            attrs = self.attrs
+            values = (model.redshift, cen.prim_haloprop_key, sat.prim_haloprop_key,
+                      getattr(cen, 'sec_haloprop_key', None),
+                      getattr(sat, 'sec_haloprop_key', None),
+                      attrs['prim_haloprop_key'], attrs.get('sec_haloprop_key'),
+                      attrs['redshift'])
         except (KeyError, AttributeError, TypeError):
-            keys = None
-        attrs = self.attrs
-        seen = (model, components, model.gal_types,
-                (getattr(model, 'redshift', None), keys,
-                 attrs.get('prim_haloprop_key'), attrs.get('sec_haloprop_key'),
-                 attrs.get('redshift')))
+            values = None
         last = self._checked_model
-        if (last is None or keys is None or last[0] is not seen[0] or
-                last[1] is not seen[1] or last[2] is not seen[2] or
-                last[3] != seen[3]):
-            self._check_consistency(model)
-            self._checked_model = seen
+        if (last is not None and values is not None and last[0] is model and
+                last[1] is components and last[2] is model.gal_types and
+                last[3] == values):
+            return
+        self._check_consistency(model)
+        self._checked_model = (model, components, model.gal_types, values)
 
     # -- mean occupation ---------------------------------------------------------
 
