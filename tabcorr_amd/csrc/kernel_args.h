@@ -341,7 +341,8 @@ struct FusedArgs {
   int part_unit_base[kFusedMaxParts];     // first unit of the component in the table
   int separate;              // 1: ngal (n_draws, 2), xi (n_draws, 3, n_r): cc, cs, ss
   int n_r;
-  int priority;              // wave priorities: phase 2 | phase 1 << 2 | phase 3 << 4
+  int priority;              // wave priorities: phase 2 | phase 1 << 2 | phase 3 << 4; bits 8 - 10:
+                             // developer knobs; bit 11: every entry of the matrix is finite
   int64_t n_draws;
   const double* log_m;       // quadrature constants as in OccArgs
   const double* m;

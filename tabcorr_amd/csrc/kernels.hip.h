@@ -2314,12 +2314,22 @@ __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, uns
 
 // The latency form's pass (40 draws per workgroup, v_mfma_f64_4x4x4_4b_f64): `count` units from
 // block (rb, cb) on for the NS r sub-tiles S0 .. S0 + NS - 1 and ALL 40 draws of the workgroup.
-// The table's unit layout serves this instruction as it stands: lane l = 16 k + 4 i + r holds
-// T[r][row 4 rb + i][column 4 cb + k] = A_block=i [r][k]; with B_block [k][j] = dens[4 cb + k][4
-// dg + j] (the same for every block) lane l receives D = sum_k T[r = l / 16][row i = (l / 4) %
-// 4][k] dens[k][draw j = l % 4] (lane <-> element map: tools/micro/mfma_map.hip), which times
-// dens[4 rb + i][4 dg + j] is the lane's share of F[r][draw]: the four i of a (r, j) are added
-// once, after the walk.  F[s][dg] += ... per lane.
+// The table's unit layout serves this instruction with the lanes permuted inside a group of 16:
+// lane 16 k + 4 i + r of a unit holds T[r][row 4 rb + i][column 4 cb + k]; lane l = 16 k + 4 r +
+// i of the WAVE fetches it (off_a: the caller's permutation) as A_block=r [i][k]; with B_block [k][j]
+// = dens[4 cb + k][4 dg + j] (the same for every block) lane l receives D = sum_k T[r = (l / 4)
+// % 4][row i = l / 16][k] dens[k][draw j = l % 4] (lane <-> element map: tools/micro/
+// mfma_map.hip), which times dens[4 rb + i][4 dg + j] is the lane's share of F[r][draw]: the four
+// i of a (r, j) -- lanes 16 apart, the k index of a B operand -- are added once, after the walk,
+// by one more matrix instruction per sum (A = 1: fused_quad_rows40).  F[s][dg] += ... per lane.
+// D[i][j] += sum_k A[i][k] value(lane 16 k + 4 block + j) with A[i][k] = 1 for i = m, else 0
+// (`select`: the lane's element of that A, 1 where lane % 4 == m): the four row shares of a (r,
+// draw) of sum m, added into the lanes 16 m + ... -- four sums per chain of four instructions,
+// every lane of the wave ends with one of them.
+__device__ __forceinline__ double fused_quad_rows40(double select, double value, double sums) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(select, value, sums, 0, 0, 0);
+}
+
 template <int S0, int NS>
 __device__ __forceinline__ void fused_quad_pass40(__amdgpu_buffer_rsrc_t rs_t, unsigned off_a,
                                                   unsigned unit_bytes, const double* dens_b,
@@ -2469,12 +2479,24 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
   // (diagnosis, TC_FUSED_SKIP: 1 no occupations -- every density 1e-3 --, 2 no matrix phase)
   const int skip = (a.priority >> 8) & 3;
   const int n_bins_occ = (skip & 1) ? 0 : a.n_bins;
+  // (TC_FUSED_STAMPS: sixteen 100 MHz stamps per workgroup, wave 0 -- 0 entry, 1 math table staged,
+  // 2 draws set up, 3 bins done, 4 sums exchanged, 5 matrix phase done, 6 waves' parts added,
+  // 7 end; 8 all waves through the matrix phase, 9 this wave's part stored, 10 all parts stored
+  // -- in the place of the likelihood's data; tools/r06_stamps.py)
+  unsigned long long* const stamps =
+      ((a.priority >> 10) & 1) && a.chi2 == nullptr ? (unsigned long long*)a.chi2_data : nullptr;
+  auto stamp = [&](int which) {
+    if (stamps != nullptr && threadIdx.x == 0)
+      stamps[blockIdx.x * 16 + which] = __builtin_amdgcn_s_memrealtime();
+  };
   if (skip & 1)
     for (int idx = threadIdx.x; idx < a.n_bins * DL; idx += blockDim.x) fused_lds[idx] = 1e-3;
 #else
   constexpr int skip = 0;
   const int n_bins_occ = a.n_bins;
+  auto stamp = [](int) {};
 #endif
+  stamp(0);
   set_priority((a.priority >> 2) & 3);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2489,6 +2511,7 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
   for (int idx = a.n_bins * DL + threadIdx.x; idx < a.dens_rows * DL; idx += blockDim.x)
     dens[idx] = 0.0;
   __syncthreads();
+  stamp(1);
 
   // ---- 1. occupations ----
   const int draw = DL != 32 ? lane : (lane & 31);
@@ -2535,6 +2558,7 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
     sc_f64 percentile = (sc_f64)a.percentile;
     const double f1 = (1.0 - a.split) / a.split, f2 = a.split / (1.0 - a.split);
     double sum_cen = 0.0, sum_sat = 0.0;
+    stamp(2);
     if (GROUPED) {
       sc_i32 group_begin = (sc_i32)a.group.begin;
       sc_f64 n_h_m = (sc_f64)a.group.n_h;
@@ -2694,9 +2718,11 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
           else sum_sat += value;
         }
     }
+    stamp(3);
     red[0][wave][lane] = sum_cen;
     red[1][wave][lane] = sum_sat;
     __syncthreads();
+    stamp(4);
     double n_cen = 0.0, n_sat = 0.0;
 #pragma unroll
     for (int w = 0; w < W; ++w) {
@@ -2725,10 +2751,10 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
   double F40a[UA][10], F40b[UB][10];
   if (DL == 40) {
     const int part = wave;
-    const unsigned off_a = lane * 16;
+    // (the unit's lane 16 k + 4 i + r for the wave's lane 16 k + 4 r + i: fused_quad_pass40)
+    const unsigned off_a = ((lane & 0x30) | ((lane & 3) << 2) | ((lane >> 2) & 3)) * 16;
     const double* dens_b = dens + (a.part_j_row0[part] + (lane >> 4)) * 40 + (lane & 3) * 10;
-    const double* dens_e =
-        dens + (a.part_i_row0[part] + ((lane >> 2) & 3)) * 40 + (lane & 3) * 10;
+    const double* dens_e = dens + (a.part_i_row0[part] + (lane >> 4)) * 40 + (lane & 3) * 10;
     const __amdgpu_buffer_rsrc_t rs_t =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.table, 0, a.table_bytes, kBufferFlags);
     const int rb = a.part_rb0[part], cb = a.part_cb0[part], count = a.part_count[part];
@@ -2774,46 +2800,49 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
                                triangular, n_cb, unit_base, F[p]);
     }
   }
+  stamp(5);
   __syncthreads();       // the densities are dead: their place takes the waves' sums
+  stamp(8);
   if (DL == 40) {
-    // lane l holds the share of row i = (l / 4) % 4 of F[r = 4 s + l / 16][draw 4 g + l % 4]:
-    // the four rows are added across the lanes (bits 2 and 3), and the lanes of row 0 store
-    // the wave's sums as (4 U, 40)
-    // (rotations inside the rows of 16 lanes -- data-parallel primitives, no LDS round trips:
-    // value + ror 4, then + ror 8 gives every lane of a (r, draw) the sum of its four rows)
-    double* out = dens + (wave * (4 * U) + kq) * 40 + (lane & 3);
-    auto rotate = [](double value, auto control) {
-      constexpr int kControl = decltype(control)::value;
-      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(value), kControl, 0xf, 0xf, false);
-      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(value), kControl, 0xf, 0xf, false);
-      return __hiloint2double(hi, lo);
+    // lane l holds the share of row i = l / 16 of F[r = 4 s + (l / 4) % 4][draw 4 g + l % 4]:
+    // the four rows are added on the matrix pipe, four sums of one r sub-tile per chain of four
+    // instructions (fused_quad_rows40), lanes 16 q + ... receiving sum q of the chain -- 50
+    // instructions of 16 cycles and 15 stores by all lanes.  (Rotations across the lanes and
+    // vector additions, 300 instructions at 4 - 8 cycles with two waves per SIMD, and 25 stores by
+    // a quarter of the lanes were 2.4 of the workgroup's 52 us, tools/r06_stamps.py.)  A chain
+    // multiplies the other three sums' shares by 0: only where every share is a finite number
+    // -- the matrix has no other entries (a.priority, bit 11) and every draw of the workgroup a
+    // pair-weight sum below 1e280.  Elsewhere every sum by an instruction of its own (A = 1,
+    // the same additions in the same order: the same bits), stored by the lanes of row 0.
+    // The wave's sums as (4 U, 40).
+    const int q = lane >> 4;
+    auto share = [&](int sub, int g) {
+      return sub < UA ? F40a[sub < UA ? sub : 0][g] : F40b[sub >= UA ? sub - UA : 0][g];
     };
-    auto reduce = [&](double value) {
-      value += rotate(value, std::integral_constant<int, 0x124>());     // row_ror:4
-      value += rotate(value, std::integral_constant<int, 0x128>());     // row_ror:8
-      return value;
-    };
+    double* out = dens + (wave * (4 * U) + ((lane >> 2) & 3)) * 40 + (lane & 3);
+    if (((a.priority >> 11) & 1) && __builtin_amdgcn_ballot_w64(!(norm < 1e280)) == 0) {
+      double select[4];
 #pragma unroll
-    for (int s = 0; s < UA; ++s)
+      for (int m = 0; m < 4; ++m) select[m] = (lane & 3) == m ? 1.0 : 0.0;
+      // draws 4 g + j, g = 4 t + q: t = 0, 1, and g = 8 + q for the lanes of q = 0, 1
 #pragma unroll
-      for (int g = 0; g < 10; ++g) F40a[s][g] = reduce(F40a[s][g]);
-    if (U > 3) {
+      for (int sub = 0; sub < U; ++sub)
 #pragma unroll
-      for (int s = 0; s < UB; ++s)
+        for (int t = 0; t < 3; ++t) {
+          double sums = 0.0;
 #pragma unroll
-        for (int g = 0; g < 10; ++g) F40b[s][g] = reduce(F40b[s][g]);
-    }
-    if (((lane >> 2) & 3) == 0) {
+          for (int m = 0; m < (t < 2 ? 4 : 2); ++m)
+            sums = fused_quad_rows40(select[m], share(sub, 4 * t + m), sums);
+          if (t < 2 || q < 2) out[(4 * sub) * 40 + 16 * t + 4 * q] = sums;
+        }
+    } else {
 #pragma unroll
-      for (int s = 0; s < UA; ++s)
+      for (int sub = 0; sub < U; ++sub)
 #pragma unroll
-        for (int g = 0; g < 10; ++g) out[(4 * s) * 40 + 4 * g] = F40a[s][g];
-      if (U > 3) {
-#pragma unroll
-        for (int s = 0; s < UB; ++s)
-#pragma unroll
-          for (int g = 0; g < 10; ++g) out[(4 * (3 + s)) * 40 + 4 * g] = F40b[s][g];
-      }
+        for (int g = 0; g < 10; ++g) {
+          const double sum = fused_quad_rows40(1.0, share(sub, g), 0.0);
+          if (q == 0) out[(4 * sub) * 40 + 4 * g] = sum;
+        }
     }
   } else {
     // r = 4 u + l / 16, draws 2 c and 2 c + 1 of the wave's tile
@@ -2825,6 +2854,7 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
     }
   }
   // ---- 3. the four quarters of every tile, normalisation, results ----
+  stamp(9);
   set_priority((a.priority >> 4) & 3);
   double(*tile)[kLanes + 1] = (double(*)[kLanes + 1])table;
   if (a.separate) {
@@ -2860,6 +2890,7 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
     for (int idx = threadIdx.x; idx < count; idx += blockDim.x) chi2_lds[idx] = a.chi2_data[idx];
   }
   __syncthreads();
+  stamp(10);
   if (DL == 40) {
     for (int rr = wave; rr < a.n_r && lane < DL; rr += W) {
       const double* first = dens + rr * 40 + lane;
@@ -2879,6 +2910,7 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
     }
   }
   __syncthreads();
+  stamp(6);
   const int64_t n_valid = a.n_draws - col < DL ? a.n_draws - col : DL;
   if (a.chi2 != nullptr) {
     // chi2 = delta^T P delta for the lane's draw (finalize_quad_kernel's fused likelihood)
@@ -2905,6 +2937,7 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
     const int d = idx / a.n_r, rr = idx % a.n_r;
     if (d < n_valid) a.xi[(col + d) * (int64_t)a.n_r + rr] = tile[rr][d];
   }
+  stamp(7);
 }
 
 // The deferred (group, draw) pairs of the mode-cross kernels (round 5): lanes that neither a

@@ -381,6 +381,8 @@ int build_quad_table(tc_table* t, bool by_type, const void* matrix, int matrix_d
     const int up = (t->quad_tiling.n_u + 1) / 2;
     out->rtile_bytes = (size_t)out->layout.n_units * up * 1024;
     out->bytes = host.size() * sizeof(double);
+    out->finite = true;
+    for (const double value : host) out->finite = out->finite && std::isfinite(value);
     status = upload(host, &out->d_table);
   }
   if (out->rtile_bytes >= ((size_t)1 << 32) - (1 << 24))
@@ -1195,7 +1197,9 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   fa.n_r = t->n_r;
   fa.priority = (t->tuning.prio_fused & 3) | ((t->tuning.prio_fused_occ & 3) << 2) |
                 ((t->tuning.prio_fused_out & 3) << 4) |
-                ((env_int_early("TC_FUSED_SKIP", 0) & 3) << 8);   // (developer builds only)
+                ((env_int_early("TC_FUSED_SKIP", 0) & 3) << 8) |  // (developer builds only)
+                // (the latency form may add its row shares four sums at a time: FusedArgs)
+                (q_table.finite ? 1 << 11 : 0);
   fa.n_draws = n_draws;
   fa.n_groups = t->node_groups.n_groups;
   fa.n_central_groups = t->node_groups.n_central_groups;
@@ -1225,6 +1229,17 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   }
   const int lds = fused_lds_bytes(t, separate, waves, draws);
   const dim3 grid((unsigned)((n_draws + draws - 1) / draws)), block(64 * waves);
+#ifdef TC_DEVELOPER_KNOBS
+  if (fa.chi2 == nullptr && env_int_early("TC_FUSED_STAMPS", 0) != 0) {
+    // (sixteen stamps per workgroup of the last launch: tc_debug_trace hands them out as 6-word
+    // records; tools/r06_stamps.py)
+    t->trace_blocks = ((size_t)grid.x * 16 + 5) / 6;
+    status = t->trace.reserve(t->trace_blocks * 6 * sizeof(unsigned long long), stream);
+    if (status != TC_OK) return status;
+    fa.chi2_data = (const double*)t->trace.ptr;
+    fa.priority |= 1 << 10;
+  }
+#endif
   hipEvent_t k0 = nullptr, k1 = nullptr;
   status = next_kernel_events(t, &k0, &k1);
   if (status != TC_OK) return status;
