@@ -985,10 +985,13 @@ def test_latency_form_is_what_a_call_alone_on_the_chip_takes():
     assert np.array_equal(np.isinf(xi_m), np.isinf(xi_3))
     good = np.isfinite(xi_3)
     assert_rel(xi_m[good], xi_3[good], 1e-12)
+    # (a workgroup with such a draw adds its waves' row shares one sum per matrix instruction
+    # instead of four: the regular draws beside it keep their bits)
     untouched = np.ones(400, dtype=bool)
     for first in (5, 9, 17, 21, 33, 34, 35):
         untouched[first::40] = False
     assert np.array_equal(xi_m[untouched], xi[:400][untouched])
+    assert np.array_equal(ngal_m[untouched], ngal[:400][untouched])
     # the fused likelihood
     force_fused(halotab)
     force_latency_form(halotab)
@@ -1001,3 +1004,40 @@ def test_latency_form_is_what_a_call_alone_on_the_chip_takes():
     assert latency_form_ran(halotab, n)
     assert np.array_equal(n_chi, ngal)
     assert_rel(chi2, want, 1e-9)
+
+
+def test_latency_form_with_entries_that_are_not_finite():
+    """A matrix with infinite / NaN entries: the latency form adds its row shares one sum per
+    instruction (0 x inf would reach the sums of other draws otherwise) -- the same NaN / inf
+    pattern as the three kernels, the same bits for r values the entries do not touch."""
+    from tabcorr_amd import synthetic
+    table = synthetic.synthetic_table(50, 1, (19, ), 'auto', seed=0)
+    clean = make_tabcorr(table)
+    force_fused(clean)
+    force_latency_form(clean)
+    theta = synthetic.zheng07_draws(400, seed=1)
+    theta[7::40, 3] = 16.5         # (hardly any satellites: densities of 0 beside the entries)
+    ngal_c, xi_c = clean.predict_batch(theta)
+    assert latency_form_ran(clean, 400)
+    matrix = np.array(table['tpcf_matrix'], dtype=np.float64, copy=True)
+    flat = matrix.reshape(19, -1)
+    flat[3, 17] = np.inf
+    flat[3, flat.shape[1] - 5] = np.inf
+    flat[11, 1234] = np.nan
+    broken = dict(table, tpcf_matrix=matrix)
+    halotab = make_tabcorr(broken)
+    with np.errstate(all='ignore'):
+        force_fused(halotab, False)
+        ngal_3, xi_3 = halotab.predict_batch(theta)
+        assert last_launch(halotab)[2] > 0
+        force_fused(halotab)
+        force_latency_form(halotab)
+        ngal, xi = halotab.predict_batch(theta)
+    assert latency_form_ran(halotab, 400)
+    assert np.array_equal(ngal, ngal_c)
+    assert np.array_equal(np.isnan(xi), np.isnan(xi_3))
+    assert np.array_equal(np.isinf(xi), np.isinf(xi_3))
+    others = [r for r in range(19) if r not in (3, 11)]
+    assert np.array_equal(xi[:, others], xi_c[:, others])
+    good = np.isfinite(xi_3)
+    assert_rel(xi[good], xi_3[good], 1e-12)
