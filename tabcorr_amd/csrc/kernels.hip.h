@@ -2479,15 +2479,21 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
   // (diagnosis, TC_FUSED_SKIP: 1 no occupations -- every density 1e-3 --, 2 no matrix phase)
   const int skip = (a.priority >> 8) & 3;
   const int n_bins_occ = (skip & 1) ? 0 : a.n_bins;
-  // (TC_FUSED_STAMPS: sixteen 100 MHz stamps per workgroup, wave 0 -- 0 entry, 1 math table staged,
+  // (TC_FUSED_STAMPS: 32 slots of 100 MHz stamps per workgroup; wave 0 -- 0 entry, 1 math table staged,
   // 2 draws set up, 3 bins done, 4 sums exchanged, 5 matrix phase done, 6 waves' parts added,
   // 7 end; 8 all waves through the matrix phase, 9 this wave's part stored, 10 all parts stored
   // -- in the place of the likelihood's data; tools/r06_stamps.py)
   unsigned long long* const stamps =
       ((a.priority >> 10) & 1) && a.chi2 == nullptr ? (unsigned long long*)a.chi2_data : nullptr;
+  // (16 + 2 wave, 17 + 2 wave: the wave's bins done, its deferred pairs done -- W = 8)
+  auto wave_stamp = [&](int which) {
+    if (stamps != nullptr && (threadIdx.x & 63) == 0 && W == 8 && ((threadIdx.x >> 6) & 3) == 0)
+      stamps[blockIdx.x * 32 + 16 + 8 * (threadIdx.x >> 8) + which] =
+          __builtin_amdgcn_s_memrealtime();
+  };
   auto stamp = [&](int which) {
     if (stamps != nullptr && threadIdx.x == 0)
-      stamps[blockIdx.x * 16 + which] = __builtin_amdgcn_s_memrealtime();
+      stamps[blockIdx.x * 32 + which] = __builtin_amdgcn_s_memrealtime();
   };
   if (skip & 1)
     for (int idx = threadIdx.x; idx < a.n_bins * DL; idx += blockDim.x) fused_lds[idx] = 1e-3;
@@ -2495,6 +2501,7 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
   constexpr int skip = 0;
   const int n_bins_occ = a.n_bins;
   auto stamp = [](int) {};
+  auto wave_stamp = [](int) {};
 #endif
   stamp(0);
   set_priority((a.priority >> 2) & 3);
@@ -2510,6 +2517,19 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
   }
   for (int idx = a.n_bins * DL + threadIdx.x; idx < a.dens_rows * DL; idx += blockDim.x)
     dens[idx] = 0.0;
+  // The latency form keeps the satellite bins' nodes and weights in LDS for its deferred pairs
+  // (behind the waves' sums: launch.hip, fused_lds_bytes).  A pass of the node loop is one wave's
+  // chain of dependent loads -- the bin's nodes by vector loads at up to 64 addresses, twice five
+  // of them -- and nothing else runs in its shadow when the workgroup has the CU to itself: 3.6
+  // of the 14 us of this phase (tools/r06_stamps.py).  The throughput form has neither the LDS
+  // (two workgroups of 78 KB per CU) nor the need (its neighbours fill the gaps).
+  double* const sat_nodes = table + fm::kTableDoubles + 2 * W * kLanes;
+  const int n_sat_values = (a.n_bins - a.n_central) * 10;
+  if (DL == 40 && SATDEFER)
+    for (int idx = threadIdx.x; idx < n_sat_values; idx += blockDim.x) {
+      sat_nodes[idx] = a.m[a.n_central * 10 + idx];
+      sat_nodes[n_sat_values + idx] = a.weight[a.n_central * 10 + idx];
+    }
   __syncthreads();
   stamp(1);
 
@@ -2618,32 +2638,54 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
       if (half == 0 && live) dens_at(g, draw) = value;
       if (central) sum_cen += value; else sum_sat += value;
     }
+    wave_stamp(0);
     if (SATDEFER) {
       // ---- deferred pairs: this wave's (bin, draw) pairs, 64 per pass (lane = pair) ----
       // A lane marks in `mine` the bins of its wave its draw needs the node loop for; the
-      // pairs are numbered in (bin, draw) order through the waves' ballots, entry p goes to lane
-      // p of a pass: the draw's constants from the lane that holds the draw, the bin's by vector
-      // loads, the result to the bin's row of the densities (this wave's rows: no barrier), from
-      // where the draw's own lane adds it to its sum in bin order.  What a draw defers depends
-      // on the draw alone: the same bits wherever it sits in the batch.
+      // pairs are numbered in (draw, bin) order -- a prefix sum of the lanes' counts, then every
+      // lane enters its own pairs: a draw defers a bin or two of a wave's dozen, so that is a
+      // loop of two or three steps where a loop over the wave's bins with a ballot each took 1.6
+      // of this phase's 14 us for counting and numbering (tools/r06_stamps.py) --, entry p goes
+      // to lane p of a pass: the draw's constants from the lane that holds the draw, the bin's
+      // by vector loads, the result to the bin's row of the densities (this wave's rows: no
+      // barrier), from where the draw's own lane adds it to its sum in bin order.  What a draw
+      // defers depends on the draw alone: the same bits wherever it sits in the batch.
       unsigned* list = (unsigned*)&red[1][wave][0];
-      const int n_mine = (n_bins_occ - wave + W - 1) / W;
-      int total = 0;
-      for (int j = 0; j < n_mine; ++j)
-        total += __builtin_popcountll(__builtin_amdgcn_ballot_w64((mine >> j) & 1u));
+      const int count = __builtin_popcount(mine);
+      int inclusive = count;
+      {
+        // (prefix sum over the wave: inside the rows of 16 lanes, then across them)
+        auto shifted = [](int value, auto control, auto rows) {
+          return __builtin_amdgcn_update_dpp(0, value, decltype(control)::value,
+                                             decltype(rows)::value, 0xf, false);
+        };
+        typedef std::integral_constant<int, 0xf> all_rows;
+        inclusive += shifted(inclusive, std::integral_constant<int, 0x111>(), all_rows());  // row_shr:1
+        inclusive += shifted(inclusive, std::integral_constant<int, 0x112>(), all_rows());  // row_shr:2
+        inclusive += shifted(inclusive, std::integral_constant<int, 0x114>(), all_rows());  // row_shr:4
+        inclusive += shifted(inclusive, std::integral_constant<int, 0x118>(), all_rows());  // row_shr:8
+        // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3
+        inclusive += shifted(inclusive, std::integral_constant<int, 0x142>(),
+                             std::integral_constant<int, 0xa>());
+        inclusive += shifted(inclusive, std::integral_constant<int, 0x143>(),
+                             std::integral_constant<int, 0xc>());
+      }
+      const int total = __builtin_amdgcn_readlane(inclusive, 63);
+      wave_stamp(2);
       for (int base = 0; base < total; base += 64) {
-        int before = 0;
-        for (int j = 0; j < n_mine; ++j) {
-          const bool bit = (mine >> j) & 1u;
-          const unsigned long long mask = __builtin_amdgcn_ballot_w64(bit);
-          if (mask == 0) continue;
-          const int rank = before + __builtin_amdgcn_mbcnt_hi(
-                                        (unsigned)(mask >> 32),
-                                        __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-          if (bit && rank >= base && rank < base + 64)
-            list[rank - base] = ((unsigned)j << 6) | (unsigned)lane;
-          before += __builtin_popcountll(mask);
+        {
+          unsigned left = mine;
+          int position = inclusive - count - base;
+          while (__builtin_amdgcn_ballot_w64(left != 0) != 0) {
+            if (left != 0) {
+              const int j = __builtin_ctz(left);
+              left &= left - 1;
+              if (position >= 0 && position < 64) list[position] = ((unsigned)j << 6) | (unsigned)lane;
+              ++position;
+            }
+          }
         }
+        wave_stamp(3);
         const int n = total - base < 64 ? total - base : 64;
         const bool active = lane < n;
         const unsigned entry = list[active ? lane : 0];
@@ -2686,10 +2728,19 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
 #pragma unroll 1
         for (int k0 = 0; k0 < 10; k0 += 5) {
           double node[5], w[5];
+          if (DL == 40) {
+            const int first = (cen_pair ? 0 : g - a.n_central) * 10 + k0;
 #pragma unroll
-          for (int k = 0; k < 5; ++k) {
-            node[k] = a.m[g * 10 + k0 + k];
-            w[k] = a.weight[g * 10 + k0 + k];
+            for (int k = 0; k < 5; ++k) {
+              node[k] = sat_nodes[first + k];
+              w[k] = sat_nodes[n_sat_values + first + k];
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+              node[k] = a.m[g * 10 + k0 + k];
+              w[k] = a.weight[g * 10 + k0 + k];
+            }
           }
 #pragma unroll
           for (int k = 0; k < 5; ++k) {
@@ -2710,14 +2761,20 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
         if (!cen_pair) acc = sat;
         }
         if (active) dens_at(g, from) = acc * a.n_h[g];
+        wave_stamp(4);
       }
-      for (int j = 0; j < n_mine; ++j)
-        if ((mine >> j) & 1u) {
+      // (the draw's deferred bins, in bin order)
+      for (unsigned left = mine; __builtin_amdgcn_ballot_w64(left != 0) != 0;) {
+        if (left != 0) {
+          const int j = __builtin_ctz(left);
+          left &= left - 1;
           const double value = dens_at(wave + W * j, draw);
           if (SATDEFER == 2 && wave + W * j < a.n_central) sum_cen += value;
           else sum_sat += value;
         }
+      }
     }
+    wave_stamp(1);
     stamp(3);
     red[0][wave][lane] = sum_cen;
     red[1][wave][lane] = sum_sat;

@@ -1043,8 +1043,10 @@ int fused_dens_rows(const tc_table* t, bool separate) {
 
 int fused_lds_bytes(const tc_table* t, bool separate, int waves, int draws) {
   const int dens_rows = fused_dens_rows(t, separate);
+  // (the latency form: the satellite bins' nodes and weights for its deferred pairs)
+  const int sat_nodes = draws == 40 ? (t->n_bins - t->plan.n_central) * 20 : 0;
   return (std::max(dens_rows * draws, tc::fused_slot_doubles(waves, draws)) +
-          tc::fused_scratch_doubles(waves)) * 8;
+          tc::fused_scratch_doubles(waves) + sat_nodes) * 8;
 }
 
 // The latency form (predict_fused_kernel with 40 draws per workgroup, one workgroup per CU,
@@ -1231,9 +1233,9 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
   const dim3 grid((unsigned)((n_draws + draws - 1) / draws)), block(64 * waves);
 #ifdef TC_DEVELOPER_KNOBS
   if (fa.chi2 == nullptr && env_int_early("TC_FUSED_STAMPS", 0) != 0) {
-    // (sixteen stamps per workgroup of the last launch: tc_debug_trace hands them out as 6-word
+    // (32 slots of stamps per workgroup of the last launch: tc_debug_trace hands them out as 6-word
     // records; tools/r06_stamps.py)
-    t->trace_blocks = ((size_t)grid.x * 16 + 5) / 6;
+    t->trace_blocks = ((size_t)grid.x * 32 + 5) / 6;
     status = t->trace.reserve(t->trace_blocks * 6 * sizeof(unsigned long long), stream);
     if (status != TC_OK) return status;
     fa.chi2_data = (const double*)t->trace.ptr;

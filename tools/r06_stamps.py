@@ -32,6 +32,7 @@ names = ['math table staged', 'draws set up', 'bins + deferred pairs', 'sums exc
          'matrix phase', 'wait for the other waves', "the wave's part to LDS", 'wait (parts)',
          'parts added, normalised', 'results written']
 rows = []
+per_wave = []      # (runs, workgroups, waves, {bins done, deferred pairs done}) after 'draws set up'
 for _ in range(20):
     for _ in range(5):
         _lib.check(lib.tc_predict_zheng07_batch_device(h, d_theta, 5, N, 10, 0, d_ngal, d_xi))
@@ -42,7 +43,8 @@ for _ in range(20):
     _lib.check(lib.tc_debug_trace(h, raw.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n.value,
                                   ctypes.byref(n)))
     n_wg = (N + draws - 1) // draws
-    stamps = raw[:n_wg * 16].reshape(n_wg, 16).astype(np.int64)
+    stamps = raw[:n_wg * 32].reshape(n_wg, 32).astype(np.int64)
+    per_wave.append(stamps[:, 16:32] - stamps[:, 2:3])
     # (in order of time: 0 .. 5, 8 all waves through the matrix phase, 9 the wave's part stored,
     # 10 every part stored, 6 parts added and normalised, 7 results written)
     rows.append(stamps[:, [0, 1, 2, 3, 4, 5, 8, 9, 10, 6, 7]])
@@ -71,3 +73,10 @@ if len(stamps) > 256:
 whole = np.stack([s[:, -1] - s[:, 0] for s in rows]).ravel() / 100.0
 print('%-24s %8.2f %8.2f %8.2f' % ('workgroup', np.median(whole), np.percentile(whole, 10),
                                    np.percentile(whole, 90)))
+waves = np.stack(per_wave) / 100.0          # (runs, workgroups, 8 slots x 2 waves)
+waves = waves.reshape(waves.shape[0], waves.shape[1], 2, 8)
+print('waves 0 and 4, us after the draws were set up (median): bins done, pairs counted, list '
+      'built, node loops done, sums added')
+for w in range(2):
+    m = np.median(waves[:, :, w, :], axis=(0, 1))
+    print('wave %d: %7.2f %7.2f %7.2f %7.2f %7.2f' % (4 * w, m[0], m[2], m[3], m[4], m[1]))
