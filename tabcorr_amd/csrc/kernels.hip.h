@@ -2485,7 +2485,8 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
   // -- in the place of the likelihood's data; tools/r06_stamps.py)
   unsigned long long* const stamps =
       ((a.priority >> 10) & 1) && a.chi2 == nullptr ? (unsigned long long*)a.chi2_data : nullptr;
-  // (16 + 2 wave, 17 + 2 wave: the wave's bins done, its deferred pairs done -- W = 8)
+  // (waves 0 and 4 of eight, slots 16 + 2 wave ...: 0 the wave's bins done, 2 its deferred pairs
+  // counted, 3 their list built, 4 their node loops done, 1 their values added to the sums)
   auto wave_stamp = [&](int which) {
     if (stamps != nullptr && (threadIdx.x & 63) == 0 && W == 8 && ((threadIdx.x >> 6) & 3) == 0)
       stamps[blockIdx.x * 32 + 16 + 8 * (threadIdx.x >> 8) + which] =
@@ -2517,19 +2518,6 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
   }
   for (int idx = a.n_bins * DL + threadIdx.x; idx < a.dens_rows * DL; idx += blockDim.x)
     dens[idx] = 0.0;
-  // The latency form keeps the satellite bins' nodes and weights in LDS for its deferred pairs
-  // (behind the waves' sums: launch.hip, fused_lds_bytes).  A pass of the node loop is one wave's
-  // chain of dependent loads -- the bin's nodes by vector loads at up to 64 addresses, twice five
-  // of them -- and nothing else runs in its shadow when the workgroup has the CU to itself: 3.6
-  // of the 14 us of this phase (tools/r06_stamps.py).  The throughput form has neither the LDS
-  // (two workgroups of 78 KB per CU) nor the need (its neighbours fill the gaps).
-  double* const sat_nodes = table + fm::kTableDoubles + 2 * W * kLanes;
-  const int n_sat_values = (a.n_bins - a.n_central) * 10;
-  if (DL == 40 && SATDEFER)
-    for (int idx = threadIdx.x; idx < n_sat_values; idx += blockDim.x) {
-      sat_nodes[idx] = a.m[a.n_central * 10 + idx];
-      sat_nodes[n_sat_values + idx] = a.weight[a.n_central * 10 + idx];
-    }
   __syncthreads();
   stamp(1);
 
@@ -2728,19 +2716,10 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
 #pragma unroll 1
         for (int k0 = 0; k0 < 10; k0 += 5) {
           double node[5], w[5];
-          if (DL == 40) {
-            const int first = (cen_pair ? 0 : g - a.n_central) * 10 + k0;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-              node[k] = sat_nodes[first + k];
-              w[k] = sat_nodes[n_sat_values + first + k];
-            }
-          } else {
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-              node[k] = a.m[g * 10 + k0 + k];
-              w[k] = a.weight[g * 10 + k0 + k];
-            }
+          for (int k = 0; k < 5; ++k) {
+            node[k] = a.m[g * 10 + k0 + k];
+            w[k] = a.weight[g * 10 + k0 + k];
           }
 #pragma unroll
           for (int k = 0; k < 5; ++k) {
@@ -2826,12 +2805,21 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
     for (int s = 0; s < UB; ++s)
 #pragma unroll
       for (int g = 0; g < 10; ++g) F40b[s][g] = 0.0;
+#ifdef TC_DEVELOPER_KNOBS
+    // (TC_FUSED_SAME_UNIT: every unit's matrix operands from the table's first unit -- wrong
+    // results, loads that hit the first-level cache: what the operands' way from the L2 costs)
+    const unsigned unit_bytes = ((a.priority >> 12) & 1) ? 0u : UP * 1024u;
+    const unsigned first_unit = ((a.priority >> 12) & 1) ? 0u : unit_base;
+#else
+    constexpr unsigned unit_bytes = UP * 1024u;
+    const unsigned first_unit = unit_base;
+#endif
     if (!(skip & 2))
-    fused_quad_pass40<0, UA>(rs_t, off_a, UP * 1024, dens_b, dens_e, rb, cb, count, triangular,
-                             n_cb, unit_base, F40a);
+    fused_quad_pass40<0, UA>(rs_t, off_a, unit_bytes, dens_b, dens_e, rb, cb, count, triangular,
+                             n_cb, first_unit, F40a);
     if (U > 3 && !(skip & 2))
-      fused_quad_pass40<(U > 3 ? 3 : 0), UB>(rs_t, off_a, UP * 1024, dens_b, dens_e, rb, cb,
-                                             count, triangular, n_cb, unit_base, F40b);
+      fused_quad_pass40<(U > 3 ? 3 : 0), UB>(rs_t, off_a, unit_bytes, dens_b, dens_e, rb, cb,
+                                             count, triangular, n_cb, first_unit, F40b);
   } else {
     const int sub = wave / PARTS, part = wave % PARTS;
     const unsigned off_a = lane * 16;

@@ -1043,10 +1043,8 @@ int fused_dens_rows(const tc_table* t, bool separate) {
 
 int fused_lds_bytes(const tc_table* t, bool separate, int waves, int draws) {
   const int dens_rows = fused_dens_rows(t, separate);
-  // (the latency form: the satellite bins' nodes and weights for its deferred pairs)
-  const int sat_nodes = draws == 40 ? (t->n_bins - t->plan.n_central) * 20 : 0;
   return (std::max(dens_rows * draws, tc::fused_slot_doubles(waves, draws)) +
-          tc::fused_scratch_doubles(waves) + sat_nodes) * 8;
+          tc::fused_scratch_doubles(waves)) * 8;
 }
 
 // The latency form (predict_fused_kernel with 40 draws per workgroup, one workgroup per CU,
@@ -1241,6 +1239,7 @@ int run_fused(tc_table* t, const double* theta_device, int n_theta, int64_t n_dr
     fa.chi2_data = (const double*)t->trace.ptr;
     fa.priority |= 1 << 10;
   }
+  if (env_int_early("TC_FUSED_SAME_UNIT", 0) != 0) fa.priority |= 1 << 12;
 #endif
   hipEvent_t k0 = nullptr, k1 = nullptr;
   status = next_kernel_events(t, &k0, &k1);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Round 6: where a workgroup of the one-launch kernel spends its time -- sixteen 100 MHz stamps per
-workgroup (developer build, TC_FUSED_STAMPS=1), the launch alone on the chip, 10^4 draws of the
+"""Round 6: where a workgroup of the one-launch kernel spends its time -- 100 MHz stamps of wave 0
+at the phase boundaries and of waves 0 and 4 inside the occupation phase (developer build,
+TC_FUSED_STAMPS=1; a stamp costs 0.1 - 0.3 us), the launch alone on the chip, 10^4 draws of the
 benchmark's table.
     gpurun -- 'bash tools/build_dev.sh && TABCORR_AMD_LIBRARY=build/ab/dev.so TC_FUSED_STAMPS=1 \
                python3 tools/r06_stamps.py [draws per workgroup] [draws]'"""
