@@ -1073,6 +1073,10 @@ bool fused_spread_eligible(const tc_table* t, int64_t n_draws, int n_gauss, unsi
   // spread smaller batches over the chip in less than a 40-draw workgroup's lifetime)
   const bool alone = t->force_lane >= 0 || !t->tuning.pipeline || t->n_lanes == 1 ||
                      t->sync_spread;
+  // (up to 32 draws per CU the 32-draw workgroups are shorter-lived)
+  if (alone && !t->sync_spread && n_draws <= (int64_t)32 * t->n_cus &&
+      t->tuning.fused_draws == 0 && fused_half_tiles(t, false, n_draws, n_gauss, flags))
+    return false;
   return alone && n_draws >= t->tuning.fused_spread_min &&
          n_draws <= (int64_t)40 * t->n_cus * std::max(1, t->tuning.fused_spread_rounds);
 }
@@ -1103,7 +1107,11 @@ bool fused_half_tiles(const tc_table* t, bool separate, int64_t n_draws, int n_g
       return tuned->second.form_for(n_draws) == 32 &&
              fused_lds_bytes(t, separate, 8, 32) <= 80 * 1024;
   }
-  if (t->tuning.fused_draws == 64 || (t->tuning.fused_draws == 0 && n_draws >= 8192))
+  // (a call that has the chip to itself: up to one 32-draw workgroup per CU INCLUSIVE -- 8192
+  // draws on 256 CUs take 41.9 us this way, 49.5 in the latency form, 55 as three kernels)
+  const bool alone = t->force_lane >= 0 || !t->tuning.pipeline || t->n_lanes == 1;
+  if (t->tuning.fused_draws == 64 ||
+      (t->tuning.fused_draws == 0 && n_draws >= 8192 && !(alone && n_draws <= (int64_t)32 * t->n_cus)))
     return false;
   if (n_gauss != 10) return false;
   if (t->tuning.fused_waves != 0 && t->tuning.fused_waves != 8) return false;

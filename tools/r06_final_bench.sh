@@ -16,4 +16,8 @@ python tools/r06_latency.py > gpurun_out/r06_latency.log 2>&1
 python tools/r06_two_tables.py > gpurun_out/r06_two_tables.log 2>&1
 bash tools/r06_alone_forms.sh > gpurun_out/r06_alone_forms.log 2>&1
 [ -f build/ab/dev.so ] && bash tools/r06_phases.sh > gpurun_out/r06_phases.log 2>&1
+[ -f build/ab/dev.so ] && TABCORR_AMD_LIBRARY=build/ab/dev.so TC_FUSED_STAMPS=1 \
+  python tools/r06_stamps.py 40 > gpurun_out/r06_stamps.log 2>&1
+[ -f build/ab/dev.so ] && TABCORR_AMD_LIBRARY=build/ab/dev.so TC_FUSED_STAMPS=1 \
+  python tools/r06_stamps.py 64 >> gpurun_out/r06_stamps.log 2>&1
 tail -2 $OUT/bench.json | cut -c1-400
