@@ -3015,6 +3015,14 @@ __device__ __forceinline__ void cross_deferred_pairs(
   // node loop (evaluated per block of 64 groups they were ~5 nearly empty passes: a sixth of the
   // kernel's vector instructions on the AbacusSummit tables).
   auto evaluate = [&](int total) {
+#ifdef TC_DEVELOPER_KNOBS
+    // (TC_FUSED_STAMPS, slot 12: the workgroup's deferred pairs; slot 13: passes of 64)
+    if (((a.priority >> 10) & 1) && a.chi2 == nullptr && lane == 0) {
+      atomicAdd((unsigned long long*)a.chi2_data + blockIdx.x * 16 + 12, (unsigned long long)total);
+      atomicAdd((unsigned long long*)a.chi2_data + blockIdx.x * 16 + 13,
+                (unsigned long long)((total + 63) / 64));
+    }
+#endif
     for (int e0 = 0; e0 < total; e0 += 64) {
       const int n = total - e0 < 64 ? total - e0 : 64;
       const bool active = lane < n;
@@ -3177,6 +3185,31 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
   double* table = cross_lds;
   double* buffers = cross_lds + kCrossTableDoubles;    // 2 x (kCrossChunkBins, 64); then the sums
   const fm::Consts kc = fm::make_consts();
+#ifdef TC_DEVELOPER_KNOBS
+  // (TC_FUSED_STAMPS: 16 slots of 100 MHz stamps per workgroup, wave 0, in the place of the
+  // likelihood's data -- 0 entry, 1 draws set up, 2 chunks done, 3 sums in LDS, 4 deferred pairs
+  // done, 5 weights and norms, 6 end; 8 / 9 / 10: ticks wave 0 spent in the occupations of the
+  // chunks, waiting at their barriers, in their products; tools/r06_stamps_cross.py)
+  unsigned long long* const stamps =
+      ((a.priority >> 10) & 1) && a.chi2 == nullptr ? (unsigned long long*)a.chi2_data : nullptr;
+  auto stamp = [&](int which) {
+    if (stamps != nullptr && threadIdx.x == 0)
+      stamps[blockIdx.x * 16 + which] = __builtin_amdgcn_s_memrealtime();
+  };
+  unsigned long long ticks_a = 0, ticks_wait = 0, ticks_b = 0, lap_from = 0;
+  auto lap = [&](unsigned long long& into) {
+    if (stamps != nullptr) {
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      into += now - lap_from;
+      lap_from = now;
+    }
+  };
+#else
+  auto stamp = [](int) {};
+  unsigned long long ticks_a = 0, ticks_wait = 0, ticks_b = 0;
+  auto lap = [](unsigned long long&) {};
+#endif
+  stamp(0);
   set_priority(a.priority & 3);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -3253,6 +3286,10 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
 #pragma unroll
           for (int v = 0; v < 4; ++v) res0[sum_index(j, i, v)] = 0.0;
     }
+    stamp(1);
+#ifdef TC_DEVELOPER_KNOBS
+    if (stamps != nullptr) lap_from = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
       if (a.separate && chunk == a.n_central_chunks && chunk > chunk_begin) {
         // (the sums of the centrals are complete: set them aside; nobody reads them before the
@@ -3318,7 +3355,9 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
 #pragma unroll
         for (int j = 0; j < N_RB; ++j)
           av[s][j] = s < n_steps ? a_lane[(s * NT + 4 * j) * 64] : 0.0;
+      lap(ticks_a);
       __syncthreads();
+      lap(ticks_wait);
       for (int q = 0; q < n_steps; q += PF) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
@@ -3339,8 +3378,10 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
           }
         }
       }
+      lap(ticks_b);
     }
   }
+  stamp(2);
   __syncthreads();      // every wave has read the last chunk: the buffers take the sums
   double* res1 = buffers;                               // all bins, or the satellites
   double* res0 = a.separate ? cross_lds + a.lds_res0 : buffers;
@@ -3359,6 +3400,7 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
         }
   }
   __syncthreads();
+  stamp(3);
   if (kDeferrable && deferring) {
     // ---- the deferred (group, draw) pairs (cross_deferred_pairs) ----
     sc_i32 chunk_groups = (sc_i32)a.chunk_group;
@@ -3374,6 +3416,7 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
           pass == 0 ? res0 : res1);
     __syncthreads();
   }
+  stamp(4);
   if (n_splits > 1) {
     // the shares of the tile's workgroups: device-scope write-through stores, the last arrival
     // (a counter per tile, reset for the next launch on this lane) adds them in split order
@@ -3463,6 +3506,7 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
     }
   }
   __syncthreads();
+  stamp(5);
   const int n_rows = n_comp * a.n_r;
   for (int row = wave; row < n_rows; row += W) {
     const int comp = row / a.n_r, r = row % a.n_r;
@@ -3499,6 +3543,14 @@ __global__ __launch_bounds__(64 * kCrossWaves, RW <= 8 ? 4 : 2) void predict_cro
     const int dd = idx / n_rows, row = idx % n_rows;
     if (dd < n_valid) a.xi[(col + dd) * (int64_t)n_rows + row] = tile[row * (kLanes + 1) + dd];
   }
+  stamp(6);
+#ifdef TC_DEVELOPER_KNOBS
+  if (stamps != nullptr && threadIdx.x == 0) {
+    stamps[blockIdx.x * 16 + 8] = ticks_a;
+    stamps[blockIdx.x * 16 + 9] = ticks_wait;
+    stamps[blockIdx.x * 16 + 10] = ticks_b;
+  }
+#endif
 }
 
 // The same for up to 16 rows (one table with up to 15 r values -- the reference's excess surface

@@ -1633,6 +1633,18 @@ int run_cross_fused(tc_table* t0, const CrossFused& cf, const tc::CrossFusedArgs
     }
   }
   const dim3 grid((unsigned)(n_tiles * n_splits)), block(64 * tc::kCrossWaves);
+#ifdef TC_DEVELOPER_KNOBS
+  if (ca.chi2 == nullptr && env_int_early("TC_FUSED_STAMPS", 0) != 0) {
+    // (16 slots of stamps per workgroup of the last launch: tools/r06_stamps_cross.py)
+    t0->trace_blocks = ((size_t)grid.x * 16 + 5) / 6;
+    status = t0->trace.reserve(t0->trace_blocks * 6 * sizeof(unsigned long long), stream);
+    if (status != TC_OK) return status;
+    TC_HIP(hipMemsetAsync(t0->trace.ptr, 0, t0->trace_blocks * 6 * sizeof(unsigned long long),
+                          stream));
+    ca.chi2_data = (const double*)t0->trace.ptr;
+    ca.priority |= 1 << 10;
+  }
+#endif
   hipEvent_t k0 = nullptr, k1 = nullptr;
   status = next_kernel_events(t0, &k0, &k1);
   if (status != TC_OK) return status;
