@@ -2322,6 +2322,24 @@ __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, uns
 // mfma_map.hip), which times dens[4 rb + i][4 dg + j] is the lane's share of F[r][draw]: the four
 // i of a (r, j) -- lanes 16 apart, the k index of a B operand -- are added once, after the walk,
 // by one more matrix instruction per sum (A = 1: fused_quad_rows40).  F[s][dg] += ... per lane.
+// Inclusive prefix sum of `value` over the 64 lanes: inside the rows of 16 lanes by shifts, then
+// across them by the two row broadcasts (data-parallel primitives: no LDS round trips).
+__device__ __forceinline__ int wave_prefix_sum(int value) {
+  auto shifted = [](int x, auto control, auto rows) {
+    return __builtin_amdgcn_update_dpp(0, x, decltype(control)::value, decltype(rows)::value, 0xf,
+                                       false);
+  };
+  typedef std::integral_constant<int, 0xf> all_rows;
+  value += shifted(value, std::integral_constant<int, 0x111>(), all_rows());      // row_shr:1
+  value += shifted(value, std::integral_constant<int, 0x112>(), all_rows());      // row_shr:2
+  value += shifted(value, std::integral_constant<int, 0x114>(), all_rows());      // row_shr:4
+  value += shifted(value, std::integral_constant<int, 0x118>(), all_rows());      // row_shr:8
+  // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3
+  value += shifted(value, std::integral_constant<int, 0x142>(), std::integral_constant<int, 0xa>());
+  value += shifted(value, std::integral_constant<int, 0x143>(), std::integral_constant<int, 0xc>());
+  return value;
+}
+
 // D[i][j] += sum_k A[i][k] value(lane 16 k + 4 block + j) with A[i][k] = 1 for i = m, else 0
 // (`select`: the lane's element of that A, 1 where lane % 4 == m): the four row shares of a (r,
 // draw) of sum m, added into the lanes 16 m + ... -- four sums per chain of four instructions,
@@ -2640,24 +2658,7 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
       // defers depends on the draw alone: the same bits wherever it sits in the batch.
       unsigned* list = (unsigned*)&red[1][wave][0];
       const int count = __builtin_popcount(mine);
-      int inclusive = count;
-      {
-        // (prefix sum over the wave: inside the rows of 16 lanes, then across them)
-        auto shifted = [](int value, auto control, auto rows) {
-          return __builtin_amdgcn_update_dpp(0, value, decltype(control)::value,
-                                             decltype(rows)::value, 0xf, false);
-        };
-        typedef std::integral_constant<int, 0xf> all_rows;
-        inclusive += shifted(inclusive, std::integral_constant<int, 0x111>(), all_rows());  // row_shr:1
-        inclusive += shifted(inclusive, std::integral_constant<int, 0x112>(), all_rows());  // row_shr:2
-        inclusive += shifted(inclusive, std::integral_constant<int, 0x114>(), all_rows());  // row_shr:4
-        inclusive += shifted(inclusive, std::integral_constant<int, 0x118>(), all_rows());  // row_shr:8
-        // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3
-        inclusive += shifted(inclusive, std::integral_constant<int, 0x142>(),
-                             std::integral_constant<int, 0xa>());
-        inclusive += shifted(inclusive, std::integral_constant<int, 0x143>(),
-                             std::integral_constant<int, 0xc>());
-      }
+      const int inclusive = wave_prefix_sum(count);
       const int total = __builtin_amdgcn_readlane(inclusive, 63);
       wave_stamp(2);
       for (int base = 0; base < total; base += 64) {
@@ -3082,6 +3083,9 @@ __device__ __forceinline__ void cross_deferred_pairs(
         // (eight pairs at a time: their coefficients requested together; a pair that is not
         // valid -- beyond the batch, beyond its group's members, the other galaxy type --
         // adds coefficient x 0)
+        // The pair's draw is j = share + SHARES slot of the wave's eight: its share of the lanes
+        // adds to the sums of that slot -- a wave-uniform choice, one product per pair where a
+        // comparison, a selection and a product per SLOT stood until round 6.
         const double nbar_lane = valid ? acc : 0.0;
         for (int p0 = 0; p0 < n; p0 += 8) {
           double c[8];
@@ -3090,11 +3094,22 @@ __device__ __forceinline__ void cross_deferred_pairs(
             c[u] = coefficient(__builtin_amdgcn_readlane(mi_safe, (p0 + u) & 63), row);
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
+            if (p0 + u >= n) break;
             const double nbar = readlane_f64(nbar_lane, (p0 + u) & 63);
             const int j = __builtin_amdgcn_readlane(draw, (p0 + u) & 63) >> 3;
-#pragma unroll
-            for (int slot = 0; slot < SLOTS; ++slot)
-              extra[slot] = fma(c[u], share + SHARES * slot == j ? nbar : 0.0, extra[slot]);
+            const double mine = share == j % SHARES ? nbar : 0.0;
+            const int slot_of_pair = j / SHARES;
+            // (a switch over constants: written as a loop with a comparison the compiler turns
+            // it into an indexed access of `extra` -- in scratch memory)
+            switch (slot_of_pair) {
+#define TC_SLOT(K)                                                     \
+  case K:                                                              \
+    if constexpr (K < SLOTS) extra[K < SLOTS ? K : 0] = fma(c[u], mine, extra[K < SLOTS ? K : 0]); \
+    break;
+              TC_SLOT(0) TC_SLOT(1) TC_SLOT(2) TC_SLOT(3) TC_SLOT(4) TC_SLOT(5) TC_SLOT(6) TC_SLOT(7)
+#undef TC_SLOT
+              default: break;
+            }
           }
         }
       }
@@ -3108,13 +3123,10 @@ __device__ __forceinline__ void cross_deferred_pairs(
     for (; gb < g_last; gb += 64) {
       const int g_lane = gb + lane;
       unsigned long long word = g_lane < g_last ? bitmap[g_lane] & owner : 0ull;
+      // (most blocks of 64 groups hold no pair of this wave's draws)
+      if (__builtin_amdgcn_ballot_w64(word != 0) == 0) continue;
       const int count = __builtin_popcountll(word);
-      int inclusive = count;
-#pragma unroll
-      for (int offset = 1; offset < 64; offset <<= 1) {
-        const int other = __shfl_up(inclusive, offset, 64);
-        if (lane >= offset) inclusive += other;
-      }
+      const int inclusive = wave_prefix_sum(count);
       const int total = __builtin_amdgcn_readlane(inclusive, 63);
       if (filled + total > 512) break;            // (the next segment starts with this block)
       int slot_out = filled + inclusive - count;
