@@ -226,7 +226,7 @@ struct QuadTable {
   tc::QuadLayout layout;
   void* d_table = nullptr;      // (n_rtiles, n_units, (n_u + 1) / 2, 64, 2) doubles
   void* d_comps = nullptr;      // QuadCompArgs per component
-  bool finite = false;          // float64: every entry is a finite number (run_fused)
+  bool finite = false;          // float64: every entry is finite and at most 1e20 in size (run_fused)
   size_t rtile_bytes = 0;
   size_t bytes = 0;
   std::map<std::vector<int64_t>, std::unique_ptr<DeviceQuadSchedule>> schedules;

@@ -2857,9 +2857,10 @@ __global__ __launch_bounds__(64 * W, DL == 40 ? 2 : W == 8 ? (SATDEFER == 2 ? 4 
     // vector additions, 300 instructions at 4 - 8 cycles with two waves per SIMD, and 25 stores by
     // a quarter of the lanes were 2.4 of the workgroup's 52 us, tools/r06_stamps.py.)  A chain
     // multiplies the other three sums' shares by 0: only where every share is a finite number
-    // -- the matrix has no other entries (a.priority, bit 11) and every draw of the workgroup a
-    // pair-weight sum below 1e280.  Elsewhere every sum by an instruction of its own (A = 1,
-    // the same additions in the same order: the same bits), stored by the lanes of row 0.
+    // -- the matrix has no other entries, none beyond 1e20 in size (a.priority, bit 11), and
+    // every draw of the workgroup a pair-weight sum below 1e280: no share can overflow.
+    // Elsewhere every sum by an instruction of its own (A = 1, the same additions in the same
+    // order: the same bits), stored by the lanes of row 0.
     // The wave's sums as (4 U, 40).
     const int q = lane >> 4;
     auto share = [&](int sub, int g) {

@@ -381,8 +381,10 @@ int build_quad_table(tc_table* t, bool by_type, const void* matrix, int matrix_d
     const int up = (t->quad_tiling.n_u + 1) / 2;
     out->rtile_bytes = (size_t)out->layout.n_units * up * 1024;
     out->bytes = host.size() * sizeof(double);
+    // (finite, and small enough that no sum of entry x density x density overflows while the
+    // draw's pair-weight sum stays below 1e280 -- predict_fused_kernel's latency form)
     out->finite = true;
-    for (const double value : host) out->finite = out->finite && std::isfinite(value);
+    for (const double value : host) out->finite = out->finite && std::fabs(value) <= 1e20;
     status = upload(host, &out->d_table);
   }
   if (out->rtile_bytes >= ((size_t)1 << 32) - (1 << 24))
