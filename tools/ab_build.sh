@@ -17,7 +17,7 @@ FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -Wall -Wno-unused
 cd $TMP/tabcorr_amd/csrc
 for f in $(ls *.hip *.cpp); do
   # (inst_single.hip: see its header)
-  UNIT_FLAGS=$([ $f = inst_single.hip ] && echo -ffp-contract=on)
+  UNIT_FLAGS=$([ $f = inst_single.hip ] && echo -ffp-contract=on || true)
   /opt/rocm/bin/hipcc $FLAGS $UNIT_FLAGS -c $f -o $TMP/${f%.*}.o &
 done
 wait
