@@ -503,14 +503,17 @@ def main():
     # --steps 20): the mean launch duration of the roofline record then belongs to the very
     # launches `value` times.  (20 000 event pairs in the default run would cost more than they
     # tell: there the same stream of calls is sampled right after the region.)  The event pairs
-    # are created beforehand.
+    # are created beforehand.  ONE launch in `lanes_used` carries a pair -- the launches of one
+    # lane: a pair costs its launch ~1.5 us on the queue, and pairs on all 20 launches of the
+    # driver's --steps 20 made that region 1.3-2.0 us per step longer than the same 20 steps
+    # without them (42.2 against 40.5 us, four runs each in alternation on one box).
     events_in_region = args.steps <= 1024
 
     def region_events(begin):
         if not events_in_region:
             return None
         if begin:
-            _lib.check(lib.tc_table_timer_begin(timer_handle, 1))
+            _lib.check(lib.tc_table_timer_begin(timer_handle, max(1, lanes_used)))
             return None
         ms, count, mean = ctypes.c_float(), ctypes.c_int(), ctypes.c_float()
         _lib.check(lib.tc_table_timer_end(timer_handle, ctypes.byref(ms)))
@@ -659,7 +662,9 @@ def main():
         sample_concurrency = overlapped_ms / overlapped_wall_ms
         if region_launches is not None:
             launch_ms, n_launch = region_launches
-            launch_source = 'events on the %d launches of the timed region' % n_launch
+            launch_source = ('events on %d of the %d launches of the timed region (one lane\'s: '
+                             'every %s launch)' % (n_launch, args.steps,
+                                                   {1: '', 2: 'second', 3: 'third', 4: 'fourth'}.get(lanes_used, '%d-th' % lanes_used)))
         elif fused_active:
             launch_ms = overlapped_ms
             launch_source = ('events on %d launches of the same stream of calls right after '

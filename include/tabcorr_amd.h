@@ -497,7 +497,9 @@ int tc_table_autotune_result(const tc_table* table, unsigned flags, int capacity
  * contraction kernel -- of this table, or of an interpolator whose first table this is --
  * additionally carries its own start / stop events (hipExtLaunchKernelGGL: the dispatch's
  * own begin and end, the interval rocprofv3 --kernel-trace reports) and
- * tc_table_kernel_time reports the count and mean duration since timer_begin. */
+ * tc_table_kernel_time reports the count and mean duration since timer_begin.  profile = n
+ * > 1: every n-th launch only, from the first on (a pair of events costs a launch ~1.5 us on
+ * its queue; with n = the number of lanes the sampled launches are those of one lane). */
 int tc_table_timer_begin(tc_table* table, int profile_kernels);
 int tc_table_timer_end(tc_table* table, float* elapsed_ms);
 int tc_table_kernel_time(tc_table* table, int* n_launches, float* mean_ms);

@@ -618,6 +618,8 @@ struct tc_table {
 
   // measurement
   bool profile_kernels = false;
+  int profile_every = 1;            // (tc_table_timer_begin: every n-th launch carries events)
+  size_t profile_launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> kernel_events;
   size_t kernel_events_used = 0;
   int last_workgroups = 0, last_waves = 0, last_splits = 0, last_lds = 0;

@@ -545,6 +545,8 @@ int get_quad_schedule(tc_table* t, QuadTable* q, int64_t n_tiles, int n_tables, 
 int next_kernel_events(tc_table* t, hipEvent_t* start, hipEvent_t* stop) {
   *start = *stop = nullptr;
   if (!t->profile_kernels) return TC_OK;
+  // (a pair of events costs a launch ~1.5 us on the queue: a short timed region samples)
+  if (t->profile_every > 1 && t->profile_launches++ % (size_t)t->profile_every != 0) return TC_OK;
   if (t->kernel_events_used == t->kernel_events.size()) {
     hipEvent_t e0, e1;
     TC_HIP(hipEventCreate(&e0));

@@ -1679,6 +1679,8 @@ int tc_table_timer_begin(tc_table* t, int profile_kernels) {
   TC_CHECK(t != nullptr, "table handle is NULL");
   TC_HIP(hipSetDevice(t->device));
   t->profile_kernels = profile_kernels != 0;
+  t->profile_every = profile_kernels > 1 ? profile_kernels : 1;
+  t->profile_launches = 0;
   t->kernel_events_used = 0;
   TC_HIP(hipEventRecord(t->ev_begin, t->stream));
   return TC_OK;
