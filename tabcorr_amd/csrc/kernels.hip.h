@@ -2312,16 +2312,6 @@ __device__ __forceinline__ void fused_quad_pass(__amdgpu_buffer_rsrc_t rs_t, uns
   }
 }
 
-// The latency form's pass (40 draws per workgroup, v_mfma_f64_4x4x4_4b_f64): `count` units from
-// block (rb, cb) on for the NS r sub-tiles S0 .. S0 + NS - 1 and ALL 40 draws of the workgroup.
-// The table's unit layout serves this instruction with the lanes permuted inside a group of 16:
-// lane 16 k + 4 i + r of a unit holds T[r][row 4 rb + i][column 4 cb + k]; lane l = 16 k + 4 r +
-// i of the WAVE fetches it (off_a: the caller's permutation) as A_block=r [i][k]; with B_block [k][j]
-// = dens[4 cb + k][4 dg + j] (the same for every block) lane l receives D = sum_k T[r = (l / 4)
-// % 4][row i = l / 16][k] dens[k][draw j = l % 4] (lane <-> element map: tools/micro/
-// mfma_map.hip), which times dens[4 rb + i][4 dg + j] is the lane's share of F[r][draw]: the four
-// i of a (r, j) -- lanes 16 apart, the k index of a B operand -- are added once, after the walk,
-// by one more matrix instruction per sum (A = 1: fused_quad_rows40).  F[s][dg] += ... per lane.
 // Inclusive prefix sum of `value` over the 64 lanes: inside the rows of 16 lanes by shifts, then
 // across them by the two row broadcasts (data-parallel primitives: no LDS round trips).
 __device__ __forceinline__ int wave_prefix_sum(int value) {
@@ -2348,6 +2338,16 @@ __device__ __forceinline__ double fused_quad_rows40(double select, double value,
   return __builtin_amdgcn_mfma_f64_4x4x4f64(select, value, sums, 0, 0, 0);
 }
 
+// The latency form's pass (40 draws per workgroup, v_mfma_f64_4x4x4_4b_f64): `count` units from
+// block (rb, cb) on for the NS r sub-tiles S0 .. S0 + NS - 1 and ALL 40 draws of the workgroup.
+// The table's unit layout serves this instruction with the lanes permuted inside a group of 16:
+// lane 16 k + 4 i + r of a unit holds T[r][row 4 rb + i][column 4 cb + k]; lane l = 16 k + 4 r +
+// i of the WAVE fetches it (off_a: the caller's permutation) as A_block=r [i][k]; with B_block [k][j]
+// = dens[4 cb + k][4 dg + j] (the same for every block) lane l receives D = sum_k T[r = (l / 4)
+// % 4][row i = l / 16][k] dens[k][draw j = l % 4] (lane <-> element map: tools/micro/
+// mfma_map.hip), which times dens[4 rb + i][4 dg + j] is the lane's share of F[r][draw]: the four
+// i of a (r, j) -- lanes 16 apart, the k index of a B operand -- are added once, after the walk,
+// on the matrix pipe as well (fused_quad_rows40: A = a row of ones).  F[s][dg] += ... per lane.
 template <int S0, int NS>
 __device__ __forceinline__ void fused_quad_pass40(__amdgpu_buffer_rsrc_t rs_t, unsigned off_a,
                                                   unsigned unit_bytes, const double* dens_b,
