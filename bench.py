@@ -403,7 +403,11 @@ def main():
             return ctypes.c_void_p(self.d_out.value + (slot * self.n_out + offset) * 8)
 
         def predict(self, slot):
-            out, second = self.out_ptr(slot), self.out_ptr(slot, n_draws)
+            # (the slot's two pointers made once: 1 us of interpreter time per call otherwise)
+            pointers = self.__dict__.setdefault('_slot_pointers', {})
+            if slot not in pointers:
+                pointers[slot] = (self.out_ptr(slot), self.out_ptr(slot, n_draws))
+            out, second = pointers[slot]
             if interp_mode and self.chi2_mode:
                 _lib.check(lib.tc_interp_chi2_zheng07_batch_device(
                     handle, d_theta, 5, d_x, n_draws, N_GAUSS, 0, data_p, precision_p,
